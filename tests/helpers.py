@@ -1,0 +1,69 @@
+"""Synthetic block systems shared by the tests (no reference data involved)."""
+import numpy as np
+
+
+def cartesian_pattern(nx, ny, nz):
+    """7-point block pattern, natural order i + nx*(j + ny*k), columns ascending."""
+    Nb = nx * ny * nz
+    idx = np.arange(Nb).reshape(nz, ny, nx)
+    nbrs = [[] for _ in range(Nb)]
+    def link(a, b):
+        for p, q in zip(a.reshape(-1), b.reshape(-1)):
+            nbrs[p].append(q)
+            nbrs[q].append(p)
+    link(idx[:, :, :-1], idx[:, :, 1:])
+    link(idx[:, :-1, :], idx[:, 1:, :])
+    link(idx[:-1, :, :], idx[1:, :, :])
+    rowptr = np.zeros(Nb + 1, np.int32)
+    cols = []
+    for i in range(Nb):
+        c = sorted(nbrs[i] + [i])
+        cols.extend(c)
+        rowptr[i + 1] = len(cols)
+    return Nb, rowptr, np.array(cols, np.int32)
+
+
+def laplace_block_system(nx, ny, nz, seed=0, dominance=1.5):
+    """Block 7-point system with random dense 3x3 blocks, made block-diagonally dominant so that ILU0
+    BiCGStab converges: a stand-in for a Jacobian when only the linear algebra is under test."""
+    rng = np.random.default_rng(seed)
+    Nb, rowptr, col = cartesian_pattern(nx, ny, nz)
+    nnzb = int(rowptr[-1])
+    val = rng.uniform(-1.0, 0.0, size=(nnzb, 3, 3)) * 0.3
+    for i in range(Nb):
+        ks = np.arange(rowptr[i], rowptr[i + 1])
+        off = ks[col[ks] != i]
+        dk = ks[col[ks] == i][0]
+        s = np.abs(val[off]).sum(axis=(0, 2))  # row sums per block row
+        val[dk] = rng.uniform(-0.1, 0.1, size=(3, 3))
+        val[dk][np.arange(3), np.arange(3)] = dominance * (s + 0.5) + rng.uniform(0, 0.2, 3)
+    return Nb, rowptr, col, np.ascontiguousarray(val.reshape(-1))
+
+
+def random_block_system(Nb, pattern="tridiag", seed=0, extra=0):
+    """Irregular patterns: 'tridiag' block-tridiagonal, 'random' adds `extra` symmetric random couplings
+    per row (row lengths vary), always with a dominant diagonal."""
+    rng = np.random.default_rng(seed)
+    nb = [set([i]) for i in range(Nb)]
+    for i in range(Nb - 1):
+        nb[i].add(i + 1)
+        nb[i + 1].add(i)
+    if pattern == "random":
+        for i in range(Nb):
+            for j in rng.choice(Nb, size=rng.integers(0, extra + 1), replace=False):
+                nb[i].add(int(j))
+                nb[int(j)].add(i)
+    rowptr = np.zeros(Nb + 1, np.int32)
+    cols = []
+    for i in range(Nb):
+        cols.extend(sorted(nb[i]))
+        rowptr[i + 1] = len(cols)
+    col = np.array(cols, np.int32)
+    nnzb = len(cols)
+    val = rng.uniform(-1, 1, size=(nnzb, 3, 3)) * 0.2
+    for i in range(Nb):
+        ks = np.arange(rowptr[i], rowptr[i + 1])
+        dk = ks[col[ks] == i][0]
+        s = np.abs(val[ks]).sum(axis=(0, 2))
+        val[dk][np.arange(3), np.arange(3)] = 1.5 * (s + 0.5)
+    return Nb, rowptr, col, np.ascontiguousarray(val.reshape(-1))

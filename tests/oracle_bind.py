@@ -1,0 +1,96 @@
+"""ctypes binding of oracle/liboracle.so — test infrastructure only (never imported by the product)."""
+import ctypes as C
+
+import numpy as np
+
+_i = np.ctypeslib.ndpointer(dtype=np.int32, flags="C_CONTIGUOUS")
+_d = np.ctypeslib.ndpointer(dtype=np.float64, flags="C_CONTIGUOUS")
+_vp = C.c_void_p
+
+REORDER = {"none": 0, "level_scheduling": 1, "graph_coloring": 2, "graph_coloring_greedy": 3}
+RELAX = {"post_scale": 0, "in_sweep": 1}
+
+
+class OrcResult(C.Structure):
+    _fields_ = [("iterations", C.c_int), ("converged", C.c_int), ("reduction", C.c_double),
+                ("conv_rate", C.c_double), ("it", C.c_double), ("t_factor", C.c_double),
+                ("t_solve", C.c_double), ("num_colors", C.c_int)]
+
+
+def _p(a):
+    return None if a is None else a.ctypes.data_as(_vp)
+
+
+class Oracle:
+    def __init__(self, path):
+        self.lib = C.CDLL(path)
+        L = self.lib
+        L.orc_spmv.argtypes = [C.c_int, _i, _i, _d, _d, _d]
+        L.orc_ilu0_factor.argtypes = [C.c_int, _i, _i, _d, C.c_int, _d]
+        L.orc_ilu0_apply.argtypes = [C.c_int, _i, _i, _d, C.c_int, _d, _d, C.c_double, C.c_int]
+        L.orc_reorder.argtypes = [C.c_int, _i, _i, C.c_int, _i, _i, _i]
+        L.orc_reorder_matrix.argtypes = [C.c_int, _i, _i, _vp, _i, _i, _i, _i, _vp]
+        L.orc_wells_apply.argtypes = [C.c_int, _i, _i, _i, _d, _d, _d, _d, _d]
+        L.orc_check_zero_diagonal.argtypes = [C.c_int, _i, _i, _d]
+        L.orc_solve.argtypes = [C.c_int, _i, _i, _d, _d, _d, C.c_double, C.c_int, C.c_double, C.c_int, C.c_int,
+                                C.c_int, C.c_int, _vp, _vp, _vp, _vp, _vp, _vp, C.c_int, _vp,
+                                C.POINTER(OrcResult)]
+        L.orc_solve_noprec.argtypes = [C.c_int, _i, _i, _d, _d, _d, C.c_double, C.c_int, C.c_int,
+                                       C.POINTER(OrcResult)]
+
+    # ---- linear algebra -------------------------------------------------------------------
+    def spmv(self, Nb, rowptr, col, val, x):
+        y = np.empty(Nb * 3)
+        self.lib.orc_spmv(Nb, rowptr, col, val, x, y)
+        return y
+
+    def ilu0_factor(self, Nb, rowptr, col, val, interior=-1):
+        lu = np.empty_like(val)
+        rc = self.lib.orc_ilu0_factor(Nb, rowptr, col, val, interior, lu)
+        assert rc == 0, rc
+        return lu
+
+    def ilu0_apply(self, Nb, rowptr, col, lu, d, w=1.0, mode="post_scale", interior=-1):
+        v = np.zeros(Nb * 3)
+        self.lib.orc_ilu0_apply(Nb, rowptr, col, lu, interior, d, v, w, RELAX[mode])
+        return v
+
+    def reorder(self, Nb, rowptr, col, kind):
+        to = np.empty(Nb, np.int32)
+        fr = np.empty(Nb, np.int32)
+        rpc = np.zeros(Nb, np.int32)
+        nc = self.lib.orc_reorder(Nb, rowptr, col, REORDER[kind], to, fr, rpc)
+        return to, fr, rpc[:nc].copy()
+
+    def reorder_matrix(self, Nb, rowptr, col, val, to, fr):
+        rr = np.empty_like(rowptr)
+        rc = np.empty_like(col)
+        rv = None if val is None else np.empty_like(val)
+        self.lib.orc_reorder_matrix(Nb, rowptr, col, _p(val), to, fr, rr, rc, _p(rv))
+        return rr, rc, rv
+
+    def wells_apply(self, wells, x, y):
+        y = y.copy()
+        self.lib.orc_wells_apply(wells["numWells"], wells["val_pointers"], wells["Ccols"], wells["Bcols"],
+                                 wells["Cnnzs"], wells["Dnnzs"], wells["Bnnzs"], x, y)
+        return y
+
+    def solve(self, Nb, rowptr, col, val, b, tol=1e-2, maxit=200, w=0.9, mode="post_scale", reorder="none",
+              zero_diag_fix=True, wells=None, sub_start=None):
+        x = np.zeros(Nb * 3)
+        res = OrcResult()
+        W = wells or {}
+        nsub = 0 if sub_start is None else len(sub_start) - 1
+        ss = None if sub_start is None else np.ascontiguousarray(sub_start, np.int32)
+        rc = self.lib.orc_solve(Nb, rowptr, col, val, b, x, tol, maxit, w, RELAX[mode], REORDER[reorder],
+                                int(zero_diag_fix), W.get("numWells", 0), _p(W.get("val_pointers")),
+                                _p(W.get("Ccols")), _p(W.get("Bcols")), _p(W.get("Cnnzs")), _p(W.get("Dnnzs")),
+                                _p(W.get("Bnnzs")), nsub, _p(ss), C.byref(res))
+        assert rc == 0, rc
+        return x, res
+
+    def solve_noprec(self, Nb, rowptr, col, val, b, tol, maxit, repeat=1):
+        x = np.zeros(Nb * 3)
+        res = OrcResult()
+        self.lib.orc_solve_noprec(Nb, rowptr, col, val, b, x, tol, maxit, repeat, C.byref(res))
+        return x, res
