@@ -1,0 +1,147 @@
+/* opmhip.h — C-ABI of libopmhip.so: the MI355X (gfx950) implementation of OPM Flow's per-Newton-iteration
+ * hot path (black-oil AD assembly + ILU0/BiCGStab solve on 3x3 block-CSR).
+ *
+ * This header is the drop-in boundary.  Every entry point names the reference interface it replaces
+ * (paths relative to the reference tree, opm-simulators 2021.10-pre).  Conventions:
+ *   - plain C types only; all pointers are caller-owned HOST memory unless the name says "dev";
+ *   - every function returns OPMHIP_SUCCESS (0) or a negative opmhip_status; nothing throws across the
+ *     boundary (the reference turns a non-success SolverStatus into a Dune fallback,
+ *     linalg/ISTLSolverEbos.hpp:277-297, so a C++ shim maps these codes back to bda::SolverStatus);
+ *   - one context per GPU, single-threaded per context (the reference calls its backend from the one
+ *     Newton-loop thread of a rank, linalg/bda/BdaBridge.cpp:192-255);
+ *   - block size is 3, values are IEEE double, indices 32-bit int (bda/BdaSolver.hpp:86-88);
+ *   - block-CSR layout exactly as BdaBridge hands it over (bda/BdaBridge.cpp:231-232): rows[Nb+1] block row
+ *     pointers, cols[nnzb] block columns ascending inside a row, vals[nnzb*9] row-major 3x3 blocks.
+ */
+#ifndef OPMHIP_H
+#define OPMHIP_H
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define OPMHIP_ABI_VERSION 1
+
+typedef struct opmhip_ctx opmhip_ctx;
+
+typedef enum opmhip_status {
+    OPMHIP_SUCCESS = 0,
+    /* the three below mirror bda::SolverStatus (bda/BdaSolver.hpp:32-37) */
+    OPMHIP_ANALYSIS_FAILED = -1,
+    OPMHIP_CREATE_PRECONDITIONER_FAILED = -2,
+    OPMHIP_UNKNOWN_ERROR = -3,
+    OPMHIP_INVALID_ARGUMENT = -4, /* bad pointer/size, dim != 3 (bda/BdaBridge.cpp:207-211) */
+    OPMHIP_NOT_READY = -5,        /* call order violated (e.g. solve before set_pattern) */
+    OPMHIP_DEVICE_ERROR = -6,     /* a HIP call failed; text in opmhip_last_error */
+    OPMHIP_NO_DEVICE = -7         /* no gfx950 device visible: the library never falls back to the CPU */
+} opmhip_status;
+
+/* --opencl-ilu-reorder (linalg/FlowLinearSolverParameters.hpp:317-321, bda/ILUReorder.hpp) */
+typedef enum opmhip_reorder {
+    OPMHIP_REORDER_LEVEL_SCHEDULING = 1, /* same factors as the CPU's natural-order ILU0 (bda/Reorder.cpp:266-318) */
+    OPMHIP_REORDER_GRAPH_COLORING = 2,   /* Jones-Plassmann rounds, deterministic weights (bda/Reorder.cpp:59-172) */
+    OPMHIP_REORDER_GRAPH_COLORING_GREEDY = 3 /* first-fit colouring: red-black on Cartesian 7-point grids */
+} opmhip_reorder;
+
+/* how the ILU relaxation factor w enters M^-1 */
+typedef enum opmhip_relax_mode {
+    OPMHIP_RELAX_POST_SCALE = 0, /* v = w * U^-1 L^-1 d : the CPU path, linalg/ParallelOverlappingILU0.hpp:848-903 */
+    OPMHIP_RELAX_IN_SWEEP = 1    /* x_i = w * D_i^-1 (y_i - sum U_ij x_j) : bda/openclKernels.cpp:301-383 */
+} opmhip_relax_mode;
+
+/* Solver configuration.  Defaults (opmhip_default_config) are Flow's: tol 1e-2, maxit 200, w 0.9
+ * (linalg/FlowLinearSolverParameters.hpp:142-154).  ctor arguments of bda::BdaSolver (bda/BdaSolver.hpp:79). */
+typedef struct opmhip_config {
+    int abi_version;       /* OPMHIP_ABI_VERSION */
+    int device_id;         /* --bda-device-id */
+    int verbosity;         /* linear_solver_verbosity */
+    int maxit;             /* --linear-solver-max-iter */
+    double tolerance;      /* --linear-solver-reduction */
+    double ilu_relaxation; /* --ilu-relaxation */
+    int relax_mode;        /* opmhip_relax_mode */
+    int reorder;           /* opmhip_reorder */
+    int zero_diag_fix;     /* 1: exact 0.0 on a diagonal block's diagonal -> 1e-15 (bda/BdaBridge.cpp:125-161) */
+    int reserved[7];
+} opmhip_config;
+
+/* bda::BdaResult (bda/BdaResult.hpp:28-40) plus the reference's per-phase timers. */
+typedef struct opmhip_result {
+    int iterations;    /* min(it, maxit), it counted in half steps (bda/cusparseSolverBackend.cu:172) */
+    int converged;     /* it != maxit + 0.5 (:176) */
+    double reduction;  /* |r| / |r0| */
+    double conv_rate;  /* reduction^(1/it) */
+    double elapsed;    /* seconds in the whole call */
+    double it;         /* raw half-iteration counter */
+    double t_copy;     /* H2D of values/rhs (0 when the system is already device resident) */
+    double t_factor;   /* ILU0 factorisation   = linear_solve_setup_time (timestepping/SimulatorReport.hpp:29-49) */
+    double t_solve;    /* BiCGStab loop        = linear_solve_time */
+    int num_colors;    /* colours / levels of the ILU ordering */
+    int reserved[3];
+} opmhip_result;
+
+/* Standard-well contributions, the data bda::WellContributions carries across the boundary
+ * (bda/WellContributions.hpp:60-214; fill order C, D, B per well, wells/StandardWellEval.cpp:1206-1250):
+ * applied after each SpMV as y -= C^T (D^-1 (B x)) (bda/WellContributions.cu:36-126). dim = 3, dim_wells = 4. */
+typedef struct opmhip_wells {
+    int num_wells;
+    const int* val_pointers; /* [num_wells+1] perforation ranges */
+    const int* Ccols;        /* [nperf] cell (block row) of each perforation */
+    const int* Bcols;        /* [nperf] */
+    const double* Cnnzs;     /* [nperf*12] 4x3 row-major */
+    const double* Dnnzs;     /* [num_wells*16] 4x4 row-major, already inverted (D^-1) */
+    const double* Bnnzs;     /* [nperf*12] */
+} opmhip_wells;
+
+/* ---- lifetime ------------------------------------------------------------------------------------------ */
+void opmhip_default_config(opmhip_config* cfg);
+/* replaces: BdaBridge ctor selecting a backend by string (bda/BdaBridge.cpp:55-121) */
+int opmhip_create(const opmhip_config* cfg, opmhip_ctx** out);
+void opmhip_destroy(opmhip_ctx* ctx);
+/* last error text of this context (or of the failed create when ctx == NULL); never NULL */
+const char* opmhip_last_error(const opmhip_ctx* ctx);
+int opmhip_abi_version(void);
+
+/* ---- linear solve (drop-in for bda::BdaSolver<3>) --------------------------------------------------- */
+/* replaces: first-call branch of solve_system -> initialize + analyse_matrix
+ * (bda/cusparseSolverBackend.cu:187-260, 348-422; bda/BILU0.cpp:51-158).  The pattern is fixed for the life of
+ * the context (linalg/ISTLSolverEbos.hpp:216-219).  Computes the ILU ordering, the device tiling and uploads
+ * the index arrays. */
+int opmhip_set_pattern(opmhip_ctx* ctx, int Nb, int nnzb, const int* rows, const int* cols);
+
+/* replaces: bda::BdaSolver<3>::solve_system(N, nnz, dim, vals, rows, cols, b, wellContribs, res)
+ * (bda/BdaSolver.hpp:86-88).  N = 3*Nb scalar rows, nnz = 9*nnzb scalars, dim = 3.  If the pattern was not set
+ * yet this call sets it from rows/cols (the reference's "initialized == false" path); afterwards rows/cols may
+ * be NULL.  vals == NULL and b == NULL mean "use the Jacobian and residual the context assembled on the
+ * device".  vals may be modified when zero_diag_fix is on, as the reference does (bda/BdaBridge.hpp:68).
+ * wells may be NULL.  A non-converged solve is NOT an error: it returns OPMHIP_SUCCESS with res->converged = 0
+ * (the caller then falls back, linalg/ISTLSolverEbos.hpp:277-289). */
+int opmhip_solve_system(opmhip_ctx* ctx, int N, int nnz, int dim, double* vals, const int* rows, const int* cols,
+                        const double* b, const opmhip_wells* wells, opmhip_result* res);
+
+/* replaces: bda::BdaSolver<3>::get_result(x) (bda/BdaSolver.hpp:90): N doubles to caller memory, natural order */
+int opmhip_get_result(opmhip_ctx* ctx, double* x);
+
+/* ---- pieces of the solve, exposed for parity tests and roofline measurement ------------------------- */
+/* upload a system (natural order in, internal order on the device) without solving */
+int opmhip_upload_system(opmhip_ctx* ctx, const double* vals, const double* b);
+/* y = A x  (Dune::MatrixAdapter::apply, linalg/WellOperators.hpp:127-138); x, y host, natural order */
+int opmhip_spmv(opmhip_ctx* ctx, const double* x, double* y);
+/* block ILU0 of the uploaded matrix (ParallelOverlappingILU0::update, linalg/ParallelOverlappingILU0.hpp:923-1068);
+ * lu_out (nullable) receives the factors in NATURAL order in the layout of Dune's in-place ILU: strict lower = L,
+ * strict upper = U, diagonal = D^-1 */
+int opmhip_ilu0_factor(opmhip_ctx* ctx, double* lu_out);
+/* v = M^-1 d (ParallelOverlappingILU0::apply, :848-903); needs opmhip_ilu0_factor first */
+int opmhip_ilu0_apply(opmhip_ctx* ctx, const double* d, double* v);
+/* the ordering chosen at set_pattern: toOrder/fromOrder [Nb], rowsPerColor [num colours] (any may be NULL);
+ * returns the number of colours/levels or a negative status */
+int opmhip_get_ordering(opmhip_ctx* ctx, int* toOrder, int* fromOrder, int* rowsPerColor);
+/* Device-timed repetitions of one kernel on the uploaded system, for bench.py's roofline object:
+ * which = 0 SpMV, 1 ILU0 apply, 2 ILU0 factor, 3 one BiCGStab iteration's vector kernels.
+ * Launches the kernel `reps` times back to back on the context's stream between two HIP events and returns the
+ * average milliseconds per launch in *ms_per_launch. */
+int opmhip_time_kernel(opmhip_ctx* ctx, int which, int reps, double* ms_per_launch);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* OPMHIP_H */

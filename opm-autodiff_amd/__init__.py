@@ -1,6 +1,7 @@
 """opm-autodiff_amd — MI355X-native Newton-iteration hot path for OPM Flow (assembly + ILU0/BiCGStab).
 
 The directory name carries a hyphen (mandated layout), so import it with
-``importlib.import_module("opm-autodiff_amd")``.
+``importlib.import_module("opm-autodiff_amd")``.  The compute path lives in ``libopmhip.so`` (HIP, gfx950),
+reached through the C-ABI declared in ``include/opmhip.h``; ``capi`` is its ctypes binding.
 """
-from . import mmio  # noqa: F401
+from . import capi, mmio  # noqa: F401

@@ -1,0 +1,194 @@
+"""ctypes binding of libopmhip.so — the same C-ABI a Flow-side shim binds (include/opmhip.h).
+
+No fallback: if the shared library is missing this module raises at import of the library handle, and every
+compute entry point returns OPMHIP_NO_DEVICE from opmhip_create when no gfx950 device is visible.
+"""
+import ctypes as C
+import os
+import re
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(HERE, "libopmhip.so")
+HEADER_PATH = os.path.join(os.path.dirname(HERE), "include", "opmhip.h")
+
+SUCCESS = 0
+ANALYSIS_FAILED, CREATE_PRECONDITIONER_FAILED, UNKNOWN_ERROR = -1, -2, -3
+INVALID_ARGUMENT, NOT_READY, DEVICE_ERROR, NO_DEVICE = -4, -5, -6, -7
+REORDER = {"level_scheduling": 1, "graph_coloring": 2, "graph_coloring_greedy": 3}
+RELAX = {"post_scale": 0, "in_sweep": 1}
+
+
+class OpmHipError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__("opmhip status %d: %s" % (code, msg))
+        self.code = code
+
+
+class Config(C.Structure):
+    _fields_ = [("abi_version", C.c_int), ("device_id", C.c_int), ("verbosity", C.c_int), ("maxit", C.c_int),
+                ("tolerance", C.c_double), ("ilu_relaxation", C.c_double), ("relax_mode", C.c_int),
+                ("reorder", C.c_int), ("zero_diag_fix", C.c_int), ("reserved", C.c_int * 7)]
+
+
+class Result(C.Structure):
+    _fields_ = [("iterations", C.c_int), ("converged", C.c_int), ("reduction", C.c_double),
+                ("conv_rate", C.c_double), ("elapsed", C.c_double), ("it", C.c_double), ("t_copy", C.c_double),
+                ("t_factor", C.c_double), ("t_solve", C.c_double), ("num_colors", C.c_int),
+                ("reserved", C.c_int * 3)]
+
+
+class Wells(C.Structure):
+    _fields_ = [("num_wells", C.c_int), ("val_pointers", C.c_void_p), ("Ccols", C.c_void_p),
+                ("Bcols", C.c_void_p), ("Cnnzs", C.c_void_p), ("Dnnzs", C.c_void_p), ("Bnnzs", C.c_void_p)]
+
+
+def declared_symbols():
+    """Every function name include/opmhip.h declares."""
+    with open(HEADER_PATH) as f:
+        txt = re.sub(r"/\*.*?\*/", "", f.read(), flags=re.S)
+    return sorted(set(re.findall(r"\b(opmhip_[a-z0-9_]+)\s*\(", txt)))
+
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise OpmHipError(NO_DEVICE, "libopmhip.so not built (%s); run `make -C %s` or "
+                              "__graft_entry__.build() - there is no CPU fallback" % (LIB_PATH, HERE))
+        L = C.CDLL(LIB_PATH)
+        vp, ip, dp = C.c_void_p, C.c_void_p, C.c_void_p
+        L.opmhip_abi_version.restype = C.c_int
+        L.opmhip_default_config.argtypes = [C.POINTER(Config)]
+        L.opmhip_default_config.restype = None
+        L.opmhip_create.argtypes = [C.POINTER(Config), C.POINTER(vp)]
+        L.opmhip_destroy.argtypes = [vp]
+        L.opmhip_destroy.restype = None
+        L.opmhip_last_error.argtypes = [vp]
+        L.opmhip_last_error.restype = C.c_char_p
+        L.opmhip_set_pattern.argtypes = [vp, C.c_int, C.c_int, ip, ip]
+        L.opmhip_solve_system.argtypes = [vp, C.c_int, C.c_int, C.c_int, dp, ip, ip, dp, C.POINTER(Wells),
+                                          C.POINTER(Result)]
+        L.opmhip_get_result.argtypes = [vp, dp]
+        L.opmhip_upload_system.argtypes = [vp, dp, dp]
+        L.opmhip_spmv.argtypes = [vp, dp, dp]
+        L.opmhip_ilu0_factor.argtypes = [vp, dp]
+        L.opmhip_ilu0_apply.argtypes = [vp, dp, dp]
+        L.opmhip_get_ordering.argtypes = [vp, ip, ip, ip]
+        L.opmhip_time_kernel.argtypes = [vp, C.c_int, C.c_int, C.POINTER(C.c_double)]
+        _lib = L
+    return _lib
+
+
+def _ptr(a):
+    return None if a is None else a.ctypes.data_as(C.c_void_p)
+
+
+def _f64(a):
+    return None if a is None else np.ascontiguousarray(a, dtype=np.float64)
+
+
+def _i32(a):
+    return None if a is None else np.ascontiguousarray(a, dtype=np.int32)
+
+
+def make_wells(w):
+    """dict(numWells, val_pointers, Ccols, Bcols, Cnnzs, Dnnzs, Bnnzs) -> (Wells struct, keep-alive list)"""
+    if not w:
+        return None, []
+    keep = [_i32(w["val_pointers"]), _i32(w["Ccols"]), _i32(w["Bcols"]), _f64(w["Cnnzs"]), _f64(w["Dnnzs"]),
+            _f64(w["Bnnzs"])]
+    s = Wells(int(w["numWells"]), *[_ptr(k) for k in keep])
+    return s, keep
+
+
+class HipSolver:
+    """Thin object wrapper over one opmhip context (mirrors how bda::BdaSolver<3> is used:
+    ctor(verbosity, maxit, tolerance, deviceID), solve_system(...), get_result(x))."""
+
+    def __init__(self, verbosity=0, maxit=200, tolerance=1e-2, device_id=0, ilu_relaxation=0.9,
+                 relax_mode="post_scale", reorder="graph_coloring", zero_diag_fix=True):
+        L = lib()
+        cfg = Config()
+        L.opmhip_default_config(C.byref(cfg))
+        cfg.verbosity, cfg.maxit, cfg.tolerance, cfg.device_id = verbosity, maxit, tolerance, device_id
+        cfg.ilu_relaxation = ilu_relaxation
+        cfg.relax_mode = RELAX[relax_mode]
+        cfg.reorder = REORDER[reorder]
+        cfg.zero_diag_fix = int(zero_diag_fix)
+        self._h = C.c_void_p()
+        rc = L.opmhip_create(C.byref(cfg), C.byref(self._h))
+        if rc != SUCCESS:
+            raise OpmHipError(rc, L.opmhip_last_error(None).decode())
+        self.Nb = self.nnzb = 0
+
+    def close(self):
+        if getattr(self, "_h", None) and self._h.value:
+            lib().opmhip_destroy(self._h)
+            self._h = C.c_void_p()
+
+    __del__ = close
+
+    def _check(self, rc):
+        if rc < 0:
+            raise OpmHipError(rc, lib().opmhip_last_error(self._h).decode())
+        return rc
+
+    def set_pattern(self, Nb, rows, cols):
+        rows, cols = _i32(rows), _i32(cols)
+        self._check(lib().opmhip_set_pattern(self._h, Nb, len(cols), _ptr(rows), _ptr(cols)))
+        self.Nb, self.nnzb = Nb, len(cols)
+
+    def solve_system(self, Nb, rows, cols, vals, b, wells=None):
+        """bda::BdaSolver::solve_system; returns the Result struct (check .converged like the reference)."""
+        rows, cols, vals, b = _i32(rows), _i32(cols), _f64(vals), _f64(b)
+        nnzb = self.nnzb if cols is None else len(cols)
+        res = Result()
+        ws, keep = make_wells(wells)
+        self._check(lib().opmhip_solve_system(self._h, 3 * Nb, 9 * nnzb, 3, _ptr(vals), _ptr(rows), _ptr(cols),
+                                              _ptr(b), C.byref(ws) if ws else None, C.byref(res)))
+        self.Nb, self.nnzb = Nb, nnzb
+        return res
+
+    def get_result(self):
+        x = np.empty(3 * self.Nb)
+        self._check(lib().opmhip_get_result(self._h, _ptr(x)))
+        return x
+
+    def upload_system(self, vals, b=None):
+        vals, b = _f64(vals), _f64(b)
+        self._check(lib().opmhip_upload_system(self._h, _ptr(vals), _ptr(b)))
+
+    def spmv(self, x):
+        x = _f64(x)
+        y = np.empty_like(x)
+        self._check(lib().opmhip_spmv(self._h, _ptr(x), _ptr(y)))
+        return y
+
+    def ilu0_factor(self, want_factors=True):
+        lu = np.empty(9 * self.nnzb) if want_factors else None
+        self._check(lib().opmhip_ilu0_factor(self._h, _ptr(lu)))
+        return lu
+
+    def ilu0_apply(self, d):
+        d = _f64(d)
+        v = np.empty_like(d)
+        self._check(lib().opmhip_ilu0_apply(self._h, _ptr(d), _ptr(v)))
+        return v
+
+    def ordering(self):
+        to = np.empty(self.Nb, np.int32)
+        fr = np.empty(self.Nb, np.int32)
+        rpc = np.zeros(self.Nb, np.int32)
+        nc = self._check(lib().opmhip_get_ordering(self._h, _ptr(to), _ptr(fr), _ptr(rpc)))
+        return to, fr, rpc[:nc].copy()
+
+    def time_kernel(self, which, reps=20):
+        ms = C.c_double()
+        self._check(lib().opmhip_time_kernel(self._h, {"spmv": 0, "ilu_apply": 1, "ilu_factor": 2, "vector": 3}[which],
+                                             reps, C.byref(ms)))
+        return ms.value

@@ -1,0 +1,361 @@
+// C-ABI of libopmhip.so (include/opmhip.h): argument checking, device memory, call ordering.  No exceptions
+// cross this file's boundary: every entry point is wrapped and maps failures to opmhip_status codes.
+#include <chrono>
+#include <cstring>
+#include <new>
+
+#include "internal.hpp"
+
+using namespace opmhip;
+
+namespace {
+thread_local std::string g_err = "";
+
+double now() {
+    return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count();
+}
+
+int alloc_system(opmhip_ctx* c) {
+    const Pattern& P = c->pat;
+    const size_t n = (size_t)P.Nb * BS;
+    int rc;
+    if ((rc = dev_alloc(c, &c->d_A, (size_t)P.nnzb * BB))) return rc;
+    if ((rc = dev_alloc(c, &c->d_L, (size_t)P.nl * BB))) return rc;
+    if ((rc = dev_alloc(c, &c->d_U, (size_t)P.nu * BB))) return rc;
+    if ((rc = dev_alloc(c, &c->d_invD, (size_t)P.Nb * BB))) return rc;
+    double** vecs[] = {&c->d_b, &c->d_x, &c->d_r, &c->d_rw, &c->d_p, &c->d_v, &c->d_s, &c->d_t, &c->d_pw, &c->d_stageV};
+    for (double** v : vecs) {
+        if ((rc = dev_alloc(c, v, n))) return rc;
+        OPMHIP_HIP(c, hipMemset(*v, 0, n * sizeof(double)));
+    }
+    if ((rc = dev_alloc(c, &c->d_stageA, (size_t)P.nnzb * BB))) return rc;
+    if ((rc = dev_alloc(c, &c->d_scal, (size_t)SC_COUNT))) return rc;
+    OPMHIP_HIP(c, hipMemset(c->d_scal, 0, SC_COUNT * sizeof(double)));
+    const int vb = (int)((n + 2047) / 2048);
+    c->npart = std::max(P.tiles.ntiles(), vb) + 1;
+    if ((rc = dev_alloc(c, &c->d_part, (size_t)2 * c->npart))) return rc;
+    OPMHIP_HIP(c, hipMemset(c->d_part, 0, (size_t)2 * c->npart * sizeof(double)));
+    OPMHIP_HIP(c, hipHostMalloc((void**)&c->h_pinned, SC_COUNT * sizeof(double)));
+    return OPMHIP_SUCCESS;
+}
+
+int upload_wells(opmhip_ctx* c, const opmhip_wells* w) {
+    WellsDev& W = c->wells;
+    W.num_wells = 0;
+    if (!w || w->num_wells <= 0) return OPMHIP_SUCCESS;
+    if (!w->val_pointers || !w->Ccols || !w->Bcols || !w->Cnnzs || !w->Dnnzs || !w->Bnnzs)
+        return fail(c, OPMHIP_INVALID_ARGUMENT, "wells: null array");
+    const int nw = w->num_wells, np = w->val_pointers[nw];
+    if (np < 0) return fail(c, OPMHIP_INVALID_ARGUMENT, "wells: bad val_pointers");
+    // cell indices arrive in natural order; the device works in the internal order
+    std::vector<int> cc(np), bc(np);
+    for (int p = 0; p < np; ++p) {
+        if (w->Ccols[p] < 0 || w->Ccols[p] >= c->pat.Nb || w->Bcols[p] < 0 || w->Bcols[p] >= c->pat.Nb)
+            return fail(c, OPMHIP_INVALID_ARGUMENT, "wells: perforation %d cell out of range", p);
+        cc[p] = c->pat.toOrder[w->Ccols[p]];
+        bc[p] = c->pat.toOrder[w->Bcols[p]];
+    }
+    int rc;
+    // device arrays grow geometrically and are then reused: wells are rebuilt for every solve
+    // (linalg/ISTLSolverEbos.hpp:265-272)
+    if ((size_t)nw > W.cap_wells) {
+        const size_t cap = std::max((size_t)nw, 2 * W.cap_wells);
+        if ((rc = dev_alloc(c, &W.d_val_pointers, cap + 1))) return rc;
+        if ((rc = dev_alloc(c, &W.d_D, cap * 16))) return rc;
+        W.cap_wells = cap;
+    }
+    if ((size_t)np > W.cap_perf) {
+        const size_t cap = std::max((size_t)np, 2 * W.cap_perf);
+        if ((rc = dev_alloc(c, &W.d_Ccols, cap))) return rc;
+        if ((rc = dev_alloc(c, &W.d_Bcols, cap))) return rc;
+        if ((rc = dev_alloc(c, &W.d_C, cap * 12))) return rc;
+        if ((rc = dev_alloc(c, &W.d_B, cap * 12))) return rc;
+        W.cap_perf = cap;
+    }
+    OPMHIP_HIP(c, hipMemcpy(W.d_val_pointers, w->val_pointers, (nw + 1) * sizeof(int), hipMemcpyHostToDevice));
+    OPMHIP_HIP(c, hipMemcpy(W.d_D, w->Dnnzs, (size_t)nw * 16 * sizeof(double), hipMemcpyHostToDevice));
+    if (np > 0) {
+        OPMHIP_HIP(c, hipMemcpy(W.d_Ccols, cc.data(), np * sizeof(int), hipMemcpyHostToDevice));
+        OPMHIP_HIP(c, hipMemcpy(W.d_Bcols, bc.data(), np * sizeof(int), hipMemcpyHostToDevice));
+        OPMHIP_HIP(c, hipMemcpy(W.d_C, w->Cnnzs, (size_t)np * 12 * sizeof(double), hipMemcpyHostToDevice));
+        OPMHIP_HIP(c, hipMemcpy(W.d_B, w->Bnnzs, (size_t)np * 12 * sizeof(double), hipMemcpyHostToDevice));
+    }
+    W.num_wells = nw;
+    W.nperf = np;
+    return OPMHIP_SUCCESS;
+}
+
+int upload_system(opmhip_ctx* c, const double* vals, const double* b) {
+    const Pattern& P = c->pat;
+    if (vals) {
+        OPMHIP_HIP(c, hipMemcpyAsync(c->d_stageA, vals, (size_t)P.nnzb * BB * sizeof(double), hipMemcpyHostToDevice, c->stream));
+        launch_permute_blocks(c, c->d_stageA, c->d_A);
+        c->factored = false;
+    }
+    if (b) {
+        OPMHIP_HIP(c, hipMemcpyAsync(c->d_stageV, b, (size_t)P.Nb * BS * sizeof(double), hipMemcpyHostToDevice, c->stream));
+        launch_vec_to_internal(c, c->d_stageV, c->d_b);
+    }
+    if (vals && c->cfg.zero_diag_fix) launch_zero_diag_fix(c);
+    OPMHIP_HIP(c, hipGetLastError());
+    if (vals) c->system_loaded = true;
+    return OPMHIP_SUCCESS;
+}
+
+int vec_in(opmhip_ctx* c, const double* h, double* d_internal) {
+    OPMHIP_HIP(c, hipMemcpyAsync(c->d_stageV, h, (size_t)c->pat.Nb * BS * sizeof(double), hipMemcpyHostToDevice, c->stream));
+    launch_vec_to_internal(c, c->d_stageV, d_internal);
+    return OPMHIP_SUCCESS;
+}
+int vec_out(opmhip_ctx* c, const double* d_internal, double* h) {
+    launch_vec_to_natural(c, d_internal, c->d_stageV);
+    OPMHIP_HIP(c, hipMemcpyAsync(h, c->d_stageV, (size_t)c->pat.Nb * BS * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+    OPMHIP_HIP(c, hipStreamSynchronize(c->stream));
+    return OPMHIP_SUCCESS;
+}
+
+template <class F>
+int guarded(opmhip_ctx* c, F&& f) {
+    try {
+        return f();
+    } catch (const std::bad_alloc&) {
+        return fail(c, OPMHIP_UNKNOWN_ERROR, "out of host memory");
+    } catch (const std::exception& e) {
+        return fail(c, OPMHIP_UNKNOWN_ERROR, "exception: %s", e.what());
+    } catch (...) {
+        return fail(c, OPMHIP_UNKNOWN_ERROR, "unknown exception");
+    }
+}
+}  // namespace
+
+extern "C" {
+
+int opmhip_abi_version(void) { return OPMHIP_ABI_VERSION; }
+
+void opmhip_default_config(opmhip_config* cfg) {
+    if (!cfg) return;
+    std::memset(cfg, 0, sizeof *cfg);
+    cfg->abi_version = OPMHIP_ABI_VERSION;
+    cfg->device_id = 0;
+    cfg->verbosity = 0;
+    cfg->maxit = 200;             // linalg/FlowLinearSolverParameters.hpp:150-154
+    cfg->tolerance = 1e-2;        // :142-146
+    cfg->ilu_relaxation = 0.9;    // :147-149
+    cfg->relax_mode = OPMHIP_RELAX_POST_SCALE;
+    cfg->reorder = OPMHIP_REORDER_GRAPH_COLORING;  // default of the accelerator path, bda/BdaBridge.cpp:72-73
+    cfg->zero_diag_fix = 1;
+}
+
+int opmhip_create(const opmhip_config* cfg, opmhip_ctx** out) {
+    if (!out) { g_err = "opmhip_create: out == NULL"; return OPMHIP_INVALID_ARGUMENT; }
+    *out = nullptr;
+    if (!cfg || cfg->abi_version != OPMHIP_ABI_VERSION) { g_err = "opmhip_create: config missing or ABI version mismatch"; return OPMHIP_INVALID_ARGUMENT; }
+    if (cfg->maxit < 1 || !(cfg->tolerance > 0.0)) { g_err = "opmhip_create: maxit/tolerance out of range"; return OPMHIP_INVALID_ARGUMENT; }
+    int ndev = 0;
+    hipError_t e = hipGetDeviceCount(&ndev);
+    if (e != hipSuccess || ndev <= 0) {
+        g_err = std::string("opmhip_create: no HIP device visible (") + hipGetErrorString(e) + "); libopmhip has no CPU fallback";
+        return OPMHIP_NO_DEVICE;
+    }
+    if (cfg->device_id < 0 || cfg->device_id >= ndev) { g_err = "opmhip_create: device_id out of range"; return OPMHIP_INVALID_ARGUMENT; }
+    opmhip_ctx* c = new (std::nothrow) opmhip_ctx();
+    if (!c) { g_err = "opmhip_create: out of memory"; return OPMHIP_UNKNOWN_ERROR; }
+    c->cfg = *cfg;
+    c->device = cfg->device_id;
+    if ((e = hipSetDevice(c->device)) != hipSuccess || (e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking)) != hipSuccess ||
+        (e = hipEventCreate(&c->ev0)) != hipSuccess || (e = hipEventCreate(&c->ev1)) != hipSuccess) {
+        g_err = std::string("opmhip_create: ") + hipGetErrorString(e);
+        delete c;
+        return OPMHIP_DEVICE_ERROR;
+    }
+    *out = c;
+    return OPMHIP_SUCCESS;
+}
+
+void opmhip_destroy(opmhip_ctx* c) {
+    if (!c) return;
+    (void)hipSetDevice(c->device);
+    if (c->stream) (void)hipStreamSynchronize(c->stream);
+    for (void* p : c->allocs) (void)hipFree(p);
+    if (c->h_pinned) (void)hipHostFree(c->h_pinned);
+    if (c->ev0) (void)hipEventDestroy(c->ev0);
+    if (c->ev1) (void)hipEventDestroy(c->ev1);
+    if (c->stream) (void)hipStreamDestroy(c->stream);
+    delete c;
+}
+
+const char* opmhip_last_error(const opmhip_ctx* c) { return c ? c->err.c_str() : g_err.c_str(); }
+
+int opmhip_set_pattern(opmhip_ctx* c, int Nb, int nnzb, const int* rows, const int* cols) {
+    if (!c) return OPMHIP_INVALID_ARGUMENT;
+    return guarded(c, [&]() -> int {
+        if (c->pattern_set) return fail(c, OPMHIP_NOT_READY, "set_pattern: the pattern of a context is immutable (linalg/ISTLSolverEbos.hpp:216-219)");
+        OPMHIP_HIP(c, hipSetDevice(c->device));
+        int rc = build_pattern(c, Nb, nnzb, rows, cols);
+        if (rc) return rc;
+        for (int i = 0; i < Nb; ++i)
+            if (rows[i + 1] - rows[i] > TILE_CAP_BLOCKS)
+                return fail(c, OPMHIP_ANALYSIS_FAILED, "row %d has %d blocks; the ILU0 tile kernel holds at most %d", i, rows[i + 1] - rows[i], TILE_CAP_BLOCKS);
+        if ((rc = alloc_system(c))) return rc;
+        c->pattern_set = true;
+        return OPMHIP_SUCCESS;
+    });
+}
+
+int opmhip_upload_system(opmhip_ctx* c, const double* vals, const double* b) {
+    if (!c) return OPMHIP_INVALID_ARGUMENT;
+    return guarded(c, [&]() -> int {
+        if (!c->pattern_set) return fail(c, OPMHIP_NOT_READY, "upload_system before set_pattern");
+        OPMHIP_HIP(c, hipSetDevice(c->device));
+        int rc = upload_system(c, vals, b);
+        if (rc) return rc;
+        OPMHIP_HIP(c, hipStreamSynchronize(c->stream));
+        return OPMHIP_SUCCESS;
+    });
+}
+
+int opmhip_solve_system(opmhip_ctx* c, int N, int nnz, int dim, double* vals, const int* rows, const int* cols, const double* b,
+                        const opmhip_wells* wells, opmhip_result* res) {
+    if (!c) return OPMHIP_INVALID_ARGUMENT;
+    return guarded(c, [&]() -> int {
+        if (!res) return fail(c, OPMHIP_INVALID_ARGUMENT, "solve_system: res == NULL");
+        std::memset(res, 0, sizeof *res);
+        if (dim != 3) return fail(c, OPMHIP_INVALID_ARGUMENT, "solve_system: only block size 3 is supported (bda/BdaBridge.cpp:207-211)");
+        if (N <= 0 || N % 3 || nnz <= 0 || nnz % 9) return fail(c, OPMHIP_INVALID_ARGUMENT, "solve_system: N/nnz not multiples of the block size");
+        OPMHIP_HIP(c, hipSetDevice(c->device));
+        const double t0 = now();
+        if (!c->pattern_set) {
+            if (!rows || !cols) return fail(c, OPMHIP_NOT_READY, "solve_system: first call needs rows/cols");
+            int rc = opmhip_set_pattern(c, N / 3, nnz / 9, rows, cols);
+            if (rc) return rc == OPMHIP_INVALID_ARGUMENT ? rc : OPMHIP_ANALYSIS_FAILED;
+        }
+        const Pattern& P = c->pat;
+        if (N != P.Nb * 3 || nnz != P.nnzb * 9) return fail(c, OPMHIP_INVALID_ARGUMENT, "solve_system: size differs from the pattern set earlier");
+        if (!vals && !c->system_loaded) return fail(c, OPMHIP_NOT_READY, "solve_system: vals == NULL but no matrix is resident on the device");
+        int rc;
+        if ((rc = upload_system(c, vals, b))) return rc;
+        if ((rc = upload_wells(c, wells))) return rc;
+        OPMHIP_HIP(c, hipStreamSynchronize(c->stream));
+        const double t1 = now();
+        launch_ilu_factor(c);
+        OPMHIP_HIP(c, hipGetLastError());
+        OPMHIP_HIP(c, hipStreamSynchronize(c->stream));
+        c->factored = true;
+        const double t2 = now();
+        if ((rc = bicgstab(c, res))) return rc;
+        OPMHIP_HIP(c, hipStreamSynchronize(c->stream));
+        const double t3 = now();
+        c->have_result = true;
+        res->t_copy = t1 - t0;
+        res->t_factor = t2 - t1;
+        res->t_solve = t3 - t2;
+        res->elapsed = t3 - t0;
+        res->num_colors = P.numColors;
+        if (c->cfg.verbosity > 0)
+            std::fprintf(stderr, "opmhip: converged %d, it %.1f, reduction %.3e, copy %.3f ms, factor %.3f ms, solve %.3f ms\n",
+                         res->converged, res->it, res->reduction, 1e3 * res->t_copy, 1e3 * res->t_factor, 1e3 * res->t_solve);
+        // a singular pivot shows up as a non-finite norm: report it the way the reference's create_preconditioner does
+        if (!std::isfinite(res->reduction)) {
+            res->converged = 0;
+            return fail(c, OPMHIP_CREATE_PRECONDITIONER_FAILED, "non-finite residual norm (singular diagonal block in ILU0?)");
+        }
+        return OPMHIP_SUCCESS;
+    });
+}
+
+int opmhip_get_result(opmhip_ctx* c, double* x) {
+    if (!c) return OPMHIP_INVALID_ARGUMENT;
+    return guarded(c, [&]() -> int {
+        if (!x) return fail(c, OPMHIP_INVALID_ARGUMENT, "get_result: x == NULL");
+        if (!c->have_result) return fail(c, OPMHIP_NOT_READY, "get_result before a solve");
+        OPMHIP_HIP(c, hipSetDevice(c->device));
+        return vec_out(c, c->d_x, x);
+    });
+}
+
+int opmhip_spmv(opmhip_ctx* c, const double* x, double* y) {
+    if (!c) return OPMHIP_INVALID_ARGUMENT;
+    return guarded(c, [&]() -> int {
+        if (!x || !y) return fail(c, OPMHIP_INVALID_ARGUMENT, "spmv: null vector");
+        if (!c->system_loaded) return fail(c, OPMHIP_NOT_READY, "spmv before a matrix was uploaded");
+        OPMHIP_HIP(c, hipSetDevice(c->device));
+        int rc;
+        if ((rc = vec_in(c, x, c->d_pw))) return rc;
+        launch_spmv(c, c->d_pw, c->d_v, 0, nullptr, nullptr);
+        OPMHIP_HIP(c, hipGetLastError());
+        return vec_out(c, c->d_v, y);
+    });
+}
+
+int opmhip_ilu0_factor(opmhip_ctx* c, double* lu_out) {
+    if (!c) return OPMHIP_INVALID_ARGUMENT;
+    return guarded(c, [&]() -> int {
+        if (!c->system_loaded) return fail(c, OPMHIP_NOT_READY, "ilu0_factor before a matrix was uploaded");
+        OPMHIP_HIP(c, hipSetDevice(c->device));
+        launch_ilu_factor(c);
+        OPMHIP_HIP(c, hipGetLastError());
+        c->factored = true;
+        if (lu_out) {
+            launch_lu_to_natural(c, c->d_stageA);
+            OPMHIP_HIP(c, hipMemcpyAsync(lu_out, c->d_stageA, (size_t)c->pat.nnzb * BB * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+        }
+        OPMHIP_HIP(c, hipStreamSynchronize(c->stream));
+        return OPMHIP_SUCCESS;
+    });
+}
+
+int opmhip_ilu0_apply(opmhip_ctx* c, const double* d, double* v) {
+    if (!c) return OPMHIP_INVALID_ARGUMENT;
+    return guarded(c, [&]() -> int {
+        if (!d || !v) return fail(c, OPMHIP_INVALID_ARGUMENT, "ilu0_apply: null vector");
+        if (!c->factored) return fail(c, OPMHIP_NOT_READY, "ilu0_apply before ilu0_factor");
+        OPMHIP_HIP(c, hipSetDevice(c->device));
+        int rc;
+        if ((rc = vec_in(c, d, c->d_p))) return rc;
+        launch_ilu_apply(c, c->d_p, c->d_pw);
+        OPMHIP_HIP(c, hipGetLastError());
+        return vec_out(c, c->d_pw, v);
+    });
+}
+
+int opmhip_get_ordering(opmhip_ctx* c, int* toOrder, int* fromOrder, int* rowsPerColor) {
+    if (!c) return OPMHIP_INVALID_ARGUMENT;
+    if (!c->pattern_set) return fail(c, OPMHIP_NOT_READY, "get_ordering before set_pattern");
+    const Pattern& P = c->pat;
+    if (toOrder) std::memcpy(toOrder, P.toOrder.data(), P.Nb * sizeof(int));
+    if (fromOrder) std::memcpy(fromOrder, P.fromOrder.data(), P.Nb * sizeof(int));
+    if (rowsPerColor)
+        for (int k = 0; k < P.numColors; ++k) rowsPerColor[k] = P.colorPrefix[k + 1] - P.colorPrefix[k];
+    return P.numColors;
+}
+
+int opmhip_time_kernel(opmhip_ctx* c, int which, int reps, double* ms_per_launch) {
+    if (!c) return OPMHIP_INVALID_ARGUMENT;
+    return guarded(c, [&]() -> int {
+        if (!ms_per_launch || reps < 1 || which < 0 || which > 3) return fail(c, OPMHIP_INVALID_ARGUMENT, "time_kernel: bad arguments");
+        if (!c->system_loaded) return fail(c, OPMHIP_NOT_READY, "time_kernel before a matrix was uploaded");
+        if (which != 2 && !c->factored) return fail(c, OPMHIP_NOT_READY, "time_kernel: factor first");
+        OPMHIP_HIP(c, hipSetDevice(c->device));
+        auto once = [&]() {
+            switch (which) {
+                case 0: launch_spmv(c, c->d_pw, c->d_v, 0, nullptr, nullptr); break;
+                case 1: launch_ilu_apply(c, c->d_p, c->d_pw); break;
+                case 2: launch_ilu_factor(c); break;
+                case 3: launch_vector_kernels_once(c); break;
+            }
+        };
+        once();  // warm
+        OPMHIP_HIP(c, hipEventRecord(c->ev0, c->stream));
+        for (int i = 0; i < reps; ++i) once();
+        OPMHIP_HIP(c, hipEventRecord(c->ev1, c->stream));
+        OPMHIP_HIP(c, hipEventSynchronize(c->ev1));
+        OPMHIP_HIP(c, hipGetLastError());
+        float ms = 0.f;
+        OPMHIP_HIP(c, hipEventElapsedTime(&ms, c->ev0, c->ev1));
+        *ms_per_launch = (double)ms / reps;
+        if (which == 2) c->factored = true;
+        return OPMHIP_SUCCESS;
+    });
+}
+
+}  // extern "C"

@@ -1,0 +1,145 @@
+// libopmhip internals: context, device buffers, error plumbing.  Product code — never includes oracle/.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <cstdarg>
+#include <cstdio>
+#include <string>
+#include <vector>
+
+#include "../../include/opmhip.h"
+
+namespace opmhip {
+
+constexpr int BS = 3;
+constexpr int BB = 9;
+
+// ---- tiling constants (see DESIGN.md "tile kernels") -------------------------------------------------
+// One workgroup = one wavefront (64 lanes) = one tile of at most TILE_ROWS block rows, one row per lane.
+// A tile's blocks are streamed into LDS with coalesced 16-byte loads, then each lane walks its own row in
+// the CPU's sequential order.  TILE_CAP_BLOCKS bounds the LDS image (72 B per block + 4 B column).
+constexpr int TILE_ROWS = 64;
+constexpr int TILE_CAP_BLOCKS = 448;  // 64 rows x 7 blocks (Cartesian 7-point stencil)
+
+struct DevBuf {
+    void* p = nullptr;
+    size_t bytes = 0;
+    template <class T> T* as() const { return static_cast<T*>(p); }
+};
+
+struct TileSet {            // tiles over one block-CSR row-pointer array, never crossing a colour boundary
+    std::vector<int> row0;  // [ntiles+1]
+    std::vector<int> colorTile;  // [numColors+1] first tile of each colour
+    int* d_row0 = nullptr;
+    int ntiles() const { return (int)row0.size() - 1; }
+};
+
+struct Pattern {
+    int Nb = 0, nnzb = 0, numColors = 0, nl = 0, nu = 0;
+    // natural order (as handed over)
+    std::vector<int> nat_rowptr, nat_col;
+    // ordering
+    std::vector<int> toOrder, fromOrder, colorPrefix;  // colorPrefix[numColors+1] in rows
+    // internal (reordered) pattern
+    std::vector<int> rowptr, col, diag, nnzMap;  // nnzMap[k_internal] = k_natural
+    std::vector<int> lrowptr, lcol, urowptr, ucol;
+    TileSet tiles;
+    // device copies
+    int *d_rowptr = nullptr, *d_col = nullptr, *d_diag = nullptr, *d_nnzMap = nullptr;
+    int *d_toOrder = nullptr, *d_fromOrder = nullptr;
+    int *d_lrowptr = nullptr, *d_lcol = nullptr, *d_urowptr = nullptr, *d_ucol = nullptr;
+};
+
+struct WellsDev {
+    int num_wells = 0, nperf = 0;
+    int *d_val_pointers = nullptr, *d_Ccols = nullptr, *d_Bcols = nullptr;
+    double *d_C = nullptr, *d_D = nullptr, *d_B = nullptr;
+    size_t cap_wells = 0, cap_perf = 0;
+};
+
+enum Scal {  // device-resident BiCGStab scalars (double d_scal[SC_COUNT])
+    SC_RHO = 0, SC_RHOP, SC_ALPHA, SC_OMEGA, SC_BETA, SC_TMP1, SC_TMP2, SC_NORM, SC_NORM0, SC_COUNT = 16
+};
+
+}  // namespace opmhip
+
+struct opmhip_ctx {
+    opmhip_config cfg;
+    int device = 0;
+    hipStream_t stream = nullptr;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    std::string err;
+    bool pattern_set = false, system_loaded = false, factored = false, have_result = false;
+    opmhip::Pattern pat;
+    // values, internal order
+    double *d_A = nullptr, *d_L = nullptr, *d_U = nullptr, *d_invD = nullptr;
+    // vectors, internal order, 3*Nb each
+    double *d_b = nullptr, *d_x = nullptr, *d_r = nullptr, *d_rw = nullptr, *d_p = nullptr, *d_v = nullptr,
+           *d_s = nullptr, *d_t = nullptr, *d_pw = nullptr;
+    // staging (natural order): matrix values and one vector
+    double *d_stageA = nullptr, *d_stageV = nullptr;
+    double* d_scal = nullptr;   // SC_COUNT doubles
+    double* d_part = nullptr;   // partial sums: 2 x npart
+    int npart = 0;
+    double* h_pinned = nullptr;  // SC_COUNT doubles, pinned
+    opmhip::WellsDev wells;
+    std::vector<void*> allocs;
+};
+
+namespace opmhip {
+
+inline int fail(opmhip_ctx* c, int code, const char* fmt, ...) {
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof buf, fmt, ap);
+    va_end(ap);
+    if (c) c->err = buf;
+    return code;
+}
+
+#define OPMHIP_HIP(ctx, call)                                                                       \
+    do {                                                                                            \
+        hipError_t e_ = (call);                                                                     \
+        if (e_ != hipSuccess)                                                                       \
+            return opmhip::fail(ctx, OPMHIP_DEVICE_ERROR, "%s failed: %s (%s:%d)", #call,           \
+                                hipGetErrorString(e_), __FILE__, __LINE__);                         \
+    } while (0)
+
+template <class T>
+int dev_alloc(opmhip_ctx* c, T** p, size_t count) {
+    void* q = nullptr;
+    size_t bytes = (count ? count : 1) * sizeof(T);
+    hipError_t e = hipMalloc(&q, bytes);
+    if (e != hipSuccess)
+        return fail(c, OPMHIP_DEVICE_ERROR, "hipMalloc(%zu) failed: %s", bytes, hipGetErrorString(e));
+    c->allocs.push_back(q);
+    *p = static_cast<T*>(q);
+    return OPMHIP_SUCCESS;
+}
+template <class T>
+int dev_upload(opmhip_ctx* c, T** p, const std::vector<T>& h) {
+    int rc = dev_alloc(c, p, h.size());
+    if (rc) return rc;
+    if (!h.empty()) OPMHIP_HIP(c, hipMemcpy(*p, h.data(), h.size() * sizeof(T), hipMemcpyHostToDevice));
+    return OPMHIP_SUCCESS;
+}
+
+// reorder.cpp (host): level scheduling / colouring, internal pattern, L/U split, tiles
+int build_pattern(opmhip_ctx* c, int Nb, int nnzb, const int* rows, const int* cols);
+
+// kernels.hip launchers (all on c->stream)
+void launch_permute_blocks(opmhip_ctx* c, const double* nat, double* internal);
+void launch_unpermute_blocks(opmhip_ctx* c, const double* internal, double* nat);  // for lu_out
+void launch_vec_to_internal(opmhip_ctx* c, const double* nat, double* internal);
+void launch_vec_to_natural(opmhip_ctx* c, const double* internal, double* nat);
+void launch_zero_diag_fix(opmhip_ctx* c);
+void launch_spmv(opmhip_ctx* c, const double* x, double* y, int ndot, const double* w0, const double* w1);
+void launch_ilu_factor(opmhip_ctx* c);
+void launch_ilu_apply(opmhip_ctx* c, const double* d, double* v);
+void launch_wells_apply(opmhip_ctx* c, const double* x, double* y);
+void launch_lu_to_natural(opmhip_ctx* c, double* d_out_internal_layout);
+int bicgstab(opmhip_ctx* c, opmhip_result* res);
+void launch_vector_kernels_once(opmhip_ctx* c);
+
+}  // namespace opmhip

@@ -1,0 +1,237 @@
+// Host-side analysis done once per sparsity pattern (the reference's "analyse_matrix",
+// bda/BILU0.cpp:51-158): ILU ordering, internal (reordered) block-CSR pattern, L/U split, device tiling.
+#include <algorithm>
+#include <cstdint>
+#include <numeric>
+
+#include "internal.hpp"
+
+namespace opmhip {
+namespace {
+
+void transpose_pattern(const Pattern& P, std::vector<int>& cptr, std::vector<int>& ridx);
+
+// level(i) = 1 + max level over the rows j < i that row i is coupled to (Saad 11.6.3).  Couplings are taken
+// from the row AND the column of i, as the reference's findLevelScheduling does with its CSR + CSC pair
+// (bda/Reorder.cpp:266-318), so that both the forward and the backward sweep are race free on a
+// structurally non-symmetric pattern.  For a symmetric pattern this is the plain row-dependency level.
+void levels(const Pattern& P, std::vector<int>& color, int& ncol) {
+    std::vector<int> cptr, ridx;
+    transpose_pattern(P, cptr, ridx);
+    color.assign(P.Nb, 0);
+    ncol = 0;
+    for (int i = 0; i < P.Nb; ++i) {
+        int l = 0;
+        for (int k = P.nat_rowptr[i]; k < P.nat_rowptr[i + 1]; ++k) {
+            const int j = P.nat_col[k];
+            if (j < i) l = std::max(l, color[j] + 1);
+        }
+        for (int k = cptr[i]; k < cptr[i + 1]; ++k) {
+            const int j = ridx[k];
+            if (j < i) l = std::max(l, color[j] + 1);
+        }
+        color[i] = l;
+        ncol = std::max(ncol, l + 1);
+    }
+}
+
+uint32_t mix(uint32_t i) {  // splitmix64 -> 31 bits: deterministic replacement for std::random_device weights
+    uint64_t z = (uint64_t)i + 0x9E3779B97F4A7C15ull;
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+    z ^= z >> 31;
+    return (uint32_t)(z & 0x7fffffffu);
+}
+
+void transpose_pattern(const Pattern& P, std::vector<int>& cptr, std::vector<int>& ridx) {
+    cptr.assign(P.Nb + 1, 0);
+    ridx.resize(P.nnzb);
+    for (int k = 0; k < P.nnzb; ++k) cptr[P.nat_col[k] + 1]++;
+    std::partial_sum(cptr.begin(), cptr.end(), cptr.begin());
+    std::vector<int> w(cptr.begin(), cptr.end() - 1);
+    for (int i = 0; i < P.Nb; ++i)
+        for (int k = P.nat_rowptr[i]; k < P.nat_rowptr[i + 1]; ++k) ridx[w[P.nat_col[k]]++] = i;
+}
+
+// Jones-Plassmann rounds (bda/Reorder.cpp:59-172): in round c an uncoloured node takes colour c when none
+// of its neighbours (row or column) already has c and it carries the largest weight among its uncoloured
+// neighbours.
+void color_jp(const Pattern& P, std::vector<int>& color, int& ncol) {
+    std::vector<int> cptr, ridx;
+    transpose_pattern(P, cptr, ridx);
+    color.assign(P.Nb, -1);
+    std::vector<uint32_t> w(P.Nb);
+    for (int i = 0; i < P.Nb; ++i) w[i] = mix((uint32_t)i);
+    int left = P.Nb;
+    ncol = 0;
+    for (int c = 0; left > 0; ++c) {
+        for (int i = 0; i < P.Nb; ++i) {
+            if (color[i] != -1) continue;
+            bool win = true;
+            auto look = [&](const int* idx, int b, int e) {
+                for (int k = b; k < e && win; ++k) {
+                    const int j = idx[k];
+                    if (j == i) continue;
+                    const int jc = color[j];
+                    if (jc == c) win = false;
+                    else if (jc == -1 && (w[i] < w[j] || (w[i] == w[j] && i < j))) win = false;
+                }
+            };
+            look(P.nat_col.data(), P.nat_rowptr[i], P.nat_rowptr[i + 1]);
+            look(ridx.data(), cptr[i], cptr[i + 1]);
+            if (win) {
+                color[i] = c;
+                --left;
+            }
+        }
+        ncol = c + 1;
+    }
+}
+
+void color_greedy(const Pattern& P, std::vector<int>& color, int& ncol) {
+    std::vector<int> cptr, ridx;
+    transpose_pattern(P, cptr, ridx);
+    color.assign(P.Nb, -1);
+    ncol = 0;
+    std::vector<char> used;
+    for (int i = 0; i < P.Nb; ++i) {
+        used.assign(ncol + 1, 0);
+        for (int k = P.nat_rowptr[i]; k < P.nat_rowptr[i + 1]; ++k)
+            if (color[P.nat_col[k]] >= 0) used[color[P.nat_col[k]]] = 1;
+        for (int k = cptr[i]; k < cptr[i + 1]; ++k)
+            if (color[ridx[k]] >= 0) used[color[ridx[k]]] = 1;
+        int c = 0;
+        while (used[c]) ++c;
+        color[i] = c;
+        ncol = std::max(ncol, c + 1);
+    }
+}
+
+void build_tiles(const std::vector<int>& rowptr, const std::vector<int>& colorPrefix, TileSet& T) {
+    T.row0.clear();
+    T.colorTile.clear();
+    const int ncol = (int)colorPrefix.size() - 1;
+    for (int c = 0; c < ncol; ++c) {
+        T.colorTile.push_back((int)T.row0.size());
+        int r = colorPrefix[c];
+        const int rend = colorPrefix[c + 1];
+        while (r < rend) {
+            T.row0.push_back(r);
+            int e = r + 1;  // a tile always holds at least one row (an over-long row is read from HBM directly)
+            while (e < rend && e - r < TILE_ROWS && rowptr[e + 1] - rowptr[r] <= TILE_CAP_BLOCKS) ++e;
+            r = e;
+        }
+    }
+    T.colorTile.push_back((int)T.row0.size());
+    T.row0.push_back(colorPrefix[ncol]);
+}
+
+}  // namespace
+
+int build_pattern(opmhip_ctx* c, int Nb, int nnzb, const int* rows, const int* cols) {
+    Pattern& P = c->pat;
+    if (Nb <= 0 || nnzb <= 0 || !rows || !cols) return fail(c, OPMHIP_INVALID_ARGUMENT, "set_pattern: bad arguments");
+    if (rows[0] != 0 || rows[Nb] != nnzb) return fail(c, OPMHIP_INVALID_ARGUMENT, "set_pattern: rows[] inconsistent with nnzb");
+    P.Nb = Nb;
+    P.nnzb = nnzb;
+    P.nat_rowptr.assign(rows, rows + Nb + 1);
+    P.nat_col.assign(cols, cols + nnzb);
+    for (int i = 0; i < Nb; ++i) {
+        bool hasDiag = false;
+        for (int k = rows[i]; k < rows[i + 1]; ++k) {
+            if (cols[k] < 0 || cols[k] >= Nb) return fail(c, OPMHIP_INVALID_ARGUMENT, "set_pattern: column out of range in row %d", i);
+            if (k > rows[i] && cols[k] <= cols[k - 1]) return fail(c, OPMHIP_INVALID_ARGUMENT, "set_pattern: columns of row %d not ascending", i);
+            hasDiag |= (cols[k] == i);
+        }
+        // "diagonal entry missing" (linalg/ParallelOverlappingILU0.hpp:484-485) -> analysis failure
+        if (!hasDiag) return fail(c, OPMHIP_ANALYSIS_FAILED, "set_pattern: row %d has no diagonal block", i);
+    }
+    std::vector<int> color;
+    int ncol = 0;
+    switch (c->cfg.reorder) {
+        case OPMHIP_REORDER_LEVEL_SCHEDULING: levels(P, color, ncol); break;
+        case OPMHIP_REORDER_GRAPH_COLORING: color_jp(P, color, ncol); break;
+        case OPMHIP_REORDER_GRAPH_COLORING_GREEDY: color_greedy(P, color, ncol); break;
+        default: return fail(c, OPMHIP_INVALID_ARGUMENT, "unknown reorder kind %d", c->cfg.reorder);
+    }
+    P.numColors = ncol;
+    // rows keep their natural relative order inside a colour (colorsToReordering, bda/Reorder.cpp:212-226)
+    P.colorPrefix.assign(ncol + 1, 0);
+    for (int i = 0; i < Nb; ++i) P.colorPrefix[color[i] + 1]++;
+    std::partial_sum(P.colorPrefix.begin(), P.colorPrefix.end(), P.colorPrefix.begin());
+    P.toOrder.resize(Nb);
+    P.fromOrder.resize(Nb);
+    {
+        std::vector<int> next(P.colorPrefix.begin(), P.colorPrefix.end() - 1);
+        for (int i = 0; i < Nb; ++i) {
+            const int p = next[color[i]]++;
+            P.toOrder[i] = p;
+            P.fromOrder[p] = i;
+        }
+    }
+    // internal pattern: row p = natural row fromOrder[p], columns renamed and re-sorted
+    // (reorderBlockedMatrixByPattern, bda/Reorder.cpp:179-207) - done once here for the pattern; values follow
+    // on the device through nnzMap.
+    P.rowptr.assign(Nb + 1, 0);
+    P.col.resize(nnzb);
+    P.nnzMap.resize(nnzb);
+    P.diag.assign(Nb, -1);
+    std::vector<std::pair<int, int>> tmp;
+    for (int p = 0; p < Nb; ++p) {
+        const int i = P.fromOrder[p];
+        tmp.clear();
+        for (int k = rows[i]; k < rows[i + 1]; ++k) tmp.emplace_back(P.toOrder[cols[k]], k);
+        std::sort(tmp.begin(), tmp.end());
+        int o = P.rowptr[p];
+        for (auto& t : tmp) {
+            P.col[o] = t.first;
+            P.nnzMap[o] = t.second;
+            if (t.first == p) P.diag[p] = o;
+            ++o;
+        }
+        P.rowptr[p + 1] = o;
+    }
+    // every lower entry must point into an earlier colour, otherwise the colour-by-colour sweeps are wrong
+    {
+        std::vector<int> colorOf(Nb);
+        for (int cc = 0; cc < ncol; ++cc)
+            for (int p = P.colorPrefix[cc]; p < P.colorPrefix[cc + 1]; ++p) colorOf[p] = cc;
+        for (int p = 0; p < Nb; ++p)
+            for (int k = P.rowptr[p]; k < P.rowptr[p + 1]; ++k)
+                if (P.col[k] != p && colorOf[P.col[k]] == colorOf[p])
+                        return fail(c, OPMHIP_ANALYSIS_FAILED, "ordering is not a valid schedule at row %d", p);
+    }
+    // L / U split (what Dune's convertToCRS produces, linalg/ParallelOverlappingILU0.hpp:497-584; here both
+    // parts keep ascending columns and the sweeps choose their own direction)
+    P.lrowptr.assign(Nb + 1, 0);
+    P.urowptr.assign(Nb + 1, 0);
+    P.lcol.clear();
+    P.ucol.clear();
+    for (int p = 0; p < Nb; ++p) {
+        for (int k = P.rowptr[p]; k < P.rowptr[p + 1]; ++k) {
+            if (P.col[k] < p) P.lcol.push_back(P.col[k]);
+            else if (P.col[k] > p) P.ucol.push_back(P.col[k]);
+        }
+        P.lrowptr[p + 1] = (int)P.lcol.size();
+        P.urowptr[p + 1] = (int)P.ucol.size();
+    }
+    P.nl = (int)P.lcol.size();
+    P.nu = (int)P.ucol.size();
+    build_tiles(P.rowptr, P.colorPrefix, P.tiles);
+
+    int rc;
+    if ((rc = dev_upload(c, &P.d_rowptr, P.rowptr))) return rc;
+    if ((rc = dev_upload(c, &P.d_col, P.col))) return rc;
+    if ((rc = dev_upload(c, &P.d_diag, P.diag))) return rc;
+    if ((rc = dev_upload(c, &P.d_nnzMap, P.nnzMap))) return rc;
+    if ((rc = dev_upload(c, &P.d_toOrder, P.toOrder))) return rc;
+    if ((rc = dev_upload(c, &P.d_fromOrder, P.fromOrder))) return rc;
+    if ((rc = dev_upload(c, &P.d_lrowptr, P.lrowptr))) return rc;
+    if ((rc = dev_upload(c, &P.d_lcol, P.lcol))) return rc;
+    if ((rc = dev_upload(c, &P.d_urowptr, P.urowptr))) return rc;
+    if ((rc = dev_upload(c, &P.d_ucol, P.ucol))) return rc;
+    if ((rc = dev_upload(c, &P.tiles.d_row0, P.tiles.row0))) return rc;
+    return OPMHIP_SUCCESS;
+}
+
+}  // namespace opmhip

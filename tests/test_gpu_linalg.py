@@ -1,0 +1,182 @@
+"""GPU parity of the linear-solve half of the hot path, through the C-ABI (libopmhip.so), against the CPU oracle
+and the reference's own fixtures.  Reads like tests/test_cusparseSolver.cpp: load matr33/rhs3, solve_system,
+get_result, compare."""
+import json
+import os
+
+import numpy as np
+import pytest
+
+from helpers import laplace_block_system, random_block_system
+
+pytestmark = pytest.mark.gpu
+
+REORDERS = ["level_scheduling", "graph_coloring", "graph_coloring_greedy"]
+
+
+def _load(pkg, golden, mat, rhs):
+    Nb, rp, ci, v, bs = pkg.mmio.read_block_matrix(os.path.join(golden, "linalg", mat))
+    b = pkg.mmio.read_block_vector(os.path.join(golden, "linalg", rhs))
+    return Nb, rp, ci, v, b
+
+
+@pytest.mark.parametrize("reorder", REORDERS)
+def test_matr33_like_test_cusparseSolver(pkg, orc, golden, reorder):
+    """tests/test_cusparseSolver.cpp:49-131 harness: tol 0.5, maxit 20 from options_flexiblesolver.json."""
+    Nb, rp, ci, v, b = _load(pkg, golden, "matr33.txt", "rhs3.txt")
+    s = pkg.capi.HipSolver(verbosity=0, maxit=20, tolerance=0.5, ilu_relaxation=1.0, reorder=reorder)
+    res = s.solve_system(Nb, rp, ci, v.copy(), b)
+    x = s.get_result()
+    assert res.converged
+    xo, ro = orc.solve(Nb, rp, ci, v, b, tol=0.5, maxit=20, w=1.0, reorder=reorder)
+    assert res.it == ro.it
+    np.testing.assert_allclose(x, xo, rtol=1e-9)
+    # exact solution pinned by tests/test_flexiblesolver.cpp:114-116 (ILU0 is exact on this block-tridiagonal matrix)
+    with open(os.path.join(golden, "linalg", "expected.json")) as f:
+        e = json.load(f)["exact_noprec_tol1e-12_maxit200"]
+    if reorder == "level_scheduling":
+        np.testing.assert_allclose(x, e["x"], rtol=2e-5)
+
+
+@pytest.mark.parametrize("reorder", REORDERS)
+@pytest.mark.parametrize("shape", [(6, 5, 4), (17, 9, 5), (40, 30, 20)])
+def test_spmv_bit_exact(pkg, orc, reorder, shape):
+    Nb, rp, ci, v = laplace_block_system(*shape, seed=11)
+    x = np.random.default_rng(5).standard_normal(Nb * 3)
+    s = pkg.capi.HipSolver(reorder=reorder)
+    s.set_pattern(Nb, rp, ci)
+    s.upload_system(v)
+    y = s.spmv(x)
+    # same matrix in the device's internal order through the oracle: identical operation order -> identical bits
+    to, fr, rpc = s.ordering()
+    rr, rc, rv = orc.reorder_matrix(Nb, rp, ci, v, to, fr)
+    xi = x.reshape(Nb, 3)[fr].reshape(-1)
+    yo = orc.spmv(Nb, rr, rc, rv, xi).reshape(Nb, 3)[to].reshape(-1)
+    assert np.array_equal(y, yo)
+    np.testing.assert_allclose(y, orc.spmv(Nb, rp, ci, v, x), rtol=1e-12, atol=1e-12)
+
+
+@pytest.mark.parametrize("reorder", REORDERS)
+@pytest.mark.parametrize("mode,w", [("post_scale", 0.9), ("in_sweep", 0.9), ("post_scale", 1.0)])
+def test_ilu0_factor_and_apply_bit_exact(pkg, orc, reorder, mode, w):
+    Nb, rp, ci, v = laplace_block_system(13, 11, 7, seed=21)
+    s = pkg.capi.HipSolver(reorder=reorder, ilu_relaxation=w, relax_mode=mode)
+    s.set_pattern(Nb, rp, ci)
+    s.upload_system(v)
+    lu = s.ilu0_factor()
+    to, fr, rpc = s.ordering()
+    rr, rc, rv = orc.reorder_matrix(Nb, rp, ci, v, to, fr)
+    lu_o = orc.ilu0_factor(Nb, rr, rc, rv)
+    assert np.array_equal(lu, lu_o)
+    d = np.random.default_rng(8).standard_normal(Nb * 3)
+    z = s.ilu0_apply(d)
+    zo = orc.ilu0_apply(Nb, rr, rc, lu_o, d.reshape(Nb, 3)[fr].reshape(-1), w=w, mode=mode)
+    assert np.array_equal(z, zo.reshape(Nb, 3)[to].reshape(-1))
+
+
+def test_level_scheduling_equals_cpu_natural_order_ilu(pkg, orc):
+    """The level-scheduled device factorisation is the CPU's natural-order ILU0 (same factors, bit for bit on a
+    Cartesian pattern where levels keep each row's lower entries in natural order)."""
+    Nb, rp, ci, v = laplace_block_system(9, 8, 7, seed=2)
+    s = pkg.capi.HipSolver(reorder="level_scheduling", ilu_relaxation=0.9)
+    s.set_pattern(Nb, rp, ci)
+    s.upload_system(v)
+    s.ilu0_factor(want_factors=False)
+    d = np.random.default_rng(3).standard_normal(Nb * 3)
+    z = s.ilu0_apply(d)
+    lu = orc.ilu0_factor(Nb, rp, ci, v)
+    zo = orc.ilu0_apply(Nb, rp, ci, lu, d, w=0.9, mode="post_scale")
+    assert np.array_equal(z, zo)
+
+
+@pytest.mark.parametrize("reorder", REORDERS)
+def test_solve_matches_oracle(pkg, orc, reorder):
+    Nb, rp, ci, v = laplace_block_system(24, 20, 12, seed=4)
+    b = np.random.default_rng(9).standard_normal(Nb * 3)
+    s = pkg.capi.HipSolver(tolerance=1e-2, maxit=200, reorder=reorder)
+    res = s.solve_system(Nb, rp, ci, v.copy(), b)
+    x = s.get_result()
+    xo, ro = orc.solve(Nb, rp, ci, v, b, tol=1e-2, maxit=200, w=0.9, reorder=reorder)
+    assert res.converged and ro.converged
+    assert res.it == ro.it and res.iterations == ro.iterations
+    # identical preconditioner and SpMV bits; only the dot products are summed in a different order
+    np.testing.assert_allclose(x, xo, rtol=1e-9, atol=1e-12)
+    assert abs(res.reduction - ro.reduction) <= 1e-9 * ro.reduction
+    # and it is a solution
+    r = b - orc.spmv(Nb, rp, ci, v, x)
+    assert np.linalg.norm(r) < 1e-2 * np.linalg.norm(b) * (1 + 1e-9)
+    # second solve on the same context (pattern reuse, "initialized == true" path) with new values
+    v2 = v * 1.01
+    res2 = s.solve_system(Nb, None, None, v2, b)
+    x2 = s.get_result()
+    xo2, _ = orc.solve(Nb, rp, ci, v2, b, tol=1e-2, maxit=200, w=0.9, reorder=reorder)
+    np.testing.assert_allclose(x2, xo2, rtol=1e-9, atol=1e-12)
+
+
+def test_irregular_rows_and_long_rows(pkg, orc):
+    Nb, rp, ci, v = random_block_system(700, pattern="random", seed=6, extra=5)
+    b = np.random.default_rng(1).standard_normal(Nb * 3)
+    for reorder in REORDERS:
+        s = pkg.capi.HipSolver(tolerance=1e-6, maxit=200, reorder=reorder)
+        res = s.solve_system(Nb, rp, ci, v.copy(), b)
+        x = s.get_result()
+        to, fr, rpc = s.ordering()
+        rr, rc, rv = orc.reorder_matrix(Nb, rp, ci, v, to, fr)
+        lu = s.ilu0_factor()
+        assert np.array_equal(lu, orc.ilu0_factor(Nb, rr, rc, rv))
+        assert res.converged
+        r = b - orc.spmv(Nb, rp, ci, v, x)
+        assert np.linalg.norm(r) < 1e-6 * np.linalg.norm(b) * 1.001
+
+
+def test_wells_operator(pkg, orc):
+    rng = np.random.default_rng(11)
+    Nb, rp, ci, v = laplace_block_system(12, 10, 6, seed=13)
+    perfs = [5, 1, 9]
+    vp = np.concatenate([[0], np.cumsum(perfs)]).astype(np.int32)
+    nperf = int(vp[-1])
+    cols = rng.choice(Nb, nperf, replace=False).astype(np.int32)
+    W = dict(numWells=3, val_pointers=vp, Ccols=cols, Bcols=cols.copy(), Cnnzs=0.05 * rng.standard_normal(nperf * 12),
+             Bnnzs=0.05 * rng.standard_normal(nperf * 12), Dnnzs=0.5 * rng.standard_normal(3 * 16))
+    b = rng.standard_normal(Nb * 3)
+    s = pkg.capi.HipSolver(tolerance=1e-8, maxit=200, reorder="graph_coloring_greedy")
+    res = s.solve_system(Nb, rp, ci, v.copy(), b, wells=W)
+    x = s.get_result()
+    xo, ro = orc.solve(Nb, rp, ci, v, b, tol=1e-8, maxit=200, w=0.9, reorder="graph_coloring_greedy", wells=W)
+    assert res.converged and res.it == ro.it
+    np.testing.assert_allclose(x, xo, rtol=1e-8, atol=1e-12)
+    # x solves (A - C^T D^-1 B) x = b
+    r = b - orc.wells_apply(W, x, orc.spmv(Nb, rp, ci, v, x))
+    assert np.linalg.norm(r) < 1e-8 * np.linalg.norm(b) * 1.001
+
+
+def test_zero_diagonal_fix_and_nonconvergence(pkg, orc):
+    Nb, rp, ci, v = laplace_block_system(6, 6, 4, seed=14)
+    b = np.ones(Nb * 3)
+    dk = [k for i in range(Nb) for k in range(rp[i], rp[i + 1]) if ci[k] == i]
+    v0 = v.copy()
+    v0[dk[3] * 9 + 4] = 0.0
+    s = pkg.capi.HipSolver(tolerance=1e-2, maxit=200, reorder="level_scheduling")
+    res = s.solve_system(Nb, rp, ci, v0.copy(), b)
+    xo, ro = orc.solve(Nb, rp, ci, v0, b, tol=1e-2, maxit=200, w=0.9, zero_diag_fix=True)
+    assert res.converged == ro.converged and res.it == ro.it
+    # maxit exhaustion is reported, not raised (ISTLSolverEbos falls back to Dune in that case)
+    s2 = pkg.capi.HipSolver(tolerance=1e-14, maxit=2, reorder="graph_coloring")
+    res2 = s2.solve_system(Nb, rp, ci, v.copy(), b)
+    assert not res2.converged and res2.iterations == 2 and res2.it == 2.5
+
+
+def test_argument_errors(pkg):
+    Nb, rp, ci, v = laplace_block_system(4, 4, 2, seed=1)
+    s = pkg.capi.HipSolver()
+    with pytest.raises(pkg.capi.OpmHipError) as e:
+        s.get_result()
+    assert e.value.code == pkg.capi.NOT_READY
+    bad = ci.copy()
+    bad[1], bad[2] = bad[2], bad[1]
+    with pytest.raises(pkg.capi.OpmHipError) as e:
+        s.set_pattern(Nb, rp, bad)
+    assert e.value.code == pkg.capi.INVALID_ARGUMENT
+    res = pkg.capi.Result()
+    import ctypes as C
+    assert pkg.capi.lib().opmhip_solve_system(s._h, 8, 16, 2, None, None, None, None, None, C.byref(res)) == pkg.capi.INVALID_ARGUMENT
