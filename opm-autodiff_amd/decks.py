@@ -1,0 +1,124 @@
+"""Synthetic black-oil cases in the form the hot path consumes (arrays, SI units): what Flow's deck-side setup
+(EclProblem / EclTransmissibility / equilibration, all outside the hot path) would hand to the assembly.
+
+Recipes follow SURVEY.md §8(d): Cartesian nx x ny x nz, DX = DY = 20 m, DZ = 5 m, tops at 2500 m, PORO 0.25,
+PERM 100 mD (homogeneous) or log-normal exp(N(ln 100, 1)) with rng(12345); SPE1 fluid; hydrostatic initial state,
+p = 250 bar at the top, Sw = 0.2 and either Sg = 0 with Rs = 0.8 RsSat(p) ("undersaturated") or Sg = 0.1
+("saturated"), perturbed with rng(2024) by +-1 % on p and +-0.02 on the saturations.
+"""
+import numpy as np
+
+from . import fluid as _fluid
+from . import grid as _grid
+
+MILLIDARCY = 9.869232667160130e-16
+SW_PO_SG, SW_PO_RS = 0, 1  # PrimaryVariables::PrimaryVarsMeaning
+
+
+def rs_sat(fl, p, region=0):
+    """Saturated Rs(p) of the PVTO table (piecewise linear in the bubble-point pressures, linear extrapolation)."""
+    nodes = fl.pvt[region]["pvto"]
+    xp = np.array([n["p"][0] for n in nodes])
+    fp = np.array([n["rs"] for n in nodes])
+    p = np.asarray(p, float)
+    s = np.clip(np.searchsorted(xp, p, side="right") - 1, 0, len(xp) - 2)
+    return fp[s] + (fp[s + 1] - fp[s]) * (p - xp[s]) / (xp[s + 1] - xp[s])
+
+
+def cartesian_case(nx, ny, nz, dx=20.0, dy=20.0, dz=5.0, top=2500.0, poro=0.25, perm_md=100.0, heterogeneous=False,
+                   state="undersaturated", perturb=True, fluid=None, seed_state=2024):
+    fl = fluid if fluid is not None else _fluid.spe1_fluid()[0]
+    pat = _grid.cartesian_pattern(nx, ny, nz)
+    Nb = pat["Nb"]
+    if heterogeneous:
+        perm = np.exp(np.random.default_rng(12345).normal(np.log(perm_md), 1.0, Nb)) * MILLIDARCY
+    else:
+        perm = np.full(Nb, perm_md * MILLIDARCY)
+    volume, depth, area = _grid.cartesian_geometry(pat, dx, dy, dz, top)
+    trans = _grid.tpfa_transmissibility(pat, perm, perm, perm, dx, dy, dz)
+    rng = np.random.default_rng(seed_state)
+    p = 250e5 + 7000.0 * (depth - top)
+    sw = np.full(Nb, 0.2)
+    if perturb:
+        p = p * (1.0 + rng.uniform(-0.01, 0.01, Nb))
+        sw = sw + rng.uniform(-0.02, 0.02, Nb)
+    pv = np.zeros((Nb, 3))
+    pv[:, 0], pv[:, 1] = sw, p
+    if state == "undersaturated":
+        meaning = np.full(Nb, SW_PO_RS, np.uint8)
+        pv[:, 2] = 0.8 * rs_sat(fl, p)
+    elif state == "saturated":
+        meaning = np.full(Nb, SW_PO_SG, np.uint8)
+        pv[:, 2] = 0.1 + (rng.uniform(-0.02, 0.02, Nb) if perturb else 0.0)
+    elif state == "mixed":  # both meanings in one grid: gas cap in the upper half
+        meaning = np.where(depth < np.median(depth), SW_PO_SG, SW_PO_RS).astype(np.uint8)
+        pv[:, 2] = np.where(meaning == SW_PO_SG, 0.1 + (rng.uniform(-0.02, 0.02, Nb) if perturb else 0.0),
+                            0.8 * rs_sat(fl, p))
+    else:
+        raise ValueError(state)
+    return dict(Nb=Nb, nx=nx, ny=ny, nz=nz, rowptr=pat["rowptr"], col=pat["col"], face_dir=pat["face_dir"],
+                trans=np.ascontiguousarray(trans), area=np.ascontiguousarray(area),
+                poro=np.full(Nb, float(poro)), volume=np.ascontiguousarray(volume), depth=np.ascontiguousarray(depth),
+                fluid=fl, pv=np.ascontiguousarray(pv.reshape(-1)), meaning=meaning)
+
+
+def spe1_case(state="equil"):
+    """The SPE1CASE1 grid (10 x 10 x 3, layered DZ/PERM, FIELD deck converted to SI) with its EQUIL-like initial
+    state: p = 4800 psia at the datum with a constant oil gradient, Sw = connate 0.12, Rs = 1.27 Mscf/stb constant
+    (RSVD), i.e. undersaturated oil everywhere (python/test_data/SPE1CASE1/SPE1CASE1.DATA:252-290)."""
+    fl, d = _fluid.spe1_fluid()
+    g = d["grid"]
+    nx, ny, nz = g["nx"], g["ny"], g["nz"]
+    pat = _grid.cartesian_pattern(nx, ny, nz)
+    Nb = pat["Nb"]
+    k = np.arange(Nb) // (nx * ny)
+    dzs = np.array(g["dz"])
+    dz = dzs[k]
+    ztop = g["tops"] + np.concatenate([[0.0], np.cumsum(dzs)[:-1]])[k]
+    depth = ztop + 0.5 * dz
+    volume = g["dx"] * g["dy"] * dz
+    perm = np.array(g["perm"])[k]
+    fd = np.abs(pat["face_dir"].astype(int))
+    row = _grid.row_of_entries(pat["rowptr"])
+    col = pat["col"]
+    area = np.zeros(len(col))
+    area[fd == 1] = (g["dy"] * dz[row])[fd == 1]
+    area[fd == 2] = (g["dx"] * dz[row])[fd == 2]
+    area[fd == 3] = g["dx"] * g["dy"]
+    # half transmissibilities with per-cell DZ (ebos/ecltransmissibility.cc:928-944), harmonic combination (:352-356)
+    T = np.zeros(len(col))
+    for dnum, h_of, a_of in ((1, lambda c: np.full(len(c), g["dx"]), lambda c: g["dy"] * dz[c]),
+                             (2, lambda c: np.full(len(c), g["dy"]), lambda c: g["dx"] * dz[c]),
+                             (3, lambda c: dz[c], lambda c: np.full(len(c), g["dx"] * g["dy"]))):
+        m = fd == dnum
+        half = lambda c: perm[c] * a_of(c) * (h_of(c) / 2.0) / (h_of(c) / 2.0) ** 2
+        t1, t2 = half(row[m]), half(col[m])
+        T[m] = 1.0 / (1.0 / t1 + 1.0 / t2)
+    e = d["equil"]
+    rho_o = d["density"]["oil"] * 0.78  # rough reservoir oil gradient; the state only has to be plausible
+    p = e["datum_pressure"] + rho_o * 9.80665 * (depth - e["datum_depth"])
+    pv = np.zeros((Nb, 3))
+    pv[:, 0] = d["swof"][0][0]
+    pv[:, 1] = p
+    pv[:, 2] = d["rsvd"][0][1]
+    meaning = np.full(Nb, SW_PO_RS, np.uint8)
+    return dict(Nb=Nb, nx=nx, ny=ny, nz=nz, rowptr=pat["rowptr"], col=col, face_dir=pat["face_dir"],
+                trans=np.ascontiguousarray(T), area=np.ascontiguousarray(area), poro=np.full(Nb, g["poro"]),
+                volume=np.ascontiguousarray(volume), depth=np.ascontiguousarray(depth), fluid=fl,
+                pv=np.ascontiguousarray(pv.reshape(-1)), meaning=meaning)
+
+
+def five_spot_source(case, rate_sm3_per_day=50.0):
+    """Fixed-rate source terms (surface m^3/s per cell, equations oil/water/gas): water injected in one corner
+    column, the same surface volume of oil (+ its dissolved gas at the initial Rs) produced in the opposite one."""
+    Nb, nx, ny, nz = case["Nb"], case["nx"], case["ny"], case["nz"]
+    src = np.zeros((Nb, 3))
+    q = rate_sm3_per_day / 86400.0 / nz
+    for k in range(nz):
+        inj = 0 + nx * (0 + ny * k)
+        prod = (nx - 1) + nx * ((ny - 1) + ny * k)
+        src[inj, 1] += q
+        src[prod, 0] -= q
+        rs = case["pv"][3 * prod + 2] if case["meaning"][prod] == SW_PO_RS else float(rs_sat(case["fluid"], case["pv"][3 * prod + 1]))
+        src[prod, 2] -= q * rs
+    return np.ascontiguousarray(src.reshape(-1))

@@ -1,0 +1,374 @@
+// ORACLE — TEST INFRASTRUCTURE ONLY (see linalg.hpp).
+// CPU restatement of the per-Newton-iteration assembly path of Flow's three-phase black-oil model
+// (live oil + dry gas + water, no extensions): intensive quantities, TPFA flux, storage, element-centred AD
+// linearisation into block-CSR, convergence norms and the Newton update with primary-variable switching.
+//
+// In-tree sources followed line by line:
+//   ebos/eclfluxmodule.hh:212-357                     (calculateGradients_: TPFA flux, upwinding, THPRES)
+//   ebos/eclproblem.hh:1430-1486, 1682-1765, 1823-1845  (porosity, depth, rock compressibility, Rs caps, source)
+//   opm/simulators/flow/BlackoilModelEbos.hpp:572-904 (convergence), :549-563 (updateSolution)
+// Out-of-tree (opm-models), restated from the public 2021.10 sources as recalled,
+// UNVERIFIED vs upstream: BlackOilIntensiveQuantities::update, BlackOilLocalResidual::{computeStorage,
+// computeFlux}, FvBaseLocalResidual::eval, FvBaseAdLocalLinearizer, FvBaseLinearizer, BlackOilNewtonMethod::update_,
+// BlackOilPrimaryVariables::adaptPrimaryVariables.
+//
+// PARITY UNPINNED for the assembly: the reference tree holds no numeric test of residual, Jacobian, intensive
+// quantities or flux (SURVEY.md §4 "What is not tested").  Independent evidence kept in tests/: finite-difference
+// check of the Jacobian, mass conservation of the fluxes, and the Norne PVT points for the oil PVT.
+//
+// Index conventions (BlackOilIndices / BlackOilFluidSystem, recalled): phases water 0, oil 1, gas 2;
+// equations (components) oil 0, water 1, gas 2; primary variables Sw 0, p 1, {Sg | Rs} 2.
+#pragma once
+#include <cstdint>
+#include <limits>
+
+#include "fluid.hpp"
+#include "linalg.hpp"
+
+namespace orc {
+
+enum { WATER = 0, OIL = 1, GAS = 2 };
+enum { EQ_OIL = 0, EQ_WATER = 1, EQ_GAS = 2 };
+enum { PV_SW = 0, PV_P = 1, PV_X = 2 };
+enum Meaning : uint8_t { Sw_po_Sg = 0, Sw_po_Rs = 1 };  // PrimaryVariables::PrimaryVarsMeaning (Sw_pg_Rv unused: dry gas)
+
+constexpr double GRAVITY = 9.80665;
+
+// What BlackOilIntensiveQuantities caches per cell (ebos/eclproblem.hh:456-458) and the flux/storage code reads.
+struct IQ {
+    Ev S[3], p[3], invB[3], mob[3], rho[3];
+    Ev Rs, Rv, poro;
+    double refPoro = 0.0;
+};
+
+struct Problem {
+    Bcrs pat;  // pattern only (val unused)
+    std::vector<int> rowOf, transIdx;  // row of each entry; transIdx[k] = entry (J,I) for entry k = (I,J)
+    std::vector<double> trans, area, thpres;  // per entry (0 on the diagonal); thpres may be empty
+    std::vector<double> poro, volume, depth;  // per cell
+    std::vector<int> pvtnum, satnum;          // per cell, 0-based
+    std::vector<double> rsMax;                // per cell; empty = no DRSDT limit (eclproblem.hh:1711-1732)
+    Fluid fluid;
+    void finish() {
+        const int Nb = pat.Nb;
+        rowOf.resize(pat.nnzb());
+        for (int i = 0; i < Nb; ++i)
+            for (int k = pat.rowptr[i]; k < pat.rowptr[i + 1]; ++k) rowOf[k] = i;
+        transIdx.assign(pat.nnzb(), -1);
+        for (int k = 0; k < pat.nnzb(); ++k) {
+            const int i = rowOf[k], j = pat.col[k];
+            for (int q = pat.rowptr[j]; q < pat.rowptr[j + 1]; ++q)
+                if (pat.col[q] == i) transIdx[k] = q;
+        }
+    }
+};
+
+// ---- BlackOilIntensiveQuantities::update ------------------------------------------------------
+// E = Ev: the focus cell (derivatives w.r.t. its own primary variables); E = double: values only.
+template <class E>
+struct IQT {
+    E S[3], p[3], invB[3], mob[3], rho[3], Rs, Rv, poro;
+    double refPoro;
+};
+template <class E> inline E mkvar(double x, int idx);
+template <> inline Ev mkvar<Ev>(double x, int idx) { return Ev::variable(x, idx); }
+template <> inline double mkvar<double>(double x, int) { return x; }
+
+template <class E>
+void update_iq(const Problem& P, int cell, const double* pv, uint8_t meaning, IQT<E>& q) {
+    const Fluid& F = P.fluid;
+    const int pr = P.pvtnum.empty() ? 0 : P.pvtnum[cell], sr = P.satnum.empty() ? 0 : P.satnum[cell];
+    const double RsMax = P.rsMax.empty() ? std::numeric_limits<double>::max() / 2.0 : P.rsMax[cell];
+    const E Sw = mkvar<E>(pv[PV_SW], PV_SW);
+    E Sg = E(0.0);
+    if (meaning == Sw_po_Sg) Sg = mkvar<E>(pv[PV_X], PV_X);
+    const E So = 1.0 - Sw - Sg;
+    q.S[WATER] = Sw; q.S[GAS] = Sg; q.S[OIL] = So;
+    E pC[3];
+    F.sat[sr].capillaryPressures(pC, Sw, Sg);
+    const E po = mkvar<E>(pv[PV_P], PV_P);
+    for (int ph = 0; ph < 3; ++ph) q.p[ph] = po + (pC[ph] - pC[OIL]);
+    F.sat[sr].relativePermeabilities(q.mob, Sw, Sg);
+    // SoMax = max(So, problem.maxOilSaturation) ; the latter is 0 without VAPPARS (eclproblem.hh:1682-1688)
+    if (meaning == Sw_po_Sg) {
+        const E RsSat = F.oil[pr].rsSat(q.p[OIL]);
+        q.Rs = min(E(RsMax), RsSat);
+    } else {
+        const E Rs = mkvar<E>(pv[PV_X], PV_X);
+        q.Rs = min(E(RsMax), Rs);
+    }
+    q.Rv = E(0.0);
+    // inverse formation volume factors and viscosities (BlackOilFluidSystem::inverseFormationVolumeFactor / viscosity)
+    {
+        const bool saturated = value(q.S[GAS]) > 0.0 && value(q.Rs) >= (1.0 - 1e-10) * F.oil[pr].rsSat(value(q.p[OIL]));
+        E mu;
+        q.invB[WATER] = F.water[pr].invB(q.p[WATER]);
+        mu = F.water[pr].viscosity(q.p[WATER]);
+        q.mob[WATER] = q.mob[WATER] / mu;
+        if (saturated) { q.invB[OIL] = F.oil[pr].invBSat(q.p[OIL]); mu = F.oil[pr].viscositySat(q.p[OIL]); }
+        else { q.invB[OIL] = F.oil[pr].invB(q.p[OIL], q.Rs); mu = F.oil[pr].viscosity(q.p[OIL], q.Rs); }
+        q.mob[OIL] = q.mob[OIL] / mu;
+        q.invB[GAS] = F.gas[pr].invB(q.p[GAS]);
+        mu = F.gas[pr].viscosity(q.p[GAS]);
+        q.mob[GAS] = q.mob[GAS] / mu;
+    }
+    const double* rr = &F.rhoRef[3 * pr];  // oil, water, gas
+    q.rho[WATER] = q.invB[WATER] * rr[1];
+    q.rho[GAS] = q.invB[GAS] * rr[2];  // dry gas: no vaporised oil term
+    q.rho[OIL] = q.invB[OIL] * rr[0];
+    q.rho[OIL] = q.rho[OIL] + q.invB[OIL] * q.Rs * rr[2];
+    // porosity with rock compressibility (BlackOilIntensiveQuantities; hooks ebos/eclproblem.hh:1454-1486)
+    q.refPoro = P.poro[cell];
+    q.poro = E(q.refPoro);
+    if (F.rock_cr > 0.0) {
+        const E x = F.rock_cr * (q.p[OIL] - F.rock_pref);
+        q.poro = q.poro * (1.0 + x + 0.5 * x * x);
+    }
+}
+
+// ---- BlackOilLocalResidual::computeStorage (App. B.4): surface volumes per pore volume ---------------------------
+template <class E>
+void compute_storage(const IQT<E>& q, E st[3]) {
+    st[0] = st[1] = st[2] = E(0.0);
+    static const int comp[3] = {EQ_WATER, EQ_OIL, EQ_GAS};
+    for (int ph = 0; ph < 3; ++ph) {
+        const E surfaceVolume = q.S[ph] * q.invB[ph] * q.poro;
+        st[comp[ph]] = st[comp[ph]] + surfaceVolume;
+        if (ph == OIL) st[EQ_GAS] = st[EQ_GAS] + q.Rs * surfaceVolume;
+    }
+}
+
+// ---- EclTransExtensiveQuantities::calculateGradients_ + BlackOilLocalResidual::computeFlux ---------------------
+// in: focus (interior) cell with derivatives, exterior cell values only.  out: flux[eq] leaving the interior cell
+// through this face, already multiplied by the face area (FvBaseLocalResidual::evalFluxes).
+inline void compute_face_flux(const IQT<Ev>& in, const IQT<double>& ex, double trans, double faceArea, double thpres,
+                              double zIn, double zEx, double Vin, double Vex, int I, int J, Ev flux[3]) {
+    flux[0] = flux[1] = flux[2] = Ev(0.0);
+    const double distZ = zIn - zEx;
+    static const int comp[3] = {EQ_WATER, EQ_OIL, EQ_GAS};
+    for (int ph = 0; ph < 3; ++ph) {
+        if (in.mob[ph].v <= 0.0 && ex.mob[ph] <= 0.0) continue;  // eclfluxmodule.hh:257-265
+        const Ev rhoAvg = (in.rho[ph] + ex.rho[ph]) / 2.0;         // :269-271
+        Ev pressureExterior = Ev(ex.p[ph]);
+        pressureExterior += rhoAvg * (distZ * GRAVITY);           // :273-279
+        Ev dp = pressureExterior - in.p[ph];                      // :281
+        bool upIsInterior;                                        // :287-321
+        if (dp.v > 0.0) upIsInterior = false;
+        else if (dp.v < 0.0) upIsInterior = true;
+        else if (Vin > Vex) upIsInterior = true;
+        else if (Vin < Vex) upIsInterior = false;
+        else upIsInterior = (I < J);
+        if (std::fabs(dp.v) > thpres) {                           // :327-337
+            if (dp.v < 0.0) dp = dp + thpres; else dp = dp - thpres;
+        } else continue;
+        Ev volumeFlux;                                            // :347-355 (transMult == 1 without ROCKCOMP)
+        if (upIsInterior) volumeFlux = dp * in.mob[ph] * Ev(1.0) * (-trans / faceArea);
+        else volumeFlux = dp * (ex.mob[ph] * 1.0 * (-trans / faceArea));
+        // computeFlux / evalPhaseFluxes_: surface volume flux, plus dissolved gas carried by the oil phase
+        Ev surf;
+        if (upIsInterior) surf = in.invB[ph] * volumeFlux; else surf = ex.invB[ph] * volumeFlux;
+        flux[comp[ph]] += surf;
+        if (ph == OIL) {
+            if (upIsInterior) flux[EQ_GAS] += in.Rs * surf; else flux[EQ_GAS] += ex.Rs * surf;
+        }
+    }
+    for (int e = 0; e < 3; ++e) flux[e] *= faceArea;  // alpha = extrusionFactor (1) * face.area()
+}
+
+struct Model {
+    Problem P;
+    std::vector<double> pv;        // solution(0), Nb x 3
+    std::vector<uint8_t> meaning;  // per cell
+    std::vector<uint8_t> wasSwitched;
+    std::vector<double> storageOld;  // cached storage of the old time level, Nb x 3 (eclproblem.hh:462-464)
+    std::vector<double> source;      // per cell, 3 equations, surface m^3/s TOTAL for the cell (wells; default 0)
+    std::vector<double> dsource;     // per cell 3x3: d(source)/d(primary variables of the cell)
+    std::vector<IQT<Ev>> iqF;        // cached IQs with derivatives
+    std::vector<IQT<double>> iqV;    // cached IQ values
+    Bcrs J;
+    std::vector<double> residual;
+
+    void init() {
+        P.finish();
+        const int Nb = P.pat.Nb;
+        pv.assign((size_t)Nb * 3, 0.0);
+        meaning.assign(Nb, Sw_po_Sg);
+        wasSwitched.assign(Nb, 0);
+        storageOld.assign((size_t)Nb * 3, 0.0);
+        source.assign((size_t)Nb * 3, 0.0);
+        dsource.assign((size_t)Nb * 9, 0.0);
+        J = P.pat;
+        J.val.assign((size_t)P.pat.nnzb() * BB, 0.0);
+        residual.assign((size_t)Nb * 3, 0.0);
+        iqF.resize(Nb);
+        iqV.resize(Nb);
+    }
+    // invalidateAndUpdateIntensiveQuantities(0)  (BlackoilModelEbos.hpp:562)
+    void update_all_iq() {
+        const int Nb = P.pat.Nb;
+#pragma omp parallel for schedule(static)
+        for (int c = 0; c < Nb; ++c) {
+            update_iq<Ev>(P, c, &pv[(size_t)c * 3], meaning[c], iqF[c]);
+            update_iq<double>(P, c, &pv[(size_t)c * 3], meaning[c], iqV[c]);
+        }
+    }
+    // FvBaseLinearizer::linearizeDomain with the AD local linearizer (App. B.2).  iteration == 0 with
+    // recycleFirstIterationStorage() (eclproblem.hh:1758-1765): the old-time-level storage is the value of this
+    // iteration's storage term.
+    void assemble(double dt, int iteration) {
+        const int Nb = P.pat.Nb;
+        const Bcrs& A = P.pat;
+#pragma omp parallel for schedule(static)
+        for (int I = 0; I < Nb; ++I) {
+            const IQT<Ev>& in = iqF[I];
+            Ev R[3] = {Ev(0.0), Ev(0.0), Ev(0.0)};
+            // flux terms first (FvBaseLocalResidual::eval), faces in ascending neighbour order
+            for (int k = A.rowptr[I]; k < A.rowptr[I + 1]; ++k) {
+                const int Jc = A.col[k];
+                if (Jc == I) continue;
+                Ev fl[3];
+                compute_face_flux(in, iqV[Jc], P.trans[k], P.area[k], P.thpres.empty() ? 0.0 : P.thpres[k], P.depth[I],
+                                  P.depth[Jc], P.volume[I], P.volume[Jc], I, Jc, fl);
+                for (int e = 0; e < 3; ++e) R[e] += fl[e];
+                // residual[j] -= flux : block (J, I) = d(-flux)/d x_I
+                double* blk = &J.val[(size_t)P.transIdx[k] * BB];
+                for (int e = 0; e < 3; ++e)
+                    for (int v = 0; v < 3; ++v) blk[e * 3 + v] = (Ev(0.0) - fl[e]).d[v];
+            }
+            // storage term, implicit Euler
+            Ev st[3];
+            compute_storage(in, st);
+            double* so = &storageOld[(size_t)I * 3];
+            if (iteration == 0)
+                for (int e = 0; e < 3; ++e) so[e] = st[e].v;
+            const double scvVolume = P.volume[I];
+            for (int e = 0; e < 3; ++e) {
+                Ev t = st[e] - so[e];
+                t *= scvVolume / dt;
+                R[e] += t;
+            }
+            // source term: rate per volume (eclproblem.hh:1823-1845), then times volume again
+            for (int e = 0; e < 3; ++e) {
+                Ev s(source[(size_t)I * 3 + e]);
+                for (int v = 0; v < 3; ++v) s.d[v] = dsource[(size_t)I * 9 + e * 3 + v];
+                s /= scvVolume;
+                s *= scvVolume;
+                R[e] -= s;
+            }
+            int kd = -1;
+            for (int k = A.rowptr[I]; k < A.rowptr[I + 1]; ++k)
+                if (A.col[k] == I) kd = k;
+            double* blk = &J.val[(size_t)kd * BB];
+            for (int e = 0; e < 3; ++e) {
+                residual[(size_t)I * 3 + e] = R[e].v;
+                for (int v = 0; v < 3; ++v) blk[e * 3 + v] = R[e].d[v];
+            }
+        }
+    }
+
+    // BlackoilModelEbos::localConvergenceData + computeCnvErrorPv + getReservoirConvergence (:628-904)
+    struct Convergence {
+        double R_sum[3], maxCoeff[3], B_avg[3], pvSum, cnvErrorPv, CNV[3], MB[3];
+    };
+    Convergence convergence(double dt, double tol_cnv) const {
+        Convergence c{};
+        const int Nb = P.pat.Nb;
+        for (int e = 0; e < 3; ++e) { c.R_sum[e] = 0.0; c.maxCoeff[e] = std::numeric_limits<double>::lowest(); c.B_avg[e] = 0.0; }
+        static const int comp[3] = {EQ_WATER, EQ_OIL, EQ_GAS};
+        double pvSum = 0.0;
+        for (int cell = 0; cell < Nb; ++cell) {
+            const double pvValue = P.poro[cell] * P.volume[cell];
+            pvSum += pvValue;
+            for (int ph = 0; ph < 3; ++ph) {
+                const int e = comp[ph];
+                c.B_avg[e] += 1.0 / iqV[cell].invB[ph];
+                const double R2 = residual[(size_t)cell * 3 + e];
+                c.R_sum[e] += R2;
+                c.maxCoeff[e] = std::max(c.maxCoeff[e], std::fabs(R2) / pvValue);
+            }
+        }
+        for (int e = 0; e < 3; ++e) c.B_avg[e] /= (double)Nb;
+        c.pvSum = pvSum;
+        double errorPV = 0.0;
+        for (int cell = 0; cell < Nb; ++cell) {
+            const double pvValue = P.poro[cell] * P.volume[cell];
+            bool violated = false;
+            for (int e = 0; e < 3; ++e) {
+                const double CNV = residual[(size_t)cell * 3 + e] * dt * c.B_avg[e] / pvValue;
+                violated = violated || (std::fabs(CNV) > tol_cnv);
+            }
+            if (violated) errorPV += pvValue;
+        }
+        c.cnvErrorPv = errorPV;
+        for (int e = 0; e < 3; ++e) {
+            c.CNV[e] = c.B_avg[e] * dt * c.maxCoeff[e];
+            c.MB[e] = std::fabs(c.B_avg[e] * c.R_sum[e]) * dt / pvSum;
+        }
+        return c;
+    }
+
+    // BlackOilNewtonMethod::update_ + adaptPrimaryVariables (App. B.7), then IQ recompute (updateSolution,
+    // BlackoilModelEbos.hpp:549-563).  Returns the number of cells whose meaning switched.
+    int update(const double* dx, double dpMaxRel = 0.3, double dsMax = 0.2, double oscThreshold = 1e-5) {
+        const int Nb = P.pat.Nb;
+        int nswitched = 0;
+        for (int c = 0; c < Nb; ++c) {
+            double* x = &pv[(size_t)c * 3];
+            const double* u = &dx[(size_t)c * 3];
+            const double deltaSw = u[PV_SW];
+            double deltaSo = -deltaSw, deltaSg = 0.0;
+            if (meaning[c] == Sw_po_Sg) { deltaSg = u[PV_X]; deltaSo -= deltaSg; }
+            double maxSatDelta = std::max(std::fabs(deltaSg), std::fabs(deltaSo));
+            maxSatDelta = std::max(maxSatDelta, std::fabs(deltaSw));
+            double satAlpha = 1.0;
+            if (maxSatDelta > dsMax) satAlpha = dsMax / maxSatDelta;
+            double nx[3];
+            for (int pvIdx = 0; pvIdx < 3; ++pvIdx) {
+                double delta = u[pvIdx];
+                if (pvIdx == PV_P) {
+                    if (std::fabs(delta) > dpMaxRel * x[pvIdx]) delta = (delta < 0.0 ? -1.0 : 1.0) * dpMaxRel * x[pvIdx];
+                } else if (pvIdx == PV_SW) delta *= satAlpha;
+                else {
+                    if (meaning[c] == Sw_po_Sg) delta *= satAlpha;
+                    else if (delta > x[PV_X]) delta = x[PV_X];  // Rs must not become negative
+                }
+                nx[pvIdx] = x[pvIdx] - delta;
+            }
+            for (int k = 0; k < 3; ++k) x[k] = nx[k];
+            const double eps = wasSwitched[c] ? oscThreshold : 0.0;
+            wasSwitched[c] = adapt(c, eps) ? 1 : 0;
+            nswitched += wasSwitched[c];
+        }
+        update_all_iq();
+        return nswitched;
+    }
+    bool adapt(int c, double eps) {
+        const Fluid& F = P.fluid;
+        const int pr = P.pvtnum.empty() ? 0 : P.pvtnum[c];
+        const double RsMax = P.rsMax.empty() ? std::numeric_limits<double>::max() / 2.0 : P.rsMax[c];
+        double* x = &pv[(size_t)c * 3];
+        const double Sw = x[PV_SW];
+        const double thresholdWaterFilledCell = 1.0;  // static const 1.0 - eps of the first call (eps = 0)
+        if (meaning[c] == Sw_po_Sg) {
+            const double Sg = x[PV_X];
+            if (Sw >= thresholdWaterFilledCell) { x[PV_SW] = 1.0; x[PV_X] = 0.0; return false; }
+            const double So = 1.0 - Sw - Sg;
+            if (Sg < -eps && So > 0.0) {
+                const double po = x[PV_P];
+                const double RsSat = F.oil[pr].rsSat(po);
+                meaning[c] = Sw_po_Rs;
+                x[PV_X] = std::min(RsMax, RsSat);
+                return true;
+            }
+            return false;
+        }
+        if (Sw >= thresholdWaterFilledCell) { meaning[c] = Sw_po_Sg; x[PV_SW] = 1.0; x[PV_X] = 0.0; return true; }
+        const double po = x[PV_P];
+        const double RsSat = F.oil[pr].rsSat(po);
+        const double Rs = x[PV_X];
+        if (Rs > std::min(RsMax, RsSat * (1.0 + eps))) { meaning[c] = Sw_po_Sg; x[PV_X] = 0.0; return true; }
+        return false;
+    }
+};
+
+}  // namespace orc

@@ -1,0 +1,275 @@
+// ORACLE — TEST INFRASTRUCTURE ONLY (see linalg.hpp).
+// Black-oil fluid and saturation-function restatement for SPE1-type decks (PVTW, PVDG, PVTO, SWOF, SGOF).
+// The arithmetic lives in opm-material, which is NOT in /root/reference: every
+// routine below is restated from the public 2021.10 sources as recalled and is UNVERIFIED vs upstream, except
+// where a reference fixture pins it:
+//   * LiveOilPvt (PVTO): pinned by the 68 (Rs, p) -> (mu_o, 1/B_o) points of tests/test_norne_pvt.cpp:64-294
+//     (tests/test_oracle_pvt.py).  Those points select the plain bilinear 2-D interpolation and mu = (1/B)/(1/(B mu)).
+// Call sites that show how Flow uses these classes: ebos/eclproblem.hh:1490-1498 (material law params),
+// opm/simulators/flow/BlackoilModelEbos.hpp:650-664 (fluidState().invB/Rs/...).
+#pragma once
+#include <algorithm>
+#include <cassert>
+#include <limits>
+#include <vector>
+
+#include "eval.hpp"
+
+namespace orc {
+
+// ---- Tabulated1DFunction: piecewise linear, linear extrapolation -------------------------------------------
+struct Tab1D {
+    std::vector<double> x, y;
+    int segment(double xv) const {  // extrapolate = true: clamp to the first / last segment
+        const int n = (int)x.size();
+        if (xv <= x[0]) return 0;
+        if (xv >= x[n - 1]) return n - 2;
+        int lo = 0, hi = n - 1;
+        while (lo + 1 < hi) {
+            const int mid = (lo + hi) / 2;
+            if (x[mid] <= xv) lo = mid; else hi = mid;
+        }
+        return lo;
+    }
+    template <class E> E eval(const E& xv) const {
+        const int s = segment(value(xv));
+        const double x0 = x[s], x1 = x[s + 1], y0 = y[s], y1 = y[s + 1];
+        return y0 + (y1 - y0) * (xv - x0) / (x1 - x0);
+    }
+};
+
+// ---- UniformXTabulated2DFunction --------------------------------------------------------------------------------
+// x = Rs nodes, per node its own ascending y = pressure samples.  Plain ("vertical") bilinear interpolation: both
+// neighbouring columns are evaluated at the SAME y, each in its own y grid, with linear extrapolation.  The Norne
+// points of tests/test_norne_pvt.cpp decide this: a variant that shifts y along the saturated curve (later
+// opm-material versions' "LeftExtreme" policy) misses them by up to 7e-3 (1/B_o) and 120 % (mu_o), this one
+// reproduces all 68 points to 9e-12 (1/B_o) and 2e-8 (mu_o, the printed precision).
+struct Tab2D {
+    std::vector<double> xs;
+    std::vector<std::vector<double>> ys, vs;
+    int xSegment(double xv) const {
+        const int n = (int)xs.size();
+        if (xv <= xs[0]) return 0;
+        if (xv >= xs[n - 1]) return n - 2;
+        int lo = 0, hi = n - 1;
+        while (lo + 1 < hi) {
+            const int mid = (lo + hi) / 2;
+            if (xs[mid] <= xv) lo = mid; else hi = mid;
+        }
+        return lo;
+    }
+    int ySegment(double yv, int i) const {
+        const std::vector<double>& y = ys[i];
+        const int n = (int)y.size();
+        if (yv <= y[0]) return 0;
+        if (yv >= y[n - 1]) return n - 2;
+        int lo = 0, hi = n - 1;
+        while (lo + 1 < hi) {
+            const int mid = (lo + hi) / 2;
+            if (y[mid] <= yv) lo = mid; else hi = mid;
+        }
+        return lo;
+    }
+    template <class E> E eval(const E& xv, const E& yv) const {
+        const int i = xSegment(value(xv));
+        const E alpha = (xv - xs[i]) / (xs[i + 1] - xs[i]);
+        const int j1 = ySegment(value(yv), i), j2 = ySegment(value(yv), i + 1);
+        const E beta1 = (yv - ys[i][j1]) / (ys[i][j1 + 1] - ys[i][j1]);
+        const E beta2 = (yv - ys[i + 1][j2]) / (ys[i + 1][j2 + 1] - ys[i + 1][j2]);
+        const E s1 = vs[i][j1] * (1.0 - beta1) + vs[i][j1 + 1] * beta1;
+        const E s2 = vs[i + 1][j2] * (1.0 - beta2) + vs[i + 1][j2 + 1] * beta2;
+        return s1 * (1.0 - alpha) + s2 * alpha;
+    }
+};
+
+// ---- deck-level input (SI units), the same flat layout the product's C-ABI takes ---------------------------
+struct PvtoNode { double rs; std::vector<double> p, bo, mu; };
+struct FluidInput {
+    // one PVT region and one saturation region per index; region ids are per cell
+    struct Pvt {
+        double pvtw[5];     // p_ref, Bw_ref, c_w, mu_ref, c_v   (PVTW)
+        double density[3];  // oil, water, gas at surface (DENSITY)
+        std::vector<double> pvdg;  // rows (p, Bg, mu_g)
+        std::vector<PvtoNode> pvto;
+    };
+    struct Sat {
+        std::vector<double> swof;  // rows (Sw, krw, krow, pcow)
+        std::vector<double> sgof;  // rows (Sg, krg, krog, pcog)
+    };
+    std::vector<Pvt> pvt;
+    std::vector<Sat> sat;
+    double rock_pref = 1e5, rock_cr = 0.0;  // ROCK (ebos/eclproblem.hh:1454-1486)
+};
+
+// ---- ConstantCompressibilityWaterPvt -------------------------------------------------------------------------
+struct WaterPvt {
+    double pref, bwref, cw, muref, cv;
+    template <class E> E invB(const E& p) const {
+        const E X = cw * (p - pref);
+        return (1.0 + X * (1.0 + X / 2.0)) / bwref;
+    }
+    template <class E> E viscosity(const E& p) const {
+        const E bw = invB(p);
+        const E Y = (cw - cv) * (p - pref);
+        return (muref * bwref) * bw / (1.0 + Y * (1.0 + Y / 2.0));
+    }
+};
+
+// ---- DryGasPvt (PVDG) -------------------------------------------------------------------------------------------
+struct GasPvt {
+    Tab1D invB_, invBMu_;
+    void init(const std::vector<double>& rows) {
+        const int n = (int)rows.size() / 3;
+        for (int i = 0; i < n; ++i) {
+            const double p = rows[3 * i], Bg = rows[3 * i + 1], mu = rows[3 * i + 2];
+            invB_.x.push_back(p); invB_.y.push_back(1.0 / Bg);
+            invBMu_.x.push_back(p); invBMu_.y.push_back((1.0 / Bg) / mu);
+        }
+    }
+    template <class E> E invB(const E& p) const { return invB_.eval(p); }
+    template <class E> E viscosity(const E& p) const { return invB_.eval(p) / invBMu_.eval(p); }
+};
+
+// ---- LiveOilPvt (PVTO) ------------------------------------------------------------------------------------------
+struct OilPvt {
+    Tab2D invB2_, invBMu2_;          // (Rs, p) -> 1/Bo, 1/(Bo mu_o)
+    Tab1D rsSat_, invBSat_, invBMuSat_;  // p -> RsSat, saturated 1/Bo, saturated 1/(Bo mu)
+    void init(const std::vector<PvtoNode>& nodes) {
+        const int nn = (int)nodes.size();
+        Tab2D mu2;
+        std::vector<double> satP, satRs;
+        for (int i = 0; i < nn; ++i) {
+            invB2_.xs.push_back(nodes[i].rs);
+            mu2.xs.push_back(nodes[i].rs);
+            std::vector<double> y = nodes[i].p, ib, mu = nodes[i].mu;
+            for (double b : nodes[i].bo) ib.push_back(1.0 / b);
+            invB2_.ys.push_back(y); invB2_.vs.push_back(ib);
+            mu2.ys.push_back(y); mu2.vs.push_back(mu);
+            satP.push_back(nodes[i].p[0]);
+            satRs.push_back(nodes[i].rs);
+        }
+        rsSat_.x = satP; rsSat_.y = satRs;
+        // Rs nodes with a single (saturated) sample inherit the undersaturated branch of the next node that has
+        // one ("master table"), keeping that table's compressibility and "viscosibility" step by step.
+        for (int i = 0; i < nn; ++i) {
+            if (invB2_.ys[i].size() > 1) continue;
+            int m = i + 1;
+            while (m < nn && nodes[m].p.size() <= 1) ++m;
+            assert(m < nn && "PVTO: the last table must have undersaturated data");
+            std::vector<double> P = nodes[i].p, Bo = nodes[i].bo, Mu = nodes[i].mu;
+            const PvtoNode& M = nodes[m];
+            for (size_t r = 1; r < M.p.size(); ++r) {
+                const double dP = M.p[r] - M.p[r - 1];
+                const double newP = P.back() + dP;
+                const double B1 = M.bo[r], B2 = M.bo[r - 1];
+                const double xB = (B1 - B2) / ((B1 + B2) / 2.0);
+                const double newBo = Bo.back() * (1.0 + xB / 2.0) / (1.0 - xB / 2.0);
+                const double m1 = M.mu[r], m2 = M.mu[r - 1];
+                const double xM = (m1 - m2) / ((m1 + m2) / 2.0);
+                const double newMu = Mu.back() * (1.0 + xM / 2.0) / (1.0 - xM / 2.0);
+                P.push_back(newP); Bo.push_back(newBo); Mu.push_back(newMu);
+                invB2_.ys[i].push_back(newP); invB2_.vs[i].push_back(1.0 / newBo);
+                mu2.ys[i].push_back(newP); mu2.vs[i].push_back(newMu);
+            }
+        }
+        // initEnd(): 1/(B mu) on the same samples; saturated 1-D tables from the first sample of each column
+        invBMu2_.xs = invB2_.xs;
+        invBMu2_.ys = invB2_.ys;
+        invBMu2_.vs.resize(nn);
+        for (int i = 0; i < nn; ++i) {
+            for (size_t j = 0; j < invB2_.ys[i].size(); ++j) invBMu2_.vs[i].push_back(invB2_.vs[i][j] / mu2.vs[i][j]);
+            invBSat_.x.push_back(invB2_.ys[i][0]); invBSat_.y.push_back(invB2_.vs[i][0]);
+            invBMuSat_.x.push_back(invB2_.ys[i][0]); invBMuSat_.y.push_back(invBMu2_.vs[i][0]);
+        }
+    }
+    template <class E> E rsSat(const E& p) const { return rsSat_.eval(p); }
+    template <class E> E invBSat(const E& p) const { return invBSat_.eval(p); }
+    template <class E> E viscositySat(const E& p) const { return invBSat_.eval(p) / invBMuSat_.eval(p); }
+    template <class E> E invB(const E& p, const E& Rs) const { return invB2_.eval(Rs, p); }
+    template <class E> E viscosity(const E& p, const E& Rs) const { return invB2_.eval(Rs, p) / invBMu2_.eval(Rs, p); }
+};
+
+// ---- PiecewiseLinearTwoPhaseMaterial: constant extrapolation ----------------------------------------------------
+struct PwLin {
+    std::vector<double> x, y;  // x ascending
+    void set(std::vector<double> xs, std::vector<double> ys) {
+        if (xs.front() > xs.back()) { std::reverse(xs.begin(), xs.end()); std::reverse(ys.begin(), ys.end()); }
+        x = std::move(xs); y = std::move(ys);
+    }
+    template <class E> E eval(const E& xv) const {
+        const double s = value(xv);
+        if (s <= x.front()) return E(y.front());
+        if (s >= x.back()) return E(y.back());
+        int lo = 0, hi = (int)x.size() - 1;
+        while (lo + 1 < hi) {
+            const int mid = (lo + hi) / 2;
+            if (x[mid] < s) lo = mid; else hi = mid;
+        }
+        const double x0 = x[lo], x1 = x[lo + 1], y0 = y[lo], y1 = y[lo + 1];
+        const double m = (y1 - y0) / (x1 - x0);
+        return y0 + (xv - x0) * m;
+    }
+};
+
+// ---- EclDefaultMaterial over SWOF / SGOF (no end-point scaling, no hysteresis) --------------------------------
+struct SatFunc {
+    double Swco = 0.0;
+    PwLin krw, krow, pcow;    // in Sw
+    PwLin krog, krg, pcgo;    // in So' = (1 - Swco) - Sg
+    void init(const std::vector<double>& swof, const std::vector<double>& sgof) {
+        const int nw = (int)swof.size() / 4, ng = (int)sgof.size() / 4;
+        std::vector<double> sw, a, b, c;
+        for (int i = 0; i < nw; ++i) { sw.push_back(swof[4 * i]); a.push_back(swof[4 * i + 1]); b.push_back(swof[4 * i + 2]); c.push_back(swof[4 * i + 3]); }
+        Swco = sw.front();
+        krw.set(sw, a); krow.set(sw, b); pcow.set(sw, c);
+        std::vector<double> so, g, og, pg;
+        for (int i = 0; i < ng; ++i) { so.push_back((1.0 - Swco) - sgof[4 * i]); g.push_back(sgof[4 * i + 1]); og.push_back(sgof[4 * i + 2]); pg.push_back(sgof[4 * i + 3]); }
+        krog.set(so, og); krg.set(so, g); pcgo.set(so, pg);
+    }
+    // pC[water] = -pcow(Sw), pC[oil] = 0, pC[gas] = +pcgo
+    template <class E> void capillaryPressures(E pC[3], const E& Sw, const E& Sg) const {
+        pC[0] = -pcow.eval(Sw);
+        pC[1] = E(0.0);
+        pC[2] = pcgo.eval(1.0 - Swco - Sg);
+    }
+    template <class E> void relativePermeabilities(E kr[3], const E& SwIn, const E& Sg) const {
+        kr[0] = krw.eval(SwIn);
+        kr[2] = krg.eval(1.0 - Swco - Sg);
+        const E Sw = max(E(Swco), SwIn);
+        const E Sw_ow = Sg + Sw;
+        const E So_go = 1.0 - Sw_ow;
+        const E kro_ow = krow.eval(Sw_ow);
+        const E kro_go = krog.eval(So_go);
+        const double eps = 1e-5;
+        if (value(Sw_ow) - Swco < eps) {
+            const E kro2 = (kro_ow + kro_go) / 2.0;
+            if (value(Sw_ow) - Swco > eps / 2.0) {
+                const E kro1 = (Sg * kro_go + (Sw - Swco) * kro_ow) / (Sw_ow - Swco);
+                const E alpha = (eps - (Sw_ow - Swco)) / (eps / 2.0);
+                kr[1] = kro2 * alpha + kro1 * (1.0 - alpha);
+            } else kr[1] = kro2;
+        } else kr[1] = (Sg * kro_go + (Sw - Swco) * kro_ow) / (Sw_ow - Swco);
+    }
+};
+
+struct Fluid {
+    std::vector<WaterPvt> water;
+    std::vector<GasPvt> gas;
+    std::vector<OilPvt> oil;
+    std::vector<SatFunc> sat;
+    std::vector<double> rhoRef;  // per PVT region: oil, water, gas
+    double rock_pref = 1e5, rock_cr = 0.0;
+    void init(const FluidInput& in) {
+        for (const auto& r : in.pvt) {
+            WaterPvt w{r.pvtw[0], r.pvtw[1], r.pvtw[2], r.pvtw[3], r.pvtw[4]};
+            water.push_back(w);
+            GasPvt g; g.init(r.pvdg); gas.push_back(g);
+            OilPvt o; o.init(r.pvto); oil.push_back(o);
+            rhoRef.push_back(r.density[0]); rhoRef.push_back(r.density[1]); rhoRef.push_back(r.density[2]);
+        }
+        for (const auto& s : in.sat) { SatFunc f; f.init(s.swof, s.sgof); sat.push_back(f); }
+        rock_pref = in.rock_pref; rock_cr = in.rock_cr;
+    }
+};
+
+}  // namespace orc

@@ -221,3 +221,153 @@ int orc_solve_noprec(int Nb, const int* rowptr, const int* col, const double* va
 }
 
 }  // extern "C"
+
+// =====================================================================================================
+// black-oil assembly path
+// =====================================================================================================
+#include "blackoil.hpp"
+
+namespace {
+// flat deck-level fluid description; identical layout to `struct opmhip_fluid` of include/opmhip.h
+struct orc_fluid_desc {
+    int num_pvt, num_sat;
+    const double *pvtw, *density;
+    const int* pvdg_ptr; const double* pvdg;
+    const int* pvto_node_ptr; const double* pvto_rs; const int* pvto_row_ptr; const double* pvto;
+    const int* swof_ptr; const double* swof;
+    const int* sgof_ptr; const double* sgof;
+    double rock_pref, rock_cr;
+};
+FluidInput to_input(const orc_fluid_desc* d) {
+    FluidInput in;
+    for (int r = 0; r < d->num_pvt; ++r) {
+        FluidInput::Pvt p;
+        for (int i = 0; i < 5; ++i) p.pvtw[i] = d->pvtw[5 * r + i];
+        for (int i = 0; i < 3; ++i) p.density[i] = d->density[3 * r + i];
+        p.pvdg.assign(d->pvdg + 3 * d->pvdg_ptr[r], d->pvdg + 3 * d->pvdg_ptr[r + 1]);
+        for (int n = d->pvto_node_ptr[r]; n < d->pvto_node_ptr[r + 1]; ++n) {
+            PvtoNode node;
+            node.rs = d->pvto_rs[n];
+            for (int q = d->pvto_row_ptr[n]; q < d->pvto_row_ptr[n + 1]; ++q) {
+                node.p.push_back(d->pvto[3 * q]); node.bo.push_back(d->pvto[3 * q + 1]); node.mu.push_back(d->pvto[3 * q + 2]);
+            }
+            p.pvto.push_back(node);
+        }
+        in.pvt.push_back(p);
+    }
+    for (int s = 0; s < d->num_sat; ++s) {
+        FluidInput::Sat t;
+        t.swof.assign(d->swof + 4 * d->swof_ptr[s], d->swof + 4 * d->swof_ptr[s + 1]);
+        t.sgof.assign(d->sgof + 4 * d->sgof_ptr[s], d->sgof + 4 * d->sgof_ptr[s + 1]);
+        in.sat.push_back(t);
+    }
+    in.rock_pref = d->rock_pref;
+    in.rock_cr = d->rock_cr;
+    return in;
+}
+}  // namespace
+
+extern "C" {
+
+// oil PVT probe used to pin LiveOilPvt against tests/test_norne_pvt.cpp:
+// for each point: RsSat(p); if rs >= RsSat -> saturated mu, 1/B at p ; else mu(p, rs), 1/B(p, rs)
+int orc_oil_pvt_probe(const orc_fluid_desc* d, int region, int n, const double* rs, const double* p, double* mu,
+                      double* invB, double* rsSat) {
+    Fluid F;
+    F.init(to_input(d));
+    const OilPvt& O = F.oil[region];
+    for (int i = 0; i < n; ++i) {
+        rsSat[i] = O.rsSat(p[i]);
+        if (rs[i] >= rsSat[i]) { mu[i] = O.viscositySat(p[i]); invB[i] = O.invBSat(p[i]); }
+        else { mu[i] = O.viscosity(p[i], rs[i]); invB[i] = O.invB(p[i], rs[i]); }
+    }
+    return 0;
+}
+
+struct orc_model { Model M; };
+
+orc_model* orc_bo_create(int Nb, const int* rowptr, const int* col, const double* trans, const double* area,
+                         const double* thpres, const double* poro, const double* volume, const double* depth,
+                         const int* pvtnum, const int* satnum, const double* rsMax, const orc_fluid_desc* fluid) {
+    orc_model* h = new orc_model();
+    Model& M = h->M;
+    M.P.pat = wrap(Nb, rowptr, col, nullptr);
+    M.P.pat.val.clear();
+    const int nnzb = rowptr[Nb];
+    M.P.trans.assign(trans, trans + nnzb);
+    M.P.area.assign(area, area + nnzb);
+    if (thpres) M.P.thpres.assign(thpres, thpres + nnzb);
+    M.P.poro.assign(poro, poro + Nb);
+    M.P.volume.assign(volume, volume + Nb);
+    M.P.depth.assign(depth, depth + Nb);
+    if (pvtnum) M.P.pvtnum.assign(pvtnum, pvtnum + Nb);
+    if (satnum) M.P.satnum.assign(satnum, satnum + Nb);
+    if (rsMax) M.P.rsMax.assign(rsMax, rsMax + Nb);
+    M.P.fluid.init(to_input(fluid));
+    M.init();
+    return h;
+}
+void orc_bo_destroy(orc_model* h) { delete h; }
+
+int orc_bo_set_state(orc_model* h, const double* pv, const unsigned char* meaning) {
+    Model& M = h->M;
+    M.pv.assign(pv, pv + M.pv.size());
+    M.meaning.assign(meaning, meaning + M.meaning.size());
+    std::fill(M.wasSwitched.begin(), M.wasSwitched.end(), 0);
+    M.update_all_iq();
+    return 0;
+}
+int orc_bo_get_state(orc_model* h, double* pv, unsigned char* meaning) {
+    Model& M = h->M;
+    std::memcpy(pv, M.pv.data(), M.pv.size() * sizeof(double));
+    std::memcpy(meaning, M.meaning.data(), M.meaning.size());
+    return 0;
+}
+int orc_bo_set_source(orc_model* h, const double* source, const double* dsource) {
+    Model& M = h->M;
+    if (source) M.source.assign(source, source + M.source.size());
+    if (dsource) M.dsource.assign(dsource, dsource + M.dsource.size());
+    return 0;
+}
+// per-cell intensive quantities, values and derivatives, in the product's export layout:
+// fields [S_w S_o S_g | p_w p_o p_g | b_w b_o b_g | mob_w mob_o mob_g | rho_w rho_o rho_g | Rs | poro] = 17 fields x 4
+int orc_bo_get_iq(orc_model* h, double* out) {
+    Model& M = h->M;
+    const int Nb = M.P.pat.Nb;
+    for (int c = 0; c < Nb; ++c) {
+        const IQT<Ev>& q = M.iqF[c];
+        const Ev* f[17] = {&q.S[0], &q.S[1], &q.S[2], &q.p[0], &q.p[1], &q.p[2], &q.invB[0], &q.invB[1], &q.invB[2],
+                           &q.mob[0], &q.mob[1], &q.mob[2], &q.rho[0], &q.rho[1], &q.rho[2], &q.Rs, &q.poro};
+        for (int k = 0; k < 17; ++k) {
+            double* o = &out[((size_t)c * 17 + k) * 4];
+            o[0] = f[k]->v; o[1] = f[k]->d[0]; o[2] = f[k]->d[1]; o[3] = f[k]->d[2];
+        }
+    }
+    return 0;
+}
+int orc_bo_assemble(orc_model* h, double dt, int iteration, double* jac, double* residual) {
+    Model& M = h->M;
+    M.assemble(dt, iteration);
+    if (jac) std::memcpy(jac, M.J.val.data(), M.J.val.size() * sizeof(double));
+    if (residual) std::memcpy(residual, M.residual.data(), M.residual.size() * sizeof(double));
+    return 0;
+}
+// out[0..2] R_sum, [3..5] maxCoeff, [6..8] B_avg, [9] pvSum, [10] cnvErrorPv, [11..13] CNV, [14..16] MB
+int orc_bo_convergence(orc_model* h, double dt, double tol_cnv, double* out) {
+    Model::Convergence c = h->M.convergence(dt, tol_cnv);
+    for (int e = 0; e < 3; ++e) { out[e] = c.R_sum[e]; out[3 + e] = c.maxCoeff[e]; out[6 + e] = c.B_avg[e]; out[11 + e] = c.CNV[e]; out[14 + e] = c.MB[e]; }
+    out[9] = c.pvSum;
+    out[10] = c.cnvErrorPv;
+    return 0;
+}
+int orc_bo_update(orc_model* h, const double* dx) { return h->M.update(dx); }
+
+// ILU0-BiCGStab on the model's own Jacobian and residual (solveJacobianSystem, BlackoilModelEbos.hpp:523-544)
+int orc_bo_solve(orc_model* h, double* x, double tol, int maxit, double w, int relax_mode, int reorder, int nsub,
+                 const int* sub_start, orc_result* out) {
+    Model& M = h->M;
+    return orc_solve(M.J.Nb, M.J.rowptr.data(), M.J.col.data(), M.J.val.data(), M.residual.data(), x, tol, maxit, w,
+                     relax_mode, reorder, 1, 0, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nsub, sub_start, out);
+}
+
+}  // extern "C"

@@ -94,3 +94,92 @@ class Oracle:
         res = OrcResult()
         self.lib.orc_solve_noprec(Nb, rowptr, col, val, b, x, tol, maxit, repeat, C.byref(res))
         return x, res
+
+
+# ---- black-oil assembly path ---------------------------------------------------------------------------
+class OracleModel:
+    """CPU restatement of the assembly/Newton path on one grid (oracle/blackoil.hpp)."""
+
+    def __init__(self, oracle, case):
+        """case: dict from opm-autodiff_amd.decks (pattern, per-entry trans/area, per-cell poro/volume/depth, fluid)."""
+        self.o = oracle
+        L = oracle.lib
+        L.orc_bo_create.restype = C.c_void_p
+        L.orc_bo_create.argtypes = [C.c_int] + [_vp] * 12
+        L.orc_bo_destroy.argtypes = [_vp]
+        L.orc_bo_set_state.argtypes = [_vp, _d, np.ctypeslib.ndpointer(dtype=np.uint8, flags="C_CONTIGUOUS")]
+        L.orc_bo_get_state.argtypes = [_vp, _d, np.ctypeslib.ndpointer(dtype=np.uint8, flags="C_CONTIGUOUS")]
+        L.orc_bo_set_source.argtypes = [_vp, _vp, _vp]
+        L.orc_bo_get_iq.argtypes = [_vp, _d]
+        L.orc_bo_assemble.argtypes = [_vp, C.c_double, C.c_int, _vp, _vp]
+        L.orc_bo_convergence.argtypes = [_vp, C.c_double, C.c_double, _d]
+        L.orc_bo_update.argtypes = [_vp, _d]
+        L.orc_bo_solve.argtypes = [_vp, _d, C.c_double, C.c_int, C.c_double, C.c_int, C.c_int, C.c_int, _vp,
+                                   C.POINTER(OrcResult)]
+        self.case = case
+        self.Nb = case["Nb"]
+        self.nnzb = len(case["col"])
+        self._fd = case["fluid"].desc()
+        g = lambda k: _p(case.get(k))
+        self.h = L.orc_bo_create(self.Nb, _p(case["rowptr"]), _p(case["col"]), _p(case["trans"]), _p(case["area"]),
+                                 g("thpres"), _p(case["poro"]), _p(case["volume"]), _p(case["depth"]), g("pvtnum"),
+                                 g("satnum"), g("rsmax"), C.addressof(self._fd))
+
+    def __del__(self):
+        if getattr(self, "h", None):
+            self.o.lib.orc_bo_destroy(self.h)
+            self.h = None
+
+    def set_state(self, pv, meaning):
+        self.o.lib.orc_bo_set_state(self.h, np.ascontiguousarray(pv, np.float64), np.ascontiguousarray(meaning, np.uint8))
+
+    def get_state(self):
+        pv = np.empty(self.Nb * 3)
+        m = np.empty(self.Nb, np.uint8)
+        self.o.lib.orc_bo_get_state(self.h, pv, m)
+        return pv, m
+
+    def set_source(self, source, dsource=None):
+        s = np.ascontiguousarray(source, np.float64)
+        d = None if dsource is None else np.ascontiguousarray(dsource, np.float64)
+        self.o.lib.orc_bo_set_source(self.h, _p(s), _p(d))
+
+    def iq(self):
+        out = np.empty(self.Nb * 17 * 4)
+        self.o.lib.orc_bo_get_iq(self.h, out)
+        return out.reshape(self.Nb, 17, 4)
+
+    def assemble(self, dt, iteration):
+        jac = np.empty(self.nnzb * 9)
+        res = np.empty(self.Nb * 3)
+        self.o.lib.orc_bo_assemble(self.h, dt, iteration, _p(jac), _p(res))
+        return jac, res
+
+    def convergence(self, dt, tol_cnv=1e-2):
+        out = np.empty(17)
+        self.o.lib.orc_bo_convergence(self.h, dt, tol_cnv, out)
+        return out
+
+    def update(self, dx):
+        return self.o.lib.orc_bo_update(self.h, np.ascontiguousarray(dx, np.float64))
+
+    def solve(self, tol=1e-2, maxit=200, w=0.9, mode="post_scale", reorder="none", sub_start=None):
+        x = np.zeros(self.Nb * 3)
+        res = OrcResult()
+        nsub = 0 if sub_start is None else len(sub_start) - 1
+        ss = None if sub_start is None else np.ascontiguousarray(sub_start, np.int32)
+        rc = self.o.lib.orc_bo_solve(self.h, x, tol, maxit, w, RELAX[mode], REORDER[reorder], nsub, _p(ss), C.byref(res))
+        assert rc == 0, rc
+        return x, res
+
+
+def oil_pvt_probe(oracle, fluid, region, rs, p):
+    L = oracle.lib
+    L.orc_oil_pvt_probe.argtypes = [_vp, C.c_int, C.c_int, _d, _d, _d, _d, _d]
+    rs = np.ascontiguousarray(rs, np.float64)
+    p = np.ascontiguousarray(p, np.float64)
+    n = len(p)
+    mu, ib, rsat = np.empty(n), np.empty(n), np.empty(n)
+    fd = fluid.desc()
+    L.orc_oil_pvt_probe(C.addressof(fd), region, n, rs[:n].copy(), p, mu, ib, rsat)
+    return mu, ib, rsat

@@ -1,0 +1,32 @@
+#!/usr/bin/env python3
+"""Quick per-kernel roofline probe on a synthetic 7-point block system (development tool; bench.py is the contract)."""
+import argparse, importlib, os, sys, time
+import numpy as np
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+pkg = importlib.import_module("opm-autodiff_amd")
+
+ap = argparse.ArgumentParser()
+ap.add_argument("--n", type=int, default=100)
+ap.add_argument("--reorder", default="graph_coloring_greedy")
+ap.add_argument("--reps", type=int, default=20)
+ap.add_argument("--solve", action="store_true")
+a = ap.parse_args()
+t0 = time.time()
+pat = pkg.grid.cartesian_pattern(a.n, a.n, a.n)
+val = pkg.grid.synthetic_block_values(pat, seed=1)
+Nb, nnzb = pat["Nb"], len(pat["col"])
+print("built %d rows %d blocks in %.1fs" % (Nb, nnzb, time.time() - t0), flush=True)
+s = pkg.capi.HipSolver(reorder=a.reorder)
+t0 = time.time(); s.set_pattern(Nb, pat["rowptr"], pat["col"]); print("set_pattern %.2fs" % (time.time() - t0), flush=True)
+b = np.random.default_rng(0).standard_normal(3 * Nb)
+s.upload_system(val, b)
+to, fr, rpc = s.ordering(); print("colours", len(rpc))
+bytes_ = {"spmv": 76 * nnzb + 4 * (Nb + 1) + 48 * Nb, "ilu_apply": 76 * nnzb + 4 * (Nb + 1) + 4 * Nb + 72 * Nb,
+          "ilu_factor": 2 * 72 * nnzb + 4 * nnzb + 4 * Nb, "vector": 18 * 24 * Nb}
+for k in ("ilu_factor", "spmv", "ilu_apply", "vector"):
+    ms = s.time_kernel(k, a.reps)
+    print("%-11s %8.3f ms  %7.1f GB/s algorithmic (%.1f MB)" % (k, ms, bytes_[k] / ms / 1e6, bytes_[k] / 1e6), flush=True)
+if a.solve:
+    s.upload_system(val, b)
+    res = s.solve_system(Nb, None, None, None, None) if False else s.solve_system(Nb, pat["rowptr"], pat["col"], val, b)
+    print("solve: it %.1f conv %d red %.2e copy %.1f ms factor %.2f ms solve %.2f ms" % (res.it, res.converged, res.reduction, 1e3*res.t_copy, 1e3*res.t_factor, 1e3*res.t_solve))
