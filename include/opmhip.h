@@ -127,8 +127,9 @@ int opmhip_upload_system(opmhip_ctx* ctx, const double* vals, const double* b);
 /* y = A x  (Dune::MatrixAdapter::apply, linalg/WellOperators.hpp:127-138); x, y host, natural order */
 int opmhip_spmv(opmhip_ctx* ctx, const double* x, double* y);
 /* block ILU0 of the uploaded matrix (ParallelOverlappingILU0::update, linalg/ParallelOverlappingILU0.hpp:923-1068);
- * lu_out (nullable) receives the factors in NATURAL order in the layout of Dune's in-place ILU: strict lower = L,
- * strict upper = U, diagonal = D^-1 */
+ * lu_out (nullable, nnzb*9) receives the factors in the layout of Dune's in-place ILU (strict lower = L, strict
+ * upper = U, diagonal = D^-1) of the REORDERED matrix, i.e. of the block-CSR pattern that
+ * reorderBlockedMatrixByPattern (bda/Reorder.cpp:179-207) produces from opmhip_get_ordering's permutation */
 int opmhip_ilu0_factor(opmhip_ctx* ctx, double* lu_out);
 /* v = M^-1 d (ParallelOverlappingILU0::apply, :848-903); needs opmhip_ilu0_factor first */
 int opmhip_ilu0_apply(opmhip_ctx* ctx, const double* d, double* v);
@@ -140,6 +141,77 @@ int opmhip_get_ordering(opmhip_ctx* ctx, int* toOrder, int* fromOrder, int* rows
  * Launches the kernel `reps` times back to back on the context's stream between two HIP events and returns the
  * average milliseconds per launch in *ms_per_launch. */
 int opmhip_time_kernel(opmhip_ctx* ctx, int which, int reps, double* ms_per_launch);
+
+/* ---- assembly ("linearization") half of the Newton iteration ------------------------------------------ */
+/* Deck-level fluid and saturation-function tables, SI units, flat arrays: what PVTW, DENSITY, PVDG, PVTO, SWOF,
+ * SGOF and ROCK provide (python/test_data/SPE1CASE1/SPE1CASE1.DATA:109-250).  Region r of the PVT tables is
+ * PVTNUM r+1, of the saturation tables SATNUM r+1.  Live oil + dry gas + water (no PVTG). */
+typedef struct opmhip_fluid {
+    int num_pvt, num_sat;
+    const double* pvtw;         /* [num_pvt*5]  p_ref, Bw_ref, c_w, mu_ref, c_v */
+    const double* density;      /* [num_pvt*3]  oil, water, gas at surface conditions */
+    const int* pvdg_ptr;        /* [num_pvt+1]  row ranges into pvdg */
+    const double* pvdg;         /* rows (p, Bg, mu_g) */
+    const int* pvto_node_ptr;   /* [num_pvt+1]  Rs-node ranges */
+    const double* pvto_rs;      /* [nodes]      Rs of each node */
+    const int* pvto_row_ptr;    /* [nodes+1]    row ranges into pvto; the first row of a node is the saturated point */
+    const double* pvto;         /* rows (p, Bo, mu_o) */
+    const int* swof_ptr;        /* [num_sat+1] */
+    const double* swof;         /* rows (Sw, krw, krow, pcow) */
+    const int* sgof_ptr;        /* [num_sat+1] */
+    const double* sgof;         /* rows (Sg, krg, krog, pcog) */
+    double rock_pref, rock_cr;  /* ROCK: reference pressure, compressibility (ebos/eclproblem.hh:1454-1486) */
+} opmhip_fluid;
+
+/* primary-variable meaning per cell: BlackOilPrimaryVariables::PrimaryVarsMeaning */
+#define OPMHIP_SW_PO_SG 0
+#define OPMHIP_SW_PO_RS 1
+
+/* replaces: FluidSystem / MaterialLawManager initialisation from the deck (setup, once) */
+int opmhip_set_fluid(opmhip_ctx* ctx, const opmhip_fluid* fluid);
+
+/* replaces: the per-cell / per-connection arrays EclProblem serves to the assembly
+ * (ebos/eclproblem.hh:1332-1340 transmissibility, :1409 thresholdPressure, :1430-1447 porosity & depth,
+ * dofTotalVolume, pvtRegionIndex/satnumRegionIndex, :1711-1732 maxGasDissolutionFactor).
+ * trans, area, thpres: one value per block-CSR entry in the NATURAL pattern order (0 on diagonal entries); must be
+ * symmetric ((I,J) == (J,I)); thpres may be NULL (= 0).  poro, volume, depth: per cell.  pvtnum/satnum: per cell,
+ * 0-based, NULL = region 0.  rsmax: per cell cap on Rs (DRSDT), NULL = unlimited.  Needs set_pattern first. */
+int opmhip_set_static(opmhip_ctx* ctx, const double* trans, const double* area, const double* thpres,
+                      const double* poro, const double* volume, const double* depth, const int* pvtnum,
+                      const int* satnum, const double* rsmax);
+
+/* replaces: model().solution(0) = ... ; model().invalidateAndUpdateIntensiveQuantities(0)
+ * (flow/BlackoilModelEbos.hpp:552-562).  pv: Nb x 3 (Sw, p_o, Sg|Rs), meaning: Nb bytes. Natural order. */
+int opmhip_set_state(opmhip_ctx* ctx, const double* pv, const unsigned char* meaning);
+int opmhip_get_state(opmhip_ctx* ctx, double* pv, unsigned char* meaning);
+
+/* replaces: EclProblem::source (ebos/eclproblem.hh:1823-1845): total surface-volume rate per cell and equation
+ * [m^3/s] (what BlackoilWellModel::computeTotalRatesForDof adds up, wells/BlackoilWellModel_impl.hpp:496-512) and
+ * its 3x3 derivative w.r.t. the cell's primary variables.  Either may be NULL (= zero). */
+int opmhip_set_source(opmhip_ctx* ctx, const double* source, const double* dsource);
+
+/* replaces: model().linearizer().linearizeDomain() (flow/BlackoilModelEbos.hpp:424), then .jacobian() /
+ * .residual() (:339-340, :526-527).  iteration == 0 also (re)fills the cached old-time-level storage term
+ * (recycleFirstIterationStorage, ebos/eclproblem.hh:1758-1765).  Jacobian and residual stay on the device for
+ * opmhip_solve_system(vals = NULL, b = NULL); jac (nnzb*9) / residual (Nb*3) are optional host copies in natural
+ * order. */
+int opmhip_assemble(opmhip_ctx* ctx, double dt, int iteration, double* jac, double* residual);
+
+/* cached intensive quantities, for parity tests: per cell 17 fields x (value, d/dSw, d/dp, d/dX):
+ * S_w S_o S_g | p_w p_o p_g | b_w b_o b_g | mob_w mob_o mob_g | rho_w rho_o rho_g | Rs | porosity */
+int opmhip_get_iq(opmhip_ctx* ctx, double* out);
+
+/* replaces: BlackoilModelEbos::localConvergenceData + computeCnvErrorPv + the CNV/MB formulas of
+ * getReservoirConvergence (flow/BlackoilModelEbos.hpp:628-904).  out[17]: R_sum[3], maxCoeff[3], B_avg[3], pvSum,
+ * cnvErrorPv, CNV[3], MB[3]; component order oil, water, gas. */
+int opmhip_convergence(opmhip_ctx* ctx, double dt, double tol_cnv, double* out);
+
+/* replaces: BlackoilModelEbos::updateSolution (flow/BlackoilModelEbos.hpp:549-563) = BlackOilNewtonMethod::update_
+ * (dp <= 0.3 p, dS <= 0.2, primary-variable switching) + invalidateAndUpdateIntensiveQuantities, preceded by
+ * NonlinearSolverEbos::stabilizeNonlinearUpdate "dampen" (flow/NonlinearSolverEbos.hpp:307-353): dx *= relax.
+ * dx == NULL uses the solution of the last opmhip_solve_system, which is still on the device.
+ * num_switched (nullable) receives the number of cells whose meaning changed. */
+int opmhip_update(opmhip_ctx* ctx, const double* dx, double relax, int* num_switched);
 
 #ifdef __cplusplus
 }

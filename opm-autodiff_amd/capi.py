@@ -192,3 +192,85 @@ class HipSolver:
         self._check(lib().opmhip_time_kernel(self._h, {"spmv": 0, "ilu_apply": 1, "ilu_factor": 2, "vector": 3}[which],
                                              reps, C.byref(ms)))
         return ms.value
+
+
+def _bind_assembly(L):
+    vp = C.c_void_p
+    L.opmhip_set_fluid.argtypes = [vp, vp]
+    L.opmhip_set_static.argtypes = [vp] + [vp] * 9
+    L.opmhip_set_state.argtypes = [vp, vp, vp]
+    L.opmhip_get_state.argtypes = [vp, vp, vp]
+    L.opmhip_set_source.argtypes = [vp, vp, vp]
+    L.opmhip_assemble.argtypes = [vp, C.c_double, C.c_int, vp, vp]
+    L.opmhip_get_iq.argtypes = [vp, vp]
+    L.opmhip_convergence.argtypes = [vp, C.c_double, C.c_double, vp]
+    L.opmhip_update.argtypes = [vp, vp, C.c_double, C.POINTER(C.c_int)]
+
+
+class HipModel(HipSolver):
+    """One context holding the whole per-Newton-iteration path on the device: the call surface follows
+    BlackoilModelEbos (assembleReservoir -> getReservoirConvergence -> solveJacobianSystem -> updateSolution,
+    opm/simulators/flow/BlackoilModelEbos.hpp:274-392) with every array resident in HBM between the calls."""
+
+    def __init__(self, case, **solver_kw):
+        super().__init__(**solver_kw)
+        L = lib()
+        if not getattr(L, "_asm_bound", False):
+            _bind_assembly(L)
+            L._asm_bound = True
+        self.case = case
+        self.set_pattern(case["Nb"], case["rowptr"], case["col"])
+        self._fd = case["fluid"].desc()
+        self._check(L.opmhip_set_fluid(self._h, C.addressof(self._fd)))
+        g = lambda k, f: _ptr(f(case[k])) if case.get(k) is not None else None
+        keep = {k: (_f64(case[k]) if k not in ("pvtnum", "satnum") else _i32(case[k]))
+                for k in ("trans", "area", "thpres", "poro", "volume", "depth", "pvtnum", "satnum", "rsmax")
+                if case.get(k) is not None}
+        p = lambda k: _ptr(keep.get(k))
+        self._check(L.opmhip_set_static(self._h, p("trans"), p("area"), p("thpres"), p("poro"), p("volume"), p("depth"),
+                                        p("pvtnum"), p("satnum"), p("rsmax")))
+
+    def set_state(self, pv, meaning):
+        pv, meaning = _f64(pv), np.ascontiguousarray(meaning, np.uint8)
+        self._check(lib().opmhip_set_state(self._h, _ptr(pv), _ptr(meaning)))
+
+    def get_state(self):
+        pv = np.empty(3 * self.Nb)
+        m = np.empty(self.Nb, np.uint8)
+        self._check(lib().opmhip_get_state(self._h, _ptr(pv), _ptr(m)))
+        return pv, m
+
+    def set_source(self, source, dsource=None):
+        s, d = _f64(source), _f64(dsource)
+        self._check(lib().opmhip_set_source(self._h, _ptr(s), _ptr(d)))
+
+    def assemble(self, dt, iteration, fetch=True):
+        """linearizeDomain(); with fetch the Jacobian values and residual are copied back (natural order)."""
+        jac = np.empty(9 * self.nnzb) if fetch else None
+        res = np.empty(3 * self.Nb) if fetch else None
+        self._check(lib().opmhip_assemble(self._h, dt, iteration, _ptr(jac), _ptr(res)))
+        return jac, res
+
+    def iq(self):
+        out = np.empty(self.Nb * 17 * 4)
+        self._check(lib().opmhip_get_iq(self._h, _ptr(out)))
+        return out.reshape(self.Nb, 17, 4)
+
+    def convergence(self, dt, tol_cnv=1e-2):
+        out = np.empty(17)
+        self._check(lib().opmhip_convergence(self._h, dt, tol_cnv, _ptr(out)))
+        return out
+
+    def solve_jacobian_system(self, wells=None):
+        """solveJacobianSystem on the device-resident Jacobian and residual (no host copies)."""
+        res = Result()
+        ws, keep = make_wells(wells)
+        self._check(lib().opmhip_solve_system(self._h, 3 * self.Nb, 9 * self.nnzb, 3, None, None, None, None,
+                                              C.byref(ws) if ws else None, C.byref(res)))
+        return res
+
+    def update(self, dx=None, relax=1.0):
+        dx = _f64(dx)
+        n = C.c_int(0)
+        self._check(lib().opmhip_update(self._h, _ptr(dx), relax, C.byref(n)))
+        return n.value

@@ -1,0 +1,634 @@
+// gfx950 kernels of the assembly half of the hot path: black-oil intensive quantities, TPFA flux and storage with
+// dense forward AD (value + 3 derivatives), element-centred linearisation straight into block-CSR, convergence
+// reductions and the Newton update with primary-variable switching.
+//
+// Reference behaviour restated (file:line under the reference tree; opm-models / opm-material routines are NOT in that
+// tree and are restated from their public 2021.10 sources):
+//   ebos/eclfluxmodule.hh:212-357 (TPFA flux), ebos/eclproblem.hh:1430-1486, 1711-1765, 1823-1845 (problem hooks),
+//   flow/BlackoilModelEbos.hpp:549-563 (updateSolution), :628-904 (convergence),
+//   BlackOilIntensiveQuantities::update, BlackOilLocalResidual::{computeStorage,computeFlux}, FvBaseLocalResidual::eval,
+//   FvBaseAdLocalLinearizer, BlackOilNewtonMethod::update_, BlackOilPrimaryVariables::adaptPrimaryVariables.
+//
+// Mapping: ONE LANE PER BLOCK-CSR ENTRY.  A 256-thread workgroup owns a tile of whole rows with at most
+// 256 entries (36 rows of a 7-point stencil: 252/256 lanes busy).  The lane of an off-diagonal entry (I,J) evaluates the
+// face flux twice, once with focus I (goes into R_I and the diagonal block) and once with focus J (its derivative is
+// the off-diagonal block (I,J), exactly the number the reference's column-wise linearisation writes there); the lane of
+// the diagonal entry evaluates the storage term and then sums its row's fluxes out of LDS in ascending column order.
+// All 3x3 blocks of the tile are staged in LDS and leave as one contiguous, 16-byte-per-lane coalesced store stream.
+#include <hip/hip_runtime.h>
+
+#include <cfloat>
+
+#include "fluid_tables.hpp"
+#include "internal.hpp"
+
+namespace opmhip {
+
+// ============================== dense AD scalar (DenseAd::Evaluation<double,3>) ==============================
+struct Ad {
+    double v, d0, d1, d2;
+};
+__device__ __forceinline__ Ad ad_const(double c) { return Ad{c, 0.0, 0.0, 0.0}; }
+__device__ __forceinline__ Ad ad_var(double x, int idx) { return Ad{x, idx == 0 ? 1.0 : 0.0, idx == 1 ? 1.0 : 0.0, idx == 2 ? 1.0 : 0.0}; }
+__device__ __forceinline__ Ad operator+(const Ad& a, const Ad& b) { return Ad{a.v + b.v, a.d0 + b.d0, a.d1 + b.d1, a.d2 + b.d2}; }
+__device__ __forceinline__ Ad operator-(const Ad& a, const Ad& b) { return Ad{a.v - b.v, a.d0 - b.d0, a.d1 - b.d1, a.d2 - b.d2}; }
+__device__ __forceinline__ Ad operator+(const Ad& a, double b) { return Ad{a.v + b, a.d0, a.d1, a.d2}; }
+__device__ __forceinline__ Ad operator+(double a, const Ad& b) { return Ad{a + b.v, b.d0, b.d1, b.d2}; }
+__device__ __forceinline__ Ad operator-(const Ad& a, double b) { return Ad{a.v - b, a.d0, a.d1, a.d2}; }
+__device__ __forceinline__ Ad operator-(double a, const Ad& b) { return Ad{a - b.v, -b.d0, -b.d1, -b.d2}; }
+__device__ __forceinline__ Ad operator-(const Ad& a) { return Ad{-a.v, -a.d0, -a.d1, -a.d2}; }
+__device__ __forceinline__ Ad operator*(const Ad& a, const Ad& b) {
+    const double u = a.v, w = b.v;
+    return Ad{u * w, a.d0 * w + b.d0 * u, a.d1 * w + b.d1 * u, a.d2 * w + b.d2 * u};
+}
+__device__ __forceinline__ Ad operator*(const Ad& a, double b) { return Ad{a.v * b, a.d0 * b, a.d1 * b, a.d2 * b}; }
+__device__ __forceinline__ Ad operator*(double a, const Ad& b) { return b * a; }
+__device__ __forceinline__ Ad operator/(const Ad& a, const Ad& b) {
+    const double u = a.v, w = b.v;
+    return Ad{u / w, (w * a.d0 - b.d0 * u) / (w * w), (w * a.d1 - b.d1 * u) / (w * w), (w * a.d2 - b.d2 * u) / (w * w)};
+}
+__device__ __forceinline__ Ad operator/(const Ad& a, double b) { return Ad{a.v / b, a.d0 / b, a.d1 / b, a.d2 / b}; }
+__device__ __forceinline__ Ad operator/(double a, const Ad& b) {
+    const double t = -a / (b.v * b.v);
+    return Ad{a / b.v, t * b.d0, t * b.d1, t * b.d2};
+}
+__device__ __forceinline__ Ad ad_max(const Ad& a, const Ad& b) { return (a.v > b.v) ? a : b; }
+__device__ __forceinline__ Ad ad_min(const Ad& a, const Ad& b) { return (a.v < b.v) ? a : b; }
+__device__ __forceinline__ double val(const Ad& a) { return a.v; }
+__device__ __forceinline__ double val(double a) { return a; }
+template <class E> __device__ __forceinline__ E mk(double x, int idx);
+template <> __device__ __forceinline__ Ad mk<Ad>(double x, int idx) { return ad_var(x, idx); }
+template <> __device__ __forceinline__ double mk<double>(double x, int) { return x; }
+template <class E> __device__ __forceinline__ E cst(double x);
+template <> __device__ __forceinline__ Ad cst<Ad>(double x) { return ad_const(x); }
+template <> __device__ __forceinline__ double cst<double>(double x) { return x; }
+__device__ __forceinline__ double emin(double a, double b) { return (a < b) ? a : b; }
+__device__ __forceinline__ Ad emin(const Ad& a, const Ad& b) { return ad_min(a, b); }
+__device__ __forceinline__ double emax(double a, double b) { return (a > b) ? a : b; }
+__device__ __forceinline__ Ad emax(const Ad& a, const Ad& b) { return ad_max(a, b); }
+
+// ============================== property tables ===============================================================
+struct Tables {
+    const double* dbl;
+    const int* idx;
+    double rock_pref, rock_cr;
+    __device__ __forceinline__ const PvtRegionDesc& pvt(int r) const { return reinterpret_cast<const PvtRegionDesc*>(idx + 2)[r]; }
+    __device__ __forceinline__ const SatRegionDesc& sat(int s) const {
+        return reinterpret_cast<const SatRegionDesc*>(idx + 2 + idx[0] * (int)(sizeof(PvtRegionDesc) / sizeof(int)))[s];
+    }
+};
+// segment of x in an ascending array with clamping (Tabulated1DFunction / UniformXTabulated2DFunction, extrapolate = true):
+// a value that sits exactly on an interior node belongs to the segment on its right
+__device__ __forceinline__ int seg_right(const double* x, int n, double xv) {
+    if (xv <= x[0]) return 0;
+    if (xv >= x[n - 1]) return n - 2;
+    int lo = 0, hi = n - 1;
+    while (lo + 1 < hi) {
+        const int mid = (lo + hi) >> 1;
+        if (x[mid] <= xv) lo = mid; else hi = mid;
+    }
+    return lo;
+}
+template <class E> __device__ __forceinline__ E tab1(const double* x, const double* y, int n, const E& xv) {
+    const int s = seg_right(x, n, val(xv));
+    const double x0 = x[s], x1 = x[s + 1], y0 = y[s], y1 = y[s + 1];
+    return y0 + (y1 - y0) * (xv - x0) / (x1 - x0);
+}
+// plain bilinear interpolation in (Rs, p) with per-column pressure grids (the policy the Norne PVT points select)
+template <class E> __device__ __forceinline__ E tab2(const Tables& T, const PvtRegionDesc& D, int voff, const E& xv, const E& yv) {
+    const double* xs = T.dbl + D.o_xs;
+    const int* yo = T.idx + D.o_yoff;
+    const int i = seg_right(xs, D.o_nx, val(xv));
+    const E alpha = (xv - xs[i]) / (xs[i + 1] - xs[i]);
+    const double* y1 = T.dbl + D.o_ys + yo[i];
+    const double* y2 = T.dbl + D.o_ys + yo[i + 1];
+    const double* v1 = T.dbl + voff + yo[i];
+    const double* v2 = T.dbl + voff + yo[i + 1];
+    const int j1 = seg_right(y1, yo[i + 1] - yo[i], val(yv)), j2 = seg_right(y2, yo[i + 2] - yo[i + 1], val(yv));
+    const E beta1 = (yv - y1[j1]) / (y1[j1 + 1] - y1[j1]);
+    const E beta2 = (yv - y2[j2]) / (y2[j2 + 1] - y2[j2]);
+    const E s1 = v1[j1] * (1.0 - beta1) + v1[j1 + 1] * beta1;
+    const E s2 = v2[j2] * (1.0 - beta2) + v2[j2 + 1] * beta2;
+    return s1 * (1.0 - alpha) + s2 * alpha;
+}
+// PiecewiseLinearTwoPhaseMaterial: constant outside the table; a value on a node belongs to the segment on its left
+template <class E> __device__ __forceinline__ E pwlin(const double* x, const double* y, int n, const E& xv) {
+    const double s = val(xv);
+    if (s <= x[0]) return cst<E>(y[0]);
+    if (s >= x[n - 1]) return cst<E>(y[n - 1]);
+    int lo = 0, hi = n - 1;
+    while (lo + 1 < hi) {
+        const int mid = (lo + hi) >> 1;
+        if (x[mid] < s) lo = mid; else hi = mid;
+    }
+    const double x0 = x[lo], x1 = x[lo + 1], y0 = y[lo], y1 = y[lo + 1];
+    const double m = (y1 - y0) / (x1 - x0);
+    return y0 + (xv - x0) * m;
+}
+__device__ __forceinline__ double rs_sat_value(const Tables& T, int pr, double po) {
+    const PvtRegionDesc& D = T.pvt(pr);
+    return tab1<double>(T.dbl + D.sat_p, T.dbl + D.sat_rs, D.sat_n, po);
+}
+
+// ============================== intensive quantities ========================================================
+constexpr int IQF = 17;            // fields per cell
+constexpr int IQS = IQF * 4;       // doubles per cell in the cache (value + 3 derivatives each)
+enum { F_S = 0, F_P = 3, F_B = 6, F_MOB = 9, F_RHO = 12, F_RS = 15, F_PORO = 16 };
+enum { WATER = 0, OIL = 1, GAS = 2 };
+enum { EQ_OIL = 0, EQ_WATER = 1, EQ_GAS = 2 };
+constexpr double GRAVITY = 9.80665;
+
+template <class E>
+struct Iq {
+    E S[3], p[3], invB[3], mob[3], rho[3], Rs, poro;
+};
+
+// BlackOilIntensiveQuantities::update for live oil + dry gas + water
+template <class E>
+__device__ __forceinline__ void update_iq(const Tables& T, int pr, int sr, double RsMax, double refPoro, const double* pv, int meaning, Iq<E>& q) {
+    const PvtRegionDesc& D = T.pvt(pr);
+    const SatRegionDesc& Sd = T.sat(sr);
+    const double* B = T.dbl;
+    const double Swco = B[Sd.swco];
+    const E Sw = mk<E>(pv[0], 0);
+    E Sg = cst<E>(0.0);
+    if (meaning == OPMHIP_SW_PO_SG) Sg = mk<E>(pv[2], 2);
+    const E So = 1.0 - Sw - Sg;
+    q.S[WATER] = Sw; q.S[GAS] = Sg; q.S[OIL] = So;
+    // capillary pressures (EclDefaultMaterial): pC[water] = -pcow(Sw), pC[oil] = 0, pC[gas] = pcgo(1 - Swco - Sg)
+    E pC[3];
+    pC[0] = -pwlin<E>(B + Sd.sw_x, B + Sd.pcow, Sd.nw, Sw);
+    pC[1] = cst<E>(0.0);
+    pC[2] = pwlin<E>(B + Sd.so_x, B + Sd.pcgo, Sd.ng, 1.0 - Swco - Sg);
+    const E po = mk<E>(pv[1], 1);
+    for (int ph = 0; ph < 3; ++ph) q.p[ph] = po + (pC[ph] - pC[OIL]);
+    // relative permeabilities (stored in mob, divided by viscosity below)
+    {
+        q.mob[WATER] = pwlin<E>(B + Sd.sw_x, B + Sd.krw, Sd.nw, Sw);
+        q.mob[GAS] = pwlin<E>(B + Sd.so_x, B + Sd.krg, Sd.ng, 1.0 - Swco - Sg);
+        const E Swm = emax(cst<E>(Swco), Sw);
+        const E Sw_ow = Sg + Swm;
+        const E So_go = 1.0 - Sw_ow;
+        const E kro_ow = pwlin<E>(B + Sd.sw_x, B + Sd.krow, Sd.nw, Sw_ow);
+        const E kro_go = pwlin<E>(B + Sd.so_x, B + Sd.krog, Sd.ng, So_go);
+        const double eps = 1e-5;
+        if (val(Sw_ow) - Swco < eps) {
+            const E kro2 = (kro_ow + kro_go) / 2.0;
+            if (val(Sw_ow) - Swco > eps / 2.0) {
+                const E kro1 = (Sg * kro_go + (Swm - Swco) * kro_ow) / (Sw_ow - Swco);
+                const E alpha = (eps - (Sw_ow - Swco)) / (eps / 2.0);
+                q.mob[OIL] = kro2 * alpha + kro1 * (1.0 - alpha);
+            } else q.mob[OIL] = kro2;
+        } else q.mob[OIL] = (Sg * kro_go + (Swm - Swco) * kro_ow) / (Sw_ow - Swco);
+    }
+    // Rs: saturated value in the three-phase case, the primary variable otherwise, capped by RsMax
+    if (meaning == OPMHIP_SW_PO_SG) {
+        const E RsSat = tab1<E>(B + D.sat_p, B + D.sat_rs, D.sat_n, q.p[OIL]);
+        q.Rs = emin(cst<E>(RsMax), RsSat);
+    } else {
+        q.Rs = emin(cst<E>(RsMax), mk<E>(pv[2], 2));
+    }
+    // 1/B and viscosity per phase, each at its own phase pressure (BlackOilFluidSystem)
+    {
+        const bool saturated = val(q.S[GAS]) > 0.0 && val(q.Rs) >= (1.0 - 1e-10) * rs_sat_value(T, pr, val(q.p[OIL]));
+        const double* W = B + D.water;  // p_ref, Bw_ref, c_w, mu_ref, c_v
+        const E X = W[2] * (q.p[WATER] - W[0]);
+        q.invB[WATER] = (1.0 + X * (1.0 + X / 2.0)) / W[1];
+        const E Y = (W[2] - W[4]) * (q.p[WATER] - W[0]);
+        E mu = (W[3] * W[1]) * q.invB[WATER] / (1.0 + Y * (1.0 + Y / 2.0));
+        q.mob[WATER] = q.mob[WATER] / mu;
+        if (saturated) {
+            q.invB[OIL] = tab1<E>(B + D.sat_p, B + D.sat_invB, D.sat_n, q.p[OIL]);
+            mu = tab1<E>(B + D.sat_p, B + D.sat_invB, D.sat_n, q.p[OIL]) / tab1<E>(B + D.sat_p, B + D.sat_invBMu, D.sat_n, q.p[OIL]);
+        } else {
+            q.invB[OIL] = tab2<E>(T, D, D.o_invB, q.Rs, q.p[OIL]);
+            mu = tab2<E>(T, D, D.o_invB, q.Rs, q.p[OIL]) / tab2<E>(T, D, D.o_invBMu, q.Rs, q.p[OIL]);
+        }
+        q.mob[OIL] = q.mob[OIL] / mu;
+        q.invB[GAS] = tab1<E>(B + D.gas_p, B + D.gas_invB, D.gas_n, q.p[GAS]);
+        mu = tab1<E>(B + D.gas_p, B + D.gas_invB, D.gas_n, q.p[GAS]) / tab1<E>(B + D.gas_p, B + D.gas_invBMu, D.gas_n, q.p[GAS]);
+        q.mob[GAS] = q.mob[GAS] / mu;
+    }
+    const double* rr = B + D.density;  // oil, water, gas
+    q.rho[WATER] = q.invB[WATER] * rr[1];
+    q.rho[GAS] = q.invB[GAS] * rr[2];
+    q.rho[OIL] = q.invB[OIL] * rr[0];
+    q.rho[OIL] = q.rho[OIL] + q.invB[OIL] * q.Rs * rr[2];
+    q.poro = cst<E>(refPoro);
+    if (T.rock_cr > 0.0) {
+        const E x = T.rock_cr * (q.p[OIL] - T.rock_pref);
+        q.poro = q.poro * (1.0 + x + 0.5 * x * x);
+    }
+}
+
+__device__ __forceinline__ void store_ad(double* o, const Ad& a) { o[0] = a.v; o[1] = a.d0; o[2] = a.d1; o[3] = a.d2; }
+__device__ __forceinline__ Ad load_ad(const double* o) {
+    const double2 a = *reinterpret_cast<const double2*>(o), b = *reinterpret_cast<const double2*>(o + 2);
+    return Ad{a.x, a.y, b.x, b.y};
+}
+__device__ __forceinline__ void store_iq(double* o, const Iq<Ad>& q) {
+    for (int k = 0; k < 3; ++k) {
+        store_ad(o + (F_S + k) * 4, q.S[k]); store_ad(o + (F_P + k) * 4, q.p[k]); store_ad(o + (F_B + k) * 4, q.invB[k]);
+        store_ad(o + (F_MOB + k) * 4, q.mob[k]); store_ad(o + (F_RHO + k) * 4, q.rho[k]);
+    }
+    store_ad(o + F_RS * 4, q.Rs);
+    store_ad(o + F_PORO * 4, q.poro);
+}
+
+struct CellStatic {
+    const double *poro, *volume, *depth, *rsmax;
+    const int *pvtnum, *satnum;
+};
+
+// invalidateAndUpdateIntensiveQuantities(0): one lane per cell
+__global__ __launch_bounds__(256) void k_iq_update(int Nb, Tables T, CellStatic C, const double* __restrict__ pv,
+                                                   const unsigned char* __restrict__ meaning, double* __restrict__ iq) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= Nb) return;
+    const double x[3] = {pv[(size_t)c * 3], pv[(size_t)c * 3 + 1], pv[(size_t)c * 3 + 2]};
+    Iq<Ad> q;
+    update_iq<Ad>(T, C.pvtnum ? C.pvtnum[c] : 0, C.satnum ? C.satnum[c] : 0, C.rsmax ? C.rsmax[c] : DBL_MAX / 2.0, C.poro[c], x, meaning[c], q);
+    store_iq(iq + (size_t)c * IQS, q);
+}
+
+// BlackOilNewtonMethod::update_ + adaptPrimaryVariables + IQ recompute, one lane per cell.
+// dx is in the INTERNAL order (the solver's x); relax = NonlinearSolverEbos "dampen" factor applied first.
+__global__ __launch_bounds__(256) void k_newton_update(int Nb, Tables T, CellStatic C, const double* __restrict__ dx, double relax,
+                                                       double* __restrict__ pv, unsigned char* __restrict__ meaning,
+                                                       unsigned char* __restrict__ wasSwitched, double* __restrict__ iq,
+                                                       int* __restrict__ nswitched) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= Nb) return;
+    const double dpMaxRel = 0.3, dsMax = 0.2, oscThreshold = 1e-5;
+    double x[3] = {pv[(size_t)c * 3], pv[(size_t)c * 3 + 1], pv[(size_t)c * 3 + 2]};
+    double u[3] = {dx[(size_t)c * 3], dx[(size_t)c * 3 + 1], dx[(size_t)c * 3 + 2]};
+    if (relax != 1.0) { u[0] *= relax; u[1] *= relax; u[2] *= relax; }
+    int mng = meaning[c];
+    const double deltaSw = u[0];
+    double deltaSo = -deltaSw, deltaSg = 0.0;
+    if (mng == OPMHIP_SW_PO_SG) { deltaSg = u[2]; deltaSo -= deltaSg; }
+    double maxSatDelta = fmax(fabs(deltaSg), fabs(deltaSo));
+    maxSatDelta = fmax(maxSatDelta, fabs(deltaSw));
+    double satAlpha = 1.0;
+    if (maxSatDelta > dsMax) satAlpha = dsMax / maxSatDelta;
+    double nx[3];
+    {
+        double delta = u[0] * satAlpha;
+        nx[0] = x[0] - delta;
+        delta = u[1];
+        if (fabs(delta) > dpMaxRel * x[1]) delta = (delta < 0.0 ? -1.0 : 1.0) * dpMaxRel * x[1];
+        nx[1] = x[1] - delta;
+        delta = u[2];
+        if (mng == OPMHIP_SW_PO_SG) delta *= satAlpha;
+        else if (delta > x[2]) delta = x[2];
+        nx[2] = x[2] - delta;
+    }
+    x[0] = nx[0]; x[1] = nx[1]; x[2] = nx[2];
+    const int pr = C.pvtnum ? C.pvtnum[c] : 0;
+    const double RsMax = C.rsmax ? C.rsmax[c] : DBL_MAX / 2.0;
+    const double eps = wasSwitched[c] ? oscThreshold : 0.0;
+    bool sw = false;
+    if (mng == OPMHIP_SW_PO_SG) {
+        if (x[0] >= 1.0) { x[0] = 1.0; x[2] = 0.0; }
+        else {
+            const double So = 1.0 - x[0] - x[2];
+            if (x[2] < -eps && So > 0.0) {
+                mng = OPMHIP_SW_PO_RS;
+                x[2] = emin(RsMax, rs_sat_value(T, pr, x[1]));
+                sw = true;
+            }
+        }
+    } else {
+        if (x[0] >= 1.0) { mng = OPMHIP_SW_PO_SG; x[0] = 1.0; x[2] = 0.0; sw = true; }
+        else {
+            const double RsSat = rs_sat_value(T, pr, x[1]);
+            if (x[2] > emin(RsMax, RsSat * (1.0 + eps))) { mng = OPMHIP_SW_PO_SG; x[2] = 0.0; sw = true; }
+        }
+    }
+    wasSwitched[c] = sw ? 1 : 0;
+    meaning[c] = (unsigned char)mng;
+    pv[(size_t)c * 3] = x[0]; pv[(size_t)c * 3 + 1] = x[1]; pv[(size_t)c * 3 + 2] = x[2];
+    if (sw) atomicAdd(nswitched, 1);
+    Iq<Ad> q;
+    update_iq<Ad>(T, pr, C.satnum ? C.satnum[c] : 0, RsMax, C.poro[c], x, mng, q);
+    store_iq(iq + (size_t)c * IQS, q);
+}
+
+// ============================== face flux ===================================================================
+// calculateGradients_ + computeFlux for one face: `in` = focus (interior) cell with derivatives, `ex` = exterior cell,
+// of which only values enter.  Both are pointers into the IQ cache.  Result: flux[eq] * faceArea.
+__device__ __forceinline__ void face_flux(const double* __restrict__ in, const double* __restrict__ ex, double trans, double faceArea,
+                                          double thpres, double zIn, double zEx, double Vin, double Vex, int I, int J, Ad flux[3]) {
+    flux[0] = flux[1] = flux[2] = ad_const(0.0);
+    const double distZ = zIn - zEx;
+    const int comp[3] = {EQ_WATER, EQ_OIL, EQ_GAS};
+#pragma unroll
+    for (int ph = 0; ph < 3; ++ph) {
+        const Ad mobIn = load_ad(in + (F_MOB + ph) * 4);
+        const double mobEx = ex[(F_MOB + ph) * 4];
+        if (mobIn.v <= 0.0 && mobEx <= 0.0) continue;
+        const Ad rhoIn = load_ad(in + (F_RHO + ph) * 4);
+        const double rhoEx = ex[(F_RHO + ph) * 4];
+        const Ad rhoAvg = (rhoIn + rhoEx) / 2.0;
+        Ad pressureExterior = ad_const(ex[(F_P + ph) * 4]);
+        pressureExterior = pressureExterior + rhoAvg * (distZ * GRAVITY);
+        Ad dp = pressureExterior - load_ad(in + (F_P + ph) * 4);
+        bool upIn;
+        if (dp.v > 0.0) upIn = false;
+        else if (dp.v < 0.0) upIn = true;
+        else if (Vin > Vex) upIn = true;
+        else if (Vin < Vex) upIn = false;
+        else upIn = (I < J);
+        if (fabs(dp.v) > thpres) {
+            if (dp.v < 0.0) dp = dp + thpres; else dp = dp - thpres;
+        } else continue;
+        Ad volumeFlux, surf;
+        if (upIn) {
+            volumeFlux = dp * mobIn * ad_const(1.0) * (-trans / faceArea);
+            surf = load_ad(in + (F_B + ph) * 4) * volumeFlux;
+        } else {
+            volumeFlux = dp * (mobEx * 1.0 * (-trans / faceArea));
+            surf = ex[(F_B + ph) * 4] * volumeFlux;
+        }
+        flux[comp[ph]] = flux[comp[ph]] + surf;
+        if (ph == OIL) {
+            if (upIn) flux[EQ_GAS] = flux[EQ_GAS] + load_ad(in + F_RS * 4) * surf;
+            else flux[EQ_GAS] = flux[EQ_GAS] + ex[F_RS * 4] * surf;
+        }
+    }
+#pragma unroll
+    for (int e = 0; e < 3; ++e) flux[e] = flux[e] * faceArea;
+}
+
+// ============================== assembly ======================================================================
+constexpr int ASM_THREADS = 256;
+struct EntryStatic {
+    const double *trans, *area, *thpres;  // per entry, internal order
+};
+// FvBaseLinearizer::linearizeDomain.  tile t: rows [row0[t], row0[t+1]) ; its entries <= ASM_THREADS.
+__global__ __launch_bounds__(ASM_THREADS) void k_assemble(const int* __restrict__ asm_row0, const int* __restrict__ rowptr,
+                                                          const int* __restrict__ col, const int* __restrict__ natOrder,
+                                                          EntryStatic ES, CellStatic C, const double* __restrict__ iq,
+                                                          double* __restrict__ storageOld, const double* __restrict__ source,
+                                                          const double* __restrict__ dsource, double dt, int iteration,
+                                                          double* __restrict__ A, double* __restrict__ resid) {
+    __shared__ __attribute__((aligned(16))) double sblk[(ASM_THREADS + 2) * BB];  // the tile's blocks, then streamed out
+    __shared__ double sflux[ASM_THREADS * 12];                                     // face flux seen from the row's cell
+    __shared__ short srow[ASM_THREADS];
+    const int t = blockIdx.x, tid = threadIdx.x;
+    const int r0 = asm_row0[t], r1 = asm_row0[t + 1];
+    const int k0 = rowptr[r0], k1 = rowptr[r1], nent = k1 - k0;
+    const int k0e = k0 & ~1;  // 16-byte aligned start of the output stream
+    if (tid < r1 - r0)
+        for (int k = rowptr[r0 + tid]; k < rowptr[r0 + tid + 1]; ++k) srow[k - k0] = (short)tid;
+    __syncthreads();
+    Ad st[3];
+    int I = -1, J = -1, k = -1;
+    bool isDiag = false;
+    if (tid < nent) {
+        k = k0 + tid;
+        I = r0 + srow[tid];
+        J = col[k];
+        isDiag = (I == J);
+        const double* qI = iq + (size_t)I * IQS;
+        if (!isDiag) {
+            const double* qJ = iq + (size_t)J * IQS;
+            const double trans = ES.trans[k], area = ES.area[k], thp = ES.thpres ? ES.thpres[k] : 0.0;
+            const double zI = C.depth[I], zJ = C.depth[J], VI = C.volume[I], VJ = C.volume[J];
+            Ad f[3];
+            face_flux(qI, qJ, trans, area, thp, zI, zJ, VI, VJ, I, J, f);  // focus I: contribution to R_I
+            for (int e = 0; e < 3; ++e) store_ad(&sflux[tid * 12 + e * 4], f[e]);
+            face_flux(qJ, qI, trans, area, thp, zJ, zI, VJ, VI, J, I, f);  // focus J: residual[I] -= flux  ->  block (I,J)
+            double* b = &sblk[(k - k0e) * BB];
+            for (int e = 0; e < 3; ++e) {
+                const Ad m = ad_const(0.0) - f[e];
+                b[e * 3 + 0] = m.d0; b[e * 3 + 1] = m.d1; b[e * 3 + 2] = m.d2;
+            }
+        } else {
+            // computeStorage: surface volumes per bulk volume
+            const Ad poro = load_ad(qI + F_PORO * 4), Rs = load_ad(qI + F_RS * 4);
+            st[0] = st[1] = st[2] = ad_const(0.0);
+            const int comp[3] = {EQ_WATER, EQ_OIL, EQ_GAS};
+#pragma unroll
+            for (int ph = 0; ph < 3; ++ph) {
+                const Ad surfaceVolume = load_ad(qI + (F_S + ph) * 4) * load_ad(qI + (F_B + ph) * 4) * poro;
+                st[comp[ph]] = st[comp[ph]] + surfaceVolume;
+                if (ph == OIL) st[EQ_GAS] = st[EQ_GAS] + Rs * surfaceVolume;
+            }
+        }
+    }
+    __syncthreads();
+    if (tid < nent && isDiag) {
+        Ad R[3] = {ad_const(0.0), ad_const(0.0), ad_const(0.0)};
+        // flux terms first (FvBaseLocalResidual::eval), faces in ascending NATURAL neighbour order whatever the
+        // internal ordering is, so that the sum is the one the natural-order CPU path forms
+        for (int qq = rowptr[I]; qq < rowptr[I + 1]; ++qq) {
+            const int q = natOrder[qq];
+            if (q == k) continue;
+            const double* f = &sflux[(q - k0) * 12];
+            for (int e = 0; e < 3; ++e) R[e] = R[e] + Ad{f[e * 4], f[e * 4 + 1], f[e * 4 + 2], f[e * 4 + 3]};
+        }
+        const double V = C.volume[I];
+        double* so = storageOld + (size_t)I * 3;
+        for (int e = 0; e < 3; ++e) {
+            double old;
+            if (iteration == 0) { old = st[e].v; so[e] = old; } else old = so[e];
+            Ad tt = st[e] - old;
+            tt = tt * (V / dt);
+            R[e] = R[e] + tt;
+        }
+        for (int e = 0; e < 3; ++e) {
+            Ad s = ad_const(source ? source[(size_t)I * 3 + e] : 0.0);
+            if (dsource) { s.d0 = dsource[(size_t)I * 9 + e * 3]; s.d1 = dsource[(size_t)I * 9 + e * 3 + 1]; s.d2 = dsource[(size_t)I * 9 + e * 3 + 2]; }
+            s = s / V;
+            s = s * V;
+            R[e] = R[e] - s;
+        }
+        double* b = &sblk[(k - k0e) * BB];
+        for (int e = 0; e < 3; ++e) {
+            resid[(size_t)I * 3 + e] = R[e].v;
+            b[e * 3 + 0] = R[e].d0; b[e * 3 + 1] = R[e].d1; b[e * 3 + 2] = R[e].d2;
+        }
+    }
+    __syncthreads();
+    // stream the tile's blocks out: contiguous range [k0, k1) x 72 B
+    {
+        const int head = (k0 - k0e) * BB;      // doubles to skip at the front (0 or 9)
+        const int n = nent * BB;
+        double* dst = A + (size_t)k0e * BB;
+        int b = head, e = head + n;
+        // unaligned head / tail doubles go out one by one, the body as double2
+        if ((b & 1) && tid == 0) dst[b] = sblk[b];
+        if ((e & 1) && tid == 0) dst[e - 1] = sblk[e - 1];
+        b = (b + 1) & ~1;
+        e = e & ~1;
+        const double2* s2 = reinterpret_cast<const double2*>(sblk);
+        double2* d2 = reinterpret_cast<double2*>(dst);
+        for (int i = (b >> 1) + tid; i < (e >> 1); i += ASM_THREADS) d2[i] = s2[i];
+    }
+}
+
+// ============================== convergence ===================================================================
+// pass 1 partials per block: R_sum[3], maxCoeff[3], sum(1/b)[3], pvSum ; pass 2: cnvErrorPv
+__global__ __launch_bounds__(256) void k_conv_pass1(int Nb, CellStatic C, const double* __restrict__ iq, const double* __restrict__ resid,
+                                                    double* __restrict__ part) {
+    __shared__ double sh[10][4];
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    double a[10];
+    for (int i = 0; i < 10; ++i) a[i] = (i >= 3 && i < 6) ? -DBL_MAX : 0.0;
+    if (c < Nb) {
+        const double pvValue = C.poro[c] * C.volume[c];
+        const int comp[3] = {EQ_WATER, EQ_OIL, EQ_GAS};
+        for (int ph = 0; ph < 3; ++ph) {
+            const int e = comp[ph];
+            a[6 + e] = 1.0 / iq[(size_t)c * IQS + (F_B + ph) * 4];
+            const double R2 = resid[(size_t)c * 3 + e];
+            a[e] = R2;
+            a[3 + e] = fabs(R2) / pvValue;
+        }
+        a[9] = pvValue;
+    }
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    for (int i = 0; i < 10; ++i) {
+        double v = a[i];
+        for (int o = 32; o > 0; o >>= 1) {
+            const double w = __shfl_down(v, o, 64);
+            v = (i >= 3 && i < 6) ? fmax(v, w) : v + w;
+        }
+        if (lane == 0) sh[i][wv] = v;
+    }
+    __syncthreads();
+    if (threadIdx.x < 10) {
+        const int i = threadIdx.x;
+        double v = sh[i][0];
+        for (int w = 1; w < 4; ++w) v = (i >= 3 && i < 6) ? fmax(v, sh[i][w]) : v + sh[i][w];
+        part[(size_t)blockIdx.x * 10 + i] = v;
+    }
+}
+// one workgroup: reduce the block partials in a fixed order; out[0..9] as above with B_avg divided by Nb
+__global__ __launch_bounds__(256) void k_conv_final1(int nblocks, int Nb, const double* __restrict__ part, double* __restrict__ out) {
+    __shared__ double sh[10][256];
+    double a[10];
+    for (int i = 0; i < 10; ++i) a[i] = (i >= 3 && i < 6) ? -DBL_MAX : 0.0;
+    for (int b = threadIdx.x; b < nblocks; b += 256)
+        for (int i = 0; i < 10; ++i) {
+            const double v = part[(size_t)b * 10 + i];
+            a[i] = (i >= 3 && i < 6) ? fmax(a[i], v) : a[i] + v;
+        }
+    for (int i = 0; i < 10; ++i) sh[i][threadIdx.x] = a[i];
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) {
+        if ((int)threadIdx.x < o)
+            for (int i = 0; i < 10; ++i) {
+                const double v = sh[i][threadIdx.x + o];
+                sh[i][threadIdx.x] = (i >= 3 && i < 6) ? fmax(sh[i][threadIdx.x], v) : sh[i][threadIdx.x] + v;
+            }
+        __syncthreads();
+    }
+    if (threadIdx.x < 10) {
+        double v = sh[threadIdx.x][0];
+        if (threadIdx.x >= 6 && threadIdx.x < 9) v /= (double)Nb;
+        out[threadIdx.x] = v;
+    }
+}
+__global__ __launch_bounds__(256) void k_conv_pass2(int Nb, CellStatic C, const double* __restrict__ resid, const double* __restrict__ out1,
+                                                    double dt, double tol_cnv, double* __restrict__ part) {
+    __shared__ double sh[4];
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    double v = 0.0;
+    if (c < Nb) {
+        const double pvValue = C.poro[c] * C.volume[c];
+        bool violated = false;
+        for (int e = 0; e < 3; ++e) {
+            const double CNV = resid[(size_t)c * 3 + e] * dt * out1[6 + e] / pvValue;
+            violated = violated || (fabs(CNV) > tol_cnv);
+        }
+        if (violated) v = pvValue;
+    }
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o, 64);
+    if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = v;
+    __syncthreads();
+    if (threadIdx.x == 0) part[blockIdx.x] = sh[0] + sh[1] + sh[2] + sh[3];
+}
+__global__ __launch_bounds__(256) void k_conv_final2(int nblocks, const double* __restrict__ part, double* __restrict__ out) {
+    __shared__ double sh[256];
+    double a = 0.0;
+    for (int b = threadIdx.x; b < nblocks; b += 256) a += part[b];
+    sh[threadIdx.x] = a;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) {
+        if ((int)threadIdx.x < o) sh[threadIdx.x] += sh[threadIdx.x + o];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) out[10] = sh[0];
+}
+
+// ============================== small permutation helpers =====================================================
+__global__ void k_cellvec_to_internal_u8(int Nb, const int* __restrict__ fromOrder, const unsigned char* __restrict__ nat, unsigned char* __restrict__ internal) {
+    const int p = blockIdx.x * blockDim.x + threadIdx.x;
+    if (p < Nb) internal[p] = nat[fromOrder[p]];
+}
+__global__ void k_cellvec_to_natural_u8(int Nb, const int* __restrict__ toOrder, const unsigned char* __restrict__ internal, unsigned char* __restrict__ nat) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < Nb) nat[i] = internal[toOrder[i]];
+}
+__global__ void k_iq_to_natural(int Nb, const int* __restrict__ toOrder, const double* __restrict__ internal, double* __restrict__ nat) {
+    const size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= (size_t)Nb * IQS) return;
+    const int i = (int)(e / IQS), q = (int)(e % IQS);
+    nat[e] = internal[(size_t)toOrder[i] * IQS + q];
+}
+__global__ void k_unpermute_blocks(int nnzb, const int* __restrict__ nnzMap, const double* __restrict__ internal, double* __restrict__ nat) {
+    const size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= (size_t)nnzb * BB) return;
+    const int k = (int)(e / BB), q = (int)(e % BB);
+    nat[(size_t)nnzMap[k] * BB + q] = internal[e];
+}
+
+// ============================== launchers ====================================================================
+static inline int cdiv(size_t a, size_t b) { return (int)((a + b - 1) / b); }
+static Tables tables_of(const opmhip_ctx* c) { return Tables{c->asmb.d_tab_dbl, c->asmb.d_tab_idx, c->asmb.rock_pref, c->asmb.rock_cr}; }
+static CellStatic cells_of(const opmhip_ctx* c) {
+    return CellStatic{c->asmb.d_poro, c->asmb.d_volume, c->asmb.d_depth, c->asmb.d_rsmax, c->asmb.d_pvtnum, c->asmb.d_satnum};
+}
+
+void launch_iq_update(opmhip_ctx* c) {
+    const int Nb = c->pat.Nb;
+    hipLaunchKernelGGL(k_iq_update, dim3(cdiv(Nb, 256)), dim3(256), 0, c->stream, Nb, tables_of(c), cells_of(c), c->asmb.d_pv, c->asmb.d_meaning, c->asmb.d_iq);
+}
+void launch_newton_update(opmhip_ctx* c, const double* d_dx, double relax) {
+    const int Nb = c->pat.Nb;
+    (void)hipMemsetAsync(c->asmb.d_nswitched, 0, sizeof(int), c->stream);
+    hipLaunchKernelGGL(k_newton_update, dim3(cdiv(Nb, 256)), dim3(256), 0, c->stream, Nb, tables_of(c), cells_of(c), d_dx, relax, c->asmb.d_pv,
+                       c->asmb.d_meaning, c->asmb.d_wasSwitched, c->asmb.d_iq, c->asmb.d_nswitched);
+}
+void launch_assemble(opmhip_ctx* c, double dt, int iteration) {
+    const Pattern& P = c->pat;
+    EntryStatic ES{c->asmb.d_trans, c->asmb.d_area, c->asmb.d_thpres};
+    hipLaunchKernelGGL(k_assemble, dim3(c->asmb.ntiles), dim3(ASM_THREADS), 0, c->stream, c->asmb.d_asm_row0, P.d_rowptr, P.d_col, c->asmb.d_natOrder, ES,
+                       cells_of(c), c->asmb.d_iq, c->asmb.d_storageOld, c->asmb.d_source, c->asmb.d_dsource, dt, iteration, c->d_A, c->d_b);
+}
+void launch_convergence(opmhip_ctx* c, double dt, double tol_cnv) {
+    const int Nb = c->pat.Nb, nb = cdiv(Nb, 256);
+    hipLaunchKernelGGL(k_conv_pass1, dim3(nb), dim3(256), 0, c->stream, Nb, cells_of(c), c->asmb.d_iq, c->d_b, c->asmb.d_conv_part);
+    hipLaunchKernelGGL(k_conv_final1, dim3(1), dim3(256), 0, c->stream, nb, Nb, c->asmb.d_conv_part, c->asmb.d_conv_out);
+    hipLaunchKernelGGL(k_conv_pass2, dim3(nb), dim3(256), 0, c->stream, Nb, cells_of(c), c->d_b, c->asmb.d_conv_out, dt, tol_cnv, c->asmb.d_conv_part);
+    hipLaunchKernelGGL(k_conv_final2, dim3(1), dim3(256), 0, c->stream, nb, c->asmb.d_conv_part, c->asmb.d_conv_out);
+}
+void launch_u8_to_internal(opmhip_ctx* c, const unsigned char* nat, unsigned char* internal) {
+    hipLaunchKernelGGL(k_cellvec_to_internal_u8, dim3(cdiv(c->pat.Nb, 256)), dim3(256), 0, c->stream, c->pat.Nb, c->pat.d_fromOrder, nat, internal);
+}
+void launch_u8_to_natural(opmhip_ctx* c, const unsigned char* internal, unsigned char* nat) {
+    hipLaunchKernelGGL(k_cellvec_to_natural_u8, dim3(cdiv(c->pat.Nb, 256)), dim3(256), 0, c->stream, c->pat.Nb, c->pat.d_toOrder, internal, nat);
+}
+void launch_iq_to_natural(opmhip_ctx* c, double* d_nat) {
+    const size_t n = (size_t)c->pat.Nb * IQS;
+    hipLaunchKernelGGL(k_iq_to_natural, dim3(cdiv(n, 256)), dim3(256), 0, c->stream, c->pat.Nb, c->pat.d_toOrder, c->asmb.d_iq, d_nat);
+}
+void launch_unpermute_blocks(opmhip_ctx* c, const double* internal, double* nat) {
+    const size_t n = (size_t)c->pat.nnzb * BB;
+    hipLaunchKernelGGL(k_unpermute_blocks, dim3(cdiv(n, 256)), dim3(256), 0, c->stream, c->pat.nnzb, c->pat.d_nnzMap, internal, nat);
+}
+int iq_doubles_per_cell() { return IQS; }
+
+}  // namespace opmhip

@@ -234,6 +234,7 @@ int opmhip_solve_system(opmhip_ctx* c, int N, int nnz, int dim, double* vals, co
         if (!vals && !c->system_loaded) return fail(c, OPMHIP_NOT_READY, "solve_system: vals == NULL but no matrix is resident on the device");
         int rc;
         if ((rc = upload_system(c, vals, b))) return rc;
+        if (!vals && c->cfg.zero_diag_fix) launch_zero_diag_fix(c);  // device-assembled Jacobian: same fix-up
         if ((rc = upload_wells(c, wells))) return rc;
         OPMHIP_HIP(c, hipStreamSynchronize(c->stream));
         const double t1 = now();

@@ -1,0 +1,301 @@
+// C-ABI, assembly half (include/opmhip.h "assembly" section): fluid tables, static grid data, state, linearisation,
+// convergence norms, Newton update.  Host arrays arrive in the NATURAL cell / entry order and are permuted on upload.
+#include <algorithm>
+#include <cstring>
+
+#include "fluid_tables.hpp"
+#include "internal.hpp"
+
+using namespace opmhip;
+
+namespace {
+
+template <class F>
+int guarded(opmhip_ctx* c, F&& f) {
+    try {
+        return f();
+    } catch (const std::exception& e) {
+        return fail(c, OPMHIP_UNKNOWN_ERROR, "exception: %s", e.what());
+    } catch (...) {
+        return fail(c, OPMHIP_UNKNOWN_ERROR, "unknown exception");
+    }
+}
+
+// host-side permutation of a per-cell array natural -> internal
+template <class T>
+std::vector<T> cells_to_internal(const Pattern& P, const T* nat, int width = 1) {
+    std::vector<T> v((size_t)P.Nb * width);
+    for (int p = 0; p < P.Nb; ++p)
+        for (int q = 0; q < width; ++q) v[(size_t)p * width + q] = nat[(size_t)P.fromOrder[p] * width + q];
+    return v;
+}
+template <class T>
+int upload_cells(opmhip_ctx* c, T** dst, const T* nat, int width = 1) {
+    const Pattern& P = c->pat;
+    std::vector<T> v = cells_to_internal(P, nat, width);
+    if (!*dst) {
+        int rc = dev_alloc(c, dst, v.size());
+        if (rc) return rc;
+    }
+    OPMHIP_HIP(c, hipMemcpy(*dst, v.data(), v.size() * sizeof(T), hipMemcpyHostToDevice));
+    return OPMHIP_SUCCESS;
+}
+int upload_entries(opmhip_ctx* c, double** dst, const double* nat) {
+    const Pattern& P = c->pat;
+    std::vector<double> v(P.nnzb);
+    for (int k = 0; k < P.nnzb; ++k) v[k] = nat[P.nnzMap[k]];
+    if (!*dst) {
+        int rc = dev_alloc(c, dst, v.size());
+        if (rc) return rc;
+    }
+    OPMHIP_HIP(c, hipMemcpy(*dst, v.data(), v.size() * sizeof(double), hipMemcpyHostToDevice));
+    return OPMHIP_SUCCESS;
+}
+}  // namespace
+
+extern "C" {
+
+int opmhip_set_fluid(opmhip_ctx* c, const opmhip_fluid* fluid) {
+    if (!c) return OPMHIP_INVALID_ARGUMENT;
+    return guarded(c, [&]() -> int {
+        OPMHIP_HIP(c, hipSetDevice(c->device));
+        FluidTables T;
+        const std::string msg = build_fluid_tables(fluid, T);
+        if (!msg.empty()) return fail(c, OPMHIP_INVALID_ARGUMENT, "set_fluid: %s", msg.c_str());
+        AsmDev& A = c->asmb;
+        int rc;
+        if ((rc = dev_upload(c, &A.d_tab_dbl, T.dbl))) return rc;
+        if ((rc = dev_upload(c, &A.d_tab_idx, T.idx))) return rc;
+        A.rock_pref = T.rock_pref;
+        A.rock_cr = T.rock_cr;
+        A.num_pvt = T.num_pvt;
+        A.num_sat = T.num_sat;
+        A.fluid_set = true;
+        return OPMHIP_SUCCESS;
+    });
+}
+
+int opmhip_set_static(opmhip_ctx* c, const double* trans, const double* area, const double* thpres, const double* poro,
+                      const double* volume, const double* depth, const int* pvtnum, const int* satnum, const double* rsmax) {
+    if (!c) return OPMHIP_INVALID_ARGUMENT;
+    return guarded(c, [&]() -> int {
+        if (!c->pattern_set) return fail(c, OPMHIP_NOT_READY, "set_static before set_pattern");
+        if (!c->asmb.fluid_set) return fail(c, OPMHIP_NOT_READY, "set_static before set_fluid");
+        if (!trans || !area || !poro || !volume || !depth) return fail(c, OPMHIP_INVALID_ARGUMENT, "set_static: null array");
+        OPMHIP_HIP(c, hipSetDevice(c->device));
+        const Pattern& P = c->pat;
+        AsmDev& A = c->asmb;
+        // symmetry of the per-connection data: entry (I,J) and (J,I) describe the same face
+        {
+            std::vector<int> tr(P.nnzb, -1);
+            for (int i = 0; i < P.Nb; ++i)
+                for (int k = P.nat_rowptr[i]; k < P.nat_rowptr[i + 1]; ++k) {
+                    const int j = P.nat_col[k];
+                    const int* b = &P.nat_col[P.nat_rowptr[j]];
+                    const int* e = &P.nat_col[P.nat_rowptr[j + 1]];
+                    const int* q = std::lower_bound(b, e, i);
+                    if (q == e || *q != i) return fail(c, OPMHIP_INVALID_ARGUMENT, "set_static: pattern is not structurally symmetric at (%d,%d)", i, j);
+                    tr[k] = (int)(q - &P.nat_col[0]);
+                }
+            for (int k = 0; k < P.nnzb; ++k)
+                if (trans[k] != trans[tr[k]] || area[k] != area[tr[k]] || (thpres && thpres[k] != thpres[tr[k]]))
+                    return fail(c, OPMHIP_INVALID_ARGUMENT, "set_static: trans/area/thpres differ between entry %d and its transpose", k);
+        }
+        for (int i = 0; i < P.Nb; ++i) {
+            if (!(volume[i] > 0.0) || !(poro[i] >= 0.0)) return fail(c, OPMHIP_INVALID_ARGUMENT, "set_static: cell %d has non-positive volume or negative porosity", i);
+            if (pvtnum && (pvtnum[i] < 0 || pvtnum[i] >= A.num_pvt)) return fail(c, OPMHIP_INVALID_ARGUMENT, "set_static: pvtnum[%d] out of range", i);
+            if (satnum && (satnum[i] < 0 || satnum[i] >= A.num_sat)) return fail(c, OPMHIP_INVALID_ARGUMENT, "set_static: satnum[%d] out of range", i);
+        }
+        int rc;
+        if ((rc = upload_entries(c, &A.d_trans, trans))) return rc;
+        if ((rc = upload_entries(c, &A.d_area, area))) return rc;
+        if (thpres) { if ((rc = upload_entries(c, &A.d_thpres, thpres))) return rc; } else A.d_thpres = nullptr;
+        if ((rc = upload_cells(c, &A.d_poro, poro))) return rc;
+        if ((rc = upload_cells(c, &A.d_volume, volume))) return rc;
+        if ((rc = upload_cells(c, &A.d_depth, depth))) return rc;
+        if (pvtnum) { if ((rc = upload_cells(c, &A.d_pvtnum, pvtnum))) return rc; } else A.d_pvtnum = nullptr;
+        if (satnum) { if ((rc = upload_cells(c, &A.d_satnum, satnum))) return rc; } else A.d_satnum = nullptr;
+        if (rsmax) { if ((rc = upload_cells(c, &A.d_rsmax, rsmax))) return rc; } else A.d_rsmax = nullptr;
+        if (!A.d_pv) {
+            const size_t Nb = P.Nb;
+            if ((rc = dev_alloc(c, &A.d_pv, Nb * 3))) return rc;
+            if ((rc = dev_alloc(c, &A.d_iq, Nb * (size_t)iq_doubles_per_cell()))) return rc;
+            if ((rc = dev_alloc(c, &A.d_storageOld, Nb * 3))) return rc;
+            if ((rc = dev_alloc(c, &A.d_source, Nb * 3))) return rc;
+            if ((rc = dev_alloc(c, &A.d_dsource, Nb * 9))) return rc;
+            if ((rc = dev_alloc(c, &A.d_meaning, Nb))) return rc;
+            if ((rc = dev_alloc(c, &A.d_wasSwitched, Nb))) return rc;
+            if ((rc = dev_alloc(c, &A.d_stage_u8, Nb))) return rc;
+            if ((rc = dev_alloc(c, &A.d_nswitched, (size_t)1))) return rc;
+            if ((rc = dev_alloc(c, &A.d_conv_part, ((Nb + 255) / 256) * 10))) return rc;
+            if ((rc = dev_alloc(c, &A.d_conv_out, (size_t)16))) return rc;
+            if ((rc = dev_alloc(c, &A.d_stage_cell, Nb * (size_t)iq_doubles_per_cell()))) return rc;
+            OPMHIP_HIP(c, hipMemset(A.d_source, 0, Nb * 3 * sizeof(double)));
+            OPMHIP_HIP(c, hipMemset(A.d_dsource, 0, Nb * 9 * sizeof(double)));
+            OPMHIP_HIP(c, hipMemset(A.d_storageOld, 0, Nb * 3 * sizeof(double)));
+            OPMHIP_HIP(c, hipMemset(A.d_wasSwitched, 0, Nb));
+            // assembly tiles: whole rows, at most 256 entries
+            std::vector<int> row0;
+            int r = 0;
+            while (r < P.Nb) {
+                row0.push_back(r);
+                int e = r;
+                while (e < P.Nb && P.rowptr[e + 1] - P.rowptr[r] <= 256) ++e;
+                if (e == r) return fail(c, OPMHIP_ANALYSIS_FAILED, "set_static: row %d has more than 256 blocks", r);
+                r = e;
+            }
+            row0.push_back(P.Nb);
+            A.ntiles = (int)row0.size() - 1;
+            if ((rc = dev_upload(c, &A.d_asm_row0, row0))) return rc;
+            // entries of each row in ascending natural-column order (= ascending natural entry index)
+            std::vector<int> natOrder(P.nnzb);
+            for (int p = 0; p < P.Nb; ++p) {
+                const int b = P.rowptr[p], e = P.rowptr[p + 1];
+                for (int k = b; k < e; ++k) natOrder[k] = k;
+                std::sort(natOrder.begin() + b, natOrder.begin() + e, [&](int x, int y) { return P.nnzMap[x] < P.nnzMap[y]; });
+            }
+            if ((rc = dev_upload(c, &A.d_natOrder, natOrder))) return rc;
+        }
+        A.static_set = true;
+        return OPMHIP_SUCCESS;
+    });
+}
+
+int opmhip_set_state(opmhip_ctx* c, const double* pv, const unsigned char* meaning) {
+    if (!c) return OPMHIP_INVALID_ARGUMENT;
+    return guarded(c, [&]() -> int {
+        if (!c->asmb.static_set) return fail(c, OPMHIP_NOT_READY, "set_state before set_static");
+        if (!pv || !meaning) return fail(c, OPMHIP_INVALID_ARGUMENT, "set_state: null array");
+        for (int i = 0; i < c->pat.Nb; ++i)
+            if (meaning[i] > OPMHIP_SW_PO_RS) return fail(c, OPMHIP_INVALID_ARGUMENT, "set_state: meaning[%d] = %d is not supported (dry gas: Sw_po_Sg or Sw_po_Rs)", i, (int)meaning[i]);
+        OPMHIP_HIP(c, hipSetDevice(c->device));
+        AsmDev& A = c->asmb;
+        OPMHIP_HIP(c, hipMemcpyAsync(c->d_stageV, pv, (size_t)c->pat.Nb * 3 * sizeof(double), hipMemcpyHostToDevice, c->stream));
+        launch_vec_to_internal(c, c->d_stageV, A.d_pv);
+        OPMHIP_HIP(c, hipMemcpyAsync(A.d_stage_u8, meaning, (size_t)c->pat.Nb, hipMemcpyHostToDevice, c->stream));
+        launch_u8_to_internal(c, A.d_stage_u8, A.d_meaning);
+        OPMHIP_HIP(c, hipMemsetAsync(A.d_wasSwitched, 0, c->pat.Nb, c->stream));
+        launch_iq_update(c);
+        OPMHIP_HIP(c, hipGetLastError());
+        OPMHIP_HIP(c, hipStreamSynchronize(c->stream));
+        A.state_set = true;
+        return OPMHIP_SUCCESS;
+    });
+}
+
+int opmhip_get_state(opmhip_ctx* c, double* pv, unsigned char* meaning) {
+    if (!c) return OPMHIP_INVALID_ARGUMENT;
+    return guarded(c, [&]() -> int {
+        if (!c->asmb.state_set) return fail(c, OPMHIP_NOT_READY, "get_state before set_state");
+        OPMHIP_HIP(c, hipSetDevice(c->device));
+        AsmDev& A = c->asmb;
+        if (pv) {
+            launch_vec_to_natural(c, A.d_pv, c->d_stageV);
+            OPMHIP_HIP(c, hipMemcpyAsync(pv, c->d_stageV, (size_t)c->pat.Nb * 3 * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+        }
+        if (meaning) {
+            launch_u8_to_natural(c, A.d_meaning, A.d_stage_u8);
+            OPMHIP_HIP(c, hipMemcpyAsync(meaning, A.d_stage_u8, (size_t)c->pat.Nb, hipMemcpyDeviceToHost, c->stream));
+        }
+        OPMHIP_HIP(c, hipStreamSynchronize(c->stream));
+        return OPMHIP_SUCCESS;
+    });
+}
+
+int opmhip_set_source(opmhip_ctx* c, const double* source, const double* dsource) {
+    if (!c) return OPMHIP_INVALID_ARGUMENT;
+    return guarded(c, [&]() -> int {
+        if (!c->asmb.static_set) return fail(c, OPMHIP_NOT_READY, "set_source before set_static");
+        OPMHIP_HIP(c, hipSetDevice(c->device));
+        AsmDev& A = c->asmb;
+        const size_t Nb = c->pat.Nb;
+        int rc;
+        if (source) { if ((rc = upload_cells(c, &A.d_source, source, 3))) return rc; }
+        else OPMHIP_HIP(c, hipMemset(A.d_source, 0, Nb * 3 * sizeof(double)));
+        if (dsource) { if ((rc = upload_cells(c, &A.d_dsource, dsource, 9))) return rc; }
+        else OPMHIP_HIP(c, hipMemset(A.d_dsource, 0, Nb * 9 * sizeof(double)));
+        return OPMHIP_SUCCESS;
+    });
+}
+
+int opmhip_assemble(opmhip_ctx* c, double dt, int iteration, double* jac, double* residual) {
+    if (!c) return OPMHIP_INVALID_ARGUMENT;
+    return guarded(c, [&]() -> int {
+        if (!c->asmb.state_set) return fail(c, OPMHIP_NOT_READY, "assemble before set_state");
+        if (!(dt > 0.0) || iteration < 0) return fail(c, OPMHIP_INVALID_ARGUMENT, "assemble: dt must be positive, iteration >= 0");
+        OPMHIP_HIP(c, hipSetDevice(c->device));
+        launch_assemble(c, dt, iteration);
+        OPMHIP_HIP(c, hipGetLastError());
+        c->system_loaded = true;
+        c->factored = false;
+        c->asmb.assembled = true;
+        if (jac) {
+            launch_unpermute_blocks(c, c->d_A, c->d_stageA);
+            OPMHIP_HIP(c, hipMemcpyAsync(jac, c->d_stageA, (size_t)c->pat.nnzb * BB * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+        }
+        if (residual) {
+            launch_vec_to_natural(c, c->d_b, c->d_stageV);
+            OPMHIP_HIP(c, hipMemcpyAsync(residual, c->d_stageV, (size_t)c->pat.Nb * 3 * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+        }
+        if (jac || residual) OPMHIP_HIP(c, hipStreamSynchronize(c->stream));
+        return OPMHIP_SUCCESS;
+    });
+}
+
+int opmhip_get_iq(opmhip_ctx* c, double* out) {
+    if (!c) return OPMHIP_INVALID_ARGUMENT;
+    return guarded(c, [&]() -> int {
+        if (!c->asmb.state_set) return fail(c, OPMHIP_NOT_READY, "get_iq before set_state");
+        if (!out) return fail(c, OPMHIP_INVALID_ARGUMENT, "get_iq: out == NULL");
+        OPMHIP_HIP(c, hipSetDevice(c->device));
+        launch_iq_to_natural(c, c->asmb.d_stage_cell);
+        OPMHIP_HIP(c, hipMemcpyAsync(out, c->asmb.d_stage_cell, (size_t)c->pat.Nb * iq_doubles_per_cell() * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+        OPMHIP_HIP(c, hipStreamSynchronize(c->stream));
+        return OPMHIP_SUCCESS;
+    });
+}
+
+int opmhip_convergence(opmhip_ctx* c, double dt, double tol_cnv, double* out) {
+    if (!c) return OPMHIP_INVALID_ARGUMENT;
+    return guarded(c, [&]() -> int {
+        if (!c->asmb.assembled) return fail(c, OPMHIP_NOT_READY, "convergence before assemble");
+        if (!out) return fail(c, OPMHIP_INVALID_ARGUMENT, "convergence: out == NULL");
+        OPMHIP_HIP(c, hipSetDevice(c->device));
+        launch_convergence(c, dt, tol_cnv);
+        OPMHIP_HIP(c, hipGetLastError());
+        double h[16];
+        OPMHIP_HIP(c, hipMemcpyAsync(h, c->asmb.d_conv_out, 11 * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+        OPMHIP_HIP(c, hipStreamSynchronize(c->stream));
+        for (int i = 0; i < 11; ++i) out[i] = h[i];
+        // CNV_c = B_avg dt maxCoeff ; MB_c = |B_avg R_sum| dt / pvSum   (flow/BlackoilModelEbos.hpp:797-801)
+        for (int e = 0; e < 3; ++e) {
+            out[11 + e] = h[6 + e] * dt * h[3 + e];
+            out[14 + e] = std::fabs(h[6 + e] * h[e]) * dt / h[9];
+        }
+        return OPMHIP_SUCCESS;
+    });
+}
+
+int opmhip_update(opmhip_ctx* c, const double* dx, double relax, int* num_switched) {
+    if (!c) return OPMHIP_INVALID_ARGUMENT;
+    return guarded(c, [&]() -> int {
+        if (!c->asmb.state_set) return fail(c, OPMHIP_NOT_READY, "update before set_state");
+        if (!dx && !c->have_result) return fail(c, OPMHIP_NOT_READY, "update: dx == NULL but no solve result is resident");
+        OPMHIP_HIP(c, hipSetDevice(c->device));
+        const double* d_dx = c->d_x;
+        if (dx) {
+            OPMHIP_HIP(c, hipMemcpyAsync(c->d_stageV, dx, (size_t)c->pat.Nb * 3 * sizeof(double), hipMemcpyHostToDevice, c->stream));
+            launch_vec_to_internal(c, c->d_stageV, c->d_t);
+            d_dx = c->d_t;
+        }
+        launch_newton_update(c, d_dx, relax);
+        OPMHIP_HIP(c, hipGetLastError());
+        if (num_switched) {
+            OPMHIP_HIP(c, hipMemcpyAsync(num_switched, c->asmb.d_nswitched, sizeof(int), hipMemcpyDeviceToHost, c->stream));
+            OPMHIP_HIP(c, hipStreamSynchronize(c->stream));
+        }
+        return OPMHIP_SUCCESS;
+    });
+}
+
+}  // extern "C"

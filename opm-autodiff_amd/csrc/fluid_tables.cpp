@@ -1,0 +1,184 @@
+// Host-side construction of the device property tables from deck-level input (see fluid_tables.hpp).
+#include "fluid_tables.hpp"
+
+#include <algorithm>
+#include <cmath>
+#include <string>
+
+namespace opmhip {
+namespace {
+
+struct Node {
+    double rs;
+    std::vector<double> p, bo, mu;
+};
+
+int push(std::vector<double>& blob, const std::vector<double>& v) {
+    const int o = (int)blob.size();
+    blob.insert(blob.end(), v.begin(), v.end());
+    return o;
+}
+
+}  // namespace
+
+std::string build_fluid_tables(const opmhip_fluid* f, FluidTables& T) {
+    if (!f) return "fluid == NULL";
+    if (f->num_pvt < 1 || f->num_sat < 1) return "need at least one PVT and one saturation region";
+    if (!f->pvtw || !f->density || !f->pvdg_ptr || !f->pvdg || !f->pvto_node_ptr || !f->pvto_rs || !f->pvto_row_ptr ||
+        !f->pvto || !f->swof_ptr || !f->swof || !f->sgof_ptr || !f->sgof)
+        return "fluid: null table pointer";
+    T = FluidTables();
+    T.num_pvt = f->num_pvt;
+    T.num_sat = f->num_sat;
+    T.rock_pref = f->rock_pref;
+    T.rock_cr = f->rock_cr;
+    std::vector<PvtRegionDesc> pd(f->num_pvt);
+    std::vector<SatRegionDesc> sd(f->num_sat);
+    std::vector<std::vector<int>> yoffs(f->num_pvt);
+    std::vector<double>& B = T.dbl;
+
+    for (int r = 0; r < f->num_pvt; ++r) {
+        PvtRegionDesc& D = pd[r];
+        // ---- ConstantCompressibilityWaterPvt / reference densities ----
+        D.water = push(B, std::vector<double>(f->pvtw + 5 * r, f->pvtw + 5 * r + 5));
+        D.density = push(B, std::vector<double>(f->density + 3 * r, f->density + 3 * r + 3));
+        // ---- DryGasPvt: p -> 1/Bg and 1/(Bg mu_g) on the deck's pressure samples ----
+        {
+            const int b = f->pvdg_ptr[r], e = f->pvdg_ptr[r + 1];
+            if (e - b < 2) return "PVDG needs at least two rows";
+            std::vector<double> p, ib, ibm;
+            for (int q = b; q < e; ++q) {
+                const double pp = f->pvdg[3 * q], Bg = f->pvdg[3 * q + 1], mu = f->pvdg[3 * q + 2];
+                if (!p.empty() && pp <= p.back()) return "PVDG pressures must ascend";
+                p.push_back(pp);
+                ib.push_back(1.0 / Bg);
+                ibm.push_back((1.0 / Bg) / mu);
+            }
+            D.gas_n = (int)p.size();
+            D.gas_p = push(B, p);
+            D.gas_invB = push(B, ib);
+            D.gas_invBMu = push(B, ibm);
+        }
+        // ---- LiveOilPvt ----
+        std::vector<Node> nodes;
+        for (int n = f->pvto_node_ptr[r]; n < f->pvto_node_ptr[r + 1]; ++n) {
+            Node nd;
+            nd.rs = f->pvto_rs[n];
+            for (int q = f->pvto_row_ptr[n]; q < f->pvto_row_ptr[n + 1]; ++q) {
+                nd.p.push_back(f->pvto[3 * q]);
+                nd.bo.push_back(f->pvto[3 * q + 1]);
+                nd.mu.push_back(f->pvto[3 * q + 2]);
+            }
+            if (nd.p.empty()) return "PVTO node without rows";
+            if (!nodes.empty() && nd.rs <= nodes.back().rs) return "PVTO Rs nodes must ascend";
+            nodes.push_back(nd);
+        }
+        const int nn = (int)nodes.size();
+        if (nn < 2) return "PVTO needs at least two Rs nodes";
+        std::vector<std::vector<double>> ys(nn), ib(nn), mu(nn);
+        for (int i = 0; i < nn; ++i) {
+            ys[i] = nodes[i].p;
+            mu[i] = nodes[i].mu;
+            for (double b : nodes[i].bo) ib[i].push_back(1.0 / b);
+        }
+        // nodes with only the saturated sample inherit the next complete node's undersaturated branch
+        // (LiveOilPvt::extendPvtoTable_: same relative compressibility / viscosibility step by step)
+        for (int i = 0; i < nn; ++i) {
+            if (nodes[i].p.size() > 1) continue;
+            int m = i + 1;
+            while (m < nn && nodes[m].p.size() <= 1) ++m;
+            if (m >= nn) return "PVTO: the last Rs node must carry undersaturated data";
+            const Node& M = nodes[m];
+            double lastP = nodes[i].p.back(), lastBo = nodes[i].bo.back(), lastMu = nodes[i].mu.back();
+            for (size_t q = 1; q < M.p.size(); ++q) {
+                const double diffPo = M.p[q] - M.p[q - 1];
+                const double newPo = lastP + diffPo;
+                const double B1 = M.bo[q], B2 = M.bo[q - 1];
+                const double x = (B1 - B2) / ((B1 + B2) / 2.0);
+                const double newBo = lastBo * (1.0 + x / 2.0) / (1.0 - x / 2.0);
+                const double mu1 = M.mu[q], mu2 = M.mu[q - 1];
+                const double xMu = (mu1 - mu2) / ((mu1 + mu2) / 2.0);
+                const double newMuo = lastMu * (1.0 + xMu / 2.0) / (1.0 - xMu / 2.0);
+                ys[i].push_back(newPo);
+                ib[i].push_back(1.0 / newBo);
+                mu[i].push_back(newMuo);
+                lastP = newPo; lastBo = newBo; lastMu = newMuo;
+            }
+        }
+        std::vector<double> xs, ysFlat, ibFlat, ibmFlat, satP, satRs, satIb, satIbm;
+        std::vector<int>& yo = yoffs[r];
+        for (int i = 0; i < nn; ++i) {
+            xs.push_back(nodes[i].rs);
+            yo.push_back((int)ysFlat.size());
+            for (size_t j = 0; j < ys[i].size(); ++j) {
+                if (j > 0 && ys[i][j] <= ys[i][j - 1]) return "PVTO pressures of a node must ascend";
+                ysFlat.push_back(ys[i][j]);
+                ibFlat.push_back(ib[i][j]);
+                ibmFlat.push_back(ib[i][j] / mu[i][j]);
+            }
+            satP.push_back(ys[i][0]);
+            satRs.push_back(nodes[i].rs);
+            satIb.push_back(ib[i][0]);
+            satIbm.push_back(ib[i][0] / mu[i][0]);
+            if (i > 0 && satP[i] <= satP[i - 1]) return "PVTO bubble-point pressures must ascend";
+        }
+        yo.push_back((int)ysFlat.size());
+        D.o_nx = nn;
+        D.o_xs = push(B, xs);
+        D.o_ys = push(B, ysFlat);
+        D.o_invB = push(B, ibFlat);
+        D.o_invBMu = push(B, ibmFlat);
+        D.sat_n = nn;
+        D.sat_p = push(B, satP);
+        D.sat_rs = push(B, satRs);
+        D.sat_invB = push(B, satIb);
+        D.sat_invBMu = push(B, satIbm);
+    }
+    for (int s = 0; s < f->num_sat; ++s) {
+        SatRegionDesc& D = sd[s];
+        const int wb = f->swof_ptr[s], we = f->swof_ptr[s + 1], gb = f->sgof_ptr[s], ge = f->sgof_ptr[s + 1];
+        if (we - wb < 2 || ge - gb < 2) return "SWOF/SGOF need at least two rows";
+        std::vector<double> sw, krw, krow, pcow;
+        for (int q = wb; q < we; ++q) {
+            if (!sw.empty() && f->swof[4 * q] <= sw.back()) return "SWOF saturations must ascend";
+            sw.push_back(f->swof[4 * q]); krw.push_back(f->swof[4 * q + 1]); krow.push_back(f->swof[4 * q + 2]); pcow.push_back(f->swof[4 * q + 3]);
+        }
+        const double swco = sw.front();
+        // gas-oil system tabulated against So' = (1 - Swco) - Sg; reversed so that x ascends
+        std::vector<double> so, krog, krg, pcgo;
+        for (int q = ge - 1; q >= gb; --q) {
+            const double x = (1.0 - swco) - f->sgof[4 * q];
+            if (!so.empty() && x <= so.back()) return "SGOF saturations must ascend";
+            so.push_back(x); krg.push_back(f->sgof[4 * q + 1]); krog.push_back(f->sgof[4 * q + 2]); pcgo.push_back(f->sgof[4 * q + 3]);
+        }
+        D.nw = (int)sw.size();
+        D.sw_x = push(B, sw); D.krw = push(B, krw); D.krow = push(B, krow); D.pcow = push(B, pcow);
+        D.ng = (int)so.size();
+        D.so_x = push(B, so); D.krog = push(B, krog); D.krg = push(B, krg); D.pcgo = push(B, pcgo);
+        D.swco = push(B, std::vector<double>{swco});
+    }
+    // int blob: header, descriptors, then the per-region y-offset arrays
+    std::vector<int>& I = T.idx;
+    I.clear();
+    I.push_back(f->num_pvt);
+    I.push_back(f->num_sat);
+    const int pdInts = (int)(sizeof(PvtRegionDesc) / sizeof(int)), sdInts = (int)(sizeof(SatRegionDesc) / sizeof(int));
+    const int base = 2 + f->num_pvt * pdInts + f->num_sat * sdInts;
+    int cursor = base;
+    for (int r = 0; r < f->num_pvt; ++r) {
+        pd[r].o_yoff = cursor;
+        cursor += (int)yoffs[r].size();
+    }
+    for (int r = 0; r < f->num_pvt; ++r) {
+        const int* q = reinterpret_cast<const int*>(&pd[r]);
+        I.insert(I.end(), q, q + pdInts);
+    }
+    for (int s = 0; s < f->num_sat; ++s) {
+        const int* q = reinterpret_cast<const int*>(&sd[s]);
+        I.insert(I.end(), q, q + sdInts);
+    }
+    for (int r = 0; r < f->num_pvt; ++r) I.insert(I.end(), yoffs[r].begin(), yoffs[r].end());
+    return "";
+}
+
+}  // namespace opmhip

@@ -1,0 +1,39 @@
+// Device-resident black-oil property tables (product code).  Host side: build the interpolation tables from the
+// deck-level input (opmhip_fluid) the way opm-material's LiveOilPvt / DryGasPvt / ConstantCompressibilityWaterPvt /
+// EclDefaultMaterial do (those classes are not in the reference tree; behaviour restated from the public 2021.10
+// sources; call sites ebos/eclproblem.hh:1490-1498, flow/BlackoilModelEbos.hpp:650-664).
+// Device side: everything is flattened into ONE double blob plus ONE int blob so that a kernel needs two pointers.
+#pragma once
+#include <vector>
+
+#include "../../include/opmhip.h"
+
+namespace opmhip {
+
+// Offsets into the blobs, per PVT region / saturation region.  POD, copied to the device as part of the int blob.
+struct PvtRegionDesc {
+    // 1-D tables: offsets of the x[] and y[] arrays (n entries each) inside the double blob
+    int gas_n, gas_p, gas_invB, gas_invBMu;            // DryGasPvt: p -> 1/Bg, 1/(Bg mu_g)
+    int sat_n, sat_p, sat_rs, sat_invB, sat_invBMu;    // saturated oil: p -> RsSat, 1/Bo, 1/(Bo mu_o)
+    // 2-D table: nx Rs nodes at xs; per node i: yoff[i] (int blob) = start of its samples inside ys / invB / invBMu
+    int o_nx, o_xs, o_yoff /*int blob, nx+1 entries*/, o_ys, o_invB, o_invBMu;
+    int water;    // 5 doubles: p_ref, Bw_ref, c_w, mu_ref, c_v
+    int density;  // 3 doubles: oil, water, gas
+};
+struct SatRegionDesc {
+    int nw, sw_x, krw, krow, pcow;  // piecewise linear in Sw, x ascending
+    int ng, so_x, krog, krg, pcgo;  // piecewise linear in So' = (1 - Swco) - Sg, x ascending
+    int swco;                       // 1 double
+};
+
+struct FluidTables {
+    std::vector<double> dbl;
+    std::vector<int> idx;  // [0] num_pvt, [1] num_sat, then PvtRegionDesc[num_pvt], SatRegionDesc[num_sat], then y offsets
+    double rock_pref = 1e5, rock_cr = 0.0;
+    int num_pvt = 0, num_sat = 0;
+};
+
+// returns "" on success, else an error text
+std::string build_fluid_tables(const opmhip_fluid* f, FluidTables& out);
+
+}  // namespace opmhip

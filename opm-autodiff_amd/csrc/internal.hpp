@@ -57,6 +57,27 @@ struct WellsDev {
     size_t cap_wells = 0, cap_perf = 0;
 };
 
+// assembly-side device state (all per-cell / per-entry arrays in the INTERNAL order)
+struct AsmDev {
+    bool fluid_set = false, static_set = false, state_set = false, assembled = false;
+    double *d_tab_dbl = nullptr;
+    int* d_tab_idx = nullptr;
+    double rock_pref = 1e5, rock_cr = 0.0;
+    int num_pvt = 0, num_sat = 0;
+    double *d_trans = nullptr, *d_area = nullptr, *d_thpres = nullptr;                      // per entry
+    double *d_poro = nullptr, *d_volume = nullptr, *d_depth = nullptr, *d_rsmax = nullptr;  // per cell
+    int *d_pvtnum = nullptr, *d_satnum = nullptr;
+    double *d_pv = nullptr, *d_iq = nullptr, *d_storageOld = nullptr, *d_source = nullptr, *d_dsource = nullptr;
+    unsigned char *d_meaning = nullptr, *d_wasSwitched = nullptr, *d_stage_u8 = nullptr;
+    int* d_nswitched = nullptr;
+    int* d_asm_row0 = nullptr;
+    int* d_natOrder = nullptr;  // per row: its entries (internal indices) sorted by natural column
+    int ntiles = 0;
+    double *d_conv_part = nullptr, *d_conv_out = nullptr;
+    double* d_stage_cell = nullptr;   // staging for per-cell doubles (natural order), Nb * max(9, IQS)
+    double* d_stage_entry = nullptr;  // staging for per-entry doubles (natural order), nnzb
+};
+
 enum Scal {  // device-resident BiCGStab scalars (double d_scal[SC_COUNT])
     SC_RHO = 0, SC_RHOP, SC_ALPHA, SC_OMEGA, SC_BETA, SC_TMP1, SC_TMP2, SC_NORM, SC_NORM0, SC_COUNT = 16
 };
@@ -83,6 +104,7 @@ struct opmhip_ctx {
     int npart = 0;
     double* h_pinned = nullptr;  // SC_COUNT doubles, pinned
     opmhip::WellsDev wells;
+    opmhip::AsmDev asmb;
     std::vector<void*> allocs;
 };
 
@@ -140,6 +162,15 @@ void launch_ilu_apply(opmhip_ctx* c, const double* d, double* v);
 void launch_wells_apply(opmhip_ctx* c, const double* x, double* y);
 void launch_lu_to_natural(opmhip_ctx* c, double* d_out_internal_layout);
 int bicgstab(opmhip_ctx* c, opmhip_result* res);
+// assemble.hip launchers
+void launch_iq_update(opmhip_ctx* c);
+void launch_newton_update(opmhip_ctx* c, const double* d_dx_internal, double relax);
+void launch_assemble(opmhip_ctx* c, double dt, int iteration);
+void launch_convergence(opmhip_ctx* c, double dt, double tol_cnv);
+void launch_u8_to_internal(opmhip_ctx* c, const unsigned char* nat, unsigned char* internal);
+void launch_u8_to_natural(opmhip_ctx* c, const unsigned char* internal, unsigned char* nat);
+void launch_iq_to_natural(opmhip_ctx* c, double* d_nat);
+int iq_doubles_per_cell();
 void launch_vector_kernels_once(opmhip_ctx* c);
 
 }  // namespace opmhip

@@ -454,7 +454,7 @@ __global__ __launch_bounds__(VB) void k_finalize(int mode, int count, const doub
     sh[0][threadIdx.x] = a; sh[1][threadIdx.x] = b;
     __syncthreads();
     for (int o = VB / 2; o > 0; o >>= 1) {
-        if (threadIdx.x < o) { sh[0][threadIdx.x] += sh[0][threadIdx.x + o]; sh[1][threadIdx.x] += sh[1][threadIdx.x + o]; }
+        if ((int)threadIdx.x < o) { sh[0][threadIdx.x] += sh[0][threadIdx.x + o]; sh[1][threadIdx.x] += sh[1][threadIdx.x + o]; }
         __syncthreads();
     }
     if (threadIdx.x != 0) return;

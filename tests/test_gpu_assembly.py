@@ -1,0 +1,160 @@
+"""GPU parity of the assembly half of the hot path, through the C-ABI, against the CPU oracle on the same seeded
+inputs: intensive quantities, Jacobian + residual (bit for bit), convergence norms, Newton update / switching, and
+whole Newton iterations.  Tolerances: 0 (bitwise) for per-cell and per-face arithmetic; 1e-12 relative for global
+reductions whose summation order differs (convergence sums, Krylov dot products)."""
+import numpy as np
+import pytest
+
+import oracle_bind
+
+pytestmark = pytest.mark.gpu
+REORDERS = ["level_scheduling", "graph_coloring", "graph_coloring_greedy"]
+
+
+def both(pkg, orc, case, reorder="graph_coloring_greedy", **kw):
+    m = pkg.capi.HipModel(case, reorder=reorder, **kw)
+    o = oracle_bind.OracleModel(orc, case)
+    m.set_state(case["pv"], case["meaning"])
+    o.set_state(case["pv"], case["meaning"])
+    return m, o
+
+
+@pytest.mark.parametrize("state", ["undersaturated", "saturated", "mixed"])
+def test_intensive_quantities_bitwise(pkg, orc, state):
+    case = pkg.decks.cartesian_case(9, 7, 5, state=state, heterogeneous=True)
+    m, o = both(pkg, orc, case)
+    assert np.array_equal(m.iq(), o.iq())
+
+
+@pytest.mark.parametrize("reorder", REORDERS)
+@pytest.mark.parametrize("state", ["undersaturated", "saturated", "mixed"])
+def test_jacobian_and_residual_bitwise(pkg, orc, reorder, state):
+    case = pkg.decks.cartesian_case(11, 9, 6, state=state, heterogeneous=True)
+    m, o = both(pkg, orc, case, reorder=reorder)
+    dt = 86400.0
+    j0, r0 = m.assemble(dt, 0)
+    jo, ro = o.assemble(dt, 0)
+    assert np.array_equal(r0, ro) and np.array_equal(j0, jo)
+    # second iteration from a moved state: storage term active, cache from iteration 0
+    rng = np.random.default_rng(3)
+    dx = np.zeros((case["Nb"], 3))
+    dx[:, 0] = rng.uniform(-0.01, 0.01, case["Nb"])
+    dx[:, 1] = rng.uniform(-2e5, 2e5, case["Nb"])
+    dx[:, 2] = np.where(case["meaning"] == 0, rng.uniform(-0.01, 0.01, case["Nb"]), rng.uniform(-1.0, 1.0, case["Nb"]))
+    assert m.update(dx.reshape(-1)) == o.update(dx.reshape(-1))
+    pm, mm = m.get_state()
+    po, mo = o.get_state()
+    assert np.array_equal(pm, po) and np.array_equal(mm, mo)
+    j1, r1 = m.assemble(dt, 1)
+    jo1, ro1 = o.assemble(dt, 1)
+    assert np.array_equal(r1, ro1) and np.array_equal(j1, jo1)
+    assert np.abs(r1).max() > 0 and not np.array_equal(j1, j0)
+
+
+def test_spe1_grid_bitwise(pkg, orc):
+    """BASELINE config 0: the SPE1 grid and fluid (300 cells); 'bit-for-bit residual' against the CPU restatement."""
+    case = pkg.decks.spe1_case()
+    m, o = both(pkg, orc, case, reorder="level_scheduling")
+    j, r = m.assemble(86400.0, 0)
+    jo, ro = o.assemble(86400.0, 0)
+    assert np.array_equal(r, ro) and np.array_equal(j, jo)
+
+
+def test_source_terms(pkg, orc):
+    case = pkg.decks.cartesian_case(8, 8, 3, state="undersaturated")
+    src = pkg.decks.five_spot_source(case)
+    dsrc = np.zeros((case["Nb"], 9))
+    dsrc[0, 4] = -1e-12  # a well-like rate derivative w.r.t. pressure on one cell
+    m, o = both(pkg, orc, case)
+    m.set_source(src, dsrc.reshape(-1))
+    o.set_source(src, dsrc.reshape(-1))
+    j, r = m.assemble(3600.0, 0)
+    jo, ro = o.assemble(3600.0, 0)
+    assert np.array_equal(r, ro) and np.array_equal(j, jo)
+    assert r.reshape(-1, 3)[0, 1] < 0  # injected water shows up with the sign "residual -= source"
+
+
+@pytest.mark.parametrize("state", ["mixed"])
+def test_convergence_norms(pkg, orc, state):
+    case = pkg.decks.cartesian_case(12, 10, 7, state=state, heterogeneous=True)
+    m, o = both(pkg, orc, case)
+    dt = 86400.0
+    m.assemble(dt, 0, fetch=False)
+    _, r = o.assemble(dt, 0)
+    cm, co = m.convergence(dt, 1e-2), o.convergence(dt, 1e-2)
+    # maxima are exact; sums differ only in summation order: bound the difference by 1e-13 of the sum of magnitudes
+    # (at iteration 0 the residual sums cancel to rounding noise - mass conservation - so a relative test on the
+    # sum itself would compare noise with noise)
+    mag = np.abs(r.reshape(-1, 3)).sum(axis=0)
+    assert np.array_equal(cm[3:6], co[3:6])
+    np.testing.assert_allclose(cm[6:10], co[6:10], rtol=1e-13)
+    assert np.all(np.abs(cm[0:3] - co[0:3]) <= 1e-13 * mag)
+    np.testing.assert_allclose(cm[10], co[10], rtol=1e-12)
+    np.testing.assert_allclose(cm[11:14], co[11:14], rtol=1e-13)
+    assert np.all(np.abs(cm[14:17] - co[14:17]) <= 1e-13 * co[6:9] * mag * dt / co[9])
+    # a state with a real imbalance: sums are O(1) of the magnitudes and must agree to 1e-10
+    src = pkg.decks.five_spot_source(case, rate_sm3_per_day=500.0)
+    m.set_source(src)
+    o.set_source(src)
+    m.assemble(dt, 0, fetch=False)
+    o.assemble(dt, 0)
+    cm, co = m.convergence(dt, 1e-2), o.convergence(dt, 1e-2)
+    np.testing.assert_allclose(cm[[0, 1, 2, 14, 15, 16]], co[[0, 1, 2, 14, 15, 16]], rtol=1e-10)
+    assert np.array_equal(cm[3:6], co[3:6]) and cm[10] > 0
+
+
+def test_update_switching_matches_oracle(pkg, orc):
+    case = pkg.decks.cartesian_case(6, 5, 4, state="mixed", perturb=False)
+    m, o = both(pkg, orc, case)
+    Nb = case["Nb"]
+    dx = np.zeros((Nb, 3))
+    dx[:, 1] = 0.5 * case["pv"].reshape(-1, 3)[:, 1]
+    dx[:, 0] = 0.5
+    dx[case["meaning"] == 0, 2] = 0.3
+    for step in range(3):
+        nm, no = m.update(dx.reshape(-1)), o.update(dx.reshape(-1))
+        pm, mm = m.get_state()
+        po, mo = o.get_state()
+        assert nm == no and np.array_equal(mm, mo) and np.array_equal(pm, po)
+        assert np.array_equal(m.iq(), o.iq())
+        dx[:, 0] = -0.05
+        dx[:, 1] *= 0.1
+        dx[:, 2] = np.where(mm == 0, 0.2, 0.0)
+    assert (mm != case["meaning"]).any()
+
+
+@pytest.mark.parametrize("reorder", ["level_scheduling", "graph_coloring_greedy"])
+def test_newton_iterations_match_oracle(pkg, orc, reorder):
+    """A full time step driven like BlackoilModelEbos::nonlinearIteration on both sides: same Newton and linear
+    iteration counts, final pressures/saturations within 1e-7 relative (FP tolerance stated by the task: results
+    within the project's own ECL-compare band, compareECLFiles.cmake:198-199, is far looser)."""
+    case = pkg.decks.cartesian_case(10, 10, 6, state="mixed", heterogeneous=True)
+    src = pkg.decks.five_spot_source(case, rate_sm3_per_day=200.0)
+    m, o = both(pkg, orc, case, reorder=reorder)
+    m.set_source(src)
+    o.set_source(src)
+    dt = 5 * 86400.0
+    lin_m, lin_o = [], []
+    for it in range(12):
+        m.assemble(dt, it, fetch=False)
+        o.assemble(dt, it)
+        cm, co = m.convergence(dt), o.convergence(dt)
+        np.testing.assert_allclose(cm[11:14], co[11:14], rtol=1e-4, atol=1e-8)  # CNV tolerance is 1e-2; Krylov rounding is amplified near convergence
+        conv = np.all(co[11:14] < 1e-2) and np.all(co[14:17] < 1e-6) and it > 0
+        if conv:
+            break
+        rm = m.solve_jacobian_system()
+        xo, ro = o.solve(reorder=reorder)
+        assert rm.converged and ro.converged
+        lin_m.append(rm.it)
+        lin_o.append(ro.it)
+        m.update(None, 1.0)
+        o.update(xo)
+    assert it < 11, "Newton did not converge"
+    assert lin_m == lin_o
+    pm, mm = m.get_state()
+    po, mo = o.get_state()
+    assert np.array_equal(mm, mo)
+    # stated FP tolerance on the converged state: 1e-7 relative (pressures) / 1e-9 absolute (saturations); the
+    # reference project itself accepts rel 1e-5 / abs 2e-2 between runs (compareECLFiles.cmake:198-199)
+    np.testing.assert_allclose(pm, po, rtol=1e-7, atol=1e-9)
