@@ -1,0 +1,215 @@
+#!/usr/bin/env python3
+"""bench.py — Newton iterations per second of the per-Newton-iteration hot path on MI355X.
+
+Metric (BASELINE.json): "Newton iterations/sec + linear-solve GB/s, 1M-cell 3-phase black-oil".
+Workload (BASELINE.json configs[1]): synthetic 100 x 100 x 100 Cartesian three-phase black-oil grid, homogeneous rock,
+SPE1 fluid, per GPU.  A "step" is one Newton iteration of BlackoilModelEbos::nonlinearIteration that does real work:
+assembleReservoir (AD linearisation into block-CSR) -> getReservoirConvergence -> solveJacobianSystem (block-ILU0
+factorisation + BiCGStab to 1e-2) -> updateSolution (chopped update, primary-variable switching, intensive
+quantities).  Time steps follow one another (1 day, then 10 days each) with a fixed-rate five-spot
+source pair; whenever a time step converges the next one starts, exactly as NonlinearSolverEbos::step would.
+Everything is resident in HBM when the timed region starts; nothing crosses PCIe inside it except ~200 bytes of
+scalars per Newton iteration.
+
+    python bench.py --gpus N --steps K --warmup W
+N > 1 is launched by the driver through torch.distributed.run (one rank per GPU): domain decomposition of an
+(N x 100^3)-cell grid, see opm-autodiff_amd/ras.py when present; until then N independent 100^3 replicas.
+Prints ONE JSON line on rank 0.
+"""
+import argparse
+import importlib
+import json
+import os
+import sys
+import time
+
+os.environ.setdefault("OMP_NUM_THREADS", "1")  # the CPU baseline below is the 1-thread port (what one Flow rank does)
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+import numpy as np  # noqa: E402
+
+DAY = 86400.0
+HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (/opt/skills/guides/MI355X_MICROARCH.md)
+
+
+def alg_bytes(Nb, nnzb):
+    """Algorithmic bytes per launch (SURVEY.md §8d / BASELINE.md §4), block size 3, double values, int32 indices."""
+    return {
+        "spmv": 76 * nnzb + 4 * (Nb + 1) + 48 * Nb,
+        "ilu_apply": 76 * nnzb + 4 * (Nb + 1) + 4 * Nb + 72 * Nb,
+        "ilu_factor": 2 * 72 * nnzb + 4 * nnzb + 4 * Nb,
+        "vector": 24 * Nb * 9,        # one group between two operator applications: (4 + 6 + 8) / 2 passes on average
+        "assemble": 85 * Nb + 12 * nnzb + 72 * nnzb + 24 * Nb,
+        "iq_update": 24 * Nb + 544 * Nb,
+        "convergence": 56 * Nb,
+    }
+
+
+class Simulation:
+    """Time stepping that hands out Newton iterations one by one."""
+
+    def __init__(self, pkg, model, dts):
+        self.newton = pkg.newton.BlackoilModelHip(model)
+        self.dts = list(dts)
+        self.step_idx = 0
+        self.iteration = 0
+        self.timesteps_done = 0
+        self.report = pkg.newton.SimulatorReportSingle()
+
+    def next_newton_iteration(self):
+        """Runs nonlinear iterations until one of them actually solved a system; returns its report."""
+        while True:
+            dt = self.dts[min(self.step_idx, len(self.dts) - 1)]
+            rep = self.newton.nonlinear_iteration(self.iteration, dt)
+            self.report += rep
+            self.iteration += 1
+            if rep.converged:
+                self.step_idx += 1
+                self.timesteps_done += 1
+                self.iteration = 0
+                continue  # the converged check cost an assembly; it is inside the timed region like in Flow
+            if self.iteration > self.newton.param.newton_max_iter:
+                raise pkg_error("time step did not converge in %d Newton iterations" % self.newton.param.newton_max_iter)
+            return rep
+
+
+def pkg_error(msg):
+    return RuntimeError(msg)
+
+
+def cpu_baseline(pkg, case, src, dt):
+    """The CPU port (oracle/) timed on one host core on a bounded sample: the first Newton iteration of the same case."""
+    import oracle_bind
+    import subprocess
+    so = os.path.join(ROOT, "oracle", "liboracle.so")
+    if not os.path.exists(so):
+        subprocess.check_call(["make", "-C", os.path.join(ROOT, "oracle")], stdout=subprocess.DEVNULL)
+    orc = oracle_bind.Oracle(so)
+    o = oracle_bind.OracleModel(orc, case)
+    o.set_state(case["pv"], case["meaning"])
+    o.set_source(src)
+    t0 = time.perf_counter()
+    o.assemble(dt, 0)
+    o.convergence(dt)
+    t1 = time.perf_counter()
+    x, res = o.solve(tol=1e-2, maxit=200, w=0.9, mode="post_scale", reorder="none")
+    t2 = time.perf_counter()
+    o.update(x)
+    t3 = time.perf_counter()
+    total = t3 - t0
+    return {
+        "value": 1.0 / total, "unit": "Newton iterations/s", "cores": 1, "kind": "port",
+        "sample": "first Newton iteration of the same %d-cell case on the CPU restatement (oracle/): assembly %.2f s, "
+                  "natural-order block-ILU0 factor %.2f s, BiCGStab %d its %.2f s, update %.2f s; 1 thread, the work of one "
+                  "Flow MPI rank" % (case["Nb"], t1 - t0, res.t_factor, res.iterations, res.t_solve, t3 - t2),
+        "linear_iterations": int(res.iterations),
+        "seconds": {"assemble": t1 - t0, "linear_setup": res.t_factor, "linear_solve": res.t_solve, "update": t3 - t2},
+    }
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--n", type=int, default=100, help="cells per edge of the per-GPU cube")
+    ap.add_argument("--reorder", default="graph_coloring_greedy")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    a = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    import torch
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group(backend="nccl" if torch.cuda.is_available() else "gloo", device_id=torch.device("cuda", local_rank) if torch.cuda.is_available() else None)
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU: libopmhip has no CPU fallback")
+    torch.cuda.set_device(local_rank)
+
+    pkg = importlib.import_module("opm-autodiff_amd")
+    n = a.n
+    case = pkg.decks.cartesian_case(n, n, n, state="mixed", heterogeneous=False)
+    src = pkg.decks.five_spot_source(case, rate_sm3_per_day=2000.0 * (n / 100.0) ** 2)
+    dts = [1 * DAY] + [10 * DAY] * 1000
+    model = pkg.capi.HipModel(case, device_id=local_rank, reorder=a.reorder, tolerance=1e-2, maxit=200, ilu_relaxation=0.9)
+    model.set_state(case["pv"], case["meaning"])
+    model.set_source(src)
+    sim = Simulation(pkg, model, dts)
+    Nb, nnzb = case["Nb"], len(case["col"])
+
+    def barrier():
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(a.warmup):
+        sim.next_newton_iteration()
+    barrier()
+    model.profile_enable(True)
+    rep0 = pkg.newton.SimulatorReportSingle()
+    rep0 += sim.report
+    ts0 = sim.timesteps_done
+    t0 = time.perf_counter()
+    for _ in range(a.steps):
+        sim.next_newton_iteration()
+    barrier()
+    elapsed = time.perf_counter() - t0
+    prof = model.profile()
+    model.profile_enable(False)
+    if dist is not None:
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    rep = sim.report
+    lin = rep.total_linear_iterations - rep0.total_linear_iterations
+    B = alg_bytes(Nb, nnzb)
+    kernels = {}
+    for name, (cnt, ms) in prof.items():
+        if cnt:
+            avg = ms / cnt
+            kernels[name] = {"launches": cnt, "avg_ms": round(avg, 5), "algorithmic_GBps": round(B[name] / avg / 1e6, 1)}
+    sp = kernels.get("spmv", {"avg_ms": float("nan"), "algorithmic_GBps": float("nan")})
+    # linear-solve GB/s: algorithmic bytes of all solver kernels / their summed device time
+    ls_bytes = sum(B[k] * prof[k][0] for k in ("spmv", "ilu_apply", "ilu_factor", "vector"))
+    ls_ms = sum(prof[k][1] for k in ("spmv", "ilu_apply", "ilu_factor", "vector"))
+    out = {
+        "metric": "Newton iterations/sec, 1M-cell 3-phase black-oil (assembly + ILU0/BiCGStab solve + update)",
+        "value": a.steps * world / elapsed if world > 1 else a.steps / elapsed,
+        "unit": "Newton iterations/s" + (" (sum over %d independent 1M-cell subdomains)" % world if world > 1 else ""),
+        "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": 1e3 * elapsed / a.steps,
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+        "config": {"workload": "synthetic %dx%dx%d Cartesian 3-phase black-oil (BASELINE configs[1]), SPE1 fluid, homogeneous "
+                               "100 mD, gas cap + undersaturated oil, five-spot rate sources, dt 1 d then 10 d" % (n, n, n),
+                   "cells_per_gpu": Nb, "blocks_per_gpu": nnzb, "ilu_ordering": a.reorder, "linear_tol": 1e-2,
+                   "ilu_relaxation": 0.9, "parallelism": "1 GPU" if world == 1 else "%d independent replicas (no halo exchange yet)" % world},
+        "linear_iterations_per_newton": lin / a.steps,
+        "timesteps_completed": sim.timesteps_done - ts0,
+        "linear_solve_GBps": round(ls_bytes / ls_ms / 1e6, 1) if ls_ms > 0 else None,
+        "report": {"assemble_time": rep.assemble_time - rep0.assemble_time,
+                   "linear_solve_setup_time": rep.linear_solve_setup_time - rep0.linear_solve_setup_time,
+                   "linear_solve_time": rep.linear_solve_time - rep0.linear_solve_time,
+                   "update_time": rep.update_time - rep0.update_time},
+        "kernels": kernels,
+        "roofline": {"bound": "hbm", "kernel": "k_spmv (block-CSR SpMV, 3x3 double blocks)", "achieved": sp["algorithmic_GBps"],
+                     "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": (sp["algorithmic_GBps"] / HBM_PEAK_GBS) if sp["algorithmic_GBps"] == sp["algorithmic_GBps"] else None,
+                     "traffic": None, "avg_launch_ms": sp["avg_ms"], "algorithmic_bytes_per_launch": B["spmv"]},
+    }
+    if rank == 0 and world == 1 and not a.no_cpu_baseline:
+        out["cpu_baseline"] = cpu_baseline(pkg, case, src, dts[0])
+        out["gpu_over_cpu"] = out["value"] / out["cpu_baseline"]["value"]
+    if rank == 0:
+        print(json.dumps(out))
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

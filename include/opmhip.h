@@ -213,6 +213,17 @@ int opmhip_convergence(opmhip_ctx* ctx, double dt, double tol_cnv, double* out);
  * num_switched (nullable) receives the number of cells whose meaning changed. */
 int opmhip_update(opmhip_ctx* ctx, const double* dx, double relax, int* num_switched);
 
+/* ---- measurement -------------------------------------------------------------------------------------------- */
+/* Device-side timing per kernel class with HIP events recorded on the context's own stream, so that bench.py can
+ * state the average launch duration of a kernel over its timed region (the reference prints the same split at
+ * verbosity >= 3/4: bda/cusparseSolverBackend.cu:303-308, bda/openclSolverBackend.cpp:451-459).
+ * classes: 0 SpMV, 1 ILU0 apply (all sweeps of one M^-1), 2 ILU0 factorisation, 3 BiCGStab vector kernels (one
+ * group between two operator applications), 4 assembly kernel, 5 intensive-quantity update, 6 convergence. */
+#define OPMHIP_PROF_CLASSES 7
+int opmhip_profile_enable(opmhip_ctx* ctx, int on);  /* also resets the accumulated numbers */
+/* waits for the stream, folds all pending event pairs in, returns launches and total milliseconds of one class */
+int opmhip_profile_get(opmhip_ctx* ctx, int cls, long long* launches, double* total_ms);
+
 #ifdef __cplusplus
 }
 #endif

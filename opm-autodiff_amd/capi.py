@@ -80,6 +80,8 @@ def lib():
         L.opmhip_ilu0_apply.argtypes = [vp, dp, dp]
         L.opmhip_get_ordering.argtypes = [vp, ip, ip, ip]
         L.opmhip_time_kernel.argtypes = [vp, C.c_int, C.c_int, C.POINTER(C.c_double)]
+        L.opmhip_profile_enable.argtypes = [vp, C.c_int]
+        L.opmhip_profile_get.argtypes = [vp, C.c_int, C.POINTER(C.c_longlong), C.POINTER(C.c_double)]
         _lib = L
     return _lib
 
@@ -186,6 +188,20 @@ class HipSolver:
         rpc = np.zeros(self.Nb, np.int32)
         nc = self._check(lib().opmhip_get_ordering(self._h, _ptr(to), _ptr(fr), _ptr(rpc)))
         return to, fr, rpc[:nc].copy()
+
+    PROF = ["spmv", "ilu_apply", "ilu_factor", "vector", "assemble", "iq_update", "convergence"]
+
+    def profile_enable(self, on=True):
+        self._check(lib().opmhip_profile_enable(self._h, int(on)))
+
+    def profile(self):
+        """-> {class: (launches, total_ms)} from HIP events on the context's stream"""
+        out = {}
+        for i, name in enumerate(self.PROF):
+            n, ms = C.c_longlong(0), C.c_double(0.0)
+            self._check(lib().opmhip_profile_get(self._h, i, C.byref(n), C.byref(ms)))
+            out[name] = (n.value, ms.value)
+        return out
 
     def time_kernel(self, which, reps=20):
         ms = C.c_double()

@@ -594,26 +594,34 @@ static CellStatic cells_of(const opmhip_ctx* c) {
 
 void launch_iq_update(opmhip_ctx* c) {
     const int Nb = c->pat.Nb;
+    const int ps = prof_begin(c, PROF_IQ_UPDATE);
     hipLaunchKernelGGL(k_iq_update, dim3(cdiv(Nb, 256)), dim3(256), 0, c->stream, Nb, tables_of(c), cells_of(c), c->asmb.d_pv, c->asmb.d_meaning, c->asmb.d_iq);
+    prof_end(c, ps);
 }
 void launch_newton_update(opmhip_ctx* c, const double* d_dx, double relax) {
     const int Nb = c->pat.Nb;
     (void)hipMemsetAsync(c->asmb.d_nswitched, 0, sizeof(int), c->stream);
+    const int ps = prof_begin(c, PROF_IQ_UPDATE);
     hipLaunchKernelGGL(k_newton_update, dim3(cdiv(Nb, 256)), dim3(256), 0, c->stream, Nb, tables_of(c), cells_of(c), d_dx, relax, c->asmb.d_pv,
                        c->asmb.d_meaning, c->asmb.d_wasSwitched, c->asmb.d_iq, c->asmb.d_nswitched);
+    prof_end(c, ps);
 }
 void launch_assemble(opmhip_ctx* c, double dt, int iteration) {
     const Pattern& P = c->pat;
     EntryStatic ES{c->asmb.d_trans, c->asmb.d_area, c->asmb.d_thpres};
+    const int ps = prof_begin(c, PROF_ASSEMBLE);
     hipLaunchKernelGGL(k_assemble, dim3(c->asmb.ntiles), dim3(ASM_THREADS), 0, c->stream, c->asmb.d_asm_row0, P.d_rowptr, P.d_col, c->asmb.d_natOrder, ES,
                        cells_of(c), c->asmb.d_iq, c->asmb.d_storageOld, c->asmb.d_source, c->asmb.d_dsource, dt, iteration, c->d_A, c->d_b);
+    prof_end(c, ps);
 }
 void launch_convergence(opmhip_ctx* c, double dt, double tol_cnv) {
     const int Nb = c->pat.Nb, nb = cdiv(Nb, 256);
+    const int ps = prof_begin(c, PROF_CONVERGENCE);
     hipLaunchKernelGGL(k_conv_pass1, dim3(nb), dim3(256), 0, c->stream, Nb, cells_of(c), c->asmb.d_iq, c->d_b, c->asmb.d_conv_part);
     hipLaunchKernelGGL(k_conv_final1, dim3(1), dim3(256), 0, c->stream, nb, Nb, c->asmb.d_conv_part, c->asmb.d_conv_out);
     hipLaunchKernelGGL(k_conv_pass2, dim3(nb), dim3(256), 0, c->stream, Nb, cells_of(c), c->d_b, c->asmb.d_conv_out, dt, tol_cnv, c->asmb.d_conv_part);
     hipLaunchKernelGGL(k_conv_final2, dim3(1), dim3(256), 0, c->stream, nb, c->asmb.d_conv_part, c->asmb.d_conv_out);
+    prof_end(c, ps);
 }
 void launch_u8_to_internal(opmhip_ctx* c, const unsigned char* nat, unsigned char* internal) {
     hipLaunchKernelGGL(k_cellvec_to_internal_u8, dim3(cdiv(c->pat.Nb, 256)), dim3(256), 0, c->stream, c->pat.Nb, c->pat.d_fromOrder, nat, internal);

@@ -180,6 +180,7 @@ void opmhip_destroy(opmhip_ctx* c) {
     if (c->h_pinned) (void)hipHostFree(c->h_pinned);
     if (c->ev0) (void)hipEventDestroy(c->ev0);
     if (c->ev1) (void)hipEventDestroy(c->ev1);
+    for (hipEvent_t e : c->prof.pool) (void)hipEventDestroy(e);
     if (c->stream) (void)hipStreamDestroy(c->stream);
     delete c;
 }
@@ -328,6 +329,40 @@ int opmhip_get_ordering(opmhip_ctx* c, int* toOrder, int* fromOrder, int* rowsPe
     if (rowsPerColor)
         for (int k = 0; k < P.numColors; ++k) rowsPerColor[k] = P.colorPrefix[k + 1] - P.colorPrefix[k];
     return P.numColors;
+}
+
+int opmhip_profile_enable(opmhip_ctx* c, int on) {
+    if (!c) return OPMHIP_INVALID_ARGUMENT;
+    return guarded(c, [&]() -> int {
+        OPMHIP_HIP(c, hipSetDevice(c->device));
+        OPMHIP_HIP(c, hipStreamSynchronize(c->stream));
+        Profiler& P = c->prof;
+        P.enabled = on != 0;
+        P.used = 0;
+        for (int k = 0; k < PROF_COUNT; ++k) { P.total_ms[k] = 0.0; P.count[k] = 0; }
+        return OPMHIP_SUCCESS;
+    });
+}
+
+int opmhip_profile_get(opmhip_ctx* c, int cls, long long* launches, double* total_ms) {
+    if (!c) return OPMHIP_INVALID_ARGUMENT;
+    return guarded(c, [&]() -> int {
+        if (cls < 0 || cls >= PROF_COUNT || !launches || !total_ms) return fail(c, OPMHIP_INVALID_ARGUMENT, "profile_get: bad arguments");
+        OPMHIP_HIP(c, hipSetDevice(c->device));
+        OPMHIP_HIP(c, hipStreamSynchronize(c->stream));
+        Profiler& P = c->prof;
+        for (size_t i = 0; i < P.used; ++i) {
+            float ms = 0.f;
+            if (hipEventElapsedTime(&ms, P.pool[2 * i], P.pool[2 * i + 1]) == hipSuccess) {
+                P.total_ms[P.cls[i]] += ms;
+                P.count[P.cls[i]] += 1;
+            }
+        }
+        P.used = 0;
+        *launches = P.count[cls];
+        *total_ms = P.total_ms[cls];
+        return OPMHIP_SUCCESS;
+    });
 }
 
 int opmhip_time_kernel(opmhip_ctx* c, int which, int reps, double* ms_per_launch) {

@@ -78,6 +78,18 @@ struct AsmDev {
     double* d_stage_entry = nullptr;  // staging for per-entry doubles (natural order), nnzb
 };
 
+// per-kernel-class device timing with HIP events on the context's stream (opmhip_profile_*)
+enum ProfClass { PROF_SPMV = 0, PROF_ILU_APPLY, PROF_ILU_FACTOR, PROF_VECTOR, PROF_ASSEMBLE, PROF_IQ_UPDATE, PROF_CONVERGENCE, PROF_COUNT };
+struct Profiler {
+    bool enabled = false;
+    std::vector<hipEvent_t> pool;             // event pairs, allocated on demand
+    std::vector<int> cls;                     // class of pair i
+    size_t used = 0;                          // pairs in use
+    static constexpr size_t CAP = 1 << 15;
+    double total_ms[PROF_COUNT] = {0};
+    long count[PROF_COUNT] = {0};
+};
+
 enum Scal {  // device-resident BiCGStab scalars (double d_scal[SC_COUNT])
     SC_RHO = 0, SC_RHOP, SC_ALPHA, SC_OMEGA, SC_BETA, SC_TMP1, SC_TMP2, SC_NORM, SC_NORM0, SC_COUNT = 16
 };
@@ -105,6 +117,7 @@ struct opmhip_ctx {
     double* h_pinned = nullptr;  // SC_COUNT doubles, pinned
     opmhip::WellsDev wells;
     opmhip::AsmDev asmb;
+    opmhip::Profiler prof;
     std::vector<void*> allocs;
 };
 
@@ -145,6 +158,26 @@ int dev_upload(opmhip_ctx* c, T** p, const std::vector<T>& h) {
     if (rc) return rc;
     if (!h.empty()) OPMHIP_HIP(c, hipMemcpy(*p, h.data(), h.size() * sizeof(T), hipMemcpyHostToDevice));
     return OPMHIP_SUCCESS;
+}
+
+// RAII-less profiling scope: prof_begin returns a slot (or -1), prof_end closes it
+inline int prof_begin(opmhip_ctx* c, int cls) {
+    Profiler& P = c->prof;
+    if (!P.enabled || P.used >= Profiler::CAP) return -1;
+    if (P.pool.size() < 2 * (P.used + 1)) {
+        hipEvent_t a, b;
+        if (hipEventCreate(&a) != hipSuccess || hipEventCreate(&b) != hipSuccess) return -1;
+        P.pool.push_back(a);
+        P.pool.push_back(b);
+        P.cls.push_back(cls);
+    }
+    const int slot = (int)P.used++;
+    P.cls[slot] = cls;
+    (void)hipEventRecord(P.pool[2 * slot], c->stream);
+    return slot;
+}
+inline void prof_end(opmhip_ctx* c, int slot) {
+    if (slot >= 0) (void)hipEventRecord(c->prof.pool[2 * slot + 1], c->stream);
 }
 
 // reorder.cpp (host): level scheduling / colouring, internal pattern, L/U split, tiles

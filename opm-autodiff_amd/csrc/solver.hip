@@ -510,12 +510,14 @@ void launch_spmv(opmhip_ctx* c, const double* x, double* y, int ndot, const doub
     const int nt = P.tiles.ntiles();
     const bool wells = c->wells.num_wells > 0;
     const int fused = wells ? 0 : ndot;
+    const int ps = prof_begin(c, PROF_SPMV);
     if (fused == 0)
         hipLaunchKernelGGL(k_spmv<0>, dim3(nt), dim3(64), 0, c->stream, P.tiles.d_row0, P.d_rowptr, P.d_col, c->d_A, x, y, w0, c->d_part, c->npart);
     else if (fused == 1)
         hipLaunchKernelGGL(k_spmv<1>, dim3(nt), dim3(64), 0, c->stream, P.tiles.d_row0, P.d_rowptr, P.d_col, c->d_A, x, y, w0, c->d_part, c->npart);
     else
         hipLaunchKernelGGL(k_spmv<2>, dim3(nt), dim3(64), 0, c->stream, P.tiles.d_row0, P.d_rowptr, P.d_col, c->d_A, x, y, w0, c->d_part, c->npart);
+    prof_end(c, ps);
     if (wells) {
         launch_wells_apply(c, x, y);
         if (ndot > 0) {
@@ -529,15 +531,18 @@ static int dot_count(opmhip_ctx* c) {  // how many partials the last launch_spmv
 }
 void launch_ilu_factor(opmhip_ctx* c) {
     const Pattern& P = c->pat;
+    const int ps = prof_begin(c, PROF_ILU_FACTOR);
     for (int col = 0; col < P.numColors; ++col) {
         const int tb = P.tiles.colorTile[col], te = P.tiles.colorTile[col + 1];
         if (te > tb)
             hipLaunchKernelGGL(k_ilu_factor, dim3(te - tb), dim3(64), 0, c->stream, tb, P.tiles.d_row0, P.d_rowptr, P.d_col, P.d_diag,
                                c->d_A, P.d_lrowptr, P.d_urowptr, P.d_ucol, c->d_L, c->d_U, c->d_invD);
     }
+    prof_end(c, ps);
 }
 void launch_ilu_apply(opmhip_ctx* c, const double* d, double* v) {
     const Pattern& P = c->pat;
+    const int ps = prof_begin(c, PROF_ILU_APPLY);
     for (int col = 0; col < P.numColors; ++col) {
         const int tb = P.tiles.colorTile[col], te = P.tiles.colorTile[col + 1];
         if (te > tb)
@@ -553,6 +558,7 @@ void launch_ilu_apply(opmhip_ctx* c, const double* d, double* v) {
         const int n = P.Nb * BS;
         hipLaunchKernelGGL(k_scale, dim3(cdiv((size_t)n, 256)), dim3(256), 0, c->stream, n, c->cfg.ilu_relaxation, v);
     }
+    prof_end(c, ps);
 }
 static void finalize(opmhip_ctx* c, int mode, int count) {
     hipLaunchKernelGGL(k_finalize, dim3(1), dim3(VB), 0, c->stream, mode, count, c->d_part, c->npart, c->d_scal);
@@ -589,21 +595,30 @@ int bicgstab(opmhip_ctx* c, opmhip_result* res) {
     double norm = norm_0;
     float it;
     for (it = 0.5f; it < maxit; it += 0.5f) {
-        if (it > 1) hipLaunchKernelGGL(k_bicg_pupdate, dim3(nb), dim3(VB), 0, c->stream, n, c->d_scal, c->d_p, c->d_v, c->d_r);
+        int ps;
+        if (it > 1) {
+            ps = prof_begin(c, PROF_VECTOR);
+            hipLaunchKernelGGL(k_bicg_pupdate, dim3(nb), dim3(VB), 0, c->stream, n, c->d_scal, c->d_p, c->d_v, c->d_r);
+            prof_end(c, ps);
+        }
         launch_ilu_apply(c, c->d_p, c->d_pw);
         launch_spmv(c, c->d_pw, c->d_v, 1, c->d_rw, nullptr);
+        ps = prof_begin(c, PROF_VECTOR);
         finalize(c, FIN_ALPHA, dot_count(c));
         hipLaunchKernelGGL(k_bicg_upd1, dim3(nb), dim3(VB), 0, c->stream, n, c->d_scal, c->d_r, c->d_v, c->d_x, c->d_pw, c->d_part, c->npart);
         finalize(c, FIN_NORM, nb);
+        prof_end(c, ps);
         if ((rc = read_scalars(c))) return rc;
         norm = c->h_pinned[SC_NORM];
         if (norm < tol * norm_0) break;
         it += 0.5f;
         launch_ilu_apply(c, c->d_r, c->d_s);
         launch_spmv(c, c->d_s, c->d_t, 2, c->d_r, nullptr);
+        ps = prof_begin(c, PROF_VECTOR);
         finalize(c, FIN_OMEGA, dot_count(c));
         hipLaunchKernelGGL(k_bicg_upd2, dim3(nb), dim3(VB), 0, c->stream, n, c->d_scal, c->d_x, c->d_s, c->d_r, c->d_t, c->d_rw, c->d_part, c->npart);
         finalize(c, FIN_NORM_RHO, nb);
+        prof_end(c, ps);
         if ((rc = read_scalars(c))) return rc;
         norm = c->h_pinned[SC_NORM];
         if (norm < tol * norm_0) break;
