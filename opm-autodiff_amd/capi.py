@@ -10,7 +10,7 @@ import re
 import numpy as np
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(HERE, "libopmhip.so")
+LIB_PATH = os.environ.get("OPMHIP_LIB", os.path.join(HERE, "libopmhip.so"))  # OPMHIP_LIB: tuning variants only
 HEADER_PATH = os.path.join(os.path.dirname(HERE), "include", "opmhip.h")
 
 SUCCESS = 0

@@ -18,8 +18,11 @@ constexpr int BB = 9;
 // One workgroup = one wavefront (64 lanes) = one tile of at most TILE_ROWS block rows, one row per lane.
 // A tile's blocks are streamed into LDS with coalesced 16-byte loads, then each lane walks its own row in
 // the CPU's sequential order.  TILE_CAP_BLOCKS bounds the LDS image (72 B per block + 4 B column).
-constexpr int TILE_ROWS = 64;
-constexpr int TILE_CAP_BLOCKS = 448;  // 64 rows x 7 blocks (Cartesian 7-point stencil)
+#ifndef OPMHIP_TILE_ROWS
+#define OPMHIP_TILE_ROWS 32
+#endif
+constexpr int TILE_ROWS = OPMHIP_TILE_ROWS;
+constexpr int TILE_CAP_BLOCKS = 7 * TILE_ROWS;  // a full tile of a Cartesian 7-point stencil
 
 struct DevBuf {
     void* p = nullptr;
