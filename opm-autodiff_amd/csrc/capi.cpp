@@ -23,7 +23,7 @@ int alloc_system(opmhip_ctx* c) {
     if ((rc = dev_alloc(c, &c->d_L, (size_t)P.nl * BB))) return rc;
     if ((rc = dev_alloc(c, &c->d_U, (size_t)P.nu * BB))) return rc;
     if ((rc = dev_alloc(c, &c->d_invD, (size_t)P.Nb * BB))) return rc;
-    double** vecs[] = {&c->d_b, &c->d_x, &c->d_r, &c->d_rw, &c->d_p, &c->d_v, &c->d_s, &c->d_t, &c->d_pw, &c->d_stageV};
+    double** vecs[] = {&c->d_b, &c->d_x, &c->d_r, &c->d_rw, &c->d_p, &c->d_v, &c->d_s, &c->d_t, &c->d_pw, &c->d_vu, &c->d_stageV};
     for (double** v : vecs) {
         if ((rc = dev_alloc(c, v, n))) return rc;
         OPMHIP_HIP(c, hipMemset(*v, 0, n * sizeof(double)));
@@ -35,6 +35,8 @@ int alloc_system(opmhip_ctx* c) {
     c->npart = std::max(P.tiles.ntiles(), vb) + 1;
     if ((rc = dev_alloc(c, &c->d_part, (size_t)2 * c->npart))) return rc;
     OPMHIP_HIP(c, hipMemset(c->d_part, 0, (size_t)2 * c->npart * sizeof(double)));
+    if ((rc = dev_alloc(c, &c->d_part2, (size_t)1024))) return rc;
+    OPMHIP_HIP(c, hipMemset(c->d_part2, 0, 1024 * sizeof(double)));
     OPMHIP_HIP(c, hipHostMalloc((void**)&c->h_pinned, SC_COUNT * sizeof(double)));
     return OPMHIP_SUCCESS;
 }

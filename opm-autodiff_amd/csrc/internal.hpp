@@ -111,11 +111,12 @@ struct opmhip_ctx {
     double *d_A = nullptr, *d_L = nullptr, *d_U = nullptr, *d_invD = nullptr;
     // vectors, internal order, 3*Nb each
     double *d_b = nullptr, *d_x = nullptr, *d_r = nullptr, *d_rw = nullptr, *d_p = nullptr, *d_v = nullptr,
-           *d_s = nullptr, *d_t = nullptr, *d_pw = nullptr;
+           *d_s = nullptr, *d_t = nullptr, *d_pw = nullptr, *d_vu = nullptr;
     // staging (natural order): matrix values and one vector
     double *d_stageA = nullptr, *d_stageV = nullptr;
     double* d_scal = nullptr;   // SC_COUNT doubles
     double* d_part = nullptr;   // partial sums: 2 x npart
+    double* d_part2 = nullptr;  // second-level partials: 2 x RED1_BLOCKS
     int npart = 0;
     double* h_pinned = nullptr;  // SC_COUNT doubles, pinned
     opmhip::WellsDev wells;

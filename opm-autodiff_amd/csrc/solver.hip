@@ -162,7 +162,8 @@ template <bool SUB>
 __device__ __forceinline__ int tile_row_product(int t, const int* __restrict__ tile_row0, const int* __restrict__ rowptr,
                                                 const int* __restrict__ col, const double* __restrict__ val,
                                                 const double* __restrict__ x, double* sval, int lane, bool reverse, double* acc,
-                                                TileCtx& T) {
+                                                TileCtx& T, const double* __restrict__ xlo = nullptr, int xsplit = 0) {
+    // vector entries of columns < xsplit are read from xlo instead of x (ILU sweeps: first colour's y equals d)
     T.r0 = tile_row0[t];
     T.r1 = tile_row0[t + 1];
     const int k0 = rowptr[T.r0], k1 = rowptr[T.r1];
@@ -200,7 +201,7 @@ __device__ __forceinline__ int tile_row_product(int t, const int* __restrict__ t
         }
 #pragma unroll
         for (int u = 0; u < GCH; ++u) {
-            const double* xc = &x[(size_t)cc[u] * BS];
+            const double* xc = (cc[u] < xsplit) ? &xlo[(size_t)cc[u] * BS] : &x[(size_t)cc[u] * BS];
             xx[u][0] = xc[0]; xx[u][1] = xc[1]; xx[u][2] = xc[2];
         }
 #pragma unroll
@@ -228,7 +229,7 @@ __device__ __forceinline__ int tile_row_product(int t, const int* __restrict__ t
     } else {
 #pragma unroll
         for (int u = 0; u < GCH; ++u) {
-            const double* xc = &x[(size_t)cc[u] * BS];
+            const double* xc = (cc[u] < xsplit) ? &xlo[(size_t)cc[u] * BS] : &x[(size_t)cc[u] * BS];
             xx[u][0] = xc[0]; xx[u][1] = xc[1]; xx[u][2] = xc[2];
         }
     }
@@ -249,7 +250,8 @@ __device__ __forceinline__ int tile_row_product(int t, const int* __restrict__ t
         for (int u = 0; u < GCH; ++u) {
             const int q = (done + u < nrow) ? done + u : nrow - 1;
             const int k = reverse ? ke - 1 - q : kb + q;
-            const double* xc = &x[(size_t)col[k] * BS];
+            const int cq = col[k];
+            const double* xc = (cq < xsplit) ? &xlo[(size_t)cq * BS] : &x[(size_t)cq * BS];
             xx[u][0] = xc[0]; xx[u][1] = xc[1]; xx[u][2] = xc[2];
         }
 #pragma unroll
@@ -341,52 +343,49 @@ __global__ __launch_bounds__(64) void k_spmv(int nt, const int* __restrict__ til
 }
 
 // ============================== ILU0 apply ===============================================================
-// forward sweep over one colour: v_i = d_i - sum_{j<i} L_ij v_j  (linalg/ParallelOverlappingILU0.hpp:867-879)
-__global__ __launch_bounds__(64) void k_ilu_lower(int tile_begin, int ntc, const int* __restrict__ tile_row0,
-                                                  const int* __restrict__ lrowptr, const int* __restrict__ lcol,
-                                                  const double* __restrict__ L, const double* __restrict__ d,
-                                                  double* __restrict__ v) {
+// One colour of M^-1 = [w] U^-1 L^-1 (linalg/ParallelOverlappingILU0.hpp:848-903).  Work vector vu holds y = L^-1 d and then
+// the unscaled U^-1 y; v receives the final (scaled) result.  Three shapes, chosen per colour by the launcher:
+//   SW_L  : forward sweep of a middle colour      vu_i = d_i - sum_{j<i} L_ij y_j                      (:867-879)
+//   SW_LF : last colour, forward + backward fused  (its rows have no U entries): vu_i = D_i^-1 (d_i - sum L_ij y_j)
+//   SW_UF : backward sweep                         vu_i = D_i^-1 (y_i - sum_{j>i} U_ij vu_j)            (:881-895)
+// y of the FIRST colour is d itself (no L entries there), so gathers of columns < n0 read d and the first colour's
+// backward sweep takes its right-hand side from d: the forward "copy" launch disappears.
+// relax_mode 0 (CPU path): backward sweep walks columns in DESCENDING order (the reference's reversed CRS), vu stays
+//   unscaled, v_i = w * vu_i  (the reference's trailing "v *= w", :899-901, folded into the store);
+// relax_mode 1 (OpenCL, bda/openclKernels.cpp:301-383): ascending columns, vu_i = v_i = w * D_i^-1 (...).
+enum { SW_L = 0, SW_LF = 1, SW_UF = 2 };
+template <int SHAPE>
+__global__ __launch_bounds__(64) void k_ilu_sweep(int tile_begin, int ntc, int n0, int rhs_from_d, const int* __restrict__ tile_row0,
+                                                  const int* __restrict__ prow, const int* __restrict__ pcol,
+                                                  const double* __restrict__ P, const double* __restrict__ invD,
+                                                  const double* __restrict__ d, double* __restrict__ vu, double* __restrict__ v,
+                                                  int relax_mode, double w) {
     TILE_LDS
     const int lane = threadIdx.x, tl = xcd_tile(blockIdx.x, ntc);
     if (tl >= ntc) return;
     const int t = tile_begin + tl;
     const int r0 = tile_row0[t], r1 = tile_row0[t + 1];
     const int rq = (r0 + lane < r1) ? r0 + lane : r1 - 1;
-    double rhs[3] = {d[(size_t)rq * BS], d[(size_t)rq * BS + 1], d[(size_t)rq * BS + 2]};
-    TileCtx T;
-    const int r = tile_row_product<true>(t, tile_row0, lrowptr, lcol, L, v, sval, lane, false, rhs, T);
-    if (r < 0) return;
-    v[(size_t)r * BS] = rhs[0]; v[(size_t)r * BS + 1] = rhs[1]; v[(size_t)r * BS + 2] = rhs[2];
-}
-// backward sweep over one colour: v_i = [w] D_i^-1 (v_i - sum_{j>i} U_ij v_j)
-// relax_mode 0 (CPU path): columns in DESCENDING order as the reference's reversed CRS walks them
-//                          (ParallelOverlappingILU0.hpp:881-895), no scaling here;
-// relax_mode 1 (OpenCL)  : ascending columns, result scaled by w in the sweep (bda/openclKernels.cpp:301-383).
-__global__ __launch_bounds__(64) void k_ilu_upper(int tile_begin, int ntc, const int* __restrict__ tile_row0,
-                                                  const int* __restrict__ urowptr, const int* __restrict__ ucol,
-                                                  const double* __restrict__ U, const double* __restrict__ invD,
-                                                  double* __restrict__ v, int relax_mode, double w) {
-    TILE_LDS
-    const int lane = threadIdx.x, tl = xcd_tile(blockIdx.x, ntc);
-    if (tl >= ntc) return;
-    const int t = tile_begin + tl;
-    const int r0 = tile_row0[t], r1 = tile_row0[t + 1];
-    const int rq = (r0 + lane < r1) ? r0 + lane : r1 - 1;
-    double rhs[3] = {v[(size_t)rq * BS], v[(size_t)rq * BS + 1], v[(size_t)rq * BS + 2]};
+    const double* rsrc = (SHAPE != SW_UF || rhs_from_d) ? d : vu;
+    double rhs[3] = {rsrc[(size_t)rq * BS], rsrc[(size_t)rq * BS + 1], rsrc[(size_t)rq * BS + 2]};
     double Di[BB];
+    if (SHAPE != SW_L) {
 #pragma unroll
-    for (int q = 0; q < BB; ++q) Di[q] = invD[(size_t)rq * BB + q];
+        for (int q = 0; q < BB; ++q) Di[q] = invD[(size_t)rq * BB + q];
+    }
     TileCtx T;
-    const int r = tile_row_product<true>(t, tile_row0, urowptr, ucol, U, v, sval, lane, relax_mode == 0, rhs, T);
+    const bool reverse = (SHAPE == SW_UF) && relax_mode == 0;
+    const int r = tile_row_product<true>(t, tile_row0, prow, pcol, P, vu, sval, lane, reverse, rhs, T, d, n0);
     if (r < 0) return;
+    if (SHAPE == SW_L) {
+        vu[(size_t)r * BS] = rhs[0]; vu[(size_t)r * BS + 1] = rhs[1]; vu[(size_t)r * BS + 2] = rhs[2];
+        return;
+    }
     double out[3] = {0.0, 0.0, 0.0};
     blk_umv(Di, rhs[0], rhs[1], rhs[2], out);  // DenseMatrix::mv: y = 0, then accumulate
     if (relax_mode == 1) { out[0] = w * out[0]; out[1] = w * out[1]; out[2] = w * out[2]; }
-    v[(size_t)r * BS] = out[0]; v[(size_t)r * BS + 1] = out[1]; v[(size_t)r * BS + 2] = out[2];
-}
-__global__ void k_scale(int n, double w, double* __restrict__ v) {
-    const int e = blockIdx.x * blockDim.x + threadIdx.x;
-    if (e < n) v[e] *= w;
+    vu[(size_t)r * BS] = out[0]; vu[(size_t)r * BS + 1] = out[1]; vu[(size_t)r * BS + 2] = out[2];
+    if (v != vu) { v[(size_t)r * BS] = w * out[0]; v[(size_t)r * BS + 1] = w * out[1]; v[(size_t)r * BS + 2] = w * out[2]; }
 }
 
 // ============================== ILU0 factorisation =======================================================
@@ -585,6 +584,23 @@ __global__ __launch_bounds__(VB) void k_dots(int n, const double* __restrict__ a
     }
     block_partials(s, q, part, npart, nsum);
 }
+// Pre-reduction for long partial lists (one partial per 32-row tile = 31250 at 100^3): RED1_BLOCKS workgroups each
+// sum one contiguous slice in a fixed order, so that the single-workgroup k_finalize reads a few hundred numbers.
+constexpr int RED1_BLOCKS = 128;
+__global__ __launch_bounds__(VB) void k_reduce_stage1(int count, const double* __restrict__ part, int npart, double* __restrict__ out) {
+    __shared__ double sh[2][VB];
+    const int chunk = (count + RED1_BLOCKS - 1) / RED1_BLOCKS;
+    const int b = blockIdx.x * chunk, e = min(count, b + chunk);
+    double a0 = 0.0, a1 = 0.0;
+    for (int i = b + threadIdx.x; i < e; i += VB) { a0 += part[i]; a1 += part[npart + i]; }
+    sh[0][threadIdx.x] = a0; sh[1][threadIdx.x] = a1;
+    __syncthreads();
+    for (int o = VB / 2; o > 0; o >>= 1) {
+        if ((int)threadIdx.x < o) { sh[0][threadIdx.x] += sh[0][threadIdx.x + o]; sh[1][threadIdx.x] += sh[1][threadIdx.x + o]; }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) { out[blockIdx.x] = sh[0][0]; out[RED1_BLOCKS + blockIdx.x] = sh[1][0]; }
+}
 // Sum the partials in a fixed order and update the device-resident scalars.  One workgroup.
 enum FinMode { FIN_INIT = 0, FIN_ALPHA = 1, FIN_NORM = 2, FIN_OMEGA = 3, FIN_NORM_RHO = 4 };
 __global__ __launch_bounds__(VB) void k_finalize(int mode, int count, const double* __restrict__ part, int npart,
@@ -685,24 +701,37 @@ void launch_ilu_factor(opmhip_ctx* c) {
 void launch_ilu_apply(opmhip_ctx* c, const double* d, double* v) {
     const Pattern& P = c->pat;
     const int ps = prof_begin(c, PROF_ILU_APPLY);
-    for (int col = 0; col < P.numColors; ++col) {
-        const int tb = P.tiles.colorTile[col], te = P.tiles.colorTile[col + 1];
-        if (te > tb)
-            hipLaunchKernelGGL(k_ilu_lower, dim3(8 * ((te - tb + 7) / 8)), dim3(64), 0, c->stream, tb, te - tb, P.tiles.d_row0, P.d_lrowptr, P.d_lcol, c->d_L, d, v);
+    const int C = P.numColors, mode = c->cfg.relax_mode;
+    const double w = c->cfg.ilu_relaxation;
+    // post-scale with w != 1 keeps the unscaled sweep vector apart from the scaled result
+    double* vu = (mode == OPMHIP_RELAX_POST_SCALE && w != 1.0) ? c->d_vu : v;
+    const int n0 = P.colorPrefix[1];  // rows of the first colour: their y is d
+    auto grid = [](int n) { return dim3(8 * ((n + 7) / 8)); };
+    for (int col = 1; col < C; ++col) {
+        const int tb = P.tiles.colorTile[col], nt = P.tiles.colorTile[col + 1] - tb;
+        if (nt <= 0) continue;
+        if (col < C - 1)
+            hipLaunchKernelGGL(k_ilu_sweep<SW_L>, grid(nt), dim3(64), 0, c->stream, tb, nt, n0, 0, P.tiles.d_row0, P.d_lrowptr, P.d_lcol, c->d_L,
+                               c->d_invD, d, vu, v, mode, w);
+        else
+            hipLaunchKernelGGL(k_ilu_sweep<SW_LF>, grid(nt), dim3(64), 0, c->stream, tb, nt, n0, 0, P.tiles.d_row0, P.d_lrowptr, P.d_lcol, c->d_L,
+                               c->d_invD, d, vu, v, mode, w);
     }
-    for (int col = P.numColors - 1; col >= 0; --col) {
-        const int tb = P.tiles.colorTile[col], te = P.tiles.colorTile[col + 1];
-        if (te > tb)
-            hipLaunchKernelGGL(k_ilu_upper, dim3(8 * ((te - tb + 7) / 8)), dim3(64), 0, c->stream, tb, te - tb, P.tiles.d_row0, P.d_urowptr, P.d_ucol, c->d_U,
-                               c->d_invD, v, c->cfg.relax_mode, c->cfg.ilu_relaxation);
-    }
-    if (c->cfg.relax_mode == OPMHIP_RELAX_POST_SCALE && c->cfg.ilu_relaxation != 1.0) {
-        const int n = P.Nb * BS;
-        hipLaunchKernelGGL(k_scale, dim3(cdiv((size_t)n, 256)), dim3(256), 0, c->stream, n, c->cfg.ilu_relaxation, v);
+    for (int col = (C > 1 ? C - 2 : 0); col >= 0; --col) {
+        const int tb = P.tiles.colorTile[col], nt = P.tiles.colorTile[col + 1] - tb;
+        if (nt <= 0) continue;
+        // gathers only reach later colours (>= n0 rows in), so the d/vu split of the gather is inert here (n0 = 0)
+        hipLaunchKernelGGL(k_ilu_sweep<SW_UF>, grid(nt), dim3(64), 0, c->stream, tb, nt, 0, col == 0 ? 1 : 0, P.tiles.d_row0, P.d_urowptr, P.d_ucol,
+                           c->d_U, c->d_invD, d, vu, v, mode, w);
     }
     prof_end(c, ps);
 }
 static void finalize(opmhip_ctx* c, int mode, int count) {
+    if (count > 4 * RED1_BLOCKS) {
+        hipLaunchKernelGGL(k_reduce_stage1, dim3(RED1_BLOCKS), dim3(VB), 0, c->stream, count, c->d_part, c->npart, c->d_part2);
+        hipLaunchKernelGGL(k_finalize, dim3(1), dim3(VB), 0, c->stream, mode, RED1_BLOCKS, c->d_part2, RED1_BLOCKS, c->d_scal);
+        return;
+    }
     hipLaunchKernelGGL(k_finalize, dim3(1), dim3(VB), 0, c->stream, mode, count, c->d_part, c->npart, c->d_scal);
 }
 // the vector kernels of one BiCGStab iteration, for opmhip_time_kernel
