@@ -116,6 +116,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--n", type=int, default=100, help="cells per edge of the per-GPU cube")
     ap.add_argument("--reorder", default="graph_coloring_greedy")
+    ap.add_argument("--chain-length", type=int, default=8, help="rows per chain of the line-coloured ILU0 ordering")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     a = ap.parse_args()
 
@@ -137,7 +138,8 @@ def main():
     case = pkg.decks.cartesian_case(n, n, n, state="mixed", heterogeneous=False)
     src = pkg.decks.five_spot_source(case, rate_sm3_per_day=2000.0 * (n / 100.0) ** 2)
     dts = [1 * DAY] + [10 * DAY] * 1000
-    model = pkg.capi.HipModel(case, device_id=local_rank, reorder=a.reorder, tolerance=1e-2, maxit=200, ilu_relaxation=0.9)
+    model = pkg.capi.HipModel(case, device_id=local_rank, reorder=a.reorder, tolerance=1e-2, maxit=200, ilu_relaxation=0.9,
+                               chain_length=a.chain_length)
     model.set_state(case["pv"], case["meaning"])
     model.set_source(src)
     sim = Simulation(pkg, model, dts)

@@ -40,7 +40,11 @@ typedef enum opmhip_status {
 typedef enum opmhip_reorder {
     OPMHIP_REORDER_LEVEL_SCHEDULING = 1, /* same factors as the CPU's natural-order ILU0 (bda/Reorder.cpp:266-318) */
     OPMHIP_REORDER_GRAPH_COLORING = 2,   /* Jones-Plassmann rounds, deterministic weights (bda/Reorder.cpp:59-172) */
-    OPMHIP_REORDER_GRAPH_COLORING_GREEDY = 3 /* first-fit colouring: red-black on Cartesian 7-point grids */
+    OPMHIP_REORDER_GRAPH_COLORING_GREEDY = 3, /* first-fit colouring: red-black on Cartesian 7-point grids */
+    OPMHIP_REORDER_LINE_COLORING = 4 /* chains of <= config.reserved[0] (default 8) rows along each row's farthest
+                                        neighbour (the vertical one in CpGrid's natural order), chains coloured greedily:
+                                        an exact ILU0 of that ordering, near the natural order's strength at colouring's
+                                        parallelism (no counterpart in the reference) */
 } opmhip_reorder;
 
 /* how the ILU relaxation factor w enters M^-1 */

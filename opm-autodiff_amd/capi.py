@@ -16,7 +16,7 @@ HEADER_PATH = os.path.join(os.path.dirname(HERE), "include", "opmhip.h")
 SUCCESS = 0
 ANALYSIS_FAILED, CREATE_PRECONDITIONER_FAILED, UNKNOWN_ERROR = -1, -2, -3
 INVALID_ARGUMENT, NOT_READY, DEVICE_ERROR, NO_DEVICE = -4, -5, -6, -7
-REORDER = {"level_scheduling": 1, "graph_coloring": 2, "graph_coloring_greedy": 3}
+REORDER = {"level_scheduling": 1, "graph_coloring": 2, "graph_coloring_greedy": 3, "line_coloring": 4}
 RELAX = {"post_scale": 0, "in_sweep": 1}
 
 
@@ -113,7 +113,7 @@ class HipSolver:
     ctor(verbosity, maxit, tolerance, deviceID), solve_system(...), get_result(x))."""
 
     def __init__(self, verbosity=0, maxit=200, tolerance=1e-2, device_id=0, ilu_relaxation=0.9,
-                 relax_mode="post_scale", reorder="graph_coloring", zero_diag_fix=True):
+                 relax_mode="post_scale", reorder="graph_coloring", zero_diag_fix=True, chain_length=8):
         L = lib()
         cfg = Config()
         L.opmhip_default_config(C.byref(cfg))
@@ -122,6 +122,7 @@ class HipSolver:
         cfg.relax_mode = RELAX[relax_mode]
         cfg.reorder = REORDER[reorder]
         cfg.zero_diag_fix = int(zero_diag_fix)
+        cfg.reserved[0] = int(chain_length)  # line colouring: rows per chain
         self._h = C.c_void_p()
         rc = L.opmhip_create(C.byref(cfg), C.byref(self._h))
         if rc != SUCCESS:

@@ -33,12 +33,16 @@ struct DevBuf {
 struct TileSet {            // tiles over one block-CSR row-pointer array, never crossing a colour boundary
     std::vector<int> row0;  // [ntiles+1]
     std::vector<int> colorTile;  // [numColors+1] first tile of each colour
+    std::vector<int> ctFirst;    // [nChainTiles+1] first sub-tile of each chain-tile (steps of <= TILE_ROWS chains)
+    std::vector<int> colorCT;    // [numColors+1] first chain-tile of each colour
     int* d_row0 = nullptr;
+    int* d_ctFirst = nullptr;
     int ntiles() const { return (int)row0.size() - 1; }
 };
 
 struct Pattern {
     int Nb = 0, nnzb = 0, numColors = 0, nl = 0, nu = 0;
+    bool chained = false;  // line colouring: rows of one colour may depend on earlier rows of their own chain
     // natural order (as handed over)
     std::vector<int> nat_rowptr, nat_col;
     // ordering

@@ -107,15 +107,26 @@ void color_greedy(const Pattern& P, std::vector<int>& color, int& ncol) {
     }
 }
 
-void build_tiles(const std::vector<int>& rowptr, const std::vector<int>& colorPrefix, TileSet& T) {
+// Sub-tiles (<= TILE_ROWS rows, <= TILE_CAP_BLOCKS blocks) grouped into chain-tiles: the sub-tiles of one chain-tile
+// are the successive steps of up to TILE_ROWS chains and must be processed in order by one workgroup; different
+// chain-tiles of a colour are independent.  Without chains every sub-tile is its own chain-tile.
+void build_tiles(const std::vector<int>& rowptr, const std::vector<int>& colorPrefix, const std::vector<int>& stepPrefix,
+                 TileSet& T) {
+    // stepPrefix: row boundaries of (chain-tile, step) groups, ascending, containing every colour boundary; a value
+    // of -1 marks the start of a new chain-tile (encoded as a parallel flag array to keep this simple)
     T.row0.clear();
     T.colorTile.clear();
+    T.ctFirst.clear();
+    T.colorCT.clear();
+    (void)stepPrefix;
     const int ncol = (int)colorPrefix.size() - 1;
     for (int c = 0; c < ncol; ++c) {
         T.colorTile.push_back((int)T.row0.size());
+        T.colorCT.push_back((int)T.ctFirst.size());
         int r = colorPrefix[c];
         const int rend = colorPrefix[c + 1];
         while (r < rend) {
+            T.ctFirst.push_back((int)T.row0.size());
             T.row0.push_back(r);
             int e = r + 1;  // a tile always holds at least one row (an over-long row is read from HBM directly)
             while (e < rend && e - r < TILE_ROWS && rowptr[e + 1] - rowptr[r] <= TILE_CAP_BLOCKS) ++e;
@@ -123,7 +134,68 @@ void build_tiles(const std::vector<int>& rowptr, const std::vector<int>& colorPr
         }
     }
     T.colorTile.push_back((int)T.row0.size());
+    T.colorCT.push_back((int)T.ctFirst.size());
+    T.ctFirst.push_back((int)T.row0.size());
     T.row0.push_back(colorPrefix[ncol]);
+}
+
+// Line colouring: chains of up to maxLen rows along each row's farthest neighbour (in the natural CpGrid order
+// i + nx*(j + ny*k) that is the vertical neighbour, the strongest coupling of a thin-layered reservoir grid), chains
+// coloured greedily so that chains of one colour share no coupling.  Inside a chain rows keep their natural order, so
+// the factorisation is an exact ILU0 of the permuted matrix; it keeps most of the natural ordering's strength at
+// two colours' worth of launches (tools/ordering_study.py: 12.5 BiCGStab iterations against 26.5 for red-black and
+// 9.5 for the natural order on a 72^3 Jacobian).
+struct Chains {
+    std::vector<int> chainOf, posIn;          // per row
+    std::vector<std::vector<int>> rows;       // per chain
+};
+void build_chains(const Pattern& P, int maxLen, Chains& C) {
+    const int Nb = P.Nb;
+    std::vector<int> succ(Nb, -1);
+    for (int i = 0; i < Nb; ++i) {
+        const int last = P.nat_col[P.nat_rowptr[i + 1] - 1];
+        if (last > i && P.nat_col[P.nat_rowptr[last]] == i) succ[i] = last;  // mutual: i is the farthest lower neighbour of last
+    }
+    C.chainOf.assign(Nb, -1);
+    C.posIn.assign(Nb, 0);
+    C.rows.clear();
+    for (int i = 0; i < Nb; ++i) {
+        if (C.chainOf[i] >= 0) continue;
+        const int id = (int)C.rows.size();
+        C.rows.emplace_back();
+        int cur = i;
+        while (cur >= 0 && C.chainOf[cur] < 0 && (int)C.rows[id].size() < maxLen) {
+            C.chainOf[cur] = id;
+            C.posIn[cur] = (int)C.rows[id].size();
+            C.rows[id].push_back(cur);
+            cur = succ[cur];
+        }
+    }
+}
+void color_chains(const Pattern& P, const Chains& C, std::vector<int>& chainColor, int& ncol) {
+    std::vector<int> cptr, ridx;
+    transpose_pattern(P, cptr, ridx);
+    const int nc = (int)C.rows.size();
+    chainColor.assign(nc, -1);
+    ncol = 0;
+    std::vector<char> used;
+    for (int id = 0; id < nc; ++id) {
+        used.assign(ncol + 1, 0);
+        for (int i : C.rows[id]) {
+            for (int k = P.nat_rowptr[i]; k < P.nat_rowptr[i + 1]; ++k) {
+                const int o = C.chainOf[P.nat_col[k]];
+                if (o != id && chainColor[o] >= 0) used[chainColor[o]] = 1;
+            }
+            for (int k = cptr[i]; k < cptr[i + 1]; ++k) {
+                const int o = C.chainOf[ridx[k]];
+                if (o != id && chainColor[o] >= 0) used[chainColor[o]] = 1;
+            }
+        }
+        int c = 0;
+        while (used[c]) ++c;
+        chainColor[id] = c;
+        ncol = std::max(ncol, c + 1);
+    }
 }
 
 }  // namespace
@@ -148,26 +220,68 @@ int build_pattern(opmhip_ctx* c, int Nb, int nnzb, const int* rows, const int* c
     }
     std::vector<int> color;
     int ncol = 0;
+    Chains CH;
+    std::vector<int> chainColor;
+    const bool chained = (c->cfg.reorder == OPMHIP_REORDER_LINE_COLORING);
+    int maxLen = 1;
     switch (c->cfg.reorder) {
         case OPMHIP_REORDER_LEVEL_SCHEDULING: levels(P, color, ncol); break;
         case OPMHIP_REORDER_GRAPH_COLORING: color_jp(P, color, ncol); break;
         case OPMHIP_REORDER_GRAPH_COLORING_GREEDY: color_greedy(P, color, ncol); break;
+        case OPMHIP_REORDER_LINE_COLORING: {
+            maxLen = c->cfg.reserved[0] > 0 ? c->cfg.reserved[0] : 8;
+            build_chains(P, maxLen, CH);
+            color_chains(P, CH, chainColor, ncol);
+            color.resize(Nb);
+            for (int i = 0; i < Nb; ++i) color[i] = chainColor[CH.chainOf[i]];
+        } break;
         default: return fail(c, OPMHIP_INVALID_ARGUMENT, "unknown reorder kind %d", c->cfg.reorder);
     }
     P.numColors = ncol;
-    // rows keep their natural relative order inside a colour (colorsToReordering, bda/Reorder.cpp:212-226)
+    P.chained = chained;
     P.colorPrefix.assign(ncol + 1, 0);
     for (int i = 0; i < Nb; ++i) P.colorPrefix[color[i] + 1]++;
     std::partial_sum(P.colorPrefix.begin(), P.colorPrefix.end(), P.colorPrefix.begin());
     P.toOrder.resize(Nb);
     P.fromOrder.resize(Nb);
-    {
+    // (chain-tile, step) row groups of the chained ordering: rows [groupRow[g], groupRow[g+1]) ; groupNewCT[g] = 1 if the
+    // group opens a new chain-tile
+    std::vector<int> groupRow, groupNewCT;
+    if (!chained) {
+        // rows keep their natural relative order inside a colour (colorsToReordering, bda/Reorder.cpp:212-226)
         std::vector<int> next(P.colorPrefix.begin(), P.colorPrefix.end() - 1);
         for (int i = 0; i < Nb; ++i) {
             const int p = next[color[i]]++;
             P.toOrder[i] = p;
             P.fromOrder[p] = i;
         }
+    } else {
+        // colour -> chain-tile of TILE_ROWS chains (longest chains first, so that the live chains of a step are a
+        // prefix) -> step -> chain
+        int p = 0;
+        for (int cc = 0; cc < ncol; ++cc) {
+            std::vector<int> ids;
+            for (int id = 0; id < (int)CH.rows.size(); ++id)
+                if (chainColor[id] == cc) ids.push_back(id);
+            std::stable_sort(ids.begin(), ids.end(), [&](int a, int b) { return CH.rows[a].size() > CH.rows[b].size(); });
+            for (size_t b0 = 0; b0 < ids.size(); b0 += TILE_ROWS) {
+                const size_t b1 = std::min(ids.size(), b0 + (size_t)TILE_ROWS);
+                const int steps = (int)CH.rows[ids[b0]].size();
+                for (int st = 0; st < steps; ++st) {
+                    groupRow.push_back(p);
+                    groupNewCT.push_back(st == 0 ? 1 : 0);
+                    for (size_t b = b0; b < b1; ++b) {
+                        if ((int)CH.rows[ids[b]].size() <= st) break;
+                        const int i = CH.rows[ids[b]][st];
+                        P.toOrder[i] = p;
+                        P.fromOrder[p] = i;
+                        ++p;
+                    }
+                }
+            }
+        }
+        groupRow.push_back(p);
+        if (p != Nb) return fail(c, OPMHIP_ANALYSIS_FAILED, "line colouring lost rows (%d of %d)", p, Nb);
     }
     // internal pattern: row p = natural row fromOrder[p], columns renamed and re-sorted
     // (reorderBlockedMatrixByPattern, bda/Reorder.cpp:179-207) - done once here for the pattern; values follow
@@ -198,7 +312,8 @@ int build_pattern(opmhip_ctx* c, int Nb, int nnzb, const int* rows, const int* c
             for (int p = P.colorPrefix[cc]; p < P.colorPrefix[cc + 1]; ++p) colorOf[p] = cc;
         for (int p = 0; p < Nb; ++p)
             for (int k = P.rowptr[p]; k < P.rowptr[p + 1]; ++k)
-                if (P.col[k] != p && colorOf[P.col[k]] == colorOf[p])
+                if (P.col[k] != p && colorOf[P.col[k]] == colorOf[p] &&
+                    !(chained && CH.chainOf[P.fromOrder[P.col[k]]] == CH.chainOf[P.fromOrder[p]]))
                         return fail(c, OPMHIP_ANALYSIS_FAILED, "ordering is not a valid schedule at row %d", p);
     }
     // L / U split (what Dune's convertToCRS produces, linalg/ParallelOverlappingILU0.hpp:497-584; here both
@@ -217,7 +332,35 @@ int build_pattern(opmhip_ctx* c, int Nb, int nnzb, const int* rows, const int* c
     }
     P.nl = (int)P.lcol.size();
     P.nu = (int)P.ucol.size();
-    build_tiles(P.rowptr, P.colorPrefix, P.tiles);
+    if (!chained) {
+        build_tiles(P.rowptr, P.colorPrefix, groupRow, P.tiles);
+    } else {
+        // one sub-tile per (chain-tile, step) group: a group has <= TILE_ROWS rows by construction; over-long groups in
+        // blocks are split (still processed in order inside the chain-tile)
+        TileSet& T = P.tiles;
+        T.row0.clear(); T.colorTile.clear(); T.ctFirst.clear(); T.colorCT.clear();
+        int cnext = 0;
+        for (size_t g = 0; g + 1 < groupRow.size(); ++g) {
+            while (cnext <= ncol - 1 && groupRow[g] == P.colorPrefix[cnext]) {
+                T.colorTile.push_back((int)T.row0.size());
+                T.colorCT.push_back((int)T.ctFirst.size());
+                ++cnext;
+            }
+            if (groupNewCT[g]) T.ctFirst.push_back((int)T.row0.size());
+            int r = groupRow[g];
+            const int rend = groupRow[g + 1];
+            while (r < rend) {
+                T.row0.push_back(r);
+                int e = r + 1;
+                while (e < rend && P.rowptr[e + 1] - P.rowptr[r] <= TILE_CAP_BLOCKS) ++e;
+                r = e;
+            }
+        }
+        T.colorTile.push_back((int)T.row0.size());
+        T.colorCT.push_back((int)T.ctFirst.size());
+        T.ctFirst.push_back((int)T.row0.size());
+        T.row0.push_back(Nb);
+    }
 
     int rc;
     if ((rc = dev_upload(c, &P.d_rowptr, P.rowptr))) return rc;
@@ -231,6 +374,7 @@ int build_pattern(opmhip_ctx* c, int Nb, int nnzb, const int* rows, const int* c
     if ((rc = dev_upload(c, &P.d_urowptr, P.urowptr))) return rc;
     if ((rc = dev_upload(c, &P.d_ucol, P.ucol))) return rc;
     if ((rc = dev_upload(c, &P.tiles.d_row0, P.tiles.row0))) return rc;
+    if ((rc = dev_upload(c, &P.tiles.d_ctFirst, P.tiles.ctFirst))) return rc;
     return OPMHIP_SUCCESS;
 }
 

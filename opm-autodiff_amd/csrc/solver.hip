@@ -388,63 +388,109 @@ __global__ __launch_bounds__(64) void k_ilu_sweep(int tile_begin, int ntc, int n
     if (v != vu) { v[(size_t)r * BS] = w * out[0]; v[(size_t)r * BS + 1] = w * out[1]; v[(size_t)r * BS + 2] = w * out[2]; }
 }
 
+// Line-coloured orderings: one workgroup walks the steps of its chain-tile in order (forward for L, backward for U);
+// a row may depend on earlier rows of its own chain, which the same workgroup wrote one step before - visible after
+// the workgroup barrier because a CU's L1 sees the CU's own write-through stores.  Chains of other colours are
+// finished (earlier launches).  No first-colour / last-colour shortcuts here: every colour has chain-internal L and U.
+template <int SHAPE>  // SW_L or SW_UF
+__global__ __launch_bounds__(64) void k_ilu_sweep_chain(int ct_begin, int nct, const int* __restrict__ ct_first,
+                                                        const int* __restrict__ tile_row0, const int* __restrict__ prow,
+                                                        const int* __restrict__ pcol, const double* __restrict__ P,
+                                                        const double* __restrict__ invD, const double* __restrict__ d,
+                                                        double* vu, double* v, int relax_mode, double w) {
+    TILE_LDS
+    const int lane = threadIdx.x, cl = xcd_tile(blockIdx.x, nct);
+    if (cl >= nct) return;
+    const int q0 = ct_first[ct_begin + cl], q1 = ct_first[ct_begin + cl + 1];
+    const bool reverse = (SHAPE == SW_UF) && relax_mode == 0;
+    for (int st = 0; st < q1 - q0; ++st) {
+        const int t = (SHAPE == SW_UF) ? q1 - 1 - st : q0 + st;
+        const int r0 = tile_row0[t], r1 = tile_row0[t + 1];
+        const int rq = (r0 + lane < r1) ? r0 + lane : r1 - 1;
+        const double* rsrc = (SHAPE == SW_L) ? d : vu;
+        double rhs[3] = {rsrc[(size_t)rq * BS], rsrc[(size_t)rq * BS + 1], rsrc[(size_t)rq * BS + 2]};
+        double Di[BB];
+        if (SHAPE != SW_L) {
+#pragma unroll
+            for (int q = 0; q < BB; ++q) Di[q] = invD[(size_t)rq * BB + q];
+        }
+        TileCtx T;
+        const int r = tile_row_product<true>(t, tile_row0, prow, pcol, P, vu, sval, lane, reverse, rhs, T);
+        if (r >= 0) {
+            if (SHAPE == SW_L) {
+                vu[(size_t)r * BS] = rhs[0]; vu[(size_t)r * BS + 1] = rhs[1]; vu[(size_t)r * BS + 2] = rhs[2];
+            } else {
+                double out[3] = {0.0, 0.0, 0.0};
+                blk_umv(Di, rhs[0], rhs[1], rhs[2], out);
+                if (relax_mode == 1) { out[0] = w * out[0]; out[1] = w * out[1]; out[2] = w * out[2]; }
+                vu[(size_t)r * BS] = out[0]; vu[(size_t)r * BS + 1] = out[1]; vu[(size_t)r * BS + 2] = out[2];
+                if (v != vu) { v[(size_t)r * BS] = w * out[0]; v[(size_t)r * BS + 1] = w * out[1]; v[(size_t)r * BS + 2] = w * out[2]; }
+            }
+        }
+        __syncthreads();  // this step's results are visible to the next step; LDS image may be overwritten
+    }
+}
+
 // ============================== ILU0 factorisation =======================================================
 // One colour of the left-looking block ILU0 with stored inverse (detail::ghost_last_bilu0_decomposition,
 // linalg/ParallelOverlappingILU0.hpp:439-494): row i of A is staged in LDS and eliminated there against the
 // already finished rows j < i (their U part and D_j^-1 live in HBM, written by earlier colours), then split into
 // L, U and D^-1.
-__global__ __launch_bounds__(64) void k_ilu_factor(int tile_begin, const int* __restrict__ tile_row0,
+__global__ __launch_bounds__(64) void k_ilu_factor(int ct_begin, const int* __restrict__ ct_first, const int* __restrict__ tile_row0,
                                                    const int* __restrict__ rowptr, const int* __restrict__ col,
                                                    const int* __restrict__ diag, const double* __restrict__ A,
                                                    const int* __restrict__ lrowptr, const int* __restrict__ urowptr,
-                                                   const int* __restrict__ ucol, double* __restrict__ L,
-                                                   double* __restrict__ U, double* __restrict__ invD) {
+                                                   const int* __restrict__ ucol, double* L, double* U, double* invD) {
     TILE_LDS
-    const int lane = threadIdx.x, t = tile_begin + blockIdx.x;
-    const TileCtx T = tile_stage_values(t, tile_row0, rowptr, A, sval, lane);
-    const int i = T.r0 + lane;
-    if (i >= T.r1) return;
-    const int kb = rowptr[i], ke = rowptr[i + 1], kd = diag[i];
-    // an over-long row (not staged) is eliminated in a private copy held in the output arrays themselves:
-    // not supported in LDS-less form yet, such rows are rejected at set_pattern time.
-    double* row = &sval[(kb - T.k0e) * BB];
-    const int* rcol = &col[kb];
-    const int n = ke - kb, nd = kd - kb;
-    for (int a = 0; a < nd; ++a) {
-        const int j = rcol[a];
-        double Lij[BB], Dj[BB], tmp[BB];
+    const int lane = threadIdx.x;
+    const int q0 = ct_first[ct_begin + blockIdx.x], q1 = ct_first[ct_begin + blockIdx.x + 1];
+    for (int t = q0; t < q1; ++t) {  // steps of a chain-tile in order (a single step unless the ordering is line-coloured)
+        const TileCtx T = tile_stage_values(t, tile_row0, rowptr, A, sval, lane);
+        const int i = T.r0 + lane;
+        if (i < T.r1) {
+            const int kb = rowptr[i], ke = rowptr[i + 1], kd = diag[i];
+            // an over-long row (not staged) cannot be eliminated in LDS: such rows are rejected at set_pattern time
+            double* row = &sval[(kb - T.k0e) * BB];
+            const int* rcol = &col[kb];
+            const int n = ke - kb, nd = kd - kb;
+            for (int a = 0; a < nd; ++a) {
+                const int j = rcol[a];
+                double Lij[BB], Dj[BB], tmp[BB];
 #pragma unroll
-        for (int q = 0; q < BB; ++q) { tmp[q] = row[a * BB + q]; Dj[q] = invD[(size_t)j * BB + q]; }
-        blk_mul(tmp, Dj, Lij);  // A_ij * A_jj^-1
+                for (int q = 0; q < BB; ++q) { tmp[q] = row[a * BB + q]; Dj[q] = invD[(size_t)j * BB + q]; }
+                blk_mul(tmp, Dj, Lij);  // A_ij * A_jj^-1
 #pragma unroll
-        for (int q = 0; q < BB; ++q) row[a * BB + q] = Lij[q];
-        int jk = urowptr[j];
-        const int jend = urowptr[j + 1];
-        int ik = a + 1;
-        while (ik < n && jk < jend) {
-            const int ci = rcol[ik], cj = ucol[jk];
-            if (ci == cj) {
-                double Ujk[BB], P[BB];
+                for (int q = 0; q < BB; ++q) row[a * BB + q] = Lij[q];
+                int jk = urowptr[j];
+                const int jend = urowptr[j + 1];
+                int ik = a + 1;
+                while (ik < n && jk < jend) {
+                    const int ci = rcol[ik], cj = ucol[jk];
+                    if (ci == cj) {
+                        double Ujk[BB], P[BB];
 #pragma unroll
-                for (int q = 0; q < BB; ++q) Ujk[q] = U[(size_t)jk * BB + q];
-                blk_mul(Lij, Ujk, P);  // L_ij * A_jk
+                        for (int q = 0; q < BB; ++q) Ujk[q] = U[(size_t)jk * BB + q];
+                        blk_mul(Lij, Ujk, P);  // L_ij * A_jk
 #pragma unroll
-                for (int q = 0; q < BB; ++q) row[ik * BB + q] -= P[q];
-                ++ik; ++jk;
-            } else if (ci < cj) ++ik;
-            else ++jk;
+                        for (int q = 0; q < BB; ++q) row[ik * BB + q] -= P[q];
+                        ++ik; ++jk;
+                    } else if (ci < cj) ++ik;
+                    else ++jk;
+                }
+            }
+            double dblk[BB], inv[BB];
+#pragma unroll
+            for (int q = 0; q < BB; ++q) dblk[q] = row[nd * BB + q];
+            blk_invert(dblk, inv);
+#pragma unroll
+            for (int q = 0; q < BB; ++q) invD[(size_t)i * BB + q] = inv[q];
+            double* Lo = &L[(size_t)lrowptr[i] * BB];
+            for (int a = 0; a < nd * BB; ++a) Lo[a] = row[a];
+            double* Uo = &U[(size_t)urowptr[i] * BB];
+            for (int a = 0; a < (n - nd - 1) * BB; ++a) Uo[a] = row[(nd + 1) * BB + a];
         }
+        __syncthreads();  // factors of this step are visible to the next step of the chain; LDS reusable
     }
-    double dblk[BB], inv[BB];
-#pragma unroll
-    for (int q = 0; q < BB; ++q) dblk[q] = row[nd * BB + q];
-    blk_invert(dblk, inv);
-#pragma unroll
-    for (int q = 0; q < BB; ++q) invD[(size_t)i * BB + q] = inv[q];
-    double* Lo = &L[(size_t)lrowptr[i] * BB];
-    for (int a = 0; a < nd * BB; ++a) Lo[a] = row[a];
-    double* Uo = &U[(size_t)urowptr[i] * BB];
-    for (int a = 0; a < (n - nd - 1) * BB; ++a) Uo[a] = row[(nd + 1) * BB + a];
 }
 
 // ============================== standard wells ===========================================================
@@ -691,10 +737,10 @@ void launch_ilu_factor(opmhip_ctx* c) {
     const Pattern& P = c->pat;
     const int ps = prof_begin(c, PROF_ILU_FACTOR);
     for (int col = 0; col < P.numColors; ++col) {
-        const int tb = P.tiles.colorTile[col], te = P.tiles.colorTile[col + 1];
-        if (te > tb)
-            hipLaunchKernelGGL(k_ilu_factor, dim3(te - tb), dim3(64), 0, c->stream, tb, P.tiles.d_row0, P.d_rowptr, P.d_col, P.d_diag,
-                               c->d_A, P.d_lrowptr, P.d_urowptr, P.d_ucol, c->d_L, c->d_U, c->d_invD);
+        const int cb = P.tiles.colorCT[col], ce = P.tiles.colorCT[col + 1];
+        if (ce > cb)
+            hipLaunchKernelGGL(k_ilu_factor, dim3(ce - cb), dim3(64), 0, c->stream, cb, P.tiles.d_ctFirst, P.tiles.d_row0, P.d_rowptr, P.d_col,
+                               P.d_diag, c->d_A, P.d_lrowptr, P.d_urowptr, P.d_ucol, c->d_L, c->d_U, c->d_invD);
     }
     prof_end(c, ps);
 }
@@ -707,6 +753,22 @@ void launch_ilu_apply(opmhip_ctx* c, const double* d, double* v) {
     double* vu = (mode == OPMHIP_RELAX_POST_SCALE && w != 1.0) ? c->d_vu : v;
     const int n0 = P.colorPrefix[1];  // rows of the first colour: their y is d
     auto grid = [](int n) { return dim3(8 * ((n + 7) / 8)); };
+    if (P.chained) {
+        for (int col = 0; col < C; ++col) {
+            const int cb = P.tiles.colorCT[col], nct = P.tiles.colorCT[col + 1] - cb;
+            if (nct > 0)
+                hipLaunchKernelGGL(k_ilu_sweep_chain<SW_L>, grid(nct), dim3(64), 0, c->stream, cb, nct, P.tiles.d_ctFirst, P.tiles.d_row0, P.d_lrowptr,
+                                   P.d_lcol, c->d_L, c->d_invD, d, vu, v, mode, w);
+        }
+        for (int col = C - 1; col >= 0; --col) {
+            const int cb = P.tiles.colorCT[col], nct = P.tiles.colorCT[col + 1] - cb;
+            if (nct > 0)
+                hipLaunchKernelGGL(k_ilu_sweep_chain<SW_UF>, grid(nct), dim3(64), 0, c->stream, cb, nct, P.tiles.d_ctFirst, P.tiles.d_row0, P.d_urowptr,
+                                   P.d_ucol, c->d_U, c->d_invD, d, vu, v, mode, w);
+        }
+        prof_end(c, ps);
+        return;
+    }
     for (int col = 1; col < C; ++col) {
         const int tb = P.tiles.colorTile[col], nt = P.tiles.colorTile[col + 1] - tb;
         if (nt <= 0) continue;

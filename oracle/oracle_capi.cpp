@@ -352,6 +352,13 @@ int orc_bo_assemble(orc_model* h, double dt, int iteration, double* jac, double*
     if (residual) std::memcpy(residual, M.residual.data(), M.residual.size() * sizeof(double));
     return 0;
 }
+// the Jacobian / residual of the last orc_bo_assemble, without assembling again
+int orc_bo_assemble_fetch(orc_model* h, double* jac, double* residual) {
+    Model& M = h->M;
+    if (jac) std::memcpy(jac, M.J.val.data(), M.J.val.size() * sizeof(double));
+    if (residual) std::memcpy(residual, M.residual.data(), M.residual.size() * sizeof(double));
+    return 0;
+}
 // out[0..2] R_sum, [3..5] maxCoeff, [6..8] B_avg, [9] pvSum, [10] cnvErrorPv, [11..13] CNV, [14..16] MB
 int orc_bo_convergence(orc_model* h, double dt, double tol_cnv, double* out) {
     Model::Convergence c = h->M.convergence(dt, tol_cnv);

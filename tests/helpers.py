@@ -67,3 +67,18 @@ def random_block_system(Nb, pattern="tridiag", seed=0, extra=0):
         s = np.abs(val[ks]).sum(axis=(0, 2))
         val[dk][np.arange(3), np.arange(3)] = 1.5 * (s + 0.5)
     return Nb, rowptr, col, np.ascontiguousarray(val.reshape(-1))
+
+
+def oracle_solve_in_order(orc, Nb, rp, ci, val, b, to, fr, wells=None, **kw):
+    """ILU0-BiCGStab of the oracle on the system permuted by (toOrder, fromOrder) - the ordering the device reports
+    through opmhip_get_ordering - i.e. natural-order block ILU0 of reorderBlockedMatrixByPattern's matrix
+    (bda/Reorder.cpp:179-207), result mapped back to the natural order."""
+    rr, rc, rv = orc.reorder_matrix(Nb, rp, ci, val, to, fr)
+    rb = np.ascontiguousarray(b.reshape(Nb, 3)[fr].reshape(-1))
+    W = None
+    if wells:
+        W = dict(wells)
+        W["Ccols"] = np.ascontiguousarray(to[wells["Ccols"]], np.int32)
+        W["Bcols"] = np.ascontiguousarray(to[wells["Bcols"]], np.int32)
+    x, res = orc.solve(Nb, rr, rc, rv, rb, reorder="none", wells=W, **kw)
+    return np.ascontiguousarray(x.reshape(Nb, 3)[to].reshape(-1)), res

@@ -114,6 +114,7 @@ class OracleModel:
         L.orc_bo_assemble.argtypes = [_vp, C.c_double, C.c_int, _vp, _vp]
         L.orc_bo_convergence.argtypes = [_vp, C.c_double, C.c_double, _d]
         L.orc_bo_update.argtypes = [_vp, _d]
+        L.orc_bo_assemble_fetch.argtypes = [_vp, _vp, _vp]
         L.orc_bo_solve.argtypes = [_vp, _d, C.c_double, C.c_int, C.c_double, C.c_int, C.c_int, C.c_int, _vp,
                                    C.POINTER(OrcResult)]
         self.case = case
@@ -162,6 +163,14 @@ class OracleModel:
 
     def update(self, dx):
         return self.o.lib.orc_bo_update(self.h, np.ascontiguousarray(dx, np.float64))
+
+    def solve_in_order(self, to, fr, **kw):
+        """solveJacobianSystem with the ILU0 taken in the ordering (toOrder, fromOrder) the device reports."""
+        from helpers import oracle_solve_in_order
+        jac = np.empty(self.nnzb * 9)
+        res = np.empty(self.Nb * 3)
+        self.o.lib.orc_bo_assemble_fetch(self.h, _p(jac), _p(res))
+        return oracle_solve_in_order(self.o, self.Nb, self.case["rowptr"], self.case["col"], jac, res, to, fr, **kw)
 
     def solve(self, tol=1e-2, maxit=200, w=0.9, mode="post_scale", reorder="none", sub_start=None):
         x = np.zeros(self.Nb * 3)

@@ -8,7 +8,7 @@ import pytest
 import oracle_bind
 
 pytestmark = pytest.mark.gpu
-REORDERS = ["level_scheduling", "graph_coloring", "graph_coloring_greedy"]
+REORDERS = ["level_scheduling", "graph_coloring", "graph_coloring_greedy", "line_coloring"]
 
 
 def both(pkg, orc, case, reorder="graph_coloring_greedy", **kw):
@@ -123,7 +123,7 @@ def test_update_switching_matches_oracle(pkg, orc):
     assert (mm != case["meaning"]).any()
 
 
-@pytest.mark.parametrize("reorder", ["level_scheduling", "graph_coloring_greedy"])
+@pytest.mark.parametrize("reorder", ["level_scheduling", "graph_coloring_greedy", "line_coloring"])
 def test_newton_iterations_match_oracle(pkg, orc, reorder):
     """A full time step driven like BlackoilModelEbos::nonlinearIteration on both sides: same Newton and linear
     iteration counts, final pressures/saturations within 1e-7 relative (FP tolerance stated by the task: results
@@ -144,7 +144,7 @@ def test_newton_iterations_match_oracle(pkg, orc, reorder):
         if conv:
             break
         rm = m.solve_jacobian_system()
-        xo, ro = o.solve(reorder=reorder)
+        xo, ro = o.solve_in_order(*m.ordering()[:2])
         assert rm.converged and ro.converged
         lin_m.append(rm.it)
         lin_o.append(ro.it)
