@@ -115,7 +115,7 @@ def main():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--n", type=int, default=100, help="cells per edge of the per-GPU cube")
-    ap.add_argument("--reorder", default="graph_coloring_greedy")
+    ap.add_argument("--reorder", default="line_coloring")
     ap.add_argument("--chain-length", type=int, default=8, help="rows per chain of the line-coloured ILU0 ordering")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     a = ap.parse_args()

@@ -360,6 +360,9 @@ int build_pattern(opmhip_ctx* c, int Nb, int nnzb, const int* rows, const int* c
         T.colorCT.push_back((int)T.ctFirst.size());
         T.ctFirst.push_back((int)T.row0.size());
         T.row0.push_back(Nb);
+        for (size_t q = 0; q + 1 < T.ctFirst.size(); ++q)
+            if (T.ctFirst[q + 1] - T.ctFirst[q] > 128)
+                return fail(c, OPMHIP_ANALYSIS_FAILED, "line colouring: a chain-tile has %d steps (limit 128); lower the chain length", T.ctFirst[q + 1] - T.ctFirst[q]);
     }
 
     int rc;

@@ -110,6 +110,11 @@ __device__ __forceinline__ void blk_invert(const double* m, double* inv) {
     inv[7] = -(m[0] * m[7] - t12) * t17;
     inv[8] = (t4 - t8) * t17;
 }
+// The tile kernels run ONE wavefront per workgroup.  A wavefront's LDS instructions execute in issue order and its
+// global stores are visible to its own later loads once they have left the wave (same CU, write-through L1), so no
+// s_barrier is needed between "lanes wrote LDS" and "other lanes read it" - only the compiler must keep the order.
+// __syncthreads() would also work but it drains vmcnt(0), i.e. it waits for every prefetch that was just issued.
+__device__ __forceinline__ void wave_sync() { asm volatile("" ::: "memory"); }
 __device__ __forceinline__ double wave_sum(double v) {
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o, 64);
@@ -146,7 +151,7 @@ __device__ __forceinline__ TileCtx tile_stage_values(int t, const int* __restric
     T.nb = k1 - T.k0e;
     T.staged = (T.nb <= TILE_CAP_BLOCKS + 1);
     if (T.staged && T.nb > 0) stage_doubles(val + (size_t)T.k0e * BB, sval, T.nb * BB, lane);
-    __syncthreads();
+    wave_sync();
     return T;
 }
 
@@ -233,7 +238,7 @@ __device__ __forceinline__ int tile_row_product(int t, const int* __restrict__ t
             xx[u][0] = xc[0]; xx[u][1] = xc[1]; xx[u][2] = xc[2];
         }
     }
-    __syncthreads();
+    wave_sync();
     if (!active) return -1;
     // first chunk
 #pragma unroll
@@ -392,6 +397,7 @@ __global__ __launch_bounds__(64) void k_ilu_sweep(int tile_begin, int ntc, int n
 // a row may depend on earlier rows of its own chain, which the same workgroup wrote one step before - visible after
 // the workgroup barrier because a CU's L1 sees the CU's own write-through stores.  Chains of other colours are
 // finished (earlier launches).  No first-colour / last-colour shortcuts here: every colour has chain-internal L and U.
+constexpr int CHAIN_MAX_STEPS = 128;
 template <int SHAPE>  // SW_L or SW_UF
 __global__ __launch_bounds__(64) void k_ilu_sweep_chain(int ct_begin, int nct, const int* __restrict__ ct_first,
                                                         const int* __restrict__ tile_row0, const int* __restrict__ prow,
@@ -399,35 +405,184 @@ __global__ __launch_bounds__(64) void k_ilu_sweep_chain(int ct_begin, int nct, c
                                                         const double* __restrict__ invD, const double* __restrict__ d,
                                                         double* vu, double* v, int relax_mode, double w) {
     TILE_LDS
+    __shared__ int srow0[CHAIN_MAX_STEPS + 2], sk0[CHAIN_MAX_STEPS + 2];
     const int lane = threadIdx.x, cl = xcd_tile(blockIdx.x, nct);
     if (cl >= nct) return;
     const int q0 = ct_first[ct_begin + cl], q1 = ct_first[ct_begin + cl + 1];
+    const int nsteps = q1 - q0;  // <= CHAIN_MAX_STEPS (checked on the host)
     const bool reverse = (SHAPE == SW_UF) && relax_mode == 0;
-    for (int st = 0; st < q1 - q0; ++st) {
-        const int t = (SHAPE == SW_UF) ? q1 - 1 - st : q0 + st;
-        const int r0 = tile_row0[t], r1 = tile_row0[t + 1];
-        const int rq = (r0 + lane < r1) ? r0 + lane : r1 - 1;
-        const double* rsrc = (SHAPE == SW_L) ? d : vu;
-        double rhs[3] = {rsrc[(size_t)rq * BS], rsrc[(size_t)rq * BS + 1], rsrc[(size_t)rq * BS + 2]};
-        double Di[BB];
+    constexpr int U = 8;  // a step streams <= 32 rows x 3 blocks: 8 x 1 KiB per wavefront covers it in one batch
+    // row and entry offsets of every step of this chain-tile, once: two dependent hops here instead of per step
+    for (int i = lane; i <= nsteps; i += 64) {
+        const int r = tile_row0[q0 + i];
+        srow0[i] = r;
+        sk0[i] = prow[r];
+    }
+    wave_sync();
+    // Three-stage software pipeline over the steps (st counts in processing order; the backward sweep walks tiles
+    // q1-1 ... q0):   A(st+2): row bounds      B(st+1): columns, value stream, right-hand side, D^-1
+    //                 C(st)  : gathers of the sweep vector (the only loads that depend on step st-1), products, store
+    auto tile_of = [&](int st) { return (SHAPE == SW_UF) ? nsteps - 1 - st : st; };
+    struct StA { int rr, kb, ke; bool active; };
+    struct StB {
+        int r, kb, ke, k0e, n, n2;
+        bool staged;
+        int cc[GCH];
+        unsigned late;          // bit u set: column cc[u] lies inside this chain-tile (written by an earlier step)
+        double xx[GCH][3];      // vector entries of the other columns, fetched one step ahead
+        double rhs[3], Di[BB];
+        double2 tmp[U];
+    };
+    const int ctR0 = srow0[0], ctR1 = srow0[nsteps];  // rows of this chain-tile
+    auto stageA = [&](int st, StA& a) {
+        const int ti = tile_of(st);
+        const int r0 = srow0[ti], r1 = srow0[ti + 1];
+        a.active = r0 + lane < r1;
+        a.rr = a.active ? r0 + lane : r1 - 1;
+        a.kb = prow[a.rr];
+        a.ke = prow[a.rr + 1];
+    };
+    auto stageB = [&](int st, const StA& a, StB& b) {
+        const int ti = tile_of(st);
+        const int k0 = sk0[ti], k1 = sk0[ti + 1];
+        b.k0e = k0 & ~1;
+        const int nb = k1 - b.k0e;
+        b.staged = nb <= TILE_CAP_BLOCKS + 1;
+        b.n = nb * BB;
+        b.n2 = b.n >> 1;
+        b.r = a.active ? a.rr : -1;
+        b.kb = a.kb;
+        b.ke = a.active ? a.ke : a.kb;
+        const double* rsrc = (SHAPE == SW_L) ? d : vu;  // the lane's own row: no earlier step of this sweep writes it
+        b.rhs[0] = rsrc[(size_t)a.rr * BS]; b.rhs[1] = rsrc[(size_t)a.rr * BS + 1]; b.rhs[2] = rsrc[(size_t)a.rr * BS + 2];
         if (SHAPE != SW_L) {
 #pragma unroll
-            for (int q = 0; q < BB; ++q) Di[q] = invD[(size_t)rq * BB + q];
+            for (int q = 0; q < BB; ++q) b.Di[q] = invD[(size_t)a.rr * BB + q];
         }
-        TileCtx T;
-        const int r = tile_row_product<true>(t, tile_row0, prow, pcol, P, vu, sval, lane, reverse, rhs, T);
+        const int nrow = b.ke - b.kb;
+#pragma unroll
+        for (int u = 0; u < GCH; ++u) {
+            const int k = reverse ? b.ke - 1 - u : b.kb + u;
+            b.cc[u] = (u < nrow) ? pcol[k] : -1;
+        }
+#pragma unroll
+        for (int u = 0; u < GCH; ++u) asm volatile("" : "+v"(b.cc[u]));
+        if (b.staged && b.n2 > 0) {
+            const double2* __restrict__ s2 = reinterpret_cast<const double2*>(P + (size_t)b.k0e * BB);
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const int i = u * 64 + lane;
+                b.tmp[u] = s2[i < b.n2 ? i : b.n2 - 1];
+            }
+        }
+        b.late = 0u;
+#pragma unroll
+        for (int u = 0; u < GCH; ++u) {
+            const int cq = b.cc[u];
+            const bool inside = cq >= ctR0 && cq < ctR1;
+            if (inside) b.late |= 1u << u;
+            const double* xc = &vu[(size_t)((cq < 0 || inside) ? a.rr : cq) * BS];  // harmless own-row address when unused
+            b.xx[u][0] = xc[0]; b.xx[u][1] = xc[1]; b.xx[u][2] = xc[2];
+        }
+    };
+    StA a0, a1;
+    StB b;
+    int myPrevRow = -1;           // the row this lane finished in the previous step, and its result
+    double myPrev[3] = {0.0, 0.0, 0.0};
+    stageA(0, a0);
+    if (nsteps > 1) stageA(1, a1);
+    stageB(0, a0, b);
+    for (int st = 0; st < nsteps; ++st) {
+        // ---- C(st), part 1: commit the prefetched values to LDS
+#pragma unroll
+        for (int u = 0; u < U; ++u) asm volatile("" : "+v"(b.tmp[u].x), "+v"(b.tmp[u].y));
+        const int r = b.r, kb = b.kb, ke = b.ke, k0e = b.k0e, n = b.n, n2 = b.n2;
+        const bool staged = b.staged;
+        double rhs[3] = {b.rhs[0], b.rhs[1], b.rhs[2]};
+        double Di[BB];
+        int cc[GCH];
+        double xx[GCH][3];
+        const unsigned late = b.late;
+#pragma unroll
+        for (int q = 0; q < BB; ++q) Di[q] = b.Di[q];
+#pragma unroll
+        for (int u = 0; u < GCH; ++u) { cc[u] = b.cc[u]; xx[u][0] = b.xx[u][0]; xx[u][1] = b.xx[u][1]; xx[u][2] = b.xx[u][2]; }
+        double2* d2 = reinterpret_cast<double2*>(sval);
+        if (staged && n2 > 0) {
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const int i = u * 64 + lane;
+                if (i < n2) d2[i] = b.tmp[u];
+            }
+            const double2* __restrict__ s2 = reinterpret_cast<const double2*>(P + (size_t)k0e * BB);
+            for (int base = 64 * U; base < n2; base += 64)  // steps larger than one batch (irregular rows): plain copy
+                if (base + lane < n2) d2[base + lane] = s2[base + lane];
+            if ((n & 1) && lane == 0) sval[n - 1] = P[(size_t)k0e * BB + n - 1];
+        }
+        wave_sync();
+        // ---- B(st+1) and A(st+2) go out now and fly during this step's work
+        if (st + 1 < nsteps) {
+            stageB(st + 1, a1, b);
+            a0 = a1;
+            if (st + 2 < nsteps) stageA(st + 2, a1);
+        }
+        // ---- C(st), part 2: the few columns inside this chain-tile are read now (the previous step wrote them; the
+        //      lane's own previous row comes straight from registers), products in the row's sequential order, store
         if (r >= 0) {
+            const int nrow = ke - kb;
+            // a column inside this chain-tile that is NOT the lane's own previous row must come from memory: make sure
+            // the previous step's stores have completed first (never taken on a line-coloured 7-point stencil)
+            bool fromMem = false;
+#pragma unroll
+            for (int u = 0; u < GCH; ++u) fromMem |= (u < nrow && ((late >> u) & 1u) && cc[u] != myPrevRow);
+            if (__any(fromMem || nrow > GCH)) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#pragma unroll
+            for (int u = 0; u < GCH; ++u) {
+                if (u < nrow && ((late >> u) & 1u)) {
+                    if (cc[u] == myPrevRow) { xx[u][0] = myPrev[0]; xx[u][1] = myPrev[1]; xx[u][2] = myPrev[2]; }
+                    else { const double* xc = &vu[(size_t)cc[u] * BS]; xx[u][0] = xc[0]; xx[u][1] = xc[1]; xx[u][2] = xc[2]; }
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < GCH; ++u) {
+                if (u < nrow) {
+                    const int k = reverse ? ke - 1 - u : kb + u;
+                    const double* A = staged ? &sval[(k - k0e) * BB] : &P[(size_t)k * BB];
+                    blk_mmv(A, xx[u][0], xx[u][1], xx[u][2], rhs);
+                }
+            }
+            for (int done = GCH; done < nrow; done += GCH) {  // rows longer than one chunk: everything read now
+                double yy[GCH][3];
+#pragma unroll
+                for (int u = 0; u < GCH; ++u) {
+                    const int q = (done + u < nrow) ? done + u : nrow - 1;
+                    const int cq = pcol[reverse ? ke - 1 - q : kb + q];
+                    const double* xc = &vu[(size_t)cq * BS];
+                    yy[u][0] = xc[0]; yy[u][1] = xc[1]; yy[u][2] = xc[2];
+                }
+#pragma unroll
+                for (int u = 0; u < GCH; ++u) {
+                    if (done + u < nrow) {
+                        const int k = reverse ? ke - 1 - (done + u) : kb + done + u;
+                        const double* A = staged ? &sval[(k - k0e) * BB] : &P[(size_t)k * BB];
+                        blk_mmv(A, yy[u][0], yy[u][1], yy[u][2], rhs);
+                    }
+                }
+            }
             if (SHAPE == SW_L) {
                 vu[(size_t)r * BS] = rhs[0]; vu[(size_t)r * BS + 1] = rhs[1]; vu[(size_t)r * BS + 2] = rhs[2];
+                myPrev[0] = rhs[0]; myPrev[1] = rhs[1]; myPrev[2] = rhs[2];
             } else {
                 double out[3] = {0.0, 0.0, 0.0};
                 blk_umv(Di, rhs[0], rhs[1], rhs[2], out);
                 if (relax_mode == 1) { out[0] = w * out[0]; out[1] = w * out[1]; out[2] = w * out[2]; }
                 vu[(size_t)r * BS] = out[0]; vu[(size_t)r * BS + 1] = out[1]; vu[(size_t)r * BS + 2] = out[2];
                 if (v != vu) { v[(size_t)r * BS] = w * out[0]; v[(size_t)r * BS + 1] = w * out[1]; v[(size_t)r * BS + 2] = w * out[2]; }
+                myPrev[0] = out[0]; myPrev[1] = out[1]; myPrev[2] = out[2];
             }
+            myPrevRow = r;
         }
-        __syncthreads();  // this step's results are visible to the next step; LDS image may be overwritten
+        wave_sync();  // this step's results are visible to the next step; LDS image may be overwritten
     }
 }
 
@@ -489,7 +644,7 @@ __global__ __launch_bounds__(64) void k_ilu_factor(int ct_begin, const int* __re
             double* Uo = &U[(size_t)urowptr[i] * BB];
             for (int a = 0; a < (n - nd - 1) * BB; ++a) Uo[a] = row[(nd + 1) * BB + a];
         }
-        __syncthreads();  // factors of this step are visible to the next step of the chain; LDS reusable
+        __syncthreads();  // drains vmcnt: this step's factors (global stores) are complete before the next step reads them
     }
 }
 
