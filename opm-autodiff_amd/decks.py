@@ -122,3 +122,25 @@ def five_spot_source(case, rate_sm3_per_day=50.0):
         rs = case["pv"][3 * prod + 2] if case["meaning"][prod] == SW_PO_RS else float(rs_sat(case["fluid"], case["pv"][3 * prod + 1]))
         src[prod, 2] -= q * rs
     return np.ascontiguousarray(src.reshape(-1))
+
+
+def write_case_binary(case, path, source=None):
+    """Case file for the C++ host driver (opm-autodiff_amd/host/test_BlackoilModelHip.cpp): named raw arrays."""
+    import struct
+    fl = case["fluid"]
+    arrs = {k: case[k] for k in ("rowptr", "col", "trans", "area", "poro", "volume", "depth", "pv", "meaning")}
+    arrs.update(fl.arrays)
+    arrs["fluid_hdr"] = np.array([len(fl.pvt), len(fl.sat)], np.int32)
+    arrs["rock"] = np.array([fl.rock_pref, fl.rock_cr], np.float64)
+    if source is not None:
+        arrs["source"] = np.asarray(source, np.float64)
+    code = {np.dtype(np.int32): 0, np.dtype(np.float64): 1, np.dtype(np.uint8): 2}
+    with open(path, "wb") as f:
+        f.write(b"OPMHIPCASE1\0")
+        for name, a in arrs.items():
+            a = np.ascontiguousarray(a)
+            if a.dtype == np.int64:
+                a = a.astype(np.int32)
+            nb = name.encode()
+            f.write(struct.pack("<I", len(nb)) + nb + struct.pack("<BQ", code[a.dtype], a.size))
+            f.write(a.tobytes())

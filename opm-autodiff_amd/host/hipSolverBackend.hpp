@@ -1,0 +1,105 @@
+// bda::hipSolverBackend<3> : the BdaSolver<block_size> plugin a Flow build selects with --accelerator-mode=hip
+// (one more branch in BdaBridge's ctor, opm/simulators/linalg/bda/BdaBridge.cpp:65-120).  Header-only shim over the
+// C-ABI of libopmhip.so: no HIP types here, so it compiles with the host compiler of the reference.
+//
+// Behaviour kept from the existing backends (bda/cusparseSolverBackend.cu:480-499, bda/openclSolverBackend.cpp:783-805):
+//   - first solve_system(): analysis of the sparsity pattern (rows/cols are constant afterwards);
+//   - values and rhs are borrowed host memory, copied to the device on every call;
+//   - a failed analysis / factorisation is reported through SolverStatus, never thrown; device errors are
+//     std::logic_error like OPM_THROW(std::logic_error, ...) in bda/cuda_header.hpp:36-44;
+//   - a non-converged solve returns SUCCESS with res.converged == false and ISTLSolverEbos falls back to Dune
+//     (linalg/ISTLSolverEbos.hpp:277-297).
+#pragma once
+#ifdef OPMHIP_USE_OPM_HEADERS
+#include <opm/simulators/linalg/bda/BdaResult.hpp>
+#include <opm/simulators/linalg/bda/BdaSolver.hpp>
+#include <opm/simulators/linalg/bda/WellContributions.hpp>
+#else
+#include "BdaCompat.hpp"
+#endif
+#include <stdexcept>
+#include <string>
+
+#include "../../include/opmhip.h"
+
+namespace bda {
+
+template <unsigned int block_size>
+class hipSolverBackend : public BdaSolver<block_size> {
+    typedef BdaSolver<block_size> Base;
+    using Base::deviceID;
+    using Base::maxit;
+    using Base::tolerance;
+    using Base::verbosity;
+    opmhip_ctx* ctx = nullptr;
+    opmhip_wells wells{};
+    bool haveWells = false;
+
+public:
+    /// ilu_reorder as --opencl-ilu-reorder: "level_scheduling" | "graph_coloring" | "line_coloring"
+    hipSolverBackend(int linear_solver_verbosity, int maxit_, double tolerance_, unsigned int deviceID_,
+                     const std::string& ilu_reorder = "graph_coloring", double ilu_relaxation = 0.9)
+        : Base(linear_solver_verbosity, maxit_, tolerance_, deviceID_) {
+        static_assert(block_size == 3, "libopmhip handles 3x3 blocks (three-phase black-oil)");
+        opmhip_config cfg;
+        opmhip_default_config(&cfg);
+        cfg.verbosity = verbosity;
+        cfg.maxit = maxit;
+        cfg.tolerance = tolerance;
+        cfg.device_id = (int)deviceID;
+        cfg.ilu_relaxation = ilu_relaxation;
+        if (ilu_reorder == "level_scheduling") cfg.reorder = OPMHIP_REORDER_LEVEL_SCHEDULING;
+        else if (ilu_reorder == "graph_coloring" || ilu_reorder.empty()) cfg.reorder = OPMHIP_REORDER_GRAPH_COLORING;
+        else if (ilu_reorder == "line_coloring") cfg.reorder = OPMHIP_REORDER_LINE_COLORING;
+        else throw std::logic_error("Error invalid argument for --opencl-ilu-reorder, usage: '--opencl-ilu-reorder=[level_scheduling|graph_coloring|line_coloring]'");
+        const int rc = opmhip_create(&cfg, &ctx);
+        if (rc != OPMHIP_SUCCESS) throw std::logic_error(std::string("hipSolverBackend: ") + opmhip_last_error(nullptr));
+    }
+    ~hipSolverBackend() override { opmhip_destroy(ctx); }
+    hipSolverBackend(const hipSolverBackend&) = delete;
+    hipSolverBackend& operator=(const hipSolverBackend&) = delete;
+
+    SolverStatus solve_system(int N_, int nnz_, int dim, double* vals, int* rows, int* cols, double* b,
+                              WellContributions& wellContribs, BdaResult& res) override {
+        opmhip_wells* wp = nullptr;
+        if (wellContribs.getNumWells() > 0) {
+            wells.num_wells = (int)wellContribs.getNumWells();
+#ifndef OPMHIP_USE_OPM_HEADERS
+            wells.val_pointers = wellContribs.valPointers.data();
+            wells.Ccols = wellContribs.Ccols.data();
+            wells.Bcols = wellContribs.Bcols.data();
+            wells.Cnnzs = wellContribs.Cnnzs.data();
+            wells.Dnnzs = wellContribs.Dnnzs.data();
+            wells.Bnnzs = wellContribs.Bnnzs.data();
+#else
+            // with the reference's WellContributions the host-side arrays are reached through the accessors the
+            // patch in INTEGRATION.md adds (the class keeps them private for the CUDA/OpenCL paths)
+            wellContribs.getHostArrays(&wells.val_pointers, &wells.Ccols, &wells.Bcols, &wells.Cnnzs, &wells.Dnnzs, &wells.Bnnzs);
+#endif
+            wp = &wells;
+        }
+        opmhip_result r;
+        const int rc = opmhip_solve_system(ctx, N_, nnz_, dim, vals, rows, cols, b, wp, &r);
+        res.iterations = r.iterations;
+        res.reduction = r.reduction;
+        res.converged = r.converged != 0;
+        res.conv_rate = r.conv_rate;
+        res.elapsed = r.elapsed;
+        this->initialized = true;
+        switch (rc) {
+        case OPMHIP_SUCCESS: return SolverStatus::BDA_SOLVER_SUCCESS;
+        case OPMHIP_ANALYSIS_FAILED: return SolverStatus::BDA_SOLVER_ANALYSIS_FAILED;
+        case OPMHIP_CREATE_PRECONDITIONER_FAILED: return SolverStatus::BDA_SOLVER_CREATE_PRECONDITIONER_FAILED;
+        case OPMHIP_DEVICE_ERROR:
+        case OPMHIP_NO_DEVICE: throw std::logic_error(std::string("hipSolverBackend: ") + opmhip_last_error(ctx));
+        default: return SolverStatus::BDA_SOLVER_UNKNOWN_ERROR;
+        }
+    }
+
+    void get_result(double* x) override {
+        if (opmhip_get_result(ctx, x) != OPMHIP_SUCCESS) throw std::logic_error(std::string("hipSolverBackend::get_result: ") + opmhip_last_error(ctx));
+    }
+    opmhip_ctx* context() { return ctx; }
+};
+
+}  // namespace bda

@@ -1,0 +1,78 @@
+// Counterpart of the reference's tests/test_cusparseSolver.cpp:49-131 for the HIP backend: read matr33.txt / rhs3.txt
+// (MatrixMarket, ISTL_STRUCT blocked 3 3), run bda::hipSolverBackend<3>::solve_system + get_result with tol / maxit
+// from the command line, print the solution.  The expected vector is checked by the calling pytest
+// (tests/test_gpu_host_cpp.py) against the fixture in tests/golden/linalg/expected.json.
+//   usage: test_hipSolver matr33.txt rhs3.txt tol maxit reorder
+#include <cstdio>
+#include <cstdlib>
+#include <fstream>
+#include <iostream>
+#include <memory>
+#include <map>
+#include <sstream>
+
+#include "hipSolverBackend.hpp"
+
+static bool readBlocked(const std::string& file, int& Nb, std::vector<int>& rows, std::vector<int>& cols, std::vector<double>& vals) {
+    std::ifstream f(file);
+    if (!f) return false;
+    std::string line;
+    int bs = 1;
+    while (std::getline(f, line) && !line.empty() && line[0] == '%') {
+        if (line.find("ISTL_STRUCT") != std::string::npos) { std::istringstream is(line); std::string a, b, c; is >> a >> b >> c >> bs; }
+    }
+    int n, m, nnz;
+    std::istringstream(line) >> n >> m >> nnz;
+    std::map<std::pair<int, int>, std::vector<double>> blocks;
+    for (int e = 0; e < nnz; ++e) {
+        int r, c; double v;
+        f >> r >> c >> v; --r; --c;
+        auto& b = blocks[{r / bs, c / bs}];
+        if (b.empty()) b.assign(bs * bs, 0.0);
+        b[(r % bs) * bs + c % bs] = v;
+    }
+    Nb = n / bs;
+    rows.assign(Nb + 1, 0);
+    for (auto& kv : blocks) rows[kv.first.first + 1]++;
+    for (int i = 0; i < Nb; ++i) rows[i + 1] += rows[i];
+    for (auto& kv : blocks) { cols.push_back(kv.first.second); vals.insert(vals.end(), kv.second.begin(), kv.second.end()); }
+    return bs == 3;
+}
+static bool readVector(const std::string& file, std::vector<double>& b) {
+    std::ifstream f(file);
+    if (!f) return false;
+    std::string line;
+    while (std::getline(f, line) && !line.empty() && line[0] == '%') {}
+    int n, one;
+    std::istringstream(line) >> n >> one;
+    b.resize(n);
+    for (auto& v : b) f >> v;
+    return true;
+}
+
+int main(int argc, char** argv) {
+    if (argc < 6) { std::fprintf(stderr, "usage: %s matrix rhs tol maxit reorder\n", argv[0]); return 2; }
+    int Nb;
+    std::vector<int> rows, cols;
+    std::vector<double> vals, rhs;
+    if (!readBlocked(argv[1], Nb, rows, cols, vals)) throw std::runtime_error("Could not read matrix file");
+    if (!readVector(argv[2], rhs)) throw std::runtime_error("Could not read rhs file");
+    const double tolerance = std::atof(argv[3]);
+    const int maxit = std::atoi(argv[4]);
+    std::unique_ptr<bda::hipSolverBackend<3>> backend;
+    try {
+        backend.reset(new bda::hipSolverBackend<3>(/*verbosity=*/0, maxit, tolerance, /*deviceID=*/0, argv[5], /*w=*/1.0));
+    } catch (const std::logic_error& error) {
+        std::fprintf(stderr, "Problem with initializing a device: %s\n", error.what());  // the reference skips here
+        return 77;
+    }
+    Opm::WellContributions wellContribs;
+    bda::BdaResult result;
+    std::vector<double> x(rhs.size());
+    const bda::SolverStatus st = backend->solve_system(3 * Nb, 9 * (int)cols.size(), 3, vals.data(), rows.data(), cols.data(), rhs.data(), wellContribs, result);
+    if (st != bda::SolverStatus::BDA_SOLVER_SUCCESS) return 3;
+    backend->get_result(x.data());
+    std::printf("converged %d iterations %d reduction %.17g\n", (int)result.converged, result.iterations, result.reduction);
+    for (double v : x) std::printf("%.17g\n", v);
+    return 0;
+}
