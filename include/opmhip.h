@@ -111,6 +111,13 @@ int opmhip_abi_version(void);
  * the context (linalg/ISTLSolverEbos.hpp:216-219).  Computes the ILU ordering, the device tiling and uploads
  * the index arrays. */
 int opmhip_set_pattern(opmhip_ctx* ctx, int Nb, int nnzb, const int* rows, const int* cols);
+/* Domain-decomposed variant (one context per GPU, one subdomain per context): the matrix has Nb owned block rows; columns
+ * may also reference Nghost ghost cells numbered Nb .. Nb+Nghost-1 - the owner-cells-first local ordering the reference
+ * requires of parallel runs (linalg/ISTLSolverEbos.hpp:171-178).  Ghost columns take part in the operator (SpMV) and in
+ * the assembly; the ILU0 is block-Jacobi per subdomain and ignores them, like detail::ghost_last_bilu0_decomposition
+ * (linalg/ParallelOverlappingILU0.hpp:439-494, loop bounds :857-860).  Per-cell state/static arrays then have
+ * Nb+Nghost entries, solver vectors (rhs, x, residual) Nb. */
+int opmhip_set_pattern_dd(opmhip_ctx* ctx, int Nb, int Nghost, int nnzb, const int* rows, const int* cols);
 
 /* replaces: bda::BdaSolver<3>::solve_system(N, nnz, dim, vals, rows, cols, b, wellContribs, res)
  * (bda/BdaSolver.hpp:86-88).  N = 3*Nb scalar rows, nnz = 9*nnzb scalars, dim = 3.  If the pattern was not set
@@ -216,6 +223,31 @@ int opmhip_convergence(opmhip_ctx* ctx, double dt, double tol_cnv, double* out);
  * dx == NULL uses the solution of the last opmhip_solve_system, which is still on the device.
  * num_switched (nullable) receives the number of cells whose meaning changed. */
 int opmhip_update(opmhip_ctx* ctx, const double* dx, double relax, int* num_switched);
+
+/* ---- domain decomposition over the GPUs of a node (restricted additive Schwarz) --------------------------------- */
+/* The reference's parallel runs are MPI domain decomposition with block-Jacobi/overlapping ILU0 and halo updates
+ * through Dune::OwnerOverlapCopyCommunication (linalg/ISTLSolverEbos.hpp:101-105, 171-178;
+ * linalg/ParallelOverlappingILU0.hpp:857-860, 897; flow/BlackoilModelEbos.hpp:599-603); its accelerator back-ends are
+ * switched off under MPI (linalg/ISTLSolverEbos.hpp:136-141), so this surface is new.  One process per GPU, one context
+ * per process; set_pattern_dd describes the subdomain.  Communication runs on the context's stream with RCCL
+ * (ncclSend/ncclRecv per neighbour for halos, ncclAllReduce for the fused scalars).
+ *   rank 0: opmhip_comm_unique_id(id) -> broadcast the 128 bytes by any means (MPI_Bcast, torch.distributed, a file)
+ *   every rank: opmhip_comm_init_rccl(ctx, nranks, rank, id) ; opmhip_set_halo(...) */
+int opmhip_comm_unique_id(char* id128);
+int opmhip_comm_init_rccl(opmhip_ctx* ctx, int nranks, int rank, const char* id128);
+/* several contexts inside ONE process (each driven by its own host thread, all on one GPU), connected by device copies
+ * and a host barrier: test vehicle for the decomposition logic on a single GPU */
+int opmhip_comm_init_loopback(opmhip_ctx* ctx, int nranks, int rank, const char* group_name);
+/* optional, before opmhip_set_static: the global id of every local cell (Nb + Nghost entries).  The assembly then adds a
+ * row's face fluxes in ascending GLOBAL neighbour order, i.e. exactly the sum an undecomposed run forms, so that
+ * residual and Jacobian do not depend on the decomposition down to the last bit. */
+int opmhip_set_cell_global_ids(opmhip_ctx* ctx, const long long* gids);
+/* halo description: for neighbour q (rank neigh_rank[q]) the owned cells send_cells[send_ptr[q] .. send_ptr[q+1])
+ * (local natural ids, in the order the neighbour numbers its ghosts) are sent, and ghost cells
+ * Nb + recv_ptr[q] .. Nb + recv_ptr[q+1] are received.  global_cells = number of cells of the whole grid (B_avg is a
+ * mean over all cells, flow/BlackoilModelEbos.hpp:722-727). */
+int opmhip_set_halo(opmhip_ctx* ctx, long long global_cells, int nneigh, const int* neigh_rank, const int* send_ptr,
+                    const int* send_cells, const int* recv_ptr);
 
 /* ---- measurement -------------------------------------------------------------------------------------------- */
 /* Device-side timing per kernel class with HIP events recorded on the context's own stream, so that bench.py can

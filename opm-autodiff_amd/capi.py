@@ -211,6 +211,19 @@ class HipSolver:
         return ms.value
 
 
+def comm_unique_id():
+    """128-byte RCCL unique id (rank 0 creates it, the launcher broadcasts it)."""
+    L = lib()
+    if not getattr(L, "_asm_bound", False):
+        _bind_assembly(L)
+        L._asm_bound = True
+    buf = C.create_string_buffer(128)
+    rc = L.opmhip_comm_unique_id(buf)
+    if rc != SUCCESS:
+        raise OpmHipError(rc, "opmhip_comm_unique_id failed (librccl not loadable?)")
+    return buf.raw
+
+
 def _bind_assembly(L):
     vp = C.c_void_p
     L.opmhip_set_fluid.argtypes = [vp, vp]
@@ -222,6 +235,12 @@ def _bind_assembly(L):
     L.opmhip_get_iq.argtypes = [vp, vp]
     L.opmhip_convergence.argtypes = [vp, C.c_double, C.c_double, vp]
     L.opmhip_update.argtypes = [vp, vp, C.c_double, C.POINTER(C.c_int)]
+    L.opmhip_set_pattern_dd.argtypes = [vp, C.c_int, C.c_int, C.c_int, vp, vp]
+    L.opmhip_comm_unique_id.argtypes = [C.c_char_p]
+    L.opmhip_comm_init_rccl.argtypes = [vp, C.c_int, C.c_int, C.c_char_p]
+    L.opmhip_comm_init_loopback.argtypes = [vp, C.c_int, C.c_int, C.c_char_p]
+    L.opmhip_set_halo.argtypes = [vp, C.c_longlong, C.c_int, vp, vp, vp, vp]
+    L.opmhip_set_cell_global_ids.argtypes = [vp, vp]
 
 
 class HipModel(HipSolver):
@@ -229,14 +248,35 @@ class HipModel(HipSolver):
     BlackoilModelEbos (assembleReservoir -> getReservoirConvergence -> solveJacobianSystem -> updateSolution,
     opm/simulators/flow/BlackoilModelEbos.hpp:274-392) with every array resident in HBM between the calls."""
 
-    def __init__(self, case, **solver_kw):
+    def __init__(self, case, comm=None, **solver_kw):
+        """comm (decomposed runs; case from ras.cartesian_subdomain_case / ras.local_problem):
+        ("rccl", nranks, rank, id128) or ("loopback", nranks, rank, group_name)."""
         super().__init__(**solver_kw)
         L = lib()
         if not getattr(L, "_asm_bound", False):
             _bind_assembly(L)
             L._asm_bound = True
         self.case = case
-        self.set_pattern(case["Nb"], case["rowptr"], case["col"])
+        self.Nghost = int(case.get("Nghost", 0))
+        if self.Nghost or comm:
+            rows, cols = _i32(case["rowptr"]), _i32(case["col"])
+            self._check(L.opmhip_set_pattern_dd(self._h, case["Nb"], self.Nghost, len(cols), _ptr(rows), _ptr(cols)))
+            self.Nb, self.nnzb = case["Nb"], len(cols)
+            if case.get("gids") is not None:
+                g64 = np.ascontiguousarray(case["gids"], np.int64)
+                self._check(L.opmhip_set_cell_global_ids(self._h, _ptr(g64)))
+            if comm:
+                kind, nranks, rank, tok = comm
+                if kind == "rccl":
+                    self._check(L.opmhip_comm_init_rccl(self._h, nranks, rank, tok))
+                else:
+                    self._check(L.opmhip_comm_init_loopback(self._h, nranks, rank, tok.encode()))
+                h = case["halo"]
+                keep = [_i32(h["neigh"]), _i32(h["send_ptr"]), _i32(h["send_cells"]), _i32(h["recv_ptr"])]
+                self._check(L.opmhip_set_halo(self._h, int(case["global_cells"]), len(keep[0]), *[_ptr(k) for k in keep]))
+        else:
+            self.set_pattern(case["Nb"], case["rowptr"], case["col"])
+        self.Nloc = self.Nb + self.Nghost
         self._fd = case["fluid"].desc()
         self._check(L.opmhip_set_fluid(self._h, C.addressof(self._fd)))
         g = lambda k, f: _ptr(f(case[k])) if case.get(k) is not None else None
@@ -252,8 +292,8 @@ class HipModel(HipSolver):
         self._check(lib().opmhip_set_state(self._h, _ptr(pv), _ptr(meaning)))
 
     def get_state(self):
-        pv = np.empty(3 * self.Nb)
-        m = np.empty(self.Nb, np.uint8)
+        pv = np.empty(3 * self.Nloc)
+        m = np.empty(self.Nloc, np.uint8)
         self._check(lib().opmhip_get_state(self._h, _ptr(pv), _ptr(m)))
         return pv, m
 
@@ -269,9 +309,9 @@ class HipModel(HipSolver):
         return jac, res
 
     def iq(self):
-        out = np.empty(self.Nb * 17 * 4)
+        out = np.empty(self.Nloc * 17 * 4)
         self._check(lib().opmhip_get_iq(self._h, _ptr(out)))
-        return out.reshape(self.Nb, 17, 4)
+        return out.reshape(self.Nloc, 17, 4)
 
     def convergence(self, dt, tol_cnv=1e-2):
         out = np.empty(17)

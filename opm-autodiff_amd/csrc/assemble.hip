@@ -241,9 +241,9 @@ struct CellStatic {
 };
 
 // invalidateAndUpdateIntensiveQuantities(0): one lane per cell
-__global__ __launch_bounds__(256) void k_iq_update(int Nb, Tables T, CellStatic C, const double* __restrict__ pv,
+__global__ __launch_bounds__(256) void k_iq_update(int c0, int Nb, Tables T, CellStatic C, const double* __restrict__ pv,
                                                    const unsigned char* __restrict__ meaning, double* __restrict__ iq) {
-    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    const int c = c0 + blockIdx.x * blockDim.x + threadIdx.x;  // cells [c0, Nb)
     if (c >= Nb) return;
     const double x[3] = {pv[(size_t)c * 3], pv[(size_t)c * 3 + 1], pv[(size_t)c * 3 + 2]};
     Iq<Ad> q;
@@ -506,6 +506,16 @@ __global__ __launch_bounds__(256) void k_conv_pass1(int Nb, CellStatic C, const 
     }
 }
 // one workgroup: reduce the block partials in a fixed order; out[0..9] as above with B_avg divided by Nb
+// decomposed runs: the local results are combined over the ranks (sum of R_sum, sum(1/b), pvSum; max of maxCoeff:
+// convergenceReduction, flow/BlackoilModelEbos.hpp:572-625) before B_avg is formed with the GLOBAL cell count (:722-727)
+__global__ void k_conv_pack(const double* __restrict__ out, double* __restrict__ red) {
+    if (threadIdx.x < 3) { red[threadIdx.x] = out[threadIdx.x]; red[3 + threadIdx.x] = out[6 + threadIdx.x]; red[8 + threadIdx.x] = out[3 + threadIdx.x]; }
+    if (threadIdx.x == 0) red[6] = out[9];
+}
+__global__ void k_conv_unpack(const double* __restrict__ red, double global_cells, double* __restrict__ out) {
+    if (threadIdx.x < 3) { out[threadIdx.x] = red[threadIdx.x]; out[6 + threadIdx.x] = red[3 + threadIdx.x] / global_cells; out[3 + threadIdx.x] = red[8 + threadIdx.x]; }
+    if (threadIdx.x == 0) out[9] = red[6];
+}
 __global__ __launch_bounds__(256) void k_conv_final1(int nblocks, int Nb, const double* __restrict__ part, double* __restrict__ out) {
     __shared__ double sh[10][256];
     double a[10];
@@ -527,7 +537,7 @@ __global__ __launch_bounds__(256) void k_conv_final1(int nblocks, int Nb, const 
     }
     if (threadIdx.x < 10) {
         double v = sh[threadIdx.x][0];
-        if (threadIdx.x >= 6 && threadIdx.x < 9) v /= (double)Nb;
+        if (threadIdx.x >= 6 && threadIdx.x < 9 && Nb > 0) v /= (double)Nb;  // Nb <= 0: keep the raw sum (decomposed run)
         out[threadIdx.x] = v;
     }
 }
@@ -593,10 +603,20 @@ static CellStatic cells_of(const opmhip_ctx* c) {
 }
 
 void launch_iq_update(opmhip_ctx* c) {
-    const int Nb = c->pat.Nb;
+    const int Nb = c->pat.Nloc;  // ghost cells too: their intensive quantities feed the faces towards them
     const int ps = prof_begin(c, PROF_IQ_UPDATE);
-    hipLaunchKernelGGL(k_iq_update, dim3(cdiv(Nb, 256)), dim3(256), 0, c->stream, Nb, tables_of(c), cells_of(c), c->asmb.d_pv, c->asmb.d_meaning, c->asmb.d_iq);
+    hipLaunchKernelGGL(k_iq_update, dim3(cdiv(Nb, 256)), dim3(256), 0, c->stream, 0, Nb, tables_of(c), cells_of(c), c->asmb.d_pv, c->asmb.d_meaning, c->asmb.d_iq);
     prof_end(c, ps);
+}
+// after a Newton update in a decomposed run: ghost primary variables come from their owners, then their IQs are redone
+int launch_ghost_refresh(opmhip_ctx* c) {
+    if (c->comm.nranks <= 1 || c->pat.Nghost == 0) return OPMHIP_SUCCESS;
+    int rc;
+    if ((rc = comm_halo_f64(c, c->asmb.d_pv, 3))) return rc;
+    if ((rc = comm_halo_u8(c, c->asmb.d_meaning))) return rc;
+    const int Nb = c->pat.Nb, Nloc = c->pat.Nloc;
+    hipLaunchKernelGGL(k_iq_update, dim3(cdiv(Nloc - Nb, 256)), dim3(256), 0, c->stream, Nb, Nloc, tables_of(c), cells_of(c), c->asmb.d_pv, c->asmb.d_meaning, c->asmb.d_iq);
+    return OPMHIP_SUCCESS;
 }
 void launch_newton_update(opmhip_ctx* c, const double* d_dx, double relax) {
     const int Nb = c->pat.Nb;
@@ -618,20 +638,28 @@ void launch_convergence(opmhip_ctx* c, double dt, double tol_cnv) {
     const int Nb = c->pat.Nb, nb = cdiv(Nb, 256);
     const int ps = prof_begin(c, PROF_CONVERGENCE);
     hipLaunchKernelGGL(k_conv_pass1, dim3(nb), dim3(256), 0, c->stream, Nb, cells_of(c), c->asmb.d_iq, c->d_b, c->asmb.d_conv_part);
-    hipLaunchKernelGGL(k_conv_final1, dim3(1), dim3(256), 0, c->stream, nb, Nb, c->asmb.d_conv_part, c->asmb.d_conv_out);
+    const bool dd = c->comm.nranks > 1;
+    hipLaunchKernelGGL(k_conv_final1, dim3(1), dim3(256), 0, c->stream, nb, dd ? 0 : Nb, c->asmb.d_conv_part, c->asmb.d_conv_out);
+    if (dd) {
+        hipLaunchKernelGGL(k_conv_pack, dim3(1), dim3(64), 0, c->stream, c->asmb.d_conv_out, c->comm.d_red);
+        (void)comm_allreduce(c, c->comm.d_red, 7, 0);
+        (void)comm_allreduce(c, c->comm.d_red + 8, 3, 1);
+        hipLaunchKernelGGL(k_conv_unpack, dim3(1), dim3(64), 0, c->stream, c->comm.d_red, (double)c->comm.global_cells, c->asmb.d_conv_out);
+    }
     hipLaunchKernelGGL(k_conv_pass2, dim3(nb), dim3(256), 0, c->stream, Nb, cells_of(c), c->d_b, c->asmb.d_conv_out, dt, tol_cnv, c->asmb.d_conv_part);
     hipLaunchKernelGGL(k_conv_final2, dim3(1), dim3(256), 0, c->stream, nb, c->asmb.d_conv_part, c->asmb.d_conv_out);
+    if (dd) (void)comm_allreduce(c, c->asmb.d_conv_out + 10, 1, 0);
     prof_end(c, ps);
 }
 void launch_u8_to_internal(opmhip_ctx* c, const unsigned char* nat, unsigned char* internal) {
-    hipLaunchKernelGGL(k_cellvec_to_internal_u8, dim3(cdiv(c->pat.Nb, 256)), dim3(256), 0, c->stream, c->pat.Nb, c->pat.d_fromOrder, nat, internal);
+    hipLaunchKernelGGL(k_cellvec_to_internal_u8, dim3(cdiv(c->pat.Nloc, 256)), dim3(256), 0, c->stream, c->pat.Nloc, c->pat.d_fromOrder, nat, internal);
 }
 void launch_u8_to_natural(opmhip_ctx* c, const unsigned char* internal, unsigned char* nat) {
-    hipLaunchKernelGGL(k_cellvec_to_natural_u8, dim3(cdiv(c->pat.Nb, 256)), dim3(256), 0, c->stream, c->pat.Nb, c->pat.d_toOrder, internal, nat);
+    hipLaunchKernelGGL(k_cellvec_to_natural_u8, dim3(cdiv(c->pat.Nloc, 256)), dim3(256), 0, c->stream, c->pat.Nloc, c->pat.d_toOrder, internal, nat);
 }
 void launch_iq_to_natural(opmhip_ctx* c, double* d_nat) {
-    const size_t n = (size_t)c->pat.Nb * IQS;
-    hipLaunchKernelGGL(k_iq_to_natural, dim3(cdiv(n, 256)), dim3(256), 0, c->stream, c->pat.Nb, c->pat.d_toOrder, c->asmb.d_iq, d_nat);
+    const size_t n = (size_t)c->pat.Nloc * IQS;
+    hipLaunchKernelGGL(k_iq_to_natural, dim3(cdiv(n, 256)), dim3(256), 0, c->stream, c->pat.Nloc, c->pat.d_toOrder, c->asmb.d_iq, d_nat);
 }
 void launch_unpermute_blocks(opmhip_ctx* c, const double* internal, double* nat) {
     const size_t n = (size_t)c->pat.nnzb * BB;

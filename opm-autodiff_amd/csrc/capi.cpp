@@ -17,7 +17,7 @@ double now() {
 
 int alloc_system(opmhip_ctx* c) {
     const Pattern& P = c->pat;
-    const size_t n = (size_t)P.Nb * BS;
+    const size_t n = (size_t)P.Nloc * BS;  // vectors carry the ghost cells at their tail (SpMV / assembly gathers)
     int rc;
     if ((rc = dev_alloc(c, &c->d_A, (size_t)P.nnzb * BB))) return rc;
     if ((rc = dev_alloc(c, &c->d_L, (size_t)P.nl * BB))) return rc;
@@ -178,6 +178,7 @@ void opmhip_destroy(opmhip_ctx* c) {
     if (!c) return;
     (void)hipSetDevice(c->device);
     if (c->stream) (void)hipStreamSynchronize(c->stream);
+    comm_release(c);
     for (void* p : c->allocs) (void)hipFree(p);
     if (c->h_pinned) (void)hipHostFree(c->h_pinned);
     if (c->ev0) (void)hipEventDestroy(c->ev0);
@@ -190,11 +191,15 @@ void opmhip_destroy(opmhip_ctx* c) {
 const char* opmhip_last_error(const opmhip_ctx* c) { return c ? c->err.c_str() : g_err.c_str(); }
 
 int opmhip_set_pattern(opmhip_ctx* c, int Nb, int nnzb, const int* rows, const int* cols) {
+    return opmhip_set_pattern_dd(c, Nb, 0, nnzb, rows, cols);
+}
+
+int opmhip_set_pattern_dd(opmhip_ctx* c, int Nb, int Nghost, int nnzb, const int* rows, const int* cols) {
     if (!c) return OPMHIP_INVALID_ARGUMENT;
     return guarded(c, [&]() -> int {
         if (c->pattern_set) return fail(c, OPMHIP_NOT_READY, "set_pattern: the pattern of a context is immutable (linalg/ISTLSolverEbos.hpp:216-219)");
         OPMHIP_HIP(c, hipSetDevice(c->device));
-        int rc = build_pattern(c, Nb, nnzb, rows, cols);
+        int rc = build_pattern(c, Nb, Nghost, nnzb, rows, cols);
         if (rc) return rc;
         for (int i = 0; i < Nb; ++i)
             if (rows[i + 1] - rows[i] > TILE_CAP_BLOCKS)
@@ -285,6 +290,7 @@ int opmhip_spmv(opmhip_ctx* c, const double* x, double* y) {
         OPMHIP_HIP(c, hipSetDevice(c->device));
         int rc;
         if ((rc = vec_in(c, x, c->d_pw))) return rc;
+        if ((rc = comm_halo_f64(c, c->d_pw, BS))) return rc;
         launch_spmv(c, c->d_pw, c->d_v, 0, nullptr, nullptr);
         OPMHIP_HIP(c, hipGetLastError());
         return vec_out(c, c->d_v, y);

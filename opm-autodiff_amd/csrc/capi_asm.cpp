@@ -24,8 +24,8 @@ int guarded(opmhip_ctx* c, F&& f) {
 // host-side permutation of a per-cell array natural -> internal
 template <class T>
 std::vector<T> cells_to_internal(const Pattern& P, const T* nat, int width = 1) {
-    std::vector<T> v((size_t)P.Nb * width);
-    for (int p = 0; p < P.Nb; ++p)
+    std::vector<T> v((size_t)P.Nloc * width);
+    for (int p = 0; p < P.Nloc; ++p)
         for (int q = 0; q < width; ++q) v[(size_t)p * width + q] = nat[(size_t)P.fromOrder[p] * width + q];
     return v;
 }
@@ -91,6 +91,7 @@ int opmhip_set_static(opmhip_ctx* c, const double* trans, const double* area, co
             for (int i = 0; i < P.Nb; ++i)
                 for (int k = P.nat_rowptr[i]; k < P.nat_rowptr[i + 1]; ++k) {
                     const int j = P.nat_col[k];
+                    if (j >= P.Nb) { tr[k] = k; continue; }  // ghost column: its row lives on the neighbouring subdomain
                     const int* b = &P.nat_col[P.nat_rowptr[j]];
                     const int* e = &P.nat_col[P.nat_rowptr[j + 1]];
                     const int* q = std::lower_bound(b, e, i);
@@ -101,7 +102,7 @@ int opmhip_set_static(opmhip_ctx* c, const double* trans, const double* area, co
                 if (trans[k] != trans[tr[k]] || area[k] != area[tr[k]] || (thpres && thpres[k] != thpres[tr[k]]))
                     return fail(c, OPMHIP_INVALID_ARGUMENT, "set_static: trans/area/thpres differ between entry %d and its transpose", k);
         }
-        for (int i = 0; i < P.Nb; ++i) {
+        for (int i = 0; i < P.Nloc; ++i) {
             if (!(volume[i] > 0.0) || !(poro[i] >= 0.0)) return fail(c, OPMHIP_INVALID_ARGUMENT, "set_static: cell %d has non-positive volume or negative porosity", i);
             if (pvtnum && (pvtnum[i] < 0 || pvtnum[i] >= A.num_pvt)) return fail(c, OPMHIP_INVALID_ARGUMENT, "set_static: pvtnum[%d] out of range", i);
             if (satnum && (satnum[i] < 0 || satnum[i] >= A.num_sat)) return fail(c, OPMHIP_INVALID_ARGUMENT, "set_static: satnum[%d] out of range", i);
@@ -117,7 +118,7 @@ int opmhip_set_static(opmhip_ctx* c, const double* trans, const double* area, co
         if (satnum) { if ((rc = upload_cells(c, &A.d_satnum, satnum))) return rc; } else A.d_satnum = nullptr;
         if (rsmax) { if ((rc = upload_cells(c, &A.d_rsmax, rsmax))) return rc; } else A.d_rsmax = nullptr;
         if (!A.d_pv) {
-            const size_t Nb = P.Nb;
+            const size_t Nb = P.Nloc;  // per-cell state includes the ghost cells
             if ((rc = dev_alloc(c, &A.d_pv, Nb * 3))) return rc;
             if ((rc = dev_alloc(c, &A.d_iq, Nb * (size_t)iq_doubles_per_cell()))) return rc;
             if ((rc = dev_alloc(c, &A.d_storageOld, Nb * 3))) return rc;
@@ -152,7 +153,11 @@ int opmhip_set_static(opmhip_ctx* c, const double* trans, const double* area, co
             for (int p = 0; p < P.Nb; ++p) {
                 const int b = P.rowptr[p], e = P.rowptr[p + 1];
                 for (int k = b; k < e; ++k) natOrder[k] = k;
-                std::sort(natOrder.begin() + b, natOrder.begin() + e, [&](int x, int y) { return P.nnzMap[x] < P.nnzMap[y]; });
+                if (P.gids.empty())
+                    std::sort(natOrder.begin() + b, natOrder.begin() + e, [&](int x, int y) { return P.nnzMap[x] < P.nnzMap[y]; });
+                else  // decomposed run: ascending GLOBAL neighbour id (natural local id of a column = fromOrder[internal col])
+                    std::sort(natOrder.begin() + b, natOrder.begin() + e,
+                              [&](int x, int y) { return P.gids[P.fromOrder[P.col[x]]] < P.gids[P.fromOrder[P.col[y]]]; });
             }
             if ((rc = dev_upload(c, &A.d_natOrder, natOrder))) return rc;
         }
@@ -166,15 +171,15 @@ int opmhip_set_state(opmhip_ctx* c, const double* pv, const unsigned char* meani
     return guarded(c, [&]() -> int {
         if (!c->asmb.static_set) return fail(c, OPMHIP_NOT_READY, "set_state before set_static");
         if (!pv || !meaning) return fail(c, OPMHIP_INVALID_ARGUMENT, "set_state: null array");
-        for (int i = 0; i < c->pat.Nb; ++i)
+        for (int i = 0; i < c->pat.Nloc; ++i)
             if (meaning[i] > OPMHIP_SW_PO_RS) return fail(c, OPMHIP_INVALID_ARGUMENT, "set_state: meaning[%d] = %d is not supported (dry gas: Sw_po_Sg or Sw_po_Rs)", i, (int)meaning[i]);
         OPMHIP_HIP(c, hipSetDevice(c->device));
         AsmDev& A = c->asmb;
-        OPMHIP_HIP(c, hipMemcpyAsync(c->d_stageV, pv, (size_t)c->pat.Nb * 3 * sizeof(double), hipMemcpyHostToDevice, c->stream));
-        launch_vec_to_internal(c, c->d_stageV, A.d_pv);
-        OPMHIP_HIP(c, hipMemcpyAsync(A.d_stage_u8, meaning, (size_t)c->pat.Nb, hipMemcpyHostToDevice, c->stream));
+        OPMHIP_HIP(c, hipMemcpyAsync(c->d_stageV, pv, (size_t)c->pat.Nloc * 3 * sizeof(double), hipMemcpyHostToDevice, c->stream));
+        launch_vec_to_internal(c, c->d_stageV, A.d_pv, c->pat.Nloc);
+        OPMHIP_HIP(c, hipMemcpyAsync(A.d_stage_u8, meaning, (size_t)c->pat.Nloc, hipMemcpyHostToDevice, c->stream));
         launch_u8_to_internal(c, A.d_stage_u8, A.d_meaning);
-        OPMHIP_HIP(c, hipMemsetAsync(A.d_wasSwitched, 0, c->pat.Nb, c->stream));
+        OPMHIP_HIP(c, hipMemsetAsync(A.d_wasSwitched, 0, c->pat.Nloc, c->stream));
         launch_iq_update(c);
         OPMHIP_HIP(c, hipGetLastError());
         OPMHIP_HIP(c, hipStreamSynchronize(c->stream));
@@ -190,12 +195,12 @@ int opmhip_get_state(opmhip_ctx* c, double* pv, unsigned char* meaning) {
         OPMHIP_HIP(c, hipSetDevice(c->device));
         AsmDev& A = c->asmb;
         if (pv) {
-            launch_vec_to_natural(c, A.d_pv, c->d_stageV);
-            OPMHIP_HIP(c, hipMemcpyAsync(pv, c->d_stageV, (size_t)c->pat.Nb * 3 * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+            launch_vec_to_natural(c, A.d_pv, c->d_stageV, c->pat.Nloc);
+            OPMHIP_HIP(c, hipMemcpyAsync(pv, c->d_stageV, (size_t)c->pat.Nloc * 3 * sizeof(double), hipMemcpyDeviceToHost, c->stream));
         }
         if (meaning) {
             launch_u8_to_natural(c, A.d_meaning, A.d_stage_u8);
-            OPMHIP_HIP(c, hipMemcpyAsync(meaning, A.d_stage_u8, (size_t)c->pat.Nb, hipMemcpyDeviceToHost, c->stream));
+            OPMHIP_HIP(c, hipMemcpyAsync(meaning, A.d_stage_u8, (size_t)c->pat.Nloc, hipMemcpyDeviceToHost, c->stream));
         }
         OPMHIP_HIP(c, hipStreamSynchronize(c->stream));
         return OPMHIP_SUCCESS;
@@ -208,7 +213,7 @@ int opmhip_set_source(opmhip_ctx* c, const double* source, const double* dsource
         if (!c->asmb.static_set) return fail(c, OPMHIP_NOT_READY, "set_source before set_static");
         OPMHIP_HIP(c, hipSetDevice(c->device));
         AsmDev& A = c->asmb;
-        const size_t Nb = c->pat.Nb;
+        const size_t Nb = c->pat.Nloc;
         int rc;
         if (source) { if ((rc = upload_cells(c, &A.d_source, source, 3))) return rc; }
         else OPMHIP_HIP(c, hipMemset(A.d_source, 0, Nb * 3 * sizeof(double)));
@@ -249,7 +254,7 @@ int opmhip_get_iq(opmhip_ctx* c, double* out) {
         if (!out) return fail(c, OPMHIP_INVALID_ARGUMENT, "get_iq: out == NULL");
         OPMHIP_HIP(c, hipSetDevice(c->device));
         launch_iq_to_natural(c, c->asmb.d_stage_cell);
-        OPMHIP_HIP(c, hipMemcpyAsync(out, c->asmb.d_stage_cell, (size_t)c->pat.Nb * iq_doubles_per_cell() * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+        OPMHIP_HIP(c, hipMemcpyAsync(out, c->asmb.d_stage_cell, (size_t)c->pat.Nloc * iq_doubles_per_cell() * sizeof(double), hipMemcpyDeviceToHost, c->stream));
         OPMHIP_HIP(c, hipStreamSynchronize(c->stream));
         return OPMHIP_SUCCESS;
     });
@@ -289,6 +294,8 @@ int opmhip_update(opmhip_ctx* c, const double* dx, double relax, int* num_switch
             d_dx = c->d_t;
         }
         launch_newton_update(c, d_dx, relax);
+        int rcg = launch_ghost_refresh(c);
+        if (rcg) return rcg;
         OPMHIP_HIP(c, hipGetLastError());
         if (num_switched) {
             OPMHIP_HIP(c, hipMemcpyAsync(num_switched, c->asmb.d_nswitched, sizeof(int), hipMemcpyDeviceToHost, c->stream));

@@ -1,0 +1,272 @@
+// Domain-decomposed (restricted additive Schwarz / block-Jacobi ILU0) variant: what the reference does over MPI with
+// Dune::OwnerOverlapCopyCommunication (linalg/ISTLSolverEbos.hpp:101-105): `copyOwnerToAll` halo updates
+// (linalg/ParallelOverlappingILU0.hpp:897,906-911; linalg/WellOperators.hpp:200-240) and scalar all-reduces inside the
+// scalar products, plus the convergence reduction `comm.sum(7) / comm.max(3)` (flow/BlackoilModelEbos.hpp:599-603).
+// Here: one context per GPU, one process per GPU; halos travel with ncclSend/ncclRecv grouped per neighbour and the
+// scalars with one small ncclAllReduce, all on the context's stream (RCCL over xGMI).  RCCL is dlopen'ed so that the
+// library also loads where no RCCL exists (single-GPU use).  A second backend, "loopback", connects several contexts of
+// ONE process (one host thread each) through device-to-device copies and a host barrier: it exists so that the whole
+// decomposition logic can be tested on a single GPU (tests/test_gpu_dd.py).
+#include <dlfcn.h>
+#include <hip/hip_runtime.h>
+#include <pthread.h>
+#include <rccl/rccl.h>
+
+#include <map>
+#include <mutex>
+
+#include "internal.hpp"
+
+namespace opmhip {
+
+// ---- RCCL entry points, resolved at run time -------------------------------------------------------------------
+struct RcclApi {
+    void* lib = nullptr;
+    ncclResult_t (*GetUniqueId)(ncclUniqueId*) = nullptr;
+    ncclResult_t (*CommInitRank)(ncclComm_t*, int, ncclUniqueId, int) = nullptr;
+    ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
+    ncclResult_t (*AllReduce)(const void*, void*, size_t, ncclDataType_t, ncclRedOp_t, ncclComm_t, hipStream_t) = nullptr;
+    ncclResult_t (*Send)(const void*, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
+    ncclResult_t (*Recv)(void*, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
+    ncclResult_t (*GroupStart)() = nullptr;
+    ncclResult_t (*GroupEnd)() = nullptr;
+    const char* (*GetErrorString)(ncclResult_t) = nullptr;
+};
+static RcclApi g_rccl;
+static std::mutex g_rccl_mutex;
+
+static const char* load_rccl() {
+    std::lock_guard<std::mutex> lk(g_rccl_mutex);
+    if (g_rccl.lib) return nullptr;
+    const char* names[] = {"librccl.so", "librccl.so.1", "/opt/rocm/lib/librccl.so.1"};
+    void* h = dlopen("librccl.so", RTLD_NOW | RTLD_NOLOAD);  // the copy the host process already loaded, if any
+    for (int i = 0; !h && i < 3; ++i) h = dlopen(names[i], RTLD_NOW | RTLD_LOCAL);
+    if (!h) return "librccl.so not found (dlopen)";
+#define SYM(f, name) *(void**)(&g_rccl.f) = dlsym(h, name); if (!g_rccl.f) return "RCCL symbol missing: " name;
+    SYM(GetUniqueId, "ncclGetUniqueId") SYM(CommInitRank, "ncclCommInitRank") SYM(CommDestroy, "ncclCommDestroy")
+    SYM(AllReduce, "ncclAllReduce") SYM(Send, "ncclSend") SYM(Recv, "ncclRecv") SYM(GroupStart, "ncclGroupStart")
+    SYM(GroupEnd, "ncclGroupEnd") SYM(GetErrorString, "ncclGetErrorString")
+#undef SYM
+    g_rccl.lib = h;
+    return nullptr;
+}
+
+// ---- loopback group: contexts of one process ---------------------------------------------------------------------
+struct LoopGroup {
+    int nranks = 0, joined = 0;
+    pthread_barrier_t barrier;
+    std::vector<opmhip_ctx*> members;
+    std::vector<std::vector<double>> scratch;  // [rank][<=16]
+};
+static std::map<std::string, LoopGroup*> g_groups;
+static std::mutex g_groups_mutex;
+
+// ---- kernels -----------------------------------------------------------------------------------------------------
+__global__ void k_pack_f64(int n, int w, const int* __restrict__ idx, const double* __restrict__ vec, double* __restrict__ buf) {
+    const int e = blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= n * w) return;
+    buf[e] = vec[(size_t)idx[e / w] * w + e % w];
+}
+__global__ void k_pack_u8(int n, const int* __restrict__ idx, const unsigned char* __restrict__ vec, unsigned char* __restrict__ buf) {
+    const int e = blockIdx.x * blockDim.x + threadIdx.x;
+    if (e < n) buf[e] = vec[idx[e]];
+}
+
+#define NCCLCHK(c, call)                                                                                              \
+    do {                                                                                                              \
+        ncclResult_t r_ = (call);                                                                                     \
+        if (r_ != ncclSuccess) return fail(c, OPMHIP_DEVICE_ERROR, "%s failed: %s", #call, g_rccl.GetErrorString(r_)); \
+    } while (0)
+
+// sum (op 0) / max (op 1) of n <= 16 doubles over all ranks, in place, result identical on every rank
+int comm_allreduce(opmhip_ctx* c, double* d_buf, int n, int op) {
+    CommDev& C = c->comm;
+    if (C.nranks <= 1) return OPMHIP_SUCCESS;
+    if (C.kind == COMM_RCCL) {
+        NCCLCHK(c, g_rccl.AllReduce(d_buf, d_buf, (size_t)n, ncclDouble, op == 0 ? ncclSum : ncclMax, (ncclComm_t)C.nccl, c->stream));
+        return OPMHIP_SUCCESS;
+    }
+    LoopGroup* G = (LoopGroup*)C.group;
+    OPMHIP_HIP(c, hipMemcpyAsync(G->scratch[C.rank].data(), d_buf, n * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+    OPMHIP_HIP(c, hipStreamSynchronize(c->stream));
+    pthread_barrier_wait(&G->barrier);
+    double acc[16];
+    for (int i = 0; i < n; ++i) {
+        double a = G->scratch[0][i];
+        for (int r = 1; r < C.nranks; ++r) a = (op == 0) ? a + G->scratch[r][i] : (a > G->scratch[r][i] ? a : G->scratch[r][i]);
+        acc[i] = a;  // fixed rank order: every rank forms the same bits
+    }
+    pthread_barrier_wait(&G->barrier);
+    OPMHIP_HIP(c, hipMemcpyAsync(d_buf, acc, n * sizeof(double), hipMemcpyHostToDevice, c->stream));
+    OPMHIP_HIP(c, hipStreamSynchronize(c->stream));
+    return OPMHIP_SUCCESS;
+}
+
+// ghost entries of `vec` (w doubles per cell, internal order, ghosts at cells Nb..) <- owners' values
+int comm_halo_f64(opmhip_ctx* c, double* vec, int w) {
+    CommDev& C = c->comm;
+    if (C.nranks <= 1 || C.nneigh == 0) return OPMHIP_SUCCESS;
+    const int nsend = C.send_ptr[C.nneigh];
+    if (nsend > 0)
+        hipLaunchKernelGGL(k_pack_f64, dim3((nsend * w + 255) / 256), dim3(256), 0, c->stream, nsend, w, C.d_send_idx, vec, C.d_sendbuf);
+    double* ghost0 = vec + (size_t)c->pat.Nb * w;
+    if (C.kind == COMM_RCCL) {
+        NCCLCHK(c, g_rccl.GroupStart());
+        for (int q = 0; q < C.nneigh; ++q) {
+            NCCLCHK(c, g_rccl.Send(C.d_sendbuf + (size_t)C.send_ptr[q] * w, (size_t)(C.send_ptr[q + 1] - C.send_ptr[q]) * w, ncclDouble, C.neigh[q], (ncclComm_t)C.nccl, c->stream));
+            NCCLCHK(c, g_rccl.Recv(ghost0 + (size_t)C.recv_ptr[q] * w, (size_t)(C.recv_ptr[q + 1] - C.recv_ptr[q]) * w, ncclDouble, C.neigh[q], (ncclComm_t)C.nccl, c->stream));
+        }
+        NCCLCHK(c, g_rccl.GroupEnd());
+        return OPMHIP_SUCCESS;
+    }
+    LoopGroup* G = (LoopGroup*)C.group;
+    OPMHIP_HIP(c, hipStreamSynchronize(c->stream));
+    pthread_barrier_wait(&G->barrier);  // every rank's send buffer is packed
+    for (int q = 0; q < C.nneigh; ++q) {
+        const opmhip_ctx* peer = G->members[C.neigh[q]];
+        const CommDev& PC = peer->comm;
+        int me = -1;
+        for (int t = 0; t < PC.nneigh; ++t)
+            if (PC.neigh[t] == C.rank) me = t;
+        if (me < 0 || PC.send_ptr[me + 1] - PC.send_ptr[me] != C.recv_ptr[q + 1] - C.recv_ptr[q])
+            return fail(c, OPMHIP_INVALID_ARGUMENT, "halo lists of ranks %d and %d do not match", C.rank, C.neigh[q]);
+        OPMHIP_HIP(c, hipMemcpyAsync(ghost0 + (size_t)C.recv_ptr[q] * w, PC.d_sendbuf + (size_t)PC.send_ptr[me] * w,
+                                     (size_t)(C.recv_ptr[q + 1] - C.recv_ptr[q]) * w * sizeof(double), hipMemcpyDeviceToDevice, c->stream));
+    }
+    OPMHIP_HIP(c, hipStreamSynchronize(c->stream));
+    pthread_barrier_wait(&G->barrier);  // nobody repacks before every copy is done
+    return OPMHIP_SUCCESS;
+}
+
+int comm_halo_u8(opmhip_ctx* c, unsigned char* vec) {
+    CommDev& C = c->comm;
+    if (C.nranks <= 1 || C.nneigh == 0) return OPMHIP_SUCCESS;
+    const int nsend = C.send_ptr[C.nneigh];
+    if (nsend > 0) hipLaunchKernelGGL(k_pack_u8, dim3((nsend + 255) / 256), dim3(256), 0, c->stream, nsend, C.d_send_idx, vec, C.d_sendbuf_u8);
+    unsigned char* ghost0 = vec + c->pat.Nb;
+    if (C.kind == COMM_RCCL) {
+        NCCLCHK(c, g_rccl.GroupStart());
+        for (int q = 0; q < C.nneigh; ++q) {
+            NCCLCHK(c, g_rccl.Send(C.d_sendbuf_u8 + C.send_ptr[q], (size_t)(C.send_ptr[q + 1] - C.send_ptr[q]), ncclUint8, C.neigh[q], (ncclComm_t)C.nccl, c->stream));
+            NCCLCHK(c, g_rccl.Recv(ghost0 + C.recv_ptr[q], (size_t)(C.recv_ptr[q + 1] - C.recv_ptr[q]), ncclUint8, C.neigh[q], (ncclComm_t)C.nccl, c->stream));
+        }
+        NCCLCHK(c, g_rccl.GroupEnd());
+        return OPMHIP_SUCCESS;
+    }
+    LoopGroup* G = (LoopGroup*)C.group;
+    OPMHIP_HIP(c, hipStreamSynchronize(c->stream));
+    pthread_barrier_wait(&G->barrier);
+    for (int q = 0; q < C.nneigh; ++q) {
+        const CommDev& PC = G->members[C.neigh[q]]->comm;
+        int me = -1;
+        for (int t = 0; t < PC.nneigh; ++t)
+            if (PC.neigh[t] == C.rank) me = t;
+        if (me < 0) return fail(c, OPMHIP_INVALID_ARGUMENT, "halo lists of ranks %d and %d do not match", C.rank, C.neigh[q]);
+        OPMHIP_HIP(c, hipMemcpyAsync(ghost0 + C.recv_ptr[q], PC.d_sendbuf_u8 + PC.send_ptr[me], (size_t)(C.recv_ptr[q + 1] - C.recv_ptr[q]),
+                                     hipMemcpyDeviceToDevice, c->stream));
+    }
+    OPMHIP_HIP(c, hipStreamSynchronize(c->stream));
+    pthread_barrier_wait(&G->barrier);
+    return OPMHIP_SUCCESS;
+}
+
+void comm_release(opmhip_ctx* c) {
+    CommDev& C = c->comm;
+    if (C.kind == COMM_RCCL && C.nccl && g_rccl.CommDestroy) (void)g_rccl.CommDestroy((ncclComm_t)C.nccl);
+    C.nccl = nullptr;
+    C.kind = COMM_NONE;
+}
+
+}  // namespace opmhip
+
+using namespace opmhip;
+
+extern "C" {
+
+int opmhip_comm_unique_id(char* id128) {
+    if (!id128) return OPMHIP_INVALID_ARGUMENT;
+    const char* e = load_rccl();
+    if (e) return OPMHIP_DEVICE_ERROR;
+    ncclUniqueId id;
+    if (g_rccl.GetUniqueId(&id) != ncclSuccess) return OPMHIP_DEVICE_ERROR;
+    std::memcpy(id128, id.internal, NCCL_UNIQUE_ID_BYTES);
+    return OPMHIP_SUCCESS;
+}
+
+int opmhip_comm_init_rccl(opmhip_ctx* c, int nranks, int rank, const char* id128) {
+    if (!c || !id128 || nranks < 1 || rank < 0 || rank >= nranks) return OPMHIP_INVALID_ARGUMENT;
+    const char* e = load_rccl();
+    if (e) return fail(c, OPMHIP_DEVICE_ERROR, "comm_init_rccl: %s", e);
+    OPMHIP_HIP(c, hipSetDevice(c->device));
+    ncclUniqueId id;
+    std::memcpy(id.internal, id128, NCCL_UNIQUE_ID_BYTES);
+    ncclComm_t comm;
+    NCCLCHK(c, g_rccl.CommInitRank(&comm, nranks, id, rank));
+    c->comm.kind = COMM_RCCL;
+    c->comm.nccl = comm;
+    c->comm.nranks = nranks;
+    c->comm.rank = rank;
+    return OPMHIP_SUCCESS;
+}
+
+int opmhip_comm_init_loopback(opmhip_ctx* c, int nranks, int rank, const char* group_name) {
+    if (!c || !group_name || nranks < 1 || rank < 0 || rank >= nranks) return OPMHIP_INVALID_ARGUMENT;
+    std::lock_guard<std::mutex> lk(g_groups_mutex);
+    LoopGroup*& G = g_groups[group_name];
+    if (!G) {
+        G = new LoopGroup();
+        G->nranks = nranks;
+        G->members.assign(nranks, nullptr);
+        G->scratch.assign(nranks, std::vector<double>(16, 0.0));
+        pthread_barrier_init(&G->barrier, nullptr, (unsigned)nranks);
+    }
+    if (G->nranks != nranks || G->members[rank]) return fail(c, OPMHIP_INVALID_ARGUMENT, "comm_init_loopback: group '%s' mismatch", group_name);
+    G->members[rank] = c;
+    c->comm.kind = COMM_LOOPBACK;
+    c->comm.group = G;
+    c->comm.nranks = nranks;
+    c->comm.rank = rank;
+    return OPMHIP_SUCCESS;
+}
+
+int opmhip_set_cell_global_ids(opmhip_ctx* c, const long long* gids) {
+    if (!c || !gids) return OPMHIP_INVALID_ARGUMENT;
+    if (!c->pattern_set) return fail(c, OPMHIP_NOT_READY, "set_cell_global_ids before set_pattern");
+    c->pat.gids.assign(gids, gids + c->pat.Nloc);
+    return OPMHIP_SUCCESS;
+}
+
+int opmhip_set_halo(opmhip_ctx* c, long long global_cells, int nneigh, const int* neigh_rank, const int* send_ptr,
+                    const int* send_cells, const int* recv_ptr) {
+    if (!c) return OPMHIP_INVALID_ARGUMENT;
+    if (!c->pattern_set) return fail(c, OPMHIP_NOT_READY, "set_halo before set_pattern");
+    if (global_cells < c->pat.Nb || nneigh < 0 || (nneigh > 0 && (!neigh_rank || !send_ptr || !send_cells || !recv_ptr)))
+        return fail(c, OPMHIP_INVALID_ARGUMENT, "set_halo: bad arguments");
+    OPMHIP_HIP(c, hipSetDevice(c->device));
+    CommDev& C = c->comm;
+    C.global_cells = global_cells;
+    C.nneigh = nneigh;
+    C.neigh.assign(neigh_rank, neigh_rank + nneigh);
+    C.send_ptr.assign(1, 0);
+    C.recv_ptr.assign(1, 0);
+    if (nneigh > 0) {
+        C.send_ptr.assign(send_ptr, send_ptr + nneigh + 1);
+        C.recv_ptr.assign(recv_ptr, recv_ptr + nneigh + 1);
+    }
+    const int nsend = C.send_ptr[nneigh];
+    if (C.recv_ptr[nneigh] != c->pat.Nghost) return fail(c, OPMHIP_INVALID_ARGUMENT, "set_halo: recv ranges cover %d ghost cells, pattern has %d", C.recv_ptr[nneigh], c->pat.Nghost);
+    std::vector<int> idx(nsend);
+    for (int q = 0; q < nsend; ++q) {
+        if (send_cells[q] < 0 || send_cells[q] >= c->pat.Nb) return fail(c, OPMHIP_INVALID_ARGUMENT, "set_halo: send cell %d is not an owned cell", send_cells[q]);
+        idx[q] = c->pat.toOrder[send_cells[q]];  // natural local id -> internal position
+    }
+    int rc;
+    if ((rc = dev_upload(c, &C.d_send_idx, idx))) return rc;
+    if ((rc = dev_alloc(c, &C.d_sendbuf, (size_t)std::max(nsend, 1) * 3))) return rc;
+    if ((rc = dev_alloc(c, &C.d_sendbuf_u8, (size_t)std::max(nsend, 1)))) return rc;
+    if ((rc = dev_alloc(c, &C.d_red, (size_t)16))) return rc;
+    C.halo_set = true;
+    return OPMHIP_SUCCESS;
+}
+
+}  // extern "C"

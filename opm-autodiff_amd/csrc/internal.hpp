@@ -4,6 +4,7 @@
 
 #include <cstdarg>
 #include <cstdio>
+#include <cstring>
 #include <string>
 #include <vector>
 
@@ -41,7 +42,8 @@ struct TileSet {            // tiles over one block-CSR row-pointer array, never
 };
 
 struct Pattern {
-    int Nb = 0, nnzb = 0, numColors = 0, nl = 0, nu = 0;
+    int Nb = 0, nnzb = 0, numColors = 0, nl = 0, nu = 0;  // Nb = owned block rows
+    int Nghost = 0, Nloc = 0;                            // ghost cells numbered Nb..Nloc-1 (vectors have Nloc entries)
     bool chained = false;  // line colouring: rows of one colour may depend on earlier rows of their own chain
     // natural order (as handed over)
     std::vector<int> nat_rowptr, nat_col;
@@ -50,6 +52,7 @@ struct Pattern {
     // internal (reordered) pattern
     std::vector<int> rowptr, col, diag, nnzMap;  // nnzMap[k_internal] = k_natural
     std::vector<int> lrowptr, lcol, urowptr, ucol;
+    std::vector<long long> gids;  // optional: global id of every local cell (decomposed runs), natural local order
     TileSet tiles;
     // device copies
     int *d_rowptr = nullptr, *d_col = nullptr, *d_diag = nullptr, *d_nnzMap = nullptr;
@@ -83,6 +86,22 @@ struct AsmDev {
     double *d_conv_part = nullptr, *d_conv_out = nullptr;
     double* d_stage_cell = nullptr;   // staging for per-cell doubles (natural order), Nb * max(9, IQS)
     double* d_stage_entry = nullptr;  // staging for per-entry doubles (natural order), nnzb
+};
+
+// domain decomposition: communicator + halo lists (comm.hip)
+enum CommKind { COMM_NONE = 0, COMM_LOOPBACK = 1, COMM_RCCL = 2 };
+struct CommDev {
+    int kind = COMM_NONE, nranks = 1, rank = 0;
+    void* nccl = nullptr;    // ncclComm_t
+    void* group = nullptr;   // LoopGroup*
+    long long global_cells = 0;
+    bool halo_set = false;
+    int nneigh = 0;
+    std::vector<int> neigh, send_ptr, recv_ptr;  // per neighbour: rank, send range (into d_send_idx), ghost range
+    int* d_send_idx = nullptr;                   // owned cells (internal positions) to send, grouped by neighbour
+    double* d_sendbuf = nullptr;                 // 3 doubles per send cell
+    unsigned char* d_sendbuf_u8 = nullptr;
+    double* d_red = nullptr;                     // 16 doubles: all-reduce buffer
 };
 
 // per-kernel-class device timing with HIP events on the context's stream (opmhip_profile_*)
@@ -125,6 +144,7 @@ struct opmhip_ctx {
     double* h_pinned = nullptr;  // SC_COUNT doubles, pinned
     opmhip::WellsDev wells;
     opmhip::AsmDev asmb;
+    opmhip::CommDev comm;
     opmhip::Profiler prof;
     std::vector<void*> allocs;
 };
@@ -189,13 +209,13 @@ inline void prof_end(opmhip_ctx* c, int slot) {
 }
 
 // reorder.cpp (host): level scheduling / colouring, internal pattern, L/U split, tiles
-int build_pattern(opmhip_ctx* c, int Nb, int nnzb, const int* rows, const int* cols);
+int build_pattern(opmhip_ctx* c, int Nb, int Nghost, int nnzb, const int* rows, const int* cols);
 
 // kernels.hip launchers (all on c->stream)
 void launch_permute_blocks(opmhip_ctx* c, const double* nat, double* internal);
 void launch_unpermute_blocks(opmhip_ctx* c, const double* internal, double* nat);  // for lu_out
-void launch_vec_to_internal(opmhip_ctx* c, const double* nat, double* internal);
-void launch_vec_to_natural(opmhip_ctx* c, const double* internal, double* nat);
+void launch_vec_to_internal(opmhip_ctx* c, const double* nat, double* internal, int cells = -1);
+void launch_vec_to_natural(opmhip_ctx* c, const double* internal, double* nat, int cells = -1);
 void launch_zero_diag_fix(opmhip_ctx* c);
 void launch_spmv(opmhip_ctx* c, const double* x, double* y, int ndot, const double* w0, const double* w1);
 void launch_ilu_factor(opmhip_ctx* c);
@@ -203,8 +223,14 @@ void launch_ilu_apply(opmhip_ctx* c, const double* d, double* v);
 void launch_wells_apply(opmhip_ctx* c, const double* x, double* y);
 void launch_lu_to_natural(opmhip_ctx* c, double* d_out_internal_layout);
 int bicgstab(opmhip_ctx* c, opmhip_result* res);
+// comm.hip
+int comm_allreduce(opmhip_ctx* c, double* d_buf, int n, int op /*0 sum, 1 max*/);
+int comm_halo_f64(opmhip_ctx* c, double* vec, int w);
+int comm_halo_u8(opmhip_ctx* c, unsigned char* vec);
+void comm_release(opmhip_ctx* c);
 // assemble.hip launchers
 void launch_iq_update(opmhip_ctx* c);
+int launch_ghost_refresh(opmhip_ctx* c);
 void launch_newton_update(opmhip_ctx* c, const double* d_dx_internal, double relax);
 void launch_assemble(opmhip_ctx* c, double dt, int iteration);
 void launch_convergence(opmhip_ctx* c, double dt, double tol_cnv);

@@ -200,18 +200,24 @@ void color_chains(const Pattern& P, const Chains& C, std::vector<int>& chainColo
 
 }  // namespace
 
-int build_pattern(opmhip_ctx* c, int Nb, int nnzb, const int* rows, const int* cols) {
+int build_pattern(opmhip_ctx* c, int Nb, int Nghost, int nnzb, const int* rows, const int* cols) {
+    // Nb = owned block rows (the rows of the matrix); columns may also point at Nghost ghost cells numbered
+    // Nb .. Nb+Nghost-1 (owner-cells-first ordering, linalg/ISTLSolverEbos.hpp:171-178).  Ghost columns take part in
+    // SpMV and assembly only; the ILU0 is the block-Jacobi one of ghost_last_bilu0_decomposition: it never sees them.
     Pattern& P = c->pat;
-    if (Nb <= 0 || nnzb <= 0 || !rows || !cols) return fail(c, OPMHIP_INVALID_ARGUMENT, "set_pattern: bad arguments");
+    if (Nb <= 0 || Nghost < 0 || nnzb <= 0 || !rows || !cols) return fail(c, OPMHIP_INVALID_ARGUMENT, "set_pattern: bad arguments");
     if (rows[0] != 0 || rows[Nb] != nnzb) return fail(c, OPMHIP_INVALID_ARGUMENT, "set_pattern: rows[] inconsistent with nnzb");
+    const int Nloc = Nb + Nghost;
     P.Nb = Nb;
+    P.Nghost = Nghost;
+    P.Nloc = Nloc;
     P.nnzb = nnzb;
     P.nat_rowptr.assign(rows, rows + Nb + 1);
     P.nat_col.assign(cols, cols + nnzb);
     for (int i = 0; i < Nb; ++i) {
         bool hasDiag = false;
         for (int k = rows[i]; k < rows[i + 1]; ++k) {
-            if (cols[k] < 0 || cols[k] >= Nb) return fail(c, OPMHIP_INVALID_ARGUMENT, "set_pattern: column out of range in row %d", i);
+            if (cols[k] < 0 || cols[k] >= Nloc) return fail(c, OPMHIP_INVALID_ARGUMENT, "set_pattern: column out of range in row %d", i);
             if (k > rows[i] && cols[k] <= cols[k - 1]) return fail(c, OPMHIP_INVALID_ARGUMENT, "set_pattern: columns of row %d not ascending", i);
             hasDiag |= (cols[k] == i);
         }
@@ -224,14 +230,24 @@ int build_pattern(opmhip_ctx* c, int Nb, int nnzb, const int* rows, const int* c
     std::vector<int> chainColor;
     const bool chained = (c->cfg.reorder == OPMHIP_REORDER_LINE_COLORING);
     int maxLen = 1;
+    // the ordering is computed on the owned-owned couplings only
+    Pattern Q;
+    Q.Nb = Nb;
+    Q.nat_rowptr.assign(Nb + 1, 0);
+    for (int i = 0; i < Nb; ++i) {
+        for (int k = rows[i]; k < rows[i + 1]; ++k)
+            if (cols[k] < Nb) Q.nat_col.push_back(cols[k]);
+        Q.nat_rowptr[i + 1] = (int)Q.nat_col.size();
+    }
+    Q.nnzb = (int)Q.nat_col.size();
     switch (c->cfg.reorder) {
-        case OPMHIP_REORDER_LEVEL_SCHEDULING: levels(P, color, ncol); break;
-        case OPMHIP_REORDER_GRAPH_COLORING: color_jp(P, color, ncol); break;
-        case OPMHIP_REORDER_GRAPH_COLORING_GREEDY: color_greedy(P, color, ncol); break;
+        case OPMHIP_REORDER_LEVEL_SCHEDULING: levels(Q, color, ncol); break;
+        case OPMHIP_REORDER_GRAPH_COLORING: color_jp(Q, color, ncol); break;
+        case OPMHIP_REORDER_GRAPH_COLORING_GREEDY: color_greedy(Q, color, ncol); break;
         case OPMHIP_REORDER_LINE_COLORING: {
             maxLen = c->cfg.reserved[0] > 0 ? c->cfg.reserved[0] : 8;
-            build_chains(P, maxLen, CH);
-            color_chains(P, CH, chainColor, ncol);
+            build_chains(Q, maxLen, CH);
+            color_chains(Q, CH, chainColor, ncol);
             color.resize(Nb);
             for (int i = 0; i < Nb; ++i) color[i] = chainColor[CH.chainOf[i]];
         } break;
@@ -242,8 +258,9 @@ int build_pattern(opmhip_ctx* c, int Nb, int nnzb, const int* rows, const int* c
     P.colorPrefix.assign(ncol + 1, 0);
     for (int i = 0; i < Nb; ++i) P.colorPrefix[color[i] + 1]++;
     std::partial_sum(P.colorPrefix.begin(), P.colorPrefix.end(), P.colorPrefix.begin());
-    P.toOrder.resize(Nb);
-    P.fromOrder.resize(Nb);
+    P.toOrder.resize(Nloc);
+    P.fromOrder.resize(Nloc);
+    for (int g = Nb; g < Nloc; ++g) P.toOrder[g] = P.fromOrder[g] = g;  // ghosts stay last, in the given order
     // (chain-tile, step) row groups of the chained ordering: rows [groupRow[g], groupRow[g+1]) ; groupNewCT[g] = 1 if the
     // group opens a new chain-tile
     std::vector<int> groupRow, groupNewCT;
@@ -312,7 +329,7 @@ int build_pattern(opmhip_ctx* c, int Nb, int nnzb, const int* rows, const int* c
             for (int p = P.colorPrefix[cc]; p < P.colorPrefix[cc + 1]; ++p) colorOf[p] = cc;
         for (int p = 0; p < Nb; ++p)
             for (int k = P.rowptr[p]; k < P.rowptr[p + 1]; ++k)
-                if (P.col[k] != p && colorOf[P.col[k]] == colorOf[p] &&
+                if (P.col[k] != p && P.col[k] < Nb && colorOf[P.col[k]] == colorOf[p] &&
                     !(chained && CH.chainOf[P.fromOrder[P.col[k]]] == CH.chainOf[P.fromOrder[p]]))
                         return fail(c, OPMHIP_ANALYSIS_FAILED, "ordering is not a valid schedule at row %d", p);
     }
@@ -325,7 +342,7 @@ int build_pattern(opmhip_ctx* c, int Nb, int nnzb, const int* rows, const int* c
     for (int p = 0; p < Nb; ++p) {
         for (int k = P.rowptr[p]; k < P.rowptr[p + 1]; ++k) {
             if (P.col[k] < p) P.lcol.push_back(P.col[k]);
-            else if (P.col[k] > p) P.ucol.push_back(P.col[k]);
+            else if (P.col[k] > p && P.col[k] < Nb) P.ucol.push_back(P.col[k]);  // ghost columns are not part of the ILU
         }
         P.lrowptr[p + 1] = (int)P.lcol.size();
         P.urowptr[p + 1] = (int)P.ucol.size();

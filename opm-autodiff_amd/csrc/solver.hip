@@ -308,6 +308,10 @@ __global__ void k_lu_to_bcrs(int Nb, const int* __restrict__ rowptr, const int* 
     if (p >= Nb) return;
     int li = lrowptr[p], ui = urowptr[p];
     for (int k = rowptr[p]; k < rowptr[p + 1]; ++k) {
+        if (col[k] >= Nb) {  // ghost column: not part of the block-Jacobi ILU0
+            for (int q = 0; q < BB; ++q) out[(size_t)k * BB + q] = 0.0;
+            continue;
+        }
         const double* src = (col[k] < p) ? &L[(size_t)(li++) * BB] : (col[k] == p) ? &invD[(size_t)p * BB] : &U[(size_t)(ui++) * BB];
         for (int q = 0; q < BB; ++q) out[(size_t)k * BB + q] = src[q];
     }
@@ -642,7 +646,8 @@ __global__ __launch_bounds__(64) void k_ilu_factor(int ct_begin, const int* __re
             double* Lo = &L[(size_t)lrowptr[i] * BB];
             for (int a = 0; a < nd * BB; ++a) Lo[a] = row[a];
             double* Uo = &U[(size_t)urowptr[i] * BB];
-            for (int a = 0; a < (n - nd - 1) * BB; ++a) Uo[a] = row[(nd + 1) * BB + a];
+            const int nu = urowptr[i + 1] - urowptr[i];  // owned upper entries; ghost columns (at the row's end) are dropped
+            for (int a = 0; a < nu * BB; ++a) Uo[a] = row[(nd + 1) * BB + a];
         }
         __syncthreads();  // drains vmcnt: this step's factors (global stores) are complete before the next step reads them
     }
@@ -802,6 +807,19 @@ __global__ __launch_bounds__(VB) void k_reduce_stage1(int count, const double* _
     }
     if (threadIdx.x == 0) { out[blockIdx.x] = sh[0][0]; out[RED1_BLOCKS + blockIdx.x] = sh[1][0]; }
 }
+// out[0], out[1] = the two sums of the partial lists, fixed order (input of the all-reduce in decomposed runs)
+__global__ __launch_bounds__(VB) void k_local_sums(int count, const double* __restrict__ part, int npart, double* __restrict__ out) {
+    __shared__ double sh[2][VB];
+    double a = 0.0, b = 0.0;
+    for (int i = threadIdx.x; i < count; i += VB) { a += part[i]; b += part[npart + i]; }
+    sh[0][threadIdx.x] = a; sh[1][threadIdx.x] = b;
+    __syncthreads();
+    for (int o = VB / 2; o > 0; o >>= 1) {
+        if ((int)threadIdx.x < o) { sh[0][threadIdx.x] += sh[0][threadIdx.x + o]; sh[1][threadIdx.x] += sh[1][threadIdx.x + o]; }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) { out[0] = sh[0][0]; out[1] = sh[1][0]; }
+}
 // Sum the partials in a fixed order and update the device-resident scalars.  One workgroup.
 enum FinMode { FIN_INIT = 0, FIN_ALPHA = 1, FIN_NORM = 2, FIN_OMEGA = 3, FIN_NORM_RHO = 4 };
 __global__ __launch_bounds__(VB) void k_finalize(int mode, int count, const double* __restrict__ part, int npart,
@@ -842,11 +860,14 @@ void launch_permute_blocks(opmhip_ctx* c, const double* nat, double* internal) {
     const size_t n = (size_t)c->pat.nnzb * BB;
     hipLaunchKernelGGL(k_permute_blocks, dim3(cdiv(n, 256)), dim3(256), 0, c->stream, c->pat.nnzb, c->pat.d_nnzMap, nat, internal);
 }
-void launch_vec_to_internal(opmhip_ctx* c, const double* nat, double* internal) {
-    hipLaunchKernelGGL(k_vec_to_internal, dim3(cdiv((size_t)c->pat.Nb * BS, 256)), dim3(256), 0, c->stream, c->pat.Nb, c->pat.d_fromOrder, nat, internal);
+// cells = -1: the owned rows (solver vectors); otherwise that many cells (state vectors include the ghosts)
+void launch_vec_to_internal(opmhip_ctx* c, const double* nat, double* internal, int cells) {
+    const int n = cells < 0 ? c->pat.Nb : cells;
+    hipLaunchKernelGGL(k_vec_to_internal, dim3(cdiv((size_t)n * BS, 256)), dim3(256), 0, c->stream, n, c->pat.d_fromOrder, nat, internal);
 }
-void launch_vec_to_natural(opmhip_ctx* c, const double* internal, double* nat) {
-    hipLaunchKernelGGL(k_vec_to_natural, dim3(cdiv((size_t)c->pat.Nb * BS, 256)), dim3(256), 0, c->stream, c->pat.Nb, c->pat.d_toOrder, internal, nat);
+void launch_vec_to_natural(opmhip_ctx* c, const double* internal, double* nat, int cells) {
+    const int n = cells < 0 ? c->pat.Nb : cells;
+    hipLaunchKernelGGL(k_vec_to_natural, dim3(cdiv((size_t)n * BS, 256)), dim3(256), 0, c->stream, n, c->pat.d_toOrder, internal, nat);
 }
 void launch_zero_diag_fix(opmhip_ctx* c) {
     hipLaunchKernelGGL(k_zero_diag_fix, dim3(cdiv((size_t)c->pat.Nb * BS, 256)), dim3(256), 0, c->stream, c->pat.Nb, c->pat.d_diag, c->d_A);
@@ -944,6 +965,20 @@ void launch_ilu_apply(opmhip_ctx* c, const double* d, double* v) {
     prof_end(c, ps);
 }
 static void finalize(opmhip_ctx* c, int mode, int count) {
+    if (c->comm.nranks > 1) {
+        // local sums -> one small all-reduce -> scalars (the reference all-reduces one double per scalar product
+        // through OwnerOverlapCopyCommunication; here the two sums of a half iteration travel together)
+        const double* src = c->d_part;
+        int np = c->npart, cnt = count;
+        if (count > 4 * RED1_BLOCKS) {
+            hipLaunchKernelGGL(k_reduce_stage1, dim3(RED1_BLOCKS), dim3(VB), 0, c->stream, count, c->d_part, c->npart, c->d_part2);
+            src = c->d_part2; np = RED1_BLOCKS; cnt = RED1_BLOCKS;
+        }
+        hipLaunchKernelGGL(k_local_sums, dim3(1), dim3(VB), 0, c->stream, cnt, src, np, c->comm.d_red);
+        (void)comm_allreduce(c, c->comm.d_red, 2, 0);
+        hipLaunchKernelGGL(k_finalize, dim3(1), dim3(VB), 0, c->stream, mode, 1, c->comm.d_red, 1, c->d_scal);
+        return;
+    }
     if (count > 4 * RED1_BLOCKS) {
         hipLaunchKernelGGL(k_reduce_stage1, dim3(RED1_BLOCKS), dim3(VB), 0, c->stream, count, c->d_part, c->npart, c->d_part2);
         hipLaunchKernelGGL(k_finalize, dim3(1), dim3(VB), 0, c->stream, mode, RED1_BLOCKS, c->d_part2, RED1_BLOCKS, c->d_scal);
@@ -990,6 +1025,7 @@ int bicgstab(opmhip_ctx* c, opmhip_result* res) {
             prof_end(c, ps);
         }
         launch_ilu_apply(c, c->d_p, c->d_pw);
+        if ((rc = comm_halo_f64(c, c->d_pw, BS))) return rc;  // copyOwnerToAll before the operator (ParallelOverlappingILU0.hpp:897)
         launch_spmv(c, c->d_pw, c->d_v, 1, c->d_rw, nullptr);
         ps = prof_begin(c, PROF_VECTOR);
         finalize(c, FIN_ALPHA, dot_count(c));
@@ -1001,6 +1037,7 @@ int bicgstab(opmhip_ctx* c, opmhip_result* res) {
         if (norm < tol * norm_0) break;
         it += 0.5f;
         launch_ilu_apply(c, c->d_r, c->d_s);
+        if ((rc = comm_halo_f64(c, c->d_s, BS))) return rc;
         launch_spmv(c, c->d_s, c->d_t, 2, c->d_r, nullptr);
         ps = prof_begin(c, PROF_VECTOR);
         finalize(c, FIN_OMEGA, dot_count(c));

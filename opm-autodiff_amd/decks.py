@@ -25,17 +25,18 @@ def rs_sat(fl, p, region=0):
     return fp[s] + (fp[s + 1] - fp[s]) * (p - xp[s]) / (xp[s + 1] - xp[s])
 
 
-def cartesian_case(nx, ny, nz, dx=20.0, dy=20.0, dz=5.0, top=2500.0, poro=0.25, perm_md=100.0, heterogeneous=False,
-                   state="undersaturated", perturb=True, fluid=None, seed_state=2024):
+def cartesian_cells(nx, ny, nz, dx=20.0, dy=20.0, dz=5.0, top=2500.0, poro=0.25, perm_md=100.0, heterogeneous=False,
+                    state="undersaturated", perturb=True, fluid=None, seed_state=2024):
+    """Per-cell arrays of the synthetic case (no connectivity): geometry, rock and the initial state."""
     fl = fluid if fluid is not None else _fluid.spe1_fluid()[0]
-    pat = _grid.cartesian_pattern(nx, ny, nz)
-    Nb = pat["Nb"]
+    Nb = nx * ny * nz
     if heterogeneous:
         perm = np.exp(np.random.default_rng(12345).normal(np.log(perm_md), 1.0, Nb)) * MILLIDARCY
     else:
         perm = np.full(Nb, perm_md * MILLIDARCY)
-    volume, depth, area = _grid.cartesian_geometry(pat, dx, dy, dz, top)
-    trans = _grid.tpfa_transmissibility(pat, perm, perm, perm, dx, dy, dz)
+    k = np.arange(Nb) // (nx * ny)
+    volume = np.full(Nb, dx * dy * dz)
+    depth = top + (k + 0.5) * dz
     rng = np.random.default_rng(seed_state)
     p = 250e5 + 7000.0 * (depth - top)
     sw = np.full(Nb, 0.2)
@@ -56,10 +57,19 @@ def cartesian_case(nx, ny, nz, dx=20.0, dy=20.0, dz=5.0, top=2500.0, poro=0.25, 
                             0.8 * rs_sat(fl, p))
     else:
         raise ValueError(state)
-    return dict(Nb=Nb, nx=nx, ny=ny, nz=nz, rowptr=pat["rowptr"], col=pat["col"], face_dir=pat["face_dir"],
-                trans=np.ascontiguousarray(trans), area=np.ascontiguousarray(area),
-                poro=np.full(Nb, float(poro)), volume=np.ascontiguousarray(volume), depth=np.ascontiguousarray(depth),
-                fluid=fl, pv=np.ascontiguousarray(pv.reshape(-1)), meaning=meaning)
+    return dict(Nb=Nb, nx=nx, ny=ny, nz=nz, dx=dx, dy=dy, dz=dz, top=top, perm=perm, poro=np.full(Nb, float(poro)),
+                volume=volume, depth=np.ascontiguousarray(depth), fluid=fl, pv=np.ascontiguousarray(pv.reshape(-1)), meaning=meaning)
+
+
+def cartesian_case(nx, ny, nz, dx=20.0, dy=20.0, dz=5.0, top=2500.0, poro=0.25, perm_md=100.0, heterogeneous=False,
+                   state="undersaturated", perturb=True, fluid=None, seed_state=2024):
+    c = cartesian_cells(nx, ny, nz, dx, dy, dz, top, poro, perm_md, heterogeneous, state, perturb, fluid, seed_state)
+    pat = _grid.cartesian_pattern(nx, ny, nz)
+    _, _, area = _grid.cartesian_geometry(pat, dx, dy, dz, top)
+    trans = _grid.tpfa_transmissibility(pat, c["perm"], c["perm"], c["perm"], dx, dy, dz)
+    return dict(Nb=c["Nb"], nx=nx, ny=ny, nz=nz, rowptr=pat["rowptr"], col=pat["col"], face_dir=pat["face_dir"],
+                trans=np.ascontiguousarray(trans), area=np.ascontiguousarray(area), poro=c["poro"],
+                volume=np.ascontiguousarray(c["volume"]), depth=c["depth"], fluid=c["fluid"], pv=c["pv"], meaning=c["meaning"])
 
 
 def spe1_case(state="equil"):

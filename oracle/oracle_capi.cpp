@@ -151,10 +151,14 @@ int orc_solve(int Nb, const int* rowptr, const int* col, const double* val, cons
     Bcrs LU = A;
     int rc = 0;
     std::vector<int> dg;
-    if (nsub > 1) {
+    if (nsub > 1 || nsub < 0) {
         // drop couplings that leave a subdomain: they stay in the pattern with value 0 so that the
-        // sweeps simply see zeros there (same effect as the ghost-last loops that never touch them)
+        // sweeps simply see zeros there (same effect as the ghost-last loops that never touch them).
+        // nsub > 1: contiguous row ranges sub_start[nsub+1]; nsub < 0: sub_start is an owner id per (natural) row.
         std::vector<int> owner(Nb);
+        if (nsub < 0) {
+            for (int i = 0; i < Nb; ++i) owner[reorder != 0 ? R.toOrder[i] : i] = sub_start[i];
+        } else
         for (int s = 0; s < nsub; ++s)
             for (int i = sub_start[s]; i < sub_start[s + 1]; ++i) owner[i] = s;
         for (int i = 0; i < Nb; ++i)

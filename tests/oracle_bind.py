@@ -76,12 +76,15 @@ class Oracle:
         return y
 
     def solve(self, Nb, rowptr, col, val, b, tol=1e-2, maxit=200, w=0.9, mode="post_scale", reorder="none",
-              zero_diag_fix=True, wells=None, sub_start=None):
+              zero_diag_fix=True, wells=None, sub_start=None, owner=None):
+        """sub_start: block-Jacobi ILU0 over contiguous row ranges; owner: the same with an owner id per row."""
         x = np.zeros(Nb * 3)
         res = OrcResult()
         W = wells or {}
         nsub = 0 if sub_start is None else len(sub_start) - 1
         ss = None if sub_start is None else np.ascontiguousarray(sub_start, np.int32)
+        if owner is not None:
+            nsub, ss = -1, np.ascontiguousarray(owner, np.int32)
         rc = self.lib.orc_solve(Nb, rowptr, col, val, b, x, tol, maxit, w, RELAX[mode], REORDER[reorder],
                                 int(zero_diag_fix), W.get("numWells", 0), _p(W.get("val_pointers")),
                                 _p(W.get("Ccols")), _p(W.get("Bcols")), _p(W.get("Cnnzs")), _p(W.get("Dnnzs")),

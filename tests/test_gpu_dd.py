@@ -1,0 +1,130 @@
+"""Domain-decomposed device path on ONE GPU: P contexts in one process (one host thread each) joined by libopmhip's
+loopback communicator, i.e. the same set_pattern_dd / set_halo / halo-exchange / all-reduce code the RCCL path runs,
+with device copies in place of ncclSend/ncclRecv.  Oracle: the CPU restatement on the GLOBAL grid, whose ILU0 drops the
+couplings between subdomains (block-Jacobi, the reference's ghost_last_bilu0_decomposition,
+opm/simulators/linalg/ParallelOverlappingILU0.hpp:439-494)."""
+import threading
+import uuid
+
+import numpy as np
+import pytest
+
+import oracle_bind
+
+pytestmark = pytest.mark.gpu
+
+
+def run_ranks(world, fn):
+    """fn(rank) in one thread per rank; returns the list of results, re-raises the first exception"""
+    out, err = [None] * world, [None] * world
+
+    def body(r):
+        try:
+            out[r] = fn(r)
+        except BaseException as e:  # noqa: BLE001
+            err[r] = e
+
+    ts = [threading.Thread(target=body, args=(r,)) for r in range(world)]
+    for t in ts:
+        t.start()
+    for t in ts:
+        t.join(timeout=300)
+    for e in err:
+        if e is not None:
+            raise e
+    return out
+
+
+def global_and_parts(pkg, n, world, **kw):
+    px, py, pz = pkg.ras.block_layout(world)
+    g = pkg.decks.cartesian_case(px * n, py * n, pz * n, **kw)
+    owner = pkg.ras.cartesian_owner(px * n, py * n, pz * n, px, py, pz)
+    parts = [pkg.ras.cartesian_subdomain_case(n, world, r, **kw) for r in range(world)]
+    return g, owner, parts
+
+
+@pytest.mark.parametrize("world", [2, 4])
+def test_dd_assembly_bitwise_and_solve(pkg, orc, world):
+    n = 6
+    g, owner, parts = global_and_parts(pkg, n, world, state="mixed", heterogeneous=True)
+    src = pkg.decks.five_spot_source(g, rate_sm3_per_day=30.0)
+    o = oracle_bind.OracleModel(orc, g)
+    o.set_state(g["pv"], g["meaning"])
+    o.set_source(src)
+    dt = 86400.0
+    jo, ro = o.assemble(dt, 0)
+    co = o.convergence(dt)
+    xo, reso = orc.solve(g["Nb"], g["rowptr"], g["col"], jo, ro, tol=1e-2, maxit=200, w=0.9, owner=owner)
+    group = "t" + uuid.uuid4().hex
+
+    def rank_fn(r):
+        c = parts[r]
+        m = pkg.capi.HipModel(c, comm=("loopback", world, r, group), reorder="level_scheduling")
+        m.set_state(c["pv"], c["meaning"])
+        m.set_source(np.ascontiguousarray(src.reshape(-1, 3)[c["gids"]].reshape(-1)))
+        j, res = m.assemble(dt, 0)
+        conv = m.convergence(dt)
+        sol = m.solve_jacobian_system()
+        x = m.get_result()
+        return j, res, conv, sol.it, sol.converged, x
+
+    outs = run_ranks(world, rank_fn)
+    for r, (j, res, conv, it, ok, x) in enumerate(outs):
+        c = parts[r]
+        gi = c["gids"][:c["Nb"]]
+        # residual and Jacobian of the owned rows: the global oracle's, bit for bit
+        assert np.array_equal(res.reshape(-1, 3)[:c["Nb"]], ro.reshape(-1, 3)[gi])
+        assert np.array_equal(j.reshape(-1, 9), jo.reshape(-1, 9)[c["halo"]["entry_global"]])
+        # convergence: global quantities, identical on every rank
+        np.testing.assert_allclose(conv[3:6], co[3:6], rtol=0, atol=0)
+        np.testing.assert_allclose(conv[6:10], co[6:10], rtol=1e-13)
+        assert ok and it == reso.it
+        np.testing.assert_allclose(x.reshape(-1, 3)[:c["Nb"]], xo.reshape(-1, 3)[gi], rtol=1e-8, atol=1e-12 * np.abs(xo).max())
+    assert all(np.array_equal(outs[0][2], o_[2]) for o_ in outs)  # every rank holds the same reduced numbers
+
+
+@pytest.mark.parametrize("reorder", ["line_coloring"])
+def test_dd_newton_step_matches_block_jacobi_oracle(pkg, orc, reorder):
+    world, n = 2, 8
+    g, owner, parts = global_and_parts(pkg, n, world, state="mixed", heterogeneous=False)
+    src = pkg.decks.five_spot_source(g, rate_sm3_per_day=40.0)
+    dt = 2 * 86400.0
+    group = "n" + uuid.uuid4().hex
+
+    def rank_fn(r):
+        c = parts[r]
+        m = pkg.capi.HipModel(c, comm=("loopback", world, r, group), reorder=reorder)
+        m.set_state(c["pv"], c["meaning"])
+        m.set_source(np.ascontiguousarray(src.reshape(-1, 3)[c["gids"]].reshape(-1)))
+        drv = pkg.newton.BlackoilModelHip(m)
+        rep = drv.step(dt)
+        pv, mean = m.get_state()
+        return rep.total_newton_iterations, rep.total_linear_iterations, pv, mean
+
+    outs = run_ranks(world, rank_fn)
+    assert outs[0][0] == outs[1][0] and outs[0][1] == outs[1][1]
+    # the decomposed run converges to the same state as the single-domain CPU restatement (Newton tolerance level)
+    o = oracle_bind.OracleModel(orc, g)
+    o.set_state(g["pv"], g["meaning"])
+    o.set_source(src)
+    for it in range(20):
+        o.assemble(dt, it)
+        c = o.convergence(dt)
+        if it > 1 and np.all(c[11:14] < 1e-2) and np.all(c[14:17] < 1e-6):
+            break
+        x, res = o.solve(tol=1e-2)
+        o.update(x)
+    po, mo = o.get_state()
+    for r in range(world):
+        c = parts[r]
+        gi = c["gids"]
+        pv = outs[r][2].reshape(-1, 3)
+        assert np.array_equal(outs[r][3][:c["Nb"]], mo[gi[:c["Nb"]]])
+        np.testing.assert_allclose(pv[:c["Nb"], 1], po.reshape(-1, 3)[gi[:c["Nb"]], 1], rtol=1e-4)       # pressure
+        np.testing.assert_allclose(pv[:c["Nb"], 0], po.reshape(-1, 3)[gi[:c["Nb"]], 0], atol=2e-3)       # Sw
+        # ghost copies equal their owners' values
+        other = outs[1 - r][2].reshape(-1, 3)
+        og = parts[1 - r]["gids"][:parts[1 - r]["Nb"]]
+        lut = {int(gg): k for k, gg in enumerate(og)}
+        for k in range(c["Nb"], c["Nloc"]):
+            assert np.array_equal(pv[k], other[lut[int(gi[k])]])
