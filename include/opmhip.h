@@ -238,6 +238,8 @@ int opmhip_comm_init_rccl(opmhip_ctx* ctx, int nranks, int rank, const char* id1
 /* several contexts inside ONE process (each driven by its own host thread, all on one GPU), connected by device copies
  * and a host barrier: test vehicle for the decomposition logic on a single GPU */
 int opmhip_comm_init_loopback(opmhip_ctx* ctx, int nranks, int rank, const char* group_name);
+/* diagnostics: one RCCL all-reduce of {1 + rank, 2} on the context's stream; sum_out[2] */
+int opmhip_comm_selftest(opmhip_ctx* ctx, double* sum_out);
 /* optional, before opmhip_set_static: the global id of every local cell (Nb + Nghost entries).  The assembly then adds a
  * row's face fluxes in ascending GLOBAL neighbour order, i.e. exactly the sum an undecomposed run forms, so that
  * residual and Jacobian do not depend on the decomposition down to the last bit. */

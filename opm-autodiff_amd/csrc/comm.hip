@@ -229,6 +229,26 @@ int opmhip_comm_init_loopback(opmhip_ctx* c, int nranks, int rank, const char* g
     return OPMHIP_SUCCESS;
 }
 
+// one RCCL all-reduce of two doubles on the context's stream, whatever the rank count: checks that librccl could be
+// loaded, the communicator works and the stream ordering holds (usable with nranks == 1 on a single GPU)
+int opmhip_comm_selftest(opmhip_ctx* c, double* sum_out) {
+    if (!c || !sum_out) return OPMHIP_INVALID_ARGUMENT;
+    if (c->comm.kind != COMM_RCCL) return fail(c, OPMHIP_NOT_READY, "comm_selftest: no RCCL communicator");
+    OPMHIP_HIP(c, hipSetDevice(c->device));
+    double* d = nullptr;
+    int rc = dev_alloc(c, &d, (size_t)2);
+    if (rc) return rc;
+    const double h[2] = {1.0 + c->comm.rank, 2.0};
+    OPMHIP_HIP(c, hipMemcpyAsync(d, h, sizeof h, hipMemcpyHostToDevice, c->stream));
+    NCCLCHK(c, g_rccl.AllReduce(d, d, 2, ncclDouble, ncclSum, (ncclComm_t)c->comm.nccl, c->stream));
+    double o[2];
+    OPMHIP_HIP(c, hipMemcpyAsync(o, d, sizeof o, hipMemcpyDeviceToHost, c->stream));
+    OPMHIP_HIP(c, hipStreamSynchronize(c->stream));
+    sum_out[0] = o[0];
+    sum_out[1] = o[1];
+    return OPMHIP_SUCCESS;
+}
+
 int opmhip_set_cell_global_ids(opmhip_ctx* c, const long long* gids) {
     if (!c || !gids) return OPMHIP_INVALID_ARGUMENT;
     if (!c->pattern_set) return fail(c, OPMHIP_NOT_READY, "set_cell_global_ids before set_pattern");

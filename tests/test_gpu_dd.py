@@ -128,3 +128,18 @@ def test_dd_newton_step_matches_block_jacobi_oracle(pkg, orc, reorder):
         lut = {int(gg): k for k, gg in enumerate(og)}
         for k in range(c["Nb"], c["Nloc"]):
             assert np.array_equal(pv[k], other[lut[int(gi[k])]])
+
+
+def test_rccl_communicator_single_rank(pkg):
+    """RCCL itself (dlopen, ncclCommInitRank, ncclAllReduce on the context's stream) with a one-rank communicator: the
+    part of the multi-GPU path that can be exercised on a single GPU."""
+    import ctypes as C
+    uid = pkg.capi.comm_unique_id()
+    assert len(uid) == 128
+    s = pkg.capi.HipSolver()
+    L = pkg.capi.lib()
+    L.opmhip_comm_selftest.argtypes = [C.c_void_p, C.c_void_p]
+    s._check(L.opmhip_comm_init_rccl(s._h, 1, 0, uid))
+    out = (C.c_double * 2)()
+    s._check(L.opmhip_comm_selftest(s._h, out))
+    assert (out[0], out[1]) == (1.0, 2.0)
