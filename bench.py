@@ -6,8 +6,9 @@ Workload (BASELINE.json configs[1]): synthetic 100 x 100 x 100 Cartesian three-p
 SPE1 fluid, per GPU.  A "step" is one Newton iteration of BlackoilModelEbos::nonlinearIteration that does real work:
 assembleReservoir (AD linearisation into block-CSR) -> getReservoirConvergence -> solveJacobianSystem (block-ILU0
 factorisation + BiCGStab to 1e-2) -> updateSolution (chopped update, primary-variable switching, intensive
-quantities).  Time steps follow one another (1 day, then 10 days each) with a fixed-rate five-spot
-source pair; whenever a time step converges the next one starts, exactly as NonlinearSolverEbos::step would.
+quantities).  Time steps follow one another under Flow's sub-step control (newton.AdaptiveTimeStepping: 1 day first,
+grown by the Newton-iteration-count rule up to the 10-day report step of SURVEY.md §8d, rolled back and chopped by
+0.33 when the Newton method gives up) with a fixed-rate five-spot source pair; failed iterations count as work.
 Everything is resident in HBM when the timed region starts; nothing crosses PCIe inside it except ~200 bytes of
 scalars per Newton iteration.
 
@@ -48,42 +49,17 @@ def alg_bytes(Nb, nnzb):
     }
 
 
-class Simulation:
-    """Time stepping that hands out Newton iterations one by one."""
-
-    def __init__(self, pkg, model, dts):
-        self.newton = pkg.newton.BlackoilModelHip(model)
-        self.dts = list(dts)
-        self.step_idx = 0
-        self.iteration = 0
-        self.timesteps_done = 0
-        self.report = pkg.newton.SimulatorReportSingle()
-
-    def next_newton_iteration(self):
-        """Runs nonlinear iterations until one of them actually solved a system; returns its report."""
-        while True:
-            dt = self.dts[min(self.step_idx, len(self.dts) - 1)]
-            rep = self.newton.nonlinear_iteration(self.iteration, dt)
-            self.report += rep
-            self.iteration += 1
-            if rep.converged:
-                self.step_idx += 1
-                self.timesteps_done += 1
-                self.iteration = 0
-                continue  # the converged check cost an assembly; it is inside the timed region like in Flow
-            if self.iteration > self.newton.param.newton_max_iter:
-                raise pkg_error("time step did not converge in %d Newton iterations" % self.newton.param.newton_max_iter)
-            return rep
+def make_simulation(pkg, model, report_step=10 * DAY):
+    """Flow's sub-stepping (newton.AdaptiveTimeStepping: 1 day first, then grown by the Newton-iteration-count rule up to
+    the report-step length, chopped by 0.33 and rolled back when the Newton method gives up) over the Newton loop."""
+    nm = pkg.newton.BlackoilModelHip(model)
+    return pkg.newton.AdaptiveTimeStepping(nm, pkg.newton.TimeSteppingParameters(initial_dt=1 * DAY, max_dt=report_step))
 
 
-def pkg_error(msg):
-    return RuntimeError(msg)
-
-
-def cpu_baseline(pkg, case, src, dts, budget_s=20.0, max_newton=10):
-    """The CPU port (oracle/) timed on one host core on a bounded sample of the same workload: the Newton iterations of
-    the same time-step sequence from the same initial state, until `budget_s` seconds or `max_newton` iterations are
-    used up.  Natural-order block ILU0 (what one Flow rank's Dune path factors), BiCGStab to 1e-2, relaxation 0.9."""
+def cpu_baseline(pkg, case, src, budget_s=20.0, max_newton=10):
+    """The CPU port (oracle/) timed on one host core on a bounded sample of the same workload: the same Newton and
+    time-stepping loop from the same initial state, until `budget_s` seconds or `max_newton` Newton iterations are used
+    up.  Natural-order block ILU0 (what one Flow rank's Dune path factors), BiCGStab to 1e-2, relaxation 0.9."""
     import oracle_bind
     import subprocess
     so = os.path.join(ROOT, "oracle", "liboracle.so")
@@ -93,35 +69,22 @@ def cpu_baseline(pkg, case, src, dts, budget_s=20.0, max_newton=10):
     o = oracle_bind.OracleModel(orc, case)
     o.set_state(case["pv"], case["meaning"])
     o.set_source(src)
-    t = {"assemble": 0.0, "linear_setup": 0.0, "linear_solve": 0.0, "update": 0.0}
-    newton = linear = 0
-    step = it = 0
+    sim = make_simulation(pkg, oracle_bind.OracleAsHipModel(o, tol=1e-2, maxit=200, w=0.9, mode="post_scale", reorder="none"))
+    newton = 0
     t_start = time.perf_counter()
     while newton < max_newton and time.perf_counter() - t_start < budget_s:
-        dt = dts[min(step, len(dts) - 1)]
-        t0 = time.perf_counter()
-        o.assemble(dt, it)
-        c = o.convergence(dt)
-        t["assemble"] += time.perf_counter() - t0
-        if it > 1 and all(c[11:14] < 1.0) and all(c[14:17] < 1e-6):   # getReservoirConvergence with the relaxed CNV
-            step, it = step + 1, 0
-            continue
-        x, res = o.solve(tol=1e-2, maxit=200, w=0.9, mode="post_scale", reorder="none")
-        t["linear_setup"] += res.t_factor
-        t["linear_solve"] += res.t_solve
-        t0 = time.perf_counter()
-        o.update(x)
-        t["update"] += time.perf_counter() - t0
+        sim.next_newton_iteration()
         newton += 1
-        linear += res.iterations
-        it += 1
-    total = sum(t.values())
+    rep = sim.report
+    total = rep.solver_time()
     return {
         "value": newton / total, "unit": "Newton iterations/s", "cores": 1, "kind": "port",
-        "sample": "the first %d Newton iterations of the same %d-cell case and time-step sequence on the CPU restatement "
+        "sample": "the first %d Newton iterations of the same %d-cell case and time-step control on the CPU restatement "
                   "(oracle/), 1 thread = the work of one Flow MPI rank: natural-order block-ILU0 + BiCGStab, %d linear "
-                  "iterations in all; %.1f s of CPU work" % (newton, case["Nb"], linear, total),
-        "newton_iterations": newton, "linear_iterations": int(linear), "seconds": t,
+                  "iterations in all; %.1f s of CPU work" % (newton, case["Nb"], rep.total_linear_iterations, total),
+        "newton_iterations": newton, "linear_iterations": int(rep.total_linear_iterations),
+        "seconds": {"assemble": rep.assemble_time, "linear_setup": rep.linear_solve_setup_time, "linear_solve": rep.linear_solve_time,
+                    "update": rep.update_time},
     }
 
 
@@ -153,11 +116,10 @@ def main():
 
     pkg = importlib.import_module("opm-autodiff_amd")
     n = a.n
-    dts = [1 * DAY] + [10 * DAY] * 1000
     skw = dict(device_id=local_rank, reorder=a.reorder, tolerance=1e-2, maxit=200, ilu_relaxation=0.9, chain_length=a.chain_length)
     if world == 1:
         case = pkg.decks.cartesian_case(n, n, n, state="mixed", heterogeneous=False)
-        src = pkg.decks.five_spot_source(case, rate_sm3_per_day=2000.0 * (n / 100.0) ** 2)
+        src = pkg.decks.five_spot_source(case, rate_sm3_per_day=pkg.decks.BENCH_RATE_SM3_PER_DAY * (n / 100.0) ** 2)
         model = pkg.capi.HipModel(case, **skw)
         layout = (1, 1, 1)
     else:
@@ -170,7 +132,7 @@ def main():
         model = pkg.capi.HipModel(case, comm=("rccl", world, rank, uid[0]), **skw)
     model.set_state(case["pv"], case["meaning"])
     model.set_source(src)
-    sim = Simulation(pkg, model, dts)
+    sim = make_simulation(pkg, model)
     Nb, nnzb = case["Nb"], len(case["col"])
 
     def barrier():
@@ -185,7 +147,7 @@ def main():
     model.profile_enable(True)
     rep0 = pkg.newton.SimulatorReportSingle()
     rep0 += sim.report
-    ts0 = sim.timesteps_done
+    ts0, tf0 = sim.timesteps_done, sim.timesteps_failed
     t0 = time.perf_counter()
     for _ in range(a.steps):
         sim.next_newton_iteration()
@@ -215,16 +177,18 @@ def main():
         # weak scaling: every rank advances the SAME coupled Newton iteration on its 1M-cell subdomain; the whole-job
         # aggregate is counted in subdomain-iterations (global iterations/s x number of 1M-cell subdomains)
         "value": a.steps * world / elapsed,
-        "unit": "Newton iterations/s" if world == 1 else "Newton iterations/s x %d-cell subdomains (coupled %d x %d x %d-block grid)" % ((n ** 3,) + layout),
+        "unit": "Newton iterations/s",
         "newton_iterations_per_s_global": a.steps / elapsed,
         "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": 1e3 * elapsed / a.steps,
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
         "config": {"workload": "synthetic %dx%dx%d Cartesian 3-phase black-oil (BASELINE configs[1]), SPE1 fluid, homogeneous "
-                               "100 mD, gas cap + undersaturated oil, five-spot rate sources, dt 1 d then 10 d" % (n, n, n),
+                               "100 mD, gas cap + undersaturated oil, five-spot rate sources, adaptive time steps 1 d -> 10 d (Flow's "
+                               "iteration-count control and 0.33 chop)" % (n, n, n),
                    "cells_per_gpu": Nb, "blocks_per_gpu": nnzb, "ilu_ordering": a.reorder, "linear_tol": 1e-2,
                    "ilu_relaxation": 0.9, "parallelism": "1 GPU" if world == 1 else "RAS domain decomposition %dx%dx%d, block-Jacobi ILU0 per GPU, halos + all-reduces over RCCL" % layout},
         "linear_iterations_per_newton": lin / a.steps,
-        "timesteps_completed": sim.timesteps_done - ts0,
+        "timesteps_completed": sim.timesteps_done - ts0, "timesteps_chopped": sim.timesteps_failed - tf0,
+        "time_steps_days": [round(h[0] / DAY, 3) for h in sim.history],
         "linear_solve_GBps": round(ls_bytes / ls_ms / 1e6, 1) if ls_ms > 0 else None,
         "report": {"assemble_time": rep.assemble_time - rep0.assemble_time,
                    "linear_solve_setup_time": rep.linear_solve_setup_time - rep0.linear_solve_setup_time,
@@ -236,7 +200,7 @@ def main():
                      "traffic": None, "avg_launch_ms": sp["avg_ms"], "algorithmic_bytes_per_launch": B["spmv"]},
     }
     if rank == 0 and world == 1 and not a.no_cpu_baseline:
-        out["cpu_baseline"] = cpu_baseline(pkg, case, src, dts)
+        out["cpu_baseline"] = cpu_baseline(pkg, case, src)
         out["gpu_over_cpu"] = out["value"] / out["cpu_baseline"]["value"]
     if rank == 0:
         print(json.dumps(out))

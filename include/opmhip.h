@@ -196,6 +196,14 @@ int opmhip_set_static(opmhip_ctx* ctx, const double* trans, const double* area, 
 int opmhip_set_state(opmhip_ctx* ctx, const double* pv, const unsigned char* meaning);
 int opmhip_get_state(opmhip_ctx* ctx, double* pv, unsigned char* meaning);
 
+/* The two time levels of the discretisation (opm-models FvBaseDiscretization: advanceTimeLevel() copies solution(0)
+ * into solution(1) when a time step starts; updateFailed() copies it back and recomputes the intensive quantities
+ * when the Newton method gave up - the path AdaptiveTimeSteppingEbos takes before it retries with a shorter step,
+ * opm/simulators/timestepping/AdaptiveTimeSteppingEbos.hpp:355-441).  Device-to-device, ghost cells included,
+ * asynchronous on the context's stream.  update_failed needs a preceding advance_time_level (else NOT_READY). */
+int opmhip_advance_time_level(opmhip_ctx* ctx);
+int opmhip_update_failed(opmhip_ctx* ctx);
+
 /* replaces: EclProblem::source (ebos/eclproblem.hh:1823-1845): total surface-volume rate per cell and equation
  * [m^3/s] (what BlackoilWellModel::computeTotalRatesForDof adds up, wells/BlackoilWellModel_impl.hpp:496-512) and
  * its 3x3 derivative w.r.t. the cell's primary variables.  Either may be NULL (= zero). */

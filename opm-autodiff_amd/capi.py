@@ -230,6 +230,8 @@ def _bind_assembly(L):
     L.opmhip_set_static.argtypes = [vp] + [vp] * 9
     L.opmhip_set_state.argtypes = [vp, vp, vp]
     L.opmhip_get_state.argtypes = [vp, vp, vp]
+    L.opmhip_advance_time_level.argtypes = [vp]
+    L.opmhip_update_failed.argtypes = [vp]
     L.opmhip_set_source.argtypes = [vp, vp, vp]
     L.opmhip_assemble.argtypes = [vp, C.c_double, C.c_int, vp, vp]
     L.opmhip_get_iq.argtypes = [vp, vp]
@@ -296,6 +298,14 @@ class HipModel(HipSolver):
         m = np.empty(self.Nloc, np.uint8)
         self._check(lib().opmhip_get_state(self._h, _ptr(pv), _ptr(m)))
         return pv, m
+
+    def advance_time_level(self):
+        """solution(1) = solution(0): call when a time step starts (FvBaseDiscretization::advanceTimeLevel)."""
+        self._check(lib().opmhip_advance_time_level(self._h))
+
+    def update_failed(self):
+        """solution(0) = solution(1) + intensive quantities: the Newton method gave up on this time step."""
+        self._check(lib().opmhip_update_failed(self._h))
 
     def set_source(self, source, dsource=None):
         s, d = _f64(source), _f64(dsource)

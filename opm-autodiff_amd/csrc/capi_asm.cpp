@@ -126,6 +126,8 @@ int opmhip_set_static(opmhip_ctx* c, const double* trans, const double* area, co
             if ((rc = dev_alloc(c, &A.d_dsource, Nb * 9))) return rc;
             if ((rc = dev_alloc(c, &A.d_meaning, Nb))) return rc;
             if ((rc = dev_alloc(c, &A.d_wasSwitched, Nb))) return rc;
+            if ((rc = dev_alloc(c, &A.d_pv_prev, Nb * 3))) return rc;
+            if ((rc = dev_alloc(c, &A.d_meaning_prev, Nb))) return rc;
             if ((rc = dev_alloc(c, &A.d_stage_u8, Nb))) return rc;
             if ((rc = dev_alloc(c, &A.d_nswitched, (size_t)1))) return rc;
             if ((rc = dev_alloc(c, &A.d_conv_part, ((Nb + 255) / 256) * 10))) return rc;
@@ -184,6 +186,37 @@ int opmhip_set_state(opmhip_ctx* c, const double* pv, const unsigned char* meani
         OPMHIP_HIP(c, hipGetLastError());
         OPMHIP_HIP(c, hipStreamSynchronize(c->stream));
         A.state_set = true;
+        A.prev_set = false;
+        return OPMHIP_SUCCESS;
+    });
+}
+
+int opmhip_advance_time_level(opmhip_ctx* c) {
+    if (!c) return OPMHIP_INVALID_ARGUMENT;
+    return guarded(c, [&]() -> int {
+        AsmDev& A = c->asmb;
+        if (!A.state_set) return fail(c, OPMHIP_NOT_READY, "advance_time_level before set_state");
+        OPMHIP_HIP(c, hipSetDevice(c->device));
+        // ghost cells included: a later update_failed needs no communication
+        OPMHIP_HIP(c, hipMemcpyAsync(A.d_pv_prev, A.d_pv, (size_t)c->pat.Nloc * 3 * sizeof(double), hipMemcpyDeviceToDevice, c->stream));
+        OPMHIP_HIP(c, hipMemcpyAsync(A.d_meaning_prev, A.d_meaning, (size_t)c->pat.Nloc, hipMemcpyDeviceToDevice, c->stream));
+        A.prev_set = true;
+        return OPMHIP_SUCCESS;
+    });
+}
+
+int opmhip_update_failed(opmhip_ctx* c) {
+    if (!c) return OPMHIP_INVALID_ARGUMENT;
+    return guarded(c, [&]() -> int {
+        AsmDev& A = c->asmb;
+        if (!A.prev_set) return fail(c, OPMHIP_NOT_READY, "update_failed before advance_time_level");
+        OPMHIP_HIP(c, hipSetDevice(c->device));
+        OPMHIP_HIP(c, hipMemcpyAsync(A.d_pv, A.d_pv_prev, (size_t)c->pat.Nloc * 3 * sizeof(double), hipMemcpyDeviceToDevice, c->stream));
+        OPMHIP_HIP(c, hipMemcpyAsync(A.d_meaning, A.d_meaning_prev, (size_t)c->pat.Nloc, hipMemcpyDeviceToDevice, c->stream));
+        OPMHIP_HIP(c, hipMemsetAsync(A.d_wasSwitched, 0, c->pat.Nloc, c->stream));
+        launch_iq_update(c);
+        OPMHIP_HIP(c, hipGetLastError());
+        A.assembled = false;
         return OPMHIP_SUCCESS;
     });
 }

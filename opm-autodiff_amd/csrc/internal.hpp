@@ -79,6 +79,9 @@ struct AsmDev {
     int *d_pvtnum = nullptr, *d_satnum = nullptr;
     double *d_pv = nullptr, *d_iq = nullptr, *d_storageOld = nullptr, *d_source = nullptr, *d_dsource = nullptr;
     unsigned char *d_meaning = nullptr, *d_wasSwitched = nullptr, *d_stage_u8 = nullptr;
+    double* d_pv_prev = nullptr;            // solution(1): primary variables at the start of the time step
+    unsigned char* d_meaning_prev = nullptr;
+    bool prev_set = false;
     int* d_nswitched = nullptr;
     int* d_asm_row0 = nullptr;
     int* d_natOrder = nullptr;  // per row: its entries (internal indices) sorted by natural column

@@ -57,16 +57,19 @@ __device__ __forceinline__ void stage_ints(const int* __restrict__ src, int* __r
 #pragma unroll 4
     for (int i = lane; i < n; i += 64) dst[i] = src[i];
 }
-// Workgroup -> tile map that keeps each XCD on one contiguous eighth of the tile range: workgroups are dealt
-// round-robin over the 8 XCDs (b and b+8 share one), so XCD g gets tiles [g*chunk, (g+1)*chunk) and the vector entries
-// its rows gather stay in that XCD's own 4 MB L2.  Speed only; any placement gives the same result.
+// Workgroup -> tile map.  Default: identity - measured on MI355X the round-robin dealing of consecutive workgroups
+// over the 8 XCDs streams the matrix through all 8 L2s at once and was faster (SpMV 0.112 vs 0.125 ms at 100^3) than
+// the XCD-contiguous map below, which keeps each XCD on one contiguous eighth of the tile range (b and b+8 share an
+// XCD) so that gathered vector entries stay in one 4 MB L2; build with -DOPMHIP_XCD_MAP to get it.  Speed only; any
+// placement gives the same result.
 __device__ __forceinline__ int xcd_tile(int b, int nt) {
-#if defined(OPMHIP_NO_XCD_MAP)
-    return b;
-#else
+#if defined(OPMHIP_XCD_MAP)
     const int chunk = (nt + 7) >> 3;
     const int t = (b & 7) * chunk + (b >> 3);
     return t;  // may be >= nt for the padded tail: callers check
+#else
+    (void)nt;
+    return b;
 #endif
 }
 
@@ -402,20 +405,23 @@ __global__ __launch_bounds__(64) void k_ilu_sweep(int tile_begin, int ntc, int n
 // the workgroup barrier because a CU's L1 sees the CU's own write-through stores.  Chains of other colours are
 // finished (earlier launches).  No first-colour / last-colour shortcuts here: every colour has chain-internal L and U.
 constexpr int CHAIN_MAX_STEPS = 128;
+#ifndef OPMHIP_CHAIN_GATHER
+#define OPMHIP_CHAIN_GATHER 6
+#endif
+#ifndef OPMHIP_CHAIN_STAGE
+#define OPMHIP_CHAIN_STAGE 12
+#endif
+constexpr int CGCH = OPMHIP_CHAIN_GATHER;   // blocks of a row whose vector entries are fetched one step ahead
+constexpr int CHAIN_STAGE = OPMHIP_CHAIN_STAGE;
 template <int SHAPE>  // SW_L or SW_UF
-__global__ __launch_bounds__(64) void k_ilu_sweep_chain(int ct_begin, int nct, const int* __restrict__ ct_first,
-                                                        const int* __restrict__ tile_row0, const int* __restrict__ prow,
-                                                        const int* __restrict__ pcol, const double* __restrict__ P,
-                                                        const double* __restrict__ invD, const double* __restrict__ d,
-                                                        double* vu, double* v, int relax_mode, double w) {
-    TILE_LDS
-    __shared__ int srow0[CHAIN_MAX_STEPS + 2], sk0[CHAIN_MAX_STEPS + 2];
-    const int lane = threadIdx.x, cl = xcd_tile(blockIdx.x, nct);
-    if (cl >= nct) return;
-    const int q0 = ct_first[ct_begin + cl], q1 = ct_first[ct_begin + cl + 1];
+__device__ __forceinline__ void chain_sweep(const int q0, const int q1, const int lane, double* sval, int* srow0, int* sk0,
+                                            const int* __restrict__ tile_row0, const int* __restrict__ prow,
+                                            const int* __restrict__ pcol, const double* __restrict__ P,
+                                            const double* __restrict__ invD, const double* d,
+                                            double* vu, double* v, int relax_mode, double w) {
     const int nsteps = q1 - q0;  // <= CHAIN_MAX_STEPS (checked on the host)
     const bool reverse = (SHAPE == SW_UF) && relax_mode == 0;
-    constexpr int U = 8;  // a step streams <= 32 rows x 3 blocks: 8 x 1 KiB per wavefront covers it in one batch
+    constexpr int U = CHAIN_STAGE;  // a step of a 2-colour line ordering streams <= 32 rows x 5 blocks = 11.25 KiB: 12 x 1 KiB per wavefront covers it in one batch
     // row and entry offsets of every step of this chain-tile, once: two dependent hops here instead of per step
     for (int i = lane; i <= nsteps; i += 64) {
         const int r = tile_row0[q0 + i];
@@ -423,17 +429,20 @@ __global__ __launch_bounds__(64) void k_ilu_sweep_chain(int ct_begin, int nct, c
         sk0[i] = prow[r];
     }
     wave_sync();
-    // Three-stage software pipeline over the steps (st counts in processing order; the backward sweep walks tiles
-    // q1-1 ... q0):   A(st+2): row bounds      B(st+1): columns, value stream, right-hand side, D^-1
-    //                 C(st)  : gathers of the sweep vector (the only loads that depend on step st-1), products, store
+    // Software pipeline over the steps (st counts in processing order; the backward sweep walks tiles q1-1 ... q0).
+    // The chain of dependent loads  row bounds -> column indices -> vector gathers  is spread over three iterations so
+    // that no iteration waits for more than the loads issued one iteration earlier:
+    //   A(st+3): row bounds      C(st+2): column indices      G(st+1): value stream, vector gathers, right-hand side, D^-1
+    //   X(st)  : values -> LDS, products in the row's sequential order, store
     auto tile_of = [&](int st) { return (SHAPE == SW_UF) ? nsteps - 1 - st : st; };
     struct StA { int rr, kb, ke; bool active; };
-    struct StB {
+    struct StC { int rr, kb, ke; bool active; int cc[CGCH]; };
+    struct StG {
         int r, kb, ke, k0e, n, n2;
         bool staged;
-        int cc[GCH];
+        int cc[CGCH];
         unsigned late;          // bit u set: column cc[u] lies inside this chain-tile (written by an earlier step)
-        double xx[GCH][3];      // vector entries of the other columns, fetched one step ahead
+        double xx[CGCH][3];     // vector entries of the other columns, fetched one step ahead
         double rhs[3], Di[BB];
         double2 tmp[U];
     };
@@ -446,7 +455,17 @@ __global__ __launch_bounds__(64) void k_ilu_sweep_chain(int ct_begin, int nct, c
         a.kb = prow[a.rr];
         a.ke = prow[a.rr + 1];
     };
-    auto stageB = [&](int st, const StA& a, StB& b) {
+    auto stageC = [&](const StA& a, StC& c) {
+        c.rr = a.rr; c.kb = a.kb; c.active = a.active;
+        c.ke = a.active ? a.ke : a.kb;
+        const int nrow = c.ke - c.kb;
+#pragma unroll
+        for (int u = 0; u < CGCH; ++u) {
+            const int k = reverse ? c.ke - 1 - u : c.kb + u;
+            c.cc[u] = (u < nrow) ? pcol[k] : -1;
+        }
+    };
+    auto stageG = [&](int st, const StC& c, StG& b) {
         const int ti = tile_of(st);
         const int k0 = sk0[ti], k1 = sk0[ti + 1];
         b.k0e = k0 & ~1;
@@ -454,24 +473,10 @@ __global__ __launch_bounds__(64) void k_ilu_sweep_chain(int ct_begin, int nct, c
         b.staged = nb <= TILE_CAP_BLOCKS + 1;
         b.n = nb * BB;
         b.n2 = b.n >> 1;
-        b.r = a.active ? a.rr : -1;
-        b.kb = a.kb;
-        b.ke = a.active ? a.ke : a.kb;
-        const double* rsrc = (SHAPE == SW_L) ? d : vu;  // the lane's own row: no earlier step of this sweep writes it
-        b.rhs[0] = rsrc[(size_t)a.rr * BS]; b.rhs[1] = rsrc[(size_t)a.rr * BS + 1]; b.rhs[2] = rsrc[(size_t)a.rr * BS + 2];
-        if (SHAPE != SW_L) {
-#pragma unroll
-            for (int q = 0; q < BB; ++q) b.Di[q] = invD[(size_t)a.rr * BB + q];
-        }
-        const int nrow = b.ke - b.kb;
-#pragma unroll
-        for (int u = 0; u < GCH; ++u) {
-            const int k = reverse ? b.ke - 1 - u : b.kb + u;
-            b.cc[u] = (u < nrow) ? pcol[k] : -1;
-        }
-#pragma unroll
-        for (int u = 0; u < GCH; ++u) asm volatile("" : "+v"(b.cc[u]));
-        if (b.staged && b.n2 > 0) {
+        b.r = c.active ? c.rr : -1;
+        b.kb = c.kb;
+        b.ke = c.ke;
+        if (b.staged && b.n2 > 0) {  // the bulk of the bytes first: they are needed first
             const double2* __restrict__ s2 = reinterpret_cast<const double2*>(P + (size_t)b.k0e * BB);
 #pragma unroll
             for (int u = 0; u < U; ++u) {
@@ -479,38 +484,48 @@ __global__ __launch_bounds__(64) void k_ilu_sweep_chain(int ct_begin, int nct, c
                 b.tmp[u] = s2[i < b.n2 ? i : b.n2 - 1];
             }
         }
+        const double* rsrc = (SHAPE == SW_L) ? d : vu;  // the lane's own row: no earlier step of this sweep writes it
+        b.rhs[0] = rsrc[(size_t)c.rr * BS]; b.rhs[1] = rsrc[(size_t)c.rr * BS + 1]; b.rhs[2] = rsrc[(size_t)c.rr * BS + 2];
         b.late = 0u;
 #pragma unroll
-        for (int u = 0; u < GCH; ++u) {
-            const int cq = b.cc[u];
+        for (int u = 0; u < CGCH; ++u) {
+            const int cq = c.cc[u];
+            b.cc[u] = cq;
             const bool inside = cq >= ctR0 && cq < ctR1;
             if (inside) b.late |= 1u << u;
-            const double* xc = &vu[(size_t)((cq < 0 || inside) ? a.rr : cq) * BS];  // harmless own-row address when unused
+            const double* xc = &vu[(size_t)((cq < 0 || inside) ? c.rr : cq) * BS];  // harmless own-row address when unused
             b.xx[u][0] = xc[0]; b.xx[u][1] = xc[1]; b.xx[u][2] = xc[2];
         }
+        if (SHAPE != SW_L) {
+#pragma unroll
+            for (int q = 0; q < BB; ++q) b.Di[q] = invD[(size_t)c.rr * BB + q];
+        }
     };
-    StA a0, a1;
-    StB b;
+    StA a;
+    StC c;
+    StG b;
     int myPrevRow = -1;           // the row this lane finished in the previous step, and its result
     double myPrev[3] = {0.0, 0.0, 0.0};
-    stageA(0, a0);
-    if (nsteps > 1) stageA(1, a1);
-    stageB(0, a0, b);
+    stageA(0, a);
+    stageC(a, c);
+    stageG(0, c, b);
+    if (nsteps > 1) { stageA(1, a); stageC(a, c); }
+    if (nsteps > 2) stageA(2, a);
     for (int st = 0; st < nsteps; ++st) {
-        // ---- C(st), part 1: commit the prefetched values to LDS
+        // ---- X(st), part 1: commit the prefetched values to LDS
 #pragma unroll
         for (int u = 0; u < U; ++u) asm volatile("" : "+v"(b.tmp[u].x), "+v"(b.tmp[u].y));
         const int r = b.r, kb = b.kb, ke = b.ke, k0e = b.k0e, n = b.n, n2 = b.n2;
         const bool staged = b.staged;
         double rhs[3] = {b.rhs[0], b.rhs[1], b.rhs[2]};
         double Di[BB];
-        int cc[GCH];
-        double xx[GCH][3];
+        int cc[CGCH];
+        double xx[CGCH][3];
         const unsigned late = b.late;
 #pragma unroll
         for (int q = 0; q < BB; ++q) Di[q] = b.Di[q];
 #pragma unroll
-        for (int u = 0; u < GCH; ++u) { cc[u] = b.cc[u]; xx[u][0] = b.xx[u][0]; xx[u][1] = b.xx[u][1]; xx[u][2] = b.xx[u][2]; }
+        for (int u = 0; u < CGCH; ++u) { cc[u] = b.cc[u]; xx[u][0] = b.xx[u][0]; xx[u][1] = b.xx[u][1]; xx[u][2] = b.xx[u][2]; }
         double2* d2 = reinterpret_cast<double2*>(sval);
         if (staged && n2 > 0) {
 #pragma unroll
@@ -524,13 +539,15 @@ __global__ __launch_bounds__(64) void k_ilu_sweep_chain(int ct_begin, int nct, c
             if ((n & 1) && lane == 0) sval[n - 1] = P[(size_t)k0e * BB + n - 1];
         }
         wave_sync();
-        // ---- B(st+1) and A(st+2) go out now and fly during this step's work
+        // ---- G(st+1), C(st+2) and A(st+3) go out now and fly during this step's work
         if (st + 1 < nsteps) {
-            stageB(st + 1, a1, b);
-            a0 = a1;
-            if (st + 2 < nsteps) stageA(st + 2, a1);
+            stageG(st + 1, c, b);
+            if (st + 2 < nsteps) {
+                stageC(a, c);
+                if (st + 3 < nsteps) stageA(st + 3, a);
+            }
         }
-        // ---- C(st), part 2: the few columns inside this chain-tile are read now (the previous step wrote them; the
+        // ---- X(st), part 2: the few columns inside this chain-tile are read now (the previous step wrote them; the
         //      lane's own previous row comes straight from registers), products in the row's sequential order, store
         if (r >= 0) {
             const int nrow = ke - kb;
@@ -538,34 +555,34 @@ __global__ __launch_bounds__(64) void k_ilu_sweep_chain(int ct_begin, int nct, c
             // the previous step's stores have completed first (never taken on a line-coloured 7-point stencil)
             bool fromMem = false;
 #pragma unroll
-            for (int u = 0; u < GCH; ++u) fromMem |= (u < nrow && ((late >> u) & 1u) && cc[u] != myPrevRow);
-            if (__any(fromMem || nrow > GCH)) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            for (int u = 0; u < CGCH; ++u) fromMem |= (u < nrow && ((late >> u) & 1u) && cc[u] != myPrevRow);
+            if (__any(fromMem || nrow > CGCH)) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 #pragma unroll
-            for (int u = 0; u < GCH; ++u) {
+            for (int u = 0; u < CGCH; ++u) {
                 if (u < nrow && ((late >> u) & 1u)) {
                     if (cc[u] == myPrevRow) { xx[u][0] = myPrev[0]; xx[u][1] = myPrev[1]; xx[u][2] = myPrev[2]; }
                     else { const double* xc = &vu[(size_t)cc[u] * BS]; xx[u][0] = xc[0]; xx[u][1] = xc[1]; xx[u][2] = xc[2]; }
                 }
             }
 #pragma unroll
-            for (int u = 0; u < GCH; ++u) {
+            for (int u = 0; u < CGCH; ++u) {
                 if (u < nrow) {
                     const int k = reverse ? ke - 1 - u : kb + u;
                     const double* A = staged ? &sval[(k - k0e) * BB] : &P[(size_t)k * BB];
                     blk_mmv(A, xx[u][0], xx[u][1], xx[u][2], rhs);
                 }
             }
-            for (int done = GCH; done < nrow; done += GCH) {  // rows longer than one chunk: everything read now
-                double yy[GCH][3];
+            for (int done = CGCH; done < nrow; done += CGCH) {  // rows longer than one chunk: everything read now
+                double yy[CGCH][3];
 #pragma unroll
-                for (int u = 0; u < GCH; ++u) {
+                for (int u = 0; u < CGCH; ++u) {
                     const int q = (done + u < nrow) ? done + u : nrow - 1;
                     const int cq = pcol[reverse ? ke - 1 - q : kb + q];
                     const double* xc = &vu[(size_t)cq * BS];
                     yy[u][0] = xc[0]; yy[u][1] = xc[1]; yy[u][2] = xc[2];
                 }
 #pragma unroll
-                for (int u = 0; u < GCH; ++u) {
+                for (int u = 0; u < CGCH; ++u) {
                     if (done + u < nrow) {
                         const int k = reverse ? ke - 1 - (done + u) : kb + done + u;
                         const double* A = staged ? &sval[(k - k0e) * BB] : &P[(size_t)k * BB];
@@ -588,6 +605,37 @@ __global__ __launch_bounds__(64) void k_ilu_sweep_chain(int ct_begin, int nct, c
         }
         wave_sync();  // this step's results are visible to the next step; LDS image may be overwritten
     }
+}
+template <int SHAPE>
+__global__ __launch_bounds__(64) void k_ilu_sweep_chain(int ct_begin, int nct, const int* __restrict__ ct_first,
+                                                        const int* __restrict__ tile_row0, const int* __restrict__ prow,
+                                                        const int* __restrict__ pcol, const double* __restrict__ P,
+                                                        const double* __restrict__ invD, const double* d,
+                                                        double* vu, double* v, int relax_mode, double w) {
+    TILE_LDS
+    __shared__ int srow0[CHAIN_MAX_STEPS + 2], sk0[CHAIN_MAX_STEPS + 2];
+    const int lane = threadIdx.x, cl = xcd_tile(blockIdx.x, nct);
+    if (cl >= nct) return;
+    chain_sweep<SHAPE>(ct_first[ct_begin + cl], ct_first[ct_begin + cl + 1], lane, sval, srow0, sk0, tile_row0, prow, pcol, P, invD, d, vu,
+                       v, relax_mode, w);
+}
+// Last colour: its rows have U entries only inside their own chain-tile, so the backward sweep of a chain-tile can
+// start the moment its forward sweep ends - one launch instead of two, and y never leaves the cache in between.
+__global__ __launch_bounds__(64) void k_ilu_sweep_chain_LU(int ct_begin, int nct, const int* __restrict__ ct_first,
+                                                           const int* __restrict__ tile_row0, const int* __restrict__ lrow,
+                                                           const int* __restrict__ lcol, const double* __restrict__ L,
+                                                           const int* __restrict__ urow, const int* __restrict__ ucol,
+                                                           const double* __restrict__ Uv, const double* __restrict__ invD,
+                                                           const double* d, double* vu, double* v, int relax_mode, double w) {
+    TILE_LDS
+    __shared__ int srow0[CHAIN_MAX_STEPS + 2], sk0[CHAIN_MAX_STEPS + 2];
+    const int lane = threadIdx.x, cl = xcd_tile(blockIdx.x, nct);
+    if (cl >= nct) return;
+    const int q0 = ct_first[ct_begin + cl], q1 = ct_first[ct_begin + cl + 1];
+    chain_sweep<SW_L>(q0, q1, lane, sval, srow0, sk0, tile_row0, lrow, lcol, L, invD, d, vu, v, relax_mode, w);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // y of this chain-tile is written before the backward sweep reads it
+    wave_sync();
+    chain_sweep<SW_UF>(q0, q1, lane, sval, srow0, sk0, tile_row0, urow, ucol, Uv, invD, d, vu, v, relax_mode, w);
 }
 
 // ============================== ILU0 factorisation =======================================================
@@ -930,13 +978,19 @@ void launch_ilu_apply(opmhip_ctx* c, const double* d, double* v) {
     const int n0 = P.colorPrefix[1];  // rows of the first colour: their y is d
     auto grid = [](int n) { return dim3(8 * ((n + 7) / 8)); };
     if (P.chained) {
-        for (int col = 0; col < C; ++col) {
+        for (int col = 0; col < C - 1; ++col) {
             const int cb = P.tiles.colorCT[col], nct = P.tiles.colorCT[col + 1] - cb;
             if (nct > 0)
                 hipLaunchKernelGGL(k_ilu_sweep_chain<SW_L>, grid(nct), dim3(64), 0, c->stream, cb, nct, P.tiles.d_ctFirst, P.tiles.d_row0, P.d_lrowptr,
                                    P.d_lcol, c->d_L, c->d_invD, d, vu, v, mode, w);
         }
-        for (int col = C - 1; col >= 0; --col) {
+        {
+            const int cb = P.tiles.colorCT[C - 1], nct = P.tiles.colorCT[C] - cb;
+            if (nct > 0)
+                hipLaunchKernelGGL(k_ilu_sweep_chain_LU, grid(nct), dim3(64), 0, c->stream, cb, nct, P.tiles.d_ctFirst, P.tiles.d_row0, P.d_lrowptr,
+                                   P.d_lcol, c->d_L, P.d_urowptr, P.d_ucol, c->d_U, c->d_invD, d, vu, v, mode, w);
+        }
+        for (int col = C - 2; col >= 0; --col) {
             const int cb = P.tiles.colorCT[col], nct = P.tiles.colorCT[col + 1] - cb;
             if (nct > 0)
                 hipLaunchKernelGGL(k_ilu_sweep_chain<SW_UF>, grid(nct), dim3(64), 0, c->stream, cb, nct, P.tiles.d_ctFirst, P.tiles.d_row0, P.d_urowptr,

@@ -118,6 +118,12 @@ def spe1_case(state="equil"):
                 pv=np.ascontiguousarray(pv.reshape(-1)), meaning=meaning)
 
 
+# Field rate of the five-spot pair on a 100 x 100 x 100 grid (scaled with the areal cell count elsewhere): 0.4 % of a well
+# cell's pore volume per day.  Fixed-rate sources do not see the mobility of the cell they drain, so rates ten times
+# higher desaturate the producer column within weeks and the Newton method then fails on 10-day steps.
+BENCH_RATE_SM3_PER_DAY = 200.0
+
+
 def five_spot_source(case, rate_sm3_per_day=50.0):
     """Fixed-rate source terms (surface m^3/s per cell, equations oil/water/gas): water injected in one corner
     column, the same surface volume of oil (+ its dissolved gas at the initial Rs) produced in the opposite one."""

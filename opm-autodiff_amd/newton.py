@@ -155,3 +155,94 @@ class BlackoilModelHip:
             raise TooManyIterations("Failed to complete a time step within %d iterations." % self.param.newton_max_iter)
         report.converged = True
         return report
+
+    # -- FvBaseDiscretization::advanceTimeLevel / updateFailed ---------------------------------------------------
+    def advance_time_level(self):
+        self.m.advance_time_level()
+
+    def update_failed(self):
+        self.m.update_failed()
+
+
+@dataclass
+class TimeSteppingParameters:
+    """AdaptiveTimeSteppingEbos.hpp:112-200 defaults (FlowTimeSteppingParameters)"""
+    restart_factor: float = 0.33          # SolverRestartFactor
+    growth_factor: float = 2.0            # SolverGrowthFactor (first step after a chop)
+    max_growth: float = 3.0               # SolverMaxGrowth
+    max_restarts: int = 10                # SolverMaxRestarts
+    target_newton_iterations: int = 8     # TimeStepControlTargetNewtonIterations
+    decay_damping: float = 1.0            # TimeStepControlDecayDampingFactor
+    growth_damping: float = 3.2           # TimeStepControlGrowthDampingFactor
+    initial_dt: float = 86400.0           # InitialTimeStepInDays
+    max_dt: float = 365.0 * 86400.0       # SolverMaxTimeStepInDays (bench.py passes its report-step length)
+
+
+class AdaptiveTimeStepping:
+    """The sub-stepping loop of AdaptiveTimeSteppingEbos::step (opm/simulators/timestepping/AdaptiveTimeSteppingEbos.hpp
+    :283-520) over any model object with nonlinear_iteration(iteration, dt) -> report, advance_time_level(),
+    update_failed() and param.newton_max_iter: a failed time step (TooManyIterations, NumericalIssue) is rolled back and
+    retried with dt * restart_factor; an accepted one sets the next dt with the Newton-iteration-count rule of
+    PIDAndIterationCountTimeStepControl::computeTimeStepSize (timestepping/TimeStepControl.cpp:188-208; its PID part
+    needs the relative change of the solution and is left out, which only makes the steps longer).
+    Hands out Newton iterations one at a time so that a benchmark can count and time them."""
+
+    def __init__(self, model, param=None):
+        self.model = model
+        self.p = param or TimeSteppingParameters()
+        self.dt = self.p.initial_dt
+        self.iteration = 0
+        self.restarts = 0
+        self.timesteps_done = 0
+        self.timesteps_failed = 0
+        self.time = 0.0
+        self.report = SimulatorReportSingle()
+        self.history = []          # (dt, newton iterations, accepted)
+
+    def _next_dt(self, dt, iterations):
+        p = self.p
+        tgt = p.target_newton_iterations
+        if iterations > tgt:
+            est = dt / (1.0 + (iterations - tgt) / tgt * p.decay_damping)
+        else:
+            est = dt * (1.0 + (tgt - iterations) / tgt * p.growth_damping)
+        est = min(est, p.max_growth * dt)                      # AdaptiveTimeSteppingEbos.hpp:404-406
+        if self.restarts > 0:                                  # :408-411
+            est = min(p.growth_factor * dt, est)
+            self.restarts = 0
+        return min(est, p.max_dt)
+
+    def next_newton_iteration(self):
+        """Runs nonlinear iterations until one of them actually solved a system; returns its report."""
+        while True:
+            if self.iteration == 0 and self.restarts == 0:
+                self.model.advance_time_level()
+            failed = False
+            try:
+                rep = self.model.nonlinear_iteration(self.iteration, self.dt)
+            except NumericalIssue:
+                failed, rep = True, None
+            if rep is not None:
+                self.report += rep
+                self.iteration += 1
+                if rep.converged:
+                    self.history.append((self.dt, self.iteration - 1, True))
+                    self.time += self.dt
+                    self.dt = self._next_dt(self.dt, self.iteration - 1)
+                    self.timesteps_done += 1
+                    self.iteration = 0
+                    continue   # the converged check cost an assembly; it is inside the timed region like in Flow
+                failed = self.iteration > self.model.param.newton_max_iter
+            if failed:
+                self.history.append((self.dt, self.iteration, False))
+                self.timesteps_failed += 1
+                self.restarts += 1
+                if self.restarts > self.p.max_restarts:
+                    raise TooManyIterations("time step chopped %d times in a row" % self.p.max_restarts)
+                self.model.update_failed()
+                self.dt *= self.p.restart_factor
+                self.iteration = 0
+                if rep is None:
+                    continue
+            if rep is not None and rep.total_newton_iterations:
+                return rep

@@ -126,7 +126,7 @@ def cartesian_subdomain_case(n_per_rank, nranks, rank, state="mixed", heterogene
                 pv=np.ascontiguousarray(cells["pv"].reshape(-1, 3)[g].reshape(-1)), meaning=np.ascontiguousarray(cells["meaning"][g]),
                 gids=g, halo=lp, global_cells=NX * NY * NZ, nx=NX, ny=NY, nz=NZ)
     src_global = _decks.five_spot_source(dict(Nb=NX * NY * NZ, nx=NX, ny=NY, nz=NZ, pv=cells["pv"], meaning=cells["meaning"], fluid=cells["fluid"]),
-                                         rate_sm3_per_day=(rate_scale if rate_scale is not None else 2000.0 * (n / 100.0) ** 2) * nranks ** (2.0 / 3.0))
+                                         rate_sm3_per_day=(rate_scale if rate_scale is not None else _decks.BENCH_RATE_SM3_PER_DAY * (n / 100.0) ** 2) * nranks ** (2.0 / 3.0))
     case["source"] = np.ascontiguousarray(src_global.reshape(-1, 3)[g].reshape(-1))
     return case
 

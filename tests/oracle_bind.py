@@ -153,9 +153,9 @@ class OracleModel:
         self.o.lib.orc_bo_get_iq(self.h, out)
         return out.reshape(self.Nb, 17, 4)
 
-    def assemble(self, dt, iteration):
-        jac = np.empty(self.nnzb * 9)
-        res = np.empty(self.Nb * 3)
+    def assemble(self, dt, iteration, fetch=True):
+        jac = np.empty(self.nnzb * 9) if fetch else None
+        res = np.empty(self.Nb * 3) if fetch else None
         self.o.lib.orc_bo_assemble(self.h, dt, iteration, _p(jac), _p(res))
         return jac, res
 
@@ -183,6 +183,38 @@ class OracleModel:
         rc = self.o.lib.orc_bo_solve(self.h, x, tol, maxit, w, RELAX[mode], REORDER[reorder], nsub, _p(ss), C.byref(res))
         assert rc == 0, rc
         return x, res
+
+
+class OracleAsHipModel:
+    """An OracleModel behind the method names of capi.HipModel that newton.BlackoilModelHip / AdaptiveTimeStepping call,
+    so that the CPU restatement can be driven by the very same Newton and time-stepping loop (bench.py's cpu_baseline,
+    tests).  Checker-side only."""
+
+    def __init__(self, om, tol=1e-2, maxit=200, w=0.9, mode="post_scale", reorder="none"):
+        self.om, self.kw = om, dict(tol=tol, maxit=maxit, w=w, mode=mode, reorder=reorder)
+        self._x = None
+        self._prev = None
+
+    def assemble(self, dt, iteration, fetch=False):
+        return self.om.assemble(dt, iteration, fetch=fetch)
+
+    def convergence(self, dt, tol_cnv=1e-2):
+        return self.om.convergence(dt, tol_cnv)
+
+    def solve_jacobian_system(self):
+        from types import SimpleNamespace
+        self._x, r = self.om.solve(**self.kw)
+        return SimpleNamespace(t_factor=r.t_factor, t_solve=r.t_solve, t_copy=0.0, iterations=r.iterations, converged=bool(r.converged), it=r.it)
+
+    def update(self, dx, relax=1.0):
+        x = self._x if dx is None else np.asarray(dx, np.float64)
+        return self.om.update(x if relax == 1.0 else relax * x)
+
+    def advance_time_level(self):
+        self._prev = self.om.get_state()
+
+    def update_failed(self):
+        self.om.set_state(*self._prev)
 
 
 def oil_pvt_probe(oracle, fluid, region, rs, p):

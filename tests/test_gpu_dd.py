@@ -43,7 +43,7 @@ def global_and_parts(pkg, n, world, **kw):
     return g, owner, parts
 
 
-@pytest.mark.parametrize("world", [2, 4])
+@pytest.mark.parametrize("world", [2, 4, 8])
 def test_dd_assembly_bitwise_and_solve(pkg, orc, world):
     n = 6
     g, owner, parts = global_and_parts(pkg, n, world, state="mixed", heterogeneous=True)

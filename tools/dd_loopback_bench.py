@@ -1,0 +1,49 @@
+#!/usr/bin/env python3
+"""Rehearsal of bench.py's multi-rank path on ONE GPU: `world` subdomains of n^3 cells each, one host thread per rank,
+the loopback communicator instead of RCCL (same set_pattern_dd / halo / all-reduce code).  Reports Newton and linear
+iteration counts per time step - the robustness check for the N = 2, 4, 8 runs only the driver can launch.
+    python tools/dd_loopback_bench.py --world 8 --n 50 --steps 30"""
+import argparse, importlib, os, sys, threading, time
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import bench  # noqa: E402
+
+ap = argparse.ArgumentParser()
+ap.add_argument("--world", type=int, default=8)
+ap.add_argument("--n", type=int, default=50)
+ap.add_argument("--steps", type=int, default=30)
+ap.add_argument("--reorder", default="line_coloring")
+a = ap.parse_args()
+pkg = importlib.import_module("opm-autodiff_amd")
+group = "ddbench%d" % os.getpid()
+out, err = [None] * a.world, [None] * a.world
+
+
+def body(r):
+    try:
+        case = pkg.ras.cartesian_subdomain_case(a.n, a.world, r, state="mixed", heterogeneous=False)
+        m = pkg.capi.HipModel(case, comm=("loopback", a.world, r, group), reorder=a.reorder, tolerance=1e-2, maxit=200, ilu_relaxation=0.9)
+        m.set_state(case["pv"], case["meaning"])
+        m.set_source(case["source"])
+        sim = bench.make_simulation(pkg, m)
+        t0 = time.perf_counter()
+        log = []
+        for _ in range(a.steps):
+            rep = sim.next_newton_iteration()
+            log.append((sim.timesteps_done, sim.iteration, rep.total_linear_iterations))
+        out[r] = (time.perf_counter() - t0, log, sim.timesteps_done, sim.history)
+    except Exception as e:  # noqa: BLE001
+        err[r] = e
+        raise
+
+
+ts = [threading.Thread(target=body, args=(r,)) for r in range(a.world)]
+[t.start() for t in ts]
+[t.join() for t in ts]
+if any(e is not None for e in err):
+    raise SystemExit("rank failures: %r" % err)
+el, log, done, hist = out[0]
+print("world %d n %d: %d Newton iterations in %.2f s, %d time steps done" % (a.world, a.n, a.steps, el, done))
+print("(step, newton, linear its):", log)
+print("time steps (days, newton its, accepted):", [(round(h[0] / bench.DAY, 3), h[1], h[2]) for h in hist])
+assert all(o[1] == log for o in out), "ranks disagree on the iteration history"

@@ -9,7 +9,7 @@ import oracle_bind
 orc = oracle_bind.Oracle(os.path.join(ROOT, "oracle", "liboracle.so"))
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 40
 case = pkg.decks.cartesian_case(n, n, n, state="mixed", heterogeneous=False)
-src = pkg.decks.five_spot_source(case, rate_sm3_per_day=2000.0 * (n / 100.0) ** 2)
+src = pkg.decks.five_spot_source(case, rate_sm3_per_day=pkg.decks.BENCH_RATE_SM3_PER_DAY * (n / 100.0) ** 2)
 m = oracle_bind.OracleModel(orc, case)
 m.set_state(case["pv"], case["meaning"]); m.set_source(src)
 dt = 10 * 86400.0
