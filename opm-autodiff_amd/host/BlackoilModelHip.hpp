@@ -158,6 +158,48 @@ public:
         report.converged = true;
         return report;
     }
+
+    /// FvBaseDiscretization::advanceTimeLevel / updateFailed: solution(1) <-> solution(0) on the device
+    void advanceTimeLevel() { check(opmhip_advance_time_level(ctx_), "advanceTimeLevel"); }
+    void updateFailed() { check(opmhip_update_failed(ctx_), "updateFailed"); }
+
+    /// The sub-step loop of AdaptiveTimeSteppingEbos::step (timestepping/AdaptiveTimeSteppingEbos.hpp:283-520) for one
+    /// report step of length `length` starting with sub-step `dt`: a failed sub-step is rolled back and retried with
+    /// dt * 0.33 (SolverRestartFactor, at most SolverMaxRestarts = 10 times in a row); an accepted one sets the next dt
+    /// by the Newton-iteration-count rule (TimeStepControl.cpp:188-208, target 8, growth damping 3.2, decay damping 1),
+    /// capped by SolverMaxGrowth = 3 and, right after a chop, by SolverGrowthFactor = 2.  Returns the suggested next dt.
+    double advanceReportStep(double length, double dt, SimulatorReportSingle& report, int* chopped = nullptr) {
+        const double restartFactor = 0.33, growthFactor = 2.0, maxGrowth = 3.0, growthDamping = 3.2, decayDamping = 1.0;
+        const int maxRestarts = 10, target = 8;
+        double t = 0.0;
+        int restarts = 0;
+        while (t < length * (1.0 - 1e-12)) {
+            dt = std::min(dt, length - t);
+            if (restarts == 0) advanceTimeLevel();
+            int newtons = 0;
+            bool ok = true;
+            try {
+                SimulatorReportSingle r = step(dt);
+                report += r;
+                newtons = r.total_newton_iterations;
+            } catch (const TooManyIterations&) { ok = false; }
+            catch (const NumericalIssue&) { ok = false; }
+            if (!ok) {
+                if (++restarts > maxRestarts) throw TooManyIterations("time step chopped " + std::to_string(maxRestarts) + " times in a row");
+                if (chopped) ++*chopped;
+                updateFailed();
+                dt *= restartFactor;
+                continue;
+            }
+            t += dt;
+            double est = newtons > target ? dt / (1.0 + double(newtons - target) / target * decayDamping)
+                                          : dt * (1.0 + double(target - newtons) / target * growthDamping);
+            est = std::min(est, maxGrowth * dt);
+            if (restarts > 0) { est = std::min(growthFactor * dt, est); restarts = 0; }
+            dt = est;
+        }
+        return dt;
+    }
 };
 
 }  // namespace Opm

@@ -70,9 +70,18 @@ int main(int argc, char** argv) {
     if (C.count("source")) CK(opmhip_set_source(ctx, C["source"].f64(), nullptr));
     Opm::BlackoilModelHip model(ctx, Nb, nnzb);
     Opm::SimulatorReportSingle total;
+    const bool adaptive = std::getenv("OPMHIP_TEST_ADAPTIVE") != nullptr;  // report steps of length dt under the sub-step control
+    double sub = dt;
     for (int s = 0; s < nsteps; ++s) {
         try {
-            Opm::SimulatorReportSingle r = model.step(dt);
+            Opm::SimulatorReportSingle r;
+            if (adaptive) {
+                int chopped = 0;
+                sub = model.advanceReportStep(dt, sub, r, &chopped);
+                std::printf("report step %d chopped %d next dt %.6g\n", s, chopped, sub);
+            } else {
+                r = model.step(dt);
+            }
             total += r;
             std::printf("step %d newton %u linear %u\n", s, r.total_newton_iterations, r.total_linear_iterations);
         } catch (const std::exception& e) {

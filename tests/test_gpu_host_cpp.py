@@ -66,3 +66,23 @@ def test_BlackoilModelHip_step_matches_python_loop(pkg, tmp_path):
     mean = raw[case["Nb"] * 24:]
     pm, mm = m.get_state()
     assert np.array_equal(mean, mm) and np.array_equal(pv, pm)  # same library, same call sequence: identical bits
+
+
+def test_BlackoilModelHip_report_step_survives_a_chop(pkg, tmp_path):
+    """advanceReportStep (C++ mirror of AdaptiveTimeSteppingEbos::step): a report step whose first sub-step is too long
+    for the Newton method is rolled back on the device, chopped and completed; the same case without the sub-step
+    control fails, as NonlinearSolverEbos::step does."""
+    case = pkg.decks.cartesian_case(8, 8, 8, state="mixed", heterogeneous=False)
+    src = pkg.decks.five_spot_source(case, rate_sm3_per_day=60.0)
+    cf, so = str(tmp_path / "case.bin"), str(tmp_path / "state.bin")
+    pkg.decks.write_case_binary(case, cf, source=src)
+    args = [_exe("test_BlackoilModelHip"), cf, "level_scheduling", repr(30 * 86400.0), "1", so]
+    plain = subprocess.run(args, capture_output=True, text=True)
+    assert plain.returncode == 4 and "Failed to complete a time step" in plain.stderr
+    out = subprocess.run(args, capture_output=True, text=True, env=dict(os.environ, OPMHIP_TEST_ADAPTIVE="1"))
+    assert out.returncode == 0, out.stderr + out.stdout
+    line = [l for l in out.stdout.splitlines() if l.startswith("report step 0")][0].split()
+    assert int(line[4]) >= 1
+    raw = np.fromfile(so, dtype=np.uint8)
+    pv = raw[:case["Nb"] * 24].view(np.float64).reshape(-1, 3)
+    assert np.all(np.isfinite(pv)) and np.all(pv[:, 1] > 1e7) and np.all(pv[:, 0] > 0.0) and np.all(pv[:, 0] < 1.0)
