@@ -37,7 +37,13 @@ int alloc_system(opmhip_ctx* c) {
     OPMHIP_HIP(c, hipMemset(c->d_part, 0, (size_t)2 * c->npart * sizeof(double)));
     if ((rc = dev_alloc(c, &c->d_part2, (size_t)1024))) return rc;
     OPMHIP_HIP(c, hipMemset(c->d_part2, 0, 1024 * sizeof(double)));
-    OPMHIP_HIP(c, hipHostMalloc((void**)&c->h_pinned, SC_COUNT * sizeof(double)));
+    if (!c->h_pinned) OPMHIP_HIP(c, hipHostMalloc((void**)&c->h_pinned, SC_COUNT * sizeof(double)));
+    if (!c->h_ring) {
+    OPMHIP_HIP(c, hipHostMalloc((void**)&c->h_ring, opmhip_ctx::RB_SLOTS * opmhip_ctx::RB_DOUBLES * sizeof(double), hipHostMallocMapped));
+    OPMHIP_HIP(c, hipHostGetDevicePointer((void**)&c->d_ring, c->h_ring, 0));
+    for (int i = 0; i < opmhip_ctx::RB_SLOTS; ++i) OPMHIP_HIP(c, hipEventCreateWithFlags(&c->rb_ev[i], hipEventDisableTiming));
+    }
+    c->d_done = c->d_scal + SC_ZERO;
     return OPMHIP_SUCCESS;
 }
 
@@ -181,6 +187,8 @@ void opmhip_destroy(opmhip_ctx* c) {
     comm_release(c);
     for (void* p : c->allocs) (void)hipFree(p);
     if (c->h_pinned) (void)hipHostFree(c->h_pinned);
+    if (c->h_ring) (void)hipHostFree(c->h_ring);
+    for (hipEvent_t e : c->rb_ev) if (e) (void)hipEventDestroy(e);
     if (c->ev0) (void)hipEventDestroy(c->ev0);
     if (c->ev1) (void)hipEventDestroy(c->ev1);
     for (hipEvent_t e : c->prof.pool) (void)hipEventDestroy(e);
@@ -361,7 +369,7 @@ int opmhip_profile_get(opmhip_ctx* c, int cls, long long* launches, double* tota
         Profiler& P = c->prof;
         for (size_t i = 0; i < P.used; ++i) {
             float ms = 0.f;
-            if (hipEventElapsedTime(&ms, P.pool[2 * i], P.pool[2 * i + 1]) == hipSuccess) {
+            if (P.cls[i] >= 0 && hipEventElapsedTime(&ms, P.pool[2 * i], P.pool[2 * i + 1]) == hipSuccess) {
                 P.total_ms[P.cls[i]] += ms;
                 P.count[P.cls[i]] += 1;
             }

@@ -112,7 +112,7 @@ enum ProfClass { PROF_SPMV = 0, PROF_ILU_APPLY, PROF_ILU_FACTOR, PROF_VECTOR, PR
 struct Profiler {
     bool enabled = false;
     std::vector<hipEvent_t> pool;             // event pairs, allocated on demand
-    std::vector<int> cls;                     // class of pair i
+    std::vector<int> cls;                     // class of pair i (-1: voided - a speculative launch past the stopping point)
     size_t used = 0;                          // pairs in use
     static constexpr size_t CAP = 1 << 15;
     double total_ms[PROF_COUNT] = {0};
@@ -120,7 +120,10 @@ struct Profiler {
 };
 
 enum Scal {  // device-resident BiCGStab scalars (double d_scal[SC_COUNT])
-    SC_RHO = 0, SC_RHOP, SC_ALPHA, SC_OMEGA, SC_BETA, SC_TMP1, SC_TMP2, SC_NORM, SC_NORM0, SC_COUNT = 16
+    SC_RHO = 0, SC_RHOP, SC_ALPHA, SC_OMEGA, SC_BETA, SC_TMP1, SC_TMP2, SC_NORM, SC_NORM0,
+    SC_DONE,   // 1.0 once the stopping rule held: every later kernel of the solve returns at once (speculative launches)
+    SC_ZERO,   // never written: the "not done" flag of launches outside a solve
+    SC_COUNT = 16
 };
 
 }  // namespace opmhip
@@ -145,6 +148,13 @@ struct opmhip_ctx {
     double* d_part2 = nullptr;  // second-level partials: 2 x RED1_BLOCKS
     int npart = 0;
     double* h_pinned = nullptr;  // SC_COUNT doubles, pinned
+    // read-back ring of the BiCGStab stopping rule: k_finalize writes (norm, norm_0, done) of half iteration h straight
+    // into pinned host slot h % RB_SLOTS, an event marks it; the host runs one half iteration ahead of the device
+    static constexpr int RB_SLOTS = 4, RB_DOUBLES = 4;
+    double* h_ring = nullptr;    // pinned, RB_SLOTS x RB_DOUBLES
+    double* d_ring = nullptr;    // the same memory through the device's eyes
+    hipEvent_t rb_ev[RB_SLOTS] = {nullptr, nullptr, nullptr, nullptr};
+    const double* d_done = nullptr;  // flag the tile kernels test first: &d_scal[SC_ZERO] outside a solve, &d_scal[SC_DONE] inside
     opmhip::WellsDev wells;
     opmhip::AsmDev asmb;
     opmhip::CommDev comm;

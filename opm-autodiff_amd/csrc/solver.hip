@@ -327,10 +327,11 @@ template <int NDOT>
 __global__ __launch_bounds__(64) void k_spmv(int nt, const int* __restrict__ tile_row0, const int* __restrict__ rowptr,
                                              const int* __restrict__ col, const double* __restrict__ val,
                                              const double* __restrict__ x, double* __restrict__ y,
-                                             const double* __restrict__ w0, double* __restrict__ part, int npart) {
+                                             const double* __restrict__ w0, double* __restrict__ part, int npart,
+                                             const double* __restrict__ done) {
     TILE_LDS
     const int lane = threadIdx.x, t = xcd_tile(blockIdx.x, nt);
-    if (t >= nt) return;
+    if (t >= nt || *done != 0.0) return;
     TileCtx T;
     double acc[3] = {0.0, 0.0, 0.0};
     const int r = tile_row_product<false>(t, tile_row0, rowptr, col, val, x, sval, lane, false, acc, T);
@@ -371,10 +372,10 @@ __global__ __launch_bounds__(64) void k_ilu_sweep(int tile_begin, int ntc, int n
                                                   const int* __restrict__ prow, const int* __restrict__ pcol,
                                                   const double* __restrict__ P, const double* __restrict__ invD,
                                                   const double* __restrict__ d, double* __restrict__ vu, double* __restrict__ v,
-                                                  int relax_mode, double w) {
+                                                  int relax_mode, double w, const double* __restrict__ done) {
     TILE_LDS
     const int lane = threadIdx.x, tl = xcd_tile(blockIdx.x, ntc);
-    if (tl >= ntc) return;
+    if (tl >= ntc || *done != 0.0) return;
     const int t = tile_begin + tl;
     const int r0 = tile_row0[t], r1 = tile_row0[t + 1];
     const int rq = (r0 + lane < r1) ? r0 + lane : r1 - 1;
@@ -611,11 +612,11 @@ __global__ __launch_bounds__(64) void k_ilu_sweep_chain(int ct_begin, int nct, c
                                                         const int* __restrict__ tile_row0, const int* __restrict__ prow,
                                                         const int* __restrict__ pcol, const double* __restrict__ P,
                                                         const double* __restrict__ invD, const double* d,
-                                                        double* vu, double* v, int relax_mode, double w) {
+                                                        double* vu, double* v, int relax_mode, double w, const double* __restrict__ done) {
     TILE_LDS
     __shared__ int srow0[CHAIN_MAX_STEPS + 2], sk0[CHAIN_MAX_STEPS + 2];
     const int lane = threadIdx.x, cl = xcd_tile(blockIdx.x, nct);
-    if (cl >= nct) return;
+    if (cl >= nct || *done != 0.0) return;
     chain_sweep<SHAPE>(ct_first[ct_begin + cl], ct_first[ct_begin + cl + 1], lane, sval, srow0, sk0, tile_row0, prow, pcol, P, invD, d, vu,
                        v, relax_mode, w);
 }
@@ -626,11 +627,12 @@ __global__ __launch_bounds__(64) void k_ilu_sweep_chain_LU(int ct_begin, int nct
                                                            const int* __restrict__ lcol, const double* __restrict__ L,
                                                            const int* __restrict__ urow, const int* __restrict__ ucol,
                                                            const double* __restrict__ Uv, const double* __restrict__ invD,
-                                                           const double* d, double* vu, double* v, int relax_mode, double w) {
+                                                           const double* d, double* vu, double* v, int relax_mode, double w,
+                                                           const double* __restrict__ done) {
     TILE_LDS
     __shared__ int srow0[CHAIN_MAX_STEPS + 2], sk0[CHAIN_MAX_STEPS + 2];
     const int lane = threadIdx.x, cl = xcd_tile(blockIdx.x, nct);
-    if (cl >= nct) return;
+    if (cl >= nct || *done != 0.0) return;
     const int q0 = ct_first[ct_begin + cl], q1 = ct_first[ct_begin + cl + 1];
     chain_sweep<SW_L>(q0, q1, lane, sval, srow0, sk0, tile_row0, lrow, lcol, L, invD, d, vu, v, relax_mode, w);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // y of this chain-tile is written before the backward sweep reads it
@@ -778,6 +780,7 @@ __global__ __launch_bounds__(VB) void k_bicg_init(int n, const double* __restric
 // p = (p - omega v) beta + r     (bda/openclKernels.cpp:130-153 "custom")
 __global__ __launch_bounds__(VB) void k_bicg_pupdate(int n, const double* __restrict__ scal, double* __restrict__ p,
                                                      const double* __restrict__ v, const double* __restrict__ r) {
+    if (scal[SC_DONE] != 0.0) return;
     const double omega = scal[SC_OMEGA], beta = scal[SC_BETA];
     const int base = blockIdx.x * VB * VPT + threadIdx.x;
 #pragma unroll
@@ -790,6 +793,7 @@ __global__ __launch_bounds__(VB) void k_bicg_pupdate(int n, const double* __rest
 __global__ __launch_bounds__(VB) void k_bicg_upd1(int n, const double* __restrict__ scal, double* __restrict__ r,
                                                   const double* __restrict__ v, double* __restrict__ x,
                                                   const double* __restrict__ pw, double* __restrict__ part, int npart) {
+    if (scal[SC_DONE] != 0.0) return;
     const double alpha = scal[SC_ALPHA];
     double s = 0.0;
     const int base = blockIdx.x * VB * VPT + threadIdx.x;
@@ -810,6 +814,7 @@ __global__ __launch_bounds__(VB) void k_bicg_upd2(int n, const double* __restric
                                                   const double* __restrict__ sv, double* __restrict__ r,
                                                   const double* __restrict__ tv, const double* __restrict__ rw,
                                                   double* __restrict__ part, int npart) {
+    if (scal[SC_DONE] != 0.0) return;
     const double omega = scal[SC_OMEGA];
     double s = 0.0, q = 0.0;
     const int base = blockIdx.x * VB * VPT + threadIdx.x;
@@ -870,9 +875,13 @@ __global__ __launch_bounds__(VB) void k_local_sums(int count, const double* __re
 }
 // Sum the partials in a fixed order and update the device-resident scalars.  One workgroup.
 enum FinMode { FIN_INIT = 0, FIN_ALPHA = 1, FIN_NORM = 2, FIN_OMEGA = 3, FIN_NORM_RHO = 4 };
+// FIN_NORM / FIN_NORM_RHO evaluate the stopping rule (norm < tol * norm_0, bda/cusparseSolverBackend.cu:115,151) on the
+// device: they raise scal[SC_DONE] and leave (norm, norm_0, done) in the pinned host slot `hslot` for the host, which
+// meanwhile has enqueued the next half iteration already.  Once the flag is up nothing changes any more.
 __global__ __launch_bounds__(VB) void k_finalize(int mode, int count, const double* __restrict__ part, int npart,
-                                                 double* __restrict__ scal) {
+                                                 double* __restrict__ scal, double tol, double* __restrict__ hslot) {
     __shared__ double sh[2][VB];
+    if (mode != FIN_INIT && scal[SC_DONE] != 0.0) return;
     double a = 0.0, b = 0.0;
     for (int i = threadIdx.x; i < count; i += VB) { a += part[i]; b += part[npart + i]; }
     sh[0][threadIdx.x] = a; sh[1][threadIdx.x] = b;
@@ -887,9 +896,10 @@ __global__ __launch_bounds__(VB) void k_finalize(int mode, int count, const doub
         case FIN_INIT:
             scal[SC_NORM0] = sqrt(s0); scal[SC_NORM] = sqrt(s0);
             scal[SC_RHO] = s0; scal[SC_RHOP] = 1.0; scal[SC_ALPHA] = 1.0; scal[SC_OMEGA] = 1.0; scal[SC_BETA] = 0.0;
+            scal[SC_DONE] = 0.0;
             break;
         case FIN_ALPHA: scal[SC_TMP1] = s0; scal[SC_ALPHA] = scal[SC_RHO] / s0; break;
-        case FIN_NORM: scal[SC_NORM] = sqrt(s0); break;
+        case FIN_NORM: scal[SC_NORM] = sqrt(s0); break;  // stopping rule: below
         case FIN_OMEGA: scal[SC_TMP1] = s0; scal[SC_TMP2] = s1; scal[SC_OMEGA] = s0 / s1; break;
         case FIN_NORM_RHO: {
             scal[SC_NORM] = sqrt(s0);
@@ -897,6 +907,12 @@ __global__ __launch_bounds__(VB) void k_finalize(int mode, int count, const doub
             scal[SC_RHOP] = rhop; scal[SC_RHO] = s1;
             scal[SC_BETA] = (s1 / rhop) * (scal[SC_ALPHA] / scal[SC_OMEGA]);
         } break;
+    }
+    if (hslot && (mode == FIN_NORM || mode == FIN_NORM_RHO)) {
+        const double norm = scal[SC_NORM], norm0 = scal[SC_NORM0];
+        const double stop = (norm < tol * norm0) ? 1.0 : 0.0;
+        scal[SC_DONE] = stop;
+        hslot[0] = norm; hslot[1] = norm0; hslot[2] = stop;
     }
 }
 
@@ -940,11 +956,11 @@ void launch_spmv(opmhip_ctx* c, const double* x, double* y, int ndot, const doub
     const int fused = wells ? 0 : ndot;
     const int ps = prof_begin(c, PROF_SPMV);
     if (fused == 0)
-        hipLaunchKernelGGL(k_spmv<0>, dim3(ntp), dim3(64), 0, c->stream, nt, P.tiles.d_row0, P.d_rowptr, P.d_col, c->d_A, x, y, w0, c->d_part, c->npart);
+        hipLaunchKernelGGL(k_spmv<0>, dim3(ntp), dim3(64), 0, c->stream, nt, P.tiles.d_row0, P.d_rowptr, P.d_col, c->d_A, x, y, w0, c->d_part, c->npart, c->d_done);
     else if (fused == 1)
-        hipLaunchKernelGGL(k_spmv<1>, dim3(ntp), dim3(64), 0, c->stream, nt, P.tiles.d_row0, P.d_rowptr, P.d_col, c->d_A, x, y, w0, c->d_part, c->npart);
+        hipLaunchKernelGGL(k_spmv<1>, dim3(ntp), dim3(64), 0, c->stream, nt, P.tiles.d_row0, P.d_rowptr, P.d_col, c->d_A, x, y, w0, c->d_part, c->npart, c->d_done);
     else
-        hipLaunchKernelGGL(k_spmv<2>, dim3(ntp), dim3(64), 0, c->stream, nt, P.tiles.d_row0, P.d_rowptr, P.d_col, c->d_A, x, y, w0, c->d_part, c->npart);
+        hipLaunchKernelGGL(k_spmv<2>, dim3(ntp), dim3(64), 0, c->stream, nt, P.tiles.d_row0, P.d_rowptr, P.d_col, c->d_A, x, y, w0, c->d_part, c->npart, c->d_done);
     prof_end(c, ps);
     if (wells) {
         launch_wells_apply(c, x, y);
@@ -982,19 +998,19 @@ void launch_ilu_apply(opmhip_ctx* c, const double* d, double* v) {
             const int cb = P.tiles.colorCT[col], nct = P.tiles.colorCT[col + 1] - cb;
             if (nct > 0)
                 hipLaunchKernelGGL(k_ilu_sweep_chain<SW_L>, grid(nct), dim3(64), 0, c->stream, cb, nct, P.tiles.d_ctFirst, P.tiles.d_row0, P.d_lrowptr,
-                                   P.d_lcol, c->d_L, c->d_invD, d, vu, v, mode, w);
+                                   P.d_lcol, c->d_L, c->d_invD, d, vu, v, mode, w, c->d_done);
         }
         {
             const int cb = P.tiles.colorCT[C - 1], nct = P.tiles.colorCT[C] - cb;
             if (nct > 0)
                 hipLaunchKernelGGL(k_ilu_sweep_chain_LU, grid(nct), dim3(64), 0, c->stream, cb, nct, P.tiles.d_ctFirst, P.tiles.d_row0, P.d_lrowptr,
-                                   P.d_lcol, c->d_L, P.d_urowptr, P.d_ucol, c->d_U, c->d_invD, d, vu, v, mode, w);
+                                   P.d_lcol, c->d_L, P.d_urowptr, P.d_ucol, c->d_U, c->d_invD, d, vu, v, mode, w, c->d_done);
         }
         for (int col = C - 2; col >= 0; --col) {
             const int cb = P.tiles.colorCT[col], nct = P.tiles.colorCT[col + 1] - cb;
             if (nct > 0)
                 hipLaunchKernelGGL(k_ilu_sweep_chain<SW_UF>, grid(nct), dim3(64), 0, c->stream, cb, nct, P.tiles.d_ctFirst, P.tiles.d_row0, P.d_urowptr,
-                                   P.d_ucol, c->d_U, c->d_invD, d, vu, v, mode, w);
+                                   P.d_ucol, c->d_U, c->d_invD, d, vu, v, mode, w, c->d_done);
         }
         prof_end(c, ps);
         return;
@@ -1004,21 +1020,22 @@ void launch_ilu_apply(opmhip_ctx* c, const double* d, double* v) {
         if (nt <= 0) continue;
         if (col < C - 1)
             hipLaunchKernelGGL(k_ilu_sweep<SW_L>, grid(nt), dim3(64), 0, c->stream, tb, nt, n0, 0, P.tiles.d_row0, P.d_lrowptr, P.d_lcol, c->d_L,
-                               c->d_invD, d, vu, v, mode, w);
+                               c->d_invD, d, vu, v, mode, w, c->d_done);
         else
             hipLaunchKernelGGL(k_ilu_sweep<SW_LF>, grid(nt), dim3(64), 0, c->stream, tb, nt, n0, 0, P.tiles.d_row0, P.d_lrowptr, P.d_lcol, c->d_L,
-                               c->d_invD, d, vu, v, mode, w);
+                               c->d_invD, d, vu, v, mode, w, c->d_done);
     }
     for (int col = (C > 1 ? C - 2 : 0); col >= 0; --col) {
         const int tb = P.tiles.colorTile[col], nt = P.tiles.colorTile[col + 1] - tb;
         if (nt <= 0) continue;
         // gathers only reach later colours (>= n0 rows in), so the d/vu split of the gather is inert here (n0 = 0)
         hipLaunchKernelGGL(k_ilu_sweep<SW_UF>, grid(nt), dim3(64), 0, c->stream, tb, nt, 0, col == 0 ? 1 : 0, P.tiles.d_row0, P.d_urowptr, P.d_ucol,
-                           c->d_U, c->d_invD, d, vu, v, mode, w);
+                           c->d_U, c->d_invD, d, vu, v, mode, w, c->d_done);
     }
     prof_end(c, ps);
 }
-static void finalize(opmhip_ctx* c, int mode, int count) {
+static void finalize(opmhip_ctx* c, int mode, int count, double* hslot = nullptr) {
+    const double tol = c->cfg.tolerance;
     if (c->comm.nranks > 1) {
         // local sums -> one small all-reduce -> scalars (the reference all-reduces one double per scalar product
         // through OwnerOverlapCopyCommunication; here the two sums of a half iteration travel together)
@@ -1030,15 +1047,15 @@ static void finalize(opmhip_ctx* c, int mode, int count) {
         }
         hipLaunchKernelGGL(k_local_sums, dim3(1), dim3(VB), 0, c->stream, cnt, src, np, c->comm.d_red);
         (void)comm_allreduce(c, c->comm.d_red, 2, 0);
-        hipLaunchKernelGGL(k_finalize, dim3(1), dim3(VB), 0, c->stream, mode, 1, c->comm.d_red, 1, c->d_scal);
+        hipLaunchKernelGGL(k_finalize, dim3(1), dim3(VB), 0, c->stream, mode, 1, c->comm.d_red, 1, c->d_scal, tol, hslot);
         return;
     }
     if (count > 4 * RED1_BLOCKS) {
         hipLaunchKernelGGL(k_reduce_stage1, dim3(RED1_BLOCKS), dim3(VB), 0, c->stream, count, c->d_part, c->npart, c->d_part2);
-        hipLaunchKernelGGL(k_finalize, dim3(1), dim3(VB), 0, c->stream, mode, RED1_BLOCKS, c->d_part2, RED1_BLOCKS, c->d_scal);
+        hipLaunchKernelGGL(k_finalize, dim3(1), dim3(VB), 0, c->stream, mode, RED1_BLOCKS, c->d_part2, RED1_BLOCKS, c->d_scal, tol, hslot);
         return;
     }
-    hipLaunchKernelGGL(k_finalize, dim3(1), dim3(VB), 0, c->stream, mode, count, c->d_part, c->npart, c->d_scal);
+    hipLaunchKernelGGL(k_finalize, dim3(1), dim3(VB), 0, c->stream, mode, count, c->d_part, c->npart, c->d_scal, tol, hslot);
 }
 // the vector kernels of one BiCGStab iteration, for opmhip_time_kernel
 void launch_vector_kernels_once(opmhip_ctx* c) {
@@ -1051,29 +1068,23 @@ void launch_vector_kernels_once(opmhip_ctx* c) {
 }
 
 // ============================== BiCGStab driver ==========================================================
-// Recurrence, half-iteration counter and stopping rule of bda/cusparseSolverBackend.cu:60-184.  Scalars stay
-// on the device; the host reads back one 128-byte record per half iteration to evaluate the stopping rule (the
-// reference reads back seven scalars per iteration, each blocking, :78-158).
+// Recurrence, half-iteration counter and stopping rule of bda/cusparseSolverBackend.cu:60-184.  Scalars stay on the
+// device and so does the stopping rule (k_finalize): the host enqueues half iteration h + 1 BEFORE it looks at the
+// outcome of half iteration h, so the queue never drains (the reference reads back seven scalars per iteration, each
+// blocking, :78-158).  If h met the stopping rule, the kernels of h + 1 see the flag and return at once; their profile
+// scopes are voided.  `it` counts exactly as in the reference: 0.5 per half iteration, maxit + 0.5 = not converged.
 static int read_scalars(opmhip_ctx* c) {
     OPMHIP_HIP(c, hipMemcpyAsync(c->h_pinned, c->d_scal, SC_COUNT * sizeof(double), hipMemcpyDeviceToHost, c->stream));
     OPMHIP_HIP(c, hipStreamSynchronize(c->stream));
     return OPMHIP_SUCCESS;
 }
-int bicgstab(opmhip_ctx* c, opmhip_result* res) {
+static int enqueue_half(opmhip_ctx* c, int h) {
     const Pattern& P = c->pat;
     const int n = P.Nb * BS, nb = vec_blocks(n);
-    const int maxit = c->cfg.maxit;
-    const double tol = c->cfg.tolerance;
-    int rc;
-    hipLaunchKernelGGL(k_bicg_init, dim3(nb), dim3(VB), 0, c->stream, n, c->d_b, c->d_r, c->d_rw, c->d_p, c->d_x, c->d_v, c->d_part, c->npart);
-    finalize(c, FIN_INIT, nb);
-    if ((rc = read_scalars(c))) return rc;
-    const double norm_0 = c->h_pinned[SC_NORM0];
-    double norm = norm_0;
-    float it;
-    for (it = 0.5f; it < maxit; it += 0.5f) {
-        int ps;
-        if (it > 1) {
+    double* hslot = c->d_ring + (size_t)(h % opmhip_ctx::RB_SLOTS) * opmhip_ctx::RB_DOUBLES;
+    int rc, ps;
+    if ((h & 1) == 0) {  // first half: p, y = M^-1 p, v = A y, alpha, x += alpha y, r -= alpha v, |r|
+        if (h > 0) {
             ps = prof_begin(c, PROF_VECTOR);
             hipLaunchKernelGGL(k_bicg_pupdate, dim3(nb), dim3(VB), 0, c->stream, n, c->d_scal, c->d_p, c->d_v, c->d_r);
             prof_end(c, ps);
@@ -1084,23 +1095,57 @@ int bicgstab(opmhip_ctx* c, opmhip_result* res) {
         ps = prof_begin(c, PROF_VECTOR);
         finalize(c, FIN_ALPHA, dot_count(c));
         hipLaunchKernelGGL(k_bicg_upd1, dim3(nb), dim3(VB), 0, c->stream, n, c->d_scal, c->d_r, c->d_v, c->d_x, c->d_pw, c->d_part, c->npart);
-        finalize(c, FIN_NORM, nb);
+        finalize(c, FIN_NORM, nb, hslot);
         prof_end(c, ps);
-        if ((rc = read_scalars(c))) return rc;
-        norm = c->h_pinned[SC_NORM];
-        if (norm < tol * norm_0) break;
-        it += 0.5f;
+    } else {             // second half: z = M^-1 r, t = A z, omega, x += omega z, r -= omega t, |r|, rho, beta
         launch_ilu_apply(c, c->d_r, c->d_s);
         if ((rc = comm_halo_f64(c, c->d_s, BS))) return rc;
         launch_spmv(c, c->d_s, c->d_t, 2, c->d_r, nullptr);
         ps = prof_begin(c, PROF_VECTOR);
         finalize(c, FIN_OMEGA, dot_count(c));
         hipLaunchKernelGGL(k_bicg_upd2, dim3(nb), dim3(VB), 0, c->stream, n, c->d_scal, c->d_x, c->d_s, c->d_r, c->d_t, c->d_rw, c->d_part, c->npart);
-        finalize(c, FIN_NORM_RHO, nb);
+        finalize(c, FIN_NORM_RHO, nb, hslot);
         prof_end(c, ps);
+    }
+    OPMHIP_HIP(c, hipEventRecord(c->rb_ev[h % opmhip_ctx::RB_SLOTS], c->stream));
+    return OPMHIP_SUCCESS;
+}
+int bicgstab(opmhip_ctx* c, opmhip_result* res) {
+    const Pattern& P = c->pat;
+    const int n = P.Nb * BS, nb = vec_blocks(n);
+    const int maxit = c->cfg.maxit;
+    const double tol = c->cfg.tolerance;
+    struct FlagScope {  // the tile kernels watch the solve's flag only while the solve runs
+        opmhip_ctx* c;
+        explicit FlagScope(opmhip_ctx* c_) : c(c_) { c->d_done = c->d_scal + SC_DONE; }
+        ~FlagScope() { c->d_done = c->d_scal + SC_ZERO; }
+    } scope(c);
+    int rc;
+    hipLaunchKernelGGL(k_bicg_init, dim3(nb), dim3(VB), 0, c->stream, n, c->d_b, c->d_r, c->d_rw, c->d_p, c->d_x, c->d_v, c->d_part, c->npart);
+    finalize(c, FIN_INIT, nb);
+    // the reference's loop "for (it = 0.5; it < maxit; it += 0.5) { first half; it += 0.5; second half }" runs the half
+    // iterations h = 0 .. 2 maxit - 1 with it = (h + 1) / 2 after half h
+    const int nhalves = 2 * maxit;
+    double norm = 0.0, norm_0 = 0.0;
+    float it = maxit + 0.5f;
+    size_t mark_next = c->prof.used;  // first profile scope of the half iteration in flight beyond the one being waited for
+    if (nhalves > 0 && (rc = enqueue_half(c, 0))) return rc;
+    for (int h = 0; h < nhalves; ++h) {
+        mark_next = c->prof.used;
+        if (h + 1 < nhalves && (rc = enqueue_half(c, h + 1))) return rc;
+        OPMHIP_HIP(c, hipEventSynchronize(c->rb_ev[h % opmhip_ctx::RB_SLOTS]));
+        const volatile double* slot = c->h_ring + (size_t)(h % opmhip_ctx::RB_SLOTS) * opmhip_ctx::RB_DOUBLES;
+        norm = slot[0];
+        norm_0 = slot[1];
+        if (norm < tol * norm_0) {
+            it = 0.5f * (float)(h + 1);
+            for (size_t i = mark_next; i < c->prof.used; ++i) c->prof.cls[i] = -1;  // half h + 1 ran as no-ops
+            break;
+        }
+    }
+    if (nhalves <= 0) {
         if ((rc = read_scalars(c))) return rc;
-        norm = c->h_pinned[SC_NORM];
-        if (norm < tol * norm_0) break;
+        norm = norm_0 = c->h_pinned[SC_NORM0];
     }
     OPMHIP_HIP(c, hipGetLastError());
     res->it = it;
