@@ -45,6 +45,9 @@ struct Pattern {
     int Nb = 0, nnzb = 0, numColors = 0, nl = 0, nu = 0;  // Nb = owned block rows
     int Nghost = 0, Nloc = 0;                            // ghost cells numbered Nb..Nloc-1 (vectors have Nloc entries)
     bool chained = false;  // line colouring: rows of one colour may depend on earlier rows of their own chain
+    // per colour: every row's L (U) part is at most the row's own chain predecessor (successor) - the sweep is then a
+    // lane-private recurrence and runs in the light kernel (no LDS staging, deep prefetch)
+    std::vector<char> lightL, lightU;
     // natural order (as handed over)
     std::vector<int> nat_rowptr, nat_col;
     // ordering

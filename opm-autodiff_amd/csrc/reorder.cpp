@@ -349,6 +349,21 @@ int build_pattern(opmhip_ctx* c, int Nb, int Nghost, int nnzb, const int* rows, 
     }
     P.nl = (int)P.lcol.size();
     P.nu = (int)P.ucol.size();
+    P.lightL.assign(ncol, 0);
+    P.lightU.assign(ncol, 0);
+    if (chained) {
+        for (int cc = 0; cc < ncol; ++cc) {
+            bool lL = true, lU = true;
+            for (int p = P.colorPrefix[cc]; p < P.colorPrefix[cc + 1] && (lL || lU); ++p) {
+                const int i = P.fromOrder[p], id = CH.chainOf[i], pos = CH.posIn[i];
+                const int nL = P.lrowptr[p + 1] - P.lrowptr[p], nU = P.urowptr[p + 1] - P.urowptr[p];
+                if (nL > 1 || (nL == 1 && (pos == 0 || P.lcol[P.lrowptr[p]] != P.toOrder[CH.rows[id][pos - 1]]))) lL = false;
+                if (nU > 1 || (nU == 1 && (pos + 1 >= (int)CH.rows[id].size() || P.ucol[P.urowptr[p]] != P.toOrder[CH.rows[id][pos + 1]]))) lU = false;
+            }
+            P.lightL[cc] = lL;
+            P.lightU[cc] = lU;
+        }
+    }
     if (!chained) {
         build_tiles(P.rowptr, P.colorPrefix, groupRow, P.tiles);
     } else {

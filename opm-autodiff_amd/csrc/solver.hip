@@ -607,6 +607,103 @@ __device__ __forceinline__ void chain_sweep(const int q0, const int q1, const in
         wave_sync();  // this step's results are visible to the next step; LDS image may be overwritten
     }
 }
+// Light sweep of a chain tile: every row's part of the factor is at most ONE block, the one towards the row the same
+// lane handled one step earlier (set_pattern verified it: Pattern::lightL / lightU).  Then a lane's rows form a private
+// recurrence - no LDS image, no workgroup-level ordering - and what limits the sweep is the latency of eight dependent
+// steps, so each lane keeps LIGHT_DEPTH steps of loads (row bounds one step further) in flight.
+#ifndef OPMHIP_LIGHT_DEPTH
+#define OPMHIP_LIGHT_DEPTH 4
+#endif
+constexpr int LIGHT_DEPTH = OPMHIP_LIGHT_DEPTH;
+template <int SHAPE>  // SW_L or SW_UF
+__device__ __forceinline__ void chain_sweep_light(const int q0, const int q1, const int lane, int* srow0,
+                                                  const int* __restrict__ tile_row0, const int* __restrict__ prow,
+                                                  const int* __restrict__ pcol, const double* __restrict__ P,
+                                                  const double* __restrict__ invD, const double* d, double* vu, double* v,
+                                                  int relax_mode, double w) {
+    constexpr int D = LIGHT_DEPTH;
+    const int nsteps = q1 - q0;
+    for (int i = lane; i <= nsteps; i += 64) srow0[i] = tile_row0[q0 + i];
+    wave_sync();
+    auto tile_of = [&](int st) { return (SHAPE == SW_UF) ? nsteps - 1 - st : st; };
+    struct StA { int rr, kb, ke; bool active; };
+    struct StB {
+        int r, cq;
+        bool has;
+        double blk[BB], rhs[3], Di[BB];
+    };
+    auto stageA = [&](int st, StA& a) {
+        const int ti = tile_of(st);
+        const int r0 = srow0[ti], r1 = srow0[ti + 1];
+        a.active = r0 + lane < r1;
+        a.rr = a.active ? r0 + lane : r1 - 1;
+        a.kb = prow[a.rr];
+        a.ke = prow[a.rr + 1];
+    };
+    auto stageB = [&](const StA& a, StB& b) {
+        b.r = a.active ? a.rr : -1;
+        b.has = a.active && a.ke > a.kb;
+        const int k = b.has ? a.kb : 0;   // any valid entry: loaded, not used
+        b.cq = pcol[k];
+#pragma unroll
+        for (int q = 0; q < BB; ++q) b.blk[q] = P[(size_t)k * BB + q];
+        const double* rsrc = (SHAPE == SW_L) ? d : vu;
+        b.rhs[0] = rsrc[(size_t)a.rr * BS]; b.rhs[1] = rsrc[(size_t)a.rr * BS + 1]; b.rhs[2] = rsrc[(size_t)a.rr * BS + 2];
+        if (SHAPE != SW_L) {
+#pragma unroll
+            for (int q = 0; q < BB; ++q) b.Di[q] = invD[(size_t)a.rr * BB + q];
+        }
+    };
+    StA aa[D + 1];
+    StB b[D];
+#pragma unroll
+    for (int u = 0; u <= D; ++u)
+        if (u < nsteps) stageA(u, aa[u]);
+#pragma unroll
+    for (int u = 0; u < D; ++u)
+        if (u < nsteps) stageB(aa[u], b[u]);
+    StA a = aa[D];
+    double prev[3] = {0.0, 0.0, 0.0};  // result of the row this lane finished one step earlier
+    for (int s0 = 0; s0 < nsteps; s0 += D) {
+#pragma unroll
+        for (int u = 0; u < D; ++u) {
+            const int st = s0 + u;
+            if (st < nsteps) {
+                StB& c = b[u];
+                if (c.r >= 0) {
+                    double rhs[3] = {c.rhs[0], c.rhs[1], c.rhs[2]};
+                    if (c.has) blk_mmv(c.blk, prev[0], prev[1], prev[2], rhs);
+                    if (SHAPE == SW_L) {
+                        vu[(size_t)c.r * BS] = rhs[0]; vu[(size_t)c.r * BS + 1] = rhs[1]; vu[(size_t)c.r * BS + 2] = rhs[2];
+                        prev[0] = rhs[0]; prev[1] = rhs[1]; prev[2] = rhs[2];
+                    } else {
+                        double out[3] = {0.0, 0.0, 0.0};
+                        blk_umv(c.Di, rhs[0], rhs[1], rhs[2], out);
+                        if (relax_mode == 1) { out[0] = w * out[0]; out[1] = w * out[1]; out[2] = w * out[2]; }
+                        vu[(size_t)c.r * BS] = out[0]; vu[(size_t)c.r * BS + 1] = out[1]; vu[(size_t)c.r * BS + 2] = out[2];
+                        if (v != vu) { v[(size_t)c.r * BS] = w * out[0]; v[(size_t)c.r * BS + 1] = w * out[1]; v[(size_t)c.r * BS + 2] = w * out[2]; }
+                        prev[0] = out[0]; prev[1] = out[1]; prev[2] = out[2];
+                    }
+                }
+                if (st + D < nsteps) {
+                    stageB(a, c);
+                    if (st + D + 1 < nsteps) stageA(st + D + 1, a);
+                }
+            }
+        }
+    }
+}
+template <int SHAPE>
+__global__ __launch_bounds__(64) void k_ilu_sweep_light(int ct_begin, int nct, const int* __restrict__ ct_first,
+                                                        const int* __restrict__ tile_row0, const int* __restrict__ prow,
+                                                        const int* __restrict__ pcol, const double* __restrict__ P,
+                                                        const double* __restrict__ invD, const double* d,
+                                                        double* vu, double* v, int relax_mode, double w, const double* __restrict__ done) {
+    __shared__ int srow0[CHAIN_MAX_STEPS + 2];
+    const int lane = threadIdx.x, cl = xcd_tile(blockIdx.x, nct);
+    if (cl >= nct || *done != 0.0) return;
+    chain_sweep_light<SHAPE>(ct_first[ct_begin + cl], ct_first[ct_begin + cl + 1], lane, srow0, tile_row0, prow, pcol, P, invD, d, vu, v, relax_mode, w);
+}
 template <int SHAPE>
 __global__ __launch_bounds__(64) void k_ilu_sweep_chain(int ct_begin, int nct, const int* __restrict__ ct_first,
                                                         const int* __restrict__ tile_row0, const int* __restrict__ prow,
@@ -622,6 +719,7 @@ __global__ __launch_bounds__(64) void k_ilu_sweep_chain(int ct_begin, int nct, c
 }
 // Last colour: its rows have U entries only inside their own chain-tile, so the backward sweep of a chain-tile can
 // start the moment its forward sweep ends - one launch instead of two, and y never leaves the cache in between.
+template <bool LIGHT_U>
 __global__ __launch_bounds__(64) void k_ilu_sweep_chain_LU(int ct_begin, int nct, const int* __restrict__ ct_first,
                                                            const int* __restrict__ tile_row0, const int* __restrict__ lrow,
                                                            const int* __restrict__ lcol, const double* __restrict__ L,
@@ -637,7 +735,8 @@ __global__ __launch_bounds__(64) void k_ilu_sweep_chain_LU(int ct_begin, int nct
     chain_sweep<SW_L>(q0, q1, lane, sval, srow0, sk0, tile_row0, lrow, lcol, L, invD, d, vu, v, relax_mode, w);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // y of this chain-tile is written before the backward sweep reads it
     wave_sync();
-    chain_sweep<SW_UF>(q0, q1, lane, sval, srow0, sk0, tile_row0, urow, ucol, Uv, invD, d, vu, v, relax_mode, w);
+    if (LIGHT_U) chain_sweep_light<SW_UF>(q0, q1, lane, srow0, tile_row0, urow, ucol, Uv, invD, d, vu, v, relax_mode, w);
+    else chain_sweep<SW_UF>(q0, q1, lane, sval, srow0, sk0, tile_row0, urow, ucol, Uv, invD, d, vu, v, relax_mode, w);
 }
 
 // ============================== ILU0 factorisation =======================================================
@@ -996,19 +1095,32 @@ void launch_ilu_apply(opmhip_ctx* c, const double* d, double* v) {
     if (P.chained) {
         for (int col = 0; col < C - 1; ++col) {
             const int cb = P.tiles.colorCT[col], nct = P.tiles.colorCT[col + 1] - cb;
-            if (nct > 0)
+            if (nct <= 0) continue;
+            if (P.lightL[col])
+                hipLaunchKernelGGL(k_ilu_sweep_light<SW_L>, grid(nct), dim3(64), 0, c->stream, cb, nct, P.tiles.d_ctFirst, P.tiles.d_row0, P.d_lrowptr,
+                                   P.d_lcol, c->d_L, c->d_invD, d, vu, v, mode, w, c->d_done);
+            else
                 hipLaunchKernelGGL(k_ilu_sweep_chain<SW_L>, grid(nct), dim3(64), 0, c->stream, cb, nct, P.tiles.d_ctFirst, P.tiles.d_row0, P.d_lrowptr,
                                    P.d_lcol, c->d_L, c->d_invD, d, vu, v, mode, w, c->d_done);
         }
         {
             const int cb = P.tiles.colorCT[C - 1], nct = P.tiles.colorCT[C] - cb;
-            if (nct > 0)
-                hipLaunchKernelGGL(k_ilu_sweep_chain_LU, grid(nct), dim3(64), 0, c->stream, cb, nct, P.tiles.d_ctFirst, P.tiles.d_row0, P.d_lrowptr,
-                                   P.d_lcol, c->d_L, P.d_urowptr, P.d_ucol, c->d_U, c->d_invD, d, vu, v, mode, w, c->d_done);
+            if (nct > 0) {
+                if (P.lightU[C - 1])
+                    hipLaunchKernelGGL(k_ilu_sweep_chain_LU<true>, grid(nct), dim3(64), 0, c->stream, cb, nct, P.tiles.d_ctFirst, P.tiles.d_row0, P.d_lrowptr,
+                                       P.d_lcol, c->d_L, P.d_urowptr, P.d_ucol, c->d_U, c->d_invD, d, vu, v, mode, w, c->d_done);
+                else
+                    hipLaunchKernelGGL(k_ilu_sweep_chain_LU<false>, grid(nct), dim3(64), 0, c->stream, cb, nct, P.tiles.d_ctFirst, P.tiles.d_row0, P.d_lrowptr,
+                                       P.d_lcol, c->d_L, P.d_urowptr, P.d_ucol, c->d_U, c->d_invD, d, vu, v, mode, w, c->d_done);
+            }
         }
         for (int col = C - 2; col >= 0; --col) {
             const int cb = P.tiles.colorCT[col], nct = P.tiles.colorCT[col + 1] - cb;
-            if (nct > 0)
+            if (nct <= 0) continue;
+            if (P.lightU[col])
+                hipLaunchKernelGGL(k_ilu_sweep_light<SW_UF>, grid(nct), dim3(64), 0, c->stream, cb, nct, P.tiles.d_ctFirst, P.tiles.d_row0, P.d_urowptr,
+                                   P.d_ucol, c->d_U, c->d_invD, d, vu, v, mode, w, c->d_done);
+            else
                 hipLaunchKernelGGL(k_ilu_sweep_chain<SW_UF>, grid(nct), dim3(64), 0, c->stream, cb, nct, P.tiles.d_ctFirst, P.tiles.d_row0, P.d_urowptr,
                                    P.d_ucol, c->d_U, c->d_invD, d, vu, v, mode, w, c->d_done);
         }
