@@ -235,7 +235,7 @@ void launch_vec_to_natural(opmhip_ctx* c, const double* internal, double* nat, i
 void launch_zero_diag_fix(opmhip_ctx* c);
 void launch_spmv(opmhip_ctx* c, const double* x, double* y, int ndot, const double* w0, const double* w1);
 void launch_ilu_factor(opmhip_ctx* c);
-void launch_ilu_apply(opmhip_ctx* c, const double* d, double* v);
+void launch_ilu_apply(opmhip_ctx* c, const double* d, double* v, int fuse = 0);
 void launch_wells_apply(opmhip_ctx* c, const double* x, double* y);
 void launch_lu_to_natural(opmhip_ctx* c, double* d_out_internal_layout);
 int bicgstab(opmhip_ctx* c, opmhip_result* res);

@@ -693,6 +693,130 @@ __device__ __forceinline__ void chain_sweep_light(const int q0, const int q1, co
         }
     }
 }
+// The first colour's light forward sweep fused with the BiCGStab vector update that produces its input, for ALL owned
+// rows: lanes 0..31 walk the chain rows (update the vector entry, then the recurrence), lanes 32..63 - idle in the plain
+// light sweep - apply the same update to an equal share of the rows of the other colours, 32 per step.
+//   DM_PUPD: dvec = p <- (p - omega v) beta + r                         (k_bicg_pupdate)
+//   DM_UPD1: dvec = r <- r - alpha v ; x += alpha pw ; part[cl] = sum r.r over this workgroup's rows   (k_bicg_upd1)
+// The later colours then read dvec as it stands.  Same expressions as the stand-alone kernels: bit-identical vectors.
+enum { DM_PUPD = 1, DM_UPD1 = 2 };
+template <int DM>
+__global__ __launch_bounds__(64) void k_ilu_sweep_light_fused(int ct_begin, int nct, const int* __restrict__ ct_first,
+                                                              const int* __restrict__ tile_row0, const int* __restrict__ prow,
+                                                              const int* __restrict__ pcol, const double* __restrict__ P,
+                                                              double* dvec, double* vu, const double* __restrict__ scal,
+                                                              const double* __restrict__ vvec, const double* __restrict__ wvec,
+                                                              double* xvec, int f0, int f1, double* __restrict__ part) {
+    constexpr int D = LIGHT_DEPTH;
+    __shared__ int srow0[CHAIN_MAX_STEPS + 2];
+    const int lane = threadIdx.x, cl = xcd_tile(blockIdx.x, nct);
+    if (cl >= nct || scal[SC_DONE] != 0.0) return;
+    const double alpha = scal[SC_ALPHA], omega = scal[SC_OMEGA], beta = scal[SC_BETA];
+    const int q0 = ct_first[ct_begin + cl], q1 = ct_first[ct_begin + cl + 1];
+    const int nsteps = q1 - q0;
+    for (int i = lane; i <= nsteps; i += 64) srow0[i] = tile_row0[q0 + i];
+    wave_sync();
+    const bool chainLane = lane < TILE_ROWS;
+    const int per = (int)(((long long)(f1 - f0) + nct - 1) / nct);
+    const int fb = f0 + (int)min((long long)(f1 - f0), (long long)cl * per), fe = min(f1, fb + per);  // this workgroup's foreign rows
+    struct StA { int rr, kb, ke; bool active; };
+    struct StB {
+        int r;
+        bool has;
+        double blk[BB], dv[3], vv[3], wv[3], xv[3];
+    };
+    auto stageA = [&](int st, StA& a) {
+        if (chainLane) {
+            const int r0 = srow0[st], r1 = srow0[st + 1];
+            a.active = r0 + lane < r1;
+            a.rr = a.active ? r0 + lane : r1 - 1;
+            a.kb = prow[a.rr];
+            a.ke = prow[a.rr + 1];
+        } else {
+            const int fr = fb + st * TILE_ROWS + (lane - TILE_ROWS);
+            a.active = fr < fe;
+            a.rr = a.active ? fr : (fe > fb ? fe - 1 : srow0[0]);  // any valid row for the unused loads
+            a.kb = a.ke = 0;
+        }
+    };
+    auto load_vec = [&](int rr, StB& b) {
+        const size_t o = (size_t)rr * BS;
+        b.dv[0] = dvec[o]; b.dv[1] = dvec[o + 1]; b.dv[2] = dvec[o + 2];
+        b.vv[0] = vvec[o]; b.vv[1] = vvec[o + 1]; b.vv[2] = vvec[o + 2];
+        b.wv[0] = wvec[o]; b.wv[1] = wvec[o + 1]; b.wv[2] = wvec[o + 2];
+        if (DM == DM_UPD1) { b.xv[0] = xvec[o]; b.xv[1] = xvec[o + 1]; b.xv[2] = xvec[o + 2]; }
+    };
+    auto stageB = [&](const StA& a, StB& b) {
+        b.r = a.active ? a.rr : -1;
+        b.has = chainLane && a.active && a.ke > a.kb;
+        if (chainLane) {
+            const int k = b.has ? a.kb : 0;
+#pragma unroll
+            for (int q = 0; q < BB; ++q) b.blk[q] = P[(size_t)k * BB + q];
+        }
+        load_vec(a.rr, b);
+    };
+    double ssum = 0.0;
+    // the vector update of one row; returns the new dvec entry in out[]
+    auto update_row = [&](int r, const StB& b, double* out) {
+        const size_t o = (size_t)r * BS;
+        if (DM == DM_PUPD) {
+#pragma unroll
+            for (int q = 0; q < 3; ++q) out[q] = (b.dv[q] - omega * b.vv[q]) * beta + b.wv[q];
+        } else {
+#pragma unroll
+            for (int q = 0; q < 3; ++q) {
+                out[q] = b.dv[q] - alpha * b.vv[q];
+                xvec[o + q] = b.xv[q] + alpha * b.wv[q];
+                ssum += out[q] * out[q];
+            }
+        }
+        dvec[o] = out[0]; dvec[o + 1] = out[1]; dvec[o + 2] = out[2];
+    };
+    StA aa[D + 1];
+    StB b[D];
+#pragma unroll
+    for (int u = 0; u <= D; ++u)
+        if (u < nsteps) stageA(u, aa[u]);
+#pragma unroll
+    for (int u = 0; u < D; ++u)
+        if (u < nsteps) stageB(aa[u], b[u]);
+    StA a = aa[D];
+    double prev[3] = {0.0, 0.0, 0.0};
+    for (int s0 = 0; s0 < nsteps; s0 += D) {
+#pragma unroll
+        for (int u = 0; u < D; ++u) {
+            const int st = s0 + u;
+            if (st < nsteps) {
+                StB& c = b[u];
+                if (c.r >= 0) {
+                    double rhs[3];
+                    update_row(c.r, c, rhs);
+                    if (chainLane) {
+                        if (c.has) blk_mmv(c.blk, prev[0], prev[1], prev[2], rhs);
+                        vu[(size_t)c.r * BS] = rhs[0]; vu[(size_t)c.r * BS + 1] = rhs[1]; vu[(size_t)c.r * BS + 2] = rhs[2];
+                        prev[0] = rhs[0]; prev[1] = rhs[1]; prev[2] = rhs[2];
+                    }
+                }
+                if (st + D < nsteps) {
+                    stageB(a, c);
+                    if (st + D + 1 < nsteps) stageA(st + D + 1, a);
+                }
+            }
+        }
+    }
+    // foreign rows beyond 32 per step (short chain tiles): all 64 lanes, plain loop
+    for (int fr = fb + nsteps * TILE_ROWS + lane; fr < fe; fr += 64) {
+        StB t;
+        load_vec(fr, t);
+        double out[3];
+        update_row(fr, t, out);
+    }
+    if (DM == DM_UPD1) {
+        ssum = wave_sum(ssum);
+        if (lane == 0) part[cl] = ssum;
+    }
+}
 template <int SHAPE>
 __global__ __launch_bounds__(64) void k_ilu_sweep_light(int ct_begin, int nct, const int* __restrict__ ct_first,
                                                         const int* __restrict__ tile_row0, const int* __restrict__ prow,
@@ -1083,7 +1207,13 @@ void launch_ilu_factor(opmhip_ctx* c) {
     }
     prof_end(c, ps);
 }
-void launch_ilu_apply(opmhip_ctx* c, const double* d, double* v) {
+// fuse = DM_PUPD / DM_UPD1: the first colour's sweep also performs that BiCGStab vector update on every owned row (d is
+// then read AND written: p or r); only where ilu_can_fuse() holds
+static bool ilu_can_fuse(const opmhip_ctx* c) {
+    const Pattern& P = c->pat;
+    return P.chained && P.numColors >= 2 && P.lightL[0] && P.tiles.colorCT[1] > P.tiles.colorCT[0];
+}
+void launch_ilu_apply(opmhip_ctx* c, const double* d, double* v, int fuse) {
     const Pattern& P = c->pat;
     const int ps = prof_begin(c, PROF_ILU_APPLY);
     const int C = P.numColors, mode = c->cfg.relax_mode;
@@ -1096,7 +1226,13 @@ void launch_ilu_apply(opmhip_ctx* c, const double* d, double* v) {
         for (int col = 0; col < C - 1; ++col) {
             const int cb = P.tiles.colorCT[col], nct = P.tiles.colorCT[col + 1] - cb;
             if (nct <= 0) continue;
-            if (P.lightL[col])
+            if (col == 0 && fuse == DM_PUPD)
+                hipLaunchKernelGGL(k_ilu_sweep_light_fused<DM_PUPD>, grid(nct), dim3(64), 0, c->stream, cb, nct, P.tiles.d_ctFirst, P.tiles.d_row0, P.d_lrowptr,
+                                   P.d_lcol, c->d_L, const_cast<double*>(d), vu, c->d_scal, c->d_v, c->d_r, (double*)nullptr, P.colorPrefix[1], P.Nb, c->d_part);
+            else if (col == 0 && fuse == DM_UPD1)
+                hipLaunchKernelGGL(k_ilu_sweep_light_fused<DM_UPD1>, grid(nct), dim3(64), 0, c->stream, cb, nct, P.tiles.d_ctFirst, P.tiles.d_row0, P.d_lrowptr,
+                                   P.d_lcol, c->d_L, const_cast<double*>(d), vu, c->d_scal, c->d_v, c->d_pw, c->d_x, P.colorPrefix[1], P.Nb, c->d_part);
+            else if (P.lightL[col])
                 hipLaunchKernelGGL(k_ilu_sweep_light<SW_L>, grid(nct), dim3(64), 0, c->stream, cb, nct, P.tiles.d_ctFirst, P.tiles.d_row0, P.d_lrowptr,
                                    P.d_lcol, c->d_L, c->d_invD, d, vu, v, mode, w, c->d_done);
             else
@@ -1193,33 +1329,46 @@ static int read_scalars(opmhip_ctx* c) {
 static int enqueue_half(opmhip_ctx* c, int h) {
     const Pattern& P = c->pat;
     const int n = P.Nb * BS, nb = vec_blocks(n);
-    double* hslot = c->d_ring + (size_t)(h % opmhip_ctx::RB_SLOTS) * opmhip_ctx::RB_DOUBLES;
+    auto slot = [&](int hh) { return c->d_ring + (size_t)(hh % opmhip_ctx::RB_SLOTS) * opmhip_ctx::RB_DOUBLES; };
+    // Line colouring with a light first colour: the p-update and the (r, x)-update ride in the first colour's sweep of
+    // the preconditioner application that follows them (k_ilu_sweep_light_fused).  The stopping rule of a first half is
+    // then evaluated after that application; the event of half h - 1 is recorded by half h.
+    const bool fused = ilu_can_fuse(c);
     int rc, ps;
     if ((h & 1) == 0) {  // first half: p, y = M^-1 p, v = A y, alpha, x += alpha y, r -= alpha v, |r|
-        if (h > 0) {
+        if (h > 0 && !fused) {
             ps = prof_begin(c, PROF_VECTOR);
             hipLaunchKernelGGL(k_bicg_pupdate, dim3(nb), dim3(VB), 0, c->stream, n, c->d_scal, c->d_p, c->d_v, c->d_r);
             prof_end(c, ps);
         }
-        launch_ilu_apply(c, c->d_p, c->d_pw);
+        launch_ilu_apply(c, c->d_p, c->d_pw, (h > 0 && fused) ? DM_PUPD : 0);
         if ((rc = comm_halo_f64(c, c->d_pw, BS))) return rc;  // copyOwnerToAll before the operator (ParallelOverlappingILU0.hpp:897)
         launch_spmv(c, c->d_pw, c->d_v, 1, c->d_rw, nullptr);
         ps = prof_begin(c, PROF_VECTOR);
         finalize(c, FIN_ALPHA, dot_count(c));
-        hipLaunchKernelGGL(k_bicg_upd1, dim3(nb), dim3(VB), 0, c->stream, n, c->d_scal, c->d_r, c->d_v, c->d_x, c->d_pw, c->d_part, c->npart);
-        finalize(c, FIN_NORM, nb, hslot);
+        if (!fused) {
+            hipLaunchKernelGGL(k_bicg_upd1, dim3(nb), dim3(VB), 0, c->stream, n, c->d_scal, c->d_r, c->d_v, c->d_x, c->d_pw, c->d_part, c->npart);
+            finalize(c, FIN_NORM, nb, slot(h));
+        }
         prof_end(c, ps);
+        if (!fused) OPMHIP_HIP(c, hipEventRecord(c->rb_ev[h % opmhip_ctx::RB_SLOTS], c->stream));
     } else {             // second half: z = M^-1 r, t = A z, omega, x += omega z, r -= omega t, |r|, rho, beta
-        launch_ilu_apply(c, c->d_r, c->d_s);
+        launch_ilu_apply(c, c->d_r, c->d_s, fused ? DM_UPD1 : 0);
+        if (fused) {
+            ps = prof_begin(c, PROF_VECTOR);
+            finalize(c, FIN_NORM, P.tiles.colorCT[1] - P.tiles.colorCT[0], slot(h - 1));
+            prof_end(c, ps);
+            OPMHIP_HIP(c, hipEventRecord(c->rb_ev[(h - 1) % opmhip_ctx::RB_SLOTS], c->stream));
+        }
         if ((rc = comm_halo_f64(c, c->d_s, BS))) return rc;
         launch_spmv(c, c->d_s, c->d_t, 2, c->d_r, nullptr);
         ps = prof_begin(c, PROF_VECTOR);
         finalize(c, FIN_OMEGA, dot_count(c));
         hipLaunchKernelGGL(k_bicg_upd2, dim3(nb), dim3(VB), 0, c->stream, n, c->d_scal, c->d_x, c->d_s, c->d_r, c->d_t, c->d_rw, c->d_part, c->npart);
-        finalize(c, FIN_NORM_RHO, nb, hslot);
+        finalize(c, FIN_NORM_RHO, nb, slot(h));
         prof_end(c, ps);
+        OPMHIP_HIP(c, hipEventRecord(c->rb_ev[h % opmhip_ctx::RB_SLOTS], c->stream));
     }
-    OPMHIP_HIP(c, hipEventRecord(c->rb_ev[h % opmhip_ctx::RB_SLOTS], c->stream));
     return OPMHIP_SUCCESS;
 }
 int bicgstab(opmhip_ctx* c, opmhip_result* res) {
