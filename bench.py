@@ -33,6 +33,7 @@ sys.path.insert(0, os.path.join(ROOT, "tests"))
 import numpy as np  # noqa: E402
 
 DAY = 86400.0
+PROFILE_EVERY = 4
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (/opt/skills/guides/MI355X_MICROARCH.md)
 
 
@@ -144,7 +145,9 @@ def main():
     for _ in range(a.warmup):
         sim.next_newton_iteration()
     barrier()
-    model.profile_enable(True)
+    # HIP-event scopes of the linear-solver kernels in every 4th linear solve of the timed region (an event record costs
+    # a few microseconds of stream bubble; a BiCGStab iteration holds seven); assembly-side scopes in every iteration
+    model.profile_enable(PROFILE_EVERY)
     rep0 = pkg.newton.SimulatorReportSingle()
     rep0 += sim.report
     ts0, tf0 = sim.timesteps_done, sim.timesteps_failed

@@ -266,7 +266,10 @@ int opmhip_set_halo(opmhip_ctx* ctx, long long global_cells, int nneigh, const i
  * classes: 0 SpMV, 1 ILU0 apply (all sweeps of one M^-1), 2 ILU0 factorisation, 3 BiCGStab vector kernels (one
  * group between two operator applications), 4 assembly kernel, 5 intensive-quantity update, 6 convergence. */
 #define OPMHIP_PROF_CLASSES 7
-int opmhip_profile_enable(opmhip_ctx* ctx, int on);  /* also resets the accumulated numbers */
+/* on = 0: off; 1: every scope; k > 1: the linear-solver classes (0, 1, 3) are recorded in every k-th solve_system call
+ * only - an event record costs a few microseconds of bubble on the stream and a BiCGStab iteration holds seven of
+ * them.  Also resets the accumulated numbers. */
+int opmhip_profile_enable(opmhip_ctx* ctx, int on);
 /* waits for the stream, folds all pending event pairs in, returns launches and total milliseconds of one class */
 int opmhip_profile_get(opmhip_ctx* ctx, int cls, long long* launches, double* total_ms);
 

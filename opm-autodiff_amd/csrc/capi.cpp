@@ -41,7 +41,7 @@ int alloc_system(opmhip_ctx* c) {
     if (!c->h_ring) {
     OPMHIP_HIP(c, hipHostMalloc((void**)&c->h_ring, opmhip_ctx::RB_SLOTS * opmhip_ctx::RB_DOUBLES * sizeof(double), hipHostMallocMapped));
     OPMHIP_HIP(c, hipHostGetDevicePointer((void**)&c->d_ring, c->h_ring, 0));
-    for (int i = 0; i < opmhip_ctx::RB_SLOTS; ++i) OPMHIP_HIP(c, hipEventCreateWithFlags(&c->rb_ev[i], hipEventDisableTiming));
+    std::memset(c->h_ring, 0, opmhip_ctx::RB_SLOTS * opmhip_ctx::RB_DOUBLES * sizeof(double));
     }
     c->d_done = c->d_scal + SC_ZERO;
     return OPMHIP_SUCCESS;
@@ -188,10 +188,9 @@ void opmhip_destroy(opmhip_ctx* c) {
     for (void* p : c->allocs) (void)hipFree(p);
     if (c->h_pinned) (void)hipHostFree(c->h_pinned);
     if (c->h_ring) (void)hipHostFree(c->h_ring);
-    for (hipEvent_t e : c->rb_ev) if (e) (void)hipEventDestroy(e);
     if (c->ev0) (void)hipEventDestroy(c->ev0);
     if (c->ev1) (void)hipEventDestroy(c->ev1);
-    for (hipEvent_t e : c->prof.pool) (void)hipEventDestroy(e);
+    for (hipEvent_t e : c->prof.ev) (void)hipEventDestroy(e);
     if (c->stream) (void)hipStreamDestroy(c->stream);
     delete c;
 }
@@ -354,7 +353,12 @@ int opmhip_profile_enable(opmhip_ctx* c, int on) {
         OPMHIP_HIP(c, hipStreamSynchronize(c->stream));
         Profiler& P = c->prof;
         P.enabled = on != 0;
+        P.every = on > 1 ? on : 1;   // on = k > 1: the linear-solver scopes of every k-th solve only
+        P.solve_no = 0;
+        P.suspended = false;
+        P.pending = -1;
         P.used = 0;
+        P.ev_used = 0;
         for (int k = 0; k < PROF_COUNT; ++k) { P.total_ms[k] = 0.0; P.count[k] = 0; }
         return OPMHIP_SUCCESS;
     });
@@ -367,14 +371,17 @@ int opmhip_profile_get(opmhip_ctx* c, int cls, long long* launches, double* tota
         OPMHIP_HIP(c, hipSetDevice(c->device));
         OPMHIP_HIP(c, hipStreamSynchronize(c->stream));
         Profiler& P = c->prof;
+        prof_flush(c);
+        OPMHIP_HIP(c, hipStreamSynchronize(c->stream));
         for (size_t i = 0; i < P.used; ++i) {
             float ms = 0.f;
-            if (P.cls[i] >= 0 && hipEventElapsedTime(&ms, P.pool[2 * i], P.pool[2 * i + 1]) == hipSuccess) {
+            if (P.cls[i] >= 0 && P.e1[i] >= 0 && hipEventElapsedTime(&ms, P.ev[P.e0[i]], P.ev[P.e1[i]]) == hipSuccess) {
                 P.total_ms[P.cls[i]] += ms;
                 P.count[P.cls[i]] += 1;
             }
         }
         P.used = 0;
+        P.ev_used = 0;
         *launches = P.count[cls];
         *total_ms = P.total_ms[cls];
         return OPMHIP_SUCCESS;

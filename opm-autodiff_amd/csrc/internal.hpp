@@ -114,9 +114,15 @@ struct CommDev {
 enum ProfClass { PROF_SPMV = 0, PROF_ILU_APPLY, PROF_ILU_FACTOR, PROF_VECTOR, PROF_ASSEMBLE, PROF_IQ_UPDATE, PROF_CONVERGENCE, PROF_COUNT };
 struct Profiler {
     bool enabled = false;
-    std::vector<hipEvent_t> pool;             // event pairs, allocated on demand
-    std::vector<int> cls;                     // class of pair i (-1: voided - a speculative launch past the stopping point)
-    size_t used = 0;                          // pairs in use
+    int every = 1;                            // solver scopes are recorded in every `every`-th linear solve (1 = all)
+    long solve_no = 0;
+    bool suspended = false;                   // inside a linear solve that is not sampled
+    std::vector<hipEvent_t> ev;               // event pool, allocated on demand
+    size_t ev_used = 0;
+    std::vector<int> cls, e0, e1;             // per scope: class (-1: voided - a speculative launch past the stopping
+    size_t used = 0;                          //   point), start and end event
+    int pending = -1;                         // scope whose end event is still to be recorded (shared with the next begin)
+    bool lazy = false;                        // prof_end leaves the end to the next prof_begin (inside a linear solve)
     static constexpr size_t CAP = 1 << 15;
     double total_ms[PROF_COUNT] = {0};
     long count[PROF_COUNT] = {0};
@@ -151,12 +157,14 @@ struct opmhip_ctx {
     double* d_part2 = nullptr;  // second-level partials: 2 x RED1_BLOCKS
     int npart = 0;
     double* h_pinned = nullptr;  // SC_COUNT doubles, pinned
-    // read-back ring of the BiCGStab stopping rule: k_finalize writes (norm, norm_0, done) of half iteration h straight
-    // into pinned host slot h % RB_SLOTS, an event marks it; the host runs one half iteration ahead of the device
-    static constexpr int RB_SLOTS = 4, RB_DOUBLES = 4;
+    // read-back ring of the BiCGStab stopping rule: the finalize kernel writes (norm, norm_0, done) of half iteration h
+    // straight into pinned host slot h % RB_SLOTS and then, system-scope release, the slot's sequence number, which the
+    // host polls (no event, no copy, no stream bubble); the host runs one half iteration ahead of the device
+    static constexpr int RB_SLOTS = 4, RB_DOUBLES = 4;   // slot: norm, norm_0, done, sequence number (written last)
     double* h_ring = nullptr;    // pinned, RB_SLOTS x RB_DOUBLES
     double* d_ring = nullptr;    // the same memory through the device's eyes
-    hipEvent_t rb_ev[RB_SLOTS] = {nullptr, nullptr, nullptr, nullptr};
+    double rb_seq = 0.0;         // last sequence number handed to a stopping-rule kernel (exact integers in a double)
+    double rb_want[RB_SLOTS] = {0, 0, 0, 0};
     const double* d_done = nullptr;  // flag the tile kernels test first: &d_scal[SC_ZERO] outside a solve, &d_scal[SC_DONE] inside
     opmhip::WellsDev wells;
     opmhip::AsmDev asmb;
@@ -204,24 +212,42 @@ int dev_upload(opmhip_ctx* c, T** p, const std::vector<T>& h) {
     return OPMHIP_SUCCESS;
 }
 
-// RAII-less profiling scope: prof_begin returns a slot (or -1), prof_end closes it
+// RAII-less profiling scope: prof_begin returns a slot (or -1), prof_end closes it.  An event record costs a few
+// microseconds of bubble on the stream, so back-to-back scopes share one: prof_end(lazy) leaves the end open and the next
+// prof_begin's event closes it (prof_flush closes it where nothing follows).
+inline int prof_event(opmhip_ctx* c) {
+    Profiler& P = c->prof;
+    if (P.ev.size() <= P.ev_used) {
+        hipEvent_t e;
+        if (hipEventCreate(&e) != hipSuccess) return -1;
+        P.ev.push_back(e);
+    }
+    const int i = (int)P.ev_used++;
+    (void)hipEventRecord(P.ev[i], c->stream);
+    return i;
+}
+inline void prof_flush(opmhip_ctx* c) {
+    Profiler& P = c->prof;
+    if (P.pending < 0) return;
+    const int e = prof_event(c);
+    if (e >= 0) P.e1[P.pending] = e; else P.cls[P.pending] = -1;
+    P.pending = -1;
+}
 inline int prof_begin(opmhip_ctx* c, int cls) {
     Profiler& P = c->prof;
-    if (!P.enabled || P.used >= Profiler::CAP) return -1;
-    if (P.pool.size() < 2 * (P.used + 1)) {
-        hipEvent_t a, b;
-        if (hipEventCreate(&a) != hipSuccess || hipEventCreate(&b) != hipSuccess) return -1;
-        P.pool.push_back(a);
-        P.pool.push_back(b);
-        P.cls.push_back(cls);
-    }
+    if (!P.enabled || P.suspended || P.used >= Profiler::CAP) { prof_flush(c); return -1; }
+    const int e = prof_event(c);
+    if (e < 0) return -1;
+    if (P.pending >= 0) { P.e1[P.pending] = e; P.pending = -1; }
+    if (P.cls.size() <= P.used) { P.cls.push_back(cls); P.e0.push_back(e); P.e1.push_back(-1); }
     const int slot = (int)P.used++;
-    P.cls[slot] = cls;
-    (void)hipEventRecord(P.pool[2 * slot], c->stream);
+    P.cls[slot] = cls; P.e0[slot] = e; P.e1[slot] = -1;
     return slot;
 }
 inline void prof_end(opmhip_ctx* c, int slot) {
-    if (slot >= 0) (void)hipEventRecord(c->prof.pool[2 * slot + 1], c->stream);
+    if (slot < 0) return;
+    c->prof.pending = slot;
+    if (!c->prof.lazy) prof_flush(c);
 }
 
 // reorder.cpp (host): level scheduling / colouring, internal pattern, L/U split, tiles

@@ -9,6 +9,7 @@
 // distinct bank pairs - conflict free.  Built with -ffp-contract=off: a*b+c is never fused, so the factors and
 // sweeps are bit-identical to the CPU restatement in the same ordering.
 #include <hip/hip_runtime.h>
+#include <atomic>
 
 #include <chrono>
 #include <cmath>
@@ -1101,20 +1102,7 @@ enum FinMode { FIN_INIT = 0, FIN_ALPHA = 1, FIN_NORM = 2, FIN_OMEGA = 3, FIN_NOR
 // FIN_NORM / FIN_NORM_RHO evaluate the stopping rule (norm < tol * norm_0, bda/cusparseSolverBackend.cu:115,151) on the
 // device: they raise scal[SC_DONE] and leave (norm, norm_0, done) in the pinned host slot `hslot` for the host, which
 // meanwhile has enqueued the next half iteration already.  Once the flag is up nothing changes any more.
-__global__ __launch_bounds__(VB) void k_finalize(int mode, int count, const double* __restrict__ part, int npart,
-                                                 double* __restrict__ scal, double tol, double* __restrict__ hslot) {
-    __shared__ double sh[2][VB];
-    if (mode != FIN_INIT && scal[SC_DONE] != 0.0) return;
-    double a = 0.0, b = 0.0;
-    for (int i = threadIdx.x; i < count; i += VB) { a += part[i]; b += part[npart + i]; }
-    sh[0][threadIdx.x] = a; sh[1][threadIdx.x] = b;
-    __syncthreads();
-    for (int o = VB / 2; o > 0; o >>= 1) {
-        if ((int)threadIdx.x < o) { sh[0][threadIdx.x] += sh[0][threadIdx.x + o]; sh[1][threadIdx.x] += sh[1][threadIdx.x + o]; }
-        __syncthreads();
-    }
-    if (threadIdx.x != 0) return;
-    const double s0 = sh[0][0], s1 = sh[1][0];
+__device__ __forceinline__ void finalize_scalars(int mode, double s0, double s1, double* __restrict__ scal, double tol, double* hslot, double seq) {
     switch (mode) {
         case FIN_INIT:
             scal[SC_NORM0] = sqrt(s0); scal[SC_NORM] = sqrt(s0);
@@ -1136,7 +1124,78 @@ __global__ __launch_bounds__(VB) void k_finalize(int mode, int count, const doub
         const double stop = (norm < tol * norm0) ? 1.0 : 0.0;
         scal[SC_DONE] = stop;
         hslot[0] = norm; hslot[1] = norm0; hslot[2] = stop;
+        __hip_atomic_store(&hslot[3], seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);  // the host polls this one
     }
+}
+__global__ __launch_bounds__(VB) void k_finalize(int mode, int count, const double* __restrict__ part, int npart,
+                                                 double* __restrict__ scal, double tol, double* hslot, double seq) {
+    __shared__ double sh[2][VB];
+    if (mode != FIN_INIT && scal[SC_DONE] != 0.0) {
+        // a speculative launch past the stopping point still answers the host, which may be polling this slot
+        if (threadIdx.x == 0 && hslot && (mode == FIN_NORM || mode == FIN_NORM_RHO)) {
+            hslot[0] = scal[SC_NORM]; hslot[1] = scal[SC_NORM0]; hslot[2] = 1.0;
+            __hip_atomic_store(&hslot[3], seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+        }
+        return;
+    }
+    double a = 0.0, b = 0.0;
+    for (int i = threadIdx.x; i < count; i += VB) { a += part[i]; b += part[npart + i]; }
+    sh[0][threadIdx.x] = a; sh[1][threadIdx.x] = b;
+    __syncthreads();
+    for (int o = VB / 2; o > 0; o >>= 1) {
+        if ((int)threadIdx.x < o) { sh[0][threadIdx.x] += sh[0][threadIdx.x + o]; sh[1][threadIdx.x] += sh[1][threadIdx.x + o]; }
+        __syncthreads();
+    }
+    if (threadIdx.x != 0) return;
+    finalize_scalars(mode, sh[0][0], sh[1][0], scal, tol, hslot, seq);
+}
+// k_reduce_stage1 and k_finalize in one launch for long partial lists: the workgroup that finishes last (ticket counter)
+// sums the RED1_BLOCKS slice sums in k_finalize's order and updates the scalars.  The slice sums cross XCDs inside one
+// kernel, so they travel as agent-scope atomics (an XCD's L2 is not coherent with the others' for plain accesses).
+static_assert(RED1_BLOCKS <= VB, "the last workgroup holds one slice sum per thread");
+__global__ __launch_bounds__(VB) void k_reduce_finalize(int mode, int count, const double* __restrict__ part, int npart, double* out,
+                                                        unsigned* ticket, double* __restrict__ scal, double tol, double* hslot, double seq) {
+    __shared__ double sh[2][VB];
+    __shared__ bool last;
+    if (mode != FIN_INIT && scal[SC_DONE] != 0.0) {
+        if (blockIdx.x == 0 && threadIdx.x == 0 && hslot && (mode == FIN_NORM || mode == FIN_NORM_RHO)) {
+            hslot[0] = scal[SC_NORM]; hslot[1] = scal[SC_NORM0]; hslot[2] = 1.0;
+            __hip_atomic_store(&hslot[3], seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+        }
+        return;
+    }
+    const int chunk = (count + RED1_BLOCKS - 1) / RED1_BLOCKS;
+    const int b0 = blockIdx.x * chunk, e0 = min(count, b0 + chunk);
+    double a0 = 0.0, a1 = 0.0;
+    for (int i = b0 + threadIdx.x; i < e0; i += VB) { a0 += part[i]; a1 += part[npart + i]; }
+    sh[0][threadIdx.x] = a0; sh[1][threadIdx.x] = a1;
+    __syncthreads();
+    for (int o = VB / 2; o > 0; o >>= 1) {
+        if ((int)threadIdx.x < o) { sh[0][threadIdx.x] += sh[0][threadIdx.x + o]; sh[1][threadIdx.x] += sh[1][threadIdx.x + o]; }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        __hip_atomic_store(&out[blockIdx.x], sh[0][0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(&out[RED1_BLOCKS + blockIdx.x], sh[1][0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const unsigned t = __hip_atomic_fetch_add(ticket, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
+        last = (t == gridDim.x - 1);
+    }
+    __syncthreads();
+    if (!last) return;
+    double a = 0.0, b = 0.0;
+    if (threadIdx.x < RED1_BLOCKS) {
+        a = __hip_atomic_load(&out[threadIdx.x], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        b = __hip_atomic_load(&out[RED1_BLOCKS + threadIdx.x], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    sh[0][threadIdx.x] = a; sh[1][threadIdx.x] = b;
+    __syncthreads();
+    for (int o = VB / 2; o > 0; o >>= 1) {
+        if ((int)threadIdx.x < o) { sh[0][threadIdx.x] += sh[0][threadIdx.x + o]; sh[1][threadIdx.x] += sh[1][threadIdx.x + o]; }
+        __syncthreads();
+    }
+    if (threadIdx.x != 0) return;
+    __hip_atomic_store(ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // ready for the next launch
+    finalize_scalars(mode, sh[0][0], sh[1][0], scal, tol, hslot, seq);
 }
 
 // ============================== launchers ================================================================
@@ -1282,8 +1341,17 @@ void launch_ilu_apply(opmhip_ctx* c, const double* d, double* v, int fuse) {
     }
     prof_end(c, ps);
 }
-static void finalize(opmhip_ctx* c, int mode, int count, double* hslot = nullptr) {
+// rb_half >= 0: this launch evaluates the stopping rule of half iteration rb_half and reports into its ring slot
+static void finalize(opmhip_ctx* c, int mode, int count, int rb_half = -1) {
     const double tol = c->cfg.tolerance;
+    double* hslot = nullptr;
+    double seq = 0.0;
+    if (rb_half >= 0) {
+        const int sl = rb_half % opmhip_ctx::RB_SLOTS;
+        hslot = c->d_ring + (size_t)sl * opmhip_ctx::RB_DOUBLES;
+        seq = (c->rb_seq += 1.0);
+        c->rb_want[sl] = seq;
+    }
     if (c->comm.nranks > 1) {
         // local sums -> one small all-reduce -> scalars (the reference all-reduces one double per scalar product
         // through OwnerOverlapCopyCommunication; here the two sums of a half iteration travel together)
@@ -1295,15 +1363,15 @@ static void finalize(opmhip_ctx* c, int mode, int count, double* hslot = nullptr
         }
         hipLaunchKernelGGL(k_local_sums, dim3(1), dim3(VB), 0, c->stream, cnt, src, np, c->comm.d_red);
         (void)comm_allreduce(c, c->comm.d_red, 2, 0);
-        hipLaunchKernelGGL(k_finalize, dim3(1), dim3(VB), 0, c->stream, mode, 1, c->comm.d_red, 1, c->d_scal, tol, hslot);
+        hipLaunchKernelGGL(k_finalize, dim3(1), dim3(VB), 0, c->stream, mode, 1, c->comm.d_red, 1, c->d_scal, tol, hslot, seq);
         return;
     }
     if (count > 4 * RED1_BLOCKS) {
-        hipLaunchKernelGGL(k_reduce_stage1, dim3(RED1_BLOCKS), dim3(VB), 0, c->stream, count, c->d_part, c->npart, c->d_part2);
-        hipLaunchKernelGGL(k_finalize, dim3(1), dim3(VB), 0, c->stream, mode, RED1_BLOCKS, c->d_part2, RED1_BLOCKS, c->d_scal, tol, hslot);
+        hipLaunchKernelGGL(k_reduce_finalize, dim3(RED1_BLOCKS), dim3(VB), 0, c->stream, mode, count, c->d_part, c->npart, c->d_part2,
+                           reinterpret_cast<unsigned*>(c->d_part2 + 2 * RED1_BLOCKS), c->d_scal, tol, hslot, seq);
         return;
     }
-    hipLaunchKernelGGL(k_finalize, dim3(1), dim3(VB), 0, c->stream, mode, count, c->d_part, c->npart, c->d_scal, tol, hslot);
+    hipLaunchKernelGGL(k_finalize, dim3(1), dim3(VB), 0, c->stream, mode, count, c->d_part, c->npart, c->d_scal, tol, hslot, seq);
 }
 // the vector kernels of one BiCGStab iteration, for opmhip_time_kernel
 void launch_vector_kernels_once(opmhip_ctx* c) {
@@ -1329,10 +1397,9 @@ static int read_scalars(opmhip_ctx* c) {
 static int enqueue_half(opmhip_ctx* c, int h) {
     const Pattern& P = c->pat;
     const int n = P.Nb * BS, nb = vec_blocks(n);
-    auto slot = [&](int hh) { return c->d_ring + (size_t)(hh % opmhip_ctx::RB_SLOTS) * opmhip_ctx::RB_DOUBLES; };
     // Line colouring with a light first colour: the p-update and the (r, x)-update ride in the first colour's sweep of
     // the preconditioner application that follows them (k_ilu_sweep_light_fused).  The stopping rule of a first half is
-    // then evaluated after that application; the event of half h - 1 is recorded by half h.
+    // then evaluated after that application: half h reports for half h - 1.
     const bool fused = ilu_can_fuse(c);
     int rc, ps;
     if ((h & 1) == 0) {  // first half: p, y = M^-1 p, v = A y, alpha, x += alpha y, r -= alpha v, |r|
@@ -1348,27 +1415,49 @@ static int enqueue_half(opmhip_ctx* c, int h) {
         finalize(c, FIN_ALPHA, dot_count(c));
         if (!fused) {
             hipLaunchKernelGGL(k_bicg_upd1, dim3(nb), dim3(VB), 0, c->stream, n, c->d_scal, c->d_r, c->d_v, c->d_x, c->d_pw, c->d_part, c->npart);
-            finalize(c, FIN_NORM, nb, slot(h));
+            finalize(c, FIN_NORM, nb, h);
         }
         prof_end(c, ps);
-        if (!fused) OPMHIP_HIP(c, hipEventRecord(c->rb_ev[h % opmhip_ctx::RB_SLOTS], c->stream));
     } else {             // second half: z = M^-1 r, t = A z, omega, x += omega z, r -= omega t, |r|, rho, beta
         launch_ilu_apply(c, c->d_r, c->d_s, fused ? DM_UPD1 : 0);
         if (fused) {
             ps = prof_begin(c, PROF_VECTOR);
-            finalize(c, FIN_NORM, P.tiles.colorCT[1] - P.tiles.colorCT[0], slot(h - 1));
+            finalize(c, FIN_NORM, P.tiles.colorCT[1] - P.tiles.colorCT[0], h - 1);
             prof_end(c, ps);
-            OPMHIP_HIP(c, hipEventRecord(c->rb_ev[(h - 1) % opmhip_ctx::RB_SLOTS], c->stream));
         }
         if ((rc = comm_halo_f64(c, c->d_s, BS))) return rc;
         launch_spmv(c, c->d_s, c->d_t, 2, c->d_r, nullptr);
         ps = prof_begin(c, PROF_VECTOR);
         finalize(c, FIN_OMEGA, dot_count(c));
         hipLaunchKernelGGL(k_bicg_upd2, dim3(nb), dim3(VB), 0, c->stream, n, c->d_scal, c->d_x, c->d_s, c->d_r, c->d_t, c->d_rw, c->d_part, c->npart);
-        finalize(c, FIN_NORM_RHO, nb, slot(h));
+        finalize(c, FIN_NORM_RHO, nb, h);
         prof_end(c, ps);
-        OPMHIP_HIP(c, hipEventRecord(c->rb_ev[h % opmhip_ctx::RB_SLOTS], c->stream));
     }
+    return OPMHIP_SUCCESS;
+}
+// the host's side of the read-back ring: spin on the sequence number of half iteration h's slot
+static int wait_half(opmhip_ctx* c, int h, double* norm, double* norm_0) {
+    const int sl = h % opmhip_ctx::RB_SLOTS;
+    const volatile double* slot = c->h_ring + (size_t)sl * opmhip_ctx::RB_DOUBLES;
+    const double want = c->rb_want[sl];
+    const auto t0 = std::chrono::steady_clock::now();
+    for (unsigned long spin = 1;; ++spin) {
+        if (slot[3] == want) break;
+        if ((spin & 0xFFFFu) == 0) {  // every ~65k polls: is the stream still alive?
+            const hipError_t e = hipStreamQuery(c->stream);
+            if (e == hipSuccess) {
+                if (slot[3] == want) break;
+                return fail(c, OPMHIP_DEVICE_ERROR, "BiCGStab: the stream drained without the stopping-rule record of half iteration %d", h);
+            }
+            if (e != hipErrorNotReady) return fail(c, OPMHIP_DEVICE_ERROR, "BiCGStab: %s", hipGetErrorString(e));
+            if (std::chrono::steady_clock::now() - t0 > std::chrono::seconds(120))
+                return fail(c, OPMHIP_DEVICE_ERROR, "BiCGStab: no stopping-rule record of half iteration %d after 120 s", h);
+        }
+        __builtin_ia32_pause();
+    }
+    std::atomic_thread_fence(std::memory_order_acquire);
+    *norm = slot[0];
+    *norm_0 = slot[1];
     return OPMHIP_SUCCESS;
 }
 int bicgstab(opmhip_ctx* c, opmhip_result* res) {
@@ -1376,10 +1465,21 @@ int bicgstab(opmhip_ctx* c, opmhip_result* res) {
     const int n = P.Nb * BS, nb = vec_blocks(n);
     const int maxit = c->cfg.maxit;
     const double tol = c->cfg.tolerance;
-    struct FlagScope {  // the tile kernels watch the solve's flag only while the solve runs
+    struct SolveScope {  // the tile kernels watch the solve's flag only while the solve runs; profile scopes share events
         opmhip_ctx* c;
-        explicit FlagScope(opmhip_ctx* c_) : c(c_) { c->d_done = c->d_scal + SC_DONE; }
-        ~FlagScope() { c->d_done = c->d_scal + SC_ZERO; }
+        explicit SolveScope(opmhip_ctx* c_) : c(c_) {
+            c->d_done = c->d_scal + SC_DONE;
+            Profiler& Q = c->prof;
+            Q.solve_no += 1;
+            Q.suspended = Q.enabled && Q.every > 1 && (Q.solve_no % Q.every) != 0;
+            Q.lazy = c->comm.nranks == 1;  // decomposed runs: halo exchanges sit between the scopes, keep them out
+        }
+        ~SolveScope() {
+            c->d_done = c->d_scal + SC_ZERO;
+            c->prof.lazy = false;
+            prof_flush(c);
+            c->prof.suspended = false;
+        }
     } scope(c);
     int rc;
     hipLaunchKernelGGL(k_bicg_init, dim3(nb), dim3(VB), 0, c->stream, n, c->d_b, c->d_r, c->d_rw, c->d_p, c->d_x, c->d_v, c->d_part, c->npart);
@@ -1394,12 +1494,10 @@ int bicgstab(opmhip_ctx* c, opmhip_result* res) {
     for (int h = 0; h < nhalves; ++h) {
         mark_next = c->prof.used;
         if (h + 1 < nhalves && (rc = enqueue_half(c, h + 1))) return rc;
-        OPMHIP_HIP(c, hipEventSynchronize(c->rb_ev[h % opmhip_ctx::RB_SLOTS]));
-        const volatile double* slot = c->h_ring + (size_t)(h % opmhip_ctx::RB_SLOTS) * opmhip_ctx::RB_DOUBLES;
-        norm = slot[0];
-        norm_0 = slot[1];
+        if ((rc = wait_half(c, h, &norm, &norm_0))) return rc;
         if (norm < tol * norm_0) {
             it = 0.5f * (float)(h + 1);
+            prof_flush(c);
             for (size_t i = mark_next; i < c->prof.used; ++i) c->prof.cls[i] = -1;  // half h + 1 ran as no-ops
             break;
         }
