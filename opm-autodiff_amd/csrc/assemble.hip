@@ -316,23 +316,37 @@ __global__ __launch_bounds__(256) void k_newton_update(int Nb, Tables T, CellSta
 
 // ============================== face flux ===================================================================
 // calculateGradients_ + computeFlux for one face: `in` = focus (interior) cell with derivatives, `ex` = exterior cell,
-// of which only values enter.  Both are pointers into the IQ cache.  Result: flux[eq] * faceArea.
-__device__ __forceinline__ void face_flux(const double* __restrict__ in, const double* __restrict__ ex, double trans, double faceArea,
+// of which only values enter.  Result: flux[eq] * faceArea.  The two cells come through accessors: PtrQ reads a record
+// of the IQ cache where it lies (here: the tile's own rows, staged in LDS), RegQ holds the flux-relevant fields of one
+// record in registers (the neighbour cell, fetched with one batch of loads before any of the branchy arithmetic).
+struct PtrQ {
+    const double* q;
+    __device__ __forceinline__ Ad ad(int f) const { return load_ad(q + f * 4); }
+    __device__ __forceinline__ double v(int f) const { return q[f * 4]; }
+};
+constexpr int RQ_F0 = F_P, RQ_NF = F_RS - F_P + 1;  // fields F_P .. F_RS: p, 1/B, mobility, density (3 phases each), Rs
+struct RegQ {
+    double r[RQ_NF * 4];
+    __device__ __forceinline__ Ad ad(int f) const { return Ad{r[(f - RQ_F0) * 4], r[(f - RQ_F0) * 4 + 1], r[(f - RQ_F0) * 4 + 2], r[(f - RQ_F0) * 4 + 3]}; }
+    __device__ __forceinline__ double v(int f) const { return r[(f - RQ_F0) * 4]; }
+};
+template <class IN, class EX>
+__device__ __forceinline__ void face_flux(const IN& in, const EX& ex, double trans, double faceArea,
                                           double thpres, double zIn, double zEx, double Vin, double Vex, int I, int J, Ad flux[3]) {
     flux[0] = flux[1] = flux[2] = ad_const(0.0);
     const double distZ = zIn - zEx;
     const int comp[3] = {EQ_WATER, EQ_OIL, EQ_GAS};
 #pragma unroll
     for (int ph = 0; ph < 3; ++ph) {
-        const Ad mobIn = load_ad(in + (F_MOB + ph) * 4);
-        const double mobEx = ex[(F_MOB + ph) * 4];
+        const Ad mobIn = in.ad(F_MOB + ph);
+        const double mobEx = ex.v(F_MOB + ph);
         if (mobIn.v <= 0.0 && mobEx <= 0.0) continue;
-        const Ad rhoIn = load_ad(in + (F_RHO + ph) * 4);
-        const double rhoEx = ex[(F_RHO + ph) * 4];
+        const Ad rhoIn = in.ad(F_RHO + ph);
+        const double rhoEx = ex.v(F_RHO + ph);
         const Ad rhoAvg = (rhoIn + rhoEx) / 2.0;
-        Ad pressureExterior = ad_const(ex[(F_P + ph) * 4]);
+        Ad pressureExterior = ad_const(ex.v(F_P + ph));
         pressureExterior = pressureExterior + rhoAvg * (distZ * GRAVITY);
-        Ad dp = pressureExterior - load_ad(in + (F_P + ph) * 4);
+        Ad dp = pressureExterior - in.ad(F_P + ph);
         bool upIn;
         if (dp.v > 0.0) upIn = false;
         else if (dp.v < 0.0) upIn = true;
@@ -345,15 +359,15 @@ __device__ __forceinline__ void face_flux(const double* __restrict__ in, const d
         Ad volumeFlux, surf;
         if (upIn) {
             volumeFlux = dp * mobIn * ad_const(1.0) * (-trans / faceArea);
-            surf = load_ad(in + (F_B + ph) * 4) * volumeFlux;
+            surf = in.ad(F_B + ph) * volumeFlux;
         } else {
             volumeFlux = dp * (mobEx * 1.0 * (-trans / faceArea));
-            surf = ex[(F_B + ph) * 4] * volumeFlux;
+            surf = ex.v(F_B + ph) * volumeFlux;
         }
         flux[comp[ph]] = flux[comp[ph]] + surf;
         if (ph == OIL) {
-            if (upIn) flux[EQ_GAS] = flux[EQ_GAS] + load_ad(in + F_RS * 4) * surf;
-            else flux[EQ_GAS] = flux[EQ_GAS] + ex[F_RS * 4] * surf;
+            if (upIn) flux[EQ_GAS] = flux[EQ_GAS] + in.ad(F_RS) * surf;
+            else flux[EQ_GAS] = flux[EQ_GAS] + ex.v(F_RS) * surf;
         }
     }
 #pragma unroll
@@ -362,11 +376,16 @@ __device__ __forceinline__ void face_flux(const double* __restrict__ in, const d
 
 // ============================== assembly ======================================================================
 constexpr int ASM_THREADS = 256;
+constexpr int ASM_MAX_ROWS = 40;  // rows of one tile (their IQ records are staged in LDS); 36 on a 7-point grid
+int asm_max_rows() { return ASM_MAX_ROWS; }
 struct EntryStatic {
     const double *trans, *area, *thpres;  // per entry, internal order
 };
-// FvBaseLinearizer::linearizeDomain.  tile t: rows [row0[t], row0[t+1]) ; its entries <= ASM_THREADS.
-__global__ __launch_bounds__(ASM_THREADS) void k_assemble(const int* __restrict__ asm_row0, const int* __restrict__ rowptr,
+// FvBaseLinearizer::linearizeDomain.  tile t: rows [row0[t], row0[t+1]) ; its entries <= ASM_THREADS, rows <= ASM_MAX_ROWS.
+// The kernel was latency-bound (PMC: waves waiting 74 % of their life, ~18 dependent load rounds per lane through the
+// branches of the flux), so every global load is issued up front in ONE round: the tile's own IQ records as a coalesced
+// copy into LDS, the neighbour's flux fields into registers, the statics; the arithmetic then runs out of LDS/registers.
+__global__ __launch_bounds__(ASM_THREADS) void k_assemble(int ntiles, const int* __restrict__ asm_order, const int* __restrict__ asm_row0, const int* __restrict__ rowptr,
                                                           const int* __restrict__ col, const int* __restrict__ natOrder,
                                                           EntryStatic ES, CellStatic C, const double* __restrict__ iq,
                                                           double* __restrict__ storageOld, const double* __restrict__ source,
@@ -374,27 +393,49 @@ __global__ __launch_bounds__(ASM_THREADS) void k_assemble(const int* __restrict_
                                                           double* __restrict__ A, double* __restrict__ resid) {
     __shared__ __attribute__((aligned(16))) double sblk[(ASM_THREADS + 2) * BB];  // the tile's blocks, then streamed out
     __shared__ double sflux[ASM_THREADS * 12];                                     // face flux seen from the row's cell
+    __shared__ __attribute__((aligned(16))) double sI[ASM_MAX_ROWS * IQS];         // IQ records of the tile's rows
     __shared__ short srow[ASM_THREADS];
-    const int t = blockIdx.x, tid = threadIdx.x;
+    // Workgroups are dealt round-robin over the 8 XCDs (b and b + 8 share one): every XCD gets one contiguous eighth of
+    // the schedule, so that the neighbour records several nearby tiles gather are found in that XCD's own L2
+    const int tid = threadIdx.x;
+    const int chunk = (ntiles + 7) >> 3;
+    const int pos = (blockIdx.x & 7) * chunk + (blockIdx.x >> 3);
+    if (pos >= ntiles) return;
+    const int t = asm_order[pos];
     const int r0 = asm_row0[t], r1 = asm_row0[t + 1];
     const int k0 = rowptr[r0], k1 = rowptr[r1], nent = k1 - k0;
     const int k0e = k0 & ~1;  // 16-byte aligned start of the output stream
+    {   // own records: one contiguous range of the cache (IQS * 8 = 544 bytes per row, 16-byte aligned)
+        const double2* g2 = reinterpret_cast<const double2*>(iq + (size_t)r0 * IQS);
+        double2* s2 = reinterpret_cast<double2*>(sI);
+        const int n2 = (r1 - r0) * (IQS / 2);
+        for (int i = tid; i < n2; i += ASM_THREADS) s2[i] = g2[i];
+    }
     if (tid < r1 - r0)
         for (int k = rowptr[r0 + tid]; k < rowptr[r0 + tid + 1]; ++k) srow[k - k0] = (short)tid;
     __syncthreads();
-    Ad st[3];
-    int I = -1, J = -1, k = -1;
+    int I = -1, J = -1, k = -1, lrow = 0;
     bool isDiag = false;
+    RegQ qJ;
+    double trans = 0.0, area = 1.0, thp = 0.0, zI = 0.0, zJ = 0.0, VI = 0.0, VJ = 0.0;
     if (tid < nent) {
         k = k0 + tid;
-        I = r0 + srow[tid];
+        lrow = srow[tid];
+        I = r0 + lrow;
         J = col[k];
         isDiag = (I == J);
-        const double* qI = iq + (size_t)I * IQS;
         if (!isDiag) {
-            const double* qJ = iq + (size_t)J * IQS;
-            const double trans = ES.trans[k], area = ES.area[k], thp = ES.thpres ? ES.thpres[k] : 0.0;
-            const double zI = C.depth[I], zJ = C.depth[J], VI = C.volume[I], VJ = C.volume[J];
+            const double2* g2 = reinterpret_cast<const double2*>(iq + (size_t)J * IQS + RQ_F0 * 4);
+#pragma unroll
+            for (int i = 0; i < RQ_NF * 2; ++i) { const double2 v = g2[i]; qJ.r[2 * i] = v.x; qJ.r[2 * i + 1] = v.y; }
+            trans = ES.trans[k]; area = ES.area[k]; thp = ES.thpres ? ES.thpres[k] : 0.0;
+            zI = C.depth[I]; zJ = C.depth[J]; VI = C.volume[I]; VJ = C.volume[J];
+        }
+    }
+    Ad st[3];
+    const PtrQ qI{sI + lrow * IQS};
+    if (tid < nent) {
+        if (!isDiag) {
             Ad f[3];
             face_flux(qI, qJ, trans, area, thp, zI, zJ, VI, VJ, I, J, f);  // focus I: contribution to R_I
             for (int e = 0; e < 3; ++e) store_ad(&sflux[tid * 12 + e * 4], f[e]);
@@ -406,12 +447,12 @@ __global__ __launch_bounds__(ASM_THREADS) void k_assemble(const int* __restrict_
             }
         } else {
             // computeStorage: surface volumes per bulk volume
-            const Ad poro = load_ad(qI + F_PORO * 4), Rs = load_ad(qI + F_RS * 4);
+            const Ad poro = qI.ad(F_PORO), Rs = qI.ad(F_RS);
             st[0] = st[1] = st[2] = ad_const(0.0);
             const int comp[3] = {EQ_WATER, EQ_OIL, EQ_GAS};
 #pragma unroll
             for (int ph = 0; ph < 3; ++ph) {
-                const Ad surfaceVolume = load_ad(qI + (F_S + ph) * 4) * load_ad(qI + (F_B + ph) * 4) * poro;
+                const Ad surfaceVolume = qI.ad(F_S + ph) * qI.ad(F_B + ph) * poro;
                 st[comp[ph]] = st[comp[ph]] + surfaceVolume;
                 if (ph == OIL) st[EQ_GAS] = st[EQ_GAS] + Rs * surfaceVolume;
             }
@@ -630,7 +671,7 @@ void launch_assemble(opmhip_ctx* c, double dt, int iteration) {
     const Pattern& P = c->pat;
     EntryStatic ES{c->asmb.d_trans, c->asmb.d_area, c->asmb.d_thpres};
     const int ps = prof_begin(c, PROF_ASSEMBLE);
-    hipLaunchKernelGGL(k_assemble, dim3(c->asmb.ntiles), dim3(ASM_THREADS), 0, c->stream, c->asmb.d_asm_row0, P.d_rowptr, P.d_col, c->asmb.d_natOrder, ES,
+    hipLaunchKernelGGL(k_assemble, dim3(8 * ((c->asmb.ntiles + 7) / 8)), dim3(ASM_THREADS), 0, c->stream, c->asmb.ntiles, c->asmb.d_asm_order, c->asmb.d_asm_row0, P.d_rowptr, P.d_col, c->asmb.d_natOrder, ES,
                        cells_of(c), c->asmb.d_iq, c->asmb.d_storageOld, c->asmb.d_source, c->asmb.d_dsource, dt, iteration, c->d_A, c->d_b);
     prof_end(c, ps);
 }

@@ -143,13 +143,32 @@ int opmhip_set_static(opmhip_ctx* c, const double* trans, const double* area, co
             while (r < P.Nb) {
                 row0.push_back(r);
                 int e = r;
-                while (e < P.Nb && P.rowptr[e + 1] - P.rowptr[r] <= 256) ++e;
+                while (e < P.Nb && P.rowptr[e + 1] - P.rowptr[r] <= 256 && e - r < asm_max_rows()) ++e;
                 if (e == r) return fail(c, OPMHIP_ANALYSIS_FAILED, "set_static: row %d has more than 256 blocks", r);
                 r = e;
             }
             row0.push_back(P.Nb);
             A.ntiles = (int)row0.size() - 1;
             if ((rc = dev_upload(c, &A.d_asm_row0, row0))) return rc;
+            // Schedule: the ILU ordering stores the colours one after the other, so a cell and its neighbours of another
+            // colour sit at the same RELATIVE position of two far-apart regions.  Tiles are therefore launched by their
+            // relative position inside their colour, colours interleaved: the intensive quantities a tile gathers from
+            // the other colours were, or will shortly be, touched by the tiles running next to it and stay in L2.
+            {
+                std::vector<int> colorOfTile(A.ntiles), first(P.numColors + 1, A.ntiles), cnt(P.numColors, 0);
+                int cc = 0;
+                for (int t = 0; t < A.ntiles; ++t) {
+                    while (cc + 1 < P.numColors && row0[t] >= P.colorPrefix[cc + 1]) ++cc;
+                    colorOfTile[t] = cc;
+                    first[cc] = std::min(first[cc], t);
+                    cnt[cc]++;
+                }
+                std::vector<int> order(A.ntiles);
+                for (int t = 0; t < A.ntiles; ++t) order[t] = t;
+                auto frac = [&](int t) { const int q = colorOfTile[t]; return (double)(t - first[q]) / (double)cnt[q]; };
+                std::stable_sort(order.begin(), order.end(), [&](int x, int y) { return frac(x) < frac(y); });
+                if ((rc = dev_upload(c, &A.d_asm_order, order))) return rc;
+            }
             // entries of each row in ascending natural-column order (= ascending natural entry index)
             std::vector<int> natOrder(P.nnzb);
             for (int p = 0; p < P.Nb; ++p) {

@@ -87,6 +87,7 @@ struct AsmDev {
     bool prev_set = false;
     int* d_nswitched = nullptr;
     int* d_asm_row0 = nullptr;
+    int* d_asm_order = nullptr;  // launch position -> tile
     int* d_natOrder = nullptr;  // per row: its entries (internal indices) sorted by natural column
     int ntiles = 0;
     double *d_conv_part = nullptr, *d_conv_out = nullptr;
@@ -280,6 +281,7 @@ void launch_u8_to_internal(opmhip_ctx* c, const unsigned char* nat, unsigned cha
 void launch_u8_to_natural(opmhip_ctx* c, const unsigned char* internal, unsigned char* nat);
 void launch_iq_to_natural(opmhip_ctx* c, double* d_nat);
 int iq_doubles_per_cell();
+int asm_max_rows();
 void launch_vector_kernels_once(opmhip_ctx* c);
 
 }  // namespace opmhip
