@@ -41,9 +41,10 @@ def alg_bytes(Nb, nnzb):
     """Algorithmic bytes per launch (SURVEY.md §8d / BASELINE.md §4), block size 3, double values, int32 indices."""
     return {
         "spmv": 76 * nnzb + 4 * (Nb + 1) + 48 * Nb,
-        "ilu_apply": 76 * nnzb + 4 * (Nb + 1) + 4 * Nb + 72 * Nb,
+        # + the BiCGStab p- and (r, x)-updates that ride in the first colour's sweep: (3 + 5) / 2 extra vector passes
+        "ilu_apply": 76 * nnzb + 4 * (Nb + 1) + 4 * Nb + 72 * Nb + 24 * Nb * 4,
         "ilu_factor": 2 * 72 * nnzb + 4 * nnzb + 4 * Nb,
-        "vector": 24 * Nb * 9,        # one group between two operator applications: (4 + 6 + 8) / 2 passes on average
+        "vector": 24 * Nb * 7 / 3,    # per scope: of the three vector scopes of an iteration two are scalar-only, one is k_bicg_upd2 (7 passes)
         "assemble": 85 * Nb + 12 * nnzb + 72 * nnzb + 24 * Nb,
         "iq_update": 24 * Nb + 544 * Nb,
         "convergence": 56 * Nb,
@@ -175,6 +176,16 @@ def main():
     # linear-solve GB/s: algorithmic bytes of all solver kernels / their summed device time
     ls_bytes = sum(B[k] * prof[k][0] for k in ("spmv", "ilu_apply", "ilu_factor", "vector"))
     ls_ms = sum(prof[k][1] for k in ("spmv", "ilu_apply", "ilu_factor", "vector"))
+    # HBM-side traffic of k_spmv per launch: PMC passes cannot run inside this process (counters need their own
+    # rocprofv3 runs), so the number comes from the committed summary of tools/pmc_quick.sh over this same command
+    traffic, traffic_src = None, None
+    tj = os.path.join(ROOT, "profiles", "r01_c_pmc_traffic.json")
+    if world == 1 and n == 100 and a.reorder == "line_coloring" and os.path.exists(tj):
+        with open(tj) as f:
+            kk = json.load(f)["kernels"]
+        vals = [v["traffic_bytes_per_launch"] for k, v in kk.items() if "k_spmv" in k]
+        if vals:
+            traffic, traffic_src = sum(vals) / len(vals), "profiles/r01_c_pmc_traffic.json"
     out = {
         "metric": "Newton iterations/sec, 1M-cell 3-phase black-oil (assembly + ILU0/BiCGStab solve + update)",
         # weak scaling: every rank advances the SAME coupled Newton iteration on its 1M-cell subdomain; the whole-job
@@ -200,7 +211,8 @@ def main():
         "kernels": kernels,
         "roofline": {"bound": "hbm", "kernel": "k_spmv (block-CSR SpMV, 3x3 double blocks)", "achieved": sp["algorithmic_GBps"],
                      "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": (sp["algorithmic_GBps"] / HBM_PEAK_GBS) if sp["algorithmic_GBps"] == sp["algorithmic_GBps"] else None,
-                     "traffic": None, "avg_launch_ms": sp["avg_ms"], "algorithmic_bytes_per_launch": B["spmv"]},
+                     "traffic": traffic, "traffic_unit": "bytes per launch (L2 fabric side; FETCH_SIZE x 2 + WRITE_SIZE, KiB -> B)",
+                     "traffic_source": traffic_src, "avg_launch_ms": sp["avg_ms"], "algorithmic_bytes_per_launch": B["spmv"]},
     }
     if rank == 0 and world == 1 and not a.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(pkg, case, src)

@@ -727,18 +727,17 @@ __global__ __launch_bounds__(64) void k_ilu_sweep_light_fused(int ct_begin, int 
         double blk[BB], dv[3], vv[3], wv[3], xv[3];
     };
     auto stageA = [&](int st, StA& a) {
-        if (chainLane) {
-            const int r0 = srow0[st], r1 = srow0[st + 1];
-            a.active = r0 + lane < r1;
-            a.rr = a.active ? r0 + lane : r1 - 1;
-            a.kb = prow[a.rr];
-            a.ke = prow[a.rr + 1];
-        } else {
-            const int fr = fb + st * TILE_ROWS + (lane - TILE_ROWS);
-            a.active = fr < fe;
-            a.rr = a.active ? fr : (fe > fb ? fe - 1 : srow0[0]);  // any valid row for the unused loads
-            a.kb = a.ke = 0;
-        }
+        const int r0 = srow0[st], r1 = srow0[st + 1];
+        const int fr = fb + st * TILE_ROWS + (lane - TILE_ROWS);
+        const bool act = chainLane ? (r0 + lane < r1) : (fr < fe);
+        // inactive lanes load from some valid row and discard it
+        const int rr = chainLane ? (act ? r0 + lane : r1 - 1) : (act ? fr : (fe > fb ? fe - 1 : r0));
+        const int rp = chainLane ? rr : r0;  // foreign lanes have no factor entry: kb == ke below
+        const int kb = prow[rp], ke = prow[rp + 1];
+        a.active = act;
+        a.rr = rr;
+        a.kb = kb;
+        a.ke = chainLane ? ke : kb;
     };
     auto load_vec = [&](int rr, StB& b) {
         const size_t o = (size_t)rr * BS;
@@ -758,9 +757,11 @@ __global__ __launch_bounds__(64) void k_ilu_sweep_light_fused(int ct_begin, int 
         load_vec(a.rr, b);
     };
     double ssum = 0.0;
-    // the vector update of one row; returns the new dvec entry in out[]
-    auto update_row = [&](int r, const StB& b, double* out) {
+    // the vector update of one row; returns the new dvec entry
+    struct V3 { double x, y, z; };
+    auto update_row = [&](int r, const StB& b) -> V3 {
         const size_t o = (size_t)r * BS;
+        double out[3];
         if (DM == DM_PUPD) {
 #pragma unroll
             for (int q = 0; q < 3; ++q) out[q] = (b.dv[q] - omega * b.vv[q]) * beta + b.wv[q];
@@ -773,6 +774,7 @@ __global__ __launch_bounds__(64) void k_ilu_sweep_light_fused(int ct_begin, int 
             }
         }
         dvec[o] = out[0]; dvec[o + 1] = out[1]; dvec[o + 2] = out[2];
+        return V3{out[0], out[1], out[2]};
     };
     StA aa[D + 1];
     StB b[D];
@@ -791,8 +793,8 @@ __global__ __launch_bounds__(64) void k_ilu_sweep_light_fused(int ct_begin, int 
             if (st < nsteps) {
                 StB& c = b[u];
                 if (c.r >= 0) {
-                    double rhs[3];
-                    update_row(c.r, c, rhs);
+                    const V3 nd = update_row(c.r, c);
+                    double rhs[3] = {nd.x, nd.y, nd.z};
                     if (chainLane) {
                         if (c.has) blk_mmv(c.blk, prev[0], prev[1], prev[2], rhs);
                         vu[(size_t)c.r * BS] = rhs[0]; vu[(size_t)c.r * BS + 1] = rhs[1]; vu[(size_t)c.r * BS + 2] = rhs[2];
@@ -808,10 +810,17 @@ __global__ __launch_bounds__(64) void k_ilu_sweep_light_fused(int ct_begin, int 
     }
     // foreign rows beyond 32 per step (short chain tiles): all 64 lanes, plain loop
     for (int fr = fb + nsteps * TILE_ROWS + lane; fr < fe; fr += 64) {
-        StB t;
-        load_vec(fr, t);
-        double out[3];
-        update_row(fr, t, out);
+        const size_t o = (size_t)fr * BS;
+#pragma unroll
+        for (int q = 0; q < 3; ++q) {
+            if (DM == DM_PUPD) dvec[o + q] = (dvec[o + q] - omega * vvec[o + q]) * beta + wvec[o + q];
+            else {
+                const double re = dvec[o + q] - alpha * vvec[o + q];
+                xvec[o + q] = xvec[o + q] + alpha * wvec[o + q];
+                ssum += re * re;
+                dvec[o + q] = re;
+            }
+        }
     }
     if (DM == DM_UPD1) {
         ssum = wave_sum(ssum);
