@@ -446,4 +446,141 @@ SolveResult bicgstab(size_t n, const double* b, double* x, Prec&& prec, Op&& op,
     return res;
 }
 
+
+// =====================================================================================================
+// Threaded variants for bench.py's multi-core CPU baseline ("CPU-N": what N MPI ranks of Flow do on one host):
+// block-Jacobi ILU0 over nsub contiguous row ranges, one range per thread (ghost_last_bilu0_decomposition per rank,
+// linalg/ParallelOverlappingILU0.hpp:439-494: couplings that leave the range are skipped), row-parallel SpMV,
+// OpenMP reductions for the scalar products.  Same recurrence as bicgstab() above.  Baseline only: no parity claim
+// rests on these (the reduction order depends on the thread count).
+// =====================================================================================================
+inline int bilu0_decompose_bj(Bcrs& A, const std::vector<int>& sub) {
+    const std::vector<int> dg = diag_index(A);
+    const int nsub = (int)sub.size() - 1;
+    int err = 0;
+#pragma omp parallel for schedule(static, 1)
+    for (int sd = 0; sd < nsub; ++sd) {
+        const int s0 = sub[sd], s1 = sub[sd + 1];
+        for (int i = s0; i < s1; ++i) {
+            const int endi = A.rowptr[i + 1];
+            int ij = A.rowptr[i];
+            for (; ij < endi && A.col[ij] < i; ++ij) {
+                const int j = A.col[ij];
+                if (j < s0) continue;  // another rank's row: not part of this rank's ILU0
+                const int jj = dg[j];
+                double* Lij = &A.val[(size_t)ij * BB];
+                blk_rightmultiply(Lij, &A.val[(size_t)jj * BB]);
+                const int endj = A.rowptr[j + 1];
+                int jk = jj + 1, ik = ij + 1;
+                while (ik < endi && jk < endj) {
+                    if (A.col[ik] == A.col[jk]) {
+                        if (A.col[ik] < s1) {
+                            double B[BB];
+                            std::memcpy(B, &A.val[(size_t)jk * BB], sizeof B);
+                            blk_leftmultiply(B, Lij);
+                            double* Aik = &A.val[(size_t)ik * BB];
+                            for (int e = 0; e < BB; ++e) Aik[e] -= B[e];
+                        }
+                        ++ik; ++jk;
+                    } else if (A.col[ik] < A.col[jk]) ++ik;
+                    else ++jk;
+                }
+            }
+            if (ij >= endi || A.col[ij] != i) { err = -(i + 1); continue; }
+            double inv[BB];
+            blk_invert(&A.val[(size_t)ij * BB], inv);
+            std::memcpy(&A.val[(size_t)ij * BB], inv, sizeof inv);
+        }
+    }
+    return err;
+}
+inline void ilu0_apply_bj(const Bcrs& LU, const std::vector<int>& dg, const std::vector<int>& sub, const double* d,
+                          double* v, double w, int mode) {
+    const int nsub = (int)sub.size() - 1;
+#pragma omp parallel for schedule(static, 1)
+    for (int sd = 0; sd < nsub; ++sd) {
+        const int s0 = sub[sd], s1 = sub[sd + 1];
+        for (int i = s0; i < s1; ++i) {
+            double rhs[BS] = {d[(size_t)i * BS], d[(size_t)i * BS + 1], d[(size_t)i * BS + 2]};
+            for (int k = LU.rowptr[i]; k < dg[i]; ++k)
+                if (LU.col[k] >= s0) blk_mmv(&LU.val[(size_t)k * BB], &v[(size_t)LU.col[k] * BS], rhs);
+            for (int r = 0; r < BS; ++r) v[(size_t)i * BS + r] = rhs[r];
+        }
+        for (int i = s1 - 1; i >= s0; --i) {
+            double rhs[BS] = {v[(size_t)i * BS], v[(size_t)i * BS + 1], v[(size_t)i * BS + 2]};
+            if (mode == 0) {
+                for (int k = LU.rowptr[i + 1] - 1; k > dg[i]; --k)
+                    if (LU.col[k] < s1) blk_mmv(&LU.val[(size_t)k * BB], &v[(size_t)LU.col[k] * BS], rhs);
+            } else {
+                for (int k = dg[i] + 1; k < LU.rowptr[i + 1]; ++k)
+                    if (LU.col[k] < s1) blk_mmv(&LU.val[(size_t)k * BB], &v[(size_t)LU.col[k] * BS], rhs);
+            }
+            double out[BS];
+            blk_mv(&LU.val[(size_t)dg[i] * BB], rhs, out);
+            for (int r = 0; r < BS; ++r) v[(size_t)i * BS + r] = (mode == 1) ? w * out[r] : out[r];
+        }
+        if (mode == 0 && w != 1.0)
+            for (size_t e = (size_t)s0 * BS; e < (size_t)s1 * BS; ++e) v[e] *= w;
+    }
+}
+inline void spmv_mt(const Bcrs& A, const double* x, double* y) {
+#pragma omp parallel for schedule(static)
+    for (int i = 0; i < A.Nb; ++i) {
+        double acc[BS] = {0.0, 0.0, 0.0};
+        for (int k = A.rowptr[i]; k < A.rowptr[i + 1]; ++k)
+            blk_umv(&A.val[(size_t)k * BB], &x[(size_t)A.col[k] * BS], acc);
+        for (int r = 0; r < BS; ++r) y[(size_t)i * BS + r] = acc[r];
+    }
+}
+inline double dot_mt(const double* a, const double* b, size_t n) {
+    double s = 0.0;
+#pragma omp parallel for schedule(static) reduction(+ : s)
+    for (long long i = 0; i < (long long)n; ++i) s += a[i] * b[i];
+    return s;
+}
+template <class Prec, class Op>
+SolveResult bicgstab_mt(size_t n, const double* b, double* x, Prec&& prec, Op&& op, double tol, int maxit) {
+    std::vector<double> r(b, b + n), rw(b, b + n), p(b, b + n), v(n, 0.0), s(n), t(n), pw(n);
+    std::fill(x, x + n, 0.0);
+    const long long N = (long long)n;
+    double rho = 1.0, rhop, alpha = 1.0, omega = 1.0, beta, tmp1, tmp2;
+    double norm = std::sqrt(dot_mt(r.data(), r.data(), n));
+    const double norm_0 = norm;
+    float it;
+    for (it = 0.5f; it < maxit; it += 0.5f) {
+        rhop = rho;
+        rho = dot_mt(rw.data(), r.data(), n);
+        if (it > 1) {
+            beta = (rho / rhop) * (alpha / omega);
+#pragma omp parallel for schedule(static)
+            for (long long i = 0; i < N; ++i) p[i] = (p[i] - omega * v[i]) * beta + r[i];
+        }
+        prec(p.data(), pw.data());
+        op(pw.data(), v.data());
+        tmp1 = dot_mt(rw.data(), v.data(), n);
+        alpha = rho / tmp1;
+#pragma omp parallel for schedule(static)
+        for (long long i = 0; i < N; ++i) { r[i] -= alpha * v[i]; x[i] += alpha * pw[i]; }
+        norm = std::sqrt(dot_mt(r.data(), r.data(), n));
+        if (norm < tol * norm_0) break;
+        it += 0.5f;
+        prec(r.data(), s.data());
+        op(s.data(), t.data());
+        tmp1 = dot_mt(t.data(), r.data(), n);
+        tmp2 = dot_mt(t.data(), t.data(), n);
+        omega = tmp1 / tmp2;
+#pragma omp parallel for schedule(static)
+        for (long long i = 0; i < N; ++i) { x[i] += omega * s[i]; r[i] -= omega * t[i]; }
+        norm = std::sqrt(dot_mt(r.data(), r.data(), n));
+        if (norm < tol * norm_0) break;
+    }
+    SolveResult res;
+    res.it = it;
+    res.iterations = (int)std::min(it, (float)maxit);
+    res.reduction = norm / norm_0;
+    res.conv_rate = std::pow(res.reduction, 1.0 / it);
+    res.converged = (it != (maxit + 0.5f));
+    return res;
+}
+
 }  // namespace orc

@@ -1,6 +1,9 @@
 // ORACLE — TEST INFRASTRUCTURE ONLY (see linalg.hpp header).  C entry points so that tests/,
 // smoke() and bench.py's cpu_baseline leg can drive the CPU restatement through ctypes.
 #include <chrono>
+#ifdef _OPENMP
+#include <omp.h>
+#endif
 #include <cstdio>
 
 #include "linalg.hpp"
@@ -372,6 +375,62 @@ int orc_bo_convergence(orc_model* h, double dt, double tol_cnv, double* out) {
     return 0;
 }
 int orc_bo_update(orc_model* h, const double* dx) { return h->M.update(dx); }
+// threads for the OpenMP loops (assembly, IQ update, the *_mt solver below); returns the previous maximum
+int orc_set_threads(int n) {
+#ifdef _OPENMP
+    const int old = omp_get_max_threads();
+    if (n > 0) omp_set_num_threads(n);
+    return old;
+#else
+    (void)n;
+    return 1;
+#endif
+}
+// solveJacobianSystem as `threads` MPI ranks of Flow would run it on one host: natural order, the rows cut into
+// `threads` contiguous ranges, block-Jacobi ILU0 (one range per thread), threaded SpMV and scalar products.
+// bench.py's multi-core CPU baseline only.
+int orc_bo_solve_mt(orc_model* h, double* x, double tol, int maxit, double w, int relax_mode, int threads, orc_result* out) {
+    using clk = std::chrono::steady_clock;
+    Model& M = h->M;
+    const int Nb = M.P.pat.Nb;
+    const size_t n = (size_t)Nb * BS;
+    if (threads < 1) threads = 1;
+    std::vector<int> sub(threads + 1);
+    for (int s = 0; s <= threads; ++s) sub[s] = (int)((long long)Nb * s / threads);
+    auto t0 = clk::now();
+    // values copied (threaded): the zero-diagonal fix and the factorisation work on copies, as in the 1-thread path
+    auto copy_mt = [](const Bcrs& S) {
+        Bcrs D;
+        D.Nb = S.Nb; D.rowptr = S.rowptr; D.col = S.col;
+        D.val.resize(S.val.size());
+        const long long m = (long long)S.val.size();
+#pragma omp parallel for schedule(static)
+        for (long long i = 0; i < m; ++i) D.val[i] = S.val[i];
+        return D;
+    };
+    Bcrs A = copy_mt(M.J);
+    check_zero_diagonal(A);
+    Bcrs LU = copy_mt(A);
+    const int rc = bilu0_decompose_bj(LU, sub);
+    if (rc != 0) return rc;
+    const std::vector<int> dg = diag_index(LU);
+    auto t1 = clk::now();
+    auto prec = [&](const double* d, double* v) { ilu0_apply_bj(LU, dg, sub, d, v, w, relax_mode); };
+    auto op = [&](const double* xin, double* y) { spmv_mt(A, xin, y); };
+    SolveResult r = bicgstab_mt(n, M.residual.data(), x, prec, op, tol, maxit);
+    auto t2 = clk::now();
+    if (out) {
+        out->iterations = r.iterations;
+        out->converged = r.converged;
+        out->reduction = r.reduction;
+        out->conv_rate = r.conv_rate;
+        out->it = r.it;
+        out->t_factor = std::chrono::duration<double>(t1 - t0).count();
+        out->t_solve = std::chrono::duration<double>(t2 - t1).count();
+        out->num_colors = 0;
+    }
+    return 0;
+}
 
 // ILU0-BiCGStab on the model's own Jacobian and residual (solveJacobianSystem, BlackoilModelEbos.hpp:523-544)
 int orc_bo_solve(orc_model* h, double* x, double tol, int maxit, double w, int relax_mode, int reorder, int nsub,

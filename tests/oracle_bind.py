@@ -120,6 +120,8 @@ class OracleModel:
         L.orc_bo_assemble_fetch.argtypes = [_vp, _vp, _vp]
         L.orc_bo_solve.argtypes = [_vp, _d, C.c_double, C.c_int, C.c_double, C.c_int, C.c_int, C.c_int, _vp,
                                    C.POINTER(OrcResult)]
+        L.orc_bo_solve_mt.argtypes = [_vp, _d, C.c_double, C.c_int, C.c_double, C.c_int, C.c_int, C.POINTER(OrcResult)]
+        L.orc_set_threads.argtypes = [C.c_int]
         self.case = case
         self.Nb = case["Nb"]
         self.nnzb = len(case["col"])
@@ -185,13 +187,29 @@ class OracleModel:
         return x, res
 
 
+def _solve_mt(self, tol=1e-2, maxit=200, w=0.9, mode="post_scale", threads=1):
+    """block-Jacobi ILU0 over `threads` contiguous row ranges, OpenMP-threaded (CPU-N baseline of bench.py)"""
+    x = np.zeros(self.Nb * 3)
+    res = OrcResult()
+    rc = self.o.lib.orc_bo_solve_mt(self.h, x, tol, maxit, w, RELAX[mode], threads, C.byref(res))
+    assert rc == 0, rc
+    return x, res
+
+
+OracleModel.solve_mt = _solve_mt
+
+
 class OracleAsHipModel:
     """An OracleModel behind the method names of capi.HipModel that newton.BlackoilModelHip / AdaptiveTimeStepping call,
     so that the CPU restatement can be driven by the very same Newton and time-stepping loop (bench.py's cpu_baseline,
     tests).  Checker-side only."""
 
-    def __init__(self, om, tol=1e-2, maxit=200, w=0.9, mode="post_scale", reorder="none"):
+    def __init__(self, om, tol=1e-2, maxit=200, w=0.9, mode="post_scale", reorder="none", threads=1):
+        """threads > 1: assembly loops and the linear solver run OpenMP-threaded, the ILU0 becomes block-Jacobi over
+        `threads` row ranges - the work of `threads` MPI ranks of Flow on one host"""
         self.om, self.kw = om, dict(tol=tol, maxit=maxit, w=w, mode=mode, reorder=reorder)
+        self.threads = threads
+        om.o.lib.orc_set_threads(threads)
         self._x = None
         self._prev = None
 
@@ -203,7 +221,11 @@ class OracleAsHipModel:
 
     def solve_jacobian_system(self):
         from types import SimpleNamespace
-        self._x, r = self.om.solve(**self.kw)
+        if self.threads > 1:
+            kw = {k: v for k, v in self.kw.items() if k != "reorder"}
+            self._x, r = self.om.solve_mt(threads=self.threads, **kw)
+        else:
+            self._x, r = self.om.solve(**self.kw)
         return SimpleNamespace(t_factor=r.t_factor, t_solve=r.t_solve, t_copy=0.0, iterations=r.iterations, converged=bool(r.converged), it=r.it)
 
     def update(self, dx, relax=1.0):
