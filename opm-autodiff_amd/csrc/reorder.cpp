@@ -381,12 +381,17 @@ int build_pattern(opmhip_ctx* c, int Nb, int Nghost, int nnzb, const int* rows, 
             if (groupNewCT[g]) T.ctFirst.push_back((int)T.row0.size());
             int r = groupRow[g];
             const int rend = groupRow[g + 1];
+            int pieces = 0;
             while (r < rend) {
                 T.row0.push_back(r);
                 int e = r + 1;
                 while (e < rend && P.rowptr[e + 1] - P.rowptr[r] <= TILE_CAP_BLOCKS) ++e;
                 r = e;
+                ++pieces;
             }
+            // a step cut into several sub-tiles no longer maps chain b to lane b: the lane-private light sweeps
+            // (which keep the chain's previous row in registers without looking) are off for that colour
+            if (pieces > 1 && cnext >= 1) P.lightL[cnext - 1] = P.lightU[cnext - 1] = 0;
         }
         T.colorTile.push_back((int)T.row0.size());
         T.colorCT.push_back((int)T.ctFirst.size());

@@ -124,7 +124,12 @@ def test_irregular_rows_and_long_rows(pkg, orc):
         to, fr, rpc = s.ordering()
         rr, rc, rv = orc.reorder_matrix(Nb, rp, ci, v, to, fr)
         lu = s.ilu0_factor()
-        assert np.array_equal(lu, orc.ilu0_factor(Nb, rr, rc, rv))
+        luo = orc.ilu0_factor(Nb, rr, rc, rv)
+        assert np.array_equal(lu, luo)
+        # M^-1 by itself (a wrong preconditioner would still let the Krylov loop converge)
+        d = np.random.default_rng(2).standard_normal(Nb * 3)
+        vo = orc.ilu0_apply(Nb, rr, rc, luo, d.reshape(Nb, 3)[fr].reshape(-1), w=0.9, mode="post_scale")
+        assert np.array_equal(s.ilu0_apply(d), vo.reshape(Nb, 3)[to].reshape(-1))
         assert res.converged
         r = b - orc.spmv(Nb, rp, ci, v, x)
         assert np.linalg.norm(r) < 1e-6 * np.linalg.norm(b) * 1.001
