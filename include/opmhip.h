@@ -132,6 +132,19 @@ int opmhip_solve_system(opmhip_ctx* ctx, int N, int nnz, int dim, double* vals, 
 /* replaces: bda::BdaSolver<3>::get_result(x) (bda/BdaSolver.hpp:90): N doubles to caller memory, natural order */
 int opmhip_get_result(opmhip_ctx* ctx, double* x);
 
+/* The two other places where the standard wells' Schur complement touches reservoir vectors, for runs that keep
+ * residual and solution on the device.  res_well: num_wells x 4 well residuals (host).
+ * replaces: BlackoilWellModel::apply(r) -> StandardWell::apply(BVector& r): r -= C^T (D^-1 resWell)
+ *   (wells/BlackoilWellModel_impl.hpp:1031-1042, wells/StandardWell_impl.hpp:1283-1296), applied to the residual the
+ *   last opmhip_assemble left on the device (before opmhip_solve_system); */
+int opmhip_wells_apply_residual(opmhip_ctx* ctx, const opmhip_wells* wells, const double* res_well);
+/* the right-hand side / residual currently on the device (after opmhip_assemble, opmhip_upload_system or
+ * opmhip_wells_apply_residual): N doubles, natural order - what linearizer().residual() holds on the host in Flow */
+int opmhip_get_rhs(opmhip_ctx* ctx, double* b);
+/* replaces: StandardWell::recoverSolutionWell: xw = D^-1 (resWell - B x) with x the solution of the last
+ *   opmhip_solve_system, still on the device (wells/StandardWell_impl.hpp:1298-1311); xw: num_wells x 4 (host, out) */
+int opmhip_wells_recover_solution(opmhip_ctx* ctx, const opmhip_wells* wells, const double* res_well, double* xw);
+
 /* ---- pieces of the solve, exposed for parity tests and roofline measurement ------------------------- */
 /* upload a system (natural order in, internal order on the device) without solving */
 int opmhip_upload_system(opmhip_ctx* ctx, const double* vals, const double* b);

@@ -74,6 +74,9 @@ def lib():
         L.opmhip_solve_system.argtypes = [vp, C.c_int, C.c_int, C.c_int, dp, ip, ip, dp, C.POINTER(Wells),
                                           C.POINTER(Result)]
         L.opmhip_get_result.argtypes = [vp, dp]
+        L.opmhip_get_rhs.argtypes = [vp, dp]
+        L.opmhip_wells_apply_residual.argtypes = [vp, C.POINTER(Wells), dp]
+        L.opmhip_wells_recover_solution.argtypes = [vp, C.POINTER(Wells), dp, dp]
         L.opmhip_upload_system.argtypes = [vp, dp, dp]
         L.opmhip_spmv.argtypes = [vp, dp, dp]
         L.opmhip_ilu0_factor.argtypes = [vp, dp]
@@ -161,6 +164,27 @@ class HipSolver:
         x = np.empty(3 * self.Nb)
         self._check(lib().opmhip_get_result(self._h, _ptr(x)))
         return x
+
+
+    def get_rhs(self):
+        """the right-hand side / residual currently on the device, natural order"""
+        b = np.empty(3 * self.Nb)
+        self._check(lib().opmhip_get_rhs(self._h, _ptr(b)))
+        return b
+
+    def wells_apply_residual(self, wells, res_well):
+        """r -= C^T (D^-1 resWell) on the device-resident residual (StandardWell::apply(BVector& r))"""
+        ws, keep = make_wells(wells)
+        rw = _f64(res_well)
+        self._check(lib().opmhip_wells_apply_residual(self._h, C.byref(ws) if ws else None, _ptr(rw)))
+
+    def wells_recover_solution(self, wells, res_well):
+        """xw = D^-1 (resWell - B x) from the device-resident solution (StandardWell::recoverSolutionWell)"""
+        ws, keep = make_wells(wells)
+        rw = _f64(res_well)
+        xw = np.empty(4 * int(wells["numWells"]))
+        self._check(lib().opmhip_wells_recover_solution(self._h, C.byref(ws) if ws else None, _ptr(rw), _ptr(xw)))
+        return xw
 
     def upload_system(self, vals, b=None):
         vals, b = _f64(vals), _f64(b)

@@ -70,6 +70,8 @@ int upload_wells(opmhip_ctx* c, const opmhip_wells* w) {
         const size_t cap = std::max((size_t)nw, 2 * W.cap_wells);
         if ((rc = dev_alloc(c, &W.d_val_pointers, cap + 1))) return rc;
         if ((rc = dev_alloc(c, &W.d_D, cap * 16))) return rc;
+        if ((rc = dev_alloc(c, &W.d_res, cap * 4))) return rc;
+        if ((rc = dev_alloc(c, &W.d_xw, cap * 4))) return rc;
         W.cap_wells = cap;
     }
     if ((size_t)np > W.cap_perf) {
@@ -275,6 +277,54 @@ int opmhip_solve_system(opmhip_ctx* c, int N, int nnz, int dim, double* vals, co
             res->converged = 0;
             return fail(c, OPMHIP_CREATE_PRECONDITIONER_FAILED, "non-finite residual norm (singular diagonal block in ILU0?)");
         }
+        return OPMHIP_SUCCESS;
+    });
+}
+
+int opmhip_wells_apply_residual(opmhip_ctx* c, const opmhip_wells* wells, const double* res_well) {
+    if (!c) return OPMHIP_INVALID_ARGUMENT;
+    return guarded(c, [&]() -> int {
+        if (!c->system_loaded && !c->asmb.assembled) return fail(c, OPMHIP_NOT_READY, "wells_apply_residual: no residual on the device");
+        if (!wells || wells->num_wells <= 0) return OPMHIP_SUCCESS;
+        if (!res_well) return fail(c, OPMHIP_INVALID_ARGUMENT, "wells_apply_residual: null res_well");
+        OPMHIP_HIP(c, hipSetDevice(c->device));
+        int rc;
+        if ((rc = upload_wells(c, wells))) return rc;
+        OPMHIP_HIP(c, hipMemcpyAsync(c->wells.d_res, res_well, (size_t)wells->num_wells * 4 * sizeof(double), hipMemcpyHostToDevice, c->stream));
+        launch_wells_residual(c, c->wells.d_res, c->d_b);
+        OPMHIP_HIP(c, hipGetLastError());
+        OPMHIP_HIP(c, hipStreamSynchronize(c->stream));  // res_well is the caller's again
+        return OPMHIP_SUCCESS;
+    });
+}
+
+int opmhip_get_rhs(opmhip_ctx* c, double* b) {
+    if (!c) return OPMHIP_INVALID_ARGUMENT;
+    return guarded(c, [&]() -> int {
+        if (!c->system_loaded && !c->asmb.assembled) return fail(c, OPMHIP_NOT_READY, "get_rhs: no right-hand side on the device");
+        if (!b) return fail(c, OPMHIP_INVALID_ARGUMENT, "get_rhs: null array");
+        OPMHIP_HIP(c, hipSetDevice(c->device));
+        int rc;
+        if ((rc = vec_out(c, c->d_b, b))) return rc;
+        OPMHIP_HIP(c, hipStreamSynchronize(c->stream));
+        return OPMHIP_SUCCESS;
+    });
+}
+
+int opmhip_wells_recover_solution(opmhip_ctx* c, const opmhip_wells* wells, const double* res_well, double* xw) {
+    if (!c) return OPMHIP_INVALID_ARGUMENT;
+    return guarded(c, [&]() -> int {
+        if (!c->have_result) return fail(c, OPMHIP_NOT_READY, "wells_recover_solution before a solve");
+        if (!wells || wells->num_wells <= 0) return OPMHIP_SUCCESS;
+        if (!res_well || !xw) return fail(c, OPMHIP_INVALID_ARGUMENT, "wells_recover_solution: null array");
+        OPMHIP_HIP(c, hipSetDevice(c->device));
+        int rc;
+        if ((rc = upload_wells(c, wells))) return rc;
+        OPMHIP_HIP(c, hipMemcpyAsync(c->wells.d_res, res_well, (size_t)wells->num_wells * 4 * sizeof(double), hipMemcpyHostToDevice, c->stream));
+        launch_wells_recover(c, c->wells.d_res, c->d_x, c->wells.d_xw);
+        OPMHIP_HIP(c, hipMemcpyAsync(xw, c->wells.d_xw, (size_t)wells->num_wells * 4 * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+        OPMHIP_HIP(c, hipGetLastError());
+        OPMHIP_HIP(c, hipStreamSynchronize(c->stream));
         return OPMHIP_SUCCESS;
     });
 }

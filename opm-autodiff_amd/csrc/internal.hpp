@@ -67,6 +67,7 @@ struct WellsDev {
     int num_wells = 0, nperf = 0;
     int *d_val_pointers = nullptr, *d_Ccols = nullptr, *d_Bcols = nullptr;
     double *d_C = nullptr, *d_D = nullptr, *d_B = nullptr;
+    double *d_res = nullptr, *d_xw = nullptr;   // 4 doubles per well each (residual in, well solution out)
     size_t cap_wells = 0, cap_perf = 0;
 };
 
@@ -261,6 +262,8 @@ void launch_vec_to_internal(opmhip_ctx* c, const double* nat, double* internal, 
 void launch_vec_to_natural(opmhip_ctx* c, const double* internal, double* nat, int cells = -1);
 void launch_zero_diag_fix(opmhip_ctx* c);
 void launch_spmv(opmhip_ctx* c, const double* x, double* y, int ndot, const double* w0, const double* w1);
+void launch_wells_residual(opmhip_ctx* c, const double* d_resWell, double* r);
+void launch_wells_recover(opmhip_ctx* c, const double* d_resWell, const double* x, double* d_xw);
 void launch_ilu_factor(opmhip_ctx* c);
 void launch_ilu_apply(opmhip_ctx* c, const double* d, double* v, int fuse = 0);
 void launch_wells_apply(opmhip_ctx* c, const double* x, double* y);

@@ -972,6 +972,51 @@ __global__ __launch_bounds__(64) void k_wells_apply(const int* __restrict__ vp, 
     }
 }
 
+// r -= C^T (D^-1 resWell) (StandardWell::apply(BVector& r), wells/StandardWell_impl.hpp:1283-1296) and
+// xw = D^-1 (resWell - B x) (recoverSolutionWell, :1298-1311); one wavefront per well, sums in the CPU's order
+__global__ __launch_bounds__(64) void k_wells_residual(const int* __restrict__ vp, const int* __restrict__ Ccols,
+                                                       const double* __restrict__ C, const double* __restrict__ D,
+                                                       const double* __restrict__ resWell, double* __restrict__ r) {
+    __shared__ double z2[4];
+    const int w = blockIdx.x, lane = threadIdx.x;
+    const int pb = vp[w], pe = vp[w + 1];
+    if (lane < 4) {
+        double s = 0.0;
+        for (int q = 0; q < 4; ++q) s += D[(size_t)w * 16 + lane * 4 + q] * resWell[(size_t)w * 4 + q];
+        z2[lane] = s;
+    }
+    __syncthreads();
+    for (int e = pb * 3 + lane; e < pe * 3; e += 64) {
+        const int p = e / 3, c = e % 3;
+        double s = 0.0;
+        for (int j = 0; j < 4; ++j) s += C[(size_t)p * 12 + j * 3 + c] * z2[j];
+        r[(size_t)Ccols[p] * 3 + c] -= s;
+    }
+}
+__global__ __launch_bounds__(64) void k_wells_recover(const int* __restrict__ vp, const int* __restrict__ Bcols,
+                                                      const double* __restrict__ B, const double* __restrict__ D,
+                                                      const double* __restrict__ resWell, const double* __restrict__ x,
+                                                      double* __restrict__ xw) {
+    __shared__ double z1[4];
+    const int w = blockIdx.x, lane = threadIdx.x;
+    const int pb = vp[w], pe = vp[w + 1];
+    if (lane < 4) {
+        double s = resWell[(size_t)w * 4 + lane];   // resWell -= B x, perforation by perforation (BCRSMatrix::mmv)
+        for (int p = pb; p < pe; ++p) {
+            const double* xb = &x[(size_t)Bcols[p] * 3];
+            const double* Bp = &B[(size_t)p * 12 + lane * 3];
+            s -= Bp[0] * xb[0]; s -= Bp[1] * xb[1]; s -= Bp[2] * xb[2];
+        }
+        z1[lane] = s;
+    }
+    __syncthreads();
+    if (lane < 4) {
+        double s = 0.0;
+        for (int q = 0; q < 4; ++q) s += D[(size_t)w * 16 + lane * 4 + q] * z1[q];
+        xw[(size_t)w * 4 + lane] = s;
+    }
+}
+
 // ============================== BiCGStab vector kernels ==================================================
 constexpr int VB = 256;          // threads per block
 constexpr int VPT = 8;           // doubles per thread
@@ -1237,6 +1282,16 @@ void launch_wells_apply(opmhip_ctx* c, const double* x, double* y) {
     if (W.num_wells <= 0) return;
     hipLaunchKernelGGL(k_wells_apply, dim3(W.num_wells), dim3(64), 0, c->stream, W.d_val_pointers, W.d_Ccols, W.d_Bcols, W.d_C, W.d_D,
                        W.d_B, x, y);
+}
+void launch_wells_residual(opmhip_ctx* c, const double* d_resWell, double* r) {
+    const WellsDev& W = c->wells;
+    if (W.num_wells <= 0) return;
+    hipLaunchKernelGGL(k_wells_residual, dim3(W.num_wells), dim3(64), 0, c->stream, W.d_val_pointers, W.d_Ccols, W.d_C, W.d_D, d_resWell, r);
+}
+void launch_wells_recover(opmhip_ctx* c, const double* d_resWell, const double* x, double* d_xw) {
+    const WellsDev& W = c->wells;
+    if (W.num_wells <= 0) return;
+    hipLaunchKernelGGL(k_wells_recover, dim3(W.num_wells), dim3(64), 0, c->stream, W.d_val_pointers, W.d_Bcols, W.d_B, W.d_D, d_resWell, x, d_xw);
 }
 // y = A x (+ wells) and, fused or not, the partial dots: ndot 0 none, 1 y.w0, 2 y.w0 and y.y
 void launch_spmv(opmhip_ctx* c, const double* x, double* y, int ndot, const double* w0, const double*) {

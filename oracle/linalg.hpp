@@ -390,6 +390,39 @@ inline void wells_apply(const Wells& W, const double* x, double* y) {
     }
 }
 
+// r -= C^T (D^-1 resWell): StandardWell::apply(BVector& r), wells/StandardWell_impl.hpp:1283-1296
+inline void wells_apply_residual(const Wells& W, const double* resWell, double* r) {
+    for (int w = 0; w < W.numWells; ++w) {
+        double z2[4];
+        for (int i = 0; i < 4; ++i) {
+            double t = 0.0;
+            for (int c = 0; c < 4; ++c) t += W.Dnnzs[(size_t)w * 16 + i * 4 + c] * resWell[(size_t)w * 4 + c];
+            z2[i] = t;
+        }
+        for (int b = W.val_pointers[w]; b < W.val_pointers[w + 1]; ++b)
+            for (int c = 0; c < 3; ++c) {
+                double t = 0.0;
+                for (int j = 0; j < 4; ++j) t += W.Cnnzs[(size_t)b * 12 + j * 3 + c] * z2[j];
+                r[(size_t)W.Ccols[b] * 3 + c] -= t;
+            }
+    }
+}
+// xw = D^-1 (resWell - B x): StandardWell::recoverSolutionWell, wells/StandardWell_impl.hpp:1298-1311
+inline void wells_recover(const Wells& W, const double* resWell, const double* x, double* xw) {
+    for (int w = 0; w < W.numWells; ++w) {
+        double z1[4];
+        for (int i = 0; i < 4; ++i) z1[i] = resWell[(size_t)w * 4 + i];
+        for (int i = 0; i < 4; ++i)
+            for (int b = W.val_pointers[w]; b < W.val_pointers[w + 1]; ++b)
+                for (int c = 0; c < 3; ++c) z1[i] -= W.Bnnzs[(size_t)b * 12 + i * 3 + c] * x[(size_t)W.Bcols[b] * 3 + c];
+        for (int i = 0; i < 4; ++i) {
+            double t = 0.0;
+            for (int c = 0; c < 4; ++c) t += W.Dnnzs[(size_t)w * 16 + i * 4 + c] * z1[c];
+            xw[(size_t)w * 4 + i] = t;
+        }
+    }
+}
+
 // ---- right-preconditioned BiCGStab, half-iteration bookkeeping ---------------------------
 // Recurrence and stopping rule of bda/cusparseSolverBackend.cu:60-184 (same as
 // bda/openclSolverBackend.cpp:317-460; the CPU path's Dune::BiCGSTABSolver, call site

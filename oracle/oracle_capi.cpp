@@ -110,6 +110,18 @@ int orc_wells_apply(int numWells, const int* val_pointers, const int* Ccols, con
     wells_apply(W, x, y);
     return 0;
 }
+int orc_wells_apply_residual(int numWells, const int* val_pointers, const int* Ccols, const int* Bcols, const double* Cnnzs,
+                             const double* Dnnzs, const double* Bnnzs, const double* resWell, double* r) {
+    Wells W = wrap_wells(numWells, val_pointers, Ccols, Bcols, Cnnzs, Dnnzs, Bnnzs);
+    wells_apply_residual(W, resWell, r);
+    return 0;
+}
+int orc_wells_recover(int numWells, const int* val_pointers, const int* Ccols, const int* Bcols, const double* Cnnzs,
+                      const double* Dnnzs, const double* Bnnzs, const double* resWell, const double* x, double* xw) {
+    Wells W = wrap_wells(numWells, val_pointers, Ccols, Bcols, Cnnzs, Dnnzs, Bnnzs);
+    wells_recover(W, resWell, x, xw);
+    return 0;
+}
 
 struct orc_result {
     int iterations;

@@ -31,6 +31,8 @@ class Oracle:
         L.orc_reorder.argtypes = [C.c_int, _i, _i, C.c_int, _i, _i, _i]
         L.orc_reorder_matrix.argtypes = [C.c_int, _i, _i, _vp, _i, _i, _i, _i, _vp]
         L.orc_wells_apply.argtypes = [C.c_int, _i, _i, _i, _d, _d, _d, _d, _d]
+        L.orc_wells_apply_residual.argtypes = [C.c_int, _i, _i, _i, _d, _d, _d, _d, _d]
+        L.orc_wells_recover.argtypes = [C.c_int, _i, _i, _i, _d, _d, _d, _d, _d, _d]
         L.orc_check_zero_diagonal.argtypes = [C.c_int, _i, _i, _d]
         L.orc_solve.argtypes = [C.c_int, _i, _i, _d, _d, _d, C.c_double, C.c_int, C.c_double, C.c_int, C.c_int,
                                 C.c_int, C.c_int, _vp, _vp, _vp, _vp, _vp, _vp, C.c_int, _vp,
@@ -74,6 +76,19 @@ class Oracle:
         self.lib.orc_wells_apply(wells["numWells"], wells["val_pointers"], wells["Ccols"], wells["Bcols"],
                                  wells["Cnnzs"], wells["Dnnzs"], wells["Bnnzs"], x, y)
         return y
+
+    def wells_apply_residual(self, wells, res_well, r):
+        r = r.copy()
+        self.lib.orc_wells_apply_residual(wells["numWells"], wells["val_pointers"], wells["Ccols"], wells["Bcols"], wells["Cnnzs"],
+                                          wells["Dnnzs"], wells["Bnnzs"], np.ascontiguousarray(res_well, np.float64), r)
+        return r
+
+    def wells_recover(self, wells, res_well, x):
+        xw = np.empty(4 * wells["numWells"])
+        self.lib.orc_wells_recover(wells["numWells"], wells["val_pointers"], wells["Ccols"], wells["Bcols"], wells["Cnnzs"],
+                                   wells["Dnnzs"], wells["Bnnzs"], np.ascontiguousarray(res_well, np.float64),
+                                   np.ascontiguousarray(x, np.float64), xw)
+        return xw
 
     def solve(self, Nb, rowptr, col, val, b, tol=1e-2, maxit=200, w=0.9, mode="post_scale", reorder="none",
               zero_diag_fix=True, wells=None, sub_start=None, owner=None):

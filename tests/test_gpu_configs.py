@@ -187,3 +187,30 @@ def test_norne_like_assembly_bitwise(pkg, orc, norne, reorder):
             m.update(None, 1.0)
             o.update(xo)
     np.testing.assert_allclose(m.convergence(86400.0)[11:17], o.convergence(86400.0)[11:17], rtol=1e-6, atol=1e-12)
+
+
+def test_spe9_shaped_well_residual_and_recovery(pkg, orc):
+    """The two other touch points of the standard wells' Schur complement on device-resident vectors:
+    r -= C^T D^-1 resWell before the solve (bit for bit) and xw = D^-1 (resWell - B x) after it."""
+    case = pkg.decks.cartesian_case(24, 25, 15, state="mixed", heterogeneous=True)
+    rng = np.random.default_rng(10)
+    W = spe9_wells(case, rng)
+    res_well = 1e-3 * rng.standard_normal(4 * W["numWells"])
+    m = pkg.capi.HipModel(case, reorder="line_coloring", tolerance=1e-6, maxit=200)
+    o = oracle_bind.OracleModel(orc, case)
+    for q in (m, o):
+        q.set_state(case["pv"], case["meaning"])
+    dt = 5 * 86400.0
+    jm, rm = m.assemble(dt, 0)
+    jo, ro = o.assemble(dt, 0)
+    assert np.array_equal(m.get_rhs(), ro)
+    m.wells_apply_residual(W, res_well)
+    r2 = orc.wells_apply_residual(W, res_well, ro)
+    assert np.array_equal(m.get_rhs(), r2) and not np.array_equal(r2, ro)
+    res = m.solve_jacobian_system(wells=W)
+    x = m.get_result()
+    assert res.converged
+    resid = r2 - orc.wells_apply(W, x, orc.spmv(case["Nb"], case["rowptr"], case["col"], jo, x))
+    assert np.linalg.norm(resid) < 1e-6 * np.linalg.norm(r2) * 1.001
+    xw = m.wells_recover_solution(W, res_well)
+    np.testing.assert_array_equal(xw, orc.wells_recover(W, res_well, x))  # same x in, same operation order: same bits
