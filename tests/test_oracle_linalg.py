@@ -240,3 +240,35 @@ def test_wells_apply_matches_dense(orc):
         for p in range(len(c)):
             ref[c[p]] -= Cm[p].T @ z2
     np.testing.assert_allclose(y, ref.reshape(-1), rtol=1e-12, atol=1e-12)
+
+
+def test_greedy_colouring_properties_of_test_graphcoloring(orc):
+    """tests/test_graphcoloring.cpp:44-110 pins the reference's colouring through properties on a 10 x 10 five-point
+    grid: two colours, checkerboard, and a renumbering that lists colour 0 first and keeps the natural order inside a
+    colour (reorderVerticesPreserving).  The greedy colouring used for the red-black ILU0 ordering has all three."""
+    N = 10
+    rows, cols = [0], []
+    for j in range(N):
+        for i in range(N):
+            idx = j * N + i
+            nb = [idx]
+            if i > 0: nb.append(idx - 1)
+            if i < N - 1: nb.append(idx + 1)
+            if j > 0: nb.append(idx - N)
+            if j < N - 1: nb.append(idx + N)
+            cols += sorted(nb)
+            rows.append(len(cols))
+    rp, ci = np.array(rows, np.int32), np.array(cols, np.int32)
+    to, fr, rpc = orc.reorder(N * N, rp, ci, "graph_coloring_greedy")
+    assert list(rpc) == [50, 50]                                   # noColors == 2, verticesPerColor
+    color = (to >= 50).astype(int)
+    first = color[0]
+    for j in range(N):
+        for i in range(N):
+            assert color[j * N + i] == (first + i + j) % 2          # checkerboard
+    assert sorted(to) == list(range(N * N))                        # checkAllIndices
+    nxt = [0, 50]
+    for v in range(N * N):                                         # colorIndex[colors[vertex]]++ == newOrder[vertex]
+        assert to[v] == nxt[color[v]]
+        nxt[color[v]] += 1
+    assert np.array_equal(fr[to], np.arange(N * N))
