@@ -375,9 +375,18 @@ __device__ __forceinline__ void face_flux(const IN& in, const EX& ex, double tra
 }
 
 // ============================== assembly ======================================================================
-constexpr int ASM_THREADS = 256;
-constexpr int ASM_MAX_ROWS = 40;  // rows of one tile (their IQ records are staged in LDS); 36 on a 7-point grid
+#ifndef OPMHIP_ASM_THREADS
+#define OPMHIP_ASM_THREADS 64
+#endif
+constexpr int ASM_THREADS = OPMHIP_ASM_THREADS;  // 64: one wavefront per tile (9 rows of a 7-point grid); measured 0.80 ms against 0.84 (128) and 0.88 (256): no cross-wave barrier stalls
+constexpr int ASM_MAX_ROWS = ASM_THREADS / 7 + 4;  // rows of one tile (their IQ records are staged in LDS); 36 of 40 on a 7-point grid
 int asm_max_rows() { return ASM_MAX_ROWS; }
+int asm_threads() { return ASM_THREADS; }
+#ifdef OPMHIP_ASM_WAVES
+#define ASM_OCC __attribute__((amdgpu_waves_per_eu(OPMHIP_ASM_WAVES, OPMHIP_ASM_WAVES)))
+#else
+#define ASM_OCC
+#endif
 struct EntryStatic {
     const double *trans, *area, *thpres;  // per entry, internal order
 };
@@ -385,7 +394,7 @@ struct EntryStatic {
 // The kernel was latency-bound (PMC: waves waiting 74 % of their life, ~18 dependent load rounds per lane through the
 // branches of the flux), so every global load is issued up front in ONE round: the tile's own IQ records as a coalesced
 // copy into LDS, the neighbour's flux fields into registers, the statics; the arithmetic then runs out of LDS/registers.
-__global__ __launch_bounds__(ASM_THREADS) void k_assemble(int ntiles, const int* __restrict__ asm_order, const int* __restrict__ asm_row0, const int* __restrict__ rowptr,
+__global__ __launch_bounds__(ASM_THREADS) ASM_OCC void k_assemble(int ntiles, const int* __restrict__ asm_order, const int* __restrict__ asm_row0, const int* __restrict__ rowptr,
                                                           const int* __restrict__ col, const int* __restrict__ natOrder,
                                                           EntryStatic ES, CellStatic C, const double* __restrict__ iq,
                                                           double* __restrict__ storageOld, const double* __restrict__ source,

@@ -143,8 +143,8 @@ int opmhip_set_static(opmhip_ctx* c, const double* trans, const double* area, co
             while (r < P.Nb) {
                 row0.push_back(r);
                 int e = r;
-                while (e < P.Nb && P.rowptr[e + 1] - P.rowptr[r] <= 256 && e - r < asm_max_rows()) ++e;
-                if (e == r) return fail(c, OPMHIP_ANALYSIS_FAILED, "set_static: row %d has more than 256 blocks", r);
+                while (e < P.Nb && P.rowptr[e + 1] - P.rowptr[r] <= asm_threads() && e - r < asm_max_rows()) ++e;
+                if (e == r) return fail(c, OPMHIP_ANALYSIS_FAILED, "set_static: row %d has more than %d blocks", r, asm_threads());
                 r = e;
             }
             row0.push_back(P.Nb);

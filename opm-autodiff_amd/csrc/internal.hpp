@@ -285,6 +285,7 @@ void launch_u8_to_natural(opmhip_ctx* c, const unsigned char* internal, unsigned
 void launch_iq_to_natural(opmhip_ctx* c, double* d_nat);
 int iq_doubles_per_cell();
 int asm_max_rows();
+int asm_threads();
 void launch_vector_kernels_once(opmhip_ctx* c);
 
 }  // namespace opmhip
