@@ -1,0 +1,41 @@
+"""Degenerate sizes through the whole path on the GPU: a single cell (no faces), a pair, one column, one layer - where
+tiles hold one row, colours hold one tile and chains have one link."""
+import numpy as np
+import pytest
+
+import oracle_bind
+
+pytestmark = pytest.mark.gpu
+REORDERS = ["level_scheduling", "graph_coloring", "graph_coloring_greedy", "line_coloring"]
+
+
+@pytest.mark.parametrize("reorder", REORDERS)
+@pytest.mark.parametrize("shape", [(1, 1, 1), (2, 1, 1), (1, 1, 7), (3, 2, 1), (1, 33, 1), (2, 2, 2)])
+def test_tiny_grids(pkg, orc, shape, reorder):
+    case = pkg.decks.cartesian_case(*shape, state="mixed", heterogeneous=True)
+    src = np.zeros((case["Nb"], 3))
+    src[0, 1] = 1e-6
+    src[-1, 0] = -1e-6
+    src = np.ascontiguousarray(src.reshape(-1))
+    m = pkg.capi.HipModel(case, reorder=reorder, tolerance=1e-2, maxit=200, ilu_relaxation=0.9)
+    o = oracle_bind.OracleModel(orc, case)
+    for q in (m, o):
+        q.set_state(case["pv"], case["meaning"])
+        q.set_source(src)
+    dt = 86400.0
+    assert np.array_equal(m.iq(), o.iq())
+    jm, rm = m.assemble(dt, 0)
+    jo, ro = o.assemble(dt, 0)
+    assert np.array_equal(jm, jo) and np.array_equal(rm, ro)
+    # MB is |sum of residuals| * dt * B / pv: pure cancellation noise where the sum vanishes (tolerance there is 1e-6)
+    np.testing.assert_allclose(m.convergence(dt)[11:17], o.convergence(dt)[11:17], rtol=1e-10, atol=1e-14)
+    res = m.solve_jacobian_system()
+    xo, reso = o.solve_in_order(*m.ordering()[:2], tol=1e-2, maxit=200, w=0.9)
+    assert res.converged == bool(reso.converged) and res.it == reso.it
+    np.testing.assert_allclose(m.get_result(), xo, rtol=1e-9, atol=1e-12 * max(1.0, np.abs(xo).max()))
+    m.update(None, 1.0)
+    o.update(xo)
+    pm, mm = m.get_state()
+    po, mo = o.get_state()
+    assert np.array_equal(mm, mo)
+    np.testing.assert_allclose(pm, po, rtol=1e-9, atol=1e-12)
