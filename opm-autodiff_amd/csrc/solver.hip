@@ -1124,6 +1124,10 @@ __global__ __launch_bounds__(VB) void k_dots(int n, const double* __restrict__ a
 // Pre-reduction for long partial lists (one partial per 32-row tile = 31250 at 100^3): RED1_BLOCKS workgroups each
 // sum one contiguous slice in a fixed order, so that the single-workgroup k_finalize reads a few hundred numbers.
 constexpr int RED1_BLOCKS = 128;
+#ifndef OPMHIP_RED1_SINGLE_MAX
+#define OPMHIP_RED1_SINGLE_MAX 512
+#endif
+constexpr int RED1_SINGLE_MAX = OPMHIP_RED1_SINGLE_MAX;  // partial lists up to this length go through one workgroup (k_finalize)
 __global__ __launch_bounds__(VB) void k_reduce_stage1(int count, const double* __restrict__ part, int npart, double* __restrict__ out) {
     __shared__ double sh[2][VB];
     const int chunk = (count + RED1_BLOCKS - 1) / RED1_BLOCKS;
@@ -1430,7 +1434,7 @@ static void finalize(opmhip_ctx* c, int mode, int count, int rb_half = -1) {
         hipLaunchKernelGGL(k_finalize, dim3(1), dim3(VB), 0, c->stream, mode, 1, c->comm.d_red, 1, c->d_scal, tol, hslot, seq);
         return;
     }
-    if (count > 4 * RED1_BLOCKS) {
+    if (count > RED1_SINGLE_MAX) {
         hipLaunchKernelGGL(k_reduce_finalize, dim3(RED1_BLOCKS), dim3(VB), 0, c->stream, mode, count, c->d_part, c->npart, c->d_part2,
                            reinterpret_cast<unsigned*>(c->d_part2 + 2 * RED1_BLOCKS), c->d_scal, tol, hslot, seq);
         return;
