@@ -201,13 +201,13 @@ def main():
     # HBM-side traffic of k_spmv per launch: PMC passes cannot run inside this process (counters need their own
     # rocprofv3 runs), so the number comes from the committed summary of tools/pmc_quick.sh over this same command
     traffic, traffic_src = None, None
-    tj = os.path.join(ROOT, "profiles", "r01_c_pmc_traffic.json")
+    tj = os.path.join(ROOT, "profiles", "r01_d_pmc_traffic.json")
     if world == 1 and n == 100 and a.reorder == "line_coloring" and os.path.exists(tj):
         with open(tj) as f:
             kk = json.load(f)["kernels"]
         vals = [v["traffic_bytes_per_launch"] for k, v in kk.items() if "k_spmv" in k]
         if vals:
-            traffic, traffic_src = sum(vals) / len(vals), "profiles/r01_c_pmc_traffic.json"
+            traffic, traffic_src = sum(vals) / len(vals), "profiles/r01_d_pmc_traffic.json"
     out = {
         "metric": "Newton iterations/sec, 1M-cell 3-phase black-oil (assembly + ILU0/BiCGStab solve + update)",
         # weak scaling: every rank advances the SAME coupled Newton iteration on its 1M-cell subdomain; the whole-job
