@@ -1123,7 +1123,10 @@ __global__ __launch_bounds__(VB) void k_dots(int n, const double* __restrict__ a
 }
 // Pre-reduction for long partial lists (one partial per 32-row tile = 31250 at 100^3): RED1_BLOCKS workgroups each
 // sum one contiguous slice in a fixed order, so that the single-workgroup k_finalize reads a few hundred numbers.
-constexpr int RED1_BLOCKS = 128;
+#ifndef OPMHIP_RED1_BLOCKS
+#define OPMHIP_RED1_BLOCKS 128
+#endif
+constexpr int RED1_BLOCKS = OPMHIP_RED1_BLOCKS;
 #ifndef OPMHIP_RED1_SINGLE_MAX
 #define OPMHIP_RED1_SINGLE_MAX 512
 #endif
