@@ -138,6 +138,12 @@ int opmhip_get_result(opmhip_ctx* ctx, double* x);
  *   (wells/BlackoilWellModel_impl.hpp:1031-1042, wells/StandardWell_impl.hpp:1283-1296), applied to the residual the
  *   last opmhip_assemble left on the device (before opmhip_solve_system); */
 int opmhip_wells_apply_residual(opmhip_ctx* ctx, const opmhip_wells* wells, const double* res_well);
+/* replaces: BlackoilWellModel::addWellContributions(mat) -> StandardWell::addWellContributions
+ *   (wells/StandardWell_impl.hpp:1688-1712), the --matrix-add-well-contributions=true mode: A -= C^T D^-1 B written into
+ *   the device-resident matrix (uploaded or assembled) instead of being applied after every SpMV; block (Ccols[c],
+ *   Bcols[b]) of every perforation pair of a well must be in the pattern given to set_pattern (the "well cliques"
+ *   ISTLSolverEbos adds to the sparsity pattern in that mode), else INVALID_ARGUMENT and the matrix is left untouched. */
+int opmhip_add_well_contributions(opmhip_ctx* ctx, const opmhip_wells* wells);
 /* the right-hand side / residual currently on the device (after opmhip_assemble, opmhip_upload_system or
  * opmhip_wells_apply_residual): N doubles, natural order - what linearizer().residual() holds on the host in Flow */
 int opmhip_get_rhs(opmhip_ctx* ctx, double* b);

@@ -75,6 +75,7 @@ def lib():
                                           C.POINTER(Result)]
         L.opmhip_get_result.argtypes = [vp, dp]
         L.opmhip_get_rhs.argtypes = [vp, dp]
+        L.opmhip_add_well_contributions.argtypes = [vp, C.POINTER(Wells)]
         L.opmhip_wells_apply_residual.argtypes = [vp, C.POINTER(Wells), dp]
         L.opmhip_wells_recover_solution.argtypes = [vp, C.POINTER(Wells), dp, dp]
         L.opmhip_upload_system.argtypes = [vp, dp, dp]
@@ -171,6 +172,12 @@ class HipSolver:
         b = np.empty(3 * self.Nb)
         self._check(lib().opmhip_get_rhs(self._h, _ptr(b)))
         return b
+
+    def add_well_contributions(self, wells):
+        """A -= C^T D^-1 B into the device-resident matrix (StandardWell::addWellContributions); the pattern must hold
+        the well cliques"""
+        ws, keep = make_wells(wells)
+        self._check(lib().opmhip_add_well_contributions(self._h, C.byref(ws) if ws else None))
 
     def wells_apply_residual(self, wells, res_well):
         """r -= C^T (D^-1 resWell) on the device-resident residual (StandardWell::apply(BVector& r))"""

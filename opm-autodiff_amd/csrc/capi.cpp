@@ -1,6 +1,8 @@
 // C-ABI of libopmhip.so (include/opmhip.h): argument checking, device memory, call ordering.  No exceptions
 // cross this file's boundary: every entry point is wrapped and maps failures to opmhip_status codes.
 #include <chrono>
+#include <unordered_map>
+#include <algorithm>
 #include <cstring>
 #include <new>
 
@@ -294,6 +296,62 @@ int opmhip_wells_apply_residual(opmhip_ctx* c, const opmhip_wells* wells, const 
         launch_wells_residual(c, c->wells.d_res, c->d_b);
         OPMHIP_HIP(c, hipGetLastError());
         OPMHIP_HIP(c, hipStreamSynchronize(c->stream));  // res_well is the caller's again
+        c->wells.num_wells = 0;  // the operator form is set per solve_system call
+        return OPMHIP_SUCCESS;
+    });
+}
+
+int opmhip_add_well_contributions(opmhip_ctx* c, const opmhip_wells* wells) {
+    if (!c) return OPMHIP_INVALID_ARGUMENT;
+    return guarded(c, [&]() -> int {
+        if (!c->system_loaded && !c->asmb.assembled) return fail(c, OPMHIP_NOT_READY, "add_well_contributions: no matrix on the device");
+        if (!wells || wells->num_wells <= 0) return OPMHIP_SUCCESS;
+        OPMHIP_HIP(c, hipSetDevice(c->device));
+        int rc;
+        if ((rc = upload_wells(c, wells))) return rc;
+        const Pattern& P = c->pat;
+        const int nw = wells->num_wells;
+        // position of every (c, b) block in the device's block-CSR; wells that touch a common block are serialised
+        std::vector<int> pair_ptr(nw + 1, 0), entry;
+        std::vector<char> shares(nw, 0);
+        std::unordered_map<int, int> owner;  // entry -> first well that writes it
+        for (int w = 0; w < nw; ++w) {
+            const int pb = wells->val_pointers[w], np = wells->val_pointers[w + 1] - pb;
+            for (int a = 0; a < np; ++a)
+                for (int b = 0; b < np; ++b) {
+                    const int row = P.toOrder[wells->Ccols[pb + a]], colv = P.toOrder[wells->Bcols[pb + b]];
+                    const int* lo = &P.col[P.rowptr[row]];
+                    const int* hi = &P.col[P.rowptr[row + 1]];
+                    const int* it = std::lower_bound(lo, hi, colv);
+                    if (it == hi || *it != colv)
+                        return fail(c, OPMHIP_INVALID_ARGUMENT, "add_well_contributions: block (%d, %d) of well %d is not in the pattern",
+                                    wells->Ccols[pb + a], wells->Bcols[pb + b], w);
+                    const int e = (int)(it - P.col.data());
+                    entry.push_back(e);
+                    auto ins = owner.emplace(e, w);
+                    if (!ins.second && ins.first->second != w) shares[w] = 1;
+                }
+            pair_ptr[w + 1] = (int)entry.size();
+        }
+        int *d_pp = nullptr, *d_en = nullptr;
+        OPMHIP_HIP(c, hipMalloc((void**)&d_pp, pair_ptr.size() * sizeof(int)));
+        OPMHIP_HIP(c, hipMalloc((void**)&d_en, std::max<size_t>(1, entry.size()) * sizeof(int)));
+        OPMHIP_HIP(c, hipMemcpyAsync(d_pp, pair_ptr.data(), pair_ptr.size() * sizeof(int), hipMemcpyHostToDevice, c->stream));
+        OPMHIP_HIP(c, hipMemcpyAsync(d_en, entry.data(), entry.size() * sizeof(int), hipMemcpyHostToDevice, c->stream));
+        // runs of wells without shared blocks go out as one launch; a well that shares a block with an earlier one starts
+        // a new launch, so that the additions to that block happen in well order (the order of well_container_)
+        int w0 = 0;
+        for (int w = 1; w <= nw; ++w)
+            if (w == nw || shares[w]) {
+                launch_wells_add_to_matrix(c, w0, w - w0, d_pp, d_en);
+                w0 = w;
+            }
+        OPMHIP_HIP(c, hipGetLastError());
+        OPMHIP_HIP(c, hipStreamSynchronize(c->stream));
+        (void)hipFree(d_pp);
+        (void)hipFree(d_en);
+        c->factored = false;
+        c->wells.num_wells = 0;  // these wells now live in the matrix: no operator form left behind for later SpMVs
         return OPMHIP_SUCCESS;
     });
 }
@@ -325,6 +383,7 @@ int opmhip_wells_recover_solution(opmhip_ctx* c, const opmhip_wells* wells, cons
         OPMHIP_HIP(c, hipMemcpyAsync(xw, c->wells.d_xw, (size_t)wells->num_wells * 4 * sizeof(double), hipMemcpyDeviceToHost, c->stream));
         OPMHIP_HIP(c, hipGetLastError());
         OPMHIP_HIP(c, hipStreamSynchronize(c->stream));
+        c->wells.num_wells = 0;
         return OPMHIP_SUCCESS;
     });
 }

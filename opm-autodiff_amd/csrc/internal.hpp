@@ -263,6 +263,7 @@ void launch_vec_to_natural(opmhip_ctx* c, const double* internal, double* nat, i
 void launch_zero_diag_fix(opmhip_ctx* c);
 void launch_spmv(opmhip_ctx* c, const double* x, double* y, int ndot, const double* w0, const double* w1);
 void launch_wells_residual(opmhip_ctx* c, const double* d_resWell, double* r);
+void launch_wells_add_to_matrix(opmhip_ctx* c, int w0, int nw, const int* d_pair_ptr, const int* d_entry);
 void launch_wells_recover(opmhip_ctx* c, const double* d_resWell, const double* x, double* d_xw);
 void launch_ilu_factor(opmhip_ctx* c);
 void launch_ilu_apply(opmhip_ctx* c, const double* d, double* v, int fuse = 0);

@@ -1017,6 +1017,38 @@ __global__ __launch_bounds__(64) void k_wells_recover(const int* __restrict__ vp
     }
 }
 
+// A(Ccols[c], Bcols[b]) += -C_c^T (D^-1 B_b) for every perforation pair (c, b) of well w0 + blockIdx.x
+// (StandardWell::addWellContributions, wells/StandardWell_impl.hpp:1688-1712; sums in the order of Detail::multMatrix
+// and Detail::negativeMultMatrixTransposed, linalg/MatrixBlock.hpp:496-570).  entry[] holds, per pair, the position of
+// the block in the device's block-CSR (found on the host).
+__global__ __launch_bounds__(64) void k_wells_add_to_matrix(int w0, const int* __restrict__ vp, const double* __restrict__ C,
+                                                            const double* __restrict__ D, const double* __restrict__ B,
+                                                            const int* __restrict__ pair_ptr, const int* __restrict__ entry,
+                                                            double* __restrict__ A) {
+    const int w = w0 + blockIdx.x;
+    const int pb = vp[w], np = vp[w + 1] - pb;
+    for (int q = threadIdx.x; q < np * np; q += 64) {
+        const int c = q / np, b = q % np;
+        const double* Bb = &B[(size_t)(pb + b) * 12];
+        const double* Cc = &C[(size_t)(pb + c) * 12];
+        const double* Dw = &D[(size_t)w * 16];
+        double tmp[4][3];
+        for (int i = 0; i < 4; ++i)
+            for (int j = 0; j < 3; ++j) {
+                double s = 0.0;
+                for (int k = 0; k < 4; ++k) s += Dw[i * 4 + k] * Bb[k * 3 + j];
+                tmp[i][j] = s;
+            }
+        double* blk = &A[(size_t)entry[pair_ptr[w] + q] * BB];
+        for (int i = 0; i < 3; ++i)
+            for (int j = 0; j < 3; ++j) {
+                double s = 0.0;
+                for (int k = 0; k < 4; ++k) s += Cc[k * 3 + i] * tmp[k][j];
+                blk[i * 3 + j] += -s;
+            }
+    }
+}
+
 // ============================== BiCGStab vector kernels ==================================================
 constexpr int VB = 256;          // threads per block
 constexpr int VPT = 8;           // doubles per thread
@@ -1289,6 +1321,10 @@ void launch_wells_apply(opmhip_ctx* c, const double* x, double* y) {
     if (W.num_wells <= 0) return;
     hipLaunchKernelGGL(k_wells_apply, dim3(W.num_wells), dim3(64), 0, c->stream, W.d_val_pointers, W.d_Ccols, W.d_Bcols, W.d_C, W.d_D,
                        W.d_B, x, y);
+}
+void launch_wells_add_to_matrix(opmhip_ctx* c, int w0, int nw, const int* d_pair_ptr, const int* d_entry) {
+    const WellsDev& W = c->wells;
+    hipLaunchKernelGGL(k_wells_add_to_matrix, dim3(nw), dim3(64), 0, c->stream, w0, W.d_val_pointers, W.d_C, W.d_D, W.d_B, d_pair_ptr, d_entry, c->d_A);
 }
 void launch_wells_residual(opmhip_ctx* c, const double* d_resWell, double* r) {
     const WellsDev& W = c->wells;

@@ -390,6 +390,33 @@ inline void wells_apply(const Wells& W, const double* x, double* y) {
     }
 }
 
+// A -= C^T D^-1 B written into the matrix: StandardWell::addWellContributions, wells/StandardWell_impl.hpp:1688-1712,
+// with Detail::multMatrix / negativeMultMatrixTransposed of linalg/MatrixBlock.hpp:496-570.  Returns -(w+1) if a block of
+// well w is missing from the pattern.
+inline int wells_add_to_matrix(const Wells& W, Bcrs& A) {
+    for (int w = 0; w < W.numWells; ++w)
+        for (int c = W.val_pointers[w]; c < W.val_pointers[w + 1]; ++c)
+            for (int b = W.val_pointers[w]; b < W.val_pointers[w + 1]; ++b) {
+                double tmp[4][3];
+                for (int i = 0; i < 4; ++i)
+                    for (int j = 0; j < 3; ++j) {
+                        tmp[i][j] = 0.0;
+                        for (int k = 0; k < 4; ++k) tmp[i][j] += W.Dnnzs[(size_t)w * 16 + i * 4 + k] * W.Bnnzs[(size_t)b * 12 + k * 3 + j];
+                    }
+                const int row = W.Ccols[c], col = W.Bcols[b];
+                int e = -1;
+                for (int k = A.rowptr[row]; k < A.rowptr[row + 1]; ++k)
+                    if (A.col[k] == col) { e = k; break; }
+                if (e < 0) return -(w + 1);
+                for (int i = 0; i < 3; ++i)
+                    for (int j = 0; j < 3; ++j) {
+                        double sum = 0.0;
+                        for (int k = 0; k < 4; ++k) sum += W.Cnnzs[(size_t)c * 12 + k * 3 + i] * tmp[k][j];
+                        A.val[(size_t)e * BB + i * 3 + j] += -sum;
+                    }
+            }
+    return 0;
+}
 // r -= C^T (D^-1 resWell): StandardWell::apply(BVector& r), wells/StandardWell_impl.hpp:1283-1296
 inline void wells_apply_residual(const Wells& W, const double* resWell, double* r) {
     for (int w = 0; w < W.numWells; ++w) {

@@ -110,6 +110,15 @@ int orc_wells_apply(int numWells, const int* val_pointers, const int* Ccols, con
     wells_apply(W, x, y);
     return 0;
 }
+// vals is modified in place
+int orc_wells_add_to_matrix(int Nb, const int* rowptr, const int* col, double* vals, int numWells, const int* val_pointers, const int* Ccols,
+                            const int* Bcols, const double* Cnnzs, const double* Dnnzs, const double* Bnnzs) {
+    Bcrs A = wrap(Nb, rowptr, col, vals);
+    Wells W = wrap_wells(numWells, val_pointers, Ccols, Bcols, Cnnzs, Dnnzs, Bnnzs);
+    const int rc = wells_add_to_matrix(W, A);
+    std::memcpy(vals, A.val.data(), A.val.size() * sizeof(double));
+    return rc;
+}
 int orc_wells_apply_residual(int numWells, const int* val_pointers, const int* Ccols, const int* Bcols, const double* Cnnzs,
                              const double* Dnnzs, const double* Bnnzs, const double* resWell, double* r) {
     Wells W = wrap_wells(numWells, val_pointers, Ccols, Bcols, Cnnzs, Dnnzs, Bnnzs);

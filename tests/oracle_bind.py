@@ -31,6 +31,7 @@ class Oracle:
         L.orc_reorder.argtypes = [C.c_int, _i, _i, C.c_int, _i, _i, _i]
         L.orc_reorder_matrix.argtypes = [C.c_int, _i, _i, _vp, _i, _i, _i, _i, _vp]
         L.orc_wells_apply.argtypes = [C.c_int, _i, _i, _i, _d, _d, _d, _d, _d]
+        L.orc_wells_add_to_matrix.argtypes = [C.c_int, _i, _i, _d, C.c_int, _i, _i, _i, _d, _d, _d]
         L.orc_wells_apply_residual.argtypes = [C.c_int, _i, _i, _i, _d, _d, _d, _d, _d]
         L.orc_wells_recover.argtypes = [C.c_int, _i, _i, _i, _d, _d, _d, _d, _d, _d]
         L.orc_check_zero_diagonal.argtypes = [C.c_int, _i, _i, _d]
@@ -76,6 +77,12 @@ class Oracle:
         self.lib.orc_wells_apply(wells["numWells"], wells["val_pointers"], wells["Ccols"], wells["Bcols"],
                                  wells["Cnnzs"], wells["Dnnzs"], wells["Bnnzs"], x, y)
         return y
+
+    def wells_add_to_matrix(self, Nb, rowptr, col, val, wells):
+        v = np.ascontiguousarray(val, np.float64).copy()
+        rc = self.lib.orc_wells_add_to_matrix(Nb, rowptr, col, v, wells["numWells"], wells["val_pointers"], wells["Ccols"], wells["Bcols"],
+                                              wells["Cnnzs"], wells["Dnnzs"], wells["Bnnzs"])
+        return rc, v
 
     def wells_apply_residual(self, wells, res_well, r):
         r = r.copy()

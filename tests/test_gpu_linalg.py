@@ -186,3 +186,63 @@ def test_argument_errors(pkg):
     res = pkg.capi.Result()
     import ctypes as C
     assert pkg.capi.lib().opmhip_solve_system(s._h, 8, 16, 2, None, None, None, None, None, C.byref(res)) == pkg.capi.INVALID_ARGUMENT
+
+
+@pytest.mark.parametrize("reorder", ["graph_coloring", "line_coloring"])
+def test_add_well_contributions_to_matrix(pkg, orc, reorder):
+    """--matrix-add-well-contributions mode (StandardWell::addWellContributions): A -= C^T D^-1 B written into the
+    device-resident matrix whose pattern carries the well cliques; bit for bit, and the solve with the modified
+    matrix equals the solve with the operator form of the same wells up to the Krylov tolerance."""
+    rng = np.random.default_rng(17)
+    Nb, rp, ci, v = laplace_block_system(10, 9, 6, seed=19)
+    perfs = [4, 2, 6]
+    vp = np.concatenate([[0], np.cumsum(perfs)]).astype(np.int32)
+    nperf = int(vp[-1])
+    cells = rng.choice(Nb, nperf, replace=False).astype(np.int32)
+    cells[6:12] = cells[6:12][np.argsort(cells[6:12])]
+    cells[5] = cells[8]            # wells 1 and 2 share a cell: their contributions to block (cell, cell) are ordered
+    W = dict(numWells=3, val_pointers=vp, Ccols=cells, Bcols=cells.copy(), Cnnzs=0.05 * rng.standard_normal(nperf * 12),
+             Bnnzs=0.05 * rng.standard_normal(nperf * 12), Dnnzs=0.5 * rng.standard_normal(3 * 16))
+    # pattern + well cliques (zero blocks)
+    nb = [set(ci[rp[i]:rp[i + 1]]) for i in range(Nb)]
+    for w in range(3):
+        cs = cells[vp[w]:vp[w + 1]]
+        for a in cs:
+            nb[a].update(int(x) for x in cs)
+    rp2 = np.zeros(Nb + 1, np.int32)
+    ci2, v2 = [], []
+    old = {(i, int(ci[k])): k for i in range(Nb) for k in range(rp[i], rp[i + 1])}
+    for i in range(Nb):
+        for j in sorted(nb[i]):
+            ci2.append(j)
+            k = old.get((i, int(j)))
+            v2.append(v[9 * k:9 * k + 9] if k is not None else np.zeros(9))
+        rp2[i + 1] = len(ci2)
+    ci2, v2 = np.array(ci2, np.int32), np.ascontiguousarray(np.concatenate(v2))
+    s = pkg.capi.HipSolver(tolerance=1e-10, maxit=200, reorder=reorder)
+    s.set_pattern(Nb, rp2, ci2)
+    s.upload_system(v2)
+    s.add_well_contributions(W)
+    rc, vo = orc.wells_add_to_matrix(Nb, rp2, ci2, v2, W)
+    assert rc == 0 and not np.array_equal(vo, v2)
+    to, fr, rpc = s.ordering()
+    rr, rc_, rv = orc.reorder_matrix(Nb, rp2, ci2, vo, to, fr)
+    for seed in range(3):
+        x = np.random.default_rng(seed).standard_normal(Nb * 3)
+        yo = orc.spmv(Nb, rr, rc_, rv, x.reshape(Nb, 3)[fr].reshape(-1)).reshape(Nb, 3)[to].reshape(-1)
+        assert np.array_equal(s.spmv(x), yo)
+    # the same physics two ways: wells inside the matrix vs wells as an operator after every SpMV
+    b = rng.standard_normal(Nb * 3)
+    s2 = pkg.capi.HipSolver(tolerance=1e-10, maxit=200, reorder=reorder)
+    r_op = s2.solve_system(Nb, rp2, ci2, v2.copy(), b, wells=W)
+    x_op = s2.get_result()
+    s3 = pkg.capi.HipSolver(tolerance=1e-10, maxit=200, reorder=reorder)
+    r_mat = s3.solve_system(Nb, rp2, ci2, vo.copy(), b)
+    assert r_op.converged and r_mat.converged
+    np.testing.assert_allclose(s3.get_result(), x_op, rtol=1e-6, atol=1e-8)
+    # a clique block missing from the pattern is an argument error and leaves the matrix alone
+    s4 = pkg.capi.HipSolver(reorder=reorder)
+    s4.set_pattern(Nb, rp, ci)
+    s4.upload_system(v)
+    with pytest.raises(pkg.capi.OpmHipError):
+        s4.add_well_contributions(W)
