@@ -333,23 +333,24 @@ int opmhip_add_well_contributions(opmhip_ctx* c, const opmhip_wells* wells) {
                 }
             pair_ptr[w + 1] = (int)entry.size();
         }
-        int *d_pp = nullptr, *d_en = nullptr;
-        OPMHIP_HIP(c, hipMalloc((void**)&d_pp, pair_ptr.size() * sizeof(int)));
-        OPMHIP_HIP(c, hipMalloc((void**)&d_en, std::max<size_t>(1, entry.size()) * sizeof(int)));
-        OPMHIP_HIP(c, hipMemcpyAsync(d_pp, pair_ptr.data(), pair_ptr.size() * sizeof(int), hipMemcpyHostToDevice, c->stream));
-        OPMHIP_HIP(c, hipMemcpyAsync(d_en, entry.data(), entry.size() * sizeof(int), hipMemcpyHostToDevice, c->stream));
+        struct Scratch {  // freed on every path out of here
+            int *pp = nullptr, *en = nullptr;
+            ~Scratch() { if (pp) (void)hipFree(pp); if (en) (void)hipFree(en); }
+        } S;
+        OPMHIP_HIP(c, hipMalloc((void**)&S.pp, pair_ptr.size() * sizeof(int)));
+        OPMHIP_HIP(c, hipMalloc((void**)&S.en, std::max<size_t>(1, entry.size()) * sizeof(int)));
+        OPMHIP_HIP(c, hipMemcpyAsync(S.pp, pair_ptr.data(), pair_ptr.size() * sizeof(int), hipMemcpyHostToDevice, c->stream));
+        OPMHIP_HIP(c, hipMemcpyAsync(S.en, entry.data(), entry.size() * sizeof(int), hipMemcpyHostToDevice, c->stream));
         // runs of wells without shared blocks go out as one launch; a well that shares a block with an earlier one starts
         // a new launch, so that the additions to that block happen in well order (the order of well_container_)
         int w0 = 0;
         for (int w = 1; w <= nw; ++w)
             if (w == nw || shares[w]) {
-                launch_wells_add_to_matrix(c, w0, w - w0, d_pp, d_en);
+                launch_wells_add_to_matrix(c, w0, w - w0, S.pp, S.en);
                 w0 = w;
             }
         OPMHIP_HIP(c, hipGetLastError());
         OPMHIP_HIP(c, hipStreamSynchronize(c->stream));
-        (void)hipFree(d_pp);
-        (void)hipFree(d_en);
         c->factored = false;
         c->wells.num_wells = 0;  // these wells now live in the matrix: no operator form left behind for later SpMVs
         return OPMHIP_SUCCESS;
