@@ -68,18 +68,23 @@ __device__ __forceinline__ double emax(double a, double b) { return (a > b) ? a 
 __device__ __forceinline__ Ad emax(const Ad& a, const Ad& b) { return ad_max(a, b); }
 
 // ============================== property tables ===============================================================
-struct Tables {
-    const double* dbl;
+typedef const double* GlobalTab;                                       // table blob where it lies in HBM (L1/K$-resident)
+typedef const __attribute__((address_space(3))) double* LdsTab;        // ... or copied into LDS by the workgroup
+template <class DP>
+struct TablesT {
+    DP dbl;
     const int* idx;
     double rock_pref, rock_cr;
+    int ndbl, nidx;   // lengths of the blobs (for the LDS copy of the per-cell kernels)
     __device__ __forceinline__ const PvtRegionDesc& pvt(int r) const { return reinterpret_cast<const PvtRegionDesc*>(idx + 2)[r]; }
     __device__ __forceinline__ const SatRegionDesc& sat(int s) const {
         return reinterpret_cast<const SatRegionDesc*>(idx + 2 + idx[0] * (int)(sizeof(PvtRegionDesc) / sizeof(int)))[s];
     }
 };
+typedef TablesT<GlobalTab> Tables;
 // segment of x in an ascending array with clamping (Tabulated1DFunction / UniformXTabulated2DFunction, extrapolate = true):
 // a value that sits exactly on an interior node belongs to the segment on its right
-__device__ __forceinline__ int seg_right(const double* x, int n, double xv) {
+template <class DP> __device__ __forceinline__ int seg_right(DP x, int n, double xv) {
     if (xv <= x[0]) return 0;
     if (xv >= x[n - 1]) return n - 2;
     int lo = 0, hi = n - 1;
@@ -89,21 +94,21 @@ __device__ __forceinline__ int seg_right(const double* x, int n, double xv) {
     }
     return lo;
 }
-template <class E> __device__ __forceinline__ E tab1(const double* x, const double* y, int n, const E& xv) {
+template <class E, class DP> __device__ __forceinline__ E tab1(DP x, DP y, int n, const E& xv) {
     const int s = seg_right(x, n, val(xv));
     const double x0 = x[s], x1 = x[s + 1], y0 = y[s], y1 = y[s + 1];
     return y0 + (y1 - y0) * (xv - x0) / (x1 - x0);
 }
 // plain bilinear interpolation in (Rs, p) with per-column pressure grids (the policy the Norne PVT points select)
-template <class E> __device__ __forceinline__ E tab2(const Tables& T, const PvtRegionDesc& D, int voff, const E& xv, const E& yv) {
-    const double* xs = T.dbl + D.o_xs;
+template <class E, class DP> __device__ __forceinline__ E tab2(const TablesT<DP>& T, const PvtRegionDesc& D, int voff, const E& xv, const E& yv) {
+    const DP xs = T.dbl + D.o_xs;
     const int* yo = T.idx + D.o_yoff;
     const int i = seg_right(xs, D.o_nx, val(xv));
     const E alpha = (xv - xs[i]) / (xs[i + 1] - xs[i]);
-    const double* y1 = T.dbl + D.o_ys + yo[i];
-    const double* y2 = T.dbl + D.o_ys + yo[i + 1];
-    const double* v1 = T.dbl + voff + yo[i];
-    const double* v2 = T.dbl + voff + yo[i + 1];
+    const DP y1 = T.dbl + D.o_ys + yo[i];
+    const DP y2 = T.dbl + D.o_ys + yo[i + 1];
+    const DP v1 = T.dbl + voff + yo[i];
+    const DP v2 = T.dbl + voff + yo[i + 1];
     const int j1 = seg_right(y1, yo[i + 1] - yo[i], val(yv)), j2 = seg_right(y2, yo[i + 2] - yo[i + 1], val(yv));
     const E beta1 = (yv - y1[j1]) / (y1[j1 + 1] - y1[j1]);
     const E beta2 = (yv - y2[j2]) / (y2[j2 + 1] - y2[j2]);
@@ -112,7 +117,7 @@ template <class E> __device__ __forceinline__ E tab2(const Tables& T, const PvtR
     return s1 * (1.0 - alpha) + s2 * alpha;
 }
 // PiecewiseLinearTwoPhaseMaterial: constant outside the table; a value on a node belongs to the segment on its left
-template <class E> __device__ __forceinline__ E pwlin(const double* x, const double* y, int n, const E& xv) {
+template <class E, class DP> __device__ __forceinline__ E pwlin(DP x, DP y, int n, const E& xv) {
     const double s = val(xv);
     if (s <= x[0]) return cst<E>(y[0]);
     if (s >= x[n - 1]) return cst<E>(y[n - 1]);
@@ -125,9 +130,9 @@ template <class E> __device__ __forceinline__ E pwlin(const double* x, const dou
     const double m = (y1 - y0) / (x1 - x0);
     return y0 + (xv - x0) * m;
 }
-__device__ __forceinline__ double rs_sat_value(const Tables& T, int pr, double po) {
+template <class DP> __device__ __forceinline__ double rs_sat_value(const TablesT<DP>& T, int pr, double po) {
     const PvtRegionDesc& D = T.pvt(pr);
-    return tab1<double>(T.dbl + D.sat_p, T.dbl + D.sat_rs, D.sat_n, po);
+    return tab1<double, DP>(T.dbl + D.sat_p, T.dbl + D.sat_rs, D.sat_n, po);
 }
 
 // ============================== intensive quantities ========================================================
@@ -144,11 +149,11 @@ struct Iq {
 };
 
 // BlackOilIntensiveQuantities::update for live oil + dry gas + water
-template <class E>
-__device__ __forceinline__ void update_iq(const Tables& T, int pr, int sr, double RsMax, double refPoro, const double* pv, int meaning, Iq<E>& q) {
+template <class E, class DP>
+__device__ __forceinline__ void update_iq(const TablesT<DP>& T, int pr, int sr, double RsMax, double refPoro, const double* pv, int meaning, Iq<E>& q) {
     const PvtRegionDesc& D = T.pvt(pr);
     const SatRegionDesc& Sd = T.sat(sr);
-    const double* B = T.dbl;
+    const DP B = T.dbl;
     const double Swco = B[Sd.swco];
     const E Sw = mk<E>(pv[0], 0);
     E Sg = cst<E>(0.0);
@@ -157,20 +162,20 @@ __device__ __forceinline__ void update_iq(const Tables& T, int pr, int sr, doubl
     q.S[WATER] = Sw; q.S[GAS] = Sg; q.S[OIL] = So;
     // capillary pressures (EclDefaultMaterial): pC[water] = -pcow(Sw), pC[oil] = 0, pC[gas] = pcgo(1 - Swco - Sg)
     E pC[3];
-    pC[0] = -pwlin<E>(B + Sd.sw_x, B + Sd.pcow, Sd.nw, Sw);
+    pC[0] = -pwlin<E, DP>(B + Sd.sw_x, B + Sd.pcow, Sd.nw, Sw);
     pC[1] = cst<E>(0.0);
-    pC[2] = pwlin<E>(B + Sd.so_x, B + Sd.pcgo, Sd.ng, 1.0 - Swco - Sg);
+    pC[2] = pwlin<E, DP>(B + Sd.so_x, B + Sd.pcgo, Sd.ng, 1.0 - Swco - Sg);
     const E po = mk<E>(pv[1], 1);
     for (int ph = 0; ph < 3; ++ph) q.p[ph] = po + (pC[ph] - pC[OIL]);
     // relative permeabilities (stored in mob, divided by viscosity below)
     {
-        q.mob[WATER] = pwlin<E>(B + Sd.sw_x, B + Sd.krw, Sd.nw, Sw);
-        q.mob[GAS] = pwlin<E>(B + Sd.so_x, B + Sd.krg, Sd.ng, 1.0 - Swco - Sg);
+        q.mob[WATER] = pwlin<E, DP>(B + Sd.sw_x, B + Sd.krw, Sd.nw, Sw);
+        q.mob[GAS] = pwlin<E, DP>(B + Sd.so_x, B + Sd.krg, Sd.ng, 1.0 - Swco - Sg);
         const E Swm = emax(cst<E>(Swco), Sw);
         const E Sw_ow = Sg + Swm;
         const E So_go = 1.0 - Sw_ow;
-        const E kro_ow = pwlin<E>(B + Sd.sw_x, B + Sd.krow, Sd.nw, Sw_ow);
-        const E kro_go = pwlin<E>(B + Sd.so_x, B + Sd.krog, Sd.ng, So_go);
+        const E kro_ow = pwlin<E, DP>(B + Sd.sw_x, B + Sd.krow, Sd.nw, Sw_ow);
+        const E kro_go = pwlin<E, DP>(B + Sd.so_x, B + Sd.krog, Sd.ng, So_go);
         const double eps = 1e-5;
         if (val(Sw_ow) - Swco < eps) {
             const E kro2 = (kro_ow + kro_go) / 2.0;
@@ -183,7 +188,7 @@ __device__ __forceinline__ void update_iq(const Tables& T, int pr, int sr, doubl
     }
     // Rs: saturated value in the three-phase case, the primary variable otherwise, capped by RsMax
     if (meaning == OPMHIP_SW_PO_SG) {
-        const E RsSat = tab1<E>(B + D.sat_p, B + D.sat_rs, D.sat_n, q.p[OIL]);
+        const E RsSat = tab1<E, DP>(B + D.sat_p, B + D.sat_rs, D.sat_n, q.p[OIL]);
         q.Rs = emin(cst<E>(RsMax), RsSat);
     } else {
         q.Rs = emin(cst<E>(RsMax), mk<E>(pv[2], 2));
@@ -191,25 +196,25 @@ __device__ __forceinline__ void update_iq(const Tables& T, int pr, int sr, doubl
     // 1/B and viscosity per phase, each at its own phase pressure (BlackOilFluidSystem)
     {
         const bool saturated = val(q.S[GAS]) > 0.0 && val(q.Rs) >= (1.0 - 1e-10) * rs_sat_value(T, pr, val(q.p[OIL]));
-        const double* W = B + D.water;  // p_ref, Bw_ref, c_w, mu_ref, c_v
+        const DP W = B + D.water;  // p_ref, Bw_ref, c_w, mu_ref, c_v
         const E X = W[2] * (q.p[WATER] - W[0]);
         q.invB[WATER] = (1.0 + X * (1.0 + X / 2.0)) / W[1];
         const E Y = (W[2] - W[4]) * (q.p[WATER] - W[0]);
         E mu = (W[3] * W[1]) * q.invB[WATER] / (1.0 + Y * (1.0 + Y / 2.0));
         q.mob[WATER] = q.mob[WATER] / mu;
         if (saturated) {
-            q.invB[OIL] = tab1<E>(B + D.sat_p, B + D.sat_invB, D.sat_n, q.p[OIL]);
-            mu = tab1<E>(B + D.sat_p, B + D.sat_invB, D.sat_n, q.p[OIL]) / tab1<E>(B + D.sat_p, B + D.sat_invBMu, D.sat_n, q.p[OIL]);
+            q.invB[OIL] = tab1<E, DP>(B + D.sat_p, B + D.sat_invB, D.sat_n, q.p[OIL]);
+            mu = tab1<E, DP>(B + D.sat_p, B + D.sat_invB, D.sat_n, q.p[OIL]) / tab1<E, DP>(B + D.sat_p, B + D.sat_invBMu, D.sat_n, q.p[OIL]);
         } else {
-            q.invB[OIL] = tab2<E>(T, D, D.o_invB, q.Rs, q.p[OIL]);
-            mu = tab2<E>(T, D, D.o_invB, q.Rs, q.p[OIL]) / tab2<E>(T, D, D.o_invBMu, q.Rs, q.p[OIL]);
+            q.invB[OIL] = tab2<E, DP>(T, D, D.o_invB, q.Rs, q.p[OIL]);
+            mu = tab2<E, DP>(T, D, D.o_invB, q.Rs, q.p[OIL]) / tab2<E, DP>(T, D, D.o_invBMu, q.Rs, q.p[OIL]);
         }
         q.mob[OIL] = q.mob[OIL] / mu;
-        q.invB[GAS] = tab1<E>(B + D.gas_p, B + D.gas_invB, D.gas_n, q.p[GAS]);
-        mu = tab1<E>(B + D.gas_p, B + D.gas_invB, D.gas_n, q.p[GAS]) / tab1<E>(B + D.gas_p, B + D.gas_invBMu, D.gas_n, q.p[GAS]);
+        q.invB[GAS] = tab1<E, DP>(B + D.gas_p, B + D.gas_invB, D.gas_n, q.p[GAS]);
+        mu = tab1<E, DP>(B + D.gas_p, B + D.gas_invB, D.gas_n, q.p[GAS]) / tab1<E, DP>(B + D.gas_p, B + D.gas_invBMu, D.gas_n, q.p[GAS]);
         q.mob[GAS] = q.mob[GAS] / mu;
     }
-    const double* rr = B + D.density;  // oil, water, gas
+    const DP rr = B + D.density;  // oil, water, gas
     q.rho[WATER] = q.invB[WATER] * rr[1];
     q.rho[GAS] = q.invB[GAS] * rr[2];
     q.rho[OIL] = q.invB[OIL] * rr[0];
@@ -241,24 +246,44 @@ struct CellStatic {
 };
 
 // invalidateAndUpdateIntensiveQuantities(0): one lane per cell
-__global__ __launch_bounds__(256) void k_iq_update(int c0, int Nb, Tables T, CellStatic C, const double* __restrict__ pv,
-                                                   const unsigned char* __restrict__ meaning, double* __restrict__ iq) {
-    const int c = c0 + blockIdx.x * blockDim.x + threadIdx.x;  // cells [c0, Nb)
-    if (c >= Nb) return;
+// The per-cell kernels walk the property tables with binary searches: ~130 dependent loads per cell, each an L1 round
+// trip (PMC: 41 us per wavefront).  The tables are a few KiB, so every workgroup copies the double blob into LDS first
+// and searches there with ds_read (LdsTab); tables too large for the LDS budget stay in global memory (GlobalTab).
+constexpr int TAB_LDS_DBL = 3072;   // 24 KiB
+template <class DP>
+__device__ __forceinline__ void iq_update_cell(const TablesT<DP>& T, const CellStatic& C, int c, const double* __restrict__ pv,
+                                               const unsigned char* __restrict__ meaning, double* __restrict__ iq) {
     const double x[3] = {pv[(size_t)c * 3], pv[(size_t)c * 3 + 1], pv[(size_t)c * 3 + 2]};
     Iq<Ad> q;
-    update_iq<Ad>(T, C.pvtnum ? C.pvtnum[c] : 0, C.satnum ? C.satnum[c] : 0, C.rsmax ? C.rsmax[c] : DBL_MAX / 2.0, C.poro[c], x, meaning[c], q);
+    update_iq<Ad, DP>(T, C.pvtnum ? C.pvtnum[c] : 0, C.satnum ? C.satnum[c] : 0, C.rsmax ? C.rsmax[c] : DBL_MAX / 2.0, C.poro[c], x, meaning[c], q);
     store_iq(iq + (size_t)c * IQS, q);
 }
-
-// BlackOilNewtonMethod::update_ + adaptPrimaryVariables + IQ recompute, one lane per cell.
-// dx is in the INTERNAL order (the solver's x); relax = NonlinearSolverEbos "dampen" factor applied first.
-__global__ __launch_bounds__(256) void k_newton_update(int Nb, Tables T, CellStatic C, const double* __restrict__ dx, double relax,
-                                                       double* __restrict__ pv, unsigned char* __restrict__ meaning,
-                                                       unsigned char* __restrict__ wasSwitched, double* __restrict__ iq,
-                                                       int* __restrict__ nswitched) {
-    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+// copies the blob into `s_tab` (workgroup-wide, contains a barrier); true if the tables fit
+__device__ __forceinline__ bool tables_to_lds(const Tables& T, double* s_tab) {
+    if (T.ndbl > TAB_LDS_DBL) return false;
+    for (int i = threadIdx.x; i < T.ndbl; i += blockDim.x) s_tab[i] = T.dbl[i];
+    __syncthreads();
+    return true;
+}
+__device__ __forceinline__ TablesT<LdsTab> lds_tables(const Tables& T, double* s_tab) {
+    return TablesT<LdsTab>{(LdsTab)s_tab, T.idx, T.rock_pref, T.rock_cr, T.ndbl, T.nidx};
+}
+__global__ __launch_bounds__(256) void k_iq_update(int c0, int Nb, Tables T, CellStatic C, const double* __restrict__ pv,
+                                                   const unsigned char* __restrict__ meaning, double* __restrict__ iq) {
+    __shared__ double s_tab[TAB_LDS_DBL];
+    const bool inLds = tables_to_lds(T, s_tab);
+    const int c = c0 + blockIdx.x * blockDim.x + threadIdx.x;  // cells [c0, Nb)
     if (c >= Nb) return;
+    if (inLds) iq_update_cell(lds_tables(T, s_tab), C, c, pv, meaning, iq);
+    else iq_update_cell(T, C, c, pv, meaning, iq);
+}
+
+// BlackOilNewtonMethod::update_ (chopped update) + BlackOilPrimaryVariables::adaptPrimaryVariables + IQ recompute
+template <class DP>
+__device__ __forceinline__ void newton_update_cell(const TablesT<DP>& T, const CellStatic& C, int c, const double* __restrict__ dx, double relax,
+                                                   double* __restrict__ pv, unsigned char* __restrict__ meaning,
+                                                   unsigned char* __restrict__ wasSwitched, double* __restrict__ iq,
+                                                   int* __restrict__ nswitched) {
     const double dpMaxRel = 0.3, dsMax = 0.2, oscThreshold = 1e-5;
     double x[3] = {pv[(size_t)c * 3], pv[(size_t)c * 3 + 1], pv[(size_t)c * 3 + 2]};
     double u[3] = {dx[(size_t)c * 3], dx[(size_t)c * 3 + 1], dx[(size_t)c * 3 + 2]};
@@ -310,8 +335,19 @@ __global__ __launch_bounds__(256) void k_newton_update(int Nb, Tables T, CellSta
     pv[(size_t)c * 3] = x[0]; pv[(size_t)c * 3 + 1] = x[1]; pv[(size_t)c * 3 + 2] = x[2];
     if (sw) atomicAdd(nswitched, 1);
     Iq<Ad> q;
-    update_iq<Ad>(T, pr, C.satnum ? C.satnum[c] : 0, RsMax, C.poro[c], x, mng, q);
+    update_iq<Ad, DP>(T, pr, C.satnum ? C.satnum[c] : 0, RsMax, C.poro[c], x, mng, q);
     store_iq(iq + (size_t)c * IQS, q);
+}
+__global__ __launch_bounds__(256) void k_newton_update(int Nb, Tables T, CellStatic C, const double* __restrict__ dx, double relax,
+                                                       double* __restrict__ pv, unsigned char* __restrict__ meaning,
+                                                       unsigned char* __restrict__ wasSwitched, double* __restrict__ iq,
+                                                       int* __restrict__ nswitched) {
+    __shared__ double s_tab[TAB_LDS_DBL];
+    const bool inLds = tables_to_lds(T, s_tab);
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= Nb) return;
+    if (inLds) newton_update_cell(lds_tables(T, s_tab), C, c, dx, relax, pv, meaning, wasSwitched, iq, nswitched);
+    else newton_update_cell(T, C, c, dx, relax, pv, meaning, wasSwitched, iq, nswitched);
 }
 
 // ============================== face flux ===================================================================
@@ -647,7 +683,7 @@ __global__ void k_unpermute_blocks(int nnzb, const int* __restrict__ nnzMap, con
 
 // ============================== launchers ====================================================================
 static inline int cdiv(size_t a, size_t b) { return (int)((a + b - 1) / b); }
-static Tables tables_of(const opmhip_ctx* c) { return Tables{c->asmb.d_tab_dbl, c->asmb.d_tab_idx, c->asmb.rock_pref, c->asmb.rock_cr}; }
+static Tables tables_of(const opmhip_ctx* c) { return Tables{c->asmb.d_tab_dbl, c->asmb.d_tab_idx, c->asmb.rock_pref, c->asmb.rock_cr, c->asmb.tab_ndbl, c->asmb.tab_nidx}; }
 static CellStatic cells_of(const opmhip_ctx* c) {
     return CellStatic{c->asmb.d_poro, c->asmb.d_volume, c->asmb.d_depth, c->asmb.d_rsmax, c->asmb.d_pvtnum, c->asmb.d_satnum};
 }

@@ -66,6 +66,8 @@ int opmhip_set_fluid(opmhip_ctx* c, const opmhip_fluid* fluid) {
         int rc;
         if ((rc = dev_upload(c, &A.d_tab_dbl, T.dbl))) return rc;
         if ((rc = dev_upload(c, &A.d_tab_idx, T.idx))) return rc;
+        A.tab_ndbl = (int)T.dbl.size();
+        A.tab_nidx = (int)T.idx.size();
         A.rock_pref = T.rock_pref;
         A.rock_cr = T.rock_cr;
         A.num_pvt = T.num_pvt;

@@ -76,6 +76,7 @@ struct AsmDev {
     bool fluid_set = false, static_set = false, state_set = false, assembled = false;
     double *d_tab_dbl = nullptr;
     int* d_tab_idx = nullptr;
+    int tab_ndbl = 0, tab_nidx = 0;   // lengths of the two table blobs
     double rock_pref = 1e5, rock_cr = 0.0;
     int num_pvt = 0, num_sat = 0;
     double *d_trans = nullptr, *d_area = nullptr, *d_thpres = nullptr;                      // per entry
