@@ -85,7 +85,9 @@ typedef struct opmhip_result {
 
 /* Standard-well contributions, the data bda::WellContributions carries across the boundary
  * (bda/WellContributions.hpp:60-214; fill order C, D, B per well, wells/StandardWellEval.cpp:1206-1250):
- * applied after each SpMV as y -= C^T (D^-1 (B x)) (bda/WellContributions.cu:36-126). dim = 3, dim_wells = 4. */
+ * applied after each SpMV as y -= C^T (D^-1 (B x)) (bda/WellContributions.cu:36-126). dim = 3, dim_wells = 4.
+ * One workgroup per well; where two wells perforate the same cell their updates of that cell are atomic adds (the
+ * reference's kernel races there), so the result is then defined up to the order of two additions. */
 typedef struct opmhip_wells {
     int num_wells;
     const int* val_pointers; /* [num_wells+1] perforation ranges */

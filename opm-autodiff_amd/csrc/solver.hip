@@ -968,7 +968,9 @@ __global__ __launch_bounds__(64) void k_wells_apply(const int* __restrict__ vp, 
         const int p = e / 3, c = e % 3;
         double s = 0.0;
         for (int j = 0; j < 4; ++j) s += C[(size_t)p * 12 + j * 3 + c] * z2[j];
-        y[(size_t)Ccols[p] * 3 + c] -= s;
+        // wells do not normally share a cell; if two do, their workgroups meet here: add atomically (one add per
+        // well and entry - the same bits as a plain update whenever the cell has a single well)
+        atomicAdd(&y[(size_t)Ccols[p] * 3 + c], -s);
     }
 }
 
@@ -990,7 +992,7 @@ __global__ __launch_bounds__(64) void k_wells_residual(const int* __restrict__ v
         const int p = e / 3, c = e % 3;
         double s = 0.0;
         for (int j = 0; j < 4; ++j) s += C[(size_t)p * 12 + j * 3 + c] * z2[j];
-        r[(size_t)Ccols[p] * 3 + c] -= s;
+        atomicAdd(&r[(size_t)Ccols[p] * 3 + c], -s);  // see k_wells_apply
     }
 }
 __global__ __launch_bounds__(64) void k_wells_recover(const int* __restrict__ vp, const int* __restrict__ Bcols,
