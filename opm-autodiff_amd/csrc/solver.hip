@@ -406,6 +406,11 @@ __global__ __launch_bounds__(64) void k_ilu_sweep(int tile_begin, int ntc, int n
 // a row may depend on earlier rows of its own chain, which the same workgroup wrote one step before - visible after
 // the workgroup barrier because a CU's L1 sees the CU's own write-through stores.  Chains of other colours are
 // finished (earlier launches).  No first-colour / last-colour shortcuts here: every colour has chain-internal L and U.
+// A load that must see what ANOTHER lane of this workgroup stored to global memory a step earlier (the rare paths of the
+// chain sweeps): agent-scope atomic load, served by L2, so that no stale line of the CU's L1 can answer it.
+__device__ __forceinline__ double coherent_load(const double* p) {
+    return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
 constexpr int CHAIN_MAX_STEPS = 128;
 #ifndef OPMHIP_CHAIN_GATHER
 #define OPMHIP_CHAIN_GATHER 6
@@ -563,7 +568,7 @@ __device__ __forceinline__ void chain_sweep(const int q0, const int q1, const in
             for (int u = 0; u < CGCH; ++u) {
                 if (u < nrow && ((late >> u) & 1u)) {
                     if (cc[u] == myPrevRow) { xx[u][0] = myPrev[0]; xx[u][1] = myPrev[1]; xx[u][2] = myPrev[2]; }
-                    else { const double* xc = &vu[(size_t)cc[u] * BS]; xx[u][0] = xc[0]; xx[u][1] = xc[1]; xx[u][2] = xc[2]; }
+                    else { const double* xc = &vu[(size_t)cc[u] * BS]; xx[u][0] = coherent_load(xc); xx[u][1] = coherent_load(xc + 1); xx[u][2] = coherent_load(xc + 2); }
                 }
             }
 #pragma unroll
@@ -580,8 +585,8 @@ __device__ __forceinline__ void chain_sweep(const int q0, const int q1, const in
                 for (int u = 0; u < CGCH; ++u) {
                     const int q = (done + u < nrow) ? done + u : nrow - 1;
                     const int cq = pcol[reverse ? ke - 1 - q : kb + q];
-                    const double* xc = &vu[(size_t)cq * BS];
-                    yy[u][0] = xc[0]; yy[u][1] = xc[1]; yy[u][2] = xc[2];
+                    const double* xc = &vu[(size_t)cq * BS];  // may be a row an earlier step of this workgroup wrote
+                    yy[u][0] = coherent_load(xc); yy[u][1] = coherent_load(xc + 1); yy[u][2] = coherent_load(xc + 2);
                 }
 #pragma unroll
                 for (int u = 0; u < CGCH; ++u) {
