@@ -891,25 +891,59 @@ __global__ __launch_bounds__(64) void k_ilu_factor(int ct_begin, const int* __re
     TILE_LDS
     const int lane = threadIdx.x;
     const int q0 = ct_first[ct_begin + blockIdx.x], q1 = ct_first[ct_begin + blockIdx.x + 1];
+    constexpr int FU = 8;  // U-row columns of a neighbour fetched in one batch (longer rows: the merge below)
+    __shared__ int scol[TILE_CAP_BLOCKS + 2];
     for (int t = q0; t < q1; ++t) {  // steps of a chain-tile in order (a single step unless the ordering is line-coloured)
         const TileCtx T = tile_stage_values(t, tile_row0, rowptr, A, sval, lane);
+        // the tile's column indices next to its values: the elimination searches them many times
+        if (T.staged) {
+            const int kk0 = rowptr[T.r0], kk1 = rowptr[T.r1];
+            for (int q = kk0 + lane; q < kk1; q += 64) scol[q - T.k0e] = col[q];
+        }
+        wave_sync();
         const int i = T.r0 + lane;
         if (i < T.r1) {
             const int kb = rowptr[i], ke = rowptr[i + 1], kd = diag[i];
             // an over-long row (not staged) cannot be eliminated in LDS: such rows are rejected at set_pattern time
             double* row = &sval[(kb - T.k0e) * BB];
-            const int* rcol = &col[kb];
+            const int* rcol = &scol[kb - T.k0e];
             const int n = ke - kb, nd = kd - kb;
             for (int a = 0; a < nd; ++a) {
                 const int j = rcol[a];
                 double Lij[BB], Dj[BB], tmp[BB];
+                // one round of loads: D_j^-1, the extent of row j's U part and (next) its first FU column indices -
+                // instead of walking them one dependent load at a time
+                const int jk0 = urowptr[j], jend = urowptr[j + 1];
 #pragma unroll
                 for (int q = 0; q < BB; ++q) { tmp[q] = row[a * BB + q]; Dj[q] = invD[(size_t)j * BB + q]; }
+                int ucj[FU];
+#pragma unroll
+                for (int u = 0; u < FU; ++u) ucj[u] = (jk0 + u < jend) ? ucol[jk0 + u] : -1;
                 blk_mul(tmp, Dj, Lij);  // A_ij * A_jj^-1
 #pragma unroll
                 for (int q = 0; q < BB; ++q) row[a * BB + q] = Lij[q];
-                int jk = urowptr[j];
-                const int jend = urowptr[j + 1];
+                if (jend - jk0 <= FU) {
+                    // every common column of (row i beyond a) and (U row of j); each match updates its own block of
+                    // row i, so the order among matches does not matter
+#pragma unroll
+                    for (int u = 0; u < FU; ++u) {
+                        const int cj = ucj[u];
+                        if (cj < 0) continue;
+                        for (int ik = a + 1; ik < n; ++ik) {
+                            if (rcol[ik] == cj) {
+                                double Ujk[BB], P[BB];
+#pragma unroll
+                                for (int q = 0; q < BB; ++q) Ujk[q] = U[(size_t)(jk0 + u) * BB + q];
+                                blk_mul(Lij, Ujk, P);  // L_ij * A_jk
+#pragma unroll
+                                for (int q = 0; q < BB; ++q) row[ik * BB + q] -= P[q];
+                                break;
+                            }
+                        }
+                    }
+                    continue;
+                }
+                int jk = jk0;
                 int ik = a + 1;
                 while (ik < n && jk < jend) {
                     const int ci = rcol[ik], cj = ucol[jk];
