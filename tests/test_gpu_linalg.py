@@ -186,6 +186,23 @@ def test_argument_errors(pkg):
     res = pkg.capi.Result()
     import ctypes as C
     assert pkg.capi.lib().opmhip_solve_system(s._h, 8, 16, 2, None, None, None, None, None, C.byref(res)) == pkg.capi.INVALID_ARGUMENT
+    # the well helpers and get_rhs need a system / a solution on the device first
+    W = dict(numWells=1, val_pointers=np.array([0, 1], np.int32), Ccols=np.array([0], np.int32), Bcols=np.array([0], np.int32),
+             Cnnzs=np.zeros(12), Bnnzs=np.zeros(12), Dnnzs=np.eye(4).reshape(-1))
+    s2 = pkg.capi.HipSolver()
+    s2.set_pattern(Nb, rp, ci)
+    for call in (lambda: s2.get_rhs(), lambda: s2.wells_apply_residual(W, np.zeros(4)), lambda: s2.add_well_contributions(W),
+                 lambda: s2.wells_recover_solution(W, np.zeros(4))):
+        with pytest.raises(pkg.capi.OpmHipError) as e:
+            call()
+        assert e.value.code == pkg.capi.NOT_READY
+    s2.upload_system(v, np.ones(3 * Nb))
+    s2.wells_apply_residual(W, np.zeros(4))      # fine now; a zero well residual changes nothing
+    assert np.array_equal(s2.get_rhs(), np.ones(3 * Nb))
+    bad_w = dict(W, Ccols=np.array([Nb], np.int32))
+    with pytest.raises(pkg.capi.OpmHipError) as e:
+        s2.wells_apply_residual(bad_w, np.zeros(4))
+    assert e.value.code == pkg.capi.INVALID_ARGUMENT
 
 
 @pytest.mark.parametrize("reorder", ["graph_coloring", "line_coloring"])
