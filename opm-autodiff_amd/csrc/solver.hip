@@ -1,13 +1,16 @@
 // gfx950 kernels of the linear-solve half of the hot path: block-CSR SpMV, block ILU0 factor/apply over a
 // level/colour schedule, standard-well operator, fused BiCGStab vector kernels with device-resident scalars.
 //
-// Design ("tile kernels"): one workgroup = one wavefront = one tile of <= 64 block rows.  The
+// Design ("tile kernels"): one workgroup = one wavefront = one tile of <= TILE_ROWS (32) block rows.  The
 // tile's 72-byte blocks form ONE contiguous byte range of the value array, so the wavefront streams that
 // range into LDS with 16-byte-per-lane coalesced loads (HBM sees only full-line, unit-stride traffic), and then
 // every lane walks its own row out of LDS in exactly the CPU's sequential operation order.  Lane stride in LDS
 // is 63 doubles for the 7-point stencil: 63*2 mod 64 banks = 62, i.e. ds_read_b64 from 32 lanes hits 32
 // distinct bank pairs - conflict free.  Built with -ffp-contract=off: a*b+c is never fused, so the factors and
 // sweeps are bit-identical to the CPU restatement in the same ordering.
+// Line-coloured orderings add the chain kernels (heavy: LDS-staged, software-pipelined over the steps of a chain tile;
+// light: lane-private recurrences, optionally fused with the BiCGStab vector updates); the BiCGStab driver keeps the
+// stopping rule on the device and runs the host one half iteration ahead of it.
 #include <hip/hip_runtime.h>
 #include <atomic>
 
