@@ -212,6 +212,14 @@ int opmhip_set_static(opmhip_ctx* ctx, const double* trans, const double* area, 
                       const double* poro, const double* volume, const double* depth, const int* pvtnum,
                       const int* satnum, const double* rsmax);
 
+/* Point evaluation of the fluid-system and saturation functions the assembly uses, ON THE DEVICE, for host-side setup
+ * code (equilibration, ebos/equil/initstateequil.hh) and for tests that pin these functions against the reference's
+ * EQUIL expectations.  For each of n points: out[8 i + 0..7] = 1/B_w(p), 1/B_g(p), 1/B_o(p, rs) (the saturated curve
+ * where rs >= RsSat(p), as the equilibration's oil density does, initstateequil.hh:214-233), RsSat(p), pcow(sw),
+ * pcgo(sg), mu_o(p, rs) [Pa s], mu_g(p).  Needs opmhip_set_fluid only.  All arrays host memory. */
+int opmhip_fluid_probe(opmhip_ctx* ctx, int pvt_region, int sat_region, int n, const double* p, const double* rs,
+                       const double* sw, const double* sg, double* out);
+
 /* replaces: model().solution(0) = ... ; model().invalidateAndUpdateIntensiveQuantities(0)
  * (flow/BlackoilModelEbos.hpp:552-562).  pv: Nb x 3 (Sw, p_o, Sg|Rs), meaning: Nb bytes. Natural order. */
 int opmhip_set_state(opmhip_ctx* ctx, const double* pv, const unsigned char* meaning);

@@ -274,6 +274,33 @@ def _bind_assembly(L):
     L.opmhip_comm_init_loopback.argtypes = [vp, C.c_int, C.c_int, C.c_char_p]
     L.opmhip_set_halo.argtypes = [vp, C.c_longlong, C.c_int, vp, vp, vp, vp]
     L.opmhip_set_cell_global_ids.argtypes = [vp, vp]
+    L.opmhip_fluid_probe.argtypes = [vp, C.c_int, C.c_int, C.c_int, vp, vp, vp, vp, vp]
+
+
+class HipFluid(HipSolver):
+    """A context that only holds the fluid tables: point evaluation of the device's property functions
+    (opmhip_fluid_probe) for host-side setup such as equilibration (equil.py)."""
+
+    COLUMNS = ("invBw", "invBg", "invBo", "rsSat", "pcow", "pcgo", "muo", "mug")
+
+    def __init__(self, fluid, **solver_kw):
+        super().__init__(**solver_kw)
+        L = lib()
+        if not getattr(L, "_asm_bound", False):
+            _bind_assembly(L)
+            L._asm_bound = True
+        self.fluid = fluid
+        self._fd = fluid.desc()
+        self._check(L.opmhip_set_fluid(self._h, C.addressof(self._fd)))
+
+    def probe(self, p, rs=0.0, sw=0.0, sg=0.0, pvt_region=0, sat_region=0):
+        """-> array (n, 8): 1/B_w(p), 1/B_g(p), 1/B_o(p, rs), RsSat(p), pcow(sw), pcgo(sg), mu_o(p, rs), mu_g(p)"""
+        p = np.atleast_1d(np.asarray(p, np.float64))
+        n = len(p)
+        a = [np.ascontiguousarray(np.broadcast_to(np.asarray(v, np.float64), (n,))) for v in (p, rs, sw, sg)]
+        out = np.empty((n, 8))
+        self._check(lib().opmhip_fluid_probe(self._h, pvt_region, sat_region, n, _ptr(a[0]), _ptr(a[1]), _ptr(a[2]), _ptr(a[3]), _ptr(out)))
+        return out
 
 
 class HipModel(HipSolver):

@@ -350,6 +350,44 @@ __global__ __launch_bounds__(256) void k_newton_update(int Nb, Tables T, CellSta
     else newton_update_cell(T, C, c, dx, relax, pv, meaning, wasSwitched, iq, nswitched);
 }
 
+static Tables tables_of(const opmhip_ctx* c);
+// opmhip_fluid_probe: the property functions of update_iq at given points (plain doubles)
+__global__ __launch_bounds__(256) void k_fluid_probe(Tables T, int pr, int sr, int n, const double* __restrict__ p,
+                                                     const double* __restrict__ rs, const double* __restrict__ sw,
+                                                     const double* __restrict__ sg, double* __restrict__ out) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const PvtRegionDesc& D = T.pvt(pr);
+    const SatRegionDesc& Sd = T.sat(sr);
+    const GlobalTab B = T.dbl;
+    double* o = out + (size_t)i * 8;
+    const double pi = p[i], rsi = rs[i];
+    {
+        const GlobalTab W = B + D.water;  // p_ref, Bw_ref, c_w, mu_ref, c_v
+        const double X = W[2] * (pi - W[0]);
+        o[0] = (1.0 + X * (1.0 + X / 2.0)) / W[1];
+    }
+    o[1] = tab1<double, GlobalTab>(B + D.gas_p, B + D.gas_invB, D.gas_n, pi);
+    const double RsSat = rs_sat_value(T, pr, pi);
+    o[3] = RsSat;
+    if (rsi >= RsSat) {
+        o[2] = tab1<double, GlobalTab>(B + D.sat_p, B + D.sat_invB, D.sat_n, pi);
+        o[6] = o[2] / tab1<double, GlobalTab>(B + D.sat_p, B + D.sat_invBMu, D.sat_n, pi);
+    } else {
+        o[2] = tab2<double, GlobalTab>(T, D, D.o_invB, rsi, pi);
+        o[6] = o[2] / tab2<double, GlobalTab>(T, D, D.o_invBMu, rsi, pi);
+    }
+    const double Swco = B[Sd.swco];
+    o[4] = pwlin<double, GlobalTab>(B + Sd.sw_x, B + Sd.pcow, Sd.nw, sw[i]);
+    o[5] = pwlin<double, GlobalTab>(B + Sd.so_x, B + Sd.pcgo, Sd.ng, 1.0 - Swco - sg[i]);
+    o[7] = o[1] / tab1<double, GlobalTab>(B + D.gas_p, B + D.gas_invBMu, D.gas_n, pi);
+}
+int launch_fluid_probe(opmhip_ctx* c, int pr, int sr, int n, const double* d_in, double* d_out) {
+    hipLaunchKernelGGL(k_fluid_probe, dim3((n + 255) / 256), dim3(256), 0, c->stream, tables_of(c), pr, sr, n, d_in, d_in + n, d_in + 2 * (size_t)n,
+                       d_in + 3 * (size_t)n, d_out);
+    return OPMHIP_SUCCESS;
+}
+
 // ============================== face flux ===================================================================
 // calculateGradients_ + computeFlux for one face: `in` = focus (interior) cell with derivatives, `ex` = exterior cell,
 // of which only values enter.  Result: flux[eq] * faceArea.  The two cells come through accessors: PtrQ reads a record

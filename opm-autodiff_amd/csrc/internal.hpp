@@ -287,6 +287,7 @@ void launch_u8_to_natural(opmhip_ctx* c, const unsigned char* internal, unsigned
 void launch_iq_to_natural(opmhip_ctx* c, double* d_nat);
 int iq_doubles_per_cell();
 int asm_max_rows();
+int launch_fluid_probe(opmhip_ctx* c, int pr, int sr, int n, const double* d_in, double* d_out);
 int asm_threads();
 void launch_vector_kernels_once(opmhip_ctx* c);
 

@@ -1,0 +1,199 @@
+"""Hydrostatic equilibration of a black-oil model (EQUIL keyword): phase pressures, saturations and Rs per cell.
+
+Deck-side input generation for the hot path, a restatement of the reference's
+Opm::EQUIL::DeckDependent::InitialStateComputer for one equilibration region with live oil, dry gas and water:
+
+  ebos/equil/initstateequil.hh  :79-147   RK4IVP (fixed-step RK4 + Hermite evaluation)
+                                :150-285  PhasePressODE::Water / Oil / Gas  (dp/dz = rho(z, p) g)
+                                :596-723  PressureTable::equil_WOG / equil_GOW / equil_OWG (which phase starts at the datum)
+                                :880-893, 1150-1330 PhaseSaturations (capillary-pressure inversion, overlapping transition zones,
+                                          pressure corrections at the saturation end points)
+                                :1985-2012 equilibrateCellCentres (EQUIL item 9 = 0)
+  ebos/equil/equilibrationhelpers.hh :186-254, 469-537 RsVD, RsSatAtContact ; :730-960 satFromPc, satFromSumOfPcs, satFromDepth
+
+The fluid and saturation functions are NOT restated here: `props.probe(p, rs, sw, sg)` evaluates them - on the device
+through capi.HipFluid (opmhip_fluid_probe), or, in tests, through the CPU oracle - so that the numbers pinned by the
+reference's tests/test_equil.cc pin those very functions.
+"""
+import numpy as np
+
+NSAMPLE = 2000  # PressureTable's default number of RK4 intervals per direction (initstateequil.hh:302)
+INVBW, INVBG, INVBO, RSSAT, PCOW, PCGO = range(6)
+
+
+class RK4IVP:
+    """y' = f(x, y), y(span[0]) = y0 on N equal steps; evaluation by the cubic Hermite of the reference (:120-136)"""
+
+    def __init__(self, f, span, y0, N):
+        self.N, self.span = N, span
+        h = self.h = (span[1] - span[0]) / N
+        y, fv = [y0], [f(span[0], y0)]
+        for i in range(N):
+            x = span[0] + i * h
+            yi, k1 = y[-1], fv[i]
+            k2 = f(x + h / 2, yi + h / 2 * k1)
+            k3 = f(x + h / 2, yi + h / 2 * k2)
+            k4 = f(x + h, yi + h * k3)
+            y.append(yi + h / 6 * (k1 + 2 * (k2 + k3) + k4))
+            fv.append(f(x + h, y[-1]))
+        self.y, self.f = y, fv
+
+    def __call__(self, x):
+        h = self.h
+        i = int((x - self.span[0]) / h)
+        t = (x - (self.span[0] + i * h)) / h
+        i = min(max(i, 0), self.N - 1)
+        y0, y1, f0, f1 = self.y[i], self.y[i + 1], self.f[i], self.f[i + 1]
+        u = (1 - 2 * t) * (y1 - y0)
+        u += h * ((t - 1) * f0 + t * f1)
+        u *= t * (t - 1)
+        u += (1 - t) * y0 + t * y1
+        return u
+
+
+class PressureFunction:
+    def __init__(self, ode, depth0, p0, span, nsample=NSAMPLE):
+        self.depth0, self.p0 = depth0, p0
+        self.up = RK4IVP(ode, (depth0, span[0]), p0, nsample)
+        self.down = RK4IVP(ode, (depth0, span[1]), p0, nsample)
+
+    def __call__(self, depth):
+        if depth < self.depth0:
+            return self.up(depth)
+        if depth > self.depth0:
+            return self.down(depth)
+        return self.p0
+
+
+class RsSatAtContact:
+    """min(RsSat(p), RsSat(p at the gas-oil contact)); the saturated value where free gas is present (:469-537)"""
+
+    def __init__(self, props, p_contact):
+        self.props = props
+        self.rs_contact = self.sat_rs(p_contact)
+
+    def sat_rs(self, p):
+        return float(self.props.probe(p)[0, RSSAT])
+
+    def __call__(self, depth, p, sat_gas=0.0):
+        if sat_gas > 0.0:
+            return self.sat_rs(p)
+        return min(self.sat_rs(p), self.rs_contact)
+
+
+class RsVD:
+    """Rs from a depth table (RSVD), capped by RsSat(p) (:186-254)"""
+
+    def __init__(self, props, depth, rs):
+        self.props, self.d, self.rs = props, np.asarray(depth, float), np.asarray(rs, float)
+
+    def __call__(self, depth, p, sat_gas=0.0):
+        sat = float(self.props.probe(p)[0, RSSAT])
+        if sat_gas > 0.0:
+            return sat
+        if self.d[0] > depth:
+            return float(self.rs[0])
+        if self.d[-1] < depth:
+            return float(self.rs[-1])
+        return min(sat, float(np.interp(depth, self.d, self.rs)))
+
+
+def equilibrate(props, rho_ref, rec, cell_depth, z_span, sat_limits, grav=9.80665, rs_func=None, nsample=NSAMPLE):
+    """props.probe(p, rs, sw, sg) -> (n, 8) (capi.HipFluid layout); rho_ref = (oil, water, gas) surface densities;
+    rec = dict(datum, pressure, zwoc, pcow_woc, zgoc, pcgo_goc); cell_depth[]: centre depths; z_span = (top, bottom) of the
+    region's cells; sat_limits = dict(Swl, Swu, Sgl, Sgu) (unscaled end points of the saturation tables).
+    -> dict(pw, po, pg, sw, so, sg, rs) arrays over the cells."""
+    rho_o, rho_w, rho_g = rho_ref
+    if rs_func is None:
+        if rec["zgoc"] != rec["datum"]:
+            raise ValueError("without an RSVD table the datum depth must be at the gas-oil contact")
+        rs_func = RsSatAtContact(props, rec["pressure"])
+
+    def f_water(z, p):
+        return float(props.probe(p)[0, INVBW]) * rho_w * grav
+
+    def f_oil(z, p):
+        rs = rs_func(z, p)
+        b = float(props.probe(p, rs=rs)[0, INVBO])     # the probe switches to the saturated curve where rs >= RsSat(p)
+        return (b * rho_o + rs * b * rho_g) * grav
+
+    def f_gas(z, p):
+        return float(props.probe(p)[0, INVBG]) * rho_g * grav
+
+    span = (min(z_span[0], rec["zgoc"], rec["zwoc"]), max(z_span[1], rec["zgoc"], rec["zwoc"]))
+    mk = lambda ode, z0, p0: PressureFunction(ode, z0, p0, span, nsample)
+    if rec["datum"] > rec["zwoc"]:      # datum in the water zone
+        wat = mk(f_water, rec["datum"], rec["pressure"])
+        oil = mk(f_oil, rec["zwoc"], wat(rec["zwoc"]) + rec["pcow_woc"])
+        gas = mk(f_gas, rec["zgoc"], oil(rec["zgoc"]) + rec["pcgo_goc"])
+    elif rec["datum"] < rec["zgoc"]:    # datum in the gas zone
+        gas = mk(f_gas, rec["datum"], rec["pressure"])
+        oil = mk(f_oil, rec["zgoc"], gas(rec["zgoc"]) - rec["pcgo_goc"])
+        wat = mk(f_water, rec["zwoc"], oil(rec["zwoc"]) - rec["pcow_woc"])
+    else:                               # datum in the oil zone
+        oil = mk(f_oil, rec["datum"], rec["pressure"])
+        wat = mk(f_water, rec["zwoc"], oil(rec["zwoc"]) - rec["pcow_woc"])
+        gas = mk(f_gas, rec["zgoc"], oil(rec["zgoc"]) + rec["pcgo_goc"])
+
+    Swl, Swu, Sgl, Sgu = (sat_limits[k] for k in ("Swl", "Swu", "Sgl", "Sgu"))
+    pcow = lambda sw: float(props.probe(1e5, sw=sw)[0, PCOW])
+    pcgo = lambda sg: float(props.probe(1e5, sg=sg)[0, PCGO])
+
+    def root(fun, s0, s1):
+        """zero of a monotone function with fun(s0) > 0 > fun(s1) (RegulaFalsiBisection to 1e-10 in the reference)"""
+        f0, f1 = fun(s0), fun(s1)
+        if f0 <= 0.0:
+            return s0
+        if f1 >= 0.0:
+            return s1
+        a, b, fa, fb = s0, s1, f0, f1
+        for _ in range(200):
+            m = 0.5 * (a + b)
+            fm = fun(m)
+            if fm > 0.0:
+                a, fa = m, fm
+            else:
+                b, fb = m, fm
+            if abs(b - a) < 1e-13:
+                break
+        return 0.5 * (a + b)
+
+    def sat_from_pc(pc_of_s, smin, smax, target, increasing):
+        s0, s1 = (smax, smin) if increasing else (smin, smax)
+        return root(lambda s: pc_of_s(s) - target, s0, s1)
+
+    n = len(cell_depth)
+    out = {k: np.zeros(n) for k in ("pw", "po", "pg", "sw", "so", "sg", "rs")}
+    const_pcow = abs(pcow(Swl) - pcow(Swu)) < np.finfo(float).eps
+    const_pcgo = abs(pcgo(Sgl) - pcgo(Sgu)) < np.finfo(float).eps
+    for c, z in enumerate(cell_depth):
+        po, pg, pw = oil(z), gas(z), wat(z)
+        # water: dPcow/dSw <= 0 ; gas: dPcgo/dSg >= 0
+        if const_pcow:
+            sw = Swl if z < rec["zwoc"] else Swu
+        else:
+            sw = sat_from_pc(pcow, Swl, Swu, po - pw, increasing=False)
+        if const_pcgo:
+            sg = Sgu if z < rec["zgoc"] else Sgl
+        else:
+            sg = sat_from_pc(pcgo, Sgl, Sgu, pg - po, increasing=True)
+        if sg + sw > 1.0:   # overlapping transition zones: gas-water contact, sw from the sum of both capillary pressures
+            pcgw = pg - pw
+            sw = root(lambda s: pcow(s) + pcgo(1.0 - s) - pcgw, Swl, Swu)
+            sg = 1.0 - sw
+            po = pg - pcgo(sg)
+        so = 1.0 - sw - sg
+        # pressure corrections at the saturation end points (accountForScaledSaturations)
+        thr = 1.0e-6
+        if sw + thr > Swu:
+            po = pw + pcow(Swu)
+        elif sg + thr > Sgu:
+            po = pg - pcgo(Sgu)
+        if sg - thr < Sgl:
+            pg = po + pcgo(Sgl)
+        if sw - thr < Swl:
+            pw = po - pcow(Swl)
+        out["pw"][c], out["po"][c], out["pg"][c] = pw, po, pg
+        out["sw"][c], out["so"][c], out["sg"][c] = sw, so, sg
+        out["rs"][c] = rs_func(z, po, sg)
+    return out

@@ -297,6 +297,30 @@ FluidInput to_input(const orc_fluid_desc* d) {
 
 extern "C" {
 
+// point evaluation of the fluid-system / saturation functions, same output layout as opmhip_fluid_probe:
+// out[8 i ..] = 1/B_w(p), 1/B_g(p), 1/B_o(p, rs) (saturated curve where rs >= RsSat(p)), RsSat(p), pcow(sw), pcgo(sg),
+// mu_o(p, rs), mu_g(p)
+int orc_fluid_probe(const orc_fluid_desc* d, int pr, int sr, int n, const double* p, const double* rs, const double* sw,
+                    const double* sg, double* out) {
+    Fluid F;
+    F.init(to_input(d));
+    const OilPvt& O = F.oil[pr];
+    for (int i = 0; i < n; ++i) {
+        double* o = out + (size_t)i * 8;
+        o[0] = F.water[pr].invB(p[i]);
+        o[1] = F.gas[pr].invB(p[i]);
+        o[3] = O.rsSat(p[i]);
+        if (rs[i] >= o[3]) { o[2] = O.invBSat(p[i]); o[6] = O.viscositySat(p[i]); }
+        else { o[2] = O.invB(p[i], rs[i]); o[6] = O.viscosity(p[i], rs[i]); }
+        double pC[3];
+        F.sat[sr].capillaryPressures(pC, sw[i], sg[i]);
+        o[4] = -pC[0];
+        o[5] = pC[2];
+        o[7] = F.gas[pr].viscosity(p[i]);
+    }
+    return 0;
+}
+
 // oil PVT probe used to pin LiveOilPvt against tests/test_norne_pvt.cpp:
 // for each point: RsSat(p); if rs >= RsSat -> saturated mu, 1/B at p ; else mu(p, rs), 1/B(p, rs)
 int orc_oil_pvt_probe(const orc_fluid_desc* d, int region, int n, const double* rs, const double* p, double* mu,

@@ -261,6 +261,24 @@ class OracleAsHipModel:
         self.om.set_state(*self._prev)
 
 
+class OracleFluid:
+    """the oracle's property functions behind the same probe() as capi.HipFluid"""
+
+    def __init__(self, oracle, fluid):
+        self.o, self.fluid = oracle, fluid
+        self._fd = fluid.desc()
+        oracle.lib.orc_fluid_probe.argtypes = [_vp, C.c_int, C.c_int, C.c_int, _d, _d, _d, _d, _d]
+
+    def probe(self, p, rs=0.0, sw=0.0, sg=0.0, pvt_region=0, sat_region=0):
+        p = np.atleast_1d(np.asarray(p, np.float64))
+        n = len(p)
+        a = [np.ascontiguousarray(np.broadcast_to(np.asarray(v, np.float64), (n,))) for v in (p, rs, sw, sg)]
+        out = np.empty(n * 8)
+        rc = self.o.lib.orc_fluid_probe(C.addressof(self._fd), pvt_region, sat_region, n, a[0], a[1], a[2], a[3], out)
+        assert rc == 0
+        return out.reshape(n, 8)
+
+
 def oil_pvt_probe(oracle, fluid, region, rs, p):
     L = oracle.lib
     L.orc_oil_pvt_probe.argtypes = [_vp, C.c_int, C.c_int, _d, _d, _d, _d, _d]
