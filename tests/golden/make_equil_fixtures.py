@@ -69,8 +69,46 @@ def liveoil():
         expected=expected_liveoil())
 
 
+def dead_oil_case(deck, test_name, next_test, gravity, sat_names, lines):
+    """A PVDO (dead oil) deck of the same family; the oil formation-volume factor travels as a table of its own"""
+    k = tokenize_sections(os.path.join(REF, "tests", deck))
+    U = METRIC
+    pvtw, dens, eq = k["PVTW"][0], k["DENSITY"][0], k["EQUIL"][0]
+    dz = [v * U["length"] for v in k["DZV"][0]]
+    with open(os.path.join(REF, "tests/test_equil.cc")) as f:
+        txt = f.read()
+    body = txt[txt.index("BOOST_AUTO_TEST_CASE(%s)" % test_name):txt.index("BOOST_AUTO_TEST_CASE(%s)" % next_test)]
+    num = r"[-+]?\d+\.?\d*(?:[eE][-+]?\d+)?"
+    vec = lambda name: [float(t) for t in re.findall(num, re.search(name + r"\s*=\s*\{(.*?)\};", body, re.S).group(1))]
+    pr = {}
+    for name, which, val in re.findall(r"BOOST_CHECK_CLOSE\(pressures\[FluidSystem::(\w+)PhaseIdx\]\s*\[(\w+)\s*\]\s*,\s*(" + num + r")\s*,\s*reltol\);", body):
+        pr["p%s_%s" % (name[0], which)] = float(val)
+    exp = dict(source="tests/test_equil.cc:%s (%s)" % (lines, test_name), reltol_percent=1.0e-4, **pr)
+    for key, nm in zip(("sw", "so", "sg"), ("water", "oil", "gas")):
+        exp[key] = vec(sat_names + r"\[FluidSystem::" + nm + r"PhaseIdx\]")
+    rock = k.get("ROCK", [[1.0, 0.0]])[0]
+    return dict(
+        source="tests/%s (METRIC units converted to SI); dead oil (PVDO), no dissolved gas; EQUIL item 9 = 0" % deck,
+        gravity=gravity,
+        pvtw=dict(p_ref=pvtw[0] * U["pressure"], bw_ref=pvtw[1], cw=pvtw[2] * U["compressibility"], mu_ref=pvtw[3] * U["viscosity"],
+                  cv=pvtw[4] * U["compressibility"]),
+        rock=dict(p_ref=rock[0] * U["pressure"], cr=rock[1] * U["compressibility"]),
+        density=dict(oil=dens[0] * U["density"], water=dens[1] * U["density"], gas=dens[2] * U["density"]),
+        swof=[[r[0], r[1], r[2], r[3] * U["pressure"]] for r in table(k["SWOF"][0], 4)],
+        sgof=[[r[0], r[1], r[2], r[3] * U["pressure"]] for r in table(k["SGOF"][0], 4)],
+        pvdg=[[r[0] * U["pressure"], r[1] * U["gas_fvf"], r[2] * U["viscosity"]] for r in table(k["PVDG"][0], 3)],
+        pvdo=[[r[0] * U["pressure"], r[1] * U["oil_fvf"], r[2] * U["viscosity"]] for r in table(k["PVDO"][0], 3)],
+        grid=dict(nz=len(dz), dz=dz, tops=(k["TOPS"][0][0] if "TOPS" in k else k["DEPTHZ"][0][0]) * U["length"]),
+        equil=dict(datum=eq[0] * U["length"], pressure=eq[1] * U["pressure"], zwoc=eq[2] * U["length"], pcow_woc=eq[3] * U["pressure"],
+                   zgoc=eq[4] * U["length"], pcgo_goc=eq[5] * U["pressure"], accuracy=int(eq[8])),
+        expected=exp)
+
+
 if __name__ == "__main__":
-    out = dict(liveoil=liveoil())
+    out = dict(liveoil=liveoil(),
+               capillary=dead_oil_case("equil_capillary.DATA", "DeckWithCapillary", "DeckWithCapillaryOverlap", 10.0, r"\bs", "556-594"),
+               capillary_overlap=dead_oil_case("equil_capillary_overlap.DATA", "DeckWithCapillaryOverlap", "DeckWithLiveOil", 9.80665,
+                                               r"s_opm", "596-654"))
     path = os.path.join(ROOT, "tests", "golden", "equil.json")
     with open(path, "w") as f:
         json.dump(out, f, indent=1)

@@ -65,3 +65,50 @@ def test_rk4_ivp_matches_closed_form():
     # integration towards smaller x (the "Up" direction of the pressure tables)
     up = pkg.equil.RK4IVP(lambda x, y: 3.0, (10.0, 4.0), 7.0, 50)
     assert abs(up(6.0) - (7.0 + 3.0 * (6.0 - 10.0))) < 1e-12
+
+
+class DeadOilProps:
+    """PVDO decks: the oil formation-volume factor is a table of its own (DeadOilPvt: 1/B linear in p, extrapolated);
+    water, gas and both capillary pressures still come from the wrapped probe"""
+
+    def __init__(self, inner, pvdo):
+        self.inner = inner
+        t = np.asarray(pvdo, float)
+        self.p, self.invb = t[:, 0], 1.0 / t[:, 1]
+
+    def probe(self, p, rs=0.0, sw=0.0, sg=0.0, **kw):
+        out = self.inner.probe(p, rs=0.0, sw=sw, sg=sg, **kw).copy()
+        pp = np.atleast_1d(np.asarray(p, float))
+        slope = (self.invb[-1] - self.invb[-2]) / (self.p[-1] - self.p[-2]) if len(self.p) > 1 else 0.0
+        lo = (self.invb[1] - self.invb[0]) / (self.p[1] - self.p[0]) if len(self.p) > 1 else 0.0
+        v = np.interp(pp, self.p, self.invb)
+        v = np.where(pp > self.p[-1], self.invb[-1] + slope * (pp - self.p[-1]), v)
+        v = np.where(pp < self.p[0], self.invb[0] + lo * (pp - self.p[0]), v)
+        out[:, 2] = v
+        return out
+
+
+@pytest.mark.parametrize("name", ["capillary", "capillary_overlap"])
+def test_dead_oil_decks(orc, name):
+    """tests/test_equil.cc DeckWithCapillary (:556-594) and DeckWithCapillaryOverlap (:596-654): regular and overlapping
+    transition zones; pins the water / gas densities and the capillary-pressure inversion once more"""
+    with open(os.path.join(GOLDEN, "equil.json")) as f:
+        d = json.load(f)[name]
+    w = d["pvtw"]
+    dummy_pvto = [dict(rs=0.0, p=[1e5, 2e5], bo=[1.0, 0.999], mu=[1e-3, 1e-3]), dict(rs=100.0, p=[200e5, 300e5], bo=[1.2, 1.19], mu=[1e-3, 1e-3])]
+    fl = pkg.fluid.Fluid([dict(pvtw=[w["p_ref"], w["bw_ref"], w["cw"], w["mu_ref"], w["cv"]],
+                               density=[d["density"]["oil"], d["density"]["water"], d["density"]["gas"]], pvdg=d["pvdg"], pvto=dummy_pvto)],
+                         [dict(swof=d["swof"], sgof=d["sgof"])])
+    dz = np.array(d["grid"]["dz"])
+    top = d["grid"]["tops"] + np.concatenate([[0.0], np.cumsum(dz)[:-1]])
+    centre = top + 0.5 * dz
+    limits = dict(Swl=d["swof"][0][0], Swu=d["swof"][-1][0], Sgl=d["sgof"][0][0], Sgu=d["sgof"][-1][0])
+    rho = (d["density"]["oil"], d["density"]["water"], d["density"]["gas"])
+    props = DeadOilProps(oracle_bind.OracleFluid(orc, fl), d["pvdo"])
+    r = pkg.equil.equilibrate(props, rho, d["equil"], centre, (float(top[0]), float(top[-1] + dz[-1])), limits, grav=d["gravity"],
+                              rs_func=lambda z, p, sat_gas=0.0: 0.0)
+    e = d["expected"]
+    rel = e["reltol_percent"] / 100.0
+    np.testing.assert_allclose([r["pw"][0], r["pw"][-1], r["po"][-1]], [e["pw_first"], e["pw_last"], e["po_last"]], rtol=rel)
+    for k in ("sw", "so", "sg"):
+        np.testing.assert_allclose(r[k], e[k], rtol=rel, atol=1e-12)
