@@ -292,8 +292,9 @@ int opmhip_set_halo(opmhip_ctx* ctx, long long global_cells, int nneigh, const i
 /* Device-side timing per kernel class with HIP events recorded on the context's own stream, so that bench.py can
  * state the average launch duration of a kernel over its timed region (the reference prints the same split at
  * verbosity >= 3/4: bda/cusparseSolverBackend.cu:303-308, bda/openclSolverBackend.cpp:451-459).
- * classes: 0 SpMV, 1 ILU0 apply (all sweeps of one M^-1), 2 ILU0 factorisation, 3 BiCGStab vector kernels (one
- * group between two operator applications), 4 assembly kernel, 5 intensive-quantity update, 6 convergence. */
+ * classes: 0 SpMV, 1 ILU0 apply (all sweeps of one M^-1; with the line-coloured ordering the first sweep also carries
+ * the BiCGStab p- / (r, x)-update), 2 ILU0 factorisation, 3 the remaining BiCGStab vector / reduction kernels (one
+ * scope between two operator applications), 4 assembly kernel, 5 intensive-quantity update, 6 convergence. */
 #define OPMHIP_PROF_CLASSES 7
 /* on = 0: off; 1: every scope; k > 1: the linear-solver classes (0, 1, 3) are recorded in every k-th solve_system call
  * only - an event record costs a few microseconds of bubble on the stream and a BiCGStab iteration holds seven of
