@@ -234,7 +234,11 @@ def main():
         "roofline": {"bound": "hbm", "kernel": "k_spmv (block-CSR SpMV, 3x3 double blocks)", "achieved": sp["algorithmic_GBps"],
                      "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": (sp["algorithmic_GBps"] / HBM_PEAK_GBS) if sp["algorithmic_GBps"] == sp["algorithmic_GBps"] else None,
                      "traffic": traffic, "traffic_unit": "bytes per launch (L2 fabric side; FETCH_SIZE x 2 + WRITE_SIZE, KiB -> B)",
-                     "traffic_source": traffic_src, "avg_launch_ms": sp["avg_ms"], "algorithmic_bytes_per_launch": B["spmv"]},
+                     "traffic_source": traffic_src, "avg_launch_ms": sp["avg_ms"], "algorithmic_bytes_per_launch": B["spmv"],
+                     # the kernel also forms the BiCGStab scalar products (y.w0, y.y) on the fly; their second operand is 24 B
+                     # per row of reads that SURVEY's plain-SpMV byte count does not contain - stated, not counted in `achieved`
+                     "fused_dot_operand_bytes_per_launch": 24 * Nb,
+                     "achieved_incl_fused_dot": round((B["spmv"] + 24 * Nb) / sp["avg_ms"] / 1e6, 1) if sp["avg_ms"] == sp["avg_ms"] else None},
     }
     if rank == 0 and world == 1 and not a.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(pkg, case, src)
