@@ -143,3 +143,94 @@ def test_rccl_communicator_single_rank(pkg):
     out = (C.c_double * 2)()
     s._check(L.opmhip_comm_selftest(s._h, out))
     assert (out[0], out[1]) == (1.0, 2.0)
+
+
+def irregular_global_case(pkg, Nb=3000, seed=41):
+    """an unstructured three-phase case: random sparse symmetric connectivity, random face and cell data"""
+    rng = np.random.default_rng(seed)
+    nbrs = [set([i]) for i in range(Nb)]
+    for i in range(Nb):
+        for o in (1, 13, 170):
+            if i + o < Nb and rng.random() < 0.8:
+                nbrs[i].add(i + o)
+                nbrs[i + o].add(i)
+    for i in np.flatnonzero(rng.random(Nb) < 0.05):
+        j = int(rng.integers(0, Nb))
+        if j != i:
+            nbrs[int(i)].add(j)
+            nbrs[j].add(int(i))
+    rp = np.zeros(Nb + 1, np.int32)
+    cols = []
+    for i in range(Nb):
+        cols.extend(sorted(nbrs[i]))
+        rp[i + 1] = len(cols)
+    ci = np.array(cols, np.int32)
+    row = np.repeat(np.arange(Nb), np.diff(rp))
+    lo, hi = np.minimum(row, ci), np.maximum(row, ci)
+    _, inv = np.unique(lo.astype(np.int64) * Nb + hi, return_inverse=True)
+    trans = np.exp(rng.normal(np.log(5e-13), 1.0, inv.max() + 1))[inv]
+    area = rng.uniform(50.0, 400.0, inv.max() + 1)[inv]
+    trans[row == ci] = 0.0
+    area[row == ci] = 0.0
+    fl = pkg.fluid.spe1_fluid()[0]
+    depth = 2500.0 + 300.0 * np.sort(rng.random(Nb))
+    p = 250e5 + 7000.0 * (depth - 2500.0) * (1.0 + rng.uniform(-0.01, 0.01, Nb))
+    meaning = np.where(depth < np.median(depth), pkg.decks.SW_PO_SG, pkg.decks.SW_PO_RS).astype(np.uint8)
+    pv = np.zeros((Nb, 3))
+    pv[:, 0] = 0.2 + rng.uniform(-0.02, 0.02, Nb)
+    pv[:, 1] = p
+    pv[:, 2] = np.where(meaning == pkg.decks.SW_PO_SG, 0.1 + rng.uniform(-0.02, 0.02, Nb), 0.8 * pkg.decks.rs_sat(fl, p))
+    return dict(Nb=Nb, rowptr=rp, col=ci, trans=np.ascontiguousarray(trans), area=np.ascontiguousarray(area), poro=rng.uniform(0.1, 0.3, Nb),
+                volume=rng.uniform(500.0, 4000.0, Nb), depth=np.ascontiguousarray(depth), fluid=fl, pv=np.ascontiguousarray(pv.reshape(-1)),
+                meaning=meaning)
+
+
+@pytest.mark.parametrize("reorder", ["graph_coloring", "line_coloring"])
+def test_dd_irregular_graph_three_ranks(pkg, orc, reorder):
+    """Three subdomains (not a power of two) of an unstructured graph with scattered ownership: ragged halos, every rank
+    a neighbour of every other.  Owned rows of the assembly bit for bit against the single-domain oracle, block-Jacobi
+    solve with the oracle's iteration count."""
+    world = 3
+    g = irregular_global_case(pkg)
+    Nb = g["Nb"]
+    rng = np.random.default_rng(8)
+    owner = ((np.arange(Nb) // 97 + rng.integers(0, 2, Nb) * (rng.random(Nb) < 0.03)) % world).astype(np.int32)
+    o = oracle_bind.OracleModel(orc, g)
+    o.set_state(g["pv"], g["meaning"])
+    dt = 86400.0
+    jo, ro = o.assemble(dt, 0)
+    group = "i" + uuid.uuid4().hex
+    parts = []
+    for r in range(world):
+        lp = pkg.ras.local_problem(g["rowptr"], g["col"], owner, r)
+        cells = lp["cells"]
+        parts.append(dict(Nb=lp["Nown"], Nghost=lp["Nghost"], Nloc=lp["Nown"] + lp["Nghost"], rowptr=lp["rows"], col=lp["cols"],
+                          trans=np.ascontiguousarray(g["trans"][lp["entry"]]), area=np.ascontiguousarray(g["area"][lp["entry"]]),
+                          poro=np.ascontiguousarray(g["poro"][cells]), volume=np.ascontiguousarray(g["volume"][cells]),
+                          depth=np.ascontiguousarray(g["depth"][cells]), fluid=g["fluid"],
+                          pv=np.ascontiguousarray(g["pv"].reshape(-1, 3)[cells].reshape(-1)), meaning=np.ascontiguousarray(g["meaning"][cells]),
+                          gids=lp["gids"], halo=lp, global_cells=Nb))
+
+    def rank_fn(r):
+        c = parts[r]
+        m = pkg.capi.HipModel(c, comm=("loopback", world, r, group), reorder=reorder)
+        m.set_state(c["pv"], c["meaning"])
+        j, res = m.assemble(dt, 0)
+        sol = m.solve_jacobian_system()
+        return j, res, sol.it, sol.converged, m.get_result()
+
+    outs = run_ranks(world, rank_fn)
+    for r, (j, res, it, ok, x) in enumerate(outs):
+        c = parts[r]
+        gi = c["gids"][:c["Nb"]]
+        assert np.array_equal(res.reshape(-1, 3)[:c["Nb"]], ro.reshape(-1, 3)[gi])
+        assert np.array_equal(j.reshape(-1, 9), jo.reshape(-1, 9)[c["halo"]["entry"]])
+        assert ok
+    # all ranks agree on the iteration count, and together they hold a solution of the global system
+    assert len({o_[2] for o_ in outs}) == 1
+    x_glob = np.zeros((Nb, 3))
+    for r, (_, _, _, _, x) in enumerate(outs):
+        c = parts[r]
+        x_glob[c["gids"][:c["Nb"]]] = x.reshape(-1, 3)[:c["Nb"]]
+    A_x = orc.spmv(Nb, g["rowptr"], g["col"], jo, x_glob.reshape(-1))
+    assert np.linalg.norm(ro - A_x) < 1e-2 * np.linalg.norm(ro) * (1 + 1e-9)
