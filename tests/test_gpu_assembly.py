@@ -218,3 +218,92 @@ def test_adaptive_time_stepping_matches_oracle_history(pkg, orc):
     # the chopped step is a diverging Newton sequence: rounding differences of the Krylov dot products (reduction order)
     # are amplified there, so the linear iteration totals agree closely but not exactly
     assert abs(sm.report.total_linear_iterations - so.report.total_linear_iterations) <= 0.05 * so.report.total_linear_iterations
+
+
+def two_region_fluid(pkg):
+    import copy
+    fl, d = pkg.fluid.spe1_fluid()
+    p0, s0 = fl.pvt[0], fl.sat[0]
+    p1 = copy.deepcopy(p0)
+    p1["density"] = [d["density"]["oil"] * 1.07, d["density"]["water"] * 1.02, d["density"]["gas"] * 0.9]
+    p1["pvtw"] = [p0["pvtw"][0], p0["pvtw"][1] * 1.01, p0["pvtw"][2] * 1.3, p0["pvtw"][3] * 0.8, p0["pvtw"][4]]
+    p1["pvdg"] = [[r[0], r[1] * 1.04, r[2] * 1.15] for r in p0["pvdg"]]
+    for n in p1["pvto"]:
+        n["bo"] = [b * 1.03 for b in n["bo"]]
+        n["mu"] = [m * 1.25 for m in n["mu"]]
+        n["rs"] = n["rs"] * 0.93
+    s1 = dict(swof=[[r[0], 0.8 * r[1], 0.9 * r[2], 2.0 * r[3]] for r in s0["swof"]],
+              sgof=[[r[0], 0.7 * r[1], 0.85 * r[2], 1.5 * r[3]] for r in s0["sgof"]])
+    return pkg.fluid.Fluid([p0, p1], [s0, s1], rock_pref=fl.rock_pref, rock_cr=fl.rock_cr)
+
+
+@pytest.mark.parametrize("reorder", ["graph_coloring", "line_coloring"])
+def test_regions_threshold_pressures_rs_cap_and_source_derivatives(pkg, orc, reorder):
+    """The inputs the plain cases leave at their defaults, all at once: two PVTNUM and two SATNUM regions, THPRES on a
+    third of the faces (eclfluxmodule.hh:269-290), a DRSDT-style cap on Rs below RsSat in some cells
+    (eclproblem.hh:1711-1732) and well-like source derivatives.  Bit for bit through assembly, update and switching."""
+    case = pkg.decks.cartesian_case(9, 8, 7, state="mixed", heterogeneous=True, fluid=two_region_fluid(pkg))
+    Nb, rp, ci = case["Nb"], case["rowptr"], case["col"]
+    rng = np.random.default_rng(77)
+    case["pvtnum"] = rng.integers(0, 2, Nb).astype(np.int32)
+    case["satnum"] = ((np.arange(Nb) // 9) % 2).astype(np.int32)
+    row = np.repeat(np.arange(Nb), np.diff(rp))
+    lo, hi = np.minimum(row, ci), np.maximum(row, ci)
+    _, inv = np.unique(lo.astype(np.int64) * Nb + hi, return_inverse=True)
+    th_face = np.where(rng.random(inv.max() + 1) < 0.33, rng.uniform(0.1e5, 3e5, inv.max() + 1), 0.0)
+    thpres = th_face[inv]
+    thpres[row == ci] = 0.0
+    case["thpres"] = np.ascontiguousarray(thpres)
+    p = case["pv"].reshape(-1, 3)[:, 1]
+    case["rsmax"] = np.where(rng.random(Nb) < 0.3, 0.6 * pkg.decks.rs_sat(case["fluid"], p), 1e30)
+    src = 1e-6 * rng.standard_normal((Nb, 3)) * (rng.random((Nb, 1)) < 0.05)
+    dsrc = 1e-13 * rng.standard_normal((Nb, 9)) * (rng.random((Nb, 1)) < 0.05)
+    m, o = both(pkg, orc, case, reorder=reorder)
+    for q in (m, o):
+        q.set_source(np.ascontiguousarray(src.reshape(-1)), np.ascontiguousarray(dsrc.reshape(-1)))
+    assert np.array_equal(m.iq(), o.iq())
+    dt = 3 * 86400.0
+    for it in range(3):
+        jm, rm = m.assemble(dt, it)
+        jo, ro = o.assemble(dt, it)
+        assert np.array_equal(rm, ro) and np.array_equal(jm, jo)
+        np.testing.assert_allclose(m.convergence(dt)[11:17], o.convergence(dt)[11:17], rtol=1e-9, atol=1e-14)
+        # the same update on both sides (so that the states stay bit-identical): a scaled random direction
+        dx = (rng.standard_normal((Nb, 3)) * np.array([0.05, 2e5, 0.05])).reshape(-1)
+        nm = m.update(dx, 1.0)
+        no = o.update(dx)
+        assert nm == no
+        pm, mm = m.get_state()
+        po, mo = o.get_state()
+        assert np.array_equal(mm, mo) and np.array_equal(pm, po)
+        assert np.array_equal(m.iq(), o.iq())
+    assert len(np.unique(mm)) == 2     # both meanings present after the switches
+
+
+@pytest.mark.parametrize("seed", [0, 1, 2])
+def test_states_outside_the_tables(pkg, orc, seed):
+    """Whatever a diverging Newton iterate can throw at the property functions: saturations outside [0, 1], pressures
+    far off the tables (extrapolation), Rs from zero to twice the saturated value, water-filled cells.  Intensive
+    quantities, Jacobian and residual stay bit-identical (NaNs, should any appear, in the same places)."""
+    case = pkg.decks.cartesian_case(7, 6, 5, state="mixed", heterogeneous=True)
+    Nb = case["Nb"]
+    rng = np.random.default_rng(100 + seed)
+    pv = np.zeros((Nb, 3))
+    pv[:, 0] = rng.uniform(-0.1, 1.2, Nb)
+    pv[:, 1] = np.exp(rng.uniform(np.log(5e5), np.log(9e7), Nb))
+    meaning = rng.integers(0, 2, Nb).astype(np.uint8)
+    rs_hi = 2.0 * pkg.decks.rs_sat(case["fluid"], pv[:, 1])
+    pv[:, 2] = np.where(meaning == pkg.decks.SW_PO_SG, rng.uniform(-0.1, 1.1, Nb), rng.uniform(0.0, 1.0, Nb) * np.maximum(rs_hi, 1.0))
+    pv[rng.random(Nb) < 0.05, 0] = 1.0
+    case["pv"], case["meaning"] = np.ascontiguousarray(pv.reshape(-1)), meaning
+    m, o = both(pkg, orc, case, reorder="line_coloring")
+    assert np.array_equal(m.iq(), o.iq(), equal_nan=True)
+    jm, rm = m.assemble(86400.0, 0)
+    jo, ro = o.assemble(86400.0, 0)
+    assert np.array_equal(rm, ro, equal_nan=True) and np.array_equal(jm, jo, equal_nan=True)
+    dx = (rng.standard_normal((Nb, 3)) * np.array([0.5, 5e6, 0.5])).reshape(-1)   # large: every chop and switch rule fires
+    assert m.update(dx, 1.0) == o.update(dx)
+    pm, mm = m.get_state()
+    po, mo = o.get_state()
+    assert np.array_equal(mm, mo) and np.array_equal(pm, po, equal_nan=True)
+    assert np.array_equal(m.iq(), o.iq(), equal_nan=True)
