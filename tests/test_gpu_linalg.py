@@ -263,3 +263,28 @@ def test_add_well_contributions_to_matrix(pkg, orc, reorder):
     s4.upload_system(v)
     with pytest.raises(pkg.capi.OpmHipError):
         s4.add_well_contributions(W)
+
+
+def test_contexts_give_their_memory_back(pkg):
+    """create / use / destroy in a loop: device memory returns to where it was (every allocation of a context is tracked
+    and freed by opmhip_destroy, including the pinned read-back ring and the profiler's events)"""
+    import gc
+    import torch
+    Nb, rp, ci, v = laplace_block_system(20, 20, 10, seed=3)
+    b = np.ones(3 * Nb)
+
+    def once():
+        s = pkg.capi.HipSolver(reorder="line_coloring")
+        s.profile_enable(1)
+        s.solve_system(Nb, rp, ci, v.copy(), b)
+        s.profile()
+        del s
+        gc.collect()
+    once()
+    torch.cuda.synchronize()
+    free0 = torch.cuda.mem_get_info()[0]
+    for _ in range(25):
+        once()
+    torch.cuda.synchronize()
+    free1 = torch.cuda.mem_get_info()[0]
+    assert free0 - free1 < 8 * 1024 * 1024, (free0, free1)
