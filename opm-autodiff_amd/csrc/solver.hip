@@ -1646,6 +1646,10 @@ int bicgstab(opmhip_ctx* c, opmhip_result* res) {
         mark_next = c->prof.used;
         if (h + 1 < nhalves && (rc = enqueue_half(c, h + 1))) return rc;
         if ((rc = wait_half(c, h, &norm, &norm_0))) return rc;
+        if (!std::isfinite(norm)) {  // a singular pivot: nothing can converge any more (the caller reports it)
+            prof_flush(c);
+            break;
+        }
         if (norm < tol * norm_0) {
             it = 0.5f * (float)(h + 1);
             prof_flush(c);

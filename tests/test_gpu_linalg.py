@@ -288,3 +288,44 @@ def test_contexts_give_their_memory_back(pkg):
     torch.cuda.synchronize()
     free1 = torch.cuda.mem_get_info()[0]
     assert free0 - free1 < 8 * 1024 * 1024, (free0, free1)
+
+
+def test_failure_statuses_of_the_backend_interface(pkg):
+    """bda::SolverStatus as the reference's back-ends report it: a pattern the analysis cannot use, and a factorisation
+    that meets a singular pivot (bda/BdaSolver.hpp:32-37; ISTLSolverEbos falls back to Dune on either)."""
+    Nb, rp, ci, v = laplace_block_system(5, 4, 3, seed=2)
+    b = np.ones(3 * Nb)
+    # analysis: a row without its diagonal block ("diagonal entry missing", ParallelOverlappingILU0.hpp:484-485)
+    keep = np.ones(len(ci), bool)
+    d7 = [k for k in range(rp[7], rp[7 + 1]) if ci[k] == 7][0]
+    keep[d7] = False
+    rp2 = np.concatenate([[0], np.cumsum(np.add.reduceat(keep.astype(int), rp[:-1]))]).astype(np.int32)
+    s = pkg.capi.HipSolver()
+    with pytest.raises(pkg.capi.OpmHipError) as e:
+        s.set_pattern(Nb, rp2, ci[keep])
+    assert e.value.code == pkg.capi.ANALYSIS_FAILED
+    # analysis: a row longer than one tile can stage
+    n = 400
+    nbr = [set([i]) for i in range(n)]
+    for j in range(1, 300):
+        nbr[0].add(j); nbr[j].add(0)
+    rpl = np.zeros(n + 1, np.int32); cl = []
+    for i in range(n):
+        cl.extend(sorted(nbr[i])); rpl[i + 1] = len(cl)
+    s = pkg.capi.HipSolver()
+    res = pkg.capi.Result()
+    import ctypes as C
+    vl = np.ascontiguousarray(np.tile(np.eye(3).reshape(-1), len(cl)))
+    bl = np.ones(3 * n)
+    cla = np.array(cl, np.int32)
+    rc = pkg.capi.lib().opmhip_solve_system(s._h, 3 * n, 9 * len(cl), 3, vl.ctypes.data_as(C.c_void_p), rpl.ctypes.data_as(C.c_void_p),
+                                            cla.ctypes.data_as(C.c_void_p), bl.ctypes.data_as(C.c_void_p), None, C.byref(res))
+    assert rc == pkg.capi.ANALYSIS_FAILED
+    # factorisation: a singular diagonal block (zero_diag_fix only repairs exact zeros ON the diagonal of the block)
+    v0 = v.copy()
+    dk = [k for k in range(rp[0], rp[0 + 1]) if ci[k] == 0][0]    # row 0 has no lower neighbours: its pivot is the block itself
+    v0[9 * dk:9 * dk + 9] = np.array([1.0, 2.0, 3.0, 2.0, 4.0, 6.0, 1.0, 1.0, 1.0])   # rank 2, determinant exactly 0
+    s = pkg.capi.HipSolver(maxit=50, reorder="level_scheduling")
+    with pytest.raises(pkg.capi.OpmHipError) as e:
+        s.solve_system(Nb, rp, ci, v0, b)
+    assert e.value.code == pkg.capi.CREATE_PRECONDITIONER_FAILED
