@@ -234,3 +234,35 @@ def test_dd_irregular_graph_three_ranks(pkg, orc, reorder):
         x_glob[c["gids"][:c["Nb"]]] = x.reshape(-1, 3)[:c["Nb"]]
     A_x = orc.spmv(Nb, g["rowptr"], g["col"], jo, x_glob.reshape(-1))
     assert np.linalg.norm(ro - A_x) < 1e-2 * np.linalg.norm(ro) * (1 + 1e-9)
+
+
+def test_dd_time_step_roll_back_restores_owned_and_ghost_cells(pkg):
+    """update_failed in a decomposed run: owned and ghost primary variables, meanings and intensive quantities of every
+    rank are those of the start of the time step again, with no communication (the saved time level holds the ghosts)."""
+    world, n = 2, 7
+    parts = [pkg.ras.cartesian_subdomain_case(n, world, r, state="mixed", heterogeneous=True, rate_scale=60.0) for r in range(world)]
+    group = "r" + uuid.uuid4().hex
+    dt = 20 * 86400.0
+
+    def rank_fn(r):
+        c = parts[r]
+        m = pkg.capi.HipModel(c, comm=("loopback", world, r, group), reorder="line_coloring")
+        m.set_state(c["pv"], c["meaning"])
+        m.set_source(c["source"])
+        m.advance_time_level()
+        iq0 = m.iq()
+        j0, r0 = m.assemble(dt, 0)
+        for it in range(3):
+            if it:
+                m.assemble(dt, it, fetch=False)
+            assert m.solve_jacobian_system().converged
+            m.update(None, 1.0)
+        pv1, _ = m.get_state()
+        m.update_failed()
+        pv2, mean2 = m.get_state()
+        j2, r2 = m.assemble(dt, 0)
+        return (not np.array_equal(pv1, c["pv"]), np.array_equal(pv2, c["pv"]), np.array_equal(mean2, c["meaning"]),
+                np.array_equal(m.iq(), iq0), np.array_equal(j2, j0) and np.array_equal(r2, r0))
+
+    for flags in run_ranks(world, rank_fn):
+        assert all(flags), flags
