@@ -84,3 +84,35 @@ def test_random_graph(pkg, orc, kind, n, seed, reorder):
         xo, ro = oracle_solve_in_order(orc, n, rp, ci, v, b, to, fr, tol=1e-8, maxit=200, w=w, mode=mode)
         assert res.converged and ro.converged and res.it == ro.it
         np.testing.assert_allclose(x, xo, rtol=1e-8, atol=1e-12)
+
+
+@pytest.mark.parametrize("chain_length", [1, 2, 3, 5, 13, 64, 128])
+@pytest.mark.parametrize("shape", [(3, 3, 140), (13, 7, 11), (1, 1, 300)])
+def test_line_colouring_chain_lengths(pkg, orc, shape, chain_length):
+    """chains of every length a tall grid allows (single rows up to the 128-step limit of a chain tile), remainders at
+    the column ends included: exact ILU0 of the permuted matrix, bit for bit"""
+    from helpers import laplace_block_system
+    n, rp, ci, v = laplace_block_system(*shape, seed=31)
+    rng = np.random.default_rng(chain_length)
+    b = rng.standard_normal(3 * n)
+    sol = pkg.capi.HipSolver(tolerance=1e-8, maxit=200, reorder="line_coloring", chain_length=chain_length)
+    res = sol.solve_system(n, rp, ci, v.copy(), b)
+    to, fr, rpc = sol.ordering()
+    rr, rc, rv = orc.reorder_matrix(n, rp, ci, v, to, fr)
+    luo = orc.ilu0_factor(n, rr, rc, rv)
+    assert np.array_equal(sol.ilu0_factor(), luo)
+    d = rng.standard_normal(3 * n)
+    vo = orc.ilu0_apply(n, rr, rc, luo, d.reshape(n, 3)[fr].reshape(-1), w=0.9, mode="post_scale")
+    assert np.array_equal(sol.ilu0_apply(d), vo.reshape(n, 3)[to].reshape(-1))
+    xo, ro = oracle_solve_in_order(orc, n, rp, ci, v, b, to, fr, tol=1e-8, maxit=200, w=0.9)
+    assert res.converged and res.it == ro.it
+    np.testing.assert_allclose(sol.get_result(), xo, rtol=1e-8, atol=1e-12)
+
+
+def test_line_colouring_rejects_chains_beyond_the_step_limit(pkg):
+    from helpers import laplace_block_system
+    n, rp, ci, v = laplace_block_system(1, 1, 300, seed=1)
+    sol = pkg.capi.HipSolver(reorder="line_coloring", chain_length=200)
+    with pytest.raises(pkg.capi.OpmHipError) as e:
+        sol.set_pattern(n, rp, ci)
+    assert e.value.code == pkg.capi.ANALYSIS_FAILED
