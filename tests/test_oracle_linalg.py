@@ -272,3 +272,18 @@ def test_greedy_colouring_properties_of_test_graphcoloring(orc):
         assert to[v] == nxt[color[v]]
         nxt[color[v]] += 1
     assert np.array_equal(fr[to], np.arange(N * N))
+
+
+def test_well_matrix_contribution_uses_the_transposed_product_of_test_multmatrixtransposed(orc):
+    """tests/test_multmatrixtransposed.cpp:47-58 pins Detail::multMatrixTransposed (A^T B) on a 3 x 3 example; the matrix
+    form of the well contributions is -C^T (D^-1 B) built from it (wells/StandardWell_impl.hpp:1688-1712).  With D = I
+    and the example's A, B as the first three rows of C and B, the one block of a one-cell system must be -A^T B."""
+    a3 = np.array([[1, 2, 3], [3, 4, 5], [6, 7, 8]], float)
+    b3 = np.array([[3, 4, 5], [5, 6, 7], [7, 8, 9]], float)
+    expect = np.array([[60, 70, 80], [75, 88, 101], [90, 106, 122]], float)
+    assert np.array_equal(a3.T @ b3, expect)
+    W = dict(numWells=1, val_pointers=np.array([0, 1], np.int32), Ccols=np.array([0], np.int32), Bcols=np.array([0], np.int32),
+             Cnnzs=np.ascontiguousarray(np.vstack([a3, np.zeros((1, 3))]).reshape(-1)),
+             Bnnzs=np.ascontiguousarray(np.vstack([b3, np.zeros((1, 3))]).reshape(-1)), Dnnzs=np.eye(4).reshape(-1).copy())
+    rc, v = orc.wells_add_to_matrix(1, np.array([0, 1], np.int32), np.array([0], np.int32), np.zeros(9), W)
+    assert rc == 0 and np.array_equal(v.reshape(3, 3), -expect)
