@@ -126,6 +126,7 @@ struct Profiler {
     size_t used = 0;                          //   point), start and end event
     int pending = -1;                         // scope whose end event is still to be recorded (shared with the next begin)
     bool lazy = false;                        // prof_end leaves the end to the next prof_begin (inside a linear solve)
+    int handoff = -1;                         // stop event of a kernel launched with its own events: starts the next scope
     static constexpr size_t CAP = 1 << 15;
     double total_ms[PROF_COUNT] = {0};
     long count[PROF_COUNT] = {0};
@@ -229,8 +230,19 @@ inline int prof_event(opmhip_ctx* c) {
     (void)hipEventRecord(P.ev[i], c->stream);
     return i;
 }
+// an event slot without recording it (for hipExtLaunchKernelGGL, which stamps kernel begin / end itself)
+inline int prof_event_slot(opmhip_ctx* c) {
+    Profiler& P = c->prof;
+    if (P.ev.size() <= P.ev_used) {
+        hipEvent_t e;
+        if (hipEventCreate(&e) != hipSuccess) return -1;
+        P.ev.push_back(e);
+    }
+    return (int)P.ev_used++;
+}
 inline void prof_flush(opmhip_ctx* c) {
     Profiler& P = c->prof;
+    P.handoff = -1;
     if (P.pending < 0) return;
     const int e = prof_event(c);
     if (e >= 0) P.e1[P.pending] = e; else P.cls[P.pending] = -1;
@@ -239,13 +251,31 @@ inline void prof_flush(opmhip_ctx* c) {
 inline int prof_begin(opmhip_ctx* c, int cls) {
     Profiler& P = c->prof;
     if (!P.enabled || P.suspended || P.used >= Profiler::CAP) { prof_flush(c); return -1; }
-    const int e = prof_event(c);
+    int e;
+    if (P.handoff >= 0) { e = P.handoff; P.handoff = -1; }   // the previous kernel's own stop event: no record needed
+    else e = prof_event(c);
     if (e < 0) return -1;
     if (P.pending >= 0) { P.e1[P.pending] = e; P.pending = -1; }
     if (P.cls.size() <= P.used) { P.cls.push_back(cls); P.e0.push_back(e); P.e1.push_back(-1); }
     const int slot = (int)P.used++;
     P.cls[slot] = cls; P.e0[slot] = e; P.e1[slot] = -1;
     return slot;
+}
+// A single kernel timed by its own dispatch (hipExtLaunchKernelGGL start / stop events: no extra packets on the stream,
+// kernel-exact like rocprofv3).  Returns false when profiling is off; else es / ee are the event slots to hand to the
+// launch.  The start event also closes a pending scope; the stop event will open the next one.
+inline bool prof_kernel_scope(opmhip_ctx* c, int cls, int* es, int* ee) {
+    Profiler& P = c->prof;
+    if (!P.enabled || P.suspended || P.used >= Profiler::CAP) return false;
+    *es = prof_event_slot(c);
+    *ee = prof_event_slot(c);
+    if (*es < 0 || *ee < 0) return false;
+    if (P.pending >= 0) { P.e1[P.pending] = *es; P.pending = -1; }
+    if (P.cls.size() <= P.used) { P.cls.push_back(cls); P.e0.push_back(*es); P.e1.push_back(*ee); }
+    const int slot = (int)P.used++;
+    P.cls[slot] = cls; P.e0[slot] = *es; P.e1[slot] = *ee;
+    P.handoff = P.lazy ? *ee : -1;
+    return true;
 }
 inline void prof_end(opmhip_ctx* c, int slot) {
     if (slot < 0) return;
