@@ -406,7 +406,7 @@ struct RegQ {
 };
 template <class IN, class EX>
 __device__ __forceinline__ void face_flux(const IN& in, const EX& ex, double trans, double faceArea,
-                                          double thpres, double zIn, double zEx, double Vin, double Vex, int I, int J, Ad flux[3]) {
+                                          double thpres, double zIn, double zEx, double Vin, double Vex, bool inLower, Ad flux[3]) {
     flux[0] = flux[1] = flux[2] = ad_const(0.0);
     const double distZ = zIn - zEx;
     const int comp[3] = {EQ_WATER, EQ_OIL, EQ_GAS};
@@ -426,7 +426,7 @@ __device__ __forceinline__ void face_flux(const IN& in, const EX& ex, double tra
         else if (dp.v < 0.0) upIn = true;
         else if (Vin > Vex) upIn = true;
         else if (Vin < Vex) upIn = false;
-        else upIn = (I < J);
+        else upIn = inLower;  // equal pressures and volumes: the lower GLOBAL index is upstream (eclfluxmodule.hh:303-314)
         if (fabs(dp.v) > thpres) {
             if (dp.v < 0.0) dp = dp + thpres; else dp = dp - thpres;
         } else continue;
@@ -463,6 +463,7 @@ int asm_threads() { return ASM_THREADS; }
 #endif
 struct EntryStatic {
     const double *trans, *area, *thpres;  // per entry, internal order
+    const unsigned char* lowFirst;        // per entry (I,J): 1 if the global (natural) index of I is below that of J
 };
 // FvBaseLinearizer::linearizeDomain.  tile t: rows [row0[t], row0[t+1]) ; its entries <= ASM_THREADS, rows <= ASM_MAX_ROWS.
 // The kernel was latency-bound (PMC: waves waiting 74 % of their life, ~18 dependent load rounds per lane through the
@@ -501,6 +502,7 @@ __global__ __launch_bounds__(ASM_THREADS) ASM_OCC void k_assemble(int ntiles, co
     bool isDiag = false;
     RegQ qJ;
     double trans = 0.0, area = 1.0, thp = 0.0, zI = 0.0, zJ = 0.0, VI = 0.0, VJ = 0.0;
+    bool lowI = false;
     if (tid < nent) {
         k = k0 + tid;
         lrow = srow[tid];
@@ -512,6 +514,7 @@ __global__ __launch_bounds__(ASM_THREADS) ASM_OCC void k_assemble(int ntiles, co
 #pragma unroll
             for (int i = 0; i < RQ_NF * 2; ++i) { const double2 v = g2[i]; qJ.r[2 * i] = v.x; qJ.r[2 * i + 1] = v.y; }
             trans = ES.trans[k]; area = ES.area[k]; thp = ES.thpres ? ES.thpres[k] : 0.0;
+            lowI = ES.lowFirst[k] != 0;
             zI = C.depth[I]; zJ = C.depth[J]; VI = C.volume[I]; VJ = C.volume[J];
         }
     }
@@ -520,9 +523,9 @@ __global__ __launch_bounds__(ASM_THREADS) ASM_OCC void k_assemble(int ntiles, co
     if (tid < nent) {
         if (!isDiag) {
             Ad f[3];
-            face_flux(qI, qJ, trans, area, thp, zI, zJ, VI, VJ, I, J, f);  // focus I: contribution to R_I
+            face_flux(qI, qJ, trans, area, thp, zI, zJ, VI, VJ, lowI, f);  // focus I: contribution to R_I
             for (int e = 0; e < 3; ++e) store_ad(&sflux[tid * 12 + e * 4], f[e]);
-            face_flux(qJ, qI, trans, area, thp, zJ, zI, VJ, VI, J, I, f);  // focus J: residual[I] -= flux  ->  block (I,J)
+            face_flux(qJ, qI, trans, area, thp, zJ, zI, VJ, VI, !lowI, f);  // focus J: residual[I] -= flux  ->  block (I,J)
             double* b = &sblk[(k - k0e) * BB];
             for (int e = 0; e < 3; ++e) {
                 const Ad m = ad_const(0.0) - f[e];
@@ -752,7 +755,7 @@ void launch_newton_update(opmhip_ctx* c, const double* d_dx, double relax) {
 }
 void launch_assemble(opmhip_ctx* c, double dt, int iteration) {
     const Pattern& P = c->pat;
-    EntryStatic ES{c->asmb.d_trans, c->asmb.d_area, c->asmb.d_thpres};
+    EntryStatic ES{c->asmb.d_trans, c->asmb.d_area, c->asmb.d_thpres, c->asmb.d_lowFirst};
     const int ps = prof_begin(c, PROF_ASSEMBLE);
     hipLaunchKernelGGL(k_assemble, dim3(8 * ((c->asmb.ntiles + 7) / 8)), dim3(ASM_THREADS), 0, c->stream, c->asmb.ntiles, c->asmb.d_asm_order, c->asmb.d_asm_row0, P.d_rowptr, P.d_col, c->asmb.d_natOrder, ES,
                        cells_of(c), c->asmb.d_iq, c->asmb.d_storageOld, c->asmb.d_source, c->asmb.d_dsource, dt, iteration, c->d_A, c->d_b);

@@ -183,6 +183,20 @@ int opmhip_set_static(opmhip_ctx* c, const double* trans, const double* area, co
                               [&](int x, int y) { return P.gids[P.fromOrder[P.col[x]]] < P.gids[P.fromOrder[P.col[y]]]; });
             }
             if ((rc = dev_upload(c, &A.d_natOrder, natOrder))) return rc;
+            // upwind tie-break of a face with equal pressures and volumes: "the DOF which exhibits the smaller global
+            // index" (ebos/eclfluxmodule.hh:303-314) - the index of the natural order (the global id in decomposed
+            // runs), never the position in the ILU ordering
+            std::vector<unsigned char> lowFirst(P.nnzb, 0);
+            for (int p = 0; p < P.Nb; ++p) {
+                const int in = P.fromOrder[p];
+                const long long gi = P.gids.empty() ? (long long)in : P.gids[in];
+                for (int k = P.rowptr[p]; k < P.rowptr[p + 1]; ++k) {
+                    const int jn = P.fromOrder[P.col[k]];
+                    const long long gj = P.gids.empty() ? (long long)jn : P.gids[jn];
+                    lowFirst[k] = gi < gj ? 1 : 0;
+                }
+            }
+            if ((rc = dev_upload(c, &A.d_lowFirst, lowFirst))) return rc;
         }
         A.static_set = true;
         return OPMHIP_SUCCESS;

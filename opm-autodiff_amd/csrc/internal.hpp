@@ -80,6 +80,7 @@ struct AsmDev {
     double rock_pref = 1e5, rock_cr = 0.0;
     int num_pvt = 0, num_sat = 0;
     double *d_trans = nullptr, *d_area = nullptr, *d_thpres = nullptr;                      // per entry
+    unsigned char* d_lowFirst = nullptr;  // per entry (I,J): global id of I < global id of J (upwind tie-break)
     double *d_poro = nullptr, *d_volume = nullptr, *d_depth = nullptr, *d_rsmax = nullptr;  // per cell
     int *d_pvtnum = nullptr, *d_satnum = nullptr;
     double *d_pv = nullptr, *d_iq = nullptr, *d_storageOld = nullptr, *d_source = nullptr, *d_dsource = nullptr;

@@ -51,6 +51,36 @@ def test_jacobian_and_residual_bitwise(pkg, orc, reorder, state):
     assert np.abs(r1).max() > 0 and not np.array_equal(j1, j0)
 
 
+@pytest.mark.parametrize("reorder", REORDERS)
+@pytest.mark.parametrize("state", ["undersaturated", "saturated", "mixed"])
+def test_degenerate_upwind_ties_bitwise(pkg, orc, reorder, state):
+    """Unperturbed, homogeneous state: every horizontal face has pressure difference exactly 0 and equal volumes, i.e.
+    the tie-break branch of ebos/eclfluxmodule.hh:287-321 (lower GLOBAL index is upstream) is taken on 2/3 of the faces
+    at Newton iteration 0.  Note that with dp == 0 the threshold test `|dp| > thpres` (:327-337) fails for every
+    thpres >= 0, so the face contributes neither flux nor derivative whichever side is called upstream: the choice is
+    not observable in J or r; this test pins exactly that, in every ordering."""
+    case = pkg.decks.cartesian_case(8, 7, 6, state=state, heterogeneous=False, perturb=False)
+    # the state really is degenerate: equal pressures and saturations inside every layer
+    pv = case["pv"].reshape(6, 56, 3)
+    assert np.all(pv == pv[:, :1, :]) and np.all(case["volume"] == case["volume"][0])
+    m, o = both(pkg, orc, case, reorder=reorder)
+    for dt, it in ((86400.0, 0), (10 * 86400.0, 1)):
+        j, r = m.assemble(dt, it)
+        jo, ro = o.assemble(dt, it)
+        assert np.array_equal(r, ro) and np.array_equal(j, jo)
+    # horizontal couplings carry no derivative at all in this state (zero blocks), vertical ones do
+    fd = np.abs(case["face_dir"])
+    jb = j.reshape(-1, 9)
+    assert not jb[(fd == 1) | (fd == 2)].any() and jb[fd == 3].any()
+    # with threshold pressures above the vertical pressure steps every face is closed
+    case2 = dict(case)
+    case2["thpres"] = np.where(fd > 0, 1e7, 0.0)
+    m2, o2 = both(pkg, orc, case2, reorder=reorder)
+    j2, r2 = m2.assemble(86400.0, 0)
+    jo2, ro2 = o2.assemble(86400.0, 0)
+    assert np.array_equal(r2, ro2) and np.array_equal(j2, jo2) and not j2.reshape(-1, 9)[fd > 0].any()
+
+
 def test_spe1_grid_bitwise(pkg, orc):
     """BASELINE config 0: the SPE1 grid and fluid (300 cells); 'bit-for-bit residual' against the CPU restatement."""
     case = pkg.decks.spe1_case()

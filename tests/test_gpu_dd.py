@@ -83,6 +83,31 @@ def test_dd_assembly_bitwise_and_solve(pkg, orc, world):
     assert all(np.array_equal(outs[0][2], o_[2]) for o_ in outs)  # every rank holds the same reduced numbers
 
 
+@pytest.mark.parametrize("world", [2, 4, 8])
+def test_dd_degenerate_upwind_ties_bitwise(pkg, orc, world):
+    """Unperturbed homogeneous state cut into 2/4/8 subdomains: pressure difference exactly 0 and equal volumes on every
+    horizontal face, including the faces between subdomains, where the tie-break of ebos/eclfluxmodule.hh:303-314 must
+    look at GLOBAL ids (local ids put every ghost after every owned cell).  Owned rows: the global oracle's bit for bit."""
+    n = 5
+    g, owner, parts = global_and_parts(pkg, n, world, state="mixed", heterogeneous=False, perturb=False)
+    o = oracle_bind.OracleModel(orc, g)
+    o.set_state(g["pv"], g["meaning"])
+    dt = 86400.0
+    jo, ro = o.assemble(dt, 0)
+    group = "u" + uuid.uuid4().hex
+
+    def rank_fn(r):
+        c = parts[r]
+        m = pkg.capi.HipModel(c, comm=("loopback", world, r, group), reorder="line_coloring")
+        m.set_state(c["pv"], c["meaning"])
+        return m.assemble(dt, 0)
+
+    for r, (j, res) in enumerate(run_ranks(world, rank_fn)):
+        c = parts[r]
+        assert np.array_equal(res.reshape(-1, 3)[:c["Nb"]], ro.reshape(-1, 3)[c["gids"][:c["Nb"]]])
+        assert np.array_equal(j.reshape(-1, 9), jo.reshape(-1, 9)[c["halo"]["entry_global"]])
+
+
 @pytest.mark.parametrize("reorder", ["line_coloring"])
 def test_dd_newton_step_matches_block_jacobi_oracle(pkg, orc, reorder):
     world, n = 2, 8
