@@ -13,15 +13,23 @@ Everything is resident in HBM when the timed region starts; nothing crosses PCIe
 scalars per Newton iteration.
 
     python bench.py --gpus N --steps K --warmup W
-N > 1 is launched by the driver through torch.distributed.run (one rank per GPU): restricted-additive-Schwarz domain
-decomposition of a (px 100) x (py 100) x (pz 100) grid (opm-autodiff_amd/ras.py), 10^6 cells per GPU, halo exchange and
-scalar all-reduces over RCCL inside libopmhip (weak scaling; 8 GPUs = BASELINE configs[3], 200^3).
-Prints ONE JSON line on rank 0.
+N > 1: one rank per GPU, either launched by the driver through torch.distributed.run (WORLD_SIZE set) or, when bench.py
+is started plainly with --gpus N, by bench.py itself (it starts torch.distributed.run as a child BEFORE anything touches
+a GPU and fails loudly when fewer than N devices are visible).  Restricted-additive-Schwarz domain decomposition of a
+(px 100) x (py 100) x (pz 100) grid (opm-autodiff_amd/ras.py), 10^6 cells per GPU, halo exchange and scalar all-reduces
+over RCCL inside libopmhip (weak scaling; 8 GPUs = BASELINE configs[3], 200^3).  Prints ONE JSON line on rank 0.
+
+After the K timed steps the run goes on (untimed) to Newton iteration `--steady-after` and times `--steady-steps` more:
+the steady-state phase of the simulation (10-day steps, ~30 linear iterations per Newton iteration) beside the easy
+start-up phase the K steps measure.  `value` is the K-step figure the contract asks for; `steady_state` is an extra key.
 """
 import argparse
+import hashlib
 import importlib
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -112,6 +120,54 @@ def cpu_baseline(pkg, case, src):
     return out
 
 
+def launch_plan(gpus, env, device_count):
+    """What `python bench.py --gpus N` has to do before any GPU call: ("inline", world) - run in this process (N = 1, or
+    a rank started by torch.distributed.run) - or ("spawn", N) - start N ranks as children.  Raises SystemExit on a
+    request that cannot be met; never silently runs fewer GPUs than asked for."""
+    if gpus < 1:
+        raise SystemExit("bench.py: --gpus must be >= 1")
+    if "WORLD_SIZE" in env:
+        world = int(env["WORLD_SIZE"])
+        if world != gpus:
+            raise SystemExit("bench.py: --gpus %d but the launcher set WORLD_SIZE=%d" % (gpus, world))
+        return ("inline", world)
+    if gpus == 1:
+        return ("inline", 1)
+    if device_count < gpus:
+        raise SystemExit("bench.py: --gpus %d but only %d GPU(s) are visible - refusing to run a smaller job" % (gpus, device_count))
+    return ("spawn", gpus)
+
+
+def spawn_command(gpus, argv, port):
+    return [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=%d" % gpus, "--master-addr", "127.0.0.1",
+            "--master-port", str(port), os.path.abspath(__file__)] + list(argv)
+
+
+def kernel_source_hash():
+    """sha256 over the kernel sources: ties a committed PMC traffic summary to the build it was measured on"""
+    h = hashlib.sha256()
+    for f in ("solver.hip", "assemble.hip", "internal.hpp"):
+        with open(os.path.join(ROOT, "opm-autodiff_amd", "csrc", f), "rb") as fh:
+            h.update(fh.read())
+    return h.hexdigest()[:16]
+
+
+def pmc_traffic(kernel_substr):
+    """HBM-side traffic of a kernel per launch from the newest committed PMC summary (PMC passes need their own
+    rocprofv3 runs, tools/pmc_quick.sh + tools/pmc_to_json.py) - only if it was measured on THESE kernel sources."""
+    import glob
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_traffic.json")))
+    for tj in reversed(files):
+        with open(tj) as f:
+            d = json.load(f)
+        if d.get("kernel_source_sha16") != kernel_source_hash():
+            continue
+        vals = [v["traffic_bytes_per_launch"] for k, v in d["kernels"].items() if kernel_substr in k]
+        if vals:
+            return sum(vals) / len(vals), os.path.relpath(tj, ROOT)
+    return None, "no PMC summary under profiles/ was measured on the present kernel sources (sha16 %s)" % kernel_source_hash()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -121,12 +177,20 @@ def main():
     ap.add_argument("--reorder", default="line_coloring")
     ap.add_argument("--chain-length", type=int, default=8, help="rows per chain of the line-coloured ILU0 ordering")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--steady-after", type=int, default=200, help="second timed window starts at this Newton iteration (0: none)")
+    ap.add_argument("--steady-steps", type=int, default=100)
     a = ap.parse_args()
 
+    import torch
+    plan, world = launch_plan(a.gpus, os.environ, torch.cuda.device_count())  # device_count() does not initialise the GPU
+    if plan == "spawn":
+        # children first, the GPU never: this process only waits for torch.distributed.run and hands on its exit code
+        with socket.socket() as sk:
+            sk.bind(("127.0.0.1", 0))
+            port = sk.getsockname()[1]
+        raise SystemExit(subprocess.call(spawn_command(a.gpus, sys.argv[1:], port)))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    import torch
     dist = None
     if world > 1:
         # control plane (rendezvous, barrier, max of the elapsed time, broadcast of the RCCL id) over gloo; the data path
@@ -136,6 +200,8 @@ def main():
         dist.init_process_group(backend="gloo")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: libopmhip has no CPU fallback")
+    if torch.cuda.device_count() <= local_rank:
+        raise SystemExit("bench.py: rank %d has no GPU (%d visible)" % (rank, torch.cuda.device_count()))
     torch.cuda.set_device(local_rank)
 
     pkg = importlib.import_module("opm-autodiff_amd")
@@ -158,6 +224,7 @@ def main():
     model.set_source(src)
     sim = make_simulation(pkg, model)
     Nb, nnzb = case["Nb"], len(case["col"])
+    B = alg_bytes(Nb, nnzb)
 
     def barrier():
         torch.cuda.synchronize()
@@ -165,55 +232,74 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    def timed_window(steps):
+        """EXACTLY `steps` Newton iterations between two barriers; max over ranks; kernel scopes of every 4th solve"""
+        barrier()
+        model.profile_enable(PROFILE_EVERY)
+        rep0 = pkg.newton.SimulatorReportSingle()
+        rep0 += sim.report
+        ts0, tf0, h0 = sim.timesteps_done, sim.timesteps_failed, len(sim.history)
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            sim.next_newton_iteration()
+        barrier()
+        elapsed = time.perf_counter() - t0
+        prof = model.profile()
+        model.profile_enable(False)
+        if dist is not None:
+            t = torch.tensor([elapsed], dtype=torch.float64)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            elapsed = float(t.item())
+        rep = sim.report
+        kernels = {}
+        for name, (cnt, ms) in prof.items():
+            if cnt:
+                avg = ms / cnt
+                kernels[name] = {"launches": cnt, "avg_ms": round(avg, 5), "algorithmic_GBps": round(B[name] / avg / 1e6, 1)}
+        ls_bytes = sum(B[k] * prof[k][0] for k in ("spmv", "ilu_apply", "ilu_factor", "vector"))
+        ls_ms = sum(prof[k][1] for k in ("spmv", "ilu_apply", "ilu_factor", "vector"))
+        return {"elapsed": elapsed, "steps": steps, "kernels": kernels,
+                "linear_iterations_per_newton": (rep.total_linear_iterations - rep0.total_linear_iterations) / steps,
+                "timesteps_completed": sim.timesteps_done - ts0, "timesteps_chopped": sim.timesteps_failed - tf0,
+                "time_steps_days": [round(h[0] / DAY, 3) for h in sim.history[h0:]],
+                "linear_solve_GBps": round(ls_bytes / ls_ms / 1e6, 1) if ls_ms > 0 else None,
+                "report": {"assemble_time": rep.assemble_time - rep0.assemble_time,
+                           "linear_solve_setup_time": rep.linear_solve_setup_time - rep0.linear_solve_setup_time,
+                           "linear_solve_time": rep.linear_solve_time - rep0.linear_solve_time,
+                           "update_time": rep.update_time - rep0.update_time}}
+
     for _ in range(a.warmup):
         sim.next_newton_iteration()
-    barrier()
-    # HIP-event scopes of the linear-solver kernels in every 4th linear solve of the timed region (an event record costs
-    # a few microseconds of stream bubble; a BiCGStab iteration holds seven); assembly-side scopes in every iteration
-    model.profile_enable(PROFILE_EVERY)
-    rep0 = pkg.newton.SimulatorReportSingle()
-    rep0 += sim.report
-    ts0, tf0 = sim.timesteps_done, sim.timesteps_failed
-    t0 = time.perf_counter()
-    for _ in range(a.steps):
-        sim.next_newton_iteration()
-    barrier()
-    elapsed = time.perf_counter() - t0
-    prof = model.profile()
-    model.profile_enable(False)
-    if dist is not None:
-        t = torch.tensor([elapsed], dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+    W = timed_window(a.steps)
+    elapsed, kernels = W["elapsed"], W["kernels"]
+    steady = None
+    if a.steady_after > 0 and a.steady_steps > 0:
+        done = a.warmup + a.steps
+        while done < a.steady_after:   # untimed: carries the simulation into its steady phase
+            sim.next_newton_iteration()
+            done += 1
+        S = timed_window(a.steady_steps)
+        steady = {"from_newton_iteration": done, "steps": S["steps"], "ms_per_step": 1e3 * S["elapsed"] / S["steps"],
+                  "newton_iterations_per_s_global": S["steps"] / S["elapsed"], "value": S["steps"] * world / S["elapsed"],
+                  "linear_iterations_per_newton": S["linear_iterations_per_newton"], "time_steps_days": S["time_steps_days"],
+                  "timesteps_chopped": S["timesteps_chopped"], "linear_solve_GBps": S["linear_solve_GBps"], "report": S["report"],
+                  "kernels": S["kernels"]}
+    # what a kernel that only streams reaches on THIS card (reads the Jacobian's values once per launch)
+    stream_ms = model.time_kernel("stream_read", reps=20)
+    stream_GBps = 72.0 * nnzb / stream_ms / 1e6
 
-    rep = sim.report
-    lin = rep.total_linear_iterations - rep0.total_linear_iterations
-    B = alg_bytes(Nb, nnzb)
-    kernels = {}
-    for name, (cnt, ms) in prof.items():
-        if cnt:
-            avg = ms / cnt
-            kernels[name] = {"launches": cnt, "avg_ms": round(avg, 5), "algorithmic_GBps": round(B[name] / avg / 1e6, 1)}
     sp = kernels.get("spmv", {"avg_ms": float("nan"), "algorithmic_GBps": float("nan")})
-    # linear-solve GB/s: algorithmic bytes of all solver kernels / their summed device time
-    ls_bytes = sum(B[k] * prof[k][0] for k in ("spmv", "ilu_apply", "ilu_factor", "vector"))
-    ls_ms = sum(prof[k][1] for k in ("spmv", "ilu_apply", "ilu_factor", "vector"))
-    # HBM-side traffic of k_spmv per launch: PMC passes cannot run inside this process (counters need their own
-    # rocprofv3 runs), so the number comes from the committed summary of tools/pmc_quick.sh over this same command
-    traffic, traffic_src = None, None
-    tj = os.path.join(ROOT, "profiles", "r01_d_pmc_traffic.json")
-    if world == 1 and n == 100 and a.reorder == "line_coloring" and os.path.exists(tj):
-        with open(tj) as f:
-            kk = json.load(f)["kernels"]
-        vals = [v["traffic_bytes_per_launch"] for k, v in kk.items() if "k_spmv" in k]
-        if vals:
-            traffic, traffic_src = sum(vals) / len(vals), "profiles/r01_d_pmc_traffic.json"
+    ok = sp["algorithmic_GBps"] == sp["algorithmic_GBps"]
+    traffic, traffic_src = (None, "single-GPU 100^3 line-colouring runs only")
+    if world == 1 and n == 100 and a.reorder == "line_coloring":
+        traffic, traffic_src = pmc_traffic("k_spmv")
     out = {
         "metric": "Newton iterations/sec, 1M-cell 3-phase black-oil (assembly + ILU0/BiCGStab solve + update)",
-        # weak scaling: every rank advances the SAME coupled Newton iteration on its 1M-cell subdomain; the whole-job
-        # aggregate is counted in subdomain-iterations (global iterations/s x number of 1M-cell subdomains)
+        # Whole-job aggregate.  Weak scaling: every rank advances the SAME coupled Newton iteration on its own 1M-cell
+        # subdomain, so the work done per second is (global iterations/s) x (number of 1M-cell subdomains); the plain
+        # global rate of the coupled (N x 1M-cell) problem is given beside it.
         "value": a.steps * world / elapsed,
-        "unit": "Newton iterations/s",
+        "unit": "Newton iterations/s" if world == 1 else "Newton iterations/s x 1M-cell subdomains (= newton_iterations_per_s_global x n_gpus)",
         "newton_iterations_per_s_global": a.steps / elapsed,
         "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": 1e3 * elapsed / a.steps,
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
@@ -222,23 +308,24 @@ def main():
                                "iteration-count control and 0.33 chop)" % (n, n, n),
                    "cells_per_gpu": Nb, "blocks_per_gpu": nnzb, "ilu_ordering": a.reorder, "linear_tol": 1e-2,
                    "ilu_relaxation": 0.9, "parallelism": "1 GPU" if world == 1 else "RAS domain decomposition %dx%dx%d, block-Jacobi ILU0 per GPU, halos + all-reduces over RCCL" % layout},
-        "linear_iterations_per_newton": lin / a.steps,
-        "timesteps_completed": sim.timesteps_done - ts0, "timesteps_chopped": sim.timesteps_failed - tf0,
-        "time_steps_days": [round(h[0] / DAY, 3) for h in sim.history],
-        "linear_solve_GBps": round(ls_bytes / ls_ms / 1e6, 1) if ls_ms > 0 else None,
-        "report": {"assemble_time": rep.assemble_time - rep0.assemble_time,
-                   "linear_solve_setup_time": rep.linear_solve_setup_time - rep0.linear_solve_setup_time,
-                   "linear_solve_time": rep.linear_solve_time - rep0.linear_solve_time,
-                   "update_time": rep.update_time - rep0.update_time},
+        "linear_iterations_per_newton": W["linear_iterations_per_newton"],
+        "timesteps_completed": W["timesteps_completed"], "timesteps_chopped": W["timesteps_chopped"],
+        "time_steps_days": W["time_steps_days"],
+        "linear_solve_GBps": W["linear_solve_GBps"],
+        "report": W["report"],
         "kernels": kernels,
+        "steady_state": steady,
+        "stream_ceiling": {"read_GBps": round(stream_GBps, 1), "bytes_per_launch": 72 * nnzb, "avg_launch_ms": round(stream_ms, 5),
+                           "kernel": "k_stream_read: the Jacobian's value array read once, 16-B loads, nothing else (back to back, 20 launches)"},
         "roofline": {"bound": "hbm", "kernel": "k_spmv (block-CSR SpMV, 3x3 double blocks)", "achieved": sp["algorithmic_GBps"],
-                     "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": (sp["algorithmic_GBps"] / HBM_PEAK_GBS) if sp["algorithmic_GBps"] == sp["algorithmic_GBps"] else None,
+                     "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": (sp["algorithmic_GBps"] / HBM_PEAK_GBS) if ok else None,
+                     "frac_of_stream_ceiling": (sp["algorithmic_GBps"] / stream_GBps) if ok else None,
                      "traffic": traffic, "traffic_unit": "bytes per launch (L2 fabric side; FETCH_SIZE x 2 + WRITE_SIZE, KiB -> B)",
                      "traffic_source": traffic_src, "avg_launch_ms": sp["avg_ms"], "algorithmic_bytes_per_launch": B["spmv"],
                      # the kernel also forms the BiCGStab scalar products (y.w0, y.y) on the fly; their second operand is 24 B
                      # per row of reads that SURVEY's plain-SpMV byte count does not contain - stated, not counted in `achieved`
                      "fused_dot_operand_bytes_per_launch": 24 * Nb,
-                     "achieved_incl_fused_dot": round((B["spmv"] + 24 * Nb) / sp["avg_ms"] / 1e6, 1) if sp["avg_ms"] == sp["avg_ms"] else None},
+                     "achieved_incl_fused_dot": round((B["spmv"] + 24 * Nb) / sp["avg_ms"] / 1e6, 1) if ok else None},
     }
     if rank == 0 and world == 1 and not a.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(pkg, case, src)

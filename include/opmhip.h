@@ -169,7 +169,8 @@ int opmhip_ilu0_apply(opmhip_ctx* ctx, const double* d, double* v);
  * returns the number of colours/levels or a negative status */
 int opmhip_get_ordering(opmhip_ctx* ctx, int* toOrder, int* fromOrder, int* rowsPerColor);
 /* Device-timed repetitions of one kernel on the uploaded system, for bench.py's roofline object:
- * which = 0 SpMV, 1 ILU0 apply, 2 ILU0 factor, 3 one BiCGStab iteration's vector kernels.
+ * which = 0 SpMV, 1 ILU0 apply, 2 ILU0 factor, 3 one BiCGStab iteration's vector kernels, 4 a plain streaming read of
+ * the Jacobian's value array (72 * nnzb bytes; the on-box HBM ceiling the roofline fractions are put beside).
  * Launches the kernel `reps` times back to back on the context's stream between two HIP events and returns the
  * average milliseconds per launch in *ms_per_launch. */
 int opmhip_time_kernel(opmhip_ctx* ctx, int which, int reps, double* ms_per_launch);

@@ -237,7 +237,7 @@ class HipSolver:
 
     def time_kernel(self, which, reps=20):
         ms = C.c_double()
-        self._check(lib().opmhip_time_kernel(self._h, {"spmv": 0, "ilu_apply": 1, "ilu_factor": 2, "vector": 3}[which],
+        self._check(lib().opmhip_time_kernel(self._h, {"spmv": 0, "ilu_apply": 1, "ilu_factor": 2, "vector": 3, "stream_read": 4}[which],
                                              reps, C.byref(ms)))
         return ms.value
 

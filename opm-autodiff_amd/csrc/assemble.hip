@@ -761,7 +761,7 @@ void launch_assemble(opmhip_ctx* c, double dt, int iteration) {
                        cells_of(c), c->asmb.d_iq, c->asmb.d_storageOld, c->asmb.d_source, c->asmb.d_dsource, dt, iteration, c->d_A, c->d_b);
     prof_end(c, ps);
 }
-void launch_convergence(opmhip_ctx* c, double dt, double tol_cnv) {
+int launch_convergence(opmhip_ctx* c, double dt, double tol_cnv) {
     const int Nb = c->pat.Nb, nb = cdiv(Nb, 256);
     const int ps = prof_begin(c, PROF_CONVERGENCE);
     hipLaunchKernelGGL(k_conv_pass1, dim3(nb), dim3(256), 0, c->stream, Nb, cells_of(c), c->asmb.d_iq, c->d_b, c->asmb.d_conv_part);
@@ -769,14 +769,19 @@ void launch_convergence(opmhip_ctx* c, double dt, double tol_cnv) {
     hipLaunchKernelGGL(k_conv_final1, dim3(1), dim3(256), 0, c->stream, nb, dd ? 0 : Nb, c->asmb.d_conv_part, c->asmb.d_conv_out);
     if (dd) {
         hipLaunchKernelGGL(k_conv_pack, dim3(1), dim3(64), 0, c->stream, c->asmb.d_conv_out, c->comm.d_red);
-        (void)comm_allreduce(c, c->comm.d_red, 7, 0);
-        (void)comm_allreduce(c, c->comm.d_red + 8, 3, 1);
+        int rc;  // a failed reduction must not be read as "converged": report it
+        if ((rc = comm_allreduce(c, c->comm.d_red, 7, 0))) return rc;
+        if ((rc = comm_allreduce(c, c->comm.d_red + 8, 3, 1))) return rc;
         hipLaunchKernelGGL(k_conv_unpack, dim3(1), dim3(64), 0, c->stream, c->comm.d_red, (double)c->comm.global_cells, c->asmb.d_conv_out);
     }
     hipLaunchKernelGGL(k_conv_pass2, dim3(nb), dim3(256), 0, c->stream, Nb, cells_of(c), c->d_b, c->asmb.d_conv_out, dt, tol_cnv, c->asmb.d_conv_part);
     hipLaunchKernelGGL(k_conv_final2, dim3(1), dim3(256), 0, c->stream, nb, c->asmb.d_conv_part, c->asmb.d_conv_out);
-    if (dd) (void)comm_allreduce(c, c->asmb.d_conv_out + 10, 1, 0);
+    if (dd) {
+        const int rc = comm_allreduce(c, c->asmb.d_conv_out + 10, 1, 0);
+        if (rc) return rc;
+    }
     prof_end(c, ps);
+    return OPMHIP_SUCCESS;
 }
 void launch_u8_to_internal(opmhip_ctx* c, const unsigned char* nat, unsigned char* internal) {
     hipLaunchKernelGGL(k_cellvec_to_internal_u8, dim3(cdiv(c->pat.Nloc, 256)), dim3(256), 0, c->stream, c->pat.Nloc, c->pat.d_fromOrder, nat, internal);

@@ -68,8 +68,11 @@ int upload_wells(opmhip_ctx* c, const opmhip_wells* w) {
     int rc;
     // device arrays grow geometrically and are then reused: wells are rebuilt for every solve
     // (linalg/ISTLSolverEbos.hpp:265-272)
+    // earlier kernels on the context's (non-blocking) stream may still read the well arrays the copies below replace
+    OPMHIP_HIP(c, hipStreamSynchronize(c->stream));
     if ((size_t)nw > W.cap_wells) {
         const size_t cap = std::max((size_t)nw, 2 * W.cap_wells);
+        dev_free(c, &W.d_val_pointers); dev_free(c, &W.d_D); dev_free(c, &W.d_res); dev_free(c, &W.d_xw);
         if ((rc = dev_alloc(c, &W.d_val_pointers, cap + 1))) return rc;
         if ((rc = dev_alloc(c, &W.d_D, cap * 16))) return rc;
         if ((rc = dev_alloc(c, &W.d_res, cap * 4))) return rc;
@@ -78,6 +81,7 @@ int upload_wells(opmhip_ctx* c, const opmhip_wells* w) {
     }
     if ((size_t)np > W.cap_perf) {
         const size_t cap = std::max((size_t)np, 2 * W.cap_perf);
+        dev_free(c, &W.d_Ccols); dev_free(c, &W.d_Bcols); dev_free(c, &W.d_C); dev_free(c, &W.d_B);
         if ((rc = dev_alloc(c, &W.d_Ccols, cap))) return rc;
         if ((rc = dev_alloc(c, &W.d_Bcols, cap))) return rc;
         if ((rc = dev_alloc(c, &W.d_C, cap * 12))) return rc;
@@ -313,7 +317,7 @@ int opmhip_add_well_contributions(opmhip_ctx* c, const opmhip_wells* wells) {
         const int nw = wells->num_wells;
         // position of every (c, b) block in the device's block-CSR; wells that touch a common block are serialised
         std::vector<int> pair_ptr(nw + 1, 0), entry;
-        std::vector<char> shares(nw, 0);
+        std::vector<char> shares(nw, 0), dup(nw, 0);
         std::unordered_map<int, int> owner;  // entry -> first well that writes it
         for (int w = 0; w < nw; ++w) {
             const int pb = wells->val_pointers[w], np = wells->val_pointers[w + 1] - pb;
@@ -329,7 +333,10 @@ int opmhip_add_well_contributions(opmhip_ctx* c, const opmhip_wells* wells) {
                     const int e = (int)(it - P.col.data());
                     entry.push_back(e);
                     auto ins = owner.emplace(e, w);
-                    if (!ins.second && ins.first->second != w) shares[w] = 1;
+                    if (!ins.second) {
+                        if (ins.first->second != w) shares[w] = 1;
+                        else dup[w] = 1;  // two perforations of this well in one cell: several pairs of ONE launch hit this block
+                    }
                 }
             pair_ptr[w + 1] = (int)entry.size();
         }
@@ -343,10 +350,11 @@ int opmhip_add_well_contributions(opmhip_ctx* c, const opmhip_wells* wells) {
         OPMHIP_HIP(c, hipMemcpyAsync(S.en, entry.data(), entry.size() * sizeof(int), hipMemcpyHostToDevice, c->stream));
         // runs of wells without shared blocks go out as one launch; a well that shares a block with an earlier one starts
         // a new launch, so that the additions to that block happen in well order (the order of well_container_)
+        // a well with two perforations in one cell goes out alone, one lane adding its pairs in perforation order
         int w0 = 0;
         for (int w = 1; w <= nw; ++w)
-            if (w == nw || shares[w]) {
-                launch_wells_add_to_matrix(c, w0, w - w0, S.pp, S.en);
+            if (w == nw || shares[w] || dup[w] || dup[w - 1]) {
+                launch_wells_add_to_matrix(c, w0, w - w0, (w - w0 == 1 && dup[w0]) ? 1 : 0, S.pp, S.en);
                 w0 = w;
             }
         OPMHIP_HIP(c, hipGetLastError());
@@ -501,9 +509,9 @@ int opmhip_profile_get(opmhip_ctx* c, int cls, long long* launches, double* tota
 int opmhip_time_kernel(opmhip_ctx* c, int which, int reps, double* ms_per_launch) {
     if (!c) return OPMHIP_INVALID_ARGUMENT;
     return guarded(c, [&]() -> int {
-        if (!ms_per_launch || reps < 1 || which < 0 || which > 3) return fail(c, OPMHIP_INVALID_ARGUMENT, "time_kernel: bad arguments");
+        if (!ms_per_launch || reps < 1 || which < 0 || which > 4) return fail(c, OPMHIP_INVALID_ARGUMENT, "time_kernel: bad arguments");
         if (!c->system_loaded) return fail(c, OPMHIP_NOT_READY, "time_kernel before a matrix was uploaded");
-        if (which != 2 && !c->factored) return fail(c, OPMHIP_NOT_READY, "time_kernel: factor first");
+        if (which != 2 && which != 4 && !c->factored) return fail(c, OPMHIP_NOT_READY, "time_kernel: factor first");
         OPMHIP_HIP(c, hipSetDevice(c->device));
         auto once = [&]() {
             switch (which) {
@@ -511,6 +519,7 @@ int opmhip_time_kernel(opmhip_ctx* c, int which, int reps, double* ms_per_launch
                 case 1: launch_ilu_apply(c, c->d_p, c->d_pw); break;
                 case 2: launch_ilu_factor(c); break;
                 case 3: launch_vector_kernels_once(c); break;
+                case 4: launch_stream_read(c); break;
             }
         };
         once();  // warm

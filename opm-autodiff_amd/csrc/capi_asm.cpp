@@ -37,6 +37,8 @@ int upload_cells(opmhip_ctx* c, T** dst, const T* nat, int width = 1) {
         int rc = dev_alloc(c, dst, v.size());
         if (rc) return rc;
     }
+    // the context's stream is non-blocking: an assembly enqueued earlier may still read this array
+    OPMHIP_HIP(c, hipStreamSynchronize(c->stream));
     OPMHIP_HIP(c, hipMemcpy(*dst, v.data(), v.size() * sizeof(T), hipMemcpyHostToDevice));
     return OPMHIP_SUCCESS;
 }
@@ -48,6 +50,7 @@ int upload_entries(opmhip_ctx* c, double** dst, const double* nat) {
         int rc = dev_alloc(c, dst, v.size());
         if (rc) return rc;
     }
+    OPMHIP_HIP(c, hipStreamSynchronize(c->stream));
     OPMHIP_HIP(c, hipMemcpy(*dst, v.data(), v.size() * sizeof(double), hipMemcpyHostToDevice));
     return OPMHIP_SUCCESS;
 }
@@ -309,9 +312,9 @@ int opmhip_set_source(opmhip_ctx* c, const double* source, const double* dsource
         const size_t Nb = c->pat.Nloc;
         int rc;
         if (source) { if ((rc = upload_cells(c, &A.d_source, source, 3))) return rc; }
-        else OPMHIP_HIP(c, hipMemset(A.d_source, 0, Nb * 3 * sizeof(double)));
+        else OPMHIP_HIP(c, hipMemsetAsync(A.d_source, 0, Nb * 3 * sizeof(double), c->stream));
         if (dsource) { if ((rc = upload_cells(c, &A.d_dsource, dsource, 9))) return rc; }
-        else OPMHIP_HIP(c, hipMemset(A.d_dsource, 0, Nb * 9 * sizeof(double)));
+        else OPMHIP_HIP(c, hipMemsetAsync(A.d_dsource, 0, Nb * 9 * sizeof(double), c->stream));
         return OPMHIP_SUCCESS;
     });
 }
@@ -359,7 +362,8 @@ int opmhip_convergence(opmhip_ctx* c, double dt, double tol_cnv, double* out) {
         if (!c->asmb.assembled) return fail(c, OPMHIP_NOT_READY, "convergence before assemble");
         if (!out) return fail(c, OPMHIP_INVALID_ARGUMENT, "convergence: out == NULL");
         OPMHIP_HIP(c, hipSetDevice(c->device));
-        launch_convergence(c, dt, tol_cnv);
+        const int rcc = launch_convergence(c, dt, tol_cnv);
+        if (rcc) return rcc;
         OPMHIP_HIP(c, hipGetLastError());
         double h[16];
         OPMHIP_HIP(c, hipMemcpyAsync(h, c->asmb.d_conv_out, 11 * sizeof(double), hipMemcpyDeviceToHost, c->stream));

@@ -86,9 +86,14 @@ int comm_allreduce(opmhip_ctx* c, double* d_buf, int n, int op) {
         NCCLCHK(c, g_rccl.AllReduce(d_buf, d_buf, (size_t)n, ncclDouble, op == 0 ? ncclSum : ncclMax, (ncclComm_t)C.nccl, c->stream));
         return OPMHIP_SUCCESS;
     }
+    // loopback: an error on this rank's stream must not strand the peers inside a barrier - remember it, keep the
+    // barrier protocol, report it afterwards
     LoopGroup* G = (LoopGroup*)C.group;
-    OPMHIP_HIP(c, hipMemcpyAsync(G->scratch[C.rank].data(), d_buf, n * sizeof(double), hipMemcpyDeviceToHost, c->stream));
-    OPMHIP_HIP(c, hipStreamSynchronize(c->stream));
+    int rc = [&]() -> int {
+        OPMHIP_HIP(c, hipMemcpyAsync(G->scratch[C.rank].data(), d_buf, n * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+        OPMHIP_HIP(c, hipStreamSynchronize(c->stream));
+        return OPMHIP_SUCCESS;
+    }();
     pthread_barrier_wait(&G->barrier);
     double acc[16];
     for (int i = 0; i < n; ++i) {
@@ -97,6 +102,7 @@ int comm_allreduce(opmhip_ctx* c, double* d_buf, int n, int op) {
         acc[i] = a;  // fixed rank order: every rank forms the same bits
     }
     pthread_barrier_wait(&G->barrier);
+    if (rc) return rc;
     OPMHIP_HIP(c, hipMemcpyAsync(d_buf, acc, n * sizeof(double), hipMemcpyHostToDevice, c->stream));
     OPMHIP_HIP(c, hipStreamSynchronize(c->stream));
     return OPMHIP_SUCCESS;
@@ -111,31 +117,40 @@ int comm_halo_f64(opmhip_ctx* c, double* vec, int w) {
         hipLaunchKernelGGL(k_pack_f64, dim3((nsend * w + 255) / 256), dim3(256), 0, c->stream, nsend, w, C.d_send_idx, vec, C.d_sendbuf);
     double* ghost0 = vec + (size_t)c->pat.Nb * w;
     if (C.kind == COMM_RCCL) {
+        // a failing call must not leave the group open: remember the first error, always reach ncclGroupEnd
         NCCLCHK(c, g_rccl.GroupStart());
-        for (int q = 0; q < C.nneigh; ++q) {
-            NCCLCHK(c, g_rccl.Send(C.d_sendbuf + (size_t)C.send_ptr[q] * w, (size_t)(C.send_ptr[q + 1] - C.send_ptr[q]) * w, ncclDouble, C.neigh[q], (ncclComm_t)C.nccl, c->stream));
-            NCCLCHK(c, g_rccl.Recv(ghost0 + (size_t)C.recv_ptr[q] * w, (size_t)(C.recv_ptr[q + 1] - C.recv_ptr[q]) * w, ncclDouble, C.neigh[q], (ncclComm_t)C.nccl, c->stream));
+        ncclResult_t err = ncclSuccess;
+        for (int q = 0; q < C.nneigh && err == ncclSuccess; ++q) {
+            err = g_rccl.Send(C.d_sendbuf + (size_t)C.send_ptr[q] * w, (size_t)(C.send_ptr[q + 1] - C.send_ptr[q]) * w, ncclDouble, C.neigh[q], (ncclComm_t)C.nccl, c->stream);
+            if (err == ncclSuccess)
+                err = g_rccl.Recv(ghost0 + (size_t)C.recv_ptr[q] * w, (size_t)(C.recv_ptr[q + 1] - C.recv_ptr[q]) * w, ncclDouble, C.neigh[q], (ncclComm_t)C.nccl, c->stream);
         }
-        NCCLCHK(c, g_rccl.GroupEnd());
+        const ncclResult_t endErr = g_rccl.GroupEnd();
+        if (err == ncclSuccess) err = endErr;
+        if (err != ncclSuccess) return fail(c, OPMHIP_DEVICE_ERROR, "halo exchange (ncclSend/ncclRecv) failed: %s", g_rccl.GetErrorString(err));
         return OPMHIP_SUCCESS;
     }
+    // loopback: errors are remembered and reported after the SECOND barrier, so that no peer waits for ever
     LoopGroup* G = (LoopGroup*)C.group;
-    OPMHIP_HIP(c, hipStreamSynchronize(c->stream));
+    int rc = (hipStreamSynchronize(c->stream) == hipSuccess) ? OPMHIP_SUCCESS : fail(c, OPMHIP_DEVICE_ERROR, "halo exchange: packing failed");
     pthread_barrier_wait(&G->barrier);  // every rank's send buffer is packed
-    for (int q = 0; q < C.nneigh; ++q) {
-        const opmhip_ctx* peer = G->members[C.neigh[q]];
-        const CommDev& PC = peer->comm;
-        int me = -1;
-        for (int t = 0; t < PC.nneigh; ++t)
-            if (PC.neigh[t] == C.rank) me = t;
-        if (me < 0 || PC.send_ptr[me + 1] - PC.send_ptr[me] != C.recv_ptr[q + 1] - C.recv_ptr[q])
-            return fail(c, OPMHIP_INVALID_ARGUMENT, "halo lists of ranks %d and %d do not match", C.rank, C.neigh[q]);
-        OPMHIP_HIP(c, hipMemcpyAsync(ghost0 + (size_t)C.recv_ptr[q] * w, PC.d_sendbuf + (size_t)PC.send_ptr[me] * w,
-                                     (size_t)(C.recv_ptr[q + 1] - C.recv_ptr[q]) * w * sizeof(double), hipMemcpyDeviceToDevice, c->stream));
-    }
-    OPMHIP_HIP(c, hipStreamSynchronize(c->stream));
+    if (!rc) rc = [&]() -> int {
+        for (int q = 0; q < C.nneigh; ++q) {
+            const opmhip_ctx* peer = G->members[C.neigh[q]];
+            const CommDev& PC = peer->comm;
+            int me = -1;
+            for (int t = 0; t < PC.nneigh; ++t)
+                if (PC.neigh[t] == C.rank) me = t;
+            if (me < 0 || PC.send_ptr[me + 1] - PC.send_ptr[me] != C.recv_ptr[q + 1] - C.recv_ptr[q])
+                return fail(c, OPMHIP_INVALID_ARGUMENT, "halo lists of ranks %d and %d do not match", C.rank, C.neigh[q]);
+            OPMHIP_HIP(c, hipMemcpyAsync(ghost0 + (size_t)C.recv_ptr[q] * w, PC.d_sendbuf + (size_t)PC.send_ptr[me] * w,
+                                         (size_t)(C.recv_ptr[q + 1] - C.recv_ptr[q]) * w * sizeof(double), hipMemcpyDeviceToDevice, c->stream));
+        }
+        OPMHIP_HIP(c, hipStreamSynchronize(c->stream));
+        return OPMHIP_SUCCESS;
+    }();
     pthread_barrier_wait(&G->barrier);  // nobody repacks before every copy is done
-    return OPMHIP_SUCCESS;
+    return rc;
 }
 
 int comm_halo_u8(opmhip_ctx* c, unsigned char* vec) {
@@ -146,28 +161,36 @@ int comm_halo_u8(opmhip_ctx* c, unsigned char* vec) {
     unsigned char* ghost0 = vec + c->pat.Nb;
     if (C.kind == COMM_RCCL) {
         NCCLCHK(c, g_rccl.GroupStart());
-        for (int q = 0; q < C.nneigh; ++q) {
-            NCCLCHK(c, g_rccl.Send(C.d_sendbuf_u8 + C.send_ptr[q], (size_t)(C.send_ptr[q + 1] - C.send_ptr[q]), ncclUint8, C.neigh[q], (ncclComm_t)C.nccl, c->stream));
-            NCCLCHK(c, g_rccl.Recv(ghost0 + C.recv_ptr[q], (size_t)(C.recv_ptr[q + 1] - C.recv_ptr[q]), ncclUint8, C.neigh[q], (ncclComm_t)C.nccl, c->stream));
+        ncclResult_t err = ncclSuccess;
+        for (int q = 0; q < C.nneigh && err == ncclSuccess; ++q) {
+            err = g_rccl.Send(C.d_sendbuf_u8 + C.send_ptr[q], (size_t)(C.send_ptr[q + 1] - C.send_ptr[q]), ncclUint8, C.neigh[q], (ncclComm_t)C.nccl, c->stream);
+            if (err == ncclSuccess)
+                err = g_rccl.Recv(ghost0 + C.recv_ptr[q], (size_t)(C.recv_ptr[q + 1] - C.recv_ptr[q]), ncclUint8, C.neigh[q], (ncclComm_t)C.nccl, c->stream);
         }
-        NCCLCHK(c, g_rccl.GroupEnd());
+        const ncclResult_t endErr = g_rccl.GroupEnd();
+        if (err == ncclSuccess) err = endErr;
+        if (err != ncclSuccess) return fail(c, OPMHIP_DEVICE_ERROR, "halo exchange (ncclSend/ncclRecv) failed: %s", g_rccl.GetErrorString(err));
         return OPMHIP_SUCCESS;
     }
     LoopGroup* G = (LoopGroup*)C.group;
-    OPMHIP_HIP(c, hipStreamSynchronize(c->stream));
+    int rc = (hipStreamSynchronize(c->stream) == hipSuccess) ? OPMHIP_SUCCESS : fail(c, OPMHIP_DEVICE_ERROR, "halo exchange: packing failed");
     pthread_barrier_wait(&G->barrier);
-    for (int q = 0; q < C.nneigh; ++q) {
-        const CommDev& PC = G->members[C.neigh[q]]->comm;
-        int me = -1;
-        for (int t = 0; t < PC.nneigh; ++t)
-            if (PC.neigh[t] == C.rank) me = t;
-        if (me < 0) return fail(c, OPMHIP_INVALID_ARGUMENT, "halo lists of ranks %d and %d do not match", C.rank, C.neigh[q]);
-        OPMHIP_HIP(c, hipMemcpyAsync(ghost0 + C.recv_ptr[q], PC.d_sendbuf_u8 + PC.send_ptr[me], (size_t)(C.recv_ptr[q + 1] - C.recv_ptr[q]),
-                                     hipMemcpyDeviceToDevice, c->stream));
-    }
-    OPMHIP_HIP(c, hipStreamSynchronize(c->stream));
+    if (!rc) rc = [&]() -> int {
+        for (int q = 0; q < C.nneigh; ++q) {
+            const CommDev& PC = G->members[C.neigh[q]]->comm;
+            int me = -1;
+            for (int t = 0; t < PC.nneigh; ++t)
+                if (PC.neigh[t] == C.rank) me = t;
+            if (me < 0 || PC.send_ptr[me + 1] - PC.send_ptr[me] != C.recv_ptr[q + 1] - C.recv_ptr[q])
+                return fail(c, OPMHIP_INVALID_ARGUMENT, "halo lists of ranks %d and %d do not match", C.rank, C.neigh[q]);
+            OPMHIP_HIP(c, hipMemcpyAsync(ghost0 + C.recv_ptr[q], PC.d_sendbuf_u8 + PC.send_ptr[me], (size_t)(C.recv_ptr[q + 1] - C.recv_ptr[q]),
+                                         hipMemcpyDeviceToDevice, c->stream));
+        }
+        OPMHIP_HIP(c, hipStreamSynchronize(c->stream));
+        return OPMHIP_SUCCESS;
+    }();
     pthread_barrier_wait(&G->barrier);
-    return OPMHIP_SUCCESS;
+    return rc;
 }
 
 void comm_release(opmhip_ctx* c) {

@@ -209,6 +209,15 @@ int dev_alloc(opmhip_ctx* c, T** p, size_t count) {
     *p = static_cast<T*>(q);
     return OPMHIP_SUCCESS;
 }
+// gives one tracked allocation back (buffers that are re-allocated larger: the old one must not pile up until destroy)
+template <class T>
+void dev_free(opmhip_ctx* c, T** p) {
+    if (!*p) return;
+    for (size_t i = 0; i < c->allocs.size(); ++i)
+        if (c->allocs[i] == (void*)*p) { c->allocs[i] = c->allocs.back(); c->allocs.pop_back(); break; }
+    (void)hipFree((void*)*p);
+    *p = nullptr;
+}
 template <class T>
 int dev_upload(opmhip_ctx* c, T** p, const std::vector<T>& h) {
     int rc = dev_alloc(c, p, h.size());
@@ -295,7 +304,7 @@ void launch_vec_to_natural(opmhip_ctx* c, const double* internal, double* nat, i
 void launch_zero_diag_fix(opmhip_ctx* c);
 void launch_spmv(opmhip_ctx* c, const double* x, double* y, int ndot, const double* w0, const double* w1);
 void launch_wells_residual(opmhip_ctx* c, const double* d_resWell, double* r);
-void launch_wells_add_to_matrix(opmhip_ctx* c, int w0, int nw, const int* d_pair_ptr, const int* d_entry);
+void launch_wells_add_to_matrix(opmhip_ctx* c, int w0, int nw, int serial, const int* d_pair_ptr, const int* d_entry);
 void launch_wells_recover(opmhip_ctx* c, const double* d_resWell, const double* x, double* d_xw);
 void launch_ilu_factor(opmhip_ctx* c);
 void launch_ilu_apply(opmhip_ctx* c, const double* d, double* v, int fuse = 0);
@@ -312,7 +321,7 @@ void launch_iq_update(opmhip_ctx* c);
 int launch_ghost_refresh(opmhip_ctx* c);
 void launch_newton_update(opmhip_ctx* c, const double* d_dx_internal, double relax);
 void launch_assemble(opmhip_ctx* c, double dt, int iteration);
-void launch_convergence(opmhip_ctx* c, double dt, double tol_cnv);
+int launch_convergence(opmhip_ctx* c, double dt, double tol_cnv);
 void launch_u8_to_internal(opmhip_ctx* c, const unsigned char* nat, unsigned char* internal);
 void launch_u8_to_natural(opmhip_ctx* c, const unsigned char* internal, unsigned char* nat);
 void launch_iq_to_natural(opmhip_ctx* c, double* d_nat);
@@ -321,5 +330,6 @@ int asm_max_rows();
 int launch_fluid_probe(opmhip_ctx* c, int pr, int sr, int n, const double* d_in, double* d_out);
 int asm_threads();
 void launch_vector_kernels_once(opmhip_ctx* c);
+void launch_stream_read(opmhip_ctx* c);
 
 }  // namespace opmhip

@@ -1066,13 +1066,16 @@ __global__ __launch_bounds__(64) void k_wells_recover(const int* __restrict__ vp
 // (StandardWell::addWellContributions, wells/StandardWell_impl.hpp:1688-1712; sums in the order of Detail::multMatrix
 // and Detail::negativeMultMatrixTransposed, linalg/MatrixBlock.hpp:496-570).  entry[] holds, per pair, the position of
 // the block in the device's block-CSR (found on the host).
-__global__ __launch_bounds__(64) void k_wells_add_to_matrix(int w0, const int* __restrict__ vp, const double* __restrict__ C,
+// serial != 0: the well has two perforations in one cell, i.e. several of its pairs hit the same block - one lane then
+// adds all pairs in the perforation order of the CPU loop (no race, same bits).
+__global__ __launch_bounds__(64) void k_wells_add_to_matrix(int w0, int serial, const int* __restrict__ vp, const double* __restrict__ C,
                                                             const double* __restrict__ D, const double* __restrict__ B,
                                                             const int* __restrict__ pair_ptr, const int* __restrict__ entry,
                                                             double* __restrict__ A) {
     const int w = w0 + blockIdx.x;
     const int pb = vp[w], np = vp[w + 1] - pb;
-    for (int q = threadIdx.x; q < np * np; q += 64) {
+    if (serial && threadIdx.x != 0) return;
+    for (int q = serial ? 0 : (int)threadIdx.x; q < np * np; q += serial ? 1 : 64) {
         const int c = q / np, b = q % np;
         const double* Bb = &B[(size_t)(pb + b) * 12];
         const double* Cc = &C[(size_t)(pb + c) * 12];
@@ -1336,6 +1339,31 @@ __global__ __launch_bounds__(VB) void k_reduce_finalize(int mode, int count, con
     finalize_scalars(mode, sh[0][0], sh[1][0], scal, tol, hslot, seq);
 }
 
+// On-box streaming ceiling (opmhip_time_kernel, which = 4): every byte of the Jacobian's value array read once with 16-byte
+// loads, eight in flight per lane, nothing else - what the HBM of THIS card delivers to a kernel that only streams, to set
+// beside the 8 TB/s spec figure the roofline fractions are quoted against (SURVEY.md section 8d asks for both).
+__global__ __launch_bounds__(256) void k_stream_read(size_t n2, const double2* __restrict__ src, double* __restrict__ sink) {
+    // consecutive workgroups read consecutive 32-KiB pieces (the access shape of the tile kernels): 8 x 4 KiB rows per
+    // workgroup iteration, all eight loads of a lane in flight before the first is used
+    double s = 0.0;
+    constexpr size_t PIECE = 256 * 8;  // double2 per workgroup iteration
+    const size_t npiece = n2 / PIECE;
+    for (size_t p = blockIdx.x; p < npiece; p += gridDim.x) {
+        const double2* q = src + p * PIECE + threadIdx.x;
+        double2 t[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) t[u] = q[u * 256];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) s += t[u].x + t[u].y;
+    }
+    for (size_t i = npiece * PIECE + (size_t)blockIdx.x * 256 + threadIdx.x; i < n2; i += (size_t)gridDim.x * 256) { const double2 t = src[i]; s += t.x + t.y; }
+    if (s == 1.2345678e300) sink[0] = s;  // never true: keeps the loads alive
+}
+void launch_stream_read(opmhip_ctx* c) {
+    const size_t n2 = (size_t)c->pat.nnzb * BB / 2;
+    hipLaunchKernelGGL(k_stream_read, dim3(256 * 8), dim3(256), 0, c->stream, n2, reinterpret_cast<const double2*>(c->d_A), c->d_part2);
+}
+
 // ============================== launchers ================================================================
 static inline int cdiv(size_t a, size_t b) { return (int)((a + b - 1) / b); }
 static inline int vec_blocks(int n) { return cdiv((size_t)n, (size_t)VB * VPT); }
@@ -1367,9 +1395,9 @@ void launch_wells_apply(opmhip_ctx* c, const double* x, double* y) {
     hipLaunchKernelGGL(k_wells_apply, dim3(W.num_wells), dim3(64), 0, c->stream, W.d_val_pointers, W.d_Ccols, W.d_Bcols, W.d_C, W.d_D,
                        W.d_B, x, y);
 }
-void launch_wells_add_to_matrix(opmhip_ctx* c, int w0, int nw, const int* d_pair_ptr, const int* d_entry) {
+void launch_wells_add_to_matrix(opmhip_ctx* c, int w0, int nw, int serial, const int* d_pair_ptr, const int* d_entry) {
     const WellsDev& W = c->wells;
-    hipLaunchKernelGGL(k_wells_add_to_matrix, dim3(nw), dim3(64), 0, c->stream, w0, W.d_val_pointers, W.d_C, W.d_D, W.d_B, d_pair_ptr, d_entry, c->d_A);
+    hipLaunchKernelGGL(k_wells_add_to_matrix, dim3(nw), dim3(64), 0, c->stream, w0, serial, W.d_val_pointers, W.d_C, W.d_D, W.d_B, d_pair_ptr, d_entry, c->d_A);
 }
 void launch_wells_residual(opmhip_ctx* c, const double* d_resWell, double* r) {
     const WellsDev& W = c->wells;
@@ -1496,7 +1524,7 @@ void launch_ilu_apply(opmhip_ctx* c, const double* d, double* v, int fuse) {
     prof_end(c, ps);
 }
 // rb_half >= 0: this launch evaluates the stopping rule of half iteration rb_half and reports into its ring slot
-static void finalize(opmhip_ctx* c, int mode, int count, int rb_half = -1) {
+static int finalize(opmhip_ctx* c, int mode, int count, int rb_half = -1) {
     const double tol = c->cfg.tolerance;
     double* hslot = nullptr;
     double seq = 0.0;
@@ -1516,25 +1544,28 @@ static void finalize(opmhip_ctx* c, int mode, int count, int rb_half = -1) {
             src = c->d_part2; np = RED1_BLOCKS; cnt = RED1_BLOCKS;
         }
         hipLaunchKernelGGL(k_local_sums, dim3(1), dim3(VB), 0, c->stream, cnt, src, np, c->comm.d_red);
-        (void)comm_allreduce(c, c->comm.d_red, 2, 0);
+        // a failed all-reduce would leave garbage in alpha / omega / the norm: stop the solve, the caller reports it
+        const int rc = comm_allreduce(c, c->comm.d_red, 2, 0);
+        if (rc) return rc;
         hipLaunchKernelGGL(k_finalize, dim3(1), dim3(VB), 0, c->stream, mode, 1, c->comm.d_red, 1, c->d_scal, tol, hslot, seq);
-        return;
+        return OPMHIP_SUCCESS;
     }
     if (count > RED1_SINGLE_MAX) {
         hipLaunchKernelGGL(k_reduce_finalize, dim3(RED1_BLOCKS), dim3(VB), 0, c->stream, mode, count, c->d_part, c->npart, c->d_part2,
                            reinterpret_cast<unsigned*>(c->d_part2 + 2 * RED1_BLOCKS), c->d_scal, tol, hslot, seq);
-        return;
+        return OPMHIP_SUCCESS;
     }
     hipLaunchKernelGGL(k_finalize, dim3(1), dim3(VB), 0, c->stream, mode, count, c->d_part, c->npart, c->d_scal, tol, hslot, seq);
+    return OPMHIP_SUCCESS;
 }
 // the vector kernels of one BiCGStab iteration, for opmhip_time_kernel
 void launch_vector_kernels_once(opmhip_ctx* c) {
     const int n = c->pat.Nb * BS, nb = vec_blocks(n);
     hipLaunchKernelGGL(k_bicg_pupdate, dim3(nb), dim3(VB), 0, c->stream, n, c->d_scal, c->d_p, c->d_v, c->d_r);
     hipLaunchKernelGGL(k_bicg_upd1, dim3(nb), dim3(VB), 0, c->stream, n, c->d_scal, c->d_r, c->d_v, c->d_x, c->d_pw, c->d_part, c->npart);
-    finalize(c, FIN_NORM, nb);
+    (void)finalize(c, FIN_NORM, nb);  // timing helper, single-rank contexts only
     hipLaunchKernelGGL(k_bicg_upd2, dim3(nb), dim3(VB), 0, c->stream, n, c->d_scal, c->d_x, c->d_s, c->d_r, c->d_t, c->d_rw, c->d_part, c->npart);
-    finalize(c, FIN_NORM_RHO, nb);
+    (void)finalize(c, FIN_NORM_RHO, nb);
 }
 
 // ============================== BiCGStab driver ==========================================================
@@ -1566,25 +1597,25 @@ static int enqueue_half(opmhip_ctx* c, int h) {
         if ((rc = comm_halo_f64(c, c->d_pw, BS))) return rc;  // copyOwnerToAll before the operator (ParallelOverlappingILU0.hpp:897)
         launch_spmv(c, c->d_pw, c->d_v, 1, c->d_rw, nullptr);
         ps = prof_begin(c, PROF_VECTOR);
-        finalize(c, FIN_ALPHA, dot_count(c));
+        if ((rc = finalize(c, FIN_ALPHA, dot_count(c)))) return rc;
         if (!fused) {
             hipLaunchKernelGGL(k_bicg_upd1, dim3(nb), dim3(VB), 0, c->stream, n, c->d_scal, c->d_r, c->d_v, c->d_x, c->d_pw, c->d_part, c->npart);
-            finalize(c, FIN_NORM, nb, h);
+            if ((rc = finalize(c, FIN_NORM, nb, h))) return rc;
         }
         prof_end(c, ps);
     } else {             // second half: z = M^-1 r, t = A z, omega, x += omega z, r -= omega t, |r|, rho, beta
         launch_ilu_apply(c, c->d_r, c->d_s, fused ? DM_UPD1 : 0);
         if (fused) {
             ps = prof_begin(c, PROF_VECTOR);
-            finalize(c, FIN_NORM, P.tiles.colorCT[1] - P.tiles.colorCT[0], h - 1);
+            if ((rc = finalize(c, FIN_NORM, P.tiles.colorCT[1] - P.tiles.colorCT[0], h - 1))) return rc;
             prof_end(c, ps);
         }
         if ((rc = comm_halo_f64(c, c->d_s, BS))) return rc;
         launch_spmv(c, c->d_s, c->d_t, 2, c->d_r, nullptr);
         ps = prof_begin(c, PROF_VECTOR);
-        finalize(c, FIN_OMEGA, dot_count(c));
+        if ((rc = finalize(c, FIN_OMEGA, dot_count(c)))) return rc;
         hipLaunchKernelGGL(k_bicg_upd2, dim3(nb), dim3(VB), 0, c->stream, n, c->d_scal, c->d_x, c->d_s, c->d_r, c->d_t, c->d_rw, c->d_part, c->npart);
-        finalize(c, FIN_NORM_RHO, nb, h);
+        if ((rc = finalize(c, FIN_NORM_RHO, nb, h))) return rc;
         prof_end(c, ps);
     }
     return OPMHIP_SUCCESS;
@@ -1607,7 +1638,11 @@ static int wait_half(opmhip_ctx* c, int h, double* norm, double* norm_0) {
             if (std::chrono::steady_clock::now() - t0 > std::chrono::seconds(120))
                 return fail(c, OPMHIP_DEVICE_ERROR, "BiCGStab: no stopping-rule record of half iteration %d after 120 s", h);
         }
+#if defined(__x86_64__) || defined(__i386__)
         __builtin_ia32_pause();
+#elif defined(__aarch64__)
+        asm volatile("yield" ::: "memory");
+#endif
     }
     std::atomic_thread_fence(std::memory_order_acquire);
     *norm = slot[0];
@@ -1637,7 +1672,7 @@ int bicgstab(opmhip_ctx* c, opmhip_result* res) {
     } scope(c);
     int rc;
     hipLaunchKernelGGL(k_bicg_init, dim3(nb), dim3(VB), 0, c->stream, n, c->d_b, c->d_r, c->d_rw, c->d_p, c->d_x, c->d_v, c->d_part, c->npart);
-    finalize(c, FIN_INIT, nb);
+    if ((rc = finalize(c, FIN_INIT, nb))) return rc;
     // the reference's loop "for (it = 0.5; it < maxit; it += 0.5) { first half; it += 0.5; second half }" runs the half
     // iterations h = 0 .. 2 maxit - 1 with it = (h + 1) / 2 after half h
     const int nhalves = 2 * maxit;

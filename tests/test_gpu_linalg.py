@@ -206,7 +206,8 @@ def test_argument_errors(pkg):
 
 
 @pytest.mark.parametrize("reorder", ["graph_coloring", "line_coloring"])
-def test_add_well_contributions_to_matrix(pkg, orc, reorder):
+@pytest.mark.parametrize("repeat_in_well", [False, True])
+def test_add_well_contributions_to_matrix(pkg, orc, reorder, repeat_in_well):
     """--matrix-add-well-contributions mode (StandardWell::addWellContributions): A -= C^T D^-1 B written into the
     device-resident matrix whose pattern carries the well cliques; bit for bit, and the solve with the modified
     matrix equals the solve with the operator form of the same wells up to the Krylov tolerance."""
@@ -218,6 +219,8 @@ def test_add_well_contributions_to_matrix(pkg, orc, reorder):
     cells = rng.choice(Nb, nperf, replace=False).astype(np.int32)
     cells[6:12] = cells[6:12][np.argsort(cells[6:12])]
     cells[5] = cells[8]            # wells 1 and 2 share a cell: their contributions to block (cell, cell) are ordered
+    if repeat_in_well:             # well 0 perforates one cell twice: four of its pairs add into the same block, in order
+        cells[2] = cells[0]
     W = dict(numWells=3, val_pointers=vp, Ccols=cells, Bcols=cells.copy(), Cnnzs=0.05 * rng.standard_normal(nperf * 12),
              Bnnzs=0.05 * rng.standard_normal(nperf * 12), Dnnzs=0.5 * rng.standard_normal(3 * 16))
     # pattern + well cliques (zero blocks)

@@ -4,7 +4,7 @@ usage: tools/pmc_to_json.py <pmc outdir> <out.json>
 Correction prescribed by /opt/skills/guides/MI355X_MICROARCH.md ("HBM / rocprofv3" section): on gfx950 FETCH_SIZE reports
 half of the bytes of a wide coalesced read -> doubled; WRITE_SIZE is exact; both are in KiB; Infinity-Cache hits are
 counted (this is fabric-side traffic of the L2, an upper bound of the HBM bytes)."""
-import collections, csv, glob, json, sys
+import collections, csv, glob, hashlib, json, os, sys
 out = collections.defaultdict(lambda: collections.defaultdict(list))
 for f in glob.glob(sys.argv[1] + "/p*/**/*counter_collection.csv", recursive=True):
     for r in csv.DictReader(open(f)):
@@ -19,7 +19,11 @@ for k, d in sorted(out.items()):
     if "TCC_HIT_sum" in d:
         h, m = sum(d["TCC_HIT_sum"]) / len(d["TCC_HIT_sum"]), sum(d["TCC_MISS_sum"]) / len(d["TCC_MISS_sum"])
         res[k]["L2_hit_rate"] = h / (h + m)
-json.dump({"source": "rocprofv3 --kernel-trace --pmc, separate passes (tools/pmc_quick.sh) over bench.py --steps 6 --warmup 1",
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+hh = hashlib.sha256()
+for f in ("solver.hip", "assemble.hip", "internal.hpp"):   # bench.py's kernel_source_hash(): ties the numbers to the build
+    hh.update(open(os.path.join(ROOT, "opm-autodiff_amd", "csrc", f), "rb").read())
+json.dump({"kernel_source_sha16": hh.hexdigest()[:16], "source": "rocprofv3 --kernel-trace --pmc, separate passes (tools/pmc_quick.sh) over bench.py --steps 6 --warmup 1",
            "correction": "FETCH_SIZE x 2 on gfx950, KiB -> bytes (MI355X_MICROARCH.md HBM/rocprofv3 section)", "kernels": res}, open(sys.argv[2], "w"), indent=1)
 for k, v in res.items():
     print("%-46s %8.1f MB per launch" % (k, v["traffic_bytes_per_launch"] / 1e6))
