@@ -198,11 +198,19 @@ def main():
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group(backend="gloo")
-    if not torch.cuda.is_available():
-        raise SystemExit("bench.py needs a GPU: libopmhip has no CPU fallback")
-    if torch.cuda.device_count() <= local_rank:
-        raise SystemExit("bench.py: rank %d has no GPU (%d visible)" % (rank, torch.cuda.device_count()))
-    torch.cuda.set_device(local_rank)
+    # The product never goes through torch: libopmhip selects device `local_rank` itself and opmhip_create fails loudly
+    # (OPMHIP_NO_DEVICE) when there is none - no CPU fallback.  torch only brackets the timed region when it sees the card.
+    import ctypes
+    hip = ctypes.CDLL("libamdhip64.so")
+    torch_sees_gpu = torch.cuda.is_available() and torch.cuda.device_count() > local_rank
+    if torch_sees_gpu:
+        torch.cuda.set_device(local_rank)
+
+    def device_sync():
+        if torch_sees_gpu:
+            torch.cuda.synchronize()
+        if hip.hipDeviceSynchronize() != 0:
+            raise SystemExit("bench.py: hipDeviceSynchronize failed")
 
     pkg = importlib.import_module("opm-autodiff_amd")
     n = a.n
@@ -227,10 +235,10 @@ def main():
     B = alg_bytes(Nb, nnzb)
 
     def barrier():
-        torch.cuda.synchronize()
+        device_sync()
         if dist is not None:
             dist.barrier()
-        torch.cuda.synchronize()
+        device_sync()
 
     def timed_window(steps):
         """EXACTLY `steps` Newton iterations between two barriers; max over ranks; kernel scopes of every 4th solve"""

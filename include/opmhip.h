@@ -65,7 +65,9 @@ typedef struct opmhip_config {
     int relax_mode;        /* opmhip_relax_mode */
     int reorder;           /* opmhip_reorder */
     int zero_diag_fix;     /* 1: exact 0.0 on a diagonal block's diagonal -> 1e-15 (bda/BdaBridge.cpp:125-161) */
-    int reserved[7];
+    int reserved[7];       /* [0] line colouring: rows per chain (0 = 8).  [1] pipelined SpMV: resident workgroups it is sized
+                            * for (0 = 2048, the MI355X default; < 0 = one tile per workgroup instead).  Tuning only: results
+                            * are the same bits either way.  Others: 0. */
 } opmhip_config;
 
 /* bda::BdaResult (bda/BdaResult.hpp:28-40) plus the reference's per-phase timers. */
@@ -233,6 +235,17 @@ int opmhip_get_state(opmhip_ctx* ctx, double* pv, unsigned char* meaning);
  * asynchronous on the context's stream.  update_failed needs a preceding advance_time_level (else NOT_READY). */
 int opmhip_advance_time_level(opmhip_ctx* ctx);
 int opmhip_update_failed(opmhip_ctx* ctx);
+
+/* replaces: the drift part of EclProblem::endTimeStep (ebos/eclproblem.hh:1126-1135) and of EclProblem::source
+ * (:1847-1875).  Flow compensates systematic mass drift by default (EclEnableDriftCompensation = true, :496-498): after
+ * every ACCEPTED time step of size dt the residual of its last linearisation, times dt, is remembered per cell and
+ * subtracted as a rate from the source term of the following steps, capped at max_compensation (default 10 x
+ * NewtonTolerance = 0.1, :352-356, :1854) of the cell's pore volume per step.  opmhip_end_time_step stores
+ * residual * dt on the device (asynchronous; a rolled-back step never reaches it, so opmhip_update_failed leaves the
+ * drift alone); opmhip_assemble applies it.  opmhip_set_drift_compensation(enable = 0) = --ecl-enable-drift-compensation=false;
+ * switching it either way clears the stored drift. */
+int opmhip_end_time_step(opmhip_ctx* ctx, double dt);
+int opmhip_set_drift_compensation(opmhip_ctx* ctx, int enable, double max_compensation);
 
 /* replaces: EclProblem::source (ebos/eclproblem.hh:1823-1845): total surface-volume rate per cell and equation
  * [m^3/s] (what BlackoilWellModel::computeTotalRatesForDof adds up, wells/BlackoilWellModel_impl.hpp:496-512) and

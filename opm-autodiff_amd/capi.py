@@ -117,7 +117,7 @@ class HipSolver:
     ctor(verbosity, maxit, tolerance, deviceID), solve_system(...), get_result(x))."""
 
     def __init__(self, verbosity=0, maxit=200, tolerance=1e-2, device_id=0, ilu_relaxation=0.9,
-                 relax_mode="post_scale", reorder="graph_coloring", zero_diag_fix=True, chain_length=8):
+                 relax_mode="post_scale", reorder="graph_coloring", zero_diag_fix=True, chain_length=8, spmv_pipe_wgs=0):
         L = lib()
         cfg = Config()
         L.opmhip_default_config(C.byref(cfg))
@@ -127,6 +127,7 @@ class HipSolver:
         cfg.reorder = REORDER[reorder]
         cfg.zero_diag_fix = int(zero_diag_fix)
         cfg.reserved[0] = int(chain_length)  # line colouring: rows per chain
+        cfg.reserved[1] = int(spmv_pipe_wgs)  # pipelined SpMV: workgroups it is sized for (0 default, < 0 off; tests use small values)
         self._h = C.c_void_p()
         rc = L.opmhip_create(C.byref(cfg), C.byref(self._h))
         if rc != SUCCESS:
@@ -263,6 +264,8 @@ def _bind_assembly(L):
     L.opmhip_get_state.argtypes = [vp, vp, vp]
     L.opmhip_advance_time_level.argtypes = [vp]
     L.opmhip_update_failed.argtypes = [vp]
+    L.opmhip_end_time_step.argtypes = [vp, C.c_double]
+    L.opmhip_set_drift_compensation.argtypes = [vp, C.c_int, C.c_double]
     L.opmhip_set_source.argtypes = [vp, vp, vp]
     L.opmhip_assemble.argtypes = [vp, C.c_double, C.c_int, vp, vp]
     L.opmhip_get_iq.argtypes = [vp, vp]
@@ -364,6 +367,13 @@ class HipModel(HipSolver):
     def update_failed(self):
         """solution(0) = solution(1) + intensive quantities: the Newton method gave up on this time step."""
         self._check(lib().opmhip_update_failed(self._h))
+
+    def end_time_step(self, dt):
+        """EclProblem::endTimeStep (drift part): remember residual * dt of the time step that was just accepted."""
+        self._check(lib().opmhip_end_time_step(self._h, dt))
+
+    def set_drift_compensation(self, enable=True, max_compensation=0.1):
+        self._check(lib().opmhip_set_drift_compensation(self._h, int(enable), max_compensation))
 
     def set_source(self, source, dsource=None):
         s, d = _f64(source), _f64(dsource)

@@ -473,8 +473,8 @@ __global__ __launch_bounds__(ASM_THREADS) ASM_OCC void k_assemble(int ntiles, co
                                                           const int* __restrict__ col, const int* __restrict__ natOrder,
                                                           EntryStatic ES, CellStatic C, const double* __restrict__ iq,
                                                           double* __restrict__ storageOld, const double* __restrict__ source,
-                                                          const double* __restrict__ dsource, double dt, int iteration,
-                                                          double* __restrict__ A, double* __restrict__ resid) {
+                                                          const double* __restrict__ dsource, const double* __restrict__ drift, double maxCompensation,
+                                                          double dt, int iteration, double* __restrict__ A, double* __restrict__ resid) {
     __shared__ __attribute__((aligned(16))) double sblk[(ASM_THREADS + 2) * BB];  // the tile's blocks, then streamed out
     __shared__ double sflux[ASM_THREADS * 12];                                     // face flux seen from the row's cell
     __shared__ __attribute__((aligned(16))) double sI[ASM_MAX_ROWS * IQS];         // IQ records of the tile's rows
@@ -564,10 +564,26 @@ __global__ __launch_bounds__(ASM_THREADS) ASM_OCC void k_assemble(int ntiles, co
             tt = tt * (V / dt);
             R[e] = R[e] + tt;
         }
+        // drift compensation (ebos/eclproblem.hh:1847-1875): what the last accepted time step left unconverged in this
+        // cell (residual * dt, opmhip_end_time_step) goes back in as a rate, capped at maxCompensation of the pore volume
+        double dofDriftRate[3] = {0.0, 0.0, 0.0};
+        if (drift) {
+            const double poro = C.poro[I];   // referencePorosity
+#pragma unroll
+            for (int e = 0; e < 3; ++e) dofDriftRate[e] = drift[(size_t)I * 3 + e] / (dt * V);
+            double totalDriftRate = 0.0;
+#pragma unroll
+            for (int e = 0; e < 3; ++e) totalDriftRate += fabs(dofDriftRate[e]) * dt * 1.0 / poro;   // eqWeight = 1 (UNVERIFIED, see oracle)
+            if (totalDriftRate > maxCompensation) {
+#pragma unroll
+                for (int e = 0; e < 3; ++e) dofDriftRate[e] *= maxCompensation / totalDriftRate;
+            }
+        }
         for (int e = 0; e < 3; ++e) {
             Ad s = ad_const(source ? source[(size_t)I * 3 + e] : 0.0);
             if (dsource) { s.d0 = dsource[(size_t)I * 9 + e * 3]; s.d1 = dsource[(size_t)I * 9 + e * 3 + 1]; s.d2 = dsource[(size_t)I * 9 + e * 3 + 2]; }
             s = s / V;
+            if (drift) s = s - dofDriftRate[e];
             s = s * V;
             R[e] = R[e] - s;
         }
@@ -700,6 +716,16 @@ __global__ __launch_bounds__(256) void k_conv_final2(int nblocks, const double* 
     if (threadIdx.x == 0) out[10] = sh[0];
 }
 
+// EclProblem::endTimeStep, drift part (ebos/eclproblem.hh:1126-1135): drift = residual * dt of the accepted step
+__global__ void k_drift_update(int n, const double* __restrict__ resid, double dt, double* __restrict__ drift) {
+    const int e = blockIdx.x * blockDim.x + threadIdx.x;
+    if (e < n) drift[e] = resid[e] * dt;
+}
+void launch_drift_update(opmhip_ctx* c, double dt) {
+    const int n = c->pat.Nb * 3;
+    hipLaunchKernelGGL(k_drift_update, dim3((n + 255) / 256), dim3(256), 0, c->stream, n, c->d_b, dt, c->asmb.d_drift);
+}
+
 // ============================== small permutation helpers =====================================================
 __global__ void k_cellvec_to_internal_u8(int Nb, const int* __restrict__ fromOrder, const unsigned char* __restrict__ nat, unsigned char* __restrict__ internal) {
     const int p = blockIdx.x * blockDim.x + threadIdx.x;
@@ -758,7 +784,8 @@ void launch_assemble(opmhip_ctx* c, double dt, int iteration) {
     EntryStatic ES{c->asmb.d_trans, c->asmb.d_area, c->asmb.d_thpres, c->asmb.d_lowFirst};
     const int ps = prof_begin(c, PROF_ASSEMBLE);
     hipLaunchKernelGGL(k_assemble, dim3(8 * ((c->asmb.ntiles + 7) / 8)), dim3(ASM_THREADS), 0, c->stream, c->asmb.ntiles, c->asmb.d_asm_order, c->asmb.d_asm_row0, P.d_rowptr, P.d_col, c->asmb.d_natOrder, ES,
-                       cells_of(c), c->asmb.d_iq, c->asmb.d_storageOld, c->asmb.d_source, c->asmb.d_dsource, dt, iteration, c->d_A, c->d_b);
+                       cells_of(c), c->asmb.d_iq, c->asmb.d_storageOld, c->asmb.d_source, c->asmb.d_dsource,
+                       c->asmb.drift_enabled ? c->asmb.d_drift : (const double*)nullptr, c->asmb.max_compensation, dt, iteration, c->d_A, c->d_b);
     prof_end(c, ps);
 }
 int launch_convergence(opmhip_ctx* c, double dt, double tol_cnv) {

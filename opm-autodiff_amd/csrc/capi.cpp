@@ -34,7 +34,7 @@ int alloc_system(opmhip_ctx* c) {
     if ((rc = dev_alloc(c, &c->d_scal, (size_t)SC_COUNT))) return rc;
     OPMHIP_HIP(c, hipMemset(c->d_scal, 0, SC_COUNT * sizeof(double)));
     const int vb = (int)((n + 2047) / 2048);
-    c->npart = std::max(P.tiles.ntiles(), vb) + 1;
+    c->npart = std::max(std::max(P.tiles.ntiles(), P.tiles.nsched), vb) + 1;
     if ((rc = dev_alloc(c, &c->d_part, (size_t)2 * c->npart))) return rc;
     OPMHIP_HIP(c, hipMemset(c->d_part, 0, (size_t)2 * c->npart * sizeof(double)));
     if ((rc = dev_alloc(c, &c->d_part2, (size_t)1024))) return rc;

@@ -127,6 +127,8 @@ int opmhip_set_static(opmhip_ctx* c, const double* trans, const double* area, co
             if ((rc = dev_alloc(c, &A.d_pv, Nb * 3))) return rc;
             if ((rc = dev_alloc(c, &A.d_iq, Nb * (size_t)iq_doubles_per_cell()))) return rc;
             if ((rc = dev_alloc(c, &A.d_storageOld, Nb * 3))) return rc;
+            if ((rc = dev_alloc(c, &A.d_drift, Nb * 3))) return rc;
+            OPMHIP_HIP(c, hipMemset(A.d_drift, 0, Nb * 3 * sizeof(double)));
             if ((rc = dev_alloc(c, &A.d_source, Nb * 3))) return rc;
             if ((rc = dev_alloc(c, &A.d_dsource, Nb * 9))) return rc;
             if ((rc = dev_alloc(c, &A.d_meaning, Nb))) return rc;
@@ -280,6 +282,34 @@ int opmhip_update_failed(opmhip_ctx* c) {
         launch_iq_update(c);
         OPMHIP_HIP(c, hipGetLastError());
         A.assembled = false;
+        return OPMHIP_SUCCESS;
+    });
+}
+
+int opmhip_end_time_step(opmhip_ctx* c, double dt) {
+    if (!c) return OPMHIP_INVALID_ARGUMENT;
+    return guarded(c, [&]() -> int {
+        AsmDev& A = c->asmb;
+        if (!A.assembled) return fail(c, OPMHIP_NOT_READY, "end_time_step before assemble: no residual of an accepted step on the device");
+        if (!(dt > 0.0)) return fail(c, OPMHIP_INVALID_ARGUMENT, "end_time_step: dt must be positive");
+        if (!A.drift_enabled) return OPMHIP_SUCCESS;
+        OPMHIP_HIP(c, hipSetDevice(c->device));
+        launch_drift_update(c, dt);
+        OPMHIP_HIP(c, hipGetLastError());
+        return OPMHIP_SUCCESS;
+    });
+}
+
+int opmhip_set_drift_compensation(opmhip_ctx* c, int enable, double max_compensation) {
+    if (!c) return OPMHIP_INVALID_ARGUMENT;
+    return guarded(c, [&]() -> int {
+        if (enable && !(max_compensation > 0.0)) return fail(c, OPMHIP_INVALID_ARGUMENT, "set_drift_compensation: max_compensation must be positive");
+        c->asmb.drift_enabled = enable != 0;
+        if (enable) c->asmb.max_compensation = max_compensation;
+        if (c->asmb.d_drift) {   // switching it on or off starts from a clean slate, like a fresh EclProblem
+            OPMHIP_HIP(c, hipSetDevice(c->device));
+            OPMHIP_HIP(c, hipMemsetAsync(c->asmb.d_drift, 0, (size_t)c->pat.Nloc * 3 * sizeof(double), c->stream));
+        }
         return OPMHIP_SUCCESS;
     });
 }

@@ -36,14 +36,23 @@ struct TileSet {            // tiles over one block-CSR row-pointer array, never
     std::vector<int> colorTile;  // [numColors+1] first tile of each colour
     std::vector<int> ctFirst;    // [nChainTiles+1] first sub-tile of each chain-tile (steps of <= TILE_ROWS chains)
     std::vector<int> colorCT;    // [numColors+1] first chain-tile of each colour
+    // launch schedules (reorder.cpp: build_schedules): position -> work item, dealt so that position % 8 (= the XCD a
+    // workgroup lands on) walks through one spatial stretch of the grid at a time
+    std::vector<int> spmvSched;  // [4 * nsched] (r0, r1, rowptr[r0], rowptr[r1]) of every SpMV launch position; r1 <= r0 = padding
+    int nsched = 0;
+    std::vector<int> ctSched;    // per colour, padded to a multiple of 8: chain-tile of every launch position or -1
+    std::vector<int> ctSchedOff; // [numColors+1] offsets into ctSched
     int* d_row0 = nullptr;
     int* d_ctFirst = nullptr;
+    int* d_spmvSched = nullptr;
+    int* d_ctSched = nullptr;
     int ntiles() const { return (int)row0.size() - 1; }
 };
 
 struct Pattern {
     int Nb = 0, nnzb = 0, numColors = 0, nl = 0, nu = 0;  // Nb = owned block rows
     int Nghost = 0, Nloc = 0;                            // ghost cells numbered Nb..Nloc-1 (vectors have Nloc entries)
+    int maxRowBlocks = 0;                                // longest row, in blocks
     bool chained = false;  // line colouring: rows of one colour may depend on earlier rows of their own chain
     // per colour: every row's L (U) part is at most the row's own chain predecessor (successor) - the sweep is then a
     // lane-private recurrence and runs in the light kernel (no LDS staging, deep prefetch)
@@ -85,6 +94,9 @@ struct AsmDev {
     int *d_pvtnum = nullptr, *d_satnum = nullptr;
     double *d_pv = nullptr, *d_iq = nullptr, *d_storageOld = nullptr, *d_source = nullptr, *d_dsource = nullptr;
     unsigned char *d_meaning = nullptr, *d_wasSwitched = nullptr, *d_stage_u8 = nullptr;
+    double* d_drift = nullptr;              // residual * dt of the last accepted time step (drift compensation), Nloc x 3
+    bool drift_enabled = true;              // EclEnableDriftCompensation defaults to true (ebos/eclproblem.hh:496-498)
+    double max_compensation = 0.1;          // 10 * NewtonTolerance (ebos/eclproblem.hh:352-356, 1854)
     double* d_pv_prev = nullptr;            // solution(1): primary variables at the start of the time step
     unsigned char* d_meaning_prev = nullptr;
     bool prev_set = false;
@@ -321,6 +333,7 @@ void launch_iq_update(opmhip_ctx* c);
 int launch_ghost_refresh(opmhip_ctx* c);
 void launch_newton_update(opmhip_ctx* c, const double* d_dx_internal, double relax);
 void launch_assemble(opmhip_ctx* c, double dt, int iteration);
+void launch_drift_update(opmhip_ctx* c, double dt);
 int launch_convergence(opmhip_ctx* c, double dt, double tol_cnv);
 void launch_u8_to_internal(opmhip_ctx* c, const unsigned char* nat, unsigned char* internal);
 void launch_u8_to_natural(opmhip_ctx* c, const unsigned char* internal, unsigned char* nat);

@@ -2,9 +2,14 @@
 // bda/BILU0.cpp:51-158): ILU ordering, internal (reordered) block-CSR pattern, L/U split, device tiling.
 #include <algorithm>
 #include <cstdint>
+#include <cstdlib>
 #include <numeric>
 
 #include "internal.hpp"
+
+#ifndef OPMHIP_XCD_GROUP_DEFAULT
+#define OPMHIP_XCD_GROUP_DEFAULT 0
+#endif
 
 namespace opmhip {
 namespace {
@@ -198,6 +203,72 @@ void color_chains(const Pattern& P, const Chains& C, std::vector<int>& chainColo
     }
 }
 
+// Launch schedules.  The hardware deals consecutive workgroups of a launch round-robin over the 8 XCDs, each with an L2 of
+// its own.  With the identity map (workgroup b = tile b) a line of the gathered vector is wanted by ~7 tiles that land
+// on ~5 different XCDs and is fetched from the fabric by each (PMC: the 24 MB input vector of the 100^3 SpMV costs
+// 116 MB).  The schedule keeps the streaming shape (all 8 XCDs walk through memory side by side) but hands every XCD
+// GROUPS of `G` consecutive chain-tiles of every colour at the same relative position of their colour - the same stretch
+// of the grid - so that most neighbours of a tile are gathered through the L2 that already holds them.
+// Results do not depend on the schedule (each tile's arithmetic is its own); only the order of the partial sums does.
+void build_schedules(Pattern& P, int G) {
+    TileSet& T = P.tiles;
+    const int ncol = P.numColors;
+    const int nt = T.ntiles();
+    auto deal = [](const std::vector<std::vector<int>>& lists, int pad, std::vector<int>& out) {
+        size_t L = 0;
+        for (const auto& l : lists) L = std::max(L, l.size());
+        for (size_t j = 0; j < L; ++j)
+            for (int k = 0; k < 8; ++k) out.push_back(j < lists[k].size() ? lists[k][j] : pad);
+    };
+    T.ctSched.clear();
+    T.ctSchedOff.assign(ncol + 1, 0);
+    std::vector<int> order;  // SpMV: tiles in launch order (-1 = padding)
+    const bool grouped = P.chained && G > 0;
+    if (!grouped) {
+        for (int t = 0; t < nt; ++t) order.push_back(t);
+        while (order.size() % 8) order.push_back(-1);
+        for (int c = 0; c < ncol; ++c) {
+            for (int q = T.colorCT[c]; q < T.colorCT[c + 1]; ++q) T.ctSched.push_back(q);
+            while (T.ctSched.size() % 8) T.ctSched.push_back(-1);
+            T.ctSchedOff[c + 1] = (int)T.ctSched.size();
+        }
+    } else {
+        int maxct = 0;
+        for (int c = 0; c < ncol; ++c) maxct = std::max(maxct, T.colorCT[c + 1] - T.colorCT[c]);
+        const int NG = std::max(1, (maxct + G - 1) / G);
+        // group of chain-tile q (0-based inside colour c): by relative position, so that the colours line up in space
+        auto group_of = [&](int c, int q) { return (int)(((long long)q * NG) / std::max(1, T.colorCT[c + 1] - T.colorCT[c])); };
+        std::vector<std::vector<int>> spmvLists(8);
+        std::vector<std::vector<std::vector<int>>> byGroup(ncol, std::vector<std::vector<int>>(NG));
+        for (int c = 0; c < ncol; ++c)
+            for (int q = T.colorCT[c]; q < T.colorCT[c + 1]; ++q) byGroup[c][group_of(c, q - T.colorCT[c])].push_back(q);
+        for (int g = 0; g < NG; ++g) {
+            size_t m = 0;
+            for (int c = 0; c < ncol; ++c) m = std::max(m, byGroup[c][g].size());
+            for (size_t i = 0; i < m; ++i)   // colours interleaved chain-tile by chain-tile
+                for (int c = 0; c < ncol; ++c)
+                    if (i < byGroup[c][g].size())
+                        for (int t = T.ctFirst[byGroup[c][g][i]]; t < T.ctFirst[byGroup[c][g][i] + 1]; ++t) spmvLists[g % 8].push_back(t);
+        }
+        deal(spmvLists, -1, order);
+        for (int c = 0; c < ncol; ++c) {
+            std::vector<std::vector<int>> lists(8);
+            for (int g = 0; g < NG; ++g)
+                for (int q : byGroup[c][g]) lists[g % 8].push_back(q);
+            deal(lists, -1, T.ctSched);
+            T.ctSchedOff[c + 1] = (int)T.ctSched.size();
+        }
+    }
+    T.nsched = (int)order.size();
+    T.spmvSched.assign((size_t)4 * T.nsched, 0);
+    for (int b = 0; b < T.nsched; ++b)
+        if (order[b] >= 0) {
+            const int r0 = T.row0[order[b]], r1 = T.row0[order[b] + 1];
+            T.spmvSched[4 * b] = r0; T.spmvSched[4 * b + 1] = r1;
+            T.spmvSched[4 * b + 2] = P.rowptr[r0]; T.spmvSched[4 * b + 3] = P.rowptr[r1];
+        }
+}
+
 }  // namespace
 
 int build_pattern(opmhip_ctx* c, int Nb, int Nghost, int nnzb, const int* rows, const int* cols) {
@@ -212,6 +283,8 @@ int build_pattern(opmhip_ctx* c, int Nb, int Nghost, int nnzb, const int* rows, 
     P.Nghost = Nghost;
     P.Nloc = Nloc;
     P.nnzb = nnzb;
+    P.maxRowBlocks = 0;
+    for (int i = 0; i < Nb; ++i) P.maxRowBlocks = std::max(P.maxRowBlocks, rows[i + 1] - rows[i]);
     P.nat_rowptr.assign(rows, rows + Nb + 1);
     P.nat_col.assign(cols, cols + nnzb);
     for (int i = 0; i < Nb; ++i) {
@@ -402,7 +475,14 @@ int build_pattern(opmhip_ctx* c, int Nb, int Nghost, int nnzb, const int* rows, 
                 return fail(c, OPMHIP_ANALYSIS_FAILED, "line colouring: a chain-tile has %d steps (limit 128); lower the chain length", T.ctFirst[q + 1] - T.ctFirst[q]);
     }
 
+    {
+        // OPMHIP_XCD_GROUP: chain-tiles per XCD group of the launch schedules (0 = identity map); tuning knob, see DESIGN.md
+        const char* e = std::getenv("OPMHIP_XCD_GROUP");
+        build_schedules(P, e ? std::atoi(e) : OPMHIP_XCD_GROUP_DEFAULT);
+    }
     int rc;
+    if ((rc = dev_upload(c, &P.tiles.d_spmvSched, P.tiles.spmvSched))) return rc;
+    if ((rc = dev_upload(c, &P.tiles.d_ctSched, P.tiles.ctSched))) return rc;
     if ((rc = dev_upload(c, &P.d_rowptr, P.rowptr))) return rc;
     if ((rc = dev_upload(c, &P.d_col, P.col))) return rc;
     if ((rc = dev_upload(c, &P.d_diag, P.diag))) return rc;

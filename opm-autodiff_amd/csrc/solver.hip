@@ -17,6 +17,7 @@
 
 #include <chrono>
 #include <cmath>
+#include <cstdlib>
 
 #include "internal.hpp"
 
@@ -29,6 +30,18 @@ namespace opmhip {
 #ifndef OPMHIP_STAGE_DEPTH
 #define OPMHIP_STAGE_DEPTH 16
 #endif
+// 16-byte load of a value that is read exactly once per launch (matrix / factor streams): nontemporal, so that the stream
+// does not push the vectors out of L2 and the Infinity Cache.  tools/probe/stream_probe.hip on MI355X: a 500 MB stream read
+// in 16-KiB tiles reaches 6.2 TB/s with plain loads and 6.9 TB/s with nontemporal ones.
+typedef double v2d_t __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ double2 ld_stream(const double2* p) {
+#if defined(OPMHIP_NO_NT_LOADS)
+    return *p;
+#else
+    const v2d_t t = __builtin_nontemporal_load(reinterpret_cast<const v2d_t*>(p));
+    return make_double2(t.x, t.y);
+#endif
+}
 __device__ __forceinline__ void stage_doubles(const double* __restrict__ src, double* __restrict__ dst, int n, int lane) {
     const double2* __restrict__ s2 = reinterpret_cast<const double2*>(src);
     double2* __restrict__ d2 = reinterpret_cast<double2*>(dst);
@@ -43,7 +56,7 @@ __device__ __forceinline__ void stage_doubles(const double* __restrict__ src, do
 #pragma unroll
         for (int u = 0; u < U; ++u) {
             const int i = base + u * 64 + lane;
-            tmp[u] = s2[i < n2 ? i : n2 - 1];  // clamped, unconditional: keeps tmp[] in registers
+            tmp[u] = ld_stream(&s2[i < n2 ? i : n2 - 1]);  // clamped, unconditional: keeps tmp[] in registers
         }
         // keep the whole batch of loads ahead of the first LDS write: without these empty asm "uses" hipcc sinks every
         // load under its store's bounds check and serialises load -> s_waitcnt vmcnt(0) -> ds_write, 1 KiB at a time
@@ -172,14 +185,17 @@ __device__ __forceinline__ void blk_apply(const double* A, const double* xx, dou
 // Accumulates acc (+/-)= sum_k A_k x[col_k] over the lane's row of tile t, blocks taken in ascending (or, with
 // reverse, descending) column order.  Returns the lane's row index or -1 for an idle lane.  Contains a barrier.
 template <bool SUB>
-__device__ __forceinline__ int tile_row_product(int t, const int* __restrict__ tile_row0, const int* __restrict__ rowptr,
+__device__ __forceinline__ int tile_row_product(int tr0, int tr1, const int* __restrict__ rowptr,
                                                 const int* __restrict__ col, const double* __restrict__ val,
                                                 const double* __restrict__ x, double* sval, int lane, bool reverse, double* acc,
-                                                TileCtx& T, const double* __restrict__ xlo = nullptr, int xsplit = 0) {
+                                                TileCtx& T, const double* __restrict__ xlo = nullptr, int xsplit = 0,
+                                                int tk0 = -1, int tk1 = -1) {
     // vector entries of columns < xsplit are read from xlo instead of x (ILU sweeps: first colour's y equals d)
-    T.r0 = tile_row0[t];
-    T.r1 = tile_row0[t + 1];
-    const int k0 = rowptr[T.r0], k1 = rowptr[T.r1];
+    // tk0, tk1 >= 0: the tile's entry range is known already (it came with the launch schedule): one dependent load less
+    // before the value stream can be issued
+    T.r0 = tr0;
+    T.r1 = tr1;
+    const int k0 = tk0 >= 0 ? tk0 : rowptr[T.r0], k1 = tk1 >= 0 ? tk1 : rowptr[T.r1];
     T.k0e = k0 & ~1;
     T.nb = k1 - T.k0e;
     T.staged = (T.nb <= TILE_CAP_BLOCKS + 1);
@@ -210,7 +226,7 @@ __device__ __forceinline__ int tile_row_product(int t, const int* __restrict__ t
 #pragma unroll
         for (int u = 0; u < U; ++u) {
             const int i = u * 64 + lane;
-            tmp[u] = s2[i < n2 ? i : n2 - 1];
+            tmp[u] = ld_stream(&s2[i < n2 ? i : n2 - 1]);
         }
 #pragma unroll
         for (int u = 0; u < GCH; ++u) {
@@ -228,7 +244,7 @@ __device__ __forceinline__ int tile_row_product(int t, const int* __restrict__ t
 #pragma unroll
             for (int u = 0; u < U; ++u) {
                 const int i = base + u * 64 + lane;
-                tmp[u] = s2[i < n2 ? i : n2 - 1];
+                tmp[u] = ld_stream(&s2[i < n2 ? i : n2 - 1]);
             }
 #pragma unroll
             for (int u = 0; u < U; ++u) asm volatile("" : "+v"(tmp[u].x), "+v"(tmp[u].y));
@@ -328,18 +344,26 @@ __global__ void k_lu_to_bcrs(int Nb, const int* __restrict__ rowptr, const int* 
 // ============================== SpMV ======================================================================
 // y = A x in BCRSMatrix::mv order (y_i = 0, then umv block by block in ascending column order).
 // NDOT = 1: part[t] = sum_rows y.w0            NDOT = 2: additionally part[npart+t] = sum_rows y.y
+// Launch position b -> rows [sched[b].x, sched[b].y) with entries [sched[b].z, sched[b].w) (an empty range = padding).  The schedule is built on the host
+// (reorder.cpp: build_schedules): consecutive workgroups land on consecutive XCDs, and the schedule gives every XCD runs of
+// tiles that gather from the same stretch of the input vector, so that a line of x is fetched by one L2, not by five.
 template <int NDOT>
-__global__ __launch_bounds__(64) void k_spmv(int nt, const int* __restrict__ tile_row0, const int* __restrict__ rowptr,
+__global__ __launch_bounds__(64) void k_spmv(const int4* __restrict__ sched, const int* __restrict__ rowptr,
                                              const int* __restrict__ col, const double* __restrict__ val,
                                              const double* __restrict__ x, double* __restrict__ y,
                                              const double* __restrict__ w0, double* __restrict__ part, int npart,
                                              const double* __restrict__ done) {
     TILE_LDS
-    const int lane = threadIdx.x, t = xcd_tile(blockIdx.x, nt);
-    if (t >= nt || *done != 0.0) return;
+    const int lane = threadIdx.x, t = blockIdx.x;
+    if (*done != 0.0) return;
+    const int4 rows = sched[t];   // r0, r1, rowptr[r0], rowptr[r1]
+    if (rows.y <= rows.x) {  // padding of the schedule: its partial sums are zero
+        if (NDOT >= 1 && lane == 0) { part[t] = 0.0; if (NDOT == 2) part[npart + t] = 0.0; }
+        return;
+    }
     TileCtx T;
     double acc[3] = {0.0, 0.0, 0.0};
-    const int r = tile_row_product<false>(t, tile_row0, rowptr, col, val, x, sval, lane, false, acc, T);
+    const int r = tile_row_product<false>(rows.x, rows.y, rowptr, col, val, x, sval, lane, false, acc, T, nullptr, 0, rows.z, rows.w);
     if (r >= 0) {
         double* yr = &y[(size_t)r * BS];
         yr[0] = acc[0]; yr[1] = acc[1]; yr[2] = acc[2];
@@ -357,6 +381,139 @@ __global__ __launch_bounds__(64) void k_spmv(int nt, const int* __restrict__ til
             part[t] = d0;
             if (NDOT == 2) part[npart + t] = d1;
         }
+    }
+}
+
+// Pipelined SpMV: the same tiles, the same per-row arithmetic, but every workgroup (one wavefront) walks through a list of
+// tiles - launch positions blockIdx.x, + gridDim.x, + 2 gridDim.x ... - in a software pipeline, so that the chain of
+// dependent loads of a tile (schedule entry -> row bounds -> column indices -> vector gathers) runs one to three tiles
+// AHEAD of the arithmetic and the next tile's 16-KiB value stream is always in flight while this tile is multiplied out
+// of LDS.  In the one-tile-per-workgroup kernel a wavefront spends most of its ~9 us life waiting for those four hops one
+// after the other and the launch moves 5.2 TB/s; a stream that is always in flight reaches 6.2-6.9 TB/s on this card
+// (tools/probe/stream_probe.hip).  Used when no row is longer than PGCH blocks (the host checks), else k_spmv.
+//   S(st+4): schedule entry (scalar)   A(st+3): row bounds   C(st+2): column indices
+//   G(st+1): value stream + vector gathers + dot operand      X(st): values -> LDS, products, store
+constexpr int PGCH = 8;
+template <int NDOT>
+__global__ __launch_bounds__(64) void k_spmv_pipe(int npos, const int4* __restrict__ sched, const int* __restrict__ rowptr,
+                                                  const int* __restrict__ col, const double* __restrict__ val,
+                                                  const double* __restrict__ x, double* __restrict__ y,
+                                                  const double* __restrict__ w0, double* __restrict__ part, int npart,
+                                                  const double* __restrict__ done) {
+    TILE_LDS
+    const int lane = threadIdx.x, G = gridDim.x;
+    if (*done != 0.0) return;
+    constexpr int U = 16;  // 16 x 64 lanes x 16 B = 16 KiB >= any staged tile
+    const int nsteps = ((int)blockIdx.x < npos) ? (npos - (int)blockIdx.x + G - 1) / G : 0;
+    struct StA { int4 rows; int rr, kb, ke; bool active; };
+    struct StC { int4 rows; int rr, kb, nrow; bool active; int cc[PGCH]; };
+    struct StG {
+        int r, kb, nrow, k0e, n, n2;
+        double2 tmp[U];
+        double xx[PGCH][3], w[3];
+    };
+    auto stageS = [&](int st) -> int4 { return sched[(int)blockIdx.x + st * G]; };
+    auto stageA = [&](const int4& rows, StA& a) {
+        a.rows = rows;
+        a.active = rows.x + lane < rows.y;
+        a.rr = a.active ? rows.x + lane : (rows.y > rows.x ? rows.y - 1 : 0);
+        a.kb = rowptr[a.rr];
+        a.ke = rowptr[a.rr + 1];
+    };
+    auto stageC = [&](const StA& a, StC& c) {
+        c.rows = a.rows; c.rr = a.rr; c.kb = a.kb; c.active = a.active;
+        c.nrow = a.active ? a.ke - a.kb : 0;
+#pragma unroll
+        for (int u = 0; u < PGCH; ++u) c.cc[u] = (u < c.nrow) ? col[a.kb + u] : a.rr;  // idle slots: the lane's own row, always valid
+    };
+    auto stageG = [&](const StC& c, StG& b) {
+        b.k0e = c.rows.z & ~1;
+        const int nb = c.rows.w - b.k0e;
+        b.n = (c.rows.y > c.rows.x) ? nb * BB : 0;
+        b.n2 = b.n >> 1;
+        b.r = c.active ? c.rr : -1;
+        b.kb = c.kb;
+        b.nrow = c.nrow;
+        if (b.n2 > 0) {
+            const double2* __restrict__ s2 = reinterpret_cast<const double2*>(val + (size_t)b.k0e * BB);
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const int i = u * 64 + lane;
+                b.tmp[u] = ld_stream(&s2[i < b.n2 ? i : b.n2 - 1]);
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < PGCH; ++u) {
+            const double* xc = &x[(size_t)c.cc[u] * BS];
+            b.xx[u][0] = xc[0]; b.xx[u][1] = xc[1]; b.xx[u][2] = xc[2];
+        }
+        if (NDOT >= 1) {
+            const double* wr = &w0[(size_t)c.rr * BS];
+            b.w[0] = wr[0]; b.w[1] = wr[1]; b.w[2] = wr[2];
+        }
+    };
+    int4 sNext = make_int4(0, 0, 0, 0);
+    StA a;
+    StC c;
+    StG b;
+    // prologue: fill the pipeline
+    if (nsteps > 0) { stageA(stageS(0), a); stageC(a, c); stageG(c, b); }
+    if (nsteps > 1) { stageA(stageS(1), a); stageC(a, c); }
+    if (nsteps > 2) stageA(stageS(2), a);
+    if (nsteps > 3) sNext = stageS(3);
+    double2* d2 = reinterpret_cast<double2*>(sval);
+    for (int st = 0; st < nsteps; ++st) {
+        // ---- X(st), part 1: this tile's values -> LDS
+#pragma unroll
+        for (int u = 0; u < U; ++u) asm volatile("" : "+v"(b.tmp[u].x), "+v"(b.tmp[u].y));
+        const int r = b.r, kb = b.kb, nrow = b.nrow, k0e = b.k0e, n = b.n, n2 = b.n2;
+        double xx[PGCH][3], w[3] = {b.w[0], b.w[1], b.w[2]};
+#pragma unroll
+        for (int u = 0; u < PGCH; ++u) { xx[u][0] = b.xx[u][0]; xx[u][1] = b.xx[u][1]; xx[u][2] = b.xx[u][2]; }
+        if (n2 > 0) {
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const int i = u * 64 + lane;
+                if (i < n2) d2[i] = b.tmp[u];
+            }
+            if ((n & 1) && lane == 0) sval[n - 1] = val[(size_t)k0e * BB + n - 1];
+        }
+        wave_sync();
+        // ---- the loads of the tiles ahead go out now and fly during this tile's arithmetic
+        if (st + 1 < nsteps) {
+            stageG(c, b);
+            if (st + 2 < nsteps) {
+                stageC(a, c);
+                if (st + 3 < nsteps) {
+                    stageA(sNext, a);
+                    if (st + 4 < nsteps) sNext = stageS(st + 4);
+                }
+            }
+        }
+        // ---- X(st), part 2: products in BCRSMatrix::mv order, store, partial dots
+        const int pos = (int)blockIdx.x + st * G;
+        double acc[3] = {0.0, 0.0, 0.0};
+        if (r >= 0) {
+#pragma unroll
+            for (int u = 0; u < PGCH; ++u)
+                if (u < nrow) blk_umv(&sval[(kb + u - k0e) * BB], xx[u][0], xx[u][1], xx[u][2], acc);
+            double* yr = &y[(size_t)r * BS];
+            yr[0] = acc[0]; yr[1] = acc[1]; yr[2] = acc[2];
+        }
+        if (NDOT >= 1) {
+            double d0 = 0.0, d1 = 0.0;
+            if (r >= 0) {
+                d0 = acc[0] * w[0]; d0 += acc[1] * w[1]; d0 += acc[2] * w[2];
+                if (NDOT == 2) { d1 = acc[0] * acc[0]; d1 += acc[1] * acc[1]; d1 += acc[2] * acc[2]; }
+            }
+            d0 = wave_sum(d0);
+            if (NDOT == 2) d1 = wave_sum(d1);
+            if (lane == 0) {
+                part[pos] = d0;
+                if (NDOT == 2) part[npart + pos] = d1;
+            }
+        }
+        wave_sync();  // the LDS image may be overwritten
     }
 }
 
@@ -393,7 +550,7 @@ __global__ __launch_bounds__(64) void k_ilu_sweep(int tile_begin, int ntc, int n
     }
     TileCtx T;
     const bool reverse = (SHAPE == SW_UF) && relax_mode == 0;
-    const int r = tile_row_product<true>(t, tile_row0, prow, pcol, P, vu, sval, lane, reverse, rhs, T, d, n0);
+    const int r = tile_row_product<true>(r0, r1, prow, pcol, P, vu, sval, lane, reverse, rhs, T, d, n0);
     if (r < 0) return;
     if (SHAPE == SW_L) {
         vu[(size_t)r * BS] = rhs[0]; vu[(size_t)r * BS + 1] = rhs[1]; vu[(size_t)r * BS + 2] = rhs[2];
@@ -492,7 +649,7 @@ __device__ __forceinline__ void chain_sweep(const int q0, const int q1, const in
 #pragma unroll
             for (int u = 0; u < U; ++u) {
                 const int i = u * 64 + lane;
-                b.tmp[u] = s2[i < b.n2 ? i : b.n2 - 1];
+                b.tmp[u] = ld_stream(&s2[i < b.n2 ? i : b.n2 - 1]);
             }
         }
         const double* rsrc = (SHAPE == SW_L) ? d : vu;  // the lane's own row: no earlier step of this sweep writes it
@@ -711,7 +868,7 @@ __device__ __forceinline__ void chain_sweep_light(const int q0, const int q1, co
 // The later colours then read dvec as it stands.  Same expressions as the stand-alone kernels: bit-identical vectors.
 enum { DM_PUPD = 1, DM_UPD1 = 2 };
 template <int DM>
-__global__ __launch_bounds__(64) void k_ilu_sweep_light_fused(int ct_begin, int nct, const int* __restrict__ ct_first,
+__global__ __launch_bounds__(64) void k_ilu_sweep_light_fused(const int* __restrict__ ct_sched, int nct, const int* __restrict__ ct_first,
                                                               const int* __restrict__ tile_row0, const int* __restrict__ prow,
                                                               const int* __restrict__ pcol, const double* __restrict__ P,
                                                               double* dvec, double* vu, const double* __restrict__ scal,
@@ -719,10 +876,11 @@ __global__ __launch_bounds__(64) void k_ilu_sweep_light_fused(int ct_begin, int 
                                                               double* xvec, int f0, int f1, double* __restrict__ part) {
     constexpr int D = LIGHT_DEPTH;
     __shared__ int srow0[CHAIN_MAX_STEPS + 2];
-    const int lane = threadIdx.x, cl = xcd_tile(blockIdx.x, nct);
-    if (cl >= nct || scal[SC_DONE] != 0.0) return;
+    const int lane = threadIdx.x, cl = blockIdx.x;  // launch position; nct = positions of this colour's schedule
+    if (scal[SC_DONE] != 0.0) return;
     const double alpha = scal[SC_ALPHA], omega = scal[SC_OMEGA], beta = scal[SC_BETA];
-    const int q0 = ct_first[ct_begin + cl], q1 = ct_first[ct_begin + cl + 1];
+    const int ct = ct_sched[cl];  // -1: padding of the schedule - no chain rows, but still its share of the other rows
+    const int q0 = ct >= 0 ? ct_first[ct] : 0, q1 = ct >= 0 ? ct_first[ct + 1] : 0;
     const int nsteps = q1 - q0;
     for (int i = lane; i <= nsteps; i += 64) srow0[i] = tile_row0[q0 + i];
     wave_sync();
@@ -837,33 +995,37 @@ __global__ __launch_bounds__(64) void k_ilu_sweep_light_fused(int ct_begin, int 
     }
 }
 template <int SHAPE>
-__global__ __launch_bounds__(64) void k_ilu_sweep_light(int ct_begin, int nct, const int* __restrict__ ct_first,
+__global__ __launch_bounds__(64) void k_ilu_sweep_light(const int* __restrict__ ct_sched, int nct, const int* __restrict__ ct_first,
                                                         const int* __restrict__ tile_row0, const int* __restrict__ prow,
                                                         const int* __restrict__ pcol, const double* __restrict__ P,
                                                         const double* __restrict__ invD, const double* d,
                                                         double* vu, double* v, int relax_mode, double w, const double* __restrict__ done) {
     __shared__ int srow0[CHAIN_MAX_STEPS + 2];
-    const int lane = threadIdx.x, cl = xcd_tile(blockIdx.x, nct);
-    if (cl >= nct || *done != 0.0) return;
-    chain_sweep_light<SHAPE>(ct_first[ct_begin + cl], ct_first[ct_begin + cl + 1], lane, srow0, tile_row0, prow, pcol, P, invD, d, vu, v, relax_mode, w);
+    const int lane = threadIdx.x;
+    if (*done != 0.0) return;
+    const int ct = ct_sched[blockIdx.x];
+    if (ct < 0) return;
+    chain_sweep_light<SHAPE>(ct_first[ct], ct_first[ct + 1], lane, srow0, tile_row0, prow, pcol, P, invD, d, vu, v, relax_mode, w);
 }
 template <int SHAPE>
-__global__ __launch_bounds__(64) void k_ilu_sweep_chain(int ct_begin, int nct, const int* __restrict__ ct_first,
+__global__ __launch_bounds__(64) void k_ilu_sweep_chain(const int* __restrict__ ct_sched, int nct, const int* __restrict__ ct_first,
                                                         const int* __restrict__ tile_row0, const int* __restrict__ prow,
                                                         const int* __restrict__ pcol, const double* __restrict__ P,
                                                         const double* __restrict__ invD, const double* d,
                                                         double* vu, double* v, int relax_mode, double w, const double* __restrict__ done) {
     TILE_LDS
     __shared__ int srow0[CHAIN_MAX_STEPS + 2], sk0[CHAIN_MAX_STEPS + 2];
-    const int lane = threadIdx.x, cl = xcd_tile(blockIdx.x, nct);
-    if (cl >= nct || *done != 0.0) return;
-    chain_sweep<SHAPE>(ct_first[ct_begin + cl], ct_first[ct_begin + cl + 1], lane, sval, srow0, sk0, tile_row0, prow, pcol, P, invD, d, vu,
+    const int lane = threadIdx.x;
+    if (*done != 0.0) return;
+    const int ct = ct_sched[blockIdx.x];
+    if (ct < 0) return;
+    chain_sweep<SHAPE>(ct_first[ct], ct_first[ct + 1], lane, sval, srow0, sk0, tile_row0, prow, pcol, P, invD, d, vu,
                        v, relax_mode, w);
 }
 // Last colour: its rows have U entries only inside their own chain-tile, so the backward sweep of a chain-tile can
 // start the moment its forward sweep ends - one launch instead of two, and y never leaves the cache in between.
 template <bool LIGHT_U>
-__global__ __launch_bounds__(64) void k_ilu_sweep_chain_LU(int ct_begin, int nct, const int* __restrict__ ct_first,
+__global__ __launch_bounds__(64) void k_ilu_sweep_chain_LU(const int* __restrict__ ct_sched, int nct, const int* __restrict__ ct_first,
                                                            const int* __restrict__ tile_row0, const int* __restrict__ lrow,
                                                            const int* __restrict__ lcol, const double* __restrict__ L,
                                                            const int* __restrict__ urow, const int* __restrict__ ucol,
@@ -872,9 +1034,11 @@ __global__ __launch_bounds__(64) void k_ilu_sweep_chain_LU(int ct_begin, int nct
                                                            const double* __restrict__ done) {
     TILE_LDS
     __shared__ int srow0[CHAIN_MAX_STEPS + 2], sk0[CHAIN_MAX_STEPS + 2];
-    const int lane = threadIdx.x, cl = xcd_tile(blockIdx.x, nct);
-    if (cl >= nct || *done != 0.0) return;
-    const int q0 = ct_first[ct_begin + cl], q1 = ct_first[ct_begin + cl + 1];
+    const int lane = threadIdx.x;
+    if (*done != 0.0) return;
+    const int ct = ct_sched[blockIdx.x];
+    if (ct < 0) return;
+    const int q0 = ct_first[ct], q1 = ct_first[ct + 1];
     chain_sweep<SW_L>(q0, q1, lane, sval, srow0, sk0, tile_row0, lrow, lcol, L, invD, d, vu, v, relax_mode, w);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // y of this chain-tile is written before the backward sweep reads it
     wave_sync();
@@ -1409,23 +1573,45 @@ void launch_wells_recover(opmhip_ctx* c, const double* d_resWell, const double* 
     if (W.num_wells <= 0) return;
     hipLaunchKernelGGL(k_wells_recover, dim3(W.num_wells), dim3(64), 0, c->stream, W.d_val_pointers, W.d_Bcols, W.d_B, W.d_D, d_resWell, x, d_xw);
 }
+#ifndef OPMHIP_SPMV_PIPE_WGS
+#define OPMHIP_SPMV_PIPE_WGS 2048
+#endif
+constexpr int SPMV_PIPE_WGS = OPMHIP_SPMV_PIPE_WGS;  // resident single-wave workgroups the pipelined SpMV is sized for (256 CUs x 8)
+static int spmv_pipe_env() {   // OPMHIP_SPMV_PIPE (tuning): 0 = off, n > 1 = workgroups the pipelined kernel is sized for
+    static const int v = [] { const char* e = std::getenv("OPMHIP_SPMV_PIPE"); return e ? std::atoi(e) : -1; }();
+    return v;
+}
 // y = A x (+ wells) and, fused or not, the partial dots: ndot 0 none, 1 y.w0, 2 y.w0 and y.y
 void launch_spmv(opmhip_ctx* c, const double* x, double* y, int ndot, const double* w0, const double*) {
     const Pattern& P = c->pat;
-    const int nt = P.tiles.ntiles();
-    const int ntp = 8 * ((nt + 7) / 8);  // padded so that the XCD-aware tile map covers every tile
+    const int ntp = P.tiles.nsched;  // schedule positions (tiles + padding)
+    const int4* sched = reinterpret_cast<const int4*>(P.tiles.d_spmvSched);
     const bool wells = c->wells.num_wells > 0;
     const int fused = wells ? 0 : ndot;
     // the SpMV is timed by its own dispatch (kernel begin to kernel end), which is what bench.py's roofline quotes
     int es = -1, ee = -1;
     const bool timed = prof_kernel_scope(c, PROF_SPMV, &es, &ee);
     hipEvent_t e0 = timed ? c->prof.ev[es] : nullptr, e1 = timed ? c->prof.ev[ee] : nullptr;
-    if (fused == 0)
-        hipExtLaunchKernelGGL(k_spmv<0>, dim3(ntp), dim3(64), 0, c->stream, e0, e1, 0, nt, P.tiles.d_row0, P.d_rowptr, P.d_col, c->d_A, x, y, w0, c->d_part, c->npart, c->d_done);
+    // cfg.reserved[1]: resident workgroups the pipelined kernel is sized for (0 = default, < 0 = never use it)
+    const int pipeWgs = c->cfg.reserved[1] != 0 ? c->cfg.reserved[1] : (spmv_pipe_env() > 1 ? spmv_pipe_env() : SPMV_PIPE_WGS);
+    if (P.maxRowBlocks <= PGCH && pipeWgs > 0 && ntp > pipeWgs && spmv_pipe_env() != 0) {
+        // pipelined kernel: every workgroup walks through ceil(ntp / grid) launch positions; the grid is sized so that all
+        // workgroups are resident at once and end together, and is a multiple of 8 (a workgroup stays on "its" XCD column of
+        // the schedule)
+        const int steps = (ntp + pipeWgs - 1) / pipeWgs;
+        const int grid = 8 * (((ntp + steps - 1) / steps + 7) / 8);
+        if (fused == 0)
+            hipExtLaunchKernelGGL(k_spmv_pipe<0>, dim3(grid), dim3(64), 0, c->stream, e0, e1, 0, ntp, sched, P.d_rowptr, P.d_col, c->d_A, x, y, w0, c->d_part, c->npart, c->d_done);
+        else if (fused == 1)
+            hipExtLaunchKernelGGL(k_spmv_pipe<1>, dim3(grid), dim3(64), 0, c->stream, e0, e1, 0, ntp, sched, P.d_rowptr, P.d_col, c->d_A, x, y, w0, c->d_part, c->npart, c->d_done);
+        else
+            hipExtLaunchKernelGGL(k_spmv_pipe<2>, dim3(grid), dim3(64), 0, c->stream, e0, e1, 0, ntp, sched, P.d_rowptr, P.d_col, c->d_A, x, y, w0, c->d_part, c->npart, c->d_done);
+    } else if (fused == 0)
+        hipExtLaunchKernelGGL(k_spmv<0>, dim3(ntp), dim3(64), 0, c->stream, e0, e1, 0, sched, P.d_rowptr, P.d_col, c->d_A, x, y, w0, c->d_part, c->npart, c->d_done);
     else if (fused == 1)
-        hipExtLaunchKernelGGL(k_spmv<1>, dim3(ntp), dim3(64), 0, c->stream, e0, e1, 0, nt, P.tiles.d_row0, P.d_rowptr, P.d_col, c->d_A, x, y, w0, c->d_part, c->npart, c->d_done);
+        hipExtLaunchKernelGGL(k_spmv<1>, dim3(ntp), dim3(64), 0, c->stream, e0, e1, 0, sched, P.d_rowptr, P.d_col, c->d_A, x, y, w0, c->d_part, c->npart, c->d_done);
     else
-        hipExtLaunchKernelGGL(k_spmv<2>, dim3(ntp), dim3(64), 0, c->stream, e0, e1, 0, nt, P.tiles.d_row0, P.d_rowptr, P.d_col, c->d_A, x, y, w0, c->d_part, c->npart, c->d_done);
+        hipExtLaunchKernelGGL(k_spmv<2>, dim3(ntp), dim3(64), 0, c->stream, e0, e1, 0, sched, P.d_rowptr, P.d_col, c->d_A, x, y, w0, c->d_part, c->npart, c->d_done);
     if (wells) {
         launch_wells_apply(c, x, y);
         if (ndot > 0) {
@@ -1435,7 +1621,7 @@ void launch_spmv(opmhip_ctx* c, const double* x, double* y, int ndot, const doub
     }
 }
 static int dot_count(opmhip_ctx* c) {  // how many partials the last launch_spmv left behind
-    return c->wells.num_wells > 0 ? vec_blocks(c->pat.Nb * BS) : c->pat.tiles.ntiles();
+    return c->wells.num_wells > 0 ? vec_blocks(c->pat.Nb * BS) : c->pat.tiles.nsched;
 }
 void launch_ilu_factor(opmhip_ctx* c) {
     const Pattern& P = c->pat;
@@ -1464,41 +1650,44 @@ void launch_ilu_apply(opmhip_ctx* c, const double* d, double* v, int fuse) {
     const int n0 = P.colorPrefix[1];  // rows of the first colour: their y is d
     auto grid = [](int n) { return dim3(8 * ((n + 7) / 8)); };
     if (P.chained) {
+        // per colour: the launch schedule of its chain-tiles (position -> chain-tile or padding) and its length
+        auto sched = [&](int col) { return P.tiles.d_ctSched + P.tiles.ctSchedOff[col]; };
+        auto npos = [&](int col) { return P.tiles.ctSchedOff[col + 1] - P.tiles.ctSchedOff[col]; };
         for (int col = 0; col < C - 1; ++col) {
-            const int cb = P.tiles.colorCT[col], nct = P.tiles.colorCT[col + 1] - cb;
+            const int nct = npos(col);
             if (nct <= 0) continue;
             if (col == 0 && fuse == DM_PUPD)
-                hipLaunchKernelGGL(k_ilu_sweep_light_fused<DM_PUPD>, grid(nct), dim3(64), 0, c->stream, cb, nct, P.tiles.d_ctFirst, P.tiles.d_row0, P.d_lrowptr,
+                hipLaunchKernelGGL(k_ilu_sweep_light_fused<DM_PUPD>, dim3(nct), dim3(64), 0, c->stream, sched(col), nct, P.tiles.d_ctFirst, P.tiles.d_row0, P.d_lrowptr,
                                    P.d_lcol, c->d_L, const_cast<double*>(d), vu, c->d_scal, c->d_v, c->d_r, (double*)nullptr, P.colorPrefix[1], P.Nb, c->d_part);
             else if (col == 0 && fuse == DM_UPD1)
-                hipLaunchKernelGGL(k_ilu_sweep_light_fused<DM_UPD1>, grid(nct), dim3(64), 0, c->stream, cb, nct, P.tiles.d_ctFirst, P.tiles.d_row0, P.d_lrowptr,
+                hipLaunchKernelGGL(k_ilu_sweep_light_fused<DM_UPD1>, dim3(nct), dim3(64), 0, c->stream, sched(col), nct, P.tiles.d_ctFirst, P.tiles.d_row0, P.d_lrowptr,
                                    P.d_lcol, c->d_L, const_cast<double*>(d), vu, c->d_scal, c->d_v, c->d_pw, c->d_x, P.colorPrefix[1], P.Nb, c->d_part);
             else if (P.lightL[col])
-                hipLaunchKernelGGL(k_ilu_sweep_light<SW_L>, grid(nct), dim3(64), 0, c->stream, cb, nct, P.tiles.d_ctFirst, P.tiles.d_row0, P.d_lrowptr,
+                hipLaunchKernelGGL(k_ilu_sweep_light<SW_L>, dim3(nct), dim3(64), 0, c->stream, sched(col), nct, P.tiles.d_ctFirst, P.tiles.d_row0, P.d_lrowptr,
                                    P.d_lcol, c->d_L, c->d_invD, d, vu, v, mode, w, c->d_done);
             else
-                hipLaunchKernelGGL(k_ilu_sweep_chain<SW_L>, grid(nct), dim3(64), 0, c->stream, cb, nct, P.tiles.d_ctFirst, P.tiles.d_row0, P.d_lrowptr,
+                hipLaunchKernelGGL(k_ilu_sweep_chain<SW_L>, dim3(nct), dim3(64), 0, c->stream, sched(col), nct, P.tiles.d_ctFirst, P.tiles.d_row0, P.d_lrowptr,
                                    P.d_lcol, c->d_L, c->d_invD, d, vu, v, mode, w, c->d_done);
         }
         {
-            const int cb = P.tiles.colorCT[C - 1], nct = P.tiles.colorCT[C] - cb;
+            const int nct = npos(C - 1);
             if (nct > 0) {
                 if (P.lightU[C - 1])
-                    hipLaunchKernelGGL(k_ilu_sweep_chain_LU<true>, grid(nct), dim3(64), 0, c->stream, cb, nct, P.tiles.d_ctFirst, P.tiles.d_row0, P.d_lrowptr,
+                    hipLaunchKernelGGL(k_ilu_sweep_chain_LU<true>, dim3(nct), dim3(64), 0, c->stream, sched(C - 1), nct, P.tiles.d_ctFirst, P.tiles.d_row0, P.d_lrowptr,
                                        P.d_lcol, c->d_L, P.d_urowptr, P.d_ucol, c->d_U, c->d_invD, d, vu, v, mode, w, c->d_done);
                 else
-                    hipLaunchKernelGGL(k_ilu_sweep_chain_LU<false>, grid(nct), dim3(64), 0, c->stream, cb, nct, P.tiles.d_ctFirst, P.tiles.d_row0, P.d_lrowptr,
+                    hipLaunchKernelGGL(k_ilu_sweep_chain_LU<false>, dim3(nct), dim3(64), 0, c->stream, sched(C - 1), nct, P.tiles.d_ctFirst, P.tiles.d_row0, P.d_lrowptr,
                                        P.d_lcol, c->d_L, P.d_urowptr, P.d_ucol, c->d_U, c->d_invD, d, vu, v, mode, w, c->d_done);
             }
         }
         for (int col = C - 2; col >= 0; --col) {
-            const int cb = P.tiles.colorCT[col], nct = P.tiles.colorCT[col + 1] - cb;
+            const int nct = npos(col);
             if (nct <= 0) continue;
             if (P.lightU[col])
-                hipLaunchKernelGGL(k_ilu_sweep_light<SW_UF>, grid(nct), dim3(64), 0, c->stream, cb, nct, P.tiles.d_ctFirst, P.tiles.d_row0, P.d_urowptr,
+                hipLaunchKernelGGL(k_ilu_sweep_light<SW_UF>, dim3(nct), dim3(64), 0, c->stream, sched(col), nct, P.tiles.d_ctFirst, P.tiles.d_row0, P.d_urowptr,
                                    P.d_ucol, c->d_U, c->d_invD, d, vu, v, mode, w, c->d_done);
             else
-                hipLaunchKernelGGL(k_ilu_sweep_chain<SW_UF>, grid(nct), dim3(64), 0, c->stream, cb, nct, P.tiles.d_ctFirst, P.tiles.d_row0, P.d_urowptr,
+                hipLaunchKernelGGL(k_ilu_sweep_chain<SW_UF>, dim3(nct), dim3(64), 0, c->stream, sched(col), nct, P.tiles.d_ctFirst, P.tiles.d_row0, P.d_urowptr,
                                    P.d_ucol, c->d_U, c->d_invD, d, vu, v, mode, w, c->d_done);
         }
         prof_end(c, ps);
@@ -1607,7 +1796,7 @@ static int enqueue_half(opmhip_ctx* c, int h) {
         launch_ilu_apply(c, c->d_r, c->d_s, fused ? DM_UPD1 : 0);
         if (fused) {
             ps = prof_begin(c, PROF_VECTOR);
-            if ((rc = finalize(c, FIN_NORM, P.tiles.colorCT[1] - P.tiles.colorCT[0], h - 1))) return rc;
+            if ((rc = finalize(c, FIN_NORM, P.tiles.ctSchedOff[1] - P.tiles.ctSchedOff[0], h - 1))) return rc;
             prof_end(c, ps);
         }
         if ((rc = comm_halo_f64(c, c->d_s, BS))) return rc;

@@ -162,6 +162,8 @@ public:
     /// FvBaseDiscretization::advanceTimeLevel / updateFailed: solution(1) <-> solution(0) on the device
     void advanceTimeLevel() { check(opmhip_advance_time_level(ctx_), "advanceTimeLevel"); }
     void updateFailed() { check(opmhip_update_failed(ctx_), "updateFailed"); }
+    /// EclProblem::endTimeStep, the drift-compensation part (ebos/eclproblem.hh:1126-1135): after an ACCEPTED time step
+    void endTimeStep(double dt) { check(opmhip_end_time_step(ctx_, dt), "endTimeStep"); }
 
     /// The sub-step loop of AdaptiveTimeSteppingEbos::step (timestepping/AdaptiveTimeSteppingEbos.hpp:283-520) for one
     /// report step of length `length` starting with sub-step `dt`: a failed sub-step is rolled back and retried with
@@ -191,6 +193,7 @@ public:
                 dt *= restartFactor;
                 continue;
             }
+            endTimeStep(dt);
             t += dt;
             double est = newtons > target ? dt / (1.0 + double(newtons - target) / target * decayDamping)
                                           : dt * (1.0 + double(target - newtons) / target * growthDamping);

@@ -163,6 +163,10 @@ class BlackoilModelHip:
     def update_failed(self):
         self.m.update_failed()
 
+    # -- EclProblem::endTimeStep (ebos/eclproblem.hh:1101-1135): the drift of the accepted step ------------------
+    def end_time_step(self, dt):
+        self.m.end_time_step(dt)
+
 
 @dataclass
 class TimeSteppingParameters:
@@ -181,7 +185,7 @@ class TimeSteppingParameters:
 class AdaptiveTimeStepping:
     """The sub-stepping loop of AdaptiveTimeSteppingEbos::step (opm/simulators/timestepping/AdaptiveTimeSteppingEbos.hpp
     :283-520) over any model object with nonlinear_iteration(iteration, dt) -> report, advance_time_level(),
-    update_failed() and param.newton_max_iter: a failed time step (TooManyIterations, NumericalIssue) is rolled back and
+    update_failed(), end_time_step(dt) and param.newton_max_iter: a failed time step (TooManyIterations, NumericalIssue) is rolled back and
     retried with dt * restart_factor; an accepted one sets the next dt with the Newton-iteration-count rule of
     PIDAndIterationCountTimeStepControl::computeTimeStepSize (timestepping/TimeStepControl.cpp:188-208; its PID part
     needs the relative change of the solution and is left out, which only makes the steps longer).
@@ -226,6 +230,7 @@ class AdaptiveTimeStepping:
                 self.report += rep
                 self.iteration += 1
                 if rep.converged:
+                    self.model.end_time_step(self.dt)   # problem.endTimeStep() of the accepted sub-step
                     self.history.append((self.dt, self.iteration - 1, True))
                     self.time += self.dt
                     self.dt = self._next_dt(self.dt, self.iteration - 1)

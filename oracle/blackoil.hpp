@@ -187,6 +187,21 @@ struct Model {
     std::vector<IQT<double>> iqV;    // cached IQ values
     Bcrs J;
     std::vector<double> residual;
+    // drift compensation (ebos/eclproblem.hh:1847-1875, on by default :496-498): what the last accepted time step left
+    // unconverged, residual * dt per cell (:1126-1135, UseVolumetricResidual = false for Flow,
+    // flow/BlackoilModelEbos.hpp:92-95), is subtracted from the source term of the following steps
+    bool enableDriftCompensation = true;
+    double maxCompensation = 10.0 * 1e-2;   // 10 * NewtonTolerance (eclproblem.hh:352-356, 1854)
+    std::vector<double> drift;              // Nb x 3, zero until the first endTimeStep (:881-884)
+
+    // EclProblem::endTimeStep, the drift part (eclproblem.hh:1126-1135): call after an ACCEPTED time step of size dt
+    void end_time_step(double dt) {
+        if (!enableDriftCompensation) return;
+        for (size_t i = 0; i < residual.size(); ++i) {
+            drift[i] = residual[i];
+            drift[i] *= dt;
+        }
+    }
 
     void init() {
         P.finish();
@@ -200,6 +215,7 @@ struct Model {
         J = P.pat;
         J.val.assign((size_t)P.pat.nnzb() * BB, 0.0);
         residual.assign((size_t)Nb * 3, 0.0);
+        drift.assign((size_t)Nb * 3, 0.0);
         iqF.resize(Nb);
         iqV.resize(Nb);
     }
@@ -247,11 +263,27 @@ struct Model {
                 t *= scvVolume / dt;
                 R[e] += t;
             }
+            // drift compensation of the source term (eclproblem.hh:1847-1875).  UNVERIFIED vs upstream: model.eqWeight()
+            // (opm-models BlackOilModel::eqWeight) is taken as 1 for all three surface-volume equations; it only enters
+            // the cap, which engages when a cell drifted by more than 10 % of its pore volume in one step
+            double dofDriftRate[3] = {0.0, 0.0, 0.0};
+            if (enableDriftCompensation) {
+                const double poro = in.refPoro;
+                for (int e = 0; e < 3; ++e) {
+                    dofDriftRate[e] = drift[(size_t)I * 3 + e];
+                    dofDriftRate[e] /= dt * scvVolume;
+                }
+                double totalDriftRate = 0.0;
+                for (int e = 0; e < 3; ++e) totalDriftRate += std::fabs(dofDriftRate[e]) * dt * 1.0 / poro;
+                if (totalDriftRate > maxCompensation)
+                    for (int e = 0; e < 3; ++e) dofDriftRate[e] *= maxCompensation / totalDriftRate;
+            }
             // source term: rate per volume (eclproblem.hh:1823-1845), then times volume again
             for (int e = 0; e < 3; ++e) {
                 Ev s(source[(size_t)I * 3 + e]);
                 for (int v = 0; v < 3; ++v) s.d[v] = dsource[(size_t)I * 9 + e * 3 + v];
                 s /= scvVolume;
+                if (enableDriftCompensation) s -= dofDriftRate[e];
                 s *= scvVolume;
                 R[e] -= s;
             }

@@ -420,6 +420,14 @@ int orc_bo_convergence(orc_model* h, double dt, double tol_cnv, double* out) {
     return 0;
 }
 int orc_bo_update(orc_model* h, const double* dx) { return h->M.update(dx); }
+// EclProblem::endTimeStep (drift part) after an accepted time step; enable < 0 leaves the switch as it is
+int orc_bo_end_time_step(orc_model* h, double dt) { h->M.end_time_step(dt); return 0; }
+int orc_bo_set_drift_compensation(orc_model* h, int enable, double max_compensation) {
+    h->M.enableDriftCompensation = enable != 0;
+    if (max_compensation > 0.0) h->M.maxCompensation = max_compensation;
+    return 0;
+}
+int orc_bo_get_drift(orc_model* h, double* out) { std::memcpy(out, h->M.drift.data(), h->M.drift.size() * sizeof(double)); return 0; }
 // threads for the OpenMP loops (assembly, IQ update, the *_mt solver below); returns the previous maximum
 int orc_set_threads(int n) {
 #ifdef _OPENMP

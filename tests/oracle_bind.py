@@ -144,6 +144,9 @@ class OracleModel:
                                    C.POINTER(OrcResult)]
         L.orc_bo_solve_mt.argtypes = [_vp, _d, C.c_double, C.c_int, C.c_double, C.c_int, C.c_int, C.POINTER(OrcResult)]
         L.orc_set_threads.argtypes = [C.c_int]
+        L.orc_bo_end_time_step.argtypes = [_vp, C.c_double]
+        L.orc_bo_set_drift_compensation.argtypes = [_vp, C.c_int, C.c_double]
+        L.orc_bo_get_drift.argtypes = [_vp, _d]
         self.case = case
         self.Nb = case["Nb"]
         self.nnzb = len(case["col"])
@@ -190,6 +193,17 @@ class OracleModel:
 
     def update(self, dx):
         return self.o.lib.orc_bo_update(self.h, np.ascontiguousarray(dx, np.float64))
+
+    def end_time_step(self, dt):
+        self.o.lib.orc_bo_end_time_step(self.h, dt)
+
+    def set_drift_compensation(self, enable=True, max_compensation=0.1):
+        self.o.lib.orc_bo_set_drift_compensation(self.h, int(enable), max_compensation)
+
+    def drift(self):
+        out = np.empty(self.Nb * 3)
+        self.o.lib.orc_bo_get_drift(self.h, out)
+        return out
 
     def solve_in_order(self, to, fr, **kw):
         """solveJacobianSystem with the ILU0 taken in the ordering (toOrder, fromOrder) the device reports."""
@@ -259,6 +273,9 @@ class OracleAsHipModel:
 
     def update_failed(self):
         self.om.set_state(*self._prev)
+
+    def end_time_step(self, dt):
+        self.om.end_time_step(dt)
 
 
 class OracleFluid:

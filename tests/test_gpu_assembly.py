@@ -337,3 +337,78 @@ def test_states_outside_the_tables(pkg, orc, seed):
     po, mo = o.get_state()
     assert np.array_equal(mm, mo) and np.array_equal(pm, po, equal_nan=True)
     assert np.array_equal(m.iq(), o.iq(), equal_nan=True)
+
+
+@pytest.mark.parametrize("reorder", ["graph_coloring_greedy", "line_coloring"])
+def test_drift_compensation_matches_oracle(pkg, orc, reorder):
+    """EclEnableDriftCompensation (default true, ebos/eclproblem.hh:496-498): after an accepted time step the residual of
+    its last linearisation, times dt, is fed back through the source term of the next step (:1126-1135, :1847-1875).
+    Device and oracle run two time steps of different length with a deliberately sloppy first step (one Newton update
+    only, so the drift is far from zero): Jacobian and residual of the second step bit for bit, with the cap of the
+    compensation hit in some cells and not in others; then the same with the switch off."""
+    case = pkg.decks.cartesian_case(9, 8, 5, state="mixed", heterogeneous=True)
+    src = pkg.decks.five_spot_source(case, rate_sm3_per_day=400.0)
+    m, o = both(pkg, orc, case, reorder=reorder)
+    for h in (m, o):
+        h.set_source(src)
+    dt1, dt2 = 5 * 86400.0, 2 * 86400.0
+    # time step 1: assemble, one (oracle-computed) Newton update on both sides, final linearisation = "accepted"
+    m.assemble(dt1, 0, fetch=False)
+    o.assemble(dt1, 0)
+    x, _ = o.solve(tol=1e-2)
+    assert m.update(x) == o.update(x)
+    j1, r1 = m.assemble(dt1, 1)
+    jo1, ro1 = o.assemble(dt1, 1)
+    assert np.array_equal(r1, ro1) and np.array_equal(j1, jo1)
+    # a tight cap so that both branches of "totalDriftRate > maxCompensation" are taken
+    tot = (np.abs(ro1.reshape(-1, 3)) * dt1 / (case["volume"] * case["poro"])[:, None]).sum(axis=1)
+    cap = float(np.median(tot))
+    for h in (m, o):
+        h.set_drift_compensation(True, cap)
+        h.end_time_step(dt1)
+    assert np.array_equal(o.drift(), ro1 * dt1)
+    # time step 2 (shorter): iteration 0 and 1
+    j2, r2 = m.assemble(dt2, 0)
+    jo2, ro2 = o.assemble(dt2, 0)
+    assert np.array_equal(r2, ro2) and np.array_equal(j2, jo2)
+    # the compensation is really in there: against an assembly without it the residual moves, the Jacobian does not
+    o.set_drift_compensation(False)
+    jn, rn = o.assemble(dt2, 0)
+    assert np.array_equal(jn, jo2) and not np.array_equal(rn, ro2)
+    frac = np.abs((rn - ro2).reshape(-1, 3)).sum(axis=1) * dt2 / (case["volume"] * case["poro"])
+    assert (frac > 0.99 * cap).any() and (frac < 0.5 * cap).any() and frac.max() <= cap * (1 + 1e-12)
+    # switch off on the device too (clears the drift): equals the oracle without compensation
+    m.set_drift_compensation(False)
+    j3, r3 = m.assemble(dt2, 0)
+    assert np.array_equal(r3, rn) and np.array_equal(j3, jn)
+
+
+def test_drift_survives_a_rolled_back_step(pkg, orc):
+    """A failed time step never reaches endTimeStep: update_failed restores the primary variables, the drift of the last
+    ACCEPTED step stays (AdaptiveTimeSteppingEbos.hpp:355-441 calls problem.endTimeStep only on success)."""
+    case = pkg.decks.cartesian_case(7, 6, 4, state="undersaturated", heterogeneous=True)
+    src = pkg.decks.five_spot_source(case, rate_sm3_per_day=300.0)
+    m, o = both(pkg, orc, case)
+    for h in (m, o):
+        h.set_source(src)
+    dt = 4 * 86400.0
+    m.advance_time_level()
+    m.assemble(dt, 0, fetch=False)
+    o.assemble(dt, 0)
+    x, _ = o.solve(tol=1e-2)
+    m.update(x), o.update(x)
+    m.assemble(dt, 1, fetch=False)
+    o.assemble(dt, 1)
+    m.end_time_step(dt), o.end_time_step(dt)
+    state = o.get_state()
+    # next step: a wild update, then the roll-back
+    m.advance_time_level()
+    m.assemble(dt, 0, fetch=False)
+    m.update(np.full(3 * case["Nb"], 1e-3))
+    m.assemble(dt, 1, fetch=False)
+    m.update_failed()
+    pm, mm = m.get_state()
+    assert np.array_equal(pm, state[0]) and np.array_equal(mm, state[1])
+    j, r = m.assemble(0.33 * dt, 0)
+    jo, ro = o.assemble(0.33 * dt, 0)
+    assert np.array_equal(r, ro) and np.array_equal(j, jo)

@@ -56,6 +56,29 @@ def test_spmv_bit_exact(pkg, orc, reorder, shape):
     np.testing.assert_allclose(y, orc.spmv(Nb, rp, ci, v, x), rtol=1e-12, atol=1e-12)
 
 
+@pytest.mark.parametrize("reorder", ["graph_coloring", "line_coloring"])
+@pytest.mark.parametrize("wgs", [8, 24, 200, -1])
+def test_pipelined_spmv_bit_exact(pkg, orc, reorder, wgs):
+    """The pipelined SpMV (every workgroup walks through several tiles with the loads of the next three tiles in flight) on
+    grids small enough for the oracle: sized for 8 / 24 / 200 resident workgroups a 13 720-row system takes 54 / 18 / 3
+    pipeline steps per workgroup (ragged last step included); -1 = the one-tile-per-workgroup kernel.  Same bits as the
+    oracle, and the fused partial dots (BiCGStab's scalars) give the same solve."""
+    Nb, rp, ci, v = laplace_block_system(28, 35, 14, seed=12)
+    x = np.random.default_rng(6).standard_normal(Nb * 3)
+    s = pkg.capi.HipSolver(reorder=reorder, spmv_pipe_wgs=wgs, tolerance=1e-8)
+    s.set_pattern(Nb, rp, ci)
+    s.upload_system(v)
+    to, fr, rpc = s.ordering()
+    rr, rc, rv = orc.reorder_matrix(Nb, rp, ci, v, to, fr)
+    yo = orc.spmv(Nb, rr, rc, rv, x.reshape(Nb, 3)[fr].reshape(-1)).reshape(Nb, 3)[to].reshape(-1)
+    assert np.array_equal(s.spmv(x), yo)
+    b = np.random.default_rng(7).standard_normal(Nb * 3)
+    res = s.solve_system(Nb, rp, ci, v.copy(), b)
+    xo, reso = oracle_solve_in_order(orc, Nb, rp, ci, v, b, to, fr, tol=1e-8, maxit=200, w=0.9)
+    assert res.converged and res.it == reso.it
+    np.testing.assert_allclose(s.get_result(), xo, rtol=1e-7, atol=1e-10)
+
+
 @pytest.mark.parametrize("reorder", REORDERS)
 @pytest.mark.parametrize("mode,w", [("post_scale", 0.9), ("in_sweep", 0.9), ("post_scale", 1.0)])
 def test_ilu0_factor_and_apply_bit_exact(pkg, orc, reorder, mode, w):
@@ -272,7 +295,6 @@ def test_contexts_give_their_memory_back(pkg):
     """create / use / destroy in a loop: device memory returns to where it was (every allocation of a context is tracked
     and freed by opmhip_destroy, including the pinned read-back ring and the profiler's events)"""
     import gc
-    import torch
     Nb, rp, ci, v = laplace_block_system(20, 20, 10, seed=3)
     b = np.ones(3 * Nb)
 
@@ -283,13 +305,21 @@ def test_contexts_give_their_memory_back(pkg):
         s.profile()
         del s
         gc.collect()
+    # free device memory straight from the HIP runtime the library itself uses (no second framework in the process)
+    import ctypes
+    hip = ctypes.CDLL("libamdhip64.so")
+
+    def free_bytes():
+        assert hip.hipDeviceSynchronize() == 0
+        fr, tot = ctypes.c_size_t(0), ctypes.c_size_t(0)
+        assert hip.hipMemGetInfo(ctypes.byref(fr), ctypes.byref(tot)) == 0
+        return fr.value
+
     once()
-    torch.cuda.synchronize()
-    free0 = torch.cuda.mem_get_info()[0]
+    free0 = free_bytes()
     for _ in range(25):
         once()
-    torch.cuda.synchronize()
-    free1 = torch.cuda.mem_get_info()[0]
+    free1 = free_bytes()
     assert free0 - free1 < 8 * 1024 * 1024, (free0, free1)
 
 

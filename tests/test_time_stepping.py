@@ -15,6 +15,7 @@ class Scripted:
         self.param = newton.ModelParameters(newton_max_iter=max_iter)
         self.calls = []
         self.advanced = self.rolled_back = 0
+        self.ended = []   # problem.endTimeStep(): accepted steps only
 
     def nonlinear_iteration(self, iteration, dt):
         self.calls.append((iteration, dt))
@@ -33,6 +34,9 @@ class Scripted:
     def update_failed(self):
         self.rolled_back += 1
 
+    def end_time_step(self, dt):
+        self.ended.append(dt)
+
 
 def test_growth_follows_the_iteration_count_rule():
     mdl = Scripted(lambda dt: 3)
@@ -42,6 +46,7 @@ def test_growth_follows_the_iteration_count_rule():
     # 3 iterations against a target of 8: factor 1 + 5/8 * 3.2 = 3 = max growth; then the 10-day cap
     assert [h[0] / DAY for h in ts.history] == pytest.approx([1.0, 3.0, 9.0])
     assert ts.dt == 10 * DAY and ts.timesteps_done == 3 and mdl.advanced == 4 and mdl.rolled_back == 0
+    assert [d / DAY for d in mdl.ended] == pytest.approx([1.0, 3.0, 9.0])
 
 
 def test_decay_above_target():
@@ -65,6 +70,7 @@ def test_chop_rolls_back_and_limits_the_next_growth():
     assert ts.history[3][0] == pytest.approx(2 * 1.089 * DAY)
     # the call that sees step 2 converge already hands out the first iteration of step 3
     assert mdl.rolled_back == 2 and mdl.advanced == 3 and ts.timesteps_failed == 2
+    assert len(mdl.ended) == 2 and mdl.ended[0] == pytest.approx(1.089 * DAY)   # failed steps never reach endTimeStep
     assert n == 5 + 5 + 2 + 2 + 1
 
 
