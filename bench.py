@@ -105,8 +105,19 @@ def cpu_baseline(pkg, case, src):
     st = cpu_baseline_run(pkg, case, src, 1, budget_s=14.0, max_newton=8)
     head = mt if (mt is not None and mt["value"] > st["value"]) else st
     cores = threads if head is mt else 1
+    cpu_model = "unknown"
+    try:
+        with open("/proc/cpuinfo") as f:
+            for line in f:
+                if line.startswith("model name"):
+                    cpu_model = line.split(":", 1)[1].strip()
+                    break
+    except OSError:
+        pass
     out = {
         "value": head["value"], "unit": "Newton iterations/s", "cores": cores, "kind": "port",
+        "host": {"cpu_model": cpu_model, "logical_cpus": os.cpu_count(), "cpus_in_affinity_mask": avail, "threads_tried": [threads, 1] if mt is not None else [1]},
+        "multi_thread": None if mt is None else {"threads": threads, "value": mt["value"], "seconds": mt["seconds"], "newton_iterations": mt["newton_iterations"]},
         "sample": "the first %d Newton iterations of the same %d-cell case and time-step control on the CPU restatement "
                   "(oracle/), %d thread(s): %s, BiCGStab to 1e-2; %d linear iterations in all; %.1f s of wall time"
                   % (head["newton_iterations"], case["Nb"], cores,

@@ -44,8 +44,13 @@ struct TileSet {            // tiles over one block-CSR row-pointer array, never
     std::vector<int> ctSchedOff; // [numColors+1] offsets into ctSched
     int* d_row0 = nullptr;
     int* d_ctFirst = nullptr;
+    // per schedule position of the chain kernels: [steps, chain-tile, -, -, first row of step 0..steps, first L entry of
+    // those rows, first U entry of those rows], descS1 numbers each, record stride descStride (solver.hip: load_desc)
+    std::vector<int> ctDesc;
+    int descStride = 0, descS1 = 0;
     int* d_spmvSched = nullptr;
     int* d_ctSched = nullptr;
+    int* d_ctDesc = nullptr;
     int ntiles() const { return (int)row0.size() - 1; }
 };
 

@@ -259,6 +259,28 @@ void build_schedules(Pattern& P, int G) {
             T.ctSchedOff[c + 1] = (int)T.ctSched.size();
         }
     }
+    // descriptor records of the chain kernels' launch positions
+    {
+        int S = 1;
+        for (size_t q = 0; q + 1 < T.ctFirst.size(); ++q) S = std::max(S, T.ctFirst[q + 1] - T.ctFirst[q]);
+        T.descS1 = S + 1;
+        T.descStride = 4 * ((4 + 3 * T.descS1 + 3) / 4);
+        T.ctDesc.assign((size_t)T.ctSched.size() * T.descStride, 0);
+        for (size_t pos = 0; pos < T.ctSched.size(); ++pos) {
+            int* rec = &T.ctDesc[pos * T.descStride];
+            const int ct = T.ctSched[pos];
+            rec[1] = ct;
+            if (ct < 0) continue;
+            const int q0 = T.ctFirst[ct], n = T.ctFirst[ct + 1] - q0;
+            rec[0] = n;
+            for (int i = 0; i <= n; ++i) {
+                const int r = T.row0[q0 + i];
+                rec[4 + i] = r;
+                rec[4 + T.descS1 + i] = P.lrowptr[r];
+                rec[4 + 2 * T.descS1 + i] = P.urowptr[r];
+            }
+        }
+    }
     T.nsched = (int)order.size();
     T.spmvSched.assign((size_t)4 * T.nsched, 0);
     for (int b = 0; b < T.nsched; ++b)
@@ -483,6 +505,7 @@ int build_pattern(opmhip_ctx* c, int Nb, int Nghost, int nnzb, const int* rows, 
     int rc;
     if ((rc = dev_upload(c, &P.tiles.d_spmvSched, P.tiles.spmvSched))) return rc;
     if ((rc = dev_upload(c, &P.tiles.d_ctSched, P.tiles.ctSched))) return rc;
+    if ((rc = dev_upload(c, &P.tiles.d_ctDesc, P.tiles.ctDesc))) return rc;
     if ((rc = dev_upload(c, &P.d_rowptr, P.rowptr))) return rc;
     if ((rc = dev_upload(c, &P.d_col, P.col))) return rc;
     if ((rc = dev_upload(c, &P.d_diag, P.diag))) return rc;

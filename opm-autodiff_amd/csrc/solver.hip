@@ -456,7 +456,7 @@ __global__ __launch_bounds__(64) void k_spmv_pipe(int npos, const int4* __restri
     StA a;
     StC c;
     StG b;
-    // prologue: fill the pipeline
+    // prologue: fill the pipeline, tile by tile (issuing the row bounds of three tiles at once was measured 7 % SLOWER)
     if (nsteps > 0) { stageA(stageS(0), a); stageC(a, c); stageG(c, b); }
     if (nsteps > 1) { stageA(stageS(1), a); stageC(a, c); }
     if (nsteps > 2) stageA(stageS(2), a);
@@ -581,22 +581,28 @@ constexpr int CHAIN_MAX_STEPS = 128;
 #endif
 constexpr int CGCH = OPMHIP_CHAIN_GATHER;   // blocks of a row whose vector entries are fetched one step ahead
 constexpr int CHAIN_STAGE = OPMHIP_CHAIN_STAGE;
+// Descriptor record of one launch position of a chain kernel (reorder.cpp: build_schedules), copied to LDS with one
+// coalesced load: [0] steps (0 = padding) [1] chain-tile [4 ..] first row of step 0..steps, then the first L entry and the
+// first U entry of those rows (S1 = longest chain-tile + 1 numbers each).  Everything the sweep needs to issue its first
+// loads - the old chain  schedule -> chain-tile -> tile -> row -> entry  cost four dependent round trips per workgroup.
+constexpr int DESC_HEAD = 4;
+constexpr int DESC_MAX = DESC_HEAD + 3 * (CHAIN_MAX_STEPS + 1) + 3;
+__device__ __forceinline__ int load_desc(const int* __restrict__ desc, int dstride, int lane, int* sdesc) {
+    const int* rec = desc + (size_t)blockIdx.x * dstride;
+    for (int i = lane; i < dstride; i += 64) sdesc[i] = rec[i];
+    wave_sync();
+    return sdesc[0];
+}
 template <int SHAPE>  // SW_L or SW_UF
-__device__ __forceinline__ void chain_sweep(const int q0, const int q1, const int lane, double* sval, int* srow0, int* sk0,
-                                            const int* __restrict__ tile_row0, const int* __restrict__ prow,
+__device__ __forceinline__ void chain_sweep(const int nsteps, const int lane, double* sval, const int* srow0, const int* sk0,
+                                            const int* __restrict__ prow,
                                             const int* __restrict__ pcol, const double* __restrict__ P,
                                             const double* __restrict__ invD, const double* d,
                                             double* vu, double* v, int relax_mode, double w) {
-    const int nsteps = q1 - q0;  // <= CHAIN_MAX_STEPS (checked on the host)
+    // nsteps <= CHAIN_MAX_STEPS (checked on the host); srow0[0..nsteps], sk0[0..nsteps]: first row / first entry of every
+    // step, out of the chain-tile's descriptor record (LDS) - no dependent loads here
     const bool reverse = (SHAPE == SW_UF) && relax_mode == 0;
     constexpr int U = CHAIN_STAGE;  // a step of a 2-colour line ordering streams <= 32 rows x 5 blocks = 11.25 KiB: 12 x 1 KiB per wavefront covers it in one batch
-    // row and entry offsets of every step of this chain-tile, once: two dependent hops here instead of per step
-    for (int i = lane; i <= nsteps; i += 64) {
-        const int r = tile_row0[q0 + i];
-        srow0[i] = r;
-        sk0[i] = prow[r];
-    }
-    wave_sync();
     // Software pipeline over the steps (st counts in processing order; the backward sweep walks tiles q1-1 ... q0).
     // The chain of dependent loads  row bounds -> column indices -> vector gathers  is spread over three iterations so
     // that no iteration waits for more than the loads issued one iteration earlier:
@@ -674,11 +680,17 @@ __device__ __forceinline__ void chain_sweep(const int q0, const int q1, const in
     StG b;
     int myPrevRow = -1;           // the row this lane finished in the previous step, and its result
     double myPrev[3] = {0.0, 0.0, 0.0};
-    stageA(0, a);
-    stageC(a, c);
-    stageG(0, c, b);
-    if (nsteps > 1) { stageA(1, a); stageC(a, c); }
-    if (nsteps > 2) stageA(2, a);
+    {   // prologue: the row bounds of the first three steps in ONE round of loads, the column indices of the first two in
+        // the next, then the first value stream - three dependent rounds instead of six
+        StA a0, a1;
+        StC c0;
+        stageA(0, a0);
+        if (nsteps > 1) stageA(1, a1);
+        if (nsteps > 2) stageA(2, a);
+        stageC(a0, c0);
+        if (nsteps > 1) stageC(a1, c);
+        stageG(0, c0, b);
+    }
     for (int st = 0; st < nsteps; ++st) {
         // ---- X(st), part 1: commit the prefetched values to LDS
 #pragma unroll
@@ -783,15 +795,12 @@ __device__ __forceinline__ void chain_sweep(const int q0, const int q1, const in
 #endif
 constexpr int LIGHT_DEPTH = OPMHIP_LIGHT_DEPTH;
 template <int SHAPE>  // SW_L or SW_UF
-__device__ __forceinline__ void chain_sweep_light(const int q0, const int q1, const int lane, int* srow0,
-                                                  const int* __restrict__ tile_row0, const int* __restrict__ prow,
+__device__ __forceinline__ void chain_sweep_light(const int nsteps, const int lane, const int* srow0,
+                                                  const int* __restrict__ prow,
                                                   const int* __restrict__ pcol, const double* __restrict__ P,
                                                   const double* __restrict__ invD, const double* d, double* vu, double* v,
                                                   int relax_mode, double w) {
     constexpr int D = LIGHT_DEPTH;
-    const int nsteps = q1 - q0;
-    for (int i = lane; i <= nsteps; i += 64) srow0[i] = tile_row0[q0 + i];
-    wave_sync();
     auto tile_of = [&](int st) { return (SHAPE == SW_UF) ? nsteps - 1 - st : st; };
     struct StA { int rr, kb, ke; bool active; };
     struct StB {
@@ -868,22 +877,20 @@ __device__ __forceinline__ void chain_sweep_light(const int q0, const int q1, co
 // The later colours then read dvec as it stands.  Same expressions as the stand-alone kernels: bit-identical vectors.
 enum { DM_PUPD = 1, DM_UPD1 = 2 };
 template <int DM>
-__global__ __launch_bounds__(64) void k_ilu_sweep_light_fused(const int* __restrict__ ct_sched, int nct, const int* __restrict__ ct_first,
-                                                              const int* __restrict__ tile_row0, const int* __restrict__ prow,
+__global__ __launch_bounds__(64) void k_ilu_sweep_light_fused(const int* __restrict__ desc, int dstride, int S1, int nct,
+                                                              const int* __restrict__ prow,
                                                               const int* __restrict__ pcol, const double* __restrict__ P,
                                                               double* dvec, double* vu, const double* __restrict__ scal,
                                                               const double* __restrict__ vvec, const double* __restrict__ wvec,
                                                               double* xvec, int f0, int f1, double* __restrict__ part) {
     constexpr int D = LIGHT_DEPTH;
-    __shared__ int srow0[CHAIN_MAX_STEPS + 2];
+    __shared__ int sdesc[DESC_MAX];
     const int lane = threadIdx.x, cl = blockIdx.x;  // launch position; nct = positions of this colour's schedule
     if (scal[SC_DONE] != 0.0) return;
     const double alpha = scal[SC_ALPHA], omega = scal[SC_OMEGA], beta = scal[SC_BETA];
-    const int ct = ct_sched[cl];  // -1: padding of the schedule - no chain rows, but still its share of the other rows
-    const int q0 = ct >= 0 ? ct_first[ct] : 0, q1 = ct >= 0 ? ct_first[ct + 1] : 0;
-    const int nsteps = q1 - q0;
-    for (int i = lane; i <= nsteps; i += 64) srow0[i] = tile_row0[q0 + i];
-    wave_sync();
+    const int nsteps = load_desc(desc, dstride, lane, sdesc);  // 0: padding of the schedule - no chain rows, but still its share of the other rows
+    const int* srow0 = sdesc + DESC_HEAD;
+    (void)S1;
     const bool chainLane = lane < TILE_ROWS;
     const int per = (int)(((long long)(f1 - f0) + nct - 1) / nct);
     const int fb = f0 + (int)min((long long)(f1 - f0), (long long)cl * per), fe = min(f1, fb + per);  // this workgroup's foreign rows
@@ -995,55 +1002,56 @@ __global__ __launch_bounds__(64) void k_ilu_sweep_light_fused(const int* __restr
     }
 }
 template <int SHAPE>
-__global__ __launch_bounds__(64) void k_ilu_sweep_light(const int* __restrict__ ct_sched, int nct, const int* __restrict__ ct_first,
-                                                        const int* __restrict__ tile_row0, const int* __restrict__ prow,
+__global__ __launch_bounds__(64) void k_ilu_sweep_light(const int* __restrict__ desc, int dstride, int S1,
+                                                        const int* __restrict__ prow,
                                                         const int* __restrict__ pcol, const double* __restrict__ P,
                                                         const double* __restrict__ invD, const double* d,
                                                         double* vu, double* v, int relax_mode, double w, const double* __restrict__ done) {
-    __shared__ int srow0[CHAIN_MAX_STEPS + 2];
+    __shared__ int sdesc[DESC_MAX];
     const int lane = threadIdx.x;
     if (*done != 0.0) return;
-    const int ct = ct_sched[blockIdx.x];
-    if (ct < 0) return;
-    chain_sweep_light<SHAPE>(ct_first[ct], ct_first[ct + 1], lane, srow0, tile_row0, prow, pcol, P, invD, d, vu, v, relax_mode, w);
+    const int nsteps = load_desc(desc, dstride, lane, sdesc);
+    if (nsteps <= 0) return;
+    (void)S1;
+    chain_sweep_light<SHAPE>(nsteps, lane, sdesc + DESC_HEAD, prow, pcol, P, invD, d, vu, v, relax_mode, w);
 }
 template <int SHAPE>
-__global__ __launch_bounds__(64) void k_ilu_sweep_chain(const int* __restrict__ ct_sched, int nct, const int* __restrict__ ct_first,
-                                                        const int* __restrict__ tile_row0, const int* __restrict__ prow,
+__global__ __launch_bounds__(64) void k_ilu_sweep_chain(const int* __restrict__ desc, int dstride, int S1,
+                                                        const int* __restrict__ prow,
                                                         const int* __restrict__ pcol, const double* __restrict__ P,
                                                         const double* __restrict__ invD, const double* d,
                                                         double* vu, double* v, int relax_mode, double w, const double* __restrict__ done) {
     TILE_LDS
-    __shared__ int srow0[CHAIN_MAX_STEPS + 2], sk0[CHAIN_MAX_STEPS + 2];
+    __shared__ int sdesc[DESC_MAX];
     const int lane = threadIdx.x;
     if (*done != 0.0) return;
-    const int ct = ct_sched[blockIdx.x];
-    if (ct < 0) return;
-    chain_sweep<SHAPE>(ct_first[ct], ct_first[ct + 1], lane, sval, srow0, sk0, tile_row0, prow, pcol, P, invD, d, vu,
-                       v, relax_mode, w);
+    const int nsteps = load_desc(desc, dstride, lane, sdesc);
+    if (nsteps <= 0) return;
+    const int* srow0 = sdesc + DESC_HEAD;
+    chain_sweep<SHAPE>(nsteps, lane, sval, srow0, srow0 + (SHAPE == SW_L ? 1 : 2) * S1, prow, pcol, P, invD, d, vu, v, relax_mode, w);
 }
 // Last colour: its rows have U entries only inside their own chain-tile, so the backward sweep of a chain-tile can
 // start the moment its forward sweep ends - one launch instead of two, and y never leaves the cache in between.
 template <bool LIGHT_U>
-__global__ __launch_bounds__(64) void k_ilu_sweep_chain_LU(const int* __restrict__ ct_sched, int nct, const int* __restrict__ ct_first,
-                                                           const int* __restrict__ tile_row0, const int* __restrict__ lrow,
+__global__ __launch_bounds__(64) void k_ilu_sweep_chain_LU(const int* __restrict__ desc, int dstride, int S1,
+                                                           const int* __restrict__ lrow,
                                                            const int* __restrict__ lcol, const double* __restrict__ L,
                                                            const int* __restrict__ urow, const int* __restrict__ ucol,
                                                            const double* __restrict__ Uv, const double* __restrict__ invD,
                                                            const double* d, double* vu, double* v, int relax_mode, double w,
                                                            const double* __restrict__ done) {
     TILE_LDS
-    __shared__ int srow0[CHAIN_MAX_STEPS + 2], sk0[CHAIN_MAX_STEPS + 2];
+    __shared__ int sdesc[DESC_MAX];
     const int lane = threadIdx.x;
     if (*done != 0.0) return;
-    const int ct = ct_sched[blockIdx.x];
-    if (ct < 0) return;
-    const int q0 = ct_first[ct], q1 = ct_first[ct + 1];
-    chain_sweep<SW_L>(q0, q1, lane, sval, srow0, sk0, tile_row0, lrow, lcol, L, invD, d, vu, v, relax_mode, w);
+    const int nsteps = load_desc(desc, dstride, lane, sdesc);
+    if (nsteps <= 0) return;
+    const int* srow0 = sdesc + DESC_HEAD;
+    chain_sweep<SW_L>(nsteps, lane, sval, srow0, srow0 + S1, lrow, lcol, L, invD, d, vu, v, relax_mode, w);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // y of this chain-tile is written before the backward sweep reads it
     wave_sync();
-    if (LIGHT_U) chain_sweep_light<SW_UF>(q0, q1, lane, srow0, tile_row0, urow, ucol, Uv, invD, d, vu, v, relax_mode, w);
-    else chain_sweep<SW_UF>(q0, q1, lane, sval, srow0, sk0, tile_row0, urow, ucol, Uv, invD, d, vu, v, relax_mode, w);
+    if (LIGHT_U) chain_sweep_light<SW_UF>(nsteps, lane, srow0, urow, ucol, Uv, invD, d, vu, v, relax_mode, w);
+    else chain_sweep<SW_UF>(nsteps, lane, sval, srow0, srow0 + 2 * S1, urow, ucol, Uv, invD, d, vu, v, relax_mode, w);
 }
 
 // ============================== ILU0 factorisation =======================================================
@@ -1650,33 +1658,34 @@ void launch_ilu_apply(opmhip_ctx* c, const double* d, double* v, int fuse) {
     const int n0 = P.colorPrefix[1];  // rows of the first colour: their y is d
     auto grid = [](int n) { return dim3(8 * ((n + 7) / 8)); };
     if (P.chained) {
-        // per colour: the launch schedule of its chain-tiles (position -> chain-tile or padding) and its length
-        auto sched = [&](int col) { return P.tiles.d_ctSched + P.tiles.ctSchedOff[col]; };
+        // per colour: the descriptor records of its launch schedule (one per position, padding included) and their count
+        const int ds = P.tiles.descStride, S1 = P.tiles.descS1;
+        auto desc = [&](int col) { return P.tiles.d_ctDesc + (size_t)P.tiles.ctSchedOff[col] * ds; };
         auto npos = [&](int col) { return P.tiles.ctSchedOff[col + 1] - P.tiles.ctSchedOff[col]; };
         for (int col = 0; col < C - 1; ++col) {
             const int nct = npos(col);
             if (nct <= 0) continue;
             if (col == 0 && fuse == DM_PUPD)
-                hipLaunchKernelGGL(k_ilu_sweep_light_fused<DM_PUPD>, dim3(nct), dim3(64), 0, c->stream, sched(col), nct, P.tiles.d_ctFirst, P.tiles.d_row0, P.d_lrowptr,
+                hipLaunchKernelGGL(k_ilu_sweep_light_fused<DM_PUPD>, dim3(nct), dim3(64), 0, c->stream, desc(col), ds, S1, nct, P.d_lrowptr,
                                    P.d_lcol, c->d_L, const_cast<double*>(d), vu, c->d_scal, c->d_v, c->d_r, (double*)nullptr, P.colorPrefix[1], P.Nb, c->d_part);
             else if (col == 0 && fuse == DM_UPD1)
-                hipLaunchKernelGGL(k_ilu_sweep_light_fused<DM_UPD1>, dim3(nct), dim3(64), 0, c->stream, sched(col), nct, P.tiles.d_ctFirst, P.tiles.d_row0, P.d_lrowptr,
+                hipLaunchKernelGGL(k_ilu_sweep_light_fused<DM_UPD1>, dim3(nct), dim3(64), 0, c->stream, desc(col), ds, S1, nct, P.d_lrowptr,
                                    P.d_lcol, c->d_L, const_cast<double*>(d), vu, c->d_scal, c->d_v, c->d_pw, c->d_x, P.colorPrefix[1], P.Nb, c->d_part);
             else if (P.lightL[col])
-                hipLaunchKernelGGL(k_ilu_sweep_light<SW_L>, dim3(nct), dim3(64), 0, c->stream, sched(col), nct, P.tiles.d_ctFirst, P.tiles.d_row0, P.d_lrowptr,
+                hipLaunchKernelGGL(k_ilu_sweep_light<SW_L>, dim3(nct), dim3(64), 0, c->stream, desc(col), ds, S1, P.d_lrowptr,
                                    P.d_lcol, c->d_L, c->d_invD, d, vu, v, mode, w, c->d_done);
             else
-                hipLaunchKernelGGL(k_ilu_sweep_chain<SW_L>, dim3(nct), dim3(64), 0, c->stream, sched(col), nct, P.tiles.d_ctFirst, P.tiles.d_row0, P.d_lrowptr,
+                hipLaunchKernelGGL(k_ilu_sweep_chain<SW_L>, dim3(nct), dim3(64), 0, c->stream, desc(col), ds, S1, P.d_lrowptr,
                                    P.d_lcol, c->d_L, c->d_invD, d, vu, v, mode, w, c->d_done);
         }
         {
             const int nct = npos(C - 1);
             if (nct > 0) {
                 if (P.lightU[C - 1])
-                    hipLaunchKernelGGL(k_ilu_sweep_chain_LU<true>, dim3(nct), dim3(64), 0, c->stream, sched(C - 1), nct, P.tiles.d_ctFirst, P.tiles.d_row0, P.d_lrowptr,
+                    hipLaunchKernelGGL(k_ilu_sweep_chain_LU<true>, dim3(nct), dim3(64), 0, c->stream, desc(C - 1), ds, S1, P.d_lrowptr,
                                        P.d_lcol, c->d_L, P.d_urowptr, P.d_ucol, c->d_U, c->d_invD, d, vu, v, mode, w, c->d_done);
                 else
-                    hipLaunchKernelGGL(k_ilu_sweep_chain_LU<false>, dim3(nct), dim3(64), 0, c->stream, sched(C - 1), nct, P.tiles.d_ctFirst, P.tiles.d_row0, P.d_lrowptr,
+                    hipLaunchKernelGGL(k_ilu_sweep_chain_LU<false>, dim3(nct), dim3(64), 0, c->stream, desc(C - 1), ds, S1, P.d_lrowptr,
                                        P.d_lcol, c->d_L, P.d_urowptr, P.d_ucol, c->d_U, c->d_invD, d, vu, v, mode, w, c->d_done);
             }
         }
@@ -1684,10 +1693,10 @@ void launch_ilu_apply(opmhip_ctx* c, const double* d, double* v, int fuse) {
             const int nct = npos(col);
             if (nct <= 0) continue;
             if (P.lightU[col])
-                hipLaunchKernelGGL(k_ilu_sweep_light<SW_UF>, dim3(nct), dim3(64), 0, c->stream, sched(col), nct, P.tiles.d_ctFirst, P.tiles.d_row0, P.d_urowptr,
+                hipLaunchKernelGGL(k_ilu_sweep_light<SW_UF>, dim3(nct), dim3(64), 0, c->stream, desc(col), ds, S1, P.d_urowptr,
                                    P.d_ucol, c->d_U, c->d_invD, d, vu, v, mode, w, c->d_done);
             else
-                hipLaunchKernelGGL(k_ilu_sweep_chain<SW_UF>, dim3(nct), dim3(64), 0, c->stream, sched(col), nct, P.tiles.d_ctFirst, P.tiles.d_row0, P.d_urowptr,
+                hipLaunchKernelGGL(k_ilu_sweep_chain<SW_UF>, dim3(nct), dim3(64), 0, c->stream, desc(col), ds, S1, P.d_urowptr,
                                    P.d_ucol, c->d_U, c->d_invD, d, vu, v, mode, w, c->d_done);
         }
         prof_end(c, ps);

@@ -514,8 +514,9 @@ SolveResult bicgstab(size_t n, const double* b, double* x, Prec&& prec, Op&& op,
 // OpenMP reductions for the scalar products.  Same recurrence as bicgstab() above.  Baseline only: no parity claim
 // rests on these (the reduction order depends on the thread count).
 // =====================================================================================================
-inline int bilu0_decompose_bj(Bcrs& A, const std::vector<int>& sub) {
-    const std::vector<int> dg = diag_index(A);
+inline int bilu0_decompose_bj(Bcrs& A, const std::vector<int>& sub, const std::vector<int>* diag = nullptr) {
+    const std::vector<int> dgOwn = diag ? std::vector<int>() : diag_index(A);
+    const std::vector<int>& dg = diag ? *diag : dgOwn;
     const int nsub = (int)sub.size() - 1;
     int err = 0;
 #pragma omp parallel for schedule(static, 1)

@@ -336,7 +336,14 @@ int orc_oil_pvt_probe(const orc_fluid_desc* d, int region, int n, const double* 
     return 0;
 }
 
-struct orc_model { Model M; };
+struct orc_model {
+    Model M;
+    // work copies of the multi-threaded solve (orc_bo_solve_mt): allocated and first-touched once, then reused - a fresh
+    // 500 MB std::vector per Newton iteration was zero-filled by ONE thread and made the 16-thread "setup" slower than the
+    // serial one
+    Bcrs mtA, mtLU;
+    std::vector<int> mtDiag;
+};
 
 orc_model* orc_bo_create(int Nb, const int* rowptr, const int* col, const double* trans, const double* area,
                          const double* thpres, const double* poro, const double* volume, const double* depth,
@@ -450,23 +457,28 @@ int orc_bo_solve_mt(orc_model* h, double* x, double tol, int maxit, double w, in
     if (threads < 1) threads = 1;
     std::vector<int> sub(threads + 1);
     for (int s = 0; s <= threads; ++s) sub[s] = (int)((long long)Nb * s / threads);
+    if (h->mtA.Nb != M.J.Nb) {   // first call: pattern copies and the diagonal positions, once (the pattern never changes)
+        for (Bcrs* D : {&h->mtA, &h->mtLU}) {
+            D->Nb = M.J.Nb; D->rowptr = M.J.rowptr; D->col = M.J.col;
+            D->val.resize(M.J.val.size());
+        }
+        h->mtDiag = diag_index(M.J);
+    }
     auto t0 = clk::now();
     // values copied (threaded): the zero-diagonal fix and the factorisation work on copies, as in the 1-thread path
-    auto copy_mt = [](const Bcrs& S) {
-        Bcrs D;
-        D.Nb = S.Nb; D.rowptr = S.rowptr; D.col = S.col;
-        D.val.resize(S.val.size());
+    auto copy_vals = [](const Bcrs& S, Bcrs& D) {
         const long long m = (long long)S.val.size();
 #pragma omp parallel for schedule(static)
         for (long long i = 0; i < m; ++i) D.val[i] = S.val[i];
-        return D;
     };
-    Bcrs A = copy_mt(M.J);
+    Bcrs& A = h->mtA;
+    Bcrs& LU = h->mtLU;
+    copy_vals(M.J, A);
     check_zero_diagonal(A);
-    Bcrs LU = copy_mt(A);
-    const int rc = bilu0_decompose_bj(LU, sub);
+    copy_vals(A, LU);
+    const std::vector<int>& dg = h->mtDiag;
+    const int rc = bilu0_decompose_bj(LU, sub, &dg);
     if (rc != 0) return rc;
-    const std::vector<int> dg = diag_index(LU);
     auto t1 = clk::now();
     auto prec = [&](const double* d, double* v) { ilu0_apply_bj(LU, dg, sub, d, v, w, relax_mode); };
     auto op = [&](const double* xin, double* y) { spmv_mt(A, xin, y); };
