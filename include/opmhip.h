@@ -20,7 +20,7 @@
 extern "C" {
 #endif
 
-#define OPMHIP_ABI_VERSION 1
+#define OPMHIP_ABI_VERSION 2
 
 typedef struct opmhip_ctx opmhip_ctx;
 
@@ -196,11 +196,26 @@ typedef struct opmhip_fluid {
     const int* sgof_ptr;        /* [num_sat+1] */
     const double* sgof;         /* rows (Sg, krg, krog, pcog) */
     double rock_pref, rock_cr;  /* ROCK: reference pressure, compressibility (ebos/eclproblem.hh:1454-1486) */
+    /* Wet gas (PVTG; NULL / no nodes = dry gas from PVDG, and then pvdg is mandatory): per PVT region its gas-pressure
+     * nodes, per node the rows (Rv, Bg, mu_g) as the deck lists them - the saturated row first, Rv descending.  With PVTG
+     * the oil component may vaporise into the gas phase: Rv, the third primary-variable meaning OPMHIP_SW_PG_RV, DRVDT cap
+     * through opmhip_set_problem_extras (FluidSystem::enableVaporizedOil). */
+    const int* pvtg_node_ptr;   /* [num_pvt+1]  pressure-node ranges */
+    const double* pvtg_pg;      /* [nodes]      gas pressure of each node */
+    const int* pvtg_row_ptr;    /* [nodes+1]    row ranges into pvtg */
+    const double* pvtg;         /* rows (Rv, Bg, mu_g) */
+    /* ROCKTAB: per rock region rows (p, pore-volume multiplier, transmissibility multiplier), evaluated with linear
+     * extrapolation at the (effective) oil pressure: rockCompPoroMultiplier / rockCompTransMultiplier
+     * (ebos/eclproblem.hh:1936-2007).  num_rock = 0: none. */
+    int num_rock;
+    const int* rocktab_ptr;     /* [num_rock+1] */
+    const double* rocktab;
 } opmhip_fluid;
 
 /* primary-variable meaning per cell: BlackOilPrimaryVariables::PrimaryVarsMeaning */
 #define OPMHIP_SW_PO_SG 0
 #define OPMHIP_SW_PO_RS 1
+#define OPMHIP_SW_PG_RV 2 /* wet gas only: oil phase absent, pressure variable = gas pressure, third variable = Rv */
 
 /* replaces: FluidSystem / MaterialLawManager initialisation from the deck (setup, once) */
 int opmhip_set_fluid(opmhip_ctx* ctx, const opmhip_fluid* fluid);
@@ -214,6 +229,12 @@ int opmhip_set_fluid(opmhip_ctx* ctx, const opmhip_fluid* fluid);
 int opmhip_set_static(opmhip_ctx* ctx, const double* trans, const double* area, const double* thpres,
                       const double* poro, const double* volume, const double* depth, const int* pvtnum,
                       const int* satnum, const double* rsmax);
+
+/* replaces: EclProblem::maxOilVaporizationFactor (DRVDT cap on Rv, ebos/eclproblem.hh:1734-1754), rockTableIdx_ (ROCKNUM,
+ * :1943-1945) and overburdenPressure_ (:1954-1955).  Per cell, natural order, any may be NULL (no cap / table 0 / none);
+ * only meaningful for a fluid with PVTG or ROCKTAB tables (else INVALID_ARGUMENT).  Needs set_static; recomputes the cached
+ * intensive quantities if a state is set. */
+int opmhip_set_problem_extras(opmhip_ctx* ctx, const double* rvmax, const int* rocknum, const double* overburden);
 
 /* Point evaluation of the fluid-system and saturation functions the assembly uses, ON THE DEVICE, for host-side setup
  * code (equilibration, ebos/equil/initstateequil.hh) and for tests that pin these functions against the reference's
@@ -260,7 +281,10 @@ int opmhip_set_source(opmhip_ctx* ctx, const double* source, const double* dsour
 int opmhip_assemble(opmhip_ctx* ctx, double dt, int iteration, double* jac, double* residual);
 
 /* cached intensive quantities, for parity tests: per cell 17 fields x (value, d/dSw, d/dp, d/dX):
- * S_w S_o S_g | p_w p_o p_g | b_w b_o b_g | mob_w mob_o mob_g | rho_w rho_o rho_g | Rs | porosity */
+ * S_w S_o S_g | p_w p_o p_g | b_w b_o b_g | mob_w mob_o mob_g | rho_w rho_o rho_g | Rs | porosity
+ * With a PVTG or ROCKTAB fluid the record has 19 fields: ... | Rs | Rv | transmissibility multiplier | porosity
+ * (opmhip_iq_fields tells which). */
+int opmhip_iq_fields(opmhip_ctx* ctx);
 int opmhip_get_iq(opmhip_ctx* ctx, double* out);
 
 /* replaces: BlackoilModelEbos::localConvergenceData + computeCnvErrorPv + the CNV/MB formulas of

@@ -278,6 +278,8 @@ def _bind_assembly(L):
     L.opmhip_set_halo.argtypes = [vp, C.c_longlong, C.c_int, vp, vp, vp, vp]
     L.opmhip_set_cell_global_ids.argtypes = [vp, vp]
     L.opmhip_fluid_probe.argtypes = [vp, C.c_int, C.c_int, C.c_int, vp, vp, vp, vp, vp]
+    L.opmhip_set_problem_extras.argtypes = [vp, vp, vp, vp]
+    L.opmhip_iq_fields.argtypes = [vp]
 
 
 class HipFluid(HipSolver):
@@ -349,6 +351,13 @@ class HipModel(HipSolver):
         p = lambda k: _ptr(keep.get(k))
         self._check(L.opmhip_set_static(self._h, p("trans"), p("area"), p("thpres"), p("poro"), p("volume"), p("depth"),
                                         p("pvtnum"), p("satnum"), p("rsmax")))
+        if any(case.get(k) is not None for k in ("rvmax", "rocknum", "overburden")):
+            self.set_problem_extras(case.get("rvmax"), case.get("rocknum"), case.get("overburden"))
+
+    def set_problem_extras(self, rvmax=None, rocknum=None, overburden=None):
+        """DRVDT cap on Rv, rock-table index (ROCKNUM), overburden pressure - per cell, any None"""
+        a, b, d = _f64(rvmax), _i32(rocknum), _f64(overburden)
+        self._check(lib().opmhip_set_problem_extras(self._h, _ptr(a), _ptr(b), _ptr(d)))
 
     def set_state(self, pv, meaning):
         pv, meaning = _f64(pv), np.ascontiguousarray(meaning, np.uint8)
@@ -387,9 +396,10 @@ class HipModel(HipSolver):
         return jac, res
 
     def iq(self):
-        out = np.empty(self.Nloc * 17 * 4)
+        nf = self._check(lib().opmhip_iq_fields(self._h))
+        out = np.empty(self.Nloc * nf * 4)
         self._check(lib().opmhip_get_iq(self._h, _ptr(out)))
-        return out.reshape(self.Nloc, 17, 4)
+        return out.reshape(self.Nloc, nf, 4)
 
     def convergence(self, dt, tol_cnv=1e-2):
         out = np.empty(17)

@@ -76,6 +76,8 @@ struct TablesT {
     const int* idx;
     double rock_pref, rock_cr;
     int ndbl, nidx;   // lengths of the blobs (for the LDS copy of the per-cell kernels)
+    int rock_desc, num_rock;   // RockTabDesc array inside the int blob (ROCKTAB), 0 tables = none
+    __device__ __forceinline__ const RockTabDesc& rock(int t) const { return reinterpret_cast<const RockTabDesc*>(idx + rock_desc)[t]; }
     __device__ __forceinline__ const PvtRegionDesc& pvt(int r) const { return reinterpret_cast<const PvtRegionDesc*>(idx + 2)[r]; }
     __device__ __forceinline__ const SatRegionDesc& sat(int s) const {
         return reinterpret_cast<const SatRegionDesc*>(idx + 2 + idx[0] * (int)(sizeof(PvtRegionDesc) / sizeof(int)))[s];
@@ -99,14 +101,16 @@ template <class E, class DP> __device__ __forceinline__ E tab1(DP x, DP y, int n
     const double x0 = x[s], x1 = x[s + 1], y0 = y[s], y1 = y[s + 1];
     return y0 + (y1 - y0) * (xv - x0) / (x1 - x0);
 }
-// plain bilinear interpolation in (Rs, p) with per-column pressure grids (the policy the Norne PVT points select)
-template <class E, class DP> __device__ __forceinline__ E tab2(const TablesT<DP>& T, const PvtRegionDesc& D, int voff, const E& xv, const E& yv) {
-    const DP xs = T.dbl + D.o_xs;
-    const int* yo = T.idx + D.o_yoff;
-    const int i = seg_right(xs, D.o_nx, val(xv));
+// plain bilinear interpolation in (x, y) with per-column y grids (UniformXTabulated2DFunction; the policy the Norne PVT
+// points select): oil (x = Rs, y = p_o), wet gas (x = p_g, y = Rv)
+struct Tab2Desc { int nx, xs, yoff, ys; };
+template <class E, class DP> __device__ __forceinline__ E tab2g(const TablesT<DP>& T, const Tab2Desc& G, int voff, const E& xv, const E& yv) {
+    const DP xs = T.dbl + G.xs;
+    const int* yo = T.idx + G.yoff;
+    const int i = seg_right(xs, G.nx, val(xv));
     const E alpha = (xv - xs[i]) / (xs[i + 1] - xs[i]);
-    const DP y1 = T.dbl + D.o_ys + yo[i];
-    const DP y2 = T.dbl + D.o_ys + yo[i + 1];
+    const DP y1 = T.dbl + G.ys + yo[i];
+    const DP y2 = T.dbl + G.ys + yo[i + 1];
     const DP v1 = T.dbl + voff + yo[i];
     const DP v2 = T.dbl + voff + yo[i + 1];
     const int j1 = seg_right(y1, yo[i + 1] - yo[i], val(yv)), j2 = seg_right(y2, yo[i + 2] - yo[i + 1], val(yv));
@@ -115,6 +119,12 @@ template <class E, class DP> __device__ __forceinline__ E tab2(const TablesT<DP>
     const E s1 = v1[j1] * (1.0 - beta1) + v1[j1 + 1] * beta1;
     const E s2 = v2[j2] * (1.0 - beta2) + v2[j2 + 1] * beta2;
     return s1 * (1.0 - alpha) + s2 * alpha;
+}
+template <class E, class DP> __device__ __forceinline__ E tab2(const TablesT<DP>& T, const PvtRegionDesc& D, int voff, const E& xv, const E& yv) {
+    return tab2g<E, DP>(T, Tab2Desc{D.o_nx, D.o_xs, D.o_yoff, D.o_ys}, voff, xv, yv);
+}
+template <class E, class DP> __device__ __forceinline__ E tab2wg(const TablesT<DP>& T, const PvtRegionDesc& D, int voff, const E& pg, const E& Rv) {
+    return tab2g<E, DP>(T, Tab2Desc{D.wg_n, D.wg_xs, D.wg_yoff, D.wg_ys}, voff, pg, Rv);
 }
 // PiecewiseLinearTwoPhaseMaterial: constant outside the table; a value on a node belongs to the segment on its left
 template <class E, class DP> __device__ __forceinline__ E pwlin(DP x, DP y, int n, const E& xv) {
@@ -134,11 +144,34 @@ template <class DP> __device__ __forceinline__ double rs_sat_value(const TablesT
     const PvtRegionDesc& D = T.pvt(pr);
     return tab1<double, DP>(T.dbl + D.sat_p, T.dbl + D.sat_rs, D.sat_n, po);
 }
+template <class DP> __device__ __forceinline__ double rv_sat_value(const TablesT<DP>& T, int pr, double pg) {
+    const PvtRegionDesc& D = T.pvt(pr);
+    return tab1<double, DP>(T.dbl + D.wg_xs, T.dbl + D.wgs_rv, D.wg_n, pg);
+}
+// EclDefaultMaterial capillary pressures: pC[water] = -pcow(Sw), pC[oil] = 0, pC[gas] = pcgo(1 - Swco - Sg)
+template <class E, class DP> __device__ __forceinline__ void cap_pressures(const TablesT<DP>& T, int sr, const E& Sw, const E& Sg, E pC[3]) {
+    const SatRegionDesc& Sd = T.sat(sr);
+    const DP B = T.dbl;
+    const double Swco = B[Sd.swco];
+    pC[0] = -pwlin<E, DP>(B + Sd.sw_x, B + Sd.pcow, Sd.nw, Sw);
+    pC[1] = cst<E>(0.0);
+    pC[2] = pwlin<E, DP>(B + Sd.so_x, B + Sd.pcgo, Sd.ng, 1.0 - Swco - Sg);
+}
 
 // ============================== intensive quantities ========================================================
-constexpr int IQF = 17;            // fields per cell
-constexpr int IQS = IQF * 4;       // doubles per cell in the cache (value + 3 derivatives each)
-enum { F_S = 0, F_P = 3, F_B = 6, F_MOB = 9, F_RHO = 12, F_RS = 15, F_PORO = 16 };
+// Record of the intensive-quantity cache: fields x (value + 3 derivatives).  Two layouts, chosen per context when the
+// fluid is set: the BASE one (live oil + dry gas + water: 17 fields) and the EXTENDED one (19 fields) for decks with wet
+// gas (PVTG: Rv) and / or rock compaction tables (ROCKTAB: transmissibility multiplier).  Kernels are templated on it, so
+// that the base instantiation is bit for bit and byte for byte what it was.
+enum { F_S = 0, F_P = 3, F_B = 6, F_MOB = 9, F_RHO = 12, F_RS = 15 };
+template <bool EXT> struct Lay {
+    static constexpr int F_RV = 16, F_TMULT = 17;                    // EXT only
+    static constexpr int F_PORO = EXT ? 18 : 16;
+    static constexpr int IQF = EXT ? 19 : 17;                        // fields per cell
+    static constexpr int IQS = IQF * 4;                              // doubles per cell
+    static constexpr int RQ_F0 = F_P;                                // neighbour fields of the flux: p, 1/B, mobility, density, Rs [, Rv, tmult]
+    static constexpr int RQ_NF = (EXT ? F_TMULT : F_RS) - F_P + 1;
+};
 enum { WATER = 0, OIL = 1, GAS = 2 };
 enum { EQ_OIL = 0, EQ_WATER = 1, EQ_GAS = 2 };
 constexpr double GRAVITY = 9.80665;
@@ -146,18 +179,30 @@ constexpr double GRAVITY = 9.80665;
 template <class E>
 struct Iq {
     E S[3], p[3], invB[3], mob[3], rho[3], Rs, poro;
+    E Rv, tmult;   // extended layout only
+};
+struct CellStatic {
+    const double *poro, *volume, *depth, *rsmax;
+    const int *pvtnum, *satnum;
+    const double *rvmax, *overburden;   // extended layout: DRVDT cap, overburden pressure (may be NULL)
+    const int* rocknum;                 // rock-table index per cell (NULL = table 0)
 };
 
-// BlackOilIntensiveQuantities::update for live oil + dry gas + water
-template <class E, class DP>
-__device__ __forceinline__ void update_iq(const TablesT<DP>& T, int pr, int sr, double RsMax, double refPoro, const double* pv, int meaning, Iq<E>& q) {
+// BlackOilIntensiveQuantities::update: live oil + water + dry gas (base) or wet gas / rock compaction tables (EXT)
+template <class E, class DP, bool EXT>
+__device__ __forceinline__ void update_iq(const TablesT<DP>& T, const CellStatic& C, int c, const double* pv, int meaning, Iq<E>& q) {
+    const int pr = C.pvtnum ? C.pvtnum[c] : 0, sr = C.satnum ? C.satnum[c] : 0;
+    const double RsMax = C.rsmax ? C.rsmax[c] : DBL_MAX / 2.0;
+    const double refPoro = C.poro[c];
     const PvtRegionDesc& D = T.pvt(pr);
     const SatRegionDesc& Sd = T.sat(sr);
     const DP B = T.dbl;
+    const bool wet = EXT && D.wg_n > 0;   // FluidSystem::enableVaporizedOil()
     const double Swco = B[Sd.swco];
     const E Sw = mk<E>(pv[0], 0);
     E Sg = cst<E>(0.0);
     if (meaning == OPMHIP_SW_PO_SG) Sg = mk<E>(pv[2], 2);
+    else if (EXT && meaning == OPMHIP_SW_PG_RV) Sg = 1.0 - Sw;   // the oil phase is absent
     const E So = 1.0 - Sw - Sg;
     q.S[WATER] = Sw; q.S[GAS] = Sg; q.S[OIL] = So;
     // capillary pressures (EclDefaultMaterial): pC[water] = -pcow(Sw), pC[oil] = 0, pC[gas] = pcgo(1 - Swco - Sg)
@@ -165,8 +210,13 @@ __device__ __forceinline__ void update_iq(const TablesT<DP>& T, int pr, int sr, 
     pC[0] = -pwlin<E, DP>(B + Sd.sw_x, B + Sd.pcow, Sd.nw, Sw);
     pC[1] = cst<E>(0.0);
     pC[2] = pwlin<E, DP>(B + Sd.so_x, B + Sd.pcgo, Sd.ng, 1.0 - Swco - Sg);
-    const E po = mk<E>(pv[1], 1);
-    for (int ph = 0; ph < 3; ++ph) q.p[ph] = po + (pC[ph] - pC[OIL]);
+    if (EXT && meaning == OPMHIP_SW_PG_RV) {   // the pressure primary variable is the GAS pressure
+        const E pg = mk<E>(pv[1], 1);
+        for (int ph = 0; ph < 3; ++ph) q.p[ph] = pg + (pC[ph] - pC[GAS]);
+    } else {
+        const E po = mk<E>(pv[1], 1);
+        for (int ph = 0; ph < 3; ++ph) q.p[ph] = po + (pC[ph] - pC[OIL]);
+    }
     // relative permeabilities (stored in mob, divided by viscosity below)
     {
         q.mob[WATER] = pwlin<E, DP>(B + Sd.sw_x, B + Sd.krw, Sd.nw, Sw);
@@ -186,12 +236,24 @@ __device__ __forceinline__ void update_iq(const TablesT<DP>& T, int pr, int sr, 
             } else q.mob[OIL] = kro2;
         } else q.mob[OIL] = (Sg * kro_go + (Swm - Swco) * kro_ow) / (Sw_ow - Swco);
     }
-    // Rs: saturated value in the three-phase case, the primary variable otherwise, capped by RsMax
+    // Rs / Rv by the meaning of the switching variable, capped by RsMax / RvMax (DRSDT / DRVDT, eclproblem.hh:1711-1754)
+    if (EXT) q.Rv = cst<E>(0.0);
     if (meaning == OPMHIP_SW_PO_SG) {
         const E RsSat = tab1<E, DP>(B + D.sat_p, B + D.sat_rs, D.sat_n, q.p[OIL]);
         q.Rs = emin(cst<E>(RsMax), RsSat);
-    } else {
+    } else if (!EXT || meaning == OPMHIP_SW_PO_RS) {
         q.Rs = emin(cst<E>(RsMax), mk<E>(pv[2], 2));
+    } else {   // Sw_pg_Rv: the oil phase is not present, its "composition" is still needed for the gravity term
+        const E RsSat = tab1<E, DP>(B + D.sat_p, B + D.sat_rs, D.sat_n, q.p[OIL]);
+        q.Rs = emin(cst<E>(RsMax), RsSat);
+    }
+    if (EXT && wet) {
+        const double RvMax = C.rvmax ? C.rvmax[c] : DBL_MAX / 2.0;
+        if (meaning == OPMHIP_SW_PG_RV) q.Rv = emin(cst<E>(RvMax), mk<E>(pv[2], 2));
+        else {
+            const E RvSat = tab1<E, DP>(B + D.wg_xs, B + D.wgs_rv, D.wg_n, q.p[GAS]);
+            q.Rv = emin(cst<E>(RvMax), RvSat);
+        }
     }
     // 1/B and viscosity per phase, each at its own phase pressure (BlackOilFluidSystem)
     {
@@ -210,19 +272,42 @@ __device__ __forceinline__ void update_iq(const TablesT<DP>& T, int pr, int sr, 
             mu = tab2<E, DP>(T, D, D.o_invB, q.Rs, q.p[OIL]) / tab2<E, DP>(T, D, D.o_invBMu, q.Rs, q.p[OIL]);
         }
         q.mob[OIL] = q.mob[OIL] / mu;
-        q.invB[GAS] = tab1<E, DP>(B + D.gas_p, B + D.gas_invB, D.gas_n, q.p[GAS]);
-        mu = tab1<E, DP>(B + D.gas_p, B + D.gas_invB, D.gas_n, q.p[GAS]) / tab1<E, DP>(B + D.gas_p, B + D.gas_invBMu, D.gas_n, q.p[GAS]);
+        if (EXT && wet) {
+            const bool gasSaturated = val(q.S[OIL]) > 0.0 && val(q.Rv) >= (1.0 - 1e-10) * rv_sat_value(T, pr, val(q.p[GAS]));
+            if (gasSaturated) {
+                q.invB[GAS] = tab1<E, DP>(B + D.wg_xs, B + D.wgs_invB, D.wg_n, q.p[GAS]);
+                mu = tab1<E, DP>(B + D.wg_xs, B + D.wgs_invB, D.wg_n, q.p[GAS]) / tab1<E, DP>(B + D.wg_xs, B + D.wgs_invBMu, D.wg_n, q.p[GAS]);
+            } else {
+                q.invB[GAS] = tab2wg<E, DP>(T, D, D.wg_invB, q.p[GAS], q.Rv);
+                mu = tab2wg<E, DP>(T, D, D.wg_invB, q.p[GAS], q.Rv) / tab2wg<E, DP>(T, D, D.wg_invBMu, q.p[GAS], q.Rv);
+            }
+        } else {
+            q.invB[GAS] = tab1<E, DP>(B + D.gas_p, B + D.gas_invB, D.gas_n, q.p[GAS]);
+            mu = tab1<E, DP>(B + D.gas_p, B + D.gas_invB, D.gas_n, q.p[GAS]) / tab1<E, DP>(B + D.gas_p, B + D.gas_invBMu, D.gas_n, q.p[GAS]);
+        }
         q.mob[GAS] = q.mob[GAS] / mu;
     }
     const DP rr = B + D.density;  // oil, water, gas
     q.rho[WATER] = q.invB[WATER] * rr[1];
     q.rho[GAS] = q.invB[GAS] * rr[2];
+    if (EXT && wet) q.rho[GAS] = q.rho[GAS] + q.invB[GAS] * q.Rv * rr[0];   // vaporised oil
     q.rho[OIL] = q.invB[OIL] * rr[0];
     q.rho[OIL] = q.rho[OIL] + q.invB[OIL] * q.Rs * rr[2];
     q.poro = cst<E>(refPoro);
     if (T.rock_cr > 0.0) {
         const E x = T.rock_cr * (q.p[OIL] - T.rock_pref);
         q.poro = q.poro * (1.0 + x + 0.5 * x * x);
+    }
+    if (EXT) {
+        // rock compaction tables: rockCompPoroMultiplier / rockCompTransMultiplier (ebos/eclproblem.hh:1936-2007), reversible form
+        q.tmult = cst<E>(1.0);
+        if (T.num_rock > 0) {
+            const RockTabDesc& R = T.rock(C.rocknum ? C.rocknum[c] : 0);
+            E effectiveOilPressure = q.p[OIL];
+            if (C.overburden) effectiveOilPressure = effectiveOilPressure - C.overburden[c];
+            q.poro = q.poro * tab1<E, DP>(B + R.p, B + R.poroMult, R.n, effectiveOilPressure);
+            q.tmult = tab1<E, DP>(B + R.p, B + R.transMult, R.n, effectiveOilPressure);
+        }
     }
 }
 
@@ -231,32 +316,29 @@ __device__ __forceinline__ Ad load_ad(const double* o) {
     const double2 a = *reinterpret_cast<const double2*>(o), b = *reinterpret_cast<const double2*>(o + 2);
     return Ad{a.x, a.y, b.x, b.y};
 }
+template <bool EXT>
 __device__ __forceinline__ void store_iq(double* o, const Iq<Ad>& q) {
     for (int k = 0; k < 3; ++k) {
         store_ad(o + (F_S + k) * 4, q.S[k]); store_ad(o + (F_P + k) * 4, q.p[k]); store_ad(o + (F_B + k) * 4, q.invB[k]);
         store_ad(o + (F_MOB + k) * 4, q.mob[k]); store_ad(o + (F_RHO + k) * 4, q.rho[k]);
     }
     store_ad(o + F_RS * 4, q.Rs);
-    store_ad(o + F_PORO * 4, q.poro);
+    if (EXT) { store_ad(o + Lay<EXT>::F_RV * 4, q.Rv); store_ad(o + Lay<EXT>::F_TMULT * 4, q.tmult); }
+    store_ad(o + Lay<EXT>::F_PORO * 4, q.poro);
 }
-
-struct CellStatic {
-    const double *poro, *volume, *depth, *rsmax;
-    const int *pvtnum, *satnum;
-};
 
 // invalidateAndUpdateIntensiveQuantities(0): one lane per cell
 // The per-cell kernels walk the property tables with binary searches: ~130 dependent loads per cell, each an L1 round
 // trip (PMC: 41 us per wavefront).  The tables are a few KiB, so every workgroup copies the double blob into LDS first
 // and searches there with ds_read (LdsTab); tables too large for the LDS budget stay in global memory (GlobalTab).
 constexpr int TAB_LDS_DBL = 3072;   // 24 KiB
-template <class DP>
+template <class DP, bool EXT>
 __device__ __forceinline__ void iq_update_cell(const TablesT<DP>& T, const CellStatic& C, int c, const double* __restrict__ pv,
                                                const unsigned char* __restrict__ meaning, double* __restrict__ iq) {
     const double x[3] = {pv[(size_t)c * 3], pv[(size_t)c * 3 + 1], pv[(size_t)c * 3 + 2]};
     Iq<Ad> q;
-    update_iq<Ad, DP>(T, C.pvtnum ? C.pvtnum[c] : 0, C.satnum ? C.satnum[c] : 0, C.rsmax ? C.rsmax[c] : DBL_MAX / 2.0, C.poro[c], x, meaning[c], q);
-    store_iq(iq + (size_t)c * IQS, q);
+    update_iq<Ad, DP, EXT>(T, C, c, x, meaning[c], q);
+    store_iq<EXT>(iq + (size_t)c * Lay<EXT>::IQS, q);
 }
 // copies the blob into `s_tab` (workgroup-wide, contains a barrier); true if the tables fit
 __device__ __forceinline__ bool tables_to_lds(const Tables& T, double* s_tab) {
@@ -266,20 +348,21 @@ __device__ __forceinline__ bool tables_to_lds(const Tables& T, double* s_tab) {
     return true;
 }
 __device__ __forceinline__ TablesT<LdsTab> lds_tables(const Tables& T, double* s_tab) {
-    return TablesT<LdsTab>{(LdsTab)s_tab, T.idx, T.rock_pref, T.rock_cr, T.ndbl, T.nidx};
+    return TablesT<LdsTab>{(LdsTab)s_tab, T.idx, T.rock_pref, T.rock_cr, T.ndbl, T.nidx, T.rock_desc, T.num_rock};
 }
+template <bool EXT>
 __global__ __launch_bounds__(256) void k_iq_update(int c0, int Nb, Tables T, CellStatic C, const double* __restrict__ pv,
                                                    const unsigned char* __restrict__ meaning, double* __restrict__ iq) {
     __shared__ double s_tab[TAB_LDS_DBL];
     const bool inLds = tables_to_lds(T, s_tab);
     const int c = c0 + blockIdx.x * blockDim.x + threadIdx.x;  // cells [c0, Nb)
     if (c >= Nb) return;
-    if (inLds) iq_update_cell(lds_tables(T, s_tab), C, c, pv, meaning, iq);
-    else iq_update_cell(T, C, c, pv, meaning, iq);
+    if (inLds) iq_update_cell<LdsTab, EXT>(lds_tables(T, s_tab), C, c, pv, meaning, iq);
+    else iq_update_cell<GlobalTab, EXT>(T, C, c, pv, meaning, iq);
 }
 
 // BlackOilNewtonMethod::update_ (chopped update) + BlackOilPrimaryVariables::adaptPrimaryVariables + IQ recompute
-template <class DP>
+template <class DP, bool EXT>
 __device__ __forceinline__ void newton_update_cell(const TablesT<DP>& T, const CellStatic& C, int c, const double* __restrict__ dx, double relax,
                                                    double* __restrict__ pv, unsigned char* __restrict__ meaning,
                                                    unsigned char* __restrict__ wasSwitched, double* __restrict__ iq,
@@ -305,29 +388,48 @@ __device__ __forceinline__ void newton_update_cell(const TablesT<DP>& T, const C
         nx[1] = x[1] - delta;
         delta = u[2];
         if (mng == OPMHIP_SW_PO_SG) delta *= satAlpha;
-        else if (delta > x[2]) delta = x[2];
+        else if (delta > x[2]) delta = x[2];   // Rs / Rv must not become negative
         nx[2] = x[2] - delta;
     }
     x[0] = nx[0]; x[1] = nx[1]; x[2] = nx[2];
-    const int pr = C.pvtnum ? C.pvtnum[c] : 0;
+    const int pr = C.pvtnum ? C.pvtnum[c] : 0, sr = C.satnum ? C.satnum[c] : 0;
     const double RsMax = C.rsmax ? C.rsmax[c] : DBL_MAX / 2.0;
+    const bool wet = EXT && T.pvt(pr).wg_n > 0;
     const double eps = wasSwitched[c] ? oscThreshold : 0.0;
     bool sw = false;
-    if (mng == OPMHIP_SW_PO_SG) {
-        if (x[0] >= 1.0) { x[0] = 1.0; x[2] = 0.0; }
-        else {
-            const double So = 1.0 - x[0] - x[2];
-            if (x[2] < -eps && So > 0.0) {
-                mng = OPMHIP_SW_PO_RS;
-                x[2] = emin(RsMax, rs_sat_value(T, pr, x[1]));
-                sw = true;
-            }
+    if (x[0] >= 1.0) {   // cells with (almost) only water
+        x[0] = 1.0; x[2] = 0.0;
+        sw = mng != OPMHIP_SW_PO_SG;
+        mng = OPMHIP_SW_PO_SG;
+    } else if (mng == OPMHIP_SW_PO_SG) {
+        const double So = 1.0 - x[0] - x[2];
+        if (x[2] < -eps && So > 0.0) {   // the gas phase disappears
+            mng = OPMHIP_SW_PO_RS;
+            x[2] = emin(RsMax, rs_sat_value(T, pr, x[1]));
+            sw = true;
+        } else if (EXT && wet && So < -eps && x[2] > 0.0) {   // the oil phase disappears: { Sw, pg, Rv }
+            double pC[3];
+            cap_pressures<double, DP>(T, sr, x[0], x[2], pC);
+            const double pg = x[1] + (pC[GAS] - pC[OIL]);
+            const double RvMax = C.rvmax ? C.rvmax[c] : DBL_MAX / 2.0;
+            mng = OPMHIP_SW_PG_RV;
+            x[1] = pg;
+            x[2] = emin(RvMax, rv_sat_value(T, pr, pg));
+            sw = true;
         }
-    } else {
-        if (x[0] >= 1.0) { mng = OPMHIP_SW_PO_SG; x[0] = 1.0; x[2] = 0.0; sw = true; }
-        else {
-            const double RsSat = rs_sat_value(T, pr, x[1]);
-            if (x[2] > emin(RsMax, RsSat * (1.0 + eps))) { mng = OPMHIP_SW_PO_SG; x[2] = 0.0; sw = true; }
+    } else if (!EXT || mng == OPMHIP_SW_PO_RS) {
+        const double RsSat = rs_sat_value(T, pr, x[1]);
+        if (x[2] > emin(RsMax, RsSat * (1.0 + eps))) { mng = OPMHIP_SW_PO_SG; x[2] = 0.0; sw = true; }
+    } else {   // Sw_pg_Rv: the oil phase appears once the gas holds more oil than saturated gas does
+        const double RvMax = C.rvmax ? C.rvmax[c] : DBL_MAX / 2.0;
+        const double RvSat = rv_sat_value(T, pr, x[1]);
+        if (x[2] > emin(RvMax, RvSat * (1.0 + eps))) {
+            double pC[3];
+            cap_pressures<double, DP>(T, sr, x[0], 1.0 - x[0], pC);
+            mng = OPMHIP_SW_PO_SG;
+            x[1] = x[1] + (pC[OIL] - pC[GAS]);
+            x[2] = 1.0 - x[0];
+            sw = true;
         }
     }
     wasSwitched[c] = sw ? 1 : 0;
@@ -335,9 +437,10 @@ __device__ __forceinline__ void newton_update_cell(const TablesT<DP>& T, const C
     pv[(size_t)c * 3] = x[0]; pv[(size_t)c * 3 + 1] = x[1]; pv[(size_t)c * 3 + 2] = x[2];
     if (sw) atomicAdd(nswitched, 1);
     Iq<Ad> q;
-    update_iq<Ad, DP>(T, pr, C.satnum ? C.satnum[c] : 0, RsMax, C.poro[c], x, mng, q);
-    store_iq(iq + (size_t)c * IQS, q);
+    update_iq<Ad, DP, EXT>(T, C, c, x, mng, q);
+    store_iq<EXT>(iq + (size_t)c * Lay<EXT>::IQS, q);
 }
+template <bool EXT>
 __global__ __launch_bounds__(256) void k_newton_update(int Nb, Tables T, CellStatic C, const double* __restrict__ dx, double relax,
                                                        double* __restrict__ pv, unsigned char* __restrict__ meaning,
                                                        unsigned char* __restrict__ wasSwitched, double* __restrict__ iq,
@@ -346,8 +449,8 @@ __global__ __launch_bounds__(256) void k_newton_update(int Nb, Tables T, CellSta
     const bool inLds = tables_to_lds(T, s_tab);
     const int c = blockIdx.x * blockDim.x + threadIdx.x;
     if (c >= Nb) return;
-    if (inLds) newton_update_cell(lds_tables(T, s_tab), C, c, dx, relax, pv, meaning, wasSwitched, iq, nswitched);
-    else newton_update_cell(T, C, c, dx, relax, pv, meaning, wasSwitched, iq, nswitched);
+    if (inLds) newton_update_cell<LdsTab, EXT>(lds_tables(T, s_tab), C, c, dx, relax, pv, meaning, wasSwitched, iq, nswitched);
+    else newton_update_cell<GlobalTab, EXT>(T, C, c, dx, relax, pv, meaning, wasSwitched, iq, nswitched);
 }
 
 static Tables tables_of(const opmhip_ctx* c);
@@ -367,7 +470,8 @@ __global__ __launch_bounds__(256) void k_fluid_probe(Tables T, int pr, int sr, i
         const double X = W[2] * (pi - W[0]);
         o[0] = (1.0 + X * (1.0 + X / 2.0)) / W[1];
     }
-    o[1] = tab1<double, GlobalTab>(B + D.gas_p, B + D.gas_invB, D.gas_n, pi);
+    const bool wetg = D.wg_n > 0;   // PVTG: the saturated curve
+    o[1] = wetg ? tab1<double, GlobalTab>(B + D.wg_xs, B + D.wgs_invB, D.wg_n, pi) : tab1<double, GlobalTab>(B + D.gas_p, B + D.gas_invB, D.gas_n, pi);
     const double RsSat = rs_sat_value(T, pr, pi);
     o[3] = RsSat;
     if (rsi >= RsSat) {
@@ -380,7 +484,7 @@ __global__ __launch_bounds__(256) void k_fluid_probe(Tables T, int pr, int sr, i
     const double Swco = B[Sd.swco];
     o[4] = pwlin<double, GlobalTab>(B + Sd.sw_x, B + Sd.pcow, Sd.nw, sw[i]);
     o[5] = pwlin<double, GlobalTab>(B + Sd.so_x, B + Sd.pcgo, Sd.ng, 1.0 - Swco - sg[i]);
-    o[7] = o[1] / tab1<double, GlobalTab>(B + D.gas_p, B + D.gas_invBMu, D.gas_n, pi);
+    o[7] = o[1] / (wetg ? tab1<double, GlobalTab>(B + D.wg_xs, B + D.wgs_invBMu, D.wg_n, pi) : tab1<double, GlobalTab>(B + D.gas_p, B + D.gas_invBMu, D.gas_n, pi));
 }
 int launch_fluid_probe(opmhip_ctx* c, int pr, int sr, int n, const double* d_in, double* d_out) {
     hipLaunchKernelGGL(k_fluid_probe, dim3((n + 255) / 256), dim3(256), 0, c->stream, tables_of(c), pr, sr, n, d_in, d_in + n, d_in + 2 * (size_t)n,
@@ -398,14 +502,15 @@ struct PtrQ {
     __device__ __forceinline__ Ad ad(int f) const { return load_ad(q + f * 4); }
     __device__ __forceinline__ double v(int f) const { return q[f * 4]; }
 };
-constexpr int RQ_F0 = F_P, RQ_NF = F_RS - F_P + 1;  // fields F_P .. F_RS: p, 1/B, mobility, density (3 phases each), Rs
-struct RegQ {
-    double r[RQ_NF * 4];
-    __device__ __forceinline__ Ad ad(int f) const { return Ad{r[(f - RQ_F0) * 4], r[(f - RQ_F0) * 4 + 1], r[(f - RQ_F0) * 4 + 2], r[(f - RQ_F0) * 4 + 3]}; }
-    __device__ __forceinline__ double v(int f) const { return r[(f - RQ_F0) * 4]; }
+template <bool EXT>
+struct RegQ {   // fields F_P .. F_RS (.. tmult): p, 1/B, mobility, density (3 phases each), Rs [, Rv, transmissibility multiplier]
+    static constexpr int F0 = Lay<EXT>::RQ_F0;
+    double r[Lay<EXT>::RQ_NF * 4];
+    __device__ __forceinline__ Ad ad(int f) const { return Ad{r[(f - F0) * 4], r[(f - F0) * 4 + 1], r[(f - F0) * 4 + 2], r[(f - F0) * 4 + 3]}; }
+    __device__ __forceinline__ double v(int f) const { return r[(f - F0) * 4]; }
 };
-template <class IN, class EX>
-__device__ __forceinline__ void face_flux(const IN& in, const EX& ex, double trans, double faceArea,
+template <bool EXT, class IN, class EX>
+__device__ __forceinline__ void face_flux(const IN& in, const EX& ex, bool wet, double trans, double faceArea,
                                           double thpres, double zIn, double zEx, double Vin, double Vex, bool inLower, Ad flux[3]) {
     flux[0] = flux[1] = flux[2] = ad_const(0.0);
     const double distZ = zIn - zEx;
@@ -430,18 +535,21 @@ __device__ __forceinline__ void face_flux(const IN& in, const EX& ex, double tra
         if (fabs(dp.v) > thpres) {
             if (dp.v < 0.0) dp = dp + thpres; else dp = dp - thpres;
         } else continue;
-        Ad volumeFlux, surf;
+        Ad volumeFlux, surf;   // transMult = rockCompTransMultiplier of the upstream cell (eclfluxmodule.hh:340-355)
         if (upIn) {
-            volumeFlux = dp * mobIn * ad_const(1.0) * (-trans / faceArea);
+            volumeFlux = dp * mobIn * (EXT ? in.ad(Lay<EXT>::F_TMULT) : ad_const(1.0)) * (-trans / faceArea);
             surf = in.ad(F_B + ph) * volumeFlux;
         } else {
-            volumeFlux = dp * (mobEx * 1.0 * (-trans / faceArea));
+            volumeFlux = dp * (mobEx * (EXT ? ex.v(Lay<EXT>::F_TMULT) : 1.0) * (-trans / faceArea));
             surf = ex.v(F_B + ph) * volumeFlux;
         }
         flux[comp[ph]] = flux[comp[ph]] + surf;
         if (ph == OIL) {
             if (upIn) flux[EQ_GAS] = flux[EQ_GAS] + in.ad(F_RS) * surf;
             else flux[EQ_GAS] = flux[EQ_GAS] + ex.v(F_RS) * surf;
+        } else if (EXT && ph == GAS && wet) {   // vaporised oil carried by the gas phase
+            if (upIn) flux[EQ_OIL] = flux[EQ_OIL] + in.ad(Lay<EXT>::F_RV) * surf;
+            else flux[EQ_OIL] = flux[EQ_OIL] + ex.v(Lay<EXT>::F_RV) * surf;
         }
     }
 #pragma unroll
@@ -469,7 +577,8 @@ struct EntryStatic {
 // The kernel was latency-bound (PMC: waves waiting 74 % of their life, ~18 dependent load rounds per lane through the
 // branches of the flux), so every global load is issued up front in ONE round: the tile's own IQ records as a coalesced
 // copy into LDS, the neighbour's flux fields into registers, the statics; the arithmetic then runs out of LDS/registers.
-__global__ __launch_bounds__(ASM_THREADS) ASM_OCC void k_assemble(int ntiles, const int* __restrict__ asm_order, const int* __restrict__ asm_row0, const int* __restrict__ rowptr,
+template <bool EXT>
+__global__ __launch_bounds__(ASM_THREADS) ASM_OCC void k_assemble(int ntiles, int wet, const int* __restrict__ asm_order, const int* __restrict__ asm_row0, const int* __restrict__ rowptr,
                                                           const int* __restrict__ col, const int* __restrict__ natOrder,
                                                           EntryStatic ES, CellStatic C, const double* __restrict__ iq,
                                                           double* __restrict__ storageOld, const double* __restrict__ source,
@@ -477,6 +586,7 @@ __global__ __launch_bounds__(ASM_THREADS) ASM_OCC void k_assemble(int ntiles, co
                                                           double dt, int iteration, double* __restrict__ A, double* __restrict__ resid) {
     __shared__ __attribute__((aligned(16))) double sblk[(ASM_THREADS + 2) * BB];  // the tile's blocks, then streamed out
     __shared__ double sflux[ASM_THREADS * 12];                                     // face flux seen from the row's cell
+    constexpr int IQS = Lay<EXT>::IQS, RQ_F0 = Lay<EXT>::RQ_F0, RQ_NF = Lay<EXT>::RQ_NF, F_PORO = Lay<EXT>::F_PORO;
     __shared__ __attribute__((aligned(16))) double sI[ASM_MAX_ROWS * IQS];         // IQ records of the tile's rows
     __shared__ short srow[ASM_THREADS];
     // Workgroups are dealt round-robin over the 8 XCDs (b and b + 8 share one): every XCD gets one contiguous eighth of
@@ -500,7 +610,7 @@ __global__ __launch_bounds__(ASM_THREADS) ASM_OCC void k_assemble(int ntiles, co
     __syncthreads();
     int I = -1, J = -1, k = -1, lrow = 0;
     bool isDiag = false;
-    RegQ qJ;
+    RegQ<EXT> qJ;
     double trans = 0.0, area = 1.0, thp = 0.0, zI = 0.0, zJ = 0.0, VI = 0.0, VJ = 0.0;
     bool lowI = false;
     if (tid < nent) {
@@ -523,9 +633,9 @@ __global__ __launch_bounds__(ASM_THREADS) ASM_OCC void k_assemble(int ntiles, co
     if (tid < nent) {
         if (!isDiag) {
             Ad f[3];
-            face_flux(qI, qJ, trans, area, thp, zI, zJ, VI, VJ, lowI, f);  // focus I: contribution to R_I
+            face_flux<EXT>(qI, qJ, wet != 0, trans, area, thp, zI, zJ, VI, VJ, lowI, f);  // focus I: contribution to R_I
             for (int e = 0; e < 3; ++e) store_ad(&sflux[tid * 12 + e * 4], f[e]);
-            face_flux(qJ, qI, trans, area, thp, zJ, zI, VJ, VI, !lowI, f);  // focus J: residual[I] -= flux  ->  block (I,J)
+            face_flux<EXT>(qJ, qI, wet != 0, trans, area, thp, zJ, zI, VJ, VI, !lowI, f);  // focus J: residual[I] -= flux  ->  block (I,J)
             double* b = &sblk[(k - k0e) * BB];
             for (int e = 0; e < 3; ++e) {
                 const Ad m = ad_const(0.0) - f[e];
@@ -541,6 +651,7 @@ __global__ __launch_bounds__(ASM_THREADS) ASM_OCC void k_assemble(int ntiles, co
                 const Ad surfaceVolume = qI.ad(F_S + ph) * qI.ad(F_B + ph) * poro;
                 st[comp[ph]] = st[comp[ph]] + surfaceVolume;
                 if (ph == OIL) st[EQ_GAS] = st[EQ_GAS] + Rs * surfaceVolume;
+                if (EXT && ph == GAS && wet) st[EQ_OIL] = st[EQ_OIL] + qI.ad(Lay<EXT>::F_RV) * surfaceVolume;   // vaporised oil
             }
         }
     }
@@ -613,7 +724,7 @@ __global__ __launch_bounds__(ASM_THREADS) ASM_OCC void k_assemble(int ntiles, co
 
 // ============================== convergence ===================================================================
 // pass 1 partials per block: R_sum[3], maxCoeff[3], sum(1/b)[3], pvSum ; pass 2: cnvErrorPv
-__global__ __launch_bounds__(256) void k_conv_pass1(int Nb, CellStatic C, const double* __restrict__ iq, const double* __restrict__ resid,
+__global__ __launch_bounds__(256) void k_conv_pass1(int Nb, int IQS, CellStatic C, const double* __restrict__ iq, const double* __restrict__ resid,
                                                     double* __restrict__ part) {
     __shared__ double sh[10][4];
     const int c = blockIdx.x * blockDim.x + threadIdx.x;
@@ -735,7 +846,7 @@ __global__ void k_cellvec_to_natural_u8(int Nb, const int* __restrict__ toOrder,
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i < Nb) nat[i] = internal[toOrder[i]];
 }
-__global__ void k_iq_to_natural(int Nb, const int* __restrict__ toOrder, const double* __restrict__ internal, double* __restrict__ nat) {
+__global__ void k_iq_to_natural(int Nb, int IQS, const int* __restrict__ toOrder, const double* __restrict__ internal, double* __restrict__ nat) {
     const size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (e >= (size_t)Nb * IQS) return;
     const int i = (int)(e / IQS), q = (int)(e % IQS);
@@ -750,15 +861,22 @@ __global__ void k_unpermute_blocks(int nnzb, const int* __restrict__ nnzMap, con
 
 // ============================== launchers ====================================================================
 static inline int cdiv(size_t a, size_t b) { return (int)((a + b - 1) / b); }
-static Tables tables_of(const opmhip_ctx* c) { return Tables{c->asmb.d_tab_dbl, c->asmb.d_tab_idx, c->asmb.rock_pref, c->asmb.rock_cr, c->asmb.tab_ndbl, c->asmb.tab_nidx}; }
-static CellStatic cells_of(const opmhip_ctx* c) {
-    return CellStatic{c->asmb.d_poro, c->asmb.d_volume, c->asmb.d_depth, c->asmb.d_rsmax, c->asmb.d_pvtnum, c->asmb.d_satnum};
+static Tables tables_of(const opmhip_ctx* c) {
+    return Tables{c->asmb.d_tab_dbl, c->asmb.d_tab_idx, c->asmb.rock_pref, c->asmb.rock_cr, c->asmb.tab_ndbl, c->asmb.tab_nidx, c->asmb.rock_desc, c->asmb.num_rock};
 }
+static CellStatic cells_of(const opmhip_ctx* c) {
+    return CellStatic{c->asmb.d_poro, c->asmb.d_volume, c->asmb.d_depth, c->asmb.d_rsmax, c->asmb.d_pvtnum, c->asmb.d_satnum,
+                      c->asmb.d_rvmax, c->asmb.d_overburden, c->asmb.d_rocknum};
+}
+// the context's record layout: extended when the fluid has PVTG or ROCKTAB tables
+#define OPMHIP_LAYOUT(c, call_base, call_ext) do { if ((c)->asmb.ext) { call_ext; } else { call_base; } } while (0)
 
 void launch_iq_update(opmhip_ctx* c) {
     const int Nb = c->pat.Nloc;  // ghost cells too: their intensive quantities feed the faces towards them
     const int ps = prof_begin(c, PROF_IQ_UPDATE);
-    hipLaunchKernelGGL(k_iq_update, dim3(cdiv(Nb, 256)), dim3(256), 0, c->stream, 0, Nb, tables_of(c), cells_of(c), c->asmb.d_pv, c->asmb.d_meaning, c->asmb.d_iq);
+    OPMHIP_LAYOUT(c,
+        hipLaunchKernelGGL(k_iq_update<false>, dim3(cdiv(Nb, 256)), dim3(256), 0, c->stream, 0, Nb, tables_of(c), cells_of(c), c->asmb.d_pv, c->asmb.d_meaning, c->asmb.d_iq),
+        hipLaunchKernelGGL(k_iq_update<true>, dim3(cdiv(Nb, 256)), dim3(256), 0, c->stream, 0, Nb, tables_of(c), cells_of(c), c->asmb.d_pv, c->asmb.d_meaning, c->asmb.d_iq));
     prof_end(c, ps);
 }
 // after a Newton update in a decomposed run: ghost primary variables come from their owners, then their IQs are redone
@@ -768,30 +886,38 @@ int launch_ghost_refresh(opmhip_ctx* c) {
     if ((rc = comm_halo_f64(c, c->asmb.d_pv, 3))) return rc;
     if ((rc = comm_halo_u8(c, c->asmb.d_meaning))) return rc;
     const int Nb = c->pat.Nb, Nloc = c->pat.Nloc;
-    hipLaunchKernelGGL(k_iq_update, dim3(cdiv(Nloc - Nb, 256)), dim3(256), 0, c->stream, Nb, Nloc, tables_of(c), cells_of(c), c->asmb.d_pv, c->asmb.d_meaning, c->asmb.d_iq);
+    OPMHIP_LAYOUT(c,
+        hipLaunchKernelGGL(k_iq_update<false>, dim3(cdiv(Nloc - Nb, 256)), dim3(256), 0, c->stream, Nb, Nloc, tables_of(c), cells_of(c), c->asmb.d_pv, c->asmb.d_meaning, c->asmb.d_iq),
+        hipLaunchKernelGGL(k_iq_update<true>, dim3(cdiv(Nloc - Nb, 256)), dim3(256), 0, c->stream, Nb, Nloc, tables_of(c), cells_of(c), c->asmb.d_pv, c->asmb.d_meaning, c->asmb.d_iq));
     return OPMHIP_SUCCESS;
 }
 void launch_newton_update(opmhip_ctx* c, const double* d_dx, double relax) {
     const int Nb = c->pat.Nb;
     (void)hipMemsetAsync(c->asmb.d_nswitched, 0, sizeof(int), c->stream);
     const int ps = prof_begin(c, PROF_IQ_UPDATE);
-    hipLaunchKernelGGL(k_newton_update, dim3(cdiv(Nb, 256)), dim3(256), 0, c->stream, Nb, tables_of(c), cells_of(c), d_dx, relax, c->asmb.d_pv,
-                       c->asmb.d_meaning, c->asmb.d_wasSwitched, c->asmb.d_iq, c->asmb.d_nswitched);
+    OPMHIP_LAYOUT(c,
+        hipLaunchKernelGGL(k_newton_update<false>, dim3(cdiv(Nb, 256)), dim3(256), 0, c->stream, Nb, tables_of(c), cells_of(c), d_dx, relax, c->asmb.d_pv,
+                           c->asmb.d_meaning, c->asmb.d_wasSwitched, c->asmb.d_iq, c->asmb.d_nswitched),
+        hipLaunchKernelGGL(k_newton_update<true>, dim3(cdiv(Nb, 256)), dim3(256), 0, c->stream, Nb, tables_of(c), cells_of(c), d_dx, relax, c->asmb.d_pv,
+                           c->asmb.d_meaning, c->asmb.d_wasSwitched, c->asmb.d_iq, c->asmb.d_nswitched));
     prof_end(c, ps);
 }
 void launch_assemble(opmhip_ctx* c, double dt, int iteration) {
     const Pattern& P = c->pat;
     EntryStatic ES{c->asmb.d_trans, c->asmb.d_area, c->asmb.d_thpres, c->asmb.d_lowFirst};
     const int ps = prof_begin(c, PROF_ASSEMBLE);
-    hipLaunchKernelGGL(k_assemble, dim3(8 * ((c->asmb.ntiles + 7) / 8)), dim3(ASM_THREADS), 0, c->stream, c->asmb.ntiles, c->asmb.d_asm_order, c->asmb.d_asm_row0, P.d_rowptr, P.d_col, c->asmb.d_natOrder, ES,
-                       cells_of(c), c->asmb.d_iq, c->asmb.d_storageOld, c->asmb.d_source, c->asmb.d_dsource,
-                       c->asmb.drift_enabled ? c->asmb.d_drift : (const double*)nullptr, c->asmb.max_compensation, dt, iteration, c->d_A, c->d_b);
+    const double* drift = c->asmb.drift_enabled ? c->asmb.d_drift : (const double*)nullptr;
+    OPMHIP_LAYOUT(c,
+        hipLaunchKernelGGL(k_assemble<false>, dim3(8 * ((c->asmb.ntiles + 7) / 8)), dim3(ASM_THREADS), 0, c->stream, c->asmb.ntiles, 0, c->asmb.d_asm_order, c->asmb.d_asm_row0, P.d_rowptr, P.d_col, c->asmb.d_natOrder, ES,
+                           cells_of(c), c->asmb.d_iq, c->asmb.d_storageOld, c->asmb.d_source, c->asmb.d_dsource, drift, c->asmb.max_compensation, dt, iteration, c->d_A, c->d_b),
+        hipLaunchKernelGGL(k_assemble<true>, dim3(8 * ((c->asmb.ntiles + 7) / 8)), dim3(ASM_THREADS), 0, c->stream, c->asmb.ntiles, c->asmb.wet_gas ? 1 : 0, c->asmb.d_asm_order, c->asmb.d_asm_row0, P.d_rowptr, P.d_col, c->asmb.d_natOrder, ES,
+                           cells_of(c), c->asmb.d_iq, c->asmb.d_storageOld, c->asmb.d_source, c->asmb.d_dsource, drift, c->asmb.max_compensation, dt, iteration, c->d_A, c->d_b));
     prof_end(c, ps);
 }
 int launch_convergence(opmhip_ctx* c, double dt, double tol_cnv) {
     const int Nb = c->pat.Nb, nb = cdiv(Nb, 256);
     const int ps = prof_begin(c, PROF_CONVERGENCE);
-    hipLaunchKernelGGL(k_conv_pass1, dim3(nb), dim3(256), 0, c->stream, Nb, cells_of(c), c->asmb.d_iq, c->d_b, c->asmb.d_conv_part);
+    hipLaunchKernelGGL(k_conv_pass1, dim3(nb), dim3(256), 0, c->stream, Nb, iq_doubles_per_cell(c), cells_of(c), c->asmb.d_iq, c->d_b, c->asmb.d_conv_part);
     const bool dd = c->comm.nranks > 1;
     hipLaunchKernelGGL(k_conv_final1, dim3(1), dim3(256), 0, c->stream, nb, dd ? 0 : Nb, c->asmb.d_conv_part, c->asmb.d_conv_out);
     if (dd) {
@@ -817,13 +943,13 @@ void launch_u8_to_natural(opmhip_ctx* c, const unsigned char* internal, unsigned
     hipLaunchKernelGGL(k_cellvec_to_natural_u8, dim3(cdiv(c->pat.Nloc, 256)), dim3(256), 0, c->stream, c->pat.Nloc, c->pat.d_toOrder, internal, nat);
 }
 void launch_iq_to_natural(opmhip_ctx* c, double* d_nat) {
-    const size_t n = (size_t)c->pat.Nloc * IQS;
-    hipLaunchKernelGGL(k_iq_to_natural, dim3(cdiv(n, 256)), dim3(256), 0, c->stream, c->pat.Nloc, c->pat.d_toOrder, c->asmb.d_iq, d_nat);
+    const size_t n = (size_t)c->pat.Nloc * iq_doubles_per_cell(c);
+    hipLaunchKernelGGL(k_iq_to_natural, dim3(cdiv(n, 256)), dim3(256), 0, c->stream, c->pat.Nloc, iq_doubles_per_cell(c), c->pat.d_toOrder, c->asmb.d_iq, d_nat);
 }
 void launch_unpermute_blocks(opmhip_ctx* c, const double* internal, double* nat) {
     const size_t n = (size_t)c->pat.nnzb * BB;
     hipLaunchKernelGGL(k_unpermute_blocks, dim3(cdiv(n, 256)), dim3(256), 0, c->stream, c->pat.nnzb, c->pat.d_nnzMap, internal, nat);
 }
-int iq_doubles_per_cell() { return IQS; }
+int iq_doubles_per_cell(const opmhip_ctx* c) { return c->asmb.ext ? Lay<true>::IQS : Lay<false>::IQS; }
 
 }  // namespace opmhip

@@ -75,6 +75,10 @@ int opmhip_set_fluid(opmhip_ctx* c, const opmhip_fluid* fluid) {
         A.rock_cr = T.rock_cr;
         A.num_pvt = T.num_pvt;
         A.num_sat = T.num_sat;
+        A.num_rock = T.num_rock;
+        A.rock_desc = T.rock_desc;
+        A.wet_gas = T.wet_gas;
+        A.ext = T.wet_gas || T.num_rock > 0;   // extended intensive-quantity record
         A.fluid_set = true;
         return OPMHIP_SUCCESS;
     });
@@ -125,7 +129,7 @@ int opmhip_set_static(opmhip_ctx* c, const double* trans, const double* area, co
         if (!A.d_pv) {
             const size_t Nb = P.Nloc;  // per-cell state includes the ghost cells
             if ((rc = dev_alloc(c, &A.d_pv, Nb * 3))) return rc;
-            if ((rc = dev_alloc(c, &A.d_iq, Nb * (size_t)iq_doubles_per_cell()))) return rc;
+            if ((rc = dev_alloc(c, &A.d_iq, Nb * (size_t)iq_doubles_per_cell(c)))) return rc;
             if ((rc = dev_alloc(c, &A.d_storageOld, Nb * 3))) return rc;
             if ((rc = dev_alloc(c, &A.d_drift, Nb * 3))) return rc;
             OPMHIP_HIP(c, hipMemset(A.d_drift, 0, Nb * 3 * sizeof(double)));
@@ -139,7 +143,7 @@ int opmhip_set_static(opmhip_ctx* c, const double* trans, const double* area, co
             if ((rc = dev_alloc(c, &A.d_nswitched, (size_t)1))) return rc;
             if ((rc = dev_alloc(c, &A.d_conv_part, ((Nb + 255) / 256) * 10))) return rc;
             if ((rc = dev_alloc(c, &A.d_conv_out, (size_t)16))) return rc;
-            if ((rc = dev_alloc(c, &A.d_stage_cell, Nb * (size_t)iq_doubles_per_cell()))) return rc;
+            if ((rc = dev_alloc(c, &A.d_stage_cell, Nb * (size_t)iq_doubles_per_cell(c)))) return rc;
             OPMHIP_HIP(c, hipMemset(A.d_source, 0, Nb * 3 * sizeof(double)));
             OPMHIP_HIP(c, hipMemset(A.d_dsource, 0, Nb * 9 * sizeof(double)));
             OPMHIP_HIP(c, hipMemset(A.d_storageOld, 0, Nb * 3 * sizeof(double)));
@@ -208,6 +212,30 @@ int opmhip_set_static(opmhip_ctx* c, const double* trans, const double* area, co
     });
 }
 
+int opmhip_set_problem_extras(opmhip_ctx* c, const double* rvmax, const int* rocknum, const double* overburden) {
+    if (!c) return OPMHIP_INVALID_ARGUMENT;
+    return guarded(c, [&]() -> int {
+        AsmDev& A = c->asmb;
+        if (!A.static_set) return fail(c, OPMHIP_NOT_READY, "set_problem_extras before set_static");
+        if ((rvmax || rocknum || overburden) && !A.ext)
+            return fail(c, OPMHIP_INVALID_ARGUMENT, "set_problem_extras: the fluid has neither PVTG nor ROCKTAB tables - nothing these arrays could act on");
+        if (rocknum)
+            for (int i = 0; i < c->pat.Nloc; ++i)
+                if (rocknum[i] < 0 || rocknum[i] >= A.num_rock) return fail(c, OPMHIP_INVALID_ARGUMENT, "set_problem_extras: rocknum[%d] out of range", i);
+        OPMHIP_HIP(c, hipSetDevice(c->device));
+        int rc;
+        if (rvmax) { if ((rc = upload_cells(c, &A.d_rvmax, rvmax))) return rc; } else A.d_rvmax = nullptr;
+        if (rocknum) { if ((rc = upload_cells(c, &A.d_rocknum, rocknum))) return rc; } else A.d_rocknum = nullptr;
+        if (overburden) { if ((rc = upload_cells(c, &A.d_overburden, overburden))) return rc; } else A.d_overburden = nullptr;
+        if (A.state_set) {   // the cached intensive quantities depend on these arrays
+            launch_iq_update(c);
+            OPMHIP_HIP(c, hipGetLastError());
+            OPMHIP_HIP(c, hipStreamSynchronize(c->stream));
+        }
+        return OPMHIP_SUCCESS;
+    });
+}
+
 int opmhip_fluid_probe(opmhip_ctx* c, int pvt_region, int sat_region, int n, const double* p, const double* rs, const double* sw,
                        const double* sg, double* out) {
     if (!c) return OPMHIP_INVALID_ARGUMENT;
@@ -239,7 +267,8 @@ int opmhip_set_state(opmhip_ctx* c, const double* pv, const unsigned char* meani
         if (!c->asmb.static_set) return fail(c, OPMHIP_NOT_READY, "set_state before set_static");
         if (!pv || !meaning) return fail(c, OPMHIP_INVALID_ARGUMENT, "set_state: null array");
         for (int i = 0; i < c->pat.Nloc; ++i)
-            if (meaning[i] > OPMHIP_SW_PO_RS) return fail(c, OPMHIP_INVALID_ARGUMENT, "set_state: meaning[%d] = %d is not supported (dry gas: Sw_po_Sg or Sw_po_Rs)", i, (int)meaning[i]);
+            if (meaning[i] > (c->asmb.wet_gas ? OPMHIP_SW_PG_RV : OPMHIP_SW_PO_RS))
+                return fail(c, OPMHIP_INVALID_ARGUMENT, "set_state: meaning[%d] = %d is not valid (Sw_po_Sg, Sw_po_Rs; Sw_pg_Rv only with a PVTG fluid)", i, (int)meaning[i]);
         OPMHIP_HIP(c, hipSetDevice(c->device));
         AsmDev& A = c->asmb;
         OPMHIP_HIP(c, hipMemcpyAsync(c->d_stageV, pv, (size_t)c->pat.Nloc * 3 * sizeof(double), hipMemcpyHostToDevice, c->stream));
@@ -373,6 +402,11 @@ int opmhip_assemble(opmhip_ctx* c, double dt, int iteration, double* jac, double
     });
 }
 
+int opmhip_iq_fields(opmhip_ctx* c) {
+    if (!c) return OPMHIP_INVALID_ARGUMENT;
+    return iq_doubles_per_cell(c) / 4;
+}
+
 int opmhip_get_iq(opmhip_ctx* c, double* out) {
     if (!c) return OPMHIP_INVALID_ARGUMENT;
     return guarded(c, [&]() -> int {
@@ -380,7 +414,7 @@ int opmhip_get_iq(opmhip_ctx* c, double* out) {
         if (!out) return fail(c, OPMHIP_INVALID_ARGUMENT, "get_iq: out == NULL");
         OPMHIP_HIP(c, hipSetDevice(c->device));
         launch_iq_to_natural(c, c->asmb.d_stage_cell);
-        OPMHIP_HIP(c, hipMemcpyAsync(out, c->asmb.d_stage_cell, (size_t)c->pat.Nloc * iq_doubles_per_cell() * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+        OPMHIP_HIP(c, hipMemcpyAsync(out, c->asmb.d_stage_cell, (size_t)c->pat.Nloc * iq_doubles_per_cell(c) * sizeof(double), hipMemcpyDeviceToHost, c->stream));
         OPMHIP_HIP(c, hipStreamSynchronize(c->stream));
         return OPMHIP_SUCCESS;
     });

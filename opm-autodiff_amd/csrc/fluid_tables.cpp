@@ -24,17 +24,21 @@ int push(std::vector<double>& blob, const std::vector<double>& v) {
 std::string build_fluid_tables(const opmhip_fluid* f, FluidTables& T) {
     if (!f) return "fluid == NULL";
     if (f->num_pvt < 1 || f->num_sat < 1) return "need at least one PVT and one saturation region";
-    if (!f->pvtw || !f->density || !f->pvdg_ptr || !f->pvdg || !f->pvto_node_ptr || !f->pvto_rs || !f->pvto_row_ptr ||
+    const bool wet = f->pvtg_node_ptr && f->pvtg_pg && f->pvtg_row_ptr && f->pvtg && f->pvtg_node_ptr[f->num_pvt] > 0;
+    if (!f->pvtw || !f->density || (!wet && (!f->pvdg_ptr || !f->pvdg)) || !f->pvto_node_ptr || !f->pvto_rs || !f->pvto_row_ptr ||
         !f->pvto || !f->swof_ptr || !f->swof || !f->sgof_ptr || !f->sgof)
         return "fluid: null table pointer";
+    if (f->num_rock < 0 || (f->num_rock > 0 && (!f->rocktab_ptr || !f->rocktab))) return "fluid: bad ROCKTAB input";
     T = FluidTables();
+    T.wet_gas = wet;
+    T.num_rock = f->num_rock;
     T.num_pvt = f->num_pvt;
     T.num_sat = f->num_sat;
     T.rock_pref = f->rock_pref;
     T.rock_cr = f->rock_cr;
     std::vector<PvtRegionDesc> pd(f->num_pvt);
     std::vector<SatRegionDesc> sd(f->num_sat);
-    std::vector<std::vector<int>> yoffs(f->num_pvt);
+    std::vector<std::vector<int>> yoffs(f->num_pvt), gyoffs(f->num_pvt);
     std::vector<double>& B = T.dbl;
 
     for (int r = 0; r < f->num_pvt; ++r) {
@@ -42,8 +46,70 @@ std::string build_fluid_tables(const opmhip_fluid* f, FluidTables& T) {
         // ---- ConstantCompressibilityWaterPvt / reference densities ----
         D.water = push(B, std::vector<double>(f->pvtw + 5 * r, f->pvtw + 5 * r + 5));
         D.density = push(B, std::vector<double>(f->density + 3 * r, f->density + 3 * r + 3));
+        D.gas_n = D.gas_p = D.gas_invB = D.gas_invBMu = 0;
+        D.wg_n = D.wg_xs = D.wg_yoff = D.wg_ys = D.wg_invB = D.wg_invBMu = D.wgs_rv = D.wgs_invB = D.wgs_invBMu = 0;
+        // ---- WetGasPvt (PVTG): see oracle/fluid.hpp WetGasPvt for the construction being restated ----
+        if (wet) {
+            struct GNode { double pg; std::vector<double> rv, bg, mu; };
+            std::vector<GNode> gn;
+            for (int n = f->pvtg_node_ptr[r]; n < f->pvtg_node_ptr[r + 1]; ++n) {
+                GNode g;
+                g.pg = f->pvtg_pg[n];
+                for (int q = f->pvtg_row_ptr[n]; q < f->pvtg_row_ptr[n + 1]; ++q) {
+                    g.rv.push_back(f->pvtg[3 * q]); g.bg.push_back(f->pvtg[3 * q + 1]); g.mu.push_back(f->pvtg[3 * q + 2]);
+                }
+                if (g.rv.empty()) return "PVTG node without rows";
+                if (!gn.empty() && g.pg <= gn.back().pg) return "PVTG pressure nodes must ascend";
+                for (size_t q = 1; q < g.rv.size(); ++q)
+                    if (g.rv[q] >= g.rv[q - 1]) return "PVTG rows of a node must start with the saturated one, Rv descending";
+                gn.push_back(g);
+            }
+            const int gnn = (int)gn.size();
+            if (gnn < 2) return "PVTG needs at least two pressure nodes";
+            std::vector<double> xs, ysFlat, ibFlat, ibmFlat, sRv, sIb, sIbm;
+            std::vector<int>& yo = gyoffs[r];
+            for (int i = 0; i < gnn; ++i) {
+                std::vector<double> Rv = gn[i].rv, Bg = gn[i].bg, Mu = gn[i].mu;
+                if (Rv.size() < 2) {
+                    int m = i + 1;
+                    while (m < gnn && gn[m].rv.size() < 2) ++m;
+                    if (m >= gnn) return "PVTG: the last pressure node must carry undersaturated data";
+                    const GNode& M = gn[m];
+                    for (size_t q = 1; q < M.rv.size(); ++q) {
+                        const double diffRv = M.rv[q] - M.rv[q - 1];
+                        const double newRv = Rv.back() + diffRv;
+                        const double B1 = M.bg[q], B2 = M.bg[q - 1];
+                        const double x = (B1 - B2) / ((B1 + B2) / 2.0);
+                        const double newBg = Bg.back() * (1.0 + x / 2.0) / (1.0 - x / 2.0);
+                        const double m1 = M.mu[q], m2 = M.mu[q - 1];
+                        const double xMu = (m1 - m2) / ((m1 + m2) / 2.0);
+                        const double newMu = Mu.back() * (1.0 + xMu / 2.0) / (1.0 - xMu / 2.0);
+                        Rv.push_back(newRv); Bg.push_back(newBg); Mu.push_back(newMu);
+                    }
+                }
+                xs.push_back(gn[i].pg);
+                yo.push_back((int)ysFlat.size());
+                for (int q = (int)Rv.size() - 1; q >= 0; --q) {   // ascending in Rv
+                    ysFlat.push_back(Rv[q]);
+                    ibFlat.push_back(1.0 / Bg[q]);
+                    ibmFlat.push_back((1.0 / Bg[q]) / Mu[q]);
+                }
+                sRv.push_back(gn[i].rv[0]);
+                sIb.push_back(ibFlat.back());     // the saturated sample is the last (largest Rv)
+                sIbm.push_back(ibmFlat.back());
+            }
+            yo.push_back((int)ysFlat.size());
+            D.wg_n = gnn;
+            D.wg_xs = push(B, xs);
+            D.wg_ys = push(B, ysFlat);
+            D.wg_invB = push(B, ibFlat);
+            D.wg_invBMu = push(B, ibmFlat);
+            D.wgs_rv = push(B, sRv);
+            D.wgs_invB = push(B, sIb);
+            D.wgs_invBMu = push(B, sIbm);
+        }
         // ---- DryGasPvt: p -> 1/Bg and 1/(Bg mu_g) on the deck's pressure samples ----
-        {
+        if (!wet) {
             const int b = f->pvdg_ptr[r], e = f->pvdg_ptr[r + 1];
             if (e - b < 2) return "PVDG needs at least two rows";
             std::vector<double> p, ib, ibm;
@@ -157,6 +223,18 @@ std::string build_fluid_tables(const opmhip_fluid* f, FluidTables& T) {
         D.so_x = push(B, so); D.krog = push(B, krog); D.krg = push(B, krg); D.pcgo = push(B, pcgo);
         D.swco = push(B, std::vector<double>{swco});
     }
+    std::vector<RockTabDesc> rd(f->num_rock);
+    for (int t = 0; t < f->num_rock; ++t) {
+        const int b = f->rocktab_ptr[t], e = f->rocktab_ptr[t + 1];
+        if (e - b < 2) return "ROCKTAB needs at least two rows";
+        std::vector<double> p, pm, tm;
+        for (int q = b; q < e; ++q) {
+            if (!p.empty() && f->rocktab[3 * q] <= p.back()) return "ROCKTAB pressures must ascend";
+            p.push_back(f->rocktab[3 * q]); pm.push_back(f->rocktab[3 * q + 1]); tm.push_back(f->rocktab[3 * q + 2]);
+        }
+        rd[t].n = (int)p.size();
+        rd[t].p = push(B, p); rd[t].poroMult = push(B, pm); rd[t].transMult = push(B, tm);
+    }
     // int blob: header, descriptors, then the per-region y-offset arrays
     std::vector<int>& I = T.idx;
     I.clear();
@@ -168,7 +246,10 @@ std::string build_fluid_tables(const opmhip_fluid* f, FluidTables& T) {
     for (int r = 0; r < f->num_pvt; ++r) {
         pd[r].o_yoff = cursor;
         cursor += (int)yoffs[r].size();
+        pd[r].wg_yoff = cursor;
+        cursor += (int)gyoffs[r].size();
     }
+    T.rock_desc = cursor;
     for (int r = 0; r < f->num_pvt; ++r) {
         const int* q = reinterpret_cast<const int*>(&pd[r]);
         I.insert(I.end(), q, q + pdInts);
@@ -177,7 +258,14 @@ std::string build_fluid_tables(const opmhip_fluid* f, FluidTables& T) {
         const int* q = reinterpret_cast<const int*>(&sd[s]);
         I.insert(I.end(), q, q + sdInts);
     }
-    for (int r = 0; r < f->num_pvt; ++r) I.insert(I.end(), yoffs[r].begin(), yoffs[r].end());
+    for (int r = 0; r < f->num_pvt; ++r) {
+        I.insert(I.end(), yoffs[r].begin(), yoffs[r].end());
+        I.insert(I.end(), gyoffs[r].begin(), gyoffs[r].end());
+    }
+    for (int t = 0; t < f->num_rock; ++t) {
+        const int* q = reinterpret_cast<const int*>(&rd[t]);
+        I.insert(I.end(), q, q + (int)(sizeof(RockTabDesc) / sizeof(int)));
+    }
     return "";
 }
 

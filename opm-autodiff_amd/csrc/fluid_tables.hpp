@@ -19,6 +19,13 @@ struct PvtRegionDesc {
     int o_nx, o_xs, o_yoff /*int blob, nx+1 entries*/, o_ys, o_invB, o_invBMu;
     int water;    // 5 doubles: p_ref, Bw_ref, c_w, mu_ref, c_v
     int density;  // 3 doubles: oil, water, gas
+    // WetGasPvt (PVTG; wg_n == 0: dry gas): 2-D table over (p_g, Rv): wg_n pressure nodes at wg_xs, per node i its ascending
+    // Rv samples wg_ys[yoff[i] .. yoff[i+1]) with 1/Bg and 1/(Bg mu_g); saturated 1-D tables on the same pressure nodes
+    int wg_n, wg_xs, wg_yoff /*int blob, wg_n+1 entries*/, wg_ys, wg_invB, wg_invBMu;
+    int wgs_rv, wgs_invB, wgs_invBMu;
+};
+struct RockTabDesc {  // ROCKTAB region: n rows, offsets of p, pore-volume multiplier, transmissibility multiplier
+    int n, p, poroMult, transMult;
 };
 struct SatRegionDesc {
     int nw, sw_x, krw, krow, pcow;  // piecewise linear in Sw, x ascending
@@ -28,9 +35,11 @@ struct SatRegionDesc {
 
 struct FluidTables {
     std::vector<double> dbl;
-    std::vector<int> idx;  // [0] num_pvt, [1] num_sat, then PvtRegionDesc[num_pvt], SatRegionDesc[num_sat], then y offsets
+    std::vector<int> idx;  // [0] num_pvt, [1] num_sat, then PvtRegionDesc[num_pvt], SatRegionDesc[num_sat], then y offsets, then RockTabDesc[num_rock]
     double rock_pref = 1e5, rock_cr = 0.0;
-    int num_pvt = 0, num_sat = 0;
+    int num_pvt = 0, num_sat = 0, num_rock = 0;
+    int rock_desc = 0;     // offset of the RockTabDesc array inside idx
+    bool wet_gas = false;  // PVTG present: vaporised oil (Rv), third primary-variable meaning
 };
 
 // returns "" on success, else an error text

@@ -92,7 +92,11 @@ struct AsmDev {
     int* d_tab_idx = nullptr;
     int tab_ndbl = 0, tab_nidx = 0;   // lengths of the two table blobs
     double rock_pref = 1e5, rock_cr = 0.0;
-    int num_pvt = 0, num_sat = 0;
+    int num_pvt = 0, num_sat = 0, num_rock = 0, rock_desc = 0;
+    bool wet_gas = false;   // PVTG: vaporised oil, third primary-variable meaning
+    bool ext = false;       // extended intensive-quantity record (wet gas and / or ROCKTAB): 19 fields instead of 17
+    double *d_rvmax = nullptr, *d_overburden = nullptr;   // per cell: DRVDT cap, overburden pressure (optional)
+    int* d_rocknum = nullptr;                             // per cell rock-table index (optional)
     double *d_trans = nullptr, *d_area = nullptr, *d_thpres = nullptr;                      // per entry
     unsigned char* d_lowFirst = nullptr;  // per entry (I,J): global id of I < global id of J (upwind tie-break)
     double *d_poro = nullptr, *d_volume = nullptr, *d_depth = nullptr, *d_rsmax = nullptr;  // per cell
@@ -343,7 +347,7 @@ int launch_convergence(opmhip_ctx* c, double dt, double tol_cnv);
 void launch_u8_to_internal(opmhip_ctx* c, const unsigned char* nat, unsigned char* internal);
 void launch_u8_to_natural(opmhip_ctx* c, const unsigned char* internal, unsigned char* nat);
 void launch_iq_to_natural(opmhip_ctx* c, double* d_nat);
-int iq_doubles_per_cell();
+int iq_doubles_per_cell(const opmhip_ctx* c);
 int asm_max_rows();
 int launch_fluid_probe(opmhip_ctx* c, int pr, int sr, int n, const double* d_in, double* d_out);
 int asm_threads();

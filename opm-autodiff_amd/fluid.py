@@ -18,22 +18,37 @@ class FluidDesc(C.Structure):
                 ("pvdg_ptr", C.c_void_p), ("pvdg", C.c_void_p),
                 ("pvto_node_ptr", C.c_void_p), ("pvto_rs", C.c_void_p), ("pvto_row_ptr", C.c_void_p), ("pvto", C.c_void_p),
                 ("swof_ptr", C.c_void_p), ("swof", C.c_void_p), ("sgof_ptr", C.c_void_p), ("sgof", C.c_void_p),
-                ("rock_pref", C.c_double), ("rock_cr", C.c_double)]
+                ("rock_pref", C.c_double), ("rock_cr", C.c_double),
+                ("pvtg_node_ptr", C.c_void_p), ("pvtg_pg", C.c_void_p), ("pvtg_row_ptr", C.c_void_p), ("pvtg", C.c_void_p),
+                ("num_rock", C.c_int), ("rocktab_ptr", C.c_void_p), ("rocktab", C.c_void_p)]
 
 
 class Fluid:
-    """pvt: list of dict(pvtw[5], density[3] (oil, water, gas), pvdg rows (p,Bg,mu), pvto nodes dict(rs,p[],bo[],mu[]));
-    sat: list of dict(swof rows (Sw,krw,krow,pcow), sgof rows (Sg,krg,krog,pcog)); all SI."""
+    """pvt: list of dict(pvtw[5], density[3] (oil, water, gas), pvdg rows (p,Bg,mu), pvto nodes dict(rs,p[],bo[],mu[]),
+    optional pvtg nodes dict(pg, rv[], bg[], mu[]) - wet gas, rows as in the deck: saturated first, Rv descending - in which
+    case pvdg may be omitted); sat: list of dict(swof rows (Sw,krw,krow,pcow), sgof rows (Sg,krg,krog,pcog));
+    rocktab: optional list (one per rock region) of rows (p, pore-volume multiplier, transmissibility multiplier); all SI."""
 
-    def __init__(self, pvt, sat, rock_pref=1e5, rock_cr=0.0):
+    def __init__(self, pvt, sat, rock_pref=1e5, rock_cr=0.0, rocktab=None):
         self.pvt, self.sat, self.rock_pref, self.rock_cr = pvt, sat, float(rock_pref), float(rock_cr)
+        self.rocktab = rocktab or []
+        self.wet_gas = bool(pvt and pvt[0].get("pvtg"))
         f64 = lambda a: np.ascontiguousarray(np.asarray(a, dtype=np.float64).reshape(-1))
         i32 = lambda a: np.ascontiguousarray(np.asarray(a, dtype=np.int32).reshape(-1))
         a = {}
         a["pvtw"] = f64([r["pvtw"] for r in pvt])
         a["density"] = f64([r["density"] for r in pvt])
-        a["pvdg_ptr"] = i32(np.concatenate([[0], np.cumsum([len(r["pvdg"]) for r in pvt])]))
-        a["pvdg"] = f64(np.concatenate([np.asarray(r["pvdg"], float).reshape(-1, 3) for r in pvt]))
+        a["pvdg_ptr"] = i32(np.concatenate([[0], np.cumsum([len(r.get("pvdg", [])) for r in pvt])]))
+        a["pvdg"] = f64(np.concatenate([np.asarray(r.get("pvdg", []), float).reshape(-1, 3) for r in pvt] + [np.zeros((0, 3))]))
+        if self.wet_gas:
+            gn = [n for r in pvt for n in r["pvtg"]]
+            a["pvtg_node_ptr"] = i32(np.concatenate([[0], np.cumsum([len(r["pvtg"]) for r in pvt])]))
+            a["pvtg_pg"] = f64([n["pg"] for n in gn])
+            a["pvtg_row_ptr"] = i32(np.concatenate([[0], np.cumsum([len(n["rv"]) for n in gn])]))
+            a["pvtg"] = f64(np.concatenate([np.stack([n["rv"], n["bg"], n["mu"]], axis=1) for n in gn]))
+        if self.rocktab:
+            a["rocktab_ptr"] = i32(np.concatenate([[0], np.cumsum([len(t) for t in self.rocktab])]))
+            a["rocktab"] = f64(np.concatenate([np.asarray(t, float).reshape(-1, 3) for t in self.rocktab]))
         a["pvto_node_ptr"] = i32(np.concatenate([[0], np.cumsum([len(r["pvto"]) for r in pvt])]))
         nodes = [n for r in pvt for n in r["pvto"]]
         a["pvto_rs"] = f64([n["rs"] for n in nodes])
@@ -51,6 +66,7 @@ class Fluid:
         for k, v in self.arrays.items():
             setattr(d, k, v.ctypes.data_as(C.c_void_p))
         d.rock_pref, d.rock_cr = self.rock_pref, self.rock_cr
+        d.num_rock = len(self.rocktab)
         return d
 
 

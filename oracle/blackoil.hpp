@@ -30,7 +30,7 @@ namespace orc {
 enum { WATER = 0, OIL = 1, GAS = 2 };
 enum { EQ_OIL = 0, EQ_WATER = 1, EQ_GAS = 2 };
 enum { PV_SW = 0, PV_P = 1, PV_X = 2 };
-enum Meaning : uint8_t { Sw_po_Sg = 0, Sw_po_Rs = 1 };  // PrimaryVariables::PrimaryVarsMeaning (Sw_pg_Rv unused: dry gas)
+enum Meaning : uint8_t { Sw_po_Sg = 0, Sw_po_Rs = 1, Sw_pg_Rv = 2 };  // PrimaryVariables::PrimaryVarsMeaning (Sw_pg_Rv: wet gas, oil phase absent)
 
 constexpr double GRAVITY = 9.80665;
 
@@ -48,6 +48,9 @@ struct Problem {
     std::vector<double> poro, volume, depth;  // per cell
     std::vector<int> pvtnum, satnum;          // per cell, 0-based
     std::vector<double> rsMax;                // per cell; empty = no DRSDT limit (eclproblem.hh:1711-1732)
+    std::vector<double> rvMax;                // per cell; empty = no DRVDT limit (maxOilVaporizationFactor, eclproblem.hh:1734-1754)
+    std::vector<int> rockNum;                 // per cell rock-table index (rockTableIdx_, eclproblem.hh:1943-1945); empty = table 0
+    std::vector<double> overburden;           // per cell overburden pressure (eclproblem.hh:1954-1955); empty = none
     Fluid fluid;
     void finish() {
         const int Nb = pat.Nb;
@@ -68,6 +71,7 @@ struct Problem {
 template <class E>
 struct IQT {
     E S[3], p[3], invB[3], mob[3], rho[3], Rs, Rv, poro;
+    E tmult;   // rockCompTransMultiplier (eclproblem.hh:1975-2007); 1 without ROCKTAB
     double refPoro;
 };
 template <class E> inline E mkvar(double x, int idx);
@@ -79,25 +83,43 @@ void update_iq(const Problem& P, int cell, const double* pv, uint8_t meaning, IQ
     const Fluid& F = P.fluid;
     const int pr = P.pvtnum.empty() ? 0 : P.pvtnum[cell], sr = P.satnum.empty() ? 0 : P.satnum[cell];
     const double RsMax = P.rsMax.empty() ? std::numeric_limits<double>::max() / 2.0 : P.rsMax[cell];
+    const double RvMax = P.rvMax.empty() ? std::numeric_limits<double>::max() / 2.0 : P.rvMax[cell];
+    const bool wet = F.hasWetGas;   // FluidSystem::enableVaporizedOil()
     const E Sw = mkvar<E>(pv[PV_SW], PV_SW);
     E Sg = E(0.0);
     if (meaning == Sw_po_Sg) Sg = mkvar<E>(pv[PV_X], PV_X);
+    else if (meaning == Sw_pg_Rv) Sg = 1.0 - Sw;   // the oil phase is absent
     const E So = 1.0 - Sw - Sg;
     q.S[WATER] = Sw; q.S[GAS] = Sg; q.S[OIL] = So;
     E pC[3];
     F.sat[sr].capillaryPressures(pC, Sw, Sg);
-    const E po = mkvar<E>(pv[PV_P], PV_P);
-    for (int ph = 0; ph < 3; ++ph) q.p[ph] = po + (pC[ph] - pC[OIL]);
+    if (meaning == Sw_pg_Rv) {   // the pressure primary variable is the GAS pressure
+        const E pg = mkvar<E>(pv[PV_P], PV_P);
+        for (int ph = 0; ph < 3; ++ph) q.p[ph] = pg + (pC[ph] - pC[GAS]);
+    } else {
+        const E po = mkvar<E>(pv[PV_P], PV_P);
+        for (int ph = 0; ph < 3; ++ph) q.p[ph] = po + (pC[ph] - pC[OIL]);
+    }
     F.sat[sr].relativePermeabilities(q.mob, Sw, Sg);
-    // SoMax = max(So, problem.maxOilSaturation) ; the latter is 0 without VAPPARS (eclproblem.hh:1682-1688)
+    // SoMax = max(So, problem.maxOilSaturation) ; the latter is 0 without VAPPARS (eclproblem.hh:1682-1688), and without
+    // VAPPARS the saturated Rs / Rv do not depend on it
     if (meaning == Sw_po_Sg) {
         const E RsSat = F.oil[pr].rsSat(q.p[OIL]);
         q.Rs = min(E(RsMax), RsSat);
-    } else {
+        if (wet) { const E RvSat = F.wetGas[pr].rvSat(q.p[GAS]); q.Rv = min(E(RvMax), RvSat); }
+        else q.Rv = E(0.0);
+    } else if (meaning == Sw_po_Rs) {
         const E Rs = mkvar<E>(pv[PV_X], PV_X);
         q.Rs = min(E(RsMax), Rs);
+        // the gas phase is not present, but its "composition" is needed for the gravity correction term
+        if (wet) { const E RvSat = F.wetGas[pr].rvSat(q.p[GAS]); q.Rv = min(E(RvMax), RvSat); }
+        else q.Rv = E(0.0);
+    } else {
+        const E Rv = mkvar<E>(pv[PV_X], PV_X);
+        q.Rv = min(E(RvMax), Rv);
+        const E RsSat = F.oil[pr].rsSat(q.p[OIL]);   // the oil phase is not present: same remark
+        q.Rs = min(E(RsMax), RsSat);
     }
-    q.Rv = E(0.0);
     // inverse formation volume factors and viscosities (BlackOilFluidSystem::inverseFormationVolumeFactor / viscosity)
     {
         const bool saturated = value(q.S[GAS]) > 0.0 && value(q.Rs) >= (1.0 - 1e-10) * F.oil[pr].rsSat(value(q.p[OIL]));
@@ -108,13 +130,20 @@ void update_iq(const Problem& P, int cell, const double* pv, uint8_t meaning, IQ
         if (saturated) { q.invB[OIL] = F.oil[pr].invBSat(q.p[OIL]); mu = F.oil[pr].viscositySat(q.p[OIL]); }
         else { q.invB[OIL] = F.oil[pr].invB(q.p[OIL], q.Rs); mu = F.oil[pr].viscosity(q.p[OIL], q.Rs); }
         q.mob[OIL] = q.mob[OIL] / mu;
-        q.invB[GAS] = F.gas[pr].invB(q.p[GAS]);
-        mu = F.gas[pr].viscosity(q.p[GAS]);
+        if (wet) {
+            const bool gasSaturated = value(q.S[OIL]) > 0.0 && value(q.Rv) >= (1.0 - 1e-10) * F.wetGas[pr].rvSat(value(q.p[GAS]));
+            if (gasSaturated) { q.invB[GAS] = F.wetGas[pr].invBSat(q.p[GAS]); mu = F.wetGas[pr].viscositySat(q.p[GAS]); }
+            else { q.invB[GAS] = F.wetGas[pr].invB(q.p[GAS], q.Rv); mu = F.wetGas[pr].viscosity(q.p[GAS], q.Rv); }
+        } else {
+            q.invB[GAS] = F.gas[pr].invB(q.p[GAS]);
+            mu = F.gas[pr].viscosity(q.p[GAS]);
+        }
         q.mob[GAS] = q.mob[GAS] / mu;
     }
     const double* rr = &F.rhoRef[3 * pr];  // oil, water, gas
     q.rho[WATER] = q.invB[WATER] * rr[1];
-    q.rho[GAS] = q.invB[GAS] * rr[2];  // dry gas: no vaporised oil term
+    q.rho[GAS] = q.invB[GAS] * rr[2];
+    if (wet) q.rho[GAS] = q.rho[GAS] + q.invB[GAS] * q.Rv * rr[0];   // vaporised oil
     q.rho[OIL] = q.invB[OIL] * rr[0];
     q.rho[OIL] = q.rho[OIL] + q.invB[OIL] * q.Rs * rr[2];
     // porosity with rock compressibility (BlackOilIntensiveQuantities; hooks ebos/eclproblem.hh:1454-1486)
@@ -124,17 +153,28 @@ void update_iq(const Problem& P, int cell, const double* pv, uint8_t meaning, IQ
         const E x = F.rock_cr * (q.p[OIL] - F.rock_pref);
         q.poro = q.poro * (1.0 + x + 0.5 * x * x);
     }
+    // rock compaction tables (ROCKTAB): rockCompPoroMultiplier / rockCompTransMultiplier, ebos/eclproblem.hh:1936-2007
+    // (reversible form: no minOilPressure_; overburden pressure subtracted when given)
+    q.tmult = E(1.0);
+    if (!F.rockTab.empty()) {
+        const RockTab& RT = F.rockTab[P.rockNum.empty() ? 0 : P.rockNum[cell]];
+        E effectiveOilPressure = q.p[OIL];
+        if (!P.overburden.empty()) effectiveOilPressure = effectiveOilPressure - P.overburden[cell];
+        q.poro = q.poro * RT.poroMult.eval(effectiveOilPressure);
+        q.tmult = RT.transMult.eval(effectiveOilPressure);
+    }
 }
 
 // ---- BlackOilLocalResidual::computeStorage (App. B.4): surface volumes per pore volume ---------------------------
 template <class E>
-void compute_storage(const IQT<E>& q, E st[3]) {
+void compute_storage(const IQT<E>& q, E st[3], bool wet = false) {
     st[0] = st[1] = st[2] = E(0.0);
     static const int comp[3] = {EQ_WATER, EQ_OIL, EQ_GAS};
     for (int ph = 0; ph < 3; ++ph) {
         const E surfaceVolume = q.S[ph] * q.invB[ph] * q.poro;
         st[comp[ph]] = st[comp[ph]] + surfaceVolume;
         if (ph == OIL) st[EQ_GAS] = st[EQ_GAS] + q.Rs * surfaceVolume;
+        if (ph == GAS && wet) st[EQ_OIL] = st[EQ_OIL] + q.Rv * surfaceVolume;   // vaporised oil
     }
 }
 
@@ -142,7 +182,7 @@ void compute_storage(const IQT<E>& q, E st[3]) {
 // in: focus (interior) cell with derivatives, exterior cell values only.  out: flux[eq] leaving the interior cell
 // through this face, already multiplied by the face area (FvBaseLocalResidual::evalFluxes).
 inline void compute_face_flux(const IQT<Ev>& in, const IQT<double>& ex, double trans, double faceArea, double thpres,
-                              double zIn, double zEx, double Vin, double Vex, int I, int J, Ev flux[3]) {
+                              double zIn, double zEx, double Vin, double Vex, int I, int J, Ev flux[3], bool wet = false) {
     flux[0] = flux[1] = flux[2] = Ev(0.0);
     const double distZ = zIn - zEx;
     static const int comp[3] = {EQ_WATER, EQ_OIL, EQ_GAS};
@@ -161,15 +201,17 @@ inline void compute_face_flux(const IQT<Ev>& in, const IQT<double>& ex, double t
         if (std::fabs(dp.v) > thpres) {                           // :327-337
             if (dp.v < 0.0) dp = dp + thpres; else dp = dp - thpres;
         } else continue;
-        Ev volumeFlux;                                            // :347-355 (transMult == 1 without ROCKCOMP)
-        if (upIsInterior) volumeFlux = dp * in.mob[ph] * Ev(1.0) * (-trans / faceArea);
-        else volumeFlux = dp * (ex.mob[ph] * 1.0 * (-trans / faceArea));
+        Ev volumeFlux;                                            // :340-355, transMult = rockCompTransMultiplier of the upstream cell
+        if (upIsInterior) volumeFlux = dp * in.mob[ph] * in.tmult * (-trans / faceArea);
+        else volumeFlux = dp * (ex.mob[ph] * ex.tmult * (-trans / faceArea));
         // computeFlux / evalPhaseFluxes_: surface volume flux, plus dissolved gas carried by the oil phase
         Ev surf;
         if (upIsInterior) surf = in.invB[ph] * volumeFlux; else surf = ex.invB[ph] * volumeFlux;
         flux[comp[ph]] += surf;
         if (ph == OIL) {
             if (upIsInterior) flux[EQ_GAS] += in.Rs * surf; else flux[EQ_GAS] += ex.Rs * surf;
+        } else if (ph == GAS && wet) {   // vaporised oil carried by the gas phase
+            if (upIsInterior) flux[EQ_OIL] += in.Rv * surf; else flux[EQ_OIL] += ex.Rv * surf;
         }
     }
     for (int e = 0; e < 3; ++e) flux[e] *= faceArea;  // alpha = extrusionFactor (1) * face.area()
@@ -244,7 +286,7 @@ struct Model {
                 if (Jc == I) continue;
                 Ev fl[3];
                 compute_face_flux(in, iqV[Jc], P.trans[k], P.area[k], P.thpres.empty() ? 0.0 : P.thpres[k], P.depth[I],
-                                  P.depth[Jc], P.volume[I], P.volume[Jc], I, Jc, fl);
+                                  P.depth[Jc], P.volume[I], P.volume[Jc], I, Jc, fl, P.fluid.hasWetGas);
                 for (int e = 0; e < 3; ++e) R[e] += fl[e];
                 // residual[j] -= flux : block (J, I) = d(-flux)/d x_I
                 double* blk = &J.val[(size_t)P.transIdx[k] * BB];
@@ -253,7 +295,7 @@ struct Model {
             }
             // storage term, implicit Euler
             Ev st[3];
-            compute_storage(in, st);
+            compute_storage(in, st, P.fluid.hasWetGas);
             double* so = &storageOld[(size_t)I * 3];
             if (iteration == 0)
                 for (int e = 0; e < 3; ++e) so[e] = st[e].v;
@@ -374,31 +416,66 @@ struct Model {
         update_all_iq();
         return nswitched;
     }
+    // BlackOilPrimaryVariables::adaptPrimaryVariables (App. B.7), three meanings.  UNVERIFIED vs upstream.
     bool adapt(int c, double eps) {
         const Fluid& F = P.fluid;
-        const int pr = P.pvtnum.empty() ? 0 : P.pvtnum[c];
+        const int pr = P.pvtnum.empty() ? 0 : P.pvtnum[c], sr = P.satnum.empty() ? 0 : P.satnum[c];
         const double RsMax = P.rsMax.empty() ? std::numeric_limits<double>::max() / 2.0 : P.rsMax[c];
+        const double RvMax = P.rvMax.empty() ? std::numeric_limits<double>::max() / 2.0 : P.rvMax[c];
         double* x = &pv[(size_t)c * 3];
         const double Sw = x[PV_SW];
         const double thresholdWaterFilledCell = 1.0;  // static const 1.0 - eps of the first call (eps = 0)
+        // special case: cells with (almost) only water
+        if (Sw >= thresholdWaterFilledCell) {
+            x[PV_SW] = 1.0;
+            x[PV_X] = 0.0;
+            const bool changed = meaning[c] != Sw_po_Sg;
+            if (changed) meaning[c] = Sw_po_Sg;
+            return changed;
+        }
         if (meaning[c] == Sw_po_Sg) {
             const double Sg = x[PV_X];
-            if (Sw >= thresholdWaterFilledCell) { x[PV_SW] = 1.0; x[PV_X] = 0.0; return false; }
             const double So = 1.0 - Sw - Sg;
-            if (Sg < -eps && So > 0.0) {
+            if (Sg < -eps && So > 0.0) {   // the gas phase disappears: { Sw, po, Rs }
                 const double po = x[PV_P];
                 const double RsSat = F.oil[pr].rsSat(po);
                 meaning[c] = Sw_po_Rs;
                 x[PV_X] = std::min(RsMax, RsSat);
                 return true;
             }
+            if (So < -eps && Sg > 0.0 && F.hasWetGas) {   // the oil phase disappears: { Sw, pg, Rv }
+                const double po = x[PV_P];
+                double pC[3];
+                F.sat[sr].capillaryPressures(pC, Sw, Sg);   // computeCapillaryPressures_(pC, So = 0, Sg, Sw)
+                const double pg = po + (pC[GAS] - pC[OIL]);
+                const double RvSat = F.wetGas[pr].rvSat(pg);
+                meaning[c] = Sw_pg_Rv;
+                x[PV_P] = pg;
+                x[PV_X] = std::min(RvMax, RvSat);
+                return true;
+            }
             return false;
         }
-        if (Sw >= thresholdWaterFilledCell) { meaning[c] = Sw_po_Sg; x[PV_SW] = 1.0; x[PV_X] = 0.0; return true; }
-        const double po = x[PV_P];
-        const double RsSat = F.oil[pr].rsSat(po);
-        const double Rs = x[PV_X];
-        if (Rs > std::min(RsMax, RsSat * (1.0 + eps))) { meaning[c] = Sw_po_Sg; x[PV_X] = 0.0; return true; }
+        if (meaning[c] == Sw_po_Rs) {
+            const double po = x[PV_P];
+            const double RsSat = F.oil[pr].rsSat(po);
+            const double Rs = x[PV_X];
+            if (Rs > std::min(RsMax, RsSat * (1.0 + eps))) { meaning[c] = Sw_po_Sg; x[PV_X] = 0.0; return true; }
+            return false;
+        }
+        // Sw_pg_Rv: the oil phase appears as soon as the gas holds more oil than saturated gas does
+        const double pg = x[PV_P];
+        const double RvSat = F.wetGas[pr].rvSat(pg);
+        const double Rv = x[PV_X];
+        if (Rv > std::min(RvMax, RvSat * (1.0 + eps))) {
+            meaning[c] = Sw_po_Sg;
+            double pC[3];
+            F.sat[sr].capillaryPressures(pC, Sw, 1.0 - Sw);
+            const double po = pg + (pC[OIL] - pC[GAS]);
+            x[PV_P] = po;
+            x[PV_X] = 1.0 - Sw;   // hydrocarbon gas saturation
+            return true;
+        }
         return false;
     }
 };

@@ -84,6 +84,8 @@ struct Tab2D {
 
 // ---- deck-level input (SI units), the same flat layout the product's C-ABI takes ---------------------------
 struct PvtoNode { double rs; std::vector<double> p, bo, mu; };
+// PVTG: per gas-pressure node the rows (Rv, Bg, mu_g) as the deck lists them: saturated gas first (largest Rv), Rv descending
+struct PvtgNode { double pg; std::vector<double> rv, bg, mu; };
 struct FluidInput {
     // one PVT region and one saturation region per index; region ids are per cell
     struct Pvt {
@@ -91,6 +93,7 @@ struct FluidInput {
         double density[3];  // oil, water, gas at surface (DENSITY)
         std::vector<double> pvdg;  // rows (p, Bg, mu_g)
         std::vector<PvtoNode> pvto;
+        std::vector<PvtgNode> pvtg;  // wet gas; empty = dry gas from PVDG
     };
     struct Sat {
         std::vector<double> swof;  // rows (Sw, krw, krow, pcow)
@@ -99,6 +102,7 @@ struct FluidInput {
     std::vector<Pvt> pvt;
     std::vector<Sat> sat;
     double rock_pref = 1e5, rock_cr = 0.0;  // ROCK (ebos/eclproblem.hh:1454-1486)
+    std::vector<std::vector<double>> rocktab;  // per rock region: rows (p, pore-volume multiplier, transmissibility multiplier)
 };
 
 // ---- ConstantCompressibilityWaterPvt -------------------------------------------------------------------------
@@ -128,6 +132,73 @@ struct GasPvt {
     }
     template <class E> E invB(const E& p) const { return invB_.eval(p); }
     template <class E> E viscosity(const E& p) const { return invB_.eval(p) / invBMu_.eval(p); }
+};
+
+// ---- WetGasPvt (PVTG) -------------------------------------------------------------------------------------------
+// opm-material WetGasPvt (not in the reference tree; UNVERIFIED vs upstream except where tests/test_equil.cc
+// DeckWithLiveGas pins 1/B_g and RvSat through the equilibration): 2-D tables over (p_g, Rv), x = pressure nodes, per node
+// its own ascending Rv samples; nodes with only the saturated row inherit the next complete node's undersaturated branch
+// step by step (extendPvtgTable_: same relative change of Bg and mu_g per Rv step); 1/(Bg mu_g) on the same samples;
+// the saturated 1-D tables take the LAST sample of every column (largest Rv).
+struct WetGasPvt {
+    Tab2D invB2_, invBMu2_;              // (p_g, Rv) -> 1/Bg, 1/(Bg mu_g)
+    Tab1D rvSat_, invBSat_, invBMuSat_;  // p_g -> RvSat, saturated 1/Bg, saturated 1/(Bg mu_g)
+    void init(const std::vector<PvtgNode>& nodes) {
+        const int nn = (int)nodes.size();
+        Tab2D mu2;
+        for (int i = 0; i < nn; ++i) {
+            std::vector<double> Rv = nodes[i].rv, Bg = nodes[i].bg, Mu = nodes[i].mu;
+            if (Rv.size() < 2) {   // master table: the next node with undersaturated rows
+                int m = i + 1;
+                while (m < nn && nodes[m].rv.size() < 2) ++m;
+                assert(m < nn && "PVTG: the last table must have undersaturated data");
+                const PvtgNode& M = nodes[m];
+                for (size_t r = 1; r < M.rv.size(); ++r) {
+                    const double diffRv = M.rv[r] - M.rv[r - 1];
+                    const double newRv = Rv.back() + diffRv;
+                    const double B1 = M.bg[r], B2 = M.bg[r - 1];
+                    const double x = (B1 - B2) / ((B1 + B2) / 2.0);
+                    const double newBg = Bg.back() * (1.0 + x / 2.0) / (1.0 - x / 2.0);
+                    const double m1 = M.mu[r], m2 = M.mu[r - 1];
+                    const double xMu = (m1 - m2) / ((m1 + m2) / 2.0);
+                    const double newMu = Mu.back() * (1.0 + xMu / 2.0) / (1.0 - xMu / 2.0);
+                    Rv.push_back(newRv); Bg.push_back(newBg); Mu.push_back(newMu);
+                }
+            }
+            // samples are kept ascending in Rv (UniformXTabulated2DFunction::appendSamplePoint sorts them in)
+            std::vector<double> y, ib, mu;
+            for (int q = (int)Rv.size() - 1; q >= 0; --q) { y.push_back(Rv[q]); ib.push_back(1.0 / Bg[q]); mu.push_back(Mu[q]); }
+            invB2_.xs.push_back(nodes[i].pg); invB2_.ys.push_back(y); invB2_.vs.push_back(ib);
+            mu2.xs.push_back(nodes[i].pg); mu2.ys.push_back(y); mu2.vs.push_back(mu);
+            rvSat_.x.push_back(nodes[i].pg); rvSat_.y.push_back(nodes[i].rv[0]);
+        }
+        invBMu2_.xs = invB2_.xs;
+        invBMu2_.ys = invB2_.ys;
+        invBMu2_.vs.resize(nn);
+        for (int i = 0; i < nn; ++i) {
+            const size_t n = invB2_.ys[i].size();
+            for (size_t j = 0; j < n; ++j) invBMu2_.vs[i].push_back(invB2_.vs[i][j] / mu2.vs[i][j]);
+            invBSat_.x.push_back(invB2_.xs[i]); invBSat_.y.push_back(invB2_.vs[i][n - 1]);
+            invBMuSat_.x.push_back(invB2_.xs[i]); invBMuSat_.y.push_back(invBMu2_.vs[i][n - 1]);
+        }
+    }
+    template <class E> E rvSat(const E& p) const { return rvSat_.eval(p); }
+    template <class E> E invBSat(const E& p) const { return invBSat_.eval(p); }
+    template <class E> E viscositySat(const E& p) const { return invBSat_.eval(p) / invBMuSat_.eval(p); }
+    template <class E> E invB(const E& p, const E& Rv) const { return invB2_.eval(p, Rv); }
+    template <class E> E viscosity(const E& p, const E& Rv) const { return invB2_.eval(p, Rv) / invBMu2_.eval(p, Rv); }
+};
+
+// ---- ROCKTAB: pressure-dependent pore-volume and transmissibility multipliers (ebos/eclproblem.hh:1936-2007:
+// rockCompPoroMult_ / rockCompTransMult_ evaluated with extrapolation) -------------------------------------------
+struct RockTab {
+    Tab1D poroMult, transMult;
+    void init(const std::vector<double>& rows) {
+        for (size_t i = 0; i + 2 < rows.size(); i += 3) {
+            poroMult.x.push_back(rows[i]); poroMult.y.push_back(rows[i + 1]);
+            transMult.x.push_back(rows[i]); transMult.y.push_back(rows[i + 2]);
+        }
+    }
 };
 
 // ---- LiveOilPvt (PVTO) ------------------------------------------------------------------------------------------
@@ -259,11 +330,18 @@ struct Fluid {
     std::vector<SatFunc> sat;
     std::vector<double> rhoRef;  // per PVT region: oil, water, gas
     double rock_pref = 1e5, rock_cr = 0.0;
+    std::vector<WetGasPvt> wetGas;   // per PVT region when the deck has PVTG (enableVaporizedOil)
+    bool hasWetGas = false;
+    std::vector<RockTab> rockTab;    // per rock region (ROCKTAB); empty = no rock compaction tables
     void init(const FluidInput& in) {
+        hasWetGas = !in.pvt.empty() && !in.pvt[0].pvtg.empty();
+        for (const auto& r : in.pvt)
+            if (hasWetGas) { WetGasPvt g; g.init(r.pvtg); wetGas.push_back(g); }
+        for (const auto& t : in.rocktab) { RockTab rt; rt.init(t); rockTab.push_back(rt); }
         for (const auto& r : in.pvt) {
             WaterPvt w{r.pvtw[0], r.pvtw[1], r.pvtw[2], r.pvtw[3], r.pvtw[4]};
             water.push_back(w);
-            GasPvt g; g.init(r.pvdg); gas.push_back(g);
+            GasPvt g; if (!r.pvdg.empty()) g.init(r.pvdg); gas.push_back(g);
             OilPvt o; o.init(r.pvto); oil.push_back(o);
             rhoRef.push_back(r.density[0]); rhoRef.push_back(r.density[1]); rhoRef.push_back(r.density[2]);
         }

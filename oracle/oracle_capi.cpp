@@ -265,6 +265,9 @@ struct orc_fluid_desc {
     const int* swof_ptr; const double* swof;
     const int* sgof_ptr; const double* sgof;
     double rock_pref, rock_cr;
+    // wet gas (PVTG) and rock compaction tables (ROCKTAB); pointers may be NULL / counts 0
+    const int* pvtg_node_ptr; const double* pvtg_pg; const int* pvtg_row_ptr; const double* pvtg;
+    int num_rock; const int* rocktab_ptr; const double* rocktab;
 };
 FluidInput to_input(const orc_fluid_desc* d) {
     FluidInput in;
@@ -272,7 +275,7 @@ FluidInput to_input(const orc_fluid_desc* d) {
         FluidInput::Pvt p;
         for (int i = 0; i < 5; ++i) p.pvtw[i] = d->pvtw[5 * r + i];
         for (int i = 0; i < 3; ++i) p.density[i] = d->density[3 * r + i];
-        p.pvdg.assign(d->pvdg + 3 * d->pvdg_ptr[r], d->pvdg + 3 * d->pvdg_ptr[r + 1]);
+        if (d->pvdg_ptr && d->pvdg) p.pvdg.assign(d->pvdg + 3 * d->pvdg_ptr[r], d->pvdg + 3 * d->pvdg_ptr[r + 1]);
         for (int n = d->pvto_node_ptr[r]; n < d->pvto_node_ptr[r + 1]; ++n) {
             PvtoNode node;
             node.rs = d->pvto_rs[n];
@@ -281,8 +284,19 @@ FluidInput to_input(const orc_fluid_desc* d) {
             }
             p.pvto.push_back(node);
         }
+        if (d->pvtg_node_ptr && d->pvtg_node_ptr[d->num_pvt] > 0)
+            for (int n = d->pvtg_node_ptr[r]; n < d->pvtg_node_ptr[r + 1]; ++n) {
+                PvtgNode node;
+                node.pg = d->pvtg_pg[n];
+                for (int q = d->pvtg_row_ptr[n]; q < d->pvtg_row_ptr[n + 1]; ++q) {
+                    node.rv.push_back(d->pvtg[3 * q]); node.bg.push_back(d->pvtg[3 * q + 1]); node.mu.push_back(d->pvtg[3 * q + 2]);
+                }
+                p.pvtg.push_back(node);
+            }
         in.pvt.push_back(p);
     }
+    for (int t = 0; t < d->num_rock; ++t)
+        in.rocktab.emplace_back(d->rocktab + 3 * d->rocktab_ptr[t], d->rocktab + 3 * d->rocktab_ptr[t + 1]);
     for (int s = 0; s < d->num_sat; ++s) {
         FluidInput::Sat t;
         t.swof.assign(d->swof + 4 * d->swof_ptr[s], d->swof + 4 * d->swof_ptr[s + 1]);
@@ -308,7 +322,7 @@ int orc_fluid_probe(const orc_fluid_desc* d, int pr, int sr, int n, const double
     for (int i = 0; i < n; ++i) {
         double* o = out + (size_t)i * 8;
         o[0] = F.water[pr].invB(p[i]);
-        o[1] = F.gas[pr].invB(p[i]);
+        o[1] = F.hasWetGas ? F.wetGas[pr].invBSat(p[i]) : F.gas[pr].invB(p[i]);
         o[3] = O.rsSat(p[i]);
         if (rs[i] >= o[3]) { o[2] = O.invBSat(p[i]); o[6] = O.viscositySat(p[i]); }
         else { o[2] = O.invB(p[i], rs[i]); o[6] = O.viscosity(p[i], rs[i]); }
@@ -316,7 +330,22 @@ int orc_fluid_probe(const orc_fluid_desc* d, int pr, int sr, int n, const double
         F.sat[sr].capillaryPressures(pC, sw[i], sg[i]);
         o[4] = -pC[0];
         o[5] = pC[2];
-        o[7] = F.gas[pr].viscosity(p[i]);
+        o[7] = F.hasWetGas ? F.wetGas[pr].viscositySat(p[i]) : F.gas[pr].viscosity(p[i]);
+    }
+    return 0;
+}
+
+// wet-gas PVT probe: per point RvSat(p); rv >= RvSat -> saturated 1/B_g, mu_g at p ; else 1/B_g(p, rv), mu_g(p, rv)
+int orc_gas_pvt_probe(const orc_fluid_desc* d, int region, int n, const double* rv, const double* p, double* mu,
+                      double* invB, double* rvSat) {
+    Fluid F;
+    F.init(to_input(d));
+    if (!F.hasWetGas) return -1;
+    const WetGasPvt& G = F.wetGas[region];
+    for (int i = 0; i < n; ++i) {
+        rvSat[i] = G.rvSat(p[i]);
+        if (rv[i] >= rvSat[i]) { mu[i] = G.viscositySat(p[i]); invB[i] = G.invBSat(p[i]); }
+        else { mu[i] = G.viscosity(p[i], rv[i]); invB[i] = G.invB(p[i], rv[i]); }
     }
     return 0;
 }
@@ -402,6 +431,31 @@ int orc_bo_get_iq(orc_model* h, double* out) {
             o[0] = f[k]->v; o[1] = f[k]->d[0]; o[2] = f[k]->d[1]; o[3] = f[k]->d[2];
         }
     }
+    return 0;
+}
+// extended layout (wet gas / ROCKTAB): 19 fields x 4 = the 16 of above up to Rs, then Rv, transmissibility multiplier, porosity
+int orc_bo_get_iq_ext(orc_model* h, double* out) {
+    Model& M = h->M;
+    const int Nb = M.P.pat.Nb;
+    for (int c = 0; c < Nb; ++c) {
+        const IQT<Ev>& q = M.iqF[c];
+        const Ev* f[19] = {&q.S[0], &q.S[1], &q.S[2], &q.p[0], &q.p[1], &q.p[2], &q.invB[0], &q.invB[1], &q.invB[2],
+                           &q.mob[0], &q.mob[1], &q.mob[2], &q.rho[0], &q.rho[1], &q.rho[2], &q.Rs, &q.Rv, &q.tmult, &q.poro};
+        for (int k = 0; k < 19; ++k) {
+            double* o = &out[((size_t)c * 19 + k) * 4];
+            o[0] = f[k]->v; o[1] = f[k]->d[0]; o[2] = f[k]->d[1]; o[3] = f[k]->d[2];
+        }
+    }
+    return 0;
+}
+// per-cell extras of the problem: DRVDT cap (maxOilVaporizationFactor), rock-table index, overburden pressure; any may be NULL
+int orc_bo_set_extras(orc_model* h, const double* rvMax, const int* rockNum, const double* overburden) {
+    Model& M = h->M;
+    const int Nb = M.P.pat.Nb;
+    if (rvMax) M.P.rvMax.assign(rvMax, rvMax + Nb); else M.P.rvMax.clear();
+    if (rockNum) M.P.rockNum.assign(rockNum, rockNum + Nb); else M.P.rockNum.clear();
+    if (overburden) M.P.overburden.assign(overburden, overburden + Nb); else M.P.overburden.clear();
+    M.update_all_iq();
     return 0;
 }
 int orc_bo_assemble(orc_model* h, double dt, int iteration, double* jac, double* residual) {

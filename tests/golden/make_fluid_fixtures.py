@@ -91,6 +91,24 @@ def parse_pvto(records, U):
     return regions
 
 
+def parse_pvtg(records, U):
+    """records of one PVTG keyword -> list of regions; region = list of dict(pg, rv[], bg[], mu[]) with the rows of a node
+    in deck order (saturated first, Rv descending)."""
+    regions, cur = [], []
+    for r in records:
+        if not r:
+            regions.append(cur)
+            cur = []
+            continue
+        pg, rest = r[0], r[1:]
+        rows = table(rest, 3)
+        cur.append(dict(pg=pg * U["pressure"], rv=[x[0] / U["rs"] for x in rows], bg=[x[1] * U["gas_fvf"] for x in rows],
+                        mu=[x[2] * U["viscosity"] for x in rows]))
+    if cur:
+        regions.append(cur)
+    return regions
+
+
 def spe1():
     k = tokenize(os.path.join(REF, "python/test_data/SPE1CASE1/SPE1CASE1.DATA"))
     U = FIELD
@@ -157,7 +175,10 @@ def norne():
                          "BOOST_CHECK_CLOSE tolerance 1e-5 percent (tests/test_norne_pvt.cpp:118-133)",
                check_close_percent=1e-5,
                density=[dict(oil=r[0], water=r[1], gas=r[2]) for r in k["DENSITY"][:2]],
-               pvto=regions, expected=exp)
+               pvto=regions, expected=exp,
+               # wet gas tables of the same file (used as realistic PVTG input of the wet-gas parity tests; the reference
+               # holds no expectations for them): Rv in Sm3/Sm3, Bg in rm3/Sm3
+               pvtg=parse_pvtg(k["PVTG"], U))
     path = os.path.join(ROOT, "tests", "golden", "norne_pvt.json")
     with open(path, "w") as f:
         json.dump(out, f, indent=1)

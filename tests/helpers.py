@@ -82,3 +82,51 @@ def oracle_solve_in_order(orc, Nb, rp, ci, val, b, to, fr, wells=None, **kw):
         W["Bcols"] = np.ascontiguousarray(to[wells["Bcols"]], np.int32)
     x, res = orc.solve(Nb, rr, rc, rv, rb, reorder="none", wells=W, **kw)
     return np.ascontiguousarray(x.reshape(Nb, 3)[to].reshape(-1)), res
+
+
+# ---- wet gas / rock compaction test cases ---------------------------------------------------------------------------
+def wetgas_fluid(pkg, rocktab=None, pvtg_region=1):
+    """The SPE1 fluid (PVTO, PVTW, SWOF, SGOF, ROCK) with Norne's PVTG table in place of PVDG (tests/golden/norne_pvt.json,
+    from the reference's tests/norne_pvt.data): oil may vaporise into the gas phase.  rocktab: optional list of ROCKTAB
+    regions, rows (p, pore-volume multiplier, transmissibility multiplier)."""
+    import json
+    import os
+    fl, d = pkg.fluid.spe1_fluid()
+    with open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "norne_pvt.json")) as f:
+        pvtg = json.load(f)["pvtg"][pvtg_region]
+    pvt = [dict(fl.pvt[0])]
+    pvt[0]["pvtg"] = pvtg
+    pvt[0].pop("pvdg", None)
+    return pkg.fluid.Fluid(pvt, fl.sat, rock_pref=fl.rock_pref, rock_cr=fl.rock_cr, rocktab=rocktab)
+
+
+def rv_sat(fluid, pg, region=0):
+    nodes = fluid.pvt[region]["pvtg"]
+    xp = np.array([n["pg"] for n in nodes])
+    fp = np.array([n["rv"][0] for n in nodes])
+    pg = np.asarray(pg, float)
+    s = np.clip(np.searchsorted(xp, pg, side="right") - 1, 0, len(xp) - 2)
+    return fp[s] + (fp[s + 1] - fp[s]) * (pg - xp[s]) / (xp[s + 1] - xp[s])
+
+
+def wetgas_case(pkg, nx, ny, nz, rocktab=None, seed=5, **kw):
+    """Cartesian case with all three primary-variable meanings: gas cap without oil (Sw, pg, Rv) on top, three-phase cells
+    (Sw, po, Sg) in the middle, undersaturated oil (Sw, po, Rs) below."""
+    fl = wetgas_fluid(pkg, rocktab)
+    case = pkg.decks.cartesian_case(nx, ny, nz, state="mixed", fluid=fl, **kw)
+    rng = np.random.default_rng(seed)
+    pv = case["pv"].reshape(-1, 3).copy()
+    m = case["meaning"].copy()
+    d = case["depth"]
+    top = d < np.quantile(d, 0.3)
+    m[top] = 2                                    # Sw_pg_Rv
+    pv[top, 2] = rv_sat(fl, pv[top, 1]) * rng.uniform(0.5, 0.95, top.sum())
+    case["pv"], case["meaning"] = np.ascontiguousarray(pv.reshape(-1)), m
+    if rocktab:
+        case["rocknum"] = (np.arange(case["Nb"]) % len(rocktab)).astype(np.int32)
+        case["overburden"] = 20e5 + 50.0 * (d - d.min())
+    return case
+
+
+ROCKTAB_2 = [[[100e5, 0.96, 0.90], [200e5, 0.985, 0.96], [300e5, 1.0, 1.0], [400e5, 1.012, 1.03]],
+             [[50e5, 0.90, 0.80], [250e5, 0.99, 0.97], [450e5, 1.03, 1.08]]]

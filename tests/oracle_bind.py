@@ -144,6 +144,8 @@ class OracleModel:
                                    C.POINTER(OrcResult)]
         L.orc_bo_solve_mt.argtypes = [_vp, _d, C.c_double, C.c_int, C.c_double, C.c_int, C.c_int, C.POINTER(OrcResult)]
         L.orc_set_threads.argtypes = [C.c_int]
+        L.orc_bo_get_iq_ext.argtypes = [_vp, _d]
+        L.orc_bo_set_extras.argtypes = [_vp, _vp, _vp, _vp]
         L.orc_bo_end_time_step.argtypes = [_vp, C.c_double]
         L.orc_bo_set_drift_compensation.argtypes = [_vp, C.c_int, C.c_double]
         L.orc_bo_get_drift.argtypes = [_vp, _d]
@@ -155,6 +157,8 @@ class OracleModel:
         self.h = L.orc_bo_create(self.Nb, _p(case["rowptr"]), _p(case["col"]), _p(case["trans"]), _p(case["area"]),
                                  g("thpres"), _p(case["poro"]), _p(case["volume"]), _p(case["depth"]), g("pvtnum"),
                                  g("satnum"), g("rsmax"), C.addressof(self._fd))
+        if any(case.get(k) is not None for k in ("rvmax", "rocknum", "overburden")):
+            self.set_problem_extras(case.get("rvmax"), case.get("rocknum"), case.get("overburden"))
 
     def __del__(self):
         if getattr(self, "h", None):
@@ -176,9 +180,20 @@ class OracleModel:
         self.o.lib.orc_bo_set_source(self.h, _p(s), _p(d))
 
     def iq(self):
+        fl = self.case["fluid"]
+        if getattr(fl, "wet_gas", False) or getattr(fl, "rocktab", None):   # extended record: ... Rs | Rv | tmult | poro
+            out = np.empty(self.Nb * 19 * 4)
+            self.o.lib.orc_bo_get_iq_ext(self.h, out)
+            return out.reshape(self.Nb, 19, 4)
         out = np.empty(self.Nb * 17 * 4)
         self.o.lib.orc_bo_get_iq(self.h, out)
         return out.reshape(self.Nb, 17, 4)
+
+    def set_problem_extras(self, rvmax=None, rocknum=None, overburden=None):
+        a = None if rvmax is None else np.ascontiguousarray(rvmax, np.float64)
+        b = None if rocknum is None else np.ascontiguousarray(rocknum, np.int32)
+        d = None if overburden is None else np.ascontiguousarray(overburden, np.float64)
+        self.o.lib.orc_bo_set_extras(self.h, _p(a), _p(b), _p(d))
 
     def assemble(self, dt, iteration, fetch=True):
         jac = np.empty(self.nnzb * 9) if fetch else None

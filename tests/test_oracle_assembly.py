@@ -170,3 +170,101 @@ def test_spe1_case_assembles(pkg, orc):
     assert np.all(np.isfinite(jac)) and np.all(np.isfinite(r))
     x, res = m.solve(tol=1e-2)
     assert res.converged
+
+
+# ---- wet gas (PVTG / Rv / third primary-variable meaning) and rock compaction tables -------------------------------------
+def _fd_check(case, m, dt=86400.0, tol=2e-5):
+    m.assemble(dt, 0)
+    rng = np.random.default_rng(0)
+    pv = case["pv"].reshape(-1, 3).copy()
+    mean = case["meaning"]
+    pv[:, 0] += rng.uniform(-0.01, 0.01, len(pv))
+    pv[:, 1] *= 1 + rng.uniform(-0.003, 0.003, len(pv))
+    sg = mean == 0
+    pv[sg, 2] += rng.uniform(-0.01, 0.01, sg.sum())
+    pv[~sg, 2] *= 1 + rng.uniform(-0.01, 0.01, (~sg).sum())
+    m.set_state(pv.reshape(-1), mean)
+    jac, r0 = m.assemble(dt, 1)
+    J = dense(case, jac)
+    n = case["Nb"] * 3
+    Jfd = np.zeros((n, n))
+    for c in range(n):
+        k, mg = c % 3, mean[c // 3]
+        h = [1e-7, 1.0, 1e-7][k]
+        if k == 2 and mg == 1:
+            h = 1e-5            # Rs ~ 1e2
+        elif k == 2 and mg == 2:
+            h = 1e-11           # Rv ~ 1e-4
+        xp = pv.reshape(-1).copy(); xp[c] += h
+        xm = pv.reshape(-1).copy(); xm[c] -= h
+        m.set_state(xp, mean); _, rp_ = m.assemble(dt, 1)
+        m.set_state(xm, mean); _, rm_ = m.assemble(dt, 1)
+        Jfd[:, c] = (rp_ - rm_) / (2 * h)
+    cs = np.maximum(np.abs(J).max(axis=0), 1e-300)
+    err = np.abs(J - Jfd) / cs[None, :]
+    assert err.max() < tol, (err.max(), np.unravel_index(err.argmax(), err.shape))
+
+
+def test_wetgas_jacobian_matches_finite_differences(pkg, orc):
+    from helpers import wetgas_case
+    case = wetgas_case(pkg, 4, 3, 6, heterogeneous=True)
+    assert set(case["meaning"]) == {0, 1, 2}
+    m = oracle_bind.OracleModel(orc, case)
+    m.set_state(case["pv"], case["meaning"])
+    _fd_check(case, m, tol=5e-5)
+
+
+def test_wetgas_fluxes_conserve_mass_and_carry_vaporised_oil(pkg, orc):
+    from helpers import wetgas_case
+    case = wetgas_case(pkg, 5, 4, 6, heterogeneous=True)
+    m = oracle_bind.OracleModel(orc, case)
+    m.set_state(case["pv"], case["meaning"])
+    _, r = m.assemble(86400.0, 0)
+    r = r.reshape(-1, 3)
+    for e in range(3):
+        assert abs(r[:, e].sum()) <= 1e-12 * np.abs(r[:, e]).sum()
+    iq = m.iq()
+    assert iq.shape[1] == 19
+    top = case["meaning"] == 2
+    assert np.all(iq[top, 1, 0] == 0.0) and np.all(iq[top, 16, 0] > 0)       # no oil phase, Rv > 0
+    assert np.abs(r[top, 0]).max() > 0                                        # yet the oil component moves (with the gas)
+    # gas density carries the vaporised oil: rho_g = b_g (rho_g,ref + Rv rho_o,ref)
+    rr = case["fluid"].pvt[0]["density"]
+    np.testing.assert_allclose(iq[:, 14, 0], iq[:, 8, 0] * rr[2] + iq[:, 8, 0] * iq[:, 16, 0] * rr[0], rtol=1e-14)
+
+
+def test_wetgas_meaning_switches(pkg, orc):
+    """(Sw, po, Sg) -> (Sw, pg, Rv) when the oil saturation turns negative, and back when Rv exceeds the saturated value"""
+    from helpers import wetgas_case, rv_sat
+    case = wetgas_case(pkg, 3, 3, 6, perturb=False)
+    m = oracle_bind.OracleModel(orc, case)
+    m.set_state(case["pv"], case["meaning"])
+    mean = case["meaning"]
+    pv = case["pv"].reshape(-1, 3)
+    dx = np.zeros_like(pv)
+    three = np.flatnonzero(mean == 0)
+    dx[three, 2] = -0.2           # Sg += 0.2 per update (the chop limit): So = 0.7 - ... turns negative after four updates
+    for _ in range(4):
+        m.update(dx.reshape(-1))
+    p1, m1 = m.get_state()
+    assert np.all(m1[three] == 2) and np.all(m1[mean == 2] == 2)
+    p1 = p1.reshape(-1, 3)
+    np.testing.assert_allclose(p1[three, 2], rv_sat(case["fluid"], p1[three, 1]), rtol=1e-12)   # starts saturated
+    # now push Rv above saturation: oil re-appears, Sg = 1 - Sw
+    dx[:] = 0.0
+    dx[three, 2] = -2.0 * p1[three, 2]
+    m.update(dx.reshape(-1))
+    p2, m2 = m.get_state()
+    p2 = p2.reshape(-1, 3)
+    assert np.all(m2[three] == 0)
+    np.testing.assert_allclose(p2[three, 2], 1.0 - p2[three, 0], rtol=0, atol=0)
+
+
+def test_rocktab_jacobian_matches_finite_differences(pkg, orc):
+    from helpers import wetgas_case, ROCKTAB_2
+    case = wetgas_case(pkg, 4, 3, 5, rocktab=ROCKTAB_2, heterogeneous=True)
+    m = oracle_bind.OracleModel(orc, case)
+    m.set_state(case["pv"], case["meaning"])
+    iq = m.iq()
+    assert iq[:, 17, 0].min() < 0.99 and iq[:, 17, 0].max() > 0.9 and np.abs(iq[:, 17, 2]).max() > 0   # tmult active, depends on p
+    _fd_check(case, m, tol=5e-5)
