@@ -66,8 +66,11 @@ typedef struct opmhip_config {
     int reorder;           /* opmhip_reorder */
     int zero_diag_fix;     /* 1: exact 0.0 on a diagonal block's diagonal -> 1e-15 (bda/BdaBridge.cpp:125-161) */
     int reserved[7];       /* [0] line colouring: rows per chain (0 = 8).  [1] pipelined SpMV: resident workgroups it is sized
-                            * for (0 = 2048, the MI355X default; < 0 = one tile per workgroup instead).  Tuning only: results
-                            * are the same bits either way.  Others: 0. */
+                            * for (0 = 2048, the MI355X default; < 0 = one tile per workgroup instead); tuning only, results
+                            * are the same bits either way.  [2] preconditioner: 0 = ILU0 (--linear-solver-configuration=ilu0),
+                            * 1 = CPR with quasi-IMPES weights (= cpr_quasiimpes, setupPropertyTree.cpp:94-138): pressure
+                            * system solved by one AMG V-cycle, ILU0 (relaxation 1) post-smoothing; see csrc/cpr.hip for what
+                            * of it is the reference's and what is not.  Others: 0. */
 } opmhip_config;
 
 /* bda::BdaResult (bda/BdaResult.hpp:28-40) plus the reference's per-phase timers. */
@@ -167,6 +170,9 @@ int opmhip_spmv(opmhip_ctx* ctx, const double* x, double* y);
 int opmhip_ilu0_factor(opmhip_ctx* ctx, double* lu_out);
 /* v = M^-1 d (ParallelOverlappingILU0::apply, :848-903); needs opmhip_ilu0_factor first */
 int opmhip_ilu0_apply(opmhip_ctx* ctx, const double* d, double* v);
+/* v = M_cpr^-1 d with the CPR preconditioner of the matrix now on the device (contexts created with reserved[2] = 1;
+ * needs opmhip_ilu0_factor first: the fine smoother's factors) - for parity tests of the preconditioner alone */
+int opmhip_cpr_apply(opmhip_ctx* ctx, const double* d, double* v);
 /* the ordering chosen at set_pattern: toOrder/fromOrder [Nb], rowsPerColor [num colours] (any may be NULL);
  * returns the number of colours/levels or a negative status */
 int opmhip_get_ordering(opmhip_ctx* ctx, int* toOrder, int* fromOrder, int* rowsPerColor);
@@ -176,6 +182,9 @@ int opmhip_get_ordering(opmhip_ctx* ctx, int* toOrder, int* fromOrder, int* rows
  * Launches the kernel `reps` times back to back on the context's stream between two HIP events and returns the
  * average milliseconds per launch in *ms_per_launch. */
 int opmhip_time_kernel(opmhip_ctx* ctx, int which, int reps, double* ms_per_launch);
+/* CPR only: unknowns and entries of the pressure-AMG levels after the first solve (n, nnz: cap entries each); returns the
+ * number of levels */
+int opmhip_cpr_levels(opmhip_ctx* ctx, int* n, int* nnz, int cap);
 
 /* ---- assembly ("linearization") half of the Newton iteration ------------------------------------------ */
 /* Deck-level fluid and saturation-function tables, SI units, flat arrays: what PVTW, DENSITY, PVDG, PVTO, SWOF,

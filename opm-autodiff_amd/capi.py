@@ -82,8 +82,10 @@ def lib():
         L.opmhip_spmv.argtypes = [vp, dp, dp]
         L.opmhip_ilu0_factor.argtypes = [vp, dp]
         L.opmhip_ilu0_apply.argtypes = [vp, dp, dp]
+        L.opmhip_cpr_apply.argtypes = [vp, dp, dp]
         L.opmhip_get_ordering.argtypes = [vp, ip, ip, ip]
         L.opmhip_time_kernel.argtypes = [vp, C.c_int, C.c_int, C.POINTER(C.c_double)]
+        L.opmhip_cpr_levels.argtypes = [vp, ip, ip, C.c_int]
         L.opmhip_profile_enable.argtypes = [vp, C.c_int]
         L.opmhip_profile_get.argtypes = [vp, C.c_int, C.POINTER(C.c_longlong), C.POINTER(C.c_double)]
         _lib = L
@@ -117,7 +119,8 @@ class HipSolver:
     ctor(verbosity, maxit, tolerance, deviceID), solve_system(...), get_result(x))."""
 
     def __init__(self, verbosity=0, maxit=200, tolerance=1e-2, device_id=0, ilu_relaxation=0.9,
-                 relax_mode="post_scale", reorder="graph_coloring", zero_diag_fix=True, chain_length=8, spmv_pipe_wgs=0):
+                 relax_mode="post_scale", reorder="graph_coloring", zero_diag_fix=True, chain_length=8, spmv_pipe_wgs=0,
+                 preconditioner="ilu0"):
         L = lib()
         cfg = Config()
         L.opmhip_default_config(C.byref(cfg))
@@ -128,6 +131,7 @@ class HipSolver:
         cfg.zero_diag_fix = int(zero_diag_fix)
         cfg.reserved[0] = int(chain_length)  # line colouring: rows per chain
         cfg.reserved[1] = int(spmv_pipe_wgs)  # pipelined SpMV: workgroups it is sized for (0 default, < 0 off; tests use small values)
+        cfg.reserved[2] = {"ilu0": 0, "cpr": 1}[preconditioner]  # --linear-solver-configuration
         self._h = C.c_void_p()
         rc = L.opmhip_create(C.byref(cfg), C.byref(self._h))
         if rc != SUCCESS:
@@ -215,6 +219,12 @@ class HipSolver:
         self._check(lib().opmhip_ilu0_apply(self._h, _ptr(d), _ptr(v)))
         return v
 
+    def cpr_apply(self, d):
+        d = _f64(d)
+        v = np.empty_like(d)
+        self._check(lib().opmhip_cpr_apply(self._h, _ptr(d), _ptr(v)))
+        return v
+
     def ordering(self):
         to = np.empty(self.Nb, np.int32)
         fr = np.empty(self.Nb, np.int32)
@@ -222,7 +232,7 @@ class HipSolver:
         nc = self._check(lib().opmhip_get_ordering(self._h, _ptr(to), _ptr(fr), _ptr(rpc)))
         return to, fr, rpc[:nc].copy()
 
-    PROF = ["spmv", "ilu_apply", "ilu_factor", "vector", "assemble", "iq_update", "convergence"]
+    PROF = ["spmv", "ilu_apply", "ilu_factor", "vector", "assemble", "iq_update", "convergence", "cpr_amg"]
 
     def profile_enable(self, on=True):
         self._check(lib().opmhip_profile_enable(self._h, int(on)))
@@ -235,6 +245,12 @@ class HipSolver:
             self._check(lib().opmhip_profile_get(self._h, i, C.byref(n), C.byref(ms)))
             out[name] = (n.value, ms.value)
         return out
+
+    def cpr_levels(self):
+        """(unknowns, entries) of the pressure-AMG levels (preconditioner="cpr", after the first solve)"""
+        n, nnz = np.zeros(32, np.int32), np.zeros(32, np.int32)
+        L = self._check(lib().opmhip_cpr_levels(self._h, _ptr(n), _ptr(nnz), 32))
+        return [int(v) for v in n[:L]], [int(v) for v in nnz[:L]]
 
     def time_kernel(self, which, reps=20):
         ms = C.c_double()

@@ -265,6 +265,10 @@ int opmhip_solve_system(opmhip_ctx* c, int N, int nnz, int dim, double* vals, co
         OPMHIP_HIP(c, hipGetLastError());
         OPMHIP_HIP(c, hipStreamSynchronize(c->stream));
         c->factored = true;
+        if (use_cpr(c)) {   // weights, pressure matrix, AMG values (the hierarchy's structure is built at the first solve)
+            if ((rc = cpr_update(c))) return rc;
+            OPMHIP_HIP(c, hipStreamSynchronize(c->stream));
+        }
         const double t2 = now();
         if ((rc = bicgstab(c, res))) return rc;
         OPMHIP_HIP(c, hipStreamSynchronize(c->stream));
@@ -453,6 +457,22 @@ int opmhip_ilu0_apply(opmhip_ctx* c, const double* d, double* v) {
     });
 }
 
+int opmhip_cpr_apply(opmhip_ctx* c, const double* d, double* v) {
+    if (!c) return OPMHIP_INVALID_ARGUMENT;
+    return guarded(c, [&]() -> int {
+        if (!d || !v) return fail(c, OPMHIP_INVALID_ARGUMENT, "cpr_apply: null vector");
+        if (!use_cpr(c)) return fail(c, OPMHIP_NOT_READY, "cpr_apply: the context was not created with the CPR preconditioner");
+        if (!c->factored) return fail(c, OPMHIP_NOT_READY, "cpr_apply before ilu0_factor (the fine smoother's factors)");
+        OPMHIP_HIP(c, hipSetDevice(c->device));
+        int rc;
+        if ((rc = cpr_update(c))) return rc;
+        if ((rc = vec_in(c, d, c->d_p))) return rc;
+        launch_cpr_apply(c, c->d_p, c->d_pw);
+        OPMHIP_HIP(c, hipGetLastError());
+        return vec_out(c, c->d_pw, v);
+    });
+}
+
 int opmhip_get_ordering(opmhip_ctx* c, int* toOrder, int* fromOrder, int* rowsPerColor) {
     if (!c) return OPMHIP_INVALID_ARGUMENT;
     if (!c->pattern_set) return fail(c, OPMHIP_NOT_READY, "get_ordering before set_pattern");
@@ -504,6 +524,11 @@ int opmhip_profile_get(opmhip_ctx* c, int cls, long long* launches, double* tota
         *total_ms = P.total_ms[cls];
         return OPMHIP_SUCCESS;
     });
+}
+
+int opmhip_cpr_levels(opmhip_ctx* c, int* n, int* nnz, int cap) {
+    if (!c || !n || !nnz || cap < 1) return OPMHIP_INVALID_ARGUMENT;
+    return cpr_level_sizes(c, n, nnz, cap);
 }
 
 int opmhip_time_kernel(opmhip_ctx* c, int which, int reps, double* ms_per_launch) {

@@ -135,8 +135,25 @@ struct CommDev {
     double* d_red = nullptr;                     // 16 doubles: all-reduce buffer
 };
 
+// CPR preconditioner (cpr.hip): pressure-AMG hierarchy, level 0 = the block pattern with scalar values
+struct CprLevelDev {
+    int n = 0, nnz = 0, nc = 0;
+    int *d_rowptr = nullptr, *d_col = nullptr, *d_diag = nullptr;
+    double *d_val = nullptr, *d_dinv = nullptr;
+    int *d_agg = nullptr, *d_mptr = nullptr, *d_midx = nullptr;   // node -> aggregate, members of every aggregate
+    int *d_gptr = nullptr, *d_gidx = nullptr;                      // Galerkin gather lists for the next level's entries
+    double *d_b = nullptr, *d_x = nullptr, *d_r = nullptr;         // level vectors
+};
+struct CprDev {
+    bool structured = false, coarse_direct = true;
+    std::vector<CprLevelDev> lv;
+    double *d_w = nullptr, *d_lu = nullptr;
+    double *d_r = nullptr, *d_y = nullptr, *d_z = nullptr;         // fine-level block vectors
+    double omega = 2.0 / 3.0, damp = 1.6, beta = 0.25;             // Jacobi damping, prolongation damping, strength threshold
+};
+
 // per-kernel-class device timing with HIP events on the context's stream (opmhip_profile_*)
-enum ProfClass { PROF_SPMV = 0, PROF_ILU_APPLY, PROF_ILU_FACTOR, PROF_VECTOR, PROF_ASSEMBLE, PROF_IQ_UPDATE, PROF_CONVERGENCE, PROF_COUNT };
+enum ProfClass { PROF_SPMV = 0, PROF_ILU_APPLY, PROF_ILU_FACTOR, PROF_VECTOR, PROF_ASSEMBLE, PROF_IQ_UPDATE, PROF_CONVERGENCE, PROF_CPR_AMG, PROF_COUNT };
 struct Profiler {
     bool enabled = false;
     int every = 1;                            // solver scopes are recorded in every `every`-th linear solve (1 = all)
@@ -195,6 +212,7 @@ struct opmhip_ctx {
     opmhip::WellsDev wells;
     opmhip::AsmDev asmb;
     opmhip::CommDev comm;
+    opmhip::CprDev cpr;
     opmhip::Profiler prof;
     std::vector<void*> allocs;
 };
@@ -328,7 +346,12 @@ void launch_wells_residual(opmhip_ctx* c, const double* d_resWell, double* r);
 void launch_wells_add_to_matrix(opmhip_ctx* c, int w0, int nw, int serial, const int* d_pair_ptr, const int* d_entry);
 void launch_wells_recover(opmhip_ctx* c, const double* d_resWell, const double* x, double* d_xw);
 void launch_ilu_factor(opmhip_ctx* c);
-void launch_ilu_apply(opmhip_ctx* c, const double* d, double* v, int fuse = 0);
+void launch_ilu_apply(opmhip_ctx* c, const double* d, double* v, int fuse = 0, double w_override = -1.0);
+// cpr.hip
+int cpr_update(opmhip_ctx* c);
+void launch_cpr_apply(opmhip_ctx* c, const double* d, double* v);
+int cpr_level_sizes(const opmhip_ctx* c, int* n, int* nnz, int cap);
+inline bool use_cpr(const opmhip_ctx* c) { return c->cfg.reserved[2] == 1; }
 void launch_wells_apply(opmhip_ctx* c, const double* x, double* y);
 void launch_lu_to_natural(opmhip_ctx* c, double* d_out_internal_layout);
 int bicgstab(opmhip_ctx* c, opmhip_result* res);

@@ -1648,11 +1648,11 @@ static bool ilu_can_fuse(const opmhip_ctx* c) {
     const Pattern& P = c->pat;
     return P.chained && P.numColors >= 2 && P.lightL[0] && P.tiles.colorCT[1] > P.tiles.colorCT[0];
 }
-void launch_ilu_apply(opmhip_ctx* c, const double* d, double* v, int fuse) {
+void launch_ilu_apply(opmhip_ctx* c, const double* d, double* v, int fuse, double w_override) {
     const Pattern& P = c->pat;
     const int ps = prof_begin(c, PROF_ILU_APPLY);
     const int C = P.numColors, mode = c->cfg.relax_mode;
-    const double w = c->cfg.ilu_relaxation;
+    const double w = w_override > 0.0 ? w_override : c->cfg.ilu_relaxation;   // CPR's fine smoother runs with relaxation 1
     // post-scale with w != 1 keeps the unscaled sweep vector apart from the scaled result
     double* vu = (mode == OPMHIP_RELAX_POST_SCALE && w != 1.0) ? c->d_vu : v;
     const int n0 = P.colorPrefix[1];  // rows of the first colour: their y is d
@@ -1783,7 +1783,8 @@ static int enqueue_half(opmhip_ctx* c, int h) {
     // Line colouring with a light first colour: the p-update and the (r, x)-update ride in the first colour's sweep of
     // the preconditioner application that follows them (k_ilu_sweep_light_fused).  The stopping rule of a first half is
     // then evaluated after that application: half h reports for half h - 1.
-    const bool fused = ilu_can_fuse(c);
+    const bool cpr = use_cpr(c);
+    const bool fused = ilu_can_fuse(c) && !cpr;   // CPR starts with the pressure restriction: nothing to ride in a first sweep
     int rc, ps;
     if ((h & 1) == 0) {  // first half: p, y = M^-1 p, v = A y, alpha, x += alpha y, r -= alpha v, |r|
         if (h > 0 && !fused) {
@@ -1791,7 +1792,8 @@ static int enqueue_half(opmhip_ctx* c, int h) {
             hipLaunchKernelGGL(k_bicg_pupdate, dim3(nb), dim3(VB), 0, c->stream, n, c->d_scal, c->d_p, c->d_v, c->d_r);
             prof_end(c, ps);
         }
-        launch_ilu_apply(c, c->d_p, c->d_pw, (h > 0 && fused) ? DM_PUPD : 0);
+        if (cpr) launch_cpr_apply(c, c->d_p, c->d_pw);
+        else launch_ilu_apply(c, c->d_p, c->d_pw, (h > 0 && fused) ? DM_PUPD : 0);
         if ((rc = comm_halo_f64(c, c->d_pw, BS))) return rc;  // copyOwnerToAll before the operator (ParallelOverlappingILU0.hpp:897)
         launch_spmv(c, c->d_pw, c->d_v, 1, c->d_rw, nullptr);
         ps = prof_begin(c, PROF_VECTOR);
@@ -1802,7 +1804,8 @@ static int enqueue_half(opmhip_ctx* c, int h) {
         }
         prof_end(c, ps);
     } else {             // second half: z = M^-1 r, t = A z, omega, x += omega z, r -= omega t, |r|, rho, beta
-        launch_ilu_apply(c, c->d_r, c->d_s, fused ? DM_UPD1 : 0);
+        if (cpr) launch_cpr_apply(c, c->d_r, c->d_s);
+        else launch_ilu_apply(c, c->d_r, c->d_s, fused ? DM_UPD1 : 0);
         if (fused) {
             ps = prof_begin(c, PROF_VECTOR);
             if ((rc = finalize(c, FIN_NORM, P.tiles.ctSchedOff[1] - P.tiles.ctSchedOff[0], h - 1))) return rc;

@@ -7,6 +7,7 @@
 #include <cstdio>
 
 #include "linalg.hpp"
+#include "cpr.hpp"
 
 using namespace orc;
 
@@ -246,6 +247,56 @@ int orc_solve_noprec(int Nb, const int* rowptr, const int* col, const double* va
         out->num_colors = 0;
     }
     return 0;
+}
+
+// ---- CPR (oracle/cpr.hpp): handle keeps the AMG hierarchy's structure between solves -------------------------------------
+struct orc_cpr { Cpr P; };
+orc_cpr* orc_cpr_create(double omega, double damp, double beta) {
+    orc_cpr* h = new orc_cpr();
+    if (omega > 0.0) h->P.amg.omega = omega;
+    if (damp > 0.0) h->P.amg.damp = damp;
+    if (beta >= 0.0) h->P.amg.beta = beta;
+    if (beta <= -2.0) h->P.amg.join = true;   // experiment switch
+    return h;
+}
+void orc_cpr_destroy(orc_cpr* h) { delete h; }
+// BiCGStab with the CPR preconditioner on the system AS GIVEN (callers hand over the matrix in the ordering they want the
+// ILU0 smoother and the aggregation to see); x natural to that ordering
+int orc_cpr_solve(orc_cpr* h, int Nb, const int* rowptr, const int* col, const double* val, const double* b, double* x,
+                  double tol, int maxit, int zero_diag_fix, orc_result* out) {
+    Bcrs A = wrap(Nb, rowptr, col, val);
+    if (zero_diag_fix) check_zero_diagonal(A);
+    const int rc = h->P.update(A);
+    if (rc) return rc;
+    const size_t n = (size_t)Nb * BS;
+    auto prec = [&](const double* d, double* v) { h->P.apply(d, v); };
+    auto op = [&](const double* xin, double* y) { spmv(A, xin, y); };
+    SolveResult r = bicgstab(n, b, x, prec, op, tol, maxit);
+    if (out) {
+        out->iterations = r.iterations; out->converged = r.converged; out->reduction = r.reduction; out->conv_rate = r.conv_rate;
+        out->it = r.it; out->t_factor = out->t_solve = 0; out->num_colors = (int)h->P.amg.lv.size();
+    }
+    return 0;
+}
+// v = M_cpr^-1 d with the preconditioner of the last orc_cpr_solve / orc_cpr_update
+int orc_cpr_update(orc_cpr* h, int Nb, const int* rowptr, const int* col, const double* val) {
+    static thread_local Bcrs keep;   // Cpr::apply reads the matrix it was updated with
+    keep = wrap(Nb, rowptr, col, val);
+    return h->P.update(keep);
+}
+int orc_cpr_apply(orc_cpr* h, const double* d, double* v) { h->P.apply(d, v); return 0; }
+// sizes of the AMG levels (unknowns, entries); returns the number of levels
+int orc_cpr_levels(orc_cpr* h, int* n, int* nnz, int cap) {
+    const int L = (int)h->P.amg.lv.size();
+    for (int l = 0; l < L && l < cap; ++l) { n[l] = h->P.amg.lv[l].A.n; nnz[l] = (int)h->P.amg.lv[l].A.col.size(); }
+    return L;
+}
+int orc_cpr_weights(orc_cpr* h, double* w) { std::memcpy(w, h->P.w.data(), h->P.w.size() * sizeof(double)); return 0; }
+// level l: aggregate of every node (for the device parity test of the host-side aggregation)
+int orc_cpr_aggregates(orc_cpr* h, int l, int* agg) {
+    const AmgLevel& L = h->P.amg.lv[l];
+    std::memcpy(agg, L.agg.data(), L.agg.size() * sizeof(int));
+    return (int)L.agg.size();
 }
 
 }  // extern "C"

@@ -41,6 +41,16 @@ class Oracle:
         L.orc_solve_noprec.argtypes = [C.c_int, _i, _i, _d, _d, _d, C.c_double, C.c_int, C.c_int,
                                        C.POINTER(OrcResult)]
 
+        L.orc_cpr_create.restype = C.c_void_p
+        L.orc_cpr_create.argtypes = [C.c_double, C.c_double, C.c_double]
+        L.orc_cpr_destroy.argtypes = [_vp]
+        L.orc_cpr_solve.argtypes = [_vp, C.c_int, _i, _i, _d, _d, _d, C.c_double, C.c_int, C.c_int, C.POINTER(OrcResult)]
+        L.orc_cpr_update.argtypes = [_vp, C.c_int, _i, _i, _d]
+        L.orc_cpr_apply.argtypes = [_vp, _d, _d]
+        L.orc_cpr_levels.argtypes = [_vp, _i, _i, C.c_int]
+        L.orc_cpr_weights.argtypes = [_vp, _d]
+        L.orc_cpr_aggregates.argtypes = [_vp, C.c_int, _i]
+
     # ---- linear algebra -------------------------------------------------------------------
     def spmv(self, Nb, rowptr, col, val, x):
         y = np.empty(Nb * 3)
@@ -321,3 +331,47 @@ def oil_pvt_probe(oracle, fluid, region, rs, p):
     fd = fluid.desc()
     L.orc_oil_pvt_probe(C.addressof(fd), region, n, rs[:n].copy(), p, mu, ib, rsat)
     return mu, ib, rsat
+
+
+class OracleCpr:
+    """CPR preconditioner of the oracle (oracle/cpr.hpp); the handle keeps the AMG hierarchy's structure between solves."""
+
+    def __init__(self, oracle, omega=0.0, damp=0.0, beta=-1.0):
+        self.o = oracle
+        self.h = oracle.lib.orc_cpr_create(omega, damp, beta)
+
+    def __del__(self):
+        if getattr(self, "h", None):
+            self.o.lib.orc_cpr_destroy(self.h)
+            self.h = None
+
+    def solve(self, Nb, rowptr, col, val, b, tol=1e-2, maxit=200, zero_diag_fix=True):
+        x = np.zeros(Nb * 3)
+        res = OrcResult()
+        rc = self.o.lib.orc_cpr_solve(self.h, Nb, rowptr, col, val, np.ascontiguousarray(b, np.float64), x, tol, maxit, int(zero_diag_fix), C.byref(res))
+        assert rc == 0, rc
+        return x, res
+
+    def update(self, Nb, rowptr, col, val):
+        self.Nb = Nb
+        assert self.o.lib.orc_cpr_update(self.h, Nb, rowptr, col, val) == 0
+
+    def apply(self, d):
+        v = np.zeros(len(d))
+        self.o.lib.orc_cpr_apply(self.h, np.ascontiguousarray(d, np.float64), v)
+        return v
+
+    def levels(self):
+        n, nnz = np.zeros(32, np.int32), np.zeros(32, np.int32)
+        L = self.o.lib.orc_cpr_levels(self.h, n, nnz, 32)
+        return list(n[:L]), list(nnz[:L])
+
+    def weights(self, Nb):
+        w = np.empty(Nb * 3)
+        self.o.lib.orc_cpr_weights(self.h, w)
+        return w.reshape(Nb, 3)
+
+    def aggregates(self, level, n):
+        a = np.empty(n, np.int32)
+        k = self.o.lib.orc_cpr_aggregates(self.h, level, a)
+        return a[:k]

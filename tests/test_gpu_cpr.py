@@ -1,0 +1,115 @@
+"""GPU parity of the CPR preconditioner (csrc/cpr.hip) through the C-ABI against its CPU restatement (oracle/cpr.hpp) on
+the same system in the device's ordering: the preconditioner application bit for bit, CPR-BiCGStab with the same half-
+iteration count, the reference's matr33 vector (tests/test_flexiblesolver.cpp:93-116), and a Newton loop."""
+import json
+import os
+
+import numpy as np
+import pytest
+
+import oracle_bind
+from helpers import laplace_block_system
+from test_oracle_linalg import _cmp, _load
+
+pytestmark = pytest.mark.gpu
+
+
+def close_per_component(x, xo, tol=1e-6):
+    """device and oracle run the same recurrence but sum their scalar products in different orders: compare every
+    component class (Sw, p, X) against its own magnitude"""
+    x, xo = x.reshape(-1, 3), xo.reshape(-1, 3)
+    for k in range(3):
+        assert np.abs(x[:, k] - xo[:, k]).max() <= tol * np.abs(xo[:, k]).max(), (k, np.abs(x[:, k] - xo[:, k]).max(), np.abs(xo[:, k]).max())
+
+
+def reordered(orc, s, Nb, rp, ci, v):
+    to, fr, _ = s.ordering()
+    rr, rc, rv = orc.reorder_matrix(Nb, rp, ci, v, to, fr)
+    return to, fr, rr, rc, rv
+
+
+def jacobian_case(pkg, orc, shape=(20, 18, 14), dt_days=10.0, its=1):
+    case = pkg.decks.cartesian_case(*shape, state="mixed", heterogeneous=True)
+    src = pkg.decks.five_spot_source(case, rate_sm3_per_day=30.0)
+    o = oracle_bind.OracleModel(orc, case)
+    o.set_state(case["pv"], case["meaning"])
+    o.set_source(src)
+    for it in range(its):
+        jac, res = o.assemble(dt_days * 86400.0, it)
+        if it + 1 < its:
+            x, _ = o.solve(tol=1e-2)
+            o.update(x)
+    return case, jac, res
+
+
+@pytest.mark.parametrize("reorder", ["graph_coloring", "line_coloring"])
+def test_cpr_apply_bitwise_and_solve(pkg, orc, reorder):
+    case, jac, res = jacobian_case(pkg, orc, its=2)
+    Nb, rp, ci = case["Nb"], case["rowptr"], case["col"]
+    s = pkg.capi.HipSolver(reorder=reorder, preconditioner="cpr", tolerance=1e-2)
+    s.set_pattern(Nb, rp, ci)
+    s.upload_system(jac)
+    s.ilu0_factor(want_factors=False)
+    to, fr, rr, rc, rv = reordered(orc, s, Nb, rp, ci, jac)
+    cpr = oracle_bind.OracleCpr(orc)
+    cpr.update(Nb, rr, rc, rv)
+    rng = np.random.default_rng(1)
+    for k in range(2):
+        d = rng.standard_normal(3 * Nb) * (1.0 if k else 1e-3)
+        vo = cpr.apply(np.ascontiguousarray(d.reshape(Nb, 3)[fr].reshape(-1))).reshape(Nb, 3)[to].reshape(-1)
+        assert np.array_equal(s.cpr_apply(d), vo)
+    assert s.cpr_levels()[0] == [int(x) for x in cpr.levels()[0]] and len(s.cpr_levels()[0]) >= 3
+    # the solve: same stopping half iteration, same solution up to the order of the scalar products
+    r = s.solve_system(Nb, rp, ci, jac.copy(), res)
+    xo, ro = cpr.solve(Nb, rr, rc, rv, np.ascontiguousarray(res.reshape(Nb, 3)[fr].reshape(-1)), tol=1e-2)
+    assert r.converged and r.it == ro.it
+    close_per_component(s.get_result(), xo.reshape(Nb, 3)[to].reshape(-1))
+    # a second matrix through the same context: the hierarchy's structure is kept, its values follow the new matrix
+    case2, jac2, res2 = jacobian_case(pkg, orc, dt_days=3.0, its=1)
+    r2 = s.solve_system(Nb, rp, ci, jac2.copy(), res2)
+    _, _, rr2, rc2, rv2 = reordered(orc, s, Nb, rp, ci, jac2)
+    xo2, ro2 = cpr.solve(Nb, rr2, rc2, rv2, np.ascontiguousarray(res2.reshape(Nb, 3)[fr].reshape(-1)), tol=1e-2)
+    assert r2.converged and r2.it == ro2.it
+    close_per_component(s.get_result(), xo2.reshape(Nb, 3)[to].reshape(-1))
+
+
+def test_cpr_matr33_flexiblesolver_vector(pkg, orc, golden):
+    Nb, rp, ci, v, b = _load(pkg, golden, "matr33.txt", "rhs3.txt")
+    with open(os.path.join(golden, "linalg", "expected.json")) as f:
+        e = json.load(f)["exact_noprec_tol1e-12_maxit200"]
+    s = pkg.capi.HipSolver(reorder="level_scheduling", preconditioner="cpr", tolerance=0.5, maxit=20, zero_diag_fix=False)
+    r = s.solve_system(Nb, rp, ci, v.copy(), b)
+    assert r.converged and r.it == 0.5
+    _cmp(s.get_result(), e)
+
+
+def test_cpr_on_a_laplace_like_block_system(pkg, orc):
+    """a system without the black-oil structure (random dense blocks): CPR must still be a valid preconditioner"""
+    Nb, rp, ci, v = laplace_block_system(16, 14, 12, seed=4)
+    b = np.random.default_rng(2).standard_normal(3 * Nb)
+    s = pkg.capi.HipSolver(reorder="line_coloring", preconditioner="cpr", tolerance=1e-8)
+    r = s.solve_system(Nb, rp, ci, v.copy(), b)
+    assert r.converged
+    x = s.get_result()
+    assert np.linalg.norm(orc.spmv(Nb, rp, ci, v, x) - b) <= 1e-7 * np.linalg.norm(b)
+
+
+def test_newton_loop_with_cpr(pkg, orc):
+    """the same time step solved with ILU0 and with CPR inside the device-resident Newton loop: about the same number of
+    Newton iterations, the same state to Newton tolerance; CPR needs fewer linear iterations in total"""
+    case = pkg.decks.cartesian_case(24, 24, 18, state="mixed", heterogeneous=True)
+    src = pkg.decks.five_spot_source(case, rate_sm3_per_day=40.0)
+    out = {}
+    for prec in ("ilu0", "cpr"):
+        m = pkg.capi.HipModel(case, reorder="line_coloring", preconditioner=prec)
+        m.set_state(case["pv"], case["meaning"])
+        m.set_source(src)
+        rep = pkg.newton.BlackoilModelHip(m).step(10 * 86400.0)
+        out[prec] = (rep.total_newton_iterations, rep.total_linear_iterations, m.get_state())
+    assert abs(out["ilu0"][0] - out["cpr"][0]) <= 2   # inexact (1e-2) linear solves: the Newton paths differ slightly
+    assert out["cpr"][1] < out["ilu0"][1], (out["ilu0"][1], out["cpr"][1])
+    pa, ma = out["ilu0"][2]
+    pb, mb = out["cpr"][2]
+    assert np.array_equal(ma, mb)
+    np.testing.assert_allclose(pa.reshape(-1, 3)[:, 1], pb.reshape(-1, 3)[:, 1], rtol=1e-4)
+    np.testing.assert_allclose(pa.reshape(-1, 3)[:, 0], pb.reshape(-1, 3)[:, 0], atol=2e-3)

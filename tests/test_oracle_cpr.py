@@ -1,0 +1,73 @@
+"""The oracle's CPR preconditioner (oracle/cpr.hpp): pinned where the reference's own test can pin it - CPR-BiCGStab on
+tests/matr33.txt gives the exact solution tests/test_flexiblesolver.cpp:93-116 expects - plus the structural properties
+of the restatement (quasi-IMPES weights, pressure system, AMG hierarchy) and its effect on a real Jacobian.  CPU only."""
+import json
+import os
+
+import numpy as np
+
+import oracle_bind
+from test_oracle_linalg import _cmp, _load
+
+
+def test_cpr_on_matr33_gives_the_flexiblesolver_vector(pkg, orc, golden):
+    """options_flexiblesolver.json: bicgstab, tol 0.5, maxiter 20, preconditioner cpr (quasi-IMPES weights, ILU0 fine
+    smoother, relaxation 1).  Block ILU0 is an exact LU of this block-tridiagonal matrix, so one post-smoothing step on the
+    residual left by the pressure correction lands on the exact solution, whatever the coarse solver did."""
+    Nb, rp, ci, v, b = _load(pkg, golden, "matr33.txt", "rhs3.txt")
+    with open(os.path.join(golden, "linalg", "expected.json")) as f:
+        e = json.load(f)["exact_noprec_tol1e-12_maxit200"]   # the same vector test_flexiblesolver.cpp:93-116 expects of the CPR run
+    cpr = oracle_bind.OracleCpr(orc)
+    x, res = cpr.solve(Nb, rp, ci, v, b, tol=0.5, maxit=20, zero_diag_fix=False)
+    assert res.converged and res.it == 0.5
+    _cmp(x, e)
+
+
+def test_weights_and_pressure_system(pkg, orc):
+    case = pkg.decks.cartesian_case(12, 10, 8, state="mixed", heterogeneous=True)
+    o = oracle_bind.OracleModel(orc, case)
+    o.set_state(case["pv"], case["meaning"])
+    jac, res = o.assemble(5 * 86400.0, 0)
+    Nb, rp, ci = case["Nb"], case["rowptr"], case["col"]
+    cpr = oracle_bind.OracleCpr(orc)
+    cpr.update(Nb, rp, ci, jac)
+    w = cpr.weights(Nb)
+    blk = jac.reshape(-1, 3, 3)
+    row = np.repeat(np.arange(Nb), np.diff(rp))
+    D = blk[ci == row]
+    # getQuasiImpesWeights.hpp:46-85: D^T w = e_p up to the max-norm scaling
+    e = np.einsum("nji,nj->ni", D, w)
+    e /= e[:, 1:2]
+    np.testing.assert_allclose(e, np.tile([0.0, 1.0, 0.0], (Nb, 1)), atol=1e-9)
+    np.testing.assert_allclose(np.abs(w).max(axis=1), 1.0, rtol=1e-14)
+    n, nnz = cpr.levels()
+    assert n[0] == Nb and nnz[0] == len(ci) and n[-1] <= 128 and all(a > b for a, b in zip(n, n[1:]))
+    agg = cpr.aggregates(0, Nb)
+    cnt = np.bincount(agg)
+    assert cnt.min() >= 1 and cnt.max() <= 4 and len(cnt) == n[1]
+    # the preconditioner is a linear operator
+    rng = np.random.default_rng(0)
+    d1, d2 = rng.standard_normal(3 * Nb), rng.standard_normal(3 * Nb)
+    np.testing.assert_allclose(cpr.apply(2.0 * d1 - d2), 2.0 * cpr.apply(d1) - cpr.apply(d2), rtol=1e-9, atol=1e-12 * np.abs(cpr.apply(d1)).max())
+
+
+def test_cpr_needs_fewer_iterations_than_ilu0_on_a_stiff_step(pkg, orc):
+    case = pkg.decks.cartesian_case(24, 24, 20, state="mixed", heterogeneous=True)
+    src = pkg.decks.five_spot_source(case, rate_sm3_per_day=40.0)
+    o = oracle_bind.OracleModel(orc, case)
+    o.set_state(case["pv"], case["meaning"])
+    o.set_source(src)
+    Nb, rp, ci = case["Nb"], case["rowptr"], case["col"]
+    cpr = oracle_bind.OracleCpr(orc)
+    dt = 10 * 86400.0
+    its = []
+    for it in range(3):
+        jac, res = o.assemble(dt, it)
+        x0, r0 = o.solve(tol=1e-2)
+        x1, r1 = cpr.solve(Nb, rp, ci, jac, res, tol=1e-2)
+        assert r0.converged and r1.converged
+        # both satisfy the stopping rule on the same system
+        A = None
+        its.append((r0.it, r1.it))
+        o.update(x0)
+    assert sum(c for _, c in its) < sum(i for i, _ in its), its
