@@ -57,6 +57,10 @@ def alg_bytes(Nb, nnzb):
         "assemble": 85 * Nb + 12 * nnzb + 72 * nnzb + 24 * Nb,
         "iq_update": 24 * Nb + 544 * Nb,
         "convergence": 56 * Nb,
+        # CPR: one V(1,1) cycle of the pressure AMG = 3 matrix passes per level (residual twice, post-smoothing) over 12-byte
+        # scalar entries + ~10 vector passes, levels shrinking ~4x (geometric sum 4/3), + the restriction / prolongation of
+        # the block vectors (72 B per cell)
+        "cpr_amg": (3 * 12 * nnzb + 10 * 8 * Nb) * 4 / 3 + 72 * Nb,
     }
 
 
@@ -190,6 +194,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--steady-after", type=int, default=200, help="second timed window starts at this Newton iteration (0: none)")
     ap.add_argument("--steady-steps", type=int, default=100)
+    ap.add_argument("--preconditioner", default="ilu0", choices=["ilu0", "cpr"], help="--linear-solver-configuration of the run behind `value`")
+    ap.add_argument("--no-cpr-side-run", action="store_true", help="skip the second, shorter run with the CPR preconditioner (extra key `cpr`)")
     a = ap.parse_args()
 
     import torch
@@ -225,7 +231,8 @@ def main():
 
     pkg = importlib.import_module("opm-autodiff_amd")
     n = a.n
-    skw = dict(device_id=local_rank, reorder=a.reorder, tolerance=1e-2, maxit=200, ilu_relaxation=0.9, chain_length=a.chain_length)
+    skw = dict(device_id=local_rank, reorder=a.reorder, tolerance=1e-2, maxit=200, ilu_relaxation=0.9, chain_length=a.chain_length,
+               preconditioner=a.preconditioner)
     if world == 1:
         case = pkg.decks.cartesian_case(n, n, n, state="mixed", heterogeneous=False)
         src = pkg.decks.five_spot_source(case, rate_sm3_per_day=pkg.decks.BENCH_RATE_SM3_PER_DAY * (n / 100.0) ** 2)
@@ -303,6 +310,31 @@ def main():
                   "linear_iterations_per_newton": S["linear_iterations_per_newton"], "time_steps_days": S["time_steps_days"],
                   "timesteps_chopped": S["timesteps_chopped"], "linear_solve_GBps": S["linear_solve_GBps"], "report": S["report"],
                   "kernels": S["kernels"]}
+    # the same workload with the CPR preconditioner (cpr_quasiimpes), side by side: its own context, warm-up, timed window
+    cpr_side = None
+    if a.preconditioner == "ilu0" and world == 1 and not a.no_cpr_side_run:
+        model2 = pkg.capi.HipModel(case, **dict(skw, preconditioner="cpr"))
+        model2.set_state(case["pv"], case["meaning"])
+        model2.set_source(src)
+        sim_main, model_main = sim, model
+        sim, model = make_simulation(pkg, model2), model2
+        for _ in range(a.warmup):
+            sim.next_newton_iteration()      # includes the one-time host-side aggregation of the pressure AMG
+        C1 = timed_window(a.steps)
+        cpr_side = {"value": C1["steps"] / C1["elapsed"], "ms_per_step": 1e3 * C1["elapsed"] / C1["steps"], "steps": C1["steps"],
+                    "linear_iterations_per_newton": C1["linear_iterations_per_newton"], "report": C1["report"], "kernels": C1["kernels"],
+                    "amg_levels": model2.cpr_levels()[0]}
+        if a.steady_after > 0 and a.steady_steps > 0:
+            done = a.warmup + a.steps
+            while done < a.steady_after:
+                sim.next_newton_iteration()
+                done += 1
+            C2 = timed_window(a.steady_steps)
+            cpr_side["steady_state"] = {"from_newton_iteration": done, "steps": C2["steps"], "value": C2["steps"] / C2["elapsed"],
+                                        "ms_per_step": 1e3 * C2["elapsed"] / C2["steps"],
+                                        "linear_iterations_per_newton": C2["linear_iterations_per_newton"], "timesteps_chopped": C2["timesteps_chopped"]}
+        sim, model = sim_main, model_main
+        del model2
     # what a kernel that only streams reaches on THIS card (reads the Jacobian's values once per launch)
     stream_ms = model.time_kernel("stream_read", reps=20)
     stream_GBps = 72.0 * nnzb / stream_ms / 1e6
@@ -334,6 +366,9 @@ def main():
         "report": W["report"],
         "kernels": kernels,
         "steady_state": steady,
+        # same case, CPR instead of ILU0 as the preconditioner of BiCGStab (extra information; `value` is the run above)
+        "cpr": cpr_side,
+        "preconditioner": a.preconditioner,
         "stream_ceiling": {"read_GBps": round(stream_GBps, 1), "bytes_per_launch": 72 * nnzb, "avg_launch_ms": round(stream_ms, 5),
                            "kernel": "k_stream_read: the Jacobian's value array read once, 16-B loads, nothing else (back to back, 20 launches)"},
         "roofline": {"bound": "hbm", "kernel": "k_spmv (block-CSR SpMV, 3x3 double blocks)", "achieved": sp["algorithmic_GBps"],

@@ -1373,8 +1373,8 @@ __global__ __launch_bounds__(VB) void k_dots(int n, const double* __restrict__ a
     }
     block_partials(s, q, part, npart, nsum);
 }
-// Pre-reduction for long partial lists (one partial per 32-row tile = 31250 at 100^3): RED1_BLOCKS workgroups each
-// sum one contiguous slice in a fixed order, so that the single-workgroup k_finalize reads a few hundred numbers.
+// Long partial lists (one partial per 32-row tile = 31250 at 100^3) are reduced by RED1_BLOCKS workgroups, each summing one
+// contiguous slice in a fixed order (k_reduce_finalize); short ones by a single workgroup (k_finalize / k_local_sums).
 #ifndef OPMHIP_RED1_BLOCKS
 #define OPMHIP_RED1_BLOCKS 128
 #endif
@@ -1383,20 +1383,6 @@ constexpr int RED1_BLOCKS = OPMHIP_RED1_BLOCKS;
 #define OPMHIP_RED1_SINGLE_MAX 512
 #endif
 constexpr int RED1_SINGLE_MAX = OPMHIP_RED1_SINGLE_MAX;  // partial lists up to this length go through one workgroup (k_finalize)
-__global__ __launch_bounds__(VB) void k_reduce_stage1(int count, const double* __restrict__ part, int npart, double* __restrict__ out) {
-    __shared__ double sh[2][VB];
-    const int chunk = (count + RED1_BLOCKS - 1) / RED1_BLOCKS;
-    const int b = blockIdx.x * chunk, e = min(count, b + chunk);
-    double a0 = 0.0, a1 = 0.0;
-    for (int i = b + threadIdx.x; i < e; i += VB) { a0 += part[i]; a1 += part[npart + i]; }
-    sh[0][threadIdx.x] = a0; sh[1][threadIdx.x] = a1;
-    __syncthreads();
-    for (int o = VB / 2; o > 0; o >>= 1) {
-        if ((int)threadIdx.x < o) { sh[0][threadIdx.x] += sh[0][threadIdx.x + o]; sh[1][threadIdx.x] += sh[1][threadIdx.x + o]; }
-        __syncthreads();
-    }
-    if (threadIdx.x == 0) { out[blockIdx.x] = sh[0][0]; out[RED1_BLOCKS + blockIdx.x] = sh[1][0]; }
-}
 // out[0], out[1] = the two sums of the partial lists, fixed order (input of the all-reduce in decomposed runs)
 __global__ __launch_bounds__(VB) void k_local_sums(int count, const double* __restrict__ part, int npart, double* __restrict__ out) {
     __shared__ double sh[2][VB];
@@ -1411,12 +1397,14 @@ __global__ __launch_bounds__(VB) void k_local_sums(int count, const double* __re
     if (threadIdx.x == 0) { out[0] = sh[0][0]; out[1] = sh[1][0]; }
 }
 // Sum the partials in a fixed order and update the device-resident scalars.  One workgroup.
-enum FinMode { FIN_INIT = 0, FIN_ALPHA = 1, FIN_NORM = 2, FIN_OMEGA = 3, FIN_NORM_RHO = 4 };
+enum FinMode { FIN_INIT = 0, FIN_ALPHA = 1, FIN_NORM = 2, FIN_OMEGA = 3, FIN_NORM_RHO = 4,
+               FIN_LOCAL = 5 };   // decomposed runs: only leave the two local sums in scal[0], scal[1] (input of the all-reduce)
 // FIN_NORM / FIN_NORM_RHO evaluate the stopping rule (norm < tol * norm_0, bda/cusparseSolverBackend.cu:115,151) on the
 // device: they raise scal[SC_DONE] and leave (norm, norm_0, done) in the pinned host slot `hslot` for the host, which
 // meanwhile has enqueued the next half iteration already.  Once the flag is up nothing changes any more.
 __device__ __forceinline__ void finalize_scalars(int mode, double s0, double s1, double* __restrict__ scal, double tol, double* hslot, double seq) {
     switch (mode) {
+        case FIN_LOCAL: scal[0] = s0; scal[1] = s1; return;
         case FIN_INIT:
             scal[SC_NORM0] = sqrt(s0); scal[SC_NORM] = sqrt(s0);
             scal[SC_RHO] = s0; scal[SC_RHOP] = 1.0; scal[SC_ALPHA] = 1.0; scal[SC_OMEGA] = 1.0; scal[SC_BETA] = 0.0;
@@ -1462,7 +1450,7 @@ __global__ __launch_bounds__(VB) void k_finalize(int mode, int count, const doub
     if (threadIdx.x != 0) return;
     finalize_scalars(mode, sh[0][0], sh[1][0], scal, tol, hslot, seq);
 }
-// k_reduce_stage1 and k_finalize in one launch for long partial lists: the workgroup that finishes last (ticket counter)
+// slice sums and k_finalize in one launch for long partial lists: the workgroup that finishes last (ticket counter)
 // sums the RED1_BLOCKS slice sums in k_finalize's order and updates the scalars.  The slice sums cross XCDs inside one
 // kernel, so they travel as agent-scope atomics (an XCD's L2 is not coherent with the others' for plain accesses).
 static_assert(RED1_BLOCKS <= VB, "the last workgroup holds one slice sum per thread");
@@ -1470,7 +1458,7 @@ __global__ __launch_bounds__(VB) void k_reduce_finalize(int mode, int count, con
                                                         unsigned* ticket, double* __restrict__ scal, double tol, double* hslot, double seq) {
     __shared__ double sh[2][VB];
     __shared__ bool last;
-    if (mode != FIN_INIT && scal[SC_DONE] != 0.0) {
+    if (mode != FIN_INIT && mode != FIN_LOCAL && scal[SC_DONE] != 0.0) {
         if (blockIdx.x == 0 && threadIdx.x == 0 && hslot && (mode == FIN_NORM || mode == FIN_NORM_RHO)) {
             hslot[0] = scal[SC_NORM]; hslot[1] = scal[SC_NORM0]; hslot[2] = 1.0;
             __hip_atomic_store(&hslot[3], seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
@@ -1735,13 +1723,13 @@ static int finalize(opmhip_ctx* c, int mode, int count, int rb_half = -1) {
     if (c->comm.nranks > 1) {
         // local sums -> one small all-reduce -> scalars (the reference all-reduces one double per scalar product
         // through OwnerOverlapCopyCommunication; here the two sums of a half iteration travel together)
-        const double* src = c->d_part;
-        int np = c->npart, cnt = count;
-        if (count > 4 * RED1_BLOCKS) {
-            hipLaunchKernelGGL(k_reduce_stage1, dim3(RED1_BLOCKS), dim3(VB), 0, c->stream, count, c->d_part, c->npart, c->d_part2);
-            src = c->d_part2; np = RED1_BLOCKS; cnt = RED1_BLOCKS;
-        }
-        hipLaunchKernelGGL(k_local_sums, dim3(1), dim3(VB), 0, c->stream, cnt, src, np, c->comm.d_red);
+        // long partial lists: slice sums and their fixed-order total in ONE launch (the last workgroup to finish folds
+        // the slices, as in the single-GPU path) instead of k_reduce_stage1 + k_local_sums
+        if (count > RED1_SINGLE_MAX)
+            hipLaunchKernelGGL(k_reduce_finalize, dim3(RED1_BLOCKS), dim3(VB), 0, c->stream, (int)FIN_LOCAL, count, c->d_part, c->npart, c->d_part2,
+                               reinterpret_cast<unsigned*>(c->d_part2 + 2 * RED1_BLOCKS), c->comm.d_red, tol, (double*)nullptr, 0.0);
+        else
+            hipLaunchKernelGGL(k_local_sums, dim3(1), dim3(VB), 0, c->stream, count, c->d_part, c->npart, c->comm.d_red);
         // a failed all-reduce would leave garbage in alpha / omega / the norm: stop the solve, the caller reports it
         const int rc = comm_allreduce(c, c->comm.d_red, 2, 0);
         if (rc) return rc;

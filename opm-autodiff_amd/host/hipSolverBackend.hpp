@@ -36,9 +36,11 @@ class hipSolverBackend : public BdaSolver<block_size> {
     bool haveWells = false;
 
 public:
-    /// ilu_reorder as --opencl-ilu-reorder: "level_scheduling" | "graph_coloring" | "line_coloring"
+    /// ilu_reorder as --opencl-ilu-reorder: "level_scheduling" | "graph_coloring" | "line_coloring";
+    /// linsolver as --linear-solver-configuration: "ilu0" | "cpr_quasiimpes" (setupPropertyTree.cpp:46-138)
     hipSolverBackend(int linear_solver_verbosity, int maxit_, double tolerance_, unsigned int deviceID_,
-                     const std::string& ilu_reorder = "graph_coloring", double ilu_relaxation = 0.9)
+                     const std::string& ilu_reorder = "graph_coloring", double ilu_relaxation = 0.9,
+                     const std::string& linsolver = "ilu0")
         : Base(linear_solver_verbosity, maxit_, tolerance_, deviceID_) {
         static_assert(block_size == 3, "libopmhip handles 3x3 blocks (three-phase black-oil)");
         opmhip_config cfg;
@@ -52,6 +54,8 @@ public:
         else if (ilu_reorder == "graph_coloring" || ilu_reorder.empty()) cfg.reorder = OPMHIP_REORDER_GRAPH_COLORING;
         else if (ilu_reorder == "line_coloring") cfg.reorder = OPMHIP_REORDER_LINE_COLORING;
         else throw std::logic_error("Error invalid argument for --opencl-ilu-reorder, usage: '--opencl-ilu-reorder=[level_scheduling|graph_coloring|line_coloring]'");
+        if (linsolver == "cpr_quasiimpes") cfg.reserved[2] = 1;
+        else if (linsolver != "ilu0") throw std::invalid_argument(linsolver + " is not a valid setting for --linear-solver-configuration with --accelerator-mode=hip. Please use ilu0 or cpr_quasiimpes");
         const int rc = opmhip_create(&cfg, &ctx);
         if (rc != OPMHIP_SUCCESS) throw std::logic_error(std::string("hipSolverBackend: ") + opmhip_last_error(nullptr));
     }

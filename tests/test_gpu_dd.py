@@ -43,9 +43,8 @@ def global_and_parts(pkg, n, world, **kw):
     return g, owner, parts
 
 
-@pytest.mark.parametrize("world", [2, 4, 8])
-def test_dd_assembly_bitwise_and_solve(pkg, orc, world):
-    n = 6
+@pytest.mark.parametrize("world,n", [(2, 6), (4, 6), (8, 6), (2, 28)])   # 28^3 cells per rank: > 512 tiles, the one-launch local reduction
+def test_dd_assembly_bitwise_and_solve(pkg, orc, world, n):
     g, owner, parts = global_and_parts(pkg, n, world, state="mixed", heterogeneous=True)
     src = pkg.decks.five_spot_source(g, rate_sm3_per_day=30.0)
     o = oracle_bind.OracleModel(orc, g)
