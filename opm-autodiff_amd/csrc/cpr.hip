@@ -116,38 +116,43 @@ __global__ __launch_bounds__(256) void k_cpr_weights(int Nb, const int* __restri
     for (int r = 0; r < BS; ++r) { bw[r] = inv[r * BS + CPR_P]; mx = fmax(mx, fabs(bw[r])); }
     for (int r = 0; r < BS; ++r) w[(size_t)i * BS + r] = bw[r] / mx;
 }
+// Level matrices live in ELL form: entry j of row i at [j * n + i] (j < W = longest row of the level; padding: column i, value 0),
+// so that the one-thread-per-row kernels read coalesced and with a uniform trip count.  Row sums run over j ascending = the
+// CSR order of the oracle; a padding term subtracts 0 * x_i and leaves the sum's bits alone.
 // pressure matrix: a_p[k] = sum_r A_k[r][p] w_row[r] (PressureTransferPolicy::calculateCoarseEntries, :116-139)
 __global__ __launch_bounds__(256) void k_cpr_pvals(int Nb, const int* __restrict__ rowptr, const double* __restrict__ A, const double* __restrict__ w,
                                                    double* __restrict__ ap) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= Nb) return;
     const double w0 = w[(size_t)i * BS], w1 = w[(size_t)i * BS + 1], w2 = w[(size_t)i * BS + 2];
-    for (int k = rowptr[i]; k < rowptr[i + 1]; ++k) {
+    const int kb = rowptr[i];
+    for (int k = kb; k < rowptr[i + 1]; ++k) {
         const double* B = &A[(size_t)k * BB];
         double s = 0.0;
         s += B[0 * BS + CPR_P] * w0; s += B[1 * BS + CPR_P] * w1; s += B[2 * BS + CPR_P] * w2;
-        ap[k] = s;
+        ap[(size_t)(k - kb) * Nb + i] = s;
     }
 }
-__global__ __launch_bounds__(256) void k_cpr_galerkin(int nce, const int* __restrict__ gptr, const int* __restrict__ gidx, const double* __restrict__ fine,
-                                                      double* __restrict__ coarse) {
+// Galerkin values: coarse entry e (at ELL position cpos[e]) = sum of its fine entries (ELL positions gidx) in ascending order
+__global__ __launch_bounds__(256) void k_cpr_galerkin(int nce, const int* __restrict__ gptr, const int* __restrict__ gidx, const int* __restrict__ cpos,
+                                                      const double* __restrict__ fine, double* __restrict__ coarse) {
     const int e = blockIdx.x * blockDim.x + threadIdx.x;
     if (e >= nce) return;
     double s = 0.0;
     for (int q = gptr[e]; q < gptr[e + 1]; ++q) s += fine[gidx[q]];
-    coarse[e] = s;
+    coarse[cpos[e]] = s;
 }
 __global__ __launch_bounds__(256) void k_cpr_dinv(int n, const int* __restrict__ diag, const double* __restrict__ val, double* __restrict__ dinv) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n) dinv[i] = 1.0 / val[diag[i]];
 }
 // dense LU without pivoting of the coarsest level, in place in global memory, one workgroup (n <= CPR_COARSE_DIRECT)
-__global__ __launch_bounds__(256) void k_cpr_dense_lu(int n, const int* __restrict__ rowptr, const int* __restrict__ col, const double* __restrict__ val,
+__global__ __launch_bounds__(256) void k_cpr_dense_lu(int n, int W, const int* __restrict__ ecol, const int* __restrict__ rlen, const double* __restrict__ val,
                                                       double* lu) {
     for (int e = threadIdx.x; e < n * n; e += 256) lu[e] = 0.0;
     __syncthreads();
     for (int i = threadIdx.x; i < n; i += 256)
-        for (int k = rowptr[i]; k < rowptr[i + 1]; ++k) lu[(size_t)i * n + col[k]] = val[k];
+        for (int j = 0; j < rlen[i]; ++j) lu[(size_t)i * n + ecol[(size_t)j * n + i]] = val[(size_t)j * n + i];
     __syncthreads();
     for (int k = 0; k < n; ++k) {
         const double piv = 1.0 / lu[(size_t)k * n + k];
@@ -187,20 +192,39 @@ __global__ __launch_bounds__(256) void k_cpr_restrict_fine(int Nb, const double*
     for (int k = 0; k < BS; ++k) s += d[(size_t)i * BS + k] * w[(size_t)i * BS + k];
     rc[i] = s;
 }
+// coarsest level without a direct solve: x = omega D^-1 b, then Jacobi sweeps x_out = x_in + omega D^-1 (b - A x_in)
 __global__ __launch_bounds__(256) void k_cpr_presmooth(int n, double omega, const double* __restrict__ dinv, const double* __restrict__ b, double* __restrict__ x,
                                                        const double* __restrict__ done) {
     CPR_DONE_CHECK
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n) x[i] = omega * dinv[i] * b[i];
 }
-__global__ __launch_bounds__(256) void k_cpr_residual(int n, const int* __restrict__ rowptr, const int* __restrict__ col, const double* __restrict__ val,
-                                                      const double* __restrict__ b, const double* __restrict__ x, double* __restrict__ r,
-                                                      const double* __restrict__ done) {
+__global__ __launch_bounds__(256) void k_cpr_jacobi(int n, int W, double omega, const int* __restrict__ ecol, const double* __restrict__ val,
+                                                    const double* __restrict__ dinv, const double* __restrict__ b, const double* __restrict__ xin,
+                                                    double* __restrict__ xout, const double* __restrict__ done) {
     CPR_DONE_CHECK
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     double s = b[i];
-    for (int k = rowptr[i]; k < rowptr[i + 1]; ++k) s -= val[k] * x[col[k]];
+#pragma unroll 4
+    for (int j = 0; j < W; ++j) s -= val[(size_t)j * n + i] * xin[ecol[(size_t)j * n + i]];
+    xout[i] = xin[i] + omega * dinv[i] * s;
+}
+// going down: pre-smoothing from x = 0 (x = omega D^-1 b) and the residual r = b - A x in one pass - the neighbours'
+// x_j = omega dinv_j b_j are formed on the fly (the same expression, hence the same bits, as the stored x_j)
+__global__ __launch_bounds__(256) void k_cpr_down(int n, int W, double omega, const int* __restrict__ ecol, const double* __restrict__ val,
+                                                  const double* __restrict__ dinv, const double* __restrict__ b, double* __restrict__ x,
+                                                  double* __restrict__ r, const double* __restrict__ done) {
+    CPR_DONE_CHECK
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    double s = b[i];
+#pragma unroll 4
+    for (int j = 0; j < W; ++j) {
+        const int c = ecol[(size_t)j * n + i];
+        s -= val[(size_t)j * n + i] * (omega * dinv[c] * b[c]);
+    }
+    x[i] = omega * dinv[i] * b[i];
     r[i] = s;
 }
 __global__ __launch_bounds__(256) void k_cpr_restrict(int nc, const int* __restrict__ mptr, const int* __restrict__ midx, const double* __restrict__ r,
@@ -212,17 +236,24 @@ __global__ __launch_bounds__(256) void k_cpr_restrict(int nc, const int* __restr
     for (int q = mptr[I]; q < mptr[I + 1]; ++q) s += r[midx[q]];
     rc[I] = s;
 }
-__global__ __launch_bounds__(256) void k_cpr_prolong(int n, double damp, const int* __restrict__ agg, const double* __restrict__ xc, double* __restrict__ x,
-                                                     const double* __restrict__ done) {
+// going up: damped piecewise-constant prolongation x' = x + damp xc[agg], residual of x', post-smoothing
+// xout = x' + omega D^-1 (b - A x') in one pass (x'_j of the neighbours formed on the fly, result into a second buffer)
+__global__ __launch_bounds__(256) void k_cpr_up(int n, int W, double omega, double damp, const int* __restrict__ ecol, const double* __restrict__ val,
+                                                const double* __restrict__ dinv, const int* __restrict__ agg, const double* __restrict__ xc,
+                                                const double* __restrict__ b, const double* __restrict__ x, double* __restrict__ xout,
+                                                const double* __restrict__ done) {
     CPR_DONE_CHECK
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < n) x[i] += damp * xc[agg[i]];
-}
-__global__ __launch_bounds__(256) void k_cpr_smooth_update(int n, double omega, const double* __restrict__ dinv, const double* __restrict__ r,
-                                                           double* __restrict__ x, const double* __restrict__ done) {
-    CPR_DONE_CHECK
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < n) x[i] += omega * dinv[i] * r[i];
+    if (i >= n) return;
+    double s = b[i];
+#pragma unroll 4
+    for (int j = 0; j < W; ++j) {
+        const int c = ecol[(size_t)j * n + i];
+        const double xp = x[c] + damp * xc[agg[c]];
+        s -= val[(size_t)j * n + i] * xp;
+    }
+    const double xi = x[i] + damp * xc[agg[i]];
+    xout[i] = xi + omega * dinv[i] * s;
 }
 // v = (0, x_p, 0)  (moveToFineLevel: the pressure component only)
 __global__ __launch_bounds__(256) void k_cpr_prolong_fine(int Nb, const double* __restrict__ xc, double* __restrict__ v, const double* __restrict__ done) {
@@ -246,6 +277,39 @@ __global__ __launch_bounds__(256) void k_cpr_add(int n, double* __restrict__ v, 
 static inline dim3 g256(int n) { return dim3((n + 255) / 256); }
 
 // ---------------------------------------------------------------- setup --------------------------------------------------
+constexpr int CPR_MAX_W = 96;   // longest row an ELL level may have
+// ELL image of a level's pattern: columns (padding: the row itself), row lengths, position of the diagonal, position of every
+// CSR entry
+static int upload_ell(opmhip_ctx* c, const HCsr& A, CprLevelDev& L, std::vector<int>& pos) {
+    const int n = A.n;
+    int W = 1;
+    for (int i = 0; i < n; ++i) W = std::max(W, A.rowptr[i + 1] - A.rowptr[i]);
+    if (W > CPR_MAX_W) return fail(c, OPMHIP_ANALYSIS_FAILED, "cpr: a row of a pressure-AMG level has %d entries (limit %d)", W, CPR_MAX_W);
+    L.n = n; L.nnz = (int)A.col.size(); L.W = W;
+    std::vector<int> ecol((size_t)W * n), rlen(n), diag(n, 0);
+    pos.resize(A.col.size());
+    for (int i = 0; i < n; ++i) {
+        const int kb = A.rowptr[i], len = A.rowptr[i + 1] - kb;
+        rlen[i] = len;
+        for (int j = 0; j < W; ++j) ecol[(size_t)j * n + i] = j < len ? A.col[kb + j] : i;
+        for (int j = 0; j < len; ++j) {
+            pos[kb + j] = j * n + i;
+            if (A.col[kb + j] == i) diag[i] = j * n + i;
+        }
+    }
+    int rc;
+    if ((rc = dev_upload(c, &L.d_ecol, ecol))) return rc;
+    if ((rc = dev_upload(c, &L.d_rlen, rlen))) return rc;
+    if ((rc = dev_upload(c, &L.d_diag, diag))) return rc;
+    if ((rc = dev_alloc(c, &L.d_val, (size_t)W * n))) return rc;
+    OPMHIP_HIP(c, hipMemset(L.d_val, 0, (size_t)W * n * sizeof(double)));   // the padding stays 0 for good
+    if ((rc = dev_alloc(c, &L.d_dinv, (size_t)n))) return rc;
+    if ((rc = dev_alloc(c, &L.d_b, (size_t)n))) return rc;
+    if ((rc = dev_alloc(c, &L.d_x, (size_t)n))) return rc;
+    if ((rc = dev_alloc(c, &L.d_x2, (size_t)n))) return rc;
+    if ((rc = dev_alloc(c, &L.d_r, (size_t)n))) return rc;
+    return OPMHIP_SUCCESS;
+}
 // structure of the hierarchy, once per context, from the values of the pressure matrix of the system now on the device
 static int cpr_setup_structure(opmhip_ctx* c) {
     const Pattern& P = c->pat;
@@ -257,24 +321,21 @@ static int cpr_setup_structure(opmhip_ctx* c) {
     if ((rc = dev_alloc(c, &R.d_y, (size_t)P.Nb * BS))) return rc;
     if ((rc = dev_alloc(c, &R.d_z, (size_t)P.Nb * BS))) return rc;
     // level 0: the block pattern itself (internal order), values = pressure matrix
-    CprLevelDev L0;
-    L0.n = P.Nb; L0.nnz = P.nnzb;
-    L0.d_rowptr = P.d_rowptr; L0.d_col = P.d_col; L0.d_diag = P.d_diag;
-    if ((rc = dev_alloc(c, &L0.d_val, (size_t)P.nnzb))) return rc;
-    hipLaunchKernelGGL(k_cpr_weights, g256(P.Nb), dim3(256), 0, c->stream, P.Nb, P.d_diag, c->d_A, R.d_w);
-    hipLaunchKernelGGL(k_cpr_pvals, g256(P.Nb), dim3(256), 0, c->stream, P.Nb, P.d_rowptr, c->d_A, R.d_w, L0.d_val);
     HCsr A;
     A.n = P.Nb; A.rowptr = P.rowptr; A.col = P.col; A.val.resize(P.nnzb);
-    OPMHIP_HIP(c, hipMemcpyAsync(A.val.data(), L0.d_val, (size_t)P.nnzb * sizeof(double), hipMemcpyDeviceToHost, c->stream));
-    OPMHIP_HIP(c, hipStreamSynchronize(c->stream));
     R.lv.clear();
-    R.lv.push_back(L0);
+    R.lv.emplace_back();
+    std::vector<int> pos;   // ELL position of every CSR entry of the level being coarsened
+    if ((rc = upload_ell(c, A, R.lv[0], pos))) return rc;
+    hipLaunchKernelGGL(k_cpr_weights, g256(P.Nb), dim3(256), 0, c->stream, P.Nb, P.d_diag, c->d_A, R.d_w);
+    hipLaunchKernelGGL(k_cpr_pvals, g256(P.Nb), dim3(256), 0, c->stream, P.Nb, P.d_rowptr, c->d_A, R.d_w, R.lv[0].d_val);
+    {
+        std::vector<double> ell((size_t)R.lv[0].W * P.Nb);
+        OPMHIP_HIP(c, hipMemcpyAsync(ell.data(), R.lv[0].d_val, ell.size() * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+        OPMHIP_HIP(c, hipStreamSynchronize(c->stream));
+        for (int k = 0; k < P.nnzb; ++k) A.val[k] = ell[pos[k]];
+    }
     while (true) {
-        CprLevelDev& L = R.lv.back();
-        if ((rc = dev_alloc(c, &L.d_dinv, (size_t)L.n))) return rc;
-        if ((rc = dev_alloc(c, &L.d_b, (size_t)L.n))) return rc;
-        if ((rc = dev_alloc(c, &L.d_x, (size_t)L.n))) return rc;
-        if ((rc = dev_alloc(c, &L.d_r, (size_t)L.n))) return rc;
         const bool last = A.n <= CPR_COARSE_DIRECT || (int)R.lv.size() >= CPR_MAX_LEVELS;
         if (last) break;
         std::vector<int> a1, a2, g1p, g1i;
@@ -293,6 +354,7 @@ static int cpr_setup_structure(opmhip_ctx* c) {
         HCsr Ac;
         std::vector<int> gptr, gidx;
         galerkin(A, agg, n2, Ac, gptr, gidx);
+        for (int& g : gidx) g = pos[g];                       // gather lists address the fine level's ELL array
         std::vector<int> mptr(n2 + 1, 0), midx(A.n);
         for (int i = 0; i < A.n; ++i) mptr[agg[i] + 1]++;
         for (int I = 0; I < n2; ++I) mptr[I + 1] += mptr[I];
@@ -300,23 +362,20 @@ static int cpr_setup_structure(opmhip_ctx* c) {
             std::vector<int> wpos(mptr.begin(), mptr.end() - 1);
             for (int i = 0; i < A.n; ++i) midx[wpos[agg[i]]++] = i;
         }
-        L.nc = n2;
-        if ((rc = dev_upload(c, &L.d_agg, agg))) return rc;
-        if ((rc = dev_upload(c, &L.d_mptr, mptr))) return rc;
-        if ((rc = dev_upload(c, &L.d_midx, midx))) return rc;
-        if ((rc = dev_upload(c, &L.d_gptr, gptr))) return rc;
-        if ((rc = dev_upload(c, &L.d_gidx, gidx))) return rc;
-        CprLevelDev C;
-        C.n = n2; C.nnz = (int)Ac.col.size();
-        std::vector<int> diag(n2, 0);
-        for (int i = 0; i < n2; ++i)
-            for (int k = Ac.rowptr[i]; k < Ac.rowptr[i + 1]; ++k)
-                if (Ac.col[k] == i) diag[i] = k;
-        if ((rc = dev_upload(c, &C.d_rowptr, Ac.rowptr))) return rc;
-        if ((rc = dev_upload(c, &C.d_col, Ac.col))) return rc;
-        if ((rc = dev_upload(c, &C.d_diag, diag))) return rc;
-        if ((rc = dev_alloc(c, &C.d_val, (size_t)C.nnz))) return rc;
-        R.lv.push_back(C);   // invalidates L
+        {
+            CprLevelDev& L = R.lv.back();
+            L.nc = n2;
+            if ((rc = dev_upload(c, &L.d_agg, agg))) return rc;
+            if ((rc = dev_upload(c, &L.d_mptr, mptr))) return rc;
+            if ((rc = dev_upload(c, &L.d_midx, midx))) return rc;
+            if ((rc = dev_upload(c, &L.d_gptr, gptr))) return rc;
+            if ((rc = dev_upload(c, &L.d_gidx, gidx))) return rc;
+        }
+        R.lv.emplace_back();
+        std::vector<int> cposv;
+        if ((rc = upload_ell(c, Ac, R.lv.back(), cposv))) return rc;
+        if ((rc = dev_upload(c, &R.lv[R.lv.size() - 2].d_cpos, cposv))) return rc;   // where the coarse entries go
+        pos = cposv;
         A = std::move(Ac);
     }
     R.coarse_direct = R.lv.back().n <= CPR_COARSE_DIRECT;
@@ -339,42 +398,43 @@ int cpr_update(opmhip_ctx* c) {
         hipLaunchKernelGGL(k_cpr_dinv, g256(L.n), dim3(256), 0, c->stream, L.n, L.d_diag, L.d_val, L.d_dinv);
         if (l + 1 < R.lv.size()) {
             CprLevelDev& C = R.lv[l + 1];
-            hipLaunchKernelGGL(k_cpr_galerkin, g256(C.nnz), dim3(256), 0, c->stream, C.nnz, L.d_gptr, L.d_gidx, L.d_val, C.d_val);
+            hipLaunchKernelGGL(k_cpr_galerkin, g256(C.nnz), dim3(256), 0, c->stream, C.nnz, L.d_gptr, L.d_gidx, L.d_cpos, L.d_val, C.d_val);
         }
     }
     if (R.coarse_direct) {
         const CprLevelDev& C = R.lv.back();
-        hipLaunchKernelGGL(k_cpr_dense_lu, dim3(1), dim3(256), 0, c->stream, C.n, C.d_rowptr, C.d_col, C.d_val, R.d_lu);
+        hipLaunchKernelGGL(k_cpr_dense_lu, dim3(1), dim3(256), 0, c->stream, C.n, C.W, C.d_ecol, C.d_rlen, C.d_val, R.d_lu);
     }
     prof_end(c, ps);
     OPMHIP_HIP(c, hipGetLastError());
     return OPMHIP_SUCCESS;
 }
 
-static void cpr_vcycle(opmhip_ctx* c, size_t l) {
+// one V(1,1) cycle on level l from x = 0; returns the buffer that holds the level's result
+static const double* cpr_vcycle(opmhip_ctx* c, size_t l) {
     CprDev& R = c->cpr;
     CprLevelDev& L = R.lv[l];
     const double* done = c->d_done;
     if (l + 1 == R.lv.size()) {
         if (R.coarse_direct) {
             hipLaunchKernelGGL(k_cpr_dense_solve, dim3(1), dim3(64), 0, c->stream, L.n, R.d_lu, L.d_b, L.d_x, done);
-        } else {   // could not coarsen further: Jacobi sweeps stand in for the coarse solve (oracle/cpr.hpp: 1 + 4)
-            hipLaunchKernelGGL(k_cpr_presmooth, g256(L.n), dim3(256), 0, c->stream, L.n, R.omega, L.d_dinv, L.d_b, L.d_x, done);
-            for (int sweep = 0; sweep < 4; ++sweep) {
-                hipLaunchKernelGGL(k_cpr_residual, g256(L.n), dim3(256), 0, c->stream, L.n, L.d_rowptr, L.d_col, L.d_val, L.d_b, L.d_x, L.d_r, done);
-                hipLaunchKernelGGL(k_cpr_smooth_update, g256(L.n), dim3(256), 0, c->stream, L.n, R.omega, L.d_dinv, L.d_r, L.d_x, done);
-            }
+            return L.d_x;
         }
-        return;
+        // could not coarsen further: Jacobi sweeps stand in for the coarse solve (oracle/cpr.hpp: 1 + 4)
+        hipLaunchKernelGGL(k_cpr_presmooth, g256(L.n), dim3(256), 0, c->stream, L.n, R.omega, L.d_dinv, L.d_b, L.d_x, done);
+        double *xin = L.d_x, *xout = L.d_x2;
+        for (int sweep = 0; sweep < 4; ++sweep) {
+            hipLaunchKernelGGL(k_cpr_jacobi, g256(L.n), dim3(256), 0, c->stream, L.n, L.W, R.omega, L.d_ecol, L.d_val, L.d_dinv, L.d_b, xin, xout, done);
+            std::swap(xin, xout);
+        }
+        return xin;
     }
     CprLevelDev& C = R.lv[l + 1];
-    hipLaunchKernelGGL(k_cpr_presmooth, g256(L.n), dim3(256), 0, c->stream, L.n, R.omega, L.d_dinv, L.d_b, L.d_x, done);
-    hipLaunchKernelGGL(k_cpr_residual, g256(L.n), dim3(256), 0, c->stream, L.n, L.d_rowptr, L.d_col, L.d_val, L.d_b, L.d_x, L.d_r, done);
+    hipLaunchKernelGGL(k_cpr_down, g256(L.n), dim3(256), 0, c->stream, L.n, L.W, R.omega, L.d_ecol, L.d_val, L.d_dinv, L.d_b, L.d_x, L.d_r, done);
     hipLaunchKernelGGL(k_cpr_restrict, g256(L.nc), dim3(256), 0, c->stream, L.nc, L.d_mptr, L.d_midx, L.d_r, C.d_b, done);
-    cpr_vcycle(c, l + 1);
-    hipLaunchKernelGGL(k_cpr_prolong, g256(L.n), dim3(256), 0, c->stream, L.n, R.damp, L.d_agg, C.d_x, L.d_x, done);
-    hipLaunchKernelGGL(k_cpr_residual, g256(L.n), dim3(256), 0, c->stream, L.n, L.d_rowptr, L.d_col, L.d_val, L.d_b, L.d_x, L.d_r, done);
-    hipLaunchKernelGGL(k_cpr_smooth_update, g256(L.n), dim3(256), 0, c->stream, L.n, R.omega, L.d_dinv, L.d_r, L.d_x, done);
+    const double* xc = cpr_vcycle(c, l + 1);
+    hipLaunchKernelGGL(k_cpr_up, g256(L.n), dim3(256), 0, c->stream, L.n, L.W, R.omega, R.damp, L.d_ecol, L.d_val, L.d_dinv, L.d_agg, xc, L.d_b, L.d_x, L.d_x2, done);
+    return L.d_x2;
 }
 
 // v = M_cpr^-1 d (TwoLevelMethodCpr::apply)
@@ -385,8 +445,8 @@ void launch_cpr_apply(opmhip_ctx* c, const double* d, double* v) {
     const double* done = c->d_done;
     int ps = prof_begin(c, PROF_CPR_AMG);
     hipLaunchKernelGGL(k_cpr_restrict_fine, g256(P.Nb), dim3(256), 0, c->stream, P.Nb, d, R.d_w, R.lv[0].d_b, done);
-    cpr_vcycle(c, 0);
-    hipLaunchKernelGGL(k_cpr_prolong_fine, g256(n), dim3(256), 0, c->stream, P.Nb, R.lv[0].d_x, v, done);
+    const double* xp = cpr_vcycle(c, 0);
+    hipLaunchKernelGGL(k_cpr_prolong_fine, g256(n), dim3(256), 0, c->stream, P.Nb, xp, v, done);
     prof_end(c, ps);
     launch_spmv(c, v, R.d_y, 0, nullptr, nullptr);                      // post-smoothing on the updated residual
     ps = prof_begin(c, PROF_VECTOR);

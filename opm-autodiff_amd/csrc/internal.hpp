@@ -137,9 +137,10 @@ struct CommDev {
 
 // CPR preconditioner (cpr.hip): pressure-AMG hierarchy, level 0 = the block pattern with scalar values
 struct CprLevelDev {
-    int n = 0, nnz = 0, nc = 0;
-    int *d_rowptr = nullptr, *d_col = nullptr, *d_diag = nullptr;
-    double *d_val = nullptr, *d_dinv = nullptr;
+    int n = 0, nnz = 0, nc = 0, W = 0;                              // W: longest row = width of the ELL image
+    int *d_ecol = nullptr, *d_rlen = nullptr, *d_diag = nullptr;    // ELL columns [W x n], row lengths, ELL position of the diagonal
+    int* d_cpos = nullptr;                                          // ELL position (next level) of every coarse entry
+    double *d_val = nullptr, *d_dinv = nullptr, *d_x2 = nullptr;    // ELL values [W x n]
     int *d_agg = nullptr, *d_mptr = nullptr, *d_midx = nullptr;   // node -> aggregate, members of every aggregate
     int *d_gptr = nullptr, *d_gidx = nullptr;                      // Galerkin gather lists for the next level's entries
     double *d_b = nullptr, *d_x = nullptr, *d_r = nullptr;         // level vectors
