@@ -131,6 +131,7 @@ int opmhip_set_static(opmhip_ctx* c, const double* trans, const double* area, co
             if ((rc = dev_alloc(c, &A.d_pv, Nb * 3))) return rc;
             if ((rc = dev_alloc(c, &A.d_iq, Nb * (size_t)iq_doubles_per_cell(c)))) return rc;
             if ((rc = dev_alloc(c, &A.d_storageOld, Nb * 3))) return rc;
+            if ((rc = dev_alloc(c, &A.d_invb, Nb * 3))) return rc;
             if ((rc = dev_alloc(c, &A.d_drift, Nb * 3))) return rc;
             OPMHIP_HIP(c, hipMemset(A.d_drift, 0, Nb * 3 * sizeof(double)));
             if ((rc = dev_alloc(c, &A.d_source, Nb * 3))) return rc;

@@ -97,6 +97,7 @@ struct AsmDev {
     bool ext = false;       // extended intensive-quantity record (wet gas and / or ROCKTAB): 19 fields instead of 17
     double *d_rvmax = nullptr, *d_overburden = nullptr;   // per cell: DRVDT cap, overburden pressure (optional)
     int* d_rocknum = nullptr;                             // per cell rock-table index (optional)
+    double* d_invb = nullptr;                             // packed 1/b per cell and phase (Nloc x 3), for the convergence check
     double *d_trans = nullptr, *d_area = nullptr, *d_thpres = nullptr;                      // per entry
     unsigned char* d_lowFirst = nullptr;  // per entry (I,J): global id of I < global id of J (upwind tie-break)
     double *d_poro = nullptr, *d_volume = nullptr, *d_depth = nullptr, *d_rsmax = nullptr;  // per cell
