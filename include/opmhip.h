@@ -253,6 +253,11 @@ int opmhip_set_problem_extras(opmhip_ctx* ctx, const double* rvmax, const int* r
 int opmhip_fluid_probe(opmhip_ctx* ctx, int pvt_region, int sat_region, int n, const double* p, const double* rs,
                        const double* sw, const double* sg, double* out);
 
+/* The gas-phase functions at (p_g, Rv) the same way: out[3 i + 0..2] = 1/B_g, mu_g (on the saturated curve where
+ * Rv >= RvSat(p_g), as the equilibration's gas density does, initstateequil.hh:240-285), RvSat(p_g).  Dry-gas fluids:
+ * 1/B_g(p), mu_g(p), 0. */
+int opmhip_gas_probe(opmhip_ctx* ctx, int pvt_region, int n, const double* p, const double* rv, double* out);
+
 /* replaces: model().solution(0) = ... ; model().invalidateAndUpdateIntensiveQuantities(0)
  * (flow/BlackoilModelEbos.hpp:552-562).  pv: Nb x 3 (Sw, p_o, Sg|Rs), meaning: Nb bytes. Natural order. */
 int opmhip_set_state(opmhip_ctx* ctx, const double* pv, const unsigned char* meaning);

@@ -295,6 +295,7 @@ def _bind_assembly(L):
     L.opmhip_set_cell_global_ids.argtypes = [vp, vp]
     L.opmhip_fluid_probe.argtypes = [vp, C.c_int, C.c_int, C.c_int, vp, vp, vp, vp, vp]
     L.opmhip_set_problem_extras.argtypes = [vp, vp, vp, vp]
+    L.opmhip_gas_probe.argtypes = [vp, C.c_int, C.c_int, vp, vp, vp]
     L.opmhip_iq_fields.argtypes = [vp]
 
 
@@ -322,6 +323,19 @@ class HipFluid(HipSolver):
         out = np.empty((n, 8))
         self._check(lib().opmhip_fluid_probe(self._h, pvt_region, sat_region, n, _ptr(a[0]), _ptr(a[1]), _ptr(a[2]), _ptr(a[3]), _ptr(out)))
         return out
+
+
+def _probe_gas(self, p, rv=0.0, pvt_region=0):
+    """-> array (n, 3): 1/B_g(p, rv) and mu_g(p, rv) (saturated curve where rv >= RvSat(p)), RvSat(p)"""
+    p = np.atleast_1d(np.asarray(p, np.float64))
+    n = len(p)
+    a = [np.ascontiguousarray(np.broadcast_to(np.asarray(v, np.float64), (n,))) for v in (p, rv)]
+    out = np.empty((n, 3))
+    self._check(lib().opmhip_gas_probe(self._h, pvt_region, n, _ptr(a[0]), _ptr(a[1]), _ptr(out)))
+    return out
+
+
+HipFluid.probe_gas = _probe_gas
 
 
 class HipModel(HipSolver):

@@ -494,6 +494,36 @@ __global__ __launch_bounds__(256) void k_fluid_probe(Tables T, int pr, int sr, i
     o[5] = pwlin<double, GlobalTab>(B + Sd.so_x, B + Sd.pcgo, Sd.ng, 1.0 - Swco - sg[i]);
     o[7] = o[1] / (wetg ? tab1<double, GlobalTab>(B + D.wg_xs, B + D.wgs_invBMu, D.wg_n, pi) : tab1<double, GlobalTab>(B + D.gas_p, B + D.gas_invBMu, D.gas_n, pi));
 }
+// opmhip_gas_probe: wet-gas functions at (p_g, Rv): 1/B_g and mu_g on the saturated curve where Rv >= RvSat(p_g), else the
+// undersaturated 2-D tables; RvSat(p_g).  Dry gas: 1/B_g(p), mu_g(p), 0.
+__global__ __launch_bounds__(256) void k_gas_probe(Tables T, int pr, int n, const double* __restrict__ p, const double* __restrict__ rv,
+                                                   double* __restrict__ out) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const PvtRegionDesc& D = T.pvt(pr);
+    const GlobalTab B = T.dbl;
+    double* o = out + (size_t)i * 3;
+    const double pi = p[i], rvi = rv[i];
+    if (D.wg_n > 0) {
+        const double RvSat = rv_sat_value(T, pr, pi);
+        o[2] = RvSat;
+        if (rvi >= RvSat) {
+            o[0] = tab1<double, GlobalTab>(B + D.wg_xs, B + D.wgs_invB, D.wg_n, pi);
+            o[1] = o[0] / tab1<double, GlobalTab>(B + D.wg_xs, B + D.wgs_invBMu, D.wg_n, pi);
+        } else {
+            o[0] = tab2wg<double, GlobalTab>(T, D, D.wg_invB, pi, rvi);
+            o[1] = o[0] / tab2wg<double, GlobalTab>(T, D, D.wg_invBMu, pi, rvi);
+        }
+    } else {
+        o[0] = tab1<double, GlobalTab>(B + D.gas_p, B + D.gas_invB, D.gas_n, pi);
+        o[1] = o[0] / tab1<double, GlobalTab>(B + D.gas_p, B + D.gas_invBMu, D.gas_n, pi);
+        o[2] = 0.0;
+    }
+}
+int launch_gas_probe(opmhip_ctx* c, int pr, int n, const double* d_in, double* d_out) {
+    hipLaunchKernelGGL(k_gas_probe, dim3((n + 255) / 256), dim3(256), 0, c->stream, tables_of(c), pr, n, d_in, d_in + n, d_out);
+    return OPMHIP_SUCCESS;
+}
 int launch_fluid_probe(opmhip_ctx* c, int pr, int sr, int n, const double* d_in, double* d_out) {
     hipLaunchKernelGGL(k_fluid_probe, dim3((n + 255) / 256), dim3(256), 0, c->stream, tables_of(c), pr, sr, n, d_in, d_in + n, d_in + 2 * (size_t)n,
                        d_in + 3 * (size_t)n, d_out);

@@ -262,6 +262,28 @@ int opmhip_fluid_probe(opmhip_ctx* c, int pvt_region, int sat_region, int n, con
     });
 }
 
+int opmhip_gas_probe(opmhip_ctx* c, int pvt_region, int n, const double* p, const double* rv, double* out) {
+    if (!c) return OPMHIP_INVALID_ARGUMENT;
+    return guarded(c, [&]() -> int {
+        AsmDev& A = c->asmb;
+        if (!A.fluid_set) return fail(c, OPMHIP_NOT_READY, "gas_probe before set_fluid");
+        if (n < 0 || (n > 0 && (!p || !rv || !out))) return fail(c, OPMHIP_INVALID_ARGUMENT, "gas_probe: null array");
+        if (pvt_region < 0 || pvt_region >= A.num_pvt) return fail(c, OPMHIP_INVALID_ARGUMENT, "gas_probe: region out of range");
+        if (n == 0) return OPMHIP_SUCCESS;
+        OPMHIP_HIP(c, hipSetDevice(c->device));
+        struct Scratch { double *in = nullptr, *out = nullptr; ~Scratch() { if (in) (void)hipFree(in); if (out) (void)hipFree(out); } } S;
+        OPMHIP_HIP(c, hipMalloc((void**)&S.in, (size_t)2 * n * sizeof(double)));
+        OPMHIP_HIP(c, hipMalloc((void**)&S.out, (size_t)3 * n * sizeof(double)));
+        OPMHIP_HIP(c, hipMemcpyAsync(S.in, p, (size_t)n * sizeof(double), hipMemcpyHostToDevice, c->stream));
+        OPMHIP_HIP(c, hipMemcpyAsync(S.in + n, rv, (size_t)n * sizeof(double), hipMemcpyHostToDevice, c->stream));
+        launch_gas_probe(c, pvt_region, n, S.in, S.out);
+        OPMHIP_HIP(c, hipGetLastError());
+        OPMHIP_HIP(c, hipMemcpyAsync(out, S.out, (size_t)3 * n * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+        OPMHIP_HIP(c, hipStreamSynchronize(c->stream));
+        return OPMHIP_SUCCESS;
+    });
+}
+
 int opmhip_set_state(opmhip_ctx* c, const double* pv, const unsigned char* meaning) {
     if (!c) return OPMHIP_INVALID_ARGUMENT;
     return guarded(c, [&]() -> int {

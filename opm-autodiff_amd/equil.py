@@ -98,11 +98,72 @@ class RsVD:
         return min(sat, float(np.interp(depth, self.d, self.rs)))
 
 
-def equilibrate(props, rho_ref, rec, cell_depth, z_span, sat_limits, grav=9.80665, rs_func=None, nsample=NSAMPLE):
+class PBVD:
+    """Rs = RsSat(min(bubble-point pressure at this depth, cell pressure)) (PBVD, :256-322)"""
+
+    def __init__(self, props, depth, pbub):
+        self.props, self.d, self.pb = props, np.asarray(depth, float), np.asarray(pbub, float)
+
+    def __call__(self, depth, p, sat_gas=0.0):
+        press = p
+        if sat_gas <= 0.0:
+            press = float(self.pb[0]) if self.d[0] > depth else float(self.pb[-1]) if self.d[-1] < depth else float(np.interp(depth, self.d, self.pb))
+        return float(self.props.probe(min(press, p))[0, RSSAT])
+
+
+def _rv_sat(props, p):
+    return float(props.probe_gas(p)[0, 2])
+
+
+class RvSatAtContact:
+    """min(RvSat(p), RvSat(p at the gas-oil contact)); the saturated value where oil is present (:540-607)"""
+
+    def __init__(self, props, p_contact):
+        self.props = props
+        self.rv_contact = _rv_sat(props, p_contact)
+
+    def __call__(self, depth, p, sat_oil=0.0):
+        if sat_oil > 0.0:
+            return _rv_sat(self.props, p)
+        return min(_rv_sat(self.props, p), self.rv_contact)
+
+
+class RvVD:
+    """Rv from a depth table (RVVD), capped by RvSat(p) (:393-468)"""
+
+    def __init__(self, props, depth, rv):
+        self.props, self.d, self.rv = props, np.asarray(depth, float), np.asarray(rv, float)
+
+    def __call__(self, depth, p, sat_oil=0.0):
+        if abs(sat_oil) > 1e-16:
+            return _rv_sat(self.props, p)
+        if self.d[0] > depth:
+            return float(self.rv[0])
+        if self.d[-1] < depth:
+            return float(self.rv[-1])
+        return min(_rv_sat(self.props, p), float(np.interp(depth, self.d, self.rv)))
+
+
+class PDVD:
+    """Rv = RvSat(min(dew-point pressure at this depth, cell pressure)) (PDVD, :324-391)"""
+
+    def __init__(self, props, depth, pdew):
+        self.props, self.d, self.pd = props, np.asarray(depth, float), np.asarray(pdew, float)
+
+    def __call__(self, depth, p, sat_oil=0.0):
+        press = p
+        if sat_oil <= 0.0:
+            press = float(self.pd[0]) if self.d[0] > depth else float(self.pd[-1]) if self.d[-1] < depth else float(np.interp(depth, self.d, self.pd))
+        return _rv_sat(self.props, min(press, p))
+
+
+def equilibrate(props, rho_ref, rec, cell_depth, z_span, sat_limits, grav=9.80665, rs_func=None, nsample=NSAMPLE, rv_func=None):
     """props.probe(p, rs, sw, sg) -> (n, 8) (capi.HipFluid layout); rho_ref = (oil, water, gas) surface densities;
     rec = dict(datum, pressure, zwoc, pcow_woc, zgoc, pcgo_goc); cell_depth[]: centre depths; z_span = (top, bottom) of the
     region's cells; sat_limits = dict(Swl, Swu, Sgl, Sgu) (unscaled end points of the saturation tables).
-    -> dict(pw, po, pg, sw, so, sg, rs) arrays over the cells."""
+    rv_func (wet gas, VAPOIL): Rv(depth, p_g, sat_oil) - RvSatAtContact / RvVD / PDVD; props then also needs
+    probe_gas(p, rv) -> (n, 3): 1/B_g(p, rv), mu_g, RvSat(p).
+    -> dict(pw, po, pg, sw, so, sg, rs, rv) arrays over the cells."""
     rho_o, rho_w, rho_g = rho_ref
     if rs_func is None:
         if rec["zgoc"] != rec["datum"]:
@@ -118,7 +179,12 @@ def equilibrate(props, rho_ref, rec, cell_depth, z_span, sat_limits, grav=9.8066
         return (b * rho_o + rs * b * rho_g) * grav
 
     def f_gas(z, p):
-        return float(props.probe(p)[0, INVBG]) * rho_g * grav
+        if rv_func is None:
+            return float(props.probe(p)[0, INVBG]) * rho_g * grav
+        # PhasePressODE::Gas (initstateequil.hh:240-285): vaporised oil adds to the gas density
+        rv = rv_func(z, p)
+        b = float(props.probe_gas(p, rv)[0, 0])       # saturated curve where rv >= RvSat(p)
+        return (b * rho_g + rv * b * rho_o) * grav
 
     span = (min(z_span[0], rec["zgoc"], rec["zwoc"]), max(z_span[1], rec["zgoc"], rec["zwoc"]))
     mk = lambda ode, z0, p0: PressureFunction(ode, z0, p0, span, nsample)
@@ -163,7 +229,7 @@ def equilibrate(props, rho_ref, rec, cell_depth, z_span, sat_limits, grav=9.8066
         return root(lambda s: pc_of_s(s) - target, s0, s1)
 
     n = len(cell_depth)
-    out = {k: np.zeros(n) for k in ("pw", "po", "pg", "sw", "so", "sg", "rs")}
+    out = {k: np.zeros(n) for k in ("pw", "po", "pg", "sw", "so", "sg", "rs", "rv")}
     const_pcow = abs(pcow(Swl) - pcow(Swu)) < np.finfo(float).eps
     const_pcgo = abs(pcgo(Sgl) - pcgo(Sgu)) < np.finfo(float).eps
     for c, z in enumerate(cell_depth):
@@ -196,4 +262,5 @@ def equilibrate(props, rho_ref, rec, cell_depth, z_span, sat_limits, grav=9.8066
         out["pw"][c], out["po"][c], out["pg"][c] = pw, po, pg
         out["sw"][c], out["so"][c], out["sg"][c] = sw, so, sg
         out["rs"][c] = rs_func(z, po, sg)
+        out["rv"][c] = rv_func(z, pg, so) if rv_func is not None else 0.0
     return out

@@ -8,7 +8,7 @@ import json
 import os
 import re
 
-from make_fluid_fixtures import METRIC, REF, ROOT, parse_pvto, table, tokenize
+from make_fluid_fixtures import METRIC, REF, ROOT, parse_pvtg, parse_pvto, table, tokenize
 
 
 def expected_liveoil():
@@ -104,11 +104,65 @@ def dead_oil_case(deck, test_name, next_test, gravity, sat_names, lines):
         expected=exp)
 
 
+def wet_gas_case(deck, test_name, next_test, lines):
+    """equil_livegas / equil_rsvd_and_rvvd / equil_pbvd_and_pdvd: wet gas (PVTG, VAPOIL) over dead (PVDO) or live (PVTO) oil,
+    with the optional depth tables RSVD / RVVD / PBVD / PDVD; expectations: the values tagged 'opm' and the test's own
+    tolerances (reltol in percent; saturations of the live-gas deck are checked at 100 x reltol)"""
+    k = tokenize_sections(os.path.join(REF, "tests", deck))
+    U = METRIC
+    pvtw, dens, eq = k["PVTW"][0], k["DENSITY"][0], k["EQUIL"][0]
+    dz = [v * U["length"] for v in (k["DZV"][0] if "DZV" in k else k["DZ"][0])]
+    with open(os.path.join(REF, "tests/test_equil.cc")) as f:
+        txt = f.read()
+    a = txt.index("BOOST_AUTO_TEST_CASE(%s)" % test_name)
+    b = txt.index("BOOST_AUTO_TEST_CASE(%s)" % next_test) if next_test else len(txt)
+    body = txt[a:b]
+    num = r"[-+]?\d+\.?\d*(?:[eE][-+]?\d+)?"
+    vec = lambda name: [float(t) for t in re.findall(num, re.search(name + r"\s*=?\s*\{(.*?)\};", body, re.S).group(1))]
+    reltol = float(re.search(r"const double reltol = (" + num + r");", body).group(1))
+    pr = {}
+    for name, which, val in re.findall(r"BOOST_CHECK_CLOSE\(pressures\[FluidSystem::(\w+)PhaseIdx\]\s*\[(\w+)\s*\]\s*,\s*(" + num + r")\s*,\s*reltol\);", body):
+        pr["p%s_%s" % (name[0], which)] = float(val)
+    exp = dict(source="tests/test_equil.cc:%s (%s), the values tagged 'opm'" % (lines, test_name), reltol_percent=reltol,
+               sat_reltol_percent=(100.0 * reltol if "100.*reltol" in body else reltol), **pr)
+    for key, nm in zip(("sw", "so", "sg"), ("water", "oil", "gas")):
+        exp[key] = vec(r"s_opm\[FluidSystem::" + nm + r"PhaseIdx\]")
+    if re.search(r"std::vector<double> rs_opm", body):
+        exp["rs"] = vec(r"const std::vector<double> rs_opm")
+    exp["rv"] = vec(r"const std::vector<double> rv_opm")
+    rock = k.get("ROCK", [[1.0, 0.0]])[0]
+    out = dict(
+        source="tests/%s (METRIC units converted to SI); EQUIL item 9 = 0: cell centres" % deck,
+        gravity=9.80665,
+        pvtw=dict(p_ref=pvtw[0] * U["pressure"], bw_ref=pvtw[1], cw=pvtw[2] * U["compressibility"], mu_ref=pvtw[3] * U["viscosity"],
+                  cv=pvtw[4] * U["compressibility"]),
+        rock=dict(p_ref=rock[0] * U["pressure"], cr=rock[1] * U["compressibility"]),
+        density=dict(oil=dens[0] * U["density"], water=dens[1] * U["density"], gas=dens[2] * U["density"]),
+        swof=[[r[0], r[1], r[2], r[3] * U["pressure"]] for r in table(k["SWOF"][0], 4)],
+        sgof=[[r[0], r[1], r[2], r[3] * U["pressure"]] for r in table(k["SGOF"][0], 4)],
+        pvtg=parse_pvtg(k["PVTG"], U)[0],
+        grid=dict(nz=len(dz), dz=dz, tops=k["TOPS"][0][0] * U["length"]),
+        equil=dict(datum=eq[0] * U["length"], pressure=eq[1] * U["pressure"], zwoc=eq[2] * U["length"], pcow_woc=eq[3] * U["pressure"],
+                   zgoc=eq[4] * U["length"], pcgo_goc=eq[5] * U["pressure"], accuracy=int(eq[8])),
+        expected=exp)
+    if "PVTO" in k:
+        out["pvto"] = parse_pvto(k["PVTO"], U)[0]
+    else:
+        out["pvdo"] = [[r[0] * U["pressure"], r[1] * U["oil_fvf"], r[2] * U["viscosity"]] for r in table(k["PVDO"][0], 3)]
+    for kw, key, scale in (("RSVD", "rsvd", U["rs"]), ("RVVD", "rvvd", 1.0 / U["rs"]), ("PBVD", "pbvd", U["pressure"]), ("PDVD", "pdvd", U["pressure"])):
+        if kw in k:
+            out[key] = [[r[0] * U["length"], r[1] * scale] for r in table(k[kw][0], 2)]
+    return out
+
+
 if __name__ == "__main__":
     out = dict(liveoil=liveoil(),
                capillary=dead_oil_case("equil_capillary.DATA", "DeckWithCapillary", "DeckWithCapillaryOverlap", 10.0, r"\bs", "556-594"),
                capillary_overlap=dead_oil_case("equil_capillary_overlap.DATA", "DeckWithCapillaryOverlap", "DeckWithLiveOil", 9.80665,
-                                               r"s_opm", "596-654"))
+                                               r"s_opm", "596-654"),
+               livegas=wet_gas_case("equil_livegas.DATA", "DeckWithLiveGas", "DeckWithRSVDAndRVVD", "734-812"),
+               rsvd_rvvd=wet_gas_case("equil_rsvd_and_rvvd.DATA", "DeckWithRSVDAndRVVD", "DeckWithPBVDAndPDVD", "814-912"),
+               pbvd_pdvd=wet_gas_case("equil_pbvd_and_pdvd.DATA", "DeckWithPBVDAndPDVD", "DeckWithSwatinit", "914-1004"))
     path = os.path.join(ROOT, "tests", "golden", "equil.json")
     with open(path, "w") as f:
         json.dump(out, f, indent=1)

@@ -311,6 +311,24 @@ class OracleFluid:
         self._fd = fluid.desc()
         oracle.lib.orc_fluid_probe.argtypes = [_vp, C.c_int, C.c_int, C.c_int, _d, _d, _d, _d, _d]
 
+    def probe_gas(self, p, rv=0.0, pvt_region=0):
+        """(n, 3): 1/B_g, mu_g (saturated curve where rv >= RvSat(p)), RvSat(p); dry gas: the PVDG functions and 0"""
+        p = np.atleast_1d(np.asarray(p, np.float64))
+        n = len(p)
+        rv = np.ascontiguousarray(np.broadcast_to(np.asarray(rv, np.float64), (n,)))
+        out = np.zeros((n, 3))
+        if not getattr(self.fluid, "wet_gas", False):
+            pr = self.probe(p, pvt_region=pvt_region)
+            out[:, 0], out[:, 1] = pr[:, 1], pr[:, 7]
+            return out
+        L = self.o.lib
+        L.orc_gas_pvt_probe.argtypes = [_vp, C.c_int, C.c_int, _d, _d, _d, _d, _d]
+        mu, ib, rs = np.empty(n), np.empty(n), np.empty(n)
+        rc = L.orc_gas_pvt_probe(C.addressof(self._fd), pvt_region, n, rv, np.ascontiguousarray(p), mu, ib, rs)
+        assert rc == 0, rc
+        out[:, 0], out[:, 1], out[:, 2] = ib, mu, rs
+        return out
+
     def probe(self, p, rs=0.0, sw=0.0, sg=0.0, pvt_region=0, sat_region=0):
         p = np.atleast_1d(np.asarray(p, np.float64))
         n = len(p)

@@ -5,7 +5,7 @@ import numpy as np
 import pytest
 
 import oracle_bind
-from test_equil import check, load_case
+from test_equil import check, check_wet_gas, load_case, wet_gas_setup
 
 pytestmark = pytest.mark.gpu
 
@@ -40,3 +40,25 @@ def test_fluid_probe_argument_errors(pkg):
     s = pkg.capi.HipSolver()
     import ctypes as C
     assert pkg.capi.lib().opmhip_fluid_probe(s._h, 0, 0, 0, None, None, None, None, None) == pkg.capi.NOT_READY
+
+
+@pytest.mark.parametrize("name", ["livegas", "rsvd_rvvd", "pbvd_pdvd"])
+def test_wet_gas_decks_with_the_device_functions(pkg, name):
+    """DeckWithLiveGas / DeckWithRSVDAndRVVD / DeckWithPBVDAndPDVD (tests/test_equil.cc:734-1004) through opmhip_fluid_probe and
+    opmhip_gas_probe: pins the DEVICE's wet-gas tables (RvSat, 1/B_g(p, Rv) saturated and undersaturated) the same way"""
+    d, r = wet_gas_setup(name, lambda fl: pkg.capi.HipFluid(fl))
+    check_wet_gas(d, r)
+
+
+def test_gas_probe_bitwise_vs_oracle(pkg, orc):
+    from helpers import wetgas_fluid
+    rng = np.random.default_rng(9)
+    fl = wetgas_fluid(pkg)
+    dev, ora = pkg.capi.HipFluid(fl), oracle_bind.OracleFluid(orc, fl)
+    n = 4000
+    p = rng.uniform(20e5, 650e5, n)
+    rv = ora.probe_gas(p)[:, 2] * rng.uniform(0.0, 1.3, n)
+    assert np.array_equal(dev.probe_gas(p, rv), ora.probe_gas(p, rv))
+    dry = pkg.fluid.spe1_fluid()[0]
+    a = pkg.capi.HipFluid(dry).probe_gas(p[:50], 0.0)
+    assert np.array_equal(a[:, 0], oracle_bind.OracleFluid(orc, dry).probe(p[:50])[:, 1]) and not a[:, 2].any()
