@@ -162,7 +162,13 @@ template <class E, class DP> __device__ __forceinline__ void cap_pressures(const
 // Record of the intensive-quantity cache: fields x (value + 3 derivatives).  Two layouts, chosen per context when the
 // fluid is set: the BASE one (live oil + dry gas + water: 17 fields) and the EXTENDED one (19 fields) for decks with wet
 // gas (PVTG: Rv) and / or rock compaction tables (ROCKTAB: transmissibility multiplier).  Kernels are templated on it, so
-// that the base instantiation is bit for bit and byte for byte what it was.
+// that the base instantiation computes bit for bit what it did.
+// The cache is stored FIELD-MAJOR: field f of cell c = the four doubles at iq[(f * ncell + c) * 4].  Lanes that walk
+// consecutive cells (the per-cell kernels) write and read contiguous memory, and the neighbours a tile of k_assemble
+// gathers - runs of consecutive cells of a few z-lines - share cache lines: 3.6x fewer L1 accesses than with per-cell
+// records, whose 544-byte stride gave every lane of a gather its own lines.
+__device__ __forceinline__ const double* iq_at(const double* iq, int ncell, int f, int c) { return iq + ((size_t)f * ncell + c) * 4; }
+__device__ __forceinline__ double* iq_at(double* iq, int ncell, int f, int c) { return iq + ((size_t)f * ncell + c) * 4; }
 enum { F_S = 0, F_P = 3, F_B = 6, F_MOB = 9, F_RHO = 12, F_RS = 15 };
 template <bool EXT> struct Lay {
     static constexpr int F_RV = 16, F_TMULT = 17;                    // EXT only
@@ -187,6 +193,7 @@ struct CellStatic {
     const double *rvmax, *overburden;   // extended layout: DRVDT cap, overburden pressure (may be NULL)
     const int* rocknum;                 // rock-table index per cell (NULL = table 0)
     double* invb;                       // packed 1/b_w, 1/b_o, 1/b_g per cell, written beside the record (convergence check)
+    int ncell;                          // cells of the intensive-quantity cache (owned + ghost): the stride between its fields
 };
 
 // BlackOilIntensiveQuantities::update: live oil + water + dry gas (base) or wet gas / rock compaction tables (EXT)
@@ -312,7 +319,10 @@ __device__ __forceinline__ void update_iq(const TablesT<DP>& T, const CellStatic
     }
 }
 
-__device__ __forceinline__ void store_ad(double* o, const Ad& a) { o[0] = a.v; o[1] = a.d0; o[2] = a.d1; o[3] = a.d2; }
+__device__ __forceinline__ void store_ad(double* o, const Ad& a) {
+    *reinterpret_cast<double2*>(o) = make_double2(a.v, a.d0);
+    *reinterpret_cast<double2*>(o + 2) = make_double2(a.d1, a.d2);
+}
 __device__ __forceinline__ Ad load_ad(const double* o) {
     const double2 a = *reinterpret_cast<const double2*>(o), b = *reinterpret_cast<const double2*>(o + 2);
     return Ad{a.x, a.y, b.x, b.y};
@@ -323,14 +333,14 @@ __device__ __forceinline__ void store_invb(double* invb, int c, const Iq<Ad>& q)
     invb[(size_t)c * 3] = q.invB[0].v; invb[(size_t)c * 3 + 1] = q.invB[1].v; invb[(size_t)c * 3 + 2] = q.invB[2].v;
 }
 template <bool EXT>
-__device__ __forceinline__ void store_iq(double* o, const Iq<Ad>& q) {
+__device__ __forceinline__ void store_iq(double* iq, int ncell, int c, const Iq<Ad>& q) {
     for (int k = 0; k < 3; ++k) {
-        store_ad(o + (F_S + k) * 4, q.S[k]); store_ad(o + (F_P + k) * 4, q.p[k]); store_ad(o + (F_B + k) * 4, q.invB[k]);
-        store_ad(o + (F_MOB + k) * 4, q.mob[k]); store_ad(o + (F_RHO + k) * 4, q.rho[k]);
+        store_ad(iq_at(iq, ncell, F_S + k, c), q.S[k]); store_ad(iq_at(iq, ncell, F_P + k, c), q.p[k]); store_ad(iq_at(iq, ncell, F_B + k, c), q.invB[k]);
+        store_ad(iq_at(iq, ncell, F_MOB + k, c), q.mob[k]); store_ad(iq_at(iq, ncell, F_RHO + k, c), q.rho[k]);
     }
-    store_ad(o + F_RS * 4, q.Rs);
-    if (EXT) { store_ad(o + Lay<EXT>::F_RV * 4, q.Rv); store_ad(o + Lay<EXT>::F_TMULT * 4, q.tmult); }
-    store_ad(o + Lay<EXT>::F_PORO * 4, q.poro);
+    store_ad(iq_at(iq, ncell, F_RS, c), q.Rs);
+    if (EXT) { store_ad(iq_at(iq, ncell, Lay<EXT>::F_RV, c), q.Rv); store_ad(iq_at(iq, ncell, Lay<EXT>::F_TMULT, c), q.tmult); }
+    store_ad(iq_at(iq, ncell, Lay<EXT>::F_PORO, c), q.poro);
 }
 
 // invalidateAndUpdateIntensiveQuantities(0): one lane per cell
@@ -344,7 +354,7 @@ __device__ __forceinline__ void iq_update_cell(const TablesT<DP>& T, const CellS
     const double x[3] = {pv[(size_t)c * 3], pv[(size_t)c * 3 + 1], pv[(size_t)c * 3 + 2]};
     Iq<Ad> q;
     update_iq<Ad, DP, EXT>(T, C, c, x, meaning[c], q);
-    store_iq<EXT>(iq + (size_t)c * Lay<EXT>::IQS, q);
+    store_iq<EXT>(iq, C.ncell, c, q);
     store_invb(C.invb, c, q);
 }
 // copies the blob into `s_tab` (workgroup-wide, contains a barrier); true if the tables fit
@@ -445,7 +455,7 @@ __device__ __forceinline__ void newton_update_cell(const TablesT<DP>& T, const C
     if (sw) atomicAdd(nswitched, 1);
     Iq<Ad> q;
     update_iq<Ad, DP, EXT>(T, C, c, x, mng, q);
-    store_iq<EXT>(iq + (size_t)c * Lay<EXT>::IQS, q);
+    store_iq<EXT>(iq, C.ncell, c, q);
     store_invb(C.invb, c, q);
 }
 template <bool EXT>
@@ -547,23 +557,35 @@ struct RegQ {   // fields F_P .. F_RS (.. tmult): p, 1/B, mobility, density (3 p
     __device__ __forceinline__ Ad ad(int f) const { return Ad{r[(f - F0) * 4], r[(f - F0) * 4 + 1], r[(f - F0) * 4 + 2], r[(f - F0) * 4 + 3]}; }
     __device__ __forceinline__ double v(int f) const { return r[(f - F0) * 4]; }
 };
+// keeps a batch of loads together: the values must exist here, so the compiler cannot sink each load into the branch
+// that consumes it (where it would cost its own LDS round trip)
+__device__ __forceinline__ void pin(Ad& a) { asm volatile("" : "+v"(a.v), "+v"(a.d0), "+v"(a.d1), "+v"(a.d2)); }
+__device__ __forceinline__ void pin(double& a) { asm volatile("" : "+v"(a)); }
 template <bool EXT, class IN, class EX>
 __device__ __forceinline__ void face_flux(const IN& in, const EX& ex, bool wet, double trans, double faceArea,
                                           double thpres, double zIn, double zEx, double Vin, double Vex, bool inLower, Ad flux[3]) {
     flux[0] = flux[1] = flux[2] = ad_const(0.0);
     const double distZ = zIn - zEx;
     const int comp[3] = {EQ_WATER, EQ_OIL, EQ_GAS};
+    Ad tmIn = ad_const(1.0);   // transMult = rockCompTransMultiplier of the upstream cell (eclfluxmodule.hh:340-355)
+    double tmEx = 1.0;
+    if (EXT) { tmIn = in.ad(Lay<EXT>::F_TMULT); tmEx = ex.v(Lay<EXT>::F_TMULT); }
 #pragma unroll
     for (int ph = 0; ph < 3; ++ph) {
-        const Ad mobIn = in.ad(F_MOB + ph);
-        const double mobEx = ex.v(F_MOB + ph);
+        // everything this phase may need of the two cells in ONE round of (LDS) loads, before the branches
+        Ad mobIn = in.ad(F_MOB + ph), rhoIn = in.ad(F_RHO + ph), pIn = in.ad(F_P + ph), bIn = in.ad(F_B + ph);
+        double mobEx = ex.v(F_MOB + ph), rhoEx = ex.v(F_RHO + ph), pEx = ex.v(F_P + ph), bEx = ex.v(F_B + ph);
+        Ad rIn = ad_const(0.0);   // Rs with the oil phase, Rv with the gas phase
+        double rEx = 0.0;
+        if (ph == OIL) { rIn = in.ad(F_RS); rEx = ex.v(F_RS); }
+        if (EXT && ph == GAS) { rIn = in.ad(Lay<EXT>::F_RV); rEx = ex.v(Lay<EXT>::F_RV); }
+        pin(mobIn); pin(rhoIn); pin(pIn); pin(bIn); pin(mobEx); pin(rhoEx); pin(pEx); pin(bEx);
+        if (ph == OIL || (EXT && ph == GAS)) { pin(rIn); pin(rEx); }
         if (mobIn.v <= 0.0 && mobEx <= 0.0) continue;
-        const Ad rhoIn = in.ad(F_RHO + ph);
-        const double rhoEx = ex.v(F_RHO + ph);
         const Ad rhoAvg = (rhoIn + rhoEx) / 2.0;
-        Ad pressureExterior = ad_const(ex.v(F_P + ph));
+        Ad pressureExterior = ad_const(pEx);
         pressureExterior = pressureExterior + rhoAvg * (distZ * GRAVITY);
-        Ad dp = pressureExterior - in.ad(F_P + ph);
+        Ad dp = pressureExterior - pIn;
         bool upIn;
         if (dp.v > 0.0) upIn = false;
         else if (dp.v < 0.0) upIn = true;
@@ -573,21 +595,21 @@ __device__ __forceinline__ void face_flux(const IN& in, const EX& ex, bool wet, 
         if (fabs(dp.v) > thpres) {
             if (dp.v < 0.0) dp = dp + thpres; else dp = dp - thpres;
         } else continue;
-        Ad volumeFlux, surf;   // transMult = rockCompTransMultiplier of the upstream cell (eclfluxmodule.hh:340-355)
+        Ad volumeFlux, surf;
         if (upIn) {
-            volumeFlux = dp * mobIn * (EXT ? in.ad(Lay<EXT>::F_TMULT) : ad_const(1.0)) * (-trans / faceArea);
-            surf = in.ad(F_B + ph) * volumeFlux;
+            volumeFlux = dp * mobIn * (EXT ? tmIn : ad_const(1.0)) * (-trans / faceArea);
+            surf = bIn * volumeFlux;
         } else {
-            volumeFlux = dp * (mobEx * (EXT ? ex.v(Lay<EXT>::F_TMULT) : 1.0) * (-trans / faceArea));
-            surf = ex.v(F_B + ph) * volumeFlux;
+            volumeFlux = dp * (mobEx * (EXT ? tmEx : 1.0) * (-trans / faceArea));
+            surf = bEx * volumeFlux;
         }
         flux[comp[ph]] = flux[comp[ph]] + surf;
         if (ph == OIL) {
-            if (upIn) flux[EQ_GAS] = flux[EQ_GAS] + in.ad(F_RS) * surf;
-            else flux[EQ_GAS] = flux[EQ_GAS] + ex.v(F_RS) * surf;
+            if (upIn) flux[EQ_GAS] = flux[EQ_GAS] + rIn * surf;
+            else flux[EQ_GAS] = flux[EQ_GAS] + rEx * surf;
         } else if (EXT && ph == GAS && wet) {   // vaporised oil carried by the gas phase
-            if (upIn) flux[EQ_OIL] = flux[EQ_OIL] + in.ad(Lay<EXT>::F_RV) * surf;
-            else flux[EQ_OIL] = flux[EQ_OIL] + ex.v(Lay<EXT>::F_RV) * surf;
+            if (upIn) flux[EQ_OIL] = flux[EQ_OIL] + rIn * surf;
+            else flux[EQ_OIL] = flux[EQ_OIL] + rEx * surf;
         }
     }
 #pragma unroll
@@ -599,164 +621,218 @@ __device__ __forceinline__ void face_flux(const IN& in, const EX& ex, bool wet, 
 #define OPMHIP_ASM_THREADS 64
 #endif
 constexpr int ASM_THREADS = OPMHIP_ASM_THREADS;  // 64: one wavefront per tile (9 rows of a 7-point grid); measured 0.80 ms against 0.84 (128) and 0.88 (256): no cross-wave barrier stalls
+static_assert(ASM_THREADS == 64, "k_assemble: one lane per entry of a one-wavefront tile");
 constexpr int ASM_MAX_ROWS = ASM_THREADS / 7 + 4;  // rows of one tile (their IQ records are staged in LDS); 36 of 40 on a 7-point grid
 int asm_max_rows() { return ASM_MAX_ROWS; }
 int asm_threads() { return ASM_THREADS; }
-#ifdef OPMHIP_ASM_WAVES
+#ifndef OPMHIP_ASM_WAVES
+#define OPMHIP_ASM_WAVES 3
+#endif
+#if OPMHIP_ASM_WAVES > 0
 #define ASM_OCC __attribute__((amdgpu_waves_per_eu(OPMHIP_ASM_WAVES, OPMHIP_ASM_WAVES)))
 #else
 #define ASM_OCC
 #endif
 struct EntryStatic {
     const double *trans, *area, *thpres;  // per entry, internal order
-    const unsigned char* lowFirst;        // per entry (I,J): 1 if the global (natural) index of I is below that of J
 };
-// FvBaseLinearizer::linearizeDomain.  tile t: rows [row0[t], row0[t+1]) ; its entries <= ASM_THREADS, rows <= ASM_MAX_ROWS.
-// The kernel was latency-bound (PMC: waves waiting 74 % of their life, ~18 dependent load rounds per lane through the
-// branches of the flux), so every global load is issued up front in ONE round: the tile's own IQ records as a coalesced
-// copy into LDS, the neighbour's flux fields into registers, the statics; the arithmetic then runs out of LDS/registers.
+constexpr int ASM_PRE = 10;  // what a diagonal lane fetches ahead for its cell: storageOld[3], source[3], drift[3], reference porosity
+// FvBaseLinearizer::linearizeDomain.  One lane per block-CSR entry, one wavefront per tile of whole rows (<= ASM_THREADS
+// entries, <= ASM_MAX_ROWS rows).  The kernel is bound by the latency of its dependent load rounds (PMC: waves wait 65 % of
+// their life with two waves per SIMD and seven rounds), so there are two of them and room for three waves per SIMD:
+//   1  the tile's schedule record (rows, entries) and - found from the workgroup index alone - every lane's entry record
+//      (column, entry word: row inside the tile, tie-break flag, natural summation order; capi_asm.cpp)
+//   2  own IQ records -> LDS (coalesced), depth / volume of the rows, per lane transmissibility, area, THPRES;
+//      off-diagonal lanes: the neighbour's flux fields -> registers; diagonal lanes: storage of the old time level, source,
+//      drift (into the same registers, parked in LDS before the arithmetic starts)
+// The arithmetic then runs out of LDS / registers.  LDS: the own records are dead once every face is evaluated; the face
+// fluxes and the tile's blocks take their place (11 KiB per workgroup instead of 18).
+#ifdef OPMHIP_ASM_SOFT_SYNC
+__device__ __forceinline__ void asm_wave_sync() { asm volatile("" ::: "memory"); }  // one wavefront per workgroup: its LDS accesses execute in program order
+#else
+__device__ __forceinline__ void asm_wave_sync() { __syncthreads(); }
+#endif
 template <bool EXT>
-__global__ __launch_bounds__(ASM_THREADS) ASM_OCC void k_assemble(int ntiles, int wet, const int* __restrict__ asm_order, const int* __restrict__ asm_row0, const int* __restrict__ rowptr,
-                                                          const int* __restrict__ col, const int* __restrict__ natOrder,
+__global__ __launch_bounds__(ASM_THREADS) ASM_OCC void k_assemble(int nsched, const int4* __restrict__ sched, const int2* __restrict__ desc, int wet,
                                                           EntryStatic ES, CellStatic C, const double* __restrict__ iq,
                                                           double* __restrict__ storageOld, const double* __restrict__ source,
                                                           const double* __restrict__ dsource, const double* __restrict__ drift, double maxCompensation,
                                                           double dt, int iteration, double* __restrict__ A, double* __restrict__ resid) {
-    __shared__ __attribute__((aligned(16))) double sblk[(ASM_THREADS + 2) * BB];  // the tile's blocks, then streamed out
-    __shared__ double sflux[ASM_THREADS * 12];                                     // face flux seen from the row's cell
     constexpr int IQS = Lay<EXT>::IQS, RQ_F0 = Lay<EXT>::RQ_F0, RQ_NF = Lay<EXT>::RQ_NF, F_PORO = Lay<EXT>::F_PORO;
-    __shared__ __attribute__((aligned(16))) double sI[ASM_MAX_ROWS * IQS];         // IQ records of the tile's rows
-    __shared__ short srow[ASM_THREADS];
-    // Workgroups are dealt round-robin over the 8 XCDs (b and b + 8 share one): every XCD gets one contiguous eighth of
-    // the schedule, so that the neighbour records several nearby tiles gather are found in that XCD's own L2
+    constexpr int N_OWN = ASM_MAX_ROWS * IQS, N_FLUX = ASM_THREADS * 12, N_OUT = N_FLUX + (ASM_THREADS + 2) * BB;
+    __shared__ __attribute__((aligned(16))) double sU[N_OWN > N_OUT ? N_OWN : N_OUT];
+    double* const sI = sU;              // until the faces are evaluated: IQ records of the tile's rows
+    double* const sflux = sU;           // then: face flux seen from the row's cell, 3 equations x (value, 3 derivatives) per entry
+    double* const sblk = sU + N_FLUX;   //       and the tile's blocks, streamed out at the end
+    __shared__ double sgeo[2 * ASM_MAX_ROWS];
+    __shared__ double spre[ASM_MAX_ROWS * ASM_PRE];
+    __shared__ unsigned char snat[ASM_THREADS];
+    __shared__ short sfirst[ASM_MAX_ROWS + 1];
+    static_assert(RQ_NF >= ASM_PRE, "the diagonal lane borrows the value slots of the neighbour record");
     const int tid = threadIdx.x;
-    const int chunk = (ntiles + 7) >> 3;
-    const int pos = (blockIdx.x & 7) * chunk + (blockIdx.x >> 3);
-    if (pos >= ntiles) return;
-    const int t = asm_order[pos];
-    const int r0 = asm_row0[t], r1 = asm_row0[t + 1];
-    const int k0 = rowptr[r0], k1 = rowptr[r1], nent = k1 - k0;
-    const int k0e = k0 & ~1;  // 16-byte aligned start of the output stream
-    {   // own records: one contiguous range of the cache (IQS * 8 = 544 bytes per row, 16-byte aligned)
-        const double2* g2 = reinterpret_cast<const double2*>(iq + (size_t)r0 * IQS);
-        double2* s2 = reinterpret_cast<double2*>(sI);
-        const int n2 = (r1 - r0) * (IQS / 2);
-        for (int i = tid; i < n2; i += ASM_THREADS) s2[i] = g2[i];
-    }
-    if (tid < r1 - r0)
-        for (int k = rowptr[r0 + tid]; k < rowptr[r0 + tid + 1]; ++k) srow[k - k0] = (short)tid;
-    __syncthreads();
-    int I = -1, J = -1, k = -1, lrow = 0;
-    bool isDiag = false;
-    RegQ<EXT> qJ;
-    double trans = 0.0, area = 1.0, thp = 0.0, zI = 0.0, zJ = 0.0, VI = 0.0, VJ = 0.0;
-    bool lowI = false;
-    if (tid < nent) {
-        k = k0 + tid;
-        lrow = srow[tid];
-        I = r0 + lrow;
-        J = col[k];
-        isDiag = (I == J);
-        if (!isDiag) {
-            const double2* g2 = reinterpret_cast<const double2*>(iq + (size_t)J * IQS + RQ_F0 * 4);
-#pragma unroll
-            for (int i = 0; i < RQ_NF * 2; ++i) { const double2 v = g2[i]; qJ.r[2 * i] = v.x; qJ.r[2 * i + 1] = v.y; }
-            trans = ES.trans[k]; area = ES.area[k]; thp = ES.thpres ? ES.thpres[k] : 0.0;
-            lowI = ES.lowFirst[k] != 0;
-            zI = C.depth[I]; zJ = C.depth[J]; VI = C.volume[I]; VJ = C.volume[J];
-        }
-    }
-    Ad st[3];
-    const PtrQ qI{sI + lrow * IQS};
-    if (tid < nent) {
-        if (!isDiag) {
-            Ad f[3];
-            face_flux<EXT>(qI, qJ, wet != 0, trans, area, thp, zI, zJ, VI, VJ, lowI, f);  // focus I: contribution to R_I
-            for (int e = 0; e < 3; ++e) store_ad(&sflux[tid * 12 + e * 4], f[e]);
-            face_flux<EXT>(qJ, qI, wet != 0, trans, area, thp, zJ, zI, VJ, VI, !lowI, f);  // focus J: residual[I] -= flux  ->  block (I,J)
-            double* b = &sblk[(k - k0e) * BB];
-            for (int e = 0; e < 3; ++e) {
-                const Ad m = ad_const(0.0) - f[e];
-                b[e * 3 + 0] = m.d0; b[e * 3 + 1] = m.d1; b[e * 3 + 2] = m.d2;
+    if ((int)blockIdx.x >= nsched) return;
+    // ---- round 1: the tile's schedule record and, independent of it, the lane's entry (column, entry word)
+    const int4 S = sched[blockIdx.x];
+    const int2 jm = desc[(size_t)blockIdx.x * ASM_THREADS + tid];
+    {
+        const int r0 = S.x, k0 = S.z, nent = S.w - S.z, nrows = S.y - S.x;
+        const int k0e = k0 & ~1;  // 16-byte aligned start of the output stream
+        const bool act = tid < nent;
+        const int k = act ? k0 + tid : k0;
+        const int J = jm.x;
+        const unsigned m = (unsigned)jm.y;
+        {   // ---- round 2.  Own records: per field one contiguous run of nrows x 32 bytes of the cache, into per-row records in LDS
+            const int n2r = nrows * 2;                              // 16-byte pieces per field
+            const unsigned inv = n2r > 0 ? (65536u + n2r - 1) / n2r : 0u;  // i / n2r == (i * inv) >> 16 for the few hundred i of a tile
+            const int n2 = n2r * Lay<EXT>::IQF;
+            const double2* g2 = reinterpret_cast<const double2*>(iq);
+            double2* s2 = reinterpret_cast<double2*>(sI);
+            for (int i = tid; i < n2; i += ASM_THREADS) {
+                const int fld = (int)(((unsigned)i * inv) >> 16), j = i - fld * n2r;
+                s2[(j >> 1) * (IQS / 2) + fld * 2 + (j & 1)] = g2[((size_t)fld * C.ncell + r0) * 2 + j];
             }
-        } else {
+        }
+        if (tid < nrows) { sgeo[tid] = C.depth[r0 + tid]; sgeo[ASM_MAX_ROWS + tid] = C.volume[r0 + tid]; }
+        const double trans = ES.trans[k], area = ES.area[k], thp = ES.thpres ? ES.thpres[k] : 0.0;
+        const int lrow = m & 63;
+        const bool lowI = ((m >> 6) & 1u) != 0;
+        const int I = r0 + lrow;
+        const bool isDiag = act && I == J, isOff = act && I != J;
+        snat[tid] = (unsigned char)(m >> 8);
+        {
+            const int prevRow = __shfl_up(lrow, 1);
+            if (act && (tid == 0 || prevRow != lrow)) sfirst[lrow] = (short)tid;
+            if (tid == 0) sfirst[nrows] = (short)nent;
+        }
+        RegQ<EXT> qJ;
+        double zJ = 0.0, VJ = 0.0;
+        if (isOff) {
+            const double2* g2 = reinterpret_cast<const double2*>(iq) + (size_t)J * 2;
+#pragma unroll
+            for (int i = 0; i < RQ_NF; ++i) {
+                const double2 a = g2[(size_t)(RQ_F0 + i) * C.ncell * 2], b = g2[(size_t)(RQ_F0 + i) * C.ncell * 2 + 1];
+                qJ.r[4 * i] = a.x; qJ.r[4 * i + 1] = a.y; qJ.r[4 * i + 2] = b.x; qJ.r[4 * i + 3] = b.y;
+            }
+            zJ = C.depth[J]; VJ = C.volume[J];
+        } else if (isDiag) {
+            const size_t o = (size_t)I * 3;
+#pragma unroll
+            for (int e = 0; e < 3; ++e) {
+                qJ.r[4 * e] = (iteration == 0) ? 0.0 : storageOld[o + e];
+                qJ.r[4 * (3 + e)] = source ? source[o + e] : 0.0;
+                qJ.r[4 * (6 + e)] = drift ? drift[o + e] : 0.0;
+            }
+            qJ.r[4 * 9] = drift ? C.poro[I] : 1.0;   // referencePorosity
+        }
+        asm_wave_sync();
+        const double zI = sgeo[lrow], VI = sgeo[ASM_MAX_ROWS + lrow];
+        Ad f[3];         // off-diagonal lane: face flux seen from cell I; diagonal lane: storage term
+        double blk[BB];  // off-diagonal lane: block (I,J)
+        const PtrQ qI{sI + lrow * IQS};
+        if (isOff) {
+            face_flux<EXT>(qJ, qI, wet != 0, trans, area, thp, zJ, zI, VJ, VI, !lowI, f);  // focus J: residual[I] -= flux  ->  block (I,J)
+#pragma unroll
+            for (int e = 0; e < 3; ++e) {
+                const Ad mm = ad_const(0.0) - f[e];
+                blk[e * 3 + 0] = mm.d0; blk[e * 3 + 1] = mm.d1; blk[e * 3 + 2] = mm.d2;
+            }
+            face_flux<EXT>(qI, qJ, wet != 0, trans, area, thp, zI, zJ, VI, VJ, lowI, f);   // focus I: contribution to R_I
+        } else if (isDiag) {
+#pragma unroll
+            for (int i = 0; i < ASM_PRE; ++i) spre[lrow * ASM_PRE + i] = qJ.r[4 * i];
             // computeStorage: surface volumes per bulk volume
             const Ad poro = qI.ad(F_PORO), Rs = qI.ad(F_RS);
-            st[0] = st[1] = st[2] = ad_const(0.0);
+            f[0] = f[1] = f[2] = ad_const(0.0);
             const int comp[3] = {EQ_WATER, EQ_OIL, EQ_GAS};
 #pragma unroll
             for (int ph = 0; ph < 3; ++ph) {
                 const Ad surfaceVolume = qI.ad(F_S + ph) * qI.ad(F_B + ph) * poro;
-                st[comp[ph]] = st[comp[ph]] + surfaceVolume;
-                if (ph == OIL) st[EQ_GAS] = st[EQ_GAS] + Rs * surfaceVolume;
-                if (EXT && ph == GAS && wet) st[EQ_OIL] = st[EQ_OIL] + qI.ad(Lay<EXT>::F_RV) * surfaceVolume;   // vaporised oil
+                f[comp[ph]] = f[comp[ph]] + surfaceVolume;
+                if (ph == OIL) f[EQ_GAS] = f[EQ_GAS] + Rs * surfaceVolume;
+                if (EXT && ph == GAS && wet) f[EQ_OIL] = f[EQ_OIL] + qI.ad(Lay<EXT>::F_RV) * surfaceVolume;   // vaporised oil
             }
         }
-    }
-    __syncthreads();
-    if (tid < nent && isDiag) {
-        Ad R[3] = {ad_const(0.0), ad_const(0.0), ad_const(0.0)};
-        // flux terms first (FvBaseLocalResidual::eval), faces in ascending NATURAL neighbour order whatever the
-        // internal ordering is, so that the sum is the one the natural-order CPU path forms
-        for (int qq = rowptr[I]; qq < rowptr[I + 1]; ++qq) {
-            const int q = natOrder[qq];
-            if (q == k) continue;
-            const double* f = &sflux[(q - k0) * 12];
-            for (int e = 0; e < 3; ++e) R[e] = R[e] + Ad{f[e * 4], f[e * 4 + 1], f[e * 4 + 2], f[e * 4 + 3]};
+        asm_wave_sync();   // every read of the own records is done: their LDS becomes sflux / sblk
+        if (isOff) {
+#pragma unroll
+            for (int e = 0; e < 3; ++e) store_ad(&sflux[tid * 12 + e * 4], f[e]);
+            double* b = &sblk[(k - k0e) * BB];
+#pragma unroll
+            for (int q = 0; q < BB; ++q) b[q] = blk[q];
         }
-        const double V = C.volume[I];
-        double* so = storageOld + (size_t)I * 3;
-        for (int e = 0; e < 3; ++e) {
-            double old;
-            if (iteration == 0) { old = st[e].v; so[e] = old; } else old = so[e];
-            Ad tt = st[e] - old;
-            tt = tt * (V / dt);
-            R[e] = R[e] + tt;
-        }
-        // drift compensation (ebos/eclproblem.hh:1847-1875): what the last accepted time step left unconverged in this
-        // cell (residual * dt, opmhip_end_time_step) goes back in as a rate, capped at maxCompensation of the pore volume
-        double dofDriftRate[3] = {0.0, 0.0, 0.0};
-        if (drift) {
-            const double poro = C.poro[I];   // referencePorosity
+        asm_wave_sync();
+        if (isDiag) {
+            Ad R[3] = {ad_const(0.0), ad_const(0.0), ad_const(0.0)};
+            // flux terms first (FvBaseLocalResidual::eval), faces in ascending NATURAL neighbour order whatever the
+            // internal ordering is, so that the sum is the one the natural-order CPU path forms
+            const int e0 = sfirst[lrow], e1 = sfirst[lrow + 1];
+            // the next face's flux is read from LDS while the present one is added
+            auto face_of = [&](int i) { const int q = e0 + snat[i < e1 ? i : e1 - 1]; return q; };
+            Ad nx[3];
+            int qn = face_of(e0);
+            for (int e = 0; e < 3; ++e) nx[e] = load_ad(&sflux[qn * 12 + e * 4]);
+            for (int i = e0; i < e1; ++i) {
+                const int q = qn;
+                Ad cur[3] = {nx[0], nx[1], nx[2]};
+                qn = face_of(i + 1);
+                for (int e = 0; e < 3; ++e) nx[e] = load_ad(&sflux[qn * 12 + e * 4]);
+                if (q == tid) continue;   // the diagonal entry itself
+                for (int e = 0; e < 3; ++e) R[e] = R[e] + cur[e];
+            }
+            const double V = VI;
+            const double* pre = &spre[lrow * ASM_PRE];
+            for (int e = 0; e < 3; ++e) {
+                double old;
+                if (iteration == 0) { old = f[e].v; storageOld[(size_t)I * 3 + e] = old; } else old = pre[e];
+                Ad tt = f[e] - old;
+                tt = tt * (V / dt);
+                R[e] = R[e] + tt;
+            }
+            // drift compensation (ebos/eclproblem.hh:1847-1875): what the last accepted time step left unconverged in this
+            // cell (residual * dt, opmhip_end_time_step) goes back in as a rate, capped at maxCompensation of the pore volume
+            double dofDriftRate[3] = {0.0, 0.0, 0.0};
+            if (drift) {
+                const double poro = pre[9];   // referencePorosity
 #pragma unroll
-            for (int e = 0; e < 3; ++e) dofDriftRate[e] = drift[(size_t)I * 3 + e] / (dt * V);
-            double totalDriftRate = 0.0;
+                for (int e = 0; e < 3; ++e) dofDriftRate[e] = pre[6 + e] / (dt * V);
+                double totalDriftRate = 0.0;
 #pragma unroll
-            for (int e = 0; e < 3; ++e) totalDriftRate += fabs(dofDriftRate[e]) * dt * 1.0 / poro;   // eqWeight = 1 (UNVERIFIED, see oracle)
-            if (totalDriftRate > maxCompensation) {
+                for (int e = 0; e < 3; ++e) totalDriftRate += fabs(dofDriftRate[e]) * dt * 1.0 / poro;   // eqWeight = 1 (UNVERIFIED, see oracle)
+                if (totalDriftRate > maxCompensation) {
 #pragma unroll
-                for (int e = 0; e < 3; ++e) dofDriftRate[e] *= maxCompensation / totalDriftRate;
+                    for (int e = 0; e < 3; ++e) dofDriftRate[e] *= maxCompensation / totalDriftRate;
+                }
+            }
+            for (int e = 0; e < 3; ++e) {
+                Ad s = ad_const(pre[3 + e]);
+                if (dsource) { s.d0 = dsource[(size_t)I * 9 + e * 3]; s.d1 = dsource[(size_t)I * 9 + e * 3 + 1]; s.d2 = dsource[(size_t)I * 9 + e * 3 + 2]; }
+                s = s / V;
+                if (drift) s = s - dofDriftRate[e];
+                s = s * V;
+                R[e] = R[e] - s;
+            }
+            double* b = &sblk[(k - k0e) * BB];
+            for (int e = 0; e < 3; ++e) {
+                resid[(size_t)I * 3 + e] = R[e].v;
+                b[e * 3 + 0] = R[e].d0; b[e * 3 + 1] = R[e].d1; b[e * 3 + 2] = R[e].d2;
             }
         }
-        for (int e = 0; e < 3; ++e) {
-            Ad s = ad_const(source ? source[(size_t)I * 3 + e] : 0.0);
-            if (dsource) { s.d0 = dsource[(size_t)I * 9 + e * 3]; s.d1 = dsource[(size_t)I * 9 + e * 3 + 1]; s.d2 = dsource[(size_t)I * 9 + e * 3 + 2]; }
-            s = s / V;
-            if (drift) s = s - dofDriftRate[e];
-            s = s * V;
-            R[e] = R[e] - s;
+        asm_wave_sync();
+        // stream the tile's blocks out: contiguous range [k0, k1) x 72 B
+        {
+            const int head = (k0 - k0e) * BB;      // doubles to skip at the front (0 or 9)
+            const int n = nent * BB;
+            double* dst = A + (size_t)k0e * BB;
+            int b = head, e = head + n;
+            // unaligned head / tail doubles go out one by one, the body as double2
+            if ((b & 1) && tid == 0) dst[b] = sblk[b];
+            if ((e & 1) && tid == 0) dst[e - 1] = sblk[e - 1];
+            b = (b + 1) & ~1;
+            e = e & ~1;
+            const double2* s2 = reinterpret_cast<const double2*>(sblk);
+            double2* d2 = reinterpret_cast<double2*>(dst);
+            for (int i = (b >> 1) + tid; i < (e >> 1); i += ASM_THREADS) d2[i] = s2[i];
         }
-        double* b = &sblk[(k - k0e) * BB];
-        for (int e = 0; e < 3; ++e) {
-            resid[(size_t)I * 3 + e] = R[e].v;
-            b[e * 3 + 0] = R[e].d0; b[e * 3 + 1] = R[e].d1; b[e * 3 + 2] = R[e].d2;
-        }
-    }
-    __syncthreads();
-    // stream the tile's blocks out: contiguous range [k0, k1) x 72 B
-    {
-        const int head = (k0 - k0e) * BB;      // doubles to skip at the front (0 or 9)
-        const int n = nent * BB;
-        double* dst = A + (size_t)k0e * BB;
-        int b = head, e = head + n;
-        // unaligned head / tail doubles go out one by one, the body as double2
-        if ((b & 1) && tid == 0) dst[b] = sblk[b];
-        if ((e & 1) && tid == 0) dst[e - 1] = sblk[e - 1];
-        b = (b + 1) & ~1;
-        e = e & ~1;
-        const double2* s2 = reinterpret_cast<const double2*>(sblk);
-        double2* d2 = reinterpret_cast<double2*>(dst);
-        for (int i = (b >> 1) + tid; i < (e >> 1); i += ASM_THREADS) d2[i] = s2[i];
     }
 }
 
@@ -887,7 +963,7 @@ __global__ void k_iq_to_natural(int Nb, int IQS, const int* __restrict__ toOrder
     const size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (e >= (size_t)Nb * IQS) return;
     const int i = (int)(e / IQS), q = (int)(e % IQS);
-    nat[e] = internal[(size_t)toOrder[i] * IQS + q];
+    nat[e] = internal[((size_t)(q >> 2) * Nb + toOrder[i]) * 4 + (q & 3)];   // field-major cache -> per-cell records
 }
 __global__ void k_unpermute_blocks(int nnzb, const int* __restrict__ nnzMap, const double* __restrict__ internal, double* __restrict__ nat) {
     const size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -903,7 +979,7 @@ static Tables tables_of(const opmhip_ctx* c) {
 }
 static CellStatic cells_of(const opmhip_ctx* c) {
     return CellStatic{c->asmb.d_poro, c->asmb.d_volume, c->asmb.d_depth, c->asmb.d_rsmax, c->asmb.d_pvtnum, c->asmb.d_satnum,
-                      c->asmb.d_rvmax, c->asmb.d_overburden, c->asmb.d_rocknum, c->asmb.d_invb};
+                      c->asmb.d_rvmax, c->asmb.d_overburden, c->asmb.d_rocknum, c->asmb.d_invb, c->pat.Nloc};
 }
 // the context's record layout: extended when the fluid has PVTG or ROCKTAB tables
 #define OPMHIP_LAYOUT(c, call_base, call_ext) do { if ((c)->asmb.ext) { call_ext; } else { call_base; } } while (0)
@@ -940,14 +1016,14 @@ void launch_newton_update(opmhip_ctx* c, const double* d_dx, double relax) {
     prof_end(c, ps);
 }
 void launch_assemble(opmhip_ctx* c, double dt, int iteration) {
-    const Pattern& P = c->pat;
-    EntryStatic ES{c->asmb.d_trans, c->asmb.d_area, c->asmb.d_thpres, c->asmb.d_lowFirst};
+    EntryStatic ES{c->asmb.d_trans, c->asmb.d_area, c->asmb.d_thpres};
     const int ps = prof_begin(c, PROF_ASSEMBLE);
     const double* drift = c->asmb.drift_enabled ? c->asmb.d_drift : (const double*)nullptr;
+    const int grid = c->asmb.nsched;
     OPMHIP_LAYOUT(c,
-        hipLaunchKernelGGL(k_assemble<false>, dim3(8 * ((c->asmb.ntiles + 7) / 8)), dim3(ASM_THREADS), 0, c->stream, c->asmb.ntiles, 0, c->asmb.d_asm_order, c->asmb.d_asm_row0, P.d_rowptr, P.d_col, c->asmb.d_natOrder, ES,
+        hipLaunchKernelGGL(k_assemble<false>, dim3(grid), dim3(ASM_THREADS), 0, c->stream, c->asmb.nsched, reinterpret_cast<const int4*>(c->asmb.d_asm_sched), reinterpret_cast<const int2*>(c->asmb.d_asm_desc), 0, ES,
                            cells_of(c), c->asmb.d_iq, c->asmb.d_storageOld, c->asmb.d_source, c->asmb.d_dsource, drift, c->asmb.max_compensation, dt, iteration, c->d_A, c->d_b),
-        hipLaunchKernelGGL(k_assemble<true>, dim3(8 * ((c->asmb.ntiles + 7) / 8)), dim3(ASM_THREADS), 0, c->stream, c->asmb.ntiles, c->asmb.wet_gas ? 1 : 0, c->asmb.d_asm_order, c->asmb.d_asm_row0, P.d_rowptr, P.d_col, c->asmb.d_natOrder, ES,
+        hipLaunchKernelGGL(k_assemble<true>, dim3(grid), dim3(ASM_THREADS), 0, c->stream, c->asmb.nsched, reinterpret_cast<const int4*>(c->asmb.d_asm_sched), reinterpret_cast<const int2*>(c->asmb.d_asm_desc), c->asmb.wet_gas ? 1 : 0, ES,
                            cells_of(c), c->asmb.d_iq, c->asmb.d_storageOld, c->asmb.d_source, c->asmb.d_dsource, drift, c->asmb.max_compensation, dt, iteration, c->d_A, c->d_b));
     prof_end(c, ps);
 }

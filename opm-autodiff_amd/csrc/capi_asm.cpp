@@ -161,11 +161,12 @@ int opmhip_set_static(opmhip_ctx* c, const double* trans, const double* area, co
             }
             row0.push_back(P.Nb);
             A.ntiles = (int)row0.size() - 1;
-            if ((rc = dev_upload(c, &A.d_asm_row0, row0))) return rc;
             // Schedule: the ILU ordering stores the colours one after the other, so a cell and its neighbours of another
             // colour sit at the same RELATIVE position of two far-apart regions.  Tiles are therefore launched by their
             // relative position inside their colour, colours interleaved: the intensive quantities a tile gathers from
             // the other colours were, or will shortly be, touched by the tiles running next to it and stay in L2.
+            // One record per tile (first row, end row, first entry, end entry): the kernel's first load.
+            std::vector<int> sched;
             {
                 std::vector<int> colorOfTile(A.ntiles), first(P.numColors + 1, A.ntiles), cnt(P.numColors, 0);
                 int cc = 0;
@@ -179,34 +180,60 @@ int opmhip_set_static(opmhip_ctx* c, const double* trans, const double* area, co
                 for (int t = 0; t < A.ntiles; ++t) order[t] = t;
                 auto frac = [&](int t) { const int q = colorOfTile[t]; return (double)(t - first[q]) / (double)cnt[q]; };
                 std::stable_sort(order.begin(), order.end(), [&](int x, int y) { return frac(x) < frac(y); });
-                if ((rc = dev_upload(c, &A.d_asm_order, order))) return rc;
-            }
-            // entries of each row in ascending natural-column order (= ascending natural entry index)
-            std::vector<int> natOrder(P.nnzb);
-            for (int p = 0; p < P.Nb; ++p) {
-                const int b = P.rowptr[p], e = P.rowptr[p + 1];
-                for (int k = b; k < e; ++k) natOrder[k] = k;
-                if (P.gids.empty())
-                    std::sort(natOrder.begin() + b, natOrder.begin() + e, [&](int x, int y) { return P.nnzMap[x] < P.nnzMap[y]; });
-                else  // decomposed run: ascending GLOBAL neighbour id (natural local id of a column = fromOrder[internal col])
-                    std::sort(natOrder.begin() + b, natOrder.begin() + e,
-                              [&](int x, int y) { return P.gids[P.fromOrder[P.col[x]]] < P.gids[P.fromOrder[P.col[y]]]; });
-            }
-            if ((rc = dev_upload(c, &A.d_natOrder, natOrder))) return rc;
-            // upwind tie-break of a face with equal pressures and volumes: "the DOF which exhibits the smaller global
-            // index" (ebos/eclfluxmodule.hh:303-314) - the index of the natural order (the global id in decomposed
-            // runs), never the position in the ILU ordering
-            std::vector<unsigned char> lowFirst(P.nnzb, 0);
-            for (int p = 0; p < P.Nb; ++p) {
-                const int in = P.fromOrder[p];
-                const long long gi = P.gids.empty() ? (long long)in : P.gids[in];
-                for (int k = P.rowptr[p]; k < P.rowptr[p + 1]; ++k) {
-                    const int jn = P.fromOrder[P.col[k]];
-                    const long long gj = P.gids.empty() ? (long long)jn : P.gids[jn];
-                    lowFirst[k] = gi < gj ? 1 : 0;
+                // Workgroup b of the launch runs on XCD b % 8; every XCD gets one contiguous eighth of this order, so that the
+                // neighbour records several nearby tiles gather are found in that XCD's own L2.  The permutation is folded
+                // into the schedule (record b = what workgroup b, b + gridDim, ... work on); the last records may be empty.
+                const int chunk = (A.ntiles + 7) / 8;
+                A.nsched = 8 * chunk;
+                sched.assign((size_t)4 * A.nsched, 0);
+                for (int b = 0; b < A.nsched; ++b) {
+                    const int pos = (b & 7) * chunk + (b >> 3);
+                    if (pos >= A.ntiles) continue;
+                    const int t = order[pos];
+                    sched[(size_t)4 * b] = row0[t];
+                    sched[(size_t)4 * b + 1] = row0[t + 1];
+                    sched[(size_t)4 * b + 2] = P.rowptr[row0[t]];
+                    sched[(size_t)4 * b + 3] = P.rowptr[row0[t + 1]];
                 }
+                if ((rc = dev_upload(c, &A.d_asm_sched, sched))) return rc;
             }
-            if ((rc = dev_upload(c, &A.d_lowFirst, lowFirst))) return rc;
+            // Per workgroup and lane = per entry (I,J) of the workgroup's tile: the column and an entry word - everything a
+            // lane needs to know about its entry, addressed by the workgroup index alone (no dependent load):
+            //   bits 0-5  row of the entry inside its tile
+            //   bit  6    upwind tie-break of a face with equal pressures and volumes: "the DOF which exhibits the smaller
+            //             global index" (ebos/eclfluxmodule.hh:303-314) - set if the global id of I (the index of the natural
+            //             order; the global id in decomposed runs) is below that of J, never the position in the ILU ordering
+            //   bits 8-15 the row's entries in ascending natural-column order (ascending GLOBAL neighbour id in decomposed
+            //             runs): in-row position of the entry that comes i-th, stored with the row's i-th entry - the order
+            //             in which the natural-order CPU path sums the face fluxes of a cell
+            {
+                const int T = asm_threads();
+                std::vector<int> desc((size_t)2 * T * A.nsched, 0);
+                std::vector<int> byNat;
+                for (int b = 0; b < A.nsched; ++b) {
+                    const int tr0 = sched[(size_t)4 * b], tr1 = sched[(size_t)4 * b + 1], tk0 = sched[(size_t)4 * b + 2];
+                    for (int p = tr0; p < tr1; ++p) {
+                        const int kb = P.rowptr[p], ke = P.rowptr[p + 1];
+                        byNat.resize(ke - kb);
+                        for (int k = kb; k < ke; ++k) byNat[k - kb] = k;
+                        if (P.gids.empty())
+                            std::sort(byNat.begin(), byNat.end(), [&](int x, int y) { return P.nnzMap[x] < P.nnzMap[y]; });
+                        else  // natural local id of a column = fromOrder[internal col]
+                            std::sort(byNat.begin(), byNat.end(),
+                                      [&](int x, int y) { return P.gids[P.fromOrder[P.col[x]]] < P.gids[P.fromOrder[P.col[y]]]; });
+                        const int in = P.fromOrder[p];
+                        const long long gi = P.gids.empty() ? (long long)in : P.gids[in];
+                        for (int k = kb; k < ke; ++k) {
+                            const int jn = P.fromOrder[P.col[k]];
+                            const long long gj = P.gids.empty() ? (long long)jn : P.gids[jn];
+                            const size_t o = (size_t)2 * ((size_t)b * T + (k - tk0));
+                            desc[o] = P.col[k];
+                            desc[o + 1] = (p - tr0) | (gi < gj ? 64 : 0) | ((byNat[k - kb] - kb) << 8);
+                        }
+                    }
+                }
+                if ((rc = dev_upload(c, &A.d_asm_desc, desc))) return rc;
+            }
         }
         A.static_set = true;
         return OPMHIP_SUCCESS;

@@ -99,7 +99,6 @@ struct AsmDev {
     int* d_rocknum = nullptr;                             // per cell rock-table index (optional)
     double* d_invb = nullptr;                             // packed 1/b per cell and phase (Nloc x 3), for the convergence check
     double *d_trans = nullptr, *d_area = nullptr, *d_thpres = nullptr;                      // per entry
-    unsigned char* d_lowFirst = nullptr;  // per entry (I,J): global id of I < global id of J (upwind tie-break)
     double *d_poro = nullptr, *d_volume = nullptr, *d_depth = nullptr, *d_rsmax = nullptr;  // per cell
     int *d_pvtnum = nullptr, *d_satnum = nullptr;
     double *d_pv = nullptr, *d_iq = nullptr, *d_storageOld = nullptr, *d_source = nullptr, *d_dsource = nullptr;
@@ -111,10 +110,9 @@ struct AsmDev {
     unsigned char* d_meaning_prev = nullptr;
     bool prev_set = false;
     int* d_nswitched = nullptr;
-    int* d_asm_row0 = nullptr;
-    int* d_asm_order = nullptr;  // launch position -> tile
-    int* d_natOrder = nullptr;  // per row: its entries (internal indices) sorted by natural column
-    int ntiles = 0;
+    int* d_asm_sched = nullptr;            // per workgroup of k_assemble: first row, end row, first entry, end entry of its tile
+    int* d_asm_desc = nullptr;             // per workgroup and lane: column and entry word (row inside the tile, upwind tie-break flag, natural summation order)
+    int ntiles = 0, nsched = 0;
     double *d_conv_part = nullptr, *d_conv_out = nullptr;
     double* d_stage_cell = nullptr;   // staging for per-cell doubles (natural order), Nb * max(9, IQS)
     double* d_stage_entry = nullptr;  // staging for per-entry doubles (natural order), nnzb
