@@ -157,24 +157,18 @@ class PDVD:
         return _rv_sat(self.props, min(press, p))
 
 
-def equilibrate(props, rho_ref, rec, cell_depth, z_span, sat_limits, grav=9.80665, rs_func=None, nsample=NSAMPLE, rv_func=None):
-    """props.probe(p, rs, sw, sg) -> (n, 8) (capi.HipFluid layout); rho_ref = (oil, water, gas) surface densities;
-    rec = dict(datum, pressure, zwoc, pcow_woc, zgoc, pcgo_goc); cell_depth[]: centre depths; z_span = (top, bottom) of the
-    region's cells; sat_limits = dict(Swl, Swu, Sgl, Sgu) (unscaled end points of the saturation tables).
-    rv_func (wet gas, VAPOIL): Rv(depth, p_g, sat_oil) - RvSatAtContact / RvVD / PDVD; props then also needs
-    probe_gas(p, rv) -> (n, 3): 1/B_g(p, rv), mu_g, RvSat(p).
-    -> dict(pw, po, pg, sw, so, sg, rs, rv) arrays over the cells."""
+def phase_pressure_tables(props, rho_ref, rec, z_span, grav=9.80665, rs_func=None, rv_func=None, nsample=NSAMPLE):
+    """PressureTable::equilibrate (initstateequil.hh:596-723): the three phase pressures as functions of depth over
+    z_span widened to the contacts; which phase starts at the datum follows from the datum's zone.
+    rs_func(depth, p_o) / rv_func(depth, p_g): dissolved gas / vaporised oil along the column (None: none).
+    -> (water, oil, gas) callables"""
     rho_o, rho_w, rho_g = rho_ref
-    if rs_func is None:
-        if rec["zgoc"] != rec["datum"]:
-            raise ValueError("without an RSVD table the datum depth must be at the gas-oil contact")
-        rs_func = RsSatAtContact(props, rec["pressure"])
 
     def f_water(z, p):
         return float(props.probe(p)[0, INVBW]) * rho_w * grav
 
     def f_oil(z, p):
-        rs = rs_func(z, p)
+        rs = rs_func(z, p) if rs_func is not None else 0.0
         b = float(props.probe(p, rs=rs)[0, INVBO])     # the probe switches to the saturated curve where rs >= RsSat(p)
         return (b * rho_o + rs * b * rho_g) * grav
 
@@ -200,33 +194,85 @@ def equilibrate(props, rho_ref, rec, cell_depth, z_span, sat_limits, grav=9.8066
         oil = mk(f_oil, rec["datum"], rec["pressure"])
         wat = mk(f_water, rec["zwoc"], oil(rec["zwoc"]) - rec["pcow_woc"])
         gas = mk(f_gas, rec["zgoc"], oil(rec["zgoc"]) + rec["pcgo_goc"])
+    return wat, oil, gas
+
+
+def _root(fun, s0, s1):
+    """zero of a monotone function with fun(s0) > 0 > fun(s1) (RegulaFalsiBisection to 1e-10 in the reference)"""
+    f0, f1 = fun(s0), fun(s1)
+    if f0 <= 0.0:
+        return s0
+    if f1 >= 0.0:
+        return s1
+    a, b = s0, s1
+    for _ in range(200):
+        m = 0.5 * (a + b)
+        if fun(m) > 0.0:
+            a = m
+        else:
+            b = m
+        if abs(b - a) < 1e-13:
+            break
+    return 0.5 * (a + b)
+
+
+def sat_from_pc(pc_of_s, smin, smax, target, increasing):
+    """satFromPc (equilibrationhelpers.hh:730-830): the saturation at which the capillary pressure equals `target`,
+    clamped to [smin, smax]; `increasing`: pc grows with the saturation (gas-oil) or falls (oil-water)"""
+    s0, s1 = (smax, smin) if increasing else (smin, smax)
+    return _root(lambda s: pc_of_s(s) - target, s0, s1)
+
+
+def sat_from_sum_of_pcs(pcow_of_sw, pcgo_of_sg, swl, swu, target):
+    """satFromSumOfPcs (equilibrationhelpers.hh:850-930): water saturation of a gas-water contact,
+    pcow(sw) + pcgo(1 - sw) = target"""
+    return _root(lambda s: pcow_of_sw(s) + pcgo_of_sg(1.0 - s) - target, swl, swu)
+
+
+def equilibrate_regions(eqlnum, records, props, rho_ref, cell_depth, cell_zmin, cell_zmax, sat_limits, grav=9.80665,
+                        rs_funcs=None, rv_funcs=None, nsample=NSAMPLE):
+    """InitialStateComputer::calcPressSatRsRv (initstateequil.hh:1882-1940): every equilibration region (EQLNUM, 0-based)
+    with its own EQUIL record over the vertical extent of ITS cells.  props / rho_ref / sat_limits / rs_funcs / rv_funcs: one
+    per region (list) or one for all.  -> the dict of `equilibrate`, arrays over all cells (zeros where no region applies)"""
+    eqlnum = np.asarray(eqlnum, int)
+    n = len(eqlnum)
+    cell_depth, cell_zmin, cell_zmax = (np.asarray(a, float) for a in (cell_depth, cell_zmin, cell_zmax))
+    per = lambda x, r: x[r] if isinstance(x, list) else x   # a list: one per region
+    out = {k: np.zeros(n) for k in ("pw", "po", "pg", "sw", "so", "sg", "rs", "rv")}
+    for r, rec in enumerate(records):
+        cells = np.nonzero(eqlnum == r)[0]
+        if len(cells) == 0:
+            continue
+        if rec.get("accuracy", 0) > 0:
+            raise ValueError("EQUIL record %d: positive item 9 is not supported (neither is it by the reference)" % (r + 1))
+        span = (float(cell_zmin[cells].min()), float(cell_zmax[cells].max()))
+        rs_f = rs_funcs[r] if rs_funcs is not None else None
+        rv_f = rv_funcs[r] if rv_funcs is not None else None
+        res = equilibrate(per(props, r), per(rho_ref, r), rec, cell_depth[cells], span, per(sat_limits, r), grav=grav,
+                          rs_func=rs_f, nsample=nsample, rv_func=rv_f)
+        for k in out:
+            out[k][cells] = res[k]
+    return out
+
+
+def equilibrate(props, rho_ref, rec, cell_depth, z_span, sat_limits, grav=9.80665, rs_func=None, nsample=NSAMPLE, rv_func=None):
+    """props.probe(p, rs, sw, sg) -> (n, 8) (capi.HipFluid layout); rho_ref = (oil, water, gas) surface densities;
+    rec = dict(datum, pressure, zwoc, pcow_woc, zgoc, pcgo_goc); cell_depth[]: centre depths; z_span = (top, bottom) of the
+    region's cells; sat_limits = dict(Swl, Swu, Sgl, Sgu) (unscaled end points of the saturation tables).
+    rv_func (wet gas, VAPOIL): Rv(depth, p_g, sat_oil) - RvSatAtContact / RvVD / PDVD; props then also needs
+    probe_gas(p, rv) -> (n, 3): 1/B_g(p, rv), mu_g, RvSat(p).
+    -> dict(pw, po, pg, sw, so, sg, rs, rv) arrays over the cells."""
+    if rs_func is None:
+        if rec["zgoc"] != rec["datum"]:
+            raise ValueError("without an RSVD table the datum depth must be at the gas-oil contact")
+        rs_func = RsSatAtContact(props, rec["pressure"])
+    wat, oil, gas = phase_pressure_tables(props, rho_ref, rec, z_span, grav, rs_func, rv_func, nsample)
 
     Swl, Swu, Sgl, Sgu = (sat_limits[k] for k in ("Swl", "Swu", "Sgl", "Sgu"))
     pcow = lambda sw: float(props.probe(1e5, sw=sw)[0, PCOW])
     pcgo = lambda sg: float(props.probe(1e5, sg=sg)[0, PCGO])
 
-    def root(fun, s0, s1):
-        """zero of a monotone function with fun(s0) > 0 > fun(s1) (RegulaFalsiBisection to 1e-10 in the reference)"""
-        f0, f1 = fun(s0), fun(s1)
-        if f0 <= 0.0:
-            return s0
-        if f1 >= 0.0:
-            return s1
-        a, b, fa, fb = s0, s1, f0, f1
-        for _ in range(200):
-            m = 0.5 * (a + b)
-            fm = fun(m)
-            if fm > 0.0:
-                a, fa = m, fm
-            else:
-                b, fb = m, fm
-            if abs(b - a) < 1e-13:
-                break
-        return 0.5 * (a + b)
-
-    def sat_from_pc(pc_of_s, smin, smax, target, increasing):
-        s0, s1 = (smax, smin) if increasing else (smin, smax)
-        return root(lambda s: pc_of_s(s) - target, s0, s1)
+    root = _root
 
     n = len(cell_depth)
     out = {k: np.zeros(n) for k in ("pw", "po", "pg", "sw", "so", "sg", "rs", "rv")}

@@ -155,6 +155,73 @@ def wet_gas_case(deck, test_name, next_test, lines):
     return out
 
 
+def all_dead_case():
+    """equil_deadfluids.DATA / DeckAllDead (tests/test_equil.cc:477-502): three pressures, tolerance 0.1 %; no saturation vectors"""
+    d = dead_oil_case_tables("equil_deadfluids.DATA", 10.0)
+    with open(os.path.join(REF, "tests/test_equil.cc")) as f:
+        txt = f.read()
+    body = txt[txt.index("BOOST_AUTO_TEST_CASE(DeckAllDead)"):txt.index("BOOST_AUTO_TEST_CASE(CapillaryInversion)")]
+    num = r"[-+]?\d+\.?\d*(?:[eE][-+]?\d+)?"
+    pr = {}
+    for name, which, val in re.findall(r"BOOST_CHECK_CLOSE\(pressures\[FluidSystem::(\w+)PhaseIdx\]\s*\[(\w+)\s*\]\s*,\s*(" + num + r")\s*,\s*reltol\);", body):
+        pr["p%s_%s" % (name[0], which)] = float(val)
+    d["expected"] = dict(source="tests/test_equil.cc:477-502 (DeckAllDead)", reltol_percent=float(re.search(r"const double reltol = (" + num + r");", body).group(1)), **pr)
+    return d
+
+
+def dead_oil_case_tables(deck, gravity):
+    """the property tables, grid and EQUIL record of a PVDO deck (no expectations)"""
+    k = tokenize_sections(os.path.join(REF, "tests", deck))
+    U = METRIC
+    pvtw, dens, eq = k["PVTW"][0], k["DENSITY"][0], k["EQUIL"][0]
+    dz = [v * U["length"] for v in k["DZV"][0]]
+    rock = k.get("ROCK", [[1.0, 0.0]])[0]
+    eq = list(eq) + [0] * (9 - len(eq))
+    return dict(
+        source="tests/%s (METRIC units converted to SI); dead oil (PVDO), no dissolved gas; EQUIL item 9 = 0" % deck,
+        gravity=gravity,
+        pvtw=dict(p_ref=pvtw[0] * U["pressure"], bw_ref=pvtw[1], cw=pvtw[2] * U["compressibility"], mu_ref=pvtw[3] * U["viscosity"],
+                  cv=pvtw[4] * U["compressibility"]),
+        rock=dict(p_ref=rock[0] * U["pressure"], cr=rock[1] * U["compressibility"]),
+        density=dict(oil=dens[0] * U["density"], water=dens[1] * U["density"], gas=dens[2] * U["density"]),
+        swof=[[r[0], r[1], r[2], r[3] * U["pressure"]] for r in table(k["SWOF"][0], 4)],
+        sgof=[[r[0], r[1], r[2], r[3] * U["pressure"]] for r in table(k["SGOF"][0], 4)],
+        pvdg=[[r[0] * U["pressure"], r[1] * U["gas_fvf"], r[2] * U["viscosity"]] for r in table(k["PVDG"][0], 3)],
+        pvdo=[[r[0] * U["pressure"], r[1] * U["oil_fvf"], r[2] * U["viscosity"]] for r in table(k["PVDO"][0], 3)],
+        grid=dict(nz=len(dz), dz=dz, tops=(k["TOPS"][0][0] if "TOPS" in k else k["DEPTHZ"][0][0]) * U["length"]),
+        equil=dict(datum=eq[0] * U["length"], pressure=eq[1] * U["pressure"], zwoc=eq[2] * U["length"], pcow_woc=eq[3] * U["pressure"],
+                   zgoc=eq[4] * U["length"], pcgo_goc=eq[5] * U["pressure"], accuracy=int(eq[8] or 0)))
+
+
+def capillary_inversion():
+    """CapillaryInversion (tests/test_equil.cc:504-554): (pc, saturation) vectors of satFromPc for oil-water and gas-oil and of
+    satFromSumOfPcs, on the saturation tables of equil_capillary.DATA (fixture 'capillary')"""
+    with open(os.path.join(REF, "tests/test_equil.cc")) as f:
+        txt = f.read()
+    body = txt[txt.index("BOOST_AUTO_TEST_CASE(CapillaryInversion)"):txt.index("BOOST_AUTO_TEST_CASE(DeckWithCapillary)")]
+    num = r"[-+]?\d+\.?\d*(?:[eE][-+]?\d+)?"
+    pcs = [[float(t) for t in re.findall(num, m)] for m in re.findall(r"std::vector<double> pc = \{(.*?)\};", body, re.S)]
+    ss = [[float(t) for t in re.findall(num, m)] for m in re.findall(r"std::vector<double> s = \{(.*?)\};", body, re.S)]
+    assert len(pcs) == 3 and len(ss) == 3
+    return dict(source="tests/test_equil.cc:504-554 (CapillaryInversion); tables: fixture 'capillary'", reltol_percent=1.0e-5,
+                oil_water=dict(pc=pcs[0], s=ss[0], increasing=False), gas_oil=dict(pc=pcs[1], s=ss[1], increasing=True),
+                gas_water=dict(pc=pcs[2], s=ss[2]))
+
+
+def default_fluid_cases():
+    """PhasePressure, CellSubset, RegMapping (tests/test_equil.cc:218-475): the test's own constant-density fluid
+    (initDefaultFluidSystem :119-182: B = 1, 700 / 1000 / 1000 kg/m3, no mixing), 10 x 1 x 10 cells of 1 m (equil_base.DATA), g = 10"""
+    rec = lambda datd, datp, zwoc, pcow, zgoc, pcgo: dict(datum=datd, pressure=datp, zwoc=zwoc, pcow_woc=pcow, zgoc=zgoc, pcgo_goc=pcgo, accuracy=0)
+    two = [rec(0, 1e5, 2.5, -0.075e5, 0, 0), rec(5, 1.35e5, 7.5, -0.225e5, 5, 0)]
+    return dict(source="tests/test_equil.cc:218-475; grid tests/equil_base.DATA (DIMENS 10 1 10, DX = DY = DZ = 1, TOPS 0)",
+                gravity=10.0, density=dict(oil=700.0, water=1000.0, gas=1000.0), grid=dict(nx=10, ny=1, nz=10, d=1.0, tops=0.0),
+                phase_pressure=dict(record=rec(0, 1e5, 5, 0, 0, 0), reltol_percent=1.0e-6,
+                                    expected=dict(pw_first=90e3, pw_last=180e3, po_first=103.5e3, po_last=166.5e3)),
+                regions=dict(records=[two[0], two[0], two[1], two[1]],
+                             cell_subset="coarse blocks of 5 x 1 x 5 cells (:309-326)", reg_mapping="EQLNUM [0 1; 2 3] by layer and column (:425-444)",
+                             reltol_percent=1.0e-6, expected=dict(pw_first=105e3, pw_last=195e3, po_first=103.5e3, po_last=166.5e3)))
+
+
 if __name__ == "__main__":
     out = dict(liveoil=liveoil(),
                capillary=dead_oil_case("equil_capillary.DATA", "DeckWithCapillary", "DeckWithCapillaryOverlap", 10.0, r"\bs", "556-594"),
@@ -162,7 +229,8 @@ if __name__ == "__main__":
                                                r"s_opm", "596-654"),
                livegas=wet_gas_case("equil_livegas.DATA", "DeckWithLiveGas", "DeckWithRSVDAndRVVD", "734-812"),
                rsvd_rvvd=wet_gas_case("equil_rsvd_and_rvvd.DATA", "DeckWithRSVDAndRVVD", "DeckWithPBVDAndPDVD", "814-912"),
-               pbvd_pdvd=wet_gas_case("equil_pbvd_and_pdvd.DATA", "DeckWithPBVDAndPDVD", "DeckWithSwatinit", "914-1004"))
+               pbvd_pdvd=wet_gas_case("equil_pbvd_and_pdvd.DATA", "DeckWithPBVDAndPDVD", "DeckWithSwatinit", "914-1004"),
+               alldead=all_dead_case(), capillary_inversion=capillary_inversion(), default_fluid=default_fluid_cases())
     path = os.path.join(ROOT, "tests", "golden", "equil.json")
     with open(path, "w") as f:
         json.dump(out, f, indent=1)

@@ -192,3 +192,110 @@ def test_wet_gas_decks_with_the_oracle_functions(orc, name):
     tolerances (1e-4 % for the RSVD/RVVD deck)."""
     d, r = wet_gas_setup(name, lambda fl: oracle_bind.OracleFluid(orc, fl))
     check_wet_gas(d, r)
+
+
+# ---- the remaining cases of tests/test_equil.cc: pressure tables per region, all-dead deck, capillary inversion --------------
+class ConstProps:
+    """initDefaultFluidSystem of the reference test (:119-182): formation-volume factors 1, no mixing, no capillary pressure"""
+
+    def probe(self, p, rs=0.0, sw=0.0, sg=0.0, **kw):
+        out = np.zeros((np.size(p), 8))
+        out[:, [pkg.equil.INVBW, pkg.equil.INVBG, pkg.equil.INVBO]] = 1.0
+        return out
+
+
+def default_fluid_case():
+    with open(os.path.join(GOLDEN, "equil.json")) as f:
+        d = json.load(f)["default_fluid"]
+    g = d["grid"]
+    nx, nz = g["nx"], g["nz"]
+    k = np.repeat(np.arange(nz), nx)                     # cell c = i + nx * k
+    i = np.tile(np.arange(nx), nz)
+    zmin = g["tops"] + k * g["d"]
+    rho = (d["density"]["oil"], d["density"]["water"], d["density"]["gas"])
+    return d, i, k, zmin, zmin + g["d"], zmin + 0.5 * g["d"], rho
+
+
+def test_phase_pressure_of_the_default_fluid():
+    """tests/test_equil.cc PhasePressure (:218-264)"""
+    d, i, k, zmin, zmax, centre, rho = default_fluid_case()
+    c = d["phase_pressure"]
+    wat, oil, gas = pkg.equil.phase_pressure_tables(ConstProps(), rho, c["record"], (zmin.min(), zmax.max()), grav=d["gravity"])
+    e, rel = c["expected"], c["reltol_percent"] / 100.0
+    np.testing.assert_allclose([wat(centre[0]), wat(centre[-1]), oil(centre[0]), oil(centre[-1])],
+                               [e["pw_first"], e["pw_last"], e["po_first"], e["po_last"]], rtol=rel)
+
+
+@pytest.mark.parametrize("mapping", ["cell_subset", "reg_mapping"])
+def test_equilibration_regions(mapping):
+    """tests/test_equil.cc CellSubset (:266-369: coarse 2 x 1 x 2 blocks) and RegMapping (:371-475: EQLNUM): four regions, two
+    EQUIL records; both describe the same partition of the 10 x 1 x 10 grid"""
+    d, i, k, zmin, zmax, centre, rho = default_fluid_case()
+    c = d["regions"]
+    if mapping == "cell_subset":
+        eqlnum = (i // 5) + 2 * (k // 5)          # ix = ic + cdim[0] * (jc + cdim[1] * kc), cdim = (2, 1, 2)
+    else:
+        eqlnum = np.where(k < 5, np.where(i < 5, 0, 1), np.where(i < 5, 2, 3))
+    limits = dict(Swl=0.0, Swu=1.0, Sgl=0.0, Sgu=1.0)
+    r = pkg.equil.equilibrate_regions(eqlnum, c["records"], ConstProps(), rho, centre, zmin, zmax, limits, grav=d["gravity"],
+                                      rs_funcs=[lambda z, p, sat_gas=0.0: 0.0] * 4)
+    e, rel = c["expected"], c["reltol_percent"] / 100.0
+    # the reference reads the pressure tables at the cell centres (ptable.water / ptable.oil): po and the water pressure
+    # before the end-point corrections of the saturation step, which only touch cells where a phase is absent
+    wat0 = pkg.equil.phase_pressure_tables(ConstProps(), rho, c["records"][0], (0.0, 10.0), grav=d["gravity"])[0]
+    wat3 = pkg.equil.phase_pressure_tables(ConstProps(), rho, c["records"][3], (0.0, 10.0), grav=d["gravity"])[0]
+    np.testing.assert_allclose([wat0(centre[0]), wat3(centre[-1])], [e["pw_first"], e["pw_last"]], rtol=rel)
+    np.testing.assert_allclose([r["po"][0]], [e["po_first"]], rtol=rel)
+    # last cell: below the contact of its region the oil pressure follows the water pressure (no oil there); the table value
+    oil3 = pkg.equil.phase_pressure_tables(ConstProps(), rho, c["records"][3], (0.0, 10.0), grav=d["gravity"])[1]
+    np.testing.assert_allclose(oil3(centre[-1]), e["po_last"], rtol=rel)
+    # the region loop: every cell belongs to exactly one region and was equilibrated with that region's record
+    assert np.all(r["sw"] + r["so"] + r["sg"] == 1.0)
+    for reg in range(4):
+        cells = np.nonzero(eqlnum == reg)[0]
+        one = pkg.equil.equilibrate(ConstProps(), rho, c["records"][reg], centre[cells], (zmin[cells].min(), zmax[cells].max()), limits,
+                                    grav=d["gravity"], rs_func=lambda z, p, sat_gas=0.0: 0.0)
+        for key in ("pw", "po", "pg", "sw", "sg"):
+            np.testing.assert_array_equal(r[key][cells], one[key])
+
+
+def dead_fluid(d):
+    w = d["pvtw"]
+    dummy_pvto = [dict(rs=0.0, p=[1e5, 2e5], bo=[1.0, 0.999], mu=[1e-3, 1e-3]), dict(rs=100.0, p=[200e5, 300e5], bo=[1.2, 1.19], mu=[1e-3, 1e-3])]
+    return pkg.fluid.Fluid([dict(pvtw=[w["p_ref"], w["bw_ref"], w["cw"], w["mu_ref"], w["cv"]],
+                                 density=[d["density"]["oil"], d["density"]["water"], d["density"]["gas"]], pvdg=d["pvdg"], pvto=dummy_pvto)],
+                           [dict(swof=d["swof"], sgof=d["sgof"])])
+
+
+def test_all_dead_deck(orc):
+    """tests/test_equil.cc DeckAllDead (:477-502): dead oil, dry gas, datum in the water zone; the reference's own tolerance 0.1 %"""
+    with open(os.path.join(GOLDEN, "equil.json")) as f:
+        d = json.load(f)["alldead"]
+    dz = np.array(d["grid"]["dz"])
+    top = d["grid"]["tops"] + np.concatenate([[0.0], np.cumsum(dz)[:-1]])
+    limits = dict(Swl=d["swof"][0][0], Swu=d["swof"][-1][0], Sgl=d["sgof"][0][0], Sgu=d["sgof"][-1][0])
+    rho = (d["density"]["oil"], d["density"]["water"], d["density"]["gas"])
+    props = DeadOilProps(oracle_bind.OracleFluid(orc, dead_fluid(d)), d["pvdo"])
+    r = pkg.equil.equilibrate(props, rho, d["equil"], top + 0.5 * dz, (float(top[0]), float(top[-1] + dz[-1])), limits, grav=d["gravity"],
+                              rs_func=lambda z, p, sat_gas=0.0: 0.0)
+    e = d["expected"]
+    np.testing.assert_allclose([r["pw"][0], r["pw"][-1], r["po"][-1]], [e["pw_first"], e["pw_last"], e["po_last"]], rtol=e["reltol_percent"] / 100.0)
+
+
+def test_capillary_inversion(orc):
+    """tests/test_equil.cc CapillaryInversion (:504-554): satFromPc (oil-water, gas-oil) and satFromSumOfPcs on the saturation
+    tables of equil_capillary.DATA, the capillary pressures evaluated by the oracle's saturation functions"""
+    with open(os.path.join(GOLDEN, "equil.json")) as f:
+        all_ = json.load(f)
+    d, e = all_["capillary"], all_["capillary_inversion"]
+    props = oracle_bind.OracleFluid(orc, dead_fluid(d))
+    pcow = lambda sw: float(props.probe(1e5, sw=sw)[0, pkg.equil.PCOW])
+    pcgo = lambda sg: float(props.probe(1e5, sg=sg)[0, pkg.equil.PCGO])
+    swl, swu, sgl, sgu = d["swof"][0][0], d["swof"][-1][0], d["sgof"][0][0], d["sgof"][-1][0]
+    rel = e["reltol_percent"] / 100.0
+    got = [pkg.equil.sat_from_pc(pcow, swl, swu, pc, increasing=False) for pc in e["oil_water"]["pc"]]
+    np.testing.assert_allclose(got, e["oil_water"]["s"], rtol=rel, atol=1e-12)
+    got = [pkg.equil.sat_from_pc(pcgo, sgl, sgu, pc, increasing=True) for pc in e["gas_oil"]["pc"]]
+    np.testing.assert_allclose(got, e["gas_oil"]["s"], rtol=rel, atol=1e-12)
+    got = [pkg.equil.sat_from_sum_of_pcs(pcow, pcgo, swl, swu, pc) for pc in e["gas_water"]["pc"]]
+    np.testing.assert_allclose(got, e["gas_water"]["s"], rtol=rel, atol=1e-12)

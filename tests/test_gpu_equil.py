@@ -62,3 +62,31 @@ def test_gas_probe_bitwise_vs_oracle(pkg, orc):
     dry = pkg.fluid.spe1_fluid()[0]
     a = pkg.capi.HipFluid(dry).probe_gas(p[:50], 0.0)
     assert np.array_equal(a[:, 0], oracle_bind.OracleFluid(orc, dry).probe(p[:50])[:, 1]) and not a[:, 2].any()
+
+
+def test_all_dead_deck_and_capillary_inversion_with_the_device_functions(pkg):
+    """tests/test_equil.cc DeckAllDead (:477-502) and CapillaryInversion (:504-554) on top of the DEVICE's water / gas
+    densities and capillary pressures"""
+    import json, os
+    from test_equil import GOLDEN, DeadOilProps, dead_fluid
+    with open(os.path.join(GOLDEN, "equil.json")) as f:
+        all_ = json.load(f)
+    d = all_["alldead"]
+    dz = np.array(d["grid"]["dz"])
+    top = d["grid"]["tops"] + np.concatenate([[0.0], np.cumsum(dz)[:-1]])
+    limits = dict(Swl=d["swof"][0][0], Swu=d["swof"][-1][0], Sgl=d["sgof"][0][0], Sgu=d["sgof"][-1][0])
+    rho = (d["density"]["oil"], d["density"]["water"], d["density"]["gas"])
+    props = DeadOilProps(pkg.capi.HipFluid(dead_fluid(d)), d["pvdo"])
+    r = pkg.equil.equilibrate(props, rho, d["equil"], top + 0.5 * dz, (float(top[0]), float(top[-1] + dz[-1])), limits, grav=d["gravity"],
+                              rs_func=lambda z, p, sat_gas=0.0: 0.0)
+    e = d["expected"]
+    np.testing.assert_allclose([r["pw"][0], r["pw"][-1], r["po"][-1]], [e["pw_first"], e["pw_last"], e["po_last"]], rtol=e["reltol_percent"] / 100.0)
+    d, e = all_["capillary"], all_["capillary_inversion"]
+    props = pkg.capi.HipFluid(dead_fluid(d))
+    pcow = lambda sw: float(props.probe(1e5, sw=sw)[0, pkg.equil.PCOW])
+    pcgo = lambda sg: float(props.probe(1e5, sg=sg)[0, pkg.equil.PCGO])
+    swl, swu, sgl, sgu = d["swof"][0][0], d["swof"][-1][0], d["sgof"][0][0], d["sgof"][-1][0]
+    rel = e["reltol_percent"] / 100.0
+    np.testing.assert_allclose([pkg.equil.sat_from_pc(pcow, swl, swu, pc, increasing=False) for pc in e["oil_water"]["pc"]], e["oil_water"]["s"], rtol=rel, atol=1e-12)
+    np.testing.assert_allclose([pkg.equil.sat_from_pc(pcgo, sgl, sgu, pc, increasing=True) for pc in e["gas_oil"]["pc"]], e["gas_oil"]["s"], rtol=rel, atol=1e-12)
+    np.testing.assert_allclose([pkg.equil.sat_from_sum_of_pcs(pcow, pcgo, swl, swu, pc) for pc in e["gas_water"]["pc"]], e["gas_water"]["s"], rtol=rel, atol=1e-12)
