@@ -412,3 +412,41 @@ def test_drift_survives_a_rolled_back_step(pkg, orc):
     j, r = m.assemble(0.33 * dt, 0)
     jo, ro = o.assemble(0.33 * dt, 0)
     assert np.array_equal(r, ro) and np.array_equal(j, jo)
+
+
+@pytest.mark.parametrize("reorder", ["graph_coloring", "line_coloring"])
+def test_deck_side_inputs_through_the_hot_path(pkg, orc, reorder):
+    """transmissibility.py + thpres.py -> set_pattern / set_static: a layered grid with an inactive cell, NTG, MULTZ, two
+    NNCs (one on top of a grid face, one between cells the grid does not connect: a pattern no Cartesian stencil has) and
+    threshold pressures between three equilibration regions, one of them defaulted from the DEVICE's initial intensive
+    quantities (ebos/eclthresholdpressure.hh:96-163).  Jacobian and residual bit for bit against the oracle."""
+    T, H = pkg.transmissibility, pkg.thpres
+    nx, ny, nz = 6, 5, 7
+    rng = np.random.default_rng(11)
+    dz = np.repeat(rng.uniform(2.0, 6.0, nz), nx * ny)
+    act = np.ones(nx * ny * nz, int); act[40] = 0
+    g = T.cartesian_faces(nx, ny, nz, 25.0, 20.0, dz, 2400.0, actnum=act)
+    n, F = g["n"], g["faces"]
+    perm = (rng.uniform(20.0, 300.0, (n, 1)) * np.array([1.0, 1.0, 0.1])) * 9.869233e-16
+    multz = np.where(rng.random(n) < 0.2, 0.05, 1.0)
+    t = T.face_transmissibilities(F, g["centroid"], perm, ntg=rng.uniform(0.5, 1.0, n), mult={"Z+": multz})
+    c1, c2, t, _ = T.apply_nnc(F["cell1"], F["cell2"], t, nnc=[(3, 4, 0.5 * t[0]), (2, n - 5, 2.0 * t.mean())])
+    pat = T.connections_to_pattern(n, c1, c2, t, g["face_area"])
+    base = pkg.decks.cartesian_cells(n, 1, 1, 25.0, 20.0, 4.0, 2400.0, 0.25, 100.0, False, "mixed", True, None, 5)
+    case = dict(Nb=n, rowptr=pat["rowptr"], col=pat["col"], trans=pat["trans"], area=pat["area"], poro=base["poro"],
+                volume=np.ascontiguousarray(g["volume"]), depth=np.ascontiguousarray(g["depth"]), fluid=base["fluid"], pv=base["pv"], meaning=base["meaning"])
+    # first pass without thresholds: the initial intensive quantities the defaults are made of
+    m0 = pkg.capi.HipModel(case, reorder=reorder)
+    m0.set_state(case["pv"], case["meaning"])
+    eql = (np.arange(n) * 3) // n
+    d = H.default_threshold_pressures(eql, 3, c1, c2, t, np.concatenate([g["face_area"], np.ones(len(t) - len(g["face_area"]))]), m0.iq()[:n], g["depth"])
+    assert d[0, 1] > 0.0 and d[1, 2] > 0.0
+    mat = H.threshold_pressure_matrix(3, [(1, 2, None), (2, 3, 0.4e5)], eql, c1, c2, defaults=d)
+    case["thpres"] = np.ascontiguousarray(H.per_entry(pat["rowptr"], pat["col"], eql, mat))
+    assert np.count_nonzero(case["thpres"]) > 0
+    m, o = both(pkg, orc, case, reorder=reorder)
+    assert np.array_equal(m.iq(), o.iq())
+    for it in range(2):
+        jm, rm = m.assemble(86400.0, it)
+        jo, ro = o.assemble(86400.0, it)
+        assert np.array_equal(rm, ro) and np.array_equal(jm, jo)

@@ -1,0 +1,144 @@
+"""Deck-side inputs of the hot path: transmissibilities (ebos/ecltransmissibility.cc) and
+threshold pressures (ebos/eclthresholdpressure.hh, eclgenericthresholdpressure.cc).  The reference holds no numbers for
+either (tests/test_thresholdpressure.cpp only checks that a vector comes back), so these are property tests of the
+restated formulas: unpinned, as DESIGN.md says."""
+import importlib
+
+import numpy as np
+import pytest
+
+pkg = importlib.import_module("opm-autodiff_amd")
+T = pkg.transmissibility
+
+
+def uniform(nx=4, ny=3, nz=5, dx=20.0, dy=30.0, dz=4.0):
+    g = T.cartesian_faces(nx, ny, nz, dx, dy, dz, 1000.0)
+    rng = np.random.default_rng(3)
+    perm = rng.uniform(1e-14, 1e-12, (g["n"], 3))
+    return g, perm
+
+
+def test_uniform_grid_reproduces_the_cartesian_formula_bit_for_bit():
+    nx, ny, nz, dx, dy, dz = 4, 3, 5, 20.0, 30.0, 4.0
+    g, perm = uniform(nx, ny, nz, dx, dy, dz)
+    t = T.face_transmissibilities(g["faces"], g["centroid"], perm)
+    pat = T.connections_to_pattern(g["n"], g["faces"]["cell1"], g["faces"]["cell2"], t, g["face_area"])
+    ref_pat = pkg.grid.cartesian_pattern(nx, ny, nz)
+    assert np.array_equal(pat["rowptr"], ref_pat["rowptr"]) and np.array_equal(pat["col"], ref_pat["col"])
+    ref_t = pkg.grid.tpfa_transmissibility(ref_pat, perm[:, 0].copy(), perm[:, 1].copy(), perm[:, 2].copy(), dx, dy, dz)
+    _, depth, ref_area = pkg.grid.cartesian_geometry(ref_pat, dx, dy, dz, 1000.0)
+    # the general formula sums A.d over three components (two of them zero) and |d|^2 likewise: same roundings
+    np.testing.assert_allclose(pat["trans"], ref_t, rtol=4e-16, atol=0.0)
+    off = pat["conn"] >= 0
+    assert np.array_equal(pat["area"][off], ref_area[off])   # the diagonal entries carry no face
+    np.testing.assert_allclose(g["depth"], depth, rtol=1e-15)
+    assert np.array_equal(g["volume"], np.full(g["n"], dx * dy * dz))
+
+
+def test_ntg_multipliers_and_region_multipliers():
+    g, perm = uniform()
+    F = g["faces"]
+    base = T.face_transmissibilities(F, g["centroid"], perm)
+    ntg = np.random.default_rng(1).uniform(0.2, 1.0, g["n"])
+    t = T.face_transmissibilities(F, g["centroid"], perm, ntg=ntg)
+    z = F["face1"] >= T.ZM
+    assert np.array_equal(t[z], base[z])                       # NTG leaves vertical transmissibilities alone (:1016-1043)
+    c1, c2 = F["cell1"][~z], F["cell2"][~z]
+    ax = F["face1"][~z] // 2
+    h1 = perm[c1, ax] * ntg[c1]
+    h2 = perm[c2, ax] * ntg[c2]
+    # the geometric factor of both halves is the same on a uniform grid: T ~ harmonic mean of K * NTG
+    np.testing.assert_allclose(t[~z] / base[~z], (1.0 / (1.0 / h1 + 1.0 / h2)) / (1.0 / (1.0 / perm[c1, ax] + 1.0 / perm[c2, ax])), rtol=1e-13)
+    # MULTX acts on the + face of its own cell, MULTX- on the - face (:982-1013): the face between i and i+1 takes both
+    mx, mxm = np.full(g["n"], 1.0), np.full(g["n"], 1.0)
+    mx[5], mxm[6] = 0.5, 0.25
+    t = T.face_transmissibilities(F, g["centroid"], perm, mult={"X+": mx, "X-": mxm})
+    ratio = t / base
+    hit = (F["cell1"] == 5) & (F["cell2"] == 6)
+    assert hit.sum() == 1 and t[hit][0] == base[hit][0] * 0.5 * 0.25
+    other = (F["face1"] == T.XP) & (((F["cell1"] == 5) | (F["cell2"] == 6)) & ~hit)
+    assert np.all(ratio[~hit & ~other] == 1.0)
+    # zero permeability closes a face without a division by zero (:352-356)
+    p0 = perm.copy(); p0[7] = 0.0
+    t = T.face_transmissibilities(F, g["centroid"], p0)
+    assert np.all(t[(F["cell1"] == 7) | (F["cell2"] == 7)] == 0.0) and np.all(np.isfinite(t))
+    # MULTREGT: a factor per region pair and direction
+    reg = (np.arange(g["n"]) % 2)
+    t = T.face_transmissibilities(F, g["centroid"], perm, region_mult=lambda a, b, axis: np.where((reg[a] != reg[b]) & (axis == 0), 0.1, 1.0))
+    sel = (reg[F["cell1"]] != reg[F["cell2"]]) & (F["face1"] // 2 == 0)
+    assert np.array_equal(t[sel], base[sel] * 0.1) and np.array_equal(t[~sel], base[~sel])
+
+
+def test_layered_grid_and_inactive_cells():
+    nx, ny, nz = 3, 2, 4
+    dz = np.repeat([2.0, 6.0, 3.0, 5.0], nx * ny)
+    act = np.ones(nx * ny * nz, int); act[7] = 0
+    g = T.cartesian_faces(nx, ny, nz, 10.0, 10.0, dz, 2000.0, actnum=act)
+    assert g["n"] == nx * ny * nz - 1 and 7 not in g["cart"]
+    np.testing.assert_allclose(g["depth"][0], 2001.0)
+    np.testing.assert_allclose(g["depth"][-1], 2000.0 + 2 + 6 + 3 + 2.5)
+    perm = np.full((g["n"], 3), 1e-13)
+    t = T.face_transmissibilities(g["faces"], g["centroid"], perm)
+    F = g["faces"]
+    zf = F["face1"] == T.ZP
+    # vertical face between layers of thickness a and b: K A / ((a + b) / 2)
+    a, b = g["volume"][F["cell1"][zf]] / 100.0, g["volume"][F["cell2"][zf]] / 100.0
+    np.testing.assert_allclose(t[zf], 1e-13 * 100.0 / (0.5 * (a + b)), rtol=1e-13)
+    assert not np.any((g["cart"][F["cell1"]] == 7) | (g["cart"][F["cell2"]] == 7))
+
+
+def test_nnc_and_editnnc():
+    g, perm = uniform(3, 1, 2)
+    F = g["faces"]
+    t = T.face_transmissibilities(F, g["centroid"], perm)
+    c1, c2, t2, bad = T.apply_nnc(F["cell1"], F["cell2"], t, nnc=[(0, 5, 7.0), (1, 0, 2.0), (-1, 3, 1.0), (-1, -1, 1.0)], editnnc=[(0, 1, 3.0), (0, 4, 9.0)])
+    q = np.nonzero((F["cell1"] == 0) & (F["cell2"] == 1))[0][0]
+    assert t2[q] == t[q] * 3.0 + 2.0                      # EDITNNC scales first, the NNC then adds (:487-488)
+    assert (c1[-1], c2[-1], t2[-1]) == (0, 5, 7.0)        # not resembled by the grid: a connection of its own
+    assert len(t2) == len(t) + 1 and bad == [(0, 4, 9.0)]
+    pat = T.connections_to_pattern(g["n"], c1, c2, t2, g["face_area"])
+    row = np.repeat(np.arange(g["n"]), np.diff(pat["rowptr"]))
+    k = np.nonzero((row == 5) & (pat["col"] == 0))[0][0]
+    assert pat["trans"][k] == 7.0 and pat["area"][k] == 1.0
+    # symmetric pattern: every entry has its transpose
+    s = set(zip(row.tolist(), pat["col"].tolist()))
+    assert all((b, a) in s for a, b in s)
+
+
+def test_threshold_pressures():
+    H = pkg.thpres
+    g, perm = uniform(4, 1, 3)
+    F = g["faces"]
+    t = T.face_transmissibilities(F, g["centroid"], perm)
+    n = g["n"]
+    eql = np.array([0, 0, 1, 2] * 3)
+    rng = np.random.default_rng(0)
+    iq = np.zeros((n, 17, 4))
+    iq[:, H.F_P:H.F_P + 3, 0] = rng.uniform(200e5, 210e5, (n, 3))
+    iq[:, H.F_RHO:H.F_RHO + 3, 0] = np.array([1000.0, 800.0, 150.0])
+    iq[:, H.F_MOB:H.F_MOB + 3, 0] = rng.uniform(0.0, 1.0, (n, 3))
+    iq[:, H.F_MOB + 2, 0] = 0.0                             # gas immobile everywhere: it must not set a default
+    d = H.default_threshold_pressures(eql, 3, F["cell1"], F["cell2"], t, g["face_area"], iq, g["depth"])
+    assert np.array_equal(d, d.T) and np.all(np.diag(d) == 0.0) and d[0, 2] == 0.0   # regions 0 and 2 never meet
+    # brute force over the faces, both orientations, as computeDefaultThresholdPressures_ walks them
+    exp = np.zeros((3, 3))
+    for a, b in zip(F["cell1"], F["cell2"]):
+        if eql[a] == eql[b]:
+            continue
+        for i, j in ((a, b), (b, a)):
+            for ph in range(2):
+                rho = (iq[i, H.F_RHO + ph, 0] + iq[j, H.F_RHO + ph, 0]) / 2.0
+                dp = iq[j, H.F_P + ph, 0] + rho * ((g["depth"][i] - g["depth"][j]) * H.GRAVITY) - iq[i, H.F_P + ph, 0]
+                up = j if dp > 0 else i
+                if iq[up, H.F_MOB + ph, 0] > 0.0:
+                    exp[eql[a], eql[b]] = exp[eql[b], eql[a]] = max(exp[eql[a], eql[b]], abs(dp))
+    np.testing.assert_allclose(d, exp, rtol=1e-15)
+    m = H.threshold_pressure_matrix(3, [(1, 2, 12.0e5), (2, 3, None), (1, 3, 5.0e5)], eql, F["cell1"], F["cell2"], defaults=d)
+    assert m[0, 1] == m[1, 0] == 12.0e5 and m[1, 2] == d[1, 2] and m[0, 2] == 0.0   # 1-3 has a record but no common face
+    with pytest.raises(ValueError):
+        H.threshold_pressure_matrix(3, [(2, 3, None)], eql, F["cell1"], F["cell2"])
+    pat = T.connections_to_pattern(n, F["cell1"], F["cell2"], t, g["face_area"])
+    e = H.per_entry(pat["rowptr"], pat["col"], eql, m)
+    row = np.repeat(np.arange(n), np.diff(pat["rowptr"]))
+    assert np.all(e[eql[row] == eql[pat["col"]]] == 0.0)
+    assert np.all(e[(eql[row] == 0) & (eql[pat["col"]] == 1)] == 12.0e5)
