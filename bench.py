@@ -299,42 +299,60 @@ def main():
     W = timed_window(a.steps)
     elapsed, kernels = W["elapsed"], W["kernels"]
     steady = None
-    if a.steady_after > 0 and a.steady_steps > 0:
+    def guarded(what, fn):
+        """the extra windows must not cost the run its line: a failure in one of them is reported in its place (all ranks
+        take the same branch: the Newton and time-step decisions hang on all-reduced numbers)"""
+        try:
+            return fn()
+        except Exception as e:   # noqa: BLE001
+            return {"error": "%s: %s: %s" % (what, type(e).__name__, e)}
+
+    def steady_window():
         done = a.warmup + a.steps
         while done < a.steady_after:   # untimed: carries the simulation into its steady phase
             sim.next_newton_iteration()
             done += 1
         S = timed_window(a.steady_steps)
-        steady = {"from_newton_iteration": done, "steps": S["steps"], "ms_per_step": 1e3 * S["elapsed"] / S["steps"],
+        return {"from_newton_iteration": done, "steps": S["steps"], "ms_per_step": 1e3 * S["elapsed"] / S["steps"],
                   "newton_iterations_per_s_global": S["steps"] / S["elapsed"], "value": S["steps"] * world / S["elapsed"],
                   "linear_iterations_per_newton": S["linear_iterations_per_newton"], "time_steps_days": S["time_steps_days"],
                   "timesteps_chopped": S["timesteps_chopped"], "linear_solve_GBps": S["linear_solve_GBps"], "report": S["report"],
                   "kernels": S["kernels"]}
+
+    if a.steady_after > 0 and a.steady_steps > 0:
+        steady = guarded("steady-state window", steady_window)
     # the same workload with the CPR preconditioner (cpr_quasiimpes), side by side: its own context, warm-up, timed window
     cpr_side = None
     if a.preconditioner == "ilu0" and world == 1 and not a.no_cpr_side_run:
-        model2 = pkg.capi.HipModel(case, **dict(skw, preconditioner="cpr"))
-        model2.set_state(case["pv"], case["meaning"])
-        model2.set_source(src)
-        sim_main, model_main = sim, model
-        sim, model = make_simulation(pkg, model2), model2
-        for _ in range(a.warmup):
-            sim.next_newton_iteration()      # includes the one-time host-side aggregation of the pressure AMG
-        C1 = timed_window(a.steps)
-        cpr_side = {"value": C1["steps"] / C1["elapsed"], "ms_per_step": 1e3 * C1["elapsed"] / C1["steps"], "steps": C1["steps"],
-                    "linear_iterations_per_newton": C1["linear_iterations_per_newton"], "report": C1["report"], "kernels": C1["kernels"],
-                    "amg_levels": model2.cpr_levels()[0]}
-        if a.steady_after > 0 and a.steady_steps > 0:
-            done = a.warmup + a.steps
-            while done < a.steady_after:
-                sim.next_newton_iteration()
-                done += 1
-            C2 = timed_window(a.steady_steps)
-            cpr_side["steady_state"] = {"from_newton_iteration": done, "steps": C2["steps"], "value": C2["steps"] / C2["elapsed"],
-                                        "ms_per_step": 1e3 * C2["elapsed"] / C2["steps"],
-                                        "linear_iterations_per_newton": C2["linear_iterations_per_newton"], "timesteps_chopped": C2["timesteps_chopped"]}
-        sim, model = sim_main, model_main
-        del model2
+        def cpr_window():
+            nonlocal sim, model
+            model2 = pkg.capi.HipModel(case, **dict(skw, preconditioner="cpr"))
+            model2.set_state(case["pv"], case["meaning"])
+            model2.set_source(src)
+            sim_main, model_main = sim, model
+            sim, model = make_simulation(pkg, model2), model2
+            try:
+                for _ in range(a.warmup):
+                    sim.next_newton_iteration()      # includes the one-time host-side aggregation of the pressure AMG
+                C1 = timed_window(a.steps)
+                side = {"value": C1["steps"] / C1["elapsed"], "ms_per_step": 1e3 * C1["elapsed"] / C1["steps"], "steps": C1["steps"],
+                        "linear_iterations_per_newton": C1["linear_iterations_per_newton"], "report": C1["report"], "kernels": C1["kernels"],
+                        "amg_levels": model2.cpr_levels()[0]}
+                if a.steady_after > 0 and a.steady_steps > 0:
+                    done = a.warmup + a.steps
+                    while done < a.steady_after:
+                        sim.next_newton_iteration()
+                        done += 1
+                    C2 = timed_window(a.steady_steps)
+                    side["steady_state"] = {"from_newton_iteration": done, "steps": C2["steps"], "value": C2["steps"] / C2["elapsed"],
+                                            "ms_per_step": 1e3 * C2["elapsed"] / C2["steps"],
+                                            "linear_iterations_per_newton": C2["linear_iterations_per_newton"], "timesteps_chopped": C2["timesteps_chopped"]}
+                return side
+            finally:
+                sim, model = sim_main, model_main
+                del model2
+
+        cpr_side = guarded("CPR side run", cpr_window)
     # what a kernel that only streams reaches on THIS card (reads the Jacobian's values once per launch)
     stream_ms = model.time_kernel("stream_read", reps=20)
     stream_GBps = 72.0 * nnzb / stream_ms / 1e6
