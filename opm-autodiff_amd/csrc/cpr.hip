@@ -87,6 +87,7 @@ void galerkin(const HCsr& A, const std::vector<int>& agg, int nc, HCsr& C, std::
 
 // ---------------------------------------------------------------- kernels -----------------------------------------------
 #define CPR_DONE_CHECK if (*done != 0.0) return;
+constexpr int CPR_MAX_W = 96;   // longest row an ELL level may have
 // closed-form 3x3 inverse, expression tree of Opm::Detail::Inverter<3> (linalg/MatrixBlock.hpp:722-747); same as solver.hip
 __device__ __forceinline__ void inv3(const double* m, double* inv) {
     const double t4 = m[0] * m[4], t6 = m[0] * m[5], t8 = m[1] * m[3];
@@ -147,12 +148,15 @@ __global__ __launch_bounds__(256) void k_cpr_dinv(int n, const int* __restrict__
     if (i < n) dinv[i] = 1.0 / val[diag[i]];
 }
 // dense LU without pivoting of the coarsest level, in place in global memory, one workgroup (n <= CPR_COARSE_DIRECT)
-__global__ __launch_bounds__(256) void k_cpr_dense_lu(int n, int W, const int* __restrict__ ecol, const int* __restrict__ rlen, const double* __restrict__ val,
+__global__ __launch_bounds__(256) void k_cpr_dense_lu(int n, int W, int rm, const int* __restrict__ ecol, const int* __restrict__ rlen, const double* __restrict__ val,
                                                       double* lu) {
     for (int e = threadIdx.x; e < n * n; e += 256) lu[e] = 0.0;
     __syncthreads();
     for (int i = threadIdx.x; i < n; i += 256)
-        for (int j = 0; j < rlen[i]; ++j) lu[(size_t)i * n + ecol[(size_t)j * n + i]] = val[(size_t)j * n + i];
+        for (int j = 0; j < rlen[i]; ++j) {
+            const size_t e = rm ? (size_t)i * W + j : (size_t)j * n + i;
+            lu[(size_t)i * n + ecol[e]] = val[e];
+        }
     __syncthreads();
     for (int k = 0; k < n; ++k) {
         const double piv = 1.0 / lu[(size_t)k * n + k];
@@ -227,6 +231,86 @@ __global__ __launch_bounds__(256) void k_cpr_down(int n, int W, double omega, co
     x[i] = omega * dinv[i] * b[i];
     r[i] = s;
 }
+// Coarse levels (<= CPR_LPR_ROWS rows, rows of up to CPR_MAX_W entries): one thread per row walks W dependent
+// (column -> vector entry) round trips - 12 us for 14 000 rows.  Here CPR_LPR lanes share a row (row-major storage): every
+// lane fetches its entries and forms its products at once, then the group subtracts the products one after the other in
+// the row's order - the same roundings as the one-thread loop (padding entries are 0 * x there too).
+constexpr int CPR_LPR = 16, CPR_LPR_SLOTS = CPR_MAX_W / CPR_LPR, CPR_LPR_ROWS = 32768;
+static_assert(CPR_MAX_W % CPR_LPR == 0 && 256 % CPR_LPR == 0, "lane groups tile a row and a workgroup");
+__device__ __forceinline__ double cpr_group_subtract(double s, const double (&p)[CPR_LPR_SLOTS], int W) {
+#pragma unroll
+    for (int slot = 0; slot < CPR_LPR_SLOTS; ++slot) {
+        if (slot * CPR_LPR >= W) break;    // W is the same for all lanes
+#pragma unroll
+        for (int l = 0; l < CPR_LPR; ++l) {
+            const double q = __shfl(p[slot], l, CPR_LPR);
+            if (slot * CPR_LPR + l < W) s -= q;
+        }
+    }
+    return s;
+}
+__global__ __launch_bounds__(256) void k_cpr_jacobi_lpr(int n, int W, double omega, const int* __restrict__ ecol, const double* __restrict__ val,
+                                                        const double* __restrict__ dinv, const double* __restrict__ b, const double* __restrict__ xin,
+                                                        double* __restrict__ xout, const double* __restrict__ done) {
+    CPR_DONE_CHECK
+    const int g = (blockIdx.x * blockDim.x + threadIdx.x) / CPR_LPR, l = threadIdx.x % CPR_LPR;
+    const int i = g < n ? g : n - 1;
+    double p[CPR_LPR_SLOTS];
+#pragma unroll
+    for (int slot = 0; slot < CPR_LPR_SLOTS; ++slot) {
+        const int j = slot * CPR_LPR + l;
+        p[slot] = 0.0;
+        if (j < W) p[slot] = val[(size_t)i * W + j] * xin[ecol[(size_t)i * W + j]];
+    }
+    const double s = cpr_group_subtract(b[i], p, W);
+    if (l == 0 && g < n) xout[i] = xin[i] + omega * dinv[i] * s;
+}
+__global__ __launch_bounds__(256) void k_cpr_down_lpr(int n, int W, double omega, const int* __restrict__ ecol, const double* __restrict__ val,
+                                                      const double* __restrict__ dinv, const double* __restrict__ b, double* __restrict__ x,
+                                                      double* __restrict__ r, const double* __restrict__ done) {
+    CPR_DONE_CHECK
+    const int g = (blockIdx.x * blockDim.x + threadIdx.x) / CPR_LPR, l = threadIdx.x % CPR_LPR;
+    const int i = g < n ? g : n - 1;
+    double p[CPR_LPR_SLOTS];
+#pragma unroll
+    for (int slot = 0; slot < CPR_LPR_SLOTS; ++slot) {
+        const int j = slot * CPR_LPR + l;
+        p[slot] = 0.0;
+        if (j < W) {
+            const int c = ecol[(size_t)i * W + j];
+            p[slot] = val[(size_t)i * W + j] * (omega * dinv[c] * b[c]);
+        }
+    }
+    const double s = cpr_group_subtract(b[i], p, W);
+    if (l == 0 && g < n) {
+        x[i] = omega * dinv[i] * b[i];
+        r[i] = s;
+    }
+}
+__global__ __launch_bounds__(256) void k_cpr_up_lpr(int n, int W, double omega, double damp, const int* __restrict__ ecol, const double* __restrict__ val,
+                                                    const double* __restrict__ dinv, const int* __restrict__ agg, const double* __restrict__ xc,
+                                                    const double* __restrict__ b, const double* __restrict__ x, double* __restrict__ xout,
+                                                    const double* __restrict__ done) {
+    CPR_DONE_CHECK
+    const int g = (blockIdx.x * blockDim.x + threadIdx.x) / CPR_LPR, l = threadIdx.x % CPR_LPR;
+    const int i = g < n ? g : n - 1;
+    double p[CPR_LPR_SLOTS];
+#pragma unroll
+    for (int slot = 0; slot < CPR_LPR_SLOTS; ++slot) {
+        const int j = slot * CPR_LPR + l;
+        p[slot] = 0.0;
+        if (j < W) {
+            const int c = ecol[(size_t)i * W + j];
+            const double xp = x[c] + damp * xc[agg[c]];
+            p[slot] = val[(size_t)i * W + j] * xp;
+        }
+    }
+    const double s = cpr_group_subtract(b[i], p, W);
+    if (l == 0 && g < n) {
+        const double xi = x[i] + damp * xc[agg[i]];
+        xout[i] = xi + omega * dinv[i] * s;
+    }
+}
 __global__ __launch_bounds__(256) void k_cpr_restrict(int nc, const int* __restrict__ mptr, const int* __restrict__ midx, const double* __restrict__ r,
                                                       double* __restrict__ rc, const double* __restrict__ done) {
     CPR_DONE_CHECK
@@ -277,24 +361,25 @@ __global__ __launch_bounds__(256) void k_cpr_add(int n, double* __restrict__ v, 
 static inline dim3 g256(int n) { return dim3((n + 255) / 256); }
 
 // ---------------------------------------------------------------- setup --------------------------------------------------
-constexpr int CPR_MAX_W = 96;   // longest row an ELL level may have
 // ELL image of a level's pattern: columns (padding: the row itself), row lengths, position of the diagonal, position of every
 // CSR entry
-static int upload_ell(opmhip_ctx* c, const HCsr& A, CprLevelDev& L, std::vector<int>& pos) {
+static int upload_ell(opmhip_ctx* c, const HCsr& A, CprLevelDev& L, std::vector<int>& pos, bool rowMajor) {
     const int n = A.n;
     int W = 1;
     for (int i = 0; i < n; ++i) W = std::max(W, A.rowptr[i + 1] - A.rowptr[i]);
     if (W > CPR_MAX_W) return fail(c, OPMHIP_ANALYSIS_FAILED, "cpr: a row of a pressure-AMG level has %d entries (limit %d)", W, CPR_MAX_W);
-    L.n = n; L.nnz = (int)A.col.size(); L.W = W;
+    L.n = n; L.nnz = (int)A.col.size(); L.W = W; L.rm = rowMajor;
+    // entry j of row i: [j * n + i] (one thread per row reads coalesced) or, row-major, [i * W + j] (a group of lanes per row does)
+    auto at = [&](int j, int i) { return rowMajor ? (size_t)i * W + j : (size_t)j * n + i; };
     std::vector<int> ecol((size_t)W * n), rlen(n), diag(n, 0);
     pos.resize(A.col.size());
     for (int i = 0; i < n; ++i) {
         const int kb = A.rowptr[i], len = A.rowptr[i + 1] - kb;
         rlen[i] = len;
-        for (int j = 0; j < W; ++j) ecol[(size_t)j * n + i] = j < len ? A.col[kb + j] : i;
+        for (int j = 0; j < W; ++j) ecol[at(j, i)] = j < len ? A.col[kb + j] : i;
         for (int j = 0; j < len; ++j) {
-            pos[kb + j] = j * n + i;
-            if (A.col[kb + j] == i) diag[i] = j * n + i;
+            pos[kb + j] = (int)at(j, i);
+            if (A.col[kb + j] == i) diag[i] = (int)at(j, i);
         }
     }
     int rc;
@@ -326,7 +411,7 @@ static int cpr_setup_structure(opmhip_ctx* c) {
     R.lv.clear();
     R.lv.emplace_back();
     std::vector<int> pos;   // ELL position of every CSR entry of the level being coarsened
-    if ((rc = upload_ell(c, A, R.lv[0], pos))) return rc;
+    if ((rc = upload_ell(c, A, R.lv[0], pos, false))) return rc;
     hipLaunchKernelGGL(k_cpr_weights, g256(P.Nb), dim3(256), 0, c->stream, P.Nb, P.d_diag, c->d_A, R.d_w);
     hipLaunchKernelGGL(k_cpr_pvals, g256(P.Nb), dim3(256), 0, c->stream, P.Nb, P.d_rowptr, c->d_A, R.d_w, R.lv[0].d_val);
     {
@@ -373,7 +458,7 @@ static int cpr_setup_structure(opmhip_ctx* c) {
         }
         R.lv.emplace_back();
         std::vector<int> cposv;
-        if ((rc = upload_ell(c, Ac, R.lv.back(), cposv))) return rc;
+        if ((rc = upload_ell(c, Ac, R.lv.back(), cposv, Ac.n <= CPR_LPR_ROWS))) return rc;
         if ((rc = dev_upload(c, &R.lv[R.lv.size() - 2].d_cpos, cposv))) return rc;   // where the coarse entries go
         pos = cposv;
         A = std::move(Ac);
@@ -403,7 +488,7 @@ int cpr_update(opmhip_ctx* c) {
     }
     if (R.coarse_direct) {
         const CprLevelDev& C = R.lv.back();
-        hipLaunchKernelGGL(k_cpr_dense_lu, dim3(1), dim3(256), 0, c->stream, C.n, C.W, C.d_ecol, C.d_rlen, C.d_val, R.d_lu);
+        hipLaunchKernelGGL(k_cpr_dense_lu, dim3(1), dim3(256), 0, c->stream, C.n, C.W, C.rm ? 1 : 0, C.d_ecol, C.d_rlen, C.d_val, R.d_lu);
     }
     prof_end(c, ps);
     OPMHIP_HIP(c, hipGetLastError());
@@ -424,16 +509,19 @@ static const double* cpr_vcycle(opmhip_ctx* c, size_t l) {
         hipLaunchKernelGGL(k_cpr_presmooth, g256(L.n), dim3(256), 0, c->stream, L.n, R.omega, L.d_dinv, L.d_b, L.d_x, done);
         double *xin = L.d_x, *xout = L.d_x2;
         for (int sweep = 0; sweep < 4; ++sweep) {
-            hipLaunchKernelGGL(k_cpr_jacobi, g256(L.n), dim3(256), 0, c->stream, L.n, L.W, R.omega, L.d_ecol, L.d_val, L.d_dinv, L.d_b, xin, xout, done);
+            if (L.rm) hipLaunchKernelGGL(k_cpr_jacobi_lpr, g256(L.n * CPR_LPR), dim3(256), 0, c->stream, L.n, L.W, R.omega, L.d_ecol, L.d_val, L.d_dinv, L.d_b, xin, xout, done);
+            else hipLaunchKernelGGL(k_cpr_jacobi, g256(L.n), dim3(256), 0, c->stream, L.n, L.W, R.omega, L.d_ecol, L.d_val, L.d_dinv, L.d_b, xin, xout, done);
             std::swap(xin, xout);
         }
         return xin;
     }
     CprLevelDev& C = R.lv[l + 1];
-    hipLaunchKernelGGL(k_cpr_down, g256(L.n), dim3(256), 0, c->stream, L.n, L.W, R.omega, L.d_ecol, L.d_val, L.d_dinv, L.d_b, L.d_x, L.d_r, done);
+    if (L.rm) hipLaunchKernelGGL(k_cpr_down_lpr, g256(L.n * CPR_LPR), dim3(256), 0, c->stream, L.n, L.W, R.omega, L.d_ecol, L.d_val, L.d_dinv, L.d_b, L.d_x, L.d_r, done);
+    else hipLaunchKernelGGL(k_cpr_down, g256(L.n), dim3(256), 0, c->stream, L.n, L.W, R.omega, L.d_ecol, L.d_val, L.d_dinv, L.d_b, L.d_x, L.d_r, done);
     hipLaunchKernelGGL(k_cpr_restrict, g256(L.nc), dim3(256), 0, c->stream, L.nc, L.d_mptr, L.d_midx, L.d_r, C.d_b, done);
     const double* xc = cpr_vcycle(c, l + 1);
-    hipLaunchKernelGGL(k_cpr_up, g256(L.n), dim3(256), 0, c->stream, L.n, L.W, R.omega, R.damp, L.d_ecol, L.d_val, L.d_dinv, L.d_agg, xc, L.d_b, L.d_x, L.d_x2, done);
+    if (L.rm) hipLaunchKernelGGL(k_cpr_up_lpr, g256(L.n * CPR_LPR), dim3(256), 0, c->stream, L.n, L.W, R.omega, R.damp, L.d_ecol, L.d_val, L.d_dinv, L.d_agg, xc, L.d_b, L.d_x, L.d_x2, done);
+    else hipLaunchKernelGGL(k_cpr_up, g256(L.n), dim3(256), 0, c->stream, L.n, L.W, R.omega, R.damp, L.d_ecol, L.d_val, L.d_dinv, L.d_agg, xc, L.d_b, L.d_x, L.d_x2, done);
     return L.d_x2;
 }
 

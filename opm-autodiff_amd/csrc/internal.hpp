@@ -137,6 +137,7 @@ struct CommDev {
 // CPR preconditioner (cpr.hip): pressure-AMG hierarchy, level 0 = the block pattern with scalar values
 struct CprLevelDev {
     int n = 0, nnz = 0, nc = 0, W = 0;                              // W: longest row = width of the ELL image
+    bool rm = false;                                                // row-major image [i * W + j] (coarse levels, lane groups per row) instead of [j * n + i]
     int *d_ecol = nullptr, *d_rlen = nullptr, *d_diag = nullptr;    // ELL columns [W x n], row lengths, ELL position of the diagonal
     int* d_cpos = nullptr;                                          // ELL position (next level) of every coarse entry
     double *d_val = nullptr, *d_dinv = nullptr, *d_x2 = nullptr;    // ELL values [W x n]
