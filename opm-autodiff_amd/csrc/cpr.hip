@@ -214,21 +214,16 @@ __global__ __launch_bounds__(256) void k_cpr_jacobi(int n, int W, double omega, 
     for (int j = 0; j < W; ++j) s -= val[(size_t)j * n + i] * xin[ecol[(size_t)j * n + i]];
     xout[i] = xin[i] + omega * dinv[i] * s;
 }
-// going down: pre-smoothing from x = 0 (x = omega D^-1 b) and the residual r = b - A x in one pass - the neighbours'
-// x_j = omega dinv_j b_j are formed on the fly (the same expression, hence the same bits, as the stored x_j)
-__global__ __launch_bounds__(256) void k_cpr_down(int n, int W, double omega, const int* __restrict__ ecol, const double* __restrict__ val,
-                                                  const double* __restrict__ dinv, const double* __restrict__ b, double* __restrict__ x,
-                                                  double* __restrict__ r, const double* __restrict__ done) {
+// r = b - A x, one thread per row (large levels; x = omega D^-1 b was stored by k_cpr_presmooth: the same bits the
+// lane-group kernel below forms on the fly)
+__global__ __launch_bounds__(256) void k_cpr_resid(int n, int W, const int* __restrict__ ecol, const double* __restrict__ val,
+                                                   const double* __restrict__ b, const double* __restrict__ x, double* __restrict__ r, const double* __restrict__ done) {
     CPR_DONE_CHECK
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     double s = b[i];
 #pragma unroll 4
-    for (int j = 0; j < W; ++j) {
-        const int c = ecol[(size_t)j * n + i];
-        s -= val[(size_t)j * n + i] * (omega * dinv[c] * b[c]);
-    }
-    x[i] = omega * dinv[i] * b[i];
+    for (int j = 0; j < W; ++j) s -= val[(size_t)j * n + i] * x[ecol[(size_t)j * n + i]];
     r[i] = s;
 }
 // Coarse levels (<= CPR_LPR_ROWS rows, rows of up to CPR_MAX_W entries): one thread per row walks W dependent
@@ -320,24 +315,25 @@ __global__ __launch_bounds__(256) void k_cpr_restrict(int nc, const int* __restr
     for (int q = mptr[I]; q < mptr[I + 1]; ++q) s += r[midx[q]];
     rc[I] = s;
 }
-// going up: damped piecewise-constant prolongation x' = x + damp xc[agg], residual of x', post-smoothing
-// xout = x' + omega D^-1 (b - A x') in one pass (x'_j of the neighbours formed on the fly, result into a second buffer)
-__global__ __launch_bounds__(256) void k_cpr_up(int n, int W, double omega, double damp, const int* __restrict__ ecol, const double* __restrict__ val,
-                                                const double* __restrict__ dinv, const int* __restrict__ agg, const double* __restrict__ xc,
-                                                const double* __restrict__ b, const double* __restrict__ x, double* __restrict__ xout,
-                                                const double* __restrict__ done) {
+// going up: damped piecewise-constant prolongation x' = x + damp xc[agg], then the residual of x' and the post-smoothing
+// xout = x' + omega D^-1 (b - A x') (large levels: two passes, one gather per entry; small levels: k_cpr_up_lpr forms the
+// x'_j of the neighbours on the fly - the same expression, hence the same bits)
+__global__ __launch_bounds__(256) void k_cpr_prolong(int n, double damp, const int* __restrict__ agg, const double* __restrict__ xc,
+                                                     const double* __restrict__ x, double* __restrict__ xp, const double* __restrict__ done) {
+    CPR_DONE_CHECK
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) xp[i] = x[i] + damp * xc[agg[i]];
+}
+__global__ __launch_bounds__(256) void k_cpr_post(int n, int W, double omega, const int* __restrict__ ecol, const double* __restrict__ val,
+                                                  const double* __restrict__ dinv, const double* __restrict__ b, const double* __restrict__ xp,
+                                                  double* __restrict__ xout, const double* __restrict__ done) {
     CPR_DONE_CHECK
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     double s = b[i];
 #pragma unroll 4
-    for (int j = 0; j < W; ++j) {
-        const int c = ecol[(size_t)j * n + i];
-        const double xp = x[c] + damp * xc[agg[c]];
-        s -= val[(size_t)j * n + i] * xp;
-    }
-    const double xi = x[i] + damp * xc[agg[i]];
-    xout[i] = xi + omega * dinv[i] * s;
+    for (int j = 0; j < W; ++j) s -= val[(size_t)j * n + i] * xp[ecol[(size_t)j * n + i]];
+    xout[i] = xp[i] + omega * dinv[i] * s;
 }
 // v = (0, x_p, 0)  (moveToFineLevel: the pressure component only)
 __global__ __launch_bounds__(256) void k_cpr_prolong_fine(int Nb, const double* __restrict__ xc, double* __restrict__ v, const double* __restrict__ done) {
@@ -517,11 +513,17 @@ static const double* cpr_vcycle(opmhip_ctx* c, size_t l) {
     }
     CprLevelDev& C = R.lv[l + 1];
     if (L.rm) hipLaunchKernelGGL(k_cpr_down_lpr, g256(L.n * CPR_LPR), dim3(256), 0, c->stream, L.n, L.W, R.omega, L.d_ecol, L.d_val, L.d_dinv, L.d_b, L.d_x, L.d_r, done);
-    else hipLaunchKernelGGL(k_cpr_down, g256(L.n), dim3(256), 0, c->stream, L.n, L.W, R.omega, L.d_ecol, L.d_val, L.d_dinv, L.d_b, L.d_x, L.d_r, done);
+    else {   // large levels: x first, then the residual with ONE gathered value per entry (0.250 -> 0.243 ms per cycle against the fused form, which gathers dinv and b)
+        hipLaunchKernelGGL(k_cpr_presmooth, g256(L.n), dim3(256), 0, c->stream, L.n, R.omega, L.d_dinv, L.d_b, L.d_x, done);
+        hipLaunchKernelGGL(k_cpr_resid, g256(L.n), dim3(256), 0, c->stream, L.n, L.W, L.d_ecol, L.d_val, L.d_b, L.d_x, L.d_r, done);
+    }
     hipLaunchKernelGGL(k_cpr_restrict, g256(L.nc), dim3(256), 0, c->stream, L.nc, L.d_mptr, L.d_midx, L.d_r, C.d_b, done);
     const double* xc = cpr_vcycle(c, l + 1);
     if (L.rm) hipLaunchKernelGGL(k_cpr_up_lpr, g256(L.n * CPR_LPR), dim3(256), 0, c->stream, L.n, L.W, R.omega, R.damp, L.d_ecol, L.d_val, L.d_dinv, L.d_agg, xc, L.d_b, L.d_x, L.d_x2, done);
-    else hipLaunchKernelGGL(k_cpr_up, g256(L.n), dim3(256), 0, c->stream, L.n, L.W, R.omega, R.damp, L.d_ecol, L.d_val, L.d_dinv, L.d_agg, xc, L.d_b, L.d_x, L.d_x2, done);
+    else {   // large levels: the prolonged iterate first (into the residual buffer, free by now), then one gathered value per entry
+        hipLaunchKernelGGL(k_cpr_prolong, g256(L.n), dim3(256), 0, c->stream, L.n, R.damp, L.d_agg, xc, L.d_x, L.d_r, done);
+        hipLaunchKernelGGL(k_cpr_post, g256(L.n), dim3(256), 0, c->stream, L.n, L.W, R.omega, L.d_ecol, L.d_val, L.d_dinv, L.d_b, L.d_r, L.d_x2, done);
+    }
     return L.d_x2;
 }
 
