@@ -674,165 +674,163 @@ __global__ __launch_bounds__(ASM_THREADS) ASM_OCC void k_assemble(int nsched, co
     // ---- round 1: the tile's schedule record and, independent of it, the lane's entry (column, entry word)
     const int4 S = sched[blockIdx.x];
     const int2 jm = desc[(size_t)blockIdx.x * ASM_THREADS + tid];
+    const int r0 = S.x, k0 = S.z, nent = S.w - S.z, nrows = S.y - S.x;
+    const int k0e = k0 & ~1;  // 16-byte aligned start of the output stream
+    const bool act = tid < nent;
+    const int k = act ? k0 + tid : k0;
+    const int J = jm.x;
+    const unsigned m = (unsigned)jm.y;
+    {   // ---- round 2.  Own records: per field one contiguous run of nrows x 32 bytes of the cache, into per-row records in LDS
+        const int n2r = nrows * 2;                              // 16-byte pieces per field
+        const unsigned inv = n2r > 0 ? (65536u + n2r - 1) / n2r : 0u;  // i / n2r == (i * inv) >> 16 for the few hundred i of a tile
+        const int n2 = n2r * Lay<EXT>::IQF;
+        const double2* g2 = reinterpret_cast<const double2*>(iq);
+        double2* s2 = reinterpret_cast<double2*>(sI);
+        for (int i = tid; i < n2; i += ASM_THREADS) {
+            const int fld = (int)(((unsigned)i * inv) >> 16), j = i - fld * n2r;
+            s2[(j >> 1) * (IQS / 2) + fld * 2 + (j & 1)] = g2[((size_t)fld * C.ncell + r0) * 2 + j];
+        }
+    }
+    if (tid < nrows) { sgeo[tid] = C.depth[r0 + tid]; sgeo[ASM_MAX_ROWS + tid] = C.volume[r0 + tid]; }
+    const double trans = ES.trans[k], area = ES.area[k], thp = ES.thpres ? ES.thpres[k] : 0.0;
+    const int lrow = m & 63;
+    const bool lowI = ((m >> 6) & 1u) != 0;
+    const int I = r0 + lrow;
+    const bool isDiag = act && I == J, isOff = act && I != J;
+    snat[tid] = (unsigned char)(m >> 8);
     {
-        const int r0 = S.x, k0 = S.z, nent = S.w - S.z, nrows = S.y - S.x;
-        const int k0e = k0 & ~1;  // 16-byte aligned start of the output stream
-        const bool act = tid < nent;
-        const int k = act ? k0 + tid : k0;
-        const int J = jm.x;
-        const unsigned m = (unsigned)jm.y;
-        {   // ---- round 2.  Own records: per field one contiguous run of nrows x 32 bytes of the cache, into per-row records in LDS
-            const int n2r = nrows * 2;                              // 16-byte pieces per field
-            const unsigned inv = n2r > 0 ? (65536u + n2r - 1) / n2r : 0u;  // i / n2r == (i * inv) >> 16 for the few hundred i of a tile
-            const int n2 = n2r * Lay<EXT>::IQF;
-            const double2* g2 = reinterpret_cast<const double2*>(iq);
-            double2* s2 = reinterpret_cast<double2*>(sI);
-            for (int i = tid; i < n2; i += ASM_THREADS) {
-                const int fld = (int)(((unsigned)i * inv) >> 16), j = i - fld * n2r;
-                s2[(j >> 1) * (IQS / 2) + fld * 2 + (j & 1)] = g2[((size_t)fld * C.ncell + r0) * 2 + j];
-            }
+        const int prevRow = __shfl_up(lrow, 1);
+        if (act && (tid == 0 || prevRow != lrow)) sfirst[lrow] = (short)tid;
+        if (tid == 0) sfirst[nrows] = (short)nent;
+    }
+    RegQ<EXT> qJ;
+    double zJ = 0.0, VJ = 0.0;
+    if (isOff) {
+        const double2* g2 = reinterpret_cast<const double2*>(iq) + (size_t)J * 2;
+#pragma unroll
+        for (int i = 0; i < RQ_NF; ++i) {
+            const double2 a = g2[(size_t)(RQ_F0 + i) * C.ncell * 2], b = g2[(size_t)(RQ_F0 + i) * C.ncell * 2 + 1];
+            qJ.r[4 * i] = a.x; qJ.r[4 * i + 1] = a.y; qJ.r[4 * i + 2] = b.x; qJ.r[4 * i + 3] = b.y;
         }
-        if (tid < nrows) { sgeo[tid] = C.depth[r0 + tid]; sgeo[ASM_MAX_ROWS + tid] = C.volume[r0 + tid]; }
-        const double trans = ES.trans[k], area = ES.area[k], thp = ES.thpres ? ES.thpres[k] : 0.0;
-        const int lrow = m & 63;
-        const bool lowI = ((m >> 6) & 1u) != 0;
-        const int I = r0 + lrow;
-        const bool isDiag = act && I == J, isOff = act && I != J;
-        snat[tid] = (unsigned char)(m >> 8);
-        {
-            const int prevRow = __shfl_up(lrow, 1);
-            if (act && (tid == 0 || prevRow != lrow)) sfirst[lrow] = (short)tid;
-            if (tid == 0) sfirst[nrows] = (short)nent;
+        zJ = C.depth[J]; VJ = C.volume[J];
+    } else if (isDiag) {
+        const size_t o = (size_t)I * 3;
+#pragma unroll
+        for (int e = 0; e < 3; ++e) {
+            qJ.r[4 * e] = (iteration == 0) ? 0.0 : storageOld[o + e];
+            qJ.r[4 * (3 + e)] = source ? source[o + e] : 0.0;
+            qJ.r[4 * (6 + e)] = drift ? drift[o + e] : 0.0;
         }
-        RegQ<EXT> qJ;
-        double zJ = 0.0, VJ = 0.0;
-        if (isOff) {
-            const double2* g2 = reinterpret_cast<const double2*>(iq) + (size_t)J * 2;
+        qJ.r[4 * 9] = drift ? C.poro[I] : 1.0;   // referencePorosity
+    }
+    asm_wave_sync();
+    const double zI = sgeo[lrow], VI = sgeo[ASM_MAX_ROWS + lrow];
+    Ad f[3];         // off-diagonal lane: face flux seen from cell I; diagonal lane: storage term
+    double blk[BB];  // off-diagonal lane: block (I,J)
+    const PtrQ qI{sI + lrow * IQS};
+    if (isOff) {
+        face_flux<EXT>(qJ, qI, wet != 0, trans, area, thp, zJ, zI, VJ, VI, !lowI, f);  // focus J: residual[I] -= flux  ->  block (I,J)
 #pragma unroll
-            for (int i = 0; i < RQ_NF; ++i) {
-                const double2 a = g2[(size_t)(RQ_F0 + i) * C.ncell * 2], b = g2[(size_t)(RQ_F0 + i) * C.ncell * 2 + 1];
-                qJ.r[4 * i] = a.x; qJ.r[4 * i + 1] = a.y; qJ.r[4 * i + 2] = b.x; qJ.r[4 * i + 3] = b.y;
-            }
-            zJ = C.depth[J]; VJ = C.volume[J];
-        } else if (isDiag) {
-            const size_t o = (size_t)I * 3;
-#pragma unroll
-            for (int e = 0; e < 3; ++e) {
-                qJ.r[4 * e] = (iteration == 0) ? 0.0 : storageOld[o + e];
-                qJ.r[4 * (3 + e)] = source ? source[o + e] : 0.0;
-                qJ.r[4 * (6 + e)] = drift ? drift[o + e] : 0.0;
-            }
-            qJ.r[4 * 9] = drift ? C.poro[I] : 1.0;   // referencePorosity
+        for (int e = 0; e < 3; ++e) {
+            const Ad mm = ad_const(0.0) - f[e];
+            blk[e * 3 + 0] = mm.d0; blk[e * 3 + 1] = mm.d1; blk[e * 3 + 2] = mm.d2;
         }
-        asm_wave_sync();
-        const double zI = sgeo[lrow], VI = sgeo[ASM_MAX_ROWS + lrow];
-        Ad f[3];         // off-diagonal lane: face flux seen from cell I; diagonal lane: storage term
-        double blk[BB];  // off-diagonal lane: block (I,J)
-        const PtrQ qI{sI + lrow * IQS};
-        if (isOff) {
-            face_flux<EXT>(qJ, qI, wet != 0, trans, area, thp, zJ, zI, VJ, VI, !lowI, f);  // focus J: residual[I] -= flux  ->  block (I,J)
+        face_flux<EXT>(qI, qJ, wet != 0, trans, area, thp, zI, zJ, VI, VJ, lowI, f);   // focus I: contribution to R_I
+    } else if (isDiag) {
 #pragma unroll
-            for (int e = 0; e < 3; ++e) {
-                const Ad mm = ad_const(0.0) - f[e];
-                blk[e * 3 + 0] = mm.d0; blk[e * 3 + 1] = mm.d1; blk[e * 3 + 2] = mm.d2;
-            }
-            face_flux<EXT>(qI, qJ, wet != 0, trans, area, thp, zI, zJ, VI, VJ, lowI, f);   // focus I: contribution to R_I
-        } else if (isDiag) {
+        for (int i = 0; i < ASM_PRE; ++i) spre[lrow * ASM_PRE + i] = qJ.r[4 * i];
+        // computeStorage: surface volumes per bulk volume
+        const Ad poro = qI.ad(F_PORO), Rs = qI.ad(F_RS);
+        f[0] = f[1] = f[2] = ad_const(0.0);
+        const int comp[3] = {EQ_WATER, EQ_OIL, EQ_GAS};
 #pragma unroll
-            for (int i = 0; i < ASM_PRE; ++i) spre[lrow * ASM_PRE + i] = qJ.r[4 * i];
-            // computeStorage: surface volumes per bulk volume
-            const Ad poro = qI.ad(F_PORO), Rs = qI.ad(F_RS);
-            f[0] = f[1] = f[2] = ad_const(0.0);
-            const int comp[3] = {EQ_WATER, EQ_OIL, EQ_GAS};
-#pragma unroll
-            for (int ph = 0; ph < 3; ++ph) {
-                const Ad surfaceVolume = qI.ad(F_S + ph) * qI.ad(F_B + ph) * poro;
-                f[comp[ph]] = f[comp[ph]] + surfaceVolume;
-                if (ph == OIL) f[EQ_GAS] = f[EQ_GAS] + Rs * surfaceVolume;
-                if (EXT && ph == GAS && wet) f[EQ_OIL] = f[EQ_OIL] + qI.ad(Lay<EXT>::F_RV) * surfaceVolume;   // vaporised oil
-            }
+        for (int ph = 0; ph < 3; ++ph) {
+            const Ad surfaceVolume = qI.ad(F_S + ph) * qI.ad(F_B + ph) * poro;
+            f[comp[ph]] = f[comp[ph]] + surfaceVolume;
+            if (ph == OIL) f[EQ_GAS] = f[EQ_GAS] + Rs * surfaceVolume;
+            if (EXT && ph == GAS && wet) f[EQ_OIL] = f[EQ_OIL] + qI.ad(Lay<EXT>::F_RV) * surfaceVolume;   // vaporised oil
         }
-        asm_wave_sync();   // every read of the own records is done: their LDS becomes sflux / sblk
-        if (isOff) {
+    }
+    asm_wave_sync();   // every read of the own records is done: their LDS becomes sflux / sblk
+    if (isOff) {
 #pragma unroll
-            for (int e = 0; e < 3; ++e) store_ad(&sflux[tid * 12 + e * 4], f[e]);
-            double* b = &sblk[(k - k0e) * BB];
+        for (int e = 0; e < 3; ++e) store_ad(&sflux[tid * 12 + e * 4], f[e]);
+        double* b = &sblk[(k - k0e) * BB];
 #pragma unroll
-            for (int q = 0; q < BB; ++q) b[q] = blk[q];
-        }
-        asm_wave_sync();
-        if (isDiag) {
-            Ad R[3] = {ad_const(0.0), ad_const(0.0), ad_const(0.0)};
-            // flux terms first (FvBaseLocalResidual::eval), faces in ascending NATURAL neighbour order whatever the
-            // internal ordering is, so that the sum is the one the natural-order CPU path forms
-            const int e0 = sfirst[lrow], e1 = sfirst[lrow + 1];
-            // the next face's flux is read from LDS while the present one is added
-            auto face_of = [&](int i) { const int q = e0 + snat[i < e1 ? i : e1 - 1]; return q; };
-            Ad nx[3];
-            int qn = face_of(e0);
+        for (int q = 0; q < BB; ++q) b[q] = blk[q];
+    }
+    asm_wave_sync();
+    if (isDiag) {
+        Ad R[3] = {ad_const(0.0), ad_const(0.0), ad_const(0.0)};
+        // flux terms first (FvBaseLocalResidual::eval), faces in ascending NATURAL neighbour order whatever the
+        // internal ordering is, so that the sum is the one the natural-order CPU path forms
+        const int e0 = sfirst[lrow], e1 = sfirst[lrow + 1];
+        // the next face's flux is read from LDS while the present one is added
+        auto face_of = [&](int i) { const int q = e0 + snat[i < e1 ? i : e1 - 1]; return q; };
+        Ad nx[3];
+        int qn = face_of(e0);
+        for (int e = 0; e < 3; ++e) nx[e] = load_ad(&sflux[qn * 12 + e * 4]);
+        for (int i = e0; i < e1; ++i) {
+            const int q = qn;
+            Ad cur[3] = {nx[0], nx[1], nx[2]};
+            qn = face_of(i + 1);
             for (int e = 0; e < 3; ++e) nx[e] = load_ad(&sflux[qn * 12 + e * 4]);
-            for (int i = e0; i < e1; ++i) {
-                const int q = qn;
-                Ad cur[3] = {nx[0], nx[1], nx[2]};
-                qn = face_of(i + 1);
-                for (int e = 0; e < 3; ++e) nx[e] = load_ad(&sflux[qn * 12 + e * 4]);
-                if (q == tid) continue;   // the diagonal entry itself
-                for (int e = 0; e < 3; ++e) R[e] = R[e] + cur[e];
-            }
-            const double V = VI;
-            const double* pre = &spre[lrow * ASM_PRE];
-            for (int e = 0; e < 3; ++e) {
-                double old;
-                if (iteration == 0) { old = f[e].v; storageOld[(size_t)I * 3 + e] = old; } else old = pre[e];
-                Ad tt = f[e] - old;
-                tt = tt * (V / dt);
-                R[e] = R[e] + tt;
-            }
-            // drift compensation (ebos/eclproblem.hh:1847-1875): what the last accepted time step left unconverged in this
-            // cell (residual * dt, opmhip_end_time_step) goes back in as a rate, capped at maxCompensation of the pore volume
-            double dofDriftRate[3] = {0.0, 0.0, 0.0};
-            if (drift) {
-                const double poro = pre[9];   // referencePorosity
+            if (q == tid) continue;   // the diagonal entry itself
+            for (int e = 0; e < 3; ++e) R[e] = R[e] + cur[e];
+        }
+        const double V = VI;
+        const double* pre = &spre[lrow * ASM_PRE];
+        for (int e = 0; e < 3; ++e) {
+            double old;
+            if (iteration == 0) { old = f[e].v; storageOld[(size_t)I * 3 + e] = old; } else old = pre[e];
+            Ad tt = f[e] - old;
+            tt = tt * (V / dt);
+            R[e] = R[e] + tt;
+        }
+        // drift compensation (ebos/eclproblem.hh:1847-1875): what the last accepted time step left unconverged in this
+        // cell (residual * dt, opmhip_end_time_step) goes back in as a rate, capped at maxCompensation of the pore volume
+        double dofDriftRate[3] = {0.0, 0.0, 0.0};
+        if (drift) {
+            const double poro = pre[9];   // referencePorosity
 #pragma unroll
-                for (int e = 0; e < 3; ++e) dofDriftRate[e] = pre[6 + e] / (dt * V);
-                double totalDriftRate = 0.0;
+            for (int e = 0; e < 3; ++e) dofDriftRate[e] = pre[6 + e] / (dt * V);
+            double totalDriftRate = 0.0;
 #pragma unroll
-                for (int e = 0; e < 3; ++e) totalDriftRate += fabs(dofDriftRate[e]) * dt * 1.0 / poro;   // eqWeight = 1 (UNVERIFIED, see oracle)
-                if (totalDriftRate > maxCompensation) {
+            for (int e = 0; e < 3; ++e) totalDriftRate += fabs(dofDriftRate[e]) * dt * 1.0 / poro;   // eqWeight = 1 (UNVERIFIED, see oracle)
+            if (totalDriftRate > maxCompensation) {
 #pragma unroll
-                    for (int e = 0; e < 3; ++e) dofDriftRate[e] *= maxCompensation / totalDriftRate;
-                }
-            }
-            for (int e = 0; e < 3; ++e) {
-                Ad s = ad_const(pre[3 + e]);
-                if (dsource) { s.d0 = dsource[(size_t)I * 9 + e * 3]; s.d1 = dsource[(size_t)I * 9 + e * 3 + 1]; s.d2 = dsource[(size_t)I * 9 + e * 3 + 2]; }
-                s = s / V;
-                if (drift) s = s - dofDriftRate[e];
-                s = s * V;
-                R[e] = R[e] - s;
-            }
-            double* b = &sblk[(k - k0e) * BB];
-            for (int e = 0; e < 3; ++e) {
-                resid[(size_t)I * 3 + e] = R[e].v;
-                b[e * 3 + 0] = R[e].d0; b[e * 3 + 1] = R[e].d1; b[e * 3 + 2] = R[e].d2;
+                for (int e = 0; e < 3; ++e) dofDriftRate[e] *= maxCompensation / totalDriftRate;
             }
         }
-        asm_wave_sync();
-        // stream the tile's blocks out: contiguous range [k0, k1) x 72 B
-        {
-            const int head = (k0 - k0e) * BB;      // doubles to skip at the front (0 or 9)
-            const int n = nent * BB;
-            double* dst = A + (size_t)k0e * BB;
-            int b = head, e = head + n;
-            // unaligned head / tail doubles go out one by one, the body as double2
-            if ((b & 1) && tid == 0) dst[b] = sblk[b];
-            if ((e & 1) && tid == 0) dst[e - 1] = sblk[e - 1];
-            b = (b + 1) & ~1;
-            e = e & ~1;
-            const double2* s2 = reinterpret_cast<const double2*>(sblk);
-            double2* d2 = reinterpret_cast<double2*>(dst);
-            for (int i = (b >> 1) + tid; i < (e >> 1); i += ASM_THREADS) d2[i] = s2[i];
+        for (int e = 0; e < 3; ++e) {
+            Ad s = ad_const(pre[3 + e]);
+            if (dsource) { s.d0 = dsource[(size_t)I * 9 + e * 3]; s.d1 = dsource[(size_t)I * 9 + e * 3 + 1]; s.d2 = dsource[(size_t)I * 9 + e * 3 + 2]; }
+            s = s / V;
+            if (drift) s = s - dofDriftRate[e];
+            s = s * V;
+            R[e] = R[e] - s;
         }
+        double* b = &sblk[(k - k0e) * BB];
+        for (int e = 0; e < 3; ++e) {
+            resid[(size_t)I * 3 + e] = R[e].v;
+            b[e * 3 + 0] = R[e].d0; b[e * 3 + 1] = R[e].d1; b[e * 3 + 2] = R[e].d2;
+        }
+    }
+    asm_wave_sync();
+    // stream the tile's blocks out: contiguous range [k0, k1) x 72 B
+    {
+        const int head = (k0 - k0e) * BB;      // doubles to skip at the front (0 or 9)
+        const int n = nent * BB;
+        double* dst = A + (size_t)k0e * BB;
+        int b = head, e = head + n;
+        // unaligned head / tail doubles go out one by one, the body as double2
+        if ((b & 1) && tid == 0) dst[b] = sblk[b];
+        if ((e & 1) && tid == 0) dst[e - 1] = sblk[e - 1];
+        b = (b + 1) & ~1;
+        e = e & ~1;
+        const double2* s2 = reinterpret_cast<const double2*>(sblk);
+        double2* d2 = reinterpret_cast<double2*>(dst);
+        for (int i = (b >> 1) + tid; i < (e >> 1); i += ASM_THREADS) d2[i] = s2[i];
     }
 }
 
