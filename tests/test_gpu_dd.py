@@ -290,3 +290,58 @@ def test_dd_time_step_roll_back_restores_owned_and_ghost_cells(pkg):
 
     for flags in run_ranks(world, rank_fn):
         assert all(flags), flags
+
+
+def test_dd_wet_gas_and_rock_tables_bitwise(pkg, orc):
+    """The extended record layout (wet gas: Rv, third primary-variable meaning; ROCKTAB multipliers with overburden) in a
+    decomposed run: ghost cells carry the 19-field records, faces towards them use Rv and the transmissibility multiplier
+    of a cell another rank owns.  Owned rows of the Jacobian, residual, the update with its switches: the global oracle's,
+    bit for bit, over two Newton iterations."""
+    import helpers
+    world, n = 4, 5
+    px, py, pz = pkg.ras.block_layout(world)
+    g = helpers.wetgas_case(pkg, px * n, py * n, pz * n, rocktab=helpers.ROCKTAB_2, heterogeneous=True)
+    parts = []
+    for r in range(world):
+        c = pkg.ras.cartesian_subdomain_case(n, world, r, state="mixed", heterogeneous=True, fluid=g["fluid"])
+        gid = c["gids"]
+        c["pv"] = np.ascontiguousarray(g["pv"].reshape(-1, 3)[gid].reshape(-1))
+        c["meaning"] = np.ascontiguousarray(g["meaning"][gid])
+        c["rocknum"] = np.ascontiguousarray(g["rocknum"][gid])
+        c["overburden"] = np.ascontiguousarray(g["overburden"][gid])
+        parts.append(c)
+    o = oracle_bind.OracleModel(orc, g)
+    o.set_state(g["pv"], g["meaning"])
+    dt = 2 * 86400.0
+    rng = np.random.default_rng(9)
+    dxs = [(rng.standard_normal((g["Nb"], 3)) * np.array([0.04, 2e5, 0.04])).reshape(-1) for _ in range(2)]
+    ref = []
+    for it in range(2):
+        jo, ro = o.assemble(dt, it)
+        o.update(dxs[it])
+        po, mo = o.get_state()
+        ref.append((jo, ro, po.copy(), mo.copy()))
+    group = "t" + uuid.uuid4().hex
+
+    def rank_fn(r):
+        c = parts[r]
+        m = pkg.capi.HipModel(c, comm=("loopback", world, r, group), reorder="line_coloring")
+        m.set_state(c["pv"], c["meaning"])
+        out = []
+        for it in range(2):
+            j, res = m.assemble(dt, it)
+            m.update(np.ascontiguousarray(dxs[it].reshape(-1, 3)[c["gids"][:c["Nb"]]].reshape(-1)), 1.0)
+            p, mm = m.get_state()
+            out.append((j, res, p.copy(), mm.copy()))
+        return out
+
+    outs = run_ranks(world, rank_fn)
+    assert len(np.unique(ref[-1][3])) == 3          # all three meanings live
+    for r, per_it in enumerate(outs):
+        c = parts[r]
+        gi = c["gids"][:c["Nb"]]
+        for it, (j, res, p, mm) in enumerate(per_it):
+            jo, ro, po, mo = ref[it]
+            assert np.array_equal(res.reshape(-1, 3)[:c["Nb"]], ro.reshape(-1, 3)[gi])
+            assert np.array_equal(j.reshape(-1, 9), jo.reshape(-1, 9)[c["halo"]["entry_global"]])
+            assert np.array_equal(mm[:c["Nb"]], mo[gi]) and np.array_equal(p.reshape(-1, 3)[:c["Nb"]], po.reshape(-1, 3)[gi])
