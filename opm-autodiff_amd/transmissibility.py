@@ -15,8 +15,12 @@ produces them for block-centred grids (DX / DY / DZ / TOPS per cell).
   NNC / EDITNNC           EDITNNC scales existing connections, NNC adds to a connection of the grid or creates one
                           (applyEditNncToGridTrans_ :864-925, applyNncToGridTrans_ :814-862, order :487-488)
 
-Not restated: PINCH / MINPV bridging and the MULTZ "ALL" option (applyAllZMultipliers_ :575-612), boundary and thermal
-half transmissibilities, diffusivities.  Faces must be given once, cell1 = the cell with the lower Cartesian index
+  PINCH option ALL        vertical connections (also those that bridge pinched-out cells) take the SMALLEST MULTZ met going down
+                          the pillar from the upper cell to the cell above the lower one, then the lower cell's MULTZ-
+                          (applyAllZMultipliers_ :575-612, selected :219-227)
+
+Not restated: the search for PINCH / MINPV connections themselves (the grid library makes them; they arrive here as faces),
+boundary and thermal half transmissibilities, diffusivities.  Faces must be given once, cell1 = the cell with the lower Cartesian index
 (the reference skips the other orientation, :296-299).  Units: SI (perm m^2, lengths m) -> m^3.
 """
 import numpy as np
@@ -39,12 +43,14 @@ def half_transmissibility(perm_dd, area_normal, distance):
     return h / norm2
 
 
-def face_transmissibilities(faces, centroid, perm, ntg=None, mult=None, region_mult=None):
+def face_transmissibilities(faces, centroid, perm, ntg=None, mult=None, region_mult=None, multz_all=None):
     """faces: dict(cell1, cell2, face1, face2, center1 (nf, 3), center2 (nf, 3), area_normal (nf, 3)); cell1 / cell2 compressed
     cell indices, face1 / face2 in XM..ZP; center1 / center2: the face centre seen from either cell (they differ across
     faults of a corner-point grid).  centroid (n, 3): cell centres as the input grid computes them (axisCentroids, :163-189).
     perm (n, 3): diagonal of the permeability tensor.  ntg (n) or None.  mult: dict 'X-','X+','Y-','Y+','Z-','Z+' -> (n)
     arrays (MULTX- ... MULTZ), missing = 1.  region_mult(cell1[], cell2[], axis[]) -> factors (MULTREGT) or None.
+    multz_all = dict(cart (n: compressed -> Cartesian index), nxny, multz (MULTZ over ALL Cartesian cells)): the PINCH "ALL"
+    option for the vertical faces (they must then run top to bottom: cell1 above cell2).
     -> transmissibility per face"""
     c1, c2 = np.asarray(faces["cell1"], np.int64), np.asarray(faces["cell2"], np.int64)
     f1, f2 = np.asarray(faces["face1"], np.int64), np.asarray(faces["face2"], np.int64)
@@ -59,12 +65,28 @@ def face_transmissibilities(faces, centroid, perm, ntg=None, mult=None, region_m
     with np.errstate(divide="ignore", invalid="ignore"):
         t = 1.0 / (1.0 / h1 + 1.0 / h2)
     t = np.where((np.abs(h1) < 1e-30) | (np.abs(h2) < 1e-30), 0.0, t)
+    zall = np.zeros(len(t), bool)
+    if multz_all is not None:
+        # applyAllZMultipliers_: the smallest MULTZ between the two cells of a vertical connection, pinched-out cells included
+        cart, nxny, mz = np.asarray(multz_all["cart"], np.int64), int(multz_all["nxny"]), np.asarray(multz_all["multz"], float)
+        zall = f1 > YP
+        if np.any(f1[zall] != ZP):
+            raise ValueError("multz_all: vertical faces must be given from the upper cell (face1 = ZP)")
+        for q in np.nonzero(zall)[0]:
+            a, b = cart[c1[q]], cart[c2[q]]
+            last = b - nxny
+            m = mz[last]
+            for cc in range(a, last, nxny):
+                m = min(m, mz[cc])
+            t[q] = t[q] * m
+        if mult and "Z-" in mult:
+            t = np.where(zall, t * np.asarray(mult["Z-"], float)[c2], t)     # the outside element's face (:606)
     if mult:
         for cells, fidx in ((c1, f1), (c2, f2)):   # the inside element's face first, then the outside element's
             m = np.ones(len(t))
             for f, key in _MULT_KEY.items():
                 if key in mult:
-                    sel = fidx == f
+                    sel = (fidx == f) & ~zall
                     m[sel] = np.asarray(mult[key], float)[cells[sel]]
             t = t * m
     if region_mult is not None:

@@ -142,3 +142,27 @@ def test_threshold_pressures():
     row = np.repeat(np.arange(n), np.diff(pat["rowptr"]))
     assert np.all(e[eql[row] == eql[pat["col"]]] == 0.0)
     assert np.all(e[(eql[row] == 0) & (eql[pat["col"]] == 1)] == 12.0e5)
+
+
+def test_multz_all_takes_the_smallest_multiplier_down_the_pillar():
+    """PINCH option ALL (ecltransmissibility.cc:575-612): one column of 5 layers, layers 1 and 2 pinched out, the connection
+    0 -> 3 takes min(MULTZ[0], MULTZ[1], MULTZ[2]) and MULTZ-[3]; a plain neighbour connection its upper cell's MULTZ only"""
+    act = np.array([1, 0, 0, 1, 1])
+    g = T.cartesian_faces(1, 1, 5, 10.0, 10.0, 2.0, 0.0, actnum=act)
+    assert g["n"] == 3 and len(g["faces"]["cell1"]) == 1            # only 3 -> 4 touch; the pinch connection is added by hand
+    F = {k: v.copy() for k, v in g["faces"].items()}
+    F["cell1"] = np.concatenate([[0], F["cell1"]]); F["cell2"] = np.concatenate([[1], F["cell2"]])
+    F["face1"] = np.concatenate([[T.ZP], F["face1"]]); F["face2"] = np.concatenate([[T.ZM], F["face2"]])
+    F["center1"] = np.vstack([[[5.0, 5.0, 2.0]], F["center1"]]); F["center2"] = np.vstack([[[5.0, 5.0, 6.0]], F["center2"]])
+    F["area_normal"] = np.vstack([[[0.0, 0.0, 100.0]], F["area_normal"]])
+    perm = np.full((3, 3), 1e-13)
+    base = T.face_transmissibilities(F, g["centroid"], perm)
+    mz_cart = np.array([0.8, 0.3, 0.5, 0.9, 1.0])
+    mzm = np.array([1.0, 0.5, 1.0])                                   # MULTZ- per compressed cell
+    t = T.face_transmissibilities(F, g["centroid"], perm, mult={"Z+": mz_cart[g["cart"]], "Z-": mzm},
+                                  multz_all=dict(cart=g["cart"], nxny=1, multz=mz_cart))
+    assert t[0] == base[0] * 0.3 * 0.5                                # min(0.8, 0.3, 0.5) and MULTZ- of cell 3
+    assert t[1] == base[1] * 0.9 * 1.0
+    # without the option: the upper cell's own MULTZ and the lower cell's MULTZ-
+    t = T.face_transmissibilities(F, g["centroid"], perm, mult={"Z+": mz_cart[g["cart"]], "Z-": mzm})
+    assert t[0] == base[0] * 0.8 * 0.5
