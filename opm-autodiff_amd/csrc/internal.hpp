@@ -75,6 +75,8 @@ struct Pattern {
     int *d_rowptr = nullptr, *d_col = nullptr, *d_diag = nullptr, *d_nnzMap = nullptr;
     int *d_toOrder = nullptr, *d_fromOrder = nullptr;
     int *d_lrowptr = nullptr, *d_lcol = nullptr, *d_urowptr = nullptr, *d_ucol = nullptr;
+    std::vector<int> fdest;      // per matrix entry: where the factorisation puts it - L index (>= 0), -2 - U index, -1 (diagonal / dropped ghost column)
+    int* d_fdest = nullptr;
 };
 
 struct WellsDev {

@@ -434,10 +434,11 @@ int build_pattern(opmhip_ctx* c, int Nb, int Nghost, int nnzb, const int* rows, 
     P.urowptr.assign(Nb + 1, 0);
     P.lcol.clear();
     P.ucol.clear();
+    P.fdest.assign(P.nnzb, -1);
     for (int p = 0; p < Nb; ++p) {
         for (int k = P.rowptr[p]; k < P.rowptr[p + 1]; ++k) {
-            if (P.col[k] < p) P.lcol.push_back(P.col[k]);
-            else if (P.col[k] > p && P.col[k] < Nb) P.ucol.push_back(P.col[k]);  // ghost columns are not part of the ILU
+            if (P.col[k] < p) { P.fdest[k] = (int)P.lcol.size(); P.lcol.push_back(P.col[k]); }
+            else if (P.col[k] > p && P.col[k] < Nb) { P.fdest[k] = -2 - (int)P.ucol.size(); P.ucol.push_back(P.col[k]); }  // ghost columns are not part of the ILU
         }
         P.lrowptr[p + 1] = (int)P.lcol.size();
         P.urowptr[p + 1] = (int)P.ucol.size();
@@ -516,6 +517,7 @@ int build_pattern(opmhip_ctx* c, int Nb, int Nghost, int nnzb, const int* rows, 
     if ((rc = dev_upload(c, &P.d_lcol, P.lcol))) return rc;
     if ((rc = dev_upload(c, &P.d_urowptr, P.urowptr))) return rc;
     if ((rc = dev_upload(c, &P.d_ucol, P.ucol))) return rc;
+    if ((rc = dev_upload(c, &P.d_fdest, P.fdest))) return rc;
     if ((rc = dev_upload(c, &P.tiles.d_row0, P.tiles.row0))) return rc;
     if ((rc = dev_upload(c, &P.tiles.d_ctFirst, P.tiles.ctFirst))) return rc;
     return OPMHIP_SUCCESS;

@@ -1062,19 +1062,20 @@ __global__ __launch_bounds__(64) void k_ilu_sweep_chain_LU(const int* __restrict
 __global__ __launch_bounds__(64) void k_ilu_factor(int ct_begin, const int* __restrict__ ct_first, const int* __restrict__ tile_row0,
                                                    const int* __restrict__ rowptr, const int* __restrict__ col,
                                                    const int* __restrict__ diag, const double* __restrict__ A,
-                                                   const int* __restrict__ lrowptr, const int* __restrict__ urowptr,
+                                                   const int* __restrict__ fdest, const int* __restrict__ urowptr,
                                                    const int* __restrict__ ucol, double* L, double* U, double* invD) {
     TILE_LDS
     const int lane = threadIdx.x;
     const int q0 = ct_first[ct_begin + blockIdx.x], q1 = ct_first[ct_begin + blockIdx.x + 1];
     constexpr int FU = 8;  // U-row columns of a neighbour fetched in one batch (longer rows: the merge below)
-    __shared__ int scol[TILE_CAP_BLOCKS + 2];
+    __shared__ int scol[TILE_CAP_BLOCKS + 2], sdest[TILE_CAP_BLOCKS + 2];
     for (int t = q0; t < q1; ++t) {  // steps of a chain-tile in order (a single step unless the ordering is line-coloured)
         const TileCtx T = tile_stage_values(t, tile_row0, rowptr, A, sval, lane);
         // the tile's column indices next to its values: the elimination searches them many times
         if (T.staged) {
             const int kk0 = rowptr[T.r0], kk1 = rowptr[T.r1];
-            for (int q = kk0 + lane; q < kk1; q += 64) scol[q - T.k0e] = col[q];
+            for (int q = kk0 + lane; q < kk1; q += 64) { scol[q - T.k0e] = col[q]; sdest[q - T.k0e] = fdest[q]; }
+            if (kk0 > T.k0e && lane == 0) sdest[0] = -1;   // the alignment block in front of the tile belongs to the previous row
         }
         wave_sync();
         const int i = T.r0 + lane;
@@ -1141,11 +1142,18 @@ __global__ __launch_bounds__(64) void k_ilu_factor(int ct_begin, const int* __re
             blk_invert(dblk, inv);
 #pragma unroll
             for (int q = 0; q < BB; ++q) invD[(size_t)i * BB + q] = inv[q];
-            double* Lo = &L[(size_t)lrowptr[i] * BB];
-            for (int a = 0; a < nd * BB; ++a) Lo[a] = row[a];
-            double* Uo = &U[(size_t)urowptr[i] * BB];
-            const int nu = urowptr[i + 1] - urowptr[i];  // owned upper entries; ghost columns (at the row's end) are dropped
-            for (int a = 0; a < nu * BB; ++a) Uo[a] = row[(nd + 1) * BB + a];
+        }
+        wave_sync();
+        // The finished rows leave LDS together: every entry knows its place in L or U (Pattern::fdest), neighbouring lanes
+        // write neighbouring doubles.  (One lane per row storing its own 6 + 6 blocks cost a third of the kernel: 63 store
+        // instructions per lane, each scattering 8 bytes into 32 different rows.)
+        if (T.staged) {
+            const int n9 = T.nb * BB;
+            for (int e = lane; e < n9; e += 64) {
+                const int blk = e / BB, dst = sdest[blk];
+                if (dst >= 0) L[(size_t)dst * BB + (e - blk * BB)] = sval[e];
+                else if (dst <= -2) U[(size_t)(-2 - dst) * BB + (e - blk * BB)] = sval[e];
+            }
         }
         __syncthreads();  // drains vmcnt: this step's factors (global stores) are complete before the next step reads them
     }
@@ -1626,7 +1634,7 @@ void launch_ilu_factor(opmhip_ctx* c) {
         const int cb = P.tiles.colorCT[col], ce = P.tiles.colorCT[col + 1];
         if (ce > cb)
             hipLaunchKernelGGL(k_ilu_factor, dim3(ce - cb), dim3(64), 0, c->stream, cb, P.tiles.d_ctFirst, P.tiles.d_row0, P.d_rowptr, P.d_col,
-                               P.d_diag, c->d_A, P.d_lrowptr, P.d_urowptr, P.d_ucol, c->d_L, c->d_U, c->d_invD);
+                               P.d_diag, c->d_A, P.d_fdest, P.d_urowptr, P.d_ucol, c->d_L, c->d_U, c->d_invD);
     }
     prof_end(c, ps);
 }
