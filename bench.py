@@ -194,7 +194,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--steady-after", type=int, default=200, help="second timed window starts at this Newton iteration (0: none)")
     ap.add_argument("--steady-steps", type=int, default=100)
-    ap.add_argument("--preconditioner", default="ilu0", choices=["ilu0", "cpr"], help="--linear-solver-configuration of the run behind `value`")
+    ap.add_argument("--preconditioner", default="ilu0", choices=["ilu0", "cpr", "cpr_trueimpes"], help="--linear-solver-configuration of the run behind `value`")
     ap.add_argument("--no-cpr-side-run", action="store_true", help="skip the second, shorter run with the CPR preconditioner (extra key `cpr`)")
     a = ap.parse_args()
 

@@ -70,7 +70,9 @@ typedef struct opmhip_config {
                             * are the same bits either way.  [2] preconditioner: 0 = ILU0 (--linear-solver-configuration=ilu0),
                             * 1 = CPR with quasi-IMPES weights (= cpr_quasiimpes, setupPropertyTree.cpp:94-138): pressure
                             * system solved by one AMG V-cycle, ILU0 (relaxation 1) post-smoothing; see csrc/cpr.hip for what
-                            * of it is the reference's and what is not.  Others: 0. */
+                            * of it is the reference's and what is not.  2 = the same with true-IMPES weights (= cpr /
+                            * cpr_trueimpes, the reference's default CPR): from the storage term of the state on the device
+                            * (contexts that assemble) or handed in with opmhip_set_cpr_weights.  Others: 0. */
 } opmhip_config;
 
 /* bda::BdaResult (bda/BdaResult.hpp:28-40) plus the reference's per-phase timers. */
@@ -170,7 +172,16 @@ int opmhip_spmv(opmhip_ctx* ctx, const double* x, double* y);
 int opmhip_ilu0_factor(opmhip_ctx* ctx, double* lu_out);
 /* v = M^-1 d (ParallelOverlappingILU0::apply, :848-903); needs opmhip_ilu0_factor first */
 int opmhip_ilu0_apply(opmhip_ctx* ctx, const double* d, double* v);
-/* v = M_cpr^-1 d with the CPR preconditioner of the matrix now on the device (contexts created with reserved[2] = 1;
+/* replaces: the weights argument of the CPR preconditioner (linalg/ISTLSolverEbos.hpp:440-475: getTrueImpesWeights /
+ * getQuasiImpesWeights handed to the preconditioner factory).  weights: 3 doubles per block row, natural order - what
+ * Amg::getTrueImpesWeights (linalg/getQuasiImpesWeights.hpp:89-128) returns; they stay in force for every later solve.
+ * NULL: back to the weights the library computes itself (quasi-IMPES from the matrix, or - reserved[2] = 2, contexts that
+ * assemble - true-IMPES from the storage term of the present state with the dt of the last opmhip_assemble). */
+int opmhip_set_cpr_weights(opmhip_ctx* ctx, const double* weights);
+/* the weights of the last CPR set-up (3 per block row, natural order): diagnosis and tests */
+int opmhip_get_cpr_weights(opmhip_ctx* ctx, double* weights);
+
+/* v = M_cpr^-1 d with the CPR preconditioner of the matrix now on the device (contexts created with reserved[2] = 1 or 2;
  * needs opmhip_ilu0_factor first: the fine smoother's factors) - for parity tests of the preconditioner alone */
 int opmhip_cpr_apply(opmhip_ctx* ctx, const double* d, double* v);
 /* the ordering chosen at set_pattern: toOrder/fromOrder [Nb], rowsPerColor [num colours] (any may be NULL);

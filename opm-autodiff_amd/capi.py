@@ -83,6 +83,8 @@ def lib():
         L.opmhip_ilu0_factor.argtypes = [vp, dp]
         L.opmhip_ilu0_apply.argtypes = [vp, dp, dp]
         L.opmhip_cpr_apply.argtypes = [vp, dp, dp]
+        L.opmhip_set_cpr_weights.argtypes = [vp, dp]
+        L.opmhip_get_cpr_weights.argtypes = [vp, dp]
         L.opmhip_get_ordering.argtypes = [vp, ip, ip, ip]
         L.opmhip_time_kernel.argtypes = [vp, C.c_int, C.c_int, C.POINTER(C.c_double)]
         L.opmhip_cpr_levels.argtypes = [vp, ip, ip, C.c_int]
@@ -131,7 +133,9 @@ class HipSolver:
         cfg.zero_diag_fix = int(zero_diag_fix)
         cfg.reserved[0] = int(chain_length)  # line colouring: rows per chain
         cfg.reserved[1] = int(spmv_pipe_wgs)  # pipelined SpMV: workgroups it is sized for (0 default, < 0 off; tests use small values)
-        cfg.reserved[2] = {"ilu0": 0, "cpr": 1}[preconditioner]  # --linear-solver-configuration
+        # --linear-solver-configuration (setupPropertyTree.cpp:62-76; there "cpr" is short for cpr_trueimpes - here it keeps
+        # meaning the quasi-IMPES variant a context without a model can always form; ask for the other one by name)
+        cfg.reserved[2] = {"ilu0": 0, "cpr": 1, "cpr_quasiimpes": 1, "cpr_trueimpes": 2}[preconditioner]
         self._h = C.c_void_p()
         rc = L.opmhip_create(C.byref(cfg), C.byref(self._h))
         if rc != SUCCESS:
@@ -218,6 +222,17 @@ class HipSolver:
         v = np.empty_like(d)
         self._check(lib().opmhip_ilu0_apply(self._h, _ptr(d), _ptr(v)))
         return v
+
+    def set_cpr_weights(self, w=None):
+        """CPR weights from outside (3 per block row, natural order - e.g. Flow's getTrueImpesWeights); None: computed again"""
+        w = None if w is None else _f64(np.asarray(w).reshape(-1))
+        self._w_keep = w
+        self._check(lib().opmhip_set_cpr_weights(self._h, _ptr(w)))
+
+    def cpr_weights(self):
+        w = np.empty(3 * self.Nb)
+        self._check(lib().opmhip_get_cpr_weights(self._h, _ptr(w)))
+        return w.reshape(-1, 3)
 
     def cpr_apply(self, d):
         d = _f64(d)

@@ -457,6 +457,26 @@ int opmhip_ilu0_apply(opmhip_ctx* c, const double* d, double* v) {
     });
 }
 
+int opmhip_set_cpr_weights(opmhip_ctx* c, const double* weights) {
+    if (!c) return OPMHIP_INVALID_ARGUMENT;
+    return guarded(c, [&]() -> int {
+        if (!use_cpr(c)) return fail(c, OPMHIP_NOT_READY, "set_cpr_weights: the context was not created with the CPR preconditioner");
+        if (!c->pattern_set) return fail(c, OPMHIP_NOT_READY, "set_cpr_weights before set_pattern");
+        OPMHIP_HIP(c, hipSetDevice(c->device));
+        return cpr_set_weights(c, weights);
+    });
+}
+
+int opmhip_get_cpr_weights(opmhip_ctx* c, double* weights) {
+    if (!c) return OPMHIP_INVALID_ARGUMENT;
+    return guarded(c, [&]() -> int {
+        if (!weights) return fail(c, OPMHIP_INVALID_ARGUMENT, "get_cpr_weights: null array");
+        if (!use_cpr(c) || !c->cpr.d_w) return fail(c, OPMHIP_NOT_READY, "get_cpr_weights: no CPR set-up on this context yet");
+        OPMHIP_HIP(c, hipSetDevice(c->device));
+        return vec_out(c, c->cpr.d_w, weights);
+    });
+}
+
 int opmhip_cpr_apply(opmhip_ctx* c, const double* d, double* v) {
     if (!c) return OPMHIP_INVALID_ARGUMENT;
     return guarded(c, [&]() -> int {

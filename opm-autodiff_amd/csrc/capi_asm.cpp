@@ -434,6 +434,7 @@ int opmhip_assemble(opmhip_ctx* c, double dt, int iteration, double* jac, double
         if (!c->asmb.state_set) return fail(c, OPMHIP_NOT_READY, "assemble before set_state");
         if (!(dt > 0.0) || iteration < 0) return fail(c, OPMHIP_INVALID_ARGUMENT, "assemble: dt must be positive, iteration >= 0");
         OPMHIP_HIP(c, hipSetDevice(c->device));
+        c->asmb.last_dt = dt;
         launch_assemble(c, dt, iteration);
         OPMHIP_HIP(c, hipGetLastError());
         c->system_loaded = true;

@@ -391,13 +391,99 @@ static int upload_ell(opmhip_ctx* c, const HCsr& A, CprLevelDev& L, std::vector<
     if ((rc = dev_alloc(c, &L.d_r, (size_t)n))) return rc;
     return OPMHIP_SUCCESS;
 }
+// True-IMPES weights (getQuasiImpesWeights.hpp:89-128): block[ii][jj] = d storage_ii / d x_jj / (V / dt), pressure column
+// times 50e5, block^T w = e_p, w /= 1000 - from the intensive quantities of the state on the device.  The storage term is
+// the one of the assembly kernel's diagonal lane (assemble.hip: same statements, same order); the 3 x 3 solve is the pivoted
+// elimination of oracle/cpr.hpp: true_impes_weights_cell, statement by statement.  Field numbers and the field-major
+// addressing of the cache: assemble.hip (F_S .. F_RS, Lay<EXT>, iq_at).
+struct WAd { double v, d[3]; };
+__device__ __forceinline__ WAd wad_load(const double* iq, int ncell, int f, int c) {
+    const double* o = iq + ((size_t)f * ncell + c) * 4;
+    return WAd{o[0], {o[1], o[2], o[3]}};
+}
+__device__ __forceinline__ WAd wad_mul(const WAd& a, const WAd& b) {
+    const double u = a.v, w = b.v;
+    return WAd{u * w, {a.d[0] * w + b.d[0] * u, a.d[1] * w + b.d[1] * u, a.d[2] * w + b.d[2] * u}};
+}
+__device__ __forceinline__ WAd wad_add(const WAd& a, const WAd& b) { return WAd{a.v + b.v, {a.d[0] + b.d[0], a.d[1] + b.d[1], a.d[2] + b.d[2]}}; }
+template <bool EXT>
+__global__ __launch_bounds__(256) void k_cpr_true_weights(int Nb, int ncell, int wet, const double* __restrict__ iq, const double* __restrict__ volume,
+                                                          double dt, double* __restrict__ w) {
+    constexpr int F_S = 0, F_B = 6, F_RS = 15, F_RV = 16, F_PORO = EXT ? 18 : 16;
+    constexpr int WATER = 0, OIL = 1, GAS = 2, EQ_OIL = 0, EQ_WATER = 1, EQ_GAS = 2;
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= Nb) return;
+    const WAd poro = wad_load(iq, ncell, F_PORO, i), Rs = wad_load(iq, ncell, F_RS, i);
+    const WAd zero{0.0, {0.0, 0.0, 0.0}};
+    WAd st[3] = {zero, zero, zero};
+    const int comp[3] = {EQ_WATER, EQ_OIL, EQ_GAS};
+#pragma unroll
+    for (int ph = 0; ph < 3; ++ph) {   // computeStorage: surface volumes per bulk volume
+        const WAd surfaceVolume = wad_mul(wad_mul(wad_load(iq, ncell, F_S + ph, i), wad_load(iq, ncell, F_B + ph, i)), poro);
+        st[comp[ph]] = wad_add(st[comp[ph]], surfaceVolume);
+        if (ph == OIL) st[EQ_GAS] = wad_add(st[EQ_GAS], wad_mul(Rs, surfaceVolume));
+        if (EXT && ph == GAS && wet) st[EQ_OIL] = wad_add(st[EQ_OIL], wad_mul(wad_load(iq, ncell, F_RV, i), surfaceVolume));
+    }
+    (void)WATER;
+    const double storage_scale = volume[i] / dt, pressure_scale = 50e5;
+    double M[BS][BS + 1];
+    for (int r = 0; r < BS; ++r) {          // M = block^T | e_p
+        for (int c = 0; c < BS; ++c) {
+            double v = st[c].d[r] / storage_scale;
+            if (r == CPR_P) v = v * pressure_scale;
+            M[r][c] = v;
+        }
+        M[r][BS] = (r == CPR_P) ? 1.0 : 0.0;
+    }
+#pragma unroll
+    for (int k = 0; k < BS; ++k) {
+        int piv = k;
+        double best = fabs(M[k][k]);
+#pragma unroll
+        for (int r = k + 1; r < BS; ++r)
+            if (fabs(M[r][k]) > best) { best = fabs(M[r][k]); piv = r; }
+#pragma unroll
+        for (int r = k + 1; r < BS; ++r)    // the swap, written without a run-time row index
+            if (piv == r)
+                for (int c = 0; c <= BS; ++c) { const double t = M[k][c]; M[k][c] = M[r][c]; M[r][c] = t; }
+#pragma unroll
+        for (int r = k + 1; r < BS; ++r) {
+            const double f = M[r][k] / M[k][k];
+            for (int c = k; c <= BS; ++c) M[r][c] = M[r][c] - f * M[k][c];
+        }
+    }
+    double x[BS];
+#pragma unroll
+    for (int r = BS - 1; r >= 0; --r) {
+        double s = M[r][BS];
+        for (int c = r + 1; c < BS; ++c) s = s - M[r][c] * x[c];
+        x[r] = s / M[r][r];
+    }
+    for (int r = 0; r < BS; ++r) w[(size_t)i * BS + r] = x[r] / 1000.0;
+}
+// the weights of this solve: handed in (kept), true-IMPES from the model's state, or quasi-IMPES from the matrix
+static int cpr_weights(opmhip_ctx* c) {
+    const Pattern& P = c->pat;
+    CprDev& R = c->cpr;
+    if (R.w_given) return OPMHIP_SUCCESS;
+    if (c->cfg.reserved[2] == 2) {
+        const AsmDev& A = c->asmb;
+        if (!A.static_set || !A.d_iq || !(A.last_dt > 0.0))
+            return fail(c, OPMHIP_NOT_READY, "cpr (true-IMPES weights): no assembled state on this context - call opmhip_assemble first or hand the weights in (opmhip_set_cpr_weights)");
+        if (A.ext) hipLaunchKernelGGL(k_cpr_true_weights<true>, g256(P.Nb), dim3(256), 0, c->stream, P.Nb, P.Nloc, A.wet_gas ? 1 : 0, A.d_iq, A.d_volume, A.last_dt, R.d_w);
+        else hipLaunchKernelGGL(k_cpr_true_weights<false>, g256(P.Nb), dim3(256), 0, c->stream, P.Nb, P.Nloc, 0, A.d_iq, A.d_volume, A.last_dt, R.d_w);
+        return OPMHIP_SUCCESS;
+    }
+    hipLaunchKernelGGL(k_cpr_weights, g256(P.Nb), dim3(256), 0, c->stream, P.Nb, P.d_diag, c->d_A, R.d_w);
+    return OPMHIP_SUCCESS;
+}
 // structure of the hierarchy, once per context, from the values of the pressure matrix of the system now on the device
 static int cpr_setup_structure(opmhip_ctx* c) {
     const Pattern& P = c->pat;
     CprDev& R = c->cpr;
     int rc;
     if (c->comm.nranks > 1) return fail(c, OPMHIP_INVALID_ARGUMENT, "cpr: not available in decomposed runs (the reference disables accelerators there too)");
-    if ((rc = dev_alloc(c, &R.d_w, (size_t)P.Nb * BS))) return rc;
+    if (!R.d_w && (rc = dev_alloc(c, &R.d_w, (size_t)P.Nb * BS))) return rc;
     if ((rc = dev_alloc(c, &R.d_r, (size_t)P.Nb * BS))) return rc;
     if ((rc = dev_alloc(c, &R.d_y, (size_t)P.Nb * BS))) return rc;
     if ((rc = dev_alloc(c, &R.d_z, (size_t)P.Nb * BS))) return rc;
@@ -408,7 +494,7 @@ static int cpr_setup_structure(opmhip_ctx* c) {
     R.lv.emplace_back();
     std::vector<int> pos;   // ELL position of every CSR entry of the level being coarsened
     if ((rc = upload_ell(c, A, R.lv[0], pos, false))) return rc;
-    hipLaunchKernelGGL(k_cpr_weights, g256(P.Nb), dim3(256), 0, c->stream, P.Nb, P.d_diag, c->d_A, R.d_w);
+    if ((rc = cpr_weights(c))) return rc;
     hipLaunchKernelGGL(k_cpr_pvals, g256(P.Nb), dim3(256), 0, c->stream, P.Nb, P.d_rowptr, c->d_A, R.d_w, R.lv[0].d_val);
     {
         std::vector<double> ell((size_t)R.lv[0].W * P.Nb);
@@ -472,7 +558,7 @@ int cpr_update(opmhip_ctx* c) {
     int rc;
     if (!R.structured && (rc = cpr_setup_structure(c))) return rc;
     const int ps = prof_begin(c, PROF_ILU_FACTOR);
-    hipLaunchKernelGGL(k_cpr_weights, g256(P.Nb), dim3(256), 0, c->stream, P.Nb, P.d_diag, c->d_A, R.d_w);
+    if ((rc = cpr_weights(c))) { prof_end(c, ps); return rc; }
     hipLaunchKernelGGL(k_cpr_pvals, g256(P.Nb), dim3(256), 0, c->stream, P.Nb, P.d_rowptr, c->d_A, R.d_w, R.lv[0].d_val);
     for (size_t l = 0; l < R.lv.size(); ++l) {
         CprLevelDev& L = R.lv[l];
@@ -548,6 +634,21 @@ void launch_cpr_apply(opmhip_ctx* c, const double* d, double* v) {
     prof_end(c, ps);
 }
 
+// weights handed in (natural order, 3 per row) / back to computed ones
+int cpr_set_weights(opmhip_ctx* c, const double* w) {
+    const Pattern& P = c->pat;
+    CprDev& R = c->cpr;
+    if (!w) { R.w_given = false; return OPMHIP_SUCCESS; }
+    int rc;
+    if (!R.d_w && (rc = dev_alloc(c, &R.d_w, (size_t)P.Nb * BS))) return rc;
+    std::vector<double> wi((size_t)P.Nb * BS);
+    for (int i = 0; i < P.Nb; ++i)
+        for (int k = 0; k < BS; ++k) wi[(size_t)P.toOrder[i] * BS + k] = w[(size_t)i * BS + k];
+    OPMHIP_HIP(c, hipMemcpyAsync(R.d_w, wi.data(), wi.size() * sizeof(double), hipMemcpyHostToDevice, c->stream));
+    OPMHIP_HIP(c, hipStreamSynchronize(c->stream));
+    R.w_given = true;
+    return OPMHIP_SUCCESS;
+}
 int cpr_level_sizes(const opmhip_ctx* c, int* n, int* nnz, int cap) {
     const int L = (int)c->cpr.lv.size();
     for (int l = 0; l < L && l < cap; ++l) { n[l] = c->cpr.lv[l].n; nnz[l] = c->cpr.lv[l].nnz; }

@@ -105,6 +105,7 @@ struct AsmDev {
     int *d_pvtnum = nullptr, *d_satnum = nullptr;
     double *d_pv = nullptr, *d_iq = nullptr, *d_storageOld = nullptr, *d_source = nullptr, *d_dsource = nullptr;
     unsigned char *d_meaning = nullptr, *d_wasSwitched = nullptr, *d_stage_u8 = nullptr;
+    double last_dt = 0.0;                   // time step of the last opmhip_assemble (true-IMPES weights scale the storage term by V / dt)
     double* d_drift = nullptr;              // residual * dt of the last accepted time step (drift compensation), Nloc x 3
     bool drift_enabled = true;              // EclEnableDriftCompensation defaults to true (ebos/eclproblem.hh:496-498)
     double max_compensation = 0.1;          // 10 * NewtonTolerance (ebos/eclproblem.hh:352-356, 1854)
@@ -151,6 +152,7 @@ struct CprDev {
     bool structured = false, coarse_direct = true;
     std::vector<CprLevelDev> lv;
     double *d_w = nullptr, *d_lu = nullptr;
+    bool w_given = false;                                          // d_w holds weights handed in (opmhip_set_cpr_weights): not recomputed
     double *d_r = nullptr, *d_y = nullptr, *d_z = nullptr;         // fine-level block vectors
     double omega = 2.0 / 3.0, damp = 1.6, beta = 0.25;             // Jacobi damping, prolongation damping, strength threshold
 };
@@ -353,8 +355,9 @@ void launch_ilu_apply(opmhip_ctx* c, const double* d, double* v, int fuse = 0, d
 // cpr.hip
 int cpr_update(opmhip_ctx* c);
 void launch_cpr_apply(opmhip_ctx* c, const double* d, double* v);
+int cpr_set_weights(opmhip_ctx* c, const double* w);
 int cpr_level_sizes(const opmhip_ctx* c, int* n, int* nnz, int cap);
-inline bool use_cpr(const opmhip_ctx* c) { return c->cfg.reserved[2] == 1; }
+inline bool use_cpr(const opmhip_ctx* c) { return c->cfg.reserved[2] == 1 || c->cfg.reserved[2] == 2; }   // 1 quasi-IMPES, 2 true-IMPES weights
 void launch_wells_apply(opmhip_ctx* c, const double* x, double* y);
 void launch_lu_to_natural(opmhip_ctx* c, double* d_out_internal_layout);
 int bicgstab(opmhip_ctx* c, opmhip_result* res);

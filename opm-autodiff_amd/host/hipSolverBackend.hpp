@@ -37,7 +37,9 @@ class hipSolverBackend : public BdaSolver<block_size> {
 
 public:
     /// ilu_reorder as --opencl-ilu-reorder: "level_scheduling" | "graph_coloring" | "line_coloring";
-    /// linsolver as --linear-solver-configuration: "ilu0" | "cpr_quasiimpes" (setupPropertyTree.cpp:46-138)
+    /// linsolver as --linear-solver-configuration: "ilu0" | "cpr_quasiimpes" | "cpr" = "cpr_trueimpes" (setupPropertyTree.cpp:46-138).
+    /// The true-IMPES variant needs the model's storage term: the caller hands the result of
+    /// ISTLSolverEbos::getTrueImpesWeights (ISTLSolverEbos.hpp:466-475) to setCprWeights() before each solve.
     hipSolverBackend(int linear_solver_verbosity, int maxit_, double tolerance_, unsigned int deviceID_,
                      const std::string& ilu_reorder = "graph_coloring", double ilu_relaxation = 0.9,
                      const std::string& linsolver = "ilu0")
@@ -55,11 +57,16 @@ public:
         else if (ilu_reorder == "line_coloring") cfg.reorder = OPMHIP_REORDER_LINE_COLORING;
         else throw std::logic_error("Error invalid argument for --opencl-ilu-reorder, usage: '--opencl-ilu-reorder=[level_scheduling|graph_coloring|line_coloring]'");
         if (linsolver == "cpr_quasiimpes") cfg.reserved[2] = 1;
-        else if (linsolver != "ilu0") throw std::invalid_argument(linsolver + " is not a valid setting for --linear-solver-configuration with --accelerator-mode=hip. Please use ilu0 or cpr_quasiimpes");
+        else if (linsolver == "cpr" || linsolver == "cpr_trueimpes") cfg.reserved[2] = 2;
+        else if (linsolver != "ilu0") throw std::invalid_argument(linsolver + " is not a valid setting for --linear-solver-configuration with --accelerator-mode=hip. Please use ilu0, cpr, cpr_trueimpes, or cpr_quasiimpes");
         const int rc = opmhip_create(&cfg, &ctx);
         if (rc != OPMHIP_SUCCESS) throw std::logic_error(std::string("hipSolverBackend: ") + opmhip_last_error(nullptr));
     }
     ~hipSolverBackend() override { opmhip_destroy(ctx); }
+    /// weights of the CPR preconditioner (3 per block row), e.g. Amg::getTrueImpesWeights; nullptr: computed by the library
+    void setCprWeights(const double* weights) {
+        if (opmhip_set_cpr_weights(ctx, weights) != OPMHIP_SUCCESS) throw std::logic_error(std::string("hipSolverBackend: ") + opmhip_last_error(ctx));
+    }
     hipSolverBackend(const hipSolverBackend&) = delete;
     hipSolverBackend& operator=(const hipSolverBackend&) = delete;
 

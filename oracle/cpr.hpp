@@ -257,12 +257,49 @@ struct CprAmg {
     }
 };
 
+// True-IMPES weights of one cell (opm/simulators/linalg/getQuasiImpesWeights.hpp:89-128): block[ii][jj] = d storage_ii /
+// d x_jj / (V / dt), the pressure column times 50e5; block^T w = e_p; w /= 1000.  dS: derivatives of the storage term
+// (equation x primary variable).  The reference solves with Dune's FieldMatrix::solve - an LU with partial pivoting whose
+// code is not in the tree; here: Gaussian elimination with row pivoting on the largest magnitude (first one on ties),
+// the same statements on the device, hence the same bits there (UNVERIFIED vs Dune's rounding sequence).
+inline void true_impes_weights_cell(const double dS[BS][BS], double storage_scale, double w[BS]) {
+    const double pressure_scale = 50e5;
+    double M[BS][BS + 1];
+    for (int r = 0; r < BS; ++r) {          // M = block^T | e_p
+        for (int c = 0; c < BS; ++c) {
+            double v = dS[c][r] / storage_scale;         // block[c][r], c = equation, r = variable
+            if (r == CPR_PRESSURE_INDEX) v = v * pressure_scale;
+            M[r][c] = v;
+        }
+        M[r][BS] = (r == CPR_PRESSURE_INDEX) ? 1.0 : 0.0;
+    }
+    for (int k = 0; k < BS; ++k) {
+        int piv = k;
+        double best = std::fabs(M[k][k]);
+        for (int r = k + 1; r < BS; ++r)
+            if (std::fabs(M[r][k]) > best) { best = std::fabs(M[r][k]); piv = r; }
+        if (piv != k)
+            for (int c = 0; c <= BS; ++c) { const double t = M[k][c]; M[k][c] = M[piv][c]; M[piv][c] = t; }
+        for (int r = k + 1; r < BS; ++r) {
+            const double f = M[r][k] / M[k][k];
+            for (int c = k; c <= BS; ++c) M[r][c] = M[r][c] - f * M[k][c];
+        }
+    }
+    for (int r = BS - 1; r >= 0; --r) {
+        double s = M[r][BS];
+        for (int c = r + 1; c < BS; ++c) s = s - M[r][c] * w[c];
+        w[r] = s / M[r][r];
+    }
+    for (int r = 0; r < BS; ++r) w[r] = w[r] / 1000.0;   // "given normal densities this scales weights to about 1"
+}
+
 // the whole preconditioner for one block system
 struct Cpr {
     const Bcrs* A = nullptr;
     Bcrs LU;
     std::vector<int> dg;
-    std::vector<double> w;          // quasi-IMPES weights, Nb x 3
+    std::vector<double> w;          // weights, Nb x 3: quasi-IMPES from the matrix, or handed in (true-IMPES: they need the model)
+    std::vector<double> w_given;    // non-empty: use these
     CprAmg amg;
     bool structured = false;
 
@@ -297,7 +334,8 @@ struct Cpr {
         const int rc = bilu0_decompose(LU, Ain.Nb);
         if (rc) return rc;
         dg = diag_index(LU);
-        quasi_impes_weights(Ain, w);
+        if (w_given.empty()) quasi_impes_weights(Ain, w);
+        else w = w_given;
         std::vector<double> ap;
         pressure_values(Ain, w, ap);
         if (!structured) {

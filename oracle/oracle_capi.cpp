@@ -291,6 +291,11 @@ int orc_cpr_levels(orc_cpr* h, int* n, int* nnz, int cap) {
     for (int l = 0; l < L && l < cap; ++l) { n[l] = h->P.amg.lv[l].A.n; nnz[l] = (int)h->P.amg.lv[l].A.col.size(); }
     return L;
 }
+// weights from outside (true-IMPES: orc_bo_true_impes_weights); n == 0: back to quasi-IMPES
+int orc_cpr_set_weights(orc_cpr* h, int n, const double* w) {
+    if (n > 0) h->P.w_given.assign(w, w + n); else h->P.w_given.clear();
+    return 0;
+}
 int orc_cpr_weights(orc_cpr* h, double* w) { std::memcpy(w, h->P.w.data(), h->P.w.size() * sizeof(double)); return 0; }
 // level l: aggregate of every node (for the device parity test of the host-side aggregation)
 int orc_cpr_aggregates(orc_cpr* h, int l, int* agg) {
@@ -514,6 +519,20 @@ int orc_bo_assemble(orc_model* h, double dt, int iteration, double* jac, double*
     M.assemble(dt, iteration);
     if (jac) std::memcpy(jac, M.J.val.data(), M.J.val.size() * sizeof(double));
     if (residual) std::memcpy(residual, M.residual.data(), M.residual.size() * sizeof(double));
+    return 0;
+}
+// true-IMPES weights of every cell from the storage term's derivatives at the present state (getQuasiImpesWeights.hpp:89-128)
+int orc_bo_true_impes_weights(orc_model* h, double dt, double* w) {
+    Model& M = h->M;
+    const int Nb = M.P.pat.Nb;
+    for (int c = 0; c < Nb; ++c) {
+        Ev st[3];
+        compute_storage(M.iqF[c], st, M.P.fluid.hasWetGas);
+        double dS[BS][BS];
+        for (int e = 0; e < BS; ++e)
+            for (int v = 0; v < BS; ++v) dS[e][v] = st[e].d[v];
+        true_impes_weights_cell(dS, M.P.volume[c] / dt, &w[(size_t)c * BS]);
+    }
     return 0;
 }
 // the Jacobian / residual of the last orc_bo_assemble, without assembling again

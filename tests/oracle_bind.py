@@ -49,6 +49,7 @@ class Oracle:
         L.orc_cpr_apply.argtypes = [_vp, _d, _d]
         L.orc_cpr_levels.argtypes = [_vp, _i, _i, C.c_int]
         L.orc_cpr_weights.argtypes = [_vp, _d]
+        L.orc_cpr_set_weights.argtypes = [_vp, C.c_int, C.c_void_p]
         L.orc_cpr_aggregates.argtypes = [_vp, C.c_int, _i]
 
     # ---- linear algebra -------------------------------------------------------------------
@@ -148,6 +149,7 @@ class OracleModel:
         L.orc_bo_get_iq.argtypes = [_vp, _d]
         L.orc_bo_assemble.argtypes = [_vp, C.c_double, C.c_int, _vp, _vp]
         L.orc_bo_convergence.argtypes = [_vp, C.c_double, C.c_double, _d]
+        L.orc_bo_true_impes_weights.argtypes = [_vp, C.c_double, _vp]
         L.orc_bo_update.argtypes = [_vp, _d]
         L.orc_bo_assemble_fetch.argtypes = [_vp, _vp, _vp]
         L.orc_bo_solve.argtypes = [_vp, _d, C.c_double, C.c_int, C.c_double, C.c_int, C.c_int, C.c_int, _vp,
@@ -215,6 +217,12 @@ class OracleModel:
         out = np.empty(17)
         self.o.lib.orc_bo_convergence(self.h, dt, tol_cnv, out)
         return out
+
+    def true_impes_weights(self, dt):
+        """getTrueImpesWeights at the present state (oracle/cpr.hpp: true_impes_weights_cell) -> (Nb, 3)"""
+        w = np.empty(self.Nb * 3)
+        self.o.lib.orc_bo_true_impes_weights(self.h, C.c_double(dt), w.ctypes.data_as(C.c_void_p))
+        return w.reshape(-1, 3)
 
     def update(self, dx):
         return self.o.lib.orc_bo_update(self.h, np.ascontiguousarray(dx, np.float64))
@@ -383,6 +391,15 @@ class OracleCpr:
         n, nnz = np.zeros(32, np.int32), np.zeros(32, np.int32)
         L = self.o.lib.orc_cpr_levels(self.h, n, nnz, 32)
         return list(n[:L]), list(nnz[:L])
+
+    def set_weights(self, w=None):
+        """weights from outside (true-IMPES: OracleModel.true_impes_weights); None: quasi-IMPES again"""
+        if w is None:
+            self.o.lib.orc_cpr_set_weights(self.h, 0, None)
+        else:
+            w = np.ascontiguousarray(np.asarray(w, np.float64).reshape(-1))
+            self._w = w
+            self.o.lib.orc_cpr_set_weights(self.h, len(w), w.ctypes.data_as(C.c_void_p))
 
     def weights(self, Nb):
         w = np.empty(Nb * 3)

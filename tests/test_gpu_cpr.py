@@ -113,3 +113,57 @@ def test_newton_loop_with_cpr(pkg, orc):
     assert np.array_equal(ma, mb)
     np.testing.assert_allclose(pa.reshape(-1, 3)[:, 1], pb.reshape(-1, 3)[:, 1], rtol=1e-4)
     np.testing.assert_allclose(pa.reshape(-1, 3)[:, 0], pb.reshape(-1, 3)[:, 0], atol=2e-3)
+
+
+@pytest.mark.parametrize("wet", [False, True])
+def test_true_impes_weights_bitwise_and_newton(pkg, orc, wet):
+    """cpr_trueimpes (the reference's "cpr", setupPropertyTree.cpp:62-76): weights from the storage term of the state on the
+    device (linalg/getQuasiImpesWeights.hpp:89-128) - bit for bit the oracle's, for the 17- and the 19-field record; the
+    preconditioner built on them applied bit for bit; the Newton loop converges with fewer linear iterations than ILU0."""
+    import helpers
+    if wet:
+        case = helpers.wetgas_case(pkg, 12, 11, 13, rocktab=helpers.ROCKTAB_2, heterogeneous=True)
+    else:
+        case = pkg.decks.cartesian_case(14, 12, 13, state="mixed", heterogeneous=True)
+    src = pkg.decks.five_spot_source(case, rate_sm3_per_day=20.0)
+    dt = 5 * 86400.0
+    m = pkg.capi.HipModel(case, reorder="line_coloring", preconditioner="cpr_trueimpes")
+    o = oracle_bind.OracleModel(orc, case)
+    for q in (m, o):
+        q.set_state(case["pv"], case["meaning"])
+        q.set_source(src)
+    jm, rm = m.assemble(dt, 0)
+    jo, ro = o.assemble(dt, 0)
+    assert np.array_equal(jm, jo)
+    sol = m.solve_jacobian_system()
+    assert sol.converged
+    wd, wo = m.cpr_weights(), o.true_impes_weights(dt)
+    assert np.array_equal(wd, wo)
+    assert np.all(np.isfinite(wo)) and np.abs(wo).max() < 1e3 and np.abs(wo[:, 1]).min() > 0.0
+    # the same weights handed to a solver-only context and to the oracle's CPR: the application bit for bit
+    Nb, rp, ci = case["Nb"], case["rowptr"], case["col"]
+    s = pkg.capi.HipSolver(reorder="line_coloring", preconditioner="cpr_trueimpes", tolerance=1e-2)
+    s.set_pattern(Nb, rp, ci)
+    s.upload_system(jo)
+    s.ilu0_factor(want_factors=False)
+    with pytest.raises(pkg.capi.OpmHipError):        # no model behind this context: true-IMPES weights must be handed in
+        s.cpr_apply(np.ones(3 * Nb))
+    s.set_cpr_weights(wo)
+    to, fr, rr, rc, rv = reordered(orc, s, Nb, rp, ci, jo)
+    cpr = oracle_bind.OracleCpr(orc)
+    cpr.set_weights(wo[fr])
+    cpr.update(Nb, rr, rc, rv)
+    d = np.random.default_rng(3).standard_normal(3 * Nb)
+    vo = cpr.apply(np.ascontiguousarray(d.reshape(Nb, 3)[fr].reshape(-1))).reshape(Nb, 3)[to].reshape(-1)
+    assert np.array_equal(s.cpr_apply(d), vo)
+    assert np.array_equal(s.cpr_weights(), wo)
+    # whole time step: true-IMPES CPR against ILU0 (the wet-gas state is a random mix of all three meanings: a short step)
+    out = {}
+    for prec in ("ilu0", "cpr_trueimpes"):
+        mm = pkg.capi.HipModel(case, reorder="line_coloring", preconditioner=prec)
+        mm.set_state(case["pv"], case["meaning"])
+        mm.set_source(src)
+        rep = pkg.newton.BlackoilModelHip(mm).step(0.2 * 86400.0 if wet else dt)
+        out[prec] = (rep.total_newton_iterations, rep.total_linear_iterations, rep.converged)
+    assert out["cpr_trueimpes"][2] and abs(out["ilu0"][0] - out["cpr_trueimpes"][0]) <= 2
+    assert out["cpr_trueimpes"][1] < out["ilu0"][1], out
