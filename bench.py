@@ -53,7 +53,7 @@ def alg_bytes(Nb, nnzb):
         # + the BiCGStab p- and (r, x)-updates that ride in the first colour's sweep: (3 + 5) / 2 extra vector passes
         "ilu_apply": 76 * nnzb + 4 * (Nb + 1) + 4 * Nb + 72 * Nb + 24 * Nb * 4,
         "ilu_factor": 2 * 72 * nnzb + 4 * nnzb + 4 * Nb,
-        "vector": 24 * Nb * 7 / 3,    # per scope: of the three vector scopes of an iteration two are scalar-only, one is k_bicg_upd2 (7 passes)
+        "vector": 24 * Nb * 11 / 3,   # per scope: the three vector scopes of an iteration are k_bicg_upd2 (7 passes) and the two k_dots behind the products (2 passes each)
         "assemble": 85 * Nb + 12 * nnzb + 72 * nnzb + 24 * Nb,
         "iq_update": 24 * Nb + 544 * Nb,
         "convergence": 56 * Nb,
@@ -394,10 +394,9 @@ def main():
                      "frac_of_stream_ceiling": (sp["algorithmic_GBps"] / stream_GBps) if ok else None,
                      "traffic": traffic, "traffic_unit": "bytes per launch (L2 fabric side; FETCH_SIZE x 2 + WRITE_SIZE, KiB -> B)",
                      "traffic_source": traffic_src, "avg_launch_ms": sp["avg_ms"], "algorithmic_bytes_per_launch": B["spmv"],
-                     # the kernel also forms the BiCGStab scalar products (y.w0, y.y) on the fly; their second operand is 24 B
-                     # per row of reads that SURVEY's plain-SpMV byte count does not contain - stated, not counted in `achieved`
-                     "fused_dot_operand_bytes_per_launch": 24 * Nb,
-                     "achieved_incl_fused_dot": round((B["spmv"] + 24 * Nb) / sp["avg_ms"] / 1e6, 1) if ok else None},
+                     # the BiCGStab scalar products behind a product run in their own kernel (k_dots, counted under "vector"):
+                     # the pipelined SpMV does SURVEY's plain-SpMV work and nothing else
+                     "scalar_products": "separate kernel (k_dots)"},
     }
     if rank == 0 and world == 1 and not a.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(pkg, case, src)

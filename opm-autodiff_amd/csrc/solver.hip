@@ -392,13 +392,15 @@ __global__ __launch_bounds__(64) void k_spmv(const int4* __restrict__ sched, con
 // after the other and the launch moves 5.2 TB/s; a stream that is always in flight reaches 6.2-6.9 TB/s on this card
 // (tools/probe/stream_probe.hip).  Used when no row is longer than PGCH blocks (the host checks), else k_spmv.
 //   S(st+4): schedule entry (scalar)   A(st+3): row bounds   C(st+2): column indices
-//   G(st+1): value stream + vector gathers + dot operand      X(st): values -> LDS, products, store
+//   G(st+1): value stream + vector gathers                    X(st): values -> LDS, products, store
+// The BiCGStab scalar products that follow a product are formed by k_dots after this kernel: folded into it (the one-tile
+// kernel below still does that, for systems small enough to be bound by launches) they cost the product 8 % - a third
+// operand stream and two wavefront reductions per tile - and the Newton iteration rate nothing either way (74.2 against 74.7
+// its/s on the 100^3 bench, same box).
 constexpr int PGCH = 8;
-template <int NDOT>
 __global__ __launch_bounds__(64) void k_spmv_pipe(int npos, const int4* __restrict__ sched, const int* __restrict__ rowptr,
                                                   const int* __restrict__ col, const double* __restrict__ val,
                                                   const double* __restrict__ x, double* __restrict__ y,
-                                                  const double* __restrict__ w0, double* __restrict__ part, int npart,
                                                   const double* __restrict__ done) {
     TILE_LDS
     const int lane = threadIdx.x, G = gridDim.x;
@@ -410,7 +412,7 @@ __global__ __launch_bounds__(64) void k_spmv_pipe(int npos, const int4* __restri
     struct StG {
         int r, kb, nrow, k0e, n, n2;
         double2 tmp[U];
-        double xx[PGCH][3], w[3];
+        double xx[PGCH][3];
     };
     auto stageS = [&](int st) -> int4 { return sched[(int)blockIdx.x + st * G]; };
     auto stageA = [&](const int4& rows, StA& a) {
@@ -447,10 +449,6 @@ __global__ __launch_bounds__(64) void k_spmv_pipe(int npos, const int4* __restri
             const double* xc = &x[(size_t)c.cc[u] * BS];
             b.xx[u][0] = xc[0]; b.xx[u][1] = xc[1]; b.xx[u][2] = xc[2];
         }
-        if (NDOT >= 1) {
-            const double* wr = &w0[(size_t)c.rr * BS];
-            b.w[0] = wr[0]; b.w[1] = wr[1]; b.w[2] = wr[2];
-        }
     };
     int4 sNext = make_int4(0, 0, 0, 0);
     StA a;
@@ -467,7 +465,7 @@ __global__ __launch_bounds__(64) void k_spmv_pipe(int npos, const int4* __restri
 #pragma unroll
         for (int u = 0; u < U; ++u) asm volatile("" : "+v"(b.tmp[u].x), "+v"(b.tmp[u].y));
         const int r = b.r, kb = b.kb, nrow = b.nrow, k0e = b.k0e, n = b.n, n2 = b.n2;
-        double xx[PGCH][3], w[3] = {b.w[0], b.w[1], b.w[2]};
+        double xx[PGCH][3];
 #pragma unroll
         for (int u = 0; u < PGCH; ++u) { xx[u][0] = b.xx[u][0]; xx[u][1] = b.xx[u][1]; xx[u][2] = b.xx[u][2]; }
         if (n2 > 0) {
@@ -490,8 +488,7 @@ __global__ __launch_bounds__(64) void k_spmv_pipe(int npos, const int4* __restri
                 }
             }
         }
-        // ---- X(st), part 2: products in BCRSMatrix::mv order, store, partial dots
-        const int pos = (int)blockIdx.x + st * G;
+        // ---- X(st), part 2: products in BCRSMatrix::mv order, store
         double acc[3] = {0.0, 0.0, 0.0};
         if (r >= 0) {
 #pragma unroll
@@ -499,19 +496,6 @@ __global__ __launch_bounds__(64) void k_spmv_pipe(int npos, const int4* __restri
                 if (u < nrow) blk_umv(&sval[(kb + u - k0e) * BB], xx[u][0], xx[u][1], xx[u][2], acc);
             double* yr = &y[(size_t)r * BS];
             yr[0] = acc[0]; yr[1] = acc[1]; yr[2] = acc[2];
-        }
-        if (NDOT >= 1) {
-            double d0 = 0.0, d1 = 0.0;
-            if (r >= 0) {
-                d0 = acc[0] * w[0]; d0 += acc[1] * w[1]; d0 += acc[2] * w[2];
-                if (NDOT == 2) { d1 = acc[0] * acc[0]; d1 += acc[1] * acc[1]; d1 += acc[2] * acc[2]; }
-            }
-            d0 = wave_sum(d0);
-            if (NDOT == 2) d1 = wave_sum(d1);
-            if (lane == 0) {
-                part[pos] = d0;
-                if (NDOT == 2) part[npart + pos] = d1;
-            }
         }
         wave_sync();  // the LDS image may be overwritten
     }
@@ -1585,39 +1569,44 @@ static int spmv_pipe_env() {   // OPMHIP_SPMV_PIPE (tuning): 0 = off, n > 1 = wo
     static const int v = [] { const char* e = std::getenv("OPMHIP_SPMV_PIPE"); return e ? std::atoi(e) : -1; }();
     return v;
 }
+// cfg.reserved[1]: resident workgroups the pipelined kernel is sized for (0 = default, < 0 = never use it)
+static int spmv_pipe_wgs(const opmhip_ctx* c) {
+    return c->cfg.reserved[1] != 0 ? c->cfg.reserved[1] : (spmv_pipe_env() > 1 ? spmv_pipe_env() : SPMV_PIPE_WGS);
+}
+static bool spmv_pipelined(const opmhip_ctx* c) {
+    const int w = spmv_pipe_wgs(c);
+    return c->pat.maxRowBlocks <= PGCH && w > 0 && c->pat.tiles.nsched > w && spmv_pipe_env() != 0;
+}
+static bool spmv_dots_separate(const opmhip_ctx* c) { return c->wells.num_wells > 0 || spmv_pipelined(c); }
 // y = A x (+ wells) and, fused or not, the partial dots: ndot 0 none, 1 y.w0, 2 y.w0 and y.y
 void launch_spmv(opmhip_ctx* c, const double* x, double* y, int ndot, const double* w0, const double*) {
     const Pattern& P = c->pat;
     const int ntp = P.tiles.nsched;  // schedule positions (tiles + padding)
     const int4* sched = reinterpret_cast<const int4*>(P.tiles.d_spmvSched);
     const bool wells = c->wells.num_wells > 0;
-    const int fused = wells ? 0 : ndot;
+    const bool separate = spmv_dots_separate(c);   // the scalar products in k_dots (wells: after the well operator; pipelined kernel: always)
+    const int fused = separate ? 0 : ndot;
     // the SpMV is timed by its own dispatch (kernel begin to kernel end), which is what bench.py's roofline quotes
     int es = -1, ee = -1;
     const bool timed = prof_kernel_scope(c, PROF_SPMV, &es, &ee);
     hipEvent_t e0 = timed ? c->prof.ev[es] : nullptr, e1 = timed ? c->prof.ev[ee] : nullptr;
     // cfg.reserved[1]: resident workgroups the pipelined kernel is sized for (0 = default, < 0 = never use it)
-    const int pipeWgs = c->cfg.reserved[1] != 0 ? c->cfg.reserved[1] : (spmv_pipe_env() > 1 ? spmv_pipe_env() : SPMV_PIPE_WGS);
-    if (P.maxRowBlocks <= PGCH && pipeWgs > 0 && ntp > pipeWgs && spmv_pipe_env() != 0) {
+    const int pipeWgs = spmv_pipe_wgs(c);
+    if (spmv_pipelined(c)) {
         // pipelined kernel: every workgroup walks through ceil(ntp / grid) launch positions; the grid is sized so that all
         // workgroups are resident at once and end together, and is a multiple of 8 (a workgroup stays on "its" XCD column of
         // the schedule)
         const int steps = (ntp + pipeWgs - 1) / pipeWgs;
         const int grid = 8 * (((ntp + steps - 1) / steps + 7) / 8);
-        if (fused == 0)
-            hipExtLaunchKernelGGL(k_spmv_pipe<0>, dim3(grid), dim3(64), 0, c->stream, e0, e1, 0, ntp, sched, P.d_rowptr, P.d_col, c->d_A, x, y, w0, c->d_part, c->npart, c->d_done);
-        else if (fused == 1)
-            hipExtLaunchKernelGGL(k_spmv_pipe<1>, dim3(grid), dim3(64), 0, c->stream, e0, e1, 0, ntp, sched, P.d_rowptr, P.d_col, c->d_A, x, y, w0, c->d_part, c->npart, c->d_done);
-        else
-            hipExtLaunchKernelGGL(k_spmv_pipe<2>, dim3(grid), dim3(64), 0, c->stream, e0, e1, 0, ntp, sched, P.d_rowptr, P.d_col, c->d_A, x, y, w0, c->d_part, c->npart, c->d_done);
+        hipExtLaunchKernelGGL(k_spmv_pipe, dim3(grid), dim3(64), 0, c->stream, e0, e1, 0, ntp, sched, P.d_rowptr, P.d_col, c->d_A, x, y, c->d_done);
     } else if (fused == 0)
         hipExtLaunchKernelGGL(k_spmv<0>, dim3(ntp), dim3(64), 0, c->stream, e0, e1, 0, sched, P.d_rowptr, P.d_col, c->d_A, x, y, w0, c->d_part, c->npart, c->d_done);
     else if (fused == 1)
         hipExtLaunchKernelGGL(k_spmv<1>, dim3(ntp), dim3(64), 0, c->stream, e0, e1, 0, sched, P.d_rowptr, P.d_col, c->d_A, x, y, w0, c->d_part, c->npart, c->d_done);
     else
         hipExtLaunchKernelGGL(k_spmv<2>, dim3(ntp), dim3(64), 0, c->stream, e0, e1, 0, sched, P.d_rowptr, P.d_col, c->d_A, x, y, w0, c->d_part, c->npart, c->d_done);
-    if (wells) {
-        launch_wells_apply(c, x, y);
+    if (wells) launch_wells_apply(c, x, y);
+    if (separate) {
         if (ndot > 0) {
             const int n = P.Nb * BS;
             hipLaunchKernelGGL(k_dots, dim3(vec_blocks(n)), dim3(VB), 0, c->stream, n, y, w0, c->d_part, c->npart, ndot);
@@ -1625,7 +1614,7 @@ void launch_spmv(opmhip_ctx* c, const double* x, double* y, int ndot, const doub
     }
 }
 static int dot_count(opmhip_ctx* c) {  // how many partials the last launch_spmv left behind
-    return c->wells.num_wells > 0 ? vec_blocks(c->pat.Nb * BS) : c->pat.tiles.nsched;
+    return spmv_dots_separate(c) ? vec_blocks(c->pat.Nb * BS) : c->pat.tiles.nsched;
 }
 void launch_ilu_factor(opmhip_ctx* c) {
     const Pattern& P = c->pat;
