@@ -1372,9 +1372,12 @@ __global__ __launch_bounds__(VB) void k_dots(int n, const double* __restrict__ a
 #endif
 constexpr int RED1_BLOCKS = OPMHIP_RED1_BLOCKS;
 #ifndef OPMHIP_RED1_SINGLE_MAX
-#define OPMHIP_RED1_SINGLE_MAX 512
+#define OPMHIP_RED1_SINGLE_MAX 1536
 #endif
-constexpr int RED1_SINGLE_MAX = OPMHIP_RED1_SINGLE_MAX;  // partial lists up to this length go through one workgroup (k_finalize)
+// partial lists up to this length go through one workgroup (k_finalize): 1465 partials of a 10^6-row vector kernel take it 5 us,
+// the two-stage kernel with its ticket 7.7 (vector scopes 0.0285 -> 0.0260 ms on the bench); the 1953 chain-tile partials of
+// the fused first sweep stay on the two-stage kernel
+constexpr int RED1_SINGLE_MAX = OPMHIP_RED1_SINGLE_MAX;
 // out[0], out[1] = the two sums of the partial lists, fixed order (input of the all-reduce in decomposed runs)
 __global__ __launch_bounds__(VB) void k_local_sums(int count, const double* __restrict__ part, int npart, double* __restrict__ out) {
     __shared__ double sh[2][VB];
