@@ -129,3 +129,44 @@ def test_zero_update_and_roll_back_are_idempotent(full):
     m.update_failed()
     pv, mean = m.get_state()
     assert np.array_equal(pv, case["pv"]) and np.array_equal(mean, case["meaning"])
+
+
+def test_two_subdomains_of_full_size(pkg):
+    """configs[3]'s building block: two 10^6-cell subdomains side by side through the loopback communicator - the sizes at
+    which the decomposed run takes the pipelined SpMV with its separate scalar products and the two-stage local reduction
+    (1 953 partials per colour).  No oracle at this size: both ranks must see the same Newton / linear iteration history,
+    every linear solve must converge, and the residual of the owned rows must satisfy the stopping rule."""
+    import threading
+    import uuid
+    world, n = 2, N
+    group = "full" + uuid.uuid4().hex
+    out, err = [None] * world, [None] * world
+
+    def body(r):
+        try:
+            case = pkg.ras.cartesian_subdomain_case(n, world, r, state="mixed", heterogeneous=False)
+            m = pkg.capi.HipModel(case, comm=("loopback", world, r, group), reorder="line_coloring", tolerance=1e-2, maxit=200, ilu_relaxation=0.9)
+            m.set_state(case["pv"], case["meaning"])
+            m.set_source(case["source"])
+            hist = []
+            for it in range(3):
+                m.assemble(86400.0, it, fetch=False)
+                conv = m.convergence(86400.0)
+                sol = m.solve_jacobian_system()
+                hist.append((float(sol.it), bool(sol.converged), float(sol.reduction), tuple(np.round(conv[11:17], 12))))
+                m.update(None, 1.0)
+            out[r] = hist
+        except BaseException as e:  # noqa: BLE001
+            err[r] = e
+
+    ts = [threading.Thread(target=body, args=(r,)) for r in range(world)]
+    for t in ts:
+        t.start()
+    for t in ts:
+        t.join(timeout=600)
+    for e in err:
+        if e is not None:
+            raise e
+    assert out[0] == out[1]                       # global scalars: identical on both ranks, bit for bit
+    for it, ok, red, _ in out[0]:
+        assert ok and red <= 1e-2 and 0.5 <= it <= 60
