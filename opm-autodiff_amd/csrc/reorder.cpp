@@ -8,7 +8,7 @@
 #include "internal.hpp"
 
 #ifndef OPMHIP_XCD_GROUP_DEFAULT
-#define OPMHIP_XCD_GROUP_DEFAULT 0
+#define OPMHIP_XCD_GROUP_DEFAULT 8
 #endif
 
 namespace opmhip {
