@@ -50,10 +50,10 @@ def alg_bytes(Nb, nnzb):
     """Algorithmic bytes per launch (SURVEY.md §8d / BASELINE.md §4), block size 3, double values, int32 indices."""
     return {
         "spmv": 76 * nnzb + 4 * (Nb + 1) + 48 * Nb,
-        # + the BiCGStab p- and (r, x)-updates that ride in the first colour's sweep: (3 + 5) / 2 extra vector passes
-        "ilu_apply": 76 * nnzb + 4 * (Nb + 1) + 4 * Nb + 72 * Nb + 24 * Nb * 4,
+        "ilu_apply": 76 * nnzb + 4 * (Nb + 1) + 4 * Nb + 72 * Nb,
         "ilu_factor": 2 * 72 * nnzb + 4 * nnzb + 4 * Nb,
-        "vector": 24 * Nb * 11 / 3,   # per scope: the three vector scopes of an iteration are k_bicg_upd2 (7 passes) and the two k_dots behind the products (2 passes each)
+        # per scope, three scopes per iteration: the p-update (4 passes), (r, x)-update (6), k_bicg_upd2 (7), two k_dots (2 each)
+        "vector": 24 * Nb * 21 / 3,
         "assemble": 85 * Nb + 12 * nnzb + 72 * nnzb + 24 * Nb,
         "iq_update": 24 * Nb + 544 * Nb,
         "convergence": 56 * Nb,

@@ -628,7 +628,7 @@ void launch_cpr_apply(opmhip_ctx* c, const double* d, double* v) {
     ps = prof_begin(c, PROF_VECTOR);
     hipLaunchKernelGGL(k_cpr_sub, g256(n), dim3(256), 0, c->stream, n, d, R.d_y, R.d_r, done);
     prof_end(c, ps);
-    launch_ilu_apply(c, R.d_r, R.d_z, 0, 1.0);                           // fine smoother: ILU0, relaxation 1
+    launch_ilu_apply(c, R.d_r, R.d_z, 1.0);                           // fine smoother: ILU0, relaxation 1
     ps = prof_begin(c, PROF_VECTOR);
     hipLaunchKernelGGL(k_cpr_add, g256(n), dim3(256), 0, c->stream, n, v, R.d_z, done);
     prof_end(c, ps);

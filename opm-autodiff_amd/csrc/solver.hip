@@ -9,7 +9,7 @@
 // distinct bank pairs - conflict free.  Built with -ffp-contract=off: a*b+c is never fused, so the factors and
 // sweeps are bit-identical to the CPU restatement in the same ordering.
 // Line-coloured orderings add the chain kernels (heavy: LDS-staged, software-pipelined over the steps of a chain tile;
-// light: lane-private recurrences, optionally fused with the BiCGStab vector updates); the BiCGStab driver keeps the
+// light: lane-private recurrences); the BiCGStab driver keeps the
 // stopping rule on the device and runs the host one half iteration ahead of it.
 #include <hip/hip_runtime.h>
 #include <hip/hip_ext.h>
@@ -853,138 +853,6 @@ __device__ __forceinline__ void chain_sweep_light(const int nsteps, const int la
         }
     }
 }
-// The first colour's light forward sweep fused with the BiCGStab vector update that produces its input, for ALL owned
-// rows: lanes 0..31 walk the chain rows (update the vector entry, then the recurrence), lanes 32..63 - idle in the plain
-// light sweep - apply the same update to an equal share of the rows of the other colours, 32 per step.
-//   DM_PUPD: dvec = p <- (p - omega v) beta + r                         (k_bicg_pupdate)
-//   DM_UPD1: dvec = r <- r - alpha v ; x += alpha pw ; part[cl] = sum r.r over this workgroup's rows   (k_bicg_upd1)
-// The later colours then read dvec as it stands.  Same expressions as the stand-alone kernels: bit-identical vectors.
-enum { DM_PUPD = 1, DM_UPD1 = 2 };
-template <int DM>
-__global__ __launch_bounds__(64) void k_ilu_sweep_light_fused(const int* __restrict__ desc, int dstride, int S1, int nct,
-                                                              const int* __restrict__ prow,
-                                                              const int* __restrict__ pcol, const double* __restrict__ P,
-                                                              double* dvec, double* vu, const double* __restrict__ scal,
-                                                              const double* __restrict__ vvec, const double* __restrict__ wvec,
-                                                              double* xvec, int f0, int f1, double* __restrict__ part) {
-    constexpr int D = LIGHT_DEPTH;
-    __shared__ int sdesc[DESC_MAX];
-    const int lane = threadIdx.x, cl = blockIdx.x;  // launch position; nct = positions of this colour's schedule
-    if (scal[SC_DONE] != 0.0) return;
-    const double alpha = scal[SC_ALPHA], omega = scal[SC_OMEGA], beta = scal[SC_BETA];
-    const int nsteps = load_desc(desc, dstride, lane, sdesc);  // 0: padding of the schedule - no chain rows, but still its share of the other rows
-    const int* srow0 = sdesc + DESC_HEAD;
-    (void)S1;
-    const bool chainLane = lane < TILE_ROWS;
-    const int per = (int)(((long long)(f1 - f0) + nct - 1) / nct);
-    const int fb = f0 + (int)min((long long)(f1 - f0), (long long)cl * per), fe = min(f1, fb + per);  // this workgroup's foreign rows
-    struct StA { int rr, kb, ke; bool active; };
-    struct StB {
-        int r;
-        bool has;
-        double blk[BB], dv[3], vv[3], wv[3], xv[3];
-    };
-    auto stageA = [&](int st, StA& a) {
-        const int r0 = srow0[st], r1 = srow0[st + 1];
-        const int fr = fb + st * TILE_ROWS + (lane - TILE_ROWS);
-        const bool act = chainLane ? (r0 + lane < r1) : (fr < fe);
-        // inactive lanes load from some valid row and discard it
-        const int rr = chainLane ? (act ? r0 + lane : r1 - 1) : (act ? fr : (fe > fb ? fe - 1 : r0));
-        const int rp = chainLane ? rr : r0;  // foreign lanes have no factor entry: kb == ke below
-        const int kb = prow[rp], ke = prow[rp + 1];
-        a.active = act;
-        a.rr = rr;
-        a.kb = kb;
-        a.ke = chainLane ? ke : kb;
-    };
-    auto load_vec = [&](int rr, StB& b) {
-        const size_t o = (size_t)rr * BS;
-        b.dv[0] = dvec[o]; b.dv[1] = dvec[o + 1]; b.dv[2] = dvec[o + 2];
-        b.vv[0] = vvec[o]; b.vv[1] = vvec[o + 1]; b.vv[2] = vvec[o + 2];
-        b.wv[0] = wvec[o]; b.wv[1] = wvec[o + 1]; b.wv[2] = wvec[o + 2];
-        if (DM == DM_UPD1) { b.xv[0] = xvec[o]; b.xv[1] = xvec[o + 1]; b.xv[2] = xvec[o + 2]; }
-    };
-    auto stageB = [&](const StA& a, StB& b) {
-        b.r = a.active ? a.rr : -1;
-        b.has = chainLane && a.active && a.ke > a.kb;
-        if (chainLane) {
-            const int k = b.has ? a.kb : 0;
-#pragma unroll
-            for (int q = 0; q < BB; ++q) b.blk[q] = P[(size_t)k * BB + q];
-        }
-        load_vec(a.rr, b);
-    };
-    double ssum = 0.0;
-    // the vector update of one row; returns the new dvec entry
-    struct V3 { double x, y, z; };
-    auto update_row = [&](int r, const StB& b) -> V3 {
-        const size_t o = (size_t)r * BS;
-        double out[3];
-        if (DM == DM_PUPD) {
-#pragma unroll
-            for (int q = 0; q < 3; ++q) out[q] = (b.dv[q] - omega * b.vv[q]) * beta + b.wv[q];
-        } else {
-#pragma unroll
-            for (int q = 0; q < 3; ++q) {
-                out[q] = b.dv[q] - alpha * b.vv[q];
-                xvec[o + q] = b.xv[q] + alpha * b.wv[q];
-                ssum += out[q] * out[q];
-            }
-        }
-        dvec[o] = out[0]; dvec[o + 1] = out[1]; dvec[o + 2] = out[2];
-        return V3{out[0], out[1], out[2]};
-    };
-    StA aa[D + 1];
-    StB b[D];
-#pragma unroll
-    for (int u = 0; u <= D; ++u)
-        if (u < nsteps) stageA(u, aa[u]);
-#pragma unroll
-    for (int u = 0; u < D; ++u)
-        if (u < nsteps) stageB(aa[u], b[u]);
-    StA a = aa[D];
-    double prev[3] = {0.0, 0.0, 0.0};
-    for (int s0 = 0; s0 < nsteps; s0 += D) {
-#pragma unroll
-        for (int u = 0; u < D; ++u) {
-            const int st = s0 + u;
-            if (st < nsteps) {
-                StB& c = b[u];
-                if (c.r >= 0) {
-                    const V3 nd = update_row(c.r, c);
-                    double rhs[3] = {nd.x, nd.y, nd.z};
-                    if (chainLane) {
-                        if (c.has) blk_mmv(c.blk, prev[0], prev[1], prev[2], rhs);
-                        vu[(size_t)c.r * BS] = rhs[0]; vu[(size_t)c.r * BS + 1] = rhs[1]; vu[(size_t)c.r * BS + 2] = rhs[2];
-                        prev[0] = rhs[0]; prev[1] = rhs[1]; prev[2] = rhs[2];
-                    }
-                }
-                if (st + D < nsteps) {
-                    stageB(a, c);
-                    if (st + D + 1 < nsteps) stageA(st + D + 1, a);
-                }
-            }
-        }
-    }
-    // foreign rows beyond 32 per step (short chain tiles): all 64 lanes, plain loop
-    for (int fr = fb + nsteps * TILE_ROWS + lane; fr < fe; fr += 64) {
-        const size_t o = (size_t)fr * BS;
-#pragma unroll
-        for (int q = 0; q < 3; ++q) {
-            if (DM == DM_PUPD) dvec[o + q] = (dvec[o + q] - omega * vvec[o + q]) * beta + wvec[o + q];
-            else {
-                const double re = dvec[o + q] - alpha * vvec[o + q];
-                xvec[o + q] = xvec[o + q] + alpha * wvec[o + q];
-                ssum += re * re;
-                dvec[o + q] = re;
-            }
-        }
-    }
-    if (DM == DM_UPD1) {
-        ssum = wave_sum(ssum);
-        if (lane == 0) part[cl] = ssum;
-    }
-}
 template <int SHAPE>
 __global__ __launch_bounds__(64) void k_ilu_sweep_light(const int* __restrict__ desc, int dstride, int S1,
                                                         const int* __restrict__ prow,
@@ -1376,7 +1244,7 @@ constexpr int RED1_BLOCKS = OPMHIP_RED1_BLOCKS;
 #endif
 // partial lists up to this length go through one workgroup (k_finalize): 1465 partials of a 10^6-row vector kernel take it 5 us,
 // the two-stage kernel with its ticket 7.7 (vector scopes 0.0285 -> 0.0260 ms on the bench); the 1953 chain-tile partials of
-// the fused first sweep stay on the two-stage kernel
+// of longer lists stay on the two-stage kernel
 constexpr int RED1_SINGLE_MAX = OPMHIP_RED1_SINGLE_MAX;
 // out[0], out[1] = the two sums of the partial lists, fixed order (input of the all-reduce in decomposed runs)
 __global__ __launch_bounds__(VB) void k_local_sums(int count, const double* __restrict__ part, int npart, double* __restrict__ out) {
@@ -1630,13 +1498,7 @@ void launch_ilu_factor(opmhip_ctx* c) {
     }
     prof_end(c, ps);
 }
-// fuse = DM_PUPD / DM_UPD1: the first colour's sweep also performs that BiCGStab vector update on every owned row (d is
-// then read AND written: p or r); only where ilu_can_fuse() holds
-static bool ilu_can_fuse(const opmhip_ctx* c) {
-    const Pattern& P = c->pat;
-    return P.chained && P.numColors >= 2 && P.lightL[0] && P.tiles.colorCT[1] > P.tiles.colorCT[0];
-}
-void launch_ilu_apply(opmhip_ctx* c, const double* d, double* v, int fuse, double w_override) {
+void launch_ilu_apply(opmhip_ctx* c, const double* d, double* v, double w_override) {
     const Pattern& P = c->pat;
     const int ps = prof_begin(c, PROF_ILU_APPLY);
     const int C = P.numColors, mode = c->cfg.relax_mode;
@@ -1653,13 +1515,7 @@ void launch_ilu_apply(opmhip_ctx* c, const double* d, double* v, int fuse, doubl
         for (int col = 0; col < C - 1; ++col) {
             const int nct = npos(col);
             if (nct <= 0) continue;
-            if (col == 0 && fuse == DM_PUPD)
-                hipLaunchKernelGGL(k_ilu_sweep_light_fused<DM_PUPD>, dim3(nct), dim3(64), 0, c->stream, desc(col), ds, S1, nct, P.d_lrowptr,
-                                   P.d_lcol, c->d_L, const_cast<double*>(d), vu, c->d_scal, c->d_v, c->d_r, (double*)nullptr, P.colorPrefix[1], P.Nb, c->d_part);
-            else if (col == 0 && fuse == DM_UPD1)
-                hipLaunchKernelGGL(k_ilu_sweep_light_fused<DM_UPD1>, dim3(nct), dim3(64), 0, c->stream, desc(col), ds, S1, nct, P.d_lrowptr,
-                                   P.d_lcol, c->d_L, const_cast<double*>(d), vu, c->d_scal, c->d_v, c->d_pw, c->d_x, P.colorPrefix[1], P.Nb, c->d_part);
-            else if (P.lightL[col])
+            if (P.lightL[col])
                 hipLaunchKernelGGL(k_ilu_sweep_light<SW_L>, dim3(nct), dim3(64), 0, c->stream, desc(col), ds, S1, P.d_lrowptr,
                                    P.d_lcol, c->d_L, c->d_invD, d, vu, v, mode, w, c->d_done);
             else
@@ -1768,37 +1624,29 @@ static int read_scalars(opmhip_ctx* c) {
 static int enqueue_half(opmhip_ctx* c, int h) {
     const Pattern& P = c->pat;
     const int n = P.Nb * BS, nb = vec_blocks(n);
-    // Line colouring with a light first colour: the p-update and the (r, x)-update ride in the first colour's sweep of
-    // the preconditioner application that follows them (k_ilu_sweep_light_fused).  The stopping rule of a first half is
-    // then evaluated after that application: half h reports for half h - 1.
+    // The p-update and the (r, x)-update are kernels of their own: riding in the first colour's light sweep of the
+    // preconditioner application that follows them (round 1) they made that sweep 0.017 ms longer and the vector scopes as
+    // much shorter - the same Newton iteration rate (76.5 / 78.1 against 78.0 / 76.3 its/s on one box).
     const bool cpr = use_cpr(c);
-    const bool fused = ilu_can_fuse(c) && !cpr;   // CPR starts with the pressure restriction: nothing to ride in a first sweep
     int rc, ps;
     if ((h & 1) == 0) {  // first half: p, y = M^-1 p, v = A y, alpha, x += alpha y, r -= alpha v, |r|
-        if (h > 0 && !fused) {
+        if (h > 0) {
             ps = prof_begin(c, PROF_VECTOR);
             hipLaunchKernelGGL(k_bicg_pupdate, dim3(nb), dim3(VB), 0, c->stream, n, c->d_scal, c->d_p, c->d_v, c->d_r);
             prof_end(c, ps);
         }
         if (cpr) launch_cpr_apply(c, c->d_p, c->d_pw);
-        else launch_ilu_apply(c, c->d_p, c->d_pw, (h > 0 && fused) ? DM_PUPD : 0);
+        else launch_ilu_apply(c, c->d_p, c->d_pw);
         if ((rc = comm_halo_f64(c, c->d_pw, BS))) return rc;  // copyOwnerToAll before the operator (ParallelOverlappingILU0.hpp:897)
         launch_spmv(c, c->d_pw, c->d_v, 1, c->d_rw, nullptr);
         ps = prof_begin(c, PROF_VECTOR);
         if ((rc = finalize(c, FIN_ALPHA, dot_count(c)))) return rc;
-        if (!fused) {
-            hipLaunchKernelGGL(k_bicg_upd1, dim3(nb), dim3(VB), 0, c->stream, n, c->d_scal, c->d_r, c->d_v, c->d_x, c->d_pw, c->d_part, c->npart);
-            if ((rc = finalize(c, FIN_NORM, nb, h))) return rc;
-        }
+        hipLaunchKernelGGL(k_bicg_upd1, dim3(nb), dim3(VB), 0, c->stream, n, c->d_scal, c->d_r, c->d_v, c->d_x, c->d_pw, c->d_part, c->npart);
+        if ((rc = finalize(c, FIN_NORM, nb, h))) return rc;
         prof_end(c, ps);
     } else {             // second half: z = M^-1 r, t = A z, omega, x += omega z, r -= omega t, |r|, rho, beta
         if (cpr) launch_cpr_apply(c, c->d_r, c->d_s);
-        else launch_ilu_apply(c, c->d_r, c->d_s, fused ? DM_UPD1 : 0);
-        if (fused) {
-            ps = prof_begin(c, PROF_VECTOR);
-            if ((rc = finalize(c, FIN_NORM, P.tiles.ctSchedOff[1] - P.tiles.ctSchedOff[0], h - 1))) return rc;
-            prof_end(c, ps);
-        }
+        else launch_ilu_apply(c, c->d_r, c->d_s);
         if ((rc = comm_halo_f64(c, c->d_s, BS))) return rc;
         launch_spmv(c, c->d_s, c->d_t, 2, c->d_r, nullptr);
         ps = prof_begin(c, PROF_VECTOR);
