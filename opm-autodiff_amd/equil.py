@@ -230,7 +230,7 @@ def sat_from_sum_of_pcs(pcow_of_sw, pcgo_of_sg, swl, swu, target):
 
 
 def equilibrate_regions(eqlnum, records, props, rho_ref, cell_depth, cell_zmin, cell_zmax, sat_limits, grav=9.80665,
-                        rs_funcs=None, rv_funcs=None, nsample=NSAMPLE):
+                        rs_funcs=None, rv_funcs=None, nsample=NSAMPLE, swatinit=None):
     """InitialStateComputer::calcPressSatRsRv (initstateequil.hh:1882-1940): every equilibration region (EQLNUM, 0-based)
     with its own EQUIL record over the vertical extent of ITS cells.  props / rho_ref / sat_limits / rs_funcs / rv_funcs: one
     per region (list) or one for all.  -> the dict of `equilibrate`, arrays over all cells (zeros where no region applies)"""
@@ -239,6 +239,9 @@ def equilibrate_regions(eqlnum, records, props, rho_ref, cell_depth, cell_zmin, 
     cell_depth, cell_zmin, cell_zmax = (np.asarray(a, float) for a in (cell_depth, cell_zmin, cell_zmax))
     per = lambda x, r: x[r] if isinstance(x, list) else x   # a list: one per region
     out = {k: np.zeros(n) for k in ("pw", "po", "pg", "sw", "so", "sg", "rs", "rv")}
+    if swatinit is not None:
+        swatinit = np.asarray(swatinit, float)
+        out["pcw_scale"] = np.ones(n)
     for r, rec in enumerate(records):
         cells = np.nonzero(eqlnum == r)[0]
         if len(cells) == 0:
@@ -249,18 +252,25 @@ def equilibrate_regions(eqlnum, records, props, rho_ref, cell_depth, cell_zmin, 
         rs_f = rs_funcs[r] if rs_funcs is not None else None
         rv_f = rv_funcs[r] if rv_funcs is not None else None
         res = equilibrate(per(props, r), per(rho_ref, r), rec, cell_depth[cells], span, per(sat_limits, r), grav=grav,
-                          rs_func=rs_f, nsample=nsample, rv_func=rv_f)
+                          rs_func=rs_f, nsample=nsample, rv_func=rv_f, swatinit=None if swatinit is None else swatinit[cells])
         for k in out:
             out[k][cells] = res[k]
     return out
 
 
-def equilibrate(props, rho_ref, rec, cell_depth, z_span, sat_limits, grav=9.80665, rs_func=None, nsample=NSAMPLE, rv_func=None):
+def equilibrate(props, rho_ref, rec, cell_depth, z_span, sat_limits, grav=9.80665, rs_func=None, nsample=NSAMPLE, rv_func=None,
+                swatinit=None):
     """props.probe(p, rs, sw, sg) -> (n, 8) (capi.HipFluid layout); rho_ref = (oil, water, gas) surface densities;
     rec = dict(datum, pressure, zwoc, pcow_woc, zgoc, pcgo_goc); cell_depth[]: centre depths; z_span = (top, bottom) of the
     region's cells; sat_limits = dict(Swl, Swu, Sgl, Sgu) (unscaled end points of the saturation tables).
     rv_func (wet gas, VAPOIL): Rv(depth, p_g, sat_oil) - RvSatAtContact / RvVD / PDVD; props then also needs
     probe_gas(p, rv) -> (n, 3): 1/B_g(p, rv), mu_g, RvSat(p).
+    swatinit (SWATINIT, per cell): the water saturation is imposed instead of derived, and the cell's oil-water capillary
+    pressure curve is rescaled so that the imposed saturation is in equilibrium with the phase pressures
+    (deriveWaterSat initstateequil.hh:1186-1214 -> applySwatInit :1330-1343 -> EclMaterialLawManager::applySwatinit of
+    opm-material, absent here, restated from its published form: pcow < 0 -> Swu; else Sw = max(Sw, Swl) and, where
+    |pcow(Sw)| > 1 Pa, maxPcow *= pcow / pcow(Sw)).  The result then carries "pcw_scale": the factor on the cell's pcow
+    curve (scaled maxPcow / table maxPcow), to be handed to the device as PCW = pcw_scale * pcow(Swl) (opmhip_set_pcw).
     -> dict(pw, po, pg, sw, so, sg, rs, rv) arrays over the cells."""
     if rs_func is None:
         if rec["zgoc"] != rec["datum"]:
@@ -269,20 +279,38 @@ def equilibrate(props, rho_ref, rec, cell_depth, z_span, sat_limits, grav=9.8066
     wat, oil, gas = phase_pressure_tables(props, rho_ref, rec, z_span, grav, rs_func, rv_func, nsample)
 
     Swl, Swu, Sgl, Sgu = (sat_limits[k] for k in ("Swl", "Swu", "Sgl", "Sgu"))
-    pcow = lambda sw: float(props.probe(1e5, sw=sw)[0, PCOW])
+    pcow_table = lambda sw: float(props.probe(1e5, sw=sw)[0, PCOW])
     pcgo = lambda sg: float(props.probe(1e5, sg=sg)[0, PCGO])
 
     root = _root
 
     n = len(cell_depth)
     out = {k: np.zeros(n) for k in ("pw", "po", "pg", "sw", "so", "sg", "rs", "rv")}
-    const_pcow = abs(pcow(Swl) - pcow(Swu)) < np.finfo(float).eps
+    if swatinit is not None:
+        swatinit = np.asarray(swatinit, float)
+        if swatinit.shape != (n,):
+            raise ValueError("swatinit: one value per cell expected")
+        out["pcw_scale"] = np.ones(n)
+    const_pcow = abs(pcow_table(Swl) - pcow_table(Swu)) < np.finfo(float).eps
     const_pcgo = abs(pcgo(Sgl) - pcgo(Sgu)) < np.finfo(float).eps
     for c, z in enumerate(cell_depth):
         po, pg, pw = oil(z), gas(z), wat(z)
+        scale = [1.0]                                   # this cell's factor on the pcow curve (SWATINIT)
+        pcow = lambda sw: scale[0] * pcow_table(sw)
+
+        def apply_swatinit(pc, sw_in):
+            if pc < 0.0:
+                return Swu
+            sw_c = max(sw_in, Swl)
+            at_sw = pcow(sw_c)
+            if abs(at_sw) > 1.0:                        # Pascal: no division by a vanishing capillary pressure
+                scale[0] *= pc / at_sw
+            return sw_c
         # water: dPcow/dSw <= 0 ; gas: dPcgo/dSg >= 0
         if const_pcow:
             sw = Swl if z < rec["zwoc"] else Swu
+        elif swatinit is not None:
+            sw = apply_swatinit(po - pw, swatinit[c])
         else:
             sw = sat_from_pc(pcow, Swl, Swu, po - pw, increasing=False)
         if const_pcgo:
@@ -291,6 +319,8 @@ def equilibrate(props, rho_ref, rec, cell_depth, z_span, sat_limits, grav=9.8066
             sg = sat_from_pc(pcgo, Sgl, Sgu, pg - po, increasing=True)
         if sg + sw > 1.0:   # overlapping transition zones: gas-water contact, sw from the sum of both capillary pressures
             pcgw = pg - pw
+            if swatinit is not None:   # the curve is rescaled once more, for a vanishing oil phase (:1229-1235)
+                sw = apply_swatinit(pcgw, sw)
             sw = root(lambda s: pcow(s) + pcgo(1.0 - s) - pcgw, Swl, Swu)
             sg = 1.0 - sw
             po = pg - pcgo(sg)
@@ -309,4 +339,6 @@ def equilibrate(props, rho_ref, rec, cell_depth, z_span, sat_limits, grav=9.8066
         out["sw"][c], out["so"][c], out["sg"][c] = sw, so, sg
         out["rs"][c] = rs_func(z, po, sg)
         out["rv"][c] = rv_func(z, pg, so) if rv_func is not None else 0.0
+        if swatinit is not None:
+            out["pcw_scale"][c] = scale[0]
     return out

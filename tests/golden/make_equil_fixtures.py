@@ -193,6 +193,47 @@ def dead_oil_case_tables(deck, gravity):
                    zgoc=eq[4] * U["length"], pcgo_goc=eq[5] * U["pressure"], accuracy=int(eq[8] or 0)))
 
 
+def swatinit_case():
+    """equil_capillary_swatinit.DATA / DeckWithSwatinit (tests/test_equil.cc:1006-1146; the case is compiled out there with
+    `#if 0`, its numbers are still the reference's own): saturations without and with SWATINIT applied, and the oil-water
+    capillary pressure the rescaled curves must give in the twelve cells above the contact; tolerance 0.1 % (reltol 1.0e-1)"""
+    deck = "equil_capillary_swatinit.DATA"
+    k = tokenize_sections(os.path.join(REF, "tests", deck))
+    U = METRIC
+    pvtw, dens, eq, rock = k["PVTW"][0], k["DENSITY"][0], k["EQUIL"][0], k["ROCK"][0]
+    eq = [0.0 if v is None else v for v in list(eq) + [0] * (9 - len(eq))]
+    dz = [v * U["length"] for v in k["DZ"][0]]
+    with open(os.path.join(REF, "tests/test_equil.cc")) as f:
+        txt = f.read()
+    body = txt[txt.index("BOOST_AUTO_TEST_CASE(DeckWithSwatinit)"):]
+    num = r"[-+]?\d+\.?\d*(?:[eE][-+]?\d+)?"
+    rows = lambda name: [[float(t) for t in re.findall(num, row)]
+                         for row in re.findall(r"\{([^{}]*)\}", re.search(r"const std::vector<double> " + name + r"\[3\]\{(.*?)\};", body, re.S).group(1))]
+    s_plain, s_swat = rows("s"), rows("swatinit")
+    pcs = [float(v) for _, v in sorted((int(i), v) for i, v in re.findall(r"pc_scaled_truth\[3\*(\d+) \+ 0\] =\s*(" + num + r");", body))]
+    assert len(s_plain) == 3 and len(s_swat) == 3 and len(pcs) == 12
+    return dict(
+        source="tests/%s (METRIC units converted to SI); dead oil (PVDO); EQUIL item 9 = 0" % deck,
+        gravity=9.81,
+        pvtw=dict(p_ref=pvtw[0] * U["pressure"], bw_ref=pvtw[1], cw=pvtw[2] * U["compressibility"], mu_ref=pvtw[3] * U["viscosity"],
+                  cv=pvtw[4] * U["compressibility"]),
+        rock=dict(p_ref=rock[0] * U["pressure"], cr=rock[1] * U["compressibility"]),
+        density=dict(oil=dens[0] * U["density"], water=dens[1] * U["density"], gas=dens[2] * U["density"]),
+        swof=[[r[0], r[1], r[2], r[3] * U["pressure"]] for r in table(k["SWOF"][0], 4)],
+        sgof=[[r[0], r[1], r[2], r[3] * U["pressure"]] for r in table(k["SGOF"][0], 4)],
+        pvdg=[[r[0] * U["pressure"], r[1] * U["gas_fvf"], r[2] * U["viscosity"]] for r in table(k["PVDG"][0], 3)],
+        pvdo=[[r[0] * U["pressure"], r[1] * U["oil_fvf"], r[2] * U["viscosity"]] for r in table(k["PVDO"][0], 3)],
+        grid=dict(nz=len(dz), dz=dz, tops=k["TOPS"][0][0] * U["length"]),
+        swatinit=list(k["SWATINIT"][0]),
+        equil=dict(datum=eq[0] * U["length"], pressure=eq[1] * U["pressure"], zwoc=eq[2] * U["length"], pcow_woc=eq[3] * U["pressure"],
+                   zgoc=eq[4] * U["length"], pcgo_goc=eq[5] * U["pressure"], accuracy=int(eq[8] or 0)),
+        expected=dict(source="tests/test_equil.cc:1006-1146 (DeckWithSwatinit, under #if 0 in the reference)", reltol_percent=1.0e-1,
+                      phase_order="water, oil, gas",
+                      without=dict(sw=s_plain[0], so=s_plain[1], sg=s_plain[2]),
+                      with_swatinit=dict(sw=s_swat[0], so=s_swat[1], sg=s_swat[2]),
+                      pcow_scaled=pcs))
+
+
 def capillary_inversion():
     """CapillaryInversion (tests/test_equil.cc:504-554): (pc, saturation) vectors of satFromPc for oil-water and gas-oil and of
     satFromSumOfPcs, on the saturation tables of equil_capillary.DATA (fixture 'capillary')"""
@@ -230,7 +271,7 @@ if __name__ == "__main__":
                livegas=wet_gas_case("equil_livegas.DATA", "DeckWithLiveGas", "DeckWithRSVDAndRVVD", "734-812"),
                rsvd_rvvd=wet_gas_case("equil_rsvd_and_rvvd.DATA", "DeckWithRSVDAndRVVD", "DeckWithPBVDAndPDVD", "814-912"),
                pbvd_pdvd=wet_gas_case("equil_pbvd_and_pdvd.DATA", "DeckWithPBVDAndPDVD", "DeckWithSwatinit", "914-1004"),
-               alldead=all_dead_case(), capillary_inversion=capillary_inversion(), default_fluid=default_fluid_cases())
+               alldead=all_dead_case(), swatinit=swatinit_case(), capillary_inversion=capillary_inversion(), default_fluid=default_fluid_cases())
     path = os.path.join(ROOT, "tests", "golden", "equil.json")
     with open(path, "w") as f:
         json.dump(out, f, indent=1)

@@ -299,3 +299,37 @@ def test_capillary_inversion(orc):
     np.testing.assert_allclose(got, e["gas_oil"]["s"], rtol=rel, atol=1e-12)
     got = [pkg.equil.sat_from_sum_of_pcs(pcow, pcgo, swl, swu, pc) for pc in e["gas_water"]["pc"]]
     np.testing.assert_allclose(got, e["gas_water"]["s"], rtol=rel, atol=1e-12)
+
+
+def test_swatinit_deck(orc):
+    """tests/test_equil.cc DeckWithSwatinit (:1006-1146, compiled out in the reference, its numbers kept): without SWATINIT the
+    saturations of the plain capillary equilibrium; with it the imposed water saturations (clipped to Swl, and Swu where
+    p_o < p_w) and per-cell rescaled oil-water curves that return p_o - p_w at those saturations.  Tolerance 0.1 % as there."""
+    with open(os.path.join(GOLDEN, "equil.json")) as f:
+        d = json.load(f)["swatinit"]
+    dz = np.array(d["grid"]["dz"])
+    top = d["grid"]["tops"] + np.concatenate([[0.0], np.cumsum(dz)[:-1]])
+    limits = dict(Swl=d["swof"][0][0], Swu=d["swof"][-1][0], Sgl=d["sgof"][0][0], Sgu=d["sgof"][-1][0])
+    rho = (d["density"]["oil"], d["density"]["water"], d["density"]["gas"])
+    props = DeadOilProps(oracle_bind.OracleFluid(orc, dead_fluid(d)), d["pvdo"])
+    args = (props, rho, d["equil"], top + 0.5 * dz, (float(top[0]), float(top[-1] + dz[-1])), limits)
+    kw = dict(grav=d["gravity"], rs_func=lambda z, p, sat_gas=0.0: 0.0)
+    e = d["expected"]
+    rel = e["reltol_percent"] / 100.0
+    plain = pkg.equil.equilibrate(*args, **kw)
+    assert "pcw_scale" not in plain
+    for k in ("sw", "so", "sg"):
+        np.testing.assert_allclose(plain[k], e["without"][k], rtol=rel, atol=1e-12)
+    r = pkg.equil.equilibrate(*args, swatinit=d["swatinit"], **kw)
+    for k in ("sw", "so", "sg"):
+        np.testing.assert_allclose(r[k], e["with_swatinit"][k], rtol=rel, atol=1e-12)
+    # the capillary pressure of the rescaled curve at the computed saturation: pc_scaled of the reference's test
+    pcow = np.array([r["pcw_scale"][c] * float(props.probe(1e5, sw=r["sw"][c])[0, pkg.equil.PCOW]) for c in range(len(dz))])
+    np.testing.assert_allclose(pcow[:12], e["pcow_scaled"], rtol=rel)
+    # cells where p_o < p_w keep the table's curve (and its value at Swu), like pc_scaled_truth = pc_original there
+    np.testing.assert_array_equal(r["pcw_scale"][12:], 1.0)
+    np.testing.assert_allclose(pcow[12:], d["swof"][-1][3], rtol=1e-12)
+    # the gas-oil side is untouched by SWATINIT
+    np.testing.assert_array_equal(r["sg"], plain["sg"])
+    # and the rescaled state is an equilibrium: p_o - p_w equals the cell's own capillary pressure wherever water is mobile
+    np.testing.assert_allclose((r["po"] - r["pw"])[:12], pcow[:12], rtol=1e-12)
