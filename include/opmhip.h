@@ -230,6 +230,9 @@ typedef struct opmhip_fluid {
     int num_rock;
     const int* rocktab_ptr;     /* [num_rock+1] */
     const double* rocktab;
+    /* End-point scaling of the oil-water capillary pressure (EclEpsConfig::enablePcScaling: the deck has PCW or SWATINIT).
+     * Non-zero: the context keeps the extended intensive-quantity record and accepts opmhip_set_pcw. */
+    int pc_scaling;
 } opmhip_fluid;
 
 /* primary-variable meaning per cell: BlackOilPrimaryVariables::PrimaryVarsMeaning */
@@ -255,6 +258,14 @@ int opmhip_set_static(opmhip_ctx* ctx, const double* trans, const double* area, 
  * only meaningful for a fluid with PVTG or ROCKTAB tables (else INVALID_ARGUMENT).  Needs set_static; recomputes the cached
  * intensive quantities if a state is set. */
 int opmhip_set_problem_extras(opmhip_ctx* ctx, const double* rvmax, const int* rocknum, const double* overburden);
+
+/* replaces: the per-cell scaled end point maxPcow of the oil-water capillary pressure - the PCW array of the deck, or
+ * what SWATINIT made of it during equilibration (ebos/equil/initstateequil.hh:1330-1343 -> EclMaterialLawManager::
+ * applySwatinit) - as EclEpsTwoPhaseLaw applies it with enablePcScaling: pcow(Sw) = table(Sw) * (pcw / table(Swl)),
+ * the factor taken as 1 where pcw equals the table's own maximum.  (opm-material is absent from the reference tree:
+ * restated from its published form, see oracle/blackoil.hpp.)  pcw: per cell, natural order, Pa; NULL = unscaled.
+ * Needs a fluid with pc_scaling set, and set_static first. */
+int opmhip_set_pcw(opmhip_ctx* ctx, const double* pcw);
 
 /* Point evaluation of the fluid-system and saturation functions the assembly uses, ON THE DEVICE, for host-side setup
  * code (equilibration, ebos/equil/initstateequil.hh) and for tests that pin these functions against the reference's

@@ -310,6 +310,7 @@ def _bind_assembly(L):
     L.opmhip_set_cell_global_ids.argtypes = [vp, vp]
     L.opmhip_fluid_probe.argtypes = [vp, C.c_int, C.c_int, C.c_int, vp, vp, vp, vp, vp]
     L.opmhip_set_problem_extras.argtypes = [vp, vp, vp, vp]
+    L.opmhip_set_pcw.argtypes = [vp, vp]
     L.opmhip_gas_probe.argtypes = [vp, C.c_int, C.c_int, vp, vp, vp]
     L.opmhip_iq_fields.argtypes = [vp]
 
@@ -398,6 +399,14 @@ class HipModel(HipSolver):
                                         p("pvtnum"), p("satnum"), p("rsmax")))
         if any(case.get(k) is not None for k in ("rvmax", "rocknum", "overburden")):
             self.set_problem_extras(case.get("rvmax"), case.get("rocknum"), case.get("overburden"))
+        if case.get("pcw") is not None:
+            self.set_pcw(case["pcw"])
+
+    def set_pcw(self, pcw):
+        """per-cell scaled maximum of the oil-water capillary pressure (PCW, or SWATINIT through equil.equilibrate's pcw_scale
+        x the table's pcow(Swl)); None = the tables' own.  The fluid needs pc_scaling=True."""
+        a = _f64(pcw)
+        self._check(lib().opmhip_set_pcw(self._h, _ptr(a)))
 
     def set_problem_extras(self, rvmax=None, rocknum=None, overburden=None):
         """DRVDT cap on Rv, rock-table index (ROCKNUM), overburden pressure - per cell, any None"""

@@ -192,6 +192,7 @@ struct CellStatic {
     const int *pvtnum, *satnum;
     const double *rvmax, *overburden;   // extended layout: DRVDT cap, overburden pressure (may be NULL)
     const int* rocknum;                 // rock-table index per cell (NULL = table 0)
+    const double* pcw;                  // extended layout: scaled maximum of pcow per cell (PCW / SWATINIT; NULL = the tables' own)
     double* invb;                       // packed 1/b_w, 1/b_o, 1/b_g per cell, written beside the record (convergence check)
     int ncell;                          // cells of the intensive-quantity cache (owned + ghost): the stride between its fields
 };
@@ -218,6 +219,13 @@ __device__ __forceinline__ void update_iq(const TablesT<DP>& T, const CellStatic
     pC[0] = -pwlin<E, DP>(B + Sd.sw_x, B + Sd.pcow, Sd.nw, Sw);
     pC[1] = cst<E>(0.0);
     pC[2] = pwlin<E, DP>(B + Sd.so_x, B + Sd.pcgo, Sd.ng, 1.0 - Swco - Sg);
+    if (EXT && C.pcw) {
+        // end-point scaling of the oil-water curve (EclEpsTwoPhaseLaw with enablePcScaling): table value x (scaled max / table max),
+        // the table's maximum being its value at the connate saturation (first row of SWOF)
+        const double scaledMax = C.pcw[c], tableMax = B[Sd.pcow];
+        const double alpha = (scaledMax == tableMax) ? 1.0 : scaledMax / tableMax;
+        pC[0] = pC[0] * alpha;
+    }
     if (EXT && meaning == OPMHIP_SW_PG_RV) {   // the pressure primary variable is the GAS pressure
         const E pg = mk<E>(pv[1], 1);
         for (int ph = 0; ph < 3; ++ph) q.p[ph] = pg + (pC[ph] - pC[GAS]);
@@ -977,7 +985,7 @@ static Tables tables_of(const opmhip_ctx* c) {
 }
 static CellStatic cells_of(const opmhip_ctx* c) {
     return CellStatic{c->asmb.d_poro, c->asmb.d_volume, c->asmb.d_depth, c->asmb.d_rsmax, c->asmb.d_pvtnum, c->asmb.d_satnum,
-                      c->asmb.d_rvmax, c->asmb.d_overburden, c->asmb.d_rocknum, c->asmb.d_invb, c->pat.Nloc};
+                      c->asmb.d_rvmax, c->asmb.d_overburden, c->asmb.d_rocknum, c->asmb.d_pcw, c->asmb.d_invb, c->pat.Nloc};
 }
 // the context's record layout: extended when the fluid has PVTG or ROCKTAB tables
 #define OPMHIP_LAYOUT(c, call_base, call_ext) do { if ((c)->asmb.ext) { call_ext; } else { call_base; } } while (0)

@@ -1,6 +1,7 @@
 // C-ABI, assembly half (include/opmhip.h "assembly" section): fluid tables, static grid data, state, linearisation,
 // convergence norms, Newton update.  Host arrays arrive in the NATURAL cell / entry order and are permuted on upload.
 #include <algorithm>
+#include <cmath>
 #include <cstring>
 
 #include "fluid_tables.hpp"
@@ -78,7 +79,8 @@ int opmhip_set_fluid(opmhip_ctx* c, const opmhip_fluid* fluid) {
         A.num_rock = T.num_rock;
         A.rock_desc = T.rock_desc;
         A.wet_gas = T.wet_gas;
-        A.ext = T.wet_gas || T.num_rock > 0;   // extended intensive-quantity record
+        A.pc_scaling = T.pc_scaling;
+        A.ext = T.wet_gas || T.num_rock > 0 || T.pc_scaling;   // extended intensive-quantity record
         A.fluid_set = true;
         return OPMHIP_SUCCESS;
     });
@@ -256,6 +258,32 @@ int opmhip_set_problem_extras(opmhip_ctx* c, const double* rvmax, const int* roc
         if (rocknum) { if ((rc = upload_cells(c, &A.d_rocknum, rocknum))) return rc; } else A.d_rocknum = nullptr;
         if (overburden) { if ((rc = upload_cells(c, &A.d_overburden, overburden))) return rc; } else A.d_overburden = nullptr;
         if (A.state_set) {   // the cached intensive quantities depend on these arrays
+            launch_iq_update(c);
+            OPMHIP_HIP(c, hipGetLastError());
+            OPMHIP_HIP(c, hipStreamSynchronize(c->stream));
+        }
+        return OPMHIP_SUCCESS;
+    });
+}
+
+int opmhip_set_pcw(opmhip_ctx* c, const double* pcw) {
+    if (!c) return OPMHIP_INVALID_ARGUMENT;
+    return guarded(c, [&]() -> int {
+        AsmDev& A = c->asmb;
+        if (!A.static_set) return fail(c, OPMHIP_NOT_READY, "set_pcw before set_static");
+        if (pcw && !A.pc_scaling)
+            return fail(c, OPMHIP_INVALID_ARGUMENT, "set_pcw: the fluid was set without pc_scaling - its capillary pressure curves have no per-cell end point");
+        if (pcw)
+            for (int i = 0; i < c->pat.Nloc; ++i)
+                if (!std::isfinite(pcw[i])) return fail(c, OPMHIP_INVALID_ARGUMENT, "set_pcw: pcw[%d] is not finite", i);
+        OPMHIP_HIP(c, hipSetDevice(c->device));
+        int rc;
+        if (pcw) { if ((rc = upload_cells(c, &A.d_pcw, pcw))) return rc; }
+        else if (A.d_pcw) {
+            OPMHIP_HIP(c, hipStreamSynchronize(c->stream));   // an assembly enqueued earlier may still read it
+            dev_free(c, &A.d_pcw);
+        }
+        if (A.state_set) {   // the cached intensive quantities depend on it
             launch_iq_update(c);
             OPMHIP_HIP(c, hipGetLastError());
             OPMHIP_HIP(c, hipStreamSynchronize(c->stream));

@@ -32,6 +32,7 @@ std::string build_fluid_tables(const opmhip_fluid* f, FluidTables& T) {
     T = FluidTables();
     T.wet_gas = wet;
     T.num_rock = f->num_rock;
+    T.pc_scaling = f->pc_scaling != 0;
     T.num_pvt = f->num_pvt;
     T.num_sat = f->num_sat;
     T.rock_pref = f->rock_pref;

@@ -40,6 +40,7 @@ struct FluidTables {
     int num_pvt = 0, num_sat = 0, num_rock = 0;
     int rock_desc = 0;     // offset of the RockTabDesc array inside idx
     bool wet_gas = false;  // PVTG present: vaporised oil (Rv), third primary-variable meaning
+    bool pc_scaling = false;  // per-cell end-point scaling of pcow (PCW / SWATINIT)
 };
 
 // returns "" on success, else an error text

@@ -99,6 +99,8 @@ struct AsmDev {
     bool ext = false;       // extended intensive-quantity record (wet gas and / or ROCKTAB): 19 fields instead of 17
     double *d_rvmax = nullptr, *d_overburden = nullptr;   // per cell: DRVDT cap, overburden pressure (optional)
     int* d_rocknum = nullptr;                             // per cell rock-table index (optional)
+    bool pc_scaling = false;                              // the fluid allows a per-cell end point of pcow (PCW / SWATINIT)
+    double* d_pcw = nullptr;                              // per cell: scaled maximum of the oil-water capillary pressure (optional)
     double* d_invb = nullptr;                             // packed 1/b per cell and phase (Nloc x 3), for the convergence check
     double *d_trans = nullptr, *d_area = nullptr, *d_thpres = nullptr;                      // per entry
     double *d_poro = nullptr, *d_volume = nullptr, *d_depth = nullptr, *d_rsmax = nullptr;  // per cell

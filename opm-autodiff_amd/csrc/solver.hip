@@ -404,9 +404,12 @@ __global__ __launch_bounds__(64) void k_spmv_pipe(int npos, const int4* __restri
                                                   const double* __restrict__ done) {
     TILE_LDS
     const int lane = threadIdx.x, G = gridDim.x;
-    if (*done != 0.0) return;
     constexpr int U = 16;  // 16 x 64 lanes x 16 B = 16 KiB >= any staged tile
     const int nsteps = ((int)blockIdx.x < npos) ? (npos - (int)blockIdx.x + G - 1) / G : 0;
+    if (nsteps <= 0) return;
+    const double stop = *done;                      // read together with the first schedule entry: one scalar round trip, not two
+    const int4 sFirst = sched[(int)blockIdx.x];
+    if (stop != 0.0) return;
     struct StA { int4 rows; int rr, kb, ke; bool active; };
     struct StC { int4 rows; int rr, kb, nrow; bool active; int cc[PGCH]; };
     struct StG {
@@ -455,7 +458,7 @@ __global__ __launch_bounds__(64) void k_spmv_pipe(int npos, const int4* __restri
     StC c;
     StG b;
     // prologue: fill the pipeline, tile by tile (issuing the row bounds of three tiles at once was measured 7 % SLOWER)
-    if (nsteps > 0) { stageA(stageS(0), a); stageC(a, c); stageG(c, b); }
+    { stageA(sFirst, a); stageC(a, c); stageG(c, b); }
     if (nsteps > 1) { stageA(stageS(1), a); stageC(a, c); }
     if (nsteps > 2) stageA(stageS(2), a);
     if (nsteps > 3) sNext = stageS(3);
@@ -861,9 +864,9 @@ __global__ __launch_bounds__(64) void k_ilu_sweep_light(const int* __restrict__ 
                                                         double* vu, double* v, int relax_mode, double w, const double* __restrict__ done) {
     __shared__ int sdesc[DESC_MAX];
     const int lane = threadIdx.x;
-    if (*done != 0.0) return;
+    const double stop = *done;   // read with the descriptor record, tested after it: one round trip instead of two
     const int nsteps = load_desc(desc, dstride, lane, sdesc);
-    if (nsteps <= 0) return;
+    if (stop != 0.0 || nsteps <= 0) return;
     (void)S1;
     chain_sweep_light<SHAPE>(nsteps, lane, sdesc + DESC_HEAD, prow, pcol, P, invD, d, vu, v, relax_mode, w);
 }
@@ -876,9 +879,9 @@ __global__ __launch_bounds__(64) void k_ilu_sweep_chain(const int* __restrict__ 
     TILE_LDS
     __shared__ int sdesc[DESC_MAX];
     const int lane = threadIdx.x;
-    if (*done != 0.0) return;
+    const double stop = *done;   // read with the descriptor record, tested after it: one round trip instead of two
     const int nsteps = load_desc(desc, dstride, lane, sdesc);
-    if (nsteps <= 0) return;
+    if (stop != 0.0 || nsteps <= 0) return;
     const int* srow0 = sdesc + DESC_HEAD;
     chain_sweep<SHAPE>(nsteps, lane, sval, srow0, srow0 + (SHAPE == SW_L ? 1 : 2) * S1, prow, pcol, P, invD, d, vu, v, relax_mode, w);
 }
@@ -895,9 +898,9 @@ __global__ __launch_bounds__(64) void k_ilu_sweep_chain_LU(const int* __restrict
     TILE_LDS
     __shared__ int sdesc[DESC_MAX];
     const int lane = threadIdx.x;
-    if (*done != 0.0) return;
+    const double stop = *done;   // read with the descriptor record, tested after it: one round trip instead of two
     const int nsteps = load_desc(desc, dstride, lane, sdesc);
-    if (nsteps <= 0) return;
+    if (stop != 0.0 || nsteps <= 0) return;
     const int* srow0 = sdesc + DESC_HEAD;
     chain_sweep<SW_L>(nsteps, lane, sval, srow0, srow0 + S1, lrow, lcol, L, invD, d, vu, v, relax_mode, w);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // y of this chain-tile is written before the backward sweep reads it

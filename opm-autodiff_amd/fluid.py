@@ -20,18 +20,21 @@ class FluidDesc(C.Structure):
                 ("swof_ptr", C.c_void_p), ("swof", C.c_void_p), ("sgof_ptr", C.c_void_p), ("sgof", C.c_void_p),
                 ("rock_pref", C.c_double), ("rock_cr", C.c_double),
                 ("pvtg_node_ptr", C.c_void_p), ("pvtg_pg", C.c_void_p), ("pvtg_row_ptr", C.c_void_p), ("pvtg", C.c_void_p),
-                ("num_rock", C.c_int), ("rocktab_ptr", C.c_void_p), ("rocktab", C.c_void_p)]
+                ("num_rock", C.c_int), ("rocktab_ptr", C.c_void_p), ("rocktab", C.c_void_p),
+                ("pc_scaling", C.c_int)]
 
 
 class Fluid:
     """pvt: list of dict(pvtw[5], density[3] (oil, water, gas), pvdg rows (p,Bg,mu), pvto nodes dict(rs,p[],bo[],mu[]),
     optional pvtg nodes dict(pg, rv[], bg[], mu[]) - wet gas, rows as in the deck: saturated first, Rv descending - in which
     case pvdg may be omitted); sat: list of dict(swof rows (Sw,krw,krow,pcow), sgof rows (Sg,krg,krog,pcog));
-    rocktab: optional list (one per rock region) of rows (p, pore-volume multiplier, transmissibility multiplier); all SI."""
+    rocktab: optional list (one per rock region) of rows (p, pore-volume multiplier, transmissibility multiplier); all SI.
+    pc_scaling: the deck scales the oil-water capillary pressure per cell (PCW or SWATINIT): set_pcw may then follow."""
 
-    def __init__(self, pvt, sat, rock_pref=1e5, rock_cr=0.0, rocktab=None):
+    def __init__(self, pvt, sat, rock_pref=1e5, rock_cr=0.0, rocktab=None, pc_scaling=False):
         self.pvt, self.sat, self.rock_pref, self.rock_cr = pvt, sat, float(rock_pref), float(rock_cr)
         self.rocktab = rocktab or []
+        self.pc_scaling = bool(pc_scaling)
         self.wet_gas = bool(pvt and pvt[0].get("pvtg"))
         f64 = lambda a: np.ascontiguousarray(np.asarray(a, dtype=np.float64).reshape(-1))
         i32 = lambda a: np.ascontiguousarray(np.asarray(a, dtype=np.int32).reshape(-1))
@@ -67,6 +70,7 @@ class Fluid:
             setattr(d, k, v.ctypes.data_as(C.c_void_p))
         d.rock_pref, d.rock_cr = self.rock_pref, self.rock_cr
         d.num_rock = len(self.rocktab)
+        d.pc_scaling = int(self.pc_scaling)
         return d
 
 

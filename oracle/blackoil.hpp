@@ -51,6 +51,14 @@ struct Problem {
     std::vector<double> rvMax;                // per cell; empty = no DRVDT limit (maxOilVaporizationFactor, eclproblem.hh:1734-1754)
     std::vector<int> rockNum;                 // per cell rock-table index (rockTableIdx_, eclproblem.hh:1943-1945); empty = table 0
     std::vector<double> overburden;           // per cell overburden pressure (eclproblem.hh:1954-1955); empty = none
+    // per cell scaled maximum of the oil-water capillary pressure (the deck's PCW, or what SWATINIT made of it:
+    // ebos/equil/initstateequil.hh:1330-1343 -> EclMaterialLawManager::applySwatinit); empty = the tables' own.
+    // UNVERIFIED against upstream sources: opm-material (EclEpsTwoPhaseLaw, EclEpsScalingPoints) is not in the reference tree;
+    // restated from its published form - with enablePcScaling and no saturation scaling the scaled curve is
+    // pcnw(Sw) = table(Sw) * alpha, alpha = scaledMaxPcnw / unscaledMaxPcnw (1 when the two are equal), unscaledMaxPcnw =
+    // the SWOF pcow column's first entry.  Pinned by the reference's own numbers for equil_capillary_swatinit.DATA
+    // (tests/test_equil.cc:1076-1091) through tests/test_equil.py::test_swatinit_deck.
+    std::vector<double> pcw;
     Fluid fluid;
     void finish() {
         const int Nb = pat.Nb;
@@ -93,6 +101,11 @@ void update_iq(const Problem& P, int cell, const double* pv, uint8_t meaning, IQ
     q.S[WATER] = Sw; q.S[GAS] = Sg; q.S[OIL] = So;
     E pC[3];
     F.sat[sr].capillaryPressures(pC, Sw, Sg);
+    if (!P.pcw.empty()) {
+        const double scaledMax = P.pcw[cell], tableMax = F.sat[sr].pcow.y.front();
+        const double alpha = (scaledMax == tableMax) ? 1.0 : scaledMax / tableMax;
+        pC[0] = pC[0] * alpha;
+    }
     if (meaning == Sw_pg_Rv) {   // the pressure primary variable is the GAS pressure
         const E pg = mkvar<E>(pv[PV_P], PV_P);
         for (int ph = 0; ph < 3; ++ph) q.p[ph] = pg + (pC[ph] - pC[GAS]);

@@ -324,6 +324,7 @@ struct orc_fluid_desc {
     // wet gas (PVTG) and rock compaction tables (ROCKTAB); pointers may be NULL / counts 0
     const int* pvtg_node_ptr; const double* pvtg_pg; const int* pvtg_row_ptr; const double* pvtg;
     int num_rock; const int* rocktab_ptr; const double* rocktab;
+    int pc_scaling;   // the product's switch for its extended record; the oracle scales whenever set_pcw gave it an array
 };
 FluidInput to_input(const orc_fluid_desc* d) {
     FluidInput in;
@@ -511,6 +512,14 @@ int orc_bo_set_extras(orc_model* h, const double* rvMax, const int* rockNum, con
     if (rvMax) M.P.rvMax.assign(rvMax, rvMax + Nb); else M.P.rvMax.clear();
     if (rockNum) M.P.rockNum.assign(rockNum, rockNum + Nb); else M.P.rockNum.clear();
     if (overburden) M.P.overburden.assign(overburden, overburden + Nb); else M.P.overburden.clear();
+    M.update_all_iq();
+    return 0;
+}
+// per-cell scaled maximum of the oil-water capillary pressure (PCW / SWATINIT); NULL = the tables' own
+int orc_bo_set_pcw(orc_model* h, const double* pcw) {
+    Model& M = h->M;
+    const int Nb = M.P.pat.Nb;
+    if (pcw) M.P.pcw.assign(pcw, pcw + Nb); else M.P.pcw.clear();
     M.update_all_iq();
     return 0;
 }

@@ -158,6 +158,7 @@ class OracleModel:
         L.orc_set_threads.argtypes = [C.c_int]
         L.orc_bo_get_iq_ext.argtypes = [_vp, _d]
         L.orc_bo_set_extras.argtypes = [_vp, _vp, _vp, _vp]
+        L.orc_bo_set_pcw.argtypes = [_vp, _vp]
         L.orc_bo_end_time_step.argtypes = [_vp, C.c_double]
         L.orc_bo_set_drift_compensation.argtypes = [_vp, C.c_int, C.c_double]
         L.orc_bo_get_drift.argtypes = [_vp, _d]
@@ -171,6 +172,12 @@ class OracleModel:
                                  g("satnum"), g("rsmax"), C.addressof(self._fd))
         if any(case.get(k) is not None for k in ("rvmax", "rocknum", "overburden")):
             self.set_problem_extras(case.get("rvmax"), case.get("rocknum"), case.get("overburden"))
+        if case.get("pcw") is not None:
+            self.set_pcw(case["pcw"])
+
+    def set_pcw(self, pcw):
+        a = None if pcw is None else np.ascontiguousarray(pcw, np.float64)
+        self.o.lib.orc_bo_set_pcw(self.h, _p(a))
 
     def __del__(self):
         if getattr(self, "h", None):
@@ -193,7 +200,7 @@ class OracleModel:
 
     def iq(self):
         fl = self.case["fluid"]
-        if getattr(fl, "wet_gas", False) or getattr(fl, "rocktab", None):   # extended record: ... Rs | Rv | tmult | poro
+        if getattr(fl, "wet_gas", False) or getattr(fl, "rocktab", None) or getattr(fl, "pc_scaling", False):   # extended record: ... Rs | Rv | tmult | poro
             out = np.empty(self.Nb * 19 * 4)
             self.o.lib.orc_bo_get_iq_ext(self.h, out)
             return out.reshape(self.Nb, 19, 4)
