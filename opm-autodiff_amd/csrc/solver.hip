@@ -1297,7 +1297,19 @@ __device__ __forceinline__ void finalize_scalars(int mode, double s0, double s1,
 __global__ __launch_bounds__(VB) void k_finalize(int mode, int count, const double* __restrict__ part, int npart,
                                                  double* __restrict__ scal, double tol, double* hslot, double seq) {
     __shared__ double sh[2][VB];
-    if (mode != FIN_INIT && scal[SC_DONE] != 0.0) {
+    // The partial sums were written by the kernel before this one, from every XCD: each load is a trip to the fabric.  All
+    // of a thread's partials (and the stop flag) are requested in ONE round and then added in the fixed order - thread t:
+    // part[t], part[t + VB], ... - instead of one dependent round trip per addend (5.2 us -> the figure in DESIGN.md).
+    constexpr int FU = 8;   // FU x VB = 2048 covers RED1_SINGLE_MAX; longer lists finish in the loop below
+    double va[FU], vb[FU];
+#pragma unroll
+    for (int u = 0; u < FU; ++u) {
+        const int i = (int)threadIdx.x + u * VB;
+        const int j = i < count ? i : 0;
+        va[u] = part[j]; vb[u] = part[npart + j];
+    }
+    const double stop = (mode != FIN_INIT) ? scal[SC_DONE] : 0.0;
+    if (stop != 0.0) {
         // a speculative launch past the stopping point still answers the host, which may be polling this slot
         if (threadIdx.x == 0 && hslot && (mode == FIN_NORM || mode == FIN_NORM_RHO)) {
             hslot[0] = scal[SC_NORM]; hslot[1] = scal[SC_NORM0]; hslot[2] = 1.0;
@@ -1306,15 +1318,24 @@ __global__ __launch_bounds__(VB) void k_finalize(int mode, int count, const doub
         return;
     }
     double a = 0.0, b = 0.0;
-    for (int i = threadIdx.x; i < count; i += VB) { a += part[i]; b += part[npart + i]; }
+#pragma unroll
+    for (int u = 0; u < FU; ++u)
+        if ((int)threadIdx.x + u * VB < count) { a += va[u]; b += vb[u]; }
+    for (int i = (int)threadIdx.x + FU * VB; i < count; i += VB) { a += part[i]; b += part[npart + i]; }
     sh[0][threadIdx.x] = a; sh[1][threadIdx.x] = b;
     __syncthreads();
-    for (int o = VB / 2; o > 0; o >>= 1) {
+    // the tree sh[t] += sh[t + o], o = VB/2 ... 1: across wavefronts through LDS, inside the first one through lane shifts
+    // (lane t takes lane t + o's value: the same additions in the same order)
+    for (int o = VB / 2; o >= 64; o >>= 1) {
         if ((int)threadIdx.x < o) { sh[0][threadIdx.x] += sh[0][threadIdx.x + o]; sh[1][threadIdx.x] += sh[1][threadIdx.x + o]; }
         __syncthreads();
     }
+    if (threadIdx.x >= 64) return;
+    a = sh[0][threadIdx.x]; b = sh[1][threadIdx.x];
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) { a += __shfl_down(a, o, 64); b += __shfl_down(b, o, 64); }
     if (threadIdx.x != 0) return;
-    finalize_scalars(mode, sh[0][0], sh[1][0], scal, tol, hslot, seq);
+    finalize_scalars(mode, a, b, scal, tol, hslot, seq);
 }
 // slice sums and k_finalize in one launch for long partial lists: the workgroup that finishes last (ticket counter)
 // sums the RED1_BLOCKS slice sums in k_finalize's order and updates the scalars.  The slice sums cross XCDs inside one
