@@ -52,8 +52,9 @@ def alg_bytes(Nb, nnzb):
         "spmv": 76 * nnzb + 4 * (Nb + 1) + 48 * Nb,
         "ilu_apply": 76 * nnzb + 4 * (Nb + 1) + 4 * Nb + 72 * Nb,
         "ilu_factor": 2 * 72 * nnzb + 4 * nnzb + 4 * Nb,
-        # per scope, three scopes per iteration: the p-update (4 passes), (r, x)-update (6), k_bicg_upd2 (7), two k_dots (2 each)
-        "vector": 24 * Nb * 21 / 3,
+        # per scope, three scopes per iteration: the p-update (4 passes), r-update (3), k_bicg_upd2 with both updates of x (8),
+        # two k_dots (2 each)
+        "vector": 24 * Nb * 19 / 3,
         "assemble": 85 * Nb + 12 * nnzb + 72 * nnzb + 24 * Nb,
         "iq_update": 24 * Nb + 544 * Nb,
         "convergence": 56 * Nb,

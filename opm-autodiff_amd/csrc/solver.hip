@@ -1182,10 +1182,11 @@ __global__ __launch_bounds__(VB) void k_bicg_pupdate(int n, const double* __rest
         if (e < n) p[e] = (p[e] - omega * v[e]) * beta + r[e];
     }
 }
-// r -= alpha v ; x += alpha pw ; partial r.r
+// r -= alpha v ; partial r.r.  The first half's "x += alpha pw" (bda/cusparseSolverBackend.cu:110) waits for the second
+// half's update of x (k_bicg_upd2 adds both terms, in the reference's order: two passes over x less per iteration); a solve
+// that meets the stopping rule right after a first half gets it from k_bicg_xhalf.
 __global__ __launch_bounds__(VB) void k_bicg_upd1(int n, const double* __restrict__ scal, double* __restrict__ r,
-                                                  const double* __restrict__ v, double* __restrict__ x,
-                                                  const double* __restrict__ pw, double* __restrict__ part, int npart) {
+                                                  const double* __restrict__ v, double* __restrict__ part, int npart) {
     if (scal[SC_DONE] != 0.0) return;
     const double alpha = scal[SC_ALPHA];
     double s = 0.0;
@@ -1196,26 +1197,36 @@ __global__ __launch_bounds__(VB) void k_bicg_upd1(int n, const double* __restric
         if (e < n) {
             const double re = r[e] - alpha * v[e];
             r[e] = re;
-            x[e] += alpha * pw[e];
             s += re * re;
         }
     }
     block_partials(s, 0.0, part, npart, 1);
 }
-// x += omega s ; r -= omega t ; partials r.r and rw.r
+// x += alpha pw, alone: the solve ended on a first half
+__global__ __launch_bounds__(VB) void k_bicg_xhalf(int n, const double* __restrict__ scal, double* __restrict__ x, const double* __restrict__ pw) {
+    const double alpha = scal[SC_ALPHA];
+    const int base = blockIdx.x * VB * VPT + threadIdx.x;
+#pragma unroll
+    for (int u = 0; u < VPT; ++u) {
+        const int e = base + u * VB;
+        if (e < n) x[e] += alpha * pw[e];
+    }
+}
+// x = (x + alpha pw) + omega s ; r -= omega t ; partials r.r and rw.r
 __global__ __launch_bounds__(VB) void k_bicg_upd2(int n, const double* __restrict__ scal, double* __restrict__ x,
-                                                  const double* __restrict__ sv, double* __restrict__ r,
+                                                  const double* __restrict__ pw, const double* __restrict__ sv, double* __restrict__ r,
                                                   const double* __restrict__ tv, const double* __restrict__ rw,
                                                   double* __restrict__ part, int npart) {
     if (scal[SC_DONE] != 0.0) return;
-    const double omega = scal[SC_OMEGA];
+    const double alpha = scal[SC_ALPHA], omega = scal[SC_OMEGA];
     double s = 0.0, q = 0.0;
     const int base = blockIdx.x * VB * VPT + threadIdx.x;
 #pragma unroll
     for (int u = 0; u < VPT; ++u) {
         const int e = base + u * VB;
         if (e < n) {
-            x[e] += omega * sv[e];
+            const double xh = x[e] + alpha * pw[e];   // the first half's update
+            x[e] = xh + omega * sv[e];
             const double re = r[e] - omega * tv[e];
             r[e] = re;
             s += re * re;
@@ -1628,9 +1639,9 @@ static int finalize(opmhip_ctx* c, int mode, int count, int rb_half = -1) {
 void launch_vector_kernels_once(opmhip_ctx* c) {
     const int n = c->pat.Nb * BS, nb = vec_blocks(n);
     hipLaunchKernelGGL(k_bicg_pupdate, dim3(nb), dim3(VB), 0, c->stream, n, c->d_scal, c->d_p, c->d_v, c->d_r);
-    hipLaunchKernelGGL(k_bicg_upd1, dim3(nb), dim3(VB), 0, c->stream, n, c->d_scal, c->d_r, c->d_v, c->d_x, c->d_pw, c->d_part, c->npart);
+    hipLaunchKernelGGL(k_bicg_upd1, dim3(nb), dim3(VB), 0, c->stream, n, c->d_scal, c->d_r, c->d_v, c->d_part, c->npart);
     (void)finalize(c, FIN_NORM, nb);  // timing helper, single-rank contexts only
-    hipLaunchKernelGGL(k_bicg_upd2, dim3(nb), dim3(VB), 0, c->stream, n, c->d_scal, c->d_x, c->d_s, c->d_r, c->d_t, c->d_rw, c->d_part, c->npart);
+    hipLaunchKernelGGL(k_bicg_upd2, dim3(nb), dim3(VB), 0, c->stream, n, c->d_scal, c->d_x, c->d_pw, c->d_s, c->d_r, c->d_t, c->d_rw, c->d_part, c->npart);
     (void)finalize(c, FIN_NORM_RHO, nb);
 }
 
@@ -1665,7 +1676,7 @@ static int enqueue_half(opmhip_ctx* c, int h) {
         launch_spmv(c, c->d_pw, c->d_v, 1, c->d_rw, nullptr);
         ps = prof_begin(c, PROF_VECTOR);
         if ((rc = finalize(c, FIN_ALPHA, dot_count(c)))) return rc;
-        hipLaunchKernelGGL(k_bicg_upd1, dim3(nb), dim3(VB), 0, c->stream, n, c->d_scal, c->d_r, c->d_v, c->d_x, c->d_pw, c->d_part, c->npart);
+        hipLaunchKernelGGL(k_bicg_upd1, dim3(nb), dim3(VB), 0, c->stream, n, c->d_scal, c->d_r, c->d_v, c->d_part, c->npart);
         if ((rc = finalize(c, FIN_NORM, nb, h))) return rc;
         prof_end(c, ps);
     } else {             // second half: z = M^-1 r, t = A z, omega, x += omega z, r -= omega t, |r|, rho, beta
@@ -1675,7 +1686,7 @@ static int enqueue_half(opmhip_ctx* c, int h) {
         launch_spmv(c, c->d_s, c->d_t, 2, c->d_r, nullptr);
         ps = prof_begin(c, PROF_VECTOR);
         if ((rc = finalize(c, FIN_OMEGA, dot_count(c)))) return rc;
-        hipLaunchKernelGGL(k_bicg_upd2, dim3(nb), dim3(VB), 0, c->stream, n, c->d_scal, c->d_x, c->d_s, c->d_r, c->d_t, c->d_rw, c->d_part, c->npart);
+        hipLaunchKernelGGL(k_bicg_upd2, dim3(nb), dim3(VB), 0, c->stream, n, c->d_scal, c->d_x, c->d_pw, c->d_s, c->d_r, c->d_t, c->d_rw, c->d_part, c->npart);
         if ((rc = finalize(c, FIN_NORM_RHO, nb, h))) return rc;
         prof_end(c, ps);
     }
@@ -1753,6 +1764,8 @@ int bicgstab(opmhip_ctx* c, opmhip_result* res) {
             it = 0.5f * (float)(h + 1);
             prof_flush(c);
             for (size_t i = mark_next; i < c->prof.used; ++i) c->prof.cls[i] = -1;  // half h + 1 ran as no-ops
+            // stopped on a first half: its update of x was left to the second half, which will not come
+            if ((h & 1) == 0) hipLaunchKernelGGL(k_bicg_xhalf, dim3(nb), dim3(VB), 0, c->stream, n, c->d_scal, c->d_x, c->d_pw);
             break;
         }
     }
