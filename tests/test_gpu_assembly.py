@@ -450,3 +450,41 @@ def test_deck_side_inputs_through_the_hot_path(pkg, orc, reorder):
         jm, rm = m.assemble(86400.0, it)
         jo, ro = o.assemble(86400.0, it)
         assert np.array_equal(rm, ro) and np.array_equal(jm, jo)
+
+
+@pytest.mark.parametrize("reorder", ["graph_coloring", "line_coloring"])
+def test_faulted_corner_point_grid_through_the_hot_path(pkg, orc, reorder):
+    """transmissibility.cornerpoint_faces -> set_pattern / set_static: a corner-point grid with sheared pillars, dipping layers,
+    an inactive cell and a fault of 1.5 layers' throw - cells next to the fault have two lateral neighbours on that side, rows
+    of up to 8 blocks, connections between different layers - then Jacobian, residual, a Newton update and a linear solve
+    against the oracle."""
+    T = pkg.transmissibility
+    nx, ny, nz = 6, 4, 7
+    coord, zcorn = T.cartesian_cornerpoint(nx, ny, nz, 25.0, 20.0, 4.0, top=2400.0, shear=(0.1, -0.05), fault_i=3, throw=6.0, dip=0.02)
+    act = np.ones(nx * ny * nz, int); act[50] = 0
+    g = T.cornerpoint_faces(nx, ny, nz, coord, zcorn, actnum=act)
+    n, F = g["n"], g["faces"]
+    lay = lambda c: g["cart"][c] // (nx * ny)
+    assert np.any(lay(F["cell1"]) != lay(F["cell2"]) - (F["face1"] == T.ZP))           # connections across layers at the fault
+    rng = np.random.default_rng(4)
+    perm = (rng.uniform(20.0, 300.0, (n, 1)) * np.array([1.0, 1.0, 0.1])) * 9.869233e-16
+    t = T.face_transmissibilities(F, g["centroid"], perm, ntg=rng.uniform(0.6, 1.0, n))
+    assert np.all(t > 0.0)
+    pat = T.connections_to_pattern(n, F["cell1"], F["cell2"], t, g["face_area"])
+    assert np.diff(pat["rowptr"]).max() == 8
+    base = pkg.decks.cartesian_cells(n, 1, 1, 25.0, 20.0, 4.0, 2400.0, 0.25, 100.0, False, "mixed", True, None, 5)
+    case = dict(Nb=n, rowptr=pat["rowptr"], col=pat["col"], trans=pat["trans"], area=pat["area"], poro=base["poro"],
+                volume=np.ascontiguousarray(g["volume"]), depth=np.ascontiguousarray(g["depth"]), fluid=base["fluid"], pv=base["pv"], meaning=base["meaning"])
+    m, o = both(pkg, orc, case, reorder=reorder)
+    dt = 86400.0
+    for it in range(2):
+        jm, rm = m.assemble(dt, it)
+        jo, ro = o.assemble(dt, it)
+        assert np.array_equal(rm, ro) and np.array_equal(jm, jo)
+        if it == 0:
+            dx = np.random.default_rng(8).uniform(-1.0, 1.0, (n, 3)) * np.array([0.01, 1e5, 0.01])
+            assert m.update(dx.reshape(-1)) == o.update(dx.reshape(-1))
+    res = m.solve_jacobian_system()
+    xo, ro_ = o.solve_in_order(*m.ordering()[:2])
+    assert res.converged and ro_.converged and res.it == ro_.it
+    np.testing.assert_allclose(m.get_result(), xo, rtol=1e-9, atol=1e-12 * np.abs(xo).max())

@@ -166,3 +166,145 @@ def test_multz_all_takes_the_smallest_multiplier_down_the_pillar():
     # without the option: the upper cell's own MULTZ and the lower cell's MULTZ-
     t = T.face_transmissibilities(F, g["centroid"], perm, mult={"Z+": mz_cart[g["cart"]], "Z-": mzm})
     assert t[0] == base[0] * 0.8 * 0.5
+
+
+# ---- corner-point geometry (cornerpoint_faces): no reference numbers exist for it, so properties -----------------------------
+def _by_pair(g):
+    f = g["faces"]
+    return {(int(a), int(b)): q for q, (a, b) in enumerate(zip(f["cell1"], f["cell2"]))}
+
+
+def test_cornerpoint_box_equals_the_block_centred_grid():
+    nx, ny, nz, dx, dy, dz = 4, 3, 5, 20.0, 30.0, 4.0
+    coord, zcorn = T.cartesian_cornerpoint(nx, ny, nz, dx, dy, dz, top=1000.0)
+    act = np.ones(nx * ny * nz, int); act[[7, 31]] = 0
+    g = T.cornerpoint_faces(nx, ny, nz, coord, zcorn, actnum=act)
+    h = T.cartesian_faces(nx, ny, nz, dx, dy, dz, 1000.0, actnum=act)
+    assert g["n"] == h["n"] == nx * ny * nz - 2 and np.array_equal(g["cart"], h["cart"])
+    np.testing.assert_allclose(g["volume"], h["volume"], rtol=1e-14)
+    np.testing.assert_allclose(g["centroid"], h["centroid"], rtol=1e-14)
+    pg, ph = _by_pair(g), _by_pair(h)
+    assert set(pg) == set(ph) and all(a < b for a, b in pg)
+    og, oh = [pg[k] for k in sorted(pg)], [ph[k] for k in sorted(ph)]
+    for key in ("face1", "face2"):
+        assert np.array_equal(g["faces"][key][og], h["faces"][key][oh])
+    for key in ("center1", "center2", "area_normal"):
+        np.testing.assert_allclose(g["faces"][key][og], h["faces"][key][oh], rtol=1e-13, atol=1e-9)
+    perm = np.random.default_rng(2).uniform(1e-14, 1e-12, (g["n"], 3))
+    np.testing.assert_allclose(T.face_transmissibilities(g["faces"], g["centroid"], perm)[og],
+                               T.face_transmissibilities(h["faces"], h["centroid"], perm)[oh], rtol=1e-12)
+
+
+def test_cornerpoint_fault_splits_faces_and_conserves_area():
+    """columns i >= 2 thrown down by 1.5 layers: a cell left of the fault meets the two cells it overlaps, half a face each"""
+    nx, ny, nz, dx, dy, dz = 4, 2, 6, 10.0, 10.0, 2.0
+    coord, zcorn = T.cartesian_cornerpoint(nx, ny, nz, dx, dy, dz, top=0.0, fault_i=2, throw=1.5 * dz)
+    g = T.cornerpoint_faces(nx, ny, nz, coord, zcorn)
+    f = g["faces"]
+    cell = lambda i, j, k: i + nx * (j + ny * k)
+    pairs = _by_pair(g)
+    for j in range(ny):
+        for k in range(nz):
+            a = cell(1, j, k)
+            partners = {b: q for (x, b), q in pairs.items() if x == a and b % nx == 2} | {x: q for (x, b), q in pairs.items() if b == a and x % nx == 2}
+            expect = {cell(2, j, kk) for kk in (k - 2, k - 1) if 0 <= kk < nz}
+            assert set(partners) == expect
+            for b, q in partners.items():
+                nrm = f["area_normal"][q] * (1.0 if f["cell1"][q] == a else -1.0)
+                np.testing.assert_allclose(nrm, [0.5 * dz * dy, 0.0, 0.0], rtol=1e-13, atol=1e-12)
+                # the centres are those of the cells' own faces, not of the overlap: they differ by the throw
+                ca, cb = (f["center1"][q], f["center2"][q]) if f["cell1"][q] == a else (f["center2"][q], f["center1"][q])
+                np.testing.assert_allclose(ca, [2 * dx, (j + 0.5) * dy, (k + 0.5) * dz], atol=1e-12)
+                np.testing.assert_allclose(cb, [2 * dx, (j + 0.5) * dy, (b // (nx * ny) + 0.5) * dz + 1.5 * dz], atol=1e-12)
+    # away from the fault nothing changed; the thrown block kept its volumes
+    np.testing.assert_allclose(g["volume"], dx * dy * dz, rtol=1e-14)
+    assert (cell(0, 0, 0), cell(1, 0, 0)) in pairs and (cell(2, 0, 0), cell(3, 0, 0)) in pairs
+    # max_fault_throw limits the search
+    g1 = T.cornerpoint_faces(nx, ny, nz, coord, zcorn, max_fault_throw=1)
+    assert all(abs(a // (nx * ny) - b // (nx * ny)) <= 1 for a, b in _by_pair(g1))
+
+
+def test_cornerpoint_scissor_fault_with_crossing_edges():
+    """the throw grows along the fault from -0.7 to +1.9 layers, so that edges of the two sides cross between the pillars: the
+    overlaps of one cell's face with all the cells of the other column still add up to that face (where the column covers
+    it), and one of them is checked against a brute-force count in the (s, z) chart"""
+    nx, ny, nz, dx, dy, dz = 2, 3, 8, 10.0, 12.0, 2.0
+    coord, zcorn = T.cartesian_cornerpoint(nx, ny, nz, dx, dy, dz, top=0.0)
+    z = zcorn.reshape(nz, 2, ny, 2, nx, 2).copy()
+    throw = lambda jp: (-0.7 + 2.6 * jp / ny) * dz
+    for jj in range(2):
+        for j in range(ny):
+            z[:, :, j, jj, 1, :] += throw(j + jj)
+    g = T.cornerpoint_faces(nx, ny, nz, coord, z.reshape(-1))
+    f = g["faces"]
+    cell = lambda i, j, k: i + nx * (j + ny * k)
+    for j in range(ny):
+        for k in range(3, nz - 3):       # faces fully covered by the other column
+            a = cell(0, j, k)
+            tot = sum(f["area_normal"][q][0] for (x, b), q in _by_pair(g).items() if x == a and b % nx == 1)
+            tot += sum(-f["area_normal"][q][0] for (x, b), q in _by_pair(g).items() if b == a and x % nx == 1)
+            np.testing.assert_allclose(tot, dy * dz, rtol=1e-12)
+    # brute force in the (s, z) chart for every partner of cell (0, 1, 4)
+    a = cell(0, 1, 4)
+    s = (np.arange(4000) + 0.5) / 4000
+    tA, bA = 4 * dz, 5 * dz
+    shapes = set()
+    for kb in range(nz):
+        b = cell(1, 1, kb)
+        tB = kb * dz + throw(1) + s * (throw(2) - throw(1)); bB = tB + dz
+        h = np.clip(np.minimum(bA, bB) - np.maximum(tA, tB), 0.0, None)
+        q = _by_pair(g).get((min(a, b), max(a, b)))
+        if h.max() == 0.0:
+            assert q is None
+            continue
+        np.testing.assert_allclose(abs(f["area_normal"][q][0]), dy * h.mean(), rtol=1e-5, atol=1e-6 * dy * dz)   # midpoint rule of the check
+        shapes.add(("partly uncovered" if (h == 0.0).any() else "covered", "edges cross" if np.ptp(np.sign(tB - tA)) + np.ptp(np.sign(bB - bA)) > 0 else "no crossing"))
+    assert ("partly uncovered", "no crossing") in shapes or ("partly uncovered", "edges cross") in shapes
+    assert any(sh[1] == "edges cross" for sh in shapes)
+
+
+def test_cornerpoint_shear_and_dip():
+    nx, ny, nz, dx, dy, dz = 3, 3, 4, 10.0, 8.0, 2.0
+    # sheared pillars: volumes unchanged, side faces are parallelograms spanned by the pillar direction
+    coord, zcorn = T.cartesian_cornerpoint(nx, ny, nz, dx, dy, dz, top=100.0, shear=(0.3, -0.2))
+    g = T.cornerpoint_faces(nx, ny, nz, coord, zcorn)
+    np.testing.assert_allclose(g["volume"], dx * dy * dz, rtol=1e-13)
+    f = g["faces"]
+    pillar = np.array([0.3 * dz, -0.2 * dz, dz])
+    for q in range(len(f["cell1"])):
+        if f["face1"][q] == T.XP:
+            exp = np.cross([0.0, dy, 0.0], pillar)
+        elif f["face1"][q] == T.YP:
+            exp = -np.cross([dx, 0.0, 0.0], pillar)
+        else:
+            exp = np.array([0.0, 0.0, dx * dy])
+        np.testing.assert_allclose(f["area_normal"][q], exp, rtol=1e-12, atol=1e-10)
+    # the centre of a sheared cell sits on the sheared axis
+    np.testing.assert_allclose(g["centroid"][0], [0.5 * dx + 0.3 * 0.5 * dz, 0.5 * dy - 0.2 * 0.5 * dz, 100.0 + 0.5 * dz], rtol=1e-13)
+    # dipping layers (dz/dx = 0.1), vertical pillars: conforming, lateral faces keep their area, top / bottom faces tilt
+    coord, zcorn = T.cartesian_cornerpoint(nx, ny, nz, dx, dy, dz, top=100.0, dip=0.1)
+    g = T.cornerpoint_faces(nx, ny, nz, coord, zcorn)
+    f = g["faces"]
+    assert len(f["cell1"]) == 3 * nx * ny * nz - nx * ny - ny * nz - nx * nz
+    np.testing.assert_allclose(g["volume"], dx * dy * dz, rtol=1e-13)
+    for q in range(len(f["cell1"])):
+        exp = {T.XP: [dy * dz, 0.0, 0.0], T.YP: [0.0, dx * dz, 0.0], T.ZP: [-0.1 * dx * dy, 0.0, dx * dy]}[int(f["face1"][q])]
+        np.testing.assert_allclose(f["area_normal"][q], exp, rtol=1e-12, atol=1e-10)
+    np.testing.assert_allclose(g["depth"][:nx], 100.0 + 0.5 * dz + 0.1 * dx * (np.arange(nx) + 0.5), rtol=1e-14)
+
+
+def test_cornerpoint_nonplanar_face_and_degenerate_pillar():
+    """one corner of a cell pulled down: the top face is no longer planar - its vector area is half the cross product of the
+    diagonals; a pillar given as a single point (top = bottom) keeps its x, y"""
+    coord, zcorn = T.cartesian_cornerpoint(1, 1, 2, 10.0, 10.0, 2.0, top=0.0)
+    coord = coord.copy(); coord[0, 3:] = coord[0, :3]          # degenerate pillar 0
+    z = zcorn.reshape(2, 2, 1, 2, 1, 2).copy()
+    z[0, 1, 0, 1, 0, 1] += 0.6; z[1, 0, 0, 1, 0, 1] += 0.6     # the shared corner (jj = 1, ii = 1) of the interface
+    g = T.cornerpoint_faces(1, 1, 2, coord, z.reshape(-1))
+    f = g["faces"]
+    assert len(f["cell1"]) == 1
+    p = np.array([[0, 0, 2.0], [10, 0, 2.0], [10, 10, 2.6], [0, 10, 2.0]], float)
+    np.testing.assert_allclose(f["area_normal"][0], 0.5 * np.cross(p[2] - p[0], p[3] - p[1]), rtol=1e-13)
+    np.testing.assert_allclose(g["volume"].sum(), 10.0 * 10.0 * 4.0, rtol=1e-13)     # what one cell lost the other gained
+    c = T.cornerpoint_corners(1, 1, 2, coord, z.reshape(-1))
+    assert np.all(c[:, :, 0, 0, 0] == 0.0) and np.all(c[:, :, 0, 0, 1] == 0.0)
