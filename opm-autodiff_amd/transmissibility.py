@@ -19,8 +19,8 @@ produces them for block-centred grids (DX / DY / DZ / TOPS per cell).
                           the pillar from the upper cell to the cell above the lower one, then the lower cell's MULTZ-
                           (applyAllZMultipliers_ :575-612, selected :219-227)
 
-Not restated: the search for PINCH / MINPV connections themselves (the grid library makes them; they arrive here as faces),
-boundary and thermal half transmissibilities, diffusivities.  Faces must be given once, cell1 = the cell with the lower Cartesian index
+Not restated: MINPV (which cells are pinched out is the caller's ACTNUM; `cornerpoint_faces(pinch=...)` then makes the
+connections across them), boundary and thermal half transmissibilities, diffusivities.  Faces must be given once, cell1 = the cell with the lower Cartesian index
 (the reference skips the other orientation, :296-299).  Units: SI (perm m^2, lengths m) -> m^3.
 """
 import numpy as np
@@ -311,13 +311,18 @@ def _pillar_overlap_area(a_t, a_b, b_t, b_b, p1, p2):
     return area
 
 
-def cornerpoint_faces(nx, ny, nz, coord, zcorn, actnum=None, max_fault_throw=None):
+def cornerpoint_faces(nx, ny, nz, coord, zcorn, actnum=None, max_fault_throw=None, pinch=None):
     """Corner-point grid -> what `face_transmissibilities` and `opmhip_set_static` want: the connections between active cells
     with their geometry, plus per-cell centres, volumes and depths (see the comment block above for the definitions).
     Vertical connections: between k and k + 1 of a column (connections ACROSS pinched-out or inactive layers are the grid
     library's PINCH search, not built: hand them over as NNCs).  Lateral connections: every pair of cells of neighbouring
     columns whose faces on the shared pillar pair overlap - k to k for a conforming grid, k to k' across a fault
     (max_fault_throw: limit on |k - k'|, default nz - 1).
+    pinch (PINCH item 1, a thickness; None = no PINCH keyword): an active cell whose lower neighbours are inactive is connected
+    to the next active cell of its column when the inactive cells in between are together no thicker than `pinch` (mean of the
+    four pillar thicknesses) - the connection the grid library creates across pinched-out layers (option GAP of item 2: the
+    thickness test applies; TOPBOT geometry: the upper cell's bottom face, each cell's own face centre).  Combine with
+    face_transmissibilities(multz_all=...) for item 4 = ALL.
     -> dict(n, cart, faces, centroid, volume, depth, face_area) like cartesian_faces"""
     N = nx * ny * nz
     c = cornerpoint_corners(nx, ny, nz, coord, zcorn)
@@ -377,6 +382,25 @@ def cornerpoint_faces(nx, ny, nz, coord, zcorn, actnum=None, max_fault_throw=Non
     bot = c[a, 1]                                                   # [cell, jj, ii]
     nrm = _quad_area_vector(bot[:, 0, 0], bot[:, 0, 1], bot[:, 1, 1], bot[:, 1, 0])
     add(a, b, ZP, ZM, bot.reshape(len(a), 4, 3).mean(axis=1), c[b, 0].reshape(len(b), 4, 3).mean(axis=1), nrm)
+    if pinch is not None:
+        thick = (c[:, 1, :, :, 2] - c[:, 0, :, :, 2]).reshape(N, 4).mean(axis=1)
+        pa, pb = [], []
+        for col in range(nx * ny):
+            cells = col + nx * ny * np.arange(nz)
+            up = -1          # the last active cell above, and the thickness of the inactive cells passed since
+            gap, passed = 0.0, 0
+            for q in cells:
+                if act[q]:
+                    if up >= 0 and passed > 0 and gap <= pinch:
+                        pa.append(up); pb.append(q)
+                    up, gap, passed = q, 0.0, 0
+                else:
+                    gap += thick[q]; passed += 1
+        if pa:
+            a, b = np.array(pa), np.array(pb)
+            bot = c[a, 1]
+            add(a, b, ZP, ZM, bot.reshape(len(a), 4, 3).mean(axis=1), c[b, 0].reshape(len(b), 4, 3).mean(axis=1),
+                _quad_area_vector(bot[:, 0, 0], bot[:, 0, 1], bot[:, 1, 1], bot[:, 1, 0]))
     faces = {key: np.concatenate(v) for key, v in F.items()}
     # one orientation per pair, cell1 the lower Cartesian index (fault connections with dk < 0 may come out reversed)
     swap = faces["cell1"] > faces["cell2"]

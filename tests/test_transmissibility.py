@@ -308,3 +308,38 @@ def test_cornerpoint_nonplanar_face_and_degenerate_pillar():
     np.testing.assert_allclose(g["volume"].sum(), 10.0 * 10.0 * 4.0, rtol=1e-13)     # what one cell lost the other gained
     c = T.cornerpoint_corners(1, 1, 2, coord, z.reshape(-1))
     assert np.all(c[:, :, 0, 0, 0] == 0.0) and np.all(c[:, :, 0, 0, 1] == 0.0)
+
+
+def test_cornerpoint_pinch_connections():
+    """PINCH: layers 2 and 3 of a column pinched out (thin and inactive) - the cells above and below are connected when the
+    gap is within the threshold; a thick inactive cell elsewhere stays a barrier; MULTZ of the pinched cells acts through
+    the option ALL"""
+    nx, ny, nz = 2, 1, 6
+    coord, zcorn = T.cartesian_cornerpoint(nx, ny, nz, 10.0, 10.0, 2.0, top=0.0)
+    z = zcorn.reshape(nz, 2, ny, 2, nx, 2).copy()
+    # column 0: squeeze layers 2 and 3 to 0.05 m each (everything below moves up)
+    col = z[:, :, 0, :, 0, :]
+    th = np.array([2.0, 2.0, 0.05, 0.05, 2.0, 2.0])
+    tops = np.concatenate([[0.0], np.cumsum(th)[:-1]])
+    col[:, 0] = tops[:, None, None]; col[:, 1] = (tops + th)[:, None, None]
+    cell = lambda i, k: i + nx * k
+    act = np.ones(nx * nz, int)
+    act[[cell(0, 2), cell(0, 3), cell(1, 3)]] = 0          # column 1: one full-thickness inactive cell
+    g0 = T.cornerpoint_faces(nx, ny, nz, coord, z.reshape(-1), actnum=act)
+    g = T.cornerpoint_faces(nx, ny, nz, coord, z.reshape(-1), actnum=act, pinch=0.2)
+    comp = {int(cc): q for q, cc in enumerate(g["cart"])}
+    p0, p = _by_pair(g0), _by_pair(g)
+    new = set(p) - set(p0)
+    assert new == {(comp[cell(0, 1)], comp[cell(0, 4)])}     # the 2 m gap of column 1 exceeds the threshold
+    q = p[(comp[cell(0, 1)], comp[cell(0, 4)])]
+    f = g["faces"]
+    assert f["face1"][q] == T.ZP and f["face2"][q] == T.ZM
+    np.testing.assert_allclose(f["area_normal"][q], [0.0, 0.0, 100.0])
+    np.testing.assert_allclose(f["center1"][q][2], 4.0); np.testing.assert_allclose(f["center2"][q][2], 4.1)
+    assert set(p0) <= set(p) and T.cornerpoint_faces(nx, ny, nz, coord, z.reshape(-1), actnum=act, pinch=0.05)["faces"]["cell1"].size == f["cell1"].size - 1
+    # option ALL: the smallest MULTZ on the way down, pinched cells included
+    perm = np.full((g["n"], 3), 1e-13)
+    mz = np.ones(nx * nz); mz[cell(0, 3)] = 0.25; mz[cell(0, 1)] = 0.5
+    base = T.face_transmissibilities(f, g["centroid"], perm)
+    t = T.face_transmissibilities(f, g["centroid"], perm, mult={"Z+": mz[g["cart"]]}, multz_all=dict(cart=g["cart"], nxny=nx * ny, multz=mz))
+    assert t[q] == base[q] * 0.25
