@@ -230,7 +230,7 @@ def sat_from_sum_of_pcs(pcow_of_sw, pcgo_of_sg, swl, swu, target):
 
 
 def equilibrate_regions(eqlnum, records, props, rho_ref, cell_depth, cell_zmin, cell_zmax, sat_limits, grav=9.80665,
-                        rs_funcs=None, rv_funcs=None, nsample=NSAMPLE, swatinit=None):
+                        rs_funcs=None, rv_funcs=None, nsample=NSAMPLE, swatinit=None, cell_zspan=None):
     """InitialStateComputer::calcPressSatRsRv (initstateequil.hh:1882-1940): every equilibration region (EQLNUM, 0-based)
     with its own EQUIL record over the vertical extent of ITS cells.  props / rho_ref / sat_limits / rs_funcs / rv_funcs: one
     per region (list) or one for all.  -> the dict of `equilibrate`, arrays over all cells (zeros where no region applies)"""
@@ -248,18 +248,20 @@ def equilibrate_regions(eqlnum, records, props, rho_ref, cell_depth, cell_zmin, 
             continue
         if rec.get("accuracy", 0) > 0:
             raise ValueError("EQUIL record %d: positive item 9 is not supported (neither is it by the reference)" % (r + 1))
+        zspan = np.stack([cell_zmin[cells], cell_zmax[cells]], axis=1) if cell_zspan is None else np.asarray(cell_zspan, float)[cells]
         span = (float(cell_zmin[cells].min()), float(cell_zmax[cells].max()))
         rs_f = rs_funcs[r] if rs_funcs is not None else None
         rv_f = rv_funcs[r] if rv_funcs is not None else None
         res = equilibrate(per(props, r), per(rho_ref, r), rec, cell_depth[cells], span, per(sat_limits, r), grav=grav,
-                          rs_func=rs_f, nsample=nsample, rv_func=rv_f, swatinit=None if swatinit is None else swatinit[cells])
+                          rs_func=rs_f, nsample=nsample, rv_func=rv_f, swatinit=None if swatinit is None else swatinit[cells],
+                          cell_zspan=zspan)
         for k in out:
             out[k][cells] = res[k]
     return out
 
 
 def equilibrate(props, rho_ref, rec, cell_depth, z_span, sat_limits, grav=9.80665, rs_func=None, nsample=NSAMPLE, rv_func=None,
-                swatinit=None):
+                swatinit=None, cell_zspan=None):
     """props.probe(p, rs, sw, sg) -> (n, 8) (capi.HipFluid layout); rho_ref = (oil, water, gas) surface densities;
     rec = dict(datum, pressure, zwoc, pcow_woc, zgoc, pcgo_goc); cell_depth[]: centre depths; z_span = (top, bottom) of the
     region's cells; sat_limits = dict(Swl, Swu, Sgl, Sgu) (unscaled end points of the saturation tables).
@@ -271,6 +273,9 @@ def equilibrate(props, rho_ref, rec, cell_depth, z_span, sat_limits, grav=9.8066
     opm-material, absent here, restated from its published form: pcow < 0 -> Swu; else Sw = max(Sw, Swl) and, where
     |pcow(Sw)| > 1 Pa, maxPcow *= pcow / pcow(Sw)).  The result then carries "pcw_scale": the factor on the cell's pcow
     curve (scaled maxPcow / table maxPcow), to be handed to the device as PCW = pcw_scale * pcow(Swl) (opmhip_set_pcw).
+    rec["accuracy"] (EQUIL item 9): 0 = cell centres; -N = the average over 2N horizontal slices of each cell between its
+    mean top and mean bottom depth (cell_zspan (n, 2), cellZSpan :1495-1512), Rs / Rv then from the averaged state at the
+    centre depth; positive values are refused, as the reference does.
     -> dict(pw, po, pg, sw, so, sg, rs, rv) arrays over the cells."""
     if rs_func is None:
         if rec["zgoc"] != rec["datum"]:
@@ -293,8 +298,16 @@ def equilibrate(props, rho_ref, rec, cell_depth, z_span, sat_limits, grav=9.8066
         out["pcw_scale"] = np.ones(n)
     const_pcow = abs(pcow_table(Swl) - pcow_table(Swu)) < np.finfo(float).eps
     const_pcgo = abs(pcgo(Sgl) - pcgo(Sgu)) < np.finfo(float).eps
-    for c, z in enumerate(cell_depth):
-        po, pg, pw = oil(z), gas(z), wat(z)
+    acc = int(rec.get("accuracy", 0) or 0)
+    if acc > 0:
+        raise ValueError("EQUIL item 9 > 0 is not supported (neither is it by the reference, initstateequil.hh:1902-1908)")
+    if acc < 0:
+        if cell_zspan is None:
+            raise ValueError("EQUIL item 9 < 0 (horizontal subdivision) needs cell_zspan: (top, bottom) depth of every cell")
+        if swatinit is not None:
+            raise ValueError("SWATINIT together with EQUIL item 9 < 0 is not supported here")
+        cell_zspan = np.asarray(cell_zspan, float).reshape(n, 2)
+    for c, zc in enumerate(cell_depth):
         scale = [1.0]                                   # this cell's factor on the pcow curve (SWATINIT)
         pcow = lambda sw: scale[0] * pcow_table(sw)
 
@@ -306,39 +319,61 @@ def equilibrate(props, rho_ref, rec, cell_depth, z_span, sat_limits, grav=9.8066
             if abs(at_sw) > 1.0:                        # Pascal: no division by a vanishing capillary pressure
                 scale[0] *= pc / at_sw
             return sw_c
-        # water: dPcow/dSw <= 0 ; gas: dPcgo/dSg >= 0
-        if const_pcow:
-            sw = Swl if z < rec["zwoc"] else Swu
-        elif swatinit is not None:
-            sw = apply_swatinit(po - pw, swatinit[c])
-        else:
-            sw = sat_from_pc(pcow, Swl, Swu, po - pw, increasing=False)
-        if const_pcgo:
-            sg = Sgu if z < rec["zgoc"] else Sgl
-        else:
-            sg = sat_from_pc(pcgo, Sgl, Sgu, pg - po, increasing=True)
-        if sg + sw > 1.0:   # overlapping transition zones: gas-water contact, sw from the sum of both capillary pressures
-            pcgw = pg - pw
-            if swatinit is not None:   # the curve is rescaled once more, for a vanishing oil phase (:1229-1235)
-                sw = apply_swatinit(pcgw, sw)
-            sw = root(lambda s: pcow(s) + pcgo(1.0 - s) - pcgw, Swl, Swu)
-            sg = 1.0 - sw
-            po = pg - pcgo(sg)
-        so = 1.0 - sw - sg
-        # pressure corrections at the saturation end points (accountForScaledSaturations)
-        thr = 1.0e-6
-        if sw + thr > Swu:
-            po = pw + pcow(Swu)
-        elif sg + thr > Sgu:
-            po = pg - pcgo(Sgu)
-        if sg - thr < Sgl:
-            pg = po + pcgo(Sgl)
-        if sw - thr < Swl:
-            pw = po - pcow(Swl)
+
+        def at_depth(z):
+            """deriveSaturations + correctedPhasePressures at one depth (initstateequil.hh:1100-1330)"""
+            po, pg, pw = oil(z), gas(z), wat(z)
+            # water: dPcow/dSw <= 0 ; gas: dPcgo/dSg >= 0
+            if const_pcow:
+                sw = Swl if z < rec["zwoc"] else Swu
+            elif swatinit is not None:
+                sw = apply_swatinit(po - pw, swatinit[c])
+            else:
+                sw = sat_from_pc(pcow, Swl, Swu, po - pw, increasing=False)
+            if const_pcgo:
+                sg = Sgu if z < rec["zgoc"] else Sgl
+            else:
+                sg = sat_from_pc(pcgo, Sgl, Sgu, pg - po, increasing=True)
+            if sg + sw > 1.0:   # overlapping transition zones: gas-water contact, sw from the sum of both capillary pressures
+                pcgw = pg - pw
+                if swatinit is not None:   # the curve is rescaled once more, for a vanishing oil phase (:1229-1235)
+                    sw = apply_swatinit(pcgw, sw)
+                sw = root(lambda s: pcow(s) + pcgo(1.0 - s) - pcgw, Swl, Swu)
+                sg = 1.0 - sw
+                po = pg - pcgo(sg)
+            so = 1.0 - sw - sg
+            # pressure corrections at the saturation end points (accountForScaledSaturations)
+            thr = 1.0e-6
+            if sw + thr > Swu:
+                po = pw + pcow(Swu)
+            elif sg + thr > Sgu:
+                po = pg - pcgo(Sgu)
+            if sg - thr < Sgl:
+                pg = po + pcgo(Sgl)
+            if sw - thr < Swl:
+                pw = po - pcow(Swl)
+            return np.array([pw, po, pg, sw, so, sg])
+
+        if acc == 0:     # centre-point method (equilibrateCellCentres :1994-2024)
+            pw, po, pg, sw, so, sg = at_depth(zc)
+        else:            # horizontal subdivision (equilibrateHorizontal :2027-2070): 2 |N| slices of equal thickness between the
+            # cell's mean top and mean bottom depth (subdivisionCentrePoints :1441-1455), weights = thickness
+            top, bot = cell_zspan[c]
+            if top > bot:
+                raise ValueError("negative thickness (inverted top / bottom faces) in cell %d" % c)
+            nint = 2 * (-acc)
+            h = (bot - top) / nint
+            tot = np.zeros(6)
+            totfrac, end = 0.0, top
+            for q in range(nint):
+                start, end = end, top + (q + 1) * h
+                tot = tot + at_depth((start + end) / 2) * h
+                totfrac += h
+            pw, po, pg, sw, so, sg = (tot / totfrac) if totfrac > 0.0 else at_depth(zc)
         out["pw"][c], out["po"][c], out["pg"][c] = pw, po, pg
         out["sw"][c], out["so"][c], out["sg"][c] = sw, so, sg
-        out["rs"][c] = rs_func(z, po, sg)
-        out["rv"][c] = rv_func(z, pg, so) if rv_func is not None else 0.0
+        out["rs"][c] = rs_func(zc, po, sg)
+        out["rv"][c] = rv_func(zc, pg, so) if rv_func is not None else 0.0
         if swatinit is not None:
             out["pcw_scale"][c] = scale[0]
     return out

@@ -333,3 +333,43 @@ def test_swatinit_deck(orc):
     np.testing.assert_array_equal(r["sg"], plain["sg"])
     # and the rescaled state is an equilibrium: p_o - p_w equals the cell's own capillary pressure wherever water is mobile
     np.testing.assert_allclose((r["po"] - r["pw"])[:12], pcow[:12], rtol=1e-12)
+
+
+def test_equil_item_9_horizontal_subdivision(orc):
+    """EQUIL item 9 = -N (equilibrateHorizontal, initstateequil.hh:2027-2070; no deck of the reference uses it, so properties):
+    with sharp contacts a cell that straddles a contact gets the thickness-weighted mix of the two zones, cells inside one zone
+    are what the centre-point method gives, and with a capillary transition zone the slice average closes in on its limit"""
+    rho = (700.0, 1000.0, 1.0)
+    limits = dict(Swl=0.1, Swu=1.0, Sgl=0.0, Sgu=0.9)
+    top = np.array([0.0, 2.0, 4.0, 6.0, 8.0])
+    span = np.stack([top, top + 2.0], axis=1)
+    centre = top + 1.0
+    rec = dict(datum=0.0, pressure=1e7, zwoc=5.3, pcow_woc=0.0, zgoc=0.0, pcgo_goc=0.0, accuracy=0)
+    kw = dict(grav=10.0, rs_func=lambda z, p, sat_gas=0.0: 0.0)
+    r0 = pkg.equil.equilibrate(ConstProps(), rho, rec, centre, (0.0, 10.0), limits, **kw)
+    assert list(r0["sw"]) == [0.1, 0.1, 0.1, 1.0, 1.0]            # cell 2 = [4, 6] has its centre above the contact
+    r5 = pkg.equil.equilibrate(ConstProps(), rho, dict(rec, accuracy=-5), centre, (0.0, 10.0), limits, cell_zspan=span, **kw)
+    np.testing.assert_allclose(r5["sw"], [0.1, 0.1, 0.6 * 0.1 + 0.4 * 1.0, 1.0, 1.0], rtol=1e-14)     # slices at 5.3 ... 5.9 are water
+    np.testing.assert_allclose(r5["so"] + r5["sw"] + r5["sg"], 1.0, rtol=1e-14)
+    for k in ("pw", "po", "pg"):
+        np.testing.assert_allclose(r5[k][[0, 1, 3, 4]], r0[k][[0, 1, 3, 4]], rtol=1e-12)
+    with pytest.raises(ValueError):
+        pkg.equil.equilibrate(ConstProps(), rho, dict(rec, accuracy=-5), centre, (0.0, 10.0), limits, **kw)       # no cell_zspan
+    with pytest.raises(ValueError):
+        pkg.equil.equilibrate(ConstProps(), rho, dict(rec, accuracy=2), centre, (0.0, 10.0), limits, cell_zspan=span, **kw)
+    with pytest.raises(ValueError):
+        pkg.equil.equilibrate(ConstProps(), rho, dict(rec, accuracy=-1), centre, (0.0, 10.0), limits, cell_zspan=span[:, ::-1], **kw)
+    # capillary transition zone (fixture 'capillary'): convergence of the slice average
+    with open(os.path.join(GOLDEN, "equil.json")) as f:
+        d = json.load(f)["capillary"]
+    dz = np.array(d["grid"]["dz"])
+    tp = d["grid"]["tops"] + np.concatenate([[0.0], np.cumsum(dz)[:-1]])
+    lim = dict(Swl=d["swof"][0][0], Swu=d["swof"][-1][0], Sgl=d["sgof"][0][0], Sgu=d["sgof"][-1][0])
+    rh = (d["density"]["oil"], d["density"]["water"], d["density"]["gas"])
+    props = DeadOilProps(oracle_bind.OracleFluid(orc, dead_fluid(d)), d["pvdo"])
+    sw = {}
+    for n in (1, 4, 32):
+        sw[n] = pkg.equil.equilibrate(props, rh, dict(d["equil"], accuracy=-n), tp + 0.5 * dz, (float(tp[0]), float(tp[-1] + dz[-1])), lim,
+                                      grav=d["gravity"], rs_func=lambda z, p, sat_gas=0.0: 0.0, cell_zspan=np.stack([tp, tp + dz], axis=1))["sw"]
+    e1, e4 = np.abs(sw[1] - sw[32]).max(), np.abs(sw[4] - sw[32]).max()
+    assert 0.0 < e4 < 0.3 * e1 and e1 < 0.05       # the profile has kinks (two-row tables): no clean order, but it closes in
