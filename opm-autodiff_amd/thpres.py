@@ -72,10 +72,22 @@ def threshold_pressure_matrix(nreg, records, eqlnum, cell1, cell2, defaults=None
     return out
 
 
-def per_entry(rowptr, col, eqlnum, matrix):
-    """thresholdPressure(I, J) for every block-CSR entry (0 on the diagonal and inside a region)"""
+def per_entry(rowptr, col, eqlnum, matrix, fault_of_cell=None, thpresft=None):
+    """thresholdPressure(I, J) for every block-CSR entry (0 on the diagonal and inside a region).
+    THPRESFT (eclgenericthresholdpressure.cc:77-100, 217-243; behind --enable-experiments in the reference): fault_of_cell
+    (per cell: index of the fault whose face list names the cell, the LAST such THPRESFT record winning, -1 = none) and
+    thpresft (value per fault, Pa).  Two cells of one fault: 0, "even across EQUIL regions"; cells of different faults, or
+    one of them on no fault: the larger of the two faults' values (0 for no fault) - the region table is then not consulted."""
     rowptr, col = np.asarray(rowptr, np.int64), np.asarray(col, np.int64)
     eqlnum = np.asarray(eqlnum, np.int64)
     row = np.repeat(np.arange(len(rowptr) - 1), np.diff(rowptr))
     ri, rj = eqlnum[row], eqlnum[col]
-    return np.where(ri == rj, 0.0, np.asarray(matrix, float)[ri, rj])
+    out = np.where(ri == rj, 0.0, np.asarray(matrix, float)[ri, rj])
+    if thpresft is not None and len(thpresft) > 0:
+        fc, val = np.asarray(fault_of_cell, np.int64), np.asarray(thpresft, float)
+        fi, fj = fc[row], fc[col]
+        vi = np.where(fi >= 0, val[np.maximum(fi, 0)], 0.0)
+        vj = np.where(fj >= 0, val[np.maximum(fj, 0)], 0.0)
+        out = np.where(fi != fj, np.maximum(vi, vj), np.where(fi >= 0, 0.0, out))
+        out = np.where(row == col, 0.0, out)
+    return out

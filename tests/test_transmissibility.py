@@ -343,3 +343,28 @@ def test_cornerpoint_pinch_connections():
     base = T.face_transmissibilities(f, g["centroid"], perm)
     t = T.face_transmissibilities(f, g["centroid"], perm, mult={"Z+": mz[g["cart"]]}, multz_all=dict(cart=g["cart"], nxny=nx * ny, multz=mz))
     assert t[q] == base[q] * 0.25
+
+
+def test_thpresft_overrides_the_region_table():
+    """THPRESFT (eclgenericthresholdpressure.cc:77-100): a row of 6 cells, regions 0 0 0 1 1 1, fault A names cells 1 and 2,
+    fault B names cell 4"""
+    H = pkg.thpres
+    n = 6
+    rowptr = np.concatenate([[0], np.cumsum([2, 3, 3, 3, 3, 2])])
+    col = np.array([0, 1, 0, 1, 2, 1, 2, 3, 2, 3, 4, 3, 4, 5, 4, 5])
+    eql = np.array([0, 0, 0, 1, 1, 1])
+    mat = np.array([[0.0, 7.0e5], [7.0e5, 0.0]])
+    plain = H.per_entry(rowptr, col, eql, mat)
+    entry = lambda a, b: [q for q in range(rowptr[a], rowptr[a + 1]) if col[q] == b][0]
+    assert plain[entry(2, 3)] == plain[entry(3, 2)] == 7.0e5 and np.count_nonzero(plain) == 2
+    fault = np.array([-1, 0, 0, -1, 1, -1])
+    e = H.per_entry(rowptr, col, eql, mat, fault_of_cell=fault, thpresft=[3.0e5, 9.0e5])
+    assert e[entry(0, 1)] == e[entry(1, 0)] == 3.0e5          # fault A against no fault
+    assert e[entry(1, 2)] == 0.0                               # inside fault A
+    assert e[entry(2, 3)] == e[entry(3, 2)] == 3.0e5          # the fault value replaces the region pair's 7e5
+    assert e[entry(3, 4)] == e[entry(4, 5)] == 9.0e5
+    assert all(e[entry(a, a)] == 0.0 for a in range(n))
+    # two cells on no fault keep the region table; an empty THPRESFT changes nothing
+    fault2 = np.array([-1, 0, -1, -1, -1, -1])
+    assert H.per_entry(rowptr, col, eql, mat, fault_of_cell=fault2, thpresft=[3.0e5])[entry(2, 3)] == 7.0e5
+    assert np.array_equal(H.per_entry(rowptr, col, eql, mat, fault_of_cell=fault, thpresft=[]), plain)
