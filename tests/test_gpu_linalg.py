@@ -137,6 +137,26 @@ def test_solve_matches_oracle(pkg, orc, reorder):
     np.testing.assert_allclose(x2, xo2, rtol=1e-9, atol=1e-12)
 
 
+def test_solves_that_stop_on_either_half_iteration(pkg, orc):
+    """The first half's update of x (x += alpha y, bda/cusparseSolverBackend.cu:110) is carried out by the second half's
+    kernel, or by k_bicg_xhalf when the stopping rule is met right after a first half: over a ladder of tolerances both
+    kinds of exit occur and every solution is the oracle's."""
+    Nb, rp, ci, v = laplace_block_system(20, 16, 10, seed=6)
+    b = np.random.default_rng(10).standard_normal(Nb * 3)
+    kinds = set()
+    for tol in (0.5, 0.2, 0.1, 0.05, 0.02, 1e-2, 5e-3, 2e-3, 1e-3, 1e-4, 1e-5, 1e-6):
+        s = pkg.capi.HipSolver(tolerance=tol, maxit=200, reorder="line_coloring")
+        res = s.solve_system(Nb, rp, ci, v.copy(), b)
+        x = s.get_result()
+        xo, ro = oracle_solve_in_order(orc, Nb, rp, ci, v, b, *s.ordering()[:2], tol=tol, maxit=200, w=0.9)
+        assert res.converged and res.it == ro.it
+        np.testing.assert_allclose(x, xo, rtol=1e-9, atol=1e-12)
+        r = b - orc.spmv(Nb, rp, ci, v, x)
+        assert np.linalg.norm(r) < tol * np.linalg.norm(b) * (1 + 1e-9)
+        kinds.add(res.it % 1.0)
+    assert kinds == {0.0, 0.5}
+
+
 def test_irregular_rows_and_long_rows(pkg, orc):
     Nb, rp, ci, v = random_block_system(700, pattern="random", seed=6, extra=5)
     b = np.random.default_rng(1).standard_normal(Nb * 3)
