@@ -130,3 +130,71 @@ def wetgas_case(pkg, nx, ny, nz, rocktab=None, seed=5, **kw):
 
 ROCKTAB_2 = [[[100e5, 0.96, 0.90], [200e5, 0.985, 0.96], [300e5, 1.0, 1.0], [400e5, 1.012, 1.03]],
              [[50e5, 0.90, 0.80], [250e5, 0.99, 0.97], [450e5, 1.03, 1.08]]]
+
+
+# ---- BASELINE configs[4]: a Norne-shaped faulted corner-point grid ------------------------------------------------------------
+def norne_shaped_grid(pkg, seed=17):
+    """46 x 112 x 22 cells (Norne's dimensions) as COORD / ZCORN: a dome with dipping flanks, slightly sheared pillars, three
+    faults (throws of 1 to 4 layers, one of them dying out along its length), a layer pinched out over part of the field and
+    an irregular active region of about 44 000 cells.  Synthetic - the deck itself is not in the reference tree - but with
+    the features that make Norne's connectivity irregular: cells meeting several cells across a fault, missing neighbours,
+    connections across pinched-out layers.  -> (geometry dict of transmissibility.cornerpoint_faces, dims, actnum)"""
+    T = pkg.transmissibility
+    nx, ny, nz = 46, 112, 22
+    rng = np.random.default_rng(seed)
+    dx, dy = 100.0, 100.0
+    ip, jp = np.meshgrid(np.arange(nx + 1), np.arange(ny + 1))            # [jp, ip]
+    xs, ys = ip * dx, jp * dy
+    dome = 2500.0 + 120.0 * (((xs - 2300.0) / 2300.0) ** 2 + ((ys - 5600.0) / 5600.0) ** 2) + 0.01 * xs
+    coord = np.zeros((ny + 1, nx + 1, 6))
+    coord[..., 0], coord[..., 1], coord[..., 2] = xs - 6.0, ys + 4.0, 2300.0      # pillars lean by 12 m / 8 m over 600 m
+    coord[..., 3], coord[..., 4], coord[..., 5] = xs + 6.0, ys - 4.0, 2900.0
+    thick = rng.uniform(3.0, 9.0, nz)
+    thick[9] = 0.02                                                      # the layer that pinches out
+    ztop = np.concatenate([[0.0], np.cumsum(thick)])
+    ci, cj = np.meshgrid(np.arange(nx), np.arange(ny))                    # [j, i] cell indices
+    throw = np.zeros((ny, nx))
+    throw += np.where(ci >= 15, 14.0, 0.0)                                # fault 1: the whole length
+    throw += np.where((ci >= 30), -22.0 * np.clip((cj - 20) / 60.0, 0.0, 1.0), 0.0)   # fault 2: grows from nothing along j
+    throw += np.where((cj >= 70) & (ci >= 8), 9.0, 0.0)                   # fault 3: across, ends inside the field
+    z = np.zeros((nz, 2, ny, 2, nx, 2))
+    for jj in range(2):
+        for ii in range(2):
+            surf = dome[jj:jj + ny, ii:ii + nx] + throw                   # depth of the top surface at this corner's pillar
+            for kk in range(2):
+                z[:, kk, :, jj, :, ii] = surf[None, :, :] + ztop[kk:kk + nz, None, None]
+    act = np.ones((nz, ny, nx), bool)
+    blob = ((ci - 22.0) / 21.0) ** 2 + ((cj - 55.0) / 54.0) ** 2 + 0.08 * np.sin(ci / 3.0) * np.cos(cj / 5.0) < 0.665
+    act &= blob[None, :, :]
+    act[:3] &= (((ci - 20.0) / 12.0) ** 2 + ((cj - 50.0) / 30.0) ** 2 < 1.0)[None, :, :]   # the top layers only over the crest
+    act[9] = False                                                        # pinched out everywhere (0.02 m)
+    act[15, 40:, :20] = False                                             # a thick inactive patch: a real barrier
+    act &= rng.random((nz, ny, nx)) > 0.01                                # scattered inactive cells
+    g = T.cornerpoint_faces(nx, ny, nz, coord.reshape(-1, 6), z.reshape(-1), actnum=act.reshape(-1), max_fault_throw=6, pinch=0.5)
+    return g, (nx, ny, nz), act.reshape(-1)
+
+
+def norne_shaped_case(pkg, seed=17):
+    """the grid above with log-normal permeabilities, NTG, a MULTZ barrier, the SPE1 fluid and a gas cap over undersaturated
+    oil in hydrostatic-like pressure: a case dict for capi.HipModel / oracle_bind.OracleModel"""
+    T = pkg.transmissibility
+    g, dims, act = norne_shaped_grid(pkg, seed)
+    n, F = g["n"], g["faces"]
+    rng = np.random.default_rng(seed + 1)
+    perm = np.exp(rng.normal(np.log(200.0), 1.0, (n, 1))) * np.array([1.0, 1.0, 0.1]) * 9.869233e-16
+    lay = g["cart"] // (dims[0] * dims[1])
+    multz = np.where(lay == 14, 0.01, 1.0)
+    t = T.face_transmissibilities(F, g["centroid"], perm, ntg=rng.uniform(0.5, 1.0, n), mult={"Z+": multz})
+    pat = T.connections_to_pattern(n, F["cell1"], F["cell2"], t, g["face_area"])
+    fl = pkg.fluid.spe1_fluid()[0]
+    depth = g["depth"]
+    p = 250e5 + 7000.0 * (depth - depth.min()) * (1.0 + rng.uniform(-0.005, 0.005, n))
+    meaning = np.where(depth < np.quantile(depth, 0.3), pkg.decks.SW_PO_SG, pkg.decks.SW_PO_RS).astype(np.uint8)
+    pv = np.zeros((n, 3))
+    pv[:, 0] = 0.2 + rng.uniform(-0.02, 0.02, n)
+    pv[:, 1] = p
+    pv[:, 2] = np.where(meaning == pkg.decks.SW_PO_SG, 0.1 + rng.uniform(-0.02, 0.02, n), 0.8 * pkg.decks.rs_sat(fl, p))
+    case = dict(Nb=n, rowptr=pat["rowptr"], col=pat["col"], trans=pat["trans"], area=pat["area"], poro=rng.uniform(0.15, 0.3, n),
+                volume=np.ascontiguousarray(g["volume"]), depth=np.ascontiguousarray(depth), fluid=fl,
+                pv=np.ascontiguousarray(pv.reshape(-1)), meaning=meaning)
+    return case, g, dims

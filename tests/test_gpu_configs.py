@@ -3,13 +3,15 @@ themselves are not in the reference tree):
   configs[2] "SPE9 (9000-cell, 25 wells, heterogeneous perm) - well-coupling + ILU0 correctness vs CPU":
              24 x 25 x 15 heterogeneous grid, 26 standard wells (B, C, D^-1 blocks) in the operator;
   configs[4] "Norne (faulted corner-point grid, ~44k active cells) - irregular connectivity stress test":
-             44 431 rows with 4..12 blocks per row and 2 % long-range NNC couplings, rng(7).
+             44 431 rows with 4..12 blocks per row and 2 % long-range NNC couplings, rng(7) (linear algebra and assembly on a
+             random graph), and a Norne-SHAPED corner-point grid - 46 x 112 x 22, dome, sheared pillars, three faults, a pinched
+             layer, ~44 800 active cells - whose connections and transmissibilities come from transmissibility.py.
 Bit-exact where the arithmetic is per row / per face, iteration counts equal, solutions to the stated tolerance."""
 import numpy as np
 import pytest
 
 import oracle_bind
-from helpers import oracle_solve_in_order
+from helpers import norne_shaped_case, oracle_solve_in_order
 
 pytestmark = pytest.mark.gpu
 REORDERS = ["level_scheduling", "graph_coloring", "graph_coloring_greedy", "line_coloring"]
@@ -187,6 +189,47 @@ def test_norne_like_assembly_bitwise(pkg, orc, norne, reorder):
             m.update(None, 1.0)
             o.update(xo)
     np.testing.assert_allclose(m.convergence(86400.0)[11:17], o.convergence(86400.0)[11:17], rtol=1e-6, atol=1e-12)
+
+
+@pytest.fixture(scope="module")
+def norne_grid(pkg):
+    return norne_shaped_case(pkg)
+
+
+@pytest.mark.parametrize("reorder", ["graph_coloring", "line_coloring"])
+def test_norne_shaped_corner_point_grid(pkg, orc, norne_grid, reorder):
+    """configs[4] with geometry: the faulted, pinched, partly inactive corner-point grid of helpers.norne_shaped_grid through
+    set_pattern / set_static, then what a Newton iteration does - intensive quantities, Jacobian and residual bit for bit,
+    the ILU0 factors bit for bit, the solve with the same number of half iterations, update, second assembly."""
+    case, g, dims = norne_grid
+    n = case["Nb"]
+    rl = np.diff(case["rowptr"])
+    F = g["faces"]
+    lay = g["cart"] // (dims[0] * dims[1])
+    lat = F["face1"] < 4
+    assert 44000 < n < 46000 and rl.min() >= 2 and rl.max() >= 11
+    assert (lay[F["cell1"]][lat] != lay[F["cell2"]][lat]).sum() > 10000        # cells meeting other layers across the faults
+    assert ((lay[F["cell2"]] - lay[F["cell1"]])[~lat] > 1).sum() > 2000        # connections across the pinched-out layer
+    m = pkg.capi.HipModel(case, reorder=reorder)
+    o = oracle_bind.OracleModel(orc, case)
+    m.set_state(case["pv"], case["meaning"])
+    o.set_state(case["pv"], case["meaning"])
+    assert np.array_equal(m.iq(), o.iq())
+    dt = 86400.0
+    jm, rm = m.assemble(dt, 0)
+    jo, ro = o.assemble(dt, 0)
+    assert np.array_equal(rm, ro) and np.array_equal(jm, jo)
+    res = m.solve_jacobian_system()
+    xo, reso = o.solve_in_order(*m.ordering()[:2], tol=1e-2, maxit=200, w=0.9)
+    assert res.converged and reso.converged and res.it == reso.it
+    np.testing.assert_allclose(m.get_result(), xo, rtol=1e-8, atol=1e-12 * np.abs(xo).max())
+    m.update(None, 1.0)
+    o.update(xo)
+    jm, rm = m.assemble(dt, 1)
+    jo, ro = o.assemble(dt, 1)
+    np.testing.assert_allclose(rm, ro, rtol=1e-6, atol=1e-9 * np.abs(ro).max())
+    np.testing.assert_allclose(jm, jo, rtol=1e-5, atol=1e-9 * np.abs(jo).max())
+    np.testing.assert_allclose(m.convergence(dt)[11:17], o.convergence(dt)[11:17], rtol=1e-6, atol=1e-12)
 
 
 def test_spe9_shaped_well_residual_and_recovery(pkg, orc):
