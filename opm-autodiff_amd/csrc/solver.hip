@@ -97,6 +97,23 @@ __device__ __forceinline__ void blk_mmv(const double* A, const double x0, const 
     y[1] -= A[3] * x0; y[1] -= A[4] * x1; y[1] -= A[5] * x2;
     y[2] -= A[6] * x0; y[2] -= A[7] * x1; y[2] -= A[8] * x2;
 }
+// The same with the block known to live in LDS.  The pointer carries its address space in its type, so that the compiler
+// can neither treat it as "flat" nor merge this path with the global-memory one behind a single flat pointer (it does
+// that to two branches that differ in nothing but the pointer): a flat load makes the wavefront wait for EVERY outstanding
+// memory access - in the pipelined sweeps that is the prefetch of the next step.
+typedef __attribute__((address_space(3))) const double lds_cdouble;
+__device__ __forceinline__ void blk_mmv_lds(const double* Agen, const double x0, const double x1, const double x2, double* y) {
+    lds_cdouble* A = (lds_cdouble*)Agen;
+    y[0] -= A[0] * x0; y[0] -= A[1] * x1; y[0] -= A[2] * x2;
+    y[1] -= A[3] * x0; y[1] -= A[4] * x1; y[1] -= A[5] * x2;
+    y[2] -= A[6] * x0; y[2] -= A[7] * x1; y[2] -= A[8] * x2;
+}
+__device__ __forceinline__ void blk_umv_lds(const double* Agen, const double x0, const double x1, const double x2, double* y) {
+    lds_cdouble* A = (lds_cdouble*)Agen;
+    y[0] += A[0] * x0; y[0] += A[1] * x1; y[0] += A[2] * x2;
+    y[1] += A[3] * x0; y[1] += A[4] * x1; y[1] += A[5] * x2;
+    y[2] += A[6] * x0; y[2] += A[7] * x1; y[2] += A[8] * x2;
+}
 __device__ __forceinline__ void blk_umv(const double* A, const double x0, const double x1, const double x2, double* y) {
     y[0] += A[0] * x0; y[0] += A[1] * x1; y[0] += A[2] * x2;
     y[1] += A[3] * x0; y[1] += A[4] * x1; y[1] += A[5] * x2;
@@ -181,6 +198,10 @@ template <bool SUB>
 __device__ __forceinline__ void blk_apply(const double* A, const double* xx, double* acc) {
     if (SUB) blk_mmv(A, xx[0], xx[1], xx[2], acc); else blk_umv(A, xx[0], xx[1], xx[2], acc);
 }
+template <bool SUB>
+__device__ __forceinline__ void blk_apply_lds(const double* A, const double* xx, double* acc) {
+    if (SUB) blk_mmv_lds(A, xx[0], xx[1], xx[2], acc); else blk_umv_lds(A, xx[0], xx[1], xx[2], acc);
+}
 
 // Accumulates acc (+/-)= sum_k A_k x[col_k] over the lane's row of tile t, blocks taken in ascending (or, with
 // reverse, descending) column order.  Returns the lane's row index or -1 for an idle lane.  Contains a barrier.
@@ -264,13 +285,16 @@ __device__ __forceinline__ int tile_row_product(int tr0, int tr1, const int* __r
     }
     wave_sync();
     if (!active) return -1;
+    const bool stagedU = __builtin_amdgcn_readfirstlane((int)T.staged) != 0;   // the same in every lane: a scalar branch
     // first chunk
 #pragma unroll
     for (int u = 0; u < GCH; ++u) {
         if (u < nrow) {
             const int k = reverse ? ke - 1 - u : kb + u;
-            const double* A = T.staged ? &sval[(k - T.k0e) * BB] : &val[(size_t)k * BB];
-            blk_apply<SUB>(A, xx[u], acc);
+            // two branches, not one pointer chosen between LDS and global memory: such a pointer is "flat", and a flat load
+            // makes the wavefront wait for EVERY outstanding memory access, the prefetched next tile included
+            if (stagedU) blk_apply_lds<SUB>(&sval[(k - T.k0e) * BB], xx[u], acc);
+            else blk_apply<SUB>(&val[(size_t)k * BB], xx[u], acc);
         }
     }
     // rows longer than one chunk
@@ -287,8 +311,8 @@ __device__ __forceinline__ int tile_row_product(int tr0, int tr1, const int* __r
         for (int u = 0; u < GCH; ++u) {
             if (done + u < nrow) {
                 const int k = reverse ? ke - 1 - (done + u) : kb + done + u;
-                const double* A = T.staged ? &sval[(k - T.k0e) * BB] : &val[(size_t)k * BB];
-                blk_apply<SUB>(A, xx[u], acc);
+                if (stagedU) blk_apply_lds<SUB>(&sval[(k - T.k0e) * BB], xx[u], acc);
+                else blk_apply<SUB>(&val[(size_t)k * BB], xx[u], acc);
             }
         }
     }
@@ -683,7 +707,7 @@ __device__ __forceinline__ void chain_sweep(const int nsteps, const int lane, do
 #pragma unroll
         for (int u = 0; u < U; ++u) asm volatile("" : "+v"(b.tmp[u].x), "+v"(b.tmp[u].y));
         const int r = b.r, kb = b.kb, ke = b.ke, k0e = b.k0e, n = b.n, n2 = b.n2;
-        const bool staged = b.staged;
+        const bool staged = __builtin_amdgcn_readfirstlane((int)b.staged) != 0;   // the same in every lane (it comes from the descriptor record)
         double rhs[3] = {b.rhs[0], b.rhs[1], b.rhs[2]};
         double Di[BB];
         int cc[CGCH];
@@ -735,8 +759,10 @@ __device__ __forceinline__ void chain_sweep(const int nsteps, const int lane, do
             for (int u = 0; u < CGCH; ++u) {
                 if (u < nrow) {
                     const int k = reverse ? ke - 1 - u : kb + u;
-                    const double* A = staged ? &sval[(k - k0e) * BB] : &P[(size_t)k * BB];
-                    blk_mmv(A, xx[u][0], xx[u][1], xx[u][2], rhs);
+                    // LDS or global memory by a (scalar) branch, never by one pointer: a pointer that may be either is "flat",
+                    // and a flat load waits for every outstanding memory access - the next step's prefetch included
+                    if (staged) blk_mmv_lds(&sval[(k - k0e) * BB], xx[u][0], xx[u][1], xx[u][2], rhs);
+                    else blk_mmv(&P[(size_t)k * BB], xx[u][0], xx[u][1], xx[u][2], rhs);
                 }
             }
             for (int done = CGCH; done < nrow; done += CGCH) {  // rows longer than one chunk: everything read now
@@ -752,8 +778,8 @@ __device__ __forceinline__ void chain_sweep(const int nsteps, const int lane, do
                 for (int u = 0; u < CGCH; ++u) {
                     if (done + u < nrow) {
                         const int k = reverse ? ke - 1 - (done + u) : kb + done + u;
-                        const double* A = staged ? &sval[(k - k0e) * BB] : &P[(size_t)k * BB];
-                        blk_mmv(A, yy[u][0], yy[u][1], yy[u][2], rhs);
+                        if (staged) blk_mmv_lds(&sval[(k - k0e) * BB], yy[u][0], yy[u][1], yy[u][2], rhs);
+                        else blk_mmv(&P[(size_t)k * BB], yy[u][0], yy[u][1], yy[u][2], rhs);
                     }
                 }
             }
