@@ -620,109 +620,134 @@ __device__ __forceinline__ void chain_sweep(const int nsteps, const int lane, do
     //   A(st+3): row bounds      C(st+2): column indices      G(st+1): value stream, vector gathers, right-hand side, D^-1
     //   X(st)  : values -> LDS, products in the row's sequential order, store
     auto tile_of = [&](int st) { return (SHAPE == SW_UF) ? nsteps - 1 - st : st; };
-    struct StA { int rr, kb, ke; bool active; };
-    struct StC { int rr, kb, ke; bool active; int cc[CGCH]; };
-    struct StG {
-        int r, kb, ke, k0e, n, n2;
+    // What a step needs is loaded in four stages, each into registers of its own:
+    //   A  row bounds (3 steps ahead)   C  column indices (2 ahead)   M  the small per-row items: right-hand side, vector
+    //   entries of the other columns, D^-1, and the row bounds once more (1 ahead)   S  the value stream (1 ahead)
+    // Every load targets registers whose previous content is dead when the load is issued, and NO loaded register is ever
+    // copied into another one that lives across the loop: a copy of a register whose load is still in flight makes the
+    // wavefront wait for it - and the newest load is the last to arrive, so that wait drains everything.  (A pipeline
+    // written with "next" and "current" copies of one struct, or one that hands the row bounds on from stage to stage, ends
+    // every step in s_waitcnt vmcnt(0): rocprofv3 showed 36 % of the wavefront cycles in s_waitcnt.)  Hence: a stage never
+    // passes loaded values on; what a later stage needs again it loads again (the row bounds: a cache hit) or receives
+    // as something COMPUTED from them when they were consumed (the masks `late` and `mine`).
+    struct StA { int kb, ke; };
+    struct StS {
+        int k0e, n, n2;
         bool staged;
-        int cc[CGCH];
-        unsigned late;          // bit u set: column cc[u] lies inside this chain-tile (written by an earlier step)
-        double xx[CGCH][3];     // vector entries of the other columns, fetched one step ahead
-        double rhs[3], Di[BB];
         double2 tmp[U];
     };
+    struct StM {
+        int kb, ke;             // loaded
+        unsigned late;          // bit u set: column u lies inside this chain-tile (written by an earlier step of this sweep)
+        unsigned mine;          // bit u set: column u is the row this lane finished one step earlier (its result is in registers)
+        double xx[CGCH][3];     // vector entries of the other columns
+        double rhs[3], Di[BB];
+    };
     const int ctR0 = srow0[0], ctR1 = srow0[nsteps];  // rows of this chain-tile
-    auto stageA = [&](int st, StA& a) {
+    auto clampst = [&](int st) { return st < nsteps ? st : nsteps - 1; };
+    auto row_of = [&](int st, bool& active) {   // the lane's row in step st (clamped to the step's last row when idle): LDS only
         const int ti = tile_of(st);
         const int r0 = srow0[ti], r1 = srow0[ti + 1];
-        a.active = r0 + lane < r1;
-        a.rr = a.active ? r0 + lane : r1 - 1;
-        a.kb = prow[a.rr];
-        a.ke = prow[a.rr + 1];
+        active = r0 + lane < r1;
+        return active ? r0 + lane : r1 - 1;
     };
-    auto stageC = [&](const StA& a, StC& c) {
-        c.rr = a.rr; c.kb = a.kb; c.active = a.active;
-        c.ke = a.active ? a.ke : a.kb;
-        const int nrow = c.ke - c.kb;
+    auto stageA = [&](int st, StA& a) {
+        bool act;
+        const int rr = row_of(st, act);
+        a.kb = prow[rr];
+        a.ke = prow[rr + 1];
+    };
+    // (loads are issued unconditionally, idle slots and steps past the end reading some valid entry again: a load under a
+    //  condition gives the two paths different numbers of outstanding loads, and every wait after their join then has to
+    //  assume the smaller one - it waits for more than it needs, in the end for everything)
+    auto stageC = [&](int st, const StA& a, int (&cc)[CGCH], unsigned& valid) {   // a = row bounds of step st
+        bool act;
+        (void)row_of(st, act);
+        const int nrow = act ? a.ke - a.kb : 0;
+        const int spare = a.kb > 0 ? a.kb - 1 : 0;   // a valid entry whatever the row looks like (the array holds >= 1)
+        valid = 0u;
 #pragma unroll
         for (int u = 0; u < CGCH; ++u) {
-            const int k = reverse ? c.ke - 1 - u : c.kb + u;
-            c.cc[u] = (u < nrow) ? pcol[k] : -1;
+            const int k = reverse ? a.ke - 1 - u : a.kb + u;
+            cc[u] = pcol[(u < nrow) ? k : spare];
+            if (u < nrow) valid |= 1u << u;
         }
     };
-    auto stageG = [&](int st, const StC& c, StG& b) {
-        const int ti = tile_of(st);
+    auto stageGs = [&](int st, StS& b) {   // the value stream of step st; st == nsteps: nothing but one line, read 12 times
+        const int ti = tile_of(clampst(st));
         const int k0 = sk0[ti], k1 = sk0[ti + 1];
         b.k0e = k0 & ~1;
         const int nb = k1 - b.k0e;
         b.staged = nb <= TILE_CAP_BLOCKS + 1;
         b.n = nb * BB;
         b.n2 = b.n >> 1;
-        b.r = c.active ? c.rr : -1;
-        b.kb = c.kb;
-        b.ke = c.ke;
-        if (b.staged && b.n2 > 0) {  // the bulk of the bytes first: they are needed first
-            const double2* __restrict__ s2 = reinterpret_cast<const double2*>(P + (size_t)b.k0e * BB);
+        const int lim = (st < nsteps && b.staged && b.n2 > 0) ? b.n2 - 1 : 0;   // (an unstaged or empty step: the same single line)
+        const double2* __restrict__ s2 = reinterpret_cast<const double2*>(P + (size_t)b.k0e * BB);
 #pragma unroll
-            for (int u = 0; u < U; ++u) {
-                const int i = u * 64 + lane;
-                b.tmp[u] = ld_stream(&s2[i < b.n2 ? i : b.n2 - 1]);
-            }
+        for (int u = 0; u < U; ++u) {
+            const int i = u * 64 + lane;
+            b.tmp[u] = ld_stream(&s2[i < lim ? i : lim]);
         }
+    };
+    auto stageGm = [&](int st, const int (&cc)[CGCH], unsigned valid, int prevRow, StM& b) {   // cc = column indices of step st
+        bool act;
+        const int rr = row_of(st, act);
+        b.kb = prow[rr];
+        b.ke = prow[rr + 1];
         const double* rsrc = (SHAPE == SW_L) ? d : vu;  // the lane's own row: no earlier step of this sweep writes it
-        b.rhs[0] = rsrc[(size_t)c.rr * BS]; b.rhs[1] = rsrc[(size_t)c.rr * BS + 1]; b.rhs[2] = rsrc[(size_t)c.rr * BS + 2];
-        b.late = 0u;
+        b.rhs[0] = rsrc[(size_t)rr * BS]; b.rhs[1] = rsrc[(size_t)rr * BS + 1]; b.rhs[2] = rsrc[(size_t)rr * BS + 2];
+        b.late = 0u; b.mine = 0u;
 #pragma unroll
         for (int u = 0; u < CGCH; ++u) {
-            const int cq = c.cc[u];
-            b.cc[u] = cq;
-            const bool inside = cq >= ctR0 && cq < ctR1;
+            const int cq = cc[u];
+            const bool used = (valid >> u) & 1u;
+            const bool inside = used && cq >= ctR0 && cq < ctR1;
             if (inside) b.late |= 1u << u;
-            const double* xc = &vu[(size_t)((cq < 0 || inside) ? c.rr : cq) * BS];  // harmless own-row address when unused
+            if (used && cq == prevRow) b.mine |= 1u << u;
+            const double* xc = &vu[(size_t)((!used || inside) ? rr : cq) * BS];  // harmless own-row address when unused or read later
             b.xx[u][0] = xc[0]; b.xx[u][1] = xc[1]; b.xx[u][2] = xc[2];
         }
+        // the masks exist HERE: left to itself the compiler forms them where they are used (the next step), which keeps the
+        // column indices alive past the loads that refill their registers - and costs the copies this pipeline avoids
+        asm volatile("" : "+v"(b.late), "+v"(b.mine));
         if (SHAPE != SW_L) {
 #pragma unroll
-            for (int q = 0; q < BB; ++q) b.Di[q] = invD[(size_t)c.rr * BB + q];
+            for (int q = 0; q < BB; ++q) b.Di[q] = invD[(size_t)rr * BB + q];
         }
     };
     StA a;
-    StC c;
-    StG b;
+    int cc[CGCH];
+    unsigned ccValid;
+    StS sb;
+    StM m;
     int myPrevRow = -1;           // the row this lane finished in the previous step, and its result
     double myPrev[3] = {0.0, 0.0, 0.0};
     {   // prologue: the row bounds of the first three steps in ONE round of loads, the column indices of the first two in
-        // the next, then the first value stream - three dependent rounds instead of six
+        // the next, then the first value stream and the first step's small items - three dependent rounds instead of six
+        // - and in the loop's own order of issue (stream, small items, column indices, row bounds): the compiler's
+        // bookkeeping of outstanding loads merges this path with the loop's back edge, and where the two disagree about
+        // which load is older it has to assume the worse
         StA a0, a1;
-        StC c0;
+        int c0[CGCH];
+        unsigned v0;
         stageA(0, a0);
-        if (nsteps > 1) stageA(1, a1);
-        if (nsteps > 2) stageA(2, a);
-        stageC(a0, c0);
-        if (nsteps > 1) stageC(a1, c);
-        stageG(0, c0, b);
+        stageA(clampst(1), a1);
+        stageC(0, a0, c0, v0);
+        stageGs(0, sb);
+        stageGm(0, c0, v0, -1, m);
+        stageC(clampst(1), a1, cc, ccValid);
+        stageA(clampst(2), a);
     }
     for (int st = 0; st < nsteps; ++st) {
         // ---- X(st), part 1: commit the prefetched values to LDS
-#pragma unroll
-        for (int u = 0; u < U; ++u) asm volatile("" : "+v"(b.tmp[u].x), "+v"(b.tmp[u].y));
-        const int r = b.r, kb = b.kb, ke = b.ke, k0e = b.k0e, n = b.n, n2 = b.n2;
-        const bool staged = __builtin_amdgcn_readfirstlane((int)b.staged) != 0;   // the same in every lane (it comes from the descriptor record)
-        double rhs[3] = {b.rhs[0], b.rhs[1], b.rhs[2]};
-        double Di[BB];
-        int cc[CGCH];
-        double xx[CGCH][3];
-        const unsigned late = b.late;
-#pragma unroll
-        for (int q = 0; q < BB; ++q) Di[q] = b.Di[q];
-#pragma unroll
-        for (int u = 0; u < CGCH; ++u) { cc[u] = b.cc[u]; xx[u][0] = b.xx[u][0]; xx[u][1] = b.xx[u][1]; xx[u][2] = b.xx[u][2]; }
+        const int k0e = sb.k0e, n = sb.n, n2 = sb.n2;
+        const bool staged = __builtin_amdgcn_readfirstlane((int)sb.staged) != 0;   // the same in every lane (it comes from the descriptor record)
         double2* d2 = reinterpret_cast<double2*>(sval);
         if (staged && n2 > 0) {
 #pragma unroll
             for (int u = 0; u < U; ++u) {
                 const int i = u * 64 + lane;
-                if (i < n2) d2[i] = b.tmp[u];
+                if (i < n2) d2[i] = sb.tmp[u];
             }
             const double2* __restrict__ s2 = reinterpret_cast<const double2*>(P + (size_t)k0e * BB);
             for (int base = 64 * U; base < n2; base += 64)  // steps larger than one batch (irregular rows): plain copy
@@ -730,39 +755,35 @@ __device__ __forceinline__ void chain_sweep(const int nsteps, const int lane, do
             if ((n & 1) && lane == 0) sval[n - 1] = P[(size_t)k0e * BB + n - 1];
         }
         wave_sync();
-        // ---- G(st+1), C(st+2) and A(st+3) go out now and fly during this step's work
-        if (st + 1 < nsteps) {
-            stageG(st + 1, c, b);
-            if (st + 2 < nsteps) {
-                stageC(a, c);
-                if (st + 3 < nsteps) stageA(st + 3, a);
-            }
-        }
+        // ---- the next step's value stream goes out now (its registers are free again) and flies during this step's work
+        stageGs(st + 1, sb);
         // ---- X(st), part 2: the few columns inside this chain-tile are read now (the previous step wrote them; the
         //      lane's own previous row comes straight from registers), products in the row's sequential order, store
+        bool active;
+        const int rrow = row_of(st, active);
+        const int r = active ? rrow : -1;
         if (r >= 0) {
+            const int kb = m.kb, ke = m.ke;
             const int nrow = ke - kb;
+            const unsigned used = (nrow >= CGCH) ? ((1u << CGCH) - 1u) : ((1u << nrow) - 1u);
             // a column inside this chain-tile that is NOT the lane's own previous row must come from memory: make sure
             // the previous step's stores have completed first (never taken on a line-coloured 7-point stencil)
-            bool fromMem = false;
-#pragma unroll
-            for (int u = 0; u < CGCH; ++u) fromMem |= (u < nrow && ((late >> u) & 1u) && cc[u] != myPrevRow);
+            const bool fromMem = (m.late & ~m.mine & used) != 0u;
             if (__any(fromMem || nrow > CGCH)) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-#pragma unroll
-            for (int u = 0; u < CGCH; ++u) {
-                if (u < nrow && ((late >> u) & 1u)) {
-                    if (cc[u] == myPrevRow) { xx[u][0] = myPrev[0]; xx[u][1] = myPrev[1]; xx[u][2] = myPrev[2]; }
-                    else { const double* xc = &vu[(size_t)cc[u] * BS]; xx[u][0] = coherent_load(xc); xx[u][1] = coherent_load(xc + 1); xx[u][2] = coherent_load(xc + 2); }
-                }
-            }
+            double rhs[3] = {m.rhs[0], m.rhs[1], m.rhs[2]};
 #pragma unroll
             for (int u = 0; u < CGCH; ++u) {
                 if (u < nrow) {
+                    double x0 = m.xx[u][0], x1 = m.xx[u][1], x2 = m.xx[u][2];
                     const int k = reverse ? ke - 1 - u : kb + u;
+                    if ((m.late >> u) & 1u) {
+                        if ((m.mine >> u) & 1u) { x0 = myPrev[0]; x1 = myPrev[1]; x2 = myPrev[2]; }
+                        else { const double* xc = &vu[(size_t)pcol[k] * BS]; x0 = coherent_load(xc); x1 = coherent_load(xc + 1); x2 = coherent_load(xc + 2); }
+                    }
                     // LDS or global memory by a (scalar) branch, never by one pointer: a pointer that may be either is "flat",
                     // and a flat load waits for every outstanding memory access - the next step's prefetch included
-                    if (staged) blk_mmv_lds(&sval[(k - k0e) * BB], xx[u][0], xx[u][1], xx[u][2], rhs);
-                    else blk_mmv(&P[(size_t)k * BB], xx[u][0], xx[u][1], xx[u][2], rhs);
+                    if (staged) blk_mmv_lds(&sval[(k - k0e) * BB], x0, x1, x2, rhs);
+                    else blk_mmv(&P[(size_t)k * BB], x0, x1, x2, rhs);
                 }
             }
             for (int done = CGCH; done < nrow; done += CGCH) {  // rows longer than one chunk: everything read now
@@ -788,7 +809,7 @@ __device__ __forceinline__ void chain_sweep(const int nsteps, const int lane, do
                 myPrev[0] = rhs[0]; myPrev[1] = rhs[1]; myPrev[2] = rhs[2];
             } else {
                 double out[3] = {0.0, 0.0, 0.0};
-                blk_umv(Di, rhs[0], rhs[1], rhs[2], out);
+                blk_umv(m.Di, rhs[0], rhs[1], rhs[2], out);
                 if (relax_mode == 1) { out[0] = w * out[0]; out[1] = w * out[1]; out[2] = w * out[2]; }
                 vu[(size_t)r * BS] = out[0]; vu[(size_t)r * BS + 1] = out[1]; vu[(size_t)r * BS + 2] = out[2];
                 if (v != vu) { v[(size_t)r * BS] = w * out[0]; v[(size_t)r * BS + 1] = w * out[1]; v[(size_t)r * BS + 2] = w * out[2]; }
@@ -797,6 +818,19 @@ __device__ __forceinline__ void chain_sweep(const int nsteps, const int lane, do
             myPrevRow = r;
         }
         wave_sync();  // this step's results are visible to the next step; LDS image may be overwritten
+        // ---- the next step's small items into the registers this step has just finished with, then the column indices
+        //      and row bounds further ahead into theirs (unconditionally, past the end with the last step's indices again -
+        //      a few loads that hit the cache: a condition here would make each of these registers a merge of "old" and
+        //      "newly loaded", which the compiler resolves with copies at the end of the loop body)
+        //      The scheduling barriers keep each stage's last use of its input registers in front of the loads that refill
+        //      them - interleaved by the instruction scheduler, old and new values would overlap and need copies again.
+        __builtin_amdgcn_sched_barrier(0);
+        stageGm(clampst(st + 1), cc, ccValid, myPrevRow, m);
+        __builtin_amdgcn_sched_barrier(0);
+        stageC(clampst(st + 2), a, cc, ccValid);
+        __builtin_amdgcn_sched_barrier(0);
+        stageA(clampst(st + 3), a);
+        __builtin_amdgcn_sched_barrier(0);
     }
 }
 // Light sweep of a chain tile: every row's part of the factor is at most ONE block, the one towards the row the same
