@@ -847,72 +847,90 @@ __device__ __forceinline__ void chain_sweep_light(const int nsteps, const int la
                                                   const int* __restrict__ pcol, const double* __restrict__ P,
                                                   const double* __restrict__ invD, const double* d, double* vu, double* v,
                                                   int relax_mode, double w) {
+    // Written by the rules chain_sweep's comment lists: every load unconditional, into registers whose content is dead,
+    // nothing loaded ever copied, and no load consumed while it is the newest one outstanding (waiting for the newest
+    // load means waiting for all of them - and, the counter being in order, waiting for a load issued k steps ago means
+    // waiting for everything older, so the prefetch is only as deep as its shortest dependency).  The row bounds of step
+    // st + 2 D are therefore requested D steps before the stage that turns them into addresses, into one of D register
+    // pairs; steps past the end repeat one address.
     constexpr int D = LIGHT_DEPTH;
     auto tile_of = [&](int st) { return (SHAPE == SW_UF) ? nsteps - 1 - st : st; };
-    struct StA { int rr, kb, ke; bool active; };
+    struct StA { int kb, ke; };
     struct StB {
-        int r, cq;
-        bool has;
+        int kb, ke;       // loaded again with the rest (a cache hit): what a stage needs later it does not inherit as a copy
+        int cq;
         double blk[BB], rhs[3], Di[BB];
     };
-    auto stageA = [&](int st, StA& a) {
+    auto row_of = [&](int st, bool& active) {   // LDS only; past the end: the tile's first row for every lane (one line)
+        if (st >= nsteps) { active = false; return srow0[0]; }
         const int ti = tile_of(st);
         const int r0 = srow0[ti], r1 = srow0[ti + 1];
-        a.active = r0 + lane < r1;
-        a.rr = a.active ? r0 + lane : r1 - 1;
-        a.kb = prow[a.rr];
-        a.ke = prow[a.rr + 1];
+        active = r0 + lane < r1;
+        return active ? r0 + lane : r1 - 1;
     };
-    auto stageB = [&](const StA& a, StB& b) {
-        b.r = a.active ? a.rr : -1;
-        b.has = a.active && a.ke > a.kb;
-        const int k = b.has ? a.kb : 0;   // any valid entry: loaded, not used
+    auto stageA = [&](int st, StA& a) {
+        bool act;
+        const int rr = row_of(st, act);
+        a.kb = prow[rr];
+        a.ke = prow[rr + 1];
+    };
+    auto stageB = [&](int st, const StA& a, StB& b) {
+        bool act;
+        const int rr = row_of(st, act);
+        const bool has = act && a.ke > a.kb;
+        const int k = has ? a.kb : (a.kb > 0 ? a.kb - 1 : 0);   // any valid entry: loaded, not used
+        b.kb = prow[rr];
+        b.ke = prow[rr + 1];
         b.cq = pcol[k];
 #pragma unroll
         for (int q = 0; q < BB; ++q) b.blk[q] = P[(size_t)k * BB + q];
         const double* rsrc = (SHAPE == SW_L) ? d : vu;
-        b.rhs[0] = rsrc[(size_t)a.rr * BS]; b.rhs[1] = rsrc[(size_t)a.rr * BS + 1]; b.rhs[2] = rsrc[(size_t)a.rr * BS + 2];
+        b.rhs[0] = rsrc[(size_t)rr * BS]; b.rhs[1] = rsrc[(size_t)rr * BS + 1]; b.rhs[2] = rsrc[(size_t)rr * BS + 2];
         if (SHAPE != SW_L) {
 #pragma unroll
-            for (int q = 0; q < BB; ++q) b.Di[q] = invD[(size_t)a.rr * BB + q];
+            for (int q = 0; q < BB; ++q) b.Di[q] = invD[(size_t)rr * BB + q];
         }
     };
-    StA aa[D + 1];
+    StA aa[D];
     StB b[D];
+    {   // prologue: row bounds of the first D steps in one round, their items in the next, then the D pairs further ahead
+        StA a0[D];
 #pragma unroll
-    for (int u = 0; u <= D; ++u)
-        if (u < nsteps) stageA(u, aa[u]);
+        for (int u = 0; u < D; ++u) stageA(u, a0[u]);
 #pragma unroll
-    for (int u = 0; u < D; ++u)
-        if (u < nsteps) stageB(aa[u], b[u]);
-    StA a = aa[D];
+        for (int u = 0; u < D; ++u) stageB(u, a0[u], b[u]);
+#pragma unroll
+        for (int u = 0; u < D; ++u) stageA(D + u, aa[u]);
+    }
     double prev[3] = {0.0, 0.0, 0.0};  // result of the row this lane finished one step earlier
     for (int s0 = 0; s0 < nsteps; s0 += D) {
 #pragma unroll
         for (int u = 0; u < D; ++u) {
             const int st = s0 + u;
-            if (st < nsteps) {
-                StB& c = b[u];
-                if (c.r >= 0) {
-                    double rhs[3] = {c.rhs[0], c.rhs[1], c.rhs[2]};
-                    if (c.has) blk_mmv(c.blk, prev[0], prev[1], prev[2], rhs);
-                    if (SHAPE == SW_L) {
-                        vu[(size_t)c.r * BS] = rhs[0]; vu[(size_t)c.r * BS + 1] = rhs[1]; vu[(size_t)c.r * BS + 2] = rhs[2];
-                        prev[0] = rhs[0]; prev[1] = rhs[1]; prev[2] = rhs[2];
-                    } else {
-                        double out[3] = {0.0, 0.0, 0.0};
-                        blk_umv(c.Di, rhs[0], rhs[1], rhs[2], out);
-                        if (relax_mode == 1) { out[0] = w * out[0]; out[1] = w * out[1]; out[2] = w * out[2]; }
-                        vu[(size_t)c.r * BS] = out[0]; vu[(size_t)c.r * BS + 1] = out[1]; vu[(size_t)c.r * BS + 2] = out[2];
-                        if (v != vu) { v[(size_t)c.r * BS] = w * out[0]; v[(size_t)c.r * BS + 1] = w * out[1]; v[(size_t)c.r * BS + 2] = w * out[2]; }
-                        prev[0] = out[0]; prev[1] = out[1]; prev[2] = out[2];
-                    }
-                }
-                if (st + D < nsteps) {
-                    stageB(a, c);
-                    if (st + D + 1 < nsteps) stageA(st + D + 1, a);
+            StB& c = b[u];
+            bool active;
+            const int rrow = row_of(st, active);
+            if (active) {
+                const int r = rrow;
+                double rhs[3] = {c.rhs[0], c.rhs[1], c.rhs[2]};
+                if (c.ke > c.kb) blk_mmv(c.blk, prev[0], prev[1], prev[2], rhs);
+                if (SHAPE == SW_L) {
+                    vu[(size_t)r * BS] = rhs[0]; vu[(size_t)r * BS + 1] = rhs[1]; vu[(size_t)r * BS + 2] = rhs[2];
+                    prev[0] = rhs[0]; prev[1] = rhs[1]; prev[2] = rhs[2];
+                } else {
+                    double out[3] = {0.0, 0.0, 0.0};
+                    blk_umv(c.Di, rhs[0], rhs[1], rhs[2], out);
+                    if (relax_mode == 1) { out[0] = w * out[0]; out[1] = w * out[1]; out[2] = w * out[2]; }
+                    vu[(size_t)r * BS] = out[0]; vu[(size_t)r * BS + 1] = out[1]; vu[(size_t)r * BS + 2] = out[2];
+                    if (v != vu) { v[(size_t)r * BS] = w * out[0]; v[(size_t)r * BS + 1] = w * out[1]; v[(size_t)r * BS + 2] = w * out[2]; }
+                    prev[0] = out[0]; prev[1] = out[1]; prev[2] = out[2];
                 }
             }
+            __builtin_amdgcn_sched_barrier(0);
+            stageB(st + D, aa[u], c);                // row bounds requested D steps ago
+            __builtin_amdgcn_sched_barrier(0);
+            stageA(st + 2 * D, aa[u]);
+            __builtin_amdgcn_sched_barrier(0);
         }
     }
 }
