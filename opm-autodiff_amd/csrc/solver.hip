@@ -838,7 +838,7 @@ __device__ __forceinline__ void chain_sweep(const int nsteps, const int lane, do
 // recurrence - no LDS image, no workgroup-level ordering - and what limits the sweep is the latency of eight dependent
 // steps, so each lane keeps LIGHT_DEPTH steps of loads (row bounds one step further) in flight.
 #ifndef OPMHIP_LIGHT_DEPTH
-#define OPMHIP_LIGHT_DEPTH 4
+#define OPMHIP_LIGHT_DEPTH 2   // one M^-1 on one box: depth 1 0.1488 ms, 2 0.1460, 3 0.1480, 4 0.1477, 6 0.1653 (more than 63 loads outstanding)
 #endif
 constexpr int LIGHT_DEPTH = OPMHIP_LIGHT_DEPTH;
 template <int SHAPE>  // SW_L or SW_UF
