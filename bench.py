@@ -46,6 +46,19 @@ PROFILE_EVERY = 4
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (/opt/skills/guides/MI355X_MICROARCH.md)
 
 
+def device_info(torch, index):
+    """what the box says about its GPU (the kernel times of this bench vary by box: see profiles/README.md)"""
+    try:
+        p = torch.cuda.get_device_properties(index)
+        info = {"name": p.name, "compute_units": p.multi_processor_count, "memory_GiB": round(p.total_memory / 2**30, 1)}
+        for k in ("clock_rate", "memory_clock_rate", "gcnArchName", "L2_cache_size"):
+            if hasattr(p, k):
+                info[k] = getattr(p, k)
+        return info
+    except Exception as e:   # never let a diagnostic take the bench line down
+        return {"error": str(e)}
+
+
 def alg_bytes(Nb, nnzb):
     """Algorithmic bytes per launch (SURVEY.md §8d / BASELINE.md §4), block size 3, double values, int32 indices."""
     return {
@@ -388,6 +401,7 @@ def main():
         # same case, CPR instead of ILU0 as the preconditioner of BiCGStab (extra information; `value` is the run above)
         "cpr": cpr_side,
         "preconditioner": a.preconditioner,
+        "device": device_info(torch, local_rank),
         "stream_ceiling": {"read_GBps": round(stream_GBps, 1), "bytes_per_launch": 72 * nnzb, "avg_launch_ms": round(stream_ms, 5),
                            "kernel": "k_stream_read: the Jacobian's value array read once, 16-B loads, nothing else (back to back, 20 launches)"},
         "roofline": {"bound": "hbm", "kernel": "k_spmv (block-CSR SpMV, 3x3 double blocks)", "achieved": sp["algorithmic_GBps"],
