@@ -422,109 +422,131 @@ __global__ __launch_bounds__(64) void k_spmv(const int4* __restrict__ sched, con
 // operand stream and two wavefront reductions per tile - and the Newton iteration rate nothing either way (74.2 against 74.7
 // its/s on the 100^3 bench, same box).
 constexpr int PGCH = 8;
+constexpr int PIPE_MAX_STEPS = 64;    // schedule entries of one workgroup, kept in LDS (1 KiB: eight workgroups per CU must still fit; the host sizes the grid accordingly)
+// Written by the rules listed at chain_sweep (which see): the tile's schedule entries come out of LDS (one round of loads
+// at the start instead of a scalar load per tile at the head of every dependency chain); stages A (row bounds, 3 tiles
+// ahead), C (column indices, 2 ahead), M (vector gathers and the row bounds once more, 1 ahead), S (value stream, 1
+// ahead); every load unconditional, into registers whose content is dead; nothing loaded is copied.
 __global__ __launch_bounds__(64) void k_spmv_pipe(int npos, const int4* __restrict__ sched, const int* __restrict__ rowptr,
                                                   const int* __restrict__ col, const double* __restrict__ val,
                                                   const double* __restrict__ x, double* __restrict__ y,
                                                   const double* __restrict__ done) {
     TILE_LDS
+    __shared__ int4 ssched[PIPE_MAX_STEPS];
     const int lane = threadIdx.x, G = gridDim.x;
     constexpr int U = 16;  // 16 x 64 lanes x 16 B = 16 KiB >= any staged tile
-    const int nsteps = ((int)blockIdx.x < npos) ? (npos - (int)blockIdx.x + G - 1) / G : 0;
+    const int nsteps = ((int)blockIdx.x < npos) ? (npos - (int)blockIdx.x + G - 1) / G : 0;   // <= PIPE_MAX_STEPS (host)
     if (nsteps <= 0) return;
-    const double stop = *done;                      // read together with the first schedule entry: one scalar round trip, not two
-    const int4 sFirst = sched[(int)blockIdx.x];
+    const double stop = *done;                      // read together with the schedule entries: one round trip, not two
+    for (int i = lane; i < nsteps; i += 64) ssched[i] = sched[(int)blockIdx.x + i * G];
     if (stop != 0.0) return;
-    struct StA { int4 rows; int rr, kb, ke; bool active; };
-    struct StC { int4 rows; int rr, kb, nrow; bool active; int cc[PGCH]; };
-    struct StG {
-        int r, kb, nrow, k0e, n, n2;
+    wave_sync();
+    struct StA { int kb, ke; };
+    struct StS {
+        int k0e, n, n2;
         double2 tmp[U];
+    };
+    struct StM {
+        int kb, ke;
         double xx[PGCH][3];
     };
-    auto stageS = [&](int st) -> int4 { return sched[(int)blockIdx.x + st * G]; };
-    auto stageA = [&](const int4& rows, StA& a) {
-        a.rows = rows;
-        a.active = rows.x + lane < rows.y;
-        a.rr = a.active ? rows.x + lane : (rows.y > rows.x ? rows.y - 1 : 0);
-        a.kb = rowptr[a.rr];
-        a.ke = rowptr[a.rr + 1];
+    auto clampst = [&](int st) { return st < nsteps ? st : nsteps - 1; };
+    auto row_of = [&](int st, bool& active) {   // LDS only
+        const int4 rows = ssched[clampst(st)];
+        active = st < nsteps && rows.x + lane < rows.y;
+        return (rows.x + lane < rows.y) ? rows.x + lane : (rows.y > rows.x ? rows.y - 1 : 0);
     };
-    auto stageC = [&](const StA& a, StC& c) {
-        c.rows = a.rows; c.rr = a.rr; c.kb = a.kb; c.active = a.active;
-        c.nrow = a.active ? a.ke - a.kb : 0;
+    auto stageA = [&](int st, StA& a) {
+        bool act;
+        const int rr = row_of(st, act);
+        a.kb = rowptr[rr];
+        a.ke = rowptr[rr + 1];
+    };
+    auto stageC = [&](int st, const StA& a, int (&cc)[PGCH]) {   // a = row bounds of tile st
+        bool act;
+        const int rr = row_of(st, act);
+        const int nrow = a.ke - a.kb;
+        const int spare = a.kb > 0 ? a.kb - 1 : 0;
+        (void)rr;
 #pragma unroll
-        for (int u = 0; u < PGCH; ++u) c.cc[u] = (u < c.nrow) ? col[a.kb + u] : a.rr;  // idle slots: the lane's own row, always valid
+        for (int u = 0; u < PGCH; ++u) cc[u] = col[(u < nrow) ? a.kb + u : spare];   // idle slots: some valid entry (a valid row to gather)
     };
-    auto stageG = [&](const StC& c, StG& b) {
-        b.k0e = c.rows.z & ~1;
-        const int nb = c.rows.w - b.k0e;
-        b.n = (c.rows.y > c.rows.x) ? nb * BB : 0;
+    auto stageGs = [&](int st, StS& b) {   // value stream of tile st; past the end: one line, read 16 times
+        const int4 rows = ssched[clampst(st)];
+        b.k0e = rows.z & ~1;
+        const int nb = rows.w - b.k0e;
+        b.n = (rows.y > rows.x) ? nb * BB : 0;
         b.n2 = b.n >> 1;
-        b.r = c.active ? c.rr : -1;
-        b.kb = c.kb;
-        b.nrow = c.nrow;
-        if (b.n2 > 0) {
-            const double2* __restrict__ s2 = reinterpret_cast<const double2*>(val + (size_t)b.k0e * BB);
+        const int lim = (st < nsteps && b.n2 > 0) ? b.n2 - 1 : 0;
+        const double2* __restrict__ s2 = reinterpret_cast<const double2*>(val + (size_t)b.k0e * BB);
 #pragma unroll
-            for (int u = 0; u < U; ++u) {
-                const int i = u * 64 + lane;
-                b.tmp[u] = ld_stream(&s2[i < b.n2 ? i : b.n2 - 1]);
-            }
+        for (int u = 0; u < U; ++u) {
+            const int i = u * 64 + lane;
+            b.tmp[u] = ld_stream(&s2[i < lim ? i : lim]);
         }
+    };
+    auto stageGm = [&](int st, const int (&cc)[PGCH], StM& b) {   // cc = column indices of tile st
+        bool act;
+        const int rr = row_of(st, act);
+        b.kb = rowptr[rr];
+        b.ke = rowptr[rr + 1];
 #pragma unroll
         for (int u = 0; u < PGCH; ++u) {
-            const double* xc = &x[(size_t)c.cc[u] * BS];
+            const double* xc = &x[(size_t)cc[u] * BS];
             b.xx[u][0] = xc[0]; b.xx[u][1] = xc[1]; b.xx[u][2] = xc[2];
         }
     };
-    int4 sNext = make_int4(0, 0, 0, 0);
     StA a;
-    StC c;
-    StG b;
-    // prologue: fill the pipeline, tile by tile (issuing the row bounds of three tiles at once was measured 7 % SLOWER)
-    { stageA(sFirst, a); stageC(a, c); stageG(c, b); }
-    if (nsteps > 1) { stageA(stageS(1), a); stageC(a, c); }
-    if (nsteps > 2) stageA(stageS(2), a);
-    if (nsteps > 3) sNext = stageS(3);
+    int cc[PGCH];
+    StS sb;
+    StM m;
+    {   // prologue, in the loop's order of issue (stream, gathers, column indices, row bounds)
+        StA a0, a1;
+        int c0[PGCH];
+        stageA(0, a0);
+        stageA(1, a1);
+        stageC(0, a0, c0);
+        stageGs(0, sb);
+        stageGm(0, c0, m);
+        stageC(1, a1, cc);
+        stageA(2, a);
+    }
     double2* d2 = reinterpret_cast<double2*>(sval);
     for (int st = 0; st < nsteps; ++st) {
         // ---- X(st), part 1: this tile's values -> LDS
-#pragma unroll
-        for (int u = 0; u < U; ++u) asm volatile("" : "+v"(b.tmp[u].x), "+v"(b.tmp[u].y));
-        const int r = b.r, kb = b.kb, nrow = b.nrow, k0e = b.k0e, n = b.n, n2 = b.n2;
-        double xx[PGCH][3];
-#pragma unroll
-        for (int u = 0; u < PGCH; ++u) { xx[u][0] = b.xx[u][0]; xx[u][1] = b.xx[u][1]; xx[u][2] = b.xx[u][2]; }
+        const int k0e = sb.k0e, n = sb.n, n2 = sb.n2;
         if (n2 > 0) {
 #pragma unroll
             for (int u = 0; u < U; ++u) {
                 const int i = u * 64 + lane;
-                if (i < n2) d2[i] = b.tmp[u];
+                if (i < n2) d2[i] = sb.tmp[u];
             }
             if ((n & 1) && lane == 0) sval[n - 1] = val[(size_t)k0e * BB + n - 1];
         }
         wave_sync();
-        // ---- the loads of the tiles ahead go out now and fly during this tile's arithmetic
-        if (st + 1 < nsteps) {
-            stageG(c, b);
-            if (st + 2 < nsteps) {
-                stageC(a, c);
-                if (st + 3 < nsteps) {
-                    stageA(sNext, a);
-                    if (st + 4 < nsteps) sNext = stageS(st + 4);
-                }
-            }
-        }
+        // ---- the next tile's value stream goes out now and flies during this tile's arithmetic
+        stageGs(st + 1, sb);
         // ---- X(st), part 2: products in BCRSMatrix::mv order, store
-        double acc[3] = {0.0, 0.0, 0.0};
-        if (r >= 0) {
+        bool active;
+        const int r = row_of(st, active);
+        if (active) {
+            const int kb = m.kb, nrow = m.ke - m.kb;
+            double acc[3] = {0.0, 0.0, 0.0};
 #pragma unroll
             for (int u = 0; u < PGCH; ++u)
-                if (u < nrow) blk_umv(&sval[(kb + u - k0e) * BB], xx[u][0], xx[u][1], xx[u][2], acc);
+                if (u < nrow) blk_umv_lds(&sval[(kb + u - k0e) * BB], m.xx[u][0], m.xx[u][1], m.xx[u][2], acc);
             double* yr = &y[(size_t)r * BS];
             yr[0] = acc[0]; yr[1] = acc[1]; yr[2] = acc[2];
         }
         wave_sync();  // the LDS image may be overwritten
+        // ---- the tiles further ahead, each stage into the registers it has just finished with
+        __builtin_amdgcn_sched_barrier(0);
+        stageGm(st + 1, cc, m);
+        __builtin_amdgcn_sched_barrier(0);
+        stageC(st + 2, a, cc);
+        __builtin_amdgcn_sched_barrier(0);
+        stageA(st + 3, a);
+        __builtin_amdgcn_sched_barrier(0);
     }
 }
 
@@ -1580,7 +1602,7 @@ void launch_spmv(opmhip_ctx* c, const double* x, double* y, int ndot, const doub
         // pipelined kernel: every workgroup walks through ceil(ntp / grid) launch positions; the grid is sized so that all
         // workgroups are resident at once and end together, and is a multiple of 8 (a workgroup stays on "its" XCD column of
         // the schedule)
-        const int steps = (ntp + pipeWgs - 1) / pipeWgs;
+        const int steps = std::min((ntp + pipeWgs - 1) / pipeWgs, PIPE_MAX_STEPS);   // beyond that: more workgroups than are resident
         const int grid = 8 * (((ntp + steps - 1) / steps + 7) / 8);
         hipExtLaunchKernelGGL(k_spmv_pipe, dim3(grid), dim3(64), 0, c->stream, e0, e1, 0, ntp, sched, P.d_rowptr, P.d_col, c->d_A, x, y, c->d_done);
     } else if (fused == 0)
