@@ -422,7 +422,7 @@ __global__ __launch_bounds__(64) void k_spmv(const int4* __restrict__ sched, con
 // operand stream and two wavefront reductions per tile - and the Newton iteration rate nothing either way (74.2 against 74.7
 // its/s on the 100^3 bench, same box).
 constexpr int PGCH = 8;
-constexpr int PIPE_MAX_STEPS = 64;    // schedule entries of one workgroup, kept in LDS (1 KiB: eight workgroups per CU must still fit; the host sizes the grid accordingly)
+constexpr int PIPE_MAX_STEPS = 128;   // schedule entries of one workgroup, kept in LDS (2 KiB: eight workgroups per CU must still fit; the host sizes the grid accordingly)
 // Written by the rules listed at chain_sweep (which see): the tile's schedule entries come out of LDS (one round of loads
 // at the start instead of a scalar load per tile at the head of every dependency chain); stages A (row bounds, 3 tiles
 // ahead), C (column indices, 2 ahead), M (vector gathers and the row bounds once more, 1 ahead), S (value stream, 1
