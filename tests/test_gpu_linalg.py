@@ -178,6 +178,38 @@ def test_irregular_rows_and_long_rows(pkg, orc):
         assert np.linalg.norm(r) < 1e-6 * np.linalg.norm(b) * 1.001
 
 
+@pytest.mark.parametrize("reorder", ["graph_coloring", "line_coloring"])
+def test_dense_random_rows(pkg, orc, reorder):
+    """rows of up to ~40 blocks (far beyond the 6 / 8 blocks the sweeps and the product prefetch per row, and beyond what one
+    step of a chain-tile was sized for): the long-row loops, the columns inside a chain-tile that are not the lane's own
+    previous row, and the one-tile product kernel - factors, M^-1 and A x bit for bit, then a solve"""
+    Nb, rp, ci, v = random_block_system(900, pattern="random", seed=21, extra=18)
+    assert np.diff(rp).max() > 24
+    s = pkg.capi.HipSolver(tolerance=1e-8, maxit=300, reorder=reorder)
+    b = np.random.default_rng(3).standard_normal(Nb * 3)
+    res = s.solve_system(Nb, rp, ci, v.copy(), b)
+    x = s.get_result()
+    to, fr, rpc = s.ordering()
+    rr, rc, rv = orc.reorder_matrix(Nb, rp, ci, v, to, fr)
+    luo = orc.ilu0_factor(Nb, rr, rc, rv)
+    assert np.array_equal(s.ilu0_factor(), luo)
+    rng = np.random.default_rng(4)
+    for mode, w in (("post_scale", 0.9), ("post_scale", 1.0)):
+        d = rng.standard_normal(Nb * 3)
+        s2 = pkg.capi.HipSolver(reorder=reorder, ilu_relaxation=w)
+        s2.set_pattern(Nb, rp, ci); s2.upload_system(v)
+        assert np.array_equal(s2.ordering()[0], to)
+        s2.ilu0_factor()
+        vo = orc.ilu0_apply(Nb, rr, rc, luo, d.reshape(Nb, 3)[fr].reshape(-1), w=w, mode=mode)
+        assert np.array_equal(s2.ilu0_apply(d), vo.reshape(Nb, 3)[to].reshape(-1))
+    y = rng.standard_normal(Nb * 3)
+    yo = orc.spmv(Nb, rr, rc, rv, y.reshape(Nb, 3)[fr].reshape(-1)).reshape(Nb, 3)[to].reshape(-1)
+    assert np.array_equal(s.spmv(y), yo)
+    assert res.converged
+    r = b - orc.spmv(Nb, rp, ci, v, x)
+    assert np.linalg.norm(r) < 1e-8 * np.linalg.norm(b) * 1.001
+
+
 def test_wells_operator(pkg, orc):
     rng = np.random.default_rng(11)
     Nb, rp, ci, v = laplace_block_system(12, 10, 6, seed=13)
