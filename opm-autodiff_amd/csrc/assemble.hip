@@ -375,15 +375,35 @@ __device__ __forceinline__ bool tables_to_lds(const Tables& T, double* s_tab) {
 __device__ __forceinline__ TablesT<LdsTab> lds_tables(const Tables& T, double* s_tab) {
     return TablesT<LdsTab>{(LdsTab)s_tab, T.idx, T.rock_pref, T.rock_cr, T.ndbl, T.nidx, T.rock_desc, T.num_rock};
 }
+// The base layout's two per-cell kernels are held to three wavefronts per SIMD (168 VGPRs; left alone they take 172-174 and
+// run two: 0.1865 -> 0.1742 ms on the bench, four waves spill and lose).  The extended layout needs 202 registers and stays free.
+#ifndef OPMHIP_IQ_WAVES
+#define OPMHIP_IQ_WAVES 3
+#endif
+#if OPMHIP_IQ_WAVES > 0
+#define IQ_OCC __attribute__((amdgpu_waves_per_eu(OPMHIP_IQ_WAVES, OPMHIP_IQ_WAVES)))
+#else
+#define IQ_OCC
+#endif
 template <bool EXT>
-__global__ __launch_bounds__(256) void k_iq_update(int c0, int Nb, Tables T, CellStatic C, const double* __restrict__ pv,
-                                                   const unsigned char* __restrict__ meaning, double* __restrict__ iq) {
+__device__ __forceinline__ void iq_update_body(int c0, int Nb, const Tables& T, const CellStatic& C, const double* __restrict__ pv,
+                                               const unsigned char* __restrict__ meaning, double* __restrict__ iq) {
     __shared__ double s_tab[TAB_LDS_DBL];
     const bool inLds = tables_to_lds(T, s_tab);
     const int c = c0 + blockIdx.x * blockDim.x + threadIdx.x;  // cells [c0, Nb)
     if (c >= Nb) return;
     if (inLds) iq_update_cell<LdsTab, EXT>(lds_tables(T, s_tab), C, c, pv, meaning, iq);
     else iq_update_cell<GlobalTab, EXT>(T, C, c, pv, meaning, iq);
+}
+template <bool EXT>
+__global__ __launch_bounds__(256) void k_iq_update(int c0, int Nb, Tables T, CellStatic C, const double* __restrict__ pv,
+                                                   const unsigned char* __restrict__ meaning, double* __restrict__ iq) {
+    iq_update_body<EXT>(c0, Nb, T, C, pv, meaning, iq);
+}
+template <>
+__global__ __launch_bounds__(256) IQ_OCC void k_iq_update<false>(int c0, int Nb, Tables T, CellStatic C, const double* __restrict__ pv,
+                                                                 const unsigned char* __restrict__ meaning, double* __restrict__ iq) {
+    iq_update_body<false>(c0, Nb, T, C, pv, meaning, iq);
 }
 
 // BlackOilNewtonMethod::update_ (chopped update) + BlackOilPrimaryVariables::adaptPrimaryVariables + IQ recompute
@@ -467,16 +487,30 @@ __device__ __forceinline__ void newton_update_cell(const TablesT<DP>& T, const C
     store_invb(C.invb, c, q);
 }
 template <bool EXT>
-__global__ __launch_bounds__(256) void k_newton_update(int Nb, Tables T, CellStatic C, const double* __restrict__ dx, double relax,
-                                                       double* __restrict__ pv, unsigned char* __restrict__ meaning,
-                                                       unsigned char* __restrict__ wasSwitched, double* __restrict__ iq,
-                                                       int* __restrict__ nswitched) {
+__device__ __forceinline__ void newton_update_body(int Nb, const Tables& T, const CellStatic& C, const double* __restrict__ dx, double relax,
+                                                   double* __restrict__ pv, unsigned char* __restrict__ meaning,
+                                                   unsigned char* __restrict__ wasSwitched, double* __restrict__ iq,
+                                                   int* __restrict__ nswitched) {
     __shared__ double s_tab[TAB_LDS_DBL];
     const bool inLds = tables_to_lds(T, s_tab);
     const int c = blockIdx.x * blockDim.x + threadIdx.x;
     if (c >= Nb) return;
     if (inLds) newton_update_cell<LdsTab, EXT>(lds_tables(T, s_tab), C, c, dx, relax, pv, meaning, wasSwitched, iq, nswitched);
     else newton_update_cell<GlobalTab, EXT>(T, C, c, dx, relax, pv, meaning, wasSwitched, iq, nswitched);
+}
+template <bool EXT>
+__global__ __launch_bounds__(256) void k_newton_update(int Nb, Tables T, CellStatic C, const double* __restrict__ dx, double relax,
+                                                       double* __restrict__ pv, unsigned char* __restrict__ meaning,
+                                                       unsigned char* __restrict__ wasSwitched, double* __restrict__ iq,
+                                                       int* __restrict__ nswitched) {
+    newton_update_body<EXT>(Nb, T, C, dx, relax, pv, meaning, wasSwitched, iq, nswitched);
+}
+template <>
+__global__ __launch_bounds__(256) IQ_OCC void k_newton_update<false>(int Nb, Tables T, CellStatic C, const double* __restrict__ dx, double relax,
+                                                                     double* __restrict__ pv, unsigned char* __restrict__ meaning,
+                                                                     unsigned char* __restrict__ wasSwitched, double* __restrict__ iq,
+                                                                     int* __restrict__ nswitched) {
+    newton_update_body<false>(Nb, T, C, dx, relax, pv, meaning, wasSwitched, iq, nswitched);
 }
 
 static Tables tables_of(const opmhip_ctx* c);
