@@ -204,6 +204,7 @@ struct opmhip_ctx {
     double *d_stageA = nullptr, *d_stageV = nullptr;
     double* d_scal = nullptr;   // SC_COUNT doubles
     double* d_part = nullptr;   // partial sums: 2 x npart
+    double minv_scale = 1.0;    // during a solve: the factor the preconditioned vectors (d_pw, d_s) are still to be multiplied by
     double* d_part2 = nullptr;  // second-level partials: 2 x RED1_BLOCKS
     int npart = 0;
     double* h_pinned = nullptr;  // SC_COUNT doubles, pinned
@@ -348,19 +349,19 @@ void launch_unpermute_blocks(opmhip_ctx* c, const double* internal, double* nat)
 void launch_vec_to_internal(opmhip_ctx* c, const double* nat, double* internal, int cells = -1);
 void launch_vec_to_natural(opmhip_ctx* c, const double* internal, double* nat, int cells = -1);
 void launch_zero_diag_fix(opmhip_ctx* c);
-void launch_spmv(opmhip_ctx* c, const double* x, double* y, int ndot, const double* w0, const double* w1);
+void launch_spmv(opmhip_ctx* c, const double* x, double* y, int ndot, const double* w0, const double* w1, double xs = 1.0);
 void launch_wells_residual(opmhip_ctx* c, const double* d_resWell, double* r);
 void launch_wells_add_to_matrix(opmhip_ctx* c, int w0, int nw, int serial, const int* d_pair_ptr, const int* d_entry);
 void launch_wells_recover(opmhip_ctx* c, const double* d_resWell, const double* x, double* d_xw);
 void launch_ilu_factor(opmhip_ctx* c);
-void launch_ilu_apply(opmhip_ctx* c, const double* d, double* v, double w_override = -1.0);
+void launch_ilu_apply(opmhip_ctx* c, const double* d, double* v, double w_override = -1.0, double* unscaled = nullptr);
 // cpr.hip
 int cpr_update(opmhip_ctx* c);
 void launch_cpr_apply(opmhip_ctx* c, const double* d, double* v);
 int cpr_set_weights(opmhip_ctx* c, const double* w);
 int cpr_level_sizes(const opmhip_ctx* c, int* n, int* nnz, int cap);
 inline bool use_cpr(const opmhip_ctx* c) { return c->cfg.reserved[2] == 1 || c->cfg.reserved[2] == 2; }   // 1 quasi-IMPES, 2 true-IMPES weights
-void launch_wells_apply(opmhip_ctx* c, const double* x, double* y);
+void launch_wells_apply(opmhip_ctx* c, const double* x, double* y, double xs = 1.0);
 void launch_lu_to_natural(opmhip_ctx* c, double* d_out_internal_layout);
 int bicgstab(opmhip_ctx* c, opmhip_result* res);
 // comm.hip

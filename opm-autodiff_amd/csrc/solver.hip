@@ -210,7 +210,7 @@ __device__ __forceinline__ int tile_row_product(int tr0, int tr1, const int* __r
                                                 const int* __restrict__ col, const double* __restrict__ val,
                                                 const double* __restrict__ x, double* sval, int lane, bool reverse, double* acc,
                                                 TileCtx& T, const double* __restrict__ xlo = nullptr, int xsplit = 0,
-                                                int tk0 = -1, int tk1 = -1) {
+                                                int tk0 = -1, int tk1 = -1, double xs = 1.0) {
     // vector entries of columns < xsplit are read from xlo instead of x (ILU sweeps: first colour's y equals d)
     // tk0, tk1 >= 0: the tile's entry range is known already (it came with the launch schedule): one dependent load less
     // before the value stream can be issued
@@ -293,8 +293,9 @@ __device__ __forceinline__ int tile_row_product(int tr0, int tr1, const int* __r
             const int k = reverse ? ke - 1 - u : kb + u;
             // two branches, not one pointer chosen between LDS and global memory: such a pointer is "flat", and a flat load
             // makes the wavefront wait for EVERY outstanding memory access, the prefetched next tile included
-            if (stagedU) blk_apply_lds<SUB>(&sval[(k - T.k0e) * BB], xx[u], acc);
-            else blk_apply<SUB>(&val[(size_t)k * BB], xx[u], acc);
+            const double xs3[3] = {xs * xx[u][0], xs * xx[u][1], xs * xx[u][2]};   // xs = 1 unless the vector is an unscaled M^-1 result
+            if (stagedU) blk_apply_lds<SUB>(&sval[(k - T.k0e) * BB], xs3, acc);
+            else blk_apply<SUB>(&val[(size_t)k * BB], xs3, acc);
         }
     }
     // rows longer than one chunk
@@ -311,8 +312,9 @@ __device__ __forceinline__ int tile_row_product(int tr0, int tr1, const int* __r
         for (int u = 0; u < GCH; ++u) {
             if (done + u < nrow) {
                 const int k = reverse ? ke - 1 - (done + u) : kb + done + u;
-                if (stagedU) blk_apply_lds<SUB>(&sval[(k - T.k0e) * BB], xx[u], acc);
-                else blk_apply<SUB>(&val[(size_t)k * BB], xx[u], acc);
+                const double xs3[3] = {xs * xx[u][0], xs * xx[u][1], xs * xx[u][2]};
+                if (stagedU) blk_apply_lds<SUB>(&sval[(k - T.k0e) * BB], xs3, acc);
+                else blk_apply<SUB>(&val[(size_t)k * BB], xs3, acc);
             }
         }
     }
@@ -376,7 +378,7 @@ __global__ __launch_bounds__(64) void k_spmv(const int4* __restrict__ sched, con
                                              const int* __restrict__ col, const double* __restrict__ val,
                                              const double* __restrict__ x, double* __restrict__ y,
                                              const double* __restrict__ w0, double* __restrict__ part, int npart,
-                                             const double* __restrict__ done) {
+                                             const double* __restrict__ done, double xs) {
     TILE_LDS
     const int lane = threadIdx.x, t = blockIdx.x;
     if (*done != 0.0) return;
@@ -387,7 +389,7 @@ __global__ __launch_bounds__(64) void k_spmv(const int4* __restrict__ sched, con
     }
     TileCtx T;
     double acc[3] = {0.0, 0.0, 0.0};
-    const int r = tile_row_product<false>(rows.x, rows.y, rowptr, col, val, x, sval, lane, false, acc, T, nullptr, 0, rows.z, rows.w);
+    const int r = tile_row_product<false>(rows.x, rows.y, rowptr, col, val, x, sval, lane, false, acc, T, nullptr, 0, rows.z, rows.w, xs);
     if (r >= 0) {
         double* yr = &y[(size_t)r * BS];
         yr[0] = acc[0]; yr[1] = acc[1]; yr[2] = acc[2];
@@ -430,7 +432,7 @@ constexpr int PIPE_MAX_STEPS = 128;   // schedule entries of one workgroup, kept
 __global__ __launch_bounds__(64) void k_spmv_pipe(int npos, const int4* __restrict__ sched, const int* __restrict__ rowptr,
                                                   const int* __restrict__ col, const double* __restrict__ val,
                                                   const double* __restrict__ x, double* __restrict__ y,
-                                                  const double* __restrict__ done) {
+                                                  const double* __restrict__ done, double xs) {
     TILE_LDS
     __shared__ int4 ssched[PIPE_MAX_STEPS];
     const int lane = threadIdx.x, G = gridDim.x;
@@ -534,7 +536,7 @@ __global__ __launch_bounds__(64) void k_spmv_pipe(int npos, const int4* __restri
             double acc[3] = {0.0, 0.0, 0.0};
 #pragma unroll
             for (int u = 0; u < PGCH; ++u)
-                if (u < nrow) blk_umv_lds(&sval[(kb + u - k0e) * BB], m.xx[u][0], m.xx[u][1], m.xx[u][2], acc);
+                if (u < nrow) blk_umv_lds(&sval[(kb + u - k0e) * BB], xs * m.xx[u][0], xs * m.xx[u][1], xs * m.xx[u][2], acc);   // xs = 1 unless x is an unscaled M^-1 result
             double* yr = &y[(size_t)r * BS];
             yr[0] = acc[0]; yr[1] = acc[1]; yr[2] = acc[2];
         }
@@ -1120,7 +1122,7 @@ __global__ __launch_bounds__(64) void k_ilu_factor(int ct_begin, const int* __re
 __global__ __launch_bounds__(64) void k_wells_apply(const int* __restrict__ vp, const int* __restrict__ Ccols,
                                                     const int* __restrict__ Bcols, const double* __restrict__ C,
                                                     const double* __restrict__ D, const double* __restrict__ B,
-                                                    const double* __restrict__ x, double* __restrict__ y) {
+                                                    const double* __restrict__ x, double* __restrict__ y, double xs) {
     __shared__ double z1[4], z2[4];
     const int w = blockIdx.x, lane = threadIdx.x;
     const int pb = vp[w], pe = vp[w + 1];
@@ -1131,7 +1133,7 @@ __global__ __launch_bounds__(64) void k_wells_apply(const int* __restrict__ vp, 
         for (int p = pb; p < pe; ++p) {
             const double* xb = &x[(size_t)Bcols[p] * 3];
             const double* Bp = &B[(size_t)p * 12 + lane * 3];
-            s += Bp[0] * xb[0]; s += Bp[1] * xb[1]; s += Bp[2] * xb[2];
+            s += Bp[0] * (xs * xb[0]); s += Bp[1] * (xs * xb[1]); s += Bp[2] * (xs * xb[2]);
         }
         z1[lane] = s;
     }
@@ -1303,20 +1305,21 @@ __global__ __launch_bounds__(VB) void k_bicg_upd1(int n, const double* __restric
     block_partials(s, 0.0, part, npart, 1);
 }
 // x += alpha pw, alone: the solve ended on a first half
-__global__ __launch_bounds__(VB) void k_bicg_xhalf(int n, const double* __restrict__ scal, double* __restrict__ x, const double* __restrict__ pw) {
+__global__ __launch_bounds__(VB) void k_bicg_xhalf(int n, const double* __restrict__ scal, double* __restrict__ x, const double* __restrict__ pw, double ws) {
     const double alpha = scal[SC_ALPHA];
     const int base = blockIdx.x * VB * VPT + threadIdx.x;
 #pragma unroll
     for (int u = 0; u < VPT; ++u) {
         const int e = base + u * VB;
-        if (e < n) x[e] += alpha * pw[e];
+        if (e < n) x[e] += alpha * (ws * pw[e]);
     }
 }
 // x = (x + alpha pw) + omega s ; r -= omega t ; partials r.r and rw.r
 __global__ __launch_bounds__(VB) void k_bicg_upd2(int n, const double* __restrict__ scal, double* __restrict__ x,
                                                   const double* __restrict__ pw, const double* __restrict__ sv, double* __restrict__ r,
                                                   const double* __restrict__ tv, const double* __restrict__ rw,
-                                                  double* __restrict__ part, int npart) {
+                                                  double* __restrict__ part, int npart, double ws) {
+    // ws: pw and sv are M^-1 results still to be multiplied by the relaxation factor (1 when they already are, see bicgstab)
     if (scal[SC_DONE] != 0.0) return;
     const double alpha = scal[SC_ALPHA], omega = scal[SC_OMEGA];
     double s = 0.0, q = 0.0;
@@ -1325,8 +1328,8 @@ __global__ __launch_bounds__(VB) void k_bicg_upd2(int n, const double* __restric
     for (int u = 0; u < VPT; ++u) {
         const int e = base + u * VB;
         if (e < n) {
-            const double xh = x[e] + alpha * pw[e];   // the first half's update
-            x[e] = xh + omega * sv[e];
+            const double xh = x[e] + alpha * (ws * pw[e]);   // the first half's update
+            x[e] = xh + omega * (ws * sv[e]);
             const double re = r[e] - omega * tv[e];
             r[e] = re;
             s += re * re;
@@ -1547,11 +1550,11 @@ void launch_lu_to_natural(opmhip_ctx* c, double* d_out) {
     hipLaunchKernelGGL(k_lu_to_bcrs, dim3(cdiv((size_t)P.Nb, 256)), dim3(256), 0, c->stream, P.Nb, P.d_rowptr, P.d_col, P.d_lrowptr,
                        P.d_urowptr, c->d_L, c->d_U, c->d_invD, d_out);
 }
-void launch_wells_apply(opmhip_ctx* c, const double* x, double* y) {
+void launch_wells_apply(opmhip_ctx* c, const double* x, double* y, double xs) {
     const WellsDev& W = c->wells;
     if (W.num_wells <= 0) return;
     hipLaunchKernelGGL(k_wells_apply, dim3(W.num_wells), dim3(64), 0, c->stream, W.d_val_pointers, W.d_Ccols, W.d_Bcols, W.d_C, W.d_D,
-                       W.d_B, x, y);
+                       W.d_B, x, y, xs);
 }
 void launch_wells_add_to_matrix(opmhip_ctx* c, int w0, int nw, int serial, const int* d_pair_ptr, const int* d_entry) {
     const WellsDev& W = c->wells;
@@ -1585,7 +1588,7 @@ static bool spmv_pipelined(const opmhip_ctx* c) {
 }
 static bool spmv_dots_separate(const opmhip_ctx* c) { return c->wells.num_wells > 0 || spmv_pipelined(c); }
 // y = A x (+ wells) and, fused or not, the partial dots: ndot 0 none, 1 y.w0, 2 y.w0 and y.y
-void launch_spmv(opmhip_ctx* c, const double* x, double* y, int ndot, const double* w0, const double*) {
+void launch_spmv(opmhip_ctx* c, const double* x, double* y, int ndot, const double* w0, const double*, double xs) {
     const Pattern& P = c->pat;
     const int ntp = P.tiles.nsched;  // schedule positions (tiles + padding)
     const int4* sched = reinterpret_cast<const int4*>(P.tiles.d_spmvSched);
@@ -1604,14 +1607,14 @@ void launch_spmv(opmhip_ctx* c, const double* x, double* y, int ndot, const doub
         // the schedule)
         const int steps = std::min((ntp + pipeWgs - 1) / pipeWgs, PIPE_MAX_STEPS);   // beyond that: more workgroups than are resident
         const int grid = 8 * (((ntp + steps - 1) / steps + 7) / 8);
-        hipExtLaunchKernelGGL(k_spmv_pipe, dim3(grid), dim3(64), 0, c->stream, e0, e1, 0, ntp, sched, P.d_rowptr, P.d_col, c->d_A, x, y, c->d_done);
+        hipExtLaunchKernelGGL(k_spmv_pipe, dim3(grid), dim3(64), 0, c->stream, e0, e1, 0, ntp, sched, P.d_rowptr, P.d_col, c->d_A, x, y, c->d_done, xs);
     } else if (fused == 0)
-        hipExtLaunchKernelGGL(k_spmv<0>, dim3(ntp), dim3(64), 0, c->stream, e0, e1, 0, sched, P.d_rowptr, P.d_col, c->d_A, x, y, w0, c->d_part, c->npart, c->d_done);
+        hipExtLaunchKernelGGL(k_spmv<0>, dim3(ntp), dim3(64), 0, c->stream, e0, e1, 0, sched, P.d_rowptr, P.d_col, c->d_A, x, y, w0, c->d_part, c->npart, c->d_done, xs);
     else if (fused == 1)
-        hipExtLaunchKernelGGL(k_spmv<1>, dim3(ntp), dim3(64), 0, c->stream, e0, e1, 0, sched, P.d_rowptr, P.d_col, c->d_A, x, y, w0, c->d_part, c->npart, c->d_done);
+        hipExtLaunchKernelGGL(k_spmv<1>, dim3(ntp), dim3(64), 0, c->stream, e0, e1, 0, sched, P.d_rowptr, P.d_col, c->d_A, x, y, w0, c->d_part, c->npart, c->d_done, xs);
     else
-        hipExtLaunchKernelGGL(k_spmv<2>, dim3(ntp), dim3(64), 0, c->stream, e0, e1, 0, sched, P.d_rowptr, P.d_col, c->d_A, x, y, w0, c->d_part, c->npart, c->d_done);
-    if (wells) launch_wells_apply(c, x, y);
+        hipExtLaunchKernelGGL(k_spmv<2>, dim3(ntp), dim3(64), 0, c->stream, e0, e1, 0, sched, P.d_rowptr, P.d_col, c->d_A, x, y, w0, c->d_part, c->npart, c->d_done, xs);
+    if (wells) launch_wells_apply(c, x, y, xs);
     if (separate) {
         if (ndot > 0) {
             const int n = P.Nb * BS;
@@ -1633,13 +1636,18 @@ void launch_ilu_factor(opmhip_ctx* c) {
     }
     prof_end(c, ps);
 }
-void launch_ilu_apply(opmhip_ctx* c, const double* d, double* v, double w_override) {
+// unscaled != NULL: with post-scaling the sweeps leave U^-1 L^-1 d in v WITHOUT the factor w and report the factor in *unscaled
+// (1 when there is none to apply): whoever reads v next multiplies on the fly - w * v_i is one rounded product either way -
+// and the second result vector (24 bytes per row written by the backward sweeps) never exists.
+void launch_ilu_apply(opmhip_ctx* c, const double* d, double* v, double w_override, double* unscaled) {
     const Pattern& P = c->pat;
     const int ps = prof_begin(c, PROF_ILU_APPLY);
     const int C = P.numColors, mode = c->cfg.relax_mode;
     const double w = w_override > 0.0 ? w_override : c->cfg.ilu_relaxation;   // CPR's fine smoother runs with relaxation 1
     // post-scale with w != 1 keeps the unscaled sweep vector apart from the scaled result
-    double* vu = (mode == OPMHIP_RELAX_POST_SCALE && w != 1.0) ? c->d_vu : v;
+    const bool post = mode == OPMHIP_RELAX_POST_SCALE && w != 1.0;
+    double* vu = (post && !unscaled) ? c->d_vu : v;
+    if (unscaled) *unscaled = post ? w : 1.0;
     const int n0 = P.colorPrefix[1];  // rows of the first colour: their y is d
     auto grid = [](int n) { return dim3(8 * ((n + 7) / 8)); };
     if (P.chained) {
@@ -1741,7 +1749,7 @@ void launch_vector_kernels_once(opmhip_ctx* c) {
     hipLaunchKernelGGL(k_bicg_pupdate, dim3(nb), dim3(VB), 0, c->stream, n, c->d_scal, c->d_p, c->d_v, c->d_r);
     hipLaunchKernelGGL(k_bicg_upd1, dim3(nb), dim3(VB), 0, c->stream, n, c->d_scal, c->d_r, c->d_v, c->d_part, c->npart);
     (void)finalize(c, FIN_NORM, nb);  // timing helper, single-rank contexts only
-    hipLaunchKernelGGL(k_bicg_upd2, dim3(nb), dim3(VB), 0, c->stream, n, c->d_scal, c->d_x, c->d_pw, c->d_s, c->d_r, c->d_t, c->d_rw, c->d_part, c->npart);
+    hipLaunchKernelGGL(k_bicg_upd2, dim3(nb), dim3(VB), 0, c->stream, n, c->d_scal, c->d_x, c->d_pw, c->d_s, c->d_r, c->d_t, c->d_rw, c->d_part, c->npart, c->minv_scale);
     (void)finalize(c, FIN_NORM_RHO, nb);
 }
 
@@ -1771,9 +1779,9 @@ static int enqueue_half(opmhip_ctx* c, int h) {
             prof_end(c, ps);
         }
         if (cpr) launch_cpr_apply(c, c->d_p, c->d_pw);
-        else launch_ilu_apply(c, c->d_p, c->d_pw);
+        else launch_ilu_apply(c, c->d_p, c->d_pw, -1.0, &c->minv_scale);   // d_pw without the relaxation factor: its readers apply it
         if ((rc = comm_halo_f64(c, c->d_pw, BS))) return rc;  // copyOwnerToAll before the operator (ParallelOverlappingILU0.hpp:897)
-        launch_spmv(c, c->d_pw, c->d_v, 1, c->d_rw, nullptr);
+        launch_spmv(c, c->d_pw, c->d_v, 1, c->d_rw, nullptr, c->minv_scale);
         ps = prof_begin(c, PROF_VECTOR);
         if ((rc = finalize(c, FIN_ALPHA, dot_count(c)))) return rc;
         hipLaunchKernelGGL(k_bicg_upd1, dim3(nb), dim3(VB), 0, c->stream, n, c->d_scal, c->d_r, c->d_v, c->d_part, c->npart);
@@ -1781,12 +1789,12 @@ static int enqueue_half(opmhip_ctx* c, int h) {
         prof_end(c, ps);
     } else {             // second half: z = M^-1 r, t = A z, omega, x += omega z, r -= omega t, |r|, rho, beta
         if (cpr) launch_cpr_apply(c, c->d_r, c->d_s);
-        else launch_ilu_apply(c, c->d_r, c->d_s);
+        else launch_ilu_apply(c, c->d_r, c->d_s, -1.0, &c->minv_scale);
         if ((rc = comm_halo_f64(c, c->d_s, BS))) return rc;
-        launch_spmv(c, c->d_s, c->d_t, 2, c->d_r, nullptr);
+        launch_spmv(c, c->d_s, c->d_t, 2, c->d_r, nullptr, c->minv_scale);
         ps = prof_begin(c, PROF_VECTOR);
         if ((rc = finalize(c, FIN_OMEGA, dot_count(c)))) return rc;
-        hipLaunchKernelGGL(k_bicg_upd2, dim3(nb), dim3(VB), 0, c->stream, n, c->d_scal, c->d_x, c->d_pw, c->d_s, c->d_r, c->d_t, c->d_rw, c->d_part, c->npart);
+        hipLaunchKernelGGL(k_bicg_upd2, dim3(nb), dim3(VB), 0, c->stream, n, c->d_scal, c->d_x, c->d_pw, c->d_s, c->d_r, c->d_t, c->d_rw, c->d_part, c->npart, c->minv_scale);
         if ((rc = finalize(c, FIN_NORM_RHO, nb, h))) return rc;
         prof_end(c, ps);
     }
@@ -1843,6 +1851,7 @@ int bicgstab(opmhip_ctx* c, opmhip_result* res) {
         }
     } scope(c);
     int rc;
+    c->minv_scale = 1.0;   // CPR delivers finished vectors; the ILU0 application sets its factor
     hipLaunchKernelGGL(k_bicg_init, dim3(nb), dim3(VB), 0, c->stream, n, c->d_b, c->d_r, c->d_rw, c->d_p, c->d_x, c->d_v, c->d_part, c->npart);
     if ((rc = finalize(c, FIN_INIT, nb))) return rc;
     // the reference's loop "for (it = 0.5; it < maxit; it += 0.5) { first half; it += 0.5; second half }" runs the half
@@ -1865,7 +1874,7 @@ int bicgstab(opmhip_ctx* c, opmhip_result* res) {
             prof_flush(c);
             for (size_t i = mark_next; i < c->prof.used; ++i) c->prof.cls[i] = -1;  // half h + 1 ran as no-ops
             // stopped on a first half: its update of x was left to the second half, which will not come
-            if ((h & 1) == 0) hipLaunchKernelGGL(k_bicg_xhalf, dim3(nb), dim3(VB), 0, c->stream, n, c->d_scal, c->d_x, c->d_pw);
+            if ((h & 1) == 0) hipLaunchKernelGGL(k_bicg_xhalf, dim3(nb), dim3(VB), 0, c->stream, n, c->d_scal, c->d_x, c->d_pw, c->minv_scale);
             break;
         }
     }
