@@ -21,9 +21,16 @@ int alloc_system(opmhip_ctx* c) {
     const Pattern& P = c->pat;
     const size_t n = (size_t)P.Nloc * BS;  // vectors carry the ghost cells at their tail (SpMV / assembly gathers)
     int rc;
-    if ((rc = dev_alloc(c, &c->d_A, (size_t)P.nnzb * BB))) return rc;
-    if ((rc = dev_alloc(c, &c->d_L, (size_t)P.nl * BB))) return rc;
-    if ((rc = dev_alloc(c, &c->d_U, (size_t)P.nu * BB))) return rc;
+    // Two blocks of slack behind the value arrays: the pipelined kernels issue their prefetch loads unconditionally (a load
+    // under a condition costs them their precise waits, see chain_sweep), and for an empty step or a step past the end that
+    // is one 16-byte line at the step's base address - which for the last, empty step is the end of the array.
+    constexpr size_t SLACK = 2 * BB;
+    if ((rc = dev_alloc(c, &c->d_A, (size_t)P.nnzb * BB + SLACK))) return rc;
+    if ((rc = dev_alloc(c, &c->d_L, (size_t)P.nl * BB + SLACK))) return rc;
+    if ((rc = dev_alloc(c, &c->d_U, (size_t)P.nu * BB + SLACK))) return rc;
+    OPMHIP_HIP(c, hipMemset(c->d_A + (size_t)P.nnzb * BB, 0, SLACK * sizeof(double)));
+    OPMHIP_HIP(c, hipMemset(c->d_L + (size_t)P.nl * BB, 0, SLACK * sizeof(double)));
+    OPMHIP_HIP(c, hipMemset(c->d_U + (size_t)P.nu * BB, 0, SLACK * sizeof(double)));
     if ((rc = dev_alloc(c, &c->d_invD, (size_t)P.Nb * BB))) return rc;
     double** vecs[] = {&c->d_b, &c->d_x, &c->d_r, &c->d_rw, &c->d_p, &c->d_v, &c->d_s, &c->d_t, &c->d_pw, &c->d_vu, &c->d_stageV};
     for (double** v : vecs) {

@@ -210,6 +210,43 @@ def test_dense_random_rows(pkg, orc, reorder):
     assert np.linalg.norm(r) < 1e-8 * np.linalg.norm(b) * 1.001
 
 
+@pytest.mark.parametrize("reorder", REORDERS)
+def test_block_diagonal_and_nearly_empty_factors(pkg, orc, reorder):
+    """No off-diagonal blocks at all (L and U are empty arrays), and a chain of three rows in a sea of isolated ones: the
+    prefetch stages of the pipelined kernels read "some valid entry" for idle slots and empty steps - here there is next to
+    none, and the base address of the last, empty step is the end of the array"""
+    rng = np.random.default_rng(8)
+    for Nb, links in ((150, []), (130, [(40, 41), (41, 42)])):
+        nb = [set([i]) for i in range(Nb)]
+        for a, b in links:
+            nb[a].add(b); nb[b].add(a)
+        rp = np.zeros(Nb + 1, np.int32)
+        cols = []
+        for i in range(Nb):
+            cols.extend(sorted(nb[i])); rp[i + 1] = len(cols)
+        ci = np.array(cols, np.int32)
+        val = rng.uniform(-0.1, 0.1, (len(ci), 3, 3))
+        row = np.repeat(np.arange(Nb), np.diff(rp))
+        val[ci == row] += 2.0 * np.eye(3)
+        v = np.ascontiguousarray(val.reshape(-1))
+        b = rng.standard_normal(Nb * 3)
+        s = pkg.capi.HipSolver(tolerance=1e-10, maxit=50, reorder=reorder)
+        res = s.solve_system(Nb, rp, ci, v.copy(), b)
+        x = s.get_result()
+        assert res.converged
+        np.testing.assert_allclose(orc.spmv(Nb, rp, ci, v, x), b, rtol=1e-8, atol=1e-10)
+        to, fr, rpc = s.ordering()
+        rr, rc, rv = orc.reorder_matrix(Nb, rp, ci, v, to, fr)
+        luo = orc.ilu0_factor(Nb, rr, rc, rv)
+        assert np.array_equal(s.ilu0_factor(), luo)
+        d = rng.standard_normal(Nb * 3)
+        vo = orc.ilu0_apply(Nb, rr, rc, luo, d.reshape(Nb, 3)[fr].reshape(-1), w=0.9, mode="post_scale")
+        assert np.array_equal(s.ilu0_apply(d), vo.reshape(Nb, 3)[to].reshape(-1))
+        y = rng.standard_normal(Nb * 3)
+        yo = orc.spmv(Nb, rr, rc, rv, y.reshape(Nb, 3)[fr].reshape(-1)).reshape(Nb, 3)[to].reshape(-1)
+        assert np.array_equal(s.spmv(y), yo)
+
+
 def test_wells_operator(pkg, orc):
     rng = np.random.default_rng(11)
     Nb, rp, ci, v = laplace_block_system(12, 10, 6, seed=13)
