@@ -20,7 +20,7 @@
 extern "C" {
 #endif
 
-#define OPMHIP_ABI_VERSION 2
+#define OPMHIP_ABI_VERSION 3 /* 3: opmhip_fluid gained pc_scaling, opmhip_set_pcw */
 
 typedef struct opmhip_ctx opmhip_ctx;
 
