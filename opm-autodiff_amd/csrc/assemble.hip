@@ -102,7 +102,7 @@ template <class E, class DP> __device__ __forceinline__ E tab1(DP x, DP y, int n
     return y0 + (y1 - y0) * (xv - x0) / (x1 - x0);
 }
 // plain bilinear interpolation in (x, y) with per-column y grids (UniformXTabulated2DFunction; the policy the Norne PVT
-// points select): oil (x = Rs, y = p_o), wet gas (x = p_g, y = Rv)
+// points select): oil (x = Rs, y = p_o)
 struct Tab2Desc { int nx, xs, yoff, ys; };
 template <class E, class DP> __device__ __forceinline__ E tab2g(const TablesT<DP>& T, const Tab2Desc& G, int voff, const E& xv, const E& yv) {
     const DP xs = T.dbl + G.xs;
@@ -123,8 +123,33 @@ template <class E, class DP> __device__ __forceinline__ E tab2g(const TablesT<DP
 template <class E, class DP> __device__ __forceinline__ E tab2(const TablesT<DP>& T, const PvtRegionDesc& D, int voff, const E& xv, const E& yv) {
     return tab2g<E, DP>(T, Tab2Desc{D.o_nx, D.o_xs, D.o_yoff, D.o_ys}, voff, xv, yv);
 }
-template <class E, class DP> __device__ __forceinline__ E tab2wg(const TablesT<DP>& T, const PvtRegionDesc& D, int voff, const E& pg, const E& Rv) {
-    return tab2g<E, DP>(T, Tab2Desc{D.wg_n, D.wg_xs, D.wg_yoff, D.wg_ys}, voff, pg, Rv);
+// wet gas (x = p_g, y = Rv): interpolation guided by the columns' LAST samples (the saturated Rv), the shift fading linearly
+// to 0 at Rv = 0 - the policy the 16-digit saturations of tests/test_equil.cc DeckWithRSVDAndRVVD / DeckWithPBVDAndPDVD
+// select (oracle/fluid.hpp Tab2D, guide = 2); same statements, same order
+template <class E, class DP> __device__ __forceinline__ E tab2wg(const TablesT<DP>& T, const PvtRegionDesc& D, int voff, const E& xv, const E& yv) {
+    const DP xs = T.dbl + D.wg_xs;
+    const int* yo = T.idx + D.wg_yoff;
+    const int i = seg_right(xs, D.wg_n, val(xv));
+    const E alpha = (xv - xs[i]) / (xs[i + 1] - xs[i]);
+    const DP y1 = T.dbl + D.wg_ys + yo[i];
+    const DP y2 = T.dbl + D.wg_ys + yo[i + 1];
+    const DP v1 = T.dbl + voff + yo[i];
+    const DP v2 = T.dbl + voff + yo[i + 1];
+    const int n1 = yo[i + 1] - yo[i], n2 = yo[i + 2] - yo[i + 1];
+    E yLower = yv, yUpper = yv;
+    const double e0 = y1[n1 - 1], e1 = y2[n2 - 1];
+    const E yEnd = e0 * (1.0 - alpha) + e1 * alpha;
+    if (val(yEnd) > 0.0) {
+        const E shift = (e1 - e0) * yv / yEnd;
+        yLower = yv - alpha * shift;
+        yUpper = yv + shift - alpha * shift;
+    }
+    const int j1 = seg_right(y1, n1, val(yLower)), j2 = seg_right(y2, n2, val(yUpper));
+    const E beta1 = (yLower - y1[j1]) / (y1[j1 + 1] - y1[j1]);
+    const E beta2 = (yUpper - y2[j2]) / (y2[j2 + 1] - y2[j2]);
+    const E s1 = v1[j1] * (1.0 - beta1) + v1[j1 + 1] * beta1;
+    const E s2 = v2[j2] * (1.0 - beta2) + v2[j2 + 1] * beta2;
+    return s1 * (1.0 - alpha) + s2 * alpha;
 }
 // PiecewiseLinearTwoPhaseMaterial: constant outside the table; a value on a node belongs to the segment on its left
 template <class E, class DP> __device__ __forceinline__ E pwlin(DP x, DP y, int n, const E& xv) {

@@ -158,28 +158,21 @@ def wet_gas_setup(name, make_props):
     return d, r
 
 
-# Saturations of the three cells next to the gas-oil contact: the reference's tolerance is 1e-4 % (5e-4 %, 10 %); we reproduce
-# them to 1e-4 ABSOLUTE only (4e-5 relative on the RSVD/RVVD deck, 3e-4 on the PBVD/PDVD deck whose gas carries more oil).  Everything else - the four phase pressures (3e-10 relative on the RSVD/RVVD deck), every Rs and
-# Rv value, the saturations of the other 17 cells - is within the reference's own tolerance.  The residual corresponds to
-# 0.5-1.3 Pa in p_g - p_w (p_g - p_o) within 7.5 m of the contact, growing linearly with the distance from it and with Rv, as if
-# the vaporised-oil term of the reference's gas density were 0.4 % smaller - while its gas pressure 42.5 m above the contact
-# agrees with ours to 0.004 Pa (the expected pressures may predate the expected saturations, which carry 16 digits).  Our gas
-# curve equals a 1e-13 DOP853 integration of the same density function, and neither the "LeftExtreme" nor the "RightExtreme"
-# interpolation policy of UniformXTabulated2DFunction (oil or gas table) removes it (tools checked in the round-2 notes of
-# DESIGN.md).  Cause not found; stated rather than hidden.
-SAT_ATOL_NEAR_CONTACT = 1e-4
+# Round 2 met the saturations of the three cells next to the gas-oil contact to 1e-4 absolute only.  Cause (round 3): the
+# reference's WetGasPvt interpolates its (p_g, Rv) tables along guide lines ("RightExtreme": parallel to the saturated line
+# at Rv = RvSat, vertical at Rv = 0), not vertically; with that policy in oracle/fluid.hpp (Tab2D, guide = 2) and on the
+# device (assemble.hip tab2wg) all 60 saturations of every deck are within the reference's own tolerance (5e-14 absolute on
+# the two decks whose expectations carry 16 digits).  The four pressures of DeckWithRSVDAndRVVD / DeckWithPBVDAndPDVD are
+# printed with 10 / 8 digits and now differ by 4.3 / 16 Pa (3e-7 / 1.1e-6 relative, tolerance 1e-6 / 5e-6): they predate the
+# saturations.
 
 
 def check_wet_gas(d, r):
     e = d["expected"]
     rel, srel = e["reltol_percent"] / 100.0, e["sat_reltol_percent"] / 100.0
     np.testing.assert_allclose([r["pw"][0], r["pw"][-1], r["po"][0], r["po"][-1]], [e["pw_first"], e["pw_last"], e["po_first"], e["po_last"]], rtol=rel)
-    near = np.zeros(len(r["sw"]), bool)
-    near[7:10] = True          # cell centres 37.5, 42.5, 47.5 m; gas-oil contact at 45 m
-    for k in ("sw", "so", "sg"):
-        a, b = np.asarray(r[k]), np.asarray(e[k])
-        np.testing.assert_allclose(a[~near], b[~near], rtol=srel, atol=1e-12)
-        np.testing.assert_allclose(a[near], b[near], rtol=srel, atol=SAT_ATOL_NEAR_CONTACT)
+    for k in ("sw", "so", "sg"):      # BOOST_CHECK_CLOSE: relative, exact where the expectation is 0
+        np.testing.assert_allclose(np.asarray(r[k]), np.asarray(e[k]), rtol=srel, atol=1e-12)
     np.testing.assert_allclose(r["rv"], e["rv"], rtol=rel)
     if "rs" in e:
         np.testing.assert_allclose(r["rs"], e["rs"], rtol=rel)
