@@ -20,7 +20,8 @@
 extern "C" {
 #endif
 
-#define OPMHIP_ABI_VERSION 3 /* 3: opmhip_fluid gained pc_scaling, opmhip_set_pcw */
+#define OPMHIP_ABI_VERSION 4 /* 4: opmhip_config names chain_length, spmv_pipe_wgs, preconditioner (were reserved[0..2]);
+                               * 3: opmhip_fluid gained pc_scaling, opmhip_set_pcw */
 
 typedef struct opmhip_ctx opmhip_ctx;
 
@@ -41,11 +42,22 @@ typedef enum opmhip_reorder {
     OPMHIP_REORDER_LEVEL_SCHEDULING = 1, /* same factors as the CPU's natural-order ILU0 (bda/Reorder.cpp:266-318) */
     OPMHIP_REORDER_GRAPH_COLORING = 2,   /* Jones-Plassmann rounds, deterministic weights (bda/Reorder.cpp:59-172) */
     OPMHIP_REORDER_GRAPH_COLORING_GREEDY = 3, /* first-fit colouring: red-black on Cartesian 7-point grids */
-    OPMHIP_REORDER_LINE_COLORING = 4 /* chains of <= config.reserved[0] (default 8) rows along each row's farthest
+    OPMHIP_REORDER_LINE_COLORING = 4 /* chains of <= config.chain_length (default 8) rows along each row's farthest
                                         neighbour (the vertical one in CpGrid's natural order), chains coloured greedily:
                                         an exact ILU0 of that ordering, near the natural order's strength at colouring's
                                         parallelism (no counterpart in the reference) */
 } opmhip_reorder;
+
+/* --linear-solver-configuration (linalg/setupPropertyTree.cpp:62-76).  The CPR variants: pressure system solved by one AMG
+ * V-cycle, ILU0 (relaxation 1) post-smoothing (setupPropertyTree.cpp:94-138); see csrc/cpr.hip for what of it is the
+ * reference's and what is not */
+typedef enum opmhip_preconditioner {
+    OPMHIP_PRECOND_ILU0 = 0,           /* "ilu0" */
+    OPMHIP_PRECOND_CPR_QUASIIMPES = 1, /* "cpr_quasiimpes": weights from the diagonal blocks (getQuasiImpesWeights.hpp:46-85) */
+    OPMHIP_PRECOND_CPR_TRUEIMPES = 2   /* "cpr" = "cpr_trueimpes" (the reference's default CPR): weights from the storage term
+                                          of the state on the device (contexts that assemble) or handed in with
+                                          opmhip_set_cpr_weights (getQuasiImpesWeights.hpp:89-128) */
+} opmhip_preconditioner;
 
 /* how the ILU relaxation factor w enters M^-1 */
 typedef enum opmhip_relax_mode {
@@ -65,14 +77,11 @@ typedef struct opmhip_config {
     int relax_mode;        /* opmhip_relax_mode */
     int reorder;           /* opmhip_reorder */
     int zero_diag_fix;     /* 1: exact 0.0 on a diagonal block's diagonal -> 1e-15 (bda/BdaBridge.cpp:125-161) */
-    int reserved[7];       /* [0] line colouring: rows per chain (0 = 8).  [1] pipelined SpMV: resident workgroups it is sized
-                            * for (0 = 2048, the MI355X default; < 0 = one tile per workgroup instead); tuning only, results
-                            * are the same bits either way.  [2] preconditioner: 0 = ILU0 (--linear-solver-configuration=ilu0),
-                            * 1 = CPR with quasi-IMPES weights (= cpr_quasiimpes, setupPropertyTree.cpp:94-138): pressure
-                            * system solved by one AMG V-cycle, ILU0 (relaxation 1) post-smoothing; see csrc/cpr.hip for what
-                            * of it is the reference's and what is not.  2 = the same with true-IMPES weights (= cpr /
-                            * cpr_trueimpes, the reference's default CPR): from the storage term of the state on the device
-                            * (contexts that assemble) or handed in with opmhip_set_cpr_weights.  Others: 0. */
+    int chain_length;      /* OPMHIP_REORDER_LINE_COLORING: rows per chain (0 = 8) */
+    int spmv_pipe_wgs;     /* pipelined SpMV: resident workgroups it is sized for (0 = 2048, the MI355X default; < 0 = one
+                            * tile per workgroup instead); tuning only, results are the same bits either way */
+    int preconditioner;    /* opmhip_preconditioner: --linear-solver-configuration */
+    int reserved[4];       /* 0 */
 } opmhip_config;
 
 /* bda::BdaResult (bda/BdaResult.hpp:28-40) plus the reference's per-phase timers. */
@@ -113,6 +122,8 @@ void opmhip_destroy(opmhip_ctx* ctx);
 /* last error text of this context (or of the failed create when ctx == NULL); never NULL */
 const char* opmhip_last_error(const opmhip_ctx* ctx);
 int opmhip_abi_version(void);
+/* waits until everything this context has enqueued on its stream is done (callers that time a region from outside) */
+int opmhip_synchronize(opmhip_ctx* ctx);
 
 /* ---- linear solve (drop-in for bda::BdaSolver<3>) --------------------------------------------------- */
 /* replaces: first-call branch of solve_system -> initialize + analyse_matrix
@@ -175,13 +186,13 @@ int opmhip_ilu0_apply(opmhip_ctx* ctx, const double* d, double* v);
 /* replaces: the weights argument of the CPR preconditioner (linalg/ISTLSolverEbos.hpp:440-475: getTrueImpesWeights /
  * getQuasiImpesWeights handed to the preconditioner factory).  weights: 3 doubles per block row, natural order - what
  * Amg::getTrueImpesWeights (linalg/getQuasiImpesWeights.hpp:89-128) returns; they stay in force for every later solve.
- * NULL: back to the weights the library computes itself (quasi-IMPES from the matrix, or - reserved[2] = 2, contexts that
+ * NULL: back to the weights the library computes itself (quasi-IMPES from the matrix, or - OPMHIP_PRECOND_CPR_TRUEIMPES, contexts that
  * assemble - true-IMPES from the storage term of the present state with the dt of the last opmhip_assemble). */
 int opmhip_set_cpr_weights(opmhip_ctx* ctx, const double* weights);
 /* the weights of the last CPR set-up (3 per block row, natural order): diagnosis and tests */
 int opmhip_get_cpr_weights(opmhip_ctx* ctx, double* weights);
 
-/* v = M_cpr^-1 d with the CPR preconditioner of the matrix now on the device (contexts created with reserved[2] = 1 or 2;
+/* v = M_cpr^-1 d with the CPR preconditioner of the matrix now on the device (contexts created with a CPR preconditioner;
  * needs opmhip_ilu0_factor first: the fine smoother's factors) - for parity tests of the preconditioner alone */
 int opmhip_cpr_apply(opmhip_ctx* ctx, const double* d, double* v);
 /* the ordering chosen at set_pattern: toOrder/fromOrder [Nb], rowsPerColor [num colours] (any may be NULL);
@@ -351,6 +362,10 @@ int opmhip_comm_init_rccl(opmhip_ctx* ctx, int nranks, int rank, const char* id1
 int opmhip_comm_init_loopback(opmhip_ctx* ctx, int nranks, int rank, const char* group_name);
 /* diagnostics: one RCCL all-reduce of {1 + rank, 2} on the context's stream; sum_out[2] */
 int opmhip_comm_selftest(opmhip_ctx* ctx, double* sum_out);
+/* what the communicator itself reports: info[0] = ncclCommCount, [1] = ncclCommUserRank, [2] = ncclCommCuDevice (the HIP
+ * device RCCL bound this rank to), [3] = kind (0 none, 1 loopback, 2 RCCL).  Loopback / no communicator: the context's own
+ * numbers.  bench.py prints them so that a multi-GPU record shows how many ranks RCCL actually connected. */
+int opmhip_comm_info(opmhip_ctx* ctx, int* info4);
 /* optional, before opmhip_set_static: the global id of every local cell (Nb + Nghost entries).  The assembly then adds a
  * row's face fluxes in ascending GLOBAL neighbour order, i.e. exactly the sum an undecomposed run forms, so that
  * residual and Jacobian do not depend on the decomposition down to the last bit. */

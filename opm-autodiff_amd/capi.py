@@ -18,6 +18,7 @@ ANALYSIS_FAILED, CREATE_PRECONDITIONER_FAILED, UNKNOWN_ERROR = -1, -2, -3
 INVALID_ARGUMENT, NOT_READY, DEVICE_ERROR, NO_DEVICE = -4, -5, -6, -7
 REORDER = {"level_scheduling": 1, "graph_coloring": 2, "graph_coloring_greedy": 3, "line_coloring": 4}
 RELAX = {"post_scale": 0, "in_sweep": 1}
+PRECONDITIONER = {"ilu0": 0, "cpr_quasiimpes": 1, "cpr": 2, "cpr_trueimpes": 2}   # opmhip_preconditioner
 
 
 class OpmHipError(RuntimeError):
@@ -29,7 +30,8 @@ class OpmHipError(RuntimeError):
 class Config(C.Structure):
     _fields_ = [("abi_version", C.c_int), ("device_id", C.c_int), ("verbosity", C.c_int), ("maxit", C.c_int),
                 ("tolerance", C.c_double), ("ilu_relaxation", C.c_double), ("relax_mode", C.c_int),
-                ("reorder", C.c_int), ("zero_diag_fix", C.c_int), ("reserved", C.c_int * 7)]
+                ("reorder", C.c_int), ("zero_diag_fix", C.c_int), ("chain_length", C.c_int), ("spmv_pipe_wgs", C.c_int),
+                ("preconditioner", C.c_int), ("reserved", C.c_int * 4)]
 
 
 class Result(C.Structure):
@@ -90,6 +92,9 @@ def lib():
         L.opmhip_cpr_levels.argtypes = [vp, ip, ip, C.c_int]
         L.opmhip_profile_enable.argtypes = [vp, C.c_int]
         L.opmhip_profile_get.argtypes = [vp, C.c_int, C.POINTER(C.c_longlong), C.POINTER(C.c_double)]
+        L.opmhip_synchronize.argtypes = [vp]
+        L.opmhip_comm_info.argtypes = [vp, ip]
+        L.opmhip_comm_selftest.argtypes = [vp, dp]
         _lib = L
     return _lib
 
@@ -131,11 +136,10 @@ class HipSolver:
         cfg.relax_mode = RELAX[relax_mode]
         cfg.reorder = REORDER[reorder]
         cfg.zero_diag_fix = int(zero_diag_fix)
-        cfg.reserved[0] = int(chain_length)  # line colouring: rows per chain
-        cfg.reserved[1] = int(spmv_pipe_wgs)  # pipelined SpMV: workgroups it is sized for (0 default, < 0 off; tests use small values)
-        # --linear-solver-configuration (setupPropertyTree.cpp:62-76; there "cpr" is short for cpr_trueimpes - here it keeps
-        # meaning the quasi-IMPES variant a context without a model can always form; ask for the other one by name)
-        cfg.reserved[2] = {"ilu0": 0, "cpr": 1, "cpr_quasiimpes": 1, "cpr_trueimpes": 2}[preconditioner]
+        cfg.chain_length = int(chain_length)  # line colouring: rows per chain
+        cfg.spmv_pipe_wgs = int(spmv_pipe_wgs)  # pipelined SpMV: workgroups it is sized for (0 default, < 0 off; tests use small values)
+        # --linear-solver-configuration (setupPropertyTree.cpp:62-76): "cpr" is short for cpr_trueimpes, as in Flow
+        cfg.preconditioner = PRECONDITIONER[preconditioner]
         self._h = C.c_void_p()
         rc = L.opmhip_create(C.byref(cfg), C.byref(self._h))
         if rc != SUCCESS:
@@ -266,6 +270,22 @@ class HipSolver:
         n, nnz = np.zeros(32, np.int32), np.zeros(32, np.int32)
         L = self._check(lib().opmhip_cpr_levels(self._h, _ptr(n), _ptr(nnz), 32))
         return [int(v) for v in n[:L]], [int(v) for v in nnz[:L]]
+
+    def synchronize(self):
+        """everything enqueued on the context's stream is done"""
+        self._check(lib().opmhip_synchronize(self._h))
+
+    def comm_info(self):
+        """what the communicator itself reports: dict(nranks = ncclCommCount, rank, device, kind)"""
+        a = np.zeros(4, np.int32)
+        self._check(lib().opmhip_comm_info(self._h, _ptr(a)))
+        return {"nranks": int(a[0]), "rank": int(a[1]), "device": int(a[2]), "kind": ["none", "loopback", "rccl"][int(a[3])]}
+
+    def comm_selftest(self):
+        """one RCCL all-reduce of (1 + rank, 2): -> (sum over ranks of 1 + rank, 2 * nranks)"""
+        a = np.zeros(2)
+        self._check(lib().opmhip_comm_selftest(self._h, _ptr(a)))
+        return float(a[0]), float(a[1])
 
     def time_kernel(self, which, reps=20):
         ms = C.c_double()

@@ -174,6 +174,8 @@ int opmhip_create(const opmhip_config* cfg, opmhip_ctx** out) {
     *out = nullptr;
     if (!cfg || cfg->abi_version != OPMHIP_ABI_VERSION) { g_err = "opmhip_create: config missing or ABI version mismatch"; return OPMHIP_INVALID_ARGUMENT; }
     if (cfg->maxit < 1 || !(cfg->tolerance > 0.0)) { g_err = "opmhip_create: maxit/tolerance out of range"; return OPMHIP_INVALID_ARGUMENT; }
+    if (cfg->preconditioner < OPMHIP_PRECOND_ILU0 || cfg->preconditioner > OPMHIP_PRECOND_CPR_TRUEIMPES) { g_err = "opmhip_create: unknown preconditioner"; return OPMHIP_INVALID_ARGUMENT; }
+    if (cfg->chain_length < 0) { g_err = "opmhip_create: chain_length < 0"; return OPMHIP_INVALID_ARGUMENT; }
     int ndev = 0;
     hipError_t e = hipGetDeviceCount(&ndev);
     if (e != hipSuccess || ndev <= 0) {
@@ -211,6 +213,13 @@ void opmhip_destroy(opmhip_ctx* c) {
 }
 
 const char* opmhip_last_error(const opmhip_ctx* c) { return c ? c->err.c_str() : g_err.c_str(); }
+
+int opmhip_synchronize(opmhip_ctx* c) {
+    if (!c) return OPMHIP_INVALID_ARGUMENT;
+    OPMHIP_HIP(c, hipSetDevice(c->device));
+    OPMHIP_HIP(c, hipStreamSynchronize(c->stream));
+    return OPMHIP_SUCCESS;
+}
 
 int opmhip_set_pattern(opmhip_ctx* c, int Nb, int nnzb, const int* rows, const int* cols) {
     return opmhip_set_pattern_dd(c, Nb, 0, nnzb, rows, cols);

@@ -63,11 +63,20 @@ int opmhip_set_fluid(opmhip_ctx* c, const opmhip_fluid* fluid) {
     if (!c) return OPMHIP_INVALID_ARGUMENT;
     return guarded(c, [&]() -> int {
         OPMHIP_HIP(c, hipSetDevice(c->device));
+        AsmDev& A = c->asmb;
+        // "setup, once": set_static sizes the intensive-quantity cache for THIS fluid's record layout and checks the region
+        // arrays against ITS table counts - another fluid afterwards would let the 19-field kernels write past 17-field buffers
+        if (A.static_set)
+            return fail(c, OPMHIP_INVALID_ARGUMENT, "set_fluid: the static data of this context is already set (opmhip_set_static) - the fluid cannot be replaced any more");
         FluidTables T;
         const std::string msg = build_fluid_tables(fluid, T);
         if (!msg.empty()) return fail(c, OPMHIP_INVALID_ARGUMENT, "set_fluid: %s", msg.c_str());
-        AsmDev& A = c->asmb;
         int rc;
+        if (A.fluid_set) {   // replaced before set_static: the old blobs go back (no kernel can be using them yet except a probe, which synchronises)
+            OPMHIP_HIP(c, hipStreamSynchronize(c->stream));
+            dev_free(c, &A.d_tab_dbl);
+            dev_free(c, &A.d_tab_idx);
+        }
         if ((rc = dev_upload(c, &A.d_tab_dbl, T.dbl))) return rc;
         if ((rc = dev_upload(c, &A.d_tab_idx, T.idx))) return rc;
         A.tab_ndbl = (int)T.dbl.size();
@@ -254,9 +263,11 @@ int opmhip_set_problem_extras(opmhip_ctx* c, const double* rvmax, const int* roc
                 if (rocknum[i] < 0 || rocknum[i] >= A.num_rock) return fail(c, OPMHIP_INVALID_ARGUMENT, "set_problem_extras: rocknum[%d] out of range", i);
         OPMHIP_HIP(c, hipSetDevice(c->device));
         int rc;
-        if (rvmax) { if ((rc = upload_cells(c, &A.d_rvmax, rvmax))) return rc; } else A.d_rvmax = nullptr;
-        if (rocknum) { if ((rc = upload_cells(c, &A.d_rocknum, rocknum))) return rc; } else A.d_rocknum = nullptr;
-        if (overburden) { if ((rc = upload_cells(c, &A.d_overburden, overburden))) return rc; } else A.d_overburden = nullptr;
+        // an array that is withdrawn goes back to the allocator (an assembly enqueued earlier may still read it: sync first)
+        if (!rvmax || !rocknum || !overburden) OPMHIP_HIP(c, hipStreamSynchronize(c->stream));
+        if (rvmax) { if ((rc = upload_cells(c, &A.d_rvmax, rvmax))) return rc; } else dev_free(c, &A.d_rvmax);
+        if (rocknum) { if ((rc = upload_cells(c, &A.d_rocknum, rocknum))) return rc; } else dev_free(c, &A.d_rocknum);
+        if (overburden) { if ((rc = upload_cells(c, &A.d_overburden, overburden))) return rc; } else dev_free(c, &A.d_overburden);
         if (A.state_set) {   // the cached intensive quantities depend on these arrays
             launch_iq_update(c);
             OPMHIP_HIP(c, hipGetLastError());

@@ -30,6 +30,9 @@ struct RcclApi {
     ncclResult_t (*Recv)(void*, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
     ncclResult_t (*GroupStart)() = nullptr;
     ncclResult_t (*GroupEnd)() = nullptr;
+    ncclResult_t (*CommCount)(const ncclComm_t, int*) = nullptr;
+    ncclResult_t (*CommUserRank)(const ncclComm_t, int*) = nullptr;
+    ncclResult_t (*CommCuDevice)(const ncclComm_t, int*) = nullptr;
     const char* (*GetErrorString)(ncclResult_t) = nullptr;
 };
 static RcclApi g_rccl;
@@ -46,6 +49,7 @@ static const char* load_rccl() {
     SYM(GetUniqueId, "ncclGetUniqueId") SYM(CommInitRank, "ncclCommInitRank") SYM(CommDestroy, "ncclCommDestroy")
     SYM(AllReduce, "ncclAllReduce") SYM(Send, "ncclSend") SYM(Recv, "ncclRecv") SYM(GroupStart, "ncclGroupStart")
     SYM(GroupEnd, "ncclGroupEnd") SYM(GetErrorString, "ncclGetErrorString")
+    SYM(CommCount, "ncclCommCount") SYM(CommUserRank, "ncclCommUserRank") SYM(CommCuDevice, "ncclCommCuDevice")
 #undef SYM
     g_rccl.lib = h;
     return nullptr;
@@ -269,6 +273,17 @@ int opmhip_comm_selftest(opmhip_ctx* c, double* sum_out) {
     OPMHIP_HIP(c, hipStreamSynchronize(c->stream));
     sum_out[0] = o[0];
     sum_out[1] = o[1];
+    return OPMHIP_SUCCESS;
+}
+
+int opmhip_comm_info(opmhip_ctx* c, int* info4) {
+    if (!c || !info4) return OPMHIP_INVALID_ARGUMENT;
+    info4[0] = c->comm.nranks; info4[1] = c->comm.rank; info4[2] = c->device; info4[3] = c->comm.kind;
+    if (c->comm.kind == COMM_RCCL) {
+        NCCLCHK(c, g_rccl.CommCount((ncclComm_t)c->comm.nccl, &info4[0]));
+        NCCLCHK(c, g_rccl.CommUserRank((ncclComm_t)c->comm.nccl, &info4[1]));
+        NCCLCHK(c, g_rccl.CommCuDevice((ncclComm_t)c->comm.nccl, &info4[2]));
+    }
     return OPMHIP_SUCCESS;
 }
 

@@ -466,7 +466,7 @@ static int cpr_weights(opmhip_ctx* c) {
     const Pattern& P = c->pat;
     CprDev& R = c->cpr;
     if (R.w_given) return OPMHIP_SUCCESS;
-    if (c->cfg.reserved[2] == 2) {
+    if (c->cfg.preconditioner == OPMHIP_PRECOND_CPR_TRUEIMPES) {
         const AsmDev& A = c->asmb;
         if (!A.static_set || !A.d_iq || !(A.last_dt > 0.0))
             return fail(c, OPMHIP_NOT_READY, "cpr (true-IMPES weights): no assembled state on this context - call opmhip_assemble first or hand the weights in (opmhip_set_cpr_weights)");

@@ -340,7 +340,7 @@ int build_pattern(opmhip_ctx* c, int Nb, int Nghost, int nnzb, const int* rows, 
         case OPMHIP_REORDER_GRAPH_COLORING: color_jp(Q, color, ncol); break;
         case OPMHIP_REORDER_GRAPH_COLORING_GREEDY: color_greedy(Q, color, ncol); break;
         case OPMHIP_REORDER_LINE_COLORING: {
-            maxLen = c->cfg.reserved[0] > 0 ? c->cfg.reserved[0] : 8;
+            maxLen = c->cfg.chain_length > 0 ? c->cfg.chain_length : 8;
             build_chains(Q, maxLen, CH);
             color_chains(Q, CH, chainColor, ncol);
             color.resize(Nb);

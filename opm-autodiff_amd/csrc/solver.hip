@@ -1578,9 +1578,9 @@ static int spmv_pipe_env() {   // OPMHIP_SPMV_PIPE (tuning): 0 = off, n > 1 = wo
     static const int v = [] { const char* e = std::getenv("OPMHIP_SPMV_PIPE"); return e ? std::atoi(e) : -1; }();
     return v;
 }
-// cfg.reserved[1]: resident workgroups the pipelined kernel is sized for (0 = default, < 0 = never use it)
+// cfg.spmv_pipe_wgs: resident workgroups the pipelined kernel is sized for (0 = default, < 0 = never use it)
 static int spmv_pipe_wgs(const opmhip_ctx* c) {
-    return c->cfg.reserved[1] != 0 ? c->cfg.reserved[1] : (spmv_pipe_env() > 1 ? spmv_pipe_env() : SPMV_PIPE_WGS);
+    return c->cfg.spmv_pipe_wgs != 0 ? c->cfg.spmv_pipe_wgs : (spmv_pipe_env() > 1 ? spmv_pipe_env() : SPMV_PIPE_WGS);
 }
 static bool spmv_pipelined(const opmhip_ctx* c) {
     const int w = spmv_pipe_wgs(c);
@@ -1599,7 +1599,7 @@ void launch_spmv(opmhip_ctx* c, const double* x, double* y, int ndot, const doub
     int es = -1, ee = -1;
     const bool timed = prof_kernel_scope(c, PROF_SPMV, &es, &ee);
     hipEvent_t e0 = timed ? c->prof.ev[es] : nullptr, e1 = timed ? c->prof.ev[ee] : nullptr;
-    // cfg.reserved[1]: resident workgroups the pipelined kernel is sized for (0 = default, < 0 = never use it)
+    // cfg.spmv_pipe_wgs: resident workgroups the pipelined kernel is sized for (0 = default, < 0 = never use it)
     const int pipeWgs = spmv_pipe_wgs(c);
     if (spmv_pipelined(c)) {
         // pipelined kernel: every workgroup walks through ceil(ntp / grid) launch positions; the grid is sized so that all

@@ -3,6 +3,7 @@
 // (opm/simulators/linalg/bda/BdaResult.hpp:28-40, BdaSolver.hpp:32-92, WellContributions.hpp:60-214) and this file is
 // not used: define OPMHIP_USE_OPM_HEADERS and include those instead.
 #pragma once
+#include <algorithm>
 #include <string>
 #include <vector>
 
@@ -58,6 +59,12 @@ public:
             cursorB += valSize;
             break;
         }
+    }
+    // the accessor INTEGRATION.md's patch adds to the reference class (its host vectors are private there)
+    void getHostArrays(const int** val_pointers, const int** Ccols_, const int** Bcols_, const double** Cnnzs_,
+                       const double** Dnnzs_, const double** Bnnzs_) const {
+        *val_pointers = valPointers.data(); *Ccols_ = Ccols.data(); *Bcols_ = Bcols.data();
+        *Cnnzs_ = Cnnzs.data(); *Dnnzs_ = Dnnzs.data(); *Bnnzs_ = Bnnzs.data();
     }
     // raw views for a backend
     unsigned dim = 3, dimWells = 4, numWells = 0;

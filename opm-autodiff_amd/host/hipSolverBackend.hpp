@@ -56,8 +56,8 @@ public:
         else if (ilu_reorder == "graph_coloring" || ilu_reorder.empty()) cfg.reorder = OPMHIP_REORDER_GRAPH_COLORING;
         else if (ilu_reorder == "line_coloring") cfg.reorder = OPMHIP_REORDER_LINE_COLORING;
         else throw std::logic_error("Error invalid argument for --opencl-ilu-reorder, usage: '--opencl-ilu-reorder=[level_scheduling|graph_coloring|line_coloring]'");
-        if (linsolver == "cpr_quasiimpes") cfg.reserved[2] = 1;
-        else if (linsolver == "cpr" || linsolver == "cpr_trueimpes") cfg.reserved[2] = 2;
+        if (linsolver == "cpr_quasiimpes") cfg.preconditioner = OPMHIP_PRECOND_CPR_QUASIIMPES;
+        else if (linsolver == "cpr" || linsolver == "cpr_trueimpes") cfg.preconditioner = OPMHIP_PRECOND_CPR_TRUEIMPES;
         else if (linsolver != "ilu0") throw std::invalid_argument(linsolver + " is not a valid setting for --linear-solver-configuration with --accelerator-mode=hip. Please use ilu0, cpr, cpr_trueimpes, or cpr_quasiimpes");
         const int rc = opmhip_create(&cfg, &ctx);
         if (rc != OPMHIP_SUCCESS) throw std::logic_error(std::string("hipSolverBackend: ") + opmhip_last_error(nullptr));

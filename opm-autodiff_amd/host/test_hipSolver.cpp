@@ -2,7 +2,7 @@
 // (MatrixMarket, ISTL_STRUCT blocked 3 3), run bda::hipSolverBackend<3>::solve_system + get_result with tol / maxit
 // from the command line, print the solution.  The expected vector is checked by the calling pytest
 // (tests/test_gpu_host_cpp.py) against the fixture in tests/golden/linalg/expected.json.
-//   usage: test_hipSolver matr33.txt rhs3.txt tol maxit reorder
+//   usage: test_hipSolver matr33.txt rhs3.txt tol maxit reorder [wells]
 #include <cstdio>
 #include <cstdlib>
 #include <fstream>
@@ -67,6 +67,21 @@ int main(int argc, char** argv) {
         return 77;
     }
     Opm::WellContributions wellContribs;
+    if (argc > 6 && std::string(argv[6]) == "wells") {
+        // one standard well with two perforations (cells 1 and Nb - 2), filled the way StandardWellEval does
+        // (wells/StandardWellEval.cpp:1206-1250: C, D, B); the shim reads the arrays back - directly from the stand-in
+        // class, or through getHostArrays when built with OPMHIP_USE_OPM_HEADERS
+        wellContribs.setBlockSize(3, 4);
+        wellContribs.addNumBlocks(2);
+        wellContribs.alloc();
+        const int wcols[2] = {1, Nb - 2};
+        double C[24], B[24], D[16];
+        for (int i = 0; i < 24; ++i) { C[i] = 0.01 * (1 + (i * 7) % 5); B[i] = 0.02 * (1 + (i * 3) % 7); }
+        for (int i = 0; i < 16; ++i) D[i] = (i % 5 == 0) ? 0.5 : 0.01 * (i % 3);
+        wellContribs.addMatrix(Opm::WellContributions::MatrixType::C, wcols, C, 2);
+        wellContribs.addMatrix(Opm::WellContributions::MatrixType::D, nullptr, D, 1);
+        wellContribs.addMatrix(Opm::WellContributions::MatrixType::B, wcols, B, 2);
+    }
     bda::BdaResult result;
     std::vector<double> x(rhs.size());
     const bda::SolverStatus st = backend->solve_system(3 * Nb, 9 * (int)cols.size(), 3, vals.data(), rows.data(), cols.data(), rhs.data(), wellContribs, result);

@@ -46,7 +46,7 @@ def jacobian_case(pkg, orc, shape=(20, 18, 14), dt_days=10.0, its=1):
 def test_cpr_apply_bitwise_and_solve(pkg, orc, reorder):
     case, jac, res = jacobian_case(pkg, orc, its=2)
     Nb, rp, ci = case["Nb"], case["rowptr"], case["col"]
-    s = pkg.capi.HipSolver(reorder=reorder, preconditioner="cpr", tolerance=1e-2)
+    s = pkg.capi.HipSolver(reorder=reorder, preconditioner="cpr_quasiimpes", tolerance=1e-2)
     s.set_pattern(Nb, rp, ci)
     s.upload_system(jac)
     s.ilu0_factor(want_factors=False)
@@ -77,7 +77,7 @@ def test_cpr_matr33_flexiblesolver_vector(pkg, orc, golden):
     Nb, rp, ci, v, b = _load(pkg, golden, "matr33.txt", "rhs3.txt")
     with open(os.path.join(golden, "linalg", "expected.json")) as f:
         e = json.load(f)["exact_noprec_tol1e-12_maxit200"]
-    s = pkg.capi.HipSolver(reorder="level_scheduling", preconditioner="cpr", tolerance=0.5, maxit=20, zero_diag_fix=False)
+    s = pkg.capi.HipSolver(reorder="level_scheduling", preconditioner="cpr_quasiimpes", tolerance=0.5, maxit=20, zero_diag_fix=False)
     r = s.solve_system(Nb, rp, ci, v.copy(), b)
     assert r.converged and r.it == 0.5
     _cmp(s.get_result(), e)
@@ -87,7 +87,7 @@ def test_cpr_on_a_laplace_like_block_system(pkg, orc):
     """a system without the black-oil structure (random dense blocks): CPR must still be a valid preconditioner"""
     Nb, rp, ci, v = laplace_block_system(16, 14, 12, seed=4)
     b = np.random.default_rng(2).standard_normal(3 * Nb)
-    s = pkg.capi.HipSolver(reorder="line_coloring", preconditioner="cpr", tolerance=1e-8)
+    s = pkg.capi.HipSolver(reorder="line_coloring", preconditioner="cpr_quasiimpes", tolerance=1e-8)
     r = s.solve_system(Nb, rp, ci, v.copy(), b)
     assert r.converged
     x = s.get_result()
@@ -100,16 +100,16 @@ def test_newton_loop_with_cpr(pkg, orc):
     case = pkg.decks.cartesian_case(24, 24, 18, state="mixed", heterogeneous=True)
     src = pkg.decks.five_spot_source(case, rate_sm3_per_day=40.0)
     out = {}
-    for prec in ("ilu0", "cpr"):
+    for prec in ("ilu0", "cpr_quasiimpes"):
         m = pkg.capi.HipModel(case, reorder="line_coloring", preconditioner=prec)
         m.set_state(case["pv"], case["meaning"])
         m.set_source(src)
         rep = pkg.newton.BlackoilModelHip(m).step(10 * 86400.0)
         out[prec] = (rep.total_newton_iterations, rep.total_linear_iterations, m.get_state())
-    assert abs(out["ilu0"][0] - out["cpr"][0]) <= 2   # inexact (1e-2) linear solves: the Newton paths differ slightly
-    assert out["cpr"][1] < out["ilu0"][1], (out["ilu0"][1], out["cpr"][1])
+    assert abs(out["ilu0"][0] - out["cpr_quasiimpes"][0]) <= 2   # inexact (1e-2) linear solves: the Newton paths differ slightly
+    assert out["cpr_quasiimpes"][1] < out["ilu0"][1], (out["ilu0"][1], out["cpr_quasiimpes"][1])
     pa, ma = out["ilu0"][2]
-    pb, mb = out["cpr"][2]
+    pb, mb = out["cpr_quasiimpes"][2]
     assert np.array_equal(ma, mb)
     np.testing.assert_allclose(pa.reshape(-1, 3)[:, 1], pb.reshape(-1, 3)[:, 1], rtol=1e-4)
     np.testing.assert_allclose(pa.reshape(-1, 3)[:, 0], pb.reshape(-1, 3)[:, 0], atol=2e-3)

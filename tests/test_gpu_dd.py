@@ -167,6 +167,11 @@ def test_rccl_communicator_single_rank(pkg):
     out = (C.c_double * 2)()
     s._check(L.opmhip_comm_selftest(s._h, out))
     assert (out[0], out[1]) == (1.0, 2.0)
+    # what RCCL itself says about the communicator (bench.py prints this for N > 1: ncclCommCount must equal --gpus)
+    info = s.comm_info()
+    assert info == {"nranks": 1, "rank": 0, "device": 0, "kind": "rccl"}
+    assert s.comm_selftest() == (1.0, 2.0)
+    assert pkg.capi.HipSolver().comm_info()["kind"] == "none"
 
 
 def irregular_global_case(pkg, Nb=3000, seed=41):

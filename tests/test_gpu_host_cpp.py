@@ -43,6 +43,33 @@ def test_hipSolverBackend_matr33(golden, reorder):
     assert np.linalg.norm(A @ x - b) < 0.5 * np.linalg.norm(b)
 
 
+def test_hipSolverBackend_built_the_way_opm_simulators_builds_it(pkg, golden):
+    """The OPMHIP_USE_OPM_HEADERS branch of hipSolverBackend.hpp - reference include paths, WellContributions reached through
+    the getHostArrays accessor of INTEGRATION.md - gives the same bits as the stand-alone build, with a standard well, and
+    both equal the C-ABI called from Python with the same well (host/Makefile: test_hipSolver_opmhdr)."""
+    args = [os.path.join(golden, "linalg", "matr33.txt"), os.path.join(golden, "linalg", "rhs3.txt"), "1e-8", "50", "level_scheduling", "wells"]
+    outs = []
+    for exe in ("test_hipSolver", "test_hipSolver_opmhdr"):
+        out = subprocess.run([_exe(exe)] + args, capture_output=True, text=True)
+        assert out.returncode == 0, out.stderr
+        outs.append(out.stdout)
+    assert outs[0] == outs[1]
+    x = np.array([float(v) for v in outs[0].strip().splitlines()[1:]])
+    Nb, rp, ci, v, _ = pkg.mmio.read_block_matrix(args[0])
+    b = pkg.mmio.read_block_vector(args[1])
+    C = np.array([0.01 * (1 + (i * 7) % 5) for i in range(24)])
+    B = np.array([0.02 * (1 + (i * 3) % 7) for i in range(24)])
+    D = np.array([0.5 if i % 5 == 0 else 0.01 * (i % 3) for i in range(16)])
+    wells = dict(numWells=1, val_pointers=[0, 2], Ccols=[1, Nb - 2], Bcols=[1, Nb - 2], Cnnzs=C, Dnnzs=D, Bnnzs=B)
+    s = pkg.capi.HipSolver(tolerance=1e-8, maxit=50, reorder="level_scheduling", ilu_relaxation=1.0)
+    res = s.solve_system(Nb, rp, ci, v.copy(), b, wells=wells)
+    assert res.converged and np.array_equal(x, s.get_result())
+    # and the well does something: the solution differs from the one without it
+    out0 = subprocess.run([_exe("test_hipSolver")] + args[:-1], capture_output=True, text=True)
+    x0 = np.array([float(t) for t in out0.stdout.strip().splitlines()[1:]])
+    assert np.abs(x - x0).max() > 1e-6 * np.abs(x0).max()
+
+
 def test_BlackoilModelHip_step_matches_python_loop(pkg, tmp_path):
     case = pkg.decks.cartesian_case(12, 12, 8, state="mixed", heterogeneous=False)
     src = pkg.decks.five_spot_source(case, rate_sm3_per_day=40.0)

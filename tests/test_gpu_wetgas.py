@@ -6,6 +6,7 @@ import numpy as np
 import pytest
 
 import oracle_bind
+import helpers
 from helpers import ROCKTAB_2, rv_sat, wetgas_case
 
 pytestmark = pytest.mark.gpu
@@ -134,3 +135,27 @@ def test_newton_steps_with_wet_gas_match_oracle(pkg, orc):
         po, mo = o.get_state()
         assert np.array_equal(mm, mo)
         np.testing.assert_allclose(pm, po, rtol=1e-7, atol=1e-12)
+
+
+def test_second_set_fluid_is_refused_once_the_static_data_is_set(pkg, orc):
+    """set_static sizes the intensive-quantity cache for the fluid's record layout (17 or 19 fields) and checks the region
+    arrays against its table counts: a PVTG fluid handed in afterwards would make the 19-field kernels write past the
+    17-field buffers.  The call is refused and the context keeps working with the fluid it has."""
+    import ctypes as C
+    case = pkg.decks.cartesian_case(6, 5, 4, state="mixed", heterogeneous=True)
+    m = pkg.capi.HipModel(case, reorder="line_coloring")
+    m.set_state(case["pv"], case["meaning"])
+    j0, r0 = m.assemble(86400.0, 0)
+    wet_fluid = helpers.wetgas_fluid(pkg)   # owns the arrays the descriptor points at
+    wet = wet_fluid.desc()
+    L = pkg.capi.lib()
+    assert L.opmhip_set_fluid(m._h, C.addressof(wet)) == pkg.capi.INVALID_ARGUMENT
+    assert b"set_static" in L.opmhip_last_error(m._h)
+    assert L.opmhip_iq_fields(m._h) == 17
+    j1, r1 = m.assemble(86400.0, 0)
+    assert np.array_equal(j0, j1) and np.array_equal(r0, r1)
+    # before set_static the fluid may still be replaced (the old table blobs are given back)
+    f = pkg.capi.HipFluid(pkg.fluid.spe1_fluid()[0])
+    assert L.opmhip_set_fluid(f._h, C.addressof(wet)) == pkg.capi.SUCCESS
+    p = np.array([150e5, 200e5])
+    assert np.array_equal(f.probe_gas(p, 0.0), pkg.capi.HipFluid(helpers.wetgas_fluid(pkg)).probe_gas(p, 0.0))
