@@ -108,21 +108,81 @@ def cpu_baseline_run(pkg, case, src, threads, budget_s, max_newton):
                         "update": rep.update_time}}
 
 
-def cpu_baseline(pkg, case, src):
-    """The CPU port (oracle/) timed on the host cores on a bounded sample of the same workload: the same Newton and
-    time-stepping loop from the same initial state.  Headline = all cores of this box's share (at most 16), run the way N
-    MPI ranks of Flow would: OpenMP-threaded assembly, block-Jacobi ILU0 over N contiguous row ranges, threaded
-    SpMV / scalar products, BiCGStab to 1e-2, relaxation 0.9.  The 1-thread run (natural-order ILU0 = one Flow rank) is
-    reported beside it."""
+def host_cpu_share():
+    """what this process may use of the host: CPUs in the affinity mask, physical cores among them, and the cgroup's CPU
+    quota (cpu.max: a box may show 256 logical CPUs and still be throttled to a share of them)"""
     try:
-        avail = len(os.sched_getaffinity(0))
+        mask = sorted(os.sched_getaffinity(0))
     except AttributeError:
-        avail = os.cpu_count() or 1
-    threads = max(1, min(16, avail))
+        mask = list(range(os.cpu_count() or 1))
+    cores = set()
+    for cpu in mask:
+        try:
+            with open("/sys/devices/system/cpu/cpu%d/topology/thread_siblings_list" % cpu) as f:
+                cores.add(f.read().strip())
+        except OSError:
+            cores.add(str(cpu))
+    quota = None
+    for path in ("/sys/fs/cgroup/cpu.max", "/sys/fs/cgroup/cpu/cpu.cfs_quota_us"):
+        try:
+            with open(path) as f:
+                t = f.read().split()
+            if path.endswith("cpu.max"):
+                quota = None if t[0] == "max" else float(t[0]) / float(t[1])
+            else:
+                q = float(t[0])
+                with open("/sys/fs/cgroup/cpu/cpu.cfs_period_us") as g:
+                    quota = None if q <= 0 else q / float(g.read())
+            break
+        except (OSError, ValueError, IndexError):
+            continue
+    return {"cpus_in_affinity_mask": len(mask), "physical_cores_in_mask": len(cores), "cgroup_cpu_quota": quota}
+
+
+def interleave_new_pages():
+    """set_mempolicy(MPOL_INTERLEAVE, all nodes): pages touched from here on are spread round-robin over the NUMA nodes,
+    so that the threads of both sockets of the host find half of every array in local memory whoever touched it first
+    (the oracle's std::vectors are value-initialised by the thread that resizes them).  Best effort: False if refused."""
+    import ctypes
+    try:
+        nodes = [int(d[4:]) for d in os.listdir("/sys/devices/system/node") if d.startswith("node") and d[4:].isdigit()]
+        if len(nodes) < 2:
+            return False
+        mask = (ctypes.c_ulong * 16)()
+        for nd in nodes:
+            mask[nd // 64] |= 1 << (nd % 64)
+        libc = ctypes.CDLL(None, use_errno=True)
+        return libc.syscall(238, 3, mask, 16 * 64 + 1) == 0   # x86-64: SYS_set_mempolicy = 238, MPOL_INTERLEAVE = 3
+    except Exception:   # noqa: BLE001
+        return False
+
+
+def cpu_baseline(pkg, case, src, nnzb):
+    """The CPU port (oracle/) timed on the host cores on a bounded sample of the same workload: the same Newton and
+    time-stepping loop from the same initial state, run the way N MPI ranks of Flow would: OpenMP-threaded assembly,
+    block-Jacobi ILU0 over N contiguous row ranges, threaded SpMV / scalar products, BiCGStab to 1e-2, relaxation 0.9.
+    N is MEASURED: a short sample at 16, 32, 64 threads and at every physical core this process may use (bounded by the
+    cgroup's CPU quota when there is one), the headline run with the fastest.  The 1-thread run (natural-order ILU0 = one
+    Flow rank) is reported beside it."""
+    share = host_cpu_share()
+    limit = share["physical_cores_in_mask"]
+    if share["cgroup_cpu_quota"]:
+        limit = max(1, min(limit, int(share["cgroup_cpu_quota"] + 0.5)))
+    interleaved = interleave_new_pages()
+    cand = sorted({t for t in (16, 32, 64, limit) if 1 < t <= limit} | ({limit} if limit > 1 else set()))
+    sweep = {}
+    for t in cand:   # 3 Newton iterations each (the first carries the one-time allocations): a few seconds per candidate
+        r = cpu_baseline_run(pkg, case, src, t, budget_s=6.0, max_newton=3)
+        sweep[t] = r["value"]
+    threads = max(sweep, key=sweep.get) if sweep else 1
     mt = cpu_baseline_run(pkg, case, src, threads, budget_s=18.0, max_newton=24) if threads > 1 else None
-    st = cpu_baseline_run(pkg, case, src, 1, budget_s=14.0, max_newton=8)
+    st = cpu_baseline_run(pkg, case, src, 1, budget_s=12.0, max_newton=8)
     head = mt if (mt is not None and mt["value"] > st["value"]) else st
     cores = threads if head is mt else 1
+    # algorithmic bytes of one BiCGStab iteration (2 SpMV + 2 M^-1 + the vector passes), as for the GPU's linear_solve_GBps
+    B = alg_bytes(case["Nb"], nnzb)
+    it_bytes = 2 * B["spmv"] + 2 * B["ilu_apply"] + 3 * B["vector"]
+    ls_gbps = lambda r: round(r["linear_iterations"] * it_bytes / r["seconds"]["linear_solve"] / 1e9, 1) if r["seconds"]["linear_solve"] > 0 else None
     cpu_model = "unknown"
     try:
         with open("/proc/cpuinfo") as f:
@@ -134,8 +194,12 @@ def cpu_baseline(pkg, case, src):
         pass
     out = {
         "value": head["value"], "unit": "Newton iterations/s", "cores": cores, "kind": "port",
-        "host": {"cpu_model": cpu_model, "logical_cpus": os.cpu_count(), "cpus_in_affinity_mask": avail, "threads_tried": [threads, 1] if mt is not None else [1]},
-        "multi_thread": None if mt is None else {"threads": threads, "value": mt["value"], "seconds": mt["seconds"], "newton_iterations": mt["newton_iterations"]},
+        "host": dict(share, cpu_model=cpu_model, logical_cpus=os.cpu_count(), numa_interleave=interleaved,
+                     thread_sweep_newton_its_per_s={str(k): round(v, 3) for k, v in sweep.items()},
+                     cores_note="threads = the fastest of the sweep; candidates are bounded by the physical cores in the affinity mask and by the cgroup CPU quota"),
+        "linear_solve_GBps": ls_gbps(head),
+        "multi_thread": None if mt is None else {"threads": threads, "value": mt["value"], "seconds": mt["seconds"], "newton_iterations": mt["newton_iterations"],
+                                                 "linear_solve_GBps": ls_gbps(mt)},
         "sample": "the first %d Newton iterations of the same %d-cell case and time-step control on the CPU restatement "
                   "(oracle/), %d thread(s): %s, BiCGStab to 1e-2; %d linear iterations in all; %.1f s of wall time"
                   % (head["newton_iterations"], case["Nb"], cores,
@@ -144,7 +208,7 @@ def cpu_baseline(pkg, case, src):
                      head["linear_iterations"], head["cpu_seconds"]),
         "newton_iterations": head["newton_iterations"], "linear_iterations": head["linear_iterations"], "seconds": head["seconds"],
         "single_thread": {"value": st["value"], "newton_iterations": st["newton_iterations"], "linear_iterations": st["linear_iterations"],
-                          "seconds": st["seconds"]},
+                          "seconds": st["seconds"], "linear_solve_GBps": ls_gbps(st)},
     }
     return out
 
@@ -208,8 +272,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--steady-after", type=int, default=200, help="second timed window starts at this Newton iteration (0: none)")
     ap.add_argument("--steady-steps", type=int, default=100)
-    ap.add_argument("--preconditioner", default="ilu0", choices=["ilu0", "cpr", "cpr_trueimpes"], help="--linear-solver-configuration of the run behind `value`")
-    ap.add_argument("--no-cpr-side-run", action="store_true", help="skip the second, shorter run with the CPR preconditioner (extra key `cpr`)")
+    ap.add_argument("--preconditioner", default="ilu0", choices=["ilu0", "cpr", "cpr_trueimpes", "cpr_quasiimpes"], help="--linear-solver-configuration of the run behind `value`")
+    ap.add_argument("--no-cpr-side-run", action="store_true", help="skip the side runs with the CPR preconditioners (extra keys `cpr`, `cpr_quasiimpes`)")
     a = ap.parse_args()
 
     import torch
@@ -231,17 +295,16 @@ def main():
         dist.init_process_group(backend="gloo")
     # The product never goes through torch: libopmhip selects device `local_rank` itself and opmhip_create fails loudly
     # (OPMHIP_NO_DEVICE) when there is none - no CPU fallback.  torch only brackets the timed region when it sees the card.
-    import ctypes
-    hip = ctypes.CDLL("libamdhip64.so")
     torch_sees_gpu = torch.cuda.is_available() and torch.cuda.device_count() > local_rank
     if torch_sees_gpu:
         torch.cuda.set_device(local_rank)
+    sync_models = []   # every context with work in flight; all of the product's work runs on its contexts' own streams
 
     def device_sync():
         if torch_sees_gpu:
             torch.cuda.synchronize()
-        if hip.hipDeviceSynchronize() != 0:
-            raise SystemExit("bench.py: hipDeviceSynchronize failed")
+        for mdl in sync_models:
+            mdl.synchronize()   # opmhip_synchronize: raises on a device error
 
     pkg = importlib.import_module("opm-autodiff_amd")
     n = a.n
@@ -260,6 +323,19 @@ def main():
         uid = [pkg.capi.comm_unique_id() if rank == 0 else None]
         dist.broadcast_object_list(uid, src=0)
         model = pkg.capi.HipModel(case, comm=("rccl", world, rank, uid[0]), **skw)
+    sync_models.append(model)
+    # N > 1: what RCCL itself says about the communicator the data path runs on, and one all-reduce through it.  A run whose
+    # communicator does not span --gpus ranks is not the run that was asked for: every rank exits non-zero.
+    rccl = None
+    if world > 1:
+        info = model.comm_info()
+        s0, s1 = model.comm_selftest()
+        gathered = [None] * world
+        dist.all_gather_object(gathered, (info["rank"], info["device"], socket.gethostname()))
+        rccl = {"nranks": info["nranks"], "kind": info["kind"], "rank_devices": [g[1] for g in sorted(gathered)],
+                "hosts": sorted({g[2] for g in gathered}), "selftest_sum": [s0, s1], "selftest_expected": [world * (world + 1) / 2.0, 2.0 * world]}
+        if info["kind"] != "rccl" or info["nranks"] != a.gpus or rccl["selftest_sum"] != rccl["selftest_expected"]:
+            raise SystemExit("bench.py: RCCL communicator spans %d rank(s) (kind %s, self-test %r), --gpus %d was asked for" % (info["nranks"], info["kind"], rccl["selftest_sum"], a.gpus))
     model.set_state(case["pv"], case["meaning"])
     model.set_source(src)
     sim = make_simulation(pkg, model)
@@ -335,16 +411,18 @@ def main():
 
     if a.steady_after > 0 and a.steady_steps > 0:
         steady = guarded("steady-state window", steady_window)
-    # the same workload with the CPR preconditioner (cpr_quasiimpes), side by side: its own context, warm-up, timed window
-    cpr_side = None
-    if a.preconditioner == "ilu0" and world == 1 and not a.no_cpr_side_run:
-        def cpr_window():
+    # the same workload with the CPR preconditioners, side by side, each in its own context with its own warm-up and timed
+    # windows: "cpr" = cpr_trueimpes (what the name means in Flow, setupPropertyTree.cpp:62-76) and "cpr_quasiimpes"
+    cpr_sides = {}
+    def cpr_window(prec):
+        def run():
             nonlocal sim, model
-            model2 = pkg.capi.HipModel(case, **dict(skw, preconditioner="cpr"))
+            model2 = pkg.capi.HipModel(case, **dict(skw, preconditioner=prec))
             model2.set_state(case["pv"], case["meaning"])
             model2.set_source(src)
             sim_main, model_main = sim, model
             sim, model = make_simulation(pkg, model2), model2
+            sync_models.append(model2)
             try:
                 for _ in range(a.warmup):
                     sim.next_newton_iteration()      # includes the one-time host-side aggregation of the pressure AMG
@@ -364,12 +442,17 @@ def main():
                 return side
             finally:
                 sim, model = sim_main, model_main
+                sync_models.remove(model2)
                 del model2
+        return run
 
-        cpr_side = guarded("CPR side run", cpr_window)
+    if a.preconditioner == "ilu0" and world == 1 and not a.no_cpr_side_run:
+        for prec in ("cpr", "cpr_quasiimpes"):
+            cpr_sides[prec] = guarded("CPR side run (%s)" % prec, cpr_window(prec))
     # what a kernel that only streams reaches on THIS card (reads the Jacobian's values once per launch)
-    stream_ms = model.time_kernel("stream_read", reps=20)
-    stream_GBps = 72.0 * nnzb / stream_ms / 1e6
+    stream = guarded("stream_read probe", lambda: {"ms": model.time_kernel("stream_read", reps=20)})
+    stream_ms = stream.get("ms")
+    stream_GBps = 72.0 * nnzb / stream_ms / 1e6 if stream_ms else None
 
     sp = kernels.get("spmv", {"avg_ms": float("nan"), "algorithmic_GBps": float("nan")})
     ok = sp["algorithmic_GBps"] == sp["algorithmic_GBps"]
@@ -398,15 +481,19 @@ def main():
         "report": W["report"],
         "kernels": kernels,
         "steady_state": steady,
-        # same case, CPR instead of ILU0 as the preconditioner of BiCGStab (extra information; `value` is the run above)
-        "cpr": cpr_side,
+        # same case, CPR instead of ILU0 as the preconditioner of BiCGStab (extra information; `value` is the run above):
+        # "cpr" is Flow's cpr = cpr_trueimpes, "cpr_quasiimpes" the quasi-IMPES variant
+        "cpr": cpr_sides.get("cpr"),
+        "cpr_quasiimpes": cpr_sides.get("cpr_quasiimpes"),
         "preconditioner": a.preconditioner,
+        "rccl": rccl,
         "device": device_info(torch, local_rank),
-        "stream_ceiling": {"read_GBps": round(stream_GBps, 1), "bytes_per_launch": 72 * nnzb, "avg_launch_ms": round(stream_ms, 5),
+        "stream_ceiling": {"read_GBps": round(stream_GBps, 1) if stream_GBps else None, "bytes_per_launch": 72 * nnzb,
+                           "avg_launch_ms": round(stream_ms, 5) if stream_ms else None, "error": stream.get("error"),
                            "kernel": "k_stream_read: the Jacobian's value array read once, 16-B loads, nothing else (back to back, 20 launches)"},
         "roofline": {"bound": "hbm", "kernel": "k_spmv (block-CSR SpMV, 3x3 double blocks)", "achieved": sp["algorithmic_GBps"],
                      "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": (sp["algorithmic_GBps"] / HBM_PEAK_GBS) if ok else None,
-                     "frac_of_stream_ceiling": (sp["algorithmic_GBps"] / stream_GBps) if ok else None,
+                     "frac_of_stream_ceiling": (sp["algorithmic_GBps"] / stream_GBps) if (ok and stream_GBps) else None,
                      "traffic": traffic, "traffic_unit": "bytes per launch (L2 fabric side; FETCH_SIZE x 2 + WRITE_SIZE, KiB -> B)",
                      "traffic_source": traffic_src, "avg_launch_ms": sp["avg_ms"], "algorithmic_bytes_per_launch": B["spmv"],
                      # the BiCGStab scalar products behind a product run in their own kernel (k_dots, counted under "vector"):
@@ -414,7 +501,7 @@ def main():
                      "scalar_products": "separate kernel (k_dots)"},
     }
     if rank == 0 and world == 1 and not a.no_cpu_baseline:
-        out["cpu_baseline"] = cpu_baseline(pkg, case, src)
+        out["cpu_baseline"] = cpu_baseline(pkg, case, src, nnzb)
         out["gpu_over_cpu"] = out["value"] / out["cpu_baseline"]["value"]
     if rank == 0:
         print(json.dumps(out))

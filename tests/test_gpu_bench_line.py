@@ -31,4 +31,8 @@ def test_bench_line_contract():
     assert ro["traffic"] is None     # PMC traffic is only quoted for the 100^3 configuration it was measured on
     cb = d["cpu_baseline"]
     assert cb["kind"] == "port" and cb["cores"] >= 1 and cb["value"] > 0 and "sample" in cb
-    assert d["steady_state"]["steps"] == 3 and d["cpr"]["value"] > 0 and d["stream_ceiling"]["read_GBps"] > 0
+    assert cb["host"]["physical_cores_in_mask"] >= 1 and cb["linear_solve_GBps"] > 0
+    assert cb["cores"] == 1 or str(cb["cores"]) in cb["host"]["thread_sweep_newton_its_per_s"]
+    assert d["steady_state"]["steps"] == 3 and d["stream_ceiling"]["read_GBps"] > 0
+    # Flow's "cpr" (true-IMPES weights) and the quasi-IMPES variant, side by side under their reference names
+    assert d["cpr"]["value"] > 0 and d["cpr_quasiimpes"]["value"] > 0 and d["rccl"] is None

@@ -170,3 +170,52 @@ def test_two_subdomains_of_full_size(pkg):
     assert out[0] == out[1]                       # global scalars: identical on both ranks, bit for bit
     for it, ok, red, _ in out[0]:
         assert ok and red <= 1e-2 and 0.5 <= it <= 60
+
+
+def test_eight_subdomains_of_full_size_configs3(pkg):
+    """BASELINE configs[3] at size: the 200 x 200 x 200 grid (8 * 10^6 cells) cut into 2 x 2 x 2 subdomains of 10^6 cells,
+    every subdomain a context of its own on this one GPU, connected by the loopback communicator - the code path of the
+    8-GPU run (set_pattern_dd, halo pack / exchange, interior / boundary products, local reductions + all-reduce) with device
+    copies in the place of RCCL.  Driven by bench.py's own time-step control for the first Newton iterations.  No oracle at
+    this size: all eight ranks must report the same history bit for bit, every linear solve must meet the stopping rule,
+    and the iteration counts must stay where the rehearsal of round 2 found them (22.8 linear iterations per Newton
+    iteration over 25 Newton iterations; 17.45 for one 10^6-cell domain, 26.8 for the 8 * 10^6-cell grid as one domain)."""
+    import os
+    import sys
+    import threading
+    import uuid
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    import bench
+    world, n, steps = 8, N, 8
+    group = "cfg3" + uuid.uuid4().hex
+    out, err = [None] * world, [None] * world
+
+    def body(r):
+        try:
+            case = pkg.ras.cartesian_subdomain_case(n, world, r, state="mixed", heterogeneous=False)
+            assert case["Nb"] == n ** 3 and case["Nghost"] == 3 * n * n and case["global_cells"] == 8 * n ** 3
+            m = pkg.capi.HipModel(case, comm=("loopback", world, r, group), reorder="line_coloring", tolerance=1e-2, maxit=200, ilu_relaxation=0.9)
+            m.set_state(case["pv"], case["meaning"])
+            m.set_source(case["source"])
+            sim = bench.make_simulation(pkg, m)
+            log = []
+            for _ in range(steps):
+                rep = sim.next_newton_iteration()
+                log.append((sim.timesteps_done, sim.iteration, int(rep.total_linear_iterations)))
+            out[r] = (log, sim.timesteps_failed)
+        except BaseException as e:  # noqa: BLE001
+            err[r] = e
+
+    ts = [threading.Thread(target=body, args=(r,)) for r in range(world)]
+    for t in ts:
+        t.start()
+    for t in ts:
+        t.join(timeout=900)
+    for e in err:
+        if e is not None:
+            raise e
+    assert all(o == out[0] for o in out)            # the global scalars steer every rank the same way
+    log, failed = out[0]
+    assert failed == 0
+    lin = sum(entry[2] for entry in log)
+    assert 10 * steps <= lin <= 32 * steps, log     # 17 ... 26 linear iterations per Newton iteration expected
