@@ -62,12 +62,13 @@ def device_info(torch, index):
 def alg_bytes(Nb, nnzb):
     """Algorithmic bytes per launch (SURVEY.md §8d / BASELINE.md §4), block size 3, double values, int32 indices."""
     return {
-        "spmv": 76 * nnzb + 4 * (Nb + 1) + 48 * Nb,
+        # block-CSR SpMV (SURVEY 8d) + the second operand of the scalar products that ride in the kernel (24 B per row)
+        "spmv": 76 * nnzb + 4 * (Nb + 1) + 48 * Nb + 24 * Nb,
         "ilu_apply": 76 * nnzb + 4 * (Nb + 1) + 4 * Nb + 72 * Nb,
         "ilu_factor": 2 * 72 * nnzb + 4 * nnzb + 4 * Nb,
-        # per scope, three scopes per iteration: the p-update (4 passes), r-update (3), k_bicg_upd2 with both updates of x (8),
-        # two k_dots (2 each)
-        "vector": 24 * Nb * 19 / 3,
+        # per scope, three scopes per iteration: the p-update (4 passes), r-update (3), k_bicg_upd2 with both updates of x (8);
+        # the scalar products behind a product ride in the product's kernel (with wells: k_dots, a scope of its own)
+        "vector": 24 * Nb * 15 / 3,
         "assemble": 85 * Nb + 12 * nnzb + 72 * nnzb + 24 * Nb,
         "iq_update": 24 * Nb + 544 * Nb,
         "convergence": 56 * Nb,
@@ -368,10 +369,16 @@ def main():
             elapsed = float(t.item())
         rep = sim.report
         kernels = {}
+        if prof.get("spmv_boundary", (0, 0.0))[0]:   # decomposed runs: one product = interior launch + boundary launch
+            prof["spmv"] = (prof["spmv"][0], prof["spmv"][1] + prof["spmv_boundary"][1])
+            kernels["spmv_boundary_share_of_time"] = round(prof["spmv_boundary"][1] / prof["spmv"][1], 4)
+        prof.pop("spmv_boundary", None)
         for name, (cnt, ms) in prof.items():
             if cnt:
                 avg = ms / cnt
                 kernels[name] = {"launches": cnt, "avg_ms": round(avg, 5), "algorithmic_GBps": round(B[name] / avg / 1e6, 1)}
+                if name == "cpr_amg":
+                    kernels[name]["bytes_are_an_estimate"] = True   # a geometric estimate of the hierarchy's passes, not a count
         ls_bytes = sum(B[k] * prof[k][0] for k in ("spmv", "ilu_apply", "ilu_factor", "vector"))
         ls_ms = sum(prof[k][1] for k in ("spmv", "ilu_apply", "ilu_factor", "vector"))
         return {"elapsed": elapsed, "steps": steps, "kernels": kernels,
@@ -496,9 +503,9 @@ def main():
                      "frac_of_stream_ceiling": (sp["algorithmic_GBps"] / stream_GBps) if (ok and stream_GBps) else None,
                      "traffic": traffic, "traffic_unit": "bytes per launch (L2 fabric side; FETCH_SIZE x 2 + WRITE_SIZE, KiB -> B)",
                      "traffic_source": traffic_src, "avg_launch_ms": sp["avg_ms"], "algorithmic_bytes_per_launch": B["spmv"],
-                     # the BiCGStab scalar products behind a product run in their own kernel (k_dots, counted under "vector"):
-                     # the pipelined SpMV does SURVEY's plain-SpMV work and nothing else
-                     "scalar_products": "separate kernel (k_dots)"},
+                     # the BiCGStab scalar products behind a product ride in the kernel: its operand set is SURVEY 8d's plain
+                     # SpMV (579.44 MB at 100^3) + the second operand of the products (24 MB), both in algorithmic_bytes_per_launch
+                     "scalar_products": "folded into the kernel (one partial sum per workgroup)"},
     }
     if rank == 0 and world == 1 and not a.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(pkg, case, src, nnzb)

@@ -200,7 +200,8 @@ int opmhip_cpr_apply(opmhip_ctx* ctx, const double* d, double* v);
 int opmhip_get_ordering(opmhip_ctx* ctx, int* toOrder, int* fromOrder, int* rowsPerColor);
 /* Device-timed repetitions of one kernel on the uploaded system, for bench.py's roofline object:
  * which = 0 SpMV, 1 ILU0 apply, 2 ILU0 factor, 3 one BiCGStab iteration's vector kernels, 4 a plain streaming read of
- * the Jacobian's value array (72 * nnzb bytes; the on-box HBM ceiling the roofline fractions are put beside).
+ * the Jacobian's value array (72 * nnzb bytes; the on-box HBM ceiling the roofline fractions are put beside), 5 / 6 the SpMV
+ * with the partial sums of one / two scalar products (the forms BiCGStab launches).
  * Launches the kernel `reps` times back to back on the context's stream between two HIP events and returns the
  * average milliseconds per launch in *ms_per_launch. */
 int opmhip_time_kernel(opmhip_ctx* ctx, int which, int reps, double* ms_per_launch);
@@ -383,8 +384,10 @@ int opmhip_set_halo(opmhip_ctx* ctx, long long global_cells, int nneigh, const i
  * verbosity >= 3/4: bda/cusparseSolverBackend.cu:303-308, bda/openclSolverBackend.cpp:451-459).
  * classes: 0 SpMV, 1 ILU0 apply (all sweeps of one M^-1; with the line-coloured ordering the first sweep also carries
  * the BiCGStab p- / (r, x)-update), 2 ILU0 factorisation, 3 the remaining BiCGStab vector / reduction kernels (one
- * scope between two operator applications), 4 assembly kernel, 5 intensive-quantity update, 6 convergence. */
-#define OPMHIP_PROF_CLASSES 7
+ * scope between two operator applications), 4 assembly kernel, 5 intensive-quantity update, 6 convergence, 7 the pressure
+ * AMG cycle of CPR, 8 decomposed runs: the second launch of an operator application (the boundary tiles, multiplied after
+ * the halo exchange that ran beside the interior tiles of class 0). */
+#define OPMHIP_PROF_CLASSES 9
 /* on = 0: off; 1: every scope; k > 1: the linear-solver classes (0, 1, 3) are recorded in every k-th solve_system call
  * only - an event record costs a few microseconds of bubble on the stream and a BiCGStab iteration holds seven of
  * them.  Also resets the accumulated numbers. */

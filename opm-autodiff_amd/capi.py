@@ -251,7 +251,7 @@ class HipSolver:
         nc = self._check(lib().opmhip_get_ordering(self._h, _ptr(to), _ptr(fr), _ptr(rpc)))
         return to, fr, rpc[:nc].copy()
 
-    PROF = ["spmv", "ilu_apply", "ilu_factor", "vector", "assemble", "iq_update", "convergence", "cpr_amg"]
+    PROF = ["spmv", "ilu_apply", "ilu_factor", "vector", "assemble", "iq_update", "convergence", "cpr_amg", "spmv_boundary"]
 
     def profile_enable(self, on=True):
         self._check(lib().opmhip_profile_enable(self._h, int(on)))
@@ -289,7 +289,7 @@ class HipSolver:
 
     def time_kernel(self, which, reps=20):
         ms = C.c_double()
-        self._check(lib().opmhip_time_kernel(self._h, {"spmv": 0, "ilu_apply": 1, "ilu_factor": 2, "vector": 3, "stream_read": 4}[which],
+        self._check(lib().opmhip_time_kernel(self._h, {"spmv": 0, "ilu_apply": 1, "ilu_factor": 2, "vector": 3, "stream_read": 4, "spmv_dot1": 5, "spmv_dot2": 6}[which],
                                              reps, C.byref(ms)))
         return ms.value
 

@@ -435,8 +435,7 @@ int opmhip_spmv(opmhip_ctx* c, const double* x, double* y) {
         OPMHIP_HIP(c, hipSetDevice(c->device));
         int rc;
         if ((rc = vec_in(c, x, c->d_pw))) return rc;
-        if ((rc = comm_halo_f64(c, c->d_pw, BS))) return rc;
-        launch_spmv(c, c->d_pw, c->d_v, 0, nullptr, nullptr);
+        if ((rc = launch_spmv(c, c->d_pw, c->d_v, 0, nullptr, 1.0, true))) return rc;
         OPMHIP_HIP(c, hipGetLastError());
         return vec_out(c, c->d_v, y);
     });
@@ -570,17 +569,19 @@ int opmhip_cpr_levels(opmhip_ctx* c, int* n, int* nnz, int cap) {
 int opmhip_time_kernel(opmhip_ctx* c, int which, int reps, double* ms_per_launch) {
     if (!c) return OPMHIP_INVALID_ARGUMENT;
     return guarded(c, [&]() -> int {
-        if (!ms_per_launch || reps < 1 || which < 0 || which > 4) return fail(c, OPMHIP_INVALID_ARGUMENT, "time_kernel: bad arguments");
+        if (!ms_per_launch || reps < 1 || which < 0 || which > 6) return fail(c, OPMHIP_INVALID_ARGUMENT, "time_kernel: bad arguments");
         if (!c->system_loaded) return fail(c, OPMHIP_NOT_READY, "time_kernel before a matrix was uploaded");
         if (which != 2 && which != 4 && !c->factored) return fail(c, OPMHIP_NOT_READY, "time_kernel: factor first");
         OPMHIP_HIP(c, hipSetDevice(c->device));
         auto once = [&]() {
             switch (which) {
-                case 0: launch_spmv(c, c->d_pw, c->d_v, 0, nullptr, nullptr); break;
+                case 0: (void)launch_spmv(c, c->d_pw, c->d_v, 0, nullptr); break;
                 case 1: launch_ilu_apply(c, c->d_p, c->d_pw); break;
                 case 2: launch_ilu_factor(c); break;
                 case 3: launch_vector_kernels_once(c); break;
                 case 4: launch_stream_read(c); break;
+                case 5: (void)launch_spmv(c, c->d_pw, c->d_v, 1, c->d_rw); break;   // with the partial sums of y.w0
+                case 6: (void)launch_spmv(c, c->d_pw, c->d_v, 2, c->d_r); break;    // ... and of y.y
             }
         };
         once();  // warm

@@ -112,22 +112,24 @@ int comm_allreduce(opmhip_ctx* c, double* d_buf, int n, int op) {
     return OPMHIP_SUCCESS;
 }
 
-// ghost entries of `vec` (w doubles per cell, internal order, ghosts at cells Nb..) <- owners' values
-int comm_halo_f64(opmhip_ctx* c, double* vec, int w) {
+// ghost entries of `vec` (w doubles per cell, internal order, ghosts at cells Nb..) <- owners' values; on stream s (default:
+// the context's).  A rank may be its own neighbour (periodic coupling; also how a single GPU exercises the RCCL path).
+int comm_halo_f64(opmhip_ctx* c, double* vec, int w, hipStream_t s) {
     CommDev& C = c->comm;
-    if (C.nranks <= 1 || C.nneigh == 0) return OPMHIP_SUCCESS;
+    if (!C.halo_set || C.nneigh == 0 || C.kind == COMM_NONE) return OPMHIP_SUCCESS;
+    if (!s) s = c->stream;
     const int nsend = C.send_ptr[C.nneigh];
     if (nsend > 0)
-        hipLaunchKernelGGL(k_pack_f64, dim3((nsend * w + 255) / 256), dim3(256), 0, c->stream, nsend, w, C.d_send_idx, vec, C.d_sendbuf);
+        hipLaunchKernelGGL(k_pack_f64, dim3((nsend * w + 255) / 256), dim3(256), 0, s, nsend, w, C.d_send_idx, vec, C.d_sendbuf);
     double* ghost0 = vec + (size_t)c->pat.Nb * w;
     if (C.kind == COMM_RCCL) {
         // a failing call must not leave the group open: remember the first error, always reach ncclGroupEnd
         NCCLCHK(c, g_rccl.GroupStart());
         ncclResult_t err = ncclSuccess;
         for (int q = 0; q < C.nneigh && err == ncclSuccess; ++q) {
-            err = g_rccl.Send(C.d_sendbuf + (size_t)C.send_ptr[q] * w, (size_t)(C.send_ptr[q + 1] - C.send_ptr[q]) * w, ncclDouble, C.neigh[q], (ncclComm_t)C.nccl, c->stream);
+            err = g_rccl.Send(C.d_sendbuf + (size_t)C.send_ptr[q] * w, (size_t)(C.send_ptr[q + 1] - C.send_ptr[q]) * w, ncclDouble, C.neigh[q], (ncclComm_t)C.nccl, s);
             if (err == ncclSuccess)
-                err = g_rccl.Recv(ghost0 + (size_t)C.recv_ptr[q] * w, (size_t)(C.recv_ptr[q + 1] - C.recv_ptr[q]) * w, ncclDouble, C.neigh[q], (ncclComm_t)C.nccl, c->stream);
+                err = g_rccl.Recv(ghost0 + (size_t)C.recv_ptr[q] * w, (size_t)(C.recv_ptr[q + 1] - C.recv_ptr[q]) * w, ncclDouble, C.neigh[q], (ncclComm_t)C.nccl, s);
         }
         const ncclResult_t endErr = g_rccl.GroupEnd();
         if (err == ncclSuccess) err = endErr;
@@ -136,7 +138,7 @@ int comm_halo_f64(opmhip_ctx* c, double* vec, int w) {
     }
     // loopback: errors are remembered and reported after the SECOND barrier, so that no peer waits for ever
     LoopGroup* G = (LoopGroup*)C.group;
-    int rc = (hipStreamSynchronize(c->stream) == hipSuccess) ? OPMHIP_SUCCESS : fail(c, OPMHIP_DEVICE_ERROR, "halo exchange: packing failed");
+    int rc = (hipStreamSynchronize(s) == hipSuccess) ? OPMHIP_SUCCESS : fail(c, OPMHIP_DEVICE_ERROR, "halo exchange: packing failed");
     pthread_barrier_wait(&G->barrier);  // every rank's send buffer is packed
     if (!rc) rc = [&]() -> int {
         for (int q = 0; q < C.nneigh; ++q) {
@@ -148,18 +150,48 @@ int comm_halo_f64(opmhip_ctx* c, double* vec, int w) {
             if (me < 0 || PC.send_ptr[me + 1] - PC.send_ptr[me] != C.recv_ptr[q + 1] - C.recv_ptr[q])
                 return fail(c, OPMHIP_INVALID_ARGUMENT, "halo lists of ranks %d and %d do not match", C.rank, C.neigh[q]);
             OPMHIP_HIP(c, hipMemcpyAsync(ghost0 + (size_t)C.recv_ptr[q] * w, PC.d_sendbuf + (size_t)PC.send_ptr[me] * w,
-                                         (size_t)(C.recv_ptr[q + 1] - C.recv_ptr[q]) * w * sizeof(double), hipMemcpyDeviceToDevice, c->stream));
+                                         (size_t)(C.recv_ptr[q + 1] - C.recv_ptr[q]) * w * sizeof(double), hipMemcpyDeviceToDevice, s));
         }
-        OPMHIP_HIP(c, hipStreamSynchronize(c->stream));
+        OPMHIP_HIP(c, hipStreamSynchronize(s));
         return OPMHIP_SUCCESS;
     }();
     pthread_barrier_wait(&G->barrier);  // nobody repacks before every copy is done
     return rc;
 }
 
+// The exchange in front of an operator application, on the halo stream: begin() orders it behind everything the main
+// stream holds so far (the input vector is complete) and returns with the exchange enqueued (RCCL) or done (loopback: the
+// host takes part in it) - the caller launches the interior tiles' product on the main stream BEFORE calling begin() would
+// be too early (x must be complete), so it launches them right AFTER ev_x is recorded: begin() records ev_x first thing,
+// and whatever the main stream gets afterwards runs beside the exchange.  end(): the main stream waits for the ghosts.
+int comm_halo_begin(opmhip_ctx* c, double* vec) {
+    CommDev& C = c->comm;
+    OPMHIP_HIP(c, hipEventRecord(C.ev_x, c->stream));
+    OPMHIP_HIP(c, hipStreamWaitEvent(C.hstream, C.ev_x, 0));
+    C.halo_vec = vec;
+    if (C.kind == COMM_RCCL) {   // asynchronous: enqueue now, the interior product is launched behind this call and overlaps on the device
+        const int rc = comm_halo_f64(c, vec, BS, C.hstream);
+        if (rc) return rc;
+        OPMHIP_HIP(c, hipEventRecord(C.ev_h, C.hstream));
+        C.halo_vec = nullptr;
+    }
+    return OPMHIP_SUCCESS;   // loopback: the host-driven exchange happens in end(), after the interior launch is on its way
+}
+int comm_halo_end(opmhip_ctx* c) {
+    CommDev& C = c->comm;
+    if (C.halo_vec) {   // loopback: barriers and device copies driven from this thread, on the halo stream, while the main stream works
+        const int rc = comm_halo_f64(c, C.halo_vec, BS, C.hstream);
+        C.halo_vec = nullptr;
+        if (rc) return rc;
+        OPMHIP_HIP(c, hipEventRecord(C.ev_h, C.hstream));
+    }
+    OPMHIP_HIP(c, hipStreamWaitEvent(c->stream, C.ev_h, 0));
+    return OPMHIP_SUCCESS;
+}
+
 int comm_halo_u8(opmhip_ctx* c, unsigned char* vec) {
     CommDev& C = c->comm;
-    if (C.nranks <= 1 || C.nneigh == 0) return OPMHIP_SUCCESS;
+    if (!C.halo_set || C.nneigh == 0 || C.kind == COMM_NONE) return OPMHIP_SUCCESS;
     const int nsend = C.send_ptr[C.nneigh];
     if (nsend > 0) hipLaunchKernelGGL(k_pack_u8, dim3((nsend + 255) / 256), dim3(256), 0, c->stream, nsend, C.d_send_idx, vec, C.d_sendbuf_u8);
     unsigned char* ghost0 = vec + c->pat.Nb;
@@ -199,6 +231,9 @@ int comm_halo_u8(opmhip_ctx* c, unsigned char* vec) {
 
 void comm_release(opmhip_ctx* c) {
     CommDev& C = c->comm;
+    if (C.hstream) { (void)hipStreamSynchronize(C.hstream); (void)hipStreamDestroy(C.hstream); C.hstream = nullptr; }
+    if (C.ev_x) { (void)hipEventDestroy(C.ev_x); C.ev_x = nullptr; }
+    if (C.ev_h) { (void)hipEventDestroy(C.ev_h); C.ev_h = nullptr; }
     if (C.kind == COMM_RCCL && C.nccl && g_rccl.CommDestroy) (void)g_rccl.CommDestroy((ncclComm_t)C.nccl);
     C.nccl = nullptr;
     C.kind = COMM_NONE;
@@ -323,6 +358,11 @@ int opmhip_set_halo(opmhip_ctx* c, long long global_cells, int nneigh, const int
     if ((rc = dev_alloc(c, &C.d_sendbuf, (size_t)std::max(nsend, 1) * 3))) return rc;
     if ((rc = dev_alloc(c, &C.d_sendbuf_u8, (size_t)std::max(nsend, 1)))) return rc;
     if ((rc = dev_alloc(c, &C.d_red, (size_t)16))) return rc;
+    if (!C.hstream) {
+        OPMHIP_HIP(c, hipStreamCreateWithFlags(&C.hstream, hipStreamNonBlocking));
+        OPMHIP_HIP(c, hipEventCreateWithFlags(&C.ev_x, hipEventDisableTiming));
+        OPMHIP_HIP(c, hipEventCreateWithFlags(&C.ev_h, hipEventDisableTiming));
+    }
     C.halo_set = true;
     return OPMHIP_SUCCESS;
 }

@@ -624,7 +624,7 @@ void launch_cpr_apply(opmhip_ctx* c, const double* d, double* v) {
     const double* xp = cpr_vcycle(c, 0);
     hipLaunchKernelGGL(k_cpr_prolong_fine, g256(n), dim3(256), 0, c->stream, P.Nb, xp, v, done);
     prof_end(c, ps);
-    launch_spmv(c, v, R.d_y, 0, nullptr, nullptr);                      // post-smoothing on the updated residual
+    (void)launch_spmv(c, v, R.d_y, 0, nullptr);                      // post-smoothing on the updated residual
     ps = prof_begin(c, PROF_VECTOR);
     hipLaunchKernelGGL(k_cpr_sub, g256(n), dim3(256), 0, c->stream, n, d, R.d_y, R.d_r, done);
     prof_end(c, ps);

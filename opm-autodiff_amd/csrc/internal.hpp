@@ -40,6 +40,9 @@ struct TileSet {            // tiles over one block-CSR row-pointer array, never
     // workgroup lands on) walks through one spatial stretch of the grid at a time
     std::vector<int> spmvSched;  // [4 * nsched] (r0, r1, rowptr[r0], rowptr[r1]) of every SpMV launch position; r1 <= r0 = padding
     int nsched = 0;
+    // decomposed runs: positions [0, nschedInt) hold the INTERIOR tiles (no row of theirs has a ghost column: they can be
+    // multiplied while the halo exchange is under way), [nschedInt, nsched) the boundary tiles; else nschedInt == nsched
+    int nschedInt = 0;
     std::vector<int> ctSched;    // per colour, padded to a multiple of 8: chain-tile of every launch position or -1
     std::vector<int> ctSchedOff; // [numColors+1] offsets into ctSched
     int* d_row0 = nullptr;
@@ -137,6 +140,11 @@ struct CommDev {
     double* d_sendbuf = nullptr;                 // 3 doubles per send cell
     unsigned char* d_sendbuf_u8 = nullptr;
     double* d_red = nullptr;                     // 16 doubles: all-reduce buffer
+    // the halo exchange in front of an operator application runs on a stream of its own, beside the product of the interior
+    // tiles: ev_x = "the input vector is complete" (main stream), ev_h = "ghost entries are in place" (halo stream)
+    hipStream_t hstream = nullptr;
+    hipEvent_t ev_x = nullptr, ev_h = nullptr;
+    double* halo_vec = nullptr;                  // loopback: the vector whose exchange comm_halo_end still has to drive
 };
 
 // CPR preconditioner (cpr.hip): pressure-AMG hierarchy, level 0 = the block pattern with scalar values
@@ -160,7 +168,9 @@ struct CprDev {
 };
 
 // per-kernel-class device timing with HIP events on the context's stream (opmhip_profile_*)
-enum ProfClass { PROF_SPMV = 0, PROF_ILU_APPLY, PROF_ILU_FACTOR, PROF_VECTOR, PROF_ASSEMBLE, PROF_IQ_UPDATE, PROF_CONVERGENCE, PROF_CPR_AMG, PROF_COUNT };
+enum ProfClass { PROF_SPMV = 0, PROF_ILU_APPLY, PROF_ILU_FACTOR, PROF_VECTOR, PROF_ASSEMBLE, PROF_IQ_UPDATE, PROF_CONVERGENCE, PROF_CPR_AMG,
+                 PROF_SPMV_BOUNDARY,   // decomposed runs: the second launch of a product (boundary tiles, after the halo exchange)
+                 PROF_COUNT };
 struct Profiler {
     bool enabled = false;
     int every = 1;                            // solver scopes are recorded in every `every`-th linear solve (1 = all)
@@ -207,6 +217,7 @@ struct opmhip_ctx {
     double minv_scale = 1.0;    // during a solve: the factor the preconditioned vectors (d_pw, d_s) are still to be multiplied by
     double* d_part2 = nullptr;  // second-level partials: 2 x RED1_BLOCKS
     int npart = 0;
+    int last_dot_count = 0;     // partial sums the last launch_spmv left in d_part (per list)
     double* h_pinned = nullptr;  // SC_COUNT doubles, pinned
     // read-back ring of the BiCGStab stopping rule: the finalize kernel writes (norm, norm_0, done) of half iteration h
     // straight into pinned host slot h % RB_SLOTS and then, system-scope release, the slot's sequence number, which the
@@ -349,7 +360,9 @@ void launch_unpermute_blocks(opmhip_ctx* c, const double* internal, double* nat)
 void launch_vec_to_internal(opmhip_ctx* c, const double* nat, double* internal, int cells = -1);
 void launch_vec_to_natural(opmhip_ctx* c, const double* internal, double* nat, int cells = -1);
 void launch_zero_diag_fix(opmhip_ctx* c);
-void launch_spmv(opmhip_ctx* c, const double* x, double* y, int ndot, const double* w0, const double* w1, double xs = 1.0);
+// y = A x (+ wells) with the partial sums of ndot scalar products.  exchange: x's ghost entries are brought up to date first
+// (copyOwnerToAll) - on the halo stream, beside the product of the interior tiles; x is then written (its ghost part)
+int launch_spmv(opmhip_ctx* c, double* x, double* y, int ndot, const double* w0, double xs = 1.0, bool exchange = false);
 void launch_wells_residual(opmhip_ctx* c, const double* d_resWell, double* r);
 void launch_wells_add_to_matrix(opmhip_ctx* c, int w0, int nw, int serial, const int* d_pair_ptr, const int* d_entry);
 void launch_wells_recover(opmhip_ctx* c, const double* d_resWell, const double* x, double* d_xw);
@@ -366,7 +379,9 @@ void launch_lu_to_natural(opmhip_ctx* c, double* d_out_internal_layout);
 int bicgstab(opmhip_ctx* c, opmhip_result* res);
 // comm.hip
 int comm_allreduce(opmhip_ctx* c, double* d_buf, int n, int op /*0 sum, 1 max*/);
-int comm_halo_f64(opmhip_ctx* c, double* vec, int w);
+int comm_halo_f64(opmhip_ctx* c, double* vec, int w, hipStream_t s = nullptr);   // s: the stream it runs on (default: the context's)
+int comm_halo_begin(opmhip_ctx* c, double* vec);   // 3 doubles per cell: the exchange on the halo stream, ordered behind the main stream's work so far
+int comm_halo_end(opmhip_ctx* c);                  // the main stream waits for it
 int comm_halo_u8(opmhip_ctx* c, unsigned char* vec);
 void comm_release(opmhip_ctx* c);
 // assemble.hip launchers

@@ -281,6 +281,24 @@ void build_schedules(Pattern& P, int G) {
             }
         }
     }
+    // decomposed runs: interior tiles first, boundary tiles (a row with a ghost column) behind them, each part keeping the
+    // dealing over the 8 XCD columns (position % 8) it had
+    T.nschedInt = (int)order.size();
+    if (P.Nghost > 0) {
+        auto boundary = [&](int t) {
+            for (int k = P.rowptr[T.row0[t]]; k < P.rowptr[T.row0[t + 1]]; ++k)
+                if (P.col[k] >= P.Nb) return true;
+            return false;
+        };
+        std::vector<std::vector<int>> in8(8), bd8(8);
+        for (size_t b = 0; b < order.size(); ++b)
+            if (order[b] >= 0) (boundary(order[b]) ? bd8 : in8)[b % 8].push_back(order[b]);
+        std::vector<int> o2;
+        deal(in8, -1, o2);
+        T.nschedInt = (int)o2.size();
+        deal(bd8, -1, o2);
+        order.swap(o2);
+    }
     T.nsched = (int)order.size();
     T.spmvSched.assign((size_t)4 * T.nsched, 0);
     for (int b = 0; b < T.nsched; ++b)

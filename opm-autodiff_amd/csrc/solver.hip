@@ -419,26 +419,32 @@ __global__ __launch_bounds__(64) void k_spmv(const int4* __restrict__ sched, con
 // (tools/probe/stream_probe.hip).  Used when no row is longer than PGCH blocks (the host checks), else k_spmv.
 //   S(st+4): schedule entry (scalar)   A(st+3): row bounds   C(st+2): column indices
 //   G(st+1): value stream + vector gathers                    X(st): values -> LDS, products, store
-// The BiCGStab scalar products that follow a product are formed by k_dots after this kernel: folded into it (the one-tile
-// kernel below still does that, for systems small enough to be bound by launches) they cost the product 8 % - a third
-// operand stream and two wavefront reductions per tile - and the Newton iteration rate nothing either way (74.2 against 74.7
-// its/s on the 100^3 bench, same box).
+// The BiCGStab scalar products that follow a product ride in this kernel (NDOT = 1: y.w0, NDOT = 2: y.w0 and y.y): the third
+// operand w0 is fetched in the stage that fetches a row's small items, every lane adds up the products of ITS rows over all
+// its tiles and the wavefront is summed once, at the end - one partial sum (pair) per workgroup.  Measured in round 2: the
+// product gets 4 % longer (a third operand stream of 24 MB), the two k_dots launches and their kernel boundaries go, +1.3 %
+// Newton iterations/s at equal iteration counts.  (Per-tile wavefront reductions, the first way this was tried, cost 8 %.)
 constexpr int PGCH = 8;
 constexpr int PIPE_MAX_STEPS = 128;   // schedule entries of one workgroup, kept in LDS (2 KiB: eight workgroups per CU must still fit; the host sizes the grid accordingly)
 // Written by the rules listed at chain_sweep (which see): the tile's schedule entries come out of LDS (one round of loads
 // at the start instead of a scalar load per tile at the head of every dependency chain); stages A (row bounds, 3 tiles
 // ahead), C (column indices, 2 ahead), M (vector gathers and the row bounds once more, 1 ahead), S (value stream, 1
 // ahead); every load unconditional, into registers whose content is dead; nothing loaded is copied.
+template <int NDOT>
 __global__ __launch_bounds__(64) void k_spmv_pipe(int npos, const int4* __restrict__ sched, const int* __restrict__ rowptr,
                                                   const int* __restrict__ col, const double* __restrict__ val,
                                                   const double* __restrict__ x, double* __restrict__ y,
+                                                  const double* __restrict__ w0, double* __restrict__ part, int npart,
                                                   const double* __restrict__ done, double xs) {
     TILE_LDS
     __shared__ int4 ssched[PIPE_MAX_STEPS];
     const int lane = threadIdx.x, G = gridDim.x;
     constexpr int U = 16;  // 16 x 64 lanes x 16 B = 16 KiB >= any staged tile
     const int nsteps = ((int)blockIdx.x < npos) ? (npos - (int)blockIdx.x + G - 1) / G : 0;   // <= PIPE_MAX_STEPS (host)
-    if (nsteps <= 0) return;
+    if (nsteps <= 0) {   // a workgroup of the rounded-up grid without work: its partial sums are zero
+        if (NDOT >= 1 && lane == 0) { part[blockIdx.x] = 0.0; if (NDOT == 2) part[npart + blockIdx.x] = 0.0; }
+        return;
+    }
     const double stop = *done;                      // read together with the schedule entries: one round trip, not two
     for (int i = lane; i < nsteps; i += 64) ssched[i] = sched[(int)blockIdx.x + i * G];
     if (stop != 0.0) return;
@@ -451,6 +457,7 @@ __global__ __launch_bounds__(64) void k_spmv_pipe(int npos, const int4* __restri
     struct StM {
         int kb, ke;
         double xx[PGCH][3];
+        double ww[NDOT >= 1 ? 3 : 1];   // the second operand of the scalar product at the lane's row
     };
     auto clampst = [&](int st) { return st < nsteps ? st : nsteps - 1; };
     auto row_of = [&](int st, bool& active) {   // LDS only
@@ -497,11 +504,16 @@ __global__ __launch_bounds__(64) void k_spmv_pipe(int npos, const int4* __restri
             const double* xc = &x[(size_t)cc[u] * BS];
             b.xx[u][0] = xc[0]; b.xx[u][1] = xc[1]; b.xx[u][2] = xc[2];
         }
+        if (NDOT >= 1) {
+            const double* wr = &w0[(size_t)rr * BS];
+            b.ww[0] = wr[0]; b.ww[1] = wr[1]; b.ww[2] = wr[2];
+        }
     };
     StA a;
     int cc[PGCH];
     StS sb;
     StM m;
+    double sd0 = 0.0, sd1 = 0.0;   // the lane's share of y.w0 and y.y: its rows, tile after tile
     {   // prologue, in the loop's order of issue (stream, gathers, column indices, row bounds)
         StA a0, a1;
         int c0[PGCH];
@@ -539,6 +551,11 @@ __global__ __launch_bounds__(64) void k_spmv_pipe(int npos, const int4* __restri
                 if (u < nrow) blk_umv_lds(&sval[(kb + u - k0e) * BB], xs * m.xx[u][0], xs * m.xx[u][1], xs * m.xx[u][2], acc);   // xs = 1 unless x is an unscaled M^-1 result
             double* yr = &y[(size_t)r * BS];
             yr[0] = acc[0]; yr[1] = acc[1]; yr[2] = acc[2];
+            if (NDOT >= 1) {
+                double d0 = acc[0] * m.ww[0]; d0 += acc[1] * m.ww[1]; d0 += acc[2] * m.ww[2];
+                sd0 += d0;
+                if (NDOT == 2) { double d1 = acc[0] * acc[0]; d1 += acc[1] * acc[1]; d1 += acc[2] * acc[2]; sd1 += d1; }
+            }
         }
         wave_sync();  // the LDS image may be overwritten
         // ---- the tiles further ahead, each stage into the registers it has just finished with
@@ -549,6 +566,11 @@ __global__ __launch_bounds__(64) void k_spmv_pipe(int npos, const int4* __restri
         __builtin_amdgcn_sched_barrier(0);
         stageA(st + 3, a);
         __builtin_amdgcn_sched_barrier(0);
+    }
+    if (NDOT >= 1) {
+        sd0 = wave_sum(sd0);
+        if (NDOT == 2) sd1 = wave_sum(sd1);
+        if (lane == 0) { part[blockIdx.x] = sd0; if (NDOT == 2) part[npart + blockIdx.x] = sd1; }
     }
 }
 
@@ -1357,7 +1379,7 @@ __global__ __launch_bounds__(VB) void k_dots(int n, const double* __restrict__ a
 #endif
 constexpr int RED1_BLOCKS = OPMHIP_RED1_BLOCKS;
 #ifndef OPMHIP_RED1_SINGLE_MAX
-#define OPMHIP_RED1_SINGLE_MAX 1536
+#define OPMHIP_RED1_SINGLE_MAX 2048
 #endif
 // partial lists up to this length go through one workgroup (k_finalize): 1465 partials of a 10^6-row vector kernel take it 5 us,
 // the two-stage kernel with its ticket 7.7 (vector scopes 0.0285 -> 0.0260 ms on the bench); the 1953 chain-tile partials of
@@ -1586,45 +1608,80 @@ static bool spmv_pipelined(const opmhip_ctx* c) {
     const int w = spmv_pipe_wgs(c);
     return c->pat.maxRowBlocks <= PGCH && w > 0 && c->pat.tiles.nsched > w && spmv_pipe_env() != 0;
 }
-static bool spmv_dots_separate(const opmhip_ctx* c) { return c->wells.num_wells > 0 || spmv_pipelined(c); }
-// y = A x (+ wells) and, fused or not, the partial dots: ndot 0 none, 1 y.w0, 2 y.w0 and y.y
-void launch_spmv(opmhip_ctx* c, const double* x, double* y, int ndot, const double* w0, const double*, double xs) {
+// the scalar products ride in the product's kernel unless wells modify y after it (then k_dots forms them afterwards)
+static bool spmv_dots_env() {   // OPMHIP_DOTS_SEPARATE=1 (tuning / A-B measurements): k_dots behind every product, as with wells
+    static const bool v = [] { const char* e = std::getenv("OPMHIP_DOTS_SEPARATE"); return e && std::atoi(e) != 0; }();
+    return v;
+}
+static bool spmv_dots_separate(const opmhip_ctx* c) { return c->wells.num_wells > 0 || spmv_dots_env(); }
+// one launch over the schedule positions [p0, p0 + np): the pipelined kernel where the pattern allows it, else one tile per
+// workgroup.  Partial sums go to part[pofs ...]; returns how many were written (0 with ndot == 0).
+static int launch_spmv_part(opmhip_ctx* c, int p0, int np, const double* x, double* y, int ndot, const double* w0, double xs, int pofs, int cls) {
     const Pattern& P = c->pat;
-    const int ntp = P.tiles.nsched;  // schedule positions (tiles + padding)
-    const int4* sched = reinterpret_cast<const int4*>(P.tiles.d_spmvSched);
-    const bool wells = c->wells.num_wells > 0;
-    const bool separate = spmv_dots_separate(c);   // the scalar products in k_dots (wells: after the well operator; pipelined kernel: always)
-    const int fused = separate ? 0 : ndot;
-    // the SpMV is timed by its own dispatch (kernel begin to kernel end), which is what bench.py's roofline quotes
+    if (np <= 0) return 0;
+    const int4* sched = reinterpret_cast<const int4*>(P.tiles.d_spmvSched) + p0;
+    double* part = c->d_part + pofs;
+    // timed by its own dispatch (kernel begin to kernel end), which is what bench.py's roofline quotes
     int es = -1, ee = -1;
-    const bool timed = prof_kernel_scope(c, PROF_SPMV, &es, &ee);
+    const bool timed = prof_kernel_scope(c, cls, &es, &ee);
     hipEvent_t e0 = timed ? c->prof.ev[es] : nullptr, e1 = timed ? c->prof.ev[ee] : nullptr;
-    // cfg.spmv_pipe_wgs: resident workgroups the pipelined kernel is sized for (0 = default, < 0 = never use it)
-    const int pipeWgs = spmv_pipe_wgs(c);
     if (spmv_pipelined(c)) {
-        // pipelined kernel: every workgroup walks through ceil(ntp / grid) launch positions; the grid is sized so that all
-        // workgroups are resident at once and end together, and is a multiple of 8 (a workgroup stays on "its" XCD column of
-        // the schedule)
-        const int steps = std::min((ntp + pipeWgs - 1) / pipeWgs, PIPE_MAX_STEPS);   // beyond that: more workgroups than are resident
-        const int grid = 8 * (((ntp + steps - 1) / steps + 7) / 8);
-        hipExtLaunchKernelGGL(k_spmv_pipe, dim3(grid), dim3(64), 0, c->stream, e0, e1, 0, ntp, sched, P.d_rowptr, P.d_col, c->d_A, x, y, c->d_done, xs);
-    } else if (fused == 0)
-        hipExtLaunchKernelGGL(k_spmv<0>, dim3(ntp), dim3(64), 0, c->stream, e0, e1, 0, sched, P.d_rowptr, P.d_col, c->d_A, x, y, w0, c->d_part, c->npart, c->d_done, xs);
-    else if (fused == 1)
-        hipExtLaunchKernelGGL(k_spmv<1>, dim3(ntp), dim3(64), 0, c->stream, e0, e1, 0, sched, P.d_rowptr, P.d_col, c->d_A, x, y, w0, c->d_part, c->npart, c->d_done, xs);
-    else
-        hipExtLaunchKernelGGL(k_spmv<2>, dim3(ntp), dim3(64), 0, c->stream, e0, e1, 0, sched, P.d_rowptr, P.d_col, c->d_A, x, y, w0, c->d_part, c->npart, c->d_done, xs);
-    if (wells) launch_wells_apply(c, x, y, xs);
-    if (separate) {
-        if (ndot > 0) {
-            const int n = P.Nb * BS;
-            hipLaunchKernelGGL(k_dots, dim3(vec_blocks(n)), dim3(VB), 0, c->stream, n, y, w0, c->d_part, c->npart, ndot);
-        }
+        // every workgroup walks through ceil(np / grid) launch positions; the grid is sized so that all workgroups are
+        // resident at once and end together, and is a multiple of 8 (a workgroup stays on "its" XCD column of the schedule)
+        const int pipeWgs = spmv_pipe_wgs(c);
+        const int steps = std::min((np + pipeWgs - 1) / pipeWgs, PIPE_MAX_STEPS);   // beyond that: more workgroups than are resident
+        const int grid = 8 * (((np + steps - 1) / steps + 7) / 8);
+        if (ndot == 0)
+            hipExtLaunchKernelGGL(k_spmv_pipe<0>, dim3(grid), dim3(64), 0, c->stream, e0, e1, 0, np, sched, P.d_rowptr, P.d_col, c->d_A, x, y, w0, part, c->npart, c->d_done, xs);
+        else if (ndot == 1)
+            hipExtLaunchKernelGGL(k_spmv_pipe<1>, dim3(grid), dim3(64), 0, c->stream, e0, e1, 0, np, sched, P.d_rowptr, P.d_col, c->d_A, x, y, w0, part, c->npart, c->d_done, xs);
+        else
+            hipExtLaunchKernelGGL(k_spmv_pipe<2>, dim3(grid), dim3(64), 0, c->stream, e0, e1, 0, np, sched, P.d_rowptr, P.d_col, c->d_A, x, y, w0, part, c->npart, c->d_done, xs);
+        return ndot > 0 ? grid : 0;
     }
+    if (ndot == 0)
+        hipExtLaunchKernelGGL(k_spmv<0>, dim3(np), dim3(64), 0, c->stream, e0, e1, 0, sched, P.d_rowptr, P.d_col, c->d_A, x, y, w0, part, c->npart, c->d_done, xs);
+    else if (ndot == 1)
+        hipExtLaunchKernelGGL(k_spmv<1>, dim3(np), dim3(64), 0, c->stream, e0, e1, 0, sched, P.d_rowptr, P.d_col, c->d_A, x, y, w0, part, c->npart, c->d_done, xs);
+    else
+        hipExtLaunchKernelGGL(k_spmv<2>, dim3(np), dim3(64), 0, c->stream, e0, e1, 0, sched, P.d_rowptr, P.d_col, c->d_A, x, y, w0, part, c->npart, c->d_done, xs);
+    return ndot > 0 ? np : 0;
 }
-static int dot_count(opmhip_ctx* c) {  // how many partials the last launch_spmv left behind
-    return spmv_dots_separate(c) ? vec_blocks(c->pat.Nb * BS) : c->pat.tiles.nsched;
+// y = A x (+ wells) and the partial sums of the scalar products: ndot 0 none, 1 y.w0, 2 y.w0 and y.y.
+// exchange (decomposed runs): the ghost entries of x are refreshed first - Dune's copyOwnerToAll in front of the operator
+// (linalg/WellOperators.hpp:127-138, ParallelOverlappingILU0.hpp:897) - on the halo stream, WHILE the interior tiles (no
+// ghost column in any of their rows) are multiplied on the main stream; the boundary tiles follow when the ghosts are in.
+// Every row's sum is formed by the same statements in the same order whichever launch it is in: the same bits as one launch.
+int launch_spmv(opmhip_ctx* c, double* x, double* y, int ndot, const double* w0, double xs, bool exchange) {
+    const Pattern& P = c->pat;
+    const bool wells = c->wells.num_wells > 0;
+    const int fused = spmv_dots_separate(c) ? 0 : ndot;
+    const bool halo = exchange && c->comm.halo_set && c->comm.nneigh > 0;
+    const int nInt = P.tiles.nschedInt, nBnd = P.tiles.nsched - nInt;
+    int rc, cnt = 0;
+    if (halo && nBnd > 0) {
+        // main: ev_x (x complete) -> interior tiles ........................ wait ev_h -> boundary tiles
+        // halo:         wait ev_x -> pack -> send / receive -> ev_h
+        if ((rc = comm_halo_begin(c, x))) return rc;     // records ev_x on the main stream; the exchange itself is behind it on the halo stream
+        cnt += launch_spmv_part(c, 0, nInt, x, y, fused, w0, xs, cnt, PROF_SPMV);
+        if ((rc = comm_halo_end(c))) return rc;
+        cnt += launch_spmv_part(c, nInt, nBnd, x, y, fused, w0, xs, cnt, PROF_SPMV_BOUNDARY);
+    } else {
+        if (halo && (rc = comm_halo_f64(c, x, BS))) return rc;
+        cnt += launch_spmv_part(c, 0, P.tiles.nsched, x, y, fused, w0, xs, cnt, PROF_SPMV);
+    }
+    if (wells) launch_wells_apply(c, x, y, xs);
+    if (fused == 0 && ndot > 0) {
+        const int n = P.Nb * BS;
+        const int ps = prof_begin(c, PROF_VECTOR);   // a scope of its own: its bytes are counted under "vector"
+        hipLaunchKernelGGL(k_dots, dim3(vec_blocks(n)), dim3(VB), 0, c->stream, n, y, w0, c->d_part, c->npart, ndot);
+        prof_end(c, ps);
+        cnt = vec_blocks(n);
+    }
+    c->last_dot_count = cnt;
+    return OPMHIP_SUCCESS;
 }
+static int dot_count(opmhip_ctx* c) { return c->last_dot_count; }  // how many partials the last launch_spmv left behind
 void launch_ilu_factor(opmhip_ctx* c) {
     const Pattern& P = c->pat;
     const int ps = prof_begin(c, PROF_ILU_FACTOR);
@@ -1780,8 +1837,7 @@ static int enqueue_half(opmhip_ctx* c, int h) {
         }
         if (cpr) launch_cpr_apply(c, c->d_p, c->d_pw);
         else launch_ilu_apply(c, c->d_p, c->d_pw, -1.0, &c->minv_scale);   // d_pw without the relaxation factor: its readers apply it
-        if ((rc = comm_halo_f64(c, c->d_pw, BS))) return rc;  // copyOwnerToAll before the operator (ParallelOverlappingILU0.hpp:897)
-        launch_spmv(c, c->d_pw, c->d_v, 1, c->d_rw, nullptr, c->minv_scale);
+        if ((rc = launch_spmv(c, c->d_pw, c->d_v, 1, c->d_rw, c->minv_scale, true))) return rc;  // with copyOwnerToAll before the operator (ParallelOverlappingILU0.hpp:897)
         ps = prof_begin(c, PROF_VECTOR);
         if ((rc = finalize(c, FIN_ALPHA, dot_count(c)))) return rc;
         hipLaunchKernelGGL(k_bicg_upd1, dim3(nb), dim3(VB), 0, c->stream, n, c->d_scal, c->d_r, c->d_v, c->d_part, c->npart);
@@ -1790,8 +1846,7 @@ static int enqueue_half(opmhip_ctx* c, int h) {
     } else {             // second half: z = M^-1 r, t = A z, omega, x += omega z, r -= omega t, |r|, rho, beta
         if (cpr) launch_cpr_apply(c, c->d_r, c->d_s);
         else launch_ilu_apply(c, c->d_r, c->d_s, -1.0, &c->minv_scale);
-        if ((rc = comm_halo_f64(c, c->d_s, BS))) return rc;
-        launch_spmv(c, c->d_s, c->d_t, 2, c->d_r, nullptr, c->minv_scale);
+        if ((rc = launch_spmv(c, c->d_s, c->d_t, 2, c->d_r, c->minv_scale, true))) return rc;
         ps = prof_begin(c, PROF_VECTOR);
         if ((rc = finalize(c, FIN_OMEGA, dot_count(c)))) return rc;
         hipLaunchKernelGGL(k_bicg_upd2, dim3(nb), dim3(VB), 0, c->stream, n, c->d_scal, c->d_x, c->d_pw, c->d_s, c->d_r, c->d_t, c->d_rw, c->d_part, c->npart, c->minv_scale);
