@@ -21,6 +21,7 @@ extern "C" {
 #endif
 
 #define OPMHIP_ABI_VERSION 4 /* 4: opmhip_config names chain_length, spmv_pipe_wgs, preconditioner (were reserved[0..2]);
+                               *    opmhip_set_endpoint_scaling, opmhip_sat_end_points, opmhip_synchronize, opmhip_comm_info;
                                * 3: opmhip_fluid gained pc_scaling, opmhip_set_pcw */
 
 typedef struct opmhip_ctx opmhip_ctx;
@@ -242,8 +243,8 @@ typedef struct opmhip_fluid {
     int num_rock;
     const int* rocktab_ptr;     /* [num_rock+1] */
     const double* rocktab;
-    /* End-point scaling of the oil-water capillary pressure (EclEpsConfig::enablePcScaling: the deck has PCW or SWATINIT).
-     * Non-zero: the context keeps the extended intensive-quantity record and accepts opmhip_set_pcw. */
+    /* Per-cell end points of the saturation functions (the deck has ENDSCALE, PCW or SWATINIT).  Non-zero: the context
+     * keeps the extended intensive-quantity record and accepts opmhip_set_pcw / opmhip_set_endpoint_scaling. */
     int pc_scaling;
 } opmhip_fluid;
 
@@ -278,6 +279,38 @@ int opmhip_set_problem_extras(opmhip_ctx* ctx, const double* rvmax, const int* r
  * restated from its published form, see oracle/blackoil.hpp.)  pcw: per cell, natural order, Pa; NULL = unscaled.
  * Needs a fluid with pc_scaling set, and set_static first. */
 int opmhip_set_pcw(opmhip_ctx* ctx, const double* pcw);
+
+/* Saturation end-point scaling (ENDSCALE, SCALECRS, SWL ... SOGCR, KRW / KRO / KRG, KRWR / KRORW / KRORG / KRGR, PCW / PCG).
+ * replaces: the per-cell scaled end points the EclMaterialLawManager holds and hands to the material laws
+ * (materialLawParams(elemIdx), ebos/eclproblem.hh:1490-1498; EclEpsScalingPointsInfo / EclEpsConfig / EclEpsTwoPhaseLaw of
+ * opm-material, which is absent from the reference tree: restated from its published form, see oracle/fluid.hpp).
+ * Indices of the end points of a cell / of a saturation region's tables: */
+enum {
+    OPMHIP_EPS_SWL = 0,  /* connate water */        OPMHIP_EPS_SWCR = 1,    /* critical water */
+    OPMHIP_EPS_SWU = 2,  /* maximum water */        OPMHIP_EPS_SOWCR = 3,   /* critical oil in water */
+    OPMHIP_EPS_SGL = 4,  /* connate gas */          OPMHIP_EPS_SGCR = 5,    /* critical gas */
+    OPMHIP_EPS_SGU = 6,  /* maximum gas */          OPMHIP_EPS_SOGCR = 7,   /* critical oil in gas */
+    OPMHIP_EPS_MAXPCOW = 8,  /* PCW */              OPMHIP_EPS_MAXPCGO = 9, /* PCG */
+    OPMHIP_EPS_MAXKRW = 10,  /* KRW */              OPMHIP_EPS_MAXKROW = 11, /* KRO (oil-water) */
+    OPMHIP_EPS_MAXKRG = 12,  /* KRG */              OPMHIP_EPS_MAXKROG = 13, /* KRO (gas-oil) */
+    OPMHIP_EPS_KRWR = 14, OPMHIP_EPS_KRORW = 15, OPMHIP_EPS_KRGR = 16, OPMHIP_EPS_KRORG = 17,   /* values at the displacing phase's critical saturation */
+    OPMHIP_EPS_COUNT = 18
+};
+typedef struct opmhip_endpoint_scaling {
+    int sat_scaling;     /* ENDSCALE: two-point scaling of the saturation axis of every curve */
+    int three_point_kr;  /* SCALECRS YES: the relative permeabilities keep a third point (the other phase's critical saturation) */
+    int krw, kro, krg;   /* vertical scaling of krw / kro (krow and krog) / krg: 0 none, 1 at the maximum (KRW / KRO / KRG), 2 also
+                          * at the displacing phase's critical saturation (KRWR / KRORW, KRORG / KRGR) */
+    int pcw, pcg;        /* PCW / PCG: capillary pressures scaled to the cell's maximum */
+    const double* points[OPMHIP_EPS_COUNT]; /* per cell (natural order, Nb + Nghost entries), SI; NULL = the end point of the
+                                             * cell's SATNUM tables (opmhip_sat_end_points) */
+} opmhip_endpoint_scaling;
+/* Needs a fluid with pc_scaling set, and set_static.  eps == NULL: scaling off.  Recomputes the cached intensive quantities
+ * if a state is set.  Not to be combined with opmhip_set_pcw (PCW then is points[OPMHIP_EPS_MAXPCOW] with pcw = 1). */
+int opmhip_set_endpoint_scaling(opmhip_ctx* ctx, const opmhip_endpoint_scaling* eps);
+/* the end points of the tables of saturation region sat_region (opm-common's satfunc end-point extraction, restated):
+ * out[OPMHIP_EPS_COUNT].  Needs opmhip_set_fluid only. */
+int opmhip_sat_end_points(opmhip_ctx* ctx, int sat_region, double* out);
 
 /* Point evaluation of the fluid-system and saturation functions the assembly uses, ON THE DEVICE, for host-side setup
  * code (equilibration, ebos/equil/initstateequil.hh) and for tests that pin these functions against the reference's

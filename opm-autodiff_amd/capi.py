@@ -41,6 +41,28 @@ class Result(C.Structure):
                 ("reserved", C.c_int * 3)]
 
 
+EPS_FIELDS = ("swl", "swcr", "swu", "sowcr", "sgl", "sgcr", "sgu", "sogcr", "max_pcow", "max_pcgo", "max_krw", "max_krow", "max_krg", "max_krog",
+              "krwr", "krorw", "krgr", "krorg")   # OPMHIP_EPS_* order
+
+
+class EndpointScaling(C.Structure):
+    _fields_ = [("sat_scaling", C.c_int), ("three_point_kr", C.c_int), ("krw", C.c_int), ("kro", C.c_int), ("krg", C.c_int),
+                ("pcw", C.c_int), ("pcg", C.c_int), ("points", C.c_void_p * 18)]
+
+
+def endpoint_scaling_struct(es):
+    """dict(sat_scaling, three_point_kr, krw, kro, krg, pcw, pcg, <EPS_FIELDS>: per-cell arrays or absent) -> (struct, keep-alive)"""
+    s = EndpointScaling()
+    for k in ("sat_scaling", "three_point_kr", "krw", "kro", "krg", "pcw", "pcg"):
+        setattr(s, k, int(es.get(k, 0)))
+    keep = []
+    for f, name in enumerate(EPS_FIELDS):
+        a = _f64(es.get(name))
+        keep.append(a)
+        s.points[f] = None if a is None else a.ctypes.data
+    return s, keep
+
+
 class Wells(C.Structure):
     _fields_ = [("num_wells", C.c_int), ("val_pointers", C.c_void_p), ("Ccols", C.c_void_p),
                 ("Bcols", C.c_void_p), ("Cnnzs", C.c_void_p), ("Dnnzs", C.c_void_p), ("Bnnzs", C.c_void_p)]
@@ -331,6 +353,8 @@ def _bind_assembly(L):
     L.opmhip_fluid_probe.argtypes = [vp, C.c_int, C.c_int, C.c_int, vp, vp, vp, vp, vp]
     L.opmhip_set_problem_extras.argtypes = [vp, vp, vp, vp]
     L.opmhip_set_pcw.argtypes = [vp, vp]
+    L.opmhip_set_endpoint_scaling.argtypes = [vp, vp]
+    L.opmhip_sat_end_points.argtypes = [vp, C.c_int, vp]
     L.opmhip_gas_probe.argtypes = [vp, C.c_int, C.c_int, vp, vp, vp]
     L.opmhip_iq_fields.argtypes = [vp]
 
@@ -372,6 +396,16 @@ def _probe_gas(self, p, rv=0.0, pvt_region=0):
 
 
 HipFluid.probe_gas = _probe_gas
+
+
+def _sat_end_points(self, sat_region=0):
+    """the end points of a saturation region's own tables: dict over capi.EPS_FIELDS (opmhip_sat_end_points)"""
+    out = np.empty(18)
+    self._check(lib().opmhip_sat_end_points(self._h, sat_region, _ptr(out)))
+    return dict(zip(EPS_FIELDS, out.tolist()))
+
+
+HipFluid.sat_end_points = _sat_end_points
 
 
 class HipModel(HipSolver):
@@ -421,6 +455,18 @@ class HipModel(HipSolver):
             self.set_problem_extras(case.get("rvmax"), case.get("rocknum"), case.get("overburden"))
         if case.get("pcw") is not None:
             self.set_pcw(case["pcw"])
+        if case.get("endscale") is not None:
+            self.set_endpoint_scaling(case["endscale"])
+
+    def set_endpoint_scaling(self, es):
+        """saturation end-point scaling (ENDSCALE family): es = dict(sat_scaling, three_point_kr, krw, kro, krg, pcw, pcg and any
+        of capi.EPS_FIELDS as per-cell arrays; absent = the end point of the cell's SATNUM tables); None = off.  The fluid needs
+        pc_scaling=True."""
+        if es is None:
+            self._check(lib().opmhip_set_endpoint_scaling(self._h, None))
+            return
+        s, keep = endpoint_scaling_struct(es)
+        self._check(lib().opmhip_set_endpoint_scaling(self._h, C.byref(s)))
 
     def set_pcw(self, pcw):
         """per-cell scaled maximum of the oil-water capillary pressure (PCW, or SWATINIT through equil.equilibrate's pcw_scale

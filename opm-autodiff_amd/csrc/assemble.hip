@@ -218,9 +218,114 @@ struct CellStatic {
     const double *rvmax, *overburden;   // extended layout: DRVDT cap, overburden pressure (may be NULL)
     const int* rocknum;                 // rock-table index per cell (NULL = table 0)
     const double* pcw;                  // extended layout: scaled maximum of pcow per cell (PCW / SWATINIT; NULL = the tables' own)
+    const double* eps;                  // extended layout: scaled end points per cell, field-major [EPS_COUNT][ncell] (NULL = no end-point scaling)
+    int epscfg;                         // EclEpsConfig: bit 0 saturation scaling, 1 three-point, 2-3 krw, 4-5 kro, 6-7 krg mode, 8 pcw, 9 pcg
     double* invb;                       // packed 1/b_w, 1/b_o, 1/b_g per cell, written beside the record (convergence check)
     int ncell;                          // cells of the intensive-quantity cache (owned + ghost): the stride between its fields
 };
+
+// ---- saturation end-point scaling (EclEpsTwoPhaseLaw; oracle/fluid.hpp eps_*: same statements, same order) ----------------
+struct EpsTriple { double s[3]; };
+__device__ __forceinline__ EpsTriple eps_pc_ow(const double* e) { return {{e[EPS_SWL], e[EPS_SWU], e[EPS_SWU]}}; }
+__device__ __forceinline__ EpsTriple eps_krw_ow(const double* e) { return {{e[EPS_SWCR], 1.0 - e[EPS_SOWCR] - e[EPS_SGL], e[EPS_SWU]}}; }
+__device__ __forceinline__ EpsTriple eps_krn_ow(const double* e) { return {{e[EPS_SWL] + e[EPS_SGL], e[EPS_SWCR] + e[EPS_SGL], 1.0 - e[EPS_SOWCR]}}; }
+__device__ __forceinline__ EpsTriple eps_pc_go(const double* e) { return {{1.0 - e[EPS_SWL] - e[EPS_SGU], 1.0 - e[EPS_SWL] - e[EPS_SGL], 1.0 - e[EPS_SWL] - e[EPS_SGL]}}; }
+__device__ __forceinline__ EpsTriple eps_krw_go(const double* e) { return {{e[EPS_SOGCR], 1.0 - e[EPS_SGCR] - e[EPS_SWL], 1.0 - e[EPS_SWL] - e[EPS_SGL]}}; }
+__device__ __forceinline__ EpsTriple eps_krn_go(const double* e) { return {{1.0 - e[EPS_SWL] - e[EPS_SGU], e[EPS_SOGCR], 1.0 - e[EPS_SWL] - e[EPS_SGCR]}}; }
+template <class E> __device__ __forceinline__ E eps_sat_two_point(const E& S, const EpsTriple& u, const EpsTriple& sc) {
+    return u.s[0] + (S - sc.s[0]) * ((u.s[2] - u.s[0]) / (sc.s[2] - sc.s[0]));
+}
+template <class E> __device__ __forceinline__ E eps_sat_three_point(const E& S, const EpsTriple& u, const EpsTriple& sc) {
+    if (val(S) <= sc.s[0]) return cst<E>(u.s[0]);
+    if (val(S) <= sc.s[1]) return u.s[0] + (S - sc.s[0]) * ((u.s[1] - u.s[0]) / (sc.s[1] - sc.s[0]));
+    if (u.s[1] == u.s[2]) return cst<E>(u.s[1]);
+    if (val(S) <= sc.s[2]) return u.s[1] + (S - sc.s[1]) * ((u.s[2] - u.s[1]) / (sc.s[2] - sc.s[1]));
+    return cst<E>(u.s[2]);
+}
+template <class E> __device__ __forceinline__ E eps_to_unscaled(int cfg, const E& S, const EpsTriple& u, const EpsTriple& sc) {
+    if (!(cfg & 1)) return S;
+    return (cfg & 2) ? eps_sat_three_point(S, u, sc) : eps_sat_two_point(S, u, sc);
+}
+template <class E> __device__ __forceinline__ E eps_vertical_krw(int mode, const E& S, const E& kr, const EpsTriple& sc, double fdisp, double fmax, double fr, double fm) {
+    if (mode == 0) return kr;
+    if (mode == 1) return kr * (fm / fmax);
+    const double sm = sc.s[2], sr = emin(sc.s[1], sm);
+    if (!(val(S) > sr)) return kr * (fr / fdisp);
+    if (fmax > fdisp) { const E t = (kr - fdisp) / (fmax - fdisp); return fr + t * (fm - fr); }
+    if (sr < sm) { const E t = (S - sr) / (sm - sr); return fr + t * (fm - fr); }
+    return cst<E>(fm);
+}
+template <class E> __device__ __forceinline__ E eps_vertical_krn(int mode, const E& S, const E& kr, const EpsTriple& sc, double fdisp, double fmax, double fr, double fm) {
+    if (mode == 0) return kr;
+    if (mode == 1) return kr * (fm / fmax);
+    const double sl = sc.s[0], sr = emax(sc.s[1], sl);
+    if (!(val(S) < sr)) return kr * (fr / fdisp);
+    if (fmax > fdisp) { const E t = (kr - fdisp) / (fmax - fdisp); return fr + t * (fm - fr); }
+    if (sr > sl) { const E t = (sr - S) / (sr - sl); return fr + t * (fm - fr); }
+    return cst<E>(fm);
+}
+// the cell's scaled end points out of the field-major array, the region's unscaled ones out of the table blob
+template <class DP> __device__ __forceinline__ void eps_load(const CellStatic& C, int c, DP B, const SatRegionDesc& Sd, double* u, double* s) {
+#pragma unroll
+    for (int f = 0; f < EPS_COUNT; ++f) { u[f] = B[Sd.eps + f]; s[f] = C.eps[(size_t)f * C.ncell + c]; }
+}
+// capillary pressures of a cell with scaled end points (SatFunc::capillaryPressuresEps)
+template <class E, class DP> __device__ __forceinline__ void cap_pressures_eps(DP B, const SatRegionDesc& Sd, int cfg, const double* u, const double* s, const E& Sw, const E& Sg, E pC[3]) {
+    const double Swco = B[Sd.swco];
+    const double SwcoS = s[EPS_SWL];
+    const E SoP = 1.0 - SwcoS - Sg;
+    E swU = Sw, soU = SoP;
+    if (cfg & 1) {
+        swU = eps_sat_two_point(Sw, eps_pc_ow(u), eps_pc_ow(s));
+        soU = eps_sat_two_point(SoP, eps_pc_go(u), eps_pc_go(s));
+    } else soU = 1.0 - Swco - Sg;
+    E pcw = pwlin<E, DP>(B + Sd.sw_x, B + Sd.pcow, Sd.nw, swU), pcg = pwlin<E, DP>(B + Sd.so_x, B + Sd.pcgo, Sd.ng, soU);
+    if (cfg & 256) {
+        const double sm = s[EPS_MAXPCOW], um = u[EPS_MAXPCOW];
+        pcw = pcw * ((sm == um) ? 1.0 : sm / um);
+    }
+    if (cfg & 512) {
+        const double sm = s[EPS_MAXPCGO], um = u[EPS_MAXPCGO];
+        pcg = pcg * ((sm == um) ? 1.0 : sm / um);
+    }
+    pC[0] = -pcw;
+    pC[1] = cst<E>(0.0);
+    pC[2] = pcg;
+}
+// relative permeabilities of a cell with scaled end points (SatFunc::relativePermeabilitiesEps)
+template <class E, class DP> __device__ __forceinline__ void rel_perms_eps(DP B, const SatRegionDesc& Sd, int cfg, const double* u, const double* s, const E& SwIn, const E& Sg, E kr[3]) {
+    const double Swco = B[Sd.swco];
+    const double SwcoS = (cfg & 1) ? s[EPS_SWL] : Swco;
+    const int mKrw = (cfg >> 2) & 3, mKro = (cfg >> 4) & 3, mKrg = (cfg >> 6) & 3;
+    const EpsTriple uKrwOw = eps_krw_ow(u), sKrwOw = eps_krw_ow(s), uKrnOw = eps_krn_ow(u), sKrnOw = eps_krn_ow(s);
+    const EpsTriple uKrwGo = eps_krw_go(u), sKrwGo = eps_krw_go(s), uKrnGo = eps_krn_go(u), sKrnGo = eps_krn_go(s);
+    kr[0] = eps_vertical_krw(mKrw, SwIn, pwlin<E, DP>(B + Sd.sw_x, B + Sd.krw, Sd.nw, eps_to_unscaled(cfg, SwIn, uKrwOw, sKrwOw)), sKrwOw, u[EPS_KRWR], u[EPS_MAXKRW], s[EPS_KRWR], s[EPS_MAXKRW]);
+    const E SoP = 1.0 - SwcoS - Sg;
+    kr[2] = eps_vertical_krn(mKrg, SoP, pwlin<E, DP>(B + Sd.so_x, B + Sd.krg, Sd.ng, eps_to_unscaled(cfg, SoP, uKrnGo, sKrnGo)), sKrnGo, u[EPS_KRGR], u[EPS_MAXKRG], s[EPS_KRGR], s[EPS_MAXKRG]);
+    const E Sw = emax(cst<E>(SwcoS), SwIn);
+    const E Sw_ow = Sg + Sw;
+    const E So_go = 1.0 - Sw_ow;
+    const E kro_ow = eps_vertical_krn(mKro, Sw_ow, pwlin<E, DP>(B + Sd.sw_x, B + Sd.krow, Sd.nw, eps_to_unscaled(cfg, Sw_ow, uKrnOw, sKrnOw)), sKrnOw, u[EPS_KRORW], u[EPS_MAXKROW], s[EPS_KRORW], s[EPS_MAXKROW]);
+    const E kro_go = eps_vertical_krw(mKro, So_go, pwlin<E, DP>(B + Sd.so_x, B + Sd.krog, Sd.ng, eps_to_unscaled(cfg, So_go, uKrwGo, sKrwGo)), sKrwGo, u[EPS_KRORG], u[EPS_MAXKROG], s[EPS_KRORG], s[EPS_MAXKROG]);
+    const double eps = 1e-5;
+    if (val(Sw_ow) - SwcoS < eps) {
+        const E kro2 = (kro_ow + kro_go) / 2.0;
+        if (val(Sw_ow) - SwcoS > eps / 2.0) {
+            const E kro1 = (Sg * kro_go + (Sw - SwcoS) * kro_ow) / (Sw_ow - SwcoS);
+            const E alpha = (eps - (Sw_ow - SwcoS)) / (eps / 2.0);
+            kr[1] = kro2 * alpha + kro1 * (1.0 - alpha);
+        } else kr[1] = kro2;
+    } else kr[1] = (Sg * kro_go + (Sw - SwcoS) * kro_ow) / (Sw_ow - SwcoS);
+}
+// the capillary pressures of cell c at (Sw, Sg), values only: what the primary-variable switches need
+// (computeCapillaryPressures_ of BlackOilPrimaryVariables), with the cell's scaled end points where the deck has them
+template <class DP, bool EXT> __device__ __forceinline__ void cell_cap_pressures(const TablesT<DP>& T, const CellStatic& C, int c, int sr, double Sw, double Sg, double pC[3]) {
+    if (EXT && C.eps) {
+        double u[EPS_COUNT], s[EPS_COUNT];
+        eps_load<DP>(C, c, T.dbl, T.sat(sr), u, s);
+        cap_pressures_eps<double, DP>(T.dbl, T.sat(sr), C.epscfg, u, s, Sw, Sg, pC);
+    } else cap_pressures<double, DP>(T, sr, Sw, Sg, pC);
+}
 
 // BlackOilIntensiveQuantities::update: live oil + water + dry gas (base) or wet gas / rock compaction tables (EXT)
 template <class E, class DP, bool EXT>
@@ -241,10 +346,17 @@ __device__ __forceinline__ void update_iq(const TablesT<DP>& T, const CellStatic
     q.S[WATER] = Sw; q.S[GAS] = Sg; q.S[OIL] = So;
     // capillary pressures (EclDefaultMaterial): pC[water] = -pcow(Sw), pC[oil] = 0, pC[gas] = pcgo(1 - Swco - Sg)
     E pC[3];
-    pC[0] = -pwlin<E, DP>(B + Sd.sw_x, B + Sd.pcow, Sd.nw, Sw);
-    pC[1] = cst<E>(0.0);
-    pC[2] = pwlin<E, DP>(B + Sd.so_x, B + Sd.pcgo, Sd.ng, 1.0 - Swco - Sg);
-    if (EXT && C.pcw) {
+    const bool scaled = EXT && C.eps;
+    double epsU[EXT ? EPS_COUNT : 1], epsS[EXT ? EPS_COUNT : 1];
+    if (scaled) {
+        eps_load<DP>(C, c, B, Sd, epsU, epsS);
+        cap_pressures_eps<E, DP>(B, Sd, C.epscfg, epsU, epsS, Sw, Sg, pC);
+    } else {
+        pC[0] = -pwlin<E, DP>(B + Sd.sw_x, B + Sd.pcow, Sd.nw, Sw);
+        pC[1] = cst<E>(0.0);
+        pC[2] = pwlin<E, DP>(B + Sd.so_x, B + Sd.pcgo, Sd.ng, 1.0 - Swco - Sg);
+    }
+    if (EXT && C.pcw && !scaled) {
         // end-point scaling of the oil-water curve (EclEpsTwoPhaseLaw with enablePcScaling): table value x (scaled max / table max),
         // the table's maximum being its value at the connate saturation (first row of SWOF)
         const double scaledMax = C.pcw[c], tableMax = B[Sd.pcow];
@@ -259,7 +371,8 @@ __device__ __forceinline__ void update_iq(const TablesT<DP>& T, const CellStatic
         for (int ph = 0; ph < 3; ++ph) q.p[ph] = po + (pC[ph] - pC[OIL]);
     }
     // relative permeabilities (stored in mob, divided by viscosity below)
-    {
+    if (scaled) rel_perms_eps<E, DP>(B, Sd, C.epscfg, epsU, epsS, Sw, Sg, q.mob);
+    else {
         q.mob[WATER] = pwlin<E, DP>(B + Sd.sw_x, B + Sd.krw, Sd.nw, Sw);
         q.mob[GAS] = pwlin<E, DP>(B + Sd.so_x, B + Sd.krg, Sd.ng, 1.0 - Swco - Sg);
         const E Swm = emax(cst<E>(Swco), Sw);
@@ -479,7 +592,7 @@ __device__ __forceinline__ void newton_update_cell(const TablesT<DP>& T, const C
             sw = true;
         } else if (EXT && wet && So < -eps && x[2] > 0.0) {   // the oil phase disappears: { Sw, pg, Rv }
             double pC[3];
-            cap_pressures<double, DP>(T, sr, x[0], x[2], pC);
+            cell_cap_pressures<DP, EXT>(T, C, c, sr, x[0], x[2], pC);
             const double pg = x[1] + (pC[GAS] - pC[OIL]);
             const double RvMax = C.rvmax ? C.rvmax[c] : DBL_MAX / 2.0;
             mng = OPMHIP_SW_PG_RV;
@@ -495,7 +608,7 @@ __device__ __forceinline__ void newton_update_cell(const TablesT<DP>& T, const C
         const double RvSat = rv_sat_value(T, pr, x[1]);
         if (x[2] > emin(RvMax, RvSat * (1.0 + eps))) {
             double pC[3];
-            cap_pressures<double, DP>(T, sr, x[0], 1.0 - x[0], pC);
+            cell_cap_pressures<DP, EXT>(T, C, c, sr, x[0], 1.0 - x[0], pC);
             mng = OPMHIP_SW_PO_SG;
             x[1] = x[1] + (pC[OIL] - pC[GAS]);
             x[2] = 1.0 - x[0];
@@ -1044,7 +1157,7 @@ static Tables tables_of(const opmhip_ctx* c) {
 }
 static CellStatic cells_of(const opmhip_ctx* c) {
     return CellStatic{c->asmb.d_poro, c->asmb.d_volume, c->asmb.d_depth, c->asmb.d_rsmax, c->asmb.d_pvtnum, c->asmb.d_satnum,
-                      c->asmb.d_rvmax, c->asmb.d_overburden, c->asmb.d_rocknum, c->asmb.d_pcw, c->asmb.d_invb, c->pat.Nloc};
+                      c->asmb.d_rvmax, c->asmb.d_overburden, c->asmb.d_rocknum, c->asmb.d_pcw, c->asmb.d_eps, c->asmb.epscfg, c->asmb.d_invb, c->pat.Nloc};
 }
 // the context's record layout: extended when the fluid has PVTG or ROCKTAB tables
 #define OPMHIP_LAYOUT(c, call_base, call_ext) do { if ((c)->asmb.ext) { call_ext; } else { call_base; } } while (0)

@@ -90,6 +90,8 @@ int opmhip_set_fluid(opmhip_ctx* c, const opmhip_fluid* fluid) {
         A.wet_gas = T.wet_gas;
         A.pc_scaling = T.pc_scaling;
         A.ext = T.wet_gas || T.num_rock > 0 || T.pc_scaling;   // extended intensive-quantity record
+        A.sat_eps.resize((size_t)T.num_sat * EPS_COUNT);
+        for (int s = 0; s < T.num_sat; ++s) sat_end_points(T, s, &A.sat_eps[(size_t)s * EPS_COUNT]);
         A.fluid_set = true;
         return OPMHIP_SUCCESS;
     });
@@ -282,6 +284,7 @@ int opmhip_set_pcw(opmhip_ctx* c, const double* pcw) {
     return guarded(c, [&]() -> int {
         AsmDev& A = c->asmb;
         if (!A.static_set) return fail(c, OPMHIP_NOT_READY, "set_pcw before set_static");
+        if (pcw && A.d_eps) return fail(c, OPMHIP_INVALID_ARGUMENT, "set_pcw: opmhip_set_endpoint_scaling is in force - PCW is its points[OPMHIP_EPS_MAXPCOW]");
         if (pcw && !A.pc_scaling)
             return fail(c, OPMHIP_INVALID_ARGUMENT, "set_pcw: the fluid was set without pc_scaling - its capillary pressure curves have no per-cell end point");
         if (pcw)
@@ -293,6 +296,67 @@ int opmhip_set_pcw(opmhip_ctx* c, const double* pcw) {
         else if (A.d_pcw) {
             OPMHIP_HIP(c, hipStreamSynchronize(c->stream));   // an assembly enqueued earlier may still read it
             dev_free(c, &A.d_pcw);
+        }
+        if (A.state_set) {   // the cached intensive quantities depend on it
+            launch_iq_update(c);
+            OPMHIP_HIP(c, hipGetLastError());
+            OPMHIP_HIP(c, hipStreamSynchronize(c->stream));
+        }
+        return OPMHIP_SUCCESS;
+    });
+}
+
+int opmhip_sat_end_points(opmhip_ctx* c, int sat_region, double* out) {
+    if (!c || !out) return OPMHIP_INVALID_ARGUMENT;
+    const AsmDev& A = c->asmb;
+    if (!A.fluid_set) return fail(c, OPMHIP_NOT_READY, "sat_end_points before set_fluid");
+    if (sat_region < 0 || sat_region >= A.num_sat) return fail(c, OPMHIP_INVALID_ARGUMENT, "sat_end_points: region out of range");
+    for (int f = 0; f < EPS_COUNT; ++f) out[f] = A.sat_eps[(size_t)sat_region * EPS_COUNT + f];
+    return OPMHIP_SUCCESS;
+}
+
+int opmhip_set_endpoint_scaling(opmhip_ctx* c, const opmhip_endpoint_scaling* e) {
+    if (!c) return OPMHIP_INVALID_ARGUMENT;
+    static_assert((int)OPMHIP_EPS_COUNT == (int)EPS_COUNT, "public and internal end-point indices");
+    return guarded(c, [&]() -> int {
+        AsmDev& A = c->asmb;
+        const Pattern& P = c->pat;
+        if (!A.static_set) return fail(c, OPMHIP_NOT_READY, "set_endpoint_scaling before set_static");
+        if (e && !A.pc_scaling)
+            return fail(c, OPMHIP_INVALID_ARGUMENT, "set_endpoint_scaling: the fluid was set without pc_scaling - its saturation functions have no per-cell end points");
+        if (e && A.d_pcw) return fail(c, OPMHIP_INVALID_ARGUMENT, "set_endpoint_scaling: opmhip_set_pcw is in force - hand PCW in as points[OPMHIP_EPS_MAXPCOW] with pcw = 1 instead");
+        OPMHIP_HIP(c, hipSetDevice(c->device));
+        if (!e) {
+            if (A.d_eps) { OPMHIP_HIP(c, hipStreamSynchronize(c->stream)); dev_free(c, &A.d_eps); }
+            A.epscfg = 0;
+        } else {
+            if (e->krw < 0 || e->krw > 2 || e->kro < 0 || e->kro > 2 || e->krg < 0 || e->krg > 2)
+                return fail(c, OPMHIP_INVALID_ARGUMENT, "set_endpoint_scaling: krw / kro / krg must be 0, 1 or 2");
+            const int N = P.Nloc;
+            std::vector<int> satnum(N, 0);   // internal order, as on the device
+            if (A.d_satnum) {
+                OPMHIP_HIP(c, hipStreamSynchronize(c->stream));
+                OPMHIP_HIP(c, hipMemcpy(satnum.data(), A.d_satnum, (size_t)N * sizeof(int), hipMemcpyDeviceToHost));
+            }
+            std::vector<double> v((size_t)EPS_COUNT * N);   // field-major, internal order
+            for (int pos = 0; pos < N; ++pos) {
+                const int i = P.fromOrder[pos];   // natural id (ghost cells keep their place behind the owned ones)
+                double s[EPS_COUNT];
+                for (int f = 0; f < EPS_COUNT; ++f) {
+                    s[f] = e->points[f] ? e->points[f][i] : A.sat_eps[(size_t)satnum[pos] * EPS_COUNT + f];
+                    if (!std::isfinite(s[f])) return fail(c, OPMHIP_INVALID_ARGUMENT, "set_endpoint_scaling: end point %d of cell %d is not finite", f, i);
+                    v[(size_t)f * N + pos] = s[f];
+                }
+                // the scaling maps [first, last] point of every curve onto the table's: the scaled intervals must not be empty
+                const bool ok = s[EPS_SWL] < s[EPS_SWU] && s[EPS_SGL] < s[EPS_SGU] && s[EPS_SWCR] < s[EPS_SWU] && s[EPS_SGCR] < s[EPS_SGU] &&
+                                s[EPS_SWL] + s[EPS_SGL] < 1.0 - s[EPS_SOWCR] && s[EPS_SOGCR] < 1.0 - s[EPS_SWL] - s[EPS_SGL];
+                if (e->sat_scaling && !ok) return fail(c, OPMHIP_INVALID_ARGUMENT, "set_endpoint_scaling: the end points of cell %d leave a curve no saturation interval", i);
+            }
+            int rc;
+            if (!A.d_eps && (rc = dev_alloc(c, &A.d_eps, v.size()))) return rc;
+            OPMHIP_HIP(c, hipStreamSynchronize(c->stream));
+            OPMHIP_HIP(c, hipMemcpy(A.d_eps, v.data(), v.size() * sizeof(double), hipMemcpyHostToDevice));
+            A.epscfg = (e->sat_scaling ? 1 : 0) | (e->three_point_kr ? 2 : 0) | (e->krw << 2) | (e->kro << 4) | (e->krg << 6) | (e->pcw ? 256 : 0) | (e->pcg ? 512 : 0);
         }
         if (A.state_set) {   // the cached intensive quantities depend on it
             launch_iq_update(c);

@@ -223,6 +223,41 @@ std::string build_fluid_tables(const opmhip_fluid* f, FluidTables& T) {
         D.ng = (int)so.size();
         D.so_x = push(B, so); D.krog = push(B, krog); D.krg = push(B, krg); D.pcgo = push(B, pcgo);
         D.swco = push(B, std::vector<double>{swco});
+        // the tables' end points (opm-common satfunc, restated: connate = first row, maximum = last row, critical = the last
+        // saturation at which the phase's relative permeability is still zero; same statements as oracle/fluid.hpp SatFunc::init)
+        {
+            const int nw = we - wb, ng = ge - gb;
+            const double* W = f->swof + 4 * (size_t)wb;
+            const double* G = f->sgof + 4 * (size_t)gb;
+            std::vector<double> u(EPS_COUNT, 0.0);
+            u[EPS_SWL] = sw.front(); u[EPS_SWU] = sw.back();
+            u[EPS_SGL] = G[0]; u[EPS_SGU] = G[4 * (ng - 1)];
+            u[EPS_SWCR] = sw.front();
+            for (int i = 0; i < nw && W[4 * i + 1] <= 0.0; ++i) u[EPS_SWCR] = sw[i];
+            u[EPS_SGCR] = G[0];
+            for (int i = 0; i < ng && G[4 * i + 1] <= 0.0; ++i) u[EPS_SGCR] = G[4 * i];
+            double swOilGone = sw.back();
+            for (int i = nw - 1; i >= 0 && W[4 * i + 2] <= 0.0; --i) swOilGone = sw[i];
+            u[EPS_SOWCR] = 1.0 - swOilGone - u[EPS_SGL];
+            double sgOilGone = G[4 * (ng - 1)];
+            for (int i = ng - 1; i >= 0 && G[4 * i + 2] <= 0.0; --i) sgOilGone = G[4 * i];
+            u[EPS_SOGCR] = 1.0 - sgOilGone - u[EPS_SWL];
+            u[EPS_MAXPCOW] = pcow.front(); u[EPS_MAXPCGO] = pcgo.front();   // pcgo is stored reversed: front = the last SGOF row
+            u[EPS_MAXKRW] = krw.back(); u[EPS_MAXKROW] = krow.front(); u[EPS_MAXKRG] = krg.front(); u[EPS_MAXKROG] = krog.back();
+            auto lin = [](const std::vector<double>& x, const std::vector<double>& y, double s) {   // PiecewiseLinearTwoPhaseMaterial
+                if (s <= x.front()) return y.front();
+                if (s >= x.back()) return y.back();
+                size_t lo = 0, hi = x.size() - 1;
+                while (lo + 1 < hi) { const size_t mid = (lo + hi) / 2; if (x[mid] < s) lo = mid; else hi = mid; }
+                const double m = (y[lo + 1] - y[lo]) / (x[lo + 1] - x[lo]);
+                return y[lo] + (s - x[lo]) * m;
+            };
+            u[EPS_KRWR] = lin(sw, krw, 1.0 - u[EPS_SOWCR] - u[EPS_SGL]);
+            u[EPS_KRORW] = lin(sw, krow, u[EPS_SWCR] + u[EPS_SGL]);
+            u[EPS_KRORG] = lin(so, krog, 1.0 - u[EPS_SGCR] - u[EPS_SWL]);
+            u[EPS_KRGR] = lin(so, krg, u[EPS_SOGCR]);
+            D.eps = push(B, u);
+        }
     }
     std::vector<RockTabDesc> rd(f->num_rock);
     for (int t = 0; t < f->num_rock; ++t) {
@@ -268,6 +303,12 @@ std::string build_fluid_tables(const opmhip_fluid* f, FluidTables& T) {
         I.insert(I.end(), q, q + (int)(sizeof(RockTabDesc) / sizeof(int)));
     }
     return "";
+}
+
+void sat_end_points(const FluidTables& T, int s, double* out) {
+    const int pdInts = (int)(sizeof(PvtRegionDesc) / sizeof(int));
+    const SatRegionDesc* sd = reinterpret_cast<const SatRegionDesc*>(T.idx.data() + 2 + T.idx[0] * pdInts);
+    for (int f = 0; f < EPS_COUNT; ++f) out[f] = T.dbl[sd[s].eps + f];
 }
 
 }  // namespace opmhip

@@ -31,7 +31,16 @@ struct SatRegionDesc {
     int nw, sw_x, krw, krow, pcow;  // piecewise linear in Sw, x ascending
     int ng, so_x, krog, krg, pcgo;  // piecewise linear in So' = (1 - Swco) - Sg, x ascending
     int swco;                       // 1 double
+    int eps;                        // EPS_COUNT doubles: the tables' own end points (saturation end-point scaling)
 };
+// end points of a saturation region's tables / of a cell (opm-material EclEpsScalingPointsInfo, absent from the reference
+// tree - restated, see oracle/fluid.hpp): connate, critical and maximum saturations, maximum capillary pressures, maximum
+// relative permeabilities and their values at the critical saturation of the displacing phase
+enum EpsField { EPS_SWL = 0, EPS_SWCR, EPS_SWU, EPS_SOWCR, EPS_SGL, EPS_SGCR, EPS_SGU, EPS_SOGCR,
+                EPS_MAXPCOW, EPS_MAXPCGO, EPS_MAXKRW, EPS_MAXKROW, EPS_MAXKRG, EPS_MAXKROG,
+                EPS_KRWR, EPS_KRORW, EPS_KRGR, EPS_KRORG, EPS_COUNT };
+// the end points of saturation region s of a table set built by build_fluid_tables (host copy of the blob)
+void sat_end_points(const struct FluidTables& T, int s, double* out);
 
 struct FluidTables {
     std::vector<double> dbl;

@@ -104,6 +104,9 @@ struct AsmDev {
     int* d_rocknum = nullptr;                             // per cell rock-table index (optional)
     bool pc_scaling = false;                              // the fluid allows a per-cell end point of pcow (PCW / SWATINIT)
     double* d_pcw = nullptr;                              // per cell: scaled maximum of the oil-water capillary pressure (optional)
+    double* d_eps = nullptr;                              // per cell scaled saturation end points, field-major [EPS_COUNT][Nloc] (optional)
+    int epscfg = 0;                                       // packed EclEpsConfig (assemble.hip CellStatic::epscfg)
+    std::vector<double> sat_eps;                          // host copy: the tables' own end points, EPS_COUNT per saturation region
     double* d_invb = nullptr;                             // packed 1/b per cell and phase (Nloc x 3), for the convergence check
     double *d_trans = nullptr, *d_area = nullptr, *d_thpres = nullptr;                      // per entry
     double *d_poro = nullptr, *d_volume = nullptr, *d_depth = nullptr, *d_rsmax = nullptr;  // per cell

@@ -59,6 +59,10 @@ struct Problem {
     // the SWOF pcow column's first entry.  Pinned by the reference's own numbers for equil_capillary_swatinit.DATA
     // (tests/test_equil.cc:1076-1091) through tests/test_equil.py::test_swatinit_deck.
     std::vector<double> pcw;
+    // saturation end-point scaling (ENDSCALE family): per cell the scaled end points (EPS_COUNT doubles, oracle/fluid.hpp) handed
+    // to EclEpsTwoPhaseLaw by the material-law manager (ebos/eclproblem.hh:1490-1498); empty = none.  UNVERIFIED (opm-material absent).
+    std::vector<EpsPoints> eps;
+    EpsConfig epsCfg;
     Fluid fluid;
     void finish() {
         const int Nb = pat.Nb;
@@ -100,8 +104,10 @@ void update_iq(const Problem& P, int cell, const double* pv, uint8_t meaning, IQ
     const E So = 1.0 - Sw - Sg;
     q.S[WATER] = Sw; q.S[GAS] = Sg; q.S[OIL] = So;
     E pC[3];
-    F.sat[sr].capillaryPressures(pC, Sw, Sg);
-    if (!P.pcw.empty()) {
+    const bool scaled = !P.eps.empty();
+    if (scaled) F.sat[sr].capillaryPressuresEps(pC, Sw, Sg, P.eps[cell], P.epsCfg);
+    else F.sat[sr].capillaryPressures(pC, Sw, Sg);
+    if (!scaled && !P.pcw.empty()) {
         const double scaledMax = P.pcw[cell], tableMax = F.sat[sr].pcow.y.front();
         const double alpha = (scaledMax == tableMax) ? 1.0 : scaledMax / tableMax;
         pC[0] = pC[0] * alpha;
@@ -113,7 +119,8 @@ void update_iq(const Problem& P, int cell, const double* pv, uint8_t meaning, IQ
         const E po = mkvar<E>(pv[PV_P], PV_P);
         for (int ph = 0; ph < 3; ++ph) q.p[ph] = po + (pC[ph] - pC[OIL]);
     }
-    F.sat[sr].relativePermeabilities(q.mob, Sw, Sg);
+    if (scaled) F.sat[sr].relativePermeabilitiesEps(q.mob, Sw, Sg, P.eps[cell], P.epsCfg);
+    else F.sat[sr].relativePermeabilities(q.mob, Sw, Sg);
     // SoMax = max(So, problem.maxOilSaturation) ; the latter is 0 without VAPPARS (eclproblem.hh:1682-1688), and without
     // VAPPARS the saturated Rs / Rv do not depend on it
     if (meaning == Sw_po_Sg) {
@@ -459,7 +466,8 @@ struct Model {
             if (So < -eps && Sg > 0.0 && F.hasWetGas) {   // the oil phase disappears: { Sw, pg, Rv }
                 const double po = x[PV_P];
                 double pC[3];
-                F.sat[sr].capillaryPressures(pC, Sw, Sg);   // computeCapillaryPressures_(pC, So = 0, Sg, Sw)
+                if (!P.eps.empty()) F.sat[sr].capillaryPressuresEps(pC, Sw, Sg, P.eps[c], P.epsCfg);
+                else F.sat[sr].capillaryPressures(pC, Sw, Sg);   // computeCapillaryPressures_(pC, So = 0, Sg, Sw)
                 const double pg = po + (pC[GAS] - pC[OIL]);
                 const double RvSat = F.wetGas[pr].rvSat(pg);
                 meaning[c] = Sw_pg_Rv;
@@ -483,7 +491,8 @@ struct Model {
         if (Rv > std::min(RvMax, RvSat * (1.0 + eps))) {
             meaning[c] = Sw_po_Sg;
             double pC[3];
-            F.sat[sr].capillaryPressures(pC, Sw, 1.0 - Sw);
+            if (!P.eps.empty()) F.sat[sr].capillaryPressuresEps(pC, Sw, 1.0 - Sw, P.eps[c], P.epsCfg);
+            else F.sat[sr].capillaryPressures(pC, Sw, 1.0 - Sw);
             const double po = pg + (pC[OIL] - pC[GAS]);
             x[PV_P] = po;
             x[PV_X] = 1.0 - Sw;   // hydrocarbon gas saturation

@@ -309,11 +309,67 @@ struct PwLin {
     }
 };
 
-// ---- EclDefaultMaterial over SWOF / SGOF (no end-point scaling, no hysteresis) --------------------------------
+// ---- saturation end-point scaling (ENDSCALE family) --------------------------------------------------------------
+// opm-material's EclEpsScalingPoints / EclEpsTwoPhaseLaw / EclEpsConfig and opm-common's satfunc end-point extraction are
+// NOT in the reference tree: UNVERIFIED against upstream, restated from their published form (2021.10).  The reference's
+// call site is ebos/eclproblem.hh:1490-1498 (materialLawParams(elemIdx) of the EclMaterialLawManager).  Pinned: the
+// capillary-pressure part by tests/test_equil.cc:1076-1091 (pc_scaled_truth of DeckWithSwatinit, tests/test_equil.py).
+// One record per saturation region (unscaled, from its SWOF / SGOF tables) and per cell (scaled):
+enum EpsField { EPS_SWL = 0, EPS_SWCR, EPS_SWU, EPS_SOWCR, EPS_SGL, EPS_SGCR, EPS_SGU, EPS_SOGCR,
+                EPS_MAXPCOW, EPS_MAXPCGO, EPS_MAXKRW, EPS_MAXKROW, EPS_MAXKRG, EPS_MAXKROG,
+                EPS_KRWR, EPS_KRORW, EPS_KRGR, EPS_KRORG, EPS_COUNT };
+struct EpsPoints { double v[EPS_COUNT]; };
+// EclEpsConfig of both two-phase systems: satScaling = ENDSCALE (two-point saturation scaling of kr and pc), threePointKr =
+// SCALECRS (three-point saturation scaling of the relative permeabilities); krw / kro / krg: 0 = the curve's values are not
+// scaled, 1 = at its maximum (KRW / KRO / KRG), 2 = three-point vertical scaling (also at the critical saturation of the
+// displacing phase: KRWR / KRORW and KRORG / KRGR); pcw / pcg: the capillary pressures are scaled to PCW / PCG
+struct EpsConfig { bool satScaling = false, threePointKr = false; int krw = 0, kro = 0, krg = 0; bool pcw = false, pcg = false; };
+// the three scaling points of one curve: [0] .. [2]
+struct EpsTriple { double s[3]; };
+inline EpsTriple eps_pc_ow(const EpsPoints& e) { return {{e.v[EPS_SWL], e.v[EPS_SWU], e.v[EPS_SWU]}}; }
+inline EpsTriple eps_krw_ow(const EpsPoints& e) { return {{e.v[EPS_SWCR], 1.0 - e.v[EPS_SOWCR] - e.v[EPS_SGL], e.v[EPS_SWU]}}; }
+inline EpsTriple eps_krn_ow(const EpsPoints& e) { return {{e.v[EPS_SWL] + e.v[EPS_SGL], e.v[EPS_SWCR] + e.v[EPS_SGL], 1.0 - e.v[EPS_SOWCR]}}; }
+inline EpsTriple eps_pc_go(const EpsPoints& e) { return {{1.0 - e.v[EPS_SWL] - e.v[EPS_SGU], 1.0 - e.v[EPS_SWL] - e.v[EPS_SGL], 1.0 - e.v[EPS_SWL] - e.v[EPS_SGL]}}; }
+inline EpsTriple eps_krw_go(const EpsPoints& e) { return {{e.v[EPS_SOGCR], 1.0 - e.v[EPS_SGCR] - e.v[EPS_SWL], 1.0 - e.v[EPS_SWL] - e.v[EPS_SGL]}}; }
+inline EpsTriple eps_krn_go(const EpsPoints& e) { return {{1.0 - e.v[EPS_SWL] - e.v[EPS_SGU], e.v[EPS_SOGCR], 1.0 - e.v[EPS_SWL] - e.v[EPS_SGCR]}}; }
+// EclEpsTwoPhaseLaw::scaledToUnscaledSatTwoPoint_ / ThreePoint_
+template <class E> inline E eps_sat_two_point(const E& S, const EpsTriple& u, const EpsTriple& sc) {
+    return u.s[0] + (S - sc.s[0]) * ((u.s[2] - u.s[0]) / (sc.s[2] - sc.s[0]));
+}
+template <class E> inline E eps_sat_three_point(const E& S, const EpsTriple& u, const EpsTriple& sc) {
+    if (value(S) <= sc.s[0]) return E(u.s[0]);
+    if (value(S) <= sc.s[1]) return u.s[0] + (S - sc.s[0]) * ((u.s[1] - u.s[0]) / (sc.s[1] - sc.s[0]));
+    if (u.s[1] == u.s[2]) return E(u.s[1]);   // no unscaled points between the two
+    if (value(S) <= sc.s[2]) return u.s[1] + (S - sc.s[1]) * ((u.s[2] - u.s[1]) / (sc.s[2] - sc.s[1]));
+    return E(u.s[2]);
+}
+// vertical scaling of a wetting-phase curve (unscaledToScaledKrw_): mode 1 = at the maximum, 2 = three-point
+template <class E> inline E eps_vertical_krw(int mode, const E& S, const E& kr, const EpsTriple& sc, double fdisp, double fmax, double fr, double fm) {
+    if (mode == 0) return kr;
+    if (mode == 1) return kr * (fm / fmax);
+    const double sm = sc.s[2], sr = std::min(sc.s[1], sm);
+    if (!(value(S) > sr)) return kr * (fr / fdisp);
+    if (fmax > fdisp) { const E t = (kr - fdisp) / (fmax - fdisp); return fr + t * (fm - fr); }
+    if (sr < sm) { const E t = (S - sr) / (sm - sr); return fr + t * (fm - fr); }
+    return E(fm);
+}
+// ... of a non-wetting-phase curve, which falls with the wetting saturation (unscaledToScaledKrn_)
+template <class E> inline E eps_vertical_krn(int mode, const E& S, const E& kr, const EpsTriple& sc, double fdisp, double fmax, double fr, double fm) {
+    if (mode == 0) return kr;
+    if (mode == 1) return kr * (fm / fmax);
+    const double sl = sc.s[0], sr = std::max(sc.s[1], sl);
+    if (!(value(S) < sr)) return kr * (fr / fdisp);
+    if (fmax > fdisp) { const E t = (kr - fdisp) / (fmax - fdisp); return fr + t * (fm - fr); }
+    if (sr > sl) { const E t = (sr - S) / (sr - sl); return fr + t * (fm - fr); }
+    return E(fm);
+}
+
+// ---- EclDefaultMaterial over SWOF / SGOF (optionally with end-point scaling; no hysteresis) ---------------------
 struct SatFunc {
     double Swco = 0.0;
     PwLin krw, krow, pcow;    // in Sw
     PwLin krog, krg, pcgo;    // in So' = (1 - Swco) - Sg
+    EpsPoints unscaled;       // the tables' own end points
     void init(const std::vector<double>& swof, const std::vector<double>& sgof) {
         const int nw = (int)swof.size() / 4, ng = (int)sgof.size() / 4;
         std::vector<double> sw, a, b, c;
@@ -323,6 +379,79 @@ struct SatFunc {
         std::vector<double> so, g, og, pg;
         for (int i = 0; i < ng; ++i) { so.push_back((1.0 - Swco) - sgof[4 * i]); g.push_back(sgof[4 * i + 1]); og.push_back(sgof[4 * i + 2]); pg.push_back(sgof[4 * i + 3]); }
         krog.set(so, og); krg.set(so, g); pcgo.set(so, pg);
+        // the tables' end points (opm-common satfunc: connate = first row, maximum = last row, critical = the last saturation
+        // at which the phase's relative permeability is still zero)
+        double* u = unscaled.v;
+        u[EPS_SWL] = sw.front(); u[EPS_SWU] = sw.back();
+        u[EPS_SGL] = sgof[0]; u[EPS_SGU] = sgof[4 * (ng - 1)];
+        u[EPS_SWCR] = sw.front();
+        for (int i = 0; i < nw && a[i] <= 0.0; ++i) u[EPS_SWCR] = sw[i];
+        u[EPS_SGCR] = sgof[0];
+        for (int i = 0; i < ng && g[i] <= 0.0; ++i) u[EPS_SGCR] = sgof[4 * i];
+        double swOilGone = sw.back();   // the smallest Sw at which krow has vanished
+        for (int i = nw - 1; i >= 0 && b[i] <= 0.0; --i) swOilGone = sw[i];
+        u[EPS_SOWCR] = 1.0 - swOilGone - u[EPS_SGL];
+        double sgOilGone = sgof[4 * (ng - 1)];   // the smallest Sg at which krog has vanished
+        for (int i = ng - 1; i >= 0 && og[i] <= 0.0; --i) sgOilGone = sgof[4 * i];
+        u[EPS_SOGCR] = 1.0 - sgOilGone - u[EPS_SWL];
+        u[EPS_MAXPCOW] = c.front(); u[EPS_MAXPCGO] = pg.back();
+        u[EPS_MAXKRW] = a.back(); u[EPS_MAXKROW] = b.front(); u[EPS_MAXKRG] = g.back(); u[EPS_MAXKROG] = og.front();
+        // values at the critical saturation of the displacing phase = at the middle scaling point of each curve
+        u[EPS_KRWR] = krw.eval(eps_krw_ow(unscaled).s[1]);
+        u[EPS_KRORW] = krow.eval(eps_krn_ow(unscaled).s[1]);
+        u[EPS_KRORG] = krog.eval(eps_krw_go(unscaled).s[1]);
+        u[EPS_KRGR] = krg.eval(eps_krn_go(unscaled).s[1]);
+    }
+    // EclEpsTwoPhaseLaw over EclDefaultMaterial with the scaled end points sc of one cell: capillary pressures ...
+    template <class E> void capillaryPressuresEps(E pC[3], const E& Sw, const E& Sg, const EpsPoints& sc, const EpsConfig& cfg) const {
+        const double SwcoS = sc.v[EPS_SWL];
+        const E SoP = 1.0 - SwcoS - Sg;   // the gas-oil system's wetting (oil) saturation
+        E swU = Sw, soU = SoP;
+        if (cfg.satScaling) {
+            swU = eps_sat_two_point(Sw, eps_pc_ow(unscaled), eps_pc_ow(sc));
+            soU = eps_sat_two_point(SoP, eps_pc_go(unscaled), eps_pc_go(sc));
+        } else soU = 1.0 - Swco - Sg;
+        E pcw = pcow.eval(swU), pcg = pcgo.eval(soU);
+        if (cfg.pcw) {
+            const double sm = sc.v[EPS_MAXPCOW], um = unscaled.v[EPS_MAXPCOW];
+            pcw = pcw * ((sm == um) ? 1.0 : sm / um);
+        }
+        if (cfg.pcg) {
+            const double sm = sc.v[EPS_MAXPCGO], um = unscaled.v[EPS_MAXPCGO];
+            pcg = pcg * ((sm == um) ? 1.0 : sm / um);
+        }
+        pC[0] = -pcw;
+        pC[1] = E(0.0);
+        pC[2] = pcg;
+    }
+    // ... and relative permeabilities (EclDefaultMaterial's oil interpolation with the CELL's connate water saturation)
+    template <class E> void relativePermeabilitiesEps(E kr[3], const E& SwIn, const E& Sg, const EpsPoints& sc, const EpsConfig& cfg) const {
+        const double* u = unscaled.v;
+        const double* s = sc.v;
+        const double SwcoS = cfg.satScaling ? s[EPS_SWL] : Swco;
+        auto to_unscaled = [&](const E& S, const EpsTriple& ut, const EpsTriple& st) {
+            if (!cfg.satScaling) return S;
+            return cfg.threePointKr ? eps_sat_three_point(S, ut, st) : eps_sat_two_point(S, ut, st);
+        };
+        const EpsTriple uKrwOw = eps_krw_ow(unscaled), sKrwOw = eps_krw_ow(sc), uKrnOw = eps_krn_ow(unscaled), sKrnOw = eps_krn_ow(sc);
+        const EpsTriple uKrwGo = eps_krw_go(unscaled), sKrwGo = eps_krw_go(sc), uKrnGo = eps_krn_go(unscaled), sKrnGo = eps_krn_go(sc);
+        kr[0] = eps_vertical_krw(cfg.krw, SwIn, krw.eval(to_unscaled(SwIn, uKrwOw, sKrwOw)), sKrwOw, u[EPS_KRWR], u[EPS_MAXKRW], s[EPS_KRWR], s[EPS_MAXKRW]);
+        const E SoP = 1.0 - SwcoS - Sg;
+        kr[2] = eps_vertical_krn(cfg.krg, SoP, krg.eval(to_unscaled(SoP, uKrnGo, sKrnGo)), sKrnGo, u[EPS_KRGR], u[EPS_MAXKRG], s[EPS_KRGR], s[EPS_MAXKRG]);
+        const E Sw = max(E(SwcoS), SwIn);
+        const E Sw_ow = Sg + Sw;
+        const E So_go = 1.0 - Sw_ow;
+        const E kro_ow = eps_vertical_krn(cfg.kro, Sw_ow, krow.eval(to_unscaled(Sw_ow, uKrnOw, sKrnOw)), sKrnOw, u[EPS_KRORW], u[EPS_MAXKROW], s[EPS_KRORW], s[EPS_MAXKROW]);
+        const E kro_go = eps_vertical_krw(cfg.kro, So_go, krog.eval(to_unscaled(So_go, uKrwGo, sKrwGo)), sKrwGo, u[EPS_KRORG], u[EPS_MAXKROG], s[EPS_KRORG], s[EPS_MAXKROG]);
+        const double eps = 1e-5;
+        if (value(Sw_ow) - SwcoS < eps) {
+            const E kro2 = (kro_ow + kro_go) / 2.0;
+            if (value(Sw_ow) - SwcoS > eps / 2.0) {
+                const E kro1 = (Sg * kro_go + (Sw - SwcoS) * kro_ow) / (Sw_ow - SwcoS);
+                const E alpha = (eps - (Sw_ow - SwcoS)) / (eps / 2.0);
+                kr[1] = kro2 * alpha + kro1 * (1.0 - alpha);
+            } else kr[1] = kro2;
+        } else kr[1] = (Sg * kro_go + (Sw - SwcoS) * kro_ow) / (Sw_ow - SwcoS);
     }
     // pC[water] = -pcow(Sw), pC[oil] = 0, pC[gas] = +pcgo
     template <class E> void capillaryPressures(E pC[3], const E& Sw, const E& Sg) const {

@@ -516,6 +516,49 @@ int orc_bo_set_extras(orc_model* h, const double* rvMax, const int* rockNum, con
     return 0;
 }
 // per-cell scaled maximum of the oil-water capillary pressure (PCW / SWATINIT); NULL = the tables' own
+// saturation end-point scaling: cfg[7] = sat_scaling, three_point_kr, krw, kro, krg, pcw, pcg; eps: Nb x EPS_COUNT scaled end
+// points (cell-major) or NULL = off
+int orc_bo_set_endpoint_scaling(orc_model* h, const int* cfg, const double* eps) {
+    Model& M = h->M;
+    const int Nb = M.P.pat.Nb;
+    M.P.eps.clear();
+    if (eps) {
+        M.P.eps.resize(Nb);
+        for (int i = 0; i < Nb; ++i)
+            for (int f = 0; f < EPS_COUNT; ++f) M.P.eps[i].v[f] = eps[(size_t)i * EPS_COUNT + f];
+        EpsConfig& C = M.P.epsCfg;
+        C.satScaling = cfg[0] != 0; C.threePointKr = cfg[1] != 0; C.krw = cfg[2]; C.kro = cfg[3]; C.krg = cfg[4]; C.pcw = cfg[5] != 0; C.pcg = cfg[6] != 0;
+    }
+    M.update_all_iq();
+    return 0;
+}
+// the end points of a saturation region's own tables: out[EPS_COUNT]
+int orc_sat_end_points(const orc_fluid_desc* fluid, int sat_region, double* out) {
+    Fluid F;
+    F.init(to_input(fluid));
+    if (sat_region < 0 || sat_region >= (int)F.sat.size()) return -1;
+    for (int f = 0; f < EPS_COUNT; ++f) out[f] = F.sat[sat_region].unscaled.v[f];
+    return 0;
+}
+// point evaluation of the scaled saturation functions: out[6 i ..] = krw, kro, krg, pcow, pcgo, 0 at (sw, sg) of point i with
+// the scaled end points eps[EPS_COUNT] (tests of the scaling's properties)
+int orc_sat_probe_eps(const orc_fluid_desc* fluid, int sat_region, const int* cfg, const double* eps, int n, const double* sw, const double* sg, double* out) {
+    Fluid F;
+    F.init(to_input(fluid));
+    if (sat_region < 0 || sat_region >= (int)F.sat.size()) return -1;
+    EpsPoints P;
+    for (int f = 0; f < EPS_COUNT; ++f) P.v[f] = eps[f];
+    EpsConfig C;
+    C.satScaling = cfg[0] != 0; C.threePointKr = cfg[1] != 0; C.krw = cfg[2]; C.kro = cfg[3]; C.krg = cfg[4]; C.pcw = cfg[5] != 0; C.pcg = cfg[6] != 0;
+    for (int i = 0; i < n; ++i) {
+        double kr[3], pc[3];
+        F.sat[sat_region].relativePermeabilitiesEps(kr, sw[i], sg[i], P, C);
+        F.sat[sat_region].capillaryPressuresEps(pc, sw[i], sg[i], P, C);
+        out[6 * i] = kr[0]; out[6 * i + 1] = kr[1]; out[6 * i + 2] = kr[2]; out[6 * i + 3] = -pc[0]; out[6 * i + 4] = pc[2]; out[6 * i + 5] = 0.0;
+    }
+    return 0;
+}
+
 int orc_bo_set_pcw(orc_model* h, const double* pcw) {
     Model& M = h->M;
     const int Nb = M.P.pat.Nb;

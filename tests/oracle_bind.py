@@ -159,6 +159,7 @@ class OracleModel:
         L.orc_bo_get_iq_ext.argtypes = [_vp, _d]
         L.orc_bo_set_extras.argtypes = [_vp, _vp, _vp, _vp]
         L.orc_bo_set_pcw.argtypes = [_vp, _vp]
+        L.orc_bo_set_endpoint_scaling.argtypes = [_vp, _vp, _vp]
         L.orc_bo_end_time_step.argtypes = [_vp, C.c_double]
         L.orc_bo_set_drift_compensation.argtypes = [_vp, C.c_int, C.c_double]
         L.orc_bo_get_drift.argtypes = [_vp, _d]
@@ -174,6 +175,24 @@ class OracleModel:
             self.set_problem_extras(case.get("rvmax"), case.get("rocknum"), case.get("overburden"))
         if case.get("pcw") is not None:
             self.set_pcw(case["pcw"])
+        if case.get("endscale") is not None:
+            self.set_endpoint_scaling(case["endscale"])
+
+    def set_endpoint_scaling(self, es):
+        """es: the dict capi.HipModel.set_endpoint_scaling takes (absent arrays = the tables' own end points); None = off"""
+        if es is None:
+            self.o.lib.orc_bo_set_endpoint_scaling(self.h, None, None)
+            return
+        pkg = __import__("importlib").import_module("opm-autodiff_amd")
+        cfg = np.array([int(es.get(k, 0)) for k in ("sat_scaling", "three_point_kr", "krw", "kro", "krg", "pcw", "pcg")], np.int32)
+        satnum = self.case.get("satnum")
+        satnum = np.zeros(self.Nb, np.int64) if satnum is None else np.asarray(satnum, np.int64)
+        tab = np.array([sat_end_points(self.o, self.case["fluid"], s) for s in range(len(self.case["fluid"].sat))])
+        eps = np.empty((self.Nb, 18))
+        for f, name in enumerate(pkg.capi.EPS_FIELDS):
+            eps[:, f] = tab[satnum, f] if es.get(name) is None else np.asarray(es[name], np.float64)[:self.Nb]
+        self._eps = np.ascontiguousarray(eps)
+        self.o.lib.orc_bo_set_endpoint_scaling(self.h, _p(cfg), _p(self._eps))
 
     def set_pcw(self, pcw):
         a = None if pcw is None else np.ascontiguousarray(pcw, np.float64)
@@ -273,6 +292,26 @@ def _solve_mt(self, tol=1e-2, maxit=200, w=0.9, mode="post_scale", threads=1):
 
 
 OracleModel.solve_mt = _solve_mt
+
+
+def sat_end_points(oracle, fluid, sat_region=0):
+    """the end points of a saturation region's tables as the oracle extracts them: array[18] in capi.EPS_FIELDS order"""
+    out = np.empty(18)
+    fd = fluid.desc()
+    oracle.lib.orc_sat_end_points.argtypes = [_vp, C.c_int, _d]
+    assert oracle.lib.orc_sat_end_points(C.addressof(fd), sat_region, out) == 0
+    return out
+
+
+def sat_probe_eps(oracle, fluid, es, eps18, sw, sg, sat_region=0):
+    """(n, 5): krw, kro, krg, pcow, pcgo of the scaled saturation functions at (sw, sg) for one set of scaled end points"""
+    cfg = np.array([int(es.get(k, 0)) for k in ("sat_scaling", "three_point_kr", "krw", "kro", "krg", "pcw", "pcg")], np.int32)
+    sw, sg = np.ascontiguousarray(sw, np.float64), np.ascontiguousarray(sg, np.float64)
+    out = np.empty(6 * len(sw))
+    fd = fluid.desc()
+    oracle.lib.orc_sat_probe_eps.argtypes = [_vp, C.c_int, _vp, _d, C.c_int, _d, _d, _d]
+    assert oracle.lib.orc_sat_probe_eps(C.addressof(fd), sat_region, _p(cfg), np.ascontiguousarray(eps18, np.float64), len(sw), sw, sg, out) == 0
+    return out.reshape(-1, 6)[:, :5]
 
 
 class OracleAsHipModel:
