@@ -21,7 +21,8 @@ extern "C" {
 #endif
 
 #define OPMHIP_ABI_VERSION 4 /* 4: opmhip_config names chain_length, spmv_pipe_wgs, preconditioner (were reserved[0..2]);
-                               *    opmhip_set_endpoint_scaling, opmhip_sat_end_points, opmhip_synchronize, opmhip_comm_info;
+                               *    opmhip_set_endpoint_scaling, opmhip_sat_end_points, opmhip_synchronize, opmhip_comm_info,
+                               *    opmhip_set_composition_change_limits, opmhip_set_irreversible_compaction, opmhip_begin_time_step;
                                * 3: opmhip_fluid gained pc_scaling, opmhip_set_pcw */
 
 typedef struct opmhip_ctx opmhip_ctx;
@@ -271,6 +272,36 @@ int opmhip_set_static(opmhip_ctx* ctx, const double* trans, const double* area, 
  * only meaningful for a fluid with PVTG or ROCKTAB tables (else INVALID_ARGUMENT).  Needs set_static; recomputes the cached
  * intensive quantities if a state is set. */
 int opmhip_set_problem_extras(opmhip_ctx* ctx, const double* rvmax, const int* rocknum, const double* overburden);
+
+/* replaces: the DRSDT / DRVDT bookkeeping of EclProblem - maxDRs_ / maxDRv_ = rate x time-step size (ebos/eclgenericproblem.cc,
+ * beginTimeStep_), lastRs_ / lastRv_ (updateCompositionChangeLimits_, ebos/eclproblem.hh:2010-2107, called when the initial
+ * solution is applied, :1811, and from endTimeStep, :1125) and maxGasDissolutionFactor / maxOilVaporizationFactor
+ * (:1711-1754).  drsdt / drvdt: per PVT region, in 1/s (Sm3/Sm3 per second); negative = no limit in that region; NULL = the
+ * keyword is not in force.  drsdt_all_cells (per region, nullable = 0): the OILVAP option - non-zero: the limit binds every
+ * cell, zero: only cells with free gas (Sg > 1e-7).  The caps then live on the device: lastRs / lastRv are taken from the
+ * state now present (call it after opmhip_set_state, like initialSolutionApplied) and after every opmhip_end_time_step;
+ * opmhip_begin_time_step(dt) turns them into this step's caps, replacing the rsmax / rvmax arrays of opmhip_set_static /
+ * opmhip_set_problem_extras.  DRVDT needs a fluid with PVTG.  (The convective DRSDTCON variant is not built.) */
+int opmhip_set_composition_change_limits(opmhip_ctx* ctx, const double* drsdt, const int* drsdt_all_cells, const double* drvdt);
+
+/* replaces: ROCKCOMP's hysteresis mode IRREVERS - minOilPressure_ (ebos/eclgenericproblem.cc:155-170; initialised from the
+ * initial state, ebos/eclproblem.hh:2293-2294; updateMinPressure_, :2172-2197; used by rockCompPoroMultiplier /
+ * rockCompTransMultiplier, :1948-1952, 1988-1992): the rock tables are read at min(p_o, lowest p_o the cell has seen at the
+ * start of a time step).  enable != 0: start tracking from the state now present; 0: reversible compaction again.  Needs a
+ * fluid with ROCKTAB. */
+int opmhip_set_irreversible_compaction(opmhip_ctx* ctx, int enable);
+
+/* replaces: the per-cell work of EclProblem::beginTimeStep (ebos/eclproblem.hh:1042-1075) for a time step of size dt [s]:
+ * updateMinPressure_, the DRSDT / DRVDT caps of this step, invalidateAndUpdateIntensiveQuantities(0); and, since
+ * recycleFirstIterationStorage() is false with DRSDT / DRVDT (:1758-1765), the old time level's storage term formed with ITS
+ * caps (time index 1: lastRs / lastRv without the increment) - opmhip_assemble(iteration 0) then leaves it alone.  Call it
+ * after opmhip_advance_time_level, and again before every retry of a chopped step.  A no-op (SUCCESS) when neither feature
+ * is in force. */
+int opmhip_begin_time_step(opmhip_ctx* ctx, double dt);
+
+/* the trackers, for restart files and tests: lastRs, lastRv, minimum oil pressure per cell (natural order, Nb + Nghost
+ * entries each; any may be NULL; an array that is not kept comes back as zeros) */
+int opmhip_get_trackers(opmhip_ctx* ctx, double* last_rs, double* last_rv, double* min_oil_pressure);
 
 /* replaces: the per-cell scaled end point maxPcow of the oil-water capillary pressure - the PCW array of the deck, or
  * what SWATINIT made of it during equilibration (ebos/equil/initstateequil.hh:1330-1343 -> EclMaterialLawManager::

@@ -354,6 +354,10 @@ def _bind_assembly(L):
     L.opmhip_set_problem_extras.argtypes = [vp, vp, vp, vp]
     L.opmhip_set_pcw.argtypes = [vp, vp]
     L.opmhip_set_endpoint_scaling.argtypes = [vp, vp]
+    L.opmhip_set_composition_change_limits.argtypes = [vp, vp, vp, vp]
+    L.opmhip_set_irreversible_compaction.argtypes = [vp, C.c_int]
+    L.opmhip_begin_time_step.argtypes = [vp, C.c_double]
+    L.opmhip_get_trackers.argtypes = [vp, vp, vp, vp]
     L.opmhip_sat_end_points.argtypes = [vp, C.c_int, vp]
     L.opmhip_gas_probe.argtypes = [vp, C.c_int, C.c_int, vp, vp, vp]
     L.opmhip_iq_fields.argtypes = [vp]
@@ -496,6 +500,26 @@ class HipModel(HipSolver):
     def update_failed(self):
         """solution(0) = solution(1) + intensive quantities: the Newton method gave up on this time step."""
         self._check(lib().opmhip_update_failed(self._h))
+
+    def set_composition_change_limits(self, drsdt=None, drsdt_all_cells=None, drvdt=None):
+        """DRSDT / DRVDT: rates per PVT region [1/s] (negative: none), None = keyword not in force; drsdt_all_cells: the OILVAP
+        option per region.  After set_state (lastRs / lastRv start from the state now present)."""
+        a, b, d = _f64(drsdt), _i32(drsdt_all_cells), _f64(drvdt)
+        self._check(lib().opmhip_set_composition_change_limits(self._h, _ptr(a), _ptr(b), _ptr(d)))
+
+    def set_irreversible_compaction(self, enable=True):
+        """ROCKCOMP IRREVERS: rock tables read at the lowest oil pressure a cell has seen.  After set_state."""
+        self._check(lib().opmhip_set_irreversible_compaction(self._h, int(enable)))
+
+    def begin_time_step(self, dt):
+        """EclProblem::beginTimeStep, per-cell part: minimum pressure, DRSDT / DRVDT caps of a step of size dt"""
+        self._check(lib().opmhip_begin_time_step(self._h, dt))
+
+    def trackers(self):
+        """-> (lastRs, lastRv, minimum oil pressure) per cell, natural order; zeros where not kept"""
+        a, b, d = np.empty(self.Nloc), np.empty(self.Nloc), np.empty(self.Nloc)
+        self._check(lib().opmhip_get_trackers(self._h, _ptr(a), _ptr(b), _ptr(d)))
+        return a, b, d
 
     def end_time_step(self, dt):
         """EclProblem::endTimeStep (drift part): remember residual * dt of the time step that was just accepted."""

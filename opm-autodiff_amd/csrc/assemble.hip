@@ -218,6 +218,7 @@ struct CellStatic {
     const double *rvmax, *overburden;   // extended layout: DRVDT cap, overburden pressure (may be NULL)
     const int* rocknum;                 // rock-table index per cell (NULL = table 0)
     const double* pcw;                  // extended layout: scaled maximum of pcow per cell (PCW / SWATINIT; NULL = the tables' own)
+    const double* minpo;                // extended layout: minimum oil pressure so far (ROCKCOMP IRREVERS; NULL = reversible compaction)
     const double* eps;                  // extended layout: scaled end points per cell, field-major [EPS_COUNT][ncell] (NULL = no end-point scaling)
     int epscfg;                         // EclEpsConfig: bit 0 saturation scaling, 1 three-point, 2-3 krw, 4-5 kro, 6-7 krg mode, 8 pcw, 9 pcg
     double* invb;                       // packed 1/b_w, 1/b_o, 1/b_g per cell, written beside the record (convergence check)
@@ -458,6 +459,7 @@ __device__ __forceinline__ void update_iq(const TablesT<DP>& T, const CellStatic
         if (T.num_rock > 0) {
             const RockTabDesc& R = T.rock(C.rocknum ? C.rocknum[c] : 0);
             E effectiveOilPressure = q.p[OIL];
+            if (C.minpo) effectiveOilPressure = emin(q.p[OIL], cst<E>(C.minpo[c]));   // the pore space change is irreversible (eclproblem.hh:1948-1952)
             if (C.overburden) effectiveOilPressure = effectiveOilPressure - C.overburden[c];
             q.poro = q.poro * tab1<E, DP>(B + R.p, B + R.poroMult, R.n, effectiveOilPressure);
             q.tmult = tab1<E, DP>(B + R.p, B + R.transMult, R.n, effectiveOilPressure);
@@ -1123,6 +1125,57 @@ __global__ void k_drift_update(int n, const double* __restrict__ resid, double d
     const int e = blockIdx.x * blockDim.x + threadIdx.x;
     if (e < n) drift[e] = resid[e] * dt;
 }
+// ---- EclProblem's per-cell bookkeeping between time steps ---------------------------------------------------------------
+// updateCompositionChangeLimits_ (ebos/eclproblem.hh:2010-2107): lastRs = Rs where the DRSDT limit binds (all cells of the
+// region, or those with free gas: Sg > freeGasMinSaturation_ = 1e-7, :2073, 2877), else infinity; lastRv = Rv
+template <bool EXT>
+__global__ __launch_bounds__(256) void k_last_rs_rv(int N, const int* __restrict__ pvtnum, const int* __restrict__ drsdt_all, const double* __restrict__ iq,
+                                                    double* __restrict__ lastRs, double* __restrict__ lastRv) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= N) return;
+    if (lastRs) {
+        const int pr = pvtnum ? pvtnum[c] : 0;
+        const double Sg = iq_at(iq, N, F_S + GAS, c)[0];
+        lastRs[c] = (drsdt_all[pr] || Sg > 1e-7) ? iq_at(iq, N, F_RS, c)[0] : INFINITY;
+    }
+    if (EXT && lastRv) lastRv[c] = iq_at(iq, N, Lay<EXT>::F_RV, c)[0];
+}
+// maxGasDissolutionFactor / maxOilVaporizationFactor (:1711-1754) of time level 0 (dt > 0: lastRs + DRSDT * dt,
+// eclgenericproblem.cc: maxDRs_ = DRSDT * timeStepSize) or of time level 1 (dt = 0)
+__global__ __launch_bounds__(256) void k_set_limits(int N, double dt, const int* __restrict__ pvtnum, const double* __restrict__ drsdt, const double* __restrict__ drvdt,
+                                                    const double* __restrict__ lastRs, const double* __restrict__ lastRv, double* __restrict__ rsmax, double* __restrict__ rvmax) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= N) return;
+    const int pr = pvtnum ? pvtnum[c] : 0;
+    if (drsdt) rsmax[c] = (drsdt[pr] < 0.0) ? DBL_MAX / 2.0 : lastRs[c] + drsdt[pr] * dt;
+    if (drvdt) rvmax[c] = (drvdt[pr] < 0.0) ? DBL_MAX / 2.0 : lastRv[c] + drvdt[pr] * dt;
+}
+// updateMinPressure_ (:2172-2197); init: minOilPressure_ = min(1e99, p_o of the initial state) (eclgenericproblem.cc:165, :2293-2294)
+__global__ __launch_bounds__(256) void k_min_pressure(int N, int init, const double* __restrict__ iq, double* __restrict__ minpo) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= N) return;
+    const double po = iq_at(iq, N, F_P + OIL, c)[0];
+    const double old = init ? 1e99 : minpo[c];
+    minpo[c] = (po < old) ? po : old;
+}
+// the storage term of the cached intensive quantities, values only (computeStorage; the statements of k_assemble's diagonal
+// lane): the old time level's storage where the first iteration's cannot be recycled (:1758-1765)
+template <bool EXT>
+__global__ __launch_bounds__(256) void k_storage_old(int Nb, int N, int wet, const double* __restrict__ iq, double* __restrict__ storageOld) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= Nb) return;
+    const double poro = iq_at(iq, N, Lay<EXT>::F_PORO, c)[0], Rs = iq_at(iq, N, F_RS, c)[0];
+    double f[3] = {0.0, 0.0, 0.0};
+    const int comp[3] = {EQ_WATER, EQ_OIL, EQ_GAS};
+#pragma unroll
+    for (int ph = 0; ph < 3; ++ph) {
+        const double surfaceVolume = iq_at(iq, N, F_S + ph, c)[0] * iq_at(iq, N, F_B + ph, c)[0] * poro;
+        f[comp[ph]] = f[comp[ph]] + surfaceVolume;
+        if (ph == OIL) f[EQ_GAS] = f[EQ_GAS] + Rs * surfaceVolume;
+        if (EXT && ph == GAS && wet) f[EQ_OIL] = f[EQ_OIL] + iq_at(iq, N, Lay<EXT>::F_RV, c)[0] * surfaceVolume;
+    }
+    for (int e = 0; e < 3; ++e) storageOld[(size_t)c * 3 + e] = f[e];
+}
 void launch_drift_update(opmhip_ctx* c, double dt) {
     const int n = c->pat.Nb * 3;
     hipLaunchKernelGGL(k_drift_update, dim3((n + 255) / 256), dim3(256), 0, c->stream, n, c->d_b, dt, c->asmb.d_drift);
@@ -1157,7 +1210,7 @@ static Tables tables_of(const opmhip_ctx* c) {
 }
 static CellStatic cells_of(const opmhip_ctx* c) {
     return CellStatic{c->asmb.d_poro, c->asmb.d_volume, c->asmb.d_depth, c->asmb.d_rsmax, c->asmb.d_pvtnum, c->asmb.d_satnum,
-                      c->asmb.d_rvmax, c->asmb.d_overburden, c->asmb.d_rocknum, c->asmb.d_pcw, c->asmb.d_eps, c->asmb.epscfg, c->asmb.d_invb, c->pat.Nloc};
+                      c->asmb.d_rvmax, c->asmb.d_overburden, c->asmb.d_rocknum, c->asmb.d_pcw, c->asmb.d_minpo, c->asmb.d_eps, c->asmb.epscfg, c->asmb.d_invb, c->pat.Nloc};
 }
 // the context's record layout: extended when the fluid has PVTG or ROCKTAB tables
 #define OPMHIP_LAYOUT(c, call_base, call_ext) do { if ((c)->asmb.ext) { call_ext; } else { call_base; } } while (0)
@@ -1198,6 +1251,7 @@ void launch_assemble(opmhip_ctx* c, double dt, int iteration) {
     const int ps = prof_begin(c, PROF_ASSEMBLE);
     const double* drift = c->asmb.drift_enabled ? c->asmb.d_drift : (const double*)nullptr;
     const int grid = c->asmb.nsched;
+    if (iteration == 0 && c->asmb.storage_frozen) iteration = 1;   // the old time level's storage was formed by opmhip_begin_time_step
     OPMHIP_LAYOUT(c,
         hipLaunchKernelGGL(k_assemble<false>, dim3(grid), dim3(ASM_THREADS), 0, c->stream, c->asmb.nsched, reinterpret_cast<const int4*>(c->asmb.d_asm_sched), reinterpret_cast<const int2*>(c->asmb.d_asm_desc), 0, ES,
                            cells_of(c), c->asmb.d_iq, c->asmb.d_storageOld, c->asmb.d_source, c->asmb.d_dsource, drift, c->asmb.max_compensation, dt, iteration, c->d_A, c->d_b),
@@ -1205,6 +1259,29 @@ void launch_assemble(opmhip_ctx* c, double dt, int iteration) {
                            cells_of(c), c->asmb.d_iq, c->asmb.d_storageOld, c->asmb.d_source, c->asmb.d_dsource, drift, c->asmb.max_compensation, dt, iteration, c->d_A, c->d_b));
     prof_end(c, ps);
 }
+void launch_last_rs_rv(opmhip_ctx* c) {
+    const AsmDev& A = c->asmb;
+    const int N = c->pat.Nloc;
+    OPMHIP_LAYOUT(c, hipLaunchKernelGGL(k_last_rs_rv<false>, dim3((N + 255) / 256), dim3(256), 0, c->stream, N, A.d_pvtnum, A.d_drsdt_all, A.d_iq, A.drsdt_on ? A.d_lastRs : nullptr, (double*)nullptr),
+                  hipLaunchKernelGGL(k_last_rs_rv<true>, dim3((N + 255) / 256), dim3(256), 0, c->stream, N, A.d_pvtnum, A.d_drsdt_all, A.d_iq, A.drsdt_on ? A.d_lastRs : nullptr, A.drvdt_on ? A.d_lastRv : nullptr));
+}
+void launch_set_limits(opmhip_ctx* c, double dt) {
+    const AsmDev& A = c->asmb;
+    const int N = c->pat.Nloc;
+    hipLaunchKernelGGL(k_set_limits, dim3((N + 255) / 256), dim3(256), 0, c->stream, N, dt, A.d_pvtnum, A.drsdt_on ? A.d_drsdt : nullptr, A.drvdt_on ? A.d_drvdt : nullptr,
+                       A.d_lastRs, A.d_lastRv, A.d_rsmax, A.d_rvmax);
+}
+void launch_min_pressure(opmhip_ctx* c, bool init) {
+    const int N = c->pat.Nloc;
+    hipLaunchKernelGGL(k_min_pressure, dim3((N + 255) / 256), dim3(256), 0, c->stream, N, init ? 1 : 0, c->asmb.d_iq, c->asmb.d_minpo);
+}
+void launch_storage_old(opmhip_ctx* c) {
+    const AsmDev& A = c->asmb;
+    const int Nb = c->pat.Nb, N = c->pat.Nloc;
+    OPMHIP_LAYOUT(c, hipLaunchKernelGGL(k_storage_old<false>, dim3((Nb + 255) / 256), dim3(256), 0, c->stream, Nb, N, 0, A.d_iq, A.d_storageOld),
+                  hipLaunchKernelGGL(k_storage_old<true>, dim3((Nb + 255) / 256), dim3(256), 0, c->stream, Nb, N, A.wet_gas ? 1 : 0, A.d_iq, A.d_storageOld));
+}
+
 int launch_convergence(opmhip_ctx* c, double dt, double tol_cnv) {
     const int Nb = c->pat.Nb, nb = cdiv(Nb, 256);
     const int ps = prof_begin(c, PROF_CONVERGENCE);

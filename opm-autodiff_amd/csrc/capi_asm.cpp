@@ -468,14 +468,133 @@ int opmhip_update_failed(opmhip_ctx* c) {
     });
 }
 
+int opmhip_set_composition_change_limits(opmhip_ctx* c, const double* drsdt, const int* drsdt_all, const double* drvdt) {
+    if (!c) return OPMHIP_INVALID_ARGUMENT;
+    return guarded(c, [&]() -> int {
+        AsmDev& A = c->asmb;
+        if (!A.state_set) return fail(c, OPMHIP_NOT_READY, "set_composition_change_limits before set_state: lastRs / lastRv are taken from the initial solution");
+        if (drvdt && !A.wet_gas) return fail(c, OPMHIP_INVALID_ARGUMENT, "set_composition_change_limits: DRVDT needs a fluid with PVTG");
+        OPMHIP_HIP(c, hipSetDevice(c->device));
+        OPMHIP_HIP(c, hipStreamSynchronize(c->stream));
+        const size_t N = c->pat.Nloc;
+        int rc;
+        auto put = [&](double** dst, const double* src) -> int {
+            if (!*dst && (rc = dev_alloc(c, dst, (size_t)A.num_pvt))) return rc;
+            OPMHIP_HIP(c, hipMemcpy(*dst, src, (size_t)A.num_pvt * sizeof(double), hipMemcpyHostToDevice));
+            return OPMHIP_SUCCESS;
+        };
+        A.drsdt_on = drsdt != nullptr;
+        A.drvdt_on = drvdt != nullptr;
+        if (drsdt) {
+            if ((rc = put(&A.d_drsdt, drsdt))) return rc;
+            std::vector<int> all(A.num_pvt, 0);
+            if (drsdt_all) all.assign(drsdt_all, drsdt_all + A.num_pvt);
+            if (!A.d_drsdt_all && (rc = dev_alloc(c, &A.d_drsdt_all, (size_t)A.num_pvt))) return rc;
+            OPMHIP_HIP(c, hipMemcpy(A.d_drsdt_all, all.data(), all.size() * sizeof(int), hipMemcpyHostToDevice));
+            if (!A.d_lastRs && (rc = dev_alloc(c, &A.d_lastRs, N))) return rc;
+            if (!A.d_rsmax && (rc = dev_alloc(c, &A.d_rsmax, N))) return rc;
+        } else if (A.d_lastRs) {   // the keyword went out of force: no cap any more
+            dev_free(c, &A.d_lastRs);
+            dev_free(c, &A.d_rsmax);
+        }
+        if (drvdt) {
+            if ((rc = put(&A.d_drvdt, drvdt))) return rc;
+            if (!A.d_lastRv && (rc = dev_alloc(c, &A.d_lastRv, N))) return rc;
+            if (!A.d_rvmax && (rc = dev_alloc(c, &A.d_rvmax, N))) return rc;
+        } else if (A.d_lastRv) {
+            dev_free(c, &A.d_lastRv);
+            dev_free(c, &A.d_rvmax);
+        }
+        A.storage_frozen = false;
+        if (A.drsdt_on || A.drvdt_on) {
+            launch_last_rs_rv(c);            // updateCompositionChangeLimits_ on the initial solution (eclproblem.hh:1811)
+            launch_set_limits(c, 0.0);       // until the first begin_time_step: the caps of the state itself
+        }
+        launch_iq_update(c);
+        OPMHIP_HIP(c, hipGetLastError());
+        OPMHIP_HIP(c, hipStreamSynchronize(c->stream));
+        return OPMHIP_SUCCESS;
+    });
+}
+
+int opmhip_set_irreversible_compaction(opmhip_ctx* c, int enable) {
+    if (!c) return OPMHIP_INVALID_ARGUMENT;
+    return guarded(c, [&]() -> int {
+        AsmDev& A = c->asmb;
+        if (!A.state_set) return fail(c, OPMHIP_NOT_READY, "set_irreversible_compaction before set_state: the minimum pressure starts from the initial solution");
+        if (enable && A.num_rock <= 0) return fail(c, OPMHIP_INVALID_ARGUMENT, "set_irreversible_compaction: the fluid has no ROCKTAB tables");
+        OPMHIP_HIP(c, hipSetDevice(c->device));
+        OPMHIP_HIP(c, hipStreamSynchronize(c->stream));
+        if (!enable) dev_free(c, &A.d_minpo);
+        else {
+            int rc;
+            if (!A.d_minpo && (rc = dev_alloc(c, &A.d_minpo, (size_t)c->pat.Nloc))) return rc;
+            launch_min_pressure(c, true);
+        }
+        launch_iq_update(c);
+        OPMHIP_HIP(c, hipGetLastError());
+        OPMHIP_HIP(c, hipStreamSynchronize(c->stream));
+        return OPMHIP_SUCCESS;
+    });
+}
+
+int opmhip_begin_time_step(opmhip_ctx* c, double dt) {
+    if (!c) return OPMHIP_INVALID_ARGUMENT;
+    return guarded(c, [&]() -> int {
+        AsmDev& A = c->asmb;
+        if (!(dt > 0.0)) return fail(c, OPMHIP_INVALID_ARGUMENT, "begin_time_step: dt must be positive");
+        const bool limits = A.drsdt_on || A.drvdt_on;
+        if (!limits && !A.d_minpo) return OPMHIP_SUCCESS;
+        if (!A.state_set) return fail(c, OPMHIP_NOT_READY, "begin_time_step before set_state");
+        OPMHIP_HIP(c, hipSetDevice(c->device));
+        if (A.d_minpo) launch_min_pressure(c, false);     // updateMinPressure_: from the intensive quantities of the state as it is
+        A.storage_frozen = false;
+        if (limits) {
+            launch_set_limits(c, 0.0);                    // time index 1: lastRs / lastRv without the increment
+            launch_iq_update(c);
+            launch_storage_old(c);
+            A.storage_frozen = true;
+            launch_set_limits(c, dt);                     // time index 0: + DRSDT * dt
+        }
+        launch_iq_update(c);
+        OPMHIP_HIP(c, hipGetLastError());
+        return OPMHIP_SUCCESS;
+    });
+}
+
+int opmhip_get_trackers(opmhip_ctx* c, double* last_rs, double* last_rv, double* min_po) {
+    if (!c) return OPMHIP_INVALID_ARGUMENT;
+    return guarded(c, [&]() -> int {
+        AsmDev& A = c->asmb;
+        const Pattern& P = c->pat;
+        if (!A.static_set) return fail(c, OPMHIP_NOT_READY, "get_trackers before set_static");
+        OPMHIP_HIP(c, hipSetDevice(c->device));
+        OPMHIP_HIP(c, hipStreamSynchronize(c->stream));
+        const int N = P.Nloc;
+        std::vector<double> tmp(N);
+        auto get = [&](double* out, const double* dev) -> int {
+            if (!out) return OPMHIP_SUCCESS;
+            if (!dev) { std::fill(out, out + N, 0.0); return OPMHIP_SUCCESS; }
+            OPMHIP_HIP(c, hipMemcpy(tmp.data(), dev, (size_t)N * sizeof(double), hipMemcpyDeviceToHost));
+            for (int pos = 0; pos < N; ++pos) out[P.fromOrder[pos]] = tmp[pos];
+            return OPMHIP_SUCCESS;
+        };
+        int rc;
+        if ((rc = get(last_rs, A.d_lastRs)) || (rc = get(last_rv, A.d_lastRv)) || (rc = get(min_po, A.d_minpo))) return rc;
+        return OPMHIP_SUCCESS;
+    });
+}
+
 int opmhip_end_time_step(opmhip_ctx* c, double dt) {
     if (!c) return OPMHIP_INVALID_ARGUMENT;
     return guarded(c, [&]() -> int {
         AsmDev& A = c->asmb;
         if (!A.assembled) return fail(c, OPMHIP_NOT_READY, "end_time_step before assemble: no residual of an accepted step on the device");
         if (!(dt > 0.0)) return fail(c, OPMHIP_INVALID_ARGUMENT, "end_time_step: dt must be positive");
-        if (!A.drift_enabled) return OPMHIP_SUCCESS;
         OPMHIP_HIP(c, hipSetDevice(c->device));
+        if (A.drsdt_on || A.drvdt_on) launch_last_rs_rv(c);   // updateCompositionChangeLimits_ (eclproblem.hh:1125)
+        A.storage_frozen = false;
+        if (!A.drift_enabled) return OPMHIP_SUCCESS;
         launch_drift_update(c, dt);
         OPMHIP_HIP(c, hipGetLastError());
         return OPMHIP_SUCCESS;

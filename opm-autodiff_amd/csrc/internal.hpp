@@ -107,6 +107,13 @@ struct AsmDev {
     double* d_eps = nullptr;                              // per cell scaled saturation end points, field-major [EPS_COUNT][Nloc] (optional)
     int epscfg = 0;                                       // packed EclEpsConfig (assemble.hip CellStatic::epscfg)
     std::vector<double> sat_eps;                          // host copy: the tables' own end points, EPS_COUNT per saturation region
+    // DRSDT / DRVDT bookkeeping (EclProblem::lastRs_ / lastRv_ / maxDRs_ / maxDRv_) and ROCKCOMP IRREVERS (minOilPressure_)
+    bool drsdt_on = false, drvdt_on = false;
+    double *d_drsdt = nullptr, *d_drvdt = nullptr;        // rates per PVT region [1/s], negative = none
+    int* d_drsdt_all = nullptr;                           // per PVT region: the limit binds all cells (OILVAP option)
+    double *d_lastRs = nullptr, *d_lastRv = nullptr;      // per cell
+    double* d_minpo = nullptr;                            // per cell minimum oil pressure so far (irreversible compaction); NULL = reversible
+    bool storage_frozen = false;                          // begin_time_step formed the old time level's storage: iteration 0 must not refill it
     double* d_invb = nullptr;                             // packed 1/b per cell and phase (Nloc x 3), for the convergence check
     double *d_trans = nullptr, *d_area = nullptr, *d_thpres = nullptr;                      // per entry
     double *d_poro = nullptr, *d_volume = nullptr, *d_depth = nullptr, *d_rsmax = nullptr;  // per cell
@@ -393,6 +400,10 @@ int launch_ghost_refresh(opmhip_ctx* c);
 void launch_newton_update(opmhip_ctx* c, const double* d_dx_internal, double relax);
 void launch_assemble(opmhip_ctx* c, double dt, int iteration);
 void launch_drift_update(opmhip_ctx* c, double dt);
+void launch_last_rs_rv(opmhip_ctx* c);
+void launch_set_limits(opmhip_ctx* c, double dt);
+void launch_min_pressure(opmhip_ctx* c, bool init);
+void launch_storage_old(opmhip_ctx* c);
 int launch_convergence(opmhip_ctx* c, double dt, double tol_cnv);
 void launch_u8_to_internal(opmhip_ctx* c, const unsigned char* nat, unsigned char* internal);
 void launch_u8_to_natural(opmhip_ctx* c, const unsigned char* internal, unsigned char* nat);

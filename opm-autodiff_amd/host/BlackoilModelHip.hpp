@@ -162,6 +162,9 @@ public:
     /// FvBaseDiscretization::advanceTimeLevel / updateFailed: solution(1) <-> solution(0) on the device
     void advanceTimeLevel() { check(opmhip_advance_time_level(ctx_), "advanceTimeLevel"); }
     void updateFailed() { check(opmhip_update_failed(ctx_), "updateFailed"); }
+    /// EclProblem::beginTimeStep, the per-cell part (ebos/eclproblem.hh:1042-1075): DRSDT / DRVDT caps of a step of size dt,
+    /// minimum oil pressure of irreversible compaction (a no-op where neither is in force)
+    void beginTimeStep(double dt) { check(opmhip_begin_time_step(ctx_, dt), "beginTimeStep"); }
     /// EclProblem::endTimeStep, the drift-compensation part (ebos/eclproblem.hh:1126-1135): after an ACCEPTED time step
     void endTimeStep(double dt) { check(opmhip_end_time_step(ctx_, dt), "endTimeStep"); }
 
@@ -178,6 +181,7 @@ public:
         while (t < length * (1.0 - 1e-12)) {
             dt = std::min(dt, length - t);
             if (restarts == 0) advanceTimeLevel();
+            beginTimeStep(dt);   // also in front of every retry of a chopped step
             int newtons = 0;
             bool ok = true;
             try {

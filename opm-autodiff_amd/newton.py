@@ -163,6 +163,11 @@ class BlackoilModelHip:
     def update_failed(self):
         self.m.update_failed()
 
+    # -- EclProblem::beginTimeStep (ebos/eclproblem.hh:1042-1075): DRSDT / DRVDT caps of a step of size dt, minimum pressure --
+    def begin_time_step(self, dt):
+        if hasattr(self.m, "begin_time_step"):
+            self.m.begin_time_step(dt)
+
     # -- EclProblem::endTimeStep (ebos/eclproblem.hh:1101-1135): the drift of the accepted step ------------------
     def end_time_step(self, dt):
         self.m.end_time_step(dt)
@@ -221,6 +226,8 @@ class AdaptiveTimeStepping:
         while True:
             if self.iteration == 0 and self.restarts == 0:
                 self.model.advance_time_level()
+            if self.iteration == 0 and hasattr(self.model, "begin_time_step"):
+                self.model.begin_time_step(self.dt)      # also in front of every retry of a chopped step
             failed = False
             try:
                 rep = self.model.nonlinear_iteration(self.iteration, self.dt)

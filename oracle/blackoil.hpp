@@ -51,6 +51,7 @@ struct Problem {
     std::vector<double> rvMax;                // per cell; empty = no DRVDT limit (maxOilVaporizationFactor, eclproblem.hh:1734-1754)
     std::vector<int> rockNum;                 // per cell rock-table index (rockTableIdx_, eclproblem.hh:1943-1945); empty = table 0
     std::vector<double> overburden;           // per cell overburden pressure (eclproblem.hh:1954-1955); empty = none
+    std::vector<double> minOilPressure;       // per cell (ROCKCOMP IRREVERS, eclproblem.hh:1948-1952, 2172-2197); empty = reversible
     // per cell scaled maximum of the oil-water capillary pressure (the deck's PCW, or what SWATINIT made of it:
     // ebos/equil/initstateequil.hh:1330-1343 -> EclMaterialLawManager::applySwatinit); empty = the tables' own.
     // UNVERIFIED against upstream sources: opm-material (EclEpsTwoPhaseLaw, EclEpsScalingPoints) is not in the reference tree;
@@ -179,6 +180,7 @@ void update_iq(const Problem& P, int cell, const double* pv, uint8_t meaning, IQ
     if (!F.rockTab.empty()) {
         const RockTab& RT = F.rockTab[P.rockNum.empty() ? 0 : P.rockNum[cell]];
         E effectiveOilPressure = q.p[OIL];
+        if (!P.minOilPressure.empty()) effectiveOilPressure = min(q.p[OIL], E(P.minOilPressure[cell]));   // the pore space change is irreversible
         if (!P.overburden.empty()) effectiveOilPressure = effectiveOilPressure - P.overburden[cell];
         q.poro = q.poro * RT.poroMult.eval(effectiveOilPressure);
         q.tmult = RT.transMult.eval(effectiveOilPressure);
@@ -256,8 +258,74 @@ struct Model {
     double maxCompensation = 10.0 * 1e-2;   // 10 * NewtonTolerance (eclproblem.hh:352-356, 1854)
     std::vector<double> drift;              // Nb x 3, zero until the first endTimeStep (:881-884)
 
-    // EclProblem::endTimeStep, the drift part (eclproblem.hh:1126-1135): call after an ACCEPTED time step of size dt
+    // DRSDT / DRVDT (eclproblem.hh:1711-1754, 2010-2107, eclgenericproblem.cc maxDRs_ = DRSDT * dt): rates per PVT region
+    // [1/s], negative = no limit; drsdtAll: the OILVAP option (the limit binds all cells, not only those with free gas)
+    std::vector<double> drsdt, drvdt;
+    std::vector<int> drsdtAll;
+    std::vector<double> lastRs, lastRv;
+    bool storageFrozen = false;   // the old-time-level storage was formed by begin_time_step (recycleFirstIterationStorage() == false)
+    bool limits_active() const { return !drsdt.empty() || !drvdt.empty(); }
+    // updateCompositionChangeLimits_ (eclproblem.hh:2010-2107): from the state as it is (initial solution; end of a time step)
+    void update_composition_change_limits() {
+        const int Nb = P.pat.Nb;
+        if (!drsdt.empty()) {
+            lastRs.resize(Nb);
+            for (int c = 0; c < Nb; ++c) {
+                const int pr = P.pvtnum.empty() ? 0 : P.pvtnum[c];
+                lastRs[c] = (drsdtAll[pr] || iqV[c].S[GAS] > 1e-7) ? iqV[c].Rs : std::numeric_limits<double>::infinity();
+            }
+        }
+        if (!drvdt.empty()) {
+            lastRv.resize(Nb);
+            for (int c = 0; c < Nb; ++c) lastRv[c] = iqV[c].Rv;
+        }
+    }
+    // maxGasDissolutionFactor / maxOilVaporizationFactor of time level 0 (maxD = rate * dt) or 1 (dt = 0)
+    void set_limits_for(double dt) {
+        const int Nb = P.pat.Nb;
+        const double none = std::numeric_limits<double>::max() / 2.0;
+        if (!drsdt.empty()) {
+            P.rsMax.resize(Nb);
+            for (int c = 0; c < Nb; ++c) {
+                const int pr = P.pvtnum.empty() ? 0 : P.pvtnum[c];
+                P.rsMax[c] = (drsdt[pr] < 0.0) ? none : lastRs[c] + drsdt[pr] * dt;
+            }
+        }
+        if (!drvdt.empty()) {
+            P.rvMax.resize(Nb);
+            for (int c = 0; c < Nb; ++c) {
+                const int pr = P.pvtnum.empty() ? 0 : P.pvtnum[c];
+                P.rvMax[c] = (drvdt[pr] < 0.0) ? none : lastRv[c] + drvdt[pr] * dt;
+            }
+        }
+    }
+    // EclProblem::beginTimeStep, the per-cell part (eclproblem.hh:1042-1075): minimum oil pressure of irreversible
+    // compaction, the DRSDT / DRVDT caps of a time step of size dt, intensive quantities; and, where the first iteration's
+    // storage term cannot be recycled (:1758-1765), the old time level's storage with ITS caps (time index 1: no increment)
+    void begin_time_step(double dt) {
+        const int Nb = P.pat.Nb;
+        if (!P.minOilPressure.empty())
+            for (int c = 0; c < Nb; ++c) P.minOilPressure[c] = std::min(P.minOilPressure[c], iqV[c].p[OIL]);
+        storageFrozen = false;
+        if (limits_active()) {
+            if (lastRs.empty() && lastRv.empty()) update_composition_change_limits();
+            set_limits_for(0.0);
+            update_all_iq();
+            for (int I = 0; I < Nb; ++I) {
+                Ev st[3];
+                compute_storage(iqF[I], st, P.fluid.hasWetGas);
+                for (int e = 0; e < 3; ++e) storageOld[(size_t)I * 3 + e] = st[e].v;
+            }
+            storageFrozen = true;
+            set_limits_for(dt);
+        }
+        update_all_iq();
+    }
+    // EclProblem::endTimeStep (eclproblem.hh:1101-1135): DRSDT / DRVDT bookkeeping, then the drift part; call after an
+    // ACCEPTED time step of size dt
     void end_time_step(double dt) {
+        if (limits_active()) update_composition_change_limits();
+        storageFrozen = false;
         if (!enableDriftCompensation) return;
         for (size_t i = 0; i < residual.size(); ++i) {
             drift[i] = residual[i];
@@ -317,7 +385,7 @@ struct Model {
             Ev st[3];
             compute_storage(in, st, P.fluid.hasWetGas);
             double* so = &storageOld[(size_t)I * 3];
-            if (iteration == 0)
+            if (iteration == 0 && !storageFrozen)
                 for (int e = 0; e < 3; ++e) so[e] = st[e].v;
             const double scvVolume = P.volume[I];
             for (int e = 0; e < 3; ++e) {

@@ -559,6 +559,44 @@ int orc_sat_probe_eps(const orc_fluid_desc* fluid, int sat_region, const int* cf
     return 0;
 }
 
+// DRSDT / DRVDT: rates per PVT region (1/s; negative = none; NULL = keyword absent), OILVAP option per region
+int orc_bo_set_composition_change_limits(orc_model* h, int num_pvt, const double* drsdt, const int* drsdt_all, const double* drvdt) {
+    Model& M = h->M;
+    M.drsdt.clear(); M.drvdt.clear(); M.drsdtAll.clear(); M.lastRs.clear(); M.lastRv.clear();
+    if (drsdt) { M.drsdt.assign(drsdt, drsdt + num_pvt); M.drsdtAll.assign(num_pvt, 0); if (drsdt_all) M.drsdtAll.assign(drsdt_all, drsdt_all + num_pvt); }
+    if (drvdt) M.drvdt.assign(drvdt, drvdt + num_pvt);
+    if (!drsdt) M.P.rsMax.clear();
+    if (!drvdt) M.P.rvMax.clear();
+    if (M.limits_active()) { M.update_composition_change_limits(); M.set_limits_for(0.0); }   // until the first begin_time_step: the caps of the state itself
+    M.storageFrozen = false;
+    M.update_all_iq();
+    return 0;
+}
+// ROCKCOMP IRREVERS: minOilPressure_ = min(1e99, initial oil pressure) (eclgenericproblem.cc:165, eclproblem.hh:2293-2294)
+int orc_bo_set_irreversible_compaction(orc_model* h, int enable) {
+    Model& M = h->M;
+    M.P.minOilPressure.clear();
+    if (enable) {
+        const int Nb = M.P.pat.Nb;
+        M.P.minOilPressure.assign(Nb, 1e99);
+        for (int c = 0; c < Nb; ++c) M.P.minOilPressure[c] = std::min(M.P.minOilPressure[c], M.iqV[c].p[OIL]);
+    }
+    M.update_all_iq();
+    return 0;
+}
+int orc_bo_begin_time_step(orc_model* h, double dt) { h->M.begin_time_step(dt); return 0; }
+// trackers, for tests: out[0..Nb) lastRs, [Nb..2Nb) lastRv, [2Nb..3Nb) minOilPressure (0 where not kept)
+int orc_bo_get_trackers(orc_model* h, double* out) {
+    Model& M = h->M;
+    const int Nb = M.P.pat.Nb;
+    for (int c = 0; c < Nb; ++c) {
+        out[c] = M.lastRs.empty() ? 0.0 : M.lastRs[c];
+        out[Nb + c] = M.lastRv.empty() ? 0.0 : M.lastRv[c];
+        out[2 * Nb + c] = M.P.minOilPressure.empty() ? 0.0 : M.P.minOilPressure[c];
+    }
+    return 0;
+}
+
 int orc_bo_set_pcw(orc_model* h, const double* pcw) {
     Model& M = h->M;
     const int Nb = M.P.pat.Nb;

@@ -160,6 +160,10 @@ class OracleModel:
         L.orc_bo_set_extras.argtypes = [_vp, _vp, _vp, _vp]
         L.orc_bo_set_pcw.argtypes = [_vp, _vp]
         L.orc_bo_set_endpoint_scaling.argtypes = [_vp, _vp, _vp]
+        L.orc_bo_set_composition_change_limits.argtypes = [_vp, C.c_int, _vp, _vp, _vp]
+        L.orc_bo_set_irreversible_compaction.argtypes = [_vp, C.c_int]
+        L.orc_bo_begin_time_step.argtypes = [_vp, C.c_double]
+        L.orc_bo_get_trackers.argtypes = [_vp, _d]
         L.orc_bo_end_time_step.argtypes = [_vp, C.c_double]
         L.orc_bo_set_drift_compensation.argtypes = [_vp, C.c_int, C.c_double]
         L.orc_bo_get_drift.argtypes = [_vp, _d]
@@ -193,6 +197,24 @@ class OracleModel:
             eps[:, f] = tab[satnum, f] if es.get(name) is None else np.asarray(es[name], np.float64)[:self.Nb]
         self._eps = np.ascontiguousarray(eps)
         self.o.lib.orc_bo_set_endpoint_scaling(self.h, _p(cfg), _p(self._eps))
+
+    def set_composition_change_limits(self, drsdt=None, drsdt_all_cells=None, drvdt=None):
+        n = len(self.case["fluid"].pvt)
+        a = None if drsdt is None else np.ascontiguousarray(drsdt, np.float64)
+        b = None if drsdt_all_cells is None else np.ascontiguousarray(drsdt_all_cells, np.int32)
+        d = None if drvdt is None else np.ascontiguousarray(drvdt, np.float64)
+        self.o.lib.orc_bo_set_composition_change_limits(self.h, n, _p(a), _p(b), _p(d))
+
+    def set_irreversible_compaction(self, enable=True):
+        self.o.lib.orc_bo_set_irreversible_compaction(self.h, int(enable))
+
+    def begin_time_step(self, dt):
+        self.o.lib.orc_bo_begin_time_step(self.h, dt)
+
+    def trackers(self):
+        out = np.empty(3 * self.Nb)
+        self.o.lib.orc_bo_get_trackers(self.h, out)
+        return out[:self.Nb], out[self.Nb:2 * self.Nb], out[2 * self.Nb:]
 
     def set_pcw(self, pcw):
         a = None if pcw is None else np.ascontiguousarray(pcw, np.float64)
@@ -355,6 +377,9 @@ class OracleAsHipModel:
 
     def end_time_step(self, dt):
         self.om.end_time_step(dt)
+
+    def begin_time_step(self, dt):
+        self.om.begin_time_step(dt)
 
 
 class OracleFluid:
