@@ -22,7 +22,7 @@ extern "C" {
 
 #define OPMHIP_ABI_VERSION 4 /* 4: opmhip_config names chain_length, spmv_pipe_wgs, preconditioner (were reserved[0..2]);
                                *    opmhip_set_endpoint_scaling, opmhip_sat_end_points, opmhip_synchronize, opmhip_comm_info,
-                               *    opmhip_set_composition_change_limits, opmhip_set_irreversible_compaction, opmhip_begin_time_step;
+                               *    opmhip_set_composition_change_limits, opmhip_set_irreversible_compaction, opmhip_set_vappars, opmhip_begin_time_step;
                                * 3: opmhip_fluid gained pc_scaling, opmhip_set_pcw */
 
 typedef struct opmhip_ctx opmhip_ctx;
@@ -291,17 +291,26 @@ int opmhip_set_composition_change_limits(opmhip_ctx* ctx, const double* drsdt, c
  * fluid with ROCKTAB. */
 int opmhip_set_irreversible_compaction(opmhip_ctx* ctx, int enable);
 
+/* replaces: VAPPARS - EclProblem::maxOilSaturation (ebos/eclproblem.hh:1682-1688; initialised from the initial state,
+ * :2291-2292; updateMaxOilSaturation_, :2110-2141) and what the PVT classes make of it: saturated Rs x max(1e-3, (S_o /
+ * S_o,max)^vap2), saturated Rv x max(1e-3, (S_o / S_o,max)^vap1) where S_o is below the largest oil saturation the cell has
+ * seen at the start of a time step (LiveOilPvt / WetGasPvt of opm-material, absent from the reference tree: restated).
+ * enable != 0: start tracking from the state now present.  The power function makes this the one feature whose device
+ * results agree with the CPU restatement to rounding (1e-12 of a quantity's magnitude, measured 1.1e-13), not to the bit.  Needs a context with the extended
+ * record (a fluid with PVTG, ROCKTAB or pc_scaling). */
+int opmhip_set_vappars(opmhip_ctx* ctx, int enable, double vap1, double vap2);
+
 /* replaces: the per-cell work of EclProblem::beginTimeStep (ebos/eclproblem.hh:1042-1075) for a time step of size dt [s]:
- * updateMinPressure_, the DRSDT / DRVDT caps of this step, invalidateAndUpdateIntensiveQuantities(0); and, since
+ * updateMinPressure_, updateMaxOilSaturation_, the DRSDT / DRVDT caps of this step, invalidateAndUpdateIntensiveQuantities(0); and, since
  * recycleFirstIterationStorage() is false with DRSDT / DRVDT (:1758-1765), the old time level's storage term formed with ITS
  * caps (time index 1: lastRs / lastRv without the increment) - opmhip_assemble(iteration 0) then leaves it alone.  Call it
  * after opmhip_advance_time_level, and again before every retry of a chopped step.  A no-op (SUCCESS) when neither feature
  * is in force. */
 int opmhip_begin_time_step(opmhip_ctx* ctx, double dt);
 
-/* the trackers, for restart files and tests: lastRs, lastRv, minimum oil pressure per cell (natural order, Nb + Nghost
- * entries each; any may be NULL; an array that is not kept comes back as zeros) */
-int opmhip_get_trackers(opmhip_ctx* ctx, double* last_rs, double* last_rv, double* min_oil_pressure);
+/* the trackers, for restart files and tests: lastRs, lastRv, minimum oil pressure, maximum oil saturation per cell (natural
+ * order, Nb + Nghost entries each; any may be NULL; an array that is not kept comes back as zeros) */
+int opmhip_get_trackers(opmhip_ctx* ctx, double* last_rs, double* last_rv, double* min_oil_pressure, double* max_oil_saturation);
 
 /* replaces: the per-cell scaled end point maxPcow of the oil-water capillary pressure - the PCW array of the deck, or
  * what SWATINIT made of it during equilibration (ebos/equil/initstateequil.hh:1330-1343 -> EclMaterialLawManager::

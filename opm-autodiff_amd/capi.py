@@ -357,7 +357,8 @@ def _bind_assembly(L):
     L.opmhip_set_composition_change_limits.argtypes = [vp, vp, vp, vp]
     L.opmhip_set_irreversible_compaction.argtypes = [vp, C.c_int]
     L.opmhip_begin_time_step.argtypes = [vp, C.c_double]
-    L.opmhip_get_trackers.argtypes = [vp, vp, vp, vp]
+    L.opmhip_get_trackers.argtypes = [vp, vp, vp, vp, vp]
+    L.opmhip_set_vappars.argtypes = [vp, C.c_int, C.c_double, C.c_double]
     L.opmhip_sat_end_points.argtypes = [vp, C.c_int, vp]
     L.opmhip_gas_probe.argtypes = [vp, C.c_int, C.c_int, vp, vp, vp]
     L.opmhip_iq_fields.argtypes = [vp]
@@ -515,11 +516,15 @@ class HipModel(HipSolver):
         """EclProblem::beginTimeStep, per-cell part: minimum pressure, DRSDT / DRVDT caps of a step of size dt"""
         self._check(lib().opmhip_begin_time_step(self._h, dt))
 
+    def set_vappars(self, vap1, vap2, enable=True):
+        """VAPPARS: exponents on the saturated Rv / Rs below the largest oil saturation seen.  After set_state."""
+        self._check(lib().opmhip_set_vappars(self._h, int(enable), float(vap1), float(vap2)))
+
     def trackers(self):
-        """-> (lastRs, lastRv, minimum oil pressure) per cell, natural order; zeros where not kept"""
-        a, b, d = np.empty(self.Nloc), np.empty(self.Nloc), np.empty(self.Nloc)
-        self._check(lib().opmhip_get_trackers(self._h, _ptr(a), _ptr(b), _ptr(d)))
-        return a, b, d
+        """-> (lastRs, lastRv, minimum oil pressure, maximum oil saturation) per cell, natural order; zeros where not kept"""
+        a, b, d, e = (np.empty(self.Nloc) for _ in range(4))
+        self._check(lib().opmhip_get_trackers(self._h, _ptr(a), _ptr(b), _ptr(d), _ptr(e)))
+        return a, b, d, e
 
     def end_time_step(self, dt):
         """EclProblem::endTimeStep (drift part): remember residual * dt of the time step that was just accepted."""

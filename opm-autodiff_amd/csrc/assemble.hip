@@ -52,6 +52,14 @@ __device__ __forceinline__ Ad operator/(double a, const Ad& b) {
     const double t = -a / (b.v * b.v);
     return Ad{a / b.v, t * b.d0, t * b.d1, t * b.d2};
 }
+// Opm::pow(Evaluation, Scalar) as oracle/eval.hpp restates it.  The device's pow() and the host's std::pow() agree to an ulp,
+// not to the bit: VAPPARS is the one place where device and oracle are compared with a tolerance (tests/test_gpu_vappars.py)
+__device__ __forceinline__ Ad epow(const Ad& a, double e) {
+    const double px = pow(a.v, e);
+    const double df = (a.v == 0.0) ? 0.0 : px / a.v * e;
+    return Ad{px, df * a.d0, df * a.d1, df * a.d2};
+}
+__device__ __forceinline__ double epow(double a, double e) { return pow(a, e); }
 __device__ __forceinline__ Ad ad_max(const Ad& a, const Ad& b) { return (a.v > b.v) ? a : b; }
 __device__ __forceinline__ Ad ad_min(const Ad& a, const Ad& b) { return (a.v < b.v) ? a : b; }
 __device__ __forceinline__ double val(const Ad& a) { return a.v; }
@@ -219,6 +227,8 @@ struct CellStatic {
     const int* rocknum;                 // rock-table index per cell (NULL = table 0)
     const double* pcw;                  // extended layout: scaled maximum of pcow per cell (PCW / SWATINIT; NULL = the tables' own)
     const double* minpo;                // extended layout: minimum oil pressure so far (ROCKCOMP IRREVERS; NULL = reversible compaction)
+    const double* maxso;                // extended layout: largest oil saturation seen at the start of a time step (VAPPARS; NULL = not in force)
+    double vap1, vap2;                  // VAPPARS: exponent on RvSat / on RsSat
     const double* eps;                  // extended layout: scaled end points per cell, field-major [EPS_COUNT][ncell] (NULL = no end-point scaling)
     int epscfg;                         // EclEpsConfig: bit 0 saturation scaling, 1 three-point, 2-3 krw, 4-5 kro, 6-7 krg mode, 8 pcw, 9 pcg
     double* invb;                       // packed 1/b_w, 1/b_o, 1/b_g per cell, written beside the record (convergence check)
@@ -328,6 +338,16 @@ template <class DP, bool EXT> __device__ __forceinline__ void cell_cap_pressures
     } else cap_pressures<double, DP>(T, sr, Sw, Sg, pC);
 }
 
+// VAPPARS factor on a saturated Rs / Rv (oracle/blackoil.hpp vappars_factor: same statements)
+template <class E> __device__ __forceinline__ E vappars_factor(const E& So, const E& SoMaxIn, double vapPar) {
+    const E maxOilSaturation = emin(SoMaxIn, cst<E>(1.0));
+    if (vapPar > 0.0 && val(maxOilSaturation) > 0.01 && val(So) < val(maxOilSaturation)) {
+        const E S = emax(So, cst<E>(0.001));
+        return emax(cst<E>(1e-3), epow(S / maxOilSaturation, vapPar));
+    }
+    return cst<E>(1.0);
+}
+
 // BlackOilIntensiveQuantities::update: live oil + water + dry gas (base) or wet gas / rock compaction tables (EXT)
 template <class E, class DP, bool EXT>
 __device__ __forceinline__ void update_iq(const TablesT<DP>& T, const CellStatic& C, int c, const double* pv, int meaning, Iq<E>& q) {
@@ -393,20 +413,23 @@ __device__ __forceinline__ void update_iq(const TablesT<DP>& T, const CellStatic
     }
     // Rs / Rv by the meaning of the switching variable, capped by RsMax / RvMax (DRSDT / DRVDT, eclproblem.hh:1711-1754)
     if (EXT) q.Rv = cst<E>(0.0);
-    if (meaning == OPMHIP_SW_PO_SG) {
-        const E RsSat = tab1<E, DP>(B + D.sat_p, B + D.sat_rs, D.sat_n, q.p[OIL]);
+    const bool vap = EXT && C.maxso;   // VAPPARS: SoMax = max(So, problem.maxOilSaturation)
+    E SoMax = So;
+    if (vap) SoMax = emax(So, cst<E>(C.maxso[c]));
+    if (meaning == OPMHIP_SW_PO_SG || (EXT && meaning == OPMHIP_SW_PG_RV)) {
+        // (Sw_pg_Rv: the oil phase is not present, its "composition" is still needed for the gravity term)
+        E RsSat = tab1<E, DP>(B + D.sat_p, B + D.sat_rs, D.sat_n, q.p[OIL]);
+        if (vap) RsSat = RsSat * vappars_factor(So, SoMax, C.vap2);
         q.Rs = emin(cst<E>(RsMax), RsSat);
-    } else if (!EXT || meaning == OPMHIP_SW_PO_RS) {
+    } else {
         q.Rs = emin(cst<E>(RsMax), mk<E>(pv[2], 2));
-    } else {   // Sw_pg_Rv: the oil phase is not present, its "composition" is still needed for the gravity term
-        const E RsSat = tab1<E, DP>(B + D.sat_p, B + D.sat_rs, D.sat_n, q.p[OIL]);
-        q.Rs = emin(cst<E>(RsMax), RsSat);
     }
     if (EXT && wet) {
         const double RvMax = C.rvmax ? C.rvmax[c] : DBL_MAX / 2.0;
         if (meaning == OPMHIP_SW_PG_RV) q.Rv = emin(cst<E>(RvMax), mk<E>(pv[2], 2));
         else {
-            const E RvSat = tab1<E, DP>(B + D.wg_xs, B + D.wgs_rv, D.wg_n, q.p[GAS]);
+            E RvSat = tab1<E, DP>(B + D.wg_xs, B + D.wgs_rv, D.wg_n, q.p[GAS]);
+            if (vap) RvSat = RvSat * vappars_factor(So, SoMax, C.vap1);
             q.Rv = emin(cst<E>(RvMax), RvSat);
         }
     }
@@ -582,6 +605,9 @@ __device__ __forceinline__ void newton_update_cell(const TablesT<DP>& T, const C
     const bool wet = EXT && T.pvt(pr).wg_n > 0;
     const double eps = wasSwitched[c] ? oscThreshold : 0.0;
     bool sw = false;
+    // VAPPARS in the switches (adaptPrimaryVariables: SoMax = max(So, problem.maxOilSaturation)); 1 where it is not in force
+    const bool vap = EXT && C.maxso;
+    auto vap_f = [&](double So_, double par) { return vap ? vappars_factor<double>(So_, emax(So_, C.maxso[c]), par) : 1.0; };
     if (x[0] >= 1.0) {   // cells with (almost) only water
         x[0] = 1.0; x[2] = 0.0;
         sw = mng != OPMHIP_SW_PO_SG;
@@ -590,7 +616,7 @@ __device__ __forceinline__ void newton_update_cell(const TablesT<DP>& T, const C
         const double So = 1.0 - x[0] - x[2];
         if (x[2] < -eps && So > 0.0) {   // the gas phase disappears
             mng = OPMHIP_SW_PO_RS;
-            x[2] = emin(RsMax, rs_sat_value(T, pr, x[1]));
+            x[2] = emin(RsMax, rs_sat_value(T, pr, x[1]) * vap_f(So, C.vap2));
             sw = true;
         } else if (EXT && wet && So < -eps && x[2] > 0.0) {   // the oil phase disappears: { Sw, pg, Rv }
             double pC[3];
@@ -599,15 +625,15 @@ __device__ __forceinline__ void newton_update_cell(const TablesT<DP>& T, const C
             const double RvMax = C.rvmax ? C.rvmax[c] : DBL_MAX / 2.0;
             mng = OPMHIP_SW_PG_RV;
             x[1] = pg;
-            x[2] = emin(RvMax, rv_sat_value(T, pr, pg));
+            x[2] = emin(RvMax, rv_sat_value(T, pr, pg) * vap_f(So, C.vap1));
             sw = true;
         }
     } else if (!EXT || mng == OPMHIP_SW_PO_RS) {
-        const double RsSat = rs_sat_value(T, pr, x[1]);
+        const double RsSat = rs_sat_value(T, pr, x[1]) * vap_f(1.0 - x[0], C.vap2);   // no gas: So = 1 - Sw
         if (x[2] > emin(RsMax, RsSat * (1.0 + eps))) { mng = OPMHIP_SW_PO_SG; x[2] = 0.0; sw = true; }
     } else {   // Sw_pg_Rv: the oil phase appears once the gas holds more oil than saturated gas does
         const double RvMax = C.rvmax ? C.rvmax[c] : DBL_MAX / 2.0;
-        const double RvSat = rv_sat_value(T, pr, x[1]);
+        const double RvSat = rv_sat_value(T, pr, x[1]) * vap_f(0.0, C.vap1);   // no oil phase: So = 0
         if (x[2] > emin(RvMax, RvSat * (1.0 + eps))) {
             double pC[3];
             cell_cap_pressures<DP, EXT>(T, C, c, sr, x[0], 1.0 - x[0], pC);
@@ -1158,6 +1184,14 @@ __global__ __launch_bounds__(256) void k_min_pressure(int N, int init, const dou
     const double old = init ? 1e99 : minpo[c];
     minpo[c] = (po < old) ? po : old;
 }
+// updateMaxOilSaturation_ (:2110-2141); init: maxOilSaturation_ = max(0, S_o of the initial state) (:2291-2292)
+__global__ __launch_bounds__(256) void k_max_oil_saturation(int N, int init, const double* __restrict__ iq, double* __restrict__ maxso) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= N) return;
+    const double So = iq_at(iq, N, F_S + OIL, c)[0];
+    const double old = init ? 0.0 : maxso[c];
+    maxso[c] = (old > So) ? old : So;   // std::max(old, So)
+}
 // the storage term of the cached intensive quantities, values only (computeStorage; the statements of k_assemble's diagonal
 // lane): the old time level's storage where the first iteration's cannot be recycled (:1758-1765)
 template <bool EXT>
@@ -1210,7 +1244,7 @@ static Tables tables_of(const opmhip_ctx* c) {
 }
 static CellStatic cells_of(const opmhip_ctx* c) {
     return CellStatic{c->asmb.d_poro, c->asmb.d_volume, c->asmb.d_depth, c->asmb.d_rsmax, c->asmb.d_pvtnum, c->asmb.d_satnum,
-                      c->asmb.d_rvmax, c->asmb.d_overburden, c->asmb.d_rocknum, c->asmb.d_pcw, c->asmb.d_minpo, c->asmb.d_eps, c->asmb.epscfg, c->asmb.d_invb, c->pat.Nloc};
+                      c->asmb.d_rvmax, c->asmb.d_overburden, c->asmb.d_rocknum, c->asmb.d_pcw, c->asmb.d_minpo, c->asmb.d_maxso, c->asmb.vap1, c->asmb.vap2, c->asmb.d_eps, c->asmb.epscfg, c->asmb.d_invb, c->pat.Nloc};
 }
 // the context's record layout: extended when the fluid has PVTG or ROCKTAB tables
 #define OPMHIP_LAYOUT(c, call_base, call_ext) do { if ((c)->asmb.ext) { call_ext; } else { call_base; } } while (0)
@@ -1274,6 +1308,10 @@ void launch_set_limits(opmhip_ctx* c, double dt) {
 void launch_min_pressure(opmhip_ctx* c, bool init) {
     const int N = c->pat.Nloc;
     hipLaunchKernelGGL(k_min_pressure, dim3((N + 255) / 256), dim3(256), 0, c->stream, N, init ? 1 : 0, c->asmb.d_iq, c->asmb.d_minpo);
+}
+void launch_max_oil_saturation(opmhip_ctx* c, bool init) {
+    const int N = c->pat.Nloc;
+    hipLaunchKernelGGL(k_max_oil_saturation, dim3((N + 255) / 256), dim3(256), 0, c->stream, N, init ? 1 : 0, c->asmb.d_iq, c->asmb.d_maxso);
 }
 void launch_storage_old(opmhip_ctx* c) {
     const AsmDev& A = c->asmb;

@@ -538,16 +538,40 @@ int opmhip_set_irreversible_compaction(opmhip_ctx* c, int enable) {
     });
 }
 
+int opmhip_set_vappars(opmhip_ctx* c, int enable, double vap1, double vap2) {
+    if (!c) return OPMHIP_INVALID_ARGUMENT;
+    return guarded(c, [&]() -> int {
+        AsmDev& A = c->asmb;
+        if (!A.state_set) return fail(c, OPMHIP_NOT_READY, "set_vappars before set_state: the maximum oil saturation starts from the initial solution");
+        if (enable && !A.ext) return fail(c, OPMHIP_INVALID_ARGUMENT, "set_vappars: needs a context with the extended record (a fluid with PVTG, ROCKTAB or pc_scaling)");
+        if (enable && (!(vap1 >= 0.0) || !(vap2 >= 0.0))) return fail(c, OPMHIP_INVALID_ARGUMENT, "set_vappars: the exponents must not be negative");
+        OPMHIP_HIP(c, hipSetDevice(c->device));
+        OPMHIP_HIP(c, hipStreamSynchronize(c->stream));
+        if (!enable) dev_free(c, &A.d_maxso);
+        else {
+            int rc;
+            if (!A.d_maxso && (rc = dev_alloc(c, &A.d_maxso, (size_t)c->pat.Nloc))) return rc;
+            A.vap1 = vap1; A.vap2 = vap2;
+            launch_max_oil_saturation(c, true);
+        }
+        launch_iq_update(c);
+        OPMHIP_HIP(c, hipGetLastError());
+        OPMHIP_HIP(c, hipStreamSynchronize(c->stream));
+        return OPMHIP_SUCCESS;
+    });
+}
+
 int opmhip_begin_time_step(opmhip_ctx* c, double dt) {
     if (!c) return OPMHIP_INVALID_ARGUMENT;
     return guarded(c, [&]() -> int {
         AsmDev& A = c->asmb;
         if (!(dt > 0.0)) return fail(c, OPMHIP_INVALID_ARGUMENT, "begin_time_step: dt must be positive");
         const bool limits = A.drsdt_on || A.drvdt_on;
-        if (!limits && !A.d_minpo) return OPMHIP_SUCCESS;
+        if (!limits && !A.d_minpo && !A.d_maxso) return OPMHIP_SUCCESS;
         if (!A.state_set) return fail(c, OPMHIP_NOT_READY, "begin_time_step before set_state");
         OPMHIP_HIP(c, hipSetDevice(c->device));
         if (A.d_minpo) launch_min_pressure(c, false);     // updateMinPressure_: from the intensive quantities of the state as it is
+        if (A.d_maxso) launch_max_oil_saturation(c, false);   // updateMaxOilSaturation_
         A.storage_frozen = false;
         if (limits) {
             launch_set_limits(c, 0.0);                    // time index 1: lastRs / lastRv without the increment
@@ -562,7 +586,7 @@ int opmhip_begin_time_step(opmhip_ctx* c, double dt) {
     });
 }
 
-int opmhip_get_trackers(opmhip_ctx* c, double* last_rs, double* last_rv, double* min_po) {
+int opmhip_get_trackers(opmhip_ctx* c, double* last_rs, double* last_rv, double* min_po, double* max_so) {
     if (!c) return OPMHIP_INVALID_ARGUMENT;
     return guarded(c, [&]() -> int {
         AsmDev& A = c->asmb;
@@ -580,7 +604,7 @@ int opmhip_get_trackers(opmhip_ctx* c, double* last_rs, double* last_rv, double*
             return OPMHIP_SUCCESS;
         };
         int rc;
-        if ((rc = get(last_rs, A.d_lastRs)) || (rc = get(last_rv, A.d_lastRv)) || (rc = get(min_po, A.d_minpo))) return rc;
+        if ((rc = get(last_rs, A.d_lastRs)) || (rc = get(last_rv, A.d_lastRv)) || (rc = get(min_po, A.d_minpo)) || (rc = get(max_so, A.d_maxso))) return rc;
         return OPMHIP_SUCCESS;
     });
 }

@@ -113,6 +113,8 @@ struct AsmDev {
     int* d_drsdt_all = nullptr;                           // per PVT region: the limit binds all cells (OILVAP option)
     double *d_lastRs = nullptr, *d_lastRv = nullptr;      // per cell
     double* d_minpo = nullptr;                            // per cell minimum oil pressure so far (irreversible compaction); NULL = reversible
+    double* d_maxso = nullptr;                            // per cell largest oil saturation at the start of a time step (VAPPARS); NULL = not in force
+    double vap1 = 0.0, vap2 = 0.0;                        // VAPPARS exponents: on RvSat, on RsSat
     bool storage_frozen = false;                          // begin_time_step formed the old time level's storage: iteration 0 must not refill it
     double* d_invb = nullptr;                             // packed 1/b per cell and phase (Nloc x 3), for the convergence check
     double *d_trans = nullptr, *d_area = nullptr, *d_thpres = nullptr;                      // per entry
@@ -404,6 +406,7 @@ void launch_last_rs_rv(opmhip_ctx* c);
 void launch_set_limits(opmhip_ctx* c, double dt);
 void launch_min_pressure(opmhip_ctx* c, bool init);
 void launch_storage_old(opmhip_ctx* c);
+void launch_max_oil_saturation(opmhip_ctx* c, bool init);
 int launch_convergence(opmhip_ctx* c, double dt, double tol_cnv);
 void launch_u8_to_internal(opmhip_ctx* c, const unsigned char* nat, unsigned char* internal);
 void launch_u8_to_natural(opmhip_ctx* c, const unsigned char* internal, unsigned char* nat);

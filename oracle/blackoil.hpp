@@ -52,6 +52,11 @@ struct Problem {
     std::vector<int> rockNum;                 // per cell rock-table index (rockTableIdx_, eclproblem.hh:1943-1945); empty = table 0
     std::vector<double> overburden;           // per cell overburden pressure (eclproblem.hh:1954-1955); empty = none
     std::vector<double> minOilPressure;       // per cell (ROCKCOMP IRREVERS, eclproblem.hh:1948-1952, 2172-2197); empty = reversible
+    // VAPPARS (eclproblem.hh:1682-1688, 2110-2141): per cell the largest oil saturation seen at the start of a time step; empty =
+    // keyword not in force (maxOilSaturation() = 0).  vapPar1 acts on RvSat, vapPar2 on RsSat (the PVT classes' 5-argument
+    // saturatedGasDissolutionFactor / saturatedOilVaporizationFactor of opm-material, absent: restated, UNVERIFIED)
+    std::vector<double> maxOilSaturation;
+    double vapPar1 = 0.0, vapPar2 = 0.0;
     // per cell scaled maximum of the oil-water capillary pressure (the deck's PCW, or what SWATINIT made of it:
     // ebos/equil/initstateequil.hh:1330-1343 -> EclMaterialLawManager::applySwatinit); empty = the tables' own.
     // UNVERIFIED against upstream sources: opm-material (EclEpsTwoPhaseLaw, EclEpsScalingPoints) is not in the reference tree;
@@ -78,6 +83,17 @@ struct Problem {
         }
     }
 };
+
+// LiveOilPvt::saturatedGasDissolutionFactor(region, T, p, So, maxSo) / WetGasPvt::saturatedOilVaporizationFactor: the factor
+// VAPPARS puts on the saturated Rs (vapPar2) / Rv (vapPar1) where the oil saturation is below the largest one seen
+template <class E> inline E vappars_factor(const E& So, const E& SoMaxIn, double vapPar) {
+    const E maxOilSaturation = min(SoMaxIn, E(1.0));
+    if (vapPar > 0.0 && value(maxOilSaturation) > 0.01 && value(So) < value(maxOilSaturation)) {
+        const E S = max(So, E(0.001));
+        return max(E(1e-3), pow(S / maxOilSaturation, vapPar));
+    }
+    return E(1.0);
+}
 
 // ---- BlackOilIntensiveQuantities::update ------------------------------------------------------
 // E = Ev: the focus cell (derivatives w.r.t. its own primary variables); E = double: values only.
@@ -124,21 +140,25 @@ void update_iq(const Problem& P, int cell, const double* pv, uint8_t meaning, IQ
     else F.sat[sr].relativePermeabilities(q.mob, Sw, Sg);
     // SoMax = max(So, problem.maxOilSaturation) ; the latter is 0 without VAPPARS (eclproblem.hh:1682-1688), and without
     // VAPPARS the saturated Rs / Rv do not depend on it
+    const bool vap = !P.maxOilSaturation.empty();
+    const E SoMax = vap ? max(So, E(P.maxOilSaturation[cell])) : So;
+    auto rs_sat = [&]() { E t = F.oil[pr].rsSat(q.p[OIL]); if (vap) t = t * vappars_factor(So, SoMax, P.vapPar2); return t; };
+    auto rv_sat = [&]() { E t = F.wetGas[pr].rvSat(q.p[GAS]); if (vap) t = t * vappars_factor(So, SoMax, P.vapPar1); return t; };
     if (meaning == Sw_po_Sg) {
-        const E RsSat = F.oil[pr].rsSat(q.p[OIL]);
+        const E RsSat = rs_sat();
         q.Rs = min(E(RsMax), RsSat);
-        if (wet) { const E RvSat = F.wetGas[pr].rvSat(q.p[GAS]); q.Rv = min(E(RvMax), RvSat); }
+        if (wet) { const E RvSat = rv_sat(); q.Rv = min(E(RvMax), RvSat); }
         else q.Rv = E(0.0);
     } else if (meaning == Sw_po_Rs) {
         const E Rs = mkvar<E>(pv[PV_X], PV_X);
         q.Rs = min(E(RsMax), Rs);
         // the gas phase is not present, but its "composition" is needed for the gravity correction term
-        if (wet) { const E RvSat = F.wetGas[pr].rvSat(q.p[GAS]); q.Rv = min(E(RvMax), RvSat); }
+        if (wet) { const E RvSat = rv_sat(); q.Rv = min(E(RvMax), RvSat); }
         else q.Rv = E(0.0);
     } else {
         const E Rv = mkvar<E>(pv[PV_X], PV_X);
         q.Rv = min(E(RvMax), Rv);
-        const E RsSat = F.oil[pr].rsSat(q.p[OIL]);   // the oil phase is not present: same remark
+        const E RsSat = rs_sat();   // the oil phase is not present: same remark
         q.Rs = min(E(RsMax), RsSat);
     }
     // inverse formation volume factors and viscosities (BlackOilFluidSystem::inverseFormationVolumeFactor / viscosity)
@@ -306,6 +326,8 @@ struct Model {
         const int Nb = P.pat.Nb;
         if (!P.minOilPressure.empty())
             for (int c = 0; c < Nb; ++c) P.minOilPressure[c] = std::min(P.minOilPressure[c], iqV[c].p[OIL]);
+        if (!P.maxOilSaturation.empty())   // updateMaxOilSaturation_ (eclproblem.hh:2110-2141)
+            for (int c = 0; c < Nb; ++c) P.maxOilSaturation[c] = std::max(P.maxOilSaturation[c], iqV[c].S[OIL]);
         storageFrozen = false;
         if (limits_active()) {
             if (lastRs.empty() && lastRv.empty()) update_composition_change_limits();
@@ -512,6 +534,10 @@ struct Model {
         const double RvMax = P.rvMax.empty() ? std::numeric_limits<double>::max() / 2.0 : P.rvMax[c];
         double* x = &pv[(size_t)c * 3];
         const double Sw = x[PV_SW];
+        // VAPPARS in the switches (BlackOilPrimaryVariables::adaptPrimaryVariables: SoMax = max(So, problem.maxOilSaturation))
+        const bool vap = !P.maxOilSaturation.empty();
+        auto vap_rs = [&](double So) { return vap ? vappars_factor<double>(So, std::max(So, P.maxOilSaturation[c]), P.vapPar2) : 1.0; };
+        auto vap_rv = [&](double So) { return vap ? vappars_factor<double>(So, std::max(So, P.maxOilSaturation[c]), P.vapPar1) : 1.0; };
         const double thresholdWaterFilledCell = 1.0;  // static const 1.0 - eps of the first call (eps = 0)
         // special case: cells with (almost) only water
         if (Sw >= thresholdWaterFilledCell) {
@@ -526,7 +552,7 @@ struct Model {
             const double So = 1.0 - Sw - Sg;
             if (Sg < -eps && So > 0.0) {   // the gas phase disappears: { Sw, po, Rs }
                 const double po = x[PV_P];
-                const double RsSat = F.oil[pr].rsSat(po);
+                const double RsSat = F.oil[pr].rsSat(po) * vap_rs(So);
                 meaning[c] = Sw_po_Rs;
                 x[PV_X] = std::min(RsMax, RsSat);
                 return true;
@@ -537,7 +563,7 @@ struct Model {
                 if (!P.eps.empty()) F.sat[sr].capillaryPressuresEps(pC, Sw, Sg, P.eps[c], P.epsCfg);
                 else F.sat[sr].capillaryPressures(pC, Sw, Sg);   // computeCapillaryPressures_(pC, So = 0, Sg, Sw)
                 const double pg = po + (pC[GAS] - pC[OIL]);
-                const double RvSat = F.wetGas[pr].rvSat(pg);
+                const double RvSat = F.wetGas[pr].rvSat(pg) * vap_rv(So);
                 meaning[c] = Sw_pg_Rv;
                 x[PV_P] = pg;
                 x[PV_X] = std::min(RvMax, RvSat);
@@ -547,14 +573,14 @@ struct Model {
         }
         if (meaning[c] == Sw_po_Rs) {
             const double po = x[PV_P];
-            const double RsSat = F.oil[pr].rsSat(po);
+            const double RsSat = F.oil[pr].rsSat(po) * vap_rs(1.0 - Sw);   // no gas: So = 1 - Sw
             const double Rs = x[PV_X];
             if (Rs > std::min(RsMax, RsSat * (1.0 + eps))) { meaning[c] = Sw_po_Sg; x[PV_X] = 0.0; return true; }
             return false;
         }
         // Sw_pg_Rv: the oil phase appears as soon as the gas holds more oil than saturated gas does
         const double pg = x[PV_P];
-        const double RvSat = F.wetGas[pr].rvSat(pg);
+        const double RvSat = F.wetGas[pr].rvSat(pg) * vap_rv(0.0);   // no oil phase: So = 0
         const double Rv = x[PV_X];
         if (Rv > std::min(RvMax, RvSat * (1.0 + eps))) {
             meaning[c] = Sw_po_Sg;

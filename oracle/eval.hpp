@@ -64,6 +64,16 @@ inline Ev& operator/=(Ev& a, double b) { a = a / b; return a; }
 inline Ev max(const Ev& a, const Ev& b) { return (a.v > b.v) ? a : b; }
 inline Ev min(const Ev& a, const Ev& b) { return (a.v < b.v) ? a : b; }
 inline double max(double a, double b) { return (a > b) ? a : b; }
+// Opm::pow(Evaluation, Scalar): value std::pow(x, e); derivative e * x^(e-1) formed as pow_x / x * e (UNVERIFIED)
+inline Ev pow(const Ev& a, double e) {
+    Ev r;
+    const double px = std::pow(a.v, e);
+    r.v = px;
+    const double df = (a.v == 0.0) ? 0.0 : px / a.v * e;
+    for (int i = 0; i < 3; ++i) r.d[i] = df * a.d[i];
+    return r;
+}
+inline double pow(double a, double e) { return std::pow(a, e); }
 inline double min(double a, double b) { return (a < b) ? a : b; }
 
 }  // namespace orc

@@ -584,6 +584,25 @@ int orc_bo_set_irreversible_compaction(orc_model* h, int enable) {
     M.update_all_iq();
     return 0;
 }
+// VAPPARS: vap1 (oil vaporisation propensity, on RvSat), vap2 (gas re-dissolution, on RsSat); enable = 0: keyword not in force.
+// maxOilSaturation_ starts from the state now present (eclproblem.hh:2291-2292)
+int orc_bo_set_vappars(orc_model* h, int enable, double vap1, double vap2) {
+    Model& M = h->M;
+    M.P.maxOilSaturation.clear();
+    M.P.vapPar1 = vap1; M.P.vapPar2 = vap2;
+    if (enable) {
+        const int Nb = M.P.pat.Nb;
+        M.P.maxOilSaturation.assign(Nb, 0.0);
+        for (int c = 0; c < Nb; ++c) M.P.maxOilSaturation[c] = std::max(M.P.maxOilSaturation[c], M.iqV[c].S[OIL]);
+    }
+    M.update_all_iq();
+    return 0;
+}
+int orc_bo_get_max_oil_saturation(orc_model* h, double* out) {
+    Model& M = h->M;
+    for (int c = 0; c < M.P.pat.Nb; ++c) out[c] = M.P.maxOilSaturation.empty() ? 0.0 : M.P.maxOilSaturation[c];
+    return 0;
+}
 int orc_bo_begin_time_step(orc_model* h, double dt) { h->M.begin_time_step(dt); return 0; }
 // trackers, for tests: out[0..Nb) lastRs, [Nb..2Nb) lastRv, [2Nb..3Nb) minOilPressure (0 where not kept)
 int orc_bo_get_trackers(orc_model* h, double* out) {

@@ -164,6 +164,8 @@ class OracleModel:
         L.orc_bo_set_irreversible_compaction.argtypes = [_vp, C.c_int]
         L.orc_bo_begin_time_step.argtypes = [_vp, C.c_double]
         L.orc_bo_get_trackers.argtypes = [_vp, _d]
+        L.orc_bo_set_vappars.argtypes = [_vp, C.c_int, C.c_double, C.c_double]
+        L.orc_bo_get_max_oil_saturation.argtypes = [_vp, _d]
         L.orc_bo_end_time_step.argtypes = [_vp, C.c_double]
         L.orc_bo_set_drift_compensation.argtypes = [_vp, C.c_int, C.c_double]
         L.orc_bo_get_drift.argtypes = [_vp, _d]
@@ -211,10 +213,15 @@ class OracleModel:
     def begin_time_step(self, dt):
         self.o.lib.orc_bo_begin_time_step(self.h, dt)
 
+    def set_vappars(self, vap1, vap2, enable=True):
+        self.o.lib.orc_bo_set_vappars(self.h, int(enable), float(vap1), float(vap2))
+
     def trackers(self):
         out = np.empty(3 * self.Nb)
         self.o.lib.orc_bo_get_trackers(self.h, out)
-        return out[:self.Nb], out[self.Nb:2 * self.Nb], out[2 * self.Nb:]
+        mx = np.empty(self.Nb)
+        self.o.lib.orc_bo_get_max_oil_saturation(self.h, mx)
+        return out[:self.Nb], out[self.Nb:2 * self.Nb], out[2 * self.Nb:], mx
 
     def set_pcw(self, pcw):
         a = None if pcw is None else np.ascontiguousarray(pcw, np.float64)

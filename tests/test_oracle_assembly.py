@@ -268,3 +268,24 @@ def test_rocktab_jacobian_matches_finite_differences(pkg, orc):
     iq = m.iq()
     assert iq[:, 17, 0].min() < 0.99 and iq[:, 17, 0].max() > 0.9 and np.abs(iq[:, 17, 2]).max() > 0   # tmult active, depends on p
     _fd_check(case, m, tol=5e-5)
+
+
+def test_vappars_jacobian_matches_finite_differences(pkg, orc):
+    """VAPPARS (maximum oil saturation below which the saturated Rs / Rv shrink with (S_o / S_o,max)^vap): the AD derivative
+    of the power against central differences, with oil saturations below the tracked maximum"""
+    import helpers
+    case = helpers.wetgas_case(pkg, 4, 4, 5, heterogeneous=True)
+    m = oracle_bind.OracleModel(orc, case)
+    m.set_state(case["pv"], case["meaning"])
+    m.set_vappars(0.5, 0.8)
+    pv = case["pv"].reshape(-1, 3).copy()
+    pv[case["meaning"] == 0, 2] += 0.06
+    pv[:, 0] += 0.02
+    shifted = dict(case, pv=np.ascontiguousarray(pv.reshape(-1)))
+    m.set_state(shifted["pv"], case["meaning"])
+    a = m.iq()
+    m.set_vappars(0.0, 0.0, enable=False)
+    assert not np.array_equal(a[:, 15, 0], m.iq()[:, 15, 0])
+    m.set_state(case["pv"], case["meaning"])
+    m.set_vappars(0.5, 0.8)
+    _fd_check(shifted, m, tol=5e-5)
