@@ -269,7 +269,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--n", type=int, default=100, help="cells per edge of the per-GPU cube")
     ap.add_argument("--reorder", default="line_coloring")
-    ap.add_argument("--chain-length", type=int, default=8, help="rows per chain of the line-coloured ILU0 ordering")
+    ap.add_argument("--chain-length", type=int, default=10, help="rows per chain of the line-coloured ILU0 ordering (10 divides the 100-cell columns evenly: 7 % more Newton its/s than 8 in the steady window, 1 % fewer in the start-up window)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--steady-after", type=int, default=200, help="second timed window starts at this Newton iteration (0: none)")
     ap.add_argument("--steady-steps", type=int, default=100)

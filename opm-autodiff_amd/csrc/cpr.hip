@@ -186,8 +186,10 @@ __global__ __launch_bounds__(64) void k_cpr_dense_solve(int n, const double* __r
         x[i] = s / lu[(size_t)i * n + i];
     }
 }
-// r_p[i] = sum_k d_i[k] w_i[k]  (moveToCoarseLevel, :141-160)
+// r_p[i] = sum_k d_i[k] w_i[k]  (moveToCoarseLevel, :141-160); x0 != NULL: the level's pre-smoothing from x = 0 rides along,
+// x0[i] = omega D^-1 r_p[i] - the statement of k_cpr_presmooth, one launch less
 __global__ __launch_bounds__(256) void k_cpr_restrict_fine(int Nb, const double* __restrict__ d, const double* __restrict__ w, double* __restrict__ rc,
+                                                           double omega, const double* __restrict__ dinv, double* __restrict__ x0,
                                                            const double* __restrict__ done) {
     CPR_DONE_CHECK
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -195,6 +197,7 @@ __global__ __launch_bounds__(256) void k_cpr_restrict_fine(int Nb, const double*
     double s = 0.0;
     for (int k = 0; k < BS; ++k) s += d[(size_t)i * BS + k] * w[(size_t)i * BS + k];
     rc[i] = s;
+    if (x0) x0[i] = omega * dinv[i] * s;
 }
 // coarsest level without a direct solve: x = omega D^-1 b, then Jacobi sweeps x_out = x_in + omega D^-1 (b - A x_in)
 __global__ __launch_bounds__(256) void k_cpr_presmooth(int n, double omega, const double* __restrict__ dinv, const double* __restrict__ b, double* __restrict__ x,
@@ -306,14 +309,17 @@ __global__ __launch_bounds__(256) void k_cpr_up_lpr(int n, int W, double omega, 
         xout[i] = xi + omega * dinv[i] * s;
     }
 }
+// xc != NULL: the coarse level's pre-smoothing from x = 0 rides along (xc[I] = omega D_c^-1 rc[I], k_cpr_presmooth's statement)
 __global__ __launch_bounds__(256) void k_cpr_restrict(int nc, const int* __restrict__ mptr, const int* __restrict__ midx, const double* __restrict__ r,
-                                                      double* __restrict__ rc, const double* __restrict__ done) {
+                                                      double* __restrict__ rc, double omega, const double* __restrict__ dinvc, double* __restrict__ xc,
+                                                      const double* __restrict__ done) {
     CPR_DONE_CHECK
     const int I = blockIdx.x * blockDim.x + threadIdx.x;
     if (I >= nc) return;
     double s = 0.0;
     for (int q = mptr[I]; q < mptr[I + 1]; ++q) s += r[midx[q]];
     rc[I] = s;
+    if (xc) xc[I] = omega * dinvc[I] * s;
 }
 // going up: damped piecewise-constant prolongation x' = x + damp xc[agg], then the residual of x' and the post-smoothing
 // xout = x' + omega D^-1 (b - A x') (large levels: two passes, one gather per entry; small levels: k_cpr_up_lpr forms the
@@ -324,16 +330,23 @@ __global__ __launch_bounds__(256) void k_cpr_prolong(int n, double damp, const i
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n) xp[i] = x[i] + damp * xc[agg[i]];
 }
+// vfine != NULL (level 0): the result goes straight into the block vector v = (0, x_p, 0) (moveToFineLevel: the pressure
+// component only) - k_cpr_prolong_fine's statement, one launch and one pass over x_p less
 __global__ __launch_bounds__(256) void k_cpr_post(int n, int W, double omega, const int* __restrict__ ecol, const double* __restrict__ val,
                                                   const double* __restrict__ dinv, const double* __restrict__ b, const double* __restrict__ xp,
-                                                  double* __restrict__ xout, const double* __restrict__ done) {
+                                                  double* __restrict__ xout, double* __restrict__ vfine, const double* __restrict__ done) {
     CPR_DONE_CHECK
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     double s = b[i];
 #pragma unroll 4
     for (int j = 0; j < W; ++j) s -= val[(size_t)j * n + i] * xp[ecol[(size_t)j * n + i]];
-    xout[i] = xp[i] + omega * dinv[i] * s;
+    const double xo = xp[i] + omega * dinv[i] * s;
+    if (vfine) {
+        double* v = &vfine[(size_t)i * BS];
+#pragma unroll
+        for (int k = 0; k < BS; ++k) v[k] = (k == CPR_P) ? xo : 0.0;
+    } else xout[i] = xo;
 }
 // v = (0, x_p, 0)  (moveToFineLevel: the pressure component only)
 __global__ __launch_bounds__(256) void k_cpr_prolong_fine(int Nb, const double* __restrict__ xc, double* __restrict__ v, const double* __restrict__ done) {
@@ -577,18 +590,26 @@ int cpr_update(opmhip_ctx* c) {
     return OPMHIP_SUCCESS;
 }
 
-// one V(1,1) cycle on level l from x = 0; returns the buffer that holds the level's result
-static const double* cpr_vcycle(opmhip_ctx* c, size_t l) {
+// does level l take its pre-smoothed iterate x = omega D^-1 b from the kernel that produces b (the restriction above it)?
+static bool cpr_presmooth_rides(const CprDev& R, size_t l) {
+    const CprLevelDev& L = R.lv[l];
+    if (l + 1 == R.lv.size()) return !R.coarse_direct;   // Jacobi coarse "solve": starts with the same statement
+    return !L.rm;                                         // lane-group levels form it on the fly inside k_cpr_down_lpr
+}
+// one V(1,1) cycle on level l from x = 0; returns the buffer that holds the level's result (fineOut != NULL on level 0: the
+// result is written there as the block vector (0, x_p, 0) instead, and NULL comes back)
+static const double* cpr_vcycle(opmhip_ctx* c, size_t l, double* fineOut = nullptr) {
     CprDev& R = c->cpr;
     CprLevelDev& L = R.lv[l];
     const double* done = c->d_done;
+    const bool havex = cpr_presmooth_rides(R, l);   // L.d_x = omega D^-1 b is there already
     if (l + 1 == R.lv.size()) {
         if (R.coarse_direct) {
             hipLaunchKernelGGL(k_cpr_dense_solve, dim3(1), dim3(64), 0, c->stream, L.n, R.d_lu, L.d_b, L.d_x, done);
             return L.d_x;
         }
         // could not coarsen further: Jacobi sweeps stand in for the coarse solve (oracle/cpr.hpp: 1 + 4)
-        hipLaunchKernelGGL(k_cpr_presmooth, g256(L.n), dim3(256), 0, c->stream, L.n, R.omega, L.d_dinv, L.d_b, L.d_x, done);
+        if (!havex) hipLaunchKernelGGL(k_cpr_presmooth, g256(L.n), dim3(256), 0, c->stream, L.n, R.omega, L.d_dinv, L.d_b, L.d_x, done);
         double *xin = L.d_x, *xout = L.d_x2;
         for (int sweep = 0; sweep < 4; ++sweep) {
             if (L.rm) hipLaunchKernelGGL(k_cpr_jacobi_lpr, g256(L.n * CPR_LPR), dim3(256), 0, c->stream, L.n, L.W, R.omega, L.d_ecol, L.d_val, L.d_dinv, L.d_b, xin, xout, done);
@@ -599,16 +620,21 @@ static const double* cpr_vcycle(opmhip_ctx* c, size_t l) {
     }
     CprLevelDev& C = R.lv[l + 1];
     if (L.rm) hipLaunchKernelGGL(k_cpr_down_lpr, g256(L.n * CPR_LPR), dim3(256), 0, c->stream, L.n, L.W, R.omega, L.d_ecol, L.d_val, L.d_dinv, L.d_b, L.d_x, L.d_r, done);
-    else {   // large levels: x first, then the residual with ONE gathered value per entry (0.250 -> 0.243 ms per cycle against the fused form, which gathers dinv and b)
-        hipLaunchKernelGGL(k_cpr_presmooth, g256(L.n), dim3(256), 0, c->stream, L.n, R.omega, L.d_dinv, L.d_b, L.d_x, done);
+    else {   // large levels: x first (it rides in the kernel that produced b), then the residual with ONE gathered value per entry (0.250 -> 0.243 ms per cycle against the fused form, which gathers dinv and b)
+        if (!havex) hipLaunchKernelGGL(k_cpr_presmooth, g256(L.n), dim3(256), 0, c->stream, L.n, R.omega, L.d_dinv, L.d_b, L.d_x, done);
         hipLaunchKernelGGL(k_cpr_resid, g256(L.n), dim3(256), 0, c->stream, L.n, L.W, L.d_ecol, L.d_val, L.d_b, L.d_x, L.d_r, done);
     }
-    hipLaunchKernelGGL(k_cpr_restrict, g256(L.nc), dim3(256), 0, c->stream, L.nc, L.d_mptr, L.d_midx, L.d_r, C.d_b, done);
+    {
+        const bool ride = cpr_presmooth_rides(R, l + 1);
+        hipLaunchKernelGGL(k_cpr_restrict, g256(L.nc), dim3(256), 0, c->stream, L.nc, L.d_mptr, L.d_midx, L.d_r, C.d_b, R.omega,
+                           ride ? C.d_dinv : (const double*)nullptr, ride ? C.d_x : (double*)nullptr, done);
+    }
     const double* xc = cpr_vcycle(c, l + 1);
     if (L.rm) hipLaunchKernelGGL(k_cpr_up_lpr, g256(L.n * CPR_LPR), dim3(256), 0, c->stream, L.n, L.W, R.omega, R.damp, L.d_ecol, L.d_val, L.d_dinv, L.d_agg, xc, L.d_b, L.d_x, L.d_x2, done);
     else {   // large levels: the prolonged iterate first (into the residual buffer, free by now), then one gathered value per entry
         hipLaunchKernelGGL(k_cpr_prolong, g256(L.n), dim3(256), 0, c->stream, L.n, R.damp, L.d_agg, xc, L.d_x, L.d_r, done);
-        hipLaunchKernelGGL(k_cpr_post, g256(L.n), dim3(256), 0, c->stream, L.n, L.W, R.omega, L.d_ecol, L.d_val, L.d_dinv, L.d_b, L.d_r, L.d_x2, done);
+        hipLaunchKernelGGL(k_cpr_post, g256(L.n), dim3(256), 0, c->stream, L.n, L.W, R.omega, L.d_ecol, L.d_val, L.d_dinv, L.d_b, L.d_r, L.d_x2, fineOut, done);
+        if (fineOut) return nullptr;
     }
     return L.d_x2;
 }
@@ -620,9 +646,15 @@ void launch_cpr_apply(opmhip_ctx* c, const double* d, double* v) {
     const int n = P.Nb * BS;
     const double* done = c->d_done;
     int ps = prof_begin(c, PROF_CPR_AMG);
-    hipLaunchKernelGGL(k_cpr_restrict_fine, g256(P.Nb), dim3(256), 0, c->stream, P.Nb, d, R.d_w, R.lv[0].d_b, done);
-    const double* xp = cpr_vcycle(c, 0);
-    hipLaunchKernelGGL(k_cpr_prolong_fine, g256(n), dim3(256), 0, c->stream, P.Nb, xp, v, done);
+    {
+        const bool ride = cpr_presmooth_rides(R, 0);
+        hipLaunchKernelGGL(k_cpr_restrict_fine, g256(P.Nb), dim3(256), 0, c->stream, P.Nb, d, R.d_w, R.lv[0].d_b, R.omega,
+                           ride ? R.lv[0].d_dinv : (const double*)nullptr, ride ? R.lv[0].d_x : (double*)nullptr, done);
+    }
+    // level 0 of a hierarchy with more than one level that is not a lane-group level writes v = (0, x_p, 0) itself
+    const bool direct = R.lv.size() > 1 && !R.lv[0].rm;
+    const double* xp = cpr_vcycle(c, 0, direct ? v : nullptr);
+    if (xp) hipLaunchKernelGGL(k_cpr_prolong_fine, g256(n), dim3(256), 0, c->stream, P.Nb, xp, v, done);
     prof_end(c, ps);
     (void)launch_spmv(c, v, R.d_y, 0, nullptr);                      // post-smoothing on the updated residual
     ps = prof_begin(c, PROF_VECTOR);

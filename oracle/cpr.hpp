@@ -257,6 +257,326 @@ struct CprAmg {
     }
 };
 
+// ---- the reference's pressure AMG, restated for comparison ----------------------------------------------------------------
+// Dune::Amg as opm-simulators configures it (linalg/PreconditionerFactory.hpp:126-151, setupPropertyTree.cpp:116-137):
+// AggregationCriterion<SymmetricDependency<Matrix, FirstDiagonal>>, alpha 1/3, beta 1e-5, maxDistance 2, aggregates of 4 to 6
+// vertices, maxConnectivity 15, coarsenTarget 1200 unknowns, at most 15 levels, minimal coarsening rate 1.2, piecewise-constant
+// prolongation damped by 1.6, ILU0 (relaxation 1) as pre- and post-smoother (1 + 1 steps), V-cycle, direct solve on the
+// coarsest level.  dune-istl is NOT in the reference tree: this is a restatement of its published algorithm
+// (dune-istl/paamg/aggregates.hh: Aggregator::build / growAggregate / the rounding step / mergeNeighbour; dependency.hh:
+// SymmetricDependency; amg.hh: mgc) from the sources as I know them - UNVERIFIED, and where the published code breaks ties
+// through internal bookkeeping (connectivity counters over neighbouring aggregates, front ordering) this restatement breaks
+// them on the lowest vertex index.  It is ORACLE-ONLY and exists for one purpose: a yardstick for the product's own pressure
+// AMG (pairwise matching + Jacobi, CprAmg above) - how many CPR-BiCGStab iterations the reference's kind of hierarchy needs
+// on the same Jacobians (tools/cpr_amg_compare.py).
+struct DuneLikeAmg {
+    struct Level {
+        Csr A;
+        std::vector<double> ilu;       // scalar ILU0 factors in A's pattern: strict lower = L, diagonal = 1 / U_ii, strict upper = U
+        std::vector<int> diag;
+        std::vector<int> agg;          // vertex -> aggregate (empty on the coarsest level)
+        int nc = 0;
+        std::vector<int> gptr, gidx;   // Galerkin gather lists (as in CprAmg)
+    };
+    std::vector<Level> lv;
+    std::vector<double> lu;            // dense LU of the coarsest level
+    double alpha = 1.0 / 3.0, beta = 1e-5, damp = 1.6, minCoarsenRate = 1.2;
+    int maxDistance = 2, minAgg = 4, maxAgg = 6, coarsenTarget = 1200, maxLevel = 15;
+
+    // SymmetricDependency with the sign-preserving norm FirstDiagonal: only negative off-diagonal pairs count;
+    // strength e_ij e_ji / (a_ii a_jj); edge strong if > alpha * row maximum; vertex isolated if its maximum < beta
+    void dependency(const Csr& A, std::vector<char>& strong, std::vector<char>& isolated) const {
+        const int n = A.n;
+        std::vector<double> d(n, 1.0);
+        for (int i = 0; i < n; ++i)
+            for (int k = A.rowptr[i]; k < A.rowptr[i + 1]; ++k)
+                if (A.col[k] == i) d[i] = A.val[k];
+        auto entry = [&](int r, int c, double& v) {   // a_rc if present
+            const int* b = &A.col[A.rowptr[r]];
+            const int* e = &A.col[A.rowptr[r + 1]];
+            const int* q = std::lower_bound(b, e, c);
+            if (q == e || *q != c) return false;
+            v = A.val[q - &A.col[0]];
+            return true;
+        };
+        strong.assign(A.col.size(), 0);
+        isolated.assign(n, 0);
+        for (int i = 0; i < n; ++i) {
+            double maxValue = -std::numeric_limits<double>::max();
+            for (int k = A.rowptr[i]; k < A.rowptr[i + 1]; ++k) {
+                const int j = A.col[k];
+                const double eij = A.val[k];
+                double eji;
+                if (j == i || !(eij < 0.0) || !entry(j, i, eji) || !(eji < 0.0)) continue;
+                maxValue = std::max(maxValue, eij / d[i] * eji / d[j]);
+            }
+            isolated[i] = maxValue < beta;
+            for (int k = A.rowptr[i]; k < A.rowptr[i + 1]; ++k) {
+                const int j = A.col[k];
+                const double eij = A.val[k];
+                double eji;
+                if (j == i || !(eij < 0.0) || !entry(j, i, eji)) continue;
+                if (eji / d[j] * eij / d[i] > alpha * maxValue) strong[k] = 1;
+            }
+        }
+        // depends / influences are set on both directions of an edge
+        for (int i = 0; i < n; ++i)
+            for (int k = A.rowptr[i]; k < A.rowptr[i + 1]; ++k)
+                if (strong[k]) {
+                    const int j = A.col[k];
+                    const int* b = &A.col[A.rowptr[j]];
+                    const int* q = std::lower_bound(b, &A.col[A.rowptr[j + 1]], i);
+                    strong[q - &A.col[0]] = 1;
+                }
+    }
+    // Aggregator::build: seeds in index order; growAggregate up to minAgg vertices within maxDistance; the rounding step up to
+    // maxAgg; a one-vertex aggregate joins a neighbouring aggregate (mergeNeighbour); isolated vertices stay alone
+    void aggregate(const Csr& A, std::vector<int>& agg, int& na) const {
+        const int n = A.n;
+        std::vector<char> strong, isolated;
+        dependency(A, strong, isolated);
+        agg.assign(n, -1);
+        na = 0;
+        std::vector<int> members, front, distOf(n, -1);
+        auto strong_into = [&](int v, int id) {   // twoWayConnections
+            int c = 0;
+            for (int k = A.rowptr[v]; k < A.rowptr[v + 1]; ++k) c += (strong[k] && agg[A.col[k]] == id);
+            return c;
+        };
+        auto nb_counts = [&](int v, int id, int& inAgg, int& freeNb, int& all) {
+            inAgg = freeNb = all = 0;
+            for (int k = A.rowptr[v]; k < A.rowptr[v + 1]; ++k) {
+                const int j = A.col[k];
+                if (j == v) continue;
+                ++all;
+                inAgg += agg[j] == id;
+                freeNb += agg[j] < 0;
+            }
+        };
+        auto rebuild_front = [&](int id) {   // unaggregated neighbours (any edge) of the members, ascending
+            front.clear();
+            for (int m : members)
+                for (int k = A.rowptr[m]; k < A.rowptr[m + 1]; ++k)
+                    if (agg[A.col[k]] < 0) front.push_back(A.col[k]);
+            std::sort(front.begin(), front.end());
+            front.erase(std::unique(front.begin(), front.end()), front.end());
+            (void)id;
+        };
+        auto distance_from = [&](int seed, int id, int extra) {   // largest graph distance from the seed inside the aggregate (+ extra vertex)
+            std::vector<int> q{seed};
+            std::vector<int> touched{seed};
+            distOf[seed] = 0;
+            int far = 0;
+            for (size_t h = 0; h < q.size(); ++h) {
+                const int v = q[h];
+                for (int k = A.rowptr[v]; k < A.rowptr[v + 1]; ++k) {
+                    const int j = A.col[k];
+                    if (distOf[j] >= 0 || (agg[j] != id && j != extra)) continue;
+                    distOf[j] = distOf[v] + 1;
+                    far = std::max(far, distOf[j]);
+                    q.push_back(j); touched.push_back(j);
+                }
+            }
+            const int de = extra >= 0 ? distOf[extra] : far;
+            for (int v : touched) distOf[v] = -1;
+            return extra >= 0 ? (de < 0 ? 1 << 20 : de) : far;
+        };
+        for (int seed = 0; seed < n; ++seed) {
+            if (agg[seed] >= 0) continue;
+            const int id = na++;
+            members.assign(1, seed);
+            agg[seed] = id;
+            if (!isolated[seed]) {
+                // growAggregate
+                int dist = 0;
+                while ((int)members.size() < minAgg && dist < maxDistance) {
+                    rebuild_front(id);
+                    int bestTwo = 0, bestFrontNb = -1;
+                    double bestCon = -1.0;
+                    std::vector<int> cand;
+                    for (int v : front) {
+                        if (isolated[v]) continue;
+                        const int two = strong_into(v, id);
+                        if (two == 0) continue;
+                        int inAgg, freeNb, all;
+                        nb_counts(v, id, inAgg, freeNb, all);
+                        const double con = all > 0 ? (double)inAgg / all : 0.0;
+                        int frontNb = 0;   // noFrontNeighbours
+                        for (int k = A.rowptr[v]; k < A.rowptr[v + 1]; ++k) frontNb += std::binary_search(front.begin(), front.end(), A.col[k]) && A.col[k] != v;
+                        if (two > bestTwo || (two == bestTwo && (con > bestCon || (con == bestCon && frontNb > bestFrontNb)))) {
+                            bestTwo = two; bestCon = con; bestFrontNb = frontNb;
+                            cand.assign(1, v);
+                        } else if (two == bestTwo && con == bestCon && frontNb == bestFrontNb) cand.push_back(v);
+                    }
+                    if (cand.empty()) break;
+                    if ((int)cand.size() > maxAgg - (int)members.size()) cand.resize(maxAgg - (int)members.size());
+                    for (int v : cand) { agg[v] = id; members.push_back(v); }
+                    dist = distance_from(seed, id, -1);
+                }
+                // the rounding step: a front vertex with a strong connection that has more neighbours inside than free ones
+                while ((int)members.size() < maxAgg) {
+                    rebuild_front(id);
+                    int pick = -1;
+                    for (int v : front) {
+                        if (isolated[v] || strong_into(v, id) == 0) continue;
+                        int inAgg, freeNb, all;
+                        nb_counts(v, id, inAgg, freeNb, all);
+                        if (freeNb >= inAgg) continue;
+                        if (distance_from(seed, id, v) > maxDistance) continue;
+                        pick = v;
+                        break;
+                    }
+                    if (pick < 0) break;
+                    agg[pick] = id;
+                    members.push_back(pick);
+                }
+                // mergeNeighbour: a lone non-isolated vertex joins the aggregate of its first aggregated, non-isolated neighbour
+                if (members.size() == 1) {
+                    int target = -1;
+                    for (int k = A.rowptr[seed]; k < A.rowptr[seed + 1] && target < 0; ++k) {
+                        const int j = A.col[k];
+                        if (j != seed && agg[j] >= 0 && agg[j] != id && !isolated[j]) target = agg[j];
+                    }
+                    if (target >= 0) { agg[seed] = target; --na; }
+                }
+            }
+        }
+    }
+    static void ilu0_scalar(const Csr& A, const std::vector<int>& diag, std::vector<double>& f) {
+        f = A.val;
+        const int n = A.n;
+        for (int i = 0; i < n; ++i) {
+            for (int k = A.rowptr[i]; k < diag[i]; ++k) {
+                const int j = A.col[k];
+                f[k] = f[k] * f[diag[j]];                 // l_ij = a_ij / u_jj (the diagonal holds the inverse)
+                int p = k + 1, q = diag[j] + 1;
+                while (p < A.rowptr[i + 1] && q < A.rowptr[j + 1]) {
+                    if (A.col[p] == A.col[q]) { f[p] -= f[k] * f[q]; ++p; ++q; }
+                    else if (A.col[p] < A.col[q]) ++p;
+                    else ++q;
+                }
+            }
+            f[diag[i]] = 1.0 / f[diag[i]];
+        }
+    }
+    static void ilu0_apply(const Level& L, const double* d, double* v) {
+        const Csr& A = L.A;
+        const int n = A.n;
+        for (int i = 0; i < n; ++i) {
+            double s = d[i];
+            for (int k = A.rowptr[i]; k < L.diag[i]; ++k) s -= L.ilu[k] * v[A.col[k]];
+            v[i] = s;
+        }
+        for (int i = n - 1; i >= 0; --i) {
+            double s = v[i];
+            for (int k = L.diag[i] + 1; k < A.rowptr[i + 1]; ++k) s -= L.ilu[k] * v[A.col[k]];
+            v[i] = s * L.ilu[L.diag[i]];
+        }
+    }
+    void finish(Level& L) const {
+        L.diag.assign(L.A.n, 0);
+        for (int i = 0; i < L.A.n; ++i)
+            for (int k = L.A.rowptr[i]; k < L.A.rowptr[i + 1]; ++k)
+                if (L.A.col[k] == i) L.diag[i] = k;
+        ilu0_scalar(L.A, L.diag, L.ilu);
+    }
+    void setup(const Csr& A0) {
+        lv.clear();
+        lv.emplace_back();
+        lv[0].A = A0;
+        while ((int)lv.size() < maxLevel && lv.back().A.n > coarsenTarget) {
+            Level& L = lv.back();
+            std::vector<int> agg;
+            int na = 0;
+            aggregate(L.A, agg, na);
+            if ((double)L.A.n / std::max(na, 1) < minCoarsenRate) break;   // coarsening stalls
+            // aggregate ids are dense again after the merges
+            std::vector<int> renum(L.A.n + 1, -1);
+            int nn = 0;
+            for (int i = 0; i < L.A.n; ++i)
+                if (renum[agg[i]] < 0) renum[agg[i]] = nn++;
+            for (int i = 0; i < L.A.n; ++i) agg[i] = renum[agg[i]];
+            L.agg = agg;
+            L.nc = nn;
+            Level C;
+            CprAmg::galerkin(L.A, L.agg, nn, C.A, L.gptr, L.gidx);
+            lv.push_back(std::move(C));
+        }
+        for (Level& L : lv) finish(L);
+        const Csr& C = lv.back().A;
+        const int n = C.n;
+        lu.assign((size_t)n * n, 0.0);
+        for (int i = 0; i < n; ++i)
+            for (int k = C.rowptr[i]; k < C.rowptr[i + 1]; ++k) lu[(size_t)i * n + C.col[k]] = C.val[k];
+        for (int k = 0; k < n; ++k)
+            for (int i = k + 1; i < n; ++i) {
+                const double f = lu[(size_t)i * n + k] / lu[(size_t)k * n + k];
+                lu[(size_t)i * n + k] = f;
+                if (f != 0.0)
+                    for (int j = k + 1; j < n; ++j) lu[(size_t)i * n + j] -= f * lu[(size_t)k * n + j];
+            }
+    }
+    // the hierarchy's structure is kept (as the reference's CPR keeps it between updates); values: Galerkin sums + factors
+    void update_values(const std::vector<double>& a0) {
+        lv[0].A.val = a0;
+        for (size_t l = 0; l + 1 < lv.size(); ++l) {
+            Level& L = lv[l];
+            Csr& C = lv[l + 1].A;
+            for (size_t e = 0; e < C.val.size(); ++e) {
+                double s = 0.0;
+                for (int q = L.gptr[e]; q < L.gptr[e + 1]; ++q) s += L.A.val[L.gidx[q]];
+                C.val[e] = s;
+            }
+        }
+        const std::vector<Level> keep;   // (structure untouched)
+        for (Level& L : lv) ilu0_scalar(L.A, L.diag, L.ilu);
+        const Csr& C = lv.back().A;
+        const int n = C.n;
+        lu.assign((size_t)n * n, 0.0);
+        for (int i = 0; i < n; ++i)
+            for (int k = C.rowptr[i]; k < C.rowptr[i + 1]; ++k) lu[(size_t)i * n + C.col[k]] = C.val[k];
+        for (int k = 0; k < n; ++k)
+            for (int i = k + 1; i < n; ++i) {
+                const double f = lu[(size_t)i * n + k] / lu[(size_t)k * n + k];
+                lu[(size_t)i * n + k] = f;
+                if (f != 0.0)
+                    for (int j = k + 1; j < n; ++j) lu[(size_t)i * n + j] -= f * lu[(size_t)k * n + j];
+            }
+    }
+    // AMG::mgc, V-cycle with one pre- and one post-smoothing step: x = update for the defect b (x starts at 0)
+    void vcycle(const double* b, double* x, size_t l = 0) const {
+        const Level& L = lv[l];
+        const int n = L.A.n;
+        if (l + 1 == lv.size()) {
+            for (int i = 0; i < n; ++i) {
+                double s = b[i];
+                for (int j = 0; j < i; ++j) s -= lu[(size_t)i * n + j] * x[j];
+                x[i] = s;
+            }
+            for (int i = n - 1; i >= 0; --i) {
+                double s = x[i];
+                for (int j = i + 1; j < n; ++j) s -= lu[(size_t)i * n + j] * x[j];
+                x[i] = s / lu[(size_t)i * n + i];
+            }
+            return;
+        }
+        std::vector<double> d(b, b + n), v(n), t(n);
+        ilu0_apply(L, d.data(), v.data());                              // pre-smoothing: update += M^-1 d ; d -= A v
+        for (int i = 0; i < n; ++i) x[i] = v[i];
+        CprAmg::residual(L.A, d.data(), v.data(), t.data());
+        d.swap(t);
+        std::vector<double> rc(L.nc, 0.0), xc(L.nc, 0.0);
+        for (int i = 0; i < n; ++i) rc[L.agg[i]] += d[i];               // restriction: sum over the aggregate
+        vcycle(rc.data(), xc.data(), l + 1);
+        for (int i = 0; i < n; ++i) v[i] = damp * xc[L.agg[i]];         // damped piecewise-constant prolongation
+        for (int i = 0; i < n; ++i) x[i] += v[i];
+        CprAmg::residual(L.A, d.data(), v.data(), t.data());
+        d.swap(t);
+        ilu0_apply(L, d.data(), v.data());                              // post-smoothing
+        for (int i = 0; i < n; ++i) x[i] += v[i];
+    }
+};
+
 // True-IMPES weights of one cell (opm/simulators/linalg/getQuasiImpesWeights.hpp:89-128): block[ii][jj] = d storage_ii /
 // d x_jj / (V / dt), the pressure column times 50e5; block^T w = e_p; w /= 1000.  dS: derivatives of the storage term
 // (equation x primary variable).  The reference solves with Dune's FieldMatrix::solve - an LU with partial pivoting whose
@@ -301,6 +621,8 @@ struct Cpr {
     std::vector<double> w;          // weights, Nb x 3: quasi-IMPES from the matrix, or handed in (true-IMPES: they need the model)
     std::vector<double> w_given;    // non-empty: use these
     CprAmg amg;
+    DuneLikeAmg dune;               // the reference's kind of hierarchy (comparison only)
+    bool useDune = false;
     bool structured = false;
 
     static void quasi_impes_weights(const Bcrs& A, std::vector<double>& w) {
@@ -341,9 +663,10 @@ struct Cpr {
         if (!structured) {
             Csr P;
             P.n = Ain.Nb; P.rowptr = Ain.rowptr; P.col = Ain.col; P.val = ap;
-            amg.setup_structure(P);
+            if (useDune) dune.setup(P); else amg.setup_structure(P);
             structured = true;
-        } else amg.update_values(ap);
+        } else if (useDune) dune.update_values(ap);
+        else amg.update_values(ap);
         return 0;
     }
     // v = M^-1 d (TwoLevelMethodCpr::apply with 0 pre- and 1 post-smoothing step)
@@ -356,7 +679,8 @@ struct Cpr {
             for (int k = 0; k < BS; ++k) s += d[(size_t)i * BS + k] * w[(size_t)i * BS + k];
             rc[i] = s;
         }
-        amg.vcycle(rc.data(), xc.data());
+        if (useDune) { std::fill(xc.begin(), xc.end(), 0.0); dune.vcycle(rc.data(), xc.data()); }
+        else amg.vcycle(rc.data(), xc.data());
         for (size_t e = 0; e < n; ++e) v[e] = 0.0;                    // moveToFineLevel: pressure component only
         for (int i = 0; i < Nb; ++i) v[(size_t)i * BS + CPR_PRESSURE_INDEX] = xc[i];
         spmv(*A, v, y.data());                                       // post-smoothing on the updated residual

@@ -260,6 +260,15 @@ orc_cpr* orc_cpr_create(double omega, double damp, double beta) {
     return h;
 }
 void orc_cpr_destroy(orc_cpr* h) { delete h; }
+// which pressure AMG the handle uses: 0 = the product's (pairwise matching + Jacobi), 1 = the restatement of the reference's
+// (Dune::Amg-like aggregation + ILU0 smoothing + direct coarse solve; comparison only).  Before the first update / solve.
+int orc_cpr_use_reference_amg(orc_cpr* h, int on) { h->P.useDune = on != 0; h->P.structured = false; return 0; }
+// levels of that hierarchy
+int orc_cpr_reference_amg_levels(orc_cpr* h, int* n, int* nnz, int cap) {
+    const int L = (int)h->P.dune.lv.size();
+    for (int l = 0; l < L && l < cap; ++l) { n[l] = h->P.dune.lv[l].A.n; nnz[l] = (int)h->P.dune.lv[l].A.col.size(); }
+    return L;
+}
 // BiCGStab with the CPR preconditioner on the system AS GIVEN (callers hand over the matrix in the ordering they want the
 // ILU0 smoother and the aggregation to see); x natural to that ordering
 int orc_cpr_solve(orc_cpr* h, int Nb, const int* rowptr, const int* col, const double* val, const double* b, double* x,

@@ -51,6 +51,8 @@ class Oracle:
         L.orc_cpr_weights.argtypes = [_vp, _d]
         L.orc_cpr_set_weights.argtypes = [_vp, C.c_int, C.c_void_p]
         L.orc_cpr_aggregates.argtypes = [_vp, C.c_int, _i]
+        L.orc_cpr_use_reference_amg.argtypes = [_vp, C.c_int]
+        L.orc_cpr_reference_amg_levels.argtypes = [_vp, _i, _i, C.c_int]
 
     # ---- linear algebra -------------------------------------------------------------------
     def spmv(self, Nb, rowptr, col, val, x):
@@ -469,6 +471,15 @@ class OracleCpr:
         n, nnz = np.zeros(32, np.int32), np.zeros(32, np.int32)
         L = self.o.lib.orc_cpr_levels(self.h, n, nnz, 32)
         return list(n[:L]), list(nnz[:L])
+
+    def use_reference_amg(self, on=True):
+        """the restatement of the reference's Dune::Amg hierarchy instead of the product's (comparison only)"""
+        self.o.lib.orc_cpr_use_reference_amg(self.h, int(on))
+
+    def reference_amg_levels(self):
+        n, nnz = np.zeros(32, np.int32), np.zeros(32, np.int32)
+        L = self.o.lib.orc_cpr_reference_amg_levels(self.h, n, nnz, 32)
+        return [int(v) for v in n[:L]], [int(v) for v in nnz[:L]]
 
     def set_weights(self, w=None):
         """weights from outside (true-IMPES: OracleModel.true_impes_weights); None: quasi-IMPES again"""

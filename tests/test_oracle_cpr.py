@@ -97,3 +97,33 @@ def test_true_impes_weights_solve_their_defining_system(orc):
         block[:, 1] *= 50e5
         x = np.linalg.solve(block.T, np.array([0.0, 1.0, 0.0])) / 1000.0
         np.testing.assert_allclose(w[c], x, rtol=1e-9, atol=1e-300)
+
+
+def test_reference_like_amg_hierarchy_and_iteration_counts(pkg, orc):
+    """The restatement of the reference's pressure AMG (Dune::Amg-like aggregation: alpha 1/3, beta 1e-5, aggregates of 4-6,
+    maxDistance 2; ILU0 smoothing; direct coarse solve; oracle/cpr.hpp DuneLikeAmg) as a yardstick for the product's own
+    hierarchy: aggregates have the prescribed sizes, the preconditioner is a linear operator that reduces the residual, and
+    CPR-BiCGStab needs about as many iterations with either hierarchy on a black-oil Jacobian."""
+    case = pkg.decks.cartesian_case(20, 20, 16, state="mixed", heterogeneous=True)
+    o = oracle_bind.OracleModel(orc, case)
+    o.set_state(case["pv"], case["meaning"])
+    o.set_source(pkg.decks.five_spot_source(case, rate_sm3_per_day=40.0))
+    jac, res = o.assemble(5 * 86400.0, 0)
+    Nb, rp, ci = case["Nb"], case["rowptr"], case["col"]
+    its = {}
+    for ref in (False, True):
+        cpr = oracle_bind.OracleCpr(orc)
+        cpr.use_reference_amg(ref)
+        x, r = cpr.solve(Nb, rp, ci, jac, res, tol=1e-2, maxit=100)
+        assert r.converged
+        its[ref] = r.it
+        if ref:
+            n, nnz = cpr.reference_amg_levels()
+            assert n[0] == Nb and n[-1] <= 1200 and len(n) >= 2
+            rates = [n[l] / n[l + 1] for l in range(len(n) - 1)]
+            assert all(3.0 <= q <= 6.5 for q in rates), (n, rates)      # aggregates of 4 to 6 vertices
+            d1, d2 = np.random.default_rng(1).standard_normal((2, 3 * Nb))
+            cpr.update(Nb, rp, ci, jac)
+            assert np.allclose(cpr.apply(2.0 * d1 - 0.5 * d2), 2.0 * cpr.apply(d1) - 0.5 * cpr.apply(d2), rtol=1e-9, atol=1e-12 * np.abs(d1).max())
+    print("CPR-BiCGStab iterations to 1e-2: product's AMG %.1f, reference-like AMG %.1f" % (its[False], its[True]))
+    assert its[True] <= its[False] + 3 and its[False] <= 2 * its[True] + 3
