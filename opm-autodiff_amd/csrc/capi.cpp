@@ -301,6 +301,8 @@ int opmhip_solve_system(opmhip_ctx* c, int N, int nnz, int dim, double* vals, co
         // a singular pivot shows up as a non-finite norm: report it the way the reference's create_preconditioner does
         if (!std::isfinite(res->reduction)) {
             res->converged = 0;
+            if (use_cpr(c) && cpr_coarse_pivot_failed(c))
+                return fail(c, OPMHIP_CREATE_PRECONDITIONER_FAILED, "CPR: the dense LU of the coarsest pressure level met a zero or non-finite pivot");
             return fail(c, OPMHIP_CREATE_PRECONDITIONER_FAILED, "non-finite residual norm (singular diagonal block in ILU0?)");
         }
         return OPMHIP_SUCCESS;

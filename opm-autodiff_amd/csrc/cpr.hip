@@ -158,8 +158,11 @@ __global__ __launch_bounds__(256) void k_cpr_dense_lu(int n, int W, int rm, cons
             lu[(size_t)i * n + ecol[e]] = val[e];
         }
     __syncthreads();
+    if (threadIdx.x == 0) lu[(size_t)n * n] = 0.0;   // flag behind the factors: 1 = a pivot vanished or is not finite (no pivoting here)
     for (int k = 0; k < n; ++k) {
-        const double piv = 1.0 / lu[(size_t)k * n + k];
+        const double pv = lu[(size_t)k * n + k];
+        if (threadIdx.x == 0 && (pv == 0.0 || !isfinite(pv))) lu[(size_t)n * n] = 1.0;
+        const double piv = 1.0 / pv;
         for (int i = k + 1 + threadIdx.x; i < n; i += 256) lu[(size_t)i * n + k] = lu[(size_t)i * n + k] * piv;
         __syncthreads();
         const int m = n - k - 1;
@@ -491,7 +494,24 @@ static int cpr_weights(opmhip_ctx* c) {
     return OPMHIP_SUCCESS;
 }
 // structure of the hierarchy, once per context, from the values of the pressure matrix of the system now on the device
+static int cpr_setup_structure_impl(opmhip_ctx* c);
+// a set-up that fails half way gives back everything it allocated: a retry starts from a clean slate, nothing piles up
 static int cpr_setup_structure(opmhip_ctx* c) {
+    CprDev& R = c->cpr;
+    const size_t mark = c->allocs.size();
+    const bool hadW = R.d_w != nullptr;
+    const int rc = cpr_setup_structure_impl(c);
+    if (rc) {
+        (void)hipStreamSynchronize(c->stream);
+        while (c->allocs.size() > mark) { (void)hipFree(c->allocs.back()); c->allocs.pop_back(); }
+        R.lv.clear();
+        R.d_r = R.d_y = R.d_z = R.d_lu = nullptr;
+        if (!hadW) R.d_w = nullptr;
+        R.structured = false;
+    }
+    return rc;
+}
+static int cpr_setup_structure_impl(opmhip_ctx* c) {
     const Pattern& P = c->pat;
     CprDev& R = c->cpr;
     int rc;
@@ -534,6 +554,11 @@ static int cpr_setup_structure(opmhip_ctx* c) {
         HCsr Ac;
         std::vector<int> gptr, gidx;
         galerkin(A, agg, n2, Ac, gptr, gidx);
+        {   // a coarse level whose rows outgrow the ELL image (fault- and NNC-heavy patterns): stop here, this level is the coarsest
+            int Wc = 1;
+            for (int I = 0; I < Ac.n; ++I) Wc = std::max(Wc, Ac.rowptr[I + 1] - Ac.rowptr[I]);
+            if (Wc > CPR_MAX_W) break;
+        }
         for (int& g : gidx) g = pos[g];                       // gather lists address the fine level's ELL array
         std::vector<int> mptr(n2 + 1, 0), midx(A.n);
         for (int i = 0; i < A.n; ++i) mptr[agg[i] + 1]++;
@@ -559,7 +584,7 @@ static int cpr_setup_structure(opmhip_ctx* c) {
         A = std::move(Ac);
     }
     R.coarse_direct = R.lv.back().n <= CPR_COARSE_DIRECT;
-    if (R.coarse_direct && (rc = dev_alloc(c, &R.d_lu, (size_t)R.lv.back().n * R.lv.back().n))) return rc;
+    if (R.coarse_direct && (rc = dev_alloc(c, &R.d_lu, (size_t)R.lv.back().n * R.lv.back().n + 1))) return rc;   // + 1: the pivot flag
     R.structured = true;
     return OPMHIP_SUCCESS;
 }
@@ -680,6 +705,15 @@ int cpr_set_weights(opmhip_ctx* c, const double* w) {
     OPMHIP_HIP(c, hipStreamSynchronize(c->stream));
     R.w_given = true;
     return OPMHIP_SUCCESS;
+}
+// did the dense LU of the coarsest level meet a vanishing / non-finite pivot in the last cpr_update?  (synchronises)
+bool cpr_coarse_pivot_failed(opmhip_ctx* c) {
+    const CprDev& R = c->cpr;
+    if (!R.structured || !R.coarse_direct || !R.d_lu) return false;
+    double flag = 0.0;
+    const size_t n = (size_t)R.lv.back().n;
+    if (hipMemcpy(&flag, R.d_lu + n * n, sizeof(double), hipMemcpyDeviceToHost) != hipSuccess) return false;
+    return flag != 0.0;
 }
 int cpr_level_sizes(const opmhip_ctx* c, int* n, int* nnz, int cap) {
     const int L = (int)c->cpr.lv.size();

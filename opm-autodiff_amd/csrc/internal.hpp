@@ -385,6 +385,7 @@ int cpr_update(opmhip_ctx* c);
 void launch_cpr_apply(opmhip_ctx* c, const double* d, double* v);
 int cpr_set_weights(opmhip_ctx* c, const double* w);
 int cpr_level_sizes(const opmhip_ctx* c, int* n, int* nnz, int cap);
+bool cpr_coarse_pivot_failed(opmhip_ctx* c);
 inline bool use_cpr(const opmhip_ctx* c) { return c->cfg.preconditioner == OPMHIP_PRECOND_CPR_QUASIIMPES || c->cfg.preconditioner == OPMHIP_PRECOND_CPR_TRUEIMPES; }
 void launch_wells_apply(opmhip_ctx* c, const double* x, double* y, double xs = 1.0);
 void launch_lu_to_natural(opmhip_ctx* c, double* d_out_internal_layout);

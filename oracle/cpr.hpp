@@ -39,6 +39,7 @@ struct Csr {
 constexpr int CPR_PRESSURE_INDEX = 1;   // pressureVarIndex of BlackOilIndices (ISTLSolverEbos.hpp: pressureIndex)
 constexpr int CPR_COARSE_DIRECT = 128;  // coarsest level: dense LU up to this many unknowns
 constexpr int CPR_MAX_LEVELS = 15;      // maxlevel (setupPropertyTree.cpp:124)
+constexpr int CPR_MAX_W = 96;           // longest row of a level the product builds (its ELL images): coarsening stops before
 
 struct AmgLevel {
     Csr A;                         // level matrix (values refreshed by update_values)
@@ -161,6 +162,15 @@ struct CprAmg {
                 L.nc = n2;
                 Csr Ac;
                 galerkin(A, L.agg, n2, Ac, L.gptr, L.gidx);
+                {   // the product keeps its levels as ELL images of at most CPR_MAX_W entries per row: a wider coarse level is not built
+                    int Wc = 1;
+                    for (int I = 0; I < Ac.n; ++I) Wc = std::max(Wc, Ac.rowptr[I + 1] - Ac.rowptr[I]);
+                    if (Wc > CPR_MAX_W) {
+                        L.agg.clear(); L.nc = 0; L.gptr.clear(); L.gidx.clear();
+                        lv.push_back(L);
+                        break;
+                    }
+                }
                 L.mptr.assign(n2 + 1, 0);
                 for (int i = 0; i < A.n; ++i) L.mptr[L.agg[i] + 1]++;
                 for (int I = 0; I < n2; ++I) L.mptr[I + 1] += L.mptr[I];

@@ -167,3 +167,49 @@ def test_true_impes_weights_bitwise_and_newton(pkg, orc, wet):
         out[prec] = (rep.total_newton_iterations, rep.total_linear_iterations, rep.converged)
     assert out["cpr_trueimpes"][2] and abs(out["ilu0"][0] - out["cpr_trueimpes"][0]) <= 2
     assert out["cpr_trueimpes"][1] < out["ilu0"][1], out
+
+
+def test_coarsening_stops_where_rows_outgrow_the_level_image(pkg, orc):
+    """A graph whose coarse levels fill in quickly (20 random neighbours per row, the way NNC- and fault-heavy grids do on
+    their coarse levels): the aggregation would produce rows beyond the 96 entries a level image holds.  The set-up stops
+    coarsening there instead of failing the solve (the oracle applies the same rule), the previous level becomes the coarsest,
+    and the preconditioner is still applied bit for bit."""
+    rng = np.random.default_rng(12)
+    Nb = 6000
+    nb = [set([i]) for i in range(Nb)]
+    for i in range(Nb):
+        for j in rng.integers(0, Nb, 10):
+            if int(j) != i:
+                nb[i].add(int(j)); nb[int(j)].add(i)
+    rp = np.zeros(Nb + 1, np.int32)
+    ci = []
+    for i in range(Nb):
+        row = sorted(nb[i])
+        ci += row
+        rp[i + 1] = len(ci)
+    ci = np.array(ci, np.int32)
+    v = np.zeros((len(ci), 3, 3))
+    rowid = np.repeat(np.arange(Nb), np.diff(rp))
+    off = ci != rowid
+    v[off] = -np.abs(rng.standard_normal((off.sum(), 3, 3))) * 0.05
+    v[off, 1, 1] = -rng.uniform(0.5, 1.5, off.sum())                    # M-matrix-like pressure couplings
+    deg = np.diff(rp) - 1
+    v[~off] = np.eye(3) * (2.0 * deg[:, None, None] + 1.0)
+    v = v.reshape(-1)
+    s = pkg.capi.HipSolver(reorder="graph_coloring", preconditioner="cpr_quasiimpes", tolerance=1e-6)
+    s.set_pattern(Nb, rp, ci)
+    s.upload_system(v)
+    s.ilu0_factor(want_factors=False)
+    to, fr, rr, rc, rv = reordered(orc, s, Nb, rp, ci, v)
+    cpr = oracle_bind.OracleCpr(orc)
+    cpr.update(Nb, rr, rc, rv)
+    d = rng.standard_normal(3 * Nb)
+    vo = cpr.apply(np.ascontiguousarray(d.reshape(Nb, 3)[fr].reshape(-1))).reshape(Nb, 3)[to].reshape(-1)
+    assert np.array_equal(s.cpr_apply(d), vo)
+    n_dev, nnz_dev = s.cpr_levels()
+    assert n_dev == [int(x) for x in cpr.levels()[0]]
+    assert n_dev[-1] > 128                                        # stopped early: the coarsest level is not the direct-solve size
+    assert max(z / n for z, n in zip(nnz_dev, n_dev)) <= 96
+    b = rng.standard_normal(3 * Nb)
+    r = s.solve_system(Nb, rp, ci, v.copy(), b)
+    assert r.converged
