@@ -121,18 +121,48 @@ __global__ __launch_bounds__(256) void k_cpr_weights(int Nb, const int* __restri
 // so that the one-thread-per-row kernels read coalesced and with a uniform trip count.  Row sums run over j ascending = the
 // CSR order of the oracle; a padding term subtracts 0 * x_i and leaves the sum's bits alone.
 // pressure matrix: a_p[k] = sum_r A_k[r][p] w_row[r] (PressureTransferPolicy::calculateCoarseEntries, :116-139)
-__global__ __launch_bounds__(256) void k_cpr_pvals(int Nb, const int* __restrict__ rowptr, const double* __restrict__ A, const double* __restrict__ w,
-                                                   double* __restrict__ ap) {
+// pcol != NULL: the pressure COLUMN of every block (3 doubles) goes into an ELL image of its own, component-major
+// [c][j * Nb + i]: what the post-smoothing residual d - A (0, x_p, 0) needs of the matrix (k_cpr_presid) - a third of its bytes
+__global__ __launch_bounds__(256) void k_cpr_pvals(int Nb, int W, const int* __restrict__ rowptr, const double* __restrict__ A, const double* __restrict__ w,
+                                                   double* __restrict__ ap, double* __restrict__ pcol) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= Nb) return;
     const double w0 = w[(size_t)i * BS], w1 = w[(size_t)i * BS + 1], w2 = w[(size_t)i * BS + 2];
     const int kb = rowptr[i];
     for (int k = kb; k < rowptr[i + 1]; ++k) {
         const double* B = &A[(size_t)k * BB];
+        const double b0 = B[0 * BS + CPR_P], b1 = B[1 * BS + CPR_P], b2 = B[2 * BS + CPR_P];
         double s = 0.0;
-        s += B[0 * BS + CPR_P] * w0; s += B[1 * BS + CPR_P] * w1; s += B[2 * BS + CPR_P] * w2;
-        ap[(size_t)(k - kb) * Nb + i] = s;
+        s += b0 * w0; s += b1 * w1; s += b2 * w2;
+        const size_t e = (size_t)(k - kb) * Nb + i;
+        ap[e] = s;
+        if (pcol) {
+            const size_t plane = (size_t)W * Nb;
+            pcol[e] = b0; pcol[plane + e] = b1; pcol[2 * plane + e] = b2;
+        }
     }
+}
+// r = d - A v for v = (0, x_p, 0): of every block only its pressure column meets a non-zero, so the row sums of
+// BCRSMatrix::mv (y_i = 0, then block by block in ascending column order, each component adding its three products) reduce
+// to the products with x_p - adding the +-0 products of the two other columns changes no bit of a sum that started at +0.
+// One thread per row on the ELL image of the pressure columns (padding entries are 0 * x_i).  Replaces a full SpMV (579 MB)
+// and the subtraction kernel behind it by one pass over 196 MB of matrix data.
+__global__ __launch_bounds__(256) void k_cpr_presid(int n, int W, const int* __restrict__ ecol, const double* __restrict__ pcol, const double* __restrict__ d,
+                                                    const double* __restrict__ xp, double* __restrict__ r, const double* __restrict__ done) {
+    CPR_DONE_CHECK
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const size_t plane = (size_t)W * n;
+    double y0 = 0.0, y1 = 0.0, y2 = 0.0;
+#pragma unroll 4
+    for (int j = 0; j < W; ++j) {
+        const size_t e = (size_t)j * n + i;
+        const double x = xp[ecol[e]];
+        y0 += pcol[e] * x; y1 += pcol[plane + e] * x; y2 += pcol[2 * plane + e] * x;
+    }
+    r[(size_t)i * BS] = d[(size_t)i * BS] - y0;
+    r[(size_t)i * BS + 1] = d[(size_t)i * BS + 1] - y1;
+    r[(size_t)i * BS + 2] = d[(size_t)i * BS + 2] - y2;
 }
 // Galerkin values: coarse entry e (at ELL position cpos[e]) = sum of its fine entries (ELL positions gidx) in ascending order
 __global__ __launch_bounds__(256) void k_cpr_galerkin(int nce, const int* __restrict__ gptr, const int* __restrict__ gidx, const int* __restrict__ cpos,
@@ -345,11 +375,12 @@ __global__ __launch_bounds__(256) void k_cpr_post(int n, int W, double omega, co
 #pragma unroll 4
     for (int j = 0; j < W; ++j) s -= val[(size_t)j * n + i] * xp[ecol[(size_t)j * n + i]];
     const double xo = xp[i] + omega * dinv[i] * s;
+    xout[i] = xo;
     if (vfine) {
         double* v = &vfine[(size_t)i * BS];
 #pragma unroll
         for (int k = 0; k < BS; ++k) v[k] = (k == CPR_P) ? xo : 0.0;
-    } else xout[i] = xo;
+    }
 }
 // v = (0, x_p, 0)  (moveToFineLevel: the pressure component only)
 __global__ __launch_bounds__(256) void k_cpr_prolong_fine(int Nb, const double* __restrict__ xc, double* __restrict__ v, const double* __restrict__ done) {
@@ -505,7 +536,7 @@ static int cpr_setup_structure(opmhip_ctx* c) {
         (void)hipStreamSynchronize(c->stream);
         while (c->allocs.size() > mark) { (void)hipFree(c->allocs.back()); c->allocs.pop_back(); }
         R.lv.clear();
-        R.d_r = R.d_y = R.d_z = R.d_lu = nullptr;
+        R.d_r = R.d_y = R.d_z = R.d_lu = R.d_pcol = nullptr;
         if (!hadW) R.d_w = nullptr;
         R.structured = false;
     }
@@ -527,8 +558,10 @@ static int cpr_setup_structure_impl(opmhip_ctx* c) {
     R.lv.emplace_back();
     std::vector<int> pos;   // ELL position of every CSR entry of the level being coarsened
     if ((rc = upload_ell(c, A, R.lv[0], pos, false))) return rc;
+    if ((rc = dev_alloc(c, &R.d_pcol, (size_t)3 * R.lv[0].W * P.Nb))) return rc;     // pressure columns of the blocks, ELL, component-major
+    OPMHIP_HIP(c, hipMemsetAsync(R.d_pcol, 0, (size_t)3 * R.lv[0].W * P.Nb * sizeof(double), c->stream));   // the padding stays 0
     if ((rc = cpr_weights(c))) return rc;
-    hipLaunchKernelGGL(k_cpr_pvals, g256(P.Nb), dim3(256), 0, c->stream, P.Nb, P.d_rowptr, c->d_A, R.d_w, R.lv[0].d_val);
+    hipLaunchKernelGGL(k_cpr_pvals, g256(P.Nb), dim3(256), 0, c->stream, P.Nb, R.lv[0].W, P.d_rowptr, c->d_A, R.d_w, R.lv[0].d_val, R.d_pcol);
     {
         std::vector<double> ell((size_t)R.lv[0].W * P.Nb);
         OPMHIP_HIP(c, hipMemcpyAsync(ell.data(), R.lv[0].d_val, ell.size() * sizeof(double), hipMemcpyDeviceToHost, c->stream));
@@ -597,7 +630,7 @@ int cpr_update(opmhip_ctx* c) {
     if (!R.structured && (rc = cpr_setup_structure(c))) return rc;
     const int ps = prof_begin(c, PROF_ILU_FACTOR);
     if ((rc = cpr_weights(c))) { prof_end(c, ps); return rc; }
-    hipLaunchKernelGGL(k_cpr_pvals, g256(P.Nb), dim3(256), 0, c->stream, P.Nb, P.d_rowptr, c->d_A, R.d_w, R.lv[0].d_val);
+    hipLaunchKernelGGL(k_cpr_pvals, g256(P.Nb), dim3(256), 0, c->stream, P.Nb, R.lv[0].W, P.d_rowptr, c->d_A, R.d_w, R.lv[0].d_val, R.d_pcol);
     for (size_t l = 0; l < R.lv.size(); ++l) {
         CprLevelDev& L = R.lv[l];
         hipLaunchKernelGGL(k_cpr_dinv, g256(L.n), dim3(256), 0, c->stream, L.n, L.d_diag, L.d_val, L.d_dinv);
@@ -680,10 +713,11 @@ void launch_cpr_apply(opmhip_ctx* c, const double* d, double* v) {
     const bool direct = R.lv.size() > 1 && !R.lv[0].rm;
     const double* xp = cpr_vcycle(c, 0, direct ? v : nullptr);
     if (xp) hipLaunchKernelGGL(k_cpr_prolong_fine, g256(n), dim3(256), 0, c->stream, P.Nb, xp, v, done);
+    else xp = R.lv[0].d_x2;   // k_cpr_post left the pressure solution there as well
     prof_end(c, ps);
-    (void)launch_spmv(c, v, R.d_y, 0, nullptr);                      // post-smoothing on the updated residual
+    // post-smoothing on the updated residual r = d - A v: v has pressure components only
     ps = prof_begin(c, PROF_VECTOR);
-    hipLaunchKernelGGL(k_cpr_sub, g256(n), dim3(256), 0, c->stream, n, d, R.d_y, R.d_r, done);
+    hipLaunchKernelGGL(k_cpr_presid, g256(P.Nb), dim3(256), 0, c->stream, P.Nb, R.lv[0].W, R.lv[0].d_ecol, R.d_pcol, d, xp, R.d_r, done);
     prof_end(c, ps);
     launch_ilu_apply(c, R.d_r, R.d_z, 1.0);                           // fine smoother: ILU0, relaxation 1
     ps = prof_begin(c, PROF_VECTOR);

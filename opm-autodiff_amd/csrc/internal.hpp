@@ -174,6 +174,7 @@ struct CprDev {
     bool structured = false, coarse_direct = true;
     std::vector<CprLevelDev> lv;
     double *d_w = nullptr, *d_lu = nullptr;
+    double* d_pcol = nullptr;                                      // level 0: the pressure column of every block, ELL, component-major [3][W x Nb]
     bool w_given = false;                                          // d_w holds weights handed in (opmhip_set_cpr_weights): not recomputed
     double *d_r = nullptr, *d_y = nullptr, *d_z = nullptr;         // fine-level block vectors
     double omega = 2.0 / 3.0, damp = 1.6, beta = 0.25;             // Jacobi damping, prolongation damping, strength threshold

@@ -58,6 +58,7 @@ struct CprAmg {
     double omega = 2.0 / 3.0;      // Jacobi damping
     double damp = 1.6;             // prolongation damping (setupPropertyTree.cpp:132)
     double beta = 0.25;            // a neighbour is a candidate if -a_ij >= beta * max_k(-a_ik)
+    int nu = 1;                    // smoothing sweeps before and after the coarse correction (the product runs V(1,1); more: experiments)
     bool join = false;             // leftover nodes join a neighbour's aggregate (uniform coarsening, but measured WORSE: see DESIGN.md)
 
     // one pass of pairwise matching, nodes visited in index order: node i takes its strongest (most negative coupling)
@@ -255,6 +256,10 @@ struct CprAmg {
         std::vector<double> r(n), rc(L.nc), xc(L.nc);
         for (int i = 0; i < n; ++i) x[i] = omega * L.dinv[i] * b[i];        // pre-smoothing from x = 0
         residual(L.A, b, x, r.data());
+        for (int sweep = 1; sweep < nu; ++sweep) {                           // nu > 1: further Jacobi sweeps (V(nu, nu))
+            for (int i = 0; i < n; ++i) x[i] += omega * L.dinv[i] * r[i];
+            residual(L.A, b, x, r.data());
+        }
         for (int I = 0; I < L.nc; ++I) {                                    // restriction: sum over the aggregate
             double s = 0.0;
             for (int q = L.mptr[I]; q < L.mptr[I + 1]; ++q) s += r[L.midx[q]];
@@ -264,6 +269,10 @@ struct CprAmg {
         for (int i = 0; i < n; ++i) x[i] += damp * xc[L.agg[i]];            // damped piecewise-constant prolongation
         residual(L.A, b, x, r.data());
         for (int i = 0; i < n; ++i) x[i] += omega * L.dinv[i] * r[i];        // post-smoothing
+        for (int sweep = 1; sweep < nu; ++sweep) {
+            residual(L.A, b, x, r.data());
+            for (int i = 0; i < n; ++i) x[i] += omega * L.dinv[i] * r[i];
+        }
     }
 };
 
