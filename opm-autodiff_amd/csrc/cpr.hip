@@ -33,11 +33,15 @@ struct HCsr {
     std::vector<int> rowptr, col;
     std::vector<double> val;
 };
-void pairwise(const HCsr& A, double beta, bool anySign, std::vector<int>& agg, int& na) {
+// natOf / atNat (level 0 only, else NULL): natural id of every internal index and its inverse - the cells are visited in
+// NATURAL order, ties to the lowest natural id: the aggregates of the natural-order matrix whatever the ILU ordering is
+// (matching colour by colour pairs cells across the grid and stalls after five levels; oracle/cpr.hpp: same statements)
+void pairwise(const HCsr& A, double beta, bool anySign, std::vector<int>& agg, int& na, const int* natOf = nullptr, const int* atNat = nullptr) {
     const int n = A.n;
     agg.assign(n, -1);
     na = 0;
-    for (int i = 0; i < n; ++i) {
+    for (int v = 0; v < n; ++v) {
+        const int i = atNat ? atNat[v] : v;
         if (agg[i] >= 0) continue;
         double mx = 0.0;
         for (int k = A.rowptr[i]; k < A.rowptr[i + 1]; ++k)
@@ -48,7 +52,7 @@ void pairwise(const HCsr& A, double beta, bool anySign, std::vector<int>& agg, i
             const int j = A.col[k];
             if (j == i || agg[j] >= 0) continue;
             const double s = anySign ? std::fabs(A.val[k]) : -A.val[k];
-            if (s > bv && s >= beta * mx) { best = j; bv = s; }
+            if (s >= beta * mx && (s > bv || (natOf && best >= 0 && s == bv && natOf[j] < natOf[best]))) { best = j; bv = s; }
         }
         agg[i] = na;
         if (best >= 0) agg[best] = na;
@@ -576,7 +580,8 @@ static int cpr_setup_structure_impl(opmhip_ctx* c) {
         HCsr A1;
         for (int attempt = 0; attempt < 3; ++attempt) {
             const double b = attempt == 0 ? R.beta : 0.0;
-            pairwise(A, b, attempt == 2, a1, n1);
+            const bool lvl0 = R.lv.size() == 1;   // the finest level is stored in the ILU ordering: visit it in natural order
+            pairwise(A, b, attempt == 2, a1, n1, lvl0 ? P.fromOrder.data() : nullptr, lvl0 ? P.toOrder.data() : nullptr);
             galerkin(A, a1, n1, A1, g1p, g1i);
             pairwise(A1, b, attempt == 2, a2, n2);
             if (n2 <= (int)(0.5 * A.n)) break;

@@ -58,17 +58,24 @@ struct CprAmg {
     double omega = 2.0 / 3.0;      // Jacobi damping
     double damp = 1.6;             // prolongation damping (setupPropertyTree.cpp:132)
     double beta = 0.25;            // a neighbour is a candidate if -a_ij >= beta * max_k(-a_ik)
+    std::vector<int> natOf, atNat; // level 0 of a reordered system: natural id of every index / index of every natural id (empty: as stored)
+    int maxLevels = CPR_MAX_LEVELS;   // levels of the hierarchy at most (the coarsest one is solved directly or by 1 + 4 Jacobi sweeps)
     int nu = 1;                    // smoothing sweeps before and after the coarse correction (the product runs V(1,1); more: experiments)
     bool join = false;             // leftover nodes join a neighbour's aggregate (uniform coarsening, but measured WORSE: see DESIGN.md)
 
     // one pass of pairwise matching, nodes visited in index order: node i takes its strongest (most negative coupling)
     // still-free neighbour, lowest index on ties
     // strength of a coupling: -a_ij (M-matrix-like rows), or |a_ij| when anySign (coarse levels that lost their sign pattern)
-    static void pairwise(const Csr& A, double beta, bool anySign, bool join_, std::vector<int>& agg, int& na) {
+    // natOf / atNat (level 0 of a REORDERED system only, else NULL): natural id of every index and its inverse - the nodes are
+    // then visited in NATURAL order and ties go to the lowest natural id, so that the aggregates are those of the natural-order
+    // matrix whatever ordering the ILU0 wants (matching in a colour-by-colour ordering pairs cells across the grid and stalls)
+    static void pairwise(const Csr& A, double beta, bool anySign, bool join_, std::vector<int>& agg, int& na,
+                         const int* natOf = nullptr, const int* atNat = nullptr) {
         const int n = A.n;
         agg.assign(n, -1);
         na = 0;
-        for (int i = 0; i < n; ++i) {
+        for (int v = 0; v < n; ++v) {
+            const int i = atNat ? atNat[v] : v;
             if (agg[i] >= 0) continue;
             double mx = 0.0;
             for (int k = A.rowptr[i]; k < A.rowptr[i + 1]; ++k)
@@ -79,7 +86,7 @@ struct CprAmg {
                 const int j = A.col[k];
                 if (j == i || agg[j] >= 0) continue;
                 const double s = anySign ? std::fabs(A.val[k]) : -A.val[k];
-                if (s > bv && s >= beta * mx) { best = j; bv = s; }
+                if (s >= beta * mx && (s > bv || (natOf && best >= 0 && s == bv && natOf[j] < natOf[best]))) { best = j; bv = s; }
             }
             if (best >= 0) {
                 agg[i] = agg[best] = na++;
@@ -140,7 +147,7 @@ struct CprAmg {
             AmgLevel L;
             L.A = A;
             finish_level(L);
-            const bool last = A.n <= CPR_COARSE_DIRECT || (int)lv.size() + 1 >= CPR_MAX_LEVELS;
+            const bool last = A.n <= CPR_COARSE_DIRECT || (int)lv.size() + 1 >= maxLevels;
             if (!last) {
                 std::vector<int> a1, a2, g1p, g1i;
                 int n1 = 0, n2 = 0;
@@ -149,7 +156,8 @@ struct CprAmg {
                 // many nodes alone, match with any negative coupling, then with the largest coupling of either sign
                 for (int attempt = 0; attempt < 3; ++attempt) {
                     const double b = attempt == 0 ? beta : 0.0;
-                    pairwise(A, b, attempt == 2, join, a1, n1);
+                    const bool lvl0 = lv.empty() && !natOf.empty();
+                    pairwise(A, b, attempt == 2, join, a1, n1, lvl0 ? natOf.data() : nullptr, lvl0 ? atNat.data() : nullptr);
                     galerkin(A, a1, n1, A1, g1p, g1i);
                     pairwise(A1, b, attempt == 2, join, a2, n2);
                     if (n2 <= (int)(0.5 * A.n)) break;

@@ -262,6 +262,16 @@ orc_cpr* orc_cpr_create(double omega, double damp, double beta) {
 void orc_cpr_destroy(orc_cpr* h) { delete h; }
 // which pressure AMG the handle uses: 0 = the product's (pairwise matching + Jacobi), 1 = the restatement of the reference's
 // (Dune::Amg-like aggregation + ILU0 smoothing + direct coarse solve; comparison only).  Before the first update / solve.
+// the system handed to this preconditioner is a REORDERED one: nat[i] = natural id of its row i (n = 0: it is in natural order)
+int orc_cpr_set_natural_ids(orc_cpr* h, int n, const int* nat) {
+    CprAmg& G = h->P.amg;
+    G.natOf.assign(nat, nat + n);
+    G.atNat.assign(n, 0);
+    for (int i = 0; i < n; ++i) G.atNat[nat[i]] = i;
+    h->P.structured = false;
+    return 0;
+}
+int orc_cpr_set_max_levels(orc_cpr* h, int n) { h->P.amg.maxLevels = n < 1 ? 1 : n; h->P.structured = false; return 0; }
 int orc_cpr_set_sweeps(orc_cpr* h, int nu) { h->P.amg.nu = nu < 1 ? 1 : nu; return 0; }   // experiments: V(nu, nu)
 int orc_cpr_use_reference_amg(orc_cpr* h, int on) { h->P.useDune = on != 0; h->P.structured = false; return 0; }
 // levels of that hierarchy

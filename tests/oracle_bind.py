@@ -472,6 +472,13 @@ class OracleCpr:
         L = self.o.lib.orc_cpr_levels(self.h, n, nnz, 32)
         return list(n[:L]), list(nnz[:L])
 
+    def set_natural_ids(self, nat):
+        """the systems this handle gets are reordered: nat[i] = natural id of row i (the device's fromOrder).  The aggregation
+        of the finest level then visits the cells in natural order, as the device's does."""
+        a = np.ascontiguousarray(nat, np.int32)
+        self.o.lib.orc_cpr_set_natural_ids.argtypes = [_vp, C.c_int, _i]
+        self.o.lib.orc_cpr_set_natural_ids(self.h, len(a), a)
+
     def use_reference_amg(self, on=True):
         """the restatement of the reference's Dune::Amg hierarchy instead of the product's (comparison only)"""
         self.o.lib.orc_cpr_use_reference_amg(self.h, int(on))

@@ -52,6 +52,7 @@ def test_cpr_apply_bitwise_and_solve(pkg, orc, reorder):
     s.ilu0_factor(want_factors=False)
     to, fr, rr, rc, rv = reordered(orc, s, Nb, rp, ci, jac)
     cpr = oracle_bind.OracleCpr(orc)
+    cpr.set_natural_ids(fr)     # the device aggregates its finest level in natural visiting order
     cpr.update(Nb, rr, rc, rv)
     rng = np.random.default_rng(1)
     for k in range(2):
@@ -151,6 +152,7 @@ def test_true_impes_weights_bitwise_and_newton(pkg, orc, wet):
     s.set_cpr_weights(wo)
     to, fr, rr, rc, rv = reordered(orc, s, Nb, rp, ci, jo)
     cpr = oracle_bind.OracleCpr(orc)
+    cpr.set_natural_ids(fr)
     cpr.set_weights(wo[fr])
     cpr.update(Nb, rr, rc, rv)
     d = np.random.default_rng(3).standard_normal(3 * Nb)
@@ -202,6 +204,7 @@ def test_coarsening_stops_where_rows_outgrow_the_level_image(pkg, orc):
     s.ilu0_factor(want_factors=False)
     to, fr, rr, rc, rv = reordered(orc, s, Nb, rp, ci, v)
     cpr = oracle_bind.OracleCpr(orc)
+    cpr.set_natural_ids(fr)
     cpr.update(Nb, rr, rc, rv)
     d = rng.standard_normal(3 * Nb)
     vo = cpr.apply(np.ascontiguousarray(d.reshape(Nb, 3)[fr].reshape(-1))).reshape(Nb, 3)[to].reshape(-1)

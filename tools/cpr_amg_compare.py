@@ -15,6 +15,7 @@ ap = argparse.ArgumentParser()
 ap.add_argument("--size", type=int, default=100)
 ap.add_argument("--at", type=int, default=200)
 ap.add_argument("--n", type=int, default=4)
+ap.add_argument("--levels", type=int, nargs="*", default=[], help="also: the product's AMG cut off at this many levels")
 a = ap.parse_args()
 pkg = importlib.import_module("opm-autodiff_amd")
 n = a.size
@@ -29,9 +30,13 @@ for _ in range(a.at):
 orc = oracle_bind.Oracle(os.path.join(ROOT, "oracle", "liboracle.so"))
 Nb, rp, ci = case["Nb"], case["rowptr"], case["col"]
 cprs = {}
-for name, ref in (("product_amg", False), ("reference_like_amg", True)):
+import ctypes
+orc.lib.orc_cpr_set_max_levels.argtypes = [ctypes.c_void_p, ctypes.c_int]
+for name, ref, lev in [("product_amg", False, 0), ("reference_like_amg", True, 0)] + [("product_amg_%d_levels" % k, False, k) for k in a.levels]:
     c = oracle_bind.OracleCpr(orc)
     c.use_reference_amg(ref)
+    if lev:
+        orc.lib.orc_cpr_set_max_levels(c.h, lev)
     cprs[name] = c
 out = {"size": n, "from_newton_iteration": a.at, "systems": []}
 for k in range(a.n):
