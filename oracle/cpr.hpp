@@ -61,6 +61,8 @@ struct CprAmg {
     std::vector<int> natOf, atNat; // level 0 of a reordered system: natural id of every index / index of every natural id (empty: as stored)
     int maxLevels = CPR_MAX_LEVELS;   // levels of the hierarchy at most (the coarsest one is solved directly or by 1 + 4 Jacobi sweeps)
     int nu = 1;                    // smoothing sweeps before and after the coarse correction (the product runs V(1,1); more: experiments)
+    int coarseSweeps = 4;          // Jacobi sweeps (after the first, from x = 0) that stand in for the coarse solve where coarsening stalled
+    bool joinAtStall = false;      // experiment switch (orc_cpr_set_sweeps with a negative argument)
     bool join = false;             // leftover nodes join a neighbour's aggregate (uniform coarsening, but measured WORSE: see DESIGN.md)
 
     // one pass of pairwise matching, nodes visited in index order: node i takes its strongest (most negative coupling)
@@ -162,6 +164,11 @@ struct CprAmg {
                     pairwise(A1, b, attempt == 2, join, a2, n2);
                     if (n2 <= (int)(0.5 * A.n)) break;
                 }
+                if (n2 >= (int)(0.8 * A.n) && joinAtStall) {   // experiment: leftover nodes join a neighbour's aggregate on the levels where matching stalls
+                    pairwise(A, 0.0, true, true, a1, n1);
+                    galerkin(A, a1, n1, A1, g1p, g1i);
+                    pairwise(A1, 0.0, true, true, a2, n2);
+                }
                 if (n2 >= (int)(0.8 * A.n)) {   // coarsening stalls (hardly any coupling left): stop here
                     lv.push_back(L);
                     break;
@@ -254,7 +261,7 @@ struct CprAmg {
             } else {   // could not coarsen further: a few Jacobi sweeps stand in for the coarse solve
                 std::vector<double> r(n);
                 for (int i = 0; i < n; ++i) x[i] = omega * L.dinv[i] * b[i];
-                for (int sweep = 0; sweep < 4; ++sweep) {
+                for (int sweep = 0; sweep < coarseSweeps; ++sweep) {
                     residual(L.A, b, x, r.data());
                     for (int i = 0; i < n; ++i) x[i] += omega * L.dinv[i] * r[i];
                 }

@@ -15,6 +15,7 @@ ap = argparse.ArgumentParser()
 ap.add_argument("--size", type=int, default=100)
 ap.add_argument("--at", type=int, default=200)
 ap.add_argument("--n", type=int, default=4)
+ap.add_argument("--first", action="store_true", help="also: hierarchies whose structure comes from the INITIAL Jacobian (as the device's does), with variants of the coarsest level")
 ap.add_argument("--levels", type=int, nargs="*", default=[], help="also: the product's AMG cut off at this many levels")
 a = ap.parse_args()
 pkg = importlib.import_module("opm-autodiff_amd")
@@ -25,6 +26,9 @@ m = pkg.capi.HipModel(case, reorder="line_coloring", tolerance=1e-2, maxit=200, 
 m.set_state(case["pv"], case["meaning"])
 m.set_source(src)
 sim = bench.make_simulation(pkg, m)
+first_jac = None
+if a.first:
+    first_jac, _ = m.assemble(sim.dt, 0, fetch=True)
 for _ in range(a.at):
     sim.next_newton_iteration()
 orc = oracle_bind.Oracle(os.path.join(ROOT, "oracle", "liboracle.so"))
@@ -37,6 +41,17 @@ for name, ref, lev in [("product_amg", False, 0), ("reference_like_amg", True, 0
     c.use_reference_amg(ref)
     if lev:
         orc.lib.orc_cpr_set_max_levels(c.h, lev)
+    cprs[name] = c
+orc.lib.orc_cpr_set_coarse_sweeps.argtypes = [ctypes.c_void_p, ctypes.c_int]
+orc.lib.orc_cpr_set_sweeps.argtypes = [ctypes.c_void_p, ctypes.c_int]
+for name, kw in (("first_product_amg", {}), ("first_coarse10", dict(cs=10)), ("first_coarse20", dict(cs=20)), ("first_join_at_stall", dict(js=True))) if a.first else ():
+    # the device keeps the hierarchy's STRUCTURE of its first matrix: build these from the initial Jacobian too
+    c = oracle_bind.OracleCpr(orc)
+    if kw.get("cs"):
+        orc.lib.orc_cpr_set_coarse_sweeps(c.h, kw["cs"])
+    if kw.get("js"):
+        orc.lib.orc_cpr_set_sweeps(c.h, -1)
+    c.update(Nb, rp, ci, first_jac)
     cprs[name] = c
 out = {"size": n, "from_newton_iteration": a.at, "systems": []}
 for k in range(a.n):
