@@ -257,3 +257,66 @@ def test_spe9_shaped_well_residual_and_recovery(pkg, orc):
     assert np.linalg.norm(resid) < 1e-6 * np.linalg.norm(r2) * 1.001
     xw = m.wells_recover_solution(W, res_well)
     np.testing.assert_array_equal(xw, orc.wells_recover(W, res_well, x))  # same x in, same operation order: same bits
+
+
+def test_norne_shaped_grid_with_the_features_the_norne_deck_uses(pkg, orc, norne_grid):
+    """configs[4] closer to the deck: on the faulted corner-point grid a fluid with PVTG (vaporised oil), two saturation
+    regions, per-cell scaled saturation end points (ENDSCALE with SCALECRS and vertical scaling, as the deck's SWL / SWCR / SGU /
+    KRW ... arrays do), DRSDT with its time-step bookkeeping, irreversible rock compaction tables - everything at once through
+    begin_time_step / assemble / solve / update / end_time_step for two time steps, device against oracle bit for bit."""
+    from test_oracle_endscale import corey_fluid, scaled_points
+    import helpers
+    base, g, dims = norne_grid
+    n = base["Nb"]
+    rng = np.random.default_rng(23)
+    wet = helpers.wetgas_fluid(pkg, rocktab=helpers.ROCKTAB_2)
+    sat0 = corey_fluid(pkg).sat[0]
+    sat1 = dict(swof=[[r[0], 0.9 * r[1], r[2], 1.3 * r[3]] for r in sat0["swof"]], sgof=[[r[0], r[1], 0.95 * r[2], r[3]] for r in sat0["sgof"]])
+    fl = pkg.fluid.Fluid(wet.pvt, [sat0, sat1], rock_pref=wet.rock_pref, rock_cr=wet.rock_cr, rocktab=helpers.ROCKTAB_2, pc_scaling=True)
+    case = dict(base, fluid=fl)
+    case["satnum"] = (rng.random(n) < 0.4).astype(np.int32)
+    case["rocknum"] = (rng.random(n) < 0.5).astype(np.int32)
+    # scaled end points around each cell's own table
+    u = [oracle_bind.sat_end_points(orc, fl, s) for s in (0, 1)]
+    pts = np.array([scaled_points(u[s], rng) for s in case["satnum"]])
+    es = dict(sat_scaling=1, three_point_kr=1, krw=2, kro=2, krg=2, pcw=1, pcg=1)
+    for f, name in enumerate(pkg.capi.EPS_FIELDS):
+        es[name] = np.ascontiguousarray(pts[:, f])
+    case["endscale"] = es
+    # state: keep Sw above every cell's connate water, the gas cap gets the third meaning in places
+    pv = case["pv"].reshape(-1, 3).copy()
+    pv[:, 0] = es["swl"] + 0.05 + 0.1 * rng.random(n)
+    mng = case["meaning"].copy()
+    cap = np.flatnonzero(mng == 0)
+    dry = cap[rng.random(len(cap)) < 0.3]
+    mng[dry] = 2
+    pv[dry, 2] = helpers.rv_sat(fl, pv[dry, 1]) * 0.7
+    case["pv"], case["meaning"] = np.ascontiguousarray(pv.reshape(-1)), mng
+    m = pkg.capi.HipModel(case, reorder="line_coloring")
+    o = oracle_bind.OracleModel(orc, case)
+    for q in (m, o):
+        q.set_state(case["pv"], case["meaning"])
+        q.set_composition_change_limits([3.0e-6], [0], [5.0e-12])
+        q.set_irreversible_compaction(True)
+    assert np.array_equal(m.iq(), o.iq())
+    for step, dt in enumerate([0.5 * 86400.0, 86400.0]):
+        for q in (m, o):
+            q.begin_time_step(dt)
+        assert np.array_equal(m.iq(), o.iq())
+        for it in range(2):
+            jm, rm = m.assemble(dt, it)
+            jo, ro = o.assemble(dt, it)
+            assert np.array_equal(jm, jo) and np.array_equal(rm, ro), (step, it)
+            res = m.solve_jacobian_system()
+            assert res.converged
+            x = m.get_result()
+            m.update(x, 1.0)
+            o.update(x)
+            pm, mm = m.get_state()
+            po, mo = o.get_state()
+            assert np.array_equal(mm, mo) and np.array_equal(pm, po), (step, it)
+        for q in (m, o):
+            q.end_time_step(dt)
+        for a, b in zip(m.trackers(), o.trackers()):
+            assert np.array_equal(a, b)
+    assert len(set(mm.tolist())) == 3

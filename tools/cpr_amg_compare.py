@@ -16,6 +16,7 @@ ap.add_argument("--size", type=int, default=100)
 ap.add_argument("--at", type=int, default=200)
 ap.add_argument("--n", type=int, default=4)
 ap.add_argument("--first", action="store_true", help="also: hierarchies whose structure comes from the INITIAL Jacobian (as the device's does), with variants of the coarsest level")
+ap.add_argument("--structure-at", type=int, nargs="*", default=[], help="also: the product's AMG with its structure built from the Jacobian of these Newton iterations")
 ap.add_argument("--levels", type=int, nargs="*", default=[], help="also: the product's AMG cut off at this many levels")
 a = ap.parse_args()
 pkg = importlib.import_module("opm-autodiff_amd")
@@ -29,7 +30,12 @@ sim = bench.make_simulation(pkg, m)
 first_jac = None
 if a.first:
     first_jac, _ = m.assemble(sim.dt, 0, fetch=True)
-for _ in range(a.at):
+early = {}
+for k in range(a.at):
+    if k in a.structure_at:     # the system the device is about to solve at Newton iteration k
+        if sim.iteration == 0:
+            sim.next_newton_iteration()
+        early[k], _ = m.assemble(sim.dt, sim.iteration, fetch=True)
     sim.next_newton_iteration()
 orc = oracle_bind.Oracle(os.path.join(ROOT, "oracle", "liboracle.so"))
 Nb, rp, ci = case["Nb"], case["rowptr"], case["col"]
@@ -53,6 +59,10 @@ for name, kw in (("first_product_amg", {}), ("first_coarse10", dict(cs=10)), ("f
         orc.lib.orc_cpr_set_sweeps(c.h, -1)
     c.update(Nb, rp, ci, first_jac)
     cprs[name] = c
+for k, jk in early.items():
+    c = oracle_bind.OracleCpr(orc)
+    c.update(Nb, rp, ci, jk)
+    cprs["structure_from_newton_%d" % k] = c
 out = {"size": n, "from_newton_iteration": a.at, "systems": []}
 for k in range(a.n):
     # the system of the next Newton iteration, exactly as the device solves it: assemble with a host copy, then let the device go on
