@@ -21,7 +21,7 @@ extern "C" {
 #endif
 
 #define OPMHIP_ABI_VERSION 4 /* 4: opmhip_config names chain_length, spmv_pipe_wgs, preconditioner (were reserved[0..2]);
-                               *    opmhip_set_endpoint_scaling, opmhip_sat_end_points, opmhip_synchronize, opmhip_comm_info,
+                               *    opmhip_set_endpoint_scaling, opmhip_sat_end_points, opmhip_sat_probe, opmhip_synchronize, opmhip_comm_info,
                                *    opmhip_set_composition_change_limits, opmhip_set_irreversible_compaction, opmhip_set_vappars, opmhip_begin_time_step;
                                * 3: opmhip_fluid gained pc_scaling, opmhip_set_pcw */
 
@@ -359,6 +359,12 @@ int opmhip_sat_end_points(opmhip_ctx* ctx, int sat_region, double* out);
  * pcgo(sg), mu_o(p, rs) [Pa s], mu_g(p).  Needs opmhip_set_fluid only.  All arrays host memory. */
 int opmhip_fluid_probe(opmhip_ctx* ctx, int pvt_region, int sat_region, int n, const double* p, const double* rs,
                        const double* sw, const double* sg, double* out);
+
+/* The saturation functions at (sw, sg) the same way, optionally with ONE set of scaled end points (eps: flags as in
+ * opmhip_set_endpoint_scaling, points[f] pointing at ONE double each or NULL = the table's own; eps == NULL: unscaled):
+ * out[5 i + 0..4] = krw, kro, krg, pcow, pcgo.  What an equilibration with ENDSCALE inverts per cell (equil.py). */
+int opmhip_sat_probe(opmhip_ctx* ctx, int sat_region, const opmhip_endpoint_scaling* eps, int n, const double* sw, const double* sg,
+                     double* out);
 
 /* The gas-phase functions at (p_g, Rv) the same way: out[3 i + 0..2] = 1/B_g, mu_g (on the saturated curve where
  * Rv >= RvSat(p_g), as the equilibration's gas density does, initstateequil.hh:240-285), RvSat(p_g).  Dry-gas fluids:

@@ -360,6 +360,7 @@ def _bind_assembly(L):
     L.opmhip_get_trackers.argtypes = [vp, vp, vp, vp, vp]
     L.opmhip_set_vappars.argtypes = [vp, C.c_int, C.c_double, C.c_double]
     L.opmhip_sat_end_points.argtypes = [vp, C.c_int, vp]
+    L.opmhip_sat_probe.argtypes = [vp, C.c_int, vp, C.c_int, vp, vp, vp]
     L.opmhip_gas_probe.argtypes = [vp, C.c_int, C.c_int, vp, vp, vp]
     L.opmhip_iq_fields.argtypes = [vp]
 
@@ -411,6 +412,26 @@ def _sat_end_points(self, sat_region=0):
 
 
 HipFluid.sat_end_points = _sat_end_points
+
+
+def _sat_probe(self, sw, sg, endscale=None, sat_region=0):
+    """(n, 5): krw, kro, krg, pcow, pcgo at (sw, sg); endscale: dict(sat_scaling, three_point_kr, krw, kro, krg, pcw, pcg and any
+    of EPS_FIELDS as ONE value each; absent = the table's own end point) or None = unscaled"""
+    sw = np.atleast_1d(np.asarray(sw, np.float64))
+    n = len(sw)
+    sw = np.ascontiguousarray(sw)
+    sg = np.ascontiguousarray(np.broadcast_to(np.asarray(sg, np.float64), (n,)))
+    out = np.empty(5 * n)
+    if endscale is None:
+        self._check(lib().opmhip_sat_probe(self._h, sat_region, None, n, _ptr(sw), _ptr(sg), _ptr(out)))
+    else:
+        es = {k: (np.array([v], np.float64) if k in EPS_FIELDS else v) for k, v in endscale.items()}
+        s, keep = endpoint_scaling_struct(es)
+        self._check(lib().opmhip_sat_probe(self._h, sat_region, C.byref(s), n, _ptr(sw), _ptr(sg), _ptr(out)))
+    return out.reshape(n, 5)
+
+
+HipFluid.sat_probe = _sat_probe
 
 
 class HipModel(HipSolver):

@@ -742,6 +742,27 @@ int launch_gas_probe(opmhip_ctx* c, int pr, int n, const double* d_in, double* d
     hipLaunchKernelGGL(k_gas_probe, dim3((n + 255) / 256), dim3(256), 0, c->stream, tables_of(c), pr, n, d_in, d_in + n, d_out);
     return OPMHIP_SUCCESS;
 }
+// opmhip_sat_probe: the saturation functions with one set of scaled end points (eps[EPS_COUNT]; cfg = packed EclEpsConfig) or,
+// cfg < 0, the tables' own: out[5 i ..] = krw, kro, krg, pcow, pcgo at (sw, sg) - the functions update_iq evaluates
+__global__ __launch_bounds__(256) void k_sat_probe(Tables T, int sr, int cfg, const double* __restrict__ eps, int n, const double* __restrict__ sw,
+                                                   const double* __restrict__ sg, double* __restrict__ out) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const SatRegionDesc& Sd = T.sat(sr);
+    const GlobalTab B = T.dbl;
+    double u[EPS_COUNT], s[EPS_COUNT];
+#pragma unroll
+    for (int f = 0; f < EPS_COUNT; ++f) { u[f] = B[Sd.eps + f]; s[f] = cfg >= 0 ? eps[f] : u[f]; }
+    double kr[3], pC[3];
+    rel_perms_eps<double, GlobalTab>(B, Sd, cfg >= 0 ? cfg : 0, u, s, sw[i], sg[i], kr);
+    cap_pressures_eps<double, GlobalTab>(B, Sd, cfg >= 0 ? cfg : 0, u, s, sw[i], sg[i], pC);
+    double* o = out + (size_t)i * 5;
+    o[0] = kr[0]; o[1] = kr[1]; o[2] = kr[2]; o[3] = -pC[0]; o[4] = pC[2];
+}
+int launch_sat_probe(opmhip_ctx* c, int sr, int cfg, const double* d_eps, int n, const double* d_in, double* d_out) {
+    hipLaunchKernelGGL(k_sat_probe, dim3((n + 255) / 256), dim3(256), 0, c->stream, tables_of(c), sr, cfg, d_eps, n, d_in, d_in + n, d_out);
+    return OPMHIP_SUCCESS;
+}
 int launch_fluid_probe(opmhip_ctx* c, int pr, int sr, int n, const double* d_in, double* d_out) {
     hipLaunchKernelGGL(k_fluid_probe, dim3((n + 255) / 256), dim3(256), 0, c->stream, tables_of(c), pr, sr, n, d_in, d_in + n, d_in + 2 * (size_t)n,
                        d_in + 3 * (size_t)n, d_out);

@@ -367,6 +367,38 @@ int opmhip_set_endpoint_scaling(opmhip_ctx* c, const opmhip_endpoint_scaling* e)
     });
 }
 
+int opmhip_sat_probe(opmhip_ctx* c, int sat_region, const opmhip_endpoint_scaling* e, int n, const double* sw, const double* sg, double* out) {
+    if (!c) return OPMHIP_INVALID_ARGUMENT;
+    return guarded(c, [&]() -> int {
+        AsmDev& A = c->asmb;
+        if (!A.fluid_set) return fail(c, OPMHIP_NOT_READY, "sat_probe before set_fluid");
+        if (n < 0 || (n > 0 && (!sw || !sg || !out))) return fail(c, OPMHIP_INVALID_ARGUMENT, "sat_probe: null array");
+        if (sat_region < 0 || sat_region >= A.num_sat) return fail(c, OPMHIP_INVALID_ARGUMENT, "sat_probe: region out of range");
+        if (e && (e->krw < 0 || e->krw > 2 || e->kro < 0 || e->kro > 2 || e->krg < 0 || e->krg > 2))
+            return fail(c, OPMHIP_INVALID_ARGUMENT, "sat_probe: krw / kro / krg must be 0, 1 or 2");
+        if (n == 0) return OPMHIP_SUCCESS;
+        OPMHIP_HIP(c, hipSetDevice(c->device));
+        double pts[EPS_COUNT];
+        int cfg = -1;
+        if (e) {
+            for (int f = 0; f < EPS_COUNT; ++f) pts[f] = e->points[f] ? e->points[f][0] : A.sat_eps[(size_t)sat_region * EPS_COUNT + f];
+            cfg = (e->sat_scaling ? 1 : 0) | (e->three_point_kr ? 2 : 0) | (e->krw << 2) | (e->kro << 4) | (e->krg << 6) | (e->pcw ? 256 : 0) | (e->pcg ? 512 : 0);
+        }
+        struct Scratch { double *in = nullptr, *out = nullptr, *eps = nullptr; ~Scratch() { if (in) (void)hipFree(in); if (out) (void)hipFree(out); if (eps) (void)hipFree(eps); } } S;
+        OPMHIP_HIP(c, hipMalloc((void**)&S.in, (size_t)2 * n * sizeof(double)));
+        OPMHIP_HIP(c, hipMalloc((void**)&S.out, (size_t)5 * n * sizeof(double)));
+        OPMHIP_HIP(c, hipMalloc((void**)&S.eps, (size_t)EPS_COUNT * sizeof(double)));
+        OPMHIP_HIP(c, hipMemcpyAsync(S.in, sw, (size_t)n * sizeof(double), hipMemcpyHostToDevice, c->stream));
+        OPMHIP_HIP(c, hipMemcpyAsync(S.in + n, sg, (size_t)n * sizeof(double), hipMemcpyHostToDevice, c->stream));
+        if (e) OPMHIP_HIP(c, hipMemcpyAsync(S.eps, pts, sizeof pts, hipMemcpyHostToDevice, c->stream));
+        launch_sat_probe(c, sat_region, cfg, S.eps, n, S.in, S.out);
+        OPMHIP_HIP(c, hipGetLastError());
+        OPMHIP_HIP(c, hipMemcpyAsync(out, S.out, (size_t)5 * n * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+        OPMHIP_HIP(c, hipStreamSynchronize(c->stream));
+        return OPMHIP_SUCCESS;
+    });
+}
+
 int opmhip_fluid_probe(opmhip_ctx* c, int pvt_region, int sat_region, int n, const double* p, const double* rs, const double* sw,
                        const double* sg, double* out) {
     if (!c) return OPMHIP_INVALID_ARGUMENT;

@@ -417,6 +417,7 @@ int iq_doubles_per_cell(const opmhip_ctx* c);
 int asm_max_rows();
 int launch_fluid_probe(opmhip_ctx* c, int pr, int sr, int n, const double* d_in, double* d_out);
 int launch_gas_probe(opmhip_ctx* c, int pr, int n, const double* d_in, double* d_out);
+int launch_sat_probe(opmhip_ctx* c, int sr, int cfg, const double* d_eps, int n, const double* d_in, double* d_out);
 int asm_threads();
 void launch_vector_kernels_once(opmhip_ctx* c);
 void launch_stream_read(opmhip_ctx* c);

@@ -261,7 +261,7 @@ def equilibrate_regions(eqlnum, records, props, rho_ref, cell_depth, cell_zmin, 
 
 
 def equilibrate(props, rho_ref, rec, cell_depth, z_span, sat_limits, grav=9.80665, rs_func=None, nsample=NSAMPLE, rv_func=None,
-                swatinit=None, cell_zspan=None):
+                swatinit=None, cell_zspan=None, endscale=None):
     """props.probe(p, rs, sw, sg) -> (n, 8) (capi.HipFluid layout); rho_ref = (oil, water, gas) surface densities;
     rec = dict(datum, pressure, zwoc, pcow_woc, zgoc, pcgo_goc); cell_depth[]: centre depths; z_span = (top, bottom) of the
     region's cells; sat_limits = dict(Swl, Swu, Sgl, Sgu) (unscaled end points of the saturation tables).
@@ -276,6 +276,11 @@ def equilibrate(props, rho_ref, rec, cell_depth, z_span, sat_limits, grav=9.8066
     rec["accuracy"] (EQUIL item 9): 0 = cell centres; -N = the average over 2N horizontal slices of each cell between its
     mean top and mean bottom depth (cell_zspan (n, 2), cellZSpan :1495-1512), Rs / Rv then from the averaged state at the
     centre depth; positive values are refused, as the reference does.
+    endscale (ENDSCALE family): the dict capi.HipModel.set_endpoint_scaling takes - flags and per-cell arrays of scaled end
+    points (over THESE cells).  Every cell then inverts ITS capillary pressure curves (props.sat_probe(sw, sg, end points of the
+    cell): the scaled EclEpsTwoPhaseLaw the device evaluates) between ITS end points, as the reference does through the
+    material-law manager (satFromPc with oilWaterScaledEpsInfoDrainage(cell), equilibrationhelpers.hh:730-960;
+    accountForScaledSaturations, initstateequil.hh:1257-1330).
     -> dict(pw, po, pg, sw, so, sg, rs, rv) arrays over the cells."""
     if rs_func is None:
         if rec["zgoc"] != rec["datum"]:
@@ -286,6 +291,17 @@ def equilibrate(props, rho_ref, rec, cell_depth, z_span, sat_limits, grav=9.8066
     Swl, Swu, Sgl, Sgu = (sat_limits[k] for k in ("Swl", "Swu", "Sgl", "Sgu"))
     pcow_table = lambda sw: float(props.probe(1e5, sw=sw)[0, PCOW])
     pcgo = lambda sg: float(props.probe(1e5, sg=sg)[0, PCGO])
+    es_flags, es_arrays = {}, {}
+    if endscale is not None:
+        for k, v in endscale.items():
+            if v is None:
+                continue
+            if np.ndim(v) == 0:
+                es_flags[k] = v
+            else:
+                es_arrays[k] = np.asarray(v, float)
+                if es_arrays[k].shape != (len(cell_depth),):
+                    raise ValueError("endscale[%r]: one value per cell expected" % k)
 
     root = _root
 
@@ -296,8 +312,9 @@ def equilibrate(props, rho_ref, rec, cell_depth, z_span, sat_limits, grav=9.8066
         if swatinit.shape != (n,):
             raise ValueError("swatinit: one value per cell expected")
         out["pcw_scale"] = np.ones(n)
-    const_pcow = abs(pcow_table(Swl) - pcow_table(Swu)) < np.finfo(float).eps
-    const_pcgo = abs(pcgo(Sgl) - pcgo(Sgu)) < np.finfo(float).eps
+    limits0 = (Swl, Swu, Sgl, Sgu)
+    const0 = (abs(pcow_table(Swl) - pcow_table(Swu)) < np.finfo(float).eps, abs(pcgo(Sgl) - pcgo(Sgu)) < np.finfo(float).eps)
+    const_pcow, const_pcgo = const0
     acc = int(rec.get("accuracy", 0) or 0)
     if acc > 0:
         raise ValueError("EQUIL item 9 > 0 is not supported (neither is it by the reference, initstateequil.hh:1902-1908)")
@@ -309,6 +326,13 @@ def equilibrate(props, rho_ref, rec, cell_depth, z_span, sat_limits, grav=9.8066
         cell_zspan = np.asarray(cell_zspan, float).reshape(n, 2)
     for c, zc in enumerate(cell_depth):
         scale = [1.0]                                   # this cell's factor on the pcow curve (SWATINIT)
+        if endscale is not None:    # this cell's curves and end points (EclEpsTwoPhaseLaw with the cell's scaled points)
+            es_c = dict(es_flags, **{k: float(a[c]) for k, a in es_arrays.items()})
+            Swl, Swu, Sgl, Sgu = (es_c.get(k, d) for k, d in zip(("swl", "swu", "sgl", "sgu"), limits0))
+            pcow_table = lambda sw, es_c=es_c: float(props.sat_probe(sw, 0.0, es_c)[0, 3])
+            pcgo = lambda sg, es_c=es_c, swl=Swl: float(props.sat_probe(swl, sg, es_c)[0, 4])
+            const_pcow = abs(pcow_table(Swl) - pcow_table(Swu)) < np.finfo(float).eps
+            const_pcgo = abs(pcgo(Sgl) - pcgo(Sgu)) < np.finfo(float).eps
         pcow = lambda sw: scale[0] * pcow_table(sw)
 
         def apply_swatinit(pc, sw_in):

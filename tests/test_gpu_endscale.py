@@ -97,3 +97,37 @@ def test_argument_errors(pkg):
     plain = pkg.decks.cartesian_case(4, 4, 3, state="mixed")    # a fluid without pc_scaling: no per-cell end points
     with pytest.raises(pkg.capi.OpmHipError):
         pkg.capi.HipModel(plain).set_endpoint_scaling(dict(sat_scaling=1))
+
+
+def test_scaled_saturation_functions_probe_bitwise(pkg, orc):
+    """opmhip_sat_probe: krw, kro, krg, pcow, pcgo with one set of scaled end points at random saturations - the device's
+    functions against the oracle's, bit for bit, for every combination of the scaling options; unscaled too"""
+    from test_oracle_endscale import scaled_points
+    fl = corey_fluid(pkg)
+    dev, ora = pkg.capi.HipFluid(fl), oracle_bind.OracleFluid(orc, fl)
+    u = oracle_bind.sat_end_points(orc, fl)
+    rng = np.random.default_rng(31)
+    sw = rng.uniform(0.0, 1.05, 3000)
+    sg = rng.uniform(-0.02, 1.0, 3000) * (1.05 - np.minimum(sw, 1.0))
+    assert np.array_equal(dev.sat_probe(sw, sg), ora.sat_probe(sw, sg))
+    for three in (0, 1):
+        for vert in (0, 1, 2):
+            pts = scaled_points(u, rng)
+            es = dict(sat_scaling=1, three_point_kr=three, krw=vert, kro=vert, krg=vert, pcw=1, pcg=1)
+            es.update({k: float(pts[f]) for f, k in enumerate(pkg.capi.EPS_FIELDS)})
+            a, b = dev.sat_probe(sw, sg, es), ora.sat_probe(sw, sg, es)
+            assert np.array_equal(a, b), (three, vert)
+    es = dict(pcw=1, max_pcow=0.2e5)                                   # vertical scaling of one curve only
+    assert np.array_equal(dev.sat_probe(sw, sg, es), ora.sat_probe(sw, sg, es))
+
+
+def test_equilibration_with_scaled_end_points_on_the_device_functions(pkg, orc):
+    """equil.equilibrate(endscale=...) on top of the DEVICE's scaled functions gives the oracle-based result bit for bit (same
+    probes, same bisection), and the state it hands over is at rest: with the cell's end points on the device the initial
+    residual of a water-oil column is far smaller than without them"""
+    from test_oracle_endscale import endscale_column
+    fl, centre, rec, rho, limits, es, span = endscale_column(pkg)
+    rd = pkg.equil.equilibrate(pkg.capi.HipFluid(fl), rho, rec, centre, span, limits, endscale=es)
+    ro = pkg.equil.equilibrate(oracle_bind.OracleFluid(orc, fl), rho, rec, centre, span, limits, endscale=es)
+    for k in ("pw", "po", "pg", "sw", "so", "sg", "rs"):
+        assert np.array_equal(rd[k], ro[k]), k

@@ -176,3 +176,48 @@ def test_jacobian_with_scaled_end_points_matches_finite_differences(pkg, orc, th
     j0, r0 = p.assemble(86400.0, 0)
     assert not np.array_equal(j0, j1)
     _fd_check(case, m, tol=5e-5)
+
+
+def endscale_column(pkg, nz=30):
+    """a 60 m column across both contacts with per-cell scaled end points and capillary-pressure maxima"""
+    fl = corey_fluid(pkg)
+    dz = 2.0
+    centre = 2000.0 + dz * (np.arange(nz) + 0.5)
+    rec = dict(datum=2025.0, pressure=250e5, zwoc=2045.0, pcow_woc=0.0, zgoc=2025.0, pcgo_goc=0.0, accuracy=0)
+    rho = tuple(fl.pvt[0]["density"])
+    rng = np.random.default_rng(6)
+    es = dict(sat_scaling=1, pcw=1, pcg=1,
+              swl=0.15 + rng.uniform(-0.04, 0.06, nz), swu=np.full(nz, 1.0), sgl=np.zeros(nz), sgu=np.zeros(nz),
+              max_pcow=0.51e5 * rng.uniform(0.6, 1.5, nz), max_pcgo=0.3e5 * rng.uniform(0.6, 1.5, nz))
+    es["sgu"] = 1.0 - es["swl"]
+    es["swcr"] = es["swl"] + 0.05
+    limits = dict(Swl=0.15, Swu=1.0, Sgl=0.0, Sgu=0.85)
+    return fl, centre, rec, rho, limits, es, (2000.0, 2000.0 + dz * nz)
+
+
+def test_equilibration_with_scaled_end_points(pkg, orc):
+    """equil.equilibrate(endscale=...): every cell inverts ITS scaled capillary-pressure curves between ITS end points
+    (satFromPc with the cell's scaled drainage end points, ebos/equil/equilibrationhelpers.hh:730-960).  No reference numbers
+    exist for an ENDSCALE deck (the tree's equil decks have none): held by properties - defaults reproduce the unscaled run,
+    the result is in capillary equilibrium with the cell's own curves, saturations respect the cell's own end points."""
+    fl, centre, rec, rho, limits, es, span = endscale_column(pkg)
+    props = oracle_bind.OracleFluid(orc, fl)
+    plain = pkg.equil.equilibrate(props, rho, rec, centre, span, limits)
+    same = pkg.equil.equilibrate(props, rho, rec, centre, span, limits, endscale=dict(sat_scaling=1, pcw=1, pcg=1))   # no arrays: the tables' own points
+    for k in ("pw", "po", "pg", "sw", "so", "sg", "rs"):
+        np.testing.assert_allclose(same[k], plain[k], rtol=1e-9, atol=1e-9)
+    r = pkg.equil.equilibrate(props, rho, rec, centre, span, limits, endscale=es)
+    sw, sg, so = r["sw"], r["sg"], r["so"]
+    assert np.all(sw >= es["swl"] - 1e-12) and np.all(sw <= 1.0 + 1e-12) and np.all(sg >= -1e-12) and np.all(sg <= es["sgu"] + 1e-12)
+    np.testing.assert_allclose(sw + sg + so, 1.0, atol=1e-12)
+    assert not np.allclose(sw, plain["sw"], atol=1e-3)                  # the end points matter
+    top, bottom = centre < rec["zgoc"] - 15.0, centre > rec["zwoc"] + 8.0
+    assert np.allclose(sw[bottom], 1.0) and np.allclose(sg[top], es["sgu"][top]) and np.allclose(sw[top], es["swl"][top])
+    # capillary equilibrium with the cell's OWN curves wherever a saturation is strictly inside its interval
+    for c in range(len(centre)):
+        e = {k: (float(v[c]) if np.ndim(v) else v) for k, v in es.items()}
+        pc = props.sat_probe(sw[c], sg[c], e)[0]
+        if es["swl"][c] + 1e-6 < sw[c] < 1.0 - 1e-6 and so[c] > 1e-6:
+            assert abs(pc[3] - (r["po"][c] - r["pw"][c])) < 1.0          # Pa
+        if 1e-6 < sg[c] < es["sgu"][c] - 1e-6 and so[c] > 1e-6:
+            assert abs(pc[4] - (r["pg"][c] - r["po"][c])) < 1.0
