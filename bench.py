@@ -274,6 +274,7 @@ def main():
     ap.add_argument("--steady-after", type=int, default=200, help="second timed window starts at this Newton iteration (0: none)")
     ap.add_argument("--steady-steps", type=int, default=100)
     ap.add_argument("--preconditioner", default="ilu0", choices=["ilu0", "cpr", "cpr_trueimpes", "cpr_quasiimpes"], help="--linear-solver-configuration of the run behind `value`")
+    ap.add_argument("--cpr-reuse-setup", type=int, default=3, choices=[0, 1, 2, 3], help="Flow's --cpr-reuse-setup for the CPR runs: when the hierarchy's structure is built anew (3 = never, the default of Flow)")
     ap.add_argument("--no-cpr-side-run", action="store_true", help="skip the side runs with the CPR preconditioners (extra keys `cpr`, `cpr_quasiimpes`)")
     a = ap.parse_args()
 
@@ -310,7 +311,7 @@ def main():
     pkg = importlib.import_module("opm-autodiff_amd")
     n = a.n
     skw = dict(device_id=local_rank, reorder=a.reorder, tolerance=1e-2, maxit=200, ilu_relaxation=0.9, chain_length=a.chain_length,
-               preconditioner=a.preconditioner)
+               preconditioner=a.preconditioner, cpr_reuse_setup=a.cpr_reuse_setup)
     if world == 1:
         case = pkg.decks.cartesian_case(n, n, n, state="mixed", heterogeneous=False)
         src = pkg.decks.five_spot_source(case, rate_sm3_per_day=pkg.decks.BENCH_RATE_SM3_PER_DAY * (n / 100.0) ** 2)
@@ -421,10 +422,10 @@ def main():
     # the same workload with the CPR preconditioners, side by side, each in its own context with its own warm-up and timed
     # windows: "cpr" = cpr_trueimpes (what the name means in Flow, setupPropertyTree.cpp:62-76) and "cpr_quasiimpes"
     cpr_sides = {}
-    def cpr_window(prec):
+    def cpr_window(prec, **over):
         def run():
             nonlocal sim, model
-            model2 = pkg.capi.HipModel(case, **dict(skw, preconditioner=prec))
+            model2 = pkg.capi.HipModel(case, **dict(skw, preconditioner=prec, **over))
             model2.set_state(case["pv"], case["meaning"])
             model2.set_source(src)
             sim_main, model_main = sim, model
@@ -456,6 +457,8 @@ def main():
     if a.preconditioner == "ilu0" and world == 1 and not a.no_cpr_side_run:
         for prec in ("cpr", "cpr_quasiimpes"):
             cpr_sides[prec] = guarded("CPR side run (%s)" % prec, cpr_window(prec))
+        if a.cpr_reuse_setup == 3:   # Flow's other --cpr-reuse-setup worth a line: the hierarchy's structure follows the state
+            cpr_sides["cpr_reuse_setup_2"] = guarded("CPR side run (cpr, --cpr-reuse-setup=2)", cpr_window("cpr", cpr_reuse_setup=2))
     # what a kernel that only streams reaches on THIS card (reads the Jacobian's values once per launch)
     stream = guarded("stream_read probe", lambda: {"ms": model.time_kernel("stream_read", reps=20)})
     stream_ms = stream.get("ms")
@@ -492,6 +495,9 @@ def main():
         # "cpr" is Flow's cpr = cpr_trueimpes, "cpr_quasiimpes" the quasi-IMPES variant
         "cpr": cpr_sides.get("cpr"),
         "cpr_quasiimpes": cpr_sides.get("cpr_quasiimpes"),
+        # "cpr" with --cpr-reuse-setup=2: the structure of the pressure hierarchy is built anew (0.3 s of host time, inside the
+        # windows where it happens) whenever a solve took more than 10 iterations; the two runs above keep Flow's default 3 (never)
+        "cpr_reuse_setup_2": cpr_sides.get("cpr_reuse_setup_2"),
         "preconditioner": a.preconditioner,
         "rccl": rccl,
         "device": device_info(torch, local_rank),

@@ -83,7 +83,12 @@ typedef struct opmhip_config {
     int spmv_pipe_wgs;     /* pipelined SpMV: resident workgroups it is sized for (0 = 2048, the MI355X default; < 0 = one
                             * tile per workgroup instead); tuning only, results are the same bits either way */
     int preconditioner;    /* opmhip_preconditioner: --linear-solver-configuration */
-    int reserved[4];       /* 0 */
+    int cpr_reuse_setup;   /* --cpr-reuse-setup (linalg/FlowLinearSolverParameters.hpp:315, ISTLSolverEbos.hpp:401-426): when the
+                            * STRUCTURE of the CPR hierarchy (aggregates, coarse patterns) is built anew from the matrix in hand:
+                            * 0 for every linear solve, 1 at the first Newton iteration of every time step (contexts that
+                            * assemble; others: never), 2 when the last solve took more than 10 iterations, 3 never after the
+                            * first (Flow's default, and opmhip_default_config's).  The VALUES always follow the matrix. */
+    int reserved[3];       /* 0 */
 } opmhip_config;
 
 /* bda::BdaResult (bda/BdaResult.hpp:28-40) plus the reference's per-phase timers. */

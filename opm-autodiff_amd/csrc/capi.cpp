@@ -167,6 +167,7 @@ void opmhip_default_config(opmhip_config* cfg) {
     cfg->relax_mode = OPMHIP_RELAX_POST_SCALE;
     cfg->reorder = OPMHIP_REORDER_GRAPH_COLORING;  // default of the accelerator path, bda/BdaBridge.cpp:72-73
     cfg->zero_diag_fix = 1;
+    cfg->cpr_reuse_setup = 3;     // CprReuseSetup (FlowLinearSolverParameters.hpp:212-214): never recreate
 }
 
 int opmhip_create(const opmhip_config* cfg, opmhip_ctx** out) {
@@ -176,6 +177,7 @@ int opmhip_create(const opmhip_config* cfg, opmhip_ctx** out) {
     if (cfg->maxit < 1 || !(cfg->tolerance > 0.0)) { g_err = "opmhip_create: maxit/tolerance out of range"; return OPMHIP_INVALID_ARGUMENT; }
     if (cfg->preconditioner < OPMHIP_PRECOND_ILU0 || cfg->preconditioner > OPMHIP_PRECOND_CPR_TRUEIMPES) { g_err = "opmhip_create: unknown preconditioner"; return OPMHIP_INVALID_ARGUMENT; }
     if (cfg->chain_length < 0) { g_err = "opmhip_create: chain_length < 0"; return OPMHIP_INVALID_ARGUMENT; }
+    if (cfg->cpr_reuse_setup < 0 || cfg->cpr_reuse_setup > 3) { g_err = "opmhip_create: cpr_reuse_setup must be 0 .. 3"; return OPMHIP_INVALID_ARGUMENT; }
     int ndev = 0;
     hipError_t e = hipGetDeviceCount(&ndev);
     if (e != hipSuccess || ndev <= 0) {
@@ -290,6 +292,7 @@ int opmhip_solve_system(opmhip_ctx* c, int N, int nnz, int dim, double* vals, co
         OPMHIP_HIP(c, hipStreamSynchronize(c->stream));
         const double t3 = now();
         c->have_result = true;
+        c->last_solve_iterations = res->iterations;
         res->t_copy = t1 - t0;
         res->t_factor = t2 - t1;
         res->t_solve = t3 - t2;

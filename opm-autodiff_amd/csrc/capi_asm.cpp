@@ -713,6 +713,7 @@ int opmhip_assemble(opmhip_ctx* c, double dt, int iteration, double* jac, double
         if (!(dt > 0.0) || iteration < 0) return fail(c, OPMHIP_INVALID_ARGUMENT, "assemble: dt must be positive, iteration >= 0");
         OPMHIP_HIP(c, hipSetDevice(c->device));
         c->asmb.last_dt = dt;
+        c->asmb.last_iteration = iteration;
         launch_assemble(c, dt, iteration);
         OPMHIP_HIP(c, hipGetLastError());
         c->system_loaded = true;

@@ -15,8 +15,11 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <chrono>
 #include <cmath>
+#include <cstdlib>
 #include <numeric>
+#include <thread>
 
 #include "internal.hpp"
 
@@ -60,32 +63,71 @@ void pairwise(const HCsr& A, double beta, bool anySign, std::vector<int>& agg, i
     }
 }
 // Galerkin product for piecewise-constant prolongation: coarse pattern (columns ascending), gather lists (fine entries of a
-// coarse entry in ascending order), values.  Sort-based: entries keyed by (coarse row, coarse column).
+// coarse entry in ascending order), values.  Row by row over the members of each aggregate: the few (coarse column, fine
+// entry) pairs of a coarse row are sorted on the spot - O(nnz log(row)) instead of a stable sort of all nnz keys (round 2: 1.5 s
+// of host time for the hierarchy of a 10^6-cell grid, most of it here); same lists, same sums, same order.
 void galerkin(const HCsr& A, const std::vector<int>& agg, int nc, HCsr& C, std::vector<int>& gptr, std::vector<int>& gidx) {
     const int nnz = (int)A.col.size();
-    std::vector<long long> key(nnz);
-    for (int i = 0; i < A.n; ++i)
-        for (int k = A.rowptr[i]; k < A.rowptr[i + 1]; ++k) key[k] = (long long)agg[i] * nc + agg[A.col[k]];
-    gidx.resize(nnz);
-    std::iota(gidx.begin(), gidx.end(), 0);
-    std::stable_sort(gidx.begin(), gidx.end(), [&](int a, int b) { return key[a] < key[b]; });   // stable: ascending fine entry inside a key
+    std::vector<int> mp(nc + 1, 0), mi(A.n);
+    for (int i = 0; i < A.n; ++i) mp[agg[i] + 1]++;
+    for (int I = 0; I < nc; ++I) mp[I + 1] += mp[I];
+    {
+        std::vector<int> w(mp.begin(), mp.end() - 1);
+        for (int i = 0; i < A.n; ++i) mi[w[agg[i]]++] = i;   // members ascending
+    }
+    // the coarse rows are independent: slices of them are built by a few host threads, each into vectors of its own, and
+    // joined in order - the same lists and sums whatever the number of threads
+    const int T = std::max(1, std::min({(int)std::thread::hardware_concurrency(), 8, nc / 4096 + 1}));
+    struct Part { std::vector<int> rowlen, col, glen, gidx; std::vector<double> val; };
+    std::vector<Part> parts(T);
+    auto work = [&](int t) {
+        Part& Q = parts[t];
+        const int I0 = (int)((long long)nc * t / T), I1 = (int)((long long)nc * (t + 1) / T);
+        std::vector<std::pair<int, int>> pairs;   // (coarse column, fine entry) of the coarse row in hand
+        Q.rowlen.reserve(I1 - I0);
+        for (int I = I0; I < I1; ++I) {
+            pairs.clear();
+            for (int q = mp[I]; q < mp[I + 1]; ++q) {
+                const int i = mi[q];
+                for (int k = A.rowptr[i]; k < A.rowptr[i + 1]; ++k) pairs.emplace_back(agg[A.col[k]], k);
+            }
+            std::sort(pairs.begin(), pairs.end());
+            int len = 0;
+            for (size_t q = 0; q < pairs.size();) {
+                const int cc = pairs[q].first;
+                double sum = 0.0;
+                size_t e = q;
+                while (e < pairs.size() && pairs[e].first == cc) { sum += A.val[pairs[e].second]; Q.gidx.push_back(pairs[e].second); ++e; }
+                Q.col.push_back(cc);
+                Q.val.push_back(sum);
+                Q.glen.push_back((int)(e - q));
+                ++len;
+                q = e;
+            }
+            Q.rowlen.push_back(len);
+        }
+    };
+    if (T == 1) work(0);
+    else {
+        std::vector<std::thread> th;
+        for (int t = 0; t < T; ++t) th.emplace_back(work, t);
+        for (auto& x : th) x.join();
+    }
     C.n = nc;
     C.rowptr.assign(nc + 1, 0);
     C.col.clear();
     C.val.clear();
     gptr.assign(1, 0);
-    for (int q = 0; q < nnz;) {
-        const long long kq = key[gidx[q]];
-        double s = 0.0;
-        int e = q;
-        while (e < nnz && key[gidx[e]] == kq) { s += A.val[gidx[e]]; ++e; }
-        C.col.push_back((int)(kq % nc));
-        C.val.push_back(s);
-        C.rowptr[(int)(kq / nc) + 1]++;
-        gptr.push_back(e);
-        q = e;
+    gidx.clear();
+    gidx.reserve(nnz);
+    int I = 0;
+    for (const Part& Q : parts) {
+        for (int len : Q.rowlen) { C.rowptr[I + 1] = C.rowptr[I] + len; ++I; }
+        C.col.insert(C.col.end(), Q.col.begin(), Q.col.end());
+        C.val.insert(C.val.end(), Q.val.begin(), Q.val.end());
+        for (int gl : Q.glen) gptr.push_back(gptr.back() + gl);
+        gidx.insert(gidx.end(), Q.gidx.begin(), Q.gidx.end());
     }
-    for (int I = 0; I < nc; ++I) C.rowptr[I + 1] += C.rowptr[I];
 }
 }  // namespace
 
@@ -550,6 +592,10 @@ static int cpr_setup_structure_impl(opmhip_ctx* c) {
     const Pattern& P = c->pat;
     CprDev& R = c->cpr;
     int rc;
+    static const bool timing = std::getenv("OPMHIP_CPR_TIMING") != nullptr;
+    auto now = [] { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+    double tAgg = 0.0, tGal = 0.0, tUp = 0.0, t0 = now();
+#define CPR_T(acc, stmt) do { const double t_ = now(); stmt; acc += now() - t_; } while (0)
     if (c->comm.nranks > 1) return fail(c, OPMHIP_INVALID_ARGUMENT, "cpr: not available in decomposed runs (the reference disables accelerators there too)");
     if (!R.d_w && (rc = dev_alloc(c, &R.d_w, (size_t)P.Nb * BS))) return rc;
     if ((rc = dev_alloc(c, &R.d_r, (size_t)P.Nb * BS))) return rc;
@@ -561,7 +607,8 @@ static int cpr_setup_structure_impl(opmhip_ctx* c) {
     R.lv.clear();
     R.lv.emplace_back();
     std::vector<int> pos;   // ELL position of every CSR entry of the level being coarsened
-    if ((rc = upload_ell(c, A, R.lv[0], pos, false))) return rc;
+    CPR_T(tUp, rc = upload_ell(c, A, R.lv[0], pos, false));
+    if (rc) return rc;
     if ((rc = dev_alloc(c, &R.d_pcol, (size_t)3 * R.lv[0].W * P.Nb))) return rc;     // pressure columns of the blocks, ELL, component-major
     OPMHIP_HIP(c, hipMemsetAsync(R.d_pcol, 0, (size_t)3 * R.lv[0].W * P.Nb * sizeof(double), c->stream));   // the padding stays 0
     if ((rc = cpr_weights(c))) return rc;
@@ -581,9 +628,9 @@ static int cpr_setup_structure_impl(opmhip_ctx* c) {
         for (int attempt = 0; attempt < 3; ++attempt) {
             const double b = attempt == 0 ? R.beta : 0.0;
             const bool lvl0 = R.lv.size() == 1;   // the finest level is stored in the ILU ordering: visit it in natural order
-            pairwise(A, b, attempt == 2, a1, n1, lvl0 ? P.fromOrder.data() : nullptr, lvl0 ? P.toOrder.data() : nullptr);
-            galerkin(A, a1, n1, A1, g1p, g1i);
-            pairwise(A1, b, attempt == 2, a2, n2);
+            CPR_T(tAgg, pairwise(A, b, attempt == 2, a1, n1, lvl0 ? P.fromOrder.data() : nullptr, lvl0 ? P.toOrder.data() : nullptr));
+            CPR_T(tGal, galerkin(A, a1, n1, A1, g1p, g1i));
+            CPR_T(tAgg, pairwise(A1, b, attempt == 2, a2, n2));
             if (n2 <= (int)(0.5 * A.n)) break;
         }
         if (n2 >= (int)(0.8 * A.n)) break;   // coarsening stalls: this level is the coarsest
@@ -591,7 +638,7 @@ static int cpr_setup_structure_impl(opmhip_ctx* c) {
         for (int i = 0; i < A.n; ++i) agg[i] = a2[a1[i]];
         HCsr Ac;
         std::vector<int> gptr, gidx;
-        galerkin(A, agg, n2, Ac, gptr, gidx);
+        CPR_T(tGal, galerkin(A, agg, n2, Ac, gptr, gidx));
         {   // a coarse level whose rows outgrow the ELL image (fault- and NNC-heavy patterns): stop here, this level is the coarsest
             int Wc = 1;
             for (int I = 0; I < Ac.n; ++I) Wc = std::max(Wc, Ac.rowptr[I + 1] - Ac.rowptr[I]);
@@ -616,7 +663,8 @@ static int cpr_setup_structure_impl(opmhip_ctx* c) {
         }
         R.lv.emplace_back();
         std::vector<int> cposv;
-        if ((rc = upload_ell(c, Ac, R.lv.back(), cposv, Ac.n <= CPR_LPR_ROWS))) return rc;
+        CPR_T(tUp, rc = upload_ell(c, Ac, R.lv.back(), cposv, Ac.n <= CPR_LPR_ROWS));
+        if (rc) return rc;
         if ((rc = dev_upload(c, &R.lv[R.lv.size() - 2].d_cpos, cposv))) return rc;   // where the coarse entries go
         pos = cposv;
         A = std::move(Ac);
@@ -624,14 +672,35 @@ static int cpr_setup_structure_impl(opmhip_ctx* c) {
     R.coarse_direct = R.lv.back().n <= CPR_COARSE_DIRECT;
     if (R.coarse_direct && (rc = dev_alloc(c, &R.d_lu, (size_t)R.lv.back().n * R.lv.back().n + 1))) return rc;   // + 1: the pivot flag
     R.structured = true;
+    if (timing) std::fprintf(stderr, "opmhip cpr set-up: %.3f s (matching %.3f, Galerkin %.3f, level images + uploads %.3f), %zu levels\n", now() - t0, tAgg, tGal, tUp, R.lv.size());
+#undef CPR_T
     return OPMHIP_SUCCESS;
 }
 
 // values: weights, pressure matrix, Galerkin values down the hierarchy, inverse diagonals, coarsest LU (every solve)
+// gives the hierarchy's device arrays back (everything cpr_setup_structure allocates; handed-in weights stay)
+static void cpr_release_structure(opmhip_ctx* c) {
+    CprDev& R = c->cpr;
+    (void)hipStreamSynchronize(c->stream);
+    for (CprLevelDev& L : R.lv) {
+        dev_free(c, &L.d_ecol); dev_free(c, &L.d_rlen); dev_free(c, &L.d_diag); dev_free(c, &L.d_cpos);
+        dev_free(c, &L.d_val); dev_free(c, &L.d_dinv); dev_free(c, &L.d_x2);
+        dev_free(c, &L.d_agg); dev_free(c, &L.d_mptr); dev_free(c, &L.d_midx); dev_free(c, &L.d_gptr); dev_free(c, &L.d_gidx);
+        dev_free(c, &L.d_b); dev_free(c, &L.d_x); dev_free(c, &L.d_r);
+    }
+    R.lv.clear();
+    dev_free(c, &R.d_r); dev_free(c, &R.d_y); dev_free(c, &R.d_z); dev_free(c, &R.d_lu); dev_free(c, &R.d_pcol);
+    R.structured = false;
+}
 int cpr_update(opmhip_ctx* c) {
     const Pattern& P = c->pat;
     CprDev& R = c->cpr;
     int rc;
+    if (R.structured) {   // --cpr-reuse-setup (ISTLSolverEbos.hpp:401-426 shouldCreateSolver): build the structure anew from this matrix?
+        const int mode = c->cfg.cpr_reuse_setup;
+        const bool anew = mode == 0 || (mode == 1 && c->asmb.assembled && c->asmb.last_iteration == 0) || (mode == 2 && c->last_solve_iterations > 10);
+        if (anew) cpr_release_structure(c);
+    }
     if (!R.structured && (rc = cpr_setup_structure(c))) return rc;
     const int ps = prof_begin(c, PROF_ILU_FACTOR);
     if ((rc = cpr_weights(c))) { prof_end(c, ps); return rc; }

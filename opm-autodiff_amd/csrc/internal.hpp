@@ -122,6 +122,7 @@ struct AsmDev {
     int *d_pvtnum = nullptr, *d_satnum = nullptr;
     double *d_pv = nullptr, *d_iq = nullptr, *d_storageOld = nullptr, *d_source = nullptr, *d_dsource = nullptr;
     unsigned char *d_meaning = nullptr, *d_wasSwitched = nullptr, *d_stage_u8 = nullptr;
+    int last_iteration = -1;                // Newton iteration index of the last opmhip_assemble (--cpr-reuse-setup=1)
     double last_dt = 0.0;                   // time step of the last opmhip_assemble (true-IMPES weights scale the storage term by V / dt)
     double* d_drift = nullptr;              // residual * dt of the last accepted time step (drift compensation), Nloc x 3
     bool drift_enabled = true;              // EclEnableDriftCompensation defaults to true (ebos/eclproblem.hh:496-498)
@@ -230,6 +231,7 @@ struct opmhip_ctx {
     double minv_scale = 1.0;    // during a solve: the factor the preconditioned vectors (d_pw, d_s) are still to be multiplied by
     double* d_part2 = nullptr;  // second-level partials: 2 x RED1_BLOCKS
     int npart = 0;
+    int last_solve_iterations = 0;   // BiCGStab iterations of the last opmhip_solve_system (--cpr-reuse-setup=2)
     int last_dot_count = 0;     // partial sums the last launch_spmv left in d_part (per list)
     double* h_pinned = nullptr;  // SC_COUNT doubles, pinned
     // read-back ring of the BiCGStab stopping rule: the finalize kernel writes (norm, norm_0, done) of half iteration h

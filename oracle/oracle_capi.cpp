@@ -272,6 +272,8 @@ int orc_cpr_set_natural_ids(orc_cpr* h, int n, const int* nat) {
     return 0;
 }
 int orc_cpr_set_coarse_sweeps(orc_cpr* h, int n) { h->P.amg.coarseSweeps = n < 0 ? 0 : n; return 0; }
+// the next update / solve builds the hierarchy's STRUCTURE anew from its matrix (what --cpr-reuse-setup 0 / 1 / 2 make the product do)
+int orc_cpr_rebuild_structure(orc_cpr* h) { h->P.structured = false; return 0; }
 int orc_cpr_set_max_levels(orc_cpr* h, int n) { h->P.amg.maxLevels = n < 1 ? 1 : n; h->P.structured = false; return 0; }
 int orc_cpr_set_sweeps(orc_cpr* h, int nu) { if (nu < 0) { h->P.amg.joinAtStall = true; h->P.structured = false; return 0; } h->P.amg.nu = nu < 1 ? 1 : nu; return 0; }   // experiments: V(nu, nu)
 int orc_cpr_use_reference_amg(orc_cpr* h, int on) { h->P.useDune = on != 0; h->P.structured = false; return 0; }

@@ -489,6 +489,11 @@ class OracleCpr:
         self.o.lib.orc_cpr_set_natural_ids.argtypes = [_vp, C.c_int, _i]
         self.o.lib.orc_cpr_set_natural_ids(self.h, len(a), a)
 
+    def rebuild_structure(self):
+        """the next update / solve builds the hierarchy's structure anew from its matrix"""
+        self.o.lib.orc_cpr_rebuild_structure.argtypes = [_vp]
+        self.o.lib.orc_cpr_rebuild_structure(self.h)
+
     def use_reference_amg(self, on=True):
         """the restatement of the reference's Dune::Amg hierarchy instead of the product's (comparison only)"""
         self.o.lib.orc_cpr_use_reference_amg(self.h, int(on))

@@ -20,6 +20,8 @@ def test_default_config_matches_flow_defaults(pkg):
     # linalg/FlowLinearSolverParameters.hpp:142-154
     assert (cfg.maxit, cfg.tolerance, cfg.ilu_relaxation) == (200, 1e-2, 0.9)
     assert cfg.reorder == pkg.capi.REORDER["graph_coloring"] and cfg.zero_diag_fix == 1
+    # --linear-solver-configuration=ilu0, --cpr-reuse-setup=3 (FlowLinearSolverParameters.hpp:212-214)
+    assert cfg.preconditioner == pkg.capi.PRECONDITIONER["ilu0"] and cfg.cpr_reuse_setup == 3 and cfg.chain_length == 0
 
 
 def test_no_gpu_means_loud_failure(pkg):

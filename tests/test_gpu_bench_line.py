@@ -35,4 +35,4 @@ def test_bench_line_contract():
     assert cb["cores"] == 1 or str(cb["cores"]) in cb["host"]["thread_sweep_newton_its_per_s"]
     assert d["steady_state"]["steps"] == 3 and d["stream_ceiling"]["read_GBps"] > 0
     # Flow's "cpr" (true-IMPES weights) and the quasi-IMPES variant, side by side under their reference names
-    assert d["cpr"]["value"] > 0 and d["cpr_quasiimpes"]["value"] > 0 and d["rccl"] is None
+    assert d["cpr"]["value"] > 0 and d["cpr_quasiimpes"]["value"] > 0 and d["cpr_reuse_setup_2"]["value"] > 0 and d["rccl"] is None
