@@ -250,12 +250,27 @@ __global__ __launch_bounds__(256) void k_cpr_dense_lu(int n, int W, int rm, cons
     }
 }
 // forward / backward substitution, one wavefront's worth of a workgroup; lane-serial (n <= 128: microseconds)
+// mem4f != NULL: b[i] = sum of the finer level's residual over aggregate i (k_cpr_restrict's statement), formed here
 __global__ __launch_bounds__(64) void k_cpr_dense_solve(int n, const double* __restrict__ lu, const double* __restrict__ b, double* __restrict__ x,
-                                                        const double* __restrict__ done) {
+                                                        const int* __restrict__ mem4f, const double* __restrict__ rf, const double* __restrict__ done) {
     CPR_DONE_CHECK
+    __shared__ double sb[CPR_COARSE_DIRECT];
+    for (int i = threadIdx.x; i < n; i += 64) {
+        double s;
+        if (mem4f) {
+            const int* m = &mem4f[4 * i];
+            s = 0.0;
+            s += rf[m[0]];
+            if (m[1] >= 0) s += rf[m[1]];
+            if (m[2] >= 0) s += rf[m[2]];
+            if (m[3] >= 0) s += rf[m[3]];
+        } else s = b[i];
+        sb[i] = s;
+    }
+    __syncthreads();
     if (threadIdx.x != 0) return;
     for (int i = 0; i < n; ++i) {
-        double s = b[i];
+        double s = sb[i];
         for (int j = 0; j < i; ++j) s -= lu[(size_t)i * n + j] * x[j];
         x[i] = s;
     }
@@ -326,25 +341,25 @@ __device__ __forceinline__ double cpr_group_subtract(double s, const double (&p)
     }
     return s;
 }
-__global__ __launch_bounds__(256) void k_cpr_jacobi_lpr(int n, int W, double omega, const int* __restrict__ ecol, const double* __restrict__ val,
-                                                        const double* __restrict__ dinv, const double* __restrict__ b, const double* __restrict__ xin,
-                                                        double* __restrict__ xout, const double* __restrict__ done) {
-    CPR_DONE_CHECK
-    const int g = (blockIdx.x * blockDim.x + threadIdx.x) / CPR_LPR, l = threadIdx.x % CPR_LPR;
-    const int i = g < n ? g : n - 1;
-    double p[CPR_LPR_SLOTS];
-#pragma unroll
-    for (int slot = 0; slot < CPR_LPR_SLOTS; ++slot) {
-        const int j = slot * CPR_LPR + l;
-        p[slot] = 0.0;
-        if (j < W) p[slot] = val[(size_t)i * W + j] * xin[ecol[(size_t)i * W + j]];
-    }
-    const double s = cpr_group_subtract(b[i], p, W);
-    if (l == 0 && g < n) xout[i] = xin[i] + omega * dinv[i] * s;
+// Right-hand side of a coarse row formed where it is needed: b[c] = sum of the finer level's residual over the aggregate's
+// members - k_cpr_restrict's statement (s = 0, then the members in ascending order), so the same bits - from a four-int member
+// record.  The lane-group kernels of a coarse level call it for the row and for every neighbour: the restriction launch
+// between two levels (5 us for a few thousand rows) is gone.
+__device__ __forceinline__ double cpr_restricted(const int4* __restrict__ mem4, const double* __restrict__ rf, int c) {
+    const int4 m = mem4[c];
+    double s = 0.0;
+    s += rf[m.x];
+    if (m.y >= 0) s += rf[m.y];
+    if (m.z >= 0) s += rf[m.z];
+    if (m.w >= 0) s += rf[m.w];
+    return s;
 }
-__global__ __launch_bounds__(256) void k_cpr_down_lpr(int n, int W, double omega, const int* __restrict__ ecol, const double* __restrict__ val,
-                                                      const double* __restrict__ dinv, const double* __restrict__ b, double* __restrict__ x,
-                                                      double* __restrict__ r, const double* __restrict__ done) {
+// FUSED (coarsest level, first sweep): b and the iterate x = omega D^-1 b it starts from are formed on the fly (b is stored for the sweeps that follow)
+template <bool FUSED>
+__global__ __launch_bounds__(256) void k_cpr_jacobi_lpr(int n, int W, double omega, const int* __restrict__ ecol, const double* __restrict__ val,
+                                                        const double* __restrict__ dinv, double* __restrict__ b, const double* __restrict__ xin,
+                                                        double* __restrict__ xout, const int4* __restrict__ mem4f, const double* __restrict__ rf,
+                                                        const double* __restrict__ done) {
     CPR_DONE_CHECK
     const int g = (blockIdx.x * blockDim.x + threadIdx.x) / CPR_LPR, l = threadIdx.x % CPR_LPR;
     const int i = g < n ? g : n - 1;
@@ -355,12 +370,40 @@ __global__ __launch_bounds__(256) void k_cpr_down_lpr(int n, int W, double omega
         p[slot] = 0.0;
         if (j < W) {
             const int c = ecol[(size_t)i * W + j];
-            p[slot] = val[(size_t)i * W + j] * (omega * dinv[c] * b[c]);
+            p[slot] = val[(size_t)i * W + j] * (FUSED ? omega * dinv[c] * cpr_restricted(mem4f, rf, c) : xin[c]);
         }
     }
-    const double s = cpr_group_subtract(b[i], p, W);
+    const double bi = FUSED ? cpr_restricted(mem4f, rf, i) : b[i];
+    const double s = cpr_group_subtract(bi, p, W);
     if (l == 0 && g < n) {
-        x[i] = omega * dinv[i] * b[i];
+        if (FUSED) b[i] = bi;
+        xout[i] = (FUSED ? omega * dinv[i] * bi : xin[i]) + omega * dinv[i] * s;
+    }
+}
+// FUSED: b comes from the finer level's residual (cpr_restricted) and is stored for the way up
+template <bool FUSED>
+__global__ __launch_bounds__(256) void k_cpr_down_lpr(int n, int W, double omega, const int* __restrict__ ecol, const double* __restrict__ val,
+                                                      const double* __restrict__ dinv, double* __restrict__ b, double* __restrict__ x,
+                                                      double* __restrict__ r, const int4* __restrict__ mem4f, const double* __restrict__ rf,
+                                                      const double* __restrict__ done) {
+    CPR_DONE_CHECK
+    const int g = (blockIdx.x * blockDim.x + threadIdx.x) / CPR_LPR, l = threadIdx.x % CPR_LPR;
+    const int i = g < n ? g : n - 1;
+    double p[CPR_LPR_SLOTS];
+#pragma unroll
+    for (int slot = 0; slot < CPR_LPR_SLOTS; ++slot) {
+        const int j = slot * CPR_LPR + l;
+        p[slot] = 0.0;
+        if (j < W) {
+            const int c = ecol[(size_t)i * W + j];
+            p[slot] = val[(size_t)i * W + j] * (omega * dinv[c] * (FUSED ? cpr_restricted(mem4f, rf, c) : b[c]));
+        }
+    }
+    const double bi = FUSED ? cpr_restricted(mem4f, rf, i) : b[i];
+    const double s = cpr_group_subtract(bi, p, W);
+    if (l == 0 && g < n) {
+        if (FUSED) b[i] = bi;
+        x[i] = omega * dinv[i] * bi;
         r[i] = s;
     }
 }
@@ -658,6 +701,15 @@ static int cpr_setup_structure_impl(opmhip_ctx* c) {
             if ((rc = dev_upload(c, &L.d_agg, agg))) return rc;
             if ((rc = dev_upload(c, &L.d_mptr, mptr))) return rc;
             if ((rc = dev_upload(c, &L.d_midx, midx))) return rc;
+            {   // four-int member records (two pairwise passes: never more than four members) for cpr_restricted
+                std::vector<int> mem4((size_t)4 * n2, -1);
+                bool fits = true;
+                for (int I = 0; I < n2 && fits; ++I) {
+                    fits = mptr[I + 1] - mptr[I] <= 4 && mptr[I + 1] > mptr[I];
+                    for (int q = mptr[I]; fits && q < mptr[I + 1]; ++q) mem4[(size_t)4 * I + (q - mptr[I])] = midx[q];
+                }
+                if (fits && (rc = dev_upload(c, &L.d_mem4, mem4))) return rc;
+            }
             if ((rc = dev_upload(c, &L.d_gptr, gptr))) return rc;
             if ((rc = dev_upload(c, &L.d_gidx, gidx))) return rc;
         }
@@ -685,7 +737,7 @@ static void cpr_release_structure(opmhip_ctx* c) {
     for (CprLevelDev& L : R.lv) {
         dev_free(c, &L.d_ecol); dev_free(c, &L.d_rlen); dev_free(c, &L.d_diag); dev_free(c, &L.d_cpos);
         dev_free(c, &L.d_val); dev_free(c, &L.d_dinv); dev_free(c, &L.d_x2);
-        dev_free(c, &L.d_agg); dev_free(c, &L.d_mptr); dev_free(c, &L.d_midx); dev_free(c, &L.d_gptr); dev_free(c, &L.d_gidx);
+        dev_free(c, &L.d_agg); dev_free(c, &L.d_mptr); dev_free(c, &L.d_midx); dev_free(c, &L.d_mem4); dev_free(c, &L.d_gptr); dev_free(c, &L.d_gidx);
         dev_free(c, &L.d_b); dev_free(c, &L.d_x); dev_free(c, &L.d_r);
     }
     R.lv.clear();
@@ -722,9 +774,17 @@ int cpr_update(opmhip_ctx* c) {
     return OPMHIP_SUCCESS;
 }
 
+// does level l (> 0) form its right-hand side itself, from the finer level's residual (cpr_restricted)?  Then no restriction
+// kernel runs between the two levels.  Lane-group levels do, and the dense solve of the coarsest level.
+static bool cpr_forms_rhs(const CprDev& R, size_t l) {
+    static const bool off = std::getenv("OPMHIP_CPR_UNFUSED") != nullptr;   // A/B switch: the restriction as a launch of its own
+    if (off || l == 0 || l >= R.lv.size() || !R.lv[l - 1].d_mem4) return false;
+    return R.lv[l].rm || (l + 1 == R.lv.size() && R.coarse_direct);
+}
 // does level l take its pre-smoothed iterate x = omega D^-1 b from the kernel that produces b (the restriction above it)?
 static bool cpr_presmooth_rides(const CprDev& R, size_t l) {
     const CprLevelDev& L = R.lv[l];
+    if (cpr_forms_rhs(R, l)) return false;
     if (l + 1 == R.lv.size()) return !R.coarse_direct;   // Jacobi coarse "solve": starts with the same statement
     return !L.rm;                                         // lane-group levels form it on the fly inside k_cpr_down_lpr
 }
@@ -734,29 +794,34 @@ static const double* cpr_vcycle(opmhip_ctx* c, size_t l, double* fineOut = nullp
     CprDev& R = c->cpr;
     CprLevelDev& L = R.lv[l];
     const double* done = c->d_done;
-    const bool havex = cpr_presmooth_rides(R, l);   // L.d_x = omega D^-1 b is there already
+    const bool fused = cpr_forms_rhs(R, l);           // b = restriction of the finer level's residual, formed by this level's first kernel
+    const bool havex = cpr_presmooth_rides(R, l);     // L.d_x = omega D^-1 b is there already
+    const int4* mem4f = fused ? (const int4*)R.lv[l - 1].d_mem4 : nullptr;
+    const double* rf = fused ? R.lv[l - 1].d_r : nullptr;
     if (l + 1 == R.lv.size()) {
         if (R.coarse_direct) {
-            hipLaunchKernelGGL(k_cpr_dense_solve, dim3(1), dim3(64), 0, c->stream, L.n, R.d_lu, L.d_b, L.d_x, done);
+            hipLaunchKernelGGL(k_cpr_dense_solve, dim3(1), dim3(64), 0, c->stream, L.n, R.d_lu, L.d_b, L.d_x, (const int*)mem4f, rf, done);
             return L.d_x;
         }
         // could not coarsen further: Jacobi sweeps stand in for the coarse solve (oracle/cpr.hpp: 1 + 4)
-        if (!havex) hipLaunchKernelGGL(k_cpr_presmooth, g256(L.n), dim3(256), 0, c->stream, L.n, R.omega, L.d_dinv, L.d_b, L.d_x, done);
+        if (!havex && !fused) hipLaunchKernelGGL(k_cpr_presmooth, g256(L.n), dim3(256), 0, c->stream, L.n, R.omega, L.d_dinv, L.d_b, L.d_x, done);
         double *xin = L.d_x, *xout = L.d_x2;
         for (int sweep = 0; sweep < 4; ++sweep) {
-            if (L.rm) hipLaunchKernelGGL(k_cpr_jacobi_lpr, g256(L.n * CPR_LPR), dim3(256), 0, c->stream, L.n, L.W, R.omega, L.d_ecol, L.d_val, L.d_dinv, L.d_b, xin, xout, done);
+            if (L.rm && fused && sweep == 0) hipLaunchKernelGGL(k_cpr_jacobi_lpr<true>, g256(L.n * CPR_LPR), dim3(256), 0, c->stream, L.n, L.W, R.omega, L.d_ecol, L.d_val, L.d_dinv, L.d_b, xin, xout, mem4f, rf, done);
+            else if (L.rm) hipLaunchKernelGGL(k_cpr_jacobi_lpr<false>, g256(L.n * CPR_LPR), dim3(256), 0, c->stream, L.n, L.W, R.omega, L.d_ecol, L.d_val, L.d_dinv, L.d_b, xin, xout, (const int4*)nullptr, (const double*)nullptr, done);
             else hipLaunchKernelGGL(k_cpr_jacobi, g256(L.n), dim3(256), 0, c->stream, L.n, L.W, R.omega, L.d_ecol, L.d_val, L.d_dinv, L.d_b, xin, xout, done);
             std::swap(xin, xout);
         }
         return xin;
     }
     CprLevelDev& C = R.lv[l + 1];
-    if (L.rm) hipLaunchKernelGGL(k_cpr_down_lpr, g256(L.n * CPR_LPR), dim3(256), 0, c->stream, L.n, L.W, R.omega, L.d_ecol, L.d_val, L.d_dinv, L.d_b, L.d_x, L.d_r, done);
+    if (L.rm && fused) hipLaunchKernelGGL(k_cpr_down_lpr<true>, g256(L.n * CPR_LPR), dim3(256), 0, c->stream, L.n, L.W, R.omega, L.d_ecol, L.d_val, L.d_dinv, L.d_b, L.d_x, L.d_r, mem4f, rf, done);
+    else if (L.rm) hipLaunchKernelGGL(k_cpr_down_lpr<false>, g256(L.n * CPR_LPR), dim3(256), 0, c->stream, L.n, L.W, R.omega, L.d_ecol, L.d_val, L.d_dinv, L.d_b, L.d_x, L.d_r, (const int4*)nullptr, (const double*)nullptr, done);
     else {   // large levels: x first (it rides in the kernel that produced b), then the residual with ONE gathered value per entry (0.250 -> 0.243 ms per cycle against the fused form, which gathers dinv and b)
         if (!havex) hipLaunchKernelGGL(k_cpr_presmooth, g256(L.n), dim3(256), 0, c->stream, L.n, R.omega, L.d_dinv, L.d_b, L.d_x, done);
         hipLaunchKernelGGL(k_cpr_resid, g256(L.n), dim3(256), 0, c->stream, L.n, L.W, L.d_ecol, L.d_val, L.d_b, L.d_x, L.d_r, done);
     }
-    {
+    if (!cpr_forms_rhs(R, l + 1)) {
         const bool ride = cpr_presmooth_rides(R, l + 1);
         hipLaunchKernelGGL(k_cpr_restrict, g256(L.nc), dim3(256), 0, c->stream, L.nc, L.d_mptr, L.d_midx, L.d_r, C.d_b, R.omega,
                            ride ? C.d_dinv : (const double*)nullptr, ride ? C.d_x : (double*)nullptr, done);

@@ -168,6 +168,7 @@ struct CprLevelDev {
     int* d_cpos = nullptr;                                          // ELL position (next level) of every coarse entry
     double *d_val = nullptr, *d_dinv = nullptr, *d_x2 = nullptr;    // ELL values [W x n]
     int *d_agg = nullptr, *d_mptr = nullptr, *d_midx = nullptr;   // node -> aggregate, members of every aggregate
+    int* d_mem4 = nullptr;                                         // members of every aggregate as four ints (-1: none), NULL if an aggregate has more: the coarse level then forms its right-hand side itself
     int *d_gptr = nullptr, *d_gidx = nullptr;                      // Galerkin gather lists for the next level's entries
     double *d_b = nullptr, *d_x = nullptr, *d_r = nullptr;         // level vectors
 };

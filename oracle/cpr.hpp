@@ -63,6 +63,7 @@ struct CprAmg {
     int nu = 1;                    // smoothing sweeps before and after the coarse correction (the product runs V(1,1); more: experiments)
     int coarseSweeps = 4;          // Jacobi sweeps (after the first, from x = 0) that stand in for the coarse solve where coarsening stalled
     bool joinAtStall = false;      // experiment switch (orc_cpr_set_sweeps with a negative argument)
+    int wFrom = 1 << 30;           // experiment: levels >= wFrom visit their coarse level twice (W-cycle below that level); the product runs V-cycles
     bool join = false;             // leftover nodes join a neighbour's aggregate (uniform coarsening, but measured WORSE: see DESIGN.md)
 
     // one pass of pairwise matching, nodes visited in index order: node i takes its strongest (most negative coupling)
@@ -281,6 +282,12 @@ struct CprAmg {
             rc[I] = s;
         }
         vcycle(rc.data(), xc.data(), l + 1);
+        if ((int)l >= wFrom && l + 2 < lv.size()) {                         // experiment (W-cycle): a second cycle on the coarse residual
+            std::vector<double> rc2(L.nc), xc2(L.nc);
+            residual(lv[l + 1].A, rc.data(), xc.data(), rc2.data());
+            vcycle(rc2.data(), xc2.data(), l + 1);
+            for (int I = 0; I < L.nc; ++I) xc[I] += xc2[I];
+        }
         for (int i = 0; i < n; ++i) x[i] += damp * xc[L.agg[i]];            // damped piecewise-constant prolongation
         residual(L.A, b, x, r.data());
         for (int i = 0; i < n; ++i) x[i] += omega * L.dinv[i] * r[i];        // post-smoothing
