@@ -20,7 +20,8 @@
 extern "C" {
 #endif
 
-#define OPMHIP_ABI_VERSION 4 /* 4: opmhip_config names chain_length, spmv_pipe_wgs, preconditioner (were reserved[0..2]);
+#define OPMHIP_ABI_VERSION 5 /* 5: opmhip_set_water_compaction, opmhip_get_max_water_saturation (additive);
+                               * 4: opmhip_config names chain_length, spmv_pipe_wgs, preconditioner (were reserved[0..2]);
                                *    opmhip_set_endpoint_scaling, opmhip_sat_end_points, opmhip_sat_probe, opmhip_synchronize, opmhip_comm_info,
                                *    opmhip_set_composition_change_limits, opmhip_set_irreversible_compaction, opmhip_set_vappars, opmhip_begin_time_step;
                                * 3: opmhip_fluid gained pc_scaling, opmhip_set_pcw */
@@ -305,8 +306,26 @@ int opmhip_set_irreversible_compaction(opmhip_ctx* ctx, int enable);
  * record (a fluid with PVTG, ROCKTAB or pc_scaling). */
 int opmhip_set_vappars(opmhip_ctx* ctx, int enable, double vap1, double vap2);
 
+/* replaces: water-induced rock compaction (ROCKCOMP with ROCK2D / ROCK2DTR / ROCKWNOD) - the tables rockCompPoroMultWc_ /
+ * rockCompTransMultWc_ (built in ebos/eclgenericproblem.cc:186-240), their use in rockCompPoroMultiplier /
+ * rockCompTransMultiplier (ebos/eclproblem.hh:1962-1967, 2001-2005: multiplier(effective oil pressure, SwMax - Sw_initial),
+ * SwMax = max(Sw, the largest Sw the cell has seen at the start of a time step), extrapolating) and the tracker
+ * maxWaterSaturation_ (initialised from the initial state, :2289-2290; updateMaxWaterSaturation_, :2144-2169, run by
+ * opmhip_begin_time_step - including its statement :2150, which hands cell 1 the stored maximum of cell 0 before the loop).
+ * num_tables rock regions (0: feature off), selected per cell by the rocknum of opmhip_set_problem_extras; table t has
+ * num_pressure[t] >= 2 pressure nodes [Pa] (ROCK2D records) and num_sw[t] >= 2 saturation nodes (ROCKWNOD), both ascending
+ * and concatenated over the tables; pv_mult / trans_mult: num_pressure[t] x num_sw[t] values per table, row-major by pressure
+ * node, concatenated; trans_mult NULL = no ROCK2DTR (multiplier 1).  The initial water saturation and the tracker start from
+ * the state now present: call it after opmhip_set_state.  Not together with ROCKTAB tables in the fluid (the reference reads
+ * the one or the other); needs a context with the extended record (a fluid with PVTG or pc_scaling).  The table class
+ * (UniformXTabulated2DFunction of opm-material) is absent from the reference tree: restated, see oracle/blackoil.hpp. */
+int opmhip_set_water_compaction(opmhip_ctx* ctx, int num_tables, const int* num_pressure, const int* num_sw, const double* pressure,
+                                const double* sw, const double* pv_mult, const double* trans_mult);
+/* the tracker of the above per cell (natural order, Nb + Nghost entries; zeros when the feature is off) */
+int opmhip_get_max_water_saturation(opmhip_ctx* ctx, double* max_water_saturation);
+
 /* replaces: the per-cell work of EclProblem::beginTimeStep (ebos/eclproblem.hh:1042-1075) for a time step of size dt [s]:
- * updateMinPressure_, updateMaxOilSaturation_, the DRSDT / DRVDT caps of this step, invalidateAndUpdateIntensiveQuantities(0); and, since
+ * updateMaxWaterSaturation_, updateMinPressure_, updateMaxOilSaturation_, the DRSDT / DRVDT caps of this step, invalidateAndUpdateIntensiveQuantities(0); and, since
  * recycleFirstIterationStorage() is false with DRSDT / DRVDT (:1758-1765), the old time level's storage term formed with ITS
  * caps (time index 1: lastRs / lastRv without the increment) - opmhip_assemble(iteration 0) then leaves it alone.  Call it
  * after opmhip_advance_time_level, and again before every retry of a chopped step.  A no-op (SUCCESS) when neither feature

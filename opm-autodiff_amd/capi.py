@@ -360,6 +360,8 @@ def _bind_assembly(L):
     L.opmhip_begin_time_step.argtypes = [vp, C.c_double]
     L.opmhip_get_trackers.argtypes = [vp, vp, vp, vp, vp]
     L.opmhip_set_vappars.argtypes = [vp, C.c_int, C.c_double, C.c_double]
+    L.opmhip_set_water_compaction.argtypes = [vp, C.c_int, vp, vp, vp, vp, vp, vp]
+    L.opmhip_get_max_water_saturation.argtypes = [vp, vp]
     L.opmhip_sat_end_points.argtypes = [vp, C.c_int, vp]
     L.opmhip_sat_probe.argtypes = [vp, C.c_int, vp, C.c_int, vp, vp, vp]
     L.opmhip_gas_probe.argtypes = [vp, C.c_int, C.c_int, vp, vp, vp]
@@ -541,6 +543,32 @@ class HipModel(HipSolver):
     def set_vappars(self, vap1, vap2, enable=True):
         """VAPPARS: exponents on the saturated Rv / Rs below the largest oil saturation seen.  After set_state."""
         self._check(lib().opmhip_set_vappars(self._h, int(enable), float(vap1), float(vap2)))
+
+    def set_water_compaction(self, tables):
+        """Water-induced rock compaction (ROCK2D / ROCK2DTR / ROCKWNOD): one dict per rock region with "pressure" [Pa] and "sw"
+        nodes (ascending), "pv_mult" [len(pressure) x len(sw)] and optionally "trans_mult" of the same shape (all tables or
+        none).  None / []: off.  After set_state."""
+        tables = list(tables or [])
+        if not tables:
+            self._check(lib().opmhip_set_water_compaction(self._h, 0, None, None, None, None, None, None))
+            return
+        npv = _i32([len(t["pressure"]) for t in tables])
+        nsw = _i32([len(t["sw"]) for t in tables])
+        pr = _f64(np.concatenate([np.asarray(t["pressure"], float) for t in tables]))
+        sw = _f64(np.concatenate([np.asarray(t["sw"], float) for t in tables]))
+        shaped = lambda t, k: np.asarray(t[k], float).reshape(len(t["pressure"]), len(t["sw"])).ravel()
+        pv = _f64(np.concatenate([shaped(t, "pv_mult") for t in tables]))
+        has_tr = [t.get("trans_mult") is not None for t in tables]
+        if any(has_tr) and not all(has_tr):
+            raise ValueError("set_water_compaction: trans_mult for all tables or for none")
+        tr = _f64(np.concatenate([shaped(t, "trans_mult") for t in tables])) if all(has_tr) else None
+        self._check(lib().opmhip_set_water_compaction(self._h, len(tables), _ptr(npv), _ptr(nsw), _ptr(pr), _ptr(sw), _ptr(pv), _ptr(tr) if tr is not None else None))
+
+    def max_water_saturation(self):
+        """the tracker of the water-induced compaction per cell, natural order (zeros when the feature is off)"""
+        a = np.empty(self.Nloc)
+        self._check(lib().opmhip_get_max_water_saturation(self._h, _ptr(a)))
+        return a
 
     def trackers(self):
         """-> (lastRs, lastRv, minimum oil pressure, maximum oil saturation) per cell, natural order; zeros where not kept"""

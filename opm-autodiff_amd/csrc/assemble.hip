@@ -160,6 +160,24 @@ template <class E, class DP> __device__ __forceinline__ E tab2wg(const TablesT<D
     return s1 * (1.0 - alpha) + s2 * alpha;
 }
 // PiecewiseLinearTwoPhaseMaterial: constant outside the table; a value on a node belongs to the segment on its left
+// water-induced compaction tables (rockCompPoroMultWc_ / rockCompTransMultWc_: UniformXTabulated2DFunction with the same S_w
+// nodes under every pressure node, vertical interpolation, extrapolating) - oracle/fluid.hpp Tab2D::eval with guide 0, same
+// statements, same order
+template <class E> __device__ __forceinline__ E wc_eval(const int* __restrict__ d, const double* __restrict__ data, int voff, const E& xv, const E& yv) {
+    const int ns = d[1];
+    const double* xs = data + d[2];
+    const double* ys = data + d[3];
+    const int i = seg_right(xs, d[0], val(xv));
+    const E alpha = (xv - xs[i]) / (xs[i + 1] - xs[i]);
+    const double* v1 = data + voff + (size_t)i * ns;
+    const double* v2 = v1 + ns;
+    const int j1 = seg_right(ys, ns, val(yv)), j2 = j1;
+    const E beta1 = (yv - ys[j1]) / (ys[j1 + 1] - ys[j1]);
+    const E beta2 = (yv - ys[j2]) / (ys[j2 + 1] - ys[j2]);
+    const E s1 = v1[j1] * (1.0 - beta1) + v1[j1 + 1] * beta1;
+    const E s2 = v2[j2] * (1.0 - beta2) + v2[j2 + 1] * beta2;
+    return s1 * (1.0 - alpha) + s2 * alpha;
+}
 template <class E, class DP> __device__ __forceinline__ E pwlin(DP x, DP y, int n, const E& xv) {
     const double s = val(xv);
     if (s <= x[0]) return cst<E>(y[0]);
@@ -229,6 +247,12 @@ struct CellStatic {
     const double* minpo;                // extended layout: minimum oil pressure so far (ROCKCOMP IRREVERS; NULL = reversible compaction)
     const double* maxso;                // extended layout: largest oil saturation seen at the start of a time step (VAPPARS; NULL = not in force)
     double vap1, vap2;                  // VAPPARS: exponent on RvSat / on RsSat
+    // extended layout: water-induced compaction (ROCK2D / ROCK2DTR / ROCKWNOD; NULL = off): largest S_w seen at the start of a
+    // time step, initial S_w, per table {np, nsw, pressure nodes at, S_w nodes at, pore-volume multipliers at, transmissibility
+    // multipliers at (-1: none)} and the tables' doubles (global memory: a handful of nodes, used by few decks)
+    const double *maxsw, *sw0;
+    const int* wcdesc;
+    const double* wcdata;
     const double* eps;                  // extended layout: scaled end points per cell, field-major [EPS_COUNT][ncell] (NULL = no end-point scaling)
     int epscfg;                         // EclEpsConfig: bit 0 saturation scaling, 1 three-point, 2-3 krw, 4-5 kro, 6-7 krg mode, 8 pcw, 9 pcg
     double* invb;                       // packed 1/b_w, 1/b_o, 1/b_g per cell, written beside the record (convergence check)
@@ -486,6 +510,15 @@ __device__ __forceinline__ void update_iq(const TablesT<DP>& T, const CellStatic
             if (C.overburden) effectiveOilPressure = effectiveOilPressure - C.overburden[c];
             q.poro = q.poro * tab1<E, DP>(B + R.p, B + R.poroMult, R.n, effectiveOilPressure);
             q.tmult = tab1<E, DP>(B + R.p, B + R.transMult, R.n, effectiveOilPressure);
+        } else if (C.wcdesc) {   // water compaction (eclproblem.hh:1962-1967, 2001-2005)
+            const int* d = C.wcdesc + 6 * (C.rocknum ? C.rocknum[c] : 0);
+            E effectiveOilPressure = q.p[OIL];
+            if (C.minpo) effectiveOilPressure = emin(q.p[OIL], cst<E>(C.minpo[c]));
+            if (C.overburden) effectiveOilPressure = effectiveOilPressure - C.overburden[c];
+            const E SwMax = emax(q.S[WATER], cst<E>(C.maxsw[c]));
+            const E SwDeltaMax = SwMax - C.sw0[c];
+            q.poro = q.poro * wc_eval<E>(d, C.wcdata, d[4], effectiveOilPressure, SwDeltaMax);
+            if (d[5] >= 0) q.tmult = wc_eval<E>(d, C.wcdata, d[5], effectiveOilPressure, SwDeltaMax);
         }
     }
 }
@@ -1213,6 +1246,17 @@ __global__ __launch_bounds__(256) void k_max_oil_saturation(int N, int init, con
     const double old = init ? 0.0 : maxso[c];
     maxso[c] = (old > So) ? old : So;   // std::max(old, So)
 }
+// updateMaxWaterSaturation_ (:2144-2169); init: maxWaterSaturation_ = max(0, S_w of the initial state) (:2289-2290) and the
+// initial saturation itself (initialFluidStates_).  The statement :2150 in front of the reference's loop (cell 1 takes over
+// cell 0's stored maximum) is launch_max_water_saturation's copy
+__global__ __launch_bounds__(256) void k_max_water_saturation(int N, int init, const double* __restrict__ iq, double* __restrict__ maxsw, double* __restrict__ sw0) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= N) return;
+    const double Sw = iq_at(iq, N, F_S + WATER, c)[0];
+    const double old = init ? 0.0 : maxsw[c];
+    maxsw[c] = (old > Sw) ? old : Sw;   // std::max(old, Sw)
+    if (init) sw0[c] = Sw;
+}
 // the storage term of the cached intensive quantities, values only (computeStorage; the statements of k_assemble's diagonal
 // lane): the old time level's storage where the first iteration's cannot be recycled (:1758-1765)
 template <bool EXT>
@@ -1265,7 +1309,8 @@ static Tables tables_of(const opmhip_ctx* c) {
 }
 static CellStatic cells_of(const opmhip_ctx* c) {
     return CellStatic{c->asmb.d_poro, c->asmb.d_volume, c->asmb.d_depth, c->asmb.d_rsmax, c->asmb.d_pvtnum, c->asmb.d_satnum,
-                      c->asmb.d_rvmax, c->asmb.d_overburden, c->asmb.d_rocknum, c->asmb.d_pcw, c->asmb.d_minpo, c->asmb.d_maxso, c->asmb.vap1, c->asmb.vap2, c->asmb.d_eps, c->asmb.epscfg, c->asmb.d_invb, c->pat.Nloc};
+                      c->asmb.d_rvmax, c->asmb.d_overburden, c->asmb.d_rocknum, c->asmb.d_pcw, c->asmb.d_minpo, c->asmb.d_maxso, c->asmb.vap1, c->asmb.vap2,
+                      c->asmb.d_maxsw, c->asmb.d_sw0, c->asmb.d_wcdesc, c->asmb.d_wcdata, c->asmb.d_eps, c->asmb.epscfg, c->asmb.d_invb, c->pat.Nloc};
 }
 // the context's record layout: extended when the fluid has PVTG or ROCKTAB tables
 #define OPMHIP_LAYOUT(c, call_base, call_ext) do { if ((c)->asmb.ext) { call_ext; } else { call_base; } } while (0)
@@ -1333,6 +1378,13 @@ void launch_min_pressure(opmhip_ctx* c, bool init) {
 void launch_max_oil_saturation(opmhip_ctx* c, bool init) {
     const int N = c->pat.Nloc;
     hipLaunchKernelGGL(k_max_oil_saturation, dim3((N + 255) / 256), dim3(256), 0, c->stream, N, init ? 1 : 0, c->asmb.d_iq, c->asmb.d_maxso);
+}
+void launch_max_water_saturation(opmhip_ctx* c, bool init) {
+    const Pattern& P = c->pat;
+    const int N = P.Nloc;
+    // eclproblem.hh:2150: the cell with index 1 takes over the stored maximum of the cell with index 0 (natural numbering)
+    if (!init && N > 1) (void)hipMemcpyAsync(c->asmb.d_maxsw + P.toOrder[1], c->asmb.d_maxsw + P.toOrder[0], sizeof(double), hipMemcpyDeviceToDevice, c->stream);
+    hipLaunchKernelGGL(k_max_water_saturation, dim3((N + 255) / 256), dim3(256), 0, c->stream, N, init ? 1 : 0, c->asmb.d_iq, c->asmb.d_maxsw, c->asmb.d_sw0);
 }
 void launch_storage_old(opmhip_ctx* c) {
     const AsmDev& A = c->asmb;

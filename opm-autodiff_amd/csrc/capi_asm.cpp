@@ -1,5 +1,6 @@
 // C-ABI, assembly half (include/opmhip.h "assembly" section): fluid tables, static grid data, state, linearisation,
 // convergence norms, Newton update.  Host arrays arrive in the NATURAL cell / entry order and are permuted on upload.
+#include <climits>
 #include <algorithm>
 #include <cmath>
 #include <cstring>
@@ -260,9 +261,17 @@ int opmhip_set_problem_extras(opmhip_ctx* c, const double* rvmax, const int* roc
         if (!A.static_set) return fail(c, OPMHIP_NOT_READY, "set_problem_extras before set_static");
         if ((rvmax || rocknum || overburden) && !A.ext)
             return fail(c, OPMHIP_INVALID_ARGUMENT, "set_problem_extras: the fluid has neither PVTG nor ROCKTAB tables - nothing these arrays could act on");
-        if (rocknum)
-            for (int i = 0; i < c->pat.Nloc; ++i)
-                if (rocknum[i] < 0 || rocknum[i] >= A.num_rock) return fail(c, OPMHIP_INVALID_ARGUMENT, "set_problem_extras: rocknum[%d] out of range", i);
+        int rockMax = -1;
+        if (rocknum) {
+            // tables: ROCKTAB of the fluid, else those of opmhip_set_water_compaction - which may still be to come (it needs the
+            // state): then the indices are checked when it arrives
+            const int limit = A.num_rock > 0 ? A.num_rock : (A.num_wc > 0 ? A.num_wc : INT_MAX);
+            for (int i = 0; i < c->pat.Nloc; ++i) {
+                if (rocknum[i] < 0 || rocknum[i] >= limit) return fail(c, OPMHIP_INVALID_ARGUMENT, "set_problem_extras: rocknum[%d] out of range", i);
+                rockMax = std::max(rockMax, rocknum[i]);
+            }
+        }
+        A.h_rocknum_max = rockMax;
         OPMHIP_HIP(c, hipSetDevice(c->device));
         int rc;
         // an array that is withdrawn goes back to the allocator (an assembly enqueued earlier may still read it: sync first)
@@ -593,15 +602,83 @@ int opmhip_set_vappars(opmhip_ctx* c, int enable, double vap1, double vap2) {
     });
 }
 
+int opmhip_set_water_compaction(opmhip_ctx* c, int num_tables, const int* num_pressure, const int* num_sw, const double* pressure, const double* sw,
+                                const double* pv_mult, const double* trans_mult) {
+    if (!c) return OPMHIP_INVALID_ARGUMENT;
+    return guarded(c, [&]() -> int {
+        AsmDev& A = c->asmb;
+        if (!A.state_set) return fail(c, OPMHIP_NOT_READY, "set_water_compaction before set_state: the initial and the maximum water saturation start from the initial solution");
+        if (num_tables < 0 || (num_tables > 0 && (!num_pressure || !num_sw || !pressure || !sw || !pv_mult)))
+            return fail(c, OPMHIP_INVALID_ARGUMENT, "set_water_compaction: null table array");
+        if (num_tables > 0 && !A.ext) return fail(c, OPMHIP_INVALID_ARGUMENT, "set_water_compaction: needs a context with the extended record (a fluid with PVTG or pc_scaling)");
+        if (num_tables > 0 && A.num_rock > 0) return fail(c, OPMHIP_INVALID_ARGUMENT, "set_water_compaction: the fluid has ROCKTAB tables (the reference reads the one or the other)");
+        std::vector<int> desc;
+        std::vector<double> data;
+        size_t op = 0, os = 0, ov = 0;
+        for (int t = 0; t < num_tables; ++t) {
+            const int np = num_pressure[t], ns = num_sw[t];
+            if (np < 2 || ns < 2) return fail(c, OPMHIP_INVALID_ARGUMENT, "set_water_compaction: table %d needs at least two pressure and two saturation nodes", t);
+            for (int i = 1; i < np; ++i) if (!(pressure[op + i] > pressure[op + i - 1])) return fail(c, OPMHIP_INVALID_ARGUMENT, "set_water_compaction: pressure nodes of table %d not ascending", t);
+            for (int j = 1; j < ns; ++j) if (!(sw[os + j] > sw[os + j - 1])) return fail(c, OPMHIP_INVALID_ARGUMENT, "set_water_compaction: saturation nodes of table %d not ascending", t);
+            const int atP = (int)data.size();
+            data.insert(data.end(), pressure + op, pressure + op + np);
+            const int atS = (int)data.size();
+            data.insert(data.end(), sw + os, sw + os + ns);
+            const int atV = (int)data.size();
+            data.insert(data.end(), pv_mult + ov, pv_mult + ov + (size_t)np * ns);
+            int atT = -1;
+            if (trans_mult) { atT = (int)data.size(); data.insert(data.end(), trans_mult + ov, trans_mult + ov + (size_t)np * ns); }
+            const int d[6] = {np, ns, atP, atS, atV, atT};
+            desc.insert(desc.end(), d, d + 6);
+            op += np; os += ns; ov += (size_t)np * ns;
+        }
+        if (num_tables > 0 && A.h_rocknum_max >= num_tables) return fail(c, OPMHIP_INVALID_ARGUMENT, "set_water_compaction: a cell's rock-table index is %d, %d tables given", A.h_rocknum_max, num_tables);
+        OPMHIP_HIP(c, hipSetDevice(c->device));
+        OPMHIP_HIP(c, hipStreamSynchronize(c->stream));
+        dev_free(c, &A.d_wcdesc); dev_free(c, &A.d_wcdata);
+        if (num_tables == 0) { dev_free(c, &A.d_maxsw); dev_free(c, &A.d_sw0); }
+        else {
+            int rc;
+            if ((rc = dev_upload(c, &A.d_wcdesc, desc)) || (rc = dev_upload(c, &A.d_wcdata, data))) return rc;
+            if (!A.d_maxsw && (rc = dev_alloc(c, &A.d_maxsw, (size_t)c->pat.Nloc))) return rc;
+            if (!A.d_sw0 && (rc = dev_alloc(c, &A.d_sw0, (size_t)c->pat.Nloc))) return rc;
+            launch_max_water_saturation(c, true);
+        }
+        A.num_wc = num_tables;
+        launch_iq_update(c);
+        OPMHIP_HIP(c, hipGetLastError());
+        OPMHIP_HIP(c, hipStreamSynchronize(c->stream));
+        return OPMHIP_SUCCESS;
+    });
+}
+
+int opmhip_get_max_water_saturation(opmhip_ctx* c, double* max_sw) {
+    if (!c || !max_sw) return OPMHIP_INVALID_ARGUMENT;
+    return guarded(c, [&]() -> int {
+        AsmDev& A = c->asmb;
+        const Pattern& P = c->pat;
+        if (!A.static_set) return fail(c, OPMHIP_NOT_READY, "get_max_water_saturation before set_static");
+        const int N = P.Nloc;
+        if (!A.d_maxsw) { std::fill(max_sw, max_sw + N, 0.0); return OPMHIP_SUCCESS; }
+        OPMHIP_HIP(c, hipSetDevice(c->device));
+        OPMHIP_HIP(c, hipStreamSynchronize(c->stream));
+        std::vector<double> tmp(N);
+        OPMHIP_HIP(c, hipMemcpy(tmp.data(), A.d_maxsw, (size_t)N * sizeof(double), hipMemcpyDeviceToHost));
+        for (int pos = 0; pos < N; ++pos) max_sw[P.fromOrder[pos]] = tmp[pos];
+        return OPMHIP_SUCCESS;
+    });
+}
+
 int opmhip_begin_time_step(opmhip_ctx* c, double dt) {
     if (!c) return OPMHIP_INVALID_ARGUMENT;
     return guarded(c, [&]() -> int {
         AsmDev& A = c->asmb;
         if (!(dt > 0.0)) return fail(c, OPMHIP_INVALID_ARGUMENT, "begin_time_step: dt must be positive");
         const bool limits = A.drsdt_on || A.drvdt_on;
-        if (!limits && !A.d_minpo && !A.d_maxso) return OPMHIP_SUCCESS;
+        if (!limits && !A.d_minpo && !A.d_maxso && !A.d_maxsw) return OPMHIP_SUCCESS;
         if (!A.state_set) return fail(c, OPMHIP_NOT_READY, "begin_time_step before set_state");
         OPMHIP_HIP(c, hipSetDevice(c->device));
+        if (A.d_maxsw) launch_max_water_saturation(c, false);   // updateMaxWaterSaturation_ (eclproblem.hh:1056)
         if (A.d_minpo) launch_min_pressure(c, false);     // updateMinPressure_: from the intensive quantities of the state as it is
         if (A.d_maxso) launch_max_oil_saturation(c, false);   // updateMaxOilSaturation_
         A.storage_frozen = false;

@@ -614,6 +614,11 @@ static int cpr_weights(opmhip_ctx* c) {
     return OPMHIP_SUCCESS;
 }
 // structure of the hierarchy, once per context, from the values of the pressure matrix of the system now on the device
+// levels of up to this many rows are kept row-major and run the lane-group kernels (OPMHIP_CPR_LPR_ROWS: measurement switch)
+static int cpr_lpr_rows() {
+    static const int v = [] { const char* e = std::getenv("OPMHIP_CPR_LPR_ROWS"); return e ? std::atoi(e) : CPR_LPR_ROWS; }();
+    return v;
+}
 static int cpr_setup_structure_impl(opmhip_ctx* c);
 // a set-up that fails half way gives back everything it allocated: a retry starts from a clean slate, nothing piles up
 static int cpr_setup_structure(opmhip_ctx* c) {
@@ -715,7 +720,7 @@ static int cpr_setup_structure_impl(opmhip_ctx* c) {
         }
         R.lv.emplace_back();
         std::vector<int> cposv;
-        CPR_T(tUp, rc = upload_ell(c, Ac, R.lv.back(), cposv, Ac.n <= CPR_LPR_ROWS));
+        CPR_T(tUp, rc = upload_ell(c, Ac, R.lv.back(), cposv, Ac.n <= cpr_lpr_rows()));
         if (rc) return rc;
         if ((rc = dev_upload(c, &R.lv[R.lv.size() - 2].d_cpos, cposv))) return rc;   // where the coarse entries go
         pos = cposv;

@@ -115,6 +115,10 @@ struct AsmDev {
     double* d_minpo = nullptr;                            // per cell minimum oil pressure so far (irreversible compaction); NULL = reversible
     double* d_maxso = nullptr;                            // per cell largest oil saturation at the start of a time step (VAPPARS); NULL = not in force
     double vap1 = 0.0, vap2 = 0.0;                        // VAPPARS exponents: on RvSat, on RsSat
+    double *d_maxsw = nullptr, *d_sw0 = nullptr;          // water-induced compaction: largest S_w at the start of a time step, initial S_w; NULL = off
+    int num_wc = 0, h_rocknum_max = -1;                   // water-compaction tables; largest rock-table index handed in (-1: none)
+    int* d_wcdesc = nullptr;                              // per table {np, nsw, pressure at, S_w at, pore-volume multipliers at, transmissibility multipliers at | -1}
+    double* d_wcdata = nullptr;
     bool storage_frozen = false;                          // begin_time_step formed the old time level's storage: iteration 0 must not refill it
     double* d_invb = nullptr;                             // packed 1/b per cell and phase (Nloc x 3), for the convergence check
     double *d_trans = nullptr, *d_area = nullptr, *d_thpres = nullptr;                      // per entry
@@ -412,6 +416,7 @@ void launch_set_limits(opmhip_ctx* c, double dt);
 void launch_min_pressure(opmhip_ctx* c, bool init);
 void launch_storage_old(opmhip_ctx* c);
 void launch_max_oil_saturation(opmhip_ctx* c, bool init);
+void launch_max_water_saturation(opmhip_ctx* c, bool init);
 int launch_convergence(opmhip_ctx* c, double dt, double tol_cnv);
 void launch_u8_to_internal(opmhip_ctx* c, const unsigned char* nat, unsigned char* internal);
 void launch_u8_to_natural(opmhip_ctx* c, const unsigned char* internal, unsigned char* nat);

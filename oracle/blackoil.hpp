@@ -57,6 +57,13 @@ struct Problem {
     // saturatedGasDissolutionFactor / saturatedOilVaporizationFactor of opm-material, absent: restated, UNVERIFIED)
     std::vector<double> maxOilSaturation;
     double vapPar1 = 0.0, vapPar2 = 0.0;
+    // water-induced rock compaction (ROCKCOMP + ROCK2D / ROCK2DTR / ROCKWNOD; tables built in ebos/eclgenericproblem.cc:186-240,
+    // read in eclproblem.hh:1962-1967, 2001-2005): per rock region a 2-D table of pore-volume (and transmissibility) multipliers
+    // over (effective oil pressure, SwMax - Sw_initial), SwMax = max(Sw, largest Sw seen at the start of a time step).  The
+    // table class (UniformXTabulated2DFunction of opm-material, default = vertical interpolation, extrapolating) is absent from
+    // the reference tree: Tab2D with guide 0, UNVERIFIED.  rock2dTrans may be empty (no ROCK2DTR: multiplier 1).
+    std::vector<Tab2D> rock2dPoro, rock2dTrans;
+    std::vector<double> maxWaterSaturation, initialSw;   // per cell; empty = no water-induced compaction
     // per cell scaled maximum of the oil-water capillary pressure (the deck's PCW, or what SWATINIT made of it:
     // ebos/equil/initstateequil.hh:1330-1343 -> EclMaterialLawManager::applySwatinit); empty = the tables' own.
     // UNVERIFIED against upstream sources: opm-material (EclEpsTwoPhaseLaw, EclEpsScalingPoints) is not in the reference tree;
@@ -204,6 +211,15 @@ void update_iq(const Problem& P, int cell, const double* pv, uint8_t meaning, IQ
         if (!P.overburden.empty()) effectiveOilPressure = effectiveOilPressure - P.overburden[cell];
         q.poro = q.poro * RT.poroMult.eval(effectiveOilPressure);
         q.tmult = RT.transMult.eval(effectiveOilPressure);
+    } else if (!P.rock2dPoro.empty()) {   // water compaction (eclproblem.hh:1962-1967, 2001-2005): taken when there is no ROCKTAB table
+        const int tableIdx = P.rockNum.empty() ? 0 : P.rockNum[cell];
+        E effectiveOilPressure = q.p[OIL];
+        if (!P.minOilPressure.empty()) effectiveOilPressure = min(q.p[OIL], E(P.minOilPressure[cell]));
+        if (!P.overburden.empty()) effectiveOilPressure = effectiveOilPressure - P.overburden[cell];
+        const E SwMax = max(q.S[WATER], E(P.maxWaterSaturation[cell]));
+        const E SwDeltaMax = SwMax - P.initialSw[cell];
+        q.poro = q.poro * P.rock2dPoro[tableIdx].eval(effectiveOilPressure, SwDeltaMax);
+        if (!P.rock2dTrans.empty()) q.tmult = P.rock2dTrans[tableIdx].eval(effectiveOilPressure, SwDeltaMax);
     }
 }
 
@@ -328,6 +344,12 @@ struct Model {
             for (int c = 0; c < Nb; ++c) P.minOilPressure[c] = std::min(P.minOilPressure[c], iqV[c].p[OIL]);
         if (!P.maxOilSaturation.empty())   // updateMaxOilSaturation_ (eclproblem.hh:2110-2141)
             for (int c = 0; c < Nb; ++c) P.maxOilSaturation[c] = std::max(P.maxOilSaturation[c], iqV[c].S[OIL]);
+        if (!P.maxWaterSaturation.empty()) {   // updateMaxWaterSaturation_ (eclproblem.hh:2144-2169)
+            // :2150 reads `maxWaterSaturation_[/*timeIdx=*/1] = maxWaterSaturation_[/*timeIdx=*/0]` on the PER-CELL vector: cell 1
+            // takes over cell 0's stored maximum before the loop.  Kept as the reference has it (same inputs, same results).
+            if (Nb > 1) P.maxWaterSaturation[1] = P.maxWaterSaturation[0];
+            for (int c = 0; c < Nb; ++c) P.maxWaterSaturation[c] = std::max(P.maxWaterSaturation[c], iqV[c].S[WATER]);
+        }
         storageFrozen = false;
         if (limits_active()) {
             if (lastRs.empty() && lastRv.empty()) update_composition_change_limits();

@@ -622,6 +622,44 @@ int orc_bo_set_vappars(orc_model* h, int enable, double vap1, double vap2) {
     M.update_all_iq();
     return 0;
 }
+// water-induced compaction: ntab tables (0: off) over (pressure, Sw delta); pv / tr row-major by pressure node; tr may be NULL.
+// maxWaterSaturation_ and the initial saturation start from the state now present (eclproblem.hh:2289-2290, initialFluidStates_)
+int orc_bo_set_water_compaction(orc_model* h, int ntab, const int* np, const int* ns, const double* p, const double* sw, const double* pv, const double* tr) {
+    Model& M = h->M;
+    M.P.rock2dPoro.clear(); M.P.rock2dTrans.clear(); M.P.maxWaterSaturation.clear(); M.P.initialSw.clear();
+    size_t op = 0, os = 0, ov = 0;
+    for (int t = 0; t < ntab; ++t) {
+        Tab2D a, b;
+        a.xs.assign(p + op, p + op + np[t]);
+        for (int i = 0; i < np[t]; ++i) {
+            a.ys.emplace_back(sw + os, sw + os + ns[t]);
+            a.vs.emplace_back(pv + ov + (size_t)i * ns[t], pv + ov + (size_t)(i + 1) * ns[t]);
+        }
+        M.P.rock2dPoro.push_back(a);
+        if (tr) {
+            b.xs = a.xs; b.ys = a.ys;
+            for (int i = 0; i < np[t]; ++i) b.vs.emplace_back(tr + ov + (size_t)i * ns[t], tr + ov + (size_t)(i + 1) * ns[t]);
+            M.P.rock2dTrans.push_back(b);
+        }
+        op += np[t]; os += ns[t]; ov += (size_t)np[t] * ns[t];
+    }
+    if (ntab > 0) {
+        const int Nb = M.P.pat.Nb;
+        M.P.maxWaterSaturation.assign(Nb, 0.0);
+        M.P.initialSw.resize(Nb);
+        for (int c = 0; c < Nb; ++c) {
+            M.P.initialSw[c] = M.iqV[c].S[WATER];
+            M.P.maxWaterSaturation[c] = std::max(M.P.maxWaterSaturation[c], M.iqV[c].S[WATER]);
+        }
+    }
+    M.update_all_iq();
+    return 0;
+}
+int orc_bo_get_max_water_saturation(orc_model* h, double* out) {
+    Model& M = h->M;
+    for (int c = 0; c < M.P.pat.Nb; ++c) out[c] = M.P.maxWaterSaturation.empty() ? 0.0 : M.P.maxWaterSaturation[c];
+    return 0;
+}
 int orc_bo_get_max_oil_saturation(orc_model* h, double* out) {
     Model& M = h->M;
     for (int c = 0; c < M.P.pat.Nb; ++c) out[c] = M.P.maxOilSaturation.empty() ? 0.0 : M.P.maxOilSaturation[c];

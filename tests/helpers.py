@@ -132,6 +132,17 @@ ROCKTAB_2 = [[[100e5, 0.96, 0.90], [200e5, 0.985, 0.96], [300e5, 1.0, 1.0], [400
              [[50e5, 0.90, 0.80], [250e5, 0.99, 0.97], [450e5, 1.03, 1.08]]]
 
 
+# water-induced compaction (ROCK2D / ROCK2DTR over ROCKWNOD's saturation nodes), two rock regions
+ROCK2D_2 = [
+    {"pressure": [100e5, 200e5, 300e5, 400e5], "sw": [0.0, 0.1, 0.3, 0.6],
+     "pv_mult": [[0.96, 0.95, 0.93, 0.90], [0.985, 0.975, 0.955, 0.93], [1.0, 0.99, 0.97, 0.945], [1.012, 1.0, 0.98, 0.955]],
+     "trans_mult": [[0.90, 0.88, 0.84, 0.80], [0.96, 0.94, 0.90, 0.85], [1.0, 0.98, 0.94, 0.89], [1.03, 1.01, 0.97, 0.92]]},
+    {"pressure": [50e5, 250e5, 450e5], "sw": [0.0, 0.2, 0.5],
+     "pv_mult": [[0.90, 0.88, 0.85], [0.99, 0.97, 0.94], [1.03, 1.01, 0.98]],
+     "trans_mult": [[0.80, 0.78, 0.74], [0.97, 0.95, 0.90], [1.08, 1.05, 1.0]]},
+]
+
+
 # ---- BASELINE configs[4]: a Norne-shaped faulted corner-point grid ------------------------------------------------------------
 def norne_shaped_grid(pkg, seed=17):
     """46 x 112 x 22 cells (Norne's dimensions) as COORD / ZCORN: a dome with dipping flanks, slightly sheared pillars, three

@@ -168,6 +168,8 @@ class OracleModel:
         L.orc_bo_get_trackers.argtypes = [_vp, _d]
         L.orc_bo_set_vappars.argtypes = [_vp, C.c_int, C.c_double, C.c_double]
         L.orc_bo_get_max_oil_saturation.argtypes = [_vp, _d]
+        L.orc_bo_set_water_compaction.argtypes = [_vp, C.c_int, _vp, _vp, _vp, _vp, _vp, _vp]
+        L.orc_bo_get_max_water_saturation.argtypes = [_vp, _d]
         L.orc_bo_end_time_step.argtypes = [_vp, C.c_double]
         L.orc_bo_set_drift_compensation.argtypes = [_vp, C.c_int, C.c_double]
         L.orc_bo_get_drift.argtypes = [_vp, _d]
@@ -217,6 +219,27 @@ class OracleModel:
 
     def set_vappars(self, vap1, vap2, enable=True):
         self.o.lib.orc_bo_set_vappars(self.h, int(enable), float(vap1), float(vap2))
+
+    def set_water_compaction(self, tables):
+        tables = list(tables or [])
+        if not tables:
+            self.o.lib.orc_bo_set_water_compaction(self.h, 0, None, None, None, None, None, None)
+            return
+        i32 = lambda v: np.ascontiguousarray(v, np.int32)
+        f64 = lambda v: np.ascontiguousarray(v, np.float64)
+        ptr = lambda a: a.ctypes.data_as(C.c_void_p)
+        npv, nsw = i32([len(t["pressure"]) for t in tables]), i32([len(t["sw"]) for t in tables])
+        pr = f64(np.concatenate([np.asarray(t["pressure"], float) for t in tables]))
+        sw = f64(np.concatenate([np.asarray(t["sw"], float) for t in tables]))
+        shaped = lambda t, k: np.asarray(t[k], float).reshape(len(t["pressure"]), len(t["sw"])).ravel()
+        pv = f64(np.concatenate([shaped(t, "pv_mult") for t in tables]))
+        tr = f64(np.concatenate([shaped(t, "trans_mult") for t in tables])) if tables[0].get("trans_mult") is not None else None
+        self.o.lib.orc_bo_set_water_compaction(self.h, len(tables), ptr(npv), ptr(nsw), ptr(pr), ptr(sw), ptr(pv), ptr(tr) if tr is not None else None)
+
+    def max_water_saturation(self):
+        out = np.empty(self.Nb)
+        self.o.lib.orc_bo_get_max_water_saturation(self.h, out)
+        return out
 
     def trackers(self):
         out = np.empty(3 * self.Nb)

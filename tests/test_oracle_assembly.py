@@ -289,3 +289,26 @@ def test_vappars_jacobian_matches_finite_differences(pkg, orc):
     m.set_state(case["pv"], case["meaning"])
     m.set_vappars(0.5, 0.8)
     _fd_check(shifted, m, tol=5e-5)
+
+
+def test_water_compaction_jacobian_matches_finite_differences(pkg, orc):
+    """water-induced compaction (ROCK2D / ROCK2DTR): the pore-volume and transmissibility multipliers over (effective oil
+    pressure, SwMax - Sw_initial) - AD derivatives in p_o and, where S_w is above the tracked maximum, in S_w - against
+    central differences"""
+    import helpers
+    case = helpers.wetgas_case(pkg, 4, 4, 5, heterogeneous=True)
+    case["rocknum"] = (np.arange(case["Nb"]) % 2).astype(np.int32)
+    m = oracle_bind.OracleModel(orc, case)
+    m.set_state(case["pv"], case["meaning"])
+    m.set_water_compaction(helpers.ROCK2D_2)
+    pv = case["pv"].reshape(-1, 3).copy()
+    up = np.arange(case["Nb"]) % 3 != 0
+    pv[up, 0] += 0.05                 # above the tracked maximum: SwMax = Sw, with its derivative
+    pv[~up, 0] -= 0.02                # below: SwMax is the constant
+    shifted = dict(case, pv=np.ascontiguousarray(pv.reshape(-1)))
+    m.set_state(shifted["pv"], case["meaning"])
+    iq = m.iq()
+    nf = iq.shape[1]
+    assert np.all(iq[up, nf - 1, 1] != 0.0) and np.all(iq[~up, nf - 1, 1] == 0.0)      # d poro / d Sw
+    assert np.abs(iq[:, nf - 2, 2]).max() > 0                                           # d tmult / d p
+    _fd_check(shifted, m, tol=5e-5)
