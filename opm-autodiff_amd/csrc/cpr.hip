@@ -853,20 +853,32 @@ void launch_cpr_apply(opmhip_ctx* c, const double* d, double* v) {
         hipLaunchKernelGGL(k_cpr_restrict_fine, g256(P.Nb), dim3(256), 0, c->stream, P.Nb, d, R.d_w, R.lv[0].d_b, R.omega,
                            ride ? R.lv[0].d_dinv : (const double*)nullptr, ride ? R.lv[0].d_x : (double*)nullptr, done);
     }
-    // level 0 of a hierarchy with more than one level that is not a lane-group level writes v = (0, x_p, 0) itself
-    const bool direct = R.lv.size() > 1 && !R.lv[0].rm;
-    const double* xp = cpr_vcycle(c, 0, direct ? v : nullptr);
-    if (xp) hipLaunchKernelGGL(k_cpr_prolong_fine, g256(n), dim3(256), 0, c->stream, P.Nb, xp, v, done);
-    else xp = R.lv[0].d_x2;   // k_cpr_post left the pressure solution there as well
+    // v = (0, x_p, 0) + ILU0(d - A (0, x_p, 0)): the block vector (0, x_p, 0) itself is never formed - the residual kernel reads
+    // x_p, and the backward sweeps of the smoother add their result to it as they store (second_result, solver.hip): the
+    // expansion pass, the addition kernel and a 24-byte-per-row store of the post-smoothing are gone
+    static const bool separate = std::getenv("OPMHIP_CPR_SEPARATE_ADD") != nullptr;   // A/B switch: the three steps as kernels of their own
+    if (separate) {
+        const bool direct = R.lv.size() > 1 && !R.lv[0].rm;   // level 0's post-smoother writes v = (0, x_p, 0) itself
+        const double* xp = cpr_vcycle(c, 0, direct ? v : nullptr);
+        if (xp) hipLaunchKernelGGL(k_cpr_prolong_fine, g256(n), dim3(256), 0, c->stream, P.Nb, xp, v, done);
+        else xp = R.lv[0].d_x2;   // k_cpr_post left the pressure solution there as well
+        prof_end(c, ps);
+        ps = prof_begin(c, PROF_VECTOR);
+        hipLaunchKernelGGL(k_cpr_presid, g256(P.Nb), dim3(256), 0, c->stream, P.Nb, R.lv[0].W, R.lv[0].d_ecol, R.d_pcol, d, xp, R.d_r, done);
+        prof_end(c, ps);
+        launch_ilu_apply(c, R.d_r, R.d_z, 1.0);                           // fine smoother: ILU0, relaxation 1
+        ps = prof_begin(c, PROF_VECTOR);
+        hipLaunchKernelGGL(k_cpr_add, g256(n), dim3(256), 0, c->stream, n, v, R.d_z, done);
+        prof_end(c, ps);
+        return;
+    }
+    const double* xp = cpr_vcycle(c, 0);
     prof_end(c, ps);
-    // post-smoothing on the updated residual r = d - A v: v has pressure components only
+    // post-smoothing on the updated residual r = d - A (0, x_p, 0)
     ps = prof_begin(c, PROF_VECTOR);
     hipLaunchKernelGGL(k_cpr_presid, g256(P.Nb), dim3(256), 0, c->stream, P.Nb, R.lv[0].W, R.lv[0].d_ecol, R.d_pcol, d, xp, R.d_r, done);
     prof_end(c, ps);
-    launch_ilu_apply(c, R.d_r, R.d_z, 1.0);                           // fine smoother: ILU0, relaxation 1
-    ps = prof_begin(c, PROF_VECTOR);
-    hipLaunchKernelGGL(k_cpr_add, g256(n), dim3(256), 0, c->stream, n, v, R.d_z, done);
-    prof_end(c, ps);
+    launch_ilu_apply(c, R.d_r, v, 1.0, nullptr, xp, R.d_z);               // fine smoother: ILU0, relaxation 1; v = (0, x_p, 0) + its result
 }
 
 // weights handed in (natural order, 3 per row) / back to computed ones

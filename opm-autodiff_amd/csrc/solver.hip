@@ -586,12 +586,19 @@ __global__ __launch_bounds__(64) void k_spmv_pipe(int npos, const int4* __restri
 //   unscaled, v_i = w * vu_i  (the reference's trailing "v *= w", :899-901, folded into the store);
 // relax_mode 1 (OpenCL, bda/openclKernels.cpp:301-383): ascending columns, vu_i = v_i = w * D_i^-1 (...).
 enum { SW_L = 0, SW_LF = 1, SW_UF = 2 };
+// The backward sweeps' second result vector v (v != vu): w * vu_i - or, addp != NULL (CPR: v = (0, x_p, 0) + ILU0(d - A (0, x_p, 0)),
+// twolevelmethodcpr.hh:476-498, w = 1), that product added to the block vector (0, addp_i, 0): the statement of the addition
+// kernel that used to follow the sweeps (v_i += z_i), folded into the store
+template <int K> __device__ __forceinline__ double second_result(const double* __restrict__ addp, int r, double wout) {
+    if (!addp) return wout;
+    return (K == 1 ? addp[r] : 0.0) + wout;
+}
 template <int SHAPE>
 __global__ __launch_bounds__(64) void k_ilu_sweep(int tile_begin, int ntc, int n0, int rhs_from_d, const int* __restrict__ tile_row0,
                                                   const int* __restrict__ prow, const int* __restrict__ pcol,
                                                   const double* __restrict__ P, const double* __restrict__ invD,
                                                   const double* __restrict__ d, double* __restrict__ vu, double* __restrict__ v,
-                                                  int relax_mode, double w, const double* __restrict__ done) {
+                                                  const double* __restrict__ addp, int relax_mode, double w, const double* __restrict__ done) {
     TILE_LDS
     const int lane = threadIdx.x, tl = xcd_tile(blockIdx.x, ntc);
     if (tl >= ntc || *done != 0.0) return;
@@ -617,7 +624,7 @@ __global__ __launch_bounds__(64) void k_ilu_sweep(int tile_begin, int ntc, int n
     blk_umv(Di, rhs[0], rhs[1], rhs[2], out);  // DenseMatrix::mv: y = 0, then accumulate
     if (relax_mode == 1) { out[0] = w * out[0]; out[1] = w * out[1]; out[2] = w * out[2]; }
     vu[(size_t)r * BS] = out[0]; vu[(size_t)r * BS + 1] = out[1]; vu[(size_t)r * BS + 2] = out[2];
-    if (v != vu) { v[(size_t)r * BS] = w * out[0]; v[(size_t)r * BS + 1] = w * out[1]; v[(size_t)r * BS + 2] = w * out[2]; }
+    if (v != vu) { v[(size_t)r * BS] = second_result<0>(addp, r, w * out[0]); v[(size_t)r * BS + 1] = second_result<1>(addp, r, w * out[1]); v[(size_t)r * BS + 2] = second_result<2>(addp, r, w * out[2]); }
 }
 
 // Line-coloured orderings: one workgroup walks the steps of its chain-tile in order (forward for L, backward for U);
@@ -655,7 +662,7 @@ __device__ __forceinline__ void chain_sweep(const int nsteps, const int lane, do
                                             const int* __restrict__ prow,
                                             const int* __restrict__ pcol, const double* __restrict__ P,
                                             const double* __restrict__ invD, const double* d,
-                                            double* vu, double* v, int relax_mode, double w) {
+                                            double* vu, double* v, const double* __restrict__ addp, int relax_mode, double w) {
     // nsteps <= CHAIN_MAX_STEPS (checked on the host); srow0[0..nsteps], sk0[0..nsteps]: first row / first entry of every
     // step, out of the chain-tile's descriptor record (LDS) - no dependent loads here
     const bool reverse = (SHAPE == SW_UF) && relax_mode == 0;
@@ -858,7 +865,7 @@ __device__ __forceinline__ void chain_sweep(const int nsteps, const int lane, do
                 blk_umv(m.Di, rhs[0], rhs[1], rhs[2], out);
                 if (relax_mode == 1) { out[0] = w * out[0]; out[1] = w * out[1]; out[2] = w * out[2]; }
                 vu[(size_t)r * BS] = out[0]; vu[(size_t)r * BS + 1] = out[1]; vu[(size_t)r * BS + 2] = out[2];
-                if (v != vu) { v[(size_t)r * BS] = w * out[0]; v[(size_t)r * BS + 1] = w * out[1]; v[(size_t)r * BS + 2] = w * out[2]; }
+                if (v != vu) { v[(size_t)r * BS] = second_result<0>(addp, r, w * out[0]); v[(size_t)r * BS + 1] = second_result<1>(addp, r, w * out[1]); v[(size_t)r * BS + 2] = second_result<2>(addp, r, w * out[2]); }
                 myPrev[0] = out[0]; myPrev[1] = out[1]; myPrev[2] = out[2];
             }
             myPrevRow = r;
@@ -892,7 +899,7 @@ __device__ __forceinline__ void chain_sweep_light(const int nsteps, const int la
                                                   const int* __restrict__ prow,
                                                   const int* __restrict__ pcol, const double* __restrict__ P,
                                                   const double* __restrict__ invD, const double* d, double* vu, double* v,
-                                                  int relax_mode, double w) {
+                                                  const double* __restrict__ addp, int relax_mode, double w) {
     // Written by the rules chain_sweep's comment lists: every load unconditional, into registers whose content is dead,
     // nothing loaded ever copied, and no load consumed while it is the newest one outstanding (waiting for the newest
     // load means waiting for all of them - and, the counter being in order, waiting for a load issued k steps ago means
@@ -968,7 +975,7 @@ __device__ __forceinline__ void chain_sweep_light(const int nsteps, const int la
                     blk_umv(c.Di, rhs[0], rhs[1], rhs[2], out);
                     if (relax_mode == 1) { out[0] = w * out[0]; out[1] = w * out[1]; out[2] = w * out[2]; }
                     vu[(size_t)r * BS] = out[0]; vu[(size_t)r * BS + 1] = out[1]; vu[(size_t)r * BS + 2] = out[2];
-                    if (v != vu) { v[(size_t)r * BS] = w * out[0]; v[(size_t)r * BS + 1] = w * out[1]; v[(size_t)r * BS + 2] = w * out[2]; }
+                    if (v != vu) { v[(size_t)r * BS] = second_result<0>(addp, r, w * out[0]); v[(size_t)r * BS + 1] = second_result<1>(addp, r, w * out[1]); v[(size_t)r * BS + 2] = second_result<2>(addp, r, w * out[2]); }
                     prev[0] = out[0]; prev[1] = out[1]; prev[2] = out[2];
                 }
             }
@@ -985,21 +992,21 @@ __global__ __launch_bounds__(64) void k_ilu_sweep_light(const int* __restrict__ 
                                                         const int* __restrict__ prow,
                                                         const int* __restrict__ pcol, const double* __restrict__ P,
                                                         const double* __restrict__ invD, const double* d,
-                                                        double* vu, double* v, int relax_mode, double w, const double* __restrict__ done) {
+                                                        double* vu, double* v, const double* __restrict__ addp, int relax_mode, double w, const double* __restrict__ done) {
     __shared__ int sdesc[DESC_MAX];
     const int lane = threadIdx.x;
     const double stop = *done;   // read with the descriptor record, tested after it: one round trip instead of two
     const int nsteps = load_desc(desc, dstride, lane, sdesc);
     if (stop != 0.0 || nsteps <= 0) return;
     (void)S1;
-    chain_sweep_light<SHAPE>(nsteps, lane, sdesc + DESC_HEAD, prow, pcol, P, invD, d, vu, v, relax_mode, w);
+    chain_sweep_light<SHAPE>(nsteps, lane, sdesc + DESC_HEAD, prow, pcol, P, invD, d, vu, v, addp, relax_mode, w);
 }
 template <int SHAPE>
 __global__ __launch_bounds__(64) void k_ilu_sweep_chain(const int* __restrict__ desc, int dstride, int S1,
                                                         const int* __restrict__ prow,
                                                         const int* __restrict__ pcol, const double* __restrict__ P,
                                                         const double* __restrict__ invD, const double* d,
-                                                        double* vu, double* v, int relax_mode, double w, const double* __restrict__ done) {
+                                                        double* vu, double* v, const double* __restrict__ addp, int relax_mode, double w, const double* __restrict__ done) {
     TILE_LDS
     __shared__ int sdesc[DESC_MAX];
     const int lane = threadIdx.x;
@@ -1007,7 +1014,7 @@ __global__ __launch_bounds__(64) void k_ilu_sweep_chain(const int* __restrict__ 
     const int nsteps = load_desc(desc, dstride, lane, sdesc);
     if (stop != 0.0 || nsteps <= 0) return;
     const int* srow0 = sdesc + DESC_HEAD;
-    chain_sweep<SHAPE>(nsteps, lane, sval, srow0, srow0 + (SHAPE == SW_L ? 1 : 2) * S1, prow, pcol, P, invD, d, vu, v, relax_mode, w);
+    chain_sweep<SHAPE>(nsteps, lane, sval, srow0, srow0 + (SHAPE == SW_L ? 1 : 2) * S1, prow, pcol, P, invD, d, vu, v, addp, relax_mode, w);
 }
 // Last colour: its rows have U entries only inside their own chain-tile, so the backward sweep of a chain-tile can
 // start the moment its forward sweep ends - one launch instead of two, and y never leaves the cache in between.
@@ -1017,7 +1024,7 @@ __global__ __launch_bounds__(64) void k_ilu_sweep_chain_LU(const int* __restrict
                                                            const int* __restrict__ lcol, const double* __restrict__ L,
                                                            const int* __restrict__ urow, const int* __restrict__ ucol,
                                                            const double* __restrict__ Uv, const double* __restrict__ invD,
-                                                           const double* d, double* vu, double* v, int relax_mode, double w,
+                                                           const double* d, double* vu, double* v, const double* __restrict__ addp, int relax_mode, double w,
                                                            const double* __restrict__ done) {
     TILE_LDS
     __shared__ int sdesc[DESC_MAX];
@@ -1026,11 +1033,11 @@ __global__ __launch_bounds__(64) void k_ilu_sweep_chain_LU(const int* __restrict
     const int nsteps = load_desc(desc, dstride, lane, sdesc);
     if (stop != 0.0 || nsteps <= 0) return;
     const int* srow0 = sdesc + DESC_HEAD;
-    chain_sweep<SW_L>(nsteps, lane, sval, srow0, srow0 + S1, lrow, lcol, L, invD, d, vu, v, relax_mode, w);
+    chain_sweep<SW_L>(nsteps, lane, sval, srow0, srow0 + S1, lrow, lcol, L, invD, d, vu, v, addp, relax_mode, w);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // y of this chain-tile is written before the backward sweep reads it
     wave_sync();
-    if (LIGHT_U) chain_sweep_light<SW_UF>(nsteps, lane, srow0, urow, ucol, Uv, invD, d, vu, v, relax_mode, w);
-    else chain_sweep<SW_UF>(nsteps, lane, sval, srow0, srow0 + 2 * S1, urow, ucol, Uv, invD, d, vu, v, relax_mode, w);
+    if (LIGHT_U) chain_sweep_light<SW_UF>(nsteps, lane, srow0, urow, ucol, Uv, invD, d, vu, v, addp, relax_mode, w);
+    else chain_sweep<SW_UF>(nsteps, lane, sval, srow0, srow0 + 2 * S1, urow, ucol, Uv, invD, d, vu, v, addp, relax_mode, w);
 }
 
 // ============================== ILU0 factorisation =======================================================
@@ -1696,14 +1703,15 @@ void launch_ilu_factor(opmhip_ctx* c) {
 // unscaled != NULL: with post-scaling the sweeps leave U^-1 L^-1 d in v WITHOUT the factor w and report the factor in *unscaled
 // (1 when there is none to apply): whoever reads v next multiplies on the fly - w * v_i is one rounded product either way -
 // and the second result vector (24 bytes per row written by the backward sweeps) never exists.
-void launch_ilu_apply(opmhip_ctx* c, const double* d, double* v, double w_override, double* unscaled) {
+void launch_ilu_apply(opmhip_ctx* c, const double* d, double* v, double w_override, double* unscaled, const double* addp, double* work) {
     const Pattern& P = c->pat;
     const int ps = prof_begin(c, PROF_ILU_APPLY);
     const int C = P.numColors, mode = c->cfg.relax_mode;
     const double w = w_override > 0.0 ? w_override : c->cfg.ilu_relaxation;   // CPR's fine smoother runs with relaxation 1
     // post-scale with w != 1 keeps the unscaled sweep vector apart from the scaled result
     const bool post = mode == OPMHIP_RELAX_POST_SCALE && w != 1.0;
-    double* vu = (post && !unscaled) ? c->d_vu : v;
+    // addp (CPR, w = 1): the sweeps run in `work`, v receives (0, addp, 0) + the result
+    double* vu = addp ? work : (post && !unscaled) ? c->d_vu : v;
     if (unscaled) *unscaled = post ? w : 1.0;
     const int n0 = P.colorPrefix[1];  // rows of the first colour: their y is d
     auto grid = [](int n) { return dim3(8 * ((n + 7) / 8)); };
@@ -1717,20 +1725,20 @@ void launch_ilu_apply(opmhip_ctx* c, const double* d, double* v, double w_overri
             if (nct <= 0) continue;
             if (P.lightL[col])
                 hipLaunchKernelGGL(k_ilu_sweep_light<SW_L>, dim3(nct), dim3(64), 0, c->stream, desc(col), ds, S1, P.d_lrowptr,
-                                   P.d_lcol, c->d_L, c->d_invD, d, vu, v, mode, w, c->d_done);
+                                   P.d_lcol, c->d_L, c->d_invD, d, vu, v, addp, mode, w, c->d_done);
             else
                 hipLaunchKernelGGL(k_ilu_sweep_chain<SW_L>, dim3(nct), dim3(64), 0, c->stream, desc(col), ds, S1, P.d_lrowptr,
-                                   P.d_lcol, c->d_L, c->d_invD, d, vu, v, mode, w, c->d_done);
+                                   P.d_lcol, c->d_L, c->d_invD, d, vu, v, addp, mode, w, c->d_done);
         }
         {
             const int nct = npos(C - 1);
             if (nct > 0) {
                 if (P.lightU[C - 1])
                     hipLaunchKernelGGL(k_ilu_sweep_chain_LU<true>, dim3(nct), dim3(64), 0, c->stream, desc(C - 1), ds, S1, P.d_lrowptr,
-                                       P.d_lcol, c->d_L, P.d_urowptr, P.d_ucol, c->d_U, c->d_invD, d, vu, v, mode, w, c->d_done);
+                                       P.d_lcol, c->d_L, P.d_urowptr, P.d_ucol, c->d_U, c->d_invD, d, vu, v, addp, mode, w, c->d_done);
                 else
                     hipLaunchKernelGGL(k_ilu_sweep_chain_LU<false>, dim3(nct), dim3(64), 0, c->stream, desc(C - 1), ds, S1, P.d_lrowptr,
-                                       P.d_lcol, c->d_L, P.d_urowptr, P.d_ucol, c->d_U, c->d_invD, d, vu, v, mode, w, c->d_done);
+                                       P.d_lcol, c->d_L, P.d_urowptr, P.d_ucol, c->d_U, c->d_invD, d, vu, v, addp, mode, w, c->d_done);
             }
         }
         for (int col = C - 2; col >= 0; --col) {
@@ -1738,10 +1746,10 @@ void launch_ilu_apply(opmhip_ctx* c, const double* d, double* v, double w_overri
             if (nct <= 0) continue;
             if (P.lightU[col])
                 hipLaunchKernelGGL(k_ilu_sweep_light<SW_UF>, dim3(nct), dim3(64), 0, c->stream, desc(col), ds, S1, P.d_urowptr,
-                                   P.d_ucol, c->d_U, c->d_invD, d, vu, v, mode, w, c->d_done);
+                                   P.d_ucol, c->d_U, c->d_invD, d, vu, v, addp, mode, w, c->d_done);
             else
                 hipLaunchKernelGGL(k_ilu_sweep_chain<SW_UF>, dim3(nct), dim3(64), 0, c->stream, desc(col), ds, S1, P.d_urowptr,
-                                   P.d_ucol, c->d_U, c->d_invD, d, vu, v, mode, w, c->d_done);
+                                   P.d_ucol, c->d_U, c->d_invD, d, vu, v, addp, mode, w, c->d_done);
         }
         prof_end(c, ps);
         return;
@@ -1751,17 +1759,17 @@ void launch_ilu_apply(opmhip_ctx* c, const double* d, double* v, double w_overri
         if (nt <= 0) continue;
         if (col < C - 1)
             hipLaunchKernelGGL(k_ilu_sweep<SW_L>, grid(nt), dim3(64), 0, c->stream, tb, nt, n0, 0, P.tiles.d_row0, P.d_lrowptr, P.d_lcol, c->d_L,
-                               c->d_invD, d, vu, v, mode, w, c->d_done);
+                               c->d_invD, d, vu, v, addp, mode, w, c->d_done);
         else
             hipLaunchKernelGGL(k_ilu_sweep<SW_LF>, grid(nt), dim3(64), 0, c->stream, tb, nt, n0, 0, P.tiles.d_row0, P.d_lrowptr, P.d_lcol, c->d_L,
-                               c->d_invD, d, vu, v, mode, w, c->d_done);
+                               c->d_invD, d, vu, v, addp, mode, w, c->d_done);
     }
     for (int col = (C > 1 ? C - 2 : 0); col >= 0; --col) {
         const int tb = P.tiles.colorTile[col], nt = P.tiles.colorTile[col + 1] - tb;
         if (nt <= 0) continue;
         // gathers only reach later colours (>= n0 rows in), so the d/vu split of the gather is inert here (n0 = 0)
         hipLaunchKernelGGL(k_ilu_sweep<SW_UF>, grid(nt), dim3(64), 0, c->stream, tb, nt, 0, col == 0 ? 1 : 0, P.tiles.d_row0, P.d_urowptr, P.d_ucol,
-                           c->d_U, c->d_invD, d, vu, v, mode, w, c->d_done);
+                           c->d_U, c->d_invD, d, vu, v, addp, mode, w, c->d_done);
     }
     prof_end(c, ps);
 }

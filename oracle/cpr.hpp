@@ -323,6 +323,7 @@ struct DuneLikeAmg {
     std::vector<double> lu;            // dense LU of the coarsest level
     double alpha = 1.0 / 3.0, beta = 1e-5, damp = 1.6, minCoarsenRate = 1.2;
     int maxDistance = 2, minAgg = 4, maxAgg = 6, coarsenTarget = 1200, maxLevel = 15;
+    bool jacobi = false;               // experiment: damped Jacobi (2/3) in place of the ILU0 smoother - which of the two, aggregation or smoother, makes the difference to the product's AMG?
 
     // SymmetricDependency with the sign-preserving norm FirstDiagonal: only negative off-diagonal pairs count;
     // strength e_ij e_ji / (a_ii a_jj); edge strong if > alpha * row maximum; vertex isolated if its maximum < beta
@@ -500,6 +501,10 @@ struct DuneLikeAmg {
             f[diag[i]] = 1.0 / f[diag[i]];
         }
     }
+    void smooth(const Level& L, const double* d, double* v) const {
+        if (!jacobi) { ilu0_apply(L, d, v); return; }
+        for (int i = 0; i < L.A.n; ++i) v[i] = (2.0 / 3.0) * d[i] / L.A.val[L.diag[i]];
+    }
     static void ilu0_apply(const Level& L, const double* d, double* v) {
         const Csr& A = L.A;
         const int n = A.n;
@@ -602,7 +607,7 @@ struct DuneLikeAmg {
             return;
         }
         std::vector<double> d(b, b + n), v(n), t(n);
-        ilu0_apply(L, d.data(), v.data());                              // pre-smoothing: update += M^-1 d ; d -= A v
+        smooth(L, d.data(), v.data());                                  // pre-smoothing: update += M^-1 d ; d -= A v
         for (int i = 0; i < n; ++i) x[i] = v[i];
         CprAmg::residual(L.A, d.data(), v.data(), t.data());
         d.swap(t);
@@ -613,7 +618,7 @@ struct DuneLikeAmg {
         for (int i = 0; i < n; ++i) x[i] += v[i];
         CprAmg::residual(L.A, d.data(), v.data(), t.data());
         d.swap(t);
-        ilu0_apply(L, d.data(), v.data());                              // post-smoothing
+        smooth(L, d.data(), v.data());                                  // post-smoothing
         for (int i = 0; i < n; ++i) x[i] += v[i];
     }
 };

@@ -277,7 +277,7 @@ int orc_cpr_rebuild_structure(orc_cpr* h) { h->P.structured = false; return 0; }
 int orc_cpr_set_max_levels(orc_cpr* h, int n) { h->P.amg.maxLevels = n < 1 ? 1 : n; h->P.structured = false; return 0; }
 int orc_cpr_set_sweeps(orc_cpr* h, int nu) { if (nu < 0) { h->P.amg.joinAtStall = true; h->P.structured = false; return 0; } h->P.amg.nu = nu < 1 ? 1 : nu; return 0; }   // experiments: V(nu, nu)
 int orc_cpr_set_wcycle_from(orc_cpr* h, int l) { h->P.amg.wFrom = l < 0 ? (1 << 30) : l; return 0; }   // experiment
-int orc_cpr_use_reference_amg(orc_cpr* h, int on) { h->P.useDune = on != 0; h->P.structured = false; return 0; }
+int orc_cpr_use_reference_amg(orc_cpr* h, int on) { h->P.useDune = on != 0; h->P.dune.jacobi = on == 2;   /* 2: experiment - its aggregation with damped Jacobi smoothing */ h->P.structured = false; return 0; }
 // levels of that hierarchy
 int orc_cpr_reference_amg_levels(orc_cpr* h, int* n, int* nnz, int cap) {
     const int L = (int)h->P.dune.lv.size();

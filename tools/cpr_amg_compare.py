@@ -42,7 +42,7 @@ Nb, rp, ci = case["Nb"], case["rowptr"], case["col"]
 cprs = {}
 import ctypes
 orc.lib.orc_cpr_set_max_levels.argtypes = [ctypes.c_void_p, ctypes.c_int]
-for name, ref, lev in [("product_amg", False, 0), ("reference_like_amg", True, 0)] + [("product_amg_%d_levels" % k, False, k) for k in a.levels]:
+for name, ref, lev in [("product_amg", False, 0), ("reference_like_amg", True, 0), ("reference_aggregation_jacobi", 2, 0)] + [("product_amg_%d_levels" % k, False, k) for k in a.levels]:
     c = oracle_bind.OracleCpr(orc)
     c.use_reference_amg(ref)
     if lev:
