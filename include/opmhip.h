@@ -20,7 +20,7 @@
 extern "C" {
 #endif
 
-#define OPMHIP_ABI_VERSION 5 /* 5: opmhip_set_water_compaction, opmhip_get_max_water_saturation (additive);
+#define OPMHIP_ABI_VERSION 5 /* 5: opmhip_set_water_compaction, opmhip_get_max_water_saturation, opmhip_relative_change (additive);
                                * 4: opmhip_config names chain_length, spmv_pipe_wgs, preconditioner (were reserved[0..2]);
                                *    opmhip_set_endpoint_scaling, opmhip_sat_end_points, opmhip_sat_probe, opmhip_synchronize, opmhip_comm_info,
                                *    opmhip_set_composition_change_limits, opmhip_set_irreversible_compaction, opmhip_set_vappars, opmhip_begin_time_step;
@@ -399,6 +399,13 @@ int opmhip_gas_probe(opmhip_ctx* ctx, int pvt_region, int n, const double* p, co
  * (flow/BlackoilModelEbos.hpp:552-562).  pv: Nb x 3 (Sw, p_o, Sg|Rs), meaning: Nb bytes. Natural order. */
 int opmhip_set_state(opmhip_ctx* ctx, const double* pv, const unsigned char* meaning);
 int opmhip_get_state(opmhip_ctx* ctx, double* pv, unsigned char* meaning);
+
+/* replaces: BlackoilModelEbos::relativeChange (flow/BlackoilModelEbos.hpp:431-510), the error measure of the PID time-step
+ * control (timestepping/TimeStepControl.cpp:127-161; Flow's default --time-step-control=pid+newtoniteration): the sum over
+ * the owned cells of (p_new - p_old)^2 + sum_phases (S_new - S_old)^2 over the sum of p_new^2 + sum_phases S_new^2, new = the
+ * state on the device, old = the time level opmhip_advance_time_level kept; summed over the ranks of a decomposed run.  Call
+ * it after an accepted time step.  The cells are summed by a fixed tree: equal to the reference's sequential sum to rounding. */
+int opmhip_relative_change(opmhip_ctx* ctx, double* relative_change);
 
 /* The two time levels of the discretisation (opm-models FvBaseDiscretization: advanceTimeLevel() copies solution(0)
  * into solution(1) when a time step starts; updateFailed() copies it back and recomputes the intensive quantities

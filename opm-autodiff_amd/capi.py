@@ -362,6 +362,7 @@ def _bind_assembly(L):
     L.opmhip_set_vappars.argtypes = [vp, C.c_int, C.c_double, C.c_double]
     L.opmhip_set_water_compaction.argtypes = [vp, C.c_int, vp, vp, vp, vp, vp, vp]
     L.opmhip_get_max_water_saturation.argtypes = [vp, vp]
+    L.opmhip_relative_change.argtypes = [vp, C.POINTER(C.c_double)]
     L.opmhip_sat_end_points.argtypes = [vp, C.c_int, vp]
     L.opmhip_sat_probe.argtypes = [vp, C.c_int, vp, C.c_int, vp, vp, vp]
     L.opmhip_gas_probe.argtypes = [vp, C.c_int, C.c_int, vp, vp, vp]
@@ -525,6 +526,13 @@ class HipModel(HipSolver):
     def update_failed(self):
         """solution(0) = solution(1) + intensive quantities: the Newton method gave up on this time step."""
         self._check(lib().opmhip_update_failed(self._h))
+
+    def relative_change(self):
+        """BlackoilModelEbos::relativeChange: squared change of pressure and saturations since advance_time_level over their
+        squared new values (the PID time-step control's error measure); summed over the ranks of a decomposed run."""
+        out = C.c_double(0.0)
+        self._check(lib().opmhip_relative_change(self._h, C.byref(out)))
+        return out.value
 
     def set_composition_change_limits(self, drsdt=None, drsdt_all_cells=None, drvdt=None):
         """DRSDT / DRVDT: rates per PVT region [1/s] (negative: none), None = keyword not in force; drsdt_all_cells: the OILVAP

@@ -1249,6 +1249,7 @@ __global__ __launch_bounds__(256) void k_max_oil_saturation(int N, int init, con
 // updateMaxWaterSaturation_ (:2144-2169); init: maxWaterSaturation_ = max(0, S_w of the initial state) (:2289-2290) and the
 // initial saturation itself (initialFluidStates_).  The statement :2150 in front of the reference's loop (cell 1 takes over
 // cell 0's stored maximum) is launch_max_water_saturation's copy
+__global__ void k_copy_entry(double* __restrict__ a, int to, int from) { a[to] = a[from]; }
 __global__ __launch_bounds__(256) void k_max_water_saturation(int N, int init, const double* __restrict__ iq, double* __restrict__ maxsw, double* __restrict__ sw0) {
     const int c = blockIdx.x * blockDim.x + threadIdx.x;
     if (c >= N) return;
@@ -1383,7 +1384,7 @@ void launch_max_water_saturation(opmhip_ctx* c, bool init) {
     const Pattern& P = c->pat;
     const int N = P.Nloc;
     // eclproblem.hh:2150: the cell with index 1 takes over the stored maximum of the cell with index 0 (natural numbering)
-    if (!init && N > 1) (void)hipMemcpyAsync(c->asmb.d_maxsw + P.toOrder[1], c->asmb.d_maxsw + P.toOrder[0], sizeof(double), hipMemcpyDeviceToDevice, c->stream);
+    if (!init && N > 1) hipLaunchKernelGGL(k_copy_entry, dim3(1), dim3(1), 0, c->stream, c->asmb.d_maxsw, P.toOrder[1], P.toOrder[0]);
     hipLaunchKernelGGL(k_max_water_saturation, dim3((N + 255) / 256), dim3(256), 0, c->stream, N, init ? 1 : 0, c->asmb.d_iq, c->asmb.d_maxsw, c->asmb.d_sw0);
 }
 void launch_storage_old(opmhip_ctx* c) {
@@ -1391,6 +1392,65 @@ void launch_storage_old(opmhip_ctx* c) {
     const int Nb = c->pat.Nb, N = c->pat.Nloc;
     OPMHIP_LAYOUT(c, hipLaunchKernelGGL(k_storage_old<false>, dim3((Nb + 255) / 256), dim3(256), 0, c->stream, Nb, N, 0, A.d_iq, A.d_storageOld),
                   hipLaunchKernelGGL(k_storage_old<true>, dim3((Nb + 255) / 256), dim3(256), 0, c->stream, Nb, N, A.wet_gas ? 1 : 0, A.d_iq, A.d_storageOld));
+}
+
+// BlackoilModelEbos::relativeChange (flow/BlackoilModelEbos.hpp:431-510): sum over the owned cells of (p_new - p_old)^2 and of
+// the squared saturation changes, over the sum of p_new^2 and the squared new saturations - what the PID time-step control
+// calls the error of a time step (timestepping/TimeStepControl.cpp:127-161).  solution(0) = the state, solution(1) = the
+// time level opmhip_advance_time_level kept.  Per cell the terms are added in the reference's order (pressure, then water,
+// oil, gas); the cells are summed by a fixed tree (a sequential sum over 10^6 cells is not what a GPU does), so the result
+// agrees with the reference's sequential sum to rounding, not to the bit.
+constexpr int RC_PARTS = 256;
+__global__ __launch_bounds__(256) void k_relative_change_part(int Nb, const double* __restrict__ pv, const unsigned char* __restrict__ mg,
+                                                              const double* __restrict__ pvOld, const unsigned char* __restrict__ mgOld,
+                                                              double* __restrict__ part) {
+    __shared__ double sd[256], sn[256];
+    double delta = 0.0, denom = 0.0;
+    for (int c = blockIdx.x * 256 + threadIdx.x; c < Nb; c += RC_PARTS * 256) {
+        const double* a = &pv[(size_t)c * 3];
+        const double* b = &pvOld[(size_t)c * 3];
+        double sN[3] = {0.0, 0.0, 0.0}, sO[3] = {0.0, 0.0, 0.0};
+        double oilN = 1.0, oilO = 1.0;
+        sN[WATER] = a[0]; oilN -= sN[WATER];
+        if (mg[c] == OPMHIP_SW_PO_SG) { sN[GAS] = a[2]; oilN -= sN[GAS]; }
+        sN[OIL] = oilN;
+        const double tmp = a[1] - b[1];
+        double d = tmp * tmp, q = a[1] * a[1];
+        sO[WATER] = b[0]; oilO -= sO[WATER];
+        if (mgOld[c] == OPMHIP_SW_PO_SG) { sO[GAS] = b[2]; oilO -= sO[GAS]; }
+        sO[OIL] = oilO;
+#pragma unroll
+        for (int ph = 0; ph < 3; ++ph) {
+            const double t = sN[ph] - sO[ph];
+            d += t * t;
+            q += sN[ph] * sN[ph];
+        }
+        delta += d;
+        denom += q;
+    }
+    sd[threadIdx.x] = delta; sn[threadIdx.x] = denom;
+    __syncthreads();
+    for (int h = 128; h > 0; h >>= 1) {
+        if ((int)threadIdx.x < h) { sd[threadIdx.x] += sd[threadIdx.x + h]; sn[threadIdx.x] += sn[threadIdx.x + h]; }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) { part[blockIdx.x] = sd[0]; part[RC_PARTS + blockIdx.x] = sn[0]; }
+}
+__global__ __launch_bounds__(64) void k_relative_change_final(const double* __restrict__ part, double* __restrict__ out) {
+    if (threadIdx.x != 0) return;
+    double d = 0.0, q = 0.0;
+    for (int i = 0; i < RC_PARTS; ++i) { d += part[i]; q += part[RC_PARTS + i]; }
+    out[0] = d; out[1] = q;
+}
+// -> d_rc[2 * RC_PARTS .. + 2): (resultDelta, resultDenom), summed over the ranks of a decomposed run (gridView.comm().sum)
+int launch_relative_change(opmhip_ctx* c) {
+    const AsmDev& A = c->asmb;
+    double* part = A.d_rc;
+    double* out = A.d_rc + 2 * RC_PARTS;
+    hipLaunchKernelGGL(k_relative_change_part, dim3(RC_PARTS), dim3(256), 0, c->stream, c->pat.Nb, A.d_pv, A.d_meaning, A.d_pv_prev, A.d_meaning_prev, part);
+    hipLaunchKernelGGL(k_relative_change_final, dim3(1), dim3(64), 0, c->stream, part, out);
+    if (c->comm.nranks > 1) return comm_allreduce(c, out, 2, 0);
+    return OPMHIP_SUCCESS;
 }
 
 int launch_convergence(opmhip_ctx* c, double dt, double tol_cnv) {

@@ -493,6 +493,23 @@ int opmhip_advance_time_level(opmhip_ctx* c) {
     });
 }
 
+int opmhip_relative_change(opmhip_ctx* c, double* relative_change) {
+    if (!c || !relative_change) return OPMHIP_INVALID_ARGUMENT;
+    return guarded(c, [&]() -> int {
+        AsmDev& A = c->asmb;
+        if (!A.prev_set) return fail(c, OPMHIP_NOT_READY, "relative_change before advance_time_level: there is no old time level to compare with");
+        OPMHIP_HIP(c, hipSetDevice(c->device));
+        int rc;
+        if (!A.d_rc && (rc = dev_alloc(c, &A.d_rc, (size_t)2 * 256 + 2))) return rc;
+        if ((rc = launch_relative_change(c))) return rc;
+        double h[2];
+        OPMHIP_HIP(c, hipMemcpyAsync(h, A.d_rc + 2 * 256, sizeof(h), hipMemcpyDeviceToHost, c->stream));
+        OPMHIP_HIP(c, hipStreamSynchronize(c->stream));
+        *relative_change = h[1] > 0.0 ? h[0] / h[1] : 0.0;
+        return OPMHIP_SUCCESS;
+    });
+}
+
 int opmhip_update_failed(opmhip_ctx* c) {
     if (!c) return OPMHIP_INVALID_ARGUMENT;
     return guarded(c, [&]() -> int {

@@ -116,6 +116,7 @@ struct AsmDev {
     double* d_maxso = nullptr;                            // per cell largest oil saturation at the start of a time step (VAPPARS); NULL = not in force
     double vap1 = 0.0, vap2 = 0.0;                        // VAPPARS exponents: on RvSat, on RsSat
     double *d_maxsw = nullptr, *d_sw0 = nullptr;          // water-induced compaction: largest S_w at the start of a time step, initial S_w; NULL = off
+    double* d_rc = nullptr;                               // relativeChange: 2 x 256 partial sums + (delta, denominator)
     int num_wc = 0, h_rocknum_max = -1;                   // water-compaction tables; largest rock-table index handed in (-1: none)
     int* d_wcdesc = nullptr;                              // per table {np, nsw, pressure at, S_w at, pore-volume multipliers at, transmissibility multipliers at | -1}
     double* d_wcdata = nullptr;
@@ -417,6 +418,7 @@ void launch_min_pressure(opmhip_ctx* c, bool init);
 void launch_storage_old(opmhip_ctx* c);
 void launch_max_oil_saturation(opmhip_ctx* c, bool init);
 void launch_max_water_saturation(opmhip_ctx* c, bool init);
+int launch_relative_change(opmhip_ctx* c);   // -> asmb.d_rc[512 .. 514)
 int launch_convergence(opmhip_ctx* c, double dt, double tol_cnv);
 void launch_u8_to_internal(opmhip_ctx* c, const unsigned char* nat, unsigned char* internal);
 void launch_u8_to_natural(opmhip_ctx* c, const unsigned char* internal, unsigned char* nat);

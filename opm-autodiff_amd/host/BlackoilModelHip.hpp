@@ -168,10 +168,32 @@ public:
     /// EclProblem::endTimeStep, the drift-compensation part (ebos/eclproblem.hh:1126-1135): after an ACCEPTED time step
     void endTimeStep(double dt) { check(opmhip_end_time_step(ctx_, dt), "endTimeStep"); }
 
+    /// BlackoilModelEbos::relativeChange (flow/BlackoilModelEbos.hpp:431-510): the PID time-step control's error measure, on the device
+    double relativeChange() const {
+        double v = 0.0;
+        check(opmhip_relative_change(ctx_, &v), "relativeChange");
+        return v;
+    }
+
+    /// PIDTimeStepControl::computeTimeStepSize (timestepping/TimeStepControl.cpp:117-161)
+    struct PIDTimeStepControl {
+        double tol;
+        double errors[3];
+        explicit PIDTimeStepControl(double t = 1e-1) : tol(t), errors{t, t, t} {}
+        double computeTimeStepSize(double dt, double error) {
+            errors[0] = errors[1]; errors[1] = errors[2]; errors[2] = error;
+            if (error > tol) return dt * tol / error;
+            const double kP = 0.075, kI = 0.175, kD = 0.01;
+            return dt * std::pow(errors[1] / errors[2], kP) * std::pow(tol / errors[2], kI) * std::pow(errors[0] * errors[0] / errors[1] / errors[2], kD);
+        }
+    };
+    PIDTimeStepControl pid_;   // Flow's default --time-step-control=pid+newtoniteration, tolerance 1e-1
+
     /// The sub-step loop of AdaptiveTimeSteppingEbos::step (timestepping/AdaptiveTimeSteppingEbos.hpp:283-520) for one
     /// report step of length `length` starting with sub-step `dt`: a failed sub-step is rolled back and retried with
     /// dt * 0.33 (SolverRestartFactor, at most SolverMaxRestarts = 10 times in a row); an accepted one sets the next dt
-    /// by the Newton-iteration-count rule (TimeStepControl.cpp:188-208, target 8, growth damping 3.2, decay damping 1),
+    /// by PIDAndIterationCountTimeStepControl (TimeStepControl.cpp:169-208): the smaller of the PID estimate from
+    /// relativeChange() and the Newton-iteration-count estimate (target 8, growth damping 3.2, decay damping 1),
     /// capped by SolverMaxGrowth = 3 and, right after a chop, by SolverGrowthFactor = 2.  Returns the suggested next dt.
     double advanceReportStep(double length, double dt, SimulatorReportSingle& report, int* chopped = nullptr) {
         const double restartFactor = 0.33, growthFactor = 2.0, maxGrowth = 3.0, growthDamping = 3.2, decayDamping = 1.0;
@@ -199,8 +221,9 @@ public:
             }
             endTimeStep(dt);
             t += dt;
-            double est = newtons > target ? dt / (1.0 + double(newtons - target) / target * decayDamping)
-                                          : dt * (1.0 + double(target - newtons) / target * growthDamping);
+            const double estIter = newtons > target ? dt / (1.0 + double(newtons - target) / target * decayDamping)
+                                                    : dt * (1.0 + double(target - newtons) / target * growthDamping);
+            double est = std::min(pid_.computeTimeStepSize(dt, relativeChange()), estIter);
             est = std::min(est, maxGrowth * dt);
             if (restarts > 0) { est = std::min(growthFactor * dt, est); restarts = 0; }
             dt = est;

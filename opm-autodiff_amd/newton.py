@@ -163,6 +163,10 @@ class BlackoilModelHip:
     def update_failed(self):
         self.m.update_failed()
 
+    def relative_change(self):
+        """BlackoilModelEbos::relativeChange (flow/BlackoilModelEbos.hpp:431-510); None where the model object has none"""
+        return self.m.relative_change() if hasattr(self.m, "relative_change") else None
+
     # -- EclProblem::beginTimeStep (ebos/eclproblem.hh:1042-1075): DRSDT / DRVDT caps of a step of size dt, minimum pressure --
     def begin_time_step(self, dt):
         if hasattr(self.m, "begin_time_step"):
@@ -183,8 +187,34 @@ class TimeSteppingParameters:
     target_newton_iterations: int = 8     # TimeStepControlTargetNewtonIterations
     decay_damping: float = 1.0            # TimeStepControlDecayDampingFactor
     growth_damping: float = 3.2           # TimeStepControlGrowthDampingFactor
+    time_step_control: str = "pid+newtoniteration"   # TimeStepControl (AdaptiveTimeSteppingEbos.hpp:168-170); "newtoniteration": without the PID part
+    time_step_control_tolerance: float = 1e-1        # TimeStepControlTolerance (:172-174)
+    min_time_step_based_on_newton_iterations: float = 0.0   # MinTimeStepBasedOnNewtonIterations (:215-217)
     initial_dt: float = 86400.0           # InitialTimeStepInDays
     max_dt: float = 365.0 * 86400.0       # SolverMaxTimeStepInDays (bench.py passes its report-step length)
+
+
+class PIDTimeStepControl:
+    """PIDTimeStepControl::computeTimeStepSize (timestepping/TimeStepControl.cpp:117-161): the last three relative changes
+    of the solution steer dt towards the tolerance; IEEE arithmetic as in C++ (a step without any change gives inf, which the
+    caller's min() with the iteration-count estimate and the growth cap then replaces)"""
+
+    def __init__(self, tol):
+        self.tol = float(tol)
+        self.errors = [self.tol] * 3
+
+    def compute(self, dt, error):
+        import numpy as np
+        e = self.errors
+        e[0], e[1] = e[1], e[2]
+        e[2] = float(error)
+        tol = self.tol
+        if error > tol:
+            return dt * tol / error
+        kP, kI, kD = 0.075, 0.175, 0.01          # "values taking from turek time stepping paper"
+        with np.errstate(divide="ignore", invalid="ignore", over="ignore"):
+            e0, e1, e2 = (np.float64(v) for v in e)
+            return float(dt * np.power(e1 / e2, kP) * np.power(tol / e2, kI) * np.power(e0 * e0 / e1 / e2, kD))
 
 
 class AdaptiveTimeStepping:
@@ -192,8 +222,9 @@ class AdaptiveTimeStepping:
     :283-520) over any model object with nonlinear_iteration(iteration, dt) -> report, advance_time_level(),
     update_failed(), end_time_step(dt) and param.newton_max_iter: a failed time step (TooManyIterations, NumericalIssue) is rolled back and
     retried with dt * restart_factor; an accepted one sets the next dt with the Newton-iteration-count rule of
-    PIDAndIterationCountTimeStepControl::computeTimeStepSize (timestepping/TimeStepControl.cpp:188-208; its PID part
-    needs the relative change of the solution and is left out, which only makes the steps longer).
+    PIDAndIterationCountTimeStepControl::computeTimeStepSize (timestepping/TimeStepControl.cpp:188-208): the smaller of the
+    PID estimate - from the model's relative_change(), BlackoilModelEbos::relativeChange on the device - and the
+    Newton-iteration-count estimate; a model object without relative_change() gets the iteration-count estimate alone.
     Hands out Newton iterations one at a time so that a benchmark can count and time them."""
 
     def __init__(self, model, param=None):
@@ -207,14 +238,22 @@ class AdaptiveTimeStepping:
         self.time = 0.0
         self.report = SimulatorReportSingle()
         self.history = []          # (dt, newton iterations, accepted)
+        self.pid = PIDTimeStepControl(self.p.time_step_control_tolerance) if self.p.time_step_control == "pid+newtoniteration" else None
+        self.relative_changes = []  # what the PID control saw, per accepted time step
 
     def _next_dt(self, dt, iterations):
         p = self.p
         tgt = p.target_newton_iterations
         if iterations > tgt:
-            est = dt / (1.0 + (iterations - tgt) / tgt * p.decay_damping)
+            est = max(dt / (1.0 + (iterations - tgt) / tgt * p.decay_damping), p.min_time_step_based_on_newton_iterations)
         else:
             est = dt * (1.0 + (tgt - iterations) / tgt * p.growth_damping)
+        if self.pid is not None:
+            err = self.model.relative_change() if hasattr(self.model, "relative_change") else None
+            if err is not None:
+                self.relative_changes.append(err)
+                est_pid = self.pid.compute(dt, err)
+                est = est if est < est_pid else est_pid      # std::min(dtEstimatePID, dtEstimateIter)
         est = min(est, p.max_growth * dt)                      # AdaptiveTimeSteppingEbos.hpp:404-406
         if self.restarts > 0:                                  # :408-411
             est = min(p.growth_factor * dt, est)

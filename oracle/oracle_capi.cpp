@@ -665,6 +665,47 @@ int orc_bo_get_max_oil_saturation(orc_model* h, double* out) {
     for (int c = 0; c < M.P.pat.Nb; ++c) out[c] = M.P.maxOilSaturation.empty() ? 0.0 : M.P.maxOilSaturation[c];
     return 0;
 }
+// BlackoilModelEbos::relativeChange (flow/BlackoilModelEbos.hpp:431-510): the state now present against an old time level
+// handed in, the cells in index order, every term added to the running sums as the reference adds it
+int orc_bo_relative_change(orc_model* h, const double* pvOld, const uint8_t* meaningOld, double* out) {
+    Model& M = h->M;
+    const int Nb = M.P.pat.Nb;
+    double resultDelta = 0.0, resultDenom = 0.0;
+    for (int c = 0; c < Nb; ++c) {
+        const double* a = &M.pv[(size_t)c * 3];
+        const double* b = &pvOld[(size_t)c * 3];
+        const double pressureNew = a[PV_P];
+        double saturationsNew[3] = {0.0, 0.0, 0.0};
+        double oilSaturationNew = 1.0;
+        saturationsNew[WATER] = a[PV_SW];
+        oilSaturationNew -= saturationsNew[WATER];
+        if (M.meaning[c] == Sw_po_Sg) {
+            saturationsNew[GAS] = a[PV_X];
+            oilSaturationNew -= saturationsNew[GAS];
+        }
+        saturationsNew[OIL] = oilSaturationNew;
+        const double pressureOld = b[PV_P];
+        double saturationsOld[3] = {0.0, 0.0, 0.0};
+        double oilSaturationOld = 1.0;
+        const double tmp = pressureNew - pressureOld;
+        resultDelta += tmp * tmp;
+        resultDenom += pressureNew * pressureNew;
+        saturationsOld[WATER] = b[PV_SW];
+        oilSaturationOld -= saturationsOld[WATER];
+        if (meaningOld[c] == Sw_po_Sg) {
+            saturationsOld[GAS] = b[PV_X];
+            oilSaturationOld -= saturationsOld[GAS];
+        }
+        saturationsOld[OIL] = oilSaturationOld;
+        for (int ph = 0; ph < 3; ++ph) {
+            const double tmpSat = saturationsNew[ph] - saturationsOld[ph];
+            resultDelta += tmpSat * tmpSat;
+            resultDenom += saturationsNew[ph] * saturationsNew[ph];
+        }
+    }
+    *out = resultDenom > 0.0 ? resultDelta / resultDenom : 0.0;
+    return 0;
+}
 int orc_bo_begin_time_step(orc_model* h, double dt) { h->M.begin_time_step(dt); return 0; }
 // trackers, for tests: out[0..Nb) lastRs, [Nb..2Nb) lastRv, [2Nb..3Nb) minOilPressure (0 where not kept)
 int orc_bo_get_trackers(orc_model* h, double* out) {

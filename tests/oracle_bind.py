@@ -170,6 +170,7 @@ class OracleModel:
         L.orc_bo_get_max_oil_saturation.argtypes = [_vp, _d]
         L.orc_bo_set_water_compaction.argtypes = [_vp, C.c_int, _vp, _vp, _vp, _vp, _vp, _vp]
         L.orc_bo_get_max_water_saturation.argtypes = [_vp, _d]
+        L.orc_bo_relative_change.argtypes = [_vp, _d, np.ctypeslib.ndpointer(dtype=np.uint8, flags="C_CONTIGUOUS"), C.POINTER(C.c_double)]
         L.orc_bo_end_time_step.argtypes = [_vp, C.c_double]
         L.orc_bo_set_drift_compensation.argtypes = [_vp, C.c_int, C.c_double]
         L.orc_bo_get_drift.argtypes = [_vp, _d]
@@ -265,6 +266,12 @@ class OracleModel:
         m = np.empty(self.Nb, np.uint8)
         self.o.lib.orc_bo_get_state(self.h, pv, m)
         return pv, m
+
+    def relative_change(self, pv_old, meaning_old):
+        """BlackoilModelEbos::relativeChange of the present state against an old time level"""
+        out = C.c_double(0.0)
+        self.o.lib.orc_bo_relative_change(self.h, np.ascontiguousarray(pv_old, np.float64), np.ascontiguousarray(meaning_old, np.uint8), C.byref(out))
+        return out.value
 
     def set_source(self, source, dsource=None):
         s = np.ascontiguousarray(source, np.float64)
@@ -406,6 +413,9 @@ class OracleAsHipModel:
 
     def update_failed(self):
         self.om.set_state(*self._prev)
+
+    def relative_change(self):
+        return self.om.relative_change(*self._prev)
 
     def end_time_step(self, dt):
         self.om.end_time_step(dt)

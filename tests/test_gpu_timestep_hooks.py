@@ -131,6 +131,45 @@ def test_irreversible_compaction_bitwise(pkg, orc):
     assert np.array_equal(m.iq(), rev.iq()) and np.array_equal(o.iq(), m.iq())
 
 
+def test_relative_change_of_a_time_step(pkg, orc):
+    """BlackoilModelEbos::relativeChange (flow/BlackoilModelEbos.hpp:431-510) on the device against the oracle's sequential
+    sum: the device adds the cells up in a fixed tree, so the two agree to rounding (1e-13), not to the bit; cells that
+    changed their primary-variable meaning during the step take their gas saturation from the meaning of each time level"""
+    case = helpers.wetgas_case(pkg, 9, 8, 7, heterogeneous=True)
+    src = pkg.decks.five_spot_source(case, rate_sm3_per_day=50.0)
+    m, o = both(pkg, orc, case)
+    with pytest.raises(pkg.capi.OpmHipError):       # no old time level yet
+        m.relative_change()
+    for q in (m, o):
+        q.set_source(src)
+    m.advance_time_level()
+    old = o.get_state()
+    assert m.relative_change() == 0.0 and o.relative_change(*old) == 0.0
+    dt = 5 * 86400.0
+    switched = 0
+    for it in range(5):
+        m.assemble(dt, it)
+        o.assemble(dt, it)
+        x, res = o.solve(tol=1e-6, maxit=200, w=0.9, mode="post_scale", reorder="none")
+        m.update(x, 1.0)
+        o.update(x)
+        assert same_state(m, o)
+        a, b = m.relative_change(), o.relative_change(*old)
+        assert a > 0.0 and abs(a - b) <= 1e-13 * b, (it, a, b)
+        switched += int(np.any(o.get_state()[1] != old[1]))
+    assert switched > 0
+    # the definition, once more in numpy: squared changes of p and of the three saturations over their squared new values
+    pn, mn = o.get_state()
+    pn, po = pn.reshape(-1, 3), old[0].reshape(-1, 3)
+    sat = lambda pv, mg: np.stack([pv[:, 0], 1.0 - pv[:, 0] - np.where(mg == 0, pv[:, 2], 0.0), np.where(mg == 0, pv[:, 2], 0.0)], axis=1)
+    sn, so = sat(pn, mn), sat(po, old[1])
+    want = (((pn[:, 1] - po[:, 1]) ** 2).sum() + ((sn - so) ** 2).sum()) / ((pn[:, 1] ** 2).sum() + (sn ** 2).sum())
+    assert m.relative_change() == pytest.approx(want, rel=1e-12)
+    # a rolled-back step compares equal time levels again
+    m.update_failed()
+    assert m.relative_change() == 0.0
+
+
 def test_argument_errors(pkg):
     case = pkg.decks.cartesian_case(4, 4, 3, state="mixed")
     m = pkg.capi.HipModel(case)

@@ -93,3 +93,49 @@ def test_numerical_issue_is_a_failed_step():
     ts = newton.AdaptiveTimeStepping(mdl, newton.TimeSteppingParameters(initial_dt=2 * DAY))
     ts.next_newton_iteration()
     assert ts.history[0] == (2 * DAY, 0, False) and mdl.rolled_back == 1 and ts.dt == pytest.approx(0.66 * DAY)
+
+
+class ScriptedWithChange(Scripted):
+    """... and reports a scripted relative change of the solution after every accepted time step"""
+
+    def __init__(self, need, changes):
+        super().__init__(need)
+        self.changes = list(changes)
+
+    def relative_change(self):
+        return self.changes.pop(0)
+
+
+def test_pid_control_is_the_formula_of_the_reference():
+    """PIDTimeStepControl::computeTimeStepSize (timestepping/TimeStepControl.cpp:127-161), by hand"""
+    pid = newton.PIDTimeStepControl(1e-1)
+    assert pid.errors == [1e-1] * 3
+    # an error above the tolerance: dt * tol / error
+    assert pid.compute(4.0, 0.4) == 4.0 * 1e-1 / 0.4
+    assert pid.errors == [1e-1, 1e-1, 0.4]
+    # below: dt (e1/e2)^kP (tol/e2)^kI (e0^2/e1/e2)^kD with the shifted history
+    e0, e1, e2 = 1e-1, 0.4, 1e-3
+    want = 2.0 * (e1 / e2) ** 0.075 * (1e-1 / e2) ** 0.175 * (e0 * e0 / e1 / e2) ** 0.01
+    assert pid.compute(2.0, 1e-3) == pytest.approx(want, rel=1e-15)
+    assert pid.errors == [e0, e1, e2]
+    # a step without any change: IEEE arithmetic as in the reference's doubles - the estimate is infinite, the caller's min() decides
+    assert pid.compute(1.0, 0.0) == float("inf")
+
+
+def test_pid_and_newton_iteration_control_takes_the_smaller_estimate():
+    """PIDAndIterationCountTimeStepControl (TimeStepControl.cpp:188-208) inside the sub-step loop, Flow's default control"""
+    # three Newton iterations per step: the iteration-count estimate alone would grow by 3 (the cap) every time
+    mdl = ScriptedWithChange(lambda dt: 3, [0.4, 1e-6, 1e-6])
+    ts = newton.AdaptiveTimeStepping(mdl, newton.TimeSteppingParameters(initial_dt=4 * DAY, max_dt=100 * DAY))
+    for _ in range(10):
+        ts.next_newton_iteration()
+    # step 1: error 0.4 > tol 0.1: the PID estimate 4 d * 0.1 / 0.4 = 1 d wins over 12 d; steps 2, 3: tiny errors, the PID
+    # estimate is far beyond the growth cap of 3
+    assert [h[0] / DAY for h in ts.history] == pytest.approx([4.0, 1.0, 3.0])
+    assert ts.dt == pytest.approx(9.0 * DAY) and ts.relative_changes == [0.4, 1e-6, 1e-6]
+    # the same model under the iteration-count control alone
+    mdl = ScriptedWithChange(lambda dt: 3, [0.4] * 3)
+    ts = newton.AdaptiveTimeStepping(mdl, newton.TimeSteppingParameters(initial_dt=4 * DAY, max_dt=100 * DAY, time_step_control="newtoniteration"))
+    for _ in range(10):
+        ts.next_newton_iteration()
+    assert [h[0] / DAY for h in ts.history] == pytest.approx([4.0, 12.0, 36.0]) and ts.relative_changes == []
