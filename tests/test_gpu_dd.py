@@ -297,6 +297,35 @@ def test_dd_time_step_roll_back_restores_owned_and_ghost_cells(pkg):
         assert all(flags), flags
 
 
+def test_dd_relative_change_is_summed_over_the_ranks(pkg):
+    """BlackoilModelEbos::relativeChange ends in gridView.comm().sum (flow/BlackoilModelEbos.hpp:501-502): every rank of a
+    decomposed run gets the same number, owned cells only, and it is the single-domain number up to the order of the sums"""
+    world, n = 4, 6
+    g, owner, parts = global_and_parts(pkg, n, world, state="mixed", heterogeneous=True)
+    rng = np.random.default_rng(5)
+    dpv = rng.normal(size=(g["Nb"], 3)) * np.array([0.01, 2e5, 0.005])     # a made-up change of the solution, natural order of the global grid
+    single = pkg.capi.HipModel(g, reorder="line_coloring")
+    single.set_state(g["pv"], g["meaning"])
+    single.advance_time_level()
+    single.update(dpv.reshape(-1), 1.0)             # a Newton update (chopped and switched cell by cell, the same on every side)
+    want = single.relative_change()
+    assert want > 0.0
+    group = "c" + uuid.uuid4().hex
+
+    def rank_fn(r):
+        c = parts[r]
+        m = pkg.capi.HipModel(c, comm=("loopback", world, r, group), reorder="line_coloring")
+        m.set_state(c["pv"], c["meaning"])
+        m.advance_time_level()
+        gid = np.asarray(c["gids"])
+        m.update(dpv[gid].reshape(-1), 1.0)
+        return m.relative_change()
+
+    got = run_ranks(world, rank_fn)
+    assert len(set(got)) == 1                       # one all-reduced number
+    assert got[0] == pytest.approx(want, rel=1e-13)
+
+
 def test_dd_wet_gas_and_rock_tables_bitwise(pkg, orc):
     """The extended record layout (wet gas: Rv, third primary-variable meaning; ROCKTAB multipliers with overburden) in a
     decomposed run: ghost cells carry the 19-field records, faces towards them use Rv and the transmissibility multiplier
