@@ -12,6 +12,7 @@
 // Galerkin VALUES are recomputed on the device for every solve), damped-Jacobi smoothing, dense LU on the coarsest level.
 // The CPU restatement of exactly this algorithm is oracle/cpr.hpp; the device reproduces its preconditioner application bit
 // for bit in the same ordering (same summation orders, -ffp-contract=off).
+#include <climits>
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
@@ -169,15 +170,18 @@ __global__ __launch_bounds__(256) void k_cpr_weights(int Nb, const int* __restri
 // pressure matrix: a_p[k] = sum_r A_k[r][p] w_row[r] (PressureTransferPolicy::calculateCoarseEntries, :116-139)
 // pcol != NULL: the pressure COLUMN of every block (3 doubles) goes into an ELL image of its own, component-major
 // [c][j * Nb + i]: what the post-smoothing residual d - A (0, x_p, 0) needs of the matrix (k_cpr_presid) - a third of its bytes
-__global__ __launch_bounds__(256) void k_cpr_pvals(int Nb, int W, const int* __restrict__ rowptr, const double* __restrict__ A, const double* __restrict__ w,
-                                                   double* __restrict__ ap, double* __restrict__ pcol) {
+// col != NULL (decomposed runs): a coupling to a ghost cell (column >= Nb) is left out of the subdomain's pressure system
+// - its slot holds 0, which the row sums treat like padding - as the block ILU0 leaves it out of its factors
+__global__ __launch_bounds__(256) void k_cpr_pvals(int Nb, int W, const int* __restrict__ rowptr, const int* __restrict__ col, const double* __restrict__ A,
+                                                   const double* __restrict__ w, double* __restrict__ ap, double* __restrict__ pcol) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= Nb) return;
     const double w0 = w[(size_t)i * BS], w1 = w[(size_t)i * BS + 1], w2 = w[(size_t)i * BS + 2];
     const int kb = rowptr[i];
     for (int k = kb; k < rowptr[i + 1]; ++k) {
         const double* B = &A[(size_t)k * BB];
-        const double b0 = B[0 * BS + CPR_P], b1 = B[1 * BS + CPR_P], b2 = B[2 * BS + CPR_P];
+        const bool ghost = col && col[k] >= Nb;
+        const double b0 = ghost ? 0.0 : B[0 * BS + CPR_P], b1 = ghost ? 0.0 : B[1 * BS + CPR_P], b2 = ghost ? 0.0 : B[2 * BS + CPR_P];
         double s = 0.0;
         s += b0 * w0; s += b1 * w1; s += b2 * w2;
         const size_t e = (size_t)(k - kb) * Nb + i;
@@ -495,7 +499,7 @@ static inline dim3 g256(int n) { return dim3((n + 255) / 256); }
 // ---------------------------------------------------------------- setup --------------------------------------------------
 // ELL image of a level's pattern: columns (padding: the row itself), row lengths, position of the diagonal, position of every
 // CSR entry
-static int upload_ell(opmhip_ctx* c, const HCsr& A, CprLevelDev& L, std::vector<int>& pos, bool rowMajor) {
+static int upload_ell(opmhip_ctx* c, const HCsr& A, CprLevelDev& L, std::vector<int>& pos, bool rowMajor, int ncols = INT_MAX) {
     const int n = A.n;
     int W = 1;
     for (int i = 0; i < n; ++i) W = std::max(W, A.rowptr[i + 1] - A.rowptr[i]);
@@ -508,7 +512,7 @@ static int upload_ell(opmhip_ctx* c, const HCsr& A, CprLevelDev& L, std::vector<
     for (int i = 0; i < n; ++i) {
         const int kb = A.rowptr[i], len = A.rowptr[i + 1] - kb;
         rlen[i] = len;
-        for (int j = 0; j < W; ++j) ecol[at(j, i)] = j < len ? A.col[kb + j] : i;
+        for (int j = 0; j < W; ++j) ecol[at(j, i)] = (j < len && A.col[kb + j] < ncols) ? A.col[kb + j] : i;   // padding and ghost columns (value 0 for good): the row itself
         for (int j = 0; j < len; ++j) {
             pos[kb + j] = (int)at(j, i);
             if (A.col[kb + j] == i) diag[i] = (int)at(j, i);
@@ -644,7 +648,9 @@ static int cpr_setup_structure_impl(opmhip_ctx* c) {
     auto now = [] { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
     double tAgg = 0.0, tGal = 0.0, tUp = 0.0, t0 = now();
 #define CPR_T(acc, stmt) do { const double t_ = now(); stmt; acc += now() - t_; } while (0)
-    if (c->comm.nranks > 1) return fail(c, OPMHIP_INVALID_ARGUMENT, "cpr: not available in decomposed runs (the reference disables accelerators there too)");
+    // Decomposed runs: every subdomain has a CPR of its own, over its owned rows and columns - the pressure hierarchy, like the
+    // block ILU0 (ParallelOverlappingILU0.hpp:439-494), leaves the couplings to ghost cells out; the Krylov method carries them.
+    // (The reference's parallel CPR coarsens ACROSS the processes with Dune's parallel AMG; this one does not.)
     if (!R.d_w && (rc = dev_alloc(c, &R.d_w, (size_t)P.Nb * BS))) return rc;
     if ((rc = dev_alloc(c, &R.d_r, (size_t)P.Nb * BS))) return rc;
     if ((rc = dev_alloc(c, &R.d_y, (size_t)P.Nb * BS))) return rc;
@@ -655,17 +661,31 @@ static int cpr_setup_structure_impl(opmhip_ctx* c) {
     R.lv.clear();
     R.lv.emplace_back();
     std::vector<int> pos;   // ELL position of every CSR entry of the level being coarsened
-    CPR_T(tUp, rc = upload_ell(c, A, R.lv[0], pos, false));
+    CPR_T(tUp, rc = upload_ell(c, A, R.lv[0], pos, false, P.Nb));
     if (rc) return rc;
+    if (P.Nghost > 0) {   // the host copy the hierarchy is built from: owned columns only (pos follows the entries that stay)
+        HCsr F;
+        std::vector<int> fpos;
+        F.n = P.Nb; F.rowptr.assign(P.Nb + 1, 0);
+        for (int i = 0; i < P.Nb; ++i) {
+            for (int k = A.rowptr[i]; k < A.rowptr[i + 1]; ++k)
+                if (A.col[k] < P.Nb) { F.col.push_back(A.col[k]); fpos.push_back(pos[k]); }
+            F.rowptr[i + 1] = (int)F.col.size();
+        }
+        F.val.resize(F.col.size());
+        A = std::move(F);
+        pos = std::move(fpos);
+    }
+    const int nnz0 = (int)A.col.size();
     if ((rc = dev_alloc(c, &R.d_pcol, (size_t)3 * R.lv[0].W * P.Nb))) return rc;     // pressure columns of the blocks, ELL, component-major
     OPMHIP_HIP(c, hipMemsetAsync(R.d_pcol, 0, (size_t)3 * R.lv[0].W * P.Nb * sizeof(double), c->stream));   // the padding stays 0
     if ((rc = cpr_weights(c))) return rc;
-    hipLaunchKernelGGL(k_cpr_pvals, g256(P.Nb), dim3(256), 0, c->stream, P.Nb, R.lv[0].W, P.d_rowptr, c->d_A, R.d_w, R.lv[0].d_val, R.d_pcol);
+    hipLaunchKernelGGL(k_cpr_pvals, g256(P.Nb), dim3(256), 0, c->stream, P.Nb, R.lv[0].W, P.d_rowptr, P.Nghost > 0 ? P.d_col : (const int*)nullptr, c->d_A, R.d_w, R.lv[0].d_val, R.d_pcol);
     {
         std::vector<double> ell((size_t)R.lv[0].W * P.Nb);
         OPMHIP_HIP(c, hipMemcpyAsync(ell.data(), R.lv[0].d_val, ell.size() * sizeof(double), hipMemcpyDeviceToHost, c->stream));
         OPMHIP_HIP(c, hipStreamSynchronize(c->stream));
-        for (int k = 0; k < P.nnzb; ++k) A.val[k] = ell[pos[k]];
+        for (int k = 0; k < nnz0; ++k) A.val[k] = ell[pos[k]];
     }
     while (true) {
         const bool last = A.n <= CPR_COARSE_DIRECT || (int)R.lv.size() >= CPR_MAX_LEVELS;
@@ -761,7 +781,7 @@ int cpr_update(opmhip_ctx* c) {
     if (!R.structured && (rc = cpr_setup_structure(c))) return rc;
     const int ps = prof_begin(c, PROF_ILU_FACTOR);
     if ((rc = cpr_weights(c))) { prof_end(c, ps); return rc; }
-    hipLaunchKernelGGL(k_cpr_pvals, g256(P.Nb), dim3(256), 0, c->stream, P.Nb, R.lv[0].W, P.d_rowptr, c->d_A, R.d_w, R.lv[0].d_val, R.d_pcol);
+    hipLaunchKernelGGL(k_cpr_pvals, g256(P.Nb), dim3(256), 0, c->stream, P.Nb, R.lv[0].W, P.d_rowptr, P.Nghost > 0 ? P.d_col : (const int*)nullptr, c->d_A, R.d_w, R.lv[0].d_val, R.d_pcol);
     for (size_t l = 0; l < R.lv.size(); ++l) {
         CprLevelDev& L = R.lv[l];
         hipLaunchKernelGGL(k_cpr_dinv, g256(L.n), dim3(256), 0, c->stream, L.n, L.d_diag, L.d_val, L.d_dinv);

@@ -302,6 +302,70 @@ int orc_cpr_solve(orc_cpr* h, int Nb, const int* rowptr, const int* col, const d
     }
     return 0;
 }
+// Decomposed runs: BiCGStab on the GLOBAL system with one CPR per subdomain (owner id per row) as preconditioner - each over its
+// owned rows and columns, the couplings between subdomains left out of the pressure hierarchy and of the block ILU0 alike, as
+// the product's per-rank CPR does; local numbering = the global order restricted to the subdomain.  weights: NULL = quasi-IMPES
+// per subdomain, else Nb x 3 (true-IMPES from the model).  levels (may be NULL): number of AMG levels of every subdomain.
+// nat (may be NULL): the system is handed over in another ordering than the natural one (the product's ILU0 ordering inside every
+// subdomain); nat[i] = natural id of row i - the finest level is then aggregated in natural visiting order, as the product does.
+int orc_cpr_solve_blocks(int Nb, const int* rowptr, const int* col, const double* val, const double* b, double* x, const int* owner, int nown,
+                         const double* weights, const int* nat, double tol, int maxit, int zero_diag_fix, int* levels, orc_result* out) {
+    Bcrs A = wrap(Nb, rowptr, col, val);
+    if (zero_diag_fix) check_zero_diagonal(A);
+    std::vector<std::vector<int>> rows(nown);
+    std::vector<int> local(Nb);
+    for (int i = 0; i < Nb; ++i) { local[i] = (int)rows[owner[i]].size(); rows[owner[i]].push_back(i); }
+    std::vector<Bcrs> sub(nown);
+    std::vector<Cpr> prec(nown);
+    for (int s = 0; s < nown; ++s) {
+        Bcrs& S = sub[s];
+        S.Nb = (int)rows[s].size();
+        S.rowptr.assign(1, 0);
+        for (int i : rows[s]) {
+            for (int k = A.rowptr[i]; k < A.rowptr[i + 1]; ++k)
+                if (owner[A.col[k]] == s) {
+                    S.col.push_back(local[A.col[k]]);
+                    S.val.insert(S.val.end(), &A.val[(size_t)k * BB], &A.val[(size_t)k * BB] + BB);
+                }
+            S.rowptr.push_back((int)S.col.size());
+        }
+        if (nat) {   // rank of every row's natural id inside the subdomain, and its inverse
+            std::vector<int> order(S.Nb);
+            for (int q = 0; q < S.Nb; ++q) order[q] = q;
+            std::sort(order.begin(), order.end(), [&](int a, int c) { return nat[rows[s][a]] < nat[rows[s][c]]; });
+            prec[s].amg.natOf.resize(S.Nb);
+            prec[s].amg.atNat = order;
+            for (int v = 0; v < S.Nb; ++v) prec[s].amg.natOf[order[v]] = v;
+        }
+        if (weights) {
+            prec[s].w_given.resize((size_t)S.Nb * BS);
+            for (int q = 0; q < S.Nb; ++q)
+                for (int k = 0; k < BS; ++k) prec[s].w_given[(size_t)q * BS + k] = weights[(size_t)rows[s][q] * BS + k];
+        }
+        const int rc = prec[s].update(S);
+        if (rc) return rc;
+        if (levels) levels[s] = (int)prec[s].amg.lv.size();
+    }
+    const size_t n = (size_t)Nb * BS;
+    auto apply = [&](const double* d, double* v) {
+        for (int s = 0; s < nown; ++s) {
+            const int m = sub[s].Nb;
+            std::vector<double> dl((size_t)m * BS), vl((size_t)m * BS);
+            for (int q = 0; q < m; ++q)
+                for (int k = 0; k < BS; ++k) dl[(size_t)q * BS + k] = d[(size_t)rows[s][q] * BS + k];
+            prec[s].apply(dl.data(), vl.data());
+            for (int q = 0; q < m; ++q)
+                for (int k = 0; k < BS; ++k) v[(size_t)rows[s][q] * BS + k] = vl[(size_t)q * BS + k];
+        }
+    };
+    auto op = [&](const double* xin, double* y) { spmv(A, xin, y); };
+    SolveResult r = bicgstab(n, b, x, apply, op, tol, maxit);
+    if (out) {
+        out->iterations = r.iterations; out->converged = r.converged; out->reduction = r.reduction; out->conv_rate = r.conv_rate;
+        out->it = r.it; out->t_factor = out->t_solve = 0; out->num_colors = nown;
+    }
+    return 0;
+}
 // v = M_cpr^-1 d with the preconditioner of the last orc_cpr_solve / orc_cpr_update
 int orc_cpr_update(orc_cpr* h, int Nb, const int* rowptr, const int* col, const double* val) {
     static thread_local Bcrs keep;   // Cpr::apply reads the matrix it was updated with

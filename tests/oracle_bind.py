@@ -46,6 +46,7 @@ class Oracle:
         L.orc_cpr_destroy.argtypes = [_vp]
         L.orc_cpr_solve.argtypes = [_vp, C.c_int, _i, _i, _d, _d, _d, C.c_double, C.c_int, C.c_int, C.POINTER(OrcResult)]
         L.orc_cpr_update.argtypes = [_vp, C.c_int, _i, _i, _d]
+        L.orc_cpr_solve_blocks.argtypes = [C.c_int, _i, _i, _d, _d, _d, _i, C.c_int, _vp, _vp, C.c_double, C.c_int, C.c_int, _vp, C.POINTER(OrcResult)]
         L.orc_cpr_apply.argtypes = [_vp, _d, _d]
         L.orc_cpr_levels.argtypes = [_vp, _i, _i, C.c_int]
         L.orc_cpr_weights.argtypes = [_vp, _d]
@@ -77,6 +78,20 @@ class Oracle:
         rpc = np.zeros(Nb, np.int32)
         nc = self.lib.orc_reorder(Nb, rowptr, col, REORDER[kind], to, fr, rpc)
         return to, fr, rpc[:nc].copy()
+
+    def cpr_solve_blocks(self, Nb, rowptr, col, val, b, owner, weights=None, natural=None, tol=1e-2, maxit=200, zero_diag_fix=True):
+        """BiCGStab on the global system, one CPR per subdomain (owner id per row) as preconditioner -> (x, result, levels per subdomain)"""
+        owner = np.ascontiguousarray(owner, np.int32)
+        nown = int(owner.max()) + 1
+        x = np.zeros(Nb * 3)
+        res = OrcResult()
+        lev = np.zeros(nown, np.int32)
+        w = None if weights is None else np.ascontiguousarray(weights, np.float64)
+        nat = None if natural is None else np.ascontiguousarray(natural, np.int32)
+        rc = self.lib.orc_cpr_solve_blocks(Nb, rowptr, col, val, np.ascontiguousarray(b, np.float64), x, owner, nown, _p(w), _p(nat), tol, maxit,
+                                           int(zero_diag_fix), _p(lev), C.byref(res))
+        assert rc == 0, rc
+        return x, res, lev
 
     def reorder_matrix(self, Nb, rowptr, col, val, to, fr):
         rr = np.empty_like(rowptr)

@@ -13,6 +13,7 @@ ap.add_argument("--world", type=int, default=8)
 ap.add_argument("--n", type=int, default=50)
 ap.add_argument("--steps", type=int, default=30)
 ap.add_argument("--reorder", default="line_coloring")
+ap.add_argument("--preconditioner", default="ilu0", choices=["ilu0", "cpr", "cpr_trueimpes", "cpr_quasiimpes"])
 a = ap.parse_args()
 pkg = importlib.import_module("opm-autodiff_amd")
 group = "ddbench%d" % os.getpid()
@@ -22,7 +23,7 @@ out, err = [None] * a.world, [None] * a.world
 def body(r):
     try:
         case = pkg.ras.cartesian_subdomain_case(a.n, a.world, r, state="mixed", heterogeneous=False)
-        m = pkg.capi.HipModel(case, comm=("loopback", a.world, r, group), reorder=a.reorder, tolerance=1e-2, maxit=200, ilu_relaxation=0.9)
+        m = pkg.capi.HipModel(case, comm=("loopback", a.world, r, group), reorder=a.reorder, tolerance=1e-2, maxit=200, ilu_relaxation=0.9, preconditioner=a.preconditioner)
         m.set_state(case["pv"], case["meaning"])
         m.set_source(case["source"])
         sim = bench.make_simulation(pkg, m)
@@ -43,7 +44,7 @@ ts = [threading.Thread(target=body, args=(r,)) for r in range(a.world)]
 if any(e is not None for e in err):
     raise SystemExit("rank failures: %r" % err)
 el, log, done, hist = out[0]
-print("world %d n %d: %d Newton iterations in %.2f s, %d time steps done" % (a.world, a.n, a.steps, el, done))
+print("world %d n %d %s: %d Newton iterations in %.2f s, %d time steps done, %d linear iterations" % (a.world, a.n, a.preconditioner, a.steps, el, done, sum(l[2] for l in log)))
 print("(step, newton, linear its):", log)
 print("time steps (days, newton its, accepted):", [(round(h[0] / bench.DAY, 3), h[1], h[2]) for h in hist])
 assert all(o[1] == log for o in out), "ranks disagree on the iteration history"
