@@ -483,7 +483,7 @@ def main():
                                "100 mD, gas cap + undersaturated oil, five-spot rate sources, adaptive time steps 1 d -> 10 d (Flow's "
                                "iteration-count control and 0.33 chop)" % (n, n, n),
                    "cells_per_gpu": Nb, "blocks_per_gpu": nnzb, "ilu_ordering": a.reorder, "linear_tol": 1e-2,
-                   "ilu_relaxation": 0.9, "parallelism": "1 GPU" if world == 1 else "RAS domain decomposition %dx%dx%d, block-Jacobi ILU0 per GPU, halos + all-reduces over RCCL" % layout},
+                   "ilu_relaxation": 0.9, "parallelism": "1 GPU" if world == 1 else "RAS domain decomposition %dx%dx%d, %s per GPU, halos + all-reduces over RCCL" % (layout + ("block-Jacobi ILU0" if a.preconditioner == "ilu0" else "one CPR (%s) per subdomain" % a.preconditioner,))},
         "linear_iterations_per_newton": W["linear_iterations_per_newton"],
         "timesteps_completed": W["timesteps_completed"], "timesteps_chopped": W["timesteps_chopped"],
         "time_steps_days": W["time_steps_days"],
