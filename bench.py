@@ -481,7 +481,7 @@ def main():
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
         "config": {"workload": "synthetic %dx%dx%d Cartesian 3-phase black-oil (BASELINE configs[1]), SPE1 fluid, homogeneous "
                                "100 mD, gas cap + undersaturated oil, five-spot rate sources, adaptive time steps 1 d -> 10 d (Flow's "
-                               "iteration-count control and 0.33 chop)" % (n, n, n),
+                               "pid+newtoniteration control and 0.33 chop)" % (n, n, n),
                    "cells_per_gpu": Nb, "blocks_per_gpu": nnzb, "ilu_ordering": a.reorder, "linear_tol": 1e-2,
                    "ilu_relaxation": 0.9, "parallelism": "1 GPU" if world == 1 else "RAS domain decomposition %dx%dx%d, %s per GPU, halos + all-reduces over RCCL" % (layout + ("block-Jacobi ILU0" if a.preconditioner == "ilu0" else "one CPR (%s) per subdomain" % a.preconditioner,))},
         "linear_iterations_per_newton": W["linear_iterations_per_newton"],
