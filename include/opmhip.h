@@ -20,7 +20,7 @@
 extern "C" {
 #endif
 
-#define OPMHIP_ABI_VERSION 5 /* 5: opmhip_set_water_compaction, opmhip_get_max_water_saturation, opmhip_relative_change (additive);
+#define OPMHIP_ABI_VERSION 5 /* 5: opmhip_set_water_compaction, opmhip_get_max_water_saturation, opmhip_relative_change, opmhip_cpr_recreate (additive);
                                * 4: opmhip_config names chain_length, spmv_pipe_wgs, preconditioner (were reserved[0..2]);
                                *    opmhip_set_endpoint_scaling, opmhip_sat_end_points, opmhip_sat_probe, opmhip_synchronize, opmhip_comm_info,
                                *    opmhip_set_composition_change_limits, opmhip_set_irreversible_compaction, opmhip_set_vappars, opmhip_begin_time_step;
@@ -197,6 +197,11 @@ int opmhip_ilu0_apply(opmhip_ctx* ctx, const double* d, double* v);
  * NULL: back to the weights the library computes itself (quasi-IMPES from the matrix, or - OPMHIP_PRECOND_CPR_TRUEIMPES, contexts that
  * assemble - true-IMPES from the storage term of the present state with the dt of the last opmhip_assemble). */
 int opmhip_set_cpr_weights(opmhip_ctx* ctx, const double* weights);
+/* replaces: the decision ISTLSolverEbos::shouldCreateSolver takes (linalg/ISTLSolverEbos.hpp:401-426) where the host takes it:
+ * the next solve builds the CPR hierarchy's structure anew from the matrix it is given, whatever opmhip_config.cpr_reuse_setup
+ * says.  (Contexts that assemble decide modes 0 - 2 themselves; a host that only hands matrices over - the BdaSolver plug-in -
+ * knows the Newton iteration number, the library does not.) */
+int opmhip_cpr_recreate(opmhip_ctx* ctx);
 /* the weights of the last CPR set-up (3 per block row, natural order): diagnosis and tests */
 int opmhip_get_cpr_weights(opmhip_ctx* ctx, double* weights);
 

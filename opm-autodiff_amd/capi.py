@@ -107,6 +107,7 @@ def lib():
         L.opmhip_ilu0_factor.argtypes = [vp, dp]
         L.opmhip_ilu0_apply.argtypes = [vp, dp, dp]
         L.opmhip_cpr_apply.argtypes = [vp, dp, dp]
+        L.opmhip_cpr_recreate.argtypes = [vp]
         L.opmhip_set_cpr_weights.argtypes = [vp, dp]
         L.opmhip_get_cpr_weights.argtypes = [vp, dp]
         L.opmhip_get_ordering.argtypes = [vp, ip, ip, ip]
@@ -260,6 +261,10 @@ class HipSolver:
         w = np.empty(3 * self.Nb)
         self._check(lib().opmhip_get_cpr_weights(self._h, _ptr(w)))
         return w.reshape(-1, 3)
+
+    def cpr_recreate(self):
+        """the next solve builds the CPR hierarchy's structure anew (the host's ISTLSolverEbos::shouldCreateSolver said so)"""
+        self._check(lib().opmhip_cpr_recreate(self._h))
 
     def cpr_apply(self, d):
         d = _f64(d)

@@ -487,6 +487,15 @@ int opmhip_set_cpr_weights(opmhip_ctx* c, const double* weights) {
     });
 }
 
+int opmhip_cpr_recreate(opmhip_ctx* c) {
+    if (!c) return OPMHIP_INVALID_ARGUMENT;
+    return guarded(c, [&]() -> int {
+        if (!use_cpr(c)) return fail(c, OPMHIP_NOT_READY, "cpr_recreate: the context was not created with the CPR preconditioner");
+        c->cpr.recreate = true;
+        return OPMHIP_SUCCESS;
+    });
+}
+
 int opmhip_get_cpr_weights(opmhip_ctx* c, double* weights) {
     if (!c) return OPMHIP_INVALID_ARGUMENT;
     return guarded(c, [&]() -> int {

@@ -775,9 +775,10 @@ int cpr_update(opmhip_ctx* c) {
     int rc;
     if (R.structured) {   // --cpr-reuse-setup (ISTLSolverEbos.hpp:401-426 shouldCreateSolver): build the structure anew from this matrix?
         const int mode = c->cfg.cpr_reuse_setup;
-        const bool anew = mode == 0 || (mode == 1 && c->asmb.assembled && c->asmb.last_iteration == 0) || (mode == 2 && c->last_solve_iterations > 10);
+        const bool anew = R.recreate || mode == 0 || (mode == 1 && c->asmb.assembled && c->asmb.last_iteration == 0) || (mode == 2 && c->last_solve_iterations > 10);
         if (anew) cpr_release_structure(c);
     }
+    R.recreate = false;
     if (!R.structured && (rc = cpr_setup_structure(c))) return rc;
     const int ps = prof_begin(c, PROF_ILU_FACTOR);
     if ((rc = cpr_weights(c))) { prof_end(c, ps); return rc; }

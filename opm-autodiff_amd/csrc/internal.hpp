@@ -179,6 +179,7 @@ struct CprLevelDev {
 };
 struct CprDev {
     bool structured = false, coarse_direct = true;
+    bool recreate = false;                                         // opmhip_cpr_recreate: the next cpr_update builds the structure anew
     std::vector<CprLevelDev> lv;
     double *d_w = nullptr, *d_lu = nullptr;
     double* d_pcol = nullptr;                                      // level 0: the pressure column of every block, ELL, component-major [3][W x Nb]

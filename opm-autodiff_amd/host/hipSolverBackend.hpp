@@ -42,7 +42,7 @@ public:
     /// ISTLSolverEbos::getTrueImpesWeights (ISTLSolverEbos.hpp:466-475) to setCprWeights() before each solve.
     hipSolverBackend(int linear_solver_verbosity, int maxit_, double tolerance_, unsigned int deviceID_,
                      const std::string& ilu_reorder = "graph_coloring", double ilu_relaxation = 0.9,
-                     const std::string& linsolver = "ilu0")
+                     const std::string& linsolver = "ilu0", int cpr_reuse_setup = 3)
         : Base(linear_solver_verbosity, maxit_, tolerance_, deviceID_) {
         static_assert(block_size == 3, "libopmhip handles 3x3 blocks (three-phase black-oil)");
         opmhip_config cfg;
@@ -59,6 +59,9 @@ public:
         if (linsolver == "cpr_quasiimpes") cfg.preconditioner = OPMHIP_PRECOND_CPR_QUASIIMPES;
         else if (linsolver == "cpr" || linsolver == "cpr_trueimpes") cfg.preconditioner = OPMHIP_PRECOND_CPR_TRUEIMPES;
         else if (linsolver != "ilu0") throw std::invalid_argument(linsolver + " is not a valid setting for --linear-solver-configuration with --accelerator-mode=hip. Please use ilu0, cpr, cpr_trueimpes, or cpr_quasiimpes");
+        // --cpr-reuse-setup (FlowLinearSolverParameters.hpp:212-214).  The library acts on 0 (every solve) and 2 (after a solve of
+        // more than 10 iterations) by itself; 1 (first Newton iteration of a time step) is the caller's to signal: recreateCprHierarchy()
+        cfg.cpr_reuse_setup = cpr_reuse_setup;
         const int rc = opmhip_create(&cfg, &ctx);
         if (rc != OPMHIP_SUCCESS) throw std::logic_error(std::string("hipSolverBackend: ") + opmhip_last_error(nullptr));
     }
@@ -66,6 +69,10 @@ public:
     /// weights of the CPR preconditioner (3 per block row), e.g. Amg::getTrueImpesWeights; nullptr: computed by the library
     void setCprWeights(const double* weights) {
         if (opmhip_set_cpr_weights(ctx, weights) != OPMHIP_SUCCESS) throw std::logic_error(std::string("hipSolverBackend: ") + opmhip_last_error(ctx));
+    }
+    /// ISTLSolverEbos::shouldCreateSolver said yes (ISTLSolverEbos.hpp:401-426): the next solve_system builds the hierarchy anew
+    void recreateCprHierarchy() {
+        if (opmhip_cpr_recreate(ctx) != OPMHIP_SUCCESS) throw std::logic_error(std::string("hipSolverBackend: ") + opmhip_last_error(ctx));
     }
     hipSolverBackend(const hipSolverBackend&) = delete;
     hipSolverBackend& operator=(const hipSolverBackend&) = delete;

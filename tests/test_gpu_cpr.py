@@ -218,7 +218,7 @@ def test_coarsening_stops_where_rows_outgrow_the_level_image(pkg, orc):
     assert r.converged
 
 
-@pytest.mark.parametrize("mode", [0, 2, 3])
+@pytest.mark.parametrize("mode", [0, 2, 3, "host"])
 def test_cpr_reuse_setup_modes(pkg, orc, mode):
     """--cpr-reuse-setup (ISTLSolverEbos.hpp:401-426): 3 keeps the hierarchy's structure of the first matrix, 0 builds it anew
     for every solve, 2 after a solve that took more than 10 iterations.  Whatever the mode decides, the preconditioner the
@@ -226,13 +226,17 @@ def test_cpr_reuse_setup_modes(pkg, orc, mode):
     case, jac1, res1 = jacobian_case(pkg, orc, its=1)
     _, jac2, res2 = jacobian_case(pkg, orc, dt_days=40.0, its=3)           # a different state: other strong couplings
     Nb, rp, ci = case["Nb"], case["rowptr"], case["col"]
-    s = pkg.capi.HipSolver(reorder="line_coloring", preconditioner="cpr_quasiimpes", tolerance=1e-10 if mode == 2 else 1e-2, maxit=100, cpr_reuse_setup=mode)
+    host = mode == "host"       # mode 3 in the library, the host says when (opmhip_cpr_recreate: what the BdaSolver plug-in does for mode 1)
+    s = pkg.capi.HipSolver(reorder="line_coloring", preconditioner="cpr_quasiimpes", tolerance=1e-10 if mode == 2 else 1e-2, maxit=100,
+                           cpr_reuse_setup=3 if host else mode)
     r1 = s.solve_system(Nb, rp, ci, jac1.copy(), res1)
     assert r1.converged and (mode != 2 or r1.iterations > 10)              # mode 2: the tight tolerance makes the first solve a long one
     lv1 = s.cpr_levels()
+    if host:
+        s.cpr_recreate()
     r2 = s.solve_system(Nb, rp, ci, jac2.copy(), res2)
     assert r2.converged
-    anew = mode in (0, 2)
+    anew = mode in (0, 2, "host")
     to, fr, rr1, rc1, rv1 = reordered(orc, s, Nb, rp, ci, jac1)
     _, _, rr2, rc2, rv2 = reordered(orc, s, Nb, rp, ci, jac2)
     cpr = oracle_bind.OracleCpr(orc)
