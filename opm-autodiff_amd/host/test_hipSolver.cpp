@@ -2,7 +2,8 @@
 // (MatrixMarket, ISTL_STRUCT blocked 3 3), run bda::hipSolverBackend<3>::solve_system + get_result with tol / maxit
 // from the command line, print the solution.  The expected vector is checked by the calling pytest
 // (tests/test_gpu_host_cpp.py) against the fixture in tests/golden/linalg/expected.json.
-//   usage: test_hipSolver matr33.txt rhs3.txt tol maxit reorder [wells]
+//   usage: test_hipSolver matr33.txt rhs3.txt tol maxit reorder [wells|-] [linsolver]     (linsolver: ilu0 | cpr | cpr_trueimpes | cpr_quasiimpes;
+//   a CPR run solves twice, the second time behind recreateCprHierarchy(): the --cpr-reuse-setup=1 path of the plug-in)
 #include <cstdio>
 #include <cstdlib>
 #include <fstream>
@@ -61,7 +62,8 @@ int main(int argc, char** argv) {
     const int maxit = std::atoi(argv[4]);
     std::unique_ptr<bda::hipSolverBackend<3>> backend;
     try {
-        backend.reset(new bda::hipSolverBackend<3>(/*verbosity=*/0, maxit, tolerance, /*deviceID=*/0, argv[5], /*w=*/1.0));
+        backend.reset(new bda::hipSolverBackend<3>(/*verbosity=*/0, maxit, tolerance, /*deviceID=*/0, argv[5], /*w=*/1.0, argc > 7 ? argv[7] : "ilu0",
+                                                   /*cpr_reuse_setup=*/argc > 7 ? 1 : 3));
     } catch (const std::logic_error& error) {
         std::fprintf(stderr, "Problem with initializing a device: %s\n", error.what());  // the reference skips here
         return 77;
@@ -86,6 +88,11 @@ int main(int argc, char** argv) {
     std::vector<double> x(rhs.size());
     const bda::SolverStatus st = backend->solve_system(3 * Nb, 9 * (int)cols.size(), 3, vals.data(), rows.data(), cols.data(), rhs.data(), wellContribs, result);
     if (st != bda::SolverStatus::BDA_SOLVER_SUCCESS) return 3;
+    if (argc > 7 && std::string(argv[7]) != "ilu0") {   // the first Newton iteration of the next time step: hierarchy anew, same answer
+        std::vector<double> v2(vals), b2(rhs);
+        backend->recreateCprHierarchy();
+        if (backend->solve_system(3 * Nb, 9 * (int)cols.size(), 3, v2.data(), rows.data(), cols.data(), b2.data(), wellContribs, result) != bda::SolverStatus::BDA_SOLVER_SUCCESS) return 3;
+    }
     backend->get_result(x.data());
     std::printf("converged %d iterations %d reduction %.17g\n", (int)result.converged, result.iterations, result.reduction);
     for (double v : x) std::printf("%.17g\n", v);

@@ -43,6 +43,23 @@ def test_hipSolverBackend_matr33(golden, reorder):
     assert np.linalg.norm(A @ x - b) < 0.5 * np.linalg.norm(b)
 
 
+def test_hipSolverBackend_cpr_through_the_plugin_class(golden):
+    """--linear-solver-configuration=cpr_quasiimpes through bda::hipSolverBackend<3> (both builds), the reference's CPR vector
+    (tests/test_flexiblesolver.cpp:93-116 with options_flexiblesolver.json: tol 0.5 on matr33), solved twice - the second
+    time behind recreateCprHierarchy(), the plug-in's --cpr-reuse-setup=1 path"""
+    args = [os.path.join(golden, "linalg", "matr33.txt"), os.path.join(golden, "linalg", "rhs3.txt"), "0.5", "20", "level_scheduling", "-", "cpr_quasiimpes"]
+    with open(os.path.join(golden, "linalg", "expected.json")) as f:
+        e = json.load(f)["exact_noprec_tol1e-12_maxit200"]
+    for exe in ("test_hipSolver", "test_hipSolver_opmhdr"):
+        out = subprocess.run([_exe(exe)] + args, capture_output=True, text=True)
+        assert out.returncode == 0, out.stderr
+        lines = out.stdout.strip().splitlines()
+        assert lines[0].startswith("converged 1")
+        np.testing.assert_allclose(np.array([float(v) for v in lines[1:]]), e["x"], rtol=2e-5)
+    bad = subprocess.run([_exe("test_hipSolver")] + args[:6] + ["amg"], capture_output=True, text=True)
+    assert bad.returncode != 0 and "not a valid setting" in (bad.stderr + bad.stdout)
+
+
 def test_hipSolverBackend_built_the_way_opm_simulators_builds_it(pkg, golden):
     """The OPMHIP_USE_OPM_HEADERS branch of hipSolverBackend.hpp - reference include paths, WellContributions reached through
     the getHostArrays accessor of INTEGRATION.md - gives the same bits as the stand-alone build, with a standard well, and
