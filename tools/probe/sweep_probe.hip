@@ -4,6 +4,9 @@
 // buy anything?  Development probe (not product code); numbers in DESIGN.md section 4.
 //   reg1   : what csrc/solver.hip's chain_sweep does - step s+1 into registers while step s is consumed out of LDS
 //   dma<N> : N LDS buffers per wavefront, steps s+1 .. s+N-1 in flight by LDS-DMA while step s is consumed
+//   "+ both, coherent": what ONE launch for all colours of an ILU0 application would have to do instead of three (review item 3 of
+//            round 2): the gathered vector entries were written by other workgroups of the same launch, so they are read with
+//            agent-scope (sc1) loads and written with sc1 stores, and every workgroup polls one flag word per step first
 #include <hip/hip_runtime.h>
 #include <cstdio>
 #include <cstdlib>
@@ -86,7 +89,11 @@ __global__ __launch_bounds__(64) void sweep_reg1_small(int nsteps, int nrows, co
 #pragma unroll
         for (int u = 0; u <= NCOL; ++u) {
             const size_t c = (size_t)colv[u] * 3;
-            if (MODE == 0) { g[u][0] = vec[c]; g[u][1] = vec[c + 1]; g[u][2] = vec[c + 2]; }
+            if (FLAGS & 4) {
+                g[u][0] = __hip_atomic_load(vec + c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                g[u][1] = __hip_atomic_load(vec + c + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                g[u][2] = __hip_atomic_load(vec + c + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            } else if (MODE == 0) { g[u][0] = vec[c]; g[u][1] = vec[c + 1]; g[u][2] = vec[c + 2]; }
             else {
                 double2 a; double b;
                 __builtin_memcpy(&a, vec + c, 16); b = vec[c + 2];
@@ -103,6 +110,9 @@ __global__ __launch_bounds__(64) void sweep_reg1_small(int nsteps, int nrows, co
             D[8] = dinv[d + 8];
         }
     };
+    if (FLAGS & 8) {   // a dependency flag of another workgroup, already set: the price of looking, not of waiting
+        while (__hip_atomic_load(idx + (blockIdx.x * 13) % nrows, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) {}
+    }
     small(0);
     for (int s = 0; s < nsteps; ++s) {
 #pragma unroll
@@ -125,8 +135,15 @@ __global__ __launch_bounds__(64) void sweep_reg1_small(int nsteps, int nrows, co
         carry = consume(reinterpret_cast<const double*>(img), lane, carry) + acc;
         if ((FLAGS & 2) && lane < 32) {   // the step's results: two vectors of 3 doubles per row
             const size_t o = (size_t)(((blockIdx.x * nsteps + s) * 32 + lane) % nrows) * 3;
-            outv[o] = carry; outv[o + 1] = carry; outv[o + 2] = carry;
-            outv[(size_t)nrows * 3 + o] = acc; outv[(size_t)nrows * 3 + o + 1] = acc; outv[(size_t)nrows * 3 + o + 2] = acc;
+            if (FLAGS & 4) {
+                for (int q = 0; q < 3; ++q) {
+                    __hip_atomic_store(outv + o + q, carry, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    __hip_atomic_store(outv + (size_t)nrows * 3 + o + q, acc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                }
+            } else {
+                outv[o] = carry; outv[o + 1] = carry; outv[o + 2] = carry;
+                outv[(size_t)nrows * 3 + o] = acc; outv[(size_t)nrows * 3 + o + 1] = acc; outv[(size_t)nrows * 3 + o + 2] = acc;
+            }
         }
         asm volatile("" ::: "memory");
     }
@@ -199,7 +216,7 @@ int main(int argc, char** argv) {
         float ms = 0;
         CK(hipEventElapsedTime(&ms, e0, e1));
         const double bytes = (double)nct * nsteps * STEP2 * 16.0;
-        printf("%-14s %5d workgroups  %8.1f us  %7.1f GB/s\n", name, nct, 1e3 * ms / reps, bytes * reps / (ms * 1e6));
+        printf("%-20s %5d workgroups  %8.1f us  %7.1f GB/s\n", name, nct, 1e3 * ms / reps, bytes * reps / (ms * 1e6));
     };
     for (int nct : ncts) {
         run("reg1", nct, [&](const double2* p) { hipLaunchKernelGGL(sweep_reg1, dim3(nct), dim3(64), 0, 0, nsteps, p, sink); });
@@ -208,6 +225,12 @@ int main(int argc, char** argv) {
         run("  + indices", nct, [&](const double2* p) { hipLaunchKernelGGL((sweep_reg1_small<5, 0, 1>), dim3(nct), dim3(64), 0, 0, nsteps, nrows, p, vec, dinv, sink, idx, outv); });
         run("  + stores", nct, [&](const double2* p) { hipLaunchKernelGGL((sweep_reg1_small<5, 0, 2>), dim3(nct), dim3(64), 0, 0, nsteps, nrows, p, vec, dinv, sink, idx, outv); });
         run("  + both", nct, [&](const double2* p) { hipLaunchKernelGGL((sweep_reg1_small<5, 0, 3>), dim3(nct), dim3(64), 0, 0, nsteps, nrows, p, vec, dinv, sink, idx, outv); });
+        run("  + both, coherent", nct, [&](const double2* p) { hipLaunchKernelGGL((sweep_reg1_small<5, 0, 3 | 4>), dim3(nct), dim3(64), 0, 0, nsteps, nrows, p, vec, dinv, sink, idx, outv); });
+        run("  + both, coh.+flag", nct, [&](const double2* p) { hipLaunchKernelGGL((sweep_reg1_small<5, 0, 3 | 4 | 8>), dim3(nct), dim3(64), 0, 0, nsteps, nrows, p, vec, dinv, sink, idx, outv); });
+        // three launches of a third of the work each against one launch of all of it: what the launch boundaries cost in this shape
+        if (nct == 1953) {
+            run("3 x (651) + both", nct, [&](const double2* p) { for (int q = 0; q < 3; ++q) hipLaunchKernelGGL((sweep_reg1_small<5, 0, 3>), dim3(651), dim3(64), 0, 0, nsteps, nrows, p + (size_t)q * 651 * nsteps * STEP2, vec, dinv, sink, idx, outv); });
+        }
         run("dma<2>", nct, [&](const double2* p) { hipLaunchKernelGGL((sweep_dma<2, 0>), dim3(nct), dim3(64), 0, 0, nsteps, p, sink); });
         run("dma<2> nt", nct, [&](const double2* p) { hipLaunchKernelGGL((sweep_dma<2, 2>), dim3(nct), dim3(64), 0, 0, nsteps, p, sink); });
         run("dma<3> nt", nct, [&](const double2* p) { hipLaunchKernelGGL((sweep_dma<3, 2>), dim3(nct), dim3(64), 0, 0, nsteps, p, sink); });
