@@ -80,6 +80,10 @@ struct Pattern {
     int *d_lrowptr = nullptr, *d_lcol = nullptr, *d_urowptr = nullptr, *d_ucol = nullptr;
     std::vector<int> fdest;      // per matrix entry: where the factorisation puts it - L index (>= 0), -2 - U index, -1 (diagonal / dropped ghost column)
     int* d_fdest = nullptr;
+    // per L entry (i, j) what its elimination step touches: the ONE entry of row i that meets the U part of row j (a 7-point grid has no
+    // triangles: it is the diagonal) as U index * 64 + offset of the target in row i; -1: none; -2: several (the general search)
+    std::vector<int> lmatch;
+    int* d_lmatch = nullptr;
 };
 
 struct WellsDev {

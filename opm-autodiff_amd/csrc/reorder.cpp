@@ -463,6 +463,27 @@ int build_pattern(opmhip_ctx* c, int Nb, int Nghost, int nnzb, const int* rows, 
     }
     P.nl = (int)P.lcol.size();
     P.nu = (int)P.ucol.size();
+    // symbolic elimination: which entries of row p the step against row j updates (k_ilu_factor looks them up instead of merging two
+    // column lists per L entry - three dependent rounds of loads became one)
+    P.lmatch.assign(P.nnzb, -2);
+    static const bool general = [] { const char* e = std::getenv("OPMHIP_FACTOR_GENERAL"); return e && e[0] == '1'; }();   // A/B switch: every step by the general search
+    for (int p = 0; p < Nb && !general; ++p) {
+        const int kb = P.rowptr[p], ke = P.rowptr[p + 1];
+        for (int k = kb; k < ke; ++k) {
+            const int j = P.col[k];
+            if (j >= p) break;
+            int count = 0, uidx = -1, target = -1;
+            int ik = k + 1, jk = P.urowptr[j];
+            const int jend = P.urowptr[j + 1];
+            while (ik < ke && jk < jend) {
+                if (P.col[ik] == P.ucol[jk]) { if (count++ == 0) { uidx = jk; target = ik - kb; } ++ik; ++jk; }
+                else if (P.col[ik] < P.ucol[jk]) ++ik;
+                else ++jk;
+            }
+            if (count == 0) P.lmatch[k] = -1;
+            else if (count == 1 && target < 64 && uidx < (1 << 25)) P.lmatch[k] = uidx * 64 + target;
+        }
+    }
     P.lightL.assign(ncol, 0);
     P.lightU.assign(ncol, 0);
     if (chained) {
@@ -536,6 +557,7 @@ int build_pattern(opmhip_ctx* c, int Nb, int Nghost, int nnzb, const int* rows, 
     if ((rc = dev_upload(c, &P.d_urowptr, P.urowptr))) return rc;
     if ((rc = dev_upload(c, &P.d_ucol, P.ucol))) return rc;
     if ((rc = dev_upload(c, &P.d_fdest, P.fdest))) return rc;
+    if ((rc = dev_upload(c, &P.d_lmatch, P.lmatch))) return rc;
     if ((rc = dev_upload(c, &P.tiles.d_row0, P.tiles.row0))) return rc;
     if ((rc = dev_upload(c, &P.tiles.d_ctFirst, P.tiles.ctFirst))) return rc;
     return OPMHIP_SUCCESS;

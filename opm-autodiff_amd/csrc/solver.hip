@@ -1048,19 +1048,19 @@ __global__ __launch_bounds__(64) void k_ilu_sweep_chain_LU(const int* __restrict
 __global__ __launch_bounds__(64) void k_ilu_factor(int ct_begin, const int* __restrict__ ct_first, const int* __restrict__ tile_row0,
                                                    const int* __restrict__ rowptr, const int* __restrict__ col,
                                                    const int* __restrict__ diag, const double* __restrict__ A,
-                                                   const int* __restrict__ fdest, const int* __restrict__ urowptr,
+                                                   const int* __restrict__ fdest, const int* __restrict__ lmatch, const int* __restrict__ urowptr,
                                                    const int* __restrict__ ucol, double* L, double* U, double* invD) {
     TILE_LDS
     const int lane = threadIdx.x;
     const int q0 = ct_first[ct_begin + blockIdx.x], q1 = ct_first[ct_begin + blockIdx.x + 1];
     constexpr int FU = 8;  // U-row columns of a neighbour fetched in one batch (longer rows: the merge below)
-    __shared__ int scol[TILE_CAP_BLOCKS + 2], sdest[TILE_CAP_BLOCKS + 2];
+    __shared__ int scol[TILE_CAP_BLOCKS + 2], sdest[TILE_CAP_BLOCKS + 2], slm[TILE_CAP_BLOCKS + 2];
     for (int t = q0; t < q1; ++t) {  // steps of a chain-tile in order (a single step unless the ordering is line-coloured)
         const TileCtx T = tile_stage_values(t, tile_row0, rowptr, A, sval, lane);
         // the tile's column indices next to its values: the elimination searches them many times
         if (T.staged) {
             const int kk0 = rowptr[T.r0], kk1 = rowptr[T.r1];
-            for (int q = kk0 + lane; q < kk1; q += 64) { scol[q - T.k0e] = col[q]; sdest[q - T.k0e] = fdest[q]; }
+            for (int q = kk0 + lane; q < kk1; q += 64) { scol[q - T.k0e] = col[q]; sdest[q - T.k0e] = fdest[q]; slm[q - T.k0e] = lmatch[q]; }
             if (kk0 > T.k0e && lane == 0) sdest[0] = -1;   // the alignment block in front of the tile belongs to the previous row
         }
         wave_sync();
@@ -1070,9 +1070,31 @@ __global__ __launch_bounds__(64) void k_ilu_factor(int ct_begin, const int* __re
             // an over-long row (not staged) cannot be eliminated in LDS: such rows are rejected at set_pattern time
             double* row = &sval[(kb - T.k0e) * BB];
             const int* rcol = &scol[kb - T.k0e];
+            const int* rlm = &slm[kb - T.k0e];
             const int n = ke - kb, nd = kd - kb;
             for (int a = 0; a < nd; ++a) {
                 const int j = rcol[a];
+                const int lm = rlm[a];
+                if (lm != -2) {
+                    // the step's one update is known (Pattern::lmatch): D_j^-1 and the U block it needs come in ONE round of loads
+                    // (no extent of row j's U part, no column list, no search) - the same products, the same subtraction
+                    const bool has = lm >= 0;
+                    const size_t ub = has ? (size_t)(lm >> 6) * BB : 0;
+                    double Lij[BB], Dj[BB], tmp[BB], Ujk[BB];
+#pragma unroll
+                    for (int q = 0; q < BB; ++q) { tmp[q] = row[a * BB + q]; Dj[q] = invD[(size_t)j * BB + q]; Ujk[q] = U[ub + q]; }
+                    blk_mul(tmp, Dj, Lij);  // A_ij * A_jj^-1
+#pragma unroll
+                    for (int q = 0; q < BB; ++q) row[a * BB + q] = Lij[q];
+                    if (has) {
+                        double Pm[BB];
+                        blk_mul(Lij, Ujk, Pm);  // L_ij * A_jk
+                        double* tgt = &row[(lm & 63) * BB];
+#pragma unroll
+                        for (int q = 0; q < BB; ++q) tgt[q] -= Pm[q];
+                    }
+                    continue;
+                }
                 double Lij[BB], Dj[BB], tmp[BB];
                 // one round of loads: D_j^-1, the extent of row j's U part and (next) its first FU column indices -
                 // instead of walking them one dependent load at a time
@@ -1696,7 +1718,7 @@ void launch_ilu_factor(opmhip_ctx* c) {
         const int cb = P.tiles.colorCT[col], ce = P.tiles.colorCT[col + 1];
         if (ce > cb)
             hipLaunchKernelGGL(k_ilu_factor, dim3(ce - cb), dim3(64), 0, c->stream, cb, P.tiles.d_ctFirst, P.tiles.d_row0, P.d_rowptr, P.d_col,
-                               P.d_diag, c->d_A, P.d_fdest, P.d_urowptr, P.d_ucol, c->d_L, c->d_U, c->d_invD);
+                               P.d_diag, c->d_A, P.d_fdest, P.d_lmatch, P.d_urowptr, P.d_ucol, c->d_L, c->d_U, c->d_invD);
     }
     prof_end(c, ps);
 }
