@@ -1072,7 +1072,46 @@ __global__ __launch_bounds__(64) void k_ilu_factor(int ct_begin, const int* __re
             const int* rcol = &scol[kb - T.k0e];
             const int* rlm = &slm[kb - T.k0e];
             const int n = ke - kb, nd = kd - kb;
-            for (int a = 0; a < nd; ++a) {
+            bool allfast = true;
+            for (int a = 0; a < nd; ++a) allfast = allfast && rlm[a] != -2;
+            // Every step of this row is a looked-up one (the rule on grids without triangles): the loads of step a + 1 - its D_j^-1
+            // and its U block, addresses known from LDS - are issued before step a is worked off, two register sets taking turns.
+            // The steps themselves stay in order: a step's L block may have been touched by an earlier one.
+#define OPMHIP_FACTOR_LOAD(D_, U_, a_)                                                                  \
+    do {                                                                                                \
+        const int j_ = rcol[a_], lm_ = rlm[a_];                                                         \
+        const size_t ub_ = lm_ >= 0 ? (size_t)(lm_ >> 6) * BB : 0;                                     \
+        _Pragma("unroll") for (int q = 0; q < BB; ++q) { D_[q] = invD[(size_t)j_ * BB + q]; U_[q] = U[ub_ + q]; } \
+    } while (0)
+#define OPMHIP_FACTOR_STEP(D_, U_, a_)                                                                  \
+    do {                                                                                                \
+        const int lm_ = rlm[a_];                                                                        \
+        double tmp_[BB], Lij_[BB];                                                                      \
+        _Pragma("unroll") for (int q = 0; q < BB; ++q) tmp_[q] = row[(a_) * BB + q];                    \
+        blk_mul(tmp_, D_, Lij_);                                                                        \
+        _Pragma("unroll") for (int q = 0; q < BB; ++q) row[(a_) * BB + q] = Lij_[q];                    \
+        if (lm_ >= 0) {                                                                                 \
+            double Pm_[BB];                                                                             \
+            blk_mul(Lij_, U_, Pm_);                                                                     \
+            double* tgt_ = &row[(lm_ & 63) * BB];                                                       \
+            _Pragma("unroll") for (int q = 0; q < BB; ++q) tgt_[q] -= Pm_[q];                           \
+        }                                                                                               \
+    } while (0)
+            if (allfast && nd > 0) {
+                double D0[BB], U0[BB], D1[BB], U1[BB];
+                OPMHIP_FACTOR_LOAD(D0, U0, 0);
+                for (int a = 0; a < nd; a += 2) {
+                    if (a + 1 < nd) OPMHIP_FACTOR_LOAD(D1, U1, a + 1);
+                    OPMHIP_FACTOR_STEP(D0, U0, a);
+                    if (a + 1 < nd) {
+                        if (a + 2 < nd) OPMHIP_FACTOR_LOAD(D0, U0, a + 2);
+                        OPMHIP_FACTOR_STEP(D1, U1, a + 1);
+                    }
+                }
+            }
+#undef OPMHIP_FACTOR_LOAD
+#undef OPMHIP_FACTOR_STEP
+            for (int a = allfast ? nd : 0; a < nd; ++a) {
                 const int j = rcol[a];
                 const int lm = rlm[a];
                 if (lm != -2) {
