@@ -1,5 +1,6 @@
 // C-ABI of libopmhip.so (include/opmhip.h): argument checking, device memory, call ordering.  No exceptions
 // cross this file's boundary: every entry point is wrapped and maps failures to opmhip_status codes.
+#include <cstdlib>
 #include <chrono>
 #include <unordered_map>
 #include <algorithm>
@@ -275,11 +276,13 @@ int opmhip_solve_system(opmhip_ctx* c, int N, int nnz, int dim, double* vals, co
         if (!vals && !c->system_loaded) return fail(c, OPMHIP_NOT_READY, "solve_system: vals == NULL but no matrix is resident on the device");
         int rc;
         if ((rc = upload_system(c, vals, b))) return rc;
-        if (!vals && c->cfg.zero_diag_fix) launch_zero_diag_fix(c);  // device-assembled Jacobian: same fix-up
+        static const bool zfixSeparate = [] { const char* e = std::getenv("OPMHIP_ZFIX_SEPARATE"); return e && e[0] == '1'; }();   // A/B switch
+        const bool zfix = !vals && c->cfg.zero_diag_fix;   // device-assembled Jacobian: the same fix-up as the uploaded one gets
+        if (zfix && zfixSeparate) launch_zero_diag_fix(c);
         if ((rc = upload_wells(c, wells))) return rc;
         OPMHIP_HIP(c, hipStreamSynchronize(c->stream));
         const double t1 = now();
-        launch_ilu_factor(c);
+        launch_ilu_factor(c, zfix && !zfixSeparate);  // ... applied as the rows are staged
         OPMHIP_HIP(c, hipGetLastError());
         OPMHIP_HIP(c, hipStreamSynchronize(c->stream));
         c->factored = true;

@@ -392,7 +392,7 @@ int launch_spmv(opmhip_ctx* c, double* x, double* y, int ndot, const double* w0,
 void launch_wells_residual(opmhip_ctx* c, const double* d_resWell, double* r);
 void launch_wells_add_to_matrix(opmhip_ctx* c, int w0, int nw, int serial, const int* d_pair_ptr, const int* d_entry);
 void launch_wells_recover(opmhip_ctx* c, const double* d_resWell, const double* x, double* d_xw);
-void launch_ilu_factor(opmhip_ctx* c);
+void launch_ilu_factor(opmhip_ctx* c, bool fix_zero_diagonal = false);
 void launch_ilu_apply(opmhip_ctx* c, const double* d, double* v, double w_override = -1.0, double* unscaled = nullptr, const double* addp = nullptr, double* work = nullptr);
 // cpr.hip
 int cpr_update(opmhip_ctx* c);

@@ -190,6 +190,42 @@ def test_newton_iterations_match_oracle(pkg, orc, reorder):
     np.testing.assert_allclose(pm, po, rtol=1e-7, atol=1e-9)
 
 
+@pytest.mark.parametrize("reorder", ["line_coloring", "graph_coloring"])
+def test_zero_diagonal_fix_of_the_device_assembled_jacobian(pkg, orc, reorder):
+    """bda/BdaBridge.cpp:125-161 on the device-resident path: a cell without pore volume and without open faces assembles an
+    all-zero diagonal block; the factorisation kernel puts 1e-15 on its diagonal as it stages the row - in the factors and
+    in the matrix the operator reads - and the solve is the oracle's (same fix, same ordering)"""
+    case = pkg.decks.cartesian_case(6, 5, 4, state="mixed", heterogeneous=True)
+    cut = 37
+    rp, ci = np.asarray(case["rowptr"]), np.asarray(case["col"])
+    case["poro"] = np.asarray(case["poro"], float).copy()
+    case["poro"][cut] = 0.0
+    tr = np.asarray(case["trans"], float).copy()
+    tr[rp[cut]:rp[cut + 1]] = 0.0
+    tr[ci == cut] = 0.0
+    case["trans"] = tr
+    src = pkg.decks.five_spot_source(case, rate_sm3_per_day=50.0)
+    src.reshape(-1, 3)[cut] = 0.0
+    m, o = both(pkg, orc, case, reorder=reorder)
+    m.set_source(src)
+    o.set_source(src)
+    dt = 86400.0
+    jm, rm = m.assemble(dt, 0)
+    jo, ro = o.assemble(dt, 0)
+    assert np.array_equal(jm, jo) and np.array_equal(rm, ro)
+    kd = [k for k in range(rp[cut], rp[cut + 1]) if ci[k] == cut][0]
+    assert np.all(jm.reshape(-1, 9)[kd] == 0.0) and np.all(rm.reshape(-1, 3)[cut] == 0.0)
+    sm = m.solve_jacobian_system()
+    xo, so = o.solve_in_order(*m.ordering()[:2])
+    assert sm.converged and so.converged and sm.it == so.it
+    x = m.get_result()
+    assert np.all(np.isfinite(x)) and np.all(x.reshape(-1, 3)[cut] == 0.0)
+    np.testing.assert_allclose(x, xo, rtol=1e-8, atol=1e-12 * np.abs(xo).max())
+    e = np.zeros(3 * case["Nb"])
+    e[3 * cut:3 * cut + 3] = 1.0
+    assert np.array_equal(m.spmv(e).reshape(-1, 3)[cut], np.full(3, 1e-15))
+
+
 def test_time_levels_roll_back_bitwise(pkg, orc):
     """advance_time_level / update_failed (FvBaseDiscretization::advanceTimeLevel / updateFailed): after a rolled-back
     time step the device holds exactly the state it had when the step started - primary variables, meanings,
