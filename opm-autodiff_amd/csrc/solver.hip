@@ -1045,14 +1045,18 @@ __global__ __launch_bounds__(64) void k_ilu_sweep_chain_LU(const int* __restrict
 // linalg/ParallelOverlappingILU0.hpp:439-494): row i of A is staged in LDS and eliminated there against the
 // already finished rows j < i (their U part and D_j^-1 live in HBM, written by earlier colours), then split into
 // L, U and D^-1.
-__global__ __launch_bounds__(64) void k_ilu_factor(int ct_begin, const int* __restrict__ ct_first, const int* __restrict__ tile_row0,
+__global__ __launch_bounds__(64) void k_ilu_factor(const int* __restrict__ sched, const int* __restrict__ ct_first, const int* __restrict__ tile_row0,
                                                    const int* __restrict__ rowptr, const int* __restrict__ col,
                                                    const int* __restrict__ diag, const double* __restrict__ A,
                                                    const int* __restrict__ fdest, const int* __restrict__ lmatch, const int* __restrict__ urowptr,
                                                    const int* __restrict__ ucol, double* L, double* U, double* invD, double* Afix) {
     TILE_LDS
     const int lane = threadIdx.x;
-    const int q0 = ct_first[ct_begin + blockIdx.x], q1 = ct_first[ct_begin + blockIdx.x + 1];
+    // launch position -> chain-tile by the colour's XCD-aware schedule (reorder.cpp: build_schedules): the chain-tiles of one stretch of
+    // the grid share an L2, so the D^-1 and U blocks that four neighbour rows of different workgroups gather are fetched once
+    const int ct = sched[blockIdx.x];
+    if (ct < 0) return;
+    const int q0 = ct_first[ct], q1 = ct_first[ct + 1];
     constexpr int FU = 8;  // U-row columns of a neighbour fetched in one batch (longer rows: the merge below)
     __shared__ int scol[TILE_CAP_BLOCKS + 2], sdest[TILE_CAP_BLOCKS + 2], slm[TILE_CAP_BLOCKS + 2];
     for (int t = q0; t < q1; ++t) {  // steps of a chain-tile in order (a single step unless the ordering is line-coloured)
@@ -1761,9 +1765,9 @@ void launch_ilu_factor(opmhip_ctx* c, bool fix_zero_diagonal) {
     const Pattern& P = c->pat;
     const int ps = prof_begin(c, PROF_ILU_FACTOR);
     for (int col = 0; col < P.numColors; ++col) {
-        const int cb = P.tiles.colorCT[col], ce = P.tiles.colorCT[col + 1];
-        if (ce > cb)
-            hipLaunchKernelGGL(k_ilu_factor, dim3(ce - cb), dim3(64), 0, c->stream, cb, P.tiles.d_ctFirst, P.tiles.d_row0, P.d_rowptr, P.d_col,
+        const int off = P.tiles.ctSchedOff[col], npos = P.tiles.ctSchedOff[col + 1] - off;
+        if (npos > 0)
+            hipLaunchKernelGGL(k_ilu_factor, dim3(npos), dim3(64), 0, c->stream, P.tiles.d_ctSched + off, P.tiles.d_ctFirst, P.tiles.d_row0, P.d_rowptr, P.d_col,
                                P.d_diag, c->d_A, P.d_fdest, P.d_lmatch, P.d_urowptr, P.d_ucol, c->d_L, c->d_U, c->d_invD, fix_zero_diagonal ? c->d_A : (double*)nullptr);
     }
     prof_end(c, ps);
