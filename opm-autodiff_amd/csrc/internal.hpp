@@ -52,6 +52,17 @@ struct TileSet {            // tiles over one block-CSR row-pointer array, never
     std::vector<int> ctDesc;
     int descStride = 0, descS1 = 0;
     int* d_spmvSched = nullptr;
+    // stencil form of the SpMV's index streams (reorder.cpp: build_schedules): the rows of a tile share their column offsets, so a launch
+    // position carries a table of <= 15 offsets (col - row) and a row one word of eight 4-bit table indices (15 = no entry) and one byte
+    // (first entry - the tile's first entry) - 5 bytes per row instead of 28 + 16 for column indices and row bounds.  stencil = false: a
+    // tile needs more offsets or a row more than eight entries; the explicit index streams are used
+    bool stencil = false;
+    std::vector<unsigned> stWord;
+    std::vector<unsigned char> stKoff;
+    std::vector<int> stTable;   // [16 * nsched]
+    unsigned* d_stWord = nullptr;
+    unsigned char* d_stKoff = nullptr;
+    int* d_stTable = nullptr;
     int* d_ctSched = nullptr;
     int* d_ctDesc = nullptr;
     int ntiles() const { return (int)row0.size() - 1; }

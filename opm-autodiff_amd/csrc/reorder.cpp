@@ -307,6 +307,33 @@ void build_schedules(Pattern& P, int G) {
             T.spmvSched[4 * b] = r0; T.spmvSched[4 * b + 1] = r1;
             T.spmvSched[4 * b + 2] = P.rowptr[r0]; T.spmvSched[4 * b + 3] = P.rowptr[r1];
         }
+    // stencil form of the index streams (internal.hpp: TileSet::stWord ...)
+    T.stencil = true;
+    T.stWord.assign(P.Nb, 0xFFFFFFFFu);
+    T.stKoff.assign(P.Nb, 0);
+    T.stTable.assign((size_t)16 * T.nsched, 0);
+    for (int b = 0; b < T.nsched && T.stencil; ++b) {
+        if (order[b] < 0) continue;
+        const int r0 = T.row0[order[b]], r1 = T.row0[order[b] + 1];
+        std::vector<int> offs;
+        for (int r = r0; r < r1; ++r)
+            for (int k = P.rowptr[r]; k < P.rowptr[r + 1]; ++k) offs.push_back(P.col[k] - r);
+        std::sort(offs.begin(), offs.end());
+        offs.erase(std::unique(offs.begin(), offs.end()), offs.end());
+        if (offs.size() > 15) { T.stencil = false; break; }
+        for (size_t q = 0; q < offs.size(); ++q) T.stTable[(size_t)16 * b + q] = offs[q];
+        for (int r = r0; r < r1; ++r) {
+            const int len = P.rowptr[r + 1] - P.rowptr[r], ko = P.rowptr[r] - P.rowptr[r0];
+            if (len > 8 || ko > 255) { T.stencil = false; break; }
+            unsigned w = 0xFFFFFFFFu;
+            for (int u = 0; u < len; ++u) {
+                const int idx = (int)(std::lower_bound(offs.begin(), offs.end(), P.col[P.rowptr[r] + u] - r) - offs.begin());
+                w = (w & ~(0xFu << (4 * u))) | ((unsigned)idx << (4 * u));
+            }
+            T.stWord[r] = w;
+            T.stKoff[r] = (unsigned char)ko;
+        }
+    }
 }
 
 }  // namespace
@@ -544,6 +571,11 @@ int build_pattern(opmhip_ctx* c, int Nb, int Nghost, int nnzb, const int* rows, 
     }
     int rc;
     if ((rc = dev_upload(c, &P.tiles.d_spmvSched, P.tiles.spmvSched))) return rc;
+    if (P.tiles.stencil) {
+        if ((rc = dev_upload(c, &P.tiles.d_stWord, P.tiles.stWord))) return rc;
+        if ((rc = dev_upload(c, &P.tiles.d_stKoff, P.tiles.stKoff))) return rc;
+        if ((rc = dev_upload(c, &P.tiles.d_stTable, P.tiles.stTable))) return rc;
+    }
     if ((rc = dev_upload(c, &P.tiles.d_ctSched, P.tiles.ctSched))) return rc;
     if ((rc = dev_upload(c, &P.tiles.d_ctDesc, P.tiles.ctDesc))) return rc;
     if ((rc = dev_upload(c, &P.d_rowptr, P.rowptr))) return rc;

@@ -574,6 +574,142 @@ __global__ __launch_bounds__(64) void k_spmv_pipe(int npos, const int4* __restri
     }
 }
 
+// The pipelined SpMV on the STENCIL form of its index streams (TileSet::stWord / stKoff / stTable): stage W (two tiles ahead)
+// fetches a row's word of eight 4-bit table indices, its first-entry byte and - lanes 0..15 - the tile's offset table; stage
+// M (one ahead) turns them into column indices (table entries travel lane to lane, no LDS, no memory) and gathers.  No row
+// bounds, no column indices: 5 bytes per row instead of 44, and the gathers wait for ONE round of loads instead of two.
+// Same tiles, same per-row arithmetic in the same order as k_spmv_pipe: the same bits.
+template <int NDOT>
+__global__ __launch_bounds__(64) void k_spmv_pipe_st(int npos, const int4* __restrict__ sched, const unsigned* __restrict__ stWord,
+                                                     const unsigned char* __restrict__ stKoff, const int* __restrict__ stTable,
+                                                     const double* __restrict__ val, const double* __restrict__ x, double* __restrict__ y,
+                                                     const double* __restrict__ w0, double* __restrict__ part, int npart,
+                                                     const double* __restrict__ done, double xs) {
+    TILE_LDS
+    __shared__ int4 ssched[PIPE_MAX_STEPS];
+    const int lane = threadIdx.x, G = gridDim.x;
+    constexpr int U = 16;
+    const int nsteps = ((int)blockIdx.x < npos) ? (npos - (int)blockIdx.x + G - 1) / G : 0;
+    if (nsteps <= 0) {
+        if (NDOT >= 1 && lane == 0) { part[blockIdx.x] = 0.0; if (NDOT == 2) part[npart + blockIdx.x] = 0.0; }
+        return;
+    }
+    const double stop = *done;
+    for (int i = lane; i < nsteps; i += 64) ssched[i] = sched[(int)blockIdx.x + i * G];
+    if (stop != 0.0) return;
+    wave_sync();
+    struct StW { unsigned w; int koff, tab; };
+    struct StS {
+        int k0e, n, n2;
+        double2 tmp[U];
+    };
+    struct StM {
+        int kb, nrow;
+        double xx[PGCH][3];
+        double ww[NDOT >= 1 ? 3 : 1];
+    };
+    auto clampst = [&](int st) { return st < nsteps ? st : nsteps - 1; };
+    auto row_of = [&](int st, bool& active) {   // LDS only
+        const int4 rows = ssched[clampst(st)];
+        active = st < nsteps && rows.x + lane < rows.y;
+        return (rows.x + lane < rows.y) ? rows.x + lane : (rows.y > rows.x ? rows.y - 1 : 0);
+    };
+    auto stageW = [&](int st, StW& a) {
+        bool act;
+        const int rr = row_of(st, act);
+        a.w = stWord[rr];
+        a.koff = stKoff[rr];
+        a.tab = stTable[((size_t)blockIdx.x + (size_t)clampst(st) * G) * 16 + (lane & 15)];
+    };
+    auto stageGs = [&](int st, StS& b) {
+        const int4 rows = ssched[clampst(st)];
+        b.k0e = rows.z & ~1;
+        const int nb = rows.w - b.k0e;
+        b.n = (rows.y > rows.x) ? nb * BB : 0;
+        b.n2 = b.n >> 1;
+        const int lim = (st < nsteps && b.n2 > 0) ? b.n2 - 1 : 0;
+        const double2* __restrict__ s2 = reinterpret_cast<const double2*>(val + (size_t)b.k0e * BB);
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int i = u * 64 + lane;
+            b.tmp[u] = ld_stream(&s2[i < lim ? i : lim]);
+        }
+    };
+    auto stageGm = [&](int st, const StW& a, StM& b) {
+        bool act;
+        const int rr = row_of(st, act);
+        const int4 rows = ssched[clampst(st)];
+        b.kb = rows.z + a.koff;
+        int cnt = 0;
+#pragma unroll
+        for (int u = 0; u < PGCH; ++u) {
+            const int nib = (int)((a.w >> (4 * u)) & 15u);
+            const int off = __shfl(a.tab, nib, 64);
+            const int cc = nib != 15 ? rr + off : rr;   // idle slots: the row itself (a valid row to gather)
+            cnt += nib != 15;
+            const double* xc = &x[(size_t)cc * BS];
+            b.xx[u][0] = xc[0]; b.xx[u][1] = xc[1]; b.xx[u][2] = xc[2];
+        }
+        b.nrow = cnt;
+        if (NDOT >= 1) {
+            const double* wr = &w0[(size_t)rr * BS];
+            b.ww[0] = wr[0]; b.ww[1] = wr[1]; b.ww[2] = wr[2];
+        }
+    };
+    StW wq;
+    StS sb;
+    StM m;
+    double sd0 = 0.0, sd1 = 0.0;
+    {   // prologue, in the loop's order of issue
+        StW w0q;
+        stageW(0, w0q);
+        stageGs(0, sb);
+        stageGm(0, w0q, m);
+        stageW(1, wq);
+    }
+    double2* d2 = reinterpret_cast<double2*>(sval);
+    for (int st = 0; st < nsteps; ++st) {
+        const int k0e = sb.k0e, n = sb.n, n2 = sb.n2;
+        if (n2 > 0) {
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const int i = u * 64 + lane;
+                if (i < n2) d2[i] = sb.tmp[u];
+            }
+            if ((n & 1) && lane == 0) sval[n - 1] = val[(size_t)k0e * BB + n - 1];
+        }
+        wave_sync();
+        stageGs(st + 1, sb);
+        bool active;
+        const int r = row_of(st, active);
+        if (active) {
+            const int kb = m.kb, nrow = m.nrow;
+            double acc[3] = {0.0, 0.0, 0.0};
+#pragma unroll
+            for (int u = 0; u < PGCH; ++u)
+                if (u < nrow) blk_umv_lds(&sval[(kb + u - k0e) * BB], xs * m.xx[u][0], xs * m.xx[u][1], xs * m.xx[u][2], acc);
+            double* yr = &y[(size_t)r * BS];
+            yr[0] = acc[0]; yr[1] = acc[1]; yr[2] = acc[2];
+            if (NDOT >= 1) {
+                double d0 = acc[0] * m.ww[0]; d0 += acc[1] * m.ww[1]; d0 += acc[2] * m.ww[2];
+                sd0 += d0;
+                if (NDOT == 2) { double d1 = acc[0] * acc[0]; d1 += acc[1] * acc[1]; d1 += acc[2] * acc[2]; sd1 += d1; }
+            }
+        }
+        wave_sync();
+        __builtin_amdgcn_sched_barrier(0);
+        stageGm(st + 1, wq, m);
+        __builtin_amdgcn_sched_barrier(0);
+        stageW(st + 2, wq);
+        __builtin_amdgcn_sched_barrier(0);
+    }
+    if (NDOT >= 1) {
+        sd0 = wave_sum(sd0);
+        if (NDOT == 2) sd1 = wave_sum(sd1);
+        if (lane == 0) { part[blockIdx.x] = sd0; if (NDOT == 2) part[npart + blockIdx.x] = sd1; }
+    }
+}
+
 // ============================== ILU0 apply ===============================================================
 // One colour of M^-1 = [w] U^-1 L^-1 (linalg/ParallelOverlappingILU0.hpp:848-903).  Work vector vu holds y = L^-1 d and then
 // the unscaled U^-1 y; v receives the final (scaled) result.  Three shapes, chosen per colour by the launcher:
@@ -1708,6 +1844,17 @@ static int launch_spmv_part(opmhip_ctx* c, int p0, int np, const double* x, doub
         const int pipeWgs = spmv_pipe_wgs(c);
         const int steps = std::min((np + pipeWgs - 1) / pipeWgs, PIPE_MAX_STEPS);   // beyond that: more workgroups than are resident
         const int grid = 8 * (((np + steps - 1) / steps + 7) / 8);
+        static const bool explicitIdx = [] { const char* e = std::getenv("OPMHIP_SPMV_EXPLICIT"); return e && e[0] == '1'; }();   // A/B switch: the explicit index streams
+        if (P.tiles.stencil && !explicitIdx) {
+            const int* tab = P.tiles.d_stTable + (size_t)p0 * 16;
+            if (ndot == 0)
+                hipExtLaunchKernelGGL(k_spmv_pipe_st<0>, dim3(grid), dim3(64), 0, c->stream, e0, e1, 0, np, sched, P.tiles.d_stWord, P.tiles.d_stKoff, tab, c->d_A, x, y, w0, part, c->npart, c->d_done, xs);
+            else if (ndot == 1)
+                hipExtLaunchKernelGGL(k_spmv_pipe_st<1>, dim3(grid), dim3(64), 0, c->stream, e0, e1, 0, np, sched, P.tiles.d_stWord, P.tiles.d_stKoff, tab, c->d_A, x, y, w0, part, c->npart, c->d_done, xs);
+            else
+                hipExtLaunchKernelGGL(k_spmv_pipe_st<2>, dim3(grid), dim3(64), 0, c->stream, e0, e1, 0, np, sched, P.tiles.d_stWord, P.tiles.d_stKoff, tab, c->d_A, x, y, w0, part, c->npart, c->d_done, xs);
+            return ndot > 0 ? grid : 0;
+        }
         if (ndot == 0)
             hipExtLaunchKernelGGL(k_spmv_pipe<0>, dim3(grid), dim3(64), 0, c->stream, e0, e1, 0, np, sched, P.d_rowptr, P.d_col, c->d_A, x, y, w0, part, c->npart, c->d_done, xs);
         else if (ndot == 1)
