@@ -91,6 +91,15 @@ struct Pattern {
     int *d_lrowptr = nullptr, *d_lcol = nullptr, *d_urowptr = nullptr, *d_ucol = nullptr;
     std::vector<int> fdest;      // per matrix entry: where the factorisation puts it - L index (>= 0), -2 - U index, -1 (diagonal / dropped ghost column)
     int* d_fdest = nullptr;
+    // stencil form of the sweeps' index streams (solver.hip: SweepStencil), per factor part: word / byte per row, table per tile;
+    // sweepStencil = false: some tile needs more than 15 offsets or a row more than CGCH entries - explicit streams
+    bool sweepStencil = false;
+    std::vector<unsigned> swWord[2];
+    std::vector<unsigned char> swKoff[2];
+    std::vector<int> swTable[2];
+    unsigned* d_swWord[2] = {nullptr, nullptr};
+    unsigned char* d_swKoff[2] = {nullptr, nullptr};
+    int* d_swTable[2] = {nullptr, nullptr};
     // per L entry (i, j) what its elimination step touches: the ONE entry of row i that meets the U part of row j (a 7-point grid has no
     // triangles: it is the diagonal) as U index * 64 + offset of the target in row i; -1: none; -2: several (the general search)
     std::vector<int> lmatch;

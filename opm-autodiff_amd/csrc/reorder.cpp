@@ -273,6 +273,7 @@ void build_schedules(Pattern& P, int G) {
             if (ct < 0) continue;
             const int q0 = T.ctFirst[ct], n = T.ctFirst[ct + 1] - q0;
             rec[0] = n;
+            rec[2] = q0;   // first tile of the chain-tile: where its steps' stencil tables start
             for (int i = 0; i <= n; ++i) {
                 const int r = T.row0[q0 + i];
                 rec[4 + i] = r;
@@ -332,6 +333,36 @@ void build_schedules(Pattern& P, int G) {
             }
             T.stWord[r] = w;
             T.stKoff[r] = (unsigned char)ko;
+        }
+    }
+    // the same for the two factor parts the sweeps stream (chained orderings only: their kernels are the ones that read it)
+    P.sweepStencil = P.chained;
+    for (int part = 0; part < 2 && P.sweepStencil; ++part) {
+        const std::vector<int>& prow = part == 0 ? P.lrowptr : P.urowptr;
+        const std::vector<int>& pcol = part == 0 ? P.lcol : P.ucol;
+        P.swWord[part].assign(P.Nb, 0xFFFFFFFFu);
+        P.swKoff[part].assign(P.Nb, 0);
+        P.swTable[part].assign((size_t)16 * nt, 0);
+        for (int t = 0; t < nt && P.sweepStencil; ++t) {
+            const int r0 = T.row0[t], r1 = T.row0[t + 1];
+            std::vector<int> offs;
+            for (int r = r0; r < r1; ++r)
+                for (int k = prow[r]; k < prow[r + 1]; ++k) offs.push_back(pcol[k] - r);
+            std::sort(offs.begin(), offs.end());
+            offs.erase(std::unique(offs.begin(), offs.end()), offs.end());
+            if (offs.size() > 15) { P.sweepStencil = false; break; }
+            for (size_t q = 0; q < offs.size(); ++q) P.swTable[part][(size_t)16 * t + q] = offs[q];
+            for (int r = r0; r < r1; ++r) {
+                const int len = prow[r + 1] - prow[r], ko = prow[r] - prow[r0];
+                if (len > 8 || ko > 255) { P.sweepStencil = false; break; }
+                unsigned w = 0xFFFFFFFFu;
+                for (int u = 0; u < len; ++u) {
+                    const int idx = (int)(std::lower_bound(offs.begin(), offs.end(), pcol[prow[r] + u] - r) - offs.begin());
+                    w = (w & ~(0xFu << (4 * u))) | ((unsigned)idx << (4 * u));
+                }
+                P.swWord[part][r] = w;
+                P.swKoff[part][r] = (unsigned char)ko;
+            }
         }
     }
 }
@@ -571,6 +602,11 @@ int build_pattern(opmhip_ctx* c, int Nb, int Nghost, int nnzb, const int* rows, 
     }
     int rc;
     if ((rc = dev_upload(c, &P.tiles.d_spmvSched, P.tiles.spmvSched))) return rc;
+    for (int part = 0; part < 2 && P.sweepStencil; ++part) {
+        if ((rc = dev_upload(c, &P.d_swWord[part], P.swWord[part]))) return rc;
+        if ((rc = dev_upload(c, &P.d_swKoff[part], P.swKoff[part]))) return rc;
+        if ((rc = dev_upload(c, &P.d_swTable[part], P.swTable[part]))) return rc;
+    }
     if (P.tiles.stencil) {
         if ((rc = dev_upload(c, &P.tiles.d_stWord, P.tiles.stWord))) return rc;
         if ((rc = dev_upload(c, &P.tiles.d_stKoff, P.tiles.stKoff))) return rc;

@@ -793,12 +793,21 @@ __device__ __forceinline__ int load_desc(const int* __restrict__ desc, int dstri
     wave_sync();
     return sdesc[0];
 }
-template <int SHAPE>  // SW_L or SW_UF
+// the stencil form of one factor part's index streams (Pattern::swL / swU, reorder.cpp: build_sweep_stencils): per tile a table of <= 15
+// column offsets (col - row), per row a word of eight 4-bit table indices in ascending column order (15 = no entry) and a byte (first
+// entry - the tile's first entry) - as for the SpMV (k_spmv_pipe_st)
+struct SweepStencil {
+    const unsigned* __restrict__ word;
+    const unsigned char* __restrict__ koff;
+    const int* __restrict__ table;   // [16 * number of tiles]
+};
+template <int SHAPE, bool ST = false>  // SW_L or SW_UF; ST: column indices and row bounds from the stencil form (q0 = the chain-tile's first tile)
 __device__ __forceinline__ void chain_sweep(const int nsteps, const int lane, double* sval, const int* srow0, const int* sk0,
                                             const int* __restrict__ prow,
                                             const int* __restrict__ pcol, const double* __restrict__ P,
                                             const double* __restrict__ invD, const double* d,
-                                            double* vu, double* v, const double* __restrict__ addp, int relax_mode, double w) {
+                                            double* vu, double* v, const double* __restrict__ addp, int relax_mode, double w,
+                                            const SweepStencil S = SweepStencil{nullptr, nullptr, nullptr}, const int q0 = 0) {
     // nsteps <= CHAIN_MAX_STEPS (checked on the host); srow0[0..nsteps], sk0[0..nsteps]: first row / first entry of every
     // step, out of the chain-tile's descriptor record (LDS) - no dependent loads here
     const bool reverse = (SHAPE == SW_UF) && relax_mode == 0;
@@ -862,6 +871,34 @@ __device__ __forceinline__ void chain_sweep(const int nsteps, const int lane, do
             if (u < nrow) valid |= 1u << u;
         }
     };
+    // ST: one stage in the place of A and C - the row's word and byte and (lanes 0..15) the tile's offset table, two steps ahead
+    struct StW { unsigned wd; int koff, tab; };
+    auto stageW = [&](int st, StW& a) {
+        bool act;
+        const int rr = row_of(st, act);
+        a.wd = S.word[rr];
+        a.koff = S.koff[rr];
+        a.tab = S.table[(size_t)(q0 + tile_of(st)) * 16 + (lane & 15)];
+    };
+    // ... and what stage M makes of it: row bounds, column indices (the table entries travel lane to lane), the mask of used slots
+    auto decodeW = [&](int st, const StW& a, int& kb, int& ke, int (&cc)[CGCH], unsigned& valid) {
+        bool act;
+        const int rr = row_of(st, act);
+        const unsigned none = a.wd & (a.wd >> 1) & (a.wd >> 2) & (a.wd >> 3) & 0x11111111u;   // bit 4u set: slot u holds no entry
+        const int cnt = none ? (__builtin_ctz(none) >> 2) : 8;
+        kb = sk0[tile_of(st)] + a.koff;
+        ke = kb + cnt;
+        const int nrow = act ? cnt : 0;
+        valid = 0u;
+#pragma unroll
+        for (int u = 0; u < CGCH; ++u) {
+            const int e = reverse ? cnt - 1 - u : u;
+            const int nib = (int)((a.wd >> (4 * (e & 7))) & 15u);
+            const int off = __shfl(a.tab, nib, 64);
+            cc[u] = (u < nrow) ? rr + off : rr;
+            if (u < nrow) valid |= 1u << u;
+        }
+    };
     auto stageGs = [&](int st, StS& b) {   // the value stream of step st; st == nsteps: nothing but one line, read 12 times
         const int ti = tile_of(clampst(st));
         const int k0 = sk0[ti], k1 = sk0[ti + 1];
@@ -878,11 +915,14 @@ __device__ __forceinline__ void chain_sweep(const int nsteps, const int lane, do
             b.tmp[u] = ld_stream(&s2[i < lim ? i : lim]);
         }
     };
-    auto stageGm = [&](int st, const int (&cc)[CGCH], unsigned valid, int prevRow, StM& b) {   // cc = column indices of step st
+    auto stageGm = [&](int st, const int (&cc)[CGCH], unsigned valid, int prevRow, StM& b, int skb = 0, int ske = 0) {   // cc = column indices of step st
         bool act;
         const int rr = row_of(st, act);
-        b.kb = prow[rr];
-        b.ke = prow[rr + 1];
+        if (ST) { b.kb = skb; b.ke = ske; }
+        else {
+            b.kb = prow[rr];
+            b.ke = prow[rr + 1];
+        }
         const double* rsrc = (SHAPE == SW_L) ? d : vu;  // the lane's own row: no earlier step of this sweep writes it
         b.rhs[0] = rsrc[(size_t)rr * BS]; b.rhs[1] = rsrc[(size_t)rr * BS + 1]; b.rhs[2] = rsrc[(size_t)rr * BS + 2];
         b.late = 0u; b.mine = 0u;
@@ -905,12 +945,23 @@ __device__ __forceinline__ void chain_sweep(const int nsteps, const int lane, do
         }
     };
     StA a;
+    StW wq;
     int cc[CGCH];
     unsigned ccValid;
     StS sb;
     StM m;
     int myPrevRow = -1;           // the row this lane finished in the previous step, and its result
     double myPrev[3] = {0.0, 0.0, 0.0};
+    if (ST) {   // prologue of the stencil form, in the loop's order of issue
+        StW w0q;
+        int c0[CGCH], kb0, ke0;
+        unsigned v0;
+        stageW(0, w0q);
+        stageGs(0, sb);
+        decodeW(0, w0q, kb0, ke0, c0, v0);
+        stageGm(0, c0, v0, -1, m, kb0, ke0);
+        stageW(clampst(1), wq);
+    } else
     {   // prologue: the row bounds of the first three steps in ONE round of loads, the column indices of the first two in
         // the next, then the first value stream and the first step's small items - three dependent rounds instead of six
         // - and in the loop's own order of issue (stream, small items, column indices, row bounds): the compiler's
@@ -1014,12 +1065,21 @@ __device__ __forceinline__ void chain_sweep(const int nsteps, const int lane, do
         //      The scheduling barriers keep each stage's last use of its input registers in front of the loads that refill
         //      them - interleaved by the instruction scheduler, old and new values would overlap and need copies again.
         __builtin_amdgcn_sched_barrier(0);
-        stageGm(clampst(st + 1), cc, ccValid, myPrevRow, m);
-        __builtin_amdgcn_sched_barrier(0);
-        stageC(clampst(st + 2), a, cc, ccValid);
-        __builtin_amdgcn_sched_barrier(0);
-        stageA(clampst(st + 3), a);
-        __builtin_amdgcn_sched_barrier(0);
+        if (ST) {
+            int skb, ske;
+            decodeW(clampst(st + 1), wq, skb, ske, cc, ccValid);
+            stageGm(clampst(st + 1), cc, ccValid, myPrevRow, m, skb, ske);
+            __builtin_amdgcn_sched_barrier(0);
+            stageW(clampst(st + 2), wq);
+            __builtin_amdgcn_sched_barrier(0);
+        } else {
+            stageGm(clampst(st + 1), cc, ccValid, myPrevRow, m);
+            __builtin_amdgcn_sched_barrier(0);
+            stageC(clampst(st + 2), a, cc, ccValid);
+            __builtin_amdgcn_sched_barrier(0);
+            stageA(clampst(st + 3), a);
+            __builtin_amdgcn_sched_barrier(0);
+        }
     }
 }
 // Light sweep of a chain tile: every row's part of the factor is at most ONE block, the one towards the row the same
@@ -1137,12 +1197,13 @@ __global__ __launch_bounds__(64) void k_ilu_sweep_light(const int* __restrict__ 
     (void)S1;
     chain_sweep_light<SHAPE>(nsteps, lane, sdesc + DESC_HEAD, prow, pcol, P, invD, d, vu, v, addp, relax_mode, w);
 }
-template <int SHAPE>
+template <int SHAPE, bool ST = false>
 __global__ __launch_bounds__(64) void k_ilu_sweep_chain(const int* __restrict__ desc, int dstride, int S1,
                                                         const int* __restrict__ prow,
                                                         const int* __restrict__ pcol, const double* __restrict__ P,
                                                         const double* __restrict__ invD, const double* d,
-                                                        double* vu, double* v, const double* __restrict__ addp, int relax_mode, double w, const double* __restrict__ done) {
+                                                        double* vu, double* v, const double* __restrict__ addp, int relax_mode, double w, const double* __restrict__ done,
+                                                        const SweepStencil S) {
     TILE_LDS
     __shared__ int sdesc[DESC_MAX];
     const int lane = threadIdx.x;
@@ -1150,18 +1211,18 @@ __global__ __launch_bounds__(64) void k_ilu_sweep_chain(const int* __restrict__ 
     const int nsteps = load_desc(desc, dstride, lane, sdesc);
     if (stop != 0.0 || nsteps <= 0) return;
     const int* srow0 = sdesc + DESC_HEAD;
-    chain_sweep<SHAPE>(nsteps, lane, sval, srow0, srow0 + (SHAPE == SW_L ? 1 : 2) * S1, prow, pcol, P, invD, d, vu, v, addp, relax_mode, w);
+    chain_sweep<SHAPE, ST>(nsteps, lane, sval, srow0, srow0 + (SHAPE == SW_L ? 1 : 2) * S1, prow, pcol, P, invD, d, vu, v, addp, relax_mode, w, S, sdesc[2]);
 }
 // Last colour: its rows have U entries only inside their own chain-tile, so the backward sweep of a chain-tile can
 // start the moment its forward sweep ends - one launch instead of two, and y never leaves the cache in between.
-template <bool LIGHT_U>
+template <bool LIGHT_U, bool ST = false>
 __global__ __launch_bounds__(64) void k_ilu_sweep_chain_LU(const int* __restrict__ desc, int dstride, int S1,
                                                            const int* __restrict__ lrow,
                                                            const int* __restrict__ lcol, const double* __restrict__ L,
                                                            const int* __restrict__ urow, const int* __restrict__ ucol,
                                                            const double* __restrict__ Uv, const double* __restrict__ invD,
                                                            const double* d, double* vu, double* v, const double* __restrict__ addp, int relax_mode, double w,
-                                                           const double* __restrict__ done) {
+                                                           const double* __restrict__ done, const SweepStencil SL, const SweepStencil SU) {
     TILE_LDS
     __shared__ int sdesc[DESC_MAX];
     const int lane = threadIdx.x;
@@ -1169,11 +1230,11 @@ __global__ __launch_bounds__(64) void k_ilu_sweep_chain_LU(const int* __restrict
     const int nsteps = load_desc(desc, dstride, lane, sdesc);
     if (stop != 0.0 || nsteps <= 0) return;
     const int* srow0 = sdesc + DESC_HEAD;
-    chain_sweep<SW_L>(nsteps, lane, sval, srow0, srow0 + S1, lrow, lcol, L, invD, d, vu, v, addp, relax_mode, w);
+    chain_sweep<SW_L, ST>(nsteps, lane, sval, srow0, srow0 + S1, lrow, lcol, L, invD, d, vu, v, addp, relax_mode, w, SL, sdesc[2]);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // y of this chain-tile is written before the backward sweep reads it
     wave_sync();
     if (LIGHT_U) chain_sweep_light<SW_UF>(nsteps, lane, srow0, urow, ucol, Uv, invD, d, vu, v, addp, relax_mode, w);
-    else chain_sweep<SW_UF>(nsteps, lane, sval, srow0, srow0 + 2 * S1, urow, ucol, Uv, invD, d, vu, v, addp, relax_mode, w);
+    else chain_sweep<SW_UF, ST>(nsteps, lane, sval, srow0, srow0 + 2 * S1, urow, ucol, Uv, invD, d, vu, v, addp, relax_mode, w, SU, sdesc[2]);
 }
 
 // ============================== ILU0 factorisation =======================================================
@@ -1939,25 +2000,31 @@ void launch_ilu_apply(opmhip_ctx* c, const double* d, double* v, double w_overri
         const int ds = P.tiles.descStride, S1 = P.tiles.descS1;
         auto desc = [&](int col) { return P.tiles.d_ctDesc + (size_t)P.tiles.ctSchedOff[col] * ds; };
         auto npos = [&](int col) { return P.tiles.ctSchedOff[col + 1] - P.tiles.ctSchedOff[col]; };
+        static const bool explicitIdx = [] { const char* e = std::getenv("OPMHIP_SWEEP_EXPLICIT"); return e && e[0] == '1'; }();   // A/B switch
+        const bool st = P.sweepStencil && !explicitIdx;   // column indices and row bounds of the heavy sweeps from the stencil form
+        const SweepStencil SL{P.d_swWord[0], P.d_swKoff[0], P.d_swTable[0]}, SU{P.d_swWord[1], P.d_swKoff[1], P.d_swTable[1]};
         for (int col = 0; col < C - 1; ++col) {
             const int nct = npos(col);
             if (nct <= 0) continue;
             if (P.lightL[col])
                 hipLaunchKernelGGL(k_ilu_sweep_light<SW_L>, dim3(nct), dim3(64), 0, c->stream, desc(col), ds, S1, P.d_lrowptr,
                                    P.d_lcol, c->d_L, c->d_invD, d, vu, v, addp, mode, w, c->d_done);
+            else if (st)
+                hipLaunchKernelGGL((k_ilu_sweep_chain<SW_L, true>), dim3(nct), dim3(64), 0, c->stream, desc(col), ds, S1, P.d_lrowptr,
+                                   P.d_lcol, c->d_L, c->d_invD, d, vu, v, addp, mode, w, c->d_done, SL);
             else
-                hipLaunchKernelGGL(k_ilu_sweep_chain<SW_L>, dim3(nct), dim3(64), 0, c->stream, desc(col), ds, S1, P.d_lrowptr,
-                                   P.d_lcol, c->d_L, c->d_invD, d, vu, v, addp, mode, w, c->d_done);
+                hipLaunchKernelGGL((k_ilu_sweep_chain<SW_L, false>), dim3(nct), dim3(64), 0, c->stream, desc(col), ds, S1, P.d_lrowptr,
+                                   P.d_lcol, c->d_L, c->d_invD, d, vu, v, addp, mode, w, c->d_done, SL);
         }
         {
             const int nct = npos(C - 1);
             if (nct > 0) {
-                if (P.lightU[C - 1])
-                    hipLaunchKernelGGL(k_ilu_sweep_chain_LU<true>, dim3(nct), dim3(64), 0, c->stream, desc(C - 1), ds, S1, P.d_lrowptr,
-                                       P.d_lcol, c->d_L, P.d_urowptr, P.d_ucol, c->d_U, c->d_invD, d, vu, v, addp, mode, w, c->d_done);
-                else
-                    hipLaunchKernelGGL(k_ilu_sweep_chain_LU<false>, dim3(nct), dim3(64), 0, c->stream, desc(C - 1), ds, S1, P.d_lrowptr,
-                                       P.d_lcol, c->d_L, P.d_urowptr, P.d_ucol, c->d_U, c->d_invD, d, vu, v, addp, mode, w, c->d_done);
+#define OPMHIP_LU_LAUNCH(LIGHT, STF)                                                                                                        \
+    hipLaunchKernelGGL((k_ilu_sweep_chain_LU<LIGHT, STF>), dim3(nct), dim3(64), 0, c->stream, desc(C - 1), ds, S1, P.d_lrowptr, P.d_lcol, c->d_L, \
+                       P.d_urowptr, P.d_ucol, c->d_U, c->d_invD, d, vu, v, addp, mode, w, c->d_done, SL, SU)
+                if (P.lightU[C - 1]) { if (st) OPMHIP_LU_LAUNCH(true, true); else OPMHIP_LU_LAUNCH(true, false); }
+                else { if (st) OPMHIP_LU_LAUNCH(false, true); else OPMHIP_LU_LAUNCH(false, false); }
+#undef OPMHIP_LU_LAUNCH
             }
         }
         for (int col = C - 2; col >= 0; --col) {
@@ -1966,9 +2033,12 @@ void launch_ilu_apply(opmhip_ctx* c, const double* d, double* v, double w_overri
             if (P.lightU[col])
                 hipLaunchKernelGGL(k_ilu_sweep_light<SW_UF>, dim3(nct), dim3(64), 0, c->stream, desc(col), ds, S1, P.d_urowptr,
                                    P.d_ucol, c->d_U, c->d_invD, d, vu, v, addp, mode, w, c->d_done);
+            else if (st)
+                hipLaunchKernelGGL((k_ilu_sweep_chain<SW_UF, true>), dim3(nct), dim3(64), 0, c->stream, desc(col), ds, S1, P.d_urowptr,
+                                   P.d_ucol, c->d_U, c->d_invD, d, vu, v, addp, mode, w, c->d_done, SU);
             else
-                hipLaunchKernelGGL(k_ilu_sweep_chain<SW_UF>, dim3(nct), dim3(64), 0, c->stream, desc(col), ds, S1, P.d_urowptr,
-                                   P.d_ucol, c->d_U, c->d_invD, d, vu, v, addp, mode, w, c->d_done);
+                hipLaunchKernelGGL((k_ilu_sweep_chain<SW_UF, false>), dim3(nct), dim3(64), 0, c->stream, desc(col), ds, S1, P.d_urowptr,
+                                   P.d_ucol, c->d_U, c->d_invD, d, vu, v, addp, mode, w, c->d_done, SU);
         }
         prof_end(c, ps);
         return;
