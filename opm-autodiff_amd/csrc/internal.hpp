@@ -56,7 +56,8 @@ struct TileSet {            // tiles over one block-CSR row-pointer array, never
     // position carries a table of <= 15 offsets (col - row) and a row one word of eight 4-bit table indices (15 = no entry) and one byte
     // (first entry - the tile's first entry) - 5 bytes per row instead of 28 + 16 for column indices and row bounds.  stencil = false: a
     // tile needs more offsets or a row more than eight entries; the explicit index streams are used
-    bool stencil = false;
+    bool stencil = false;           // some part of the schedule has it
+    bool stencilPart[2] = {false, false};   // [0] positions [0, nschedInt), [1] the boundary tiles of a decomposed run
     std::vector<unsigned> stWord;
     std::vector<unsigned char> stKoff;
     std::vector<int> stTable;   // [16 * nsched]

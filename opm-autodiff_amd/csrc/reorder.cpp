@@ -308,24 +308,27 @@ void build_schedules(Pattern& P, int G) {
             T.spmvSched[4 * b] = r0; T.spmvSched[4 * b + 1] = r1;
             T.spmvSched[4 * b + 2] = P.rowptr[r0]; T.spmvSched[4 * b + 3] = P.rowptr[r1];
         }
-    // stencil form of the index streams (internal.hpp: TileSet::stWord ...)
-    T.stencil = true;
+    // stencil form of the index streams (internal.hpp: TileSet::stWord ...), judged per part of the schedule: the interior tiles of a
+    // decomposed run are as regular as a single domain's, its boundary tiles (ghost columns at arbitrary offsets) usually are not
+    T.stencilPart[0] = T.stencilPart[1] = true;
     T.stWord.assign(P.Nb, 0xFFFFFFFFu);
     T.stKoff.assign(P.Nb, 0);
     T.stTable.assign((size_t)16 * T.nsched, 0);
-    for (int b = 0; b < T.nsched && T.stencil; ++b) {
+    for (int b = 0; b < T.nsched; ++b) {
         if (order[b] < 0) continue;
+        const int part = b < T.nschedInt ? 0 : 1;
+        if (!T.stencilPart[part]) continue;
         const int r0 = T.row0[order[b]], r1 = T.row0[order[b] + 1];
         std::vector<int> offs;
         for (int r = r0; r < r1; ++r)
             for (int k = P.rowptr[r]; k < P.rowptr[r + 1]; ++k) offs.push_back(P.col[k] - r);
         std::sort(offs.begin(), offs.end());
         offs.erase(std::unique(offs.begin(), offs.end()), offs.end());
-        if (offs.size() > 15) { T.stencil = false; break; }
+        if (offs.size() > 15) { T.stencilPart[part] = false; continue; }
         for (size_t q = 0; q < offs.size(); ++q) T.stTable[(size_t)16 * b + q] = offs[q];
         for (int r = r0; r < r1; ++r) {
             const int len = P.rowptr[r + 1] - P.rowptr[r], ko = P.rowptr[r] - P.rowptr[r0];
-            if (len > 8 || ko > 255) { T.stencil = false; break; }
+            if (len > 8 || ko > 255) { T.stencilPart[part] = false; break; }
             unsigned w = 0xFFFFFFFFu;
             for (int u = 0; u < len; ++u) {
                 const int idx = (int)(std::lower_bound(offs.begin(), offs.end(), P.col[P.rowptr[r] + u] - r) - offs.begin());
@@ -335,6 +338,7 @@ void build_schedules(Pattern& P, int G) {
             T.stKoff[r] = (unsigned char)ko;
         }
     }
+    T.stencil = T.stencilPart[0] || T.stencilPart[1];
     // the same for the two factor parts the sweeps stream (chained orderings only: their kernels are the ones that read it)
     P.sweepStencil = P.chained;
     for (int part = 0; part < 2 && P.sweepStencil; ++part) {

@@ -1906,7 +1906,8 @@ static int launch_spmv_part(opmhip_ctx* c, int p0, int np, const double* x, doub
         const int steps = std::min((np + pipeWgs - 1) / pipeWgs, PIPE_MAX_STEPS);   // beyond that: more workgroups than are resident
         const int grid = 8 * (((np + steps - 1) / steps + 7) / 8);
         static const bool explicitIdx = [] { const char* e = std::getenv("OPMHIP_SPMV_EXPLICIT"); return e && e[0] == '1'; }();   // A/B switch: the explicit index streams
-        if (P.tiles.stencil && !explicitIdx) {
+        const bool inInt = p0 < P.tiles.nschedInt, inBnd = p0 + np > P.tiles.nschedInt;   // which parts of the schedule this launch covers
+        if ((!inInt || P.tiles.stencilPart[0]) && (!inBnd || P.tiles.stencilPart[1]) && !explicitIdx) {
             const int* tab = P.tiles.d_stTable + (size_t)p0 * 16;
             if (ndot == 0)
                 hipExtLaunchKernelGGL(k_spmv_pipe_st<0>, dim3(grid), dim3(64), 0, c->stream, e0, e1, 0, np, sched, P.tiles.d_stWord, P.tiles.d_stKoff, tab, c->d_A, x, y, w0, part, c->npart, c->d_done, xs);
