@@ -192,23 +192,59 @@ __global__ __launch_bounds__(256) void k_cpr_pvals(int Nb, int W, const int* __r
         }
     }
 }
+// The ELL columns of level 0 in stencil form (the SpMV's encoding, k_spmv_pipe_st): in the ILU ordering the rows of an aligned group of 32
+// share their column offsets, so a row needs one word of 4-bit indices (15 = padding: the row itself) into the group's table instead of W
+// column indices - a quarter of what the one-thread-per-row kernels of level 0 read.  The table entries travel lane to lane: every lane of
+// a wavefront must get here (rows past the end are clamped, their results not stored).
+struct EllStencil {
+    const unsigned* __restrict__ word;   // NULL: explicit columns
+    const int* __restrict__ table;
+};
+struct EllCols {
+    unsigned w;
+    int tab, i, half;
+    __device__ __forceinline__ EllCols(const EllStencil S, int i_) : i(i_), half((int)(threadIdx.x & 32u)) {
+        w = S.word[i];
+        tab = S.table[(size_t)(i >> 5) * 16 + (threadIdx.x & 15u)];
+    }
+    __device__ __forceinline__ int col(int j) const {
+        const int nib = (int)((w >> (4 * j)) & 15u);
+        const int off = __shfl(tab, half + nib, 64);
+        return nib != 15 ? i + off : i;
+    }
+};
 // r = d - A v for v = (0, x_p, 0): of every block only its pressure column meets a non-zero, so the row sums of
 // BCRSMatrix::mv (y_i = 0, then block by block in ascending column order, each component adding its three products) reduce
 // to the products with x_p - adding the +-0 products of the two other columns changes no bit of a sum that started at +0.
 // One thread per row on the ELL image of the pressure columns (padding entries are 0 * x_i).  Replaces a full SpMV (579 MB)
 // and the subtraction kernel behind it by one pass over 196 MB of matrix data.
+template <bool ST>
 __global__ __launch_bounds__(256) void k_cpr_presid(int n, int W, const int* __restrict__ ecol, const double* __restrict__ pcol, const double* __restrict__ d,
-                                                    const double* __restrict__ xp, double* __restrict__ r, const double* __restrict__ done) {
+                                                    const double* __restrict__ xp, double* __restrict__ r, const double* __restrict__ done, const EllStencil S) {
     CPR_DONE_CHECK
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
+    const int i0 = blockIdx.x * blockDim.x + threadIdx.x;
+    if (!ST && i0 >= n) return;
+    const int i = i0 < n ? i0 : n - 1;
     const size_t plane = (size_t)W * n;
     double y0 = 0.0, y1 = 0.0, y2 = 0.0;
+    if (ST) {
+        const EllCols C(S, i);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {   // W <= 8 in this form (the same for every lane)
+            if (j < W) {
+                const size_t e = (size_t)j * n + i;
+                const double x = xp[C.col(j)];
+                y0 += pcol[e] * x; y1 += pcol[plane + e] * x; y2 += pcol[2 * plane + e] * x;
+            }
+        }
+        if (i0 >= n) return;
+    } else {
 #pragma unroll 4
-    for (int j = 0; j < W; ++j) {
-        const size_t e = (size_t)j * n + i;
-        const double x = xp[ecol[e]];
-        y0 += pcol[e] * x; y1 += pcol[plane + e] * x; y2 += pcol[2 * plane + e] * x;
+        for (int j = 0; j < W; ++j) {
+            const size_t e = (size_t)j * n + i;
+            const double x = xp[ecol[e]];
+            y0 += pcol[e] * x; y1 += pcol[plane + e] * x; y2 += pcol[2 * plane + e] * x;
+        }
     }
     r[(size_t)i * BS] = d[(size_t)i * BS] - y0;
     r[(size_t)i * BS + 1] = d[(size_t)i * BS + 1] - y1;
@@ -317,14 +353,25 @@ __global__ __launch_bounds__(256) void k_cpr_jacobi(int n, int W, double omega, 
 }
 // r = b - A x, one thread per row (large levels; x = omega D^-1 b was stored by k_cpr_presmooth: the same bits the
 // lane-group kernel below forms on the fly)
+template <bool ST>
 __global__ __launch_bounds__(256) void k_cpr_resid(int n, int W, const int* __restrict__ ecol, const double* __restrict__ val,
-                                                   const double* __restrict__ b, const double* __restrict__ x, double* __restrict__ r, const double* __restrict__ done) {
+                                                   const double* __restrict__ b, const double* __restrict__ x, double* __restrict__ r, const double* __restrict__ done,
+                                                   const EllStencil S) {
     CPR_DONE_CHECK
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
+    const int i0 = blockIdx.x * blockDim.x + threadIdx.x;
+    if (!ST && i0 >= n) return;
+    const int i = i0 < n ? i0 : n - 1;
     double s = b[i];
+    if (ST) {
+        const EllCols C(S, i);
+#pragma unroll
+        for (int j = 0; j < 8; ++j)
+            if (j < W) s -= val[(size_t)j * n + i] * x[C.col(j)];
+        if (i0 >= n) return;
+    } else {
 #pragma unroll 4
-    for (int j = 0; j < W; ++j) s -= val[(size_t)j * n + i] * x[ecol[(size_t)j * n + i]];
+        for (int j = 0; j < W; ++j) s -= val[(size_t)j * n + i] * x[ecol[(size_t)j * n + i]];
+    }
     r[i] = s;
 }
 // Coarse levels (<= CPR_LPR_ROWS rows, rows of up to CPR_MAX_W entries): one thread per row walks W dependent
@@ -458,15 +505,25 @@ __global__ __launch_bounds__(256) void k_cpr_prolong(int n, double damp, const i
 }
 // vfine != NULL (level 0): the result goes straight into the block vector v = (0, x_p, 0) (moveToFineLevel: the pressure
 // component only) - k_cpr_prolong_fine's statement, one launch and one pass over x_p less
+template <bool ST>
 __global__ __launch_bounds__(256) void k_cpr_post(int n, int W, double omega, const int* __restrict__ ecol, const double* __restrict__ val,
                                                   const double* __restrict__ dinv, const double* __restrict__ b, const double* __restrict__ xp,
-                                                  double* __restrict__ xout, double* __restrict__ vfine, const double* __restrict__ done) {
+                                                  double* __restrict__ xout, double* __restrict__ vfine, const double* __restrict__ done, const EllStencil S) {
     CPR_DONE_CHECK
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
+    const int i0 = blockIdx.x * blockDim.x + threadIdx.x;
+    if (!ST && i0 >= n) return;
+    const int i = i0 < n ? i0 : n - 1;
     double s = b[i];
+    if (ST) {
+        const EllCols C(S, i);
+#pragma unroll
+        for (int j = 0; j < 8; ++j)
+            if (j < W) s -= val[(size_t)j * n + i] * xp[C.col(j)];
+        if (i0 >= n) return;
+    } else {
 #pragma unroll 4
-    for (int j = 0; j < W; ++j) s -= val[(size_t)j * n + i] * xp[ecol[(size_t)j * n + i]];
+        for (int j = 0; j < W; ++j) s -= val[(size_t)j * n + i] * xp[ecol[(size_t)j * n + i]];
+    }
     const double xo = xp[i] + omega * dinv[i] * s;
     xout[i] = xo;
     if (vfine) {
@@ -677,6 +734,35 @@ static int cpr_setup_structure_impl(opmhip_ctx* c) {
         pos = std::move(fpos);
     }
     const int nnz0 = (int)A.col.size();
+    {   // level 0's ELL columns in stencil form (EllStencil), where the pattern has it: single domain, rows of <= 8 entries, <= 15 offsets per group of 32 rows
+        static const bool off = [] { const char* e = std::getenv("OPMHIP_CPR_ELL_EXPLICIT"); return e && e[0] == '1'; }();   // A/B switch
+        bool ok = !off && P.Nghost == 0 && R.lv[0].W <= 8;
+        const int ng = (P.Nb + 31) / 32;
+        std::vector<unsigned> word(ok ? P.Nb : 0, 0xFFFFFFFFu);
+        std::vector<int> table(ok ? (size_t)16 * ng : 0, 0);
+        for (int g = 0; g < ng && ok; ++g) {
+            const int r0 = 32 * g, r1 = std::min(P.Nb, r0 + 32);
+            std::vector<int> offs;
+            for (int r = r0; r < r1; ++r)
+                for (int k = P.rowptr[r]; k < P.rowptr[r + 1]; ++k) offs.push_back(P.col[k] - r);
+            std::sort(offs.begin(), offs.end());
+            offs.erase(std::unique(offs.begin(), offs.end()), offs.end());
+            if (offs.size() > 15) { ok = false; break; }
+            for (size_t q = 0; q < offs.size(); ++q) table[(size_t)16 * g + q] = offs[q];
+            for (int r = r0; r < r1; ++r) {
+                unsigned w = 0xFFFFFFFFu;
+                for (int u = 0; u < P.rowptr[r + 1] - P.rowptr[r]; ++u) {
+                    const int idx = (int)(std::lower_bound(offs.begin(), offs.end(), P.col[P.rowptr[r] + u] - r) - offs.begin());
+                    w = (w & ~(0xFu << (4 * u))) | ((unsigned)idx << (4 * u));
+                }
+                word[r] = w;
+            }
+        }
+        if (ok) {
+            if ((rc = dev_upload(c, &R.lv[0].d_sword, word))) return rc;
+            if ((rc = dev_upload(c, &R.lv[0].d_stable, table))) return rc;
+        }
+    }
     if ((rc = dev_alloc(c, &R.d_pcol, (size_t)3 * R.lv[0].W * P.Nb))) return rc;     // pressure columns of the blocks, ELL, component-major
     OPMHIP_HIP(c, hipMemsetAsync(R.d_pcol, 0, (size_t)3 * R.lv[0].W * P.Nb * sizeof(double), c->stream));   // the padding stays 0
     if ((rc = cpr_weights(c))) return rc;
@@ -763,7 +849,7 @@ static void cpr_release_structure(opmhip_ctx* c) {
         dev_free(c, &L.d_ecol); dev_free(c, &L.d_rlen); dev_free(c, &L.d_diag); dev_free(c, &L.d_cpos);
         dev_free(c, &L.d_val); dev_free(c, &L.d_dinv); dev_free(c, &L.d_x2);
         dev_free(c, &L.d_agg); dev_free(c, &L.d_mptr); dev_free(c, &L.d_midx); dev_free(c, &L.d_mem4); dev_free(c, &L.d_gptr); dev_free(c, &L.d_gidx);
-        dev_free(c, &L.d_b); dev_free(c, &L.d_x); dev_free(c, &L.d_r);
+        dev_free(c, &L.d_b); dev_free(c, &L.d_x); dev_free(c, &L.d_r); dev_free(c, &L.d_sword); dev_free(c, &L.d_stable);
     }
     R.lv.clear();
     dev_free(c, &R.d_r); dev_free(c, &R.d_y); dev_free(c, &R.d_z); dev_free(c, &R.d_lu); dev_free(c, &R.d_pcol);
@@ -845,7 +931,11 @@ static const double* cpr_vcycle(opmhip_ctx* c, size_t l, double* fineOut = nullp
     else if (L.rm) hipLaunchKernelGGL(k_cpr_down_lpr<false>, g256(L.n * CPR_LPR), dim3(256), 0, c->stream, L.n, L.W, R.omega, L.d_ecol, L.d_val, L.d_dinv, L.d_b, L.d_x, L.d_r, (const int4*)nullptr, (const double*)nullptr, done);
     else {   // large levels: x first (it rides in the kernel that produced b), then the residual with ONE gathered value per entry (0.250 -> 0.243 ms per cycle against the fused form, which gathers dinv and b)
         if (!havex) hipLaunchKernelGGL(k_cpr_presmooth, g256(L.n), dim3(256), 0, c->stream, L.n, R.omega, L.d_dinv, L.d_b, L.d_x, done);
-        hipLaunchKernelGGL(k_cpr_resid, g256(L.n), dim3(256), 0, c->stream, L.n, L.W, L.d_ecol, L.d_val, L.d_b, L.d_x, L.d_r, done);
+        {
+            const EllStencil S{L.d_sword, L.d_stable};
+            if (S.word) hipLaunchKernelGGL(k_cpr_resid<true>, g256(L.n), dim3(256), 0, c->stream, L.n, L.W, L.d_ecol, L.d_val, L.d_b, L.d_x, L.d_r, done, S);
+            else hipLaunchKernelGGL(k_cpr_resid<false>, g256(L.n), dim3(256), 0, c->stream, L.n, L.W, L.d_ecol, L.d_val, L.d_b, L.d_x, L.d_r, done, S);
+        }
     }
     if (!cpr_forms_rhs(R, l + 1)) {
         const bool ride = cpr_presmooth_rides(R, l + 1);
@@ -856,7 +946,11 @@ static const double* cpr_vcycle(opmhip_ctx* c, size_t l, double* fineOut = nullp
     if (L.rm) hipLaunchKernelGGL(k_cpr_up_lpr, g256(L.n * CPR_LPR), dim3(256), 0, c->stream, L.n, L.W, R.omega, R.damp, L.d_ecol, L.d_val, L.d_dinv, L.d_agg, xc, L.d_b, L.d_x, L.d_x2, done);
     else {   // large levels: the prolonged iterate first (into the residual buffer, free by now), then one gathered value per entry
         hipLaunchKernelGGL(k_cpr_prolong, g256(L.n), dim3(256), 0, c->stream, L.n, R.damp, L.d_agg, xc, L.d_x, L.d_r, done);
-        hipLaunchKernelGGL(k_cpr_post, g256(L.n), dim3(256), 0, c->stream, L.n, L.W, R.omega, L.d_ecol, L.d_val, L.d_dinv, L.d_b, L.d_r, L.d_x2, fineOut, done);
+        {
+            const EllStencil S{L.d_sword, L.d_stable};
+            if (S.word) hipLaunchKernelGGL(k_cpr_post<true>, g256(L.n), dim3(256), 0, c->stream, L.n, L.W, R.omega, L.d_ecol, L.d_val, L.d_dinv, L.d_b, L.d_r, L.d_x2, fineOut, done, S);
+            else hipLaunchKernelGGL(k_cpr_post<false>, g256(L.n), dim3(256), 0, c->stream, L.n, L.W, R.omega, L.d_ecol, L.d_val, L.d_dinv, L.d_b, L.d_r, L.d_x2, fineOut, done, S);
+        }
         if (fineOut) return nullptr;
     }
     return L.d_x2;
@@ -885,7 +979,11 @@ void launch_cpr_apply(opmhip_ctx* c, const double* d, double* v) {
         else xp = R.lv[0].d_x2;   // k_cpr_post left the pressure solution there as well
         prof_end(c, ps);
         ps = prof_begin(c, PROF_VECTOR);
-        hipLaunchKernelGGL(k_cpr_presid, g256(P.Nb), dim3(256), 0, c->stream, P.Nb, R.lv[0].W, R.lv[0].d_ecol, R.d_pcol, d, xp, R.d_r, done);
+        {
+        const EllStencil S{R.lv[0].d_sword, R.lv[0].d_stable};
+        if (S.word) hipLaunchKernelGGL(k_cpr_presid<true>, g256(P.Nb), dim3(256), 0, c->stream, P.Nb, R.lv[0].W, R.lv[0].d_ecol, R.d_pcol, d, xp, R.d_r, done, S);
+        else hipLaunchKernelGGL(k_cpr_presid<false>, g256(P.Nb), dim3(256), 0, c->stream, P.Nb, R.lv[0].W, R.lv[0].d_ecol, R.d_pcol, d, xp, R.d_r, done, S);
+    }
         prof_end(c, ps);
         launch_ilu_apply(c, R.d_r, R.d_z, 1.0);                           // fine smoother: ILU0, relaxation 1
         ps = prof_begin(c, PROF_VECTOR);
@@ -897,7 +995,11 @@ void launch_cpr_apply(opmhip_ctx* c, const double* d, double* v) {
     prof_end(c, ps);
     // post-smoothing on the updated residual r = d - A (0, x_p, 0)
     ps = prof_begin(c, PROF_VECTOR);
-    hipLaunchKernelGGL(k_cpr_presid, g256(P.Nb), dim3(256), 0, c->stream, P.Nb, R.lv[0].W, R.lv[0].d_ecol, R.d_pcol, d, xp, R.d_r, done);
+    {
+        const EllStencil S{R.lv[0].d_sword, R.lv[0].d_stable};
+        if (S.word) hipLaunchKernelGGL(k_cpr_presid<true>, g256(P.Nb), dim3(256), 0, c->stream, P.Nb, R.lv[0].W, R.lv[0].d_ecol, R.d_pcol, d, xp, R.d_r, done, S);
+        else hipLaunchKernelGGL(k_cpr_presid<false>, g256(P.Nb), dim3(256), 0, c->stream, P.Nb, R.lv[0].W, R.lv[0].d_ecol, R.d_pcol, d, xp, R.d_r, done, S);
+    }
     prof_end(c, ps);
     launch_ilu_apply(c, R.d_r, v, 1.0, nullptr, xp, R.d_z);               // fine smoother: ILU0, relaxation 1; v = (0, x_p, 0) + its result
 }

@@ -201,6 +201,10 @@ struct CprLevelDev {
     int* d_mem4 = nullptr;                                         // members of every aggregate as four ints (-1: none), NULL if an aggregate has more: the coarse level then forms its right-hand side itself
     int *d_gptr = nullptr, *d_gidx = nullptr;                      // Galerkin gather lists for the next level's entries
     double *d_b = nullptr, *d_x = nullptr, *d_r = nullptr;         // level vectors
+    // level 0 of a single domain on a regular pattern: the ELL columns in stencil form (cpr.hip: EllStencil) - per row a word of 4-bit indices
+    // into the table of <= 15 column offsets its aligned group of 32 rows shares; NULL: the explicit column image d_ecol is read
+    unsigned* d_sword = nullptr;
+    int* d_stable = nullptr;
 };
 struct CprDev {
     bool structured = false, coarse_direct = true;
