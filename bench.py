@@ -42,7 +42,7 @@ sys.path.insert(0, os.path.join(ROOT, "tests"))
 import numpy as np  # noqa: E402
 
 DAY = 86400.0
-PROFILE_EVERY = 4
+PROFILE_EVERY = 3   # kernel scopes are recorded in every 3rd linear solve: the steady phase runs 2 Newton iterations per time step, a stride of 4 sampled only its first (harder) solves
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (/opt/skills/guides/MI355X_MICROARCH.md)
 
 
@@ -62,8 +62,10 @@ def device_info(torch, index):
 def alg_bytes(Nb, nnzb):
     """Algorithmic bytes per launch (SURVEY.md §8d / BASELINE.md §4), block size 3, double values, int32 indices."""
     return {
-        # block-CSR SpMV (SURVEY 8d) + the second operand of the scalar products that ride in the kernel (24 B per row)
-        "spmv": 76 * nnzb + 4 * (Nb + 1) + 48 * Nb + 24 * Nb,
+        # block-CSR SpMV exactly as SURVEY 8d counts it: 72-B blocks + 4-B column indices, row pointers, x and y (579.44 MB at 100^3)
+        "spmv": 76 * nnzb + 4 * (Nb + 1) + 48 * Nb,
+        # ... + the second operand of the BiCGStab scalar products when they ride in the kernel (24 B per row; no wells, no OPMHIP_DOTS_SEPARATE)
+        "spmv_operands": 76 * nnzb + 4 * (Nb + 1) + 48 * Nb + 24 * Nb,
         "ilu_apply": 76 * nnzb + 4 * (Nb + 1) + 4 * Nb + 72 * Nb,
         "ilu_factor": 2 * 72 * nnzb + 4 * nnzb + 4 * Nb,
         # per scope, three scopes per iteration: the p-update (4 passes), r-update (3), k_bicg_upd2 with both updates of x (8);
@@ -72,11 +74,26 @@ def alg_bytes(Nb, nnzb):
         "assemble": 85 * Nb + 12 * nnzb + 72 * nnzb + 24 * Nb,
         "iq_update": 24 * Nb + 544 * Nb,
         "convergence": 56 * Nb,
-        # CPR: one V(1,1) cycle of the pressure AMG = 3 matrix passes per level (residual twice, post-smoothing) over 12-byte
-        # scalar entries + ~10 vector passes, levels shrinking ~4x (geometric sum 4/3), + the restriction / prolongation of
-        # the block vectors (72 B per cell)
-        "cpr_amg": (3 * 12 * nnzb + 10 * 8 * Nb) * 4 / 3 + 72 * Nb,
+        # CPR V-cycle: cpr_amg_bytes() from the hierarchy's actual level sizes (set per context once the hierarchy exists)
+        "cpr_amg": None,
     }
+
+
+def cpr_amg_bytes(Nb, level_n, level_nnz):
+    """Algorithmic bytes of one application of the pressure AMG (csrc/cpr.hip: k_cpr_restrict_fine + cpr_vcycle, the scope the
+    profiler books under `cpr_amg`), from the hierarchy's own level sizes (opmhip_cpr_levels): per level that is not the coarsest
+    TWO matrix passes (residual on the way down, post-smoothing on the way up) over 8-byte values and 4-byte column indices of
+    the level's entries, and its vector passes - residual (b, x in, r out), restriction (r in; b and x of the coarser level out),
+    prolongation (aggregate map, x in, x' out, the coarse x in), post-smoothing (1/diag, b, x' in, x out): 84 B per row + 24 B per
+    coarse row; the restriction of the block residual in front (d and the weights in, b and x out: 64 B per cell); the coarsest
+    level: a dense triangular solve (8 n^2) when it has <= 128 rows, else 1 + 4 Jacobi sweeps (12 B per entry + 32 B per row each)."""
+    total = 64 * Nb
+    L = len(level_n)
+    for l in range(L - 1):
+        total += 2 * 12 * level_nnz[l] + 84 * level_n[l] + 24 * level_n[l + 1]
+    nl, zl = level_n[-1], level_nnz[-1]
+    total += 8 * nl * nl if nl <= 128 else 5 * (12 * zl + 32 * nl)
+    return total
 
 
 def make_simulation(pkg, model, report_step=10 * DAY):
@@ -344,6 +361,10 @@ def main():
     Nb, nnzb = case["Nb"], len(case["col"])
     B = alg_bytes(Nb, nnzb)
 
+    def use_cpr_of(mdl):
+        return getattr(mdl, "_bench_preconditioner", "ilu0") != "ilu0"
+    model._bench_preconditioner = a.preconditioner
+
     def barrier():
         device_sync()
         if dist is not None:
@@ -370,19 +391,32 @@ def main():
             elapsed = float(t.item())
         rep = sim.report
         kernels = {}
+        boundary_share = None
         if prof.get("spmv_boundary", (0, 0.0))[0]:   # decomposed runs: one product = interior launch + boundary launch
             prof["spmv"] = (prof["spmv"][0], prof["spmv"][1] + prof["spmv_boundary"][1])
-            kernels["spmv_boundary_share_of_time"] = round(prof["spmv_boundary"][1] / prof["spmv"][1], 4)
+            boundary_share = round(prof["spmv_boundary"][1] / prof["spmv"][1], 4)
         prof.pop("spmv_boundary", None)
+        Bm = dict(B)
+        if use_cpr_of(model):
+            lv = model.cpr_levels()
+            Bm["cpr_amg"] = cpr_amg_bytes(Nb, [int(v) for v in lv[0]], [int(v) for v in lv[1]])
+        # what the profiled solves were: solves = factorisations, BiCGStab iterations = products / 2 (two per iteration; a solve that
+        # stops on a first half adds one) - so that launches x avg_ms can be put beside the window's ms_per_step
+        solves_profiled = prof.get("ilu_factor", (0, 0.0))[0] // (2 if use_cpr_of(model) else 1)   # CPR: the value set-up of the hierarchy is a second scope of that class
+        its_profiled = prof.get("spmv", (0, 0.0))[0] / 2.0
         for name, (cnt, ms) in prof.items():
-            if cnt:
+            if cnt and Bm.get(name):
                 avg = ms / cnt
-                kernels[name] = {"launches": cnt, "avg_ms": round(avg, 5), "algorithmic_GBps": round(B[name] / avg / 1e6, 1)}
-                if name == "cpr_amg":
-                    kernels[name]["bytes_are_an_estimate"] = True   # a geometric estimate of the hierarchy's passes, not a count
-        ls_bytes = sum(B[k] * prof[k][0] for k in ("spmv", "ilu_apply", "ilu_factor", "vector"))
+                kernels[name] = {"launches": cnt, "avg_ms": round(avg, 5), "algorithmic_GBps": round(Bm[name] / avg / 1e6, 1),
+                                 "algorithmic_bytes_per_launch": int(Bm[name])}
+                if name in ("spmv", "ilu_apply", "vector", "cpr_amg"):
+                    kernels[name]["iterations_profiled"] = its_profiled
+                    kernels[name]["solves_profiled"] = solves_profiled
+        ls_bytes = sum(Bm[k] * prof[k][0] for k in ("spmv", "ilu_apply", "ilu_factor", "vector"))
         ls_ms = sum(prof[k][1] for k in ("spmv", "ilu_apply", "ilu_factor", "vector"))
-        return {"elapsed": elapsed, "steps": steps, "kernels": kernels,
+        return {"elapsed": elapsed, "steps": steps, "kernels": kernels, "spmv_boundary_share_of_time": boundary_share,
+                "profiled": {"every": PROFILE_EVERY, "solves": solves_profiled, "linear_iterations": its_profiled,
+                             "linear_iterations_per_profiled_solve": (its_profiled / solves_profiled) if solves_profiled else None},
                 "linear_iterations_per_newton": (rep.total_linear_iterations - rep0.total_linear_iterations) / steps,
                 "timesteps_completed": sim.timesteps_done - ts0, "timesteps_chopped": sim.timesteps_failed - tf0,
                 "time_steps_days": [round(h[0] / DAY, 3) for h in sim.history[h0:]],
@@ -415,7 +449,7 @@ def main():
                   "newton_iterations_per_s_global": S["steps"] / S["elapsed"], "value": S["steps"] * world / S["elapsed"],
                   "linear_iterations_per_newton": S["linear_iterations_per_newton"], "time_steps_days": S["time_steps_days"],
                   "timesteps_chopped": S["timesteps_chopped"], "linear_solve_GBps": S["linear_solve_GBps"], "report": S["report"],
-                  "kernels": S["kernels"]}
+                  "kernels": S["kernels"], "profiled": S["profiled"]}
 
     if a.steady_after > 0 and a.steady_steps > 0:
         steady = guarded("steady-state window", steady_window)
@@ -426,6 +460,7 @@ def main():
         def run():
             nonlocal sim, model
             model2 = pkg.capi.HipModel(case, **dict(skw, preconditioner=prec, **over))
+            model2._bench_preconditioner = prec
             model2.set_state(case["pv"], case["meaning"])
             model2.set_source(src)
             sim_main, model_main = sim, model
@@ -436,7 +471,7 @@ def main():
                     sim.next_newton_iteration()      # includes the one-time host-side aggregation of the pressure AMG
                 C1 = timed_window(a.steps)
                 side = {"value": C1["steps"] / C1["elapsed"], "ms_per_step": 1e3 * C1["elapsed"] / C1["steps"], "steps": C1["steps"],
-                        "linear_iterations_per_newton": C1["linear_iterations_per_newton"], "report": C1["report"], "kernels": C1["kernels"],
+                        "linear_iterations_per_newton": C1["linear_iterations_per_newton"], "report": C1["report"], "kernels": C1["kernels"], "profiled": C1["profiled"],
                         "amg_levels": model2.cpr_levels()[0]}
                 if a.steady_after > 0 and a.steady_steps > 0:
                     done = a.warmup + a.steps
@@ -446,7 +481,8 @@ def main():
                     C2 = timed_window(a.steady_steps)
                     side["steady_state"] = {"from_newton_iteration": done, "steps": C2["steps"], "value": C2["steps"] / C2["elapsed"],
                                             "ms_per_step": 1e3 * C2["elapsed"] / C2["steps"],
-                                            "linear_iterations_per_newton": C2["linear_iterations_per_newton"], "timesteps_chopped": C2["timesteps_chopped"]}
+                                            "linear_iterations_per_newton": C2["linear_iterations_per_newton"], "timesteps_chopped": C2["timesteps_chopped"],
+                                            "kernels": C2["kernels"], "profiled": C2["profiled"]}
                 return side
             finally:
                 sim, model = sim_main, model_main
@@ -464,6 +500,7 @@ def main():
     stream_ms = stream.get("ms")
     stream_GBps = 72.0 * nnzb / stream_ms / 1e6 if stream_ms else None
 
+    dots_separate = os.environ.get("OPMHIP_DOTS_SEPARATE", "0") not in ("", "0")
     sp = kernels.get("spmv", {"avg_ms": float("nan"), "algorithmic_GBps": float("nan")})
     ok = sp["algorithmic_GBps"] == sp["algorithmic_GBps"]
     traffic, traffic_src = (None, "single-GPU 100^3 line-colouring runs only")
@@ -490,6 +527,8 @@ def main():
         "linear_solve_GBps": W["linear_solve_GBps"],
         "report": W["report"],
         "kernels": kernels,
+        "profiled": W["profiled"],
+        "spmv_boundary_share_of_time": W["spmv_boundary_share_of_time"],
         "steady_state": steady,
         # same case, CPR instead of ILU0 as the preconditioner of BiCGStab (extra information; `value` is the run above):
         # "cpr" is Flow's cpr = cpr_trueimpes, "cpr_quasiimpes" the quasi-IMPES variant
@@ -508,10 +547,13 @@ def main():
                      "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": (sp["algorithmic_GBps"] / HBM_PEAK_GBS) if ok else None,
                      "frac_of_stream_ceiling": (sp["algorithmic_GBps"] / stream_GBps) if (ok and stream_GBps) else None,
                      "traffic": traffic, "traffic_unit": "bytes per launch (L2 fabric side; FETCH_SIZE x 2 + WRITE_SIZE, KiB -> B)",
-                     "traffic_source": traffic_src, "avg_launch_ms": sp["avg_ms"], "algorithmic_bytes_per_launch": B["spmv"],
-                     # the BiCGStab scalar products behind a product ride in the kernel: its operand set is SURVEY 8d's plain
-                     # SpMV (579.44 MB at 100^3) + the second operand of the products (24 MB), both in algorithmic_bytes_per_launch
-                     "scalar_products": "folded into the kernel (one partial sum per workgroup)"},
+                     "traffic_source": traffic_src, "avg_launch_ms": sp["avg_ms"],
+                     # achieved / frac are quoted on SURVEY 8d's plain block-SpMV bytes (579.44 MB at 100^3).  The BiCGStab scalar
+                     # products behind a product ride in the kernel (no wells here, unless OPMHIP_DOTS_SEPARATE is set): their
+                     # second operand (24 B per row) is part of what the kernel reads but not of the figure the fraction is taken of
+                     "algorithmic_bytes_per_launch": B["spmv"],
+                     "operand_bytes_per_launch": B["spmv"] if dots_separate else B["spmv_operands"],
+                     "scalar_products": "k_dots behind every product (OPMHIP_DOTS_SEPARATE)" if dots_separate else "folded into the kernel (one partial sum per workgroup)"},
     }
     if rank == 0 and world == 1 and not a.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(pkg, case, src, nnzb)

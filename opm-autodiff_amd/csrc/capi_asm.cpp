@@ -139,7 +139,12 @@ int opmhip_set_static(opmhip_ctx* c, const double* trans, const double* area, co
         if ((rc = upload_cells(c, &A.d_depth, depth))) return rc;
         if (pvtnum) { if ((rc = upload_cells(c, &A.d_pvtnum, pvtnum))) return rc; } else A.d_pvtnum = nullptr;
         if (satnum) { if ((rc = upload_cells(c, &A.d_satnum, satnum))) return rc; } else A.d_satnum = nullptr;
-        if (rsmax) { if ((rc = upload_cells(c, &A.d_rsmax, rsmax))) return rc; } else A.d_rsmax = nullptr;
+        // DRSDT in force (opmhip_set_composition_change_limits): the cap array belongs to the library - lastRs + rate * dt, written by
+        // begin_time_step - and must neither be overwritten nor withdrawn here
+        if (A.drsdt_on) {
+            if (rsmax) return fail(c, OPMHIP_INVALID_ARGUMENT, "set_static: rsmax handed in while DRSDT is in force (opmhip_set_composition_change_limits owns the dissolution cap)");
+        } else if (rsmax) { if ((rc = upload_cells(c, &A.d_rsmax, rsmax))) return rc; }
+        else { OPMHIP_HIP(c, hipStreamSynchronize(c->stream)); dev_free(c, &A.d_rsmax); }
         if (!A.d_pv) {
             const size_t Nb = P.Nloc;  // per-cell state includes the ghost cells
             if ((rc = dev_alloc(c, &A.d_pv, Nb * 3))) return rc;
@@ -276,7 +281,10 @@ int opmhip_set_problem_extras(opmhip_ctx* c, const double* rvmax, const int* roc
         int rc;
         // an array that is withdrawn goes back to the allocator (an assembly enqueued earlier may still read it: sync first)
         if (!rvmax || !rocknum || !overburden) OPMHIP_HIP(c, hipStreamSynchronize(c->stream));
-        if (rvmax) { if ((rc = upload_cells(c, &A.d_rvmax, rvmax))) return rc; } else dev_free(c, &A.d_rvmax);
+        // DRVDT in force: the cap array is the library's (lastRv + rate * dt); re-sending rocknum / overburden must leave it alone
+        if (A.drvdt_on) {
+            if (rvmax) return fail(c, OPMHIP_INVALID_ARGUMENT, "set_problem_extras: rvmax handed in while DRVDT is in force (opmhip_set_composition_change_limits owns the vaporisation cap)");
+        } else if (rvmax) { if ((rc = upload_cells(c, &A.d_rvmax, rvmax))) return rc; } else dev_free(c, &A.d_rvmax);
         if (rocknum) { if ((rc = upload_cells(c, &A.d_rocknum, rocknum))) return rc; } else dev_free(c, &A.d_rocknum);
         if (overburden) { if ((rc = upload_cells(c, &A.d_overburden, overburden))) return rc; } else dev_free(c, &A.d_overburden);
         if (A.state_set) {   // the cached intensive quantities depend on these arrays
@@ -692,6 +700,8 @@ int opmhip_begin_time_step(opmhip_ctx* c, double dt) {
         AsmDev& A = c->asmb;
         if (!(dt > 0.0)) return fail(c, OPMHIP_INVALID_ARGUMENT, "begin_time_step: dt must be positive");
         const bool limits = A.drsdt_on || A.drvdt_on;
+        if ((A.drsdt_on && (!A.d_rsmax || !A.d_lastRs)) || (A.drvdt_on && (!A.d_rvmax || !A.d_lastRv)))
+            return fail(c, OPMHIP_UNKNOWN_ERROR, "begin_time_step: DRSDT / DRVDT is in force but its cap array is gone (internal error)");
         if (!limits && !A.d_minpo && !A.d_maxso && !A.d_maxsw) return OPMHIP_SUCCESS;
         if (!A.state_set) return fail(c, OPMHIP_NOT_READY, "begin_time_step before set_state");
         OPMHIP_HIP(c, hipSetDevice(c->device));

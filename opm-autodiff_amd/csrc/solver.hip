@@ -2119,7 +2119,10 @@ static int read_scalars(opmhip_ctx* c) {
     OPMHIP_HIP(c, hipStreamSynchronize(c->stream));
     return OPMHIP_SUCCESS;
 }
-static int enqueue_half(opmhip_ctx* c, int h) {
+// part: HALF_ALL, or the half iteration in two pieces - HALF_PRECOND (everything up to and including the preconditioner
+// application: no communication) and HALF_REST (operator with its halo exchange, scalar products with their all-reduces, updates)
+enum { HALF_ALL = 0, HALF_PRECOND = 1, HALF_REST = 2 };
+static int enqueue_half(opmhip_ctx* c, int h, int part = HALF_ALL) {
     const Pattern& P = c->pat;
     const int n = P.Nb * BS, nb = vec_blocks(n);
     // The p-update and the (r, x)-update are kernels of their own: riding in the first colour's light sweep of the
@@ -2128,13 +2131,16 @@ static int enqueue_half(opmhip_ctx* c, int h) {
     const bool cpr = use_cpr(c);
     int rc, ps;
     if ((h & 1) == 0) {  // first half: p, y = M^-1 p, v = A y, alpha, x += alpha y, r -= alpha v, |r|
-        if (h > 0) {
-            ps = prof_begin(c, PROF_VECTOR);
-            hipLaunchKernelGGL(k_bicg_pupdate, dim3(nb), dim3(VB), 0, c->stream, n, c->d_scal, c->d_p, c->d_v, c->d_r);
-            prof_end(c, ps);
+        if (part != HALF_REST) {
+            if (h > 0) {
+                ps = prof_begin(c, PROF_VECTOR);
+                hipLaunchKernelGGL(k_bicg_pupdate, dim3(nb), dim3(VB), 0, c->stream, n, c->d_scal, c->d_p, c->d_v, c->d_r);
+                prof_end(c, ps);
+            }
+            if (cpr) launch_cpr_apply(c, c->d_p, c->d_pw);
+            else launch_ilu_apply(c, c->d_p, c->d_pw, -1.0, &c->minv_scale);   // d_pw without the relaxation factor: its readers apply it
         }
-        if (cpr) launch_cpr_apply(c, c->d_p, c->d_pw);
-        else launch_ilu_apply(c, c->d_p, c->d_pw, -1.0, &c->minv_scale);   // d_pw without the relaxation factor: its readers apply it
+        if (part == HALF_PRECOND) return OPMHIP_SUCCESS;
         if ((rc = launch_spmv(c, c->d_pw, c->d_v, 1, c->d_rw, c->minv_scale, true))) return rc;  // with copyOwnerToAll before the operator (ParallelOverlappingILU0.hpp:897)
         ps = prof_begin(c, PROF_VECTOR);
         if ((rc = finalize(c, FIN_ALPHA, dot_count(c)))) return rc;
@@ -2142,8 +2148,11 @@ static int enqueue_half(opmhip_ctx* c, int h) {
         if ((rc = finalize(c, FIN_NORM, nb, h))) return rc;
         prof_end(c, ps);
     } else {             // second half: z = M^-1 r, t = A z, omega, x += omega z, r -= omega t, |r|, rho, beta
-        if (cpr) launch_cpr_apply(c, c->d_r, c->d_s);
-        else launch_ilu_apply(c, c->d_r, c->d_s, -1.0, &c->minv_scale);
+        if (part != HALF_REST) {
+            if (cpr) launch_cpr_apply(c, c->d_r, c->d_s);
+            else launch_ilu_apply(c, c->d_r, c->d_s, -1.0, &c->minv_scale);
+        }
+        if (part == HALF_PRECOND) return OPMHIP_SUCCESS;
         if ((rc = launch_spmv(c, c->d_s, c->d_t, 2, c->d_r, c->minv_scale, true))) return rc;
         ps = prof_begin(c, PROF_VECTOR);
         if ((rc = finalize(c, FIN_OMEGA, dot_count(c)))) return rc;
@@ -2213,10 +2222,16 @@ int bicgstab(opmhip_ctx* c, opmhip_result* res) {
     double norm = 0.0, norm_0 = 0.0;
     float it = maxit + 0.5f;
     size_t mark_next = c->prof.used;  // first profile scope of the half iteration in flight beyond the one being waited for
+    // Decomposed runs: only the communication-free head of half iteration h + 1 (p-update, preconditioner application: 0.14 ms and
+    // more of device work, enough to cover the host's look at h) is enqueued ahead of the stopping rule of h; its operator, with
+    // the halo exchange, and its all-reduces follow once the (all-reduced, hence rank-independent) norm says the solve goes on.  A
+    // solve that stops therefore posts NO collective beyond the stopping point - enqueueing the whole half ahead cost every solve
+    // two halo exchanges and two all-reduces on a latency-bound path (round-3 review).
+    const bool split = c->comm.nranks > 1;
     if (nhalves > 0 && (rc = enqueue_half(c, 0))) return rc;
     for (int h = 0; h < nhalves; ++h) {
         mark_next = c->prof.used;
-        if (h + 1 < nhalves && (rc = enqueue_half(c, h + 1))) return rc;
+        if (h + 1 < nhalves && (rc = enqueue_half(c, h + 1, split ? HALF_PRECOND : HALF_ALL))) return rc;
         if ((rc = wait_half(c, h, &norm, &norm_0))) return rc;
         if (!std::isfinite(norm)) {  // a singular pivot: nothing can converge any more (the caller reports it)
             prof_flush(c);
@@ -2230,6 +2245,7 @@ int bicgstab(opmhip_ctx* c, opmhip_result* res) {
             if ((h & 1) == 0) hipLaunchKernelGGL(k_bicg_xhalf, dim3(nb), dim3(VB), 0, c->stream, n, c->d_scal, c->d_x, c->d_pw, c->minv_scale);
             break;
         }
+        if (split && h + 1 < nhalves && (rc = enqueue_half(c, h + 1, HALF_REST))) return rc;
     }
     if (nhalves <= 0) {
         if ((rc = read_scalars(c))) return rc;

@@ -183,3 +183,28 @@ def test_argument_errors(pkg):
     m.begin_time_step(86400.0)                     # nothing in force: a no-op
     with pytest.raises(pkg.capi.OpmHipError):
         m.begin_time_step(0.0)
+
+
+def test_extras_resent_while_the_limits_are_in_force(pkg, orc):
+    """ the DRSDT / DRVDT cap arrays belong to the library once opmhip_set_composition_change_limits is in force:
+    re-sending rocknum through opmhip_set_problem_extras (rvmax = NULL) - a plausible host sequence for water compaction -
+    must neither free nor null them; caller-owned caps are refused; the next begin_time_step works and equals the oracle"""
+    case = helpers.wetgas_case(pkg, 6, 5, 6, rocktab=helpers.ROCKTAB_2, heterogeneous=True)
+    case["rocknum"] = (np.arange(case["Nb"]) % 2).astype(np.int32)
+    src = pkg.decks.five_spot_source(case, rate_sm3_per_day=20.0)
+    m, o = both(pkg, orc, case)
+    for q in (m, o):
+        q.set_source(src)
+        q.set_composition_change_limits([1.0e-6], [1], [2.0e-12])
+    m.set_problem_extras(None, case["rocknum"], None)          # rvmax = NULL while DRVDT is on: the library's array stays
+    with pytest.raises(pkg.capi.OpmHipError):
+        m.set_problem_extras(np.full(case["Nb"], 1e-4), case["rocknum"], None)
+    dt = 0.3 * 86400.0
+    for q in (m, o):
+        q.begin_time_step(dt)
+    assert np.array_equal(m.iq(), o.iq())
+    jm, rm = m.assemble(dt, 0)
+    jo, ro = o.assemble(dt, 0)
+    assert np.array_equal(jm, jo) and np.array_equal(rm, ro)
+    ta, tb = m.trackers(), o.trackers()
+    assert np.array_equal(ta[0], tb[0]) and np.array_equal(ta[1], tb[1])
