@@ -20,7 +20,8 @@
 extern "C" {
 #endif
 
-#define OPMHIP_ABI_VERSION 5 /* 5: opmhip_set_water_compaction, opmhip_get_max_water_saturation, opmhip_relative_change, opmhip_cpr_recreate (additive);
+#define OPMHIP_ABI_VERSION 6 /* 6: opmhip_set_hysteresis, opmhip_get_hysteresis, opmhip_set_hysteresis_params (additive);
+                               * 5: opmhip_set_water_compaction, opmhip_get_max_water_saturation, opmhip_relative_change, opmhip_cpr_recreate (additive);
                                * 4: opmhip_config names chain_length, spmv_pipe_wgs, preconditioner (were reserved[0..2]);
                                *    opmhip_set_endpoint_scaling, opmhip_sat_end_points, opmhip_sat_probe, opmhip_synchronize, opmhip_comm_info,
                                *    opmhip_set_composition_change_limits, opmhip_set_irreversible_compaction, opmhip_set_vappars, opmhip_begin_time_step;
@@ -333,8 +334,8 @@ int opmhip_get_max_water_saturation(opmhip_ctx* ctx, double* max_water_saturatio
  * updateMaxWaterSaturation_, updateMinPressure_, updateMaxOilSaturation_, the DRSDT / DRVDT caps of this step, invalidateAndUpdateIntensiveQuantities(0); and, since
  * recycleFirstIterationStorage() is false with DRSDT / DRVDT (:1758-1765), the old time level's storage term formed with ITS
  * caps (time index 1: lastRs / lastRv without the increment) - opmhip_assemble(iteration 0) then leaves it alone.  Call it
- * after opmhip_advance_time_level, and again before every retry of a chopped step.  A no-op (SUCCESS) when neither feature
- * is in force. */
+ * after opmhip_advance_time_level, and again before every retry of a chopped step.  Also updateHysteresis_ (:1060) when
+ * opmhip_set_hysteresis is in force.  A no-op (SUCCESS) when none of these features is in force. */
 int opmhip_begin_time_step(opmhip_ctx* ctx, double dt);
 
 /* the trackers, for restart files and tests: lastRs, lastRv, minimum oil pressure, maximum oil saturation per cell (natural
@@ -380,6 +381,31 @@ int opmhip_set_endpoint_scaling(opmhip_ctx* ctx, const opmhip_endpoint_scaling* 
 /* the end points of the tables of saturation region sat_region (opm-common's satfunc end-point extraction, restated):
  * out[OPMHIP_EPS_COUNT].  Needs opmhip_set_fluid only. */
 int opmhip_sat_end_points(opmhip_ctx* ctx, int sat_region, double* out);
+
+/* replaces: relative-permeability hysteresis - SATOPTS HYSTER / EHYSTR / IMBNUM: the per-cell material-law parameters the
+ * EclMaterialLawManager serves (ebos/eclproblem.hh:1490-1498 materialLawParams) with EclHysteresisTwoPhaseLaw as the two-phase
+ * law, and their update at the start of a time step (updateHysteresis_, :1060, 2603-2626, done by opmhip_begin_time_step).
+ * kr_model = EHYSTR item 2: 0 = Carlson's model for the non-wetting phases (oil in the oil-water system, gas in the gas-oil
+ * system), wetting phases on their drainage curves; 1 = the same with the wetting phases on their IMBIBITION curves; other
+ * values are refused as the reference refuses them (opm/simulators/utils/PartiallySupportedFlowKeywords.cpp:299-302: "only
+ * Carlson Hysteresis Models supported (0 or 1)"; capillary pressures stay on the drainage curves, :502-507); negative = not in
+ * force.  imbnum: per cell (natural order, Nb + Nghost) the saturation region (0-based, of opmhip_fluid's SWOF / SGOF tables)
+ * that holds the imbibition curves; the drainage curves are those of set_static's satnum.  imb (nullable; only with
+ * opmhip_set_endpoint_scaling in force): its points[] are the scaled end points of the IMBIBITION curves (ISWL, ISWCR, ...;
+ * NULL entries = the imbibition tables' own), its flags are ignored (those of the drainage scaling apply).  The state per cell
+ * and two-phase system - the smallest wetting saturation seen at the start of a time step (krnSwMdc; restart vectors KRNSW_OW /
+ * KRNSW_GO, ebos/eclwriter.hh:285-288) and the imbibition curve's shift (deltaSwImbKrn) - starts at "nothing seen" (2, 0);
+ * the first opmhip_begin_time_step sets it from the state then present, as the reference's first beginTimeStep does.  Needs a
+ * context with the extended record (a fluid with PVTG, ROCKTAB or pc_scaling) and set_static.  The law itself lives in
+ * opm-material, which is not in the reference tree: restated from its published form, UNVERIFIED (oracle/fluid.hpp). */
+int opmhip_set_hysteresis(opmhip_ctx* ctx, int kr_model, const int* imbnum, const opmhip_endpoint_scaling* imb);
+/* the hysteresis state per cell (natural order, Nb + Nghost; any NULL): turning point and shift of the oil-water system, of
+ * the gas-oil system (what eclwriter writes as KRNSW_OW / KRNSW_GO - PCSWM_* are equal to them: the reference updates both with
+ * the same saturation) */
+int opmhip_get_hysteresis(opmhip_ctx* ctx, double* krn_sw_mdc_ow, double* delta_sw_imb_krn_ow, double* krn_sw_mdc_go, double* delta_sw_imb_krn_go);
+/* replaces: initHysteresisParams of a restarted run (ebos/ecloutputblackoilmodule.hh:569-589 -> setOilWaterHysteresisParams /
+ * setGasOilHysteresisParams): the turning points handed in, the shifts recomputed from them */
+int opmhip_set_hysteresis_params(opmhip_ctx* ctx, const double* krn_sw_mdc_ow, const double* krn_sw_mdc_go);
 
 /* Point evaluation of the fluid-system and saturation functions the assembly uses, ON THE DEVICE, for host-side setup
  * code (equilibration, ebos/equil/initstateequil.hh) and for tests that pin these functions against the reference's

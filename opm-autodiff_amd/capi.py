@@ -372,6 +372,9 @@ def _bind_assembly(L):
     L.opmhip_sat_probe.argtypes = [vp, C.c_int, vp, C.c_int, vp, vp, vp]
     L.opmhip_gas_probe.argtypes = [vp, C.c_int, C.c_int, vp, vp, vp]
     L.opmhip_iq_fields.argtypes = [vp]
+    L.opmhip_set_hysteresis.argtypes = [vp, C.c_int, vp, vp]
+    L.opmhip_get_hysteresis.argtypes = [vp, vp, vp, vp, vp]
+    L.opmhip_set_hysteresis_params.argtypes = [vp, vp, vp]
 
 
 class HipFluid(HipSolver):
@@ -502,6 +505,30 @@ class HipModel(HipSolver):
             return
         s, keep = endpoint_scaling_struct(es)
         self._check(lib().opmhip_set_endpoint_scaling(self._h, C.byref(s)))
+
+    def set_hysteresis(self, kr_model, imbnum=None, imb_endscale=None):
+        """relative-permeability hysteresis (SATOPTS HYSTER): kr_model = EHYSTR item 2 (0 | 1; None / negative = off), imbnum = per
+        cell imbibition saturation region (0-based), imb_endscale = dict of per-cell scaled end points of the imbibition curves (any
+        of capi.EPS_FIELDS, absent = the imbibition tables' own; only with set_endpoint_scaling in force)"""
+        if kr_model is None or kr_model < 0:
+            self._check(lib().opmhip_set_hysteresis(self._h, -1, None, None))
+            return
+        imb = _i32(imbnum)
+        if imb_endscale is None:
+            self._check(lib().opmhip_set_hysteresis(self._h, int(kr_model), _ptr(imb), None))
+            return
+        s, keep = endpoint_scaling_struct(imb_endscale)
+        self._check(lib().opmhip_set_hysteresis(self._h, int(kr_model), _ptr(imb), C.byref(s)))
+
+    def hysteresis(self):
+        """(krnSwMdc, deltaSwImbKrn) of the oil-water system, then of the gas-oil system: four per-cell arrays (natural order)"""
+        out = [np.empty(self.Nloc) for _ in range(4)]
+        self._check(lib().opmhip_get_hysteresis(self._h, *[_ptr(a) for a in out]))
+        return tuple(a[:self.Nb] for a in out) if self.Nghost == 0 else tuple(out)
+
+    def set_hysteresis_params(self, sw_ow, sw_go):
+        a, b = _f64(sw_ow), _f64(sw_go)
+        self._check(lib().opmhip_set_hysteresis_params(self._h, _ptr(a), _ptr(b)))
 
     def set_pcw(self, pcw):
         """per-cell scaled maximum of the oil-water capillary pressure (PCW, or SWATINIT through equil.equilibrate's pcw_scale

@@ -255,6 +255,14 @@ struct CellStatic {
     const double* wcdata;
     const double* eps;                  // extended layout: scaled end points per cell, field-major [EPS_COUNT][ncell] (NULL = no end-point scaling)
     int epscfg;                         // EclEpsConfig: bit 0 saturation scaling, 1 three-point, 2-3 krw, 4-5 kro, 6-7 krg mode, 8 pcw, 9 pcg
+    // extended layout: relative-permeability hysteresis (SATOPTS HYSTER; NULL = not in force): per cell the turning point and the
+    // imbibition curve's shift of the oil-water and of the gas-oil system, field-major [4][ncell] (krnSwMdc_ow, deltaSwImbKrn_ow,
+    // krnSwMdc_go, deltaSwImbKrn_go), the imbibition saturation region (IMBNUM) and, with end-point scaling in force, the
+    // scaled end points of the imbibition curves [EPS_COUNT][ncell] (NULL: the imbibition tables' own); hystModel = EHYSTR item 2
+    const double* hyst;
+    const int* imbnum;
+    const double* epsImb;
+    int hystModel;
     double* invb;                       // packed 1/b_w, 1/b_o, 1/b_g per cell, written beside the record (convergence check)
     int ncell;                          // cells of the intensive-quantity cache (owned + ghost): the stride between its fields
 };
@@ -352,6 +360,99 @@ template <class E, class DP> __device__ __forceinline__ void rel_perms_eps(DP B,
         } else kr[1] = kro2;
     } else kr[1] = (Sg * kro_go + (Sw - SwcoS) * kro_ow) / (Sw_ow - SwcoS);
 }
+// ---- relative-permeability hysteresis (oracle/fluid.hpp: SatFunc::curve / curveInv / hystSee / relativePermeabilitiesHyst - same
+//      statements, same order; EclHysteresisTwoPhaseLaw of opm-material restated, UNVERIFIED vs upstream) -------------------------
+enum { KRW_OW = 0, KRN_OW = 1, KRW_GO = 2, KRN_GO = 3 };
+// one relative-permeability curve of a saturation region at the (scaled) wetting saturation S of its two-phase system
+template <class E, class DP> __device__ __forceinline__ E sat_curve(DP B, const SatRegionDesc& Sd, int kind, const E& S, bool scaled, int cfg, const double* u, const double* s) {
+    const DP x = B + (kind <= KRN_OW ? Sd.sw_x : Sd.so_x);
+    const DP y = B + (kind == KRW_OW ? Sd.krw : kind == KRN_OW ? Sd.krow : kind == KRW_GO ? Sd.krog : Sd.krg);
+    const int n = kind <= KRN_OW ? Sd.nw : Sd.ng;
+    if (!scaled) return pwlin<E, DP>(x, y, n, S);
+    const EpsTriple ut = kind == KRW_OW ? eps_krw_ow(u) : kind == KRN_OW ? eps_krn_ow(u) : kind == KRW_GO ? eps_krw_go(u) : eps_krn_go(u);
+    const EpsTriple st = kind == KRW_OW ? eps_krw_ow(s) : kind == KRN_OW ? eps_krn_ow(s) : kind == KRW_GO ? eps_krw_go(s) : eps_krn_go(s);
+    const E k = pwlin<E, DP>(x, y, n, eps_to_unscaled(cfg, S, ut, st));
+    if (kind == KRW_OW) return eps_vertical_krw((cfg >> 2) & 3, S, k, st, u[EPS_KRWR], u[EPS_MAXKRW], s[EPS_KRWR], s[EPS_MAXKRW]);
+    if (kind == KRN_OW) return eps_vertical_krn((cfg >> 4) & 3, S, k, st, u[EPS_KRORW], u[EPS_MAXKROW], s[EPS_KRORW], s[EPS_MAXKROW]);
+    if (kind == KRW_GO) return eps_vertical_krw((cfg >> 4) & 3, S, k, st, u[EPS_KRORG], u[EPS_MAXKROG], s[EPS_KRORG], s[EPS_MAXKROG]);
+    return eps_vertical_krn((cfg >> 6) & 3, S, k, st, u[EPS_KRGR], u[EPS_MAXKRG], s[EPS_KRGR], s[EPS_MAXKRG]);
+}
+// PwLin::inv: the abscissa at which a piecewise-linear curve takes the value yv
+template <class DP> __device__ __forceinline__ double pwlin_inv(DP x, DP y, int n, double yv) {
+    if (y[0] > y[n - 1]) {
+        if (yv >= y[0]) return x[0];
+        if (yv <= y[n - 1]) return x[n - 1];
+        int lo = 0, hi = n - 1;
+        while (lo + 1 < hi) {
+            const int mid = (lo + hi) / 2;
+            if (y[mid] >= yv) lo = mid; else hi = mid;
+        }
+        const double m = (x[lo + 1] - x[lo]) / (y[lo + 1] - y[lo]);
+        return x[lo] + (yv - y[lo]) * m;
+    }
+    if (yv <= y[0]) return x[0];
+    if (yv >= y[n - 1]) return x[n - 1];
+    int lo = 0, hi = n - 1;
+    while (lo + 1 < hi) {
+        const int mid = (lo + hi) / 2;
+        if (y[mid] <= yv) lo = mid; else hi = mid;
+    }
+    const double m = (x[lo + 1] - x[lo]) / (y[lo + 1] - y[lo]);
+    return x[lo] + (yv - y[lo]) * m;
+}
+// SatFunc::curveInv: the (scaled) wetting saturation at which non-wetting curve `kind` takes the value k
+template <class DP> __device__ __forceinline__ double sat_curve_inv(DP B, const SatRegionDesc& Sd, int kind, double k, bool scaled, int cfg, const double* u, const double* s) {
+    const double Su = kind == KRN_OW ? pwlin_inv<DP>(B + Sd.sw_x, B + Sd.krow, Sd.nw, k) : pwlin_inv<DP>(B + Sd.so_x, B + Sd.krg, Sd.ng, k);
+    if (!scaled || !(cfg & 1)) return Su;
+    const EpsTriple ut = kind == KRN_OW ? eps_krn_ow(u) : eps_krn_go(u);
+    const EpsTriple st = kind == KRN_OW ? eps_krn_ow(s) : eps_krn_go(s);
+    if (cfg & 2) {   // eps_unscaled_to_scaled_three_point
+        if (Su <= ut.s[0]) return st.s[0];
+        if (Su < ut.s[1]) return st.s[0] + (Su - ut.s[0]) * ((st.s[1] - st.s[0]) / (ut.s[1] - ut.s[0]));
+        if (Su < ut.s[2]) return st.s[1] + (Su - ut.s[1]) * ((st.s[2] - st.s[1]) / (ut.s[2] - ut.s[1]));
+        return st.s[2];
+    }
+    return st.s[0] + (Su - ut.s[0]) * ((st.s[2] - st.s[0]) / (ut.s[2] - ut.s[0]));
+}
+// the imbibition region's end points of cell c: the tables' own and the scaled ones (IS* arrays, else the tables' own)
+template <class DP> __device__ __forceinline__ void eps_load_imb(const CellStatic& C, int c, DP B, const SatRegionDesc& Si, double* u, double* s) {
+#pragma unroll
+    for (int f = 0; f < EPS_COUNT; ++f) { u[f] = B[Si.eps + f]; s[f] = C.epsImb ? C.epsImb[(size_t)f * C.ncell + c] : u[f]; }
+}
+// SatFunc::relativePermeabilitiesHyst
+template <class E, class DP> __device__ __forceinline__ void rel_perms_hyst(const TablesT<DP>& T, const CellStatic& C, int c, const SatRegionDesc& Sd, bool scaled,
+                                                                             const double* uD, const double* sD, const E& SwIn, const E& Sg, E kr[3]) {
+    const DP B = T.dbl;
+    const SatRegionDesc& Si = T.sat(C.imbnum[c]);
+    const int cfg = C.epscfg;
+    double uI[EPS_COUNT], sI[EPS_COUNT];
+    if (scaled) eps_load_imb<DP>(C, c, B, Si, uI, sI);
+    const double Swco = B[Sd.swco];
+    const double SwcoS = (scaled && (cfg & 1)) ? sD[EPS_SWL] : Swco;
+    const size_t N = C.ncell;
+    const double mdcOw = C.hyst[c], dOw = C.hyst[N + c], mdcGo = C.hyst[2 * N + c], dGo = C.hyst[3 * N + c];
+    const bool wetImb = C.hystModel == 1;
+    kr[0] = wetImb ? sat_curve<E, DP>(B, Si, KRW_OW, SwIn, scaled, cfg, uI, sI) : sat_curve<E, DP>(B, Sd, KRW_OW, SwIn, scaled, cfg, uD, sD);
+    const E SoP = 1.0 - SwcoS - Sg;
+    if (val(SoP) <= mdcGo) kr[2] = sat_curve<E, DP>(B, Sd, KRN_GO, SoP, scaled, cfg, uD, sD);
+    else kr[2] = sat_curve<E, DP>(B, Si, KRN_GO, SoP + dGo, scaled, cfg, uI, sI);
+    const E Sw = emax(cst<E>(SwcoS), SwIn);
+    const E Sw_ow = Sg + Sw;
+    const E So_go = 1.0 - Sw_ow;
+    E kro_ow;
+    if (val(Sw_ow) <= mdcOw) kro_ow = sat_curve<E, DP>(B, Sd, KRN_OW, Sw_ow, scaled, cfg, uD, sD);
+    else kro_ow = sat_curve<E, DP>(B, Si, KRN_OW, Sw_ow + dOw, scaled, cfg, uI, sI);
+    const E kro_go = wetImb ? sat_curve<E, DP>(B, Si, KRW_GO, So_go, scaled, cfg, uI, sI) : sat_curve<E, DP>(B, Sd, KRW_GO, So_go, scaled, cfg, uD, sD);
+    const double eps = 1e-5;
+    if (val(Sw_ow) - SwcoS < eps) {
+        const E kro2 = (kro_ow + kro_go) / 2.0;
+        if (val(Sw_ow) - SwcoS > eps / 2.0) {
+            const E kro1 = (Sg * kro_go + (Sw - SwcoS) * kro_ow) / (Sw_ow - SwcoS);
+            const E alpha = (eps - (Sw_ow - SwcoS)) / (eps / 2.0);
+            kr[1] = kro2 * alpha + kro1 * (1.0 - alpha);
+        } else kr[1] = kro2;
+    } else kr[1] = (Sg * kro_go + (Sw - SwcoS) * kro_ow) / (Sw_ow - SwcoS);
+}
 // the capillary pressures of cell c at (Sw, Sg), values only: what the primary-variable switches need
 // (computeCapillaryPressures_ of BlackOilPrimaryVariables), with the cell's scaled end points where the deck has them
 template <class DP, bool EXT> __device__ __forceinline__ void cell_cap_pressures(const TablesT<DP>& T, const CellStatic& C, int c, int sr, double Sw, double Sg, double pC[3]) {
@@ -416,7 +517,8 @@ __device__ __forceinline__ void update_iq(const TablesT<DP>& T, const CellStatic
         for (int ph = 0; ph < 3; ++ph) q.p[ph] = po + (pC[ph] - pC[OIL]);
     }
     // relative permeabilities (stored in mob, divided by viscosity below)
-    if (scaled) rel_perms_eps<E, DP>(B, Sd, C.epscfg, epsU, epsS, Sw, Sg, q.mob);
+    if (EXT && C.hyst) rel_perms_hyst<E, DP>(T, C, c, Sd, scaled, epsU, epsS, Sw, Sg, q.mob);
+    else if (scaled) rel_perms_eps<E, DP>(B, Sd, C.epscfg, epsU, epsS, Sw, Sg, q.mob);
     else {
         q.mob[WATER] = pwlin<E, DP>(B + Sd.sw_x, B + Sd.krw, Sd.nw, Sw);
         q.mob[GAS] = pwlin<E, DP>(B + Sd.so_x, B + Sd.krg, Sd.ng, 1.0 - Swco - Sg);
@@ -1258,6 +1360,46 @@ __global__ __launch_bounds__(256) void k_max_water_saturation(int N, int init, c
     maxsw[c] = (old > Sw) ? old : Sw;   // std::max(old, Sw)
     if (init) sw0[c] = Sw;
 }
+// updateHysteresis_ (:2603-2626) -> EclDefaultMaterial::updateHysteresis (its default "inconsistent" form): the oil-water system sees
+// 1 - So, the gas-oil system 1 - Sg (Sg clamped to [0, 1]); a system whose wetting saturation falls below its turning point moves
+// the turning point and recomputes the imbibition curve's shift (EclHysteresisTwoPhaseLawParams::update / updateDynamicParams_;
+// oracle/fluid.hpp SatFunc::hystSee, same statements).  sw_ow / sw_go != NULL: restart (initHysteresisParams) - the turning
+// points handed in (cell order of the device), starting from "nothing seen"
+__global__ __launch_bounds__(256) void k_hyst_update(int N, Tables T, CellStatic C, const double* __restrict__ iq, double* __restrict__ hyst,
+                                                     const double* __restrict__ sw_ow, const double* __restrict__ sw_go) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= N) return;
+    const GlobalTab B = T.dbl;
+    const SatRegionDesc& Sd = T.sat(C.satnum ? C.satnum[c] : 0);
+    const SatRegionDesc& Si = T.sat(C.imbnum[c]);
+    const bool scaled = C.eps != nullptr;
+    const int cfg = C.epscfg;
+    double uD[EPS_COUNT], sD[EPS_COUNT], uI[EPS_COUNT], sI[EPS_COUNT];
+    if (scaled) { eps_load<GlobalTab>(C, c, B, Sd, uD, sD); eps_load_imb<GlobalTab>(C, c, B, Si, uI, sI); }
+    double mdcOw = 2.0, dOw = 0.0, mdcGo = 2.0, dGo = 0.0, sOw, sGo;
+    if (sw_ow) { sOw = sw_ow[c]; sGo = sw_go[c]; }
+    else {
+        mdcOw = hyst[c]; dOw = hyst[(size_t)N + c]; mdcGo = hyst[(size_t)2 * N + c]; dGo = hyst[(size_t)3 * N + c];
+        const double So = iq_at(iq, N, F_S + OIL, c)[0];
+        double Sg = iq_at(iq, N, F_S + GAS, c)[0];
+        Sg = emin(1.0, emax(0.0, Sg));
+        sOw = 1.0 - So;
+        sGo = 1.0 - Sg;
+    }
+    if (sOw < mdcOw) {
+        mdcOw = sOw;
+        const double krnMdcDrainage = sat_curve<double, GlobalTab>(B, Sd, KRN_OW, sOw, scaled, cfg, uD, sD);
+        const double SwKrnMdcImbibition = sat_curve_inv<GlobalTab>(B, Si, KRN_OW, krnMdcDrainage, scaled, cfg, uI, sI);
+        dOw = SwKrnMdcImbibition - sOw;
+    }
+    if (sGo < mdcGo) {
+        mdcGo = sGo;
+        const double krnMdcDrainage = sat_curve<double, GlobalTab>(B, Sd, KRN_GO, sGo, scaled, cfg, uD, sD);
+        const double SwKrnMdcImbibition = sat_curve_inv<GlobalTab>(B, Si, KRN_GO, krnMdcDrainage, scaled, cfg, uI, sI);
+        dGo = SwKrnMdcImbibition - sGo;
+    }
+    hyst[c] = mdcOw; hyst[(size_t)N + c] = dOw; hyst[(size_t)2 * N + c] = mdcGo; hyst[(size_t)3 * N + c] = dGo;
+}
 // the storage term of the cached intensive quantities, values only (computeStorage; the statements of k_assemble's diagonal
 // lane): the old time level's storage where the first iteration's cannot be recycled (:1758-1765)
 template <bool EXT>
@@ -1311,7 +1453,13 @@ static Tables tables_of(const opmhip_ctx* c) {
 static CellStatic cells_of(const opmhip_ctx* c) {
     return CellStatic{c->asmb.d_poro, c->asmb.d_volume, c->asmb.d_depth, c->asmb.d_rsmax, c->asmb.d_pvtnum, c->asmb.d_satnum,
                       c->asmb.d_rvmax, c->asmb.d_overburden, c->asmb.d_rocknum, c->asmb.d_pcw, c->asmb.d_minpo, c->asmb.d_maxso, c->asmb.vap1, c->asmb.vap2,
-                      c->asmb.d_maxsw, c->asmb.d_sw0, c->asmb.d_wcdesc, c->asmb.d_wcdata, c->asmb.d_eps, c->asmb.epscfg, c->asmb.d_invb, c->pat.Nloc};
+                      c->asmb.d_maxsw, c->asmb.d_sw0, c->asmb.d_wcdesc, c->asmb.d_wcdata, c->asmb.d_eps, c->asmb.epscfg,
+                      c->asmb.d_hyst, c->asmb.d_imbnum, c->asmb.d_eps_imb, c->asmb.hyst_model, c->asmb.d_invb, c->pat.Nloc};
+}
+// sw_ow / sw_go (device, internal order, Nloc each) or NULL: from the intensive quantities of the state at hand
+void launch_hyst_update(opmhip_ctx* c, const double* d_sw_ow, const double* d_sw_go) {
+    const int N = c->pat.Nloc;   // all cells, the ghost ones too ("to avoid desynchronization of the processes", :2608-2609)
+    hipLaunchKernelGGL(k_hyst_update, dim3((N + 255) / 256), dim3(256), 0, c->stream, N, tables_of(c), cells_of(c), c->asmb.d_iq, c->asmb.d_hyst, d_sw_ow, d_sw_go);
 }
 // the context's record layout: extended when the fluid has PVTG or ROCKTAB tables
 #define OPMHIP_LAYOUT(c, call_base, call_ext) do { if ((c)->asmb.ext) { call_ext; } else { call_base; } } while (0)

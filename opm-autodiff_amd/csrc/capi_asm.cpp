@@ -702,11 +702,12 @@ int opmhip_begin_time_step(opmhip_ctx* c, double dt) {
         const bool limits = A.drsdt_on || A.drvdt_on;
         if ((A.drsdt_on && (!A.d_rsmax || !A.d_lastRs)) || (A.drvdt_on && (!A.d_rvmax || !A.d_lastRv)))
             return fail(c, OPMHIP_UNKNOWN_ERROR, "begin_time_step: DRSDT / DRVDT is in force but its cap array is gone (internal error)");
-        if (!limits && !A.d_minpo && !A.d_maxso && !A.d_maxsw) return OPMHIP_SUCCESS;
+        if (!limits && !A.d_minpo && !A.d_maxso && !A.d_maxsw && !A.d_hyst) return OPMHIP_SUCCESS;
         if (!A.state_set) return fail(c, OPMHIP_NOT_READY, "begin_time_step before set_state");
         OPMHIP_HIP(c, hipSetDevice(c->device));
         if (A.d_maxsw) launch_max_water_saturation(c, false);   // updateMaxWaterSaturation_ (eclproblem.hh:1056)
         if (A.d_minpo) launch_min_pressure(c, false);     // updateMinPressure_: from the intensive quantities of the state as it is
+        if (A.d_hyst) launch_hyst_update(c);              // updateHysteresis_ (eclproblem.hh:1060, 2603-2626)
         if (A.d_maxso) launch_max_oil_saturation(c, false);   // updateMaxOilSaturation_
         A.storage_frozen = false;
         if (limits) {
@@ -718,6 +719,97 @@ int opmhip_begin_time_step(opmhip_ctx* c, double dt) {
         }
         launch_iq_update(c);
         OPMHIP_HIP(c, hipGetLastError());
+        return OPMHIP_SUCCESS;
+    });
+}
+
+int opmhip_set_hysteresis(opmhip_ctx* c, int kr_model, const int* imbnum, const opmhip_endpoint_scaling* imb) {
+    if (!c) return OPMHIP_INVALID_ARGUMENT;
+    return guarded(c, [&]() -> int {
+        AsmDev& A = c->asmb;
+        const Pattern& P = c->pat;
+        if (!A.static_set) return fail(c, OPMHIP_NOT_READY, "set_hysteresis before set_static");
+        OPMHIP_HIP(c, hipSetDevice(c->device));
+        OPMHIP_HIP(c, hipStreamSynchronize(c->stream));
+        const int N = P.Nloc;
+        if (kr_model < 0) {   // the keyword is not in force
+            A.hyst_model = -1;
+            dev_free(c, &A.d_hyst);
+            dev_free(c, &A.d_imbnum);
+            dev_free(c, &A.d_eps_imb);
+        } else {
+            if (kr_model > 1) return fail(c, OPMHIP_INVALID_ARGUMENT, "set_hysteresis: EHYSTR item 2 = %d - only the Carlson models 0 and 1 are supported (as in the reference, PartiallySupportedFlowKeywords.cpp:301)", kr_model);
+            if (!A.ext) return fail(c, OPMHIP_INVALID_ARGUMENT, "set_hysteresis: needs a context with the extended record (a fluid with PVTG, ROCKTAB or pc_scaling)");
+            if (!imbnum) return fail(c, OPMHIP_INVALID_ARGUMENT, "set_hysteresis: imbnum is NULL");
+            if (imb && !A.d_eps) return fail(c, OPMHIP_INVALID_ARGUMENT, "set_hysteresis: scaled end points of the imbibition curves without opmhip_set_endpoint_scaling in force");
+            for (int i = 0; i < N; ++i)
+                if (imbnum[i] < 0 || imbnum[i] >= A.num_sat) return fail(c, OPMHIP_INVALID_ARGUMENT, "set_hysteresis: imbnum[%d] out of range", i);
+            int rc;
+            if ((rc = upload_cells(c, &A.d_imbnum, imbnum))) return rc;
+            if (imb) {
+                std::vector<double> v((size_t)EPS_COUNT * N);   // field-major, internal order
+                for (int pos = 0; pos < N; ++pos) {
+                    const int i = P.fromOrder[pos];
+                    for (int f = 0; f < EPS_COUNT; ++f) {
+                        const double x = imb->points[f] ? imb->points[f][i] : A.sat_eps[(size_t)imbnum[i] * EPS_COUNT + f];
+                        if (!std::isfinite(x)) return fail(c, OPMHIP_INVALID_ARGUMENT, "set_hysteresis: imbibition end point %d of cell %d is not finite", f, i);
+                        v[(size_t)f * N + pos] = x;
+                    }
+                }
+                if (!A.d_eps_imb && (rc = dev_alloc(c, &A.d_eps_imb, v.size()))) return rc;
+                OPMHIP_HIP(c, hipMemcpy(A.d_eps_imb, v.data(), v.size() * sizeof(double), hipMemcpyHostToDevice));
+            } else dev_free(c, &A.d_eps_imb);
+            // "nothing seen yet": turning points 2, shifts 0 - the first begin_time_step sets them (or opmhip_set_hysteresis_params)
+            std::vector<double> h((size_t)4 * N, 0.0);
+            for (int q = 0; q < N; ++q) h[q] = h[(size_t)2 * N + q] = 2.0;
+            if (!A.d_hyst && (rc = dev_alloc(c, &A.d_hyst, h.size()))) return rc;
+            OPMHIP_HIP(c, hipMemcpy(A.d_hyst, h.data(), h.size() * sizeof(double), hipMemcpyHostToDevice));
+            A.hyst_model = kr_model;
+        }
+        if (A.state_set) {
+            launch_iq_update(c);
+            OPMHIP_HIP(c, hipGetLastError());
+            OPMHIP_HIP(c, hipStreamSynchronize(c->stream));
+        }
+        return OPMHIP_SUCCESS;
+    });
+}
+
+int opmhip_get_hysteresis(opmhip_ctx* c, double* sw_ow, double* delta_ow, double* sw_go, double* delta_go) {
+    if (!c) return OPMHIP_INVALID_ARGUMENT;
+    return guarded(c, [&]() -> int {
+        AsmDev& A = c->asmb;
+        const Pattern& P = c->pat;
+        if (!A.d_hyst) return fail(c, OPMHIP_NOT_READY, "get_hysteresis: opmhip_set_hysteresis is not in force");
+        OPMHIP_HIP(c, hipSetDevice(c->device));
+        OPMHIP_HIP(c, hipStreamSynchronize(c->stream));
+        const int N = P.Nloc;
+        std::vector<double> h((size_t)4 * N);
+        OPMHIP_HIP(c, hipMemcpy(h.data(), A.d_hyst, h.size() * sizeof(double), hipMemcpyDeviceToHost));
+        double* out[4] = {sw_ow, delta_ow, sw_go, delta_go};
+        for (int f = 0; f < 4; ++f)
+            if (out[f])
+                for (int pos = 0; pos < N; ++pos) out[f][P.fromOrder[pos]] = h[(size_t)f * N + pos];
+        return OPMHIP_SUCCESS;
+    });
+}
+
+int opmhip_set_hysteresis_params(opmhip_ctx* c, const double* sw_ow, const double* sw_go) {
+    if (!c) return OPMHIP_INVALID_ARGUMENT;
+    return guarded(c, [&]() -> int {
+        AsmDev& A = c->asmb;
+        if (!A.d_hyst) return fail(c, OPMHIP_NOT_READY, "set_hysteresis_params: opmhip_set_hysteresis is not in force");
+        if (!sw_ow || !sw_go) return fail(c, OPMHIP_INVALID_ARGUMENT, "set_hysteresis_params: null array");
+        OPMHIP_HIP(c, hipSetDevice(c->device));
+        OPMHIP_HIP(c, hipStreamSynchronize(c->stream));   // the staging area may still be read by an earlier download
+        const size_t N = c->pat.Nloc;
+        const std::vector<double> a = cells_to_internal(c->pat, sw_ow), b = cells_to_internal(c->pat, sw_go);
+        OPMHIP_HIP(c, hipMemcpy(A.d_stage_cell, a.data(), N * sizeof(double), hipMemcpyHostToDevice));   // staged as [2][Nloc]
+        OPMHIP_HIP(c, hipMemcpy(A.d_stage_cell + N, b.data(), N * sizeof(double), hipMemcpyHostToDevice));
+        launch_hyst_update(c, A.d_stage_cell, A.d_stage_cell + N);
+        if (A.state_set) launch_iq_update(c);
+        OPMHIP_HIP(c, hipGetLastError());
+        OPMHIP_HIP(c, hipStreamSynchronize(c->stream));
         return OPMHIP_SUCCESS;
     });
 }

@@ -141,6 +141,12 @@ struct AsmDev {
     double* d_maxso = nullptr;                            // per cell largest oil saturation at the start of a time step (VAPPARS); NULL = not in force
     double vap1 = 0.0, vap2 = 0.0;                        // VAPPARS exponents: on RvSat, on RsSat
     double *d_maxsw = nullptr, *d_sw0 = nullptr;          // water-induced compaction: largest S_w at the start of a time step, initial S_w; NULL = off
+    // relative-permeability hysteresis (SATOPTS HYSTER; EHYSTR item 2 = hyst_model 0 | 1, -1 = off): turning points and shifts
+    // [4][Nloc], imbibition region per cell, scaled end points of the imbibition curves [EPS_COUNT][Nloc] (optional)
+    int hyst_model = -1;
+    double* d_hyst = nullptr;
+    int* d_imbnum = nullptr;
+    double* d_eps_imb = nullptr;
     double* d_rc = nullptr;                               // relativeChange: 2 x 256 partial sums + (delta, denominator)
     int num_wc = 0, h_rocknum_max = -1;                   // water-compaction tables; largest rock-table index handed in (-1: none)
     int* d_wcdesc = nullptr;                              // per table {np, nsw, pressure at, S_w at, pore-volume multipliers at, transmissibility multipliers at | -1}
@@ -448,6 +454,7 @@ void launch_min_pressure(opmhip_ctx* c, bool init);
 void launch_storage_old(opmhip_ctx* c);
 void launch_max_oil_saturation(opmhip_ctx* c, bool init);
 void launch_max_water_saturation(opmhip_ctx* c, bool init);
+void launch_hyst_update(opmhip_ctx* c, const double* d_sw_ow = nullptr, const double* d_sw_go = nullptr);
 int launch_relative_change(opmhip_ctx* c);   // -> asmb.d_rc[512 .. 514)
 int launch_convergence(opmhip_ctx* c, double dt, double tol_cnv);
 void launch_u8_to_internal(opmhip_ctx* c, const unsigned char* nat, unsigned char* internal);

@@ -76,6 +76,13 @@ struct Problem {
     // to EclEpsTwoPhaseLaw by the material-law manager (ebos/eclproblem.hh:1490-1498); empty = none.  UNVERIFIED (opm-material absent).
     std::vector<EpsPoints> eps;
     EpsConfig epsCfg;
+    // relative-permeability hysteresis (SATOPTS HYSTER, EHYSTR item 2 = hystKrModel 0 | 1; oracle/fluid.hpp HystCell): per cell the
+    // imbibition saturation region (IMBNUM), the turning points of its two two-phase systems and, with ENDSCALE, the scaled end
+    // points of the imbibition curves (ISWL ... ; empty with ENDSCALE on: the imbibition tables' own).  hyst empty = not in force.
+    int hystKrModel = -1;
+    std::vector<int> imbnum;
+    std::vector<HystCell> hyst;
+    std::vector<EpsPoints> epsImb;
     Fluid fluid;
     void finish() {
         const int Nb = pat.Nb;
@@ -143,7 +150,13 @@ void update_iq(const Problem& P, int cell, const double* pv, uint8_t meaning, IQ
         const E po = mkvar<E>(pv[PV_P], PV_P);
         for (int ph = 0; ph < 3; ++ph) q.p[ph] = po + (pC[ph] - pC[OIL]);
     }
-    if (scaled) F.sat[sr].relativePermeabilitiesEps(q.mob, Sw, Sg, P.eps[cell], P.epsCfg);
+    if (!P.hyst.empty()) {
+        const SatFunc& imb = F.sat[P.imbnum[cell]];
+        EpsPoints own;
+        const EpsPoints* scI = nullptr;
+        if (scaled) { if (P.epsImb.empty()) { own = imb.unscaled; scI = &own; } else scI = &P.epsImb[cell]; }
+        F.sat[sr].relativePermeabilitiesHyst(q.mob, Sw, Sg, P.hyst[cell], P.hystKrModel, imb, scaled ? &P.eps[cell] : nullptr, scI, P.epsCfg);
+    } else if (scaled) F.sat[sr].relativePermeabilitiesEps(q.mob, Sw, Sg, P.eps[cell], P.epsCfg);
     else F.sat[sr].relativePermeabilities(q.mob, Sw, Sg);
     // SoMax = max(So, problem.maxOilSaturation) ; the latter is 0 without VAPPARS (eclproblem.hh:1682-1688), and without
     // VAPPARS the saturated Rs / Rv do not depend on it
@@ -335,6 +348,22 @@ struct Model {
             }
         }
     }
+    // EclProblem::updateHysteresis_ (eclproblem.hh:2603-2626) -> EclMaterialLawManager::updateHysteresis -> EclDefaultMaterial::
+    // updateHysteresis: every cell's two two-phase systems see the saturations of the state at hand
+    bool update_hysteresis() {
+        if (P.hyst.empty()) return false;
+        const int Nb = P.pat.Nb;
+        const bool scaled = !P.eps.empty();
+        for (int c = 0; c < Nb; ++c) {
+            const int sr = P.satnum.empty() ? 0 : P.satnum[c];
+            const SatFunc& imb = P.fluid.sat[P.imbnum[c]];
+            EpsPoints own;
+            const EpsPoints* scI = nullptr;
+            if (scaled) { if (P.epsImb.empty()) { own = imb.unscaled; scI = &own; } else scI = &P.epsImb[c]; }
+            P.fluid.sat[sr].hystUpdate(P.hyst[c], iqV[c].S[OIL], iqV[c].S[GAS], imb, scaled ? &P.eps[c] : nullptr, scI, P.epsCfg);
+        }
+        return true;
+    }
     // EclProblem::beginTimeStep, the per-cell part (eclproblem.hh:1042-1075): minimum oil pressure of irreversible
     // compaction, the DRSDT / DRVDT caps of a time step of size dt, intensive quantities; and, where the first iteration's
     // storage term cannot be recycled (:1758-1765), the old time level's storage with ITS caps (time index 1: no increment)
@@ -350,6 +379,7 @@ struct Model {
             if (Nb > 1) P.maxWaterSaturation[1] = P.maxWaterSaturation[0];
             for (int c = 0; c < Nb; ++c) P.maxWaterSaturation[c] = std::max(P.maxWaterSaturation[c], iqV[c].S[WATER]);
         }
+        update_hysteresis();   // updateHysteresis_ (eclproblem.hh:1060, 2603-2626); the intensive quantities are redone below (:1064-1066)
         storageFrozen = false;
         if (limits_active()) {
             if (lastRs.empty() && lastRv.empty()) update_composition_change_limits();

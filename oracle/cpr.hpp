@@ -49,6 +49,10 @@ struct AmgLevel {
     int nc = 0;
     std::vector<int> mptr, midx;   // members of each aggregate, ascending
     std::vector<int> gptr, gidx;   // Galerkin: coarse entry e = sum of the fine entries gidx[gptr[e] .. gptr[e+1]), ascending
+    // ILU0 smoothing (CprAmg::iluLevels): scalar ILU0 factors in A's pattern (strict lower = L, diagonal = 1 / U_ii, strict upper
+    // = U) for the elimination order `ord` (pos = its inverse; empty: the stored order)
+    std::vector<double> ilu;
+    std::vector<int> ord, pos;
 };
 
 struct CprAmg {
@@ -65,6 +69,12 @@ struct CprAmg {
     bool joinAtStall = false;      // experiment switch (orc_cpr_set_sweeps with a negative argument)
     int wFrom = 1 << 30;           // experiment: levels >= wFrom visit their coarse level twice (W-cycle below that level); the product runs V-cycles
     bool join = false;             // leftover nodes join a neighbour's aggregate (uniform coarsening, but measured WORSE: see DESIGN.md)
+    // smoother: levels l < iluLevels (that are not the coarsest) smooth with a scalar ILU0, relaxation 1 - the reference's smoother
+    // (PreconditionerFactory.hpp:126-151) - instead of damped Jacobi.  Elimination order of such a level: the stored order
+    // (level 0: whatever ordering the block ILU0 uses - on the device a line colouring) or, iluColour, a greedy multi-colouring
+    // of the level's graph, colour by colour (what a device sweep of an irregular coarse level would need)
+    int iluLevels = 0;
+    int iluColourFrom = 1 << 30;   // levels >= iluColourFrom eliminate in greedy multi-colour order
 
     // one pass of pairwise matching, nodes visited in index order: node i takes its strongest (most negative coupling)
     // still-free neighbour, lowest index on ties
@@ -211,6 +221,8 @@ struct CprAmg {
             AmgLevel& L = lv[l];
             L.dinv.resize(L.A.n);
             for (int i = 0; i < L.A.n; ++i) L.dinv[i] = 1.0 / L.A.val[L.diag[i]];
+            if ((int)l < iluLevels && l + 1 < lv.size()) ilu_factor(L, (int)l >= iluColourFrom);
+            else L.ilu.clear();
             if (l + 1 < lv.size()) {
                 Csr& C = lv[l + 1].A;
                 for (size_t e = 0; e < C.col.size(); ++e) {
@@ -234,6 +246,81 @@ struct CprAmg {
                     for (int j = k + 1; j < n; ++j) lu[(size_t)i * n + j] -= f * lu[(size_t)k * n + j];
                 }
             }
+        }
+    }
+    // scalar ILU0 of a level in the elimination order L.ord (IKJ form: row i against the finished rows j in ascending position)
+    static void ilu_factor(AmgLevel& L, bool colour) {
+        const Csr& A = L.A;
+        const int n = A.n;
+        if ((int)L.ord.size() != n) {
+            L.ord.resize(n);
+            L.pos.resize(n);
+            if (!colour) for (int i = 0; i < n; ++i) L.ord[i] = i;
+            else {   // greedy colouring in index order, then colour-major, index order inside a colour
+                std::vector<int> col(n, -1);
+                int nc = 0;
+                std::vector<char> used;
+                for (int i = 0; i < n; ++i) {
+                    used.assign(nc + 1, 0);
+                    for (int k = A.rowptr[i]; k < A.rowptr[i + 1]; ++k)
+                        if (col[A.col[k]] >= 0) used[col[A.col[k]]] = 1;
+                    int c = 0;
+                    while (used[c]) ++c;
+                    col[i] = c;
+                    nc = std::max(nc, c + 1);
+                }
+                int p = 0;
+                for (int c = 0; c < nc; ++c)
+                    for (int i = 0; i < n; ++i)
+                        if (col[i] == c) L.ord[p++] = i;
+            }
+            for (int p = 0; p < n; ++p) L.pos[L.ord[p]] = p;
+        }
+        std::vector<double>& f = L.ilu;
+        f = A.val;
+        std::vector<std::pair<int, int>> low;
+        for (int p = 0; p < n; ++p) {
+            const int i = L.ord[p];
+            low.clear();
+            for (int k = A.rowptr[i]; k < A.rowptr[i + 1]; ++k)
+                if (L.pos[A.col[k]] < p) low.emplace_back(L.pos[A.col[k]], k);
+            std::sort(low.begin(), low.end());
+            for (auto& e : low) {
+                const int k = e.second, j = A.col[k];
+                f[k] = f[k] * f[L.diag[j]];
+                for (int q = A.rowptr[j]; q < A.rowptr[j + 1]; ++q) {
+                    const int c = A.col[q];
+                    if (L.pos[c] <= e.first) continue;                 // U part of row j only
+                    const int* b = &A.col[A.rowptr[i]];
+                    const int* en = &A.col[A.rowptr[i + 1]];
+                    const int* t = std::lower_bound(b, en, c);
+                    if (t != en && *t == c) f[t - &A.col[0]] -= f[k] * f[q];
+                }
+            }
+            f[L.diag[i]] = 1.0 / f[L.diag[i]];
+        }
+    }
+    // v = M^-1 d of level l's smoother: damped Jacobi, or (U^-1 L^-1) of the level's ILU0 in its elimination order
+    void smooth(const AmgLevel& L, const double* d, double* v) const {
+        const int n = L.A.n;
+        if (L.ilu.empty()) {
+            for (int i = 0; i < n; ++i) v[i] = omega * L.dinv[i] * d[i];
+            return;
+        }
+        const Csr& A = L.A;
+        for (int p = 0; p < n; ++p) {
+            const int i = L.ord[p];
+            double s = d[i];
+            for (int k = A.rowptr[i]; k < A.rowptr[i + 1]; ++k)
+                if (L.pos[A.col[k]] < p) s -= L.ilu[k] * v[A.col[k]];
+            v[i] = s;
+        }
+        for (int p = n - 1; p >= 0; --p) {
+            const int i = L.ord[p];
+            double s = v[i];
+            for (int k = A.rowptr[i]; k < A.rowptr[i + 1]; ++k)
+                if (L.pos[A.col[k]] > p) s -= L.ilu[k] * v[A.col[k]];
+            v[i] = s * L.ilu[L.diag[i]];
         }
     }
     static void residual(const Csr& A, const double* b, const double* x, double* r) {
@@ -269,8 +356,9 @@ struct CprAmg {
             }
             return;
         }
-        std::vector<double> r(n), rc(L.nc), xc(L.nc);
-        for (int i = 0; i < n; ++i) x[i] = omega * L.dinv[i] * b[i];        // pre-smoothing from x = 0
+        std::vector<double> r(n), rc(L.nc), xc(L.nc), t;
+        if (L.ilu.empty()) for (int i = 0; i < n; ++i) x[i] = omega * L.dinv[i] * b[i];        // pre-smoothing from x = 0
+        else { t.resize(n); smooth(L, b, x); }
         residual(L.A, b, x, r.data());
         for (int sweep = 1; sweep < nu; ++sweep) {                           // nu > 1: further Jacobi sweeps (V(nu, nu))
             for (int i = 0; i < n; ++i) x[i] += omega * L.dinv[i] * r[i];
@@ -290,7 +378,8 @@ struct CprAmg {
         }
         for (int i = 0; i < n; ++i) x[i] += damp * xc[L.agg[i]];            // damped piecewise-constant prolongation
         residual(L.A, b, x, r.data());
-        for (int i = 0; i < n; ++i) x[i] += omega * L.dinv[i] * r[i];        // post-smoothing
+        if (L.ilu.empty()) for (int i = 0; i < n; ++i) x[i] += omega * L.dinv[i] * r[i];        // post-smoothing
+        else { smooth(L, r.data(), t.data()); for (int i = 0; i < n; ++i) x[i] += t[i]; }
         for (int sweep = 1; sweep < nu; ++sweep) {
             residual(L.A, b, x, r.data());
             for (int i = 0; i < n; ++i) x[i] += omega * L.dinv[i] * r[i];

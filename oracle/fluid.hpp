@@ -307,6 +307,32 @@ struct PwLin {
         const double m = (y1 - y0) / (x1 - x0);
         return y0 + (xv - x0) * m;
     }
+    // the abscissa at which the curve takes the value yv (PiecewiseLinearTwoPhaseMaterial::twoPhaseSatKrnInv = eval_(krnSamples,
+    // SwSamples, krn): the samples' roles exchanged, constant outside their range; on a run of equal values the segment that
+    // bisection with ">=" / "<=" ends on).  UNVERIFIED vs upstream (opm-material is not in the reference tree).
+    double inv(double yv) const {
+        const int n = (int)y.size();
+        if (y.front() > y.back()) {   // falling curve (a non-wetting phase's relative permeability over the wetting saturation)
+            if (yv >= y.front()) return x.front();
+            if (yv <= y.back()) return x.back();
+            int lo = 0, hi = n - 1;
+            while (lo + 1 < hi) {
+                const int mid = (lo + hi) / 2;
+                if (y[mid] >= yv) lo = mid; else hi = mid;
+            }
+            const double m = (x[lo + 1] - x[lo]) / (y[lo + 1] - y[lo]);
+            return x[lo] + (yv - y[lo]) * m;
+        }
+        if (yv <= y.front()) return x.front();
+        if (yv >= y.back()) return x.back();
+        int lo = 0, hi = n - 1;
+        while (lo + 1 < hi) {
+            const int mid = (lo + hi) / 2;
+            if (y[mid] <= yv) lo = mid; else hi = mid;
+        }
+        const double m = (x[lo + 1] - x[lo]) / (y[lo + 1] - y[lo]);
+        return x[lo] + (yv - y[lo]) * m;
+    }
 };
 
 // ---- saturation end-point scaling (ENDSCALE family) --------------------------------------------------------------
@@ -364,7 +390,36 @@ template <class E> inline E eps_vertical_krn(int mode, const E& S, const E& kr, 
     return E(fm);
 }
 
-// ---- EclDefaultMaterial over SWOF / SGOF (optionally with end-point scaling; no hysteresis) ---------------------
+// EclEpsTwoPhaseLaw::unscaledToScaledSatTwoPoint_ / ThreePoint_: the inverse saturation maps (hysteresis: twoPhaseSatKrnInv)
+inline double eps_unscaled_to_scaled_two_point(double Su, const EpsTriple& u, const EpsTriple& sc) {
+    return sc.s[0] + (Su - u.s[0]) * ((sc.s[2] - sc.s[0]) / (u.s[2] - u.s[0]));
+}
+inline double eps_unscaled_to_scaled_three_point(double Su, const EpsTriple& u, const EpsTriple& sc) {
+    if (Su <= u.s[0]) return sc.s[0];
+    if (Su < u.s[1]) return sc.s[0] + (Su - u.s[0]) * ((sc.s[1] - sc.s[0]) / (u.s[1] - u.s[0]));
+    if (Su < u.s[2]) return sc.s[1] + (Su - u.s[1]) * ((sc.s[2] - sc.s[1]) / (u.s[2] - u.s[1]));
+    return sc.s[2];
+}
+
+// ---- relative-permeability hysteresis (EclHysteresisTwoPhaseLaw / EclHysteresisTwoPhaseLawParams / EclHysteresisConfig) --------
+// opm-material is NOT in the reference tree: restated from its published 2021.10 form, UNVERIFIED vs upstream.  What the tree
+// itself says about it: SATOPTS HYSTER + EHYSTR, "only Carlson Hysteresis Models supported (0 or 1)", the curvature and Killough
+// items ignored (opm/simulators/utils/PartiallySupportedFlowKeywords.cpp:299-302, 502-507); the per-cell state is (pcSwMdc,
+// krnSwMdc) of the oil-water and of the gas-oil system (ebos/ecloutputblackoilmodule.hh:569-589, ebos/eclwriter.hh:285-288);
+// it is updated in EclProblem::beginTimeStep (ebos/eclproblem.hh:1060, 2603-2626) from the saturations of the state at hand.
+//   krModel 0: Carlson for the non-wetting phases (oil in oil-water, gas in gas-oil), the wetting phases (water, oil in gas-oil)
+//              on their drainage curves;  krModel 1: the same, wetting phases on their IMBIBITION curves (no shift);
+//   capillary pressures: drainage curves (pc hysteresis is a TODO in that version).
+// Carlson: while the wetting saturation of a system is at or below the smallest one seen so far (krnSwMdc, "maximum drainage
+// ... saturation") the non-wetting phase follows its drainage curve; above it, the imbibition curve shifted by deltaSwImbKrn =
+// SwImb(krn_drainage(krnSwMdc)) - krnSwMdc, so that the scanning curve leaves the drainage curve at the turning point.
+struct HystCell {
+    double krnSwMdcOw = 2.0, deltaSwImbKrnOw = 0.0;   // oil-water system (non-wetting: oil); 2.0 = nothing seen yet
+    double krnSwMdcGo = 2.0, deltaSwImbKrnGo = 0.0;   // gas-oil system (non-wetting: gas)
+};
+enum SatCurve { KRW_OW = 0, KRN_OW = 1, KRW_GO = 2, KRN_GO = 3 };
+
+// ---- EclDefaultMaterial over SWOF / SGOF (optionally with end-point scaling and hysteresis) --------------------
 struct SatFunc {
     double Swco = 0.0;
     PwLin krw, krow, pcow;    // in Sw
@@ -443,6 +498,85 @@ struct SatFunc {
         const E So_go = 1.0 - Sw_ow;
         const E kro_ow = eps_vertical_krn(cfg.kro, Sw_ow, krow.eval(to_unscaled(Sw_ow, uKrnOw, sKrnOw)), sKrnOw, u[EPS_KRORW], u[EPS_MAXKROW], s[EPS_KRORW], s[EPS_MAXKROW]);
         const E kro_go = eps_vertical_krw(cfg.kro, So_go, krog.eval(to_unscaled(So_go, uKrwGo, sKrwGo)), sKrwGo, u[EPS_KRORG], u[EPS_MAXKROG], s[EPS_KRORG], s[EPS_MAXKROG]);
+        const double eps = 1e-5;
+        if (value(Sw_ow) - SwcoS < eps) {
+            const E kro2 = (kro_ow + kro_go) / 2.0;
+            if (value(Sw_ow) - SwcoS > eps / 2.0) {
+                const E kro1 = (Sg * kro_go + (Sw - SwcoS) * kro_ow) / (Sw_ow - SwcoS);
+                const E alpha = (eps - (Sw_ow - SwcoS)) / (eps / 2.0);
+                kr[1] = kro2 * alpha + kro1 * (1.0 - alpha);
+            } else kr[1] = kro2;
+        } else kr[1] = (Sg * kro_go + (Sw - SwcoS) * kro_ow) / (Sw_ow - SwcoS);
+    }
+    // one relative-permeability curve of this region at the (scaled) saturation S of its two-phase system's wetting phase: the
+    // table itself (sc == NULL) or EclEpsTwoPhaseLaw over it with the scaled end points sc - the statements of
+    // relativePermeabilities / relativePermeabilitiesEps, curve by curve
+    template <class E> E curve(int kind, const E& S, const EpsPoints* sc, const EpsConfig& cfg) const {
+        const PwLin& tab = kind == KRW_OW ? krw : kind == KRN_OW ? krow : kind == KRW_GO ? krog : krg;
+        if (!sc) return tab.eval(S);
+        const double* u = unscaled.v;
+        const double* s = sc->v;
+        const EpsTriple ut = kind == KRW_OW ? eps_krw_ow(unscaled) : kind == KRN_OW ? eps_krn_ow(unscaled) : kind == KRW_GO ? eps_krw_go(unscaled) : eps_krn_go(unscaled);
+        const EpsTriple st = kind == KRW_OW ? eps_krw_ow(*sc) : kind == KRN_OW ? eps_krn_ow(*sc) : kind == KRW_GO ? eps_krw_go(*sc) : eps_krn_go(*sc);
+        E Su = S;
+        if (cfg.satScaling) Su = cfg.threePointKr ? eps_sat_three_point(S, ut, st) : eps_sat_two_point(S, ut, st);
+        const E k = tab.eval(Su);
+        switch (kind) {
+            case KRW_OW: return eps_vertical_krw(cfg.krw, S, k, st, u[EPS_KRWR], u[EPS_MAXKRW], s[EPS_KRWR], s[EPS_MAXKRW]);
+            case KRN_OW: return eps_vertical_krn(cfg.kro, S, k, st, u[EPS_KRORW], u[EPS_MAXKROW], s[EPS_KRORW], s[EPS_MAXKROW]);
+            case KRW_GO: return eps_vertical_krw(cfg.kro, S, k, st, u[EPS_KRORG], u[EPS_MAXKROG], s[EPS_KRORG], s[EPS_MAXKROG]);
+            default: return eps_vertical_krn(cfg.krg, S, k, st, u[EPS_KRGR], u[EPS_MAXKRG], s[EPS_KRGR], s[EPS_MAXKRG]);
+        }
+    }
+    // the (scaled) wetting saturation at which non-wetting curve `kind` (KRN_OW / KRN_GO) takes the value k: twoPhaseSatKrnInv
+    // of the table, mapped back through the saturation scaling (no inverse of the vertical scaling, as upstream)
+    double curveInv(int kind, double k, const EpsPoints* sc, const EpsConfig& cfg) const {
+        const PwLin& tab = kind == KRN_OW ? krow : krg;
+        const double Su = tab.inv(k);
+        if (!sc || !cfg.satScaling) return Su;
+        const EpsTriple ut = kind == KRN_OW ? eps_krn_ow(unscaled) : eps_krn_go(unscaled);
+        const EpsTriple st = kind == KRN_OW ? eps_krn_ow(*sc) : eps_krn_go(*sc);
+        return cfg.threePointKr ? eps_unscaled_to_scaled_three_point(Su, ut, st) : eps_unscaled_to_scaled_two_point(Su, ut, st);
+    }
+    // EclHysteresisTwoPhaseLawParams::update + updateDynamicParams_ for both two-phase systems of a cell, the way
+    // EclDefaultMaterial::updateHysteresis hands the saturations over (its default "inconsistent" form: oil-water system
+    // 1 - So, gas-oil system 1 - Sg with Sg clamped to [0, 1]).  *this = the cell's drainage region, imb = its imbibition region.
+    void hystUpdate(HystCell& h, double So, double SgIn, const SatFunc& imb, const EpsPoints* scD, const EpsPoints* scI, const EpsConfig& cfg) const {
+        const double Sg = std::min(1.0, std::max(0.0, SgIn));
+        hystSee(h, 1.0 - So, 1.0 - Sg, imb, scD, scI, cfg);
+    }
+    // ... with the wetting saturations the two systems are to see (params.update(pcSw, krwSw, krnSw), the krn part)
+    void hystSee(HystCell& h, double sOw, double sGo, const SatFunc& imb, const EpsPoints* scD, const EpsPoints* scI, const EpsConfig& cfg) const {
+        if (sOw < h.krnSwMdcOw) {
+            h.krnSwMdcOw = sOw;
+            const double krnMdcDrainage = curve<double>(KRN_OW, sOw, scD, cfg);
+            const double SwKrnMdcImbibition = imb.curveInv(KRN_OW, krnMdcDrainage, scI, cfg);
+            h.deltaSwImbKrnOw = SwKrnMdcImbibition - sOw;
+        }
+        if (sGo < h.krnSwMdcGo) {
+            h.krnSwMdcGo = sGo;
+            const double krnMdcDrainage = curve<double>(KRN_GO, sGo, scD, cfg);
+            const double SwKrnMdcImbibition = imb.curveInv(KRN_GO, krnMdcDrainage, scI, cfg);
+            h.deltaSwImbKrnGo = SwKrnMdcImbibition - sGo;
+        }
+    }
+    // EclDefaultMaterial's relative permeabilities with EclHysteresisTwoPhaseLaw as its two-phase laws (krModel 0 | 1)
+    template <class E> void relativePermeabilitiesHyst(E kr[3], const E& SwIn, const E& Sg, const HystCell& h, int krModel, const SatFunc& imb,
+                                                       const EpsPoints* scD, const EpsPoints* scI, const EpsConfig& cfg) const {
+        const double SwcoS = (scD && cfg.satScaling) ? scD->v[EPS_SWL] : Swco;
+        const SatFunc& wetF = krModel == 1 ? imb : *this;
+        const EpsPoints* wetS = krModel == 1 ? scI : scD;
+        kr[0] = wetF.curve(KRW_OW, SwIn, wetS, cfg);
+        const E SoP = 1.0 - SwcoS - Sg;
+        if (value(SoP) <= h.krnSwMdcGo) kr[2] = curve(KRN_GO, SoP, scD, cfg);
+        else kr[2] = imb.curve(KRN_GO, SoP + h.deltaSwImbKrnGo, scI, cfg);
+        const E Sw = max(E(SwcoS), SwIn);
+        const E Sw_ow = Sg + Sw;
+        const E So_go = 1.0 - Sw_ow;
+        E kro_ow;
+        if (value(Sw_ow) <= h.krnSwMdcOw) kro_ow = curve(KRN_OW, Sw_ow, scD, cfg);
+        else kro_ow = imb.curve(KRN_OW, Sw_ow + h.deltaSwImbKrnOw, scI, cfg);
+        const E kro_go = wetF.curve(KRW_GO, So_go, wetS, cfg);
         const double eps = 1e-5;
         if (value(Sw_ow) - SwcoS < eps) {
             const E kro2 = (kro_ow + kro_go) / 2.0;

@@ -276,6 +276,8 @@ int orc_cpr_set_coarse_sweeps(orc_cpr* h, int n) { h->P.amg.coarseSweeps = n < 0
 int orc_cpr_rebuild_structure(orc_cpr* h) { h->P.structured = false; return 0; }
 int orc_cpr_set_max_levels(orc_cpr* h, int n) { h->P.amg.maxLevels = n < 1 ? 1 : n; h->P.structured = false; return 0; }
 int orc_cpr_set_sweeps(orc_cpr* h, int nu) { if (nu < 0) { h->P.amg.joinAtStall = true; h->P.structured = false; return 0; } h->P.amg.nu = nu < 1 ? 1 : nu; return 0; }   // experiments: V(nu, nu)
+// smoother of the product's hierarchy: scalar ILU0 (relaxation 1) on levels < levels, eliminating in greedy multi-colour order on levels >= colour_from
+int orc_cpr_set_ilu_smoother(orc_cpr* h, int levels, int colour_from) { h->P.amg.iluLevels = levels < 0 ? 0 : levels; h->P.amg.iluColourFrom = colour_from < 0 ? (1 << 30) : colour_from; h->P.structured = false; return 0; }
 int orc_cpr_set_wcycle_from(orc_cpr* h, int l) { h->P.amg.wFrom = l < 0 ? (1 << 30) : l; return 0; }   // experiment
 int orc_cpr_use_reference_amg(orc_cpr* h, int on) { h->P.useDune = on != 0; h->P.dune.jacobi = on == 2;   /* 2: experiment - its aggregation with damped Jacobi smoothing */ h->P.structured = false; return 0; }
 // levels of that hierarchy
@@ -715,6 +717,61 @@ int orc_bo_set_water_compaction(orc_model* h, int ntab, const int* np, const int
             M.P.initialSw[c] = M.iqV[c].S[WATER];
             M.P.maxWaterSaturation[c] = std::max(M.P.maxWaterSaturation[c], M.iqV[c].S[WATER]);
         }
+    }
+    M.update_all_iq();
+    return 0;
+}
+// relative-permeability hysteresis: kr_model 0 | 1 (EHYSTR item 2; < 0: off), imbnum per cell (0-based), eps_imb: Nb x EPS_COUNT
+// scaled end points of the imbibition curves (cell-major) or NULL.  The turning points start at 2.0 ("nothing seen"): the first
+// begin_time_step sets them, as the reference's first beginTimeStep does.
+int orc_bo_set_hysteresis(orc_model* h, int kr_model, const int* imbnum, const double* eps_imb) {
+    Model& M = h->M;
+    const int Nb = M.P.pat.Nb;
+    M.P.hyst.clear(); M.P.imbnum.clear(); M.P.epsImb.clear();
+    M.P.hystKrModel = kr_model;
+    if (kr_model >= 0) {
+        if (!imbnum) return -1;
+        for (int c = 0; c < Nb; ++c)
+            if (imbnum[c] < 0 || imbnum[c] >= (int)M.P.fluid.sat.size()) return -1;
+        M.P.imbnum.assign(imbnum, imbnum + Nb);
+        M.P.hyst.assign(Nb, HystCell());
+        if (eps_imb) {
+            M.P.epsImb.resize(Nb);
+            for (int i = 0; i < Nb; ++i)
+                for (int f = 0; f < EPS_COUNT; ++f) M.P.epsImb[i].v[f] = eps_imb[(size_t)i * EPS_COUNT + f];
+        }
+    }
+    M.update_all_iq();
+    return 0;
+}
+// the hysteresis state, per cell: krnSwMdc and deltaSwImbKrn of the oil-water and of the gas-oil system (4 arrays, any NULL)
+int orc_bo_get_hysteresis(orc_model* h, double* sw_ow, double* delta_ow, double* sw_go, double* delta_go) {
+    Model& M = h->M;
+    if (M.P.hyst.empty()) return -1;
+    for (int c = 0; c < M.P.pat.Nb; ++c) {
+        const HystCell& q = M.P.hyst[c];
+        if (sw_ow) sw_ow[c] = q.krnSwMdcOw;
+        if (delta_ow) delta_ow[c] = q.deltaSwImbKrnOw;
+        if (sw_go) sw_go[c] = q.krnSwMdcGo;
+        if (delta_go) delta_go[c] = q.deltaSwImbKrnGo;
+    }
+    return 0;
+}
+// restart (initHysteresisParams, ebos/ecloutputblackoilmodule.hh:569-589 -> setOilWaterHysteresisParams / setGasOilHysteresisParams):
+// the turning points handed in, the shifts recomputed from them
+int orc_bo_set_hysteresis_params(orc_model* h, const double* sw_ow, const double* sw_go) {
+    Model& M = h->M;
+    if (M.P.hyst.empty()) return -1;
+    const bool scaled = !M.P.eps.empty();
+    for (int c = 0; c < M.P.pat.Nb; ++c) {
+        HystCell q;   // from "nothing seen": update() takes any value below 2
+        const int sr = M.P.satnum.empty() ? 0 : M.P.satnum[c];
+        const SatFunc& imb = M.P.fluid.sat[M.P.imbnum[c]];
+        EpsPoints own;
+        const EpsPoints* scI = nullptr;
+        if (scaled) { if (M.P.epsImb.empty()) { own = imb.unscaled; scI = &own; } else scI = &M.P.epsImb[c]; }
+        M.P.fluid.sat[sr].hystSee(q, sw_ow[c], sw_go[c], imb, scaled ? &M.P.eps[c] : nullptr, scI, M.P.epsCfg);
+        M.P.hyst[c] = q;
     }
     M.update_all_iq();
     return 0;

@@ -209,3 +209,38 @@ def norne_shaped_case(pkg, seed=17):
                 volume=np.ascontiguousarray(g["volume"]), depth=np.ascontiguousarray(depth), fluid=fl,
                 pv=np.ascontiguousarray(pv.reshape(-1)), meaning=meaning)
     return case, g, dims
+
+
+# ---- relative-permeability hysteresis: a drainage and an imbibition saturation region ------------------------------------------
+def hysteresis_sat_regions(pkg):
+    """[drainage, imbibition] saturation regions from the SPE1 tables: the imbibition curves trap the non-wetting phases - gas
+    becomes immobile below Sg = 0.15 (drainage: 0.02), oil below So = 1 - 0.78 (drainage: 1 - 0.84) - and carry the wetting
+    phases a little lower, so that EHYSTR's second item (0: wetting phases on the drainage curves, 1: on the imbibition curves)
+    can be told apart; capillary pressures made non-zero so that they are seen to stay on the drainage curves"""
+    fl, d = pkg.fluid.spe1_fluid()
+    swof = np.array(d["swof"], float)
+    sgof = np.array(d["sgof"], float)
+    swof[:, 3] = 0.3e5 * (1.0 - (swof[:, 0] - swof[0, 0]) / (1.0 - swof[0, 0])) ** 2
+    sgof[:, 3] = 0.2e5 * (sgof[:, 0] / sgof[-1, 0]) ** 2
+    swi, sgi = swof.copy(), sgof.copy()
+    # imbibition krg: the drainage curve squeezed into [0.15, max]: krg_i(Sg) = krg_d(Sgcr_d + (Sg - 0.15) (Sgmax - Sgcr_d) / (Sgmax - 0.15))
+    sgmax, sgcr_d, sgcr_i = sgof[-1, 0], 0.02, 0.15
+    sg_src = np.where(sgof[:, 0] <= sgcr_i, sgcr_d * sgof[:, 0] / sgcr_i, sgcr_d + (sgof[:, 0] - sgcr_i) * (sgmax - sgcr_d) / (sgmax - sgcr_i))
+    sgi[:, 1] = np.interp(sg_src, sgof[:, 0], sgof[:, 1])
+    sgi[:, 2] = sgof[:, 2] * 0.9                     # krog on the imbibition curve (wetting phase of the gas-oil system)
+    # imbibition krow: oil immobile from Sw = 0.78 on (drainage: 0.84)
+    sw_src = np.minimum(1.0, swof[0, 0] + (swof[:, 0] - swof[0, 0]) * (0.84 - swof[0, 0]) / (0.78 - swof[0, 0]))
+    swi[:, 2] = np.interp(sw_src, swof[:, 0], swof[:, 2])
+    swi[:, 1] = swof[:, 1] * 0.8                     # krw on the imbibition curve (wetting phase of the oil-water system)
+    return [dict(swof=swof.tolist(), sgof=sgof.tolist()), dict(swof=swi.tolist(), sgof=sgi.tolist())]
+
+
+def hysteresis_case(pkg, nx, ny, nz, wetgas=False, **kw):
+    """Cartesian three-phase case whose cells have a drainage (SATNUM 1) and an imbibition (IMBNUM 2) saturation region; the fluid
+    carries the extended record (pc_scaling) that opmhip_set_hysteresis needs"""
+    base = wetgas_fluid(pkg) if wetgas else pkg.fluid.spe1_fluid()[0]
+    fl = pkg.fluid.Fluid(base.pvt, hysteresis_sat_regions(pkg), rock_pref=base.rock_pref, rock_cr=base.rock_cr, pc_scaling=True)
+    case = pkg.decks.cartesian_case(nx, ny, nz, state="mixed", fluid=fl, **kw)
+    case["satnum"] = np.zeros(case["Nb"], np.int32)
+    case["imbnum"] = np.ones(case["Nb"], np.int32)
+    return case

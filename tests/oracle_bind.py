@@ -189,6 +189,9 @@ class OracleModel:
         L.orc_bo_end_time_step.argtypes = [_vp, C.c_double]
         L.orc_bo_set_drift_compensation.argtypes = [_vp, C.c_int, C.c_double]
         L.orc_bo_get_drift.argtypes = [_vp, _d]
+        L.orc_bo_set_hysteresis.argtypes = [_vp, C.c_int, _vp, _vp]
+        L.orc_bo_get_hysteresis.argtypes = [_vp, _d, _d, _d, _d]
+        L.orc_bo_set_hysteresis_params.argtypes = [_vp, _d, _d]
         self.case = case
         self.Nb = case["Nb"]
         self.nnzb = len(case["col"])
@@ -219,6 +222,40 @@ class OracleModel:
             eps[:, f] = tab[satnum, f] if es.get(name) is None else np.asarray(es[name], np.float64)[:self.Nb]
         self._eps = np.ascontiguousarray(eps)
         self.o.lib.orc_bo_set_endpoint_scaling(self.h, _p(cfg), _p(self._eps))
+
+    def _eps_table(self, es, region_of_cell):
+        """per-cell end points (Nb x 18) from an end-point dict: absent arrays = the end points of the cell's region's tables"""
+        pkg = __import__("importlib").import_module("opm-autodiff_amd")
+        tab = np.array([sat_end_points(self.o, self.case["fluid"], s) for s in range(len(self.case["fluid"].sat))])
+        eps = np.empty((self.Nb, 18))
+        for f, name in enumerate(pkg.capi.EPS_FIELDS):
+            eps[:, f] = tab[region_of_cell, f] if es.get(name) is None else np.asarray(es[name], np.float64)[:self.Nb]
+        return np.ascontiguousarray(eps)
+
+    def set_hysteresis(self, kr_model, imbnum=None, imb_endscale=None):
+        """relative-permeability hysteresis (SATOPTS HYSTER; EHYSTR item 2 = kr_model 0 | 1; None / negative = off); imbnum: per cell
+        imbibition saturation region (0-based); imb_endscale: dict of per-cell scaled end points of the imbibition curves (any of
+        capi.EPS_FIELDS; absent = the imbibition tables' own), only with end-point scaling in force"""
+        if kr_model is None or kr_model < 0:
+            assert self.o.lib.orc_bo_set_hysteresis(self.h, -1, None, None) == 0
+            return
+        imb = np.ascontiguousarray(imbnum, np.int32)
+        self._imbnum = imb
+        e = None
+        if imb_endscale is not None:
+            e = self._eps_table(imb_endscale, np.asarray(imb, np.int64)[:self.Nb])
+            self._eps_imb = e
+        assert self.o.lib.orc_bo_set_hysteresis(self.h, int(kr_model), _p(imb), _p(e)) == 0
+
+    def hysteresis(self):
+        """(krnSwMdc, deltaSwImbKrn) of the oil-water system, then of the gas-oil system: four per-cell arrays"""
+        out = [np.empty(self.Nb) for _ in range(4)]
+        assert self.o.lib.orc_bo_get_hysteresis(self.h, *out) == 0
+        return tuple(out)
+
+    def set_hysteresis_params(self, sw_ow, sw_go):
+        a, b = np.ascontiguousarray(sw_ow, np.float64), np.ascontiguousarray(sw_go, np.float64)
+        assert self.o.lib.orc_bo_set_hysteresis_params(self.h, a, b) == 0
 
     def set_composition_change_limits(self, drsdt=None, drsdt_all_cells=None, drvdt=None):
         n = len(self.case["fluid"].pvt)

@@ -130,3 +130,37 @@ def test_BlackoilModelHip_report_step_survives_a_chop(pkg, tmp_path):
     raw = np.fromfile(so, dtype=np.uint8)
     pv = raw[:case["Nb"] * 24].view(np.float64).reshape(-1, 3)
     assert np.all(np.isfinite(pv)) and np.all(pv[:, 1] > 1e7) and np.all(pv[:, 0] > 0.0) and np.all(pv[:, 0] < 1.0)
+
+
+@pytest.mark.parametrize("mode", ["host", "device"])
+def test_HipLinearizer_drives_newton_iterations(pkg, tmp_path, mode):
+    """Opm::HipLinearizer<TypeTag> (host/HipLinearizer.hpp), compiled against the property-system include path and driven through
+    the linearizer's public face - linearizeDomain(), jacobian(), residual(), solution(0) hand-off, invalidateAndUpdateIntensive
+    Quantities (flow/BlackoilModelEbos.hpp:339-340, 424, 526-527, 552-562): every iteration's system and state are the bits the
+    plain C-ABI sequence gives (the driver compares them itself, with host copies of J and r or with both left in HBM), and the
+    final state equals the one this process reaches through the Python binding"""
+    case = pkg.decks.cartesian_case(10, 9, 7, state="mixed", heterogeneous=True)
+    src = pkg.decks.five_spot_source(case, rate_sm3_per_day=40.0)
+    cf, so = str(tmp_path / "case.bin"), str(tmp_path / "state.bin")
+    pkg.decks.write_case_binary(case, cf, source=src)
+    dt, its = 2 * 86400.0, 3
+    out = subprocess.run([_exe("test_HipLinearizer"), cf, mode, repr(dt), str(its), so], capture_output=True, text=True)
+    assert out.returncode == 0, out.stderr + out.stdout
+    lines = [l for l in out.stdout.splitlines() if l.startswith("iteration")]
+    assert len(lines) == its and all("DIFFERS" not in l for l in lines) and out.stdout.strip().endswith("ok")
+    m = pkg.capi.HipModel(case, reorder="line_coloring")
+    m.set_state(case["pv"], case["meaning"])
+    m.set_source(src)
+    for it in range(its):
+        m.assemble(dt, it, fetch=False)
+        res = m.solve_jacobian_system()
+        assert res.iterations == int(lines[it].split()[3])
+        m.update(None, 1.0)
+        pv, mg = m.get_state()
+        pv = pv.reshape(-1, 3).copy()
+        pv[::7, 0] += 1e-4                      # the driver's host-side change of solution(0)
+        m.set_state(pv.reshape(-1), mg)
+    raw = np.fromfile(so, dtype=np.uint8)
+    pvc = raw[:case["Nb"] * 24].view(np.float64)
+    pm, mm = m.get_state()
+    assert np.array_equal(raw[case["Nb"] * 24:], mm) and np.array_equal(pvc, pm)

@@ -196,9 +196,9 @@ def test_extras_resent_while_the_limits_are_in_force(pkg, orc):
     for q in (m, o):
         q.set_source(src)
         q.set_composition_change_limits([1.0e-6], [1], [2.0e-12])
-    m.set_problem_extras(None, case["rocknum"], None)          # rvmax = NULL while DRVDT is on: the library's array stays
+    m.set_problem_extras(None, case["rocknum"], case.get("overburden"))   # rvmax = NULL while DRVDT is on: the library's array stays
     with pytest.raises(pkg.capi.OpmHipError):
-        m.set_problem_extras(np.full(case["Nb"], 1e-4), case["rocknum"], None)
+        m.set_problem_extras(np.full(case["Nb"], 1e-4), case["rocknum"], case.get("overburden"))
     dt = 0.3 * 86400.0
     for q in (m, o):
         q.begin_time_step(dt)

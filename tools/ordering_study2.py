@@ -25,7 +25,7 @@ ap.add_argument("--at", type=int, nargs="*", default=[200])
 ap.add_argument("--n", type=int, default=2)
 ap.add_argument("--dir", default="/tmp/ord")
 ap.add_argument("--workers", type=int, default=8)
-ap.add_argument("--set", default="main", help="which list of orderings: main | wide")
+ap.add_argument("--set", default="main", help="which list of orderings: main | wide | focus")
 ap.add_argument("--out", default="")
 a = ap.parse_args()
 pkg = importlib.import_module("opm-autodiff_amd")
@@ -100,6 +100,10 @@ def orderings(which):
            ("red-black", lambda: perm_from_keys((I + J + K) % 2, idx)),
            ("z-chains 10, 2 colours (today)", lambda: perm_from_keys((I + J + K // 10) % 2, I + n * (J + n * (K // 10)), K)),
            ("z-chains 20, 2 colours", lambda: perm_from_keys((I + J + K // 20) % 2, I + n * (J + n * (K // 20)), K))]
+    if which == "focus":
+        for b in ((2, 2, 10), (4, 8, 10), (5, 5, 10), (8, 8, 10), (10, 10, 10), (10, 10, 20)):
+            out.append(("box %dx%dx%d, 2 colours" % b, lambda b=b: box_perm(*b, 2)))
+        return [o for o in out if not o[0].startswith(("red", "z-chains 20"))]
     boxes = [(2, 2, 10), (4, 4, 10), (4, 8, 10), (5, 5, 10), (5, 5, 20), (8, 8, 8), (10, 10, 10), (4, 4, 20), (2, 4, 10), (4, 4, 5), (2, 2, 20), (1, 2, 10), (1, 4, 10), (2, 16, 10), (1, 32, 10)]
     if which == "wide":
         boxes += [(8, 8, 10), (10, 10, 20), (20, 20, 20), (4, 4, 100), (10, 10, 100), (4, 8, 20), (8, 8, 4), (16, 16, 4), (25, 25, 25)]
