@@ -20,7 +20,8 @@
 extern "C" {
 #endif
 
-#define OPMHIP_ABI_VERSION 6 /* 6: opmhip_set_hysteresis, opmhip_get_hysteresis, opmhip_set_hysteresis_params (additive);
+#define OPMHIP_ABI_VERSION 6 /* 6: opmhip_set_hysteresis, opmhip_get_hysteresis, opmhip_set_hysteresis_params (additive); opmhip_config names
+                               *    cpr_async_setup (was reserved[0]);
                                * 5: opmhip_set_water_compaction, opmhip_get_max_water_saturation, opmhip_relative_change, opmhip_cpr_recreate (additive);
                                * 4: opmhip_config names chain_length, spmv_pipe_wgs, preconditioner (were reserved[0..2]);
                                *    opmhip_set_endpoint_scaling, opmhip_sat_end_points, opmhip_sat_probe, opmhip_synchronize, opmhip_comm_info,
@@ -90,7 +91,12 @@ typedef struct opmhip_config {
                             * 0 for every linear solve, 1 at the first Newton iteration of every time step (contexts that
                             * assemble; others: never), 2 when the last solve took more than 10 iterations, 3 never after the
                             * first (Flow's default, and opmhip_default_config's).  The VALUES always follow the matrix. */
-    int reserved[3];       /* 0 */
+    int cpr_async_setup;   /* 1: with cpr_reuse_setup = 2 the new structure is built on a host thread BESIDE the solves and swapped in at
+                            * the first solve boundary after it is ready (the solves in between keep the old one; one build at a time);
+                            * which solve that is depends on the host's speed, so iteration counts are no longer reproducible run to
+                            * run.  0 (default): the reference's rule to the letter - the solve that finds the rule met waits for the
+                            * rebuild (0.28 s of host work at 10^6 cells).  (was reserved[0] until ABI 6) */
+    int reserved[2];       /* 0 */
 } opmhip_config;
 
 /* bda::BdaResult (bda/BdaResult.hpp:28-40) plus the reference's per-phase timers. */

@@ -179,6 +179,7 @@ int opmhip_create(const opmhip_config* cfg, opmhip_ctx** out) {
     if (cfg->preconditioner < OPMHIP_PRECOND_ILU0 || cfg->preconditioner > OPMHIP_PRECOND_CPR_TRUEIMPES) { g_err = "opmhip_create: unknown preconditioner"; return OPMHIP_INVALID_ARGUMENT; }
     if (cfg->chain_length < 0) { g_err = "opmhip_create: chain_length < 0"; return OPMHIP_INVALID_ARGUMENT; }
     if (cfg->cpr_reuse_setup < 0 || cfg->cpr_reuse_setup > 3) { g_err = "opmhip_create: cpr_reuse_setup must be 0 .. 3"; return OPMHIP_INVALID_ARGUMENT; }
+    if (cfg->cpr_async_setup < 0 || cfg->cpr_async_setup > 1) { g_err = "opmhip_create: cpr_async_setup must be 0 or 1"; return OPMHIP_INVALID_ARGUMENT; }
     int ndev = 0;
     hipError_t e = hipGetDeviceCount(&ndev);
     if (e != hipSuccess || ndev <= 0) {
@@ -204,6 +205,7 @@ void opmhip_destroy(opmhip_ctx* c) {
     if (!c) return;
     (void)hipSetDevice(c->device);
     if (c->stream) (void)hipStreamSynchronize(c->stream);
+    cpr_shutdown(c);
     comm_release(c);
     for (void* p : c->allocs) (void)hipFree(p);
     if (c->h_pinned) (void)hipHostFree(c->h_pinned);

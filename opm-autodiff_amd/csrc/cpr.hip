@@ -20,6 +20,9 @@
 #include <cmath>
 #include <cstdlib>
 #include <numeric>
+#include <atomic>
+#include <memory>
+#include <string>
 #include <thread>
 
 #include "internal.hpp"
@@ -554,31 +557,59 @@ __global__ __launch_bounds__(256) void k_cpr_add(int n, double* __restrict__ v, 
 static inline dim3 g256(int n) { return dim3((n + 255) / 256); }
 
 // ---------------------------------------------------------------- setup --------------------------------------------------
+// Host-side description of the hierarchy (cpr_build_coarse_host): everything the device arrays of a level are uploaded from.
+// The set-up is split in two so that its expensive half - matching, Galerkin lists, level images: pure host work on copies -
+// can run on a thread of its own beside the solves (--cpr-reuse-setup=2 with opmhip_config.cpr_async_setup), and only the uploads
+// touch the context.
+struct CprHostLevel {
+    int n = 0, nnz = 0, nc = 0, W = 0;
+    bool rm = false;
+    std::vector<int> ecol, rlen, diag;                           // ELL image of the level's pattern
+    std::vector<int> agg, mptr, midx, mem4, gptr, gidx, cpos;    // transfer to the next level (empty on the coarsest)
+};
+struct CprHostCoarse {
+    CprHostLevel l0;                 // of level 0 only the transfer part (its image belongs to the pattern: cpr_setup_level0)
+    std::vector<CprHostLevel> lv;    // levels 1 ..
+    double tAgg = 0.0, tGal = 0.0, tImg = 0.0;
+    std::string error;               // non-empty: the build failed
+};
+struct CprAsyncJob {
+    std::thread th;
+    std::atomic<int> ready{0};
+    CprHostCoarse result;
+    ~CprAsyncJob() { if (th.joinable()) th.join(); }
+};
 // ELL image of a level's pattern: columns (padding: the row itself), row lengths, position of the diagonal, position of every
 // CSR entry
-static int upload_ell(opmhip_ctx* c, const HCsr& A, CprLevelDev& L, std::vector<int>& pos, bool rowMajor, int ncols = INT_MAX) {
+static bool ell_image(const HCsr& A, CprHostLevel& L, std::vector<int>& pos, bool rowMajor, int ncols = INT_MAX) {
     const int n = A.n;
     int W = 1;
     for (int i = 0; i < n; ++i) W = std::max(W, A.rowptr[i + 1] - A.rowptr[i]);
-    if (W > CPR_MAX_W) return fail(c, OPMHIP_ANALYSIS_FAILED, "cpr: a row of a pressure-AMG level has %d entries (limit %d)", W, CPR_MAX_W);
     L.n = n; L.nnz = (int)A.col.size(); L.W = W; L.rm = rowMajor;
+    if (W > CPR_MAX_W) return false;
     // entry j of row i: [j * n + i] (one thread per row reads coalesced) or, row-major, [i * W + j] (a group of lanes per row does)
     auto at = [&](int j, int i) { return rowMajor ? (size_t)i * W + j : (size_t)j * n + i; };
-    std::vector<int> ecol((size_t)W * n), rlen(n), diag(n, 0);
+    L.ecol.assign((size_t)W * n, 0); L.rlen.assign(n, 0); L.diag.assign(n, 0);
     pos.resize(A.col.size());
     for (int i = 0; i < n; ++i) {
         const int kb = A.rowptr[i], len = A.rowptr[i + 1] - kb;
-        rlen[i] = len;
-        for (int j = 0; j < W; ++j) ecol[at(j, i)] = (j < len && A.col[kb + j] < ncols) ? A.col[kb + j] : i;   // padding and ghost columns (value 0 for good): the row itself
+        L.rlen[i] = len;
+        for (int j = 0; j < W; ++j) L.ecol[at(j, i)] = (j < len && A.col[kb + j] < ncols) ? A.col[kb + j] : i;   // padding and ghost columns (value 0 for good): the row itself
         for (int j = 0; j < len; ++j) {
             pos[kb + j] = (int)at(j, i);
-            if (A.col[kb + j] == i) diag[i] = (int)at(j, i);
+            if (A.col[kb + j] == i) L.diag[i] = (int)at(j, i);
         }
     }
+    return true;
+}
+static int upload_ell(opmhip_ctx* c, const CprHostLevel& H, CprLevelDev& L) {
+    const int n = H.n, W = H.W;
+    if (W > CPR_MAX_W) return fail(c, OPMHIP_ANALYSIS_FAILED, "cpr: a row of a pressure-AMG level has %d entries (limit %d)", W, CPR_MAX_W);
+    L.n = n; L.nnz = H.nnz; L.W = W; L.rm = H.rm;
     int rc;
-    if ((rc = dev_upload(c, &L.d_ecol, ecol))) return rc;
-    if ((rc = dev_upload(c, &L.d_rlen, rlen))) return rc;
-    if ((rc = dev_upload(c, &L.d_diag, diag))) return rc;
+    if ((rc = dev_upload(c, &L.d_ecol, H.ecol))) return rc;
+    if ((rc = dev_upload(c, &L.d_rlen, H.rlen))) return rc;
+    if ((rc = dev_upload(c, &L.d_diag, H.diag))) return rc;
     if ((rc = dev_alloc(c, &L.d_val, (size_t)W * n))) return rc;
     OPMHIP_HIP(c, hipMemset(L.d_val, 0, (size_t)W * n * sizeof(double)));   // the padding stays 0 for good
     if ((rc = dev_alloc(c, &L.d_dinv, (size_t)n))) return rc;
@@ -674,37 +705,16 @@ static int cpr_weights(opmhip_ctx* c) {
     hipLaunchKernelGGL(k_cpr_weights, g256(P.Nb), dim3(256), 0, c->stream, P.Nb, P.d_diag, c->d_A, R.d_w);
     return OPMHIP_SUCCESS;
 }
-// structure of the hierarchy, once per context, from the values of the pressure matrix of the system now on the device
 // levels of up to this many rows are kept row-major and run the lane-group kernels (OPMHIP_CPR_LPR_ROWS: measurement switch)
 static int cpr_lpr_rows() {
     static const int v = [] { const char* e = std::getenv("OPMHIP_CPR_LPR_ROWS"); return e ? std::atoi(e) : CPR_LPR_ROWS; }();
     return v;
 }
-static int cpr_setup_structure_impl(opmhip_ctx* c);
-// a set-up that fails half way gives back everything it allocated: a retry starts from a clean slate, nothing piles up
-static int cpr_setup_structure(opmhip_ctx* c) {
-    CprDev& R = c->cpr;
-    const size_t mark = c->allocs.size();
-    const bool hadW = R.d_w != nullptr;
-    const int rc = cpr_setup_structure_impl(c);
-    if (rc) {
-        (void)hipStreamSynchronize(c->stream);
-        while (c->allocs.size() > mark) { (void)hipFree(c->allocs.back()); c->allocs.pop_back(); }
-        R.lv.clear();
-        R.d_r = R.d_y = R.d_z = R.d_lu = R.d_pcol = nullptr;
-        if (!hadW) R.d_w = nullptr;
-        R.structured = false;
-    }
-    return rc;
-}
-static int cpr_setup_structure_impl(opmhip_ctx* c) {
+// ---- level 0: belongs to the PATTERN (image, stencil form, block-vector work space): built once per context ------------------
+static int cpr_setup_level0(opmhip_ctx* c) {
     const Pattern& P = c->pat;
     CprDev& R = c->cpr;
     int rc;
-    static const bool timing = std::getenv("OPMHIP_CPR_TIMING") != nullptr;
-    auto now = [] { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
-    double tAgg = 0.0, tGal = 0.0, tUp = 0.0, t0 = now();
-#define CPR_T(acc, stmt) do { const double t_ = now(); stmt; acc += now() - t_; } while (0)
     // Decomposed runs: every subdomain has a CPR of its own, over its owned rows and columns - the pressure hierarchy, like the
     // block ILU0 (ParallelOverlappingILU0.hpp:439-494), leaves the couplings to ghost cells out; the Krylov method carries them.
     // (The reference's parallel CPR coarsens ACROSS the processes with Dune's parallel AMG; this one does not.)
@@ -712,28 +722,14 @@ static int cpr_setup_structure_impl(opmhip_ctx* c) {
     if ((rc = dev_alloc(c, &R.d_r, (size_t)P.Nb * BS))) return rc;
     if ((rc = dev_alloc(c, &R.d_y, (size_t)P.Nb * BS))) return rc;
     if ((rc = dev_alloc(c, &R.d_z, (size_t)P.Nb * BS))) return rc;
-    // level 0: the block pattern itself (internal order), values = pressure matrix
     HCsr A;
-    A.n = P.Nb; A.rowptr = P.rowptr; A.col = P.col; A.val.resize(P.nnzb);
+    A.n = P.Nb; A.rowptr = P.rowptr; A.col = P.col;
     R.lv.clear();
     R.lv.emplace_back();
-    std::vector<int> pos;   // ELL position of every CSR entry of the level being coarsened
-    CPR_T(tUp, rc = upload_ell(c, A, R.lv[0], pos, false, P.Nb));
-    if (rc) return rc;
-    if (P.Nghost > 0) {   // the host copy the hierarchy is built from: owned columns only (pos follows the entries that stay)
-        HCsr F;
-        std::vector<int> fpos;
-        F.n = P.Nb; F.rowptr.assign(P.Nb + 1, 0);
-        for (int i = 0; i < P.Nb; ++i) {
-            for (int k = A.rowptr[i]; k < A.rowptr[i + 1]; ++k)
-                if (A.col[k] < P.Nb) { F.col.push_back(A.col[k]); fpos.push_back(pos[k]); }
-            F.rowptr[i + 1] = (int)F.col.size();
-        }
-        F.val.resize(F.col.size());
-        A = std::move(F);
-        pos = std::move(fpos);
-    }
-    const int nnz0 = (int)A.col.size();
+    CprHostLevel H0;
+    std::vector<int> pos;
+    (void)ell_image(A, H0, pos, false, P.Nb);
+    if ((rc = upload_ell(c, H0, R.lv[0]))) return rc;
     {   // level 0's ELL columns in stencil form (EllStencil), where the pattern has it: single domain, rows of <= 8 entries, <= 15 offsets per group of 32 rows
         static const bool off = [] { const char* e = std::getenv("OPMHIP_CPR_ELL_EXPLICIT"); return e && e[0] == '1'; }();   // A/B switch
         bool ok = !off && P.Nghost == 0 && R.lv[0].W <= 8;
@@ -765,26 +761,51 @@ static int cpr_setup_structure_impl(opmhip_ctx* c) {
     }
     if ((rc = dev_alloc(c, &R.d_pcol, (size_t)3 * R.lv[0].W * P.Nb))) return rc;     // pressure columns of the blocks, ELL, component-major
     OPMHIP_HIP(c, hipMemsetAsync(R.d_pcol, 0, (size_t)3 * R.lv[0].W * P.Nb * sizeof(double), c->stream));   // the padding stays 0
-    if ((rc = cpr_weights(c))) return rc;
-    hipLaunchKernelGGL(k_cpr_pvals, g256(P.Nb), dim3(256), 0, c->stream, P.Nb, R.lv[0].W, P.d_rowptr, P.Nghost > 0 ? P.d_col : (const int*)nullptr, c->d_A, R.d_w, R.lv[0].d_val, R.d_pcol);
-    {
-        std::vector<double> ell((size_t)R.lv[0].W * P.Nb);
-        OPMHIP_HIP(c, hipMemcpyAsync(ell.data(), R.lv[0].d_val, ell.size() * sizeof(double), hipMemcpyDeviceToHost, c->stream));
-        OPMHIP_HIP(c, hipStreamSynchronize(c->stream));
-        for (int k = 0; k < nnz0; ++k) A.val[k] = ell[pos[k]];
+    R.level0 = true;
+    return OPMHIP_SUCCESS;
+}
+// ---- everything below level 0's image, on the host: two passes of pairwise matching per level, Galerkin lists, level images.
+//      Pure host work on its arguments (no context, no HIP call): may run on a thread of its own.  ell0: level 0's value image
+//      (W0 x Nb, as on the device) of the pressure matrix the structure is built from.
+static void cpr_build_coarse_host(const Pattern& P, const std::vector<double>& ell0, double beta, int lprRows, CprHostCoarse& out) {
+    auto now = [] { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+#define CPR_T(acc, stmt) do { const double t_ = now(); stmt; acc += now() - t_; } while (0)
+    HCsr A;
+    A.n = P.Nb; A.rowptr = P.rowptr; A.col = P.col;
+    CprHostLevel img0;
+    std::vector<int> pos;   // ELL position of every CSR entry of the level being coarsened
+    CPR_T(out.tImg, (void)ell_image(A, img0, pos, false, P.Nb));
+    if (P.Nghost > 0) {   // the host copy the hierarchy is built from: owned columns only (pos follows the entries that stay)
+        HCsr F;
+        std::vector<int> fpos;
+        F.n = P.Nb; F.rowptr.assign(P.Nb + 1, 0);
+        for (int i = 0; i < P.Nb; ++i) {
+            for (int k = A.rowptr[i]; k < A.rowptr[i + 1]; ++k)
+                if (A.col[k] < P.Nb) { F.col.push_back(A.col[k]); fpos.push_back(pos[k]); }
+            F.rowptr[i + 1] = (int)F.col.size();
+        }
+        A = std::move(F);
+        pos = std::move(fpos);
     }
+    const int nnz0 = (int)A.col.size();
+    A.val.resize(nnz0);
+    for (int k = 0; k < nnz0; ++k) A.val[k] = ell0[pos[k]];
+    out.lv.clear();
+    CprHostLevel* cur = &out.l0;   // the level being coarsened (its transfer part is filled here)
+    cur->n = A.n;
+    int nlev = 1;
     while (true) {
-        const bool last = A.n <= CPR_COARSE_DIRECT || (int)R.lv.size() >= CPR_MAX_LEVELS;
+        const bool last = A.n <= CPR_COARSE_DIRECT || nlev >= CPR_MAX_LEVELS;
         if (last) break;
         std::vector<int> a1, a2, g1p, g1i;
         int n1 = 0, n2 = 0;
         HCsr A1;
         for (int attempt = 0; attempt < 3; ++attempt) {
-            const double b = attempt == 0 ? R.beta : 0.0;
-            const bool lvl0 = R.lv.size() == 1;   // the finest level is stored in the ILU ordering: visit it in natural order
-            CPR_T(tAgg, pairwise(A, b, attempt == 2, a1, n1, lvl0 ? P.fromOrder.data() : nullptr, lvl0 ? P.toOrder.data() : nullptr));
-            CPR_T(tGal, galerkin(A, a1, n1, A1, g1p, g1i));
-            CPR_T(tAgg, pairwise(A1, b, attempt == 2, a2, n2));
+            const double b = attempt == 0 ? beta : 0.0;
+            const bool lvl0 = nlev == 1;   // the finest level is stored in the ILU ordering: visit it in natural order
+            CPR_T(out.tAgg, pairwise(A, b, attempt == 2, a1, n1, lvl0 ? P.fromOrder.data() : nullptr, lvl0 ? P.toOrder.data() : nullptr));
+            CPR_T(out.tGal, galerkin(A, a1, n1, A1, g1p, g1i));
+            CPR_T(out.tAgg, pairwise(A1, b, attempt == 2, a2, n2));
             if (n2 <= (int)(0.5 * A.n)) break;
         }
         if (n2 >= (int)(0.8 * A.n)) break;   // coarsening stalls: this level is the coarsest
@@ -792,7 +813,7 @@ static int cpr_setup_structure_impl(opmhip_ctx* c) {
         for (int i = 0; i < A.n; ++i) agg[i] = a2[a1[i]];
         HCsr Ac;
         std::vector<int> gptr, gidx;
-        CPR_T(tGal, galerkin(A, agg, n2, Ac, gptr, gidx));
+        CPR_T(out.tGal, galerkin(A, agg, n2, Ac, gptr, gidx));
         {   // a coarse level whose rows outgrow the ELL image (fault- and NNC-heavy patterns): stop here, this level is the coarsest
             int Wc = 1;
             for (int I = 0; I < Ac.n; ++I) Wc = std::max(Wc, Ac.rowptr[I + 1] - Ac.rowptr[I]);
@@ -806,69 +827,167 @@ static int cpr_setup_structure_impl(opmhip_ctx* c) {
             std::vector<int> wpos(mptr.begin(), mptr.end() - 1);
             for (int i = 0; i < A.n; ++i) midx[wpos[agg[i]]++] = i;
         }
-        {
-            CprLevelDev& L = R.lv.back();
-            L.nc = n2;
-            if ((rc = dev_upload(c, &L.d_agg, agg))) return rc;
-            if ((rc = dev_upload(c, &L.d_mptr, mptr))) return rc;
-            if ((rc = dev_upload(c, &L.d_midx, midx))) return rc;
-            {   // four-int member records (two pairwise passes: never more than four members) for cpr_restricted
-                std::vector<int> mem4((size_t)4 * n2, -1);
-                bool fits = true;
-                for (int I = 0; I < n2 && fits; ++I) {
-                    fits = mptr[I + 1] - mptr[I] <= 4 && mptr[I + 1] > mptr[I];
-                    for (int q = mptr[I]; fits && q < mptr[I + 1]; ++q) mem4[(size_t)4 * I + (q - mptr[I])] = midx[q];
-                }
-                if (fits && (rc = dev_upload(c, &L.d_mem4, mem4))) return rc;
+        cur->nc = n2;
+        {   // four-int member records (two pairwise passes: never more than four members) for cpr_restricted
+            std::vector<int> mem4((size_t)4 * n2, -1);
+            bool fits = true;
+            for (int I = 0; I < n2 && fits; ++I) {
+                fits = mptr[I + 1] - mptr[I] <= 4 && mptr[I + 1] > mptr[I];
+                for (int q = mptr[I]; fits && q < mptr[I + 1]; ++q) mem4[(size_t)4 * I + (q - mptr[I])] = midx[q];
             }
-            if ((rc = dev_upload(c, &L.d_gptr, gptr))) return rc;
-            if ((rc = dev_upload(c, &L.d_gidx, gidx))) return rc;
+            if (fits) cur->mem4 = std::move(mem4); else cur->mem4.clear();
         }
-        R.lv.emplace_back();
+        cur->agg = std::move(agg); cur->mptr = std::move(mptr); cur->midx = std::move(midx);
+        cur->gptr = std::move(gptr); cur->gidx = std::move(gidx);
+        out.lv.emplace_back();
         std::vector<int> cposv;
-        CPR_T(tUp, rc = upload_ell(c, Ac, R.lv.back(), cposv, Ac.n <= cpr_lpr_rows()));
-        if (rc) return rc;
-        if ((rc = dev_upload(c, &R.lv[R.lv.size() - 2].d_cpos, cposv))) return rc;   // where the coarse entries go
-        pos = cposv;
+        bool fitsW = true;
+        CPR_T(out.tImg, fitsW = ell_image(Ac, out.lv.back(), cposv, Ac.n <= lprRows));
+        if (!fitsW) { out.error = "cpr: a row of a pressure-AMG level outgrew the level image"; return; }
+        // (out.lv may have reallocated: cur is looked up again)
+        CprHostLevel* fine = out.lv.size() == 1 ? &out.l0 : &out.lv[out.lv.size() - 2];
+        fine->cpos = cposv;                                   // where the coarse entries go
+        cur = &out.lv.back();
+        pos = std::move(cposv);
         A = std::move(Ac);
+        ++nlev;
+    }
+#undef CPR_T
+}
+// ---- the device side of it: transfer arrays of every level, images of the levels below level 0 --------------------------------
+static int cpr_upload_coarse(opmhip_ctx* c, const CprHostCoarse& H) {
+    CprDev& R = c->cpr;
+    int rc;
+    if (!H.error.empty()) return fail(c, OPMHIP_ANALYSIS_FAILED, "%s", H.error.c_str());
+    auto transfer = [&](const CprHostLevel& h, CprLevelDev& L) -> int {
+        if (h.agg.empty()) return OPMHIP_SUCCESS;   // the coarsest level
+        L.nc = h.nc;
+        if ((rc = dev_upload(c, &L.d_agg, h.agg))) return rc;
+        if ((rc = dev_upload(c, &L.d_mptr, h.mptr))) return rc;
+        if ((rc = dev_upload(c, &L.d_midx, h.midx))) return rc;
+        if (!h.mem4.empty() && (rc = dev_upload(c, &L.d_mem4, h.mem4))) return rc;
+        if ((rc = dev_upload(c, &L.d_gptr, h.gptr))) return rc;
+        if ((rc = dev_upload(c, &L.d_gidx, h.gidx))) return rc;
+        if ((rc = dev_upload(c, &L.d_cpos, h.cpos))) return rc;
+        return OPMHIP_SUCCESS;
+    };
+    R.lv.resize(1);
+    if ((rc = transfer(H.l0, R.lv[0]))) return rc;
+    for (const CprHostLevel& h : H.lv) {
+        R.lv.emplace_back();
+        if ((rc = upload_ell(c, h, R.lv.back()))) return rc;
+        if ((rc = transfer(h, R.lv.back()))) return rc;
     }
     R.coarse_direct = R.lv.back().n <= CPR_COARSE_DIRECT;
     if (R.coarse_direct && (rc = dev_alloc(c, &R.d_lu, (size_t)R.lv.back().n * R.lv.back().n + 1))) return rc;   // + 1: the pivot flag
     R.structured = true;
-    if (timing) std::fprintf(stderr, "opmhip cpr set-up: %.3f s (matching %.3f, Galerkin %.3f, level images + uploads %.3f), %zu levels\n", now() - t0, tAgg, tGal, tUp, R.lv.size());
-#undef CPR_T
     return OPMHIP_SUCCESS;
 }
-
-// values: weights, pressure matrix, Galerkin values down the hierarchy, inverse diagonals, coarsest LU (every solve)
-// gives the hierarchy's device arrays back (everything cpr_setup_structure allocates; handed-in weights stay)
-static void cpr_release_structure(opmhip_ctx* c) {
+// gives back what cpr_upload_coarse allocated: level 0 keeps its image, the levels below it go
+static void cpr_release_coarse(opmhip_ctx* c) {
     CprDev& R = c->cpr;
     (void)hipStreamSynchronize(c->stream);
-    for (CprLevelDev& L : R.lv) {
-        dev_free(c, &L.d_ecol); dev_free(c, &L.d_rlen); dev_free(c, &L.d_diag); dev_free(c, &L.d_cpos);
+    for (size_t l = 0; l < R.lv.size(); ++l) {
+        CprLevelDev& L = R.lv[l];
+        dev_free(c, &L.d_agg); dev_free(c, &L.d_mptr); dev_free(c, &L.d_midx); dev_free(c, &L.d_mem4); dev_free(c, &L.d_gptr); dev_free(c, &L.d_gidx); dev_free(c, &L.d_cpos);
+        L.nc = 0;
+        if (l == 0) continue;
+        dev_free(c, &L.d_ecol); dev_free(c, &L.d_rlen); dev_free(c, &L.d_diag);
         dev_free(c, &L.d_val); dev_free(c, &L.d_dinv); dev_free(c, &L.d_x2);
-        dev_free(c, &L.d_agg); dev_free(c, &L.d_mptr); dev_free(c, &L.d_midx); dev_free(c, &L.d_mem4); dev_free(c, &L.d_gptr); dev_free(c, &L.d_gidx);
         dev_free(c, &L.d_b); dev_free(c, &L.d_x); dev_free(c, &L.d_r); dev_free(c, &L.d_sword); dev_free(c, &L.d_stable);
     }
-    R.lv.clear();
-    dev_free(c, &R.d_r); dev_free(c, &R.d_y); dev_free(c, &R.d_z); dev_free(c, &R.d_lu); dev_free(c, &R.d_pcol);
+    if (!R.lv.empty()) R.lv.resize(1);
+    dev_free(c, &R.d_lu);
     R.structured = false;
 }
+// level 0's values as they are on the device now (k_cpr_pvals ran): the matrix a structure is built from
+static int cpr_download_level0(opmhip_ctx* c, std::vector<double>& ell) {
+    const CprLevelDev& L0 = c->cpr.lv[0];
+    ell.resize((size_t)L0.W * c->pat.Nb);
+    OPMHIP_HIP(c, hipMemcpyAsync(ell.data(), L0.d_val, ell.size() * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+    OPMHIP_HIP(c, hipStreamSynchronize(c->stream));
+    return OPMHIP_SUCCESS;
+}
+// the structure from the pressure matrix now in level 0's image, synchronously; a set-up that fails half way gives back
+// everything it allocated: a retry starts from a clean slate, nothing piles up
+static int cpr_setup_coarse_now(opmhip_ctx* c) {
+    CprDev& R = c->cpr;
+    static const bool timing = std::getenv("OPMHIP_CPR_TIMING") != nullptr;
+    auto now = [] { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+    const double t0 = now();
+    std::vector<double> ell;
+    int rc;
+    if ((rc = cpr_download_level0(c, ell))) return rc;
+    CprHostCoarse H;
+    cpr_build_coarse_host(c->pat, ell, R.beta, cpr_lpr_rows(), H);
+    const double t1 = now();
+    const size_t mark = c->allocs.size();
+    rc = cpr_upload_coarse(c, H);
+    if (rc) {
+        (void)hipStreamSynchronize(c->stream);
+        while (c->allocs.size() > mark) { (void)hipFree(c->allocs.back()); c->allocs.pop_back(); }
+        for (size_t l = 0; l < R.lv.size(); ++l) {
+            CprLevelDev& L = R.lv[l];
+            L.d_agg = L.d_mptr = L.d_midx = L.d_mem4 = L.d_gptr = L.d_gidx = L.d_cpos = nullptr;
+        }
+        if (!R.lv.empty()) R.lv.resize(1);
+        R.d_lu = nullptr;
+        R.structured = false;
+        return rc;
+    }
+    if (timing) std::fprintf(stderr, "opmhip cpr set-up: %.3f s (matching %.3f, Galerkin %.3f, level images %.3f, uploads %.3f), %zu levels\n", now() - t0, H.tAgg, H.tGal, H.tImg, now() - t1, R.lv.size());
+    return OPMHIP_SUCCESS;
+}
+void cpr_shutdown(opmhip_ctx* c) { c->cpr.job.reset(); }
 int cpr_update(opmhip_ctx* c) {
     const Pattern& P = c->pat;
     CprDev& R = c->cpr;
     int rc;
+    bool startAsync = false;
     if (R.structured) {   // --cpr-reuse-setup (ISTLSolverEbos.hpp:401-426 shouldCreateSolver): build the structure anew from this matrix?
         const int mode = c->cfg.cpr_reuse_setup;
-        const bool anew = R.recreate || mode == 0 || (mode == 1 && c->asmb.assembled && c->asmb.last_iteration == 0) || (mode == 2 && c->last_solve_iterations > 10);
-        if (anew) cpr_release_structure(c);
+        bool anew = R.recreate || mode == 0 || (mode == 1 && c->asmb.assembled && c->asmb.last_iteration == 0) || (mode == 2 && c->last_solve_iterations > 10);
+        if (mode == 2 && c->cfg.cpr_async_setup && !R.recreate) {
+            // the rebuild beside the solves: a build that has finished is swapped in at this solve boundary; a new one is started
+            // when the rule asks for it and none is under way; this solve goes on with the structure it has
+            if (R.job && R.job->ready.load(std::memory_order_acquire)) {
+                R.job->th.join();
+                cpr_release_coarse(c);
+                const size_t mark = c->allocs.size();
+                rc = cpr_upload_coarse(c, R.job->result);
+                R.job.reset();
+                if (rc) {   // (cannot happen for a pattern that was set up once; if it does: back to a synchronous set-up below)
+                    (void)hipStreamSynchronize(c->stream);
+                    while (c->allocs.size() > mark) { (void)hipFree(c->allocs.back()); c->allocs.pop_back(); }
+                    for (CprLevelDev& L : R.lv) L.d_agg = L.d_mptr = L.d_midx = L.d_mem4 = L.d_gptr = L.d_gidx = L.d_cpos = nullptr;
+                    R.lv.resize(1); R.d_lu = nullptr; R.structured = false;
+                }
+            } else if (anew && !R.job) startAsync = true;
+            anew = false;
+        }
+        if (anew) { R.job.reset(); cpr_release_coarse(c); }
     }
     R.recreate = false;
-    if (!R.structured && (rc = cpr_setup_structure(c))) return rc;
+    if (!R.level0 && (rc = cpr_setup_level0(c))) return rc;
     const int ps = prof_begin(c, PROF_ILU_FACTOR);
     if ((rc = cpr_weights(c))) { prof_end(c, ps); return rc; }
     hipLaunchKernelGGL(k_cpr_pvals, g256(P.Nb), dim3(256), 0, c->stream, P.Nb, R.lv[0].W, P.d_rowptr, P.Nghost > 0 ? P.d_col : (const int*)nullptr, c->d_A, R.d_w, R.lv[0].d_val, R.d_pcol);
+    if (!R.structured) {   // first solve, or a synchronous rebuild: from the pressure matrix just formed
+        if ((rc = cpr_setup_coarse_now(c))) { prof_end(c, ps); return rc; }
+    } else if (startAsync) {
+        R.job = std::make_shared<CprAsyncJob>();
+        std::shared_ptr<CprAsyncJob> job = R.job;
+        auto ell = std::make_shared<std::vector<double>>();
+        if ((rc = cpr_download_level0(c, *ell))) { R.job.reset(); prof_end(c, ps); return rc; }
+        const Pattern* pat = &c->pat;   // outlives the job: cpr_release_structure / cpr_shutdown join it before the pattern goes
+        const double beta = R.beta;
+        const int lpr = cpr_lpr_rows();
+        CprAsyncJob* raw = job.get();
+        job->th = std::thread([raw, ell, pat, beta, lpr]() {
+            cpr_build_coarse_host(*pat, *ell, beta, lpr, raw->result);
+            raw->ready.store(1, std::memory_order_release);
+        });
+    }
     for (size_t l = 0; l < R.lv.size(); ++l) {
         CprLevelDev& L = R.lv[l];
         hipLaunchKernelGGL(k_cpr_dinv, g256(L.n), dim3(256), 0, c->stream, L.n, L.d_diag, L.d_val, L.d_dinv);

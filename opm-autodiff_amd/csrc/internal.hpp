@@ -5,6 +5,7 @@
 #include <cstdarg>
 #include <cstdio>
 #include <cstring>
+#include <memory>
 #include <string>
 #include <vector>
 
@@ -212,8 +213,11 @@ struct CprLevelDev {
     unsigned* d_sword = nullptr;
     int* d_stable = nullptr;
 };
+struct CprAsyncJob;   // cpr.hip: a structure being built on a host thread (--cpr-reuse-setup=2 with cpr_async_setup)
 struct CprDev {
     bool structured = false, coarse_direct = true;
+    bool level0 = false;                                           // level 0's image (it belongs to the pattern) is on the device
+    std::shared_ptr<CprAsyncJob> job;
     bool recreate = false;                                         // opmhip_cpr_recreate: the next cpr_update builds the structure anew
     std::vector<CprLevelDev> lv;
     double *d_w = nullptr, *d_lu = nullptr;
@@ -430,6 +434,7 @@ int cpr_update(opmhip_ctx* c);
 void launch_cpr_apply(opmhip_ctx* c, const double* d, double* v);
 int cpr_set_weights(opmhip_ctx* c, const double* w);
 int cpr_level_sizes(const opmhip_ctx* c, int* n, int* nnz, int cap);
+void cpr_shutdown(opmhip_ctx* c);   // joins a structure build in flight (before the context goes)
 bool cpr_coarse_pivot_failed(opmhip_ctx* c);
 inline bool use_cpr(const opmhip_ctx* c) { return c->cfg.preconditioner == OPMHIP_PRECOND_CPR_QUASIIMPES || c->cfg.preconditioner == OPMHIP_PRECOND_CPR_TRUEIMPES; }
 void launch_wells_apply(opmhip_ctx* c, const double* x, double* y, double xs = 1.0);

@@ -171,8 +171,8 @@ int main(int argc, char** argv) {
             same = std::memcmp(rdev.data(), r.data(), r.size() * 8) == 0;
         }
         opmhip_result ra{}, rb{};
-        CK(lin.context(), opmhip_solve_system(lin.context(), N, nnz, 3, nullptr, nullptr, nullptr, nullptr, nullptr, &ra));
-        CK(ref, opmhip_solve_system(ref, N, nnz, 3, nullptr, nullptr, nullptr, nullptr, nullptr, &rb));
+        CK(lin.context(), opmhip_solve_system(lin.context(), N * 3, nnz * 9, 3, nullptr, nullptr, nullptr, nullptr, nullptr, &ra));
+        CK(ref, opmhip_solve_system(ref, N * 3, nnz * 9, 3, nullptr, nullptr, nullptr, nullptr, nullptr, &rb));
         lin.updateSolutionOnDevice(1.0);
         CK(ref, opmhip_update(ref, nullptr, 1.0, nullptr));
         CK(ref, opmhip_get_state(ref, pvB.data(), mB.data()));

@@ -11,7 +11,7 @@ def test_library_exports_every_declared_symbol(pkg):
     assert len(names) >= 12
     missing = [n for n in names if not hasattr(L, n)]
     assert not missing, missing
-    assert L.opmhip_abi_version() == 5
+    assert L.opmhip_abi_version() == 6
 
 
 def test_default_config_matches_flow_defaults(pkg):
@@ -21,7 +21,7 @@ def test_default_config_matches_flow_defaults(pkg):
     assert (cfg.maxit, cfg.tolerance, cfg.ilu_relaxation) == (200, 1e-2, 0.9)
     assert cfg.reorder == pkg.capi.REORDER["graph_coloring"] and cfg.zero_diag_fix == 1
     # --linear-solver-configuration=ilu0, --cpr-reuse-setup=3 (FlowLinearSolverParameters.hpp:212-214)
-    assert cfg.preconditioner == pkg.capi.PRECONDITIONER["ilu0"] and cfg.cpr_reuse_setup == 3 and cfg.chain_length == 0
+    assert cfg.preconditioner == pkg.capi.PRECONDITIONER["ilu0"] and cfg.cpr_reuse_setup == 3 and cfg.cpr_async_setup == 0 and cfg.chain_length == 0
 
 
 def test_no_gpu_means_loud_failure(pkg):

@@ -262,8 +262,10 @@ def test_spe9_shaped_well_residual_and_recovery(pkg, orc):
 def test_norne_shaped_grid_with_the_features_the_norne_deck_uses(pkg, orc, norne_grid):
     """configs[4] closer to the deck: on the faulted corner-point grid a fluid with PVTG (vaporised oil), two saturation
     regions, per-cell scaled saturation end points (ENDSCALE with SCALECRS and vertical scaling, as the deck's SWL / SWCR / SGU /
-    KRW ... arrays do), DRSDT with its time-step bookkeeping, irreversible rock compaction tables - everything at once through
-    begin_time_step / assemble / solve / update / end_time_step for two time steps, device against oracle bit for bit."""
+    KRW ... arrays do), relative-permeability hysteresis (SATOPTS HYSTER / EHYSTR / IMBNUM with ISWL ... end points of the
+    imbibition curves, as the deck has them), DRSDT with its time-step bookkeeping, irreversible rock compaction tables -
+    everything at once through begin_time_step / assemble / solve / update / end_time_step for three time steps (sources
+    reversed in the last: scanning curves), device against oracle bit for bit."""
     from test_oracle_endscale import corey_fluid, scaled_points
     import helpers
     base, g, dims = norne_grid
@@ -298,10 +300,26 @@ def test_norne_shaped_grid_with_the_features_the_norne_deck_uses(pkg, orc, norne
         q.set_state(case["pv"], case["meaning"])
         q.set_composition_change_limits([3.0e-6], [0], [5.0e-12])
         q.set_irreversible_compaction(True)
+    # hysteresis: every cell's imbibition curves are those of the OTHER saturation region, with end points of their own
+    imbnum = (1 - case["satnum"]).astype(np.int32)
+    ptsI = np.array([scaled_points(u[s], rng) for s in imbnum])
+    imb = {name: np.ascontiguousarray(ptsI[:, f]) for f, name in enumerate(pkg.capi.EPS_FIELDS)}
+    for q in (m, o):
+        q.set_hysteresis(1, imbnum, imb)
     assert np.array_equal(m.iq(), o.iq())
-    for step, dt in enumerate([0.5 * 86400.0, 86400.0]):
+    src = np.zeros((n, 3))
+    wellcells = rng.choice(n, 12, replace=False)
+    src[wellcells[:6], 1] = 2e-3       # water in
+    src[wellcells[6:], 0] = -1.5e-3    # oil out
+    src = src.reshape(-1)
+    scanning = 0
+    for step, dt in enumerate([0.5 * 86400.0, 86400.0, 86400.0]):
         for q in (m, o):
+            q.set_source(src if step < 2 else -src)
             q.begin_time_step(dt)
+        for a, b in zip(m.hysteresis(), o.hysteresis()):
+            assert np.array_equal(a, b)
+        scanning += int(np.sum(1.0 - m.iq()[:, 1, 0] > m.hysteresis()[0]))
         assert np.array_equal(m.iq(), o.iq())
         for it in range(2):
             jm, rm = m.assemble(dt, it)
@@ -319,4 +337,4 @@ def test_norne_shaped_grid_with_the_features_the_norne_deck_uses(pkg, orc, norne
             q.end_time_step(dt)
         for a, b in zip(m.trackers(), o.trackers()):
             assert np.array_equal(a, b)
-    assert len(set(mm.tolist())) == 3
+    assert len(set(mm.tolist())) == 3 and scanning > 0

@@ -251,3 +251,38 @@ def test_cpr_reuse_setup_modes(pkg, orc, mode):
     assert s.cpr_levels()[0] == [int(x) for x in cpr.levels()[0]]
     if not anew:
         assert s.cpr_levels() == lv1
+
+
+def test_cpr_rebuild_beside_the_solves(pkg, orc):
+    """--cpr-reuse-setup=2 with opmhip_config.cpr_async_setup: the solve that meets the rule (> 10 iterations) keeps the structure
+    it has and a host thread builds the new one from ITS matrix; a later solve swaps it in.  Once swapped in, the preconditioner
+    is the oracle's CPR with the structure of the triggering matrix and the values of the matrix in hand, bit for bit."""
+    import time
+    case, jac1, res1 = jacobian_case(pkg, orc, its=1)
+    _, jac2, res2 = jacobian_case(pkg, orc, dt_days=40.0, its=3)
+    Nb, rp, ci = case["Nb"], case["rowptr"], case["col"]
+    s = pkg.capi.HipSolver(reorder="line_coloring", preconditioner="cpr_quasiimpes", tolerance=1e-10, maxit=100, cpr_reuse_setup=2, cpr_async_setup=1)
+    r1 = s.solve_system(Nb, rp, ci, jac1.copy(), res1)        # first solve: synchronous set-up from jac1; a long solve
+    assert r1.converged and r1.iterations > 10
+    d = np.random.default_rng(5).standard_normal(3 * Nb)
+    r2 = s.solve_system(Nb, rp, ci, jac2.copy(), res2)        # meets the rule: starts the build from jac2, solves with jac1's structure
+    assert r2.converged
+    to, fr, rr1, rc1, rv1 = reordered(orc, s, Nb, rp, ci, jac1)
+    _, _, rr2, rc2, rv2 = reordered(orc, s, Nb, rp, ci, jac2)
+    old = oracle_bind.OracleCpr(orc)
+    old.set_natural_ids(fr)
+    old.update(Nb, rr1, rc1, rv1)
+    old.update(Nb, rr2, rc2, rv2)                             # structure of jac1, values of jac2
+    new = oracle_bind.OracleCpr(orc)
+    new.set_natural_ids(fr)
+    new.update(Nb, rr2, rc2, rv2)                             # structure and values of jac2
+    d_int = np.ascontiguousarray(d.reshape(Nb, 3)[fr].reshape(-1))
+    v_old = old.apply(d_int).reshape(Nb, 3)[to].reshape(-1)
+    v_new = new.apply(d_int).reshape(Nb, 3)[to].reshape(-1)
+    assert not np.array_equal(v_old, v_new)
+    assert np.array_equal(s.cpr_apply(d), v_old)              # the triggering solve kept the old structure
+    time.sleep(1.0)                                           # the build of a few thousand cells takes milliseconds
+    r3 = s.solve_system(Nb, rp, ci, jac2.copy(), res2)        # this solve boundary swaps the finished structure in
+    assert r3.converged
+    assert np.array_equal(s.cpr_apply(d), v_new)
+    assert s.cpr_levels()[0] == [int(x) for x in new.levels()[0]]
