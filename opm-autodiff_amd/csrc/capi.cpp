@@ -519,7 +519,7 @@ int opmhip_cpr_apply(opmhip_ctx* c, const double* d, double* v) {
         if (!c->factored) return fail(c, OPMHIP_NOT_READY, "cpr_apply before ilu0_factor (the fine smoother's factors)");
         OPMHIP_HIP(c, hipSetDevice(c->device));
         int rc;
-        if ((rc = cpr_update(c))) return rc;
+        if ((rc = cpr_update(c, false))) return rc;
         if ((rc = vec_in(c, d, c->d_p))) return rc;
         launch_cpr_apply(c, c->d_p, c->d_pw);
         OPMHIP_HIP(c, hipGetLastError());

@@ -939,12 +939,12 @@ static int cpr_setup_coarse_now(opmhip_ctx* c) {
     return OPMHIP_SUCCESS;
 }
 void cpr_shutdown(opmhip_ctx* c) { c->cpr.job.reset(); }
-int cpr_update(opmhip_ctx* c) {
+int cpr_update(opmhip_ctx* c, bool solveBoundary) {
     const Pattern& P = c->pat;
     CprDev& R = c->cpr;
     int rc;
     bool startAsync = false;
-    if (R.structured) {   // --cpr-reuse-setup (ISTLSolverEbos.hpp:401-426 shouldCreateSolver): build the structure anew from this matrix?
+    if (R.structured && (solveBoundary || R.recreate)) {   // --cpr-reuse-setup (ISTLSolverEbos.hpp:401-426 shouldCreateSolver): build the structure anew from this matrix?
         const int mode = c->cfg.cpr_reuse_setup;
         bool anew = R.recreate || mode == 0 || (mode == 1 && c->asmb.assembled && c->asmb.last_iteration == 0) || (mode == 2 && c->last_solve_iterations > 10);
         if (mode == 2 && c->cfg.cpr_async_setup && !R.recreate) {

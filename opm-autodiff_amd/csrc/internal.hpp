@@ -212,6 +212,18 @@ struct CprLevelDev {
     // into the table of <= 15 column offsets its aligned group of 32 rows shares; NULL: the explicit column image d_ecol is read
     unsigned* d_sword = nullptr;
     int* d_stable = nullptr;
+    // ILU0 smoothing (opmhip_config.cpr_amg_ilu_levels; cpr.hip: CprIluHost): scalar factors in the level's own image (strict lower = L,
+    // diagonal = 1 / U_ii, strict upper = U), per row the words that say which slots are lower / upper entries in the level's elimination
+    // order, the lower slots in the order the factorisation visits them, and a launch schedule: colour by colour, one thread per SEQUENCE
+    // of rows that depend on each other inside the colour (level 0 of a line-coloured pattern: the chains; otherwise single rows)
+    bool ilu = false;
+    int iluMW = 0, iluWL = 0;                                      // mask words per kind, lower slots per row at most
+    double *d_fval = nullptr, *d_t = nullptr;
+    unsigned* d_imask = nullptr;                                   // [2 * iluMW][n]: lower words, then upper words
+    unsigned char* d_lorder = nullptr;                             // [iluWL][n], 255 = none
+    int* d_rowAt = nullptr;                                        // per colour [steps][sequences]: row or -1
+    std::vector<int> iluNseq, iluNsteps, iluOff;                   // per colour
+    std::vector<char> iluFast;                                     // per colour: same-colour couplings are the sequence's neighbours only (register forwarding)
 };
 struct CprAsyncJob;   // cpr.hip: a structure being built on a host thread (--cpr-reuse-setup=2 with cpr_async_setup)
 struct CprDev {
@@ -430,7 +442,9 @@ void launch_wells_recover(opmhip_ctx* c, const double* d_resWell, const double* 
 void launch_ilu_factor(opmhip_ctx* c, bool fix_zero_diagonal = false);
 void launch_ilu_apply(opmhip_ctx* c, const double* d, double* v, double w_override = -1.0, double* unscaled = nullptr, const double* addp = nullptr, double* work = nullptr);
 // cpr.hip
-int cpr_update(opmhip_ctx* c);
+// solveBoundary: the --cpr-reuse-setup rules are looked at (a structure may be rebuilt, started or swapped in); false (opmhip_cpr_apply:
+// a look at the preconditioner between two solves): values only, the structure stays as the last solve left it
+int cpr_update(opmhip_ctx* c, bool solveBoundary = true);
 void launch_cpr_apply(opmhip_ctx* c, const double* d, double* v);
 int cpr_set_weights(opmhip_ctx* c, const double* w);
 int cpr_level_sizes(const opmhip_ctx* c, int* n, int* nnz, int cap);
