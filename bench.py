@@ -79,18 +79,22 @@ def alg_bytes(Nb, nnzb):
     }
 
 
-def cpr_amg_bytes(Nb, level_n, level_nnz):
+def cpr_amg_bytes(Nb, level_n, level_nnz, ilu_levels=0):
     """Algorithmic bytes of one application of the pressure AMG (csrc/cpr.hip: k_cpr_restrict_fine + cpr_vcycle, the scope the
     profiler books under `cpr_amg`), from the hierarchy's own level sizes (opmhip_cpr_levels): per level that is not the coarsest
     TWO matrix passes (residual on the way down, post-smoothing on the way up) over 8-byte values and 4-byte column indices of
     the level's entries, and its vector passes - residual (b, x in, r out), restriction (r in; b and x of the coarser level out),
     prolongation (aggregate map, x in, x' out, the coarse x in), post-smoothing (1/diag, b, x' in, x out): 84 B per row + 24 B per
     coarse row; the restriction of the block residual in front (d and the weights in, b and x out: 64 B per cell); the coarsest
-    level: a dense triangular solve (8 n^2) when it has <= 128 rows, else 1 + 4 Jacobi sweeps (12 B per entry + 32 B per row each)."""
+    level: a dense triangular solve (8 n^2) when it has <= 128 rows, else 1 + 4 Jacobi sweeps (12 B per entry + 32 B per row each).
+    A level smoothed with ILU0 (--cpr-amg-ilu-levels): two applications of its factors (every off-diagonal entry once per application
+    as 8-byte value + 4-byte column, 1 / U_ii, d in, v out twice) and two residual passes instead of one residual and one Jacobi pass."""
     total = 64 * Nb
     L = len(level_n)
     for l in range(L - 1):
         total += 2 * 12 * level_nnz[l] + 84 * level_n[l] + 24 * level_n[l + 1]
+        if l < ilu_levels:
+            total += 2 * (12 * (level_nnz[l] - level_n[l]) + 40 * level_n[l]) + 16 * level_n[l]
     nl, zl = level_n[-1], level_nnz[-1]
     total += 8 * nl * nl if nl <= 128 else 5 * (12 * zl + 32 * nl)
     return total
@@ -292,6 +296,7 @@ def main():
     ap.add_argument("--steady-steps", type=int, default=100)
     ap.add_argument("--preconditioner", default="ilu0", choices=["ilu0", "cpr", "cpr_trueimpes", "cpr_quasiimpes"], help="--linear-solver-configuration of the run behind `value`")
     ap.add_argument("--cpr-reuse-setup", type=int, default=3, choices=[0, 1, 2, 3], help="Flow's --cpr-reuse-setup for the CPR runs: when the hierarchy's structure is built anew (3 = never, the default of Flow)")
+    ap.add_argument("--cpr-amg-ilu-levels", type=int, default=0, help="CPR runs: this many of the pressure AMG's finest levels smooth with ILU0 (the reference's AMG smoother) instead of damped Jacobi")
     ap.add_argument("--no-cpr-side-run", action="store_true", help="skip the side runs with the CPR preconditioners (extra keys `cpr`, `cpr_quasiimpes`)")
     a = ap.parse_args()
 
@@ -328,7 +333,7 @@ def main():
     pkg = importlib.import_module("opm-autodiff_amd")
     n = a.n
     skw = dict(device_id=local_rank, reorder=a.reorder, tolerance=1e-2, maxit=200, ilu_relaxation=0.9, chain_length=a.chain_length,
-               preconditioner=a.preconditioner, cpr_reuse_setup=a.cpr_reuse_setup)
+               preconditioner=a.preconditioner, cpr_reuse_setup=a.cpr_reuse_setup, cpr_amg_ilu_levels=a.cpr_amg_ilu_levels)
     if world == 1:
         case = pkg.decks.cartesian_case(n, n, n, state="mixed", heterogeneous=False)
         src = pkg.decks.five_spot_source(case, rate_sm3_per_day=pkg.decks.BENCH_RATE_SM3_PER_DAY * (n / 100.0) ** 2)
@@ -399,7 +404,7 @@ def main():
         Bm = dict(B)
         if use_cpr_of(model):
             lv = model.cpr_levels()
-            Bm["cpr_amg"] = cpr_amg_bytes(Nb, [int(v) for v in lv[0]], [int(v) for v in lv[1]])
+            Bm["cpr_amg"] = cpr_amg_bytes(Nb, [int(v) for v in lv[0]], [int(v) for v in lv[1]], getattr(model, "_bench_ilu_levels", a.cpr_amg_ilu_levels))
         # what the profiled solves were: solves = factorisations, BiCGStab iterations = products / 2 (two per iteration; a solve that
         # stops on a first half adds one) - so that launches x avg_ms can be put beside the window's ms_per_step
         solves_profiled = prof.get("ilu_factor", (0, 0.0))[0] // (2 if use_cpr_of(model) else 1)   # CPR: the value set-up of the hierarchy is a second scope of that class
@@ -461,6 +466,7 @@ def main():
             nonlocal sim, model
             model2 = pkg.capi.HipModel(case, **dict(skw, preconditioner=prec, **over))
             model2._bench_preconditioner = prec
+            model2._bench_ilu_levels = over.get("cpr_amg_ilu_levels", a.cpr_amg_ilu_levels)
             model2.set_state(case["pv"], case["meaning"])
             model2.set_source(src)
             sim_main, model_main = sim, model
@@ -493,6 +499,8 @@ def main():
     if a.preconditioner == "ilu0" and world == 1 and not a.no_cpr_side_run:
         for prec in ("cpr", "cpr_quasiimpes"):
             cpr_sides[prec] = guarded("CPR side run (%s)" % prec, cpr_window(prec))
+        if a.cpr_amg_ilu_levels == 0:   # the pressure AMG with the reference's kind of smoother (ILU0) on its two finest levels
+            cpr_sides["cpr_amg_ilu0_smoother"] = guarded("CPR side run (cpr, ILU0-smoothed AMG levels 0-1)", cpr_window("cpr", cpr_amg_ilu_levels=2))
         if a.cpr_reuse_setup == 3:   # Flow's other --cpr-reuse-setup worth a line: the hierarchy's structure follows the state
             # ... rebuilt on a host thread beside the solves (opmhip_config.cpr_async_setup), and - the reference's rule to the letter -
             # by the solve that finds the rule met (0.28 s of host work inside the window where it happens)
@@ -541,6 +549,9 @@ def main():
         # iterations - on a host thread beside the solves (cpr_async_setup = 1: the new structure takes over at the first solve
         # boundary after it is ready) and, "_sync", by the solve itself (0.3 s of host time inside the windows where it happens);
         # the two runs above keep Flow's default 3 (never)
+        # "cpr" with the two finest levels of the pressure AMG smoothed by ILU0 - the reference's AMG smoother - instead of damped Jacobi
+        # (opmhip_config.cpr_amg_ilu_levels = 2)
+        "cpr_amg_ilu0_smoother": cpr_sides.get("cpr_amg_ilu0_smoother"),
         "cpr_reuse_setup_2": cpr_sides.get("cpr_reuse_setup_2"),
         "cpr_reuse_setup_2_sync": cpr_sides.get("cpr_reuse_setup_2_sync"),
         "preconditioner": a.preconditioner,

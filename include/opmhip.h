@@ -20,7 +20,8 @@
 extern "C" {
 #endif
 
-#define OPMHIP_ABI_VERSION 6 /* 6: opmhip_set_hysteresis, opmhip_get_hysteresis, opmhip_set_hysteresis_params (additive); opmhip_config names
+#define OPMHIP_ABI_VERSION 7 /* 7: opmhip_config names cpr_amg_ilu_levels, cpr_gather_rows (were reserved[0..1]);
+                               * 6: opmhip_set_hysteresis, opmhip_get_hysteresis, opmhip_set_hysteresis_params (additive); opmhip_config names
                                *    cpr_async_setup (was reserved[0]);
                                * 5: opmhip_set_water_compaction, opmhip_get_max_water_saturation, opmhip_relative_change, opmhip_cpr_recreate (additive);
                                * 4: opmhip_config names chain_length, spmv_pipe_wgs, preconditioner (were reserved[0..2]);
@@ -96,7 +97,16 @@ typedef struct opmhip_config {
                             * which solve that is depends on the host's speed, so iteration counts are no longer reproducible run to
                             * run.  0 (default): the reference's rule to the letter - the solve that finds the rule met waits for the
                             * rebuild (0.28 s of host work at 10^6 cells).  (was reserved[0] until ABI 6) */
-    int reserved[2];       /* 0 */
+    int cpr_amg_ilu_levels; /* the pressure AMG's smoother: this many of its finest levels smooth with a scalar ILU0, relaxation 1 - the
+                            * reference's AMG smoother (linalg/PreconditionerFactory.hpp:126-151, setupPropertyTree.cpp:116-137) - the others
+                            * with damped Jacobi.  Level 0 eliminates in the ordering of the block ILU0 (opmhip_reorder), the levels below
+                            * colour by colour of a greedy multi-colouring.  0 (default): Jacobi on every level.  (was reserved[0] until ABI 7) */
+    int cpr_gather_rows;   /* decomposed runs (opmhip_comm_init_*): a rank's pressure hierarchy is continued ACROSS the ranks from its first
+                            * level of at most this many rows - the right-hand sides of that level are gathered, every rank continues the
+                            * coarsening on the joined system (couplings between the subdomains included) and takes its slice of the
+                            * correction back: the coarse part of the reference's parallel AMG (linalg/OwningTwoLevelPreconditioner.hpp,
+                            * PressureTransferPolicy.hpp:92-160).  0: the default (4096); < 0: off, one hierarchy per subdomain with no
+                            * communication.  Ignored on a single rank.  (was reserved[1] until ABI 7) */
 } opmhip_config;
 
 /* bda::BdaResult (bda/BdaResult.hpp:28-40) plus the reference's per-phase timers. */

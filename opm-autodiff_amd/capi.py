@@ -31,7 +31,7 @@ class Config(C.Structure):
     _fields_ = [("abi_version", C.c_int), ("device_id", C.c_int), ("verbosity", C.c_int), ("maxit", C.c_int),
                 ("tolerance", C.c_double), ("ilu_relaxation", C.c_double), ("relax_mode", C.c_int),
                 ("reorder", C.c_int), ("zero_diag_fix", C.c_int), ("chain_length", C.c_int), ("spmv_pipe_wgs", C.c_int),
-                ("preconditioner", C.c_int), ("cpr_reuse_setup", C.c_int), ("cpr_async_setup", C.c_int), ("reserved", C.c_int * 2)]
+                ("preconditioner", C.c_int), ("cpr_reuse_setup", C.c_int), ("cpr_async_setup", C.c_int), ("cpr_amg_ilu_levels", C.c_int), ("cpr_gather_rows", C.c_int)]
 
 
 class Result(C.Structure):
@@ -150,7 +150,7 @@ class HipSolver:
 
     def __init__(self, verbosity=0, maxit=200, tolerance=1e-2, device_id=0, ilu_relaxation=0.9,
                  relax_mode="post_scale", reorder="graph_coloring", zero_diag_fix=True, chain_length=8, spmv_pipe_wgs=0,
-                 preconditioner="ilu0", cpr_reuse_setup=3, cpr_async_setup=0):
+                 preconditioner="ilu0", cpr_reuse_setup=3, cpr_async_setup=0, cpr_amg_ilu_levels=0, cpr_gather_rows=0):
         L = lib()
         cfg = Config()
         L.opmhip_default_config(C.byref(cfg))
@@ -163,6 +163,8 @@ class HipSolver:
         cfg.spmv_pipe_wgs = int(spmv_pipe_wgs)  # pipelined SpMV: workgroups it is sized for (0 default, < 0 off; tests use small values)
         # --linear-solver-configuration (setupPropertyTree.cpp:62-76): "cpr" is short for cpr_trueimpes, as in Flow
         cfg.preconditioner = PRECONDITIONER[preconditioner]
+        cfg.cpr_amg_ilu_levels = int(cpr_amg_ilu_levels)   # finest levels of the pressure AMG that smooth with ILU0 (0: Jacobi everywhere)
+        cfg.cpr_gather_rows = int(cpr_gather_rows)         # decomposed runs: the hierarchy is continued across the ranks from the first level this small (0 default, < 0 off)
         cfg.cpr_async_setup = int(cpr_async_setup)   # mode 2 only: the rebuild on a host thread beside the solves
         cfg.cpr_reuse_setup = int(cpr_reuse_setup)   # --cpr-reuse-setup: 0 every solve, 1 every time step, 2 after > 10 iterations, 3 never
         self._h = C.c_void_p()

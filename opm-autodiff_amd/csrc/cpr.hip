@@ -554,6 +554,200 @@ __global__ __launch_bounds__(256) void k_cpr_add(int n, double* __restrict__ v, 
     if (e < n) v[e] += z[e];
 }
 
+
+// ---------------------------------------------------------------- ILU0 smoothing of the finest AMG levels -----------------
+// The reference's pressure AMG smooths with ILU0, relaxation 1 (PreconditionerFactory.hpp:126-151, setupPropertyTree.cpp:116-137);
+// opmhip_config.cpr_amg_ilu_levels = L gives the L finest levels of this hierarchy that smoother in place of damped Jacobi
+// (oracle/cpr.hpp: CprAmg::iluLevels, ilu_factor, smooth - the same statements in the same order).  Elimination order: level 0 in
+// its stored order (whatever ordering the block ILU0 uses: its colours are this one's), the levels below in a greedy multi-colouring
+// of their graphs, colour by colour.  One launch per colour; a thread walks one SEQUENCE of rows that depend on each other inside
+// the colour (the chains of a line-coloured level 0; single rows elsewhere).
+template <bool RM> __device__ __forceinline__ size_t cpr_at(int j, int i, int n, int W) { return RM ? (size_t)i * W + j : (size_t)j * n + i; }
+// the rows of one colour: row i against the finished rows j of its lower slots, in ascending elimination position (IKJ); fval is
+// read where another thread (an earlier launch) or this thread (an earlier step) wrote it: no __restrict__
+template <bool RM>
+__global__ __launch_bounds__(256) void k_cpr_ilu_factor(int nseq, int nsteps, const int* __restrict__ rowAt, int n, int W, int MW, int WL,
+                                                        const int* __restrict__ ecol, const int* __restrict__ rlen, const int* __restrict__ diag,
+                                                        const unsigned* __restrict__ mask, const unsigned char* __restrict__ lorder, double* fval) {
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= nseq) return;
+    for (int st = 0; st < nsteps; ++st) {
+        const int i = rowAt[(size_t)st * nseq + t];
+        if (i < 0) break;
+        const int len = rlen[i];
+        for (int q = 0; q < WL; ++q) {
+            const int slot = lorder[(size_t)q * n + i];
+            if (slot == 255) break;
+            const size_t e = cpr_at<RM>(slot, i, n, W);
+            const int j = ecol[e];
+            const double l = fval[e] * fval[diag[j]];
+            fval[e] = l;
+            const int lenj = rlen[j];
+            for (int sj = 0; sj < lenj; ++sj) {   // the U part of row j, in the row's order
+                if (!((mask[(size_t)(MW + (sj >> 5)) * n + j] >> (sj & 31)) & 1u)) continue;
+                const size_t ej = cpr_at<RM>(sj, j, n, W);
+                const int cc = ecol[ej];
+                size_t tgt = (size_t)-1;
+                if (cc == i) tgt = (size_t)diag[i];
+                else
+                    for (int si = 0; si < len; ++si) {
+                        const size_t ei = cpr_at<RM>(si, i, n, W);
+                        if (ecol[ei] == cc) { tgt = ei; break; }
+                    }
+                if (tgt != (size_t)-1) fval[tgt] -= l * fval[ej];
+            }
+        }
+        fval[diag[i]] = 1.0 / fval[diag[i]];
+    }
+}
+// The factors as the sweeps read them: per row its lower entries (value, column) in the row's order, its upper entries likewise and
+// 1 / U_ii, each kind in a compact image of its own ([q * n + i], column -1 = none) - a forward sweep of a colour whose rows have
+// one lower entry reads one, not the level's whole row.  Written once per factorisation.
+__global__ __launch_bounds__(256) void k_cpr_ilu_pack(int n, int W, int MW, int rm, int WLc, int WUc, const int* __restrict__ ecol, const int* __restrict__ rlen,
+                                                      const int* __restrict__ diag, const unsigned* __restrict__ mask, const double* __restrict__ fval,
+                                                      double* __restrict__ lv, int* __restrict__ lc, double* __restrict__ uv, int* __restrict__ uc, double* __restrict__ ud) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const int len = rlen[i];
+    int ql = 0, qu = 0;
+    for (int j = 0; j < len; ++j) {
+        const size_t e = rm ? (size_t)i * W + j : (size_t)j * n + i;
+        if ((mask[(size_t)(j >> 5) * n + i] >> (j & 31)) & 1u) { lv[(size_t)ql * n + i] = fval[e]; lc[(size_t)ql * n + i] = ecol[e]; ++ql; }
+        else if ((mask[(size_t)(MW + (j >> 5)) * n + i] >> (j & 31)) & 1u) { uv[(size_t)qu * n + i] = fval[e]; uc[(size_t)qu * n + i] = ecol[e]; ++qu; }
+    }
+    for (; ql < WLc; ++ql) lc[(size_t)ql * n + i] = -1;
+    for (; qu < WUc; ++qu) uc[(size_t)qu * n + i] = -1;
+    ud[i] = fval[diag[i]];
+}
+// One colour of a sweep; a thread walks its sequence of rows.  BWD = false: v_i = d_i - sum over the lower entries, in the row's
+// order; BWD = true: v_i = (v_i - sum over the upper entries) / U_ii, steps in reverse; out != NULL (the backward sweeps of a
+// post-smoothing): out_i = add_i + v_i, the statement "x += t" of the cycle (vfine: and the block vector (0, out_i, 0)).
+// FAST (cpr_ilu_schedule: every coupling inside the colour joins neighbours of a sequence): the value of the row before is handed
+// on in a register, every value read from memory was written by an earlier launch - gathers (vg) and stores (v) touch different
+// entries, so the loads of later steps need not wait for the stores of earlier ones.  Otherwise values of the thread's own earlier
+// steps come back through memory (vg == v, no __restrict__).  WQ: entries per row of this colour and direction at most.
+template <bool BWD, bool FAST, int WQ>
+__device__ __forceinline__ void cpr_ilu_sweep_body(int t, int nseq, int nsteps, const int* __restrict__ rowAt, int n, int wq, const double* __restrict__ fv,
+                                                   const int* __restrict__ fc, const double* __restrict__ ud, const double* __restrict__ d, const double* vg,
+                                                   double* v, const double* __restrict__ add, double* __restrict__ out, double* __restrict__ vfine) {
+    int iprev = -1;
+    double vprev = 0.0;
+#pragma unroll 2
+    for (int s0 = 0; s0 < nsteps; ++s0) {
+        const int st = BWD ? nsteps - 1 - s0 : s0;
+        const int i = rowAt[(size_t)st * nseq + t];
+        if (i < 0) { if (BWD) continue; else break; }
+        double s = BWD ? v[i] : d[i];
+        if constexpr (WQ == 0) {   // long rows (coarse levels): entry by entry
+            for (int q = 0; q < wq; ++q) {
+                const int c = fc[(size_t)q * n + i];
+                if (c < 0) break;
+                s -= fv[(size_t)q * n + i] * ((FAST && c == iprev) ? vprev : vg[c]);
+            }
+        } else {
+            double f[WQ], x[WQ];
+            int cc[WQ];
+#pragma unroll
+            for (int q = 0; q < WQ; ++q) {
+                cc[q] = q < wq ? fc[(size_t)q * n + i] : -1;
+                f[q] = q < wq ? fv[(size_t)q * n + i] : 0.0;
+            }
+#pragma unroll
+            for (int q = 0; q < WQ; ++q) x[q] = (cc[q] >= 0 && !(FAST && cc[q] == iprev)) ? vg[cc[q]] : 0.0;
+#pragma unroll
+            for (int q = 0; q < WQ; ++q)
+                if (cc[q] >= 0) s -= f[q] * ((FAST && cc[q] == iprev) ? vprev : x[q]);
+        }
+        if (BWD) s = s * ud[i];
+        v[i] = s;
+        if (FAST) { iprev = i; vprev = s; }
+        if (BWD && out) {
+            const double xo = add[i] + s;
+            out[i] = xo;
+            if (vfine) {
+                double* vf = &vfine[(size_t)i * BS];
+#pragma unroll
+                for (int k = 0; k < BS; ++k) vf[k] = (k == CPR_P) ? xo : 0.0;
+            }
+        }
+    }
+}
+// FAST colours, written for the shape the launch has: a colour of a line-coloured level 0 offers one thread per chain - 50 000 threads for
+// 10^6 rows, not one wavefront per SIMD - so a walk that waits for memory at every step takes ten round trips however little it moves.
+// Nothing a step loads depends on the steps before it (the value handed on travels in a register), so the steps are taken G at a time:
+// all row numbers, then all entries, then all gathered values, then the recurrence - three rounds of loads per group instead of three
+// per step.  One wavefront per workgroup: the registers are there (one wavefront per SIMD at most anyway).
+template <bool BWD, int WQ, int G>
+__global__ __launch_bounds__(64) void k_cpr_ilu_sweep_fast(int nseq, int nsteps, const int* __restrict__ rowAt, int n, int wq, const double* __restrict__ fv,
+                                                           const int* __restrict__ fc, const double* __restrict__ ud, const double* __restrict__ d,
+                                                           const double* __restrict__ vg, double* __restrict__ v, const double* __restrict__ add,
+                                                           double* __restrict__ out, double* __restrict__ vfine, const double* __restrict__ done) {
+    CPR_DONE_CHECK
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= nseq) return;
+    int iprev = -1;
+    double vprev = 0.0;
+    for (int g0 = 0; g0 < nsteps; g0 += G) {
+        // step of slot u of this group: forward g0 + u, backward nsteps - 1 - g0 - u (descending)
+        int ri[G];
+#pragma unroll
+        for (int u = 0; u < G; ++u) {
+            const int st = BWD ? nsteps - 1 - g0 - u : g0 + u;
+            ri[u] = (st >= 0 && st < nsteps) ? rowAt[(size_t)st * nseq + t] : -1;
+        }
+        double f[G][WQ], x[G][WQ], dd[G], du[G], da[G];
+        int cc[G][WQ];
+#pragma unroll
+        for (int u = 0; u < G; ++u) {
+            const int ic = ri[u] < 0 ? 0 : ri[u];
+#pragma unroll
+            for (int q = 0; q < WQ; ++q) {
+                cc[u][q] = (q < wq && ri[u] >= 0) ? fc[(size_t)q * n + ic] : -1;
+                f[u][q] = q < wq ? fv[(size_t)q * n + ic] : 0.0;
+            }
+            dd[u] = BWD ? v[ic] : d[ic];
+            du[u] = BWD ? ud[ic] : 1.0;
+            da[u] = (BWD && out) ? add[ic] : 0.0;
+        }
+#pragma unroll
+        for (int u = 0; u < G; ++u) {
+            const int nb = u == 0 ? iprev : ri[u - 1];   // the row before in walking order
+#pragma unroll
+            for (int q = 0; q < WQ; ++q) x[u][q] = (cc[u][q] >= 0 && cc[u][q] != nb) ? vg[cc[u][q]] : 0.0;
+        }
+#pragma unroll
+        for (int u = 0; u < G; ++u) {
+            if (ri[u] < 0) continue;
+            double s = dd[u];
+#pragma unroll
+            for (int q = 0; q < WQ; ++q)
+                if (cc[u][q] >= 0) s -= f[u][q] * (cc[u][q] == iprev ? vprev : x[u][q]);
+            if (BWD) s = s * du[u];
+            v[ri[u]] = s;
+            iprev = ri[u];
+            vprev = s;
+            if (BWD && out) {
+                const double xo = da[u] + s;
+                out[ri[u]] = xo;
+                if (vfine) {
+                    double* vf = &vfine[(size_t)ri[u] * BS];
+#pragma unroll
+                    for (int k = 0; k < BS; ++k) vf[k] = (k == CPR_P) ? xo : 0.0;
+                }
+            }
+        }
+    }
+}
+template <bool BWD, int WQ>
+__global__ __launch_bounds__(256) void k_cpr_ilu_sweep(int nseq, int nsteps, const int* __restrict__ rowAt, int n, int wq, const double* __restrict__ fv,
+                                                       const int* __restrict__ fc, const double* __restrict__ ud, const double* __restrict__ d,
+                                                       double* v, const double* __restrict__ add, double* __restrict__ out, double* __restrict__ vfine,
+                                                       const double* __restrict__ done) {
+    CPR_DONE_CHECK
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t < nseq) cpr_ilu_sweep_body<BWD, false, WQ>(t, nseq, nsteps, rowAt, n, wq, fv, fc, ud, d, v, v, add, out, vfine);
+}
+
 static inline dim3 g256(int n) { return dim3((n + 255) / 256); }
 
 // ---------------------------------------------------------------- setup --------------------------------------------------
@@ -561,11 +755,23 @@ static inline dim3 g256(int n) { return dim3((n + 255) / 256); }
 // The set-up is split in two so that its expensive half - matching, Galerkin lists, level images: pure host work on copies -
 // can run on a thread of its own beside the solves (--cpr-reuse-setup=2 with opmhip_config.cpr_async_setup), and only the uploads
 // touch the context.
+// ILU0 smoothing schedule of one level, from its image: which slots of a row are lower / upper entries in the elimination order
+// `pos`, the lower slots in ascending position, and per colour the sequences of rows a thread walks.  colour[i] ascending = the
+// order of the launches; rows of one colour may depend on each other only along a sequence (a chain of level 0's line colouring).
+struct CprIluHost {
+    int ncol = 0, MW = 0, WL = 0, WU = 0;
+    std::vector<int> nseq, nsteps, off, rowAt, wl, wu;   // wl / wu: lower / upper entries per row of a colour at most
+    std::vector<char> fast;
+    std::vector<unsigned> mask;
+    std::vector<unsigned char> lorder;
+    std::string error;
+};
 struct CprHostLevel {
     int n = 0, nnz = 0, nc = 0, W = 0;
     bool rm = false;
     std::vector<int> ecol, rlen, diag;                           // ELL image of the level's pattern
     std::vector<int> agg, mptr, midx, mem4, gptr, gidx, cpos;    // transfer to the next level (empty on the coarsest)
+    CprIluHost ilu;                                              // ncol > 0: the level's ILU0 smoothing schedule
 };
 struct CprHostCoarse {
     CprHostLevel l0;                 // of level 0 only the transfer part (its image belongs to the pattern: cpr_setup_level0)
@@ -601,6 +807,129 @@ static bool ell_image(const HCsr& A, CprHostLevel& L, std::vector<int>& pos, boo
         }
     }
     return true;
+}
+
+static void cpr_ilu_schedule(const CprHostLevel& L, const std::vector<int>& pos, const std::vector<int>& colour, int ncol, CprIluHost& S) {
+    const int n = L.n, W = L.W;
+    auto at = [&](int j, int i) { return L.rm ? (size_t)i * W + j : (size_t)j * n + i; };
+    S.ncol = ncol;
+    S.MW = (W + 31) / 32;
+    S.mask.assign((size_t)2 * S.MW * n, 0u);
+    std::vector<std::vector<std::pair<int, int>>> low(n);   // (position, slot) of every lower entry
+    int WL = 0;
+    for (int i = 0; i < n; ++i) {
+        for (int j = 0; j < L.rlen[i]; ++j) {
+            const int c = L.ecol[at(j, i)];
+            if (c == i) continue;   // the diagonal, or a ghost column's slot (value 0 for good)
+            if (pos[c] < pos[i]) { S.mask[(size_t)(j >> 5) * n + i] |= 1u << (j & 31); low[i].emplace_back(pos[c], j); }
+            else S.mask[(size_t)(S.MW + (j >> 5)) * n + i] |= 1u << (j & 31);
+        }
+        std::sort(low[i].begin(), low[i].end());
+        WL = std::max(WL, (int)low[i].size());
+    }
+    S.WL = std::max(WL, 1);
+    if (W > 254) { S.error = "cpr: ILU0 smoothing of a level with rows of more than 254 entries"; return; }
+    S.lorder.assign((size_t)S.WL * n, 255);
+    for (int i = 0; i < n; ++i)
+        for (size_t q = 0; q < low[i].size(); ++q) S.lorder[q * n + i] = (unsigned char)low[i][q].second;
+    // sequences: rows of a colour in ascending position; a row with a lower entry of its own colour continues that row's sequence
+    std::vector<int> byPos(n);
+    for (int i = 0; i < n; ++i) byPos[pos[i]] = i;
+    std::vector<int> seqOf(n, -1), idxIn(n, 0);
+    std::vector<std::vector<std::vector<int>>> seqs(ncol);
+    for (int p = 0; p < n; ++p) {
+        const int i = byPos[p], cc = colour[i];
+        int sq = -1;
+        for (auto& e : low[i]) {
+            const int j = L.ecol[at(e.second, i)];
+            if (colour[j] != cc) {
+                if (colour[j] > cc) { S.error = "cpr: ILU0 smoothing: the colours are not an elimination order"; return; }
+                continue;
+            }
+            if (sq >= 0 && seqOf[j] != sq) { S.error = "cpr: ILU0 smoothing: a row depends on two sequences of its own colour"; return; }
+            sq = seqOf[j];
+        }
+        if (sq < 0) { sq = (int)seqs[cc].size(); seqs[cc].emplace_back(); }
+        seqOf[i] = sq;
+        idxIn[i] = (int)seqs[cc][sq].size();
+        seqs[cc][sq].push_back(i);
+    }
+    S.wl.assign(ncol, 0); S.wu.assign(ncol, 0);
+    for (int i = 0; i < n; ++i) {
+        int nu = 0;
+        for (int w = 0; w < S.MW; ++w) nu += __builtin_popcount(S.mask[(size_t)(S.MW + w) * n + i]);
+        S.wl[colour[i]] = std::max(S.wl[colour[i]], (int)low[i].size());
+        S.wu[colour[i]] = std::max(S.wu[colour[i]], nu);
+        S.WU = std::max(S.WU, nu);
+    }
+    S.WU = std::max(S.WU, 1);
+    S.nseq.assign(ncol, 0); S.nsteps.assign(ncol, 0); S.off.assign(ncol + 1, 0); S.fast.assign(ncol, 1);
+    for (int cc = 0; cc < ncol; ++cc) {
+        int steps = 0;
+        for (auto& q : seqs[cc]) steps = std::max(steps, (int)q.size());
+        S.nseq[cc] = (int)seqs[cc].size();
+        S.nsteps[cc] = steps;
+        S.off[cc + 1] = S.off[cc] + steps * S.nseq[cc];
+    }
+    S.rowAt.assign(S.off[ncol], -1);
+    for (int cc = 0; cc < ncol; ++cc)
+        for (int t = 0; t < S.nseq[cc]; ++t)
+            for (size_t st = 0; st < seqs[cc][t].size(); ++st) S.rowAt[S.off[cc] + st * S.nseq[cc] + t] = seqs[cc][t][st];
+    // fast: every coupling inside the colour joins neighbours of a sequence (the sweeps may then hand the value on in a register)
+    for (int i = 0; i < n; ++i)
+        for (int j = 0; j < L.rlen[i]; ++j) {
+            const int c = L.ecol[at(j, i)];
+            if (c == i || colour[c] != colour[i]) continue;
+            if (seqOf[c] != seqOf[i] || std::abs(idxIn[c] - idxIn[i]) != 1) S.fast[colour[i]] = 0;
+        }
+}
+// greedy multi-colouring of a level's graph in index order, colour-major elimination positions (oracle/cpr.hpp: ilu_factor, colour = true)
+static int cpr_greedy_colours(const CprHostLevel& L, std::vector<int>& colour, std::vector<int>& pos) {
+    const int n = L.n, W = L.W;
+    auto at = [&](int j, int i) { return L.rm ? (size_t)i * W + j : (size_t)j * n + i; };
+    colour.assign(n, -1);
+    int nc = 0;
+    std::vector<char> used;
+    for (int i = 0; i < n; ++i) {
+        used.assign(nc + 1, 0);
+        for (int j = 0; j < L.rlen[i]; ++j) {
+            const int c = L.ecol[at(j, i)];
+            if (colour[c] >= 0) used[colour[c]] = 1;
+        }
+        int k = 0;
+        while (used[k]) ++k;
+        colour[i] = k;
+        nc = std::max(nc, k + 1);
+    }
+    pos.assign(n, 0);
+    int p = 0;
+    for (int k = 0; k < nc; ++k)
+        for (int i = 0; i < n; ++i)
+            if (colour[i] == k) pos[i] = p++;
+    return nc;
+}
+static int cpr_upload_ilu(opmhip_ctx* c, const CprIluHost& S, CprLevelDev& L) {
+    if (!S.error.empty()) return fail(c, OPMHIP_ANALYSIS_FAILED, "%s", S.error.c_str());
+    int rc;
+    L.iluMW = S.MW; L.iluWL = S.WL; L.iluWU = S.WU;
+    L.iluNseq = S.nseq; L.iluNsteps = S.nsteps; L.iluOff = S.off; L.iluFast = S.fast; L.iluWl = S.wl; L.iluWu = S.wu;
+    if ((rc = dev_alloc(c, &L.d_ilv, (size_t)S.WL * L.n))) return rc;
+    if ((rc = dev_alloc(c, &L.d_ilc, (size_t)S.WL * L.n))) return rc;
+    if ((rc = dev_alloc(c, &L.d_iuv, (size_t)S.WU * L.n))) return rc;
+    if ((rc = dev_alloc(c, &L.d_iuc, (size_t)S.WU * L.n))) return rc;
+    if ((rc = dev_alloc(c, &L.d_iud, (size_t)L.n))) return rc;
+    if ((rc = dev_upload(c, &L.d_imask, S.mask))) return rc;
+    if ((rc = dev_upload(c, &L.d_lorder, S.lorder))) return rc;
+    if ((rc = dev_upload(c, &L.d_rowAt, S.rowAt))) return rc;
+    if ((rc = dev_alloc(c, &L.d_fval, (size_t)L.W * L.n))) return rc;
+    if ((rc = dev_alloc(c, &L.d_t, (size_t)L.n))) return rc;
+    L.ilu = true;
+    return OPMHIP_SUCCESS;
+}
+static void cpr_free_ilu(opmhip_ctx* c, CprLevelDev& L) {
+    dev_free(c, &L.d_imask); dev_free(c, &L.d_lorder); dev_free(c, &L.d_rowAt); dev_free(c, &L.d_fval); dev_free(c, &L.d_t);
+    dev_free(c, &L.d_ilv); dev_free(c, &L.d_ilc); dev_free(c, &L.d_iuv); dev_free(c, &L.d_iuc); dev_free(c, &L.d_iud);
+    L.ilu = false;
 }
 static int upload_ell(opmhip_ctx* c, const CprHostLevel& H, CprLevelDev& L) {
     const int n = H.n, W = H.W;
@@ -759,6 +1088,15 @@ static int cpr_setup_level0(opmhip_ctx* c) {
             if ((rc = dev_upload(c, &R.lv[0].d_stable, table))) return rc;
         }
     }
+    if (c->cfg.cpr_amg_ilu_levels > 0) {   // ILU0 smoothing of level 0: in the stored order, the block ILU0's colours are this one's
+        std::vector<int> posv(P.Nb), colour(P.Nb);
+        for (int cc = 0; cc < P.numColors; ++cc)
+            for (int p = P.colorPrefix[cc]; p < P.colorPrefix[cc + 1]; ++p) colour[p] = cc;
+        std::iota(posv.begin(), posv.end(), 0);
+        CprIluHost S;
+        cpr_ilu_schedule(H0, posv, colour, P.numColors, S);
+        if ((rc = cpr_upload_ilu(c, S, R.lv[0]))) return rc;
+    }
     if ((rc = dev_alloc(c, &R.d_pcol, (size_t)3 * R.lv[0].W * P.Nb))) return rc;     // pressure columns of the blocks, ELL, component-major
     OPMHIP_HIP(c, hipMemsetAsync(R.d_pcol, 0, (size_t)3 * R.lv[0].W * P.Nb * sizeof(double), c->stream));   // the padding stays 0
     R.level0 = true;
@@ -767,7 +1105,7 @@ static int cpr_setup_level0(opmhip_ctx* c) {
 // ---- everything below level 0's image, on the host: two passes of pairwise matching per level, Galerkin lists, level images.
 //      Pure host work on its arguments (no context, no HIP call): may run on a thread of its own.  ell0: level 0's value image
 //      (W0 x Nb, as on the device) of the pressure matrix the structure is built from.
-static void cpr_build_coarse_host(const Pattern& P, const std::vector<double>& ell0, double beta, int lprRows, CprHostCoarse& out) {
+static void cpr_build_coarse_host(const Pattern& P, const std::vector<double>& ell0, double beta, int lprRows, int iluLevels, CprHostCoarse& out) {
     auto now = [] { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
 #define CPR_T(acc, stmt) do { const double t_ = now(); stmt; acc += now() - t_; } while (0)
     HCsr A;
@@ -842,8 +1180,15 @@ static void cpr_build_coarse_host(const Pattern& P, const std::vector<double>& e
         out.lv.emplace_back();
         std::vector<int> cposv;
         bool fitsW = true;
-        CPR_T(out.tImg, fitsW = ell_image(Ac, out.lv.back(), cposv, Ac.n <= lprRows));
+        const bool iluLevel = nlev < iluLevels;   // (level index nlev: the one being added)
+        CPR_T(out.tImg, fitsW = ell_image(Ac, out.lv.back(), cposv, Ac.n <= lprRows && !iluLevel));
         if (!fitsW) { out.error = "cpr: a row of a pressure-AMG level outgrew the level image"; return; }
+        if (iluLevel) {   // ILU0 smoothing: greedy multi-colouring of the level's graph, colour by colour
+            std::vector<int> colour, posv;
+            const int ncolours = cpr_greedy_colours(out.lv.back(), colour, posv);
+            CPR_T(out.tImg, cpr_ilu_schedule(out.lv.back(), posv, colour, ncolours, out.lv.back().ilu));
+            if (!out.lv.back().ilu.error.empty()) { out.error = out.lv.back().ilu.error; return; }
+        }
         // (out.lv may have reallocated: cur is looked up again)
         CprHostLevel* fine = out.lv.size() == 1 ? &out.l0 : &out.lv[out.lv.size() - 2];
         fine->cpos = cposv;                                   // where the coarse entries go
@@ -876,6 +1221,7 @@ static int cpr_upload_coarse(opmhip_ctx* c, const CprHostCoarse& H) {
     for (const CprHostLevel& h : H.lv) {
         R.lv.emplace_back();
         if ((rc = upload_ell(c, h, R.lv.back()))) return rc;
+        if (h.ilu.ncol > 0 && (rc = cpr_upload_ilu(c, h.ilu, R.lv.back()))) return rc;
         if ((rc = transfer(h, R.lv.back()))) return rc;
     }
     R.coarse_direct = R.lv.back().n <= CPR_COARSE_DIRECT;
@@ -895,6 +1241,7 @@ static void cpr_release_coarse(opmhip_ctx* c) {
         dev_free(c, &L.d_ecol); dev_free(c, &L.d_rlen); dev_free(c, &L.d_diag);
         dev_free(c, &L.d_val); dev_free(c, &L.d_dinv); dev_free(c, &L.d_x2);
         dev_free(c, &L.d_b); dev_free(c, &L.d_x); dev_free(c, &L.d_r); dev_free(c, &L.d_sword); dev_free(c, &L.d_stable);
+        cpr_free_ilu(c, L);
     }
     if (!R.lv.empty()) R.lv.resize(1);
     dev_free(c, &R.d_lu);
@@ -919,7 +1266,7 @@ static int cpr_setup_coarse_now(opmhip_ctx* c) {
     int rc;
     if ((rc = cpr_download_level0(c, ell))) return rc;
     CprHostCoarse H;
-    cpr_build_coarse_host(c->pat, ell, R.beta, cpr_lpr_rows(), H);
+    cpr_build_coarse_host(c->pat, ell, R.beta, cpr_lpr_rows(), c->cfg.cpr_amg_ilu_levels, H);
     const double t1 = now();
     const size_t mark = c->allocs.size();
     rc = cpr_upload_coarse(c, H);
@@ -938,6 +1285,7 @@ static int cpr_setup_coarse_now(opmhip_ctx* c) {
     if (timing) std::fprintf(stderr, "opmhip cpr set-up: %.3f s (matching %.3f, Galerkin %.3f, level images %.3f, uploads %.3f), %zu levels\n", now() - t0, H.tAgg, H.tGal, H.tImg, now() - t1, R.lv.size());
     return OPMHIP_SUCCESS;
 }
+static bool cpr_ilu_active(const CprDev& R, size_t l);
 void cpr_shutdown(opmhip_ctx* c) { c->cpr.job.reset(); }
 int cpr_update(opmhip_ctx* c, bool solveBoundary) {
     const Pattern& P = c->pat;
@@ -981,16 +1329,26 @@ int cpr_update(opmhip_ctx* c, bool solveBoundary) {
         if ((rc = cpr_download_level0(c, *ell))) { R.job.reset(); prof_end(c, ps); return rc; }
         const Pattern* pat = &c->pat;   // outlives the job: cpr_release_structure / cpr_shutdown join it before the pattern goes
         const double beta = R.beta;
-        const int lpr = cpr_lpr_rows();
+        const int lpr = cpr_lpr_rows(), iluLevels = c->cfg.cpr_amg_ilu_levels;
         CprAsyncJob* raw = job.get();
-        job->th = std::thread([raw, ell, pat, beta, lpr]() {
-            cpr_build_coarse_host(*pat, *ell, beta, lpr, raw->result);
+        job->th = std::thread([raw, ell, pat, beta, lpr, iluLevels]() {
+            cpr_build_coarse_host(*pat, *ell, beta, lpr, iluLevels, raw->result);
             raw->ready.store(1, std::memory_order_release);
         });
     }
     for (size_t l = 0; l < R.lv.size(); ++l) {
         CprLevelDev& L = R.lv[l];
         hipLaunchKernelGGL(k_cpr_dinv, g256(L.n), dim3(256), 0, c->stream, L.n, L.d_diag, L.d_val, L.d_dinv);
+        if (cpr_ilu_active(R, l)) {   // scalar ILU0 of the level, colour by colour
+            OPMHIP_HIP(c, hipMemcpyAsync(L.d_fval, L.d_val, (size_t)L.W * L.n * sizeof(double), hipMemcpyDeviceToDevice, c->stream));
+            for (size_t cc = 0; cc < L.iluNseq.size(); ++cc) {
+                if (L.iluNseq[cc] == 0) continue;
+                if (L.rm) hipLaunchKernelGGL(k_cpr_ilu_factor<true>, g256(L.iluNseq[cc]), dim3(256), 0, c->stream, L.iluNseq[cc], L.iluNsteps[cc], L.d_rowAt + L.iluOff[cc], L.n, L.W, L.iluMW, L.iluWL, L.d_ecol, L.d_rlen, L.d_diag, L.d_imask, L.d_lorder, L.d_fval);
+                else hipLaunchKernelGGL(k_cpr_ilu_factor<false>, g256(L.iluNseq[cc]), dim3(256), 0, c->stream, L.iluNseq[cc], L.iluNsteps[cc], L.d_rowAt + L.iluOff[cc], L.n, L.W, L.iluMW, L.iluWL, L.d_ecol, L.d_rlen, L.d_diag, L.d_imask, L.d_lorder, L.d_fval);
+            }
+            hipLaunchKernelGGL(k_cpr_ilu_pack, g256(L.n), dim3(256), 0, c->stream, L.n, L.W, L.iluMW, L.rm ? 1 : 0, L.iluWL, L.iluWU, L.d_ecol, L.d_rlen, L.d_diag, L.d_imask, L.d_fval,
+                               L.d_ilv, L.d_ilc, L.d_iuv, L.d_iuc, L.d_iud);
+        }
         if (l + 1 < R.lv.size()) {
             CprLevelDev& C = R.lv[l + 1];
             hipLaunchKernelGGL(k_cpr_galerkin, g256(C.nnz), dim3(256), 0, c->stream, C.nnz, L.d_gptr, L.d_gidx, L.d_cpos, L.d_val, C.d_val);
@@ -1005,6 +1363,37 @@ int cpr_update(opmhip_ctx* c, bool solveBoundary) {
     return OPMHIP_SUCCESS;
 }
 
+// is level l smoothed with its ILU0 (a level that has the schedule and is not the coarsest)?
+static bool cpr_ilu_active(const CprDev& R, size_t l) { return l + 1 < R.lv.size() && R.lv[l].ilu; }
+// v = (U^-1 L^-1) d with the level's ILU0: forward colour by colour, backward in reverse; out != NULL: out = add + v as the
+// backward sweeps store (and, vfine, the block vector (0, out, 0))
+template <bool BWD, int WQ>
+static void cpr_ilu_launch(opmhip_ctx* c, const CprLevelDev& L, int cc, const double* d, double* v, const double* add, double* out, double* vfine) {
+    const int nseq = L.iluNseq[cc], nsteps = L.iluNsteps[cc], wq = BWD ? L.iluWu[cc] : L.iluWl[cc];
+    const int* rowAt = L.d_rowAt + L.iluOff[cc];
+    const double* fv = BWD ? L.d_iuv : L.d_ilv;
+    const int* fc = BWD ? L.d_iuc : L.d_ilc;
+    if (L.iluFast[cc] && WQ > 0 && nsteps > 1) {
+        constexpr int G = WQ <= 4 ? 12 : WQ <= 6 ? 10 : 6;   // (WQ = 6, G = 10: about 440 registers, no spills - and one wavefront per SIMD is all a colour offers)
+        hipLaunchKernelGGL((k_cpr_ilu_sweep_fast<BWD, (WQ > 0 ? WQ : 1), G>), dim3((nseq + 63) / 64), dim3(64), 0, c->stream, nseq, nsteps, rowAt, L.n, wq, fv, fc, L.d_iud, d, (const double*)v, v, add, out, vfine, c->d_done);
+    } else hipLaunchKernelGGL((k_cpr_ilu_sweep<BWD, WQ>), g256(nseq), dim3(256), 0, c->stream, nseq, nsteps, rowAt, L.n, wq, fv, fc, L.d_iud, d, v, add, out, vfine, c->d_done);
+}
+template <bool BWD>
+static void cpr_ilu_colour(opmhip_ctx* c, const CprLevelDev& L, int cc, const double* d, double* v, const double* add, double* out, double* vfine) {
+    if (L.iluNseq[cc] == 0) return;
+    const int wq = BWD ? L.iluWu[cc] : L.iluWl[cc];
+    if (wq <= 1) cpr_ilu_launch<BWD, 1>(c, L, cc, d, v, add, out, vfine);
+    else if (wq <= 2) cpr_ilu_launch<BWD, 2>(c, L, cc, d, v, add, out, vfine);
+    else if (wq <= 4) cpr_ilu_launch<BWD, 4>(c, L, cc, d, v, add, out, vfine);
+    else if (wq <= 6) cpr_ilu_launch<BWD, 6>(c, L, cc, d, v, add, out, vfine);
+    else if (wq <= 8) cpr_ilu_launch<BWD, 8>(c, L, cc, d, v, add, out, vfine);
+    else cpr_ilu_launch<BWD, 0>(c, L, cc, d, v, add, out, vfine);
+}
+static void cpr_ilu_smooth(opmhip_ctx* c, const CprLevelDev& L, const double* d, double* v, const double* add, double* out, double* vfine) {
+    const int nc = (int)L.iluNseq.size();
+    for (int cc = 0; cc < nc; ++cc) cpr_ilu_colour<false>(c, L, cc, d, v, nullptr, nullptr, nullptr);
+    for (int cc = nc - 1; cc >= 0; --cc) cpr_ilu_colour<true>(c, L, cc, d, v, add, out, vfine);
+}
 // does level l (> 0) form its right-hand side itself, from the finer level's residual (cpr_restricted)?  Then no restriction
 // kernel runs between the two levels.  Lane-group levels do, and the dense solve of the coarsest level.
 static bool cpr_forms_rhs(const CprDev& R, size_t l) {
@@ -1015,7 +1404,7 @@ static bool cpr_forms_rhs(const CprDev& R, size_t l) {
 // does level l take its pre-smoothed iterate x = omega D^-1 b from the kernel that produces b (the restriction above it)?
 static bool cpr_presmooth_rides(const CprDev& R, size_t l) {
     const CprLevelDev& L = R.lv[l];
-    if (cpr_forms_rhs(R, l)) return false;
+    if (cpr_forms_rhs(R, l) || cpr_ilu_active(R, l)) return false;
     if (l + 1 == R.lv.size()) return !R.coarse_direct;   // Jacobi coarse "solve": starts with the same statement
     return !L.rm;                                         // lane-group levels form it on the fly inside k_cpr_down_lpr
 }
@@ -1046,6 +1435,13 @@ static const double* cpr_vcycle(opmhip_ctx* c, size_t l, double* fineOut = nullp
         return xin;
     }
     CprLevelDev& C = R.lv[l + 1];
+    const bool ilu = cpr_ilu_active(R, l);
+    const EllStencil S0{L.d_sword, L.d_stable};
+    if (ilu) {   // pre-smoothing from x = 0 with the level's ILU0, then the residual
+        cpr_ilu_smooth(c, L, L.d_b, L.d_x, nullptr, nullptr, nullptr);
+        if (S0.word) hipLaunchKernelGGL(k_cpr_resid<true>, g256(L.n), dim3(256), 0, c->stream, L.n, L.W, L.d_ecol, L.d_val, L.d_b, L.d_x, L.d_r, done, S0);
+        else hipLaunchKernelGGL(k_cpr_resid<false>, g256(L.n), dim3(256), 0, c->stream, L.n, L.W, L.d_ecol, L.d_val, L.d_b, L.d_x, L.d_r, done, S0);
+    } else
     if (L.rm && fused) hipLaunchKernelGGL(k_cpr_down_lpr<true>, g256(L.n * CPR_LPR), dim3(256), 0, c->stream, L.n, L.W, R.omega, L.d_ecol, L.d_val, L.d_dinv, L.d_b, L.d_x, L.d_r, mem4f, rf, done);
     else if (L.rm) hipLaunchKernelGGL(k_cpr_down_lpr<false>, g256(L.n * CPR_LPR), dim3(256), 0, c->stream, L.n, L.W, R.omega, L.d_ecol, L.d_val, L.d_dinv, L.d_b, L.d_x, L.d_r, (const int4*)nullptr, (const double*)nullptr, done);
     else {   // large levels: x first (it rides in the kernel that produced b), then the residual with ONE gathered value per entry (0.250 -> 0.243 ms per cycle against the fused form, which gathers dinv and b)
@@ -1062,6 +1458,13 @@ static const double* cpr_vcycle(opmhip_ctx* c, size_t l, double* fineOut = nullp
                            ride ? C.d_dinv : (const double*)nullptr, ride ? C.d_x : (double*)nullptr, done);
     }
     const double* xc = cpr_vcycle(c, l + 1);
+    if (ilu) {   // x' = x + damp P xc; r = b - A x'; x = x' + ILU0(r)
+        hipLaunchKernelGGL(k_cpr_prolong, g256(L.n), dim3(256), 0, c->stream, L.n, R.damp, L.d_agg, xc, L.d_x, L.d_r, done);
+        if (S0.word) hipLaunchKernelGGL(k_cpr_resid<true>, g256(L.n), dim3(256), 0, c->stream, L.n, L.W, L.d_ecol, L.d_val, L.d_b, L.d_r, L.d_x, done, S0);
+        else hipLaunchKernelGGL(k_cpr_resid<false>, g256(L.n), dim3(256), 0, c->stream, L.n, L.W, L.d_ecol, L.d_val, L.d_b, L.d_r, L.d_x, done, S0);
+        cpr_ilu_smooth(c, L, L.d_x, L.d_t, L.d_r, L.d_x2, fineOut);
+        return fineOut ? nullptr : L.d_x2;
+    }
     if (L.rm) hipLaunchKernelGGL(k_cpr_up_lpr, g256(L.n * CPR_LPR), dim3(256), 0, c->stream, L.n, L.W, R.omega, R.damp, L.d_ecol, L.d_val, L.d_dinv, L.d_agg, xc, L.d_b, L.d_x, L.d_x2, done);
     else {   // large levels: the prolonged iterate first (into the residual buffer, free by now), then one gathered value per entry
         hipLaunchKernelGGL(k_cpr_prolong, g256(L.n), dim3(256), 0, c->stream, L.n, R.damp, L.d_agg, xc, L.d_x, L.d_r, done);

@@ -217,8 +217,11 @@ struct CprLevelDev {
     // order, the lower slots in the order the factorisation visits them, and a launch schedule: colour by colour, one thread per SEQUENCE
     // of rows that depend on each other inside the colour (level 0 of a line-coloured pattern: the chains; otherwise single rows)
     bool ilu = false;
-    int iluMW = 0, iluWL = 0;                                      // mask words per kind, lower slots per row at most
+    int iluMW = 0, iluWL = 0, iluWU = 0;                           // mask words per kind, lower / upper entries per row at most
     double *d_fval = nullptr, *d_t = nullptr;
+    double *d_ilv = nullptr, *d_iuv = nullptr, *d_iud = nullptr;   // what the sweeps read: lower entries [iluWL][n], upper entries [iluWU][n], 1 / U_ii
+    int *d_ilc = nullptr, *d_iuc = nullptr;                        // their columns (-1: none)
+    std::vector<int> iluWl, iluWu;                                 // per colour: lower / upper entries per row at most
     unsigned* d_imask = nullptr;                                   // [2 * iluMW][n]: lower words, then upper words
     unsigned char* d_lorder = nullptr;                             // [iluWL][n], 255 = none
     int* d_rowAt = nullptr;                                        // per colour [steps][sequences]: row or -1

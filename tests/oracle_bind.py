@@ -574,6 +574,12 @@ class OracleCpr:
         self.o.lib.orc_cpr_set_natural_ids.argtypes = [_vp, C.c_int, _i]
         self.o.lib.orc_cpr_set_natural_ids(self.h, len(a), a)
 
+    def set_ilu_smoother(self, levels, colour_from=1):
+        """the `levels` finest AMG levels smooth with a scalar ILU0 (relaxation 1) instead of damped Jacobi: level 0 in the order
+        the system is stored in, levels >= colour_from in a greedy multi-colour order (what the device does)"""
+        self.o.lib.orc_cpr_set_ilu_smoother.argtypes = [_vp, C.c_int, C.c_int]
+        self.o.lib.orc_cpr_set_ilu_smoother(self.h, int(levels), int(colour_from))
+
     def rebuild_structure(self):
         """the next update / solve builds the hierarchy's structure anew from its matrix"""
         self.o.lib.orc_cpr_rebuild_structure.argtypes = [_vp]

@@ -74,6 +74,46 @@ def test_cpr_apply_bitwise_and_solve(pkg, orc, reorder):
     close_per_component(s.get_result(), xo2.reshape(Nb, 3)[to].reshape(-1))
 
 
+@pytest.mark.parametrize("reorder,ilu_levels", [("line_coloring", 1), ("line_coloring", 2), ("line_coloring", 3), ("graph_coloring", 2)])
+def test_cpr_amg_with_ilu0_smoothing(pkg, orc, reorder, ilu_levels):
+    """opmhip_config.cpr_amg_ilu_levels: the finest levels of the pressure AMG smooth with a scalar ILU0 (the reference's AMG
+    smoother, PreconditionerFactory.hpp:126-151) - level 0 in the block ILU0's ordering, the levels below colour by colour of a
+    greedy multi-colouring.  Device = oracle (CprAmg::iluLevels) bit for bit, same half-iteration count; and the smoother does
+    what it is for: no more iterations than with Jacobi."""
+    case, jac, res = jacobian_case(pkg, orc, shape=(24, 22, 20), its=2)
+    Nb, rp, ci = case["Nb"], case["rowptr"], case["col"]
+    s = pkg.capi.HipSolver(reorder=reorder, preconditioner="cpr_quasiimpes", tolerance=1e-6, cpr_amg_ilu_levels=ilu_levels)
+    s.set_pattern(Nb, rp, ci)
+    s.upload_system(jac)
+    s.ilu0_factor(want_factors=False)
+    to, fr, rr, rc, rv = reordered(orc, s, Nb, rp, ci, jac)
+    cpr = oracle_bind.OracleCpr(orc)
+    cpr.set_natural_ids(fr)
+    cpr.set_ilu_smoother(ilu_levels, 1)
+    cpr.update(Nb, rr, rc, rv)
+    rng = np.random.default_rng(3)
+    for k in range(2):
+        d = rng.standard_normal(3 * Nb) * (1.0 if k else 1e-3)
+        vo = cpr.apply(np.ascontiguousarray(d.reshape(Nb, 3)[fr].reshape(-1))).reshape(Nb, 3)[to].reshape(-1)
+        assert np.array_equal(s.cpr_apply(d), vo)
+    assert s.cpr_levels()[0] == [int(x) for x in cpr.levels()[0]] and len(s.cpr_levels()[0]) > ilu_levels
+    r = s.solve_system(Nb, rp, ci, jac.copy(), res)
+    xo, ro = cpr.solve(Nb, rr, rc, rv, np.ascontiguousarray(res.reshape(Nb, 3)[fr].reshape(-1)), tol=1e-6)
+    assert r.converged and r.it == ro.it
+    close_per_component(s.get_result(), xo.reshape(Nb, 3)[to].reshape(-1), tol=1e-4)   # both solve to 1e-6; the scalar products are summed in different orders
+    sj = pkg.capi.HipSolver(reorder=reorder, preconditioner="cpr_quasiimpes", tolerance=1e-6)
+    rj = sj.solve_system(Nb, rp, ci, jac.copy(), res)
+    assert rj.converged and r.it <= rj.it, (r.it, rj.it)
+    # new values through the same structure: the factors follow the matrix
+    case2, jac2, res2 = jacobian_case(pkg, orc, shape=(24, 22, 20), dt_days=3.0, its=1)
+    r2 = s.solve_system(Nb, rp, ci, jac2.copy(), res2)
+    _, _, rr2, rc2, rv2 = reordered(orc, s, Nb, rp, ci, jac2)
+    cpr.update(Nb, rr2, rc2, rv2)
+    d = rng.standard_normal(3 * Nb)
+    vo = cpr.apply(np.ascontiguousarray(d.reshape(Nb, 3)[fr].reshape(-1))).reshape(Nb, 3)[to].reshape(-1)
+    assert r2.converged and np.array_equal(s.cpr_apply(d), vo)
+
+
 def test_cpr_matr33_flexiblesolver_vector(pkg, orc, golden):
     Nb, rp, ci, v, b = _load(pkg, golden, "matr33.txt", "rhs3.txt")
     with open(os.path.join(golden, "linalg", "expected.json")) as f:
