@@ -522,6 +522,7 @@ int opmhip_cpr_apply(opmhip_ctx* c, const double* d, double* v) {
         if ((rc = cpr_update(c, false))) return rc;
         if ((rc = vec_in(c, d, c->d_p))) return rc;
         launch_cpr_apply(c, c->d_p, c->d_pw);
+        if (c->cpr.apply_rc) { rc = c->cpr.apply_rc; c->cpr.apply_rc = 0; return rc; }
         OPMHIP_HIP(c, hipGetLastError());
         return vec_out(c, c->d_pw, v);
     });

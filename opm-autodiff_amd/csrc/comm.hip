@@ -26,6 +26,7 @@ struct RcclApi {
     ncclResult_t (*CommInitRank)(ncclComm_t*, int, ncclUniqueId, int) = nullptr;
     ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
     ncclResult_t (*AllReduce)(const void*, void*, size_t, ncclDataType_t, ncclRedOp_t, ncclComm_t, hipStream_t) = nullptr;
+    ncclResult_t (*AllGather)(const void*, void*, size_t, ncclDataType_t, ncclComm_t, hipStream_t) = nullptr;
     ncclResult_t (*Send)(const void*, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
     ncclResult_t (*Recv)(void*, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
     ncclResult_t (*GroupStart)() = nullptr;
@@ -47,7 +48,7 @@ static const char* load_rccl() {
     if (!h) return "librccl.so not found (dlopen)";
 #define SYM(f, name) *(void**)(&g_rccl.f) = dlsym(h, name); if (!g_rccl.f) return "RCCL symbol missing: " name;
     SYM(GetUniqueId, "ncclGetUniqueId") SYM(CommInitRank, "ncclCommInitRank") SYM(CommDestroy, "ncclCommDestroy")
-    SYM(AllReduce, "ncclAllReduce") SYM(Send, "ncclSend") SYM(Recv, "ncclRecv") SYM(GroupStart, "ncclGroupStart")
+    SYM(AllReduce, "ncclAllReduce") SYM(AllGather, "ncclAllGather") SYM(Send, "ncclSend") SYM(Recv, "ncclRecv") SYM(GroupStart, "ncclGroupStart")
     SYM(GroupEnd, "ncclGroupEnd") SYM(GetErrorString, "ncclGetErrorString")
     SYM(CommCount, "ncclCommCount") SYM(CommUserRank, "ncclCommUserRank") SYM(CommCuDevice, "ncclCommCuDevice")
 #undef SYM
@@ -110,6 +111,33 @@ int comm_allreduce(opmhip_ctx* c, double* d_buf, int n, int op) {
     OPMHIP_HIP(c, hipMemcpyAsync(d_buf, acc, n * sizeof(double), hipMemcpyHostToDevice, c->stream));
     OPMHIP_HIP(c, hipStreamSynchronize(c->stream));
     return OPMHIP_SUCCESS;
+}
+
+// d_recv[r * count .. (r + 1) * count) = rank r's d_send[0 .. count) on every rank (count doubles per rank, the same on all ranks): the
+// right-hand sides, matrix values and - at set-up - the patterns of the pressure hierarchy's level that is continued across the ranks
+// (cpr.hip).  On the context's stream; RCCL: one ncclAllGather; loopback: device copies between two barriers.
+int comm_allgather(opmhip_ctx* c, const double* d_send, double* d_recv, size_t count) {
+    CommDev& C = c->comm;
+    if (C.nranks <= 1 || C.kind == COMM_NONE) {
+        if (count > 0) OPMHIP_HIP(c, hipMemcpyAsync(d_recv, d_send, count * sizeof(double), hipMemcpyDeviceToDevice, c->stream));
+        return OPMHIP_SUCCESS;
+    }
+    if (C.kind == COMM_RCCL) {
+        NCCLCHK(c, g_rccl.AllGather(d_send, d_recv, count, ncclDouble, (ncclComm_t)C.nccl, c->stream));
+        return OPMHIP_SUCCESS;
+    }
+    LoopGroup* G = (LoopGroup*)C.group;
+    C.ag_send = d_send;
+    int rc = (hipStreamSynchronize(c->stream) == hipSuccess) ? OPMHIP_SUCCESS : fail(c, OPMHIP_DEVICE_ERROR, "allgather: the stream failed before the exchange");
+    pthread_barrier_wait(&G->barrier);   // every rank's contribution is complete and its address published
+    if (!rc) rc = [&]() -> int {
+        for (int r = 0; r < C.nranks && count > 0; ++r)
+            OPMHIP_HIP(c, hipMemcpyAsync(d_recv + (size_t)r * count, G->members[r]->comm.ag_send, count * sizeof(double), hipMemcpyDeviceToDevice, c->stream));
+        OPMHIP_HIP(c, hipStreamSynchronize(c->stream));
+        return OPMHIP_SUCCESS;
+    }();
+    pthread_barrier_wait(&G->barrier);   // nobody overwrites its contribution before every copy is done
+    return rc;
 }
 
 // ghost entries of `vec` (w doubles per cell, internal order, ghosts at cells Nb..) <- owners' values; on stream s (default:

@@ -21,6 +21,7 @@
 #include <cstdlib>
 #include <numeric>
 #include <atomic>
+#include <map>
 #include <memory>
 #include <string>
 #include <thread>
@@ -748,6 +749,49 @@ __global__ __launch_bounds__(256) void k_cpr_ilu_sweep(int nseq, int nsteps, con
     if (t < nseq) cpr_ilu_sweep_body<BWD, false, WQ>(t, nseq, nsteps, rowAt, n, wq, fv, fc, ud, d, v, v, add, out, vfine);
 }
 
+
+// ---------------------------------------------------------------- the level that is continued across the ranks ------------
+// pressure values of the couplings to ghost cells (k_cpr_pvals leaves them out of the subdomain's own system): entry of the joined level's
+// matrix between aggregates of two subdomains = the sum of these over the fine couplings between them (Galerkin, piecewise-constant
+// prolongation); k_cpr_pvals's statement
+__global__ __launch_bounds__(256) void k_cpr_ghost_pvals(int nq, const int* __restrict__ qrow, const int* __restrict__ qentry, const double* __restrict__ A,
+                                                         const double* __restrict__ w, double* __restrict__ apg) {
+    const int q = blockIdx.x * blockDim.x + threadIdx.x;
+    if (q >= nq) return;
+    const int i = qrow[q];
+    const double* B = &A[(size_t)qentry[q] * BB];
+    double s = 0.0;
+    s += B[0 * BS + CPR_P] * w[(size_t)i * BS]; s += B[1 * BS + CPR_P] * w[(size_t)i * BS + 1]; s += B[2 * BS + CPR_P] * w[(size_t)i * BS + 2];
+    apg[q] = s;
+}
+// my entries of the joined level's matrix: the value of my last level's entry, or the sum over the fine couplings of a pair of aggregates
+__global__ __launch_bounds__(256) void k_cpr_gather_vals(int nnzloc, const int* __restrict__ src, const int* __restrict__ xptr, const int* __restrict__ xidx,
+                                                         const double* __restrict__ apg, const double* __restrict__ lastval, double* __restrict__ vsend) {
+    const int e = blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= nnzloc) return;
+    const int sidx = src[e];
+    if (sidx >= 0) { vsend[e] = lastval[sidx]; return; }
+    const int x = -1 - sidx;
+    double s = 0.0;
+    for (int t = xptr[x]; t < xptr[x + 1]; ++t) s += apg[xidx[t]];
+    vsend[e] = s;
+}
+__global__ __launch_bounds__(256) void k_cpr_scatter_vals(int nnzG, const int* __restrict__ vunpad, const int* __restrict__ vpos, const double* __restrict__ vrecv,
+                                                          double* __restrict__ val) {
+    const int e = blockIdx.x * blockDim.x + threadIdx.x;
+    if (e < nnzG) val[vpos[e]] = vrecv[vunpad[e]];
+}
+// the gathered right-hand sides, slice by slice, into the joined level's b; x0 != NULL: its pre-smoothed iterate rides along (k_cpr_presmooth's statement)
+__global__ __launch_bounds__(256) void k_cpr_unpad(int NG, const int* __restrict__ unpad, const double* __restrict__ recv, double* __restrict__ b, double omega,
+                                                   const double* __restrict__ dinv, double* __restrict__ x0, const double* __restrict__ done) {
+    CPR_DONE_CHECK
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= NG) return;
+    const double s = recv[unpad[i]];
+    b[i] = s;
+    if (x0) x0[i] = omega * dinv[i] * s;
+}
+
 static inline dim3 g256(int n) { return dim3((n + 255) / 256); }
 
 // ---------------------------------------------------------------- setup --------------------------------------------------
@@ -778,6 +822,8 @@ struct CprHostCoarse {
     std::vector<CprHostLevel> lv;    // levels 1 ..
     double tAgg = 0.0, tGal = 0.0, tImg = 0.0;
     std::string error;               // non-empty: the build failed
+    HCsr lastA;                      // the last level's matrix and the place of its entries in that level's image
+    std::vector<int> lastPos;
 };
 struct CprAsyncJob {
     std::thread th;
@@ -931,8 +977,10 @@ static void cpr_free_ilu(opmhip_ctx* c, CprLevelDev& L) {
     dev_free(c, &L.d_ilv); dev_free(c, &L.d_ilc); dev_free(c, &L.d_iuv); dev_free(c, &L.d_iuc); dev_free(c, &L.d_iud);
     L.ilu = false;
 }
-static int upload_ell(opmhip_ctx* c, const CprHostLevel& H, CprLevelDev& L) {
+// nvec: entries of the level's vectors (level 0 of a rank whose pressure stage spans the ranks: ghost cells included)
+static int upload_ell(opmhip_ctx* c, const CprHostLevel& H, CprLevelDev& L, int nvec = 0) {
     const int n = H.n, W = H.W;
+    if (nvec < n) nvec = n;
     if (W > CPR_MAX_W) return fail(c, OPMHIP_ANALYSIS_FAILED, "cpr: a row of a pressure-AMG level has %d entries (limit %d)", W, CPR_MAX_W);
     L.n = n; L.nnz = H.nnz; L.W = W; L.rm = H.rm;
     int rc;
@@ -942,10 +990,14 @@ static int upload_ell(opmhip_ctx* c, const CprHostLevel& H, CprLevelDev& L) {
     if ((rc = dev_alloc(c, &L.d_val, (size_t)W * n))) return rc;
     OPMHIP_HIP(c, hipMemset(L.d_val, 0, (size_t)W * n * sizeof(double)));   // the padding stays 0 for good
     if ((rc = dev_alloc(c, &L.d_dinv, (size_t)n))) return rc;
-    if ((rc = dev_alloc(c, &L.d_b, (size_t)n))) return rc;
-    if ((rc = dev_alloc(c, &L.d_x, (size_t)n))) return rc;
-    if ((rc = dev_alloc(c, &L.d_x2, (size_t)n))) return rc;
-    if ((rc = dev_alloc(c, &L.d_r, (size_t)n))) return rc;
+    if ((rc = dev_alloc(c, &L.d_b, (size_t)nvec))) return rc;
+    OPMHIP_HIP(c, hipMemsetAsync(L.d_b, 0, (size_t)nvec * sizeof(double), c->stream));
+    if ((rc = dev_alloc(c, &L.d_x, (size_t)nvec))) return rc;
+    OPMHIP_HIP(c, hipMemsetAsync(L.d_x, 0, (size_t)nvec * sizeof(double), c->stream));
+    if ((rc = dev_alloc(c, &L.d_x2, (size_t)nvec))) return rc;
+    OPMHIP_HIP(c, hipMemsetAsync(L.d_x2, 0, (size_t)nvec * sizeof(double), c->stream));
+    if ((rc = dev_alloc(c, &L.d_r, (size_t)nvec))) return rc;
+    OPMHIP_HIP(c, hipMemsetAsync(L.d_r, 0, (size_t)nvec * sizeof(double), c->stream));
     return OPMHIP_SUCCESS;
 }
 // True-IMPES weights (getQuasiImpesWeights.hpp:89-128): block[ii][jj] = d storage_ii / d x_jj / (V / dt), pressure column
@@ -1039,6 +1091,7 @@ static int cpr_lpr_rows() {
     static const int v = [] { const char* e = std::getenv("OPMHIP_CPR_LPR_ROWS"); return e ? std::atoi(e) : CPR_LPR_ROWS; }();
     return v;
 }
+static bool cpr_gathering(const opmhip_ctx* c);
 // ---- level 0: belongs to the PATTERN (image, stencil form, block-vector work space): built once per context ------------------
 static int cpr_setup_level0(opmhip_ctx* c) {
     const Pattern& P = c->pat;
@@ -1057,8 +1110,9 @@ static int cpr_setup_level0(opmhip_ctx* c) {
     R.lv.emplace_back();
     CprHostLevel H0;
     std::vector<int> pos;
-    (void)ell_image(A, H0, pos, false, P.Nb);
-    if ((rc = upload_ell(c, H0, R.lv[0]))) return rc;
+    const bool spans = cpr_gathering(c);   // the pressure stage spans the ranks: level 0 keeps its couplings to ghost cells (columns Nb ..), its vectors their ghost entries
+    (void)ell_image(A, H0, pos, false, spans ? P.Nloc : P.Nb);
+    if ((rc = upload_ell(c, H0, R.lv[0], spans ? P.Nloc : P.Nb))) return rc;
     {   // level 0's ELL columns in stencil form (EllStencil), where the pattern has it: single domain, rows of <= 8 entries, <= 15 offsets per group of 32 rows
         static const bool off = [] { const char* e = std::getenv("OPMHIP_CPR_ELL_EXPLICIT"); return e && e[0] == '1'; }();   // A/B switch
         bool ok = !off && P.Nghost == 0 && R.lv[0].W <= 8;
@@ -1088,7 +1142,7 @@ static int cpr_setup_level0(opmhip_ctx* c) {
             if ((rc = dev_upload(c, &R.lv[0].d_stable, table))) return rc;
         }
     }
-    if (c->cfg.cpr_amg_ilu_levels > 0) {   // ILU0 smoothing of level 0: in the stored order, the block ILU0's colours are this one's
+    if (c->cfg.cpr_amg_ilu_levels > 0 && !spans) {   // ILU0 smoothing of level 0: in the stored order, the block ILU0's colours are this one's
         std::vector<int> posv(P.Nb), colour(P.Nb);
         for (int cc = 0; cc < P.numColors; ++cc)
             for (int p = P.colorPrefix[cc]; p < P.colorPrefix[cc + 1]; ++p) colour[p] = cc;
@@ -1102,38 +1156,19 @@ static int cpr_setup_level0(opmhip_ctx* c) {
     R.level0 = true;
     return OPMHIP_SUCCESS;
 }
-// ---- everything below level 0's image, on the host: two passes of pairwise matching per level, Galerkin lists, level images.
-//      Pure host work on its arguments (no context, no HIP call): may run on a thread of its own.  ell0: level 0's value image
-//      (W0 x Nb, as on the device) of the pressure matrix the structure is built from.
-static void cpr_build_coarse_host(const Pattern& P, const std::vector<double>& ell0, double beta, int lprRows, int iluLevels, CprHostCoarse& out) {
+// The coarsening itself: A = the finest level of the hierarchy being built (CSR with values), pos = the place of every entry of A in
+// that level's image on the device; natOf / atNat: see pairwise (level 0 of a reordered system, else NULL).  stopRows: a level of at
+// most this many rows is the last one (CPR_COARSE_DIRECT: it is solved directly; a rank whose hierarchy is continued across the ranks
+// stops at opmhip_config.cpr_gather_rows).  The last level's matrix stays in out.lastA / lastPos.
+static void cpr_coarsen_host(HCsr A, std::vector<int> pos, const int* natOf, const int* atNat, double beta, int lprRows, int iluLevels, int stopRows, CprHostCoarse& out) {
     auto now = [] { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
 #define CPR_T(acc, stmt) do { const double t_ = now(); stmt; acc += now() - t_; } while (0)
-    HCsr A;
-    A.n = P.Nb; A.rowptr = P.rowptr; A.col = P.col;
-    CprHostLevel img0;
-    std::vector<int> pos;   // ELL position of every CSR entry of the level being coarsened
-    CPR_T(out.tImg, (void)ell_image(A, img0, pos, false, P.Nb));
-    if (P.Nghost > 0) {   // the host copy the hierarchy is built from: owned columns only (pos follows the entries that stay)
-        HCsr F;
-        std::vector<int> fpos;
-        F.n = P.Nb; F.rowptr.assign(P.Nb + 1, 0);
-        for (int i = 0; i < P.Nb; ++i) {
-            for (int k = A.rowptr[i]; k < A.rowptr[i + 1]; ++k)
-                if (A.col[k] < P.Nb) { F.col.push_back(A.col[k]); fpos.push_back(pos[k]); }
-            F.rowptr[i + 1] = (int)F.col.size();
-        }
-        A = std::move(F);
-        pos = std::move(fpos);
-    }
-    const int nnz0 = (int)A.col.size();
-    A.val.resize(nnz0);
-    for (int k = 0; k < nnz0; ++k) A.val[k] = ell0[pos[k]];
     out.lv.clear();
     CprHostLevel* cur = &out.l0;   // the level being coarsened (its transfer part is filled here)
     cur->n = A.n;
     int nlev = 1;
     while (true) {
-        const bool last = A.n <= CPR_COARSE_DIRECT || nlev >= CPR_MAX_LEVELS;
+        const bool last = A.n <= stopRows || nlev >= CPR_MAX_LEVELS;
         if (last) break;
         std::vector<int> a1, a2, g1p, g1i;
         int n1 = 0, n2 = 0;
@@ -1141,7 +1176,7 @@ static void cpr_build_coarse_host(const Pattern& P, const std::vector<double>& e
         for (int attempt = 0; attempt < 3; ++attempt) {
             const double b = attempt == 0 ? beta : 0.0;
             const bool lvl0 = nlev == 1;   // the finest level is stored in the ILU ordering: visit it in natural order
-            CPR_T(out.tAgg, pairwise(A, b, attempt == 2, a1, n1, lvl0 ? P.fromOrder.data() : nullptr, lvl0 ? P.toOrder.data() : nullptr));
+            CPR_T(out.tAgg, pairwise(A, b, attempt == 2, a1, n1, lvl0 ? natOf : nullptr, lvl0 ? atNat : nullptr));
             CPR_T(out.tGal, galerkin(A, a1, n1, A1, g1p, g1i));
             CPR_T(out.tAgg, pairwise(A1, b, attempt == 2, a2, n2));
             if (n2 <= (int)(0.5 * A.n)) break;
@@ -1197,11 +1232,39 @@ static void cpr_build_coarse_host(const Pattern& P, const std::vector<double>& e
         A = std::move(Ac);
         ++nlev;
     }
+    out.lastA = std::move(A);
+    out.lastPos = std::move(pos);
 #undef CPR_T
 }
+// ---- everything below level 0's image, on the host: two passes of pairwise matching per level, Galerkin lists, level images.
+//      Pure host work on its arguments (no context, no HIP call): may run on a thread of its own.  ell0: level 0's value image
+//      (W0 x Nb, as on the device) of the pressure matrix the structure is built from.
+static void cpr_build_coarse_host(const Pattern& P, const std::vector<double>& ell0, double beta, int lprRows, int iluLevels, int stopRows, CprHostCoarse& out) {
+    HCsr A;
+    A.n = P.Nb; A.rowptr = P.rowptr; A.col = P.col;
+    CprHostLevel img0;
+    std::vector<int> pos;   // ELL position of every CSR entry of the level being coarsened
+    (void)ell_image(A, img0, pos, false, P.Nb);
+    if (P.Nghost > 0) {   // the host copy the hierarchy is built from: owned columns only (pos follows the entries that stay)
+        HCsr F;
+        std::vector<int> fpos;
+        F.n = P.Nb; F.rowptr.assign(P.Nb + 1, 0);
+        for (int i = 0; i < P.Nb; ++i) {
+            for (int k = A.rowptr[i]; k < A.rowptr[i + 1]; ++k)
+                if (A.col[k] < P.Nb) { F.col.push_back(A.col[k]); fpos.push_back(pos[k]); }
+            F.rowptr[i + 1] = (int)F.col.size();
+        }
+        A = std::move(F);
+        pos = std::move(fpos);
+    }
+    const int nnz0 = (int)A.col.size();
+    A.val.resize(nnz0);
+    for (int k = 0; k < nnz0; ++k) A.val[k] = ell0[pos[k]];
+    cpr_coarsen_host(std::move(A), std::move(pos), P.fromOrder.data(), P.toOrder.data(), beta, lprRows, iluLevels, stopRows, out);
+}
 // ---- the device side of it: transfer arrays of every level, images of the levels below level 0 --------------------------------
-static int cpr_upload_coarse(opmhip_ctx* c, const CprHostCoarse& H) {
-    CprDev& R = c->cpr;
+// gathered: R's last level is continued across the ranks (cpr_gather_setup), not solved by R
+static int cpr_upload_coarse(opmhip_ctx* c, CprDev& R, const CprHostCoarse& H, bool gathered) {
     int rc;
     if (!H.error.empty()) return fail(c, OPMHIP_ANALYSIS_FAILED, "%s", H.error.c_str());
     auto transfer = [&](const CprHostLevel& h, CprLevelDev& L) -> int {
@@ -1224,26 +1287,33 @@ static int cpr_upload_coarse(opmhip_ctx* c, const CprHostCoarse& H) {
         if (h.ilu.ncol > 0 && (rc = cpr_upload_ilu(c, h.ilu, R.lv.back()))) return rc;
         if ((rc = transfer(h, R.lv.back()))) return rc;
     }
-    R.coarse_direct = R.lv.back().n <= CPR_COARSE_DIRECT;
+    R.coarse_direct = !gathered && R.lv.back().n <= CPR_COARSE_DIRECT;
     if (R.coarse_direct && (rc = dev_alloc(c, &R.d_lu, (size_t)R.lv.back().n * R.lv.back().n + 1))) return rc;   // + 1: the pivot flag
     R.structured = true;
     return OPMHIP_SUCCESS;
 }
-// gives back what cpr_upload_coarse allocated: level 0 keeps its image, the levels below it go
-static void cpr_release_coarse(opmhip_ctx* c) {
-    CprDev& R = c->cpr;
+// gives back what cpr_upload_coarse allocated: level 0 keeps its image (keep0; the joined hierarchy of a decomposed run goes as a whole),
+// the levels below it go
+static void cpr_release_coarse(opmhip_ctx* c, CprDev& R, bool keep0 = true) {
     (void)hipStreamSynchronize(c->stream);
+    if (R.gather.glob) cpr_release_coarse(c, *R.gather.glob, false);
+    {
+        CprGatherDev& G = R.gather;
+        dev_free(c, &G.d_recv); dev_free(c, &G.d_vsend); dev_free(c, &G.d_vrecv); dev_free(c, &G.d_unpad); dev_free(c, &G.d_vunpad); dev_free(c, &G.d_vpos);
+        dev_free(c, &G.d_cagg); dev_free(c, &G.d_send); dev_free(c, &G.d_src); dev_free(c, &G.d_xptr); dev_free(c, &G.d_xidx); dev_free(c, &G.d_qrow); dev_free(c, &G.d_qentry); dev_free(c, &G.d_apg);
+        G = CprGatherDev();
+    }
     for (size_t l = 0; l < R.lv.size(); ++l) {
         CprLevelDev& L = R.lv[l];
         dev_free(c, &L.d_agg); dev_free(c, &L.d_mptr); dev_free(c, &L.d_midx); dev_free(c, &L.d_mem4); dev_free(c, &L.d_gptr); dev_free(c, &L.d_gidx); dev_free(c, &L.d_cpos);
         L.nc = 0;
-        if (l == 0) continue;
+        if (l == 0 && keep0) continue;
         dev_free(c, &L.d_ecol); dev_free(c, &L.d_rlen); dev_free(c, &L.d_diag);
         dev_free(c, &L.d_val); dev_free(c, &L.d_dinv); dev_free(c, &L.d_x2);
         dev_free(c, &L.d_b); dev_free(c, &L.d_x); dev_free(c, &L.d_r); dev_free(c, &L.d_sword); dev_free(c, &L.d_stable);
         cpr_free_ilu(c, L);
     }
-    if (!R.lv.empty()) R.lv.resize(1);
+    if (!R.lv.empty()) R.lv.resize(keep0 ? 1 : 0);
     dev_free(c, &R.d_lu);
     R.structured = false;
 }
@@ -1254,6 +1324,219 @@ static int cpr_download_level0(opmhip_ctx* c, std::vector<double>& ell) {
     OPMHIP_HIP(c, hipMemcpyAsync(ell.data(), L0.d_val, ell.size() * sizeof(double), hipMemcpyDeviceToHost, c->stream));
     OPMHIP_HIP(c, hipStreamSynchronize(c->stream));
     return OPMHIP_SUCCESS;
+}
+static int cpr_update_values(opmhip_ctx* c, CprDev& R);
+static int cpr_upload_coarse(opmhip_ctx* c, CprDev& R, const CprHostCoarse& H, bool gathered);
+
+// ---- decomposed runs: the hierarchy continued across the ranks ------------------------------------------------------------------
+// The reference's parallel CPR keeps a coarse pressure problem that spans the processes (Dune's parallel AMG behind
+// linalg/OwningTwoLevelPreconditioner.hpp; aggregates never cross a process boundary, the coarse operators carry the couplings between
+// the processes).  Here: every rank coarsens its own subdomain down to its first level of at most opmhip_config.cpr_gather_rows rows
+// (couplings to ghost cells left out of those levels: they smooth, and smoothing is local); that level's matrix rows - its own entries
+// plus the Galerkin sums of the fine couplings between the aggregates of different subdomains - are gathered into ONE system that every
+// rank holds, coarsens further and cycles on redundantly: one all-gather of a right-hand side per application, one of matrix values per
+// solve.  oracle: orc_cpr_solve_blocks with gather_rows.
+static bool cpr_gathering(const opmhip_ctx* c) { return c->comm.nranks > 1 && c->comm.kind != COMM_NONE && c->cfg.cpr_gather_rows >= 0; }
+static int cpr_stop_rows(const opmhip_ctx* c) { return cpr_gathering(c) ? (c->cfg.cpr_gather_rows > 0 ? c->cfg.cpr_gather_rows : 32768) : CPR_COARSE_DIRECT; }
+// `bytes` bytes of every rank, in rank order, on every rank (set-up only: staged through device buffers of its own)
+static int cpr_host_allgather(opmhip_ctx* c, const void* src, size_t bytes, std::vector<char>& dst) {
+    const int nr = c->comm.nranks;
+    const size_t cnt = std::max<size_t>((bytes + 7) / 8, 1);
+    std::vector<double> sb(cnt, 0.0), rb(cnt * nr, 0.0);
+    if (bytes) std::memcpy(sb.data(), src, bytes);
+    double *d_s = nullptr, *d_r = nullptr;
+    if (hipMalloc((void**)&d_s, cnt * sizeof(double)) != hipSuccess || hipMalloc((void**)&d_r, cnt * nr * sizeof(double)) != hipSuccess) {
+        if (d_s) (void)hipFree(d_s);
+        // (the peers would wait for this rank in the exchange: take part in it with what there is)
+        return fail(c, OPMHIP_DEVICE_ERROR, "cpr: no device memory for the set-up exchange of the joined level");
+    }
+    int rc = [&]() -> int {
+        OPMHIP_HIP(c, hipMemcpyAsync(d_s, sb.data(), cnt * sizeof(double), hipMemcpyHostToDevice, c->stream));
+        int r2 = comm_allgather(c, d_s, d_r, cnt);
+        if (r2) return r2;
+        OPMHIP_HIP(c, hipMemcpyAsync(rb.data(), d_r, cnt * nr * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+        OPMHIP_HIP(c, hipStreamSynchronize(c->stream));
+        return OPMHIP_SUCCESS;
+    }();
+    (void)hipFree(d_s); (void)hipFree(d_r);
+    if (rc) return rc;
+    dst.resize(bytes * nr);
+    for (int r = 0; r < nr; ++r)
+        if (bytes) std::memcpy(dst.data() + (size_t)r * bytes, rb.data() + (size_t)r * cnt, bytes);
+    return OPMHIP_SUCCESS;
+}
+// after the rank's own hierarchy is on the device (its last level = the one that is gathered; H: the host side of it, with that level's matrix)
+static int cpr_gather_setup(opmhip_ctx* c, const CprHostCoarse& H) {
+    const Pattern& P = c->pat;
+    CprDev& R = c->cpr;
+    CprGatherDev& G = R.gather;
+    const int nr = c->comm.nranks, me = c->comm.rank;
+    if (P.Nghost > 0 && !c->comm.halo_set) return fail(c, OPMHIP_NOT_READY, "cpr: the joined coarse level needs the halo lists (opmhip_set_halo) before the first solve");
+    int rc;
+    std::vector<char> buf;
+    const size_t g = R.lv.size() - 1;
+    const int nloc = R.lv[g].n;
+    // 1. sizes of everybody's slice, of everybody's subdomain
+    const int mine[2] = {nloc, P.Nb};
+    if ((rc = cpr_host_allgather(c, mine, sizeof mine, buf))) return rc;
+    std::vector<int> offs(nr + 1, 0), foffs(nr + 1, 0);
+    int maxn = 1;
+    for (int r = 0; r < nr; ++r) {
+        int v[2];
+        std::memcpy(v, buf.data() + (size_t)r * sizeof v, sizeof v);
+        offs[r + 1] = offs[r] + v[0];
+        foffs[r + 1] = foffs[r] + v[1];
+        maxn = std::max(maxn, v[0]);
+    }
+    // 2. aggregate (on the gathered level) of every owned cell
+    std::vector<int> cagg(P.Nb);
+    std::iota(cagg.begin(), cagg.end(), 0);
+    for (size_t l = 0; l < g; ++l) {
+        const std::vector<int>& a = l == 0 ? H.l0.agg : H.lv[l - 1].agg;
+        for (int i = 0; i < P.Nb; ++i) cagg[i] = a[cagg[i]];
+    }
+    // 3. the same for the ghost cells, from their owners: row of the joined level, and the owner-side place of the cell (what orders the
+    //    fine couplings inside one joined entry: subdomain by subdomain, each in its rank's internal order)
+    std::vector<double> hv((size_t)2 * P.Nloc, 0.0);
+    for (int i = 0; i < P.Nb; ++i) { hv[(size_t)2 * i] = (double)(offs[me] + cagg[i]); hv[(size_t)2 * i + 1] = (double)(foffs[me] + i); }
+    {
+        double* d_hv = nullptr;
+        if (hipMalloc((void**)&d_hv, hv.size() * sizeof(double)) != hipSuccess) return fail(c, OPMHIP_DEVICE_ERROR, "cpr: no device memory for the set-up exchange of the joined level");
+        rc = [&]() -> int {
+            OPMHIP_HIP(c, hipMemcpyAsync(d_hv, hv.data(), hv.size() * sizeof(double), hipMemcpyHostToDevice, c->stream));
+            int r2 = comm_halo_f64(c, d_hv, 2);
+            if (r2) return r2;
+            OPMHIP_HIP(c, hipMemcpyAsync(hv.data(), d_hv, hv.size() * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+            OPMHIP_HIP(c, hipStreamSynchronize(c->stream));
+            return OPMHIP_SUCCESS;
+        }();
+        (void)hipFree(d_hv);
+        if (rc) return rc;
+    }
+    // 4. my rows of the joined level: my last level's entries, and one entry per pair (my aggregate, an aggregate of another rank) that a
+    //    fine coupling joins
+    std::vector<int> qrow, qentry;
+    struct Fine { int i; long long gf; int q; };
+    std::vector<std::map<int, std::vector<Fine>>> cross(nloc);
+    for (int i = 0; i < P.Nb; ++i)
+        for (int k = P.rowptr[i]; k < P.rowptr[i + 1]; ++k) {
+            const int gh = P.col[k];
+            if (gh < P.Nb) continue;
+            const int q = (int)qrow.size();
+            qrow.push_back(i); qentry.push_back(k);
+            cross[cagg[i]][(int)hv[(size_t)2 * gh]].push_back(Fine{i, (long long)hv[(size_t)2 * gh + 1], q});
+        }
+    G.nq = (int)qrow.size();
+    std::vector<double> apg(std::max(G.nq, 1), 0.0);
+    if ((rc = dev_upload(c, &G.d_qrow, qrow))) return rc;
+    if ((rc = dev_upload(c, &G.d_qentry, qentry))) return rc;
+    if ((rc = dev_alloc(c, &G.d_apg, (size_t)std::max(G.nq, 1)))) return rc;
+    if (G.nq > 0) {
+        hipLaunchKernelGGL(k_cpr_ghost_pvals, g256(G.nq), dim3(256), 0, c->stream, G.nq, G.d_qrow, G.d_qentry, c->d_A, R.d_w, G.d_apg);
+        OPMHIP_HIP(c, hipMemcpyAsync(apg.data(), G.d_apg, (size_t)G.nq * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+        OPMHIP_HIP(c, hipStreamSynchronize(c->stream));
+    }
+    const HCsr& LA = H.lastA;
+    std::vector<int> rowlen(nloc, 0), cols, src, xptr(1, 0), xidx;
+    std::vector<double> vals;
+    for (int I = 0; I < nloc; ++I) {
+        auto cr = cross[I].begin();
+        auto emit_cross = [&](int upto) {   // the entries towards other ranks whose joined column lies below `upto`
+            for (; cr != cross[I].end() && cr->first < upto; ++cr) {
+                std::vector<Fine>& f = cr->second;
+                std::sort(f.begin(), f.end(), [](const Fine& a, const Fine& b) { return a.i != b.i ? a.i < b.i : a.gf < b.gf; });
+                double sum = 0.0;
+                for (const Fine& e : f) { sum += apg[e.q]; xidx.push_back(e.q); }
+                cols.push_back(cr->first); vals.push_back(sum);
+                src.push_back(-1 - (int)(xptr.size() - 1));
+                xptr.push_back((int)xidx.size());
+                ++rowlen[I];
+            }
+        };
+        for (int k = LA.rowptr[I]; k < LA.rowptr[I + 1]; ++k) {
+            emit_cross(offs[me] + LA.col[k]);
+            cols.push_back(offs[me] + LA.col[k]); vals.push_back(LA.val[k]); src.push_back(H.lastPos[k]);
+            ++rowlen[I];
+        }
+        emit_cross(INT_MAX);
+    }
+    G.nnzloc = (int)cols.size();
+    // 5. everybody's rows
+    if ((rc = cpr_host_allgather(c, &G.nnzloc, sizeof(int), buf))) return rc;
+    std::vector<int> nnzs(nr);
+    int maxnnz = 1;
+    for (int r = 0; r < nr; ++r) { std::memcpy(&nnzs[r], buf.data() + (size_t)r * sizeof(int), sizeof(int)); maxnnz = std::max(maxnnz, nnzs[r]); }
+    std::vector<char> bl, bc, bv;
+    {
+        std::vector<int> t(maxn, 0);
+        std::copy(rowlen.begin(), rowlen.end(), t.begin());
+        if ((rc = cpr_host_allgather(c, t.data(), (size_t)maxn * sizeof(int), bl))) return rc;
+        std::vector<int> tc(maxnnz, 0);
+        std::copy(cols.begin(), cols.end(), tc.begin());
+        if ((rc = cpr_host_allgather(c, tc.data(), (size_t)maxnnz * sizeof(int), bc))) return rc;
+        std::vector<double> tv(maxnnz, 0.0);
+        std::copy(vals.begin(), vals.end(), tv.begin());
+        if ((rc = cpr_host_allgather(c, tv.data(), (size_t)maxnnz * sizeof(double), bv))) return rc;
+    }
+    HCsr J;
+    const int NG = offs[nr];
+    J.n = NG;
+    J.rowptr.assign(1, 0);
+    std::vector<int> unpad, vunpad;
+    for (int r = 0; r < nr; ++r) {
+        const int* rl = reinterpret_cast<const int*>(bl.data() + (size_t)r * maxn * sizeof(int));
+        const int* rcs = reinterpret_cast<const int*>(bc.data() + (size_t)r * maxnnz * sizeof(int));
+        const double* rv = reinterpret_cast<const double*>(bv.data() + (size_t)r * maxnnz * sizeof(double));
+        int e = 0;
+        for (int I = 0; I < offs[r + 1] - offs[r]; ++I) {
+            for (int t = 0; t < rl[I]; ++t, ++e) {
+                if (rcs[e] < 0 || rcs[e] >= NG || e >= nnzs[r]) return fail(c, OPMHIP_ANALYSIS_FAILED, "cpr: the joined level's rows of rank %d are inconsistent", r);
+                J.col.push_back(rcs[e]); J.val.push_back(rv[e]); vunpad.push_back(r * maxnnz + e);
+            }
+            J.rowptr.push_back((int)J.col.size());
+            unpad.push_back(r * maxn + I);
+        }
+    }
+    // 6. the hierarchy all ranks share: level 0 = the joined level (the same matrix on every rank, hence the same hierarchy)
+    G.glob = std::make_shared<CprDev>();
+    CprDev& JD = *G.glob;
+    JD.omega = R.omega; JD.damp = R.damp; JD.beta = R.beta;
+    CprHostLevel img0;
+    std::vector<int> posg;
+    if (!ell_image(J, img0, posg, NG <= cpr_lpr_rows())) return fail(c, OPMHIP_ANALYSIS_FAILED, "cpr: a row of the joined level has %d entries (limit %d): lower opmhip_config.cpr_gather_rows' level count or raise the limit", img0.W, CPR_MAX_W);
+    JD.lv.emplace_back();
+    if ((rc = upload_ell(c, img0, JD.lv[0]))) return rc;
+    CprHostCoarse HJ;
+    cpr_coarsen_host(J, posg, nullptr, nullptr, R.beta, cpr_lpr_rows(), 0, CPR_COARSE_DIRECT, HJ);
+    if ((rc = cpr_upload_coarse(c, JD, HJ, false))) return rc;
+    // 7. what the solves need on the device
+    G.nloc = nloc; G.off = offs[me]; G.NG = NG; G.maxn = maxn; G.maxnnz = maxnnz; G.nnzG = (int)J.col.size();
+    if ((rc = dev_alloc(c, &G.d_recv, (size_t)nr * maxn))) return rc;
+    if ((rc = dev_alloc(c, &G.d_vsend, (size_t)maxnnz))) return rc;
+    OPMHIP_HIP(c, hipMemsetAsync(G.d_vsend, 0, (size_t)maxnnz * sizeof(double), c->stream));
+    if ((rc = dev_alloc(c, &G.d_vrecv, (size_t)nr * maxnnz))) return rc;
+    if ((rc = dev_upload(c, &G.d_unpad, unpad))) return rc;
+    if ((rc = dev_upload(c, &G.d_vunpad, vunpad))) return rc;
+    if ((rc = dev_upload(c, &G.d_vpos, posg))) return rc;
+    if ((rc = dev_upload(c, &G.d_src, src))) return rc;
+    if ((rc = dev_upload(c, &G.d_xptr, xptr))) return rc;
+    if ((rc = dev_upload(c, &G.d_xidx, xidx))) return rc;
+    if ((rc = dev_upload(c, &G.d_cagg, cagg))) return rc;
+    if ((rc = dev_alloc(c, &G.d_send, (size_t)maxn))) return rc;   // my slice of the joined level's right-hand side: room for the largest slice
+    OPMHIP_HIP(c, hipMemsetAsync(G.d_send, 0, (size_t)maxn * sizeof(double), c->stream));
+    G.on = true;
+    return OPMHIP_SUCCESS;
+}
+// per solve: my rows' values of the joined level's matrix, everybody's, the values of the shared hierarchy below it
+static int cpr_gather_values(opmhip_ctx* c) {
+    CprDev& R = c->cpr;
+    CprGatherDev& G = R.gather;
+    int rc;
+    if (G.nq > 0) hipLaunchKernelGGL(k_cpr_ghost_pvals, g256(G.nq), dim3(256), 0, c->stream, G.nq, G.d_qrow, G.d_qentry, c->d_A, R.d_w, G.d_apg);
+    if (G.nnzloc > 0) hipLaunchKernelGGL(k_cpr_gather_vals, g256(G.nnzloc), dim3(256), 0, c->stream, G.nnzloc, G.d_src, G.d_xptr, G.d_xidx, G.d_apg, R.lv.back().d_val, G.d_vsend);
+    if ((rc = comm_allgather(c, G.d_vsend, G.d_vrecv, (size_t)G.maxnnz))) return rc;
+    hipLaunchKernelGGL(k_cpr_scatter_vals, g256(G.nnzG), dim3(256), 0, c->stream, G.nnzG, G.d_vunpad, G.d_vpos, G.d_vrecv, G.glob->lv[0].d_val);
+    return cpr_update_values(c, *G.glob);
 }
 // the structure from the pressure matrix now in level 0's image, synchronously; a set-up that fails half way gives back
 // everything it allocated: a retry starts from a clean slate, nothing piles up
@@ -1266,12 +1549,15 @@ static int cpr_setup_coarse_now(opmhip_ctx* c) {
     int rc;
     if ((rc = cpr_download_level0(c, ell))) return rc;
     CprHostCoarse H;
-    cpr_build_coarse_host(c->pat, ell, R.beta, cpr_lpr_rows(), c->cfg.cpr_amg_ilu_levels, H);
+    cpr_build_coarse_host(c->pat, ell, R.beta, cpr_lpr_rows(), cpr_gathering(c) ? 0 : c->cfg.cpr_amg_ilu_levels, cpr_stop_rows(c), H);
     const double t1 = now();
     const size_t mark = c->allocs.size();
-    rc = cpr_upload_coarse(c, H);
+    const bool gathered = cpr_gathering(c);
+    rc = cpr_upload_coarse(c, R, H, gathered);
+    if (!rc && gathered) rc = cpr_gather_setup(c, H);
     if (rc) {
         (void)hipStreamSynchronize(c->stream);
+        R.gather = CprGatherDev();
         while (c->allocs.size() > mark) { (void)hipFree(c->allocs.back()); c->allocs.pop_back(); }
         for (size_t l = 0; l < R.lv.size(); ++l) {
             CprLevelDev& L = R.lv[l];
@@ -1285,57 +1571,11 @@ static int cpr_setup_coarse_now(opmhip_ctx* c) {
     if (timing) std::fprintf(stderr, "opmhip cpr set-up: %.3f s (matching %.3f, Galerkin %.3f, level images %.3f, uploads %.3f), %zu levels\n", now() - t0, H.tAgg, H.tGal, H.tImg, now() - t1, R.lv.size());
     return OPMHIP_SUCCESS;
 }
+static int cpr_gather_values(opmhip_ctx* c);
+// the values of a hierarchy below its level 0 (whose image holds the matrix already): 1 / diagonal, the ILU0 factors of the levels that
+// smooth with them, Galerkin values level by level, the dense LU of the coarsest level
 static bool cpr_ilu_active(const CprDev& R, size_t l);
-void cpr_shutdown(opmhip_ctx* c) { c->cpr.job.reset(); }
-int cpr_update(opmhip_ctx* c, bool solveBoundary) {
-    const Pattern& P = c->pat;
-    CprDev& R = c->cpr;
-    int rc;
-    bool startAsync = false;
-    if (R.structured && (solveBoundary || R.recreate)) {   // --cpr-reuse-setup (ISTLSolverEbos.hpp:401-426 shouldCreateSolver): build the structure anew from this matrix?
-        const int mode = c->cfg.cpr_reuse_setup;
-        bool anew = R.recreate || mode == 0 || (mode == 1 && c->asmb.assembled && c->asmb.last_iteration == 0) || (mode == 2 && c->last_solve_iterations > 10);
-        if (mode == 2 && c->cfg.cpr_async_setup && !R.recreate) {
-            // the rebuild beside the solves: a build that has finished is swapped in at this solve boundary; a new one is started
-            // when the rule asks for it and none is under way; this solve goes on with the structure it has
-            if (R.job && R.job->ready.load(std::memory_order_acquire)) {
-                R.job->th.join();
-                cpr_release_coarse(c);
-                const size_t mark = c->allocs.size();
-                rc = cpr_upload_coarse(c, R.job->result);
-                R.job.reset();
-                if (rc) {   // (cannot happen for a pattern that was set up once; if it does: back to a synchronous set-up below)
-                    (void)hipStreamSynchronize(c->stream);
-                    while (c->allocs.size() > mark) { (void)hipFree(c->allocs.back()); c->allocs.pop_back(); }
-                    for (CprLevelDev& L : R.lv) L.d_agg = L.d_mptr = L.d_midx = L.d_mem4 = L.d_gptr = L.d_gidx = L.d_cpos = nullptr;
-                    R.lv.resize(1); R.d_lu = nullptr; R.structured = false;
-                }
-            } else if (anew && !R.job) startAsync = true;
-            anew = false;
-        }
-        if (anew) { R.job.reset(); cpr_release_coarse(c); }
-    }
-    R.recreate = false;
-    if (!R.level0 && (rc = cpr_setup_level0(c))) return rc;
-    const int ps = prof_begin(c, PROF_ILU_FACTOR);
-    if ((rc = cpr_weights(c))) { prof_end(c, ps); return rc; }
-    hipLaunchKernelGGL(k_cpr_pvals, g256(P.Nb), dim3(256), 0, c->stream, P.Nb, R.lv[0].W, P.d_rowptr, P.Nghost > 0 ? P.d_col : (const int*)nullptr, c->d_A, R.d_w, R.lv[0].d_val, R.d_pcol);
-    if (!R.structured) {   // first solve, or a synchronous rebuild: from the pressure matrix just formed
-        if ((rc = cpr_setup_coarse_now(c))) { prof_end(c, ps); return rc; }
-    } else if (startAsync) {
-        R.job = std::make_shared<CprAsyncJob>();
-        std::shared_ptr<CprAsyncJob> job = R.job;
-        auto ell = std::make_shared<std::vector<double>>();
-        if ((rc = cpr_download_level0(c, *ell))) { R.job.reset(); prof_end(c, ps); return rc; }
-        const Pattern* pat = &c->pat;   // outlives the job: cpr_release_structure / cpr_shutdown join it before the pattern goes
-        const double beta = R.beta;
-        const int lpr = cpr_lpr_rows(), iluLevels = c->cfg.cpr_amg_ilu_levels;
-        CprAsyncJob* raw = job.get();
-        job->th = std::thread([raw, ell, pat, beta, lpr, iluLevels]() {
-            cpr_build_coarse_host(*pat, *ell, beta, lpr, iluLevels, raw->result);
-            raw->ready.store(1, std::memory_order_release);
-        });
-    }
+static int cpr_update_values(opmhip_ctx* c, CprDev& R) {
     for (size_t l = 0; l < R.lv.size(); ++l) {
         CprLevelDev& L = R.lv[l];
         hipLaunchKernelGGL(k_cpr_dinv, g256(L.n), dim3(256), 0, c->stream, L.n, L.d_diag, L.d_val, L.d_dinv);
@@ -1358,6 +1598,60 @@ int cpr_update(opmhip_ctx* c, bool solveBoundary) {
         const CprLevelDev& C = R.lv.back();
         hipLaunchKernelGGL(k_cpr_dense_lu, dim3(1), dim3(256), 0, c->stream, C.n, C.W, C.rm ? 1 : 0, C.d_ecol, C.d_rlen, C.d_val, R.d_lu);
     }
+    return OPMHIP_SUCCESS;
+}
+void cpr_shutdown(opmhip_ctx* c) { c->cpr.job.reset(); }
+int cpr_update(opmhip_ctx* c, bool solveBoundary) {
+    const Pattern& P = c->pat;
+    CprDev& R = c->cpr;
+    int rc;
+    bool startAsync = false;
+    if (R.structured && (solveBoundary || R.recreate)) {   // --cpr-reuse-setup (ISTLSolverEbos.hpp:401-426 shouldCreateSolver): build the structure anew from this matrix?
+        const int mode = c->cfg.cpr_reuse_setup;
+        bool anew = R.recreate || mode == 0 || (mode == 1 && c->asmb.assembled && c->asmb.last_iteration == 0) || (mode == 2 && c->last_solve_iterations > 10);
+        if (mode == 2 && c->cfg.cpr_async_setup && !R.recreate && !cpr_gathering(c)) {
+            // the rebuild beside the solves: a build that has finished is swapped in at this solve boundary; a new one is started
+            // when the rule asks for it and none is under way; this solve goes on with the structure it has
+            if (R.job && R.job->ready.load(std::memory_order_acquire)) {
+                R.job->th.join();
+                cpr_release_coarse(c, R);
+                const size_t mark = c->allocs.size();
+                rc = cpr_upload_coarse(c, R, R.job->result, false);
+                R.job.reset();
+                if (rc) {   // (cannot happen for a pattern that was set up once; if it does: back to a synchronous set-up below)
+                    (void)hipStreamSynchronize(c->stream);
+                    while (c->allocs.size() > mark) { (void)hipFree(c->allocs.back()); c->allocs.pop_back(); }
+                    for (CprLevelDev& L : R.lv) L.d_agg = L.d_mptr = L.d_midx = L.d_mem4 = L.d_gptr = L.d_gidx = L.d_cpos = nullptr;
+                    R.lv.resize(1); R.d_lu = nullptr; R.structured = false;
+                }
+            } else if (anew && !R.job) startAsync = true;
+            anew = false;
+        }
+        if (anew) { R.job.reset(); cpr_release_coarse(c, R); }
+    }
+    R.recreate = false;
+    if (!R.level0 && (rc = cpr_setup_level0(c))) return rc;
+    const int ps = prof_begin(c, PROF_ILU_FACTOR);
+    if ((rc = cpr_weights(c))) { prof_end(c, ps); return rc; }
+    hipLaunchKernelGGL(k_cpr_pvals, g256(P.Nb), dim3(256), 0, c->stream, P.Nb, R.lv[0].W, P.d_rowptr, (P.Nghost > 0 && !cpr_gathering(c)) ? P.d_col : (const int*)nullptr, c->d_A, R.d_w, R.lv[0].d_val, R.d_pcol);
+    if (!R.structured) {   // first solve, or a synchronous rebuild: from the pressure matrix just formed
+        if ((rc = cpr_setup_coarse_now(c))) { prof_end(c, ps); return rc; }
+    } else if (startAsync) {
+        R.job = std::make_shared<CprAsyncJob>();
+        std::shared_ptr<CprAsyncJob> job = R.job;
+        auto ell = std::make_shared<std::vector<double>>();
+        if ((rc = cpr_download_level0(c, *ell))) { R.job.reset(); prof_end(c, ps); return rc; }
+        const Pattern* pat = &c->pat;   // outlives the job: cpr_release_structure / cpr_shutdown join it before the pattern goes
+        const double beta = R.beta;
+        const int lpr = cpr_lpr_rows(), iluLevels = c->cfg.cpr_amg_ilu_levels;
+        CprAsyncJob* raw = job.get();
+        job->th = std::thread([raw, ell, pat, beta, lpr, iluLevels]() {
+            cpr_build_coarse_host(*pat, *ell, beta, lpr, iluLevels, CPR_COARSE_DIRECT, raw->result);
+            raw->ready.store(1, std::memory_order_release);
+        });
+    }
+    if ((rc = cpr_update_values(c, R))) { prof_end(c, ps); return rc; }
+    if (R.gather.on && (rc = cpr_gather_values(c))) { prof_end(c, ps); return rc; }
     prof_end(c, ps);
     OPMHIP_HIP(c, hipGetLastError());
     return OPMHIP_SUCCESS;
@@ -1399,19 +1693,20 @@ static void cpr_ilu_smooth(opmhip_ctx* c, const CprLevelDev& L, const double* d,
 static bool cpr_forms_rhs(const CprDev& R, size_t l) {
     static const bool off = std::getenv("OPMHIP_CPR_UNFUSED") != nullptr;   // A/B switch: the restriction as a launch of its own
     if (off || l == 0 || l >= R.lv.size() || !R.lv[l - 1].d_mem4) return false;
+    if (R.gather.on && l + 1 == R.lv.size()) return false;   // the level that is gathered: its right-hand side is what travels
     return R.lv[l].rm || (l + 1 == R.lv.size() && R.coarse_direct);
 }
 // does level l take its pre-smoothed iterate x = omega D^-1 b from the kernel that produces b (the restriction above it)?
 static bool cpr_presmooth_rides(const CprDev& R, size_t l) {
     const CprLevelDev& L = R.lv[l];
     if (cpr_forms_rhs(R, l) || cpr_ilu_active(R, l)) return false;
+    if (R.gather.on && l + 1 == R.lv.size()) return false;
     if (l + 1 == R.lv.size()) return !R.coarse_direct;   // Jacobi coarse "solve": starts with the same statement
     return !L.rm;                                         // lane-group levels form it on the fly inside k_cpr_down_lpr
 }
 // one V(1,1) cycle on level l from x = 0; returns the buffer that holds the level's result (fineOut != NULL on level 0: the
 // result is written there as the block vector (0, x_p, 0) instead, and NULL comes back)
-static const double* cpr_vcycle(opmhip_ctx* c, size_t l, double* fineOut = nullptr) {
-    CprDev& R = c->cpr;
+static const double* cpr_vcycle(opmhip_ctx* c, CprDev& R, size_t l, double* fineOut = nullptr) {
     CprLevelDev& L = R.lv[l];
     const double* done = c->d_done;
     const bool fused = cpr_forms_rhs(R, l);           // b = restriction of the finer level's residual, formed by this level's first kernel
@@ -1457,7 +1752,7 @@ static const double* cpr_vcycle(opmhip_ctx* c, size_t l, double* fineOut = nullp
         hipLaunchKernelGGL(k_cpr_restrict, g256(L.nc), dim3(256), 0, c->stream, L.nc, L.d_mptr, L.d_midx, L.d_r, C.d_b, R.omega,
                            ride ? C.d_dinv : (const double*)nullptr, ride ? C.d_x : (double*)nullptr, done);
     }
-    const double* xc = cpr_vcycle(c, l + 1);
+    const double* xc = cpr_vcycle(c, R, l + 1);
     if (ilu) {   // x' = x + damp P xc; r = b - A x'; x = x' + ILU0(r)
         hipLaunchKernelGGL(k_cpr_prolong, g256(L.n), dim3(256), 0, c->stream, L.n, R.damp, L.d_agg, xc, L.d_x, L.d_r, done);
         if (S0.word) hipLaunchKernelGGL(k_cpr_resid<true>, g256(L.n), dim3(256), 0, c->stream, L.n, L.W, L.d_ecol, L.d_val, L.d_b, L.d_r, L.d_x, done, S0);
@@ -1478,6 +1773,46 @@ static const double* cpr_vcycle(opmhip_ctx* c, size_t l, double* fineOut = nullp
     return L.d_x2;
 }
 
+// The pressure stage of a rank whose CPR spans the ranks (cpr_gather_setup): level 0 smooths with the operator of the WHOLE system
+// (its couplings to ghost cells are in its image; the iterates' ghost entries come from their owners), its residual is summed over
+// the aggregates level by level down to the joined level, one V-cycle there on every rank, the result back per aggregate.  Returns
+// x_p, ghost entries up to date (the post-smoothing residual d - A (0, x_p, 0) is the whole system's as well).  Three exchanges of one
+// double per boundary cell and one all-gather of the joined level's right-hand side.  oracle: orc_cpr_solve_blocks, gather_rows >= 0.
+static const double* cpr_gathered_cycle(opmhip_ctx* c, const double* d) {
+    const Pattern& P = c->pat;
+    CprDev& R = c->cpr;
+    CprGatherDev& G = R.gather;
+    CprDev& J = *G.glob;
+    CprLevelDev& L = R.lv[0];
+    const double* done = c->d_done;
+    auto keep = [&](int rc) { if (rc && !R.apply_rc) R.apply_rc = rc; };
+    hipLaunchKernelGGL(k_cpr_restrict_fine, g256(P.Nb), dim3(256), 0, c->stream, P.Nb, d, R.d_w, L.d_b, R.omega, L.d_dinv, L.d_x, done);   // b = r_p, x = omega D^-1 b
+    keep(comm_halo_f64(c, L.d_x, 1));
+    const EllStencil S{nullptr, nullptr};
+    hipLaunchKernelGGL(k_cpr_resid<false>, g256(L.n), dim3(256), 0, c->stream, L.n, L.W, L.d_ecol, L.d_val, L.d_b, L.d_x, L.d_r, done, S);
+    const size_t g = R.lv.size() - 1;
+    const double* rl = L.d_r;
+    for (size_t l = 0; l < g; ++l) {   // sums over the aggregates, level by level (no smoothing in between)
+        CprLevelDev& F = R.lv[l];
+        double* to = l + 1 == g ? G.d_send : R.lv[l + 1].d_b;
+        hipLaunchKernelGGL(k_cpr_restrict, g256(F.nc), dim3(256), 0, c->stream, F.nc, F.d_mptr, F.d_midx, rl, to, R.omega, (const double*)nullptr, (double*)nullptr, done);
+        rl = to;
+    }
+    if (g == 0) keep(hipMemcpyAsync(G.d_send, L.d_r, (size_t)L.n * sizeof(double), hipMemcpyDeviceToDevice, c->stream) == hipSuccess ? 0 : OPMHIP_DEVICE_ERROR);
+    keep(comm_allgather(c, G.d_send, G.d_recv, (size_t)G.maxn));
+    {
+        const bool ride = cpr_presmooth_rides(J, 0);
+        hipLaunchKernelGGL(k_cpr_unpad, g256(G.NG), dim3(256), 0, c->stream, G.NG, G.d_unpad, G.d_recv, J.lv[0].d_b, J.omega,
+                           ride ? J.lv[0].d_dinv : (const double*)nullptr, ride ? J.lv[0].d_x : (double*)nullptr, done);
+    }
+    const double* xG = cpr_vcycle(c, J, 0);
+    hipLaunchKernelGGL(k_cpr_prolong, g256(L.n), dim3(256), 0, c->stream, L.n, 1.0, G.d_cagg, xG + G.off, L.d_x, L.d_r, done);   // x' = x + (the joined level's result, per aggregate)
+    keep(comm_halo_f64(c, L.d_r, 1));
+    hipLaunchKernelGGL(k_cpr_post<false>, g256(L.n), dim3(256), 0, c->stream, L.n, L.W, R.omega, L.d_ecol, L.d_val, L.d_dinv, L.d_b, L.d_r, L.d_x2, (double*)nullptr, done, S);
+    keep(comm_halo_f64(c, L.d_x2, 1));
+    return L.d_x2;
+}
+
 // v = M_cpr^-1 d (TwoLevelMethodCpr::apply)
 void launch_cpr_apply(opmhip_ctx* c, const double* d, double* v) {
     const Pattern& P = c->pat;
@@ -1485,6 +1820,16 @@ void launch_cpr_apply(opmhip_ctx* c, const double* d, double* v) {
     const int n = P.Nb * BS;
     const double* done = c->d_done;
     int ps = prof_begin(c, PROF_CPR_AMG);
+    if (R.gather.on) {
+        const double* xp = cpr_gathered_cycle(c, d);
+        prof_end(c, ps);
+        ps = prof_begin(c, PROF_VECTOR);
+        const EllStencil S{nullptr, nullptr};
+        hipLaunchKernelGGL(k_cpr_presid<false>, g256(P.Nb), dim3(256), 0, c->stream, P.Nb, R.lv[0].W, R.lv[0].d_ecol, R.d_pcol, d, xp, R.d_r, done, S);
+        prof_end(c, ps);
+        launch_ilu_apply(c, R.d_r, v, 1.0, nullptr, xp, R.d_z);
+        return;
+    }
     {
         const bool ride = cpr_presmooth_rides(R, 0);
         hipLaunchKernelGGL(k_cpr_restrict_fine, g256(P.Nb), dim3(256), 0, c->stream, P.Nb, d, R.d_w, R.lv[0].d_b, R.omega,
@@ -1496,7 +1841,7 @@ void launch_cpr_apply(opmhip_ctx* c, const double* d, double* v) {
     static const bool separate = std::getenv("OPMHIP_CPR_SEPARATE_ADD") != nullptr;   // A/B switch: the three steps as kernels of their own
     if (separate) {
         const bool direct = R.lv.size() > 1 && !R.lv[0].rm;   // level 0's post-smoother writes v = (0, x_p, 0) itself
-        const double* xp = cpr_vcycle(c, 0, direct ? v : nullptr);
+        const double* xp = cpr_vcycle(c, R, 0, direct ? v : nullptr);
         if (xp) hipLaunchKernelGGL(k_cpr_prolong_fine, g256(n), dim3(256), 0, c->stream, P.Nb, xp, v, done);
         else xp = R.lv[0].d_x2;   // k_cpr_post left the pressure solution there as well
         prof_end(c, ps);
@@ -1513,7 +1858,7 @@ void launch_cpr_apply(opmhip_ctx* c, const double* d, double* v) {
         prof_end(c, ps);
         return;
     }
-    const double* xp = cpr_vcycle(c, 0);
+    const double* xp = cpr_vcycle(c, R, 0);
     prof_end(c, ps);
     // post-smoothing on the updated residual r = d - A (0, x_p, 0)
     ps = prof_begin(c, PROF_VECTOR);
@@ -1543,7 +1888,7 @@ int cpr_set_weights(opmhip_ctx* c, const double* w) {
 }
 // did the dense LU of the coarsest level meet a vanishing / non-finite pivot in the last cpr_update?  (synchronises)
 bool cpr_coarse_pivot_failed(opmhip_ctx* c) {
-    const CprDev& R = c->cpr;
+    const CprDev& R = c->cpr.gather.on ? *c->cpr.gather.glob : c->cpr;   // decomposed run with a joined level: that hierarchy's coarsest level
     if (!R.structured || !R.coarse_direct || !R.d_lu) return false;
     double flag = 0.0;
     const size_t n = (size_t)R.lv.back().n;
@@ -1551,8 +1896,11 @@ bool cpr_coarse_pivot_failed(opmhip_ctx* c) {
     return flag != 0.0;
 }
 int cpr_level_sizes(const opmhip_ctx* c, int* n, int* nnz, int cap) {
-    const int L = (int)c->cpr.lv.size();
-    for (int l = 0; l < L && l < cap; ++l) { n[l] = c->cpr.lv[l].n; nnz[l] = c->cpr.lv[l].nnz; }
+    // the rank's own levels, then - decomposed runs with a joined level - the levels of the hierarchy all ranks share
+    int L = 0;
+    for (const CprLevelDev& lv : c->cpr.lv) { if (L < cap) { n[L] = lv.n; nnz[L] = lv.nnz; } ++L; }
+    if (c->cpr.gather.on)
+        for (const CprLevelDev& lv : c->cpr.gather.glob->lv) { if (L < cap) { n[L] = lv.n; nnz[L] = lv.nnz; } ++L; }
     return L;
 }
 

@@ -195,6 +195,7 @@ struct CommDev {
     hipStream_t hstream = nullptr;
     hipEvent_t ev_x = nullptr, ev_h = nullptr;
     double* halo_vec = nullptr;                  // loopback: the vector whose exchange comm_halo_end still has to drive
+    const double* ag_send = nullptr;             // loopback: this rank's contribution to the all-gather under way
 };
 
 // CPR preconditioner (cpr.hip): pressure-AMG hierarchy, level 0 = the block pattern with scalar values
@@ -229,6 +230,24 @@ struct CprLevelDev {
     std::vector<char> iluFast;                                     // per colour: same-colour couplings are the sequence's neighbours only (register forwarding)
 };
 struct CprAsyncJob;   // cpr.hip: a structure being built on a host thread (--cpr-reuse-setup=2 with cpr_async_setup)
+struct CprDev;
+// Decomposed runs (opmhip_config.cpr_gather_rows): the LAST level of a rank's own hierarchy is not solved by the rank - its right-hand
+// sides are gathered over the ranks, every rank runs the rest of the cycle on the joined system (`glob`: a hierarchy of its own whose
+// level 0 is the joined level, the couplings between the subdomains included) and takes its slice of the result (cpr.hip: cpr_gather_*)
+struct CprGatherDev {
+    bool on = false;
+    int nloc = 0, off = 0, NG = 0, maxn = 0;                       // my rows of the joined level, where they start, its size, the largest slice
+    int nnzloc = 0, maxnnz = 0, nnzG = 0;                          // the same for its entries
+    double *d_recv = nullptr, *d_vsend = nullptr, *d_vrecv = nullptr;   // gathered right-hand sides [nranks x maxn]; my entries' values, everybody's [nranks x maxnnz]
+    int* d_cagg = nullptr;                                         // aggregate (on my last level) of every owned cell
+    double* d_send = nullptr;                                      // my slice of the joined level's right-hand side [maxn]
+    int *d_unpad = nullptr, *d_vunpad = nullptr, *d_vpos = nullptr;    // joined row -> place in d_recv; joined entry -> place in d_vrecv and in level 0's image of `glob`
+    int *d_src = nullptr, *d_xptr = nullptr, *d_xidx = nullptr;    // my entries: place in my last level's image, or (-1 - q) the q-th coupling between subdomains = sum over d_apg[d_xidx[d_xptr[q] ..)]
+    int nq = 0;                                                    // fine couplings to ghost cells
+    int *d_qrow = nullptr, *d_qentry = nullptr;                    // their row and block-matrix entry
+    double* d_apg = nullptr;                                       // their pressure values (k_cpr_ghost_pvals)
+    std::shared_ptr<CprDev> glob;
+};
 struct CprDev {
     bool structured = false, coarse_direct = true;
     bool level0 = false;                                           // level 0's image (it belongs to the pattern) is on the device
@@ -240,6 +259,8 @@ struct CprDev {
     bool w_given = false;                                          // d_w holds weights handed in (opmhip_set_cpr_weights): not recomputed
     double *d_r = nullptr, *d_y = nullptr, *d_z = nullptr;         // fine-level block vectors
     double omega = 2.0 / 3.0, damp = 1.6, beta = 0.25;             // Jacobi damping, prolongation damping, strength threshold
+    CprGatherDev gather;
+    int apply_rc = 0;                                              // first failure of a collective inside an application (the BiCGStab driver looks at it)
 };
 
 // per-kernel-class device timing with HIP events on the context's stream (opmhip_profile_*)
@@ -459,6 +480,7 @@ void launch_lu_to_natural(opmhip_ctx* c, double* d_out_internal_layout);
 int bicgstab(opmhip_ctx* c, opmhip_result* res);
 // comm.hip
 int comm_allreduce(opmhip_ctx* c, double* d_buf, int n, int op /*0 sum, 1 max*/);
+int comm_allgather(opmhip_ctx* c, const double* d_send, double* d_recv, size_t count);   // count doubles per rank -> nranks * count on every rank
 int comm_halo_f64(opmhip_ctx* c, double* vec, int w, hipStream_t s = nullptr);   // s: the stream it runs on (default: the context's)
 int comm_halo_begin(opmhip_ctx* c, double* vec);   // 3 doubles per cell: the exchange on the halo stream, ordered behind the main stream's work so far
 int comm_halo_end(opmhip_ctx* c);                  // the main stream waits for it

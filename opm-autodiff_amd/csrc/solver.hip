@@ -2139,6 +2139,7 @@ static int enqueue_half(opmhip_ctx* c, int h, int part = HALF_ALL) {
             }
             if (cpr) launch_cpr_apply(c, c->d_p, c->d_pw);
             else launch_ilu_apply(c, c->d_p, c->d_pw, -1.0, &c->minv_scale);   // d_pw without the relaxation factor: its readers apply it
+            if (cpr && c->cpr.apply_rc) { rc = c->cpr.apply_rc; c->cpr.apply_rc = 0; return rc; }   // a collective of the joined coarse level failed
         }
         if (part == HALF_PRECOND) return OPMHIP_SUCCESS;
         if ((rc = launch_spmv(c, c->d_pw, c->d_v, 1, c->d_rw, c->minv_scale, true))) return rc;  // with copyOwnerToAll before the operator (ParallelOverlappingILU0.hpp:897)
@@ -2151,6 +2152,7 @@ static int enqueue_half(opmhip_ctx* c, int h, int part = HALF_ALL) {
         if (part != HALF_REST) {
             if (cpr) launch_cpr_apply(c, c->d_r, c->d_s);
             else launch_ilu_apply(c, c->d_r, c->d_s, -1.0, &c->minv_scale);
+            if (cpr && c->cpr.apply_rc) { rc = c->cpr.apply_rc; c->cpr.apply_rc = 0; return rc; }
         }
         if (part == HALF_PRECOND) return OPMHIP_SUCCESS;
         if ((rc = launch_spmv(c, c->d_s, c->d_t, 2, c->d_r, c->minv_scale, true))) return rc;

@@ -75,6 +75,11 @@ struct CprAmg {
     // of the level's graph, colour by colour (what a device sweep of an irregular coarse level would need)
     int iluLevels = 0;
     int iluColourFrom = 1 << 30;   // levels >= iluColourFrom eliminate in greedy multi-colour order
+    // decomposed runs (orc_cpr_solve_blocks with gather_rows): the hierarchy of a subdomain ends at its first level of at most stopRows
+    // rows, and that level is not solved here (external): its right-hand side joins those of the other subdomains (vcycle_down), the
+    // joined system is cycled on, and the subdomain's slice of the result comes back (vcycle_up)
+    int stopRows = CPR_COARSE_DIRECT;
+    bool external = false;
 
     // one pass of pairwise matching, nodes visited in index order: node i takes its strongest (most negative coupling)
     // still-free neighbour, lowest index on ties
@@ -160,7 +165,7 @@ struct CprAmg {
             AmgLevel L;
             L.A = A;
             finish_level(L);
-            const bool last = A.n <= CPR_COARSE_DIRECT || (int)lv.size() + 1 >= maxLevels;
+            const bool last = A.n <= stopRows || (int)lv.size() + 1 >= maxLevels;
             if (!last) {
                 std::vector<int> a1, a2, g1p, g1i;
                 int n1 = 0, n2 = 0;
@@ -211,7 +216,7 @@ struct CprAmg {
             lv.push_back(L);
             break;
         }
-        coarse_direct = lv.back().A.n <= CPR_COARSE_DIRECT;
+        coarse_direct = !external && lv.back().A.n <= CPR_COARSE_DIRECT;
         update_values(A0.val);
     }
     // new level-0 values (same pattern): Galerkin values down the hierarchy, inverse diagonals, coarsest LU
@@ -329,6 +334,43 @@ struct CprAmg {
             for (int k = A.rowptr[i]; k < A.rowptr[i + 1]; ++k) s -= A.val[k] * x[A.col[k]];
             r[i] = s;
         }
+    }
+    // The cycle in two halves around a coarsest level that somebody else solves (external): down - smoothing, residuals and
+    // restrictions of the levels above it, the coarsest level's right-hand side comes back in st.back().b; up - with the coarsest
+    // level's solution in st.back().x the way back, x = the finest level's result.  Statement for statement vcycle's (V(1,1), no W-cycle).
+    struct LevelState { std::vector<double> b, x, r; };
+    void vcycle_down(const double* b0, std::vector<LevelState>& st, size_t last) const {   // last: the level somebody else solves
+        st.assign(last + 1, LevelState());
+        st[0].b.assign(b0, b0 + lv[0].A.n);
+        for (size_t l = 0; l < last; ++l) {
+            const AmgLevel& L = lv[l];
+            const int n = L.A.n;
+            LevelState& S = st[l];
+            S.x.assign(n, 0.0); S.r.assign(n, 0.0);
+            if (L.ilu.empty()) for (int i = 0; i < n; ++i) S.x[i] = omega * L.dinv[i] * S.b[i];
+            else smooth(L, S.b.data(), S.x.data());
+            residual(L.A, S.b.data(), S.x.data(), S.r.data());
+            st[l + 1].b.assign(L.nc, 0.0);
+            for (int I = 0; I < L.nc; ++I) {
+                double s = 0.0;
+                for (int q = L.mptr[I]; q < L.mptr[I + 1]; ++q) s += S.r[L.midx[q]];
+                st[l + 1].b[I] = s;
+            }
+        }
+        st.back().x.assign(lv[last].A.n, 0.0);
+    }
+    void vcycle_up(std::vector<LevelState>& st, double* x0) const {
+        for (size_t l = st.size() - 1; l-- > 0;) {
+            const AmgLevel& L = lv[l];
+            const int n = L.A.n;
+            LevelState& S = st[l];
+            const std::vector<double>& xc = st[l + 1].x;
+            for (int i = 0; i < n; ++i) S.x[i] += damp * xc[L.agg[i]];
+            residual(L.A, S.b.data(), S.x.data(), S.r.data());
+            if (L.ilu.empty()) for (int i = 0; i < n; ++i) S.x[i] += omega * L.dinv[i] * S.r[i];
+            else { std::vector<double> t(n); smooth(L, S.r.data(), t.data()); for (int i = 0; i < n; ++i) S.x[i] += t[i]; }
+        }
+        std::copy(st[0].x.begin(), st[0].x.end(), x0);
     }
     // one V(1,1) cycle from x = 0
     void vcycle(const double* b, double* x, size_t l = 0) const {
@@ -804,18 +846,28 @@ struct Cpr {
         else amg.update_values(ap);
         return 0;
     }
-    // v = M^-1 d (TwoLevelMethodCpr::apply with 0 pre- and 1 post-smoothing step)
-    void apply(const double* d, double* v) const {
-        const int Nb = A->Nb;
-        const size_t n = (size_t)Nb * BS;
-        std::vector<double> rc(Nb), xc(Nb), r(n), y(n), z(n);
-        for (int i = 0; i < Nb; ++i) {                               // moveToCoarseLevel
+    // moveToCoarseLevel: r_p[i] = sum_k d_i[k] w_i[k]
+    void restrict_fine(const double* d, double* rc) const {
+        for (int i = 0; i < A->Nb; ++i) {
             double s = 0.0;
             for (int k = 0; k < BS; ++k) s += d[(size_t)i * BS + k] * w[(size_t)i * BS + k];
             rc[i] = s;
         }
+    }
+    // v = M^-1 d (TwoLevelMethodCpr::apply with 0 pre- and 1 post-smoothing step)
+    void apply(const double* d, double* v) const {
+        const int Nb = A->Nb;
+        std::vector<double> rc(Nb), xc(Nb);
+        restrict_fine(d, rc.data());
         if (useDune) { std::fill(xc.begin(), xc.end(), 0.0); dune.vcycle(rc.data(), xc.data()); }
         else amg.vcycle(rc.data(), xc.data());
+        finish(d, xc.data(), v);
+    }
+    // the rest of apply once the pressure correction xc is there: v = (0, xc, 0) + ILU0(d - A (0, xc, 0))
+    void finish(const double* d, const double* xc, double* v) const {
+        const int Nb = A->Nb;
+        const size_t n = (size_t)Nb * BS;
+        std::vector<double> r(n), y(n), z(n);
         for (size_t e = 0; e < n; ++e) v[e] = 0.0;                    // moveToFineLevel: pressure component only
         for (int i = 0; i < Nb; ++i) v[(size_t)i * BS + CPR_PRESSURE_INDEX] = xc[i];
         spmv(*A, v, y.data());                                       // post-smoothing on the updated residual

@@ -310,10 +310,24 @@ int orc_cpr_solve(orc_cpr* h, int Nb, const int* rowptr, const int* col, const d
 // per subdomain, else Nb x 3 (true-IMPES from the model).  levels (may be NULL): number of AMG levels of every subdomain.
 // nat (may be NULL): the system is handed over in another ordering than the natural one (the product's ILU0 ordering inside every
 // subdomain); nat[i] = natural id of row i - the finest level is then aggregated in natural visiting order, as the product does.
+// gather_rows >= 0 (0: 4096): a pressure stage that spans the subdomains (the product: csrc/cpr.hip, cpr_gather_*; the reference: Dune's
+// parallel AMG behind linalg/OwningTwoLevelPreconditioner.hpp).  Every subdomain coarsens on its own (aggregates never cross a
+// boundary) down to its first level of at most that many rows; those levels are joined into ONE system - their own entries plus,
+// between aggregates of different subdomains, the Galerkin sums of the fine couplings - which is coarsened further and cycled on as a
+// whole.  One application:  x = omega D^-1 r_p;  r = r_p - A_p x with the pressure matrix of the WHOLE system;  r summed over the
+// aggregates level by level down to the joined level;  one V-cycle there;  x' = x + (the result, per aggregate);  x'' = x' + omega
+// D^-1 (r_p - A_p x');  v = (0, x'', 0) + ILU0_subdomain(d - A (0, x'', 0)), again with the whole system's operator.  The levels between
+// level 0 and the joined one carry no smoothing (measured: it is level 0's and the block ILU0's that count, tools/cpr_gather_study.py).
+// Row sums run over the subdomain's own columns first (ascending), then over the others by (owner, natural id) - the order of a rank's
+// local numbering, ghost cells last (ras.py).  < 0: off.
+// glevels (may be NULL, room for 32): rows of the joined hierarchy's levels, their number in *nglevels.  probe_d / probe_v (may be NULL):
+// one application of the preconditioner to probe_d, for the device's parity check.
 int orc_cpr_solve_blocks(int Nb, const int* rowptr, const int* col, const double* val, const double* b, double* x, const int* owner, int nown,
-                         const double* weights, const int* nat, double tol, int maxit, int zero_diag_fix, int* levels, orc_result* out) {
+                         const double* weights, const int* nat, double tol, int maxit, int zero_diag_fix, int* levels, orc_result* out,
+                         int gather_rows, int* glevels, int* nglevels, const double* probe_d, double* probe_v) {
     Bcrs A = wrap(Nb, rowptr, col, val);
     if (zero_diag_fix) check_zero_diagonal(A);
+    const bool gather = gather_rows >= 0;
     std::vector<std::vector<int>> rows(nown);
     std::vector<int> local(Nb);
     for (int i = 0; i < Nb; ++i) { local[i] = (int)rows[owner[i]].size(); rows[owner[i]].push_back(i); }
@@ -344,22 +358,149 @@ int orc_cpr_solve_blocks(int Nb, const int* rowptr, const int* col, const double
             for (int q = 0; q < S.Nb; ++q)
                 for (int k = 0; k < BS; ++k) prec[s].w_given[(size_t)q * BS + k] = weights[(size_t)rows[s][q] * BS + k];
         }
+        if (gather) { prec[s].amg.stopRows = gather_rows > 0 ? gather_rows : 4096; prec[s].amg.external = true; }
         const int rc = prec[s].update(S);
         if (rc) return rc;
         if (levels) levels[s] = (int)prec[s].amg.lv.size();
     }
+    CprAmg G;
+    std::vector<int> offs(nown + 1, 0), gcid(Nb, 0), korder, pdiag(Nb, -1);
+    std::vector<double> ap, pdinv(Nb, 0.0);
+    if (gather) {
+        for (int s = 0; s < nown; ++s) offs[s + 1] = offs[s] + prec[s].amg.lv.back().A.n;
+        for (int s = 0; s < nown; ++s) {   // row of the joined level every cell belongs to
+            const CprAmg& M = prec[s].amg;
+            for (int q = 0; q < sub[s].Nb; ++q) {
+                int a = q;
+                for (size_t l = 0; l + 1 < M.lv.size(); ++l) a = M.lv[l].agg[a];
+                gcid[rows[s][q]] = offs[s] + a;
+            }
+        }
+        // the pressure matrix of the whole system, every row with its subdomain's weights; korder: a row's entries in the order a rank
+        // walks them (own columns, then the others by owner and natural id)
+        ap.resize(A.col.size());
+        korder.resize(A.col.size());
+        for (int i = 0; i < Nb; ++i) {
+            const int s = owner[i];
+            const double* w = &prec[s].w[(size_t)local[i] * BS];
+            std::vector<int> own, other;
+            for (int k = A.rowptr[i]; k < A.rowptr[i + 1]; ++k) {
+                double v = 0.0;
+                for (int r = 0; r < BS; ++r) v += A.val[(size_t)k * BB + r * BS + CPR_PRESSURE_INDEX] * w[r];
+                ap[k] = v;
+                (owner[A.col[k]] == s ? own : other).push_back(k);
+                if (A.col[k] == i) pdiag[i] = k;
+            }
+            std::sort(other.begin(), other.end(), [&](int ka, int kb) {
+                const int ja = A.col[ka], jb = A.col[kb];
+                if (owner[ja] != owner[jb]) return owner[ja] < owner[jb];
+                return (nat ? nat[ja] : ja) < (nat ? nat[jb] : jb);
+            });
+            int o = A.rowptr[i];
+            for (int k : own) korder[o++] = k;
+            for (int k : other) korder[o++] = k;
+            pdinv[i] = 1.0 / ap[pdiag[i]];
+        }
+        // couplings between subdomains, summed per pair of aggregates in ascending (row, column)
+        std::vector<std::map<int, double>> cross(offs[nown]);
+        for (int i = 0; i < Nb; ++i)
+            for (int k = A.rowptr[i]; k < A.rowptr[i + 1]; ++k) {
+                const int j = A.col[k];
+                if (owner[j] == owner[i]) continue;
+                auto it = cross[gcid[i]].find(gcid[j]);
+                if (it == cross[gcid[i]].end()) cross[gcid[i]][gcid[j]] = 0.0 + ap[k]; else it->second += ap[k];
+            }
+        Csr J;
+        J.n = offs[nown];
+        J.rowptr.assign(1, 0);
+        for (int s = 0; s < nown; ++s) {
+            const Csr& LA = prec[s].amg.lv.back().A;
+            for (int I = 0; I < LA.n; ++I) {
+                std::map<int, double> row(cross[offs[s] + I]);
+                for (int k = LA.rowptr[I]; k < LA.rowptr[I + 1]; ++k) row[offs[s] + LA.col[k]] = LA.val[k];
+                for (auto& e : row) { J.col.push_back(e.first); J.val.push_back(e.second); }
+                J.rowptr.push_back((int)J.col.size());
+            }
+        }
+        G.omega = prec[0].amg.omega; G.damp = prec[0].amg.damp; G.beta = prec[0].amg.beta;
+        G.setup_structure(J);
+        if (nglevels) *nglevels = (int)G.lv.size();
+        if (glevels) for (size_t l = 0; l < G.lv.size() && l < 32; ++l) glevels[l] = G.lv[l].A.n;
+    } else if (nglevels) *nglevels = 0;
     const size_t n = (size_t)Nb * BS;
+    // s = bi - sum over row i's entries, in the rank's order, of a_p x
+    auto prow = [&](int i, double bi, const std::vector<double>& xv) {
+        double sres = bi;
+        for (int o = A.rowptr[i]; o < A.rowptr[i + 1]; ++o) sres -= ap[korder[o]] * xv[A.col[korder[o]]];
+        return sres;
+    };
     auto apply = [&](const double* d, double* v) {
+        std::vector<std::vector<double>> dl(nown);
         for (int s = 0; s < nown; ++s) {
             const int m = sub[s].Nb;
-            std::vector<double> dl((size_t)m * BS), vl((size_t)m * BS);
+            dl[s].resize((size_t)m * BS);
             for (int q = 0; q < m; ++q)
-                for (int k = 0; k < BS; ++k) dl[(size_t)q * BS + k] = d[(size_t)rows[s][q] * BS + k];
-            prec[s].apply(dl.data(), vl.data());
+                for (int k = 0; k < BS; ++k) dl[s][(size_t)q * BS + k] = d[(size_t)rows[s][q] * BS + k];
+        }
+        if (!gather) {
+            for (int s = 0; s < nown; ++s) {
+                const int m = sub[s].Nb;
+                std::vector<double> vl((size_t)m * BS);
+                prec[s].apply(dl[s].data(), vl.data());
+                for (int q = 0; q < m; ++q)
+                    for (int k = 0; k < BS; ++k) v[(size_t)rows[s][q] * BS + k] = vl[(size_t)q * BS + k];
+            }
+            return;
+        }
+        const double om = prec[0].amg.omega;
+        std::vector<double> rp(Nb), x0(Nb), r(Nb), x1(Nb), x2(Nb), bG(offs[nown], 0.0), xG(offs[nown], 0.0);
+        for (int s = 0; s < nown; ++s) {
+            std::vector<double> rc(sub[s].Nb);
+            prec[s].restrict_fine(dl[s].data(), rc.data());
+            for (int q = 0; q < sub[s].Nb; ++q) rp[rows[s][q]] = rc[q];
+        }
+        for (int i = 0; i < Nb; ++i) x0[i] = om * pdinv[i] * rp[i];
+        for (int i = 0; i < Nb; ++i) r[i] = prow(i, rp[i], x0);
+        for (int s = 0; s < nown; ++s) {   // the residual summed over the aggregates, level by level, down to the joined level
+            const CprAmg& M = prec[s].amg;
+            std::vector<double> cur(sub[s].Nb);
+            for (int q = 0; q < sub[s].Nb; ++q) cur[q] = r[rows[s][q]];
+            for (size_t l = 0; l + 1 < M.lv.size(); ++l) {
+                const AmgLevel& L = M.lv[l];
+                std::vector<double> nx(L.nc);
+                for (int I = 0; I < L.nc; ++I) {
+                    double sum = 0.0;
+                    for (int q = L.mptr[I]; q < L.mptr[I + 1]; ++q) sum += cur[L.midx[q]];
+                    nx[I] = sum;
+                }
+                cur.swap(nx);
+            }
+            std::copy(cur.begin(), cur.end(), bG.begin() + offs[s]);
+        }
+        G.vcycle(bG.data(), xG.data());
+        for (int i = 0; i < Nb; ++i) x1[i] = x0[i] + 1.0 * xG[gcid[i]];
+        for (int i = 0; i < Nb; ++i) x2[i] = x1[i] + om * pdinv[i] * prow(i, rp[i], x1);
+        // v = (0, x'', 0) + ILU0_subdomain(d - A (0, x'', 0)) with the whole system's operator, rows in the rank's order
+        std::vector<double> rr(n);
+        for (int i = 0; i < Nb; ++i) {
+            double y[BS] = {0.0, 0.0, 0.0};
+            for (int o = A.rowptr[i]; o < A.rowptr[i + 1]; ++o) {
+                const int k = korder[o];
+                for (int cidx = 0; cidx < BS; ++cidx) y[cidx] += A.val[(size_t)k * BB + cidx * BS + CPR_PRESSURE_INDEX] * x2[A.col[k]];
+            }
+            for (int cidx = 0; cidx < BS; ++cidx) rr[(size_t)i * BS + cidx] = d[(size_t)i * BS + cidx] - y[cidx];
+        }
+        for (int s = 0; s < nown; ++s) {
+            const int m = sub[s].Nb;
+            std::vector<double> rl((size_t)m * BS), zl((size_t)m * BS);
             for (int q = 0; q < m; ++q)
-                for (int k = 0; k < BS; ++k) v[(size_t)rows[s][q] * BS + k] = vl[(size_t)q * BS + k];
+                for (int k = 0; k < BS; ++k) rl[(size_t)q * BS + k] = rr[(size_t)rows[s][q] * BS + k];
+            ilu0_apply(prec[s].LU, prec[s].dg, m, rl.data(), zl.data(), 1.0, 0);
+            for (int q = 0; q < m; ++q)
+                for (int k = 0; k < BS; ++k) v[(size_t)rows[s][q] * BS + k] = (k == CPR_PRESSURE_INDEX ? x2[rows[s][q]] : 0.0) + zl[(size_t)q * BS + k];
         }
     };
+    if (probe_d && probe_v) apply(probe_d, probe_v);
     auto op = [&](const double* xin, double* y) { spmv(A, xin, y); };
     SolveResult r = bicgstab(n, b, x, apply, op, tol, maxit);
     if (out) {

@@ -299,7 +299,7 @@ def test_dd_time_step_roll_back_restores_owned_and_ghost_cells(pkg):
 
 @pytest.mark.parametrize("world,prec", [(2, "cpr_quasiimpes"), (4, "cpr")])
 def test_dd_cpr_one_hierarchy_per_subdomain(pkg, orc, world, prec):
-    """CPR in a decomposed run: every rank builds the pressure hierarchy of its own subdomain (owned rows and columns; the
+    """CPR in a decomposed run with opmhip_config.cpr_gather_rows < 0 (nothing between the subdomains): every rank builds the pressure hierarchy of its own subdomain (owned rows and columns; the
     couplings to ghost cells left out, as the block ILU0 leaves them out) - the preconditioner application of every rank is
     the oracle's CPR of that subdomain's matrix bit for bit, and the solve takes the half-iteration count of the oracle's
     BiCGStab on the global system with one CPR per subdomain"""
@@ -319,7 +319,7 @@ def test_dd_cpr_one_hierarchy_per_subdomain(pkg, orc, world, prec):
     def rank_fn(r):
         c = parts[r]
         Nb = c["Nb"]
-        m = pkg.capi.HipModel(c, comm=("loopback", world, r, group), reorder="line_coloring", preconditioner=prec, tolerance=1e-2)
+        m = pkg.capi.HipModel(c, comm=("loopback", world, r, group), reorder="line_coloring", preconditioner=prec, tolerance=1e-2, cpr_gather_rows=-1)
         m.set_state(c["pv"], c["meaning"])
         m.set_source(np.ascontiguousarray(src.reshape(-1, 3)[c["gids"]].reshape(-1)))
         j, res = m.assemble(dt, 0)
@@ -543,3 +543,64 @@ def test_halo_exchange_beside_the_interior_product_one_rank_periodic(pkg, transp
     # periodic product, but it can form the owned-columns part - compare through linearity instead: A (x1 + x2) = A x1 + A x2
     x1, x2 = rng.standard_normal(3 * Nb), rng.standard_normal(3 * Nb)
     assert np.allclose(s.spmv(x1 + x2), s.spmv(x1) + s.spmv(x2), rtol=1e-12, atol=1e-12)
+
+
+@pytest.mark.parametrize("world,prec,n,rows", [(2, "cpr_quasiimpes", 8, 100), (4, "cpr", 8, 40), (8, "cpr_quasiimpes", 6, 1000), (2, "cpr_quasiimpes", 12, 0)])
+def test_dd_cpr_pressure_stage_across_the_ranks(pkg, orc, world, prec, n, rows):
+    """opmhip_config.cpr_gather_rows: the pressure stage of a decomposed CPR spans the ranks - level 0 smooths with the whole system's
+    pressure operator (ghost entries exchanged), its residual goes down to each rank's first level of at most `rows` rows, those levels
+    are joined (the couplings between the subdomains included), gathered and cycled on by every rank, and the post-smoothing residual is
+    the whole system's too: the coarse part of the reference's parallel AMG (OwningTwoLevelPreconditioner.hpp).  Every rank's
+    application = the oracle's (orc_cpr_solve_blocks with gather_rows) bit for bit; the solves stop on the same half iteration (+-1:
+    the scalar products are summed in different orders) and need fewer iterations than one hierarchy per subdomain.  rows = 1000: above
+    the subdomain size, level 0 itself is joined; rows = 0: the default."""
+    g, owner, parts = global_and_parts(pkg, n, world, state="mixed", heterogeneous=True)
+    src = pkg.decks.five_spot_source(g, rate_sm3_per_day=30.0)
+    o = oracle_bind.OracleModel(orc, g)
+    o.set_state(g["pv"], g["meaning"])
+    o.set_source(src)
+    dt = 5 * 86400.0
+    jo, ro = o.assemble(dt, 0)
+    wts = o.true_impes_weights(dt) if prec == "cpr" else None
+    rng = np.random.default_rng(7)
+    probe = rng.standard_normal(3 * g["Nb"])
+
+    def run(gather_rows):
+        group = "p" + uuid.uuid4().hex
+
+        def rank_fn(r):
+            c = parts[r]
+            Nb = c["Nb"]
+            m = pkg.capi.HipModel(c, comm=("loopback", world, r, group), reorder="line_coloring", preconditioner=prec, tolerance=1e-4, cpr_gather_rows=gather_rows)
+            m.set_state(c["pv"], c["meaning"])
+            m.set_source(np.ascontiguousarray(src.reshape(-1, 3)[c["gids"]].reshape(-1)))
+            m.assemble(dt, 0)
+            sol = m.solve_jacobian_system()
+            x = m.get_result()
+            d = np.ascontiguousarray(probe.reshape(-1, 3)[c["gids"][:Nb]].reshape(-1))
+            v = m.cpr_apply(d)
+            return sol.it, sol.converged, x, v, m.ordering(), m.cpr_levels()[0]
+        return run_ranks(world, rank_fn)
+
+    outs = run(rows)
+    frg = np.concatenate([np.asarray(parts[r]["gids"][:parts[r]["Nb"]])[outs[r][4][1]] for r in range(world)]).astype(np.int32)
+    tog = np.empty_like(frg)
+    tog[frg] = np.arange(len(frg), dtype=np.int32)
+    gr, gc, gv = orc.reorder_matrix(g["Nb"], g["rowptr"], g["col"], jo, tog, frg)
+    xo, reso, lev, glev, pv = orc.cpr_solve_blocks(g["Nb"], gr, gc, gv, np.ascontiguousarray(ro.reshape(-1, 3)[frg].reshape(-1)), np.asarray(owner)[frg],
+                                                   weights=None if wts is None else wts[frg], natural=frg, tol=1e-4, gather_rows=rows,
+                                                   probe=np.ascontiguousarray(probe.reshape(-1, 3)[frg].reshape(-1)))
+    pv = pv.reshape(-1, 3)[tog]
+    assert reso.converged
+    for r, (it, ok, x, v, (to, fr, _), levels) in enumerate(outs):
+        c = parts[r]
+        Nb = c["Nb"]
+        assert levels[-len(glev):] == glev and len(levels) == int(lev[r]) + len(glev), (levels, lev, glev)
+        assert np.array_equal(v[:3 * Nb].reshape(-1, 3), pv[c["gids"][:Nb]]), r
+        assert ok and abs(it - reso.it) <= 1.0, (it, reso.it)
+    xd = np.zeros((g["Nb"], 3))
+    for r in range(world):
+        xd[parts[r]["gids"][:parts[r]["Nb"]]] = outs[r][2].reshape(-1, 3)[:parts[r]["Nb"]]
+    assert np.linalg.norm(orc.spmv(g["Nb"], g["rowptr"], g["col"], jo, xd.reshape(-1)) - ro) < 1e-4 * np.linalg.norm(ro)
+    alone = run(-1)   # one hierarchy per subdomain, nothing between them
+    assert alone[0][1] and outs[0][0] <= alone[0][0], (outs[0][0], alone[0][0])

@@ -127,3 +127,36 @@ def test_reference_like_amg_hierarchy_and_iteration_counts(pkg, orc):
             assert np.allclose(cpr.apply(2.0 * d1 - 0.5 * d2), 2.0 * cpr.apply(d1) - 0.5 * cpr.apply(d2), rtol=1e-9, atol=1e-12 * np.abs(d1).max())
     print("CPR-BiCGStab iterations to 1e-2: product's AMG %.1f, reference-like AMG %.1f" % (its[False], its[True]))
     assert its[True] <= its[False] + 3 and its[False] <= 2 * its[True] + 3
+
+
+def test_decomposed_cpr_with_a_joined_coarse_level(pkg, orc):
+    """Decomposed CPR (orc_cpr_solve_blocks): with one hierarchy per subdomain and nothing between them the iteration count grows
+    with the number of subdomains; with the hierarchies continued on the joined system from a small level on (gather_rows) it stays
+    close to the single-domain count - the coarse part of the reference's parallel AMG (OwningTwoLevelPreconditioner.hpp).  Also: the
+    joined level is what it claims to be - its rows sum like the Galerkin product of the global pressure matrix (constant vectors)."""
+    n, world = 10, 8
+    px, py, pz = pkg.ras.block_layout(world)
+    g = pkg.decks.cartesian_case(px * n, py * n, pz * n, state="mixed", heterogeneous=True)
+    owner = np.asarray(pkg.ras.cartesian_owner(px * n, py * n, pz * n, px, py, pz), np.int32)
+    src = pkg.decks.five_spot_source(g, rate_sm3_per_day=60.0)
+    o = oracle_bind.OracleModel(orc, g)
+    o.set_state(g["pv"], g["meaning"])
+    o.set_source(src)
+    jac, res = o.assemble(20 * 86400.0, 0)
+    Nb, rp, ci = g["Nb"], g["rowptr"], g["col"]
+    cpr = oracle_bind.OracleCpr(orc)
+    _, one = cpr.solve(Nb, rp, ci, jac, res, tol=1e-6)
+    _, alone, lev = orc.cpr_solve_blocks(Nb, rp, ci, jac, res, owner, tol=1e-6)
+    probe = np.random.default_rng(3).standard_normal(3 * Nb)
+    its = {}
+    for rows in (64, 300, 5000):   # joined from the third level / the second / level 0 itself (10^3 = 1000 cells per subdomain)
+        x, r, lev, glev, pv = orc.cpr_solve_blocks(Nb, rp, ci, jac, res, owner, tol=1e-6, gather_rows=rows, probe=probe)
+        assert r.converged and np.linalg.norm(orc.spmv(Nb, rp, ci, jac, x) - res) <= 2e-6 * np.linalg.norm(res)
+        assert len(glev) >= 2 and glev[0] <= world * rows and np.isfinite(pv).all()
+        its[rows] = r.it
+    assert lev.max() == 1 and glev[0] == Nb        # gather_rows above the subdomain size: level 0 itself is joined
+    assert one.converged and alone.converged
+    # nothing between the subdomains costs iterations; the joined level takes (most of) that back
+    assert alone.it >= 1.3 * one.it, (one.it, alone.it)
+    for rows, it in its.items():
+        assert it <= 1.3 * one.it + 1, (rows, it, one.it, alone.it)
