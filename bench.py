@@ -511,7 +511,7 @@ def main():
     stream_ms = stream.get("ms")
     stream_GBps = 72.0 * nnzb / stream_ms / 1e6 if stream_ms else None
 
-    dots_separate = os.environ.get("OPMHIP_DOTS_SEPARATE", "0") not in ("", "0")
+    dots_separate = os.environ.get("OPMHIP_TUNING", "") == "1" and os.environ.get("OPMHIP_DOTS_SEPARATE", "0") not in ("", "0")
     sp = kernels.get("spmv", {"avg_ms": float("nan"), "algorithmic_GBps": float("nan")})
     ok = sp["algorithmic_GBps"] == sp["algorithmic_GBps"]
     traffic, traffic_src = (None, "single-GPU 100^3 line-colouring runs only")

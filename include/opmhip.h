@@ -101,12 +101,17 @@ typedef struct opmhip_config {
                             * reference's AMG smoother (linalg/PreconditionerFactory.hpp:126-151, setupPropertyTree.cpp:116-137) - the others
                             * with damped Jacobi.  Level 0 eliminates in the ordering of the block ILU0 (opmhip_reorder), the levels below
                             * colour by colour of a greedy multi-colouring.  0 (default): Jacobi on every level.  (was reserved[0] until ABI 7) */
-    int cpr_gather_rows;   /* decomposed runs (opmhip_comm_init_*): a rank's pressure hierarchy is continued ACROSS the ranks from its first
-                            * level of at most this many rows - the right-hand sides of that level are gathered, every rank continues the
-                            * coarsening on the joined system (couplings between the subdomains included) and takes its slice of the
-                            * correction back: the coarse part of the reference's parallel AMG (linalg/OwningTwoLevelPreconditioner.hpp,
-                            * PressureTransferPolicy.hpp:92-160).  0: the default (4096); < 0: off, one hierarchy per subdomain with no
-                            * communication.  Ignored on a single rank.  (was reserved[1] until ABI 7) */
+    int cpr_gather_rows;   /* decomposed runs (opmhip_comm_init_*): the pressure stage of the CPR spans the ranks, as the reference's does (Dune's
+                            * parallel AMG behind linalg/OwningTwoLevelPreconditioner.hpp, PressureTransferPolicy.hpp:92-160).  Level 0 smooths
+                            * with the pressure operator of the WHOLE system (ghost entries of the iterates exchanged: one double per boundary
+                            * cell), its residual is summed over the aggregates down to the rank's first level of at most this many rows,
+                            * those levels - their own entries plus the Galerkin sums of the couplings between aggregates of different
+                            * subdomains - are joined into one system that every rank holds, coarsens further and cycles on (one all-gather
+                            * of a right-hand side per application, one of matrix values per solve), and the post-smoothing residual
+                            * d - A (0, x_p, 0) is the whole system's.  Aggregates never cross a rank boundary.  0: the default (32 768);
+                            * < 0: off - one hierarchy per subdomain, no communication inside the preconditioner, iteration counts that
+                            * grow with the number of ranks.  Ignored on a single rank; cpr_amg_ilu_levels and cpr_async_setup are ignored
+                            * where it is in force.  (was reserved[1] until ABI 7) */
 } opmhip_config;
 
 /* bda::BdaResult (bda/BdaResult.hpp:28-40) plus the reference's per-phase timers. */

@@ -278,7 +278,7 @@ int opmhip_solve_system(opmhip_ctx* c, int N, int nnz, int dim, double* vals, co
         if (!vals && !c->system_loaded) return fail(c, OPMHIP_NOT_READY, "solve_system: vals == NULL but no matrix is resident on the device");
         int rc;
         if ((rc = upload_system(c, vals, b))) return rc;
-        static const bool zfixSeparate = [] { const char* e = std::getenv("OPMHIP_ZFIX_SEPARATE"); return e && e[0] == '1'; }();   // A/B switch
+        static const bool zfixSeparate = [] { const char* e = tuning_env("OPMHIP_ZFIX_SEPARATE"); return e && e[0] == '1'; }();   // A/B switch
         const bool zfix = !vals && c->cfg.zero_diag_fix;   // device-assembled Jacobian: the same fix-up as the uploaded one gets
         if (zfix && zfixSeparate) launch_zero_diag_fix(c);
         if ((rc = upload_wells(c, wells))) return rc;

@@ -197,10 +197,19 @@ int comm_halo_begin(opmhip_ctx* c, double* vec) {
     OPMHIP_HIP(c, hipEventRecord(C.ev_x, c->stream));
     OPMHIP_HIP(c, hipStreamWaitEvent(C.hstream, C.ev_x, 0));
     C.halo_vec = vec;
+    // Every begin() is followed by an end() before anything else touches the communicator or d_sendbuf (launch_spmv is the only caller
+    // of the pair).  A failure on the way must not leave halo-stream work unordered against what the main stream does next - packs into
+    // the same send buffer, all-reduces on the same communicator: the main stream is made to wait for the halo stream before the error
+    // goes back, and no exchange stays pending.
+    auto fail_ordered = [&](int rc) {
+        C.halo_vec = nullptr;
+        if (hipEventRecord(C.ev_h, C.hstream) != hipSuccess || hipStreamWaitEvent(c->stream, C.ev_h, 0) != hipSuccess) (void)hipStreamSynchronize(C.hstream);
+        return rc;
+    };
     if (C.kind == COMM_RCCL) {   // asynchronous: enqueue now, the interior product is launched behind this call and overlaps on the device
         const int rc = comm_halo_f64(c, vec, BS, C.hstream);
-        if (rc) return rc;
-        OPMHIP_HIP(c, hipEventRecord(C.ev_h, C.hstream));
+        if (rc) return fail_ordered(rc);
+        if (hipEventRecord(C.ev_h, C.hstream) != hipSuccess) return fail_ordered(fail(c, OPMHIP_DEVICE_ERROR, "halo exchange: hipEventRecord failed"));
         C.halo_vec = nullptr;
     }
     return OPMHIP_SUCCESS;   // loopback: the host-driven exchange happens in end(), after the interior launch is on its way
@@ -210,7 +219,7 @@ int comm_halo_end(opmhip_ctx* c) {
     if (C.halo_vec) {   // loopback: barriers and device copies driven from this thread, on the halo stream, while the main stream works
         const int rc = comm_halo_f64(c, C.halo_vec, BS, C.hstream);
         C.halo_vec = nullptr;
-        if (rc) return rc;
+        if (rc) { (void)hipStreamSynchronize(C.hstream); return rc; }   // nothing of the halo stream is left in flight behind the error
         OPMHIP_HIP(c, hipEventRecord(C.ev_h, C.hstream));
     }
     OPMHIP_HIP(c, hipStreamWaitEvent(c->stream, C.ev_h, 0));

@@ -1088,7 +1088,7 @@ static int cpr_weights(opmhip_ctx* c) {
 }
 // levels of up to this many rows are kept row-major and run the lane-group kernels (OPMHIP_CPR_LPR_ROWS: measurement switch)
 static int cpr_lpr_rows() {
-    static const int v = [] { const char* e = std::getenv("OPMHIP_CPR_LPR_ROWS"); return e ? std::atoi(e) : CPR_LPR_ROWS; }();
+    static const int v = [] { const char* e = tuning_env("OPMHIP_CPR_LPR_ROWS"); return e ? std::atoi(e) : CPR_LPR_ROWS; }();
     return v;
 }
 static bool cpr_gathering(const opmhip_ctx* c);
@@ -1114,7 +1114,7 @@ static int cpr_setup_level0(opmhip_ctx* c) {
     (void)ell_image(A, H0, pos, false, spans ? P.Nloc : P.Nb);
     if ((rc = upload_ell(c, H0, R.lv[0], spans ? P.Nloc : P.Nb))) return rc;
     {   // level 0's ELL columns in stencil form (EllStencil), where the pattern has it: single domain, rows of <= 8 entries, <= 15 offsets per group of 32 rows
-        static const bool off = [] { const char* e = std::getenv("OPMHIP_CPR_ELL_EXPLICIT"); return e && e[0] == '1'; }();   // A/B switch
+        static const bool off = [] { const char* e = tuning_env("OPMHIP_CPR_ELL_EXPLICIT"); return e && e[0] == '1'; }();   // A/B switch
         bool ok = !off && P.Nghost == 0 && R.lv[0].W <= 8;
         const int ng = (P.Nb + 31) / 32;
         std::vector<unsigned> word(ok ? P.Nb : 0, 0xFFFFFFFFu);
@@ -1542,7 +1542,7 @@ static int cpr_gather_values(opmhip_ctx* c) {
 // everything it allocated: a retry starts from a clean slate, nothing piles up
 static int cpr_setup_coarse_now(opmhip_ctx* c) {
     CprDev& R = c->cpr;
-    static const bool timing = std::getenv("OPMHIP_CPR_TIMING") != nullptr;
+    static const bool timing = tuning_env("OPMHIP_CPR_TIMING") != nullptr;
     auto now = [] { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
     const double t0 = now();
     std::vector<double> ell;
@@ -1691,7 +1691,7 @@ static void cpr_ilu_smooth(opmhip_ctx* c, const CprLevelDev& L, const double* d,
 // does level l (> 0) form its right-hand side itself, from the finer level's residual (cpr_restricted)?  Then no restriction
 // kernel runs between the two levels.  Lane-group levels do, and the dense solve of the coarsest level.
 static bool cpr_forms_rhs(const CprDev& R, size_t l) {
-    static const bool off = std::getenv("OPMHIP_CPR_UNFUSED") != nullptr;   // A/B switch: the restriction as a launch of its own
+    static const bool off = tuning_env("OPMHIP_CPR_UNFUSED") != nullptr;   // A/B switch: the restriction as a launch of its own
     if (off || l == 0 || l >= R.lv.size() || !R.lv[l - 1].d_mem4) return false;
     if (R.gather.on && l + 1 == R.lv.size()) return false;   // the level that is gathered: its right-hand side is what travels
     return R.lv[l].rm || (l + 1 == R.lv.size() && R.coarse_direct);
@@ -1838,7 +1838,7 @@ void launch_cpr_apply(opmhip_ctx* c, const double* d, double* v) {
     // v = (0, x_p, 0) + ILU0(d - A (0, x_p, 0)): the block vector (0, x_p, 0) itself is never formed - the residual kernel reads
     // x_p, and the backward sweeps of the smoother add their result to it as they store (second_result, solver.hip): the
     // expansion pass, the addition kernel and a 24-byte-per-row store of the post-smoothing are gone
-    static const bool separate = std::getenv("OPMHIP_CPR_SEPARATE_ADD") != nullptr;   // A/B switch: the three steps as kernels of their own
+    static const bool separate = tuning_env("OPMHIP_CPR_SEPARATE_ADD") != nullptr;   // A/B switch: the three steps as kernels of their own
     if (separate) {
         const bool direct = R.lv.size() > 1 && !R.lv[0].rm;   // level 0's post-smoother writes v = (0, x_p, 0) itself
         const double* xp = cpr_vcycle(c, R, 0, direct ? v : nullptr);

@@ -4,6 +4,7 @@
 
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <memory>
 #include <string>
@@ -334,6 +335,21 @@ struct opmhip_ctx {
 };
 
 namespace opmhip {
+
+// The library's measurement switches (tools/README.md: two forms that give the same bits, chosen by an environment variable so that a
+// change can be judged by alternating runs inside one GPU session) are read only under the master switch OPMHIP_TUNING=1: a stray
+// variable in a user's environment changes nothing, and every switch that is in force says so on stderr (once per call site).
+inline const char* tuning_env(const char* name) {
+    static const bool on = [] { const char* e = std::getenv("OPMHIP_TUNING"); return e && e[0] == '1'; }();
+    const char* v = std::getenv(name);
+    if (!v) return nullptr;
+    if (!on) {
+        std::fprintf(stderr, "opmhip: %s is set but OPMHIP_TUNING=1 is not - ignored\n", name);
+        return nullptr;
+    }
+    std::fprintf(stderr, "opmhip: measurement switch %s=%s is in force\n", name, v);
+    return v;
+}
 
 inline int fail(opmhip_ctx* c, int code, const char* fmt, ...) {
     char buf[512];

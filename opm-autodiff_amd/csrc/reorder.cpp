@@ -528,7 +528,7 @@ int build_pattern(opmhip_ctx* c, int Nb, int Nghost, int nnzb, const int* rows, 
     // symbolic elimination: which entries of row p the step against row j updates (k_ilu_factor looks them up instead of merging two
     // column lists per L entry - three dependent rounds of loads became one)
     P.lmatch.assign(P.nnzb, -2);
-    static const bool general = [] { const char* e = std::getenv("OPMHIP_FACTOR_GENERAL"); return e && e[0] == '1'; }();   // A/B switch: every step by the general search
+    static const bool general = [] { const char* e = tuning_env("OPMHIP_FACTOR_GENERAL"); return e && e[0] == '1'; }();   // A/B switch: every step by the general search
     for (int p = 0; p < Nb && !general; ++p) {
         const int kb = P.rowptr[p], ke = P.rowptr[p + 1];
         for (int k = kb; k < ke; ++k) {
@@ -601,7 +601,7 @@ int build_pattern(opmhip_ctx* c, int Nb, int Nghost, int nnzb, const int* rows, 
 
     {
         // OPMHIP_XCD_GROUP: chain-tiles per XCD group of the launch schedules (0 = identity map); tuning knob, see DESIGN.md
-        const char* e = std::getenv("OPMHIP_XCD_GROUP");
+        const char* e = tuning_env("OPMHIP_XCD_GROUP");
         build_schedules(P, e ? std::atoi(e) : OPMHIP_XCD_GROUP_DEFAULT);
     }
     int rc;

@@ -1871,7 +1871,7 @@ void launch_wells_recover(opmhip_ctx* c, const double* d_resWell, const double* 
 #endif
 constexpr int SPMV_PIPE_WGS = OPMHIP_SPMV_PIPE_WGS;  // resident single-wave workgroups the pipelined SpMV is sized for (256 CUs x 8)
 static int spmv_pipe_env() {   // OPMHIP_SPMV_PIPE (tuning): 0 = off, n > 1 = workgroups the pipelined kernel is sized for
-    static const int v = [] { const char* e = std::getenv("OPMHIP_SPMV_PIPE"); return e ? std::atoi(e) : -1; }();
+    static const int v = [] { const char* e = tuning_env("OPMHIP_SPMV_PIPE"); return e ? std::atoi(e) : -1; }();
     return v;
 }
 // cfg.spmv_pipe_wgs: resident workgroups the pipelined kernel is sized for (0 = default, < 0 = never use it)
@@ -1884,7 +1884,7 @@ static bool spmv_pipelined(const opmhip_ctx* c) {
 }
 // the scalar products ride in the product's kernel unless wells modify y after it (then k_dots forms them afterwards)
 static bool spmv_dots_env() {   // OPMHIP_DOTS_SEPARATE=1 (tuning / A-B measurements): k_dots behind every product, as with wells
-    static const bool v = [] { const char* e = std::getenv("OPMHIP_DOTS_SEPARATE"); return e && std::atoi(e) != 0; }();
+    static const bool v = [] { const char* e = tuning_env("OPMHIP_DOTS_SEPARATE"); return e && std::atoi(e) != 0; }();
     return v;
 }
 static bool spmv_dots_separate(const opmhip_ctx* c) { return c->wells.num_wells > 0 || spmv_dots_env(); }
@@ -1905,7 +1905,7 @@ static int launch_spmv_part(opmhip_ctx* c, int p0, int np, const double* x, doub
         const int pipeWgs = spmv_pipe_wgs(c);
         const int steps = std::min((np + pipeWgs - 1) / pipeWgs, PIPE_MAX_STEPS);   // beyond that: more workgroups than are resident
         const int grid = 8 * (((np + steps - 1) / steps + 7) / 8);
-        static const bool explicitIdx = [] { const char* e = std::getenv("OPMHIP_SPMV_EXPLICIT"); return e && e[0] == '1'; }();   // A/B switch: the explicit index streams
+        static const bool explicitIdx = [] { const char* e = tuning_env("OPMHIP_SPMV_EXPLICIT"); return e && e[0] == '1'; }();   // A/B switch: the explicit index streams
         const bool inInt = p0 < P.tiles.nschedInt, inBnd = p0 + np > P.tiles.nschedInt;   // which parts of the schedule this launch covers
         if ((!inInt || P.tiles.stencilPart[0]) && (!inBnd || P.tiles.stencilPart[1]) && !explicitIdx) {
             const int* tab = P.tiles.d_stTable + (size_t)p0 * 16;
@@ -2001,7 +2001,7 @@ void launch_ilu_apply(opmhip_ctx* c, const double* d, double* v, double w_overri
         const int ds = P.tiles.descStride, S1 = P.tiles.descS1;
         auto desc = [&](int col) { return P.tiles.d_ctDesc + (size_t)P.tiles.ctSchedOff[col] * ds; };
         auto npos = [&](int col) { return P.tiles.ctSchedOff[col + 1] - P.tiles.ctSchedOff[col]; };
-        static const bool explicitIdx = [] { const char* e = std::getenv("OPMHIP_SWEEP_EXPLICIT"); return e && e[0] == '1'; }();   // A/B switch
+        static const bool explicitIdx = [] { const char* e = tuning_env("OPMHIP_SWEEP_EXPLICIT"); return e && e[0] == '1'; }();   // A/B switch
         const bool st = P.sweepStencil && !explicitIdx;   // column indices and row bounds of the heavy sweeps from the stencil form
         const SweepStencil SL{P.d_swWord[0], P.d_swKoff[0], P.d_swTable[0]}, SU{P.d_swWord[1], P.d_swKoff[1], P.d_swTable[1]};
         for (int col = 0; col < C - 1; ++col) {

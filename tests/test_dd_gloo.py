@@ -106,3 +106,54 @@ def test_window_built_subdomain_equals_global_slice(pkg):
         assert np.array_equal(c["depth"], g["depth"][gi])
         for k in ("neigh", "send_ptr", "send_cells", "recv_ptr"):
             assert np.array_equal(c["halo"][k], lp[k])
+
+
+def _gather_worker(rank, world, port, q):
+    """the exchange pattern of the CPR pressure stage that spans the ranks (csrc/cpr.hip: cpr_gather_setup / cpr_gathered_cycle), over
+    gloo: slices of different lengths, padded to the longest, all-gathered, unpadded through the index list r * maxn + i"""
+    sys.path.insert(0, ROOT)
+    import torch
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    nloc = 5 + 3 * rank                                   # my rows of the joined level
+    mine = torch.tensor([nloc], dtype=torch.int64)
+    sizes = [torch.zeros(1, dtype=torch.int64) for _ in range(world)]
+    dist.all_gather(sizes, mine)
+    sizes = [int(s.item()) for s in sizes]
+    offs = np.concatenate([[0], np.cumsum(sizes)])
+    maxn = max(sizes)
+    rng = np.random.default_rng(100 + rank)
+    b = rng.standard_normal(nloc)
+    send = torch.zeros(maxn, dtype=torch.float64)
+    send[:nloc] = torch.from_numpy(b)
+    recv = [torch.zeros(maxn, dtype=torch.float64) for _ in range(world)]
+    dist.all_gather(recv, send)
+    flat = torch.cat(recv).numpy()
+    unpad = np.concatenate([r * maxn + np.arange(sizes[r]) for r in range(world)])
+    joined = flat[unpad]
+    expect = np.concatenate([np.random.default_rng(100 + r).standard_normal(sizes[r]) for r in range(world)])
+    ok = bool(np.array_equal(joined, expect)) and len(joined) == offs[-1]
+    # every rank cycles on the same joined vector: its slice of the (here: doubled) result is what it keeps
+    mine_back = (2.0 * joined)[offs[rank]:offs[rank + 1]]
+    ok &= bool(np.array_equal(mine_back, 2.0 * b))
+    q.put((rank, ok))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_joined_level_gather_protocol_over_gloo(world):
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 31500 + (os.getpid() % 2000) + world
+    procs = [ctx.Process(target=_gather_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=120) for _ in range(world)]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert all(ok for _, ok in res), res

@@ -1,6 +1,7 @@
 #!/bin/bash
 # tools/cpr_ab.sh OUT VAR v1 v2 ...: bench.py with the CPR preconditioner behind `value`, environment variable VAR set to each value
 # ("-" = unset), alternating inside one gpurun call; prints Newton its/s of both windows and the V-cycle's time
+export OPMHIP_TUNING=1   # the library reads its measurement switches only under this master switch
 OUT=$1; VAR=$2; shift; shift
 mkdir -p $OUT
 for ROUND in 1 2; do

@@ -1,5 +1,6 @@
 #!/bin/bash
 # tools/env_ab.sh OUT VAR v1 v2 ...: bench.py kernel times with the environment variable VAR set to each value (A/B inside one gpurun call)
+export OPMHIP_TUNING=1   # the library reads its measurement switches only under this master switch
 OUT=$1; VAR=$2; shift; shift
 mkdir -p $OUT
 for V in "$@"; do

@@ -1,5 +1,6 @@
 #!/bin/bash
 # tools/env_sweep.sh OUT "ENV1=a ENV2=b" "ENV1=c" ...: bench.py's kernel times under different environment settings
+export OPMHIP_TUNING=1   # the library reads its measurement switches only under this master switch
 OUT=$1; shift
 mkdir -p $OUT
 i=0

@@ -1,5 +1,6 @@
 #!/bin/bash
 # time and FETCH_SIZE of the pipelined SpMV for several XCD group sizes
+export OPMHIP_TUNING=1   # the library reads its measurement switches only under this master switch
 R=$PWD
 for G in 0 2 8 32; do
   export OPMHIP_XCD_GROUP=$G

@@ -1,5 +1,6 @@
 #!/bin/bash
 # tools/xcd_group_sweep.sh OUT G1 G2 ...: bench.py's kernel times for several OPMHIP_XCD_GROUP values (launch-schedule tuning)
+export OPMHIP_TUNING=1   # the library reads its measurement switches only under this master switch
 OUT=$1; shift
 mkdir -p $OUT
 for G in "$@"; do
