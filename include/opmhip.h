@@ -108,7 +108,7 @@ typedef struct opmhip_config {
                             * those levels - their own entries plus the Galerkin sums of the couplings between aggregates of different
                             * subdomains - are joined into one system that every rank holds, coarsens further and cycles on (one all-gather
                             * of a right-hand side per application, one of matrix values per solve), and the post-smoothing residual
-                            * d - A (0, x_p, 0) is the whole system's.  Aggregates never cross a rank boundary.  0: the default (32 768);
+                            * d - A (0, x_p, 0) is the whole system's.  Aggregates never cross a rank boundary.  0: the default (100 000: on a 10^6-cell subdomain its third level, aggregates of ~15 cells);
                             * < 0: off - one hierarchy per subdomain, no communication inside the preconditioner, iteration counts that
                             * grow with the number of ranks.  Ignored on a single rank; cpr_amg_ilu_levels and cpr_async_setup are ignored
                             * where it is in force.  (was reserved[1] until ABI 7) */

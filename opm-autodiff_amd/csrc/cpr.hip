@@ -1337,7 +1337,7 @@ static int cpr_upload_coarse(opmhip_ctx* c, CprDev& R, const CprHostCoarse& H, b
 // rank holds, coarsens further and cycles on redundantly: one all-gather of a right-hand side per application, one of matrix values per
 // solve.  oracle: orc_cpr_solve_blocks with gather_rows.
 static bool cpr_gathering(const opmhip_ctx* c) { return c->comm.nranks > 1 && c->comm.kind != COMM_NONE && c->cfg.cpr_gather_rows >= 0; }
-static int cpr_stop_rows(const opmhip_ctx* c) { return cpr_gathering(c) ? (c->cfg.cpr_gather_rows > 0 ? c->cfg.cpr_gather_rows : 32768) : CPR_COARSE_DIRECT; }
+static int cpr_stop_rows(const opmhip_ctx* c) { return cpr_gathering(c) ? (c->cfg.cpr_gather_rows > 0 ? c->cfg.cpr_gather_rows : 100000) : CPR_COARSE_DIRECT; }
 // `bytes` bytes of every rank, in rank order, on every rank (set-up only: staged through device buffers of its own)
 static int cpr_host_allgather(opmhip_ctx* c, const void* src, size_t bytes, std::vector<char>& dst) {
     const int nr = c->comm.nranks;

@@ -310,7 +310,7 @@ int orc_cpr_solve(orc_cpr* h, int Nb, const int* rowptr, const int* col, const d
 // per subdomain, else Nb x 3 (true-IMPES from the model).  levels (may be NULL): number of AMG levels of every subdomain.
 // nat (may be NULL): the system is handed over in another ordering than the natural one (the product's ILU0 ordering inside every
 // subdomain); nat[i] = natural id of row i - the finest level is then aggregated in natural visiting order, as the product does.
-// gather_rows >= 0 (0: 4096): a pressure stage that spans the subdomains (the product: csrc/cpr.hip, cpr_gather_*; the reference: Dune's
+// gather_rows >= 0 (0: 100 000, the product's default): a pressure stage that spans the subdomains (the product: csrc/cpr.hip, cpr_gather_*; the reference: Dune's
 // parallel AMG behind linalg/OwningTwoLevelPreconditioner.hpp).  Every subdomain coarsens on its own (aggregates never cross a
 // boundary) down to its first level of at most that many rows; those levels are joined into ONE system - their own entries plus,
 // between aggregates of different subdomains, the Galerkin sums of the fine couplings - which is coarsened further and cycled on as a
@@ -358,7 +358,7 @@ int orc_cpr_solve_blocks(int Nb, const int* rowptr, const int* col, const double
             for (int q = 0; q < S.Nb; ++q)
                 for (int k = 0; k < BS; ++k) prec[s].w_given[(size_t)q * BS + k] = weights[(size_t)rows[s][q] * BS + k];
         }
-        if (gather) { prec[s].amg.stopRows = gather_rows > 0 ? gather_rows : 4096; prec[s].amg.external = true; }
+        if (gather) { prec[s].amg.stopRows = gather_rows > 0 ? gather_rows : 100000; prec[s].amg.external = true; }
         const int rc = prec[s].update(S);
         if (rc) return rc;
         if (levels) levels[s] = (int)prec[s].amg.lv.size();

@@ -83,7 +83,7 @@ class Oracle:
     def cpr_solve_blocks(self, Nb, rowptr, col, val, b, owner, weights=None, natural=None, tol=1e-2, maxit=200, zero_diag_fix=True,
                          gather_rows=-1, probe=None):
         """BiCGStab on the global system, one CPR per subdomain (owner id per row) as preconditioner -> (x, result, levels per subdomain).
-        gather_rows >= 0: the subdomains' hierarchies end at their first level of at most that many rows (0: 4096) and are continued on
+        gather_rows >= 0: the subdomains' hierarchies end at their first level of at most that many rows (0: 100 000) and are continued on
         the joined system -> (x, result, levels per subdomain, rows of the joined hierarchy's levels[, M^-1 probe])"""
         owner = np.ascontiguousarray(owner, np.int32)
         nown = int(owner.max()) + 1

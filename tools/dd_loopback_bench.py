@@ -14,7 +14,7 @@ ap.add_argument("--n", type=int, default=50)
 ap.add_argument("--steps", type=int, default=30)
 ap.add_argument("--reorder", default="line_coloring")
 ap.add_argument("--preconditioner", default="ilu0", choices=["ilu0", "cpr", "cpr_trueimpes", "cpr_quasiimpes"])
-ap.add_argument("--cpr-gather-rows", type=int, default=0, help="CPR: the pressure stage spans the ranks from each rank's first level of at most this many rows (0: the default, 32768; < 0: one hierarchy per subdomain)")
+ap.add_argument("--cpr-gather-rows", type=int, default=0, help="CPR: the pressure stage spans the ranks from each rank's first level of at most this many rows (0: the default, 100000; < 0: one hierarchy per subdomain)")
 a = ap.parse_args()
 pkg = importlib.import_module("opm-autodiff_amd")
 group = "ddbench%d" % os.getpid()
