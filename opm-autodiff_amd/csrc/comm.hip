@@ -345,6 +345,17 @@ int opmhip_comm_selftest(opmhip_ctx* c, double* sum_out) {
     OPMHIP_HIP(c, hipStreamSynchronize(c->stream));
     sum_out[0] = o[0];
     sum_out[1] = o[1];
+    {   // ... and one ncclAllGather (the CPR pressure stage that spans the ranks gathers with it): every rank's two doubles, this rank's slice checked
+        double* g = nullptr;
+        if ((rc = dev_alloc(c, &g, (size_t)2 * c->comm.nranks))) return rc;
+        NCCLCHK(c, g_rccl.AllGather(d, g, 2, ncclDouble, (ncclComm_t)c->comm.nccl, c->stream));
+        double back[2] = {0.0, 0.0};
+        OPMHIP_HIP(c, hipMemcpyAsync(back, g + (size_t)2 * c->comm.rank, sizeof back, hipMemcpyDeviceToHost, c->stream));
+        OPMHIP_HIP(c, hipStreamSynchronize(c->stream));
+        dev_free(c, &g);
+        if (back[0] != o[0] || back[1] != o[1]) return fail(c, OPMHIP_DEVICE_ERROR, "comm_selftest: ncclAllGather returned (%g, %g) for this rank's (%g, %g)", back[0], back[1], o[0], o[1]);
+    }
+    dev_free(c, &d);
     return OPMHIP_SUCCESS;
 }
 

@@ -604,3 +604,55 @@ def test_dd_cpr_pressure_stage_across_the_ranks(pkg, orc, world, prec, n, rows):
     assert np.linalg.norm(orc.spmv(g["Nb"], g["rowptr"], g["col"], jo, xd.reshape(-1)) - ro) < 1e-4 * np.linalg.norm(ro)
     alone = run(-1)   # one hierarchy per subdomain, nothing between them
     assert alone[0][1] and outs[0][0] <= alone[0][0], (outs[0][0], alone[0][0])
+
+
+@pytest.mark.parametrize("rows", [60, 5000])
+def test_dd_cpr_pressure_stage_on_an_irregular_graph(pkg, orc, rows):
+    """the pressure stage that spans the ranks on three subdomains of an unstructured graph with scattered ownership - every rank a
+    neighbour of every other, rows with several couplings into one aggregate of another rank, rows of 2 to 9 blocks: every rank's
+    application of the preconditioner = the oracle's bit for bit, same half-iteration count (+-1)"""
+    world = 3
+    g = irregular_global_case(pkg)
+    Nb = g["Nb"]
+    rng = np.random.default_rng(8)
+    owner = ((np.arange(Nb) // 97 + rng.integers(0, 2, Nb) * (rng.random(Nb) < 0.03)) % world).astype(np.int32)
+    o = oracle_bind.OracleModel(orc, g)
+    o.set_state(g["pv"], g["meaning"])
+    dt = 5 * 86400.0
+    jo, ro = o.assemble(dt, 0)
+    group = "q" + uuid.uuid4().hex
+    parts = []
+    for r in range(world):
+        lp = pkg.ras.local_problem(g["rowptr"], g["col"], owner, r)
+        cells = lp["cells"]
+        parts.append(dict(Nb=lp["Nown"], Nghost=lp["Nghost"], Nloc=lp["Nown"] + lp["Nghost"], rowptr=lp["rows"], col=lp["cols"],
+                          trans=np.ascontiguousarray(g["trans"][lp["entry"]]), area=np.ascontiguousarray(g["area"][lp["entry"]]),
+                          poro=np.ascontiguousarray(g["poro"][cells]), volume=np.ascontiguousarray(g["volume"][cells]),
+                          depth=np.ascontiguousarray(g["depth"][cells]), fluid=g["fluid"],
+                          pv=np.ascontiguousarray(g["pv"].reshape(-1, 3)[cells].reshape(-1)), meaning=np.ascontiguousarray(g["meaning"][cells]),
+                          gids=lp["gids"], halo=lp, global_cells=Nb))
+    probe = np.random.default_rng(11).standard_normal(3 * Nb)
+
+    def rank_fn(r):
+        c = parts[r]
+        m = pkg.capi.HipModel(c, comm=("loopback", world, r, group), reorder="line_coloring", preconditioner="cpr_quasiimpes", tolerance=1e-4, cpr_gather_rows=rows)
+        m.set_state(c["pv"], c["meaning"])
+        m.assemble(dt, 0)
+        sol = m.solve_jacobian_system()
+        d = np.ascontiguousarray(probe.reshape(-1, 3)[c["gids"][:c["Nb"]]].reshape(-1))
+        return sol.it, sol.converged, m.cpr_apply(d), m.ordering(), m.cpr_levels()[0]
+
+    outs = run_ranks(world, rank_fn)
+    frg = np.concatenate([np.asarray(parts[r]["gids"][:parts[r]["Nb"]])[outs[r][3][1]] for r in range(world)]).astype(np.int32)
+    tog = np.empty_like(frg)
+    tog[frg] = np.arange(len(frg), dtype=np.int32)
+    gr, gc, gv = orc.reorder_matrix(Nb, g["rowptr"], g["col"], jo, tog, frg)
+    xo, reso, lev, glev, pv = orc.cpr_solve_blocks(Nb, gr, gc, gv, np.ascontiguousarray(ro.reshape(-1, 3)[frg].reshape(-1)), owner[frg], natural=frg, tol=1e-4,
+                                                   gather_rows=rows, probe=np.ascontiguousarray(probe.reshape(-1, 3)[frg].reshape(-1)))
+    pv = pv.reshape(-1, 3)[tog]
+    assert reso.converged
+    for r, (it, ok, v, _, levels) in enumerate(outs):
+        c = parts[r]
+        assert levels[-len(glev):] == glev
+        assert np.array_equal(v[:3 * c["Nb"]].reshape(-1, 3), pv[c["gids"][:c["Nb"]]]), r
+        assert ok and abs(it - reso.it) <= 1.0, (it, reso.it)
