@@ -297,8 +297,8 @@ def test_dd_time_step_roll_back_restores_owned_and_ghost_cells(pkg):
         assert all(flags), flags
 
 
-@pytest.mark.parametrize("world,prec", [(2, "cpr_quasiimpes"), (4, "cpr")])
-def test_dd_cpr_one_hierarchy_per_subdomain(pkg, orc, world, prec):
+@pytest.mark.parametrize("world,prec,ilu", [(2, "cpr_quasiimpes", 0), (4, "cpr", 0), (2, "cpr_quasiimpes", 2)])
+def test_dd_cpr_one_hierarchy_per_subdomain(pkg, orc, world, prec, ilu):
     """CPR in a decomposed run with opmhip_config.cpr_gather_rows < 0 (nothing between the subdomains): every rank builds the pressure hierarchy of its own subdomain (owned rows and columns; the
     couplings to ghost cells left out, as the block ILU0 leaves them out) - the preconditioner application of every rank is
     the oracle's CPR of that subdomain's matrix bit for bit, and the solve takes the half-iteration count of the oracle's
@@ -319,7 +319,7 @@ def test_dd_cpr_one_hierarchy_per_subdomain(pkg, orc, world, prec):
     def rank_fn(r):
         c = parts[r]
         Nb = c["Nb"]
-        m = pkg.capi.HipModel(c, comm=("loopback", world, r, group), reorder="line_coloring", preconditioner=prec, tolerance=1e-2, cpr_gather_rows=-1)
+        m = pkg.capi.HipModel(c, comm=("loopback", world, r, group), reorder="line_coloring", preconditioner=prec, tolerance=1e-2, cpr_gather_rows=-1, cpr_amg_ilu_levels=ilu)
         m.set_state(c["pv"], c["meaning"])
         m.set_source(np.ascontiguousarray(src.reshape(-1, 3)[c["gids"]].reshape(-1)))
         j, res = m.assemble(dt, 0)
@@ -353,6 +353,8 @@ def test_dd_cpr_one_hierarchy_per_subdomain(pkg, orc, world, prec):
         rr, rc, rv = orc.reorder_matrix(Nb, lrp, lci, lv, to, fr)
         cpr = oracle_bind.OracleCpr(orc)
         cpr.set_natural_ids(fr)
+        if ilu:
+            cpr.set_ilu_smoother(ilu, 1)   # the AMG's finest levels smooth with ILU0 (ghost columns play no part in it)
         if wts is not None:
             assert np.array_equal(w.reshape(-1, 3), wts[gi])
             cpr.set_weights(np.ascontiguousarray(wts[gi][fr].reshape(-1)))
@@ -360,7 +362,7 @@ def test_dd_cpr_one_hierarchy_per_subdomain(pkg, orc, world, prec):
         vo = cpr.apply(np.ascontiguousarray(d.reshape(Nb, 3)[fr].reshape(-1))).reshape(Nb, 3)[to].reshape(-1)
         assert np.array_equal(v[:3 * Nb], vo), r
         assert levels == [int(q) for q in cpr.levels()[0]]
-        assert ok and abs(it - reso.it) <= 1.0
+        assert ok and (ilu or abs(it - reso.it) <= 1.0)   # (the global oracle solve runs the Jacobi-smoothed hierarchies)
     # the two solutions: both meet the tolerance on the global system.  (They are not compared entry by entry: with the
     # couplings between the subdomains missing from the pressure hierarchy the first BiCGStab steps overshoot - the residual
     # grows fourfold before it falls - and the different summation orders of the scalar products show in the iterates.)
