@@ -296,7 +296,7 @@ def main():
     ap.add_argument("--steady-steps", type=int, default=100)
     ap.add_argument("--preconditioner", default="ilu0", choices=["ilu0", "cpr", "cpr_trueimpes", "cpr_quasiimpes"], help="--linear-solver-configuration of the run behind `value`")
     ap.add_argument("--cpr-reuse-setup", type=int, default=3, choices=[0, 1, 2, 3], help="Flow's --cpr-reuse-setup for the CPR runs: when the hierarchy's structure is built anew (3 = never, the default of Flow)")
-    ap.add_argument("--cpr-amg-ilu-levels", type=int, default=0, help="CPR runs: this many of the pressure AMG's finest levels smooth with ILU0 (the reference's AMG smoother) instead of damped Jacobi")
+    ap.add_argument("--cpr-amg-ilu-levels", type=int, default=1, help="CPR runs: this many of the pressure AMG's finest levels smooth with ILU0 (the reference's AMG smoother) instead of damped Jacobi; 1 (level 0, in the line-coloured order of the block ILU0) is the best of 0 / 1 / 2 / 3 on this case in every CPR configuration (DESIGN.md section 5b); the library's own default is 0")
     ap.add_argument("--no-cpr-side-run", action="store_true", help="skip the side runs with the CPR preconditioners (extra keys `cpr`, `cpr_quasiimpes`)")
     a = ap.parse_args()
 
@@ -499,8 +499,8 @@ def main():
     if a.preconditioner == "ilu0" and world == 1 and not a.no_cpr_side_run:
         for prec in ("cpr", "cpr_quasiimpes"):
             cpr_sides[prec] = guarded("CPR side run (%s)" % prec, cpr_window(prec))
-        if a.cpr_amg_ilu_levels == 0:   # the pressure AMG with the reference's kind of smoother (ILU0) on its two finest levels
-            cpr_sides["cpr_amg_ilu0_smoother"] = guarded("CPR side run (cpr, ILU0-smoothed AMG levels 0-1)", cpr_window("cpr", cpr_amg_ilu_levels=2))
+        if a.cpr_amg_ilu_levels != 0:   # the same with damped Jacobi on every level of the pressure AMG (the library's default smoother)
+            cpr_sides["cpr_amg_jacobi_smoother"] = guarded("CPR side run (cpr, Jacobi-smoothed AMG)", cpr_window("cpr", cpr_amg_ilu_levels=0))
         if a.cpr_reuse_setup == 3:   # Flow's other --cpr-reuse-setup worth a line: the hierarchy's structure follows the state
             # ... rebuilt on a host thread beside the solves (opmhip_config.cpr_async_setup), and - the reference's rule to the letter -
             # by the solve that finds the rule met (0.28 s of host work inside the window where it happens)
@@ -549,9 +549,10 @@ def main():
         # iterations - on a host thread beside the solves (cpr_async_setup = 1: the new structure takes over at the first solve
         # boundary after it is ready) and, "_sync", by the solve itself (0.3 s of host time inside the windows where it happens);
         # the two runs above keep Flow's default 3 (never)
-        # "cpr" with the two finest levels of the pressure AMG smoothed by ILU0 - the reference's AMG smoother - instead of damped Jacobi
-        # (opmhip_config.cpr_amg_ilu_levels = 2)
-        "cpr_amg_ilu0_smoother": cpr_sides.get("cpr_amg_ilu0_smoother"),
+        # the CPR runs smooth level 0 of the pressure AMG with ILU0, the reference's AMG smoother (opmhip_config.cpr_amg_ilu_levels =
+        # --cpr-amg-ilu-levels, default 1 here); "cpr_amg_jacobi_smoother": "cpr" with damped Jacobi on every level instead (the library's default)
+        "cpr_amg_ilu_levels": a.cpr_amg_ilu_levels,
+        "cpr_amg_jacobi_smoother": cpr_sides.get("cpr_amg_jacobi_smoother"),
         "cpr_reuse_setup_2": cpr_sides.get("cpr_reuse_setup_2"),
         "cpr_reuse_setup_2_sync": cpr_sides.get("cpr_reuse_setup_2_sync"),
         "preconditioner": a.preconditioner,

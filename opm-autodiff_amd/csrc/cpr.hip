@@ -620,6 +620,60 @@ __global__ __launch_bounds__(256) void k_cpr_ilu_pack(int n, int W, int MW, int 
     for (; qu < WUc; ++qu) uc[(size_t)qu * n + i] = -1;
     ud[i] = fval[diag[i]];
 }
+// The factorisation of a SIMPLE level (CprIluHost::simple), one colour: lv holds the lower entries a_ij on entry (k_cpr_ilu_pack of the
+// matrix itself) and l_ij = a_ij / u_jj on exit, ud receives 1 / u_ii with u_ii = a_ii - sum_j l_ij a_ji, the lower entries in the row's
+// order - the statements of k_cpr_ilu_factor where nothing but the diagonal is ever updated.  Written like k_cpr_ilu_sweep_fast: the
+// steps of a sequence G at a time, every load independent of what the walk computes (1 / u_jj of the row before travels in a register).
+template <int WQ, int G>
+__global__ __launch_bounds__(64) void k_cpr_ilu_factor_simple(int nseq, int nsteps, const int* __restrict__ rowAt, int n, int wq, const double* __restrict__ val,
+                                                              const int* __restrict__ diag, const int* __restrict__ lc, const int* __restrict__ tpos,
+                                                              double* __restrict__ lv, const double* __restrict__ udg, double* __restrict__ ud) {
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= nseq) return;
+    int iprev = -1;
+    double dprev = 0.0;
+    for (int g0 = 0; g0 < nsteps; g0 += G) {
+        int ri[G];
+#pragma unroll
+        for (int u = 0; u < G; ++u) ri[u] = (g0 + u < nsteps) ? rowAt[(size_t)(g0 + u) * nseq + t] : -1;
+        double a[G][WQ], at[G][WQ], dj[G][WQ], dd[G];
+        int cc[G][WQ];
+#pragma unroll
+        for (int u = 0; u < G; ++u) {
+            const int ic = ri[u] < 0 ? 0 : ri[u];
+#pragma unroll
+            for (int q = 0; q < WQ; ++q) {
+                cc[u][q] = (q < wq && ri[u] >= 0) ? lc[(size_t)q * n + ic] : -1;
+                a[u][q] = q < wq ? lv[(size_t)q * n + ic] : 0.0;
+                const int tp = q < wq ? tpos[(size_t)q * n + ic] : -1;
+                at[u][q] = (tp >= 0 && cc[u][q] >= 0) ? val[tp] : 0.0;
+            }
+            dd[u] = val[diag[ic]];
+        }
+#pragma unroll
+        for (int u = 0; u < G; ++u) {
+            const int nb = u == 0 ? iprev : ri[u - 1];
+#pragma unroll
+            for (int q = 0; q < WQ; ++q) dj[u][q] = (cc[u][q] >= 0 && cc[u][q] != nb) ? udg[cc[u][q]] : 0.0;
+        }
+#pragma unroll
+        for (int u = 0; u < G; ++u) {
+            if (ri[u] < 0) continue;
+            double sdiag = dd[u];
+#pragma unroll
+            for (int q = 0; q < WQ; ++q)
+                if (cc[u][q] >= 0) {
+                    const double l = a[u][q] * (cc[u][q] == iprev ? dprev : dj[u][q]);
+                    lv[(size_t)q * n + ri[u]] = l;
+                    sdiag -= l * at[u][q];
+                }
+            const double inv = 1.0 / sdiag;
+            ud[ri[u]] = inv;
+            iprev = ri[u];
+            dprev = inv;
+        }
+    }
+}
 // One colour of a sweep; a thread walks its sequence of rows.  BWD = false: v_i = d_i - sum over the lower entries, in the row's
 // order; BWD = true: v_i = (v_i - sum over the upper entries) / U_ii, steps in reverse; out != NULL (the backward sweeps of a
 // post-smoothing): out_i = add_i + v_i, the statement "x += t" of the cycle (vfine: and the block vector (0, out_i, 0)).
@@ -808,6 +862,13 @@ struct CprIluHost {
     std::vector<char> fast;
     std::vector<unsigned> mask;
     std::vector<unsigned char> lorder;
+    // simple: a level whose elimination steps touch nothing but the diagonal (no triangles in its graph: step (i, j) finds of row j's
+    // upper entries only (j, i) in row i - a seven-point grid in any of the orderings here), whose couplings inside a colour join
+    // neighbours of a sequence and whose rows hold their lower entries in elimination order: U keeps the matrix's own values,
+    // l_ij = a_ij / u_jj, u_ii = a_ii - sum_j l_ij a_ji - a recurrence along the sequences with loads that depend on nothing it computes
+    // (k_cpr_ilu_factor_simple).  tpos: per lower entry (slot order) the place of the transposed entry (j, i) in the level's image
+    bool simple = false;
+    std::vector<int> tpos;
     std::string error;
 };
 struct CprHostLevel {
@@ -928,6 +989,33 @@ static void cpr_ilu_schedule(const CprHostLevel& L, const std::vector<int>& pos,
             if (c == i || colour[c] != colour[i]) continue;
             if (seqOf[c] != seqOf[i] || std::abs(idxIn[c] - idxIn[i]) != 1) S.fast[colour[i]] = 0;
         }
+    // simple?
+    bool simple = !L.rm;
+    for (int cc = 0; cc < ncol && simple; ++cc) simple = S.fast[cc] != 0;
+    std::vector<int> tpos(simple ? (size_t)S.WL * n : 0, -1);
+    for (int i = 0; i < n && simple; ++i) {
+        int q = 0, lastPos = -1;
+        for (int j = 0; j < L.rlen[i] && simple; ++j) {
+            if (!((S.mask[(size_t)(j >> 5) * n + i] >> (j & 31)) & 1u)) continue;
+            const int cj = L.ecol[at(j, i)];
+            if (pos[cj] < lastPos) simple = false;   // the row's order is not the elimination order
+            lastPos = pos[cj];
+            // row cj's upper entries that row i holds too: must be (cj, i) alone
+            int found = -1;
+            for (int t = 0; t < L.rlen[cj] && simple; ++t) {
+                if (!((S.mask[(size_t)(S.MW + (t >> 5)) * n + cj] >> (t & 31)) & 1u)) continue;
+                const int ct = L.ecol[at(t, cj)];
+                if (ct == i) { found = (int)at(t, cj); continue; }
+                for (int u = 0; u < L.rlen[i]; ++u)
+                    if (L.ecol[at(u, i)] == ct && (int)at(u, i) != L.diag[i] && ct != i) { simple = false; break; }
+            }
+            if (found < 0) simple = false;   // (an unsymmetric pattern)
+            if (simple) tpos[(size_t)q * n + i] = found;
+            ++q;
+        }
+    }
+    S.simple = simple;
+    if (simple) S.tpos = std::move(tpos);
 }
 // greedy multi-colouring of a level's graph in index order, colour-major elimination positions (oracle/cpr.hpp: ilu_factor, colour = true)
 static int cpr_greedy_colours(const CprHostLevel& L, std::vector<int>& colour, std::vector<int>& pos) {
@@ -967,14 +1055,16 @@ static int cpr_upload_ilu(opmhip_ctx* c, const CprIluHost& S, CprLevelDev& L) {
     if ((rc = dev_upload(c, &L.d_imask, S.mask))) return rc;
     if ((rc = dev_upload(c, &L.d_lorder, S.lorder))) return rc;
     if ((rc = dev_upload(c, &L.d_rowAt, S.rowAt))) return rc;
-    if ((rc = dev_alloc(c, &L.d_fval, (size_t)L.W * L.n))) return rc;
+    L.iluSimple = S.simple;
+    if (S.simple) { if ((rc = dev_upload(c, &L.d_tpos, S.tpos))) return rc; }
+    else if ((rc = dev_alloc(c, &L.d_fval, (size_t)L.W * L.n))) return rc;
     if ((rc = dev_alloc(c, &L.d_t, (size_t)L.n))) return rc;
     L.ilu = true;
     return OPMHIP_SUCCESS;
 }
 static void cpr_free_ilu(opmhip_ctx* c, CprLevelDev& L) {
     dev_free(c, &L.d_imask); dev_free(c, &L.d_lorder); dev_free(c, &L.d_rowAt); dev_free(c, &L.d_fval); dev_free(c, &L.d_t);
-    dev_free(c, &L.d_ilv); dev_free(c, &L.d_ilc); dev_free(c, &L.d_iuv); dev_free(c, &L.d_iuc); dev_free(c, &L.d_iud);
+    dev_free(c, &L.d_ilv); dev_free(c, &L.d_ilc); dev_free(c, &L.d_iuv); dev_free(c, &L.d_iuc); dev_free(c, &L.d_iud); dev_free(c, &L.d_tpos);
     L.ilu = false;
 }
 // nvec: entries of the level's vectors (level 0 of a rank whose pressure stage spans the ranks: ghost cells included)
@@ -1579,6 +1669,18 @@ static int cpr_update_values(opmhip_ctx* c, CprDev& R) {
     for (size_t l = 0; l < R.lv.size(); ++l) {
         CprLevelDev& L = R.lv[l];
         hipLaunchKernelGGL(k_cpr_dinv, g256(L.n), dim3(256), 0, c->stream, L.n, L.d_diag, L.d_val, L.d_dinv);
+        if (cpr_ilu_active(R, l) && L.iluSimple) {   // scalar ILU0 of a level without triangles: the sweeps' images straight from the matrix, then the recurrence
+            hipLaunchKernelGGL(k_cpr_ilu_pack, g256(L.n), dim3(256), 0, c->stream, L.n, L.W, L.iluMW, 0, L.iluWL, L.iluWU, L.d_ecol, L.d_rlen, L.d_diag, L.d_imask, L.d_val,
+                               L.d_ilv, L.d_ilc, L.d_iuv, L.d_iuc, L.d_iud);
+            for (size_t cc = 0; cc < L.iluNseq.size(); ++cc) {
+                const int nseq = L.iluNseq[cc], wq = L.iluWl[cc];
+                if (nseq == 0) continue;
+                const dim3 grid((nseq + 63) / 64);
+#define CPR_FS(WQ, G) hipLaunchKernelGGL((k_cpr_ilu_factor_simple<WQ, G>), grid, dim3(64), 0, c->stream, nseq, L.iluNsteps[cc], L.d_rowAt + L.iluOff[cc], L.n, wq, L.d_val, L.d_diag, L.d_ilc, L.d_tpos, L.d_ilv, (const double*)L.d_iud, L.d_iud)
+                if (wq <= 1) CPR_FS(1, 12); else if (wq <= 2) CPR_FS(2, 12); else if (wq <= 4) CPR_FS(4, 10); else if (wq <= 6) CPR_FS(6, 8); else CPR_FS(8, 6);
+#undef CPR_FS
+            }
+        } else
         if (cpr_ilu_active(R, l)) {   // scalar ILU0 of the level, colour by colour
             OPMHIP_HIP(c, hipMemcpyAsync(L.d_fval, L.d_val, (size_t)L.W * L.n * sizeof(double), hipMemcpyDeviceToDevice, c->stream));
             for (size_t cc = 0; cc < L.iluNseq.size(); ++cc) {

@@ -223,6 +223,8 @@ struct CprLevelDev {
     double *d_fval = nullptr, *d_t = nullptr;
     double *d_ilv = nullptr, *d_iuv = nullptr, *d_iud = nullptr;   // what the sweeps read: lower entries [iluWL][n], upper entries [iluWU][n], 1 / U_ii
     int *d_ilc = nullptr, *d_iuc = nullptr;                        // their columns (-1: none)
+    bool iluSimple = false;                                        // no elimination step touches anything but a diagonal: k_cpr_ilu_factor_simple
+    int* d_tpos = nullptr;                                         // simple levels: per lower entry the place of the transposed entry in the level's image
     std::vector<int> iluWl, iluWu;                                 // per colour: lower / upper entries per row at most
     unsigned* d_imask = nullptr;                                   // [2 * iluMW][n]: lower words, then upper words
     unsigned char* d_lorder = nullptr;                             // [iluWL][n], 255 = none
