@@ -4,6 +4,7 @@ against the oracle in the device's ordering, and the solve's iteration count."""
 import numpy as np
 import pytest
 
+import oracle_bind
 from helpers import oracle_solve_in_order
 
 pytestmark = pytest.mark.gpu
@@ -116,3 +117,30 @@ def test_line_colouring_rejects_chains_beyond_the_step_limit(pkg):
     with pytest.raises(pkg.capi.OpmHipError) as e:
         sol.set_pattern(n, rp, ci)
     assert e.value.code == pkg.capi.ANALYSIS_FAILED
+
+
+@pytest.mark.parametrize("reorder", ["graph_coloring", "line_coloring", "level_scheduling"])
+@pytest.mark.parametrize("kind,n,seed", [("random", 333, 2), ("random", 2500, 3), ("banded", 1500, 8), ("path", 1000, 6), ("isolated", 300, 7), ("random", 1, 9), ("path", 2, 10)])
+def test_cpr_with_ilu0_smoothed_amg_levels_on_random_graphs(pkg, orc, kind, n, seed, reorder):
+    """opmhip_config.cpr_amg_ilu_levels on patterns with triangles, rows of 1 to 20 entries, isolated rows, hierarchies of one level: the
+    general scalar factorisation (these levels are not `simple`), sweeps over many colours - the application of the preconditioner is the
+    oracle's bit for bit"""
+    rng = np.random.default_rng(seed)
+    rp, ci, v = graph(kind, n, rng)
+    s = pkg.capi.HipSolver(tolerance=1e-8, maxit=200, reorder=reorder, preconditioner="cpr_quasiimpes", cpr_amg_ilu_levels=2)
+    s.set_pattern(n, rp, ci)
+    s.upload_system(v)
+    s.ilu0_factor(want_factors=False)
+    to, fr, _ = s.ordering()
+    rr, rc, rv = orc.reorder_matrix(n, rp, ci, v, to, fr)
+    cpr = oracle_bind.OracleCpr(orc)
+    cpr.set_natural_ids(fr)
+    cpr.set_ilu_smoother(2, 1)
+    cpr.update(n, rr, rc, rv)
+    d = rng.standard_normal(3 * n)
+    vo = cpr.apply(np.ascontiguousarray(d.reshape(n, 3)[fr].reshape(-1))).reshape(n, 3)[to].reshape(-1)
+    assert np.array_equal(s.cpr_apply(d), vo)
+    b = rng.standard_normal(3 * n)
+    r = s.solve_system(n, rp, ci, v.copy(), b)
+    assert r.converged
+    assert np.linalg.norm(orc.spmv(n, rp, ci, v, s.get_result()) - b) <= 1e-7 * np.linalg.norm(b)
