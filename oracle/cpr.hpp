@@ -75,6 +75,7 @@ struct CprAmg {
     // of the level's graph, colour by colour (what a device sweep of an irregular coarse level would need)
     int iluLevels = 0;
     int iluColourFrom = 1 << 30;   // levels >= iluColourFrom eliminate in greedy multi-colour order
+    bool iluAlways0 = false;       // level 0 is factored even where it is the hierarchy's only level (a subdomain whose level 0 itself joins the other subdomains')
     // decomposed runs (orc_cpr_solve_blocks with gather_rows): the hierarchy of a subdomain ends at its first level of at most stopRows
     // rows, and that level is not solved here (external): its right-hand side joins those of the other subdomains (vcycle_down), the
     // joined system is cycled on, and the subdomain's slice of the result comes back (vcycle_up)
@@ -226,7 +227,7 @@ struct CprAmg {
             AmgLevel& L = lv[l];
             L.dinv.resize(L.A.n);
             for (int i = 0; i < L.A.n; ++i) L.dinv[i] = 1.0 / L.A.val[L.diag[i]];
-            if ((int)l < iluLevels && l + 1 < lv.size()) ilu_factor(L, (int)l >= iluColourFrom);
+            if ((int)l < iluLevels && (l + 1 < lv.size() || (l == 0 && iluAlways0))) ilu_factor(L, (int)l >= iluColourFrom);
             else L.ilu.clear();
             if (l + 1 < lv.size()) {
                 Csr& C = lv[l + 1].A;

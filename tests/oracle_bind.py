@@ -47,7 +47,7 @@ class Oracle:
         L.orc_cpr_solve.argtypes = [_vp, C.c_int, _i, _i, _d, _d, _d, C.c_double, C.c_int, C.c_int, C.POINTER(OrcResult)]
         L.orc_cpr_update.argtypes = [_vp, C.c_int, _i, _i, _d]
         L.orc_cpr_solve_blocks.argtypes = [C.c_int, _i, _i, _d, _d, _d, _i, C.c_int, _vp, _vp, C.c_double, C.c_int, C.c_int, _vp, C.POINTER(OrcResult),
-                                           C.c_int, _vp, _vp, _vp, _vp]
+                                           C.c_int, _vp, _vp, _vp, _vp, C.c_int]
         L.orc_cpr_apply.argtypes = [_vp, _d, _d]
         L.orc_cpr_levels.argtypes = [_vp, _i, _i, C.c_int]
         L.orc_cpr_weights.argtypes = [_vp, _d]
@@ -81,7 +81,7 @@ class Oracle:
         return to, fr, rpc[:nc].copy()
 
     def cpr_solve_blocks(self, Nb, rowptr, col, val, b, owner, weights=None, natural=None, tol=1e-2, maxit=200, zero_diag_fix=True,
-                         gather_rows=-1, probe=None):
+                         gather_rows=-1, probe=None, ilu_levels=0):
         """BiCGStab on the global system, one CPR per subdomain (owner id per row) as preconditioner -> (x, result, levels per subdomain).
         gather_rows >= 0: the subdomains' hierarchies end at their first level of at most that many rows (0: 100 000) and are continued on
         the joined system -> (x, result, levels per subdomain, rows of the joined hierarchy's levels[, M^-1 probe])"""
@@ -97,7 +97,7 @@ class Oracle:
         pd = None if probe is None else np.ascontiguousarray(probe, np.float64)
         pv = None if probe is None else np.zeros(Nb * 3)
         rc = self.lib.orc_cpr_solve_blocks(Nb, rowptr, col, val, np.ascontiguousarray(b, np.float64), x, owner, nown, _p(w), _p(nat), tol, maxit,
-                                           int(zero_diag_fix), _p(lev), C.byref(res), int(gather_rows), _p(glev), _p(ngl), _p(pd), _p(pv))
+                                           int(zero_diag_fix), _p(lev), C.byref(res), int(gather_rows), _p(glev), _p(ngl), _p(pd), _p(pv), int(ilu_levels))
         assert rc == 0, rc
         if gather_rows < 0 and probe is None:
             return x, res, lev
