@@ -42,7 +42,7 @@ public:
     /// ISTLSolverEbos::getTrueImpesWeights (ISTLSolverEbos.hpp:466-475) to setCprWeights() before each solve.
     hipSolverBackend(int linear_solver_verbosity, int maxit_, double tolerance_, unsigned int deviceID_,
                      const std::string& ilu_reorder = "graph_coloring", double ilu_relaxation = 0.9,
-                     const std::string& linsolver = "ilu0", int cpr_reuse_setup = 3)
+                     const std::string& linsolver = "ilu0", int cpr_reuse_setup = 3, int cpr_amg_ilu_levels = -1, int cpr_gather_rows = 0)
         : Base(linear_solver_verbosity, maxit_, tolerance_, deviceID_) {
         static_assert(block_size == 3, "libopmhip handles 3x3 blocks (three-phase black-oil)");
         opmhip_config cfg;
@@ -62,6 +62,12 @@ public:
         // --cpr-reuse-setup (FlowLinearSolverParameters.hpp:212-214).  The library acts on 0 (every solve) and 2 (after a solve of
         // more than 10 iterations) by itself; 1 (first Newton iteration of a time step) is the caller's to signal: recreateCprHierarchy()
         cfg.cpr_reuse_setup = cpr_reuse_setup;
+        // The reference's pressure AMG smooths with ILU0 on every level (PreconditionerFactory.hpp:126-151).  Here: on the
+        // cpr_amg_ilu_levels finest levels; < 0 = this plug-in's choice: level 0 where the block ILU0 is line-coloured (two colours:
+        // four sweep launches per application, +5 ... +8 % Newton iterations/s on the 100^3 case), Jacobi elsewhere (level 0's sweeps follow
+        // the block ILU0's colours: with level scheduling that would be hundreds of launches)
+        cfg.cpr_amg_ilu_levels = cpr_amg_ilu_levels >= 0 ? cpr_amg_ilu_levels : (cfg.reorder == OPMHIP_REORDER_LINE_COLORING ? 1 : 0);
+        cfg.cpr_gather_rows = cpr_gather_rows;   // parallel runs: the pressure stage spans the ranks (0: default size of the joined level; < 0: off)
         const int rc = opmhip_create(&cfg, &ctx);
         if (rc != OPMHIP_SUCCESS) throw std::logic_error(std::string("hipSolverBackend: ") + opmhip_last_error(nullptr));
     }
