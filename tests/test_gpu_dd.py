@@ -658,3 +658,56 @@ def test_dd_cpr_pressure_stage_on_an_irregular_graph(pkg, orc, rows):
         assert levels[-len(glev):] == glev
         assert np.array_equal(v[:3 * c["Nb"]].reshape(-1, 3), pv[c["gids"][:c["Nb"]]]), r
         assert ok and abs(it - reso.it) <= 1.0, (it, reso.it)
+
+
+def test_dd_cpr_pressure_stage_rebuilt_with_the_structure(pkg, orc):
+    """--cpr-reuse-setup=0 with the pressure stage that spans the ranks: every solve builds the ranks' hierarchies AND the joined level
+    anew, all ranks together - after a second Newton iteration every rank's application is the oracle's built from the second matrix"""
+    world, n, rows = 2, 8, 60
+    g, owner, parts = global_and_parts(pkg, n, world, state="mixed", heterogeneous=True)
+    src = pkg.decks.five_spot_source(g, rate_sm3_per_day=30.0)
+    dt = 5 * 86400.0
+    o = oracle_bind.OracleModel(orc, g)
+    o.set_state(g["pv"], g["meaning"])
+    o.set_source(src)
+    probe = np.random.default_rng(9).standard_normal(3 * g["Nb"])
+    group = "s" + uuid.uuid4().hex
+
+    def rank_fn(r):
+        c = parts[r]
+        Nb = c["Nb"]
+        m = pkg.capi.HipModel(c, comm=("loopback", world, r, group), reorder="line_coloring", preconditioner="cpr_quasiimpes", tolerance=1e-4, cpr_gather_rows=rows, cpr_reuse_setup=0)
+        m.set_state(c["pv"], c["meaning"])
+        m.set_source(np.ascontiguousarray(src.reshape(-1, 3)[c["gids"]].reshape(-1)))
+        its = []
+        for it in range(2):
+            m.assemble(dt, it, fetch=False)
+            sol = m.solve_jacobian_system()
+            its.append((sol.it, sol.converged))
+            if it == 0:
+                m.update(None, 1.0)
+        d = np.ascontiguousarray(probe.reshape(-1, 3)[c["gids"][:Nb]].reshape(-1))
+        v = m.cpr_apply(d)
+        j2, _ = m.assemble(dt, 1)   # the second Jacobian once more, fetched: what the oracle builds its structure from
+        return its, v, m.ordering(), m.cpr_levels()[0], j2
+
+    outs = run_ranks(world, rank_fn)
+    assert all(ok for its, *_ in outs for _, ok in its)
+    assert outs[0][0] == outs[1][0]                                   # the ranks agree on the iteration history
+    # the global second Jacobian from the ranks' owned rows, then the oracle's preconditioner built from it
+    j2g = np.zeros((len(g["col"]), 9))
+    for r in range(world):
+        j2g[parts[r]["halo"]["entry_global"]] = outs[r][4].reshape(-1, 9)
+    j2g = np.ascontiguousarray(j2g.reshape(-1))
+    frg = np.concatenate([np.asarray(parts[r]["gids"][:parts[r]["Nb"]])[outs[r][2][1]] for r in range(world)]).astype(np.int32)
+    tog = np.empty_like(frg)
+    tog[frg] = np.arange(len(frg), dtype=np.int32)
+    gr, gc, gv = orc.reorder_matrix(g["Nb"], g["rowptr"], g["col"], j2g, tog, frg)
+    b = np.random.default_rng(1).standard_normal(3 * g["Nb"])
+    _, _, lev, glev, pv = orc.cpr_solve_blocks(g["Nb"], gr, gc, gv, b, np.asarray(owner)[frg], natural=frg, tol=1e-2, gather_rows=rows,
+                                               probe=np.ascontiguousarray(probe.reshape(-1, 3)[frg].reshape(-1)))
+    pv = pv.reshape(-1, 3)[tog]
+    for r in range(world):
+        c = parts[r]
+        assert outs[r][3][-len(glev):] == glev
+        assert np.array_equal(outs[r][1][:3 * c["Nb"]].reshape(-1, 3), pv[c["gids"][:c["Nb"]]]), r
