@@ -293,7 +293,8 @@ def test_cpr_reuse_setup_modes(pkg, orc, mode):
         assert s.cpr_levels() == lv1
 
 
-def test_cpr_rebuild_beside_the_solves(pkg, orc):
+@pytest.mark.parametrize("ilu", [0, 2])
+def test_cpr_rebuild_beside_the_solves(pkg, orc, ilu):
     """--cpr-reuse-setup=2 with opmhip_config.cpr_async_setup: the solve that meets the rule (> 10 iterations) keeps the structure
     it has and a host thread builds the new one from ITS matrix; a later solve swaps it in.  Once swapped in, the preconditioner
     is the oracle's CPR with the structure of the triggering matrix and the values of the matrix in hand, bit for bit."""
@@ -301,7 +302,7 @@ def test_cpr_rebuild_beside_the_solves(pkg, orc):
     case, jac1, res1 = jacobian_case(pkg, orc, its=1)
     _, jac2, res2 = jacobian_case(pkg, orc, dt_days=40.0, its=3)
     Nb, rp, ci = case["Nb"], case["rowptr"], case["col"]
-    s = pkg.capi.HipSolver(reorder="line_coloring", preconditioner="cpr_quasiimpes", tolerance=1e-10, maxit=100, cpr_reuse_setup=2, cpr_async_setup=1)
+    s = pkg.capi.HipSolver(reorder="line_coloring", preconditioner="cpr_quasiimpes", tolerance=1e-10, maxit=100, cpr_reuse_setup=2, cpr_async_setup=1, cpr_amg_ilu_levels=ilu)
     r1 = s.solve_system(Nb, rp, ci, jac1.copy(), res1)        # first solve: synchronous set-up from jac1; a long solve
     assert r1.converged and r1.iterations > 10
     d = np.random.default_rng(5).standard_normal(3 * Nb)
@@ -311,10 +312,14 @@ def test_cpr_rebuild_beside_the_solves(pkg, orc):
     _, _, rr2, rc2, rv2 = reordered(orc, s, Nb, rp, ci, jac2)
     old = oracle_bind.OracleCpr(orc)
     old.set_natural_ids(fr)
+    if ilu:
+        old.set_ilu_smoother(ilu, 1)   # (the schedules of the levels below level 0 are part of what the host thread builds)
     old.update(Nb, rr1, rc1, rv1)
     old.update(Nb, rr2, rc2, rv2)                             # structure of jac1, values of jac2
     new = oracle_bind.OracleCpr(orc)
     new.set_natural_ids(fr)
+    if ilu:
+        new.set_ilu_smoother(ilu, 1)
     new.update(Nb, rr2, rc2, rv2)                             # structure and values of jac2
     d_int = np.ascontiguousarray(d.reshape(Nb, 3)[fr].reshape(-1))
     v_old = old.apply(d_int).reshape(Nb, 3)[to].reshape(-1)
