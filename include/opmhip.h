@@ -228,7 +228,10 @@ int opmhip_cpr_recreate(opmhip_ctx* ctx);
 int opmhip_get_cpr_weights(opmhip_ctx* ctx, double* weights);
 
 /* v = M_cpr^-1 d with the CPR preconditioner of the matrix now on the device (contexts created with a CPR preconditioner;
- * needs opmhip_ilu0_factor first: the fine smoother's factors) - for parity tests of the preconditioner alone */
+ * needs opmhip_ilu0_factor first: the fine smoother's factors) - for parity tests of the preconditioner alone.  It refreshes the
+ * hierarchy's values but does not advance the --cpr-reuse-setup rules.  In decomposed runs with opmhip_config.cpr_gather_rows >= 0
+ * it is a COLLECTIVE like opmhip_solve_system: every rank must call it (the joined level's values and right-hand side are
+ * all-gathered); a rank that fails before it reaches a collective leaves its peers waiting, as with any MPI-style exchange. */
 int opmhip_cpr_apply(opmhip_ctx* ctx, const double* d, double* v);
 /* the ordering chosen at set_pattern: toOrder/fromOrder [Nb], rowsPerColor [num colours] (any may be NULL);
  * returns the number of colours/levels or a negative status */
