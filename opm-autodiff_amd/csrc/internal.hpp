@@ -503,6 +503,7 @@ int comm_halo_f64(opmhip_ctx* c, double* vec, int w, hipStream_t s = nullptr);  
 int comm_halo_begin(opmhip_ctx* c, double* vec);   // 3 doubles per cell: the exchange on the halo stream, ordered behind the main stream's work so far
 int comm_halo_end(opmhip_ctx* c);                  // the main stream waits for it
 int comm_halo_u8(opmhip_ctx* c, unsigned char* vec);
+void comm_halo_bystander(opmhip_ctx* c);           // a rank without neighbours, where its peers exchange (loopback: their barriers count every rank)
 void comm_release(opmhip_ctx* c);
 // assemble.hip launchers
 void launch_iq_update(opmhip_ctx* c);

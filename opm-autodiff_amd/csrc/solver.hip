@@ -1943,6 +1943,7 @@ int launch_spmv(opmhip_ctx* c, double* x, double* y, int ndot, const double* w0,
     const bool wells = c->wells.num_wells > 0;
     const int fused = spmv_dots_separate(c) ? 0 : ndot;
     const bool halo = exchange && c->comm.halo_set && c->comm.nneigh > 0;
+    if (exchange && !halo && c->comm.nranks > 1) comm_halo_bystander(c);   // a subdomain that touches no other: nothing to exchange, but the peers' exchange counts this rank in (loopback)
     const int nInt = P.tiles.nschedInt, nBnd = P.tiles.nsched - nInt;
     int rc, cnt = 0;
     if (halo && nBnd > 0) {

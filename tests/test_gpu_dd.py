@@ -28,7 +28,7 @@ def run_ranks(world, fn):
     for t in ts:
         t.start()
     for t in ts:
-        t.join(timeout=300)
+        t.join(timeout=120)
     for e in err:
         if e is not None:
             raise e
@@ -711,3 +711,56 @@ def test_dd_cpr_pressure_stage_rebuilt_with_the_structure(pkg, orc):
         c = parts[r]
         assert outs[r][3][-len(glev):] == glev
         assert np.array_equal(outs[r][1][:3 * c["Nb"]].reshape(-1, 3), pv[c["gids"][:c["Nb"]]]), r
+
+
+@pytest.mark.parametrize("prec", ["ilu0", "cpr_quasiimpes"])
+def test_dd_a_rank_without_neighbours(pkg, orc, prec):
+    """three ranks, the third owns a part of the reservoir that touches no other (two grids in one system): it has no halo, its
+    peers have - every exchange, all-reduce and (CPR) all-gather still counts it in.  The ranks agree on the iteration history and
+    hold a solution of the whole system."""
+    a = pkg.decks.cartesian_case(8, 6, 4, state="mixed", heterogeneous=True)
+    b = pkg.decks.cartesian_case(5, 4, 3, state="mixed", heterogeneous=True)
+    na = a["Nb"]
+    g = dict(Nb=na + b["Nb"], fluid=a["fluid"],
+             rowptr=np.concatenate([a["rowptr"], a["rowptr"][-1] + b["rowptr"][1:]]).astype(np.int32),
+             col=np.concatenate([a["col"], b["col"] + na]).astype(np.int32))
+    for k in ("trans", "area"):
+        g[k] = np.concatenate([a[k], b[k]])
+    for k in ("poro", "volume", "depth", "meaning"):
+        g[k] = np.concatenate([a[k], b[k]])
+    g["pv"] = np.concatenate([a["pv"], b["pv"]])
+    owner = np.concatenate([(np.arange(na) >= na // 2).astype(np.int32), np.full(b["Nb"], 2, np.int32)])
+    world = 3
+    o = oracle_bind.OracleModel(orc, g)
+    o.set_state(g["pv"], g["meaning"])
+    dt = 5 * 86400.0
+    jo, ro = o.assemble(dt, 0)
+    group = "b" + uuid.uuid4().hex
+    parts = []
+    for r in range(world):
+        lp = pkg.ras.local_problem(g["rowptr"], g["col"], owner, r)
+        cells = lp["cells"]
+        parts.append(dict(Nb=lp["Nown"], Nghost=lp["Nghost"], Nloc=lp["Nown"] + lp["Nghost"], rowptr=lp["rows"], col=lp["cols"],
+                          trans=np.ascontiguousarray(g["trans"][lp["entry"]]), area=np.ascontiguousarray(g["area"][lp["entry"]]),
+                          poro=np.ascontiguousarray(g["poro"][cells]), volume=np.ascontiguousarray(g["volume"][cells]),
+                          depth=np.ascontiguousarray(g["depth"][cells]), fluid=g["fluid"],
+                          pv=np.ascontiguousarray(g["pv"].reshape(-1, 3)[cells].reshape(-1)), meaning=np.ascontiguousarray(g["meaning"][cells]),
+                          gids=lp["gids"], halo=lp, global_cells=g["Nb"]))
+    assert parts[2]["Nghost"] == 0 and parts[0]["Nghost"] > 0
+
+    def rank_fn(r):
+        c = parts[r]
+        m = pkg.capi.HipModel(c, comm=("loopback", world, r, group), reorder="line_coloring", preconditioner=prec, tolerance=1e-6, cpr_gather_rows=40)
+        m.set_state(c["pv"], c["meaning"])
+        m.assemble(dt, 0, fetch=False)
+        sol = m.solve_jacobian_system()
+        return sol.it, sol.converged, m.get_result()
+
+    outs = run_ranks(world, rank_fn)
+    assert all(o_ is not None for o_ in outs), "a rank never came back: the exchange lost count of the rank without neighbours"
+    assert len({o_[0] for o_ in outs}) == 1 and all(o_[1] for o_ in outs)
+    x = np.zeros((g["Nb"], 3))
+    for r in range(world):
+        c = parts[r]
+        x[c["gids"][:c["Nb"]]] = outs[r][2].reshape(-1, 3)[:c["Nb"]]
+    assert np.linalg.norm(orc.spmv(g["Nb"], g["rowptr"], g["col"], jo, x.reshape(-1)) - ro) < 1e-6 * np.linalg.norm(ro) * 1.001
