@@ -41,3 +41,31 @@ def test_bad_config_rejected(pkg):
     h = C.c_void_p()
     assert L.opmhip_create(C.byref(cfg), C.byref(h)) == pkg.capi.INVALID_ARGUMENT
     assert b"ABI" in L.opmhip_last_error(None)
+
+
+def test_ctypes_structs_match_the_header(pkg, tmp_path):
+    """the Python binding's opmhip_config / opmhip_result mirror the C structs field by field: size and every offset, as a C compiler
+    sees include/opmhip.h (a field added on one side only would shift everything behind it silently)"""
+    import ctypes
+    import os
+    import subprocess
+    ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    cfg_fields = [f[0] for f in pkg.capi.Config._fields_]
+    res_fields = [f[0] for f in pkg.capi.Result._fields_]
+    src = tmp_path / "layout.c"
+    lines = ['#include <stddef.h>', '#include <stdio.h>', '#include "opmhip.h"', 'int main(void) {',
+             '  printf("config %zu\\n", sizeof(opmhip_config));', '  printf("result %zu\\n", sizeof(opmhip_result));']
+    for f in cfg_fields:
+        lines.append('  printf("config.%s %%zu\\n", offsetof(opmhip_config, %s));' % (f, f))
+    for f in res_fields:
+        lines.append('  printf("result.%s %%zu\\n", offsetof(opmhip_result, %s));' % (f, f))
+    lines += ['  return 0;', '}']
+    src.write_text("\n".join(lines))
+    exe = tmp_path / "layout"
+    subprocess.check_call(["gcc", "-I", os.path.join(ROOT, "include"), "-o", str(exe), str(src)])
+    out = dict(l.split() for l in subprocess.check_output([str(exe)], text=True).splitlines())
+    assert int(out["config"]) == ctypes.sizeof(pkg.capi.Config) and int(out["result"]) == ctypes.sizeof(pkg.capi.Result)
+    for f in cfg_fields:
+        assert int(out["config." + f]) == getattr(pkg.capi.Config, f).offset, f
+    for f in res_fields:
+        assert int(out["result." + f]) == getattr(pkg.capi.Result, f).offset, f
