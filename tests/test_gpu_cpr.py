@@ -135,14 +135,15 @@ def test_cpr_on_a_laplace_like_block_system(pkg, orc):
     assert np.linalg.norm(orc.spmv(Nb, rp, ci, v, x) - b) <= 1e-7 * np.linalg.norm(b)
 
 
-def test_newton_loop_with_cpr(pkg, orc):
+@pytest.mark.parametrize("ilu", [0, 1])
+def test_newton_loop_with_cpr(pkg, orc, ilu):
     """the same time step solved with ILU0 and with CPR inside the device-resident Newton loop: about the same number of
     Newton iterations, the same state to Newton tolerance; CPR needs fewer linear iterations in total"""
     case = pkg.decks.cartesian_case(24, 24, 18, state="mixed", heterogeneous=True)
     src = pkg.decks.five_spot_source(case, rate_sm3_per_day=40.0)
     out = {}
     for prec in ("ilu0", "cpr_quasiimpes"):
-        m = pkg.capi.HipModel(case, reorder="line_coloring", preconditioner=prec)
+        m = pkg.capi.HipModel(case, reorder="line_coloring", preconditioner=prec, cpr_amg_ilu_levels=ilu)   # (ilu: level 0 of the pressure AMG smoothed by ILU0, what bench.py's CPR runs use)
         m.set_state(case["pv"], case["meaning"])
         m.set_source(src)
         rep = pkg.newton.BlackoilModelHip(m).step(10 * 86400.0)
