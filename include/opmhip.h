@@ -48,10 +48,14 @@ typedef enum opmhip_reorder {
     OPMHIP_REORDER_LEVEL_SCHEDULING = 1, /* same factors as the CPU's natural-order ILU0 (bda/Reorder.cpp:266-318) */
     OPMHIP_REORDER_GRAPH_COLORING = 2,   /* Jones-Plassmann rounds, deterministic weights (bda/Reorder.cpp:59-172) */
     OPMHIP_REORDER_GRAPH_COLORING_GREEDY = 3, /* first-fit colouring: red-black on Cartesian 7-point grids */
-    OPMHIP_REORDER_LINE_COLORING = 4 /* chains of <= config.chain_length (default 8) rows along each row's farthest
+    OPMHIP_REORDER_LINE_COLORING = 4, /* chains of <= config.chain_length (default 8) rows along each row's farthest
                                         neighbour (the vertical one in CpGrid's natural order), chains coloured greedily:
                                         an exact ILU0 of that ordering, near the natural order's strength at colouring's
                                         parallelism (no counterpart in the reference) */
+    OPMHIP_REORDER_AUTO = 5          /* line colouring (chains of 10) where it pays - a structured grid in its natural order of at least
+                                        150 000 rows - and the greedy colouring elsewhere: the chain sweeps walk their 8-10 steps one after
+                                        the other, which a small system cannot hide (a 44 777-cell corner-point grid: 31 Newton its/s
+                                        line-coloured, 259 greedy; regular grids below ~125 000 cells likewise).  ABI 7 */
 } opmhip_reorder;
 
 /* --linear-solver-configuration (linalg/setupPropertyTree.cpp:62-76).  The CPR variants: pressure system solved by one AMG

@@ -16,7 +16,7 @@ HEADER_PATH = os.path.join(os.path.dirname(HERE), "include", "opmhip.h")
 SUCCESS = 0
 ANALYSIS_FAILED, CREATE_PRECONDITIONER_FAILED, UNKNOWN_ERROR = -1, -2, -3
 INVALID_ARGUMENT, NOT_READY, DEVICE_ERROR, NO_DEVICE = -4, -5, -6, -7
-REORDER = {"level_scheduling": 1, "graph_coloring": 2, "graph_coloring_greedy": 3, "line_coloring": 4}
+REORDER = {"level_scheduling": 1, "graph_coloring": 2, "graph_coloring_greedy": 3, "line_coloring": 4, "auto": 5}
 RELAX = {"post_scale": 0, "in_sweep": 1}
 PRECONDITIONER = {"ilu0": 0, "cpr_quasiimpes": 1, "cpr": 2, "cpr_trueimpes": 2}   # opmhip_preconditioner
 
@@ -149,7 +149,7 @@ class HipSolver:
     ctor(verbosity, maxit, tolerance, deviceID), solve_system(...), get_result(x))."""
 
     def __init__(self, verbosity=0, maxit=200, tolerance=1e-2, device_id=0, ilu_relaxation=0.9,
-                 relax_mode="post_scale", reorder="graph_coloring", zero_diag_fix=True, chain_length=8, spmv_pipe_wgs=0,
+                 relax_mode="post_scale", reorder="graph_coloring", zero_diag_fix=True, chain_length=0, spmv_pipe_wgs=0,
                  preconditioner="ilu0", cpr_reuse_setup=3, cpr_async_setup=0, cpr_amg_ilu_levels=0, cpr_gather_rows=0):
         L = lib()
         cfg = Config()
@@ -159,7 +159,7 @@ class HipSolver:
         cfg.relax_mode = RELAX[relax_mode]
         cfg.reorder = REORDER[reorder]
         cfg.zero_diag_fix = int(zero_diag_fix)
-        cfg.chain_length = int(chain_length)  # line colouring: rows per chain
+        cfg.chain_length = int(chain_length)  # line colouring: rows per chain (0: the library's default, 8; 10 with reorder="auto")
         cfg.spmv_pipe_wgs = int(spmv_pipe_wgs)  # pipelined SpMV: workgroups it is sized for (0 default, < 0 off; tests use small values)
         # --linear-solver-configuration (setupPropertyTree.cpp:62-76): "cpr" is short for cpr_trueimpes, as in Flow
         cfg.preconditioner = PRECONDITIONER[preconditioner]

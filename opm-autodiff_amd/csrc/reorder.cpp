@@ -403,7 +403,33 @@ int build_pattern(opmhip_ctx* c, int Nb, int Nghost, int nnzb, const int* rows, 
     int ncol = 0;
     Chains CH;
     std::vector<int> chainColor;
-    const bool chained = (c->cfg.reorder == OPMHIP_REORDER_LINE_COLORING);
+    // OPMHIP_REORDER_AUTO: the line colouring where it pays, the greedy colouring elsewhere.  Measured (tools/ordering_by_size.py,
+    // tools/config_rates.py): the chain kernels walk a chain-tile's 8-10 steps one after the other, each step a few
+    // dependent rounds of loads - on 10^6 rows eight workgroups per CU hide that, on a small system nothing does (44 777-cell corner-point
+    // grid: 31 Newton its/s line-coloured, 259 greedy; regular grids: the greedy colouring wins below ~125 000 cells although it needs
+    // twice the iterations), and on an irregular pattern the sweeps lose their stencil form as well.  Line colouring: at least
+    // AUTO_LINE_MIN_ROWS rows, rows of at most 8 blocks, at most 15 distinct column offsets (col - row) in the natural order - a
+    // structured grid handed over in its natural order.
+    int kind = c->cfg.reorder;
+    if (kind == OPMHIP_REORDER_AUTO) {
+        constexpr int AUTO_LINE_MIN_ROWS = 150000;
+        bool regular = Nb >= AUTO_LINE_MIN_ROWS;
+        std::vector<int> offs;
+        for (int i = 0; i < Nb && regular; ++i) {
+            if (rows[i + 1] - rows[i] > 8) regular = false;
+            for (int k = rows[i]; k < rows[i + 1] && regular; ++k) {
+                if (cols[k] >= Nb) continue;
+                const int o = cols[k] - i;
+                if (std::find(offs.begin(), offs.end(), o) == offs.end()) {
+                    offs.push_back(o);
+                    if (offs.size() > 15) regular = false;
+                }
+            }
+        }
+        kind = regular ? OPMHIP_REORDER_LINE_COLORING : OPMHIP_REORDER_GRAPH_COLORING_GREEDY;
+        if (c->cfg.verbosity > 0) std::fprintf(stderr, "opmhip: reorder auto -> %s (%d rows)\n", regular ? "line_coloring" : "graph_coloring_greedy", Nb);
+    }
+    const bool chained = (kind == OPMHIP_REORDER_LINE_COLORING);
     int maxLen = 1;
     // the ordering is computed on the owned-owned couplings only
     Pattern Q;
@@ -415,12 +441,12 @@ int build_pattern(opmhip_ctx* c, int Nb, int Nghost, int nnzb, const int* rows, 
         Q.nat_rowptr[i + 1] = (int)Q.nat_col.size();
     }
     Q.nnzb = (int)Q.nat_col.size();
-    switch (c->cfg.reorder) {
+    switch (kind) {
         case OPMHIP_REORDER_LEVEL_SCHEDULING: levels(Q, color, ncol); break;
         case OPMHIP_REORDER_GRAPH_COLORING: color_jp(Q, color, ncol); break;
         case OPMHIP_REORDER_GRAPH_COLORING_GREEDY: color_greedy(Q, color, ncol); break;
         case OPMHIP_REORDER_LINE_COLORING: {
-            maxLen = c->cfg.chain_length > 0 ? c->cfg.chain_length : 8;
+            maxLen = c->cfg.chain_length > 0 ? c->cfg.chain_length : (c->cfg.reorder == OPMHIP_REORDER_AUTO ? 10 : 8);
             build_chains(Q, maxLen, CH);
             color_chains(Q, CH, chainColor, ncol);
             color.resize(Nb);

@@ -55,7 +55,8 @@ public:
         if (ilu_reorder == "level_scheduling") cfg.reorder = OPMHIP_REORDER_LEVEL_SCHEDULING;
         else if (ilu_reorder == "graph_coloring" || ilu_reorder.empty()) cfg.reorder = OPMHIP_REORDER_GRAPH_COLORING;
         else if (ilu_reorder == "line_coloring") cfg.reorder = OPMHIP_REORDER_LINE_COLORING;
-        else throw std::logic_error("Error invalid argument for --opencl-ilu-reorder, usage: '--opencl-ilu-reorder=[level_scheduling|graph_coloring|line_coloring]'");
+        else if (ilu_reorder == "auto") cfg.reorder = OPMHIP_REORDER_AUTO;   // line colouring on large structured grids, greedy colouring elsewhere
+        else throw std::logic_error("Error invalid argument for --opencl-ilu-reorder, usage: '--opencl-ilu-reorder=[level_scheduling|graph_coloring|line_coloring|auto]'");
         if (linsolver == "cpr_quasiimpes") cfg.preconditioner = OPMHIP_PRECOND_CPR_QUASIIMPES;
         else if (linsolver == "cpr" || linsolver == "cpr_trueimpes") cfg.preconditioner = OPMHIP_PRECOND_CPR_TRUEIMPES;
         else if (linsolver != "ilu0") throw std::invalid_argument(linsolver + " is not a valid setting for --linear-solver-configuration with --accelerator-mode=hip. Please use ilu0, cpr, cpr_trueimpes, or cpr_quasiimpes");
@@ -66,7 +67,7 @@ public:
         // cpr_amg_ilu_levels finest levels; < 0 = this plug-in's choice: level 0 where the block ILU0 is line-coloured (two colours:
         // four sweep launches per application, +5 ... +8 % Newton iterations/s on the 100^3 case), Jacobi elsewhere (level 0's sweeps follow
         // the block ILU0's colours: with level scheduling that would be hundreds of launches)
-        cfg.cpr_amg_ilu_levels = cpr_amg_ilu_levels >= 0 ? cpr_amg_ilu_levels : (cfg.reorder == OPMHIP_REORDER_LINE_COLORING ? 1 : 0);
+        cfg.cpr_amg_ilu_levels = cpr_amg_ilu_levels >= 0 ? cpr_amg_ilu_levels : ((cfg.reorder == OPMHIP_REORDER_LINE_COLORING || cfg.reorder == OPMHIP_REORDER_AUTO) ? 1 : 0);
         cfg.cpr_gather_rows = cpr_gather_rows;   // parallel runs: the pressure stage spans the ranks (0: default size of the joined level; < 0: off)
         const int rc = opmhip_create(&cfg, &ctx);
         if (rc != OPMHIP_SUCCESS) throw std::logic_error(std::string("hipSolverBackend: ") + opmhip_last_error(nullptr));

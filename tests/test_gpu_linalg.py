@@ -451,3 +451,36 @@ def test_failure_statuses_of_the_backend_interface(pkg):
     with pytest.raises(pkg.capi.OpmHipError) as e:
         s.solve_system(Nb, rp, ci, v0, b)
     assert e.value.code == pkg.capi.CREATE_PRECONDITIONER_FAILED
+
+
+def test_reorder_auto_picks_by_size_and_regularity(pkg):
+    """OPMHIP_REORDER_AUTO: the greedy colouring on small or irregular patterns, the line colouring (chains of 10) on a structured grid of
+    at least 150 000 rows in its natural order - the orderings of the explicit choices, entry for entry"""
+    from helpers import cartesian_pattern
+    def ordering(Nb, rp, ci, reorder, **kw):
+        s = pkg.capi.HipSolver(reorder=reorder, **kw)
+        s.set_pattern(Nb, rp, ci)
+        return s.ordering()
+    Nb, rp, ci = cartesian_pattern(12, 10, 9)
+    ta, fa, ca = ordering(Nb, rp, ci, "auto")
+    tg, fg, cg = ordering(Nb, rp, ci, "graph_coloring_greedy")
+    assert np.array_equal(ta, tg) and np.array_equal(ca, cg)
+    Nb, rp, ci = cartesian_pattern(60, 60, 50)          # 180 000 rows, seven column offsets
+    ta, fa, ca = ordering(Nb, rp, ci, "auto")
+    tl, fl, cl = ordering(Nb, rp, ci, "line_coloring", chain_length=10)
+    assert np.array_equal(ta, tl) and np.array_equal(ca, cl) and len(ca) == 2
+    # the same size with scattered extra couplings (more than 15 distinct column offsets): greedy
+    rng = np.random.default_rng(1)
+    extra = {}
+    for a, b in zip(rng.integers(0, Nb, 400), rng.integers(0, Nb, 400)):
+        if a != b:
+            extra.setdefault(int(a), set()).add(int(b)); extra.setdefault(int(b), set()).add(int(a))
+    rows = []
+    for i in range(Nb):
+        r = set(ci[rp[i]:rp[i + 1]].tolist()) | extra.get(i, set())
+        rows.append(sorted(r))
+    rp2 = np.concatenate([[0], np.cumsum([len(r) for r in rows])]).astype(np.int32)
+    ci2 = np.concatenate(rows).astype(np.int32)
+    ta, fa, ca = ordering(Nb, rp2, ci2, "auto")
+    tg, fg, cg = ordering(Nb, rp2, ci2, "graph_coloring_greedy")
+    assert np.array_equal(ta, tg) and np.array_equal(ca, cg)
