@@ -52,10 +52,11 @@ typedef enum opmhip_reorder {
                                         neighbour (the vertical one in CpGrid's natural order), chains coloured greedily:
                                         an exact ILU0 of that ordering, near the natural order's strength at colouring's
                                         parallelism (no counterpart in the reference) */
-    OPMHIP_REORDER_AUTO = 5          /* line colouring (chains of 10) where it pays - a structured grid in its natural order of at least
-                                        150 000 rows - and the greedy colouring elsewhere: the chain sweeps walk their 8-10 steps one after
-                                        the other, which a small system cannot hide (a 44 777-cell corner-point grid: 31 Newton its/s
-                                        line-coloured, 259 greedy; regular grids below ~125 000 cells likewise).  ABI 7 */
+    OPMHIP_REORDER_AUTO = 5          /* line colouring where it pays - a structured grid in its natural order of at least 30 000 rows,
+                                        chains of 4 below 200 000 rows, of 8 below 700 000, of 10 above (chain_length = 0; a non-zero
+                                        chain_length is taken as given) - and the greedy colouring elsewhere: the chain sweeps walk their
+                                        steps one after the other, which a small or irregular system cannot hide (a 44 777-cell
+                                        corner-point grid: 31 Newton its/s with chains of 10, 259 greedy).  ABI 7 */
 } opmhip_reorder;
 
 /* --linear-solver-configuration (linalg/setupPropertyTree.cpp:62-76).  The CPR variants: pressure system solved by one AMG

@@ -407,12 +407,17 @@ int build_pattern(opmhip_ctx* c, int Nb, int Nghost, int nnzb, const int* rows, 
     // tools/config_rates.py): the chain kernels walk a chain-tile's 8-10 steps one after the other, each step a few
     // dependent rounds of loads - on 10^6 rows eight workgroups per CU hide that, on a small system nothing does (44 777-cell corner-point
     // grid: 31 Newton its/s line-coloured, 259 greedy; regular grids: the greedy colouring wins below ~125 000 cells although it needs
-    // twice the iterations), and on an irregular pattern the sweeps lose their stencil form as well.  Line colouring: at least
-    // AUTO_LINE_MIN_ROWS rows, rows of at most 8 blocks, at most 15 distinct column offsets (col - row) in the natural order - a
-    // structured grid handed over in its natural order.
+    // twice the iterations - with chains of 10; shorter chains move that point down), and on an irregular pattern the sweeps lose their
+    // stencil form as well.  Line colouring: at least AUTO_LINE_MIN_ROWS rows, rows of at most 8 blocks, at most 15 distinct column
+    // offsets (col - row) in the natural order - a structured grid handed over in its natural order; the chain length grows with the size.
     int kind = c->cfg.reorder;
+    int autoChain = 10;
     if (kind == OPMHIP_REORDER_AUTO) {
-        constexpr int AUTO_LINE_MIN_ROWS = 150000;
+        // structured grids (tools/chain_by_size.py, Newton its/s): 32^3 greedy 568, chains of 4: 583; 40^3 423 / 487 (chains of 3-4); 50^3
+        // 267 / 361 (4); 64^3 165 / 246 (8; 239 with 4, 208 with 10); 80^3 99 / 168 (8; 153 with 10); 100^3: 10 (section 5) - the shorter
+        // the chains, the fewer dependent steps a launch walks through, the more iterations
+        constexpr int AUTO_LINE_MIN_ROWS = 30000;
+        autoChain = Nb < 200000 ? 4 : Nb < 700000 ? 8 : 10;
         bool regular = Nb >= AUTO_LINE_MIN_ROWS;
         std::vector<int> offs;
         for (int i = 0; i < Nb && regular; ++i) {
@@ -446,7 +451,7 @@ int build_pattern(opmhip_ctx* c, int Nb, int Nghost, int nnzb, const int* rows, 
         case OPMHIP_REORDER_GRAPH_COLORING: color_jp(Q, color, ncol); break;
         case OPMHIP_REORDER_GRAPH_COLORING_GREEDY: color_greedy(Q, color, ncol); break;
         case OPMHIP_REORDER_LINE_COLORING: {
-            maxLen = c->cfg.chain_length > 0 ? c->cfg.chain_length : (c->cfg.reorder == OPMHIP_REORDER_AUTO ? 10 : 8);
+            maxLen = c->cfg.chain_length > 0 ? c->cfg.chain_length : (c->cfg.reorder == OPMHIP_REORDER_AUTO ? autoChain : 8);
             build_chains(Q, maxLen, CH);
             color_chains(Q, CH, chainColor, ncol);
             color.resize(Nb);

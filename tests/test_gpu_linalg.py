@@ -454,8 +454,8 @@ def test_failure_statuses_of_the_backend_interface(pkg):
 
 
 def test_reorder_auto_picks_by_size_and_regularity(pkg):
-    """OPMHIP_REORDER_AUTO: the greedy colouring on small or irregular patterns, the line colouring (chains of 10) on a structured grid of
-    at least 150 000 rows in its natural order - the orderings of the explicit choices, entry for entry"""
+    """OPMHIP_REORDER_AUTO: the greedy colouring on small or irregular patterns, the line colouring on a structured grid of at least
+    30 000 rows in its natural order (chains of 4 / 8 / 10 by size) - the orderings of the explicit choices, entry for entry"""
     from helpers import cartesian_pattern
     def ordering(Nb, rp, ci, reorder, **kw):
         s = pkg.capi.HipSolver(reorder=reorder, **kw)
@@ -465,10 +465,13 @@ def test_reorder_auto_picks_by_size_and_regularity(pkg):
     ta, fa, ca = ordering(Nb, rp, ci, "auto")
     tg, fg, cg = ordering(Nb, rp, ci, "graph_coloring_greedy")
     assert np.array_equal(ta, tg) and np.array_equal(ca, cg)
-    Nb, rp, ci = cartesian_pattern(60, 60, 50)          # 180 000 rows, seven column offsets
+    Nb, rp, ci = cartesian_pattern(60, 60, 50)          # 180 000 rows, seven column offsets: chains of 4
     ta, fa, ca = ordering(Nb, rp, ci, "auto")
-    tl, fl, cl = ordering(Nb, rp, ci, "line_coloring", chain_length=10)
+    tl, fl, cl = ordering(Nb, rp, ci, "line_coloring", chain_length=4)
     assert np.array_equal(ta, tl) and np.array_equal(ca, cl) and len(ca) == 2
+    ta, fa, ca = ordering(Nb, rp, ci, "auto", chain_length=7)   # a chain length that is given is kept
+    tl, fl, cl = ordering(Nb, rp, ci, "line_coloring", chain_length=7)
+    assert np.array_equal(ta, tl)
     # the same size with scattered extra couplings (more than 15 distinct column offsets): greedy
     rng = np.random.default_rng(1)
     extra = {}
