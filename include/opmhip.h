@@ -105,7 +105,9 @@ typedef struct opmhip_config {
     int cpr_amg_ilu_levels; /* the pressure AMG's smoother: this many of its finest levels smooth with a scalar ILU0, relaxation 1 - the
                             * reference's AMG smoother (linalg/PreconditionerFactory.hpp:126-151, setupPropertyTree.cpp:116-137) - the others
                             * with damped Jacobi.  Level 0 eliminates in the ordering of the block ILU0 (opmhip_reorder), the levels below
-                            * colour by colour of a greedy multi-colouring.  0 (default): Jacobi on every level.  (was reserved[0] until ABI 7) */
+                            * colour by colour of a greedy multi-colouring.  0 (default): Jacobi on every level.  < 0: the library's choice -
+                            * level 0 where the block ILU0's ordering has at most three colours (level 0's sweeps are one launch per colour),
+                            * Jacobi otherwise.  (was reserved[0] until ABI 7) */
     int cpr_gather_rows;   /* decomposed runs (opmhip_comm_init_*): the pressure stage of the CPR spans the ranks, as the reference's does (Dune's
                             * parallel AMG behind linalg/OwningTwoLevelPreconditioner.hpp, PressureTransferPolicy.hpp:92-160).  Level 0 smooths
                             * with the pressure operator of the WHOLE system (ghost entries of the iterates exchanged: one double per boundary

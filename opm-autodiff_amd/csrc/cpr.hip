@@ -1182,6 +1182,13 @@ static int cpr_lpr_rows() {
     return v;
 }
 static bool cpr_gathering(const opmhip_ctx* c);
+// opmhip_config.cpr_amg_ilu_levels as it is in force: < 0 = the library's choice - level 0 where the block ILU0's ordering has few colours
+// (a sweep of level 0 is one launch per colour: four launches per application with two colours, +5 ... +8 % Newton iterations/s on the
+// 10^6-cell case; with the seven colours of a greedy-coloured corner-point grid 28, and Jacobi is 1.5 x faster there), Jacobi otherwise
+static int cpr_ilu_levels(const opmhip_ctx* c) {
+    const int v = c->cfg.cpr_amg_ilu_levels;
+    return v >= 0 ? v : (c->pat.numColors <= 3 ? 1 : 0);
+}
 // ---- level 0: belongs to the PATTERN (image, stencil form, block-vector work space): built once per context ------------------
 static int cpr_setup_level0(opmhip_ctx* c) {
     const Pattern& P = c->pat;
@@ -1232,7 +1239,7 @@ static int cpr_setup_level0(opmhip_ctx* c) {
             if ((rc = dev_upload(c, &R.lv[0].d_stable, table))) return rc;
         }
     }
-    if (c->cfg.cpr_amg_ilu_levels > 0 && !spans) {   // ILU0 smoothing of level 0: in the stored order, the block ILU0's colours are this one's
+    if (cpr_ilu_levels(c) > 0 && !spans) {   // ILU0 smoothing of level 0: in the stored order, the block ILU0's colours are this one's
         std::vector<int> posv(P.Nb), colour(P.Nb);
         for (int cc = 0; cc < P.numColors; ++cc)
             for (int p = P.colorPrefix[cc]; p < P.colorPrefix[cc + 1]; ++p) colour[p] = cc;
@@ -1639,7 +1646,7 @@ static int cpr_setup_coarse_now(opmhip_ctx* c) {
     int rc;
     if ((rc = cpr_download_level0(c, ell))) return rc;
     CprHostCoarse H;
-    cpr_build_coarse_host(c->pat, ell, R.beta, cpr_lpr_rows(), cpr_gathering(c) ? 0 : c->cfg.cpr_amg_ilu_levels, cpr_stop_rows(c), H);
+    cpr_build_coarse_host(c->pat, ell, R.beta, cpr_lpr_rows(), cpr_gathering(c) ? 0 : cpr_ilu_levels(c), cpr_stop_rows(c), H);
     const double t1 = now();
     const size_t mark = c->allocs.size();
     const bool gathered = cpr_gathering(c);
@@ -1745,7 +1752,7 @@ int cpr_update(opmhip_ctx* c, bool solveBoundary) {
         if ((rc = cpr_download_level0(c, *ell))) { R.job.reset(); prof_end(c, ps); return rc; }
         const Pattern* pat = &c->pat;   // outlives the job: cpr_release_structure / cpr_shutdown join it before the pattern goes
         const double beta = R.beta;
-        const int lpr = cpr_lpr_rows(), iluLevels = c->cfg.cpr_amg_ilu_levels;
+        const int lpr = cpr_lpr_rows(), iluLevels = cpr_ilu_levels(c);
         CprAsyncJob* raw = job.get();
         job->th = std::thread([raw, ell, pat, beta, lpr, iluLevels]() {
             cpr_build_coarse_host(*pat, *ell, beta, lpr, iluLevels, CPR_COARSE_DIRECT, raw->result);

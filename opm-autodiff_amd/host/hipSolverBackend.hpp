@@ -64,10 +64,10 @@ public:
         // more than 10 iterations) by itself; 1 (first Newton iteration of a time step) is the caller's to signal: recreateCprHierarchy()
         cfg.cpr_reuse_setup = cpr_reuse_setup;
         // The reference's pressure AMG smooths with ILU0 on every level (PreconditionerFactory.hpp:126-151).  Here: on the
-        // cpr_amg_ilu_levels finest levels; < 0 = this plug-in's choice: level 0 where the block ILU0 is line-coloured (two colours:
-        // four sweep launches per application, +5 ... +8 % Newton iterations/s on the 100^3 case), Jacobi elsewhere (level 0's sweeps follow
-        // the block ILU0's colours: with level scheduling that would be hundreds of launches)
-        cfg.cpr_amg_ilu_levels = cpr_amg_ilu_levels >= 0 ? cpr_amg_ilu_levels : ((cfg.reorder == OPMHIP_REORDER_LINE_COLORING || cfg.reorder == OPMHIP_REORDER_AUTO) ? 1 : 0);
+        // cpr_amg_ilu_levels finest levels; < 0 = the library's choice: level 0 where the block ILU0's ordering has at most three colours
+        // (four sweep launches per application, +5 ... +8 % Newton iterations/s on the 100^3 case), Jacobi elsewhere (with the seven colours
+        // of a greedy-coloured corner-point grid Jacobi is 1.5 x faster)
+        cfg.cpr_amg_ilu_levels = cpr_amg_ilu_levels;
         cfg.cpr_gather_rows = cpr_gather_rows;   // parallel runs: the pressure stage spans the ranks (0: default size of the joined level; < 0: off)
         const int rc = opmhip_create(&cfg, &ctx);
         if (rc != OPMHIP_SUCCESS) throw std::logic_error(std::string("hipSolverBackend: ") + opmhip_last_error(nullptr));

@@ -13,6 +13,7 @@ import helpers  # noqa: E402
 ap = argparse.ArgumentParser()
 ap.add_argument("--steps", type=int, default=40)
 ap.add_argument("--warmup", type=int, default=5)
+ap.add_argument("--cpr-amg-ilu-levels", type=int, default=-1, help="-1: the library picks (level 0 with ILU0 where the ordering has at most three colours)")
 a = ap.parse_args()
 pkg = importlib.import_module("opm-autodiff_amd")
 
@@ -36,7 +37,7 @@ def run(name, case, src, **kw):
     out = []
     for prec in ("ilu0", "cpr"):
         m = pkg.capi.HipModel(case, reorder="auto", tolerance=1e-2, maxit=200, ilu_relaxation=0.9, preconditioner=prec,
-                              cpr_amg_ilu_levels=1 if prec == "cpr" else 0, **kw)
+                              cpr_amg_ilu_levels=a.cpr_amg_ilu_levels if prec == "cpr" else 0, **kw)
         m.set_state(case["pv"], case["meaning"])
         m.set_source(src)
         sim = bench.make_simulation(pkg, m)
