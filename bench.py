@@ -235,6 +235,59 @@ def cpu_baseline(pkg, case, src, nnzb):
     return out
 
 
+LINE_LIMIT = 4096   # bytes of the one line on stdout (round 4's 22 KB line could not be parsed from the driver's 8 KB tail)
+
+
+def _r(v, nd=4):
+    return round(v, nd) if isinstance(v, float) else v
+
+
+def compact_line(out, detail_path):
+    """The ONE line on stdout: the contract's keys, `config`, `roofline`, `cpu_baseline`, one number per extra window.  Everything
+    else (kernel scopes per window, reports, time steps, thread sweep, device) is in the file `detail` names."""
+    keep = ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data")
+    line = {k: _r(out[k]) for k in keep}
+    line["config"] = out["config"]
+    line["newton_iterations_per_s_global"] = _r(out["newton_iterations_per_s_global"])
+    line["linear_iterations_per_newton"] = _r(out["linear_iterations_per_newton"], 2)
+    line["linear_solve_GBps"] = out["linear_solve_GBps"]
+    ro = out["roofline"]
+    line["roofline"] = {k: _r(ro[k]) for k in ("bound", "kernel", "achieved", "peak", "unit", "frac", "traffic", "avg_launch_ms", "algorithmic_bytes_per_launch",
+                                               "frac_of_stream_ceiling")}
+    line["roofline"]["traffic_source"] = ro["traffic_source"] if len(str(ro["traffic_source"])) < 80 else str(ro["traffic_source"])[:77] + "..."
+    # the other kernels of the window behind `value`: algorithmic GB/s (bytes per launch in DESIGN.md section 4)
+    line["kernel_GBps"] = {k: v["algorithmic_GBps"] for k, v in out["kernels"].items()}
+    cb = out.get("cpu_baseline")
+    if cb:
+        line["cpu_baseline"] = {"value": _r(cb["value"]), "unit": cb["unit"], "cores": cb["cores"], "kind": cb["kind"],
+                                "sample": cb["sample"], "single_thread_value": _r(cb["single_thread"]["value"]),
+                                "cpu_model": cb["host"]["cpu_model"], "linear_solve_GBps": cb["linear_solve_GBps"]}
+        line["gpu_over_cpu"] = _r(out["gpu_over_cpu"], 2)
+
+    def one(w):   # one number (or the error) per extra window
+        if not w:
+            return None
+        if "error" in w:
+            return {"error": w["error"][:120]}
+        o = {"value": _r(w["value"], 2), "lin_its": _r(w["linear_iterations_per_newton"], 2)}
+        if "steady_state" in w:
+            o["steady"] = _r(w["steady_state"]["value"], 2)
+        return o
+    line["steady_state"] = one(out.get("steady_state"))
+    for k in ("cpr", "cpr_quasiimpes", "cpr_amg_jacobi_smoother", "cpr_reuse_setup_2", "cpr_reuse_setup_2_sync"):
+        if out.get(k) is not None:
+            line[k] = one(out[k])
+    line["cpr_amg_ilu_levels"] = out.get("cpr_amg_ilu_levels")
+    line["stream_read_GBps"] = out["stream_ceiling"]["read_GBps"]
+    if out.get("rccl"):
+        line["rccl"] = {"nranks": out["rccl"]["nranks"], "kind": out["rccl"]["kind"]}
+    if out.get("comm"):
+        line["comm"] = out["comm"]
+    line["device"] = out["device"].get("name")
+    line["detail"] = detail_path
+    return line
+
+
 def launch_plan(gpus, env, device_count):
     """What `python bench.py --gpus N` has to do before any GPU call: ("inline", world) - run in this process (N = 1, or
     a rank started by torch.distributed.run) - or ("spawn", N) - start N ranks as children.  Raises SystemExit on a
@@ -289,14 +342,15 @@ def main():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--n", type=int, default=100, help="cells per edge of the per-GPU cube")
-    ap.add_argument("--reorder", default="line_coloring")
-    ap.add_argument("--chain-length", type=int, default=10, help="rows per chain of the line-coloured ILU0 ordering (10 divides the 100-cell columns evenly: 7 % more Newton its/s than 8 in the steady window, 1 % fewer in the start-up window)")
+    ap.add_argument("--reorder", default=None, help="ILU0 ordering; default: the library's own choice (opmhip_default_config: auto), reported in config.ilu_ordering")
+    ap.add_argument("--chain-length", type=int, default=0, help="rows per chain of the line-coloured ILU0 ordering; 0: the library's choice (10 at 10^6 cells)")
+    ap.add_argument("--detail", default=None, help="file for the full record (per-window kernel scopes, reports, time steps); default gpurun_out/bench_detail.json")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--steady-after", type=int, default=200, help="second timed window starts at this Newton iteration (0: none)")
     ap.add_argument("--steady-steps", type=int, default=100)
     ap.add_argument("--preconditioner", default="ilu0", choices=["ilu0", "cpr", "cpr_trueimpes", "cpr_quasiimpes"], help="--linear-solver-configuration of the run behind `value`")
     ap.add_argument("--cpr-reuse-setup", type=int, default=3, choices=[0, 1, 2, 3], help="Flow's --cpr-reuse-setup for the CPR runs: when the hierarchy's structure is built anew (3 = never, the default of Flow)")
-    ap.add_argument("--cpr-amg-ilu-levels", type=int, default=1, help="CPR runs: this many of the pressure AMG's finest levels smooth with ILU0 (the reference's AMG smoother) instead of damped Jacobi; 1 (level 0, in the line-coloured order of the block ILU0) is the best of 0 / 1 / 2 / 3 on this case in every CPR configuration (DESIGN.md section 5b); the library's own default is 0")
+    ap.add_argument("--cpr-amg-ilu-levels", type=int, default=None, help="CPR runs: this many of the pressure AMG's finest levels smooth with ILU0 (the reference's AMG smoother) instead of damped Jacobi; default: the library's choice (opmhip_default_config: -1 = level 0 where the block ordering has at most three colours), reported in cpr_amg_ilu_levels")
     ap.add_argument("--no-cpr-side-run", action="store_true", help="skip the side runs with the CPR preconditioners (extra keys `cpr`, `cpr_quasiimpes`)")
     a = ap.parse_args()
 
@@ -404,7 +458,7 @@ def main():
         Bm = dict(B)
         if use_cpr_of(model):
             lv = model.cpr_levels()
-            Bm["cpr_amg"] = cpr_amg_bytes(Nb, [int(v) for v in lv[0]], [int(v) for v in lv[1]], getattr(model, "_bench_ilu_levels", a.cpr_amg_ilu_levels))
+            Bm["cpr_amg"] = cpr_amg_bytes(Nb, [int(v) for v in lv[0]], [int(v) for v in lv[1]], model.ordering_info()["cpr_amg_ilu_levels"])
         # what the profiled solves were: solves = factorisations, BiCGStab iterations = products / 2 (two per iteration; a solve that
         # stops on a first half adds one) - so that launches x avg_ms can be put beside the window's ms_per_step
         solves_profiled = prof.get("ilu_factor", (0, 0.0))[0] // (2 if use_cpr_of(model) else 1)   # CPR: the value set-up of the hierarchy is a second scope of that class
@@ -466,7 +520,6 @@ def main():
             nonlocal sim, model
             model2 = pkg.capi.HipModel(case, **dict(skw, preconditioner=prec, **over))
             model2._bench_preconditioner = prec
-            model2._bench_ilu_levels = over.get("cpr_amg_ilu_levels", a.cpr_amg_ilu_levels)
             model2.set_state(case["pv"], case["meaning"])
             model2.set_source(src)
             sim_main, model_main = sim, model
@@ -478,7 +531,7 @@ def main():
                 C1 = timed_window(a.steps)
                 side = {"value": C1["steps"] / C1["elapsed"], "ms_per_step": 1e3 * C1["elapsed"] / C1["steps"], "steps": C1["steps"],
                         "linear_iterations_per_newton": C1["linear_iterations_per_newton"], "report": C1["report"], "kernels": C1["kernels"], "profiled": C1["profiled"],
-                        "amg_levels": model2.cpr_levels()[0]}
+                        "amg_levels": [int(v) for v in model2.cpr_levels()[0]], "cpr_amg_ilu_levels": model2.ordering_info()["cpr_amg_ilu_levels"]}
                 if a.steady_after > 0 and a.steady_steps > 0:
                     done = a.warmup + a.steps
                     while done < a.steady_after:
@@ -499,7 +552,7 @@ def main():
     if a.preconditioner == "ilu0" and world == 1 and not a.no_cpr_side_run:
         for prec in ("cpr", "cpr_quasiimpes"):
             cpr_sides[prec] = guarded("CPR side run (%s)" % prec, cpr_window(prec))
-        if a.cpr_amg_ilu_levels != 0:   # the same with damped Jacobi on every level of the pressure AMG (the library's default smoother)
+        if a.cpr_amg_ilu_levels != 0:   # the same with damped Jacobi on every level of the pressure AMG
             cpr_sides["cpr_amg_jacobi_smoother"] = guarded("CPR side run (cpr, Jacobi-smoothed AMG)", cpr_window("cpr", cpr_amg_ilu_levels=0))
         if a.cpr_reuse_setup == 3:   # Flow's other --cpr-reuse-setup worth a line: the hierarchy's structure follows the state
             # ... rebuilt on a host thread beside the solves (opmhip_config.cpr_async_setup), and - the reference's rule to the letter -
@@ -515,7 +568,8 @@ def main():
     sp = kernels.get("spmv", {"avg_ms": float("nan"), "algorithmic_GBps": float("nan")})
     ok = sp["algorithmic_GBps"] == sp["algorithmic_GBps"]
     traffic, traffic_src = (None, "single-GPU 100^3 line-colouring runs only")
-    if world == 1 and n == 100 and a.reorder == "line_coloring":
+    chosen = model.ordering_info()   # what the library's defaults resolved to (or what the flags forced)
+    if world == 1 and n == 100 and chosen["ilu_ordering"] == "line_coloring" and chosen["chain_length"] == 10:
         traffic, traffic_src = pmc_traffic("k_spmv")
     out = {
         "metric": "Newton iterations/sec, 1M-cell 3-phase black-oil (assembly + ILU0/BiCGStab solve + update)",
@@ -530,7 +584,8 @@ def main():
         "config": {"workload": "synthetic %dx%dx%d Cartesian 3-phase black-oil (BASELINE configs[1]), SPE1 fluid, homogeneous "
                                "100 mD, gas cap + undersaturated oil, five-spot rate sources, adaptive time steps 1 d -> 10 d (Flow's "
                                "pid+newtoniteration control and 0.33 chop)" % (n, n, n),
-                   "cells_per_gpu": Nb, "blocks_per_gpu": nnzb, "ilu_ordering": a.reorder, "linear_tol": 1e-2,
+                   "cells_per_gpu": Nb, "blocks_per_gpu": nnzb, "ilu_ordering": chosen["ilu_ordering"], "ilu_chain_length": chosen["chain_length"],
+                   "ilu_colors": chosen["colors"], "ilu_ordering_chosen_by": "library default (auto)" if a.reorder is None else "--reorder", "linear_tol": 1e-2,
                    "ilu_relaxation": 0.9, "parallelism": "1 GPU" if world == 1 else "RAS domain decomposition %dx%dx%d, %s per GPU, halos + all-reduces over RCCL" % (layout + ("block-Jacobi ILU0" if a.preconditioner == "ilu0" else "one CPR (%s) per subdomain" % a.preconditioner,))},
         "linear_iterations_per_newton": W["linear_iterations_per_newton"],
         "timesteps_completed": W["timesteps_completed"], "timesteps_chopped": W["timesteps_chopped"],
@@ -551,7 +606,7 @@ def main():
         # the two runs above keep Flow's default 3 (never)
         # the CPR runs smooth level 0 of the pressure AMG with ILU0, the reference's AMG smoother (opmhip_config.cpr_amg_ilu_levels =
         # --cpr-amg-ilu-levels, default 1 here); "cpr_amg_jacobi_smoother": "cpr" with damped Jacobi on every level instead (the library's default)
-        "cpr_amg_ilu_levels": a.cpr_amg_ilu_levels,
+        "cpr_amg_ilu_levels": (cpr_sides.get("cpr") or {}).get("cpr_amg_ilu_levels"),   # in force in the CPR side runs (library's choice unless --cpr-amg-ilu-levels)
         "cpr_amg_jacobi_smoother": cpr_sides.get("cpr_amg_jacobi_smoother"),
         "cpr_reuse_setup_2": cpr_sides.get("cpr_reuse_setup_2"),
         "cpr_reuse_setup_2_sync": cpr_sides.get("cpr_reuse_setup_2_sync"),
@@ -577,7 +632,18 @@ def main():
         out["cpu_baseline"] = cpu_baseline(pkg, case, src, nnzb)
         out["gpu_over_cpu"] = out["value"] / out["cpu_baseline"]["value"]
     if rank == 0:
-        print(json.dumps(out))
+        # the full record goes to a file; the line on stdout is what the driver parses and stays under 4 KB
+        detail = a.detail or os.path.join(ROOT, "gpurun_out", "bench_detail.json")
+        try:
+            os.makedirs(os.path.dirname(os.path.abspath(detail)), exist_ok=True)
+            with open(detail, "w") as f:
+                json.dump(out, f, indent=1)
+        except OSError as e:
+            detail = "not written: %s" % e
+        line = json.dumps(compact_line(out, os.path.relpath(detail, ROOT) if os.path.isabs(detail) and detail.startswith(ROOT) else detail))
+        assert len(line) < LINE_LIMIT, "bench.py: the line grew to %d bytes" % len(line)
+        print(line)
+        sys.stdout.flush()
     if dist is not None:
         dist.destroy_process_group()
 

@@ -20,7 +20,9 @@
 extern "C" {
 #endif
 
-#define OPMHIP_ABI_VERSION 7 /* 7: opmhip_config names cpr_amg_ilu_levels, cpr_gather_rows (were reserved[0..1]);
+#define OPMHIP_ABI_VERSION 8 /* 8: opmhip_default_config: reorder = OPMHIP_REORDER_AUTO, cpr_amg_ilu_levels = -1 (the measured configuration);
+                               *    opmhip_get_ordering_info, opmhip_wells gained the multisegment-well leg (num_ms_wells, ms_apply);
+                               * 7: opmhip_config names cpr_amg_ilu_levels, cpr_gather_rows (were reserved[0..1]);
                                * 6: opmhip_set_hysteresis, opmhip_get_hysteresis, opmhip_set_hysteresis_params (additive); opmhip_config names
                                *    cpr_async_setup (was reserved[0]);
                                * 5: opmhip_set_water_compaction, opmhip_get_max_water_saturation, opmhip_relative_change, opmhip_cpr_recreate (additive);
@@ -140,15 +142,28 @@ typedef struct opmhip_result {
  * (bda/WellContributions.hpp:60-214; fill order C, D, B per well, wells/StandardWellEval.cpp:1206-1250):
  * applied after each SpMV as y -= C^T (D^-1 (B x)) (bda/WellContributions.cu:36-126). dim = 3, dim_wells = 4.
  * One workgroup per well; where two wells perforate the same cell their updates of that cell are atomic adds (the
- * reference's kernel races there), so the result is then defined up to the order of two additions. */
+ * reference's kernel races there), so the result is then defined up to the order of two additions.
+ *
+ * Multisegment wells (ABI 8): the reference's WellContributions counts them in getNumWells() (bda/WellContributions.hpp:164-166) but
+ * keeps their data in MultisegmentWellContribution objects whose D^-1 is a sparse LU on the HOST (UMFPack,
+ * bda/MultisegmentWellContribution.cpp:35-62); its back-ends apply them through a host round trip after every product, in front of
+ * the standard wells in the CUDA back-end (bda/WellContributions.cu:160-187), behind them in the OpenCL one (WellContributions.cpp:116-150).  The same here, in the CUDA back-end's order: with num_ms_wells > 0 the
+ * library brings x and y (N doubles each, NATURAL order - the caller's objects know nothing of the ILU ordering, so there is no
+ * setReordering to do) to pinned host memory after every product, calls ms_apply(ms_user, h_x, h_y) - which performs
+ * y -= C^T (D^-1 (B x)) for every multisegment well, e.g. by looping MultisegmentWellContribution::apply(h_x, h_y) - and takes
+ * h_y back.  num_wells counts the STANDARD wells only.  The callback runs on the calling thread, inside opmhip_solve_system. */
+typedef void (*opmhip_ms_apply_fn)(void* user, const double* h_x, double* h_y);
 typedef struct opmhip_wells {
-    int num_wells;
+    int num_wells;           /* standard wells (num_std_wells of the reference, NOT getNumWells()) */
     const int* val_pointers; /* [num_wells+1] perforation ranges */
     const int* Ccols;        /* [nperf] cell (block row) of each perforation */
     const int* Bcols;        /* [nperf] */
     const double* Cnnzs;     /* [nperf*12] 4x3 row-major */
     const double* Dnnzs;     /* [num_wells*16] 4x4 row-major, already inverted (D^-1) */
     const double* Bnnzs;     /* [nperf*12] */
+    int num_ms_wells;        /* multisegment wells behind ms_apply (0: none) */
+    opmhip_ms_apply_fn ms_apply; /* must be non-NULL when num_ms_wells > 0 */
+    void* ms_user;           /* handed back to ms_apply */
 } opmhip_wells;
 
 /* ---- lifetime ------------------------------------------------------------------------------------------ */
@@ -243,6 +258,11 @@ int opmhip_cpr_apply(opmhip_ctx* ctx, const double* d, double* v);
 /* the ordering chosen at set_pattern: toOrder/fromOrder [Nb], rowsPerColor [num colours] (any may be NULL);
  * returns the number of colours/levels or a negative status */
 int opmhip_get_ordering(opmhip_ctx* ctx, int* toOrder, int* fromOrder, int* rowsPerColor);
+/* what opmhip_config's "the library chooses" settings resolved to at set_pattern: info[0] the opmhip_reorder in force (never
+ * OPMHIP_REORDER_AUTO), info[1] rows per chain of the line colouring (0: no chains), info[2] colours / levels, info[3] the
+ * cpr_amg_ilu_levels in force (0 without a CPR preconditioner).  The reference prints the same kind of line at set-up
+ * (bda/openclSolverBackend.cpp:229-246, BILU0.cpp:106-108).  ABI 8 */
+int opmhip_get_ordering_info(opmhip_ctx* ctx, int info[4]);
 /* Device-timed repetitions of one kernel on the uploaded system, for bench.py's roofline object:
  * which = 0 SpMV, 1 ILU0 apply, 2 ILU0 factor, 3 one BiCGStab iteration's vector kernels, 4 a plain streaming read of
  * the Jacobian's value array (72 * nnzb bytes; the on-box HBM ceiling the roofline fractions are put beside), 5 / 6 the SpMV

@@ -63,9 +63,13 @@ def endpoint_scaling_struct(es):
     return s, keep
 
 
+MS_APPLY_FN = C.CFUNCTYPE(None, C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_double))   # opmhip_ms_apply_fn
+
+
 class Wells(C.Structure):
     _fields_ = [("num_wells", C.c_int), ("val_pointers", C.c_void_p), ("Ccols", C.c_void_p),
-                ("Bcols", C.c_void_p), ("Cnnzs", C.c_void_p), ("Dnnzs", C.c_void_p), ("Bnnzs", C.c_void_p)]
+                ("Bcols", C.c_void_p), ("Cnnzs", C.c_void_p), ("Dnnzs", C.c_void_p), ("Bnnzs", C.c_void_p),
+                ("num_ms_wells", C.c_int), ("ms_apply", MS_APPLY_FN), ("ms_user", C.c_void_p)]
 
 
 def declared_symbols():
@@ -111,6 +115,7 @@ def lib():
         L.opmhip_set_cpr_weights.argtypes = [vp, dp]
         L.opmhip_get_cpr_weights.argtypes = [vp, dp]
         L.opmhip_get_ordering.argtypes = [vp, ip, ip, ip]
+        L.opmhip_get_ordering_info.argtypes = [vp, C.POINTER(C.c_int * 4)]
         L.opmhip_time_kernel.argtypes = [vp, C.c_int, C.c_int, C.POINTER(C.c_double)]
         L.opmhip_cpr_levels.argtypes = [vp, ip, ip, C.c_int]
         L.opmhip_profile_enable.argtypes = [vp, C.c_int]
@@ -135,12 +140,26 @@ def _i32(a):
 
 
 def make_wells(w):
-    """dict(numWells, val_pointers, Ccols, Bcols, Cnnzs, Dnnzs, Bnnzs) -> (Wells struct, keep-alive list)"""
+    """dict(numWells, val_pointers, Ccols, Bcols, Cnnzs, Dnnzs, Bnnzs[, numMsWells, ms_apply]) -> (Wells struct, keep-alive list).
+    numWells counts the standard wells; ms_apply(x, y) - numpy views of the pinned host vectors, natural order - performs
+    y -= C^T (D^-1 (B x)) for the numMsWells multisegment wells in place (opmhip_wells.ms_apply)."""
     if not w:
         return None, []
-    keep = [_i32(w["val_pointers"]), _i32(w["Ccols"]), _i32(w["Bcols"]), _f64(w["Cnnzs"]), _f64(w["Dnnzs"]),
-            _f64(w["Bnnzs"])]
-    s = Wells(int(w["numWells"]), *[_ptr(k) for k in keep])
+    nstd = int(w.get("numWells", 0))
+    if nstd > 0:
+        keep = [_i32(w["val_pointers"]), _i32(w["Ccols"]), _i32(w["Bcols"]), _f64(w["Cnnzs"]), _f64(w["Dnnzs"]), _f64(w["Bnnzs"])]
+        s = Wells(nstd, *[_ptr(k) for k in keep])
+    else:
+        keep, s = [], Wells(0)
+    nms = int(w.get("numMsWells", 0))
+    if nms > 0:
+        fn, n = w["ms_apply"], int(w["N"])
+
+        def tramp(_user, hx, hy):
+            fn(np.ctypeslib.as_array(hx, shape=(n,)), np.ctypeslib.as_array(hy, shape=(n,)))
+        cb = MS_APPLY_FN(tramp)
+        keep.append(cb)
+        s.num_ms_wells, s.ms_apply = nms, cb
     return s, keep
 
 
@@ -149,22 +168,27 @@ class HipSolver:
     ctor(verbosity, maxit, tolerance, deviceID), solve_system(...), get_result(x))."""
 
     def __init__(self, verbosity=0, maxit=200, tolerance=1e-2, device_id=0, ilu_relaxation=0.9,
-                 relax_mode="post_scale", reorder="graph_coloring", zero_diag_fix=True, chain_length=0, spmv_pipe_wgs=0,
-                 preconditioner="ilu0", cpr_reuse_setup=3, cpr_async_setup=0, cpr_amg_ilu_levels=0, cpr_gather_rows=0):
+                 relax_mode="post_scale", reorder=None, zero_diag_fix=True, chain_length=0, spmv_pipe_wgs=0,
+                 preconditioner="ilu0", cpr_reuse_setup=3, cpr_async_setup=0, cpr_amg_ilu_levels=None, cpr_gather_rows=None):
+        """reorder / cpr_amg_ilu_levels / cpr_gather_rows = None: what opmhip_default_config says (reorder "auto", the library's choice of
+        the AMG smoother, the pressure stage across the ranks as the communicator's kind allows)"""
         L = lib()
         cfg = Config()
         L.opmhip_default_config(C.byref(cfg))
         cfg.verbosity, cfg.maxit, cfg.tolerance, cfg.device_id = verbosity, maxit, tolerance, device_id
         cfg.ilu_relaxation = ilu_relaxation
         cfg.relax_mode = RELAX[relax_mode]
-        cfg.reorder = REORDER[reorder]
+        if reorder is not None:
+            cfg.reorder = REORDER[reorder]
         cfg.zero_diag_fix = int(zero_diag_fix)
         cfg.chain_length = int(chain_length)  # line colouring: rows per chain (0: the library's default, 8; 10 with reorder="auto")
         cfg.spmv_pipe_wgs = int(spmv_pipe_wgs)  # pipelined SpMV: workgroups it is sized for (0 default, < 0 off; tests use small values)
         # --linear-solver-configuration (setupPropertyTree.cpp:62-76): "cpr" is short for cpr_trueimpes, as in Flow
         cfg.preconditioner = PRECONDITIONER[preconditioner]
-        cfg.cpr_amg_ilu_levels = int(cpr_amg_ilu_levels)   # finest levels of the pressure AMG that smooth with ILU0 (0: Jacobi everywhere)
-        cfg.cpr_gather_rows = int(cpr_gather_rows)         # decomposed runs: the hierarchy is continued across the ranks from the first level this small (0 default, < 0 off)
+        if cpr_amg_ilu_levels is not None:
+            cfg.cpr_amg_ilu_levels = int(cpr_amg_ilu_levels)   # finest levels of the pressure AMG that smooth with ILU0 (0: Jacobi everywhere, < 0: the library's choice)
+        if cpr_gather_rows is not None:
+            cfg.cpr_gather_rows = int(cpr_gather_rows)         # decomposed runs: the hierarchy is continued across the ranks from the first level this small (0 default, < 0 off)
         cfg.cpr_async_setup = int(cpr_async_setup)   # mode 2 only: the rebuild on a host thread beside the solves
         cfg.cpr_reuse_setup = int(cpr_reuse_setup)   # --cpr-reuse-setup: 0 every solve, 1 every time step, 2 after > 10 iterations, 3 never
         self._h = C.c_void_p()
@@ -281,6 +305,13 @@ class HipSolver:
         rpc = np.zeros(self.Nb, np.int32)
         nc = self._check(lib().opmhip_get_ordering(self._h, _ptr(to), _ptr(fr), _ptr(rpc)))
         return to, fr, rpc[:nc].copy()
+
+    def ordering_info(self):
+        """what the library's own choices resolved to (opmhip_get_ordering_info)"""
+        info = (C.c_int * 4)()
+        self._check(lib().opmhip_get_ordering_info(self._h, C.byref(info)))
+        names = {v: k for k, v in REORDER.items()}
+        return {"ilu_ordering": names[info[0]], "chain_length": int(info[1]), "colors": int(info[2]), "cpr_amg_ilu_levels": int(info[3])}
 
     PROF = ["spmv", "ilu_apply", "ilu_factor", "vector", "assemble", "iq_update", "convergence", "cpr_amg", "spmv_boundary"]
 

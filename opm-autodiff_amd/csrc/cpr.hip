@@ -1189,6 +1189,7 @@ static int cpr_ilu_levels(const opmhip_ctx* c) {
     const int v = c->cfg.cpr_amg_ilu_levels;
     return v >= 0 ? v : (c->pat.numColors <= 3 ? 1 : 0);
 }
+int cpr_ilu_levels_in_force(const opmhip_ctx* c) { return use_cpr(c) ? (cpr_gathering(c) ? 0 : cpr_ilu_levels(c)) : 0; }
 // ---- level 0: belongs to the PATTERN (image, stencil form, block-vector work space): built once per context ------------------
 static int cpr_setup_level0(opmhip_ctx* c) {
     const Pattern& P = c->pat;

@@ -76,6 +76,7 @@ struct Pattern {
     int Nghost = 0, Nloc = 0;                            // ghost cells numbered Nb..Nloc-1 (vectors have Nloc entries)
     int maxRowBlocks = 0;                                // longest row, in blocks
     bool chained = false;  // line colouring: rows of one colour may depend on earlier rows of their own chain
+    int kindInForce = 0, chainLen = 0;  // the opmhip_reorder the pattern was ordered with (OPMHIP_REORDER_AUTO resolved) and its rows per chain (0: no chains)
     // per colour: every row's L (U) part is at most the row's own chain predecessor (successor) - the sweep is then a
     // lane-private recurrence and runs in the light kernel (no LDS staging, deep prefetch)
     std::vector<char> lightL, lightU;
@@ -115,6 +116,12 @@ struct WellsDev {
     double *d_C = nullptr, *d_D = nullptr, *d_B = nullptr;
     double *d_res = nullptr, *d_xw = nullptr;   // 4 doubles per well each (residual in, well solution out)
     size_t cap_wells = 0, cap_perf = 0;
+    // multisegment wells: applied on the host between the product and the standard wells (opmhip_wells.ms_apply)
+    int num_ms = 0;
+    opmhip_ms_apply_fn ms_apply = nullptr;
+    void* ms_user = nullptr;
+    double *h_x = nullptr, *h_y = nullptr;   // pinned, Nb * 3 doubles each, natural order
+    bool any() const { return num_wells > 0 || num_ms > 0; }
 };
 
 // assembly-side device state (all per-cell / per-entry arrays in the INTERNAL order)
@@ -492,6 +499,7 @@ int cpr_set_weights(opmhip_ctx* c, const double* w);
 int cpr_level_sizes(const opmhip_ctx* c, int* n, int* nnz, int cap);
 void cpr_shutdown(opmhip_ctx* c);   // joins a structure build in flight (before the context goes)
 bool cpr_coarse_pivot_failed(opmhip_ctx* c);
+int cpr_ilu_levels_in_force(const opmhip_ctx* c);   // opmhip_config.cpr_amg_ilu_levels with "< 0: the library's choice" resolved (0 without CPR)
 inline bool use_cpr(const opmhip_ctx* c) { return c->cfg.preconditioner == OPMHIP_PRECOND_CPR_QUASIIMPES || c->cfg.preconditioner == OPMHIP_PRECOND_CPR_TRUEIMPES; }
 void launch_wells_apply(opmhip_ctx* c, const double* x, double* y, double xs = 1.0);
 void launch_lu_to_natural(opmhip_ctx* c, double* d_out_internal_layout);

@@ -461,6 +461,8 @@ int build_pattern(opmhip_ctx* c, int Nb, int Nghost, int nnzb, const int* rows, 
     }
     P.numColors = ncol;
     P.chained = chained;
+    P.kindInForce = kind;
+    P.chainLen = chained ? maxLen : 0;
     P.colorPrefix.assign(ncol + 1, 0);
     for (int i = 0; i < Nb; ++i) P.colorPrefix[color[i] + 1]++;
     std::partial_sum(P.colorPrefix.begin(), P.colorPrefix.end(), P.colorPrefix.begin());

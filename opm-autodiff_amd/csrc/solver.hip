@@ -1887,7 +1887,7 @@ static bool spmv_dots_env() {   // OPMHIP_DOTS_SEPARATE=1 (tuning / A-B measurem
     static const bool v = [] { const char* e = tuning_env("OPMHIP_DOTS_SEPARATE"); return e && std::atoi(e) != 0; }();
     return v;
 }
-static bool spmv_dots_separate(const opmhip_ctx* c) { return c->wells.num_wells > 0 || spmv_dots_env(); }
+static bool spmv_dots_separate(const opmhip_ctx* c) { return c->wells.any() || spmv_dots_env(); }
 // one launch over the schedule positions [p0, p0 + np): the pipelined kernel where the pattern allows it, else one tile per
 // workgroup.  Partial sums go to part[pofs ...]; returns how many were written (0 with ndot == 0).
 static int launch_spmv_part(opmhip_ctx* c, int p0, int np, const double* x, double* y, int ndot, const double* w0, double xs, int pofs, int cls) {
@@ -1933,6 +1933,26 @@ static int launch_spmv_part(opmhip_ctx* c, int p0, int np, const double* x, doub
         hipExtLaunchKernelGGL(k_spmv<2>, dim3(np), dim3(64), 0, c->stream, e0, e1, 0, sched, P.d_rowptr, P.d_col, c->d_A, x, y, w0, part, c->npart, c->d_done, xs);
     return ndot > 0 ? np : 0;
 }
+// Multisegment wells: y -= C^T (D^-1 (B (xs x))) on the HOST, by the caller's objects (opmhip_wells.ms_apply) - x and y to pinned memory in
+// the natural order, the callback, y back: the round trip the reference's back-ends make after every product
+// (bda/WellContributions.cu:160-187; MultisegmentWellContribution::apply, bda/MultisegmentWellContribution.cpp:70-110).  The stream is
+// drained twice per product; a deck with multisegment wells pays what it pays in the reference.
+static int ms_wells_apply(opmhip_ctx* c, const double* x, double* y, double xs) {
+    WellsDev& W = c->wells;
+    const size_t n = (size_t)c->pat.Nb * BS;
+    launch_vec_to_natural(c, x, c->d_stageV);
+    OPMHIP_HIP(c, hipMemcpyAsync(W.h_x, c->d_stageV, n * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+    launch_vec_to_natural(c, y, c->d_stageV);
+    OPMHIP_HIP(c, hipMemcpyAsync(W.h_y, c->d_stageV, n * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+    OPMHIP_HIP(c, hipStreamSynchronize(c->stream));
+    if (xs != 1.0)   // x arrives without the relaxation factor of M^-1 (launch_ilu_apply's `unscaled`): one rounded product per entry, as on the device
+        for (size_t i = 0; i < n; ++i) W.h_x[i] *= xs;
+    W.ms_apply(W.ms_user, W.h_x, W.h_y);
+    OPMHIP_HIP(c, hipMemcpyAsync(c->d_stageV, W.h_y, n * sizeof(double), hipMemcpyHostToDevice, c->stream));
+    launch_vec_to_internal(c, c->d_stageV, y);
+    OPMHIP_HIP(c, hipStreamSynchronize(c->stream));   // h_y may be written again by the next product
+    return OPMHIP_SUCCESS;
+}
 // y = A x (+ wells) and the partial sums of the scalar products: ndot 0 none, 1 y.w0, 2 y.w0 and y.y.
 // exchange (decomposed runs): the ghost entries of x are refreshed first - Dune's copyOwnerToAll in front of the operator
 // (linalg/WellOperators.hpp:127-138, ParallelOverlappingILU0.hpp:897) - on the halo stream, WHILE the interior tiles (no
@@ -1957,6 +1977,7 @@ int launch_spmv(opmhip_ctx* c, double* x, double* y, int ndot, const double* w0,
         if (halo && (rc = comm_halo_f64(c, x, BS))) return rc;
         cnt += launch_spmv_part(c, 0, P.tiles.nsched, x, y, fused, w0, xs, cnt, PROF_SPMV);
     }
+    if (c->wells.num_ms > 0 && (rc = ms_wells_apply(c, x, y, xs))) return rc;   // in front of the standard wells, bda/WellContributions.cu:160-187
     if (wells) launch_wells_apply(c, x, y, xs);
     if (fused == 0 && ndot > 0) {
         const int n = P.Nb * BS;

@@ -36,12 +36,15 @@ class hipSolverBackend : public BdaSolver<block_size> {
     bool haveWells = false;
 
 public:
-    /// ilu_reorder as --opencl-ilu-reorder: "level_scheduling" | "graph_coloring" | "line_coloring";
+    /// ilu_reorder as --opencl-ilu-reorder: "auto" (default: the library's measured choice - line colouring on large structured grids,
+    /// the greedy colouring elsewhere) | "level_scheduling" | "graph_coloring" (the reference's Jones-Plassmann rounds, bda/Reorder.cpp:59-172)
+    /// | "graph_coloring_greedy" | "line_coloring".  The BdaBridge branch of INTEGRATION.md hands over "auto" when the user left
+    /// --opencl-ilu-reorder untouched and the user's string otherwise (bda/BdaBridge.cpp:72-73);
     /// linsolver as --linear-solver-configuration: "ilu0" | "cpr_quasiimpes" | "cpr" = "cpr_trueimpes" (setupPropertyTree.cpp:46-138).
     /// The true-IMPES variant needs the model's storage term: the caller hands the result of
     /// ISTLSolverEbos::getTrueImpesWeights (ISTLSolverEbos.hpp:466-475) to setCprWeights() before each solve.
     hipSolverBackend(int linear_solver_verbosity, int maxit_, double tolerance_, unsigned int deviceID_,
-                     const std::string& ilu_reorder = "graph_coloring", double ilu_relaxation = 0.9,
+                     const std::string& ilu_reorder = "auto", double ilu_relaxation = 0.9,
                      const std::string& linsolver = "ilu0", int cpr_reuse_setup = 3, int cpr_amg_ilu_levels = -1, int cpr_gather_rows = 0)
         : Base(linear_solver_verbosity, maxit_, tolerance_, deviceID_) {
         static_assert(block_size == 3, "libopmhip handles 3x3 blocks (three-phase black-oil)");
@@ -53,10 +56,11 @@ public:
         cfg.device_id = (int)deviceID;
         cfg.ilu_relaxation = ilu_relaxation;
         if (ilu_reorder == "level_scheduling") cfg.reorder = OPMHIP_REORDER_LEVEL_SCHEDULING;
-        else if (ilu_reorder == "graph_coloring" || ilu_reorder.empty()) cfg.reorder = OPMHIP_REORDER_GRAPH_COLORING;
+        else if (ilu_reorder == "graph_coloring") cfg.reorder = OPMHIP_REORDER_GRAPH_COLORING;
+        else if (ilu_reorder == "graph_coloring_greedy") cfg.reorder = OPMHIP_REORDER_GRAPH_COLORING_GREEDY;
         else if (ilu_reorder == "line_coloring") cfg.reorder = OPMHIP_REORDER_LINE_COLORING;
-        else if (ilu_reorder == "auto") cfg.reorder = OPMHIP_REORDER_AUTO;   // line colouring on large structured grids, greedy colouring elsewhere
-        else throw std::logic_error("Error invalid argument for --opencl-ilu-reorder, usage: '--opencl-ilu-reorder=[level_scheduling|graph_coloring|line_coloring|auto]'");
+        else if (ilu_reorder == "auto" || ilu_reorder.empty()) cfg.reorder = OPMHIP_REORDER_AUTO;   // opmhip_default_config's
+        else throw std::logic_error("Error invalid argument for --opencl-ilu-reorder, usage: '--opencl-ilu-reorder=[auto|level_scheduling|graph_coloring|graph_coloring_greedy|line_coloring]'");
         if (linsolver == "cpr_quasiimpes") cfg.preconditioner = OPMHIP_PRECOND_CPR_QUASIIMPES;
         else if (linsolver == "cpr" || linsolver == "cpr_trueimpes") cfg.preconditioner = OPMHIP_PRECOND_CPR_TRUEIMPES;
         else if (linsolver != "ilu0") throw std::invalid_argument(linsolver + " is not a valid setting for --linear-solver-configuration with --accelerator-mode=hip. Please use ilu0, cpr, cpr_trueimpes, or cpr_quasiimpes");

@@ -1,5 +1,6 @@
 """BASELINE.json's full size (configs[1]: 100 x 100 x 100, 10^6 cells, 6.94 * 10^6 blocks) on the GPU, through
-size-independent properties - the oracle would need minutes here, so nothing in this file calls it:
+size-independent properties (this file calls no oracle; the bit-for-bit comparison with the oracle AT this size - Jacobian, residual,
+factors, one product, one M^-1, the solve's half iteration - is tests/test_gpu_fullsize_oracle.py, about 10 s of oracle time per ordering):
   SpMV          linearity, and A * 1 against row sums formed independently with numpy;
   ILU0          M^-1 (L (U z)) = z with L, U taken from the factors the device reports (w = 1);
   BiCGStab      the returned x satisfies ||b - A x|| <= tol ||b|| with A x formed by scipy on the host;

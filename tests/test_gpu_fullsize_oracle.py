@@ -1,0 +1,104 @@
+"""The benchmarked kernels at the benchmarked size, bit for bit against the oracle.
+
+BASELINE.json configs[1] (100 x 100 x 100, 10^6 cells, 6.94 * 10^6 blocks) in the configuration bench.py runs - no ordering
+flag: opmhip_default_config's `auto`, which must resolve to the line colouring with chains of 10 here - and once in the
+reference's accelerator default (`graph_coloring`, Jones-Plassmann rounds, bda/Reorder.cpp:59-172).  What is timed there is what is
+compared here: k_assemble over 111 112 tiles, k_spmv_pipe_st with ~16 tiles per workgroup, k_ilu_factor with its symbolic
+elimination lists on 62 500 chains per colour, the stencil-form chain sweeps of M^-1, BiCGStab's half-iteration bookkeeping.
+
+The oracle (oracle/, one thread) needs about 0.7 s for an assembly, 0.2 s for a factorisation and 0.2 s for a BiCGStab iteration at
+this size (bench.py's cpu_baseline.single_thread), so the whole module costs it well under a minute.  Order of operations the oracle
+follows: linalg/ParallelOverlappingILU0.hpp:439-494 (factorisation), :848-903 (application), bda/cusparseSolverBackend.cu:60-184
+(BiCGStab's half steps)."""
+import numpy as np
+import pytest
+
+from helpers import oracle_solve_in_order
+
+pytestmark = pytest.mark.gpu
+N = 100
+DT = 86400.0       # bench.py's first time step
+
+
+@pytest.fixture(scope="module", params=[None, "graph_coloring"], ids=["library_default", "graph_coloring"])
+def big(request, pkg, orc):
+    import oracle_bind
+    case = pkg.decks.cartesian_case(N, N, N, state="mixed", heterogeneous=False)
+    src = pkg.decks.five_spot_source(case, rate_sm3_per_day=pkg.decks.BENCH_RATE_SM3_PER_DAY)
+    kw = {} if request.param is None else {"reorder": request.param}
+    m = pkg.capi.HipModel(case, tolerance=1e-2, maxit=200, ilu_relaxation=0.9, **kw)     # bench.py's solver settings
+    o = oracle_bind.OracleModel(orc, case)
+    for h in (m, o):
+        h.set_state(case["pv"], case["meaning"])
+        h.set_source(src)
+    jac, res = m.assemble(DT, 0)
+    jo, ro = o.assemble(DT, 0)
+    to, fr, rpc = m.ordering()
+    rr, rc, rv = orc.reorder_matrix(case["Nb"], case["rowptr"], case["col"], jo, to, fr)
+    return dict(case=case, m=m, o=o, jac=jac, res=res, jo=jo, ro=ro, to=to, fr=fr, rpc=rpc, rr=rr, rc=rc, rv=rv, param=request.param)
+
+
+def test_the_default_is_the_measured_configuration(big):
+    """opmhip_default_config: reorder = auto -> line colouring, chains of 10, two colours at 10^6 structured rows (what bench.py
+    reports in config.ilu_ordering without being told); an explicit graph_coloring stays the reference's Jones-Plassmann"""
+    info = big["m"].ordering_info()
+    if big["param"] is None:
+        assert info["ilu_ordering"] == "line_coloring" and info["chain_length"] == 10 and info["colors"] == 2
+    else:
+        assert info["ilu_ordering"] == "graph_coloring" and info["chain_length"] == 0 and info["colors"] >= 2
+    assert info["colors"] == len(big["rpc"]) and int(big["rpc"].sum()) == big["case"]["Nb"]
+
+
+def test_jacobian_and_residual_bitwise(big):
+    assert np.array_equal(big["res"], big["ro"])
+    assert np.array_equal(big["jac"], big["jo"])
+
+
+def test_spmv_bitwise(big, orc):
+    m, case, to, fr = big["m"], big["case"], big["to"], big["fr"]
+    Nb = case["Nb"]
+    x = np.random.default_rng(41).standard_normal(3 * Nb)
+    y = m.spmv(x)
+    yo = orc.spmv(Nb, big["rr"], big["rc"], big["rv"], np.ascontiguousarray(x.reshape(Nb, 3)[fr].reshape(-1))).reshape(Nb, 3)[to].reshape(-1)
+    assert np.array_equal(y, yo)
+
+
+def test_ilu0_factors_and_application_bitwise(big, orc):
+    m, case, to, fr = big["m"], big["case"], big["to"], big["fr"]
+    Nb = case["Nb"]
+    lu = m.ilu0_factor()
+    lu_o = orc.ilu0_factor(Nb, big["rr"], big["rc"], big["rv"])
+    assert np.array_equal(lu, lu_o)
+    d = np.random.default_rng(42).standard_normal(3 * Nb)
+    z = m.ilu0_apply(d)
+    zo = orc.ilu0_apply(Nb, big["rr"], big["rc"], lu_o, np.ascontiguousarray(d.reshape(Nb, 3)[fr].reshape(-1)), w=0.9, mode="post_scale")
+    assert np.array_equal(z, zo.reshape(Nb, 3)[to].reshape(-1))
+
+
+def test_solve_stops_on_the_oracles_half_iteration_and_the_next_iteration_follows(big, orc):
+    """solveJacobianSystem on the assembled system: the oracle's half iteration, its reduction and its x (identical preconditioner and
+    product bits; the scalar products are summed in another order); then updateSolution on both sides and a second assembly -
+    Jacobian and residual of Newton iteration 1, storage term and switched cells included, again bit for bit"""
+    m, o, case, to, fr = big["m"], big["o"], big["case"], big["to"], big["fr"]
+    Nb = case["Nb"]
+    m.assemble(DT, 0, fetch=False)            # the tests before this one may have left other factors / vectors behind
+    sol = m.solve_jacobian_system()
+    x = m.get_result()
+    xo, so = oracle_solve_in_order(orc, Nb, case["rowptr"], case["col"], big["jo"], big["ro"], to, fr, tol=1e-2, maxit=200, w=0.9)
+    assert sol.converged and so.converged and sol.it == so.it and sol.iterations == so.iterations
+    assert abs(sol.reduction - so.reduction) <= 1e-8 * so.reduction
+    np.testing.assert_allclose(x, xo, rtol=1e-8, atol=1e-11 * np.abs(xo).max())
+    # the same update on both sides (the oracle's x: the two states stay comparable bit for bit)
+    m.update(xo, 1.0)
+    o.update(xo)
+    pm, mm = m.get_state()
+    po, mo = o.get_state()
+    assert np.array_equal(mm, mo) and np.array_equal(pm, po)
+    j1, r1 = m.assemble(DT, 1)
+    j1o, r1o = o.assemble(DT, 1)
+    assert np.array_equal(r1, r1o) and np.array_equal(j1, j1o)
+    # and the convergence norms of that iteration (getReservoirConvergence): same cells, same maxima
+    cm, co = m.convergence(DT, 1e-2), o.convergence(DT, 1e-2)
+    assert np.array_equal(cm[3:6], co[3:6])                       # the maxima (CNV numerators) are exact
+    np.testing.assert_allclose(cm[6:10], co[6:10], rtol=1e-12)    # sums over 10^6 cells: order of summation only
+    np.testing.assert_allclose(cm[[0, 1, 2, 14, 15, 16]], co[[0, 1, 2, 14, 15, 16]], rtol=1e-9)
