@@ -235,6 +235,12 @@ def cpu_baseline(pkg, case, src, nnzb):
     return out
 
 
+# linear iterations per Newton iteration of the N = 1 run of this bench (start-up window, default flags; profiles/r05_*): what the
+# decomposed runs' counts are put beside
+SINGLE_DOMAIN_LIN_ITS = {"ilu0": 17.5, "cpr": 4.75, "cpr_trueimpes": 4.75, "cpr_quasiimpes": 3.8}
+# linear iterations per Newton iteration of the N = 1 run of this bench (start-up window, default flags; profiles/r05_*): what the
+# decomposed runs' counts are put beside
+SINGLE_DOMAIN_LIN_ITS = {"ilu0": 17.5, "cpr": 4.75, "cpr_trueimpes": 4.75, "cpr_quasiimpes": 3.8}
 LINE_LIMIT = 4096   # bytes of the one line on stdout (round 4's 22 KB line could not be parsed from the driver's 8 KB tail)
 
 
@@ -471,9 +477,39 @@ def main():
                 if name in ("spmv", "ilu_apply", "vector", "cpr_amg"):
                     kernels[name]["iterations_profiled"] = its_profiled
                     kernels[name]["solves_profiled"] = solves_profiled
+        # communication spans (decomposed runs; they overlap the kernel scopes): per rank launches and milliseconds, then max / mean over
+        # the ranks - with the iteration count beside them, so that "slower because of more iterations" and "slower because of the
+        # exchanges" come apart (parity caveat)
+        comm = None
+        if dist is not None:
+            mine = {k: (prof.get(k, (0, 0.0))[0], prof.get(k, (0, 0.0))[1]) for k in ("halo", "allreduce", "cpr_gather")}
+            every = [None] * world
+            dist.all_gather_object(every, mine)
+            comm = {}
+            for k in mine:
+                avg = [e[k][1] / e[k][0] for e in every if e[k][0]]
+                tot = [e[k][1] for e in every]
+                if avg:
+                    comm[k] = {"launches_per_rank": max(e[k][0] for e in every), "avg_ms_max": round(max(avg), 5), "avg_ms_mean": round(sum(avg) / len(avg), 5),
+                               "total_ms_max": round(max(tot), 3), "total_ms_mean": round(sum(tot) / len(tot), 3)}
+        # communication spans (decomposed runs; they overlap the kernel scopes): per rank launches and milliseconds, then max / mean over
+        # the ranks - with the iteration count beside them, so that "slower because of more iterations" and "slower because of the
+        # exchanges" come apart (parity caveat)
+        comm = None
+        if dist is not None:
+            mine = {k: (prof.get(k, (0, 0.0))[0], prof.get(k, (0, 0.0))[1]) for k in ("halo", "allreduce", "cpr_gather")}
+            every = [None] * world
+            dist.all_gather_object(every, mine)
+            comm = {}
+            for k in mine:
+                avg = [e[k][1] / e[k][0] for e in every if e[k][0]]
+                tot = [e[k][1] for e in every]
+                if avg:
+                    comm[k] = {"launches_per_rank": max(e[k][0] for e in every), "avg_ms_max": round(max(avg), 5), "avg_ms_mean": round(sum(avg) / len(avg), 5),
+                               "total_ms_max": round(max(tot), 3), "total_ms_mean": round(sum(tot) / len(tot), 3)}
         ls_bytes = sum(Bm[k] * prof[k][0] for k in ("spmv", "ilu_apply", "ilu_factor", "vector"))
         ls_ms = sum(prof[k][1] for k in ("spmv", "ilu_apply", "ilu_factor", "vector"))
-        return {"elapsed": elapsed, "steps": steps, "kernels": kernels, "spmv_boundary_share_of_time": boundary_share,
+        return {"elapsed": elapsed, "steps": steps, "kernels": kernels, "spmv_boundary_share_of_time": boundary_share, "comm": comm, "comm": comm,
                 "profiled": {"every": PROFILE_EVERY, "solves": solves_profiled, "linear_iterations": its_profiled,
                              "linear_iterations_per_profiled_solve": (its_profiled / solves_profiled) if solves_profiled else None},
                 "linear_iterations_per_newton": (rep.total_linear_iterations - rep0.total_linear_iterations) / steps,
@@ -612,6 +648,12 @@ def main():
         "cpr_reuse_setup_2_sync": cpr_sides.get("cpr_reuse_setup_2_sync"),
         "preconditioner": a.preconditioner,
         "rccl": rccl,
+        # decomposed runs: the communication spans of the profiled solves of the window behind `value` (halo: pack -> exchange -> ghosts in, on
+        # the halo stream beside the interior tiles; allreduce: local sums -> all-reduce; cpr_gather: the joined level's all-gather + cycle),
+        # max / mean over the ranks, and the iteration count next to the one-domain figure of the same case (N = 1 run of this bench)
+        "comm": None if W["comm"] is None else dict(W["comm"], profiled_solves=W["profiled"]["solves"], profiled_every=PROFILE_EVERY,
+                                                    linear_iterations_per_newton=round(W["linear_iterations_per_newton"], 2),
+                                                    single_domain_linear_iterations_per_newton=SINGLE_DOMAIN_LIN_ITS.get(a.preconditioner)),
         "device": device_info(torch, local_rank),
         "stream_ceiling": {"read_GBps": round(stream_GBps, 1) if stream_GBps else None, "bytes_per_launch": 72 * nnzb,
                            "avg_launch_ms": round(stream_ms, 5) if stream_ms else None, "error": stream.get("error"),

@@ -117,7 +117,8 @@ typedef struct opmhip_config {
                             * those levels - their own entries plus the Galerkin sums of the couplings between aggregates of different
                             * subdomains - are joined into one system that every rank holds, coarsens further and cycles on (one all-gather
                             * of a right-hand side per application, one of matrix values per solve), and the post-smoothing residual
-                            * d - A (0, x_p, 0) is the whole system's.  Aggregates never cross a rank boundary.  0: the default (100 000: on a 10^6-cell subdomain its third level, aggregates of ~15 cells);
+                            * d - A (0, x_p, 0) is the whole system's.  Aggregates never cross a rank boundary.  0: the default - over the loopback communicator ON with 100 000 rows (on a 10^6-cell subdomain its third level, aggregates of ~15 cells), over
+                            * RCCL OFF until a multi-GPU run has covered its collectives (no round has had more than one GPU; ask for it with a positive value);
                             * < 0: off - one hierarchy per subdomain, no communication inside the preconditioner, iteration counts that
                             * grow with the number of ranks.  Ignored on a single rank; cpr_amg_ilu_levels and cpr_async_setup are ignored
                             * where it is in force.  (was reserved[1] until ABI 7) */
@@ -578,8 +579,14 @@ int opmhip_set_halo(opmhip_ctx* ctx, long long global_cells, int nneigh, const i
  * the BiCGStab p- / (r, x)-update), 2 ILU0 factorisation, 3 the remaining BiCGStab vector / reduction kernels (one
  * scope between two operator applications), 4 assembly kernel, 5 intensive-quantity update, 6 convergence, 7 the pressure
  * AMG cycle of CPR, 8 decomposed runs: the second launch of an operator application (the boundary tiles, multiplied after
- * the halo exchange that ran beside the interior tiles of class 0). */
-#define OPMHIP_PROF_CLASSES 9
+ * the halo exchange that ran beside the interior tiles of class 0).
+ * Communication spans of decomposed runs (ABI 8; they OVERLAP the kernel classes - a halo exchange runs beside class 0, an
+ * all-reduce inside class 3 - and are what the reference's back-ends have no counterpart for, being single-process): 9 one halo
+ * exchange, pack -> send / receive -> ghosts in place, on the stream it runs on (Dune's copyOwnerToAll in front of the operator,
+ * linalg/ParallelOverlappingILU0.hpp:897, WellOperators.hpp:127-138); 10 one global reduction, local sums' kernel -> all-reduce ->
+ * result on the device (BiCGStab's scalar products; the convergence sums of BlackoilModelEbos.hpp:599-603); 11 CPR across the ranks:
+ * the all-gather of the joined level's right-hand side plus the cycle every rank runs on it. */
+#define OPMHIP_PROF_CLASSES 12
 /* on = 0: off; 1: every scope; k > 1: the linear-solver classes (0, 1, 3) are recorded in every k-th solve_system call
  * only - an event record costs a few microseconds of bubble on the stream and a BiCGStab iteration holds seven of
  * them.  Also resets the accumulated numbers. */

@@ -313,7 +313,8 @@ class HipSolver:
         names = {v: k for k, v in REORDER.items()}
         return {"ilu_ordering": names[info[0]], "chain_length": int(info[1]), "colors": int(info[2]), "cpr_amg_ilu_levels": int(info[3])}
 
-    PROF = ["spmv", "ilu_apply", "ilu_factor", "vector", "assemble", "iq_update", "convergence", "cpr_amg", "spmv_boundary"]
+    PROF = ["spmv", "ilu_apply", "ilu_factor", "vector", "assemble", "iq_update", "convergence", "cpr_amg", "spmv_boundary",
+            "halo", "allreduce", "cpr_gather"]   # the last three: communication spans of decomposed runs (they overlap the kernel scopes)
 
     def profile_enable(self, on=True):
         self._check(lib().opmhip_profile_enable(self._h, int(on)))

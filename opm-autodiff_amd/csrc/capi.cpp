@@ -307,7 +307,9 @@ int opmhip_solve_system(opmhip_ctx* c, int N, int nnz, int dim, double* vals, co
         if ((rc = upload_wells(c, wells))) return rc;
         OPMHIP_HIP(c, hipStreamSynchronize(c->stream));
         const double t1 = now();
-        launch_ilu_factor(c, zfix && !zfixSeparate);  // ... applied as the rows are staged
+        FactorRider rider;   // CPR: weights and level 0's values of the pressure hierarchy are formed while the rows are in LDS
+        if ((rc = cpr_factor_rider(c, &rider))) return rc;
+        launch_ilu_factor(c, zfix && !zfixSeparate, &rider);  // ... applied as the rows are staged
         OPMHIP_HIP(c, hipGetLastError());
         OPMHIP_HIP(c, hipStreamSynchronize(c->stream));
         c->factored = true;
@@ -600,6 +602,7 @@ int opmhip_profile_get(opmhip_ctx* c, int cls, long long* launches, double* tota
         Profiler& P = c->prof;
         prof_flush(c);
         OPMHIP_HIP(c, hipStreamSynchronize(c->stream));
+        if (c->comm.hstream) OPMHIP_HIP(c, hipStreamSynchronize(c->comm.hstream));   // halo spans are stamped on the halo stream
         for (size_t i = 0; i < P.used; ++i) {
             float ms = 0.f;
             if (P.cls[i] >= 0 && P.e1[i] >= 0 && hipEventElapsedTime(&ms, P.ev[P.e0[i]], P.ev[P.e1[i]]) == hipSuccess) {

@@ -84,9 +84,16 @@ __global__ void k_pack_u8(int n, const int* __restrict__ idx, const unsigned cha
     } while (0)
 
 // sum (op 0) / max (op 1) of n <= 16 doubles over all ranks, in place, result identical on every rank
+static int allreduce_body(opmhip_ctx* c, double* d_buf, int n, int op);
 int comm_allreduce(opmhip_ctx* c, double* d_buf, int n, int op) {
+    if (c->comm.nranks <= 1) return OPMHIP_SUCCESS;
+    const int span = c->comm.reduce_span_open ? -1 : prof_span_begin(c, PROF_ALLREDUCE);   // a caller's span already covers its local sums and this
+    const int rc = allreduce_body(c, d_buf, n, op);
+    prof_span_end(c, span);
+    return rc;
+}
+static int allreduce_body(opmhip_ctx* c, double* d_buf, int n, int op) {
     CommDev& C = c->comm;
-    if (C.nranks <= 1) return OPMHIP_SUCCESS;
     if (C.kind == COMM_RCCL) {
         NCCLCHK(c, g_rccl.AllReduce(d_buf, d_buf, (size_t)n, ncclDouble, op == 0 ? ncclSum : ncclMax, (ncclComm_t)C.nccl, c->stream));
         return OPMHIP_SUCCESS;
@@ -152,11 +159,19 @@ static bool loopback_bystander(CommDev& C) {
     pthread_barrier_wait(&G->barrier);
     return true;
 }
+static int halo_f64_body(opmhip_ctx* c, double* vec, int w, hipStream_t s);
 int comm_halo_f64(opmhip_ctx* c, double* vec, int w, hipStream_t s) {
     CommDev& C = c->comm;
     if (loopback_bystander(C)) return OPMHIP_SUCCESS;
     if (!C.halo_set || C.nneigh == 0 || C.kind == COMM_NONE) return OPMHIP_SUCCESS;
     if (!s) s = c->stream;
+    const int span = prof_span_begin(c, PROF_HALO, s);   // pack -> exchange -> ghosts in, on the stream the exchange runs on
+    const int rc = halo_f64_body(c, vec, w, s);
+    prof_span_end(c, span, s);
+    return rc;
+}
+static int halo_f64_body(opmhip_ctx* c, double* vec, int w, hipStream_t s) {
+    CommDev& C = c->comm;
     const int nsend = C.send_ptr[C.nneigh];
     if (nsend > 0)
         hipLaunchKernelGGL(k_pack_f64, dim3((nsend * w + 255) / 256), dim3(256), 0, s, nsend, w, C.d_send_idx, vec, C.d_sendbuf);

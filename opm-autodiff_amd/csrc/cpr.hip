@@ -1176,6 +1176,29 @@ static int cpr_weights(opmhip_ctx* c) {
     hipLaunchKernelGGL(k_cpr_weights, g256(P.Nb), dim3(256), 0, c->stream, P.Nb, P.d_diag, c->d_A, R.d_w);
     return OPMHIP_SUCCESS;
 }
+// The rider of this solve's factorisation (FactorRider, solver.hip: k_ilu_factor<RIDER>): level 0's image is set up if it is not yet,
+// weights that do not come from the matrix (true-IMPES from the state, or handed in) are formed now, quasi-IMPES weights ride along.
+// OPMHIP_CPR_PVALS_SEPARATE=1 (measurement switch): the passes of their own, as before.
+static int cpr_setup_level0(opmhip_ctx* c);
+static bool cpr_gathering(const opmhip_ctx* c);
+int cpr_factor_rider(opmhip_ctx* c, FactorRider* r) {
+    CprDev& R = c->cpr;
+    *r = FactorRider();
+    static const bool separate = tuning_env("OPMHIP_CPR_PVALS_SEPARATE") != nullptr;
+    if (separate || !use_cpr(c)) return OPMHIP_SUCCESS;
+    int rc;
+    if (!R.level0 && (rc = cpr_setup_level0(c))) return rc;
+    const bool fromMatrix = !R.w_given && c->cfg.preconditioner != OPMHIP_PRECOND_CPR_TRUEIMPES;
+    if (!fromMatrix && (rc = cpr_weights(c))) return rc;
+    r->mode = fromMatrix ? 2 : 1;
+    r->w = R.d_w;
+    r->ap = R.lv[0].d_val;
+    r->pcol = R.d_pcol;
+    r->W = R.lv[0].W;
+    r->ghostFrom = (c->pat.Nghost > 0 && !cpr_gathering(c)) ? c->pat.Nb : INT_MAX;
+    R.pvals_fresh = true;
+    return OPMHIP_SUCCESS;
+}
 // levels of up to this many rows are kept row-major and run the lane-group kernels (OPMHIP_CPR_LPR_ROWS: measurement switch)
 static int cpr_lpr_rows() {
     static const int v = [] { const char* e = tuning_env("OPMHIP_CPR_LPR_ROWS"); return e ? std::atoi(e) : CPR_LPR_ROWS; }();
@@ -1191,7 +1214,25 @@ static int cpr_ilu_levels(const opmhip_ctx* c) {
 }
 int cpr_ilu_levels_in_force(const opmhip_ctx* c) { return use_cpr(c) ? (cpr_gathering(c) ? 0 : cpr_ilu_levels(c)) : 0; }
 // ---- level 0: belongs to the PATTERN (image, stencil form, block-vector work space): built once per context ------------------
+static int cpr_setup_level0_body(opmhip_ctx* c);
+// a set-up that fails half way (an ILU schedule the level cannot take, a failed allocation) gives back what it allocated: the retry of
+// the next solve starts from a clean slate and nothing piles up in the context
 static int cpr_setup_level0(opmhip_ctx* c) {
+    CprDev& R = c->cpr;
+    const size_t mark = c->allocs.size();
+    const bool hadW = R.d_w != nullptr;
+    const int rc = cpr_setup_level0_body(c);
+    if (rc) {
+        (void)hipStreamSynchronize(c->stream);
+        while (c->allocs.size() > mark) { (void)hipFree(c->allocs.back()); c->allocs.pop_back(); }
+        if (!hadW) R.d_w = nullptr;
+        R.d_r = R.d_y = R.d_z = R.d_pcol = nullptr;
+        R.lv.clear();
+        R.level0 = false;
+    }
+    return rc;
+}
+static int cpr_setup_level0_body(opmhip_ctx* c) {
     const Pattern& P = c->pat;
     CprDev& R = c->cpr;
     int rc;
@@ -1434,7 +1475,15 @@ static int cpr_upload_coarse(opmhip_ctx* c, CprDev& R, const CprHostCoarse& H, b
 // plus the Galerkin sums of the fine couplings between the aggregates of different subdomains - are gathered into ONE system that every
 // rank holds, coarsens further and cycles on redundantly: one all-gather of a right-hand side per application, one of matrix values per
 // solve.  oracle: orc_cpr_solve_blocks with gather_rows.
-static bool cpr_gathering(const opmhip_ctx* c) { return c->comm.nranks > 1 && c->comm.kind != COMM_NONE && c->cfg.cpr_gather_rows >= 0; }
+// cpr_gather_rows = 0 ("the default") means ON over the loopback communicator and OFF over RCCL: the spanning stage's collectives
+// (ncclAllGather on the context stream, the w = 1 / w = 2 halo exchanges inside launch_cpr_apply, the joined level's set-up exchanges) have
+// only ever run as threads on one GPU - no record of any round takes them with nranks > 1 over RCCL - and a default must not be a path
+// that was never executed.  A positive cpr_gather_rows asks for it explicitly on either communicator.
+static bool cpr_gathering(const opmhip_ctx* c) {
+    if (c->comm.nranks <= 1 || c->comm.kind == COMM_NONE) return false;
+    const int g = c->cfg.cpr_gather_rows;
+    return g > 0 || (g == 0 && c->comm.kind != COMM_RCCL);
+}
 static int cpr_stop_rows(const opmhip_ctx* c) { return cpr_gathering(c) ? (c->cfg.cpr_gather_rows > 0 ? c->cfg.cpr_gather_rows : 100000) : CPR_COARSE_DIRECT; }
 // `bytes` bytes of every rank, in rank order, on every rank (set-up only: staged through device buffers of its own)
 static int cpr_host_allgather(opmhip_ctx* c, const void* src, size_t bytes, std::vector<char>& dst) {
@@ -1445,7 +1494,8 @@ static int cpr_host_allgather(opmhip_ctx* c, const void* src, size_t bytes, std:
     double *d_s = nullptr, *d_r = nullptr;
     if (hipMalloc((void**)&d_s, cnt * sizeof(double)) != hipSuccess || hipMalloc((void**)&d_r, cnt * nr * sizeof(double)) != hipSuccess) {
         if (d_s) (void)hipFree(d_s);
-        // (the peers would wait for this rank in the exchange: take part in it with what there is)
+        // without its buffers this rank cannot enter the exchange and its peers wait in it - the one failure of the set-up that is not
+        // agreed on first (cpr_gather_setup); the buffers are a few integers per row of the joined level
         return fail(c, OPMHIP_DEVICE_ERROR, "cpr: no device memory for the set-up exchange of the joined level");
     }
     int rc = [&]() -> int {
@@ -1469,18 +1519,31 @@ static int cpr_gather_setup(opmhip_ctx* c, const CprHostCoarse& H) {
     CprDev& R = c->cpr;
     CprGatherDev& G = R.gather;
     const int nr = c->comm.nranks, me = c->comm.rank;
-    if (P.Nghost > 0 && !c->comm.halo_set) return fail(c, OPMHIP_NOT_READY, "cpr: the joined coarse level needs the halo lists (opmhip_set_halo) before the first solve");
-    int rc;
+    // A failure of ONE rank between two exchanges must not leave the others waiting in the next one: the rank notes its first error
+    // (text in c->err), goes on through every exchange with what it has, and the error flag travels with the next payload - all ranks
+    // then leave together, the failed one with its own status, the others with a status that names it.
+    int lerr = 0, rc;
+    auto note = [&](int e) { if (e && !lerr) lerr = e; };
+    auto first_failed = [&](const std::vector<char>& b, size_t stride, size_t at, const char* where) -> int {   // the flag at byte `at` of every rank's record
+        for (int r = 0; r < nr; ++r) {
+            int f;
+            std::memcpy(&f, b.data() + (size_t)r * stride + at, sizeof f);
+            if (f) return lerr ? lerr : fail(c, f, "cpr: rank %d failed in the set-up of the joined level (%s)", r, where);
+        }
+        return OPMHIP_SUCCESS;
+    };
+    if (P.Nghost > 0 && !c->comm.halo_set) note(fail(c, OPMHIP_NOT_READY, "cpr: the joined coarse level needs the halo lists (opmhip_set_halo) before the first solve"));
     std::vector<char> buf;
     const size_t g = R.lv.size() - 1;
     const int nloc = R.lv[g].n;
     // 1. sizes of everybody's slice, of everybody's subdomain
-    const int mine[2] = {nloc, P.Nb};
+    const int mine[3] = {nloc, P.Nb, lerr};
     if ((rc = cpr_host_allgather(c, mine, sizeof mine, buf))) return rc;
+    if ((rc = first_failed(buf, sizeof mine, 2 * sizeof(int), "halo lists"))) return rc;
     std::vector<int> offs(nr + 1, 0), foffs(nr + 1, 0);
     int maxn = 1;
     for (int r = 0; r < nr; ++r) {
-        int v[2];
+        int v[3];
         std::memcpy(v, buf.data() + (size_t)r * sizeof v, sizeof v);
         offs[r + 1] = offs[r] + v[0];
         foffs[r + 1] = foffs[r] + v[1];
@@ -1498,18 +1561,11 @@ static int cpr_gather_setup(opmhip_ctx* c, const CprHostCoarse& H) {
     std::vector<double> hv((size_t)2 * P.Nloc, 0.0);
     for (int i = 0; i < P.Nb; ++i) { hv[(size_t)2 * i] = (double)(offs[me] + cagg[i]); hv[(size_t)2 * i + 1] = (double)(foffs[me] + i); }
     {
-        double* d_hv = nullptr;
-        if (hipMalloc((void**)&d_hv, hv.size() * sizeof(double)) != hipSuccess) return fail(c, OPMHIP_DEVICE_ERROR, "cpr: no device memory for the set-up exchange of the joined level");
-        rc = [&]() -> int {
-            OPMHIP_HIP(c, hipMemcpyAsync(d_hv, hv.data(), hv.size() * sizeof(double), hipMemcpyHostToDevice, c->stream));
-            int r2 = comm_halo_f64(c, d_hv, 2);
-            if (r2) return r2;
-            OPMHIP_HIP(c, hipMemcpyAsync(hv.data(), d_hv, hv.size() * sizeof(double), hipMemcpyDeviceToHost, c->stream));
-            OPMHIP_HIP(c, hipStreamSynchronize(c->stream));
-            return OPMHIP_SUCCESS;
-        }();
-        (void)hipFree(d_hv);
-        if (rc) return rc;
+        double* d_hv = c->d_stageV;   // 3 doubles per local cell, idle between the uploads and the solve: nothing to allocate, nothing to fail
+        OPMHIP_HIP(c, hipMemcpyAsync(d_hv, hv.data(), hv.size() * sizeof(double), hipMemcpyHostToDevice, c->stream));
+        if ((rc = comm_halo_f64(c, d_hv, 2))) return rc;
+        OPMHIP_HIP(c, hipMemcpyAsync(hv.data(), d_hv, hv.size() * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+        OPMHIP_HIP(c, hipStreamSynchronize(c->stream));
     }
     // 4. my rows of the joined level: my last level's entries, and one entry per pair (my aggregate, an aggregate of another rank) that a
     //    fine coupling joins
@@ -1526,10 +1582,10 @@ static int cpr_gather_setup(opmhip_ctx* c, const CprHostCoarse& H) {
         }
     G.nq = (int)qrow.size();
     std::vector<double> apg(std::max(G.nq, 1), 0.0);
-    if ((rc = dev_upload(c, &G.d_qrow, qrow))) return rc;
-    if ((rc = dev_upload(c, &G.d_qentry, qentry))) return rc;
-    if ((rc = dev_alloc(c, &G.d_apg, (size_t)std::max(G.nq, 1)))) return rc;
-    if (G.nq > 0) {
+    note(dev_upload(c, &G.d_qrow, qrow));
+    note(dev_upload(c, &G.d_qentry, qentry));
+    note(dev_alloc(c, &G.d_apg, (size_t)std::max(G.nq, 1)));
+    if (G.nq > 0 && !lerr) {
         hipLaunchKernelGGL(k_cpr_ghost_pvals, g256(G.nq), dim3(256), 0, c->stream, G.nq, G.d_qrow, G.d_qentry, c->d_A, R.d_w, G.d_apg);
         OPMHIP_HIP(c, hipMemcpyAsync(apg.data(), G.d_apg, (size_t)G.nq * sizeof(double), hipMemcpyDeviceToHost, c->stream));
         OPMHIP_HIP(c, hipStreamSynchronize(c->stream));
@@ -1560,10 +1616,12 @@ static int cpr_gather_setup(opmhip_ctx* c, const CprHostCoarse& H) {
     }
     G.nnzloc = (int)cols.size();
     // 5. everybody's rows
-    if ((rc = cpr_host_allgather(c, &G.nnzloc, sizeof(int), buf))) return rc;
+    const int mine5[2] = {G.nnzloc, lerr};
+    if ((rc = cpr_host_allgather(c, mine5, sizeof mine5, buf))) return rc;
+    if ((rc = first_failed(buf, sizeof mine5, sizeof(int), "boundary couplings"))) return rc;
     std::vector<int> nnzs(nr);
     int maxnnz = 1;
-    for (int r = 0; r < nr; ++r) { std::memcpy(&nnzs[r], buf.data() + (size_t)r * sizeof(int), sizeof(int)); maxnnz = std::max(maxnnz, nnzs[r]); }
+    for (int r = 0; r < nr; ++r) { std::memcpy(&nnzs[r], buf.data() + (size_t)r * sizeof mine5, sizeof(int)); maxnnz = std::max(maxnnz, nnzs[r]); }
     std::vector<char> bl, bc, bv;
     {
         std::vector<int> t(maxn, 0);
@@ -1588,7 +1646,7 @@ static int cpr_gather_setup(opmhip_ctx* c, const CprHostCoarse& H) {
         int e = 0;
         for (int I = 0; I < offs[r + 1] - offs[r]; ++I) {
             for (int t = 0; t < rl[I]; ++t, ++e) {
-                if (rcs[e] < 0 || rcs[e] >= NG || e >= nnzs[r]) return fail(c, OPMHIP_ANALYSIS_FAILED, "cpr: the joined level's rows of rank %d are inconsistent", r);
+                if (rcs[e] < 0 || rcs[e] >= NG || e >= nnzs[r]) return fail(c, OPMHIP_ANALYSIS_FAILED, "cpr: the joined level's rows of rank %d are inconsistent", r);   // the same data on every rank: all leave here
                 J.col.push_back(rcs[e]); J.val.push_back(rv[e]); vunpad.push_back(r * maxnnz + e);
             }
             J.rowptr.push_back((int)J.col.size());
@@ -1603,25 +1661,28 @@ static int cpr_gather_setup(opmhip_ctx* c, const CprHostCoarse& H) {
     std::vector<int> posg;
     if (!ell_image(J, img0, posg, NG <= cpr_lpr_rows())) return fail(c, OPMHIP_ANALYSIS_FAILED, "cpr: a row of the joined level has %d entries (limit %d): lower opmhip_config.cpr_gather_rows' level count or raise the limit", img0.W, CPR_MAX_W);
     JD.lv.emplace_back();
-    if ((rc = upload_ell(c, img0, JD.lv[0]))) return rc;
+    // (from here on only device memory can fail, and on one rank alone: noted, agreed on at the end)
+    note(upload_ell(c, img0, JD.lv[0]));
     CprHostCoarse HJ;
     cpr_coarsen_host(J, posg, nullptr, nullptr, R.beta, cpr_lpr_rows(), 0, CPR_COARSE_DIRECT, HJ);
-    if ((rc = cpr_upload_coarse(c, JD, HJ, false))) return rc;
+    if (!lerr) note(cpr_upload_coarse(c, JD, HJ, false));
     // 7. what the solves need on the device
     G.nloc = nloc; G.off = offs[me]; G.NG = NG; G.maxn = maxn; G.maxnnz = maxnnz; G.nnzG = (int)J.col.size();
-    if ((rc = dev_alloc(c, &G.d_recv, (size_t)nr * maxn))) return rc;
-    if ((rc = dev_alloc(c, &G.d_vsend, (size_t)maxnnz))) return rc;
-    OPMHIP_HIP(c, hipMemsetAsync(G.d_vsend, 0, (size_t)maxnnz * sizeof(double), c->stream));
-    if ((rc = dev_alloc(c, &G.d_vrecv, (size_t)nr * maxnnz))) return rc;
-    if ((rc = dev_upload(c, &G.d_unpad, unpad))) return rc;
-    if ((rc = dev_upload(c, &G.d_vunpad, vunpad))) return rc;
-    if ((rc = dev_upload(c, &G.d_vpos, posg))) return rc;
-    if ((rc = dev_upload(c, &G.d_src, src))) return rc;
-    if ((rc = dev_upload(c, &G.d_xptr, xptr))) return rc;
-    if ((rc = dev_upload(c, &G.d_xidx, xidx))) return rc;
-    if ((rc = dev_upload(c, &G.d_cagg, cagg))) return rc;
-    if ((rc = dev_alloc(c, &G.d_send, (size_t)maxn))) return rc;   // my slice of the joined level's right-hand side: room for the largest slice
-    OPMHIP_HIP(c, hipMemsetAsync(G.d_send, 0, (size_t)maxn * sizeof(double), c->stream));
+    if (!lerr) note(dev_alloc(c, &G.d_recv, (size_t)nr * maxn));
+    if (!lerr) note(dev_alloc(c, &G.d_vsend, (size_t)maxnnz));
+    if (!lerr) OPMHIP_HIP(c, hipMemsetAsync(G.d_vsend, 0, (size_t)maxnnz * sizeof(double), c->stream));
+    if (!lerr) note(dev_alloc(c, &G.d_vrecv, (size_t)nr * maxnnz));
+    if (!lerr) note(dev_upload(c, &G.d_unpad, unpad));
+    if (!lerr) note(dev_upload(c, &G.d_vunpad, vunpad));
+    if (!lerr) note(dev_upload(c, &G.d_vpos, posg));
+    if (!lerr) note(dev_upload(c, &G.d_src, src));
+    if (!lerr) note(dev_upload(c, &G.d_xptr, xptr));
+    if (!lerr) note(dev_upload(c, &G.d_xidx, xidx));
+    if (!lerr) note(dev_upload(c, &G.d_cagg, cagg));
+    if (!lerr) note(dev_alloc(c, &G.d_send, (size_t)maxn));   // my slice of the joined level's right-hand side: room for the largest slice
+    if (!lerr) OPMHIP_HIP(c, hipMemsetAsync(G.d_send, 0, (size_t)maxn * sizeof(double), c->stream));
+    if ((rc = cpr_host_allgather(c, &lerr, sizeof lerr, buf))) return rc;
+    if ((rc = first_failed(buf, sizeof lerr, 0, "uploads of the joined level"))) return rc;
     G.on = true;
     return OPMHIP_SUCCESS;
 }
@@ -1652,6 +1713,17 @@ static int cpr_setup_coarse_now(opmhip_ctx* c) {
     const size_t mark = c->allocs.size();
     const bool gathered = cpr_gathering(c);
     rc = cpr_upload_coarse(c, R, H, gathered);
+    if (gathered) {   // a rank whose own hierarchy failed must not leave its peers waiting in the joined level's set-up: agree first
+        std::vector<char> flags;
+        const int mine = rc;
+        int r2 = cpr_host_allgather(c, &mine, sizeof mine, flags);
+        for (int r = 0; !r2 && !rc && r < c->comm.nranks; ++r) {
+            int f;
+            std::memcpy(&f, flags.data() + (size_t)r * sizeof f, sizeof f);
+            if (f) rc = fail(c, f, "cpr: rank %d failed to build its pressure hierarchy", r);
+        }
+        if (!rc) rc = r2;
+    }
     if (!rc && gathered) rc = cpr_gather_setup(c, H);
     if (rc) {
         (void)hipStreamSynchronize(c->stream);
@@ -1742,8 +1814,11 @@ int cpr_update(opmhip_ctx* c, bool solveBoundary) {
     R.recreate = false;
     if (!R.level0 && (rc = cpr_setup_level0(c))) return rc;
     const int ps = prof_begin(c, PROF_ILU_FACTOR);
-    if ((rc = cpr_weights(c))) { prof_end(c, ps); return rc; }
-    hipLaunchKernelGGL(k_cpr_pvals, g256(P.Nb), dim3(256), 0, c->stream, P.Nb, R.lv[0].W, P.d_rowptr, (P.Nghost > 0 && !cpr_gathering(c)) ? P.d_col : (const int*)nullptr, c->d_A, R.d_w, R.lv[0].d_val, R.d_pcol);
+    if (R.pvals_fresh) R.pvals_fresh = false;   // this solve's factorisation formed the weights and level 0's values as it staged the rows (FactorRider)
+    else {
+        if ((rc = cpr_weights(c))) { prof_end(c, ps); return rc; }
+        hipLaunchKernelGGL(k_cpr_pvals, g256(P.Nb), dim3(256), 0, c->stream, P.Nb, R.lv[0].W, P.d_rowptr, (P.Nghost > 0 && !cpr_gathering(c)) ? P.d_col : (const int*)nullptr, c->d_A, R.d_w, R.lv[0].d_val, R.d_pcol);
+    }
     if (!R.structured) {   // first solve, or a synchronous rebuild: from the pressure matrix just formed
         if ((rc = cpr_setup_coarse_now(c))) { prof_end(c, ps); return rc; }
     } else if (startAsync) {
@@ -1909,6 +1984,7 @@ static const double* cpr_gathered_cycle(opmhip_ctx* c, const double* d) {
         rl = to;
     }
     if (g == 0) keep(hipMemcpyAsync(G.d_send, L.d_r, (size_t)L.n * sizeof(double), hipMemcpyDeviceToDevice, c->stream) == hipSuccess ? 0 : OPMHIP_DEVICE_ERROR);
+    const int span = prof_span_begin(c, PROF_CPR_GATHER);   // the joined level: all-gather of its right-hand side, the cycle every rank runs on it
     keep(comm_allgather(c, G.d_send, G.d_recv, (size_t)G.maxn));
     {
         const bool ride = cpr_presmooth_rides(J, 0);
@@ -1916,6 +1992,7 @@ static const double* cpr_gathered_cycle(opmhip_ctx* c, const double* d) {
                            ride ? J.lv[0].d_dinv : (const double*)nullptr, ride ? J.lv[0].d_x : (double*)nullptr, done);
     }
     const double* xG = cpr_vcycle(c, J, 0);
+    prof_span_end(c, span);
     hipLaunchKernelGGL(k_cpr_prolong, g256(L.n), dim3(256), 0, c->stream, L.n, 1.0, G.d_cagg, xG + G.off, L.d_x, L.d_r, done);   // x' = x + (the joined level's result, per aggregate)
     keep(comm_halo_f64(c, L.d_r, 1));
     hipLaunchKernelGGL(k_cpr_post<false>, g256(L.n), dim3(256), 0, c->stream, L.n, L.W, R.omega, L.d_ecol, L.d_val, L.d_dinv, L.d_b, L.d_r, L.d_x2, (double*)nullptr, done, S);

@@ -7,6 +7,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <memory>
+#include <climits>
 #include <string>
 #include <vector>
 
@@ -204,6 +205,7 @@ struct CommDev {
     hipEvent_t ev_x = nullptr, ev_h = nullptr;
     double* halo_vec = nullptr;                  // loopback: the vector whose exchange comm_halo_end still has to drive
     const double* ag_send = nullptr;             // loopback: this rank's contribution to the all-gather under way
+    bool reduce_span_open = false;               // a caller of comm_allreduce times the reduction itself (its local sums included)
 };
 
 // CPR preconditioner (cpr.hip): pressure-AMG hierarchy, level 0 = the block pattern with scalar values
@@ -271,11 +273,30 @@ struct CprDev {
     double omega = 2.0 / 3.0, damp = 1.6, beta = 0.25;             // Jacobi damping, prolongation damping, strength threshold
     CprGatherDev gather;
     int apply_rc = 0;                                              // first failure of a collective inside an application (the BiCGStab driver looks at it)
+    bool pvals_fresh = false;                                      // the factorisation of this solve left weights and level 0's values behind (FactorRider): cpr_update skips its own pass
+};
+// What the block ILU0 factorisation does for the CPR on its way through the matrix (k_ilu_factor's rider): every row is in LDS, fixed up,
+// before its elimination starts - the pressure-column image of its blocks and its entries of the pressure matrix
+// a_p[k] = sum_r A_k[r][p] w_row[r] (PressureTransferPolicy::calculateCoarseEntries, PressureTransferPolicy.hpp:116-139) are written from
+// there (k_cpr_pvals' statements on the same values: the same bits) instead of by a second pass over the Jacobian.
+struct FactorRider {
+    int mode = 0;                 // 0: none; 1: weights read from w (true-IMPES or handed in); 2: quasi-IMPES weights formed from the row's diagonal block (k_cpr_weights' statements) and stored to w
+    double* w = nullptr;          // [Nb x 3]
+    double* ap = nullptr;         // level 0's ELL values [W x Nb]
+    double* pcol = nullptr;       // pressure columns, component-major [3][W x Nb]
+    int W = 0;
+    int ghostFrom = INT_MAX;      // columns >= this are left out (a subdomain's own pressure system): value 0
 };
 
 // per-kernel-class device timing with HIP events on the context's stream (opmhip_profile_*)
 enum ProfClass { PROF_SPMV = 0, PROF_ILU_APPLY, PROF_ILU_FACTOR, PROF_VECTOR, PROF_ASSEMBLE, PROF_IQ_UPDATE, PROF_CONVERGENCE, PROF_CPR_AMG,
                  PROF_SPMV_BOUNDARY,   // decomposed runs: the second launch of a product (boundary tiles, after the halo exchange)
+                 // communication spans of decomposed runs (prof_span_*): event pairs on the stream the step runs on, outside the chain of
+                 // the kernel scopes above and overlapping them - the per-phase timers of the reference's back-ends
+                 // (bda/cusparseSolverBackend.cu:303-308, 412-417; bda/openclSolverBackend.cpp:451-459) for what it has no kernels for
+                 PROF_HALO,            // one halo exchange: pack -> send / receive -> the ghosts are in (copyOwnerToAll, ParallelOverlappingILU0.hpp:897), on the stream it runs on
+                 PROF_ALLREDUCE,       // one global reduction: the local sums' kernel -> the all-reduce -> its result on the device (the sums behind BlackoilModelEbos.hpp:599-603 and the scalar products of BiCGStab)
+                 PROF_CPR_GATHER,      // CPR across the ranks: the all-gather of the joined level's right-hand side and the cycle every rank runs on it
                  PROF_COUNT };
 struct Profiler {
     bool enabled = false;
@@ -409,7 +430,7 @@ int dev_upload(opmhip_ctx* c, T** p, const std::vector<T>& h) {
 // RAII-less profiling scope: prof_begin returns a slot (or -1), prof_end closes it.  An event record costs a few
 // microseconds of bubble on the stream, so back-to-back scopes share one: prof_end(lazy) leaves the end open and the next
 // prof_begin's event closes it (prof_flush closes it where nothing follows).
-inline int prof_event(opmhip_ctx* c) {
+inline int prof_event(opmhip_ctx* c, hipStream_t s = nullptr) {
     Profiler& P = c->prof;
     if (P.ev.size() <= P.ev_used) {
         hipEvent_t e;
@@ -417,7 +438,7 @@ inline int prof_event(opmhip_ctx* c) {
         P.ev.push_back(e);
     }
     const int i = (int)P.ev_used++;
-    (void)hipEventRecord(P.ev[i], c->stream);
+    (void)hipEventRecord(P.ev[i], s ? s : c->stream);
     return i;
 }
 // an event slot without recording it (for hipExtLaunchKernelGGL, which stamps kernel begin / end itself)
@@ -472,6 +493,23 @@ inline void prof_end(opmhip_ctx* c, int slot) {
     c->prof.pending = slot;
     if (!c->prof.lazy) prof_flush(c);
 }
+// A span: two events of its own on stream s (default: the context's), independent of the kernel scopes' chain - it may enclose or
+// overlap them and may run on the halo stream.  Costs two event records, only in the solves the profiler samples.
+inline int prof_span_begin(opmhip_ctx* c, int cls, hipStream_t s = nullptr) {
+    Profiler& P = c->prof;
+    if (!P.enabled || P.suspended || P.used >= Profiler::CAP) return -1;
+    const int e = prof_event(c, s);
+    if (e < 0) return -1;
+    if (P.cls.size() <= P.used) { P.cls.push_back(cls); P.e0.push_back(e); P.e1.push_back(-1); }
+    const int slot = (int)P.used++;
+    P.cls[slot] = cls; P.e0[slot] = e; P.e1[slot] = -1;
+    return slot;
+}
+inline void prof_span_end(opmhip_ctx* c, int slot, hipStream_t s = nullptr) {
+    if (slot < 0) return;
+    const int e = prof_event(c, s);
+    if (e >= 0) c->prof.e1[slot] = e; else c->prof.cls[slot] = -1;
+}
 
 // reorder.cpp (host): level scheduling / colouring, internal pattern, L/U split, tiles
 int build_pattern(opmhip_ctx* c, int Nb, int Nghost, int nnzb, const int* rows, const int* cols);
@@ -488,7 +526,8 @@ int launch_spmv(opmhip_ctx* c, double* x, double* y, int ndot, const double* w0,
 void launch_wells_residual(opmhip_ctx* c, const double* d_resWell, double* r);
 void launch_wells_add_to_matrix(opmhip_ctx* c, int w0, int nw, int serial, const int* d_pair_ptr, const int* d_entry);
 void launch_wells_recover(opmhip_ctx* c, const double* d_resWell, const double* x, double* d_xw);
-void launch_ilu_factor(opmhip_ctx* c, bool fix_zero_diagonal = false);
+void launch_ilu_factor(opmhip_ctx* c, bool fix_zero_diagonal = false, const FactorRider* rider = nullptr);
+int cpr_factor_rider(opmhip_ctx* c, FactorRider* r);   // cpr.hip: level 0 in place, this solve's weights where they do not come from the matrix; r->mode = 0: no rider this time
 void launch_ilu_apply(opmhip_ctx* c, const double* d, double* v, double w_override = -1.0, double* unscaled = nullptr, const double* addp = nullptr, double* work = nullptr);
 // cpr.hip
 // solveBoundary: the --cpr-reuse-setup rules are looked at (a structure may be rebuilt, started or swapped in); false (opmhip_cpr_apply:

@@ -1242,11 +1242,16 @@ __global__ __launch_bounds__(64) void k_ilu_sweep_chain_LU(const int* __restrict
 // linalg/ParallelOverlappingILU0.hpp:439-494): row i of A is staged in LDS and eliminated there against the
 // already finished rows j < i (their U part and D_j^-1 live in HBM, written by earlier colours), then split into
 // L, U and D^-1.
+// RIDER (CPR, FactorRider): the staged, fixed-up row also leaves its pressure-column image and its entries of the pressure matrix behind
+// - and with RIDER == 2 its quasi-IMPES weights - before the elimination touches it: the pass k_cpr_pvals / k_cpr_weights made over the
+// whole Jacobian right after this kernel (1 142 MB of traffic, 0.20 ms per solve) rides here on values that are in LDS anyway.
+template <int RIDER>
 __global__ __launch_bounds__(64) void k_ilu_factor(const int* __restrict__ sched, const int* __restrict__ ct_first, const int* __restrict__ tile_row0,
                                                    const int* __restrict__ rowptr, const int* __restrict__ col,
                                                    const int* __restrict__ diag, const double* __restrict__ A,
                                                    const int* __restrict__ fdest, const int* __restrict__ lmatch, const int* __restrict__ urowptr,
-                                                   const int* __restrict__ ucol, double* L, double* U, double* invD, double* Afix) {
+                                                   const int* __restrict__ ucol, double* L, double* U, double* invD, double* Afix,
+                                                   int Nb, int ellW, int ghostFrom, double* rw, double* __restrict__ rap, double* __restrict__ rpcol) {
     TILE_LDS
     const int lane = threadIdx.x;
     // launch position -> chain-tile by the colour's XCD-aware schedule (reorder.cpp: build_schedules): the chain-tiles of one stretch of
@@ -1277,6 +1282,35 @@ __global__ __launch_bounds__(64) void k_ilu_factor(const int* __restrict__ sched
 #pragma unroll
                 for (int dgn = 0; dgn < BS; ++dgn)
                     if (row[nd * BB + dgn * 4] == 0.0) { row[nd * BB + dgn * 4] = 1e-15; Afix[(size_t)kd * BB + dgn * 4] = 1e-15; }
+            }
+            if (RIDER) {
+                constexpr int PCOL = 1;   // pressure index inside a block (BlackOilIndices::pressureSwitchIdx; cpr.hip: CPR_P)
+                double w0, w1, w2;
+                if (RIDER == 2) {   // w_i = D_ii^-T e_p / max|.| (getQuasiImpesWeights.hpp:46-85): k_cpr_weights' statements on the staged diagonal block
+                    double Dt[BB], inv[BB];
+#pragma unroll
+                    for (int r = 0; r < BS; ++r)
+#pragma unroll
+                        for (int cc = 0; cc < BS; ++cc) Dt[r * BS + cc] = row[nd * BB + cc * BS + r];
+                    blk_invert(Dt, inv);
+                    const double b0 = inv[0 * BS + PCOL], b1 = inv[1 * BS + PCOL], b2 = inv[2 * BS + PCOL];
+                    double mx = 0.0;
+                    mx = fmax(mx, fabs(b0)); mx = fmax(mx, fabs(b1)); mx = fmax(mx, fabs(b2));
+                    w0 = b0 / mx; w1 = b1 / mx; w2 = b2 / mx;
+                    rw[(size_t)i * BS] = w0; rw[(size_t)i * BS + 1] = w1; rw[(size_t)i * BS + 2] = w2;
+                } else {
+                    w0 = rw[(size_t)i * BS]; w1 = rw[(size_t)i * BS + 1]; w2 = rw[(size_t)i * BS + 2];
+                }
+                const size_t plane = (size_t)ellW * Nb;
+                for (int a = 0; a < n; ++a) {   // k_cpr_pvals' statements: a_p = sum_r A[r][p] w[r], r ascending; a ghost coupling of a subdomain's own system: 0
+                    const bool ghost = rcol[a] >= ghostFrom;
+                    const double b0 = ghost ? 0.0 : row[a * BB + 0 * BS + PCOL], b1 = ghost ? 0.0 : row[a * BB + 1 * BS + PCOL], b2 = ghost ? 0.0 : row[a * BB + 2 * BS + PCOL];
+                    double sp = 0.0;
+                    sp += b0 * w0; sp += b1 * w1; sp += b2 * w2;
+                    const size_t e = (size_t)a * Nb + i;
+                    rap[e] = sp;
+                    rpcol[e] = b0; rpcol[plane + e] = b1; rpcol[2 * plane + e] = b2;
+                }
             }
             bool allfast = true;
             for (int a = 0; a < nd; ++a) allfast = allfast && rlm[a] != -2;
@@ -1992,14 +2026,20 @@ int launch_spmv(opmhip_ctx* c, double* x, double* y, int ndot, const double* w0,
 static int dot_count(opmhip_ctx* c) { return c->last_dot_count; }  // how many partials the last launch_spmv left behind
 // fix_zero_diagonal: exact zeros on the diagonal of a diagonal block become 1e-15 on the way (bda/BdaBridge.cpp:125-161) - in the factors'
 // input and in the matrix: the separate pass over the diagonal blocks (38 us, 198 MB of traffic for 24 MB of data) is gone from the solve
-void launch_ilu_factor(opmhip_ctx* c, bool fix_zero_diagonal) {
+void launch_ilu_factor(opmhip_ctx* c, bool fix_zero_diagonal, const FactorRider* rider) {
     const Pattern& P = c->pat;
     const int ps = prof_begin(c, PROF_ILU_FACTOR);
+    const FactorRider none;
+    const FactorRider& R = rider ? *rider : none;
     for (int col = 0; col < P.numColors; ++col) {
         const int off = P.tiles.ctSchedOff[col], npos = P.tiles.ctSchedOff[col + 1] - off;
-        if (npos > 0)
-            hipLaunchKernelGGL(k_ilu_factor, dim3(npos), dim3(64), 0, c->stream, P.tiles.d_ctSched + off, P.tiles.d_ctFirst, P.tiles.d_row0, P.d_rowptr, P.d_col,
-                               P.d_diag, c->d_A, P.d_fdest, P.d_lmatch, P.d_urowptr, P.d_ucol, c->d_L, c->d_U, c->d_invD, fix_zero_diagonal ? c->d_A : (double*)nullptr);
+        if (npos <= 0) continue;
+#define OPMHIP_FACTOR_LAUNCH(RID)                                                                                                                          \
+    hipLaunchKernelGGL(k_ilu_factor<RID>, dim3(npos), dim3(64), 0, c->stream, P.tiles.d_ctSched + off, P.tiles.d_ctFirst, P.tiles.d_row0, P.d_rowptr, P.d_col, \
+                       P.d_diag, c->d_A, P.d_fdest, P.d_lmatch, P.d_urowptr, P.d_ucol, c->d_L, c->d_U, c->d_invD, fix_zero_diagonal ? c->d_A : (double*)nullptr, \
+                       P.Nb, R.W, R.ghostFrom, R.w, R.ap, R.pcol)
+        if (R.mode == 1) OPMHIP_FACTOR_LAUNCH(1); else if (R.mode == 2) OPMHIP_FACTOR_LAUNCH(2); else OPMHIP_FACTOR_LAUNCH(0);
+#undef OPMHIP_FACTOR_LAUNCH
     }
     prof_end(c, ps);
 }
@@ -2101,13 +2141,17 @@ static int finalize(opmhip_ctx* c, int mode, int count, int rb_half = -1) {
         // through OwnerOverlapCopyCommunication; here the two sums of a half iteration travel together)
         // long partial lists: slice sums and their fixed-order total in ONE launch (the last workgroup to finish folds
         // the slices, as in the single-GPU path) instead of k_reduce_stage1 + k_local_sums
+        const int span = prof_span_begin(c, PROF_ALLREDUCE);   // local sums -> all-reduce -> the sums are on the device
         if (count > RED1_SINGLE_MAX)
             hipLaunchKernelGGL(k_reduce_finalize, dim3(RED1_BLOCKS), dim3(VB), 0, c->stream, (int)FIN_LOCAL, count, c->d_part, c->npart, c->d_part2,
                                reinterpret_cast<unsigned*>(c->d_part2 + 2 * RED1_BLOCKS), c->comm.d_red, tol, (double*)nullptr, 0.0);
         else
             hipLaunchKernelGGL(k_local_sums, dim3(1), dim3(VB), 0, c->stream, count, c->d_part, c->npart, c->comm.d_red);
         // a failed all-reduce would leave garbage in alpha / omega / the norm: stop the solve, the caller reports it
+        c->comm.reduce_span_open = true;
         const int rc = comm_allreduce(c, c->comm.d_red, 2, 0);
+        c->comm.reduce_span_open = false;
+        prof_span_end(c, span);
         if (rc) return rc;
         hipLaunchKernelGGL(k_finalize, dim3(1), dim3(VB), 0, c->stream, mode, 1, c->comm.d_red, 1, c->d_scal, tol, hslot, seq);
         return OPMHIP_SUCCESS;
@@ -2141,8 +2185,10 @@ static int read_scalars(opmhip_ctx* c) {
     OPMHIP_HIP(c, hipStreamSynchronize(c->stream));
     return OPMHIP_SUCCESS;
 }
-// part: HALF_ALL, or the half iteration in two pieces - HALF_PRECOND (everything up to and including the preconditioner
-// application: no communication) and HALF_REST (operator with its halo exchange, scalar products with their all-reduces, updates)
+// part: HALF_ALL, or the half iteration in two pieces - HALF_PRECOND (the communication-free head: the p-update and the preconditioner
+// application) and HALF_REST (operator with its halo exchange, scalar products with their all-reduces, updates).  A CPR whose pressure
+// stage spans the ranks (cpr.gather.on) communicates INSIDE its application - three halo exchanges and an all-gather - so it belongs to
+// the rest: enqueued ahead of the stopping rule it would cost every solve one round of collectives past its last half iteration.
 enum { HALF_ALL = 0, HALF_PRECOND = 1, HALF_REST = 2 };
 static int enqueue_half(opmhip_ctx* c, int h, int part = HALF_ALL) {
     const Pattern& P = c->pat;
@@ -2151,19 +2197,22 @@ static int enqueue_half(opmhip_ctx* c, int h, int part = HALF_ALL) {
     // preconditioner application that follows them (round 1) they made that sweep 0.017 ms longer and the vector scopes as
     // much shorter - the same Newton iteration rate (76.5 / 78.1 against 78.0 / 76.3 its/s on one box).
     const bool cpr = use_cpr(c);
+    const bool precTalks = cpr && c->cpr.gather.on;                  // the preconditioner posts collectives
+    const bool head = part != HALF_REST, rest = part != HALF_PRECOND;
+    const bool applyNow = part == HALF_ALL || (precTalks ? part == HALF_REST : part == HALF_PRECOND);
     int rc, ps;
     if ((h & 1) == 0) {  // first half: p, y = M^-1 p, v = A y, alpha, x += alpha y, r -= alpha v, |r|
-        if (part != HALF_REST) {
-            if (h > 0) {
-                ps = prof_begin(c, PROF_VECTOR);
-                hipLaunchKernelGGL(k_bicg_pupdate, dim3(nb), dim3(VB), 0, c->stream, n, c->d_scal, c->d_p, c->d_v, c->d_r);
-                prof_end(c, ps);
-            }
+        if (head && h > 0) {
+            ps = prof_begin(c, PROF_VECTOR);
+            hipLaunchKernelGGL(k_bicg_pupdate, dim3(nb), dim3(VB), 0, c->stream, n, c->d_scal, c->d_p, c->d_v, c->d_r);
+            prof_end(c, ps);
+        }
+        if (applyNow) {
             if (cpr) launch_cpr_apply(c, c->d_p, c->d_pw);
             else launch_ilu_apply(c, c->d_p, c->d_pw, -1.0, &c->minv_scale);   // d_pw without the relaxation factor: its readers apply it
             if (cpr && c->cpr.apply_rc) { rc = c->cpr.apply_rc; c->cpr.apply_rc = 0; return rc; }   // a collective of the joined coarse level failed
         }
-        if (part == HALF_PRECOND) return OPMHIP_SUCCESS;
+        if (!rest) return OPMHIP_SUCCESS;
         if ((rc = launch_spmv(c, c->d_pw, c->d_v, 1, c->d_rw, c->minv_scale, true))) return rc;  // with copyOwnerToAll before the operator (ParallelOverlappingILU0.hpp:897)
         ps = prof_begin(c, PROF_VECTOR);
         if ((rc = finalize(c, FIN_ALPHA, dot_count(c)))) return rc;
@@ -2171,12 +2220,12 @@ static int enqueue_half(opmhip_ctx* c, int h, int part = HALF_ALL) {
         if ((rc = finalize(c, FIN_NORM, nb, h))) return rc;
         prof_end(c, ps);
     } else {             // second half: z = M^-1 r, t = A z, omega, x += omega z, r -= omega t, |r|, rho, beta
-        if (part != HALF_REST) {
+        if (applyNow) {
             if (cpr) launch_cpr_apply(c, c->d_r, c->d_s);
             else launch_ilu_apply(c, c->d_r, c->d_s, -1.0, &c->minv_scale);
             if (cpr && c->cpr.apply_rc) { rc = c->cpr.apply_rc; c->cpr.apply_rc = 0; return rc; }
         }
-        if (part == HALF_PRECOND) return OPMHIP_SUCCESS;
+        if (!rest) return OPMHIP_SUCCESS;
         if ((rc = launch_spmv(c, c->d_s, c->d_t, 2, c->d_r, c->minv_scale, true))) return rc;
         ps = prof_begin(c, PROF_VECTOR);
         if ((rc = finalize(c, FIN_OMEGA, dot_count(c)))) return rc;
@@ -2250,7 +2299,9 @@ int bicgstab(opmhip_ctx* c, opmhip_result* res) {
     // more of device work, enough to cover the host's look at h) is enqueued ahead of the stopping rule of h; its operator, with
     // the halo exchange, and its all-reduces follow once the (all-reduced, hence rank-independent) norm says the solve goes on.  A
     // solve that stops therefore posts NO collective beyond the stopping point - enqueueing the whole half ahead cost every solve
-    // two halo exchanges and two all-reduces on a latency-bound path (round-3 review).
+    // two halo exchanges and two all-reduces on a latency-bound path (round-3 review).  With a CPR that spans the ranks the
+    // head shrinks to the p-update (enqueue_half: precTalks): the device then idles for the host's look at h in every half iteration -
+    // the price of not posting that application's three halo exchanges and its all-gather once too often per solve.
     const bool split = c->comm.nranks > 1;
     if (nhalves > 0 && (rc = enqueue_half(c, 0))) return rc;
     for (int h = 0; h < nhalves; ++h) {

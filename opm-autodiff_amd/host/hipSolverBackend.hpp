@@ -90,21 +90,34 @@ public:
 
     SolverStatus solve_system(int N_, int nnz_, int dim, double* vals, int* rows, int* cols, double* b,
                               WellContributions& wellContribs, BdaResult& res) override {
+        // WellContributions::getNumWells() counts standard AND multisegment wells (bda/WellContributions.hpp:164-166); the C arrays
+        // belong to the standard ones only.  Multisegment wells stay what they are in the reference - host objects with a sparse LU of D -
+        // and are applied through the host round trip of its back-ends (bda/WellContributions.cu:160-187): the library calls back.
         opmhip_wells* wp = nullptr;
         if (wellContribs.getNumWells() > 0) {
-            wells.num_wells = (int)wellContribs.getNumWells();
+            wells = opmhip_wells{};
+            wells.num_wells = (int)wellContribs.getNumStdWells();
+            if (wells.num_wells > 0) {
 #ifndef OPMHIP_USE_OPM_HEADERS
-            wells.val_pointers = wellContribs.valPointers.data();
-            wells.Ccols = wellContribs.Ccols.data();
-            wells.Bcols = wellContribs.Bcols.data();
-            wells.Cnnzs = wellContribs.Cnnzs.data();
-            wells.Dnnzs = wellContribs.Dnnzs.data();
-            wells.Bnnzs = wellContribs.Bnnzs.data();
+                wells.val_pointers = wellContribs.valPointers.data();
+                wells.Ccols = wellContribs.Ccols.data();
+                wells.Bcols = wellContribs.Bcols.data();
+                wells.Cnnzs = wellContribs.Cnnzs.data();
+                wells.Dnnzs = wellContribs.Dnnzs.data();
+                wells.Bnnzs = wellContribs.Bnnzs.data();
 #else
-            // with the reference's WellContributions the host-side arrays are reached through the accessors the
-            // patch in INTEGRATION.md adds (the class keeps them private for the CUDA/OpenCL paths)
-            wellContribs.getHostArrays(&wells.val_pointers, &wells.Ccols, &wells.Bcols, &wells.Cnnzs, &wells.Dnnzs, &wells.Bnnzs);
+                // with the reference's WellContributions the host-side arrays are reached through the accessors the
+                // patch in INTEGRATION.md adds (the class keeps them private for the CUDA/OpenCL paths)
+                wellContribs.getHostArrays(&wells.val_pointers, &wells.Ccols, &wells.Bcols, &wells.Cnnzs, &wells.Dnnzs, &wells.Bnnzs);
 #endif
+            }
+            wells.num_ms_wells = (int)wellContribs.getNumMSWells();
+            if (wells.num_ms_wells > 0) {
+                wells.ms_user = &wellContribs;
+                wells.ms_apply = [](void* user, const double* h_x, double* h_y) {
+                    static_cast<WellContributions*>(user)->applyMSWellsHost(const_cast<double*>(h_x), h_y);   // apply() reads x (MultisegmentWellContribution.cpp:78-90)
+                };
+            }
             wp = &wells;
         }
         opmhip_result r;

@@ -2,8 +2,10 @@
 // (MatrixMarket, ISTL_STRUCT blocked 3 3), run bda::hipSolverBackend<3>::solve_system + get_result with tol / maxit
 // from the command line, print the solution.  The expected vector is checked by the calling pytest
 // (tests/test_gpu_host_cpp.py) against the fixture in tests/golden/linalg/expected.json.
-//   usage: test_hipSolver matr33.txt rhs3.txt tol maxit reorder [wells|-] [linsolver]     (linsolver: ilu0 | cpr | cpr_trueimpes | cpr_quasiimpes;
+//   usage: test_hipSolver matr33.txt rhs3.txt tol maxit reorder [wells|mswells|msonly|-] [linsolver]     (linsolver: ilu0 | cpr | cpr_trueimpes | cpr_quasiimpes;
 //   a CPR run solves twice, the second time behind recreateCprHierarchy(): the --cpr-reuse-setup=1 path of the plug-in)
+//   wells: one standard well; mswells: that standard well and one multisegment well (two segments, three perforations); msonly: the
+//   multisegment well alone - WellContributions::getNumWells() then counts wells the C arrays do not hold (bda/WellContributions.hpp:164-166)
 #include <cstdio>
 #include <cstdlib>
 #include <fstream>
@@ -69,7 +71,8 @@ int main(int argc, char** argv) {
         return 77;
     }
     Opm::WellContributions wellContribs;
-    if (argc > 6 && std::string(argv[6]) == "wells") {
+    const std::string wellMode = argc > 6 ? argv[6] : "-";
+    if (wellMode == "wells" || wellMode == "mswells") {
         // one standard well with two perforations (cells 1 and Nb - 2), filled the way StandardWellEval does
         // (wells/StandardWellEval.cpp:1206-1250: C, D, B); the shim reads the arrays back - directly from the stand-in
         // class, or through getHostArrays when built with OPMHIP_USE_OPM_HEADERS
@@ -83,6 +86,25 @@ int main(int argc, char** argv) {
         wellContribs.addMatrix(Opm::WellContributions::MatrixType::C, wcols, C, 2);
         wellContribs.addMatrix(Opm::WellContributions::MatrixType::D, nullptr, D, 1);
         wellContribs.addMatrix(Opm::WellContributions::MatrixType::B, wcols, B, 2);
+    }
+    if (wellMode == "mswells" || wellMode == "msonly") {
+        // one multisegment well the way MultisegmentWell::addWellContribution hands it over (wells/MultisegmentWellEval.cpp:1940-1982: B and C blocked
+        // CSR with one pattern, D in CSC - WellContributions.hpp:196-213): segment 0 perforates cell 0, segment 1 cells 2 and Nb - 1
+        const unsigned dimW = 4, Mb = 2, M = Mb * dimW;
+        std::vector<unsigned> Bcols = {0u, 2u, (unsigned)(Nb - 1)}, Brows = {0u, 1u, 3u};
+        std::vector<double> Bv(3 * 12), Cv(3 * 12);
+        for (int i = 0; i < 36; ++i) { Bv[i] = 0.03 * (1 + (i * 5) % 7) - 0.05; Cv[i] = 0.02 * (1 + (i * 3) % 5); }
+        // D (8 x 8): diagonally dominant, both segments coupled; CSC, every entry present
+        std::vector<double> Dv;
+        std::vector<int> Dcp(M + 1, 0), Dri;
+        for (unsigned c = 0; c < M; ++c) {
+            for (unsigned r = 0; r < M; ++r) {
+                Dv.push_back(r == c ? 2.0 + 0.1 * r : 0.05 * ((r * 3 + c * 5) % 4) - 0.04);
+                Dri.push_back((int)r);
+            }
+            Dcp[c + 1] = (int)Dv.size();
+        }
+        wellContribs.addMultisegmentWellContribution(3, dimW, Mb, Bv, Bcols, Brows, (unsigned)(Dv.size() / (dimW * dimW)), Dv.data(), Dcp.data(), Dri.data(), Cv);
     }
     bda::BdaResult result;
     std::vector<double> x(rhs.size());

@@ -54,6 +54,7 @@ def test_ctypes_structs_match_the_header(pkg, tmp_path):
     ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     cfg_fields = [f[0] for f in pkg.capi.Config._fields_]
     res_fields = [f[0] for f in pkg.capi.Result._fields_]
+    wells_fields = [f[0] for f in pkg.capi.Wells._fields_]      # incl. the multisegment leg (num_ms_wells, ms_apply, ms_user; ABI 8)
     src = tmp_path / "layout.c"
     lines = ['#include <stddef.h>', '#include <stdio.h>', '#include "opmhip.h"', 'int main(void) {',
              '  printf("config %zu\\n", sizeof(opmhip_config));', '  printf("result %zu\\n", sizeof(opmhip_result));']
@@ -61,6 +62,9 @@ def test_ctypes_structs_match_the_header(pkg, tmp_path):
         lines.append('  printf("config.%s %%zu\\n", offsetof(opmhip_config, %s));' % (f, f))
     for f in res_fields:
         lines.append('  printf("result.%s %%zu\\n", offsetof(opmhip_result, %s));' % (f, f))
+    lines.append('  printf("wells %zu\\n", sizeof(opmhip_wells));')
+    for f in wells_fields:
+        lines.append('  printf("wells.%s %%zu\\n", offsetof(opmhip_wells, %s));' % (f, f))
     lines += ['  return 0;', '}']
     src.write_text("\n".join(lines))
     exe = tmp_path / "layout"
@@ -71,3 +75,6 @@ def test_ctypes_structs_match_the_header(pkg, tmp_path):
         assert int(out["config." + f]) == getattr(pkg.capi.Config, f).offset, f
     for f in res_fields:
         assert int(out["result." + f]) == getattr(pkg.capi.Result, f).offset, f
+    assert int(out["wells"]) == ctypes.sizeof(pkg.capi.Wells)
+    for f in wells_fields:
+        assert int(out["wells." + f]) == getattr(pkg.capi.Wells, f).offset, f

@@ -46,7 +46,7 @@ def jacobian_case(pkg, orc, shape=(20, 18, 14), dt_days=10.0, its=1):
 def test_cpr_apply_bitwise_and_solve(pkg, orc, reorder):
     case, jac, res = jacobian_case(pkg, orc, its=2)
     Nb, rp, ci = case["Nb"], case["rowptr"], case["col"]
-    s = pkg.capi.HipSolver(reorder=reorder, preconditioner="cpr_quasiimpes", tolerance=1e-2)
+    s = pkg.capi.HipSolver(reorder=reorder, preconditioner="cpr_quasiimpes", tolerance=1e-2, cpr_amg_ilu_levels=0)
     s.set_pattern(Nb, rp, ci)
     s.upload_system(jac)
     s.ilu0_factor(want_factors=False)
@@ -101,7 +101,7 @@ def test_cpr_amg_with_ilu0_smoothing(pkg, orc, reorder, ilu_levels):
     xo, ro = cpr.solve(Nb, rr, rc, rv, np.ascontiguousarray(res.reshape(Nb, 3)[fr].reshape(-1)), tol=1e-6)
     assert r.converged and r.it == ro.it
     close_per_component(s.get_result(), xo.reshape(Nb, 3)[to].reshape(-1), tol=1e-4)   # both solve to 1e-6; the scalar products are summed in different orders
-    sj = pkg.capi.HipSolver(reorder=reorder, preconditioner="cpr_quasiimpes", tolerance=1e-6)
+    sj = pkg.capi.HipSolver(reorder=reorder, preconditioner="cpr_quasiimpes", tolerance=1e-6, cpr_amg_ilu_levels=0)
     rj = sj.solve_system(Nb, rp, ci, jac.copy(), res)
     assert rj.converged and r.it <= rj.it, (r.it, rj.it)
     # new values through the same structure: the factors follow the matrix
@@ -118,7 +118,7 @@ def test_cpr_matr33_flexiblesolver_vector(pkg, orc, golden):
     Nb, rp, ci, v, b = _load(pkg, golden, "matr33.txt", "rhs3.txt")
     with open(os.path.join(golden, "linalg", "expected.json")) as f:
         e = json.load(f)["exact_noprec_tol1e-12_maxit200"]
-    s = pkg.capi.HipSolver(reorder="level_scheduling", preconditioner="cpr_quasiimpes", tolerance=0.5, maxit=20, zero_diag_fix=False)
+    s = pkg.capi.HipSolver(reorder="level_scheduling", preconditioner="cpr_quasiimpes", tolerance=0.5, maxit=20, zero_diag_fix=False, cpr_amg_ilu_levels=0)
     r = s.solve_system(Nb, rp, ci, v.copy(), b)
     assert r.converged and r.it == 0.5
     _cmp(s.get_result(), e)
@@ -128,7 +128,7 @@ def test_cpr_on_a_laplace_like_block_system(pkg, orc):
     """a system without the black-oil structure (random dense blocks): CPR must still be a valid preconditioner"""
     Nb, rp, ci, v = laplace_block_system(16, 14, 12, seed=4)
     b = np.random.default_rng(2).standard_normal(3 * Nb)
-    s = pkg.capi.HipSolver(reorder="line_coloring", preconditioner="cpr_quasiimpes", tolerance=1e-8)
+    s = pkg.capi.HipSolver(reorder="line_coloring", preconditioner="cpr_quasiimpes", tolerance=1e-8, cpr_amg_ilu_levels=0)
     r = s.solve_system(Nb, rp, ci, v.copy(), b)
     assert r.converged
     x = s.get_result()
@@ -169,7 +169,7 @@ def test_true_impes_weights_bitwise_and_newton(pkg, orc, wet):
         case = pkg.decks.cartesian_case(14, 12, 13, state="mixed", heterogeneous=True)
     src = pkg.decks.five_spot_source(case, rate_sm3_per_day=20.0)
     dt = 5 * 86400.0
-    m = pkg.capi.HipModel(case, reorder="line_coloring", preconditioner="cpr_trueimpes")
+    m = pkg.capi.HipModel(case, reorder="line_coloring", preconditioner="cpr_trueimpes", cpr_amg_ilu_levels=0)
     o = oracle_bind.OracleModel(orc, case)
     for q in (m, o):
         q.set_state(case["pv"], case["meaning"])
@@ -184,7 +184,7 @@ def test_true_impes_weights_bitwise_and_newton(pkg, orc, wet):
     assert np.all(np.isfinite(wo)) and np.abs(wo).max() < 1e3 and np.abs(wo[:, 1]).min() > 0.0
     # the same weights handed to a solver-only context and to the oracle's CPR: the application bit for bit
     Nb, rp, ci = case["Nb"], case["rowptr"], case["col"]
-    s = pkg.capi.HipSolver(reorder="line_coloring", preconditioner="cpr_trueimpes", tolerance=1e-2)
+    s = pkg.capi.HipSolver(reorder="line_coloring", preconditioner="cpr_trueimpes", tolerance=1e-2, cpr_amg_ilu_levels=0)
     s.set_pattern(Nb, rp, ci)
     s.upload_system(jo)
     s.ilu0_factor(want_factors=False)
@@ -203,7 +203,7 @@ def test_true_impes_weights_bitwise_and_newton(pkg, orc, wet):
     # whole time step: true-IMPES CPR against ILU0 (the wet-gas state is a random mix of all three meanings: a short step)
     out = {}
     for prec in ("ilu0", "cpr_trueimpes"):
-        mm = pkg.capi.HipModel(case, reorder="line_coloring", preconditioner=prec)
+        mm = pkg.capi.HipModel(case, reorder="line_coloring", preconditioner=prec, cpr_amg_ilu_levels=0)
         mm.set_state(case["pv"], case["meaning"])
         mm.set_source(src)
         rep = pkg.newton.BlackoilModelHip(mm).step(0.2 * 86400.0 if wet else dt)
@@ -239,7 +239,7 @@ def test_coarsening_stops_where_rows_outgrow_the_level_image(pkg, orc):
     deg = np.diff(rp) - 1
     v[~off] = np.eye(3) * (2.0 * deg[:, None, None] + 1.0)
     v = v.reshape(-1)
-    s = pkg.capi.HipSolver(reorder="graph_coloring", preconditioner="cpr_quasiimpes", tolerance=1e-6)
+    s = pkg.capi.HipSolver(reorder="graph_coloring", preconditioner="cpr_quasiimpes", tolerance=1e-6, cpr_amg_ilu_levels=0)
     s.set_pattern(Nb, rp, ci)
     s.upload_system(v)
     s.ilu0_factor(want_factors=False)
@@ -269,7 +269,7 @@ def test_cpr_reuse_setup_modes(pkg, orc, mode):
     Nb, rp, ci = case["Nb"], case["rowptr"], case["col"]
     host = mode == "host"       # mode 3 in the library, the host says when (opmhip_cpr_recreate: what the BdaSolver plug-in does for mode 1)
     s = pkg.capi.HipSolver(reorder="line_coloring", preconditioner="cpr_quasiimpes", tolerance=1e-10 if mode == 2 else 1e-2, maxit=100,
-                           cpr_reuse_setup=3 if host else mode)
+                           cpr_reuse_setup=3 if host else mode, cpr_amg_ilu_levels=0)
     r1 = s.solve_system(Nb, rp, ci, jac1.copy(), res1)
     assert r1.converged and (mode != 2 or r1.iterations > 10)              # mode 2: the tight tolerance makes the first solve a long one
     lv1 = s.cpr_levels()
@@ -332,3 +332,54 @@ def test_cpr_rebuild_beside_the_solves(pkg, orc, ilu):
     assert r3.converged
     assert np.array_equal(s.cpr_apply(d), v_new)
     assert s.cpr_levels()[0] == [int(x) for x in new.levels()[0]]
+
+
+RIDER_SCRIPT = r"""
+import importlib, sys, numpy as np
+sys.path.insert(0, sys.argv[1])
+pkg = importlib.import_module("opm-autodiff_amd")
+prec, out = sys.argv[2], sys.argv[3]
+case = pkg.decks.cartesian_case(22, 17, 12, state="mixed", heterogeneous=True)
+src = pkg.decks.five_spot_source(case, rate_sm3_per_day=30.0)
+xs = []
+for reorder, world in (("line_coloring", 1), ("graph_coloring", 1), ("line_coloring", 2)):
+    if world == 1:
+        m = pkg.capi.HipModel(case, reorder=reorder, preconditioner=prec, tolerance=1e-6)
+        m.set_state(case["pv"], case["meaning"]); m.set_source(src)
+    else:   # a subdomain with ghost columns, alone on its communicator: the rider leaves the ghost couplings out of the pressure system
+        sub = pkg.ras.cartesian_subdomain_case(12, 2, 0, state="mixed", heterogeneous=True)
+        m = pkg.capi.HipModel(sub, reorder=reorder, preconditioner=prec, tolerance=1e-6, cpr_gather_rows=-1)
+        m.set_state(sub["pv"], sub["meaning"]); m.set_source(sub["source"])
+    for it in range(3):
+        m.assemble(5 * 86400.0, it, fetch=False)
+        r = m.solve_jacobian_system()
+        xs += [m.get_result().copy(), m.cpr_weights().copy(), np.array([r.it, r.reduction])]
+        m.update(None, 1.0)
+np.savez(out, *xs)
+"""
+
+
+@pytest.mark.parametrize("prec", ["cpr_quasiimpes", "cpr_trueimpes"])
+def test_factor_rider_gives_the_bits_of_the_separate_passes(pkg, tmp_path, prec):
+    """CPR value set-up without a second pass over the Jacobian: k_ilu_factor's rider writes the weights (quasi-IMPES), the pressure-column
+    image and level 0's values a_p = sum_r A[r][p] w[r] (PressureTransferPolicy.hpp:116-139) from the rows it has staged - the same
+    statements on the same values as k_cpr_weights / k_cpr_pvals, which OPMHIP_CPR_PVALS_SEPARATE=1 brings back: three Newton iterations
+    (line colouring, Jones-Plassmann, and a subdomain with ghost columns) give the same solutions, weights, stopping half iteration
+    and reduction bit for bit either way."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    outs = []
+    for sep in (False, True):
+        env = dict(os.environ)
+        env.pop("OPMHIP_CPR_PVALS_SEPARATE", None)
+        if sep:
+            env.update(OPMHIP_TUNING="1", OPMHIP_CPR_PVALS_SEPARATE="1")
+        f = str(tmp_path / ("sep%d.npz" % sep))
+        r = subprocess.run([sys.executable, "-c", RIDER_SCRIPT, root, prec, f], capture_output=True, text=True, env=env, timeout=600)
+        assert r.returncode == 0, r.stderr[-3000:]
+        assert ("OPMHIP_CPR_PVALS_SEPARATE=1 is in force" in r.stderr) == sep
+        outs.append(np.load(f))
+    assert len(outs[0].files) == len(outs[1].files) == 27
+    for k in outs[0].files:
+        assert np.array_equal(outs[0][k], outs[1][k]), k

@@ -573,7 +573,7 @@ def test_dd_cpr_pressure_stage_across_the_ranks(pkg, orc, world, prec, n, rows):
         def rank_fn(r):
             c = parts[r]
             Nb = c["Nb"]
-            m = pkg.capi.HipModel(c, comm=("loopback", world, r, group), reorder="line_coloring", preconditioner=prec, tolerance=1e-4, cpr_gather_rows=gather_rows)
+            m = pkg.capi.HipModel(c, comm=("loopback", world, r, group), reorder="line_coloring", preconditioner=prec, tolerance=1e-4, cpr_gather_rows=gather_rows, cpr_amg_ilu_levels=0)
             m.set_state(c["pv"], c["meaning"])
             m.set_source(np.ascontiguousarray(src.reshape(-1, 3)[c["gids"]].reshape(-1)))
             m.assemble(dt, 0)
@@ -637,7 +637,7 @@ def test_dd_cpr_pressure_stage_on_an_irregular_graph(pkg, orc, rows):
 
     def rank_fn(r):
         c = parts[r]
-        m = pkg.capi.HipModel(c, comm=("loopback", world, r, group), reorder="line_coloring", preconditioner="cpr_quasiimpes", tolerance=1e-4, cpr_gather_rows=rows)
+        m = pkg.capi.HipModel(c, comm=("loopback", world, r, group), reorder="line_coloring", preconditioner="cpr_quasiimpes", tolerance=1e-4, cpr_gather_rows=rows, cpr_amg_ilu_levels=0)
         m.set_state(c["pv"], c["meaning"])
         m.assemble(dt, 0)
         sol = m.solve_jacobian_system()
@@ -676,7 +676,7 @@ def test_dd_cpr_pressure_stage_rebuilt_with_the_structure(pkg, orc):
     def rank_fn(r):
         c = parts[r]
         Nb = c["Nb"]
-        m = pkg.capi.HipModel(c, comm=("loopback", world, r, group), reorder="line_coloring", preconditioner="cpr_quasiimpes", tolerance=1e-4, cpr_gather_rows=rows, cpr_reuse_setup=0)
+        m = pkg.capi.HipModel(c, comm=("loopback", world, r, group), reorder="line_coloring", preconditioner="cpr_quasiimpes", tolerance=1e-4, cpr_gather_rows=rows, cpr_reuse_setup=0, cpr_amg_ilu_levels=0)
         m.set_state(c["pv"], c["meaning"])
         m.set_source(np.ascontiguousarray(src.reshape(-1, 3)[c["gids"]].reshape(-1)))
         its = []
@@ -750,7 +750,7 @@ def test_dd_a_rank_without_neighbours(pkg, orc, prec):
 
     def rank_fn(r):
         c = parts[r]
-        m = pkg.capi.HipModel(c, comm=("loopback", world, r, group), reorder="line_coloring", preconditioner=prec, tolerance=1e-6, cpr_gather_rows=40)
+        m = pkg.capi.HipModel(c, comm=("loopback", world, r, group), reorder="line_coloring", preconditioner=prec, tolerance=1e-6, cpr_gather_rows=40, cpr_amg_ilu_levels=0)
         m.set_state(c["pv"], c["meaning"])
         m.assemble(dt, 0, fetch=False)
         sol = m.solve_jacobian_system()
@@ -764,3 +764,45 @@ def test_dd_a_rank_without_neighbours(pkg, orc, prec):
         c = parts[r]
         x[c["gids"][:c["Nb"]]] = outs[r][2].reshape(-1, 3)[:c["Nb"]]
     assert np.linalg.norm(orc.spmv(g["Nb"], g["rowptr"], g["col"], jo, x.reshape(-1)) - ro) < 1e-6 * np.linalg.norm(ro) * 1.001
+
+
+@pytest.mark.parametrize("prec", ["ilu0", "cpr_quasiimpes"])
+def test_dd_communication_scopes(pkg, prec):
+    """The profiler's communication spans of a decomposed solve (opmhip_profile_get classes 9-11): one halo span per product - two per
+    BiCGStab iteration, pack -> exchange -> ghosts in place, stamped on the halo stream it runs on (copyOwnerToAll in front of the operator,
+    ParallelOverlappingILU0.hpp:897) - one all-reduce span per global reduction (local sums -> all-reduce), and with a CPR that spans the
+    ranks three more halo spans and one gather span (the joined level's all-gather + its cycle) per application.  Counted against the
+    solve's own iteration count; the times are positive and the halo spans do not exceed the wall time of the solve."""
+    world, n = 2, 16
+    group = "scopes" + uuid.uuid4().hex
+    parts = [pkg.ras.cartesian_subdomain_case(n, world, r, state="mixed", heterogeneous=True) for r in range(world)]
+
+    def rank_fn(r):
+        import time
+        c = parts[r]
+        m = pkg.capi.HipModel(c, comm=("loopback", world, r, group), preconditioner=prec, tolerance=1e-6, cpr_amg_ilu_levels=0)
+        m.set_state(c["pv"], c["meaning"])
+        m.set_source(c["source"])
+        m.assemble(86400.0, 0, fetch=False)
+        m.profile_enable(True)
+        t0 = time.perf_counter()
+        sol = m.solve_jacobian_system()
+        wall_ms = 1e3 * (time.perf_counter() - t0)
+        return float(sol.it), bool(sol.converged), m.profile(), wall_ms
+
+    outs = run_ranks(world, rank_fn)
+    for it, ok, prof, wall_ms in outs:
+        assert ok
+        halves = int(round(2 * it))                       # products = preconditioner applications = half iterations run
+        # a product = the interior tiles' launch (class "spmv"; none on a subdomain this thin) + the boundary tiles' behind the exchange
+        products = prof["spmv_boundary"][0] or prof["spmv"][0]
+        assert products == halves and prof["spmv"][0] in (0, halves)
+        gathers = prof.get("cpr_gather", (0, 0.0))[0]
+        if prec == "ilu0":
+            assert gathers == 0 and prof["halo"][0] == products
+        else:
+            # (+ 1: the first solve's set-up of the joined level sends every ghost cell's aggregate number through the same exchange)
+            assert gathers == halves and prof["halo"][0] == products + 3 * gathers + 1 and prof["cpr_gather"][1] > 0.0
+        # one reduction behind the initial residual, two per half iteration (the scalar product, the norm)
+        assert prof["allreduce"][0] == 1 + 2 * halves
+        assert 0.0 < prof["halo"][1] < wall_ms and 0.0 < prof["allreduce"][1] < wall_ms

@@ -52,7 +52,7 @@ def test_tiny_grids_with_cpr(pkg, orc, shape, prec):
     src[0, 1] = 1e-6
     src[-1, 0] = -1e-6
     src = np.ascontiguousarray(src.reshape(-1))
-    m = pkg.capi.HipModel(case, reorder="line_coloring", tolerance=1e-8, maxit=200, preconditioner=prec)
+    m = pkg.capi.HipModel(case, reorder="line_coloring", tolerance=1e-8, maxit=200, preconditioner=prec, cpr_amg_ilu_levels=0)
     o = oracle_bind.OracleModel(orc, case)
     for q in (m, o):
         q.set_state(case["pv"], case["meaning"])

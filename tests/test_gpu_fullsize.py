@@ -149,7 +149,7 @@ def test_two_subdomains_of_full_size(pkg, prec):
     def body(r):
         try:
             case = pkg.ras.cartesian_subdomain_case(n, world, r, state="mixed", heterogeneous=False)
-            m = pkg.capi.HipModel(case, comm=("loopback", world, r, group), reorder="line_coloring", tolerance=1e-2, maxit=200, ilu_relaxation=0.9, preconditioner=prec)
+            m = pkg.capi.HipModel(case, comm=("loopback", world, r, group), reorder="line_coloring", tolerance=1e-2, maxit=200, ilu_relaxation=0.9, preconditioner=prec, cpr_amg_ilu_levels=0)
             m.set_state(case["pv"], case["meaning"])
             m.set_source(case["source"])
             hist = []

@@ -87,6 +87,91 @@ def test_hipSolverBackend_built_the_way_opm_simulators_builds_it(pkg, golden):
     assert np.abs(x - x0).max() > 1e-6 * np.abs(x0).max()
 
 
+def _ms_well(Nb):
+    """the multisegment well of host/test_hipSolver.cpp (mswells / msonly) as dense matrices: B, C (8 x 3 Nb), D (8 x 8)"""
+    Bv = np.array([0.03 * (1 + (i * 5) % 7) - 0.05 for i in range(36)]).reshape(3, 4, 3)
+    Cv = np.array([0.02 * (1 + (i * 3) % 5) for i in range(36)]).reshape(3, 4, 3)
+    cols, seg = [0, 2, Nb - 1], [0, 1, 1]
+    B, Cm = np.zeros((8, 3 * Nb)), np.zeros((8, 3 * Nb))
+    for blk in range(3):
+        B[4 * seg[blk]:4 * seg[blk] + 4, 3 * cols[blk]:3 * cols[blk] + 3] += Bv[blk]
+        Cm[4 * seg[blk]:4 * seg[blk] + 4, 3 * cols[blk]:3 * cols[blk] + 3] += Cv[blk]
+    D = np.array([[2.0 + 0.1 * r if r == c else 0.05 * ((r * 3 + c * 5) % 4) - 0.04 for c in range(8)] for r in range(8)])
+    return B, Cm, D
+
+
+@pytest.mark.parametrize("mode", ["mswells", "msonly"])
+def test_hipSolverBackend_with_a_multisegment_well(pkg, golden, mode):
+    """A WellContributions that holds a multisegment well - getNumWells() counts it, the standard wells' C arrays do not hold it
+    (bda/WellContributions.hpp:164-166).  The plug-in hands the library the standard-well count and a callback; the library applies the
+    multisegment operator on the host after every product, as the reference's back-ends do (bda/WellContributions.cu:160-187).  Both builds
+    of the plug-in give the same bits, the solution solves (A - sum C^T D^-1 B) x = b with the operators formed densely here, and the
+    same system through the C ABI from Python with a numpy callback gives the same x."""
+    args = [os.path.join(golden, "linalg", "matr33.txt"), os.path.join(golden, "linalg", "rhs3.txt"), "1e-10", "50", "level_scheduling", mode]
+    outs = []
+    for exe in ("test_hipSolver", "test_hipSolver_opmhdr"):
+        out = subprocess.run([_exe(exe)] + args, capture_output=True, text=True)
+        assert out.returncode == 0, out.stderr
+        outs.append(out.stdout)
+    assert outs[0] == outs[1] and outs[0].startswith("converged 1")
+    x = np.array([float(v) for v in outs[0].strip().splitlines()[1:]])
+    Nb, rp, ci, v, _ = pkg.mmio.read_block_matrix(args[0])
+    b = pkg.mmio.read_block_vector(args[1])
+    A = np.zeros((3 * Nb, 3 * Nb))
+    for i in range(Nb):
+        for k in range(rp[i], rp[i + 1]):
+            A[3 * i:3 * i + 3, 3 * ci[k]:3 * ci[k] + 3] = v[9 * k:9 * k + 9].reshape(3, 3)
+    B, Cm, D = _ms_well(Nb)
+    Aeff = A - Cm.T @ np.linalg.solve(D, B)
+    wells = dict(numWells=0)
+    if mode == "mswells":   # plus the standard well of the `wells` mode (D^-1 arrives inverted: applied as it is)
+        Cs = np.array([0.01 * (1 + (i * 7) % 5) for i in range(24)])
+        Bs = np.array([0.02 * (1 + (i * 3) % 7) for i in range(24)])
+        Ds = np.array([0.5 if i % 5 == 0 else 0.01 * (i % 3) for i in range(16)])
+        Bd, Cd = np.zeros((4, 3 * Nb)), np.zeros((4, 3 * Nb))
+        for blk, col in enumerate([1, Nb - 2]):
+            Bd[:, 3 * col:3 * col + 3] += Bs[12 * blk:12 * blk + 12].reshape(4, 3)     # (+=: matr33 has three block rows, both perforations sit in cell 1)
+            Cd[:, 3 * col:3 * col + 3] += Cs[12 * blk:12 * blk + 12].reshape(4, 3)
+        Aeff = Aeff - Cd.T @ (Ds.reshape(4, 4) @ Bd)
+        wells = dict(numWells=1, val_pointers=[0, 2], Ccols=[1, Nb - 2], Bcols=[1, Nb - 2], Cnnzs=Cs, Dnnzs=Ds, Bnnzs=Bs)
+    assert np.linalg.norm(Aeff @ x - b) <= 1e-10 * np.linalg.norm(b) * (1 + 1e-6)
+    # the well does something
+    out0 = subprocess.run([_exe("test_hipSolver")] + args[:-1], capture_output=True, text=True)
+    x0 = np.array([float(t) for t in out0.stdout.strip().splitlines()[1:]])
+    assert np.abs(x - x0).max() > 1e-6 * np.abs(x0).max()
+    # the same through the C ABI from Python: the callback sees natural-order host vectors although the ILU runs in its own order
+    calls = []
+
+    def ms_apply(hx, hy):
+        calls.append(1)
+        hy -= Cm.T @ np.linalg.solve(D, B @ hx)
+    wells.update(numMsWells=1, ms_apply=ms_apply, N=3 * Nb)
+    for reorder in ("level_scheduling", "graph_coloring"):
+        s = pkg.capi.HipSolver(tolerance=1e-10, maxit=50, reorder=reorder, ilu_relaxation=1.0)
+        res = s.solve_system(Nb, rp, ci, v.copy(), b, wells=wells)
+        assert res.converged and len(calls) >= 2
+        xs = s.get_result()
+        assert np.linalg.norm(Aeff @ xs - b) <= 1e-10 * np.linalg.norm(b) * (1 + 1e-6)
+        if reorder == "level_scheduling":
+            # two solves to 1e-10 with differently rounded well operators (numpy's dense product here, the stand-in's LU there)
+            np.testing.assert_allclose(xs, x, rtol=1e-5, atol=1e-7 * np.abs(x).max())
+
+
+def test_multisegment_wells_need_their_callback(pkg, golden):
+    """num_ms_wells > 0 without ms_apply is refused (OPMHIP_INVALID_ARGUMENT), not silently dropped from the operator"""
+    import ctypes as C
+    Nb, rp, ci, v, _ = pkg.mmio.read_block_matrix(os.path.join(golden, "linalg", "matr33.txt"))
+    b = pkg.mmio.read_block_vector(os.path.join(golden, "linalg", "rhs3.txt"))
+    s = pkg.capi.HipSolver(tolerance=1e-2, maxit=20)
+    s.set_pattern(Nb, rp, ci)
+    w = pkg.capi.Wells(0)
+    w.num_ms_wells = 1
+    res = pkg.capi.Result()
+    rc = pkg.capi.lib().opmhip_solve_system(s._h, 3 * Nb, 9 * len(ci), 3, v.ctypes.data_as(C.c_void_p), None, None, b.ctypes.data_as(C.c_void_p),
+                                            C.byref(w), C.byref(res))
+    assert rc == pkg.capi.INVALID_ARGUMENT and b"ms_apply" in pkg.capi.lib().opmhip_last_error(s._h)
+
+
 def test_BlackoilModelHip_step_matches_python_loop(pkg, tmp_path):
     case = pkg.decks.cartesian_case(12, 12, 8, state="mixed", heterogeneous=False)
     src = pkg.decks.five_spot_source(case, rate_sm3_per_day=40.0)

@@ -12,7 +12,7 @@ ap = argparse.ArgumentParser()
 ap.add_argument("--world", type=int, default=8)
 ap.add_argument("--n", type=int, default=50)
 ap.add_argument("--steps", type=int, default=30)
-ap.add_argument("--reorder", default="line_coloring")
+ap.add_argument("--reorder", default=None, help="default: the library's choice")
 ap.add_argument("--preconditioner", default="ilu0", choices=["ilu0", "cpr", "cpr_trueimpes", "cpr_quasiimpes"])
 ap.add_argument("--cpr-gather-rows", type=int, default=0, help="CPR: the pressure stage spans the ranks from each rank's first level of at most this many rows (0: the default, 100000; < 0: one hierarchy per subdomain)")
 a = ap.parse_args()
@@ -28,12 +28,14 @@ def body(r):
         m.set_state(case["pv"], case["meaning"])
         m.set_source(case["source"])
         sim = bench.make_simulation(pkg, m)
+        m.profile_enable(bench.PROFILE_EVERY)
         t0 = time.perf_counter()
         log = []
         for _ in range(a.steps):
             rep = sim.next_newton_iteration()
             log.append((sim.timesteps_done, sim.iteration, rep.total_linear_iterations))
-        out[r] = (time.perf_counter() - t0, log, sim.timesteps_done, sim.history)
+        el = time.perf_counter() - t0
+        out[r] = (el, log, sim.timesteps_done, sim.history, m.profile())
     except Exception as e:  # noqa: BLE001
         err[r] = e
         raise
@@ -44,8 +46,20 @@ ts = [threading.Thread(target=body, args=(r,)) for r in range(a.world)]
 [t.join() for t in ts]
 if any(e is not None for e in err):
     raise SystemExit("rank failures: %r" % err)
-el, log, done, hist = out[0]
+el, log, done, hist, _ = out[0]
 print("world %d n %d %s: %d Newton iterations in %.2f s, %d time steps done, %d linear iterations" % (a.world, a.n, a.preconditioner, a.steps, el, done, sum(l[2] for l in log)))
 print("(step, newton, linear its):", log)
 print("time steps (days, newton its, accepted):", [(round(h[0] / bench.DAY, 3), h[1], h[2]) for h in hist])
 assert all(o[1] == log for o in out), "ranks disagree on the iteration history"
+# the communication spans (halo: pack -> exchange -> ghosts in; allreduce: local sums -> all-reduce; cpr_gather: the joined level's all-gather
+# + cycle) of every bench.PROFILE_EVERY-th solve, per rank; on the loopback communicator the host drives the exchanges between two barriers,
+# so these are rehearsal numbers for the plumbing, not xGMI times
+lin = sum(l[2] for l in log)
+print("linear iterations per Newton iteration: %.2f" % (lin / a.steps))
+for k in ("halo", "allreduce", "cpr_gather", "spmv", "spmv_boundary", "ilu_apply", "cpr_amg", "vector"):
+    per = [o[4].get(k, (0, 0.0)) for o in out]
+    if not any(p[0] for p in per):
+        continue
+    avg = [p[1] / p[0] for p in per if p[0]]
+    print("%-14s launches/rank %6d   avg ms max %.4f mean %.4f   total ms max %.2f mean %.2f" % (k, max(p[0] for p in per), max(avg), sum(avg) / len(avg),
+                                                                                             max(p[1] for p in per), sum(p[1] for p in per) / len(per)))
