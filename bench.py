@@ -350,6 +350,7 @@ def main():
     ap.add_argument("--n", type=int, default=100, help="cells per edge of the per-GPU cube")
     ap.add_argument("--reorder", default=None, help="ILU0 ordering; default: the library's own choice (opmhip_default_config: auto), reported in config.ilu_ordering")
     ap.add_argument("--chain-length", type=int, default=0, help="rows per chain of the line-coloured ILU0 ordering; 0: the library's choice (10 at 10^6 cells)")
+    ap.add_argument("--full-line", action="store_true", help="tools/ only: print the full record as the one line (tens of KB: the driver could not parse that from its tail of stdout)")
     ap.add_argument("--detail", default=None, help="file for the full record (per-window kernel scopes, reports, time steps); default gpurun_out/bench_detail.json")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--steady-after", type=int, default=200, help="second timed window starts at this Newton iteration (0: none)")
@@ -684,7 +685,7 @@ def main():
             detail = "not written: %s" % e
         line = json.dumps(compact_line(out, os.path.relpath(detail, ROOT) if os.path.isabs(detail) and detail.startswith(ROOT) else detail))
         assert len(line) < LINE_LIMIT, "bench.py: the line grew to %d bytes" % len(line)
-        print(line)
+        print(json.dumps(out) if a.full_line else line)
         sys.stdout.flush()
     if dist is not None:
         dist.destroy_process_group()

@@ -1,6 +1,6 @@
 export OPMHIP_TUNING=1   # the library reads its measurement switches only under this master switch
 for L in 6 8 10 12 16; do
-  python bench.py --steps 20 --warmup 5 --steady-after 0 --no-cpu-baseline --no-cpr-side-run --chain-length $L > gpurun_out/chain$L.json 2> gpurun_out/chain$L.err || echo "$L failed"
+  python bench.py --full-line --steps 20 --warmup 5 --steady-after 0 --no-cpu-baseline --no-cpr-side-run --chain-length $L > gpurun_out/chain$L.json 2> gpurun_out/chain$L.err || echo "$L failed"
   python - gpurun_out/chain$L.json $L <<'PY'
 import json, sys
 d = json.loads(open(sys.argv[1]).read().strip().splitlines()[-1])

@@ -7,13 +7,13 @@ mkdir -p $OUT
 for ROUND in 1 2; do
 for V in "$@"; do
   if [ "$V" = "-" ]; then unset $VAR; else export $VAR=$V; fi
-  python bench.py --steps ${STEPS:-20} --warmup 5 --preconditioner ${PRECOND:-cpr} --no-cpu-baseline --no-cpr-side-run > $OUT/$VAR$V.$ROUND.json 2> $OUT/$VAR$V.$ROUND.err || echo "$V failed"
-  python - $OUT/$VAR$V.$ROUND.json $VAR=$V <<'PY'
+  python bench.py --steps ${STEPS:-20} --warmup 5 --preconditioner ${PRECOND:-cpr} --no-cpu-baseline --no-cpr-side-run --detail $OUT/$VAR$V.$ROUND.detail.json > $OUT/$VAR$V.$ROUND.json 2> $OUT/$VAR$V.$ROUND.err || echo "$V failed"
+  python - $OUT/$VAR$V.$ROUND.detail.json $VAR=$V <<'PY'
 import json, sys
-d = json.loads(open(sys.argv[1]).read().strip().splitlines()[-1])
+d = json.load(open(sys.argv[1]))   # the full record (the line on stdout carries one number per window)
 k = d["kernels"]
 st = d.get("steady_state") or {}
-print("%-24s value %.2f steady %.2f  cpr_amg %.4f  ilu_apply %.4f spmv %.4f vector %.4f  its/newton %.2f / %s" % (sys.argv[2], d["value"], st.get("value", 0.0), k["cpr_amg"]["avg_ms"], k["ilu_apply"]["avg_ms"], k["spmv"]["avg_ms"], k["vector"]["avg_ms"], d["linear_iterations_per_newton"], st.get("linear_iterations_per_newton")), flush=True)
+print("%-28s value %.2f steady %.2f  cpr_amg %.4f  ilu_apply %.4f spmv %.4f vector %.4f  factor+setup scope %.4f ms x %d  its/newton %.2f / %s" % (sys.argv[2], d["value"], st.get("value", 0.0), k["cpr_amg"]["avg_ms"], k["ilu_apply"]["avg_ms"], k["spmv"]["avg_ms"], k["vector"]["avg_ms"], k["ilu_factor"]["avg_ms"], k["ilu_factor"]["launches"], d["linear_iterations_per_newton"], st.get("linear_iterations_per_newton")), flush=True)
 PY
 done
 done

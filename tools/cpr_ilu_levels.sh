@@ -5,7 +5,7 @@ R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
 cd $R
 for rep in 1 2; do
 for lv in ${@:-0 1 2}; do
-  python bench.py --steps 20 --warmup 5 --no-cpu-baseline --preconditioner ${PREC:-cpr} --cpr-reuse-setup ${REUSE:-3} --cpr-amg-ilu-levels $lv 2>/dev/null | tail -1 | python3 -c "
+  python bench.py --full-line --steps 20 --warmup 5 --no-cpu-baseline --preconditioner ${PREC:-cpr} --cpr-reuse-setup ${REUSE:-3} --cpr-amg-ilu-levels $lv 2>/dev/null | tail -1 | python3 -c "
 import json,sys
 d=json.loads(sys.stdin.read())
 s=d['steady_state']

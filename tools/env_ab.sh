@@ -5,7 +5,7 @@ OUT=$1; VAR=$2; shift; shift
 mkdir -p $OUT
 for V in "$@"; do
   export $VAR=$V
-  python bench.py --steps ${STEPS:-20} --warmup 5 --steady-after 0 --no-cpu-baseline --no-cpr-side-run > $OUT/$VAR$V.json 2> $OUT/$VAR$V.err || echo "$V failed"
+  python bench.py --full-line --steps ${STEPS:-20} --warmup 5 --steady-after 0 --no-cpu-baseline --no-cpr-side-run > $OUT/$VAR$V.json 2> $OUT/$VAR$V.err || echo "$V failed"
   python - $OUT/$VAR$V.json $VAR=$V <<'PY'
 import json, sys
 d = json.loads(open(sys.argv[1]).read().strip().splitlines()[-1])

@@ -6,7 +6,7 @@ mkdir -p $OUT
 i=0
 for E in "$@"; do
   i=$((i+1))
-  env $E python bench.py --steps ${STEPS:-40} --warmup 5 --steady-after 0 --no-cpu-baseline > $OUT/e$i.json 2> $OUT/e$i.err || echo "$E failed"
+  env $E python bench.py --full-line --steps ${STEPS:-40} --warmup 5 --steady-after 0 --no-cpu-baseline > $OUT/e$i.json 2> $OUT/e$i.err || echo "$E failed"
   python - $OUT/e$i.json "$E" <<'PY'
 import json, sys
 d = json.loads(open(sys.argv[1]).read().strip().splitlines()[-1])

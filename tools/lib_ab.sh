@@ -6,7 +6,7 @@ i=0
 for V in "$@"; do
   i=$((i+1))
   export OPMHIP_LIB=build_variants/libopmhip_$V.so
-  python bench.py --steps ${STEPS:-20} --warmup 5 --steady-after 0 --no-cpu-baseline --no-cpr-side-run > $OUT/$i$V.json 2> $OUT/$i$V.err || echo "$V failed"
+  python bench.py --full-line --steps ${STEPS:-20} --warmup 5 --steady-after 0 --no-cpu-baseline --no-cpr-side-run > $OUT/$i$V.json 2> $OUT/$i$V.err || echo "$V failed"
   python - $OUT/$i$V.json $V <<'PY'
 import json, sys
 d = json.loads(open(sys.argv[1]).read().strip().splitlines()[-1])

@@ -4,7 +4,7 @@ OUT=$1; shift
 mkdir -p $OUT
 for V in "$@"; do
   if [ "$V" = default ]; then unset OPMHIP_LIB; else export OPMHIP_LIB=$PWD/build_variants/libopmhip_$V.so; fi
-  python bench.py --steps ${STEPS:-40} --warmup 5 --steady-after 0 --no-cpu-baseline > $OUT/$V.json 2> $OUT/$V.err || echo "$V failed"
+  python bench.py --full-line --steps ${STEPS:-40} --warmup 5 --steady-after 0 --no-cpu-baseline > $OUT/$V.json 2> $OUT/$V.err || echo "$V failed"
   python - $OUT/$V.json $V <<'PY'
 import json, sys
 d = json.loads(open(sys.argv[1]).read().strip().splitlines()[-1])

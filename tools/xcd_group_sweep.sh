@@ -4,7 +4,7 @@ export OPMHIP_TUNING=1   # the library reads its measurement switches only under
 OUT=$1; shift
 mkdir -p $OUT
 for G in "$@"; do
-  OPMHIP_XCD_GROUP=$G python bench.py --steps 20 --warmup 5 --steady-after 0 --no-cpu-baseline > $OUT/g$G.json 2> $OUT/g$G.err || echo "G=$G failed"
+  OPMHIP_XCD_GROUP=$G python bench.py --full-line --steps 20 --warmup 5 --steady-after 0 --no-cpu-baseline > $OUT/g$G.json 2> $OUT/g$G.err || echo "G=$G failed"
   python - $OUT/g$G.json $G <<'PY'
 import json, sys
 d = json.loads(open(sys.argv[1]).read().strip().splitlines()[-1])
