@@ -241,6 +241,22 @@ SINGLE_DOMAIN_LIN_ITS = {"ilu0": 17.5, "cpr": 4.75, "cpr_trueimpes": 4.75, "cpr_
 # linear iterations per Newton iteration of the N = 1 run of this bench (start-up window, default flags; profiles/r05_*): what the
 # decomposed runs' counts are put beside
 SINGLE_DOMAIN_LIN_ITS = {"ilu0": 17.5, "cpr": 4.75, "cpr_trueimpes": 4.75, "cpr_quasiimpes": 3.8}
+COMM_SCOPES = ("halo", "allreduce", "cpr_gather")
+
+
+def comm_summary(every):
+    """every: per rank {scope: (launches, total_ms)} of the profiler's communication spans -> per scope the launches per rank and the average /
+    total milliseconds as max and mean over the ranks (a scope no rank recorded is left out)"""
+    out = {}
+    for k in COMM_SCOPES:
+        avg = [e[k][1] / e[k][0] for e in every if e.get(k, (0, 0.0))[0]]
+        tot = [e.get(k, (0, 0.0))[1] for e in every]
+        if avg:
+            out[k] = {"launches_per_rank": max(e.get(k, (0, 0.0))[0] for e in every), "avg_ms_max": round(max(avg), 5), "avg_ms_mean": round(sum(avg) / len(avg), 5),
+                      "total_ms_max": round(max(tot), 3), "total_ms_mean": round(sum(tot) / len(tot), 3)}
+    return out
+
+
 LINE_LIMIT = 4096   # bytes of the one line on stdout (round 4's 22 KB line could not be parsed from the driver's 8 KB tail)
 
 
@@ -483,31 +499,10 @@ def main():
         # exchanges" come apart (parity caveat)
         comm = None
         if dist is not None:
-            mine = {k: (prof.get(k, (0, 0.0))[0], prof.get(k, (0, 0.0))[1]) for k in ("halo", "allreduce", "cpr_gather")}
+            mine = {k: (prof.get(k, (0, 0.0))[0], prof.get(k, (0, 0.0))[1]) for k in COMM_SCOPES}
             every = [None] * world
             dist.all_gather_object(every, mine)
-            comm = {}
-            for k in mine:
-                avg = [e[k][1] / e[k][0] for e in every if e[k][0]]
-                tot = [e[k][1] for e in every]
-                if avg:
-                    comm[k] = {"launches_per_rank": max(e[k][0] for e in every), "avg_ms_max": round(max(avg), 5), "avg_ms_mean": round(sum(avg) / len(avg), 5),
-                               "total_ms_max": round(max(tot), 3), "total_ms_mean": round(sum(tot) / len(tot), 3)}
-        # communication spans (decomposed runs; they overlap the kernel scopes): per rank launches and milliseconds, then max / mean over
-        # the ranks - with the iteration count beside them, so that "slower because of more iterations" and "slower because of the
-        # exchanges" come apart (parity caveat)
-        comm = None
-        if dist is not None:
-            mine = {k: (prof.get(k, (0, 0.0))[0], prof.get(k, (0, 0.0))[1]) for k in ("halo", "allreduce", "cpr_gather")}
-            every = [None] * world
-            dist.all_gather_object(every, mine)
-            comm = {}
-            for k in mine:
-                avg = [e[k][1] / e[k][0] for e in every if e[k][0]]
-                tot = [e[k][1] for e in every]
-                if avg:
-                    comm[k] = {"launches_per_rank": max(e[k][0] for e in every), "avg_ms_max": round(max(avg), 5), "avg_ms_mean": round(sum(avg) / len(avg), 5),
-                               "total_ms_max": round(max(tot), 3), "total_ms_mean": round(sum(tot) / len(tot), 3)}
+            comm = comm_summary(every)
         ls_bytes = sum(Bm[k] * prof[k][0] for k in ("spmv", "ilu_apply", "ilu_factor", "vector"))
         ls_ms = sum(prof[k][1] for k in ("spmv", "ilu_apply", "ilu_factor", "vector"))
         return {"elapsed": elapsed, "steps": steps, "kernels": kernels, "spmv_boundary_share_of_time": boundary_share, "comm": comm, "comm": comm,

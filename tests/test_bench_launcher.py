@@ -58,3 +58,27 @@ def test_traffic_is_tied_to_the_kernel_sources(bench):
     else:
         import json
         assert json.load(open(os.path.join(ROOT, src)))["kernel_source_sha16"] == h
+
+
+def test_comm_summary_and_the_line_with_eight_ranks(bench):
+    """what `bench.py --gpus 8` adds to its line - the communication spans per rank as max / mean, the RCCL communicator - from synthetic
+    per-rank records (no run with more than one GPU has been possible): the arithmetic, and the line still under 4 KB"""
+    every = [{"halo": (70, 7.0 + r), "allreduce": (141, 14.1), "cpr_gather": (0, 0.0)} for r in range(8)]
+    c = bench.comm_summary(every)
+    assert set(c) == {"halo", "allreduce"}                       # no rank recorded a gather span: left out
+    assert c["halo"]["launches_per_rank"] == 70 and abs(c["halo"]["avg_ms_max"] - 14.0 / 70) < 1e-5 and abs(c["halo"]["avg_ms_mean"] - 10.5 / 70) < 1e-5
+    assert c["halo"]["total_ms_max"] == 14.0 and c["halo"]["total_ms_mean"] == 10.5 and c["allreduce"]["avg_ms_max"] == 0.1
+    kern = {k: {"algorithmic_GBps": 4321.0} for k in ("spmv", "ilu_apply", "ilu_factor", "vector", "assemble", "iq_update", "convergence")}
+    out = {"metric": "m" * 90, "value": 640.123456, "unit": "u" * 100, "n_gpus": 8, "steps": 20, "warmup": 3, "ms_per_step": 12.5, "higher_is_better": True, "scaling": "weak",
+           "vs_baseline": None, "dtype": "f64", "data": "synthetic", "config": {"workload": "w" * 300, "parallelism": "p" * 120, "cells_per_gpu": 1000000},
+           "newton_iterations_per_s_global": 80.0, "linear_iterations_per_newton": 21.3, "linear_solve_GBps": 4000.0, "kernels": kern,
+           "roofline": {"bound": "hbm", "kernel": "k_spmv", "achieved": 5000.0, "peak": 8000.0, "unit": "GB/s", "frac": 0.625, "traffic": None, "avg_launch_ms": 0.11,
+                        "algorithmic_bytes_per_launch": 579440004, "frac_of_stream_ceiling": 0.9, "traffic_source": "s" * 200},
+           "steady_state": {"value": 400.0, "linear_iterations_per_newton": 30.0}, "stream_ceiling": {"read_GBps": 5900.0},
+           "rccl": {"nranks": 8, "kind": "rccl", "rank_devices": list(range(8)), "hosts": ["h"]},
+           "comm": dict(c, profiled_solves=7, profiled_every=3, linear_iterations_per_newton=21.3, single_domain_linear_iterations_per_newton=17.5),
+           "device": {"name": "AMD Instinct MI355X"}}
+    import json
+    line = bench.compact_line(out, "gpurun_out/bench_detail.json")
+    assert len(json.dumps(line)) < bench.LINE_LIMIT and line["comm"]["halo"]["avg_ms_max"] == c["halo"]["avg_ms_max"] and line["rccl"] == {"nranks": 8, "kind": "rccl"}
+    assert "cpu_baseline" not in line and line["n_gpus"] == 8 and line["steady_state"]["value"] == 400.0
