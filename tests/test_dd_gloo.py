@@ -110,7 +110,11 @@ def test_window_built_subdomain_equals_global_slice(pkg):
 
 def _gather_worker(rank, world, port, q):
     """the exchange pattern of the CPR pressure stage that spans the ranks (csrc/cpr.hip: cpr_gather_setup / cpr_gathered_cycle), over
-    gloo: slices of different lengths, padded to the longest, all-gathered, unpadded through the index list r * maxn + i"""
+    gloo: slices of different lengths, padded to the longest, all-gathered, unpadded through the index list r * maxn + i.
+    What this does NOT do: run a line of csrc/comm.hip or csrc/cpr.hip - it re-enacts the protocol's index arithmetic in Python between
+    real processes (a world-size-2/3 rendezvous, a real all-gather of ragged slices), so a mistake in the PROTOCOL shows here without a
+    GPU; the library's own implementation of it is compared with the oracle on the loopback communicator (tests/test_gpu_dd.py::
+    test_dd_cpr_pressure_stage_across_the_ranks) and has never run over RCCL with more than one rank."""
     sys.path.insert(0, ROOT)
     import torch
     import torch.distributed as dist
