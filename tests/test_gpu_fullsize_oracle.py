@@ -102,3 +102,42 @@ def test_solve_stops_on_the_oracles_half_iteration_and_the_next_iteration_follow
     assert np.array_equal(cm[3:6], co[3:6])                       # the maxima (CNV numerators) are exact
     np.testing.assert_allclose(cm[6:10], co[6:10], rtol=1e-12)    # sums over 10^6 cells: order of summation only
     np.testing.assert_allclose(cm[[0, 1, 2, 14, 15, 16]], co[[0, 1, 2, 14, 15, 16]], rtol=1e-9)
+
+
+def test_cpr_at_the_benchmarked_size(pkg, orc):
+    """bench.py's fastest configuration at its own size: `cpr` (= cpr_trueimpes, setupPropertyTree.cpp:62-76) on the 100^3 case with the
+    library's defaults - line colouring, level 0 of the pressure AMG smoothed by ILU0 (asserted).  True-IMPES weights, the hierarchy's
+    level sizes and one application of the preconditioner equal the oracle's bit for bit (the eight-level hierarchy over 10^6 rows with
+    its lane-group levels and the Jacobi sweeps of the coarsest one: what the bench times, not a 9 000-row stand-in), and the solve -
+    whose factorisation writes the pressure system as it stages the rows (k_ilu_factor's rider) - stops on the oracle's half iteration."""
+    import oracle_bind
+    case = pkg.decks.cartesian_case(N, N, N, state="mixed", heterogeneous=False)
+    src = pkg.decks.five_spot_source(case, rate_sm3_per_day=pkg.decks.BENCH_RATE_SM3_PER_DAY)
+    Nb = case["Nb"]
+    m = pkg.capi.HipModel(case, tolerance=1e-2, maxit=200, ilu_relaxation=0.9, preconditioner="cpr")
+    o = oracle_bind.OracleModel(orc, case)
+    for h in (m, o):
+        h.set_state(case["pv"], case["meaning"])
+        h.set_source(src)
+    m.assemble(DT, 0, fetch=False)
+    jo, ro = o.assemble(DT, 0)
+    sol = m.solve_jacobian_system()
+    info = m.ordering_info()
+    assert info["ilu_ordering"] == "line_coloring" and info["chain_length"] == 10 and info["cpr_amg_ilu_levels"] == 1
+    wo = o.true_impes_weights(DT)
+    assert np.array_equal(m.cpr_weights(), wo)
+    to, fr, _ = m.ordering()
+    rr, rc, rv = orc.reorder_matrix(Nb, case["rowptr"], case["col"], jo, to, fr)
+    cpr = oracle_bind.OracleCpr(orc)
+    cpr.set_natural_ids(fr)
+    cpr.set_weights(wo[fr])
+    cpr.set_ilu_smoother(1, 1)
+    cpr.update(Nb, rr, rc, rv)
+    levels = m.cpr_levels()[0]
+    assert levels == [int(x) for x in cpr.levels()[0]] and levels[0] == Nb and len(levels) >= 6
+    d = np.random.default_rng(43).standard_normal(3 * Nb)
+    vo = cpr.apply(np.ascontiguousarray(d.reshape(Nb, 3)[fr].reshape(-1))).reshape(Nb, 3)[to].reshape(-1)
+    assert np.array_equal(m.cpr_apply(d), vo)
+    xo, so = cpr.solve(Nb, rr, rc, rv, np.ascontiguousarray(ro.reshape(Nb, 3)[fr].reshape(-1)), tol=1e-2)
+    assert sol.converged and so.converged and sol.it == so.it
+    assert abs(sol.reduction - so.reduction) <= 1e-6 * so.reduction
