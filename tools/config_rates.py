@@ -36,8 +36,8 @@ def scattered_sources(case, rate_sm3_per_day, n=12, seed=3):
 def run(name, case, src, **kw):
     out = []
     for prec in ("ilu0", "cpr"):
-        m = pkg.capi.HipModel(case, reorder="auto", tolerance=1e-2, maxit=200, ilu_relaxation=0.9, preconditioner=prec,
-                              cpr_amg_ilu_levels=a.cpr_amg_ilu_levels if prec == "cpr" else 0, **kw)
+        m = pkg.capi.HipModel(case, tolerance=1e-2, maxit=200, ilu_relaxation=0.9, preconditioner=prec,
+                              cpr_amg_ilu_levels=a.cpr_amg_ilu_levels, **kw)   # no reorder argument: the library's default (auto)
         m.set_state(case["pv"], case["meaning"])
         m.set_source(src)
         sim = bench.make_simulation(pkg, m)
