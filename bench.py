@@ -363,7 +363,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--n", type=int, default=100, help="cells per edge of the per-GPU cube")
+    ap.add_argument("--n", "--cells-per-edge", dest="n", type=int, default=100, help="cells per edge of the per-GPU cube (behind torch.distributed.run use the long form: its own parser takes a bare --n for an abbreviation of its options)")
     ap.add_argument("--reorder", default=None, help="ILU0 ordering; default: the library's own choice (opmhip_default_config: auto), reported in config.ilu_ordering")
     ap.add_argument("--chain-length", type=int, default=0, help="rows per chain of the line-coloured ILU0 ordering; 0: the library's choice (10 at 10^6 cells)")
     ap.add_argument("--full-line", action="store_true", help="tools/ only: print the full record as the one line (tens of KB: the driver could not parse that from its tail of stdout)")

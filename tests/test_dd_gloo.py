@@ -161,3 +161,39 @@ def test_joined_level_gather_protocol_over_gloo(world):
         p.join(timeout=60)
         assert p.exitcode == 0
     assert all(ok for _, ok in res), res
+
+
+def test_bench_two_ranks_control_plane_over_gloo(tmp_path):
+    """`bench.py --gpus 2` the way the driver starts it (torch.distributed.run, two ranks, 127.0.0.1) on the CPU: the device context is a
+    stand-in (tests/bench_fake_rank.py), everything else is bench.py's own multi-rank code - rendezvous over gloo, the communicator id
+    broadcast from rank 0, the gathered RCCL record (and the rule that refuses a communicator that does not span --gpus ranks), barriers, the
+    MAX of the elapsed times, the communication spans gathered over the ranks as max / mean, ONE line of < 4 KB from rank 0 with `value` =
+    steps x ranks / time.  No run with more than one GPU has been possible: this is what can be checked of it here."""
+    import json
+    import subprocess
+    import sys
+    port = 29800 + os.getpid() % 150
+    detail = str(tmp_path / "detail.json")
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1", "--master-port", str(port),
+           os.path.join(ROOT, "tests", "bench_fake_rank.py"), "--gpus", "2", "--steps", "6", "--warmup", "2", "--cells-per-edge", "10", "--steady-after", "12", "--steady-steps", "4",
+           "--detail", detail]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=600, env=env, cwd=ROOT)
+    assert r.returncode == 0, (r.stdout[-1500:], r.stderr[-3000:])
+    lines = [ln for ln in r.stdout.strip().splitlines() if ln.startswith("{")]
+    assert len(lines) == 1 and len(lines[0]) < 4096          # rank 0 alone prints
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["steps"] == 6 and d["scaling"] == "weak" and "cpu_baseline" not in d and d["rccl"] == {"nranks": 2, "kind": "rccl"}
+    assert abs(d["value"] - 2 * d["newton_iterations_per_s_global"]) < 1e-3 * d["value"] and "2x1x1" in d["config"]["parallelism"]
+    assert d["unit"].startswith("Newton iterations/s x 1M-cell subdomains")
+    c = d["comm"]
+    assert c["halo"]["launches_per_rank"] > 0 and c["halo"]["avg_ms_max"] > c["halo"]["avg_ms_mean"] > 0     # rank 1's stand-in spans are twice rank 0's
+    assert abs(c["halo"]["avg_ms_max"] / c["halo"]["avg_ms_mean"] - 4.0 / 3.0) < 1e-3 and "cpr_gather" not in c
+    assert c["single_domain_linear_iterations_per_newton"] == 17.5 and c["linear_iterations_per_newton"] > 0
+    full = json.load(open(detail))
+    assert full["rccl"]["rank_devices"] == [0, 1] and full["rccl"]["selftest_sum"] == full["rccl"]["selftest_expected"] == [3.0, 4.0]
+    assert full["steady_state"]["steps"] == 4 and full["spmv_boundary_share_of_time"] == 0.2
+    # a communicator that does not span the ranks that were asked for: every rank exits non-zero, no line
+    bad = subprocess.run(cmd[:8] + [str(port + 1), cmd[9]] + ["--gpus", "2", "--steps", "2", "--warmup", "1", "--cells-per-edge", "10", "--steady-after", "0"], capture_output=True, text=True, timeout=600,
+                         env=dict(env, OPMHIP_FAKE_NRANKS="1"), cwd=ROOT)
+    assert bad.returncode != 0 and "RCCL communicator spans 1 rank" in (bad.stderr + bad.stdout)
