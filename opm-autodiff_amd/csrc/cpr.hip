@@ -293,12 +293,97 @@ __global__ __launch_bounds__(256) void k_cpr_dense_lu(int n, int W, int rm, cons
         __syncthreads();
     }
 }
-// forward / backward substitution, one wavefront's worth of a workgroup; lane-serial (n <= 128: microseconds)
+// the same factorisation with the matrix in LDS (n x n doubles of dynamic shared memory: 128 KB at n = 128, which gfx950's 160 KB hold) and
+// 1 024 threads on a 32 x 32 tiling of the trailing block: every entry's updates still come in the order k ascending, each one the same
+// rounded product and subtraction - the same factors - without 2 n barriers over global memory (0.56 ms per solve on a 100-row level).
+__global__ __launch_bounds__(1024) void k_cpr_dense_lu_lds(int n, int W, int rm, const int* __restrict__ ecol, const int* __restrict__ rlen, const double* __restrict__ val,
+                                                           double* __restrict__ lu) {
+    extern __shared__ double slu[];
+    const int tid = threadIdx.x, tx = tid & 31, ty = tid >> 5;
+    for (int e = tid; e < n * n; e += 1024) slu[e] = 0.0;
+    __syncthreads();
+    for (int i = tid; i < n; i += 1024)
+        for (int j = 0; j < rlen[i]; ++j) {
+            const size_t e = rm ? (size_t)i * W + j : (size_t)j * n + i;
+            slu[i * n + ecol[e]] = val[e];
+        }
+    __syncthreads();
+    bool bad = false;   // (thread 0's copy is the one that counts)
+    for (int k = 0; k < n; ++k) {
+        const double pv = slu[k * n + k];
+        if (pv == 0.0 || !isfinite(pv)) bad = true;
+        const double piv = 1.0 / pv;
+        __syncthreads();   // every thread has read the pivot before column k is scaled (the pivot itself is not touched)
+        for (int i = k + 1 + tid; i < n; i += 1024) slu[i * n + k] = slu[i * n + k] * piv;
+        __syncthreads();
+        for (int i = k + 1 + ty; i < n; i += 32) {
+            const double f = slu[i * n + k];
+            for (int j = k + 1 + tx; j < n; j += 32) slu[i * n + j] -= f * slu[k * n + j];
+        }
+        __syncthreads();
+    }
+    for (int e = tid; e < n * n; e += 1024) lu[e] = slu[e];
+    if (tid == 0) lu[(size_t)n * n] = bad ? 1.0 : 0.0;   // flag behind the factors: 1 = a pivot vanished or is not finite (no pivoting here)
+}
+// x = U^-1 L^-1 b with the dense factors of the coarsest level (n <= CPR_COARSE_DIRECT), in LDS: s holds b on entry and x on return.  Every
+// row's sum runs over j ascending, as the oracle's does (same bits).  Forward (unit lower factor): x_j is final once the columns before j
+// are applied, so the rows below j subtract l_ij x_j in parallel, column by column.  Backward: row i subtracts u_ij x_j for j = i + 1 .. n - 1
+// in THAT order, and x_{i+1} - the first one it needs - is the last to become known: the rows follow one another, one lane walks them (its
+// sums are the only chain: the row's products u_ij x_j are formed by all lanes at once - each the one rounded product the sequential loop
+// forms - and lane 0 subtracts them in order).  Until round 5 the iterate lived in global memory
+// and one thread walked both triangles through dependent loads of what it had just stored: 0.7 ms per application on a 100-row level
+// (`cpr` on the SPE9-shaped grid: 87 -> 340 Newton its/s, on SPE1's grid 238 -> 850, with the factorisation in LDS as well;
+// profiles/r05_config_rates.txt).
+// ONE wavefront (64 lanes, n <= 128 = two rows / two columns per lane): LDS accesses of a wavefront execute in program order, so the steps
+// need no workgroup barrier; the factors' column (forward) or row (backward) of the NEXT step is loaded while the present one is worked off.
+__device__ __forceinline__ void cpr_dense_substitute(int n, const double* __restrict__ lu, double* s, double* sp) {
+    const int lane = threadIdx.x;
+    const int i0 = lane, i1 = lane + 64;
+    auto at = [&](int i, int j) { return (i < n && j < n) ? lu[(size_t)i * n + j] : 0.0; };
+    __builtin_amdgcn_wave_barrier();
+    {   // forward: column by column, the rows below the diagonal in parallel
+        double c0 = at(i0, 0), c1 = at(i1, 0);
+        for (int j = 0; j + 1 < n; ++j) {
+            const double l0 = c0, l1 = c1;
+            c0 = at(i0, j + 1); c1 = at(i1, j + 1);
+            const double xj = s[j];
+            if (i0 > j && i0 < n) s[i0] -= l0 * xj;
+            if (i1 > j && i1 < n) s[i1] -= l1 * xj;
+            __builtin_amdgcn_wave_barrier();
+        }
+    }
+    {   // backward: row by row; the row's products all at once, the ordered subtraction by lane 0
+        double r0 = at(n - 1, i0), r1 = at(n - 1, i1);
+        for (int i = n - 1; i >= 0; --i) {
+            const double u0 = r0, u1 = r1;
+            if (i > 0) { r0 = at(i - 1, i0); r1 = at(i - 1, i1); }
+            if (i0 > i && i0 < n) sp[i0] = u0 * s[i0];
+            if (i1 > i && i1 < n) sp[i1] = u1 * s[i1];
+            if (i0 == i) sp[n] = u0;               // the diagonal entry u_ii, behind the products
+            if (i1 == i) sp[n] = u1;
+            __builtin_amdgcn_wave_barrier();
+            if (lane == 0) {
+                double t = s[i];
+                int j = i + 1;
+                for (; j + 8 <= n; j += 8) {
+                    double q[8];
+#pragma unroll
+                    for (int u = 0; u < 8; ++u) q[u] = sp[j + u];
+#pragma unroll
+                    for (int u = 0; u < 8; ++u) t -= q[u];
+                }
+                for (; j < n; ++j) t -= sp[j];
+                s[i] = t / sp[n];
+            }
+            __builtin_amdgcn_wave_barrier();
+        }
+    }
+}
 // mem4f != NULL: b[i] = sum of the finer level's residual over aggregate i (k_cpr_restrict's statement), formed here
 __global__ __launch_bounds__(64) void k_cpr_dense_solve(int n, const double* __restrict__ lu, const double* __restrict__ b, double* __restrict__ x,
                                                         const int* __restrict__ mem4f, const double* __restrict__ rf, const double* __restrict__ done) {
     CPR_DONE_CHECK
-    __shared__ double sb[CPR_COARSE_DIRECT];
+    __shared__ double sb[CPR_COARSE_DIRECT], sp[CPR_COARSE_DIRECT + 1];
     for (int i = threadIdx.x; i < n; i += 64) {
         double s;
         if (mem4f) {
@@ -311,18 +396,8 @@ __global__ __launch_bounds__(64) void k_cpr_dense_solve(int n, const double* __r
         } else s = b[i];
         sb[i] = s;
     }
-    __syncthreads();
-    if (threadIdx.x != 0) return;
-    for (int i = 0; i < n; ++i) {
-        double s = sb[i];
-        for (int j = 0; j < i; ++j) s -= lu[(size_t)i * n + j] * x[j];
-        x[i] = s;
-    }
-    for (int i = n - 1; i >= 0; --i) {
-        double s = x[i];
-        for (int j = i + 1; j < n; ++j) s -= lu[(size_t)i * n + j] * x[j];
-        x[i] = s / lu[(size_t)i * n + i];
-    }
+    cpr_dense_substitute(n, lu, sb, sp);
+    for (int i = threadIdx.x; i < n; i += 64) x[i] = sb[i];
 }
 // r_p[i] = sum_k d_i[k] w_i[k]  (moveToCoarseLevel, :141-160); x0 != NULL: the level's pre-smoothing from x = 0 rides along,
 // x0[i] = omega D^-1 r_p[i] - the statement of k_cpr_presmooth, one launch less
@@ -1778,7 +1853,11 @@ static int cpr_update_values(opmhip_ctx* c, CprDev& R) {
     }
     if (R.coarse_direct) {
         const CprLevelDev& C = R.lv.back();
-        hipLaunchKernelGGL(k_cpr_dense_lu, dim3(1), dim3(256), 0, c->stream, C.n, C.W, C.rm ? 1 : 0, C.d_ecol, C.d_rlen, C.d_val, R.d_lu);
+        // in LDS where the device grants n x n doubles of dynamic shared memory (gfx950: yes, up to n = 128), else in place in global memory
+        static const bool ldsOk = hipFuncSetAttribute(reinterpret_cast<const void*>(k_cpr_dense_lu_lds), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                                      CPR_COARSE_DIRECT * CPR_COARSE_DIRECT * (int)sizeof(double)) == hipSuccess;
+        if (ldsOk) hipLaunchKernelGGL(k_cpr_dense_lu_lds, dim3(1), dim3(1024), (size_t)C.n * C.n * sizeof(double), c->stream, C.n, C.W, C.rm ? 1 : 0, C.d_ecol, C.d_rlen, C.d_val, R.d_lu);
+        else hipLaunchKernelGGL(k_cpr_dense_lu, dim3(1), dim3(256), 0, c->stream, C.n, C.W, C.rm ? 1 : 0, C.d_ecol, C.d_rlen, C.d_val, R.d_lu);
     }
     return OPMHIP_SUCCESS;
 }
