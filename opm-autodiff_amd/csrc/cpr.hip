@@ -325,23 +325,21 @@ __global__ __launch_bounds__(1024) void k_cpr_dense_lu_lds(int n, int W, int rm,
     for (int e = tid; e < n * n; e += 1024) lu[e] = slu[e];
     if (tid == 0) lu[(size_t)n * n] = bad ? 1.0 : 0.0;   // flag behind the factors: 1 = a pivot vanished or is not finite (no pivoting here)
 }
-// x = U^-1 L^-1 b with the dense factors of the coarsest level (n <= CPR_COARSE_DIRECT), in LDS: s holds b on entry and x on return.  Every
-// row's sum runs over j ascending, as the oracle's does (same bits).  Forward (unit lower factor): x_j is final once the columns before j
-// are applied, so the rows below j subtract l_ij x_j in parallel, column by column.  Backward: row i subtracts u_ij x_j for j = i + 1 .. n - 1
-// in THAT order, and x_{i+1} - the first one it needs - is the last to become known: the rows follow one another, one lane walks them (its
-// sums are the only chain: the row's products u_ij x_j are formed by all lanes at once - each the one rounded product the sequential loop
-// forms - and lane 0 subtracts them in order).  Until round 5 the iterate lived in global memory
-// and one thread walked both triangles through dependent loads of what it had just stored: 0.7 ms per application on a 100-row level
-// (`cpr` on the SPE9-shaped grid: 87 -> 340 Newton its/s, on SPE1's grid 238 -> 850, with the factorisation in LDS as well;
-// profiles/r05_config_rates.txt).
-// ONE wavefront (64 lanes, n <= 128 = two rows / two columns per lane): LDS accesses of a wavefront execute in program order, so the steps
-// need no workgroup barrier; the factors' column (forward) or row (backward) of the NEXT step is loaded while the present one is worked off.
-__device__ __forceinline__ void cpr_dense_substitute(int n, const double* __restrict__ lu, double* s, double* sp) {
+// x = U^-1 L^-1 b with the dense factors of the coarsest level (n <= CPR_COARSE_DIRECT), in LDS: s holds b on entry and x on return.
+// Both substitutions go COLUMN by column, as the oracle's do (oracle/cpr.hpp: vcycle; the same terms in the same order, the same bits):
+// forward (unit lower factor) x_j is final once the columns before it are applied, and the rows below take l_ij x_j off at once;
+// backward x_j = s_j / u_jj is final once the columns behind it are applied, and the rows above take u_ij x_j off at once - a row's
+// terms in the order j = n - 1 ... i + 1.  ONE wavefront (64 lanes, n <= 128: two rows per lane): its LDS accesses execute in program
+// order, so the 2 n steps need no workgroup barrier; the factors' next column is loaded while the present one is worked off.
+// Until round 5 the iterate lived in global memory and one thread walked both triangles row by row through dependent loads of what it
+// had just stored: 0.7 ms per application on a 100-row level; rows in the row-oriented order still cost 0.13 ms (a chain of n^2 / 2
+// dependent subtractions), which is why the order changed on both sides (profiles/r05_config_rates.txt, r05_cpr_tail_ab.txt).
+__device__ __forceinline__ void cpr_dense_substitute(int n, const double* __restrict__ lu, double* s) {
     const int lane = threadIdx.x;
     const int i0 = lane, i1 = lane + 64;
-    auto at = [&](int i, int j) { return (i < n && j < n) ? lu[(size_t)i * n + j] : 0.0; };
+    auto at = [&](int i, int j) { return (i < n && j >= 0 && j < n) ? lu[(size_t)i * n + j] : 0.0; };
     __builtin_amdgcn_wave_barrier();
-    {   // forward: column by column, the rows below the diagonal in parallel
+    {
         double c0 = at(i0, 0), c1 = at(i1, 0);
         for (int j = 0; j + 1 < n; ++j) {
             const double l0 = c0, l1 = c1;
@@ -352,29 +350,17 @@ __device__ __forceinline__ void cpr_dense_substitute(int n, const double* __rest
             __builtin_amdgcn_wave_barrier();
         }
     }
-    {   // backward: row by row; the row's products all at once, the ordered subtraction by lane 0
-        double r0 = at(n - 1, i0), r1 = at(n - 1, i1);
-        for (int i = n - 1; i >= 0; --i) {
-            const double u0 = r0, u1 = r1;
-            if (i > 0) { r0 = at(i - 1, i0); r1 = at(i - 1, i1); }
-            if (i0 > i && i0 < n) sp[i0] = u0 * s[i0];
-            if (i1 > i && i1 < n) sp[i1] = u1 * s[i1];
-            if (i0 == i) sp[n] = u0;               // the diagonal entry u_ii, behind the products
-            if (i1 == i) sp[n] = u1;
+    {
+        double c0 = at(i0, n - 1), c1 = at(i1, n - 1);
+        for (int j = n - 1; j >= 0; --j) {
+            const double u0 = c0, u1 = c1;
+            c0 = at(i0, j - 1); c1 = at(i1, j - 1);
+            if (i0 == j) s[j] = s[j] / u0;            // the lane that holds row j holds u_jj
+            if (i1 == j) s[j] = s[j] / u1;
             __builtin_amdgcn_wave_barrier();
-            if (lane == 0) {
-                double t = s[i];
-                int j = i + 1;
-                for (; j + 8 <= n; j += 8) {
-                    double q[8];
-#pragma unroll
-                    for (int u = 0; u < 8; ++u) q[u] = sp[j + u];
-#pragma unroll
-                    for (int u = 0; u < 8; ++u) t -= q[u];
-                }
-                for (; j < n; ++j) t -= sp[j];
-                s[i] = t / sp[n];
-            }
+            const double xj = s[j];
+            if (i0 < j) s[i0] -= u0 * xj;
+            if (i1 < j) s[i1] -= u1 * xj;
             __builtin_amdgcn_wave_barrier();
         }
     }
@@ -383,7 +369,7 @@ __device__ __forceinline__ void cpr_dense_substitute(int n, const double* __rest
 __global__ __launch_bounds__(64) void k_cpr_dense_solve(int n, const double* __restrict__ lu, const double* __restrict__ b, double* __restrict__ x,
                                                         const int* __restrict__ mem4f, const double* __restrict__ rf, const double* __restrict__ done) {
     CPR_DONE_CHECK
-    __shared__ double sb[CPR_COARSE_DIRECT], sp[CPR_COARSE_DIRECT + 1];
+    __shared__ double sb[CPR_COARSE_DIRECT];
     for (int i = threadIdx.x; i < n; i += 64) {
         double s;
         if (mem4f) {
@@ -396,7 +382,7 @@ __global__ __launch_bounds__(64) void k_cpr_dense_solve(int n, const double* __r
         } else s = b[i];
         sb[i] = s;
     }
-    cpr_dense_substitute(n, lu, sb, sp);
+    cpr_dense_substitute(n, lu, sb);
     for (int i = threadIdx.x; i < n; i += 64) x[i] = sb[i];
 }
 // r_p[i] = sum_k d_i[k] w_i[k]  (moveToCoarseLevel, :141-160); x0 != NULL: the level's pre-smoothing from x = 0 rides along,

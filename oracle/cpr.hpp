@@ -384,10 +384,13 @@ struct CprAmg {
                     for (int j = 0; j < i; ++j) s -= lu[(size_t)i * n + j] * x[j];
                     x[i] = s;
                 }
-                for (int i = n - 1; i >= 0; --i) {
-                    double s = x[i];
-                    for (int j = i + 1; j < n; ++j) s -= lu[(size_t)i * n + j] * x[j];
-                    x[i] = s / lu[(size_t)i * n + i];
+                // backward substitution COLUMN by column: once x_j is final every row above it takes u_ij x_j off - a row's terms go in the
+                // order j = n - 1 ... i + 1, then the division.  (Round 5: the row-oriented form - j ascending - made the device walk the
+                // rows one after the other, 0.13 ms per application on a 100-row level; this order lets the rows above a column work at once.
+                // Both are backward substitutions of the same factors; the AMG is this design's own, no reference number pins the order.)
+                for (int j = n - 1; j >= 0; --j) {
+                    x[j] = x[j] / lu[(size_t)j * n + j];
+                    for (int i = 0; i < j; ++i) x[i] -= lu[(size_t)i * n + j] * x[j];
                 }
             } else {   // could not coarsen further: a few Jacobi sweeps stand in for the coarse solve
                 std::vector<double> r(n);
