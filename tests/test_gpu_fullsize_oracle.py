@@ -141,3 +141,75 @@ def test_cpr_at_the_benchmarked_size(pkg, orc):
     xo, so = cpr.solve(Nb, rr, rc, rv, np.ascontiguousarray(ro.reshape(Nb, 3)[fr].reshape(-1)), tol=1e-2)
     assert sol.converged and so.converged and sol.it == so.it
     assert abs(sol.reduction - so.reduction) <= 1e-6 * so.reduction
+
+
+@pytest.mark.parametrize("reorder", [None, "level_scheduling"], ids=["library_default", "level_scheduling"])
+def test_two_subdomains_of_full_size_against_the_global_oracle(pkg, orc, reorder):
+    """configs[3]'s building block with the oracle AT size: a 200 x 100 x 100 grid cut into two subdomains of 10^6 cells (+ 10^4 ghost cells
+    each), two contexts on this GPU joined by the loopback communicator - set_pattern_dd, halo exchange beside the interior tiles, local
+    reductions + all-reduce: the code path of the 8-GPU run with device copies in RCCL's place.  The oracle assembles the GLOBAL grid and
+    solves it with the reference's block-Jacobi ILU0 (ghost_last_bilu0_decomposition: couplings between subdomains dropped,
+    linalg/ParallelOverlappingILU0.hpp:439-494).  Every rank's owned rows of J and r equal the global oracle's bit for bit, the convergence
+    sums are the global ones on both ranks; with level scheduling (the device's factors are then the oracle's natural-order ones) the solve
+    stops on the oracle's half iteration with its x; with the library's default ordering (line colouring per subdomain) it meets the
+    stopping rule on the global residual."""
+    import threading
+    import uuid
+    import oracle_bind
+    world = 2
+    px, py, pz = pkg.ras.block_layout(world)
+    g = pkg.decks.cartesian_case(px * N, py * N, pz * N, state="mixed", heterogeneous=False)
+    owner = pkg.ras.cartesian_owner(px * N, py * N, pz * N, px, py, pz)
+    parts = [pkg.ras.cartesian_subdomain_case(N, world, r, state="mixed", heterogeneous=False) for r in range(world)]
+    src = pkg.decks.five_spot_source(g, rate_sm3_per_day=pkg.decks.BENCH_RATE_SM3_PER_DAY)
+    o = oracle_bind.OracleModel(orc, g)
+    o.set_state(g["pv"], g["meaning"])
+    o.set_source(src)
+    jo, ro = o.assemble(DT, 0)
+    co = o.convergence(DT, 1e-2)
+    group = "full2" + uuid.uuid4().hex
+    out, err = [None] * world, [None] * world
+
+    def body(r):
+        try:
+            c = parts[r]
+            kw = {} if reorder is None else {"reorder": reorder}
+            m = pkg.capi.HipModel(c, comm=("loopback", world, r, group), tolerance=1e-2, maxit=200, ilu_relaxation=0.9, **kw)
+            m.set_state(c["pv"], c["meaning"])
+            m.set_source(np.ascontiguousarray(src.reshape(-1, 3)[c["gids"]].reshape(-1)))
+            j, res = m.assemble(DT, 0)
+            conv = m.convergence(DT, 1e-2)
+            sol = m.solve_jacobian_system()
+            out[r] = (j, res, conv, float(sol.it), bool(sol.converged), float(sol.reduction), m.get_result(), m.ordering_info())
+        except BaseException as e:  # noqa: BLE001
+            err[r] = e
+
+    ts = [threading.Thread(target=body, args=(r,)) for r in range(world)]
+    for t in ts:
+        t.start()
+    for t in ts:
+        t.join(timeout=900)
+    for e in err:
+        if e is not None:
+            raise e
+    xd = np.zeros((g["Nb"], 3))
+    for r, (j, res, conv, it, ok, red, x, info) in enumerate(out):
+        c = parts[r]
+        Nb = c["Nb"]
+        gi = c["gids"][:Nb]
+        assert Nb == N ** 3 and c["Nghost"] == N * N
+        assert np.array_equal(res.reshape(-1, 3)[:Nb], ro.reshape(-1, 3)[gi])
+        assert np.array_equal(j.reshape(-1, 9), jo.reshape(-1, 9)[c["halo"]["entry_global"]])
+        assert np.array_equal(conv[3:6], co[3:6])
+        np.testing.assert_allclose(conv[6:10], co[6:10], rtol=1e-12)
+        assert ok and red <= 1e-2
+        xd[gi] = x.reshape(-1, 3)[:Nb]
+        if reorder is None:
+            assert info["ilu_ordering"] == "line_coloring" and info["chain_length"] == 10
+    assert out[0][3] == out[1][3] and out[0][5] == out[1][5] and np.array_equal(out[0][2], out[1][2])   # the global scalars: the same bits on both ranks
+    rg = ro - orc.spmv(g["Nb"], g["rowptr"], g["col"], jo, xd.reshape(-1))
+    assert np.linalg.norm(rg) <= 1e-2 * np.linalg.norm(ro) * (1 + 1e-6)
+    if reorder == "level_scheduling":
+        xo, so = orc.solve(g["Nb"], g["rowptr"], g["col"], jo, ro, tol=1e-2, maxit=200, w=0.9, owner=owner)
+        assert so.converged and out[0][3] == so.it
+        np.testing.assert_allclose(xd.reshape(-1), xo, rtol=1e-7, atol=1e-11 * np.abs(xo).max())
