@@ -278,6 +278,7 @@ int orc_cpr_set_max_levels(orc_cpr* h, int n) { h->P.amg.maxLevels = n < 1 ? 1 :
 int orc_cpr_set_sweeps(orc_cpr* h, int nu) { if (nu < 0) { h->P.amg.joinAtStall = true; h->P.structured = false; return 0; } h->P.amg.nu = nu < 1 ? 1 : nu; return 0; }   // experiments: V(nu, nu)
 // smoother of the product's hierarchy: scalar ILU0 (relaxation 1) on levels < levels, eliminating in greedy multi-colour order on levels >= colour_from
 int orc_cpr_set_ilu_smoother(orc_cpr* h, int levels, int colour_from) { h->P.amg.iluLevels = levels < 0 ? 0 : levels; h->P.amg.iluColourFrom = colour_from < 0 ? (1 << 30) : colour_from; h->P.structured = false; return 0; }
+int orc_cpr_set_aggregation(orc_cpr* h, int kind) { h->P.amg.duneAgg = kind == 1; h->P.structured = false; return 0; }   // experiment: 1 = the reference's kind of aggregation in the product's hierarchy
 int orc_cpr_set_wcycle_from(orc_cpr* h, int l) { h->P.amg.wFrom = l < 0 ? (1 << 30) : l; return 0; }   // experiment
 int orc_cpr_use_reference_amg(orc_cpr* h, int on) { h->P.useDune = on != 0; h->P.dune.jacobi = on == 2;   /* 2: experiment - its aggregation with damped Jacobi smoothing */ h->P.structured = false; return 0; }
 // levels of that hierarchy

@@ -17,6 +17,7 @@ ap.add_argument("--size", type=int, default=100)
 ap.add_argument("--workers", type=int, default=8)
 ap.add_argument("--out", default="")
 ap.add_argument("--max-systems", type=int, default=0)
+ap.add_argument("--only", default="", help="comma-separated substrings: run only the variants whose name contains one of them")
 a = ap.parse_args()
 pkg = importlib.import_module("opm-autodiff_amd")
 n = a.size
@@ -24,10 +25,14 @@ case = pkg.decks.cartesian_case(n, n, n, state="mixed", heterogeneous=False)
 Nb, rp, ci = case["Nb"], case["rowptr"], case["col"]
 orc = oracle_bind.Oracle(os.path.join(ROOT, "oracle", "liboracle.so"))
 orc.lib.orc_cpr_set_ilu_smoother.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_int]
+orc.lib.orc_cpr_set_aggregation.argtypes = [ctypes.c_void_p, ctypes.c_int]
 idx = np.arange(Nb); I = idx % n; J = (idx // n) % n; K = idx // (n * n)
 
-# name -> (reference AMG?, ILU levels, colour from, line-coloured level 0?)
+# name -> (reference AMG? [3: the product's hierarchy with the reference's kind of AGGREGATION], ILU levels, colour from, line-coloured level 0?)
 VARIANTS = {
+    "product with aggregates of 4-6 (reference's kind), Jacobi": (3, 0, -1, False),
+    "product with aggregates of 4-6 + ILU0 level 0 (natural order)": (3, 1, -1, False),
+    "product with aggregates of 4-6 + ILU0 levels 0-1 (natural / multi-colour)": (3, 2, 1, False),
     "product: Jacobi V(1,1)": (False, 0, -1, False),
     "reference-like: aggregates 4-6, ILU0": (True, 0, -1, False),
     "product + ILU0 level 0 (natural order)": (False, 1, -1, False),
@@ -56,7 +61,8 @@ def one(job):
         rr, rc, rv = orc.reorder_matrix(Nb, rp, ci, jac, to, fr)
         b = res.reshape(Nb, 3)[fr].reshape(-1).copy()
         c.set_natural_ids(fr)
-    c.use_reference_amg(ref)
+    c.use_reference_amg(ref if ref != 3 else False)
+    orc.lib.orc_cpr_set_aggregation(c.h, 1 if ref == 3 else 0)
     orc.lib.orc_cpr_set_ilu_smoother(c.h, ilu, colfrom)
     t0 = time.time()
     x, r = c.solve(Nb, rr, rc, rv, b, tol=1e-2, maxit=200)
@@ -70,7 +76,8 @@ if __name__ == "__main__":
     tags = [s["tag"] for s in meta["systems"]]
     if a.max_systems:
         tags = tags[:a.max_systems]
-    jobs = [(name, tag) for name in VARIANTS for tag in tags]
+    names = [nm for nm in VARIANTS if not a.only or any(t in nm for t in a.only.split(","))]
+    jobs = [(name, tag) for name in names for tag in tags]
     table = {}
     with mp.Pool(a.workers) as pool:
         for name, tag, it, conv, sec in pool.imap_unordered(one, jobs):
