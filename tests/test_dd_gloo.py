@@ -172,7 +172,13 @@ def test_bench_two_ranks_control_plane_over_gloo(tmp_path):
     import json
     import subprocess
     import sys
-    port = 29800 + os.getpid() % 150
+    import socket
+
+    def free_port():
+        with socket.socket() as sk:
+            sk.bind(("127.0.0.1", 0))
+            return sk.getsockname()[1]
+    port = free_port()
     detail = str(tmp_path / "detail.json")
     env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1", "--master-port", str(port),
@@ -194,6 +200,6 @@ def test_bench_two_ranks_control_plane_over_gloo(tmp_path):
     assert full["rccl"]["rank_devices"] == [0, 1] and full["rccl"]["selftest_sum"] == full["rccl"]["selftest_expected"] == [3.0, 4.0]
     assert full["steady_state"]["steps"] == 4 and full["spmv_boundary_share_of_time"] == 0.2
     # a communicator that does not span the ranks that were asked for: every rank exits non-zero, no line
-    bad = subprocess.run(cmd[:8] + [str(port + 1), cmd[9]] + ["--gpus", "2", "--steps", "2", "--warmup", "1", "--cells-per-edge", "10", "--steady-after", "0"], capture_output=True, text=True, timeout=600,
+    bad = subprocess.run(cmd[:8] + [str(free_port()), cmd[9]] + ["--gpus", "2", "--steps", "2", "--warmup", "1", "--cells-per-edge", "10", "--steady-after", "0"], capture_output=True, text=True, timeout=600,
                          env=dict(env, OPMHIP_FAKE_NRANKS="1"), cwd=ROOT)
     assert bad.returncode != 0 and "RCCL communicator spans 1 rank" in (bad.stderr + bad.stdout)
