@@ -79,7 +79,8 @@ typedef enum opmhip_relax_mode {
 } opmhip_relax_mode;
 
 /* Solver configuration.  Defaults (opmhip_default_config) are Flow's: tol 1e-2, maxit 200, w 0.9
- * (linalg/FlowLinearSolverParameters.hpp:142-154).  ctor arguments of bda::BdaSolver (bda/BdaSolver.hpp:79). */
+ * (linalg/FlowLinearSolverParameters.hpp:142-154) - and, where Flow has no say because the choice is this library's (the ILU ordering of the
+ * accelerator path, the pressure AMG's smoother), the configuration bench.py measures.  ctor arguments of bda::BdaSolver (bda/BdaSolver.hpp:79). */
 typedef struct opmhip_config {
     int abi_version;       /* OPMHIP_ABI_VERSION */
     int device_id;         /* --bda-device-id */
@@ -88,7 +89,7 @@ typedef struct opmhip_config {
     double tolerance;      /* --linear-solver-reduction */
     double ilu_relaxation; /* --ilu-relaxation */
     int relax_mode;        /* opmhip_relax_mode */
-    int reorder;           /* opmhip_reorder */
+    int reorder;           /* opmhip_reorder (opmhip_default_config: OPMHIP_REORDER_AUTO since ABI 8; opmhip_get_ordering_info says what it became) */
     int zero_diag_fix;     /* 1: exact 0.0 on a diagonal block's diagonal -> 1e-15 (bda/BdaBridge.cpp:125-161) */
     int chain_length;      /* OPMHIP_REORDER_LINE_COLORING: rows per chain (0 = 8) */
     int spmv_pipe_wgs;     /* pipelined SpMV: resident workgroups it is sized for (0 = 2048, the MI355X default; < 0 = one
@@ -107,7 +108,7 @@ typedef struct opmhip_config {
     int cpr_amg_ilu_levels; /* the pressure AMG's smoother: this many of its finest levels smooth with a scalar ILU0, relaxation 1 - the
                             * reference's AMG smoother (linalg/PreconditionerFactory.hpp:126-151, setupPropertyTree.cpp:116-137) - the others
                             * with damped Jacobi.  Level 0 eliminates in the ordering of the block ILU0 (opmhip_reorder), the levels below
-                            * colour by colour of a greedy multi-colouring.  0 (default): Jacobi on every level.  < 0: the library's choice -
+                            * colour by colour of a greedy multi-colouring.  0: Jacobi on every level.  < 0 (opmhip_default_config's -1 since ABI 8): the library's choice -
                             * level 0 where the block ILU0's ordering has at most three colours (level 0's sweeps are one launch per colour),
                             * Jacobi otherwise.  (was reserved[0] until ABI 7) */
     int cpr_gather_rows;   /* decomposed runs (opmhip_comm_init_*): the pressure stage of the CPR spans the ranks, as the reference's does (Dune's
