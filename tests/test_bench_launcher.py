@@ -82,3 +82,17 @@ def test_comm_summary_and_the_line_with_eight_ranks(bench):
     line = bench.compact_line(out, "gpurun_out/bench_detail.json")
     assert len(json.dumps(line)) < bench.LINE_LIMIT and line["comm"]["halo"]["avg_ms_max"] == c["halo"]["avg_ms_max"] and line["rccl"] == {"nranks": 8, "kind": "rccl"}
     assert "cpu_baseline" not in line and line["n_gpus"] == 8 and line["steady_state"]["value"] == 400.0
+
+
+def test_the_line_stays_short_whatever_an_extra_window_says(bench):
+    """a long error text in an extra window must not cost the run its line: extras are dropped (and named), the contract's keys stay"""
+    import json
+    base = {"metric": "m", "value": 1.0, "unit": "u", "n_gpus": 1, "steps": 2, "warmup": 1, "ms_per_step": 1.0, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f64", "data": "synthetic", "config": {"workload": "w" * 300}, "roofline": {"bound": "hbm", "frac": 0.6}, "cpu_baseline": {"value": 1.0, "cores": 16, "kind": "port", "sample": "s" * 300, "cpu_model": "c"},
+            "device": "d" * 5000, "cpr": {"error": "e" * 120}, "kernel_GBps": {str(i): 1.0 for i in range(200)}}
+    txt = bench.fit_line(dict(base))
+    d = json.loads(txt)
+    assert len(txt) < bench.LINE_LIMIT and d["value"] == 1.0 and d["roofline"]["frac"] == 0.6 and d["cpu_baseline"]["cores"] == 16 and "workload" in d["config"]
+    assert "device" in d["dropped_for_length"] and "device" not in d
+    small = bench.fit_line({k: v for k, v in base.items() if k not in ("device", "kernel_GBps")})
+    assert "dropped_for_length" not in json.loads(small)
