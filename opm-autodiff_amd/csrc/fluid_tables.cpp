@@ -187,7 +187,10 @@ std::string build_fluid_tables(const opmhip_fluid* f, FluidTables& T) {
             satRs.push_back(nodes[i].rs);
             satIb.push_back(ib[i][0]);
             satIbm.push_back(ib[i][0] / mu[i][0]);
-            if (i > 0 && satP[i] <= satP[i - 1]) return "PVTO bubble-point pressures must ascend";
+            // equal bubble points of two nodes are let through, as the reference lets them (its own test deck
+            // tests/SUMMARY_DECK_NON_CONSTANT_POROSITY.DATA has Rs = 0 and Rs = 1 both saturated at 1 bar): RsSat(p) has a jump there,
+            // which only a state that sits exactly on it and asks for RsSat would see
+            if (i > 0 && satP[i] < satP[i - 1]) return "PVTO bubble-point pressures must not descend";
         }
         yo.push_back((int)ysFlat.size());
         D.o_nx = nn;

@@ -244,3 +244,68 @@ def hysteresis_case(pkg, nx, ny, nz, wetgas=False, **kw):
     case["satnum"] = np.zeros(case["Nb"], np.int32)
     case["imbnum"] = np.ones(case["Nb"], np.int32)
     return case
+
+
+# ---- the deck of the reference's tests/test_ecl_output.cc ----------------------------------------------------------------
+def summary_deck_case(pkg):
+    """tests/SUMMARY_DECK_NON_CONSTANT_POROSITY.DATA as a case (METRIC -> SI): 10 x 10 x 10 cells of 1 m^3, porosity 0.1 in the upper
+    five layers and 0.2 below, PVTO with one saturated node at Rs = 0 and an undersaturated branch at Rs = 1 (1 / B_o grows linearly from
+    0.1 at 1 bar to 1 at 10 bar), PVTW B_w = 1000 with no compressibility, PVDG, ROCK 3e-6 / bar at 14.7 bar, SWOF / SGOF of the deck;
+    state from its SOLUTION section: p = 1 ... 10 bar layer by layer, S_w = 0.2, S_g = 0, Rs = 0 (undersaturated oil everywhere).
+    FIPNUM: 400 cells region 1, 200 region 2, 400 region 3.  Returns (case, fipnum)."""
+    import numpy as np
+    bar, cP = 1e5, 1e-3
+    swof = [[0.12, 0, 1, 0], [0.18, 4.64876033057851e-8, 1, 0], [0.24, 0.000000186, 0.997, 0], [0.3, 4.18388429752066e-7, 0.98, 0],
+            [0.36, 7.43801652892562e-7, 0.7, 0], [0.42, 1.16219008264463e-6, 0.35, 0], [0.48, 1.67355371900826e-6, 0.2, 0],
+            [0.54, 2.27789256198347e-6, 0.09, 0], [0.6, 2.97520661157025e-6, 0.021, 0], [0.66, 3.7654958677686e-6, 0.01, 0],
+            [0.72, 4.64876033057851e-6, 0.001, 0], [0.78, 0.000005625, 0.0001, 0], [0.84, 6.69421487603306e-6, 0, 0],
+            [0.91, 8.05914256198347e-6, 0, 0], [1, 0.00001, 0, 0]]
+    sgof = [[0, 0, 1, 0], [0.001, 0, 1, 0], [0.02, 0, 0.997, 0], [0.05, 0.005, 0.980, 0], [0.12, 0.025, 0.700, 0], [0.2, 0.075, 0.350, 0],
+            [0.25, 0.125, 0.200, 0], [0.3, 0.190, 0.090, 0], [0.4, 0.410, 0.021, 0], [0.45, 0.60, 0.010, 0], [0.5, 0.72, 0.001, 0],
+            [0.6, 0.87, 0.0001, 0], [0.7, 0.94, 0.000, 0], [0.85, 0.98, 0.000, 0], [0.88, 0.984, 0.000, 0]]
+    pvt = [dict(pvtw=[1 * bar, 1000.0, 0.0, 0.318 * cP, 0.0], density=[53.66, 64.49, 0.0533],
+                pvdg=[[1 * bar, 100.0, 1 * cP], [10 * bar, 10.0, 1 * cP]],
+                pvto=[dict(rs=0.0, p=[1 * bar], bo=[10.0], mu=[1 * cP]), dict(rs=1.0, p=[1 * bar, 10 * bar], bo=[10.001, 1.0], mu=[1 * cP, 1 * cP])])]
+    fl = pkg.fluid.Fluid(pvt, [dict(swof=swof, sgof=sgof)], rock_pref=14.7 * bar, rock_cr=3e-6 / bar)
+    with np.errstate(divide="ignore", invalid="ignore"):   # (the generator's default state interpolates RsSat(p) between the deck's two nodes at 1 bar; replaced below)
+        case = pkg.decks.cartesian_case(10, 10, 10, dx=1.0, dy=1.0, dz=1.0, top=1.0, poro=0.1, perm_md=500.0, state="undersaturated", perturb=False, fluid=fl)
+    Nb = case["Nb"]
+    k = np.arange(Nb) // 100
+    case["poro"] = np.ascontiguousarray(np.where(k < 5, 0.1, 0.2))
+    pvars = np.zeros((Nb, 3))
+    pvars[:, 0] = 0.2                    # Sw
+    pvars[:, 1] = (k + 1.0) * bar        # p_o
+    pvars[:, 2] = 0.0                    # Rs
+    case["pv"] = np.ascontiguousarray(pvars.reshape(-1))
+    case["meaning"] = np.full(Nb, pkg.decks.SW_PO_RS, np.uint8)
+    fipnum = np.concatenate([np.full(400, 1), np.full(200, 2), np.full(400, 3)])
+    return case, fipnum
+
+
+def summary_deck_expectations():
+    """the numbers tests/test_ecl_output.cc:192-225 expects of that deck at the first report step (METRIC: bar, sm^3) with its tolerances
+    in per cent (BOOST_CHECK_CLOSE): field and region pressures weighted by hydrocarbon pore volume, fluids in place = sum b S pv"""
+    return {"FPR": (((3 * 0.1 + 8 * 0.2) * 500 * (1 - 0.2)) / ((500 * 0.1 + 500 * 0.2) * (1 - 0.2)), 1e-3),
+            "FOIP": ((0.3 * 0.1 + 0.8 * 0.2) * 500 * (1 - 0.2), 1e-1), "FGIP": (0.0, 1e-1), "FWIP": (1.0 / 1000 * (0.1 + 0.2) * 500 * 0.2, 1e-1),
+            "RPR:1": ((2.5 * 0.1 * 400 * (1 - 0.2)) / (400 * 0.1 * (1 - 0.2)), 1e-3), "ROIP:1": (0.25 * 0.1 * 400 * (1 - 0.2), 1e-1),
+            "RPR:2": (((5 * 0.1 * 100 + 6 * 0.2 * 100) * (1 - 0.2)) / ((100 * 0.1 + 100 * 0.2) * (1 - 0.2)), 1e-3),
+            "ROIP:2": ((0.5 * 0.1 * 100 + 0.6 * 0.2 * 100) * (1 - 0.2), 1e-1)}
+
+
+def summary_from_iq(iq, volume, fipnum):
+    """FPR / F?IP / RPR / ROIP from intensive-quantity records (fields 0-2 saturations, 3-5 phase pressures, 6-8 inverse formation volume
+    factors - water, oil, gas -, 15 Rs, 16 porosity incl. rock compressibility), as ebos/ecloutputblackoilmodule.hh forms them:
+    in place = sum b S pv; pressures weighted by the hydrocarbon pore volume pv (1 - Sw).  METRIC units out (bar)."""
+    import numpy as np
+    sw, so, sg = iq[:, 0, 0], iq[:, 1, 0], iq[:, 2, 0]
+    po = iq[:, 4, 0]
+    bw, bo, bg = iq[:, 6, 0], iq[:, 7, 0], iq[:, 8, 0]
+    pv = iq[:, 16, 0] * volume
+    hcpv = pv * (1.0 - sw)
+    out = {"FPR": float((po * hcpv).sum() / hcpv.sum()) / 1e5, "FOIP": float((bo * so * pv).sum()), "FWIP": float((bw * sw * pv).sum()),
+           "FGIP": float((bg * sg * pv).sum() + (iq[:, 15, 0] * bo * so * pv).sum())}
+    for r in (1, 2):
+        m = fipnum == r
+        out["RPR:%d" % r] = float((po[m] * hcpv[m]).sum() / hcpv[m].sum()) / 1e5
+        out["ROIP:%d" % r] = float((bo[m] * so[m] * pv[m]).sum())
+    return out
