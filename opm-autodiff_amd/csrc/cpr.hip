@@ -290,6 +290,7 @@ __global__ __launch_bounds__(256) void k_cpr_dense_lu(int n, int W, int rm, cons
             const int i = k + 1 + e / m, j = k + 1 + e % m;
             lu[(size_t)i * n + j] -= lu[(size_t)i * n + k] * lu[(size_t)k * n + j];
         }
+        if (threadIdx.x == 0) lu[(size_t)k * n + k] = piv;   // the diagonal keeps 1 / u_kk: the substitution multiplies (oracle/cpr.hpp: update_values)
         __syncthreads();
     }
 }
@@ -320,70 +321,97 @@ __global__ __launch_bounds__(1024) void k_cpr_dense_lu_lds(int n, int W, int rm,
             const double f = slu[i * n + k];
             for (int j = k + 1 + tx; j < n; j += 32) slu[i * n + j] -= f * slu[k * n + j];
         }
+        if (tid == 0) slu[k * n + k] = piv;   // the diagonal keeps 1 / u_kk (nobody reads it again in the factorisation)
         __syncthreads();
     }
     for (int e = tid; e < n * n; e += 1024) lu[e] = slu[e];
     if (tid == 0) lu[(size_t)n * n] = bad ? 1.0 : 0.0;   // flag behind the factors: 1 = a pivot vanished or is not finite (no pivoting here)
 }
-// x = U^-1 L^-1 b with the dense factors of the coarsest level (n <= CPR_COARSE_DIRECT), in LDS: s holds b on entry and x on return.
-// Both substitutions go COLUMN by column, as the oracle's do (oracle/cpr.hpp: vcycle; the same terms in the same order, the same bits):
-// forward (unit lower factor) x_j is final once the columns before it are applied, and the rows below take l_ij x_j off at once;
-// backward x_j = s_j / u_jj is final once the columns behind it are applied, and the rows above take u_ij x_j off at once - a row's
-// terms in the order j = n - 1 ... i + 1.  ONE wavefront (64 lanes, n <= 128: two rows per lane): its LDS accesses execute in program
-// order, so the 2 n steps need no workgroup barrier; the factors' next column is loaded while the present one is worked off.
-// Until round 5 the iterate lived in global memory and one thread walked both triangles row by row through dependent loads of what it
-// had just stored: 0.7 ms per application on a 100-row level; rows in the row-oriented order still cost 0.13 ms (a chain of n^2 / 2
-// dependent subtractions), which is why the order changed on both sides (profiles/r05_config_rates.txt, r05_cpr_tail_ab.txt).
-__device__ __forceinline__ void cpr_dense_substitute(int n, const double* __restrict__ lu, double* s) {
-    const int lane = threadIdx.x;
-    const int i0 = lane, i1 = lane + 64;
-    auto at = [&](int i, int j) { return (i < n && j >= 0 && j < n) ? lu[(size_t)i * n + j] : 0.0; };
-    __builtin_amdgcn_wave_barrier();
-    {
-        double c0 = at(i0, 0), c1 = at(i1, 0);
-        for (int j = 0; j + 1 < n; ++j) {
-            const double l0 = c0, l1 = c1;
-            c0 = at(i0, j + 1); c1 = at(i1, j + 1);
-            const double xj = s[j];
-            if (i0 > j && i0 < n) s[i0] -= l0 * xj;
-            if (i1 > j && i1 < n) s[i1] -= l1 * xj;
-            __builtin_amdgcn_wave_barrier();
-        }
-    }
-    {
-        double c0 = at(i0, n - 1), c1 = at(i1, n - 1);
-        for (int j = n - 1; j >= 0; --j) {
-            const double u0 = c0, u1 = c1;
-            c0 = at(i0, j - 1); c1 = at(i1, j - 1);
-            if (i0 == j) s[j] = s[j] / u0;            // the lane that holds row j holds u_jj
-            if (i1 == j) s[j] = s[j] / u1;
-            __builtin_amdgcn_wave_barrier();
-            const double xj = s[j];
-            if (i0 < j) s[i0] -= u0 * xj;
-            if (i1 < j) s[i1] -= u1 * xj;
-            __builtin_amdgcn_wave_barrier();
-        }
-    }
+// x = U^-1 L^-1 b with the dense factors of the coarsest level (n <= CPR_COARSE_DIRECT).  Both substitutions go COLUMN by column, as the
+// oracle's do (oracle/cpr.hpp: vcycle; the same terms in the same order, the same bits): forward (unit lower factor) x_j is final once the
+// columns before it are applied, and the rows below take l_ij x_j off at once; backward x_j = s_j * (1 / u_jj) - the factorisation leaves the reciprocal on the diagonal - is final once the columns behind
+// it are applied, and the rows above take u_ij x_j off at once - a row's terms in the order j = n - 1 ... i + 1.  ONE wavefront, two rows per
+// lane IN REGISTERS: the 2 n steps are chained only through "x_j of its owner lane -> everybody" (v_readlane with a uniform lane: a few
+// cycles, where a round trip through LDS is a hundred) and one multiply-subtract; the factors are staged into LDS once (rows padded to an
+// odd length: the lanes' column reads then spread over the banks) and a step's two entries are read four steps ahead.
+// History: until round 5 the iterate lived in global memory and one thread walked both triangles row by row through dependent loads of
+// what it had just stored - 0.7 ms per application on a 100-row level; row-oriented in LDS 0.13 ms (a chain of n^2 / 2 subtractions:
+// why the backward ORDER changed, on both sides); column-oriented through LDS 0.06 ms (2 n LDS round trips).
+// (profiles/r05_config_rates.txt, r05_cpr_tail_ab.txt).
+__device__ __forceinline__ double cpr_bcast_lane(double v, int src) {   // src: the same for all lanes
+    const int lo = __builtin_amdgcn_readlane(__double2loint(v), src), hi = __builtin_amdgcn_readlane(__double2hiint(v), src);
+    return __hiloint2double(hi, lo);
 }
+constexpr int CPR_DENSE_AHEAD = 4;
 // mem4f != NULL: b[i] = sum of the finer level's residual over aggregate i (k_cpr_restrict's statement), formed here
-__global__ __launch_bounds__(64) void k_cpr_dense_solve(int n, const double* __restrict__ lu, const double* __restrict__ b, double* __restrict__ x,
+constexpr int CPR_DENSE_THREADS = 512;   // all of them stage the factors; the first wavefront substitutes
+__global__ __launch_bounds__(CPR_DENSE_THREADS) void k_cpr_dense_solve(int n, const double* __restrict__ lu, const double* __restrict__ b, double* __restrict__ x,
                                                         const int* __restrict__ mem4f, const double* __restrict__ rf, const double* __restrict__ done) {
     CPR_DONE_CHECK
-    __shared__ double sb[CPR_COARSE_DIRECT];
-    for (int i = threadIdx.x; i < n; i += 64) {
-        double s;
-        if (mem4f) {
-            const int* m = &mem4f[4 * i];
-            s = 0.0;
-            s += rf[m[0]];
-            if (m[1] >= 0) s += rf[m[1]];
-            if (m[2] >= 0) s += rf[m[2]];
-            if (m[3] >= 0) s += rf[m[3]];
-        } else s = b[i];
-        sb[i] = s;
+    extern __shared__ double slu[];   // n rows of np doubles
+    const int lane = threadIdx.x, np = n | 1;
+    {   // thread t: column t mod 128 of the rows t / 128, t / 128 + 4, ... - eight loads in flight per thread, no division
+        const int j = lane & 127;
+#pragma unroll 8
+        for (int i = lane >> 7; i < n; i += CPR_DENSE_THREADS / 128)
+            if (j < n) slu[i * np + j] = lu[(size_t)i * n + j];
     }
-    cpr_dense_substitute(n, lu, sb);
-    for (int i = threadIdx.x; i < n; i += 64) x[i] = sb[i];
+    __syncthreads();
+    if (lane >= 64) return;
+    const int i0 = lane, i1 = lane + 64;
+    auto rhs = [&](int i) {
+        if (i >= n) return 0.0;
+        if (!mem4f) return b[i];
+        const int* m = &mem4f[4 * i];
+        double s = 0.0;
+        s += rf[m[0]];
+        if (m[1] >= 0) s += rf[m[1]];
+        if (m[2] >= 0) s += rf[m[2]];
+        if (m[3] >= 0) s += rf[m[3]];
+        return s;
+    };
+    double s0 = rhs(i0), s1 = rhs(i1);
+    auto at = [&](int i, int j) { return (i < n && j >= 0 && j < n) ? slu[i * np + j] : 0.0; };
+    {   // forward
+        double a0[CPR_DENSE_AHEAD], a1[CPR_DENSE_AHEAD];
+#pragma unroll
+        for (int u = 0; u < CPR_DENSE_AHEAD; ++u) { a0[u] = at(i0, u); a1[u] = at(i1, u); }
+        for (int jb = 0; jb + 1 < n; jb += CPR_DENSE_AHEAD) {
+            double c0[CPR_DENSE_AHEAD], c1[CPR_DENSE_AHEAD];
+#pragma unroll
+            for (int u = 0; u < CPR_DENSE_AHEAD; ++u) { c0[u] = a0[u]; c1[u] = a1[u]; a0[u] = at(i0, jb + CPR_DENSE_AHEAD + u); a1[u] = at(i1, jb + CPR_DENSE_AHEAD + u); }
+#pragma unroll
+            for (int u = 0; u < CPR_DENSE_AHEAD; ++u) {
+                const int j = jb + u;
+                if (j + 1 >= n) break;
+                const double xj = cpr_bcast_lane(j < 64 ? s0 : s1, j & 63);
+                s0 -= (i0 > j ? c0[u] : 0.0) * xj;     // rows at or above the column take 0 * x_j = 0 off: their bits stay (at() gave 0 for rows >= n)
+                s1 -= (i1 > j ? c1[u] : 0.0) * xj;
+            }
+        }
+    }
+    {   // backward
+        double a0[CPR_DENSE_AHEAD], a1[CPR_DENSE_AHEAD];
+#pragma unroll
+        for (int u = 0; u < CPR_DENSE_AHEAD; ++u) { a0[u] = at(i0, n - 1 - u); a1[u] = at(i1, n - 1 - u); }
+        for (int jb = n - 1; jb >= 0; jb -= CPR_DENSE_AHEAD) {
+            double c0[CPR_DENSE_AHEAD], c1[CPR_DENSE_AHEAD];
+#pragma unroll
+            for (int u = 0; u < CPR_DENSE_AHEAD; ++u) { c0[u] = a0[u]; c1[u] = a1[u]; a0[u] = at(i0, jb - CPR_DENSE_AHEAD - u); a1[u] = at(i1, jb - CPR_DENSE_AHEAD - u); }
+#pragma unroll
+            for (int u = 0; u < CPR_DENSE_AHEAD; ++u) {
+                const int j = jb - u;
+                if (j < 0) break;
+                s0 = s0 * (i0 == j ? c0[u] : 1.0);     // the lane that holds row j holds the diagonal entry 1 / u_jj; s * 1 = s for the others
+                s1 = s1 * (i1 == j ? c1[u] : 1.0);
+                const double xj = cpr_bcast_lane(j < 64 ? s0 : s1, j & 63);
+                s0 -= (i0 < j ? c0[u] : 0.0) * xj;
+                s1 -= (i1 < j ? c1[u] : 0.0) * xj;
+            }
+        }
+    }
+    if (i0 < n) x[i0] = s0;
+    if (i1 < n) x[i1] = s1;
 }
 // r_p[i] = sum_k d_i[k] w_i[k]  (moveToCoarseLevel, :141-160); x0 != NULL: the level's pre-smoothing from x = 0 rides along,
 // x0[i] = omega D^-1 r_p[i] - the statement of k_cpr_presmooth, one launch less
@@ -444,6 +472,7 @@ __global__ __launch_bounds__(256) void k_cpr_resid(int n, int W, const int* __re
 // lane fetches its entries and forms its products at once, then the group subtracts the products one after the other in
 // the row's order - the same roundings as the one-thread loop (padding entries are 0 * x there too).
 constexpr int CPR_LPR = 16, CPR_LPR_SLOTS = CPR_MAX_W / CPR_LPR, CPR_LPR_ROWS = 32768;
+static_assert(CPR_COARSE_DIRECT <= 128, "k_cpr_dense_solve: two rows per lane of one wavefront, 128 columns per staging pass");
 static_assert(CPR_MAX_W % CPR_LPR == 0 && 256 % CPR_LPR == 0, "lane groups tile a row and a workgroup");
 __device__ __forceinline__ double cpr_group_subtract(double s, const double (&p)[CPR_LPR_SLOTS], int W) {
 #pragma unroll
@@ -1488,6 +1517,12 @@ static int cpr_upload_coarse(opmhip_ctx* c, CprDev& R, const CprHostCoarse& H, b
         if ((rc = transfer(h, R.lv.back()))) return rc;
     }
     R.coarse_direct = !gathered && R.lv.back().n <= CPR_COARSE_DIRECT;
+    if (R.coarse_direct) {   // the direct solve keeps the factors in LDS: n x (n | 1) doubles of dynamic shared memory, more than the 64 KB a kernel gets unasked
+        static const bool ldsOk = hipFuncSetAttribute(reinterpret_cast<const void*>(k_cpr_dense_solve), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                                      CPR_COARSE_DIRECT * (CPR_COARSE_DIRECT | 1) * (int)sizeof(double)) == hipSuccess;
+        if (!ldsOk && (size_t)R.lv.back().n * (R.lv.back().n | 1) * sizeof(double) > 65536)
+            return fail(c, OPMHIP_DEVICE_ERROR, "cpr: the device refuses %d KB of dynamic shared memory for the coarsest level's direct solve", CPR_COARSE_DIRECT * (CPR_COARSE_DIRECT | 1) / 128);
+    }
     if (R.coarse_direct && (rc = dev_alloc(c, &R.d_lu, (size_t)R.lv.back().n * R.lv.back().n + 1))) return rc;   // + 1: the pivot flag
     R.structured = true;
     return OPMHIP_SUCCESS;
@@ -1965,7 +2000,8 @@ static const double* cpr_vcycle(opmhip_ctx* c, CprDev& R, size_t l, double* fine
     const double* rf = fused ? R.lv[l - 1].d_r : nullptr;
     if (l + 1 == R.lv.size()) {
         if (R.coarse_direct) {
-            hipLaunchKernelGGL(k_cpr_dense_solve, dim3(1), dim3(64), 0, c->stream, L.n, R.d_lu, L.d_b, L.d_x, (const int*)mem4f, rf, done);
+            // (n rows of n | 1 doubles of dynamic shared memory: 129 KB at n = 128 - gfx950's 160 KB hold it; cpr_upload_coarse checked the attribute)
+            hipLaunchKernelGGL(k_cpr_dense_solve, dim3(1), dim3(CPR_DENSE_THREADS), (size_t)L.n * (L.n | 1) * sizeof(double), c->stream, L.n, R.d_lu, L.d_b, L.d_x, (const int*)mem4f, rf, done);
             return L.d_x;
         }
         // could not coarsen further: Jacobi sweeps stand in for the coarse solve (oracle/cpr.hpp: 1 + 4)

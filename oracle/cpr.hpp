@@ -260,6 +260,7 @@ struct CprAmg {
                     lu[(size_t)i * n + k] = f;
                     for (int j = k + 1; j < n; ++j) lu[(size_t)i * n + j] -= f * lu[(size_t)k * n + j];
                 }
+                lu[(size_t)k * n + k] = piv;   // the diagonal keeps 1 / u_kk (as the block ILU0 keeps D^-1): the substitution multiplies
             }
         }
     }
@@ -398,7 +399,7 @@ struct CprAmg {
                 // rows one after the other, 0.13 ms per application on a 100-row level; this order lets the rows above a column work at once.
                 // Both are backward substitutions of the same factors; the AMG is this design's own, no reference number pins the order.)
                 for (int j = n - 1; j >= 0; --j) {
-                    x[j] = x[j] / lu[(size_t)j * n + j];
+                    x[j] = x[j] * lu[(size_t)j * n + j];   // (the diagonal holds 1 / u_jj)
                     for (int i = 0; i < j; ++i) x[i] -= lu[(size_t)i * n + j] * x[j];
                 }
             } else {   // could not coarsen further: a few Jacobi sweeps stand in for the coarse solve
