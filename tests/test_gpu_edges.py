@@ -77,3 +77,25 @@ def test_tiny_grids_with_cpr(pkg, orc, shape, prec):
     d = np.random.default_rng(3).standard_normal(3 * case["Nb"])
     vo = cpr.apply(np.ascontiguousarray(d.reshape(-1, 3)[fr].reshape(-1))).reshape(-1, 3)[to].reshape(-1)
     assert np.array_equal(m.cpr_apply(d), vo)
+
+
+def test_call_order_and_refusals_of_round_5_entry_points(pkg):
+    """opmhip_get_ordering_info before a pattern is set is a call-order violation (OPMHIP_NOT_READY), not garbage; a decomposed context
+    refuses multisegment wells through the host callback (OPMHIP_INVALID_ARGUMENT, so that Flow falls back to Dune,
+    ISTLSolverEbos.hpp:277-297) instead of applying a rank-local operator silently; a level-scheduled context reports its levels as colours"""
+    import uuid
+    s = pkg.capi.HipSolver()
+    with pytest.raises(pkg.capi.OpmHipError) as e:
+        s.ordering_info()
+    assert e.value.code == pkg.capi.NOT_READY
+    case = pkg.ras.cartesian_subdomain_case(6, 2, 0, state="mixed", heterogeneous=False)
+    m = pkg.capi.HipModel(case, comm=("loopback", 2, 0, "edge" + uuid.uuid4().hex), reorder="level_scheduling")
+    info = m.ordering_info()
+    assert info["ilu_ordering"] == "level_scheduling" and info["chain_length"] == 0 and info["colors"] == len(m.ordering()[2]) and info["cpr_amg_ilu_levels"] == 0
+    m.set_state(case["pv"], case["meaning"])
+    m.set_source(case["source"])
+    m.assemble(86400.0, 0, fetch=False)
+    wells = dict(numWells=0, numMsWells=1, ms_apply=lambda x, y: None, N=3 * case["Nb"])
+    with pytest.raises(pkg.capi.OpmHipError) as e:
+        m.solve_jacobian_system(wells=wells)     # refused while the wells are taken over: before any collective of the solve
+    assert e.value.code == pkg.capi.INVALID_ARGUMENT and "decomposed" in str(e.value)
