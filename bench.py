@@ -35,6 +35,7 @@ import time
 
 os.environ.setdefault("OMP_NUM_THREADS", "1")      # the CPU baseline sets its own thread count (orc_set_threads)
 os.environ.setdefault("OMP_WAIT_POLICY", "passive")  # idle OpenMP threads sleep: the box's CPU share may be a quota
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # RCCL between processes: the host driver supports dmabuf IPC only (exported on the boxes already; kept for an environment that lost it)
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
