@@ -20,7 +20,8 @@
 extern "C" {
 #endif
 
-#define OPMHIP_ABI_VERSION 8 /* 8: opmhip_default_config: reorder = OPMHIP_REORDER_AUTO, cpr_amg_ilu_levels = -1 (the measured configuration);
+#define OPMHIP_ABI_VERSION 9 /* 9: opmhip_wells gained `distributed` (standard wells whose perforations lie in several subdomains of a decomposed run);
+                               * 8: opmhip_default_config: reorder = OPMHIP_REORDER_AUTO, cpr_amg_ilu_levels = -1 (the measured configuration);
                                *    opmhip_get_ordering_info, opmhip_wells gained the multisegment-well leg (num_ms_wells, ms_apply);
                                * 7: opmhip_config names cpr_amg_ilu_levels, cpr_gather_rows (were reserved[0..1]);
                                * 6: opmhip_set_hysteresis, opmhip_get_hysteresis, opmhip_set_hysteresis_params (additive); opmhip_config names
@@ -153,7 +154,19 @@ typedef struct opmhip_result {
  * library brings x and y (N doubles each, NATURAL order - the caller's objects know nothing of the ILU ordering, so there is no
  * setReordering to do) to pinned host memory after every product, calls ms_apply(ms_user, h_x, h_y) - which performs
  * y -= C^T (D^-1 (B x)) for every multisegment well, e.g. by looping MultisegmentWellContribution::apply(h_x, h_y) - and takes
- * h_y back.  num_wells counts the STANDARD wells only.  The callback runs on the calling thread, inside opmhip_solve_system. */
+ * h_y back.  num_wells counts the STANDARD wells only.  The callback runs on the calling thread, inside opmhip_solve_system.
+ *
+ * Decomposed runs (ABI 9).  Cell indices are the rank's local ones and must be OWNED cells (< Nb).  By default Flow's partitioner keeps
+ * every well inside one subdomain (--allow-distributed-wells=false, ebos/eclbasevanguard.hh:148-151): distributed = 0, each rank hands
+ * over its own wells, nothing is exchanged.  With distributed wells the reference sums B x over the ranks that share the well
+ * (wellhelpers::ParallelStandardWellB::mv, wells/WellHelpers.hpp:68-123, called from StandardWell::apply, wells/StandardWell_impl.hpp:
+ * 1254-1280) and has D and the well residual summed at assembly (sumDistributedWellEntries, StandardWell_impl.hpp:260-261), so that D^-1
+ * and C^T are applied rank by rank without further exchange.  The same here with distributed = 1: EVERY rank hands over the SAME list
+ * of wells in the same order - its own perforations of each (none: val_pointers[w] == val_pointers[w + 1]) and the complete D^-1 - and
+ * the num_wells x 4 partial products travel through one all-reduce per operator application (all ranks, not a sub-communicator per
+ * well: ranks without perforations add zeros).  Every call that takes such a list is then COLLECTIVE (all ranks, same order); a
+ * different num_wells on some rank is reported on every rank (INVALID_ARGUMENT) instead of hanging in the reduction.
+ * opmhip_wells_recover_solution forms resWell - sum_ranks(B x) as the reference's mmv does for a shared well (WellHelpers.hpp:126-142). */
 typedef void (*opmhip_ms_apply_fn)(void* user, const double* h_x, double* h_y);
 typedef struct opmhip_wells {
     int num_wells;           /* standard wells (num_std_wells of the reference, NOT getNumWells()) */
@@ -166,6 +179,8 @@ typedef struct opmhip_wells {
     int num_ms_wells;        /* multisegment wells behind ms_apply (0: none) */
     opmhip_ms_apply_fn ms_apply; /* must be non-NULL when num_ms_wells > 0 */
     void* ms_user;           /* handed back to ms_apply */
+    int distributed;         /* decomposed runs only (ignored on one rank); see above.  0: every well of the list lies inside this rank's
+                              * subdomain; 1: the same list of wells on every rank, each rank with the perforations in ITS cells */
 } opmhip_wells;
 
 /* ---- lifetime ------------------------------------------------------------------------------------------ */

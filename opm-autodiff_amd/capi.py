@@ -69,7 +69,7 @@ MS_APPLY_FN = C.CFUNCTYPE(None, C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c
 class Wells(C.Structure):
     _fields_ = [("num_wells", C.c_int), ("val_pointers", C.c_void_p), ("Ccols", C.c_void_p),
                 ("Bcols", C.c_void_p), ("Cnnzs", C.c_void_p), ("Dnnzs", C.c_void_p), ("Bnnzs", C.c_void_p),
-                ("num_ms_wells", C.c_int), ("ms_apply", MS_APPLY_FN), ("ms_user", C.c_void_p)]
+                ("num_ms_wells", C.c_int), ("ms_apply", MS_APPLY_FN), ("ms_user", C.c_void_p), ("distributed", C.c_int)]
 
 
 def declared_symbols():
@@ -140,7 +140,7 @@ def _i32(a):
 
 
 def make_wells(w):
-    """dict(numWells, val_pointers, Ccols, Bcols, Cnnzs, Dnnzs, Bnnzs[, numMsWells, ms_apply]) -> (Wells struct, keep-alive list).
+    """dict(numWells, val_pointers, Ccols, Bcols, Cnnzs, Dnnzs, Bnnzs[, numMsWells, ms_apply][, distributed]) -> (Wells struct, keep-alive list).
     numWells counts the standard wells; ms_apply(x, y) - numpy views of the pinned host vectors, natural order - performs
     y -= C^T (D^-1 (B x)) for the numMsWells multisegment wells in place (opmhip_wells.ms_apply)."""
     if not w:
@@ -160,6 +160,7 @@ def make_wells(w):
         cb = MS_APPLY_FN(tramp)
         keep.append(cb)
         s.num_ms_wells, s.ms_apply = nms, cb
+    s.distributed = int(w.get("distributed", 0))   # decomposed runs: the same list on every rank, each with its own perforations (opmhip_wells.distributed)
     return s, keep
 
 

@@ -63,8 +63,25 @@ int upload_wells(opmhip_ctx* c, const opmhip_wells* w) {
     W.num_ms = 0;
     W.ms_apply = nullptr;
     W.ms_user = nullptr;
+    W.distributed = false;
     if (!w) return OPMHIP_SUCCESS;
     if (w->num_ms_wells < 0 || w->num_wells < 0) return fail(c, OPMHIP_INVALID_ARGUMENT, "wells: negative well count");
+    const bool shared = w->distributed != 0 && c->comm.nranks > 1;
+    if (shared) {
+        // the list must be the same on every rank: the products travel through one all-reduce of num_wells x 4 doubles, and ranks that
+        // disagree about its length would wait for each other for ever.  max(n) and max(-n) in one reduction: every rank sees both.
+        if (!c->d_scal) return fail(c, OPMHIP_NOT_READY, "wells: distributed wells before the pattern is set");
+        double h[2] = {(double)w->num_wells, -(double)w->num_wells};
+        double* d = c->d_scal + SC_TMP1;   // SC_TMP1, SC_TMP2: scratch between solves
+        OPMHIP_HIP(c, hipMemcpyAsync(d, h, sizeof h, hipMemcpyHostToDevice, c->stream));
+        int rca = comm_allreduce(c, d, 2, 1);
+        if (rca) return rca;
+        OPMHIP_HIP(c, hipMemcpyAsync(h, d, sizeof h, hipMemcpyDeviceToHost, c->stream));
+        OPMHIP_HIP(c, hipStreamSynchronize(c->stream));
+        if (h[0] != -h[1])
+            return fail(c, OPMHIP_INVALID_ARGUMENT, "wells: distributed = 1 but the ranks hold lists of %d to %d wells (this rank: %d) - every rank must hand over the same wells in the same order",
+                        (int)-h[1], (int)h[0], w->num_wells);
+    }
     if (w->num_ms_wells > 0) {
         // multisegment wells stay with the caller (their D^-1 is a sparse LU on the host, bda/MultisegmentWellContribution.cpp:35-62):
         // what the library needs is the callback and two pinned vectors for the round trip (bda/WellContributions.cu:160-187)
@@ -78,10 +95,11 @@ int upload_wells(opmhip_ctx* c, const opmhip_wells* w) {
         W.ms_user = w->ms_user;
     }
     if (w->num_wells <= 0) return OPMHIP_SUCCESS;
-    if (!w->val_pointers || !w->Ccols || !w->Bcols || !w->Cnnzs || !w->Dnnzs || !w->Bnnzs)
-        return fail(c, OPMHIP_INVALID_ARGUMENT, "wells: null array");
+    if (!w->val_pointers || !w->Dnnzs) return fail(c, OPMHIP_INVALID_ARGUMENT, "wells: null array");
     const int nw = w->num_wells, np = w->val_pointers[nw];
     if (np < 0) return fail(c, OPMHIP_INVALID_ARGUMENT, "wells: bad val_pointers");
+    // (a rank of a decomposed run may hold none of the perforations of the wells it shares with others: np == 0, no arrays to look at)
+    if (np > 0 && (!w->Ccols || !w->Bcols || !w->Cnnzs || !w->Bnnzs)) return fail(c, OPMHIP_INVALID_ARGUMENT, "wells: null array");
     // cell indices arrive in natural order; the device works in the internal order
     std::vector<int> cc(np), bc(np);
     for (int p = 0; p < np; ++p) {
@@ -97,11 +115,12 @@ int upload_wells(opmhip_ctx* c, const opmhip_wells* w) {
     OPMHIP_HIP(c, hipStreamSynchronize(c->stream));
     if ((size_t)nw > W.cap_wells) {
         const size_t cap = std::max((size_t)nw, 2 * W.cap_wells);
-        dev_free(c, &W.d_val_pointers); dev_free(c, &W.d_D); dev_free(c, &W.d_res); dev_free(c, &W.d_xw);
+        dev_free(c, &W.d_val_pointers); dev_free(c, &W.d_D); dev_free(c, &W.d_res); dev_free(c, &W.d_xw); dev_free(c, &W.d_bx);
         if ((rc = dev_alloc(c, &W.d_val_pointers, cap + 1))) return rc;
         if ((rc = dev_alloc(c, &W.d_D, cap * 16))) return rc;
         if ((rc = dev_alloc(c, &W.d_res, cap * 4))) return rc;
         if ((rc = dev_alloc(c, &W.d_xw, cap * 4))) return rc;
+        if ((rc = dev_alloc(c, &W.d_bx, cap * 4))) return rc;
         W.cap_wells = cap;
     }
     if ((size_t)np > W.cap_perf) {
@@ -123,6 +142,7 @@ int upload_wells(opmhip_ctx* c, const opmhip_wells* w) {
     }
     W.num_wells = nw;
     W.nperf = np;
+    W.distributed = shared;
     return OPMHIP_SUCCESS;
 }
 
@@ -443,7 +463,7 @@ int opmhip_wells_recover_solution(opmhip_ctx* c, const opmhip_wells* wells, cons
         int rc;
         if ((rc = upload_wells(c, wells))) return rc;
         OPMHIP_HIP(c, hipMemcpyAsync(c->wells.d_res, res_well, (size_t)wells->num_wells * 4 * sizeof(double), hipMemcpyHostToDevice, c->stream));
-        launch_wells_recover(c, c->wells.d_res, c->d_x, c->wells.d_xw);
+        if ((rc = launch_wells_recover(c, c->wells.d_res, c->d_x, c->wells.d_xw))) return rc;
         OPMHIP_HIP(c, hipMemcpyAsync(xw, c->wells.d_xw, (size_t)wells->num_wells * 4 * sizeof(double), hipMemcpyDeviceToHost, c->stream));
         OPMHIP_HIP(c, hipGetLastError());
         OPMHIP_HIP(c, hipStreamSynchronize(c->stream));

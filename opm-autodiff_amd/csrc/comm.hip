@@ -61,7 +61,7 @@ struct LoopGroup {
     int nranks = 0, joined = 0;
     pthread_barrier_t barrier;
     std::vector<opmhip_ctx*> members;
-    std::vector<std::vector<double>> scratch;  // [rank][<=16]
+    std::vector<std::vector<double>> scratch;  // [rank][n of the largest all-reduce so far, >= 16]
 };
 static std::map<std::string, LoopGroup*> g_groups;
 static std::mutex g_groups_mutex;
@@ -83,7 +83,8 @@ __global__ void k_pack_u8(int n, const int* __restrict__ idx, const unsigned cha
         if (r_ != ncclSuccess) return fail(c, OPMHIP_DEVICE_ERROR, "%s failed: %s", #call, g_rccl.GetErrorString(r_)); \
     } while (0)
 
-// sum (op 0) / max (op 1) of n <= 16 doubles over all ranks, in place, result identical on every rank
+// sum (op 0) / max (op 1) of n doubles over all ranks, in place, result identical on every rank (n: a handful of scalars; num_wells x 4
+// for wells shared between subdomains)
 static int allreduce_body(opmhip_ctx* c, double* d_buf, int n, int op);
 int comm_allreduce(opmhip_ctx* c, double* d_buf, int n, int op) {
     if (c->comm.nranks <= 1) return OPMHIP_SUCCESS;
@@ -101,13 +102,16 @@ static int allreduce_body(opmhip_ctx* c, double* d_buf, int n, int op) {
     // loopback: an error on this rank's stream must not strand the peers inside a barrier - remember it, keep the
     // barrier protocol, report it afterwards
     LoopGroup* G = (LoopGroup*)C.group;
+    if (G->scratch[C.rank].size() < (size_t)n) G->scratch[C.rank].resize(n);   // this rank's own slot; the peers read it between the two barriers only
     int rc = [&]() -> int {
         OPMHIP_HIP(c, hipMemcpyAsync(G->scratch[C.rank].data(), d_buf, n * sizeof(double), hipMemcpyDeviceToHost, c->stream));
         OPMHIP_HIP(c, hipStreamSynchronize(c->stream));
         return OPMHIP_SUCCESS;
     }();
     pthread_barrier_wait(&G->barrier);
-    double acc[16];
+    double few[16];
+    std::vector<double> many(n > 16 ? n : 0);
+    double* acc = n > 16 ? many.data() : few;
     for (int i = 0; i < n; ++i) {
         double a = G->scratch[0][i];
         for (int r = 1; r < C.nranks; ++r) a = (op == 0) ? a + G->scratch[r][i] : (a > G->scratch[r][i] ? a : G->scratch[r][i]);

@@ -116,6 +116,10 @@ struct WellsDev {
     int *d_val_pointers = nullptr, *d_Ccols = nullptr, *d_Bcols = nullptr;
     double *d_C = nullptr, *d_D = nullptr, *d_B = nullptr;
     double *d_res = nullptr, *d_xw = nullptr;   // 4 doubles per well each (residual in, well solution out)
+    // decomposed runs, wells whose perforations lie in several subdomains (opmhip_wells.distributed): every rank holds the list, B x is
+    // summed over the ranks (wells/WellHelpers.hpp:68-123)
+    bool distributed = false;
+    double* d_bx = nullptr;   // 4 doubles per well: this rank's part of B x, then the sum
     size_t cap_wells = 0, cap_perf = 0;
     // multisegment wells: applied on the host between the product and the standard wells (opmhip_wells.ms_apply)
     int num_ms = 0;
@@ -525,7 +529,7 @@ void launch_zero_diag_fix(opmhip_ctx* c);
 int launch_spmv(opmhip_ctx* c, double* x, double* y, int ndot, const double* w0, double xs = 1.0, bool exchange = false);
 void launch_wells_residual(opmhip_ctx* c, const double* d_resWell, double* r);
 void launch_wells_add_to_matrix(opmhip_ctx* c, int w0, int nw, int serial, const int* d_pair_ptr, const int* d_entry);
-void launch_wells_recover(opmhip_ctx* c, const double* d_resWell, const double* x, double* d_xw);
+int launch_wells_recover(opmhip_ctx* c, const double* d_resWell, const double* x, double* d_xw);   // distributed wells: one all-reduce inside
 void launch_ilu_factor(opmhip_ctx* c, bool fix_zero_diagonal = false, const FactorRider* rider = nullptr);
 int cpr_factor_rider(opmhip_ctx* c, FactorRider* r);   // cpr.hip: level 0 in place, this solve's weights where they do not come from the matrix; r->mode = 0: no rider this time
 void launch_ilu_apply(opmhip_ctx* c, const double* d, double* v, double w_override = -1.0, double* unscaled = nullptr, const double* addp = nullptr, double* work = nullptr);
@@ -540,7 +544,7 @@ void cpr_shutdown(opmhip_ctx* c);   // joins a structure build in flight (before
 bool cpr_coarse_pivot_failed(opmhip_ctx* c);
 int cpr_ilu_levels_in_force(const opmhip_ctx* c);   // opmhip_config.cpr_amg_ilu_levels with "< 0: the library's choice" resolved (0 without CPR)
 inline bool use_cpr(const opmhip_ctx* c) { return c->cfg.preconditioner == OPMHIP_PRECOND_CPR_QUASIIMPES || c->cfg.preconditioner == OPMHIP_PRECOND_CPR_TRUEIMPES; }
-void launch_wells_apply(opmhip_ctx* c, const double* x, double* y, double xs = 1.0);
+int launch_wells_apply(opmhip_ctx* c, const double* x, double* y, double xs = 1.0);   // distributed wells: one all-reduce inside
 void launch_lu_to_natural(opmhip_ctx* c, double* d_out_internal_layout);
 int bicgstab(opmhip_ctx* c, opmhip_result* res);
 // comm.hip

@@ -1484,6 +1484,20 @@ __global__ __launch_bounds__(64) void k_wells_apply(const int* __restrict__ vp, 
     }
 }
 
+// this rank's part of B x of every well, 4 doubles per well, for the sum over the ranks (distributed wells); the sums of k_wells_apply
+__global__ __launch_bounds__(64) void k_wells_bx(const int* __restrict__ vp, const int* __restrict__ Bcols, const double* __restrict__ B,
+                                                 const double* __restrict__ x, double xs, double* __restrict__ bx) {
+    const int w = blockIdx.x, lane = threadIdx.x;
+    if (lane >= 4) return;
+    double s = 0.0;
+    for (int p = vp[w]; p < vp[w + 1]; ++p) {
+        const double* xb = &x[(size_t)Bcols[p] * 3];
+        const double* Bp = &B[(size_t)p * 12 + lane * 3];
+        s += Bp[0] * (xs * xb[0]); s += Bp[1] * (xs * xb[1]); s += Bp[2] * (xs * xb[2]);
+    }
+    bx[(size_t)w * 4 + lane] = s;
+}
+
 // r -= C^T (D^-1 resWell) (StandardWell::apply(BVector& r), wells/StandardWell_impl.hpp:1283-1296) and
 // xw = D^-1 (resWell - B x) (recoverSolutionWell, :1298-1311); one wavefront per well, sums in the CPU's order
 __global__ __launch_bounds__(64) void k_wells_residual(const int* __restrict__ vp, const int* __restrict__ Ccols,
@@ -1508,13 +1522,14 @@ __global__ __launch_bounds__(64) void k_wells_residual(const int* __restrict__ v
 __global__ __launch_bounds__(64) void k_wells_recover(const int* __restrict__ vp, const int* __restrict__ Bcols,
                                                       const double* __restrict__ B, const double* __restrict__ D,
                                                       const double* __restrict__ resWell, const double* __restrict__ x,
-                                                      double* __restrict__ xw) {
+                                                      const double* __restrict__ bxAll, double* __restrict__ xw) {
     __shared__ double z1[4];
     const int w = blockIdx.x, lane = threadIdx.x;
     const int pb = vp[w], pe = vp[w + 1];
     if (lane < 4) {
         double s = resWell[(size_t)w * 4 + lane];   // resWell -= B x, perforation by perforation (BCRSMatrix::mmv)
-        for (int p = pb; p < pe; ++p) {
+        if (bxAll) s -= bxAll[(size_t)w * 4 + lane];   // a well shared by several ranks: the product summed over them, subtracted as a whole
+        else for (int p = pb; p < pe; ++p) {
             const double* xb = &x[(size_t)Bcols[p] * 3];
             const double* Bp = &B[(size_t)p * 12 + lane * 3];
             s -= Bp[0] * xb[0]; s -= Bp[1] * xb[1]; s -= Bp[2] * xb[2];
@@ -1880,11 +1895,22 @@ void launch_lu_to_natural(opmhip_ctx* c, double* d_out) {
     hipLaunchKernelGGL(k_lu_to_bcrs, dim3(cdiv((size_t)P.Nb, 256)), dim3(256), 0, c->stream, P.Nb, P.d_rowptr, P.d_col, P.d_lrowptr,
                        P.d_urowptr, c->d_L, c->d_U, c->d_invD, d_out);
 }
-void launch_wells_apply(opmhip_ctx* c, const double* x, double* y, double xs) {
+int launch_wells_apply(opmhip_ctx* c, const double* x, double* y, double xs) {
     const WellsDev& W = c->wells;
-    if (W.num_wells <= 0) return;
+    if (W.num_wells <= 0) return OPMHIP_SUCCESS;
+    if (W.distributed) {
+        // a well shared by several subdomains: this rank's perforations give its part of B x, the parts are summed over the ranks, D^-1 and
+        // C^T follow on every rank for its own cells (ParallelStandardWellB::mv, wells/WellHelpers.hpp:68-123; StandardWell::apply,
+        // wells/StandardWell_impl.hpp:1254-1280)
+        hipLaunchKernelGGL(k_wells_bx, dim3(W.num_wells), dim3(64), 0, c->stream, W.d_val_pointers, W.d_Bcols, W.d_B, x, xs, W.d_bx);
+        const int rc = comm_allreduce(c, W.d_bx, W.num_wells * 4, 0);
+        if (rc) return rc;
+        hipLaunchKernelGGL(k_wells_residual, dim3(W.num_wells), dim3(64), 0, c->stream, W.d_val_pointers, W.d_Ccols, W.d_C, W.d_D, W.d_bx, y);
+        return OPMHIP_SUCCESS;
+    }
     hipLaunchKernelGGL(k_wells_apply, dim3(W.num_wells), dim3(64), 0, c->stream, W.d_val_pointers, W.d_Ccols, W.d_Bcols, W.d_C, W.d_D,
                        W.d_B, x, y, xs);
+    return OPMHIP_SUCCESS;
 }
 void launch_wells_add_to_matrix(opmhip_ctx* c, int w0, int nw, int serial, const int* d_pair_ptr, const int* d_entry) {
     const WellsDev& W = c->wells;
@@ -1895,10 +1921,17 @@ void launch_wells_residual(opmhip_ctx* c, const double* d_resWell, double* r) {
     if (W.num_wells <= 0) return;
     hipLaunchKernelGGL(k_wells_residual, dim3(W.num_wells), dim3(64), 0, c->stream, W.d_val_pointers, W.d_Ccols, W.d_C, W.d_D, d_resWell, r);
 }
-void launch_wells_recover(opmhip_ctx* c, const double* d_resWell, const double* x, double* d_xw) {
+int launch_wells_recover(opmhip_ctx* c, const double* d_resWell, const double* x, double* d_xw) {
     const WellsDev& W = c->wells;
-    if (W.num_wells <= 0) return;
-    hipLaunchKernelGGL(k_wells_recover, dim3(W.num_wells), dim3(64), 0, c->stream, W.d_val_pointers, W.d_Bcols, W.d_B, W.d_D, d_resWell, x, d_xw);
+    if (W.num_wells <= 0) return OPMHIP_SUCCESS;
+    if (W.distributed) {   // resWell - (sum over the ranks of B x): ParallelStandardWellB::mmv's branch for a shared well, wells/WellHelpers.hpp:136-141
+        hipLaunchKernelGGL(k_wells_bx, dim3(W.num_wells), dim3(64), 0, c->stream, W.d_val_pointers, W.d_Bcols, W.d_B, x, 1.0, W.d_bx);
+        const int rc = comm_allreduce(c, W.d_bx, W.num_wells * 4, 0);
+        if (rc) return rc;
+    }
+    hipLaunchKernelGGL(k_wells_recover, dim3(W.num_wells), dim3(64), 0, c->stream, W.d_val_pointers, W.d_Bcols, W.d_B, W.d_D, d_resWell, x,
+                       W.distributed ? W.d_bx : nullptr, d_xw);
+    return OPMHIP_SUCCESS;
 }
 #ifndef OPMHIP_SPMV_PIPE_WGS
 #define OPMHIP_SPMV_PIPE_WGS 2048
@@ -2012,7 +2045,7 @@ int launch_spmv(opmhip_ctx* c, double* x, double* y, int ndot, const double* w0,
         cnt += launch_spmv_part(c, 0, P.tiles.nsched, x, y, fused, w0, xs, cnt, PROF_SPMV);
     }
     if (c->wells.num_ms > 0 && (rc = ms_wells_apply(c, x, y, xs))) return rc;   // in front of the standard wells, bda/WellContributions.cu:160-187
-    if (wells) launch_wells_apply(c, x, y, xs);
+    if (wells && (rc = launch_wells_apply(c, x, y, xs))) return rc;
     if (fused == 0 && ndot > 0) {
         const int n = P.Nb * BS;
         const int ps = prof_begin(c, PROF_VECTOR);   // a scope of its own: its bytes are counted under "vector"

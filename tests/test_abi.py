@@ -11,7 +11,7 @@ def test_library_exports_every_declared_symbol(pkg):
     assert len(names) >= 12
     missing = [n for n in names if not hasattr(L, n)]
     assert not missing, missing
-    assert L.opmhip_abi_version() == 8
+    assert L.opmhip_abi_version() == 9
 
 
 def test_default_config_matches_flow_defaults(pkg):
@@ -54,7 +54,7 @@ def test_ctypes_structs_match_the_header(pkg, tmp_path):
     ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     cfg_fields = [f[0] for f in pkg.capi.Config._fields_]
     res_fields = [f[0] for f in pkg.capi.Result._fields_]
-    wells_fields = [f[0] for f in pkg.capi.Wells._fields_]      # incl. the multisegment leg (num_ms_wells, ms_apply, ms_user; ABI 8)
+    wells_fields = [f[0] for f in pkg.capi.Wells._fields_]      # incl. the multisegment leg (num_ms_wells, ms_apply, ms_user; ABI 8) and `distributed` (ABI 9)
     src = tmp_path / "layout.c"
     lines = ['#include <stddef.h>', '#include <stdio.h>', '#include "opmhip.h"', 'int main(void) {',
              '  printf("config %zu\\n", sizeof(opmhip_config));', '  printf("result %zu\\n", sizeof(opmhip_result));']

@@ -806,3 +806,138 @@ def test_dd_communication_scopes(pkg, prec):
         # one reduction behind the initial residual, two per half iteration (the scalar product, the norm)
         assert prof["allreduce"][0] == 1 + 2 * halves
         assert 0.0 < prof["halo"][1] < wall_ms and 0.0 < prof["allreduce"][1] < wall_ms
+
+
+def wells_on_the_cut_grid(g, owner, rng, world):
+    """Standard wells on the global grid: one horizontal well per pair of neighbouring subdomains crossing the cut between them (a few
+    perforations on either side), and one vertical well inside every subdomain.  B, C: 4 x 3 blocks per perforation, D^-1 per well."""
+    nx, ny, nz = g["nx"], g["ny"], g["nz"]
+    cell = lambda i, j, k: i + nx * (j + ny * k)   # noqa: E731
+    lists = []
+    j0, k0 = ny // 4, nz // 2
+    lists.append([cell(i, j0, k0) for i in range(nx // 2 - 3, nx // 2 + 3)])              # along x, across the first cut
+    if world >= 4:
+        lists.append([cell(nx // 4, j, k0 + 1) for j in range(ny // 2 - 2, ny // 2 + 4)])  # along y, across the second cut
+        lists.append([cell(nx // 2 - 1 + a, ny // 2 - 1 + b, nz - 2) for a, b in ((0, 0), (1, 0), (1, 1), (0, 1))])   # around the corner: four owners
+    for r in range(world):   # a vertical well in the middle of every subdomain
+        mine = np.flatnonzero(owner == r)
+        c = int(mine[len(mine) // 2])
+        i, j = c % nx, (c // nx) % ny
+        col = [cell(i, j, k) for k in range(nz) if owner[cell(i, j, k)] == r][:4]
+        lists.append(col)
+    vp = np.cumsum([0] + [len(q) for q in lists]).astype(np.int32)
+    cells = np.array([c for q in lists for c in q], np.int32)
+    nw, n = len(lists), len(cells)
+    D = np.empty((nw, 4, 4))
+    for w in range(nw):
+        D[w] = np.linalg.inv(0.2 * rng.standard_normal((4, 4)) + np.diag(2.0 + rng.random(4)))
+    return dict(numWells=nw, val_pointers=vp, Ccols=cells, Bcols=cells.copy(), Cnnzs=np.ascontiguousarray(1e-9 * rng.standard_normal(n * 12)),
+                Bnnzs=np.ascontiguousarray(1e-9 * rng.standard_normal(n * 12)), Dnnzs=np.ascontiguousarray(D.reshape(-1)))
+
+
+def wells_of_rank(W, part, shared):
+    """What rank `part` hands over.  shared: every well of the list with the perforations in cells the rank owns (possibly none);
+    else only the wells that lie in the rank's subdomain as a whole."""
+    local = {int(gid): k for k, gid in enumerate(part["gids"][:part["Nb"]])}
+    vp, cells, keep, wells = [0], [], [], []
+    for w in range(W["numWells"]):
+        perfs = range(W["val_pointers"][w], W["val_pointers"][w + 1])
+        mine = [p for p in perfs if int(W["Ccols"][p]) in local]
+        if not shared and len(mine) != len(perfs):
+            continue
+        wells.append(w)
+        keep += mine
+        cells += [local[int(W["Ccols"][p])] for p in mine]
+        vp.append(len(cells))
+    keep = np.array(keep, np.int64)
+    blk = lambda a, m: np.ascontiguousarray(a.reshape(-1, m)[keep].reshape(-1)) if len(keep) else np.zeros(0)   # noqa: E731
+    return dict(numWells=len(wells), val_pointers=np.array(vp, np.int32), Ccols=np.array(cells, np.int32), Bcols=np.array(cells, np.int32),
+                Cnnzs=blk(W["Cnnzs"], 12), Bnnzs=blk(W["Bnnzs"], 12), Dnnzs=np.ascontiguousarray(W["Dnnzs"].reshape(-1, 16)[wells].reshape(-1)),
+                distributed=int(shared)), wells
+
+
+@pytest.mark.parametrize("world,shared", [(2, True), (4, True), (8, True), (4, False)])
+def test_dd_standard_wells(pkg, orc, world, shared):
+    """Standard wells in a decomposed run.  shared: wells whose perforations lie in two or three subdomains (Flow with
+    --allow-distributed-wells=true: ParallelStandardWellB sums B x over the ranks, wells/WellHelpers.hpp:68-123) - every rank hands over
+    the whole list with its own perforations, opmhip_wells.distributed = 1.  Not shared: the default of the reference's partitioner, every
+    well inside one subdomain, every rank hands over its own wells and nothing is exchanged for them.  Oracle: the global system with
+    the global wells and the subdomains' block-Jacobi ILU0; r -= C^T D^-1 resWell bit for bit, the solve to the iteration count, the
+    recovered well solutions identical on every rank."""
+    n = 8
+    g, owner, parts = global_and_parts(pkg, n, world, state="mixed", heterogeneous=True)
+    rng = np.random.default_rng(100 + world)
+    Wall = wells_on_the_cut_grid(g, owner, rng, world)
+    if not shared:   # the global list without the wells that cross a cut
+        inside = [w for w in range(Wall["numWells"]) if len(set(owner[Wall["Ccols"][Wall["val_pointers"][w]:Wall["val_pointers"][w + 1]]])) == 1]
+        keep = np.concatenate([np.arange(Wall["val_pointers"][w], Wall["val_pointers"][w + 1]) for w in inside])
+        vp = np.cumsum([0] + [Wall["val_pointers"][w + 1] - Wall["val_pointers"][w] for w in inside]).astype(np.int32)
+        Wall = dict(numWells=len(inside), val_pointers=vp, Ccols=Wall["Ccols"][keep].copy(), Bcols=Wall["Bcols"][keep].copy(),
+                    Cnnzs=np.ascontiguousarray(Wall["Cnnzs"].reshape(-1, 12)[keep].reshape(-1)), Bnnzs=np.ascontiguousarray(Wall["Bnnzs"].reshape(-1, 12)[keep].reshape(-1)),
+                    Dnnzs=np.ascontiguousarray(Wall["Dnnzs"].reshape(-1, 16)[inside].reshape(-1)))
+        assert len(inside) == world
+    else:
+        crossing = [w for w in range(Wall["numWells"]) if len(set(owner[Wall["Ccols"][Wall["val_pointers"][w]:Wall["val_pointers"][w + 1]]])) > 1]
+        assert len(crossing) >= (1 if world == 2 else 3)
+    res_well = 1e-3 * rng.standard_normal(4 * Wall["numWells"])
+    src = pkg.decks.five_spot_source(g, rate_sm3_per_day=30.0)
+    o = oracle_bind.OracleModel(orc, g)
+    o.set_state(g["pv"], g["meaning"])
+    o.set_source(src)
+    dt = 86400.0
+    jo, ro = o.assemble(dt, 0)
+    r2 = orc.wells_apply_residual(Wall, res_well, ro)
+    xo, reso = orc.solve(g["Nb"], g["rowptr"], g["col"], jo, r2, tol=1e-4, maxit=200, w=0.9, wells=Wall, owner=owner)
+    xwo = orc.wells_recover(Wall, res_well, xo)
+    assert reso.converged
+    group = "w" + uuid.uuid4().hex
+
+    def rank_fn(r):
+        c = parts[r]
+        Wr, ids = wells_of_rank(Wall, c, shared)
+        m = pkg.capi.HipModel(c, comm=("loopback", world, r, group), reorder="level_scheduling", tolerance=1e-4, maxit=200)   # the oracle's ILU0 runs in the natural order
+        m.set_state(c["pv"], c["meaning"])
+        m.set_source(np.ascontiguousarray(src.reshape(-1, 3)[c["gids"]].reshape(-1)))
+        m.assemble(dt, 0)
+        rw = np.ascontiguousarray(res_well.reshape(-1, 4)[ids].reshape(-1))
+        m.wells_apply_residual(Wr, rw)
+        rhs = m.get_rhs()
+        sol = m.solve_jacobian_system(wells=Wr)
+        x = m.get_result()
+        xw = m.wells_recover_solution(Wr, rw) if Wr["numWells"] else np.zeros(0)
+        return rhs, sol.it, sol.converged, x, xw, ids
+
+    outs = run_ranks(world, rank_fn)
+    for r, (rhs, it, ok, x, xw, ids) in enumerate(outs):
+        c = parts[r]
+        gi = c["gids"][:c["Nb"]]
+        assert np.array_equal(rhs.reshape(-1, 3)[:c["Nb"]], r2.reshape(-1, 3)[gi])
+        assert ok and it == reso.it
+        np.testing.assert_allclose(x.reshape(-1, 3)[:c["Nb"]], xo.reshape(-1, 3)[gi], rtol=1e-7, atol=1e-11 * np.abs(xo).max())
+        np.testing.assert_allclose(xw, xwo.reshape(-1, 4)[ids].reshape(-1), rtol=1e-6, atol=1e-9 * np.abs(xwo).max())
+        if shared:
+            assert np.array_equal(xw, outs[0][4])   # one sum over the ranks: the same bits everywhere
+    assert not np.array_equal(r2, ro)
+
+
+def test_dd_shared_wells_need_the_same_list_on_every_rank(pkg):
+    """distributed = 1 with lists of different lengths: INVALID_ARGUMENT on every rank, nobody waits inside the reduction"""
+    world, n = 2, 6
+    g, owner, parts = global_and_parts(pkg, n, world, state="mixed", heterogeneous=False)
+    Wall = wells_on_the_cut_grid(g, owner, np.random.default_rng(5), world)
+    group = "v" + uuid.uuid4().hex
+
+    def rank_fn(r):
+        c = parts[r]
+        Wr, _ = wells_of_rank(Wall, c, True)
+        if r == 1:   # one well fewer
+            Wr = dict(Wr, numWells=Wr["numWells"] - 1, val_pointers=Wr["val_pointers"][:-1].copy())
+        m = pkg.capi.HipModel(c, comm=("loopback", world, r, group))
+        m.set_state(c["pv"], c["meaning"])
+        m.assemble(86400.0, 0)
+        with pytest.raises(pkg.capi.OpmHipError) as e:
+            m.solve_jacobian_system(wells=Wr)
+        return str(e.value)
+
+    msgs = run_ranks(world, rank_fn)
+    assert all("same wells" in s for s in msgs), msgs
