@@ -399,8 +399,8 @@ int opmhip_add_well_contributions(opmhip_ctx* c, const opmhip_wells* wells) {
             for (int a = 0; a < np; ++a)
                 for (int b = 0; b < np; ++b) {
                     const int row = P.toOrder[wells->Ccols[pb + a]], colv = P.toOrder[wells->Bcols[pb + b]];
-                    const int* lo = &P.col[P.rowptr[row]];
-                    const int* hi = &P.col[P.rowptr[row + 1]];
+                    const int* lo = P.col.data() + P.rowptr[row];
+                    const int* hi = P.col.data() + P.rowptr[row + 1];   // (not &P.col[...]: one past the end for the last row)
                     const int* it = std::lower_bound(lo, hi, colv);
                     if (it == hi || *it != colv)
                         return fail(c, OPMHIP_INVALID_ARGUMENT, "add_well_contributions: block (%d, %d) of well %d is not in the pattern",

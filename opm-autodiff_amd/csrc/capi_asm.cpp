@@ -115,11 +115,11 @@ int opmhip_set_static(opmhip_ctx* c, const double* trans, const double* area, co
                 for (int k = P.nat_rowptr[i]; k < P.nat_rowptr[i + 1]; ++k) {
                     const int j = P.nat_col[k];
                     if (j >= P.Nb) { tr[k] = k; continue; }  // ghost column: its row lives on the neighbouring subdomain
-                    const int* b = &P.nat_col[P.nat_rowptr[j]];
-                    const int* e = &P.nat_col[P.nat_rowptr[j + 1]];
+                    const int* b = P.nat_col.data() + P.nat_rowptr[j];
+                    const int* e = P.nat_col.data() + P.nat_rowptr[j + 1];   // (not &nat_col[...]: one past the end for the last row)
                     const int* q = std::lower_bound(b, e, i);
                     if (q == e || *q != i) return fail(c, OPMHIP_INVALID_ARGUMENT, "set_static: pattern is not structurally symmetric at (%d,%d)", i, j);
-                    tr[k] = (int)(q - &P.nat_col[0]);
+                    tr[k] = (int)(q - P.nat_col.data());
                 }
             for (int k = 0; k < P.nnzb; ++k)
                 if (trans[k] != trans[tr[k]] || area[k] != area[tr[k]] || (thpres && thpres[k] != thpres[tr[k]]))

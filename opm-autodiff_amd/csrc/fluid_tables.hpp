@@ -4,6 +4,7 @@
 // sources; call sites ebos/eclproblem.hh:1490-1498, flow/BlackoilModelEbos.hpp:650-664).
 // Device side: everything is flattened into ONE double blob plus ONE int blob so that a kernel needs two pointers.
 #pragma once
+#include <string>
 #include <vector>
 
 #include "../../include/opmhip.h"

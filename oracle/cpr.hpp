@@ -307,10 +307,10 @@ struct CprAmg {
                 for (int q = A.rowptr[j]; q < A.rowptr[j + 1]; ++q) {
                     const int c = A.col[q];
                     if (L.pos[c] <= e.first) continue;                 // U part of row j only
-                    const int* b = &A.col[A.rowptr[i]];
-                    const int* en = &A.col[A.rowptr[i + 1]];
+                    const int* b = A.col.data() + A.rowptr[i];
+                    const int* en = A.col.data() + A.rowptr[i + 1];
                     const int* t = std::lower_bound(b, en, c);
-                    if (t != en && *t == c) f[t - &A.col[0]] -= f[k] * f[q];
+                    if (t != en && *t == c) f[t - A.col.data()] -= f[k] * f[q];
                 }
             }
             f[L.diag[i]] = 1.0 / f[L.diag[i]];
@@ -479,11 +479,11 @@ struct DuneLikeAmg {
             for (int k = A.rowptr[i]; k < A.rowptr[i + 1]; ++k)
                 if (A.col[k] == i) d[i] = A.val[k];
         auto entry = [&](int r, int c, double& v) {   // a_rc if present
-            const int* b = &A.col[A.rowptr[r]];
-            const int* e = &A.col[A.rowptr[r + 1]];
+            const int* b = A.col.data() + A.rowptr[r];
+            const int* e = A.col.data() + A.rowptr[r + 1];
             const int* q = std::lower_bound(b, e, c);
             if (q == e || *q != c) return false;
-            v = A.val[q - &A.col[0]];
+            v = A.val[q - A.col.data()];
             return true;
         };
         strong.assign(A.col.size(), 0);
@@ -511,9 +511,9 @@ struct DuneLikeAmg {
             for (int k = A.rowptr[i]; k < A.rowptr[i + 1]; ++k)
                 if (strong[k]) {
                     const int j = A.col[k];
-                    const int* b = &A.col[A.rowptr[j]];
-                    const int* q = std::lower_bound(b, &A.col[A.rowptr[j + 1]], i);
-                    strong[q - &A.col[0]] = 1;
+                    const int* b = A.col.data() + A.rowptr[j];
+                    const int* q = std::lower_bound(b, A.col.data() + A.rowptr[j + 1], i);
+                    strong[q - A.col.data()] = 1;
                 }
     }
     // Aggregator::build: seeds in index order; growAggregate up to minAgg vertices within maxDistance; the rounding step up to

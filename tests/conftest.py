@@ -31,8 +31,11 @@ def pkg():
 @pytest.fixture(scope="session")
 def orc():
     """ctypes handle on the CPU oracle (test infrastructure)."""
-    _ensure(os.path.join(ROOT, "oracle", "liboracle.so"), os.path.join(ROOT, "oracle"))
     import oracle_bind
+    alt = os.environ.get("ORACLE_LIB")   # another build of the same sources, e.g. tools/sanitize.sh's (ASan + UBSan + libstdc++ assertions)
+    if alt:
+        return oracle_bind.Oracle(alt)
+    _ensure(os.path.join(ROOT, "oracle", "liboracle.so"), os.path.join(ROOT, "oracle"))
     return oracle_bind.Oracle(os.path.join(ROOT, "oracle", "liboracle.so"))
 
 
