@@ -165,7 +165,8 @@ typedef struct opmhip_result {
  * of wells in the same order - its own perforations of each (none: val_pointers[w] == val_pointers[w + 1]) and the complete D^-1 - and
  * the num_wells x 4 partial products travel through one all-reduce per operator application (all ranks, not a sub-communicator per
  * well: ranks without perforations add zeros).  Every call that takes such a list is then COLLECTIVE (all ranks, same order); a
- * different num_wells on some rank is reported on every rank (INVALID_ARGUMENT) instead of hanging in the reduction.
+ * different num_wells on some rank - including 0: an empty list with distributed = 1 still takes part in the comparison - is reported on
+ * every rank (INVALID_ARGUMENT) instead of hanging in the reduction; a rank that passes NULL where the others pass a list cannot be caught.
  * opmhip_wells_recover_solution forms resWell - sum_ranks(B x) as the reference's mmv does for a shared well (WellHelpers.hpp:126-142). */
 typedef void (*opmhip_ms_apply_fn)(void* user, const double* h_x, double* h_y);
 typedef struct opmhip_wells {

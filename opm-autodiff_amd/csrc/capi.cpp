@@ -57,6 +57,12 @@ int alloc_system(opmhip_ctx* c) {
     return OPMHIP_SUCCESS;
 }
 
+// nothing to do for this list?  (A shared list - opmhip_wells.distributed in a decomposed run - always goes through upload_wells, where the
+// ranks compare its length: a rank that stepped out here with no wells would leave the others waiting in that comparison.)
+static bool no_standard_wells(const opmhip_ctx* c, const opmhip_wells* w) {
+    return !w || (w->num_wells <= 0 && !(w->distributed != 0 && c->comm.nranks > 1));
+}
+
 int upload_wells(opmhip_ctx* c, const opmhip_wells* w) {
     WellsDev& W = c->wells;
     W.num_wells = 0;
@@ -366,11 +372,12 @@ int opmhip_wells_apply_residual(opmhip_ctx* c, const opmhip_wells* wells, const 
     if (!c) return OPMHIP_INVALID_ARGUMENT;
     return guarded(c, [&]() -> int {
         if (!c->system_loaded && !c->asmb.assembled) return fail(c, OPMHIP_NOT_READY, "wells_apply_residual: no residual on the device");
-        if (!wells || wells->num_wells <= 0) return OPMHIP_SUCCESS;
-        if (!res_well) return fail(c, OPMHIP_INVALID_ARGUMENT, "wells_apply_residual: null res_well");
+        if (no_standard_wells(c, wells)) return OPMHIP_SUCCESS;
+        if (wells->num_wells > 0 && !res_well) return fail(c, OPMHIP_INVALID_ARGUMENT, "wells_apply_residual: null res_well");
         OPMHIP_HIP(c, hipSetDevice(c->device));
         int rc;
         if ((rc = upload_wells(c, wells))) return rc;
+        if (wells->num_wells <= 0) return OPMHIP_SUCCESS;   // an empty shared list: the ranks have agreed that it is empty
         OPMHIP_HIP(c, hipMemcpyAsync(c->wells.d_res, res_well, (size_t)wells->num_wells * 4 * sizeof(double), hipMemcpyHostToDevice, c->stream));
         launch_wells_residual(c, c->wells.d_res, c->d_b);
         OPMHIP_HIP(c, hipGetLastError());
@@ -384,10 +391,11 @@ int opmhip_add_well_contributions(opmhip_ctx* c, const opmhip_wells* wells) {
     if (!c) return OPMHIP_INVALID_ARGUMENT;
     return guarded(c, [&]() -> int {
         if (!c->system_loaded && !c->asmb.assembled) return fail(c, OPMHIP_NOT_READY, "add_well_contributions: no matrix on the device");
-        if (!wells || wells->num_wells <= 0) return OPMHIP_SUCCESS;
+        if (no_standard_wells(c, wells)) return OPMHIP_SUCCESS;
         OPMHIP_HIP(c, hipSetDevice(c->device));
         int rc;
         if ((rc = upload_wells(c, wells))) return rc;
+        if (wells->num_wells <= 0) return OPMHIP_SUCCESS;
         const Pattern& P = c->pat;
         const int nw = wells->num_wells;
         // position of every (c, b) block in the device's block-CSR; wells that touch a common block are serialised
@@ -457,11 +465,12 @@ int opmhip_wells_recover_solution(opmhip_ctx* c, const opmhip_wells* wells, cons
     if (!c) return OPMHIP_INVALID_ARGUMENT;
     return guarded(c, [&]() -> int {
         if (!c->have_result) return fail(c, OPMHIP_NOT_READY, "wells_recover_solution before a solve");
-        if (!wells || wells->num_wells <= 0) return OPMHIP_SUCCESS;
-        if (!res_well || !xw) return fail(c, OPMHIP_INVALID_ARGUMENT, "wells_recover_solution: null array");
+        if (no_standard_wells(c, wells)) return OPMHIP_SUCCESS;
+        if (wells->num_wells > 0 && (!res_well || !xw)) return fail(c, OPMHIP_INVALID_ARGUMENT, "wells_recover_solution: null array");
         OPMHIP_HIP(c, hipSetDevice(c->device));
         int rc;
         if ((rc = upload_wells(c, wells))) return rc;
+        if (wells->num_wells <= 0) return OPMHIP_SUCCESS;
         OPMHIP_HIP(c, hipMemcpyAsync(c->wells.d_res, res_well, (size_t)wells->num_wells * 4 * sizeof(double), hipMemcpyHostToDevice, c->stream));
         if ((rc = launch_wells_recover(c, c->wells.d_res, c->d_x, c->wells.d_xw))) return rc;
         OPMHIP_HIP(c, hipMemcpyAsync(xw, c->wells.d_xw, (size_t)wells->num_wells * 4 * sizeof(double), hipMemcpyDeviceToHost, c->stream));

@@ -920,8 +920,10 @@ def test_dd_standard_wells(pkg, orc, world, shared):
     assert not np.array_equal(r2, ro)
 
 
-def test_dd_shared_wells_need_the_same_list_on_every_rank(pkg):
-    """distributed = 1 with lists of different lengths: INVALID_ARGUMENT on every rank, nobody waits inside the reduction"""
+@pytest.mark.parametrize("short", ["one_fewer", "none"])
+def test_dd_shared_wells_need_the_same_list_on_every_rank(pkg, short):
+    """distributed = 1 with lists of different lengths (one well fewer on rank 1; no well at all on rank 1): INVALID_ARGUMENT on every
+    rank, nobody waits inside the reduction"""
     world, n = 2, 6
     g, owner, parts = global_and_parts(pkg, n, world, state="mixed", heterogeneous=False)
     Wall = wells_on_the_cut_grid(g, owner, np.random.default_rng(5), world)
@@ -930,8 +932,10 @@ def test_dd_shared_wells_need_the_same_list_on_every_rank(pkg):
     def rank_fn(r):
         c = parts[r]
         Wr, _ = wells_of_rank(Wall, c, True)
-        if r == 1:   # one well fewer
+        if r == 1 and short == "one_fewer":
             Wr = dict(Wr, numWells=Wr["numWells"] - 1, val_pointers=Wr["val_pointers"][:-1].copy())
+        elif r == 1:
+            Wr = dict(numWells=0, distributed=1)
         m = pkg.capi.HipModel(c, comm=("loopback", world, r, group))
         m.set_state(c["pv"], c["meaning"])
         m.assemble(86400.0, 0)
@@ -941,3 +945,22 @@ def test_dd_shared_wells_need_the_same_list_on_every_rank(pkg):
 
     msgs = run_ranks(world, rank_fn)
     assert all("same wells" in s for s in msgs), msgs
+
+
+def test_dd_an_empty_shared_list_is_agreed_on(pkg):
+    """distributed = 1 and no well on any rank: the ranks agree that the list is empty and every entry point returns"""
+    world, n = 2, 6
+    g, owner, parts = global_and_parts(pkg, n, world, state="mixed", heterogeneous=False)
+    group = "e" + uuid.uuid4().hex
+
+    def rank_fn(r):
+        c = parts[r]
+        m = pkg.capi.HipModel(c, comm=("loopback", world, r, group))
+        m.set_state(c["pv"], c["meaning"])
+        m.assemble(86400.0, 0)
+        W = dict(numWells=0, distributed=1)
+        m.wells_apply_residual(W, np.zeros(0))
+        sol = m.solve_jacobian_system(wells=W)
+        return sol.converged
+
+    assert all(run_ranks(world, rank_fn))
