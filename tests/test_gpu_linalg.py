@@ -268,6 +268,33 @@ def test_wells_operator(pkg, orc):
     assert np.linalg.norm(r) < 1e-8 * np.linalg.norm(b) * 1.001
 
 
+@pytest.mark.parametrize("reorder", ["level_scheduling", "graph_coloring", "line_coloring"])
+def test_wells_operator_in_every_ordering(pkg, orc, reorder):
+    """The well operator inside a solve under the other orderings (the perforated cells are renamed at upload, opmhip_wells' indices are
+    natural ones): wells large enough to be felt - forgetting them leaves a residual a thousand tolerances large - device against the
+    oracle's solve in the device's ordering, to the iteration count."""
+    import helpers
+    rng = np.random.default_rng(12)
+    Nb, rp, ci, v = laplace_block_system(12, 10, 6, seed=13)
+    perfs = [7, 1, 4, 12]
+    vp = np.concatenate([[0], np.cumsum(perfs)]).astype(np.int32)
+    nperf = int(vp[-1])
+    cols = rng.choice(Nb, nperf, replace=False).astype(np.int32)
+    W = dict(numWells=4, val_pointers=vp, Ccols=cols, Bcols=cols.copy(), Cnnzs=0.05 * rng.standard_normal(nperf * 12),
+             Bnnzs=0.05 * rng.standard_normal(nperf * 12), Dnnzs=0.5 * rng.standard_normal(4 * 16))
+    b = rng.standard_normal(Nb * 3)
+    s = pkg.capi.HipSolver(tolerance=1e-8, maxit=200, reorder=reorder)
+    res = s.solve_system(Nb, rp, ci, v.copy(), b, wells=W)
+    x = s.get_result()
+    to, fr, _ = s.ordering()
+    xo, ro = helpers.oracle_solve_in_order(orc, Nb, rp, ci, v, b, to, fr, wells=W, tol=1e-8, maxit=200, w=0.9)
+    assert res.converged and ro.converged and res.it == ro.it
+    np.testing.assert_allclose(x, xo, rtol=1e-8, atol=1e-12)
+    ax = orc.spmv(Nb, rp, ci, v, x)
+    assert np.linalg.norm(b - orc.wells_apply(W, x, ax)) < 1e-8 * np.linalg.norm(b) * 1.001
+    assert np.linalg.norm(b - ax) > 1e3 * 1e-8 * np.linalg.norm(b)
+
+
 def test_zero_diagonal_fix_and_nonconvergence(pkg, orc):
     Nb, rp, ci, v = laplace_block_system(6, 6, 4, seed=14)
     b = np.ones(Nb * 3)
