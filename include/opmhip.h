@@ -20,7 +20,8 @@
 extern "C" {
 #endif
 
-#define OPMHIP_ABI_VERSION 9 /* 9: opmhip_wells gained `distributed` (standard wells whose perforations lie in several subdomains of a decomposed run);
+#define OPMHIP_ABI_VERSION 10 /* 10: opmhip_config gained half_product (the product after an ILU0 application from the sweep's row sums), opmhip_get_product_form;
+                               * 9: opmhip_wells gained `distributed` (standard wells whose perforations lie in several subdomains of a decomposed run);
                                * 8: opmhip_default_config: reorder = OPMHIP_REORDER_AUTO, cpr_amg_ilu_levels = -1 (the measured configuration);
                                *    opmhip_get_ordering_info, opmhip_wells gained the multisegment-well leg (num_ms_wells, ms_apply);
                                * 7: opmhip_config names cpr_amg_ilu_levels, cpr_gather_rows (were reserved[0..1]);
@@ -124,6 +125,19 @@ typedef struct opmhip_config {
                             * < 0: off - one hierarchy per subdomain, no communication inside the preconditioner, iteration counts that
                             * grow with the number of ranks.  Ignored on a single rank; cpr_amg_ilu_levels and cpr_async_setup are ignored
                             * where it is in force.  (was reserved[1] until ABI 7) */
+    int half_product;      /* ILU0-BiCGStab: the product that follows an M^-1 application is formed from the backward sweep's row sums.  On a
+                            * pattern without triangles (every TPFA grid without well cliques or NNC triangles) no elimination step of the block
+                            * ILU0 touches an entry right of the diagonal (linalg/ParallelOverlappingILU0.hpp:466-481 modifies A_ik only where
+                            * (i,j), (j,k) and (i,k) all exist), so U == upper(A) bit for bit and u_i = sum_{j>i} U_ij z_j, which the backward
+                            * sweep of z = U^-1 y forms anyway (:881-895), IS the upper part of (A z)_i.  The sweep stores u (24 bytes per row)
+                            * and the product streams the matrix without its U part: y_i = (sum over lower entries, diagonal and ghost columns,
+                            * ascending, of A_ik (w z_k)) + w u_i - 0.8 GB per preconditioned product instead of 1.0 (bda/cusparseSolverBackend.cu:
+                            * 103-118 runs the sweep and then bsrmv over the whole matrix on the same vector).  Same products as the reference's
+                            * A (w z), summed in another order: results differ from the plain form in the last bits, iteration counts
+                            * agree (tests/test_gpu_half_product.py; the oracle states the same order).  0 (default): the library's choice - on
+                            * where the pattern allows it, the ordering is line-coloured and the system is large enough for the pipelined
+                            * kernels, single domain; > 0: wherever the pattern and the ordering allow it; < 0: never.  Ignored with a CPR
+                            * preconditioner.  opmhip_get_product_form says what is in force.  ABI 10 */
 } opmhip_config;
 
 /* bda::BdaResult (bda/BdaResult.hpp:28-40) plus the reference's per-phase timers. */
@@ -166,7 +180,9 @@ typedef struct opmhip_result {
  * the num_wells x 4 partial products travel through one all-reduce per operator application (all ranks, not a sub-communicator per
  * well: ranks without perforations add zeros).  Every call that takes such a list is then COLLECTIVE (all ranks, same order); a
  * different num_wells on some rank - including 0: an empty list with distributed = 1 still takes part in the comparison - is reported on
- * every rank (INVALID_ARGUMENT) instead of hanging in the reduction; a rank that passes NULL where the others pass a list cannot be caught.
+ * every rank (INVALID_ARGUMENT) instead of hanging in the reduction, and so is a rank-local failure to take the list (a null array, a
+ * perforation outside the owned cells, an allocation): the local checks run first, their outcome travels in the same reduction and every
+ * rank leaves with an error.  A rank that passes NULL or distributed = 0 where the others pass a shared list cannot be caught.
  * opmhip_wells_recover_solution forms resWell - sum_ranks(B x) as the reference's mmv does for a shared well (WellHelpers.hpp:126-142). */
 typedef void (*opmhip_ms_apply_fn)(void* user, const double* h_x, double* h_y);
 typedef struct opmhip_wells {
@@ -232,7 +248,10 @@ int opmhip_wells_apply_residual(opmhip_ctx* ctx, const opmhip_wells* wells, cons
  *   (wells/StandardWell_impl.hpp:1688-1712), the --matrix-add-well-contributions=true mode: A -= C^T D^-1 B written into
  *   the device-resident matrix (uploaded or assembled) instead of being applied after every SpMV; block (Ccols[c],
  *   Bcols[b]) of every perforation pair of a well must be in the pattern given to set_pattern (the "well cliques"
- *   ISTLSolverEbos adds to the sparsity pattern in that mode), else INVALID_ARGUMENT and the matrix is left untouched. */
+ *   ISTLSolverEbos adds to the sparsity pattern in that mode), else INVALID_ARGUMENT and the matrix is left untouched.
+ *   Decomposed runs: only wells that lie inside this rank's subdomain (distributed = 0).  A shared list (distributed = 1) is refused with
+ *   INVALID_ARGUMENT on every rank, before anything is exchanged: the blocks that couple perforations of different subdomains are in no
+ *   rank's pattern - such wells go through the operator form (opmhip_solve_system's `wells`). */
 int opmhip_add_well_contributions(opmhip_ctx* ctx, const opmhip_wells* wells);
 /* the right-hand side / residual currently on the device (after opmhip_assemble, opmhip_upload_system or
  * opmhip_wells_apply_residual): N doubles, natural order - what linearizer().residual() holds on the host in Flow */
@@ -253,6 +272,11 @@ int opmhip_spmv(opmhip_ctx* ctx, const double* x, double* y);
 int opmhip_ilu0_factor(opmhip_ctx* ctx, double* lu_out);
 /* v = M^-1 d (ParallelOverlappingILU0::apply, :848-903); needs opmhip_ilu0_factor first */
 int opmhip_ilu0_apply(opmhip_ctx* ctx, const double* d, double* v);
+/* t = A (M^-1 d) formed the way ILU0-BiCGStab forms it inside a solve - the ILU0 application, then the product, in the form in force
+ * (opmhip_get_product_form: the whole matrix, or the matrix beside its U part plus the backward sweep's row sums, opmhip_config.half_product)
+ * - the pair bda/cusparseSolverBackend.cu:103-118 runs per half iteration.  z (nullable) receives M^-1 d.  Needs opmhip_ilu0_factor first;
+ * for parity tests of the half-product form.  ABI 10 */
+int opmhip_preconditioned_product(opmhip_ctx* ctx, const double* d, double* t, double* z);
 /* replaces: the weights argument of the CPR preconditioner (linalg/ISTLSolverEbos.hpp:440-475: getTrueImpesWeights /
  * getQuasiImpesWeights handed to the preconditioner factory).  weights: 3 doubles per block row, natural order - what
  * Amg::getTrueImpesWeights (linalg/getQuasiImpesWeights.hpp:89-128) returns; they stay in force for every later solve.
@@ -281,10 +305,17 @@ int opmhip_get_ordering(opmhip_ctx* ctx, int* toOrder, int* fromOrder, int* rows
  * cpr_amg_ilu_levels in force (0 without a CPR preconditioner).  The reference prints the same kind of line at set-up
  * (bda/openclSolverBackend.cpp:229-246, BILU0.cpp:106-108).  ABI 8 */
 int opmhip_get_ordering_info(opmhip_ctx* ctx, int info[4]);
+/* what opmhip_config.half_product resolved to at set_pattern: info[0] 1 if ILU0-BiCGStab forms the product after M^-1 from the backward
+ * sweep's row sums, else 0; info[1] 1 if the pattern has the property it rests on (no elimination step touches an entry right of the
+ * diagonal: U == upper(A)); info[2] blocks of the matrix beside its U part (what that product streams); info[3] launch positions of that
+ * product.  ABI 10 */
+int opmhip_get_product_form(opmhip_ctx* ctx, int info[4]);
 /* Device-timed repetitions of one kernel on the uploaded system, for bench.py's roofline object:
  * which = 0 SpMV, 1 ILU0 apply, 2 ILU0 factor, 3 one BiCGStab iteration's vector kernels, 4 a plain streaming read of
  * the Jacobian's value array (72 * nnzb bytes; the on-box HBM ceiling the roofline fractions are put beside), 5 / 6 the SpMV
- * with the partial sums of one / two scalar products (the forms BiCGStab launches).
+ * with the partial sums of one / two scalar products (the forms BiCGStab launches); contexts with the half-product form in force
+ * (opmhip_get_product_form): 7 the product over the matrix beside its U part, 8 the same with two scalar products, 9 the ILU0 application
+ * with the backward sweeps' row sums stored.
  * Launches the kernel `reps` times back to back on the context's stream between two HIP events and returns the
  * average milliseconds per launch in *ms_per_launch. */
 int opmhip_time_kernel(opmhip_ctx* ctx, int which, int reps, double* ms_per_launch);

@@ -31,7 +31,8 @@ class Config(C.Structure):
     _fields_ = [("abi_version", C.c_int), ("device_id", C.c_int), ("verbosity", C.c_int), ("maxit", C.c_int),
                 ("tolerance", C.c_double), ("ilu_relaxation", C.c_double), ("relax_mode", C.c_int),
                 ("reorder", C.c_int), ("zero_diag_fix", C.c_int), ("chain_length", C.c_int), ("spmv_pipe_wgs", C.c_int),
-                ("preconditioner", C.c_int), ("cpr_reuse_setup", C.c_int), ("cpr_async_setup", C.c_int), ("cpr_amg_ilu_levels", C.c_int), ("cpr_gather_rows", C.c_int)]
+                ("preconditioner", C.c_int), ("cpr_reuse_setup", C.c_int), ("cpr_async_setup", C.c_int), ("cpr_amg_ilu_levels", C.c_int), ("cpr_gather_rows", C.c_int),
+                ("half_product", C.c_int)]
 
 
 class Result(C.Structure):
@@ -111,11 +112,13 @@ def lib():
         L.opmhip_ilu0_factor.argtypes = [vp, dp]
         L.opmhip_ilu0_apply.argtypes = [vp, dp, dp]
         L.opmhip_cpr_apply.argtypes = [vp, dp, dp]
+        L.opmhip_preconditioned_product.argtypes = [vp, dp, dp, dp]
         L.opmhip_cpr_recreate.argtypes = [vp]
         L.opmhip_set_cpr_weights.argtypes = [vp, dp]
         L.opmhip_get_cpr_weights.argtypes = [vp, dp]
         L.opmhip_get_ordering.argtypes = [vp, ip, ip, ip]
         L.opmhip_get_ordering_info.argtypes = [vp, C.POINTER(C.c_int * 4)]
+        L.opmhip_get_product_form.argtypes = [vp, C.POINTER(C.c_int * 4)]
         L.opmhip_time_kernel.argtypes = [vp, C.c_int, C.c_int, C.POINTER(C.c_double)]
         L.opmhip_cpr_levels.argtypes = [vp, ip, ip, C.c_int]
         L.opmhip_profile_enable.argtypes = [vp, C.c_int]
@@ -170,9 +173,10 @@ class HipSolver:
 
     def __init__(self, verbosity=0, maxit=200, tolerance=1e-2, device_id=0, ilu_relaxation=0.9,
                  relax_mode="post_scale", reorder=None, zero_diag_fix=True, chain_length=0, spmv_pipe_wgs=0,
-                 preconditioner="ilu0", cpr_reuse_setup=3, cpr_async_setup=0, cpr_amg_ilu_levels=None, cpr_gather_rows=None):
+                 preconditioner="ilu0", cpr_reuse_setup=3, cpr_async_setup=0, cpr_amg_ilu_levels=None, cpr_gather_rows=None, half_product=0):
         """reorder / cpr_amg_ilu_levels / cpr_gather_rows = None: what opmhip_default_config says (reorder "auto", the library's choice of
-        the AMG smoother, the pressure stage across the ranks as the communicator's kind allows)"""
+        the AMG smoother, the pressure stage across the ranks as the communicator's kind allows).  half_product: ILU0-BiCGStab forms the
+        product after M^-1 from the backward sweep's row sums (0 the library's choice, > 0 wherever the pattern allows, < 0 never)"""
         L = lib()
         cfg = Config()
         L.opmhip_default_config(C.byref(cfg))
@@ -190,6 +194,7 @@ class HipSolver:
             cfg.cpr_amg_ilu_levels = int(cpr_amg_ilu_levels)   # finest levels of the pressure AMG that smooth with ILU0 (0: Jacobi everywhere, < 0: the library's choice)
         if cpr_gather_rows is not None:
             cfg.cpr_gather_rows = int(cpr_gather_rows)         # decomposed runs: the hierarchy is continued across the ranks from the first level this small (0 default, < 0 off)
+        cfg.half_product = int(half_product)
         cfg.cpr_async_setup = int(cpr_async_setup)   # mode 2 only: the rebuild on a host thread beside the solves
         cfg.cpr_reuse_setup = int(cpr_reuse_setup)   # --cpr-reuse-setup: 0 every solve, 1 every time step, 2 after > 10 iterations, 3 never
         self._h = C.c_void_p()
@@ -300,6 +305,13 @@ class HipSolver:
         self._check(lib().opmhip_cpr_apply(self._h, _ptr(d), _ptr(v)))
         return v
 
+    def preconditioned_product(self, d):
+        """(A (M^-1 d), M^-1 d) in the form ILU0-BiCGStab uses inside a solve (opmhip_preconditioned_product)"""
+        d = _f64(d)
+        t, z = np.empty_like(d), np.empty_like(d)
+        self._check(lib().opmhip_preconditioned_product(self._h, _ptr(d), _ptr(t), _ptr(z)))
+        return t, z
+
     def ordering(self):
         to = np.empty(self.Nb, np.int32)
         fr = np.empty(self.Nb, np.int32)
@@ -313,6 +325,12 @@ class HipSolver:
         self._check(lib().opmhip_get_ordering_info(self._h, C.byref(info)))
         names = {v: k for k, v in REORDER.items()}
         return {"ilu_ordering": names[info[0]], "chain_length": int(info[1]), "colors": int(info[2]), "cpr_amg_ilu_levels": int(info[3])}
+
+    def product_form(self):
+        """what opmhip_config.half_product resolved to (opmhip_get_product_form)"""
+        info = (C.c_int * 4)()
+        self._check(lib().opmhip_get_product_form(self._h, C.byref(info)))
+        return {"half_product": bool(info[0]), "u_is_upper_a": bool(info[1]), "rest_blocks": int(info[2]), "rest_positions": int(info[3])}
 
     PROF = ["spmv", "ilu_apply", "ilu_factor", "vector", "assemble", "iq_update", "convergence", "cpr_amg", "spmv_boundary",
             "halo", "allreduce", "cpr_gather"]   # the last three: communication spans of decomposed runs (they overlap the kernel scopes)
@@ -353,7 +371,8 @@ class HipSolver:
 
     def time_kernel(self, which, reps=20):
         ms = C.c_double()
-        self._check(lib().opmhip_time_kernel(self._h, {"spmv": 0, "ilu_apply": 1, "ilu_factor": 2, "vector": 3, "stream_read": 4, "spmv_dot1": 5, "spmv_dot2": 6}[which],
+        self._check(lib().opmhip_time_kernel(self._h, {"spmv": 0, "ilu_apply": 1, "ilu_factor": 2, "vector": 3, "stream_read": 4, "spmv_dot1": 5, "spmv_dot2": 6,
+                                                              "rest_product": 7, "rest_product_dot2": 8, "ilu_apply_rowsums": 9}[which],
                                              reps, C.byref(ms)))
         return ms.value
 

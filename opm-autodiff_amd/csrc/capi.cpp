@@ -33,6 +33,13 @@ int alloc_system(opmhip_ctx* c) {
     OPMHIP_HIP(c, hipMemset(c->d_L + (size_t)P.nl * BB, 0, SLACK * sizeof(double)));
     OPMHIP_HIP(c, hipMemset(c->d_U + (size_t)P.nu * BB, 0, SLACK * sizeof(double)));
     if ((rc = dev_alloc(c, &c->d_invD, (size_t)P.Nb * BB))) return rc;
+    c->half_product = half_product_wanted(c);
+    if (c->half_product) {   // the matrix beside its U part (written by the factorisation) and the backward sweeps' row sums
+        if ((rc = dev_alloc(c, &c->d_R, (size_t)P.nr * BB + SLACK))) return rc;
+        OPMHIP_HIP(c, hipMemset(c->d_R, 0, ((size_t)P.nr * BB + SLACK) * sizeof(double)));
+        if ((rc = dev_alloc(c, &c->d_usum, n))) return rc;
+        OPMHIP_HIP(c, hipMemset(c->d_usum, 0, n * sizeof(double)));
+    }
     double** vecs[] = {&c->d_b, &c->d_x, &c->d_r, &c->d_rw, &c->d_p, &c->d_v, &c->d_s, &c->d_t, &c->d_pw, &c->d_vu, &c->d_stageV};
     for (double** v : vecs) {
         if ((rc = dev_alloc(c, v, n))) return rc;
@@ -63,31 +70,9 @@ static bool no_standard_wells(const opmhip_ctx* c, const opmhip_wells* w) {
     return !w || (w->num_wells <= 0 && !(w->distributed != 0 && c->comm.nranks > 1));
 }
 
-int upload_wells(opmhip_ctx* c, const opmhip_wells* w) {
+// the rank-local part of upload_wells: everything that can fail on this rank alone (validation, allocation, copies)
+static int upload_wells_local(opmhip_ctx* c, const opmhip_wells* w) {
     WellsDev& W = c->wells;
-    W.num_wells = 0;
-    W.num_ms = 0;
-    W.ms_apply = nullptr;
-    W.ms_user = nullptr;
-    W.distributed = false;
-    if (!w) return OPMHIP_SUCCESS;
-    if (w->num_ms_wells < 0 || w->num_wells < 0) return fail(c, OPMHIP_INVALID_ARGUMENT, "wells: negative well count");
-    const bool shared = w->distributed != 0 && c->comm.nranks > 1;
-    if (shared) {
-        // the list must be the same on every rank: the products travel through one all-reduce of num_wells x 4 doubles, and ranks that
-        // disagree about its length would wait for each other for ever.  max(n) and max(-n) in one reduction: every rank sees both.
-        if (!c->d_scal) return fail(c, OPMHIP_NOT_READY, "wells: distributed wells before the pattern is set");
-        double h[2] = {(double)w->num_wells, -(double)w->num_wells};
-        double* d = c->d_scal + SC_TMP1;   // SC_TMP1, SC_TMP2: scratch between solves
-        OPMHIP_HIP(c, hipMemcpyAsync(d, h, sizeof h, hipMemcpyHostToDevice, c->stream));
-        int rca = comm_allreduce(c, d, 2, 1);
-        if (rca) return rca;
-        OPMHIP_HIP(c, hipMemcpyAsync(h, d, sizeof h, hipMemcpyDeviceToHost, c->stream));
-        OPMHIP_HIP(c, hipStreamSynchronize(c->stream));
-        if (h[0] != -h[1])
-            return fail(c, OPMHIP_INVALID_ARGUMENT, "wells: distributed = 1 but the ranks hold lists of %d to %d wells (this rank: %d) - every rank must hand over the same wells in the same order",
-                        (int)-h[1], (int)h[0], w->num_wells);
-    }
     if (w->num_ms_wells > 0) {
         // multisegment wells stay with the caller (their D^-1 is a sparse LU on the host, bda/MultisegmentWellContribution.cpp:35-62):
         // what the library needs is the callback and two pinned vectors for the round trip (bda/WellContributions.cu:160-187)
@@ -122,6 +107,7 @@ int upload_wells(opmhip_ctx* c, const opmhip_wells* w) {
     if ((size_t)nw > W.cap_wells) {
         const size_t cap = std::max((size_t)nw, 2 * W.cap_wells);
         dev_free(c, &W.d_val_pointers); dev_free(c, &W.d_D); dev_free(c, &W.d_res); dev_free(c, &W.d_xw); dev_free(c, &W.d_bx);
+        W.cap_wells = 0;
         if ((rc = dev_alloc(c, &W.d_val_pointers, cap + 1))) return rc;
         if ((rc = dev_alloc(c, &W.d_D, cap * 16))) return rc;
         if ((rc = dev_alloc(c, &W.d_res, cap * 4))) return rc;
@@ -132,6 +118,7 @@ int upload_wells(opmhip_ctx* c, const opmhip_wells* w) {
     if ((size_t)np > W.cap_perf) {
         const size_t cap = std::max((size_t)np, 2 * W.cap_perf);
         dev_free(c, &W.d_Ccols); dev_free(c, &W.d_Bcols); dev_free(c, &W.d_C); dev_free(c, &W.d_B);
+        W.cap_perf = 0;
         if ((rc = dev_alloc(c, &W.d_Ccols, cap))) return rc;
         if ((rc = dev_alloc(c, &W.d_Bcols, cap))) return rc;
         if ((rc = dev_alloc(c, &W.d_C, cap * 12))) return rc;
@@ -146,8 +133,49 @@ int upload_wells(opmhip_ctx* c, const opmhip_wells* w) {
         OPMHIP_HIP(c, hipMemcpy(W.d_C, w->Cnnzs, (size_t)np * 12 * sizeof(double), hipMemcpyHostToDevice));
         OPMHIP_HIP(c, hipMemcpy(W.d_B, w->Bnnzs, (size_t)np * 12 * sizeof(double), hipMemcpyHostToDevice));
     }
-    W.num_wells = nw;
     W.nperf = np;
+    return OPMHIP_SUCCESS;
+}
+
+int upload_wells(opmhip_ctx* c, const opmhip_wells* w) {
+    WellsDev& W = c->wells;
+    W.num_wells = 0;
+    W.num_ms = 0;
+    W.ms_apply = nullptr;
+    W.ms_user = nullptr;
+    W.distributed = false;
+    if (!w) return OPMHIP_SUCCESS;
+    const bool shared = w->distributed != 0 && c->comm.nranks > 1;
+    // Everything that can fail on this rank alone runs FIRST; a shared list (every call that takes one is collective) then settles the
+    // outcome in ONE max-reduction - the list's length as max(n) and max(-n), and whether some rank failed - so that the ranks leave
+    // together: with INVALID_ARGUMENT if they hold different lists or one of them could not take its part, instead of one rank returning
+    // alone and its peers waiting in the first all-reduce of the solve that follows.  (What the reduction cannot catch: a rank that
+    // passes NULL or distributed = 0 where the others pass a shared list never enters it.)
+    int local = (w->num_ms_wells < 0 || w->num_wells < 0) ? fail(c, OPMHIP_INVALID_ARGUMENT, "wells: negative well count") : OPMHIP_SUCCESS;
+    if (!local && shared && !c->d_scal) local = fail(c, OPMHIP_NOT_READY, "wells: distributed wells before the pattern is set");
+    if (!local) local = upload_wells_local(c, w);
+    if (shared && c->d_scal) {
+        double h[3] = {(double)w->num_wells, -(double)w->num_wells, local ? 1.0 : 0.0};
+        double* d = c->d_scal + SC_TMP1;   // SC_TMP1, SC_TMP2, SC_NORM: scratch between solves
+        static_assert(SC_TMP2 == SC_TMP1 + 1 && SC_NORM == SC_TMP1 + 2, "three consecutive scratch scalars");
+        const std::string mine = c->err;   // this rank's own failure text survives the exchange
+        OPMHIP_HIP(c, hipMemcpyAsync(d, h, sizeof h, hipMemcpyHostToDevice, c->stream));
+        int rca = comm_allreduce(c, d, 3, 1);
+        if (rca) return rca;
+        OPMHIP_HIP(c, hipMemcpyAsync(h, d, sizeof h, hipMemcpyDeviceToHost, c->stream));
+        OPMHIP_HIP(c, hipStreamSynchronize(c->stream));
+        if (local) { c->err = mine; W.num_ms = 0; return local; }
+        if (h[2] != 0.0) { W.num_ms = 0; return fail(c, OPMHIP_INVALID_ARGUMENT, "wells: another rank could not take its part of the shared list"); }
+        if (h[0] != -h[1]) {
+            W.num_ms = 0;
+            return fail(c, OPMHIP_INVALID_ARGUMENT, "wells: distributed = 1 but the ranks hold lists of %d to %d wells (this rank: %d) - every rank must hand over the same wells in the same order",
+                        (int)-h[1], (int)h[0], w->num_wells);
+        }
+    } else if (local) {
+        W.num_ms = 0;
+        return local;
+    }
+    W.num_wells = w->num_wells > 0 ? w->num_wells : 0;
     W.distributed = shared;
     return OPMHIP_SUCCESS;
 }
@@ -339,6 +367,7 @@ int opmhip_solve_system(opmhip_ctx* c, int N, int nnz, int dim, double* vals, co
         OPMHIP_HIP(c, hipGetLastError());
         OPMHIP_HIP(c, hipStreamSynchronize(c->stream));
         c->factored = true;
+        c->cpr.pvals_fresh = rider.mode != 0;   // only now: the factorisation that formed weights and level 0's values has completed
         if (use_cpr(c)) {   // weights, pressure matrix, AMG values (the hierarchy's structure is built at the first solve)
             if ((rc = cpr_update(c))) return rc;
             OPMHIP_HIP(c, hipStreamSynchronize(c->stream));
@@ -391,6 +420,13 @@ int opmhip_add_well_contributions(opmhip_ctx* c, const opmhip_wells* wells) {
     if (!c) return OPMHIP_INVALID_ARGUMENT;
     return guarded(c, [&]() -> int {
         if (!c->system_loaded && !c->asmb.assembled) return fail(c, OPMHIP_NOT_READY, "add_well_contributions: no matrix on the device");
+        // A well shared by several subdomains has blocks -C_c^T D^-1 B_b with c and b on different ranks: they are in no rank's pattern
+        // (the reference's matrix-add mode keeps every well inside one process, ebos/eclbasevanguard.hh:148-151 with
+        // --matrix-add-well-contributions).  Refused on every rank alike - the flag and the communicator are the same everywhere - before
+        // any collective is entered; shared wells go through the operator form (opmhip_solve_system's `wells`).
+        if (wells && wells->distributed != 0 && c->comm.nranks > 1)
+            return fail(c, OPMHIP_INVALID_ARGUMENT, "add_well_contributions: a shared list (distributed = 1) cannot be written into the matrix - the blocks that couple "
+                                                    "perforations of different subdomains are in no rank's pattern; hand it to opmhip_solve_system instead");
         if (no_standard_wells(c, wells)) return OPMHIP_SUCCESS;
         OPMHIP_HIP(c, hipSetDevice(c->device));
         int rc;
@@ -536,6 +572,31 @@ int opmhip_ilu0_apply(opmhip_ctx* c, const double* d, double* v) {
     });
 }
 
+int opmhip_preconditioned_product(opmhip_ctx* c, const double* d, double* t, double* z) {
+    if (!c) return OPMHIP_INVALID_ARGUMENT;
+    return guarded(c, [&]() -> int {
+        if (!d || !t) return fail(c, OPMHIP_INVALID_ARGUMENT, "preconditioned_product: null vector");
+        if (!c->factored) return fail(c, OPMHIP_NOT_READY, "preconditioned_product before ilu0_factor");
+        OPMHIP_HIP(c, hipSetDevice(c->device));
+        int rc;
+        if ((rc = vec_in(c, d, c->d_p))) return rc;
+        // BiCGStab's statements for one half iteration (solver.hip: enqueue_half): the sweeps leave the vector without the relaxation factor,
+        // the product applies it; with the half-product form the backward sweeps' row sums go along
+        double scale = 1.0;
+        double* us = c->half_product ? c->d_usum : nullptr;
+        launch_ilu_apply(c, c->d_p, c->d_pw, -1.0, &scale, nullptr, nullptr, us);
+        if ((rc = launch_spmv(c, c->d_pw, c->d_v, 0, nullptr, scale, true, us))) return rc;
+        OPMHIP_HIP(c, hipGetLastError());
+        if ((rc = vec_out(c, c->d_v, t))) return rc;
+        if (z) {   // M^-1 d itself, relaxation factor applied (one rounded product per entry, as its readers form it)
+            if ((rc = vec_out(c, c->d_pw, z))) return rc;
+            if (scale != 1.0)
+                for (size_t i = 0; i < (size_t)c->pat.Nb * BS; ++i) z[i] = scale * z[i];
+        }
+        return OPMHIP_SUCCESS;
+    });
+}
+
 int opmhip_set_cpr_weights(opmhip_ctx* c, const double* weights) {
     if (!c) return OPMHIP_INVALID_ARGUMENT;
     return guarded(c, [&]() -> int {
@@ -604,6 +665,17 @@ int opmhip_get_ordering_info(opmhip_ctx* c, int info[4]) {
     return OPMHIP_SUCCESS;
 }
 
+int opmhip_get_product_form(opmhip_ctx* c, int info[4]) {
+    if (!c || !info) return OPMHIP_INVALID_ARGUMENT;
+    if (!c->pattern_set) return fail(c, OPMHIP_NOT_READY, "get_product_form before set_pattern");
+    const Pattern& P = c->pat;
+    info[0] = (c->half_product && !use_cpr(c)) ? 1 : 0;
+    info[1] = P.ualias ? 1 : 0;
+    info[2] = P.nr;
+    info[3] = P.rest.on ? P.rest.nsched : 0;
+    return OPMHIP_SUCCESS;
+}
+
 int opmhip_profile_enable(opmhip_ctx* c, int on) {
     if (!c) return OPMHIP_INVALID_ARGUMENT;
     return guarded(c, [&]() -> int {
@@ -655,7 +727,8 @@ int opmhip_cpr_levels(opmhip_ctx* c, int* n, int* nnz, int cap) {
 int opmhip_time_kernel(opmhip_ctx* c, int which, int reps, double* ms_per_launch) {
     if (!c) return OPMHIP_INVALID_ARGUMENT;
     return guarded(c, [&]() -> int {
-        if (!ms_per_launch || reps < 1 || which < 0 || which > 6) return fail(c, OPMHIP_INVALID_ARGUMENT, "time_kernel: bad arguments");
+        if (!ms_per_launch || reps < 1 || which < 0 || which > 9) return fail(c, OPMHIP_INVALID_ARGUMENT, "time_kernel: bad arguments");
+        if (which >= 7 && !c->half_product) return fail(c, OPMHIP_NOT_READY, "time_kernel: the half-product form is not in force on this context");
         if (!c->system_loaded) return fail(c, OPMHIP_NOT_READY, "time_kernel before a matrix was uploaded");
         if (which != 2 && which != 4 && !c->factored) return fail(c, OPMHIP_NOT_READY, "time_kernel: factor first");
         OPMHIP_HIP(c, hipSetDevice(c->device));
@@ -668,6 +741,9 @@ int opmhip_time_kernel(opmhip_ctx* c, int which, int reps, double* ms_per_launch
                 case 4: launch_stream_read(c); break;
                 case 5: (void)launch_spmv(c, c->d_pw, c->d_v, 1, c->d_rw); break;   // with the partial sums of y.w0
                 case 6: (void)launch_spmv(c, c->d_pw, c->d_v, 2, c->d_r); break;    // ... and of y.y
+                case 7: (void)launch_spmv(c, c->d_pw, c->d_v, 0, nullptr, 1.0, false, c->d_usum); break;   // the rest product
+                case 8: (void)launch_spmv(c, c->d_pw, c->d_v, 2, c->d_r, 1.0, false, c->d_usum); break;    // ... with two scalar products
+                case 9: launch_ilu_apply(c, c->d_p, c->d_pw, -1.0, nullptr, nullptr, nullptr, c->d_usum); break;   // M^-1 with the row sums stored
             }
         };
         once();  // warm

@@ -1287,7 +1287,8 @@ int cpr_factor_rider(opmhip_ctx* c, FactorRider* r) {
     r->pcol = R.d_pcol;
     r->W = R.lv[0].W;
     r->ghostFrom = (c->pat.Nghost > 0 && !cpr_gathering(c)) ? c->pat.Nb : INT_MAX;
-    R.pvals_fresh = true;
+    // (CprDev::pvals_fresh is raised by the caller once the factorisation that carries this rider has run without an error: a solve that
+    //  leaves before that must not make the next cpr_update skip its own pass over the matrix)
     return OPMHIP_SUCCESS;
 }
 // levels of up to this many rows are kept row-major and run the lane-group kernels (OPMHIP_CPR_LPR_ROWS: measurement switch)
@@ -1621,6 +1622,8 @@ static int cpr_gather_setup(opmhip_ctx* c, const CprHostCoarse& H) {
     // then leave together, the failed one with its own status, the others with a status that names it.
     int lerr = 0, rc;
     auto note = [&](int e) { if (e && !lerr) lerr = e; };
+    // a HIP call between two exchanges goes through note() as well (OPMHIP_HIP would return at once, alone)
+    auto hipnote = [&](hipError_t e, const char* what) { if (e != hipSuccess) note(fail(c, OPMHIP_DEVICE_ERROR, "%s failed: %s (cpr_gather_setup)", what, hipGetErrorString(e))); };
     auto first_failed = [&](const std::vector<char>& b, size_t stride, size_t at, const char* where) -> int {   // the flag at byte `at` of every rank's record
         for (int r = 0; r < nr; ++r) {
             int f;
@@ -1658,11 +1661,11 @@ static int cpr_gather_setup(opmhip_ctx* c, const CprHostCoarse& H) {
     std::vector<double> hv((size_t)2 * P.Nloc, 0.0);
     for (int i = 0; i < P.Nb; ++i) { hv[(size_t)2 * i] = (double)(offs[me] + cagg[i]); hv[(size_t)2 * i + 1] = (double)(foffs[me] + i); }
     {
-        double* d_hv = c->d_stageV;   // 3 doubles per local cell, idle between the uploads and the solve: nothing to allocate, nothing to fail
-        OPMHIP_HIP(c, hipMemcpyAsync(d_hv, hv.data(), hv.size() * sizeof(double), hipMemcpyHostToDevice, c->stream));
-        if ((rc = comm_halo_f64(c, d_hv, 2))) return rc;
-        OPMHIP_HIP(c, hipMemcpyAsync(hv.data(), d_hv, hv.size() * sizeof(double), hipMemcpyDeviceToHost, c->stream));
-        OPMHIP_HIP(c, hipStreamSynchronize(c->stream));
+        double* d_hv = c->d_stageV;   // 3 doubles per local cell, idle between the uploads and the solve: nothing to allocate
+        hipnote(hipMemcpyAsync(d_hv, hv.data(), hv.size() * sizeof(double), hipMemcpyHostToDevice, c->stream), "hipMemcpyAsync");
+        if ((rc = comm_halo_f64(c, d_hv, 2))) return rc;   // (a failed exchange is every rank's: the communicator reports it to all)
+        hipnote(hipMemcpyAsync(hv.data(), d_hv, hv.size() * sizeof(double), hipMemcpyDeviceToHost, c->stream), "hipMemcpyAsync");
+        hipnote(hipStreamSynchronize(c->stream), "hipStreamSynchronize");
     }
     // 4. my rows of the joined level: my last level's entries, and one entry per pair (my aggregate, an aggregate of another rank) that a
     //    fine coupling joins
@@ -1684,8 +1687,8 @@ static int cpr_gather_setup(opmhip_ctx* c, const CprHostCoarse& H) {
     note(dev_alloc(c, &G.d_apg, (size_t)std::max(G.nq, 1)));
     if (G.nq > 0 && !lerr) {
         hipLaunchKernelGGL(k_cpr_ghost_pvals, g256(G.nq), dim3(256), 0, c->stream, G.nq, G.d_qrow, G.d_qentry, c->d_A, R.d_w, G.d_apg);
-        OPMHIP_HIP(c, hipMemcpyAsync(apg.data(), G.d_apg, (size_t)G.nq * sizeof(double), hipMemcpyDeviceToHost, c->stream));
-        OPMHIP_HIP(c, hipStreamSynchronize(c->stream));
+        hipnote(hipMemcpyAsync(apg.data(), G.d_apg, (size_t)G.nq * sizeof(double), hipMemcpyDeviceToHost, c->stream), "hipMemcpyAsync");
+        hipnote(hipStreamSynchronize(c->stream), "hipStreamSynchronize");
     }
     const HCsr& LA = H.lastA;
     std::vector<int> rowlen(nloc, 0), cols, src, xptr(1, 0), xidx;
@@ -1767,7 +1770,7 @@ static int cpr_gather_setup(opmhip_ctx* c, const CprHostCoarse& H) {
     G.nloc = nloc; G.off = offs[me]; G.NG = NG; G.maxn = maxn; G.maxnnz = maxnnz; G.nnzG = (int)J.col.size();
     if (!lerr) note(dev_alloc(c, &G.d_recv, (size_t)nr * maxn));
     if (!lerr) note(dev_alloc(c, &G.d_vsend, (size_t)maxnnz));
-    if (!lerr) OPMHIP_HIP(c, hipMemsetAsync(G.d_vsend, 0, (size_t)maxnnz * sizeof(double), c->stream));
+    if (!lerr) hipnote(hipMemsetAsync(G.d_vsend, 0, (size_t)maxnnz * sizeof(double), c->stream), "hipMemsetAsync");
     if (!lerr) note(dev_alloc(c, &G.d_vrecv, (size_t)nr * maxnnz));
     if (!lerr) note(dev_upload(c, &G.d_unpad, unpad));
     if (!lerr) note(dev_upload(c, &G.d_vunpad, vunpad));
@@ -1777,7 +1780,7 @@ static int cpr_gather_setup(opmhip_ctx* c, const CprHostCoarse& H) {
     if (!lerr) note(dev_upload(c, &G.d_xidx, xidx));
     if (!lerr) note(dev_upload(c, &G.d_cagg, cagg));
     if (!lerr) note(dev_alloc(c, &G.d_send, (size_t)maxn));   // my slice of the joined level's right-hand side: room for the largest slice
-    if (!lerr) OPMHIP_HIP(c, hipMemsetAsync(G.d_send, 0, (size_t)maxn * sizeof(double), c->stream));
+    if (!lerr) hipnote(hipMemsetAsync(G.d_send, 0, (size_t)maxn * sizeof(double), c->stream), "hipMemsetAsync");
     if ((rc = cpr_host_allgather(c, &lerr, sizeof lerr, buf))) return rc;
     if ((rc = first_failed(buf, sizeof lerr, 0, "uploads of the joined level"))) return rc;
     G.on = true;

@@ -72,6 +72,22 @@ struct TileSet {            // tiles over one block-CSR row-pointer array, never
     int ntiles() const { return (int)row0.size() - 1; }
 };
 
+// Launch schedule of the "rest product" (Pattern::ualias): the tiles of y = R x + s u over the block-CSR of the matrix entries that are NOT
+// in the factor's U part - lower entries, diagonal, ghost columns.  Same record formats as the SpMV's stencil form (TileSet::spmvSched /
+// stWord / stKoff / stTable, read by k_spmv_pipe_st); tiles hold up to 64 rows (one per lane) and TILE_CAP_BLOCKS blocks.
+struct RestSched {
+    bool on = false;
+    int nsched = 0, nschedInt = 0;            // launch positions; [0, nschedInt) interior tiles, the rest boundary tiles (decomposed runs)
+    std::vector<int> sched;                   // [4 * nsched] (r0, r1, rrowptr[r0], rrowptr[r1]); r1 <= r0 = padding
+    std::vector<unsigned> word;               // per row: eight 4-bit table indices (15 = no entry)
+    std::vector<unsigned char> koff;          // per row: first entry - the tile's first entry
+    std::vector<int> table;                   // [16 * nsched]
+    int* d_sched = nullptr;
+    unsigned* d_word = nullptr;
+    unsigned char* d_koff = nullptr;
+    int* d_table = nullptr;
+};
+
 struct Pattern {
     int Nb = 0, nnzb = 0, numColors = 0, nl = 0, nu = 0;  // Nb = owned block rows
     int Nghost = 0, Nloc = 0;                            // ghost cells numbered Nb..Nloc-1 (vectors have Nloc entries)
@@ -109,6 +125,17 @@ struct Pattern {
     // triangles: it is the diagonal) as U index * 64 + offset of the target in row i; -1: none; -2: several (the general search)
     std::vector<int> lmatch;
     int* d_lmatch = nullptr;
+    // "U is upper(A)": no elimination step of the block ILU0 touches an entry right of the diagonal (linalg/ParallelOverlappingILU0.hpp:466-481
+    // modifies A_ik only where (i,j), (j,k) and (i,k) all exist: on a pattern without triangles that is k == i alone), so the factor's U part
+    // equals the matrix's own upper part bit for bit and the backward sweep's row sums u_i = sum_{j>i} U_ij x_j ARE the upper part of A x.
+    // The product that follows an M^-1 application inside BiCGStab then needs only the REST of the matrix (lower entries, diagonal, ghost
+    // columns): y_i = sum_rest A_ik x_k + u_i.  rrowptr / rcol: that rest as a block-CSR of its own, ascending columns; rdest: per matrix entry
+    // its place there or -1; its values (d_R in the context) are written by the factorisation from the rows it has staged.
+    bool ualias = false;
+    int nr = 0;
+    std::vector<int> rrowptr, rcol, rdest;
+    int *d_rdest = nullptr, *d_rrowptr = nullptr;
+    RestSched rest;
 };
 
 struct WellsDev {
@@ -338,6 +365,8 @@ struct opmhip_ctx {
     opmhip::Pattern pat;
     // values, internal order
     double *d_A = nullptr, *d_L = nullptr, *d_U = nullptr, *d_invD = nullptr;
+    double *d_R = nullptr, *d_usum = nullptr;   // Pattern::ualias: the rest of the matrix beside U (values), the backward sweeps' row sums (3 per row)
+    bool half_product = false;                  // BiCGStab forms the product after an ILU0 application from d_R and d_usum (opmhip_config.half_product)
     // vectors, internal order, 3*Nb each
     double *d_b = nullptr, *d_x = nullptr, *d_r = nullptr, *d_rw = nullptr, *d_p = nullptr, *d_v = nullptr,
            *d_s = nullptr, *d_t = nullptr, *d_pw = nullptr, *d_vu = nullptr;
@@ -526,13 +555,14 @@ void launch_vec_to_natural(opmhip_ctx* c, const double* internal, double* nat, i
 void launch_zero_diag_fix(opmhip_ctx* c);
 // y = A x (+ wells) with the partial sums of ndot scalar products.  exchange: x's ghost entries are brought up to date first
 // (copyOwnerToAll) - on the halo stream, beside the product of the interior tiles; x is then written (its ghost part)
-int launch_spmv(opmhip_ctx* c, double* x, double* y, int ndot, const double* w0, double xs = 1.0, bool exchange = false);
+int launch_spmv(opmhip_ctx* c, double* x, double* y, int ndot, const double* w0, double xs = 1.0, bool exchange = false, const double* uadd = nullptr);
+bool half_product_wanted(const opmhip_ctx* c);   // solver.hip: opmhip_config.half_product resolved for the pattern in hand (asked once, when the system's buffers are allocated)
 void launch_wells_residual(opmhip_ctx* c, const double* d_resWell, double* r);
 void launch_wells_add_to_matrix(opmhip_ctx* c, int w0, int nw, int serial, const int* d_pair_ptr, const int* d_entry);
 int launch_wells_recover(opmhip_ctx* c, const double* d_resWell, const double* x, double* d_xw);   // distributed wells: one all-reduce inside
 void launch_ilu_factor(opmhip_ctx* c, bool fix_zero_diagonal = false, const FactorRider* rider = nullptr);
 int cpr_factor_rider(opmhip_ctx* c, FactorRider* r);   // cpr.hip: level 0 in place, this solve's weights where they do not come from the matrix; r->mode = 0: no rider this time
-void launch_ilu_apply(opmhip_ctx* c, const double* d, double* v, double w_override = -1.0, double* unscaled = nullptr, const double* addp = nullptr, double* work = nullptr);
+void launch_ilu_apply(opmhip_ctx* c, const double* d, double* v, double w_override = -1.0, double* unscaled = nullptr, const double* addp = nullptr, double* work = nullptr, double* usum = nullptr);
 // cpr.hip
 // solveBoundary: the --cpr-reuse-setup rules are looked at (a structure may be rebuilt, started or swapped in); false (opmhip_cpr_apply:
 // a look at the preconditioner between two solves): values only, the structure stays as the last solve left it

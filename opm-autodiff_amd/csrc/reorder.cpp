@@ -210,6 +210,82 @@ void color_chains(const Pattern& P, const Chains& C, std::vector<int>& chainColo
 // GROUPS of `G` consecutive chain-tiles of every colour at the same relative position of their colour - the same stretch
 // of the grid - so that most neighbours of a tile are gathered through the L2 that already holds them.
 // Results do not depend on the schedule (each tile's arithmetic is its own); only the order of the partial sums does.
+// Launch schedule of the rest product (internal.hpp: RestSched).  The tiles follow the SpMV's launch order - position b and b + 8 of it are
+// consecutive tiles of one stretch of the grid on one XCD - and consecutive tiles are merged while the rows stay contiguous, the tile holds
+// at most 64 rows (one per lane) and TILE_CAP_BLOCKS blocks and its rows share at most 15 column offsets: a row of the rest has 2 - 6 blocks
+// where the full row has 7, so a tile of the SpMV's 32 rows would stream 4.6 - 13.8 KB per step of the pipelined kernel instead of 16.
+// Off (R.on = false) unless the pattern has the property the product rests on (Pattern::ualias), the ordering is line-coloured (the chain
+// sweeps are the ones that emit the row sums) and every tile fits the stencil form.
+void build_rest_schedule(Pattern& P, const std::vector<int>& order) {
+    RestSched& R = P.rest;
+    const TileSet& T = P.tiles;
+    R.on = false;
+    if (!P.ualias || !P.chained) return;
+    struct Rt { int r0, r1; };
+    auto offsets_of = [&](int r0, int r1, std::vector<int>& offs) {
+        offs.clear();
+        for (int r = r0; r < r1; ++r)
+            for (int k = P.rrowptr[r]; k < P.rrowptr[r + 1]; ++k) offs.push_back(P.rcol[k] - r);
+        std::sort(offs.begin(), offs.end());
+        offs.erase(std::unique(offs.begin(), offs.end()), offs.end());
+    };
+    std::vector<int> offs;
+    std::vector<Rt> out;   // launch positions of both parts, padding = {0, 0}
+    int nInt = 0;
+    for (int part = 0; part < 2; ++part) {
+        const int p0 = part == 0 ? 0 : T.nschedInt, p1 = part == 0 ? T.nschedInt : T.nsched;
+        std::vector<std::vector<Rt>> lists(8);
+        for (int k = 0; k < 8; ++k) {
+            Rt cur{0, 0};
+            for (int b = p0 + k; b < p1; b += 8) {
+                if (order[b] < 0) continue;
+                const int r0 = T.row0[order[b]], r1 = T.row0[order[b] + 1];
+                if (r1 <= r0) continue;
+                if (cur.r1 > cur.r0 && r0 == cur.r1 && r1 - cur.r0 <= 64 && P.rrowptr[r1] - P.rrowptr[cur.r0] <= TILE_CAP_BLOCKS) {
+                    offsets_of(cur.r0, r1, offs);
+                    if (offs.size() <= 15) { cur.r1 = r1; continue; }
+                }
+                if (cur.r1 > cur.r0) lists[k].push_back(cur);
+                cur = Rt{r0, r1};
+            }
+            if (cur.r1 > cur.r0) lists[k].push_back(cur);
+        }
+        size_t L = 0;
+        for (const auto& l : lists) L = std::max(L, l.size());
+        for (size_t j = 0; j < L; ++j)
+            for (int k = 0; k < 8; ++k) out.push_back(j < lists[k].size() ? lists[k][j] : Rt{0, 0});
+        if (part == 0) nInt = (int)out.size();
+    }
+    R.nsched = (int)out.size();
+    R.nschedInt = nInt;
+    R.sched.assign((size_t)4 * R.nsched, 0);
+    R.word.assign(P.Nb, 0xFFFFFFFFu);
+    R.koff.assign(P.Nb, 0);
+    R.table.assign((size_t)16 * std::max(1, R.nsched), 0);
+    for (int b = 0; b < R.nsched; ++b) {
+        const int r0 = out[b].r0, r1 = out[b].r1;
+        if (r1 <= r0) continue;
+        R.sched[4 * b] = r0; R.sched[4 * b + 1] = r1;
+        R.sched[4 * b + 2] = P.rrowptr[r0]; R.sched[4 * b + 3] = P.rrowptr[r1];
+        if (P.rrowptr[r1] - P.rrowptr[r0] > TILE_CAP_BLOCKS || r1 - r0 > 64) return;   // a single SpMV tile too large for the form: off
+        offsets_of(r0, r1, offs);
+        if (offs.size() > 15) return;
+        for (size_t q = 0; q < offs.size(); ++q) R.table[(size_t)16 * b + q] = offs[q];
+        for (int r = r0; r < r1; ++r) {
+            const int len = P.rrowptr[r + 1] - P.rrowptr[r], ko = P.rrowptr[r] - P.rrowptr[r0];
+            if (len > 8 || ko > 255) return;
+            unsigned w = 0xFFFFFFFFu;
+            for (int u = 0; u < len; ++u) {
+                const int idx = (int)(std::lower_bound(offs.begin(), offs.end(), P.rcol[P.rrowptr[r] + u] - r) - offs.begin());
+                w = (w & ~(0xFu << (4 * u))) | ((unsigned)idx << (4 * u));
+            }
+            R.word[r] = w;
+            R.koff[r] = (unsigned char)ko;
+        }
+    }
+    R.on = R.nsched > 0;
+}
+
 void build_schedules(Pattern& P, int G) {
     TileSet& T = P.tiles;
     const int ncol = P.numColors;
@@ -339,6 +415,7 @@ void build_schedules(Pattern& P, int G) {
         }
     }
     T.stencil = T.stencilPart[0] || T.stencilPart[1];
+    build_rest_schedule(P, order);
     // the same for the two factor parts the sweeps stream (chained orderings only: their kernels are the ones that read it)
     P.sweepStencil = P.chained;
     for (int part = 0; part < 2 && P.sweepStencil; ++part) {
@@ -579,6 +656,32 @@ int build_pattern(opmhip_ctx* c, int Nb, int Nghost, int nnzb, const int* rows, 
             else if (count == 1 && target < 64 && uidx < (1 << 25)) P.lmatch[k] = uidx * 64 + target;
         }
     }
+    // U == upper(A)?  (Pattern::ualias)  Every match of an elimination step must lie on or left of the diagonal of the row being eliminated.
+    P.ualias = true;
+    for (int p = 0; p < Nb && P.ualias; ++p) {
+        const int kb = P.rowptr[p], ke = P.rowptr[p + 1];
+        for (int k = kb; k < ke && P.ualias; ++k) {
+            const int j = P.col[k];
+            if (j >= p) break;
+            int ik = k + 1, jk = P.urowptr[j];
+            const int jend = P.urowptr[j + 1];
+            while (ik < ke && jk < jend) {
+                if (P.col[ik] == P.ucol[jk]) { if (P.col[ik] > p) { P.ualias = false; break; } ++ik; ++jk; }
+                else if (P.col[ik] < P.ucol[jk]) ++ik;
+                else ++jk;
+            }
+        }
+    }
+    // the rest of the matrix beside the U part, as a block-CSR of its own (ascending columns: the order of the full row without its U entries)
+    P.rrowptr.assign(Nb + 1, 0);
+    P.rcol.clear();
+    P.rdest.assign(P.nnzb, -1);
+    for (int p = 0; p < Nb; ++p) {
+        for (int k = P.rowptr[p]; k < P.rowptr[p + 1]; ++k)
+            if (P.fdest[k] > -2) { P.rdest[k] = (int)P.rcol.size(); P.rcol.push_back(P.col[k]); }
+        P.rrowptr[p + 1] = (int)P.rcol.size();
+    }
+    P.nr = (int)P.rcol.size();
     P.lightL.assign(ncol, 0);
     P.lightU.assign(ncol, 0);
     if (chained) {
@@ -663,6 +766,14 @@ int build_pattern(opmhip_ctx* c, int Nb, int Nghost, int nnzb, const int* rows, 
     if ((rc = dev_upload(c, &P.d_ucol, P.ucol))) return rc;
     if ((rc = dev_upload(c, &P.d_fdest, P.fdest))) return rc;
     if ((rc = dev_upload(c, &P.d_lmatch, P.lmatch))) return rc;
+    if (P.rest.on) {
+        if ((rc = dev_upload(c, &P.d_rdest, P.rdest))) return rc;
+        if ((rc = dev_upload(c, &P.d_rrowptr, P.rrowptr))) return rc;
+        if ((rc = dev_upload(c, &P.rest.d_sched, P.rest.sched))) return rc;
+        if ((rc = dev_upload(c, &P.rest.d_word, P.rest.word))) return rc;
+        if ((rc = dev_upload(c, &P.rest.d_koff, P.rest.koff))) return rc;
+        if ((rc = dev_upload(c, &P.rest.d_table, P.rest.table))) return rc;
+    }
     if ((rc = dev_upload(c, &P.tiles.d_row0, P.tiles.row0))) return rc;
     if ((rc = dev_upload(c, &P.tiles.d_ctFirst, P.tiles.ctFirst))) return rc;
     return OPMHIP_SUCCESS;

@@ -42,6 +42,10 @@ __device__ __forceinline__ double2 ld_stream(const double2* p) {
     return make_double2(t.x, t.y);
 #endif
 }
+// the backward sweeps' row sums: written once per application, read once by the product that follows
+__device__ __forceinline__ void st_rowsum(double* p, double v) {
+    __builtin_nontemporal_store(v, p);   // one M^-1 with the row sums back to back: 0.136 - 0.139 ms with plain stores, 0.132 - 0.133 nontemporal
+}
 __device__ __forceinline__ void stage_doubles(const double* __restrict__ src, double* __restrict__ dst, int n, int lane) {
     const double2* __restrict__ s2 = reinterpret_cast<const double2*>(src);
     double2* __restrict__ d2 = reinterpret_cast<double2*>(dst);
@@ -107,6 +111,20 @@ __device__ __forceinline__ void blk_mmv_lds(const double* Agen, const double x0,
     y[0] -= A[0] * x0; y[0] -= A[1] * x1; y[0] -= A[2] * x2;
     y[1] -= A[3] * x0; y[1] -= A[4] * x1; y[1] -= A[5] * x2;
     y[2] -= A[6] * x0; y[2] -= A[7] * x1; y[2] -= A[8] * x2;
+}
+// y -= A x and, beside it, u += A x from the SAME rounded products: the backward sweep's row sums u_i = sum_{j>i} U_ij x_j (Pattern::ualias)
+__device__ __forceinline__ void blk_mmv_u(const double* A, const double x0, const double x1, const double x2, double* y, double* u) {
+    double p;
+    p = A[0] * x0; y[0] -= p; u[0] += p; p = A[1] * x1; y[0] -= p; u[0] += p; p = A[2] * x2; y[0] -= p; u[0] += p;
+    p = A[3] * x0; y[1] -= p; u[1] += p; p = A[4] * x1; y[1] -= p; u[1] += p; p = A[5] * x2; y[1] -= p; u[1] += p;
+    p = A[6] * x0; y[2] -= p; u[2] += p; p = A[7] * x1; y[2] -= p; u[2] += p; p = A[8] * x2; y[2] -= p; u[2] += p;
+}
+__device__ __forceinline__ void blk_mmv_lds_u(const double* Agen, const double x0, const double x1, const double x2, double* y, double* u) {
+    lds_cdouble* A = (lds_cdouble*)Agen;
+    double p;
+    p = A[0] * x0; y[0] -= p; u[0] += p; p = A[1] * x1; y[0] -= p; u[0] += p; p = A[2] * x2; y[0] -= p; u[0] += p;
+    p = A[3] * x0; y[1] -= p; u[1] += p; p = A[4] * x1; y[1] -= p; u[1] += p; p = A[5] * x2; y[1] -= p; u[1] += p;
+    p = A[6] * x0; y[2] -= p; u[2] += p; p = A[7] * x1; y[2] -= p; u[2] += p; p = A[8] * x2; y[2] -= p; u[2] += p;
 }
 __device__ __forceinline__ void blk_umv_lds(const double* Agen, const double x0, const double x1, const double x2, double* y) {
     lds_cdouble* A = (lds_cdouble*)Agen;
@@ -579,12 +597,15 @@ __global__ __launch_bounds__(64) void k_spmv_pipe(int npos, const int4* __restri
 // M (one ahead) turns them into column indices (table entries travel lane to lane, no LDS, no memory) and gathers.  No row
 // bounds, no column indices: 5 bytes per row instead of 44, and the gathers wait for ONE round of loads instead of two.
 // Same tiles, same per-row arithmetic in the same order as k_spmv_pipe: the same bits.
-template <int NDOT>
+// UADD (the "rest product", Pattern::ualias): val / sched / stWord ... describe the matrix WITHOUT its U part and the row's sum ends with
+// + xs * uadd_i, uadd = the row sums sum_{j>i} U_ij x_j the backward sweep of the ILU0 application left behind (U == upper(A) bit for bit):
+// y_i = (sum over the lower entries, the diagonal and the ghost columns, ascending, of A_ik (xs x_k)) + xs u_i.
+template <int NDOT, bool UADD = false>
 __global__ __launch_bounds__(64) void k_spmv_pipe_st(int npos, const int4* __restrict__ sched, const unsigned* __restrict__ stWord,
                                                      const unsigned char* __restrict__ stKoff, const int* __restrict__ stTable,
                                                      const double* __restrict__ val, const double* __restrict__ x, double* __restrict__ y,
                                                      const double* __restrict__ w0, double* __restrict__ part, int npart,
-                                                     const double* __restrict__ done, double xs) {
+                                                     const double* __restrict__ done, double xs, const double* __restrict__ uadd = nullptr) {
     TILE_LDS
     __shared__ int4 ssched[PIPE_MAX_STEPS];
     const int lane = threadIdx.x, G = gridDim.x;
@@ -607,6 +628,7 @@ __global__ __launch_bounds__(64) void k_spmv_pipe_st(int npos, const int4* __res
         int kb, nrow;
         double xx[PGCH][3];
         double ww[NDOT >= 1 ? 3 : 1];
+        double uu[UADD ? 3 : 1];
     };
     auto clampst = [&](int st) { return st < nsteps ? st : nsteps - 1; };
     auto row_of = [&](int st, bool& active) {   // LDS only
@@ -655,6 +677,10 @@ __global__ __launch_bounds__(64) void k_spmv_pipe_st(int npos, const int4* __res
             const double* wr = &w0[(size_t)rr * BS];
             b.ww[0] = wr[0]; b.ww[1] = wr[1]; b.ww[2] = wr[2];
         }
+        if (UADD) {
+            const double* ur = &uadd[(size_t)rr * BS];
+            b.uu[0] = ur[0]; b.uu[1] = ur[1]; b.uu[2] = ur[2];
+        }
     };
     StW wq;
     StS sb;
@@ -688,6 +714,7 @@ __global__ __launch_bounds__(64) void k_spmv_pipe_st(int npos, const int4* __res
 #pragma unroll
             for (int u = 0; u < PGCH; ++u)
                 if (u < nrow) blk_umv_lds(&sval[(kb + u - k0e) * BB], xs * m.xx[u][0], xs * m.xx[u][1], xs * m.xx[u][2], acc);
+            if (UADD) { acc[0] += xs * m.uu[0]; acc[1] += xs * m.uu[1]; acc[2] += xs * m.uu[2]; }
             double* yr = &y[(size_t)r * BS];
             yr[0] = acc[0]; yr[1] = acc[1]; yr[2] = acc[2];
             if (NDOT >= 1) {
@@ -801,13 +828,13 @@ struct SweepStencil {
     const unsigned char* __restrict__ koff;
     const int* __restrict__ table;   // [16 * number of tiles]
 };
-template <int SHAPE, bool ST = false>  // SW_L or SW_UF; ST: column indices and row bounds from the stencil form (q0 = the chain-tile's first tile)
+template <int SHAPE, bool ST = false, bool UA = false>  // SW_L or SW_UF; ST: column indices and row bounds from the stencil form (q0 = the chain-tile's first tile); UA (SW_UF): the row sums sum_j U_ij x_j are left in ua (Pattern::ualias)
 __device__ __forceinline__ void chain_sweep(const int nsteps, const int lane, double* sval, const int* srow0, const int* sk0,
                                             const int* __restrict__ prow,
                                             const int* __restrict__ pcol, const double* __restrict__ P,
                                             const double* __restrict__ invD, const double* d,
                                             double* vu, double* v, const double* __restrict__ addp, int relax_mode, double w,
-                                            const SweepStencil S = SweepStencil{nullptr, nullptr, nullptr}, const int q0 = 0) {
+                                            const SweepStencil S = SweepStencil{nullptr, nullptr, nullptr}, const int q0 = 0, double* __restrict__ ua = nullptr) {
     // nsteps <= CHAIN_MAX_STEPS (checked on the host); srow0[0..nsteps], sk0[0..nsteps]: first row / first entry of every
     // step, out of the chain-tile's descriptor record (LDS) - no dependent loads here
     const bool reverse = (SHAPE == SW_UF) && relax_mode == 0;
@@ -1011,6 +1038,7 @@ __device__ __forceinline__ void chain_sweep(const int nsteps, const int lane, do
             const bool fromMem = (m.late & ~m.mine & used) != 0u;
             if (__any(fromMem || nrow > CGCH)) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             double rhs[3] = {m.rhs[0], m.rhs[1], m.rhs[2]};
+            double us[3] = {0.0, 0.0, 0.0};
 #pragma unroll
             for (int u = 0; u < CGCH; ++u) {
                 if (u < nrow) {
@@ -1022,8 +1050,13 @@ __device__ __forceinline__ void chain_sweep(const int nsteps, const int lane, do
                     }
                     // LDS or global memory by a (scalar) branch, never by one pointer: a pointer that may be either is "flat",
                     // and a flat load waits for every outstanding memory access - the next step's prefetch included
-                    if (staged) blk_mmv_lds(&sval[(k - k0e) * BB], x0, x1, x2, rhs);
-                    else blk_mmv(&P[(size_t)k * BB], x0, x1, x2, rhs);
+                    if (UA) {
+                        if (staged) blk_mmv_lds_u(&sval[(k - k0e) * BB], x0, x1, x2, rhs, us);
+                        else blk_mmv_u(&P[(size_t)k * BB], x0, x1, x2, rhs, us);
+                    } else {
+                        if (staged) blk_mmv_lds(&sval[(k - k0e) * BB], x0, x1, x2, rhs);
+                        else blk_mmv(&P[(size_t)k * BB], x0, x1, x2, rhs);
+                    }
                 }
             }
             for (int done = CGCH; done < nrow; done += CGCH) {  // rows longer than one chunk: everything read now
@@ -1039,8 +1072,13 @@ __device__ __forceinline__ void chain_sweep(const int nsteps, const int lane, do
                 for (int u = 0; u < CGCH; ++u) {
                     if (done + u < nrow) {
                         const int k = reverse ? ke - 1 - (done + u) : kb + done + u;
-                        if (staged) blk_mmv_lds(&sval[(k - k0e) * BB], yy[u][0], yy[u][1], yy[u][2], rhs);
-                        else blk_mmv(&P[(size_t)k * BB], yy[u][0], yy[u][1], yy[u][2], rhs);
+                        if (UA) {
+                            if (staged) blk_mmv_lds_u(&sval[(k - k0e) * BB], yy[u][0], yy[u][1], yy[u][2], rhs, us);
+                            else blk_mmv_u(&P[(size_t)k * BB], yy[u][0], yy[u][1], yy[u][2], rhs, us);
+                        } else {
+                            if (staged) blk_mmv_lds(&sval[(k - k0e) * BB], yy[u][0], yy[u][1], yy[u][2], rhs);
+                            else blk_mmv(&P[(size_t)k * BB], yy[u][0], yy[u][1], yy[u][2], rhs);
+                        }
                     }
                 }
             }
@@ -1053,6 +1091,7 @@ __device__ __forceinline__ void chain_sweep(const int nsteps, const int lane, do
                 if (relax_mode == 1) { out[0] = w * out[0]; out[1] = w * out[1]; out[2] = w * out[2]; }
                 vu[(size_t)r * BS] = out[0]; vu[(size_t)r * BS + 1] = out[1]; vu[(size_t)r * BS + 2] = out[2];
                 if (v != vu) { v[(size_t)r * BS] = second_result<0>(addp, r, w * out[0]); v[(size_t)r * BS + 1] = second_result<1>(addp, r, w * out[1]); v[(size_t)r * BS + 2] = second_result<2>(addp, r, w * out[2]); }
+                if (UA) { st_rowsum(&ua[(size_t)r * BS], us[0]); st_rowsum(&ua[(size_t)r * BS + 1], us[1]); st_rowsum(&ua[(size_t)r * BS + 2], us[2]); }
                 myPrev[0] = out[0]; myPrev[1] = out[1]; myPrev[2] = out[2];
             }
             myPrevRow = r;
@@ -1090,12 +1129,12 @@ __device__ __forceinline__ void chain_sweep(const int nsteps, const int lane, do
 #define OPMHIP_LIGHT_DEPTH 2   // one M^-1 on one box: depth 1 0.1488 ms, 2 0.1460, 3 0.1480, 4 0.1477, 6 0.1653 (more than 63 loads outstanding)
 #endif
 constexpr int LIGHT_DEPTH = OPMHIP_LIGHT_DEPTH;
-template <int SHAPE>  // SW_L or SW_UF
+template <int SHAPE, bool UA = false>  // SW_L or SW_UF; UA: as in chain_sweep
 __device__ __forceinline__ void chain_sweep_light(const int nsteps, const int lane, const int* srow0,
                                                   const int* __restrict__ prow,
                                                   const int* __restrict__ pcol, const double* __restrict__ P,
                                                   const double* __restrict__ invD, const double* d, double* vu, double* v,
-                                                  const double* __restrict__ addp, int relax_mode, double w) {
+                                                  const double* __restrict__ addp, int relax_mode, double w, double* __restrict__ ua = nullptr) {
     // Written by the rules chain_sweep's comment lists: every load unconditional, into registers whose content is dead,
     // nothing loaded ever copied, and no load consumed while it is the newest one outstanding (waiting for the newest
     // load means waiting for all of them - and, the counter being in order, waiting for a load issued k steps ago means
@@ -1162,7 +1201,11 @@ __device__ __forceinline__ void chain_sweep_light(const int nsteps, const int la
             if (active) {
                 const int r = rrow;
                 double rhs[3] = {c.rhs[0], c.rhs[1], c.rhs[2]};
-                if (c.ke > c.kb) blk_mmv(c.blk, prev[0], prev[1], prev[2], rhs);
+                double us[3] = {0.0, 0.0, 0.0};
+                if (c.ke > c.kb) {
+                    if (UA) blk_mmv_u(c.blk, prev[0], prev[1], prev[2], rhs, us);
+                    else blk_mmv(c.blk, prev[0], prev[1], prev[2], rhs);
+                }
                 if (SHAPE == SW_L) {
                     vu[(size_t)r * BS] = rhs[0]; vu[(size_t)r * BS + 1] = rhs[1]; vu[(size_t)r * BS + 2] = rhs[2];
                     prev[0] = rhs[0]; prev[1] = rhs[1]; prev[2] = rhs[2];
@@ -1172,6 +1215,7 @@ __device__ __forceinline__ void chain_sweep_light(const int nsteps, const int la
                     if (relax_mode == 1) { out[0] = w * out[0]; out[1] = w * out[1]; out[2] = w * out[2]; }
                     vu[(size_t)r * BS] = out[0]; vu[(size_t)r * BS + 1] = out[1]; vu[(size_t)r * BS + 2] = out[2];
                     if (v != vu) { v[(size_t)r * BS] = second_result<0>(addp, r, w * out[0]); v[(size_t)r * BS + 1] = second_result<1>(addp, r, w * out[1]); v[(size_t)r * BS + 2] = second_result<2>(addp, r, w * out[2]); }
+                    if (UA) { st_rowsum(&ua[(size_t)r * BS], us[0]); st_rowsum(&ua[(size_t)r * BS + 1], us[1]); st_rowsum(&ua[(size_t)r * BS + 2], us[2]); }
                     prev[0] = out[0]; prev[1] = out[1]; prev[2] = out[2];
                 }
             }
@@ -1183,27 +1227,28 @@ __device__ __forceinline__ void chain_sweep_light(const int nsteps, const int la
         }
     }
 }
-template <int SHAPE>
+template <int SHAPE, bool UA = false>
 __global__ __launch_bounds__(64) void k_ilu_sweep_light(const int* __restrict__ desc, int dstride, int S1,
                                                         const int* __restrict__ prow,
                                                         const int* __restrict__ pcol, const double* __restrict__ P,
                                                         const double* __restrict__ invD, const double* d,
-                                                        double* vu, double* v, const double* __restrict__ addp, int relax_mode, double w, const double* __restrict__ done) {
+                                                        double* vu, double* v, const double* __restrict__ addp, int relax_mode, double w, const double* __restrict__ done,
+                                                        double* __restrict__ ua = nullptr) {
     __shared__ int sdesc[DESC_MAX];
     const int lane = threadIdx.x;
     const double stop = *done;   // read with the descriptor record, tested after it: one round trip instead of two
     const int nsteps = load_desc(desc, dstride, lane, sdesc);
     if (stop != 0.0 || nsteps <= 0) return;
     (void)S1;
-    chain_sweep_light<SHAPE>(nsteps, lane, sdesc + DESC_HEAD, prow, pcol, P, invD, d, vu, v, addp, relax_mode, w);
+    chain_sweep_light<SHAPE, UA>(nsteps, lane, sdesc + DESC_HEAD, prow, pcol, P, invD, d, vu, v, addp, relax_mode, w, ua);
 }
-template <int SHAPE, bool ST = false>
+template <int SHAPE, bool ST = false, bool UA = false>
 __global__ __launch_bounds__(64) void k_ilu_sweep_chain(const int* __restrict__ desc, int dstride, int S1,
                                                         const int* __restrict__ prow,
                                                         const int* __restrict__ pcol, const double* __restrict__ P,
                                                         const double* __restrict__ invD, const double* d,
                                                         double* vu, double* v, const double* __restrict__ addp, int relax_mode, double w, const double* __restrict__ done,
-                                                        const SweepStencil S) {
+                                                        const SweepStencil S, double* __restrict__ ua = nullptr) {
     TILE_LDS
     __shared__ int sdesc[DESC_MAX];
     const int lane = threadIdx.x;
@@ -1211,18 +1256,18 @@ __global__ __launch_bounds__(64) void k_ilu_sweep_chain(const int* __restrict__ 
     const int nsteps = load_desc(desc, dstride, lane, sdesc);
     if (stop != 0.0 || nsteps <= 0) return;
     const int* srow0 = sdesc + DESC_HEAD;
-    chain_sweep<SHAPE, ST>(nsteps, lane, sval, srow0, srow0 + (SHAPE == SW_L ? 1 : 2) * S1, prow, pcol, P, invD, d, vu, v, addp, relax_mode, w, S, sdesc[2]);
+    chain_sweep<SHAPE, ST, UA>(nsteps, lane, sval, srow0, srow0 + (SHAPE == SW_L ? 1 : 2) * S1, prow, pcol, P, invD, d, vu, v, addp, relax_mode, w, S, sdesc[2], ua);
 }
 // Last colour: its rows have U entries only inside their own chain-tile, so the backward sweep of a chain-tile can
 // start the moment its forward sweep ends - one launch instead of two, and y never leaves the cache in between.
-template <bool LIGHT_U, bool ST = false>
+template <bool LIGHT_U, bool ST = false, bool UA = false>
 __global__ __launch_bounds__(64) void k_ilu_sweep_chain_LU(const int* __restrict__ desc, int dstride, int S1,
                                                            const int* __restrict__ lrow,
                                                            const int* __restrict__ lcol, const double* __restrict__ L,
                                                            const int* __restrict__ urow, const int* __restrict__ ucol,
                                                            const double* __restrict__ Uv, const double* __restrict__ invD,
                                                            const double* d, double* vu, double* v, const double* __restrict__ addp, int relax_mode, double w,
-                                                           const double* __restrict__ done, const SweepStencil SL, const SweepStencil SU) {
+                                                           const double* __restrict__ done, const SweepStencil SL, const SweepStencil SU, double* __restrict__ ua = nullptr) {
     TILE_LDS
     __shared__ int sdesc[DESC_MAX];
     const int lane = threadIdx.x;
@@ -1233,8 +1278,8 @@ __global__ __launch_bounds__(64) void k_ilu_sweep_chain_LU(const int* __restrict
     chain_sweep<SW_L, ST>(nsteps, lane, sval, srow0, srow0 + S1, lrow, lcol, L, invD, d, vu, v, addp, relax_mode, w, SL, sdesc[2]);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // y of this chain-tile is written before the backward sweep reads it
     wave_sync();
-    if (LIGHT_U) chain_sweep_light<SW_UF>(nsteps, lane, srow0, urow, ucol, Uv, invD, d, vu, v, addp, relax_mode, w);
-    else chain_sweep<SW_UF, ST>(nsteps, lane, sval, srow0, srow0 + 2 * S1, urow, ucol, Uv, invD, d, vu, v, addp, relax_mode, w, SU, sdesc[2]);
+    if (LIGHT_U) chain_sweep_light<SW_UF, UA>(nsteps, lane, srow0, urow, ucol, Uv, invD, d, vu, v, addp, relax_mode, w, ua);
+    else chain_sweep<SW_UF, ST, UA>(nsteps, lane, sval, srow0, srow0 + 2 * S1, urow, ucol, Uv, invD, d, vu, v, addp, relax_mode, w, SU, sdesc[2], ua);
 }
 
 // ============================== ILU0 factorisation =======================================================
@@ -1251,7 +1296,8 @@ __global__ __launch_bounds__(64) void k_ilu_factor(const int* __restrict__ sched
                                                    const int* __restrict__ diag, const double* __restrict__ A,
                                                    const int* __restrict__ fdest, const int* __restrict__ lmatch, const int* __restrict__ urowptr,
                                                    const int* __restrict__ ucol, double* L, double* U, double* invD, double* Afix,
-                                                   int Nb, int ellW, int ghostFrom, double* rw, double* __restrict__ rap, double* __restrict__ rpcol) {
+                                                   int Nb, int ellW, int ghostFrom, double* rw, double* __restrict__ rap, double* __restrict__ rpcol,
+                                                   const int* __restrict__ rdest, const int* __restrict__ rrowptr, double* __restrict__ Rv) {
     TILE_LDS
     const int lane = threadIdx.x;
     // launch position -> chain-tile by the colour's XCD-aware schedule (reorder.cpp: build_schedules): the chain-tiles of one stretch of
@@ -1261,16 +1307,49 @@ __global__ __launch_bounds__(64) void k_ilu_factor(const int* __restrict__ sched
     const int q0 = ct_first[ct], q1 = ct_first[ct + 1];
     constexpr int FU = 8;  // U-row columns of a neighbour fetched in one batch (longer rows: the merge below)
     __shared__ int scol[TILE_CAP_BLOCKS + 2], sdest[TILE_CAP_BLOCKS + 2], slm[TILE_CAP_BLOCKS + 2];
+    __shared__ short ssrc[TILE_CAP_BLOCKS + 2];   // Rv != NULL: per block of the tile's stretch of the rest stream, its place in the staged tile
     for (int t = q0; t < q1; ++t) {  // steps of a chain-tile in order (a single step unless the ordering is line-coloured)
         const TileCtx T = tile_stage_values(t, tile_row0, rowptr, A, sval, lane);
         // the tile's column indices next to its values: the elimination searches them many times
         if (T.staged) {
             const int kk0 = rowptr[T.r0], kk1 = rowptr[T.r1];
-            for (int q = kk0 + lane; q < kk1; q += 64) { scol[q - T.k0e] = col[q]; sdest[q - T.k0e] = fdest[q]; slm[q - T.k0e] = lmatch[q]; }
+            const int rb0 = Rv ? rrowptr[T.r0] : 0;
+            for (int q = kk0 + lane; q < kk1; q += 64) {
+                scol[q - T.k0e] = col[q]; sdest[q - T.k0e] = fdest[q]; slm[q - T.k0e] = lmatch[q];
+                if (Rv) { const int rd = rdest[q]; if (rd >= 0) ssrc[rd - rb0] = (short)(q - T.k0e); }
+            }
             if (kk0 > T.k0e && lane == 0) sdest[0] = -1;   // the alignment block in front of the tile belongs to the previous row
         }
         wave_sync();
         const int i = T.r0 + lane;
+        if (Afix && i < T.r1) {   // the zero-diagonal fix of the device-assembled Jacobian (k_zero_diag_fix's statement), on the staged row and - rarely - in the matrix itself, which the operator reads later
+            const int kd = diag[i];
+            double* dblk = &sval[(kd - T.k0e) * BB];
+#pragma unroll
+            for (int dgn = 0; dgn < BS; ++dgn)
+                if (dblk[dgn * 4] == 0.0) { dblk[dgn * 4] = 1e-15; Afix[(size_t)kd * BB + dgn * 4] = 1e-15; }
+        }
+        if (Rv && T.staged) {
+            // Pattern::ualias: the matrix's own entries beside the U part - lower entries, diagonal, ghost columns - leave LDS BEFORE the
+            // elimination touches them, as one stream the product after an M^-1 application reads in place of the whole matrix
+            // (rows are stored one after the other in the rest stream as in the matrix: the tile's stretch of it is ONE range, written
+            //  output-major - neighbouring lanes, neighbouring doubles, 16 bytes per lane where the range's alignment allows)
+            wave_sync();
+            const int rb = rrowptr[T.r0], nout = (rrowptr[T.r1] - rb) * BB;
+            double* out = Rv + (size_t)rb * BB;
+            const int h = (rb * BB) & 1;   // the range starts on an odd double: one leading single
+            auto src = [&](int o) { const int ob = o / BB; return sval[(int)ssrc[ob] * BB + (o - ob * BB)]; };
+            if (h && lane == 0 && nout > 0) out[0] = src(0);
+            const int np2 = (nout - h) >> 1;
+            double2* out2 = reinterpret_cast<double2*>(out + h);
+            for (int p2 = lane; p2 < np2; p2 += 64) {   // nontemporal: read once, by the products of the solve (0.473 -> 0.460 ms per factorisation)
+                v2d_t t;
+                t.x = src(h + 2 * p2); t.y = src(h + 2 * p2 + 1);
+                __builtin_nontemporal_store(t, reinterpret_cast<v2d_t*>(&out2[p2]));
+            }
+            if (((nout - h) & 1) && lane == 0) out[nout - 1] = src(nout - 1);
+            wave_sync();
+        }
         if (i < T.r1) {
             const int kb = rowptr[i], ke = rowptr[i + 1], kd = diag[i];
             // an over-long row (not staged) cannot be eliminated in LDS: such rows are rejected at set_pattern time
@@ -1278,11 +1357,6 @@ __global__ __launch_bounds__(64) void k_ilu_factor(const int* __restrict__ sched
             const int* rcol = &scol[kb - T.k0e];
             const int* rlm = &slm[kb - T.k0e];
             const int n = ke - kb, nd = kd - kb;
-            if (Afix) {   // the zero-diagonal fix of the device-assembled Jacobian (k_zero_diag_fix's statement), on the staged row and - rarely - in the matrix itself, which the operator reads later
-#pragma unroll
-                for (int dgn = 0; dgn < BS; ++dgn)
-                    if (row[nd * BB + dgn * 4] == 0.0) { row[nd * BB + dgn * 4] = 1e-15; Afix[(size_t)kd * BB + dgn * 4] = 1e-15; }
-            }
             if (RIDER) {
                 constexpr int PCOL = 1;   // pressure index inside a block (BlackOilIndices::pressureSwitchIdx; cpr.hip: CPR_P)
                 double w0, w1, w2;
@@ -1949,6 +2023,16 @@ static bool spmv_pipelined(const opmhip_ctx* c) {
     const int w = spmv_pipe_wgs(c);
     return c->pat.maxRowBlocks <= PGCH && w > 0 && c->pat.tiles.nsched > w && spmv_pipe_env() != 0;
 }
+// opmhip_config.half_product resolved: > 0 wherever the pattern allows it (Pattern::ualias, a line-coloured ordering, the rest's stencil
+// form - RestSched::on); 0, the library's choice: there, on one domain, where the system is large enough for the pipelined kernels (the
+// size the form was measured at); < 0 never.  Patterns with ghost columns: only when asked for.
+bool half_product_wanted(const opmhip_ctx* c) {
+    const Pattern& P = c->pat;
+    if (!P.rest.on || c->cfg.half_product < 0 || use_cpr(c)) return false;   // (CPR: the product follows the two-level application, not a sweep)
+    if (c->cfg.half_product > 0) return true;
+    static const bool off = [] { const char* e = tuning_env("OPMHIP_HALF_PRODUCT"); return e && e[0] == '0'; }();   // A/B switch
+    return !off && P.Nghost == 0 && spmv_pipelined(c);
+}
 // the scalar products ride in the product's kernel unless wells modify y after it (then k_dots forms them afterwards)
 static bool spmv_dots_env() {   // OPMHIP_DOTS_SEPARATE=1 (tuning / A-B measurements): k_dots behind every product, as with wells
     static const bool v = [] { const char* e = tuning_env("OPMHIP_DOTS_SEPARATE"); return e && std::atoi(e) != 0; }();
@@ -1957,15 +2041,34 @@ static bool spmv_dots_env() {   // OPMHIP_DOTS_SEPARATE=1 (tuning / A-B measurem
 static bool spmv_dots_separate(const opmhip_ctx* c) { return c->wells.any() || spmv_dots_env(); }
 // one launch over the schedule positions [p0, p0 + np): the pipelined kernel where the pattern allows it, else one tile per
 // workgroup.  Partial sums go to part[pofs ...]; returns how many were written (0 with ndot == 0).
-static int launch_spmv_part(opmhip_ctx* c, int p0, int np, const double* x, double* y, int ndot, const double* w0, double xs, int pofs, int cls) {
+static int launch_spmv_part(opmhip_ctx* c, int p0, int np, const double* x, double* y, int ndot, const double* w0, double xs, int pofs, int cls,
+                            const double* uadd = nullptr) {
     const Pattern& P = c->pat;
     if (np <= 0) return 0;
-    const int4* sched = reinterpret_cast<const int4*>(P.tiles.d_spmvSched) + p0;
     double* part = c->d_part + pofs;
     // timed by its own dispatch (kernel begin to kernel end), which is what bench.py's roofline quotes
     int es = -1, ee = -1;
     const bool timed = prof_kernel_scope(c, cls, &es, &ee);
     hipEvent_t e0 = timed ? c->prof.ev[es] : nullptr, e1 = timed ? c->prof.ev[ee] : nullptr;
+    if (uadd) {
+        // the rest product (Pattern::ualias): the pipelined kernel on the schedule, the index streams and the values of the matrix WITHOUT
+        // its U part, the row sums of the backward sweep added at the end of every row.  The grid as for the full product: every workgroup
+        // resident, all ending together; small systems: one tile per workgroup.
+        const RestSched& R = P.rest;
+        const int4* rsched = reinterpret_cast<const int4*>(R.d_sched) + p0;
+        const int pipeWgs = std::max(8, spmv_pipe_wgs(c));
+        const int steps = std::min((np + pipeWgs - 1) / pipeWgs, PIPE_MAX_STEPS);
+        const int grid = 8 * (((np + steps - 1) / steps + 7) / 8);
+        const int* tab = R.d_table + (size_t)p0 * 16;
+        if (ndot == 0)
+            hipExtLaunchKernelGGL((k_spmv_pipe_st<0, true>), dim3(grid), dim3(64), 0, c->stream, e0, e1, 0, np, rsched, R.d_word, R.d_koff, tab, c->d_R, x, y, w0, part, c->npart, c->d_done, xs, uadd);
+        else if (ndot == 1)
+            hipExtLaunchKernelGGL((k_spmv_pipe_st<1, true>), dim3(grid), dim3(64), 0, c->stream, e0, e1, 0, np, rsched, R.d_word, R.d_koff, tab, c->d_R, x, y, w0, part, c->npart, c->d_done, xs, uadd);
+        else
+            hipExtLaunchKernelGGL((k_spmv_pipe_st<2, true>), dim3(grid), dim3(64), 0, c->stream, e0, e1, 0, np, rsched, R.d_word, R.d_koff, tab, c->d_R, x, y, w0, part, c->npart, c->d_done, xs, uadd);
+        return ndot > 0 ? grid : 0;
+    }
+    const int4* sched = reinterpret_cast<const int4*>(P.tiles.d_spmvSched) + p0;
     if (spmv_pipelined(c)) {
         // every workgroup walks through ceil(np / grid) launch positions; the grid is sized so that all workgroups are
         // resident at once and end together, and is a multiple of 8 (a workgroup stays on "its" XCD column of the schedule)
@@ -1977,11 +2080,11 @@ static int launch_spmv_part(opmhip_ctx* c, int p0, int np, const double* x, doub
         if ((!inInt || P.tiles.stencilPart[0]) && (!inBnd || P.tiles.stencilPart[1]) && !explicitIdx) {
             const int* tab = P.tiles.d_stTable + (size_t)p0 * 16;
             if (ndot == 0)
-                hipExtLaunchKernelGGL(k_spmv_pipe_st<0>, dim3(grid), dim3(64), 0, c->stream, e0, e1, 0, np, sched, P.tiles.d_stWord, P.tiles.d_stKoff, tab, c->d_A, x, y, w0, part, c->npart, c->d_done, xs);
+                hipExtLaunchKernelGGL((k_spmv_pipe_st<0, false>), dim3(grid), dim3(64), 0, c->stream, e0, e1, 0, np, sched, P.tiles.d_stWord, P.tiles.d_stKoff, tab, c->d_A, x, y, w0, part, c->npart, c->d_done, xs, (const double*)nullptr);
             else if (ndot == 1)
-                hipExtLaunchKernelGGL(k_spmv_pipe_st<1>, dim3(grid), dim3(64), 0, c->stream, e0, e1, 0, np, sched, P.tiles.d_stWord, P.tiles.d_stKoff, tab, c->d_A, x, y, w0, part, c->npart, c->d_done, xs);
+                hipExtLaunchKernelGGL((k_spmv_pipe_st<1, false>), dim3(grid), dim3(64), 0, c->stream, e0, e1, 0, np, sched, P.tiles.d_stWord, P.tiles.d_stKoff, tab, c->d_A, x, y, w0, part, c->npart, c->d_done, xs, (const double*)nullptr);
             else
-                hipExtLaunchKernelGGL(k_spmv_pipe_st<2>, dim3(grid), dim3(64), 0, c->stream, e0, e1, 0, np, sched, P.tiles.d_stWord, P.tiles.d_stKoff, tab, c->d_A, x, y, w0, part, c->npart, c->d_done, xs);
+                hipExtLaunchKernelGGL((k_spmv_pipe_st<2, false>), dim3(grid), dim3(64), 0, c->stream, e0, e1, 0, np, sched, P.tiles.d_stWord, P.tiles.d_stKoff, tab, c->d_A, x, y, w0, part, c->npart, c->d_done, xs, (const double*)nullptr);
             return ndot > 0 ? grid : 0;
         }
         if (ndot == 0)
@@ -2025,24 +2128,27 @@ static int ms_wells_apply(opmhip_ctx* c, const double* x, double* y, double xs) 
 // (linalg/WellOperators.hpp:127-138, ParallelOverlappingILU0.hpp:897) - on the halo stream, WHILE the interior tiles (no
 // ghost column in any of their rows) are multiplied on the main stream; the boundary tiles follow when the ghosts are in.
 // Every row's sum is formed by the same statements in the same order whichever launch it is in: the same bits as one launch.
-int launch_spmv(opmhip_ctx* c, double* x, double* y, int ndot, const double* w0, double xs, bool exchange) {
+// uadd != NULL: the rest product - x is the (unscaled) result of the ILU0 application that has just left its row sums in uadd:
+// y_i = sum_rest A_ik (xs x_k) + xs uadd_i  (Pattern::ualias; the same wells, halo exchange and scalar products around it)
+int launch_spmv(opmhip_ctx* c, double* x, double* y, int ndot, const double* w0, double xs, bool exchange, const double* uadd) {
     const Pattern& P = c->pat;
     const bool wells = c->wells.num_wells > 0;
     const int fused = spmv_dots_separate(c) ? 0 : ndot;
     const bool halo = exchange && c->comm.halo_set && c->comm.nneigh > 0;
     if (exchange && !halo && c->comm.nranks > 1) comm_halo_bystander(c);   // a subdomain that touches no other: nothing to exchange, but the peers' exchange counts this rank in (loopback)
-    const int nInt = P.tiles.nschedInt, nBnd = P.tiles.nsched - nInt;
+    const int nAll = uadd ? P.rest.nsched : P.tiles.nsched;
+    const int nInt = uadd ? P.rest.nschedInt : P.tiles.nschedInt, nBnd = nAll - nInt;
     int rc, cnt = 0;
     if (halo && nBnd > 0) {
         // main: ev_x (x complete) -> interior tiles ........................ wait ev_h -> boundary tiles
         // halo:         wait ev_x -> pack -> send / receive -> ev_h
         if ((rc = comm_halo_begin(c, x))) return rc;     // records ev_x on the main stream; the exchange itself is behind it on the halo stream
-        cnt += launch_spmv_part(c, 0, nInt, x, y, fused, w0, xs, cnt, PROF_SPMV);
+        cnt += launch_spmv_part(c, 0, nInt, x, y, fused, w0, xs, cnt, PROF_SPMV, uadd);
         if ((rc = comm_halo_end(c))) return rc;
-        cnt += launch_spmv_part(c, nInt, nBnd, x, y, fused, w0, xs, cnt, PROF_SPMV_BOUNDARY);
+        cnt += launch_spmv_part(c, nInt, nBnd, x, y, fused, w0, xs, cnt, PROF_SPMV_BOUNDARY, uadd);
     } else {
         if (halo && (rc = comm_halo_f64(c, x, BS))) return rc;
-        cnt += launch_spmv_part(c, 0, P.tiles.nsched, x, y, fused, w0, xs, cnt, PROF_SPMV);
+        cnt += launch_spmv_part(c, 0, nAll, x, y, fused, w0, xs, cnt, PROF_SPMV, uadd);
     }
     if (c->wells.num_ms > 0 && (rc = ms_wells_apply(c, x, y, xs))) return rc;   // in front of the standard wells, bda/WellContributions.cu:160-187
     if (wells && (rc = launch_wells_apply(c, x, y, xs))) return rc;
@@ -2070,7 +2176,8 @@ void launch_ilu_factor(opmhip_ctx* c, bool fix_zero_diagonal, const FactorRider*
 #define OPMHIP_FACTOR_LAUNCH(RID)                                                                                                                          \
     hipLaunchKernelGGL(k_ilu_factor<RID>, dim3(npos), dim3(64), 0, c->stream, P.tiles.d_ctSched + off, P.tiles.d_ctFirst, P.tiles.d_row0, P.d_rowptr, P.d_col, \
                        P.d_diag, c->d_A, P.d_fdest, P.d_lmatch, P.d_urowptr, P.d_ucol, c->d_L, c->d_U, c->d_invD, fix_zero_diagonal ? c->d_A : (double*)nullptr, \
-                       P.Nb, R.W, R.ghostFrom, R.w, R.ap, R.pcol)
+                       P.Nb, R.W, R.ghostFrom, R.w, R.ap, R.pcol, c->half_product ? P.d_rdest : (const int*)nullptr, c->half_product ? P.d_rrowptr : (const int*)nullptr, \
+                       c->half_product ? c->d_R : (double*)nullptr)
         if (R.mode == 1) OPMHIP_FACTOR_LAUNCH(1); else if (R.mode == 2) OPMHIP_FACTOR_LAUNCH(2); else OPMHIP_FACTOR_LAUNCH(0);
 #undef OPMHIP_FACTOR_LAUNCH
     }
@@ -2079,7 +2186,9 @@ void launch_ilu_factor(opmhip_ctx* c, bool fix_zero_diagonal, const FactorRider*
 // unscaled != NULL: with post-scaling the sweeps leave U^-1 L^-1 d in v WITHOUT the factor w and report the factor in *unscaled
 // (1 when there is none to apply): whoever reads v next multiplies on the fly - w * v_i is one rounded product either way -
 // and the second result vector (24 bytes per row written by the backward sweeps) never exists.
-void launch_ilu_apply(opmhip_ctx* c, const double* d, double* v, double w_override, double* unscaled, const double* addp, double* work) {
+// usum != NULL (chained orderings, Pattern::ualias): the backward sweeps also leave u_i = sum_{j>i} U_ij x_j there, x = the sweep's own
+// (unscaled) result - the upper part of A x, bit for bit, since U == upper(A)
+void launch_ilu_apply(opmhip_ctx* c, const double* d, double* v, double w_override, double* unscaled, const double* addp, double* work, double* usum) {
     const Pattern& P = c->pat;
     const int ps = prof_begin(c, PROF_ILU_APPLY);
     const int C = P.numColors, mode = c->cfg.relax_mode;
@@ -2103,38 +2212,53 @@ void launch_ilu_apply(opmhip_ctx* c, const double* d, double* v, double w_overri
             const int nct = npos(col);
             if (nct <= 0) continue;
             if (P.lightL[col])
-                hipLaunchKernelGGL(k_ilu_sweep_light<SW_L>, dim3(nct), dim3(64), 0, c->stream, desc(col), ds, S1, P.d_lrowptr,
-                                   P.d_lcol, c->d_L, c->d_invD, d, vu, v, addp, mode, w, c->d_done);
+                hipLaunchKernelGGL((k_ilu_sweep_light<SW_L, false>), dim3(nct), dim3(64), 0, c->stream, desc(col), ds, S1, P.d_lrowptr,
+                                   P.d_lcol, c->d_L, c->d_invD, d, vu, v, addp, mode, w, c->d_done, (double*)nullptr);
             else if (st)
-                hipLaunchKernelGGL((k_ilu_sweep_chain<SW_L, true>), dim3(nct), dim3(64), 0, c->stream, desc(col), ds, S1, P.d_lrowptr,
-                                   P.d_lcol, c->d_L, c->d_invD, d, vu, v, addp, mode, w, c->d_done, SL);
+                hipLaunchKernelGGL((k_ilu_sweep_chain<SW_L, true, false>), dim3(nct), dim3(64), 0, c->stream, desc(col), ds, S1, P.d_lrowptr,
+                                   P.d_lcol, c->d_L, c->d_invD, d, vu, v, addp, mode, w, c->d_done, SL, (double*)nullptr);
             else
-                hipLaunchKernelGGL((k_ilu_sweep_chain<SW_L, false>), dim3(nct), dim3(64), 0, c->stream, desc(col), ds, S1, P.d_lrowptr,
-                                   P.d_lcol, c->d_L, c->d_invD, d, vu, v, addp, mode, w, c->d_done, SL);
+                hipLaunchKernelGGL((k_ilu_sweep_chain<SW_L, false, false>), dim3(nct), dim3(64), 0, c->stream, desc(col), ds, S1, P.d_lrowptr,
+                                   P.d_lcol, c->d_L, c->d_invD, d, vu, v, addp, mode, w, c->d_done, SL, (double*)nullptr);
         }
         {
             const int nct = npos(C - 1);
             if (nct > 0) {
-#define OPMHIP_LU_LAUNCH(LIGHT, STF)                                                                                                        \
-    hipLaunchKernelGGL((k_ilu_sweep_chain_LU<LIGHT, STF>), dim3(nct), dim3(64), 0, c->stream, desc(C - 1), ds, S1, P.d_lrowptr, P.d_lcol, c->d_L, \
-                       P.d_urowptr, P.d_ucol, c->d_U, c->d_invD, d, vu, v, addp, mode, w, c->d_done, SL, SU)
-                if (P.lightU[C - 1]) { if (st) OPMHIP_LU_LAUNCH(true, true); else OPMHIP_LU_LAUNCH(true, false); }
-                else { if (st) OPMHIP_LU_LAUNCH(false, true); else OPMHIP_LU_LAUNCH(false, false); }
+#define OPMHIP_LU_LAUNCH(LIGHT, STF, UAF)                                                                                                   \
+    hipLaunchKernelGGL((k_ilu_sweep_chain_LU<LIGHT, STF, UAF>), dim3(nct), dim3(64), 0, c->stream, desc(C - 1), ds, S1, P.d_lrowptr, P.d_lcol, c->d_L, \
+                       P.d_urowptr, P.d_ucol, c->d_U, c->d_invD, d, vu, v, addp, mode, w, c->d_done, SL, SU, usum)
+                if (usum) {
+                    if (P.lightU[C - 1]) { if (st) OPMHIP_LU_LAUNCH(true, true, true); else OPMHIP_LU_LAUNCH(true, false, true); }
+                    else { if (st) OPMHIP_LU_LAUNCH(false, true, true); else OPMHIP_LU_LAUNCH(false, false, true); }
+                } else {
+                    if (P.lightU[C - 1]) { if (st) OPMHIP_LU_LAUNCH(true, true, false); else OPMHIP_LU_LAUNCH(true, false, false); }
+                    else { if (st) OPMHIP_LU_LAUNCH(false, true, false); else OPMHIP_LU_LAUNCH(false, false, false); }
+                }
 #undef OPMHIP_LU_LAUNCH
             }
         }
         for (int col = C - 2; col >= 0; --col) {
             const int nct = npos(col);
             if (nct <= 0) continue;
-            if (P.lightU[col])
-                hipLaunchKernelGGL(k_ilu_sweep_light<SW_UF>, dim3(nct), dim3(64), 0, c->stream, desc(col), ds, S1, P.d_urowptr,
-                                   P.d_ucol, c->d_U, c->d_invD, d, vu, v, addp, mode, w, c->d_done);
+            if (usum) {
+                if (P.lightU[col])
+                    hipLaunchKernelGGL((k_ilu_sweep_light<SW_UF, true>), dim3(nct), dim3(64), 0, c->stream, desc(col), ds, S1, P.d_urowptr,
+                                       P.d_ucol, c->d_U, c->d_invD, d, vu, v, addp, mode, w, c->d_done, usum);
+                else if (st)
+                    hipLaunchKernelGGL((k_ilu_sweep_chain<SW_UF, true, true>), dim3(nct), dim3(64), 0, c->stream, desc(col), ds, S1, P.d_urowptr,
+                                       P.d_ucol, c->d_U, c->d_invD, d, vu, v, addp, mode, w, c->d_done, SU, usum);
+                else
+                    hipLaunchKernelGGL((k_ilu_sweep_chain<SW_UF, false, true>), dim3(nct), dim3(64), 0, c->stream, desc(col), ds, S1, P.d_urowptr,
+                                       P.d_ucol, c->d_U, c->d_invD, d, vu, v, addp, mode, w, c->d_done, SU, usum);
+            } else if (P.lightU[col])
+                hipLaunchKernelGGL((k_ilu_sweep_light<SW_UF, false>), dim3(nct), dim3(64), 0, c->stream, desc(col), ds, S1, P.d_urowptr,
+                                   P.d_ucol, c->d_U, c->d_invD, d, vu, v, addp, mode, w, c->d_done, (double*)nullptr);
             else if (st)
-                hipLaunchKernelGGL((k_ilu_sweep_chain<SW_UF, true>), dim3(nct), dim3(64), 0, c->stream, desc(col), ds, S1, P.d_urowptr,
-                                   P.d_ucol, c->d_U, c->d_invD, d, vu, v, addp, mode, w, c->d_done, SU);
+                hipLaunchKernelGGL((k_ilu_sweep_chain<SW_UF, true, false>), dim3(nct), dim3(64), 0, c->stream, desc(col), ds, S1, P.d_urowptr,
+                                   P.d_ucol, c->d_U, c->d_invD, d, vu, v, addp, mode, w, c->d_done, SU, (double*)nullptr);
             else
-                hipLaunchKernelGGL((k_ilu_sweep_chain<SW_UF, false>), dim3(nct), dim3(64), 0, c->stream, desc(col), ds, S1, P.d_urowptr,
-                                   P.d_ucol, c->d_U, c->d_invD, d, vu, v, addp, mode, w, c->d_done, SU);
+                hipLaunchKernelGGL((k_ilu_sweep_chain<SW_UF, false, false>), dim3(nct), dim3(64), 0, c->stream, desc(col), ds, S1, P.d_urowptr,
+                                   P.d_ucol, c->d_U, c->d_invD, d, vu, v, addp, mode, w, c->d_done, SU, (double*)nullptr);
         }
         prof_end(c, ps);
         return;
@@ -2230,6 +2354,9 @@ static int enqueue_half(opmhip_ctx* c, int h, int part = HALF_ALL) {
     // preconditioner application that follows them (round 1) they made that sweep 0.017 ms longer and the vector scopes as
     // much shorter - the same Newton iteration rate (76.5 / 78.1 against 78.0 / 76.3 its/s on one box).
     const bool cpr = use_cpr(c);
+    // Pattern::ualias: the backward sweeps of the ILU0 application leave the upper part of the product that follows behind as row sums;
+    // that product then streams the matrix without its U part (d_R, written by this solve's factorisation)
+    const bool hp = !cpr && c->half_product;
     const bool precTalks = cpr && c->cpr.gather.on;                  // the preconditioner posts collectives
     const bool head = part != HALF_REST, rest = part != HALF_PRECOND;
     const bool applyNow = part == HALF_ALL || (precTalks ? part == HALF_REST : part == HALF_PRECOND);
@@ -2242,11 +2369,11 @@ static int enqueue_half(opmhip_ctx* c, int h, int part = HALF_ALL) {
         }
         if (applyNow) {
             if (cpr) launch_cpr_apply(c, c->d_p, c->d_pw);
-            else launch_ilu_apply(c, c->d_p, c->d_pw, -1.0, &c->minv_scale);   // d_pw without the relaxation factor: its readers apply it
+            else launch_ilu_apply(c, c->d_p, c->d_pw, -1.0, &c->minv_scale, nullptr, nullptr, hp ? c->d_usum : nullptr);   // d_pw without the relaxation factor: its readers apply it
             if (cpr && c->cpr.apply_rc) { rc = c->cpr.apply_rc; c->cpr.apply_rc = 0; return rc; }   // a collective of the joined coarse level failed
         }
         if (!rest) return OPMHIP_SUCCESS;
-        if ((rc = launch_spmv(c, c->d_pw, c->d_v, 1, c->d_rw, c->minv_scale, true))) return rc;  // with copyOwnerToAll before the operator (ParallelOverlappingILU0.hpp:897)
+        if ((rc = launch_spmv(c, c->d_pw, c->d_v, 1, c->d_rw, c->minv_scale, true, hp ? c->d_usum : nullptr))) return rc;  // with copyOwnerToAll before the operator (ParallelOverlappingILU0.hpp:897)
         ps = prof_begin(c, PROF_VECTOR);
         if ((rc = finalize(c, FIN_ALPHA, dot_count(c)))) return rc;
         hipLaunchKernelGGL(k_bicg_upd1, dim3(nb), dim3(VB), 0, c->stream, n, c->d_scal, c->d_r, c->d_v, c->d_part, c->npart);
@@ -2255,11 +2382,11 @@ static int enqueue_half(opmhip_ctx* c, int h, int part = HALF_ALL) {
     } else {             // second half: z = M^-1 r, t = A z, omega, x += omega z, r -= omega t, |r|, rho, beta
         if (applyNow) {
             if (cpr) launch_cpr_apply(c, c->d_r, c->d_s);
-            else launch_ilu_apply(c, c->d_r, c->d_s, -1.0, &c->minv_scale);
+            else launch_ilu_apply(c, c->d_r, c->d_s, -1.0, &c->minv_scale, nullptr, nullptr, hp ? c->d_usum : nullptr);
             if (cpr && c->cpr.apply_rc) { rc = c->cpr.apply_rc; c->cpr.apply_rc = 0; return rc; }
         }
         if (!rest) return OPMHIP_SUCCESS;
-        if ((rc = launch_spmv(c, c->d_s, c->d_t, 2, c->d_r, c->minv_scale, true))) return rc;
+        if ((rc = launch_spmv(c, c->d_s, c->d_t, 2, c->d_r, c->minv_scale, true, hp ? c->d_usum : nullptr))) return rc;
         ps = prof_begin(c, PROF_VECTOR);
         if ((rc = finalize(c, FIN_OMEGA, dot_count(c)))) return rc;
         hipLaunchKernelGGL(k_bicg_upd2, dim3(nb), dim3(VB), 0, c->stream, n, c->d_scal, c->d_x, c->d_pw, c->d_s, c->d_r, c->d_t, c->d_rw, c->d_part, c->npart, c->minv_scale);

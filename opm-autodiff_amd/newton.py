@@ -64,12 +64,17 @@ class ModelParameters:
 class BlackoilModelHip:
     """model = capi.HipModel (device context) ; one instance drives one grid on one GPU."""
 
-    def __init__(self, model, param=None):
+    def __init__(self, model, param=None, well_model=None):
+        """well_model (wells.StandardWells or None): the host-side well equations of BlackoilWellModel - assembled in front of the
+        reservoir's linearisation (BlackoilModelEbos::assembleReservoir -> wellModel().assemble, flow/BlackoilModelEbos.hpp:418-428),
+        eliminated from the linear system by the device (wells/StandardWell_impl.hpp:1254-1311) and updated with the reservoir"""
         self.m = model
         self.param = param or ModelParameters()
+        self.wells = well_model
         self.residual_norms_history = []
         self.current_relaxation = 1.0
         self.last_linear_iterations = 0
+        self._well_saved = None
 
     # -- BlackoilModelEbos::getReservoirConvergence ------------------------------------------------------------
     def get_convergence(self, dt, iteration):
@@ -111,8 +116,20 @@ class BlackoilModelHip:
             self.current_relaxation = 1.0
         rep.total_linearizations = 1
         t0 = time.perf_counter()
+        wa = None
+        if self.wells is not None:
+            # wellModel().beginIteration / assemble (wells/BlackoilWellModel_impl.hpp:148-171, 1033-1101): controls, well equations at the
+            # present reservoir state, their connection rates as the perforated cells' source terms (computeTotalRatesForDof :496-512)
+            iq = self.m.iq()
+            if iteration == 0:
+                self.wells.solve_well_equations(iq)          # prepareTimeStep: the wells alone against the frozen reservoir
+            self.wells.update_well_controls()
+            wa = self.wells.assemble(iq, iq.shape[0])
+            self.m.set_source(wa["source"], wa["dsource"])
         self.m.assemble(dt, iteration, fetch=False)          # assembleReservoir -> linearizeDomain (asynchronous)
         conv, norms = self.get_convergence(dt, iteration)    # synchronises: reads the reduced scalars back
+        if wa is not None:
+            conv = conv and self.wells.converged(wa["res_well"])   # getWellConvergence (flow/BlackoilModelEbos.hpp:906-912)
         t1 = time.perf_counter()
         # The reference books assembly under assemble_time and the convergence check under update_time
         # (BlackoilModelEbos.hpp:296-297, 311-323).  Both are enqueued back to back here and only the convergence
@@ -124,7 +141,11 @@ class BlackoilModelHip:
         self.residual_norms_history.append(norms)
         if not rep.converged:
             rep.total_newton_iterations = 1
-            res = self.m.solve_jacobian_system()             # solveJacobianSystem: ILU0 setup + BiCGStab
+            if wa is not None:
+                self.m.wells_apply_residual(wa["wells"], wa["res_well"])        # wellModel().apply(r): r -= C^T D^-1 r_w (:523-527)
+                res = self.m.solve_jacobian_system(wells=wa["wells"])           # the operator A - C^T D^-1 B (WellModelMatrixAdapter)
+            else:
+                res = self.m.solve_jacobian_system()         # solveJacobianSystem: ILU0 setup + BiCGStab
             rep.linear_solve_setup_time += res.t_factor
             rep.linear_solve_time += res.t_solve + res.t_copy
             rep.total_linear_iterations += res.iterations
@@ -135,6 +156,8 @@ class BlackoilModelHip:
             t2 = time.perf_counter()
             if self.param.use_update_stabilization and self.detect_oscillations(iteration):
                 self.current_relaxation = max(self.current_relaxation - self.param.relax_increment, self.param.relax_max)
+            if wa is not None:   # recoverWellSolutionAndUpdateWellState (:1033-1042): x_w = D^-1 (r_w - B x), same relaxation
+                self.wells.update(self.m.wells_recover_solution(wa["wells"], wa["res_well"]), self.current_relaxation)
             self.m.update(None, self.current_relaxation)      # stabilizeNonlinearUpdate (dampen) + updateSolution
             rep.update_time += time.perf_counter() - t2
         return rep
@@ -159,9 +182,13 @@ class BlackoilModelHip:
     # -- FvBaseDiscretization::advanceTimeLevel / updateFailed ---------------------------------------------------
     def advance_time_level(self):
         self.m.advance_time_level()
+        if self.wells is not None:
+            self._well_saved = self.wells.state()      # the well state of the last accepted step (WellState copy of a failed step's restart)
 
     def update_failed(self):
         self.m.update_failed()
+        if self.wells is not None and self._well_saved is not None:
+            self.wells.set_state(self._well_saved)
 
     def relative_change(self):
         """BlackoilModelEbos::relativeChange (flow/BlackoilModelEbos.hpp:431-510); None where the model object has none"""

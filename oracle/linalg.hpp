@@ -208,6 +208,76 @@ inline void ilu0_apply(const Bcrs& LU, const std::vector<int>& dg, int interiorS
         for (size_t e = 0; e < (size_t)interiorSize * BS; ++e) v[e] *= w;
 }
 
+// ---- the product after an ILU0 application, formed from the backward sweep's row sums -----------------
+// libopmhip's opmhip_config.half_product (include/opmhip.h): on a pattern without triangles no elimination step of bilu0_decompose
+// touches an entry right of the diagonal (the update above needs (i,j), (j,k) and (i,k): k == i alone), so the strict upper part of LU
+// equals that of A bit for bit and u_i = sum_{j>i} U_ij x_j - formed by the backward sweep anyway - is the upper part of (A x)_i.
+// ilu0_apply_u is ilu0_apply (same statements, same order, the same v) that also leaves those row sums in u: the same rounded products
+// U_ij x_j, added up from 0 in the sweep's column order (x = the sweep's own result: unscaled in mode 0, relaxed in mode 1).
+// spmv_rest forms y_i = (sum over the entries NOT in the ILU's U part - columns <= i, and columns of another subdomain where `owner`
+// is given - ascending, of A_ik x_k) + s u_i, s = the factor x carries beside the sweep's own result (w in mode 0, 1 in mode 1).
+// This restates the order libopmhip's kernels use (csrc/solver.hip: chain_sweep<.., UA>, k_spmv_pipe_st<.., UADD>); the reference runs
+// the sweep and then the whole product (bda/cusparseSolverBackend.cu:103-118).  is_upper_alias says whether the property holds.
+inline void ilu0_apply_u(const Bcrs& LU, const std::vector<int>& dg, int interiorSize, const double* d, double* v, double w, int mode, double* u) {
+    for (int i = 0; i < interiorSize; ++i) {
+        double rhs[BS] = {d[(size_t)i * BS], d[(size_t)i * BS + 1], d[(size_t)i * BS + 2]};
+        for (int k = LU.rowptr[i]; k < dg[i]; ++k)
+            blk_mmv(&LU.val[(size_t)k * BB], &v[(size_t)LU.col[k] * BS], rhs);
+        for (int r = 0; r < BS; ++r) v[(size_t)i * BS + r] = rhs[r];
+    }
+    auto step = [&](int k, double* rhs, double* us) {
+        const double* A = &LU.val[(size_t)k * BB];
+        const double* x = &v[(size_t)LU.col[k] * BS];
+        for (int r = 0; r < BS; ++r)
+            for (int c = 0; c < BS; ++c) {
+                const double p = A[r * BS + c] * x[c];
+                rhs[r] -= p;
+                us[r] += p;
+            }
+    };
+    for (int i = interiorSize - 1; i >= 0; --i) {
+        double rhs[BS] = {v[(size_t)i * BS], v[(size_t)i * BS + 1], v[(size_t)i * BS + 2]};
+        double us[BS] = {0.0, 0.0, 0.0};
+        if (mode == 0) {
+            for (int k = LU.rowptr[i + 1] - 1; k > dg[i]; --k) step(k, rhs, us);
+        } else {
+            for (int k = dg[i] + 1; k < LU.rowptr[i + 1]; ++k) step(k, rhs, us);
+        }
+        double out[BS];
+        blk_mv(&LU.val[(size_t)dg[i] * BB], rhs, out);
+        for (int r = 0; r < BS; ++r) {
+            v[(size_t)i * BS + r] = (mode == 1) ? w * out[r] : out[r];
+            u[(size_t)i * BS + r] = us[r];
+        }
+    }
+    if (mode == 0 && w != 1.0)
+        for (size_t e = 0; e < (size_t)interiorSize * BS; ++e) v[e] *= w;
+}
+inline void spmv_rest(const Bcrs& A, const double* x, const double* u, double s, double* y, const int* owner = nullptr) {
+    for (int i = 0; i < A.Nb; ++i) {
+        double acc[BS] = {0.0, 0.0, 0.0};
+        for (int k = A.rowptr[i]; k < A.rowptr[i + 1]; ++k)
+            if (A.col[k] <= i || (owner && owner[A.col[k]] != owner[i]))
+                blk_umv(&A.val[(size_t)k * BB], &x[(size_t)A.col[k] * BS], acc);
+        for (int r = 0; r < BS; ++r) y[(size_t)i * BS + r] = acc[r] + s * u[(size_t)i * BS + r];
+    }
+}
+// does any elimination step of the block ILU0 touch an entry right of the diagonal?  (pattern only)
+inline bool is_upper_alias(const Bcrs& A) {
+    const std::vector<int> dg = diag_index(A);
+    for (int i = 0; i < A.Nb; ++i)
+        for (int ij = A.rowptr[i]; ij < A.rowptr[i + 1] && A.col[ij] < i; ++ij) {
+            const int j = A.col[ij];
+            int jk = dg[j] + 1, ik = ij + 1;
+            while (ik < A.rowptr[i + 1] && jk < A.rowptr[j + 1]) {
+                if (A.col[ik] == A.col[jk]) { if (A.col[ik] > i) return false; ++ik; ++jk; }
+                else if (A.col[ik] < A.col[jk]) ++ik;
+                else ++jk;
+            }
+        }
+    return true;
+}
+
 // ---- reorderings (accelerator path) ----------------------------------------------------
 struct Reordering {
     std::vector<int> toOrder, fromOrder, rowsPerColor;  // as bda/Reorder.cpp

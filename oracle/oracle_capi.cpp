@@ -153,10 +153,24 @@ struct orc_result {
 //  nsub > 1: block-Jacobi ILU0 over nsub contiguous row ranges (couplings across ranges dropped in the
 //            preconditioner only) - the CPU-N baseline of BASELINE.md §3, modelled on
 //            ghost_last_bilu0_decomposition (ParallelOverlappingILU0.hpp:439-494).  sub_start[nsub+1].
+int orc_solve_hp(int Nb, const int* rowptr, const int* col, const double* val, const double* b, double* x,
+                 double tol, int maxit, double w, int relax_mode, int reorder, int zero_diag_fix, int numWells,
+                 const int* val_pointers, const int* Ccols, const int* Bcols, const double* Cnnzs,
+                 const double* Dnnzs, const double* Bnnzs, int nsub, const int* sub_start, int half_product, orc_result* out);
 int orc_solve(int Nb, const int* rowptr, const int* col, const double* val, const double* b, double* x,
               double tol, int maxit, double w, int relax_mode, int reorder, int zero_diag_fix, int numWells,
               const int* val_pointers, const int* Ccols, const int* Bcols, const double* Cnnzs,
               const double* Dnnzs, const double* Bnnzs, int nsub, const int* sub_start, orc_result* out) {
+    return orc_solve_hp(Nb, rowptr, col, val, b, x, tol, maxit, w, relax_mode, reorder, zero_diag_fix, numWells, val_pointers, Ccols, Bcols, Cnnzs,
+                        Dnnzs, Bnnzs, nsub, sub_start, 0, out);
+}
+// half_product != 0: the product after every ILU0 application is formed from the backward sweep's row sums (oracle/linalg.hpp:
+// ilu0_apply_u / spmv_rest - the order libopmhip's opmhip_config.half_product states); returns -1000 if the (reordered) pattern does not
+// have the property that rests on (is_upper_alias)
+int orc_solve_hp(int Nb, const int* rowptr, const int* col, const double* val, const double* b, double* x,
+                 double tol, int maxit, double w, int relax_mode, int reorder, int zero_diag_fix, int numWells,
+                 const int* val_pointers, const int* Ccols, const int* Bcols, const double* Cnnzs,
+                 const double* Dnnzs, const double* Bnnzs, int nsub, const int* sub_start, int half_product, orc_result* out) {
     using clk = std::chrono::steady_clock;
     Bcrs A = wrap(Nb, rowptr, col, val);
     if (zero_diag_fix) check_zero_diagonal(A);
@@ -176,11 +190,12 @@ int orc_solve(int Nb, const int* rowptr, const int* col, const double* val, cons
     Bcrs LU = A;
     int rc = 0;
     std::vector<int> dg;
+    std::vector<int> owner;
     if (nsub > 1 || nsub < 0) {
         // drop couplings that leave a subdomain: they stay in the pattern with value 0 so that the
         // sweeps simply see zeros there (same effect as the ghost-last loops that never touch them).
         // nsub > 1: contiguous row ranges sub_start[nsub+1]; nsub < 0: sub_start is an owner id per (natural) row.
-        std::vector<int> owner(Nb);
+        owner.resize(Nb);
         if (nsub < 0) {
             for (int i = 0; i < Nb; ++i) owner[reorder != 0 ? R.toOrder[i] : i] = sub_start[i];
         } else
@@ -194,10 +209,16 @@ int orc_solve(int Nb, const int* rowptr, const int* col, const double* val, cons
     dg = diag_index(LU);
     auto t1 = clk::now();
     if (rc != 0) return rc;
-    std::vector<double> tmp(n);
-    auto prec = [&](const double* d, double* v) { ilu0_apply(LU, dg, Nb, d, v, w, relax_mode); };
+    if (half_product && !is_upper_alias(A)) return -1000;
+    std::vector<double> ubuf(half_product ? n : 0);
+    auto prec = [&](const double* d, double* v) {
+        if (half_product) ilu0_apply_u(LU, dg, Nb, d, v, w, relax_mode, ubuf.data());
+        else ilu0_apply(LU, dg, Nb, d, v, w, relax_mode);
+    };
     auto op = [&](const double* xin, double* y) {
-        spmv(A, xin, y);
+        // (half_product: xin is the vector the last prec() call produced - BiCGStab applies the operator to nothing else)
+        if (half_product) spmv_rest(A, xin, ubuf.data(), relax_mode == 0 ? w : 1.0, y, owner.empty() ? nullptr : owner.data());
+        else spmv(A, xin, y);
         if (W.numWells > 0) wells_apply(W, xin, y);
     };
     SolveResult r = bicgstab(n, rb.data(), rx.data(), prec, op, tol, maxit);
@@ -217,6 +238,26 @@ int orc_solve(int Nb, const int* rowptr, const int* col, const double* val, cons
         out->t_factor = std::chrono::duration<double>(t1 - t0).count();
         out->t_solve = std::chrono::duration<double>(t2 - t1).count();
         out->num_colors = reorder ? R.numColors() : 0;
+    }
+    return 0;
+}
+
+// t = A (M^-1 d), z = M^-1 d: one ILU0 application and the product behind it - plain (ilu0_apply, spmv) or in the half-product form
+// (ilu0_apply_u, spmv_rest); lu = the factors of orc_ilu0_factor.  The pair of bda/cusparseSolverBackend.cu:103-118.
+int orc_preconditioned_product(int Nb, const int* rowptr, const int* col, const double* val, const double* lu, const double* d, double w,
+                               int relax_mode, int half_product, double* t, double* z) {
+    Bcrs A = wrap(Nb, rowptr, col, val);
+    Bcrs LU = wrap(Nb, rowptr, col, lu);
+    const std::vector<int> dg = diag_index(LU);
+    const size_t n = (size_t)Nb * BS;
+    if (half_product) {
+        if (!is_upper_alias(A)) return -1000;
+        std::vector<double> u(n);
+        ilu0_apply_u(LU, dg, Nb, d, z, w, relax_mode, u.data());
+        spmv_rest(A, z, u.data(), relax_mode == 0 ? w : 1.0, t);
+    } else {
+        ilu0_apply(LU, dg, Nb, d, z, w, relax_mode);
+        spmv(A, z, t);
     }
     return 0;
 }

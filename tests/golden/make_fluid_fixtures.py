@@ -4,7 +4,8 @@
 own PVT test), never program text:
 
   opm-autodiff_amd/data/spe1_fluid.json  <- python/test_data/SPE1CASE1/SPE1CASE1.DATA (GRID :64-108, PROPS :109-250,
-                                            SOLUTION/EQUIL/RSVD :252-290), FIELD units -> SI
+                                            SOLUTION/EQUIL/RSVD :252-290, SCHEDULE :370-440: DRSDT, WELSPECS, COMPDAT,
+                                            WCONPROD, WCONINJE, TSTEP), FIELD units -> SI
   tests/golden/norne_pvt.json            <- tests/norne_pvt.data (PVTO, DENSITY; METRIC -> SI) and the (Rs, p) ->
                                             (mu_o, 1/B_o) expectations of tests/test_norne_pvt.cpp:64-294
 
@@ -55,8 +56,11 @@ def tokenize(path):
                 for tok in head.split():
                     tok = tok.strip("'")
                     mm = re.fullmatch(r"(\d+)\*(.+)", tok)
+                    md = re.fullmatch(r"(\d+)\*", tok)
                     try:
-                        if mm:
+                        if md:      # N defaulted items
+                            rec.extend([None] * int(md.group(1)))
+                        elif mm:
                             rec.extend([float(mm.group(2))] * int(mm.group(1)))
                         else:
                             rec.append(float(tok))
@@ -137,6 +141,22 @@ def spe1():
     out["equil"] = dict(datum_depth=eq[0] * U["length"], datum_pressure=eq[1] * U["pressure"], woc=eq[2] * U["length"],
                         goc=eq[4] * U["length"])
     out["rsvd"] = [[r[0] * U["length"], r[1] * U["rs"]] for r in table(k["RSVD"][0], 2)]
+    # SCHEDULE (:370-...): DRSDT, the two wells with their completions and controls, the report steps.  FIELD: liquid rates stb/day,
+    # gas rates Mscf/day, well diameter ft, TSTEP days; cell indices 1-based in the deck, 0-based here
+    DAY = 86400.0
+    ws = {r[0]: dict(name=r[0], i=int(r[2]) - 1, j=int(r[3]) - 1, ref_depth=r[4] * U["length"], preferred_phase=r[5].lower()) for r in k["WELSPECS"] if r}
+    for r in k["COMPDAT"]:
+        if r:
+            ws[r[0]].update(k_upper=int(r[3]) - 1, k_lower=int(r[4]) - 1, diameter=r[8] * U["length"])
+    for r in k["WCONPROD"]:
+        if r:   # name, OPEN, ORAT, oil rate, 4 defaulted items, BHP limit
+            assert r[2] == "ORAT", r
+            ws[r[0]].update(kind="producer", control=r[2].lower(), oil_rate=r[3] * STB / DAY, bhp_limit=r[8] * U["pressure"])
+    for r in k["WCONINJE"]:
+        if r:   # name, GAS, OPEN, RATE, surface rate, defaulted, BHP limit
+            assert r[1] == "GAS" and r[3] == "RATE", r
+            ws[r[0]].update(kind="injector", injected=r[1].lower(), control=r[3].lower(), surface_rate=r[4] * 1000.0 * SCF / DAY, bhp_limit=r[6] * U["pressure"])
+    out["schedule"] = dict(drsdt=k["DRSDT"][0][0] * U["rs"] / DAY, wells=[ws[n] for n in sorted(ws)], tstep=[d * DAY for d in k["TSTEP"][0]])
     out["units"] = {kk: vv for kk, vv in U.items()}
     path = os.path.join(ROOT, "opm-autodiff_amd", "data", "spe1_fluid.json")
     with open(path, "w") as f:

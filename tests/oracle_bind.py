@@ -38,8 +38,12 @@ class Oracle:
         L.orc_solve.argtypes = [C.c_int, _i, _i, _d, _d, _d, C.c_double, C.c_int, C.c_double, C.c_int, C.c_int,
                                 C.c_int, C.c_int, _vp, _vp, _vp, _vp, _vp, _vp, C.c_int, _vp,
                                 C.POINTER(OrcResult)]
+        L.orc_solve_hp.argtypes = [C.c_int, _i, _i, _d, _d, _d, C.c_double, C.c_int, C.c_double, C.c_int, C.c_int,
+                                   C.c_int, C.c_int, _vp, _vp, _vp, _vp, _vp, _vp, C.c_int, _vp, C.c_int,
+                                   C.POINTER(OrcResult)]
         L.orc_solve_noprec.argtypes = [C.c_int, _i, _i, _d, _d, _d, C.c_double, C.c_int, C.c_int,
                                        C.POINTER(OrcResult)]
+        L.orc_preconditioned_product.argtypes = [C.c_int, _i, _i, _d, _d, _d, C.c_double, C.c_int, C.c_int, _d, _d]
 
         L.orc_cpr_create.restype = C.c_void_p
         L.orc_cpr_create.argtypes = [C.c_double, C.c_double, C.c_double]
@@ -136,8 +140,10 @@ class Oracle:
         return xw
 
     def solve(self, Nb, rowptr, col, val, b, tol=1e-2, maxit=200, w=0.9, mode="post_scale", reorder="none",
-              zero_diag_fix=True, wells=None, sub_start=None, owner=None):
-        """sub_start: block-Jacobi ILU0 over contiguous row ranges; owner: the same with an owner id per row."""
+              zero_diag_fix=True, wells=None, sub_start=None, owner=None, half_product=False):
+        """sub_start: block-Jacobi ILU0 over contiguous row ranges; owner: the same with an owner id per row.
+        half_product: the product after every ILU0 application from the backward sweep's row sums (oracle/linalg.hpp: ilu0_apply_u,
+        spmv_rest - the order of libopmhip's opmhip_config.half_product)."""
         x = np.zeros(Nb * 3)
         res = OrcResult()
         W = wells or {}
@@ -145,12 +151,20 @@ class Oracle:
         ss = None if sub_start is None else np.ascontiguousarray(sub_start, np.int32)
         if owner is not None:
             nsub, ss = -1, np.ascontiguousarray(owner, np.int32)
-        rc = self.lib.orc_solve(Nb, rowptr, col, val, b, x, tol, maxit, w, RELAX[mode], REORDER[reorder],
-                                int(zero_diag_fix), W.get("numWells", 0), _p(W.get("val_pointers")),
-                                _p(W.get("Ccols")), _p(W.get("Bcols")), _p(W.get("Cnnzs")), _p(W.get("Dnnzs")),
-                                _p(W.get("Bnnzs")), nsub, _p(ss), C.byref(res))
+        rc = self.lib.orc_solve_hp(Nb, rowptr, col, val, b, x, tol, maxit, w, RELAX[mode], REORDER[reorder],
+                                   int(zero_diag_fix), W.get("numWells", 0), _p(W.get("val_pointers")),
+                                   _p(W.get("Ccols")), _p(W.get("Bcols")), _p(W.get("Cnnzs")), _p(W.get("Dnnzs")),
+                                   _p(W.get("Bnnzs")), nsub, _p(ss), int(bool(half_product)), C.byref(res))
         assert rc == 0, rc
         return x, res
+
+    def preconditioned_product(self, Nb, rowptr, col, val, lu, d, w=0.9, mode="post_scale", half_product=False):
+        """(A (M^-1 d), M^-1 d) with the factors of ilu0_factor; half_product: the product from the backward sweep's row sums"""
+        t, z = np.empty(Nb * 3), np.empty(Nb * 3)
+        rc = self.lib.orc_preconditioned_product(Nb, rowptr, col, val, lu, np.ascontiguousarray(d, np.float64), w, RELAX[mode],
+                                                 int(bool(half_product)), t, z)
+        assert rc == 0, rc
+        return t, z
 
     def solve_noprec(self, Nb, rowptr, col, val, b, tol, maxit, repeat=1):
         x = np.zeros(Nb * 3)
@@ -457,8 +471,40 @@ class OracleAsHipModel:
     def convergence(self, dt, tol_cnv=1e-2):
         return self.om.convergence(dt, tol_cnv)
 
-    def solve_jacobian_system(self):
+    # -- the well hooks newton.BlackoilModelHip calls when it carries a well model (wells.StandardWells) --------------------------------
+    def iq(self):
+        return self.om.iq()
+
+    def set_source(self, source, dsource=None):
+        self.om.set_source(source, dsource)
+
+    def wells_apply_residual(self, wells, res_well):
+        self._pending = (wells, np.array(res_well, np.float64))     # applied to the residual the next solve fetches
+
+    def wells_recover_solution(self, wells, res_well):
+        return self.om.o.wells_recover(wells, res_well, self._x)
+
+    def get_result(self):
+        return self._x.copy()
+
+    def solve_jacobian_system(self, wells=None):
         from types import SimpleNamespace
+        pending = getattr(self, "_pending", None)
+        if wells is not None or pending is not None:
+            om = self.om
+            jac, res = np.empty(om.nnzb * 9), np.empty(om.Nb * 3)
+            om.o.lib.orc_bo_assemble_fetch(om.h, _p(jac), _p(res))
+            if pending is not None:
+                res = om.o.wells_apply_residual(pending[0], pending[1], res)
+                self._pending = None
+            kw = dict(self.kw)
+            order = kw.pop("order", None)
+            if order is not None:     # the device's ordering (toOrder, fromOrder): natural-order ILU0 of the permuted system
+                from helpers import oracle_solve_in_order
+                self._x, r = oracle_solve_in_order(om.o, om.Nb, om.case["rowptr"], om.case["col"], jac, res, order[0], order[1], wells=wells, **kw)
+            else:
+                self._x, r = om.o.solve(om.Nb, om.case["rowptr"], om.case["col"], jac, res, wells=wells, **kw)
+            return SimpleNamespace(t_factor=r.t_factor, t_solve=r.t_solve, t_copy=0.0, iterations=r.iterations, converged=bool(r.converged), it=r.it)
         if self.threads > 1:
             kw = {k: v for k, v in self.kw.items() if k != "reorder"}
             self._x, r = self.om.solve_mt(threads=self.threads, **kw)

@@ -47,6 +47,12 @@ def test_the_default_is_the_measured_configuration(big):
     else:
         assert info["ilu_ordering"] == "graph_coloring" and info["chain_length"] == 0 and info["colors"] >= 2
     assert info["colors"] == len(big["rpc"]) and int(big["rpc"].sum()) == big["case"]["Nb"]
+    # ... and, round 6, the half-product form of ILU0-BiCGStab where the ordering is the line colouring (a 7-point grid has no triangles:
+    # U == upper(A)); the reference's Jones-Plassmann colouring keeps the plain form (its sweeps do not emit the row sums)
+    form = big["m"].product_form()
+    assert form["u_is_upper_a"] and form["half_product"] == (big["param"] is None)
+    if big["param"] is None:
+        assert form["rest_blocks"] == (len(big["case"]["col"]) + big["case"]["Nb"]) // 2     # lower entries + the diagonal
 
 
 def test_jacobian_and_residual_bitwise(big):
@@ -75,6 +81,23 @@ def test_ilu0_factors_and_application_bitwise(big, orc):
     assert np.array_equal(z, zo.reshape(Nb, 3)[to].reshape(-1))
 
 
+def test_preconditioned_product_bitwise(big, orc):
+    """the pair BiCGStab runs per half iteration - M^-1 d, then the product - in the form in force: with the library's default at this size
+    the backward sweeps store their row sums and the product streams the matrix without its U part (k_spmv_pipe_st<.., UADD> over tiles of
+    up to 64 rows, the rest stream written by k_ilu_factor), in the order oracle/linalg.hpp: ilu0_apply_u / spmv_rest state"""
+    m, case, to, fr = big["m"], big["case"], big["to"], big["fr"]
+    Nb = case["Nb"]
+    hp = big["param"] is None
+    m.ilu0_factor(want_factors=False)
+    lu_o = orc.ilu0_factor(Nb, big["rr"], big["rc"], big["rv"])
+    d = np.random.default_rng(43).standard_normal(3 * Nb)
+    t, z = m.preconditioned_product(d)
+    to_, zo = orc.preconditioned_product(Nb, big["rr"], big["rc"], big["rv"], lu_o, np.ascontiguousarray(d.reshape(Nb, 3)[fr].reshape(-1)), w=0.9,
+                                         mode="post_scale", half_product=hp)
+    assert np.array_equal(z, zo.reshape(Nb, 3)[to].reshape(-1))
+    assert np.array_equal(t, to_.reshape(Nb, 3)[to].reshape(-1))
+
+
 def test_solve_stops_on_the_oracles_half_iteration_and_the_next_iteration_follows(big, orc):
     """solveJacobianSystem on the assembled system: the oracle's half iteration, its reduction and its x (identical preconditioner and
     product bits; the scalar products are summed in another order); then updateSolution on both sides and a second assembly -
@@ -84,7 +107,8 @@ def test_solve_stops_on_the_oracles_half_iteration_and_the_next_iteration_follow
     m.assemble(DT, 0, fetch=False)            # the tests before this one may have left other factors / vectors behind
     sol = m.solve_jacobian_system()
     x = m.get_result()
-    xo, so = oracle_solve_in_order(orc, Nb, case["rowptr"], case["col"], big["jo"], big["ro"], to, fr, tol=1e-2, maxit=200, w=0.9)
+    xo, so = oracle_solve_in_order(orc, Nb, case["rowptr"], case["col"], big["jo"], big["ro"], to, fr, tol=1e-2, maxit=200, w=0.9,
+                                   half_product=big["param"] is None)
     assert sol.converged and so.converged and sol.it == so.it and sol.iterations == so.iterations
     assert abs(sol.reduction - so.reduction) <= 1e-8 * so.reduction
     np.testing.assert_allclose(x, xo, rtol=1e-8, atol=1e-11 * np.abs(xo).max())

@@ -7,7 +7,7 @@ pkg = importlib.import_module("opm-autodiff_amd")
 
 ap = argparse.ArgumentParser()
 ap.add_argument("--n", type=int, default=100)
-ap.add_argument("--reorder", default="graph_coloring_greedy")
+ap.add_argument("--reorder", default="graph_coloring_greedy", help="'auto': the library's own choice")
 ap.add_argument("--reps", type=int, default=20)
 ap.add_argument("--solve", action="store_true")
 a = ap.parse_args()
@@ -16,7 +16,7 @@ pat = pkg.grid.cartesian_pattern(a.n, a.n, a.n)
 val = pkg.grid.synthetic_block_values(pat, seed=1)
 Nb, nnzb = pat["Nb"], len(pat["col"])
 print("built %d rows %d blocks in %.1fs" % (Nb, nnzb, time.time() - t0), flush=True)
-s = pkg.capi.HipSolver(reorder=a.reorder)
+s = pkg.capi.HipSolver(reorder=None if a.reorder == "auto" else a.reorder)
 t0 = time.time(); s.set_pattern(Nb, pat["rowptr"], pat["col"]); print("set_pattern %.2fs" % (time.time() - t0), flush=True)
 b = np.random.default_rng(0).standard_normal(3 * Nb)
 s.upload_system(val, b)
@@ -26,6 +26,12 @@ bytes_ = {"spmv": 76 * nnzb + 4 * (Nb + 1) + 48 * Nb, "ilu_apply": 76 * nnzb + 4
 for k in ("ilu_factor", "spmv", "ilu_apply", "vector"):
     ms = s.time_kernel(k, a.reps)
     print("%-11s %8.3f ms  %7.1f GB/s algorithmic (%.1f MB)" % (k, ms, bytes_[k] / ms / 1e6, bytes_[k] / 1e6), flush=True)
+if s.product_form()["half_product"]:   # the forms ILU0-BiCGStab runs where U == upper(A) (opmhip_config.half_product)
+    nr = s.product_form()["rest_blocks"]
+    hb = {"rest_product": 76 * nr // 1 + 5 * Nb + 72 * Nb, "rest_product_dot2": 76 * nr + 5 * Nb + 96 * Nb, "ilu_apply_rowsums": bytes_["ilu_apply"] + 24 * Nb}
+    for k in ("rest_product", "rest_product_dot2", "ilu_apply_rowsums"):
+        ms = s.time_kernel(k, a.reps)
+        print("%-18s %8.3f ms  %7.1f GB/s algorithmic (%.1f MB)" % (k, ms, hb[k] / ms / 1e6, hb[k] / 1e6), flush=True)
 if a.solve:
     s.upload_system(val, b)
     res = s.solve_system(Nb, None, None, None, None) if False else s.solve_system(Nb, pat["rowptr"], pat["col"], val, b)
