@@ -60,8 +60,23 @@ def device_info(torch, index):
         return {"error": str(e)}
 
 
-def alg_bytes(Nb, nnzb):
-    """Algorithmic bytes per launch (SURVEY.md §8d / BASELINE.md §4), block size 3, double values, int32 indices."""
+def alg_bytes(Nb, nnzb, rest_blocks=0):
+    """Algorithmic bytes per launch (SURVEY.md §8d / BASELINE.md §4), block size 3, double values, int32 indices.
+    rest_blocks > 0: the half-product form of ILU0-BiCGStab is in force (opmhip_get_product_form: U == upper(A)) - the product inside a solve
+    streams the matrix WITHOUT its U part (that many blocks: lower entries and diagonal) plus the backward sweep's row sums, the ILU0
+    application stores those sums, the factorisation writes the rest stream.  The same accounting rules as SURVEY 8d: every array once
+    per kernel, 4-byte column indices, row pointers, vectors 24 B per row."""
+    B = alg_bytes_plain(Nb, nnzb)
+    if rest_blocks:
+        B["spmv_full"], B["spmv_full_operands"] = B["spmv"], B["spmv_operands"]
+        B["spmv"] = 76 * rest_blocks + 4 * (Nb + 1) + 72 * Nb                 # values + indices of the rest, x (gathered), the row sums, y
+        B["spmv_operands"] = B["spmv"] + 24 * Nb                              # + the second operand of the folded scalar products
+        B["ilu_apply"] += 24 * Nb                                             # the row sums written
+        B["ilu_factor"] += 72 * rest_blocks                                   # the rest stream written
+    return B
+
+
+def alg_bytes_plain(Nb, nnzb):
     return {
         # block-CSR SpMV exactly as SURVEY 8d counts it: 72-B blocks + 4-B column indices, row pointers, x and y (579.44 MB at 100^3)
         "spmv": 76 * nnzb + 4 * (Nb + 1) + 48 * Nb,
@@ -236,13 +251,30 @@ def cpu_baseline(pkg, case, src, nnzb):
     return out
 
 
-# linear iterations per Newton iteration of the N = 1 run of this bench (start-up window, default flags; profiles/r05_*): what the
-# decomposed runs' counts are put beside
-SINGLE_DOMAIN_LIN_ITS = {"ilu0": 17.5, "cpr": 4.75, "cpr_trueimpes": 4.75, "cpr_quasiimpes": 3.8}
-# linear iterations per Newton iteration of the N = 1 run of this bench (start-up window, default flags; profiles/r05_*): what the
-# decomposed runs' counts are put beside
-SINGLE_DOMAIN_LIN_ITS = {"ilu0": 17.5, "cpr": 4.75, "cpr_trueimpes": 4.75, "cpr_quasiimpes": 3.8}
 COMM_SCOPES = ("halo", "allreduce", "cpr_gather")
+
+
+def single_domain_comparator(detail_path, n, steps, warmup, preconditioner, flags_default):
+    """Linear iterations per Newton iteration of the ONE-domain run of this bench that a decomposed run's count is put beside - read from the
+    detail file an N = 1 run left on this box (the driver runs N = 1 first), and only if that run was the same case: same cells per GPU, same
+    window, same preconditioner, default ordering / smoother flags on both sides.  None otherwise: no typed-in figure stands in for a
+    measurement nobody made on this box."""
+    try:
+        with open(detail_path) as f:
+            d = json.load(f)
+    except (OSError, ValueError):
+        return None
+    try:
+        if d.get("n_gpus") != 1 or d["config"]["cells_per_gpu"] != n ** 3 or d["steps"] != steps or d["warmup"] != warmup:
+            return None
+        if not flags_default or d["config"].get("ilu_ordering_chosen_by") != "library default (auto)":
+            return None
+        if d.get("preconditioner") == preconditioner:
+            return round(float(d["linear_iterations_per_newton"]), 2)
+        side = d.get("cpr" if preconditioner in ("cpr", "cpr_trueimpes") else preconditioner)
+        return round(float(side["linear_iterations_per_newton"]), 2) if side and "linear_iterations_per_newton" in side else None
+    except (KeyError, TypeError, ValueError):
+        return None
 
 
 def comm_summary(every):
@@ -278,6 +310,14 @@ def compact_line(out, detail_path):
     line["roofline"] = {k: _r(ro[k]) for k in ("bound", "kernel", "achieved", "peak", "unit", "frac", "traffic", "avg_launch_ms", "algorithmic_bytes_per_launch",
                                                "frac_of_stream_ceiling")}
     line["roofline"]["traffic_source"] = ro["traffic_source"] if len(str(ro["traffic_source"])) < 80 else str(ro["traffic_source"])[:77] + "..."
+    if ro.get("full_spmv"):
+        line["roofline"]["full_spmv"] = {k: ro["full_spmv"][k] for k in ("avg_launch_ms", "achieved", "frac")}
+    if isinstance(line["roofline"].get("kernel"), str) and len(line["roofline"]["kernel"]) > 120:
+        line["roofline"]["kernel"] = line["roofline"]["kernel"][:117] + "..."
+    if out.get("product_form"):
+        line["half_product"] = bool(out["product_form"]["half_product"])
+    if out.get("plugin"):
+        line["plugin"] = {"error": out["plugin"]["error"][:120]} if "error" in out["plugin"] else {k: out["plugin"][k] for k in ("t_copy_ms", "t_copy_ms_pageable", "t_factor_ms", "t_solve_ms", "GBps_h2d")}
     # the other kernels of the window behind `value`: algorithmic GB/s (bytes per launch in DESIGN.md section 4)
     line["kernel_GBps"] = {k: v["algorithmic_GBps"] for k, v in out["kernels"].items()}
     cb = out.get("cpu_baseline")
@@ -317,7 +357,7 @@ def fit_line(line):
     says what was dropped; the detail file keeps everything"""
     txt = json.dumps(line)
     dropped = []
-    for k in ("cpr_reuse_setup_2_sync", "cpr_amg_jacobi_smoother", "cpr_reuse_setup_2", "cpr_quasiimpes", "cpr", "comm", "kernel_GBps", "steady_state", "rccl", "device"):
+    for k in ("cpr_reuse_setup_2_sync", "cpr_amg_jacobi_smoother", "cpr_reuse_setup_2", "cpr_quasiimpes", "plugin", "cpr", "comm", "kernel_GBps", "steady_state", "rccl", "device"):
         if len(txt) < LINE_LIMIT:
             break
         if k in line:
@@ -366,7 +406,7 @@ def kernel_source_hash():
     return h.hexdigest()[:16]
 
 
-def pmc_traffic(kernel_substr):
+def pmc_traffic(*kernel_substrs):
     """HBM-side traffic of a kernel per launch from the newest committed PMC summary (PMC passes need their own
     rocprofv3 runs, tools/pmc_quick.sh + tools/pmc_to_json.py) - only if it was measured on THESE kernel sources."""
     import glob
@@ -376,7 +416,7 @@ def pmc_traffic(kernel_substr):
             d = json.load(f)
         if d.get("kernel_source_sha16") != kernel_source_hash():
             continue
-        vals = [v["traffic_bytes_per_launch"] for k, v in d["kernels"].items() if kernel_substr in k]
+        vals = [v["traffic_bytes_per_launch"] for k, v in d["kernels"].items() if all(sub in k for sub in kernel_substrs)]
         if vals:
             return sum(vals) / len(vals), os.path.relpath(tj, ROOT)
     return None, "no PMC summary under profiles/ was measured on the present kernel sources (sha16 %s)" % kernel_source_hash()
@@ -391,7 +431,7 @@ def main():
     ap.add_argument("--reorder", default=None, help="ILU0 ordering; default: the library's own choice (opmhip_default_config: auto), reported in config.ilu_ordering")
     ap.add_argument("--chain-length", type=int, default=0, help="rows per chain of the line-coloured ILU0 ordering; 0: the library's choice (10 at 10^6 cells)")
     ap.add_argument("--full-line", action="store_true", help="tools/ only: print the full record as the one line (tens of KB: the driver could not parse that from its tail of stdout)")
-    ap.add_argument("--detail", default=None, help="file for the full record (per-window kernel scopes, reports, time steps); default gpurun_out/bench_detail.json")
+    ap.add_argument("--detail", default=None, help="file for the full record (per-window kernel scopes, reports, time steps); default gpurun_out/bench_detail.json (N > 1: bench_detail_nN.json)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--steady-after", type=int, default=200, help="second timed window starts at this Newton iteration (0: none)")
     ap.add_argument("--steady-steps", type=int, default=100)
@@ -465,7 +505,8 @@ def main():
     model.set_source(src)
     sim = make_simulation(pkg, model)
     Nb, nnzb = case["Nb"], len(case["col"])
-    B = alg_bytes(Nb, nnzb)
+    product_form = model.product_form()     # what opmhip_config.half_product resolved to on this pattern
+    B = alg_bytes(Nb, nnzb, product_form["rest_blocks"] if product_form["half_product"] else 0)
 
     def use_cpr_of(mdl):
         return getattr(mdl, "_bench_preconditioner", "ilu0") != "ilu0"
@@ -529,7 +570,7 @@ def main():
             comm = comm_summary(every)
         ls_bytes = sum(Bm[k] * prof[k][0] for k in ("spmv", "ilu_apply", "ilu_factor", "vector"))
         ls_ms = sum(prof[k][1] for k in ("spmv", "ilu_apply", "ilu_factor", "vector"))
-        return {"elapsed": elapsed, "steps": steps, "kernels": kernels, "spmv_boundary_share_of_time": boundary_share, "comm": comm, "comm": comm,
+        return {"elapsed": elapsed, "steps": steps, "kernels": kernels, "spmv_boundary_share_of_time": boundary_share, "comm": comm,
                 "profiled": {"every": PROFILE_EVERY, "solves": solves_profiled, "linear_iterations": its_profiled,
                              "linear_iterations_per_profiled_solve": (its_profiled / solves_profiled) if solves_profiled else None},
                 "linear_iterations_per_newton": (rep.total_linear_iterations - rep0.total_linear_iterations) / steps,
@@ -617,8 +658,41 @@ def main():
             cpr_sides["cpr_reuse_setup_2_sync"] = guarded("CPR side run (cpr, --cpr-reuse-setup=2)", cpr_window("cpr", cpr_reuse_setup=2))
     # what a kernel that only streams reaches on THIS card (reads the Jacobian's values once per launch)
     stream = guarded("stream_read probe", lambda: {"ms": model.time_kernel("stream_read", reps=20)})
+    # the whole block-CSR product (SURVEY 8d's 579.44 MB at 100^3) back to back, 20 launches: with the half-product form in force no kernel
+    # of a solve computes it any more, so it is timed here, outside the solve, for the record north_star asks for
+    full_spmv = guarded("full SpMV probe", lambda: {"ms": model.time_kernel("spmv", reps=20)}) if a.preconditioner == "ilu0" else {}
     stream_ms = stream.get("ms")
     stream_GBps = 72.0 * nnzb / stream_ms / 1e6 if stream_ms else None
+
+    # The drop-in at its own speed: opmhip_solve_system with HOST pointers - what a Flow that applies INTEGRATION.md
+    # section 1 only (--accelerator-mode=hip, assembly on the host) gets per linear solve: the copy of 500 MB of values over PCIe, the
+    # factorisation, BiCGStab.  The Jacobian and residual of the present state are fetched once and handed to a second context three times,
+    # with the arrays registered for DMA (opmhip_config.pin_host_arrays, what host/hipSolverBackend.hpp asks for) and without.
+    def plugin_window():
+        jac, res = model.assemble(DAY, 0)
+        rp, ci = case["rowptr"], case["col"]
+        o = {}
+        for pin in (1, 0):
+            sv = pkg.capi.HipSolver(device_id=local_rank, tolerance=1e-2, maxit=200, ilu_relaxation=0.9, pin_host_arrays=pin)
+            runs = []
+            for k in range(4):
+                r = sv.solve_system(Nb, rp if k == 0 else None, ci if k == 0 else None, jac, res)
+                x = sv.get_result()
+                runs.append((r.t_copy, r.t_factor, r.t_solve, r.iterations, bool(r.converged)))
+            later = runs[1:]      # the first call orders the pattern and (pin = 1) registers the arrays
+            key = "" if pin else "_pageable"
+            o["t_copy_ms" + key] = round(1e3 * min(t[0] for t in later), 3)
+            if pin:
+                o["t_factor_ms"] = round(1e3 * min(t[1] for t in later), 3)
+                o["t_solve_ms"] = round(1e3 * min(t[2] for t in later), 3)
+                o["iterations"] = later[0][3]
+                o["converged"] = later[0][4]
+                o["first_call_t_copy_ms"] = round(1e3 * runs[0][0], 1)
+                o["GBps_h2d"] = round((72.0 * nnzb + 24.0 * Nb) / min(t[0] for t in later) / 1e9, 1)
+            del sv
+        o["bytes_h2d"] = 72 * nnzb + 24 * Nb
+        return o
+    plugin = guarded("plug-in window", plugin_window) if (world == 1 and a.preconditioner == "ilu0" and not a.no_cpr_side_run) else None
 
     dots_separate = os.environ.get("OPMHIP_TUNING", "") == "1" and os.environ.get("OPMHIP_DOTS_SEPARATE", "0") not in ("", "0")
     sp = kernels.get("spmv", {"avg_ms": float("nan"), "algorithmic_GBps": float("nan")})
@@ -626,7 +700,8 @@ def main():
     traffic, traffic_src = (None, "single-GPU 100^3 line-colouring runs only")
     chosen = model.ordering_info()   # what the library's defaults resolved to (or what the flags forced)
     if world == 1 and n == 100 and chosen["ilu_ordering"] == "line_coloring" and chosen["chain_length"] == 10:
-        traffic, traffic_src = pmc_traffic("k_spmv")
+        # (half-product form: the product kernels of the solve are the <.., true> instantiations; the whole product timed by the probe is not)
+        traffic, traffic_src = pmc_traffic("k_spmv_pipe_st<", ", true>") if product_form["half_product"] else pmc_traffic("k_spmv")
     out = {
         "metric": "Newton iterations/sec, 1M-cell 3-phase black-oil (assembly + ILU0/BiCGStab solve + update)",
         # Whole-job aggregate.  Weak scaling: every rank advances the SAME coupled Newton iteration on its own 1M-cell
@@ -667,18 +742,26 @@ def main():
         "cpr_reuse_setup_2": cpr_sides.get("cpr_reuse_setup_2"),
         "cpr_reuse_setup_2_sync": cpr_sides.get("cpr_reuse_setup_2_sync"),
         "preconditioner": a.preconditioner,
+        # opmhip_solve_system with host pointers on this case's Jacobian (second context): milliseconds per linear solve by phase
+        "plugin": plugin,
         "rccl": rccl,
         # decomposed runs: the communication spans of the profiled solves of the window behind `value` (halo: pack -> exchange -> ghosts in, on
         # the halo stream beside the interior tiles; allreduce: local sums -> all-reduce; cpr_gather: the joined level's all-gather + cycle),
         # max / mean over the ranks, and the iteration count next to the one-domain figure of the same case (N = 1 run of this bench)
         "comm": None if W["comm"] is None else dict(W["comm"], profiled_solves=W["profiled"]["solves"], profiled_every=PROFILE_EVERY,
                                                     linear_iterations_per_newton=round(W["linear_iterations_per_newton"], 2),
-                                                    single_domain_linear_iterations_per_newton=SINGLE_DOMAIN_LIN_ITS.get(a.preconditioner)),
+                                                    single_domain_linear_iterations_per_newton=single_domain_comparator(
+                                                        os.path.join(ROOT, "gpurun_out", "bench_detail.json"), n, a.steps, a.warmup, a.preconditioner,
+                                                        a.reorder is None and a.chain_length == 0 and a.cpr_amg_ilu_levels is None and a.cpr_reuse_setup == 3)),
         "device": device_info(torch, local_rank),
         "stream_ceiling": {"read_GBps": round(stream_GBps, 1) if stream_GBps else None, "bytes_per_launch": 72 * nnzb,
                            "avg_launch_ms": round(stream_ms, 5) if stream_ms else None, "error": stream.get("error"),
                            "kernel": "k_stream_read: the Jacobian's value array read once, 16-B loads, nothing else (back to back, 20 launches)"},
-        "roofline": {"bound": "hbm", "kernel": "k_spmv (block-CSR SpMV, 3x3 double blocks)", "achieved": sp["algorithmic_GBps"],
+        "product_form": product_form,
+        "roofline": {"bound": "hbm", "kernel": ("k_spmv_pipe_st<UADD>: the block-CSR product in its half-product form - the matrix without its U part "
+                                                "(%d of %d blocks) + the backward sweep's row sums" % (product_form["rest_blocks"], nnzb))
+                                               if product_form["half_product"] else "k_spmv (block-CSR SpMV, 3x3 double blocks)",
+                     "achieved": sp["algorithmic_GBps"],
                      "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": (sp["algorithmic_GBps"] / HBM_PEAK_GBS) if ok else None,
                      "frac_of_stream_ceiling": (sp["algorithmic_GBps"] / stream_GBps) if (ok and stream_GBps) else None,
                      "traffic": traffic, "traffic_unit": "bytes per launch (L2 fabric side; FETCH_SIZE x 2 + WRITE_SIZE, KiB -> B)",
@@ -687,6 +770,10 @@ def main():
                      # products behind a product ride in the kernel (no wells here, unless OPMHIP_DOTS_SEPARATE is set): their
                      # second operand (24 B per row) is part of what the kernel reads but not of the figure the fraction is taken of
                      "algorithmic_bytes_per_launch": B["spmv"],
+                     # the whole product (579.44 MB), timed back to back outside the solve: {avg_launch_ms, achieved GB/s, frac of 8 TB/s}
+                     "full_spmv": None if not full_spmv.get("ms") else {"avg_launch_ms": round(full_spmv["ms"], 5), "achieved": round(alg_bytes_plain(Nb, nnzb)["spmv"] / full_spmv["ms"] / 1e6, 1),
+                                                                         "frac": round(alg_bytes_plain(Nb, nnzb)["spmv"] / full_spmv["ms"] / 1e6 / HBM_PEAK_GBS, 4),
+                                                                         "algorithmic_bytes_per_launch": alg_bytes_plain(Nb, nnzb)["spmv"]},
                      "operand_bytes_per_launch": B["spmv"] if dots_separate else B["spmv_operands"],
                      "scalar_products": "k_dots behind every product (OPMHIP_DOTS_SEPARATE)" if dots_separate else "folded into the kernel (one partial sum per workgroup)"},
     }
@@ -695,7 +782,8 @@ def main():
         out["gpu_over_cpu"] = out["value"] / out["cpu_baseline"]["value"]
     if rank == 0:
         # the full record goes to a file; the line on stdout is what the driver parses and stays under 4 KB
-        detail = a.detail or os.path.join(ROOT, "gpurun_out", "bench_detail.json")
+        # (N > 1 runs write a file of their own: the N = 1 record stays where the later runs of a scaling series look for their comparators)
+        detail = a.detail or os.path.join(ROOT, "gpurun_out", "bench_detail.json" if world == 1 else "bench_detail_n%d.json" % world)
         try:
             os.makedirs(os.path.dirname(os.path.abspath(detail)), exist_ok=True)
             with open(detail, "w") as f:

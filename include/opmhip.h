@@ -138,6 +138,15 @@ typedef struct opmhip_config {
                             * where the pattern allows it, the ordering is line-coloured and the system is large enough for the pipelined
                             * kernels, single domain; > 0: wherever the pattern and the ordering allow it; < 0: never.  Ignored with a CPR
                             * preconditioner.  opmhip_get_product_form says what is in force.  ABI 10 */
+    int pin_host_arrays;   /* 1: the host arrays handed to opmhip_solve_system (vals, b) and opmhip_get_result (x) are registered with the
+                            * driver (hipHostRegister) the first time each address is seen, so that every later copy is a DMA at the link's
+                            * rate instead of a staged copy out of pageable memory (500 MB of values at 10^6 cells: 13.5 ms -> the PCIe
+                            * figure).  For callers whose arrays keep their addresses for the life of the context - Flow's do:
+                            * the matrix and the vectors are allocated once (bda/BdaBridge.cpp:199-232, linalg/ISTLSolverEbos.hpp:216-219),
+                            * which is what the reference's CUDA back-end relies on when it copies from them every solve
+                            * (bda/cusparseSolverBackend.cu:314-338); host/hipSolverBackend.hpp sets it.  The ranges are unregistered by
+                            * opmhip_destroy; a refused registration falls back to the plain copy.  0 (default): plain copies - arrays that
+                            * come and go (numpy temporaries) must not be pinned behind their owner's back.  ABI 10 */
 } opmhip_config;
 
 /* bda::BdaResult (bda/BdaResult.hpp:28-40) plus the reference's per-phase timers. */

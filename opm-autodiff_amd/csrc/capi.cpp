@@ -180,8 +180,23 @@ int upload_wells(opmhip_ctx* c, const opmhip_wells* w) {
     return OPMHIP_SUCCESS;
 }
 
+// opmhip_config.pin_host_arrays: the caller's array becomes page-locked and mapped for DMA the first time its address is seen (the
+// reference's CUDA back-end copies from the same fixed addresses every solve, bda/cusparseSolverBackend.cu:314-338; Flow allocates them
+// once, bda/BdaBridge.cpp:199-232).  A refused registration is remembered and the plain copy stays.
+void pin_host_range(opmhip_ctx* c, const void* p, size_t bytes) {
+    if (!c->cfg.pin_host_arrays || !p || bytes == 0) return;
+    for (const auto& r : c->pinned)
+        if (r.p == p) return;
+    const hipError_t e = hipHostRegister(const_cast<void*>(p), bytes, hipHostRegisterDefault);
+    if (e != hipSuccess) (void)hipGetLastError();   // (clears the sticky error: the fallback is the ordinary copy)
+    c->pinned.push_back({p, e == hipSuccess ? bytes : 0});
+    if (c->cfg.verbosity > 0) std::fprintf(stderr, "opmhip: host range %p (%zu bytes) %s\n", p, bytes, e == hipSuccess ? "registered for DMA" : "could not be registered: plain copies");
+}
+
 int upload_system(opmhip_ctx* c, const double* vals, const double* b) {
     const Pattern& P = c->pat;
+    pin_host_range(c, vals, (size_t)P.nnzb * BB * sizeof(double));
+    pin_host_range(c, b, (size_t)P.Nb * BS * sizeof(double));
     if (vals) {
         OPMHIP_HIP(c, hipMemcpyAsync(c->d_stageA, vals, (size_t)P.nnzb * BB * sizeof(double), hipMemcpyHostToDevice, c->stream));
         launch_permute_blocks(c, c->d_stageA, c->d_A);
@@ -255,6 +270,7 @@ int opmhip_create(const opmhip_config* cfg, opmhip_ctx** out) {
     if (cfg->chain_length < 0) { g_err = "opmhip_create: chain_length < 0"; return OPMHIP_INVALID_ARGUMENT; }
     if (cfg->cpr_reuse_setup < 0 || cfg->cpr_reuse_setup > 3) { g_err = "opmhip_create: cpr_reuse_setup must be 0 .. 3"; return OPMHIP_INVALID_ARGUMENT; }
     if (cfg->cpr_async_setup < 0 || cfg->cpr_async_setup > 1) { g_err = "opmhip_create: cpr_async_setup must be 0 or 1"; return OPMHIP_INVALID_ARGUMENT; }
+    if (cfg->pin_host_arrays < 0 || cfg->pin_host_arrays > 1) { g_err = "opmhip_create: pin_host_arrays must be 0 or 1"; return OPMHIP_INVALID_ARGUMENT; }
     int ndev = 0;
     hipError_t e = hipGetDeviceCount(&ndev);
     if (e != hipSuccess || ndev <= 0) {
@@ -282,6 +298,8 @@ void opmhip_destroy(opmhip_ctx* c) {
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     cpr_shutdown(c);
     comm_release(c);
+    for (const auto& r : c->pinned)
+        if (r.bytes) (void)hipHostUnregister(const_cast<void*>(r.p));
     for (void* p : c->allocs) (void)hipFree(p);
     if (c->h_pinned) (void)hipHostFree(c->h_pinned);
     if (c->wells.h_x) (void)hipHostFree(c->wells.h_x);
@@ -523,6 +541,7 @@ int opmhip_get_result(opmhip_ctx* c, double* x) {
         if (!x) return fail(c, OPMHIP_INVALID_ARGUMENT, "get_result: x == NULL");
         if (!c->have_result) return fail(c, OPMHIP_NOT_READY, "get_result before a solve");
         OPMHIP_HIP(c, hipSetDevice(c->device));
+        pin_host_range(c, x, (size_t)c->pat.Nb * BS * sizeof(double));
         return vec_out(c, c->d_x, x);
     });
 }

@@ -395,6 +395,9 @@ struct opmhip_ctx {
     opmhip::CprDev cpr;
     opmhip::Profiler prof;
     std::vector<void*> allocs;
+    // opmhip_config.pin_host_arrays: host ranges of the caller registered for DMA (first address seen -> hipHostRegister; bytes == 0: refused, not tried again)
+    struct HostRange { const void* p; size_t bytes; };
+    std::vector<HostRange> pinned;
 };
 
 namespace opmhip {

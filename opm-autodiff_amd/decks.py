@@ -72,10 +72,16 @@ def cartesian_case(nx, ny, nz, dx=20.0, dy=20.0, dz=5.0, top=2500.0, poro=0.25, 
                 volume=np.ascontiguousarray(c["volume"]), depth=c["depth"], fluid=c["fluid"], pv=c["pv"], meaning=c["meaning"])
 
 
-def spe1_case(state="equil"):
-    """The SPE1CASE1 grid (10 x 10 x 3, layered DZ/PERM, FIELD deck converted to SI) with its EQUIL-like initial
-    state: p = 4800 psia at the datum with a constant oil gradient, Sw = connate 0.12, Rs = 1.27 Mscf/stb constant
-    (RSVD), i.e. undersaturated oil everywhere (python/test_data/SPE1CASE1/SPE1CASE1.DATA:252-290)."""
+def spe1_case(props=None, state="equil"):
+    """The SPE1CASE1 deck (python/test_data/SPE1CASE1/SPE1CASE1.DATA; FIELD units converted to SI in data/spe1_fluid.json): its grid
+    (10 x 10 x 3, layered DZ / PERM, :64-108), its PROPS (:109-250) and, state = "equil", its SOLUTION section (:252-290) - EQUIL 8400 ft /
+    4800 psia, contacts outside the reservoir, RSVD 1.27 Mscf/stb - equilibrated by equil.equilibrate (initstateequil.hh's algorithm, held
+    by the twelve decks of tests/test_equil.cc) on top of `props`: an object with probe(p, rs, sw, sg) - capi.HipFluid(fluid), the DEVICE's
+    property functions (the default: a GPU is needed), or the oracle's in CPU tests.  The case carries the SCHEDULE section's DRSDT 0
+    ("drsdt", "drsdt_all_cells": the Rs cap of eclproblem.hh:1711-1732 with the keyword's option ALL - every cell's Rs is held at its value
+    of the last accepted step, :2053-2070) and, under "schedule", its wells and report steps (spe1_wells builds the well model).
+    state = "rough" (no props needed): a constant oil gradient from the datum pressure, Sw = connate, Rs = the RSVD value - a plausible
+    undersaturated state for tests that only need one."""
     fl, d = _fluid.spe1_fluid()
     g = d["grid"]
     nx, ny, nz = g["nx"], g["ny"], g["nz"]
@@ -105,17 +111,57 @@ def spe1_case(state="equil"):
         t1, t2 = half(row[m]), half(col[m])
         T[m] = 1.0 / (1.0 / t1 + 1.0 / t2)
     e = d["equil"]
-    rho_o = d["density"]["oil"] * 0.78  # rough reservoir oil gradient; the state only has to be plausible
-    p = e["datum_pressure"] + rho_o * 9.80665 * (depth - e["datum_depth"])
     pv = np.zeros((Nb, 3))
-    pv[:, 0] = d["swof"][0][0]
-    pv[:, 1] = p
-    pv[:, 2] = d["rsvd"][0][1]
     meaning = np.full(Nb, SW_PO_RS, np.uint8)
+    if state == "rough":
+        rho_o = d["density"]["oil"] * 0.78  # rough reservoir oil gradient; the state only has to be plausible
+        pv[:, 0] = d["swof"][0][0]
+        pv[:, 1] = e["datum_pressure"] + rho_o * 9.80665 * (depth - e["datum_depth"])
+        pv[:, 2] = d["rsvd"][0][1]
+    else:
+        from . import equil as _equil
+        if props is None:
+            from . import capi as _capi
+            props = _capi.HipFluid(fl)           # the device's fluid and saturation functions (raises without a GPU: no CPU fallback)
+        rec = dict(datum=e["datum_depth"], pressure=e["datum_pressure"], zwoc=e["woc"], pcow_woc=0.0, zgoc=e["goc"], pcgo_goc=0.0)
+        rsvd = np.array(d["rsvd"])
+        limits = dict(Swl=d["swof"][0][0], Swu=d["swof"][-1][0], Sgl=d["sgof"][0][0], Sgu=d["sgof"][-1][0])
+        rho = (d["density"]["oil"], d["density"]["water"], d["density"]["gas"])
+        # one equilibration per layer (cells of a layer share their centre depth), spread over the layer's cells
+        zc = g["tops"] + np.concatenate([[0.0], np.cumsum(dzs)[:-1]]) + 0.5 * dzs
+        r = _equil.equilibrate(props, rho, rec, zc, (g["tops"], g["tops"] + float(dzs.sum())), limits,
+                               rs_func=_equil.RsVD(props, rsvd[:, 0], rsvd[:, 1]))
+        sg = r["sg"][k]
+        pv[:, 0] = r["sw"][k]
+        pv[:, 1] = r["po"][k]
+        pv[:, 2] = np.where(sg > 0.0, sg, r["rs"][k])
+        meaning = np.where(sg > 0.0, SW_PO_SG, SW_PO_RS).astype(np.uint8)
+    sched = d.get("schedule", {})
     return dict(Nb=Nb, nx=nx, ny=ny, nz=nz, rowptr=pat["rowptr"], col=col, face_dir=pat["face_dir"],
                 trans=np.ascontiguousarray(T), area=np.ascontiguousarray(area), poro=np.full(Nb, g["poro"]),
                 volume=np.ascontiguousarray(volume), depth=np.ascontiguousarray(depth), fluid=fl,
-                pv=np.ascontiguousarray(pv.reshape(-1)), meaning=meaning)
+                pv=np.ascontiguousarray(pv.reshape(-1)), meaning=meaning, perm=perm, dx=g["dx"], dy=g["dy"], dz_cell=dz,
+                drsdt=[sched["drsdt"]] if "drsdt" in sched else None,
+                drsdt_all_cells=[1 if sched.get("drsdt_option", "ALL") == "ALL" else 0] if "drsdt" in sched else None, schedule=sched)
+
+
+def spe1_wells(case):
+    """The deck's two wells (SPE1CASE1.DATA:383-425) as a wells.StandardWells: INJ, gas at a surface rate of 100 MMscf/day into (1, 1, 1),
+    BHP limit 9014 psia; PROD, 20 000 stb/day of oil out of (10, 10, 3), BHP limit 1000 psia; connection factors by Peaceman's formula from
+    the cell's permeability and the wellbore diameter (COMPDAT item 9)"""
+    from . import wells as _wells
+    nx, ny = case["nx"], case["ny"]
+    out = []
+    for w in case["schedule"]["wells"]:
+        cells = [w["i"] + nx * (w["j"] + ny * kk) for kk in range(w["k_upper"], w["k_lower"] + 1)]
+        tw = [_wells.peaceman_factor(case["perm"][c], case["dx"], case["dy"], case["dz_cell"][c], w["diameter"]) for c in cells]
+        if w["kind"] == "producer":
+            ctl = ("rate", _wells.OIL, w["oil_rate"])
+            out.append(_wells.Well(w["name"], cells, tw, w["ref_depth"], True, ctl, w["bhp_limit"]))
+        else:
+            comp = {"gas": _wells.GAS, "water": _wells.WATER, "oil": _wells.OIL}[w["injected"]]
+            out.append(_wells.Well(w["name"], cells, tw, w["ref_depth"], False, ("rate", comp, w["surface_rate"]), w["bhp_limit"], inj_phase=w["injected"]))
+    return _wells.StandardWells(out, case["depth"])
 
 
 # Field rate of the five-spot pair on a 100 x 100 x 100 grid (scaled with the areal cell count elsewhere): 0.4 % of a well

@@ -73,6 +73,9 @@ public:
         // of a greedy-coloured corner-point grid Jacobi is 1.5 x faster)
         cfg.cpr_amg_ilu_levels = cpr_amg_ilu_levels;
         cfg.cpr_gather_rows = cpr_gather_rows;   // parallel runs: the pressure stage spans the ranks (0: default size of the joined level; < 0: off)
+        // Flow's matrix values, right-hand side and solution vector keep their addresses for the life of the run (bda/BdaBridge.cpp:199-232,
+        // linalg/ISTLSolverEbos.hpp:216-219): registered for DMA the first time they are seen, every later copy runs at the link's rate
+        cfg.pin_host_arrays = 1;
         const int rc = opmhip_create(&cfg, &ctx);
         if (rc != OPMHIP_SUCCESS) throw std::logic_error(std::string("hipSolverBackend: ") + opmhip_last_error(nullptr));
     }

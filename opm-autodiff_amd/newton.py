@@ -267,6 +267,9 @@ class AdaptiveTimeStepping:
         self.history = []          # (dt, newton iterations, accepted)
         self.pid = PIDTimeStepControl(self.p.time_step_control_tolerance) if self.p.time_step_control == "pid+newtoniteration" else None
         self.relative_changes = []  # what the PID control saw, per accepted time step
+        self.t_end = None           # end of the report step under way (advance_report_step): sub-steps are cut to land on it
+        self.on_accept = None       # callable(dt): after every accepted sub-step, with the model still in that step's converged state (Flow's
+                                    # per-step reporting hooks in AdaptiveTimeSteppingEbos::step; here: tests that integrate well rates)
 
     def _next_dt(self, dt, iterations):
         p = self.p
@@ -290,6 +293,10 @@ class AdaptiveTimeStepping:
     def next_newton_iteration(self):
         """Runs nonlinear iterations until one of them actually solved a system; returns its report."""
         while True:
+            if self.t_end is not None and self.iteration == 0:
+                if self.time >= self.t_end - 1e-9 * max(1.0, abs(self.t_end)):
+                    return None                                   # the report step is complete
+                self.dt = min(self.dt, self.t_end - self.time)    # the sub-step timer never runs past the report step (AdaptiveSimulatorTimer)
             if self.iteration == 0 and self.restarts == 0:
                 self.model.advance_time_level()
             if self.iteration == 0 and hasattr(self.model, "begin_time_step"):
@@ -304,6 +311,8 @@ class AdaptiveTimeStepping:
                 self.iteration += 1
                 if rep.converged:
                     self.model.end_time_step(self.dt)   # problem.endTimeStep() of the accepted sub-step
+                    if self.on_accept is not None:
+                        self.on_accept(self.dt)
                     self.history.append((self.dt, self.iteration - 1, True))
                     self.time += self.dt
                     self.dt = self._next_dt(self.dt, self.iteration - 1)
@@ -324,3 +333,17 @@ class AdaptiveTimeStepping:
                     continue
             if rep is not None and rep.total_newton_iterations:
                 return rep
+
+    def advance_report_step(self, length):
+        """AdaptiveTimeSteppingEbos::step over one report step of the SCHEDULE section (TSTEP): sub-steps under the time-step control until
+        its end, the last one cut to land on it (:283-520).  -> the reports of its Newton iterations"""
+        self.t_end = self.time + float(length)
+        reports = []
+        try:
+            while True:
+                r = self.next_newton_iteration()
+                if r is None:
+                    return reports
+                reports.append(r)
+        finally:
+            self.t_end = None

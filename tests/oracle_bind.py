@@ -501,6 +501,7 @@ class OracleAsHipModel:
             order = kw.pop("order", None)
             if order is not None:     # the device's ordering (toOrder, fromOrder): natural-order ILU0 of the permuted system
                 from helpers import oracle_solve_in_order
+                kw.pop("reorder", None)
                 self._x, r = oracle_solve_in_order(om.o, om.Nb, om.case["rowptr"], om.case["col"], jac, res, order[0], order[1], wells=wells, **kw)
             else:
                 self._x, r = om.o.solve(om.Nb, om.case["rowptr"], om.case["col"], jac, res, wells=wells, **kw)

@@ -96,3 +96,31 @@ def test_the_line_stays_short_whatever_an_extra_window_says(bench):
     assert "device" in d["dropped_for_length"] and "device" not in d
     small = bench.fit_line({k: v for k, v in base.items() if k not in ("device", "kernel_GBps")})
     assert "dropped_for_length" not in json.loads(small)
+
+
+def test_single_domain_comparator_comes_from_a_measurement_or_not_at_all(bench, tmp_path):
+    """the N > 1 line's single-domain iteration count: read from the detail file an N = 1 run of the SAME case left on the box, None when
+    there is none, when it was another case, another window or non-default flags - never a typed-in constant"""
+    import json
+    f = tmp_path / "bench_detail.json"
+    assert bench.single_domain_comparator(str(f), 100, 20, 3, "ilu0", True) is None                 # no file
+    rec = {"n_gpus": 1, "steps": 20, "warmup": 3, "preconditioner": "ilu0", "linear_iterations_per_newton": 17.049,
+           "config": {"cells_per_gpu": 10 ** 6, "ilu_ordering_chosen_by": "library default (auto)"},
+           "cpr": {"linear_iterations_per_newton": 4.45}, "cpr_quasiimpes": {"error": "x"}}
+    f.write_text(json.dumps(rec))
+    assert bench.single_domain_comparator(str(f), 100, 20, 3, "ilu0", True) == 17.05
+    assert bench.single_domain_comparator(str(f), 100, 20, 3, "cpr", True) == 4.45                  # from the N = 1 run's CPR side window
+    assert bench.single_domain_comparator(str(f), 100, 20, 3, "cpr_trueimpes", True) == 4.45
+    assert bench.single_domain_comparator(str(f), 100, 20, 3, "cpr_quasiimpes", True) is None       # that side window failed: nothing to quote
+    assert bench.single_domain_comparator(str(f), 64, 20, 3, "ilu0", True) is None                  # another size
+    assert bench.single_domain_comparator(str(f), 100, 40, 3, "ilu0", True) is None                 # another window
+    assert bench.single_domain_comparator(str(f), 100, 20, 3, "ilu0", False) is None                # this run has ordering / smoother flags
+    rec["config"]["ilu_ordering_chosen_by"] = "--reorder"
+    f.write_text(json.dumps(rec))
+    assert bench.single_domain_comparator(str(f), 100, 20, 3, "ilu0", True) is None                 # ... or the N = 1 run had
+    rec["n_gpus"] = 2
+    f.write_text(json.dumps(rec))
+    assert bench.single_domain_comparator(str(f), 100, 20, 3, "ilu0", True) is None
+    f.write_text("not json")
+    assert bench.single_domain_comparator(str(f), 100, 20, 3, "ilu0", True) is None
+    assert not hasattr(bench, "SINGLE_DOMAIN_LIN_ITS")

@@ -338,3 +338,142 @@ def test_norne_shaped_grid_with_the_features_the_norne_deck_uses(pkg, orc, norne
         for a, b in zip(m.trackers(), o.trackers()):
             assert np.array_equal(a, b)
     assert len(set(mm.tolist())) == 3 and scanning > 0
+
+
+def test_spe1case1_report_steps(pkg, orc):
+    """BASELINE.json configs[0] as the deck it is (python/test_data/SPE1CASE1/SPE1CASE1.DATA): the deck's own SOLUTION section - EQUIL
+    8400 ft / 4800 psia, RSVD 1.27 Mscf/stb, equilibrated on the DEVICE's property functions by equil.equilibrate - and its SCHEDULE:
+    DRSDT 0 (the Rs cap of eclproblem.hh:1711-1732, through opmhip_set_composition_change_limits), the gas injector (100 MMscf/day into
+    (1, 1, 1)) and the oil producer (20 000 stb/day out of (10, 10, 3)) as standard wells - well equations assembled on the host
+    (wells.StandardWells), eliminated by the device (wells_apply_residual, the operator form inside the solve, wells_recover_solution) -
+    over the first three report steps (TSTEP 31 28 31 days) under Flow's adaptive time-step control.  Device against oracle running the
+    SAME loop: equal sub-steps, Newton and linear iteration counts, final pressures / saturations / Rs to 1e-7, the well state, and the
+    DRSDT cap in force.  (What this does NOT pin: the reference's own numbers for this deck - the tree holds no output of it.)"""
+    fl = pkg.fluid.spe1_fluid()[0]
+    case = pkg.decks.spe1_case()                         # EQUIL on capi.HipFluid: the device's functions
+    case_o = pkg.decks.spe1_case(props=oracle_bind.OracleFluid(orc, fl))
+    assert np.array_equal(case["pv"], case_o["pv"]) and np.array_equal(case["meaning"], case_o["meaning"])   # bit-identical property functions
+    pv0 = case["pv"].reshape(-1, 3)
+    psia = 6894.757293168361
+    # the deck's datum: 4800 psia at 8400 ft = the centre depth of layer 3; undersaturated oil at the RSVD value, connate water
+    np.testing.assert_allclose(pv0[200:, 1], 4800.0 * psia, rtol=1e-6)
+    assert np.all(pv0[:, 0] == 0.12) and np.all(case["meaning"] == 1)
+    np.testing.assert_allclose(pv0[:, 2], 1.27 * 178.10760667903526, rtol=1e-12)
+    assert case["drsdt"] == [0.0] and len(case["schedule"]["tstep"]) == 12
+    m = pkg.capi.HipModel(case, tolerance=1e-2, maxit=200, ilu_relaxation=0.9)
+    om = oracle_bind.OracleModel(orc, case)
+    runs = []
+    for side, h in (("device", m), ("oracle", om)):
+        h.set_state(case["pv"], case["meaning"])
+        h.set_composition_change_limits(drsdt=case["drsdt"], drsdt_all_cells=case["drsdt_all_cells"])
+        wells = pkg.decks.spe1_wells(case)
+        if side == "oracle":
+            hm = oracle_bind.OracleAsHipModel(om, tol=1e-2, maxit=200, w=0.9)
+            hm.kw["order"] = m.ordering()[:2]            # the ILU0 in the ordering the device chose
+        else:
+            hm = h
+        model = pkg.newton.BlackoilModelHip(hm, well_model=wells)
+        ts = pkg.newton.AdaptiveTimeStepping(model, pkg.newton.TimeSteppingParameters(initial_dt=86400.0))
+        steps = []
+        for length in case["schedule"]["tstep"][:3]:
+            reps = ts.advance_report_step(length)
+            steps.append((len(reps), sum(r.total_linear_iterations for r in reps)))
+        runs.append(dict(steps=steps, history=list(ts.history), time=ts.time, wells=wells.x.copy(), controls=[w.control[0] for w in wells.wells],
+                         state=h.get_state(), iq=h.iq()))
+    dev, ora = runs
+    np.testing.assert_allclose([dev["time"], ora["time"]], sum(case["schedule"]["tstep"][:3]), rtol=1e-12)
+    assert all(ok for _, _, ok in dev["history"]) and all(ok for _, _, ok in ora["history"])       # no sub-step was chopped on either side
+    # How close can the two runs be?  They start bit-identical (state, well blocks, J, r: tools/spe1_debug.py) and differ only in the order
+    # the scalar products of BiCGStab are summed in: 3e-15 in the first update.  A linear solve to 1e-2 on a Jacobian of condition 1e5 ... 1e6
+    # turns that into 1e-10, and the deck is not smooth there - gas appears at Sg = 0, a node of SGOF, where kr's slope jumps - so that a
+    # few Newton iterations later two solves stop half an iteration apart and the runs are two equally valid paths through the same time
+    # steps, no longer one path computed twice.  DRSDT 0 with its option ALL makes that the rule: every undersaturated cell sits exactly ON
+    # its cap (Rs = lastRs + 0), where min(Rs, cap) changes branch - and d Rs / d(primary variable) jumps between 1 and 0 - on the last bit.
+    # Hence: the first Newton iterations in lock step (test below), the whole run to what two converged runs share - Newton iterations within
+    # two per report step, linear iterations per Newton iteration within a third, the state to the reach of the Newton tolerances.
+    (pd, md), (po, mo) = dev["state"], ora["state"]
+    pd2, po2 = pd.reshape(-1, 3), po.reshape(-1, 3)
+    # (the primary variable's MEANING is not compared: with every cell on its Rs cap, "undersaturated at Rs = cap" and "saturated with Sg = 0"
+    #  are one physical state under two names, and which name a cell carries hangs on the last bit; saturations and Rs are compared instead)
+    qd, qo = dev["iq"], ora["iq"]
+    print("SPE1CASE1, 3 report steps: (Newton, linear) per step device %r oracle %r; sub-steps %r | %r; cells whose meaning differs %d; max relative "
+          "pressure difference %.2e, |dS| %.2e, Rs %.2e, bhp %.2e" %
+          (dev["steps"], ora["steps"], [round(h[0] / 86400.0, 2) for h in dev["history"]], [round(h[0] / 86400.0, 2) for h in ora["history"]], int((md != mo).sum()),
+           np.abs(pd2[:, 1] / po2[:, 1] - 1).max(), np.abs(qd[:, 0:3, 0] - qo[:, 0:3, 0]).max(), np.abs(qd[:, 15, 0] / qo[:, 15, 0] - 1).max(),
+           np.abs(dev["wells"][:, 3] / ora["wells"][:, 3] - 1).max()))
+    for (nd, ld), (no, lo) in zip(dev["steps"], ora["steps"]):
+        assert abs(nd - no) <= 2 and abs(ld / nd - lo / no) <= 0.35 * max(ld / nd, lo / no), (dev["steps"], ora["steps"])
+    assert sum(n for n, _ in dev["steps"]) >= 20 and abs(len(dev["history"]) - len(ora["history"])) <= 1
+    np.testing.assert_allclose(pd2[:, 1], po2[:, 1], rtol=2e-4)                        # pressures: 1 psi in 5000 - two converged runs, CNV 1e-2 / MB 1e-6 (measured: 1.1e-5)
+    np.testing.assert_allclose(qd[:, 0:3, 0], qo[:, 0:3, 0], atol=1e-4)                # saturations of the three phases
+    np.testing.assert_allclose(qd[:, 15, 0], qo[:, 15, 0], rtol=2e-4)                  # Rs
+    np.testing.assert_allclose(dev["wells"][:, 3], ora["wells"][:, 3], rtol=2e-4)      # bottom-hole pressures
+    assert dev["controls"] == ["rate", "rate"]                                       # both wells still on their rate targets
+    qg_inj, bhp_inj = dev["wells"][0, 2], dev["wells"][0, 3]
+    qo_prod, bhp_prod = dev["wells"][1, 0], dev["wells"][1, 3]
+    np.testing.assert_allclose([qg_inj, -qo_prod], [case["schedule"]["wells"][0]["surface_rate"], case["schedule"]["wells"][1]["oil_rate"]], rtol=1e-9)
+    assert 1000.0 * psia < bhp_prod < 4800.0 * psia < bhp_inj < 9014.0 * psia
+    # the injected gas has formed a free-gas region around the injector; DRSDT 0: nowhere did Rs rise above its initial value
+    pd = pd.reshape(-1, 3)
+    assert qd[0, 2, 0] > 0.05 and (qd[:, 2, 0] > 1e-3).sum() >= 3                     # free gas at the injector and around it
+    assert np.all(qd[:, 15, 0] <= 1.27 * 178.10760667903526 * (1 + 1e-12))           # Rs of every cell: DRSDT 0 / ALL holds it at or below its initial value
+
+
+def test_spe1case1_first_time_step_in_lock_step(pkg, orc):
+    """the deck's first sub-step (1 day) Newton iteration by Newton iteration on both sides: intensive quantities, well blocks, Jacobian and
+    residual of iteration 0 and the residual after the wells' elimination bit for bit, its linear solve on the oracle's half iteration with
+    the oracle's reduction and solution (1e-9: the scalar products' order); the next iteration on the same half iteration, later ones within
+    one; the converged state of the step to 1e-4 - the lock-step part of what test_spe1case1_report_steps cannot ask of three months"""
+    from helpers import oracle_solve_in_order
+    case = pkg.decks.spe1_case()
+    m = pkg.capi.HipModel(case, tolerance=1e-2, maxit=200, ilu_relaxation=0.9)
+    om = oracle_bind.OracleModel(orc, case)
+    for h in (m, om):
+        h.set_state(case["pv"], case["meaning"])
+        h.set_composition_change_limits(drsdt=case["drsdt"], drsdt_all_cells=case["drsdt_all_cells"])
+        h.begin_time_step(86400.0)
+    to, fr, _ = m.ordering()
+    wd, wo = pkg.decks.spe1_wells(case), pkg.decks.spe1_wells(case)
+    nm = pkg.newton.BlackoilModelHip(m)
+    dt = 86400.0
+    for it in range(12):
+        iqd, iqo = m.iq(), om.iq()
+        if it == 0:
+            assert np.array_equal(iqd, iqo)
+            wd.solve_well_equations(iqd)
+            wo.solve_well_equations(iqo)
+        ad, ao = wd.assemble(iqd, case["Nb"]), wo.assemble(iqo, case["Nb"])
+        m.set_source(ad["source"], ad["dsource"])
+        om.set_source(ao["source"], ao["dsource"])
+        jd, rd = m.assemble(dt, it)
+        jo, ro = om.assemble(dt, it)
+        if it == 0:
+            assert all(np.array_equal(ad["wells"][k], ao["wells"][k]) for k in ("Cnnzs", "Bnnzs", "Dnnzs")) and np.array_equal(ad["res_well"], ao["res_well"])
+            assert np.array_equal(jd, jo) and np.array_equal(rd, ro)
+        conv, _ = nm.get_convergence(dt, it)
+        if conv and it > 1 and wd.converged(ad["res_well"]):
+            break
+        m.wells_apply_residual(ad["wells"], ad["res_well"])
+        ro2 = orc.wells_apply_residual(ao["wells"], ao["res_well"], ro)
+        if it == 0:
+            assert np.array_equal(m.get_rhs(), ro2)          # r -= C^T D^-1 r_w: the same bits
+        res = m.solve_jacobian_system(wells=ad["wells"])
+        xo, reso = oracle_solve_in_order(orc, case["Nb"], case["rowptr"], case["col"], jo, ro2, to, fr, wells=ao["wells"], tol=1e-2, maxit=200, w=0.9)
+        # (iteration 0: identical systems, the scalar products' order alone; from then on two neighbouring systems - see above)
+        assert res.converged and reso.converged and abs(res.it - reso.it) <= (0.0 if it < 2 else 1.0), (it, res.it, reso.it)
+        if it == 0:
+            assert abs(res.reduction - reso.reduction) <= 1e-9 * reso.reduction
+            np.testing.assert_allclose(m.get_result(), xo, rtol=1e-9, atol=1e-12 * np.abs(xo).max())
+        wd.update(m.wells_recover_solution(ad["wells"], ad["res_well"]))
+        wo.update(orc.wells_recover(ao["wells"], ao["res_well"], xo))
+        m.update(None, 1.0)
+        om.update(xo)
+    assert 2 <= it <= 10
+    (pd, md), (po, mo) = m.get_state(), om.get_state()
+    print("first sub-step: %d Newton iterations; max relative pressure difference %.2e, bhp %.2e" %
+          (it, np.abs(pd.reshape(-1, 3)[:, 1] / po.reshape(-1, 3)[:, 1] - 1).max(), np.abs(wd.x[:, 3] / wo.x[:, 3] - 1).max()))
+    qd, qo = m.iq(), om.iq()      # (saturations and Rs instead of the primary variables' meanings: see test_spe1case1_report_steps)
+    np.testing.assert_allclose(pd.reshape(-1, 3)[:, 1], po.reshape(-1, 3)[:, 1], rtol=1e-5)
+    np.testing.assert_allclose(qd[:, 0:3, 0], qo[:, 0:3, 0], atol=1e-6)
+    np.testing.assert_allclose(qd[:, 15, 0], qo[:, 15, 0], rtol=1e-5)
+    np.testing.assert_allclose(wd.x[:, 3], wo.x[:, 3], rtol=1e-5)

@@ -16,9 +16,8 @@ DT = 10 * 86400.0
 
 
 @pytest.fixture(scope="module")
-def full(pkg):
-    case = pkg.decks.cartesian_case(N, N, N, state="mixed", heterogeneous=False)
-    src = pkg.decks.five_spot_source(case, rate_sm3_per_day=pkg.decks.BENCH_RATE_SM3_PER_DAY)
+def full(pkg, case100):
+    case, src = case100["case"], case100["src"]      # the session's one 100^3 case (tests/conftest.py)
     m = pkg.capi.HipModel(case, reorder="line_coloring", tolerance=1e-2, maxit=200, ilu_relaxation=1.0)
     m.set_state(case["pv"], case["meaning"])
     m.set_source(src)

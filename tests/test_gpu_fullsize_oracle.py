@@ -21,21 +21,18 @@ DT = 86400.0       # bench.py's first time step
 
 
 @pytest.fixture(scope="module", params=[None, "graph_coloring"], ids=["library_default", "graph_coloring"])
-def big(request, pkg, orc):
-    import oracle_bind
-    case = pkg.decks.cartesian_case(N, N, N, state="mixed", heterogeneous=False)
-    src = pkg.decks.five_spot_source(case, rate_sm3_per_day=pkg.decks.BENCH_RATE_SM3_PER_DAY)
+def big(request, pkg, orc, case100, oracle100):
+    case, src = case100["case"], case100["src"]      # the session's one 100^3 case and its one oracle model (tests/conftest.py)
+    assert oracle100.DT == DT
     kw = {} if request.param is None else {"reorder": request.param}
     m = pkg.capi.HipModel(case, tolerance=1e-2, maxit=200, ilu_relaxation=0.9, **kw)     # bench.py's solver settings
-    o = oracle_bind.OracleModel(orc, case)
-    for h in (m, o):
-        h.set_state(case["pv"], case["meaning"])
-        h.set_source(src)
+    m.set_state(case["pv"], case["meaning"])
+    m.set_source(src)
     jac, res = m.assemble(DT, 0)
-    jo, ro = o.assemble(DT, 0)
+    o, jo, ro = oracle100.o, oracle100.jo, oracle100.ro
     to, fr, rpc = m.ordering()
     rr, rc, rv = orc.reorder_matrix(case["Nb"], case["rowptr"], case["col"], jo, to, fr)
-    return dict(case=case, m=m, o=o, jac=jac, res=res, jo=jo, ro=ro, to=to, fr=fr, rpc=rpc, rr=rr, rc=rc, rv=rv, param=request.param)
+    return dict(case=case, m=m, o=o, jac=jac, res=res, jo=jo, ro=ro, to=to, fr=fr, rpc=rpc, rr=rr, rc=rc, rv=rv, param=request.param, oracle100=oracle100)
 
 
 def test_the_default_is_the_measured_configuration(big):
@@ -98,12 +95,13 @@ def test_preconditioned_product_bitwise(big, orc):
     assert np.array_equal(t, to_.reshape(Nb, 3)[to].reshape(-1))
 
 
-def test_solve_stops_on_the_oracles_half_iteration_and_the_next_iteration_follows(big, orc):
+def test_solve_stops_on_the_oracles_half_iteration_and_the_next_iteration_follows(big, orc, request):
     """solveJacobianSystem on the assembled system: the oracle's half iteration, its reduction and its x (identical preconditioner and
     product bits; the scalar products are summed in another order); then updateSolution on both sides and a second assembly -
     Jacobian and residual of Newton iteration 1, storage term and switched cells included, again bit for bit"""
     m, o, case, to, fr = big["m"], big["o"], big["case"], big["to"], big["fr"]
     Nb = case["Nb"]
+    request.addfinalizer(big["oracle100"].reset)   # this test moves the session's oracle model on: back to (initial state, assembled at iteration 0) afterwards, pass or fail
     m.assemble(DT, 0, fetch=False)            # the tests before this one may have left other factors / vectors behind
     sol = m.solve_jacobian_system()
     x = m.get_result()
@@ -128,23 +126,20 @@ def test_solve_stops_on_the_oracles_half_iteration_and_the_next_iteration_follow
     np.testing.assert_allclose(cm[[0, 1, 2, 14, 15, 16]], co[[0, 1, 2, 14, 15, 16]], rtol=1e-9)
 
 
-def test_cpr_at_the_benchmarked_size(pkg, orc):
+def test_cpr_at_the_benchmarked_size(pkg, orc, case100, oracle100):
     """bench.py's fastest configuration at its own size: `cpr` (= cpr_trueimpes, setupPropertyTree.cpp:62-76) on the 100^3 case with the
     library's defaults - line colouring, level 0 of the pressure AMG smoothed by ILU0 (asserted).  True-IMPES weights, the hierarchy's
     level sizes and one application of the preconditioner equal the oracle's bit for bit (the eight-level hierarchy over 10^6 rows with
     its lane-group levels and the Jacobi sweeps of the coarsest one: what the bench times, not a 9 000-row stand-in), and the solve -
     whose factorisation writes the pressure system as it stages the rows (k_ilu_factor's rider) - stops on the oracle's half iteration."""
     import oracle_bind
-    case = pkg.decks.cartesian_case(N, N, N, state="mixed", heterogeneous=False)
-    src = pkg.decks.five_spot_source(case, rate_sm3_per_day=pkg.decks.BENCH_RATE_SM3_PER_DAY)
+    case, src = case100["case"], case100["src"]
     Nb = case["Nb"]
     m = pkg.capi.HipModel(case, tolerance=1e-2, maxit=200, ilu_relaxation=0.9, preconditioner="cpr")
-    o = oracle_bind.OracleModel(orc, case)
-    for h in (m, o):
-        h.set_state(case["pv"], case["meaning"])
-        h.set_source(src)
+    m.set_state(case["pv"], case["meaning"])
+    m.set_source(src)
     m.assemble(DT, 0, fetch=False)
-    jo, ro = o.assemble(DT, 0)
+    o, jo, ro = oracle100.o, oracle100.jo, oracle100.ro     # the session's oracle model, assembled at (DT, iteration 0)
     sol = m.solve_jacobian_system()
     info = m.ordering_info()
     assert info["ilu_ordering"] == "line_coloring" and info["chain_length"] == 10 and info["cpr_amg_ilu_levels"] == 1
