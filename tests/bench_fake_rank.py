@@ -64,6 +64,7 @@ class FakeModel:
     def comm_info(self): return {"nranks": int(os.environ.get("OPMHIP_FAKE_NRANKS", self.world)), "rank": self.rank, "device": self.rank, "kind": "rccl"}
     def comm_selftest(self): return self.world * (self.world + 1) / 2.0, 2.0 * self.world
     def ordering_info(self): return {"ilu_ordering": "graph_coloring_greedy", "chain_length": 0, "colors": 2, "cpr_amg_ilu_levels": 0}
+    def product_form(self): return {"half_product": False, "u_is_upper_a": True, "rest_blocks": 0, "rest_positions": 0}   # subdomains with ghost columns: the plain form
     def time_kernel(self, which, reps=20): return 0.1
     def cpr_levels(self): return [self.case["Nb"]], [len(self.case["col"])]
 

@@ -195,7 +195,9 @@ def test_bench_two_ranks_control_plane_over_gloo(tmp_path):
     c = d["comm"]
     assert c["halo"]["launches_per_rank"] > 0 and c["halo"]["avg_ms_max"] > c["halo"]["avg_ms_mean"] > 0     # rank 1's stand-in spans are twice rank 0's
     assert abs(c["halo"]["avg_ms_max"] / c["halo"]["avg_ms_mean"] - 4.0 / 3.0) < 1e-3 and "cpr_gather" not in c
-    assert c["single_domain_linear_iterations_per_newton"] == 17.5 and c["linear_iterations_per_newton"] > 0
+    # the one-domain comparator comes from an N = 1 run of the SAME case on this box or not at all (tests/test_bench_launcher.py): no 10^3-cell
+    # N = 1 record exists here, so it is null - not a typed-in figure
+    assert c["single_domain_linear_iterations_per_newton"] is None and c["linear_iterations_per_newton"] > 0
     full = json.load(open(detail))
     assert full["rccl"]["rank_devices"] == [0, 1] and full["rccl"]["selftest_sum"] == full["rccl"]["selftest_expected"] == [3.0, 4.0]
     assert full["steady_state"]["steps"] == 4 and full["spmv_boundary_share_of_time"] == 0.2

@@ -162,7 +162,8 @@ def test_update_chopping_and_switching(pkg, orc):
 
 
 def test_spe1_case_assembles(pkg, orc):
-    case = pkg.decks.spe1_case()
+    # (the deck's EQUIL state on the oracle's property functions: without arguments spe1_case asks the device's, and there is no GPU here)
+    case = pkg.decks.spe1_case(props=oracle_bind.OracleFluid(orc, pkg.fluid.spe1_fluid()[0]))
     assert case["Nb"] == 300 and len(case["col"]) == 1780  # faces 740 -> nnzb = 300 + 2*740
     m = oracle_bind.OracleModel(orc, case)
     m.set_state(case["pv"], case["meaning"])
