@@ -438,6 +438,7 @@ def main():
     ap.add_argument("--preconditioner", default="ilu0", choices=["ilu0", "cpr", "cpr_trueimpes", "cpr_quasiimpes"], help="--linear-solver-configuration of the run behind `value`")
     ap.add_argument("--cpr-reuse-setup", type=int, default=3, choices=[0, 1, 2, 3], help="Flow's --cpr-reuse-setup for the CPR runs: when the hierarchy's structure is built anew (3 = never, the default of Flow)")
     ap.add_argument("--cpr-amg-ilu-levels", type=int, default=None, help="CPR runs: this many of the pressure AMG's finest levels smooth with ILU0 (the reference's AMG smoother) instead of damped Jacobi; default: the library's choice (opmhip_default_config: -1 = level 0 where the block ordering has at most three colours), reported in cpr_amg_ilu_levels")
+    ap.add_argument("--fused-reductions", action="store_true", help="BiCGStab with one reduction per half iteration (opmhip_config.fused_reductions; off by default: A/B measurements and runs over several GPUs)")
     ap.add_argument("--no-cpr-side-run", action="store_true", help="skip the side runs with the CPR preconditioners (extra keys `cpr`, `cpr_quasiimpes`)")
     a = ap.parse_args()
 
@@ -474,7 +475,8 @@ def main():
     pkg = importlib.import_module("opm-autodiff_amd")
     n = a.n
     skw = dict(device_id=local_rank, reorder=a.reorder, tolerance=1e-2, maxit=200, ilu_relaxation=0.9, chain_length=a.chain_length,
-               preconditioner=a.preconditioner, cpr_reuse_setup=a.cpr_reuse_setup, cpr_amg_ilu_levels=a.cpr_amg_ilu_levels)
+               preconditioner=a.preconditioner, cpr_reuse_setup=a.cpr_reuse_setup, cpr_amg_ilu_levels=a.cpr_amg_ilu_levels,
+               fused_reductions=int(a.fused_reductions))
     if world == 1:
         case = pkg.decks.cartesian_case(n, n, n, state="mixed", heterogeneous=False)
         src = pkg.decks.five_spot_source(case, rate_sm3_per_day=pkg.decks.BENCH_RATE_SM3_PER_DAY * (n / 100.0) ** 2)
@@ -717,7 +719,7 @@ def main():
                                "pid+newtoniteration control and 0.33 chop)" % (n, n, n),
                    "cells_per_gpu": Nb, "blocks_per_gpu": nnzb, "ilu_ordering": chosen["ilu_ordering"], "ilu_chain_length": chosen["chain_length"],
                    "ilu_colors": chosen["colors"], "ilu_ordering_chosen_by": "library default (auto)" if a.reorder is None else "--reorder", "linear_tol": 1e-2,
-                   "ilu_relaxation": 0.9, "parallelism": "1 GPU" if world == 1 else "RAS domain decomposition %dx%dx%d, %s per GPU, halos + all-reduces over RCCL" % (layout + ("block-Jacobi ILU0" if a.preconditioner == "ilu0" else "one CPR (%s) per subdomain" % a.preconditioner,))},
+                   "ilu_relaxation": 0.9, "bicgstab_reductions_per_iteration": 2 if a.fused_reductions else 4, "parallelism": "1 GPU" if world == 1 else "RAS domain decomposition %dx%dx%d, %s per GPU, halos + all-reduces over RCCL" % (layout + ("block-Jacobi ILU0" if a.preconditioner == "ilu0" else "one CPR (%s) per subdomain" % a.preconditioner,))},
         "linear_iterations_per_newton": W["linear_iterations_per_newton"],
         "timesteps_completed": W["timesteps_completed"], "timesteps_chopped": W["timesteps_chopped"],
         "time_steps_days": W["time_steps_days"],

@@ -20,7 +20,8 @@
 extern "C" {
 #endif
 
-#define OPMHIP_ABI_VERSION 10 /* 10: opmhip_config gained half_product (the product after an ILU0 application from the sweep's row sums), opmhip_get_product_form;
+#define OPMHIP_ABI_VERSION 10 /* 10: opmhip_config gained half_product (the product after an ILU0 application from the sweep's row sums), pin_host_arrays,
+                               *     fused_reductions; opmhip_get_product_form, opmhip_preconditioned_product;
                                * 9: opmhip_wells gained `distributed` (standard wells whose perforations lie in several subdomains of a decomposed run);
                                * 8: opmhip_default_config: reorder = OPMHIP_REORDER_AUTO, cpr_amg_ilu_levels = -1 (the measured configuration);
                                *    opmhip_get_ordering_info, opmhip_wells gained the multisegment-well leg (num_ms_wells, ms_apply);
@@ -147,6 +148,22 @@ typedef struct opmhip_config {
                             * (bda/cusparseSolverBackend.cu:314-338); host/hipSolverBackend.hpp sets it.  The ranges are unregistered by
                             * opmhip_destroy; a refused registration falls back to the plain copy.  0 (default): plain copies - arrays that
                             * come and go (numpy temporaries) must not be pinned behind their owner's back.  ABI 10 */
+    int fused_reductions;  /* 1: BiCGStab with ONE reduction per half iteration instead of two.  The reference forms alpha, |r|, omega, |r| and
+                            * rho from five scalar products in four reductions per iteration (bda/cusparseSolverBackend.cu:92, 120-127, 151-161;
+                            * in parallel runs each is an all-reduce, flow/BlackoilModelEbos.hpp:599-603 for the convergence sums alike).  Here
+                            * the product's kernel leaves three sums - v.rw, v.v, v.r in the first half, t.r, t.t, t.rw in the second - and
+                            *   |r - alpha v|^2 = r.r - 2 alpha v.r + alpha^2 v.v,   |r - omega t|^2 = r.r - 2 omega t.r + omega^2 t.t,
+                            *   rho' = (rho - alpha v.rw) - omega t.rw
+                            * give the norms and rho without a second pass: two reductions (of three doubles) and two scalar kernels per
+                            * iteration instead of four, update kernels without partial sums.  The stopping rule then looks at RECURRED norms;
+                            * the residual vector itself is still updated explicitly, its true norm is formed once at the end of the solve and
+                            * reported in opmhip_result.reduction, and a solve whose true norm exceeds twice the tolerance although the recurred
+                            * one met it comes back with converged = 0.  Same mathematics, other rounding: iteration counts may differ by a half
+                            * step from the default form's; the oracle states the same arithmetic (oracle/linalg.hpp: bicgstab_fused_reductions).
+                            * The recurred |r|^2 carries an absolute error of eps |r_0|^2, i.e. the norm a floor of 1.5e-8 |r_0|: opmhip_create refuses
+                            * the mode with tolerance < 1e-6 (Flow's default is 1e-2).
+                            * 0 (default): the reference's recurrence to the letter.  Meant for runs over many GPUs, where a half iteration's
+                            * time is its all-reduces; measured on one GPU in DESIGN.md section 7.  ABI 10 */
 } opmhip_config;
 
 /* bda::BdaResult (bda/BdaResult.hpp:28-40) plus the reference's per-phase timers. */

@@ -32,7 +32,7 @@ class Config(C.Structure):
                 ("tolerance", C.c_double), ("ilu_relaxation", C.c_double), ("relax_mode", C.c_int),
                 ("reorder", C.c_int), ("zero_diag_fix", C.c_int), ("chain_length", C.c_int), ("spmv_pipe_wgs", C.c_int),
                 ("preconditioner", C.c_int), ("cpr_reuse_setup", C.c_int), ("cpr_async_setup", C.c_int), ("cpr_amg_ilu_levels", C.c_int), ("cpr_gather_rows", C.c_int),
-                ("half_product", C.c_int), ("pin_host_arrays", C.c_int)]
+                ("half_product", C.c_int), ("pin_host_arrays", C.c_int), ("fused_reductions", C.c_int)]
 
 
 class Result(C.Structure):
@@ -173,7 +173,7 @@ class HipSolver:
 
     def __init__(self, verbosity=0, maxit=200, tolerance=1e-2, device_id=0, ilu_relaxation=0.9,
                  relax_mode="post_scale", reorder=None, zero_diag_fix=True, chain_length=0, spmv_pipe_wgs=0,
-                 preconditioner="ilu0", cpr_reuse_setup=3, cpr_async_setup=0, cpr_amg_ilu_levels=None, cpr_gather_rows=None, half_product=0, pin_host_arrays=0):
+                 preconditioner="ilu0", cpr_reuse_setup=3, cpr_async_setup=0, cpr_amg_ilu_levels=None, cpr_gather_rows=None, half_product=0, pin_host_arrays=0, fused_reductions=0):
         """reorder / cpr_amg_ilu_levels / cpr_gather_rows = None: what opmhip_default_config says (reorder "auto", the library's choice of
         the AMG smoother, the pressure stage across the ranks as the communicator's kind allows).  half_product: ILU0-BiCGStab forms the
         product after M^-1 from the backward sweep's row sums (0 the library's choice, > 0 wherever the pattern allows, < 0 never)"""
@@ -195,6 +195,7 @@ class HipSolver:
         if cpr_gather_rows is not None:
             cfg.cpr_gather_rows = int(cpr_gather_rows)         # decomposed runs: the hierarchy is continued across the ranks from the first level this small (0 default, < 0 off)
         cfg.half_product = int(half_product)
+        cfg.fused_reductions = int(fused_reductions)   # 1: one reduction (three sums) per BiCGStab half iteration, recurred norms
         cfg.pin_host_arrays = int(pin_host_arrays)   # 1: vals / b / x keep their addresses (Flow's do): registered for DMA on first sight
         cfg.cpr_async_setup = int(cpr_async_setup)   # mode 2 only: the rebuild on a host thread beside the solves
         cfg.cpr_reuse_setup = int(cpr_reuse_setup)   # --cpr-reuse-setup: 0 every solve, 1 every time step, 2 after > 10 iterations, 3 never

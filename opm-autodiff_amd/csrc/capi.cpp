@@ -50,8 +50,8 @@ int alloc_system(opmhip_ctx* c) {
     OPMHIP_HIP(c, hipMemset(c->d_scal, 0, SC_COUNT * sizeof(double)));
     const int vb = (int)((n + 2047) / 2048);
     c->npart = std::max(std::max(P.tiles.ntiles(), P.tiles.nsched), vb) + 1;
-    if ((rc = dev_alloc(c, &c->d_part, (size_t)2 * c->npart))) return rc;
-    OPMHIP_HIP(c, hipMemset(c->d_part, 0, (size_t)2 * c->npart * sizeof(double)));
+    if ((rc = dev_alloc(c, &c->d_part, (size_t)3 * c->npart))) return rc;   // three lists of partial sums (the third: opmhip_config.fused_reductions)
+    OPMHIP_HIP(c, hipMemset(c->d_part, 0, (size_t)3 * c->npart * sizeof(double)));
     if ((rc = dev_alloc(c, &c->d_part2, (size_t)1024))) return rc;
     OPMHIP_HIP(c, hipMemset(c->d_part2, 0, 1024 * sizeof(double)));
     if (!c->h_pinned) OPMHIP_HIP(c, hipHostMalloc((void**)&c->h_pinned, SC_COUNT * sizeof(double)));
@@ -270,6 +270,10 @@ int opmhip_create(const opmhip_config* cfg, opmhip_ctx** out) {
     if (cfg->chain_length < 0) { g_err = "opmhip_create: chain_length < 0"; return OPMHIP_INVALID_ARGUMENT; }
     if (cfg->cpr_reuse_setup < 0 || cfg->cpr_reuse_setup > 3) { g_err = "opmhip_create: cpr_reuse_setup must be 0 .. 3"; return OPMHIP_INVALID_ARGUMENT; }
     if (cfg->cpr_async_setup < 0 || cfg->cpr_async_setup > 1) { g_err = "opmhip_create: cpr_async_setup must be 0 or 1"; return OPMHIP_INVALID_ARGUMENT; }
+    if (cfg->fused_reductions < 0 || cfg->fused_reductions > 1) { g_err = "opmhip_create: fused_reductions must be 0 or 1"; return OPMHIP_INVALID_ARGUMENT; }
+    // the recurred |r|^2 = r.r - 2 a v.r + a^2 v.v carries an absolute error of eps |r_0|^2: the norm it yields has a floor of sqrt(eps) |r_0| =
+    // 1.5e-8 |r_0| and a stopping rule below it would never be met
+    if (cfg->fused_reductions && cfg->tolerance < 1e-6) { g_err = "opmhip_create: fused_reductions needs tolerance >= 1e-6 (the recurred residual norm cannot resolve less than sqrt(eps) |r_0|)"; return OPMHIP_INVALID_ARGUMENT; }
     if (cfg->pin_host_arrays < 0 || cfg->pin_host_arrays > 1) { g_err = "opmhip_create: pin_host_arrays must be 0 or 1"; return OPMHIP_INVALID_ARGUMENT; }
     int ndev = 0;
     hipError_t e = hipGetDeviceCount(&ndev);

@@ -350,6 +350,9 @@ enum Scal {  // device-resident BiCGStab scalars (double d_scal[SC_COUNT])
     SC_RHO = 0, SC_RHOP, SC_ALPHA, SC_OMEGA, SC_BETA, SC_TMP1, SC_TMP2, SC_NORM, SC_NORM0,
     SC_DONE,   // 1.0 once the stopping rule held: every later kernel of the solve returns at once (speculative launches)
     SC_ZERO,   // never written: the "not done" flag of launches outside a solve
+    SC_RR,     // opmhip_config.fused_reductions: r.r carried from half iteration to half iteration
+    SC_RHOH,   //   rw.r after the first half (rho - alpha v.rw)
+    SC_DONEH,  //   number of the half iteration that met the stopping rule (its own update kernels still run), -1: none
     SC_COUNT = 16
 };
 
@@ -558,7 +561,7 @@ void launch_vec_to_natural(opmhip_ctx* c, const double* internal, double* nat, i
 void launch_zero_diag_fix(opmhip_ctx* c);
 // y = A x (+ wells) with the partial sums of ndot scalar products.  exchange: x's ghost entries are brought up to date first
 // (copyOwnerToAll) - on the halo stream, beside the product of the interior tiles; x is then written (its ghost part)
-int launch_spmv(opmhip_ctx* c, double* x, double* y, int ndot, const double* w0, double xs = 1.0, bool exchange = false, const double* uadd = nullptr);
+int launch_spmv(opmhip_ctx* c, double* x, double* y, int ndot, const double* w0, double xs = 1.0, bool exchange = false, const double* uadd = nullptr, const double* w1 = nullptr);
 bool half_product_wanted(const opmhip_ctx* c);   // solver.hip: opmhip_config.half_product resolved for the pattern in hand (asked once, when the system's buffers are allocated)
 void launch_wells_residual(opmhip_ctx* c, const double* d_resWell, double* r);
 void launch_wells_add_to_matrix(opmhip_ctx* c, int w0, int nw, int serial, const int* d_pair_ptr, const int* d_entry);

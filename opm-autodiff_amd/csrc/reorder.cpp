@@ -230,6 +230,8 @@ void build_rest_schedule(Pattern& P, const std::vector<int>& order) {
         offs.erase(std::unique(offs.begin(), offs.end()), offs.end());
     };
     std::vector<int> offs;
+    static const int maxRows = [] { const char* e = tuning_env("OPMHIP_REST_ROWS"); const int v = e ? std::atoi(e) : 64; return v < 1 ? 1 : (v > 64 ? 64 : v); }();   // measurement switch: rows per tile at most
+    static const int maxBlocks = [] { const char* e = tuning_env("OPMHIP_REST_BLOCKS"); const int v = e ? std::atoi(e) : TILE_CAP_BLOCKS; return v < 8 ? 8 : (v > TILE_CAP_BLOCKS ? TILE_CAP_BLOCKS : v); }();
     std::vector<Rt> out;   // launch positions of both parts, padding = {0, 0}
     int nInt = 0;
     for (int part = 0; part < 2; ++part) {
@@ -241,7 +243,7 @@ void build_rest_schedule(Pattern& P, const std::vector<int>& order) {
                 if (order[b] < 0) continue;
                 const int r0 = T.row0[order[b]], r1 = T.row0[order[b] + 1];
                 if (r1 <= r0) continue;
-                if (cur.r1 > cur.r0 && r0 == cur.r1 && r1 - cur.r0 <= 64 && P.rrowptr[r1] - P.rrowptr[cur.r0] <= TILE_CAP_BLOCKS) {
+                if (cur.r1 > cur.r0 && r0 == cur.r1 && r1 - cur.r0 <= maxRows && P.rrowptr[r1] - P.rrowptr[cur.r0] <= maxBlocks) {
                     offsets_of(cur.r0, r1, offs);
                     if (offs.size() <= 15) { cur.r1 = r1; continue; }
                 }

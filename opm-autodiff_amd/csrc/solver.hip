@@ -605,14 +605,16 @@ __global__ __launch_bounds__(64) void k_spmv_pipe_st(int npos, const int4* __res
                                                      const unsigned char* __restrict__ stKoff, const int* __restrict__ stTable,
                                                      const double* __restrict__ val, const double* __restrict__ x, double* __restrict__ y,
                                                      const double* __restrict__ w0, double* __restrict__ part, int npart,
-                                                     const double* __restrict__ done, double xs, const double* __restrict__ uadd = nullptr) {
+                                                     const double* __restrict__ done, double xs, const double* __restrict__ uadd = nullptr,
+                                                     const double* __restrict__ w1 = nullptr) {
+    // NDOT == 3 (opmhip_config.fused_reductions: one reduction per half iteration): y.w0, y.y and y.w1
     TILE_LDS
     __shared__ int4 ssched[PIPE_MAX_STEPS];
     const int lane = threadIdx.x, G = gridDim.x;
     constexpr int U = 16;
     const int nsteps = ((int)blockIdx.x < npos) ? (npos - (int)blockIdx.x + G - 1) / G : 0;
     if (nsteps <= 0) {
-        if (NDOT >= 1 && lane == 0) { part[blockIdx.x] = 0.0; if (NDOT == 2) part[npart + blockIdx.x] = 0.0; }
+        if (NDOT >= 1 && lane == 0) { part[blockIdx.x] = 0.0; if (NDOT >= 2) part[npart + blockIdx.x] = 0.0; if (NDOT == 3) part[2 * npart + blockIdx.x] = 0.0; }
         return;
     }
     const double stop = *done;
@@ -628,6 +630,7 @@ __global__ __launch_bounds__(64) void k_spmv_pipe_st(int npos, const int4* __res
         int kb, nrow;
         double xx[PGCH][3];
         double ww[NDOT >= 1 ? 3 : 1];
+        double w2[NDOT == 3 ? 3 : 1];
         double uu[UADD ? 3 : 1];
     };
     auto clampst = [&](int st) { return st < nsteps ? st : nsteps - 1; };
@@ -673,11 +676,15 @@ __global__ __launch_bounds__(64) void k_spmv_pipe_st(int npos, const int4* __res
             b.xx[u][0] = xc[0]; b.xx[u][1] = xc[1]; b.xx[u][2] = xc[2];
         }
         b.nrow = cnt;
-        if (NDOT >= 1) {
+        if constexpr (NDOT >= 1) {
             const double* wr = &w0[(size_t)rr * BS];
             b.ww[0] = wr[0]; b.ww[1] = wr[1]; b.ww[2] = wr[2];
         }
-        if (UADD) {
+        if constexpr (NDOT == 3) {
+            const double* wr = &w1[(size_t)rr * BS];
+            b.w2[0] = wr[0]; b.w2[1] = wr[1]; b.w2[2] = wr[2];
+        }
+        if constexpr (UADD) {
             const double* ur = &uadd[(size_t)rr * BS];
             b.uu[0] = ur[0]; b.uu[1] = ur[1]; b.uu[2] = ur[2];
         }
@@ -685,7 +692,7 @@ __global__ __launch_bounds__(64) void k_spmv_pipe_st(int npos, const int4* __res
     StW wq;
     StS sb;
     StM m;
-    double sd0 = 0.0, sd1 = 0.0;
+    double sd0 = 0.0, sd1 = 0.0, sd2 = 0.0;
     {   // prologue, in the loop's order of issue
         StW w0q;
         stageW(0, w0q);
@@ -714,13 +721,14 @@ __global__ __launch_bounds__(64) void k_spmv_pipe_st(int npos, const int4* __res
 #pragma unroll
             for (int u = 0; u < PGCH; ++u)
                 if (u < nrow) blk_umv_lds(&sval[(kb + u - k0e) * BB], xs * m.xx[u][0], xs * m.xx[u][1], xs * m.xx[u][2], acc);
-            if (UADD) { acc[0] += xs * m.uu[0]; acc[1] += xs * m.uu[1]; acc[2] += xs * m.uu[2]; }
+            if constexpr (UADD) { acc[0] += xs * m.uu[0]; acc[1] += xs * m.uu[1]; acc[2] += xs * m.uu[2]; }
             double* yr = &y[(size_t)r * BS];
             yr[0] = acc[0]; yr[1] = acc[1]; yr[2] = acc[2];
-            if (NDOT >= 1) {
+            if constexpr (NDOT >= 1) {
                 double d0 = acc[0] * m.ww[0]; d0 += acc[1] * m.ww[1]; d0 += acc[2] * m.ww[2];
                 sd0 += d0;
-                if (NDOT == 2) { double d1 = acc[0] * acc[0]; d1 += acc[1] * acc[1]; d1 += acc[2] * acc[2]; sd1 += d1; }
+                if (NDOT >= 2) { double d1 = acc[0] * acc[0]; d1 += acc[1] * acc[1]; d1 += acc[2] * acc[2]; sd1 += d1; }
+                if constexpr (NDOT == 3) { double d2 = acc[0] * m.w2[0]; d2 += acc[1] * m.w2[1]; d2 += acc[2] * m.w2[2]; sd2 += d2; }
             }
         }
         wave_sync();
@@ -732,8 +740,9 @@ __global__ __launch_bounds__(64) void k_spmv_pipe_st(int npos, const int4* __res
     }
     if (NDOT >= 1) {
         sd0 = wave_sum(sd0);
-        if (NDOT == 2) sd1 = wave_sum(sd1);
-        if (lane == 0) { part[blockIdx.x] = sd0; if (NDOT == 2) part[npart + blockIdx.x] = sd1; }
+        if (NDOT >= 2) sd1 = wave_sum(sd1);
+        if (NDOT == 3) sd2 = wave_sum(sd2);
+        if (lane == 0) { part[blockIdx.x] = sd0; if (NDOT >= 2) part[npart + blockIdx.x] = sd1; if (NDOT == 3) part[2 * npart + blockIdx.x] = sd2; }
     }
 }
 
@@ -1706,9 +1715,13 @@ __global__ __launch_bounds__(VB) void k_bicg_pupdate(int n, const double* __rest
 // r -= alpha v ; partial r.r.  The first half's "x += alpha pw" (bda/cusparseSolverBackend.cu:110) waits for the second
 // half's update of x (k_bicg_upd2 adds both terms, in the reference's order: two passes over x less per iteration); a solve
 // that meets the stopping rule right after a first half gets it from k_bicg_xhalf.
+// SR (opmhip_config.fused_reductions): the norm of the new residual was formed from the product's scalar products BEFORE this kernel ran
+// (finalize_scalars3), so there are no partial sums to leave - and a half iteration that met the stopping rule still carries out ITS update
+// (`half` = its number; later, speculative halves return)
+template <bool SR = false>
 __global__ __launch_bounds__(VB) void k_bicg_upd1(int n, const double* __restrict__ scal, double* __restrict__ r,
-                                                  const double* __restrict__ v, double* __restrict__ part, int npart) {
-    if (scal[SC_DONE] != 0.0) return;
+                                                  const double* __restrict__ v, double* __restrict__ part, int npart, double half = -1.0) {
+    if (scal[SC_DONE] != 0.0 && !(SR && scal[SC_DONEH] == half)) return;
     const double alpha = scal[SC_ALPHA];
     double s = 0.0;
     const int base = blockIdx.x * VB * VPT + threadIdx.x;
@@ -1721,7 +1734,7 @@ __global__ __launch_bounds__(VB) void k_bicg_upd1(int n, const double* __restric
             s += re * re;
         }
     }
-    block_partials(s, 0.0, part, npart, 1);
+    if (!SR) block_partials(s, 0.0, part, npart, 1);
 }
 // x += alpha pw, alone: the solve ended on a first half
 __global__ __launch_bounds__(VB) void k_bicg_xhalf(int n, const double* __restrict__ scal, double* __restrict__ x, const double* __restrict__ pw, double ws) {
@@ -1734,12 +1747,13 @@ __global__ __launch_bounds__(VB) void k_bicg_xhalf(int n, const double* __restri
     }
 }
 // x = (x + alpha pw) + omega s ; r -= omega t ; partials r.r and rw.r
+template <bool SR = false>
 __global__ __launch_bounds__(VB) void k_bicg_upd2(int n, const double* __restrict__ scal, double* __restrict__ x,
                                                   const double* __restrict__ pw, const double* __restrict__ sv, double* __restrict__ r,
                                                   const double* __restrict__ tv, const double* __restrict__ rw,
-                                                  double* __restrict__ part, int npart, double ws) {
+                                                  double* __restrict__ part, int npart, double ws, double half = -1.0) {
     // ws: pw and sv are M^-1 results still to be multiplied by the relaxation factor (1 when they already are, see bicgstab)
-    if (scal[SC_DONE] != 0.0) return;
+    if (scal[SC_DONE] != 0.0 && !(SR && scal[SC_DONEH] == half)) return;
     const double alpha = scal[SC_ALPHA], omega = scal[SC_OMEGA];
     double s = 0.0, q = 0.0;
     const int base = blockIdx.x * VB * VPT + threadIdx.x;
@@ -1755,7 +1769,7 @@ __global__ __launch_bounds__(VB) void k_bicg_upd2(int n, const double* __restric
             q += rw[e] * re;
         }
     }
-    block_partials(s, q, part, npart, 2);
+    if (!SR) block_partials(s, q, part, npart, 2);
 }
 // plain dots for the path where wells modify y after the SpMV: part0 = a.b, part1 = a.a
 __global__ __launch_bounds__(VB) void k_dots(int n, const double* __restrict__ a, const double* __restrict__ b,
@@ -1768,6 +1782,29 @@ __global__ __launch_bounds__(VB) void k_dots(int n, const double* __restrict__ a
         if (e < n) { s += a[e] * b[e]; q += a[e] * a[e]; }
     }
     block_partials(s, q, part, npart, nsum);
+}
+// the three scalar products of a half iteration with fused reductions where they do not ride in the product's kernel (wells modify y after
+// it; patterns without the stencil form): part0 = a.b, part1 = a.a, part2 = a.c; grid-stride, at most RED1_SINGLE_MAX workgroups
+__global__ __launch_bounds__(VB) void k_dots3(int n, const double* __restrict__ a, const double* __restrict__ b, const double* __restrict__ c3,
+                                              double* __restrict__ part, int npart) {
+    __shared__ double sh[3][VB / 64];
+    double s = 0.0, q = 0.0, t = 0.0;
+    for (int base = blockIdx.x * VB * VPT + threadIdx.x; base < n; base += gridDim.x * VB * VPT) {
+#pragma unroll
+        for (int u = 0; u < VPT; ++u) {
+            const int e = base + u * VB;
+            if (e < n) { const double ae = a[e]; s += ae * b[e]; q += ae * ae; t += ae * c3[e]; }
+        }
+    }
+    s = wave_sum(s); q = wave_sum(q); t = wave_sum(t);
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    if (lane == 0) { sh[0][wv] = s; sh[1][wv] = q; sh[2][wv] = t; }
+    __syncthreads();
+    if (threadIdx.x < 3) {
+        double a0 = sh[threadIdx.x][0];
+        for (int i = 1; i < VB / 64; ++i) a0 += sh[threadIdx.x][i];
+        part[threadIdx.x * npart + blockIdx.x] = a0;
+    }
 }
 // Long partial lists (one partial per 32-row tile = 31250 at 100^3) are reduced by RED1_BLOCKS workgroups, each summing one
 // contiguous slice in a fixed order (k_reduce_finalize); short ones by a single workgroup (k_finalize / k_local_sums).
@@ -1797,7 +1834,9 @@ __global__ __launch_bounds__(VB) void k_local_sums(int count, const double* __re
 }
 // Sum the partials in a fixed order and update the device-resident scalars.  One workgroup.
 enum FinMode { FIN_INIT = 0, FIN_ALPHA = 1, FIN_NORM = 2, FIN_OMEGA = 3, FIN_NORM_RHO = 4,
-               FIN_LOCAL = 5 };   // decomposed runs: only leave the two local sums in scal[0], scal[1] (input of the all-reduce)
+               FIN_LOCAL = 5,     // decomposed runs: only leave the two local sums in scal[0], scal[1] (input of the all-reduce)
+               FIN_SR1 = 6, FIN_SR2 = 7,   // opmhip_config.fused_reductions: ONE reduction of three sums per half iteration (finalize_scalars3)
+               FIN_TRUE = 8 };             // ... and, once per solve, the norm of the residual vector itself (scal[SC_TMP1])
 // FIN_NORM / FIN_NORM_RHO evaluate the stopping rule (norm < tol * norm_0, bda/cusparseSolverBackend.cu:115,151) on the
 // device: they raise scal[SC_DONE] and leave (norm, norm_0, done) in the pinned host slot `hslot` for the host, which
 // meanwhile has enqueued the next half iteration already.  Once the flag is up nothing changes any more.
@@ -1808,7 +1847,9 @@ __device__ __forceinline__ void finalize_scalars(int mode, double s0, double s1,
             scal[SC_NORM0] = sqrt(s0); scal[SC_NORM] = sqrt(s0);
             scal[SC_RHO] = s0; scal[SC_RHOP] = 1.0; scal[SC_ALPHA] = 1.0; scal[SC_OMEGA] = 1.0; scal[SC_BETA] = 0.0;
             scal[SC_DONE] = 0.0;
+            scal[SC_RR] = s0; scal[SC_RHOH] = s0; scal[SC_DONEH] = -1.0;
             break;
+        case FIN_TRUE: scal[SC_TMP1] = sqrt(s0); return;
         case FIN_ALPHA: scal[SC_TMP1] = s0; scal[SC_ALPHA] = scal[SC_RHO] / s0; break;
         case FIN_NORM: scal[SC_NORM] = sqrt(s0); break;  // stopping rule: below
         case FIN_OMEGA: scal[SC_TMP1] = s0; scal[SC_TMP2] = s1; scal[SC_OMEGA] = s0 / s1; break;
@@ -1827,6 +1868,83 @@ __device__ __forceinline__ void finalize_scalars(int mode, double s0, double s1,
         __hip_atomic_store(&hslot[3], seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);  // the host polls this one
     }
 }
+// One reduction per half iteration (opmhip_config.fused_reductions; the reference forms alpha, the norm, omega, the norm and rho from five
+// scalar products in four reductions, bda/cusparseSolverBackend.cu:92, 120-127, 151-161).  The product's kernel leaves three sums:
+//   first half,  v = A M^-1 p:  s0 = v.rw, s1 = v.v, s2 = v.r      alpha = rho / s0
+//       |r - alpha v|^2 = r.r - 2 alpha s2 + alpha^2 s1            rw.(r - alpha v) = rho - alpha s0   (0 but for rounding)
+//   second half, t = A M^-1 r:  s0 = t.r, s1 = t.t, s2 = t.rw      omega = s0 / s1
+//       |r - omega t|^2 = r.r - 2 omega s0 + omega^2 s1            rho' = rw.(r - omega t) = (rho - alpha v.rw) - omega s2
+// with r.r carried from half iteration to half iteration (SC_RR; negative results of the cancellation are clamped to 0).  The stopping
+// rule is evaluated HERE, before the update kernels of the half run: a half that meets it is remembered (SC_DONEH) so that its own
+// updates are still carried out.  oracle/linalg.hpp: bicgstab_fused_reductions states the same arithmetic.
+__device__ __forceinline__ void finalize_scalars3(int mode, double s0, double s1, double s2, double* __restrict__ scal, double tol, double* hslot, double seq, double half) {
+    const double rr = scal[SC_RR];
+    double rrn;
+    if (mode == FIN_SR1) {
+        const double rho = scal[SC_RHO];
+        const double alpha = rho / s0;
+        scal[SC_TMP1] = s0;
+        scal[SC_ALPHA] = alpha;
+        rrn = (rr - 2.0 * alpha * s2) + alpha * alpha * s1;
+        scal[SC_RHOH] = rho - alpha * s0;
+    } else {
+        const double omega = s0 / s1;
+        scal[SC_TMP1] = s0; scal[SC_TMP2] = s1;
+        scal[SC_OMEGA] = omega;
+        rrn = (rr - 2.0 * omega * s0) + omega * omega * s1;
+        const double rhop = scal[SC_RHO], rhon = scal[SC_RHOH] - omega * s2;
+        scal[SC_RHOP] = rhop; scal[SC_RHO] = rhon;
+        scal[SC_BETA] = (rhon / rhop) * (scal[SC_ALPHA] / omega);
+    }
+    if (!(rrn > 0.0)) rrn = (rrn != rrn) ? rrn : 0.0;   // (a NaN stays a NaN: the caller reports it)
+    scal[SC_RR] = rrn;
+    const double norm = sqrt(rrn), norm0 = scal[SC_NORM0];
+    scal[SC_NORM] = norm;
+    const double stop = (norm < tol * norm0) ? 1.0 : 0.0;
+    if (stop != 0.0) scal[SC_DONEH] = half;
+    scal[SC_DONE] = stop;
+    if (hslot) {
+        hslot[0] = norm; hslot[1] = norm0; hslot[2] = stop;
+        __hip_atomic_store(&hslot[3], seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
+}
+__global__ __launch_bounds__(VB) void k_finalize3(int mode, int count, const double* __restrict__ part, int npart,
+                                                  double* __restrict__ scal, double tol, double* hslot, double seq, double half) {
+    __shared__ double sh[3][VB];
+    constexpr int FU = 8;
+    double va[FU], vb[FU], vc[FU];
+#pragma unroll
+    for (int u = 0; u < FU; ++u) {
+        const int i = (int)threadIdx.x + u * VB;
+        const int j = i < count ? i : 0;
+        va[u] = part[j]; vb[u] = part[npart + j]; vc[u] = part[2 * npart + j];
+    }
+    if (mode != FIN_LOCAL && scal[SC_DONE] != 0.0) {   // a speculative launch past the stopping point still answers the host
+        if (threadIdx.x == 0 && hslot) {
+            hslot[0] = scal[SC_NORM]; hslot[1] = scal[SC_NORM0]; hslot[2] = 1.0;
+            __hip_atomic_store(&hslot[3], seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+        }
+        return;
+    }
+    double a = 0.0, b = 0.0, c3 = 0.0;
+#pragma unroll
+    for (int u = 0; u < FU; ++u)
+        if ((int)threadIdx.x + u * VB < count) { a += va[u]; b += vb[u]; c3 += vc[u]; }
+    for (int i = (int)threadIdx.x + FU * VB; i < count; i += VB) { a += part[i]; b += part[npart + i]; c3 += part[2 * npart + i]; }
+    sh[0][threadIdx.x] = a; sh[1][threadIdx.x] = b; sh[2][threadIdx.x] = c3;
+    __syncthreads();
+    for (int o = VB / 2; o >= 64; o >>= 1) {
+        if ((int)threadIdx.x < o) { sh[0][threadIdx.x] += sh[0][threadIdx.x + o]; sh[1][threadIdx.x] += sh[1][threadIdx.x + o]; sh[2][threadIdx.x] += sh[2][threadIdx.x + o]; }
+        __syncthreads();
+    }
+    if (threadIdx.x >= 64) return;
+    a = sh[0][threadIdx.x]; b = sh[1][threadIdx.x]; c3 = sh[2][threadIdx.x];
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) { a += __shfl_down(a, o, 64); b += __shfl_down(b, o, 64); c3 += __shfl_down(c3, o, 64); }
+    if (threadIdx.x != 0) return;
+    if (mode == FIN_LOCAL) { scal[0] = a; scal[1] = b; scal[2] = c3; return; }   // decomposed runs: the three local sums, input of the all-reduce
+    finalize_scalars3(mode, a, b, c3, scal, tol, hslot, seq, half);
+}
 __global__ __launch_bounds__(VB) void k_finalize(int mode, int count, const double* __restrict__ part, int npart,
                                                  double* __restrict__ scal, double tol, double* hslot, double seq) {
     __shared__ double sh[2][VB];
@@ -1841,7 +1959,7 @@ __global__ __launch_bounds__(VB) void k_finalize(int mode, int count, const doub
         const int j = i < count ? i : 0;
         va[u] = part[j]; vb[u] = part[npart + j];
     }
-    const double stop = (mode != FIN_INIT) ? scal[SC_DONE] : 0.0;
+    const double stop = (mode != FIN_INIT && mode != FIN_TRUE) ? scal[SC_DONE] : 0.0;
     if (stop != 0.0) {
         // a speculative launch past the stopping point still answers the host, which may be polling this slot
         if (threadIdx.x == 0 && hslot && (mode == FIN_NORM || mode == FIN_NORM_RHO)) {
@@ -1878,7 +1996,7 @@ __global__ __launch_bounds__(VB) void k_reduce_finalize(int mode, int count, con
                                                         unsigned* ticket, double* __restrict__ scal, double tol, double* hslot, double seq) {
     __shared__ double sh[2][VB];
     __shared__ bool last;
-    if (mode != FIN_INIT && mode != FIN_LOCAL && scal[SC_DONE] != 0.0) {
+    if (mode != FIN_INIT && mode != FIN_LOCAL && mode != FIN_TRUE && scal[SC_DONE] != 0.0) {
         if (blockIdx.x == 0 && threadIdx.x == 0 && hslot && (mode == FIN_NORM || mode == FIN_NORM_RHO)) {
             hslot[0] = scal[SC_NORM]; hslot[1] = scal[SC_NORM0]; hslot[2] = 1.0;
             __hip_atomic_store(&hslot[3], seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
@@ -2042,7 +2160,7 @@ static bool spmv_dots_separate(const opmhip_ctx* c) { return c->wells.any() || s
 // one launch over the schedule positions [p0, p0 + np): the pipelined kernel where the pattern allows it, else one tile per
 // workgroup.  Partial sums go to part[pofs ...]; returns how many were written (0 with ndot == 0).
 static int launch_spmv_part(opmhip_ctx* c, int p0, int np, const double* x, double* y, int ndot, const double* w0, double xs, int pofs, int cls,
-                            const double* uadd = nullptr) {
+                            const double* uadd = nullptr, const double* w1 = nullptr) {
     const Pattern& P = c->pat;
     if (np <= 0) return 0;
     double* part = c->d_part + pofs;
@@ -2056,16 +2174,19 @@ static int launch_spmv_part(opmhip_ctx* c, int p0, int np, const double* x, doub
         // resident, all ending together; small systems: one tile per workgroup.
         const RestSched& R = P.rest;
         const int4* rsched = reinterpret_cast<const int4*>(R.d_sched) + p0;
-        const int pipeWgs = std::max(8, spmv_pipe_wgs(c));
+        static const int restWgs = [] { const char* e = tuning_env("OPMHIP_REST_WGS"); return e ? std::atoi(e) : 0; }();   // measurement switch
+        const int pipeWgs = restWgs > 0 ? restWgs : std::max(8, spmv_pipe_wgs(c));
         const int steps = std::min((np + pipeWgs - 1) / pipeWgs, PIPE_MAX_STEPS);
         const int grid = 8 * (((np + steps - 1) / steps + 7) / 8);
         const int* tab = R.d_table + (size_t)p0 * 16;
         if (ndot == 0)
-            hipExtLaunchKernelGGL((k_spmv_pipe_st<0, true>), dim3(grid), dim3(64), 0, c->stream, e0, e1, 0, np, rsched, R.d_word, R.d_koff, tab, c->d_R, x, y, w0, part, c->npart, c->d_done, xs, uadd);
+            hipExtLaunchKernelGGL((k_spmv_pipe_st<0, true>), dim3(grid), dim3(64), 0, c->stream, e0, e1, 0, np, rsched, R.d_word, R.d_koff, tab, c->d_R, x, y, w0, part, c->npart, c->d_done, xs, uadd, (const double*)nullptr);
         else if (ndot == 1)
-            hipExtLaunchKernelGGL((k_spmv_pipe_st<1, true>), dim3(grid), dim3(64), 0, c->stream, e0, e1, 0, np, rsched, R.d_word, R.d_koff, tab, c->d_R, x, y, w0, part, c->npart, c->d_done, xs, uadd);
+            hipExtLaunchKernelGGL((k_spmv_pipe_st<1, true>), dim3(grid), dim3(64), 0, c->stream, e0, e1, 0, np, rsched, R.d_word, R.d_koff, tab, c->d_R, x, y, w0, part, c->npart, c->d_done, xs, uadd, (const double*)nullptr);
+        else if (ndot == 2)
+            hipExtLaunchKernelGGL((k_spmv_pipe_st<2, true>), dim3(grid), dim3(64), 0, c->stream, e0, e1, 0, np, rsched, R.d_word, R.d_koff, tab, c->d_R, x, y, w0, part, c->npart, c->d_done, xs, uadd, (const double*)nullptr);
         else
-            hipExtLaunchKernelGGL((k_spmv_pipe_st<2, true>), dim3(grid), dim3(64), 0, c->stream, e0, e1, 0, np, rsched, R.d_word, R.d_koff, tab, c->d_R, x, y, w0, part, c->npart, c->d_done, xs, uadd);
+            hipExtLaunchKernelGGL((k_spmv_pipe_st<3, true>), dim3(grid), dim3(64), 0, c->stream, e0, e1, 0, np, rsched, R.d_word, R.d_koff, tab, c->d_R, x, y, w0, part, c->npart, c->d_done, xs, uadd, w1);
         return ndot > 0 ? grid : 0;
     }
     const int4* sched = reinterpret_cast<const int4*>(P.tiles.d_spmvSched) + p0;
@@ -2080,11 +2201,13 @@ static int launch_spmv_part(opmhip_ctx* c, int p0, int np, const double* x, doub
         if ((!inInt || P.tiles.stencilPart[0]) && (!inBnd || P.tiles.stencilPart[1]) && !explicitIdx) {
             const int* tab = P.tiles.d_stTable + (size_t)p0 * 16;
             if (ndot == 0)
-                hipExtLaunchKernelGGL((k_spmv_pipe_st<0, false>), dim3(grid), dim3(64), 0, c->stream, e0, e1, 0, np, sched, P.tiles.d_stWord, P.tiles.d_stKoff, tab, c->d_A, x, y, w0, part, c->npart, c->d_done, xs, (const double*)nullptr);
+                hipExtLaunchKernelGGL((k_spmv_pipe_st<0, false>), dim3(grid), dim3(64), 0, c->stream, e0, e1, 0, np, sched, P.tiles.d_stWord, P.tiles.d_stKoff, tab, c->d_A, x, y, w0, part, c->npart, c->d_done, xs, (const double*)nullptr, (const double*)nullptr);
             else if (ndot == 1)
-                hipExtLaunchKernelGGL((k_spmv_pipe_st<1, false>), dim3(grid), dim3(64), 0, c->stream, e0, e1, 0, np, sched, P.tiles.d_stWord, P.tiles.d_stKoff, tab, c->d_A, x, y, w0, part, c->npart, c->d_done, xs, (const double*)nullptr);
+                hipExtLaunchKernelGGL((k_spmv_pipe_st<1, false>), dim3(grid), dim3(64), 0, c->stream, e0, e1, 0, np, sched, P.tiles.d_stWord, P.tiles.d_stKoff, tab, c->d_A, x, y, w0, part, c->npart, c->d_done, xs, (const double*)nullptr, (const double*)nullptr);
+            else if (ndot == 2)
+                hipExtLaunchKernelGGL((k_spmv_pipe_st<2, false>), dim3(grid), dim3(64), 0, c->stream, e0, e1, 0, np, sched, P.tiles.d_stWord, P.tiles.d_stKoff, tab, c->d_A, x, y, w0, part, c->npart, c->d_done, xs, (const double*)nullptr, (const double*)nullptr);
             else
-                hipExtLaunchKernelGGL((k_spmv_pipe_st<2, false>), dim3(grid), dim3(64), 0, c->stream, e0, e1, 0, np, sched, P.tiles.d_stWord, P.tiles.d_stKoff, tab, c->d_A, x, y, w0, part, c->npart, c->d_done, xs, (const double*)nullptr);
+                hipExtLaunchKernelGGL((k_spmv_pipe_st<3, false>), dim3(grid), dim3(64), 0, c->stream, e0, e1, 0, np, sched, P.tiles.d_stWord, P.tiles.d_stKoff, tab, c->d_A, x, y, w0, part, c->npart, c->d_done, xs, (const double*)nullptr, w1);
             return ndot > 0 ? grid : 0;
         }
         if (ndot == 0)
@@ -2130,10 +2253,14 @@ static int ms_wells_apply(opmhip_ctx* c, const double* x, double* y, double xs) 
 // Every row's sum is formed by the same statements in the same order whichever launch it is in: the same bits as one launch.
 // uadd != NULL: the rest product - x is the (unscaled) result of the ILU0 application that has just left its row sums in uadd:
 // y_i = sum_rest A_ik (xs x_k) + xs uadd_i  (Pattern::ualias; the same wells, halo exchange and scalar products around it)
-int launch_spmv(opmhip_ctx* c, double* x, double* y, int ndot, const double* w0, double xs, bool exchange, const double* uadd) {
+// ndot == 3 (fused reductions): y.w0, y.y and y.w1 - riding in the product's kernel where every launch of it is the pipelined stencil kernel,
+// else formed by k_dots3 behind it
+int launch_spmv(opmhip_ctx* c, double* x, double* y, int ndot, const double* w0, double xs, bool exchange, const double* uadd, const double* w1) {
     const Pattern& P = c->pat;
     const bool wells = c->wells.num_wells > 0;
-    const int fused = spmv_dots_separate(c) ? 0 : ndot;
+    static const bool explicitIdx3 = [] { const char* e = tuning_env("OPMHIP_SPMV_EXPLICIT"); return e && e[0] == '1'; }();
+    const bool rides3 = uadd ? true : (spmv_pipelined(c) && P.tiles.stencilPart[0] && (P.tiles.nsched == P.tiles.nschedInt || P.tiles.stencilPart[1]) && !explicitIdx3);
+    const int fused = (spmv_dots_separate(c) || (ndot == 3 && !rides3)) ? 0 : ndot;
     const bool halo = exchange && c->comm.halo_set && c->comm.nneigh > 0;
     if (exchange && !halo && c->comm.nranks > 1) comm_halo_bystander(c);   // a subdomain that touches no other: nothing to exchange, but the peers' exchange counts this rank in (loopback)
     const int nAll = uadd ? P.rest.nsched : P.tiles.nsched;
@@ -2143,21 +2270,26 @@ int launch_spmv(opmhip_ctx* c, double* x, double* y, int ndot, const double* w0,
         // main: ev_x (x complete) -> interior tiles ........................ wait ev_h -> boundary tiles
         // halo:         wait ev_x -> pack -> send / receive -> ev_h
         if ((rc = comm_halo_begin(c, x))) return rc;     // records ev_x on the main stream; the exchange itself is behind it on the halo stream
-        cnt += launch_spmv_part(c, 0, nInt, x, y, fused, w0, xs, cnt, PROF_SPMV, uadd);
+        cnt += launch_spmv_part(c, 0, nInt, x, y, fused, w0, xs, cnt, PROF_SPMV, uadd, w1);
         if ((rc = comm_halo_end(c))) return rc;
-        cnt += launch_spmv_part(c, nInt, nBnd, x, y, fused, w0, xs, cnt, PROF_SPMV_BOUNDARY, uadd);
+        cnt += launch_spmv_part(c, nInt, nBnd, x, y, fused, w0, xs, cnt, PROF_SPMV_BOUNDARY, uadd, w1);
     } else {
         if (halo && (rc = comm_halo_f64(c, x, BS))) return rc;
-        cnt += launch_spmv_part(c, 0, nAll, x, y, fused, w0, xs, cnt, PROF_SPMV, uadd);
+        cnt += launch_spmv_part(c, 0, nAll, x, y, fused, w0, xs, cnt, PROF_SPMV, uadd, w1);
     }
     if (c->wells.num_ms > 0 && (rc = ms_wells_apply(c, x, y, xs))) return rc;   // in front of the standard wells, bda/WellContributions.cu:160-187
     if (wells && (rc = launch_wells_apply(c, x, y, xs))) return rc;
     if (fused == 0 && ndot > 0) {
         const int n = P.Nb * BS;
         const int ps = prof_begin(c, PROF_VECTOR);   // a scope of its own: its bytes are counted under "vector"
-        hipLaunchKernelGGL(k_dots, dim3(vec_blocks(n)), dim3(VB), 0, c->stream, n, y, w0, c->d_part, c->npart, ndot);
+        if (ndot == 3) {
+            cnt = std::min(vec_blocks(n), RED1_SINGLE_MAX);
+            hipLaunchKernelGGL(k_dots3, dim3(cnt), dim3(VB), 0, c->stream, n, y, w0, w1, c->d_part, c->npart);
+        } else {
+            hipLaunchKernelGGL(k_dots, dim3(vec_blocks(n)), dim3(VB), 0, c->stream, n, y, w0, c->d_part, c->npart, ndot);
+            cnt = vec_blocks(n);
+        }
         prof_end(c, ps);
-        cnt = vec_blocks(n);
     }
     c->last_dot_count = cnt;
     return OPMHIP_SUCCESS;
@@ -2321,13 +2453,35 @@ static int finalize(opmhip_ctx* c, int mode, int count, int rb_half = -1) {
     hipLaunchKernelGGL(k_finalize, dim3(1), dim3(VB), 0, c->stream, mode, count, c->d_part, c->npart, c->d_scal, tol, hslot, seq);
     return OPMHIP_SUCCESS;
 }
+// opmhip_config.fused_reductions: the ONE reduction of a half iteration (three sums) and its scalar stage; decomposed runs: local sums ->
+// one all-reduce of three doubles -> scalars
+static int finalize3(opmhip_ctx* c, int mode, int count, int rb_half) {
+    const double tol = c->cfg.tolerance;
+    const int sl = rb_half % opmhip_ctx::RB_SLOTS;
+    double* hslot = c->d_ring + (size_t)sl * opmhip_ctx::RB_DOUBLES;
+    const double seq = (c->rb_seq += 1.0);
+    c->rb_want[sl] = seq;
+    if (c->comm.nranks > 1) {
+        const int span = prof_span_begin(c, PROF_ALLREDUCE);
+        hipLaunchKernelGGL(k_finalize3, dim3(1), dim3(VB), 0, c->stream, (int)FIN_LOCAL, count, c->d_part, c->npart, c->comm.d_red, tol, (double*)nullptr, 0.0, 0.0);
+        c->comm.reduce_span_open = true;
+        const int rc = comm_allreduce(c, c->comm.d_red, 3, 0);
+        c->comm.reduce_span_open = false;
+        prof_span_end(c, span);
+        if (rc) return rc;
+        hipLaunchKernelGGL(k_finalize3, dim3(1), dim3(VB), 0, c->stream, mode, 1, c->comm.d_red, 1, c->d_scal, tol, hslot, seq, (double)rb_half);
+        return OPMHIP_SUCCESS;
+    }
+    hipLaunchKernelGGL(k_finalize3, dim3(1), dim3(VB), 0, c->stream, mode, count, c->d_part, c->npart, c->d_scal, tol, hslot, seq, (double)rb_half);
+    return OPMHIP_SUCCESS;
+}
 // the vector kernels of one BiCGStab iteration, for opmhip_time_kernel
 void launch_vector_kernels_once(opmhip_ctx* c) {
     const int n = c->pat.Nb * BS, nb = vec_blocks(n);
     hipLaunchKernelGGL(k_bicg_pupdate, dim3(nb), dim3(VB), 0, c->stream, n, c->d_scal, c->d_p, c->d_v, c->d_r);
-    hipLaunchKernelGGL(k_bicg_upd1, dim3(nb), dim3(VB), 0, c->stream, n, c->d_scal, c->d_r, c->d_v, c->d_part, c->npart);
+    hipLaunchKernelGGL(k_bicg_upd1<false>, dim3(nb), dim3(VB), 0, c->stream, n, c->d_scal, c->d_r, c->d_v, c->d_part, c->npart, -1.0);
     (void)finalize(c, FIN_NORM, nb);  // timing helper, single-rank contexts only
-    hipLaunchKernelGGL(k_bicg_upd2, dim3(nb), dim3(VB), 0, c->stream, n, c->d_scal, c->d_x, c->d_pw, c->d_s, c->d_r, c->d_t, c->d_rw, c->d_part, c->npart, c->minv_scale);
+    hipLaunchKernelGGL(k_bicg_upd2<false>, dim3(nb), dim3(VB), 0, c->stream, n, c->d_scal, c->d_x, c->d_pw, c->d_s, c->d_r, c->d_t, c->d_rw, c->d_part, c->npart, c->minv_scale, -1.0);
     (void)finalize(c, FIN_NORM_RHO, nb);
 }
 
@@ -2357,6 +2511,7 @@ static int enqueue_half(opmhip_ctx* c, int h, int part = HALF_ALL) {
     // Pattern::ualias: the backward sweeps of the ILU0 application leave the upper part of the product that follows behind as row sums;
     // that product then streams the matrix without its U part (d_R, written by this solve's factorisation)
     const bool hp = !cpr && c->half_product;
+    const bool sr = c->cfg.fused_reductions > 0;   // one reduction of three sums per half iteration (finalize_scalars3)
     const bool precTalks = cpr && c->cpr.gather.on;                  // the preconditioner posts collectives
     const bool head = part != HALF_REST, rest = part != HALF_PRECOND;
     const bool applyNow = part == HALF_ALL || (precTalks ? part == HALF_REST : part == HALF_PRECOND);
@@ -2373,10 +2528,18 @@ static int enqueue_half(opmhip_ctx* c, int h, int part = HALF_ALL) {
             if (cpr && c->cpr.apply_rc) { rc = c->cpr.apply_rc; c->cpr.apply_rc = 0; return rc; }   // a collective of the joined coarse level failed
         }
         if (!rest) return OPMHIP_SUCCESS;
+        if (sr) {   // one reduction: v.rw, v.v, v.r ride in the product; alpha, the new norm and the stopping rule follow at once
+            if ((rc = launch_spmv(c, c->d_pw, c->d_v, 3, c->d_rw, c->minv_scale, true, hp ? c->d_usum : nullptr, c->d_r))) return rc;
+            ps = prof_begin(c, PROF_VECTOR);
+            if ((rc = finalize3(c, FIN_SR1, dot_count(c), h))) return rc;
+            hipLaunchKernelGGL(k_bicg_upd1<true>, dim3(nb), dim3(VB), 0, c->stream, n, c->d_scal, c->d_r, c->d_v, c->d_part, c->npart, (double)h);
+            prof_end(c, ps);
+            return OPMHIP_SUCCESS;
+        }
         if ((rc = launch_spmv(c, c->d_pw, c->d_v, 1, c->d_rw, c->minv_scale, true, hp ? c->d_usum : nullptr))) return rc;  // with copyOwnerToAll before the operator (ParallelOverlappingILU0.hpp:897)
         ps = prof_begin(c, PROF_VECTOR);
         if ((rc = finalize(c, FIN_ALPHA, dot_count(c)))) return rc;
-        hipLaunchKernelGGL(k_bicg_upd1, dim3(nb), dim3(VB), 0, c->stream, n, c->d_scal, c->d_r, c->d_v, c->d_part, c->npart);
+        hipLaunchKernelGGL(k_bicg_upd1<false>, dim3(nb), dim3(VB), 0, c->stream, n, c->d_scal, c->d_r, c->d_v, c->d_part, c->npart, -1.0);
         if ((rc = finalize(c, FIN_NORM, nb, h))) return rc;
         prof_end(c, ps);
     } else {             // second half: z = M^-1 r, t = A z, omega, x += omega z, r -= omega t, |r|, rho, beta
@@ -2386,10 +2549,18 @@ static int enqueue_half(opmhip_ctx* c, int h, int part = HALF_ALL) {
             if (cpr && c->cpr.apply_rc) { rc = c->cpr.apply_rc; c->cpr.apply_rc = 0; return rc; }
         }
         if (!rest) return OPMHIP_SUCCESS;
+        if (sr) {   // t.r, t.t, t.rw: omega, the new norm, rho and beta from one reduction
+            if ((rc = launch_spmv(c, c->d_s, c->d_t, 3, c->d_r, c->minv_scale, true, hp ? c->d_usum : nullptr, c->d_rw))) return rc;
+            ps = prof_begin(c, PROF_VECTOR);
+            if ((rc = finalize3(c, FIN_SR2, dot_count(c), h))) return rc;
+            hipLaunchKernelGGL(k_bicg_upd2<true>, dim3(nb), dim3(VB), 0, c->stream, n, c->d_scal, c->d_x, c->d_pw, c->d_s, c->d_r, c->d_t, c->d_rw, c->d_part, c->npart, c->minv_scale, (double)h);
+            prof_end(c, ps);
+            return OPMHIP_SUCCESS;
+        }
         if ((rc = launch_spmv(c, c->d_s, c->d_t, 2, c->d_r, c->minv_scale, true, hp ? c->d_usum : nullptr))) return rc;
         ps = prof_begin(c, PROF_VECTOR);
         if ((rc = finalize(c, FIN_OMEGA, dot_count(c)))) return rc;
-        hipLaunchKernelGGL(k_bicg_upd2, dim3(nb), dim3(VB), 0, c->stream, n, c->d_scal, c->d_x, c->d_pw, c->d_s, c->d_r, c->d_t, c->d_rw, c->d_part, c->npart, c->minv_scale);
+        hipLaunchKernelGGL(k_bicg_upd2<false>, dim3(nb), dim3(VB), 0, c->stream, n, c->d_scal, c->d_x, c->d_pw, c->d_s, c->d_r, c->d_t, c->d_rw, c->d_part, c->npart, c->minv_scale, -1.0);
         if ((rc = finalize(c, FIN_NORM_RHO, nb, h))) return rc;
         prof_end(c, ps);
     }
@@ -2486,12 +2657,24 @@ int bicgstab(opmhip_ctx* c, opmhip_result* res) {
         if ((rc = read_scalars(c))) return rc;
         norm = norm_0 = c->h_pinned[SC_NORM0];
     }
+    bool drifted = false;
+    if (c->cfg.fused_reductions > 0 && nhalves > 0 && std::isfinite(norm)) {
+        // the norms above came out of a recurrence (finalize_scalars3); the residual VECTOR was updated explicitly all along: its own norm,
+        // once per solve (one more reduction), is what is reported - and a solve whose recurred norm met the tolerance while the vector's is
+        // more than twice it is reported as not converged (the caller then falls back as after any failure, linalg/ISTLSolverEbos.hpp:277-289)
+        hipLaunchKernelGGL(k_dots, dim3(nb), dim3(VB), 0, c->stream, n, c->d_r, c->d_r, c->d_part, c->npart, 1);
+        if ((rc = finalize(c, FIN_TRUE, nb))) return rc;
+        if ((rc = read_scalars(c))) return rc;
+        const double truth = c->h_pinned[SC_TMP1];
+        drifted = it != (maxit + 0.5f) && !(truth < 2.0 * tol * norm_0);
+        norm = truth;
+    }
     OPMHIP_HIP(c, hipGetLastError());
     res->it = it;
     res->iterations = (int)std::fmin(it, (float)maxit);
     res->reduction = norm / norm_0;
     res->conv_rate = std::pow(res->reduction, 1.0 / it);
-    res->converged = (it != (maxit + 0.5f));
+    res->converged = (it != (maxit + 0.5f)) && !drifted;
     return OPMHIP_SUCCESS;
 }
 

@@ -577,6 +577,66 @@ SolveResult bicgstab(size_t n, const double* b, double* x, Prec&& prec, Op&& op,
 }
 
 
+// ---- the same recurrence with ONE reduction per half iteration (libopmhip's opmhip_config.fused_reductions) ---------------------------
+// The reference (above) forms alpha, |r|, omega, |r| and rho from five scalar products in four reductions per iteration.  Here a half
+// iteration has three scalar products, all with the product's result, and everything else follows from them:
+//   first half,  v = A M^-1 p:  v.rw, v.v, v.r     alpha = rho / v.rw      |r - alpha v|^2 = r.r - 2 alpha v.r + alpha^2 v.v
+//   second half, t = A M^-1 r:  t.r, t.t, t.rw     omega = t.r / t.t       |r - omega t|^2 = r.r - 2 omega t.r + omega^2 t.t
+//                                                  rho'  = (rho - alpha v.rw) - omega t.rw
+// r.r is carried along (a cancellation that comes out negative is clamped to 0), the stopping rule looks at these recurred norms, and the
+// vector r is still updated explicitly: its own norm is formed once at the end and reported as the reduction (csrc/solver.hip:
+// finalize_scalars3 states the same arithmetic; the scalar products themselves are summed in another order there).
+template <class Prec, class Op>
+SolveResult bicgstab_fused_reductions(size_t n, const double* b, double* x, Prec&& prec, Op&& op, double tol, int maxit) {
+    std::vector<double> r(b, b + n), rw(b, b + n), p(b, b + n), v(n, 0.0), s(n), t(n), pw(n);
+    std::fill(x, x + n, 0.0);
+    double rr = dot(r.data(), r.data(), n);
+    double rho = rr, rhoh = rr, alpha = 1.0, omega = 1.0, beta = 0.0;
+    double norm = std::sqrt(rr);
+    const double norm_0 = norm;
+    auto clamp = [](double q) { return (q > 0.0) ? q : ((q != q) ? q : 0.0); };
+    float it;
+    for (it = 0.5f; it < maxit; it += 0.5f) {
+        if (it > 1)
+            for (size_t i = 0; i < n; ++i) p[i] = (p[i] - omega * v[i]) * beta + r[i];
+        prec(p.data(), pw.data());
+        op(pw.data(), v.data());
+        {
+            const double s0 = dot(v.data(), rw.data(), n), s1 = dot(v.data(), v.data(), n), s2 = dot(v.data(), r.data(), n);
+            alpha = rho / s0;
+            rr = clamp((rr - 2.0 * alpha * s2) + alpha * alpha * s1);
+            rhoh = rho - alpha * s0;
+            norm = std::sqrt(rr);
+        }
+        for (size_t i = 0; i < n; ++i) r[i] -= alpha * v[i];
+        for (size_t i = 0; i < n; ++i) x[i] += alpha * pw[i];
+        if (norm < tol * norm_0) break;
+        it += 0.5f;
+        prec(r.data(), s.data());
+        op(s.data(), t.data());
+        {
+            const double s0 = dot(t.data(), r.data(), n), s1 = dot(t.data(), t.data(), n), s2 = dot(t.data(), rw.data(), n);
+            omega = s0 / s1;
+            rr = clamp((rr - 2.0 * omega * s0) + omega * omega * s1);
+            const double rhop = rho;
+            rho = rhoh - omega * s2;
+            beta = (rho / rhop) * (alpha / omega);
+            norm = std::sqrt(rr);
+        }
+        for (size_t i = 0; i < n; ++i) x[i] += omega * s[i];
+        for (size_t i = 0; i < n; ++i) r[i] -= omega * t[i];
+        if (norm < tol * norm_0) break;
+    }
+    const double truth = norm2(r.data(), n);
+    SolveResult res;
+    res.it = it;
+    res.iterations = (int)std::min(it, (float)maxit);
+    res.reduction = truth / norm_0;
+    res.conv_rate = std::pow(res.reduction, 1.0 / it);
+    res.converged = (it != (maxit + 0.5f)) && (truth < 2.0 * tol * norm_0);
+    return res;
+}
+
 // =====================================================================================================
 // Threaded variants for bench.py's multi-core CPU baseline ("CPU-N": what N MPI ranks of Flow do on one host):
 // block-Jacobi ILU0 over nsub contiguous row ranges, one range per thread (ghost_last_bilu0_decomposition per rank,

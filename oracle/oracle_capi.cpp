@@ -172,6 +172,8 @@ int orc_solve_hp(int Nb, const int* rowptr, const int* col, const double* val, c
                  const int* val_pointers, const int* Ccols, const int* Bcols, const double* Cnnzs,
                  const double* Dnnzs, const double* Bnnzs, int nsub, const int* sub_start, int half_product, orc_result* out) {
     using clk = std::chrono::steady_clock;
+    const bool fused = (half_product & 2) != 0;
+    half_product &= 1;
     Bcrs A = wrap(Nb, rowptr, col, val);
     if (zero_diag_fix) check_zero_diagonal(A);
     Wells W = wrap_wells(numWells, val_pointers, Ccols, Bcols, Cnnzs, Dnnzs, Bnnzs);
@@ -221,7 +223,8 @@ int orc_solve_hp(int Nb, const int* rowptr, const int* col, const double* val, c
         else spmv(A, xin, y);
         if (W.numWells > 0) wells_apply(W, xin, y);
     };
-    SolveResult r = bicgstab(n, rb.data(), rx.data(), prec, op, tol, maxit);
+    // half_product bit 1 (value 2 or 3): the recurrence with one reduction per half iteration (bicgstab_fused_reductions)
+    SolveResult r = fused ? bicgstab_fused_reductions(n, rb.data(), rx.data(), prec, op, tol, maxit) : bicgstab(n, rb.data(), rx.data(), prec, op, tol, maxit);
     auto t2 = clk::now();
     if (reorder != 0) {
         for (int i = 0; i < Nb; ++i)

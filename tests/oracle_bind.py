@@ -140,10 +140,11 @@ class Oracle:
         return xw
 
     def solve(self, Nb, rowptr, col, val, b, tol=1e-2, maxit=200, w=0.9, mode="post_scale", reorder="none",
-              zero_diag_fix=True, wells=None, sub_start=None, owner=None, half_product=False):
+              zero_diag_fix=True, wells=None, sub_start=None, owner=None, half_product=False, fused_reductions=False):
         """sub_start: block-Jacobi ILU0 over contiguous row ranges; owner: the same with an owner id per row.
         half_product: the product after every ILU0 application from the backward sweep's row sums (oracle/linalg.hpp: ilu0_apply_u,
-        spmv_rest - the order of libopmhip's opmhip_config.half_product)."""
+        spmv_rest - the order of libopmhip's opmhip_config.half_product).  fused_reductions: BiCGStab with one reduction per half iteration
+        (oracle/linalg.hpp: bicgstab_fused_reductions, opmhip_config.fused_reductions)."""
         x = np.zeros(Nb * 3)
         res = OrcResult()
         W = wells or {}
@@ -154,7 +155,7 @@ class Oracle:
         rc = self.lib.orc_solve_hp(Nb, rowptr, col, val, b, x, tol, maxit, w, RELAX[mode], REORDER[reorder],
                                    int(zero_diag_fix), W.get("numWells", 0), _p(W.get("val_pointers")),
                                    _p(W.get("Ccols")), _p(W.get("Bcols")), _p(W.get("Cnnzs")), _p(W.get("Dnnzs")),
-                                   _p(W.get("Bnnzs")), nsub, _p(ss), int(bool(half_product)), C.byref(res))
+                                   _p(W.get("Bnnzs")), nsub, _p(ss), int(bool(half_product)) + 2 * int(bool(fused_reductions)), C.byref(res))
         assert rc == 0, rc
         return x, res
 

@@ -110,3 +110,34 @@ def test_patterns_with_triangles_are_refused(orc):
     assert not _upper_equal(Nb, rp, ci, v, lu)
     rc = orc.lib.orc_preconditioned_product(Nb, rp, ci, v, lu, np.zeros(3 * Nb), 0.9, 0, 1, np.zeros(3 * Nb), np.zeros(3 * Nb))
     assert rc == -1000
+
+
+def test_fused_reductions_recurrence(pkg, orc, golden):
+    """BiCGStab with one reduction per half iteration (oracle/linalg.hpp: bicgstab_fused_reductions; opmhip_config.fused_reductions): on the
+    reference's matr33 / rhs3 it lands on the pinned exact solution in the first half iteration like the reference's recurrence; on
+    Jacobians it stops within half an iteration of it down to 1e-6, reports the TRUE residual norm of its iterate, and that iterate solves
+    the system to the tolerance"""
+    import json
+    import oracle_bind
+    with open(os.path.join(golden, "linalg", "expected.json")) as f:
+        e = json.load(f)["exact_noprec_tol1e-12_maxit200"]
+    Nb, rp, ci, v, b = _load(pkg, golden, e["matrix"], e["rhs"])
+    x, res = orc.solve(Nb, rp, ci, v, b, tol=1e-6, maxit=20, w=1.0, fused_reductions=True)
+    assert res.converged and res.it == 0.5
+    for xi, ri in zip(x, np.array(e["x"])):
+        assert abs(xi - ri) <= 2e-4 * abs(ri)
+    case = pkg.decks.cartesian_case(10, 9, 8, state="mixed", heterogeneous=True)
+    o = oracle_bind.OracleModel(orc, case)
+    o.set_state(case["pv"], case["meaning"])
+    o.set_source(pkg.decks.five_spot_source(case, rate_sm3_per_day=50.0))
+    jac, r = o.assemble(10 * 86400.0, 0)
+    Nb = case["Nb"]
+    for tol in (1e-2, 1e-4, 1e-6):
+        for hp in (False, True):
+            x0, r0 = orc.solve(Nb, case["rowptr"], case["col"], jac, r, tol=tol, maxit=200, w=0.9, half_product=hp)
+            x1, r1 = orc.solve(Nb, case["rowptr"], case["col"], jac, r, tol=tol, maxit=200, w=0.9, half_product=hp, fused_reductions=True)
+            assert r0.converged and r1.converged and abs(r0.it - r1.it) <= 0.5
+            true = np.linalg.norm(r - orc.spmv(Nb, case["rowptr"], case["col"], jac, x1)) / np.linalg.norm(r)
+            assert abs(true - r1.reduction) <= 1e-6 * r1.reduction + 1e-12 and true < 2.0 * tol       # the reported reduction is the iterate's own
+            if r0.it == r1.it:
+                np.testing.assert_allclose(x1, x0, rtol=1e-6, atol=1e-9 * np.abs(x0).max())
