@@ -196,6 +196,7 @@ class HipSolver:
             cfg.cpr_gather_rows = int(cpr_gather_rows)         # decomposed runs: the hierarchy is continued across the ranks from the first level this small (0 default, < 0 off)
         cfg.half_product = int(half_product)
         cfg.fused_reductions = int(fused_reductions)   # 1: one reduction (three sums) per BiCGStab half iteration, recurred norms
+        self._pin = bool(pin_host_arrays)
         cfg.pin_host_arrays = int(pin_host_arrays)   # 1: vals / b / x keep their addresses (Flow's do): registered for DMA on first sight
         cfg.cpr_async_setup = int(cpr_async_setup)   # mode 2 only: the rebuild on a host thread beside the solves
         cfg.cpr_reuse_setup = int(cpr_reuse_setup)   # --cpr-reuse-setup: 0 every solve, 1 every time step, 2 after > 10 iterations, 3 never
@@ -234,6 +235,12 @@ class HipSolver:
         return res
 
     def get_result(self):
+        if getattr(self, "_pin", False):
+            # registered arrays must keep their addresses (opmhip_config.pin_host_arrays): one result buffer per context, handed out as a copy
+            if getattr(self, "_xbuf", None) is None or len(self._xbuf) != 3 * self.Nb:
+                self._xbuf = np.empty(3 * self.Nb)
+            self._check(lib().opmhip_get_result(self._h, _ptr(self._xbuf)))
+            return self._xbuf.copy()
         x = np.empty(3 * self.Nb)
         self._check(lib().opmhip_get_result(self._h, _ptr(x)))
         return x

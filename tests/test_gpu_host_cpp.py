@@ -249,3 +249,32 @@ def test_HipLinearizer_drives_newton_iterations(pkg, tmp_path, mode):
     pvc = raw[:case["Nb"] * 24].view(np.float64)
     pm, mm = m.get_state()
     assert np.array_equal(raw[case["Nb"] * 24:], mm) and np.array_equal(pvc, pm)
+
+
+def test_registered_host_arrays_give_the_same_solve(pkg, orc):
+    """opmhip_config.pin_host_arrays (what host/hipSolverBackend.hpp sets: Flow's value array, right-hand side and solution vector keep their
+    addresses, bda/BdaBridge.cpp:199-232): the arrays are registered for DMA the first time they are seen and every later solve copies from
+    / to them directly - same iterations, same solution bits as the plain copies, for new values in the same arrays and for a second set of
+    arrays on the same context"""
+    from helpers import laplace_block_system
+    Nb, rp, ci, v = laplace_block_system(20, 16, 10, seed=6)
+    b = np.random.default_rng(10).standard_normal(3 * Nb)
+    ref = pkg.capi.HipSolver(tolerance=1e-6, reorder="line_coloring")
+    r0 = ref.solve_system(Nb, rp, ci, v.copy(), b)
+    x0 = ref.get_result()
+    s = pkg.capi.HipSolver(tolerance=1e-6, reorder="line_coloring", pin_host_arrays=1)
+    vals, rhs = v.copy(), b.copy()                 # these two keep their addresses over the solves, like Flow's
+    for k in range(3):
+        r = s.solve_system(Nb, rp if k == 0 else None, ci if k == 0 else None, vals, rhs)
+        assert r.converged and r.it == r0.it
+        assert np.array_equal(s.get_result(), x0)
+    vals *= 1.01                                   # new values in the SAME (registered) array
+    r1 = s.solve_system(Nb, None, None, vals, rhs)
+    ref1 = ref.solve_system(Nb, None, None, v * 1.01, b)
+    assert r1.it == ref1.it and np.array_equal(s.get_result(), ref.get_result())
+    other = (v * 0.99).copy()                      # another array: registered in turn
+    r2 = s.solve_system(Nb, None, None, other, rhs)
+    ref2 = ref.solve_system(Nb, None, None, v * 0.99, b)
+    assert r2.it == ref2.it and np.array_equal(s.get_result(), ref.get_result())
+    with pytest.raises(pkg.capi.OpmHipError):
+        pkg.capi.HipSolver(pin_host_arrays=2)
