@@ -137,8 +137,11 @@ typedef struct opmhip_config {
                             * A (w z), summed in another order: results differ from the plain form in the last bits, iteration counts
                             * agree (tests/test_gpu_half_product.py; the oracle states the same order).  0 (default): the library's choice - on
                             * where the pattern allows it, the ordering is line-coloured and the system is large enough for the pipelined
-                            * kernels, single domain; > 0: wherever the pattern and the ordering allow it; < 0: never.  Ignored with a CPR
-                            * preconditioner.  opmhip_get_product_form says what is in force.  ABI 10 */
+                            * kernels; > 0: wherever the pattern and the ordering allow it; < 0: never.  Ignored with a CPR preconditioner.
+                            * Subdomains of a decomposed run: the tiles none of whose rows has a ghost column take the form (68 % of them on a
+                            * 10^6-cell subdomain of a 2 x 2 x 2 decomposition), the boundary tiles keep the whole product - behind the halo
+                            * exchange, as before; a subdomain without such tiles keeps the plain form.  opmhip_get_product_form says what
+                            * is in force.  ABI 10 */
     int pin_host_arrays;   /* 1: the host arrays handed to opmhip_solve_system (vals, b) and opmhip_get_result (x) are registered with the
                             * driver (hipHostRegister) the first time each address is seen, so that every later copy is a DMA at the link's
                             * rate instead of a staged copy out of pageable memory (500 MB of values at 10^6 cells: 13.5 ms -> the PCIe

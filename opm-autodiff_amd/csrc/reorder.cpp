@@ -234,7 +234,10 @@ void build_rest_schedule(Pattern& P, const std::vector<int>& order) {
     static const int maxBlocks = [] { const char* e = tuning_env("OPMHIP_REST_BLOCKS"); const int v = e ? std::atoi(e) : TILE_CAP_BLOCKS; return v < 8 ? 8 : (v > TILE_CAP_BLOCKS ? TILE_CAP_BLOCKS : v); }();
     std::vector<Rt> out;   // launch positions of both parts, padding = {0, 0}
     int nInt = 0;
-    for (int part = 0; part < 2; ++part) {
+    // Decomposed runs (ghost columns): the INTERIOR tiles take this form; the boundary tiles - rows with ghost columns at arbitrary offsets,
+    // which rarely fit a table of 15 - keep the whole product over the matrix itself (launch_spmv), so only part 0 is built
+    const int nparts = P.Nghost > 0 ? 1 : 2;
+    for (int part = 0; part < nparts; ++part) {
         const int p0 = part == 0 ? 0 : T.nschedInt, p1 = part == 0 ? T.nschedInt : T.nsched;
         std::vector<std::vector<Rt>> lists(8);
         for (int k = 0; k < 8; ++k) {
@@ -259,7 +262,7 @@ void build_rest_schedule(Pattern& P, const std::vector<int>& order) {
         if (part == 0) nInt = (int)out.size();
     }
     R.nsched = (int)out.size();
-    R.nschedInt = nInt;
+    R.nschedInt = P.Nghost > 0 ? R.nsched : nInt;
     R.sched.assign((size_t)4 * R.nsched, 0);
     R.word.assign(P.Nb, 0xFFFFFFFFu);
     R.koff.assign(P.Nb, 0);

@@ -2142,14 +2142,15 @@ static bool spmv_pipelined(const opmhip_ctx* c) {
     return c->pat.maxRowBlocks <= PGCH && w > 0 && c->pat.tiles.nsched > w && spmv_pipe_env() != 0;
 }
 // opmhip_config.half_product resolved: > 0 wherever the pattern allows it (Pattern::ualias, a line-coloured ordering, the rest's stencil
-// form - RestSched::on); 0, the library's choice: there, on one domain, where the system is large enough for the pipelined kernels (the
-// size the form was measured at); < 0 never.  Patterns with ghost columns: only when asked for.
+// form - RestSched::on); 0, the library's choice: there, where the system is large enough for the pipelined kernels (the size the form
+// was measured at); < 0 never.  Subdomains of a decomposed run: the interior tiles take the form, the boundary tiles (rows with ghost
+// columns) keep the whole product - each row's sum is one or the other, as the schedules say.
 bool half_product_wanted(const opmhip_ctx* c) {
     const Pattern& P = c->pat;
     if (!P.rest.on || c->cfg.half_product < 0 || use_cpr(c)) return false;   // (CPR: the product follows the two-level application, not a sweep)
     if (c->cfg.half_product > 0) return true;
     static const bool off = [] { const char* e = tuning_env("OPMHIP_HALF_PRODUCT"); return e && e[0] == '0'; }();   // A/B switch
-    return !off && P.Nghost == 0 && spmv_pipelined(c);
+    return !off && spmv_pipelined(c);
 }
 // the scalar products ride in the product's kernel unless wells modify y after it (then k_dots forms them afterwards)
 static bool spmv_dots_env() {   // OPMHIP_DOTS_SEPARATE=1 (tuning / A-B measurements): k_dots behind every product, as with wells
@@ -2259,12 +2260,19 @@ int launch_spmv(opmhip_ctx* c, double* x, double* y, int ndot, const double* w0,
     const Pattern& P = c->pat;
     const bool wells = c->wells.num_wells > 0;
     static const bool explicitIdx3 = [] { const char* e = tuning_env("OPMHIP_SPMV_EXPLICIT"); return e && e[0] == '1'; }();
-    const bool rides3 = uadd ? true : (spmv_pipelined(c) && P.tiles.stencilPart[0] && (P.tiles.nsched == P.tiles.nschedInt || P.tiles.stencilPart[1]) && !explicitIdx3);
+    const bool bndPlain = uadd && P.Nghost > 0 && P.tiles.nsched > P.tiles.nschedInt;   // half-product form in a subdomain: its boundary tiles run the whole product
+    const bool plain3 = spmv_pipelined(c) && !explicitIdx3;                              // the plain pipelined stencil kernel can carry three sums
+    const bool rides3 = uadd ? (!bndPlain || (plain3 && P.tiles.stencilPart[1]))
+                             : (plain3 && P.tiles.stencilPart[0] && (P.tiles.nsched == P.tiles.nschedInt || P.tiles.stencilPart[1]));
     const int fused = (spmv_dots_separate(c) || (ndot == 3 && !rides3)) ? 0 : ndot;
     const bool halo = exchange && c->comm.halo_set && c->comm.nneigh > 0;
     if (exchange && !halo && c->comm.nranks > 1) comm_halo_bystander(c);   // a subdomain that touches no other: nothing to exchange, but the peers' exchange counts this rank in (loopback)
-    const int nAll = uadd ? P.rest.nsched : P.tiles.nsched;
-    const int nInt = uadd ? P.rest.nschedInt : P.tiles.nschedInt, nBnd = nAll - nInt;
+    // (half-product form in a subdomain with ghost columns: the rest schedule holds the interior tiles only; the boundary tiles are the
+    //  whole product's, positions [nschedInt, nsched) of the matrix's own schedule)
+    const int nInt = uadd ? P.rest.nschedInt : P.tiles.nschedInt;
+    const int bnd0 = (uadd && !bndPlain) ? P.rest.nschedInt : P.tiles.nschedInt;
+    const int nBnd = (uadd && !bndPlain) ? P.rest.nsched - P.rest.nschedInt : P.tiles.nsched - P.tiles.nschedInt;
+    const double* uBnd = bndPlain ? nullptr : uadd;
     int rc, cnt = 0;
     if (halo && nBnd > 0) {
         // main: ev_x (x complete) -> interior tiles ........................ wait ev_h -> boundary tiles
@@ -2272,10 +2280,11 @@ int launch_spmv(opmhip_ctx* c, double* x, double* y, int ndot, const double* w0,
         if ((rc = comm_halo_begin(c, x))) return rc;     // records ev_x on the main stream; the exchange itself is behind it on the halo stream
         cnt += launch_spmv_part(c, 0, nInt, x, y, fused, w0, xs, cnt, PROF_SPMV, uadd, w1);
         if ((rc = comm_halo_end(c))) return rc;
-        cnt += launch_spmv_part(c, nInt, nBnd, x, y, fused, w0, xs, cnt, PROF_SPMV_BOUNDARY, uadd, w1);
+        cnt += launch_spmv_part(c, bnd0, nBnd, x, y, fused, w0, xs, cnt, PROF_SPMV_BOUNDARY, uBnd, w1);
     } else {
         if (halo && (rc = comm_halo_f64(c, x, BS))) return rc;
-        cnt += launch_spmv_part(c, 0, nAll, x, y, fused, w0, xs, cnt, PROF_SPMV, uadd, w1);
+        cnt += launch_spmv_part(c, 0, nInt, x, y, fused, w0, xs, cnt, PROF_SPMV, uadd, w1);
+        if (nBnd > 0) cnt += launch_spmv_part(c, bnd0, nBnd, x, y, fused, w0, xs, cnt, bndPlain ? PROF_SPMV_BOUNDARY : PROF_SPMV, uBnd, w1);
     }
     if (c->wells.num_ms > 0 && (rc = ms_wells_apply(c, x, y, xs))) return rc;   // in front of the standard wells, bda/WellContributions.cu:160-187
     if (wells && (rc = launch_wells_apply(c, x, y, xs))) return rc;

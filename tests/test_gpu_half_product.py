@@ -169,3 +169,63 @@ def test_cpr_ignores_the_form(pkg, orc):
     s = pkg.capi.HipSolver(reorder="line_coloring", half_product=1, preconditioner="cpr_quasiimpes")
     s.set_pattern(Nb, rp, ci)
     assert not s.product_form()["half_product"]
+
+
+@pytest.mark.parametrize("world,n,wgs", [(2, 20, 8), (4, 16, 8), (8, 8, 8), (2, 28, 0)])
+def test_subdomains_interior_tiles_take_the_form(pkg, orc, world, n, wgs):
+    """Decomposed runs (loopback communicator, the code path of the RCCL run): the interior tiles of a subdomain - no ghost column in any of
+    their rows - take the half-product form, the boundary tiles keep the whole product, the halo exchange runs beside the interior launch as
+    before.  Every row's sum is the plain form's up to the order of its additions: against the same decomposition with the form switched
+    off the preconditioned product agrees to rounding on every rank, M^-1 d is identical, the solves stop on the same half
+    iteration with the same solution (1e-8); the global oracle's block-Jacobi solve (natural order: other iterates) agrees to the tolerance"""
+    import uuid
+    import oracle_bind
+    from test_gpu_dd import global_and_parts, run_ranks
+    g, owner, parts = global_and_parts(pkg, n, world, state="mixed", heterogeneous=True)
+    src = pkg.decks.five_spot_source(g, rate_sm3_per_day=30.0)
+    o = oracle_bind.OracleModel(orc, g)
+    o.set_state(g["pv"], g["meaning"])
+    o.set_source(src)
+    dt = 86400.0
+    jo, ro = o.assemble(dt, 0)
+    xo, reso = orc.solve(g["Nb"], g["rowptr"], g["col"], jo, ro, tol=1e-4, maxit=200, w=0.9, owner=owner)
+    rng = np.random.default_rng(77)
+    dglob = rng.standard_normal(3 * g["Nb"])
+    out = {}
+    for hp in (1, -1):
+        group = "h" + uuid.uuid4().hex
+
+        def rank_fn(r, hp=hp, group=group):
+            c = parts[r]
+            m = pkg.capi.HipModel(c, comm=("loopback", world, r, group), reorder="line_coloring", chain_length=4, spmv_pipe_wgs=wgs, tolerance=1e-4, half_product=hp)
+            m.set_state(c["pv"], c["meaning"])
+            m.set_source(np.ascontiguousarray(src.reshape(-1, 3)[c["gids"]].reshape(-1)))
+            m.assemble(dt, 0, fetch=False)
+            form = m.product_form()
+            m.ilu0_factor(want_factors=False)
+            d = np.ascontiguousarray(dglob.reshape(-1, 3)[c["gids"][:c["Nb"]]].reshape(-1))
+            t, z = m.preconditioned_product(d)       # collective: the halo exchange of M^-1 d in front of the product
+            sol = m.solve_jacobian_system()
+            return form, t, z, sol.it, sol.converged, m.get_result()
+        out[hp] = run_ranks(world, rank_fn)
+    for r in range(world):
+        c = parts[r]
+        gi = c["gids"][:c["Nb"]]
+        (f1, t1, z1, it1, ok1, x1), (f0, t0, z0, it0, ok0, x0) = out[1][r], out[-1][r]
+        # a subdomain so small that every tile of 32 chains touches a cut has no interior tile: the form is then off, whatever was asked (8 x 8^3)
+        assert f1["u_is_upper_a"] and not f0["half_product"] and f1["half_product"] == (f1["rest_positions"] > 0)
+        if world == 2:
+            assert f1["half_product"], f1     # one cut: tiles away from it exist (with cuts in x AND y every tile of 32 chains of these small boxes meets one)
+        assert np.array_equal(z1, z0)                                    # the sweeps' statements are untouched
+        assert np.all(np.abs(t1 - t0) <= 1e-12 * np.abs(t0).max())       # the same products, another order of a row's additions
+        assert np.array_equal(t1, t0) == (not f1["half_product"])        # (interior rows DID take another order where the form is on)
+        assert ok1 and ok0 and it1 == it0
+        np.testing.assert_allclose(x1, x0, rtol=1e-8, atol=1e-11 * np.abs(x0).max())
+    # the ranks' solutions put together solve the GLOBAL system to the tolerance (the global oracle's own iterate - block-Jacobi ILU0 in the
+    # natural order - is another one of the same quality)
+    xg = np.zeros_like(xo)
+    for r in range(world):
+        c = parts[r]
+        xg.reshape(-1, 3)[c["gids"][:c["Nb"]]] = out[1][r][5].reshape(-1, 3)[:c["Nb"]]
+    rg = ro - orc.spmv(g["Nb"], g["rowptr"], g["col"], jo, xg)
+    assert np.linalg.norm(rg) <= 1e-4 * np.linalg.norm(ro) * (1 + 1e-6) and reso.converged

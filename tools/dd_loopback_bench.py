@@ -35,7 +35,7 @@ def body(r):
             rep = sim.next_newton_iteration()
             log.append((sim.timesteps_done, sim.iteration, rep.total_linear_iterations))
         el = time.perf_counter() - t0
-        out[r] = (el, log, sim.timesteps_done, sim.history, m.profile())
+        out[r] = (el, log, sim.timesteps_done, sim.history, m.profile(), m.product_form())
     except Exception as e:  # noqa: BLE001
         err[r] = e
         raise
@@ -46,7 +46,8 @@ ts = [threading.Thread(target=body, args=(r,)) for r in range(a.world)]
 [t.join() for t in ts]
 if any(e is not None for e in err):
     raise SystemExit("rank failures: %r" % err)
-el, log, done, hist, _ = out[0]
+el, log, done, hist, _, form = out[0]
+print("product form on rank 0:", form, "(half-product form: its interior tiles; the boundary tiles run the whole product)")
 print("world %d n %d %s: %d Newton iterations in %.2f s, %d time steps done, %d linear iterations" % (a.world, a.n, a.preconditioner, a.steps, el, done, sum(l[2] for l in log)))
 print("(step, newton, linear its):", log)
 print("time steps (days, newton its, accepted):", [(round(h[0] / bench.DAY, 3), h[1], h[2]) for h in hist])
