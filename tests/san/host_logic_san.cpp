@@ -227,8 +227,66 @@ static void check_pattern(const char* name, const Graph& g, int kind, int chain)
             }
         CHECK(std::count(ctSeen.begin(), ctSeen.end(), 0) == 0, "%s: chain-tiles without a launch position", name);
     }
-    std::printf("ok  %-34s Nb %7d ghosts %5d kind %d chain %2d -> kind in force %d, %d colours, %d tiles, stencil %d/%d\n", name, Nb, g.Nghost, kind, chain,
-                P.kindInForce, ncol, T.ntiles(), (int)T.stencil, (int)P.sweepStencil);
+    // the rest of a row (what the half-product form streams): the entries that are NOT U entries, in the row's own order
+    CHECK((int)P.rrowptr.size() == Nb + 1 && (int)P.rdest.size() == P.nnzb && P.nr == (int)P.rcol.size() && P.rrowptr[Nb] == P.nr, "%s: rest sizes", name);
+    CHECK(P.nr + P.nu == P.nnzb, "%s: rest %d + U %d != %d blocks", name, P.nr, P.nu, P.nnzb);
+    for (int r = 0; r < Nb; ++r) {
+        int q = P.rrowptr[r];
+        for (int k = P.rowptr[r]; k < P.rowptr[r + 1]; ++k) {
+            if (P.fdest[k] <= -2) { CHECK(P.rdest[k] == -1, "%s: U entry %d has a rest place", name, k); continue; }
+            CHECK(P.rdest[k] == q && q < P.rrowptr[r + 1] && P.rcol[q] == P.col[k], "%s: rest place of entry %d", name, k);
+            ++q;
+        }
+        CHECK(q == P.rrowptr[r + 1], "%s: rest row %d has %d entries too many", name, r, P.rrowptr[r + 1] - q);
+    }
+    // U == upper(A): restated from the definition (an elimination step i <- i - L_ij U_j. touches a U entry of row i iff rows i and j share a column beyond i)
+    {
+        bool alias = true;
+        std::vector<int> mark(P.Nloc > 0 ? P.Nloc : Nb, -1);
+        for (int i = 0; i < Nb && alias; ++i) {
+            for (int k = P.rowptr[i]; k < P.rowptr[i + 1]; ++k) if (P.col[k] < Nb && P.col[k] > i) mark[P.col[k]] = i;
+            for (int k = P.rowptr[i]; k < P.rowptr[i + 1] && alias; ++k) {
+                const int j = P.col[k];
+                if (j >= i || j >= Nb) continue;
+                for (int q = P.rowptr[j]; q < P.rowptr[j + 1]; ++q)
+                    if (P.col[q] < Nb && P.col[q] > i && mark[P.col[q]] == i) { alias = false; break; }
+            }
+        }
+        CHECK(alias == P.ualias, "%s: ualias %d, the definition says %d", name, (int)P.ualias, (int)alias);
+    }
+    // the rest product's schedule: rows once each over the part it covers, tables reproduce the columns
+    const RestSched& R = P.rest;
+    if (R.on) {
+        CHECK(P.ualias && P.chained, "%s: rest schedule without its premises", name);
+        CHECK((int)R.sched.size() == 4 * R.nsched && (int)R.table.size() >= 16 * R.nsched && (int)R.word.size() == Nb && (int)R.koff.size() == Nb, "%s: rest schedule sizes", name);
+        CHECK(R.nschedInt >= 0 && R.nschedInt <= R.nsched && R.nsched % 8 == 0, "%s: rest schedule positions %d / %d", name, R.nschedInt, R.nsched);
+        std::vector<char> seen(Nb, 0);
+        for (int p = 0; p < R.nsched; ++p) {
+            const int r0 = R.sched[4 * p], r1 = R.sched[4 * p + 1];
+            if (r1 <= r0) continue;
+            CHECK(r0 >= 0 && r1 <= Nb && r1 - r0 <= 64 && R.sched[4 * p + 2] == P.rrowptr[r0] && R.sched[4 * p + 3] == P.rrowptr[r1] && P.rrowptr[r1] - P.rrowptr[r0] <= TILE_CAP_BLOCKS,
+                  "%s: rest position %d", name, p);
+            for (int r = r0; r < r1; ++r) {
+                CHECK(!seen[r], "%s: row %d in two rest positions", name, r);
+                seen[r] = 1;
+                const int len = P.rrowptr[r + 1] - P.rrowptr[r];
+                CHECK(len <= 8 && (int)R.koff[r] == P.rrowptr[r] - P.rrowptr[r0], "%s: rest row %d: %d entries, first at %d", name, r, len, (int)R.koff[r]);
+                for (int u = 0; u < 8; ++u) {
+                    const unsigned idx = (R.word[r] >> (4 * u)) & 0xFu;
+                    if (u >= len) { CHECK(idx == 15u, "%s: rest row %d slot %d not empty", name, r, u); continue; }
+                    CHECK(idx < 15u && r + R.table[(size_t)16 * p + idx] == P.rcol[P.rrowptr[r] + u], "%s: rest row %d slot %d column", name, r, u);
+                }
+                if (g.Nghost > 0)
+                    for (int k = P.rowptr[r]; k < P.rowptr[r + 1]; ++k) CHECK(P.col[k] < Nb, "%s: rest position %d (interior) reads ghost column %d", name, p, P.col[k]);
+            }
+        }
+        // without ghosts every row is covered; with ghosts exactly the rows of the product's interior positions
+        int want = 0;
+        for (int p = 0; p < (g.Nghost > 0 ? T.nschedInt : T.nsched); ++p) want += std::max(0, T.spmvSched[4 * p + 1] - T.spmvSched[4 * p]);
+        CHECK((int)std::count(seen.begin(), seen.end(), 1) == want, "%s: rest schedule covers %d rows of %d", name, (int)std::count(seen.begin(), seen.end(), 1), want);
+    }
+    std::printf("ok  %-34s Nb %7d ghosts %5d kind %d chain %2d -> kind in force %d, %d colours, %d tiles, stencil %d/%d, U==upper(A) %d, rest %d positions\n", name, Nb, g.Nghost,
+                kind, chain, P.kindInForce, ncol, T.ntiles(), (int)T.stencil, (int)P.sweepStencil, (int)P.ualias, R.on ? R.nsched : 0);
 }
 
 static void check_refusals() {
