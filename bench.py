@@ -545,7 +545,8 @@ def main():
             prof["spmv"] = (prof["spmv"][0], prof["spmv"][1] + prof["spmv_boundary"][1])
             boundary_share = round(prof["spmv_boundary"][1] / prof["spmv"][1], 4)
         prof.pop("spmv_boundary", None)
-        Bm = dict(B)
+        pf = model.product_form()   # this window's model: a CPR context keeps the whole product, whatever the headline context took
+        Bm = dict(alg_bytes(Nb, nnzb, pf["rest_blocks"] if pf["half_product"] else 0))
         if use_cpr_of(model):
             lv = model.cpr_levels()
             Bm["cpr_amg"] = cpr_amg_bytes(Nb, [int(v) for v in lv[0]], [int(v) for v in lv[1]], model.ordering_info()["cpr_amg_ilu_levels"])

@@ -336,7 +336,8 @@ int opmhip_get_ordering(opmhip_ctx* ctx, int* toOrder, int* fromOrder, int* rows
 int opmhip_get_ordering_info(opmhip_ctx* ctx, int info[4]);
 /* what opmhip_config.half_product resolved to at set_pattern: info[0] 1 if ILU0-BiCGStab forms the product after M^-1 from the backward
  * sweep's row sums, else 0; info[1] 1 if the pattern has the property it rests on (no elimination step touches an entry right of the
- * diagonal: U == upper(A)); info[2] blocks of the matrix beside its U part (what that product streams); info[3] launch positions of that
+ * diagonal: U == upper(A)); info[2] the blocks that product streams: the matrix beside its U part (a subdomain with ghost columns: its interior tiles' rows beside
+ * their U part plus its boundary tiles' whole rows); info[3] launch positions of that
  * product.  ABI 10 */
 int opmhip_get_product_form(opmhip_ctx* ctx, int info[4]);
 /* Device-timed repetitions of one kernel on the uploaded system, for bench.py's roofline object:

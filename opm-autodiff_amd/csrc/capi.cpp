@@ -695,6 +695,12 @@ int opmhip_get_product_form(opmhip_ctx* c, int info[4]) {
     info[0] = (c->half_product && !use_cpr(c)) ? 1 : 0;
     info[1] = P.ualias ? 1 : 0;
     info[2] = P.nr;
+    if (P.Nghost > 0 && P.rest.on) {   // a subdomain: the interior tiles stream their rows without the U part, the boundary tiles whole rows
+        long long blocks = 0;
+        for (int b = 0; b < P.rest.nsched; ++b) blocks += P.rest.sched[4 * b + 3] - P.rest.sched[4 * b + 2];
+        for (int p = P.tiles.nschedInt; p < P.tiles.nsched; ++p) blocks += P.tiles.spmvSched[4 * p + 3] - P.tiles.spmvSched[4 * p + 2];
+        info[2] = (int)blocks;
+    }
     info[3] = P.rest.on ? P.rest.nsched : 0;
     return OPMHIP_SUCCESS;
 }

@@ -216,6 +216,10 @@ def test_subdomains_interior_tiles_take_the_form(pkg, orc, world, n, wgs):
         assert f1["u_is_upper_a"] and not f0["half_product"] and f1["half_product"] == (f1["rest_positions"] > 0)
         if world == 2:
             assert f1["half_product"], f1     # one cut: tiles away from it exist (with cuts in x AND y every tile of 32 chains of these small boxes meets one)
+        if f1["half_product"]:
+            # what the product streams: interior rows without their U part, boundary rows whole - between the rest of every row and the whole matrix
+            nloc, rest_all = len(c["col"]), sum(1 for i in range(c["Nb"]) for k in range(c["rowptr"][i], c["rowptr"][i + 1]) if c["col"][k] >= c["Nb"])
+            assert (nloc - rest_all + c["Nb"]) // 2 + rest_all < f1["rest_blocks"] < nloc
         assert np.array_equal(z1, z0)                                    # the sweeps' statements are untouched
         assert np.all(np.abs(t1 - t0) <= 1e-12 * np.abs(t0).max())       # the same products, another order of a row's additions
         assert np.array_equal(t1, t0) == (not f1["half_product"])        # (interior rows DID take another order where the form is on)
