@@ -20,7 +20,8 @@
 extern "C" {
 #endif
 
-#define OPMHIP_ABI_VERSION 10 /* 10: opmhip_config gained half_product (the product after an ILU0 application from the sweep's row sums), pin_host_arrays,
+#define OPMHIP_ABI_VERSION 11 /* 11: opmhip_get_iq_cells, opmhip_set_source_cells (the well model's traffic is its perforated cells, not the grid);
+                               * 10: opmhip_config gained half_product (the product after an ILU0 application from the sweep's row sums), pin_host_arrays,
                                *     fused_reductions; opmhip_get_product_form, opmhip_preconditioned_product;
                                * 9: opmhip_wells gained `distributed` (standard wells whose perforations lie in several subdomains of a decomposed run);
                                * 8: opmhip_default_config: reorder = OPMHIP_REORDER_AUTO, cpr_amg_ilu_levels = -1 (the measured configuration);
@@ -591,6 +592,11 @@ int opmhip_set_drift_compensation(opmhip_ctx* ctx, int enable, double max_compen
  * [m^3/s] (what BlackoilWellModel::computeTotalRatesForDof adds up, wells/BlackoilWellModel_impl.hpp:496-512) and
  * its 3x3 derivative w.r.t. the cell's primary variables.  Either may be NULL (= zero). */
 int opmhip_set_source(opmhip_ctx* ctx, const double* source, const double* dsource);
+/* The same for a well model: the rates of `n` perforated cells (natural local ids; a cell named twice receives the sum), every other
+ * cell's source and derivative zero.  source[n*3], dsource[n*9] (nullable = zero).  What crosses PCIe is 100 bytes per perforation
+ * instead of 96 bytes per cell of the grid (computeTotalRatesForDof visits the perforations, wells/BlackoilWellModel_impl.hpp:496-512).
+ * n == 0: no sources at all.  ABI 11 */
+int opmhip_set_source_cells(opmhip_ctx* ctx, int n, const int* cells, const double* source, const double* dsource);
 
 /* replaces: model().linearizer().linearizeDomain() (flow/BlackoilModelEbos.hpp:424), then .jacobian() /
  * .residual() (:339-340, :526-527).  iteration == 0 also (re)fills the cached old-time-level storage term
@@ -605,6 +611,10 @@ int opmhip_assemble(opmhip_ctx* ctx, double dt, int iteration, double* jac, doub
  * (opmhip_iq_fields tells which). */
 int opmhip_iq_fields(opmhip_ctx* ctx);
 int opmhip_get_iq(opmhip_ctx* ctx, double* out);
+/* the records of `n` cells (natural local ids, any order, repeats allowed), out[n * fields * 4]: what a well model reads per Newton
+ * iteration - BlackoilWellModel::updatePerforationIntensiveQuantities evaluates the perforated cells only
+ * (wells/BlackoilWellModel_impl.hpp:1606-1630) - gathered on the device, so that the copy is 544 bytes per perforation.  ABI 11 */
+int opmhip_get_iq_cells(opmhip_ctx* ctx, int n, const int* cells, double* out);
 
 /* replaces: BlackoilModelEbos::localConvergenceData + computeCnvErrorPv + the CNV/MB formulas of
  * getReservoirConvergence (flow/BlackoilModelEbos.hpp:628-904).  out[17]: R_sum[3], maxCoeff[3], B_avg[3], pvSum,

@@ -412,6 +412,8 @@ def _bind_assembly(L):
     L.opmhip_set_source.argtypes = [vp, vp, vp]
     L.opmhip_assemble.argtypes = [vp, C.c_double, C.c_int, vp, vp]
     L.opmhip_get_iq.argtypes = [vp, vp]
+    L.opmhip_get_iq_cells.argtypes = [vp, C.c_int, vp, vp]
+    L.opmhip_set_source_cells.argtypes = [vp, C.c_int, vp, vp, vp]
     L.opmhip_convergence.argtypes = [vp, C.c_double, C.c_double, vp]
     L.opmhip_update.argtypes = [vp, vp, C.c_double, C.POINTER(C.c_int)]
     L.opmhip_set_pattern_dd.argtypes = [vp, C.c_int, C.c_int, C.c_int, vp, vp]
@@ -691,6 +693,11 @@ class HipModel(HipSolver):
         s, d = _f64(source), _f64(dsource)
         self._check(lib().opmhip_set_source(self._h, _ptr(s), _ptr(d)))
 
+    def set_source_cells(self, cells, source, dsource=None):
+        """the source terms of the cells named (a well model's connection rates), zero everywhere else: opmhip_set_source_cells"""
+        cl, s, d = _i32(cells), _f64(source), _f64(dsource)
+        self._check(lib().opmhip_set_source_cells(self._h, len(cl), _ptr(cl), _ptr(s), _ptr(d)))
+
     def assemble(self, dt, iteration, fetch=True):
         """linearizeDomain(); with fetch the Jacobian values and residual are copied back (natural order)."""
         jac = np.empty(9 * self.nnzb) if fetch else None
@@ -703,6 +710,14 @@ class HipModel(HipSolver):
         out = np.empty(self.Nloc * nf * 4)
         self._check(lib().opmhip_get_iq(self._h, _ptr(out)))
         return out.reshape(self.Nloc, nf, 4)
+
+    def iq_cells(self, cells):
+        """the records of the cells named (a well model's perforated cells), gathered on the device: opmhip_get_iq_cells"""
+        cl = _i32(cells)
+        nf = self._check(lib().opmhip_iq_fields(self._h))
+        out = np.empty(len(cl) * nf * 4)
+        self._check(lib().opmhip_get_iq_cells(self._h, len(cl), _ptr(cl), _ptr(out)))
+        return out.reshape(len(cl), nf, 4)
 
     def convergence(self, dt, tol_cnv=1e-2):
         out = np.empty(17)

@@ -1438,6 +1438,22 @@ __global__ void k_iq_to_natural(int Nb, int IQS, const int* __restrict__ toOrder
     const int i = (int)(e / IQS), q = (int)(e % IQS);
     nat[e] = internal[((size_t)(q >> 2) * Nb + toOrder[i]) * 4 + (q & 3)];   // field-major cache -> per-cell records
 }
+// records of n named cells out of the field-major cache (opmhip_get_iq_cells)
+__global__ void k_iq_gather(int n, int IQS, int Nb, const int* __restrict__ pos, const double* __restrict__ internal, double* __restrict__ out) {
+    const size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= (size_t)n * IQS) return;
+    const int i = (int)(e / IQS), q = (int)(e % IQS);
+    out[e] = internal[((size_t)(q >> 2) * Nb + pos[i]) * 4 + (q & 3)];
+}
+// source terms of n DISTINCT cells into the (zeroed) per-cell arrays (opmhip_set_source_cells)
+__global__ void k_source_scatter(int n, const int* __restrict__ pos, const double* __restrict__ src, const double* __restrict__ dsrc,
+                                 double* __restrict__ source, double* __restrict__ dsource) {
+    const int e = blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= n * 12) return;
+    const int i = e / 12, q = e % 12;
+    if (q < 3) source[(size_t)pos[i] * 3 + q] = src[(size_t)i * 3 + q];
+    else if (dsrc) dsource[(size_t)pos[i] * 9 + (q - 3)] = dsrc[(size_t)i * 9 + (q - 3)];
+}
 __global__ void k_unpermute_blocks(int nnzb, const int* __restrict__ nnzMap, const double* __restrict__ internal, double* __restrict__ nat) {
     const size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (e >= (size_t)nnzb * BB) return;
@@ -1632,6 +1648,13 @@ void launch_u8_to_natural(opmhip_ctx* c, const unsigned char* internal, unsigned
 void launch_iq_to_natural(opmhip_ctx* c, double* d_nat) {
     const size_t n = (size_t)c->pat.Nloc * iq_doubles_per_cell(c);
     hipLaunchKernelGGL(k_iq_to_natural, dim3(cdiv(n, 256)), dim3(256), 0, c->stream, c->pat.Nloc, iq_doubles_per_cell(c), c->pat.d_toOrder, c->asmb.d_iq, d_nat);
+}
+void launch_iq_gather(opmhip_ctx* c, int n, const int* d_pos, double* d_out) {
+    const int IQS = iq_doubles_per_cell(c);
+    hipLaunchKernelGGL(k_iq_gather, dim3(cdiv((size_t)n * IQS, 256)), dim3(256), 0, c->stream, n, IQS, c->pat.Nloc, d_pos, c->asmb.d_iq, d_out);
+}
+void launch_source_scatter(opmhip_ctx* c, int n, const int* d_pos, const double* d_src, const double* d_dsrc) {
+    hipLaunchKernelGGL(k_source_scatter, dim3(cdiv((size_t)n * 12, 256)), dim3(256), 0, c->stream, n, d_pos, d_src, d_dsrc, c->asmb.d_source, c->asmb.d_dsource);
 }
 void launch_unpermute_blocks(opmhip_ctx* c, const double* internal, double* nat) {
     const size_t n = (size_t)c->pat.nnzb * BB;

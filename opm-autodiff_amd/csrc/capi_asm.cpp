@@ -4,6 +4,8 @@
 #include <algorithm>
 #include <cmath>
 #include <cstring>
+#include <map>
+#include <vector>
 
 #include "fluid_tables.hpp"
 #include "internal.hpp"
@@ -902,6 +904,71 @@ int opmhip_set_source(opmhip_ctx* c, const double* source, const double* dsource
     });
 }
 
+// internal positions of n named cells on the device (d_cell_pos, grown on demand); the host copy stays valid until the caller's synchronise
+static int stage_cell_positions(opmhip_ctx* c, const std::vector<int>& pos) {
+    AsmDev& A = c->asmb;
+    if (pos.size() > A.cell_pos_cap) {
+        OPMHIP_HIP(c, hipStreamSynchronize(c->stream));
+        dev_free(c, &A.d_cell_pos);
+        A.cell_pos_cap = 0;
+        const size_t cap = std::max<size_t>(256, 2 * pos.size());
+        int rc = dev_alloc(c, &A.d_cell_pos, cap);
+        if (rc) return rc;
+        A.cell_pos_cap = cap;
+    }
+    OPMHIP_HIP(c, hipMemcpyAsync(A.d_cell_pos, pos.data(), pos.size() * sizeof(int), hipMemcpyHostToDevice, c->stream));
+    return OPMHIP_SUCCESS;
+}
+
+int opmhip_set_source_cells(opmhip_ctx* c, int n, const int* cells, const double* source, const double* dsource) {
+    if (!c) return OPMHIP_INVALID_ARGUMENT;
+    return guarded(c, [&]() -> int {
+        if (!c->asmb.static_set) return fail(c, OPMHIP_NOT_READY, "set_source_cells before set_static");
+        if (n < 0 || (n > 0 && (!cells || !source))) return fail(c, OPMHIP_INVALID_ARGUMENT, "set_source_cells: n = %d, cells / source missing", n);
+        OPMHIP_HIP(c, hipSetDevice(c->device));
+        AsmDev& A = c->asmb;
+        const Pattern& P = c->pat;
+        // distinct cells, each with the sum of what was named for it (two wells may perforate one cell), in the order of first mention
+        std::vector<int> pos;
+        std::vector<double> val;    // [distinct][3] then [distinct][9]
+        std::vector<double> dval;
+        {
+            std::map<int, int> slot;
+            for (int i = 0; i < n; ++i) {
+                if (cells[i] < 0 || cells[i] >= P.Nloc) return fail(c, OPMHIP_INVALID_ARGUMENT, "set_source_cells: cell %d of %d", cells[i], P.Nloc);
+                auto it = slot.find(cells[i]);
+                int sidx;
+                if (it == slot.end()) {
+                    sidx = (int)pos.size();
+                    slot.emplace(cells[i], sidx);
+                    pos.push_back(P.toOrder[cells[i]]);
+                    val.insert(val.end(), 3, 0.0);
+                    dval.insert(dval.end(), 9, 0.0);
+                } else sidx = it->second;
+                for (int q = 0; q < 3; ++q) {
+                    if (!std::isfinite(source[(size_t)i * 3 + q])) return fail(c, OPMHIP_INVALID_ARGUMENT, "set_source_cells: source of cell %d is not finite", cells[i]);
+                    val[(size_t)sidx * 3 + q] += source[(size_t)i * 3 + q];
+                }
+                if (dsource)
+                    for (int q = 0; q < 9; ++q) dval[(size_t)sidx * 9 + q] += dsource[(size_t)i * 9 + q];
+            }
+        }
+        const size_t Nloc = P.Nloc, m = pos.size();
+        OPMHIP_HIP(c, hipMemsetAsync(A.d_source, 0, Nloc * 3 * sizeof(double), c->stream));   // behind whatever assembly still reads them: same stream
+        OPMHIP_HIP(c, hipMemsetAsync(A.d_dsource, 0, Nloc * 9 * sizeof(double), c->stream));
+        if (m == 0) return OPMHIP_SUCCESS;
+        int rc = stage_cell_positions(c, pos);
+        if (rc) return rc;
+        // values staged in d_stage_cell (Nloc * IQS doubles >= 12 per distinct cell)
+        OPMHIP_HIP(c, hipMemcpyAsync(A.d_stage_cell, val.data(), m * 3 * sizeof(double), hipMemcpyHostToDevice, c->stream));
+        OPMHIP_HIP(c, hipMemcpyAsync(A.d_stage_cell + m * 3, dval.data(), m * 9 * sizeof(double), hipMemcpyHostToDevice, c->stream));
+        launch_source_scatter(c, (int)m, A.d_cell_pos, A.d_stage_cell, A.d_stage_cell + m * 3);
+        OPMHIP_HIP(c, hipGetLastError());
+        OPMHIP_HIP(c, hipStreamSynchronize(c->stream));   // the host vectors above end here
+        return OPMHIP_SUCCESS;
+    });
+}
+
 int opmhip_assemble(opmhip_ctx* c, double dt, int iteration, double* jac, double* residual) {
     if (!c) return OPMHIP_INVALID_ARGUMENT;
     return guarded(c, [&]() -> int {
@@ -941,6 +1008,30 @@ int opmhip_get_iq(opmhip_ctx* c, double* out) {
         OPMHIP_HIP(c, hipSetDevice(c->device));
         launch_iq_to_natural(c, c->asmb.d_stage_cell);
         OPMHIP_HIP(c, hipMemcpyAsync(out, c->asmb.d_stage_cell, (size_t)c->pat.Nloc * iq_doubles_per_cell(c) * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+        OPMHIP_HIP(c, hipStreamSynchronize(c->stream));
+        return OPMHIP_SUCCESS;
+    });
+}
+
+int opmhip_get_iq_cells(opmhip_ctx* c, int n, const int* cells, double* out) {
+    if (!c) return OPMHIP_INVALID_ARGUMENT;
+    return guarded(c, [&]() -> int {
+        if (!c->asmb.state_set) return fail(c, OPMHIP_NOT_READY, "get_iq_cells before set_state");
+        if (n < 0 || (n > 0 && (!cells || !out))) return fail(c, OPMHIP_INVALID_ARGUMENT, "get_iq_cells: n = %d, cells / out missing", n);
+        if (n == 0) return OPMHIP_SUCCESS;
+        const Pattern& P = c->pat;
+        if (n > P.Nloc) return fail(c, OPMHIP_INVALID_ARGUMENT, "get_iq_cells: %d cells asked for, the grid has %d (opmhip_get_iq copies them all)", n, P.Nloc);
+        std::vector<int> pos(n);
+        for (int i = 0; i < n; ++i) {
+            if (cells[i] < 0 || cells[i] >= P.Nloc) return fail(c, OPMHIP_INVALID_ARGUMENT, "get_iq_cells: cell %d of %d", cells[i], P.Nloc);
+            pos[i] = P.toOrder[cells[i]];
+        }
+        OPMHIP_HIP(c, hipSetDevice(c->device));
+        int rc = stage_cell_positions(c, pos);
+        if (rc) return rc;
+        launch_iq_gather(c, n, c->asmb.d_cell_pos, c->asmb.d_stage_cell);
+        OPMHIP_HIP(c, hipGetLastError());
+        OPMHIP_HIP(c, hipMemcpyAsync(out, c->asmb.d_stage_cell, (size_t)n * iq_doubles_per_cell(c) * sizeof(double), hipMemcpyDeviceToHost, c->stream));
         OPMHIP_HIP(c, hipStreamSynchronize(c->stream));
         return OPMHIP_SUCCESS;
     });

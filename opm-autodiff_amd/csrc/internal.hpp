@@ -213,6 +213,8 @@ struct AsmDev {
     int ntiles = 0, nsched = 0;
     double *d_conv_part = nullptr, *d_conv_out = nullptr;
     double* d_stage_cell = nullptr;   // staging for per-cell doubles (natural order), Nb * max(9, IQS)
+    int* d_cell_pos = nullptr;        // opmhip_get_iq_cells / opmhip_set_source_cells: internal positions of the cells named, grown on demand
+    size_t cell_pos_cap = 0;
     double* d_stage_entry = nullptr;  // staging for per-entry doubles (natural order), nnzb
 };
 
@@ -610,6 +612,8 @@ int launch_convergence(opmhip_ctx* c, double dt, double tol_cnv);
 void launch_u8_to_internal(opmhip_ctx* c, const unsigned char* nat, unsigned char* internal);
 void launch_u8_to_natural(opmhip_ctx* c, const unsigned char* internal, unsigned char* nat);
 void launch_iq_to_natural(opmhip_ctx* c, double* d_nat);
+void launch_iq_gather(opmhip_ctx* c, int n, const int* d_pos, double* d_out);                                    // records of n cells (internal positions)
+void launch_source_scatter(opmhip_ctx* c, int n, const int* d_pos, const double* d_src, const double* d_dsrc);   // d_dsrc nullable
 int iq_doubles_per_cell(const opmhip_ctx* c);
 int asm_max_rows();
 int launch_fluid_probe(opmhip_ctx* c, int pr, int sr, int n, const double* d_in, double* d_out);

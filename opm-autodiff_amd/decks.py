@@ -69,7 +69,8 @@ def cartesian_case(nx, ny, nz, dx=20.0, dy=20.0, dz=5.0, top=2500.0, poro=0.25, 
     trans = _grid.tpfa_transmissibility(pat, c["perm"], c["perm"], c["perm"], dx, dy, dz)
     return dict(Nb=c["Nb"], nx=nx, ny=ny, nz=nz, rowptr=pat["rowptr"], col=pat["col"], face_dir=pat["face_dir"],
                 trans=np.ascontiguousarray(trans), area=np.ascontiguousarray(area), poro=c["poro"],
-                volume=np.ascontiguousarray(c["volume"]), depth=c["depth"], fluid=c["fluid"], pv=c["pv"], meaning=c["meaning"])
+                volume=np.ascontiguousarray(c["volume"]), depth=c["depth"], fluid=c["fluid"], pv=c["pv"], meaning=c["meaning"],
+                perm=c["perm"], dx=dx, dy=dy, dz=dz)
 
 
 def spe1_case(props=None, state="equil"):
@@ -161,6 +162,39 @@ def spe1_wells(case):
         else:
             comp = {"gas": _wells.GAS, "water": _wells.WATER, "oil": _wells.OIL}[w["injected"]]
             out.append(_wells.Well(w["name"], cells, tw, w["ref_depth"], False, ("rate", comp, w["surface_rate"]), w["bhp_limit"], inj_phase=w["injected"]))
+    return _wells.StandardWells(out, case["depth"])
+
+
+STB_PER_DAY = 0.158987294928 / 86400.0
+PSIA = 6894.757293168361
+# (i, j), one-based, of SPE9's 25 producers in the order of the public deck's COMPDAT (the deck is not in the reference tree: a stand-in
+# that completes its wells where the comparative-solution project does)
+SPE9_PRODUCERS_IJ = [(5, 1), (8, 2), (11, 3), (10, 4), (12, 5), (4, 6), (8, 7), (14, 8), (11, 9), (12, 10), (10, 11), (5, 12), (8, 13),
+                     (11, 14), (13, 15), (15, 16), (11, 17), (12, 18), (5, 19), (8, 20), (11, 21), (15, 22), (12, 23), (10, 24), (17, 25)]
+
+
+def spe9_shaped_wells(case, oil_rate_stb_day=1500.0, water_rate_stb_day=5000.0, producer_bhp_limit=1000.0 * PSIA, injector_bhp_limit=400e5,
+                      diameter=0.1524):
+    """BASELINE.json configs[2] with wells that are wells (wells.StandardWells) on a 24 x 25 x 15 cartesian_case: SPE9's water injector at
+    (24, 25), completed in layers 11-15, on a surface-rate target with an upper BHP limit, and its 25 oil producers, completed in layers
+    2-4, on an oil-rate target (1500 stb/day; the SPE9 schedule cuts it to 100 stb/day for a while) with a lower BHP limit of 1000 psia;
+    reference depth = the centre of the topmost completion; connection factors by Peaceman's formula from the cell's own permeability,
+    so that on the log-normal field some producers cannot hold their target and fall to the BHP limit.  A stand-in like the grid itself:
+    the SPE9 deck is not in the reference tree, its fluid and its dipping layers are not reproduced."""
+    from . import wells as _wells
+    nx, ny, nz = case["nx"], case["ny"], case["nz"]
+    if (nx, ny) != (24, 25) or nz < 15:
+        raise ValueError("spe9_shaped_wells: a 24 x 25 x 15 grid is expected")
+    def column(i, j, k0, k1):
+        cells = [(i - 1) + nx * ((j - 1) + ny * k) for k in range(k0 - 1, k1)]
+        tw = [_wells.peaceman_factor(case["perm"][c], case["dx"], case["dy"], case["dz"], diameter) for c in cells]
+        return cells, tw
+    cells, tw = column(24, 25, 11, 15)
+    out = [_wells.Well("INJE1", cells, tw, case["depth"][cells[0]], False, ("rate", _wells.WATER, water_rate_stb_day * STB_PER_DAY), injector_bhp_limit,
+                       inj_phase="water")]
+    for n, (i, j) in enumerate(SPE9_PRODUCERS_IJ):
+        cells, tw = column(i, j, 2, 4)
+        out.append(_wells.Well("PRODU%d" % (n + 2), cells, tw, case["depth"][cells[0]], True, ("rate", _wells.OIL, oil_rate_stb_day * STB_PER_DAY), producer_bhp_limit))
     return _wells.StandardWells(out, case["depth"])
 
 

@@ -120,12 +120,19 @@ class BlackoilModelHip:
         if self.wells is not None:
             # wellModel().beginIteration / assemble (wells/BlackoilWellModel_impl.hpp:148-171, 1033-1101): controls, well equations at the
             # present reservoir state, their connection rates as the perforated cells' source terms (computeTotalRatesForDof :496-512)
-            iq = self.m.iq()
+            # (only the perforated cells' records come back from the device and only their rates go there: updatePerforationIntensiveQuantities
+            #  :1606-1630 - opmhip_get_iq_cells / opmhip_set_source_cells; a model without the two calls is asked for / handed whole arrays)
+            iq = self.wells.records(self.m)
             if iteration == 0:
+                self.wells.calculate_explicit_quantities(iq)  # the completions' pressure differences, constant through the time step (:824-827)
                 self.wells.solve_well_equations(iq)          # prepareTimeStep: the wells alone against the frozen reservoir
             self.wells.update_well_controls()
-            wa = self.wells.assemble(iq, iq.shape[0])
-            self.m.set_source(wa["source"], wa["dsource"])
+            if hasattr(self.m, "set_source_cells"):
+                wa = self.wells.assemble(iq)
+                self.m.set_source_cells(wa["cells"], wa["source_cells"], wa["dsource_cells"])
+            else:
+                wa = self.wells.assemble(iq, iq.shape[0])
+                self.m.set_source(wa["source"], wa["dsource"])
         self.m.assemble(dt, iteration, fetch=False)          # assembleReservoir -> linearizeDomain (asynchronous)
         conv, norms = self.get_convergence(dt, iteration)    # synchronises: reads the reduced scalars back
         if wa is not None:

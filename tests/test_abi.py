@@ -11,7 +11,7 @@ def test_library_exports_every_declared_symbol(pkg):
     assert len(names) >= 12
     missing = [n for n in names if not hasattr(L, n)]
     assert not missing, missing
-    assert L.opmhip_abi_version() == 10
+    assert L.opmhip_abi_version() == 11
 
 
 def test_default_config_matches_flow_defaults(pkg):

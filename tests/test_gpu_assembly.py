@@ -524,3 +524,63 @@ def test_faulted_corner_point_grid_through_the_hot_path(pkg, orc, reorder):
     xo, ro_ = o.solve_in_order(*m.ordering()[:2])
     assert res.converged and ro_.converged and res.it == ro_.it
     np.testing.assert_allclose(m.get_result(), xo, rtol=1e-9, atol=1e-12 * np.abs(xo).max())
+
+
+@pytest.mark.parametrize("reorder", ["level_scheduling", "line_coloring"])
+def test_well_model_traffic_is_per_cell(pkg, orc, reorder):
+    """opmhip_get_iq_cells / opmhip_set_source_cells (what a well model moves per Newton iteration: its perforated cells' records in, their
+    rates out - updatePerforationIntensiveQuantities and computeTotalRatesForDof visit the perforations, wells/BlackoilWellModel_impl.hpp:
+    1606-1630, 496-512) against the whole-grid forms opmhip_get_iq / opmhip_set_source: the same records bit for bit, in the order asked for,
+    repeats included; the same Jacobian and residual bit for bit, a cell named twice receiving the sum; n = 0 clears every source; the error
+    returns"""
+    case = pkg.decks.cartesian_case(12, 9, 7, state="mixed", heterogeneous=True)
+    m, o = both(pkg, orc, case, reorder=reorder)
+    Nb = case["Nb"]
+    rng = np.random.default_rng(31)
+    full = m.iq()
+    cells = rng.choice(Nb, 40, replace=False).astype(np.int32)
+    cells = np.concatenate([cells, cells[:5], [0, Nb - 1]]).astype(np.int32)           # repeats, both ends of the grid
+    got = m.iq_cells(cells)
+    assert got.shape == (len(cells),) + full.shape[1:] and np.array_equal(got, full[cells])
+    assert m.iq_cells(np.zeros(0, np.int32)).shape[0] == 0
+    # sources: 30 distinct cells, five of them named a second time
+    c1 = rng.choice(Nb, 30, replace=False).astype(np.int32)
+    named = np.concatenate([c1, c1[:5]]).astype(np.int32)
+    src = rng.uniform(-1e-3, 1e-3, (len(named), 3))
+    dsrc = rng.uniform(-1e-9, 1e-9, (len(named), 3, 3))
+    dense, ddense = np.zeros((Nb, 3)), np.zeros((Nb, 3, 3))
+    np.add.at(dense, named, src)
+    np.add.at(ddense, named, dsrc)
+    dt = 86400.0
+    m.set_source(dense.reshape(-1), ddense.reshape(-1))
+    j0, r0 = m.assemble(dt, 0)
+    o.set_source(dense.reshape(-1), ddense.reshape(-1))
+    jo, ro = o.assemble(dt, 0)
+    assert np.array_equal(j0, jo) and np.array_equal(r0, ro)
+    m.set_source(None, None)
+    m.set_source_cells(named, src.reshape(-1), dsrc.reshape(-1))
+    j1, r1 = m.assemble(dt, 0)
+    assert np.array_equal(j1, j0) and np.array_equal(r1, r0)
+    m.set_source_cells(c1[:3], src[:3].reshape(-1))                                      # no derivative handed in: zero; the other 27 cells cleared
+    j2, r2 = m.assemble(dt, 0)
+    d3, z = np.zeros((Nb, 3)), np.zeros((Nb, 3, 3))
+    d3[c1[:3]] = src[:3]
+    o.set_source(d3.reshape(-1), z.reshape(-1))
+    jo2, ro2 = o.assemble(dt, 0)
+    assert np.array_equal(j2, jo2) and np.array_equal(r2, ro2) and not np.array_equal(r2, r0)
+    m.set_source_cells(np.zeros(0, np.int32), np.zeros(0))                               # n = 0: no sources at all
+    j3, r3 = m.assemble(dt, 0)
+    o.set_source(np.zeros(3 * Nb), z.reshape(-1))
+    jo3, ro3 = o.assemble(dt, 0)
+    assert np.array_equal(j3, jo3) and np.array_equal(r3, ro3)
+    for bad in ([Nb], [-1]):
+        with pytest.raises(pkg.capi.OpmHipError) as e:
+            m.iq_cells(np.array(bad, np.int32))
+        assert e.value.code == pkg.capi.INVALID_ARGUMENT
+        with pytest.raises(pkg.capi.OpmHipError) as e:
+            m.set_source_cells(np.array(bad, np.int32), np.zeros(3))
+        assert e.value.code == pkg.capi.INVALID_ARGUMENT
+    with pytest.raises(pkg.capi.OpmHipError):
+        m.set_source_cells(c1[:1], np.array([np.nan, 0.0, 0.0]))
+    j4, r4 = m.assemble(dt, 0)                                                           # a refused call left the sources as they were
+    assert np.array_equal(j4, j3) and np.array_equal(r4, r3)

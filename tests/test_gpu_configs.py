@@ -1,7 +1,8 @@
 """BASELINE.json's remaining parity configurations on the GPU (SURVEY.md §8d recipes; synthetic stand-ins, the decks
 themselves are not in the reference tree):
   configs[2] "SPE9 (9000-cell, 25 wells, heterogeneous perm) - well-coupling + ILU0 correctness vs CPU":
-             24 x 25 x 15 heterogeneous grid, 26 standard wells (B, C, D^-1 blocks) in the operator;
+             24 x 25 x 15 heterogeneous grid, 26 standard wells (B, C, D^-1 blocks) in the operator - synthetic blocks in the single iterations,
+             the well model itself (wells.StandardWells: SPE9's completions, rate targets, BHP limits, a schedule event) over three report steps;
   configs[4] "Norne (faulted corner-point grid, ~44k active cells) - irregular connectivity stress test":
              44 431 rows with 4..12 blocks per row and 2 % long-range NNC couplings, rng(7) (linear algebra and assembly on a
              random graph), and a Norne-SHAPED corner-point grid - 46 x 112 x 22, dome, sheared pillars, three faults, a pinched
@@ -417,6 +418,58 @@ def test_spe1case1_report_steps(pkg, orc):
     pd = pd.reshape(-1, 3)
     assert qd[0, 2, 0] > 0.05 and (qd[:, 2, 0] > 1e-3).sum() >= 3                     # free gas at the injector and around it
     assert np.all(qd[:, 15, 0] <= 1.27 * 178.10760667903526 * (1 + 1e-12))           # Rs of every cell: DRSDT 0 / ALL holds it at or below its initial value
+
+
+def test_spe9_shaped_schedule_with_standard_wells(pkg, orc):
+    """BASELINE.json configs[2] with wells that are wells: SPE9's injector (five completions) and 25 producers (three each) as
+    wells.StandardWells on the 24 x 25 x 15 log-normal stand-in grid with a gas cap, over the shape of SPE9's schedule - producers at 1500
+    stb/day, cut to 100 stb/day at a report step (StandardWells.set_rate_target: the PRODUCTION_UPDATE event), back at 1500 - under Flow's
+    time-step control.  Producers fall to their BHP limit and return, the injector meets its upper limit: 26 wells x 4 unknowns eliminated
+    by the device in every linear solve (wells_apply_residual, the operator C^T D^-1 B inside BiCGStab, wells_recover_solution).  Device
+    against the oracle running the SAME loop (tests/test_spe9_shaped_wells.py holds the CPU side: finite differences of the blocks, the
+    three components' balance): the same sub-steps, Newton iterations and controls at the end of every report step, the states and the
+    well unknowns to 1e-7.  (The SPE9 deck is not in the reference tree: no number of it is pinned here.)"""
+    from test_spe9_shaped_wells import DAY, PRODUCER_BHP_LIMIT, SCHEDULE, run_schedule
+    case = pkg.decks.cartesian_case(24, 25, 15, dx=91.44, dy=91.44, dz=6.0, heterogeneous=True, state="mixed")
+    m = pkg.capi.HipModel(case, tolerance=1e-2, maxit=200, ilu_relaxation=0.9)
+    om = oracle_bind.OracleModel(orc, case)
+    runs = []
+    for side, h in (("device", m), ("oracle", om)):
+        h.set_state(case["pv"], case["meaning"])
+        wells = pkg.decks.spe9_shaped_wells(case, producer_bhp_limit=PRODUCER_BHP_LIMIT)
+        if side == "oracle":
+            hm = oracle_bind.OracleAsHipModel(om, tol=1e-2, maxit=200, w=0.9)
+            hm.kw["order"] = m.ordering()[:2]            # the ILU0 in the ordering the device chose
+        else:
+            hm = h
+        ts, steps = run_schedule(pkg, hm, wells, SCHEDULE)
+        runs.append(dict(steps=steps, history=list(ts.history), time=ts.time, wells=wells.x.copy(), state=h.get_state(), iq=h.iq()))
+    dev, ora = runs
+    np.testing.assert_allclose([dev["time"], ora["time"]], 30 * DAY, rtol=1e-12)
+    assert all(ok for _, _, ok in dev["history"]) and all(ok for _, _, ok in ora["history"])
+    (pd, md), (po, mo) = dev["state"], ora["state"]
+    pd2, po2 = pd.reshape(-1, 3), po.reshape(-1, 3)
+    qd, qo = dev["iq"], ora["iq"]
+    rate_scale = np.abs(ora["wells"][:, :3]).max(axis=1, keepdims=True)
+    print("SPE9-shaped schedule, 3 report steps: (Newton, linear, controls) device %r oracle %r; sub-steps %r | %r; cells whose meaning differs %d; max relative "
+          "pressure difference %.2e, |dS| %.2e, Rs %.2e, bhp %.2e, rates / the well's largest %.2e" %
+          (dev["steps"], ora["steps"], [round(h[0] / DAY, 2) for h in dev["history"]], [round(h[0] / DAY, 2) for h in ora["history"]], int((md != mo).sum()),
+           np.abs(pd2[:, 1] / po2[:, 1] - 1).max(), np.abs(qd[:, 0:3, 0] - qo[:, 0:3, 0]).max(), np.abs(qd[:, 15, 0] / qo[:, 15, 0] - 1).max(),
+           np.abs(dev["wells"][:, 3] / ora["wells"][:, 3] - 1).max(), (np.abs(dev["wells"][:, :3] - ora["wells"][:, :3]) / rate_scale).max()))
+    for (nd, ld, cd), (no, lo, co) in zip(dev["steps"], ora["steps"]):
+        assert cd == co, (cd, co)                                                      # every well under the same control at the end of the report step
+        # this run is smooth where SPE1 under DRSDT 0 is not (no cell on a switching threshold): the two sides stay one path - the same
+        # Newton iterations, the linear iterations within a few (the scalar products' order moves a solve by half an iteration now and then)
+        assert nd == no and abs(ld - lo) <= 5, (dev["steps"], ora["steps"])
+    assert dev["steps"][0][2].count("B") >= 3 and dev["steps"][1][2] == "B" + "R" * 25 and dev["steps"][2][2][0] == "B"
+    assert [h[0] for h in dev["history"]] == [h[0] for h in ora["history"]]                 # the same sub-steps
+    # measured: pressures 3e-10, saturations 2e-9, Rs 1e-9, bottom-hole pressures 3e-10, rates 5e-9 of the well's largest
+    np.testing.assert_allclose(pd2[:, 1], po2[:, 1], rtol=1e-7)
+    np.testing.assert_allclose(qd[:, 0:3, 0], qo[:, 0:3, 0], atol=1e-7)
+    np.testing.assert_allclose(qd[:, 15, 0], qo[:, 15, 0], rtol=1e-7)
+    np.testing.assert_allclose(dev["wells"][:, 3], ora["wells"][:, 3], rtol=1e-7)
+    assert (np.abs(dev["wells"][:, :3] - ora["wells"][:, :3]) / rate_scale).max() <= 1e-6
+    assert np.array_equal(md, mo)                                                     # (no cell sits on a switching threshold here, unlike SPE1 under DRSDT 0)
 
 
 def test_spe1case1_first_time_step_in_lock_step(pkg, orc):

@@ -1,0 +1,162 @@
+"""BASELINE.json configs[2] ("SPE9, 9000 cells, 25 wells, heterogeneous perm - well-coupling + ILU0 correctness vs CPU") with wells that are
+wells, on the CPU side: decks.spe9_shaped_wells (SPE9's injector and 25 producers as wells.StandardWells on the 24 x 25 x 15 stand-in grid -
+the deck itself is not in the reference tree), multi-perforation wells, control switching in both directions and a schedule event
+(StandardWells.set_rate_target: SPE9 cuts its producers to 100 stb/day for a while), driven over the oracle.  The device run of the same loop:
+tests/test_gpu_configs.py::test_spe9_shaped_schedule_with_standard_wells.
+
+Checked by properties (no output of SPE9 exists in the tree): the completions, the well blocks of multi-perforation wells against finite
+differences, rates on target / BHP on its limit per control, and the surface-volume balance of all three components over the schedule."""
+import numpy as np
+import pytest
+
+import oracle_bind
+
+DAY = 86400.0
+
+
+@pytest.fixture(scope="module")
+def spe9(pkg):
+    return pkg.decks.cartesian_case(24, 25, 15, dx=91.44, dy=91.44, dz=6.0, heterogeneous=True, state="mixed")
+
+
+def test_completions(pkg, spe9):
+    w = pkg.decks.spe9_shaped_wells(spe9)
+    assert w.nw == 26 and list(w.vp) == [0] + [5 + 3 * k for k in range(26)]
+    inj = w.wells[0]
+    assert not inj.producer and inj.inj_phase == "water" and list(inj.cells) == [23 + 24 * 24 + 600 * k for k in range(10, 15)]
+    np.testing.assert_allclose(inj.control[2], 5000.0 * 0.158987294928 / DAY, rtol=1e-12)
+    assert len({(int(p.cells[0]) % 600) for p in w.wells[1:]}) == 25                       # 25 distinct columns
+    for p, (i, j) in zip(w.wells[1:], pkg.decks.SPE9_PRODUCERS_IJ):
+        assert p.producer and list(p.cells) == [(i - 1) + 24 * (j - 1) + 600 * k for k in (1, 2, 3)] and p.control[:2] == ("rate", 0)
+        assert p.ref_depth == spe9["depth"][p.cells[0]] and p.bhp_limit == 1000.0 * pkg.decks.PSIA
+    # connection factors follow the cell's own permeability (log-normal field): they differ inside one well
+    assert len({float(t) for t in w.wells[1].tw}) == 3
+    with pytest.raises(ValueError):
+        pkg.decks.spe9_shaped_wells(pkg.decks.cartesian_case(10, 10, 3))
+
+
+def test_multi_perforation_well_blocks_against_finite_differences(pkg, orc, spe9):
+    """a producer with three completions in the gas cap (all three phases in its stream, a hydrostatic head between the completions) and the
+    injector with five: B, C, D and dsource against central differences of the quantities the well model itself evaluates"""
+    case = spe9
+    pv = case["pv"].reshape(-1, 3).copy()
+    meaning = case["meaning"].copy()
+    om = oracle_bind.OracleModel(orc, case)
+    om.set_state(case["pv"], meaning)
+    wells = pkg.decks.spe9_shaped_wells(case)
+    iq = om.iq()
+    wells.solve_well_equations(iq)
+    x0 = wells.x.copy()
+    x0[:, :3] *= 1.02
+    x0[:, 3] += np.where(np.arange(26) == 0, 3e5, -2e5)
+    wells.x = x0.copy()
+    a = wells.assemble(iq, case["Nb"])
+    W = a["wells"]
+    nperf = len(wells.cells)
+    B, C = W["Bnnzs"].reshape(nperf, 4, 3), W["Cnnzs"].reshape(nperf, 4, 3)
+    Dinv = W["Dnnzs"].reshape(26, 4, 4)
+
+    def residuals(pvx, xw):
+        om.set_state(np.ascontiguousarray(pvx.reshape(-1)), meaning)
+        wells.x = xw.copy()
+        r = wells.assemble(om.iq(), case["Nb"])
+        return r["res_well"].reshape(26, 4).copy(), r["source"].reshape(-1, 3).copy()
+    for k in (0, 7):                                                  # the injector; a producer
+        D = np.linalg.inv(Dinv[k])
+        for j in range(wells.vp[k], wells.vp[k + 1]):
+            cell = int(wells.cells[j])
+            for v, h in enumerate((1e-6, 50.0, 1e-6 if meaning[cell] == 0 else 1e-4)):
+                pp, pm = pv.copy(), pv.copy()
+                pp[cell, v] += h
+                pm[cell, v] -= h
+                (rp, sp), (rm, sm) = residuals(pp, x0), residuals(pm, x0)
+                np.testing.assert_allclose(B[j][:, v], (rp[k] - rm[k]) / (2 * h), rtol=5e-5, atol=1e-9 * np.abs(B[j]).max())
+                np.testing.assert_allclose(a["dsource"].reshape(-1, 3, 3)[cell][:, v], (sp[cell] - sm[cell]) / (2 * h), rtol=5e-5,
+                                           atol=1e-9 * np.abs(a["dsource"]).max())
+        for u, h in enumerate((1e-7, 1e-7, 1e-5, 100.0)):
+            xp, xm = x0.copy(), x0.copy()
+            xp[k, u] += h
+            xm[k, u] -= h
+            (rp, sp), (rm, sm) = residuals(pv, xp), residuals(pv, xm)
+            np.testing.assert_allclose(D[:, u], (rp[k] - rm[k]) / (2 * h), rtol=5e-5, atol=1e-9 * np.abs(D).max())
+            for j in range(wells.vp[k], wells.vp[k + 1]):
+                cell = int(wells.cells[j])
+                np.testing.assert_allclose(C[j][u, :], -(sp[cell] - sm[cell]) / (2 * h), rtol=5e-5, atol=1e-9 * max(np.abs(C[j]).max(), 1e-30))
+    # the completions of one well do not flow alike: head and permeability differ
+    src = a["source"].reshape(-1, 3)
+    assert len({float(src[c, 0]) for c in wells.wells[7].cells}) == 3 and all(src[c, 0] < 0.0 for c in wells.wells[7].cells)
+
+
+def _in_place(iq, case):
+    """surface volumes in place: oil, water, gas"""
+    pvol = case["volume"] * iq[:, 16, 0]
+    sw, so, sg = iq[:, 0, 0], iq[:, 1, 0], iq[:, 2, 0]
+    bw, bo, bg, rs = iq[:, 6, 0], iq[:, 7, 0], iq[:, 8, 0], iq[:, 15, 0]
+    return np.array([(pvol * bo * so).sum(), (pvol * bw * sw).sum(), (pvol * (bg * sg + rs * bo * so)).sum()])
+
+
+def run_schedule(pkg, hm, wells, schedule, on_accept=None):
+    """three report steps of 10 days: producers at 1500 stb/day, cut to 100, back at 1500 (the SPE9 schedule's shape); -> per report step
+    (Newton iterations, linear iterations, controls at its end)"""
+    model = pkg.newton.BlackoilModelHip(hm, well_model=wells)
+    ts = pkg.newton.AdaptiveTimeStepping(model, pkg.newton.TimeSteppingParameters(initial_dt=DAY))
+    ts.on_accept = on_accept
+    out = []
+    for length, rate in schedule:
+        if rate is not None:
+            for k in range(1, wells.nw):
+                wells.set_rate_target(k, rate * pkg.decks.STB_PER_DAY)
+        reps = ts.advance_report_step(length)
+        out.append((len(reps), sum(r.total_linear_iterations for r in reps), "".join("R" if w.control[0] == "rate" else "B" for w in wells.wells)))
+    return ts, out
+
+
+SCHEDULE = ((10 * DAY, None), (10 * DAY, 100.0), (10 * DAY, 1500.0))
+PRODUCER_BHP_LIMIT = 235e5      # (SPE9's 1000 psia is never met in a month on this grid: a limit some of the 25 wells do meet on the log-normal field)
+
+
+def test_schedule_on_the_oracle(pkg, orc, spe9):
+    case = spe9
+    om = oracle_bind.OracleModel(orc, case)
+    om.set_state(case["pv"], case["meaning"])
+    before = _in_place(om.iq(), case)
+    wells = pkg.decks.spe9_shaped_wells(case, producer_bhp_limit=PRODUCER_BHP_LIMIT)
+    hm = oracle_bind.OracleAsHipModel(om, tol=1e-2, maxit=200, w=0.9)
+    moved = np.zeros(3)
+
+    def on_accept(dt):
+        moved[:] += wells.x[:, :3].sum(axis=0) * dt
+    ts, steps = run_schedule(pkg, hm, wells, SCHEDULE, on_accept)
+    np.testing.assert_allclose(ts.time, 30 * DAY, rtol=1e-12)
+    assert all(ok for _, _, ok in ts.history)
+    stb = pkg.decks.STB_PER_DAY
+    # report step 1: the injector holds its rate; on the log-normal field some producers cannot hold 1500 stb/day above the limit
+    c1, c2, c3 = (s[2] for s in steps)
+    assert c1[0] == "R" and 3 <= c1[1:].count("B") <= 20
+    # report step 2 (100 stb/day): every producer is back on its (new) target - the event put it under rate control and it can hold it -
+    # while the injector, pushing 5000 stb/day into a reservoir nobody drains, has met its upper limit
+    assert c2 == "B" + "R" * 25
+    # report step 3: the producers that could not hold 1500 stb/day fall back to the limit
+    assert c3[0] == "B" and 3 <= c3[1:].count("B") <= 22
+    for k, w in enumerate(wells.wells):
+        x = wells.x[k]
+        if w.control[0] == "rate":
+            np.testing.assert_allclose(abs(x[w.control[1]]), w.control[2], rtol=1e-7)
+            assert x[3] >= w.bhp_limit * (1 - 1e-9) if w.producer else x[3] <= w.bhp_limit * (1 + 1e-9)
+        else:
+            np.testing.assert_allclose(x[3], w.bhp_limit, rtol=1e-9)
+            assert abs(x[w.rate_control[1]]) <= w.rate_control[2] * (1 + 1e-9)          # ... because it cannot reach the target there
+    assert np.all(wells.x[1:, 0] < 0) and np.all(wells.x[1:, 2] < 0) and wells.x[0, 1] > 0 and abs(wells.x[0, 0]) + abs(wells.x[0, 2]) == 0.0
+    assert np.all(-wells.x[1:, 0] >= 400.0 * stb)                    # every producer still flows a good part of its target
+    # surface volumes in place follow what the wells moved, component by component, to what the Newton method's stopping rule leaves per
+    # sub-step (MB <= 1e-6 of the pore volume, in surface volumes through 1/B of the order of 1 for liquids and 200 for gas)
+    after = _in_place(om.iq(), case)
+    pore = float((case["volume"] * case["poro"]).sum())
+    slack = 2.0 * 1e-6 * pore * len(ts.history)
+    assert moved[0] < -25 * 400.0 * stb * 20 * DAY and moved[1] > 2000.0 * stb * 30 * DAY and moved[2] < 0
+    # (that bound is the stopping rule's; the sub-steps end far below it - measured: 7e-3 m^3 of 1.0e5 of oil, 2e-4 of 2.0e4 of water, 1.5 of
+    #  4.6e7 of gas - so the tighter of the bound and 1e-4 of what moved is asked for)
+    for c, factor in ((0, 1.0), (1, 1.0), (2, 250.0)):
+        assert abs((after[c] - before[c]) - moved[c]) <= min(factor * slack, 1e-4 * abs(moved[c])), c
+    print("SPE9-shaped schedule on the oracle: (Newton, linear, controls) per report step %r; moved %r; balance errors %r of slack %.3g" %
+          (steps, moved.tolist(), ((after - before) - moved).tolist(), slack))

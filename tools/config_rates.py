@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Newton iterations/s of the device path AND of the CPU port beside it (the oracle through the same loop: bench.py's cpu_baseline) on
 BASELINE.json's other configurations (the bench line is configs[1]):
-configs[0] the SPE1CASE1 deck itself (EQUIL state, DRSDT 0, its two wells; and its 10 x 10 x 3 grid with rate sources), configs[2] an SPE9-shaped 24 x 25 x 15 grid (heterogeneous permeability; rate sources in place of its wells), configs[4] the
+configs[0] the SPE1CASE1 deck itself (EQUIL state, DRSDT 0, its two wells; and its 10 x 10 x 3 grid with rate sources), configs[2] an SPE9-shaped 24 x 25 x 15 grid (heterogeneous permeability; with rate sources, and with SPE9's 26 wells as wells.StandardWells), configs[4] the
 Norne-shaped corner-point grid of the tests (46 x 112 x 22, 44 777 active cells, faults, pinch-outs: rows of 2 to 12 blocks) - each under
 bench.py's own time-step control, with ILU0 and with CPR.  These sizes do not fill the chip: what they show is the launch-bound end of the
 path (a Newton iteration is ~60 kernel launches with ILU0).    python tools/config_rates.py [--steps 40]"""
@@ -101,6 +101,8 @@ for n3 in ((20, 20, 10), (32, 32, 32)):
     run("(ladder) %d x %d x %d homogeneous" % n3, cc, five_spot(cc, pkg.decks.BENCH_RATE_SM3_PER_DAY * n3[0] * n3[1] / 1e4))
 c2 = pkg.decks.cartesian_case(24, 25, 15, state="mixed", heterogeneous=True)
 run("configs[2]: SPE9-shaped, 24 x 25 x 15, heterogeneous", c2, five_spot(c2, 60.0))
+c2w = pkg.decks.cartesian_case(24, 25, 15, dx=91.44, dy=91.44, dz=6.0, state="mixed", heterogeneous=True)
+run("            the same grid at SPE9's cell size, its 26 wells as wells", c2w, None, wells=lambda: pkg.decks.spe9_shaped_wells(c2w, producer_bhp_limit=235e5))
 c4, _, _ = helpers.norne_shaped_case(pkg)
 run("configs[4]: Norne-shaped corner-point grid, 46 x 112 x 22", c4, scattered_sources(c4, 200.0))
 c1 = pkg.decks.cartesian_case(50, 50, 50, state="mixed", heterogeneous=False)
