@@ -31,11 +31,17 @@
 #include <set>
 #include <stdexcept>
 #include <string>
+#include <type_traits>
+#include <utility>
 #include <vector>
 
 #include "../../include/opmhip.h"
 
 namespace Opm {
+
+/// does the problem name the dofs its source terms can sit in (`const std::vector<int>& sourceDofs() const`)?
+template <class Problem, class = void> struct HasSourceDofs : std::false_type {};
+template <class Problem> struct HasSourceDofs<Problem, std::void_t<decltype(std::declval<const Problem&>().sourceDofs())>> : std::true_type {};
 
 template <class TypeTag>
 class HipLinearizer {
@@ -107,14 +113,23 @@ public:
         if (!stateOnDevice_) solutionToDevice();
         // EclProblem::source (:1823-1845): the wells' total rates per dof and equation, with derivatives
         RateVector rate;
-        for (int i = 0; i < N_; ++i) {
+        auto record = [&](int i, size_t slot) {
             sim.problem().source(rate, i, /*timeIdx=*/0);
             for (int e = 0; e < 3; ++e) {
-                source_[(size_t)i * 3 + e] = rate.value(e);
-                for (int v = 0; v < 3; ++v) dsource_[(size_t)i * 9 + e * 3 + v] = rate.derivative(e, v);
+                source_[slot * 3 + e] = rate.value(e);
+                for (int v = 0; v < 3; ++v) dsource_[slot * 9 + e * 3 + v] = rate.derivative(e, v);
             }
+        };
+        if constexpr (HasSourceDofs<std::decay_t<decltype(sim.problem())>>::value) {
+            // a problem that names the dofs a source can sit in (Flow: the cells BlackoilWellModel::is_cell_perforated_ marks,
+            // wells/BlackoilWellModel_impl.hpp:496-512, 1606-1630): only their rates are evaluated and cross PCIe
+            const std::vector<int>& dofs = sim.problem().sourceDofs();
+            for (size_t q = 0; q < dofs.size(); ++q) record(dofs[q], q);
+            check_(opmhip_set_source_cells(ctx_, (int)dofs.size(), dofs.data(), source_.data(), dsource_.data()), "opmhip_set_source_cells");
+        } else {
+            for (int i = 0; i < N_; ++i) record(i, (size_t)i);
+            check_(opmhip_set_source(ctx_, source_.data(), dsource_.data()), "opmhip_set_source");
         }
-        check_(opmhip_set_source(ctx_, source_.data(), dsource_.data()), "opmhip_set_source");
         const int iteration = sim.model().newtonMethod().numIterations();
         // the block values of a BCRSMatrix and the entries of a BlockVector are contiguous: the pointers BdaBridge hands its
         // back-ends (linalg/bda/BdaBridge.cpp:231-232) are the ones the assembled system is written through

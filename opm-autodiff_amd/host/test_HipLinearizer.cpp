@@ -89,6 +89,18 @@ struct Problem {
         rate = RateVector();
         if (C->count("source")) for (int e = 0; e < 3; ++e) rate.v[e] = (*C)["source"].f64()[(size_t)i * 3 + e];
     }
+#ifdef STUB_SOURCE_DOFS   // the second build of this driver: a problem that names the dofs with sources (the perforated cells)
+    mutable std::vector<int> dofs;
+    const std::vector<int>& sourceDofs() const {
+        if (dofs.empty() && C->count("source")) {
+            const int N = (int)(*C)["source"].count / 3;
+            for (int i = 0; i < N; ++i)
+                for (int e = 0; e < 3; ++e)
+                    if ((*C)["source"].f64()[(size_t)i * 3 + e] != 0.0) { dofs.push_back(i); break; }
+        }
+        return dofs;
+    }
+#endif
 };
 struct Simulator {
     Problem problem_;

@@ -217,19 +217,21 @@ def test_BlackoilModelHip_report_step_survives_a_chop(pkg, tmp_path):
     assert np.all(np.isfinite(pv)) and np.all(pv[:, 1] > 1e7) and np.all(pv[:, 0] > 0.0) and np.all(pv[:, 0] < 1.0)
 
 
-@pytest.mark.parametrize("mode", ["host", "device"])
-def test_HipLinearizer_drives_newton_iterations(pkg, tmp_path, mode):
+@pytest.mark.parametrize("mode,exe", [("host", "test_HipLinearizer"), ("device", "test_HipLinearizer"), ("device", "test_HipLinearizer_source_dofs")])
+def test_HipLinearizer_drives_newton_iterations(pkg, tmp_path, mode, exe):
     """Opm::HipLinearizer<TypeTag> (host/HipLinearizer.hpp), compiled against the property-system include path and driven through
     the linearizer's public face - linearizeDomain(), jacobian(), residual(), solution(0) hand-off, invalidateAndUpdateIntensive
     Quantities (flow/BlackoilModelEbos.hpp:339-340, 424, 526-527, 552-562): every iteration's system and state are the bits the
     plain C-ABI sequence gives (the driver compares them itself, with host copies of J and r or with both left in HBM), and the
-    final state equals the one this process reaches through the Python binding"""
+    final state equals the one this process reaches through the Python binding.  test_HipLinearizer_source_dofs: the same driver over a
+    problem that names the dofs its sources sit in (sourceDofs(), Flow's perforated cells): their rates alone travel, through
+    opmhip_set_source_cells"""
     case = pkg.decks.cartesian_case(10, 9, 7, state="mixed", heterogeneous=True)
     src = pkg.decks.five_spot_source(case, rate_sm3_per_day=40.0)
     cf, so = str(tmp_path / "case.bin"), str(tmp_path / "state.bin")
     pkg.decks.write_case_binary(case, cf, source=src)
     dt, its = 2 * 86400.0, 3
-    out = subprocess.run([_exe("test_HipLinearizer"), cf, mode, repr(dt), str(its), so], capture_output=True, text=True)
+    out = subprocess.run([_exe(exe), cf, mode, repr(dt), str(its), so], capture_output=True, text=True)
     assert out.returncode == 0, out.stderr + out.stdout
     lines = [l for l in out.stdout.splitlines() if l.startswith("iteration")]
     assert len(lines) == its and all("DIFFERS" not in l for l in lines) and out.stdout.strip().endswith("ok")
