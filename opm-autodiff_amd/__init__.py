@@ -4,4 +4,4 @@ The directory name carries a hyphen (mandated layout), so import it with
 ``importlib.import_module("opm-autodiff_amd")``.  The compute path lives in ``libopmhip.so`` (HIP, gfx950),
 reached through the C-ABI declared in ``include/opmhip.h``; ``capi`` is its ctypes binding.
 """
-from . import capi, decks, equil, fluid, grid, mmio, newton, ras, thpres, transmissibility  # noqa: F401
+from . import capi, decks, equil, fluid, grid, mmio, newton, ras, thpres, transmissibility, wells  # noqa: F401

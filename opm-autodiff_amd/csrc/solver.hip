@@ -1532,24 +1532,50 @@ __global__ __launch_bounds__(64) void k_ilu_factor(const int* __restrict__ sched
 // ============================== standard wells ===========================================================
 // y -= C^T (D^-1 (B x)) per well (bda/WellContributions.cu:36-126); one wavefront per well, any number of
 // perforations (the CUDA kernel's 32-lane masks assume <= 2 blocks per warp pass, :82).
+// (B x)_w added to (SUB: subtracted from) s on lanes 0..3, one well equation each, in the order of the CPU's per-perforation loop
+// (wells/StandardWell_impl.hpp:1254-1275).  Walking the perforations one by one on four lanes costs a round trip to memory per
+// perforation (100 completions: ~50 us per application, twice per BiCGStab iteration); here every lane forms the twelve products of one
+// perforation - 64 perforations' loads in flight together - and lanes 0..3 then add the products up out of LDS in that same order: the
+// same products, the same additions, the same bits.
+template <bool SUB>
+__device__ __forceinline__ double well_Bx(double s, int pb, int pe, const int* __restrict__ Bcols, const double* __restrict__ B,
+                                          const double* __restrict__ x, double xs, int lane, double* prod /* LDS, 64 x 12 */) {
+    for (int p0 = pb; p0 < pe; p0 += 64) {
+        const int p = p0 + lane;
+        if (p < pe) {
+            const double* xb = &x[(size_t)Bcols[p] * 3];
+            const double x0 = xs * xb[0], x1 = xs * xb[1], x2 = xs * xb[2];
+            const double* Bp = &B[(size_t)p * 12];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                prod[lane * 12 + q * 3] = Bp[q * 3] * x0;
+                prod[lane * 12 + q * 3 + 1] = Bp[q * 3 + 1] * x1;
+                prod[lane * 12 + q * 3 + 2] = Bp[q * 3 + 2] * x2;
+            }
+        }
+        __syncthreads();
+        if (lane < 4) {
+            const int m = pe - p0 < 64 ? pe - p0 : 64;
+            for (int j = 0; j < m; ++j) {
+                const double* pj = &prod[j * 12 + lane * 3];
+                if (SUB) { s -= pj[0]; s -= pj[1]; s -= pj[2]; }
+                else { s += pj[0]; s += pj[1]; s += pj[2]; }
+            }
+        }
+        __syncthreads();
+    }
+    return s;
+}
 __global__ __launch_bounds__(64) void k_wells_apply(const int* __restrict__ vp, const int* __restrict__ Ccols,
                                                     const int* __restrict__ Bcols, const double* __restrict__ C,
                                                     const double* __restrict__ D, const double* __restrict__ B,
                                                     const double* __restrict__ x, double* __restrict__ y, double xs) {
-    __shared__ double z1[4], z2[4];
+    __shared__ double z1[4], z2[4], prod[64 * 12];
     const int w = blockIdx.x, lane = threadIdx.x;
     const int pb = vp[w], pe = vp[w + 1];
-    // z1 = B x : lanes 0..3 own one well equation each and walk the perforations in order (the sum order of
-    // the CPU's per-perforation loop, wells/StandardWell_impl.hpp:1254-1275)
-    if (lane < 4) {
-        double s = 0.0;
-        for (int p = pb; p < pe; ++p) {
-            const double* xb = &x[(size_t)Bcols[p] * 3];
-            const double* Bp = &B[(size_t)p * 12 + lane * 3];
-            s += Bp[0] * (xs * xb[0]); s += Bp[1] * (xs * xb[1]); s += Bp[2] * (xs * xb[2]);
-        }
-        z1[lane] = s;
-    }
+    // z1 = B x : lanes 0..3 own one well equation each
+    const double bx = well_Bx<false>(0.0, pb, pe, Bcols, B, x, xs, lane, prod);
+    if (lane < 4) z1[lane] = bx;
     __syncthreads();
     if (lane < 4) {
         double s = 0.0;
@@ -1570,15 +1596,10 @@ __global__ __launch_bounds__(64) void k_wells_apply(const int* __restrict__ vp, 
 // this rank's part of B x of every well, 4 doubles per well, for the sum over the ranks (distributed wells); the sums of k_wells_apply
 __global__ __launch_bounds__(64) void k_wells_bx(const int* __restrict__ vp, const int* __restrict__ Bcols, const double* __restrict__ B,
                                                  const double* __restrict__ x, double xs, double* __restrict__ bx) {
+    __shared__ double prod[64 * 12];
     const int w = blockIdx.x, lane = threadIdx.x;
-    if (lane >= 4) return;
-    double s = 0.0;
-    for (int p = vp[w]; p < vp[w + 1]; ++p) {
-        const double* xb = &x[(size_t)Bcols[p] * 3];
-        const double* Bp = &B[(size_t)p * 12 + lane * 3];
-        s += Bp[0] * (xs * xb[0]); s += Bp[1] * (xs * xb[1]); s += Bp[2] * (xs * xb[2]);
-    }
-    bx[(size_t)w * 4 + lane] = s;
+    const double s = well_Bx<false>(0.0, vp[w], vp[w + 1], Bcols, B, x, xs, lane, prod);
+    if (lane < 4) bx[(size_t)w * 4 + lane] = s;
 }
 
 // r -= C^T (D^-1 resWell) (StandardWell::apply(BVector& r), wells/StandardWell_impl.hpp:1283-1296) and
@@ -1607,18 +1628,13 @@ __global__ __launch_bounds__(64) void k_wells_recover(const int* __restrict__ vp
                                                       const double* __restrict__ resWell, const double* __restrict__ x,
                                                       const double* __restrict__ bxAll, double* __restrict__ xw) {
     __shared__ double z1[4];
+    __shared__ double prod[64 * 12];
     const int w = blockIdx.x, lane = threadIdx.x;
     const int pb = vp[w], pe = vp[w + 1];
-    if (lane < 4) {
-        double s = resWell[(size_t)w * 4 + lane];   // resWell -= B x, perforation by perforation (BCRSMatrix::mmv)
-        if (bxAll) s -= bxAll[(size_t)w * 4 + lane];   // a well shared by several ranks: the product summed over them, subtracted as a whole
-        else for (int p = pb; p < pe; ++p) {
-            const double* xb = &x[(size_t)Bcols[p] * 3];
-            const double* Bp = &B[(size_t)p * 12 + lane * 3];
-            s -= Bp[0] * xb[0]; s -= Bp[1] * xb[1]; s -= Bp[2] * xb[2];
-        }
-        z1[lane] = s;
-    }
+    double s = lane < 4 ? resWell[(size_t)w * 4 + lane] : 0.0;   // resWell -= B x, perforation by perforation (BCRSMatrix::mmv)
+    if (bxAll) { if (lane < 4) s -= bxAll[(size_t)w * 4 + lane]; }   // a well shared by several ranks: the product summed over them, subtracted as a whole
+    else s = well_Bx<true>(s, pb, pe, Bcols, B, x, 1.0, lane, prod);
+    if (lane < 4) z1[lane] = s;
     __syncthreads();
     if (lane < 4) {
         double s = 0.0;

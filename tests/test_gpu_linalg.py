@@ -268,6 +268,34 @@ def test_wells_operator(pkg, orc):
     assert np.linalg.norm(r) < 1e-8 * np.linalg.norm(b) * 1.001
 
 
+def test_wells_with_more_completions_than_a_wavefront_has_lanes(pkg, orc):
+    """B x of a well is formed 64 completions at a time (well_Bx in csrc/solver.hip: the products in parallel, their sum in the CPU loop's
+    order): wells of 150, 64, 65 and 1 completions - the solve stops where the oracle's does with its solution, and x_w = D^-1 (r_w - B x),
+    whose subtractions run through the same code, equals the oracle's bit for bit on the same x"""
+    rng = np.random.default_rng(21)
+    Nb, rp, ci, v = laplace_block_system(16, 12, 10, seed=23)
+    perfs = [150, 64, 65, 1]
+    vp = np.concatenate([[0], np.cumsum(perfs)]).astype(np.int32)
+    nperf = int(vp[-1])
+    cols = rng.choice(Nb, nperf, replace=False).astype(np.int32)
+    Dm = [np.linalg.inv(0.2 * rng.standard_normal((4, 4)) + np.diag(2.0 + rng.random(4))) for _ in perfs]
+    W = dict(numWells=len(perfs), val_pointers=vp, Ccols=cols, Bcols=cols.copy(), Cnnzs=0.02 * rng.standard_normal(nperf * 12),
+             Bnnzs=0.02 * rng.standard_normal(nperf * 12), Dnnzs=np.ascontiguousarray(np.stack(Dm).reshape(-1)))
+    b = rng.standard_normal(Nb * 3)
+    rw = rng.standard_normal(4 * len(perfs))
+    for reorder in ("graph_coloring_greedy", "line_coloring"):
+        s = pkg.capi.HipSolver(tolerance=1e-8, maxit=200, reorder=reorder)
+        res = s.solve_system(Nb, rp, ci, v.copy(), b, wells=W)
+        x = s.get_result()
+        to, fr, _ = s.ordering()
+        xo, ro = oracle_solve_in_order(orc, Nb, rp, ci, v, b, to, fr, wells=W, tol=1e-8, maxit=200, w=0.9)
+        assert res.converged and res.it == ro.it
+        np.testing.assert_allclose(x, xo, rtol=1e-8, atol=1e-12)
+        r = b - orc.wells_apply(W, x, orc.spmv(Nb, rp, ci, v, x))
+        assert np.linalg.norm(r) < 1e-8 * np.linalg.norm(b) * 1.001
+        np.testing.assert_array_equal(s.wells_recover_solution(W, rw), orc.wells_recover(W, rw, x))
+
+
 @pytest.mark.parametrize("reorder", ["level_scheduling", "graph_coloring", "line_coloring"])
 def test_wells_operator_in_every_ordering(pkg, orc, reorder):
     """The well operator inside a solve under the other orderings (the perforated cells are renamed at upload, opmhip_wells' indices are
