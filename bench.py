@@ -438,7 +438,10 @@ def main():
     ap.add_argument("--preconditioner", default="ilu0", choices=["ilu0", "cpr", "cpr_trueimpes", "cpr_quasiimpes"], help="--linear-solver-configuration of the run behind `value`")
     ap.add_argument("--cpr-reuse-setup", type=int, default=3, choices=[0, 1, 2, 3], help="Flow's --cpr-reuse-setup for the CPR runs: when the hierarchy's structure is built anew (3 = never, the default of Flow)")
     ap.add_argument("--cpr-amg-ilu-levels", type=int, default=None, help="CPR runs: this many of the pressure AMG's finest levels smooth with ILU0 (the reference's AMG smoother) instead of damped Jacobi; default: the library's choice (opmhip_default_config: -1 = level 0 where the block ordering has at most three colours), reported in cpr_amg_ilu_levels")
-    ap.add_argument("--fused-reductions", action="store_true", help="BiCGStab with one reduction per half iteration (opmhip_config.fused_reductions; off by default: A/B measurements and runs over several GPUs)")
+    ap.add_argument("--fused-reductions", dest="fused_reductions", action="store_true", default=None,
+                    help="BiCGStab with one reduction per half iteration (opmhip_config.fused_reductions). Default: off on one GPU (there it is even, profiles/r06_fused_ab.txt), "
+                         "on for --gpus N > 1 with ILU0, where every reduction is an all-reduce over xGMI (two per iteration instead of four); --no-fused-reductions: off")
+    ap.add_argument("--no-fused-reductions", dest="fused_reductions", action="store_false")
     ap.add_argument("--no-cpr-side-run", action="store_true", help="skip the side runs with the CPR preconditioners (extra keys `cpr`, `cpr_quasiimpes`)")
     a = ap.parse_args()
 
@@ -474,6 +477,8 @@ def main():
 
     pkg = importlib.import_module("opm-autodiff_amd")
     n = a.n
+    fused_side = bool(a.fused_reductions)                                       # the CPR side runs: only when asked for
+    a.fused_reductions = (world > 1 and a.preconditioner == "ilu0") if a.fused_reductions is None else a.fused_reductions
     skw = dict(device_id=local_rank, reorder=a.reorder, tolerance=1e-2, maxit=200, ilu_relaxation=0.9, chain_length=a.chain_length,
                preconditioner=a.preconditioner, cpr_reuse_setup=a.cpr_reuse_setup, cpr_amg_ilu_levels=a.cpr_amg_ilu_levels,
                fused_reductions=int(a.fused_reductions))
@@ -618,7 +623,7 @@ def main():
     def cpr_window(prec, **over):
         def run():
             nonlocal sim, model
-            model2 = pkg.capi.HipModel(case, **dict(skw, preconditioner=prec, **over))
+            model2 = pkg.capi.HipModel(case, **dict(skw, preconditioner=prec, fused_reductions=int(fused_side), **over))
             model2._bench_preconditioner = prec
             model2.set_state(case["pv"], case["meaning"])
             model2.set_source(src)
