@@ -117,3 +117,53 @@ def test_decomposed_run_with_one_all_reduce_per_half_iteration(pkg, orc, world):
         halves = int(round(2 * it))
         assert spans == 1 + halves + 1, (spans, halves)            # b.b, one per half iteration, the true norm at the end
         assert out[0][r][4] == 1 + 2 * int(round(2 * out[0][r][0]))   # the default recurrence: two per half iteration
+
+
+def test_decomposed_run_in_the_benchs_configuration(pkg, orc):
+    """what `bench.py --gpus N` runs for N > 1: line colouring, the pipelined kernels, the half-product form on the interior tiles AND one
+    all-reduce per half iteration - two subdomains over the loopback communicator.  Against the same decomposition with the plain product
+    (same recurrence): the same half iteration, the same solution to rounding; against the default recurrence: within half an iteration;
+    1 + halves + 1 all-reduces per solve; the reported reduction is the true residual's"""
+    import oracle_bind
+    from test_gpu_dd import global_and_parts, run_ranks
+    n, world = 20, 2      # (large enough for tiles away from the cut: the interior part of the product exists)
+    g, owner, parts = global_and_parts(pkg, n, world, state="mixed", heterogeneous=True)
+    src = pkg.decks.five_spot_source(g, rate_sm3_per_day=30.0)
+    dt = 86400.0
+    out = {}
+    for hp, fused in ((1, 1), (-1, 1), (1, 0)):
+        group = "b" + uuid.uuid4().hex
+
+        def rank_fn(r, hp=hp, fused=fused, group=group):
+            c = parts[r]
+            m = pkg.capi.HipModel(c, comm=("loopback", world, r, group), reorder="line_coloring", chain_length=4, spmv_pipe_wgs=8, tolerance=1e-4,
+                                  half_product=hp, fused_reductions=fused)
+            m.set_state(c["pv"], c["meaning"])
+            m.set_source(np.ascontiguousarray(src.reshape(-1, 3)[c["gids"]].reshape(-1)))
+            m.assemble(dt, 0, fetch=False)
+            form = m.product_form()
+            m.profile_enable(True)
+            sol = m.solve_jacobian_system()
+            spans = m.profile()["allreduce"][0]
+            return form, sol.it, sol.converged, sol.reduction, m.get_result(), spans
+        out[(hp, fused)] = run_ranks(world, rank_fn)
+    # the global system and the iterate's own residual
+    o = oracle_bind.OracleModel(orc, g)
+    o.set_state(g["pv"], g["meaning"])
+    o.set_source(src)
+    jo, ro = o.assemble(dt, 0)
+    xg = np.zeros((g["Nb"], 3))
+    for r in range(world):
+        c = parts[r]
+        xg[c["gids"][:c["Nb"]]] = out[(1, 1)][r][4].reshape(-1, 3)[:c["Nb"]]
+    true = np.linalg.norm(ro - orc.spmv(g["Nb"], g["rowptr"], g["col"], jo, xg.reshape(-1))) / np.linalg.norm(ro)
+    for r in range(world):
+        f11, it11, ok11, red11, x11, sp11 = out[(1, 1)][r]
+        f01, it01, ok01, red01, x01, sp01 = out[(-1, 1)][r]
+        f10, it10, ok10, red10, x10, sp10 = out[(1, 0)][r]
+        assert f11["half_product"] and f10["half_product"] and not f01["half_product"]
+        assert ok11 and ok01 and ok10 and it11 == it01 and abs(it11 - it10) <= 0.5, (it11, it01, it10)
+        nb = parts[r]["Nb"]
+        np.testing.assert_allclose(x11.reshape(-1, 3)[:nb], x01.reshape(-1, 3)[:nb], rtol=1e-7, atol=1e-10 * np.abs(x01).max())
+        assert sp11 == 1 + int(round(2 * it11)) + 1 and sp10 == 1 + 2 * int(round(2 * it10))
+        assert abs(red11 - true) <= 1e-6 * true and true < 2e-4
