@@ -15,6 +15,7 @@ ap.add_argument("--steps", type=int, default=30)
 ap.add_argument("--reorder", default=None, help="default: the library's choice")
 ap.add_argument("--preconditioner", default="ilu0", choices=["ilu0", "cpr", "cpr_trueimpes", "cpr_quasiimpes"])
 ap.add_argument("--cpr-gather-rows", type=int, default=0, help="CPR: the pressure stage spans the ranks from each rank's first level of at most this many rows (0: the default, 100000; < 0: one hierarchy per subdomain)")
+ap.add_argument("--fused-reductions", type=int, default=1, help="1 (default, as bench.py --gpus N > 1 with ILU0): one all-reduce per half iteration; 0: the reference's recurrence")
 a = ap.parse_args()
 pkg = importlib.import_module("opm-autodiff_amd")
 group = "ddbench%d" % os.getpid()
@@ -24,7 +25,8 @@ out, err = [None] * a.world, [None] * a.world
 def body(r):
     try:
         case = pkg.ras.cartesian_subdomain_case(a.n, a.world, r, state="mixed", heterogeneous=False)
-        m = pkg.capi.HipModel(case, comm=("loopback", a.world, r, group), reorder=a.reorder, tolerance=1e-2, maxit=200, ilu_relaxation=0.9, preconditioner=a.preconditioner, cpr_gather_rows=a.cpr_gather_rows)
+        m = pkg.capi.HipModel(case, comm=("loopback", a.world, r, group), reorder=a.reorder, tolerance=1e-2, maxit=200, ilu_relaxation=0.9, preconditioner=a.preconditioner, cpr_gather_rows=a.cpr_gather_rows,
+                              fused_reductions=a.fused_reductions if a.preconditioner == "ilu0" else 0)
         m.set_state(case["pv"], case["meaning"])
         m.set_source(case["source"])
         sim = bench.make_simulation(pkg, m)
