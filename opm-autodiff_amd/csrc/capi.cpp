@@ -102,6 +102,16 @@ static int upload_wells_local(opmhip_ctx* c, const opmhip_wells* w) {
     int rc;
     // device arrays grow geometrically and are then reused: wells are rebuilt for every solve
     // (linalg/ISTLSolverEbos.hpp:265-272)
+    // what of the list differs from what the device already holds (a Newton iteration hands the same list over three times)
+    auto same_i = [](const std::vector<int>& h, const int* p, size_t n) { return h.size() == n && (n == 0 || std::memcmp(h.data(), p, n * sizeof(int)) == 0); };
+    auto same_d = [](const std::vector<double>& h, const double* p, size_t n) { return h.size() == n && (n == 0 || std::memcmp(h.data(), p, n * sizeof(double)) == 0); };
+    const bool sVp = same_i(W.h_vp, w->val_pointers, (size_t)nw + 1), sD = same_d(W.h_D, w->Dnnzs, (size_t)nw * 16);
+    const bool sCc = same_i(W.h_cc, cc.data(), (size_t)np), sBc = same_i(W.h_bc, bc.data(), (size_t)np);
+    const bool sC = same_d(W.h_C, w->Cnnzs, (size_t)np * 12), sB = same_d(W.h_B, w->Bnnzs, (size_t)np * 12);
+    if (sVp && sD && sCc && sBc && sC && sB && (size_t)nw <= W.cap_wells && (size_t)np <= W.cap_perf) {
+        W.nperf = np;
+        return OPMHIP_SUCCESS;
+    }
     // earlier kernels on the context's (non-blocking) stream may still read the well arrays the copies below replace
     OPMHIP_HIP(c, hipStreamSynchronize(c->stream));
     if ((size_t)nw > W.cap_wells) {
@@ -114,6 +124,7 @@ static int upload_wells_local(opmhip_ctx* c, const opmhip_wells* w) {
         if ((rc = dev_alloc(c, &W.d_xw, cap * 4))) return rc;
         if ((rc = dev_alloc(c, &W.d_bx, cap * 4))) return rc;
         W.cap_wells = cap;
+        W.h_vp.clear(); W.h_D.clear();     // new arrays: nothing of the old content is there
     }
     if ((size_t)np > W.cap_perf) {
         const size_t cap = std::max((size_t)np, 2 * W.cap_perf);
@@ -124,15 +135,27 @@ static int upload_wells_local(opmhip_ctx* c, const opmhip_wells* w) {
         if ((rc = dev_alloc(c, &W.d_C, cap * 12))) return rc;
         if ((rc = dev_alloc(c, &W.d_B, cap * 12))) return rc;
         W.cap_perf = cap;
+        W.h_cc.clear(); W.h_bc.clear(); W.h_C.clear(); W.h_B.clear();
     }
-    OPMHIP_HIP(c, hipMemcpy(W.d_val_pointers, w->val_pointers, (nw + 1) * sizeof(int), hipMemcpyHostToDevice));
-    OPMHIP_HIP(c, hipMemcpy(W.d_D, w->Dnnzs, (size_t)nw * 16 * sizeof(double), hipMemcpyHostToDevice));
-    if (np > 0) {
-        OPMHIP_HIP(c, hipMemcpy(W.d_Ccols, cc.data(), np * sizeof(int), hipMemcpyHostToDevice));
-        OPMHIP_HIP(c, hipMemcpy(W.d_Bcols, bc.data(), np * sizeof(int), hipMemcpyHostToDevice));
-        OPMHIP_HIP(c, hipMemcpy(W.d_C, w->Cnnzs, (size_t)np * 12 * sizeof(double), hipMemcpyHostToDevice));
-        OPMHIP_HIP(c, hipMemcpy(W.d_B, w->Bnnzs, (size_t)np * 12 * sizeof(double), hipMemcpyHostToDevice));
-    }
+    // a failed copy leaves the record of that array empty: the next call copies it again
+    auto put_i = [&](int* d, std::vector<int>& h, const int* p, size_t n) -> int {
+        h.clear();
+        if (n > 0) OPMHIP_HIP(c, hipMemcpy(d, p, n * sizeof(int), hipMemcpyHostToDevice));
+        h.assign(p, p + n);
+        return OPMHIP_SUCCESS;
+    };
+    auto put_d = [&](double* d, std::vector<double>& h, const double* p, size_t n) -> int {
+        h.clear();
+        if (n > 0) OPMHIP_HIP(c, hipMemcpy(d, p, n * sizeof(double), hipMemcpyHostToDevice));
+        h.assign(p, p + n);
+        return OPMHIP_SUCCESS;
+    };
+    if (!same_i(W.h_vp, w->val_pointers, (size_t)nw + 1) && (rc = put_i(W.d_val_pointers, W.h_vp, w->val_pointers, (size_t)nw + 1))) return rc;
+    if (!same_d(W.h_D, w->Dnnzs, (size_t)nw * 16) && (rc = put_d(W.d_D, W.h_D, w->Dnnzs, (size_t)nw * 16))) return rc;
+    if (!same_i(W.h_cc, cc.data(), (size_t)np) && (rc = put_i(W.d_Ccols, W.h_cc, cc.data(), (size_t)np))) return rc;
+    if (!same_i(W.h_bc, bc.data(), (size_t)np) && (rc = put_i(W.d_Bcols, W.h_bc, bc.data(), (size_t)np))) return rc;
+    if (!same_d(W.h_C, w->Cnnzs, (size_t)np * 12) && (rc = put_d(W.d_C, W.h_C, w->Cnnzs, (size_t)np * 12))) return rc;
+    if (!same_d(W.h_B, w->Bnnzs, (size_t)np * 12) && (rc = put_d(W.d_B, W.h_B, w->Bnnzs, (size_t)np * 12))) return rc;
     W.nperf = np;
     return OPMHIP_SUCCESS;
 }

@@ -148,6 +148,10 @@ struct WellsDev {
     bool distributed = false;
     double* d_bx = nullptr;   // 4 doubles per well: this rank's part of B x, then the sum
     size_t cap_wells = 0, cap_perf = 0;
+    // what the device arrays hold, as handed over last time: a Newton iteration passes the same list three times (residual, solve, well
+    // solution) and the perforated cells never change - an array that arrives unchanged is not copied again (upload_wells_local)
+    std::vector<int> h_vp, h_cc, h_bc;
+    std::vector<double> h_D, h_C, h_B;
     // multisegment wells: applied on the host between the product and the standard wells (opmhip_wells.ms_apply)
     int num_ms = 0;
     opmhip_ms_apply_fn ms_apply = nullptr;
