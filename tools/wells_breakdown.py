@@ -1,3 +1,6 @@
+#!/usr/bin/env python3
+"""Where a Newton iteration with a host-side well model spends its time at the bench's size (two wells of 100 completions on the 100^3 case, as
+tools/wells_at_scale.py): every call of the model and of wells.StandardWells wrapped with a wall-clock timer.    python tools/wells_breakdown.py"""
 import importlib, os, sys, time, collections
 sys.path.insert(0, "/root/repo"); sys.path.insert(0, "/root/repo/tools")
 sys.argv = ["x", "--steps", "0", "--warmup", "0"]
@@ -41,4 +44,4 @@ m.synchronize()
 el = time.perf_counter() - t0
 print("total %.2f ms per Newton iteration" % (1e3 * el / 20))
 for k in sorted(T, key=lambda k: -T[k]): print("  %-34s %3d calls  %7.3f ms per Newton iteration" % (k, Nn[k], 1e3 * T[k] / 20))
-print("  unaccounted %.3f ms" % (1e3 * (el - sum(v for k, v in T.items() if k != "iq_cells" or True) + T.get("wells.records", 0.0) * 0 ) / 20))
+print("  unaccounted %.3f ms (the wrapped calls nest: wells.records contains iq_cells)" % (1e3 * (el - sum(v for k, v in T.items() if k != "iq_cells")) / 20))
