@@ -117,6 +117,25 @@ def test_assembly_conserves_mass_and_matches_its_jacobian(full, pkg):
     m.assemble(DT, 0, fetch=False)
 
 
+def test_per_cell_well_calls_at_full_size(full):
+    """opmhip_set_source_cells / opmhip_get_iq_cells on 10^6 cells: the five-spot's 200 cells named one by one give the residual and the
+    Jacobian of the whole-grid call bit for bit (the staging of the per-cell calls is sized by the grid, their traffic by the cells
+    named); the records of cells from all over the grid equal the whole array's rows"""
+    m, case, src, jac, res = full["m"], full["case"], full["src"], full["jac"], full["res"]
+    Nb = case["Nb"]
+    s3 = src.reshape(Nb, 3)
+    cells = np.flatnonzero(np.abs(s3).sum(axis=1) > 0).astype(np.int32)
+    assert len(cells) == 200
+    m.set_source_cells(cells, np.ascontiguousarray(s3[cells].reshape(-1)))
+    j1, r1 = m.assemble(DT, 0)
+    assert np.array_equal(r1, res) and np.array_equal(j1, jac)
+    rng = np.random.default_rng(5)
+    pick = np.concatenate([rng.choice(Nb, 500, replace=False), [0, Nb - 1]]).astype(np.int32)
+    assert np.array_equal(m.iq_cells(pick), m.iq()[pick])
+    m.set_source(src)                                  # as the tests that follow expect it
+    m.assemble(DT, 0, fetch=False)
+
+
 def test_zero_update_and_roll_back_are_idempotent(full):
     m, case = full["m"], full["case"]
     m.advance_time_level()
