@@ -29,31 +29,31 @@ int alloc_system(opmhip_ctx* c) {
     if ((rc = dev_alloc(c, &c->d_A, (size_t)P.nnzb * BB + SLACK))) return rc;
     if ((rc = dev_alloc(c, &c->d_L, (size_t)P.nl * BB + SLACK))) return rc;
     if ((rc = dev_alloc(c, &c->d_U, (size_t)P.nu * BB + SLACK))) return rc;
-    OPMHIP_HIP(c, hipMemset(c->d_A + (size_t)P.nnzb * BB, 0, SLACK * sizeof(double)));
-    OPMHIP_HIP(c, hipMemset(c->d_L + (size_t)P.nl * BB, 0, SLACK * sizeof(double)));
-    OPMHIP_HIP(c, hipMemset(c->d_U + (size_t)P.nu * BB, 0, SLACK * sizeof(double)));
+    OPMHIP_HIP(c, hipMemsetAsync(c->d_A + (size_t)P.nnzb * BB, 0, SLACK * sizeof(double), c->stream));
+    OPMHIP_HIP(c, hipMemsetAsync(c->d_L + (size_t)P.nl * BB, 0, SLACK * sizeof(double), c->stream));
+    OPMHIP_HIP(c, hipMemsetAsync(c->d_U + (size_t)P.nu * BB, 0, SLACK * sizeof(double), c->stream));
     if ((rc = dev_alloc(c, &c->d_invD, (size_t)P.Nb * BB))) return rc;
     c->half_product = half_product_wanted(c);
     if (c->half_product) {   // the matrix beside its U part (written by the factorisation) and the backward sweeps' row sums
         if ((rc = dev_alloc(c, &c->d_R, (size_t)P.nr * BB + SLACK))) return rc;
-        OPMHIP_HIP(c, hipMemset(c->d_R, 0, ((size_t)P.nr * BB + SLACK) * sizeof(double)));
+        OPMHIP_HIP(c, hipMemsetAsync(c->d_R, 0, ((size_t)P.nr * BB + SLACK) * sizeof(double), c->stream));
         if ((rc = dev_alloc(c, &c->d_usum, n))) return rc;
-        OPMHIP_HIP(c, hipMemset(c->d_usum, 0, n * sizeof(double)));
+        OPMHIP_HIP(c, hipMemsetAsync(c->d_usum, 0, n * sizeof(double), c->stream));
     }
     double** vecs[] = {&c->d_b, &c->d_x, &c->d_r, &c->d_rw, &c->d_p, &c->d_v, &c->d_s, &c->d_t, &c->d_pw, &c->d_vu, &c->d_stageV};
     for (double** v : vecs) {
         if ((rc = dev_alloc(c, v, n))) return rc;
-        OPMHIP_HIP(c, hipMemset(*v, 0, n * sizeof(double)));
+        OPMHIP_HIP(c, hipMemsetAsync(*v, 0, n * sizeof(double), c->stream));
     }
     if ((rc = dev_alloc(c, &c->d_stageA, (size_t)P.nnzb * BB))) return rc;
     if ((rc = dev_alloc(c, &c->d_scal, (size_t)SC_COUNT))) return rc;
-    OPMHIP_HIP(c, hipMemset(c->d_scal, 0, SC_COUNT * sizeof(double)));
+    OPMHIP_HIP(c, hipMemsetAsync(c->d_scal, 0, SC_COUNT * sizeof(double), c->stream));
     const int vb = (int)((n + 2047) / 2048);
     c->npart = std::max(std::max(P.tiles.ntiles(), P.tiles.nsched), vb) + 1;
     if ((rc = dev_alloc(c, &c->d_part, (size_t)3 * c->npart))) return rc;   // three lists of partial sums (the third: opmhip_config.fused_reductions)
-    OPMHIP_HIP(c, hipMemset(c->d_part, 0, (size_t)3 * c->npart * sizeof(double)));
+    OPMHIP_HIP(c, hipMemsetAsync(c->d_part, 0, (size_t)3 * c->npart * sizeof(double), c->stream));
     if ((rc = dev_alloc(c, &c->d_part2, (size_t)1024))) return rc;
-    OPMHIP_HIP(c, hipMemset(c->d_part2, 0, 1024 * sizeof(double)));
+    OPMHIP_HIP(c, hipMemsetAsync(c->d_part2, 0, 1024 * sizeof(double), c->stream));
     if (!c->h_pinned) OPMHIP_HIP(c, hipHostMalloc((void**)&c->h_pinned, SC_COUNT * sizeof(double)));
     if (!c->h_ring) {
     OPMHIP_HIP(c, hipHostMalloc((void**)&c->h_ring, opmhip_ctx::RB_SLOTS * opmhip_ctx::RB_DOUBLES * sizeof(double), hipHostMallocMapped));
@@ -61,6 +61,14 @@ int alloc_system(opmhip_ctx* c) {
     std::memset(c->h_ring, 0, opmhip_ctx::RB_SLOTS * opmhip_ctx::RB_DOUBLES * sizeof(double));
     }
     c->d_done = c->d_scal + SC_ZERO;
+    // Every fill above went to the context's stream - the one every kernel that touches these arrays runs on.  (Until round 6 they were
+    // hipMemset calls: work for the device's NULL stream that returns to the host at once (2 us for a fill of 0.33 ms) and with which a
+    // non-blocking stream is not ordered - tools/probe/memset_probe.hip, profiles/r06_memset_probe.txt: with the NULL stream busy, a
+    // kernel launched on a non-blocking stream right behind such a fill of the same array is overwritten by it in 199 rounds of 200.
+    // The one such fill inside a solve, the zeroing of a new AMG level's value array in cpr.hip's upload_ell, is what one run in nine of
+    // the test suite met: eight contexts of one process busy on one GPU, a non-finite norm in the first solve of
+    // tests/test_gpu_dd.py::test_dd_cpr_pressure_stage_across_the_ranks[8-...], never reproduced in isolation.)
+    OPMHIP_HIP(c, hipStreamSynchronize(c->stream));
     return OPMHIP_SUCCESS;
 }
 

@@ -154,7 +154,7 @@ int opmhip_set_static(opmhip_ctx* c, const double* trans, const double* area, co
             if ((rc = dev_alloc(c, &A.d_storageOld, Nb * 3))) return rc;
             if ((rc = dev_alloc(c, &A.d_invb, Nb * 3))) return rc;
             if ((rc = dev_alloc(c, &A.d_drift, Nb * 3))) return rc;
-            OPMHIP_HIP(c, hipMemset(A.d_drift, 0, Nb * 3 * sizeof(double)));
+            OPMHIP_HIP(c, hipMemsetAsync(A.d_drift, 0, Nb * 3 * sizeof(double), c->stream));
             if ((rc = dev_alloc(c, &A.d_source, Nb * 3))) return rc;
             if ((rc = dev_alloc(c, &A.d_dsource, Nb * 9))) return rc;
             if ((rc = dev_alloc(c, &A.d_meaning, Nb))) return rc;
@@ -166,10 +166,11 @@ int opmhip_set_static(opmhip_ctx* c, const double* trans, const double* area, co
             if ((rc = dev_alloc(c, &A.d_conv_part, ((Nb + 255) / 256) * 10))) return rc;
             if ((rc = dev_alloc(c, &A.d_conv_out, (size_t)16))) return rc;
             if ((rc = dev_alloc(c, &A.d_stage_cell, Nb * (size_t)iq_doubles_per_cell(c)))) return rc;
-            OPMHIP_HIP(c, hipMemset(A.d_source, 0, Nb * 3 * sizeof(double)));
-            OPMHIP_HIP(c, hipMemset(A.d_dsource, 0, Nb * 9 * sizeof(double)));
-            OPMHIP_HIP(c, hipMemset(A.d_storageOld, 0, Nb * 3 * sizeof(double)));
-            OPMHIP_HIP(c, hipMemset(A.d_wasSwitched, 0, Nb));
+            OPMHIP_HIP(c, hipMemsetAsync(A.d_source, 0, Nb * 3 * sizeof(double), c->stream));
+            OPMHIP_HIP(c, hipMemsetAsync(A.d_dsource, 0, Nb * 9 * sizeof(double), c->stream));
+            OPMHIP_HIP(c, hipMemsetAsync(A.d_storageOld, 0, Nb * 3 * sizeof(double), c->stream));
+            OPMHIP_HIP(c, hipMemsetAsync(A.d_wasSwitched, 0, Nb, c->stream));
+            OPMHIP_HIP(c, hipStreamSynchronize(c->stream));   // (fills on the context's stream, complete before anything else can reach these arrays: capi.cpp, alloc_system)
             // assembly tiles: whole rows, at most 256 entries
             std::vector<int> row0;
             int r = 0;

@@ -1169,7 +1169,9 @@ static int upload_ell(opmhip_ctx* c, const CprHostLevel& H, CprLevelDev& L, int 
     if ((rc = dev_upload(c, &L.d_rlen, H.rlen))) return rc;
     if ((rc = dev_upload(c, &L.d_diag, H.diag))) return rc;
     if ((rc = dev_alloc(c, &L.d_val, (size_t)W * n))) return rc;
-    OPMHIP_HIP(c, hipMemset(L.d_val, 0, (size_t)W * n * sizeof(double)));   // the padding stays 0 for good
+    // the padding stays 0 for good.  On the context's stream, like the kernels that write the level's values behind it: a hipMemset - the
+    // device's NULL stream, which a non-blocking stream is not ordered with - could land behind them (capi.cpp, alloc_system)
+    OPMHIP_HIP(c, hipMemsetAsync(L.d_val, 0, (size_t)W * n * sizeof(double), c->stream));
     if ((rc = dev_alloc(c, &L.d_dinv, (size_t)n))) return rc;
     if ((rc = dev_alloc(c, &L.d_b, (size_t)nvec))) return rc;
     OPMHIP_HIP(c, hipMemsetAsync(L.d_b, 0, (size_t)nvec * sizeof(double), c->stream));

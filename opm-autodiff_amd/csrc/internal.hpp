@@ -9,6 +9,7 @@
 #include <memory>
 #include <climits>
 #include <string>
+#include <type_traits>
 #include <vector>
 
 #include "../../include/opmhip.h"
@@ -444,6 +445,13 @@ inline int fail(opmhip_ctx* c, int code, const char* fmt, ...) {
                                 hipGetErrorString(e_), __FILE__, __LINE__);                         \
     } while (0)
 
+// OPMHIP_POISON_ALLOC=1 (under OPMHIP_TUNING=1; a debugging aid): every floating-point array starts as NaNs, every other array as
+// zeros - an entry that is read before it was written then shows in every run instead of in the runs in which hipMalloc hands
+// back memory some earlier context left its numbers in
+inline bool poison_allocations() {
+    static const bool on = [] { const char* e = tuning_env("OPMHIP_POISON_ALLOC"); return e && e[0] == '1'; }();
+    return on;
+}
 template <class T>
 int dev_alloc(opmhip_ctx* c, T** p, size_t count) {
     void* q = nullptr;
@@ -451,6 +459,11 @@ int dev_alloc(opmhip_ctx* c, T** p, size_t count) {
     hipError_t e = hipMalloc(&q, bytes);
     if (e != hipSuccess)
         return fail(c, OPMHIP_DEVICE_ERROR, "hipMalloc(%zu) failed: %s", bytes, hipGetErrorString(e));
+    // (the contexts' streams do not wait for the null stream: the fill is complete before anybody can enqueue a kernel that writes the array)
+    if (poison_allocations() && ((e = hipMemset(q, std::is_floating_point<T>::value ? 0xFF : 0x00, bytes)) != hipSuccess || (e = hipDeviceSynchronize()) != hipSuccess)) {
+        (void)hipFree(q);
+        return fail(c, OPMHIP_DEVICE_ERROR, "hipMemset(%zu) failed: %s", bytes, hipGetErrorString(e));
+    }
     c->allocs.push_back(q);
     *p = static_cast<T*>(q);
     return OPMHIP_SUCCESS;
