@@ -42,6 +42,8 @@ __device__ __forceinline__ double2 ld_stream(const double2* p) {
     return make_double2(t.x, t.y);
 #endif
 }
+// (round 6, measured and not kept: the sweeps' own once-read items - D^-1, the light sweeps' blocks, the right-hand side - as nontemporal
+// loads: one M^-1 0.143 -> 0.153 / 0.152 / 0.142 ms, all three 0.171; profiles/r06_nt_operands_ab.txt)
 // the backward sweeps' row sums: written once per application, read once by the product that follows
 __device__ __forceinline__ void st_rowsum(double* p, double v) {
     __builtin_nontemporal_store(v, p);   // one M^-1 with the row sums back to back: 0.136 - 0.139 ms with plain stores, 0.132 - 0.133 nontemporal
@@ -676,18 +678,27 @@ __global__ __launch_bounds__(64) void k_spmv_pipe_st(int npos, const int4* __res
             b.xx[u][0] = xc[0]; b.xx[u][1] = xc[1]; b.xx[u][2] = xc[2];
         }
         b.nrow = cnt;
+        // the operands every row reads once per launch (the scalar products' second vectors, the backward sweep's row sums): nontemporal, so
+        // that they do not push the gathered vector out of L2 - the rest product 0.0792 -> 0.0758 ms, +1.9 % Newton its/s in alternation
+        // (profiles/r06_nt_operands_ab.txt); the result's stores stay plain (the vector kernel behind the product reads them at once)
+#ifdef OPMHIP_PLAIN_OPERANDS
+#define OPMHIP_LD1(p) (*(p))
+#else
+#define OPMHIP_LD1(p) __builtin_nontemporal_load(p)
+#endif
         if constexpr (NDOT >= 1) {
             const double* wr = &w0[(size_t)rr * BS];
-            b.ww[0] = wr[0]; b.ww[1] = wr[1]; b.ww[2] = wr[2];
+            b.ww[0] = OPMHIP_LD1(wr); b.ww[1] = OPMHIP_LD1(wr + 1); b.ww[2] = OPMHIP_LD1(wr + 2);
         }
         if constexpr (NDOT == 3) {
             const double* wr = &w1[(size_t)rr * BS];
-            b.w2[0] = wr[0]; b.w2[1] = wr[1]; b.w2[2] = wr[2];
+            b.w2[0] = OPMHIP_LD1(wr); b.w2[1] = OPMHIP_LD1(wr + 1); b.w2[2] = OPMHIP_LD1(wr + 2);
         }
         if constexpr (UADD) {
             const double* ur = &uadd[(size_t)rr * BS];
-            b.uu[0] = ur[0]; b.uu[1] = ur[1]; b.uu[2] = ur[2];
+            b.uu[0] = OPMHIP_LD1(ur); b.uu[1] = OPMHIP_LD1(ur + 1); b.uu[2] = OPMHIP_LD1(ur + 2);
         }
+#undef OPMHIP_LD1
     };
     StW wq;
     StS sb;
