@@ -1,6 +1,6 @@
 // Host-side logic of libopmhip under AddressSanitizer + UBSan + libstdc++'s container assertions (test infrastructure; built and run by
 // tests/test_host_logic_sanitized.py with g++, no GPU): csrc/reorder.cpp (orderings, L/U split, tiles, launch schedules, stencil
-// tables - index arithmetic a GPU test only sees through its results) and csrc/fluid_tables.cpp (table blobs).  The three HIP runtime
+// tables - index arithmetic a GPU test only sees through its results) and csrc/fluid_tables.cpp (table blobs).  The HIP runtime
 // calls reorder.cpp makes (hipMalloc, hipMemcpy for the uploads at its end) are served from the host heap here, so that an upload that
 // reads past a vector's end is seen as well.  Beside the sanitizers the harness checks what every ordering must satisfy: the
 // permutations are inverse to each other, the reordered pattern is the natural one renamed, rows of one colour do not meet unless they
@@ -32,6 +32,12 @@ extern "C" hipError_t hipMemcpy(void* d, const void* s, size_t n, hipMemcpyKind)
     std::memcpy(d, s, n);
     return hipSuccess;
 }
+// (dev_alloc's debugging fill, internal.hpp: OPMHIP_POISON_ALLOC - not switched on here, but referenced)
+extern "C" hipError_t hipMemset(void* d, int v, size_t n) {
+    std::memset(d, v, n);
+    return hipSuccess;
+}
+extern "C" hipError_t hipDeviceSynchronize() { return hipSuccess; }
 extern "C" const char* hipGetErrorString(hipError_t) { return "host stand-in"; }
 
 static int g_fail = 0;
