@@ -958,15 +958,19 @@ int opmhip_set_source_cells(opmhip_ctx* c, int n, const int* cells, const double
         OPMHIP_HIP(c, hipMemsetAsync(A.d_source, 0, Nloc * 3 * sizeof(double), c->stream));   // behind whatever assembly still reads them: same stream
         OPMHIP_HIP(c, hipMemsetAsync(A.d_dsource, 0, Nloc * 9 * sizeof(double), c->stream));
         if (m == 0) return OPMHIP_SUCCESS;
-        int rc = stage_cell_positions(c, pos);
-        if (rc) return rc;
-        // values staged in d_stage_cell (Nloc * IQS doubles >= 12 per distinct cell)
-        OPMHIP_HIP(c, hipMemcpyAsync(A.d_stage_cell, val.data(), m * 3 * sizeof(double), hipMemcpyHostToDevice, c->stream));
-        OPMHIP_HIP(c, hipMemcpyAsync(A.d_stage_cell + m * 3, dval.data(), m * 9 * sizeof(double), hipMemcpyHostToDevice, c->stream));
-        launch_source_scatter(c, (int)m, A.d_cell_pos, A.d_stage_cell, A.d_stage_cell + m * 3);
-        OPMHIP_HIP(c, hipGetLastError());
-        OPMHIP_HIP(c, hipStreamSynchronize(c->stream));   // the host vectors above end here
-        return OPMHIP_SUCCESS;
+        const int rc = [&]() -> int {
+            int r = stage_cell_positions(c, pos);
+            if (r) return r;
+            // values staged in d_stage_cell (Nloc * IQS doubles >= 12 per distinct cell)
+            OPMHIP_HIP(c, hipMemcpyAsync(A.d_stage_cell, val.data(), m * 3 * sizeof(double), hipMemcpyHostToDevice, c->stream));
+            OPMHIP_HIP(c, hipMemcpyAsync(A.d_stage_cell + m * 3, dval.data(), m * 9 * sizeof(double), hipMemcpyHostToDevice, c->stream));
+            launch_source_scatter(c, (int)m, A.d_cell_pos, A.d_stage_cell, A.d_stage_cell + m * 3);
+            OPMHIP_HIP(c, hipGetLastError());
+            return OPMHIP_SUCCESS;
+        }();
+        // the host vectors above end here - on the way out of a failure as well: no copy may still be reading them
+        if (hipStreamSynchronize(c->stream) != hipSuccess && !rc) return fail(c, OPMHIP_DEVICE_ERROR, "set_source_cells: hipStreamSynchronize failed");
+        return rc;
     });
 }
 
@@ -1028,13 +1032,16 @@ int opmhip_get_iq_cells(opmhip_ctx* c, int n, const int* cells, double* out) {
             pos[i] = P.toOrder[cells[i]];
         }
         OPMHIP_HIP(c, hipSetDevice(c->device));
-        int rc = stage_cell_positions(c, pos);
-        if (rc) return rc;
-        launch_iq_gather(c, n, c->asmb.d_cell_pos, c->asmb.d_stage_cell);
-        OPMHIP_HIP(c, hipGetLastError());
-        OPMHIP_HIP(c, hipMemcpyAsync(out, c->asmb.d_stage_cell, (size_t)n * iq_doubles_per_cell(c) * sizeof(double), hipMemcpyDeviceToHost, c->stream));
-        OPMHIP_HIP(c, hipStreamSynchronize(c->stream));
-        return OPMHIP_SUCCESS;
+        const int rc = [&]() -> int {
+            int r = stage_cell_positions(c, pos);
+            if (r) return r;
+            launch_iq_gather(c, n, c->asmb.d_cell_pos, c->asmb.d_stage_cell);
+            OPMHIP_HIP(c, hipGetLastError());
+            OPMHIP_HIP(c, hipMemcpyAsync(out, c->asmb.d_stage_cell, (size_t)n * iq_doubles_per_cell(c) * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+            return OPMHIP_SUCCESS;
+        }();
+        if (hipStreamSynchronize(c->stream) != hipSuccess && !rc) return fail(c, OPMHIP_DEVICE_ERROR, "get_iq_cells: hipStreamSynchronize failed");   // `pos` ends here
+        return rc;
     });
 }
 
