@@ -191,6 +191,12 @@ class StandardWells:
         D[:, [0, 1, 2], [0, 1, 2]] = 1.0
         D[:, :3, 3] = -np.add.reduceat(pr[:, :, 4], seg, axis=0)
         r[:, 3], D[:, 3, :] = self._control_rows()
+        # a well none of whose completions flows (its bottom-hole pressure on the wrong side of every completion's pressure) has no rate that
+        # answers to its bottom-hole pressure: under a rate target its equations would be singular.  It keeps its bottom-hole pressure for
+        # this iteration and its rates go to zero (the reference takes such a well out of operation: checkWellOperability,
+        # wells/BlackoilWellModel_impl.hpp:1421-1423)
+        for k in np.flatnonzero(np.all(D[:, :3, 3] == 0.0, axis=1) & (D[:, 3, 3] == 0.0)):
+            r[k, 3], D[k, 3, :] = 0.0, (0.0, 0.0, 0.0, 1.0)
         B, C = np.zeros((nperf, 4, 3)), np.zeros((nperf, 4, 3))
         B[:, :3, :] = -pr[:, :, 1:4]                 # d r_w[c] / d (Sw, p, X) of the perforated cell
         C[:, 3, :] = -pr[:, :, 4]                    # d r_cell[c] / d bhp = - d(connection rate) / d bhp

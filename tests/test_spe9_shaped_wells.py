@@ -160,3 +160,92 @@ def test_schedule_on_the_oracle(pkg, orc, spe9):
         assert abs((after[c] - before[c]) - moved[c]) <= min(factor * slack, 1e-4 * abs(moved[c])), c
     print("SPE9-shaped schedule on the oracle: (Newton, linear, controls) per report step %r; moved %r; balance errors %r of slack %.3g" %
           (steps, moved.tolist(), ((after - before) - moved).tolist(), slack))
+
+
+class _PerCellAdapter:
+    """an oracle-backed model that offers the per-cell calls (what capi.HipModel does on the device): newton.BlackoilModelHip then moves the
+    perforated cells' records and rates only"""
+
+    def __init__(self, hm):
+        self._hm = hm
+        self.calls = {"iq_cells": 0, "set_source_cells": 0}
+
+    def __getattr__(self, k):
+        return getattr(self._hm, k)
+
+    def iq_cells(self, cells):
+        self.calls["iq_cells"] += 1
+        return self._hm.iq()[np.asarray(cells, int)]
+
+    def set_source_cells(self, cells, source, dsource=None):
+        self.calls["set_source_cells"] += 1
+        n = self._hm.iq().shape[0]
+        s, d = np.zeros((n, 3)), np.zeros((n, 3, 3))
+        np.add.at(s, np.asarray(cells, int), np.asarray(source).reshape(-1, 3))
+        if dsource is not None:
+            np.add.at(d, np.asarray(cells, int), np.asarray(dsource).reshape(-1, 3, 3))
+        self._hm.set_source(s.reshape(-1), d.reshape(-1))
+
+
+def test_per_cell_path_equals_the_whole_grid_path(pkg, orc, spe9):
+    """the Newton loop's two ways of talking to the model - records and rates of the perforated cells only (a model with iq_cells /
+    set_source_cells) or whole arrays - run the schedule to the same bits: same sub-steps, iteration counts, well unknowns, state"""
+    runs = []
+    for per_cell in (False, True):
+        om = oracle_bind.OracleModel(orc, spe9)
+        om.set_state(spe9["pv"], spe9["meaning"])
+        wells = pkg.decks.spe9_shaped_wells(spe9, producer_bhp_limit=PRODUCER_BHP_LIMIT)
+        hm = oracle_bind.OracleAsHipModel(om, tol=1e-2, maxit=200, w=0.9)
+        model = _PerCellAdapter(hm) if per_cell else hm
+        ts, steps = run_schedule(pkg, model, wells, SCHEDULE[:2])
+        runs.append((steps, [h[0] for h in ts.history], wells.x.copy(), om.get_state()))
+        if per_cell:
+            assert model.calls["iq_cells"] == model.calls["set_source_cells"] > 10
+    (s0, h0, x0, (p0, m0)), (s1, h1, x1, (p1, m1)) = runs
+    assert s0 == s1 and h0 == h1 and np.array_equal(x0, x1) and np.array_equal(p0, p1) and np.array_equal(m0, m1)
+
+
+def test_well_model_edges(pkg, orc, spe9):
+    """a completion that would flow against its well's kind is closed (no crossflow); a rate target that the limit does not allow sends
+    the well to its BHP limit and a lower target brings it back; the target event scales the well's other rates with the controlled one"""
+    om = oracle_bind.OracleModel(orc, spe9)
+    om.set_state(spe9["pv"], spe9["meaning"])
+    iq = om.iq()
+    wells = pkg.decks.spe9_shaped_wells(spe9)
+    wells.solve_well_equations(iq)
+    k = 3
+    w = wells.wells[k]
+    p_cells = iq[w.cells][:, 4, 0]
+    # bottom-hole pressure above every completion's pressure: a producer's completions all close, its rates vanish
+    wells.x[k, 3] = p_cells.max() + 50e5
+    a = wells.assemble(iq, spe9["Nb"])
+    src = a["source"].reshape(-1, 3)
+    assert np.all(src[w.cells] == 0.0)
+    # ... and the injector with its pressure below the reservoir's injects nothing
+    wells.x[0, 3] = iq[wells.wells[0].cells][:, 4, 0].min() - 50e5
+    a = wells.assemble(iq, spe9["Nb"])
+    assert np.all(a["source"].reshape(-1, 3)[wells.wells[0].cells] == 0.0)
+    # (such a well keeps its bottom-hole pressure and loses its rates: its equations stay regular)
+    wells.solve_well_equations(iq)
+    assert np.all(wells.x[k, :3] == 0.0) and wells.x[k, 3] == p_cells.max() + 50e5
+    # control switching: BHP below the limit under rate control -> BHP control at the limit; back once the rate there exceeds the target
+    wells.initialised = False                    # start the wells over from the reservoir's pressures
+    wells.x[:] = 0.0
+    wells.solve_well_equations(iq)
+    np.testing.assert_allclose(-wells.x[k, 0], w.control[2], rtol=1e-9)
+    w.bhp_limit = wells.x[k, 3] + 5e5           # the limit is now above what the target needs
+    wells.update_well_controls()
+    assert w.control == ("bhp", w.bhp_limit) and wells.x[k, 3] == w.bhp_limit
+    wells.solve_well_equations(iq)               # the rate the limit allows: below the target
+    assert 0.0 < -wells.x[k, 0] < w.rate_control[2]
+    wells.update_well_controls()
+    assert w.control[0] == "bhp"
+    wells.set_rate_target(k, 0.25 * (-wells.x[k, 0]))      # a target the limit does allow
+    assert w.control[0] == "rate"
+    q_before = wells.x[k, :3].copy()
+    wells.solve_well_equations(iq)
+    wells.update_well_controls()
+    assert w.control[0] == "rate" and wells.x[k, 3] > w.bhp_limit
+    np.testing.assert_allclose(-wells.x[k, 0], w.control[2], rtol=1e-9)
+    # the event scaled the three rates together (their ratios are the well stream's composition at the time)
+    np.testing.assert_allclose(q_before[1] / q_before[0], wells.x[k, 1] / wells.x[k, 0], rtol=0.2)
