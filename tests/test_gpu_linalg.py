@@ -296,6 +296,42 @@ def test_wells_with_more_completions_than_a_wavefront_has_lanes(pkg, orc):
         np.testing.assert_array_equal(s.wells_recover_solution(W, rw), orc.wells_recover(W, rw, x))
 
 
+def test_a_well_list_that_arrives_again(pkg, orc):
+    """the device keeps a record of the well list it holds and copies an array only when it differs (a Newton iteration hands the same list
+    over three times: residual, solve, well solution): the same list again, the same list with other values of ONE array, a list of another
+    shape and the first list once more - every solve and every well solution equals the oracle's on that list"""
+    rng = np.random.default_rng(41)
+    Nb, rp, ci, v = laplace_block_system(14, 11, 8, seed=43)
+    b = rng.standard_normal(Nb * 3)
+    rw_all = rng.standard_normal(4 * 5)
+
+    def make(perfs, seed):
+        r = np.random.default_rng(seed)
+        vp = np.concatenate([[0], np.cumsum(perfs)]).astype(np.int32)
+        n = int(vp[-1])
+        cols = r.choice(Nb, n, replace=False).astype(np.int32)
+        Dm = [np.linalg.inv(0.2 * r.standard_normal((4, 4)) + np.diag(2.0 + r.random(4))) for _ in perfs]
+        return dict(numWells=len(perfs), val_pointers=vp, Ccols=cols, Bcols=cols.copy(), Cnnzs=0.03 * r.standard_normal(n * 12),
+                    Bnnzs=0.03 * r.standard_normal(n * 12), Dnnzs=np.ascontiguousarray(np.stack(Dm).reshape(-1)))
+    W1 = make([4, 2, 7], 1)
+    W1d = dict(W1, Dnnzs=W1["Dnnzs"] * 1.25)                       # only D differs
+    W1c = dict(W1, Cnnzs=W1["Cnnzs"] * -0.5)                       # only C differs
+    W2 = make([3, 9, 1, 2, 5], 2)                                  # other wells, other cells, more of both
+    s = pkg.capi.HipSolver(tolerance=1e-9, maxit=300, reorder="line_coloring")
+    first = True
+    for W in (W1, W1, W1d, W1c, W2, W1, W2):
+        res = s.solve_system(Nb, rp if first else None, ci if first else None, v.copy(), b, wells=W)
+        first = False
+        x = s.get_result()
+        to, fr, _ = s.ordering()
+        xo, ro = oracle_solve_in_order(orc, Nb, rp, ci, v, b, to, fr, wells=W, tol=1e-9, maxit=300, w=0.9)
+        assert res.converged and res.it == ro.it
+        np.testing.assert_allclose(x, xo, rtol=1e-8, atol=1e-12)
+        rw = rw_all[:4 * W["numWells"]]
+        for _ in range(2):                                           # the same list twice more, as a Newton iteration does
+            np.testing.assert_array_equal(s.wells_recover_solution(W, rw), orc.wells_recover(W, rw, x))
+
+
 @pytest.mark.parametrize("reorder", ["level_scheduling", "graph_coloring", "line_coloring"])
 def test_wells_operator_in_every_ordering(pkg, orc, reorder):
     """The well operator inside a solve under the other orderings (the perforated cells are renamed at upload, opmhip_wells' indices are
