@@ -578,3 +578,49 @@ def test_reorder_auto_picks_by_size_and_regularity(pkg):
     ta, fa, ca = ordering(Nb, rp2, ci2, "auto")
     tg, fg, cg = ordering(Nb, rp2, ci2, "graph_coloring_greedy")
     assert np.array_equal(ta, tg) and np.array_equal(ca, cg)
+
+
+def test_solves_under_poisoned_allocations(tmp_path):
+    """OPMHIP_POISON_ALLOC=1 (a debugging switch, tools/README.md): every floating-point device array starts as NaNs - a solve (ILU0 and
+    CPR, the device-assembled Newton step included) that reads nothing it has not written gives the bits it gives without the switch"""
+    import subprocess
+    import sys
+    code = r'''
+import importlib, sys
+import numpy as np
+sys.path.insert(0, "tests")
+from helpers import laplace_block_system
+pkg = importlib.import_module("opm-autodiff_amd")
+out = []
+Nb, rp, ci, v = laplace_block_system(14, 12, 9, seed=3)
+b = np.random.default_rng(4).standard_normal(3 * Nb)
+for kw in (dict(reorder="line_coloring"), dict(reorder="graph_coloring_greedy"), dict(reorder="line_coloring", preconditioner="cpr_quasiimpes")):
+    s = pkg.capi.HipSolver(tolerance=1e-8, maxit=200, **kw)
+    res = s.solve_system(Nb, rp, ci, v.copy(), b)
+    out.append(np.concatenate([[res.it, float(res.converged)], s.get_result()]))
+case = pkg.decks.cartesian_case(9, 8, 6, state="mixed", heterogeneous=True)
+m = pkg.capi.HipModel(case, tolerance=1e-6)
+m.set_state(case["pv"], case["meaning"])
+m.set_source(pkg.decks.five_spot_source(case, rate_sm3_per_day=20.0))
+for it in range(2):
+    m.assemble(86400.0, it, fetch=False)
+    res = m.solve_jacobian_system()
+    out.append(np.concatenate([[res.it, float(res.converged)], m.get_result()]))
+    m.update(None, 1.0)
+out.append(m.get_state()[0])
+np.save(sys.argv[1], np.concatenate(out))
+'''
+    import os
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    got = []
+    for tag, extra in (("plain", {}), ("poison", {"OPMHIP_TUNING": "1", "OPMHIP_POISON_ALLOC": "1"})):
+        f = str(tmp_path / (tag + ".npy"))
+        env = dict(os.environ, **extra)
+        if not extra:
+            env.pop("OPMHIP_POISON_ALLOC", None)
+        r = subprocess.run([sys.executable, "-c", code, f], cwd=root, env=env, capture_output=True, text=True, timeout=300)
+        assert r.returncode == 0, r.stderr[-2000:]
+        if extra:
+            assert "OPMHIP_POISON_ALLOC=1 is in force" in r.stderr
+        got.append(np.load(f))
+    assert np.all(np.isfinite(got[0])) and np.array_equal(got[0], got[1])
